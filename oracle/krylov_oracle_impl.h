@@ -1,0 +1,1211 @@
+/* ==========================================================================
+ * krylov_oracle_impl.h  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Type-generic body of the CPU oracle.  Included twice by krylov_oracle.c,
+ * once with T=double / SUF(x)=x##_f64 and once with T=float / SUF(x)=x##_f32.
+ *
+ * Every function is a plain-C restatement of the arithmetic of the reference
+ * host/OpenMP backend (rocALUTION 3.2.0, /root/reference); the file:line each
+ * function follows is cited above it (paths relative to /root/reference/).
+ * The evaluation order of every floating point expression is the reference's
+ * (left-to-right, no FMA contraction: build with -ffp-contract=off).
+ * ========================================================================== */
+
+#ifndef T
+#error "define T and SUF before including"
+#endif
+
+/* ---- OpenMP thread policy ------------------------------------------------
+ * src/base/backend_manager.cpp:590-607 (_set_omp_backend_threads): host kernels
+ * run on ONE thread when size <= OpenMP_threshold (10000, :78), else on the
+ * configured thread count. orc_threads_for() is defined in krylov_oracle.c. */
+
+/* ---- SpMV ---------------------------------------------------------------- */
+
+/* src/base/host/host_matrix_csr.cpp:702-735  HostMatrixCSR::Apply */
+void SUF(orc_csr_apply)(int nrow, const int* row_offset, const int* col, const T* val,
+                        const T* in, T* out)
+{
+    int nt = orc_threads_for(nrow);
+#pragma omp parallel for num_threads(nt)
+    for(int ai = 0; ai < nrow; ++ai)
+    {
+        T sum = (T)0;
+        for(int aj = row_offset[ai]; aj < row_offset[ai + 1]; ++aj)
+        {
+            sum += val[aj] * in[col[aj]];
+        }
+        out[ai] = sum;
+    }
+}
+
+/* src/base/host/host_matrix_csr.cpp:737-769  HostMatrixCSR::ApplyAdd
+ * (accumulates term by term straight into out[ai]; scalar*val first) */
+void SUF(orc_csr_apply_add)(int nrow, int64_t nnz, const int* row_offset, const int* col,
+                            const T* val, const T* in, T scalar, T* out)
+{
+    if(nnz <= 0)
+        return;
+    int nt = orc_threads_for(nrow);
+#pragma omp parallel for num_threads(nt)
+    for(int ai = 0; ai < nrow; ++ai)
+    {
+        for(int aj = row_offset[ai]; aj < row_offset[ai + 1]; ++aj)
+        {
+            out[ai] += scalar * val[aj] * in[col[aj]];
+        }
+    }
+}
+
+/* src/base/host/host_matrix_ell.cpp:280-323  HostMatrixELL::Apply
+ * ELL_IND(row,el,nrow,max_row) = el*nrow + row  (src/base/matrix_formats_ind.hpp:38-40)
+ * stops at the first negative column; does nothing when nnz == 0 */
+void SUF(orc_ell_apply)(int nrow, int max_row, const int* col, const T* val, const T* in, T* out)
+{
+    if((int64_t)nrow * max_row <= 0)
+        return;
+    int nt = orc_threads_for(nrow);
+#pragma omp parallel for num_threads(nt)
+    for(int ai = 0; ai < nrow; ++ai)
+    {
+        T sum = (T)0;
+        for(int n = 0; n < max_row; ++n)
+        {
+            int aj     = n * nrow + ai;
+            int col_aj = col[aj];
+            if(col_aj >= 0)
+                sum += val[aj] * in[col_aj];
+            else
+                break;
+        }
+        out[ai] = sum;
+    }
+}
+
+/* src/base/host/host_matrix_ell.cpp:325-370  HostMatrixELL::ApplyAdd */
+void SUF(orc_ell_apply_add)(int nrow, int max_row, const int* col, const T* val, const T* in,
+                            T scalar, T* out)
+{
+    if((int64_t)nrow * max_row <= 0)
+        return;
+    int nt = orc_threads_for(nrow);
+#pragma omp parallel for num_threads(nt)
+    for(int ai = 0; ai < nrow; ++ai)
+    {
+        for(int n = 0; n < max_row; ++n)
+        {
+            int aj     = n * nrow + ai;
+            int col_aj = col[aj];
+            if(col_aj >= 0)
+                out[ai] += scalar * val[aj] * in[col_aj];
+            else
+                break;
+        }
+    }
+}
+
+/* src/base/host/host_matrix_coo.cpp:354-378  HostMatrixCOO::Apply (serial) */
+void SUF(orc_coo_apply)(int nrow, int64_t nnz, const int* row, const int* col, const T* val,
+                        const T* in, T* out)
+{
+    for(int i = 0; i < nrow; ++i)
+        out[i] = (T)0;
+    for(int64_t i = 0; i < nnz; ++i)
+        out[row[i]] += val[i] * in[col[i]];
+}
+
+/* src/base/host/host_matrix_coo.cpp:380-402  HostMatrixCOO::ApplyAdd (serial) */
+void SUF(orc_coo_apply_add)(int64_t nnz, const int* row, const int* col, const T* val,
+                            const T* in, T scalar, T* out)
+{
+    for(int64_t i = 0; i < nnz; ++i)
+        out[row[i]] += scalar * val[i] * in[col[i]];
+}
+
+/* src/base/host/host_matrix_hyb.cpp:315-369  HostMatrixHYB::Apply
+ * ELL part skips (does not stop at) invalid columns and accumulates into out[ai];
+ * COO part is serial. Nothing happens when nnz == 0. */
+void SUF(orc_hyb_apply)(int nrow, int ncol, int ell_max_row, const int* ell_col, const T* ell_val,
+                        int64_t coo_nnz, const int* coo_row, const int* coo_col, const T* coo_val,
+                        const T* in, T* out)
+{
+    int64_t ell_nnz = (int64_t)ell_max_row * nrow;
+    if(ell_nnz + coo_nnz <= 0)
+        return;
+    if(ell_nnz > 0)
+    {
+        int nt = orc_threads_for(nrow);
+#pragma omp parallel for num_threads(nt)
+        for(int ai = 0; ai < nrow; ++ai)
+        {
+            out[ai] = (T)0;
+            for(int n = 0; n < ell_max_row; ++n)
+            {
+                int aj = n * nrow + ai;
+                if((ell_col[aj] >= 0) && (ell_col[aj] < ncol))
+                    out[ai] += ell_val[aj] * in[ell_col[aj]];
+            }
+        }
+    }
+    for(int64_t i = 0; i < coo_nnz; ++i)
+        out[coo_row[i]] += coo_val[i] * in[coo_col[i]];
+}
+
+/* src/base/host/host_matrix_hyb.cpp:371-420  HostMatrixHYB::ApplyAdd */
+void SUF(orc_hyb_apply_add)(int nrow, int ncol, int ell_max_row, const int* ell_col,
+                            const T* ell_val, int64_t coo_nnz, const int* coo_row,
+                            const int* coo_col, const T* coo_val, const T* in, T scalar, T* out)
+{
+    int64_t ell_nnz = (int64_t)ell_max_row * nrow;
+    if(ell_nnz + coo_nnz <= 0)
+        return;
+    if(ell_nnz > 0)
+    {
+        int nt = orc_threads_for(nrow);
+#pragma omp parallel for num_threads(nt)
+        for(int ai = 0; ai < nrow; ++ai)
+        {
+            for(int n = 0; n < ell_max_row; ++n)
+            {
+                int aj = n * nrow + ai;
+                if((ell_col[aj] >= 0) && (ell_col[aj] < ncol))
+                    out[ai] += scalar * ell_val[aj] * in[ell_col[aj]];
+            }
+        }
+    }
+    for(int64_t i = 0; i < coo_nnz; ++i)
+        out[coo_row[i]] += scalar * coo_val[i] * in[coo_col[i]];
+}
+
+/* ---- format conversion (layout rules) ------------------------------------ */
+
+/* src/base/host/host_conversion.cpp:621-687  csr_to_ell
+ * width = max row nnz; REFUSES (returns 0) when width > 5*(nnz/nrow) (integer division);
+ * padding col=-1, val=0; in-row order preserved. ell_col/ell_val must hold width*nrow. */
+int SUF(orc_csr_to_ell_fill)(int nrow, int64_t nnz, const int* row_offset, const int* col,
+                             const T* val, int max_row, int* ell_col, T* ell_val)
+{
+    (void)nnz;
+    for(int i = 0; i < nrow; ++i)
+    {
+        int n = 0;
+        for(int j = row_offset[i]; j < row_offset[i + 1]; ++j)
+        {
+            int64_t ind  = (int64_t)n * nrow + i;
+            ell_val[ind] = val[j];
+            ell_col[ind] = col[j];
+            ++n;
+        }
+        for(int j = row_offset[i + 1] - row_offset[i]; j < max_row; ++j)
+        {
+            int64_t ind  = (int64_t)n * nrow + i;
+            ell_val[ind] = (T)0;
+            ell_col[ind] = -1;
+            ++n;
+        }
+    }
+    return 1;
+}
+
+/* src/base/host/host_conversion.cpp:1117-1239  csr_to_hyb
+ * ELL width = (nnz-1)/nrow+1; entries beyond the width spill to COO in row order. */
+int SUF(orc_csr_to_hyb_fill)(int nrow, const int* row_offset, const int* col, const T* val,
+                             int ell_max_row, int* ell_col, T* ell_val, int* coo_row, int* coo_col,
+                             T* coo_val)
+{
+    int64_t coo_idx = 0;
+    for(int i = 0; i < nrow; ++i)
+    {
+        int p = 0;
+        for(int j = row_offset[i]; j < row_offset[i + 1]; ++j)
+        {
+            if(p < ell_max_row)
+            {
+                int64_t idx  = (int64_t)(p++) * nrow + i;
+                ell_col[idx] = col[j];
+                ell_val[idx] = val[j];
+            }
+            else
+            {
+                coo_row[coo_idx] = i;
+                coo_col[coo_idx] = col[j];
+                coo_val[coo_idx] = val[j];
+                ++coo_idx;
+            }
+        }
+        for(int j = row_offset[i + 1] - row_offset[i]; j < ell_max_row; ++j)
+        {
+            int64_t idx  = (int64_t)(p++) * nrow + i;
+            ell_col[idx] = -1;
+            ell_val[idx] = (T)0;
+        }
+    }
+    return 1;
+}
+
+/* ---- diagonal ------------------------------------------------------------- */
+
+/* src/base/host/host_matrix_csr.cpp:772-797  ExtractDiagonal (rows w/o diagonal untouched) */
+void SUF(orc_csr_extract_diag)(int nrow, const int* row_offset, const int* col, const T* val,
+                               T* diag)
+{
+    for(int ai = 0; ai < nrow; ++ai)
+        for(int aj = row_offset[ai]; aj < row_offset[ai + 1]; ++aj)
+            if(ai == col[aj])
+            {
+                diag[ai] = val[aj];
+                break;
+            }
+}
+
+/* src/base/host/host_matrix_csr.cpp:800-845  ExtractInverseDiagonal
+ * d = 1/a_ii; a_ii == 0 -> 1; rows without a stored diagonal are left unwritten
+ * (the caller's Allocate zero-filled them, src/base/local_matrix.cpp:2294-2299).
+ * returns 1 if a zero diagonal was detected. */
+int SUF(orc_csr_extract_inv_diag)(int nrow, const int* row_offset, const int* col, const T* val,
+                                  T* inv_diag)
+{
+    int detect_zero_diag = 0;
+    for(int ai = 0; ai < nrow; ++ai)
+        for(int aj = row_offset[ai]; aj < row_offset[ai + 1]; ++aj)
+            if(ai == col[aj])
+            {
+                if(val[aj] != (T)0)
+                    inv_diag[ai] = (T)1 / val[aj];
+                else
+                {
+                    inv_diag[ai]     = (T)1;
+                    detect_zero_diag = 1;
+                }
+                break;
+            }
+    return detect_zero_diag;
+}
+
+/* ---- BLAS-1 (src/base/host/host_vector.cpp) ------------------------------- */
+
+/* :635-651 AddScale   this = this + alpha*x */
+void SUF(orc_add_scale)(int64_t n, T* v, const T* x, T alpha)
+{
+    int nt = orc_threads_for(n);
+#pragma omp parallel for num_threads(nt)
+    for(int64_t i = 0; i < n; ++i)
+        v[i] = v[i] + alpha * x[i];
+}
+
+/* :654-670 ScaleAdd   this = alpha*this + x */
+void SUF(orc_scale_add)(int64_t n, T* v, T alpha, const T* x)
+{
+    int nt = orc_threads_for(n);
+#pragma omp parallel for num_threads(nt)
+    for(int64_t i = 0; i < n; ++i)
+        v[i] = alpha * v[i] + x[i];
+}
+
+/* :672-690 ScaleAddScale   this = alpha*this + beta*x */
+void SUF(orc_scale_add_scale)(int64_t n, T* v, T alpha, const T* x, T beta)
+{
+    int nt = orc_threads_for(n);
+#pragma omp parallel for num_threads(nt)
+    for(int64_t i = 0; i < n; ++i)
+        v[i] = alpha * v[i] + beta * x[i];
+}
+
+/* :723-747 ScaleAdd2   this = alpha*this + beta*x + gamma*y */
+void SUF(orc_scale_add2)(int64_t n, T* v, T alpha, const T* x, T beta, const T* y, T gamma)
+{
+    int nt = orc_threads_for(n);
+#pragma omp parallel for num_threads(nt)
+    for(int64_t i = 0; i < n; ++i)
+        v[i] = alpha * v[i] + beta * x[i] + gamma * y[i];
+}
+
+/* :750-760 Scale */
+void SUF(orc_scale)(int64_t n, T* v, T alpha)
+{
+    int nt = orc_threads_for(n);
+#pragma omp parallel for num_threads(nt)
+    for(int64_t i = 0; i < n; ++i)
+        v[i] *= alpha;
+}
+
+/* :771-791 Dot, :852-872 DotNonConj (identical for real types): OpenMP reduction(+) */
+T SUF(orc_dot)(int64_t n, const T* a, const T* b)
+{
+    T   dot = (T)0;
+    int nt  = orc_threads_for(n);
+#pragma omp parallel for reduction(+ : dot) num_threads(nt)
+    for(int64_t i = 0; i < n; ++i)
+        dot += a[i] * b[i];
+    return dot;
+}
+
+/* :1019-1035 Norm = sqrt(sum x^2), OpenMP reduction(+) */
+T SUF(orc_norm)(int64_t n, const T* a)
+{
+    T   norm2 = (T)0;
+    int nt    = orc_threads_for(n);
+#pragma omp parallel for reduction(+ : norm2) num_threads(nt)
+    for(int64_t i = 0; i < n; ++i)
+        norm2 += a[i] * a[i];
+    return (T)ORC_SQRT(norm2);
+}
+
+/* :1231-1255 PointWiseMult(x): this = this*x ;  :1257-1279 PointWiseMult(x,y): this = y*x */
+void SUF(orc_pointwise_mult)(int64_t n, T* v, const T* x)
+{
+    int nt = orc_threads_for(n);
+#pragma omp parallel for num_threads(nt)
+    for(int64_t i = 0; i < n; ++i)
+        v[i] = v[i] * x[i];
+}
+void SUF(orc_pointwise_mult2)(int64_t n, T* v, const T* x, const T* y)
+{
+    int nt = orc_threads_for(n);
+#pragma omp parallel for num_threads(nt)
+    for(int64_t i = 0; i < n; ++i)
+        v[i] = y[i] * x[i];
+}
+
+/* :1365-1388 CopyFromPermute: this[perm[i]] = src[i] */
+void SUF(orc_copy_permute)(int64_t n, T* dst, const T* src, const int* perm)
+{
+    for(int64_t i = 0; i < n; ++i)
+        dst[perm[i]] = src[i];
+}
+/* :1390-1412 CopyFromPermuteBackward: this[i] = src[perm[i]] */
+void SUF(orc_copy_permute_backward)(int64_t n, T* dst, const T* src, const int* perm)
+{
+    for(int64_t i = 0; i < n; ++i)
+        dst[i] = src[perm[i]];
+}
+
+/* ---- ILU(0) and triangular solves ----------------------------------------- */
+
+/* src/base/host/host_matrix_csr.cpp:2096-2171  ILU0Factorize (serial IKJ, sorted CSR).
+ * Keeps the reference's "0 == absent" scatter-map quirk (:2142). */
+int SUF(orc_csr_ilu0)(int nrow, const int* row_offset, const int* col, T* val)
+{
+    int* diag_offset = (int*)calloc((size_t)nrow, sizeof(int));
+    int* nnz_entries = (int*)calloc((size_t)nrow, sizeof(int));
+    if(!diag_offset || !nnz_entries)
+    {
+        free(diag_offset);
+        free(nnz_entries);
+        return 0;
+    }
+    for(int ai = 0; ai < nrow; ++ai)
+    {
+        int row_start = row_offset[ai];
+        int row_end   = row_offset[ai + 1];
+        int j;
+        for(j = row_start; j < row_end; ++j)
+            nnz_entries[col[j]] = j;
+        for(j = row_start; j < row_end; ++j)
+        {
+            if(col[j] < ai)
+            {
+                int col_j  = col[j];
+                int diag_j = diag_offset[col_j];
+                if(val[diag_j] != (T)0)
+                {
+                    val[j] = val[j] / val[diag_j];
+                    for(int k = diag_j + 1; k < row_offset[col_j + 1]; ++k)
+                    {
+                        if(nnz_entries[col[k]] != 0)
+                            val[nnz_entries[col[k]]] -= val[j] * val[k];
+                    }
+                }
+            }
+            else
+                break;
+        }
+        diag_offset[ai] = j;
+        for(j = row_start; j < row_end; ++j)
+            nnz_entries[col[j]] = 0;
+    }
+    free(diag_offset);
+    free(nnz_entries);
+    return 1;
+}
+
+/* src/base/host/host_matrix_csr.cpp:1163-1221  LUSolve (serial): unit-lower forward
+ * sweep that stops at the first col >= row, then backward sweep dividing by the diagonal
+ * found by equality scan (falls back to the previously found position). */
+void SUF(orc_csr_lusolve)(int nrow, int64_t nnz, const int* row_offset, const int* col,
+                          const T* val, const T* in, T* out)
+{
+    for(int ai = 0; ai < nrow; ++ai)
+    {
+        out[ai] = in[ai];
+        for(int aj = row_offset[ai]; aj < row_offset[ai + 1]; ++aj)
+        {
+            if(col[aj] < ai)
+                out[ai] -= val[aj] * out[col[aj]];
+            else
+                break;
+        }
+    }
+    int64_t diag_aj = nnz - 1;
+    for(int ai = nrow - 1; ai >= 0; --ai)
+    {
+        for(int aj = row_offset[ai]; aj < row_offset[ai + 1]; ++aj)
+        {
+            if(col[aj] > ai)
+                out[ai] -= val[aj] * out[col[aj]];
+            if(col[aj] == ai)
+                diag_aj = aj;
+        }
+        out[ai] /= val[diag_aj];
+    }
+}
+
+/* src/base/host/host_matrix_csr.cpp:1357-1404  LSolve with L_diag_unit_ flag */
+void SUF(orc_csr_lsolve)(int nrow, const int* row_offset, const int* col, const T* val,
+                         int diag_unit, const T* in, T* out)
+{
+    int diag_aj = 0;
+    for(int ai = 0; ai < nrow; ++ai)
+    {
+        out[ai] = in[ai];
+        for(int aj = row_offset[ai]; aj < row_offset[ai + 1]; ++aj)
+        {
+            if(col[aj] < ai)
+                out[ai] -= val[aj] * out[col[aj]];
+            else
+            {
+                if(!diag_unit)
+                    diag_aj = aj;
+                break;
+            }
+        }
+        if(!diag_unit)
+            out[ai] /= val[diag_aj];
+    }
+}
+
+/* src/base/host/host_matrix_csr.cpp:1420-1466  USolve with U_diag_unit_ flag */
+void SUF(orc_csr_usolve)(int nrow, int64_t nnz, const int* row_offset, const int* col,
+                         const T* val, int diag_unit, const T* in, T* out)
+{
+    int64_t diag_aj = nnz - 1;
+    for(int ai = nrow - 1; ai >= 0; --ai)
+    {
+        out[ai] = in[ai];
+        for(int aj = row_offset[ai]; aj < row_offset[ai + 1]; ++aj)
+        {
+            if(col[aj] > ai)
+                out[ai] -= val[aj] * out[col[aj]];
+            if(!diag_unit)
+                if(col[aj] == ai)
+                    diag_aj = aj;
+        }
+        if(!diag_unit)
+            out[ai] /= val[diag_aj];
+    }
+}
+
+/* ---- permutation / extraction --------------------------------------------- */
+
+/* src/base/host/host_matrix_csr.cpp:3848-3958  Permute:  B = P A P^T, rows moved to
+ * perm[i], columns relabelled perm[col] and insertion-sorted inside each row. */
+void SUF(orc_csr_permute)(int nrow, int64_t nnz, const int* row_offset, const int* col,
+                          const T* val, const int* perm, int* out_row_offset, int* out_col,
+                          T* out_val)
+{
+    if(nnz <= 0)
+    {
+        for(int i = 0; i <= nrow; ++i)
+            out_row_offset[i] = 0;
+        return;
+    }
+    int* perm_row_nnz = (int*)malloc(sizeof(int) * (size_t)nrow);
+    int* tcol         = (int*)malloc(sizeof(int) * (size_t)nnz);
+    T*   tval         = (T*)malloc(sizeof(T) * (size_t)nnz);
+    for(int i = 0; i < nrow; ++i)
+        perm_row_nnz[perm[i]] = row_offset[i + 1] - row_offset[i];
+    int sum = 0;
+    for(int i = 0; i < nrow; ++i)
+    {
+        out_row_offset[i] = sum;
+        sum += perm_row_nnz[i];
+    }
+    out_row_offset[nrow] = sum;
+    for(int i = 0; i < nrow; ++i)
+    {
+        int permIndex = out_row_offset[perm[i]];
+        int prevIndex = row_offset[i];
+        int rn        = row_offset[i + 1] - row_offset[i];
+        for(int j = 0; j < rn; ++j)
+        {
+            tcol[permIndex + j] = col[prevIndex + j];
+            tval[permIndex + j] = val[prevIndex + j];
+        }
+    }
+    for(int i = 0; i < nrow; ++i)
+    {
+        int row_index = out_row_offset[i];
+        for(int j = 0; j < perm_row_nnz[i]; ++j)
+        {
+            int k    = j - 1;
+            int comp = perm[tcol[row_index + j]];
+            for(; k >= 0; --k)
+            {
+                if(out_col[row_index + k] > comp)
+                {
+                    out_val[row_index + k + 1] = out_val[row_index + k];
+                    out_col[row_index + k + 1] = out_col[row_index + k];
+                }
+                else
+                    break;
+            }
+            out_val[row_index + k + 1] = tval[row_index + j];
+            out_col[row_index + k + 1] = comp;
+        }
+    }
+    free(perm_row_nnz);
+    free(tcol);
+    free(tval);
+}
+
+/* src/base/host/host_matrix_csr.cpp:848-916  ExtractSubMatrix: count pass (out_col==NULL)
+ * or fill pass; columns shifted by col_offset, in-row order preserved. returns nnz. */
+int64_t SUF(orc_csr_extract_submatrix)(const int* row_offset, const int* col, const T* val,
+                                       int r0, int c0, int rsize, int csize, int* out_row_offset,
+                                       int* out_col, T* out_val)
+{
+    int64_t m = 0;
+    if(out_row_offset)
+        out_row_offset[0] = 0;
+    for(int ai = r0; ai < r0 + rsize; ++ai)
+    {
+        for(int aj = row_offset[ai]; aj < row_offset[ai + 1]; ++aj)
+        {
+            if((col[aj] >= c0) && (col[aj] < c0 + csize))
+            {
+                if(out_col)
+                {
+                    out_col[m] = col[aj] - c0;
+                    out_val[m] = val[aj];
+                }
+                ++m;
+            }
+        }
+        if(out_row_offset)
+            out_row_offset[ai - r0 + 1] = (int)m;
+    }
+    return m;
+}
+
+/* ---- operator + preconditioner objects used by the solver restatements ---- */
+
+typedef struct
+{
+    int        format; /* ORC_CSR / ORC_ELL / ORC_HYB */
+    int        nrow;
+    int64_t    nnz;
+    const int* row_offset;
+    const int* col;
+    const T*   val;
+    /* ELL / HYB storage built by the oracle's own conversion */
+    int  ell_max_row;
+    int* ell_col;
+    T*   ell_val;
+    int64_t coo_nnz;
+    int *   coo_row, *coo_col;
+    T*      coo_val;
+} SUF(orc_op);
+
+static void SUF(op_apply)(const SUF(orc_op) * A, const T* in, T* out)
+{
+    /* src/base/local_matrix.cpp:2154-2182: nnz == 0 -> zero fill */
+    if(A->nnz <= 0)
+    {
+        for(int i = 0; i < A->nrow; ++i)
+            out[i] = (T)0;
+        return;
+    }
+    if(A->format == ORC_ELL)
+        SUF(orc_ell_apply)(A->nrow, A->ell_max_row, A->ell_col, A->ell_val, in, out);
+    else if(A->format == ORC_HYB)
+        SUF(orc_hyb_apply)(A->nrow, A->nrow, A->ell_max_row, A->ell_col, A->ell_val, A->coo_nnz,
+                           A->coo_row, A->coo_col, A->coo_val, in, out);
+    else
+        SUF(orc_csr_apply)(A->nrow, A->row_offset, A->col, A->val, in, out);
+}
+
+static int SUF(op_build)(SUF(orc_op) * A, int format, int nrow, int64_t nnz, const int* row_offset,
+                         const int* col, const T* val)
+{
+    memset(A, 0, sizeof(*A));
+    A->format     = ORC_CSR;
+    A->nrow       = nrow;
+    A->nnz        = nnz;
+    A->row_offset = row_offset;
+    A->col        = col;
+    A->val        = val;
+    if(format == ORC_ELL)
+    {
+        int w = orc_csr_ell_width(nrow, nnz, row_offset);
+        if(w < 0) /* refused: stays CSR (src/base/local_matrix.cpp:2093-2114) */
+            return 1;
+        A->ell_max_row = w;
+        A->ell_col     = (int*)malloc(sizeof(int) * (size_t)w * nrow + 16);
+        A->ell_val     = (T*)malloc(sizeof(T) * (size_t)w * nrow + 16);
+        SUF(orc_csr_to_ell_fill)(nrow, nnz, row_offset, col, val, w, A->ell_col, A->ell_val);
+        A->format = ORC_ELL;
+    }
+    else if(format == ORC_HYB)
+    {
+        int     w = orc_csr_hyb_width(nrow, nnz);
+        int64_t c = orc_csr_hyb_coo_nnz(nrow, row_offset, w);
+        A->ell_max_row = w;
+        A->ell_col     = (int*)malloc(sizeof(int) * (size_t)w * nrow + 16);
+        A->ell_val     = (T*)malloc(sizeof(T) * (size_t)w * nrow + 16);
+        A->coo_nnz     = c;
+        A->coo_row     = (int*)malloc(sizeof(int) * (size_t)c + 16);
+        A->coo_col     = (int*)malloc(sizeof(int) * (size_t)c + 16);
+        A->coo_val     = (T*)malloc(sizeof(T) * (size_t)c + 16);
+        SUF(orc_csr_to_hyb_fill)(nrow, row_offset, col, val, w, A->ell_col, A->ell_val, A->coo_row,
+                                 A->coo_col, A->coo_val);
+        A->format = ORC_HYB;
+    }
+    return 1;
+}
+
+static void SUF(op_free)(SUF(orc_op) * A)
+{
+    free(A->ell_col);
+    free(A->ell_val);
+    free(A->coo_row);
+    free(A->coo_col);
+    free(A->coo_val);
+}
+
+typedef struct
+{
+    int kind; /* ORC_PC_* */
+    int n;
+    /* Jacobi */
+    T* inv_diag;
+    /* ILU(0): factored copy (shares pattern with A) */
+    const int* row_offset;
+    const int* col;
+    T*         lu_val;
+    int64_t    nnz;
+    /* MC-SGS (decomposed, omega = 1) */
+    int   num_blocks;
+    int*  block_sizes;
+    int*  block_offsets;
+    int*  perm;
+    int** blk_row_offset; /* [i*nb+j] */
+    int** blk_col;
+    T**   blk_val;
+    int64_t* blk_nnz;
+    T**   blk_inv_diag; /* diag_solver_[i] = Jacobi(block_ii) */
+    T**   blk_diag; /* diag_block_[i] */
+    T*    xperm; /* x_ */
+    T*    xtmp;
+} SUF(orc_pc);
+
+static void SUF(pc_free)(SUF(orc_pc) * P)
+{
+    free(P->inv_diag);
+    free(P->lu_val);
+    if(P->kind == ORC_PC_MCSGS)
+    {
+        int nb = P->num_blocks;
+        for(int i = 0; i < nb * nb; ++i)
+        {
+            free(P->blk_row_offset[i]);
+            free(P->blk_col[i]);
+            free(P->blk_val[i]);
+        }
+        for(int i = 0; i < nb; ++i)
+        {
+            free(P->blk_inv_diag[i]);
+            free(P->blk_diag[i]);
+        }
+        free(P->blk_row_offset);
+        free(P->blk_col);
+        free(P->blk_val);
+        free(P->blk_nnz);
+        free(P->blk_inv_diag);
+        free(P->blk_diag);
+        free(P->block_sizes);
+        free(P->block_offsets);
+        free(P->perm);
+        free(P->xperm);
+        free(P->xtmp);
+    }
+    memset(P, 0, sizeof(*P));
+}
+
+/* Build: Jacobi  src/solvers/preconditioners/preconditioner.cpp:95-112
+ *        ILU(0)  :449-470 (CloneFrom -> ILUpFactorize(0) -> LUAnalyse [host no-op])
+ *        MC-SGS  src/solvers/preconditioners/preconditioner_multicolored.cpp:303-340
+ *                (Analyse_ :162-177, Permute_ :180-187, Decompose_ :195-300) */
+static int SUF(pc_build)(SUF(orc_pc) * P, int kind, int nrow, int64_t nnz, const int* row_offset,
+                         const int* col, const T* val)
+{
+    memset(P, 0, sizeof(*P));
+    P->kind = kind;
+    P->n    = nrow;
+    if(kind == ORC_PC_JACOBI)
+    {
+        P->inv_diag = (T*)calloc((size_t)nrow, sizeof(T)); /* Allocate() zero-fills */
+        SUF(orc_csr_extract_inv_diag)(nrow, row_offset, col, val, P->inv_diag);
+    }
+    else if(kind == ORC_PC_ILU0)
+    {
+        P->row_offset = row_offset;
+        P->col        = col;
+        P->nnz        = nnz;
+        P->lu_val     = (T*)malloc(sizeof(T) * (size_t)nnz);
+        memcpy(P->lu_val, val, sizeof(T) * (size_t)nnz);
+        SUF(orc_csr_ilu0)(nrow, row_offset, col, P->lu_val);
+    }
+    else if(kind == ORC_PC_MCSGS)
+    {
+        P->perm       = (int*)malloc(sizeof(int) * (size_t)nrow);
+        int  nb       = 0;
+        int* sizes    = (int*)malloc(sizeof(int) * (size_t)(nrow > 0 ? nrow : 1));
+        orc_csr_multicoloring(nrow, nnz, row_offset, col, &nb, sizes, P->perm);
+        P->num_blocks    = nb;
+        P->block_sizes   = (int*)malloc(sizeof(int) * (size_t)nb);
+        P->block_offsets = (int*)malloc(sizeof(int) * (size_t)(nb + 1));
+        P->block_offsets[0] = 0;
+        for(int i = 0; i < nb; ++i)
+        {
+            P->block_sizes[i]       = sizes[i];
+            P->block_offsets[i + 1] = P->block_offsets[i] + sizes[i];
+        }
+        free(sizes);
+        /* permuted copy */
+        int* pro  = (int*)malloc(sizeof(int) * (size_t)(nrow + 1));
+        int* pcol = (int*)malloc(sizeof(int) * (size_t)nnz);
+        T*   pval = (T*)malloc(sizeof(T) * (size_t)nnz);
+        SUF(orc_csr_permute)(nrow, nnz, row_offset, col, val, P->perm, pro, pcol, pval);
+        P->blk_row_offset = (int**)calloc((size_t)nb * nb, sizeof(int*));
+        P->blk_col        = (int**)calloc((size_t)nb * nb, sizeof(int*));
+        P->blk_val        = (T**)calloc((size_t)nb * nb, sizeof(T*));
+        P->blk_nnz        = (int64_t*)calloc((size_t)nb * nb, sizeof(int64_t));
+        P->blk_inv_diag   = (T**)calloc((size_t)nb, sizeof(T*));
+        P->blk_diag       = (T**)calloc((size_t)nb, sizeof(T*));
+        for(int i = 0; i < nb; ++i)
+            for(int j = 0; j < nb; ++j)
+            {
+                int r0 = P->block_offsets[i], c0 = P->block_offsets[j];
+                int rs = P->block_sizes[i], cs = P->block_sizes[j];
+                int64_t m = SUF(orc_csr_extract_submatrix)(pro, pcol, pval, r0, c0, rs, cs, NULL,
+                                                           NULL, NULL);
+                int id                = i * nb + j;
+                P->blk_nnz[id]        = m;
+                P->blk_row_offset[id] = (int*)calloc((size_t)rs + 1, sizeof(int));
+                P->blk_col[id]        = (int*)malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
+                P->blk_val[id]        = (T*)malloc(sizeof(T) * (size_t)(m > 0 ? m : 1));
+                if(m > 0)
+                    SUF(orc_csr_extract_submatrix)(pro, pcol, pval, r0, c0, rs, cs,
+                                                   P->blk_row_offset[id], P->blk_col[id],
+                                                   P->blk_val[id]);
+            }
+        for(int i = 0; i < nb; ++i)
+        {
+            int id = i * nb + i, rs = P->block_sizes[i];
+            P->blk_diag[i]     = (T*)calloc((size_t)rs, sizeof(T));
+            P->blk_inv_diag[i] = (T*)calloc((size_t)rs, sizeof(T));
+            SUF(orc_csr_extract_diag)(rs, P->blk_row_offset[id], P->blk_col[id], P->blk_val[id],
+                                      P->blk_diag[i]);
+            /* Jacobi::Build on block ii; an empty block leaves an empty inverse diagonal,
+             * which Jacobi::Solve treats as identity (preconditioner.cpp:137-152) */
+            if(P->blk_nnz[id] > 0)
+                SUF(orc_csr_extract_inv_diag)(rs, P->blk_row_offset[id], P->blk_col[id],
+                                              P->blk_val[id], P->blk_inv_diag[i]);
+            else
+            {
+                free(P->blk_inv_diag[i]);
+                P->blk_inv_diag[i] = NULL;
+            }
+        }
+        free(pro);
+        free(pcol);
+        free(pval);
+        P->xperm = (T*)calloc((size_t)nrow, sizeof(T));
+        P->xtmp  = (T*)calloc((size_t)nrow, sizeof(T));
+    }
+    return 1;
+}
+
+/* Solve(rhs, x):
+ *   Jacobi  preconditioner.cpp:137-166 (x = inv_diag * rhs)
+ *   ILU     preconditioner.cpp:501-511 -> LUSolve
+ *   MC-SGS  preconditioner_multicolored.cpp:348-413 + preconditioner_multicolored_gs.cpp:127-199 */
+static void SUF(pc_solve)(SUF(orc_pc) * P, const T* rhs, T* x)
+{
+    int n = P->n;
+    if(P->kind == ORC_PC_JACOBI)
+    {
+        if(x != rhs)
+            SUF(orc_pointwise_mult2)(n, x, P->inv_diag, rhs);
+        else
+            SUF(orc_pointwise_mult)(n, x, P->inv_diag);
+    }
+    else if(P->kind == ORC_PC_ILU0)
+    {
+        SUF(orc_csr_lusolve)(n, P->nnz, P->row_offset, P->col, P->lu_val, rhs, x);
+    }
+    else if(P->kind == ORC_PC_MCSGS)
+    {
+        int nb = P->num_blocks;
+        T*  xb = P->xtmp; /* x_block_[i] = xb + block_offsets[i] */
+        /* ExtractRHSinX_: x = P rhs ; slices copied into x_block_ */
+        SUF(orc_copy_permute)(n, x, rhs, P->perm);
+        memcpy(xb, x, sizeof(T) * (size_t)n);
+        /* SolveL_ */
+        for(int i = 0; i < nb; ++i)
+        {
+            T* xi = xb + P->block_offsets[i];
+            for(int j = 0; j < i; ++j)
+            {
+                int id = i * nb + j;
+                if(P->blk_nnz[id] > 0)
+                    SUF(orc_csr_apply_add)(P->block_sizes[i], P->blk_nnz[id],
+                                           P->blk_row_offset[id], P->blk_col[id], P->blk_val[id],
+                                           xb + P->block_offsets[j], (T)-1, xi);
+            }
+            if(P->blk_inv_diag[i])
+                SUF(orc_pointwise_mult)(P->block_sizes[i], xi, P->blk_inv_diag[i]);
+        }
+        /* SolveD_ */
+        for(int i = 0; i < nb; ++i)
+            SUF(orc_pointwise_mult)(P->block_sizes[i], xb + P->block_offsets[i], P->blk_diag[i]);
+        /* SolveR_ (j descending) */
+        for(int i = nb - 1; i >= 0; --i)
+        {
+            T* xi = xb + P->block_offsets[i];
+            for(int j = nb - 1; j > i; --j)
+            {
+                int id = i * nb + j;
+                if(P->blk_nnz[id] > 0)
+                    SUF(orc_csr_apply_add)(P->block_sizes[i], P->blk_nnz[id],
+                                           P->blk_row_offset[id], P->blk_col[id], P->blk_val[id],
+                                           xb + P->block_offsets[j], (T)-1, xi);
+            }
+            if(P->blk_inv_diag[i])
+                SUF(orc_pointwise_mult)(P->block_sizes[i], xi, P->blk_inv_diag[i]);
+        }
+        /* InsertSolution_: x_ = concat blocks ; x = P^T x_ */
+        memcpy(P->xperm, xb, sizeof(T) * (size_t)n);
+        SUF(orc_copy_permute_backward)(n, x, P->xperm, P->perm);
+    }
+}
+
+/* stand-alone preconditioner apply for parity tests: builds, applies once, frees */
+int SUF(orc_precond_apply)(int kind, int nrow, int64_t nnz, const int* row_offset, const int* col,
+                           const T* val, const T* rhs, T* x)
+{
+    SUF(orc_pc) P;
+    if(kind == ORC_PC_NONE)
+    {
+        memcpy(x, rhs, sizeof(T) * (size_t)nrow);
+        return 1;
+    }
+    SUF(pc_build)(&P, kind, nrow, nnz, row_offset, col, val);
+    SUF(pc_solve)(&P, rhs, x);
+    SUF(pc_free)(&P);
+    return 1;
+}
+
+/* ---- Krylov drivers --------------------------------------------------------- */
+
+static void SUF(residual)(const SUF(orc_op) * A, const T* rhs, const T* x, T* r)
+{
+    /* op->Apply(*x, r); r->ScaleAdd(-1, rhs);   (cg.cpp:388-389 and twins) */
+    SUF(op_apply)(A, x, r);
+    SUF(orc_scale_add)(A->nrow, r, (T)-1, rhs);
+}
+
+/* src/solvers/krylov/cg.cpp:291-362 (no preconditioner) and :366-446 (preconditioned) */
+static void SUF(solve_cg)(const SUF(orc_op) * A, SUF(orc_pc) * P, const T* rhs, T* x,
+                          orc_iter_ctrl* ic)
+{
+    int n = A->nrow;
+    T*  r = (T*)calloc((size_t)n, sizeof(T));
+    T*  z = (T*)calloc((size_t)n, sizeof(T));
+    T*  p = (T*)calloc((size_t)n, sizeof(T));
+    T*  q = (T*)calloc((size_t)n, sizeof(T));
+    T   alpha, beta, rho, rho_old;
+
+    SUF(residual)(A, rhs, x, r);
+    T res_norm = SUF(orc_norm)(n, r);
+    if(orc_ic_init_residual(ic, fabs((double)res_norm)))
+    {
+        if(P)
+        {
+            SUF(pc_solve)(P, r, z);
+            memcpy(p, z, sizeof(T) * (size_t)n);
+            rho = SUF(orc_dot)(n, r, z);
+        }
+        else
+        {
+            memcpy(p, r, sizeof(T) * (size_t)n);
+            rho = SUF(orc_dot)(n, r, r);
+        }
+        while(1)
+        {
+            SUF(op_apply)(A, p, q);
+            alpha = rho / SUF(orc_dot)(n, p, q);
+            SUF(orc_add_scale)(n, x, p, alpha);
+            SUF(orc_add_scale)(n, r, q, -alpha);
+            res_norm = SUF(orc_norm)(n, r);
+            if(orc_ic_check_residual(ic, fabs((double)res_norm)))
+                break;
+            rho_old = rho;
+            if(P)
+            {
+                SUF(pc_solve)(P, r, z);
+                rho  = SUF(orc_dot)(n, r, z);
+                beta = rho / rho_old;
+                SUF(orc_scale_add)(n, p, beta, z);
+            }
+            else
+            {
+                rho  = SUF(orc_dot)(n, r, r);
+                beta = rho / rho_old;
+                SUF(orc_scale_add)(n, p, beta, r);
+            }
+        }
+    }
+    free(r);
+    free(z);
+    free(p);
+    free(q);
+}
+
+/* src/solvers/krylov/gmres.cpp:565-607 Givens helpers */
+static void SUF(gen_givens)(T dx, T dy, T* c, T* s)
+{
+    if(dy == (T)0)
+    {
+        *c = (T)1;
+        *s = (T)0;
+    }
+    else if(dx == (T)0)
+    {
+        *c = (T)0;
+        *s = (T)1;
+    }
+    else if(ORC_FABS(dy) > ORC_FABS(dx))
+    {
+        T tmp = dx / dy;
+        *s    = (T)1 / (T)ORC_SQRT((T)1 + tmp * tmp);
+        *c    = tmp * *s;
+    }
+    else
+    {
+        T tmp = dy / dx;
+        *c    = (T)1 / (T)ORC_SQRT((T)1 + tmp * tmp);
+        *s    = tmp * *c;
+    }
+}
+static void SUF(app_givens)(T c, T s, T* dx, T* dy)
+{
+    T temp = *dx;
+    *dx    = c * *dx + s * *dy;
+    *dy    = -s * temp + c * *dy;
+}
+
+/* src/solvers/krylov/gmres.cpp:274-413 (no preconditioner) / :416-562 (left preconditioned).
+ * H is (m+1) x m column-major: DENSE_IND(i,j,m+1,m) = i + j*(m+1) (matrix_formats_ind.hpp:30) */
+static void SUF(solve_gmres)(const SUF(orc_op) * A, SUF(orc_pc) * P, const T* rhs, T* x,
+                             orc_iter_ctrl* ic, int size)
+{
+    int  n = A->nrow;
+    T**  v = (T**)malloc(sizeof(T*) * (size_t)(size + 1));
+    for(int i = 0; i <= size; ++i)
+        v[i] = (T*)calloc((size_t)n, sizeof(T));
+    T* z = (T*)calloc((size_t)n, sizeof(T));
+    T* c = (T*)calloc((size_t)size, sizeof(T));
+    T* s = (T*)calloc((size_t)size, sizeof(T));
+    T* r = (T*)calloc((size_t)size + 1, sizeof(T));
+    T* H = (T*)calloc((size_t)(size + 1) * size, sizeof(T));
+    T  one = (T)1;
+#define HIND(i, j) ((i) + (j) * (size + 1))
+
+    if(P)
+    {
+        SUF(residual)(A, rhs, x, z);
+        SUF(pc_solve)(P, z, v[0]);
+    }
+    else
+        SUF(residual)(A, rhs, x, v[0]);
+    for(int i = 0; i <= size; ++i)
+        r[i] = (T)0;
+    r[0] = SUF(orc_norm)(n, v[0]);
+
+    if(orc_ic_init_residual(ic, fabs((double)r[0])))
+    {
+        while(1)
+        {
+            SUF(orc_scale)(n, v[0], one / r[0]);
+            int i = 0;
+            while(i < size)
+            {
+                if(P)
+                {
+                    SUF(op_apply)(A, v[i], z);
+                    SUF(pc_solve)(P, z, v[i + 1]);
+                }
+                else
+                    SUF(op_apply)(A, v[i], v[i + 1]);
+                for(int k = 0; k <= i; ++k)
+                {
+                    int idx = HIND(k, i);
+                    H[idx]  = SUF(orc_dot)(n, v[k], v[i + 1]);
+                    SUF(orc_add_scale)(n, v[i + 1], v[k], -H[idx]);
+                }
+                int ii = HIND(i, i), ip1i = HIND(i + 1, i);
+                H[ip1i] = SUF(orc_norm)(n, v[i + 1]);
+                SUF(orc_scale)(n, v[i + 1], one / H[ip1i]);
+                for(int k = 0; k < i; ++k)
+                    SUF(app_givens)(c[k], s[k], &H[HIND(k, i)], &H[HIND(k + 1, i)]);
+                SUF(gen_givens)(H[ii], H[ip1i], &c[i], &s[i]);
+                SUF(app_givens)(c[i], s[i], &H[ii], &H[ip1i]);
+                SUF(app_givens)(c[i], s[i], &r[i], &r[i + 1]);
+                ++i;
+                if(orc_ic_check_residual(ic, fabs((double)r[i])))
+                    break;
+            }
+            for(int j = i - 1; j >= 0; --j)
+            {
+                r[j] /= H[HIND(j, j)];
+                for(int k = 0; k < j; ++k)
+                    r[k] -= H[HIND(k, j)] * r[j];
+            }
+            SUF(orc_add_scale)(n, x, v[0], r[0]);
+            for(int j = 1; j < i; ++j)
+                SUF(orc_add_scale)(n, x, v[j], r[j]);
+            if(P)
+            {
+                SUF(residual)(A, rhs, x, z);
+                SUF(pc_solve)(P, z, v[0]);
+            }
+            else
+                SUF(residual)(A, rhs, x, v[0]);
+            for(int k = 0; k <= size; ++k)
+                r[k] = (T)0;
+            r[0] = SUF(orc_norm)(n, v[0]);
+            if(orc_ic_check_residual_nocount(ic, fabs((double)r[0])))
+                break;
+        }
+    }
+#undef HIND
+    for(int i = 0; i <= size; ++i)
+        free(v[i]);
+    free(v);
+    free(z);
+    free(c);
+    free(s);
+    free(r);
+    free(H);
+}
+
+/* src/solvers/krylov/bicgstab.cpp:245-361 (no preconditioner) / :365-489 (right preconditioned) */
+static void SUF(solve_bicgstab)(const SUF(orc_op) * A, SUF(orc_pc) * P, const T* rhs, T* x,
+                                orc_iter_ctrl* ic)
+{
+    int n  = A->nrow;
+    T*  r  = (T*)calloc((size_t)n, sizeof(T));
+    T*  r0 = (T*)calloc((size_t)n, sizeof(T));
+    T*  p  = (T*)calloc((size_t)n, sizeof(T));
+    T*  q  = (T*)calloc((size_t)n, sizeof(T));
+    T*  t  = (T*)calloc((size_t)n, sizeof(T));
+    T*  v  = (T*)calloc((size_t)n, sizeof(T));
+    T*  z  = (T*)calloc((size_t)n, sizeof(T));
+    T   alpha, beta, omega, rho, rho_old;
+
+    SUF(residual)(A, rhs, x, r0);
+    T res_norm = SUF(orc_norm)(n, r0);
+    if(orc_ic_init_residual(ic, fabs((double)res_norm)))
+    {
+        memcpy(r, r0, sizeof(T) * (size_t)n);
+        memcpy(p, r, sizeof(T) * (size_t)n);
+        rho = SUF(orc_dot)(n, r, r);
+        if(P)
+            SUF(pc_solve)(P, r, z);
+        while(1)
+        {
+            const T* dir = P ? z : p; /* q = A z  (precond)  /  q = A p */
+            SUF(op_apply)(A, dir, q);
+            alpha = rho / SUF(orc_dot)(n, r0, q);
+            SUF(orc_add_scale)(n, r, q, -alpha);
+            const T* sv = r;
+            if(P)
+            {
+                SUF(pc_solve)(P, r, v);
+                sv = v;
+            }
+            SUF(op_apply)(A, sv, t);
+            omega = SUF(orc_dot)(n, t, r) / SUF(orc_dot)(n, t, t);
+            if((ORC_FABS(omega) == (T)INFINITY) || (omega != omega) || (omega == (T)0))
+            {
+                SUF(orc_add_scale)(n, x, p, alpha);
+                SUF(op_apply)(A, x, p);
+                SUF(orc_scale_add)(n, p, (T)-1, rhs);
+                res_norm = SUF(orc_norm)(n, p);
+                orc_ic_check_residual(ic, fabs((double)res_norm));
+                break;
+            }
+            /* x = x + alpha*dir + omega*sv */
+            SUF(orc_scale_add2)(n, x, (T)1, dir, alpha, sv, omega);
+            SUF(orc_add_scale)(n, r, t, -omega);
+            res_norm = SUF(orc_norm)(n, r);
+            if(orc_ic_check_residual(ic, fabs((double)res_norm)))
+                break;
+            rho_old = rho;
+            rho     = SUF(orc_dot)(n, r0, r);
+            if(rho == (T)0)
+                break;
+            beta = (rho / rho_old) * (alpha / omega);
+            SUF(orc_scale_add2)(n, p, beta, q, -beta * omega, r, (T)1);
+            if(P)
+                SUF(pc_solve)(P, p, z);
+        }
+    }
+    free(r);
+    free(r0);
+    free(p);
+    free(q);
+    free(t);
+    free(v);
+    free(z);
+}
+
+/* Build()+Solve() of one solver/preconditioner/format combination.
+ * The preconditioner is built from the CSR state and the operator is converted afterwards,
+ * as in the reference tests (clients/include/testing_cg.hpp:151-155). */
+int SUF(orc_solve)(int nrow, int64_t nnz, const int* row_offset, const int* col, const T* val,
+                   const T* rhs, T* x, orc_solve_cfg* cfg)
+{
+    SUF(orc_op) A;
+    SUF(orc_pc) P;
+    orc_iter_ctrl ic;
+    int           have_pc = cfg->precond != ORC_PC_NONE;
+    if(have_pc)
+        SUF(pc_build)(&P, cfg->precond, nrow, nnz, row_offset, col, val);
+    SUF(op_build)(&A, cfg->format, nrow, nnz, row_offset, col, val);
+    orc_ic_setup(&ic, cfg);
+    if(cfg->solver == ORC_CG)
+        SUF(solve_cg)(&A, have_pc ? &P : NULL, rhs, x, &ic);
+    else if(cfg->solver == ORC_GMRES)
+        SUF(solve_gmres)(&A, have_pc ? &P : NULL, rhs, x, &ic, cfg->basis > 0 ? cfg->basis : 30);
+    else if(cfg->solver == ORC_BICGSTAB)
+        SUF(solve_bicgstab)(&A, have_pc ? &P : NULL, rhs, x, &ic);
+    else
+        return 0;
+    orc_ic_finish(&ic, cfg);
+    SUF(op_free)(&A);
+    if(have_pc)
+        SUF(pc_free)(&P);
+    return 1;
+}

@@ -1,0 +1,544 @@
+// ref_probe.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// Own driver (no reference source copied) that links the GENUINE rocALUTION library the ROCm
+// image ships (/opt/rocm/lib/librocalution.so, public headers /opt/rocm/include/rocalution) and
+// runs its host/OpenMP backend (accelerator disabled) -- or, for the optional vendor column, its
+// rocSPARSE/rocBLAS HIP backend -- on inputs handed over as raw binary files.
+//
+//   ref_probe gen   <indir> <outdir>            golden fixtures (see oracle/gen_golden.py)
+//   ref_probe bench <N> <iters> <threads> <accel 0|1> [solver=cg|gmres|bicgstab] [precond=...]
+//                                               CG+Jacobi etc. on 3-D 7-pt Poisson N^3, prints JSON
+//
+// Built by oracle/Makefile into oracle/_ref/ (git-ignored). Used by oracle/gen_golden.py in the
+// dev container and by bench.py's cpu_baseline leg ("kind":"reference") on the GPU box.
+#include <rocalution/rocalution.hpp>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+using namespace rocalution;
+
+typedef LocalMatrix<double> MatD;
+typedef LocalVector<double> VecD;
+typedef LocalMatrix<float>  MatF;
+typedef LocalVector<float>  VecF;
+
+static std::string g_out;
+
+template <typename X>
+static void dump(const std::string& name, const X* p, size_t n)
+{
+    std::ofstream f(g_out + "/" + name + ".bin", std::ios::binary);
+    f.write(reinterpret_cast<const char*>(p), sizeof(X) * n);
+}
+static void dump_vec(const std::string& name, const VecD& v)
+{
+    std::vector<double> h(v.GetSize());
+    v.CopyToHostData(h.data());
+    dump(name, h.data(), h.size());
+}
+template <typename X>
+static std::vector<X> slurp(const std::string& path)
+{
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if(!f)
+    {
+        std::cerr << "cannot open " << path << std::endl;
+        exit(2);
+    }
+    size_t         sz = f.tellg();
+    std::vector<X> v(sz / sizeof(X));
+    f.seekg(0);
+    f.read(reinterpret_cast<char*>(v.data()), sz);
+    return v;
+}
+
+struct Csr
+{
+    int64_t              n, nnz;
+    std::vector<int32_t> rp, ci;
+    std::vector<double>  va;
+};
+
+static void load_into(const Csr& A, MatD& m, const std::string& name)
+{
+    m.Clear();
+    m.AllocateCSR(name, A.nnz, A.n, A.n);
+    m.CopyFromCSR(A.rp.data(), A.ci.data(), A.va.data());
+}
+
+static void dump_csr(const std::string& name, const MatD& m)
+{
+    std::vector<int32_t> rp(m.GetM() + 1), ci(m.GetNnz());
+    std::vector<double>  va(m.GetNnz());
+    m.CopyToCSR(rp.data(), ci.data(), va.data());
+    dump(name + "_rowptr", rp.data(), rp.size());
+    dump(name + "_col", ci.data(), ci.size());
+    dump(name + "_val", va.data(), va.size());
+}
+
+// one Build()+Solve(); writes <tag>_hist (text->bin), <tag>_x, <tag>_meta (iters,status,res)
+template <class Solver>
+static void run_solver(const std::string& tag, Solver& ls, VecD& rhs, VecD& x)
+{
+    ls.Verbose(0);
+    ls.RecordResidualHistory();
+    ls.Solve(rhs, &x);
+    std::string hf = g_out + "/" + tag + "_hist.txt";
+    ls.RecordHistory(hf);
+    double meta[3] = {(double)ls.GetIterationCount(), (double)ls.GetSolverStatus(),
+                      ls.GetCurrentResidual()};
+    dump(tag + "_meta", meta, 3);
+    dump_vec(tag + "_x", x);
+}
+
+static int cmd_gen(const std::string& in, const std::string& out)
+{
+    g_out = out;
+    disable_accelerator_rocalution(true);
+    init_rocalution();
+    set_omp_threads_rocalution(1); // fixtures are generated single-threaded (deterministic sums)
+
+    std::vector<int64_t> hdr = slurp<int64_t>(in + "/hdr.bin");
+    Csr                  A;
+    A.n   = hdr[0];
+    A.nnz = hdr[1];
+    A.rp  = slurp<int32_t>(in + "/rowptr.bin");
+    A.ci  = slurp<int32_t>(in + "/col.bin");
+    A.va  = slurp<double>(in + "/val.bin");
+    std::vector<double> xin = slurp<double>(in + "/x.bin");
+    std::vector<double> yin = slurp<double>(in + "/y.bin");
+    int                 do_solvers = (int)hdr[2];
+    int                 basis      = (int)hdr[3];
+
+    MatD mat;
+    load_into(A, mat, "A");
+    VecD x, y, ones, rhs, tmp;
+    x.Allocate("x", A.n);
+    y.Allocate("y", A.n);
+    ones.Allocate("ones", A.n);
+    rhs.Allocate("rhs", A.n);
+    tmp.Allocate("tmp", A.n);
+    x.CopyFromHostData(xin.data());
+    ones.Ones();
+
+    // --- SpMV in every format -------------------------------------------------------------
+    mat.Apply(x, &y);
+    dump_vec("spmv_csr", y);
+    y.CopyFromHostData(yin.data());
+    mat.ApplyAdd(x, -0.75, &y);
+    dump_vec("spmv_csr_add", y);
+    mat.Apply(ones, &rhs);
+    dump_vec("rhs_ones", rhs);
+
+    {
+        MatD e;
+        e.CloneFrom(mat);
+        e.ConvertToELL();
+        int fmt = e.GetFormat();
+        dump("ell_format", &fmt, 1);
+        if(fmt == ELL)
+        {
+            e.Apply(x, &y);
+            dump_vec("spmv_ell", y);
+            y.CopyFromHostData(yin.data());
+            e.ApplyAdd(x, -0.75, &y);
+            dump_vec("spmv_ell_add", y);
+            int*    ec = NULL;
+            double* ev = NULL;
+            int     w  = 0;
+            e.LeaveDataPtrELL(&ec, &ev, w);
+            dump("ell_width", &w, 1);
+            dump("ell_col", ec, (size_t)w * A.n);
+            dump("ell_val", ev, (size_t)w * A.n);
+            delete[] ec;
+            delete[] ev;
+        }
+    }
+    {
+        MatD h;
+        h.CloneFrom(mat);
+        h.ConvertToHYB();
+        h.Apply(x, &y);
+        dump_vec("spmv_hyb", y);
+        y.CopyFromHostData(yin.data());
+        h.ApplyAdd(x, -0.75, &y);
+        dump_vec("spmv_hyb_add", y);
+    }
+    {
+        MatD c;
+        c.CloneFrom(mat);
+        c.ConvertToCOO();
+        c.Apply(x, &y);
+        dump_vec("spmv_coo", y);
+        y.CopyFromHostData(yin.data());
+        c.ApplyAdd(x, -0.75, &y);
+        dump_vec("spmv_coo_add", y);
+    }
+
+    // --- BLAS-1 ----------------------------------------------------------------------------
+    {
+        VecD a, b;
+        a.Allocate("a", A.n);
+        b.Allocate("b", A.n);
+        a.CopyFromHostData(xin.data());
+        b.CopyFromHostData(yin.data());
+        double sc[3] = {a.Dot(b), a.DotNonConj(b), a.Norm()};
+        dump("blas_scalars", sc, 3);
+        tmp.CopyFrom(a);
+        tmp.AddScale(b, 0.375);
+        dump_vec("blas_add_scale", tmp);
+        tmp.CopyFrom(a);
+        tmp.ScaleAdd(-1.25, b);
+        dump_vec("blas_scale_add", tmp);
+        tmp.CopyFrom(a);
+        tmp.ScaleAdd2(0.3, b, -1.7, rhs, 0.11);
+        dump_vec("blas_scale_add2", tmp);
+        tmp.CopyFrom(a);
+        tmp.Scale(1.0 / 3.0);
+        dump_vec("blas_scale", tmp);
+        tmp.PointWiseMult(a, b);
+        dump_vec("blas_pointwise", tmp);
+    }
+
+    // --- diagonal, ILU(0), triangular solves -----------------------------------------------
+    {
+        VecD d;
+        mat.ExtractInverseDiagonal(&d);
+        dump_vec("inv_diag", d);
+    }
+    {
+        MatD lu;
+        lu.CloneFrom(mat);
+        lu.ILU0Factorize();
+        dump_csr("ilu0", lu);
+        lu.LUAnalyse();
+        lu.LUSolve(x, &y);
+        dump_vec("lusolve", y);
+        lu.LUAnalyseClear();
+    }
+    {
+        MatD t;
+        t.CloneFrom(mat);
+        t.LAnalyse(false);
+        t.LSolve(x, &y);
+        dump_vec("lsolve_nonunit", y);
+        t.LAnalyseClear();
+        t.UAnalyse(false);
+        t.USolve(x, &y);
+        dump_vec("usolve_nonunit", y);
+        t.UAnalyseClear();
+    }
+
+    // --- multi-colouring, permutation -------------------------------------------------------
+    {
+        int              nc    = 0;
+        int*             sizes = NULL;
+        LocalVector<int> perm;
+        mat.MultiColoring(nc, &sizes, &perm);
+        dump("mc_num_colors", &nc, 1);
+        dump("mc_sizes", sizes, nc);
+        std::vector<int> hp(A.n);
+        perm.CopyToHostData(hp.data());
+        dump("mc_perm", hp.data(), hp.size());
+        MatD pm;
+        pm.CloneFrom(mat);
+        pm.Permute(perm);
+        dump_csr("permuted", pm);
+        tmp.CopyFromPermute(x, perm);
+        dump_vec("vec_permute", tmp);
+        tmp.CopyFromPermuteBackward(x, perm);
+        dump_vec("vec_permute_backward", tmp);
+        free_host(&sizes);
+    }
+
+    // --- preconditioner applies -------------------------------------------------------------
+    {
+        Jacobi<MatD, VecD, double> p;
+        p.SetOperator(mat);
+        p.Build();
+        p.Solve(x, &y);
+        dump_vec("pc_jacobi", y);
+        p.Clear();
+    }
+    {
+        ILU<MatD, VecD, double> p;
+        p.SetOperator(mat);
+        p.Build();
+        p.Solve(x, &y);
+        dump_vec("pc_ilu0", y);
+        p.Clear();
+    }
+    {
+        MultiColoredSGS<MatD, VecD, double> p;
+        p.SetOperator(mat);
+        p.Build();
+        p.Solve(x, &y);
+        dump_vec("pc_mcsgs", y);
+        p.Clear();
+    }
+
+    // --- solvers (rhs = A*1, x0 = 0, default tolerances) -------------------------------------
+    if(do_solvers)
+    {
+        VecD sol;
+        sol.Allocate("sol", A.n);
+        {
+            CG<MatD, VecD, double> ls;
+            ls.SetOperator(mat);
+            ls.Build();
+            sol.Zeros();
+            run_solver("cg_none", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            CG<MatD, VecD, double>     ls;
+            Jacobi<MatD, VecD, double> p;
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(p);
+            ls.Build();
+            sol.Zeros();
+            run_solver("cg_jacobi", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            // x0 = x (seeded random), tighter tolerance, like clients/include/testing_cg.hpp
+            CG<MatD, VecD, double>     ls;
+            Jacobi<MatD, VecD, double> p;
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(p);
+            ls.Init(1e-8, 0.0, 1e8, 10000);
+            ls.Build();
+            sol.CopyFrom(x);
+            run_solver("cg_jacobi_x0", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            GMRES<MatD, VecD, double> ls;
+            ls.SetOperator(mat);
+            ls.SetBasisSize(basis);
+            ls.Build();
+            sol.Zeros();
+            run_solver("gmres_none", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            GMRES<MatD, VecD, double> ls;
+            ILU<MatD, VecD, double>   p;
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(p);
+            ls.SetBasisSize(basis);
+            ls.Build();
+            sol.Zeros();
+            run_solver("gmres_ilu0", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            BiCGStab<MatD, VecD, double> ls;
+            ls.SetOperator(mat);
+            ls.Build();
+            sol.Zeros();
+            run_solver("bicgstab_none", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            BiCGStab<MatD, VecD, double>        ls;
+            MultiColoredSGS<MatD, VecD, double> p;
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(p);
+            ls.Build();
+            sol.Zeros();
+            run_solver("bicgstab_mcsgs", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            // operator converted AFTER Build, as the reference tests do (testing_cg.hpp:151-155)
+            MatD e;
+            e.CloneFrom(mat);
+            BiCGStab<MatD, VecD, double>        ls;
+            MultiColoredSGS<MatD, VecD, double> p;
+            ls.SetOperator(e);
+            ls.SetPreconditioner(p);
+            ls.Build();
+            e.ConvertToELL();
+            sol.Zeros();
+            run_solver("bicgstab_mcsgs_ell", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            MatD e;
+            e.CloneFrom(mat);
+            CG<MatD, VecD, double>     ls;
+            Jacobi<MatD, VecD, double> p;
+            ls.SetOperator(e);
+            ls.SetPreconditioner(p);
+            ls.Build();
+            e.ConvertToHYB();
+            sol.Zeros();
+            run_solver("cg_jacobi_hyb", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            // mixed precision: fp64 defect correction around fp32 CG+Jacobi with the sample's
+            // inner tolerances (clients/samples/mixed-precision.cpp:85)
+            MixedPrecisionDC<MatD, VecD, double, MatF, VecF, float> mp;
+            CG<MatF, VecF, float>                                     cg;
+            Jacobi<MatF, VecF, float>                                 p;
+            cg.SetPreconditioner(p);
+            cg.Init(1e-5, 1e-2, 1e+20, 100000);
+            cg.Verbose(0);
+            mp.SetOperator(mat);
+            mp.Set(cg);
+            mp.Build();
+            sol.Zeros();
+            run_solver("mixed_cg_jacobi", mp, rhs, sol);
+            mp.Clear();
+        }
+    }
+
+    stop_rocalution();
+    return 0;
+}
+
+// 3-D 7-point Poisson, natural ordering, ascending columns
+static void poisson7(int N, std::vector<int32_t>& rp, std::vector<int32_t>& ci,
+                     std::vector<double>& va)
+{
+    int64_t n = (int64_t)N * N * N;
+    rp.resize(n + 1);
+    ci.clear();
+    va.clear();
+    ci.reserve(7 * n);
+    va.reserve(7 * n);
+    int64_t N2 = (int64_t)N * N;
+    rp[0]      = 0;
+    for(int z = 0; z < N; ++z)
+        for(int y = 0; y < N; ++y)
+            for(int x = 0; x < N; ++x)
+            {
+                int64_t r = ((int64_t)z * N + y) * N + x;
+                if(z > 0) { ci.push_back((int32_t)(r - N2)); va.push_back(-1.0); }
+                if(y > 0) { ci.push_back((int32_t)(r - N)); va.push_back(-1.0); }
+                if(x > 0) { ci.push_back((int32_t)(r - 1)); va.push_back(-1.0); }
+                ci.push_back((int32_t)r);
+                va.push_back(6.0);
+                if(x < N - 1) { ci.push_back((int32_t)(r + 1)); va.push_back(-1.0); }
+                if(y < N - 1) { ci.push_back((int32_t)(r + N)); va.push_back(-1.0); }
+                if(z < N - 1) { ci.push_back((int32_t)(r + N2)); va.push_back(-1.0); }
+                rp[r + 1] = (int32_t)ci.size();
+            }
+}
+
+static int cmd_bench(int argc, char** argv)
+{
+    int         N       = atoi(argv[2]);
+    int         iters   = atoi(argv[3]);
+    int         threads = atoi(argv[4]);
+    int         accel   = atoi(argv[5]);
+    std::string solver  = argc > 6 ? argv[6] : "cg";
+    std::string precond = argc > 7 ? argv[7] : "jacobi";
+
+    if(!accel)
+        disable_accelerator_rocalution(true);
+    init_rocalution();
+    if(threads > 0)
+        set_omp_threads_rocalution(threads);
+
+    std::vector<int32_t> rp, ci;
+    std::vector<double>  va;
+    poisson7(N, rp, ci, va);
+    int64_t n = (int64_t)N * N * N, nnz = (int64_t)ci.size();
+    MatD    mat;
+    mat.AllocateCSR("poisson7", nnz, n, n);
+    mat.CopyFromCSR(rp.data(), ci.data(), va.data());
+    VecD x, rhs, e;
+    if(accel)
+    {
+        mat.MoveToAccelerator();
+        x.MoveToAccelerator();
+        rhs.MoveToAccelerator();
+        e.MoveToAccelerator();
+    }
+    x.Allocate("x", n);
+    rhs.Allocate("rhs", n);
+    e.Allocate("e", n);
+    e.Ones();
+    mat.Apply(e, &rhs);
+    x.Zeros();
+
+    // SpMV micro-benchmark (clients/samples/benchmark.cpp method: timed reps + sync)
+    int    reps = accel ? 200 : 20;
+    for(int i = 0; i < 3; ++i)
+        mat.Apply(e, &x);
+    _rocalution_sync();
+    double t0 = rocalution_time();
+    for(int i = 0; i < reps; ++i)
+        mat.Apply(e, &x);
+    _rocalution_sync();
+    double t_spmv = (rocalution_time() - t0) / 1e6 / reps;
+    x.Zeros();
+
+    IterativeLinearSolver<MatD, VecD, double>* ls = NULL;
+    CG<MatD, VecD, double>                     cg;
+    GMRES<MatD, VecD, double>                  gm;
+    BiCGStab<MatD, VecD, double>               bi;
+    if(solver == "gmres")
+    {
+        gm.SetBasisSize(30);
+        ls = &gm;
+    }
+    else if(solver == "bicgstab")
+        ls = &bi;
+    else
+        ls = &cg;
+    Jacobi<MatD, VecD, double>          pj;
+    ILU<MatD, VecD, double>             pi;
+    MultiColoredSGS<MatD, VecD, double> ps;
+    ls->SetOperator(mat);
+    if(precond == "jacobi")
+        ls->SetPreconditioner(pj);
+    else if(precond == "ilu0")
+        ls->SetPreconditioner(pi);
+    else if(precond == "mcsgs")
+        ls->SetPreconditioner(ps);
+    // exactly `iters` iterations: tolerances that can never be met
+    ls->Init(0.0, 0.0, 1e300, iters);
+    ls->Verbose(0);
+    double tb0 = rocalution_time();
+    ls->Build();
+    _rocalution_sync();
+    double t_build = (rocalution_time() - tb0) / 1e6;
+    _rocalution_sync();
+    double ts0 = rocalution_time();
+    ls->Solve(rhs, &x);
+    _rocalution_sync();
+    double t_solve = (rocalution_time() - ts0) / 1e6;
+    int    it      = ls->GetIterationCount();
+    double bytes   = 4.0 * (n + nnz) + 8.0 * (2.0 * n + nnz);
+    printf("{\"ref_probe\":\"bench\",\"N\":%d,\"n\":%lld,\"nnz\":%lld,\"accel\":%d,\"threads\":%d,"
+           "\"solver\":\"%s\",\"precond\":\"%s\",\"iters\":%d,\"t_build_s\":%.6f,\"t_solve_s\":%.6f,"
+           "\"iters_per_s\":%.4f,\"t_spmv_s\":%.9f,\"spmv_GBps\":%.3f,\"final_res\":%.17g}\n",
+           N, (long long)n, (long long)nnz, accel, threads, solver.c_str(), precond.c_str(), it,
+           t_build, t_solve, it / t_solve, t_spmv, bytes / t_spmv / 1e9, ls->GetCurrentResidual());
+    ls->Clear();
+    stop_rocalution();
+    return 0;
+}
+
+int main(int argc, char** argv)
+{
+    if(argc >= 4 && std::string(argv[1]) == "gen")
+        return cmd_gen(argv[2], argv[3]);
+    if(argc >= 6 && std::string(argv[1]) == "bench")
+        return cmd_bench(argc, argv);
+    std::cerr << "usage: ref_probe gen <indir> <outdir> | bench <N> <iters> <threads> <accel>"
+              << std::endl;
+    return 1;
+}
