@@ -1,0 +1,201 @@
+/* ==========================================================================
+ * rocalution_amd.h -- C ABI of the MI355X-native Krylov backend (librocalution_amd.so)
+ *
+ * This is the drop-in boundary.  In the reference the host library talks to
+ * its accelerator plugin through 30 C++ symbols (lifecycle + factories, declared in
+ * src/base/hip/backend_hip.hpp:40-82) and through the virtual tables of
+ * AcceleratorVector<T> (src/base/base_vector.hpp:43-232) and AcceleratorMatrix<T>
+ * (src/base/base_matrix.hpp:78-866).  Each entry point below is the flat-C form of ONE of
+ * those symbols / virtual methods; the comment on it cites the reference interface it
+ * replaces.  Plain pointers and sizes only -- no torch / STL types.
+ *
+ * Conventions
+ *   - every function returns an int status (RAMD_OK == 0); ramd_last_error() gives text.
+ *     (The reference aborts via LOG_INFO+exit(1), src/utils/log.hpp:95-100; the C++ API
+ *      layer in include/rocalution/ restores that behaviour on top of these codes.)
+ *   - "optional" backend operations that the reference lets a backend decline by returning
+ *     false (host fallback protocol, src/base/local_matrix.cpp:2299-2340) return
+ *     RAMD_ERR_UNSUPPORTED here; nothing in this library falls back to host compute.
+ *   - one host thread drives the library; work is queued on the CURRENT stream
+ *     (ramd_compute_default/interior/ghost switch it, like the reference).
+ *   - value types: fp64 and fp32; index vectors: int32.  Row offsets and column indices
+ *     are int32 (the reference's default PtrType / int, src/utils/types.hpp.in:30-32).
+ * ========================================================================== */
+#ifndef ROCALUTION_AMD_H_
+#define ROCALUTION_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ---- */
+enum
+{
+    RAMD_OK              = 0,
+    RAMD_ERR_HIP         = 1, /* a HIP runtime call failed */
+    RAMD_ERR_ARG         = 2, /* bad argument (the reference asserts) */
+    RAMD_ERR_UNSUPPORTED = 3, /* optional op not provided by this backend ("return false") */
+    RAMD_ERR_REFUSED     = 4, /* conversion refused by the reference's own rule (ELL width) */
+    RAMD_ERR_NO_DEVICE   = 5,
+    RAMD_ERR_STATE       = 6 /* object in the wrong state (not analysed, wrong format ...) */
+};
+
+/* value / index types of vectors and matrices */
+enum { RAMD_F64 = 0, RAMD_F32 = 1, RAMD_I32 = 2 };
+
+/* matrix formats: numbering of src/base/matrix_formats.hpp (CSR=1, COO=4, ELL=6, HYB=7) */
+enum { RAMD_CSR = 1, RAMD_COO = 4, RAMD_ELL = 6, RAMD_HYB = 7 };
+
+typedef struct ramd_vec_s* ramd_vec_t; /* an AcceleratorVector<T> instance */
+typedef struct ramd_mat_s* ramd_mat_t; /* an AcceleratorMatrix<T> instance (any format) */
+
+/* ======================================================================= lifecycle
+ * rocalution_init_hip / rocalution_stop_hip / rocalution_info_hip / rocalution_get_arch_hip
+ * (src/base/hip/backend_hip.hpp:40-60, backend_hip.cpp:50-190), called from
+ * init_rocalution/stop_rocalution (src/base/backend_manager.cpp:110-290). */
+int         ramd_init(int device); /* device < 0: keep the current device */
+int         ramd_stop(void);
+int         ramd_is_initialized(void);
+int         ramd_info(char* buf, int buflen); /* human readable backend description */
+const char* ramd_get_arch(void); /* "gfx950" ... */
+const char* ramd_last_error(void);
+int         ramd_device_count(int* count);
+
+/* rocalution_hip_sync{,_default,_interior,_ghost} (backend_hip.hpp:48-57) */
+int ramd_sync(void);
+int ramd_sync_default(void);
+int ramd_sync_interior(void);
+int ramd_sync_ghost(void);
+/* rocalution_hip_compute_{default,interior,ghost} (backend_hip.hpp:63-69): select the
+ * stream every following op is queued on (reference: HIP_stream_current). */
+int   ramd_compute_default(void);
+int   ramd_compute_interior(void);
+int   ramd_compute_ghost(void);
+void* ramd_current_stream(void); /* hipStream_t, for callers that interleave own work */
+
+/* allocate_pinned<T>/free_pinned<T> (src/base/hip/hip_allocate_free.hpp) */
+int ramd_alloc_pinned(void** ptr, int64_t bytes);
+int ramd_free_pinned(void* ptr);
+
+/* ======================================================================= vectors
+ * factory: _rocalution_init_base_hip_vector<T> (backend_hip.hpp:73). */
+int ramd_vec_create(int dtype, ramd_vec_t* out);
+int ramd_vec_destroy(ramd_vec_t v);
+int ramd_vec_allocate(ramd_vec_t v, int64_t n); /* BaseVector::Allocate (base_vector.hpp:63), zero-filled */
+int ramd_vec_clear(ramd_vec_t v); /* ::Clear :71 */
+int ramd_vec_size(ramd_vec_t v, int64_t* n);
+int ramd_vec_dtype(ramd_vec_t v, int* dtype);
+void* ramd_vec_data(ramd_vec_t v); /* raw device pointer (LeaveDataPtr-style view, :68) */
+int ramd_vec_zeros(ramd_vec_t v); /* :73 */
+int ramd_vec_ones(ramd_vec_t v); /* :75 */
+int ramd_vec_set_values(ramd_vec_t v, double val); /* :77 */
+/* AcceleratorVector::CopyFromHost / CopyToHost (base_vector.hpp:224-226), CopyFromHostData :114 */
+int ramd_vec_copy_from_host(ramd_vec_t v, const void* host);
+int ramd_vec_copy_to_host(ramd_vec_t v, void* host);
+int ramd_vec_copy_from(ramd_vec_t v, ramd_vec_t src); /* CopyFrom :85 (resizes like the reference) */
+int ramd_vec_copy_from_offset(ramd_vec_t v, ramd_vec_t src, int64_t src_offset, int64_t dst_offset,
+                              int64_t size); /* CopyFrom(src,so,do,size) :98 */
+int ramd_vec_copy_from_float(ramd_vec_t v_f64, ramd_vec_t src_f32); /* :89 */
+int ramd_vec_copy_from_double(ramd_vec_t v_f32, ramd_vec_t src_f64); /* :91 */
+int ramd_vec_copy_from_permute(ramd_vec_t v, ramd_vec_t src, ramd_vec_t perm_i32); /* :105 v[p[i]]=src[i] */
+int ramd_vec_copy_from_permute_backward(ramd_vec_t v, ramd_vec_t src, ramd_vec_t perm_i32); /* :109 */
+int ramd_vec_add_scale(ramd_vec_t v, ramd_vec_t x, double alpha); /* AddScale :126  v = v + alpha*x */
+int ramd_vec_scale_add(ramd_vec_t v, double alpha, ramd_vec_t x); /* ScaleAdd :128  v = alpha*v + x */
+int ramd_vec_scale_add_scale(ramd_vec_t v, double alpha, ramd_vec_t x, double beta); /* :130 */
+int ramd_vec_scale_add2(ramd_vec_t v, double alpha, ramd_vec_t x, double beta, ramd_vec_t y,
+                        double gamma); /* ScaleAdd2 :142 */
+int ramd_vec_scale(ramd_vec_t v, double alpha); /* Scale :149 */
+int ramd_vec_dot(ramd_vec_t v, ramd_vec_t x, double* result); /* Dot :151 / DotNonConj :153 (blocking) */
+int ramd_vec_norm(ramd_vec_t v, double* result); /* Norm :155  sqrt(sum x^2) */
+int ramd_vec_reduce(ramd_vec_t v, double* result); /* Reduce :157 */
+int ramd_vec_asum(ramd_vec_t v, double* result); /* Asum :163 */
+int ramd_vec_amax(ramd_vec_t v, double* value, int64_t* index); /* Amax :165 */
+int ramd_vec_pointwise_mult(ramd_vec_t v, ramd_vec_t x); /* :167  v = v*x */
+int ramd_vec_pointwise_mult2(ramd_vec_t v, ramd_vec_t x, ramd_vec_t y); /* :169  v = y*x */
+int ramd_vec_get_index_values(ramd_vec_t v, ramd_vec_t index_i32, ramd_vec_t out); /* :175 halo pack */
+
+/* ======================================================================= matrices
+ * factory: _rocalution_init_base_hip_matrix<T>(desc, format, blockdim) (backend_hip.hpp:78);
+ * here one object can hold any of the four formats and ramd_mat_convert switches it. */
+int ramd_mat_create(int dtype, ramd_mat_t* out);
+int ramd_mat_destroy(ramd_mat_t m);
+int ramd_mat_clear(ramd_mat_t m); /* BaseMatrix::Clear (base_matrix.hpp:167) */
+int ramd_mat_info(ramd_mat_t m, int* nrow, int* ncol, int64_t* nnz, int* format, int* dtype);
+/* AcceleratorMatrix::CopyFromHost / CopyFromHostCSR (base_matrix.hpp:847, :262): host CSR in */
+int ramd_mat_set_csr_from_host(ramd_mat_t m, int nrow, int ncol, int64_t nnz, const int32_t* row_offset,
+                               const int32_t* col, const void* val);
+/* CopyToHost / CopyToCSR (:853, :253); only valid in CSR format */
+int ramd_mat_copy_csr_to_host(ramd_mat_t m, int32_t* row_offset, int32_t* col, void* val);
+int ramd_mat_clone(ramd_mat_t src, ramd_mat_t* out); /* CopyFrom :238 (LocalMatrix::CloneFrom) */
+int ramd_mat_cast(ramd_mat_t src_f64, ramd_mat_t* out_f32); /* value-cast CSR copy (mixed_precision.cpp:201-229) */
+/* ConvertFrom :235 -- layout rules of src/base/host/host_conversion.cpp:621-687 (ELL, may return
+ * RAMD_ERR_REFUSED and leave the matrix CSR) and :1117-1239 (HYB); COO :582 */
+int ramd_mat_convert(ramd_mat_t m, int format);
+/* ELL/HYB/COO raw views for tests (device -> host) */
+int ramd_mat_ell_info(ramd_mat_t m, int* width, int64_t* coo_nnz);
+int ramd_mat_copy_ell_to_host(ramd_mat_t m, int32_t* ell_col, void* ell_val);
+int ramd_mat_copy_coo_to_host(ramd_mat_t m, int32_t* row, int32_t* col, void* val);
+/* Apply :450 / ApplyAdd :452 -- y = A x ; y += scalar * A x, in the matrix' current format */
+int ramd_mat_apply(ramd_mat_t m, ramd_vec_t x, ramd_vec_t y);
+int ramd_mat_apply_add(ramd_mat_t m, ramd_vec_t x, double scalar, ramd_vec_t y);
+int ramd_mat_extract_diag(ramd_mat_t m, ramd_vec_t d); /* :193 */
+int ramd_mat_extract_inv_diag(ramd_mat_t m, ramd_vec_t d); /* :195 ; *d resized to min(nrow,ncol) */
+int ramd_mat_extract_submatrix(ramd_mat_t m, int row_offset, int col_offset, int row_size, int col_size,
+                               ramd_mat_t out); /* :186 */
+int ramd_mat_permute(ramd_mat_t m, ramd_vec_t perm_i32); /* :206  P A P^T */
+/* MultiColoring (host-serial greedy in BOTH reference backends: host_matrix_csr.cpp:2469-2599,
+ * hip_matrix_csr.cpp:3915-4060).  size_colors must hold nrow ints. */
+int ramd_mat_multicoloring(ramd_mat_t m, int* num_colors, int* size_colors, ramd_vec_t perm_i32);
+int ramd_mat_ilu0_factorize(ramd_mat_t m); /* :321 */
+int ramd_mat_lu_analyse(ramd_mat_t m); /* :344 */
+int ramd_mat_lu_analyse_clear(ramd_mat_t m); /* :346 */
+int ramd_mat_lu_solve(ramd_mat_t m, ramd_vec_t in, ramd_vec_t out); /* :349 */
+int ramd_mat_l_analyse(ramd_mat_t m, int diag_unit); /* :365 */
+int ramd_mat_l_analyse_clear(ramd_mat_t m);
+int ramd_mat_l_solve(ramd_mat_t m, ramd_vec_t in, ramd_vec_t out); /* :370 */
+int ramd_mat_u_analyse(ramd_mat_t m, int diag_unit); /* :375 */
+int ramd_mat_u_analyse_clear(ramd_mat_t m);
+int ramd_mat_u_solve(ramd_mat_t m, ramd_vec_t in, ramd_vec_t out); /* :380 */
+
+/* device-side synthetic operator: 3-D 7-point Poisson N^3 in CSR */
+int ramd_mat_gen_poisson7(ramd_mat_t m, int N);
+/* rows [row_begin,row_end) of the same operator split into interior (local columns) and ghost
+ * (remote columns, renumbered into the halo receive buffer) parts -- the per-rank pieces a
+ * GlobalMatrix holds (src/base/global_matrix.cpp:913-921). */
+int ramd_mat_gen_poisson7_slab(ramd_mat_t interior, ramd_mat_t ghost, int N, int64_t row_begin,
+                               int64_t row_end);
+
+/* ======================================================================= fused hot-path ops
+ * New entry points (no counterpart in the reference's plugin interface): single-launch
+ * fusions of the BLAS-1 sequences of the Krylov loops.  Scalars live in a device record of
+ * RAMD_NSCALARS doubles; ramd_scalars_fetch copies a record to the host (blocking on the
+ * stream).  Element-wise arithmetic is the reference's expression for each op, so results
+ * equal the unfused sequence except for the summation order of the reductions. */
+enum { RAMD_NSCALARS = 64 };
+int ramd_scalars_set(int slot, double value);
+int ramd_scalars_fetch(double* host, int first, int count);
+int ramd_scalars_fetch_async_begin(int record, int first, int count); /* record in 0..7 */
+int ramd_scalars_fetch_async_end(int record, double* host, int count);
+
+/* y = A x  and  s[slot_dot] = <x, y>   (cg.cpp:415-418: q = A p ; p.q) */
+int ramd_fused_apply_dot(ramd_mat_t m, ramd_vec_t x, ramd_vec_t y, int slot_dot);
+/* alpha = s[slot_rho] / s[slot_pq];  x += alpha p;  r += (-alpha) q;  s[slot_rr] = <r,r>;
+ * if dinv: z = dinv * r, s[slot_rz] = <r,z>   else s[slot_rz] = <r,r>       (cg.cpp:418-438) */
+int ramd_fused_cg_update(ramd_vec_t x, ramd_vec_t r, ramd_vec_t p, ramd_vec_t q, ramd_vec_t dinv,
+                         ramd_vec_t z, int slot_rho, int slot_pq, int slot_rr, int slot_rz);
+/* beta = s[slot_num] / s[slot_den];  p = beta*p + z                              (cg.cpp:441-442) */
+int ramd_fused_cg_direction(ramd_vec_t p, ramd_vec_t z, int slot_num, int slot_den);
+/* several dot products against one vector in one pass: s[slot0+k] = <v_k, w>, k < count */
+int ramd_fused_multi_dot(const ramd_vec_t* vs, int count, ramd_vec_t w, int slot0);
+/* w += (-h) v ; s[slot_dot] = <u, w>   (one MGS step fused with the next dot, gmres.cpp:480-486);
+ * h is read from s[slot_h]; u may be NULL (then only the update and s[slot_dot]=<w,w>) */
+int ramd_fused_mgs_step(ramd_vec_t w, ramd_vec_t v, int slot_h, ramd_vec_t u, int slot_dot);
+/* v = v * (1/s[slot]) with s[slot] = sqrt(s[slot_sq]) computed on device (gmres.cpp:493-496) */
+int ramd_fused_normalize(ramd_vec_t v, int slot_sq, int slot_norm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROCALUTION_AMD_H_ */

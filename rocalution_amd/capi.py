@@ -1,0 +1,150 @@
+"""ctypes declaration of the C ABI in include/rocalution_amd.h (one entry per exported symbol).
+
+The library is the product: importing it never falls back to anything else.  If
+librocalution_amd.so is missing it is built (hipcc); if there is no GPU, ``ramd_init`` fails
+loudly -- there is no host compute path in this package.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librocalution_amd.so")
+
+OK, ERR_HIP, ERR_ARG, ERR_UNSUPPORTED, ERR_REFUSED, ERR_NO_DEVICE, ERR_STATE = range(7)
+F64, F32, I32 = 0, 1, 2
+CSR, COO, ELL, HYB = 1, 4, 6, 7
+
+vec_t = C.c_void_p
+mat_t = C.c_void_p
+i32, i64, f64, ptr = C.c_int, C.c_int64, C.c_double, C.c_void_p
+pi32, pi64, pf64 = C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_double)
+
+# name -> (restype, [argtypes]); every function returning a status uses i32
+SIGNATURES = {
+    "ramd_init": (i32, [i32]),
+    "ramd_stop": (i32, []),
+    "ramd_is_initialized": (i32, []),
+    "ramd_info": (i32, [C.c_char_p, i32]),
+    "ramd_get_arch": (C.c_char_p, []),
+    "ramd_last_error": (C.c_char_p, []),
+    "ramd_device_count": (i32, [pi32]),
+    "ramd_sync": (i32, []),
+    "ramd_sync_default": (i32, []),
+    "ramd_sync_interior": (i32, []),
+    "ramd_sync_ghost": (i32, []),
+    "ramd_compute_default": (i32, []),
+    "ramd_compute_interior": (i32, []),
+    "ramd_compute_ghost": (i32, []),
+    "ramd_current_stream": (ptr, []),
+    "ramd_alloc_pinned": (i32, [C.POINTER(ptr), i64]),
+    "ramd_free_pinned": (i32, [ptr]),
+    # vectors
+    "ramd_vec_create": (i32, [i32, C.POINTER(vec_t)]),
+    "ramd_vec_destroy": (i32, [vec_t]),
+    "ramd_vec_allocate": (i32, [vec_t, i64]),
+    "ramd_vec_clear": (i32, [vec_t]),
+    "ramd_vec_size": (i32, [vec_t, pi64]),
+    "ramd_vec_dtype": (i32, [vec_t, pi32]),
+    "ramd_vec_data": (ptr, [vec_t]),
+    "ramd_vec_zeros": (i32, [vec_t]),
+    "ramd_vec_ones": (i32, [vec_t]),
+    "ramd_vec_set_values": (i32, [vec_t, f64]),
+    "ramd_vec_copy_from_host": (i32, [vec_t, ptr]),
+    "ramd_vec_copy_to_host": (i32, [vec_t, ptr]),
+    "ramd_vec_copy_from": (i32, [vec_t, vec_t]),
+    "ramd_vec_copy_from_offset": (i32, [vec_t, vec_t, i64, i64, i64]),
+    "ramd_vec_copy_from_float": (i32, [vec_t, vec_t]),
+    "ramd_vec_copy_from_double": (i32, [vec_t, vec_t]),
+    "ramd_vec_copy_from_permute": (i32, [vec_t, vec_t, vec_t]),
+    "ramd_vec_copy_from_permute_backward": (i32, [vec_t, vec_t, vec_t]),
+    "ramd_vec_add_scale": (i32, [vec_t, vec_t, f64]),
+    "ramd_vec_scale_add": (i32, [vec_t, f64, vec_t]),
+    "ramd_vec_scale_add_scale": (i32, [vec_t, f64, vec_t, f64]),
+    "ramd_vec_scale_add2": (i32, [vec_t, f64, vec_t, f64, vec_t, f64]),
+    "ramd_vec_scale": (i32, [vec_t, f64]),
+    "ramd_vec_dot": (i32, [vec_t, vec_t, pf64]),
+    "ramd_vec_norm": (i32, [vec_t, pf64]),
+    "ramd_vec_reduce": (i32, [vec_t, pf64]),
+    "ramd_vec_asum": (i32, [vec_t, pf64]),
+    "ramd_vec_amax": (i32, [vec_t, pf64, pi64]),
+    "ramd_vec_pointwise_mult": (i32, [vec_t, vec_t]),
+    "ramd_vec_pointwise_mult2": (i32, [vec_t, vec_t, vec_t]),
+    "ramd_vec_get_index_values": (i32, [vec_t, vec_t, vec_t]),
+    # matrices
+    "ramd_mat_create": (i32, [i32, C.POINTER(mat_t)]),
+    "ramd_mat_destroy": (i32, [mat_t]),
+    "ramd_mat_clear": (i32, [mat_t]),
+    "ramd_mat_info": (i32, [mat_t, pi32, pi32, pi64, pi32, pi32]),
+    "ramd_mat_set_csr_from_host": (i32, [mat_t, i32, i32, i64, ptr, ptr, ptr]),
+    "ramd_mat_copy_csr_to_host": (i32, [mat_t, ptr, ptr, ptr]),
+    "ramd_mat_clone": (i32, [mat_t, C.POINTER(mat_t)]),
+    "ramd_mat_cast": (i32, [mat_t, C.POINTER(mat_t)]),
+    "ramd_mat_convert": (i32, [mat_t, i32]),
+    "ramd_mat_ell_info": (i32, [mat_t, pi32, pi64]),
+    "ramd_mat_copy_ell_to_host": (i32, [mat_t, ptr, ptr]),
+    "ramd_mat_copy_coo_to_host": (i32, [mat_t, ptr, ptr, ptr]),
+    "ramd_mat_apply": (i32, [mat_t, vec_t, vec_t]),
+    "ramd_mat_apply_add": (i32, [mat_t, vec_t, f64, vec_t]),
+    "ramd_mat_extract_diag": (i32, [mat_t, vec_t]),
+    "ramd_mat_extract_inv_diag": (i32, [mat_t, vec_t]),
+    "ramd_mat_extract_submatrix": (i32, [mat_t, i32, i32, i32, i32, mat_t]),
+    "ramd_mat_permute": (i32, [mat_t, vec_t]),
+    "ramd_mat_multicoloring": (i32, [mat_t, pi32, ptr, vec_t]),
+    "ramd_mat_ilu0_factorize": (i32, [mat_t]),
+    "ramd_mat_lu_analyse": (i32, [mat_t]),
+    "ramd_mat_lu_analyse_clear": (i32, [mat_t]),
+    "ramd_mat_lu_solve": (i32, [mat_t, vec_t, vec_t]),
+    "ramd_mat_l_analyse": (i32, [mat_t, i32]),
+    "ramd_mat_l_analyse_clear": (i32, [mat_t]),
+    "ramd_mat_l_solve": (i32, [mat_t, vec_t, vec_t]),
+    "ramd_mat_u_analyse": (i32, [mat_t, i32]),
+    "ramd_mat_u_analyse_clear": (i32, [mat_t]),
+    "ramd_mat_u_solve": (i32, [mat_t, vec_t, vec_t]),
+    "ramd_mat_gen_poisson7": (i32, [mat_t, i32]),
+    "ramd_mat_gen_poisson7_slab": (i32, [mat_t, mat_t, i32, i64, i64]),
+    # fused ops / scalar records
+    "ramd_scalars_set": (i32, [i32, f64]),
+    "ramd_scalars_fetch": (i32, [pf64, i32, i32]),
+    "ramd_scalars_fetch_async_begin": (i32, [i32, i32, i32]),
+    "ramd_scalars_fetch_async_end": (i32, [i32, pf64, i32]),
+    "ramd_fused_apply_dot": (i32, [mat_t, vec_t, vec_t, i32]),
+    "ramd_fused_cg_update": (i32, [vec_t, vec_t, vec_t, vec_t, vec_t, vec_t, i32, i32, i32, i32]),
+    "ramd_fused_cg_direction": (i32, [vec_t, vec_t, i32, i32]),
+    "ramd_fused_multi_dot": (i32, [C.POINTER(vec_t), i32, vec_t, i32]),
+    "ramd_fused_mgs_step": (i32, [vec_t, vec_t, i32, vec_t, i32]),
+    "ramd_fused_normalize": (i32, [vec_t, i32, i32]),
+}
+
+_lib = None
+
+
+class RamdError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("rocalution_amd status %d: %s" % (status, msg))
+        self.status = status
+
+
+def load(build_if_missing=True):
+    """dlopen librocalution_amd.so and attach the prototypes of SIGNATURES (missing symbols are an
+    error: the header, this table and the library must agree)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if not build_if_missing:
+            raise FileNotFoundError(LIB_PATH)
+        from . import build as _build
+        _build.build()
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != OK:
+        raise RamdError(status, (load().ramd_last_error() or b"").decode())
+    return status

@@ -1,0 +1,241 @@
+// backend.hip -- lifecycle, streams, error state, scalar records.
+// Replaces src/base/hip/backend_hip.cpp:50-487 of the reference (init/stop/info, the three
+// streams and the compute_{default,interior,ghost} switches) -- no rocBLAS/rocSPARSE handles.
+#include "common.hpp"
+
+#include <mutex>
+
+namespace ramd
+{
+
+static thread_local std::string g_err;
+static Backend                  g_backend;
+
+void set_error(const char* file, int line, const std::string& msg)
+{
+    const char* base = strrchr(file, '/');
+    g_err = std::string(base ? base + 1 : file) + ":" + std::to_string(line) + ": " + msg;
+}
+const char* last_error()
+{
+    return g_err.c_str();
+}
+Backend& backend()
+{
+    return g_backend;
+}
+
+int ensure_init()
+{
+    if(g_backend.initialized)
+        return RAMD_OK;
+    return ramd_init(-1);
+}
+
+} // namespace ramd
+
+using namespace ramd;
+
+extern "C" {
+
+const char* ramd_last_error(void)
+{
+    return last_error();
+}
+
+int ramd_device_count(int* count)
+{
+    int        c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if(e != hipSuccess)
+        c = 0;
+    if(count)
+        *count = c;
+    return RAMD_OK;
+}
+
+int ramd_init(int device)
+{
+    Backend& b = backend();
+    if(b.initialized)
+        return RAMD_OK;
+    int        ndev = 0;
+    hipError_t e    = hipGetDeviceCount(&ndev);
+    if(e != hipSuccess || ndev <= 0)
+        RAMD_FAIL(RAMD_ERR_NO_DEVICE,
+                  "no HIP device available: this backend has no host compute path (the reference "
+                  "would fall back to its OpenMP backend; use the reference/oracle for that)");
+    if(device >= 0)
+        RAMD_HIP(hipSetDevice(device % ndev));
+    RAMD_HIP(hipGetDevice(&b.device));
+    hipDeviceProp_t prop;
+    RAMD_HIP(hipGetDeviceProperties(&prop, b.device));
+    b.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    snprintf(b.arch, sizeof(b.arch), "%s", prop.gcnArchName);
+    if(char* colon = strchr(b.arch, ':'))
+        *colon = 0;
+    // default stream = NULL stream as in the reference (backend_hip.cpp:80); interior / ghost
+    // are non-blocking side streams used by the GlobalMatrix choreography.
+    b.stream_default = nullptr;
+    RAMD_HIP(hipStreamCreateWithFlags(&b.stream_interior, hipStreamNonBlocking));
+    RAMD_HIP(hipStreamCreateWithFlags(&b.stream_ghost, hipStreamNonBlocking));
+    b.cur = b.stream_default;
+    RAMD_HIP(hipMalloc((void**)&b.d_partials, sizeof(double) * kScalarSlots * kReduceBlocks));
+    RAMD_HIP(hipMalloc((void**)&b.d_ticket, sizeof(unsigned int) * 64));
+    RAMD_HIP(hipMemset(b.d_ticket, 0, sizeof(unsigned int) * 64));
+    RAMD_HIP(hipMalloc((void**)&b.d_scalars, sizeof(double) * kScalarSlots));
+    RAMD_HIP(hipMemset(b.d_scalars, 0, sizeof(double) * kScalarSlots));
+    RAMD_HIP(hipHostMalloc((void**)&b.h_scalars, sizeof(double) * kScalarSlots * kScalarRecords,
+                           hipHostMallocDefault));
+    for(int i = 0; i < kScalarRecords; ++i)
+        RAMD_HIP(hipEventCreateWithFlags(&b.ev_scalar[i], hipEventDisableTiming));
+    b.initialized = true;
+    return RAMD_OK;
+}
+
+int ramd_stop(void)
+{
+    Backend& b = backend();
+    if(!b.initialized)
+        return RAMD_OK;
+    (void)hipDeviceSynchronize();
+    (void)hipFree(b.d_partials);
+    (void)hipFree(b.d_ticket);
+    (void)hipFree(b.d_scalars);
+    (void)hipHostFree(b.h_scalars);
+    for(int i = 0; i < kScalarRecords; ++i)
+        (void)hipEventDestroy(b.ev_scalar[i]);
+    (void)hipStreamDestroy(b.stream_interior);
+    (void)hipStreamDestroy(b.stream_ghost);
+    b = Backend();
+    return RAMD_OK;
+}
+
+int ramd_is_initialized(void)
+{
+    return backend().initialized ? 1 : 0;
+}
+
+const char* ramd_get_arch(void)
+{
+    return backend().arch;
+}
+
+int ramd_info(char* buf, int buflen)
+{
+    Backend& b = backend();
+    if(!b.initialized)
+    {
+        snprintf(buf, buflen, "rocalution_amd: backend not initialized");
+        return RAMD_OK;
+    }
+    hipDeviceProp_t prop;
+    RAMD_HIP(hipGetDeviceProperties(&prop, b.device));
+    snprintf(buf, buflen,
+             "rocalution_amd MI355X-native backend: device %d '%s' arch %s, %d CUs, %.1f GiB HBM, "
+             "wavefront %d, hand-written HIP kernels (no rocSPARSE/rocBLAS)",
+             b.device, prop.name, b.arch, b.num_cu, prop.totalGlobalMem / 1073741824.0,
+             prop.warpSize);
+    return RAMD_OK;
+}
+
+int ramd_sync(void)
+{
+    RAMD_HIP(hipDeviceSynchronize());
+    return RAMD_OK;
+}
+int ramd_sync_default(void)
+{
+    RAMD_HIP(hipStreamSynchronize(backend().stream_default));
+    return RAMD_OK;
+}
+int ramd_sync_interior(void)
+{
+    RAMD_HIP(hipStreamSynchronize(backend().stream_interior));
+    return RAMD_OK;
+}
+int ramd_sync_ghost(void)
+{
+    RAMD_HIP(hipStreamSynchronize(backend().stream_ghost));
+    return RAMD_OK;
+}
+int ramd_compute_default(void)
+{
+    backend().cur = backend().stream_default;
+    return RAMD_OK;
+}
+int ramd_compute_interior(void)
+{
+    backend().cur = backend().stream_interior;
+    return RAMD_OK;
+}
+int ramd_compute_ghost(void)
+{
+    backend().cur = backend().stream_ghost;
+    return RAMD_OK;
+}
+void* ramd_current_stream(void)
+{
+    return (void*)backend().cur;
+}
+
+int ramd_alloc_pinned(void** ptr, int64_t bytes)
+{
+    RAMD_HIP(hipHostMalloc(ptr, (size_t)bytes, hipHostMallocDefault));
+    return RAMD_OK;
+}
+int ramd_free_pinned(void* ptr)
+{
+    RAMD_HIP(hipHostFree(ptr));
+    return RAMD_OK;
+}
+
+// ---------------------------------------------------------------- scalar records
+int ramd_scalars_set(int slot, double value)
+{
+    RAMD_TRY(ensure_init());
+    if(slot < 0 || slot >= kScalarSlots)
+        RAMD_FAIL(RAMD_ERR_ARG, "scalar slot out of range");
+    Backend& b = backend();
+    // pageable source is staged by the runtime before the call returns
+    RAMD_HIP(hipMemcpyAsync(b.d_scalars + slot, &value, sizeof(double), hipMemcpyHostToDevice, b.cur));
+    return RAMD_OK;
+}
+
+int ramd_scalars_fetch(double* host, int first, int count)
+{
+    RAMD_TRY(ensure_init());
+    if(first < 0 || count < 0 || first + count > kScalarSlots)
+        RAMD_FAIL(RAMD_ERR_ARG, "scalar range out of bounds");
+    Backend& b = backend();
+    RAMD_HIP(hipMemcpyAsync(b.h_scalars, b.d_scalars + first, sizeof(double) * count,
+                            hipMemcpyDeviceToHost, b.cur));
+    RAMD_HIP(hipStreamSynchronize(b.cur));
+    memcpy(host, b.h_scalars, sizeof(double) * count);
+    return RAMD_OK;
+}
+
+int ramd_scalars_fetch_async_begin(int record, int first, int count)
+{
+    RAMD_TRY(ensure_init());
+    if(record < 0 || record >= kScalarRecords || first < 0 || count < 0
+       || first + count > kScalarSlots)
+        RAMD_FAIL(RAMD_ERR_ARG, "scalar record/range out of bounds");
+    Backend& b = backend();
+    RAMD_HIP(hipMemcpyAsync(b.h_scalars + (size_t)record * kScalarSlots, b.d_scalars + first,
+                            sizeof(double) * count, hipMemcpyDeviceToHost, b.cur));
+    RAMD_HIP(hipEventRecord(b.ev_scalar[record], b.cur));
+    return RAMD_OK;
+}
+
+int ramd_scalars_fetch_async_end(int record, double* host, int count)
+{
+    Backend& b = backend();
+    if(record < 0 || record >= kScalarRecords || count < 0 || count > kScalarSlots)
+        RAMD_FAIL(RAMD_ERR_ARG, "scalar record out of bounds");
+    RAMD_HIP(hipEventSynchronize(b.ev_scalar[record]));
+    memcpy(host, b.h_scalars + (size_t)record * kScalarSlots, sizeof(double) * count);
+    return RAMD_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,162 @@
+// common.hpp -- shared definitions of the MI355X (gfx950) backend.
+//
+// Replaces the role of src/base/hip/{hip_utils.hpp,hip_allocate_free.*,backend_hip.*} of the
+// reference (error macros, allocation, stream bookkeeping) -- written from scratch, no
+// rocSPARSE/rocBLAS/rocPRIM anywhere.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "../../include/rocalution_amd.h"
+
+namespace ramd
+{
+
+// ---------------------------------------------------------------- error handling
+void        set_error(const char* file, int line, const std::string& msg);
+const char* last_error();
+
+#define RAMD_FAIL(code, msg)                          \
+    do                                                \
+    {                                                 \
+        ::ramd::set_error(__FILE__, __LINE__, (msg)); \
+        return (code);                                \
+    } while(0)
+
+#define RAMD_HIP(expr)                                                                      \
+    do                                                                                      \
+    {                                                                                       \
+        hipError_t e_ = (expr);                                                             \
+        if(e_ != hipSuccess)                                                                \
+        {                                                                                   \
+            ::ramd::set_error(__FILE__, __LINE__,                                           \
+                              std::string(#expr) + " -> " + hipGetErrorString(e_));         \
+            return RAMD_ERR_HIP;                                                            \
+        }                                                                                   \
+    } while(0)
+
+#define RAMD_TRY(expr)           \
+    do                           \
+    {                            \
+        int s_ = (expr);         \
+        if(s_ != RAMD_OK)        \
+            return s_;           \
+    } while(0)
+
+// ---------------------------------------------------------------- backend state
+// One host thread drives the backend (as in the reference, SURVEY.md §8b "Threading").
+// Three streams mirror the reference's default / interior / ghost choreography
+// (src/base/hip/backend_hip.cpp:358-410); `cur` is what every op launches on.
+constexpr int kReduceBlocks  = 2048; // partial sums per reduction launch
+constexpr int kScalarSlots   = 64; // doubles per scalar record
+constexpr int kScalarRecords = 8; // ring of records in host-mapped memory
+
+struct Backend
+{
+    bool        initialized = false;
+    int         device      = 0;
+    int         num_cu      = 256;
+    int         num_xcd     = 8;
+    hipStream_t stream_default  = nullptr;
+    hipStream_t stream_interior = nullptr;
+    hipStream_t stream_ghost    = nullptr;
+    hipStream_t cur             = nullptr;
+    // reduction workspace
+    double*       d_partials = nullptr; // [kScalarSlots][kReduceBlocks]
+    unsigned int* d_ticket   = nullptr; // arrival counters (one per concurrent reduction)
+    double*       d_scalars  = nullptr; // device-resident scalar records
+    double*       h_scalars  = nullptr; // pinned host mirror (async copies land here)
+    hipEvent_t    ev_scalar[kScalarRecords] = {};
+    char          arch[64] = {0};
+};
+
+Backend& backend();
+int      ensure_init();
+
+// ---------------------------------------------------------------- allocation
+// All device arrays are over-allocated by kPad bytes so that 16-byte vector loads that start
+// inside an array may run past its logical end (never dereferenced for results).
+constexpr size_t kPad = 256;
+
+template <typename X>
+int dev_alloc(X** p, int64_t n)
+{
+    *p = nullptr;
+    void*  q     = nullptr;
+    size_t bytes = (size_t)(n > 0 ? n : 0) * sizeof(X) + kPad;
+    RAMD_HIP(hipMalloc(&q, bytes));
+    *p = static_cast<X*>(q);
+    return RAMD_OK;
+}
+template <typename X>
+void dev_free(X** p)
+{
+    if(*p)
+        (void)hipFree(*p);
+    *p = nullptr;
+}
+
+// ---------------------------------------------------------------- launch geometry
+constexpr int kBlock = 256;
+
+// grid for bandwidth-bound elementwise kernels: enough workgroups to fill 256 CUs several
+// times over, capped so that each thread still streams a few 16-byte packets (grid-stride).
+inline int ew_grid(int64_t n_vec_items)
+{
+    int64_t g   = (n_vec_items + kBlock - 1) / kBlock;
+    int64_t cap = (int64_t)backend().num_cu * 16;
+    if(g > cap)
+        g = cap;
+    if(g < 1)
+        g = 1;
+    return (int)g;
+}
+
+} // namespace ramd
+
+// ---------------------------------------------------------------- object layouts (C handles)
+struct ramd_vec_s
+{
+    int     dtype = RAMD_F64;
+    int64_t n     = 0;
+    void*   d     = nullptr;
+};
+
+struct ramd_mat_s
+{
+    int     dtype  = RAMD_F64;
+    int     format = RAMD_CSR;
+    int     nrow = 0, ncol = 0;
+    int64_t nnz = 0;
+    // CSR (also the storage of the LU factors after ilu0_factorize)
+    int*  rp  = nullptr;
+    int*  ci  = nullptr;
+    void* val = nullptr;
+    // ELL part (ELL and HYB): column-major, ELL_IND(row,el) = el*nrow + row
+    int   ell_width = 0;
+    int*  ell_col   = nullptr;
+    void* ell_val   = nullptr;
+    // COO part (COO and HYB tail)
+    int64_t coo_nnz = 0;
+    int*    coo_row = nullptr;
+    int*    coo_col = nullptr;
+    void*   coo_val = nullptr;
+    // COO row grouping (built once): touched rows and their entry ranges in stable row order
+    int   coo_ngroups = 0;
+    int*  coo_grow    = nullptr; // [ngroups] row index
+    int*  coo_gptr    = nullptr; // [ngroups+1] entry ranges (COO data is row-sorted)
+    // triangular-solve analysis (LUAnalyse / LAnalyse / UAnalyse)
+    bool  lu_analysed = false;
+    bool  l_analysed = false, u_analysed = false;
+    bool  l_diag_unit = true, u_diag_unit = false;
+    int*  diag_pos = nullptr; // [nrow] position of the first entry with col >= row (ILU0)
+    void* tri      = nullptr; // ramd::TriState* (level-ordered solve plans), trisolve.hip
+    // CSR SpMV analysis
+    int max_row_nnz = -1;
+};

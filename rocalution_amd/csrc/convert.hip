@@ -1,0 +1,574 @@
+// convert.hip -- format conversion, value cast, sub-matrix extraction, P A P^T (setup-time kernels).
+//
+// Replaces src/base/hip/hip_conversion.cpp (rocsparse_csr2ell, custom csr2hyb + rocPRIM scan),
+// and the Permute / ExtractSubMatrix kernels of src/base/hip/hip_matrix_csr.cpp:962-1190, :3374-3478.
+// Layout RULES are the reference's (src/base/host/host_conversion.cpp, cited per function): the
+// resulting arrays are identical to the host backend's, entry for entry.
+#include "device_utils.hpp"
+#include "matrix_impl.hpp"
+
+namespace ramd
+{
+
+__global__ __launch_bounds__(kBlock) void k_row_nnz(int nrow, const int* __restrict__ rp,
+                                                    int* __restrict__ out, int minus, int clamp0)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+    {
+        int v = rp[i + 1] - rp[i] - minus;
+        out[i] = (clamp0 && v < 0) ? 0 : v;
+    }
+}
+
+// host_conversion.cpp:658-684: fill ELL (column-major), pad col=-1 val=0
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_csr2ell(int nrow, int width, const int* __restrict__ rp,
+                                                    const int* __restrict__ ci,
+                                                    const T* __restrict__ val,
+                                                    int* __restrict__ ecol, T* __restrict__ eval)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+    {
+        int n = 0;
+        for(int j = rp[i]; j < rp[i + 1]; ++j, ++n)
+        {
+            ecol[(int64_t)n * nrow + i] = ci[j];
+            eval[(int64_t)n * nrow + i] = val[j];
+        }
+        for(; n < width; ++n)
+        {
+            ecol[(int64_t)n * nrow + i] = -1;
+            eval[(int64_t)n * nrow + i] = (T)0;
+        }
+    }
+}
+
+// host_conversion.cpp:1199-1234: first `width` entries of a row -> ELL, the rest -> COO
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_csr2hyb(int nrow, int width, const int* __restrict__ rp,
+                                                    const int* __restrict__ ci,
+                                                    const T* __restrict__ val,
+                                                    const int* __restrict__ coo_rp,
+                                                    int* __restrict__ ecol, T* __restrict__ eval,
+                                                    int* __restrict__ crow, int* __restrict__ ccol,
+                                                    T* __restrict__ cval)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+    {
+        int p = 0;
+        int c = coo_rp[i];
+        for(int j = rp[i]; j < rp[i + 1]; ++j)
+        {
+            if(p < width)
+            {
+                ecol[(int64_t)p * nrow + i] = ci[j];
+                eval[(int64_t)p * nrow + i] = val[j];
+                ++p;
+            }
+            else
+            {
+                crow[c] = (int)i;
+                ccol[c] = ci[j];
+                cval[c] = val[j];
+                ++c;
+            }
+        }
+        for(; p < width; ++p)
+        {
+            ecol[(int64_t)p * nrow + i] = -1;
+            eval[(int64_t)p * nrow + i] = (T)0;
+        }
+    }
+}
+
+// host_conversion.cpp:596-610: COO row index expansion
+__global__ __launch_bounds__(kBlock) void k_expand_rows(int nrow, const int* __restrict__ rp,
+                                                        int* __restrict__ crow)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+        for(int j = rp[i]; j < rp[i + 1]; ++j)
+            crow[j] = (int)i;
+}
+
+// compaction of the non-empty rows of a row-pointer array: grow[k] = row, gptr[k] = rp[row]
+__global__ __launch_bounds__(kBlock) void k_compact_rows(int nrow, const int* __restrict__ rp,
+                                                         const int* __restrict__ pos,
+                                                         int* __restrict__ grow,
+                                                         int* __restrict__ gptr)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+        if(rp[i + 1] > rp[i])
+        {
+            grow[pos[i]] = (int)i;
+            gptr[pos[i]] = rp[i];
+        }
+}
+
+__global__ __launch_bounds__(kBlock) void k_flag_nonempty(int nrow, const int* __restrict__ rp,
+                                                          int* __restrict__ flag)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= nrow; i += gsz)
+        flag[i] = (i < nrow && rp[i + 1] > rp[i]) ? 1 : 0;
+}
+
+template <typename D, typename S>
+__global__ __launch_bounds__(kBlock) void k_cast_vals(int64_t n, D* dst, const S* src)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gsz)
+        dst[i] = static_cast<D>(src[i]);
+}
+
+// ---- sub-matrix extraction: host_matrix_csr.cpp:848-916
+__global__ __launch_bounds__(kBlock) void k_sub_count(int r0, int c0, int rs, int cs,
+                                                      const int* __restrict__ rp,
+                                                      const int* __restrict__ ci,
+                                                      int* __restrict__ cnt)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= rs; i += gsz)
+    {
+        int c = 0;
+        if(i < rs)
+            for(int j = rp[r0 + i]; j < rp[r0 + i + 1]; ++j)
+                if(ci[j] >= c0 && ci[j] < c0 + cs)
+                    ++c;
+        cnt[i] = c;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_sub_fill(int r0, int c0, int rs, int cs,
+                                                     const int* __restrict__ rp,
+                                                     const int* __restrict__ ci,
+                                                     const T* __restrict__ val,
+                                                     const int* __restrict__ orp,
+                                                     int* __restrict__ oci, T* __restrict__ oval)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rs; i += gsz)
+    {
+        int p = orp[i];
+        for(int j = rp[r0 + i]; j < rp[r0 + i + 1]; ++j)
+            if(ci[j] >= c0 && ci[j] < c0 + cs)
+            {
+                oci[p]  = ci[j] - c0;
+                oval[p] = val[j];
+                ++p;
+            }
+    }
+}
+
+// ---- P A P^T: host_matrix_csr.cpp:3848-3958 (row i -> perm[i]; col -> perm[col]; columns of each
+// row sorted ascending by insertion -- entries are unique, so the result equals the reference's)
+__global__ __launch_bounds__(kBlock) void k_perm_row_nnz(int nrow, const int* __restrict__ rp,
+                                                         const int* __restrict__ perm,
+                                                         int* __restrict__ out)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= nrow; i += gsz)
+    {
+        if(i < nrow)
+            out[perm[i]] = rp[i + 1] - rp[i];
+        else
+            out[nrow] = 0;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_perm_fill(int nrow, const int* __restrict__ rp,
+                                                      const int* __restrict__ ci,
+                                                      const T* __restrict__ val,
+                                                      const int* __restrict__ perm,
+                                                      const int* __restrict__ orp,
+                                                      int* __restrict__ oci, T* __restrict__ oval)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+    {
+        const int base = orp[perm[i]];
+        const int src  = rp[i];
+        const int rn   = rp[i + 1] - src;
+        for(int j = 0; j < rn; ++j)
+        {
+            const int comp = perm[ci[src + j]];
+            const T   v    = val[src + j];
+            int       k    = j - 1;
+            for(; k >= 0; --k)
+            {
+                if(oci[base + k] > comp)
+                {
+                    oci[base + k + 1]  = oci[base + k];
+                    oval[base + k + 1] = oval[base + k];
+                }
+                else
+                    break;
+            }
+            oci[base + k + 1]  = comp;
+            oval[base + k + 1] = v;
+        }
+    }
+}
+
+static int build_coo_groups(ramd_mat_s* m, const int* rowptr_like)
+{
+    // rowptr_like: [nrow+1] offsets of every row's COO entries (CSR rp, or the HYB overflow scan)
+    Backend& b    = backend();
+    int*     flag = nullptr;
+    RAMD_TRY(dev_alloc(&flag, (int64_t)m->nrow + 1));
+    const int grid = ew_grid((int64_t)m->nrow + 1);
+    hipLaunchKernelGGL(k_flag_nonempty, dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, rowptr_like, flag);
+    int s = device_exclusive_scan(flag, flag, (int64_t)m->nrow + 1);
+    int ng = 0;
+    if(s == RAMD_OK)
+    {
+        hipError_t e = hipMemcpyAsync(&ng, flag + m->nrow, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+        if(e == hipSuccess)
+            e = hipStreamSynchronize(b.cur);
+        if(e != hipSuccess)
+            s = RAMD_ERR_HIP;
+    }
+    if(s == RAMD_OK)
+        s = dev_alloc(&m->coo_grow, ng);
+    if(s == RAMD_OK)
+        s = dev_alloc(&m->coo_gptr, (int64_t)ng + 1);
+    if(s == RAMD_OK)
+    {
+        m->coo_ngroups = ng;
+        hipLaunchKernelGGL(k_compact_rows, dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, rowptr_like,
+                           flag, m->coo_grow, m->coo_gptr);
+        int        last = (int)m->coo_nnz;
+        hipError_t e = hipMemcpyAsync(m->coo_gptr + ng, &last, sizeof(int), hipMemcpyHostToDevice, b.cur);
+        if(e == hipSuccess)
+            e = hipStreamSynchronize(b.cur);
+        if(e != hipSuccess)
+            s = RAMD_ERR_HIP;
+    }
+    dev_free(&flag);
+    return s;
+}
+
+template <typename T>
+static int convert_from_csr(ramd_mat_s* m, int format)
+{
+    Backend&  b    = backend();
+    const int grid = ew_grid(std::max(m->nrow, 1));
+    if(format == RAMD_ELL)
+    {
+        int* rn = nullptr;
+        RAMD_TRY(dev_alloc(&rn, m->nrow));
+        hipLaunchKernelGGL(k_row_nnz, dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, m->rp, rn, 0, 0);
+        int width = 0;
+        int s     = device_max_int(rn, m->nrow, &width);
+        dev_free(&rn);
+        RAMD_TRY(s);
+        if(m->nrow == 0)
+            width = 0;
+        // host_conversion.cpp:648-651: "Limit ELL size to 5 times CSR nnz" -- integer division
+        if(m->nrow > 0 && width > 5 * (m->nnz / m->nrow))
+            RAMD_FAIL(RAMD_ERR_REFUSED, "csr_to_ell refused: max row nnz > 5 * (nnz / nrow); matrix stays CSR");
+        const int64_t nnz_ell = (int64_t)width * m->nrow;
+        RAMD_TRY(dev_alloc(&m->ell_col, nnz_ell));
+        void* ev = nullptr;
+        RAMD_HIP(hipMalloc(&ev, (size_t)nnz_ell * sizeof(T) + kPad));
+        m->ell_val   = ev;
+        m->ell_width = width;
+        if(nnz_ell > 0)
+            hipLaunchKernelGGL((k_csr2ell<T>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, width, m->rp,
+                               m->ci, (const T*)m->val, m->ell_col, (T*)m->ell_val);
+        RAMD_HIP(hipGetLastError());
+        RAMD_HIP(hipStreamSynchronize(b.cur));
+        mat_free_csr(m);
+        m->format = RAMD_ELL;
+        m->nnz    = nnz_ell;
+        return RAMD_OK;
+    }
+    if(format == RAMD_HYB)
+    {
+        if(m->nrow == 0 || m->nnz <= 0)
+            RAMD_FAIL(RAMD_ERR_REFUSED, "csr_to_hyb refused: empty matrix (nnz_hyb <= 0)");
+        const int     width   = (int)((m->nnz - 1) / m->nrow + 1); // host_conversion.cpp:1131-1135
+        const int64_t nnz_ell = (int64_t)width * m->nrow;
+        int*          crp     = nullptr;
+        RAMD_TRY(dev_alloc(&crp, (int64_t)m->nrow + 1));
+        hipLaunchKernelGGL(k_row_nnz, dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, m->rp, crp, width, 1);
+        int s    = device_exclusive_scan(crp, crp, (int64_t)m->nrow + 1);
+        int ncoo = 0;
+        if(s == RAMD_OK)
+        {
+            hipError_t e = hipMemcpyAsync(&ncoo, crp + m->nrow, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+            if(e == hipSuccess)
+                e = hipStreamSynchronize(b.cur);
+            if(e != hipSuccess)
+                s = RAMD_ERR_HIP;
+        }
+        if(s == RAMD_OK)
+            s = dev_alloc(&m->ell_col, nnz_ell);
+        void *ev = nullptr, *cv = nullptr;
+        if(s == RAMD_OK && hipMalloc(&ev, (size_t)nnz_ell * sizeof(T) + kPad) != hipSuccess)
+            s = RAMD_ERR_HIP;
+        if(s == RAMD_OK)
+            s = dev_alloc(&m->coo_row, ncoo);
+        if(s == RAMD_OK)
+            s = dev_alloc(&m->coo_col, ncoo);
+        if(s == RAMD_OK && hipMalloc(&cv, (size_t)ncoo * sizeof(T) + kPad) != hipSuccess)
+            s = RAMD_ERR_HIP;
+        if(s != RAMD_OK)
+        {
+            dev_free(&crp);
+            if(ev)
+                (void)hipFree(ev);
+            if(cv)
+                (void)hipFree(cv);
+            mat_free_ell(m);
+            mat_free_coo(m);
+            RAMD_FAIL(s, "csr_to_hyb: allocation failed");
+        }
+        m->ell_val   = ev;
+        m->coo_val   = cv;
+        m->ell_width = width;
+        m->coo_nnz   = ncoo;
+        hipLaunchKernelGGL((k_csr2hyb<T>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, width, m->rp,
+                           m->ci, (const T*)m->val, crp, m->ell_col, (T*)m->ell_val, m->coo_row,
+                           m->coo_col, (T*)m->coo_val);
+        if(ncoo > 0)
+            s = build_coo_groups(m, crp);
+        hipError_t e = hipStreamSynchronize(b.cur);
+        dev_free(&crp);
+        RAMD_TRY(s);
+        RAMD_HIP(e);
+        mat_free_csr(m);
+        m->format = RAMD_HYB;
+        m->nnz    = nnz_ell + ncoo;
+        return RAMD_OK;
+    }
+    if(format == RAMD_COO)
+    {
+        RAMD_TRY(dev_alloc(&m->coo_row, m->nnz));
+        m->coo_nnz = m->nnz;
+        if(m->nnz > 0)
+        {
+            hipLaunchKernelGGL(k_expand_rows, dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, m->rp,
+                               m->coo_row);
+            RAMD_TRY(build_coo_groups(m, m->rp));
+        }
+        RAMD_HIP(hipStreamSynchronize(b.cur));
+        // column and value arrays are adopted unchanged (host_conversion.cpp:611-612 copies them)
+        m->coo_col = m->ci;
+        m->coo_val = m->val;
+        m->ci      = nullptr;
+        m->val     = nullptr;
+        dev_free(&m->rp);
+        m->format = RAMD_COO;
+        return RAMD_OK;
+    }
+    RAMD_FAIL(RAMD_ERR_UNSUPPORTED, "conversion target not provided by this backend");
+}
+
+} // namespace ramd
+
+using namespace ramd;
+
+extern "C" {
+
+int ramd_mat_convert(ramd_mat_t m, int format)
+{
+    if(!m)
+        RAMD_FAIL(RAMD_ERR_ARG, "null matrix handle");
+    if(m->format == format)
+        return RAMD_OK;
+    if(m->format != RAMD_CSR)
+        return RAMD_ERR_UNSUPPORTED; // X -> CSR -> Y goes through the caller (front-end protocol)
+    if(m->lu_analysed || m->l_analysed || m->u_analysed)
+        mat_free_analysis(m);
+    if(m->dtype == RAMD_F64)
+        return convert_from_csr<double>(m, format);
+    return convert_from_csr<float>(m, format);
+}
+
+int ramd_mat_ell_info(ramd_mat_t m, int* width, int64_t* coo_nnz)
+{
+    if(!m)
+        RAMD_FAIL(RAMD_ERR_ARG, "null matrix handle");
+    if(width)
+        *width = m->ell_width;
+    if(coo_nnz)
+        *coo_nnz = m->coo_nnz;
+    return RAMD_OK;
+}
+
+int ramd_mat_copy_ell_to_host(ramd_mat_t m, int32_t* ell_col, void* ell_val)
+{
+    if(!m || (m->format != RAMD_ELL && m->format != RAMD_HYB))
+        RAMD_FAIL(RAMD_ERR_STATE, "matrix has no ELL part");
+    Backend&     b = backend();
+    const size_t n = (size_t)m->ell_width * m->nrow;
+    if(n > 0)
+    {
+        RAMD_HIP(hipMemcpyAsync(ell_col, m->ell_col, sizeof(int) * n, hipMemcpyDeviceToHost, b.cur));
+        RAMD_HIP(hipMemcpyAsync(ell_val, m->ell_val, val_size(m->dtype) * n, hipMemcpyDeviceToHost,
+                                b.cur));
+        RAMD_HIP(hipStreamSynchronize(b.cur));
+    }
+    return RAMD_OK;
+}
+
+int ramd_mat_copy_coo_to_host(ramd_mat_t m, int32_t* row, int32_t* col, void* val)
+{
+    if(!m || (m->format != RAMD_COO && m->format != RAMD_HYB))
+        RAMD_FAIL(RAMD_ERR_STATE, "matrix has no COO part");
+    Backend&     b = backend();
+    const size_t n = (size_t)m->coo_nnz;
+    if(n > 0)
+    {
+        RAMD_HIP(hipMemcpyAsync(row, m->coo_row, sizeof(int) * n, hipMemcpyDeviceToHost, b.cur));
+        RAMD_HIP(hipMemcpyAsync(col, m->coo_col, sizeof(int) * n, hipMemcpyDeviceToHost, b.cur));
+        RAMD_HIP(hipMemcpyAsync(val, m->coo_val, val_size(m->dtype) * n, hipMemcpyDeviceToHost, b.cur));
+        RAMD_HIP(hipStreamSynchronize(b.cur));
+    }
+    return RAMD_OK;
+}
+
+int ramd_mat_cast(ramd_mat_t src, ramd_mat_t* out)
+{
+    if(!src || !out)
+        RAMD_FAIL(RAMD_ERR_ARG, "null handle");
+    if(src->format != RAMD_CSR)
+        RAMD_FAIL(RAMD_ERR_STATE, "cast: source must be CSR (mixed_precision.cpp:201 uses CopyToCSR)");
+    const int  dt = (src->dtype == RAMD_F64) ? RAMD_F32 : RAMD_F64;
+    ramd_mat_t m  = nullptr;
+    RAMD_TRY(ramd_mat_create(dt, &m));
+    int s = mat_alloc_csr(m, src->nrow, src->ncol, src->nnz);
+    if(s != RAMD_OK)
+    {
+        ramd_mat_destroy(m);
+        return s;
+    }
+    Backend& b = backend();
+    RAMD_HIP(hipMemcpyAsync(m->rp, src->rp, sizeof(int) * ((size_t)src->nrow + 1),
+                            hipMemcpyDeviceToDevice, b.cur));
+    if(src->nnz > 0)
+    {
+        RAMD_HIP(hipMemcpyAsync(m->ci, src->ci, sizeof(int) * (size_t)src->nnz, hipMemcpyDeviceToDevice,
+                                b.cur));
+        const int grid = ew_grid(src->nnz);
+        if(dt == RAMD_F32)
+            hipLaunchKernelGGL((k_cast_vals<float, double>), dim3(grid), dim3(kBlock), 0, b.cur, src->nnz,
+                               (float*)m->val, (const double*)src->val);
+        else
+            hipLaunchKernelGGL((k_cast_vals<double, float>), dim3(grid), dim3(kBlock), 0, b.cur, src->nnz,
+                               (double*)m->val, (const float*)src->val);
+        RAMD_HIP(hipGetLastError());
+    }
+    *out = m;
+    return RAMD_OK;
+}
+
+int ramd_mat_extract_submatrix(ramd_mat_t m, int r0, int c0, int rs, int cs, ramd_mat_t out)
+{
+    if(!m || !out || m == out)
+        RAMD_FAIL(RAMD_ERR_ARG, "bad handles");
+    if(m->format != RAMD_CSR)
+        return RAMD_ERR_UNSUPPORTED;
+    if(out->dtype != m->dtype || r0 < 0 || c0 < 0 || rs < 0 || cs < 0 || r0 + rs > m->nrow
+       || c0 + cs > m->ncol)
+        RAMD_FAIL(RAMD_ERR_ARG, "ExtractSubMatrix: range out of bounds / dtype mismatch");
+    Backend& b   = backend();
+    int*     cnt = nullptr;
+    RAMD_TRY(dev_alloc(&cnt, (int64_t)rs + 1));
+    const int grid = ew_grid((int64_t)rs + 1);
+    hipLaunchKernelGGL(k_sub_count, dim3(grid), dim3(kBlock), 0, b.cur, r0, c0, rs, cs, m->rp, m->ci, cnt);
+    int s   = device_exclusive_scan(cnt, cnt, (int64_t)rs + 1);
+    int nnz = 0;
+    if(s == RAMD_OK)
+    {
+        hipError_t e = hipMemcpyAsync(&nnz, cnt + rs, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+        if(e == hipSuccess)
+            e = hipStreamSynchronize(b.cur);
+        if(e != hipSuccess)
+            s = RAMD_ERR_HIP;
+    }
+    if(s == RAMD_OK)
+        s = mat_alloc_csr(out, rs, cs, nnz);
+    if(s == RAMD_OK)
+    {
+        hipError_t e = hipMemcpyAsync(out->rp, cnt, sizeof(int) * ((size_t)rs + 1),
+                                      hipMemcpyDeviceToDevice, b.cur);
+        if(e != hipSuccess)
+            s = RAMD_ERR_HIP;
+    }
+    if(s == RAMD_OK && nnz > 0)
+    {
+        if(m->dtype == RAMD_F64)
+            hipLaunchKernelGGL((k_sub_fill<double>), dim3(grid), dim3(kBlock), 0, b.cur, r0, c0, rs, cs,
+                               m->rp, m->ci, (const double*)m->val, out->rp, out->ci, (double*)out->val);
+        else
+            hipLaunchKernelGGL((k_sub_fill<float>), dim3(grid), dim3(kBlock), 0, b.cur, r0, c0, rs, cs,
+                               m->rp, m->ci, (const float*)m->val, out->rp, out->ci, (float*)out->val);
+    }
+    hipError_t e = hipStreamSynchronize(b.cur);
+    dev_free(&cnt);
+    RAMD_TRY(s);
+    RAMD_HIP(e);
+    return RAMD_OK;
+}
+
+int ramd_mat_permute(ramd_mat_t m, ramd_vec_t perm)
+{
+    if(!m || !perm)
+        RAMD_FAIL(RAMD_ERR_ARG, "bad handles");
+    if(m->format != RAMD_CSR)
+        return RAMD_ERR_UNSUPPORTED;
+    if(perm->dtype != RAMD_I32 || perm->n != m->nrow || m->nrow != m->ncol)
+        RAMD_FAIL(RAMD_ERR_ARG, "Permute: need a square matrix and an int32 permutation of its size");
+    if(m->nnz <= 0)
+        return RAMD_OK;
+    Backend& b   = backend();
+    int*     orp = nullptr;
+    int*     oci = nullptr;
+    void*    ova = nullptr;
+    RAMD_TRY(dev_alloc(&orp, (int64_t)m->nrow + 1));
+    int s = dev_alloc(&oci, m->nnz);
+    if(s == RAMD_OK && hipMalloc(&ova, (size_t)m->nnz * val_size(m->dtype) + kPad) != hipSuccess)
+        s = RAMD_ERR_HIP;
+    if(s == RAMD_OK)
+    {
+        const int grid = ew_grid((int64_t)m->nrow + 1);
+        hipLaunchKernelGGL(k_perm_row_nnz, dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, m->rp,
+                           (const int*)perm->d, orp);
+        s = device_exclusive_scan(orp, orp, (int64_t)m->nrow + 1);
+        if(s == RAMD_OK)
+        {
+            if(m->dtype == RAMD_F64)
+                hipLaunchKernelGGL((k_perm_fill<double>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow,
+                                   m->rp, m->ci, (const double*)m->val, (const int*)perm->d, orp, oci,
+                                   (double*)ova);
+            else
+                hipLaunchKernelGGL((k_perm_fill<float>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow,
+                                   m->rp, m->ci, (const float*)m->val, (const int*)perm->d, orp, oci,
+                                   (float*)ova);
+            if(hipStreamSynchronize(b.cur) != hipSuccess)
+                s = RAMD_ERR_HIP;
+        }
+    }
+    if(s != RAMD_OK)
+    {
+        dev_free(&orp);
+        dev_free(&oci);
+        if(ova)
+            (void)hipFree(ova);
+        RAMD_FAIL(s, "Permute failed");
+    }
+    mat_free_csr(m);
+    mat_free_analysis(m);
+    m->rp  = orp;
+    m->ci  = oci;
+    m->val = ova;
+    return RAMD_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,170 @@
+// device_utils.hpp -- wave64 / workgroup primitives shared by all kernels (gfx950).
+#pragma once
+
+#include "common.hpp"
+
+namespace ramd
+{
+
+// 16-byte packets: the coalescing sweet spot for bandwidth-bound kernels (1 KiB / wave-instr)
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+typedef float  v4f32 __attribute__((ext_vector_type(4)));
+typedef int    v4i32 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct Pack;
+template <>
+struct Pack<double>
+{
+    using type             = v2f64;
+    static constexpr int N = 2;
+};
+template <>
+struct Pack<float>
+{
+    using type             = v4f32;
+    static constexpr int N = 4;
+};
+template <>
+struct Pack<int>
+{
+    using type             = v4i32;
+    static constexpr int N = 4;
+};
+
+template <typename T>
+__device__ __forceinline__ T* pk_elems(typename Pack<T>::type& p)
+{
+    return reinterpret_cast<T*>(&p);
+}
+
+// streaming (read-once / write-once) accesses: keep val/col/y out of the way of the x vector
+// that the SpMV wants resident in L2.
+template <typename X>
+__device__ __forceinline__ X nt_load(const X* p)
+{
+    return __builtin_nontemporal_load(p);
+}
+template <typename X>
+__device__ __forceinline__ void nt_store(X v, X* p)
+{
+    __builtin_nontemporal_store(v, p);
+}
+
+// ---- wave64 / block reductions (fixed order => deterministic) ----
+__device__ __forceinline__ double wave_reduce_sum(double v)
+{
+#pragma unroll
+    for(int off = 32; off > 0; off >>= 1)
+        v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// sum over a 256-thread workgroup; result valid in thread 0. `lds` holds >= 4 doubles per value.
+__device__ __forceinline__ double block_reduce_sum(double v, double* lds)
+{
+    v         = wave_reduce_sum(v);
+    int lane  = threadIdx.x & 63;
+    int wave  = threadIdx.x >> 6;
+    int nwave = (blockDim.x + 63) >> 6;
+    if(lane == 0)
+        lds[wave] = v;
+    __syncthreads();
+    double r = 0.0;
+    if(threadIdx.x == 0)
+        for(int w = 0; w < nwave; ++w)
+            r += lds[w];
+    __syncthreads();
+    return r;
+}
+
+// ---- single-launch grid reduction ---------------------------------------------------------
+// Every workgroup deposits NS partial sums, takes a ticket, and the LAST arriver adds the
+// partials of all workgroups in a fixed order and writes the NS results into the scalar
+// record -- one launch, deterministic, no atomics on the data.  Hand-off follows the
+// gfx950 rule (MI355X_MICROARCH.md "inter-workgroup visibility"): agent-scope release on the
+// producer (+ explicit vmcnt drain, the compiler may drop it), ticket, agent-scope acquire on
+// the consumer, L1-bypassing loads of the partials.
+struct ReduceCtx
+{
+    double*       partials; // [slot][kReduceBlocks]
+    unsigned int* ticket; // one counter per concurrently running reduction kernel
+    double*       scalars; // device scalar record
+};
+
+enum ReduceOp
+{
+    RED_SUM  = 0,
+    RED_SQRT = 1 // result = sqrt(sum)  (Norm)
+};
+
+template <int NS>
+__device__ __forceinline__ void grid_reduce_finish(const ReduceCtx& ctx, const double (&val)[NS],
+                                                   const int (&slot)[NS], const int (&op)[NS],
+                                                   double* lds /* >= 4*NS + 1 doubles */)
+{
+    __shared__ int s_last;
+    double         bsum[NS];
+#pragma unroll
+    for(int k = 0; k < NS; ++k)
+        bsum[k] = block_reduce_sum(val[k], lds + 4 * k);
+    if(threadIdx.x == 0)
+    {
+#pragma unroll
+        for(int k = 0; k < NS; ++k)
+            __hip_atomic_store(&ctx.partials[(size_t)slot[k] * kReduceBlocks + blockIdx.x], bsum[k],
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned int t = __hip_atomic_fetch_add(ctx.ticket, 1u, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+        s_last         = (t == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if(s_last)
+    {
+        if(threadIdx.x == 0)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+#pragma unroll
+        for(int k = 0; k < NS; ++k)
+        {
+            double a = 0.0;
+            for(int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x)
+                a += __hip_atomic_load(&ctx.partials[(size_t)slot[k] * kReduceBlocks + b],
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            double tot = block_reduce_sum(a, lds + 4 * k);
+            if(threadIdx.x == 0)
+            {
+                if(op[k] == RED_SQRT)
+                    tot = sqrt(tot);
+                ctx.scalars[slot[k]] = tot;
+            }
+        }
+        if(threadIdx.x == 0)
+            __hip_atomic_store(ctx.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+inline ReduceCtx reduce_ctx(int ticket_id = 0)
+{
+    Backend&  b = backend();
+    ReduceCtx c;
+    c.partials = b.d_partials;
+    c.ticket   = b.d_ticket + ticket_id;
+    c.scalars  = b.d_scalars;
+    return c;
+}
+
+// grid for reduction kernels: never more than kReduceBlocks workgroups
+inline int reduce_grid(int64_t n_items)
+{
+    int64_t g = (n_items + kBlock - 1) / kBlock;
+    if(g > kReduceBlocks)
+        g = kReduceBlocks;
+    if(g < 1)
+        g = 1;
+    return (int)g;
+}
+
+} // namespace ramd

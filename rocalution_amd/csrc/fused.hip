@@ -1,0 +1,432 @@
+// fused.hip -- single-launch fusions of the Krylov BLAS-1 sequences (new entry points; the
+// reference runs each update / dot / norm as its own rocBLAS call or kernel with a blocking
+// device->host scalar read after every reduction, src/base/hip/hip_vector.cpp:569-931).
+//
+// Scalars (rho, p.q, ||r||^2, ...) stay in a device record; kernels read their coefficients from
+// it, so a whole CG iteration needs no host round trip except the convergence test.
+// Per element the arithmetic is exactly the reference's host expression for the fused ops
+// (host_vector.cpp AddScale :635, ScaleAdd :654, PointWiseMult :1257), so vectors are bit-identical
+// to the unfused sequence; only the summation order of the reductions differs.
+#include "device_utils.hpp"
+#include "matrix_impl.hpp"
+
+namespace ramd
+{
+
+// CG update (src/solvers/krylov/cg.cpp:418-438):
+//   alpha = rho / (p.q) ; x = x + alpha*p ; r = r + (-alpha)*q ; rr = <r,r>
+//   PRECOND: z = dinv * r ; rz = <r,z>        else rz = rr
+template <typename T, bool PRECOND>
+__global__ __launch_bounds__(kBlock) void k_cg_update(int64_t n, T* __restrict__ x, T* __restrict__ r,
+                                                      const T* __restrict__ p,
+                                                      const T* __restrict__ q,
+                                                      const T* __restrict__ dinv, T* __restrict__ z,
+                                                      ReduceCtx ctx, int slot_rho, int slot_pq,
+                                                      int slot_rr, int slot_rz)
+{
+    using P          = typename Pack<T>::type;
+    constexpr int NP = Pack<T>::N;
+    __shared__ double lds[12];
+    const T alpha  = (T)ctx.scalars[slot_rho] / (T)ctx.scalars[slot_pq];
+    const T malpha = -alpha;
+    int64_t np     = n / NP;
+    int64_t gtid   = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t gsz    = (int64_t)gridDim.x * blockDim.x;
+    double  rr = 0.0, rz = 0.0;
+    for(int64_t i = gtid; i < np; i += gsz)
+    {
+        P px = reinterpret_cast<P*>(x)[i];
+        P pr = reinterpret_cast<P*>(r)[i];
+        P pp = reinterpret_cast<const P*>(p)[i];
+        P pq = reinterpret_cast<const P*>(q)[i];
+        P pd, pz;
+        if(PRECOND)
+            pd = reinterpret_cast<const P*>(dinv)[i];
+#pragma unroll
+        for(int k = 0; k < NP; ++k)
+        {
+            pk_elems<T>(px)[k] = pk_elems<T>(px)[k] + alpha * pk_elems<T>(pp)[k];
+            T rn               = pk_elems<T>(pr)[k] + malpha * pk_elems<T>(pq)[k];
+            pk_elems<T>(pr)[k] = rn;
+            rr += (double)rn * (double)rn;
+            if(PRECOND)
+            {
+                T zn               = pk_elems<T>(pd)[k] * rn;
+                pk_elems<T>(pz)[k] = zn;
+                rz += (double)rn * (double)zn;
+            }
+        }
+        reinterpret_cast<P*>(x)[i] = px;
+        reinterpret_cast<P*>(r)[i] = pr;
+        if(PRECOND)
+            reinterpret_cast<P*>(z)[i] = pz;
+    }
+    for(int64_t i = np * NP + gtid; i < n; i += gsz)
+    {
+        x[i]  = x[i] + alpha * p[i];
+        T rn  = r[i] + malpha * q[i];
+        r[i]  = rn;
+        rr += (double)rn * (double)rn;
+        if(PRECOND)
+        {
+            T zn = dinv[i] * rn;
+            z[i] = zn;
+            rz += (double)rn * (double)zn;
+        }
+    }
+    if(!PRECOND)
+        rz = rr;
+    const double vals[2]  = {rr, rz};
+    const int    slots[2] = {slot_rr, slot_rz};
+    const int    ops[2]   = {RED_SUM, RED_SUM};
+    grid_reduce_finish<2>(ctx, vals, slots, ops, lds);
+}
+
+// p = beta*p + z with beta = s[num]/s[den]   (cg.cpp:441-442, ScaleAdd)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_cg_direction(int64_t n, T* __restrict__ p,
+                                                         const T* __restrict__ z,
+                                                         const double* __restrict__ scalars,
+                                                         int slot_num, int slot_den)
+{
+    using P          = typename Pack<T>::type;
+    constexpr int NP = Pack<T>::N;
+    const T       beta = (T)scalars[slot_num] / (T)scalars[slot_den];
+    int64_t       np   = n / NP;
+    int64_t       gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t       gsz  = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = gtid; i < np; i += gsz)
+    {
+        P pp = reinterpret_cast<P*>(p)[i];
+        P pz = reinterpret_cast<const P*>(z)[i];
+#pragma unroll
+        for(int k = 0; k < NP; ++k)
+            pk_elems<T>(pp)[k] = beta * pk_elems<T>(pp)[k] + pk_elems<T>(pz)[k];
+        reinterpret_cast<P*>(p)[i] = pp;
+    }
+    for(int64_t i = np * NP + gtid; i < n; i += gsz)
+        p[i] = beta * p[i] + z[i];
+}
+
+// up to 8 dots against one vector in one pass over w: s[slot0+k] = <v_k, w>
+constexpr int kMaxMultiDot = 8;
+template <typename T>
+struct MultiDotArgs
+{
+    const T* v[kMaxMultiDot];
+};
+
+template <typename T, int NV>
+__global__ __launch_bounds__(kBlock) void k_multi_dot(int64_t n, MultiDotArgs<T> a,
+                                                      const T* __restrict__ w, ReduceCtx ctx, int slot0)
+{
+    using P          = typename Pack<T>::type;
+    constexpr int NP = Pack<T>::N;
+    __shared__ double lds[4 * NV + 4];
+    int64_t np   = n / NP;
+    int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t gsz  = (int64_t)gridDim.x * blockDim.x;
+    double  acc[NV];
+#pragma unroll
+    for(int j = 0; j < NV; ++j)
+        acc[j] = 0.0;
+    for(int64_t i = gtid; i < np; i += gsz)
+    {
+        P pw = reinterpret_cast<const P*>(w)[i];
+#pragma unroll
+        for(int j = 0; j < NV; ++j)
+        {
+            P pv = reinterpret_cast<const P*>(a.v[j])[i];
+#pragma unroll
+            for(int k = 0; k < NP; ++k)
+                acc[j] += (double)pk_elems<T>(pv)[k] * (double)pk_elems<T>(pw)[k];
+        }
+    }
+    for(int64_t i = np * NP + gtid; i < n; i += gsz)
+#pragma unroll
+        for(int j = 0; j < NV; ++j)
+            acc[j] += (double)a.v[j][i] * (double)w[i];
+    int slots[NV], ops[NV];
+#pragma unroll
+    for(int j = 0; j < NV; ++j)
+    {
+        slots[j] = slot0 + j;
+        ops[j]   = RED_SUM;
+    }
+    grid_reduce_finish<NV>(ctx, acc, slots, ops, lds);
+}
+
+// one modified-Gram-Schmidt step fused with the NEXT projection's dot (gmres.cpp:480-486):
+//   w = w + (-h)*v ; s[slot_dot] = <u, w>   (u == nullptr: <w, w>)
+template <typename T, bool HAVE_U>
+__global__ __launch_bounds__(kBlock) void k_mgs_step(int64_t n, T* __restrict__ w,
+                                                     const T* __restrict__ v,
+                                                     const T* __restrict__ u, ReduceCtx ctx,
+                                                     int slot_h, int slot_dot)
+{
+    using P          = typename Pack<T>::type;
+    constexpr int NP = Pack<T>::N;
+    __shared__ double lds[8];
+    const T mh   = -(T)ctx.scalars[slot_h];
+    int64_t np   = n / NP;
+    int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t gsz  = (int64_t)gridDim.x * blockDim.x;
+    double  acc  = 0.0;
+    for(int64_t i = gtid; i < np; i += gsz)
+    {
+        P pw = reinterpret_cast<P*>(w)[i];
+        P pv = reinterpret_cast<const P*>(v)[i];
+        P pu;
+        if(HAVE_U)
+            pu = reinterpret_cast<const P*>(u)[i];
+#pragma unroll
+        for(int k = 0; k < NP; ++k)
+        {
+            T wn               = pk_elems<T>(pw)[k] + mh * pk_elems<T>(pv)[k];
+            pk_elems<T>(pw)[k] = wn;
+            acc += (double)(HAVE_U ? pk_elems<T>(pu)[k] : wn) * (double)wn;
+        }
+        reinterpret_cast<P*>(w)[i] = pw;
+    }
+    for(int64_t i = np * NP + gtid; i < n; i += gsz)
+    {
+        T wn = w[i] + mh * v[i];
+        w[i] = wn;
+        acc += (double)(HAVE_U ? u[i] : wn) * (double)wn;
+    }
+    const double vals[1]  = {acc};
+    const int    slots[1] = {slot_dot};
+    const int    ops[1]   = {RED_SUM};
+    grid_reduce_finish<1>(ctx, vals, slots, ops, lds);
+}
+
+// v *= 1/sqrt(s[slot_sq]); the norm itself is left in s[slot_norm]   (gmres.cpp:493-496)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_normalize(int64_t n, T* __restrict__ v,
+                                                      double* __restrict__ scalars, int slot_sq,
+                                                      int slot_norm)
+{
+    using P          = typename Pack<T>::type;
+    constexpr int NP = Pack<T>::N;
+    const T       nrm = (T)sqrt(scalars[slot_sq]);
+    const T       inv = (T)1 / nrm;
+    int64_t       np   = n / NP;
+    int64_t       gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t       gsz  = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = gtid; i < np; i += gsz)
+    {
+        P pv = reinterpret_cast<P*>(v)[i];
+#pragma unroll
+        for(int k = 0; k < NP; ++k)
+            pk_elems<T>(pv)[k] *= inv;
+        reinterpret_cast<P*>(v)[i] = pv;
+    }
+    for(int64_t i = np * NP + gtid; i < n; i += gsz)
+        v[i] *= inv;
+    if(gtid == 0)
+        scalars[slot_norm] = (double)nrm;
+}
+
+} // namespace ramd
+
+using namespace ramd;
+
+static bool slot_ok(int s)
+{
+    return s >= 0 && s < kScalarSlots;
+}
+
+#define CHECK_SAMEV(a, b)                                                     \
+    do                                                                        \
+    {                                                                         \
+        if(!(a) || !(b) || (a)->dtype != (b)->dtype || (a)->n != (b)->n)      \
+            RAMD_FAIL(RAMD_ERR_ARG, "fused op: vector handles/sizes/types mismatch"); \
+    } while(0)
+
+extern "C" {
+
+int ramd_fused_apply_dot(ramd_mat_t m, ramd_vec_t x, ramd_vec_t y, int slot_dot)
+{
+    if(!m || !x || !y || !slot_ok(slot_dot))
+        RAMD_FAIL(RAMD_ERR_ARG, "fused_apply_dot: bad arguments");
+    if(x->dtype != m->dtype || y->dtype != m->dtype || x->n != m->ncol || y->n != m->nrow || x == y)
+        RAMD_FAIL(RAMD_ERR_ARG, "fused_apply_dot: vector sizes/types do not match the matrix");
+    int s = (m->dtype == RAMD_F64)
+                ? mat_apply_dot_impl<double>(m, (const double*)x->d, (double*)y->d, slot_dot)
+                : mat_apply_dot_impl<float>(m, (const float*)x->d, (float*)y->d, slot_dot);
+    if(s != RAMD_ERR_UNSUPPORTED)
+        return s;
+    // formats without a fused epilogue: SpMV, then a one-launch dot into the same slot
+    RAMD_TRY(ramd_mat_apply(m, x, y));
+    const ramd_vec_t vs[1] = {x};
+    return ramd_fused_multi_dot(vs, 1, y, slot_dot);
+}
+
+int ramd_fused_cg_update(ramd_vec_t x, ramd_vec_t r, ramd_vec_t p, ramd_vec_t q, ramd_vec_t dinv,
+                         ramd_vec_t z, int slot_rho, int slot_pq, int slot_rr, int slot_rz)
+{
+    CHECK_SAMEV(x, r);
+    CHECK_SAMEV(x, p);
+    CHECK_SAMEV(x, q);
+    if(dinv)
+    {
+        CHECK_SAMEV(x, dinv);
+        CHECK_SAMEV(x, z);
+    }
+    if(!slot_ok(slot_rho) || !slot_ok(slot_pq) || !slot_ok(slot_rr) || !slot_ok(slot_rz))
+        RAMD_FAIL(RAMD_ERR_ARG, "scalar slot out of range");
+    if(x->n == 0)
+        return RAMD_OK;
+    Backend&  b    = backend();
+    const int grid = reduce_grid((x->n + 1) / 2);
+    ReduceCtx ctx  = reduce_ctx();
+#define GO(T)                                                                                          \
+    do                                                                                                 \
+    {                                                                                                  \
+        if(dinv)                                                                                       \
+            hipLaunchKernelGGL((k_cg_update<T, true>), dim3(grid), dim3(kBlock), 0, b.cur, x->n,       \
+                               (T*)x->d, (T*)r->d, (const T*)p->d, (const T*)q->d, (const T*)dinv->d,  \
+                               (T*)z->d, ctx, slot_rho, slot_pq, slot_rr, slot_rz);                    \
+        else                                                                                           \
+            hipLaunchKernelGGL((k_cg_update<T, false>), dim3(grid), dim3(kBlock), 0, b.cur, x->n,      \
+                               (T*)x->d, (T*)r->d, (const T*)p->d, (const T*)q->d, (const T*)nullptr,  \
+                               (T*)nullptr, ctx, slot_rho, slot_pq, slot_rr, slot_rz);                 \
+    } while(0)
+    if(x->dtype == RAMD_F64)
+        GO(double);
+    else if(x->dtype == RAMD_F32)
+        GO(float);
+    else
+        RAMD_FAIL(RAMD_ERR_ARG, "fused_cg_update needs real vectors");
+#undef GO
+    RAMD_HIP(hipGetLastError());
+    return RAMD_OK;
+}
+
+int ramd_fused_cg_direction(ramd_vec_t p, ramd_vec_t z, int slot_num, int slot_den)
+{
+    CHECK_SAMEV(p, z);
+    if(!slot_ok(slot_num) || !slot_ok(slot_den))
+        RAMD_FAIL(RAMD_ERR_ARG, "scalar slot out of range");
+    if(p->n == 0)
+        return RAMD_OK;
+    Backend&  b    = backend();
+    const int grid = ew_grid((p->n + 1) / 2);
+    if(p->dtype == RAMD_F64)
+        hipLaunchKernelGGL((k_cg_direction<double>), dim3(grid), dim3(kBlock), 0, b.cur, p->n,
+                           (double*)p->d, (const double*)z->d, b.d_scalars, slot_num, slot_den);
+    else if(p->dtype == RAMD_F32)
+        hipLaunchKernelGGL((k_cg_direction<float>), dim3(grid), dim3(kBlock), 0, b.cur, p->n,
+                           (float*)p->d, (const float*)z->d, b.d_scalars, slot_num, slot_den);
+    else
+        RAMD_FAIL(RAMD_ERR_ARG, "fused_cg_direction needs real vectors");
+    RAMD_HIP(hipGetLastError());
+    return RAMD_OK;
+}
+
+} // extern "C"
+
+template <typename T>
+static int multi_dot_t(const ramd_vec_t* vs, int count, ramd_vec_t w, int slot0)
+{
+    Backend&  b    = backend();
+    const int grid = reduce_grid((w->n + Pack<T>::N - 1) / Pack<T>::N);
+    ReduceCtx ctx  = reduce_ctx();
+    int       done = 0;
+    while(done < count)
+    {
+        const int        nv = std::min(count - done, kMaxMultiDot);
+        MultiDotArgs<T> a;
+        for(int j = 0; j < kMaxMultiDot; ++j)
+            a.v[j] = (const T*)vs[done + std::min(j, nv - 1)]->d;
+#define GO(NV)                                                                                     \
+    case NV:                                                                                       \
+        hipLaunchKernelGGL((k_multi_dot<T, NV>), dim3(grid), dim3(kBlock), 0, b.cur, w->n, a,      \
+                           (const T*)w->d, ctx, slot0 + done);                                     \
+        break;
+        switch(nv)
+        {
+            GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8)
+        }
+#undef GO
+        RAMD_HIP(hipGetLastError());
+        done += nv;
+    }
+    return RAMD_OK;
+}
+
+extern "C" {
+
+int ramd_fused_multi_dot(const ramd_vec_t* vs, int count, ramd_vec_t w, int slot0)
+{
+    if(!vs || !w || count < 1 || !slot_ok(slot0) || !slot_ok(slot0 + count - 1))
+        RAMD_FAIL(RAMD_ERR_ARG, "fused_multi_dot: bad arguments");
+    for(int j = 0; j < count; ++j)
+        CHECK_SAMEV(vs[j], w);
+    if(w->n == 0)
+    {
+        for(int j = 0; j < count; ++j)
+            RAMD_TRY(ramd_scalars_set(slot0 + j, 0.0));
+        return RAMD_OK;
+    }
+    if(w->dtype == RAMD_F64)
+        return multi_dot_t<double>(vs, count, w, slot0);
+    if(w->dtype == RAMD_F32)
+        return multi_dot_t<float>(vs, count, w, slot0);
+    RAMD_FAIL(RAMD_ERR_ARG, "fused_multi_dot needs real vectors");
+}
+
+int ramd_fused_mgs_step(ramd_vec_t w, ramd_vec_t v, int slot_h, ramd_vec_t u, int slot_dot)
+{
+    CHECK_SAMEV(w, v);
+    if(u)
+        CHECK_SAMEV(w, u);
+    if(!slot_ok(slot_h) || !slot_ok(slot_dot))
+        RAMD_FAIL(RAMD_ERR_ARG, "scalar slot out of range");
+    if(w->n == 0)
+        return RAMD_OK;
+    Backend&  b    = backend();
+    const int grid = reduce_grid((w->n + 1) / 2);
+    ReduceCtx ctx  = reduce_ctx();
+#define GO(T)                                                                                      \
+    do                                                                                             \
+    {                                                                                              \
+        if(u)                                                                                      \
+            hipLaunchKernelGGL((k_mgs_step<T, true>), dim3(grid), dim3(kBlock), 0, b.cur, w->n,    \
+                               (T*)w->d, (const T*)v->d, (const T*)u->d, ctx, slot_h, slot_dot);   \
+        else                                                                                       \
+            hipLaunchKernelGGL((k_mgs_step<T, false>), dim3(grid), dim3(kBlock), 0, b.cur, w->n,   \
+                               (T*)w->d, (const T*)v->d, (const T*)nullptr, ctx, slot_h, slot_dot); \
+    } while(0)
+    if(w->dtype == RAMD_F64)
+        GO(double);
+    else if(w->dtype == RAMD_F32)
+        GO(float);
+    else
+        RAMD_FAIL(RAMD_ERR_ARG, "fused_mgs_step needs real vectors");
+#undef GO
+    RAMD_HIP(hipGetLastError());
+    return RAMD_OK;
+}
+
+int ramd_fused_normalize(ramd_vec_t v, int slot_sq, int slot_norm)
+{
+    if(!v || !slot_ok(slot_sq) || !slot_ok(slot_norm) || slot_sq == slot_norm)
+        RAMD_FAIL(RAMD_ERR_ARG, "fused_normalize: bad arguments (slots must differ)");
+    if(v->n == 0)
+        return RAMD_OK;
+    Backend&  b    = backend();
+    const int grid = ew_grid((v->n + 1) / 2);
+    if(v->dtype == RAMD_F64)
+        hipLaunchKernelGGL((k_normalize<double>), dim3(grid), dim3(kBlock), 0, b.cur, v->n,
+                           (double*)v->d, b.d_scalars, slot_sq, slot_norm);
+    else if(v->dtype == RAMD_F32)
+        hipLaunchKernelGGL((k_normalize<float>), dim3(grid), dim3(kBlock), 0, b.cur, v->n, (float*)v->d,
+                           b.d_scalars, slot_sq, slot_norm);
+    else
+        RAMD_FAIL(RAMD_ERR_ARG, "fused_normalize needs a real vector");
+    RAMD_HIP(hipGetLastError());
+    return RAMD_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,30 @@
+// matrix_impl.hpp -- internal (non-ABI) declarations shared by the .hip translation units.
+#pragma once
+
+#include "common.hpp"
+
+namespace ramd
+{
+
+size_t val_size(int dtype);
+void   mat_free_csr(ramd_mat_s* m);
+void   mat_free_ell(ramd_mat_s* m);
+void   mat_free_coo(ramd_mat_s* m);
+void   mat_free_analysis(ramd_mat_s* m);
+int    mat_alloc_csr(ramd_mat_s* m, int nrow, int ncol, int64_t nnz);
+
+// trisolve.hip
+void tri_release(ramd_mat_s* m);
+
+// spmv.hip
+template <typename T>
+int mat_apply_impl(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar);
+template <typename T>
+int mat_apply_dot_impl(const ramd_mat_s* m, const T* x, T* y, int slot);
+
+// scan.hip: out[i] = sum_{k<i} in[k] for i < n (in and out may alias); int32 sums
+int device_exclusive_scan(const int* in, int* out, int64_t n);
+// max over an int array -> host
+int device_max_int(const int* in, int64_t n, int* result);
+
+} // namespace ramd

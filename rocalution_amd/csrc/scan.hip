@@ -1,0 +1,129 @@
+// scan.hip -- device exclusive scan / max (own implementation; the reference uses rocPRIM for the
+// same setup steps, e.g. src/base/hip/hip_conversion.cpp:584-680).  Setup-time only.
+#include "device_utils.hpp"
+#include "matrix_impl.hpp"
+
+namespace ramd
+{
+
+constexpr int kScanItems = 8; // per thread
+constexpr int kScanTile  = kBlock * kScanItems;
+
+// tile-local exclusive scan; tile totals go to tsum[blockIdx.x]
+__global__ __launch_bounds__(kBlock) void k_scan_tiles(const int* __restrict__ in,
+                                                       int* __restrict__ out, int64_t n,
+                                                       int* __restrict__ tsum)
+{
+    __shared__ int wsum[4];
+    const int64_t  base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    int            v[kScanItems];
+    int            tot = 0;
+#pragma unroll
+    for(int k = 0; k < kScanItems; ++k)
+    {
+        v[k] = (base + k < n) ? in[base + k] : 0;
+        tot += v[k];
+    }
+    // inclusive scan of per-thread totals inside the wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int       inc  = tot;
+#pragma unroll
+    for(int off = 1; off < 64; off <<= 1)
+    {
+        int t = __shfl_up(inc, off, 64);
+        if(lane >= off)
+            inc += t;
+    }
+    if(lane == 63)
+        wsum[wave] = inc;
+    __syncthreads();
+    int woff = 0;
+    for(int w = 0; w < wave; ++w)
+        woff += wsum[w];
+    int run = woff + inc - tot;
+#pragma unroll
+    for(int k = 0; k < kScanItems; ++k)
+    {
+        if(base + k < n)
+            out[base + k] = run;
+        run += v[k];
+    }
+    if(threadIdx.x == kBlock - 1 && tsum)
+        tsum[blockIdx.x] = woff + inc;
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_add(int* __restrict__ out, int64_t n,
+                                                     const int* __restrict__ toff)
+{
+    const int     add  = toff[blockIdx.x];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile;
+    for(int k = threadIdx.x; k < kScanTile; k += kBlock)
+        if(base + k < n)
+            out[base + k] += add;
+}
+
+int device_exclusive_scan(const int* in, int* out, int64_t n)
+{
+    if(n <= 0)
+        return RAMD_OK;
+    Backend&      b      = backend();
+    const int64_t ntiles = (n + kScanTile - 1) / kScanTile;
+    if(ntiles == 1)
+    {
+        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(kBlock), 0, b.cur, in, out, n, (int*)nullptr);
+        RAMD_HIP(hipGetLastError());
+        return RAMD_OK;
+    }
+    int* tsum = nullptr;
+    RAMD_TRY(dev_alloc(&tsum, ntiles));
+    hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)ntiles), dim3(kBlock), 0, b.cur, in, out, n, tsum);
+    int s = device_exclusive_scan(tsum, tsum, ntiles);
+    if(s == RAMD_OK)
+    {
+        hipLaunchKernelGGL(k_scan_add, dim3((unsigned)ntiles), dim3(kBlock), 0, b.cur, out, n, tsum);
+        if(hipGetLastError() != hipSuccess)
+            s = RAMD_ERR_HIP;
+    }
+    // tsum is freed after the queued kernels ran (hipFree synchronises)
+    dev_free(&tsum);
+    return s;
+}
+
+__global__ __launch_bounds__(kBlock) void k_max_int(const int* __restrict__ in, int64_t n,
+                                                    int* __restrict__ result)
+{
+    __shared__ int sm[kBlock];
+    int            m   = INT_MIN;
+    const int64_t  gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gsz)
+        m = max(m, in[i]);
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for(int s = kBlock / 2; s > 0; s >>= 1)
+    {
+        if((int)threadIdx.x < s)
+            sm[threadIdx.x] = max(sm[threadIdx.x], sm[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if(threadIdx.x == 0)
+        atomicMax(result, sm[0]);
+}
+
+int device_max_int(const int* in, int64_t n, int* result)
+{
+    Backend& b = backend();
+    int*     d = nullptr;
+    RAMD_TRY(dev_alloc(&d, 1));
+    int init = INT_MIN;
+    RAMD_HIP(hipMemcpyAsync(d, &init, sizeof(int), hipMemcpyHostToDevice, b.cur));
+    if(n > 0)
+        hipLaunchKernelGGL(k_max_int, dim3(reduce_grid(n)), dim3(kBlock), 0, b.cur, in, n, d);
+    hipError_t e = hipMemcpyAsync(result, d, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+    if(e == hipSuccess)
+        e = hipStreamSynchronize(b.cur);
+    dev_free(&d);
+    RAMD_HIP(e);
+    return RAMD_OK;
+}
+
+} // namespace ramd
