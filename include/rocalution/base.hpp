@@ -1,0 +1,1009 @@
+// rocalution/base.hpp -- source-compatible front end (subset) of rocALUTION's LocalVector /
+// LocalMatrix and backend free functions, implemented on the C ABI of librocalution_amd.so.
+//
+// Mirrors, for the preconditioned-Krylov hot path only:
+//   src/base/backend_manager.hpp:169-377   init_rocalution, stop_rocalution, info_rocalution, ...
+//   src/base/local_vector.hpp:126-641      LocalVector<ValueType>
+//   src/base/local_matrix.hpp:77-1027      LocalMatrix<ValueType>
+// Same names, argument meaning and error behaviour (LOG + exit(1) on fatal errors,
+// src/utils/log.hpp:95-100).  Drivers written against <rocalution/rocalution.hpp> that stay inside
+// this subset recompile unchanged with a plain host compiler (no HIP headers needed here).
+//
+// There is NO host compute backend in this implementation: objects hold plain host storage until
+// MoveToAccelerator() and every numerical operation requires the accelerator.  (The reference's
+// host/OpenMP backend is what the oracle restates; it is deliberately not shipped here.)
+#pragma once
+
+#include <algorithm>
+#include <cassert>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../rocalution_amd.h"
+
+namespace rocalution
+{
+
+typedef int32_t PtrType; // src/utils/types.hpp.in:30-32 (default build)
+
+enum _matrix_format // src/base/matrix_formats.hpp
+{
+    DENSE = 0,
+    CSR   = 1,
+    MCSR  = 2,
+    BCSR  = 3,
+    COO   = 4,
+    DIA   = 5,
+    ELL   = 6,
+    HYB   = 7
+};
+
+#define LOG_INFO(stream)                   \
+    do                                     \
+    {                                      \
+        std::cout << stream << std::endl;  \
+    } while(0)
+
+#define FATAL_ERROR(file, line)                                                            \
+    do                                                                                     \
+    {                                                                                      \
+        std::cout << "Fatal error - the program will be terminated" << std::endl;          \
+        std::cout << "File: " << file << "; line: " << line << std::endl;                  \
+        exit(1);                                                                           \
+    } while(0)
+
+// status of a C-ABI call -> reference error convention
+inline void _check(int status, const char* what, const char* file, int line)
+{
+    if(status != RAMD_OK)
+    {
+        LOG_INFO("rocalution_amd: " << what << " failed (status " << status
+                                    << "): " << ramd_last_error());
+        FATAL_ERROR(file, line);
+    }
+}
+#define RAMD_CHECK(call) ::rocalution::_check((call), #call, __FILE__, __LINE__)
+
+template <typename T>
+struct _dtype;
+template <>
+struct _dtype<double>
+{
+    static constexpr int value = RAMD_F64;
+};
+template <>
+struct _dtype<float>
+{
+    static constexpr int value = RAMD_F32;
+};
+template <>
+struct _dtype<int>
+{
+    static constexpr int value = RAMD_I32;
+};
+
+// ---------------------------------------------------------------------------- backend
+struct _backend_state
+{
+    bool init          = false;
+    bool accel_disable = false;
+    int  device        = -1;
+};
+inline _backend_state& _state()
+{
+    static _backend_state s;
+    return s;
+}
+
+inline int init_rocalution(int rank = -1, int dev_per_node = 1)
+{
+    _backend_state& s = _state();
+    if(s.init)
+        return 0;
+    if(s.accel_disable)
+    {
+        LOG_INFO("rocalution_amd: the accelerator is disabled, but this library has no host compute "
+                 "backend (use the reference library for host runs)");
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+    int dev = s.device;
+    if(rank >= 0 && dev_per_node > 0) // backend_manager.cpp:180-185: device = rank % dev_per_node
+        dev = rank % dev_per_node;
+    RAMD_CHECK(ramd_init(dev));
+    s.init = true;
+    return 0;
+}
+inline int stop_rocalution(void)
+{
+    if(_state().init)
+        RAMD_CHECK(ramd_stop());
+    _state().init = false;
+    return 0;
+}
+inline void set_device_rocalution(int dev)
+{
+    _state().device = dev;
+}
+inline void disable_accelerator_rocalution(bool onoff = true)
+{
+    _state().accel_disable = onoff;
+}
+inline void set_omp_threads_rocalution(int) {}
+inline void set_omp_affinity_rocalution(bool) {}
+inline void set_omp_threshold_rocalution(int) {}
+inline void info_rocalution(void)
+{
+    char buf[512];
+    RAMD_CHECK(ramd_info(buf, (int)sizeof(buf)));
+    LOG_INFO(buf);
+}
+inline void _rocalution_sync(void)
+{
+    if(_state().init)
+        RAMD_CHECK(ramd_sync());
+}
+// microseconds, device synchronised first (src/utils/time_functions.cpp:46-69)
+inline double rocalution_time(void)
+{
+    _rocalution_sync();
+    auto now = std::chrono::steady_clock::now().time_since_epoch();
+    return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(now).count() / 1e3;
+}
+
+template <typename DataType>
+void allocate_host(int64_t n, DataType** ptr)
+{
+    *ptr = (n > 0) ? new DataType[n] : NULL;
+}
+template <typename DataType>
+void free_host(DataType** ptr)
+{
+    delete[] * ptr;
+    *ptr = NULL;
+}
+template <typename DataType>
+void set_to_zero_host(int64_t n, DataType* ptr)
+{
+    if(n > 0)
+        memset(ptr, 0, sizeof(DataType) * (size_t)n);
+}
+
+// ---------------------------------------------------------------------------- LocalVector
+template <typename ValueType>
+class LocalMatrix;
+
+template <typename ValueType>
+class LocalVector
+{
+public:
+    LocalVector() {}
+    ~LocalVector()
+    {
+        if(this->dev_ && this->own_) // adopted (non-owned) handles are left untouched
+            ramd_vec_destroy(this->dev_);
+    }
+    LocalVector(const LocalVector&)            = delete;
+    LocalVector& operator=(const LocalVector&) = delete;
+
+    void MoveToAccelerator(void)
+    {
+        if(this->on_accel_)
+            return;
+        this->ensure_dev_();
+        if(!this->host_.empty())
+        {
+            RAMD_CHECK(ramd_vec_allocate(this->dev_, (int64_t)this->host_.size()));
+            RAMD_CHECK(ramd_vec_copy_from_host(this->dev_, this->host_.data()));
+            std::vector<ValueType>().swap(this->host_);
+        }
+        this->on_accel_ = true;
+    }
+    void MoveToHost(void)
+    {
+        if(!this->on_accel_)
+            return;
+        int64_t n = this->GetSize();
+        this->host_.assign((size_t)n, ValueType(0));
+        if(n > 0)
+            RAMD_CHECK(ramd_vec_copy_to_host(this->dev_, this->host_.data()));
+        RAMD_CHECK(ramd_vec_clear(this->dev_));
+        this->on_accel_ = false;
+    }
+    bool is_accel_(void) const
+    {
+        return this->on_accel_;
+    }
+    template <class Obj>
+    void CloneBackend(const Obj& src)
+    {
+        if(src.is_accel_())
+            this->MoveToAccelerator();
+        else
+            this->MoveToHost();
+    }
+
+    void Allocate(std::string name, int64_t size)
+    {
+        assert(size >= 0);
+        this->name_ = name;
+        if(this->on_accel_)
+        {
+            this->ensure_dev_();
+            RAMD_CHECK(ramd_vec_allocate(this->dev_, size));
+        }
+        else
+            this->host_.assign((size_t)size, ValueType(0));
+    }
+    void Clear(void)
+    {
+        if(this->dev_)
+            ramd_vec_clear(this->dev_);
+        std::vector<ValueType>().swap(this->host_);
+    }
+    int64_t GetSize(void) const
+    {
+        if(this->on_accel_)
+        {
+            int64_t n = 0;
+            if(this->dev_)
+                RAMD_CHECK(ramd_vec_size(this->dev_, &n));
+            return n;
+        }
+        return (int64_t)this->host_.size();
+    }
+    int64_t GetLocalSize(void) const
+    {
+        return this->GetSize();
+    }
+    void Info(void) const
+    {
+        LOG_INFO("LocalVector name=" << this->name_ << "; size=" << this->GetSize()
+                                     << "; prec=" << 8 * sizeof(ValueType) << "bit; "
+                                     << (this->on_accel_ ? "accelerator backend: MI355X-native HIP"
+                                                         : "host storage (no host compute backend)"));
+    }
+
+    // storage-level operations work on both sides; numerical ones need the accelerator
+    void Zeros(void)
+    {
+        if(this->on_accel_)
+            RAMD_CHECK(ramd_vec_zeros(this->dev_));
+        else
+            std::fill(this->host_.begin(), this->host_.end(), ValueType(0));
+    }
+    void Ones(void)
+    {
+        this->SetValues(ValueType(1));
+    }
+    void SetValues(ValueType val)
+    {
+        if(this->on_accel_)
+            RAMD_CHECK(ramd_vec_set_values(this->dev_, (double)val));
+        else
+            std::fill(this->host_.begin(), this->host_.end(), val);
+    }
+    ValueType& operator[](int64_t i)
+    {
+        assert(!this->on_accel_ && i >= 0 && i < (int64_t)this->host_.size());
+        return this->host_[(size_t)i];
+    }
+    const ValueType& operator[](int64_t i) const
+    {
+        assert(!this->on_accel_ && i >= 0 && i < (int64_t)this->host_.size());
+        return this->host_[(size_t)i];
+    }
+    void SetDataPtr(ValueType** ptr, std::string name, int64_t size)
+    {
+        assert(ptr != NULL && *ptr != NULL && size >= 0);
+        this->Clear();
+        this->name_ = name;
+        if(this->on_accel_)
+        {
+            RAMD_CHECK(ramd_vec_allocate(this->dev_, size));
+            RAMD_CHECK(ramd_vec_copy_from_host(this->dev_, *ptr));
+        }
+        else
+            this->host_.assign(*ptr, *ptr + size);
+        delete[] * ptr; // ownership moves into the object (local_vector.cpp SetDataPtr)
+        *ptr = NULL;
+    }
+    void LeaveDataPtr(ValueType** ptr)
+    {
+        assert(*ptr == NULL);
+        int64_t n = this->GetSize();
+        allocate_host(n, ptr);
+        this->CopyToHostData(*ptr);
+        this->Clear();
+    }
+    void CopyFromData(const ValueType* data)
+    {
+        this->CopyFromHostData(data);
+    }
+    void CopyFromHostData(const ValueType* data)
+    {
+        if(this->GetSize() == 0)
+            return;
+        if(this->on_accel_)
+            RAMD_CHECK(ramd_vec_copy_from_host(this->dev_, data));
+        else
+            std::copy(data, data + this->host_.size(), this->host_.begin());
+    }
+    void CopyToData(ValueType* data) const
+    {
+        this->CopyToHostData(data);
+    }
+    void CopyToHostData(ValueType* data) const
+    {
+        if(this->GetSize() == 0)
+            return;
+        if(this->on_accel_)
+            RAMD_CHECK(ramd_vec_copy_to_host(this->dev_, data));
+        else
+            std::copy(this->host_.begin(), this->host_.end(), data);
+    }
+    void CopyFrom(const LocalVector<ValueType>& src)
+    {
+        assert(this != &src);
+        if(this->on_accel_ && src.on_accel_)
+            RAMD_CHECK(ramd_vec_copy_from(this->dev_, src.dev_));
+        else if(!this->on_accel_ && !src.on_accel_)
+            this->host_ = src.host_;
+        else if(this->on_accel_)
+        {
+            if(this->GetSize() != src.GetSize())
+                RAMD_CHECK(ramd_vec_allocate(this->dev_, src.GetSize()));
+            if(src.GetSize() > 0)
+                RAMD_CHECK(ramd_vec_copy_from_host(this->dev_, src.host_.data()));
+        }
+        else
+        {
+            this->host_.assign((size_t)src.GetSize(), ValueType(0));
+            if(src.GetSize() > 0)
+                RAMD_CHECK(ramd_vec_copy_to_host(src.dev_, this->host_.data()));
+        }
+    }
+    void CopyFrom(const LocalVector<ValueType>& src, int64_t src_offset, int64_t dst_offset,
+                  int64_t size)
+    {
+        if(this->on_accel_ && src.on_accel_)
+            RAMD_CHECK(ramd_vec_copy_from_offset(this->dev_, src.dev_, src_offset, dst_offset, size));
+        else if(!this->on_accel_ && !src.on_accel_)
+            std::copy(src.host_.begin() + src_offset, src.host_.begin() + src_offset + size,
+                      this->host_.begin() + dst_offset);
+        else
+            this->no_host_("CopyFrom(offset) across backends");
+    }
+    void CloneFrom(const LocalVector<ValueType>& src)
+    {
+        this->CloneBackend(src);
+        this->CopyFrom(src);
+    }
+    void CopyFromFloat(const LocalVector<float>& src)
+    {
+        this->need_accel_("CopyFromFloat");
+        RAMD_CHECK(ramd_vec_copy_from_float(this->dev_, src.handle()));
+    }
+    void CopyFromDouble(const LocalVector<double>& src)
+    {
+        this->need_accel_("CopyFromDouble");
+        RAMD_CHECK(ramd_vec_copy_from_double(this->dev_, src.handle()));
+    }
+    void CopyFromPermute(const LocalVector<ValueType>& src, const LocalVector<int>& permutation)
+    {
+        this->need_accel_("CopyFromPermute");
+        RAMD_CHECK(ramd_vec_copy_from_permute(this->dev_, src.dev_, permutation.handle()));
+    }
+    void CopyFromPermuteBackward(const LocalVector<ValueType>& src,
+                                 const LocalVector<int>&       permutation)
+    {
+        this->need_accel_("CopyFromPermuteBackward");
+        RAMD_CHECK(ramd_vec_copy_from_permute_backward(this->dev_, src.dev_, permutation.handle()));
+    }
+
+    // ---- BLAS-1 (accelerator only)
+    void AddScale(const LocalVector<ValueType>& x, ValueType alpha)
+    {
+        this->need_accel_("AddScale");
+        RAMD_CHECK(ramd_vec_add_scale(this->dev_, x.dev_, (double)alpha));
+    }
+    void ScaleAdd(ValueType alpha, const LocalVector<ValueType>& x)
+    {
+        this->need_accel_("ScaleAdd");
+        RAMD_CHECK(ramd_vec_scale_add(this->dev_, (double)alpha, x.dev_));
+    }
+    void ScaleAddScale(ValueType alpha, const LocalVector<ValueType>& x, ValueType beta)
+    {
+        this->need_accel_("ScaleAddScale");
+        RAMD_CHECK(ramd_vec_scale_add_scale(this->dev_, (double)alpha, x.dev_, (double)beta));
+    }
+    void ScaleAdd2(ValueType alpha, const LocalVector<ValueType>& x, ValueType beta,
+                   const LocalVector<ValueType>& y, ValueType gamma)
+    {
+        this->need_accel_("ScaleAdd2");
+        RAMD_CHECK(ramd_vec_scale_add2(this->dev_, (double)alpha, x.dev_, (double)beta, y.dev_,
+                                       (double)gamma));
+    }
+    void Scale(ValueType alpha)
+    {
+        this->need_accel_("Scale");
+        RAMD_CHECK(ramd_vec_scale(this->dev_, (double)alpha));
+    }
+    ValueType Dot(const LocalVector<ValueType>& x) const
+    {
+        this->need_accel_("Dot");
+        double r = 0;
+        RAMD_CHECK(ramd_vec_dot(this->dev_, x.dev_, &r));
+        return (ValueType)r;
+    }
+    ValueType DotNonConj(const LocalVector<ValueType>& x) const
+    {
+        return this->Dot(x);
+    }
+    ValueType Norm(void) const
+    {
+        this->need_accel_("Norm");
+        double r = 0;
+        RAMD_CHECK(ramd_vec_norm(this->dev_, &r));
+        return (ValueType)r;
+    }
+    ValueType Reduce(void) const
+    {
+        this->need_accel_("Reduce");
+        double r = 0;
+        RAMD_CHECK(ramd_vec_reduce(this->dev_, &r));
+        return (ValueType)r;
+    }
+    ValueType Asum(void) const
+    {
+        this->need_accel_("Asum");
+        double r = 0;
+        RAMD_CHECK(ramd_vec_asum(this->dev_, &r));
+        return (ValueType)r;
+    }
+    int64_t Amax(ValueType& value) const
+    {
+        this->need_accel_("Amax");
+        double  r = 0;
+        int64_t i = 0;
+        RAMD_CHECK(ramd_vec_amax(this->dev_, &r, &i));
+        value = (ValueType)r;
+        return i;
+    }
+    void PointWiseMult(const LocalVector<ValueType>& x)
+    {
+        this->need_accel_("PointWiseMult");
+        RAMD_CHECK(ramd_vec_pointwise_mult(this->dev_, x.dev_));
+    }
+    void PointWiseMult(const LocalVector<ValueType>& x, const LocalVector<ValueType>& y)
+    {
+        this->need_accel_("PointWiseMult");
+        RAMD_CHECK(ramd_vec_pointwise_mult2(this->dev_, x.dev_, y.dev_));
+    }
+    void GetIndexValues(const LocalVector<int>& index, LocalVector<ValueType>* values) const
+    {
+        this->need_accel_("GetIndexValues");
+        RAMD_CHECK(ramd_vec_get_index_values(this->dev_, index.handle(), values->dev_));
+    }
+
+    // ---- extensions used by this library's own layers
+    ramd_vec_t handle(void) const
+    {
+        return this->dev_;
+    }
+    // non-owning view of an existing accelerator vector (Python / C bindings)
+    void AdoptDeviceHandle(ramd_vec_t h)
+    {
+        std::vector<ValueType>().swap(this->host_);
+        if(this->dev_ && this->own_)
+            ramd_vec_destroy(this->dev_);
+        this->dev_      = h;
+        this->own_      = false;
+        this->on_accel_ = true;
+    }
+
+private:
+    void ensure_dev_(void)
+    {
+        if(!this->dev_)
+        {
+            RAMD_CHECK(ramd_vec_create(_dtype<ValueType>::value, &this->dev_));
+            this->own_ = true;
+        }
+    }
+    void need_accel_(const char* op) const
+    {
+        if(!this->on_accel_)
+            this->no_host_(op);
+    }
+    void no_host_(const char* op) const
+    {
+        LOG_INFO("LocalVector::" << op << "() on a host object: this library has no host compute "
+                                 << "backend - call MoveToAccelerator() first");
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+
+    std::string            name_;
+    std::vector<ValueType> host_;
+    ramd_vec_t             dev_      = NULL;
+    bool                   own_      = true;
+    bool                   on_accel_ = false;
+};
+
+// ---------------------------------------------------------------------------- LocalMatrix
+template <typename ValueType>
+class LocalMatrix
+{
+public:
+    LocalMatrix() {}
+    ~LocalMatrix()
+    {
+        if(this->dev_ && this->own_) // adopted (non-owned) handles are left untouched
+            ramd_mat_destroy(this->dev_);
+    }
+    LocalMatrix(const LocalMatrix&)            = delete;
+    LocalMatrix& operator=(const LocalMatrix&) = delete;
+
+    bool is_accel_(void) const
+    {
+        return this->on_accel_;
+    }
+    ramd_mat_t handle(void) const
+    {
+        return this->dev_;
+    }
+    void AdoptDeviceHandle(ramd_mat_t h)
+    {
+        this->Clear();
+        if(this->dev_ && this->own_)
+            ramd_mat_destroy(this->dev_);
+        this->dev_      = h;
+        this->own_      = false;
+        this->on_accel_ = true;
+    }
+
+    void Clear(void)
+    {
+        if(this->dev_ && this->own_)
+            ramd_mat_clear(this->dev_);
+        std::vector<PtrType>().swap(this->h_rp_);
+        std::vector<int>().swap(this->h_ci_);
+        std::vector<ValueType>().swap(this->h_val_);
+        this->h_nrow_ = this->h_ncol_ = 0;
+    }
+    void Info(void) const
+    {
+        static const char* fmt[] = {"DENSE", "CSR", "MCSR", "BCSR", "COO", "DIA", "ELL", "HYB"};
+        LOG_INFO("LocalMatrix name=" << this->name_ << "; rows=" << this->GetM() << "; cols="
+                                     << this->GetN() << "; nnz=" << this->GetNnz() << "; prec="
+                                     << 8 * sizeof(ValueType) << "bit; format=" << fmt[this->GetFormat()]
+                                     << "; "
+                                     << (this->on_accel_ ? "accelerator backend: MI355X-native HIP"
+                                                         : "host storage (no host compute backend)"));
+    }
+    int64_t GetM(void) const
+    {
+        if(!this->on_accel_)
+            return this->h_nrow_;
+        int nr = 0;
+        this->dev_info_(&nr, NULL, NULL, NULL);
+        return nr;
+    }
+    int64_t GetN(void) const
+    {
+        if(!this->on_accel_)
+            return this->h_ncol_;
+        int nc = 0;
+        this->dev_info_(NULL, &nc, NULL, NULL);
+        return nc;
+    }
+    int64_t GetNnz(void) const
+    {
+        if(!this->on_accel_)
+            return (int64_t)this->h_ci_.size();
+        int64_t nnz = 0;
+        this->dev_info_(NULL, NULL, &nnz, NULL);
+        return nnz;
+    }
+    int64_t GetLocalM(void) const
+    {
+        return this->GetM();
+    }
+    int64_t GetLocalN(void) const
+    {
+        return this->GetN();
+    }
+    int64_t GetLocalNnz(void) const
+    {
+        return this->GetNnz();
+    }
+    unsigned int GetFormat(void) const
+    {
+        if(!this->on_accel_)
+            return CSR;
+        int f = CSR;
+        this->dev_info_(NULL, NULL, NULL, &f);
+        return (unsigned int)f;
+    }
+
+    // ---- host-side construction (CSR only)
+    void AllocateCSR(const std::string& name, int64_t nnz, int64_t nrow, int64_t ncol)
+    {
+        this->Clear();
+        this->name_ = name;
+        this->h_rp_.assign((size_t)nrow + 1, 0);
+        this->h_ci_.assign((size_t)nnz, 0);
+        this->h_val_.assign((size_t)nnz, ValueType(0));
+        this->h_nrow_ = nrow;
+        this->h_ncol_ = ncol;
+        if(this->on_accel_)
+            this->upload_();
+    }
+    void SetDataPtrCSR(PtrType** row_offset, int** col, ValueType** val, std::string name,
+                       int64_t nnz, int64_t nrow, int64_t ncol)
+    {
+        assert(row_offset != NULL && *row_offset != NULL);
+        this->Clear();
+        this->name_ = name;
+        this->h_rp_.assign(*row_offset, *row_offset + nrow + 1);
+        if(nnz > 0)
+        {
+            this->h_ci_.assign(*col, *col + nnz);
+            this->h_val_.assign(*val, *val + nnz);
+        }
+        this->h_nrow_ = nrow;
+        this->h_ncol_ = ncol;
+        // the object takes ownership of the arrays and nulls the caller's pointers
+        // (src/base/local_matrix.cpp:714-780)
+        delete[] * row_offset;
+        delete[] * col;
+        delete[] * val;
+        *row_offset = NULL;
+        *col        = NULL;
+        *val        = NULL;
+        if(this->on_accel_)
+            this->upload_();
+    }
+    void LeaveDataPtrCSR(PtrType** row_offset, int** col, ValueType** val)
+    {
+        int64_t nr = this->GetM(), nnz = this->GetNnz();
+        allocate_host(nr + 1, row_offset);
+        allocate_host(nnz, col);
+        allocate_host(nnz, val);
+        this->CopyToCSR(*row_offset, *col, *val);
+        this->Clear();
+    }
+    void CopyFromCSR(const PtrType* row_offsets, const int* col, const ValueType* val)
+    {
+        int64_t nr = this->GetM(), nc = this->GetN(), nnz = this->GetNnz();
+        if(this->on_accel_)
+            RAMD_CHECK(ramd_mat_set_csr_from_host(this->dev_, (int)nr, (int)nc, nnz, row_offsets, col,
+                                                  val));
+        else
+        {
+            std::copy(row_offsets, row_offsets + nr + 1, this->h_rp_.begin());
+            std::copy(col, col + nnz, this->h_ci_.begin());
+            std::copy(val, val + nnz, this->h_val_.begin());
+        }
+    }
+    void CopyToCSR(PtrType* row_offsets, int* col, ValueType* val) const
+    {
+        if(this->on_accel_)
+            RAMD_CHECK(ramd_mat_copy_csr_to_host(this->dev_, row_offsets, col, val));
+        else
+        {
+            std::copy(this->h_rp_.begin(), this->h_rp_.end(), row_offsets);
+            std::copy(this->h_ci_.begin(), this->h_ci_.end(), col);
+            std::copy(this->h_val_.begin(), this->h_val_.end(), val);
+        }
+    }
+    // MatrixMarket reader with the reference's semantics: include/rocalution/io.hpp
+    bool ReadFileMTX(const std::string& filename);
+
+    void MoveToAccelerator(void)
+    {
+        if(this->on_accel_)
+            return;
+        this->ensure_dev_();
+        this->on_accel_ = true;
+        if(this->h_nrow_ > 0 || !this->h_rp_.empty())
+            this->upload_();
+    }
+    void MoveToHost(void)
+    {
+        if(!this->on_accel_)
+            return;
+        if(this->GetFormat() != CSR)
+        {
+            LOG_INFO("LocalMatrix::MoveToHost(): only CSR matrices can leave the accelerator");
+            FATAL_ERROR(__FILE__, __LINE__);
+        }
+        int64_t nr = this->GetM(), nc = this->GetN(), nnz = this->GetNnz();
+        this->h_rp_.assign((size_t)nr + 1, 0);
+        this->h_ci_.assign((size_t)nnz, 0);
+        this->h_val_.assign((size_t)nnz, ValueType(0));
+        if(nr > 0)
+            RAMD_CHECK(ramd_mat_copy_csr_to_host(this->dev_, this->h_rp_.data(), this->h_ci_.data(),
+                                                 this->h_val_.data()));
+        this->h_nrow_ = nr;
+        this->h_ncol_ = nc;
+        RAMD_CHECK(ramd_mat_clear(this->dev_));
+        this->on_accel_ = false;
+    }
+    template <class Obj>
+    void CloneBackend(const Obj& src)
+    {
+        if(src.is_accel_())
+            this->MoveToAccelerator();
+        else
+            this->MoveToHost();
+    }
+    void CloneFrom(const LocalMatrix<ValueType>& src)
+    {
+        this->Clear();
+        this->name_ = src.name_;
+        if(src.on_accel_)
+        {
+            if(this->dev_ && this->own_)
+                ramd_mat_destroy(this->dev_);
+            this->dev_ = NULL;
+            RAMD_CHECK(ramd_mat_clone(src.dev_, &this->dev_));
+            this->own_      = true;
+            this->on_accel_ = true;
+        }
+        else
+        {
+            if(this->on_accel_)
+                RAMD_CHECK(ramd_mat_clear(this->dev_));
+            this->on_accel_ = false;
+            this->h_rp_     = src.h_rp_;
+            this->h_ci_     = src.h_ci_;
+            this->h_val_    = src.h_val_;
+            this->h_nrow_   = src.h_nrow_;
+            this->h_ncol_   = src.h_ncol_;
+        }
+    }
+
+    // ---- format conversion: LocalMatrix::ConvertTo (src/base/local_matrix.cpp:2064-2151).
+    // A refused ELL conversion leaves the matrix in CSR with a warning, as in the reference.
+    void ConvertTo(unsigned int matrix_format, int blockdim = 1)
+    {
+        (void)blockdim;
+        this->need_accel_("ConvertTo");
+        int s = ramd_mat_convert(this->dev_, (int)matrix_format);
+        if(s == RAMD_ERR_REFUSED)
+        {
+            LOG_INFO("*** warning: LocalMatrix::ConvertTo() the conversion was refused ("
+                     << ramd_last_error() << "); the matrix stays in CSR format");
+            return;
+        }
+        if(s == RAMD_ERR_UNSUPPORTED)
+        {
+            LOG_INFO("LocalMatrix::ConvertTo(): format " << matrix_format
+                                                         << " is not provided by this backend");
+            FATAL_ERROR(__FILE__, __LINE__);
+        }
+        RAMD_CHECK(s);
+    }
+    void ConvertToCSR(void)
+    {
+        this->ConvertTo(CSR);
+    }
+    void ConvertToELL(void)
+    {
+        this->ConvertTo(ELL);
+    }
+    void ConvertToHYB(void)
+    {
+        this->ConvertTo(HYB);
+    }
+    void ConvertToCOO(void)
+    {
+        this->ConvertTo(COO);
+    }
+
+    // ---- numerical operations
+    void Apply(const LocalVector<ValueType>& in, LocalVector<ValueType>* out) const
+    {
+        this->need_accel_("Apply");
+        RAMD_CHECK(ramd_mat_apply(this->dev_, in.handle(), out->handle()));
+    }
+    void ApplyAdd(const LocalVector<ValueType>& in, ValueType scalar, LocalVector<ValueType>* out) const
+    {
+        this->need_accel_("ApplyAdd");
+        RAMD_CHECK(ramd_mat_apply_add(this->dev_, in.handle(), (double)scalar, out->handle()));
+    }
+    void ExtractDiagonal(LocalVector<ValueType>* vec_diag) const
+    {
+        this->need_accel_("ExtractDiagonal");
+        if(vec_diag->GetSize() == 0)
+            vec_diag->Allocate("Diagonal elements", std::min(this->GetM(), this->GetN()));
+        RAMD_CHECK(ramd_mat_extract_diag(this->dev_, vec_diag->handle()));
+    }
+    void ExtractInverseDiagonal(LocalVector<ValueType>* vec_inv_diag) const
+    {
+        this->need_accel_("ExtractInverseDiagonal");
+        RAMD_CHECK(ramd_mat_extract_inv_diag(this->dev_, vec_inv_diag->handle()));
+    }
+    void ExtractSubMatrix(int64_t row_offset, int64_t col_offset, int64_t row_size, int64_t col_size,
+                          LocalMatrix<ValueType>* mat) const
+    {
+        this->need_accel_("ExtractSubMatrix");
+        mat->MoveToAccelerator();
+        RAMD_CHECK(ramd_mat_extract_submatrix(this->dev_, (int)row_offset, (int)col_offset,
+                                              (int)row_size, (int)col_size, mat->dev_));
+    }
+    // src/base/local_matrix.cpp:2492: mat[i][j] = rows [row_offset[i],row_offset[i+1]) x cols [...]
+    void ExtractSubMatrices(int row_num_blocks, int col_num_blocks, const int* row_offset,
+                            const int* col_offset, LocalMatrix<ValueType>*** mat) const
+    {
+        for(int i = 0; i < row_num_blocks; ++i)
+            for(int j = 0; j < col_num_blocks; ++j)
+                this->ExtractSubMatrix(row_offset[i], col_offset[j], row_offset[i + 1] - row_offset[i],
+                                       col_offset[j + 1] - col_offset[j], mat[i][j]);
+    }
+    void Permute(const LocalVector<int>& permutation)
+    {
+        this->need_accel_("Permute");
+        RAMD_CHECK(ramd_mat_permute(this->dev_, permutation.handle()));
+    }
+    void MultiColoring(int& num_colors, int** size_colors, LocalVector<int>* permutation) const
+    {
+        this->need_accel_("MultiColoring");
+        assert(*size_colors == NULL);
+        std::vector<int> sizes((size_t)std::max<int64_t>(this->GetM(), 1));
+        permutation->MoveToAccelerator();
+        if(permutation->handle() == NULL)
+            permutation->Allocate("permutation", 0);
+        RAMD_CHECK(ramd_mat_multicoloring(this->dev_, &num_colors, sizes.data(), permutation->handle()));
+        allocate_host(num_colors, size_colors);
+        std::copy(sizes.begin(), sizes.begin() + num_colors, *size_colors);
+    }
+    void ILU0Factorize(void)
+    {
+        this->need_accel_("ILU0Factorize");
+        RAMD_CHECK(ramd_mat_ilu0_factorize(this->dev_));
+    }
+    void ILUpFactorize(int p, bool level = true)
+    {
+        (void)level;
+        if(p != 0)
+        {
+            LOG_INFO("LocalMatrix::ILUpFactorize(): only p = 0 is provided by this backend");
+            FATAL_ERROR(__FILE__, __LINE__);
+        }
+        this->ILU0Factorize();
+    }
+    void LUAnalyse(void)
+    {
+        this->need_accel_("LUAnalyse");
+        RAMD_CHECK(ramd_mat_lu_analyse(this->dev_));
+    }
+    void LUAnalyseClear(void)
+    {
+        if(this->on_accel_ && this->dev_)
+            RAMD_CHECK(ramd_mat_lu_analyse_clear(this->dev_));
+    }
+    void LUSolve(const LocalVector<ValueType>& in, LocalVector<ValueType>* out) const
+    {
+        this->need_accel_("LUSolve");
+        RAMD_CHECK(ramd_mat_lu_solve(this->dev_, in.handle(), out->handle()));
+    }
+    void LAnalyse(bool diag_unit = false)
+    {
+        this->need_accel_("LAnalyse");
+        RAMD_CHECK(ramd_mat_l_analyse(this->dev_, diag_unit ? 1 : 0));
+    }
+    void LAnalyseClear(void)
+    {
+        if(this->on_accel_ && this->dev_)
+            RAMD_CHECK(ramd_mat_l_analyse_clear(this->dev_));
+    }
+    void LSolve(const LocalVector<ValueType>& in, LocalVector<ValueType>* out) const
+    {
+        this->need_accel_("LSolve");
+        RAMD_CHECK(ramd_mat_l_solve(this->dev_, in.handle(), out->handle()));
+    }
+    void UAnalyse(bool diag_unit = false)
+    {
+        this->need_accel_("UAnalyse");
+        RAMD_CHECK(ramd_mat_u_analyse(this->dev_, diag_unit ? 1 : 0));
+    }
+    void UAnalyseClear(void)
+    {
+        if(this->on_accel_ && this->dev_)
+            RAMD_CHECK(ramd_mat_u_analyse_clear(this->dev_));
+    }
+    void USolve(const LocalVector<ValueType>& in, LocalVector<ValueType>* out) const
+    {
+        this->need_accel_("USolve");
+        RAMD_CHECK(ramd_mat_u_solve(this->dev_, in.handle(), out->handle()));
+    }
+
+    // extension: device-side synthetic operator (3-D 7-point Poisson N^3)
+    void GeneratePoisson7(int N)
+    {
+        this->MoveToAccelerator();
+        RAMD_CHECK(ramd_mat_gen_poisson7(this->dev_, N));
+    }
+    // extension: value-cast copy used by MixedPrecisionDC (mixed_precision.cpp:201-229)
+    template <typename OtherType>
+    void CastFrom(const LocalMatrix<OtherType>& src)
+    {
+        this->Clear();
+        if(this->dev_ && this->own_)
+            ramd_mat_destroy(this->dev_);
+        this->dev_ = NULL;
+        RAMD_CHECK(ramd_mat_cast(src.handle(), &this->dev_));
+        this->own_      = true;
+        this->on_accel_ = true;
+    }
+
+private:
+    template <typename>
+    friend class LocalMatrix;
+
+    void ensure_dev_(void)
+    {
+        if(!this->dev_)
+        {
+            RAMD_CHECK(ramd_mat_create(_dtype<ValueType>::value, &this->dev_));
+            this->own_ = true;
+        }
+    }
+    void upload_(void)
+    {
+        this->ensure_dev_();
+        RAMD_CHECK(ramd_mat_set_csr_from_host(this->dev_, (int)this->h_nrow_, (int)this->h_ncol_,
+                                              (int64_t)this->h_ci_.size(), this->h_rp_.data(),
+                                              this->h_ci_.data(), this->h_val_.data()));
+        std::vector<PtrType>().swap(this->h_rp_);
+        std::vector<int>().swap(this->h_ci_);
+        std::vector<ValueType>().swap(this->h_val_);
+        this->h_nrow_ = this->h_ncol_ = 0;
+    }
+    void dev_info_(int* nr, int* nc, int64_t* nnz, int* fmt) const
+    {
+        if(!this->dev_)
+        {
+            if(nr)
+                *nr = 0;
+            if(nc)
+                *nc = 0;
+            if(nnz)
+                *nnz = 0;
+            if(fmt)
+                *fmt = CSR;
+            return;
+        }
+        RAMD_CHECK(ramd_mat_info(this->dev_, nr, nc, nnz, fmt, NULL));
+    }
+    void need_accel_(const char* op) const
+    {
+        if(!this->on_accel_)
+        {
+            LOG_INFO("LocalMatrix::" << op << "() on a host object: this library has no host compute "
+                                     << "backend - call MoveToAccelerator() first");
+            FATAL_ERROR(__FILE__, __LINE__);
+        }
+    }
+
+    std::string            name_;
+    std::vector<PtrType>   h_rp_;
+    std::vector<int>       h_ci_;
+    std::vector<ValueType> h_val_;
+    int64_t                h_nrow_ = 0, h_ncol_ = 0;
+    ramd_mat_t             dev_      = NULL;
+    bool                   own_      = true;
+    bool                   on_accel_ = false;
+};
+
+} // namespace rocalution

@@ -1,0 +1,544 @@
+// rocalution/global.hpp -- ParallelManager / GlobalVector / GlobalMatrix / BlockJacobi (subset):
+// row-block domain decomposition, one process per GPU.
+//   src/base/parallel_manager.hpp:60-148, parallel_manager.cpp:726-787   ParallelManager
+//   src/base/global_vector.cpp:139-680                                   GlobalVector
+//   src/base/global_matrix.cpp:913-1009                                  GlobalMatrix::ConvertTo/Apply
+//   src/solvers/preconditioners/preconditioner_blockjacobi.cpp:80-141    BlockJacobi
+// Same object model as the reference (interior matrix + ghost matrix indexed into a compact receive
+// buffer + boundary index list), but the halo never touches the host: pack kernel -> RCCL
+// send/recv on the ghost stream over xGMI, overlapped with the interior SpMV; scalars are summed by
+// one RCCL all-reduce on the device (ramd_comm_* in rocalution_amd.h).  The communicator handle
+// passed to SetMPICommunicator() is a ramd_comm_t (the reference passes an MPI_Comm*).
+#pragma once
+
+#include "solvers.hpp"
+
+namespace rocalution
+{
+
+class ParallelManager
+{
+public:
+    ParallelManager()
+        : comm_(NULL)
+        , rank_(0)
+        , num_procs_(1)
+        , global_nrow_(0)
+        , global_ncol_(0)
+        , local_nrow_(0)
+        , local_ncol_(0)
+    {
+    }
+    void SetMPICommunicator(const void* comm)
+    {
+        this->comm_ = (ramd_comm_t) const_cast<void*>(comm);
+        ramd_comm_rank(this->comm_, &this->rank_);
+        ramd_comm_size(this->comm_, &this->num_procs_);
+    }
+    void Clear(void)
+    {
+        this->boundary_index_.clear();
+        this->recvs_.clear();
+        this->sends_.clear();
+        this->recv_offset_.clear();
+        this->send_offset_.clear();
+    }
+    ramd_comm_t GetComm(void) const
+    {
+        return this->comm_;
+    }
+    int GetRank(void) const
+    {
+        return this->rank_;
+    }
+    int GetNumProcs(void) const
+    {
+        return this->num_procs_;
+    }
+    int64_t GetGlobalNrow(void) const
+    {
+        return this->global_nrow_;
+    }
+    int64_t GetGlobalNcol(void) const
+    {
+        return this->global_ncol_;
+    }
+    int64_t GetLocalNrow(void) const
+    {
+        return this->local_nrow_;
+    }
+    int64_t GetLocalNcol(void) const
+    {
+        return this->local_ncol_;
+    }
+    int GetNumReceivers(void) const
+    {
+        return this->recv_offset_.empty() ? 0 : (int)this->recv_offset_.back();
+    }
+    int GetNumSenders(void) const
+    {
+        return this->send_offset_.empty() ? 0 : (int)this->send_offset_.back();
+    }
+    void SetGlobalNrow(int64_t nrow)
+    {
+        this->global_nrow_ = nrow;
+    }
+    void SetGlobalNcol(int64_t ncol)
+    {
+        this->global_ncol_ = ncol;
+    }
+    void SetLocalNrow(int64_t nrow)
+    {
+        this->local_nrow_ = nrow;
+    }
+    void SetLocalNcol(int64_t ncol)
+    {
+        this->local_ncol_ = ncol;
+    }
+    // local row indices whose values are sent, concatenated per receiving neighbour
+    void SetBoundaryIndex(int size, const int* index)
+    {
+        this->boundary_index_.assign(index, index + size);
+    }
+    const int* GetBoundaryIndex(void) const
+    {
+        return this->boundary_index_.data();
+    }
+    int GetBoundarySize(void) const
+    {
+        return (int)this->boundary_index_.size();
+    }
+    void SetReceivers(int nrecv, const int* recvs, const int* recv_offset)
+    {
+        this->recvs_.assign(recvs, recvs + nrecv);
+        this->recv_offset_.assign(recv_offset, recv_offset + nrecv + 1);
+    }
+    void SetSenders(int nsend, const int* sends, const int* send_offset)
+    {
+        this->sends_.assign(sends, sends + nsend);
+        this->send_offset_.assign(send_offset, send_offset + nsend + 1);
+    }
+    bool Status(void) const
+    {
+        // every neighbour is both sender and receiver in this implementation (symmetric patterns)
+        return this->global_nrow_ > 0 && this->local_nrow_ >= 0 && this->recvs_ == this->sends_
+               && (int)this->boundary_index_.size() == this->GetNumSenders();
+    }
+    const std::vector<int>& peers(void) const
+    {
+        return this->sends_;
+    }
+    const std::vector<int64_t>& send_offset(void) const
+    {
+        return this->send_offset_;
+    }
+    const std::vector<int64_t>& recv_offset(void) const
+    {
+        return this->recv_offset_;
+    }
+
+private:
+    ramd_comm_t          comm_;
+    int                  rank_, num_procs_;
+    int64_t              global_nrow_, global_ncol_, local_nrow_, local_ncol_;
+    std::vector<int>     boundary_index_;
+    std::vector<int>     recvs_, sends_;
+    std::vector<int64_t> recv_offset_, send_offset_;
+};
+
+template <typename ValueType>
+class GlobalMatrix;
+
+template <typename ValueType>
+class GlobalVector
+{
+public:
+    GlobalVector()
+        : pm_(NULL)
+    {
+    }
+    explicit GlobalVector(const ParallelManager& pm)
+        : pm_(&pm)
+    {
+    }
+    void SetParallelManager(const ParallelManager& pm)
+    {
+        this->pm_ = &pm;
+    }
+    const ParallelManager* pm(void) const
+    {
+        return this->pm_;
+    }
+    bool is_accel_(void) const
+    {
+        return this->vector_interior_.is_accel_();
+    }
+    void MoveToAccelerator(void)
+    {
+        this->vector_interior_.MoveToAccelerator();
+    }
+    void MoveToHost(void)
+    {
+        this->vector_interior_.MoveToHost();
+    }
+    template <class Obj>
+    void CloneBackend(const Obj& src) // also adopts the parallel manager (base_rocalution.cpp:109)
+    {
+        this->pm_ = src.pm();
+        if(src.is_accel_())
+            this->MoveToAccelerator();
+        else
+            this->MoveToHost();
+    }
+    // global_vector.cpp:139-166: size is GLOBAL, the interior gets the local share
+    void Allocate(std::string name, int64_t size)
+    {
+        int64_t local = size;
+        if(this->pm_ != NULL)
+        {
+            assert(this->pm_->GetGlobalNrow() == size || this->pm_->GetGlobalNcol() == size);
+            local = (this->pm_->GetGlobalNrow() == size) ? this->pm_->GetLocalNrow()
+                                                         : this->pm_->GetLocalNcol();
+        }
+        this->vector_interior_.Allocate("Interior of " + name, local);
+    }
+    void Clear(void)
+    {
+        this->vector_interior_.Clear();
+    }
+    int64_t GetSize(void) const
+    {
+        return this->pm_ ? this->pm_->GetGlobalNrow() : this->vector_interior_.GetSize();
+    }
+    int64_t GetLocalSize(void) const
+    {
+        return this->vector_interior_.GetSize();
+    }
+    LocalVector<ValueType>& GetInterior(void)
+    {
+        return this->vector_interior_;
+    }
+    const LocalVector<ValueType>& GetInterior(void) const
+    {
+        return this->vector_interior_;
+    }
+    void Info(void) const
+    {
+        LOG_INFO("GlobalVector size=" << this->GetSize() << "; local=" << this->GetLocalSize());
+    }
+    void Zeros(void)
+    {
+        this->vector_interior_.Zeros();
+    }
+    void Ones(void)
+    {
+        this->vector_interior_.Ones();
+    }
+    void SetValues(ValueType val)
+    {
+        this->vector_interior_.SetValues(val);
+    }
+    void CopyFrom(const GlobalVector<ValueType>& src)
+    {
+        this->vector_interior_.CopyFrom(src.vector_interior_);
+    }
+    void AddScale(const GlobalVector<ValueType>& x, ValueType alpha)
+    {
+        this->vector_interior_.AddScale(x.vector_interior_, alpha);
+    }
+    void ScaleAdd(ValueType alpha, const GlobalVector<ValueType>& x)
+    {
+        this->vector_interior_.ScaleAdd(alpha, x.vector_interior_);
+    }
+    void ScaleAdd2(ValueType alpha, const GlobalVector<ValueType>& x, ValueType beta,
+                   const GlobalVector<ValueType>& y, ValueType gamma)
+    {
+        this->vector_interior_.ScaleAdd2(alpha, x.vector_interior_, beta, y.vector_interior_, gamma);
+    }
+    void ScaleAddScale(ValueType alpha, const GlobalVector<ValueType>& x, ValueType beta)
+    {
+        this->vector_interior_.ScaleAddScale(alpha, x.vector_interior_, beta);
+    }
+    void Scale(ValueType alpha)
+    {
+        this->vector_interior_.Scale(alpha);
+    }
+    void PointWiseMult(const GlobalVector<ValueType>& x)
+    {
+        this->vector_interior_.PointWiseMult(x.vector_interior_);
+    }
+    void PointWiseMult(const GlobalVector<ValueType>& x, const GlobalVector<ValueType>& y)
+    {
+        this->vector_interior_.PointWiseMult(x.vector_interior_, y.vector_interior_);
+    }
+    // global_vector.cpp:547-588: local reduction, then sum over ranks; Norm = sqrt(allreduce(dot))
+    ValueType Dot(const GlobalVector<ValueType>& x) const
+    {
+        return (ValueType)this->reduce_(x.vector_interior_.handle(), false);
+    }
+    ValueType DotNonConj(const GlobalVector<ValueType>& x) const
+    {
+        return this->Dot(x);
+    }
+    ValueType Norm(void) const
+    {
+        return (ValueType)std::sqrt(this->reduce_(this->vector_interior_.handle(), false));
+    }
+    ValueType Asum(void) const
+    {
+        double     local = (double)this->vector_interior_.Asum();
+        return (ValueType)this->sum_ranks_(local);
+    }
+    int64_t Amax(ValueType& value) const
+    {
+        LOG_INFO("GlobalVector::Amax() is not provided by this backend");
+        FATAL_ERROR(__FILE__, __LINE__);
+        value = 0;
+        return -1;
+    }
+
+private:
+    double reduce_(ramd_vec_t other, bool) const
+    {
+        const int        slot  = RAMD_NSCALARS - 2;
+        const ramd_vec_t vs[1] = {this->vector_interior_.handle()};
+        RAMD_CHECK(ramd_fused_multi_dot(vs, 1, other, slot));
+        if(this->pm_ != NULL && this->pm_->GetNumProcs() > 1)
+            RAMD_CHECK(ramd_comm_allreduce_scalars(this->pm_->GetComm(), slot, 1));
+        double r = 0.0;
+        RAMD_CHECK(ramd_scalars_fetch(&r, slot, 1));
+        return r;
+    }
+    double sum_ranks_(double local) const
+    {
+        if(this->pm_ == NULL || this->pm_->GetNumProcs() == 1)
+            return local;
+        const int slot = RAMD_NSCALARS - 2;
+        RAMD_CHECK(ramd_scalars_set(slot, local));
+        RAMD_CHECK(ramd_comm_allreduce_scalars(this->pm_->GetComm(), slot, 1));
+        double r = 0.0;
+        RAMD_CHECK(ramd_scalars_fetch(&r, slot, 1));
+        return r;
+    }
+    const ParallelManager* pm_;
+    LocalVector<ValueType> vector_interior_;
+    friend class GlobalMatrix<ValueType>;
+};
+
+template <typename ValueType>
+class GlobalMatrix
+{
+public:
+    GlobalMatrix()
+        : pm_(NULL)
+    {
+    }
+    explicit GlobalMatrix(const ParallelManager& pm)
+        : pm_(&pm)
+    {
+    }
+    void SetParallelManager(const ParallelManager& pm)
+    {
+        this->pm_ = &pm;
+    }
+    const ParallelManager* pm(void) const
+    {
+        return this->pm_;
+    }
+    bool is_accel_(void) const
+    {
+        return this->matrix_interior_.is_accel_();
+    }
+    int64_t GetM(void) const
+    {
+        return this->pm_ ? this->pm_->GetGlobalNrow() : this->matrix_interior_.GetM();
+    }
+    int64_t GetN(void) const
+    {
+        return this->pm_ ? this->pm_->GetGlobalNcol() : this->matrix_interior_.GetN();
+    }
+    int64_t GetLocalM(void) const
+    {
+        return this->matrix_interior_.GetM();
+    }
+    int64_t GetLocalN(void) const
+    {
+        return this->matrix_interior_.GetN();
+    }
+    int64_t GetLocalNnz(void) const
+    {
+        return this->matrix_interior_.GetNnz();
+    }
+    int64_t GetGhostNnz(void) const
+    {
+        return this->matrix_ghost_.GetNnz();
+    }
+    LocalMatrix<ValueType>& GetInterior(void)
+    {
+        return this->matrix_interior_;
+    }
+    const LocalMatrix<ValueType>& GetInterior(void) const
+    {
+        return this->matrix_interior_;
+    }
+    LocalMatrix<ValueType>& GetGhost(void)
+    {
+        return this->matrix_ghost_;
+    }
+    const LocalMatrix<ValueType>& GetGhost(void) const
+    {
+        return this->matrix_ghost_;
+    }
+    void Info(void) const
+    {
+        LOG_INFO("GlobalMatrix rows=" << this->GetM() << "; cols=" << this->GetN()
+                                      << "; local nnz=" << this->GetLocalNnz()
+                                      << "; ghost nnz=" << this->GetGhostNnz());
+    }
+    void SetLocalDataPtrCSR(PtrType** row_offset, int** col, ValueType** val, std::string name,
+                            int64_t nnz)
+    {
+        assert(this->pm_ != NULL);
+        this->matrix_interior_.SetDataPtrCSR(row_offset, col, val, "Interior of " + name, nnz,
+                                             this->pm_->GetLocalNrow(), this->pm_->GetLocalNcol());
+    }
+    void SetGhostDataPtrCSR(PtrType** row_offset, int** col, ValueType** val, std::string name,
+                            int64_t nnz)
+    {
+        assert(this->pm_ != NULL);
+        this->matrix_ghost_.SetDataPtrCSR(row_offset, col, val, "Ghost of " + name, nnz,
+                                          this->pm_->GetLocalNrow(), this->pm_->GetNumReceivers());
+    }
+    void MoveToAccelerator(void)
+    {
+        this->matrix_interior_.MoveToAccelerator();
+        this->matrix_ghost_.MoveToAccelerator();
+        this->InitCommPattern_();
+    }
+    // global_matrix.cpp:913-921: interior in the requested format, ghost part always COO
+    void ConvertTo(unsigned int matrix_format, int blockdim = 1)
+    {
+        this->matrix_interior_.ConvertTo(matrix_format, blockdim);
+        if(this->matrix_ghost_.GetNnz() > 0)
+            this->matrix_ghost_.ConvertTo(COO);
+    }
+    void ConvertToCSR(void)
+    {
+        this->ConvertTo(CSR);
+    }
+    void ConvertToELL(void)
+    {
+        this->ConvertTo(ELL);
+    }
+    void ConvertToHYB(void)
+    {
+        this->ConvertTo(HYB);
+    }
+    void ExtractInverseDiagonal(GlobalVector<ValueType>* vec_inv_diag) const
+    {
+        this->matrix_interior_.ExtractInverseDiagonal(&vec_inv_diag->vector_interior_);
+    }
+    // extension: per-rank slab of the synthetic 3-D Poisson operator, built on the device
+    void GeneratePoisson7Slab(int N, int64_t row_begin, int64_t row_end)
+    {
+        this->matrix_interior_.MoveToAccelerator();
+        this->matrix_ghost_.MoveToAccelerator();
+        RAMD_CHECK(ramd_mat_gen_poisson7_slab(this->matrix_interior_.handle(), this->matrix_ghost_.handle(),
+                                              N, row_begin, row_end));
+        this->InitCommPattern_();
+    }
+
+    // global_matrix.cpp:924-1009, device-resident: pack | halo over xGMI || interior SpMV | ghost +=
+    void Apply(const GlobalVector<ValueType>& in, GlobalVector<ValueType>* out) const
+    {
+        const bool comm = this->pm_ != NULL && !this->pm_->peers().empty();
+        if(comm)
+        {
+            in.vector_interior_.GetIndexValues(this->halo_, &this->send_buffer_);
+            RAMD_CHECK(ramd_comm_halo_begin(this->pm_->GetComm(), this->send_buffer_.handle(),
+                                            this->recv_buffer_.handle(), (int)this->pm_->peers().size(),
+                                            this->pm_->peers().data(), this->pm_->send_offset().data(),
+                                            this->pm_->recv_offset().data()));
+        }
+        this->matrix_interior_.Apply(in.vector_interior_, &out->vector_interior_);
+        if(comm)
+        {
+            RAMD_CHECK(ramd_comm_halo_end(this->pm_->GetComm()));
+            this->matrix_ghost_.ApplyAdd(this->recv_buffer_, static_cast<ValueType>(1),
+                                         &out->vector_interior_);
+        }
+    }
+
+private:
+    // global_matrix.cpp:4476-4513: halo index vector + device send/recv buffers
+    void InitCommPattern_(void)
+    {
+        if(this->pm_ == NULL || this->pm_->peers().empty())
+            return;
+        const int nb = this->pm_->GetBoundarySize();
+        this->halo_.MoveToAccelerator();
+        this->halo_.Allocate("halo", nb);
+        if(nb > 0)
+            this->halo_.CopyFromHostData(this->pm_->GetBoundaryIndex());
+        this->send_buffer_.MoveToAccelerator();
+        this->send_buffer_.Allocate("send buffer", this->pm_->GetNumSenders());
+        this->recv_buffer_.MoveToAccelerator();
+        this->recv_buffer_.Allocate("recv buffer", this->pm_->GetNumReceivers());
+    }
+    const ParallelManager*         pm_;
+    LocalMatrix<ValueType>         matrix_interior_;
+    LocalMatrix<ValueType>         matrix_ghost_;
+    LocalVector<int>               halo_;
+    mutable LocalVector<ValueType> send_buffer_;
+    mutable LocalVector<ValueType> recv_buffer_;
+};
+
+// preconditioner_blockjacobi.cpp:80-141: the local preconditioner acts on the interior block only
+template <class OperatorType, class VectorType, typename ValueType>
+class BlockJacobi : public Preconditioner<OperatorType, VectorType, ValueType>
+{
+public:
+    BlockJacobi()
+        : local_precond_(NULL)
+    {
+    }
+    virtual ~BlockJacobi()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("BlockJacobi preconditioner with local preconditioner:");
+        if(this->local_precond_)
+            this->local_precond_->Print();
+    }
+    void Set(Solver<LocalMatrix<ValueType>, LocalVector<ValueType>, ValueType>& precond)
+    {
+        this->local_precond_ = &precond;
+    }
+    virtual void Build(void)
+    {
+        if(this->build_)
+            this->Clear();
+        assert(this->local_precond_ != NULL && this->op_ != NULL);
+        this->build_ = true;
+        this->local_precond_->SetOperator(this->op_->GetInterior());
+        this->local_precond_->Build();
+    }
+    virtual void Clear(void)
+    {
+        if(this->local_precond_ != NULL)
+            this->local_precond_->Clear();
+        this->local_precond_ = NULL;
+        this->build_         = false;
+    }
+    virtual void Solve(const VectorType& rhs, VectorType* x)
+    {
+        this->local_precond_->Solve(rhs.GetInterior(), &x->GetInterior());
+    }
+
+private:
+    Solver<LocalMatrix<ValueType>, LocalVector<ValueType>, ValueType>* local_precond_;
+};
+
+} // namespace rocalution

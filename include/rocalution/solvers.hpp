@@ -1,0 +1,1527 @@
+// rocalution/solvers.hpp -- Solver / IterativeLinearSolver / IterationControl / Preconditioners /
+// CG / GMRES / BiCGStab / MixedPrecisionDC with the reference's API surface and control flow:
+//   src/solvers/solver.hpp:179-444, solver.cpp:443-512       Solver, IterativeLinearSolver
+//   src/solvers/iter_ctrl.cpp:38-345                          IterationControl
+//   src/solvers/preconditioners/preconditioner.cpp:66-166     Preconditioner, Jacobi
+//   src/solvers/preconditioners/preconditioner.cpp:449-511    ILU
+//   src/solvers/preconditioners/preconditioner_multicolored{,_gs}.cpp   MultiColored, MultiColoredSGS
+//   src/solvers/krylov/cg.cpp:99-446, gmres.cpp:109-607, bicgstab.cpp:109-489
+//   src/solvers/mixed_precision.cpp:159-437                   MixedPrecisionDC
+// The numerical sequence of every solver is the reference's (same operations in the same order, same
+// stopping rules).  On top of it, CG and GMRES have FUSED device paths (SetFused(true), default on)
+// that run the identical arithmetic per element through the single-launch kernels of
+// rocalution_amd.h ("fused hot-path ops"): 3 launches and ONE host read-back per CG iteration instead
+// of 8 launches and 3 blocking reads, with the read-back hidden behind the next SpMV.
+#pragma once
+
+#include <cmath>
+#include <limits>
+
+#include "base.hpp"
+
+namespace rocalution
+{
+
+// ============================================================================ IterationControl
+class IterationControl
+{
+public:
+    IterationControl()
+    {
+        this->Clear();
+        this->rec_            = false;
+        this->verb_           = 1;
+        this->absolute_tol_   = 1e-15;
+        this->relative_tol_   = 1e-6;
+        this->divergence_tol_ = 1e+8;
+        this->minimum_iter_   = 0;
+        this->maximum_iter_   = 1000000;
+        this->initial_residual_ = 0.0;
+    }
+    void Clear(void)
+    {
+        this->residual_history_.clear();
+        this->iteration_     = 0;
+        this->init_res_      = false;
+        this->reached_       = 0;
+        this->current_res_   = 0.0;
+        this->current_index_ = -1;
+    }
+    void Init(double abs, double rel, double div, int max)
+    {
+        this->InitTolerance(abs, rel, div);
+        this->InitMaximumIterations(max);
+    }
+    void Init(double abs, double rel, double div, int min, int max)
+    {
+        this->InitTolerance(abs, rel, div);
+        this->InitMinimumIterations(min);
+        this->InitMaximumIterations(max);
+    }
+    void InitTolerance(double abs, double rel, double div)
+    {
+        this->absolute_tol_   = abs;
+        this->relative_tol_   = rel;
+        this->divergence_tol_ = div;
+    }
+    void InitMinimumIterations(int min)
+    {
+        assert(min >= 0 && min <= this->maximum_iter_);
+        this->minimum_iter_ = min;
+    }
+    void InitMaximumIterations(int max)
+    {
+        assert(max >= 0 && max >= this->minimum_iter_);
+        this->maximum_iter_ = max;
+    }
+    int GetMinimumIterations(void) const
+    {
+        return this->minimum_iter_;
+    }
+    int GetMaximumIterations(void) const
+    {
+        return this->maximum_iter_;
+    }
+    int GetIterationCount(void) const
+    {
+        return this->iteration_;
+    }
+    double GetCurrentResidual(void) const
+    {
+        return this->current_res_;
+    }
+    int64_t GetAmaxResidualIndex(void) const
+    {
+        return this->current_index_;
+    }
+    int GetSolverStatus(void) const
+    {
+        return this->reached_;
+    }
+    const std::vector<double>& GetResidualHistory(void) const
+    {
+        return this->residual_history_;
+    }
+    void RecordHistory(void)
+    {
+        this->rec_ = true;
+    }
+    void Verbose(int verb)
+    {
+        this->verb_ = verb;
+    }
+    // iter_ctrl.cpp:89-121
+    bool InitResidual(double res)
+    {
+        this->init_res_         = true;
+        this->initial_residual_ = res;
+        this->current_res_      = res;
+        this->reached_          = 0;
+        this->iteration_        = 0;
+        if(this->verb_ > 0)
+            LOG_INFO("IterationControl initial residual = " << res);
+        if(this->rec_)
+            this->residual_history_.push_back(res);
+        if(this->bad_(res))
+        {
+            LOG_INFO("Residual = " << res << " !!!");
+            return false;
+        }
+        if(std::abs(res) <= this->absolute_tol_)
+        {
+            this->reached_ = 1;
+            return false;
+        }
+        return true;
+    }
+    // iter_ctrl.cpp:195-248
+    bool CheckResidual(double res)
+    {
+        assert(this->init_res_ == true);
+        this->iteration_++;
+        this->current_res_ = res;
+        if(this->verb_ > 1)
+            LOG_INFO("IterationControl iter=" << this->iteration_ << "; residual=" << res);
+        if(this->rec_)
+            this->residual_history_.push_back(res);
+        if(this->bad_(res))
+        {
+            LOG_INFO("Residual = " << res << " !!!");
+            return true;
+        }
+        if(this->iteration_ >= this->minimum_iter_)
+        {
+            if(std::abs(res) <= this->absolute_tol_)
+            {
+                this->reached_ = 1;
+                return true;
+            }
+            if(res / this->initial_residual_ <= this->relative_tol_)
+            {
+                this->reached_ = 2;
+                return true;
+            }
+            if(this->iteration_ >= this->maximum_iter_)
+            {
+                this->reached_ = 4;
+                return true;
+            }
+        }
+        if(res / this->initial_residual_ >= this->divergence_tol_)
+        {
+            this->reached_ = 3;
+            return true;
+        }
+        return false;
+    }
+    bool CheckResidual(double res, int64_t index)
+    {
+        this->current_index_ = index;
+        return this->CheckResidual(res);
+    }
+    // iter_ctrl.cpp:256-289
+    bool CheckResidualNoCount(double res)
+    {
+        assert(this->init_res_ == true);
+        if(this->bad_(res))
+        {
+            LOG_INFO("Residual = " << res << " !!!");
+            return true;
+        }
+        if(std::abs(res) <= this->absolute_tol_)
+        {
+            this->reached_ = 1;
+            return true;
+        }
+        if(res / this->initial_residual_ <= this->relative_tol_)
+        {
+            this->reached_ = 2;
+            return true;
+        }
+        if(res / this->initial_residual_ >= this->divergence_tol_)
+        {
+            this->reached_ = 3;
+            return true;
+        }
+        if(this->iteration_ >= this->maximum_iter_)
+        {
+            this->reached_ = 4;
+            return true;
+        }
+        return false;
+    }
+    // iter_ctrl.cpp:317-345: the first `iteration_` entries, scientific notation
+    void WriteHistoryToFile(const std::string& filename) const
+    {
+        std::ofstream file(filename.c_str());
+        if(!file.is_open())
+        {
+            LOG_INFO("Can not open file [write]:" << filename);
+            FATAL_ERROR(__FILE__, __LINE__);
+        }
+        file.setf(std::ios::scientific);
+        for(int n = 0; n < this->iteration_ && n < (int)this->residual_history_.size(); n++)
+            file << this->residual_history_[n] << std::endl;
+    }
+    void PrintInit(void) const
+    {
+        LOG_INFO("IterationControl criteria: abs tol=" << this->absolute_tol_ << "; rel tol="
+                                                       << this->relative_tol_ << "; div tol="
+                                                       << this->divergence_tol_ << "; max iter="
+                                                       << this->maximum_iter_);
+    }
+    void PrintStatus(void) const
+    {
+        static const char* why[] = {"NO CRITERIA", "ABSOLUTE criteria", "RELATIVE criteria",
+                                    "DIVERGENCE criteria", "MAX ITER criteria"};
+        LOG_INFO("IterationControl " << why[this->reached_] << " has been reached: res norm="
+                                     << this->current_res_ << "; rel val="
+                                     << this->current_res_ / this->initial_residual_
+                                     << "; iter=" << this->iteration_);
+    }
+
+private:
+    static bool bad_(double res)
+    {
+        return (std::abs(res) == std::numeric_limits<double>::infinity()) || (res != res);
+    }
+    std::vector<double> residual_history_;
+    int                 iteration_;
+    bool                init_res_, rec_;
+    int                 verb_, reached_;
+    double              initial_residual_, current_res_;
+    int64_t             current_index_;
+    double              absolute_tol_, relative_tol_, divergence_tol_;
+    int                 minimum_iter_, maximum_iter_;
+};
+
+// ============================================================================ Solver
+template <class OperatorType, class VectorType, typename ValueType>
+class Solver
+{
+public:
+    Solver()
+        : op_(NULL)
+        , precond_(NULL)
+        , build_(false)
+        , verb_(1)
+        , is_precond_(false)
+    {
+    }
+    virtual ~Solver() {}
+
+    void SetOperator(const OperatorType& op)
+    {
+        assert(this->build_ == false);
+        this->op_ = &op;
+    }
+    virtual void ResetOperator(const OperatorType& op)
+    {
+        this->op_ = &op;
+    }
+    virtual void Print(void) const = 0;
+    virtual void Solve(const VectorType& rhs, VectorType* x) = 0;
+    virtual void SolveZeroSol(const VectorType& rhs, VectorType* x)
+    {
+        x->Zeros();
+        this->Solve(rhs, x);
+    }
+    virtual void Build(void)
+    {
+        if(this->build_)
+            this->Clear();
+        this->build_ = true;
+    }
+    virtual void Clear(void)
+    {
+        this->build_ = false;
+    }
+    virtual void MoveToHost(void) {}
+    virtual void MoveToAccelerator(void) {}
+    virtual void Verbose(int verb = 1)
+    {
+        this->verb_ = verb;
+    }
+    void FlagPrecond(void)
+    {
+        this->is_precond_ = true;
+    }
+
+protected:
+    const OperatorType*                          op_;
+    Solver<OperatorType, VectorType, ValueType>* precond_;
+    bool                                         build_;
+    int                                          verb_;
+    bool                                         is_precond_;
+};
+
+// ============================================================================ Preconditioner
+template <class OperatorType, class VectorType, typename ValueType>
+class Preconditioner : public Solver<OperatorType, VectorType, ValueType>
+{
+public:
+    // preconditioner.cpp:66-72: no zero fill, plain Solve
+    virtual void SolveZeroSol(const VectorType& rhs, VectorType* x)
+    {
+        this->Solve(rhs, x);
+    }
+};
+
+// ---- Jacobi: preconditioner.cpp:95-166
+template <class OperatorType, class VectorType, typename ValueType>
+class Jacobi : public Preconditioner<OperatorType, VectorType, ValueType>
+{
+public:
+    virtual ~Jacobi()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("Jacobi preconditioner");
+    }
+    virtual void Build(void)
+    {
+        if(this->build_)
+            this->Clear();
+        this->build_ = true;
+        assert(this->op_ != NULL);
+        this->inv_diag_entries_.CloneBackend(*this->op_);
+        this->op_->ExtractInverseDiagonal(&this->inv_diag_entries_);
+    }
+    virtual void Clear(void)
+    {
+        this->inv_diag_entries_.Clear();
+        this->build_ = false;
+    }
+    virtual void Solve(const VectorType& rhs, VectorType* x)
+    {
+        assert(this->build_ == true && x != NULL);
+        if(this->inv_diag_entries_.GetSize() == 0) // empty inverse diagonal == identity
+        {
+            if(x != &rhs)
+                x->CopyFrom(rhs);
+            return;
+        }
+        if(x != &rhs)
+            x->PointWiseMult(this->inv_diag_entries_, rhs);
+        else
+            x->PointWiseMult(this->inv_diag_entries_);
+    }
+    const VectorType& GetInverseDiagonal(void) const
+    {
+        return this->inv_diag_entries_;
+    }
+
+private:
+    VectorType inv_diag_entries_;
+};
+
+// ---- ILU(p = 0): preconditioner.cpp:449-511
+template <class OperatorType, class VectorType, typename ValueType>
+class ILU : public Preconditioner<OperatorType, VectorType, ValueType>
+{
+public:
+    ILU()
+        : p_(0)
+        , level_(true)
+    {
+    }
+    virtual ~ILU()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("ILU(" << this->p_ << ") preconditioner");
+    }
+    virtual void Set(int p, bool level = true)
+    {
+        assert(p >= 0 && this->build_ == false);
+        this->p_     = p;
+        this->level_ = level;
+    }
+    virtual void Build(void)
+    {
+        if(this->build_)
+            this->Clear();
+        this->build_ = true;
+        assert(this->op_ != NULL);
+        this->ILU_.CloneFrom(*this->op_);
+        this->ILU_.ILUpFactorize(this->p_, this->level_);
+        this->ILU_.LUAnalyse();
+    }
+    virtual void Clear(void)
+    {
+        this->ILU_.LUAnalyseClear();
+        this->ILU_.Clear();
+        this->build_ = false;
+    }
+    virtual void Solve(const VectorType& rhs, VectorType* x)
+    {
+        assert(this->build_ == true && x != NULL && x != &rhs);
+        this->ILU_.LUSolve(rhs, x);
+    }
+    const OperatorType& GetFactors(void) const
+    {
+        return this->ILU_;
+    }
+
+private:
+    OperatorType ILU_;
+    int          p_;
+    bool         level_;
+};
+
+// ---- MultiColored framework + MC-SGS: preconditioner_multicolored.cpp:148-413, _gs.cpp:127-215
+template <class OperatorType, class VectorType, typename ValueType>
+class MultiColored : public Preconditioner<OperatorType, VectorType, ValueType>
+{
+public:
+    MultiColored()
+        : op_mat_format_(false)
+        , precond_mat_format_(CSR)
+        , format_block_dim_(1)
+        , decomp_(true)
+        , preconditioner_(NULL)
+        , num_blocks_(0)
+        , block_sizes_(NULL)
+    {
+    }
+    virtual ~MultiColored()
+    {
+        this->Clear();
+    }
+    virtual void SetPrecondMatrixFormat(unsigned int mat_format, int blockdim = 1)
+    {
+        this->op_mat_format_      = true;
+        this->precond_mat_format_ = mat_format;
+        this->format_block_dim_   = blockdim;
+    }
+    virtual void SetDecomposition(bool decomp)
+    {
+        this->decomp_ = decomp;
+    }
+    int GetNumColors(void) const
+    {
+        return this->num_blocks_;
+    }
+    virtual void Build(void)
+    {
+        if(this->build_)
+            this->Clear();
+        assert(this->op_ != NULL);
+        // Build_Analyser_: work on a clone of the operator
+        this->preconditioner_ = new OperatorType;
+        this->preconditioner_->CloneFrom(*this->op_);
+        this->permutation_.CloneBackend(*this->op_);
+        // Analyse_: greedy multi-colouring -> block sizes + permutation
+        this->op_->MultiColoring(this->num_blocks_, &this->block_sizes_, &this->permutation_);
+        // Permute_: P A P^T
+        this->preconditioner_->Permute(this->permutation_);
+        this->Factorize_();
+        this->Decompose_();
+        this->build_ = true;
+        if(this->decomp_)
+            this->preconditioner_->Clear();
+        else
+            this->PostAnalyse_();
+    }
+    virtual void Clear(void)
+    {
+        if(this->preconditioner_ != NULL)
+        {
+            this->preconditioner_->LAnalyseClear();
+            this->preconditioner_->UAnalyseClear();
+            delete this->preconditioner_;
+            this->preconditioner_ = NULL;
+        }
+        for(size_t i = 0; i < this->block_.size(); ++i)
+            delete this->block_[i];
+        for(size_t i = 0; i < this->x_block_.size(); ++i)
+        {
+            delete this->x_block_[i];
+            delete this->diag_block_[i];
+            delete this->diag_solver_[i];
+        }
+        this->block_.clear();
+        this->x_block_.clear();
+        this->diag_block_.clear();
+        this->diag_solver_.clear();
+        free_host(&this->block_sizes_);
+        this->num_blocks_ = 0;
+        this->diag_.Clear();
+        this->x_.Clear();
+        this->permutation_.Clear();
+        this->build_ = false;
+    }
+    virtual void Solve(const VectorType& rhs, VectorType* x)
+    {
+        assert(this->build_ == true && x != NULL && x != &rhs);
+        if(this->decomp_)
+        {
+            this->ExtractRHSinX_(rhs, x);
+            this->SolveL_();
+            this->SolveD_();
+            this->SolveR_();
+            this->InsertSolution_(x);
+        }
+        else
+            this->Solve_(rhs, x);
+    }
+
+protected:
+    virtual void Factorize_(void) {}
+    virtual void PostAnalyse_(void) {}
+    virtual void SolveL_(void) = 0;
+    virtual void SolveD_(void) = 0;
+    virtual void SolveR_(void) = 0;
+    virtual void Solve_(const VectorType& rhs, VectorType* x) = 0;
+
+    OperatorType* blk_(int i, int j)
+    {
+        return this->block_[(size_t)i * this->num_blocks_ + j];
+    }
+    void Decompose_(void)
+    {
+        const int nb = this->num_blocks_;
+        if(this->decomp_)
+        {
+            std::vector<int> offsets((size_t)nb + 1, 0);
+            for(int i = 0; i < nb; ++i)
+                offsets[i + 1] = offsets[i] + this->block_sizes_[i];
+            this->block_.assign((size_t)nb * nb, NULL);
+            std::vector<OperatorType**> rows((size_t)nb);
+            for(int i = 0; i < nb; ++i)
+            {
+                for(int j = 0; j < nb; ++j)
+                {
+                    this->block_[(size_t)i * nb + j] = new OperatorType;
+                    this->block_[(size_t)i * nb + j]->CloneBackend(*this->op_);
+                }
+                rows[i] = &this->block_[(size_t)i * nb];
+            }
+            this->preconditioner_->ExtractSubMatrices(nb, nb, offsets.data(), offsets.data(),
+                                                      rows.data());
+            this->x_block_.assign((size_t)nb, NULL);
+            this->diag_block_.assign((size_t)nb, NULL);
+            this->diag_solver_.assign((size_t)nb, NULL);
+            for(int i = 0; i < nb; ++i)
+            {
+                this->diag_block_[i] = new VectorType;
+                this->diag_block_[i]->CloneBackend(*this->op_);
+                this->diag_block_[i]->Allocate("Diagonal preconditioners blocks", this->block_sizes_[i]);
+                this->blk_(i, i)->ExtractDiagonal(this->diag_block_[i]);
+                this->x_block_[i] = new VectorType;
+                this->x_block_[i]->CloneBackend(*this->op_);
+                this->x_block_[i]->Allocate("MultiColored Preconditioner x_block_",
+                                            this->block_sizes_[i]);
+                Jacobi<OperatorType, VectorType, ValueType>* jacobi
+                    = new Jacobi<OperatorType, VectorType, ValueType>;
+                jacobi->SetOperator(*this->blk_(i, i));
+                jacobi->Build();
+                this->diag_solver_[i] = jacobi;
+                this->blk_(i, i)->Clear();
+            }
+            if(this->op_mat_format_)
+                for(int i = 0; i < nb; ++i)
+                    for(int j = 0; j < nb; ++j)
+                        if(this->blk_(i, j)->GetNnz() > 0)
+                            this->blk_(i, j)->ConvertTo(this->precond_mat_format_,
+                                                        this->format_block_dim_);
+        }
+        else
+        {
+            this->diag_.CloneBackend(*this->op_);
+            this->preconditioner_->ExtractDiagonal(&this->diag_);
+        }
+        this->x_.CloneBackend(*this->op_);
+        this->x_.Allocate("Permuted solution vector", this->op_->GetM());
+    }
+    void ExtractRHSinX_(const VectorType& rhs, VectorType* x)
+    {
+        x->CopyFromPermute(rhs, this->permutation_);
+        int64_t off = 0;
+        for(int i = 0; i < this->num_blocks_; ++i)
+        {
+            this->x_block_[i]->CopyFrom(*x, off, 0, this->block_sizes_[i]);
+            off += this->block_sizes_[i];
+        }
+    }
+    void InsertSolution_(VectorType* x)
+    {
+        int64_t off = 0;
+        for(int i = 0; i < this->num_blocks_; ++i)
+        {
+            this->x_.CopyFrom(*this->x_block_[i], 0, off, this->block_sizes_[i]);
+            off += this->block_sizes_[i];
+        }
+        x->CopyFromPermuteBackward(this->x_, this->permutation_);
+    }
+
+    bool                          op_mat_format_;
+    unsigned int                  precond_mat_format_;
+    int                           format_block_dim_;
+    bool                          decomp_;
+    OperatorType*                 preconditioner_;
+    std::vector<OperatorType*>    block_; // [i*nb+j]
+    std::vector<VectorType*>      x_block_;
+    std::vector<VectorType*>      diag_block_;
+    std::vector<Solver<OperatorType, VectorType, ValueType>*> diag_solver_;
+    VectorType                    x_;
+    VectorType                    diag_;
+    int                           num_blocks_;
+    int*                          block_sizes_;
+    LocalVector<int>              permutation_;
+};
+
+template <class OperatorType, class VectorType, typename ValueType>
+class MultiColoredSGS : public MultiColored<OperatorType, VectorType, ValueType>
+{
+public:
+    MultiColoredSGS()
+        : omega_(static_cast<ValueType>(1))
+    {
+    }
+    virtual ~MultiColoredSGS()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("Multicolored Symmetric Gauss-Seidel (SGS) preconditioner");
+        if(this->build_)
+            LOG_INFO("number of colors = " << this->num_blocks_);
+    }
+    virtual void SetRelaxation(ValueType omega)
+    {
+        this->omega_ = omega;
+    }
+
+protected:
+    virtual void PostAnalyse_(void)
+    {
+        this->preconditioner_->LAnalyse(false);
+        this->preconditioner_->UAnalyse(false);
+    }
+    void sweep_block_(int i, int j)
+    {
+        if(this->blk_(i, j)->GetNnz() > 0)
+            this->blk_(i, j)->ApplyAdd(*this->x_block_[j], static_cast<ValueType>(-1),
+                                       this->x_block_[i]);
+    }
+    virtual void SolveL_(void)
+    {
+        for(int i = 0; i < this->num_blocks_; ++i)
+        {
+            for(int j = 0; j < i; ++j)
+                this->sweep_block_(i, j);
+            this->diag_solver_[i]->Solve(*this->x_block_[i], this->x_block_[i]);
+            if(this->omega_ != static_cast<ValueType>(1))
+                this->x_block_[i]->Scale(static_cast<ValueType>(1) / this->omega_);
+        }
+    }
+    virtual void SolveD_(void)
+    {
+        for(int i = 0; i < this->num_blocks_; ++i)
+        {
+            this->x_block_[i]->PointWiseMult(*this->diag_block_[i]);
+            if(this->omega_ != static_cast<ValueType>(1))
+                this->x_block_[i]->Scale(this->omega_ / (static_cast<ValueType>(2) - this->omega_));
+        }
+    }
+    virtual void SolveR_(void)
+    {
+        for(int i = this->num_blocks_ - 1; i >= 0; --i)
+        {
+            for(int j = this->num_blocks_ - 1; j > i; --j) // descending j, as the reference
+                this->sweep_block_(i, j);
+            this->diag_solver_[i]->Solve(*this->x_block_[i], this->x_block_[i]);
+            if(this->omega_ != static_cast<ValueType>(1))
+                this->x_block_[i]->Scale(static_cast<ValueType>(1) / this->omega_);
+        }
+    }
+    virtual void Solve_(const VectorType& rhs, VectorType* x)
+    {
+        this->x_.CopyFromPermute(rhs, this->permutation_);
+        this->preconditioner_->LSolve(this->x_, x);
+        x->PointWiseMult(this->diag_);
+        this->preconditioner_->USolve(*x, &this->x_);
+        x->CopyFromPermuteBackward(this->x_, this->permutation_);
+    }
+    ValueType omega_;
+};
+
+// ============================================================================ IterativeLinearSolver
+template <class OperatorType, class VectorType, typename ValueType>
+class IterativeLinearSolver : public Solver<OperatorType, VectorType, ValueType>
+{
+public:
+    IterativeLinearSolver()
+        : res_norm_type_(2)
+        , index_(-1)
+        , fused_(true)
+    {
+    }
+    void Init(double abs_tol, double rel_tol, double div_tol, int max_iter)
+    {
+        this->iter_ctrl_.Init(abs_tol, rel_tol, div_tol, max_iter);
+    }
+    void Init(double abs_tol, double rel_tol, double div_tol, int min_iter, int max_iter)
+    {
+        this->iter_ctrl_.Init(abs_tol, rel_tol, div_tol, min_iter, max_iter);
+    }
+    void InitMinIter(int min_iter)
+    {
+        this->iter_ctrl_.InitMinimumIterations(min_iter);
+    }
+    void InitMaxIter(int max_iter)
+    {
+        this->iter_ctrl_.InitMaximumIterations(max_iter);
+    }
+    void InitTol(double abs, double rel, double div)
+    {
+        this->iter_ctrl_.InitTolerance(abs, rel, div);
+    }
+    void SetResidualNorm(int resnorm)
+    {
+        assert(resnorm == 1 || resnorm == 2 || resnorm == 3);
+        this->res_norm_type_ = resnorm;
+    }
+    void RecordResidualHistory(void)
+    {
+        this->iter_ctrl_.RecordHistory();
+    }
+    void RecordHistory(const std::string& filename) const
+    {
+        this->iter_ctrl_.WriteHistoryToFile(filename);
+    }
+    const std::vector<double>& GetResidualHistory(void) const
+    {
+        return this->iter_ctrl_.GetResidualHistory();
+    }
+    virtual void Verbose(int verb = 1)
+    {
+        this->verb_ = verb;
+        this->iter_ctrl_.Verbose(verb);
+    }
+    virtual int GetIterationCount(void)
+    {
+        return this->iter_ctrl_.GetIterationCount();
+    }
+    virtual double GetCurrentResidual(void)
+    {
+        return this->iter_ctrl_.GetCurrentResidual();
+    }
+    virtual int GetSolverStatus(void)
+    {
+        return this->iter_ctrl_.GetSolverStatus();
+    }
+    virtual int64_t GetAmaxResidualIndex(void)
+    {
+        return this->iter_ctrl_.GetAmaxResidualIndex();
+    }
+    virtual void SetPreconditioner(Solver<OperatorType, VectorType, ValueType>& precond)
+    {
+        assert(this != &precond);
+        this->precond_ = &precond;
+        this->precond_->FlagPrecond();
+    }
+    // extension: switch the fused device path of CG / GMRES on or off (default on). Both paths run
+    // the same per-element arithmetic; only the summation order of the reductions differs.
+    void SetFused(bool fused)
+    {
+        this->fused_ = fused;
+    }
+    // solver.cpp:470-500
+    virtual void Solve(const VectorType& rhs, VectorType* x)
+    {
+        assert(x != NULL && x != &rhs && this->op_ != NULL && this->build_ == true);
+        if(this->verb_ > 0)
+        {
+            this->PrintStart_();
+            this->iter_ctrl_.PrintInit();
+        }
+        if(this->precond_ == NULL)
+            this->SolveNonPrecond_(rhs, x);
+        else
+            this->SolvePrecond_(rhs, x);
+        if(this->verb_ > 0)
+        {
+            this->iter_ctrl_.PrintStatus();
+            this->PrintEnd_();
+        }
+    }
+
+protected:
+    virtual void PrintStart_(void) const = 0;
+    virtual void PrintEnd_(void) const   = 0;
+    virtual void SolveNonPrecond_(const VectorType& rhs, VectorType* x) = 0;
+    virtual void SolvePrecond_(const VectorType& rhs, VectorType* x)    = 0;
+    // solver.cpp:443-468
+    ValueType Norm_(const VectorType& vec)
+    {
+        if(this->res_norm_type_ == 1)
+            return vec.Asum();
+        if(this->res_norm_type_ == 2)
+            return vec.Norm();
+        ValueType amax;
+        this->index_ = vec.Amax(amax);
+        return amax;
+    }
+    IterationControl iter_ctrl_;
+    int              res_norm_type_;
+    int64_t          index_;
+    bool             fused_;
+};
+
+// fused kernels exist for accelerator-resident LocalMatrix/LocalVector only
+template <class OperatorType, class VectorType, typename ValueType>
+struct _fusable
+{
+    static constexpr bool value = false;
+};
+template <typename ValueType>
+struct _fusable<LocalMatrix<ValueType>, LocalVector<ValueType>, ValueType>
+{
+    static constexpr bool value = true;
+};
+
+// ============================================================================ CG
+template <class OperatorType, class VectorType, typename ValueType>
+class CG : public IterativeLinearSolver<OperatorType, VectorType, ValueType>
+{
+public:
+    virtual ~CG()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("CG solver" << (this->precond_ ? ", with preconditioner" : " (non-precond)"));
+    }
+    // cg.cpp:99-137
+    virtual void Build(void)
+    {
+        if(this->build_)
+            this->Clear();
+        assert(this->op_ != NULL && this->op_->GetM() == this->op_->GetN() && this->op_->GetM() > 0);
+        this->build_ = true;
+        if(this->precond_ != NULL)
+        {
+            this->precond_->SetOperator(*this->op_);
+            this->precond_->Build();
+            this->z_.CloneBackend(*this->op_);
+            this->z_.Allocate("z", this->op_->GetM());
+        }
+        this->r_.CloneBackend(*this->op_);
+        this->r_.Allocate("r", this->op_->GetM());
+        this->p_.CloneBackend(*this->op_);
+        this->p_.Allocate("p", this->op_->GetM());
+        this->q_.CloneBackend(*this->op_);
+        this->q_.Allocate("q", this->op_->GetM());
+    }
+    virtual void Clear(void)
+    {
+        if(this->build_)
+        {
+            if(this->precond_ != NULL)
+            {
+                this->precond_->Clear();
+                this->precond_ = NULL;
+            }
+            this->r_.Clear();
+            this->z_.Clear();
+            this->p_.Clear();
+            this->q_.Clear();
+            this->iter_ctrl_.Clear();
+            this->build_ = false;
+        }
+    }
+
+protected:
+    virtual void PrintStart_(void) const
+    {
+        LOG_INFO("CG " << (this->precond_ ? "" : "(non-precond) ") << "linear solver starts");
+    }
+    virtual void PrintEnd_(void) const
+    {
+        LOG_INFO("CG ends");
+    }
+    virtual void SolveNonPrecond_(const VectorType& rhs, VectorType* x)
+    {
+        this->Solve_(rhs, x, false);
+    }
+    virtual void SolvePrecond_(const VectorType& rhs, VectorType* x)
+    {
+        this->Solve_(rhs, x, true);
+    }
+
+private:
+    // cg.cpp:291-362 / :366-446
+    void Solve_(const VectorType& rhs, VectorType* x, bool precond)
+    {
+        const OperatorType* op = this->op_;
+        VectorType *        r = &this->r_, *z = &this->z_, *p = &this->p_, *q = &this->q_;
+        ValueType           alpha, beta, rho, rho_old;
+
+        op->Apply(*x, r);
+        r->ScaleAdd(static_cast<ValueType>(-1), rhs);
+        ValueType res_norm = this->Norm_(*r);
+        if(this->iter_ctrl_.InitResidual(std::abs(res_norm)) == false)
+            return;
+        if(precond)
+        {
+            this->precond_->SolveZeroSol(*r, z);
+            p->CopyFrom(*z);
+        }
+        else
+            p->CopyFrom(*r);
+
+        if(this->fused_ && this->res_norm_type_ == 2 && this->FusedLoop_(rhs, x, precond))
+            return;
+
+        rho = precond ? r->DotNonConj(*z) : r->DotNonConj(*r);
+        while(true)
+        {
+            op->Apply(*p, q);
+            alpha = rho / p->DotNonConj(*q);
+            x->AddScale(*p, alpha);
+            r->AddScale(*q, -alpha);
+            res_norm = this->Norm_(*r);
+            if(this->iter_ctrl_.CheckResidual(std::abs(res_norm), this->index_))
+                break;
+            rho_old = rho;
+            if(precond)
+            {
+                this->precond_->SolveZeroSol(*r, z);
+                rho  = r->DotNonConj(*z);
+                beta = rho / rho_old;
+                p->ScaleAdd(beta, *z);
+            }
+            else
+            {
+                rho  = r->DotNonConj(*r);
+                beta = rho / rho_old;
+                p->ScaleAdd(beta, *r);
+            }
+        }
+    }
+
+    // Fused device loop (Local objects on the accelerator).  Per iteration:
+    //   K1  q = A p, <p,q>                                   (ramd_fused_apply_dot)
+    //   K2  x += a p ; r -= a q ; <r,r> ; [z = D^-1 r ; <r,z>]  (ramd_fused_cg_update)
+    //   K3  p = (rho'/rho) p + z                              (ramd_fused_cg_direction)
+    // The ||r|| read-back for iteration k overlaps K3(k) and K1(k+1), which are queued before the
+    // host waits; the convergence decision is the reference's, made on the same ||r||.
+    template <class O = OperatorType, class V = VectorType>
+    typename std::enable_if<_fusable<O, V, ValueType>::value, bool>::type
+        FusedLoop_(const VectorType& rhs, VectorType* x, bool precond)
+    {
+        (void)rhs;
+        if(!this->op_->is_accel_() || !x->is_accel_())
+            return false;
+        VectorType *r = &this->r_, *z = &this->z_, *p = &this->p_, *q = &this->q_;
+        typedef Jacobi<OperatorType, VectorType, ValueType> JacobiType;
+        JacobiType* jac = precond ? dynamic_cast<JacobiType*>(this->precond_) : NULL;
+        ramd_vec_t  dinv = NULL;
+        if(jac != NULL && jac->GetInverseDiagonal().GetSize() == r->GetSize())
+            dinv = jac->GetInverseDiagonal().handle();
+        const bool generic_pc = precond && dinv == NULL;
+        VectorType* zdir      = precond ? z : r;
+
+        enum { S_PQ = 1, S_RR = 2 };
+        int s_rho = 0, s_new = 3; // rho slots alternate between 0 and 3
+        // rho = <r, z> (or <r, r>)
+        const ramd_vec_t first[1] = {r->handle()};
+        RAMD_CHECK(ramd_fused_multi_dot(first, 1, zdir->handle(), s_rho));
+        RAMD_CHECK(ramd_fused_apply_dot(this->op_->handle(), p->handle(), q->handle(), S_PQ));
+        int rec = 0;
+        while(true)
+        {
+            RAMD_CHECK(ramd_fused_cg_update(x->handle(), r->handle(), p->handle(), q->handle(), dinv,
+                                            dinv ? z->handle() : NULL, s_rho, S_PQ, S_RR, s_new));
+            if(generic_pc)
+            {
+                this->precond_->SolveZeroSol(*r, z);
+                RAMD_CHECK(ramd_fused_multi_dot(first, 1, z->handle(), s_new));
+            }
+            RAMD_CHECK(ramd_scalars_fetch_async_begin(rec, S_RR, 1));
+            RAMD_CHECK(ramd_fused_cg_direction(p->handle(), zdir->handle(), s_new, s_rho));
+            RAMD_CHECK(ramd_fused_apply_dot(this->op_->handle(), p->handle(), q->handle(), S_PQ));
+            double rr = 0.0;
+            RAMD_CHECK(ramd_scalars_fetch_async_end(rec, &rr, 1));
+            ValueType res_norm = (ValueType)std::sqrt(rr);
+            if(this->iter_ctrl_.CheckResidual(std::abs(res_norm), this->index_))
+                break;
+            std::swap(s_rho, s_new);
+            rec = (rec + 1) & 7;
+        }
+        return true;
+    }
+    template <class O = OperatorType, class V = VectorType>
+    typename std::enable_if<!_fusable<O, V, ValueType>::value, bool>::type
+        FusedLoop_(const VectorType&, VectorType*, bool)
+    {
+        return false;
+    }
+
+    VectorType r_, z_, p_, q_;
+};
+
+// ============================================================================ GMRES
+template <class OperatorType, class VectorType, typename ValueType>
+class GMRES : public IterativeLinearSolver<OperatorType, VectorType, ValueType>
+{
+public:
+    GMRES()
+        : size_basis_(30) // gmres.cpp:50
+        , v_(NULL)
+    {
+    }
+    virtual ~GMRES()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("GMRES(" << this->size_basis_ << ") solver"
+                          << (this->precond_ ? ", with preconditioner" : " (non-precond)"));
+    }
+    virtual void SetBasisSize(int size_basis)
+    {
+        assert(size_basis > 0 && this->build_ == false);
+        this->size_basis_ = size_basis;
+    }
+    // gmres.cpp:109-156
+    virtual void Build(void)
+    {
+        if(this->build_)
+            this->Clear();
+        assert(this->op_ != NULL && this->op_->GetM() == this->op_->GetN() && this->op_->GetM() > 0);
+        this->build_ = true;
+        const int m  = this->size_basis_;
+        this->c_.assign((size_t)m, ValueType(0));
+        this->s_.assign((size_t)m, ValueType(0));
+        this->r_.assign((size_t)m + 1, ValueType(0));
+        this->H_.assign((size_t)(m + 1) * m, ValueType(0));
+        this->v_ = new VectorType*[m + 1];
+        for(int i = 0; i < m + 1; ++i)
+        {
+            this->v_[i] = new VectorType;
+            this->v_[i]->CloneBackend(*this->op_);
+            this->v_[i]->Allocate("v", this->op_->GetM());
+        }
+        if(this->precond_ != NULL)
+        {
+            this->z_.CloneBackend(*this->op_);
+            this->z_.Allocate("z", this->op_->GetM());
+            this->precond_->SetOperator(*this->op_);
+            this->precond_->Build();
+        }
+    }
+    virtual void Clear(void)
+    {
+        if(this->build_)
+        {
+            if(this->precond_ != NULL)
+            {
+                this->precond_->Clear();
+                this->precond_ = NULL;
+            }
+            for(int i = 0; i < this->size_basis_ + 1; ++i)
+                delete this->v_[i];
+            delete[] this->v_;
+            this->v_ = NULL;
+            this->z_.Clear();
+            this->iter_ctrl_.Clear();
+            this->build_ = false;
+        }
+    }
+
+protected:
+    virtual void PrintStart_(void) const
+    {
+        LOG_INFO("GMRES(" << this->size_basis_ << ") " << (this->precond_ ? "" : "(non-precond) ")
+                          << "linear solver starts");
+    }
+    virtual void PrintEnd_(void) const
+    {
+        LOG_INFO("GMRES(" << this->size_basis_ << ") ends");
+    }
+    virtual void SolveNonPrecond_(const VectorType& rhs, VectorType* x)
+    {
+        this->Solve_(rhs, x, false);
+    }
+    virtual void SolvePrecond_(const VectorType& rhs, VectorType* x)
+    {
+        this->Solve_(rhs, x, true);
+    }
+
+private:
+    int hidx_(int i, int j) const // DENSE_IND, column-major (m+1) x m (matrix_formats_ind.hpp:30)
+    {
+        return i + j * (this->size_basis_ + 1);
+    }
+    // gmres.cpp:565-607
+    static void GenerateGivensRotation_(ValueType dx, ValueType dy, ValueType& c, ValueType& s)
+    {
+        const ValueType zero = static_cast<ValueType>(0), one = static_cast<ValueType>(1);
+        if(dy == zero)
+        {
+            c = one;
+            s = zero;
+        }
+        else if(dx == zero)
+        {
+            c = zero;
+            s = one;
+        }
+        else if(std::abs(dy) > std::abs(dx))
+        {
+            ValueType tmp = dx / dy;
+            s             = one / std::sqrt(one + tmp * tmp);
+            c             = tmp * s;
+        }
+        else
+        {
+            ValueType tmp = dy / dx;
+            c             = one / std::sqrt(one + tmp * tmp);
+            s             = tmp * c;
+        }
+    }
+    static void ApplyGivensRotation_(ValueType c, ValueType s, ValueType& dx, ValueType& dy)
+    {
+        ValueType temp = dx;
+        dx             = c * dx + s * dy;
+        dy             = -s * temp + c * dy;
+    }
+    // residual -> v_0 (through z_ and M^-1 when preconditioned): gmres.cpp:444-454, :542-552
+    void Residual_(const VectorType& rhs, VectorType* x, bool precond)
+    {
+        const ValueType one = static_cast<ValueType>(1);
+        if(precond)
+        {
+            this->op_->Apply(*x, &this->z_);
+            this->z_.ScaleAdd(-one, rhs);
+            this->precond_->SolveZeroSol(this->z_, this->v_[0]);
+        }
+        else
+        {
+            this->op_->Apply(*x, this->v_[0]);
+            this->v_[0]->ScaleAdd(-one, rhs);
+        }
+    }
+    // one Arnoldi step: fills column i of H (rows 0..i+1) and normalises v_{i+1}
+    void Arnoldi_(int i, bool precond)
+    {
+        VectorType**    v   = this->v_;
+        ValueType*      H   = this->H_.data();
+        const ValueType one = static_cast<ValueType>(1);
+        if(precond)
+        {
+            this->op_->Apply(*v[i], &this->z_);
+            this->precond_->SolveZeroSol(this->z_, v[i + 1]);
+        }
+        else
+            this->op_->Apply(*v[i], v[i + 1]);
+        if(this->fused_ && this->res_norm_type_ == 2 && this->FusedMGS_(i))
+            return;
+        for(int k = 0; k <= i; ++k) // modified Gram-Schmidt
+        {
+            H[this->hidx_(k, i)] = v[k]->Dot(*v[i + 1]);
+            v[i + 1]->AddScale(*v[k], -H[this->hidx_(k, i)]);
+        }
+        H[this->hidx_(i + 1, i)] = this->Norm_(*v[i + 1]);
+        v[i + 1]->Scale(one / H[this->hidx_(i + 1, i)]);
+    }
+    // Fused MGS: every projection  w -= h_k v_k  is fused with the NEXT dot <v_{k+1}, w> (or with
+    // <w,w> for the last one) and the normalisation reads ||w|| on the device: i+2 launches and
+    // ONE host read per Arnoldi step instead of 2i+4 launches and i+2 blocking reads.  Same MGS
+    // order and per-element arithmetic as the loop above.
+    template <class O = OperatorType, class V = VectorType>
+    typename std::enable_if<_fusable<O, V, ValueType>::value, bool>::type FusedMGS_(int i)
+    {
+        if(i + 3 > RAMD_NSCALARS - 2 || !this->v_[0]->is_accel_())
+            return false;
+        VectorType** v = this->v_;
+        ValueType*   H = this->H_.data();
+        ramd_vec_t   w = v[i + 1]->handle();
+        const ramd_vec_t v0[1] = {v[0]->handle()};
+        RAMD_CHECK(ramd_fused_multi_dot(v0, 1, w, 0)); // s[0] = <v_0, w>
+        for(int k = 0; k <= i; ++k) // s[k+1] = <v_{k+1}, w - h_k v_k>  (k == i: <w,w>)
+            RAMD_CHECK(ramd_fused_mgs_step(w, v[k]->handle(), k, (k < i) ? v[k + 1]->handle() : NULL,
+                                           k + 1));
+        RAMD_CHECK(ramd_fused_normalize(w, i + 1, i + 2)); // s[i+2] = ||w|| ; w /= ||w||
+        std::vector<double> h((size_t)i + 3);
+        RAMD_CHECK(ramd_scalars_fetch(h.data(), 0, i + 3));
+        for(int k = 0; k <= i; ++k)
+            H[this->hidx_(k, i)] = (ValueType)h[k];
+        H[this->hidx_(i + 1, i)] = (ValueType)h[i + 2];
+        return true;
+    }
+    template <class O = OperatorType, class V = VectorType>
+    typename std::enable_if<!_fusable<O, V, ValueType>::value, bool>::type FusedMGS_(int)
+    {
+        return false;
+    }
+
+    // gmres.cpp:274-413 / :416-562
+    void Solve_(const VectorType& rhs, VectorType* x, bool precond)
+    {
+        VectorType**    v    = this->v_;
+        ValueType *     c = this->c_.data(), *s = this->s_.data(), *r = this->r_.data();
+        ValueType*      H    = this->H_.data();
+        const ValueType one  = static_cast<ValueType>(1);
+        const int       size = this->size_basis_;
+
+        this->Residual_(rhs, x, precond);
+        std::fill(this->r_.begin(), this->r_.end(), ValueType(0));
+        r[0] = this->Norm_(*v[0]);
+        if(this->iter_ctrl_.InitResidual(std::abs(r[0])) == false)
+            return;
+        while(true)
+        {
+            v[0]->Scale(one / r[0]);
+            int i = 0;
+            while(i < size)
+            {
+                this->Arnoldi_(i, precond);
+                for(int k = 0; k < i; ++k)
+                    ApplyGivensRotation_(c[k], s[k], H[this->hidx_(k, i)], H[this->hidx_(k + 1, i)]);
+                GenerateGivensRotation_(H[this->hidx_(i, i)], H[this->hidx_(i + 1, i)], c[i], s[i]);
+                ApplyGivensRotation_(c[i], s[i], H[this->hidx_(i, i)], H[this->hidx_(i + 1, i)]);
+                ApplyGivensRotation_(c[i], s[i], r[i], r[i + 1]);
+                if(this->iter_ctrl_.CheckResidual(std::abs(r[++i])))
+                    break;
+            }
+            for(int j = i - 1; j >= 0; --j) // back substitution on the host
+            {
+                r[j] /= H[this->hidx_(j, j)];
+                for(int k = 0; k < j; ++k)
+                    r[k] -= H[this->hidx_(k, j)] * r[j];
+            }
+            x->AddScale(*v[0], r[0]);
+            for(int j = 1; j < i; ++j)
+                x->AddScale(*v[j], r[j]);
+            this->Residual_(rhs, x, precond);
+            std::fill(this->r_.begin(), this->r_.end(), ValueType(0));
+            r[0] = this->Norm_(*v[0]);
+            if(this->iter_ctrl_.CheckResidualNoCount(std::abs(r[0])))
+                break;
+        }
+    }
+
+    int                    size_basis_;
+    VectorType**           v_;
+    VectorType             z_;
+    std::vector<ValueType> c_, s_, r_, H_;
+};
+
+// ============================================================================ BiCGStab
+template <class OperatorType, class VectorType, typename ValueType>
+class BiCGStab : public IterativeLinearSolver<OperatorType, VectorType, ValueType>
+{
+public:
+    virtual ~BiCGStab()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("BiCGStab solver" << (this->precond_ ? ", with preconditioner" : " (non-precond)"));
+    }
+    // bicgstab.cpp:109-160
+    virtual void Build(void)
+    {
+        if(this->build_)
+            this->Clear();
+        assert(this->op_ != NULL && this->op_->GetM() == this->op_->GetN() && this->op_->GetM() > 0);
+        this->build_ = true;
+        VectorType* all[] = {&this->r_, &this->r0_, &this->p_, &this->q_, &this->t_};
+        for(VectorType* vec : all)
+        {
+            vec->CloneBackend(*this->op_);
+            vec->Allocate("bicgstab", this->op_->GetM());
+        }
+        if(this->precond_ != NULL)
+        {
+            this->precond_->SetOperator(*this->op_);
+            this->precond_->Build();
+            this->v_.CloneBackend(*this->op_);
+            this->v_.Allocate("v", this->op_->GetM());
+            this->z_.CloneBackend(*this->op_);
+            this->z_.Allocate("z", this->op_->GetM());
+        }
+    }
+    virtual void Clear(void)
+    {
+        if(this->build_)
+        {
+            if(this->precond_ != NULL)
+            {
+                this->precond_->Clear();
+                this->precond_ = NULL;
+            }
+            VectorType* all[] = {&this->r_, &this->r0_, &this->p_, &this->q_, &this->t_, &this->v_,
+                                 &this->z_};
+            for(VectorType* vec : all)
+                vec->Clear();
+            this->iter_ctrl_.Clear();
+            this->build_ = false;
+        }
+    }
+
+protected:
+    virtual void PrintStart_(void) const
+    {
+        LOG_INFO("BiCGStab " << (this->precond_ ? "" : "(non-precond) ") << "linear solver starts");
+    }
+    virtual void PrintEnd_(void) const
+    {
+        LOG_INFO("BiCGStab ends");
+    }
+    virtual void SolveNonPrecond_(const VectorType& rhs, VectorType* x)
+    {
+        this->Solve_(rhs, x, false);
+    }
+    virtual void SolvePrecond_(const VectorType& rhs, VectorType* x)
+    {
+        this->Solve_(rhs, x, true);
+    }
+
+private:
+    // bicgstab.cpp:245-361 / :365-489 (right preconditioned: z = M^-1 p, v = M^-1 r)
+    void Solve_(const VectorType& rhs, VectorType* x, bool precond)
+    {
+        const OperatorType* op = this->op_;
+        VectorType *r = &this->r_, *r0 = &this->r0_, *p = &this->p_, *q = &this->q_, *t = &this->t_;
+        VectorType *v = &this->v_, *z = &this->z_;
+        ValueType   alpha, beta, omega, rho, rho_old;
+        const ValueType one = static_cast<ValueType>(1);
+
+        op->Apply(*x, r0);
+        r0->ScaleAdd(-one, rhs);
+        ValueType res_norm = this->Norm_(*r0);
+        if(this->iter_ctrl_.InitResidual(std::abs(res_norm)) == false)
+            return;
+        r->CopyFrom(*r0);
+        p->CopyFrom(*r);
+        rho = r->Dot(*r);
+        if(precond)
+            this->precond_->SolveZeroSol(*r, z);
+        while(true)
+        {
+            const VectorType* dir = precond ? z : p;
+            op->Apply(*dir, q);
+            alpha = rho / r0->Dot(*q);
+            r->AddScale(*q, -alpha);
+            const VectorType* sv = r;
+            if(precond)
+            {
+                this->precond_->SolveZeroSol(*r, v);
+                sv = v;
+            }
+            op->Apply(*sv, t);
+            omega = t->Dot(*r) / t->Dot(*t);
+            if((std::abs(omega) == std::numeric_limits<ValueType>::infinity()) || (omega != omega)
+               || (omega == static_cast<ValueType>(0)))
+            {
+                LOG_INFO("BiCGStab omega == 0 || Nan || Inf !!! Updated solution only in p-direction");
+                x->AddScale(*p, alpha);
+                op->Apply(*x, p);
+                p->ScaleAdd(-one, rhs);
+                res_norm = this->Norm_(*p);
+                this->iter_ctrl_.CheckResidual(std::abs(res_norm), this->index_);
+                break;
+            }
+            x->ScaleAdd2(one, *dir, alpha, *sv, omega);
+            r->AddScale(*t, -omega);
+            res_norm = this->Norm_(*r);
+            if(this->iter_ctrl_.CheckResidual(std::abs(res_norm), this->index_))
+                break;
+            rho_old = rho;
+            rho     = r0->Dot(*r);
+            if(rho == static_cast<ValueType>(0))
+            {
+                LOG_INFO("BiCGStab rho == 0 !!!");
+                break;
+            }
+            beta = (rho / rho_old) * (alpha / omega);
+            p->ScaleAdd2(beta, *q, -beta * omega, *r, one);
+            if(precond)
+                this->precond_->SolveZeroSol(*p, z);
+        }
+    }
+    VectorType r_, r0_, p_, q_, t_, v_, z_;
+};
+
+// ============================================================================ MixedPrecisionDC
+// mixed_precision.cpp:159-236 (Build) and :372-437 (solve).  The reference keeps the fp64 defect
+// correction on the HOST and ships r / d across PCIe every outer step; here both levels live on the
+// accelerator (cast kernels instead of host loops), the arithmetic and control flow are unchanged.
+template <class OperatorTypeH, class VectorTypeH, typename ValueTypeH, class OperatorTypeL,
+          class VectorTypeL, typename ValueTypeL>
+class MixedPrecisionDC : public IterativeLinearSolver<OperatorTypeH, VectorTypeH, ValueTypeH>
+{
+public:
+    MixedPrecisionDC()
+        : Solver_L_(NULL)
+        , op_l_(NULL)
+    {
+    }
+    virtual ~MixedPrecisionDC()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("MixedPrecisionDC [" << 8 * sizeof(ValueTypeH) << "bit-" << 8 * sizeof(ValueTypeL)
+                                      << "bit] solver");
+    }
+    void Set(Solver<OperatorTypeL, VectorTypeL, ValueTypeL>& Solver_L)
+    {
+        this->Solver_L_ = &Solver_L;
+    }
+    virtual void Build(void)
+    {
+        if(this->build_)
+            this->Clear();
+        assert(this->Solver_L_ != NULL && this->op_ != NULL);
+        this->build_ = true;
+        this->op_l_  = new OperatorTypeL;
+        this->op_l_->template CastFrom<ValueTypeH>(*this->op_); // value-cast CSR copy (:201-229)
+        this->r_h_.CloneBackend(*this->op_);
+        this->r_h_.Allocate("r_h", this->op_->GetM());
+        this->d_h_.CloneBackend(*this->op_);
+        this->d_h_.Allocate("d_h", this->op_->GetM());
+        this->r_l_.CloneBackend(*this->op_);
+        this->r_l_.Allocate("r_l", this->op_->GetM());
+        this->d_l_.CloneBackend(*this->op_);
+        this->d_l_.Allocate("d_l", this->op_->GetM());
+        this->Solver_L_->SetOperator(*this->op_l_);
+        this->Solver_L_->Build();
+    }
+    virtual void Clear(void)
+    {
+        if(this->build_)
+        {
+            if(this->Solver_L_ != NULL)
+            {
+                this->Solver_L_->Clear();
+                this->Solver_L_ = NULL;
+            }
+            delete this->op_l_;
+            this->op_l_ = NULL;
+            this->r_h_.Clear();
+            this->d_h_.Clear();
+            this->r_l_.Clear();
+            this->d_l_.Clear();
+            this->iter_ctrl_.Clear();
+            this->build_ = false;
+        }
+    }
+
+protected:
+    virtual void PrintStart_(void) const
+    {
+        LOG_INFO("MixedPrecisionDC linear solver starts");
+    }
+    virtual void PrintEnd_(void) const
+    {
+        LOG_INFO("MixedPrecisionDC ends");
+    }
+    virtual void SolveNonPrecond_(const VectorTypeH& rhs, VectorTypeH* x)
+    {
+        const ValueTypeH one = static_cast<ValueTypeH>(1);
+        this->op_->Apply(*x, &this->r_h_);
+        this->r_h_.ScaleAdd(-one, rhs);
+        ValueTypeH res = this->Norm_(this->r_h_);
+        if(this->iter_ctrl_.InitResidual(res) == false)
+            return;
+        while(!this->iter_ctrl_.CheckResidual(res, this->index_))
+        {
+            this->r_l_.CopyFromDouble(this->r_h_);
+            this->d_l_.Zeros();
+            this->Solver_L_->Solve(this->r_l_, &this->d_l_);
+            this->d_h_.CopyFromFloat(this->d_l_);
+            x->AddScale(this->d_h_, one);
+            this->op_->Apply(*x, &this->r_h_);
+            this->r_h_.ScaleAdd(-one, rhs);
+            res = this->Norm_(this->r_h_);
+        }
+    }
+    virtual void SolvePrecond_(const VectorTypeH&, VectorTypeH*)
+    {
+        LOG_INFO("MixedPrecisionDC:: the preconditioner belongs to the inner solver");
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+
+private:
+    Solver<OperatorTypeL, VectorTypeL, ValueTypeL>* Solver_L_;
+    OperatorTypeL*                                  op_l_;
+    VectorTypeH                                     r_h_, d_h_;
+    VectorTypeL                                     r_l_, d_l_;
+};
+
+} // namespace rocalution

@@ -195,6 +195,93 @@ int ramd_fused_mgs_step(ramd_vec_t w, ramd_vec_t v, int slot_h, ramd_vec_t u, in
 /* v = v * (1/s[slot]) with s[slot] = sqrt(s[slot_sq]) computed on device (gmres.cpp:493-496) */
 int ramd_fused_normalize(ramd_vec_t v, int slot_sq, int slot_norm);
 
+/* ======================================================================= communicator
+ * Replaces the reference's MPI layer for the hot path (src/utils/communicator.cpp:41-95 allreduce,
+ * :606-748 Isend/Irecv/Waitall, used by GlobalMatrix::Apply src/base/global_matrix.cpp:924-1009 and
+ * GlobalVector::Dot/Norm src/base/global_vector.cpp:547-588).  One process per GPU.
+ *   rccl     : device buffers go straight over xGMI (ncclSend/ncclRecv group on the ghost stream,
+ *              ncclAllReduce of a short fp64 scalar vector); bootstrap = 128-byte unique id that the
+ *              launcher (torch.distributed, MPI, ...) broadcasts.
+ *   callback : host-staged exchange through user callbacks (the reference's own pattern); used to
+ *              run >1 rank on a single GPU in tests and as a fallback transport.
+ */
+typedef struct ramd_comm_s* ramd_comm_t;
+typedef int (*ramd_exchange_cb)(void* user, int npeers, const int* peers, const void* send_host,
+                                const int64_t* send_offset_bytes, void* recv_host,
+                                const int64_t* recv_offset_bytes);
+typedef int (*ramd_allreduce_cb)(void* user, double* values, int count);
+int ramd_comm_unique_id(char id[128]);
+int ramd_comm_init_rccl(int rank, int nranks, const char id[128], ramd_comm_t* out);
+int ramd_comm_init_callback(int rank, int nranks, ramd_exchange_cb exchange, ramd_allreduce_cb allreduce,
+                            void* user, ramd_comm_t* out);
+int ramd_comm_destroy(ramd_comm_t c);
+int ramd_comm_rank(ramd_comm_t c, int* rank);
+int ramd_comm_size(ramd_comm_t c, int* size);
+/* in-place sum over all ranks of scalar slots [first, first+count) of the device record, queued on
+ * the current stream (one call for ALL scalars of a fused reduction) */
+int ramd_comm_allreduce_scalars(ramd_comm_t c, int first, int count);
+/* halo exchange (CommunicateAsync_/CommunicateSync_, src/base/parallel_manager.cpp:726-787):
+ * begin: after the work already queued on the current stream (the pack kernel), exchange
+ *        send[send_offset[k] .. send_offset[k+1]) -> peer k and recv[recv_offset[k] ..) <- peer k on
+ *        the ghost stream, so it overlaps whatever is queued on the current stream next;
+ * end  : the current stream waits for the exchange. */
+int ramd_comm_halo_begin(ramd_comm_t c, ramd_vec_t send, ramd_vec_t recv, int npeers, const int* peers,
+                         const int64_t* send_offset, const int64_t* recv_offset);
+int ramd_comm_halo_end(ramd_comm_t c);
+
+/* ======================================================================= solver layer
+ * C handles onto the compiled C++ API layer (include/rocalution/: Solver<Operator,Vector>::Build()/
+ * Solve(), src/solvers/solver.hpp:179-444 of the reference) for callers without a C++ compiler
+ * (the Python tests and bench.py).  Semantics are those of the C++ classes of the same name. */
+typedef struct ramd_solver_s* ramd_solver_t;
+enum { RAMD_SOLVER_CG = 0, RAMD_SOLVER_GMRES = 1, RAMD_SOLVER_BICGSTAB = 2 };
+enum { RAMD_PC_NONE = 0, RAMD_PC_JACOBI = 1, RAMD_PC_ILU0 = 2, RAMD_PC_MCSGS = 3 };
+int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out);
+/* MixedPrecisionDC<fp64 outer, fp32 inner>: inner solver/preconditioner kinds */
+int ramd_solver_create_mixed(int inner_solver, int inner_precond, ramd_solver_t* out);
+int ramd_solver_destroy(ramd_solver_t s);
+int ramd_solver_init(ramd_solver_t s, double abs_tol, double rel_tol, double div_tol, int min_iter,
+                     int max_iter); /* IterativeLinearSolver::Init */
+int ramd_solver_init_inner(ramd_solver_t s, double abs_tol, double rel_tol, double div_tol, int max_iter);
+int ramd_solver_set_basis(ramd_solver_t s, int size_basis); /* GMRES::SetBasisSize */
+int ramd_solver_set_fused(ramd_solver_t s, int on); /* fused device loops on/off (default on) */
+int ramd_solver_set_verbose(ramd_solver_t s, int verb);
+int ramd_solver_set_precond_format(ramd_solver_t s, int format); /* MultiColored::SetPrecondMatrixFormat */
+int ramd_solver_build(ramd_solver_t s, ramd_mat_t op); /* SetOperator + [SetPreconditioner] + Build */
+int ramd_solver_solve(ramd_solver_t s, ramd_vec_t rhs, ramd_vec_t x);
+int ramd_solver_precond_apply(ramd_solver_t s, ramd_vec_t rhs, ramd_vec_t x); /* M^-1 rhs (test hook) */
+int ramd_solver_result(ramd_solver_t s, int* iters, int* status, double* final_res);
+int ramd_solver_history(ramd_solver_t s, double* buf, int cap, int* len);
+int ramd_solver_num_colors(ramd_solver_t s, int* ncolors);
+int ramd_solver_clear(ramd_solver_t s);
+
+/* distributed driver: GlobalMatrix/GlobalVector + Solver<GlobalMatrix,GlobalVector> on one rank of a
+ * row-block decomposition (clients/samples/cg_mpi.cpp, bicgstab_mpi.cpp of the reference).  The local
+ * preconditioner of MC-SGS / ILU(0) is wrapped in BlockJacobi as the reference samples do. */
+typedef struct ramd_gsolver_s* ramd_gsolver_t;
+int ramd_gsolver_create(ramd_comm_t comm, int solver, int precond, ramd_gsolver_t* out);
+int ramd_gsolver_destroy(ramd_gsolver_t g);
+/* rank's slab of the 3-D 7-point Poisson operator N^3: planes [z_begin, z_end) */
+int ramd_gsolver_setup_poisson(ramd_gsolver_t g, int N, int z_begin, int z_end);
+/* general operator: interior CSR (local columns), ghost CSR (columns = positions in the receive
+ * buffer), boundary index list and neighbour offsets (ParallelManager setters) */
+int ramd_gsolver_setup_csr(ramd_gsolver_t g, int64_t global_nrow, int local_nrow, int64_t int_nnz,
+                           const int32_t* int_rp, const int32_t* int_ci, const double* int_val,
+                           int64_t gh_nnz, const int32_t* gh_rp, const int32_t* gh_ci, const double* gh_val,
+                           int npeers, const int* peers, const int* send_offset, const int* recv_offset,
+                           const int* boundary_index);
+int ramd_gsolver_convert(ramd_gsolver_t g, int format); /* GlobalMatrix::ConvertTo */
+int ramd_gsolver_init(ramd_gsolver_t g, double abs_tol, double rel_tol, double div_tol, int min_iter,
+                      int max_iter);
+int ramd_gsolver_set_basis(ramd_gsolver_t g, int size_basis);
+int ramd_gsolver_set_verbose(ramd_gsolver_t g, int verb);
+int ramd_gsolver_build(ramd_gsolver_t g);
+int ramd_gsolver_apply(ramd_gsolver_t g, const double* x_local, double* y_local); /* y = A x (test hook) */
+int ramd_gsolver_solve(ramd_gsolver_t g, const double* rhs_local, double* x_local); /* NULL rhs: A*1 ; x0 = x_local or 0 */
+int ramd_gsolver_solve_ones(ramd_gsolver_t g); /* rhs = A*1, x0 = 0, everything stays on the device */
+int ramd_gsolver_result(ramd_gsolver_t g, int* iters, int* status, double* final_res);
+int ramd_gsolver_dot_check(ramd_gsolver_t g, double* x_dot_x); /* <x,x> over all ranks after a solve */
+
 #ifdef __cplusplus
 }
 #endif

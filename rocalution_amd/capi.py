@@ -11,6 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librocalution_amd.so")
 
 OK, ERR_HIP, ERR_ARG, ERR_UNSUPPORTED, ERR_REFUSED, ERR_NO_DEVICE, ERR_STATE = range(7)
+SOLVER_CG, SOLVER_GMRES, SOLVER_BICGSTAB = 0, 1, 2
+PC_NONE, PC_JACOBI, PC_ILU0, PC_MCSGS = 0, 1, 2, 3
 F64, F32, I32 = 0, 1, 2
 CSR, COO, ELL, HYB = 1, 4, 6, 7
 
@@ -113,6 +115,49 @@ SIGNATURES = {
     "ramd_fused_multi_dot": (i32, [C.POINTER(vec_t), i32, vec_t, i32]),
     "ramd_fused_mgs_step": (i32, [vec_t, vec_t, i32, vec_t, i32]),
     "ramd_fused_normalize": (i32, [vec_t, i32, i32]),
+    # communicator
+    "ramd_comm_unique_id": (i32, [C.c_char_p]),
+    "ramd_comm_init_rccl": (i32, [i32, i32, C.c_char_p, C.POINTER(ptr)]),
+    "ramd_comm_init_callback": (i32, [i32, i32, ptr, ptr, ptr, C.POINTER(ptr)]),
+    "ramd_comm_destroy": (i32, [ptr]),
+    "ramd_comm_rank": (i32, [ptr, pi32]),
+    "ramd_comm_size": (i32, [ptr, pi32]),
+    "ramd_comm_allreduce_scalars": (i32, [ptr, i32, i32]),
+    "ramd_comm_halo_begin": (i32, [ptr, vec_t, vec_t, i32, pi32, pi64, pi64]),
+    "ramd_comm_halo_end": (i32, [ptr]),
+    # solver layer
+    "ramd_solver_create": (i32, [i32, i32, i32, C.POINTER(ptr)]),
+    "ramd_solver_create_mixed": (i32, [i32, i32, C.POINTER(ptr)]),
+    "ramd_solver_destroy": (i32, [ptr]),
+    "ramd_solver_init": (i32, [ptr, f64, f64, f64, i32, i32]),
+    "ramd_solver_init_inner": (i32, [ptr, f64, f64, f64, i32]),
+    "ramd_solver_set_basis": (i32, [ptr, i32]),
+    "ramd_solver_set_fused": (i32, [ptr, i32]),
+    "ramd_solver_set_verbose": (i32, [ptr, i32]),
+    "ramd_solver_set_precond_format": (i32, [ptr, i32]),
+    "ramd_solver_build": (i32, [ptr, mat_t]),
+    "ramd_solver_solve": (i32, [ptr, vec_t, vec_t]),
+    "ramd_solver_precond_apply": (i32, [ptr, vec_t, vec_t]),
+    "ramd_solver_result": (i32, [ptr, pi32, pi32, pf64]),
+    "ramd_solver_history": (i32, [ptr, pf64, i32, pi32]),
+    "ramd_solver_num_colors": (i32, [ptr, pi32]),
+    "ramd_solver_clear": (i32, [ptr]),
+    # distributed driver
+    "ramd_gsolver_create": (i32, [ptr, i32, i32, C.POINTER(ptr)]),
+    "ramd_gsolver_destroy": (i32, [ptr]),
+    "ramd_gsolver_setup_poisson": (i32, [ptr, i32, i32, i32]),
+    "ramd_gsolver_setup_csr": (i32, [ptr, i64, i32, i64, ptr, ptr, ptr, i64, ptr, ptr, ptr, i32, ptr, ptr,
+                                     ptr, ptr]),
+    "ramd_gsolver_convert": (i32, [ptr, i32]),
+    "ramd_gsolver_init": (i32, [ptr, f64, f64, f64, i32, i32]),
+    "ramd_gsolver_set_basis": (i32, [ptr, i32]),
+    "ramd_gsolver_set_verbose": (i32, [ptr, i32]),
+    "ramd_gsolver_build": (i32, [ptr]),
+    "ramd_gsolver_apply": (i32, [ptr, ptr, ptr]),
+    "ramd_gsolver_solve": (i32, [ptr, ptr, ptr]),
+    "ramd_gsolver_solve_ones": (i32, [ptr]),
+    "ramd_gsolver_result": (i32, [ptr, pi32, pi32, pf64]),
+    "ramd_gsolver_dot_check": (i32, [ptr, pf64]),
 }
 
 _lib = None

@@ -1,0 +1,679 @@
+// capi_solvers.cpp -- C handles onto the compiled C++ API layer (include/rocalution/*.hpp).
+// Host-only translation unit: it instantiates Solver<LocalMatrix,LocalVector> and
+// Solver<GlobalMatrix,GlobalVector> exactly as a reference driver would (clients/samples/cg.cpp,
+// gmres.cpp, bicgstab.cpp, mixed-precision.cpp, cg_mpi.cpp, bicgstab_mpi.cpp) and exposes
+// Build()/Solve() through the flat C ABI for Python / C callers.
+#include <memory>
+#include <stdexcept>
+
+#include "../../include/rocalution/rocalution.hpp"
+
+using namespace rocalution;
+
+namespace
+{
+
+// the C++ layer aborts on fatal errors like the reference does; argument errors that can be
+// detected up front are reported through the status code instead
+void set_err(const char* msg);
+
+struct SolverBase
+{
+    virtual ~SolverBase() {}
+    virtual void init(double a, double r, double d, int mn, int mx) = 0;
+    virtual void init_inner(double, double, double, int) {}
+    virtual void set_basis(int) {}
+    virtual void set_fused(bool)                                         = 0;
+    virtual void set_verbose(int)                                        = 0;
+    virtual void set_precond_format(int) {}
+    virtual void build(ramd_mat_t op)                                    = 0;
+    virtual void solve(ramd_vec_t rhs, ramd_vec_t x)                     = 0;
+    virtual bool precond_apply(ramd_vec_t, ramd_vec_t)                   = 0;
+    virtual void result(int* it, int* st, double* res)                   = 0;
+    virtual const std::vector<double>& history()                         = 0;
+    virtual int                        num_colors()
+    {
+        return 0;
+    }
+    virtual void clear() = 0;
+};
+
+template <typename T>
+struct Precs
+{
+    typedef LocalMatrix<T> M;
+    typedef LocalVector<T> V;
+    Jacobi<M, V, T>          jacobi;
+    ILU<M, V, T>             ilu;
+    MultiColoredSGS<M, V, T> mcsgs;
+    Solver<M, V, T>*         get(int kind)
+    {
+        switch(kind)
+        {
+        case RAMD_PC_JACOBI:
+            return &jacobi;
+        case RAMD_PC_ILU0:
+            return &ilu;
+        case RAMD_PC_MCSGS:
+            return &mcsgs;
+        default:
+            return NULL;
+        }
+    }
+};
+
+template <typename T>
+struct LocalSolver : SolverBase
+{
+    typedef LocalMatrix<T> M;
+    typedef LocalVector<T> V;
+    int                                             solver_kind, pc_kind;
+    CG<M, V, T>                                     cg;
+    GMRES<M, V, T>                                  gmres;
+    BiCGStab<M, V, T>                               bicg;
+    Precs<T>                                        pcs;
+    M                                               op; // non-owning view of the caller's matrix
+    bool                                            built = false;
+    LocalSolver(int s, int p)
+        : solver_kind(s)
+        , pc_kind(p)
+    {
+        ls()->Verbose(0);
+        ls()->RecordResidualHistory();
+    }
+    IterativeLinearSolver<M, V, T>* ls()
+    {
+        if(solver_kind == RAMD_SOLVER_GMRES)
+            return &gmres;
+        if(solver_kind == RAMD_SOLVER_BICGSTAB)
+            return &bicg;
+        return &cg;
+    }
+    void init(double a, double r, double d, int mn, int mx) override
+    {
+        ls()->Init(a, r, d, mn, mx);
+    }
+    void set_basis(int m) override
+    {
+        gmres.SetBasisSize(m);
+    }
+    void set_fused(bool f) override
+    {
+        ls()->SetFused(f);
+    }
+    void set_verbose(int v) override
+    {
+        ls()->Verbose(v);
+    }
+    void set_precond_format(int f) override
+    {
+        pcs.mcsgs.SetPrecondMatrixFormat((unsigned)f);
+    }
+    void build(ramd_mat_t h) override
+    {
+        if(built)
+            clear();
+        op.AdoptDeviceHandle(h);
+        ls()->SetOperator(op);
+        if(Solver<M, V, T>* p = pcs.get(pc_kind))
+            ls()->SetPreconditioner(*p);
+        ls()->Build();
+        built = true;
+    }
+    void solve(ramd_vec_t rhs, ramd_vec_t x) override
+    {
+        V vr, vx;
+        vr.AdoptDeviceHandle(rhs);
+        vx.AdoptDeviceHandle(x);
+        ls()->Solve(vr, &vx);
+    }
+    bool precond_apply(ramd_vec_t rhs, ramd_vec_t x) override
+    {
+        Solver<M, V, T>* p = pcs.get(pc_kind);
+        if(!p || !built)
+            return false;
+        V vr, vx;
+        vr.AdoptDeviceHandle(rhs);
+        vx.AdoptDeviceHandle(x);
+        p->SolveZeroSol(vr, &vx);
+        return true;
+    }
+    void result(int* it, int* st, double* res) override
+    {
+        *it  = ls()->GetIterationCount();
+        *st  = ls()->GetSolverStatus();
+        *res = ls()->GetCurrentResidual();
+    }
+    const std::vector<double>& history() override
+    {
+        return ls()->GetResidualHistory();
+    }
+    int num_colors() override
+    {
+        return pcs.mcsgs.GetNumColors();
+    }
+    void clear() override
+    {
+        if(built)
+            ls()->Clear(); // also clears (and detaches) the preconditioner, like the reference
+        built = false;
+    }
+};
+
+struct MixedSolver : SolverBase
+{
+    typedef LocalMatrix<double> MH;
+    typedef LocalVector<double> VH;
+    typedef LocalMatrix<float>  ML;
+    typedef LocalVector<float>  VL;
+    MixedPrecisionDC<MH, VH, double, ML, VL, float> mp;
+    int                                             inner_kind, pc_kind;
+    CG<ML, VL, float>                               cg;
+    GMRES<ML, VL, float>                            gmres;
+    BiCGStab<ML, VL, float>                         bicg;
+    Precs<float>                                    pcs;
+    MH                                              op;
+    bool                                            built = false;
+    MixedSolver(int s, int p)
+        : inner_kind(s)
+        , pc_kind(p)
+    {
+        mp.Verbose(0);
+        mp.RecordResidualHistory();
+        inner()->Verbose(0);
+    }
+    IterativeLinearSolver<ML, VL, float>* inner()
+    {
+        if(inner_kind == RAMD_SOLVER_GMRES)
+            return &gmres;
+        if(inner_kind == RAMD_SOLVER_BICGSTAB)
+            return &bicg;
+        return &cg;
+    }
+    void init(double a, double r, double d, int mn, int mx) override
+    {
+        mp.Init(a, r, d, mn, mx);
+    }
+    void init_inner(double a, double r, double d, int mx) override
+    {
+        inner()->Init(a, r, d, mx);
+    }
+    void set_basis(int m) override
+    {
+        gmres.SetBasisSize(m);
+    }
+    void set_fused(bool f) override
+    {
+        inner()->SetFused(f);
+    }
+    void set_verbose(int v) override
+    {
+        mp.Verbose(v);
+    }
+    void build(ramd_mat_t h) override
+    {
+        if(built)
+            clear();
+        op.AdoptDeviceHandle(h);
+        if(Solver<ML, VL, float>* p = pcs.get(pc_kind))
+            inner()->SetPreconditioner(*p);
+        mp.SetOperator(op);
+        mp.Set(*inner());
+        mp.Build();
+        built = true;
+    }
+    void solve(ramd_vec_t rhs, ramd_vec_t x) override
+    {
+        VH vr, vx;
+        vr.AdoptDeviceHandle(rhs);
+        vx.AdoptDeviceHandle(x);
+        mp.Solve(vr, &vx);
+    }
+    bool precond_apply(ramd_vec_t, ramd_vec_t) override
+    {
+        return false;
+    }
+    void result(int* it, int* st, double* res) override
+    {
+        *it  = mp.GetIterationCount();
+        *st  = mp.GetSolverStatus();
+        *res = mp.GetCurrentResidual();
+    }
+    const std::vector<double>& history() override
+    {
+        return mp.GetResidualHistory();
+    }
+    void clear() override
+    {
+        if(built)
+            mp.Clear();
+        built = false;
+    }
+};
+
+} // namespace
+
+struct ramd_solver_s
+{
+    std::unique_ptr<SolverBase> impl;
+};
+
+// ------------------------------------------------------------------------------------ distributed
+struct ramd_gsolver_s
+{
+    typedef GlobalMatrix<double> GM;
+    typedef GlobalVector<double> GV;
+    typedef LocalMatrix<double>  LM;
+    typedef LocalVector<double>  LV;
+    ParallelManager              pm;
+    GM                           A;
+    GV                           x, rhs, tmp;
+    int                          solver_kind, pc_kind;
+    CG<GM, GV, double>           cg;
+    GMRES<GM, GV, double>        gmres;
+    BiCGStab<GM, GV, double>     bicg;
+    Jacobi<GM, GV, double>       jacobi; // global Jacobi == interior diagonal
+    BlockJacobi<GM, GV, double>  bj;
+    ILU<LM, LV, double>          ilu;
+    MultiColoredSGS<LM, LV, double> mcsgs;
+    bool                         setup = false, built = false;
+    IterativeLinearSolver<GM, GV, double>* ls()
+    {
+        if(solver_kind == RAMD_SOLVER_GMRES)
+            return &gmres;
+        if(solver_kind == RAMD_SOLVER_BICGSTAB)
+            return &bicg;
+        return &cg;
+    }
+    void alloc_vectors()
+    {
+        GV* vs[] = {&x, &rhs, &tmp};
+        for(GV* v : vs)
+        {
+            v->SetParallelManager(pm);
+            v->MoveToAccelerator();
+            v->Allocate("v", pm.GetGlobalNrow());
+        }
+    }
+};
+
+#define GUARD_BEGIN try {
+#define GUARD_END                                       \
+    }                                                   \
+    catch(const std::exception& e)                      \
+    {                                                   \
+        fprintf(stderr, "rocalution_amd: %s\n", e.what()); \
+        return RAMD_ERR_STATE;                          \
+    }                                                   \
+    return RAMD_OK;
+
+extern "C" {
+
+int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out)
+{
+    if(!out || solver < 0 || solver > 2 || precond < 0 || precond > 3
+       || (dtype != RAMD_F64 && dtype != RAMD_F32))
+        return RAMD_ERR_ARG;
+    GUARD_BEGIN
+    ramd_solver_s* s = new ramd_solver_s;
+    if(dtype == RAMD_F64)
+        s->impl.reset(new LocalSolver<double>(solver, precond));
+    else
+        s->impl.reset(new LocalSolver<float>(solver, precond));
+    *out = s;
+    GUARD_END
+}
+
+int ramd_solver_create_mixed(int inner_solver, int inner_precond, ramd_solver_t* out)
+{
+    if(!out || inner_solver < 0 || inner_solver > 2 || inner_precond < 0 || inner_precond > 3)
+        return RAMD_ERR_ARG;
+    GUARD_BEGIN
+    ramd_solver_s* s = new ramd_solver_s;
+    s->impl.reset(new MixedSolver(inner_solver, inner_precond));
+    *out = s;
+    GUARD_END
+}
+
+int ramd_solver_destroy(ramd_solver_t s)
+{
+    if(s)
+    {
+        s->impl->clear();
+        delete s;
+    }
+    return RAMD_OK;
+}
+
+int ramd_solver_init(ramd_solver_t s, double a, double r, double d, int mn, int mx)
+{
+    if(!s || mn < 0 || mx < mn)
+        return RAMD_ERR_ARG;
+    s->impl->init(a, r, d, mn, mx);
+    return RAMD_OK;
+}
+int ramd_solver_init_inner(ramd_solver_t s, double a, double r, double d, int mx)
+{
+    if(!s)
+        return RAMD_ERR_ARG;
+    s->impl->init_inner(a, r, d, mx);
+    return RAMD_OK;
+}
+int ramd_solver_set_basis(ramd_solver_t s, int m)
+{
+    if(!s || m < 1)
+        return RAMD_ERR_ARG;
+    s->impl->set_basis(m);
+    return RAMD_OK;
+}
+int ramd_solver_set_fused(ramd_solver_t s, int on)
+{
+    if(!s)
+        return RAMD_ERR_ARG;
+    s->impl->set_fused(on != 0);
+    return RAMD_OK;
+}
+int ramd_solver_set_verbose(ramd_solver_t s, int v)
+{
+    if(!s)
+        return RAMD_ERR_ARG;
+    s->impl->set_verbose(v);
+    return RAMD_OK;
+}
+int ramd_solver_set_precond_format(ramd_solver_t s, int f)
+{
+    if(!s)
+        return RAMD_ERR_ARG;
+    s->impl->set_precond_format(f);
+    return RAMD_OK;
+}
+int ramd_solver_build(ramd_solver_t s, ramd_mat_t op)
+{
+    if(!s || !op)
+        return RAMD_ERR_ARG;
+    GUARD_BEGIN
+    s->impl->build(op);
+    GUARD_END
+}
+int ramd_solver_solve(ramd_solver_t s, ramd_vec_t rhs, ramd_vec_t x)
+{
+    if(!s || !rhs || !x || rhs == x)
+        return RAMD_ERR_ARG;
+    GUARD_BEGIN
+    s->impl->solve(rhs, x);
+    GUARD_END
+}
+int ramd_solver_precond_apply(ramd_solver_t s, ramd_vec_t rhs, ramd_vec_t x)
+{
+    if(!s || !rhs || !x || rhs == x)
+        return RAMD_ERR_ARG;
+    return s->impl->precond_apply(rhs, x) ? RAMD_OK : RAMD_ERR_STATE;
+}
+int ramd_solver_result(ramd_solver_t s, int* iters, int* status, double* final_res)
+{
+    if(!s)
+        return RAMD_ERR_ARG;
+    int    it, st;
+    double res;
+    s->impl->result(&it, &st, &res);
+    if(iters)
+        *iters = it;
+    if(status)
+        *status = st;
+    if(final_res)
+        *final_res = res;
+    return RAMD_OK;
+}
+int ramd_solver_history(ramd_solver_t s, double* buf, int cap, int* len)
+{
+    if(!s)
+        return RAMD_ERR_ARG;
+    const std::vector<double>& h = s->impl->history();
+    if(len)
+        *len = (int)h.size();
+    for(int i = 0; i < cap && i < (int)h.size(); ++i)
+        buf[i] = h[(size_t)i];
+    return RAMD_OK;
+}
+int ramd_solver_num_colors(ramd_solver_t s, int* n)
+{
+    if(!s || !n)
+        return RAMD_ERR_ARG;
+    *n = s->impl->num_colors();
+    return RAMD_OK;
+}
+int ramd_solver_clear(ramd_solver_t s)
+{
+    if(!s)
+        return RAMD_ERR_ARG;
+    s->impl->clear();
+    return RAMD_OK;
+}
+
+// ------------------------------------------------------------------------------------ distributed
+int ramd_gsolver_create(ramd_comm_t comm, int solver, int precond, ramd_gsolver_t* out)
+{
+    if(!out || solver < 0 || solver > 2 || precond < 0 || precond > 3)
+        return RAMD_ERR_ARG;
+    GUARD_BEGIN
+    ramd_gsolver_s* g = new ramd_gsolver_s;
+    g->solver_kind    = solver;
+    g->pc_kind        = precond;
+    g->pm.SetMPICommunicator(comm);
+    g->ls()->Verbose(0);
+    *out = g;
+    GUARD_END
+}
+
+int ramd_gsolver_destroy(ramd_gsolver_t g)
+{
+    if(g)
+    {
+        if(g->built)
+            g->ls()->Clear();
+        delete g;
+    }
+    return RAMD_OK;
+}
+
+int ramd_gsolver_setup_poisson(ramd_gsolver_t g, int N, int z_begin, int z_end)
+{
+    if(!g || N < 1 || z_begin < 0 || z_end > N || z_begin >= z_end)
+        return RAMD_ERR_ARG;
+    GUARD_BEGIN
+    const int64_t N2 = (int64_t)N * N, n = N2 * N;
+    const int64_t lo = z_begin * N2, hi = z_end * N2, nloc = hi - lo;
+    const int     rank = g->pm.GetRank(), np = g->pm.GetNumProcs();
+    // neighbours: lower z-slab first, then upper -- the order of the ghost columns generated by
+    // ramd_mat_gen_poisson7_slab ([lower plane | upper plane])
+    std::vector<int> peers, soff(1, 0), roff(1, 0), bidx;
+    if(z_begin > 0)
+    {
+        if(rank == 0)
+            throw std::runtime_error("setup_poisson: rank 0 must own the first slab");
+        peers.push_back(rank - 1);
+        for(int64_t i = 0; i < N2; ++i)
+            bidx.push_back((int)i); // my first plane goes down
+        soff.push_back((int)bidx.size());
+        roff.push_back(roff.back() + (int)N2);
+    }
+    if(z_end < N)
+    {
+        if(rank == np - 1)
+            throw std::runtime_error("setup_poisson: the last rank must own the last slab");
+        peers.push_back(rank + 1);
+        for(int64_t i = 0; i < N2; ++i)
+            bidx.push_back((int)(nloc - N2 + i)); // my last plane goes up
+        soff.push_back((int)bidx.size());
+        roff.push_back(roff.back() + (int)N2);
+    }
+    g->pm.SetGlobalNrow(n);
+    g->pm.SetGlobalNcol(n);
+    g->pm.SetLocalNrow(nloc);
+    g->pm.SetLocalNcol(nloc);
+    g->pm.SetBoundaryIndex((int)bidx.size(), bidx.data());
+    g->pm.SetReceivers((int)peers.size(), peers.data(), roff.data());
+    g->pm.SetSenders((int)peers.size(), peers.data(), soff.data());
+    g->A.SetParallelManager(g->pm);
+    g->A.GeneratePoisson7Slab(N, lo, hi);
+    g->alloc_vectors();
+    g->setup = true;
+    GUARD_END
+}
+
+int ramd_gsolver_setup_csr(ramd_gsolver_t g, int64_t global_nrow, int local_nrow, int64_t int_nnz,
+                           const int32_t* int_rp, const int32_t* int_ci, const double* int_val,
+                           int64_t gh_nnz, const int32_t* gh_rp, const int32_t* gh_ci,
+                           const double* gh_val, int npeers, const int* peers, const int* send_offset,
+                           const int* recv_offset, const int* boundary_index)
+{
+    if(!g || local_nrow < 0 || !int_rp || !gh_rp || npeers < 0)
+        return RAMD_ERR_ARG;
+    GUARD_BEGIN
+    g->pm.SetGlobalNrow(global_nrow);
+    g->pm.SetGlobalNcol(global_nrow);
+    g->pm.SetLocalNrow(local_nrow);
+    g->pm.SetLocalNcol(local_nrow);
+    const int nsend = npeers ? send_offset[npeers] : 0;
+    g->pm.SetBoundaryIndex(nsend, boundary_index);
+    const int zero[1] = {0};
+    g->pm.SetReceivers(npeers, peers, npeers ? recv_offset : zero);
+    g->pm.SetSenders(npeers, peers, npeers ? send_offset : zero);
+    g->A.SetParallelManager(g->pm);
+    auto dup = [](const auto* p, int64_t n) {
+        typedef typename std::remove_cv<typename std::remove_pointer<decltype(p)>::type>::type X;
+        X* q = new X[(size_t)std::max<int64_t>(n, 1)];
+        std::copy(p, p + n, q);
+        return q;
+    };
+    {
+        PtrType* rp = dup(int_rp, (int64_t)local_nrow + 1);
+        int*     ci = dup(int_ci, int_nnz);
+        double*  va = dup(int_val, int_nnz);
+        g->A.SetLocalDataPtrCSR(&rp, &ci, &va, "A", int_nnz);
+    }
+    {
+        PtrType* rp = dup(gh_rp, (int64_t)local_nrow + 1);
+        int*     ci = dup(gh_ci, gh_nnz);
+        double*  va = dup(gh_val, gh_nnz);
+        g->A.SetGhostDataPtrCSR(&rp, &ci, &va, "A", gh_nnz);
+    }
+    g->A.MoveToAccelerator();
+    g->alloc_vectors();
+    g->setup = true;
+    GUARD_END
+}
+
+int ramd_gsolver_convert(ramd_gsolver_t g, int format)
+{
+    if(!g || !g->setup)
+        return RAMD_ERR_STATE;
+    GUARD_BEGIN
+    g->A.ConvertTo((unsigned)format);
+    GUARD_END
+}
+int ramd_gsolver_init(ramd_gsolver_t g, double a, double r, double d, int mn, int mx)
+{
+    if(!g)
+        return RAMD_ERR_ARG;
+    g->ls()->Init(a, r, d, mn, mx);
+    return RAMD_OK;
+}
+int ramd_gsolver_set_basis(ramd_gsolver_t g, int m)
+{
+    if(!g || m < 1)
+        return RAMD_ERR_ARG;
+    g->gmres.SetBasisSize(m);
+    return RAMD_OK;
+}
+int ramd_gsolver_set_verbose(ramd_gsolver_t g, int v)
+{
+    if(!g)
+        return RAMD_ERR_ARG;
+    g->ls()->Verbose(v);
+    return RAMD_OK;
+}
+int ramd_gsolver_build(ramd_gsolver_t g)
+{
+    if(!g || !g->setup)
+        return RAMD_ERR_STATE;
+    GUARD_BEGIN
+    if(g->built)
+        g->ls()->Clear();
+    g->ls()->SetOperator(g->A);
+    if(g->pc_kind == RAMD_PC_JACOBI)
+        g->ls()->SetPreconditioner(g->jacobi);
+    else if(g->pc_kind == RAMD_PC_ILU0)
+    {
+        g->bj.Set(g->ilu);
+        g->ls()->SetPreconditioner(g->bj);
+    }
+    else if(g->pc_kind == RAMD_PC_MCSGS)
+    {
+        g->bj.Set(g->mcsgs);
+        g->ls()->SetPreconditioner(g->bj);
+    }
+    g->ls()->Build();
+    g->built = true;
+    GUARD_END
+}
+int ramd_gsolver_apply(ramd_gsolver_t g, const double* x_local, double* y_local)
+{
+    if(!g || !g->setup || !x_local || !y_local)
+        return RAMD_ERR_STATE;
+    GUARD_BEGIN
+    g->x.GetInterior().CopyFromHostData(x_local);
+    g->A.Apply(g->x, &g->tmp);
+    g->tmp.GetInterior().CopyToHostData(y_local);
+    GUARD_END
+}
+int ramd_gsolver_solve(ramd_gsolver_t g, const double* rhs_local, double* x_local)
+{
+    if(!g || !g->built || !x_local)
+        return RAMD_ERR_STATE;
+    GUARD_BEGIN
+    if(rhs_local)
+        g->rhs.GetInterior().CopyFromHostData(rhs_local);
+    else
+    {
+        g->tmp.Ones();
+        g->A.Apply(g->tmp, &g->rhs);
+    }
+    g->x.GetInterior().CopyFromHostData(x_local);
+    g->ls()->Solve(g->rhs, &g->x);
+    g->x.GetInterior().CopyToHostData(x_local);
+    GUARD_END
+}
+int ramd_gsolver_solve_ones(ramd_gsolver_t g)
+{
+    if(!g || !g->built)
+        return RAMD_ERR_STATE;
+    GUARD_BEGIN
+    g->tmp.Ones();
+    g->A.Apply(g->tmp, &g->rhs);
+    g->x.Zeros();
+    g->ls()->Solve(g->rhs, &g->x);
+    GUARD_END
+}
+int ramd_gsolver_result(ramd_gsolver_t g, int* iters, int* status, double* final_res)
+{
+    if(!g)
+        return RAMD_ERR_ARG;
+    if(iters)
+        *iters = g->ls()->GetIterationCount();
+    if(status)
+        *status = g->ls()->GetSolverStatus();
+    if(final_res)
+        *final_res = g->ls()->GetCurrentResidual();
+    return RAMD_OK;
+}
+int ramd_gsolver_dot_check(ramd_gsolver_t g, double* xx)
+{
+    if(!g || !g->setup || !xx)
+        return RAMD_ERR_STATE;
+    GUARD_BEGIN
+    *xx = g->x.Dot(g->x);
+    GUARD_END
+}
+
+} // extern "C"

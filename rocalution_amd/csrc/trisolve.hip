@@ -81,6 +81,15 @@ __global__ __launch_bounds__(kBlock) void k_fill_sentinel(int64_t n, T* __restri
         w[i] = s;
 }
 
+// every spin is bounded: a dependency that never arrives (a bug, by construction of the ticket
+// order) becomes a loud kernel abort instead of a hung GPU
+constexpr int kSpinLimit = 1 << 24;
+__device__ __forceinline__ void spin_guard(int& spins)
+{
+    if(++spins > kSpinLimit)
+        __builtin_trap();
+}
+
 // workgroup ticket: the k-th workgroup to START works on block k (deadlock freedom does not depend
 // on the dispatch order).  `base` is the counter value before this launch.
 __device__ __forceinline__ unsigned take_ticket(unsigned* counter, unsigned base)
@@ -108,36 +117,45 @@ __global__ __launch_bounds__(kBlock) void k_levels(int nrow, const int* __restri
     int       j   = rp[i];
     const int end = rp[i + 1];
     int       lev = 0;
-    // NOTE: the result is published INSIDE the loop: lanes of one wave may depend on each other, and
-    // a lane that has left the loop cannot execute anything until the whole wave leaves it.
-    while(true)
+    // SIMT hazard: lanes of one wave may depend on each other, and a lane that has LEFT a loop cannot
+    // execute anything until the whole wave leaves it.  So results are published inside the loop and
+    // the loop exit is made wave-uniform with a ballot (otherwise the compiler is free to sink the
+    // publish into the loop's exit block, which deadlocks).
+    bool fin = false;
+    int  spins = 0;
+    do
     {
-        if(j < end)
+        spin_guard(spins);
+        if(!fin)
         {
-            const int c = ci[j];
-            if(LOWER ? (c >= i) : (c <= i))
+            if(j < end)
             {
-                if(LOWER)
-                    j = end; // sorted rows: nothing below the diagonal follows
+                const int c = ci[j];
+                if(LOWER ? (c >= i) : (c <= i))
+                {
+                    if(LOWER)
+                        j = end; // sorted rows: nothing below the diagonal follows
+                    else
+                        ++j;
+                }
                 else
-                    ++j;
+                {
+                    const int lc
+                        = __hip_atomic_load(level + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if(lc != 0)
+                    {
+                        lev = max(lev, lc);
+                        ++j;
+                    }
+                }
             }
             else
             {
-                const int lc = __hip_atomic_load(level + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if(lc != 0)
-                {
-                    lev = max(lev, lc);
-                    ++j;
-                }
+                __hip_atomic_store(level + i, lev + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                fin = true;
             }
         }
-        else
-        {
-            __hip_atomic_store(level + i, lev + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
-    }
+    } while(__ballot(!fin) != 0ull);
 }
 
 __global__ __launch_bounds__(kBlock) void k_level_hist(int nrow, const int* __restrict__ level,
@@ -269,35 +287,42 @@ __global__ __launch_bounds__(kBlock) void k_trsv(int nrow, const int* __restrict
     int           k    = 0;
     int           c    = (wd > 0) ? nt_load(ecol + b0 + lane) : -1;
     T             a    = (wd > 0) ? nt_load(eval + b0 + lane) : (T)0;
-    // publish inside the loop (see k_levels): small levels can put dependent rows in one wave
-    while(true)
+    // publish inside a wave-uniform-exit loop (see k_levels): small levels can put dependent rows
+    // into one wave
+    bool fin = false;
+    int  spins = 0;
+    do
     {
-        if(c >= 0)
+        spin_guard(spins);
+        if(!fin)
         {
-            const typename Sentinel<T>::bits bits = poll_load(w + c);
-            if(bits != Sentinel<T>::value)
+            if(c >= 0)
             {
-                sum -= a * Sentinel<T>::from_bits(bits);
-                ++k;
-                if(k < wd)
+                const typename Sentinel<T>::bits bits = poll_load(w + c);
+                if(bits != Sentinel<T>::value)
                 {
-                    c = nt_load(ecol + b0 + k * 64 + lane);
-                    a = nt_load(eval + b0 + k * 64 + lane);
+                    sum -= a * Sentinel<T>::from_bits(bits);
+                    ++k;
+                    if(k < wd)
+                    {
+                        c = nt_load(ecol + b0 + k * 64 + lane);
+                        a = nt_load(eval + b0 + k * 64 + lane);
+                    }
+                    else
+                        c = -1;
                 }
-                else
-                    c = -1;
+            }
+            else
+            {
+                if(!UNIT_DIAG)
+                    sum /= diag[t];
+                publish(w + t, sum);
+                if(out)
+                    out[order[t]] = sum;
+                fin = true;
             }
         }
-        else
-        {
-            if(!UNIT_DIAG)
-                sum /= diag[t];
-            publish(w + t, sum);
-            if(out)
-                out[order[t]] = sum;
-            break;
-        }
-    }
+    } while(__ballot(!fin) != 0ull);
 }
 
 // ---------------------------------------------------------------- ILU(0), natural order, sync-free
@@ -324,54 +349,61 @@ __global__ __launch_bounds__(kBlock) void k_ilu0(int nrow, const int* __restrict
     int dj = rs;
     while(dj < re && ci[dj] < i)
         ++dj;
-    while(true)
+    bool fin = false; // wave-uniform loop exit, see k_levels
+    int  spins = 0;
+    do
     {
-        if(j < dj)
+        spin_guard(spins);
+        if(!fin)
         {
-            const int k = ci[j];
-            if(__hip_atomic_load(done + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+            if(j < dj)
             {
-                const int kd  = __hip_atomic_load(diag_pos + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int kre = rp[k + 1];
-                const T   pivot = Sentinel<T>::from_bits(
-                    __hip_atomic_load(reinterpret_cast<const B*>(val + kd), __ATOMIC_RELAXED,
-                                      __HIP_MEMORY_SCOPE_AGENT));
-                if(pivot != (T)0)
+                const int k = ci[j];
+                if(__hip_atomic_load(done + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
                 {
-                    const T f = val[j] / pivot;
-                    val[j]    = f;
-                    int m     = j + 1; // own entries right of (i,k), ascending
-                    for(int q = kd + 1; q < kre; ++q)
+                    const int kd
+                        = __hip_atomic_load(diag_pos + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int kre   = rp[k + 1];
+                    const T   pivot = Sentinel<T>::from_bits(
+                        __hip_atomic_load(reinterpret_cast<const B*>(val + kd), __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT));
+                    if(pivot != (T)0)
                     {
-                        const int cq = ci[q];
-                        while(m < re && ci[m] < cq)
-                            ++m;
-                        if(m >= re)
-                            break;
-                        if(ci[m] == cq)
+                        const T f = val[j] / pivot;
+                        val[j]    = f;
+                        int m     = j + 1; // own entries right of (i,k), ascending
+                        for(int q = kd + 1; q < kre; ++q)
                         {
-                            const T akq = Sentinel<T>::from_bits(
-                                __hip_atomic_load(reinterpret_cast<const B*>(val + q), __ATOMIC_RELAXED,
-                                                  __HIP_MEMORY_SCOPE_AGENT));
-                            val[m] -= f * akq;
+                            const int cq = ci[q];
+                            while(m < re && ci[m] < cq)
+                                ++m;
+                            if(m >= re)
+                                break;
+                            if(ci[m] == cq)
+                            {
+                                const T akq = Sentinel<T>::from_bits(__hip_atomic_load(
+                                    reinterpret_cast<const B*>(val + q), __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT));
+                                val[m] -= f * akq;
+                            }
                         }
                     }
+                    ++j;
                 }
-                ++j;
+            }
+            else
+            {
+                // publish the finished upper part (incl. diagonal) write-through, then the flag
+                for(int q = dj; q < re; ++q)
+                    __hip_atomic_store(reinterpret_cast<B*>(val + q), Sentinel<T>::as_bits(val[q]),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(diag_pos + i, dj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(done + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                fin = true;
             }
         }
-        else
-        {
-            // publish the finished upper part (incl. diagonal) write-through, then the flag
-            for(int q = dj; q < re; ++q)
-                __hip_atomic_store(reinterpret_cast<B*>(val + q), Sentinel<T>::as_bits(val[q]),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(diag_pos + i, dj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(done + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
-    }
+    } while(__ballot(!fin) != 0ull);
 }
 
 // ---------------------------------------------------------------- plans

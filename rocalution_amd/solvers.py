@@ -1,0 +1,189 @@
+"""Krylov solvers / preconditioners: Python handles onto the compiled C++ layer
+(include/rocalution/solvers.hpp, instantiated in csrc/capi_solvers.cpp).
+
+Class and method names follow the reference (src/solvers/solver.hpp:179-444): SetOperator,
+SetPreconditioner, Init, Build, Solve, Clear, GetIterationCount, GetCurrentResidual,
+GetSolverStatus, GMRES.SetBasisSize, MixedPrecisionDC.Set.  The numerical work happens in the
+library; nothing here computes.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import PC_ILU0, PC_JACOBI, PC_MCSGS, PC_NONE, SOLVER_BICGSTAB, SOLVER_CG, SOLVER_GMRES
+
+
+def _lib():
+    return capi.load()
+
+
+class _Precond:
+    kind = PC_NONE
+
+    def __init__(self):
+        self.precond_format = None
+
+    def SetPrecondMatrixFormat(self, fmt):
+        self.precond_format = int(fmt)
+
+
+class Jacobi(_Precond):
+    kind = PC_JACOBI
+
+
+class ILU(_Precond):
+    kind = PC_ILU0
+
+    def Set(self, p, level=True):
+        if p != 0:
+            raise ValueError("only ILU(0) is provided by this backend")
+
+
+class MultiColoredSGS(_Precond):
+    kind = PC_MCSGS
+
+
+class _IterativeLinearSolver:
+    kind = SOLVER_CG
+
+    def __init__(self, dtype=np.float64):
+        self.dtype = np.dtype(dtype)
+        self._h = None
+        self._op = None
+        self._precond = None
+        self._init = None
+        self._basis = None
+        self._fused = True
+        self._verbose = 0
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib().ramd_solver_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def SetOperator(self, op):
+        self._op = op
+
+    def SetPreconditioner(self, p):
+        self._precond = p
+
+    def Init(self, abs_tol, rel_tol, div_tol, max_iter, min_iter=0):
+        self._init = (float(abs_tol), float(rel_tol), float(div_tol), int(min_iter), int(max_iter))
+
+    def InitMaxIter(self, max_iter):
+        a = self._init or (1e-15, 1e-6, 1e8, 0, 1000000)
+        self._init = (a[0], a[1], a[2], a[3], int(max_iter))
+
+    def SetFused(self, on):
+        self._fused = bool(on)
+
+    def Verbose(self, v=1):
+        self._verbose = int(v)
+
+    def _create(self):
+        h = C.c_void_p()
+        pk = self._precond.kind if self._precond is not None else PC_NONE
+        dt = capi.F64 if self.dtype == np.float64 else capi.F32
+        capi.check(_lib().ramd_solver_create(self.kind, pk, dt, C.byref(h)))
+        return h
+
+    def Build(self):
+        assert self._op is not None
+        if self._h:
+            _lib().ramd_solver_destroy(self._h)
+        self._h = self._create()
+        if self._init:
+            capi.check(_lib().ramd_solver_init(self._h, *self._init))
+        if self._basis:
+            capi.check(_lib().ramd_solver_set_basis(self._h, self._basis))
+        if self._precond is not None and self._precond.precond_format is not None:
+            capi.check(_lib().ramd_solver_set_precond_format(self._h, self._precond.precond_format))
+        capi.check(_lib().ramd_solver_set_fused(self._h, int(self._fused)))
+        capi.check(_lib().ramd_solver_set_verbose(self._h, self._verbose))
+        self._configure_extra()
+        capi.check(_lib().ramd_solver_build(self._h, self._op._h))
+
+    def _configure_extra(self):
+        pass
+
+    def Solve(self, rhs, x):
+        capi.check(_lib().ramd_solver_solve(self._h, rhs._h, x._h))
+
+    def PrecondApply(self, rhs, x):
+        capi.check(_lib().ramd_solver_precond_apply(self._h, rhs._h, x._h))
+
+    def Clear(self):
+        if self._h:
+            capi.check(_lib().ramd_solver_clear(self._h))
+
+    def _result(self):
+        it, st, res = C.c_int(0), C.c_int(0), C.c_double(0)
+        capi.check(_lib().ramd_solver_result(self._h, C.byref(it), C.byref(st), C.byref(res)))
+        return it.value, st.value, res.value
+
+    def GetIterationCount(self):
+        return self._result()[0]
+
+    def GetSolverStatus(self):
+        return self._result()[1]
+
+    def GetCurrentResidual(self):
+        return self._result()[2]
+
+    def GetNumColors(self):
+        n = C.c_int(0)
+        capi.check(_lib().ramd_solver_num_colors(self._h, C.byref(n)))
+        return n.value
+
+    def GetResidualHistory(self):
+        n = C.c_int(0)
+        capi.check(_lib().ramd_solver_history(self._h, None, 0, C.byref(n)))
+        buf = np.zeros(max(n.value, 1), dtype=np.float64)
+        capi.check(_lib().ramd_solver_history(self._h, buf.ctypes.data_as(C.POINTER(C.c_double)), n.value,
+                                              C.byref(n)))
+        return buf[:n.value]
+
+
+class CG(_IterativeLinearSolver):
+    kind = SOLVER_CG
+
+
+class GMRES(_IterativeLinearSolver):
+    kind = SOLVER_GMRES
+
+    def SetBasisSize(self, m):
+        self._basis = int(m)
+
+
+class BiCGStab(_IterativeLinearSolver):
+    kind = SOLVER_BICGSTAB
+
+
+class MixedPrecisionDC(_IterativeLinearSolver):
+    """MixedPrecisionDC<fp64, fp32>: Set(inner) takes a float32 CG/GMRES/BiCGStab object whose
+    preconditioner and Init() settings are applied to the inner solver."""
+
+    def __init__(self):
+        super().__init__(np.float64)
+        self._inner = None
+
+    def Set(self, inner):
+        self._inner = inner
+
+    def _create(self):
+        h = C.c_void_p()
+        pk = self._inner._precond.kind if self._inner._precond is not None else PC_NONE
+        capi.check(_lib().ramd_solver_create_mixed(self._inner.kind, pk, C.byref(h)))
+        return h
+
+    def _configure_extra(self):
+        if self._inner._init:
+            a = self._inner._init
+            capi.check(_lib().ramd_solver_init_inner(self._h, a[0], a[1], a[2], a[4]))
+        if self._inner._basis:
+            capi.check(_lib().ramd_solver_set_basis(self._h, self._inner._basis))
+        capi.check(_lib().ramd_solver_set_fused(self._h, int(self._inner._fused)))

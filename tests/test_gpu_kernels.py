@@ -64,9 +64,15 @@ def test_blas1_sizes_vs_oracle(ra, oracle, n, dtype):
     b = rng.uniform(-1, 1, n).astype(dtype)
     c = rng.uniform(-1, 1, n).astype(dtype)
     va, vb, vc = (ra.LocalVector(dtype, data=v) for v in (a, b, c))
-    rtol = 1e-12 if dtype == np.float64 else 2e-4  # the fp32 reference sums in fp32
     if n:
-        close(va.Dot(vb), float(oracle.dot(a, b)), rtol * 10 + 1e-15)
+        # exact (fp64) values: the kernels accumulate in fp64 with a fixed-order tree
+        a64, b64 = a.astype(np.float64), b.astype(np.float64)
+        assert abs(va.Dot(vb) - np.dot(a64, b64)) <= 1e-12 * np.abs(a64 * b64).sum() + 1e-300
+        close(va.Norm(), float(np.sqrt(np.dot(a64, a64))), 1e-13)
+        # the oracle sums like the reference (sequentially, in ValueType): fp32 sums of 1e6 terms are
+        # only good to ~1e-3 there, so the oracle comparison is loose for fp32 and tight for fp64
+        rtol = 1e-12 if dtype == np.float64 else 2e-3
+        assert abs(va.Dot(vb) - float(oracle.dot(a, b))) <= rtol * np.abs(a64 * b64).sum() + 1e-300
         close(va.Norm(), float(oracle.norm(a)), rtol)
         assert abs(va.Asum() - np.abs(a.astype(np.float64)).sum()) <= 1e-6 * max(1, n)
         i, v = va.Amax()
