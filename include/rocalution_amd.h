@@ -195,6 +195,15 @@ int ramd_fused_mgs_step(ramd_vec_t w, ramd_vec_t v, int slot_h, ramd_vec_t u, in
 /* v = v * (1/s[slot]) with s[slot] = sqrt(s[slot_sq]) computed on device (gmres.cpp:493-496) */
 int ramd_fused_normalize(ramd_vec_t v, int slot_sq, int slot_norm);
 
+/* ======================================================================= measurement hooks
+ * HIP-event timing on the stream the kernels are launched on (bench.py): a stopwatch around any
+ * region, and an optional per-launch bracket of every SpMV (Apply / fused Apply+dot) so that the
+ * kernel's average duration is measured live inside a solver run. */
+int ramd_timer_start(void); /* records an event on the current stream */
+int ramd_timer_stop(double* elapsed_ms); /* records, synchronises, returns the elapsed time */
+int ramd_prof_spmv_enable(int on); /* bracket SpMV launches with event pairs (ring of 8192) */
+int ramd_prof_spmv_result(int* launches, double* avg_ms, double* min_ms, double* max_ms);
+
 /* ======================================================================= communicator
  * Replaces the reference's MPI layer for the hot path (src/utils/communicator.cpp:41-95 allreduce,
  * :606-748 Isend/Irecv/Waitall, used by GlobalMatrix::Apply src/base/global_matrix.cpp:924-1009 and
@@ -279,6 +288,8 @@ int ramd_gsolver_build(ramd_gsolver_t g);
 int ramd_gsolver_apply(ramd_gsolver_t g, const double* x_local, double* y_local); /* y = A x (test hook) */
 int ramd_gsolver_solve(ramd_gsolver_t g, const double* rhs_local, double* x_local); /* NULL rhs: A*1 ; x0 = x_local or 0 */
 int ramd_gsolver_solve_ones(ramd_gsolver_t g); /* rhs = A*1, x0 = 0, everything stays on the device */
+int ramd_gsolver_prepare_ones(ramd_gsolver_t g); /* rhs = A*1, x = 0 (on the device) */
+int ramd_gsolver_solve_device(ramd_gsolver_t g); /* Solve(rhs, &x) on the prepared device vectors */
 int ramd_gsolver_result(ramd_gsolver_t g, int* iters, int* status, double* final_res);
 int ramd_gsolver_dot_check(ramd_gsolver_t g, double* x_dot_x); /* <x,x> over all ranks after a solve */
 

@@ -115,6 +115,11 @@ SIGNATURES = {
     "ramd_fused_multi_dot": (i32, [C.POINTER(vec_t), i32, vec_t, i32]),
     "ramd_fused_mgs_step": (i32, [vec_t, vec_t, i32, vec_t, i32]),
     "ramd_fused_normalize": (i32, [vec_t, i32, i32]),
+    # measurement hooks
+    "ramd_timer_start": (i32, []),
+    "ramd_timer_stop": (i32, [pf64]),
+    "ramd_prof_spmv_enable": (i32, [i32]),
+    "ramd_prof_spmv_result": (i32, [pi32, pf64, pf64, pf64]),
     # communicator
     "ramd_comm_unique_id": (i32, [C.c_char_p]),
     "ramd_comm_init_rccl": (i32, [i32, i32, C.c_char_p, C.POINTER(ptr)]),
@@ -156,6 +161,8 @@ SIGNATURES = {
     "ramd_gsolver_apply": (i32, [ptr, ptr, ptr]),
     "ramd_gsolver_solve": (i32, [ptr, ptr, ptr]),
     "ramd_gsolver_solve_ones": (i32, [ptr]),
+    "ramd_gsolver_prepare_ones": (i32, [ptr]),
+    "ramd_gsolver_solve_device": (i32, [ptr]),
     "ramd_gsolver_result": (i32, [ptr, pi32, pi32, pf64]),
     "ramd_gsolver_dot_check": (i32, [ptr, pf64]),
 }

@@ -190,6 +190,97 @@ int ramd_free_pinned(void* ptr)
     return RAMD_OK;
 }
 
+// ---------------------------------------------------------------- measurement hooks
+static hipEvent_t g_t0 = nullptr, g_t1 = nullptr;
+
+int ramd_timer_start(void)
+{
+    RAMD_TRY(ensure_init());
+    if(!g_t0)
+    {
+        RAMD_HIP(hipEventCreate(&g_t0));
+        RAMD_HIP(hipEventCreate(&g_t1));
+    }
+    RAMD_HIP(hipEventRecord(g_t0, backend().cur));
+    return RAMD_OK;
+}
+int ramd_timer_stop(double* elapsed_ms)
+{
+    if(!g_t0)
+        RAMD_FAIL(RAMD_ERR_STATE, "timer_stop without timer_start");
+    RAMD_HIP(hipEventRecord(g_t1, backend().cur));
+    RAMD_HIP(hipEventSynchronize(g_t1));
+    float ms = 0.f;
+    RAMD_HIP(hipEventElapsedTime(&ms, g_t0, g_t1));
+    if(elapsed_ms)
+        *elapsed_ms = (double)ms;
+    return RAMD_OK;
+}
+
+} // extern "C"
+
+namespace ramd
+{
+constexpr int     kProfRing = 8192;
+static bool       g_prof_on = false;
+static int        g_prof_n  = 0;
+static hipEvent_t g_prof_ev[2 * kProfRing];
+static bool       g_prof_init = false;
+
+void prof_spmv_begin()
+{
+    if(g_prof_on && g_prof_n < kProfRing)
+        (void)hipEventRecord(g_prof_ev[2 * g_prof_n], backend().cur);
+}
+void prof_spmv_end()
+{
+    if(g_prof_on && g_prof_n < kProfRing)
+    {
+        (void)hipEventRecord(g_prof_ev[2 * g_prof_n + 1], backend().cur);
+        ++g_prof_n;
+    }
+}
+} // namespace ramd
+
+extern "C" {
+
+int ramd_prof_spmv_enable(int on)
+{
+    RAMD_TRY(ensure_init());
+    if(on && !g_prof_init)
+    {
+        for(int i = 0; i < 2 * kProfRing; ++i)
+            RAMD_HIP(hipEventCreate(&g_prof_ev[i]));
+        g_prof_init = true;
+    }
+    g_prof_on = on != 0;
+    if(on)
+        g_prof_n = 0;
+    return RAMD_OK;
+}
+int ramd_prof_spmv_result(int* launches, double* avg_ms, double* min_ms, double* max_ms)
+{
+    RAMD_HIP(hipDeviceSynchronize());
+    double sum = 0.0, mn = 1e30, mx = 0.0;
+    for(int i = 0; i < g_prof_n; ++i)
+    {
+        float ms = 0.f;
+        RAMD_HIP(hipEventElapsedTime(&ms, g_prof_ev[2 * i], g_prof_ev[2 * i + 1]));
+        sum += ms;
+        mn = ms < mn ? ms : mn;
+        mx = ms > mx ? ms : mx;
+    }
+    if(launches)
+        *launches = g_prof_n;
+    if(avg_ms)
+        *avg_ms = g_prof_n ? sum / g_prof_n : 0.0;
+    if(min_ms)
+        *min_ms = g_prof_n ? mn : 0.0;
+    if(max_ms)
+        *max_ms = mx;
+    return RAMD_OK;
+}
+
 // ---------------------------------------------------------------- scalar records
 int ramd_scalars_set(int slot, double value)
 {

@@ -655,6 +655,24 @@ int ramd_gsolver_solve_ones(ramd_gsolver_t g)
     g->ls()->Solve(g->rhs, &g->x);
     GUARD_END
 }
+int ramd_gsolver_prepare_ones(ramd_gsolver_t g)
+{
+    if(!g || !g->setup)
+        return RAMD_ERR_STATE;
+    GUARD_BEGIN
+    g->tmp.Ones();
+    g->A.Apply(g->tmp, &g->rhs);
+    g->x.Zeros();
+    GUARD_END
+}
+int ramd_gsolver_solve_device(ramd_gsolver_t g)
+{
+    if(!g || !g->built)
+        return RAMD_ERR_STATE;
+    GUARD_BEGIN
+    g->ls()->Solve(g->rhs, &g->x);
+    GUARD_END
+}
 int ramd_gsolver_result(ramd_gsolver_t g, int* iters, int* status, double* final_res)
 {
     if(!g)

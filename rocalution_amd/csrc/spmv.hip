@@ -14,6 +14,7 @@
 // cache-resident thanks to the XCD-aware row mapping), parks the products in LDS, and then each
 // thread adds up ITS row's products sequentially from LDS.  Bandwidth-bound: 12 B/nnz + 20 B/row.
 #include "device_utils.hpp"
+#include "matrix_impl.hpp"
 
 namespace ramd
 {
@@ -332,7 +333,19 @@ static int launch_coo(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar)
 
 // mode 0: Apply, 1: ApplyAdd
 template <typename T>
+static int mat_apply_inner(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar);
+
+template <typename T>
 int mat_apply_impl(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar)
+{
+    prof_spmv_begin();
+    int s = mat_apply_inner<T>(m, x, y, mode, scalar);
+    prof_spmv_end();
+    return s;
+}
+
+template <typename T>
+static int mat_apply_inner(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar)
 {
     Backend& b = backend();
     // LocalMatrix::Apply zero-fills when nnz == 0, ApplyAdd does nothing
@@ -371,7 +384,12 @@ template <typename T>
 int mat_apply_dot_impl(const ramd_mat_s* m, const T* x, T* y, int slot)
 {
     if(m->format == RAMD_CSR && m->nnz > 0 && m->nrow == m->ncol)
-        return launch_csr<T>(m, x, y, 0, (T)1, true, slot);
+    {
+        prof_spmv_begin();
+        int s = launch_csr<T>(m, x, y, 0, (T)1, true, slot);
+        prof_spmv_end();
+        return s;
+    }
     return RAMD_ERR_UNSUPPORTED; // caller falls back to apply + dot (two launches)
 }
 template int mat_apply_dot_impl<double>(const ramd_mat_s*, const double*, double*, int);
