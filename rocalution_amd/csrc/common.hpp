@@ -157,6 +157,7 @@ struct ramd_mat_s
     bool  l_diag_unit = true, u_diag_unit = false;
     int*  diag_pos = nullptr; // [nrow] position of the first entry with col >= row (ILU0)
     void* tri      = nullptr; // ramd::TriState* (level-ordered solve plans), trisolve.hip
-    // CSR SpMV analysis
-    int max_row_nnz = -1;
+    // workspace of the fused CSR SpMV + <x,y> (spmv.hip)
+    double* dot_part1 = nullptr; // [dot_nblk] per-workgroup partials
+    int     dot_nblk  = 0;
 };

@@ -26,6 +26,9 @@ int mat_apply_impl(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar);
 template <typename T>
 int mat_apply_dot_impl(const ramd_mat_s* m, const T* x, T* y, int slot);
 
+// vector.hip: scalars[slot] = sum(a[0..n)) in one launch, fixed order
+int reduce_sum_to_slot(const double* a, int64_t n, int slot);
+
 // scan.hip: out[i] = sum_{k<i} in[k] for i < n (in and out may alias); int32 sums
 int device_exclusive_scan(const int* in, int* out, int64_t n);
 // max over an int array -> host

@@ -8,11 +8,8 @@
 //  host_matrix_hyb.cpp:330-364; host_matrix_coo.cpp:368-376), so y is bit-identical to the
 // OpenMP backend (products are formed as in the reference, no FMA contraction).
 //
-// CSR kernel ("stream" layout): a 256-thread workgroup owns 256 consecutive rows.  Its nnz range
-// is contiguous in val/col, so the workgroup streams it with fully coalesced 16-byte loads
-// (non-temporal: read once), gathers x through L1/L2 (x is the only reused operand and stays
-// cache-resident thanks to the XCD-aware row mapping), parks the products in LDS, and then each
-// thread adds up ITS row's products sequentially from LDS.  Bandwidth-bound: 12 B/nnz + 20 B/row.
+// CSR kernel: see k_csr_tr below (row-blocked, LDS-staged, XCD-aware).  Bandwidth-bound:
+// 12 B/nnz + 20 B/row of algorithmic traffic (clients/samples/benchmark.cpp:213-233 accounting).
 #include "device_utils.hpp"
 #include "matrix_impl.hpp"
 
@@ -20,66 +17,66 @@ namespace ramd
 {
 
 constexpr int kCsrRows  = 256; // rows per workgroup (one per thread)
-constexpr int kCsrChunk = 2048; // products staged in LDS per pass (16 KiB fp64)
+constexpr int kCsrChunk = 2048; // entries staged in LDS per pass (16 KiB values + 8 KiB columns)
 
-// XCD-aware persistent mapping: hardware places workgroup b on XCD b % 8 (observed, used for speed
-// only).  Every XCD gets one contiguous eighth of the row blocks, and the (up to) 256 workgroups
-// of an XCD walk that eighth block-cyclically -- the same order a plain launch would dispatch
-// them in -- so rows that gather the same x planes are in flight on the same L2 at the same time.
-// A persistent grid (<= kReduceBlocks workgroups) also gives the fused <x,y> reduction exactly one
-// partial per workgroup.
-constexpr int kCsrWgPerXcd = kReduceBlocks / 8;
+// XCD-aware mapping: hardware places workgroup b on XCD b % 8 (observed, used for speed only).
+// Every XCD gets one contiguous eighth of the row blocks and walks it in dispatch order, so rows that
+// gather the same x planes are in flight on the same L2 at the same time.
+__device__ __forceinline__ int xcd_block(int nblk, int per_xcd)
+{
+    const int b = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    return b < nblk ? b : -1;
+}
 
 template <typename T>
-struct ValPack4; // 4 consecutive values as 16-byte packets
+struct ValPk; // 16-byte packet of values
 template <>
-struct ValPack4<double>
+struct ValPk<double>
 {
-    v2f64 a, b;
-    __device__ __forceinline__ void load(const double* p)
-    {
-        a = nt_load(reinterpret_cast<const v2f64*>(p));
-        b = nt_load(reinterpret_cast<const v2f64*>(p) + 1);
-    }
-    __device__ __forceinline__ double get(int e) const
-    {
-        return e == 0 ? a.x : e == 1 ? a.y : e == 2 ? b.x : b.y;
-    }
+    using type             = v2f64;
+    static constexpr int N = 2;
 };
 template <>
-struct ValPack4<float>
+struct ValPk<float>
 {
-    v4f32 a;
-    __device__ __forceinline__ void load(const float* p)
-    {
-        a = nt_load(reinterpret_cast<const v4f32*>(p));
-    }
-    __device__ __forceinline__ float get(int e) const
-    {
-        return e == 0 ? a.x : e == 1 ? a.y : e == 2 ? a.z : a.w;
-    }
+    using type             = v4f32;
+    static constexpr int N = 4;
 };
 
-// MODE 0: y = A x      MODE 1: y += scalar * A x (term by term into y, as the host ApplyAdd)
-// DOT: additionally reduce <x, y> into scalar slot `slot` (needs a square matrix)
-template <typename T, int MODE, bool DOT>
-__global__ __launch_bounds__(kBlock) void k_csr_stream(int nrow, int per_xcd, int wg_per_xcd,
-                                                       const int* __restrict__ rp,
-                                                       const int* __restrict__ ci,
-                                                       const T* __restrict__ val,
-                                                       const T* __restrict__ x, T* __restrict__ y,
-                                                       T scalar, ReduceCtx ctx, int slot)
+// workspace of the fused <x, y> epilogue
+struct CsrDotWs
 {
-    __shared__ T      prod[kCsrChunk];
+    double* part1; // [nblk] one partial per workgroup
+};
+
+// CSR SpMV, "LDS transpose" layout.  Measured on MI355X (tools/spmv_lab.py): the kernel is bound by
+// HBM *and* by L1/TA line throughput, so every global access is made as line-efficient as possible:
+//   1. the workgroup's contiguous nnz range is streamed RAW into LDS with independent, fully
+//      coalesced 16-byte packets (int4 columns, double2/float4 values; non-temporal: read once);
+//   2. thread t then walks ITS row in LDS and gathers x[col] -- lanes = consecutive rows, so for
+//      banded matrices a gather instruction touches ~4 cache lines instead of ~10, and same-row
+//      neighbours hit the same lines;
+//   3. the row sum runs left to right in storage order (bit-identical to the host backend);
+//      y is written once, non-temporal.
+// MODE 0: y = A x      MODE 1: y += scalar * A x (term by term into y, as the host ApplyAdd)
+// DOT   : additionally reduce <x, y> into scalar slot `slot` (square matrix)
+template <typename T, int MODE, bool DOT>
+__global__ __launch_bounds__(kBlock) void k_csr_tr(int nrow, int nblk, int per_xcd,
+                                                   const int* __restrict__ rp,
+                                                   const int* __restrict__ ci,
+                                                   const T* __restrict__ val,
+                                                   const T* __restrict__ x, T* __restrict__ y, T scalar,
+                                                   CsrDotWs ws, int slot)
+{
+    using VP          = typename ValPk<T>::type;
+    constexpr int VN  = ValPk<T>::N;
+    __shared__ T      sval[kCsrChunk];
+    __shared__ int    scol[kCsrChunk];
     __shared__ double red[8];
-    const int xcd  = blockIdx.x & 7;
-    const int nblk = (nrow + kCsrRows - 1) / kCsrRows;
+    const int blk  = xcd_block(nblk, per_xcd);
     double    dacc = 0.0;
-    for(int lb = blockIdx.x >> 3; lb < per_xcd; lb += wg_per_xcd)
+    if(blk >= 0)
     {
-        const int blk = xcd * per_xcd + lb;
-        if(blk >= nblk)
-            break;
         const int r0   = blk * kCsrRows;
         const int rend = min(r0 + kCsrRows, nrow);
         const int row  = r0 + threadIdx.x;
@@ -96,59 +93,86 @@ __global__ __launch_bounds__(kBlock) void k_csr_stream(int nrow, int per_xcd, in
             sum = y[row];
         for(int cb = start & ~3; cb < end; cb += kCsrChunk)
         {
-            // ---- stream val/col, gather x, park products
+            v4i32 c[kCsrChunk / (4 * kBlock)];
+            VP    a[kCsrChunk / (VN * kBlock)];
+#pragma unroll
+            for(int k = 0; k < kCsrChunk / (4 * kBlock); ++k)
+            {
+                const int j = cb + (k * kBlock + threadIdx.x) * 4;
+                if(j < end)
+                    c[k] = nt_load(reinterpret_cast<const v4i32*>(ci + j));
+            }
+#pragma unroll
+            for(int k = 0; k < kCsrChunk / (VN * kBlock); ++k)
+            {
+                const int j = cb + (k * kBlock + threadIdx.x) * VN;
+                if(j < end)
+                    a[k] = nt_load(reinterpret_cast<const VP*>(val + j));
+            }
 #pragma unroll
             for(int k = 0; k < kCsrChunk / (4 * kBlock); ++k)
             {
                 const int g = (k * kBlock + threadIdx.x) * 4;
-                const int j = cb + g;
-                if(j < end)
-                {
-                    v4i32 c = nt_load(reinterpret_cast<const v4i32*>(ci + j));
-                    ValPack4<T> v;
-                    v.load(val + j);
-                    const int cc[4] = {c.x, c.y, c.z, c.w};
-                    T         p[4];
+                if(cb + g < end)
+                    *reinterpret_cast<v4i32*>(scol + g) = c[k];
+            }
 #pragma unroll
-                    for(int e = 0; e < 4; ++e)
-                    {
-                        const int jj = j + e;
-                        if(jj >= start && jj < end)
-                        {
-                            if(MODE == 0)
-                                p[e] = v.get(e) * x[cc[e]];
-                            else
-                                p[e] = scalar * v.get(e) * x[cc[e]];
-                        }
-                        else
-                            p[e] = (T)0;
-                    }
-#pragma unroll
-                    for(int e = 0; e < 4; ++e)
-                        prod[g + e] = p[e];
-                }
+            for(int k = 0; k < kCsrChunk / (VN * kBlock); ++k)
+            {
+                const int g = (k * kBlock + threadIdx.x) * VN;
+                if(cb + g < end)
+                    *reinterpret_cast<VP*>(sval + g) = a[k];
             }
             __syncthreads();
-            // ---- every thread adds up its own row, left to right
-            const int lo = max(rs, cb);
-            const int hi = min(re, cb + kCsrChunk);
-            for(int j = lo; j < hi; ++j)
-                sum += prod[j - cb];
+            const int lo = max(rs, cb), hi = min(re, cb + kCsrChunk);
+            int       j  = lo;
+            for(; j + 4 <= hi; j += 4) // issue 4 independent gathers, then accumulate IN ORDER
+            {
+                int cc[4];
+                T   v[4], xv[4];
+#pragma unroll
+                for(int e = 0; e < 4; ++e)
+                {
+                    cc[e] = scol[j - cb + e];
+                    v[e]  = sval[j - cb + e];
+                }
+#pragma unroll
+                for(int e = 0; e < 4; ++e)
+                    xv[e] = x[cc[e]];
+#pragma unroll
+                for(int e = 0; e < 4; ++e)
+                {
+                    if(MODE == 0)
+                        sum += v[e] * xv[e];
+                    else
+                        sum += scalar * v[e] * xv[e];
+                }
+            }
+            for(; j < hi; ++j)
+            {
+                if(MODE == 0)
+                    sum += sval[j - cb] * x[scol[j - cb]];
+                else
+                    sum += scalar * sval[j - cb] * x[scol[j - cb]];
+            }
             __syncthreads();
         }
         if(row < nrow)
         {
             nt_store(sum, y + row);
             if(DOT)
-                dacc += (double)sum * (double)x[row];
+                dacc = (double)sum * (double)x[row];
         }
     }
     if(DOT)
     {
-        const double vals[1]  = {dacc};
-        const int    slots[1] = {slot};
-        const int    ops[1]   = {RED_SUM};
-        grid_reduce_finish<1>(ctx, vals, slots, ops, red);
+        // one partial per workgroup, fire-and-forget; a tiny second launch (reduce_sum_to_slot) adds the
+        // partials in a fixed order.  (A ticketed in-kernel finish was measured 9% slower: every
+        // workgroup would have to drain its partial store before taking the ticket, which holds its
+        // wave slots for a full memory round trip.)
+        const double bsum = block_reduce_sum(dacc, red);
+        if(threadIdx.x == 0 && blk >= 0)
+            ws.part1[blk] = bsum;
     }
 }
 
@@ -271,12 +295,22 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
     Backend&  b       = backend();
     const int nblk    = (m->nrow + kCsrRows - 1) / kCsrRows;
     const int per_xcd = (nblk + 7) / 8;
-    const int wg_xcd  = std::min(per_xcd, kCsrWgPerXcd);
-    const int grid    = wg_xcd * 8;
-    ReduceCtx ctx     = reduce_ctx();
-#define LAUNCH(MODE, DOT)                                                                           \
-    hipLaunchKernelGGL((k_csr_stream<T, MODE, DOT>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow,   \
-                       per_xcd, wg_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ctx, slot)
+    const int grid    = per_xcd * 8;
+    CsrDotWs  ws      = {};
+    if(dot)
+    {
+        ramd_mat_s* mm = const_cast<ramd_mat_s*>(m);
+        if(!mm->dot_part1 || mm->dot_nblk != nblk)
+        {
+            dev_free(&mm->dot_part1);
+            RAMD_TRY(dev_alloc(&mm->dot_part1, nblk));
+            mm->dot_nblk = nblk;
+        }
+        ws.part1 = mm->dot_part1;
+    }
+#define LAUNCH(MODE, DOT)                                                                          \
+    hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
+                       per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot)
     if(mode == 0 && !dot)
         LAUNCH(0, false);
     else if(mode == 0 && dot)
@@ -285,6 +319,8 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
         LAUNCH(1, false);
 #undef LAUNCH
     RAMD_HIP(hipGetLastError());
+    if(dot)
+        return reduce_sum_to_slot(ws.part1, nblk, slot);
     return RAMD_OK;
 }
 

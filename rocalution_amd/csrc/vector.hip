@@ -6,6 +6,7 @@
 // -ffp-contract=off so that updates are bit-identical to the OpenMP backend; reductions use a
 // fixed-order tree (the reference's OpenMP reduction order is itself thread-count dependent).
 #include "device_utils.hpp"
+#include "matrix_impl.hpp"
 
 namespace ramd
 {
@@ -324,6 +325,16 @@ __global__ __launch_bounds__(kBlock) void k_amax_partial(int64_t n, const T* a, 
         pval[blockIdx.x] = sv[0];
         pidx[blockIdx.x] = si[0];
     }
+}
+
+int reduce_sum_to_slot(const double* a, int64_t n, int slot)
+{
+    if(n <= 0)
+        return ramd_scalars_set(slot, 0.0);
+    hipLaunchKernelGGL((k_reduce<double, 1>), dim3(reduce_grid((n + 1) / 2)), dim3(kBlock), 0,
+                       backend().cur, n, a, a, reduce_ctx(), slot, (int)RED_SUM);
+    RAMD_HIP(hipGetLastError());
+    return RAMD_OK;
 }
 
 } // namespace ramd
