@@ -1,0 +1,169 @@
+"""Worker for the 2-rank tests (spawned by test_cpu_host.py / test_gpu_distributed.py)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _init(rank, world, initfile):
+    import torch.distributed as dist
+    dist.init_process_group(backend="gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    return dist
+
+
+def _gather_obj(dist, world):
+    def f(obj):
+        out = [None] * world
+        dist.all_gather_object(out, obj)
+        return out
+    return f
+
+
+def _matrix(kind):
+    from rocalution_amd import generators as gen
+    if kind == "poisson":
+        return gen.poisson7(12)
+    if kind == "gr3030":
+        return gen.gr_30_30()
+    return gen.random_sparse(500, 5, seed=3)
+
+
+def _symmetrize_pattern(rp, ci, va):
+    import scipy.sparse as sp
+    n = len(rp) - 1
+    A = sp.csr_matrix((va, ci, rp), shape=(n, n))
+    B = (A + A.T).tocsr()  # symmetric pattern + values (SPD-ish with the dominant diagonal)
+    B.sort_indices()
+    return B.indptr.astype(np.int32), B.indices.astype(np.int32), B.data.astype(np.float64)
+
+
+def cpu_worker(rank, world, initfile, kind, outdir):
+    """CPU (gloo) emulation of GlobalMatrix::Apply + CG<GlobalMatrix> built from the PRODUCT's host
+    logic (rocalution_amd.distributed) with the oracle supplying the local kernels."""
+    import torch
+    from oracle import oracle as orc
+    from rocalution_amd import distributed as D
+    dist = _init(rank, world, initfile)
+    orc.build(); orc.set_threads(1)
+    rp, ci, va = _matrix(kind)
+    if kind == "random":
+        rp, ci, va = _symmetrize_pattern(rp, ci, va)
+    n = len(rp) - 1
+    off = D.partition_rows(n, world)
+    piece = D.split_rows(rp, ci, va, off, rank)
+    plan = D.build_halo_plan(piece, off, rank, _gather_obj(dist, world))
+    lo, hi = piece["row_begin"], piece["row_end"]
+    irp, ici, iva = piece["interior"]
+    grp, gci, gva = piece["ghost"]
+
+    def halo(xloc):
+        send = xloc[plan["boundary_index"]]
+        recv = np.zeros(int(plan["recv_offset"][-1]))
+        ops = []
+        for k, p in enumerate(plan["peers"]):
+            s = torch.from_numpy(np.ascontiguousarray(send[plan["send_offset"][k]:plan["send_offset"][k + 1]]))
+            r = torch.from_numpy(recv[plan["recv_offset"][k]:plan["recv_offset"][k + 1]])
+            ops += [dist.P2POp(dist.isend, s, int(p)), dist.P2POp(dist.irecv, r, int(p))]
+        if ops:
+            for q in dist.batch_isend_irecv(ops):
+                q.wait()
+        return recv
+
+    def apply(xloc):
+        recv = halo(xloc)
+        y = orc.csr_apply(irp, ici, iva, xloc)
+        if len(gva):
+            y = orc.csr_apply_add(grp, gci, gva, recv, 1.0, y)
+        return y
+
+    def gdot(a, b):
+        t = torch.tensor([float(orc.dot(a, b))], dtype=torch.float64)
+        dist.all_reduce(t)
+        return float(t[0])
+
+    x = np.random.default_rng(5).uniform(-1, 1, n)
+    y = apply(x[lo:hi])
+    # CG + Jacobi, global semantics (cg.cpp:366-446 with GlobalVector reductions)
+    b = apply(np.ones(hi - lo))
+    dinv = orc.extract_inv_diag(irp, ici, iva)
+    xs = np.zeros(hi - lo)
+    r = b - apply(xs)
+    res0 = np.sqrt(gdot(r, r))
+    z = dinv * r
+    p = z.copy()
+    rho = gdot(r, z)
+    it = 0
+    while True:
+        q = apply(p)
+        alpha = rho / gdot(p, q)
+        xs = xs + alpha * p
+        r = r + (-alpha) * q
+        it += 1
+        res = np.sqrt(gdot(r, r))
+        if res / res0 <= 1e-6 or it >= 500:
+            break
+        z = dinv * r
+        rho_old, rho = rho, gdot(r, z)
+        p = (rho / rho_old) * p + z
+    np.savez(os.path.join(outdir, "r%d.npz" % rank), lo=lo, hi=hi, y=y, xs=xs, it=it, res=res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def gpu_worker(rank, world, initfile, kind, outdir):
+    """2 ranks sharing ONE GPU: the real GlobalMatrix / GlobalVector / CG path of the library with the
+    host-staged callback transport (RCCL refuses two ranks on one device)."""
+    from rocalution_amd import capi, distributed as D
+    import rocalution_amd as ra
+    dist = _init(rank, world, initfile)
+    ra.init_rocalution(0)
+    comm = D.make_callback_comm(rank, world, dist)
+    out = {}
+    if kind == "poisson_slab":
+        N = 12
+        z0, z1 = (N * rank) // world, (N * (rank + 1)) // world
+        n = N ** 3
+        lo, hi = z0 * N * N, z1 * N * N
+        g = D.DistributedSolver(comm, capi.SOLVER_CG, capi.PC_JACOBI)
+        g.setup_poisson(N, z0, z1)
+    else:
+        rp, ci, va = _matrix(kind)
+        if kind == "random":
+            rp, ci, va = _symmetrize_pattern(rp, ci, va)
+        n = len(rp) - 1
+        off = D.partition_rows(n, world)
+        piece = D.split_rows(rp, ci, va, off, rank)
+        plan = D.build_halo_plan(piece, off, rank, _gather_obj(dist, world))
+        lo, hi = piece["row_begin"], piece["row_end"]
+        g = D.DistributedSolver(comm, capi.SOLVER_CG, capi.PC_JACOBI)
+        g.setup_csr(n, piece, plan)
+    x = np.random.default_rng(5).uniform(-1, 1, n)
+    out["y"] = g.apply(x[lo:hi])
+    g.init(1e-15, 1e-6, 1e8, 500)
+    g.build()
+    out["xs"] = g.solve(None, np.zeros(hi - lo))
+    it, st, res = g.result()
+    # same system again after converting the interior to ELL (ghost -> COO), BiCGStab + BlockJacobi(MC-SGS)
+    g2 = D.DistributedSolver(comm, capi.SOLVER_BICGSTAB, capi.PC_MCSGS)
+    if kind == "poisson_slab":
+        g2.setup_poisson(N, z0, z1)
+    else:
+        g2.setup_csr(n, piece, plan)
+    g2.init(1e-15, 1e-6, 1e8, 500)
+    g2.build()
+    g2.convert(ra.ELL)
+    out["y_ell"] = g2.apply(x[lo:hi])
+    out["xs2"] = g2.solve(None, np.zeros(hi - lo))
+    it2, st2, res2 = g2.result()
+    np.savez(os.path.join(outdir, "r%d.npz" % rank), lo=lo, hi=hi, it=it, res=res, st=st, it2=it2, st2=st2,
+             res2=res2, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    mode, rank, world, initfile, kind, outdir = sys.argv[1:7]
+    (cpu_worker if mode == "cpu" else gpu_worker)(int(rank), int(world), initfile, kind, outdir)
