@@ -493,6 +493,32 @@ private:
     mutable LocalVector<ValueType> recv_buffer_;
 };
 
+// ---- fused-loop helpers for Global objects (see solvers.hpp: _fusable / _fh / _f_apply_dot / _f_allreduce)
+template <typename ValueType>
+struct _fusable<GlobalMatrix<ValueType>, GlobalVector<ValueType>, ValueType>
+{
+    static constexpr bool value = true;
+};
+template <typename ValueType>
+inline ramd_vec_t _fh(const GlobalVector<ValueType>& v)
+{
+    return v.GetInterior().handle();
+}
+template <typename ValueType>
+inline void _f_apply_dot(const GlobalMatrix<ValueType>& A, const GlobalVector<ValueType>& p,
+                         GlobalVector<ValueType>* q, int slot)
+{
+    A.Apply(p, q); // pack | halo || interior SpMV | ghost +=
+    const ramd_vec_t vs[1] = {p.GetInterior().handle()};
+    RAMD_CHECK(ramd_fused_multi_dot(vs, 1, q->GetInterior().handle(), slot)); // local part of <p,q>
+}
+template <typename ValueType>
+inline void _f_allreduce(const GlobalMatrix<ValueType>& A, int first, int count)
+{
+    if(A.pm() != NULL && A.pm()->GetNumProcs() > 1)
+        RAMD_CHECK(ramd_comm_allreduce_scalars(A.pm()->GetComm(), first, count));
+}
+
 // preconditioner_blockjacobi.cpp:80-141: the local preconditioner acts on the interior block only
 template <class OperatorType, class VectorType, typename ValueType>
 class BlockJacobi : public Preconditioner<OperatorType, VectorType, ValueType>

@@ -835,7 +835,10 @@ protected:
     bool             fused_;
 };
 
-// fused kernels exist for accelerator-resident LocalMatrix/LocalVector only
+// The fused device loops are written against four small helpers so that the same loop serves
+// Local objects (one GPU) and Global objects (one rank of a row-block decomposition; global.hpp adds
+// the overloads: interior handle, halo-exchanging Apply + dot, and an RCCL all-reduce of the scalar
+// record between the kernels -- stream-ordered, no host round trip).
 template <class OperatorType, class VectorType, typename ValueType>
 struct _fusable
 {
@@ -846,6 +849,21 @@ struct _fusable<LocalMatrix<ValueType>, LocalVector<ValueType>, ValueType>
 {
     static constexpr bool value = true;
 };
+template <typename ValueType>
+inline ramd_vec_t _fh(const LocalVector<ValueType>& v)
+{
+    return v.handle();
+}
+template <typename ValueType>
+inline void _f_apply_dot(const LocalMatrix<ValueType>& A, const LocalVector<ValueType>& p,
+                         LocalVector<ValueType>* q, int slot)
+{
+    RAMD_CHECK(ramd_fused_apply_dot(A.handle(), p.handle(), q->handle(), slot));
+}
+template <typename ValueType>
+inline void _f_allreduce(const LocalMatrix<ValueType>&, int, int)
+{
+}
 
 // ============================================================================ CG
 template <class OperatorType, class VectorType, typename ValueType>
@@ -981,34 +999,40 @@ private:
         (void)rhs;
         if(!this->op_->is_accel_() || !x->is_accel_())
             return false;
+        const OperatorType& A = *this->op_;
         VectorType *r = &this->r_, *z = &this->z_, *p = &this->p_, *q = &this->q_;
         typedef Jacobi<OperatorType, VectorType, ValueType> JacobiType;
         JacobiType* jac = precond ? dynamic_cast<JacobiType*>(this->precond_) : NULL;
         ramd_vec_t  dinv = NULL;
         if(jac != NULL && jac->GetInverseDiagonal().GetSize() == r->GetSize())
-            dinv = jac->GetInverseDiagonal().handle();
-        const bool generic_pc = precond && dinv == NULL;
-        VectorType* zdir      = precond ? z : r;
+            dinv = _fh(jac->GetInverseDiagonal());
+        const bool  generic_pc = precond && dinv == NULL;
+        VectorType* zdir       = precond ? z : r;
 
-        enum { S_PQ = 1, S_RR = 2 };
-        int s_rho = 0, s_new = 3; // rho slots alternate between 0 and 3
-        // rho = <r, z> (or <r, r>)
-        const ramd_vec_t first[1] = {r->handle()};
-        RAMD_CHECK(ramd_fused_multi_dot(first, 1, zdir->handle(), s_rho));
-        RAMD_CHECK(ramd_fused_apply_dot(this->op_->handle(), p->handle(), q->handle(), S_PQ));
+        // scalar slots: <p,q> = 0, ||r||^2 = 2, rho alternates between 1 and 3 (always adjacent to
+        // slot 2, so the two scalars of the update kernel are summed over ranks by ONE all-reduce)
+        enum { S_PQ = 0, S_RR = 2 };
+        int s_rho = 1, s_new = 3;
+        const ramd_vec_t first[1] = {_fh(*r)};
+        RAMD_CHECK(ramd_fused_multi_dot(first, 1, _fh(*zdir), s_rho)); // rho = <r, z> (or <r, r>)
+        _f_allreduce(A, s_rho, 1);
+        _f_apply_dot(A, *p, q, S_PQ);
+        _f_allreduce(A, S_PQ, 1);
         int rec = 0;
         while(true)
         {
-            RAMD_CHECK(ramd_fused_cg_update(x->handle(), r->handle(), p->handle(), q->handle(), dinv,
-                                            dinv ? z->handle() : NULL, s_rho, S_PQ, S_RR, s_new));
+            RAMD_CHECK(ramd_fused_cg_update(_fh(*x), _fh(*r), _fh(*p), _fh(*q), dinv,
+                                            dinv ? _fh(*z) : NULL, s_rho, S_PQ, S_RR, s_new));
             if(generic_pc)
             {
                 this->precond_->SolveZeroSol(*r, z);
-                RAMD_CHECK(ramd_fused_multi_dot(first, 1, z->handle(), s_new));
+                RAMD_CHECK(ramd_fused_multi_dot(first, 1, _fh(*z), s_new));
             }
+            _f_allreduce(A, s_new < S_RR ? s_new : S_RR, 2);
             RAMD_CHECK(ramd_scalars_fetch_async_begin(rec, S_RR, 1));
-            RAMD_CHECK(ramd_fused_cg_direction(p->handle(), zdir->handle(), s_new, s_rho));
-            RAMD_CHECK(ramd_fused_apply_dot(this->op_->handle(), p->handle(), q->handle(), S_PQ));
+            RAMD_CHECK(ramd_fused_cg_direction(_fh(*p), _fh(*zdir), s_new, s_rho));
+            _f_apply_dot(A, *p, q, S_PQ);
+            _f_allreduce(A, S_PQ, 1);
             double rr = 0.0;
             RAMD_CHECK(ramd_scalars_fetch_async_end(rec, &rr, 1));
             ValueType res_norm = (ValueType)std::sqrt(rr);
@@ -1204,14 +1228,18 @@ private:
     {
         if(i + 3 > RAMD_NSCALARS - 2 || !this->v_[0]->is_accel_())
             return false;
-        VectorType** v = this->v_;
-        ValueType*   H = this->H_.data();
-        ramd_vec_t   w = v[i + 1]->handle();
-        const ramd_vec_t v0[1] = {v[0]->handle()};
+        const OperatorType& A = *this->op_;
+        VectorType**        v = this->v_;
+        ValueType*          H = this->H_.data();
+        ramd_vec_t          w = _fh(*v[i + 1]);
+        const ramd_vec_t    v0[1] = {_fh(*v[0])};
         RAMD_CHECK(ramd_fused_multi_dot(v0, 1, w, 0)); // s[0] = <v_0, w>
+        _f_allreduce(A, 0, 1);
         for(int k = 0; k <= i; ++k) // s[k+1] = <v_{k+1}, w - h_k v_k>  (k == i: <w,w>)
-            RAMD_CHECK(ramd_fused_mgs_step(w, v[k]->handle(), k, (k < i) ? v[k + 1]->handle() : NULL,
-                                           k + 1));
+        {
+            RAMD_CHECK(ramd_fused_mgs_step(w, _fh(*v[k]), k, (k < i) ? _fh(*v[k + 1]) : NULL, k + 1));
+            _f_allreduce(A, k + 1, 1);
+        }
         RAMD_CHECK(ramd_fused_normalize(w, i + 1, i + 2)); // s[i+2] = ||w|| ; w /= ||w||
         std::vector<double> h((size_t)i + 3);
         RAMD_CHECK(ramd_scalars_fetch(h.data(), 0, i + 3));
