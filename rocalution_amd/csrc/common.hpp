@@ -158,6 +158,7 @@ struct ramd_mat_s
     int*  diag_pos = nullptr; // [nrow] position of the first entry with col >= row (ILU0)
     void* tri      = nullptr; // ramd::TriState* (level-ordered solve plans), trisolve.hip
     // workspace of the fused CSR SpMV + <x,y> (spmv.hip)
+    int     band_dist = -1; // far-band distance in rows for the band-aware traversal (-1 unknown, 0 none)
     double* dot_part1 = nullptr; // [dot_nblk] per-workgroup partials
     int     dot_nblk  = 0;
 };

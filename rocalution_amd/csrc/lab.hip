@@ -688,6 +688,9 @@ extern "C" int ramdx_lab_csr(ramd_mat_t m, ramd_vec_t x, ramd_vec_t y, int varia
         case 0:
             mat_apply_impl<double>(m, xv, yv, 0, 1.0);
             break;
+        case 50:
+            mat_apply_dot_impl<double>(m, xv, yv, 5);
+            break;
         case 1:
             L((k_lab_scalar<4, true, true>));
             break;

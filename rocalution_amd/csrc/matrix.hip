@@ -48,7 +48,8 @@ void mat_free_analysis(ramd_mat_s* m)
 {
     dev_free(&m->diag_pos);
     dev_free(&m->dot_part1);
-    m->dot_nblk = 0;
+    m->dot_nblk  = 0;
+    m->band_dist = -1;
     tri_release(m);
     m->lu_analysed = m->l_analysed = m->u_analysed = false;
     m->l_diag_unit                                 = true;

@@ -13,6 +13,9 @@
 #include "device_utils.hpp"
 #include "matrix_impl.hpp"
 
+#include <algorithm>
+#include <vector>
+
 namespace ramd
 {
 
@@ -22,10 +25,31 @@ constexpr int kCsrChunk = 2048; // entries staged in LDS per pass (16 KiB values
 // XCD-aware mapping: hardware places workgroup b on XCD b % 8 (observed, used for speed only).
 // Every XCD gets one contiguous eighth of the row blocks and walks it in dispatch order, so rows that
 // gather the same x planes are in flight on the same L2 at the same time.
-__device__ __forceinline__ int xcd_block(int nblk, int per_xcd)
+//
+// Band-aware traversal (P > 0): matrices with a far band at distance D rows (3-D stencils: D = one
+// grid plane) gather x[r-D], x[r], x[r+D]; walking the rows plane by plane puts 2 planes (4 MiB of x at
+// 512^3) between the first and the last use of an x entry -- more than an XCD's L2, so x is fetched from
+// HBM three times (measured: +2 GB per SpMV).  Instead the XCD's range is cut into in-plane tiles of W
+// row blocks and every tile is swept through all planes before the next tile starts: the reuse window
+// shrinks to 3 x W x 2 KiB.  P = D / 256 row blocks per plane, Z = planes in the XCD's range.
+struct BandMap
 {
-    const int b = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    return b < nblk ? b : -1;
+    int P, W, Z; // P == 0: linear order
+};
+__device__ __forceinline__ int xcd_block(int nblk, int per_xcd, BandMap bm)
+{
+    const int i = blockIdx.x >> 3; // position in this XCD's dispatch sequence
+    int       l = i;
+    if(bm.P > 0 && i < bm.Z * bm.P)
+    {
+        const int tile   = i / (bm.W * bm.Z);
+        const int within = i - tile * (bm.W * bm.Z);
+        const int z      = within / bm.W;
+        const int w      = within - z * bm.W;
+        l                = z * bm.P + tile * bm.W + w;
+    }
+    const int b = (blockIdx.x & 7) * per_xcd + l;
+    return (i < per_xcd && b < nblk) ? b : -1;
 }
 
 template <typename T>
@@ -66,14 +90,14 @@ __global__ __launch_bounds__(kBlock) void k_csr_tr(int nrow, int nblk, int per_x
                                                    const int* __restrict__ ci,
                                                    const T* __restrict__ val,
                                                    const T* __restrict__ x, T* __restrict__ y, T scalar,
-                                                   CsrDotWs ws, int slot)
+                                                   CsrDotWs ws, int slot, BandMap bm)
 {
     using VP          = typename ValPk<T>::type;
     constexpr int VN  = ValPk<T>::N;
     __shared__ T      sval[kCsrChunk];
     __shared__ int    scol[kCsrChunk];
     __shared__ double red[8];
-    const int blk  = xcd_block(nblk, per_xcd);
+    const int blk  = xcd_block(nblk, per_xcd, bm);
     double    dacc = 0.0;
     if(blk >= 0)
     {
@@ -289,6 +313,45 @@ __global__ __launch_bounds__(kBlock) void k_coo_grouped(int ngroups, const int* 
 }
 
 // ------------------------------------------------------------------------------------------
+// sample ~2048 rows: the farthest column of a row, in rows.  A band is accepted when at least half
+// of the samples agree on the same distance D, D is a multiple of the row-block size, and one "plane"
+// of x (8 D bytes) is big enough to fall out of an XCD's L2 when two of them have to stay resident.
+__global__ __launch_bounds__(kBlock) void k_band_sample(int nrow, int stride, const int* __restrict__ rp,
+                                                        const int* __restrict__ ci, int* __restrict__ out)
+{
+    const int s   = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = (int)(((int64_t)s * stride + stride / 2) % nrow);
+    int       far = 0;
+    for(int j = rp[row]; j < rp[row + 1]; ++j)
+        far = max(far, abs(ci[j] - row));
+    out[s] = far;
+}
+
+static int analyse_band(ramd_mat_s* m)
+{
+    m->band_dist = 0;
+    if(m->format != RAMD_CSR || m->nrow < (1 << 20) || m->nrow != m->ncol)
+        return RAMD_OK;
+    Backend&  b       = backend();
+    const int samples = 2048;
+    int*      d       = nullptr;
+    RAMD_TRY(dev_alloc(&d, samples));
+    hipLaunchKernelGGL(k_band_sample, dim3(samples / kBlock), dim3(kBlock), 0, b.cur, m->nrow,
+                       std::max(1, m->nrow / samples), m->rp, m->ci, d);
+    std::vector<int> h((size_t)samples);
+    hipError_t       e = hipMemcpyAsync(h.data(), d, sizeof(int) * samples, hipMemcpyDeviceToHost, b.cur);
+    if(e == hipSuccess)
+        e = hipStreamSynchronize(b.cur);
+    dev_free(&d);
+    RAMD_HIP(e);
+    std::sort(h.begin(), h.end());
+    const int med = h[samples / 2];
+    const int cnt = (int)(std::upper_bound(h.begin(), h.end(), med) - std::lower_bound(h.begin(), h.end(), med));
+    if(cnt * 2 >= samples && med % kCsrRows == 0 && (int64_t)med * 8 >= (1 << 20) && med < m->nrow / 16)
+        m->band_dist = med;
+    return RAMD_OK;
+}
+
 template <typename T>
 static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar, bool dot, int slot)
 {
@@ -297,6 +360,19 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
     const int per_xcd = (nblk + 7) / 8;
     const int grid    = per_xcd * 8;
     CsrDotWs  ws      = {};
+    if(m->band_dist < 0)
+        RAMD_TRY(analyse_band(const_cast<ramd_mat_s*>(m)));
+    BandMap bm = {0, 0, 0};
+    if(m->band_dist > 0)
+    {
+        bm.P = m->band_dist / kCsrRows;
+        bm.Z = per_xcd / bm.P;
+        bm.W = 32;
+        while(bm.W > 1 && bm.P % bm.W != 0)
+            bm.W >>= 1;
+        if(bm.Z < 3)
+            bm.P = 0;
+    }
     if(dot)
     {
         ramd_mat_s* mm = const_cast<ramd_mat_s*>(m);
@@ -308,9 +384,11 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
         }
         ws.part1 = mm->dot_part1;
     }
+    if(dot)
+        prof_spmv_begin();
 #define LAUNCH(MODE, DOT)                                                                          \
     hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
-                       per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot)
+                       per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm)
     if(mode == 0 && !dot)
         LAUNCH(0, false);
     else if(mode == 0 && dot)
@@ -320,7 +398,10 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
 #undef LAUNCH
     RAMD_HIP(hipGetLastError());
     if(dot)
+    {
+        prof_spmv_end();
         return reduce_sum_to_slot(ws.part1, nblk, slot);
+    }
     return RAMD_OK;
 }
 
@@ -420,12 +501,7 @@ template <typename T>
 int mat_apply_dot_impl(const ramd_mat_s* m, const T* x, T* y, int slot)
 {
     if(m->format == RAMD_CSR && m->nnz > 0 && m->nrow == m->ncol)
-    {
-        prof_spmv_begin();
-        int s = launch_csr<T>(m, x, y, 0, (T)1, true, slot);
-        prof_spmv_end();
-        return s;
-    }
+        return launch_csr<T>(m, x, y, 0, (T)1, true, slot); // bracketed inside (SpMV kernel only)
     return RAMD_ERR_UNSUPPORTED; // caller falls back to apply + dot (two launches)
 }
 template int mat_apply_dot_impl<double>(const ramd_mat_s*, const double*, double*, int);
