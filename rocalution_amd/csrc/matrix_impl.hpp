@@ -31,6 +31,8 @@ int reduce_sum_to_slot(const double* a, int64_t n, int slot);
 
 // scan.hip: out[i] = sum_{k<i} in[k] for i < n (in and out may alias); int32 sums
 int device_exclusive_scan(const int* in, int* out, int64_t n);
+// order_out = indices 0..n-1 sorted by keys (0 <= key <= max_key), stable
+int device_stable_sort_by_key(const int* keys, int64_t n, int max_key, int* order_out);
 // max over an int array -> host
 int device_max_int(const int* in, int64_t n, int* result);
 

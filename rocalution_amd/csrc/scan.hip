@@ -3,6 +3,9 @@
 #include "device_utils.hpp"
 #include "matrix_impl.hpp"
 
+#include <utility>
+#include <vector>
+
 namespace ramd
 {
 
@@ -86,6 +89,94 @@ int device_exclusive_scan(const int* in, int* out, int64_t n)
     }
     // tsum is freed after the queued kernels ran (hipFree synchronises)
     dev_free(&tsum);
+    return s;
+}
+
+// ---- stable LSD radix sort by key, one bit per pass, built on the scan above (setup-time only).
+// Used to order rows by dependency level while keeping ascending row order inside a level, which makes
+// the level-ordered triangular solve poll and gather contiguous memory.
+__global__ __launch_bounds__(kBlock) void k_sort_flag(int64_t n, const int* __restrict__ keys, int bit,
+                                                      int* __restrict__ flag)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += gsz)
+        flag[i] = (i < n && ((keys[i] >> bit) & 1) == 0) ? 1 : 0;
+}
+__global__ __launch_bounds__(kBlock) void k_sort_scatter(int64_t n, const int* __restrict__ keys,
+                                                         const int* __restrict__ vals, int bit,
+                                                         const int* __restrict__ pos0,
+                                                         int* __restrict__ okeys, int* __restrict__ ovals)
+{
+    const int64_t gsz   = (int64_t)gridDim.x * blockDim.x;
+    const int     zeros = pos0[n];
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gsz)
+    {
+        const int k = keys[i];
+        const int d = (((k >> bit) & 1) == 0) ? pos0[i] : zeros + (int)(i - pos0[i]);
+        okeys[d]    = k;
+        ovals[d]    = vals ? vals[i] : (int)i;
+    }
+}
+
+int device_stable_sort_by_key(const int* keys, int64_t n, int max_key, int* order_out)
+{
+    if(n <= 0)
+        return RAMD_OK;
+    Backend& b    = backend();
+    int      bits = 0;
+    while((1ll << bits) <= (long long)max_key)
+        ++bits;
+    int *ka = nullptr, *kb = nullptr, *va = nullptr, *vb = nullptr, *fl = nullptr;
+    int  s = dev_alloc(&ka, n);
+    if(s == RAMD_OK)
+        s = dev_alloc(&kb, n);
+    if(s == RAMD_OK)
+        s = dev_alloc(&va, n);
+    if(s == RAMD_OK)
+        s = dev_alloc(&vb, n);
+    if(s == RAMD_OK)
+        s = dev_alloc(&fl, n + 1);
+    if(s == RAMD_OK && hipMemcpyAsync(ka, keys, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, b.cur) != hipSuccess)
+        s = RAMD_ERR_HIP;
+    const int grid   = ew_grid(n + 1);
+    bool      first  = true;
+    for(int bit = 0; bit < bits && s == RAMD_OK; ++bit)
+    {
+        hipLaunchKernelGGL(k_sort_flag, dim3(grid), dim3(kBlock), 0, b.cur, n, ka, bit, fl);
+        s = device_exclusive_scan(fl, fl, n + 1);
+        if(s != RAMD_OK)
+            break;
+        hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(kBlock), 0, b.cur, n, ka, first ? nullptr : va,
+                           bit, fl, kb, vb);
+        std::swap(ka, kb);
+        std::swap(va, vb);
+        first = false;
+    }
+    if(s == RAMD_OK)
+    {
+        if(first) // all keys equal: identity order
+            hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(kBlock), 0, b.cur, (int64_t)0, ka, nullptr, 0,
+                               fl, kb, vb);
+        hipError_t e = hipSuccess;
+        if(first)
+        {
+            std::vector<int> iota((size_t)n);
+            for(int64_t i = 0; i < n; ++i)
+                iota[(size_t)i] = (int)i;
+            e = hipMemcpy(order_out, iota.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice);
+        }
+        else
+            e = hipMemcpyAsync(order_out, va, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, b.cur);
+        if(e == hipSuccess)
+            e = hipStreamSynchronize(b.cur);
+        if(e != hipSuccess)
+            s = RAMD_ERR_HIP;
+    }
+    dev_free(&ka);
+    dev_free(&kb);
+    dev_free(&va);
+    dev_free(&vb);
+    dev_free(&fl);
     return s;
 }
 

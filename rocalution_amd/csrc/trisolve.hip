@@ -158,28 +158,12 @@ __global__ __launch_bounds__(kBlock) void k_levels(int nrow, const int* __restri
     } while(__ballot(!fin) != 0ull);
 }
 
-__global__ __launch_bounds__(kBlock) void k_level_hist(int nrow, const int* __restrict__ level,
-                                                       int* __restrict__ hist)
+__global__ __launch_bounds__(kBlock) void k_invert_perm(int n, const int* __restrict__ order,
+                                                        int* __restrict__ pos)
 {
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
-    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
-        atomicAdd(hist + level[i], 1);
-}
-
-// position of every row inside its level (rows of one level are interchangeable: the order inside
-// a level only changes the memory layout, never a result)
-__global__ __launch_bounds__(kBlock) void k_level_scatter(int nrow, const int* __restrict__ level,
-                                                          int* __restrict__ cursor,
-                                                          int* __restrict__ order,
-                                                          int* __restrict__ pos)
-{
-    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
-    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
-    {
-        const int p = atomicAdd(cursor + level[i], 1);
-        order[p]    = (int)i;
-        pos[i]      = p;
-    }
+    for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gsz)
+        pos[order[t]] = (int)t;
 }
 
 // ---------------------------------------------------------------- sliced-ELL packing
@@ -273,8 +257,10 @@ __global__ __launch_bounds__(kBlock) void k_trsv(int nrow, const int* __restrict
                                                  const T* __restrict__ rhs_src,
                                                  const int* __restrict__ rhs_idx, T* w,
                                                  T* __restrict__ out, const int* __restrict__ order,
-                                                 unsigned* counter, unsigned base)
+                                                 unsigned* counter, unsigned base, int sleep_cycles)
 {
+    extern __shared__ __attribute__((aligned(16))) char occupancy_pad[]; // launch-time occupancy limiter
+    (void)occupancy_pad;
     const unsigned blk = take_ticket(counter, base);
     const int64_t  t   = (int64_t)blk * kBlock + threadIdx.x;
     if(t >= nrow)
@@ -284,44 +270,70 @@ __global__ __launch_bounds__(kBlock) void k_trsv(int nrow, const int* __restrict
     const int     b0   = slice_off[s];
     const int     wd   = (slice_off[s + 1] - b0) >> 6;
     T             sum  = rhs_src[rhs_idx[t]];
-    int           k    = 0;
-    int           c    = (wd > 0) ? nt_load(ecol + b0 + lane) : -1;
-    T             a    = (wd > 0) ? nt_load(eval + b0 + lane) : (T)0;
+    const T       dg   = UNIT_DIAG ? (T)1 : diag[t]; // fetched before the wait, not after it
+    const int     onat = out ? order[t] : 0;
+    // A row's dependencies mostly sit in the previous level and become ready together, so they are
+    // polled TOGETHER (one L2 round trip per attempt, not one per dependency) and the row's entries are
+    // fetched up front in chunks of kDepChunk; the subtraction itself still runs in storage order.
+    constexpr int kDepChunk = 8;
+    int           c[kDepChunk];
+    T             a[kDepChunk];
+    auto          load_chunk = [&](int k0) {
+#pragma unroll
+        for(int e = 0; e < kDepChunk; ++e)
+        {
+            const int k = k0 + e;
+            c[e]        = (k < wd) ? nt_load(ecol + b0 + k * 64 + lane) : -1;
+            a[e]        = (k < wd) ? nt_load(eval + b0 + k * 64 + lane) : (T)0;
+        }
+    };
+    int k0 = 0;
+    load_chunk(0);
     // publish inside a wave-uniform-exit loop (see k_levels): small levels can put dependent rows
     // into one wave
-    bool fin = false;
+    bool fin   = false;
     int  spins = 0;
     do
     {
         spin_guard(spins);
+        bool progress = true;
         if(!fin)
         {
-            if(c >= 0)
-            {
-                const typename Sentinel<T>::bits bits = poll_load(w + c);
-                if(bits != Sentinel<T>::value)
+            typename Sentinel<T>::bits bits[kDepChunk];
+            bool                       all = true;
+#pragma unroll
+            for(int e = 0; e < kDepChunk; ++e)
+                if(c[e] >= 0)
                 {
-                    sum -= a * Sentinel<T>::from_bits(bits);
-                    ++k;
-                    if(k < wd)
-                    {
-                        c = nt_load(ecol + b0 + k * 64 + lane);
-                        a = nt_load(eval + b0 + k * 64 + lane);
-                    }
-                    else
-                        c = -1;
+                    bits[e] = poll_load(w + c[e]);
+                    all     = all && (bits[e] != Sentinel<T>::value);
+                }
+            if(all)
+            {
+#pragma unroll
+                for(int e = 0; e < kDepChunk; ++e)
+                    if(c[e] >= 0)
+                        sum -= a[e] * Sentinel<T>::from_bits(bits[e]);
+                k0 += kDepChunk;
+                if(k0 < wd)
+                    load_chunk(k0);
+                else
+                {
+                    if(!UNIT_DIAG)
+                        sum /= dg;
+                    publish(w + t, sum);
+                    if(out)
+                        out[onat] = sum;
+                    fin = true;
                 }
             }
             else
-            {
-                if(!UNIT_DIAG)
-                    sum /= diag[t];
-                publish(w + t, sum);
-                if(out)
-                    out[order[t]] = sum;
-                fin = true;
-            }
+                progress = false;
         }
+        // nobody in the wave could advance: back off instead of hammering the L2 with polls
+        if(__ballot(progress && !fin) == 0ull && __ballot(!fin) != 0ull)
+            for(int z = 0; z < sleep_cycles; ++z)
+                __builtin_amdgcn_s_sleep(1);
     } while(__ballot(!fin) != 0ull);
 }
 
@@ -516,29 +528,17 @@ static int build_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower)
     st->ticket += nb;
     int nlev = 0;
     int s    = device_max_int(level, n, &nlev);
-    // histogram over levels 1..nlev (index 0 unused), exclusive scan -> level offsets
-    int* hist = nullptr;
-    if(s == RAMD_OK)
-        s = dev_alloc(&hist, (int64_t)nlev + 2);
-    if(s == RAMD_OK)
-    {
-        hipError_t e = hipMemsetAsync(hist, 0, sizeof(int) * ((size_t)nlev + 2), b.cur);
-        if(e != hipSuccess)
-            s = RAMD_ERR_HIP;
-    }
+    // rows ordered by (level, row): stable sort, so rows of one level keep ascending row order and
+    // neighbouring positions poll / gather neighbouring memory
     const int grid = ew_grid(n);
-    if(s == RAMD_OK)
-    {
-        hipLaunchKernelGGL(k_level_hist, dim3(grid), dim3(kBlock), 0, b.cur, n, level, hist);
-        s = device_exclusive_scan(hist, hist, (int64_t)nlev + 2);
-    }
     if(s == RAMD_OK)
         s = dev_alloc(&P->order, n);
     if(s == RAMD_OK)
         s = dev_alloc(&P->pos, n);
     if(s == RAMD_OK)
-        hipLaunchKernelGGL(k_level_scatter, dim3(grid), dim3(kBlock), 0, b.cur, n, level, hist,
-                           P->order, P->pos);
+        s = device_stable_sort_by_key(level, n, nlev, P->order);
+    if(s == RAMD_OK)
+        hipLaunchKernelGGL(k_invert_perm, dim3(grid), dim3(kBlock), 0, b.cur, n, P->order, P->pos);
     // slice widths -> offsets
     if(s == RAMD_OK)
         s = dev_alloc(&P->slice_off, (int64_t)P->nslices + 1);
@@ -606,7 +606,6 @@ static int build_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower)
     }
     P->nlevels = nlev;
     dev_free(&level);
-    dev_free(&hist);
     dev_free(&nodiag);
     if(s != RAMD_OK)
         P->release();
@@ -631,14 +630,23 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
     const unsigned nb = nblocks_of(P->n);
     hipLaunchKernelGGL((k_fill_sentinel<T>), dim3(ew_grid(P->n)), dim3(kBlock), 0, b.cur, (int64_t)P->n,
                        (T*)P->w);
+    // tuning knobs (measured defaults; the env overrides are for tools/ experiments only)
+    static int lds_pad = -1, sleep_cycles = -1;
+    if(lds_pad < 0)
+    {
+        const char* e1 = getenv("RAMD_TRSV_LDS");
+        const char* e2 = getenv("RAMD_TRSV_SLEEP");
+        lds_pad        = e1 ? atoi(e1) : 0;
+        sleep_cycles   = e2 ? atoi(e2) : 4;
+    }
     if(unit)
-        hipLaunchKernelGGL((k_trsv<T, true>), dim3(nb), dim3(kBlock), 0, b.cur, P->n, P->slice_off,
-                           P->ecol, (const T*)P->eval, (const T*)P->diag, rhs_src, rhs_idx, (T*)P->w,
-                           out, P->order, st->counter, st->ticket);
+        hipLaunchKernelGGL((k_trsv<T, true>), dim3(nb), dim3(kBlock), (size_t)lds_pad, b.cur, P->n,
+                           P->slice_off, P->ecol, (const T*)P->eval, (const T*)P->diag, rhs_src, rhs_idx,
+                           (T*)P->w, out, P->order, st->counter, st->ticket, sleep_cycles);
     else
-        hipLaunchKernelGGL((k_trsv<T, false>), dim3(nb), dim3(kBlock), 0, b.cur, P->n, P->slice_off,
-                           P->ecol, (const T*)P->eval, (const T*)P->diag, rhs_src, rhs_idx, (T*)P->w,
-                           out, P->order, st->counter, st->ticket);
+        hipLaunchKernelGGL((k_trsv<T, false>), dim3(nb), dim3(kBlock), (size_t)lds_pad, b.cur, P->n,
+                           P->slice_off, P->ecol, (const T*)P->eval, (const T*)P->diag, rhs_src, rhs_idx,
+                           (T*)P->w, out, P->order, st->counter, st->ticket, sleep_cycles);
     st->ticket += nb;
     RAMD_HIP(hipGetLastError());
     return RAMD_OK;
