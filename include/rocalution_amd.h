@@ -264,6 +264,14 @@ int ramd_solver_history(ramd_solver_t s, double* buf, int cap, int* len);
 int ramd_solver_num_colors(ramd_solver_t s, int* ncolors);
 int ramd_solver_clear(ramd_solver_t s);
 
+/* LocalMatrix::ReadFileMTX (src/base/local_matrix.cpp:1269-1326, src/base/host/host_io.cpp:51-320):
+ * MatrixMarket coordinate file -> sorted CSR on the accelerator, reference semantics (1-based indices,
+ * pattern -> 1, symmetric/hermitian mirrored without duplicating the diagonal). */
+int ramd_mat_read_mtx(const char* filename, int dtype, ramd_mat_t* out);
+/* MultiColored::SetDecomposition (preconditioner_multicolored.cpp:140-146): false = L/U sweeps on the
+ * permuted matrix (LSolve/USolve) instead of the colour-block decomposition */
+int ramd_solver_set_decomposition(ramd_solver_t s, int decomp);
+
 /* distributed driver: GlobalMatrix/GlobalVector + Solver<GlobalMatrix,GlobalVector> on one rank of a
  * row-block decomposition (clients/samples/cg_mpi.cpp, bicgstab_mpi.cpp of the reference).  The local
  * preconditioner of MC-SGS / ILU(0) is wrapped in BlockJacobi as the reference samples do. */

@@ -353,5 +353,12 @@ class LocalMatrix:
     def USolve(self, b, x):
         capi.check(_lib().ramd_mat_u_solve(self._h, b._h, x._h))
 
+    def ReadFileMTX(self, filename):
+        """LocalMatrix::ReadFileMTX with the reference's MatrixMarket semantics (include/rocalution/io.hpp)"""
+        h = capi.mat_t()
+        capi.check(_lib().ramd_mat_read_mtx(str(filename).encode(), _DT[self.dtype], C.byref(h)))
+        _lib().ramd_mat_destroy(self._h)
+        self._h = h
+
     def GenPoisson7(self, N):
         capi.check(_lib().ramd_mat_gen_poisson7(self._h, int(N)))

@@ -140,6 +140,8 @@ SIGNATURES = {
     "ramd_solver_set_fused": (i32, [ptr, i32]),
     "ramd_solver_set_verbose": (i32, [ptr, i32]),
     "ramd_solver_set_precond_format": (i32, [ptr, i32]),
+    "ramd_solver_set_decomposition": (i32, [ptr, i32]),
+    "ramd_mat_read_mtx": (i32, [C.c_char_p, i32, C.POINTER(mat_t)]),
     "ramd_solver_build": (i32, [ptr, mat_t]),
     "ramd_solver_solve": (i32, [ptr, vec_t, vec_t]),
     "ramd_solver_precond_apply": (i32, [ptr, vec_t, vec_t]),

@@ -26,6 +26,7 @@ struct SolverBase
     virtual void set_fused(bool)                                         = 0;
     virtual void set_verbose(int)                                        = 0;
     virtual void set_precond_format(int) {}
+    virtual void set_decomposition(bool) {}
     virtual void build(ramd_mat_t op)                                    = 0;
     virtual void solve(ramd_vec_t rhs, ramd_vec_t x)                     = 0;
     virtual bool precond_apply(ramd_vec_t, ramd_vec_t)                   = 0;
@@ -108,6 +109,10 @@ struct LocalSolver : SolverBase
     void set_precond_format(int f) override
     {
         pcs.mcsgs.SetPrecondMatrixFormat((unsigned)f);
+    }
+    void set_decomposition(bool d) override
+    {
+        pcs.mcsgs.SetDecomposition(d);
     }
     void build(ramd_mat_t h) override
     {
@@ -386,6 +391,36 @@ int ramd_solver_set_precond_format(ramd_solver_t s, int f)
         return RAMD_ERR_ARG;
     s->impl->set_precond_format(f);
     return RAMD_OK;
+}
+int ramd_solver_set_decomposition(ramd_solver_t s, int d)
+{
+    if(!s)
+        return RAMD_ERR_ARG;
+    s->impl->set_decomposition(d != 0);
+    return RAMD_OK;
+}
+int ramd_mat_read_mtx(const char* filename, int dtype, ramd_mat_t* out)
+{
+    if(!filename || !out || (dtype != RAMD_F64 && dtype != RAMD_F32))
+        return RAMD_ERR_ARG;
+    GUARD_BEGIN
+    ramd_mat_t h = NULL;
+    if(ramd_mat_create(dtype, &h) != RAMD_OK)
+        return RAMD_ERR_HIP;
+    if(dtype == RAMD_F64)
+    {
+        LocalMatrix<double> m;
+        m.AdoptDeviceHandle(h);
+        m.ReadFileMTX(filename);
+    }
+    else
+    {
+        LocalMatrix<float> m;
+        m.AdoptDeviceHandle(h);
+        m.ReadFileMTX(filename);
+    }
+    *out = h;
+    GUARD_END
 }
 int ramd_solver_build(ramd_solver_t s, ramd_mat_t op)
 {

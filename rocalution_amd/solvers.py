@@ -43,6 +43,13 @@ class ILU(_Precond):
 class MultiColoredSGS(_Precond):
     kind = PC_MCSGS
 
+    def __init__(self):
+        super().__init__()
+        self.decomposition = True
+
+    def SetDecomposition(self, decomp):
+        self.decomposition = bool(decomp)
+
 
 class _IterativeLinearSolver:
     kind = SOLVER_CG
@@ -102,6 +109,8 @@ class _IterativeLinearSolver:
             capi.check(_lib().ramd_solver_set_basis(self._h, self._basis))
         if self._precond is not None and self._precond.precond_format is not None:
             capi.check(_lib().ramd_solver_set_precond_format(self._h, self._precond.precond_format))
+        if self._precond is not None and getattr(self._precond, "decomposition", True) is False:
+            capi.check(_lib().ramd_solver_set_decomposition(self._h, 0))
         capi.check(_lib().ramd_solver_set_fused(self._h, int(self._fused)))
         capi.check(_lib().ramd_solver_set_verbose(self._h, self._verbose))
         self._configure_extra()

@@ -197,3 +197,53 @@ def test_solvers_vs_oracle_larger(ra, S, oracle, N, tag):
     assert abs(ls.GetIterationCount() - ref["iters"]) <= 2
     _check_hist(ls.GetResidualHistory(), ref["history"], tag.startswith("bicgstab"), rtol=1e-6)
     assert np.linalg.norm(x.numpy() - ref["x"]) / np.linalg.norm(ref["x"]) < 1e-6
+
+
+def test_read_mtx_reference_semantics(ra, S, tmp_path):
+    """symmetric MatrixMarket storage of gr_30_30 (lower triangle, 4322 entries) -> 7744-entry sorted CSR,
+    and config 1 of BASELINE.json: CG without preconditioner converges in 36 iterations"""
+    rp, ci, va = gen.gr_30_30()
+    n = len(rp) - 1
+    path = tmp_path / "gr_30_30.mtx"
+    with open(path, "w") as f:
+        rows = np.repeat(np.arange(n), np.diff(rp))
+        keep = ci <= rows
+        f.write("%%MatrixMarket matrix coordinate real symmetric\n% synthesised gr_30_30\n")
+        f.write("%d %d %d\n" % (n, n, keep.sum()))
+        # deliberately unsorted: the reader sorts
+        order = np.random.default_rng(1).permutation(np.flatnonzero(keep))
+        for k in order:
+            f.write("%d %d %.17g\n" % (rows[k] + 1, ci[k] + 1, va[k]))
+    assert int(keep.sum()) == 4322
+    A = ra.LocalMatrix(); A.ReadFileMTX(path)
+    grp, gci, gva = A.CopyToCSR()
+    eq(grp, rp); eq(gci, ci); eq(gva, va)
+    g = load_golden("gr3030")
+    rhs = ra.LocalVector(data=g["rhs_ones"]); x = ra.LocalVector(); x.Allocate("", n)
+    ls = S.CG(); ls.SetOperator(A); ls.Build(); ls.Solve(rhs, x)
+    assert ls.GetIterationCount() == 36
+    assert abs(ls.GetCurrentResidual() / 2.0320619894765594e-05 - 1) < 1e-6
+    # pattern + general
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket MATRIX Coordinate Pattern General\n3 3 4\n1 1\n3 2\n2 3\n1 3\n")
+    B = ra.LocalMatrix(); B.ReadFileMTX(path)
+    brp, bci, bva = B.CopyToCSR()
+    eq(brp, [0, 2, 3, 4]); eq(bci, [0, 2, 2, 1]); eq(bva, [1.0, 1.0, 1.0, 1.0])
+
+
+@pytest.mark.parametrize("name", ["gr3030", "poisson8"])
+def test_mcsgs_without_decomposition(ra, S, oracle, name):
+    """MultiColored::SetDecomposition(false): LSolve / D / USolve on the permuted matrix
+    (preconditioner_multicolored_gs.cpp:202-215) -- the same operator M as the decomposed form"""
+    g = load_golden(name)
+    A = ra.LocalMatrix(); A.SetDataPtrCSR(g["rowptr"], g["col"], g["val"])
+    n = A.GetM()
+    x = ra.LocalVector(data=g["x"])
+    pc = S.MultiColoredSGS(); pc.SetDecomposition(False)
+    ls = S.BiCGStab(); ls.SetOperator(A); ls.SetPreconditioner(pc); ls.Build()
+    z = ra.LocalVector(); z.Allocate("", n)
+    ls.PrecondApply(x, z)
+    assert np.allclose(z.numpy(), g["pc_mcsgs"], rtol=1e-12, atol=1e-13)
+    rhs = ra.LocalVector(data=g["rhs_ones"]); sol = ra.LocalVector(); sol.Allocate("", n)
+    ls.Solve(rhs, sol)
+    assert abs(ls.GetIterationCount() - int(g["bicgstab_mcsgs_meta"][0])) <= 2
