@@ -988,8 +988,8 @@ private:
 
     // Fused device loop (Local objects on the accelerator).  Per iteration:
     //   K1  q = A p, <p,q>                                   (ramd_fused_apply_dot)
-    //   K2  x += a p ; r -= a q ; <r,r> ; [z = D^-1 r ; <r,z>]  (ramd_fused_cg_update)
-    //   K3  p = (rho'/rho) p + z                              (ramd_fused_cg_direction)
+    //   K2  r -= a q ; <r,r> ; [z = D^-1 r ; <r,z>]            (ramd_fused_cg_update)
+    //   K3  x += a p ; p = (rho'/rho) p + z                    (ramd_fused_cg_direction)
     // The ||r|| read-back for iteration k overlaps K3(k) and K1(k+1), which are queued before the
     // host waits; the convergence decision is the reference's, made on the same ||r||.
     template <class O = OperatorType, class V = VectorType>
@@ -1021,8 +1021,8 @@ private:
         int rec = 0;
         while(true)
         {
-            RAMD_CHECK(ramd_fused_cg_update(_fh(*x), _fh(*r), _fh(*p), _fh(*q), dinv,
-                                            dinv ? _fh(*z) : NULL, s_rho, S_PQ, S_RR, s_new));
+            RAMD_CHECK(ramd_fused_cg_update(_fh(*r), _fh(*q), dinv, dinv ? _fh(*z) : NULL, s_rho, S_PQ,
+                                            S_RR, s_new));
             if(generic_pc)
             {
                 this->precond_->SolveZeroSol(*r, z);
@@ -1030,7 +1030,7 @@ private:
             }
             _f_allreduce(A, s_new < S_RR ? s_new : S_RR, 2);
             RAMD_CHECK(ramd_scalars_fetch_async_begin(rec, S_RR, 1));
-            RAMD_CHECK(ramd_fused_cg_direction(_fh(*p), _fh(*zdir), s_new, s_rho));
+            RAMD_CHECK(ramd_fused_cg_direction(_fh(*x), _fh(*p), _fh(*zdir), s_rho, S_PQ, s_new));
             _f_apply_dot(A, *p, q, S_PQ);
             _f_allreduce(A, S_PQ, 1);
             double rr = 0.0;

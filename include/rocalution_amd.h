@@ -181,12 +181,15 @@ int ramd_scalars_fetch_async_end(int record, double* host, int count);
 
 /* y = A x  and  s[slot_dot] = <x, y>   (cg.cpp:415-418: q = A p ; p.q) */
 int ramd_fused_apply_dot(ramd_mat_t m, ramd_vec_t x, ramd_vec_t y, int slot_dot);
-/* alpha = s[slot_rho] / s[slot_pq];  x += alpha p;  r += (-alpha) q;  s[slot_rr] = <r,r>;
- * if dinv: z = dinv * r, s[slot_rz] = <r,z>   else s[slot_rz] = <r,r>       (cg.cpp:418-438) */
-int ramd_fused_cg_update(ramd_vec_t x, ramd_vec_t r, ramd_vec_t p, ramd_vec_t q, ramd_vec_t dinv,
-                         ramd_vec_t z, int slot_rho, int slot_pq, int slot_rr, int slot_rz);
-/* beta = s[slot_num] / s[slot_den];  p = beta*p + z                              (cg.cpp:441-442) */
-int ramd_fused_cg_direction(ramd_vec_t p, ramd_vec_t z, int slot_num, int slot_den);
+/* alpha = s[slot_rho] / s[slot_pq];  r += (-alpha) q;  s[slot_rr] = <r,r>;
+ * if dinv: z = dinv * r, s[slot_rz] = <r,z>   else s[slot_rz] = <r,r>            (cg.cpp:418-438) */
+int ramd_fused_cg_update(ramd_vec_t r, ramd_vec_t q, ramd_vec_t dinv, ramd_vec_t z, int slot_rho,
+                         int slot_pq, int slot_rr, int slot_rz);
+/* alpha = s[slot_rho] / s[slot_pq];  beta = s[slot_new] / s[slot_rho];
+ * x = x + alpha*p (cg.cpp:421, with the OLD p);  p = beta*p + z (cg.cpp:441-442).  Moving the x update
+ * next to the direction update reads p once per iteration instead of twice. */
+int ramd_fused_cg_direction(ramd_vec_t x, ramd_vec_t p, ramd_vec_t z, int slot_rho, int slot_pq,
+                            int slot_new);
 /* several dot products against one vector in one pass: s[slot0+k] = <v_k, w>, k < count */
 int ramd_fused_multi_dot(const ramd_vec_t* vs, int count, ramd_vec_t w, int slot0);
 /* w += (-h) v ; s[slot_dot] = <u, w>   (one MGS step fused with the next dot, gmres.cpp:480-486);

@@ -110,8 +110,8 @@ SIGNATURES = {
     "ramd_scalars_fetch_async_begin": (i32, [i32, i32, i32]),
     "ramd_scalars_fetch_async_end": (i32, [i32, pf64, i32]),
     "ramd_fused_apply_dot": (i32, [mat_t, vec_t, vec_t, i32]),
-    "ramd_fused_cg_update": (i32, [vec_t, vec_t, vec_t, vec_t, vec_t, vec_t, i32, i32, i32, i32]),
-    "ramd_fused_cg_direction": (i32, [vec_t, vec_t, i32, i32]),
+    "ramd_fused_cg_update": (i32, [vec_t, vec_t, vec_t, vec_t, i32, i32, i32, i32]),
+    "ramd_fused_cg_direction": (i32, [vec_t, vec_t, vec_t, i32, i32, i32]),
     "ramd_fused_multi_dot": (i32, [C.POINTER(vec_t), i32, vec_t, i32]),
     "ramd_fused_mgs_step": (i32, [vec_t, vec_t, i32, vec_t, i32]),
     "ramd_fused_normalize": (i32, [vec_t, i32, i32]),

@@ -13,12 +13,11 @@
 namespace ramd
 {
 
-// CG update (src/solvers/krylov/cg.cpp:418-438):
-//   alpha = rho / (p.q) ; x = x + alpha*p ; r = r + (-alpha)*q ; rr = <r,r>
+// CG residual update (src/solvers/krylov/cg.cpp:418-438):
+//   alpha = rho / (p.q) ; r = r + (-alpha)*q ; rr = <r,r>
 //   PRECOND: z = dinv * r ; rz = <r,z>        else rz = rr
 template <typename T, bool PRECOND>
-__global__ __launch_bounds__(kBlock) void k_cg_update(int64_t n, T* __restrict__ x, T* __restrict__ r,
-                                                      const T* __restrict__ p,
+__global__ __launch_bounds__(kBlock) void k_cg_update(int64_t n, T* __restrict__ r,
                                                       const T* __restrict__ q,
                                                       const T* __restrict__ dinv, T* __restrict__ z,
                                                       ReduceCtx ctx, int slot_rho, int slot_pq,
@@ -35,17 +34,14 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(int64_t n, T* __restrict__
     double  rr = 0.0, rz = 0.0;
     for(int64_t i = gtid; i < np; i += gsz)
     {
-        P px = reinterpret_cast<P*>(x)[i];
         P pr = reinterpret_cast<P*>(r)[i];
-        P pp = reinterpret_cast<const P*>(p)[i];
-        P pq = reinterpret_cast<const P*>(q)[i];
+        P pq = nt_load(reinterpret_cast<const P*>(q) + i);
         P pd, pz;
         if(PRECOND)
             pd = reinterpret_cast<const P*>(dinv)[i];
 #pragma unroll
         for(int k = 0; k < NP; ++k)
         {
-            pk_elems<T>(px)[k] = pk_elems<T>(px)[k] + alpha * pk_elems<T>(pp)[k];
             T rn               = pk_elems<T>(pr)[k] + malpha * pk_elems<T>(pq)[k];
             pk_elems<T>(pr)[k] = rn;
             rr += (double)rn * (double)rn;
@@ -56,16 +52,14 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(int64_t n, T* __restrict__
                 rz += (double)rn * (double)zn;
             }
         }
-        reinterpret_cast<P*>(x)[i] = px;
         reinterpret_cast<P*>(r)[i] = pr;
         if(PRECOND)
             reinterpret_cast<P*>(z)[i] = pz;
     }
     for(int64_t i = np * NP + gtid; i < n; i += gsz)
     {
-        x[i]  = x[i] + alpha * p[i];
-        T rn  = r[i] + malpha * q[i];
-        r[i]  = rn;
+        T rn = r[i] + malpha * q[i];
+        r[i] = rn;
         rr += (double)rn * (double)rn;
         if(PRECOND)
         {
@@ -82,30 +76,39 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(int64_t n, T* __restrict__
     grid_reduce_finish<2>(ctx, vals, slots, ops, lds);
 }
 
-// p = beta*p + z with beta = s[num]/s[den]   (cg.cpp:441-442, ScaleAdd)
+// x = x + alpha*p (old p) ; p = beta*p + z       (cg.cpp:421 AddScale, :441-442 ScaleAdd)
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_cg_direction(int64_t n, T* __restrict__ p,
+__global__ __launch_bounds__(kBlock) void k_cg_direction(int64_t n, T* __restrict__ x, T* __restrict__ p,
                                                          const T* __restrict__ z,
                                                          const double* __restrict__ scalars,
-                                                         int slot_num, int slot_den)
+                                                         int slot_rho, int slot_pq, int slot_new)
 {
     using P          = typename Pack<T>::type;
     constexpr int NP = Pack<T>::N;
-    const T       beta = (T)scalars[slot_num] / (T)scalars[slot_den];
-    int64_t       np   = n / NP;
-    int64_t       gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t       gsz  = (int64_t)gridDim.x * blockDim.x;
+    const T       alpha = (T)scalars[slot_rho] / (T)scalars[slot_pq];
+    const T       beta  = (T)scalars[slot_new] / (T)scalars[slot_rho];
+    int64_t       np    = n / NP;
+    int64_t       gtid  = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t       gsz   = (int64_t)gridDim.x * blockDim.x;
     for(int64_t i = gtid; i < np; i += gsz)
     {
+        P px = reinterpret_cast<P*>(x)[i];
         P pp = reinterpret_cast<P*>(p)[i];
         P pz = reinterpret_cast<const P*>(z)[i];
 #pragma unroll
         for(int k = 0; k < NP; ++k)
+        {
+            pk_elems<T>(px)[k] = pk_elems<T>(px)[k] + alpha * pk_elems<T>(pp)[k];
             pk_elems<T>(pp)[k] = beta * pk_elems<T>(pp)[k] + pk_elems<T>(pz)[k];
+        }
+        reinterpret_cast<P*>(x)[i] = px;
         reinterpret_cast<P*>(p)[i] = pp;
     }
     for(int64_t i = np * NP + gtid; i < n; i += gsz)
+    {
+        x[i] = x[i] + alpha * p[i];
         p[i] = beta * p[i] + z[i];
+    }
 }
 
 // up to 8 dots against one vector in one pass over w: s[slot0+k] = <v_k, w>
@@ -262,39 +265,37 @@ int ramd_fused_apply_dot(ramd_mat_t m, ramd_vec_t x, ramd_vec_t y, int slot_dot)
     return ramd_fused_multi_dot(vs, 1, y, slot_dot);
 }
 
-int ramd_fused_cg_update(ramd_vec_t x, ramd_vec_t r, ramd_vec_t p, ramd_vec_t q, ramd_vec_t dinv,
-                         ramd_vec_t z, int slot_rho, int slot_pq, int slot_rr, int slot_rz)
+int ramd_fused_cg_update(ramd_vec_t r, ramd_vec_t q, ramd_vec_t dinv, ramd_vec_t z, int slot_rho,
+                         int slot_pq, int slot_rr, int slot_rz)
 {
-    CHECK_SAMEV(x, r);
-    CHECK_SAMEV(x, p);
-    CHECK_SAMEV(x, q);
+    CHECK_SAMEV(r, q);
     if(dinv)
     {
-        CHECK_SAMEV(x, dinv);
-        CHECK_SAMEV(x, z);
+        CHECK_SAMEV(r, dinv);
+        CHECK_SAMEV(r, z);
     }
     if(!slot_ok(slot_rho) || !slot_ok(slot_pq) || !slot_ok(slot_rr) || !slot_ok(slot_rz))
         RAMD_FAIL(RAMD_ERR_ARG, "scalar slot out of range");
-    if(x->n == 0)
+    if(r->n == 0)
         return RAMD_OK;
     Backend&  b    = backend();
-    const int grid = reduce_grid((x->n + 1) / 2);
+    const int grid = reduce_grid((r->n + 1) / 2);
     ReduceCtx ctx  = reduce_ctx();
 #define GO(T)                                                                                          \
     do                                                                                                 \
     {                                                                                                  \
         if(dinv)                                                                                       \
-            hipLaunchKernelGGL((k_cg_update<T, true>), dim3(grid), dim3(kBlock), 0, b.cur, x->n,       \
-                               (T*)x->d, (T*)r->d, (const T*)p->d, (const T*)q->d, (const T*)dinv->d,  \
-                               (T*)z->d, ctx, slot_rho, slot_pq, slot_rr, slot_rz);                    \
+            hipLaunchKernelGGL((k_cg_update<T, true>), dim3(grid), dim3(kBlock), 0, b.cur, r->n,       \
+                               (T*)r->d, (const T*)q->d, (const T*)dinv->d, (T*)z->d, ctx, slot_rho,   \
+                               slot_pq, slot_rr, slot_rz);                                             \
         else                                                                                           \
-            hipLaunchKernelGGL((k_cg_update<T, false>), dim3(grid), dim3(kBlock), 0, b.cur, x->n,      \
-                               (T*)x->d, (T*)r->d, (const T*)p->d, (const T*)q->d, (const T*)nullptr,  \
-                               (T*)nullptr, ctx, slot_rho, slot_pq, slot_rr, slot_rz);                 \
+            hipLaunchKernelGGL((k_cg_update<T, false>), dim3(grid), dim3(kBlock), 0, b.cur, r->n,      \
+                               (T*)r->d, (const T*)q->d, (const T*)nullptr, (T*)nullptr, ctx,          \
+                               slot_rho, slot_pq, slot_rr, slot_rz);                                   \
     } while(0)
-    if(x->dtype == RAMD_F64)
+    if(r->dtype == RAMD_F64)
         GO(double);
-    else if(x->dtype == RAMD_F32)
+    else if(r->dtype == RAMD_F32)
         GO(float);
     else
         RAMD_FAIL(RAMD_ERR_ARG, "fused_cg_update needs real vectors");
@@ -303,10 +304,12 @@ int ramd_fused_cg_update(ramd_vec_t x, ramd_vec_t r, ramd_vec_t p, ramd_vec_t q,
     return RAMD_OK;
 }
 
-int ramd_fused_cg_direction(ramd_vec_t p, ramd_vec_t z, int slot_num, int slot_den)
+int ramd_fused_cg_direction(ramd_vec_t x, ramd_vec_t p, ramd_vec_t z, int slot_rho, int slot_pq,
+                            int slot_new)
 {
+    CHECK_SAMEV(x, p);
     CHECK_SAMEV(p, z);
-    if(!slot_ok(slot_num) || !slot_ok(slot_den))
+    if(!slot_ok(slot_rho) || !slot_ok(slot_pq) || !slot_ok(slot_new))
         RAMD_FAIL(RAMD_ERR_ARG, "scalar slot out of range");
     if(p->n == 0)
         return RAMD_OK;
@@ -314,10 +317,11 @@ int ramd_fused_cg_direction(ramd_vec_t p, ramd_vec_t z, int slot_num, int slot_d
     const int grid = ew_grid((p->n + 1) / 2);
     if(p->dtype == RAMD_F64)
         hipLaunchKernelGGL((k_cg_direction<double>), dim3(grid), dim3(kBlock), 0, b.cur, p->n,
-                           (double*)p->d, (const double*)z->d, b.d_scalars, slot_num, slot_den);
+                           (double*)x->d, (double*)p->d, (const double*)z->d, b.d_scalars, slot_rho,
+                           slot_pq, slot_new);
     else if(p->dtype == RAMD_F32)
-        hipLaunchKernelGGL((k_cg_direction<float>), dim3(grid), dim3(kBlock), 0, b.cur, p->n,
-                           (float*)p->d, (const float*)z->d, b.d_scalars, slot_num, slot_den);
+        hipLaunchKernelGGL((k_cg_direction<float>), dim3(grid), dim3(kBlock), 0, b.cur, p->n, (float*)x->d,
+                           (float*)p->d, (const float*)z->d, b.d_scalars, slot_rho, slot_pq, slot_new);
     else
         RAMD_FAIL(RAMD_ERR_ARG, "fused_cg_direction needs real vectors");
     RAMD_HIP(hipGetLastError());
