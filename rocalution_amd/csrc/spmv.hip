@@ -70,7 +70,7 @@ struct ValPk<float>
 // workspace of the fused <x, y> epilogue
 struct CsrDotWs
 {
-    double* part1; // [nblk] one partial per workgroup
+    double* part1; // [4 * nblk] one partial per wave
 };
 
 // CSR SpMV, "LDS transpose" layout.  Measured on MI355X (tools/spmv_lab.py): the kernel is bound by
@@ -96,7 +96,6 @@ __global__ __launch_bounds__(kBlock) void k_csr_tr(int nrow, int nblk, int per_x
     constexpr int VN  = ValPk<T>::N;
     __shared__ T      sval[kCsrChunk];
     __shared__ int    scol[kCsrChunk];
-    __shared__ double red[8];
     const int blk  = xcd_block(nblk, per_xcd, bm);
     double    dacc = 0.0;
     if(blk >= 0)
@@ -115,6 +114,9 @@ __global__ __launch_bounds__(kBlock) void k_csr_tr(int nrow, int nblk, int per_x
         T         sum   = (T)0;
         if(MODE == 1 && row < nrow)
             sum = y[row];
+        T xrow = (T)0; // for the fused <x,y>: fetched up front so its latency hides behind the stream
+        if(DOT && row < nrow)
+            xrow = x[row];
         for(int cb = start & ~3; cb < end; cb += kCsrChunk)
         {
             v4i32 c[kCsrChunk / (4 * kBlock)];
@@ -185,18 +187,18 @@ __global__ __launch_bounds__(kBlock) void k_csr_tr(int nrow, int nblk, int per_x
         {
             nt_store(sum, y + row);
             if(DOT)
-                dacc = (double)sum * (double)x[row];
+                dacc = (double)sum * (double)xrow;
         }
     }
     if(DOT)
     {
-        // one partial per workgroup, fire-and-forget; a tiny second launch (reduce_sum_to_slot) adds the
-        // partials in a fixed order.  (A ticketed in-kernel finish was measured 9% slower: every
-        // workgroup would have to drain its partial store before taking the ticket, which holds its
-        // wave slots for a full memory round trip.)
-        const double bsum = block_reduce_sum(dacc, red);
-        if(threadIdx.x == 0 && blk >= 0)
-            ws.part1[blk] = bsum;
+        // one partial per WAVE, fire-and-forget (no workgroup barrier in the epilogue); a tiny second
+        // launch (reduce_sum_to_slot) adds the partials in a fixed order.  (A ticketed in-kernel finish
+        // was measured 9% slower: every workgroup would have to drain its partial store before taking
+        // the ticket, which holds its wave slots for a full memory round trip.)
+        const double wsum = wave_reduce_sum(dacc);
+        if((threadIdx.x & 63) == 0 && blk >= 0)
+            ws.part1[blk * (kBlock / 64) + (threadIdx.x >> 6)] = wsum;
     }
 }
 
@@ -379,7 +381,7 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
         if(!mm->dot_part1 || mm->dot_nblk != nblk)
         {
             dev_free(&mm->dot_part1);
-            RAMD_TRY(dev_alloc(&mm->dot_part1, nblk));
+            RAMD_TRY(dev_alloc(&mm->dot_part1, (int64_t)nblk * (kBlock / 64)));
             mm->dot_nblk = nblk;
         }
         ws.part1 = mm->dot_part1;
@@ -400,7 +402,7 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
     if(dot)
     {
         prof_spmv_end();
-        return reduce_sum_to_slot(ws.part1, nblk, slot);
+        return reduce_sum_to_slot(ws.part1, (int64_t)nblk * (kBlock / 64), slot);
     }
     return RAMD_OK;
 }
