@@ -271,6 +271,14 @@ public:
     {
         this->vector_interior_.PointWiseMult(x.vector_interior_, y.vector_interior_);
     }
+    void CopyFromFloat(const GlobalVector<float>& src)
+    {
+        this->vector_interior_.CopyFromFloat(src.GetInterior());
+    }
+    void CopyFromDouble(const GlobalVector<double>& src)
+    {
+        this->vector_interior_.CopyFromDouble(src.GetInterior());
+    }
     // global_vector.cpp:547-588: local reduction, then sum over ranks; Norm = sqrt(allreduce(dot))
     ValueType Dot(const GlobalVector<ValueType>& x) const
     {
@@ -437,6 +445,17 @@ public:
     void ExtractInverseDiagonal(GlobalVector<ValueType>* vec_inv_diag) const
     {
         this->matrix_interior_.ExtractInverseDiagonal(&vec_inv_diag->vector_interior_);
+    }
+    // extension: value-cast copy (interior + ghost, same parallel manager) for MixedPrecisionDC on
+    // Global objects -- the reference instantiates MixedPrecisionDC for LocalMatrix only
+    // (src/solvers/mixed_precision.cpp:463-468); this is the row-block generalisation of :201-229
+    template <typename OtherType>
+    void CastFrom(const GlobalMatrix<OtherType>& src)
+    {
+        this->pm_ = src.pm();
+        this->matrix_interior_.template CastFrom<OtherType>(src.GetInterior());
+        this->matrix_ghost_.template CastFrom<OtherType>(src.GetGhost());
+        this->InitCommPattern_();
     }
     // extension: per-rank slab of the synthetic 3-D Poisson operator, built on the device
     void GeneratePoisson7Slab(int N, int64_t row_begin, int64_t row_end)

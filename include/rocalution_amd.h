@@ -280,6 +280,10 @@ int ramd_solver_set_decomposition(ramd_solver_t s, int decomp);
  * preconditioner of MC-SGS / ILU(0) is wrapped in BlockJacobi as the reference samples do. */
 typedef struct ramd_gsolver_s* ramd_gsolver_t;
 int ramd_gsolver_create(ramd_comm_t comm, int solver, int precond, ramd_gsolver_t* out);
+/* MixedPrecisionDC<fp64 Global outer, fp32 Global inner> (config 5 of BASELINE.json); inner
+ * preconditioner: RAMD_PC_NONE or RAMD_PC_JACOBI */
+int ramd_gsolver_create_mixed(ramd_comm_t comm, int inner_solver, int inner_precond, ramd_gsolver_t* out);
+int ramd_gsolver_init_inner(ramd_gsolver_t g, double abs_tol, double rel_tol, double div_tol, int max_iter);
 int ramd_gsolver_destroy(ramd_gsolver_t g);
 /* rank's slab of the 3-D 7-point Poisson operator N^3: planes [z_begin, z_end) */
 int ramd_gsolver_setup_poisson(ramd_gsolver_t g, int N, int z_begin, int z_end);

@@ -151,6 +151,8 @@ SIGNATURES = {
     "ramd_solver_clear": (i32, [ptr]),
     # distributed driver
     "ramd_gsolver_create": (i32, [ptr, i32, i32, C.POINTER(ptr)]),
+    "ramd_gsolver_create_mixed": (i32, [ptr, i32, i32, C.POINTER(ptr)]),
+    "ramd_gsolver_init_inner": (i32, [ptr, f64, f64, f64, i32]),
     "ramd_gsolver_destroy": (i32, [ptr]),
     "ramd_gsolver_setup_poisson": (i32, [ptr, i32, i32, i32]),
     "ramd_gsolver_setup_csr": (i32, [ptr, i64, i32, i64, ptr, ptr, ptr, i64, ptr, ptr, ptr, i32, ptr, ptr,

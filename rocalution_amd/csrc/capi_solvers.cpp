@@ -281,9 +281,29 @@ struct ramd_gsolver_s
     BlockJacobi<GM, GV, double>  bj;
     ILU<LM, LV, double>          ilu;
     MultiColoredSGS<LM, LV, double> mcsgs;
+    // mixed precision: fp64 defect correction around an fp32 Global solver
+    typedef GlobalMatrix<float>  GMF;
+    typedef GlobalVector<float>  GVF;
+    bool                         mixed = false;
+    int                          inner_kind = RAMD_SOLVER_CG;
+    MixedPrecisionDC<GM, GV, double, GMF, GVF, float> mp;
+    CG<GMF, GVF, float>          cgf;
+    GMRES<GMF, GVF, float>       gmresf;
+    BiCGStab<GMF, GVF, float>    bicgf;
+    Jacobi<GMF, GVF, float>      jacobif;
     bool                         setup = false, built = false;
+    IterativeLinearSolver<GMF, GVF, float>* inner()
+    {
+        if(inner_kind == RAMD_SOLVER_GMRES)
+            return &gmresf;
+        if(inner_kind == RAMD_SOLVER_BICGSTAB)
+            return &bicgf;
+        return &cgf;
+    }
     IterativeLinearSolver<GM, GV, double>* ls()
     {
+        if(mixed)
+            return &mp;
         if(solver_kind == RAMD_SOLVER_GMRES)
             return &gmres;
         if(solver_kind == RAMD_SOLVER_BICGSTAB)
@@ -500,6 +520,30 @@ int ramd_gsolver_create(ramd_comm_t comm, int solver, int precond, ramd_gsolver_
     GUARD_END
 }
 
+int ramd_gsolver_create_mixed(ramd_comm_t comm, int inner_solver, int inner_precond, ramd_gsolver_t* out)
+{
+    if(!out || inner_solver < 0 || inner_solver > 2
+       || (inner_precond != RAMD_PC_NONE && inner_precond != RAMD_PC_JACOBI))
+        return RAMD_ERR_ARG;
+    GUARD_BEGIN
+    ramd_gsolver_s* g = new ramd_gsolver_s;
+    g->mixed          = true;
+    g->inner_kind     = inner_solver;
+    g->solver_kind    = RAMD_SOLVER_CG;
+    g->pc_kind        = inner_precond;
+    g->pm.SetMPICommunicator(comm);
+    g->mp.Verbose(0);
+    g->inner()->Verbose(0);
+    *out = g;
+    GUARD_END
+}
+int ramd_gsolver_init_inner(ramd_gsolver_t g, double a, double r, double d, int mx)
+{
+    if(!g || !g->mixed)
+        return RAMD_ERR_ARG;
+    g->inner()->Init(a, r, d, mx);
+    return RAMD_OK;
+}
 int ramd_gsolver_destroy(ramd_gsolver_t g)
 {
     if(g)
@@ -636,6 +680,15 @@ int ramd_gsolver_build(ramd_gsolver_t g)
     if(g->built)
         g->ls()->Clear();
     g->ls()->SetOperator(g->A);
+    if(g->mixed)
+    {
+        if(g->pc_kind == RAMD_PC_JACOBI)
+            g->inner()->SetPreconditioner(g->jacobif);
+        g->mp.Set(*g->inner());
+        g->mp.Build();
+        g->built = true;
+        return RAMD_OK;
+    }
     if(g->pc_kind == RAMD_PC_JACOBI)
         g->ls()->SetPreconditioner(g->jacobi);
     else if(g->pc_kind == RAMD_PC_ILU0)

@@ -163,11 +163,18 @@ def make_callback_comm(rank, world, dist):
 class DistributedSolver:
     """Solver<GlobalMatrix,GlobalVector> on one rank (ramd_gsolver_* of the C ABI)."""
 
-    def __init__(self, comm, solver, precond):
+    def __init__(self, comm, solver, precond, mixed=False):
+        """mixed=True: MixedPrecisionDC (fp64 outer) around an fp32 `solver` with `precond` (none/Jacobi)"""
         from . import capi
         self._capi, self._lib = capi, capi.load()
         self._g = C.c_void_p()
-        capi.check(self._lib.ramd_gsolver_create(comm, int(solver), int(precond), C.byref(self._g)))
+        if mixed:
+            capi.check(self._lib.ramd_gsolver_create_mixed(comm, int(solver), int(precond), C.byref(self._g)))
+        else:
+            capi.check(self._lib.ramd_gsolver_create(comm, int(solver), int(precond), C.byref(self._g)))
+
+    def init_inner(self, abs_tol, rel_tol, div_tol, max_iter):
+        self._capi.check(self._lib.ramd_gsolver_init_inner(self._g, abs_tol, rel_tol, div_tol, max_iter))
 
     def __del__(self):
         try:

@@ -158,8 +158,19 @@ def gpu_worker(rank, world, initfile, kind, outdir):
     out["y_ell"] = g2.apply(x[lo:hi])
     out["xs2"] = g2.solve(None, np.zeros(hi - lo))
     it2, st2, res2 = g2.result()
+    # config-5 shape: fp64 defect correction around fp32 CG+Jacobi, both levels Global
+    g3 = D.DistributedSolver(comm, capi.SOLVER_CG, capi.PC_JACOBI, mixed=True)
+    if kind == "poisson_slab":
+        g3.setup_poisson(N, z0, z1)
+    else:
+        g3.setup_csr(n, piece, plan)
+    g3.init(1e-15, 1e-6, 1e8, 500)
+    g3.init_inner(1e-5, 1e-2, 1e20, 100000)
+    g3.build()
+    out["xs3"] = g3.solve(None, np.zeros(hi - lo))
+    it3, st3, res3 = g3.result()
     np.savez(os.path.join(outdir, "r%d.npz" % rank), lo=lo, hi=hi, it=it, res=res, st=st, it2=it2, st2=st2,
-             res2=res2, **out)
+             res2=res2, it3=it3, st3=st3, res3=res3, **out)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -42,3 +42,11 @@ def test_two_ranks_one_gpu(kind, oracle):
     xs2 = np.concatenate([r["xs2"] for r in res])
     assert int(res[0]["st2"]) == 2
     assert np.linalg.norm(xs2 - 1.0) / np.sqrt(n) < 1e-4
+    # mixed precision on Global objects (no reference counterpart, SURVEY.md headline 6): pinned by the
+    # 1-process MixedPrecisionDC oracle -- same outer iteration count +-1, same solution
+    refm = oracle.solve_mixed(rp, ci, va, b, outer={}, inner=dict(solver=oracle.CG, precond=oracle.PC_JACOBI,
+                                                                   abs_tol=1e-5, rel_tol=1e-2, div_tol=1e20,
+                                                                   max_iter=100000))
+    xs3 = np.concatenate([r["xs3"] for r in res])
+    assert abs(int(res[0]["it3"]) - refm["iters"]) <= 1 and int(res[0]["st3"]) == refm["status"]
+    assert np.linalg.norm(xs3 - refm["x"]) / np.linalg.norm(refm["x"]) < 1e-5
