@@ -27,6 +27,8 @@ import subprocess
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -109,6 +111,9 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-gpu", action="store_true")
+    ap.add_argument("--solver", default="cg", choices=["cg", "gmres", "bicgstab", "mixed"],
+                    help="headline = cg; the others run the remaining BASELINE.json configs through the same harness")
+    ap.add_argument("--precond", default="jacobi", choices=["none", "jacobi", "ilu0", "mcsgs"])
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the GMRES(30)+ILU(0) and BiCGStab+MC-SGS legs (reported under `extras`)")
     args = ap.parse_args()
@@ -192,12 +197,31 @@ def main():
             ls.Clear()
             return dt, it, res, tb
 
-        run(W)  # warmup
-        dt, it, res, tbuild = run(K)
+        HEAD = {"cg": S.CG, "gmres": S.GMRES, "bicgstab": S.BiCGStab}.get(args.solver, S.CG)
+        HPC = {"none": None, "jacobi": S.Jacobi, "ilu0": S.ILU, "mcsgs": S.MultiColoredSGS}[args.precond]
+        if args.solver == "mixed":
+            def run(iters, *_a):  # noqa: F811  (config 5 on one GPU)
+                inner = S.CG(np.float32)
+                if HPC is not None:
+                    inner.SetPreconditioner(HPC())
+                inner.Init(1e-5, 1e-2, 1e20, 100000)
+                mp = S.MixedPrecisionDC(); mp.SetOperator(A); mp.Set(inner)
+                mp.Init(NEVER[0], NEVER[1], NEVER[2], iters)
+                mp.Build(); x.Zeros(); barrier()
+                t0 = time.perf_counter(); mp.Solve(rhs, x); barrier()
+                dt = time.perf_counter() - t0
+                r = (dt, mp.GetIterationCount(), mp.GetCurrentResidual(), 0.0)
+                mp.Clear()
+                return r
+            run(W)
+            dt, it, res, tbuild = run(K)
+        else:
+            run(W, HEAD, HPC, 30 if args.solver == "gmres" else None)  # warmup
+            dt, it, res, tbuild = run(K, HEAD, HPC, 30 if args.solver == "gmres" else None)
         assert it == K, (it, K)
         # --- roofline leg: same run with every SpMV launch bracketed by HIP events
         capi.check(lib.ramd_prof_spmv_enable(1))
-        run(min(K, 200))
+        run(min(K, 200), S.CG, S.Jacobi, None) if args.solver != "mixed" else run(min(K, 20))
         cnt, avg, mn, mx = C.c_int(0), C.c_double(0), C.c_double(0), C.c_double(0)
         capi.check(lib.ramd_prof_spmv_result(C.byref(cnt), C.byref(avg), C.byref(mn), C.byref(mx)))
         capi.check(lib.ramd_prof_spmv_enable(0))
@@ -209,7 +233,7 @@ def main():
                     if args.format == "csr" else "k_ell<double>", launches=cnt.value, avg_ms=round(avg.value, 5),
                     min_ms=round(mn.value, 5), max_ms=round(mx.value, 5), algorithmic_bytes=bytes_alg)
         extras = {}
-        if not args.no_extras:
+        if not args.no_extras and args.solver == "cg" and args.precond == "jacobi":
             # the other two solver/preconditioner pairs of BASELINE.json on the same operator (same
             # "exactly K iterations" protocol; Build() reported separately, as in the reference samples)
             for name, sc, pc, basis, iters in (("gmres30_ilu0", S.GMRES, S.ILU, 30, min(K, 60)),
@@ -222,14 +246,20 @@ def main():
     else:
         z0, z1 = (N * rank) // world, (N * (rank + 1)) // world
         g = C.c_void_p()
-        capi.check(lib.ramd_gsolver_create(comm, capi.SOLVER_CG, capi.PC_JACOBI, C.byref(g)))
+        SK = {"cg": capi.SOLVER_CG, "gmres": capi.SOLVER_GMRES, "bicgstab": capi.SOLVER_BICGSTAB}
+        PK = {"none": capi.PC_NONE, "jacobi": capi.PC_JACOBI, "ilu0": capi.PC_ILU0, "mcsgs": capi.PC_MCSGS}
+        if args.solver == "mixed":  # config 5: fp64 defect correction around fp32 CG + Jacobi
+            capi.check(lib.ramd_gsolver_create_mixed(comm, capi.SOLVER_CG, PK[args.precond], C.byref(g)))
+            capi.check(lib.ramd_gsolver_init_inner(g, 1e-5, 1e-2, 1e20, 100000))
+        else:
+            capi.check(lib.ramd_gsolver_create(comm, SK[args.solver], PK[args.precond], C.byref(g)))
         capi.check(lib.ramd_gsolver_setup_poisson(g, N, z0, z1))
-        if fmt != ra.CSR:
-            capi.check(lib.ramd_gsolver_convert(g, fmt))
 
         def run(iters):
             capi.check(lib.ramd_gsolver_init(g, NEVER[0], NEVER[1], NEVER[2], 0, iters))
             capi.check(lib.ramd_gsolver_build(g))
+            if fmt != ra.CSR:  # converted after Build(), as the reference tests do
+                capi.check(lib.ramd_gsolver_convert(g, fmt))
             capi.check(lib.ramd_gsolver_prepare_ones(g))
             barrier()
             t0 = time.perf_counter()
@@ -251,12 +281,16 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "CG+Jacobi iterations/s, 3D 7-pt Poisson %d^3 CSR fp64" % N,
+            "metric": "%s iterations/s, 3D 7-pt Poisson %d^3 %s fp64" % (
+                {"cg": "CG", "gmres": "GMRES(30)", "bicgstab": "BiCGStab", "mixed": "MixedPrecisionDC(fp64/fp32 CG)"}[args.solver]
+                + "+" + {"none": "none", "jacobi": "Jacobi", "ilu0": "ILU(0)", "mcsgs": "MC-SGS"}[args.precond], N,
+                args.format.upper()),
             "value": round(it / dt, 3), "unit": "iters/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / it * 1e3, 5), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "CG+Jacobi, 3-D 7-point Poisson %d^3 (n=%d, nnz=%d) %s fp64, rhs=A*1, x0=0, "
-                                   "row-split over %d GPU(s)" % (N, n, nnz, args.format.upper(), world),
+            "config": {"workload": "%s+%s, 3-D 7-point Poisson %d^3 (n=%d, nnz=%d) %s fp64, rhs=A*1, x0=0, "
+                                   "row-split over %d GPU(s)" % (args.solver, args.precond, N, n, nnz,
+                                                                 args.format.upper(), world),
                        "parallelism": "rows%d" % world, "fused": True},
             "final_residual": res, "build_s": round(tbuild, 4),
         }

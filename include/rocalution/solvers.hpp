@@ -443,10 +443,18 @@ public:
         , precond_mat_format_(CSR)
         , format_block_dim_(1)
         , decomp_(true)
+        , fused_sweeps_(true)
+        , sweeps_(NULL)
         , preconditioner_(NULL)
         , num_blocks_(0)
         , block_sizes_(NULL)
     {
+    }
+    // extension: run the decomposed apply as 2*nb-1 fused colour sweeps (default) instead of the
+    // reference's block-by-block sequence; both produce bit-identical results
+    void SetFusedSweeps(bool on)
+    {
+        this->fused_sweeps_ = on;
     }
     virtual ~MultiColored()
     {
@@ -480,6 +488,13 @@ public:
         // Permute_: P A P^T
         this->preconditioner_->Permute(this->permutation_);
         this->Factorize_();
+        if(this->decomp_ && this->fused_sweeps_ && !this->op_mat_format_ && this->CanFuseSweeps_()
+           && this->TryBuildSweeps_())
+        {
+            this->build_ = true;
+            this->preconditioner_->Clear();
+            return;
+        }
         this->Decompose_();
         this->build_ = true;
         if(this->decomp_)
@@ -489,6 +504,11 @@ public:
     }
     virtual void Clear(void)
     {
+        if(this->sweeps_ != NULL)
+        {
+            ramd_mcsgs_destroy(this->sweeps_);
+            this->sweeps_ = NULL;
+        }
         if(this->preconditioner_ != NULL)
         {
             this->preconditioner_->LAnalyseClear();
@@ -518,6 +538,11 @@ public:
     virtual void Solve(const VectorType& rhs, VectorType* x)
     {
         assert(this->build_ == true && x != NULL && x != &rhs);
+        if(this->sweeps_ != NULL)
+        {
+            this->ApplySweeps_(rhs, x);
+            return;
+        }
         if(this->decomp_)
         {
             this->ExtractRHSinX_(rhs, x);
@@ -533,6 +558,41 @@ public:
 protected:
     virtual void Factorize_(void) {}
     virtual void PostAnalyse_(void) {}
+    virtual bool CanFuseSweeps_(void) const
+    {
+        return false;
+    }
+    template <class O = OperatorType>
+    typename std::enable_if<std::is_same<O, LocalMatrix<ValueType>>::value, bool>::type TryBuildSweeps_(void)
+    {
+        if(!this->preconditioner_->is_accel_())
+            return false;
+        int s = ramd_mcsgs_build(this->preconditioner_->handle(), this->num_blocks_, this->block_sizes_,
+                                 this->permutation_.handle(), &this->sweeps_);
+        if(s == RAMD_ERR_UNSUPPORTED)
+        {
+            this->sweeps_ = NULL;
+            return false;
+        }
+        RAMD_CHECK(s);
+        return true;
+    }
+    template <class O = OperatorType>
+    typename std::enable_if<!std::is_same<O, LocalMatrix<ValueType>>::value, bool>::type TryBuildSweeps_(void)
+    {
+        return false;
+    }
+    template <class V = VectorType>
+    typename std::enable_if<std::is_same<V, LocalVector<ValueType>>::value, void>::type
+        ApplySweeps_(const VectorType& rhs, VectorType* x)
+    {
+        RAMD_CHECK(ramd_mcsgs_apply(this->sweeps_, rhs.handle(), x->handle()));
+    }
+    template <class V = VectorType>
+    typename std::enable_if<!std::is_same<V, LocalVector<ValueType>>::value, void>::type
+        ApplySweeps_(const VectorType&, VectorType*)
+    {
+    }
     virtual void SolveL_(void) = 0;
     virtual void SolveD_(void) = 0;
     virtual void SolveR_(void) = 0;
@@ -623,6 +683,8 @@ protected:
     unsigned int                  precond_mat_format_;
     int                           format_block_dim_;
     bool                          decomp_;
+    bool                          fused_sweeps_;
+    ramd_mcsgs_t                  sweeps_;
     OperatorType*                 preconditioner_;
     std::vector<OperatorType*>    block_; // [i*nb+j]
     std::vector<VectorType*>      x_block_;
@@ -659,6 +721,10 @@ public:
     }
 
 protected:
+    virtual bool CanFuseSweeps_(void) const
+    {
+        return this->omega_ == static_cast<ValueType>(1); // the SSOR scalings are not fused
+    }
     virtual void PostAnalyse_(void)
     {
         this->preconditioner_->LAnalyse(false);

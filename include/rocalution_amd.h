@@ -190,6 +190,13 @@ int ramd_fused_cg_update(ramd_vec_t r, ramd_vec_t q, ramd_vec_t dinv, ramd_vec_t
  * next to the direction update reads p once per iteration instead of twice. */
 int ramd_fused_cg_direction(ramd_vec_t x, ramd_vec_t p, ramd_vec_t z, int slot_rho, int slot_pq,
                             int slot_new);
+/* multi-coloured SGS apply as 2*nb-1 fused colour sweeps on the permuted matrix P A P^T (arithmetic of
+ * MultiColored::Solve decomposed form, preconditioner_multicolored.cpp:348-413, _gs.cpp:127-199) */
+typedef struct ramd_mcsgs_s* ramd_mcsgs_t;
+int ramd_mcsgs_build(ramd_mat_t permuted, int num_blocks, const int* block_sizes, ramd_vec_t perm_i32,
+                     ramd_mcsgs_t* out);
+int ramd_mcsgs_apply(ramd_mcsgs_t h, ramd_vec_t rhs, ramd_vec_t x);
+int ramd_mcsgs_destroy(ramd_mcsgs_t h);
 /* several dot products against one vector in one pass: s[slot0+k] = <v_k, w>, k < count */
 int ramd_fused_multi_dot(const ramd_vec_t* vs, int count, ramd_vec_t w, int slot0);
 /* w += (-h) v ; s[slot_dot] = <u, w>   (one MGS step fused with the next dot, gmres.cpp:480-486);
@@ -274,6 +281,7 @@ int ramd_mat_read_mtx(const char* filename, int dtype, ramd_mat_t* out);
 /* MultiColored::SetDecomposition (preconditioner_multicolored.cpp:140-146): false = L/U sweeps on the
  * permuted matrix (LSolve/USolve) instead of the colour-block decomposition */
 int ramd_solver_set_decomposition(ramd_solver_t s, int decomp);
+int ramd_solver_set_fused_sweeps(ramd_solver_t s, int on); /* MultiColored::SetFusedSweeps (default on) */
 
 /* distributed driver: GlobalMatrix/GlobalVector + Solver<GlobalMatrix,GlobalVector> on one rank of a
  * row-block decomposition (clients/samples/cg_mpi.cpp, bicgstab_mpi.cpp of the reference).  The local

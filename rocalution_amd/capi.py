@@ -112,6 +112,9 @@ SIGNATURES = {
     "ramd_fused_apply_dot": (i32, [mat_t, vec_t, vec_t, i32]),
     "ramd_fused_cg_update": (i32, [vec_t, vec_t, vec_t, vec_t, i32, i32, i32, i32]),
     "ramd_fused_cg_direction": (i32, [vec_t, vec_t, vec_t, i32, i32, i32]),
+    "ramd_mcsgs_build": (i32, [mat_t, i32, pi32, vec_t, C.POINTER(ptr)]),
+    "ramd_mcsgs_apply": (i32, [ptr, vec_t, vec_t]),
+    "ramd_mcsgs_destroy": (i32, [ptr]),
     "ramd_fused_multi_dot": (i32, [C.POINTER(vec_t), i32, vec_t, i32]),
     "ramd_fused_mgs_step": (i32, [vec_t, vec_t, i32, vec_t, i32]),
     "ramd_fused_normalize": (i32, [vec_t, i32, i32]),
@@ -141,6 +144,7 @@ SIGNATURES = {
     "ramd_solver_set_verbose": (i32, [ptr, i32]),
     "ramd_solver_set_precond_format": (i32, [ptr, i32]),
     "ramd_solver_set_decomposition": (i32, [ptr, i32]),
+    "ramd_solver_set_fused_sweeps": (i32, [ptr, i32]),
     "ramd_mat_read_mtx": (i32, [C.c_char_p, i32, C.POINTER(mat_t)]),
     "ramd_solver_build": (i32, [ptr, mat_t]),
     "ramd_solver_solve": (i32, [ptr, vec_t, vec_t]),

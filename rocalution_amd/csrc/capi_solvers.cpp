@@ -27,6 +27,7 @@ struct SolverBase
     virtual void set_verbose(int)                                        = 0;
     virtual void set_precond_format(int) {}
     virtual void set_decomposition(bool) {}
+    virtual void set_fused_sweeps(bool) {}
     virtual void build(ramd_mat_t op)                                    = 0;
     virtual void solve(ramd_vec_t rhs, ramd_vec_t x)                     = 0;
     virtual bool precond_apply(ramd_vec_t, ramd_vec_t)                   = 0;
@@ -113,6 +114,10 @@ struct LocalSolver : SolverBase
     void set_decomposition(bool d) override
     {
         pcs.mcsgs.SetDecomposition(d);
+    }
+    void set_fused_sweeps(bool f) override
+    {
+        pcs.mcsgs.SetFusedSweeps(f);
     }
     void build(ramd_mat_t h) override
     {
@@ -417,6 +422,13 @@ int ramd_solver_set_decomposition(ramd_solver_t s, int d)
     if(!s)
         return RAMD_ERR_ARG;
     s->impl->set_decomposition(d != 0);
+    return RAMD_OK;
+}
+int ramd_solver_set_fused_sweeps(ramd_solver_t s, int on)
+{
+    if(!s)
+        return RAMD_ERR_ARG;
+    s->impl->set_fused_sweeps(on != 0);
     return RAMD_OK;
 }
 int ramd_mat_read_mtx(const char* filename, int dtype, ramd_mat_t* out)

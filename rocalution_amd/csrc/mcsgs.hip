@@ -1,0 +1,401 @@
+// mcsgs.hip -- multi-coloured symmetric Gauss-Seidel apply as 2*nb-1 fused colour sweeps.
+//
+// Reference (decomposed form): src/solvers/preconditioners/preconditioner_multicolored.cpp:348-413 and
+// preconditioner_multicolored_gs.cpp:127-199 -- per apply, for nb colours:
+//   x = P rhs ; slice copies ; for i: [for j<i: x_i += -1*A_ij x_j] ; x_i *= Dinv_i      (SolveL_)
+//   x_i *= D_i (SolveD_) ; for i desc: [for j>i DESC: x_i += -1*A_ij x_j] ; x_i *= Dinv_i (SolveR_)
+//   gather slices ; x = P^T x_
+// i.e. 1 + nb + (nb(nb-1)/2 + nb) + nb + (nb(nb-1)/2 + nb) + nb + 1 kernels (14 for 2 colours), each a
+// separate pass over memory.  Here every row's whole L-part (resp. U-part) is one sweep: the permuted
+// matrix is split ONCE into a strictly-lower and a strictly-upper wave-sliced ELL (64 rows per slice,
+// column-major => coalesced), U entries stored in the reference's accumulation order (colour block
+// descending, column ascending), the permutation gather/scatter and the three diagonal scalings are
+// folded into the sweeps.  Arithmetic per row is the reference's, operation for operation
+// (x + (-1*a)*y == x - a*y exactly), so results are bit-identical to the block form.
+#include "device_utils.hpp"
+#include "matrix_impl.hpp"
+
+#include <vector>
+
+namespace ramd
+{
+
+struct McsgsPlan
+{
+    int   dtype = RAMD_F64;
+    int   n = 0, nb = 0;
+    std::vector<int> off; // [nb+1] colour block offsets (positions in the permuted order)
+    std::vector<char> identity; // block (i,i) empty -> Jacobi::Solve is the identity
+    int*  iperm   = nullptr; // [n] position -> original row
+    int*  blk_of  = nullptr; // [n] colour of a position
+    void* d       = nullptr; // [n] diag_block_ (0 where the row stores no diagonal)
+    void* dinv    = nullptr; // [n] Jacobi inverse diagonal (1 for a zero diagonal, 0 where none is stored)
+    void* xp      = nullptr; // [n] permuted work vector
+    // sliced ELL of the strictly lower / upper colour parts (slice = 64 consecutive positions)
+    int * l_off = nullptr, *l_col = nullptr, *u_off = nullptr, *u_col = nullptr;
+    void *l_val = nullptr, *u_val = nullptr;
+    void  release()
+    {
+        dev_free(&iperm);
+        dev_free(&blk_of);
+        dev_free(&l_off);
+        dev_free(&l_col);
+        dev_free(&u_off);
+        dev_free(&u_col);
+        void** ps[] = {&d, &dinv, &xp, &l_val, &u_val};
+        for(void** p : ps)
+        {
+            if(*p)
+                (void)hipFree(*p);
+            *p = nullptr;
+        }
+    }
+};
+
+__global__ __launch_bounds__(kBlock) void k_mc_prepare(int n, int nb, const int* __restrict__ off,
+                                                       const int* __restrict__ perm,
+                                                       int* __restrict__ iperm, int* __restrict__ blk_of)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gsz)
+    {
+        iperm[perm[i]] = (int)i;
+        int b = 0;
+        while(b + 1 < nb && (int)i >= off[b + 1])
+            ++b;
+        blk_of[i] = b;
+    }
+}
+
+// per position: entries strictly below / above its colour block; per slice: 64 * max
+template <bool LOWER>
+__global__ __launch_bounds__(kBlock) void k_mc_width(int n, const int* __restrict__ rp,
+                                                     const int* __restrict__ ci,
+                                                     const int* __restrict__ off,
+                                                     const int* __restrict__ blk_of,
+                                                     int* __restrict__ slice_w)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int           c = 0;
+    if(t < n)
+    {
+        const int b  = blk_of[t];
+        const int lo = off[b], hi = off[b + 1];
+        for(int j = rp[t]; j < rp[t + 1]; ++j)
+            if(LOWER ? (ci[j] < lo) : (ci[j] >= hi))
+                ++c;
+    }
+#pragma unroll
+    for(int o = 32; o > 0; o >>= 1)
+        c = max(c, __shfl_xor(c, o, 64));
+    if((threadIdx.x & 63) == 0 && (t >> 6) * 64 < n)
+        slice_w[t >> 6] = c * 64;
+}
+
+// fill; also extracts diag / inverse diagonal (host_matrix_csr.cpp:772-845 semantics)
+template <typename T, bool LOWER>
+__global__ __launch_bounds__(kBlock) void k_mc_fill(int n, int nb, const int* __restrict__ rp,
+                                                    const int* __restrict__ ci,
+                                                    const T* __restrict__ val,
+                                                    const int* __restrict__ off,
+                                                    const int* __restrict__ blk_of,
+                                                    const int* __restrict__ slice_off,
+                                                    int* __restrict__ ecol, T* __restrict__ eval,
+                                                    T* __restrict__ d, T* __restrict__ dinv)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= n)
+        return;
+    const int b    = blk_of[t];
+    const int lane = (int)(t & 63);
+    const int base = slice_off[t >> 6];
+    const int w    = (slice_off[(t >> 6) + 1] - base) >> 6;
+    const int rs = rp[t], re = rp[t + 1];
+    int       k = 0;
+    if(LOWER)
+    {
+        for(int j = rs; j < re && ci[j] < off[b]; ++j, ++k) // ascending columns == ascending blocks
+        {
+            ecol[base + k * 64 + lane] = ci[j];
+            eval[base + k * 64 + lane] = val[j];
+        }
+        // diagonal of the colour block (first match wins)
+        T dv = (T)0, iv = (T)0;
+        for(int j = rs; j < re; ++j)
+            if(ci[j] == (int)t)
+            {
+                dv = val[j];
+                iv = (dv != (T)0) ? (T)1 / dv : (T)1;
+                break;
+            }
+        d[t]    = dv;
+        dinv[t] = iv;
+    }
+    else
+    {
+        // reference order of SolveR_: colour blocks DESCENDING, columns ascending inside a block
+        int hi_end = re;
+        for(int bb = nb - 1; bb > b; --bb)
+        {
+            int lo = hi_end;
+            while(lo > rs && ci[lo - 1] >= off[bb])
+                --lo;
+            for(int j = lo; j < hi_end; ++j, ++k)
+            {
+                ecol[base + k * 64 + lane] = ci[j];
+                eval[base + k * 64 + lane] = val[j];
+            }
+            hi_end = lo;
+        }
+    }
+    for(; k < w; ++k)
+    {
+        ecol[base + k * 64 + lane] = -1;
+        eval[base + k * 64 + lane] = (T)0;
+    }
+}
+
+// one colour sweep over positions [p0, p1)
+//   FROM_RHS : s = rhs[iperm[t]]          (L sweep: first touch of the row; folds x = P rhs)
+//   else     : s = xp[t]
+//   MULT_D   : s = s * d[t]               (SolveD_)           -- before the U entries
+//   entries  : s = s - a * xp[col]        (ApplyAdd with scalar -1, storage order)
+//   !ident   : s = s * dinv[t]            (diag_solver_[i]->Solve in place)
+//   BOTH     : last colour: L sweep, D and R sweep of the same row in one go (it has no U part)
+//   TO_OUT   : out[iperm[t]] = s          (folds x = P^T x_)
+template <typename T, bool FROM_RHS, bool MULT_D, bool BOTH, bool TO_OUT>
+__global__ __launch_bounds__(kBlock) void k_mc_sweep(int p0, int p1, const int* __restrict__ slice_off,
+                                                     const int* __restrict__ ecol,
+                                                     const T* __restrict__ eval,
+                                                     const T* __restrict__ d, const T* __restrict__ dinv,
+                                                     const int* __restrict__ iperm,
+                                                     const T* __restrict__ rhs, T* xp,
+                                                     T* __restrict__ out, int identity)
+{
+    const int64_t t = (int64_t)p0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= p1)
+        return;
+    const int lane = (int)(t & 63);
+    const int base = slice_off[t >> 6];
+    const int w    = (slice_off[(t >> 6) + 1] - base) >> 6;
+    const int orow = (FROM_RHS || TO_OUT) ? iperm[t] : 0;
+    T         s    = FROM_RHS ? rhs[orow] : xp[t];
+    if(MULT_D)
+        s = s * d[t];
+    for(int k = 0; k < w; ++k)
+    {
+        const int c = nt_load(ecol + base + k * 64 + lane);
+        if(c < 0)
+            break;
+        s -= nt_load(eval + base + k * 64 + lane) * xp[c];
+    }
+    if(!identity)
+        s = s * dinv[t];
+    if(BOTH)
+    {
+        s = s * d[t];
+        if(!identity)
+            s = s * dinv[t];
+    }
+    xp[t] = s;
+    if(TO_OUT)
+        out[orow] = s;
+}
+
+template <typename T>
+static int mc_pack(McsgsPlan* P, const ramd_mat_s* m, bool lower, const int* d_off)
+{
+    Backend&  b       = backend();
+    const int n       = P->n;
+    const int nslices = (n + 63) / 64;
+    int**     soff    = lower ? &P->l_off : &P->u_off;
+    int**     scol    = lower ? &P->l_col : &P->u_col;
+    void**    sval    = lower ? &P->l_val : &P->u_val;
+    RAMD_TRY(dev_alloc(soff, (int64_t)nslices + 1));
+    RAMD_HIP(hipMemsetAsync(*soff, 0, sizeof(int) * ((size_t)nslices + 1), b.cur));
+    const unsigned g64 = (unsigned)(((int64_t)nslices * 64 + kBlock - 1) / kBlock);
+    if(lower)
+        hipLaunchKernelGGL((k_mc_width<true>), dim3(g64), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, d_off,
+                           P->blk_of, *soff);
+    else
+        hipLaunchKernelGGL((k_mc_width<false>), dim3(g64), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, d_off,
+                           P->blk_of, *soff);
+    RAMD_TRY(device_exclusive_scan(*soff, *soff, (int64_t)nslices + 1));
+    int total = 0;
+    RAMD_HIP(hipMemcpyAsync(&total, *soff + nslices, sizeof(int), hipMemcpyDeviceToHost, b.cur));
+    RAMD_HIP(hipStreamSynchronize(b.cur));
+    RAMD_TRY(dev_alloc(scol, total));
+    RAMD_HIP(hipMalloc(sval, (size_t)total * sizeof(T) + kPad));
+    const unsigned nbk = (unsigned)((n + kBlock - 1) / kBlock);
+    if(lower)
+        hipLaunchKernelGGL((k_mc_fill<T, true>), dim3(nbk), dim3(kBlock), 0, b.cur, n, P->nb, m->rp, m->ci,
+                           (const T*)m->val, d_off, P->blk_of, *soff, *scol, (T*)*sval, (T*)P->d,
+                           (T*)P->dinv);
+    else
+        hipLaunchKernelGGL((k_mc_fill<T, false>), dim3(nbk), dim3(kBlock), 0, b.cur, n, P->nb, m->rp, m->ci,
+                           (const T*)m->val, d_off, P->blk_of, *soff, *scol, (T*)*sval, (T*)P->d,
+                           (T*)P->dinv);
+    RAMD_HIP(hipGetLastError());
+    return RAMD_OK;
+}
+
+// number of stored entries of the diagonal colour block (i,i): 0 -> Jacobi inverse diagonal empty
+__global__ __launch_bounds__(kBlock) void k_mc_block_nnz(int n, const int* __restrict__ rp,
+                                                         const int* __restrict__ ci,
+                                                         const int* __restrict__ off,
+                                                         const int* __restrict__ blk_of,
+                                                         int* __restrict__ cnt)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gsz)
+    {
+        const int b = blk_of[t];
+        int       c = 0;
+        for(int j = rp[t]; j < rp[t + 1]; ++j)
+            if(ci[j] >= off[b] && ci[j] < off[b + 1])
+                ++c;
+        if(c)
+            atomicAdd(cnt + b, c);
+    }
+}
+
+template <typename T>
+static int mc_build(McsgsPlan* P, const ramd_mat_s* m, const int* perm)
+{
+    Backend&  b = backend();
+    const int n = P->n, nb = P->nb;
+    int*      d_off = nullptr;
+    RAMD_TRY(dev_alloc(&d_off, (int64_t)nb + 1));
+    RAMD_HIP(hipMemcpyAsync(d_off, P->off.data(), sizeof(int) * ((size_t)nb + 1), hipMemcpyHostToDevice, b.cur));
+    RAMD_TRY(dev_alloc(&P->iperm, n));
+    RAMD_TRY(dev_alloc(&P->blk_of, n));
+    RAMD_HIP(hipMalloc(&P->d, (size_t)n * sizeof(T) + kPad));
+    RAMD_HIP(hipMalloc(&P->dinv, (size_t)n * sizeof(T) + kPad));
+    RAMD_HIP(hipMalloc(&P->xp, (size_t)n * sizeof(T) + kPad));
+    hipLaunchKernelGGL(k_mc_prepare, dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, nb, d_off, perm, P->iperm,
+                       P->blk_of);
+    int s = mc_pack<T>(P, m, true, d_off);
+    if(s == RAMD_OK)
+        s = mc_pack<T>(P, m, false, d_off);
+    int* cnt = nullptr;
+    if(s == RAMD_OK)
+        s = dev_alloc(&cnt, nb);
+    if(s == RAMD_OK)
+    {
+        hipError_t e = hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)nb, b.cur);
+        hipLaunchKernelGGL(k_mc_block_nnz, dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, d_off,
+                           P->blk_of, cnt);
+        std::vector<int> h((size_t)nb);
+        if(e == hipSuccess)
+            e = hipMemcpyAsync(h.data(), cnt, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, b.cur);
+        if(e == hipSuccess)
+            e = hipStreamSynchronize(b.cur);
+        if(e != hipSuccess)
+            s = RAMD_ERR_HIP;
+        P->identity.assign((size_t)nb, 0);
+        for(int i = 0; i < nb; ++i)
+            P->identity[(size_t)i] = (h[(size_t)i] == 0) ? 1 : 0;
+    }
+    dev_free(&cnt);
+    dev_free(&d_off);
+    return s;
+}
+
+template <typename T>
+static int mc_apply(McsgsPlan* P, const T* rhs, T* out)
+{
+    Backend&  b  = backend();
+    const int nb = P->nb;
+#define SWEEP(FR, MD, BO, TO, i, OFFP, COLP, VALP)                                                       \
+    do                                                                                                   \
+    {                                                                                                    \
+        const int p0 = P->off[(size_t)(i)], p1 = P->off[(size_t)(i) + 1];                                \
+        if(p1 > p0)                                                                                      \
+            hipLaunchKernelGGL((k_mc_sweep<T, FR, MD, BO, TO>), dim3((p1 - p0 + kBlock - 1) / kBlock),   \
+                               dim3(kBlock), 0, b.cur, p0, p1, OFFP, COLP, (const T*)VALP,               \
+                               (const T*)P->d, (const T*)P->dinv, P->iperm, rhs, (T*)P->xp, out,         \
+                               (int)P->identity[(size_t)(i)]);                                           \
+    } while(0)
+    // SolveL_ for colours 0 .. nb-2
+    for(int i = 0; i + 1 < nb; ++i)
+        SWEEP(true, false, false, false, i, P->l_off, P->l_col, P->l_val);
+    // last colour: SolveL_ + SolveD_ + SolveR_ of its rows in one sweep (no U part)
+    SWEEP(true, false, true, true, nb - 1, P->l_off, P->l_col, P->l_val);
+    // SolveD_ + SolveR_ for colours nb-2 .. 0
+    for(int i = nb - 2; i >= 0; --i)
+        SWEEP(false, true, false, true, i, P->u_off, P->u_col, P->u_val);
+#undef SWEEP
+    RAMD_HIP(hipGetLastError());
+    return RAMD_OK;
+}
+
+} // namespace ramd
+
+using namespace ramd;
+
+struct ramd_mcsgs_s
+{
+    McsgsPlan plan;
+};
+
+extern "C" {
+
+int ramd_mcsgs_build(ramd_mat_t permuted, int num_blocks, const int* block_sizes, ramd_vec_t perm,
+                     ramd_mcsgs_t* out)
+{
+    if(!permuted || !block_sizes || !perm || !out || num_blocks < 1)
+        RAMD_FAIL(RAMD_ERR_ARG, "mcsgs_build: bad arguments");
+    if(permuted->format != RAMD_CSR)
+        return RAMD_ERR_UNSUPPORTED;
+    if(perm->dtype != RAMD_I32 || perm->n != permuted->nrow || permuted->nrow != permuted->ncol)
+        RAMD_FAIL(RAMD_ERR_ARG, "mcsgs_build: permutation / matrix size mismatch");
+    ramd_mcsgs_s* h = new ramd_mcsgs_s;
+    McsgsPlan&    P = h->plan;
+    P.dtype         = permuted->dtype;
+    P.n             = permuted->nrow;
+    P.nb            = num_blocks;
+    P.off.assign((size_t)num_blocks + 1, 0);
+    for(int i = 0; i < num_blocks; ++i)
+        P.off[(size_t)i + 1] = P.off[(size_t)i] + block_sizes[i];
+    if(P.off[(size_t)num_blocks] != P.n)
+    {
+        delete h;
+        RAMD_FAIL(RAMD_ERR_ARG, "mcsgs_build: block sizes do not add up to the matrix size");
+    }
+    int s = (P.dtype == RAMD_F64) ? mc_build<double>(&P, permuted, (const int*)perm->d)
+                                  : mc_build<float>(&P, permuted, (const int*)perm->d);
+    if(s != RAMD_OK)
+    {
+        P.release();
+        delete h;
+        return s;
+    }
+    *out = h;
+    return RAMD_OK;
+}
+
+int ramd_mcsgs_apply(ramd_mcsgs_t h, ramd_vec_t rhs, ramd_vec_t x)
+{
+    if(!h || !rhs || !x || rhs == x)
+        RAMD_FAIL(RAMD_ERR_ARG, "mcsgs_apply: bad arguments");
+    McsgsPlan& P = h->plan;
+    if(rhs->dtype != P.dtype || x->dtype != P.dtype || rhs->n != P.n || x->n != P.n)
+        RAMD_FAIL(RAMD_ERR_ARG, "mcsgs_apply: vector size / type mismatch");
+    if(P.n == 0)
+        return RAMD_OK;
+    if(P.dtype == RAMD_F64)
+        return mc_apply<double>(&P, (const double*)rhs->d, (double*)x->d);
+    return mc_apply<float>(&P, (const float*)rhs->d, (float*)x->d);
+}
+
+int ramd_mcsgs_destroy(ramd_mcsgs_t h)
+{
+    if(h)
+    {
+        h->plan.release();
+        delete h;
+    }
+    return RAMD_OK;
+}
+
+} // extern "C"

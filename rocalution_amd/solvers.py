@@ -46,9 +46,13 @@ class MultiColoredSGS(_Precond):
     def __init__(self):
         super().__init__()
         self.decomposition = True
+        self.fused_sweeps = True
 
     def SetDecomposition(self, decomp):
         self.decomposition = bool(decomp)
+
+    def SetFusedSweeps(self, on):
+        self.fused_sweeps = bool(on)
 
 
 class _IterativeLinearSolver:
@@ -111,6 +115,8 @@ class _IterativeLinearSolver:
             capi.check(_lib().ramd_solver_set_precond_format(self._h, self._precond.precond_format))
         if self._precond is not None and getattr(self._precond, "decomposition", True) is False:
             capi.check(_lib().ramd_solver_set_decomposition(self._h, 0))
+        if self._precond is not None and getattr(self._precond, "fused_sweeps", True) is False:
+            capi.check(_lib().ramd_solver_set_fused_sweeps(self._h, 0))
         capi.check(_lib().ramd_solver_set_fused(self._h, int(self._fused)))
         capi.check(_lib().ramd_solver_set_verbose(self._h, self._verbose))
         self._configure_extra()

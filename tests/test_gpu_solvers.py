@@ -55,6 +55,22 @@ PC_CASES = ["gr3030", "poisson8", "lap2d7", "rand300", "rand300ell"]
 
 
 @pytest.mark.parametrize("name", PC_CASES)
+def test_mcsgs_block_form_bit_exact(ra, S, name):
+    """the reference's block-by-block sequence (SetFusedSweeps(False)) next to the fused colour sweeps"""
+    g = load_golden(name)
+    A = ra.LocalMatrix(); A.SetDataPtrCSR(g["rowptr"], g["col"], g["val"])
+    n = A.GetM()
+    x = ra.LocalVector(data=g["x"])
+    for fused in (True, False):
+        pc = S.MultiColoredSGS(); pc.SetFusedSweeps(fused)
+        ls = S.BiCGStab(); ls.SetOperator(A); ls.SetPreconditioner(pc); ls.Build()
+        z = ra.LocalVector(); z.Allocate("", n)
+        ls.PrecondApply(x, z)
+        eq(z.numpy(), g["pc_mcsgs"])
+        ls.Clear()
+
+
+@pytest.mark.parametrize("name", PC_CASES)
 def test_preconditioner_apply_bit_exact(ra, S, name):
     g = load_golden(name)
     A = ra.LocalMatrix(); A.SetDataPtrCSR(g["rowptr"], g["col"], g["val"])
