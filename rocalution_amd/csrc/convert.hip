@@ -385,6 +385,8 @@ int ramd_mat_convert(ramd_mat_t m, int format)
         return RAMD_ERR_UNSUPPORTED; // X -> CSR -> Y goes through the caller (front-end protocol)
     if(m->lu_analysed || m->l_analysed || m->u_analysed)
         mat_free_analysis(m);
+    if(m->band_dist < 0) // the ELL/HYB kernels walk the rows in the same band-aware order as CSR
+        RAMD_TRY(csr_analyse_band(m));
     if(m->dtype == RAMD_F64)
         return convert_from_csr<double>(m, format);
     return convert_from_csr<float>(m, format);

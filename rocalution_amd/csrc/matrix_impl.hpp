@@ -13,6 +13,9 @@ void   mat_free_coo(ramd_mat_s* m);
 void   mat_free_analysis(ramd_mat_s* m);
 int    mat_alloc_csr(ramd_mat_s* m, int nrow, int ncol, int64_t nnz);
 
+// spmv.hip: detect a far band (3-D stencil plane distance) for the band-aware row-block traversal
+int csr_analyse_band(ramd_mat_s* m);
+
 // backend.hip: optional HIP-event bracket around every SpMV launch (bench.py roofline leg)
 void prof_spmv_begin();
 void prof_spmv_end();

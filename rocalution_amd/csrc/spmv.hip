@@ -210,12 +210,14 @@ __global__ __launch_bounds__(kBlock) void k_ell(int nrow, int ncol, int width,
                                                 const int* __restrict__ ecol,
                                                 const T* __restrict__ eval,
                                                 const T* __restrict__ x, T* __restrict__ y, T scalar,
-                                                ReduceCtx ctx, int slot)
+                                                ReduceCtx ctx, int slot, int nblk, int per_xcd, BandMap bm)
 {
     __shared__ double red[8];
     double            dacc = 0.0;
-    const int64_t     gsz  = (int64_t)gridDim.x * blockDim.x;
-    for(int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < nrow; row += gsz)
+    // one workgroup per 256 rows, XCD- and band-aware order (same mapping as the CSR kernel)
+    const int     blk = xcd_block(nblk, per_xcd, bm);
+    const int64_t row = (int64_t)blk * kCsrRows + threadIdx.x;
+    if(blk >= 0 && row < nrow)
     {
         T sum = (T)0;
         if(MODE == 1)
@@ -252,10 +254,7 @@ __global__ __launch_bounds__(kBlock) void k_ell(int nrow, int ncol, int width,
                     sum += scalar * v[e] * x[c[e]];
             }
             if(STOP && stop)
-            {
-                el = width;
-                break;
-            }
+                el = width; // leaves both loops
         }
         for(; el < width; ++el)
         {
@@ -329,7 +328,7 @@ __global__ __launch_bounds__(kBlock) void k_band_sample(int nrow, int stride, co
     out[s] = far;
 }
 
-static int analyse_band(ramd_mat_s* m)
+int csr_analyse_band(ramd_mat_s* m)
 {
     m->band_dist = 0;
     if(m->format != RAMD_CSR || m->nrow < (1 << 20) || m->nrow != m->ncol)
@@ -354,6 +353,8 @@ static int analyse_band(ramd_mat_s* m)
     return RAMD_OK;
 }
 
+static BandMap band_map_for(const ramd_mat_s* m, int per_xcd);
+
 template <typename T>
 static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar, bool dot, int slot)
 {
@@ -363,18 +364,8 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
     const int grid    = per_xcd * 8;
     CsrDotWs  ws      = {};
     if(m->band_dist < 0)
-        RAMD_TRY(analyse_band(const_cast<ramd_mat_s*>(m)));
-    BandMap bm = {0, 0, 0};
-    if(m->band_dist > 0)
-    {
-        bm.P = m->band_dist / kCsrRows;
-        bm.Z = per_xcd / bm.P;
-        bm.W = 32;
-        while(bm.W > 1 && bm.P % bm.W != 0)
-            bm.W >>= 1;
-        if(bm.Z < 3)
-            bm.P = 0;
-    }
+        RAMD_TRY(csr_analyse_band(const_cast<ramd_mat_s*>(m)));
+    const BandMap bm = band_map_for(m, per_xcd);
     if(dot)
     {
         ramd_mat_s* mm = const_cast<ramd_mat_s*>(m);
@@ -407,15 +398,35 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
     return RAMD_OK;
 }
 
+static BandMap band_map_for(const ramd_mat_s* m, int per_xcd)
+{
+    BandMap bm = {0, 0, 0};
+    if(m->band_dist > 0)
+    {
+        bm.P = m->band_dist / kCsrRows;
+        bm.Z = per_xcd / bm.P;
+        bm.W = 32;
+        while(bm.W > 1 && bm.P % bm.W != 0)
+            bm.W >>= 1;
+        if(bm.Z < 3)
+            bm.P = 0;
+    }
+    return bm;
+}
+
 template <typename T>
 static int launch_ell(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar, bool stop)
 {
-    Backend&  b    = backend();
-    const int grid = (int)std::min<int64_t>(((int64_t)m->nrow + kBlock - 1) / kBlock, 1 << 22);
-    ReduceCtx ctx  = reduce_ctx();
+    Backend&      b       = backend();
+    const int     nblk    = (m->nrow + kCsrRows - 1) / kCsrRows;
+    const int     per_xcd = (nblk + 7) / 8;
+    const int     grid    = per_xcd * 8;
+    ReduceCtx     ctx     = reduce_ctx();
+    const BandMap bm      = band_map_for(m, per_xcd);
 #define LAUNCH(MODE, STOP)                                                                        \
     hipLaunchKernelGGL((k_ell<T, MODE, STOP, false>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, \
-                       m->ncol, m->ell_width, m->ell_col, (const T*)m->ell_val, x, y, scalar, ctx, 0)
+                       m->ncol, m->ell_width, m->ell_col, (const T*)m->ell_val, x, y, scalar, ctx, 0, \
+                       nblk, per_xcd, bm)
     if(mode == 0 && stop)
         LAUNCH(0, true);
     else if(mode == 0)
