@@ -16,7 +16,16 @@ namespace ramd
 // CG residual update (src/solvers/krylov/cg.cpp:418-438):
 //   alpha = rho / (p.q) ; r = r + (-alpha)*q ; rr = <r,r>
 //   PRECOND: z = dinv * r ; rz = <r,z>        else rz = rr
-template <typename T, bool PRECOND>
+template <typename P_>
+__device__ __forceinline__ void st_pack(P_* p, P_ v, bool nts)
+{
+    if(nts)
+        __builtin_nontemporal_store(v, p);
+    else
+        *p = v;
+}
+
+template <typename T, bool PRECOND, bool NTS>
 __global__ __launch_bounds__(kBlock) void k_cg_update(int64_t n, T* __restrict__ r,
                                                       const T* __restrict__ q,
                                                       const T* __restrict__ dinv, T* __restrict__ z,
@@ -52,9 +61,9 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(int64_t n, T* __restrict__
                 rz += (double)rn * (double)zn;
             }
         }
-        reinterpret_cast<P*>(r)[i] = pr;
+        st_pack(reinterpret_cast<P*>(r) + i, pr, NTS);
         if(PRECOND)
-            reinterpret_cast<P*>(z)[i] = pz;
+            st_pack(reinterpret_cast<P*>(z) + i, pz, NTS);
     }
     for(int64_t i = np * NP + gtid; i < n; i += gsz)
     {
@@ -77,7 +86,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(int64_t n, T* __restrict__
 }
 
 // x = x + alpha*p (old p) ; p = beta*p + z       (cg.cpp:421 AddScale, :441-442 ScaleAdd)
-template <typename T>
+template <typename T, bool NTS>
 __global__ __launch_bounds__(kBlock) void k_cg_direction(int64_t n, T* __restrict__ x, T* __restrict__ p,
                                                          const T* __restrict__ z,
                                                          const double* __restrict__ scalars,
@@ -101,8 +110,8 @@ __global__ __launch_bounds__(kBlock) void k_cg_direction(int64_t n, T* __restric
             pk_elems<T>(px)[k] = pk_elems<T>(px)[k] + alpha * pk_elems<T>(pp)[k];
             pk_elems<T>(pp)[k] = beta * pk_elems<T>(pp)[k] + pk_elems<T>(pz)[k];
         }
-        reinterpret_cast<P*>(x)[i] = px;
-        reinterpret_cast<P*>(p)[i] = pp;
+        st_pack(reinterpret_cast<P*>(x) + i, px, NTS);
+        st_pack(reinterpret_cast<P*>(p) + i, pp, NTS);
     }
     for(int64_t i = np * NP + gtid; i < n; i += gsz)
     {
@@ -281,15 +290,22 @@ int ramd_fused_cg_update(ramd_vec_t r, ramd_vec_t q, ramd_vec_t dinv, ramd_vec_t
     Backend&  b    = backend();
     const int grid = reduce_grid((r->n + 1) / 2);
     ReduceCtx ctx  = reduce_ctx();
+    static int nts = -1;
+    if(nts < 0)
+        nts = getenv("RAMD_NT_STORES") ? atoi(getenv("RAMD_NT_STORES")) : 0;
 #define GO(T)                                                                                          \
     do                                                                                                 \
     {                                                                                                  \
-        if(dinv)                                                                                       \
-            hipLaunchKernelGGL((k_cg_update<T, true>), dim3(grid), dim3(kBlock), 0, b.cur, r->n,       \
+        if(dinv && nts)                                                                                \
+            hipLaunchKernelGGL((k_cg_update<T, true, true>), dim3(grid), dim3(kBlock), 0, b.cur, r->n, \
+                               (T*)r->d, (const T*)q->d, (const T*)dinv->d, (T*)z->d, ctx, slot_rho,   \
+                               slot_pq, slot_rr, slot_rz);                                             \
+        else if(dinv)                                                                                  \
+            hipLaunchKernelGGL((k_cg_update<T, true, false>), dim3(grid), dim3(kBlock), 0, b.cur, r->n, \
                                (T*)r->d, (const T*)q->d, (const T*)dinv->d, (T*)z->d, ctx, slot_rho,   \
                                slot_pq, slot_rr, slot_rz);                                             \
         else                                                                                           \
-            hipLaunchKernelGGL((k_cg_update<T, false>), dim3(grid), dim3(kBlock), 0, b.cur, r->n,      \
+            hipLaunchKernelGGL((k_cg_update<T, false, false>), dim3(grid), dim3(kBlock), 0, b.cur, r->n, \
                                (T*)r->d, (const T*)q->d, (const T*)nullptr, (T*)nullptr, ctx,          \
                                slot_rho, slot_pq, slot_rr, slot_rz);                                   \
     } while(0)
@@ -315,13 +331,21 @@ int ramd_fused_cg_direction(ramd_vec_t x, ramd_vec_t p, ramd_vec_t z, int slot_r
         return RAMD_OK;
     Backend&  b    = backend();
     const int grid = ew_grid((p->n + 1) / 2);
-    if(p->dtype == RAMD_F64)
-        hipLaunchKernelGGL((k_cg_direction<double>), dim3(grid), dim3(kBlock), 0, b.cur, p->n,
+    static int nts = -1;
+    if(nts < 0)
+        nts = getenv("RAMD_NT_STORES") ? atoi(getenv("RAMD_NT_STORES")) : 0;
+    if(p->dtype == RAMD_F64 && nts)
+        hipLaunchKernelGGL((k_cg_direction<double, true>), dim3(grid), dim3(kBlock), 0, b.cur, p->n,
+                           (double*)x->d, (double*)p->d, (const double*)z->d, b.d_scalars, slot_rho,
+                           slot_pq, slot_new);
+    else if(p->dtype == RAMD_F64)
+        hipLaunchKernelGGL((k_cg_direction<double, false>), dim3(grid), dim3(kBlock), 0, b.cur, p->n,
                            (double*)x->d, (double*)p->d, (const double*)z->d, b.d_scalars, slot_rho,
                            slot_pq, slot_new);
     else if(p->dtype == RAMD_F32)
-        hipLaunchKernelGGL((k_cg_direction<float>), dim3(grid), dim3(kBlock), 0, b.cur, p->n, (float*)x->d,
-                           (float*)p->d, (const float*)z->d, b.d_scalars, slot_rho, slot_pq, slot_new);
+        hipLaunchKernelGGL((k_cg_direction<float, false>), dim3(grid), dim3(kBlock), 0, b.cur, p->n,
+                           (float*)x->d, (float*)p->d, (const float*)z->d, b.d_scalars, slot_rho, slot_pq,
+                           slot_new);
     else
         RAMD_FAIL(RAMD_ERR_ARG, "fused_cg_direction needs real vectors");
     RAMD_HIP(hipGetLastError());
