@@ -228,8 +228,12 @@ def main():
         nnz_fmt = nnz if args.format == "csr" else 7 * n
         bytes_alg = spmv_bytes(n, nnz) if args.format == "csr" else 4 * nnz_fmt + 8 * (2 * n + nnz_fmt)
         ach = bytes_alg / (avg.value * 1e-3) / 1e9 if avg.value > 0 else 0.0
+        traffic = None  # HBM bytes per launch from the PMC counters: measured offline with rocprofv3
+        tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")  # (separate --pmc passes), see that file
+        if os.path.exists(tfile) and N == 512 and args.format == "csr":
+            traffic = json.load(open(tfile)).get("traffic_bytes")
         prof = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
-                    frac=round(ach / HBM_PEAK_GBPS, 4), traffic=None, kernel="k_csr_tr<double,0,true> (CSR SpMV + fused <p,q>)"
+                    frac=round(ach / HBM_PEAK_GBPS, 4), traffic=traffic, kernel="k_csr_tr<double,0,true> (CSR SpMV + fused <p,q>)"
                     if args.format == "csr" else "k_ell<double>", launches=cnt.value, avg_ms=round(avg.value, 5),
                     min_ms=round(mn.value, 5), max_ms=round(mx.value, 5), algorithmic_bytes=bytes_alg)
         extras = {}

@@ -254,7 +254,19 @@ __global__ __launch_bounds__(kBlock) void k_mc_block_nnz(int n, const int* __res
         for(int j = rp[t]; j < rp[t + 1]; ++j)
             if(ci[j] >= off[b] && ci[j] < off[b + 1])
                 ++c;
-        if(c)
+        // one atomic per wave when the whole wave sits in one colour (the common case): 67M
+        // same-address atomics took 1.5 s at 512^3
+        const int b0 = __shfl(b, 0, 64);
+        if(__ballot(b != b0) == 0ull)
+        {
+            int w = c;
+#pragma unroll
+            for(int o = 32; o > 0; o >>= 1)
+                w += __shfl_xor(w, o, 64);
+            if((threadIdx.x & 63) == 0 && w)
+                atomicAdd(cnt + b0, w);
+        }
+        else if(c)
             atomicAdd(cnt + b, c);
     }
 }
