@@ -90,7 +90,7 @@ def reference_gpu(args):
     if not (os.path.exists(probe) and os.path.exists("/opt/rocm/lib/librocalution_hip.so")):
         return None
     try:
-        out = subprocess.check_output([probe, "bench", str(args.grid), str(min(args.steps, 100)), "0", "1", "cg",
+        out = subprocess.check_output([probe, "bench", str(args.grid), str(args.steps), "0", "1", "cg",
                                        "jacobi"], stderr=subprocess.DEVNULL, timeout=900).decode()
         rec = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
         return dict(iters_per_s=rec["iters_per_s"], spmv_GBps=rec["spmv_GBps"], t_spmv_ms=rec["t_spmv_s"] * 1e3,
@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--solver", default="cg", choices=["cg", "gmres", "bicgstab", "mixed"],
                     help="headline = cg; the others run the remaining BASELINE.json configs through the same harness")
     ap.add_argument("--precond", default="jacobi", choices=["none", "jacobi", "ilu0", "mcsgs"])
+    ap.add_argument("--force-global", action="store_true",
+                    help="1 process: still go through the GlobalMatrix/RCCL code path (communicator of size 1, "
+                         "collectives not skipped) - a check of the N>1 plumbing on a 1-GPU box")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the GMRES(30)+ILU(0) and BiCGStab+MC-SGS legs (reported under `extras`)")
     args = ap.parse_args()
@@ -126,6 +129,8 @@ def main():
             log("bench.py: --gpus %d needs one process per GPU (torch.distributed.run); running 1" % args.gpus)
         args.gpus = world
 
+    if args.force_global:
+        os.environ["RAMD_COMM_FORCE_COLLECTIVES"] = "1"
     import rocalution_amd as ra
     from rocalution_amd import capi
     lib = capi.load()
@@ -148,6 +153,10 @@ def main():
         dist.broadcast(t, src=0)
         uid = C.create_string_buffer(bytes(t.tolist()), 128)
         capi.check(lib.ramd_comm_init_rccl(rank, world, uid, C.byref(comm)))  # data plane: RCCL over xGMI
+    elif args.force_global:
+        uid = C.create_string_buffer(128)
+        capi.check(lib.ramd_comm_unique_id(uid))
+        capi.check(lib.ramd_comm_init_rccl(0, 1, uid, C.byref(comm)))
 
     def barrier():
         ra.sync()
@@ -161,7 +170,7 @@ def main():
     NEVER = (0.0, 0.0, 1e300)  # abs / rel / div tolerances that cannot trigger: exactly max_iter steps
 
     prof = None
-    if world == 1:
+    if world == 1 and not args.force_global:
         from rocalution_amd import solvers as S
         A = ra.LocalMatrix()
         A.GenPoisson7(N)
@@ -277,10 +286,11 @@ def main():
         run(W)
         dt, it, res, tbuild = run(K)
         assert it == K, (it, K)
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
+        if dist is not None:
+            import torch
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t[0])
         extras = {}
 
     if rank == 0:
@@ -303,9 +313,9 @@ def main():
             out["spmv_GBps"] = prof["achieved"]
         if extras:
             out["extras"] = extras
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.force_global:
             out["cpu_baseline"] = cpu_baseline(args)
-        if world == 1 and not args.no_reference_gpu:
+        if world == 1 and not args.no_reference_gpu and not args.force_global:
             rg = reference_gpu(args)
             if rg is not None:
                 out["reference_gpu"] = rg
