@@ -778,6 +778,9 @@ public:
     {
         (void)blockdim;
         this->need_accel_("ConvertTo");
+        // local_matrix.cpp:2085-2093: anything -> CSR first, then CSR -> target
+        if(this->GetFormat() != CSR && matrix_format != CSR && matrix_format != this->GetFormat())
+            RAMD_CHECK(ramd_mat_convert(this->dev_, (int)CSR));
         int s = ramd_mat_convert(this->dev_, (int)matrix_format);
         if(s == RAMD_ERR_REFUSED)
         {

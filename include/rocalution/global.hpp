@@ -430,6 +430,13 @@ public:
         if(this->matrix_ghost_.GetNnz() > 0)
             this->matrix_ghost_.ConvertTo(COO);
     }
+    // extension: only the ghost part to (row-grouped) COO -- a CSR ghost part is walked over ALL local rows
+    // although only the boundary rows have entries.  Results are bit-identical (same per-row order).
+    void CompactGhost(void)
+    {
+        if(this->matrix_ghost_.GetNnz() > 0 && this->matrix_ghost_.GetFormat() == CSR)
+            this->matrix_ghost_.ConvertTo(COO);
+    }
     void ConvertToCSR(void)
     {
         this->ConvertTo(CSR);
@@ -454,7 +461,17 @@ public:
     {
         this->pm_ = src.pm();
         this->matrix_interior_.template CastFrom<OtherType>(src.GetInterior());
-        this->matrix_ghost_.template CastFrom<OtherType>(src.GetGhost());
+        const unsigned int gfmt = src.GetGhost().GetFormat();
+        if(gfmt == CSR)
+            this->matrix_ghost_.template CastFrom<OtherType>(src.GetGhost());
+        else // the value cast is defined on CSR (mixed_precision.cpp:201); keep the source's ghost format
+        {
+            LocalMatrix<OtherType> tmp;
+            tmp.CloneFrom(src.GetGhost());
+            tmp.ConvertTo(CSR);
+            this->matrix_ghost_.template CastFrom<OtherType>(tmp);
+            this->matrix_ghost_.ConvertTo(gfmt);
+        }
         this->InitCommPattern_();
     }
     // extension: per-rank slab of the synthetic 3-D Poisson operator, built on the device
@@ -485,6 +502,30 @@ public:
             RAMD_CHECK(ramd_comm_halo_end(this->pm_->GetComm()));
             this->matrix_ghost_.ApplyAdd(this->recv_buffer_, static_cast<ValueType>(1),
                                          &out->vector_interior_);
+        }
+    }
+
+    // Apply + the rank-local part of <in, out> into a device scalar slot, without a second pass over
+    // the vectors: the interior SpMV carries the dot, the ghost ApplyAdd corrects it on the rows it touches
+    void ApplyDot(const GlobalVector<ValueType>& in, GlobalVector<ValueType>* out, int slot) const
+    {
+        const bool comm = this->pm_ != NULL && !this->pm_->peers().empty();
+        if(comm)
+        {
+            in.vector_interior_.GetIndexValues(this->halo_, &this->send_buffer_);
+            RAMD_CHECK(ramd_comm_halo_begin(this->pm_->GetComm(), this->send_buffer_.handle(),
+                                            this->recv_buffer_.handle(), (int)this->pm_->peers().size(),
+                                            this->pm_->peers().data(), this->pm_->send_offset().data(),
+                                            this->pm_->recv_offset().data()));
+        }
+        RAMD_CHECK(ramd_fused_apply_dot(this->matrix_interior_.handle(), in.vector_interior_.handle(),
+                                        out->vector_interior_.handle(), slot));
+        if(comm)
+        {
+            RAMD_CHECK(ramd_comm_halo_end(this->pm_->GetComm()));
+            RAMD_CHECK(ramd_fused_apply_add_dot(this->matrix_ghost_.handle(), this->recv_buffer_.handle(), 1.0,
+                                                out->vector_interior_.handle(),
+                                                in.vector_interior_.handle(), slot));
         }
     }
 
@@ -527,9 +568,7 @@ template <typename ValueType>
 inline void _f_apply_dot(const GlobalMatrix<ValueType>& A, const GlobalVector<ValueType>& p,
                          GlobalVector<ValueType>* q, int slot)
 {
-    A.Apply(p, q); // pack | halo || interior SpMV | ghost +=
-    const ramd_vec_t vs[1] = {p.GetInterior().handle()};
-    RAMD_CHECK(ramd_fused_multi_dot(vs, 1, q->GetInterior().handle(), slot)); // local part of <p,q>
+    A.ApplyDot(p, q, slot); // pack | halo || interior SpMV + <p,q> | ghost += and dot correction
 }
 template <typename ValueType>
 inline void _f_allreduce(const GlobalMatrix<ValueType>& A, int first, int count)

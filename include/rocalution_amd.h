@@ -181,6 +181,12 @@ int ramd_scalars_fetch_async_end(int record, double* host, int count);
 
 /* y = A x  and  s[slot_dot] = <x, y>   (cg.cpp:415-418: q = A p ; p.q) */
 int ramd_fused_apply_dot(ramd_mat_t m, ramd_vec_t x, ramd_vec_t y, int slot_dot);
+/* y += scalar * A x  and  s[slot_dot] = <p, y>, GIVEN that s[slot_dot] already holds <p, y> of the
+ * incoming y: only the rows A touches are corrected (the ghost part of GlobalMatrix::Apply,
+ * global_matrix.cpp:1001-1007, followed by the interior part of GlobalVector::Dot,
+ * global_vector.cpp:549-560, without a second pass over the vectors) */
+int ramd_fused_apply_add_dot(ramd_mat_t m, ramd_vec_t x, double scalar, ramd_vec_t y, ramd_vec_t p,
+                             int slot_dot);
 /* alpha = s[slot_rho] / s[slot_pq];  r += (-alpha) q;  s[slot_rr] = <r,r>;
  * if dinv: z = dinv * r, s[slot_rz] = <r,z>   else s[slot_rz] = <r,r>            (cg.cpp:418-438) */
 int ramd_fused_cg_update(ramd_vec_t r, ramd_vec_t q, ramd_vec_t dinv, ramd_vec_t z, int slot_rho,

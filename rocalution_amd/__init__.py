@@ -256,6 +256,9 @@ class LocalMatrix:
     def ConvertTo(self, fmt):
         """LocalMatrix::ConvertTo (src/base/local_matrix.cpp:2064-2151): a refused ELL conversion
         leaves the matrix in CSR (level-2 warning in the reference); returns the resulting format."""
+        cur = self.GetFormat()
+        if cur != CSR and int(fmt) != CSR and int(fmt) != cur:  # X -> CSR -> Y (local_matrix.cpp:2085-2093)
+            capi.check(_lib().ramd_mat_convert(self._h, CSR))
         s = _lib().ramd_mat_convert(self._h, int(fmt))
         if s == capi.ERR_REFUSED:
             return self.GetFormat()

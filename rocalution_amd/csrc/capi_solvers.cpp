@@ -607,6 +607,7 @@ int ramd_gsolver_setup_poisson(ramd_gsolver_t g, int N, int z_begin, int z_end)
     g->pm.SetSenders((int)peers.size(), peers.data(), soff.data());
     g->A.SetParallelManager(g->pm);
     g->A.GeneratePoisson7Slab(N, lo, hi);
+    g->A.CompactGhost();
     g->alloc_vectors();
     g->setup = true;
     GUARD_END
@@ -650,6 +651,7 @@ int ramd_gsolver_setup_csr(ramd_gsolver_t g, int64_t global_nrow, int local_nrow
         g->A.SetGhostDataPtrCSR(&rp, &ci, &va, "A", gh_nnz);
     }
     g->A.MoveToAccelerator();
+    g->A.CompactGhost();
     g->alloc_vectors();
     g->setup = true;
     GUARD_END

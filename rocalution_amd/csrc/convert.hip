@@ -214,6 +214,89 @@ __global__ __launch_bounds__(kBlock) void k_perm_fill(int nrow, const int* __res
     }
 }
 
+// ---- X -> CSR (host_conversion.cpp:690-760 ell_to_csr, :765-880 hyb_to_csr, :884-960 coo_to_csr):
+// a row keeps its valid ELL entries (0 <= col < ncol) in slot order, then its COO entries in storage
+// order; plain COO additionally gets its columns sorted inside every row (stable, as the bubble sort).
+__global__ __launch_bounds__(kBlock) void k_x2csr_count_ell(int nrow, int ncol, int width,
+                                                            const int* __restrict__ ecol,
+                                                            int* __restrict__ cnt)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t <= nrow; t += gsz)
+    {
+        int c = 0;
+        if(t < nrow)
+            for(int el = 0; el < width; ++el)
+            {
+                const int col = ecol[(int64_t)el * nrow + t];
+                if(col >= 0 && col < ncol)
+                    ++c;
+            }
+        cnt[t] = c;
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_x2csr_count_coo(int ngroups, const int* __restrict__ grow,
+                                                            const int* __restrict__ gptr,
+                                                            int* __restrict__ cnt)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += gsz)
+        cnt[grow[g]] += gptr[g + 1] - gptr[g]; // a row is in at most one group
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_x2csr_fill_ell(int nrow, int ncol, int width,
+                                                           const int* __restrict__ ecol,
+                                                           const T* __restrict__ eval,
+                                                           const int* __restrict__ rp,
+                                                           int* __restrict__ oci, T* __restrict__ oval)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nrow; t += gsz)
+    {
+        int ind = rp[t];
+        for(int el = 0; el < width; ++el)
+        {
+            const int col = ecol[(int64_t)el * nrow + t];
+            if(col >= 0 && col < ncol)
+            {
+                oci[ind]  = col;
+                oval[ind] = eval[(int64_t)el * nrow + t];
+                ++ind;
+            }
+        }
+    }
+}
+template <typename T, bool SORT>
+__global__ __launch_bounds__(kBlock) void k_x2csr_fill_coo(int ngroups, const int* __restrict__ grow,
+                                                           const int* __restrict__ gptr,
+                                                           const int* __restrict__ ccol,
+                                                           const T* __restrict__ cval,
+                                                           const int* __restrict__ rp,
+                                                           int* __restrict__ oci, T* __restrict__ oval)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += gsz)
+    {
+        const int row = grow[g];
+        const int s = gptr[g], e = gptr[g + 1];
+        const int base = rp[row + 1] - (e - s); // COO entries close the row
+        for(int i = s; i < e; ++i)
+        {
+            const int col = ccol[i];
+            const T   v   = cval[i];
+            int       k   = base + (i - s);
+            if(SORT) // stable insertion: move strictly greater columns up
+                for(; k > base && oci[k - 1] > col; --k)
+                {
+                    oci[k]  = oci[k - 1];
+                    oval[k] = oval[k - 1];
+                }
+            oci[k]  = col;
+            oval[k] = v;
+        }
+    }
+}
+
 static int build_coo_groups(ramd_mat_s* m, const int* rowptr_like)
 {
     // rowptr_like: [nrow+1] offsets of every row's COO entries (CSR rp, or the HYB overflow scan)
@@ -369,6 +452,70 @@ static int convert_from_csr(ramd_mat_s* m, int format)
     RAMD_FAIL(RAMD_ERR_UNSUPPORTED, "conversion target not provided by this backend");
 }
 
+template <typename T>
+static int convert_to_csr(ramd_mat_s* m)
+{
+    Backend&  b    = backend();
+    const int nrow = m->nrow;
+    int*      rp   = nullptr;
+    RAMD_TRY(dev_alloc(&rp, (int64_t)nrow + 1));
+    const int  grid    = ew_grid((int64_t)nrow + 1);
+    const bool has_ell = (m->format == RAMD_ELL || m->format == RAMD_HYB);
+    const bool has_coo = (m->format == RAMD_COO || m->format == RAMD_HYB) && m->coo_ngroups > 0;
+    hipLaunchKernelGGL(k_x2csr_count_ell, dim3(grid), dim3(kBlock), 0, b.cur, nrow, m->ncol,
+                       has_ell ? m->ell_width : 0, m->ell_col, rp);
+    if(has_coo)
+        hipLaunchKernelGGL(k_x2csr_count_coo, dim3(ew_grid(m->coo_ngroups)), dim3(kBlock), 0, b.cur,
+                           m->coo_ngroups, m->coo_grow, m->coo_gptr, rp);
+    int s   = device_exclusive_scan(rp, rp, (int64_t)nrow + 1);
+    int nnz = 0;
+    if(s == RAMD_OK)
+    {
+        hipError_t e = hipMemcpyAsync(&nnz, rp + nrow, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+        if(e == hipSuccess)
+            e = hipStreamSynchronize(b.cur);
+        if(e != hipSuccess)
+            s = RAMD_ERR_HIP;
+    }
+    int*  ci  = nullptr;
+    void* val = nullptr;
+    if(s == RAMD_OK)
+        s = dev_alloc(&ci, nnz);
+    if(s == RAMD_OK && hipMalloc(&val, (size_t)nnz * sizeof(T) + kPad) != hipSuccess)
+        s = RAMD_ERR_HIP;
+    if(s != RAMD_OK)
+    {
+        dev_free(&rp);
+        dev_free(&ci);
+        return s;
+    }
+    if(has_ell && m->ell_width > 0 && nrow > 0)
+        hipLaunchKernelGGL((k_x2csr_fill_ell<T>), dim3(grid), dim3(kBlock), 0, b.cur, nrow, m->ncol, m->ell_width,
+                           m->ell_col, (const T*)m->ell_val, rp, ci, (T*)val);
+    if(has_coo)
+    {
+        const int g2 = ew_grid(m->coo_ngroups);
+        if(m->format == RAMD_COO)
+            hipLaunchKernelGGL((k_x2csr_fill_coo<T, true>), dim3(g2), dim3(kBlock), 0, b.cur, m->coo_ngroups,
+                               m->coo_grow, m->coo_gptr, m->coo_col, (const T*)m->coo_val, rp, ci, (T*)val);
+        else
+            hipLaunchKernelGGL((k_x2csr_fill_coo<T, false>), dim3(g2), dim3(kBlock), 0, b.cur, m->coo_ngroups,
+                               m->coo_grow, m->coo_gptr, m->coo_col, (const T*)m->coo_val, rp, ci, (T*)val);
+    }
+    hipError_t e = hipGetLastError();
+    if(e == hipSuccess)
+        e = hipStreamSynchronize(b.cur);
+    mat_free_ell(m);
+    mat_free_coo(m);
+    m->rp     = rp;
+    m->ci     = ci;
+    m->val    = val;
+    m->nnz    = nnz;
+    m->format = RAMD_CSR;
+    RAMD_HIP(e);
+    return RAMD_OK;
+}
+
 } // namespace ramd
 
 using namespace ramd;
@@ -382,7 +529,13 @@ int ramd_mat_convert(ramd_mat_t m, int format)
     if(m->format == format)
         return RAMD_OK;
     if(m->format != RAMD_CSR)
-        return RAMD_ERR_UNSUPPORTED; // X -> CSR -> Y goes through the caller (front-end protocol)
+    {
+        if(format != RAMD_CSR)
+            return RAMD_ERR_UNSUPPORTED; // X -> CSR -> Y goes through the caller (local_matrix.cpp:2085-2093)
+        if(m->format != RAMD_ELL && m->format != RAMD_HYB && m->format != RAMD_COO)
+            return RAMD_ERR_UNSUPPORTED;
+        return (m->dtype == RAMD_F64) ? convert_to_csr<double>(m) : convert_to_csr<float>(m);
+    }
     if(m->lu_analysed || m->l_analysed || m->u_analysed)
         mat_free_analysis(m);
     if(m->band_dist < 0) // the ELL/HYB kernels walk the rows in the same band-aware order as CSR

@@ -95,7 +95,8 @@ struct ReduceCtx
 enum ReduceOp
 {
     RED_SUM  = 0,
-    RED_SQRT = 1 // result = sqrt(sum)  (Norm)
+    RED_SQRT = 1, // result = sqrt(sum)  (Norm)
+    RED_ACC  = 2  // result = slot + sum (correction of a dot already in the slot)
 };
 
 template <int NS>
@@ -138,6 +139,8 @@ __device__ __forceinline__ void grid_reduce_finish(const ReduceCtx& ctx, const d
             {
                 if(op[k] == RED_SQRT)
                     tot = sqrt(tot);
+                else if(op[k] == RED_ACC)
+                    tot = ctx.scalars[slot[k]] + tot;
                 ctx.scalars[slot[k]] = tot;
             }
         }

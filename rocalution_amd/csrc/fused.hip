@@ -274,6 +274,29 @@ int ramd_fused_apply_dot(ramd_mat_t m, ramd_vec_t x, ramd_vec_t y, int slot_dot)
     return ramd_fused_multi_dot(vs, 1, y, slot_dot);
 }
 
+int ramd_fused_apply_add_dot(ramd_mat_t m, ramd_vec_t x, double scalar, ramd_vec_t y, ramd_vec_t p,
+                             int slot_dot)
+{
+    if(!m || !x || !y || !p || !slot_ok(slot_dot))
+        RAMD_FAIL(RAMD_ERR_ARG, "fused_apply_add_dot: bad arguments");
+    if(x->dtype != m->dtype || y->dtype != m->dtype || p->dtype != m->dtype || x->n != m->ncol
+       || y->n != m->nrow || p->n != y->n || x == y)
+        RAMD_FAIL(RAMD_ERR_ARG, "fused_apply_add_dot: vector sizes/types do not match the matrix");
+    if(m->nnz <= 0)
+        return RAMD_OK; // ApplyAdd with an empty matrix does nothing; the dot stays valid
+    int s = (m->dtype == RAMD_F64)
+                ? mat_apply_add_dot_impl<double>(m, (const double*)x->d, (double*)y->d, scalar,
+                                                 (const double*)p->d, slot_dot)
+                : mat_apply_add_dot_impl<float>(m, (const float*)x->d, (float*)y->d, (float)scalar,
+                                                (const float*)p->d, slot_dot);
+    if(s != RAMD_ERR_UNSUPPORTED)
+        return s;
+    // other formats: ApplyAdd, then the dot once more over the whole vectors
+    RAMD_TRY(ramd_mat_apply_add(m, x, scalar, y));
+    const ramd_vec_t vs[1] = {p};
+    return ramd_fused_multi_dot(vs, 1, y, slot_dot);
+}
+
 int ramd_fused_cg_update(ramd_vec_t r, ramd_vec_t q, ramd_vec_t dinv, ramd_vec_t z, int slot_rho,
                          int slot_pq, int slot_rr, int slot_rz)
 {

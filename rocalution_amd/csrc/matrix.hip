@@ -294,25 +294,63 @@ int ramd_mat_copy_csr_to_host(ramd_mat_t m, int32_t* rp, int32_t* ci, void* val)
 int ramd_mat_clone(ramd_mat_t src, ramd_mat_t* out)
 {
     CHECK_MAT(src);
-    if(src->format != RAMD_CSR)
-        RAMD_FAIL(RAMD_ERR_UNSUPPORTED, "clone: only CSR sources (preconditioners clone at Build, in CSR)");
     ramd_mat_t m = nullptr;
     RAMD_TRY(ramd_mat_create(src->dtype, &m));
-    int s = mat_alloc_csr(m, src->nrow, src->ncol, src->nnz);
+    Backend&     b  = backend();
+    const size_t vs = val_size(src->dtype);
+    int          s  = RAMD_OK;
+    // deep copy of whatever the format holds (analysis data is not cloned: CloneFrom copies the matrix)
+    auto dup_i = [&](int** dst, const int* from, int64_t n) {
+        if(s != RAMD_OK || !from)
+            return;
+        s = dev_alloc(dst, n);
+        if(s == RAMD_OK && n > 0
+           && hipMemcpyAsync(*dst, from, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, b.cur) != hipSuccess)
+            s = RAMD_ERR_HIP;
+    };
+    auto dup_v = [&](void** dst, const void* from, int64_t n) {
+        if(s != RAMD_OK || !from)
+            return;
+        if(hipMalloc(dst, (size_t)(n > 0 ? n : 0) * vs + kPad) != hipSuccess)
+        {
+            s = RAMD_ERR_HIP;
+            return;
+        }
+        if(n > 0 && hipMemcpyAsync(*dst, from, vs * (size_t)n, hipMemcpyDeviceToDevice, b.cur) != hipSuccess)
+            s = RAMD_ERR_HIP;
+    };
+    m->format = src->format;
+    m->nrow   = src->nrow;
+    m->ncol   = src->ncol;
+    m->nnz    = src->nnz;
+    if(src->format == RAMD_CSR)
+    {
+        dup_i(&m->rp, src->rp, (int64_t)src->nrow + 1);
+        dup_i(&m->ci, src->ci, src->nnz);
+        dup_v(&m->val, src->val, src->nnz);
+    }
+    if(src->format == RAMD_ELL || src->format == RAMD_HYB)
+    {
+        const int64_t ne = (int64_t)src->ell_width * src->nrow;
+        m->ell_width     = src->ell_width;
+        dup_i(&m->ell_col, src->ell_col, ne);
+        dup_v(&m->ell_val, src->ell_val, ne);
+    }
+    if(src->format == RAMD_COO || src->format == RAMD_HYB)
+    {
+        m->coo_nnz     = src->coo_nnz;
+        m->coo_ngroups = src->coo_ngroups;
+        dup_i(&m->coo_row, src->coo_row, src->coo_nnz);
+        dup_i(&m->coo_col, src->coo_col, src->coo_nnz);
+        dup_v(&m->coo_val, src->coo_val, src->coo_nnz);
+        dup_i(&m->coo_grow, src->coo_grow, src->coo_ngroups);
+        dup_i(&m->coo_gptr, src->coo_gptr, (int64_t)src->coo_ngroups + 1);
+    }
+    m->band_dist = src->band_dist;
     if(s != RAMD_OK)
     {
         ramd_mat_destroy(m);
-        return s;
-    }
-    Backend& b = backend();
-    RAMD_HIP(hipMemcpyAsync(m->rp, src->rp, sizeof(int) * ((size_t)src->nrow + 1),
-                            hipMemcpyDeviceToDevice, b.cur));
-    if(src->nnz > 0)
-    {
-        RAMD_HIP(hipMemcpyAsync(m->ci, src->ci, sizeof(int) * (size_t)src->nnz, hipMemcpyDeviceToDevice,
-                                b.cur));
-        RAMD_HIP(hipMemcpyAsync(m->val, src->val, val_size(src->dtype) * (size_t)src->nnz,
-                                hipMemcpyDeviceToDevice, b.cur));
+        RAMD_FAIL(s, "clone: allocation / copy failed");
     }
     *out = m;
     return RAMD_OK;

@@ -28,6 +28,8 @@ template <typename T>
 int mat_apply_impl(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar);
 template <typename T>
 int mat_apply_dot_impl(const ramd_mat_s* m, const T* x, T* y, int slot);
+template <typename T>
+int mat_apply_add_dot_impl(const ramd_mat_s* m, const T* x, T* y, T scalar, const T* p, int slot);
 
 // vector.hip: scalars[slot] = sum(a[0..n)) in one launch, fixed order
 int reduce_sum_to_slot(const double* a, int64_t n, int slot);

@@ -316,6 +316,37 @@ __global__ __launch_bounds__(kBlock) void k_coo_grouped(int ngroups, const int* 
     }
 }
 
+// ApplyAdd + correction of a dot product that already holds <p, y_old>: the touched rows add
+// p_i * y_new_i - p_i * y_old_i (each product rounded as the full dot would round it)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_coo_grouped_dot(int ngroups, const int* __restrict__ grow,
+                                                            const int* __restrict__ gptr,
+                                                            const int* __restrict__ ccol,
+                                                            const T* __restrict__ cval,
+                                                            const T* __restrict__ x, T* __restrict__ y,
+                                                            T scalar, const T* __restrict__ p,
+                                                            ReduceCtx ctx, int slot)
+{
+    __shared__ double red[8];
+    const int64_t     gsz  = (int64_t)gridDim.x * blockDim.x;
+    double            dacc = 0.0;
+    for(int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += gsz)
+    {
+        const int row = grow[g];
+        const T   old = y[row];
+        T         sum = old;
+        for(int i = gptr[g]; i < gptr[g + 1]; ++i)
+            sum += scalar * cval[i] * x[ccol[i]];
+        y[row] = sum;
+        const double pr = (double)p[row];
+        dacc += pr * (double)sum - pr * (double)old;
+    }
+    const double vals[1]  = {dacc};
+    const int    slots[1] = {slot};
+    const int    ops[1]   = {RED_ACC};
+    grid_reduce_finish<1>(ctx, vals, slots, ops, red);
+}
+
 // ------------------------------------------------------------------------------------------
 // sample ~2048 rows: the farthest column of a row, in rows.  A band is accepted when at least half
 // of the samples agree on the same distance D, D is a multiple of the row-block size, and one "plane"
@@ -523,6 +554,23 @@ int mat_apply_dot_impl(const ramd_mat_s* m, const T* x, T* y, int slot)
         return launch_csr<T>(m, x, y, 0, (T)1, true, slot); // bracketed inside (SpMV kernel only)
     return RAMD_ERR_UNSUPPORTED; // caller falls back to apply + dot (two launches)
 }
+// y += scalar A x ; slot (holding <p, y_old>) corrected to <p, y>: grouped COO only
+template <typename T>
+int mat_apply_add_dot_impl(const ramd_mat_s* m, const T* x, T* y, T scalar, const T* p, int slot)
+{
+    if(m->format != RAMD_COO || !m->coo_gptr)
+        return RAMD_ERR_UNSUPPORTED;
+    if(m->coo_nnz <= 0)
+        return RAMD_OK;
+    Backend&  b    = backend();
+    const int grid = reduce_grid(m->coo_ngroups);
+    hipLaunchKernelGGL((k_coo_grouped_dot<T>), dim3(grid), dim3(kBlock), 0, b.cur, m->coo_ngroups, m->coo_grow,
+                       m->coo_gptr, m->coo_col, (const T*)m->coo_val, x, y, scalar, p, reduce_ctx(), slot);
+    RAMD_HIP(hipGetLastError());
+    return RAMD_OK;
+}
+template int mat_apply_add_dot_impl<double>(const ramd_mat_s*, const double*, double*, double, const double*, int);
+template int mat_apply_add_dot_impl<float>(const ramd_mat_s*, const float*, float*, float, const float*, int);
 template int mat_apply_dot_impl<double>(const ramd_mat_s*, const double*, double*, int);
 template int mat_apply_dot_impl<float>(const ramd_mat_s*, const float*, float*, int);
 

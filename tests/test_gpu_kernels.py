@@ -254,3 +254,85 @@ def test_ilu_lusolve_poisson_vs_oracle(ra, oracle, N):
         b = rng.uniform(-1, 1, n)
         A.LUSolve(ra.LocalVector(data=b), y)
         eq(y.numpy(), oracle.lusolve(rp, ci, lu, b))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_convert_back_to_csr_and_clone(ra, name):
+    """ELL/HYB/COO -> CSR (host_conversion.cpp:690-960) restores the CSR arrays (golden matrices have
+    sorted rows), X -> Y goes through CSR (local_matrix.cpp:2085-2093), CloneFrom works in any format"""
+    g = load_golden(name)
+    n = len(g["rowptr"]) - 1
+    x = ra.LocalVector(data=g["x"])
+    for fmt in (ra.ELL, ra.HYB, ra.COO):
+        A = _mat(ra, g)
+        if A.ConvertTo(fmt) != fmt:
+            continue
+        B = ra.LocalMatrix(); B.CloneFrom(A)
+        assert B.GetFormat() == fmt
+        y = ra.LocalVector(); y.Allocate("", n)
+        B.Apply(x, y)
+        eq(y.numpy(), g["spmv_" + {ra.ELL: "ell", ra.HYB: "hyb", ra.COO: "coo"}[fmt]])
+        assert B.ConvertTo(ra.CSR) == ra.CSR
+        rp, ci, va = B.CopyToCSR()
+        eq(rp, g["rowptr"]); eq(ci, g["col"]); eq(va, g["val"])
+        other = ra.HYB if fmt != ra.HYB else ra.COO
+        assert A.ConvertTo(other) == other  # X -> CSR -> Y
+        A.Apply(x, y)
+        eq(y.numpy(), g["spmv_hyb"] if other == ra.HYB else g["spmv_coo"])
+
+
+def test_coo_to_csr_sorts_columns(ra):
+    # rows with unsorted columns: COO keeps storage order, coo_to_csr sorts inside each row (stable)
+    rng = np.random.default_rng(11)
+    n = 300
+    rows = [rng.permutation(n)[:rng.integers(0, 12)].tolist() for _ in range(n)]
+    rp = np.zeros(n + 1, np.int32); rp[1:] = np.cumsum([len(r) for r in rows])
+    ci = np.array([c for r in rows for c in r], np.int32)
+    va = rng.uniform(-1, 1, len(ci))
+    A = ra.LocalMatrix(); A.SetDataPtrCSR(rp, ci, va)
+    assert A.ConvertTo(ra.COO) == ra.COO
+    assert A.ConvertTo(ra.CSR) == ra.CSR
+    rp2, ci2, va2 = A.CopyToCSR()
+    eq(rp2, rp)
+    for i in range(n):
+        o = np.argsort(ci[rp[i]:rp[i + 1]], kind="stable")
+        eq(ci2[rp[i]:rp[i + 1]], ci[rp[i]:rp[i + 1]][o])
+        eq(va2[rp[i]:rp[i + 1]], va[rp[i]:rp[i + 1]][o])
+    # HYB -> CSR keeps the row order (ELL slots, then the COO tail) even when unsorted
+    B = ra.LocalMatrix(); B.SetDataPtrCSR(rp, ci, va)
+    assert B.ConvertTo(ra.HYB) == ra.HYB
+    assert B.ConvertTo(ra.CSR) == ra.CSR
+    rp3, ci3, va3 = B.CopyToCSR()
+    eq(rp3, rp); eq(ci3, ci); eq(va3, va)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_fused_apply_add_dot(ra, oracle, dtype):
+    """ghost-part ApplyAdd with the dot correction: y bit-exact with ApplyAdd, slot == <p, y_new>"""
+    import ctypes as C
+    from rocalution_amd import capi
+    lib = capi.load()
+    rng = np.random.default_rng(3)
+    n, nc = 5000, 700
+    touched = np.sort(rng.choice(n, 900, replace=False))
+    cnt = np.zeros(n, np.int64); cnt[touched] = rng.integers(1, 4, len(touched))
+    rp = np.zeros(n + 1, np.int32); rp[1:] = np.cumsum(cnt)
+    ci = rng.integers(0, nc, rp[-1]).astype(np.int32)
+    va = rng.uniform(-1, 1, rp[-1]).astype(dtype)
+    xr = rng.uniform(-1, 1, nc).astype(dtype)
+    y0 = rng.uniform(-1, 1, n).astype(dtype)
+    p = rng.uniform(-1, 1, n).astype(dtype)
+    for fmt in (ra.COO, ra.CSR):  # COO: fused kernel; CSR: ApplyAdd + full dot
+        G = ra.LocalMatrix(dtype); G.SetDataPtrCSR(rp, ci, va, nrow=n, ncol=nc)
+        assert G.ConvertTo(fmt) == fmt
+        y = ra.LocalVector(dtype, data=y0); yref = ra.LocalVector(dtype, data=y0)
+        vp, vx = ra.LocalVector(dtype, data=p), ra.LocalVector(dtype, data=xr)
+        slot = 5
+        capi.check(lib.ramd_scalars_set(slot, float(np.dot(p.astype(np.float64), y0.astype(np.float64)))))
+        capi.check(lib.ramd_fused_apply_add_dot(G._h, vx._h, 1.0, y._h, vp._h, slot))
+        G.ApplyAdd(vx, 1.0, yref)
+        eq(y.numpy(), yref.numpy())
+        out = (C.c_double * 1)()
+        capi.check(lib.ramd_scalars_fetch(out, slot, 1))
+        exact = float(np.dot(p.astype(np.float64), y.numpy().astype(np.float64)))
+        close(out[0], exact, 1e-12 if dtype == np.float64 else 1e-6)
