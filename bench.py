@@ -158,6 +158,9 @@ def main():
         capi.check(lib.ramd_comm_unique_id(uid))
         capi.check(lib.ramd_comm_init_rccl(0, 1, uid, C.byref(comm)))
 
+    if comm:
+        C.CDLL(None).fflush(None)  # RCCL's version banner sits in C stdio: get it out before the JSON line
+
     def barrier():
         ra.sync()
         if dist is not None:
@@ -319,6 +322,7 @@ def main():
             rg = reference_gpu(args)
             if rg is not None:
                 out["reference_gpu"] = rg
+        C.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
