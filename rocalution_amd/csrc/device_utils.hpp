@@ -149,6 +149,26 @@ __device__ __forceinline__ void grid_reduce_finish(const ReduceCtx& ctx, const d
     }
 }
 
+// every spin is bounded: a dependency that never arrives (a bug, by construction of the ticket
+// order) becomes a loud kernel abort instead of a hung GPU
+constexpr int kSpinLimit = 1 << 24;
+__device__ __forceinline__ void spin_guard(int& spins)
+{
+    if(++spins > kSpinLimit)
+        __builtin_trap();
+}
+
+// workgroup ticket: the k-th workgroup to START works on block k (deadlock freedom does not depend
+// on the dispatch order).  `base` is the counter value before this launch.
+__device__ __forceinline__ unsigned take_ticket(unsigned* counter, unsigned base)
+{
+    __shared__ unsigned s_t;
+    if(threadIdx.x == 0)
+        s_t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base;
+    __syncthreads();
+    return s_t;
+}
+
 inline ReduceCtx reduce_ctx(int ticket_id = 0)
 {
     Backend&  b = backend();

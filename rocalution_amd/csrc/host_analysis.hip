@@ -22,6 +22,18 @@ extern "C" int ramd_mat_multicoloring(ramd_mat_t m, int* num_colors, int* size_c
         RAMD_FAIL(RAMD_ERR_ARG, "MultiColoring: permutation must be an int32 vector");
     if(m->nrow != m->ncol)
         RAMD_FAIL(RAMD_ERR_ARG, "MultiColoring: square matrix expected");
+    // device sweep when it applies (structurally symmetric pattern, <= 64 colours): same colours;
+    // RAMD_COLORING=host forces the serial sweep below
+    static const bool force_host = [] {
+        const char* e = getenv("RAMD_COLORING");
+        return e && std::string(e) == "host";
+    }();
+    if(!force_host)
+    {
+        int s = multicoloring_device(m, num_colors, size_colors, perm);
+        if(s != RAMD_ERR_UNSUPPORTED)
+            return s;
+    }
     Backend&  b   = backend();
     const int n   = m->nrow;
     const int64_t nnz = m->nnz;

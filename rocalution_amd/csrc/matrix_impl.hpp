@@ -23,6 +23,9 @@ void prof_spmv_end();
 // trisolve.hip
 void tri_release(ramd_mat_s* m);
 
+// coloring.hip: device greedy colouring; RAMD_ERR_UNSUPPORTED -> caller runs the host sweep
+int multicoloring_device(const ramd_mat_s* m, int* num_colors, int* size_colors, ramd_vec_s* perm);
+
 // spmv.hip
 template <typename T>
 int mat_apply_impl(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar);

@@ -81,26 +81,6 @@ __global__ __launch_bounds__(kBlock) void k_fill_sentinel(int64_t n, T* __restri
         w[i] = s;
 }
 
-// every spin is bounded: a dependency that never arrives (a bug, by construction of the ticket
-// order) becomes a loud kernel abort instead of a hung GPU
-constexpr int kSpinLimit = 1 << 24;
-__device__ __forceinline__ void spin_guard(int& spins)
-{
-    if(++spins > kSpinLimit)
-        __builtin_trap();
-}
-
-// workgroup ticket: the k-th workgroup to START works on block k (deadlock freedom does not depend
-// on the dispatch order).  `base` is the counter value before this launch.
-__device__ __forceinline__ unsigned take_ticket(unsigned* counter, unsigned base)
-{
-    __shared__ unsigned s_t;
-    if(threadIdx.x == 0)
-        s_t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base;
-    __syncthreads();
-    return s_t;
-}
-
 // ---------------------------------------------------------------- levels (natural order, once)
 // level[i] = 1 + max(level[dep]); 0 means "not computed yet" and doubles as the poll flag.
 // LOWER: deps are columns < i, rows taken in ascending order; else columns > i, descending order.

@@ -336,3 +336,39 @@ def test_fused_apply_add_dot(ra, oracle, dtype):
         capi.check(lib.ramd_scalars_fetch(out, slot, 1))
         exact = float(np.dot(p.astype(np.float64), y.numpy().astype(np.float64)))
         close(out[0], exact, 1e-12 if dtype == np.float64 else 1e-6)
+
+
+def _sym_pattern(n, deg, seed):
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    r = rng.integers(0, n, n * deg); c = rng.integers(0, n, n * deg)
+    M = sp.coo_matrix((np.ones(len(r)), (r, c)), shape=(n, n))
+    M = ((M + M.T + sp.eye(n)) > 0).astype(np.float64).tocsr()
+    M.sort_indices()
+    return M.indptr.astype(np.int32), M.indices.astype(np.int32), np.arange(1, M.nnz + 1, dtype=np.float64)
+
+
+@pytest.mark.parametrize("case", ["poisson24", "sym5000", "sym_dense_rows", "lap2d", "overflow80", "unsym"])
+def test_multicoloring_device_vs_oracle(ra, oracle, case):
+    """the device sweep (symmetric patterns), the > 64 colour fallback and the unsymmetric fallback all give
+    the colours of the serial reference sweep"""
+    from rocalution_amd import generators as gen
+    if case == "poisson24":
+        rp, ci, va = gen.poisson7(24)
+    elif case == "sym5000":
+        rp, ci, va = _sym_pattern(5000, 3, 1)
+    elif case == "sym_dense_rows":
+        rp, ci, va = _sym_pattern(600, 12, 2)
+    elif case == "lap2d":
+        rp, ci, va = gen.laplace2d(70)
+    elif case == "overflow80":
+        n = 80
+        rp = (np.arange(n + 1) * n).astype(np.int32); ci = np.tile(np.arange(n, dtype=np.int32), n)
+        va = np.ones(n * n)
+    else:
+        rp, ci, va = gen.random_sparse(700, 5, seed=9)
+    A = ra.LocalMatrix(); A.SetDataPtrCSR(rp, ci, va)
+    nc, sizes, perm = A.MultiColoring()
+    onc, osizes, operm = oracle.multicoloring(rp, ci)
+    assert nc == onc
+    eq(sizes, osizes); eq(perm.numpy(), operm)
