@@ -324,6 +324,11 @@ public:
         this->CopyToHostData(*ptr);
         this->Clear();
     }
+    // vector files (host_vector.cpp:415-632): include/rocalution/io.hpp
+    void ReadFileASCII(const std::string& filename);
+    void WriteFileASCII(const std::string& filename) const;
+    void ReadFileBinary(const std::string& filename);
+    void WriteFileBinary(const std::string& filename) const;
     void CopyFromData(const ValueType* data)
     {
         this->CopyFromHostData(data);
@@ -705,8 +710,11 @@ public:
             std::copy(this->h_val_.begin(), this->h_val_.end(), val);
         }
     }
-    // MatrixMarket reader with the reference's semantics: include/rocalution/io.hpp
+    // file IO with the reference's formats and semantics: include/rocalution/io.hpp
     bool ReadFileMTX(const std::string& filename);
+    bool WriteFileMTX(const std::string& filename) const;
+    bool ReadFileCSR(const std::string& filename);
+    bool WriteFileCSR(const std::string& filename) const;
 
     void MoveToAccelerator(void)
     {

@@ -5,10 +5,17 @@
 //   * 1-based indices -> 0-based; pattern entries get the value 1;
 //   * symmetric / hermitian storage is mirrored without duplicating the diagonal (:218-272);
 //   * the result is CSR with every row sorted by column (ReadFileMTX always calls Sort()).
+// Also: WriteFileMTX (host_io.cpp:367-395: "general" coordinate file, CSR order, %0.12g values),
+// ReadFileCSR / WriteFileCSR (binary "#rocALUTION binary csr file", host_io.cpp:497-609, :3236-3289:
+// int version, then 64-bit sizes (32-bit before version 30000), 32-bit row offsets while
+// nnz < INT_MAX, int32 columns, values ALWAYS stored as double), and the vector files of
+// host_vector.cpp:415-632 (ASCII: one value per line, scientific; binary: header, version, size, doubles).
 // Host-side setup code; the matrix lands in host storage and is moved by MoveToAccelerator().
 #pragma once
 
 #include <cctype>
+#include <fstream>
+#include <limits>
 #include <numeric>
 
 #include "base.hpp"
@@ -190,6 +197,302 @@ bool LocalMatrix<ValueType>::ReadFileMTX(const std::string& filename)
         this->MoveToAccelerator();
     LOG_INFO("ReadFileMTX: filename=" << filename << "; done");
     return true;
+}
+
+// version stamp written into binary files: that of the reference this API mirrors (3.2.0)
+#ifndef __ROCALUTION_VER
+#define __ROCALUTION_VER 30200
+#endif
+
+namespace detail
+{
+// CSR arrays of a matrix wherever it lives (a converted matrix is cloned and converted back first)
+template <typename ValueType>
+inline void csr_on_host(const LocalMatrix<ValueType>& A, std::vector<PtrType>& rp, std::vector<int>& ci,
+                        std::vector<ValueType>& va)
+{
+    const LocalMatrix<ValueType>* src = &A;
+    LocalMatrix<ValueType>        tmp;
+    if(A.GetFormat() != CSR)
+    {
+        tmp.CloneFrom(A);
+        tmp.ConvertTo(CSR);
+        src = &tmp;
+    }
+    rp.assign((size_t)src->GetM() + 1, 0);
+    ci.assign((size_t)src->GetNnz(), 0);
+    va.assign((size_t)src->GetNnz(), ValueType(0));
+    if(src->GetM() > 0)
+        src->CopyToCSR(rp.data(), ci.data(), va.data());
+}
+} // namespace detail
+
+template <typename ValueType>
+bool LocalMatrix<ValueType>::WriteFileMTX(const std::string& filename) const
+{
+    LOG_INFO("WriteFileMTX: filename=" << filename << "; writing...");
+    std::vector<PtrType>   rp;
+    std::vector<int>       ci;
+    std::vector<ValueType> va;
+    detail::csr_on_host(*this, rp, ci, va);
+    FILE* file = fopen(filename.c_str(), "w");
+    if(!file)
+    {
+        LOG_INFO("WriteFileMTX: cannot open file " << filename);
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+    fprintf(file, "%%%%MatrixMarket matrix coordinate real general\n");
+    fprintf(file, "%d %d %lld\n", (int)this->GetM(), (int)this->GetN(), (long long)ci.size());
+    for(size_t i = 0; i + 1 < rp.size(); ++i)
+        for(PtrType j = rp[i]; j < rp[i + 1]; ++j)
+            fprintf(file, "%d %d %0.12g\n", (int)i + 1, ci[j] + 1, (double)va[j]);
+    fclose(file);
+    LOG_INFO("WriteFileMTX: filename=" << filename << "; done");
+    return true;
+}
+
+template <typename ValueType>
+bool LocalMatrix<ValueType>::WriteFileCSR(const std::string& filename) const
+{
+    LOG_INFO("WriteFileCSR: filename=" << filename << "; writing...");
+    std::vector<PtrType>   rp;
+    std::vector<int>       ci;
+    std::vector<ValueType> va;
+    detail::csr_on_host(*this, rp, ci, va);
+    std::ofstream out(filename.c_str(), std::ios::out | std::ios::binary);
+    if(!out.is_open())
+    {
+        LOG_INFO("WriteFileCSR: cannot open file " << filename);
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+    out << "#rocALUTION binary csr file" << std::endl;
+    const int     version = __ROCALUTION_VER;
+    const int64_t nrow = this->GetM(), ncol = this->GetN(), nnz = (int64_t)ci.size();
+    out.write((const char*)&version, sizeof(int));
+    out.write((const char*)&nrow, sizeof(int64_t));
+    out.write((const char*)&ncol, sizeof(int64_t));
+    out.write((const char*)&nnz, sizeof(int64_t));
+    static_assert(sizeof(PtrType) == 4, "row offsets are 32-bit here (nnz < INT_MAX)");
+    out.write((const char*)rp.data(), sizeof(int) * rp.size());
+    out.write((const char*)ci.data(), sizeof(int) * ci.size());
+    std::vector<double> dv(va.begin(), va.end()); // values are always stored in double precision
+    out.write((const char*)dv.data(), sizeof(double) * dv.size());
+    if(!out)
+    {
+        LOG_INFO("WriteFileCSR: filename=" << filename << "; could not write to file");
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+    out.close();
+    LOG_INFO("WriteFileCSR: filename=" << filename << "; done");
+    return true;
+}
+
+template <typename ValueType>
+bool LocalMatrix<ValueType>::ReadFileCSR(const std::string& filename)
+{
+    LOG_INFO("ReadFileCSR: filename=" << filename << "; reading...");
+    std::ifstream in(filename.c_str(), std::ios::in | std::ios::binary);
+    if(!in.is_open())
+    {
+        LOG_INFO("ReadFileCSR: cannot open file " << filename);
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+    std::string header;
+    std::getline(in, header);
+    if(header != "#rocALUTION binary csr file")
+    {
+        LOG_INFO("ReadFileCSR: invalid rocALUTION matrix header");
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+    int     version = 0;
+    int64_t nrow = 0, ncol = 0, nnz = 0;
+    in.read((char*)&version, sizeof(int));
+    if(version < 30000) // 32-bit sizes before 3.0.0
+    {
+        int s32[3] = {0, 0, 0};
+        in.read((char*)s32, sizeof(s32));
+        nrow = s32[0];
+        ncol = s32[1];
+        nnz  = s32[2];
+    }
+    else
+    {
+        in.read((char*)&nrow, sizeof(int64_t));
+        in.read((char*)&ncol, sizeof(int64_t));
+        in.read((char*)&nnz, sizeof(int64_t));
+    }
+    if(!in || nrow < 0 || ncol < 0 || nnz < 0)
+    {
+        LOG_INFO("ReadFileCSR: invalid matrix data");
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+    if(version >= 30000 && nnz >= std::numeric_limits<int>::max())
+    {
+        LOG_INFO("ReadFileCSR: cannot read 64 bit sparsity pattern into 32 bit structure");
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+    std::vector<PtrType>   rp((size_t)nrow + 1);
+    std::vector<int>       ci((size_t)nnz);
+    std::vector<ValueType> va((size_t)nnz);
+    in.read((char*)rp.data(), sizeof(int) * rp.size());
+    in.read((char*)ci.data(), sizeof(int) * ci.size());
+    {
+        std::vector<double> dv((size_t)nnz);
+        in.read((char*)dv.data(), sizeof(double) * dv.size());
+        for(size_t i = 0; i < dv.size(); ++i)
+            va[i] = static_cast<ValueType>(dv[i]);
+    }
+    if(!in)
+    {
+        LOG_INFO("ReadFileCSR: invalid matrix data");
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+    const bool was_accel = this->on_accel_;
+    this->Clear();
+    if(was_accel)
+        RAMD_CHECK(ramd_mat_clear(this->dev_));
+    this->on_accel_ = false;
+    this->name_     = filename;
+    this->h_rp_.swap(rp);
+    this->h_ci_.swap(ci);
+    this->h_val_.swap(va);
+    this->h_nrow_ = nrow;
+    this->h_ncol_ = ncol;
+    if(was_accel)
+        this->MoveToAccelerator();
+    LOG_INFO("ReadFileCSR: filename=" << filename << "; done");
+    return true;
+}
+
+// ---- vectors
+template <typename ValueType>
+void LocalVector<ValueType>::ReadFileASCII(const std::string& filename)
+{
+    LOG_INFO("ReadFileASCII: filename=" << filename << "; reading...");
+    std::ifstream file(filename.c_str(), std::ifstream::in);
+    if(!file.is_open())
+    {
+        LOG_INFO("Can not open vector file [read]:" << filename);
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+    int64_t     n = 0; // the size is the number of LINES (host_vector.cpp:433-437)
+    std::string line;
+    while(std::getline(file, line))
+        ++n;
+    std::vector<ValueType> data((size_t)n, ValueType(0));
+    file.clear();
+    file.seekg(0, std::ios_base::beg);
+    for(int64_t i = 0; i < n; ++i)
+        file >> data[(size_t)i];
+    file.close();
+    this->Allocate(filename, n);
+    this->CopyFromHostData(data.data());
+    LOG_INFO("ReadFileASCII: filename=" << filename << "; done");
+}
+
+template <typename ValueType>
+void LocalVector<ValueType>::WriteFileASCII(const std::string& filename) const
+{
+    LOG_INFO("WriteFileASCII: filename=" << filename << "; writing...");
+    std::vector<ValueType> data((size_t)this->GetSize());
+    this->CopyToHostData(data.data());
+    std::ofstream file(filename.c_str(), std::ifstream::out);
+    if(!file.is_open())
+    {
+        LOG_INFO("Can not open vector file [write]:" << filename);
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+    file.setf(std::ios::scientific);
+    for(size_t i = 0; i < data.size(); ++i)
+        file << data[i] << std::endl;
+    file.close();
+    LOG_INFO("WriteFileASCII: filename=" << filename << "; done");
+}
+
+template <typename ValueType>
+void LocalVector<ValueType>::ReadFileBinary(const std::string& filename)
+{
+    LOG_INFO("ReadFileBinary: filename=" << filename << "; reading...");
+    std::ifstream in(filename.c_str(), std::ios::in | std::ios::binary);
+    if(!in.is_open())
+    {
+        LOG_INFO("ReadFileBinary: filename=" << filename << "; cannot open file");
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+    std::string header;
+    std::getline(in, header);
+    if(header != "#rocALUTION binary vector file")
+    {
+        LOG_INFO("ReadFileBinary: filename=" << filename << " is not a rocALUTION vector");
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+    int     version = 0;
+    int64_t n       = 0;
+    in.read((char*)&version, sizeof(int));
+    if(version < 30000)
+    {
+        int size32 = 0;
+        in.read((char*)&size32, sizeof(int));
+        n = size32;
+    }
+    else
+        in.read((char*)&n, sizeof(int64_t));
+    if(!in || n < 0)
+    {
+        LOG_INFO("ReadFileBinary: filename=" << filename << "; could not read from file");
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+    std::vector<ValueType> data((size_t)n);
+    if(std::is_floating_point<ValueType>::value) // real data is always stored in double precision
+    {
+        std::vector<double> tmp((size_t)n);
+        in.read((char*)tmp.data(), sizeof(double) * tmp.size());
+        for(size_t i = 0; i < tmp.size(); ++i)
+            data[i] = static_cast<ValueType>(tmp[i]);
+    }
+    else
+        in.read((char*)data.data(), sizeof(ValueType) * data.size());
+    if(!in)
+    {
+        LOG_INFO("ReadFileBinary: filename=" << filename << "; could not read from file");
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+    this->Allocate(filename, n);
+    this->CopyFromHostData(data.data());
+    LOG_INFO("ReadFileBinary: filename=" << filename << "; done");
+}
+
+template <typename ValueType>
+void LocalVector<ValueType>::WriteFileBinary(const std::string& filename) const
+{
+    LOG_INFO("WriteFileBinary: filename=" << filename << "; writing...");
+    const int64_t          n = this->GetSize();
+    std::vector<ValueType> data((size_t)n);
+    this->CopyToHostData(data.data());
+    std::ofstream out(filename.c_str(), std::ios::out | std::ios::binary);
+    if(!out.is_open())
+    {
+        LOG_INFO("WriteFileBinary: filename=" << filename << "; cannot open file");
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+    out << "#rocALUTION binary vector file" << std::endl;
+    const int version = __ROCALUTION_VER;
+    out.write((const char*)&version, sizeof(int));
+    out.write((const char*)&n, sizeof(int64_t));
+    if(std::is_floating_point<ValueType>::value)
+    {
+        std::vector<double> tmp(data.begin(), data.end());
+        out.write((const char*)tmp.data(), sizeof(double) * tmp.size());
+    }
+    else
+        out.write((const char*)data.data(), sizeof(ValueType) * data.size());
+    if(!out)
+    {
+        LOG_INFO("WriteFileBinary: filename=" << filename << "; could not write to file");
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+    out.close();
+    LOG_INFO("WriteFileBinary: filename=" << filename << "; done");
 }
 
 } // namespace rocalution

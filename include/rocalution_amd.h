@@ -284,6 +284,16 @@ int ramd_solver_clear(ramd_solver_t s);
  * MatrixMarket coordinate file -> sorted CSR on the accelerator, reference semantics (1-based indices,
  * pattern -> 1, symmetric/hermitian mirrored without duplicating the diagonal). */
 int ramd_mat_read_mtx(const char* filename, int dtype, ramd_mat_t* out);
+/* LocalMatrix::ReadFileMTX / ReadFileCSR and WriteFileMTX / WriteFileCSR (local_matrix.cpp:1269-1460;
+ * formats: host_io.cpp:51-395 MatrixMarket, :497-609 + :3236-3289 "#rocALUTION binary csr file").
+ * kind: 0 = MatrixMarket, 1 = rocALUTION binary CSR */
+enum { RAMD_FILE_MTX = 0, RAMD_FILE_CSR = 1, RAMD_FILE_ASCII = 0, RAMD_FILE_BINARY = 1 };
+int ramd_mat_read_file(const char* filename, int kind, int dtype, ramd_mat_t* out);
+int ramd_mat_write_file(ramd_mat_t m, const char* filename, int kind);
+/* LocalVector::ReadFileASCII / ReadFileBinary / WriteFileASCII / WriteFileBinary
+ * (host_vector.cpp:415-632).  kind: 0 = ASCII (one value per line), 1 = binary (values as double) */
+int ramd_vec_read_file(ramd_vec_t v, const char* filename, int kind);
+int ramd_vec_write_file(ramd_vec_t v, const char* filename, int kind);
 /* MultiColored::SetDecomposition (preconditioner_multicolored.cpp:140-146): false = L/U sweeps on the
  * permuted matrix (LSolve/USolve) instead of the colour-block decomposition */
 int ramd_solver_set_decomposition(ramd_solver_t s, int decomp);

@@ -532,8 +532,52 @@ static int cmd_bench(int argc, char** argv)
     return 0;
 }
 
+// file-format fixtures: the genuine library writes a matrix / a vector in its four formats and
+// reads MatrixMarket files back (symmetric / pattern storage) -- outputs pin the own IO layer
+static int cmd_io(const std::string& in, const std::string& out)
+{
+    g_out = out;
+    disable_accelerator_rocalution(true);
+    init_rocalution();
+    set_omp_threads_rocalution(1);
+    std::vector<int64_t> hdr = slurp<int64_t>(in + "/hdr.bin");
+    Csr                  A;
+    A.n   = hdr[0];
+    A.nnz = hdr[1];
+    A.rp  = slurp<int32_t>(in + "/rowptr.bin");
+    A.ci  = slurp<int32_t>(in + "/col.bin");
+    A.va  = slurp<double>(in + "/val.bin");
+    MatD m;
+    load_into(A, m, "A");
+    m.WriteFileMTX(out + "/A.mtx");
+    m.WriteFileCSR(out + "/A.csr");
+    std::vector<double> xv = slurp<double>(in + "/x.bin");
+    VecD                x;
+    x.Allocate("x", (int64_t)xv.size());
+    x.CopyFromData(xv.data());
+    x.WriteFileASCII(out + "/x.dat");
+    x.WriteFileBinary(out + "/x.bin");
+    const char* names[] = {"sym", "pat", "gen"};
+    for(const char* nm : names)
+    {
+        std::string   f = in + "/" + nm + ".mtx";
+        std::ifstream t(f.c_str());
+        if(!t.good())
+            continue;
+        MatD r;
+        r.ReadFileMTX(f);
+        dump_csr(std::string("read_") + nm, r);
+        int64_t dims[2] = {r.GetM(), r.GetN()};
+        dump(std::string("read_") + nm + "_dims", dims, 2);
+    }
+    stop_rocalution();
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if(argc >= 4 && std::string(argv[1]) == "io")
+        return cmd_io(argv[2], argv[3]);
     if(argc >= 4 && std::string(argv[1]) == "gen")
         return cmd_gen(argv[2], argv[3]);
     if(argc >= 6 && std::string(argv[1]) == "bench")

@@ -144,6 +144,19 @@ class LocalVector:
 
     DotNonConj = Dot
 
+    def ReadFileASCII(self, filename):
+        """LocalVector file IO with the reference's formats (host_vector.cpp:415-632)"""
+        capi.check(_lib().ramd_vec_read_file(self._h, str(filename).encode(), 0))
+
+    def ReadFileBinary(self, filename):
+        capi.check(_lib().ramd_vec_read_file(self._h, str(filename).encode(), 1))
+
+    def WriteFileASCII(self, filename):
+        capi.check(_lib().ramd_vec_write_file(self._h, str(filename).encode(), 0))
+
+    def WriteFileBinary(self, filename):
+        capi.check(_lib().ramd_vec_write_file(self._h, str(filename).encode(), 1))
+
     def Norm(self):
         r = C.c_double(0)
         capi.check(_lib().ramd_vec_norm(self._h, C.byref(r)))
@@ -362,6 +375,19 @@ class LocalMatrix:
         capi.check(_lib().ramd_mat_read_mtx(str(filename).encode(), _DT[self.dtype], C.byref(h)))
         _lib().ramd_mat_destroy(self._h)
         self._h = h
+
+    def ReadFileCSR(self, filename):
+        """LocalMatrix::ReadFileCSR: the reference's binary CSR file (host_io.cpp:497-609)"""
+        h = capi.mat_t()
+        capi.check(_lib().ramd_mat_read_file(str(filename).encode(), 1, _DT[self.dtype], C.byref(h)))
+        _lib().ramd_mat_destroy(self._h)
+        self._h = h
+
+    def WriteFileMTX(self, filename):
+        capi.check(_lib().ramd_mat_write_file(self._h, str(filename).encode(), 0))
+
+    def WriteFileCSR(self, filename):
+        capi.check(_lib().ramd_mat_write_file(self._h, str(filename).encode(), 1))
 
     def GenPoisson7(self, N):
         capi.check(_lib().ramd_mat_gen_poisson7(self._h, int(N)))

@@ -147,6 +147,10 @@ SIGNATURES = {
     "ramd_solver_set_decomposition": (i32, [ptr, i32]),
     "ramd_solver_set_fused_sweeps": (i32, [ptr, i32]),
     "ramd_mat_read_mtx": (i32, [C.c_char_p, i32, C.POINTER(mat_t)]),
+    "ramd_mat_read_file": (i32, [C.c_char_p, i32, i32, C.POINTER(mat_t)]),
+    "ramd_mat_write_file": (i32, [mat_t, C.c_char_p, i32]),
+    "ramd_vec_read_file": (i32, [vec_t, C.c_char_p, i32]),
+    "ramd_vec_write_file": (i32, [vec_t, C.c_char_p, i32]),
     "ramd_solver_build": (i32, [ptr, mat_t]),
     "ramd_solver_solve": (i32, [ptr, vec_t, vec_t]),
     "ramd_solver_precond_apply": (i32, [ptr, vec_t, vec_t]),

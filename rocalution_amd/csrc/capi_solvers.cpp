@@ -337,6 +337,26 @@ struct ramd_gsolver_s
     }                                                   \
     return RAMD_OK;
 
+template <typename T>
+static void mat_file_io(ramd_mat_t h, const char* filename, int kind, bool read)
+{
+    LocalMatrix<T> m;
+    m.AdoptDeviceHandle(h);
+    if(read)
+        kind == RAMD_FILE_MTX ? m.ReadFileMTX(filename) : m.ReadFileCSR(filename);
+    else
+        kind == RAMD_FILE_MTX ? m.WriteFileMTX(filename) : m.WriteFileCSR(filename);
+}
+template <typename T>
+static void vec_file_io(ramd_vec_t h, const char* filename, int kind, bool read)
+{
+    LocalVector<T> v;
+    v.AdoptDeviceHandle(h);
+    if(read)
+        kind == RAMD_FILE_ASCII ? v.ReadFileASCII(filename) : v.ReadFileBinary(filename);
+    else
+        kind == RAMD_FILE_ASCII ? v.WriteFileASCII(filename) : v.WriteFileBinary(filename);
+}
 extern "C" {
 
 int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out)
@@ -453,6 +473,55 @@ int ramd_mat_read_mtx(const char* filename, int dtype, ramd_mat_t* out)
     }
     *out = h;
     GUARD_END
+}
+int ramd_mat_read_file(const char* filename, int kind, int dtype, ramd_mat_t* out)
+{
+    if(!filename || !out || (dtype != RAMD_F64 && dtype != RAMD_F32) || (kind != 0 && kind != 1))
+        return RAMD_ERR_ARG;
+    GUARD_BEGIN
+    ramd_mat_t h = NULL;
+    if(ramd_mat_create(dtype, &h) != RAMD_OK)
+        return RAMD_ERR_HIP;
+    if(dtype == RAMD_F64)
+        mat_file_io<double>(h, filename, kind, true);
+    else
+        mat_file_io<float>(h, filename, kind, true);
+    *out = h;
+    GUARD_END
+}
+int ramd_mat_write_file(ramd_mat_t m, const char* filename, int kind)
+{
+    int dtype = 0;
+    if(!m || !filename || (kind != 0 && kind != 1) || ramd_mat_info(m, NULL, NULL, NULL, NULL, &dtype) != RAMD_OK)
+        return RAMD_ERR_ARG;
+    GUARD_BEGIN
+    if(dtype == RAMD_F64)
+        mat_file_io<double>(m, filename, kind, false);
+    else
+        mat_file_io<float>(m, filename, kind, false);
+    GUARD_END
+}
+static int vec_file(ramd_vec_t v, const char* filename, int kind, bool read)
+{
+    int dtype = 0;
+    if(!v || !filename || (kind != 0 && kind != 1) || ramd_vec_dtype(v, &dtype) != RAMD_OK)
+        return RAMD_ERR_ARG;
+    GUARD_BEGIN
+    if(dtype == RAMD_F64)
+        vec_file_io<double>(v, filename, kind, read);
+    else if(dtype == RAMD_F32)
+        vec_file_io<float>(v, filename, kind, read);
+    else
+        vec_file_io<int>(v, filename, kind, read);
+    GUARD_END
+}
+int ramd_vec_read_file(ramd_vec_t v, const char* filename, int kind)
+{
+    return vec_file(v, filename, kind, true);
+}
+int ramd_vec_write_file(ramd_vec_t v, const char* filename, int kind)
+{
+    return vec_file(v, filename, kind, false);
 }
 int ramd_solver_build(ramd_solver_t s, ramd_mat_t op)
 {

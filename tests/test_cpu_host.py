@@ -163,3 +163,69 @@ def test_two_rank_gloo_spmv_and_cg_match_single_rank(kind, oracle):
     assert np.allclose(y, yref, rtol=1e-13, atol=1e-13)
     assert abs(int(res[0]["it"]) - ref["iters"]) <= 1
     assert np.linalg.norm(xs - ref["x"]) / np.linalg.norm(ref["x"]) < 1e-8
+
+
+# ------------------------------------------------------------------ file formats
+def _parse_csr_file(path):
+    """the reference's binary CSR layout (src/base/host/host_io.cpp:497-609)"""
+    raw = open(path, "rb").read()
+    head = b"#rocALUTION binary csr file\n"
+    assert raw.startswith(head)
+    o = len(head)
+    version = int(np.frombuffer(raw, np.int32, 1, o)[0]); o += 4
+    nrow, ncol, nnz = (int(v) for v in np.frombuffer(raw, np.int64, 3, o)); o += 24
+    rp = np.frombuffer(raw, np.int32, nrow + 1, o); o += 4 * (nrow + 1)
+    ci = np.frombuffer(raw, np.int32, nnz, o); o += 4 * nnz
+    va = np.frombuffer(raw, np.float64, nnz, o); o += 8 * nnz
+    assert o == len(raw)
+    return version, nrow, ncol, rp, ci, va
+
+
+def _same_but_version(a, b, header):
+    """binary files carry the writer's version right after the header line"""
+    ra, rb = open(a, "rb").read(), open(b, "rb").read()
+    o = len(header)
+    assert ra[:o] == rb[:o] == header
+    assert ra[o + 4:] == rb[o + 4:]
+
+
+def test_file_io_matches_reference_files(tmp_path):
+    """read what the genuine library wrote, write it again: same bytes (binary: except the version
+    stamp); MatrixMarket symmetric / pattern / unsorted general files give the reference's CSR"""
+    import subprocess
+    from rocalution_amd import build as B
+    B.build()
+    gold = os.path.join(ROOT, "tests", "golden", "io")
+    exe = str(tmp_path / "io_driver")
+    libdir = os.path.join(ROOT, "rocalution_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "drivers", "io_driver.cpp"), "-o", exe,
+                           "-L", libdir, "-lrocalution_amd", "-Wl,-rpath," + libdir])
+    out = tmp_path / "out"; out.mkdir()
+    r = subprocess.run([exe, gold, str(out)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert r.returncode == 0, r.stdout.decode()
+    exp = np.load(os.path.join(gold, "io_expected.npz"))
+    ref_mtx = open(os.path.join(gold, "ref_A.mtx"), "rb").read()
+    assert open(out / "A_from_mtx.mtx", "rb").read() == ref_mtx
+    assert open(out / "A_from_csr.mtx", "rb").read() == ref_mtx
+    head = b"#rocALUTION binary csr file\n"
+    _same_but_version(str(out / "A_from_csr.csr"), os.path.join(gold, "ref_A.csr"), head)
+    vf = _parse_csr_file(str(out / "A_float.csr"))  # fp32 matrix: values still stored as double
+    assert np.array_equal(vf[5], exp["val"].astype(np.float32).astype(np.float64))
+    v, nr, nc, rp, ci, va = _parse_csr_file(str(out / "A_from_csr.csr"))
+    assert (nr, nc) == (25, 25) and v == 30200
+    assert np.array_equal(rp, exp["rowptr"]) and np.array_equal(ci, exp["col"]) and np.array_equal(va, exp["val"])
+    # the MatrixMarket text carries 12 significant digits
+    v, nr, nc, rp, ci, va = _parse_csr_file(str(out / "A_from_mtx.csr"))
+    assert np.array_equal(rp, exp["rowptr"]) and np.array_equal(ci, exp["col"])
+    assert np.allclose(va, exp["val"], rtol=1e-11, atol=0)
+    for nm in ("sym", "pat", "gen"):
+        v, nr, nc, rp, ci, va = _parse_csr_file(str(out / ("read_%s.csr" % nm)))
+        assert [nr, nc] == exp["read_%s_dims" % nm].tolist()
+        assert np.array_equal(rp, exp["read_%s_rowptr" % nm])
+        assert np.array_equal(ci, exp["read_%s_col" % nm])
+        assert np.array_equal(va, exp["read_%s_val" % nm])
+    ref_dat = open(os.path.join(gold, "ref_x.dat"), "rb").read()
+    assert open(out / "x_from_ascii.dat", "rb").read() == ref_dat
+    assert open(out / "x_from_bin.dat", "rb").read() == ref_dat
+    _same_but_version(str(out / "x_from_bin.bin"), os.path.join(gold, "ref_x.bin"), b"#rocALUTION binary vector file\n")
