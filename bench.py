@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--no-reference-gpu", action="store_true")
     ap.add_argument("--solver", default="cg", choices=["cg", "gmres", "bicgstab", "mixed"],
                     help="headline = cg; the others run the remaining BASELINE.json configs through the same harness")
-    ap.add_argument("--precond", default="jacobi", choices=["none", "jacobi", "ilu0", "mcsgs"])
+    ap.add_argument("--precond", default="jacobi", choices=["none", "jacobi", "ilu0", "mcsgs", "mcgs", "mcilu"])
     ap.add_argument("--force-global", action="store_true",
                     help="1 process: still go through the GlobalMatrix/RCCL code path (communicator of size 1, "
                          "collectives not skipped) - a check of the N>1 plumbing on a 1-GPU box")
@@ -210,7 +210,8 @@ def main():
             return dt, it, res, tb
 
         HEAD = {"cg": S.CG, "gmres": S.GMRES, "bicgstab": S.BiCGStab}.get(args.solver, S.CG)
-        HPC = {"none": None, "jacobi": S.Jacobi, "ilu0": S.ILU, "mcsgs": S.MultiColoredSGS}[args.precond]
+        HPC = {"none": None, "jacobi": S.Jacobi, "ilu0": S.ILU, "mcsgs": S.MultiColoredSGS,
+               "mcgs": S.MultiColoredGS, "mcilu": S.MultiColoredILU}[args.precond]
         if args.solver == "mixed":
             def run(iters, *_a):  # noqa: F811  (config 5 on one GPU)
                 inner = S.CG(np.float32)
@@ -264,6 +265,8 @@ def main():
         g = C.c_void_p()
         SK = {"cg": capi.SOLVER_CG, "gmres": capi.SOLVER_GMRES, "bicgstab": capi.SOLVER_BICGSTAB}
         PK = {"none": capi.PC_NONE, "jacobi": capi.PC_JACOBI, "ilu0": capi.PC_ILU0, "mcsgs": capi.PC_MCSGS}
+        if args.precond not in PK:
+            raise SystemExit("--precond %s: not wired into the distributed driver" % args.precond)
         if args.solver == "mixed":  # config 5: fp64 defect correction around fp32 CG + Jacobi
             capi.check(lib.ramd_gsolver_create_mixed(comm, capi.SOLVER_CG, PK[args.precond], C.byref(g)))
             capi.check(lib.ramd_gsolver_init_inner(g, 1e-5, 1e-2, 1e20, 100000))
@@ -300,7 +303,8 @@ def main():
         out = {
             "metric": "%s iterations/s, 3D 7-pt Poisson %d^3 %s fp64" % (
                 {"cg": "CG", "gmres": "GMRES(30)", "bicgstab": "BiCGStab", "mixed": "MixedPrecisionDC(fp64/fp32 CG)"}[args.solver]
-                + "+" + {"none": "none", "jacobi": "Jacobi", "ilu0": "ILU(0)", "mcsgs": "MC-SGS"}[args.precond], N,
+                + "+" + {"none": "none", "jacobi": "Jacobi", "ilu0": "ILU(0)", "mcsgs": "MC-SGS", "mcgs": "MC-GS",
+                         "mcilu": "MC-ILU(0,1)"}[args.precond], N,
                 args.format.upper()),
             "value": round(it / dt, 3), "unit": "iters/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / it * 1e3, 5), "higher_is_better": True,

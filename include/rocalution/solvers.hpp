@@ -513,6 +513,7 @@ public:
         {
             this->preconditioner_->LAnalyseClear();
             this->preconditioner_->UAnalyseClear();
+            this->preconditioner_->LUAnalyseClear();
             delete this->preconditioner_;
             this->preconditioner_ = NULL;
         }
@@ -562,6 +563,10 @@ protected:
     {
         return false;
     }
+    virtual int SweepKind_(void) const
+    {
+        return RAMD_MC_SGS;
+    }
     template <class O = OperatorType>
     typename std::enable_if<std::is_same<O, LocalMatrix<ValueType>>::value, bool>::type TryBuildSweeps_(void)
     {
@@ -586,7 +591,7 @@ protected:
     typename std::enable_if<std::is_same<V, LocalVector<ValueType>>::value, void>::type
         ApplySweeps_(const VectorType& rhs, VectorType* x)
     {
-        RAMD_CHECK(ramd_mcsgs_apply(this->sweeps_, rhs.handle(), x->handle()));
+        RAMD_CHECK(ramd_mcsgs_apply_kind(this->sweeps_, this->SweepKind_(), rhs.handle(), x->handle()));
     }
     template <class V = VectorType>
     typename std::enable_if<!std::is_same<V, LocalVector<ValueType>>::value, void>::type
@@ -776,6 +781,138 @@ protected:
         x->CopyFromPermuteBackward(this->x_, this->permutation_);
     }
     ValueType omega_;
+};
+
+// preconditioner_multicolored_gs.cpp:218-288: class MultiColoredGS : public MultiColoredSGS --
+// backward sweep only (SolveL_/SolveD_ empty); the non-decomposed form is "No implemented yet" there too
+template <class OperatorType, class VectorType, typename ValueType>
+class MultiColoredGS : public MultiColoredSGS<OperatorType, VectorType, ValueType>
+{
+public:
+    MultiColoredGS() {}
+    virtual ~MultiColoredGS()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("Multicolored Gauss-Seidel (GS) preconditioner");
+        if(this->build_)
+            LOG_INFO("number of colors = " << this->num_blocks_);
+    }
+
+protected:
+    virtual int SweepKind_(void) const
+    {
+        return RAMD_MC_GS;
+    }
+    virtual void PostAnalyse_(void)
+    {
+        this->preconditioner_->UAnalyse(false);
+    }
+    virtual void SolveL_(void) {}
+    virtual void SolveD_(void) {}
+    virtual void Solve_(const VectorType&, VectorType*)
+    {
+        LOG_INFO("No implemented yet");
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+};
+
+// preconditioner_multicolored_ilu.cpp: ILU(p,q) with the power(q)-pattern method.  Provided here:
+// the default ILU(0,1) (colouring of A itself, ILU(0) of P A P^T).  p > 0 / q > 1 need
+// SymbolicPower + ILUpFactorize, which this backend does not provide (fails loudly).
+template <class OperatorType, class VectorType, typename ValueType>
+class MultiColoredILU : public MultiColored<OperatorType, VectorType, ValueType>
+{
+public:
+    MultiColoredILU()
+        : q_(1)
+        , p_(0)
+        , level_(true)
+        , nnz_(0)
+    {
+    }
+    virtual ~MultiColoredILU()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("Multicolored ILU preconditioner (power(q)-pattern method), ILU(" << this->p_ << ","
+                                                                                   << this->q_ << ")");
+        if(this->build_)
+            LOG_INFO("number of colors = " << this->num_blocks_ << "; ILU nnz = " << this->nnz_);
+    }
+    virtual void Set(int p)
+    {
+        assert(this->build_ == false && p >= 0);
+        this->p_ = p;
+        this->q_ = p + 1;
+    }
+    virtual void Set(int p, int q, bool level = true)
+    {
+        assert(this->build_ == false && p >= 0 && q >= 1);
+        this->p_     = p;
+        this->q_     = q;
+        this->level_ = level;
+    }
+
+protected:
+    virtual bool CanFuseSweeps_(void) const
+    {
+        return true;
+    }
+    virtual int SweepKind_(void) const
+    {
+        return RAMD_MC_ILU;
+    }
+    virtual void Factorize_(void)
+    {
+        if(this->p_ != 0 || this->q_ != 1)
+        {
+            LOG_INFO("MultiColoredILU: only ILU(0,1) is provided by this backend (no SymbolicPower / "
+                     "ILUpFactorize for p > 0)");
+            FATAL_ERROR(__FILE__, __LINE__);
+        }
+        this->preconditioner_->ILU0Factorize(); // ILUpFactorize(0) (local_matrix.cpp:3920-3923)
+        this->nnz_ = this->preconditioner_->GetNnz();
+    }
+    virtual void PostAnalyse_(void)
+    {
+        this->preconditioner_->LUAnalyse();
+    }
+    void sweep_block_(int i, int j)
+    {
+        if(this->blk_(i, j)->GetNnz() > 0)
+            this->blk_(i, j)->ApplyAdd(*this->x_block_[j], static_cast<ValueType>(-1),
+                                       this->x_block_[i]);
+    }
+    virtual void SolveL_(void)
+    {
+        for(int i = 0; i < this->num_blocks_; ++i)
+            for(int j = 0; j < i; ++j)
+                this->sweep_block_(i, j);
+    }
+    virtual void SolveD_(void) {}
+    virtual void SolveR_(void)
+    {
+        for(int i = this->num_blocks_ - 1; i >= 0; --i)
+        {
+            for(int j = this->num_blocks_ - 1; j > i; --j)
+                this->sweep_block_(i, j);
+            this->diag_solver_[i]->Solve(*this->x_block_[i], this->x_block_[i]);
+        }
+    }
+    virtual void Solve_(const VectorType& rhs, VectorType* x)
+    {
+        x->CopyFromPermute(rhs, this->permutation_);
+        this->preconditioner_->LUSolve(*x, &this->x_);
+        x->CopyFromPermuteBackward(this->x_, this->permutation_);
+    }
+    int     q_, p_;
+    bool    level_;
+    int64_t nnz_;
 };
 
 // ============================================================================ IterativeLinearSolver

@@ -202,6 +202,11 @@ typedef struct ramd_mcsgs_s* ramd_mcsgs_t;
 int ramd_mcsgs_build(ramd_mat_t permuted, int num_blocks, const int* block_sizes, ramd_vec_t perm_i32,
                      ramd_mcsgs_t* out);
 int ramd_mcsgs_apply(ramd_mcsgs_t h, ramd_vec_t rhs, ramd_vec_t x);
+/* the same sweep plan applied as MultiColoredGS (backward sweep only,
+ * preconditioner_multicolored_gs.cpp:250-288) or, when `permuted` held the ILU(0) factors of P A P^T,
+ * as MultiColoredILU(0,1) (preconditioner_multicolored_ilu.cpp:187-232) */
+enum { RAMD_MC_SGS = 0, RAMD_MC_GS = 1, RAMD_MC_ILU = 2 };
+int ramd_mcsgs_apply_kind(ramd_mcsgs_t h, int kind, ramd_vec_t rhs, ramd_vec_t x);
 int ramd_mcsgs_destroy(ramd_mcsgs_t h);
 /* several dot products against one vector in one pass: s[slot0+k] = <v_k, w>, k < count */
 int ramd_fused_multi_dot(const ramd_vec_t* vs, int count, ramd_vec_t w, int slot0);
@@ -260,7 +265,7 @@ int ramd_comm_halo_end(ramd_comm_t c);
  * (the Python tests and bench.py).  Semantics are those of the C++ classes of the same name. */
 typedef struct ramd_solver_s* ramd_solver_t;
 enum { RAMD_SOLVER_CG = 0, RAMD_SOLVER_GMRES = 1, RAMD_SOLVER_BICGSTAB = 2 };
-enum { RAMD_PC_NONE = 0, RAMD_PC_JACOBI = 1, RAMD_PC_ILU0 = 2, RAMD_PC_MCSGS = 3 };
+enum { RAMD_PC_NONE = 0, RAMD_PC_JACOBI = 1, RAMD_PC_ILU0 = 2, RAMD_PC_MCSGS = 3, RAMD_PC_MCGS = 4, RAMD_PC_MCILU = 5 };
 int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out);
 /* MixedPrecisionDC<fp64 outer, fp32 inner>: inner solver/preconditioner kinds */
 int ramd_solver_create_mixed(int inner_solver, int inner_precond, ramd_solver_t* out);

@@ -10,7 +10,8 @@ extern "C" {
 
 enum { ORC_CSR = 1, ORC_ELL = 6, ORC_HYB = 7 }; /* numbering of src/base/matrix_formats.hpp */
 enum { ORC_CG = 0, ORC_GMRES = 1, ORC_BICGSTAB = 2 };
-enum { ORC_PC_NONE = 0, ORC_PC_JACOBI = 1, ORC_PC_ILU0 = 2, ORC_PC_MCSGS = 3 };
+enum { ORC_PC_NONE = 0, ORC_PC_JACOBI = 1, ORC_PC_ILU0 = 2, ORC_PC_MCSGS = 3, ORC_PC_MCGS = 4, ORC_PC_MCILU = 5 };
+#define ORC_PC_IS_MC(k) ((k) == ORC_PC_MCSGS || (k) == ORC_PC_MCGS || (k) == ORC_PC_MCILU)
 
 typedef struct
 {

@@ -712,7 +712,7 @@ static void SUF(pc_free)(SUF(orc_pc) * P)
 {
     free(P->inv_diag);
     free(P->lu_val);
-    if(P->kind == ORC_PC_MCSGS)
+    if(ORC_PC_IS_MC(P->kind))
     {
         int nb = P->num_blocks;
         for(int i = 0; i < nb * nb; ++i)
@@ -765,8 +765,11 @@ static int SUF(pc_build)(SUF(orc_pc) * P, int kind, int nrow, int64_t nnz, const
         memcpy(P->lu_val, val, sizeof(T) * (size_t)nnz);
         SUF(orc_csr_ilu0)(nrow, row_offset, col, P->lu_val);
     }
-    else if(kind == ORC_PC_MCSGS)
+    else if(ORC_PC_IS_MC(kind))
     {
+        /* MC-GS: same build as MC-SGS (class MultiColoredGS : MultiColoredSGS);
+         * MC-ILU(0,1): preconditioner_multicolored_ilu.cpp:95-130 -- colouring of A itself (q = 1),
+         * Permute_, Factorize_ = ILUpFactorize(0) = ILU0Factorize on the permuted matrix, Decompose_ */
         P->perm       = (int*)malloc(sizeof(int) * (size_t)nrow);
         int  nb       = 0;
         int* sizes    = (int*)malloc(sizeof(int) * (size_t)(nrow > 0 ? nrow : 1));
@@ -786,6 +789,8 @@ static int SUF(pc_build)(SUF(orc_pc) * P, int kind, int nrow, int64_t nnz, const
         int* pcol = (int*)malloc(sizeof(int) * (size_t)nnz);
         T*   pval = (T*)malloc(sizeof(T) * (size_t)nnz);
         SUF(orc_csr_permute)(nrow, nnz, row_offset, col, val, P->perm, pro, pcol, pval);
+        if(kind == ORC_PC_MCILU)
+            SUF(orc_csr_ilu0)(nrow, pro, pcol, pval);
         P->blk_row_offset = (int**)calloc((size_t)nb * nb, sizeof(int*));
         P->blk_col        = (int**)calloc((size_t)nb * nb, sizeof(int*));
         P->blk_val        = (T**)calloc((size_t)nb * nb, sizeof(T*));
@@ -839,7 +844,10 @@ static int SUF(pc_build)(SUF(orc_pc) * P, int kind, int nrow, int64_t nnz, const
 /* Solve(rhs, x):
  *   Jacobi  preconditioner.cpp:137-166 (x = inv_diag * rhs)
  *   ILU     preconditioner.cpp:501-511 -> LUSolve
- *   MC-SGS  preconditioner_multicolored.cpp:348-413 + preconditioner_multicolored_gs.cpp:127-199 */
+ *   MC-SGS  preconditioner_multicolored.cpp:348-413 + preconditioner_multicolored_gs.cpp:127-199
+ *   MC-GS   same frame, SolveL_/SolveD_ empty (preconditioner_multicolored_gs.cpp:250-288)
+ *   MC-ILU  same frame, SolveL_ without the diagonal solve, SolveD_ empty, SolveR_ as MC-SGS
+ *           (preconditioner_multicolored_ilu.cpp:187-232) */
 static void SUF(pc_solve)(SUF(orc_pc) * P, const T* rhs, T* x)
 {
     int n = P->n;
@@ -854,15 +862,17 @@ static void SUF(pc_solve)(SUF(orc_pc) * P, const T* rhs, T* x)
     {
         SUF(orc_csr_lusolve)(n, P->nnz, P->row_offset, P->col, P->lu_val, rhs, x);
     }
-    else if(P->kind == ORC_PC_MCSGS)
+    else if(ORC_PC_IS_MC(P->kind))
     {
+        const int do_l = (P->kind != ORC_PC_MCGS), l_diag = (P->kind == ORC_PC_MCSGS);
+        const int do_d = (P->kind == ORC_PC_MCSGS);
         int nb = P->num_blocks;
         T*  xb = P->xtmp; /* x_block_[i] = xb + block_offsets[i] */
         /* ExtractRHSinX_: x = P rhs ; slices copied into x_block_ */
         SUF(orc_copy_permute)(n, x, rhs, P->perm);
         memcpy(xb, x, sizeof(T) * (size_t)n);
         /* SolveL_ */
-        for(int i = 0; i < nb; ++i)
+        for(int i = 0; do_l && i < nb; ++i)
         {
             T* xi = xb + P->block_offsets[i];
             for(int j = 0; j < i; ++j)
@@ -873,11 +883,11 @@ static void SUF(pc_solve)(SUF(orc_pc) * P, const T* rhs, T* x)
                                            P->blk_row_offset[id], P->blk_col[id], P->blk_val[id],
                                            xb + P->block_offsets[j], (T)-1, xi);
             }
-            if(P->blk_inv_diag[i])
+            if(l_diag && P->blk_inv_diag[i])
                 SUF(orc_pointwise_mult)(P->block_sizes[i], xi, P->blk_inv_diag[i]);
         }
         /* SolveD_ */
-        for(int i = 0; i < nb; ++i)
+        for(int i = 0; do_d && i < nb; ++i)
             SUF(orc_pointwise_mult)(P->block_sizes[i], xb + P->block_offsets[i], P->blk_diag[i]);
         /* SolveR_ (j descending) */
         for(int i = nb - 1; i >= 0; --i)

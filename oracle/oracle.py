@@ -16,7 +16,7 @@ _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 CSR, ELL, HYB = 1, 6, 7
 CG, GMRES, BICGSTAB = 0, 1, 2
-PC_NONE, PC_JACOBI, PC_ILU0, PC_MCSGS = 0, 1, 2, 3
+PC_NONE, PC_JACOBI, PC_ILU0, PC_MCSGS, PC_MCGS, PC_MCILU = 0, 1, 2, 3, 4, 5
 
 
 def build(force=False):

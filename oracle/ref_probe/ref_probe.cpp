@@ -284,6 +284,22 @@ static int cmd_gen(const std::string& in, const std::string& out)
         dump_vec("pc_mcsgs", y);
         p.Clear();
     }
+    {
+        MultiColoredGS<MatD, VecD, double> p;
+        p.SetOperator(mat);
+        p.Build();
+        p.Solve(x, &y);
+        dump_vec("pc_mcgs", y);
+        p.Clear();
+    }
+    {
+        MultiColoredILU<MatD, VecD, double> p; // default ILU(0,1)
+        p.SetOperator(mat);
+        p.Build();
+        p.Solve(x, &y);
+        dump_vec("pc_mcilu", y);
+        p.Clear();
+    }
 
     // --- solvers (rhs = A*1, x0 = 0, default tolerances) -------------------------------------
     if(do_solvers)
@@ -356,6 +372,27 @@ static int cmd_gen(const std::string& in, const std::string& out)
             ls.Build();
             sol.Zeros();
             run_solver("bicgstab_mcsgs", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            BiCGStab<MatD, VecD, double>       ls;
+            MultiColoredGS<MatD, VecD, double> p;
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(p);
+            ls.Build();
+            sol.Zeros();
+            run_solver("bicgstab_mcgs", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            GMRES<MatD, VecD, double>           ls;
+            MultiColoredILU<MatD, VecD, double> p;
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(p);
+            ls.SetBasisSize(basis);
+            ls.Build();
+            sol.Zeros();
+            run_solver("gmres_mcilu", ls, rhs, sol);
             ls.Clear();
         }
         {

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "librocalution_amd.so")
 
 OK, ERR_HIP, ERR_ARG, ERR_UNSUPPORTED, ERR_REFUSED, ERR_NO_DEVICE, ERR_STATE = range(7)
 SOLVER_CG, SOLVER_GMRES, SOLVER_BICGSTAB = 0, 1, 2
-PC_NONE, PC_JACOBI, PC_ILU0, PC_MCSGS = 0, 1, 2, 3
+PC_NONE, PC_JACOBI, PC_ILU0, PC_MCSGS, PC_MCGS, PC_MCILU = 0, 1, 2, 3, 4, 5
 F64, F32, I32 = 0, 1, 2
 CSR, COO, ELL, HYB = 1, 4, 6, 7
 
@@ -115,6 +115,7 @@ SIGNATURES = {
     "ramd_fused_cg_direction": (i32, [vec_t, vec_t, vec_t, i32, i32, i32]),
     "ramd_mcsgs_build": (i32, [mat_t, i32, pi32, vec_t, C.POINTER(ptr)]),
     "ramd_mcsgs_apply": (i32, [ptr, vec_t, vec_t]),
+    "ramd_mcsgs_apply_kind": (i32, [ptr, i32, vec_t, vec_t]),
     "ramd_mcsgs_destroy": (i32, [ptr]),
     "ramd_fused_multi_dot": (i32, [C.POINTER(vec_t), i32, vec_t, i32]),
     "ramd_fused_mgs_step": (i32, [vec_t, vec_t, i32, vec_t, i32]),

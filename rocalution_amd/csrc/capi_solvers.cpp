@@ -48,6 +48,8 @@ struct Precs
     Jacobi<M, V, T>          jacobi;
     ILU<M, V, T>             ilu;
     MultiColoredSGS<M, V, T> mcsgs;
+    MultiColoredGS<M, V, T>  mcgs;
+    MultiColoredILU<M, V, T> mcilu;
     Solver<M, V, T>*         get(int kind)
     {
         switch(kind)
@@ -58,9 +60,21 @@ struct Precs
             return &ilu;
         case RAMD_PC_MCSGS:
             return &mcsgs;
+        case RAMD_PC_MCGS:
+            return &mcgs;
+        case RAMD_PC_MCILU:
+            return &mcilu;
         default:
             return NULL;
         }
+    }
+    MultiColored<M, V, T>* mc(int kind)
+    {
+        if(kind == RAMD_PC_MCGS)
+            return &mcgs;
+        if(kind == RAMD_PC_MCILU)
+            return &mcilu;
+        return &mcsgs;
     }
 };
 
@@ -109,15 +123,15 @@ struct LocalSolver : SolverBase
     }
     void set_precond_format(int f) override
     {
-        pcs.mcsgs.SetPrecondMatrixFormat((unsigned)f);
+        pcs.mc(pc_kind)->SetPrecondMatrixFormat((unsigned)f);
     }
     void set_decomposition(bool d) override
     {
-        pcs.mcsgs.SetDecomposition(d);
+        pcs.mc(pc_kind)->SetDecomposition(d);
     }
     void set_fused_sweeps(bool f) override
     {
-        pcs.mcsgs.SetFusedSweeps(f);
+        pcs.mc(pc_kind)->SetFusedSweeps(f);
     }
     void build(ramd_mat_t h) override
     {
@@ -160,7 +174,7 @@ struct LocalSolver : SolverBase
     }
     int num_colors() override
     {
-        return pcs.mcsgs.GetNumColors();
+        return pcs.mc(pc_kind)->GetNumColors();
     }
     void clear() override
     {
@@ -361,7 +375,7 @@ extern "C" {
 
 int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out)
 {
-    if(!out || solver < 0 || solver > 2 || precond < 0 || precond > 3
+    if(!out || solver < 0 || solver > 2 || precond < 0 || precond > RAMD_PC_MCILU
        || (dtype != RAMD_F64 && dtype != RAMD_F32))
         return RAMD_ERR_ARG;
     GUARD_BEGIN
@@ -376,7 +390,7 @@ int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out)
 
 int ramd_solver_create_mixed(int inner_solver, int inner_precond, ramd_solver_t* out)
 {
-    if(!out || inner_solver < 0 || inner_solver > 2 || inner_precond < 0 || inner_precond > 3)
+    if(!out || inner_solver < 0 || inner_solver > 2 || inner_precond < 0 || inner_precond > RAMD_PC_MCILU)
         return RAMD_ERR_ARG;
     GUARD_BEGIN
     ramd_solver_s* s = new ramd_solver_s;

@@ -314,11 +314,11 @@ static int mc_build(McsgsPlan* P, const ramd_mat_s* m, const int* perm)
 }
 
 template <typename T>
-static int mc_apply(McsgsPlan* P, const T* rhs, T* out)
+static int mc_apply(McsgsPlan* P, int kind, const T* rhs, T* out)
 {
     Backend&  b  = backend();
     const int nb = P->nb;
-#define SWEEP(FR, MD, BO, TO, i, OFFP, COLP, VALP)                                                       \
+#define SWEEP_ID(FR, MD, BO, TO, i, OFFP, COLP, VALP, IDENT)                                             \
     do                                                                                                   \
     {                                                                                                    \
         const int p0 = P->off[(size_t)(i)], p1 = P->off[(size_t)(i) + 1];                                \
@@ -326,8 +326,30 @@ static int mc_apply(McsgsPlan* P, const T* rhs, T* out)
             hipLaunchKernelGGL((k_mc_sweep<T, FR, MD, BO, TO>), dim3((p1 - p0 + kBlock - 1) / kBlock),   \
                                dim3(kBlock), 0, b.cur, p0, p1, OFFP, COLP, (const T*)VALP,               \
                                (const T*)P->d, (const T*)P->dinv, P->iperm, rhs, (T*)P->xp, out,         \
-                               (int)P->identity[(size_t)(i)]);                                           \
+                               (int)(IDENT));                                                            \
     } while(0)
+#define SWEEP(FR, MD, BO, TO, i, OFFP, COLP, VALP)                                                       \
+    SWEEP_ID(FR, MD, BO, TO, i, OFFP, COLP, VALP, P->identity[(size_t)(i)])
+    if(kind == RAMD_MC_GS)
+    {
+        // MultiColoredGS (preconditioner_multicolored_gs.cpp:250-288): x = P rhs, SolveR_ only
+        for(int i = nb - 1; i >= 0; --i)
+            SWEEP(true, false, false, true, i, P->u_off, P->u_col, P->u_val);
+        RAMD_HIP(hipGetLastError());
+        return RAMD_OK;
+    }
+    if(kind == RAMD_MC_ILU)
+    {
+        // MultiColoredILU on the ILU(0) factors of P A P^T (preconditioner_multicolored_ilu.cpp:187-232):
+        // SolveL_ has no diagonal solve (unit L), SolveD_ is empty, SolveR_ divides by the U diagonal
+        for(int i = 0; i + 1 < nb; ++i)
+            SWEEP_ID(true, false, false, false, i, P->l_off, P->l_col, P->l_val, 1);
+        SWEEP(true, false, false, true, nb - 1, P->l_off, P->l_col, P->l_val); // last colour: L and R in one
+        for(int i = nb - 2; i >= 0; --i)
+            SWEEP(false, false, false, true, i, P->u_off, P->u_col, P->u_val);
+        RAMD_HIP(hipGetLastError());
+        return RAMD_OK;
+    }
     // SolveL_ for colours 0 .. nb-2
     for(int i = 0; i + 1 < nb; ++i)
         SWEEP(true, false, false, false, i, P->l_off, P->l_col, P->l_val);
@@ -337,6 +359,7 @@ static int mc_apply(McsgsPlan* P, const T* rhs, T* out)
     for(int i = nb - 2; i >= 0; --i)
         SWEEP(false, true, false, true, i, P->u_off, P->u_col, P->u_val);
 #undef SWEEP
+#undef SWEEP_ID
     RAMD_HIP(hipGetLastError());
     return RAMD_OK;
 }
@@ -388,7 +411,12 @@ int ramd_mcsgs_build(ramd_mat_t permuted, int num_blocks, const int* block_sizes
 
 int ramd_mcsgs_apply(ramd_mcsgs_t h, ramd_vec_t rhs, ramd_vec_t x)
 {
-    if(!h || !rhs || !x || rhs == x)
+    return ramd_mcsgs_apply_kind(h, RAMD_MC_SGS, rhs, x);
+}
+
+int ramd_mcsgs_apply_kind(ramd_mcsgs_t h, int kind, ramd_vec_t rhs, ramd_vec_t x)
+{
+    if(!h || !rhs || !x || rhs == x || kind < RAMD_MC_SGS || kind > RAMD_MC_ILU)
         RAMD_FAIL(RAMD_ERR_ARG, "mcsgs_apply: bad arguments");
     McsgsPlan& P = h->plan;
     if(rhs->dtype != P.dtype || x->dtype != P.dtype || rhs->n != P.n || x->n != P.n)
@@ -396,8 +424,8 @@ int ramd_mcsgs_apply(ramd_mcsgs_t h, ramd_vec_t rhs, ramd_vec_t x)
     if(P.n == 0)
         return RAMD_OK;
     if(P.dtype == RAMD_F64)
-        return mc_apply<double>(&P, (const double*)rhs->d, (double*)x->d);
-    return mc_apply<float>(&P, (const float*)rhs->d, (float*)x->d);
+        return mc_apply<double>(&P, kind, (const double*)rhs->d, (double*)x->d);
+    return mc_apply<float>(&P, kind, (const float*)rhs->d, (float*)x->d);
 }
 
 int ramd_mcsgs_destroy(ramd_mcsgs_t h)

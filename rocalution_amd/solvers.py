@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import capi
-from .capi import PC_ILU0, PC_JACOBI, PC_MCSGS, PC_NONE, SOLVER_BICGSTAB, SOLVER_CG, SOLVER_GMRES
+from .capi import PC_ILU0, PC_JACOBI, PC_MCGS, PC_MCILU, PC_MCSGS, PC_NONE, SOLVER_BICGSTAB, SOLVER_CG, SOLVER_GMRES
 
 
 def _lib():
@@ -53,6 +53,20 @@ class MultiColoredSGS(_Precond):
 
     def SetFusedSweeps(self, on):
         self.fused_sweeps = bool(on)
+
+
+class MultiColoredGS(MultiColoredSGS):
+    """backward colour sweeps only (preconditioner_multicolored_gs.cpp:218-288)"""
+    kind = PC_MCGS
+
+
+class MultiColoredILU(MultiColoredSGS):
+    """ILU(0,1) of the multi-coloured matrix (preconditioner_multicolored_ilu.cpp); p > 0 is not provided"""
+    kind = PC_MCILU
+
+    def Set(self, p, q=None, level=True):
+        if p != 0 or (q is not None and q != 1):
+            raise ValueError("only MultiColoredILU(0,1) is provided by this backend")
 
 
 class _IterativeLinearSolver:

@@ -45,7 +45,8 @@ def _inputs(name, g):
 
 def _mk(S, tag, dtype=np.float64):
     solver = {"cg": S.CG, "gmres": S.GMRES, "bicgstab": S.BiCGStab}[tag.split("_")[0]](dtype)
-    pc = {"none": None, "jacobi": S.Jacobi, "ilu0": S.ILU, "mcsgs": S.MultiColoredSGS}[tag.split("_")[1]]
+    pc = {"none": None, "jacobi": S.Jacobi, "ilu0": S.ILU, "mcsgs": S.MultiColoredSGS, "mcgs": S.MultiColoredGS,
+          "mcilu": S.MultiColoredILU}[tag.split("_")[1]]
     if pc is not None:
         solver.SetPreconditioner(pc())
     return solver
@@ -61,13 +62,15 @@ def test_mcsgs_block_form_bit_exact(ra, S, name):
     A = ra.LocalMatrix(); A.SetDataPtrCSR(g["rowptr"], g["col"], g["val"])
     n = A.GetM()
     x = ra.LocalVector(data=g["x"])
-    for fused in (True, False):
-        pc = S.MultiColoredSGS(); pc.SetFusedSweeps(fused)
-        ls = S.BiCGStab(); ls.SetOperator(A); ls.SetPreconditioner(pc); ls.Build()
-        z = ra.LocalVector(); z.Allocate("", n)
-        ls.PrecondApply(x, z)
-        eq(z.numpy(), g["pc_mcsgs"])
-        ls.Clear()
+    for cls, key in ((S.MultiColoredSGS, "pc_mcsgs"), (S.MultiColoredGS, "pc_mcgs"), (S.MultiColoredILU, "pc_mcilu")):
+        for fused in (True, False):
+            pc = cls(); pc.SetFusedSweeps(fused)
+            ls = S.BiCGStab(); ls.SetOperator(A); ls.SetPreconditioner(pc); ls.Build()
+            z = ra.LocalVector(); z.Allocate("", n)
+            ls.PrecondApply(x, z)
+            eq(z.numpy(), g[key])
+            assert ls.GetNumColors() == int(g["mc_num_colors"][0])
+            ls.Clear()
 
 
 @pytest.mark.parametrize("name", PC_CASES)
@@ -86,7 +89,8 @@ def test_preconditioner_apply_bit_exact(ra, S, name):
         ls.Clear()
 
 
-SOLVER_TAGS = ["cg_none", "cg_jacobi", "gmres_none", "gmres_ilu0", "bicgstab_none", "bicgstab_mcsgs"]
+SOLVER_TAGS = ["cg_none", "cg_jacobi", "gmres_none", "gmres_ilu0", "bicgstab_none", "bicgstab_mcsgs", "bicgstab_mcgs",
+               "gmres_mcilu"]
 SOLVER_CASES = ["gr3030", "poisson8", "lap2d7", "poisson16", "poisson32"]
 
 
@@ -263,3 +267,21 @@ def test_mcsgs_without_decomposition(ra, S, oracle, name):
     rhs = ra.LocalVector(data=g["rhs_ones"]); sol = ra.LocalVector(); sol.Allocate("", n)
     ls.Solve(rhs, sol)
     assert abs(ls.GetIterationCount() - int(g["bicgstab_mcsgs_meta"][0])) <= 2
+
+
+@pytest.mark.parametrize("name", ["gr3030", "poisson8"])
+def test_mcilu_without_decomposition(ra, S, name):
+    """MultiColoredILU with SetDecomposition(false): LUSolve on the factored permuted matrix
+    (preconditioner_multicolored_ilu.cpp:235-243) -- same operator as the colour sweeps"""
+    g = load_golden(name)
+    A = ra.LocalMatrix(); A.SetDataPtrCSR(g["rowptr"], g["col"], g["val"])
+    n = A.GetM()
+    x = ra.LocalVector(data=g["x"])
+    pc = S.MultiColoredILU(); pc.SetDecomposition(False)
+    ls = S.GMRES(); ls.SetOperator(A); ls.SetPreconditioner(pc); ls.SetBasisSize(int(g["basis"][0])); ls.Build()
+    z = ra.LocalVector(); z.Allocate("", n)
+    ls.PrecondApply(x, z)
+    assert np.allclose(z.numpy(), g["pc_mcilu"], rtol=1e-12, atol=1e-13)
+    rhs = ra.LocalVector(data=g["rhs_ones"]); sol = ra.LocalVector(); sol.Allocate("", n)
+    ls.Solve(rhs, sol)
+    assert abs(ls.GetIterationCount() - int(g["gmres_mcilu_meta"][0])) <= 2

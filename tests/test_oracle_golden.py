@@ -137,6 +137,8 @@ def test_preconditioner_apply(oracle, name):
     eq(oracle.precond_apply(oracle.PC_JACOBI, rp, ci, va, x), g["pc_jacobi"])
     eq(oracle.precond_apply(oracle.PC_ILU0, rp, ci, va, x), g["pc_ilu0"])
     eq(oracle.precond_apply(oracle.PC_MCSGS, rp, ci, va, x), g["pc_mcsgs"])
+    eq(oracle.precond_apply(oracle.PC_MCGS, rp, ci, va, x), g["pc_mcgs"])
+    eq(oracle.precond_apply(oracle.PC_MCILU, rp, ci, va, x), g["pc_mcilu"])
 
 
 SOLVER_TABLE = {
@@ -150,6 +152,8 @@ SOLVER_TABLE = {
     "bicgstab_mcsgs": ("BICGSTAB", "PC_MCSGS", "CSR", {}),
     "bicgstab_mcsgs_ell": ("BICGSTAB", "PC_MCSGS", "ELL", {}),
     "cg_jacobi_hyb": ("CG", "PC_JACOBI", "HYB", {}),
+    "bicgstab_mcgs": ("BICGSTAB", "PC_MCGS", "CSR", {}),
+    "gmres_mcilu": ("GMRES", "PC_MCILU", "CSR", {}),
 }
 
 
