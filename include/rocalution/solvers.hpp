@@ -1262,8 +1262,10 @@ class GMRES : public IterativeLinearSolver<OperatorType, VectorType, ValueType>
 {
 public:
     GMRES()
-        : size_basis_(30) // gmres.cpp:50
+        : flexible_(false)
+        , size_basis_(30) // gmres.cpp:50
         , v_(NULL)
+        , zb_(NULL)
     {
     }
     virtual ~GMRES()
@@ -1272,8 +1274,9 @@ public:
     }
     virtual void Print(void) const
     {
-        LOG_INFO("GMRES(" << this->size_basis_ << ") solver"
-                          << (this->precond_ ? ", with preconditioner" : " (non-precond)"));
+        LOG_INFO((this->flexible_ ? "FGMRES(" : "GMRES(")
+                 << this->size_basis_ << ") solver"
+                 << (this->precond_ ? ", with preconditioner" : " (non-precond)"));
     }
     virtual void SetBasisSize(int size_basis)
     {
@@ -1301,8 +1304,21 @@ public:
         }
         if(this->precond_ != NULL)
         {
-            this->z_.CloneBackend(*this->op_);
-            this->z_.Allocate("z", this->op_->GetM());
+            if(this->flexible_) // fgmres.cpp:139-150: one z per basis vector
+            {
+                this->zb_ = new VectorType*[m + 1];
+                for(int i = 0; i < m + 1; ++i)
+                {
+                    this->zb_[i] = new VectorType;
+                    this->zb_[i]->CloneBackend(*this->op_);
+                    this->zb_[i]->Allocate("z", this->op_->GetM());
+                }
+            }
+            else
+            {
+                this->z_.CloneBackend(*this->op_);
+                this->z_.Allocate("z", this->op_->GetM());
+            }
             this->precond_->SetOperator(*this->op_);
             this->precond_->Build();
         }
@@ -1317,9 +1333,15 @@ public:
                 this->precond_ = NULL;
             }
             for(int i = 0; i < this->size_basis_ + 1; ++i)
+            {
                 delete this->v_[i];
+                if(this->zb_ != NULL)
+                    delete this->zb_[i];
+            }
             delete[] this->v_;
-            this->v_ = NULL;
+            delete[] this->zb_;
+            this->v_  = NULL;
+            this->zb_ = NULL;
             this->z_.Clear();
             this->iter_ctrl_.Clear();
             this->build_ = false;
@@ -1329,12 +1351,13 @@ public:
 protected:
     virtual void PrintStart_(void) const
     {
-        LOG_INFO("GMRES(" << this->size_basis_ << ") " << (this->precond_ ? "" : "(non-precond) ")
-                          << "linear solver starts");
+        LOG_INFO((this->flexible_ ? "FGMRES(" : "GMRES(")
+                 << this->size_basis_ << ") " << (this->precond_ ? "" : "(non-precond) ")
+                 << "linear solver starts");
     }
     virtual void PrintEnd_(void) const
     {
-        LOG_INFO("GMRES(" << this->size_basis_ << ") ends");
+        LOG_INFO((this->flexible_ ? "FGMRES(" : "GMRES(") << this->size_basis_ << ") ends");
     }
     virtual void SolveNonPrecond_(const VectorType& rhs, VectorType* x)
     {
@@ -1387,7 +1410,7 @@ private:
     void Residual_(const VectorType& rhs, VectorType* x, bool precond)
     {
         const ValueType one = static_cast<ValueType>(1);
-        if(precond)
+        if(precond && !this->flexible_)
         {
             this->op_->Apply(*x, &this->z_);
             this->z_.ScaleAdd(-one, rhs);
@@ -1405,7 +1428,12 @@ private:
         VectorType**    v   = this->v_;
         ValueType*      H   = this->H_.data();
         const ValueType one = static_cast<ValueType>(1);
-        if(precond)
+        if(precond && this->flexible_) // fgmres.cpp:462-466: M z_i = v_i ; v_i+1 = A z_i
+        {
+            this->precond_->SolveZeroSol(*v[i], this->zb_[i]);
+            this->op_->Apply(*this->zb_[i], v[i + 1]);
+        }
+        else if(precond)
         {
             this->op_->Apply(*v[i], &this->z_);
             this->precond_->SolveZeroSol(this->z_, v[i + 1]);
@@ -1492,9 +1520,10 @@ private:
                 for(int k = 0; k < j; ++k)
                     r[k] -= H[this->hidx_(k, j)] * r[j];
             }
-            x->AddScale(*v[0], r[0]);
+            VectorType** upd = (precond && this->flexible_) ? this->zb_ : v; // fgmres.cpp:527-532
+            x->AddScale(*upd[0], r[0]);
             for(int j = 1; j < i; ++j)
-                x->AddScale(*v[j], r[j]);
+                x->AddScale(*upd[j], r[j]);
             this->Residual_(rhs, x, precond);
             std::fill(this->r_.begin(), this->r_.end(), ValueType(0));
             r[0] = this->Norm_(*v[0]);
@@ -1503,10 +1532,32 @@ private:
         }
     }
 
+protected:
+    bool flexible_; // FGMRES: right preconditioning with a stored z_i per basis vector
+
+private:
     int                    size_basis_;
     VectorType**           v_;
+    VectorType**           zb_;
     VectorType             z_;
     std::vector<ValueType> c_, s_, r_, H_;
+};
+
+// fgmres.cpp: flexible GMRES -- same Arnoldi/Givens machinery as GMRES (it is the same code in the
+// reference), right-preconditioned: z_i = M^-1 v_i is kept for the solution update, the residual is
+// the true one
+template <class OperatorType, class VectorType, typename ValueType>
+class FGMRES : public GMRES<OperatorType, VectorType, ValueType>
+{
+public:
+    FGMRES()
+    {
+        this->flexible_ = true;
+    }
+    virtual ~FGMRES()
+    {
+        this->Clear();
+    }
 };
 
 // ============================================================================ BiCGStab
@@ -1645,6 +1696,649 @@ private:
         }
     }
     VectorType r_, r0_, p_, q_, t_, v_, z_;
+};
+
+// ============================================================================ FCG
+// src/solvers/krylov/fcg.cpp:232-318 / :321-420 (flexible CG).  InitResidual's verdict is not consulted.
+template <class OperatorType, class VectorType, typename ValueType>
+class FCG : public IterativeLinearSolver<OperatorType, VectorType, ValueType>
+{
+public:
+    virtual ~FCG()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO((this->precond_ ? "Flexible PCG solver, with preconditioner" : "Flexible CG (non-precond) solver"));
+    }
+    virtual void Build(void)
+    {
+        if(this->build_)
+            this->Clear();
+        assert(this->op_ != NULL && this->op_->GetM() == this->op_->GetN() && this->op_->GetM() > 0);
+        this->build_ = true;
+        if(this->precond_ != NULL)
+        {
+            this->precond_->SetOperator(*this->op_);
+            this->precond_->Build();
+            this->z_.CloneBackend(*this->op_);
+            this->z_.Allocate("z", this->op_->GetM());
+        }
+        VectorType* all[] = {&this->r_, &this->w_, &this->p_, &this->q_};
+        for(VectorType* vec : all)
+        {
+            vec->CloneBackend(*this->op_);
+            vec->Allocate("fcg", this->op_->GetM());
+        }
+    }
+    virtual void Clear(void)
+    {
+        if(this->build_)
+        {
+            if(this->precond_ != NULL)
+            {
+                this->precond_->Clear();
+                this->precond_ = NULL;
+            }
+            VectorType* all[] = {&this->r_, &this->w_, &this->p_, &this->q_, &this->z_};
+            for(VectorType* vec : all)
+                vec->Clear();
+            this->iter_ctrl_.Clear();
+            this->build_ = false;
+        }
+    }
+
+protected:
+    virtual void PrintStart_(void) const
+    {
+        LOG_INFO((this->precond_ ? "Flexible PCG solver starts, with preconditioner:" : "Flexible CG (non-precond) linear solver starts"));
+    }
+    virtual void PrintEnd_(void) const
+    {
+        LOG_INFO((this->precond_ ? "Flexible PCG ends" : "Flexible CG (non-precond) ends"));
+    }
+    virtual void SolveNonPrecond_(const VectorType& rhs, VectorType* x)
+    {
+        this->Solve_(rhs, x, false);
+    }
+    virtual void SolvePrecond_(const VectorType& rhs, VectorType* x)
+    {
+        this->Solve_(rhs, x, true);
+    }
+
+private:
+    void Solve_(const VectorType& rhs, VectorType* x, bool precond)
+    {
+        const OperatorType* op = this->op_;
+        VectorType *r = &this->r_, *w = &this->w_, *p = &this->p_, *q = &this->q_;
+        VectorType* z = precond ? &this->z_ : r; // without a preconditioner z IS r
+        ValueType   alpha, beta, rho, gamma, gamma_rho;
+        op->Apply(*x, r);
+        r->ScaleAdd(static_cast<ValueType>(-1), rhs);
+        ValueType res = this->Norm_(*r);
+        this->iter_ctrl_.InitResidual(std::abs(res));
+        if(precond)
+            this->precond_->SolveZeroSol(*r, z);
+        op->Apply(*z, w);
+        alpha = z->Dot(*r);
+        beta  = z->Dot(*w);
+        p->CopyFrom(*z);
+        q->CopyFrom(*w);
+        rho = beta;
+        x->AddScale(*p, alpha / rho);
+        r->AddScale(*q, -alpha / rho);
+        res = this->Norm_(*r);
+        while(!this->iter_ctrl_.CheckResidual(std::abs(res), this->index_))
+        {
+            if(precond)
+                this->precond_->SolveZeroSol(*r, z);
+            op->Apply(*z, w);
+            beta      = z->Dot(*w);
+            gamma     = z->Dot(*q);
+            gamma_rho = -gamma / rho;
+            p->ScaleAdd(gamma_rho, *z);
+            q->ScaleAdd(gamma_rho, *w);
+            rho   = beta + gamma * gamma_rho;
+            alpha = z->Dot(*r) / rho;
+            x->AddScale(*p, alpha);
+            r->AddScale(*q, -alpha);
+            res = this->Norm_(*r);
+        }
+    }
+    VectorType r_, w_, z_, p_, q_;
+};
+
+// ============================================================================ CR
+// src/solvers/krylov/cr.cpp:240-318 / :321-430 (conjugate residual; the preconditioned variant tests
+// convergence on t, the unpreconditioned residual)
+template <class OperatorType, class VectorType, typename ValueType>
+class CR : public IterativeLinearSolver<OperatorType, VectorType, ValueType>
+{
+public:
+    virtual ~CR()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO((this->precond_ ? "PCR solver, with preconditioner" : "CR (non-precond) solver"));
+    }
+    virtual void Build(void)
+    {
+        if(this->build_)
+            this->Clear();
+        assert(this->op_ != NULL && this->op_->GetM() == this->op_->GetN() && this->op_->GetM() > 0);
+        this->build_ = true;
+        if(this->precond_ != NULL)
+        {
+            this->precond_->SetOperator(*this->op_);
+            this->precond_->Build();
+            this->z_.CloneBackend(*this->op_);
+            this->z_.Allocate("z", this->op_->GetM());
+            this->t_.CloneBackend(*this->op_);
+            this->t_.Allocate("t", this->op_->GetM());
+        }
+        VectorType* all[] = {&this->r_, &this->p_, &this->q_, &this->v_};
+        for(VectorType* vec : all)
+        {
+            vec->CloneBackend(*this->op_);
+            vec->Allocate("cr", this->op_->GetM());
+        }
+    }
+    virtual void Clear(void)
+    {
+        if(this->build_)
+        {
+            if(this->precond_ != NULL)
+            {
+                this->precond_->Clear();
+                this->precond_ = NULL;
+            }
+            VectorType* all[] = {&this->r_, &this->p_, &this->q_, &this->v_, &this->z_, &this->t_};
+            for(VectorType* vec : all)
+                vec->Clear();
+            this->iter_ctrl_.Clear();
+            this->build_ = false;
+        }
+    }
+
+protected:
+    virtual void PrintStart_(void) const
+    {
+        LOG_INFO((this->precond_ ? "PCR solver starts, with preconditioner:" : "CR (non-precond) linear solver starts"));
+    }
+    virtual void PrintEnd_(void) const
+    {
+        LOG_INFO((this->precond_ ? "PCR ends" : "CR (non-precond) ends"));
+    }
+    virtual void SolveNonPrecond_(const VectorType& rhs, VectorType* x)
+    {
+        const OperatorType* op = this->op_;
+        VectorType *r = &this->r_, *p = &this->p_, *q = &this->q_, *v = &this->v_;
+        ValueType   alpha, beta, rho, rho_old;
+        op->Apply(*x, r);
+        r->ScaleAdd(static_cast<ValueType>(-1), rhs);
+        p->CopyFrom(*r);
+        ValueType res_norm = this->Norm_(*r);
+        if(this->iter_ctrl_.InitResidual(std::abs(res_norm)) == false)
+            return;
+        op->Apply(*r, v);
+        rho = r->DotNonConj(*v);
+        op->Apply(*p, q);
+        alpha = rho / q->DotNonConj(*q);
+        x->AddScale(*p, alpha);
+        r->AddScale(*q, -alpha);
+        res_norm = this->Norm_(*r);
+        while(!this->iter_ctrl_.CheckResidual(std::abs(res_norm), this->index_))
+        {
+            rho_old = rho;
+            op->Apply(*r, v);
+            rho  = r->DotNonConj(*v);
+            beta = rho / rho_old;
+            p->ScaleAdd(beta, *r);
+            q->ScaleAdd(beta, *v);
+            alpha = rho / q->DotNonConj(*q);
+            x->AddScale(*p, alpha);
+            r->AddScale(*q, -alpha);
+            res_norm = this->Norm_(*r);
+        }
+    }
+    virtual void SolvePrecond_(const VectorType& rhs, VectorType* x)
+    {
+        const OperatorType* op = this->op_;
+        VectorType *r = &this->r_, *z = &this->z_, *p = &this->p_, *q = &this->q_, *v = &this->v_, *t = &this->t_;
+        ValueType   alpha, beta, rho, rho_old;
+        op->Apply(*x, z);
+        z->ScaleAdd(static_cast<ValueType>(-1), rhs);
+        this->precond_->SolveZeroSol(*z, r);
+        p->CopyFrom(*r);
+        t->CopyFrom(*z);
+        ValueType res_norm = this->Norm_(*t);
+        if(this->iter_ctrl_.InitResidual(std::abs(res_norm)) == false)
+            return;
+        op->Apply(*r, v);
+        rho = r->DotNonConj(*v);
+        op->Apply(*p, q);
+        this->precond_->SolveZeroSol(*q, z);
+        alpha = rho / q->DotNonConj(*z);
+        x->AddScale(*p, alpha);
+        r->AddScale(*z, -alpha);
+        t->AddScale(*q, -alpha);
+        res_norm = this->Norm_(*t);
+        while(!this->iter_ctrl_.CheckResidual(std::abs(res_norm), this->index_))
+        {
+            rho_old = rho;
+            op->Apply(*r, v);
+            rho  = r->DotNonConj(*v);
+            beta = rho / rho_old;
+            p->ScaleAdd(beta, *r);
+            q->ScaleAdd(beta, *v);
+            this->precond_->SolveZeroSol(*q, z);
+            alpha = rho / q->DotNonConj(*z);
+            x->AddScale(*p, alpha);
+            r->AddScale(*z, -alpha);
+            t->AddScale(*q, -alpha);
+            res_norm = this->Norm_(*t);
+        }
+    }
+
+private:
+    VectorType r_, z_, p_, q_, v_, t_;
+};
+
+// ============================================================================ BiCGStab(l)
+// src/solvers/krylov/bicgstabl.cpp:292-496 / :499-695.  l = 2 by default (SetOrder).  The
+// preconditioned variant applies M^-1 after every operator product (left preconditioning) and tests
+// the preconditioned residual.  One "iteration" is one outer sweep (l BiCG steps + the MR part).
+template <class OperatorType, class VectorType, typename ValueType>
+class BiCGStabl : public IterativeLinearSolver<OperatorType, VectorType, ValueType>
+{
+public:
+    BiCGStabl()
+        : l_(2)
+        , r_(NULL)
+        , u_(NULL)
+    {
+    }
+    virtual ~BiCGStabl()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("BiCGStab(" << this->l_ << ") solver" << (this->precond_ ? ", with preconditioner" : " (non-precond)"));
+    }
+    virtual void SetOrder(int l)
+    {
+        assert(l > 0 && this->build_ == false);
+        this->l_ = l;
+    }
+    virtual void Build(void)
+    {
+        if(this->build_)
+            this->Clear();
+        assert(this->op_ != NULL && this->op_->GetM() == this->op_->GetN() && this->op_->GetM() > 0);
+        this->build_ = true;
+        if(this->precond_ != NULL)
+        {
+            this->precond_->SetOperator(*this->op_);
+            this->precond_->Build();
+            this->z_.CloneBackend(*this->op_);
+            this->z_.Allocate("z", this->op_->GetM());
+        }
+        this->r0_.CloneBackend(*this->op_);
+        this->r0_.Allocate("r0", this->op_->GetM());
+        const int l = this->l_;
+        this->r_    = new VectorType*[l + 1];
+        this->u_    = new VectorType*[l + 1];
+        for(int i = 0; i < l + 1; ++i)
+        {
+            this->r_[i] = new VectorType;
+            this->r_[i]->CloneBackend(*this->op_);
+            this->r_[i]->Allocate("r", this->op_->GetM());
+            this->u_[i] = new VectorType;
+            this->u_[i]->CloneBackend(*this->op_);
+            this->u_[i]->Allocate("u", this->op_->GetM());
+        }
+        this->gamma0_.assign((size_t)l, ValueType(0));
+        this->gamma1_.assign((size_t)l, ValueType(0));
+        this->gamma2_.assign((size_t)l, ValueType(0));
+        this->sigma_.assign((size_t)l, ValueType(0));
+        this->tau_.assign((size_t)l * l, ValueType(0));
+    }
+    virtual void Clear(void)
+    {
+        if(this->build_)
+        {
+            this->r0_.Clear();
+            for(int i = 0; i < this->l_ + 1; ++i)
+            {
+                delete this->r_[i];
+                delete this->u_[i];
+            }
+            delete[] this->r_;
+            delete[] this->u_;
+            this->r_ = this->u_ = NULL;
+            if(this->precond_ != NULL)
+            {
+                this->precond_->Clear();
+                this->precond_ = NULL;
+                this->z_.Clear();
+            }
+            this->iter_ctrl_.Clear();
+            this->build_ = false;
+        }
+    }
+
+protected:
+    virtual void PrintStart_(void) const
+    {
+        LOG_INFO("BiCGStab(" << this->l_ << ") " << (this->precond_ ? "" : "(non-precond) ") << "linear solver starts");
+    }
+    virtual void PrintEnd_(void) const
+    {
+        LOG_INFO("BiCGStab(" << this->l_ << ") ends");
+    }
+    virtual void SolveNonPrecond_(const VectorType& rhs, VectorType* x)
+    {
+        this->Solve_(rhs, x, false);
+    }
+    virtual void SolvePrecond_(const VectorType& rhs, VectorType* x)
+    {
+        this->Solve_(rhs, x, true);
+    }
+
+private:
+    // y = A in  (followed by M^-1 when preconditioned)
+    void ApplyPrec_(const VectorType& in, VectorType* out, bool precond)
+    {
+        if(precond)
+        {
+            this->op_->Apply(in, &this->z_);
+            this->precond_->SolveZeroSol(this->z_, out);
+        }
+        else
+            this->op_->Apply(in, out);
+    }
+    void Solve_(const VectorType& rhs, VectorType* x, bool precond)
+    {
+        VectorType*  r0 = &this->r0_;
+        VectorType** r  = this->r_;
+        VectorType** u  = this->u_;
+        const int    l  = this->l_;
+        bool         converged = false;
+        ValueType    alpha = static_cast<ValueType>(0), beta = static_cast<ValueType>(0);
+        ValueType    omega = static_cast<ValueType>(1), rho_old = static_cast<ValueType>(-1), rho;
+        ValueType *  gamma0 = this->gamma0_.data(), *gamma1 = this->gamma1_.data();
+        ValueType *  gamma2 = this->gamma2_.data(), *sigma = this->sigma_.data(), *tau = this->tau_.data();
+        const ValueType zero = static_cast<ValueType>(0);
+        if(precond)
+        {
+            this->op_->Apply(*x, &this->z_);
+            this->z_.ScaleAdd(static_cast<ValueType>(-1), rhs);
+            this->precond_->SolveZeroSol(this->z_, r0);
+        }
+        else
+        {
+            this->op_->Apply(*x, r0);
+            r0->ScaleAdd(static_cast<ValueType>(-1), rhs);
+        }
+        ValueType res = this->Norm_(*r0);
+        this->iter_ctrl_.InitResidual(std::abs(res));
+        r[0]->CopyFrom(*r0);
+        u[0]->Zeros();
+        while(true)
+        {
+            rho_old *= -omega;
+            for(int j = 0; j < l; ++j) // BiCG part
+            {
+                rho = r0->Dot(*r[j]);
+                if(rho == zero)
+                {
+                    LOG_INFO("BiCGStab(l) rho == 0 !!!");
+                    converged = true;
+                    break;
+                }
+                beta = alpha * rho / rho_old;
+                for(int i = 0; i <= j; ++i)
+                    u[i]->ScaleAdd(-beta, *r[i]);
+                this->ApplyPrec_(*u[j], u[j + 1], precond);
+                rho_old = r0->Dot(*u[j + 1]);
+                if(rho_old == zero)
+                {
+                    LOG_INFO("BiCGStab(l) sigma == 0 !!!");
+                    converged = true;
+                    break;
+                }
+                alpha   = rho / rho_old;
+                rho_old = rho;
+                for(int i = 0; i <= j; ++i)
+                    r[i]->AddScale(*u[i + 1], -alpha);
+                this->ApplyPrec_(*r[j], r[j + 1], precond);
+                x->AddScale(*u[0], alpha);
+                res = this->Norm_(*r[0]);
+                if(this->iter_ctrl_.CheckResidualNoCount(std::abs(res)))
+                {
+                    converged = true;
+                    break;
+                }
+            }
+            if(converged)
+                break;
+            for(int j = 0; j < l; ++j) // modified Gram-Schmidt (MR part)
+            {
+                for(int i = 0; i < j; ++i)
+                {
+                    tau[i * l + j] = r[j + 1]->Dot(*r[i + 1]) / sigma[i];
+                    r[j + 1]->AddScale(*r[i + 1], -tau[i * l + j]);
+                }
+                sigma[j]  = r[j + 1]->Dot(*r[j + 1]);
+                gamma1[j] = r[0]->Dot(*r[j + 1]) / sigma[j];
+            }
+            gamma0[l - 1] = gamma1[l - 1];
+            omega         = gamma1[l - 1];
+            for(int j = l - 2; j >= 0; --j)
+            {
+                gamma0[j] = gamma1[j];
+                for(int i = j + 1; i < l; ++i)
+                    gamma0[j] -= tau[j * l + i] * gamma0[i];
+            }
+            for(int j = 0; j < l - 1; ++j)
+            {
+                gamma2[j] = gamma0[j + 1];
+                for(int i = j + 1; i < l - 1; ++i)
+                    gamma2[j] += tau[j * l + i] * gamma0[i + 1];
+            }
+            x->AddScale(*r[0], gamma0[0]);
+            r[0]->AddScale(*r[l], -gamma1[l - 1]);
+            u[0]->AddScale(*u[l], -gamma0[l - 1]);
+            for(int j = 1; j < l; ++j)
+            {
+                u[0]->AddScale(*u[j], -gamma0[j - 1]);
+                x->AddScale(*r[j], gamma2[j - 1]);
+                r[0]->AddScale(*r[j], -gamma1[j - 1]);
+            }
+            res = this->Norm_(*r[0]);
+            if(this->iter_ctrl_.CheckResidual(std::abs(res), this->index_))
+                break;
+        }
+    }
+    int                    l_;
+    VectorType             r0_, z_;
+    VectorType**           r_;
+    VectorType**           u_;
+    std::vector<ValueType> gamma0_, gamma1_, gamma2_, sigma_, tau_;
+};
+
+// ============================================================================ QMRCGStab
+// src/solvers/krylov/qmrcgstab.cpp:262-460 / :463-690.  The iteration control sees the bound
+// sqrt(#iter+1)*|tau|; after the loop the TRUE residual is computed and checked once more (one more
+// counted iteration).  p is only zero-filled by Build(), as in the reference.
+template <class OperatorType, class VectorType, typename ValueType>
+class QMRCGStab : public IterativeLinearSolver<OperatorType, VectorType, ValueType>
+{
+public:
+    virtual ~QMRCGStab()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("QMRCGStab solver" << (this->precond_ ? ", with preconditioner" : " (non-precond)"));
+    }
+    virtual void Build(void)
+    {
+        if(this->build_)
+            this->Clear();
+        assert(this->op_ != NULL && this->op_->GetM() == this->op_->GetN() && this->op_->GetM() > 0);
+        this->build_ = true;
+        if(this->precond_ != NULL)
+        {
+            this->precond_->SetOperator(*this->op_);
+            this->precond_->Build();
+            this->z_.CloneBackend(*this->op_);
+            this->z_.Allocate("z", this->op_->GetM());
+        }
+        VectorType* all[] = {&this->r0_, &this->r_, &this->p_, &this->t_, &this->v_, &this->d_};
+        for(VectorType* vec : all)
+        {
+            vec->CloneBackend(*this->op_);
+            vec->Allocate("qmrcgstab", this->op_->GetM());
+        }
+    }
+    virtual void Clear(void)
+    {
+        if(this->build_)
+        {
+            if(this->precond_ != NULL)
+            {
+                this->precond_->Clear();
+                this->precond_ = NULL;
+            }
+            VectorType* all[] = {&this->r0_, &this->r_, &this->p_, &this->t_, &this->v_, &this->d_, &this->z_};
+            for(VectorType* vec : all)
+                vec->Clear();
+            this->iter_ctrl_.Clear();
+            this->build_ = false;
+        }
+    }
+
+protected:
+    virtual void PrintStart_(void) const
+    {
+        LOG_INFO("QMRCGStab " << (this->precond_ ? "" : "(non-precond) ") << "linear solver starts");
+    }
+    virtual void PrintEnd_(void) const
+    {
+        LOG_INFO("QMRCGStab ends");
+    }
+    virtual void SolveNonPrecond_(const VectorType& rhs, VectorType* x)
+    {
+        this->Solve_(rhs, x, false);
+    }
+    virtual void SolvePrecond_(const VectorType& rhs, VectorType* x)
+    {
+        this->Solve_(rhs, x, true);
+    }
+
+private:
+    void Solve_(const VectorType& rhs, VectorType* x, bool precond)
+    {
+        const OperatorType* op = this->op_;
+        VectorType *r0 = &this->r0_, *r = &this->r_, *p = &this->p_, *t = &this->t_, *v = &this->v_, *d = &this->d_;
+        VectorType* z = &this->z_;
+        VectorType* pz = precond ? z : p; // what A is applied to in the first half step
+        VectorType* rz = precond ? z : r; // ... and in the second
+        const ValueType one = static_cast<ValueType>(1), zero = static_cast<ValueType>(0);
+        ValueType alpha, beta, omega, theta1, theta1sq, theta2, theta2sq, eta1, eta2, tau1, tau2, rho, rho_old, c;
+        op->Apply(*x, r0);
+        r0->ScaleAdd(-one, rhs);
+        r->CopyFrom(*r0);
+        tau2            = this->Norm_(*r0);
+        double res_norm = std::abs(tau2);
+        this->iter_ctrl_.InitResidual(res_norm);
+        rho  = r0->Dot(*r);
+        beta = rho;
+        (void)beta;
+        p->AddScale(*r, one);
+        if(precond)
+            this->precond_->SolveZeroSol(*p, z);
+        op->Apply(*pz, v);
+        rho_old = r0->Dot(*v);
+        alpha   = rho / rho_old;
+        r->AddScale(*v, -alpha);
+        theta1   = this->Norm_(*r) / tau2;
+        theta1sq = theta1 * theta1;
+        c        = one / std::sqrt(one + theta1sq);
+        tau1     = tau2 * theta1 * c;
+        eta1     = c * c * alpha;
+        d->CopyFrom(*pz);
+        x->AddScale(*d, eta1);
+        if(precond)
+            this->precond_->SolveZeroSol(*r, z);
+        op->Apply(*rz, t);
+        omega = t->Dot(*r) / t->Dot(*t);
+        d->ScaleAdd(theta1sq * eta1 / omega, *rz);
+        r->AddScale(*t, -omega);
+        theta2   = this->Norm_(*r) / tau1;
+        theta2sq = theta2 * theta2;
+        c        = one / std::sqrt(one + theta2sq);
+        tau2     = tau1 * theta2 * c;
+        eta2     = c * c * omega;
+        x->AddScale(*d, eta2);
+        res_norm = std::sqrt(static_cast<double>(this->iter_ctrl_.GetIterationCount() + 1)) * std::abs(tau2);
+        while(!this->iter_ctrl_.CheckResidual(res_norm, this->index_))
+        {
+            rho_old = rho;
+            rho     = r0->Dot(*r);
+            beta    = (rho * alpha) / (rho_old * omega);
+            p->AddScale(*v, -omega);
+            p->Scale(beta);
+            p->AddScale(*r, one);
+            if(precond)
+                this->precond_->SolveZeroSol(*p, z);
+            op->Apply(*pz, v);
+            rho_old = r0->Dot(*v);
+            if(rho_old == zero)
+            {
+                LOG_INFO("QMRCGStab break rho_old == 0 !!!");
+                break;
+            }
+            alpha = rho / rho_old;
+            r->AddScale(*v, -alpha);
+            theta1   = this->Norm_(*r) / tau2;
+            theta1sq = theta1 * theta1;
+            c        = one / std::sqrt(one + theta1sq);
+            tau1     = tau2 * theta1 * c;
+            eta1     = c * c * alpha;
+            d->ScaleAdd(theta2sq * eta2 / alpha, *pz);
+            x->AddScale(*d, eta1);
+            if(precond)
+                this->precond_->SolveZeroSol(*r, z);
+            op->Apply(*rz, t);
+            omega = t->Dot(*t);
+            if(omega == zero)
+            {
+                LOG_INFO("QMRCGStab omega == 0 !!!");
+                break;
+            }
+            omega = t->Dot(*r) / omega;
+            d->ScaleAdd(theta1sq * eta1 / omega, *rz);
+            r->AddScale(*t, -omega);
+            theta2   = this->Norm_(*r) / tau1;
+            theta2sq = theta2 * theta2;
+            c        = one / std::sqrt(one + theta2sq);
+            tau2     = tau1 * theta2 * c;
+            eta2     = c * c * omega;
+            x->AddScale(*d, eta2);
+            res_norm = std::sqrt(static_cast<double>(this->iter_ctrl_.GetIterationCount() + 1)) * std::abs(tau2);
+        }
+        op->Apply(*x, r0);
+        r0->ScaleAdd(-one, rhs);
+        this->iter_ctrl_.CheckResidual(std::abs(this->Norm_(*r0)));
+    }
+    VectorType r0_, r_, p_, t_, v_, d_, z_;
 };
 
 // ============================================================================ MixedPrecisionDC

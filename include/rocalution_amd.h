@@ -264,7 +264,11 @@ int ramd_comm_halo_end(ramd_comm_t c);
  * Solve(), src/solvers/solver.hpp:179-444 of the reference) for callers without a C++ compiler
  * (the Python tests and bench.py).  Semantics are those of the C++ classes of the same name. */
 typedef struct ramd_solver_s* ramd_solver_t;
-enum { RAMD_SOLVER_CG = 0, RAMD_SOLVER_GMRES = 1, RAMD_SOLVER_BICGSTAB = 2 };
+enum { RAMD_SOLVER_CG = 0, RAMD_SOLVER_GMRES = 1, RAMD_SOLVER_BICGSTAB = 2,
+       /* src/solvers/krylov/{fcg,cr,fgmres,bicgstabl,qmrcgstab}.cpp; ramd_solver_set_basis sets the
+        * restart length of (F)GMRES and the order l of BiCGStab(l) */
+       RAMD_SOLVER_FCG = 3, RAMD_SOLVER_CR = 4, RAMD_SOLVER_FGMRES = 5, RAMD_SOLVER_BICGSTABL = 6,
+       RAMD_SOLVER_QMRCGSTAB = 7 };
 enum { RAMD_PC_NONE = 0, RAMD_PC_JACOBI = 1, RAMD_PC_ILU0 = 2, RAMD_PC_MCSGS = 3, RAMD_PC_MCGS = 4, RAMD_PC_MCILU = 5 };
 int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out);
 /* MixedPrecisionDC<fp64 outer, fp32 inner>: inner solver/preconditioner kinds */

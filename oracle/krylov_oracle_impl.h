@@ -1120,6 +1120,472 @@ static void SUF(solve_gmres)(const SUF(orc_op) * A, SUF(orc_pc) * P, const T* rh
     free(H);
 }
 
+/* src/solvers/krylov/fcg.cpp:232-318 (no preconditioner) / :321-420 (preconditioned).
+ * The return value of InitResidual is NOT consulted there. */
+static void SUF(solve_fcg)(const SUF(orc_op) * A, SUF(orc_pc) * P, const T* rhs, T* x, orc_iter_ctrl* ic)
+{
+    int n = A->nrow;
+    T*  r = (T*)calloc((size_t)n, sizeof(T));
+    T*  w = (T*)calloc((size_t)n, sizeof(T));
+    T*  z = (T*)calloc((size_t)n, sizeof(T));
+    T*  p = (T*)calloc((size_t)n, sizeof(T));
+    T*  q = (T*)calloc((size_t)n, sizeof(T));
+    T   alpha, beta, rho, gamma, gamma_rho;
+    SUF(residual)(A, rhs, x, r);
+    T res = SUF(orc_norm)(n, r);
+    (void)orc_ic_init_residual(ic, fabs((double)res));
+    const T* zz = r; /* non-precond: z == r */
+    if(P)
+    {
+        SUF(pc_solve)(P, r, z);
+        zz = z;
+    }
+    SUF(op_apply)(A, zz, w);
+    alpha = SUF(orc_dot)(n, zz, r);
+    beta  = SUF(orc_dot)(n, zz, w);
+    memcpy(p, zz, sizeof(T) * (size_t)n);
+    memcpy(q, w, sizeof(T) * (size_t)n);
+    rho = beta;
+    SUF(orc_add_scale)(n, x, p, alpha / rho);
+    SUF(orc_add_scale)(n, r, q, -alpha / rho);
+    res = SUF(orc_norm)(n, r);
+    while(!orc_ic_check_residual(ic, fabs((double)res)))
+    {
+        if(P)
+            SUF(pc_solve)(P, r, z);
+        SUF(op_apply)(A, zz, w);
+        beta      = SUF(orc_dot)(n, zz, w);
+        gamma     = SUF(orc_dot)(n, zz, q);
+        gamma_rho = -gamma / rho;
+        SUF(orc_scale_add)(n, p, gamma_rho, zz);
+        SUF(orc_scale_add)(n, q, gamma_rho, w);
+        rho   = beta + gamma * gamma_rho;
+        alpha = SUF(orc_dot)(n, zz, r) / rho;
+        SUF(orc_add_scale)(n, x, p, alpha);
+        SUF(orc_add_scale)(n, r, q, -alpha);
+        res = SUF(orc_norm)(n, r);
+    }
+    free(r);
+    free(w);
+    free(z);
+    free(p);
+    free(q);
+}
+
+/* src/solvers/krylov/cr.cpp:240-318 (no preconditioner) / :321-430 (preconditioned; the convergence
+ * test runs on t, the unpreconditioned residual) */
+static void SUF(solve_cr)(const SUF(orc_op) * A, SUF(orc_pc) * P, const T* rhs, T* x, orc_iter_ctrl* ic)
+{
+    int n = A->nrow;
+    T*  r = (T*)calloc((size_t)n, sizeof(T));
+    T*  z = (T*)calloc((size_t)n, sizeof(T));
+    T*  p = (T*)calloc((size_t)n, sizeof(T));
+    T*  q = (T*)calloc((size_t)n, sizeof(T));
+    T*  v = (T*)calloc((size_t)n, sizeof(T));
+    T*  t = (T*)calloc((size_t)n, sizeof(T));
+    T   alpha, beta, rho, rho_old, res_norm;
+    if(!P)
+    {
+        SUF(residual)(A, rhs, x, r);
+        memcpy(p, r, sizeof(T) * (size_t)n);
+        res_norm = SUF(orc_norm)(n, r);
+        if(orc_ic_init_residual(ic, fabs((double)res_norm)))
+        {
+            SUF(op_apply)(A, r, v);
+            rho = SUF(orc_dot)(n, r, v);
+            SUF(op_apply)(A, p, q);
+            alpha = rho / SUF(orc_dot)(n, q, q);
+            SUF(orc_add_scale)(n, x, p, alpha);
+            SUF(orc_add_scale)(n, r, q, -alpha);
+            res_norm = SUF(orc_norm)(n, r);
+            while(!orc_ic_check_residual(ic, fabs((double)res_norm)))
+            {
+                rho_old = rho;
+                SUF(op_apply)(A, r, v);
+                rho  = SUF(orc_dot)(n, r, v);
+                beta = rho / rho_old;
+                SUF(orc_scale_add)(n, p, beta, r);
+                SUF(orc_scale_add)(n, q, beta, v);
+                alpha = rho / SUF(orc_dot)(n, q, q);
+                SUF(orc_add_scale)(n, x, p, alpha);
+                SUF(orc_add_scale)(n, r, q, -alpha);
+                res_norm = SUF(orc_norm)(n, r);
+            }
+        }
+    }
+    else
+    {
+        SUF(residual)(A, rhs, x, z);
+        SUF(pc_solve)(P, z, r);
+        memcpy(p, r, sizeof(T) * (size_t)n);
+        memcpy(t, z, sizeof(T) * (size_t)n);
+        res_norm = SUF(orc_norm)(n, t);
+        if(orc_ic_init_residual(ic, fabs((double)res_norm)))
+        {
+            SUF(op_apply)(A, r, v);
+            rho = SUF(orc_dot)(n, r, v);
+            SUF(op_apply)(A, p, q);
+            SUF(pc_solve)(P, q, z);
+            alpha = rho / SUF(orc_dot)(n, q, z);
+            SUF(orc_add_scale)(n, x, p, alpha);
+            SUF(orc_add_scale)(n, r, z, -alpha);
+            SUF(orc_add_scale)(n, t, q, -alpha);
+            res_norm = SUF(orc_norm)(n, t);
+            while(!orc_ic_check_residual(ic, fabs((double)res_norm)))
+            {
+                rho_old = rho;
+                SUF(op_apply)(A, r, v);
+                rho  = SUF(orc_dot)(n, r, v);
+                beta = rho / rho_old;
+                SUF(orc_scale_add)(n, p, beta, r);
+                SUF(orc_scale_add)(n, q, beta, v);
+                SUF(pc_solve)(P, q, z);
+                alpha = rho / SUF(orc_dot)(n, q, z);
+                SUF(orc_add_scale)(n, x, p, alpha);
+                SUF(orc_add_scale)(n, r, z, -alpha);
+                SUF(orc_add_scale)(n, t, q, -alpha);
+                res_norm = SUF(orc_norm)(n, t);
+            }
+        }
+    }
+    free(r);
+    free(z);
+    free(p);
+    free(q);
+    free(v);
+    free(t);
+}
+
+/* src/solvers/krylov/fgmres.cpp:298-419 / :422-548: right-preconditioned GMRES that keeps every
+ * z_i = M^-1 v_i (the residual itself is NOT preconditioned) */
+static void SUF(solve_fgmres)(const SUF(orc_op) * A, SUF(orc_pc) * P, const T* rhs, T* x,
+                              orc_iter_ctrl* ic, int size)
+{
+    int  n = A->nrow;
+    T**  v = (T**)malloc(sizeof(T*) * (size_t)(size + 1));
+    T**  z = (T**)malloc(sizeof(T*) * (size_t)(size + 1));
+    for(int i = 0; i <= size; ++i)
+    {
+        v[i] = (T*)calloc((size_t)n, sizeof(T));
+        z[i] = P ? (T*)calloc((size_t)n, sizeof(T)) : NULL;
+    }
+    T* c = (T*)calloc((size_t)size, sizeof(T));
+    T* s = (T*)calloc((size_t)size, sizeof(T));
+    T* r = (T*)calloc((size_t)size + 1, sizeof(T));
+    T* H = (T*)calloc((size_t)(size + 1) * size, sizeof(T));
+    T  one = (T)1;
+#define HIND(i, j) ((i) + (j) * (size + 1))
+    SUF(residual)(A, rhs, x, v[0]);
+    r[0] = SUF(orc_norm)(n, v[0]);
+    if(orc_ic_init_residual(ic, fabs((double)r[0])))
+    {
+        while(1)
+        {
+            SUF(orc_scale)(n, v[0], one / r[0]);
+            int i = 0;
+            while(i < size)
+            {
+                if(P)
+                {
+                    SUF(pc_solve)(P, v[i], z[i]);
+                    SUF(op_apply)(A, z[i], v[i + 1]);
+                }
+                else
+                    SUF(op_apply)(A, v[i], v[i + 1]);
+                for(int k = 0; k <= i; ++k)
+                {
+                    int idx = HIND(k, i);
+                    H[idx]  = SUF(orc_dot)(n, v[k], v[i + 1]);
+                    SUF(orc_add_scale)(n, v[i + 1], v[k], -H[idx]);
+                }
+                int ii = HIND(i, i), ip1i = HIND(i + 1, i);
+                H[ip1i] = SUF(orc_norm)(n, v[i + 1]);
+                SUF(orc_scale)(n, v[i + 1], one / H[ip1i]);
+                for(int k = 0; k < i; ++k)
+                    SUF(app_givens)(c[k], s[k], &H[HIND(k, i)], &H[HIND(k + 1, i)]);
+                SUF(gen_givens)(H[ii], H[ip1i], &c[i], &s[i]);
+                SUF(app_givens)(c[i], s[i], &H[ii], &H[ip1i]);
+                SUF(app_givens)(c[i], s[i], &r[i], &r[i + 1]);
+                ++i;
+                if(orc_ic_check_residual(ic, fabs((double)r[i])))
+                    break;
+            }
+            for(int j = i - 1; j >= 0; --j)
+            {
+                r[j] /= H[HIND(j, j)];
+                for(int k = 0; k < j; ++k)
+                    r[k] -= H[HIND(k, j)] * r[j];
+            }
+            T** upd = P ? z : v;
+            SUF(orc_add_scale)(n, x, upd[0], r[0]);
+            for(int j = 1; j < i; ++j)
+                SUF(orc_add_scale)(n, x, upd[j], r[j]);
+            SUF(residual)(A, rhs, x, v[0]);
+            for(int k = 0; k <= size; ++k)
+                r[k] = (T)0;
+            r[0] = SUF(orc_norm)(n, v[0]);
+            if(orc_ic_check_residual_nocount(ic, fabs((double)r[0])))
+                break;
+        }
+    }
+#undef HIND
+    for(int i = 0; i <= size; ++i)
+    {
+        free(v[i]);
+        free(z[i]);
+    }
+    free(v);
+    free(z);
+    free(c);
+    free(s);
+    free(r);
+    free(H);
+}
+
+/* src/solvers/krylov/bicgstabl.cpp:292-496 / :499-695.  The preconditioned variant is LEFT
+ * preconditioned: every A u / A r is followed by M^-1, the residual in the convergence test is the
+ * preconditioned one.  The return value of InitResidual is not consulted. */
+static void SUF(solve_bicgstabl)(const SUF(orc_op) * A, SUF(orc_pc) * P, const T* rhs, T* x,
+                                 orc_iter_ctrl* ic, int l)
+{
+    int  n  = A->nrow;
+    T*   r0 = (T*)calloc((size_t)n, sizeof(T));
+    T*   z  = (T*)calloc((size_t)n, sizeof(T));
+    T**  r  = (T**)malloc(sizeof(T*) * (size_t)(l + 1));
+    T**  u  = (T**)malloc(sizeof(T*) * (size_t)(l + 1));
+    for(int i = 0; i <= l; ++i)
+    {
+        r[i] = (T*)calloc((size_t)n, sizeof(T));
+        u[i] = (T*)calloc((size_t)n, sizeof(T));
+    }
+    T* gamma0 = (T*)calloc((size_t)l, sizeof(T));
+    T* gamma1 = (T*)calloc((size_t)l, sizeof(T));
+    T* gamma2 = (T*)calloc((size_t)l, sizeof(T));
+    T* sigma  = (T*)calloc((size_t)l, sizeof(T));
+    T* tau    = (T*)calloc((size_t)l * l, sizeof(T)); /* tau[i][j] -> tau[i*l+j] */
+    int converged = 0;
+    T   alpha = (T)0, beta = (T)0, omega = (T)1, rho_old = (T)-1, rho, res;
+    if(P)
+    {
+        SUF(residual)(A, rhs, x, z);
+        SUF(pc_solve)(P, z, r0);
+    }
+    else
+        SUF(residual)(A, rhs, x, r0);
+    res = SUF(orc_norm)(n, r0);
+    (void)orc_ic_init_residual(ic, fabs((double)res));
+    memcpy(r[0], r0, sizeof(T) * (size_t)n);
+    memset(u[0], 0, sizeof(T) * (size_t)n);
+    while(1)
+    {
+        rho_old *= -omega;
+        for(int j = 0; j < l; ++j)
+        {
+            rho = SUF(orc_dot)(n, r0, r[j]);
+            if(rho == (T)0)
+            {
+                converged = 1;
+                break;
+            }
+            beta = alpha * rho / rho_old;
+            for(int i = 0; i <= j; ++i)
+                SUF(orc_scale_add)(n, u[i], -beta, r[i]);
+            if(P)
+            {
+                SUF(op_apply)(A, u[j], z);
+                SUF(pc_solve)(P, z, u[j + 1]);
+            }
+            else
+                SUF(op_apply)(A, u[j], u[j + 1]);
+            rho_old = SUF(orc_dot)(n, r0, u[j + 1]);
+            if(rho_old == (T)0)
+            {
+                converged = 1;
+                break;
+            }
+            alpha   = rho / rho_old;
+            rho_old = rho;
+            for(int i = 0; i <= j; ++i)
+                SUF(orc_add_scale)(n, r[i], u[i + 1], -alpha);
+            if(P)
+            {
+                SUF(op_apply)(A, r[j], z);
+                SUF(pc_solve)(P, z, r[j + 1]);
+            }
+            else
+                SUF(op_apply)(A, r[j], r[j + 1]);
+            SUF(orc_add_scale)(n, x, u[0], alpha);
+            res = SUF(orc_norm)(n, r[0]);
+            if(orc_ic_check_residual_nocount(ic, fabs((double)res)))
+            {
+                converged = 1;
+                break;
+            }
+        }
+        if(converged)
+            break;
+        for(int j = 0; j < l; ++j)
+        {
+            for(int i = 0; i < j; ++i)
+            {
+                tau[i * l + j] = SUF(orc_dot)(n, r[j + 1], r[i + 1]) / sigma[i];
+                SUF(orc_add_scale)(n, r[j + 1], r[i + 1], -tau[i * l + j]);
+            }
+            sigma[j]  = SUF(orc_dot)(n, r[j + 1], r[j + 1]);
+            gamma1[j] = SUF(orc_dot)(n, r[0], r[j + 1]) / sigma[j];
+        }
+        gamma0[l - 1] = gamma1[l - 1];
+        omega         = gamma1[l - 1];
+        for(int j = l - 2; j >= 0; --j)
+        {
+            gamma0[j] = gamma1[j];
+            for(int i = j + 1; i < l; ++i)
+                gamma0[j] -= tau[j * l + i] * gamma0[i];
+        }
+        for(int j = 0; j < l - 1; ++j)
+        {
+            gamma2[j] = gamma0[j + 1];
+            for(int i = j + 1; i < l - 1; ++i)
+                gamma2[j] += tau[j * l + i] * gamma0[i + 1];
+        }
+        SUF(orc_add_scale)(n, x, r[0], gamma0[0]);
+        SUF(orc_add_scale)(n, r[0], r[l], -gamma1[l - 1]);
+        SUF(orc_add_scale)(n, u[0], u[l], -gamma0[l - 1]);
+        for(int j = 1; j < l; ++j)
+        {
+            SUF(orc_add_scale)(n, u[0], u[j], -gamma0[j - 1]);
+            SUF(orc_add_scale)(n, x, r[j], gamma2[j - 1]);
+            SUF(orc_add_scale)(n, r[0], r[j], -gamma1[j - 1]);
+        }
+        res = SUF(orc_norm)(n, r[0]);
+        if(orc_ic_check_residual(ic, fabs((double)res)))
+            break;
+    }
+    for(int i = 0; i <= l; ++i)
+    {
+        free(r[i]);
+        free(u[i]);
+    }
+    free(r);
+    free(u);
+    free(r0);
+    free(z);
+    free(gamma0);
+    free(gamma1);
+    free(gamma2);
+    free(sigma);
+    free(tau);
+}
+
+/* src/solvers/krylov/qmrcgstab.cpp:262-460 / :463-690 (right preconditioned through z).
+ * The residual handed to the iteration control is the bound sqrt(#iter+1)*|tau|; after the loop the
+ * true residual is computed and checked once more (which counts one more iteration). */
+static void SUF(solve_qmrcgstab)(const SUF(orc_op) * A, SUF(orc_pc) * P, const T* rhs, T* x,
+                                 orc_iter_ctrl* ic)
+{
+    int n  = A->nrow;
+    T*  r0 = (T*)calloc((size_t)n, sizeof(T));
+    T*  r  = (T*)calloc((size_t)n, sizeof(T));
+    T*  p  = (T*)calloc((size_t)n, sizeof(T)); /* Build() zero-fills; p += r below */
+    T*  t  = (T*)calloc((size_t)n, sizeof(T));
+    T*  v  = (T*)calloc((size_t)n, sizeof(T));
+    T*  d  = (T*)calloc((size_t)n, sizeof(T));
+    T*  z  = (T*)calloc((size_t)n, sizeof(T));
+    T   alpha, beta, omega, theta1, theta1sq, theta2, theta2sq, eta1, eta2, tau1, tau2, rho, rho_old, c;
+    SUF(residual)(A, rhs, x, r0);
+    memcpy(r, r0, sizeof(T) * (size_t)n);
+    tau2            = SUF(orc_norm)(n, r0);
+    double res_norm = fabs((double)tau2);
+    (void)orc_ic_init_residual(ic, res_norm);
+    rho  = SUF(orc_dot)(n, r0, r);
+    beta = rho;
+    (void)beta;
+    SUF(orc_add_scale)(n, p, r, (T)1);
+    const T* pz = p; /* direction handed to A: p, or z = M^-1 p */
+    if(P)
+    {
+        SUF(pc_solve)(P, p, z);
+        pz = z;
+    }
+    SUF(op_apply)(A, pz, v);
+    rho_old = SUF(orc_dot)(n, r0, v);
+    alpha   = rho / rho_old;
+    SUF(orc_add_scale)(n, r, v, -alpha);
+    theta1   = SUF(orc_norm)(n, r) / tau2;
+    theta1sq = theta1 * theta1;
+    c        = (T)1 / (T)sqrt((double)((T)1 + theta1sq));
+    tau1     = tau2 * theta1 * c;
+    eta1     = c * c * alpha;
+    memcpy(d, pz, sizeof(T) * (size_t)n);
+    SUF(orc_add_scale)(n, x, d, eta1);
+    const T* rz = r;
+    if(P)
+    {
+        SUF(pc_solve)(P, r, z);
+        rz = z;
+    }
+    SUF(op_apply)(A, rz, t);
+    omega = SUF(orc_dot)(n, t, r) / SUF(orc_dot)(n, t, t);
+    SUF(orc_scale_add)(n, d, theta1sq * eta1 / omega, rz);
+    SUF(orc_add_scale)(n, r, t, -omega);
+    theta2   = SUF(orc_norm)(n, r) / tau1;
+    theta2sq = theta2 * theta2;
+    c        = (T)1 / (T)sqrt((double)((T)1 + theta2sq));
+    tau2     = tau1 * theta2 * c;
+    eta2     = c * c * omega;
+    SUF(orc_add_scale)(n, x, d, eta2);
+    res_norm = sqrt((double)(ic->iteration + 1)) * fabs((double)tau2);
+    while(!orc_ic_check_residual(ic, res_norm))
+    {
+        rho_old = rho;
+        rho     = SUF(orc_dot)(n, r0, r);
+        beta    = (rho * alpha) / (rho_old * omega);
+        SUF(orc_add_scale)(n, p, v, -omega);
+        SUF(orc_scale)(n, p, beta);
+        SUF(orc_add_scale)(n, p, r, (T)1);
+        if(P)
+            SUF(pc_solve)(P, p, z);
+        SUF(op_apply)(A, pz, v);
+        rho_old = SUF(orc_dot)(n, r0, v);
+        if(rho_old == (T)0)
+            break;
+        alpha = rho / rho_old;
+        SUF(orc_add_scale)(n, r, v, -alpha);
+        theta1   = SUF(orc_norm)(n, r) / tau2;
+        theta1sq = theta1 * theta1;
+        c        = (T)1 / (T)sqrt((double)((T)1 + theta1sq));
+        tau1     = tau2 * theta1 * c;
+        eta1     = c * c * alpha;
+        SUF(orc_scale_add)(n, d, theta2sq * eta2 / alpha, pz);
+        SUF(orc_add_scale)(n, x, d, eta1);
+        if(P)
+            SUF(pc_solve)(P, r, z);
+        SUF(op_apply)(A, rz, t);
+        omega = SUF(orc_dot)(n, t, t);
+        if(omega == (T)0)
+            break;
+        omega = SUF(orc_dot)(n, t, r) / omega;
+        SUF(orc_scale_add)(n, d, theta1sq * eta1 / omega, rz);
+        SUF(orc_add_scale)(n, r, t, -omega);
+        theta2   = SUF(orc_norm)(n, r) / tau1;
+        theta2sq = theta2 * theta2;
+        c        = (T)1 / (T)sqrt((double)((T)1 + theta2sq));
+        tau2     = tau1 * theta2 * c;
+        eta2     = c * c * omega;
+        SUF(orc_add_scale)(n, x, d, eta2);
+        res_norm = sqrt((double)(ic->iteration + 1)) * fabs((double)tau2);
+    }
+    SUF(residual)(A, rhs, x, r0);
+    (void)orc_ic_check_residual(ic, fabs((double)SUF(orc_norm)(n, r0)));
+    free(r0);
+    free(r);
+    free(p);
+    free(t);
+    free(v);
+    free(d);
+    free(z);
+}
+
 /* src/solvers/krylov/bicgstab.cpp:245-361 (no preconditioner) / :365-489 (right preconditioned) */
 static void SUF(solve_bicgstab)(const SUF(orc_op) * A, SUF(orc_pc) * P, const T* rhs, T* x,
                                 orc_iter_ctrl* ic)
@@ -1211,6 +1677,16 @@ int SUF(orc_solve)(int nrow, int64_t nnz, const int* row_offset, const int* col,
         SUF(solve_gmres)(&A, have_pc ? &P : NULL, rhs, x, &ic, cfg->basis > 0 ? cfg->basis : 30);
     else if(cfg->solver == ORC_BICGSTAB)
         SUF(solve_bicgstab)(&A, have_pc ? &P : NULL, rhs, x, &ic);
+    else if(cfg->solver == ORC_FCG)
+        SUF(solve_fcg)(&A, have_pc ? &P : NULL, rhs, x, &ic);
+    else if(cfg->solver == ORC_CR)
+        SUF(solve_cr)(&A, have_pc ? &P : NULL, rhs, x, &ic);
+    else if(cfg->solver == ORC_FGMRES)
+        SUF(solve_fgmres)(&A, have_pc ? &P : NULL, rhs, x, &ic, cfg->basis > 0 ? cfg->basis : 30);
+    else if(cfg->solver == ORC_BICGSTABL)
+        SUF(solve_bicgstabl)(&A, have_pc ? &P : NULL, rhs, x, &ic, cfg->basis > 0 ? cfg->basis : 2);
+    else if(cfg->solver == ORC_QMRCGSTAB)
+        SUF(solve_qmrcgstab)(&A, have_pc ? &P : NULL, rhs, x, &ic);
     else
         return 0;
     orc_ic_finish(&ic, cfg);

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 CSR, ELL, HYB = 1, 6, 7
-CG, GMRES, BICGSTAB = 0, 1, 2
+CG, GMRES, BICGSTAB, FCG, CR, FGMRES, BICGSTABL, QMRCGSTAB = 0, 1, 2, 3, 4, 5, 6, 7
 PC_NONE, PC_JACOBI, PC_ILU0, PC_MCSGS, PC_MCGS, PC_MCILU = 0, 1, 2, 3, 4, 5
 
 

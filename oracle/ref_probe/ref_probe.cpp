@@ -395,6 +395,110 @@ static int cmd_gen(const std::string& in, const std::string& out)
             run_solver("gmres_mcilu", ls, rhs, sol);
             ls.Clear();
         }
+        // --- further Krylov drivers, each bare and with a preconditioner
+        {
+            FCG<MatD, VecD, double> ls;
+            ls.SetOperator(mat);
+            ls.Build();
+            sol.Zeros();
+            run_solver("fcg_none", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            FCG<MatD, VecD, double>    ls;
+            Jacobi<MatD, VecD, double> p;
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(p);
+            ls.Build();
+            sol.Zeros();
+            run_solver("fcg_jacobi", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            FCG<MatD, VecD, double>             ls;
+            MultiColoredSGS<MatD, VecD, double> p;
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(p);
+            ls.Build();
+            sol.Zeros();
+            run_solver("fcg_mcsgs", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            CR<MatD, VecD, double> ls;
+            ls.SetOperator(mat);
+            ls.Build();
+            sol.Zeros();
+            run_solver("cr_none", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            CR<MatD, VecD, double>     ls;
+            Jacobi<MatD, VecD, double> p;
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(p);
+            ls.Build();
+            sol.Zeros();
+            run_solver("cr_jacobi", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            FGMRES<MatD, VecD, double> ls;
+            ls.SetOperator(mat);
+            ls.SetBasisSize(basis);
+            ls.Build();
+            sol.Zeros();
+            run_solver("fgmres_none", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            FGMRES<MatD, VecD, double> ls;
+            ILU<MatD, VecD, double>    p;
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(p);
+            ls.SetBasisSize(basis);
+            ls.Build();
+            sol.Zeros();
+            run_solver("fgmres_ilu0", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            BiCGStabl<MatD, VecD, double> ls; // default l = 2
+            ls.SetOperator(mat);
+            ls.Build();
+            sol.Zeros();
+            run_solver("bicgstabl_none", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            BiCGStabl<MatD, VecD, double> ls;
+            Jacobi<MatD, VecD, double>    p;
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(p);
+            ls.SetOrder(3);
+            ls.Build();
+            sol.Zeros();
+            run_solver("bicgstabl3_jacobi", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            QMRCGStab<MatD, VecD, double> ls;
+            ls.SetOperator(mat);
+            ls.Build();
+            sol.Zeros();
+            run_solver("qmrcgstab_none", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            QMRCGStab<MatD, VecD, double>       ls;
+            MultiColoredSGS<MatD, VecD, double> p;
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(p);
+            ls.Build();
+            sol.Zeros();
+            run_solver("qmrcgstab_mcsgs", ls, rhs, sol);
+            ls.Clear();
+        }
         {
             // operator converted AFTER Build, as the reference tests do (testing_cg.hpp:151-155)
             MatD e;

@@ -87,6 +87,11 @@ struct LocalSolver : SolverBase
     CG<M, V, T>                                     cg;
     GMRES<M, V, T>                                  gmres;
     BiCGStab<M, V, T>                               bicg;
+    FCG<M, V, T>                                    fcg;
+    CR<M, V, T>                                     cr;
+    FGMRES<M, V, T>                                 fgmres;
+    BiCGStabl<M, V, T>                              bicgl;
+    QMRCGStab<M, V, T>                              qmr;
     Precs<T>                                        pcs;
     M                                               op; // non-owning view of the caller's matrix
     bool                                            built = false;
@@ -99,11 +104,25 @@ struct LocalSolver : SolverBase
     }
     IterativeLinearSolver<M, V, T>* ls()
     {
-        if(solver_kind == RAMD_SOLVER_GMRES)
+        switch(solver_kind)
+        {
+        case RAMD_SOLVER_GMRES:
             return &gmres;
-        if(solver_kind == RAMD_SOLVER_BICGSTAB)
+        case RAMD_SOLVER_BICGSTAB:
             return &bicg;
-        return &cg;
+        case RAMD_SOLVER_FCG:
+            return &fcg;
+        case RAMD_SOLVER_CR:
+            return &cr;
+        case RAMD_SOLVER_FGMRES:
+            return &fgmres;
+        case RAMD_SOLVER_BICGSTABL:
+            return &bicgl;
+        case RAMD_SOLVER_QMRCGSTAB:
+            return &qmr;
+        default:
+            return &cg;
+        }
     }
     void init(double a, double r, double d, int mn, int mx) override
     {
@@ -111,7 +130,12 @@ struct LocalSolver : SolverBase
     }
     void set_basis(int m) override
     {
-        gmres.SetBasisSize(m);
+        if(solver_kind == RAMD_SOLVER_BICGSTABL)
+            bicgl.SetOrder(m);
+        else if(solver_kind == RAMD_SOLVER_FGMRES)
+            fgmres.SetBasisSize(m);
+        else
+            gmres.SetBasisSize(m);
     }
     void set_fused(bool f) override
     {
@@ -375,7 +399,7 @@ extern "C" {
 
 int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out)
 {
-    if(!out || solver < 0 || solver > 2 || precond < 0 || precond > RAMD_PC_MCILU
+    if(!out || solver < 0 || solver > RAMD_SOLVER_QMRCGSTAB || precond < 0 || precond > RAMD_PC_MCILU
        || (dtype != RAMD_F64 && dtype != RAMD_F32))
         return RAMD_ERR_ARG;
     GUARD_BEGIN

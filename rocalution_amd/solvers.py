@@ -11,7 +11,8 @@ import ctypes as C
 import numpy as np
 
 from . import capi
-from .capi import PC_ILU0, PC_JACOBI, PC_MCGS, PC_MCILU, PC_MCSGS, PC_NONE, SOLVER_BICGSTAB, SOLVER_CG, SOLVER_GMRES
+from .capi import (PC_ILU0, PC_JACOBI, PC_MCGS, PC_MCILU, PC_MCSGS, PC_NONE, SOLVER_BICGSTAB, SOLVER_BICGSTABL,
+                   SOLVER_CG, SOLVER_CR, SOLVER_FCG, SOLVER_FGMRES, SOLVER_GMRES, SOLVER_QMRCGSTAB)
 
 
 def _lib():
@@ -190,6 +191,34 @@ class GMRES(_IterativeLinearSolver):
 
 class BiCGStab(_IterativeLinearSolver):
     kind = SOLVER_BICGSTAB
+
+
+class FCG(_IterativeLinearSolver):
+    """flexible CG (src/solvers/krylov/fcg.cpp)"""
+    kind = SOLVER_FCG
+
+
+class CR(_IterativeLinearSolver):
+    """conjugate residual (src/solvers/krylov/cr.cpp)"""
+    kind = SOLVER_CR
+
+
+class FGMRES(GMRES):
+    """flexible GMRES (src/solvers/krylov/fgmres.cpp)"""
+    kind = SOLVER_FGMRES
+
+
+class BiCGStabl(_IterativeLinearSolver):
+    """BiCGStab(l) (src/solvers/krylov/bicgstabl.cpp), l = 2 unless SetOrder is called"""
+    kind = SOLVER_BICGSTABL
+
+    def SetOrder(self, l):
+        self._basis = int(l)
+
+
+class QMRCGStab(_IterativeLinearSolver):
+    """QMRCGStab (src/solvers/krylov/qmrcgstab.cpp)"""
+    kind = SOLVER_QMRCGSTAB
 
 
 class MixedPrecisionDC(_IterativeLinearSolver):

@@ -44,7 +44,11 @@ def _inputs(name, g):
 
 
 def _mk(S, tag, dtype=np.float64):
-    solver = {"cg": S.CG, "gmres": S.GMRES, "bicgstab": S.BiCGStab}[tag.split("_")[0]](dtype)
+    sname = tag.split("_")[0]
+    solver = {"cg": S.CG, "gmres": S.GMRES, "bicgstab": S.BiCGStab, "fcg": S.FCG, "cr": S.CR, "fgmres": S.FGMRES,
+              "bicgstabl": S.BiCGStabl, "bicgstabl3": S.BiCGStabl, "qmrcgstab": S.QMRCGStab}[sname](dtype)
+    if sname == "bicgstabl3":
+        solver.SetOrder(3)
     pc = {"none": None, "jacobi": S.Jacobi, "ilu0": S.ILU, "mcsgs": S.MultiColoredSGS, "mcgs": S.MultiColoredGS,
           "mcilu": S.MultiColoredILU}[tag.split("_")[1]]
     if pc is not None:
@@ -90,7 +94,8 @@ def test_preconditioner_apply_bit_exact(ra, S, name):
 
 
 SOLVER_TAGS = ["cg_none", "cg_jacobi", "gmres_none", "gmres_ilu0", "bicgstab_none", "bicgstab_mcsgs", "bicgstab_mcgs",
-               "gmres_mcilu"]
+               "gmres_mcilu", "fcg_none", "fcg_jacobi", "fcg_mcsgs", "cr_none", "cr_jacobi", "fgmres_none",
+               "fgmres_ilu0", "bicgstabl_none", "bicgstabl3_jacobi", "qmrcgstab_none", "qmrcgstab_mcsgs"]
 SOLVER_CASES = ["gr3030", "poisson8", "lap2d7", "poisson16", "poisson32"]
 
 
@@ -103,6 +108,8 @@ def _check_hist(hist, ref_hist, bicgstab, rtol=2e-6):
     a factor of 10 of each other -- the reference's own OpenMP backend moves by as much between thread
     counts."""
     m = min(len(hist), len(ref_hist)) - 2
+    if m <= 0:  # runs of one or two iterations: nothing between start and end to compare
+        return
     h, r = np.asarray(hist[:m]), np.asarray(ref_hist[:m])
     floor = 1e-12 * h[0]
     k = min(m, 8) if bicgstab else m
@@ -115,7 +122,10 @@ def _check_hist(hist, ref_hist, bicgstab, rtol=2e-6):
 
 def _check_run(hist, ref_hist, iters, ref_iters, status, ref_status, slack, bicgstab=False):
     assert abs(iters - ref_iters) <= slack, (iters, ref_iters)
-    assert status == ref_status
+    # a tiny system that converges to round-off in its last step may cross the absolute (1) and the
+    # relative (2) tolerance in the same iteration: which one is reported depends on the last bits
+    roundoff = min(hist[-1], ref_hist[-1]) <= 1e-12 * ref_hist[0] and {status, ref_status} <= {1, 2}
+    assert status == ref_status or roundoff, (status, ref_status)
     _check_hist(hist, ref_hist, bicgstab)
 
 
@@ -131,14 +141,14 @@ def test_solvers_vs_golden(ra, S, name, tag, fused):
     A.Apply(ones, rhs)
     eq(rhs.numpy(), g["rhs_ones"])
     ls = _mk(S, tag); ls.SetOperator(A); ls.SetFused(fused)
-    if tag.startswith("gmres"):
+    if "gmres" in tag:
         ls.SetBasisSize(int(g["basis"][0]))
     ls.Build()
     x = ra.LocalVector(); x.Allocate("", n)
     ls.Solve(rhs, x)
     meta = g[tag + "_meta"]
-    slack = 1 if tag.startswith("cg") else 2
-    bicg = tag.startswith("bicgstab")
+    slack = 1 if tag.split("_")[0] in ("cg", "fcg", "cr") else 2
+    bicg = tag.startswith("bicgstab") or tag.startswith("qmrcgstab")  # BiCG-type recurrences, see _check_hist
     _check_run(ls.GetResidualHistory(), g[tag + "_hist"], ls.GetIterationCount(), int(meta[0]),
                ls.GetSolverStatus(), int(meta[1]), slack, bicg)
     if ls.GetIterationCount() == int(meta[0]) and not bicg:

@@ -154,6 +154,17 @@ SOLVER_TABLE = {
     "cg_jacobi_hyb": ("CG", "PC_JACOBI", "HYB", {}),
     "bicgstab_mcgs": ("BICGSTAB", "PC_MCGS", "CSR", {}),
     "gmres_mcilu": ("GMRES", "PC_MCILU", "CSR", {}),
+    "fcg_none": ("FCG", "PC_NONE", "CSR", {}),
+    "fcg_jacobi": ("FCG", "PC_JACOBI", "CSR", {}),
+    "fcg_mcsgs": ("FCG", "PC_MCSGS", "CSR", {}),
+    "cr_none": ("CR", "PC_NONE", "CSR", {}),
+    "cr_jacobi": ("CR", "PC_JACOBI", "CSR", {}),
+    "fgmres_none": ("FGMRES", "PC_NONE", "CSR", {}),
+    "fgmres_ilu0": ("FGMRES", "PC_ILU0", "CSR", {}),
+    "bicgstabl_none": ("BICGSTABL", "PC_NONE", "CSR", dict(basis=2)),
+    "bicgstabl3_jacobi": ("BICGSTABL", "PC_JACOBI", "CSR", dict(basis=3)),
+    "qmrcgstab_none": ("QMRCGSTAB", "PC_NONE", "CSR", {}),
+    "qmrcgstab_mcsgs": ("QMRCGSTAB", "PC_MCSGS", "CSR", {}),
 }
 
 
@@ -166,8 +177,10 @@ def test_solver_history_bit_exact(oracle, name, tag):
     rhs = oracle.csr_apply(rp, ci, va, np.ones(len(rp) - 1))
     eq(rhs, g["rhs_ones"])
     x0 = x if tag.endswith("_x0") else None
+    kw = dict(kw)
+    basis = kw.pop("basis", int(g["basis"][0]))
     r = oracle.solve(rp, ci, va, rhs, x0=x0, solver=getattr(oracle, s), precond=getattr(oracle, p),
-                     fmt=getattr(oracle, f), basis=int(g["basis"][0]), **kw)
+                     fmt=getattr(oracle, f), basis=basis, **kw)
     meta = g[tag + "_meta"]
     assert r["iters"] == int(meta[0])
     assert r["status"] == int(meta[1])
