@@ -81,6 +81,22 @@ int main(int argc, char** argv)
     CG<GlobalMatrix<double>, GlobalVector<double>, double> gls;
     BlockJacobi<GlobalMatrix<double>, GlobalVector<double>, double> bj;
     bj.Set(sgs); gls.SetOperator(gmat); gls.SetPreconditioner(bj);
+    // the remaining Krylov drivers / multi-coloured preconditioners, Local and Global instantiations
+    FCG<LocalMatrix<double>, LocalVector<double>, double> fcg; fcg.SetOperator(mat);
+    CR<LocalMatrix<double>, LocalVector<double>, double> cr; cr.SetOperator(mat);
+    FGMRES<LocalMatrix<double>, LocalVector<double>, double> fg; fg.SetBasisSize(20); fg.SetOperator(mat);
+    BiCGStabl<LocalMatrix<double>, LocalVector<double>, double> bl; bl.SetOrder(4); bl.SetOperator(mat);
+    QMRCGStab<LocalMatrix<double>, LocalVector<double>, double> qm; qm.SetOperator(mat);
+    MultiColoredGS<LocalMatrix<double>, LocalVector<double>, double> mgs;
+    MultiColoredILU<LocalMatrix<double>, LocalVector<double>, double> milu; milu.Set(0);
+    qm.SetPreconditioner(mgs); fg.SetPreconditioner(milu);
+    FCG<GlobalMatrix<double>, GlobalVector<double>, double> gfcg; gfcg.SetOperator(gmat);
+    CR<GlobalMatrix<double>, GlobalVector<double>, double> gcr; gcr.SetOperator(gmat);
+    FGMRES<GlobalMatrix<double>, GlobalVector<double>, double> gfg; gfg.SetOperator(gmat);
+    BiCGStabl<GlobalMatrix<double>, GlobalVector<double>, double> gbl; gbl.SetOperator(gmat);
+    QMRCGStab<GlobalMatrix<double>, GlobalVector<double>, double> gqm; gqm.SetOperator(gmat);
+    mat.WriteFileMTX("a.mtx"); mat.WriteFileCSR("a.csr"); mat.ReadFileCSR("a.csr");
+    x.WriteFileASCII("x.dat"); x.ReadFileBinary("x.bin");
     e.ScaleAdd(-1.0, x);
     std::cout << "||e - x||_2 = " << e.Norm() << std::endl;
     stop_rocalution();
