@@ -213,10 +213,9 @@ __global__ __launch_bounds__(kBlock) void k_ell(int nrow, int ncol, int width,
                                                 const int* __restrict__ ecol,
                                                 const T* __restrict__ eval,
                                                 const T* __restrict__ x, T* __restrict__ y, T scalar,
-                                                ReduceCtx ctx, int slot, int nblk, int per_xcd, BandMap bm)
+                                                double* __restrict__ part1, int nblk, int per_xcd, BandMap bm)
 {
-    __shared__ double red[8];
-    double            dacc = 0.0;
+    double dacc = 0.0;
     // one workgroup per 256 rows, XCD- and band-aware order (same mapping as the CSR kernel)
     const int     blk = xcd_block(nblk, per_xcd, bm);
     const int64_t row = (int64_t)blk * kCsrRows + threadIdx.x;
@@ -279,12 +278,11 @@ __global__ __launch_bounds__(kBlock) void k_ell(int nrow, int ncol, int width,
         if(DOT)
             dacc += (double)sum * (double)x[row];
     }
-    if(DOT)
+    if(DOT) // one partial per wave, summed in fixed order by a second tiny launch (as the CSR kernel)
     {
-        const double vals[1]  = {dacc};
-        const int    slots[1] = {slot};
-        const int    ops[1]   = {RED_SUM};
-        grid_reduce_finish<1>(ctx, vals, slots, ops, red);
+        const double wsum = wave_reduce_sum(dacc);
+        if((threadIdx.x & 63) == 0 && blk >= 0)
+            part1[blk * (kBlock / 64) + (threadIdx.x >> 6)] = wsum;
     }
 }
 
@@ -452,28 +450,46 @@ static BandMap band_map_for(const ramd_mat_s* m, int per_xcd)
 }
 
 template <typename T>
-static int launch_ell(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar, bool stop)
+static int launch_ell(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar, bool stop, bool dot = false,
+                      int slot = 0)
 {
     Backend&      b       = backend();
     const int     nblk    = (m->nrow + kCsrRows - 1) / kCsrRows;
     const int     per_xcd = (nblk + 7) / 8;
     const int     grid    = per_xcd * 8;
-    ReduceCtx     ctx     = reduce_ctx();
     const BandMap bm      = band_map_for(m, per_xcd);
-#define LAUNCH(MODE, STOP)                                                                        \
-    hipLaunchKernelGGL((k_ell<T, MODE, STOP, false>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, \
-                       m->ncol, m->ell_width, m->ell_col, (const T*)m->ell_val, x, y, scalar, ctx, 0, \
+    double*       part1   = nullptr;
+    if(dot) // Apply + <x,y>: per-wave partials in the matrix' workspace (shared with the CSR kernel)
+    {
+        ramd_mat_s* mm = const_cast<ramd_mat_s*>(m);
+        if(!mm->dot_part1 || mm->dot_nblk != nblk)
+        {
+            dev_free(&mm->dot_part1);
+            RAMD_TRY(dev_alloc(&mm->dot_part1, (int64_t)nblk * (kBlock / 64)));
+            mm->dot_nblk = nblk;
+        }
+        part1 = mm->dot_part1;
+    }
+#define LAUNCH(MODE, STOP, DOT)                                                                        \
+    hipLaunchKernelGGL((k_ell<T, MODE, STOP, DOT>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow,       \
+                       m->ncol, m->ell_width, m->ell_col, (const T*)m->ell_val, x, y, scalar, part1, \
                        nblk, per_xcd, bm)
-    if(mode == 0 && stop)
-        LAUNCH(0, true);
+    if(dot && stop)
+        LAUNCH(0, true, true);
+    else if(dot)
+        LAUNCH(0, false, true);
+    else if(mode == 0 && stop)
+        LAUNCH(0, true, false);
     else if(mode == 0)
-        LAUNCH(0, false);
+        LAUNCH(0, false, false);
     else if(stop)
-        LAUNCH(1, true);
+        LAUNCH(1, true, false);
     else
-        LAUNCH(1, false);
+        LAUNCH(1, false, false);
 #undef LAUNCH
     RAMD_HIP(hipGetLastError());
+    if(dot)
+        return reduce_sum_to_slot(part1, (int64_t)nblk * (kBlock / 64), slot);
     return RAMD_OK;
 }
 
@@ -552,6 +568,23 @@ int mat_apply_dot_impl(const ramd_mat_s* m, const T* x, T* y, int slot)
 {
     if(m->format == RAMD_CSR && m->nnz > 0 && m->nrow == m->ncol)
         return launch_csr<T>(m, x, y, 0, (T)1, true, slot); // bracketed inside (SpMV kernel only)
+    if((m->format == RAMD_ELL || m->format == RAMD_HYB) && m->ell_width > 0 && m->nrow == m->ncol && m->nrow > 0)
+    {
+        prof_spmv_begin();
+        int s = launch_ell<T>(m, x, y, 0, (T)1, m->format == RAMD_ELL, true, slot);
+        prof_spmv_end();
+        RAMD_TRY(s);
+        if(m->format == RAMD_HYB && m->coo_nnz > 0) // tail: y += COO x, the dot corrected on the touched rows
+        {
+            Backend&  b    = backend();
+            const int grid = reduce_grid(m->coo_ngroups);
+            hipLaunchKernelGGL((k_coo_grouped_dot<T>), dim3(grid), dim3(kBlock), 0, b.cur, m->coo_ngroups,
+                               m->coo_grow, m->coo_gptr, m->coo_col, (const T*)m->coo_val, x, y, (T)1, x,
+                               reduce_ctx(), slot);
+            RAMD_HIP(hipGetLastError());
+        }
+        return RAMD_OK;
+    }
     return RAMD_ERR_UNSUPPORTED; // caller falls back to apply + dot (two launches)
 }
 // y += scalar A x ; slot (holding <p, y_old>) corrected to <p, y>: grouped COO only

@@ -396,3 +396,24 @@ def test_file_io_device_objects(ra, tmp_path):
     assert open(f, "rb").read() == open(os.path.join(gold, "ref_x.dat"), "rb").read()
     y = ra.LocalVector(); y.ReadFileASCII(f)
     assert np.allclose(y.numpy(), exp["x"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["gr3030", "rand300", "rand300ell"])
+def test_fused_apply_dot_all_formats(ra, name):
+    """y = A x with <x,y> in the same pass: y bit-exact with Apply in every format (HYB incl. its COO tail)"""
+    import ctypes as C
+    from rocalution_amd import capi
+    lib = capi.load()
+    g = load_golden(name)
+    n = len(g["rowptr"]) - 1
+    x = ra.LocalVector(data=g["x"])
+    for fmt, key in ((ra.CSR, "csr"), (ra.ELL, "ell"), (ra.HYB, "hyb"), (ra.COO, "coo")):
+        A = _mat(ra, g)
+        if A.ConvertTo(fmt) != fmt:
+            continue
+        y = ra.LocalVector(); y.Allocate("", n)
+        capi.check(lib.ramd_fused_apply_dot(A._h, x._h, y._h, 7))
+        eq(y.numpy(), g["spmv_" + key])
+        out = (C.c_double * 1)()
+        capi.check(lib.ramd_scalars_fetch(out, 7, 1))
+        close(out[0], float(np.dot(g["x"], y.numpy())), 1e-12)
