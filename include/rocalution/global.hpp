@@ -509,6 +509,12 @@ public:
     // the vectors: the interior SpMV carries the dot, the ghost ApplyAdd corrects it on the rows it touches
     void ApplyDot(const GlobalVector<ValueType>& in, GlobalVector<ValueType>* out, int slot) const
     {
+        this->ApplyDotV(in, in, out, slot);
+    }
+    // ... the same with the dot taken against another vector: slot = local part of <w, out>
+    void ApplyDotV(const GlobalVector<ValueType>& in, const GlobalVector<ValueType>& w,
+                   GlobalVector<ValueType>* out, int slot) const
+    {
         const bool comm = this->pm_ != NULL && !this->pm_->peers().empty();
         if(comm)
         {
@@ -518,14 +524,19 @@ public:
                                             this->pm_->peers().data(), this->pm_->send_offset().data(),
                                             this->pm_->recv_offset().data()));
         }
-        RAMD_CHECK(ramd_fused_apply_dot(this->matrix_interior_.handle(), in.vector_interior_.handle(),
-                                        out->vector_interior_.handle(), slot));
+        if(&w == &in)
+            RAMD_CHECK(ramd_fused_apply_dot(this->matrix_interior_.handle(), in.vector_interior_.handle(),
+                                            out->vector_interior_.handle(), slot));
+        else
+            RAMD_CHECK(ramd_fused_apply_dotv(this->matrix_interior_.handle(), in.vector_interior_.handle(),
+                                             out->vector_interior_.handle(), w.vector_interior_.handle(),
+                                             slot));
         if(comm)
         {
             RAMD_CHECK(ramd_comm_halo_end(this->pm_->GetComm()));
             RAMD_CHECK(ramd_fused_apply_add_dot(this->matrix_ghost_.handle(), this->recv_buffer_.handle(), 1.0,
                                                 out->vector_interior_.handle(),
-                                                in.vector_interior_.handle(), slot));
+                                                w.vector_interior_.handle(), slot));
         }
     }
 
@@ -569,6 +580,12 @@ inline void _f_apply_dot(const GlobalMatrix<ValueType>& A, const GlobalVector<Va
                          GlobalVector<ValueType>* q, int slot)
 {
     A.ApplyDot(p, q, slot); // pack | halo || interior SpMV + <p,q> | ghost += and dot correction
+}
+template <typename ValueType>
+inline void _f_apply_dotv(const GlobalMatrix<ValueType>& A, const GlobalVector<ValueType>& x,
+                          GlobalVector<ValueType>* y, const GlobalVector<ValueType>& w, int slot)
+{
+    A.ApplyDotV(x, w, y, slot);
 }
 template <typename ValueType>
 inline void _f_allreduce(const GlobalMatrix<ValueType>& A, int first, int count)

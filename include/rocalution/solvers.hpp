@@ -1064,6 +1064,12 @@ inline void _f_apply_dot(const LocalMatrix<ValueType>& A, const LocalVector<Valu
     RAMD_CHECK(ramd_fused_apply_dot(A.handle(), p.handle(), q->handle(), slot));
 }
 template <typename ValueType>
+inline void _f_apply_dotv(const LocalMatrix<ValueType>& A, const LocalVector<ValueType>& x,
+                          LocalVector<ValueType>* y, const LocalVector<ValueType>& w, int slot)
+{
+    RAMD_CHECK(ramd_fused_apply_dotv(A.handle(), x.handle(), y->handle(), w.handle(), slot)); // y = A x ; <w,y>
+}
+template <typename ValueType>
 inline void _f_allreduce(const LocalMatrix<ValueType>&, int, int)
 {
 }
@@ -1633,6 +1639,85 @@ protected:
     }
 
 private:
+    // Fused device loop: per iteration  K1 q = A dir + <r0,q> | K2 r -= alpha q | [v = M^-1 r] |
+    // t = A sv, one pass for <t,r>,<t,t> | K3 x,r updates + <r,r>,<r0,r> | K4 p update | [z = M^-1 p].
+    // alpha/omega/beta never leave the device; ONE host read per iteration (the four dots of K3's
+    // record), overlapped with K4 and the next preconditioner apply.  Same per-element arithmetic and
+    // the same breakdown / stopping decisions as the loop below.
+    template <class O = OperatorType, class V = VectorType>
+    typename std::enable_if<_fusable<O, V, ValueType>::value, bool>::type
+        FusedLoop_(const VectorType& rhs, VectorType* x, bool precond)
+    {
+        if(!this->op_->is_accel_() || !x->is_accel_())
+            return false;
+        const OperatorType& A = *this->op_;
+        VectorType *r = &this->r_, *r0 = &this->r0_, *p = &this->p_, *q = &this->q_, *t = &this->t_;
+        VectorType *v = &this->v_, *z = &this->z_;
+        const ValueType one = static_cast<ValueType>(1);
+        // slots: <t,r> = 0, <t,t> = 1, <r0,q> = 2, ||r||^2 = 4, rho alternates between 3 and 5 (always next
+        // to slot 4: the two sums of K3 cross the ranks in ONE all-reduce), breakdown flag = 6
+        enum { S_TR = 0, S_R0Q = 2, S_RR = 4, S_FLAG = 6 };
+        int s_rho = 3, s_new = 5;
+        const ramd_vec_t rv[1] = {_fh(*r)};
+        RAMD_CHECK(ramd_fused_multi_dot(rv, 1, _fh(*r), s_rho)); // rho = <r,r>
+        _f_allreduce(A, s_rho, 1);
+        int rec = 0;
+        while(true)
+        {
+            const VectorType* dir = precond ? z : p;
+            _f_apply_dotv(A, *dir, q, *r0, S_R0Q);
+            _f_allreduce(A, S_R0Q, 1);
+            RAMD_CHECK(ramd_fused_bicg_r_update(_fh(*r), _fh(*q), s_rho, S_R0Q));
+            const VectorType* sv = r;
+            if(precond)
+            {
+                this->precond_->SolveZeroSol(*r, v);
+                sv = v;
+            }
+            A.Apply(*sv, t);
+            const ramd_vec_t rt[2] = {_fh(*r), _fh(*t)};
+            RAMD_CHECK(ramd_fused_multi_dot(rt, 2, _fh(*t), S_TR)); // <t,r>, <t,t> in one pass
+            _f_allreduce(A, S_TR, 2);
+            RAMD_CHECK(ramd_fused_bicg_xr_update(_fh(*x), precond ? _fh(*dir) : NULL, precond ? _fh(*sv) : NULL,
+                                                 _fh(*r), _fh(*t), _fh(*r0), _fh(*p), s_rho, S_R0Q, S_TR, S_RR,
+                                                 s_new, S_FLAG));
+            _f_allreduce(A, s_new < S_RR ? s_new : S_RR, 2);
+            RAMD_CHECK(ramd_scalars_fetch_async_begin(rec, 0, 7));
+            // queued ahead of the host's decision; they only touch p / z, which a finished solve discards
+            RAMD_CHECK(ramd_fused_bicg_direction(_fh(*p), _fh(*q), _fh(*r), s_rho, S_R0Q, S_TR, s_new));
+            if(precond)
+                this->precond_->SolveZeroSol(*p, z);
+            double h[7];
+            RAMD_CHECK(ramd_scalars_fetch_async_end(rec, h, 7));
+            rec = (rec + 1) & 7;
+            if(h[S_FLAG] != 0.0) // bicgstab.cpp:430-447 (x += alpha p was done by the kernel)
+            {
+                LOG_INFO("BiCGStab omega == 0 || Nan || Inf !!! Updated solution only in p-direction");
+                A.Apply(*x, p);
+                p->ScaleAdd(-one, rhs);
+                ValueType res_norm = this->Norm_(*p);
+                this->iter_ctrl_.CheckResidual(std::abs(res_norm), this->index_);
+                break;
+            }
+            ValueType res_norm = (ValueType)std::sqrt(h[S_RR]);
+            if(this->iter_ctrl_.CheckResidual(std::abs(res_norm), this->index_))
+                break;
+            if((ValueType)h[s_new] == static_cast<ValueType>(0))
+            {
+                LOG_INFO("BiCGStab rho == 0 !!!");
+                break;
+            }
+            std::swap(s_rho, s_new);
+        }
+        return true;
+    }
+    template <class O = OperatorType, class V = VectorType>
+    typename std::enable_if<!_fusable<O, V, ValueType>::value, bool>::type
+        FusedLoop_(const VectorType&, VectorType*, bool)
+    {
+        return false;
+    }
+
     // bicgstab.cpp:245-361 / :365-489 (right preconditioned: z = M^-1 p, v = M^-1 r)
     void Solve_(const VectorType& rhs, VectorType* x, bool precond)
     {
@@ -1649,9 +1734,11 @@ private:
             return;
         r->CopyFrom(*r0);
         p->CopyFrom(*r);
-        rho = r->Dot(*r);
         if(precond)
             this->precond_->SolveZeroSol(*r, z);
+        if(this->fused_ && this->res_norm_type_ == 2 && this->FusedLoop_(rhs, x, precond))
+            return;
+        rho = r->Dot(*r);
         while(true)
         {
             const VectorType* dir = precond ? z : p;

@@ -181,6 +181,8 @@ int ramd_scalars_fetch_async_end(int record, double* host, int count);
 
 /* y = A x  and  s[slot_dot] = <x, y>   (cg.cpp:415-418: q = A p ; p.q) */
 int ramd_fused_apply_dot(ramd_mat_t m, ramd_vec_t x, ramd_vec_t y, int slot_dot);
+/* y = A x  and  s[slot_dot] = <w, y>   (bicgstab.cpp:397-400: q = A z ; r0.q) */
+int ramd_fused_apply_dotv(ramd_mat_t m, ramd_vec_t x, ramd_vec_t y, ramd_vec_t w, int slot_dot);
 /* y += scalar * A x  and  s[slot_dot] = <p, y>, GIVEN that s[slot_dot] already holds <p, y> of the
  * incoming y: only the rows A touches are corrected (the ghost part of GlobalMatrix::Apply,
  * global_matrix.cpp:1001-1007, followed by the interior part of GlobalVector::Dot,
@@ -189,6 +191,20 @@ int ramd_fused_apply_add_dot(ramd_mat_t m, ramd_vec_t x, double scalar, ramd_vec
                              int slot_dot);
 /* alpha = s[slot_rho] / s[slot_pq];  r += (-alpha) q;  s[slot_rr] = <r,r>;
  * if dinv: z = dinv * r, s[slot_rz] = <r,z>   else s[slot_rz] = <r,r>            (cg.cpp:418-438) */
+/* BiCGStab (bicgstab.cpp:365-489) with its scalars on the device: alpha = s[rho]/s[r0q],
+ * omega = s[tr]/s[tr+1] (<t,r>, <t,t>), beta = (s[new]/s[rho]) * (alpha/omega).
+ *   r_update : r += (-alpha) q
+ *   xr_update: x = 1*x + alpha*dir + omega*sv ; r += (-omega) t ; s[rr] = <r,r> ; s[new] = <r0,r> ; s[flag] = 0
+ *              (dir = sv = NULL: the unpreconditioned form, dir = p and sv = old r);
+ *              omega 0/NaN/Inf: only x += alpha*p and s[flag] = 1 -- the caller runs the reference's
+ *              breakdown branch (:430-447)
+ *   direction: p = beta*p + (-beta*omega)*q + 1*r */
+int ramd_fused_bicg_r_update(ramd_vec_t r, ramd_vec_t q, int slot_rho, int slot_r0q);
+int ramd_fused_bicg_xr_update(ramd_vec_t x, ramd_vec_t dir, ramd_vec_t sv, ramd_vec_t r, ramd_vec_t t,
+                              ramd_vec_t r0, ramd_vec_t p, int slot_rho, int slot_r0q, int slot_tr,
+                              int slot_rr, int slot_new, int slot_flag);
+int ramd_fused_bicg_direction(ramd_vec_t p, ramd_vec_t q, ramd_vec_t r, int slot_rho, int slot_r0q, int slot_tr,
+                              int slot_new);
 int ramd_fused_cg_update(ramd_vec_t r, ramd_vec_t q, ramd_vec_t dinv, ramd_vec_t z, int slot_rho,
                          int slot_pq, int slot_rr, int slot_rz);
 /* alpha = s[slot_rho] / s[slot_pq];  beta = s[slot_new] / s[slot_rho];

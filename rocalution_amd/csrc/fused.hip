@@ -239,6 +239,136 @@ __global__ __launch_bounds__(kBlock) void k_normalize(int64_t n, T* __restrict__
         scalars[slot_norm] = (double)nrm;
 }
 
+// ---- BiCGStab (src/solvers/krylov/bicgstab.cpp:245-361 / :365-489), three fused updates.
+// Scalars come from the device record: alpha = rho / <r0,q>, omega = <t,r> / <t,t>,
+// beta = (rho_new / rho) * (alpha / omega) -- the host's expressions, evaluated in T.
+//   r = r + (-alpha) q                                          (r->AddScale(*q, -alpha))
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_bicg_r_update(int64_t n, T* __restrict__ r, const T* __restrict__ q,
+                                                          const double* __restrict__ scalars, int slot_rho,
+                                                          int slot_r0q)
+{
+    using P          = typename Pack<T>::type;
+    constexpr int NP = Pack<T>::N;
+    const T       malpha = -((T)scalars[slot_rho] / (T)scalars[slot_r0q]);
+    int64_t       np   = n / NP;
+    int64_t       gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t       gsz  = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = gtid; i < np; i += gsz)
+    {
+        P pr = reinterpret_cast<P*>(r)[i];
+        P pq = reinterpret_cast<const P*>(q)[i];
+#pragma unroll
+        for(int k = 0; k < NP; ++k)
+            pk_elems<T>(pr)[k] = pk_elems<T>(pr)[k] + malpha * pk_elems<T>(pq)[k];
+        reinterpret_cast<P*>(r)[i] = pr;
+    }
+    for(int64_t i = np * NP + gtid; i < n; i += gsz)
+        r[i] = r[i] + malpha * q[i];
+}
+
+//   omega valid:  x = one*x + alpha*dir + omega*sv   (x->ScaleAdd2(one, dir, alpha, sv, omega))
+//                 r = r + (-omega) t ; s[rr] = <r,r> ; s[rho_new] = <r0,r>
+//   omega == 0 / NaN / Inf:  x = x + alpha*p only, s[flag] = 1 (the host then runs the reference's
+//                 breakdown branch, bicgstab.cpp:430-447)
+//   PRECOND false: dir == p and sv == r (the old r), so they are not passed separately
+template <typename T, bool PRECOND>
+__global__ __launch_bounds__(kBlock) void k_bicg_xr_update(int64_t n, T* __restrict__ x, const T* __restrict__ dir,
+                                                           const T* __restrict__ sv, T* __restrict__ r,
+                                                           const T* __restrict__ t, const T* __restrict__ r0,
+                                                           const T* __restrict__ p, ReduceCtx ctx, int slot_rho,
+                                                           int slot_r0q, int slot_tr, int slot_rr,
+                                                           int slot_new, int slot_flag)
+{
+    using P          = typename Pack<T>::type;
+    constexpr int NP = Pack<T>::N;
+    __shared__ double lds[12];
+    const T    alpha = (T)ctx.scalars[slot_rho] / (T)ctx.scalars[slot_r0q];
+    const T    omega = (T)ctx.scalars[slot_tr] / (T)ctx.scalars[slot_tr + 1];
+    const T    one   = (T)1;
+    const bool bad   = (fabs((double)omega) == INFINITY) || (omega != omega) || (omega == (T)0);
+    const T    mo    = -omega;
+    int64_t    np    = n / NP;
+    int64_t    gtid  = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t    gsz   = (int64_t)gridDim.x * blockDim.x;
+    double     rr = 0.0, rn = 0.0;
+    if(bad)
+    {
+        for(int64_t i = gtid; i < n; i += gsz)
+            x[i] = x[i] + alpha * p[i];
+    }
+    else
+    {
+        for(int64_t i = gtid; i < np; i += gsz)
+        {
+            P px = reinterpret_cast<P*>(x)[i];
+            P pr = reinterpret_cast<P*>(r)[i];
+            P pt = reinterpret_cast<const P*>(t)[i];
+            P p0 = reinterpret_cast<const P*>(r0)[i];
+            P pd = PRECOND ? reinterpret_cast<const P*>(dir)[i] : reinterpret_cast<const P*>(p)[i];
+            P ps = PRECOND ? reinterpret_cast<const P*>(sv)[i] : pr;
+#pragma unroll
+            for(int k = 0; k < NP; ++k)
+            {
+                pk_elems<T>(px)[k] = one * pk_elems<T>(px)[k] + alpha * pk_elems<T>(pd)[k] + omega * pk_elems<T>(ps)[k];
+                const T rnew       = pk_elems<T>(pr)[k] + mo * pk_elems<T>(pt)[k];
+                pk_elems<T>(pr)[k] = rnew;
+                rr += (double)rnew * (double)rnew;
+                rn += (double)pk_elems<T>(p0)[k] * (double)rnew;
+            }
+            reinterpret_cast<P*>(x)[i] = px;
+            reinterpret_cast<P*>(r)[i] = pr;
+        }
+        for(int64_t i = np * NP + gtid; i < n; i += gsz)
+        {
+            const T dv = PRECOND ? dir[i] : p[i];
+            const T s0 = PRECOND ? sv[i] : r[i];
+            x[i]         = one * x[i] + alpha * dv + omega * s0;
+            const T rnew = r[i] + mo * t[i];
+            r[i]         = rnew;
+            rr += (double)rnew * (double)rnew;
+            rn += (double)r0[i] * (double)rnew;
+        }
+    }
+    if(gtid == 0)
+        ctx.scalars[slot_flag] = bad ? 1.0 : 0.0;
+    const double vals[2]  = {rr, rn};
+    const int    slots[2] = {slot_rr, slot_new};
+    const int    ops[2]   = {RED_SUM, RED_SUM};
+    grid_reduce_finish<2>(ctx, vals, slots, ops, lds);
+}
+
+//   p = beta*p + (-beta*omega)*q + one*r                 (p->ScaleAdd2(beta, *q, -beta * omega, *r, one))
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_bicg_direction(int64_t n, T* __restrict__ p, const T* __restrict__ q,
+                                                           const T* __restrict__ r,
+                                                           const double* __restrict__ scalars, int slot_rho,
+                                                           int slot_r0q, int slot_tr, int slot_new)
+{
+    using P          = typename Pack<T>::type;
+    constexpr int NP = Pack<T>::N;
+    const T       alpha = (T)scalars[slot_rho] / (T)scalars[slot_r0q];
+    const T       omega = (T)scalars[slot_tr] / (T)scalars[slot_tr + 1];
+    const T       beta  = ((T)scalars[slot_new] / (T)scalars[slot_rho]) * (alpha / omega);
+    const T       mbo   = -beta * omega;
+    const T       one   = (T)1;
+    int64_t       np    = n / NP;
+    int64_t       gtid  = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t       gsz   = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = gtid; i < np; i += gsz)
+    {
+        P pp = reinterpret_cast<P*>(p)[i];
+        P pq = reinterpret_cast<const P*>(q)[i];
+        P pr = reinterpret_cast<const P*>(r)[i];
+#pragma unroll
+        for(int k = 0; k < NP; ++k)
+            pk_elems<T>(pp)[k] = beta * pk_elems<T>(pp)[k] + mbo * pk_elems<T>(pq)[k] + one * pk_elems<T>(pr)[k];
+        reinterpret_cast<P*>(p)[i] = pp;
+    }
+    for(int64_t i = np * NP + gtid; i < n; i += gsz)
+        p[i] = beta * p[i] + mbo * q[i] + one * r[i];
+}
+
 } // namespace ramd
 
 using namespace ramd;
@@ -295,6 +425,112 @@ int ramd_fused_apply_add_dot(ramd_mat_t m, ramd_vec_t x, double scalar, ramd_vec
     RAMD_TRY(ramd_mat_apply_add(m, x, scalar, y));
     const ramd_vec_t vs[1] = {p};
     return ramd_fused_multi_dot(vs, 1, y, slot_dot);
+}
+
+int ramd_fused_apply_dotv(ramd_mat_t m, ramd_vec_t x, ramd_vec_t y, ramd_vec_t w, int slot_dot)
+{
+    if(!m || !x || !y || !w || !slot_ok(slot_dot))
+        RAMD_FAIL(RAMD_ERR_ARG, "fused_apply_dotv: bad arguments");
+    if(x->dtype != m->dtype || y->dtype != m->dtype || w->dtype != m->dtype || x->n != m->ncol || y->n != m->nrow
+       || w->n != m->nrow || x == y || w == y)
+        RAMD_FAIL(RAMD_ERR_ARG, "fused_apply_dotv: vector sizes/types do not match the matrix");
+    int s = (m->dtype == RAMD_F64) ? mat_apply_dot_impl<double>(m, (const double*)x->d, (double*)y->d, slot_dot,
+                                                                (const double*)w->d)
+                                   : mat_apply_dot_impl<float>(m, (const float*)x->d, (float*)y->d, slot_dot,
+                                                               (const float*)w->d);
+    if(s != RAMD_ERR_UNSUPPORTED)
+        return s;
+    RAMD_TRY(ramd_mat_apply(m, x, y));
+    const ramd_vec_t vs[1] = {w};
+    return ramd_fused_multi_dot(vs, 1, y, slot_dot);
+}
+
+int ramd_fused_bicg_r_update(ramd_vec_t r, ramd_vec_t q, int slot_rho, int slot_r0q)
+{
+    CHECK_SAMEV(r, q);
+    if(!slot_ok(slot_rho) || !slot_ok(slot_r0q) || r == q)
+        RAMD_FAIL(RAMD_ERR_ARG, "bicg_r_update: bad arguments");
+    if(r->n == 0)
+        return RAMD_OK;
+    Backend&  b    = backend();
+    const int grid = ew_grid((r->n + 1) / 2);
+    if(r->dtype == RAMD_F64)
+        hipLaunchKernelGGL((k_bicg_r_update<double>), dim3(grid), dim3(kBlock), 0, b.cur, r->n, (double*)r->d,
+                           (const double*)q->d, b.d_scalars, slot_rho, slot_r0q);
+    else
+        hipLaunchKernelGGL((k_bicg_r_update<float>), dim3(grid), dim3(kBlock), 0, b.cur, r->n, (float*)r->d,
+                           (const float*)q->d, b.d_scalars, slot_rho, slot_r0q);
+    RAMD_HIP(hipGetLastError());
+    return RAMD_OK;
+}
+
+int ramd_fused_bicg_xr_update(ramd_vec_t x, ramd_vec_t dir, ramd_vec_t sv, ramd_vec_t r, ramd_vec_t t,
+                              ramd_vec_t r0, ramd_vec_t p, int slot_rho, int slot_r0q, int slot_tr,
+                              int slot_rr, int slot_new, int slot_flag)
+{
+    CHECK_SAMEV(x, r);
+    CHECK_SAMEV(x, t);
+    CHECK_SAMEV(x, r0);
+    CHECK_SAMEV(x, p);
+    const bool precond = (dir != NULL) || (sv != NULL);
+    if(precond)
+    {
+        CHECK_SAMEV(x, dir);
+        CHECK_SAMEV(x, sv);
+    }
+    if(!slot_ok(slot_rho) || !slot_ok(slot_r0q) || !slot_ok(slot_tr) || !slot_ok(slot_tr + 1) || !slot_ok(slot_rr)
+       || !slot_ok(slot_new) || !slot_ok(slot_flag))
+        RAMD_FAIL(RAMD_ERR_ARG, "scalar slot out of range");
+    if(x->n == 0)
+        return RAMD_OK;
+    Backend&  b    = backend();
+    const int grid = reduce_grid((x->n + 1) / 2);
+    ReduceCtx ctx  = reduce_ctx();
+#define GO(T, PC)                                                                                              \
+    hipLaunchKernelGGL((k_bicg_xr_update<T, PC>), dim3(grid), dim3(kBlock), 0, b.cur, x->n, (T*)x->d,          \
+                       (const T*)(dir ? dir->d : NULL), (const T*)(sv ? sv->d : NULL), (T*)r->d, (const T*)t->d, \
+                       (const T*)r0->d, (const T*)p->d, ctx, slot_rho, slot_r0q, slot_tr, slot_rr, slot_new,   \
+                       slot_flag)
+    if(x->dtype == RAMD_F64)
+    {
+        if(precond)
+            GO(double, true);
+        else
+            GO(double, false);
+    }
+    else
+    {
+        if(precond)
+            GO(float, true);
+        else
+            GO(float, false);
+    }
+#undef GO
+    RAMD_HIP(hipGetLastError());
+    return RAMD_OK;
+}
+
+int ramd_fused_bicg_direction(ramd_vec_t p, ramd_vec_t q, ramd_vec_t r, int slot_rho, int slot_r0q, int slot_tr,
+                              int slot_new)
+{
+    CHECK_SAMEV(p, q);
+    CHECK_SAMEV(p, r);
+    if(!slot_ok(slot_rho) || !slot_ok(slot_r0q) || !slot_ok(slot_tr) || !slot_ok(slot_tr + 1) || !slot_ok(slot_new))
+        RAMD_FAIL(RAMD_ERR_ARG, "scalar slot out of range");
+    if(p->n == 0)
+        return RAMD_OK;
+    Backend&  b    = backend();
+    const int grid = ew_grid((p->n + 1) / 2);
+    if(p->dtype == RAMD_F64)
+        hipLaunchKernelGGL((k_bicg_direction<double>), dim3(grid), dim3(kBlock), 0, b.cur, p->n, (double*)p->d,
+                           (const double*)q->d, (const double*)r->d, b.d_scalars, slot_rho, slot_r0q, slot_tr,
+                           slot_new);
+    else
+        hipLaunchKernelGGL((k_bicg_direction<float>), dim3(grid), dim3(kBlock), 0, b.cur, p->n, (float*)p->d,
+                           (const float*)q->d, (const float*)r->d, b.d_scalars, slot_rho, slot_r0q, slot_tr,
+                           slot_new);
+    RAMD_HIP(hipGetLastError());
+    return RAMD_OK;
 }
 
 int ramd_fused_cg_update(ramd_vec_t r, ramd_vec_t q, ramd_vec_t dinv, ramd_vec_t z, int slot_rho,

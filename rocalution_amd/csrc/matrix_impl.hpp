@@ -30,7 +30,7 @@ int multicoloring_device(const ramd_mat_s* m, int* num_colors, int* size_colors,
 template <typename T>
 int mat_apply_impl(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar);
 template <typename T>
-int mat_apply_dot_impl(const ramd_mat_s* m, const T* x, T* y, int slot);
+int mat_apply_dot_impl(const ramd_mat_s* m, const T* x, T* y, int slot, const T* dotv = nullptr);
 template <typename T>
 int mat_apply_add_dot_impl(const ramd_mat_s* m, const T* x, T* y, T scalar, const T* p, int slot);
 

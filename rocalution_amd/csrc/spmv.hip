@@ -70,7 +70,8 @@ struct ValPk<float>
 // workspace of the fused <x, y> epilogue
 struct CsrDotWs
 {
-    double* part1; // [4 * nblk] one partial per wave
+    double*     part1; // [4 * nblk] one partial per wave
+    const void* dotv; // the dot runs against this vector (nullptr: against x)
 };
 
 // CSR SpMV, "LDS transpose" layout.  Measured on MI355X (tools/spmv_lab.py): the kernel is bound by
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(kBlock) void k_csr_tr(int nrow, int nblk, int per_x
             sum = y[row];
         T xrow = (T)0; // for the fused <x,y>: fetched up front so its latency hides behind the stream
         if(DOT && row < nrow)
-            xrow = x[row];
+            xrow = ws.dotv ? static_cast<const T*>(ws.dotv)[row] : x[row];
         for(int cb = start & ~3; cb < end; cb += kCsrChunk)
         {
             v4i32 c[kCsrChunk / (4 * kBlock)];
@@ -213,7 +214,8 @@ __global__ __launch_bounds__(kBlock) void k_ell(int nrow, int ncol, int width,
                                                 const int* __restrict__ ecol,
                                                 const T* __restrict__ eval,
                                                 const T* __restrict__ x, T* __restrict__ y, T scalar,
-                                                double* __restrict__ part1, int nblk, int per_xcd, BandMap bm)
+                                                double* __restrict__ part1, const T* __restrict__ dotv,
+                                                int nblk, int per_xcd, BandMap bm)
 {
     double dacc = 0.0;
     // one workgroup per 256 rows, XCD- and band-aware order (same mapping as the CSR kernel)
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(kBlock) void k_ell(int nrow, int ncol, int width,
         }
         nt_store(sum, y + row);
         if(DOT)
-            dacc += (double)sum * (double)x[row];
+            dacc += (double)sum * (double)(dotv ? dotv[row] : x[row]);
     }
     if(DOT) // one partial per wave, summed in fixed order by a second tiny launch (as the CSR kernel)
     {
@@ -388,7 +390,8 @@ int csr_analyse_band(ramd_mat_s* m)
 static BandMap band_map_for(const ramd_mat_s* m, int per_xcd);
 
 template <typename T>
-static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar, bool dot, int slot)
+static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar, bool dot, int slot,
+                      const T* dotv = nullptr)
 {
     Backend&  b       = backend();
     const int nblk    = (m->nrow + kCsrRows - 1) / kCsrRows;
@@ -411,6 +414,7 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
             mm->dot_nblk = nblk;
         }
         ws.part1 = mm->dot_part1;
+        ws.dotv  = dotv;
     }
     if(dot)
         prof_spmv_begin();
@@ -451,7 +455,7 @@ static BandMap band_map_for(const ramd_mat_s* m, int per_xcd)
 
 template <typename T>
 static int launch_ell(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar, bool stop, bool dot = false,
-                      int slot = 0)
+                      int slot = 0, const T* dotv = nullptr)
 {
     Backend&      b       = backend();
     const int     nblk    = (m->nrow + kCsrRows - 1) / kCsrRows;
@@ -473,7 +477,7 @@ static int launch_ell(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
 #define LAUNCH(MODE, STOP, DOT)                                                                        \
     hipLaunchKernelGGL((k_ell<T, MODE, STOP, DOT>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow,       \
                        m->ncol, m->ell_width, m->ell_col, (const T*)m->ell_val, x, y, scalar, part1, \
-                       nblk, per_xcd, bm)
+                       dotv, nblk, per_xcd, bm)
     if(dot && stop)
         LAUNCH(0, true, true);
     else if(dot)
@@ -564,14 +568,14 @@ template int mat_apply_impl<double>(const ramd_mat_s*, const double*, double*, i
 template int mat_apply_impl<float>(const ramd_mat_s*, const float*, float*, int, float);
 
 template <typename T>
-int mat_apply_dot_impl(const ramd_mat_s* m, const T* x, T* y, int slot)
+int mat_apply_dot_impl(const ramd_mat_s* m, const T* x, T* y, int slot, const T* dotv)
 {
     if(m->format == RAMD_CSR && m->nnz > 0 && m->nrow == m->ncol)
-        return launch_csr<T>(m, x, y, 0, (T)1, true, slot); // bracketed inside (SpMV kernel only)
+        return launch_csr<T>(m, x, y, 0, (T)1, true, slot, dotv); // bracketed inside (SpMV kernel only)
     if((m->format == RAMD_ELL || m->format == RAMD_HYB) && m->ell_width > 0 && m->nrow == m->ncol && m->nrow > 0)
     {
         prof_spmv_begin();
-        int s = launch_ell<T>(m, x, y, 0, (T)1, m->format == RAMD_ELL, true, slot);
+        int s = launch_ell<T>(m, x, y, 0, (T)1, m->format == RAMD_ELL, true, slot, dotv);
         prof_spmv_end();
         RAMD_TRY(s);
         if(m->format == RAMD_HYB && m->coo_nnz > 0) // tail: y += COO x, the dot corrected on the touched rows
@@ -579,8 +583,8 @@ int mat_apply_dot_impl(const ramd_mat_s* m, const T* x, T* y, int slot)
             Backend&  b    = backend();
             const int grid = reduce_grid(m->coo_ngroups);
             hipLaunchKernelGGL((k_coo_grouped_dot<T>), dim3(grid), dim3(kBlock), 0, b.cur, m->coo_ngroups,
-                               m->coo_grow, m->coo_gptr, m->coo_col, (const T*)m->coo_val, x, y, (T)1, x,
-                               reduce_ctx(), slot);
+                               m->coo_grow, m->coo_gptr, m->coo_col, (const T*)m->coo_val, x, y, (T)1,
+                               dotv ? dotv : x, reduce_ctx(), slot);
             RAMD_HIP(hipGetLastError());
         }
         return RAMD_OK;
@@ -604,7 +608,7 @@ int mat_apply_add_dot_impl(const ramd_mat_s* m, const T* x, T* y, T scalar, cons
 }
 template int mat_apply_add_dot_impl<double>(const ramd_mat_s*, const double*, double*, double, const double*, int);
 template int mat_apply_add_dot_impl<float>(const ramd_mat_s*, const float*, float*, float, const float*, int);
-template int mat_apply_dot_impl<double>(const ramd_mat_s*, const double*, double*, int);
-template int mat_apply_dot_impl<float>(const ramd_mat_s*, const float*, float*, int);
+template int mat_apply_dot_impl<double>(const ramd_mat_s*, const double*, double*, int, const double*);
+template int mat_apply_dot_impl<float>(const ramd_mat_s*, const float*, float*, int, const float*);
 
 } // namespace ramd

@@ -417,3 +417,65 @@ def test_fused_apply_dot_all_formats(ra, name):
         out = (C.c_double * 1)()
         capi.check(lib.ramd_scalars_fetch(out, 7, 1))
         close(out[0], float(np.dot(g["x"], y.numpy())), 1e-12)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("precond", [False, True])
+def test_fused_bicgstab_updates(ra, dtype, precond):
+    """the three BiCGStab update kernels against the unfused vector ops (bit-exact vectors), incl. the
+    omega breakdown branch"""
+    import ctypes as C
+    from rocalution_amd import capi
+    lib = capi.load()
+    rng = np.random.default_rng(17)
+    n = 100003
+    mk = lambda: rng.uniform(-1, 1, n).astype(dtype)
+    x, d, sv, r, t, r0, p, q = (mk() for _ in range(8))
+    rho, r0q, tr, tt = 0.731, -1.917, 0.377, 2.113
+    S_TR, S_R0Q, S_RHO, S_RR, S_NEW, S_FLAG = 0, 2, 3, 4, 5, 6
+    T = dtype
+
+    def setslots(tr_):
+        for s_, v_ in ((S_RHO, rho), (S_R0Q, r0q), (S_TR, tr_), (S_TR + 1, tt)):
+            capi.check(lib.ramd_scalars_set(s_, float(v_)))
+
+    V = lambda a: ra.LocalVector(dtype, data=a)
+    alpha = T(T(rho) / T(r0q)); omega = T(T(tr) / T(tt))
+    # r_update == AddScale(q, -alpha)
+    setslots(tr)
+    vr, vq = V(r), V(q)
+    capi.check(lib.ramd_fused_bicg_r_update(vr._h, vq._h, S_RHO, S_R0Q))
+    ref = V(r); ref.AddScale(vq, float(-alpha))
+    eq(vr.numpy(), ref.numpy())
+    # xr_update == ScaleAdd2 + AddScale + two dots
+    vx, vd, vs, vr, vt, v0, vp = V(x), V(d), V(sv), V(r), V(t), V(r0), V(p)
+    capi.check(lib.ramd_fused_bicg_xr_update(vx._h, vd._h if precond else None, vs._h if precond else None, vr._h,
+                                             vt._h, v0._h, vp._h, S_RHO, S_R0Q, S_TR, S_RR, S_NEW, S_FLAG))
+    rx, rr_ = V(x), V(r)
+    if precond:
+        rx.ScaleAdd2(1.0, vd, float(alpha), vs, float(omega))
+    else:
+        rx.ScaleAdd2(1.0, vp, float(alpha), V(r), float(omega))
+    rr_.AddScale(vt, float(-omega))
+    eq(vx.numpy(), rx.numpy()); eq(vr.numpy(), rr_.numpy())
+    out = (C.c_double * 7)()
+    capi.check(lib.ramd_scalars_fetch(out, 0, 7))
+    rn = rr_.numpy().astype(np.float64)
+    tol = 1e-12 if dtype == np.float64 else 1e-6
+    close(out[S_RR], float(rn @ rn), tol); close(out[S_NEW], float(r0.astype(np.float64) @ rn), tol)
+    assert out[S_FLAG] == 0.0
+    # direction == ScaleAdd2(beta, q, -beta*omega, r, 1) with beta from the record
+    beta = T(T(T(out[S_NEW]) / T(rho)) * T(alpha / omega))
+    vp2 = V(p)
+    capi.check(lib.ramd_fused_bicg_direction(vp2._h, vq._h, vr._h, S_RHO, S_R0Q, S_TR, S_NEW))
+    rp_ = V(p); rp_.ScaleAdd2(float(beta), vq, float(T(-beta) * omega), vr, 1.0)
+    eq(vp2.numpy(), rp_.numpy())
+    # breakdown: <t,r> = 0 -> omega = 0 -> only x += alpha p, flag raised, r untouched
+    setslots(0.0)
+    vx, vr = V(x), V(r)
+    capi.check(lib.ramd_fused_bicg_xr_update(vx._h, vd._h if precond else None, vs._h if precond else None, vr._h,
+                                             vt._h, v0._h, vp._h, S_RHO, S_R0Q, S_TR, S_RR, S_NEW, S_FLAG))
+    rx = V(x); rx.AddScale(vp, float(alpha))
+    eq(vx.numpy(), rx.numpy()); eq(vr.numpy(), r)
+    capi.check(lib.ramd_scalars_fetch(out, 0, 7))
+    assert out[S_FLAG] == 1.0
