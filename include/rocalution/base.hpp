@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cassert>
 #include <chrono>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -290,6 +291,33 @@ public:
             RAMD_CHECK(ramd_vec_set_values(this->dev_, (double)val));
         else
             std::fill(this->host_.begin(), this->host_.end(), val);
+    }
+    // HostVector::SetRandomUniform / SetRandomNormal (src/base/host/host_vector.cpp:374-405): the C
+    // library's srand/rand sequence (Box-Muller for the normal variant).  Generated on the host exactly
+    // as the reference's host backend does and uploaded when the vector lives on the accelerator.
+    void SetRandomUniform(unsigned long long seed, ValueType a = static_cast<ValueType>(-1),
+                          ValueType b = static_cast<ValueType>(1))
+    {
+        assert(a <= b);
+        std::vector<ValueType> h((size_t)this->GetSize());
+        srand((unsigned)seed);
+        for(size_t i = 0; i < h.size(); ++i)
+            h[i] = a + static_cast<ValueType>(rand()) / static_cast<ValueType>(RAND_MAX) * (b - a);
+        this->CopyFromHostData(h.data());
+    }
+    void SetRandomNormal(unsigned long long seed, ValueType mean = static_cast<ValueType>(0),
+                         ValueType var = static_cast<ValueType>(1))
+    {
+        std::vector<ValueType> h((size_t)this->GetSize());
+        srand((unsigned)seed);
+        for(size_t i = 0; i < h.size(); ++i)
+        {
+            ValueType u1 = static_cast<ValueType>(rand()) / static_cast<ValueType>(RAND_MAX);
+            ValueType u2 = static_cast<ValueType>(rand()) / static_cast<ValueType>(RAND_MAX);
+            h[i] = std::sqrt(static_cast<ValueType>(-2) * std::log(u1)) * std::cos(static_cast<ValueType>(2 * 3.14159265358979323846) * u2);
+            h[i] = mean + var * h[i];
+        }
+        this->CopyFromHostData(h.data());
     }
     ValueType& operator[](int64_t i)
     {

@@ -238,6 +238,17 @@ public:
     {
         this->vector_interior_.SetValues(val);
     }
+    // global_vector.cpp:317-330: every rank fills its interior part from the same seed
+    void SetRandomUniform(unsigned long long seed, ValueType a = static_cast<ValueType>(-1),
+                          ValueType b = static_cast<ValueType>(1))
+    {
+        this->vector_interior_.SetRandomUniform(seed, a, b);
+    }
+    void SetRandomNormal(unsigned long long seed, ValueType mean = static_cast<ValueType>(0),
+                         ValueType var = static_cast<ValueType>(1))
+    {
+        this->vector_interior_.SetRandomNormal(seed, mean, var);
+    }
     void CopyFrom(const GlobalVector<ValueType>& src)
     {
         this->vector_interior_.CopyFrom(src.vector_interior_);

@@ -14,6 +14,8 @@
 // of 8 launches and 3 blocking reads, with the read-back hidden behind the next SpMV.
 #pragma once
 
+#include <ctime>
+
 #include <cmath>
 #include <limits>
 
@@ -2426,6 +2428,260 @@ private:
         this->iter_ctrl_.CheckResidual(std::abs(this->Norm_(*r0)));
     }
     VectorType r0_, r_, p_, t_, v_, d_, z_;
+};
+
+// ============================================================================ IDR(s)
+// src/solvers/krylov/idr.cpp: Build :127-185 (shadow space: s random-normal vectors, seed (i+1)*seed_,
+// made orthonormal by modified Gram-Schmidt), SolveNonPrecond_ :335-520, SolvePrecond_ :523-730.
+// The default seed is time(NULL) as in the reference: call SetRandomSeed for reproducible runs.
+template <class OperatorType, class VectorType, typename ValueType>
+class IDR : public IterativeLinearSolver<OperatorType, VectorType, ValueType>
+{
+public:
+    IDR()
+        : s_(4)
+        , seed_((unsigned long long)time(NULL))
+        , kappa_(static_cast<ValueType>(0.7f))
+        , G_(NULL)
+        , U_(NULL)
+        , P_(NULL)
+    {
+    }
+    virtual ~IDR()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("IDR(" << this->s_ << ") solver" << (this->precond_ ? ", with preconditioner" : " (non-precond)"));
+    }
+    void SetShadowSpace(int s)
+    {
+        assert(this->build_ == false && s > 0);
+        this->s_ = s;
+    }
+    void SetRandomSeed(unsigned long long seed)
+    {
+        assert(this->build_ == false && seed > 0ULL);
+        this->seed_ = seed;
+    }
+    virtual void Build(void)
+    {
+        if(this->build_)
+            this->Clear();
+        assert(this->op_ != NULL && this->op_->GetM() == this->op_->GetN() && this->op_->GetM() > 0);
+        assert((int64_t)this->s_ <= this->op_->GetM());
+        const int s = this->s_;
+        this->r_.CloneBackend(*this->op_);
+        this->v_.CloneBackend(*this->op_);
+        this->r_.Allocate("r", this->op_->GetM());
+        this->v_.Allocate("v", this->op_->GetM());
+        this->c_.assign((size_t)s, ValueType(0));
+        this->f_.assign((size_t)s, ValueType(0));
+        this->M_.assign((size_t)s * s, ValueType(0));
+        this->G_ = new VectorType*[s];
+        this->U_ = new VectorType*[s];
+        this->P_ = new VectorType*[s];
+        for(int i = 0; i < s; ++i)
+        {
+            this->G_[i] = new VectorType;
+            this->U_[i] = new VectorType;
+            this->P_[i] = new VectorType;
+            this->G_[i]->CloneBackend(*this->op_);
+            this->U_[i]->CloneBackend(*this->op_);
+            this->P_[i]->CloneBackend(*this->op_);
+            this->G_[i]->Allocate("g", this->op_->GetM());
+            this->U_[i]->Allocate("u", this->op_->GetM());
+            this->P_[i]->Allocate("P", this->op_->GetM());
+            this->P_[i]->SetRandomNormal((unsigned long long)(i + 1) * this->seed_, 0.0, 1.0);
+        }
+        if(this->precond_ != NULL)
+        {
+            this->precond_->SetOperator(*this->op_);
+            this->precond_->Build();
+            this->t_.CloneBackend(*this->op_);
+            this->t_.Allocate("t", this->op_->GetM());
+        }
+        for(int k = 0; k < s; ++k) // orthonormal basis of the shadow space (modified Gram-Schmidt)
+        {
+            this->P_[k]->Scale(static_cast<ValueType>(1) / this->P_[k]->Norm());
+            ValueType invdotk = static_cast<ValueType>(1) / this->P_[k]->Dot(*this->P_[k]);
+            for(int j = k + 1; j < s; ++j)
+                this->P_[j]->AddScale(*this->P_[k], -this->P_[j]->Dot(*this->P_[k]) * invdotk);
+        }
+        this->build_ = true;
+    }
+    virtual void Clear(void)
+    {
+        if(this->build_)
+        {
+            this->r_.Clear();
+            this->v_.Clear();
+            this->t_.Clear();
+            for(int i = 0; i < this->s_; ++i)
+            {
+                delete this->U_[i];
+                delete this->G_[i];
+                delete this->P_[i];
+            }
+            delete[] this->U_;
+            delete[] this->G_;
+            delete[] this->P_;
+            this->U_ = this->G_ = this->P_ = NULL;
+            if(this->precond_ != NULL)
+            {
+                this->precond_->Clear();
+                this->precond_ = NULL;
+            }
+            this->iter_ctrl_.Clear();
+            this->build_ = false;
+        }
+    }
+
+protected:
+    virtual void PrintStart_(void) const
+    {
+        LOG_INFO((this->precond_ ? "PIDR(" : "IDR(") << this->s_ << (this->precond_ ? ") solver starts, with preconditioner:" : ") (non-precond) linear solver starts"));
+    }
+    virtual void PrintEnd_(void) const
+    {
+        LOG_INFO((this->precond_ ? "PIDR(" : "IDR(") << this->s_ << (this->precond_ ? ") ends" : ") (non-precond) ends"));
+    }
+    virtual void SolveNonPrecond_(const VectorType& rhs, VectorType* x)
+    {
+        this->Solve_(rhs, x, false);
+    }
+    virtual void SolvePrecond_(const VectorType& rhs, VectorType* x)
+    {
+        this->Solve_(rhs, x, true);
+    }
+
+private:
+    int mind_(int i, int j) const // DENSE_IND(i, j, s, s), column-major
+    {
+        return i + j * this->s_;
+    }
+    void Breakdown_(const char* what) const
+    {
+        LOG_INFO("IDR(s) break down ; " << what);
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+    void CheckScalar_(ValueType val, const char* z, const char* nan, const char* inf) const
+    {
+        if(val == static_cast<ValueType>(0))
+            this->Breakdown_(z);
+        if(val != val)
+            this->Breakdown_(nan);
+        if(val == std::numeric_limits<ValueType>::infinity())
+            this->Breakdown_(inf);
+    }
+    void Solve_(const VectorType& rhs, VectorType* x, bool precond)
+    {
+        const OperatorType* op = this->op_;
+        VectorType *        r = &this->r_, *v = &this->v_, *t = &this->t_;
+        VectorType **       G = this->G_, **U = this->U_, **P = this->P_;
+        const int           s = this->s_;
+        const ValueType     zero = static_cast<ValueType>(0), one = static_cast<ValueType>(1), kappa = this->kappa_;
+        ValueType *         c = this->c_.data(), *f = this->f_.data(), *M = this->M_.data();
+        ValueType           alpha, beta, rho, omega = one;
+        op->Apply(*x, r);
+        r->ScaleAdd(-one, rhs);
+        ValueType res_norm = this->Norm_(*r);
+        if(this->iter_ctrl_.InitResidual(std::abs(res_norm)) == false)
+            return;
+        for(int i = 0; i < s; ++i)
+        {
+            G[i]->Zeros();
+            U[i]->Zeros();
+            for(int j = 0; j < s; ++j)
+                M[this->mind_(i, j)] = (i == j) ? one : zero;
+        }
+        while(true)
+        {
+            for(int i = 0; i < s; ++i) // f = P^T r
+                f[i] = P[i]->Dot(*r);
+            for(int k = 0; k < s; ++k) // loop over the shadow space
+            {
+                v->CopyFrom(*r);
+                for(int i = k; i < s; ++i) // lower triangular system M c = f
+                {
+                    c[i] = f[i];
+                    for(int j = k; j < i; ++j)
+                        c[i] -= M[this->mind_(i, j)] * c[j];
+                    c[i] /= M[this->mind_(i, i)];
+                    v->AddScale(*G[i], -c[i]);
+                }
+                if(precond)
+                {
+                    this->precond_->SolveZeroSol(*v, t);
+                    U[k]->ScaleAddScale(c[k], *t, omega);
+                }
+                else
+                    U[k]->ScaleAddScale(c[k], *v, omega);
+                for(int i = k + 1; i < s; ++i)
+                    U[k]->AddScale(*U[i], c[i]);
+                op->Apply(*U[k], G[k]);
+                for(int i = 0; i < k; ++i) // make G_k orthogonal to P
+                {
+                    alpha = P[i]->Dot(*G[k]) / M[this->mind_(i, i)];
+                    G[k]->AddScale(*G[i], -alpha);
+                    U[k]->AddScale(*U[i], -alpha);
+                }
+                for(int i = k; i < s; ++i)
+                    M[this->mind_(i, k)] = P[i]->Dot(*G[k]);
+                this->CheckScalar_(M[this->mind_(k, k)], "M(k,k) == 0.0", "M(k,k) == NaN", "M(k,k) == inf");
+                beta = f[k] / M[this->mind_(k, k)];
+                r->AddScale(*G[k], -beta);
+                x->AddScale(*U[k], beta);
+                res_norm = this->Norm_(*r);
+                if(this->iter_ctrl_.CheckResidualNoCount(std::abs(res_norm)))
+                    break;
+                for(int i = k + 1; i < s; ++i)
+                    f[i] -= beta * M[this->mind_(i, k)];
+            }
+            if(this->iter_ctrl_.CheckResidual(std::abs(res_norm), this->index_))
+                break;
+            ValueType rt, nt; // dimension reduction step
+            if(precond)
+            {
+                this->precond_->SolveZeroSol(*r, v);
+                op->Apply(*v, t);
+                rt = t->Dot(*r);
+                nt = t->Norm();
+            }
+            else
+            {
+                op->Apply(*r, v);
+                rt = v->Dot(*r);
+                nt = v->Norm();
+            }
+            rt /= nt;
+            rho   = std::abs(rt / res_norm);
+            omega = rt / nt;
+            if(rho < kappa)
+                omega *= kappa / rho;
+            this->CheckScalar_(omega, "w == 0.0", "w == NaN", "w == inf");
+            if(precond)
+            {
+                r->AddScale(*t, -omega);
+                x->AddScale(*v, omega);
+            }
+            else
+            {
+                x->AddScale(*r, omega);
+                r->AddScale(*v, -omega);
+            }
+            res_norm = this->Norm_(*r);
+        }
+    }
+    int                    s_;
+    unsigned long long     seed_;
+    ValueType              kappa_;
+    VectorType             r_, v_, t_;
+    VectorType**           G_;
+    VectorType**           U_;
+    VectorType**           P_;
+    std::vector<ValueType> c_, f_, M_;
 };
 
 // ============================================================================ MixedPrecisionDC

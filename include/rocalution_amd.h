@@ -284,7 +284,8 @@ enum { RAMD_SOLVER_CG = 0, RAMD_SOLVER_GMRES = 1, RAMD_SOLVER_BICGSTAB = 2,
        /* src/solvers/krylov/{fcg,cr,fgmres,bicgstabl,qmrcgstab}.cpp; ramd_solver_set_basis sets the
         * restart length of (F)GMRES and the order l of BiCGStab(l) */
        RAMD_SOLVER_FCG = 3, RAMD_SOLVER_CR = 4, RAMD_SOLVER_FGMRES = 5, RAMD_SOLVER_BICGSTABL = 6,
-       RAMD_SOLVER_QMRCGSTAB = 7 };
+       RAMD_SOLVER_QMRCGSTAB = 7,
+       RAMD_SOLVER_IDR = 8 /* idr.cpp; set_basis = SetShadowSpace, ramd_solver_set_seed = SetRandomSeed */ };
 enum { RAMD_PC_NONE = 0, RAMD_PC_JACOBI = 1, RAMD_PC_ILU0 = 2, RAMD_PC_MCSGS = 3, RAMD_PC_MCGS = 4, RAMD_PC_MCILU = 5 };
 int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out);
 /* MixedPrecisionDC<fp64 outer, fp32 inner>: inner solver/preconditioner kinds */
@@ -294,6 +295,7 @@ int ramd_solver_init(ramd_solver_t s, double abs_tol, double rel_tol, double div
                      int max_iter); /* IterativeLinearSolver::Init */
 int ramd_solver_init_inner(ramd_solver_t s, double abs_tol, double rel_tol, double div_tol, int max_iter);
 int ramd_solver_set_basis(ramd_solver_t s, int size_basis); /* GMRES::SetBasisSize */
+int ramd_solver_set_seed(ramd_solver_t s, unsigned long long seed); /* IDR::SetRandomSeed (idr.cpp:277-285) */
 int ramd_solver_set_fused(ramd_solver_t s, int on); /* fused device loops on/off (default on) */
 int ramd_solver_set_verbose(ramd_solver_t s, int verb);
 int ramd_solver_set_precond_format(ramd_solver_t s, int format); /* MultiColored::SetPrecondMatrixFormat */

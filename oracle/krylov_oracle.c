@@ -18,6 +18,7 @@
  *
  * Build: oracle/Makefile  (gcc -O2 -ffp-contract=off -fopenmp)
  * ========================================================================== */
+#define _GNU_SOURCE 1 /* M_PI */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -295,7 +296,9 @@ int orc_csr_multicoloring(int nrow, int64_t nnz, const int* row_offset, const in
 #define SUF(x) x##_f32
 #define ORC_SQRT sqrtf
 #define ORC_FABS fabsf
+#define ORC_T_IS_FLOAT 1
 #include "krylov_oracle_impl.h"
+#undef ORC_T_IS_FLOAT
 #undef T
 #undef SUF
 #undef ORC_SQRT

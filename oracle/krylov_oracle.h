@@ -10,7 +10,7 @@ extern "C" {
 
 enum { ORC_CSR = 1, ORC_ELL = 6, ORC_HYB = 7 }; /* numbering of src/base/matrix_formats.hpp */
 enum { ORC_CG = 0, ORC_GMRES = 1, ORC_BICGSTAB = 2, ORC_FCG = 3, ORC_CR = 4, ORC_FGMRES = 5, ORC_BICGSTABL = 6,
-       ORC_QMRCGSTAB = 7 };
+       ORC_QMRCGSTAB = 7, ORC_IDR = 8 };
 enum { ORC_PC_NONE = 0, ORC_PC_JACOBI = 1, ORC_PC_ILU0 = 2, ORC_PC_MCSGS = 3, ORC_PC_MCGS = 4, ORC_PC_MCILU = 5 };
 #define ORC_PC_IS_MC(k) ((k) == ORC_PC_MCSGS || (k) == ORC_PC_MCGS || (k) == ORC_PC_MCILU)
 
@@ -20,7 +20,9 @@ typedef struct
     int    solver; /* ORC_CG / ORC_GMRES / ORC_BICGSTAB */
     int    precond; /* ORC_PC_* */
     int    format; /* operator format used by Apply during Solve */
-    int    basis; /* GMRES / FGMRES restart length (default 30, gmres.cpp:50); BiCGStab(l): l (default 2) */
+    int    basis; /* GMRES / FGMRES restart length (default 30, gmres.cpp:50); BiCGStab(l): l (default 2);
+                     IDR(s): s (default 4) */
+    unsigned long long seed; /* IDR: SetRandomSeed (shadow space P_i = SetRandomNormal((i+1)*seed)) */
     double abs_tol, rel_tol, div_tol; /* defaults 1e-15 / 1e-6 / 1e8 (iter_ctrl.cpp:52-56) */
     int    min_iter, max_iter;
     double* history; /* optional: residual per InitResidual/CheckResidual call */

@@ -1586,6 +1586,166 @@ static void SUF(solve_qmrcgstab)(const SUF(orc_op) * A, SUF(orc_pc) * P, const T
     free(z);
 }
 
+/* HostVector::SetRandomNormal (src/base/host/host_vector.cpp:388-405): srand/rand Box-Muller */
+void SUF(orc_set_random_normal)(int64_t n, T* v, unsigned long long seed, T mean, T var)
+{
+    srand((unsigned)seed);
+    for(int64_t i = 0; i < n; ++i)
+    {
+        T u1 = (T)rand() / (T)RAND_MAX;
+        T u2 = (T)rand() / (T)RAND_MAX;
+#ifdef ORC_T_IS_FLOAT
+        v[i] = sqrtf((T)-2 * logf(u1)) * cosf((T)(2 * M_PI) * u2);
+#else
+        v[i] = sqrt((T)-2 * log(u1)) * cos((T)(2 * M_PI) * u2);
+#endif
+        v[i] = mean + var * v[i];
+    }
+}
+
+/* src/solvers/krylov/idr.cpp: Build :127-185 (shadow space P: random normal vectors made orthonormal
+ * by modified Gram-Schmidt), SolveNonPrecond_ :335-520, SolvePrecond_ :523-730 */
+static void SUF(solve_idr)(const SUF(orc_op) * A, SUF(orc_pc) * P_, const T* rhs, T* x, orc_iter_ctrl* ic,
+                           int s, unsigned long long seed)
+{
+    int  n = A->nrow;
+    T*   r = (T*)calloc((size_t)n, sizeof(T));
+    T*   v = (T*)calloc((size_t)n, sizeof(T));
+    T*   t = (T*)calloc((size_t)n, sizeof(T));
+    T**  G = (T**)malloc(sizeof(T*) * (size_t)s);
+    T**  U = (T**)malloc(sizeof(T*) * (size_t)s);
+    T**  P = (T**)malloc(sizeof(T*) * (size_t)s);
+    T*   c = (T*)calloc((size_t)s, sizeof(T));
+    T*   f = (T*)calloc((size_t)s, sizeof(T));
+    T*   M = (T*)calloc((size_t)s * s, sizeof(T));
+#define MIND(i, j) ((i) + (j) * s)
+    const T zero = (T)0, one = (T)1, kappa = (T)0.7f;
+    T       alpha, beta, rho, omega = one;
+    for(int i = 0; i < s; ++i)
+    {
+        G[i] = (T*)calloc((size_t)n, sizeof(T));
+        U[i] = (T*)calloc((size_t)n, sizeof(T));
+        P[i] = (T*)calloc((size_t)n, sizeof(T));
+        SUF(orc_set_random_normal)(n, P[i], (unsigned long long)(i + 1) * seed, (T)0.0, (T)1.0);
+    }
+    for(int k = 0; k < s; ++k)
+    {
+        SUF(orc_scale)(n, P[k], one / SUF(orc_norm)(n, P[k]));
+        T invdotk = one / SUF(orc_dot)(n, P[k], P[k]);
+        for(int j = k + 1; j < s; ++j)
+            SUF(orc_add_scale)(n, P[j], P[k], -SUF(orc_dot)(n, P[j], P[k]) * invdotk);
+    }
+    SUF(residual)(A, rhs, x, r);
+    T res_norm = SUF(orc_norm)(n, r);
+    if(orc_ic_init_residual(ic, fabs((double)res_norm)))
+    {
+        for(int i = 0; i < s; ++i)
+            for(int j = 0; j < s; ++j)
+                M[MIND(i, j)] = (i == j) ? one : zero;
+        while(1)
+        {
+            for(int i = 0; i < s; ++i)
+                f[i] = SUF(orc_dot)(n, P[i], r);
+            int stop = 0;
+            for(int k = 0; k < s; ++k)
+            {
+                memcpy(v, r, sizeof(T) * (size_t)n);
+                for(int i = k; i < s; ++i)
+                {
+                    c[i] = f[i];
+                    for(int j = k; j < i; ++j)
+                        c[i] -= M[MIND(i, j)] * c[j];
+                    c[i] /= M[MIND(i, i)];
+                    SUF(orc_add_scale)(n, v, G[i], -c[i]);
+                }
+                if(P_)
+                {
+                    SUF(pc_solve)(P_, v, t);
+                    SUF(orc_scale_add_scale)(n, U[k], c[k], t, omega);
+                }
+                else
+                    SUF(orc_scale_add_scale)(n, U[k], c[k], v, omega);
+                for(int i = k + 1; i < s; ++i)
+                    SUF(orc_add_scale)(n, U[k], U[i], c[i]);
+                SUF(op_apply)(A, U[k], G[k]);
+                for(int i = 0; i < k; ++i)
+                {
+                    alpha = SUF(orc_dot)(n, P[i], G[k]) / M[MIND(i, i)];
+                    SUF(orc_add_scale)(n, G[k], G[i], -alpha);
+                    SUF(orc_add_scale)(n, U[k], U[i], -alpha);
+                }
+                for(int i = k; i < s; ++i)
+                    M[MIND(i, k)] = SUF(orc_dot)(n, P[i], G[k]);
+                if(M[MIND(k, k)] == zero || M[MIND(k, k)] != M[MIND(k, k)] || M[MIND(k, k)] == (T)INFINITY)
+                {
+                    stop = 2; /* the reference aborts here (FATAL_ERROR) */
+                    break;
+                }
+                beta = f[k] / M[MIND(k, k)];
+                SUF(orc_add_scale)(n, r, G[k], -beta);
+                SUF(orc_add_scale)(n, x, U[k], beta);
+                res_norm = SUF(orc_norm)(n, r);
+                if(orc_ic_check_residual_nocount(ic, fabs((double)res_norm)))
+                    break;
+                for(int i = k + 1; i < s; ++i)
+                    f[i] -= beta * M[MIND(i, k)];
+            }
+            if(stop == 2)
+                break;
+            if(orc_ic_check_residual(ic, fabs((double)res_norm)))
+                break;
+            T rt, nt;
+            if(P_)
+            {
+                SUF(pc_solve)(P_, r, v);
+                SUF(op_apply)(A, v, t);
+                rt = SUF(orc_dot)(n, t, r);
+                nt = SUF(orc_norm)(n, t);
+            }
+            else
+            {
+                SUF(op_apply)(A, r, v);
+                rt = SUF(orc_dot)(n, v, r);
+                nt = SUF(orc_norm)(n, v);
+            }
+            rt /= nt;
+            rho   = (T)fabs((double)(rt / res_norm));
+            omega = rt / nt;
+            if(rho < kappa)
+                omega *= kappa / rho;
+            if(omega == zero || omega != omega || omega == (T)INFINITY)
+                break; /* FATAL_ERROR in the reference */
+            if(P_)
+            {
+                SUF(orc_add_scale)(n, r, t, -omega);
+                SUF(orc_add_scale)(n, x, v, omega);
+            }
+            else
+            {
+                SUF(orc_add_scale)(n, x, r, omega);
+                SUF(orc_add_scale)(n, r, v, -omega);
+            }
+            res_norm = SUF(orc_norm)(n, r);
+        }
+    }
+#undef MIND
+    for(int i = 0; i < s; ++i)
+    {
+        free(G[i]);
+        free(U[i]);
+        free(P[i]);
+    }
+    free(G);
+    free(U);
+    free(P);
+    free(c);
+    free(f);
+    free(M);
+    free(r);
+    free(v);
+    free(t);
+}
+
 /* src/solvers/krylov/bicgstab.cpp:245-361 (no preconditioner) / :365-489 (right preconditioned) */
 static void SUF(solve_bicgstab)(const SUF(orc_op) * A, SUF(orc_pc) * P, const T* rhs, T* x,
                                 orc_iter_ctrl* ic)
@@ -1687,6 +1847,9 @@ int SUF(orc_solve)(int nrow, int64_t nnz, const int* row_offset, const int* col,
         SUF(solve_bicgstabl)(&A, have_pc ? &P : NULL, rhs, x, &ic, cfg->basis > 0 ? cfg->basis : 2);
     else if(cfg->solver == ORC_QMRCGSTAB)
         SUF(solve_qmrcgstab)(&A, have_pc ? &P : NULL, rhs, x, &ic);
+    else if(cfg->solver == ORC_IDR)
+        SUF(solve_idr)(&A, have_pc ? &P : NULL, rhs, x, &ic, cfg->basis > 0 ? cfg->basis : 4,
+                       cfg->seed ? cfg->seed : 1ULL);
     else
         return 0;
     orc_ic_finish(&ic, cfg);

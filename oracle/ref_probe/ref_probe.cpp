@@ -500,6 +500,27 @@ static int cmd_gen(const std::string& in, const std::string& out)
             ls.Clear();
         }
         {
+            IDR<MatD, VecD, double> ls; // default s = 4; the seed must be fixed (default: time(NULL))
+            ls.SetOperator(mat);
+            ls.SetRandomSeed(12345ULL);
+            ls.Build();
+            sol.Zeros();
+            run_solver("idr_none", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            IDR<MatD, VecD, double>    ls;
+            Jacobi<MatD, VecD, double> p;
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(p);
+            ls.SetShadowSpace(2);
+            ls.SetRandomSeed(777ULL);
+            ls.Build();
+            sol.Zeros();
+            run_solver("idr2_jacobi", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
             // operator converted AFTER Build, as the reference tests do (testing_cg.hpp:151-155)
             MatD e;
             e.CloneFrom(mat);

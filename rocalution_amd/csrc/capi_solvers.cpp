@@ -28,6 +28,7 @@ struct SolverBase
     virtual void set_precond_format(int) {}
     virtual void set_decomposition(bool) {}
     virtual void set_fused_sweeps(bool) {}
+    virtual void set_seed(unsigned long long) {}
     virtual void build(ramd_mat_t op)                                    = 0;
     virtual void solve(ramd_vec_t rhs, ramd_vec_t x)                     = 0;
     virtual bool precond_apply(ramd_vec_t, ramd_vec_t)                   = 0;
@@ -92,6 +93,7 @@ struct LocalSolver : SolverBase
     FGMRES<M, V, T>                                 fgmres;
     BiCGStabl<M, V, T>                              bicgl;
     QMRCGStab<M, V, T>                              qmr;
+    IDR<M, V, T>                                    idr;
     Precs<T>                                        pcs;
     M                                               op; // non-owning view of the caller's matrix
     bool                                            built = false;
@@ -120,6 +122,8 @@ struct LocalSolver : SolverBase
             return &bicgl;
         case RAMD_SOLVER_QMRCGSTAB:
             return &qmr;
+        case RAMD_SOLVER_IDR:
+            return &idr;
         default:
             return &cg;
         }
@@ -134,8 +138,14 @@ struct LocalSolver : SolverBase
             bicgl.SetOrder(m);
         else if(solver_kind == RAMD_SOLVER_FGMRES)
             fgmres.SetBasisSize(m);
+        else if(solver_kind == RAMD_SOLVER_IDR)
+            idr.SetShadowSpace(m);
         else
             gmres.SetBasisSize(m);
+    }
+    void set_seed(unsigned long long seed) override
+    {
+        idr.SetRandomSeed(seed);
     }
     void set_fused(bool f) override
     {
@@ -399,7 +409,7 @@ extern "C" {
 
 int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out)
 {
-    if(!out || solver < 0 || solver > RAMD_SOLVER_QMRCGSTAB || precond < 0 || precond > RAMD_PC_MCILU
+    if(!out || solver < 0 || solver > RAMD_SOLVER_IDR || precond < 0 || precond > RAMD_PC_MCILU
        || (dtype != RAMD_F64 && dtype != RAMD_F32))
         return RAMD_ERR_ARG;
     GUARD_BEGIN
@@ -446,6 +456,14 @@ int ramd_solver_init_inner(ramd_solver_t s, double a, double r, double d, int mx
         return RAMD_ERR_ARG;
     s->impl->init_inner(a, r, d, mx);
     return RAMD_OK;
+}
+int ramd_solver_set_seed(ramd_solver_t s, unsigned long long seed)
+{
+    if(!s || seed == 0ULL)
+        return RAMD_ERR_ARG;
+    GUARD_BEGIN
+    s->impl->set_seed(seed);
+    GUARD_END
 }
 int ramd_solver_set_basis(ramd_solver_t s, int m)
 {

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import capi
 from .capi import (PC_ILU0, PC_JACOBI, PC_MCGS, PC_MCILU, PC_MCSGS, PC_NONE, SOLVER_BICGSTAB, SOLVER_BICGSTABL,
-                   SOLVER_CG, SOLVER_CR, SOLVER_FCG, SOLVER_FGMRES, SOLVER_GMRES, SOLVER_QMRCGSTAB)
+                   SOLVER_CG, SOLVER_CR, SOLVER_FCG, SOLVER_FGMRES, SOLVER_GMRES, SOLVER_IDR, SOLVER_QMRCGSTAB)
 
 
 def _lib():
@@ -214,6 +214,25 @@ class BiCGStabl(_IterativeLinearSolver):
 
     def SetOrder(self, l):
         self._basis = int(l)
+
+
+class IDR(_IterativeLinearSolver):
+    """IDR(s) (src/solvers/krylov/idr.cpp); s = 4 and seed = time() unless set"""
+    kind = SOLVER_IDR
+
+    def __init__(self, dtype=np.float64):
+        super().__init__(dtype)
+        self._seed = None
+
+    def SetShadowSpace(self, s):
+        self._basis = int(s)
+
+    def SetRandomSeed(self, seed):
+        self._seed = int(seed)
+
+    def _configure_extra(self):
+        if self._seed is not None:
+            capi.check(_lib().ramd_solver_set_seed(self._h, self._seed))
 
 
 class QMRCGStab(_IterativeLinearSolver):

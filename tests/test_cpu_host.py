@@ -95,6 +95,9 @@ int main(int argc, char** argv)
     FGMRES<GlobalMatrix<double>, GlobalVector<double>, double> gfg; gfg.SetOperator(gmat);
     BiCGStabl<GlobalMatrix<double>, GlobalVector<double>, double> gbl; gbl.SetOperator(gmat);
     QMRCGStab<GlobalMatrix<double>, GlobalVector<double>, double> gqm; gqm.SetOperator(gmat);
+    IDR<LocalMatrix<double>, LocalVector<double>, double> idr; idr.SetOperator(mat); idr.SetShadowSpace(4); idr.SetRandomSeed(7ULL);
+    IDR<GlobalMatrix<double>, GlobalVector<double>, double> gidr; gidr.SetOperator(gmat);
+    x.SetRandomUniform(12345ULL, -4.0, 6.0);
     mat.WriteFileMTX("a.mtx"); mat.WriteFileCSR("a.csr"); mat.ReadFileCSR("a.csr");
     x.WriteFileASCII("x.dat"); x.ReadFileBinary("x.bin");
     e.ScaleAdd(-1.0, x);

@@ -46,9 +46,14 @@ def _inputs(name, g):
 def _mk(S, tag, dtype=np.float64):
     sname = tag.split("_")[0]
     solver = {"cg": S.CG, "gmres": S.GMRES, "bicgstab": S.BiCGStab, "fcg": S.FCG, "cr": S.CR, "fgmres": S.FGMRES,
-              "bicgstabl": S.BiCGStabl, "bicgstabl3": S.BiCGStabl, "qmrcgstab": S.QMRCGStab}[sname](dtype)
+              "bicgstabl": S.BiCGStabl, "bicgstabl3": S.BiCGStabl, "qmrcgstab": S.QMRCGStab, "idr": S.IDR,
+              "idr2": S.IDR}[sname](dtype)
     if sname == "bicgstabl3":
         solver.SetOrder(3)
+    if sname == "idr":
+        solver.SetRandomSeed(12345)
+    if sname == "idr2":
+        solver.SetShadowSpace(2); solver.SetRandomSeed(777)
     pc = {"none": None, "jacobi": S.Jacobi, "ilu0": S.ILU, "mcsgs": S.MultiColoredSGS, "mcgs": S.MultiColoredGS,
           "mcilu": S.MultiColoredILU}[tag.split("_")[1]]
     if pc is not None:
@@ -95,7 +100,8 @@ def test_preconditioner_apply_bit_exact(ra, S, name):
 
 SOLVER_TAGS = ["cg_none", "cg_jacobi", "gmres_none", "gmres_ilu0", "bicgstab_none", "bicgstab_mcsgs", "bicgstab_mcgs",
                "gmres_mcilu", "fcg_none", "fcg_jacobi", "fcg_mcsgs", "cr_none", "cr_jacobi", "fgmres_none",
-               "fgmres_ilu0", "bicgstabl_none", "bicgstabl3_jacobi", "qmrcgstab_none", "qmrcgstab_mcsgs"]
+               "fgmres_ilu0", "bicgstabl_none", "bicgstabl3_jacobi", "qmrcgstab_none", "qmrcgstab_mcsgs", "idr_none",
+               "idr2_jacobi"]
 SOLVER_CASES = ["gr3030", "poisson8", "lap2d7", "poisson16", "poisson32"]
 
 
@@ -148,7 +154,7 @@ def test_solvers_vs_golden(ra, S, name, tag, fused):
     ls.Solve(rhs, x)
     meta = g[tag + "_meta"]
     slack = 1 if tag.split("_")[0] in ("cg", "fcg", "cr") else 2
-    bicg = tag.startswith("bicgstab") or tag.startswith("qmrcgstab")  # BiCG-type recurrences, see _check_hist
+    bicg = tag.split("_")[0] in ("bicgstab", "bicgstabl", "bicgstabl3", "qmrcgstab", "idr", "idr2")  # see _check_hist
     _check_run(ls.GetResidualHistory(), g[tag + "_hist"], ls.GetIterationCount(), int(meta[0]),
                ls.GetSolverStatus(), int(meta[1]), slack, bicg)
     if ls.GetIterationCount() == int(meta[0]) and not bicg:

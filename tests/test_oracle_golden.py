@@ -165,6 +165,8 @@ SOLVER_TABLE = {
     "bicgstabl3_jacobi": ("BICGSTABL", "PC_JACOBI", "CSR", dict(basis=3)),
     "qmrcgstab_none": ("QMRCGSTAB", "PC_NONE", "CSR", {}),
     "qmrcgstab_mcsgs": ("QMRCGSTAB", "PC_MCSGS", "CSR", {}),
+    "idr_none": ("IDR", "PC_NONE", "CSR", dict(basis=4, seed=12345)),
+    "idr2_jacobi": ("IDR", "PC_JACOBI", "CSR", dict(basis=2, seed=777)),
 }
 
 
