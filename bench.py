@@ -239,16 +239,21 @@ def main():
         capi.check(lib.ramd_prof_spmv_result(C.byref(cnt), C.byref(avg), C.byref(mn), C.byref(mx)))
         capi.check(lib.ramd_prof_spmv_enable(0))
         nnz_fmt = nnz if args.format == "csr" else 7 * n
-        bytes_alg = spmv_bytes(n, nnz) if args.format == "csr" else 4 * nnz_fmt + 8 * (2 * n + nnz_fmt)
+        mixed = args.solver == "mixed"
+        vb = 4 if mixed else 8  # the launches of a mixed-precision run are (all but a handful) the fp32 inner SpMVs
+        bytes_alg = spmv_bytes(n, nnz, vb) if args.format == "csr" else 4 * nnz_fmt + vb * (2 * n + nnz_fmt)
         ach = bytes_alg / (avg.value * 1e-3) / 1e9 if avg.value > 0 else 0.0
         traffic = None  # HBM bytes per launch from the PMC counters: measured offline with rocprofv3
         tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")  # (separate --pmc passes), see that file
-        if os.path.exists(tfile) and N == 512 and args.format == "csr":
+        if os.path.exists(tfile) and N == 512 and args.format == "csr" and not mixed:
             traffic = json.load(open(tfile)).get("traffic_bytes")
+        kname = ("k_csr_tr<float,0,true> (fp32 inner CSR SpMV + fused <p,q>; the few fp64 outer residual SpMVs are "
+                 "in the average)" if mixed else "k_csr_tr<double,0,true> (CSR SpMV + fused <p,q>)")
         prof = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
-                    frac=round(ach / HBM_PEAK_GBPS, 4), traffic=traffic, kernel="k_csr_tr<double,0,true> (CSR SpMV + fused <p,q>)"
-                    if args.format == "csr" else "k_ell<double>", launches=cnt.value, avg_ms=round(avg.value, 5),
-                    min_ms=round(mn.value, 5), max_ms=round(mx.value, 5), algorithmic_bytes=bytes_alg)
+                    frac=round(ach / HBM_PEAK_GBPS, 4), traffic=traffic, kernel=kname
+                    if args.format == "csr" else "k_ell<%s>" % ("float" if mixed else "double"), launches=cnt.value,
+                    avg_ms=round(avg.value, 5), min_ms=round(mn.value, 5), max_ms=round(mx.value, 5),
+                    algorithmic_bytes=bytes_alg)
         extras = {}
         if not args.no_extras and args.solver == "cg" and args.precond == "jacobi":
             # the other two solver/preconditioner pairs of BASELINE.json on the same operator (same
@@ -308,7 +313,8 @@ def main():
                 args.format.upper()),
             "value": round(it / dt, 3), "unit": "iters/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / it * 1e3, 5), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64/f32" if args.solver == "mixed" else "f64",
+            "data": "synthetic",
             "config": {"workload": "%s+%s, 3-D 7-point Poisson %d^3 (n=%d, nnz=%d) %s fp64, rhs=A*1, x0=0, "
                                    "row-split over %d GPU(s)" % (args.solver, args.precond, N, n, nnz,
                                                                  args.format.upper(), world),
