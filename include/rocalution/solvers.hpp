@@ -435,6 +435,97 @@ private:
     bool         level_;
 };
 
+// ---- GS / SGS: preconditioner.cpp:206-257 / :302-379 (sparse triangular solves on the matrix itself).
+// SGS::Build fills diag_entries_ with the INVERSE diagonal (:318, ExtractInverseDiagonal) -- kept as is.
+template <class OperatorType, class VectorType, typename ValueType>
+class GS : public Preconditioner<OperatorType, VectorType, ValueType>
+{
+public:
+    GS() {}
+    virtual ~GS()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("Gauss-Seidel (GS) preconditioner");
+    }
+    virtual void Build(void)
+    {
+        if(this->build_)
+            this->Clear();
+        this->build_ = true;
+        assert(this->op_ != NULL);
+        this->GS_.CloneFrom(*this->op_);
+        this->GS_.LAnalyse(false);
+    }
+    virtual void Clear(void)
+    {
+        this->GS_.LAnalyseClear();
+        this->GS_.Clear();
+        this->build_ = false;
+    }
+    virtual void Solve(const VectorType& rhs, VectorType* x)
+    {
+        assert(this->build_ == true && x != NULL);
+        this->GS_.LSolve(rhs, x);
+    }
+
+private:
+    OperatorType GS_;
+};
+
+template <class OperatorType, class VectorType, typename ValueType>
+class SGS : public Preconditioner<OperatorType, VectorType, ValueType>
+{
+public:
+    SGS() {}
+    virtual ~SGS()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("Symmetric Gauss-Seidel (SGS) preconditioner");
+    }
+    virtual void Build(void)
+    {
+        if(this->build_)
+            this->Clear();
+        this->build_ = true;
+        assert(this->op_ != NULL);
+        this->SGS_.CloneFrom(*this->op_);
+        this->SGS_.LAnalyse(false);
+        this->SGS_.UAnalyse(false);
+        this->diag_entries_.CloneBackend(*this->op_);
+        this->diag_entries_.Allocate("diag", this->op_->GetM());
+        this->SGS_.ExtractInverseDiagonal(&this->diag_entries_);
+        this->v_.CloneBackend(*this->op_);
+        this->v_.Allocate("v", this->op_->GetM());
+    }
+    virtual void Clear(void)
+    {
+        this->SGS_.LAnalyseClear();
+        this->SGS_.UAnalyseClear();
+        this->SGS_.Clear();
+        this->diag_entries_.Clear();
+        this->v_.Clear();
+        this->build_ = false;
+    }
+    virtual void Solve(const VectorType& rhs, VectorType* x)
+    {
+        assert(this->build_ == true && x != NULL);
+        this->SGS_.LSolve(rhs, &this->v_);
+        this->v_.PointWiseMult(this->diag_entries_);
+        this->SGS_.USolve(this->v_, x);
+    }
+
+private:
+    OperatorType SGS_;
+    VectorType   diag_entries_;
+    VectorType   v_;
+};
+
 // ---- MultiColored framework + MC-SGS: preconditioner_multicolored.cpp:148-413, _gs.cpp:127-215
 template <class OperatorType, class VectorType, typename ValueType>
 class MultiColored : public Preconditioner<OperatorType, VectorType, ValueType>

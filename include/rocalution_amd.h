@@ -286,7 +286,8 @@ enum { RAMD_SOLVER_CG = 0, RAMD_SOLVER_GMRES = 1, RAMD_SOLVER_BICGSTAB = 2,
        RAMD_SOLVER_FCG = 3, RAMD_SOLVER_CR = 4, RAMD_SOLVER_FGMRES = 5, RAMD_SOLVER_BICGSTABL = 6,
        RAMD_SOLVER_QMRCGSTAB = 7,
        RAMD_SOLVER_IDR = 8 /* idr.cpp; set_basis = SetShadowSpace, ramd_solver_set_seed = SetRandomSeed */ };
-enum { RAMD_PC_NONE = 0, RAMD_PC_JACOBI = 1, RAMD_PC_ILU0 = 2, RAMD_PC_MCSGS = 3, RAMD_PC_MCGS = 4, RAMD_PC_MCILU = 5 };
+enum { RAMD_PC_NONE = 0, RAMD_PC_JACOBI = 1, RAMD_PC_ILU0 = 2, RAMD_PC_MCSGS = 3, RAMD_PC_MCGS = 4, RAMD_PC_MCILU = 5,
+       RAMD_PC_GS = 6, RAMD_PC_SGS = 7 /* preconditioner.cpp:206-257 / :302-379 */ };
 int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out);
 /* MixedPrecisionDC<fp64 outer, fp32 inner>: inner solver/preconditioner kinds */
 int ramd_solver_create_mixed(int inner_solver, int inner_precond, ramd_solver_t* out);

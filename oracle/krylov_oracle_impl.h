@@ -712,6 +712,8 @@ static void SUF(pc_free)(SUF(orc_pc) * P)
 {
     free(P->inv_diag);
     free(P->lu_val);
+    if(P->kind == ORC_PC_SGS)
+        free(P->xtmp);
     if(ORC_PC_IS_MC(P->kind))
     {
         int nb = P->num_blocks;
@@ -764,6 +766,22 @@ static int SUF(pc_build)(SUF(orc_pc) * P, int kind, int nrow, int64_t nnz, const
         P->lu_val     = (T*)malloc(sizeof(T) * (size_t)nnz);
         memcpy(P->lu_val, val, sizeof(T) * (size_t)nnz);
         SUF(orc_csr_ilu0)(nrow, row_offset, col, P->lu_val);
+    }
+    else if(kind == ORC_PC_GS || kind == ORC_PC_SGS)
+    {
+        /* GS / SGS (preconditioner.cpp:206-225 / :302-325): clone of A, LAnalyse(false) [+ UAnalyse(false)];
+         * SGS::Build extracts the INVERSE diagonal into diag_entries_ (:318) */
+        P->row_offset = row_offset;
+        P->col        = col;
+        P->nnz        = nnz;
+        P->lu_val     = (T*)malloc(sizeof(T) * (size_t)nnz); /* the clone's values */
+        memcpy(P->lu_val, val, sizeof(T) * (size_t)nnz);
+        if(kind == ORC_PC_SGS)
+        {
+            P->inv_diag = (T*)calloc((size_t)nrow, sizeof(T));
+            SUF(orc_csr_extract_inv_diag)(nrow, row_offset, col, val, P->inv_diag);
+            P->xtmp = (T*)calloc((size_t)nrow, sizeof(T));
+        }
     }
     else if(ORC_PC_IS_MC(kind))
     {
@@ -861,6 +879,18 @@ static void SUF(pc_solve)(SUF(orc_pc) * P, const T* rhs, T* x)
     else if(P->kind == ORC_PC_ILU0)
     {
         SUF(orc_csr_lusolve)(n, P->nnz, P->row_offset, P->col, P->lu_val, rhs, x);
+    }
+    else if(P->kind == ORC_PC_GS)
+    {
+        /* GS::Solve (preconditioner.cpp:250-257): LSolve with the stored (non-unit) diagonal */
+        SUF(orc_csr_lsolve)(n, P->row_offset, P->col, P->lu_val, 0, rhs, x);
+    }
+    else if(P->kind == ORC_PC_SGS)
+    {
+        /* SGS::Solve (preconditioner.cpp:367-379): v = LSolve(rhs); v *= diag_entries_; x = USolve(v) */
+        SUF(orc_csr_lsolve)(n, P->row_offset, P->col, P->lu_val, 0, rhs, P->xtmp);
+        SUF(orc_pointwise_mult)(n, P->xtmp, P->inv_diag);
+        SUF(orc_csr_usolve)(n, P->nnz, P->row_offset, P->col, P->lu_val, 0, P->xtmp, x);
     }
     else if(ORC_PC_IS_MC(P->kind))
     {

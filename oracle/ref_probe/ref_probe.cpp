@@ -293,6 +293,22 @@ static int cmd_gen(const std::string& in, const std::string& out)
         p.Clear();
     }
     {
+        GS<MatD, VecD, double> p;
+        p.SetOperator(mat);
+        p.Build();
+        p.Solve(x, &y);
+        dump_vec("pc_gs", y);
+        p.Clear();
+    }
+    {
+        SGS<MatD, VecD, double> p;
+        p.SetOperator(mat);
+        p.Build();
+        p.Solve(x, &y);
+        dump_vec("pc_sgs", y);
+        p.Clear();
+    }
+    {
         MultiColoredILU<MatD, VecD, double> p; // default ILU(0,1)
         p.SetOperator(mat);
         p.Build();
@@ -497,6 +513,26 @@ static int cmd_gen(const std::string& in, const std::string& out)
             ls.Build();
             sol.Zeros();
             run_solver("qmrcgstab_mcsgs", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            CG<MatD, VecD, double>  ls;
+            SGS<MatD, VecD, double> p;
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(p);
+            ls.Build();
+            sol.Zeros();
+            run_solver("cg_sgs", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            BiCGStab<MatD, VecD, double> ls;
+            GS<MatD, VecD, double>       p;
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(p);
+            ls.Build();
+            sol.Zeros();
+            run_solver("bicgstab_gs", ls, rhs, sol);
             ls.Clear();
         }
         {

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "librocalution_amd.so")
 OK, ERR_HIP, ERR_ARG, ERR_UNSUPPORTED, ERR_REFUSED, ERR_NO_DEVICE, ERR_STATE = range(7)
 SOLVER_CG, SOLVER_GMRES, SOLVER_BICGSTAB = 0, 1, 2
 SOLVER_FCG, SOLVER_CR, SOLVER_FGMRES, SOLVER_BICGSTABL, SOLVER_QMRCGSTAB, SOLVER_IDR = 3, 4, 5, 6, 7, 8
-PC_NONE, PC_JACOBI, PC_ILU0, PC_MCSGS, PC_MCGS, PC_MCILU = 0, 1, 2, 3, 4, 5
+PC_NONE, PC_JACOBI, PC_ILU0, PC_MCSGS, PC_MCGS, PC_MCILU, PC_GS, PC_SGS = 0, 1, 2, 3, 4, 5, 6, 7
 F64, F32, I32 = 0, 1, 2
 CSR, COO, ELL, HYB = 1, 4, 6, 7
 

@@ -51,10 +51,16 @@ struct Precs
     MultiColoredSGS<M, V, T> mcsgs;
     MultiColoredGS<M, V, T>  mcgs;
     MultiColoredILU<M, V, T> mcilu;
+    GS<M, V, T>              gs;
+    SGS<M, V, T>             sgs;
     Solver<M, V, T>*         get(int kind)
     {
         switch(kind)
         {
+        case RAMD_PC_GS:
+            return &gs;
+        case RAMD_PC_SGS:
+            return &sgs;
         case RAMD_PC_JACOBI:
             return &jacobi;
         case RAMD_PC_ILU0:
@@ -409,7 +415,7 @@ extern "C" {
 
 int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out)
 {
-    if(!out || solver < 0 || solver > RAMD_SOLVER_IDR || precond < 0 || precond > RAMD_PC_MCILU
+    if(!out || solver < 0 || solver > RAMD_SOLVER_IDR || precond < 0 || precond > RAMD_PC_SGS
        || (dtype != RAMD_F64 && dtype != RAMD_F32))
         return RAMD_ERR_ARG;
     GUARD_BEGIN
@@ -424,7 +430,7 @@ int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out)
 
 int ramd_solver_create_mixed(int inner_solver, int inner_precond, ramd_solver_t* out)
 {
-    if(!out || inner_solver < 0 || inner_solver > 2 || inner_precond < 0 || inner_precond > RAMD_PC_MCILU)
+    if(!out || inner_solver < 0 || inner_solver > 2 || inner_precond < 0 || inner_precond > RAMD_PC_SGS)
         return RAMD_ERR_ARG;
     GUARD_BEGIN
     ramd_solver_s* s = new ramd_solver_s;

@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import capi
-from .capi import (PC_ILU0, PC_JACOBI, PC_MCGS, PC_MCILU, PC_MCSGS, PC_NONE, SOLVER_BICGSTAB, SOLVER_BICGSTABL,
+from .capi import (PC_GS, PC_ILU0, PC_JACOBI, PC_MCGS, PC_MCILU, PC_MCSGS, PC_NONE, PC_SGS, SOLVER_BICGSTAB, SOLVER_BICGSTABL,
                    SOLVER_CG, SOLVER_CR, SOLVER_FCG, SOLVER_FGMRES, SOLVER_GMRES, SOLVER_IDR, SOLVER_QMRCGSTAB)
 
 
@@ -39,6 +39,16 @@ class ILU(_Precond):
     def Set(self, p, level=True):
         if p != 0:
             raise ValueError("only ILU(0) is provided by this backend")
+
+
+class GS(_Precond):
+    """Gauss-Seidel: LSolve on the matrix (preconditioner.cpp:206-257)"""
+    kind = PC_GS
+
+
+class SGS(_Precond):
+    """symmetric Gauss-Seidel: LSolve, diagonal scaling, USolve (preconditioner.cpp:302-379)"""
+    kind = PC_SGS
 
 
 class MultiColoredSGS(_Precond):

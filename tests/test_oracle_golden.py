@@ -139,6 +139,8 @@ def test_preconditioner_apply(oracle, name):
     eq(oracle.precond_apply(oracle.PC_MCSGS, rp, ci, va, x), g["pc_mcsgs"])
     eq(oracle.precond_apply(oracle.PC_MCGS, rp, ci, va, x), g["pc_mcgs"])
     eq(oracle.precond_apply(oracle.PC_MCILU, rp, ci, va, x), g["pc_mcilu"])
+    eq(oracle.precond_apply(oracle.PC_GS, rp, ci, va, x), g["pc_gs"])
+    eq(oracle.precond_apply(oracle.PC_SGS, rp, ci, va, x), g["pc_sgs"])
 
 
 SOLVER_TABLE = {
@@ -167,6 +169,8 @@ SOLVER_TABLE = {
     "qmrcgstab_mcsgs": ("QMRCGSTAB", "PC_MCSGS", "CSR", {}),
     "idr_none": ("IDR", "PC_NONE", "CSR", dict(basis=4, seed=12345)),
     "idr2_jacobi": ("IDR", "PC_JACOBI", "CSR", dict(basis=2, seed=777)),
+    "cg_sgs": ("CG", "PC_SGS", "CSR", {}),
+    "bicgstab_gs": ("BICGSTAB", "PC_GS", "CSR", {}),
 }
 
 
