@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kBlock) void k_csr_tr(int nrow, int nblk, int per_x
                                                    const int* __restrict__ ci,
                                                    const T* __restrict__ val,
                                                    const T* __restrict__ x, T* __restrict__ y, T scalar,
-                                                   CsrDotWs ws, int slot, BandMap bm, int nt_y)
+                                                   CsrDotWs ws, int slot, BandMap bm)
 {
     using VP          = typename ValPk<T>::type;
     constexpr int VN  = ValPk<T>::N;
@@ -186,10 +186,9 @@ __global__ __launch_bounds__(kBlock) void k_csr_tr(int nrow, int nblk, int per_x
         }
         if(row < nrow)
         {
-            if(nt_y)
-                nt_store(sum, y + row);
-            else
-                y[row] = sum;
+            // non-temporal, unconditionally: a run-time switch here let the compiler merge both branches
+            // into ONE plain store (the hint was lost and the kernel ran 15% slower at 256^3)
+            nt_store(sum, y + row);
             if(DOT)
                 dacc = (double)sum * (double)xrow;
         }
@@ -401,9 +400,6 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
     if(m->band_dist < 0)
         RAMD_TRY(csr_analyse_band(const_cast<ramd_mat_s*>(m)));
     const BandMap bm = band_map_for(m, per_xcd);
-    static int nt_y = -1;
-    if(nt_y < 0)
-        nt_y = getenv("RAMD_SPMV_NT_Y") ? atoi(getenv("RAMD_SPMV_NT_Y")) : 1;
     if(dot)
     {
         ramd_mat_s* mm = const_cast<ramd_mat_s*>(m);
@@ -420,7 +416,7 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
         prof_spmv_begin();
 #define LAUNCH(MODE, DOT)                                                                          \
     hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
-                       per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, nt_y)
+                       per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm)
     if(mode == 0 && !dot)
         LAUNCH(0, false);
     else if(mode == 0 && dot)
