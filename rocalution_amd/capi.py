@@ -9,6 +9,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librocalution_amd.so")
+if os.environ.get("RAMD_LIB"):  # A/B runs of differently built libraries (tools/)
+    LIB_PATH = os.environ["RAMD_LIB"]
 
 OK, ERR_HIP, ERR_ARG, ERR_UNSUPPORTED, ERR_REFUSED, ERR_NO_DEVICE, ERR_STATE = range(7)
 SOLVER_CG, SOLVER_GMRES, SOLVER_BICGSTAB = 0, 1, 2

@@ -20,6 +20,10 @@ namespace ramd
 {
 
 constexpr int kCsrRows  = 256; // rows per workgroup (one per thread)
+#ifndef RAMD_GATHER_W
+#define RAMD_GATHER_W 8
+#endif
+constexpr int kGatherW = RAMD_GATHER_W; // x gathers in flight per row and batch
 constexpr int kCsrChunk = 2048; // entries staged in LDS per pass (16 KiB values + 8 KiB columns)
 
 // XCD-aware mapping: hardware places workgroup b on XCD b % 8 (observed, used for speed only).
@@ -85,8 +89,10 @@ struct CsrDotWs
 //      y is written once, non-temporal.
 // MODE 0: y = A x      MODE 1: y += scalar * A x (term by term into y, as the host ApplyAdd)
 // DOT   : additionally reduce <x, y> into scalar slot `slot` (square matrix)
+// LDS (24 KiB per workgroup) allows 6 workgroups = 6 waves per SIMD: keep the register budget inside
+// 512/6 VGPRs (the fused-dot variant sat at 86 and lost a whole wave per SIMD: -4%)
 template <typename T, int MODE, bool DOT>
-__global__ __launch_bounds__(kBlock) void k_csr_tr(int nrow, int nblk, int per_xcd,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_csr_tr(int nrow, int nblk, int per_xcd,
                                                    const int* __restrict__ rp,
                                                    const int* __restrict__ ci,
                                                    const T* __restrict__ val,
@@ -115,9 +121,6 @@ __global__ __launch_bounds__(kBlock) void k_csr_tr(int nrow, int nblk, int per_x
         T         sum   = (T)0;
         if(MODE == 1 && row < nrow)
             sum = y[row];
-        T xrow = (T)0; // for the fused <x,y>: fetched up front so its latency hides behind the stream
-        if(DOT && row < nrow)
-            xrow = ws.dotv ? static_cast<const T*>(ws.dotv)[row] : x[row];
         for(int cb = start & ~3; cb < end; cb += kCsrChunk)
         {
             v4i32 c[kCsrChunk / (4 * kBlock)];
@@ -152,35 +155,33 @@ __global__ __launch_bounds__(kBlock) void k_csr_tr(int nrow, int nblk, int per_x
             }
             __syncthreads();
             const int lo = max(rs, cb), hi = min(re, cb + kCsrChunk);
-            int       j  = lo;
-            for(; j + 4 <= hi; j += 4) // issue 4 independent gathers, then accumulate IN ORDER
+            // masked batches of kGatherW entries: all gathers of a batch are issued before the first use,
+            // the products are added IN ORDER.  (A row of 7 used to cost one batch of 4 plus three
+            // one-by-one gathers = 4 dependent L2 round trips; now it is one batch.)
+            for(int j = lo; j < hi; j += kGatherW)
             {
-                int cc[4];
-                T   v[4], xv[4];
+                int cc[kGatherW];
+                T   v[kGatherW], xv[kGatherW];
 #pragma unroll
-                for(int e = 0; e < 4; ++e)
-                {
-                    cc[e] = scol[j - cb + e];
-                    v[e]  = sval[j - cb + e];
-                }
+                for(int e = 0; e < kGatherW; ++e)
+                    if(j + e < hi)
+                    {
+                        cc[e] = scol[j - cb + e];
+                        v[e]  = sval[j - cb + e];
+                    }
 #pragma unroll
-                for(int e = 0; e < 4; ++e)
-                    xv[e] = x[cc[e]];
+                for(int e = 0; e < kGatherW; ++e)
+                    if(j + e < hi)
+                        xv[e] = x[cc[e]];
 #pragma unroll
-                for(int e = 0; e < 4; ++e)
-                {
-                    if(MODE == 0)
-                        sum += v[e] * xv[e];
-                    else
-                        sum += scalar * v[e] * xv[e];
-                }
-            }
-            for(; j < hi; ++j)
-            {
-                if(MODE == 0)
-                    sum += sval[j - cb] * x[scol[j - cb]];
-                else
-                    sum += scalar * sval[j - cb] * x[scol[j - cb]];
+                for(int e = 0; e < kGatherW; ++e)
+                    if(j + e < hi)
+                    {
+                        if(MODE == 0)
+                            sum += v[e] * xv[e];
+                        else
+                            sum += scalar * v[e] * xv[e];
+                    }
             }
             __syncthreads();
         }
@@ -189,8 +190,8 @@ __global__ __launch_bounds__(kBlock) void k_csr_tr(int nrow, int nblk, int per_x
             // non-temporal, unconditionally: a run-time switch here let the compiler merge both branches
             // into ONE plain store (the hint was lost and the kernel ran 15% slower at 256^3)
             nt_store(sum, y + row);
-            if(DOT)
-                dacc = (double)sum * (double)xrow;
+            if(DOT) // w_row is fetched last: no live register across the stream (x[row] is an L1/L2 hit by now)
+                dacc = (double)sum * (double)(ws.dotv ? static_cast<const T*>(ws.dotv)[row] : x[row]);
         }
     }
     if(DOT)
