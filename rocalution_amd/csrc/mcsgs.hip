@@ -182,12 +182,36 @@ __global__ __launch_bounds__(kBlock) void k_mc_sweep(int p0, int p1, const int* 
     T         s    = FROM_RHS ? rhs[orow] : xp[t];
     if(MULT_D)
         s = s * d[t];
-    for(int k = 0; k < w; ++k)
+    // masked batches of 8 slots: loads, then gathers, then the updates IN ORDER (padding col = -1 ends a row)
+    bool done = false;
+    for(int k0 = 0; k0 < w && !done; k0 += 8)
     {
-        const int c = nt_load(ecol + base + k * 64 + lane);
-        if(c < 0)
-            break;
-        s -= nt_load(eval + base + k * 64 + lane) * xp[c];
+        int c[8];
+        T   a[8], xv[8];
+#pragma unroll
+        for(int e = 0; e < 8; ++e)
+        {
+            c[e] = -1;
+            if(k0 + e < w)
+            {
+                c[e] = nt_load(ecol + base + (k0 + e) * 64 + lane);
+                a[e] = nt_load(eval + base + (k0 + e) * 64 + lane);
+            }
+        }
+#pragma unroll
+        for(int e = 0; e < 8; ++e)
+        {
+            if(c[e] < 0)
+                done = true;
+            if(!done)
+                xv[e] = xp[c[e]];
+            else
+                c[e] = -1;
+        }
+#pragma unroll
+        for(int e = 0; e < 8; ++e)
+            if(c[e] >= 0)
+                s -= a[e] * xv[e];
     }
     if(!identity)
         s = s * dinv[t];

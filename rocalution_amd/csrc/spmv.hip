@@ -226,55 +226,47 @@ __global__ __launch_bounds__(kBlock) void k_ell(int nrow, int ncol, int width,
         T sum = (T)0;
         if(MODE == 1)
             sum = y[row];
-        int el = 0;
-        // 4-wide unrolled: issue the independent col/val loads before the dependent gathers
-        for(; el + 4 <= width; el += 4)
+        // masked batches of kGatherW slots: the independent col/val loads of a batch first, then all its
+        // gathers, then the products IN ORDER (a width-7 row is one batch, not 4 + three dependent steps)
+        bool stopped = false;
+        for(int el = 0; el < width && !stopped; el += kGatherW)
         {
-            int c[4];
-            T   v[4];
+            int c[kGatherW];
+            T   v[kGatherW], xv[kGatherW];
 #pragma unroll
-            for(int e = 0; e < 4; ++e)
+            for(int e = 0; e < kGatherW; ++e)
             {
-                c[e] = nt_load(ecol + (int64_t)(el + e) * nrow + row);
-                v[e] = nt_load(eval + (int64_t)(el + e) * nrow + row);
-            }
-            bool stop = false;
-#pragma unroll
-            for(int e = 0; e < 4; ++e)
-            {
-                if(STOP)
+                c[e] = -1;
+                if(el + e < width)
                 {
-                    if(stop || c[e] < 0)
-                    {
-                        stop = true;
-                        continue;
-                    }
+                    c[e] = nt_load(ecol + (int64_t)(el + e) * nrow + row);
+                    v[e] = nt_load(eval + (int64_t)(el + e) * nrow + row);
                 }
-                else if(c[e] < 0 || c[e] >= ncol)
-                    continue;
-                if(MODE == 0)
-                    sum += v[e] * x[c[e]];
-                else
-                    sum += scalar * v[e] * x[c[e]];
             }
-            if(STOP && stop)
-                el = width; // leaves both loops
-        }
-        for(; el < width; ++el)
-        {
-            int c = nt_load(ecol + (int64_t)el * nrow + row);
-            if(STOP)
+            bool use[kGatherW];
+#pragma unroll
+            for(int e = 0; e < kGatherW; ++e)
             {
-                if(c < 0)
-                    break;
+                if(STOP) // ELL: everything after the first negative column is padding
+                {
+                    if(el + e < width && c[e] < 0)
+                        stopped = true;
+                    use[e] = (el + e < width) && !stopped;
+                }
+                else // HYB-ELL: skip invalid columns
+                    use[e] = (el + e < width) && c[e] >= 0 && c[e] < ncol;
+                if(use[e])
+                    xv[e] = x[c[e]];
             }
-            else if(c < 0 || c >= ncol)
-                continue;
-            T v = nt_load(eval + (int64_t)el * nrow + row);
-            if(MODE == 0)
-                sum += v * x[c];
-            else
-                sum += scalar * v * x[c];
+#pragma unroll
+            for(int e = 0; e < kGatherW; ++e)
+                if(use[e])
+                {
+                    if(MODE == 0)
+                        sum += v[e] * xv[e];
+                    else
+                        sum += scalar * v[e] * xv[e];
+                }
         }
         nt_store(sum, y + row);
         if(DOT)
