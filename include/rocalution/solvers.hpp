@@ -116,8 +116,7 @@ public:
     bool InitResidual(double res)
     {
         this->init_res_         = true;
-        this->initial_residual_ = res;
-        this->current_res_      = res;
+        this->initial_residual_ = res; // current_res_ is NOT touched here (iter_ctrl.cpp:89-96)
         this->reached_          = 0;
         this->iteration_        = 0;
         if(this->verb_ > 0)
@@ -180,6 +179,17 @@ public:
     {
         this->current_index_ = index;
         return this->CheckResidual(res);
+    }
+    // iter_ctrl.cpp:295-306
+    bool CheckMaximumIterNoCount(void)
+    {
+        assert(this->init_res_ == true);
+        if(this->iteration_ + 1 >= this->maximum_iter_)
+        {
+            this->reached_ = 4;
+            return true;
+        }
+        return false;
     }
     // iter_ctrl.cpp:256-289
     bool CheckResidualNoCount(double res)
@@ -268,6 +278,7 @@ public:
         , build_(false)
         , verb_(1)
         , is_precond_(false)
+        , is_smoother_(false)
     {
     }
     virtual ~Solver() {}
@@ -308,6 +319,10 @@ public:
     {
         this->is_precond_ = true;
     }
+    void FlagSmoother(void) // solver.hpp:254-258
+    {
+        this->is_smoother_ = true;
+    }
 
 protected:
     const OperatorType*                          op_;
@@ -315,6 +330,7 @@ protected:
     bool                                         build_;
     int                                          verb_;
     bool                                         is_precond_;
+    bool                                         is_smoother_;
 };
 
 // ============================================================================ Preconditioner
@@ -2773,6 +2789,239 @@ private:
     VectorType**           U_;
     VectorType**           P_;
     std::vector<ValueType> c_, f_, M_;
+};
+
+// ============================================================================ FixedPoint
+// src/solvers/solver.cpp:517-775: x_{k+1} = x_k + omega M^-1 (b - A x_k); a preconditioner is mandatory.
+// FlagSmoother(): exactly max_iter sweeps, no norms (the form multigrid uses).
+template <class OperatorType, class VectorType, typename ValueType>
+class FixedPoint : public IterativeLinearSolver<OperatorType, VectorType, ValueType>
+{
+public:
+    FixedPoint()
+        : omega_(static_cast<ValueType>(1))
+    {
+    }
+    virtual ~FixedPoint()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("Fixed Point Iteration solver, with preconditioner:");
+        if(this->precond_)
+            this->precond_->Print();
+    }
+    virtual void SetRelaxation(ValueType omega)
+    {
+        this->omega_ = omega;
+    }
+    virtual void Build(void)
+    {
+        if(this->build_)
+            this->Clear();
+        assert(this->op_ != NULL && this->precond_ != NULL);
+        this->build_ = true;
+        this->x_old_.CloneBackend(*this->op_);
+        this->x_old_.Allocate("x_old", this->op_->GetM());
+        this->x_res_.CloneBackend(*this->op_);
+        this->x_res_.Allocate("x_res", this->op_->GetM());
+        this->precond_->SetOperator(*this->op_);
+        this->precond_->Build();
+    }
+    virtual void Clear(void)
+    {
+        if(this->build_)
+        {
+            if(this->precond_ != NULL)
+            {
+                this->precond_->Clear();
+                this->precond_ = NULL;
+            }
+            this->x_old_.Clear();
+            this->x_res_.Clear();
+            this->iter_ctrl_.Clear();
+            this->build_ = false;
+        }
+    }
+
+protected:
+    virtual void PrintStart_(void) const
+    {
+        LOG_INFO("Fixed Point Iteration solver starts");
+    }
+    virtual void PrintEnd_(void) const
+    {
+        LOG_INFO("Fixed Point Iteration solver ends");
+    }
+    virtual void SolveNonPrecond_(const VectorType&, VectorType*)
+    {
+        LOG_INFO("Preconditioner for the Fixed Point method is required");
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+    virtual void SolvePrecond_(const VectorType& rhs, VectorType* x)
+    {
+        const ValueType one = static_cast<ValueType>(1);
+        if(this->is_smoother_)
+        {
+            const int steps = this->iter_ctrl_.GetMaximumIterations();
+            if(steps < 1)
+                return;
+            this->iter_ctrl_.InitResidual(1.0); // dummy: the smoother never looks at a residual
+            for(int iter = 0; iter < steps; ++iter)
+            {
+                this->op_->Apply(*x, &this->x_res_);
+                this->x_res_.ScaleAdd(-one, rhs);
+                this->precond_->SolveZeroSol(this->x_res_, &this->x_old_);
+                x->AddScale(this->x_old_, this->omega_);
+            }
+            return;
+        }
+        if(this->iter_ctrl_.GetMaximumIterations() < 1)
+            return;
+        this->op_->Apply(*x, &this->x_res_);
+        this->x_res_.ScaleAdd(-one, rhs);
+        ValueType res = this->Norm_(this->x_res_);
+        if(this->iter_ctrl_.InitResidual(std::abs(res)) == false)
+            return;
+        while(true)
+        {
+            this->precond_->SolveZeroSol(this->x_res_, &this->x_old_);
+            x->AddScale(this->x_old_, this->omega_);
+            if(this->iter_ctrl_.CheckMaximumIterNoCount()) // the last residual is never needed
+                break;
+            this->op_->Apply(*x, &this->x_res_);
+            this->x_res_.ScaleAdd(-one, rhs);
+            res = this->Norm_(this->x_res_);
+            if(this->iter_ctrl_.CheckResidual(std::abs(res), this->index_))
+                break;
+        }
+    }
+
+private:
+    ValueType  omega_;
+    VectorType x_old_, x_res_;
+};
+
+// ============================================================================ Chebyshev
+// src/solvers/chebyshev.cpp:230-360; the eigenvalue bounds come from the caller (Set)
+template <class OperatorType, class VectorType, typename ValueType>
+class Chebyshev : public IterativeLinearSolver<OperatorType, VectorType, ValueType>
+{
+public:
+    Chebyshev()
+        : init_lambda_(false)
+        , lambda_min_(static_cast<ValueType>(0))
+        , lambda_max_(static_cast<ValueType>(0))
+    {
+    }
+    virtual ~Chebyshev()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("Chebyshev solver" << (this->precond_ ? ", with preconditioner" : " (non-precond)"));
+    }
+    void Set(ValueType lambda_min, ValueType lambda_max)
+    {
+        this->lambda_min_  = lambda_min;
+        this->lambda_max_  = lambda_max;
+        this->init_lambda_ = true;
+    }
+    virtual void Build(void)
+    {
+        if(this->build_)
+            this->Clear();
+        assert(this->op_ != NULL && this->op_->GetM() == this->op_->GetN() && this->op_->GetM() > 0);
+        assert(this->init_lambda_ == true);
+        this->build_ = true;
+        if(this->precond_ != NULL)
+        {
+            this->precond_->SetOperator(*this->op_);
+            this->precond_->Build();
+            this->z_.CloneBackend(*this->op_);
+            this->z_.Allocate("z", this->op_->GetM());
+        }
+        this->r_.CloneBackend(*this->op_);
+        this->r_.Allocate("r", this->op_->GetM());
+        this->p_.CloneBackend(*this->op_);
+        this->p_.Allocate("p", this->op_->GetM());
+    }
+    virtual void Clear(void)
+    {
+        if(this->build_)
+        {
+            if(this->precond_ != NULL)
+            {
+                this->precond_->Clear();
+                this->precond_ = NULL;
+            }
+            this->r_.Clear();
+            this->z_.Clear();
+            this->p_.Clear();
+            this->iter_ctrl_.Clear();
+            this->build_ = false;
+        }
+    }
+
+protected:
+    virtual void PrintStart_(void) const
+    {
+        LOG_INFO("Chebyshev " << (this->precond_ ? "" : "(non-precond) ") << "linear solver starts");
+    }
+    virtual void PrintEnd_(void) const
+    {
+        LOG_INFO("Chebyshev ends");
+    }
+    virtual void SolveNonPrecond_(const VectorType& rhs, VectorType* x)
+    {
+        this->Solve_(rhs, x, false);
+    }
+    virtual void SolvePrecond_(const VectorType& rhs, VectorType* x)
+    {
+        this->Solve_(rhs, x, true);
+    }
+
+private:
+    void Solve_(const VectorType& rhs, VectorType* x, bool precond)
+    {
+        const OperatorType* op = this->op_;
+        VectorType *        r = &this->r_, *p = &this->p_;
+        VectorType*         z = precond ? &this->z_ : r;
+        const ValueType     two = static_cast<ValueType>(2), one = static_cast<ValueType>(1);
+        ValueType           alpha, beta;
+        const ValueType     d = (this->lambda_max_ + this->lambda_min_) / two;
+        const ValueType     c = (this->lambda_max_ - this->lambda_min_) / two;
+        op->Apply(*x, r);
+        r->ScaleAdd(-one, rhs);
+        ValueType res = this->Norm_(*r);
+        if(this->iter_ctrl_.InitResidual(std::abs(res)) == false)
+            return;
+        if(precond)
+            this->precond_->SolveZeroSol(*r, z);
+        p->CopyFrom(*z);
+        alpha = two / d;
+        x->AddScale(*p, alpha);
+        op->Apply(*x, r);
+        r->ScaleAdd(-one, rhs);
+        res = this->Norm_(*r);
+        while(!this->iter_ctrl_.CheckResidual(std::abs(res), this->index_))
+        {
+            if(precond)
+                this->precond_->SolveZeroSol(*r, z);
+            beta  = (c * alpha / two) * (c * alpha / two);
+            alpha = one / (d - beta);
+            p->ScaleAdd(beta, *z);
+            x->AddScale(*p, alpha);
+            op->Apply(*x, r);
+            r->ScaleAdd(-one, rhs);
+            res = this->Norm_(*r);
+        }
+    }
+    bool       init_lambda_;
+    ValueType  lambda_min_, lambda_max_;
+    VectorType r_, z_, p_;
 };
 
 // ============================================================================ MixedPrecisionDC

@@ -285,7 +285,9 @@ enum { RAMD_SOLVER_CG = 0, RAMD_SOLVER_GMRES = 1, RAMD_SOLVER_BICGSTAB = 2,
         * restart length of (F)GMRES and the order l of BiCGStab(l) */
        RAMD_SOLVER_FCG = 3, RAMD_SOLVER_CR = 4, RAMD_SOLVER_FGMRES = 5, RAMD_SOLVER_BICGSTABL = 6,
        RAMD_SOLVER_QMRCGSTAB = 7,
-       RAMD_SOLVER_IDR = 8 /* idr.cpp; set_basis = SetShadowSpace, ramd_solver_set_seed = SetRandomSeed */ };
+       RAMD_SOLVER_IDR = 8, /* idr.cpp; set_basis = SetShadowSpace, ramd_solver_set_seed = SetRandomSeed */
+       /* solver.cpp:517-775 FixedPoint, chebyshev.cpp; parameters through ramd_solver_set_params */
+       RAMD_SOLVER_FIXEDPOINT = 9, RAMD_SOLVER_CHEBYSHEV = 10 };
 enum { RAMD_PC_NONE = 0, RAMD_PC_JACOBI = 1, RAMD_PC_ILU0 = 2, RAMD_PC_MCSGS = 3, RAMD_PC_MCGS = 4, RAMD_PC_MCILU = 5,
        RAMD_PC_GS = 6, RAMD_PC_SGS = 7 /* preconditioner.cpp:206-257 / :302-379 */ };
 int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out);
@@ -297,6 +299,8 @@ int ramd_solver_init(ramd_solver_t s, double abs_tol, double rel_tol, double div
 int ramd_solver_init_inner(ramd_solver_t s, double abs_tol, double rel_tol, double div_tol, int max_iter);
 int ramd_solver_set_basis(ramd_solver_t s, int size_basis); /* GMRES::SetBasisSize */
 int ramd_solver_set_seed(ramd_solver_t s, unsigned long long seed); /* IDR::SetRandomSeed (idr.cpp:277-285) */
+/* FixedPoint: p0 = SetRelaxation(omega), p1 != 0 -> FlagSmoother();  Chebyshev: Set(lambda_min = p0, lambda_max = p1) */
+int ramd_solver_set_params(ramd_solver_t s, double p0, double p1);
 int ramd_solver_set_fused(ramd_solver_t s, int on); /* fused device loops on/off (default on) */
 int ramd_solver_set_verbose(ramd_solver_t s, int verb);
 int ramd_solver_set_precond_format(ramd_solver_t s, int format); /* MultiColored::SetPrecondMatrixFormat */

@@ -99,8 +99,7 @@ static void orc_ic_finish(const orc_iter_ctrl* ic, orc_solve_cfg* cfg)
 /* iter_ctrl.cpp:89-121 InitResidual: returns 0 ("false") when the solver must not iterate */
 static int orc_ic_init_residual(orc_iter_ctrl* ic, double res)
 {
-    ic->initial_residual = res;
-    ic->current_res      = res;
+    ic->initial_residual = res; /* current_res_ is not touched by InitResidual */
     ic->reached          = 0;
     ic->iteration        = 0;
     ic_record(ic, res);
@@ -143,6 +142,17 @@ static int orc_ic_check_residual(orc_iter_ctrl* ic, double res)
     if(res / ic->initial_residual >= ic->div_tol)
     {
         ic->reached = 3;
+        return 1;
+    }
+    return 0;
+}
+
+/* iter_ctrl.cpp:295-306 CheckMaximumIterNoCount (FixedPoint: skip the last residual) */
+static int orc_ic_check_max_iter_nocount(orc_iter_ctrl* ic)
+{
+    if(ic->iteration + 1 >= ic->max_iter)
+    {
+        ic->reached = 4;
         return 1;
     }
     return 0;

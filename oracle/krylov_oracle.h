@@ -10,7 +10,7 @@ extern "C" {
 
 enum { ORC_CSR = 1, ORC_ELL = 6, ORC_HYB = 7 }; /* numbering of src/base/matrix_formats.hpp */
 enum { ORC_CG = 0, ORC_GMRES = 1, ORC_BICGSTAB = 2, ORC_FCG = 3, ORC_CR = 4, ORC_FGMRES = 5, ORC_BICGSTABL = 6,
-       ORC_QMRCGSTAB = 7, ORC_IDR = 8 };
+       ORC_QMRCGSTAB = 7, ORC_IDR = 8, ORC_FIXEDPOINT = 9, ORC_CHEBYSHEV = 10 };
 enum { ORC_PC_NONE = 0, ORC_PC_JACOBI = 1, ORC_PC_ILU0 = 2, ORC_PC_MCSGS = 3, ORC_PC_MCGS = 4, ORC_PC_MCILU = 5,
        ORC_PC_GS = 6, ORC_PC_SGS = 7 };
 #define ORC_PC_IS_MC(k) ((k) == ORC_PC_MCSGS || (k) == ORC_PC_MCGS || (k) == ORC_PC_MCILU)
@@ -23,6 +23,7 @@ typedef struct
     int    format; /* operator format used by Apply during Solve */
     int    basis; /* GMRES / FGMRES restart length (default 30, gmres.cpp:50); BiCGStab(l): l (default 2);
                      IDR(s): s (default 4) */
+    double p0, p1; /* FixedPoint: p0 = omega (0 -> 1), p1 != 0 -> FlagSmoother(); Chebyshev: lambda_min, lambda_max */
     unsigned long long seed; /* IDR: SetRandomSeed (shadow space P_i = SetRandomNormal((i+1)*seed)) */
     double abs_tol, rel_tol, div_tol; /* defaults 1e-15 / 1e-6 / 1e8 (iter_ctrl.cpp:52-56) */
     int    min_iter, max_iter;

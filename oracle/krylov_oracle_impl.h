@@ -1776,6 +1776,94 @@ static void SUF(solve_idr)(const SUF(orc_op) * A, SUF(orc_pc) * P_, const T* rhs
     free(t);
 }
 
+/* src/solvers/solver.cpp:679-775 FixedPoint::SolvePrecond_ (modified Richardson, x += omega M^-1 (b - A x));
+ * the smoother form (FlagSmoother) runs max_iter steps without any norm */
+static void SUF(solve_fixedpoint)(const SUF(orc_op) * A, SUF(orc_pc) * P, const T* rhs, T* x, orc_iter_ctrl* ic,
+                                  T omega, int smoother)
+{
+    int n     = A->nrow;
+    T*  x_res = (T*)calloc((size_t)n, sizeof(T));
+    T*  x_old = (T*)calloc((size_t)n, sizeof(T));
+    if(P && smoother)
+    {
+        int steps = ic->max_iter;
+        if(steps >= 1)
+        {
+            (void)orc_ic_init_residual(ic, 1.0);
+            for(int iter = 0; iter < steps; ++iter)
+            {
+                SUF(residual)(A, rhs, x, x_res);
+                SUF(pc_solve)(P, x_res, x_old);
+                SUF(orc_add_scale)(n, x, x_old, omega);
+            }
+        }
+    }
+    else if(P && ic->max_iter >= 1)
+    {
+        SUF(residual)(A, rhs, x, x_res);
+        T res = SUF(orc_norm)(n, x_res);
+        if(orc_ic_init_residual(ic, fabs((double)res)))
+        {
+            while(1)
+            {
+                SUF(pc_solve)(P, x_res, x_old);
+                SUF(orc_add_scale)(n, x, x_old, omega);
+                if(orc_ic_check_max_iter_nocount(ic))
+                    break;
+                SUF(residual)(A, rhs, x, x_res);
+                res = SUF(orc_norm)(n, x_res);
+                if(orc_ic_check_residual(ic, fabs((double)res)))
+                    break;
+            }
+        }
+    }
+    free(x_res);
+    free(x_old);
+}
+
+/* src/solvers/chebyshev.cpp:230-287 / :290-360 (lambda_min / lambda_max set by the caller) */
+static void SUF(solve_chebyshev)(const SUF(orc_op) * A, SUF(orc_pc) * P, const T* rhs, T* x, orc_iter_ctrl* ic,
+                                 T lambda_min, T lambda_max)
+{
+    int n = A->nrow;
+    T*  r = (T*)calloc((size_t)n, sizeof(T));
+    T*  z = (T*)calloc((size_t)n, sizeof(T));
+    T*  p = (T*)calloc((size_t)n, sizeof(T));
+    T   two = (T)2, alpha, beta;
+    T   d = (lambda_max + lambda_min) / two;
+    T   c = (lambda_max - lambda_min) / two;
+    SUF(residual)(A, rhs, x, r);
+    T res = SUF(orc_norm)(n, r);
+    if(orc_ic_init_residual(ic, fabs((double)res)))
+    {
+        const T* zz = r;
+        if(P)
+        {
+            SUF(pc_solve)(P, r, z);
+            zz = z;
+        }
+        memcpy(p, zz, sizeof(T) * (size_t)n);
+        alpha = two / d;
+        SUF(orc_add_scale)(n, x, p, alpha);
+        SUF(residual)(A, rhs, x, r);
+        res = SUF(orc_norm)(n, r);
+        while(!orc_ic_check_residual(ic, fabs((double)res)))
+        {
+            if(P)
+                SUF(pc_solve)(P, r, z);
+            beta  = (c * alpha / two) * (c * alpha / two);
+            alpha = (T)1 / (d - beta);
+            SUF(orc_scale_add)(n, p, beta, zz);
+            SUF(orc_add_scale)(n, x, p, alpha);
+            SUF(residual)(A, rhs, x, r);
+            res = SUF(orc_norm)(n, r);
+        }
+    }
+    free(r);
+    free(z);
+    free(p);
+}
+
 /* src/solvers/krylov/bicgstab.cpp:245-361 (no preconditioner) / :365-489 (right preconditioned) */
 static void SUF(solve_bicgstab)(const SUF(orc_op) * A, SUF(orc_pc) * P, const T* rhs, T* x,
                                 orc_iter_ctrl* ic)
@@ -1877,6 +1965,11 @@ int SUF(orc_solve)(int nrow, int64_t nnz, const int* row_offset, const int* col,
         SUF(solve_bicgstabl)(&A, have_pc ? &P : NULL, rhs, x, &ic, cfg->basis > 0 ? cfg->basis : 2);
     else if(cfg->solver == ORC_QMRCGSTAB)
         SUF(solve_qmrcgstab)(&A, have_pc ? &P : NULL, rhs, x, &ic);
+    else if(cfg->solver == ORC_FIXEDPOINT)
+        SUF(solve_fixedpoint)(&A, have_pc ? &P : NULL, rhs, x, &ic, cfg->p0 != 0.0 ? (T)cfg->p0 : (T)1,
+                              cfg->p1 != 0.0);
+    else if(cfg->solver == ORC_CHEBYSHEV)
+        SUF(solve_chebyshev)(&A, have_pc ? &P : NULL, rhs, x, &ic, (T)cfg->p0, (T)cfg->p1);
     else if(cfg->solver == ORC_IDR)
         SUF(solve_idr)(&A, have_pc ? &P : NULL, rhs, x, &ic, cfg->basis > 0 ? cfg->basis : 4,
                        cfg->seed ? cfg->seed : 1ULL);

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 CSR, ELL, HYB = 1, 6, 7
-CG, GMRES, BICGSTAB, FCG, CR, FGMRES, BICGSTABL, QMRCGSTAB, IDR = 0, 1, 2, 3, 4, 5, 6, 7, 8
+CG, GMRES, BICGSTAB, FCG, CR, FGMRES, BICGSTABL, QMRCGSTAB, IDR, FIXEDPOINT, CHEBYSHEV = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 PC_NONE, PC_JACOBI, PC_ILU0, PC_MCSGS, PC_MCGS, PC_MCILU, PC_GS, PC_SGS = 0, 1, 2, 3, 4, 5, 6, 7
 
 
@@ -32,6 +32,7 @@ def build(force=False):
 class SolveCfg(C.Structure):
     _fields_ = [
         ("solver", C.c_int), ("precond", C.c_int), ("format", C.c_int), ("basis", C.c_int),
+        ("p0", C.c_double), ("p1", C.c_double),
         ("seed", C.c_ulonglong),
         ("abs_tol", C.c_double), ("rel_tol", C.c_double), ("div_tol", C.c_double),
         ("min_iter", C.c_int), ("max_iter", C.c_int),
@@ -352,7 +353,7 @@ def _cfg(solver, precond, fmt, basis, abs_tol, rel_tol, div_tol, max_iter, min_i
 
 
 def solve(rp, ci, va, rhs, x0=None, solver=CG, precond=PC_NONE, fmt=CSR, basis=30, abs_tol=1e-15,
-          rel_tol=1e-6, div_tol=1e8, max_iter=1000000, min_iter=0, history=True, hist_cap=None, seed=0):
+          rel_tol=1e-6, div_tol=1e8, max_iter=1000000, min_iter=0, history=True, hist_cap=None, seed=0, p0=0.0, p1=0.0):
     """Build()+Solve() with the reference's control flow. Returns dict(x, iters, status, init_res,
     final_res, history)."""
     rp, ci = _i32(rp), _i32(ci)
@@ -362,6 +363,7 @@ def solve(rp, ci, va, rhs, x0=None, solver=CG, precond=PC_NONE, fmt=CSR, basis=3
     cap = (hist_cap if hist_cap is not None else min(max_iter + 2, 200000)) if history else 0
     cfg, hist = _cfg(solver, precond, fmt, basis, abs_tol, rel_tol, div_tol, max_iter, min_iter, cap)
     cfg.seed = int(seed)
+    cfg.p0, cfg.p1 = float(p0), float(p1)
     f, _ = _fn("orc_solve", dtype)
     f(C.c_int(n), C.c_int64(len(va)), _p(rp), _p(ci), _p(va), _p(np.ascontiguousarray(rhs, dtype=dtype)),
       _p(x), C.byref(cfg))

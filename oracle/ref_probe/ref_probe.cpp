@@ -92,7 +92,12 @@ static void run_solver(const std::string& tag, Solver& ls, VecD& rhs, VecD& x)
     ls.RecordResidualHistory();
     ls.Solve(rhs, &x);
     std::string hf = g_out + "/" + tag + "_hist.txt";
-    ls.RecordHistory(hf);
+    if(ls.GetIterationCount() > 0) // WriteHistoryToFile asserts on a run without counted iterations
+        ls.RecordHistory(hf);
+    else
+    {
+        std::ofstream empty(hf.c_str());
+    }
     double meta[3] = {(double)ls.GetIterationCount(), (double)ls.GetSolverStatus(),
                       ls.GetCurrentResidual()};
     dump(tag + "_meta", meta, 3);
@@ -533,6 +538,52 @@ static int cmd_gen(const std::string& in, const std::string& out)
             ls.Build();
             sol.Zeros();
             run_solver("bicgstab_gs", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            FixedPoint<MatD, VecD, double> ls; // damped Jacobi iteration, capped
+            Jacobi<MatD, VecD, double>     p;
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(p);
+            ls.SetRelaxation(0.8);
+            ls.InitMaxIter(40);
+            ls.Build();
+            sol.Zeros();
+            run_solver("fixedpoint_jacobi", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            FixedPoint<MatD, VecD, double>      ls; // as a smoother: 3 steps, no norms
+            MultiColoredSGS<MatD, VecD, double> p;
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(p);
+            ls.FlagSmoother();
+            ls.InitMaxIter(3);
+            ls.Build();
+            sol.Zeros();
+            run_solver("fixedpoint_smoother_mcsgs", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            Chebyshev<MatD, VecD, double> ls; // Gershgorin-style bounds of the test operators: (0.05, 16)
+            ls.SetOperator(mat);
+            ls.Set(0.05, 16.0);
+            ls.InitMaxIter(60);
+            ls.Build();
+            sol.Zeros();
+            run_solver("chebyshev_none", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            Chebyshev<MatD, VecD, double> ls;
+            Jacobi<MatD, VecD, double>    p;
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(p);
+            ls.Set(0.01, 2.0);
+            ls.InitMaxIter(60);
+            ls.Build();
+            sol.Zeros();
+            run_solver("chebyshev_jacobi", ls, rhs, sol);
             ls.Clear();
         }
         {

@@ -15,6 +15,7 @@ if os.environ.get("RAMD_LIB"):  # A/B runs of differently built libraries (tools
 OK, ERR_HIP, ERR_ARG, ERR_UNSUPPORTED, ERR_REFUSED, ERR_NO_DEVICE, ERR_STATE = range(7)
 SOLVER_CG, SOLVER_GMRES, SOLVER_BICGSTAB = 0, 1, 2
 SOLVER_FCG, SOLVER_CR, SOLVER_FGMRES, SOLVER_BICGSTABL, SOLVER_QMRCGSTAB, SOLVER_IDR = 3, 4, 5, 6, 7, 8
+SOLVER_FIXEDPOINT, SOLVER_CHEBYSHEV = 9, 10
 PC_NONE, PC_JACOBI, PC_ILU0, PC_MCSGS, PC_MCGS, PC_MCILU, PC_GS, PC_SGS = 0, 1, 2, 3, 4, 5, 6, 7
 F64, F32, I32 = 0, 1, 2
 CSR, COO, ELL, HYB = 1, 4, 6, 7
@@ -150,6 +151,7 @@ SIGNATURES = {
     "ramd_solver_init_inner": (i32, [ptr, f64, f64, f64, i32]),
     "ramd_solver_set_basis": (i32, [ptr, i32]),
     "ramd_solver_set_seed": (i32, [ptr, C.c_ulonglong]),
+    "ramd_solver_set_params": (i32, [ptr, f64, f64]),
     "ramd_solver_set_fused": (i32, [ptr, i32]),
     "ramd_solver_set_verbose": (i32, [ptr, i32]),
     "ramd_solver_set_precond_format": (i32, [ptr, i32]),

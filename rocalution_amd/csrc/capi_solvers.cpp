@@ -29,6 +29,7 @@ struct SolverBase
     virtual void set_decomposition(bool) {}
     virtual void set_fused_sweeps(bool) {}
     virtual void set_seed(unsigned long long) {}
+    virtual void set_params(double, double) {}
     virtual void build(ramd_mat_t op)                                    = 0;
     virtual void solve(ramd_vec_t rhs, ramd_vec_t x)                     = 0;
     virtual bool precond_apply(ramd_vec_t, ramd_vec_t)                   = 0;
@@ -100,6 +101,8 @@ struct LocalSolver : SolverBase
     BiCGStabl<M, V, T>                              bicgl;
     QMRCGStab<M, V, T>                              qmr;
     IDR<M, V, T>                                    idr;
+    FixedPoint<M, V, T>                             fp;
+    Chebyshev<M, V, T>                              cheb;
     Precs<T>                                        pcs;
     M                                               op; // non-owning view of the caller's matrix
     bool                                            built = false;
@@ -130,6 +133,10 @@ struct LocalSolver : SolverBase
             return &qmr;
         case RAMD_SOLVER_IDR:
             return &idr;
+        case RAMD_SOLVER_FIXEDPOINT:
+            return &fp;
+        case RAMD_SOLVER_CHEBYSHEV:
+            return &cheb;
         default:
             return &cg;
         }
@@ -152,6 +159,17 @@ struct LocalSolver : SolverBase
     void set_seed(unsigned long long seed) override
     {
         idr.SetRandomSeed(seed);
+    }
+    void set_params(double p0, double p1) override
+    {
+        if(solver_kind == RAMD_SOLVER_FIXEDPOINT)
+        {
+            fp.SetRelaxation((T)p0);
+            if(p1 != 0.0)
+                fp.FlagSmoother();
+        }
+        else if(solver_kind == RAMD_SOLVER_CHEBYSHEV)
+            cheb.Set((T)p0, (T)p1);
     }
     void set_fused(bool f) override
     {
@@ -415,7 +433,7 @@ extern "C" {
 
 int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out)
 {
-    if(!out || solver < 0 || solver > RAMD_SOLVER_IDR || precond < 0 || precond > RAMD_PC_SGS
+    if(!out || solver < 0 || solver > RAMD_SOLVER_CHEBYSHEV || precond < 0 || precond > RAMD_PC_SGS
        || (dtype != RAMD_F64 && dtype != RAMD_F32))
         return RAMD_ERR_ARG;
     GUARD_BEGIN
@@ -462,6 +480,14 @@ int ramd_solver_init_inner(ramd_solver_t s, double a, double r, double d, int mx
         return RAMD_ERR_ARG;
     s->impl->init_inner(a, r, d, mx);
     return RAMD_OK;
+}
+int ramd_solver_set_params(ramd_solver_t s, double p0, double p1)
+{
+    if(!s)
+        return RAMD_ERR_ARG;
+    GUARD_BEGIN
+    s->impl->set_params(p0, p1);
+    GUARD_END
 }
 int ramd_solver_set_seed(ramd_solver_t s, unsigned long long seed)
 {

@@ -12,7 +12,8 @@ import numpy as np
 
 from . import capi
 from .capi import (PC_GS, PC_ILU0, PC_JACOBI, PC_MCGS, PC_MCILU, PC_MCSGS, PC_NONE, PC_SGS, SOLVER_BICGSTAB, SOLVER_BICGSTABL,
-                   SOLVER_CG, SOLVER_CR, SOLVER_FCG, SOLVER_FGMRES, SOLVER_GMRES, SOLVER_IDR, SOLVER_QMRCGSTAB)
+                   SOLVER_CG, SOLVER_CHEBYSHEV, SOLVER_CR, SOLVER_FCG, SOLVER_FGMRES, SOLVER_FIXEDPOINT, SOLVER_GMRES,
+                   SOLVER_IDR, SOLVER_QMRCGSTAB)
 
 
 def _lib():
@@ -243,6 +244,39 @@ class IDR(_IterativeLinearSolver):
     def _configure_extra(self):
         if self._seed is not None:
             capi.check(_lib().ramd_solver_set_seed(self._h, self._seed))
+
+
+class FixedPoint(_IterativeLinearSolver):
+    """x += omega M^-1 (b - A x) (src/solvers/solver.cpp:517-775); needs a preconditioner"""
+    kind = SOLVER_FIXEDPOINT
+
+    def __init__(self, dtype=np.float64):
+        super().__init__(dtype)
+        self._omega, self._smoother = 1.0, False
+
+    def SetRelaxation(self, omega):
+        self._omega = float(omega)
+
+    def FlagSmoother(self):
+        self._smoother = True
+
+    def _configure_extra(self):
+        capi.check(_lib().ramd_solver_set_params(self._h, self._omega, 1.0 if self._smoother else 0.0))
+
+
+class Chebyshev(_IterativeLinearSolver):
+    """Chebyshev iteration with caller-supplied eigenvalue bounds (src/solvers/chebyshev.cpp)"""
+    kind = SOLVER_CHEBYSHEV
+
+    def __init__(self, dtype=np.float64):
+        super().__init__(dtype)
+        self._lmin = self._lmax = None
+
+    def Set(self, lambda_min, lambda_max):
+        self._lmin, self._lmax = float(lambda_min), float(lambda_max)
+
+    def _configure_extra(self):
+        capi.check(_lib().ramd_solver_set_params(self._h, self._lmin, self._lmax))
 
 
 class QMRCGStab(_IterativeLinearSolver):

@@ -171,6 +171,10 @@ SOLVER_TABLE = {
     "idr2_jacobi": ("IDR", "PC_JACOBI", "CSR", dict(basis=2, seed=777)),
     "cg_sgs": ("CG", "PC_SGS", "CSR", {}),
     "bicgstab_gs": ("BICGSTAB", "PC_GS", "CSR", {}),
+    "fixedpoint_jacobi": ("FIXEDPOINT", "PC_JACOBI", "CSR", dict(p0=0.8, max_iter=40)),
+    "fixedpoint_smoother_mcsgs": ("FIXEDPOINT", "PC_MCSGS", "CSR", dict(p0=1.0, p1=1.0, max_iter=3)),
+    "chebyshev_none": ("CHEBYSHEV", "PC_NONE", "CSR", dict(p0=0.05, p1=16.0, max_iter=60)),
+    "chebyshev_jacobi": ("CHEBYSHEV", "PC_JACOBI", "CSR", dict(p0=0.01, p1=2.0, max_iter=60)),
 }
 
 
