@@ -236,6 +236,8 @@ int ramd_fused_normalize(ramd_vec_t v, int slot_sq, int slot_norm);
  * HIP-event timing on the stream the kernels are launched on (bench.py): a stopwatch around any
  * region, and an optional per-launch bracket of every SpMV (Apply / fused Apply+dot) so that the
  * kernel's average duration is measured live inside a solver run. */
+/* free / total device memory in bytes (hipMemGetInfo): leak checks, sizing */
+int ramd_mem_info(uint64_t* free_bytes, uint64_t* total_bytes);
 int ramd_timer_start(void); /* records an event on the current stream */
 int ramd_timer_stop(double* elapsed_ms); /* records, synchronises, returns the elapsed time */
 int ramd_prof_spmv_enable(int on); /* bracket SpMV launches with event pairs (ring of 8192) */

@@ -193,6 +193,18 @@ int ramd_free_pinned(void* ptr)
 // ---------------------------------------------------------------- measurement hooks
 static hipEvent_t g_t0 = nullptr, g_t1 = nullptr;
 
+int ramd_mem_info(uint64_t* free_bytes, uint64_t* total_bytes)
+{
+    RAMD_TRY(ensure_init());
+    size_t f = 0, t = 0;
+    RAMD_HIP(hipMemGetInfo(&f, &t));
+    if(free_bytes)
+        *free_bytes = (uint64_t)f;
+    if(total_bytes)
+        *total_bytes = (uint64_t)t;
+    return RAMD_OK;
+}
+
 int ramd_timer_start(void)
 {
     RAMD_TRY(ensure_init());

@@ -192,3 +192,44 @@ def test_fp32_solvers_vs_oracle(ra, S, oracle, sname):
     # backend may need FEWER iterations near the fp32 limit, never noticeably more
     assert ls.GetIterationCount() <= r["iters"] + 2 and ls.GetSolverStatus() == r["status"]
     assert np.max(np.abs(x.numpy() - 1.0)) < 1e-3
+
+
+def test_build_clear_cycles_do_not_leak_device_memory(ra, S):
+    """every Build()/Clear() pair (preconditioner plans, analysis data, work vectors, format conversions) gives
+    its device memory back: free memory after 12 cycles == after 2 cycles"""
+    import ctypes as C
+    from rocalution_amd import capi
+    lib = capi.load()
+
+    def free_bytes():
+        f, t = C.c_uint64(0), C.c_uint64(0)
+        capi.check(lib.ramd_mem_info(C.byref(f), C.byref(t)))
+        return f.value
+    rp, ci, va = gen.poisson7(40)
+    n = len(rp) - 1
+
+    def cycle():
+        A = ra.LocalMatrix(); A.SetDataPtrCSR(rp, ci, va)
+        rhs = ra.LocalVector(data=np.ones(n)); x = ra.LocalVector(); x.Allocate("", n)
+        for sname, pname in (("CG", "Jacobi"), ("GMRES", "ILU"), ("BiCGStab", "MultiColoredSGS"), ("FGMRES", "MultiColoredILU"),
+                             ("IDR", "SGS"), ("BiCGStabl", "GS"), ("QMRCGStab", "MultiColoredGS"), ("CR", None)):
+            ls = getattr(S, sname)(); ls.SetOperator(A)
+            if pname:
+                ls.SetPreconditioner(getattr(S, pname)())
+            if sname == "IDR":
+                ls.SetRandomSeed(5)
+            ls.InitMaxIter(5); ls.Build(); x.Zeros(); ls.Solve(rhs, x); ls.Clear()
+        for fmt in (ra.ELL, ra.CSR, ra.HYB, ra.COO, ra.CSR):
+            A.ConvertTo(fmt)
+        B = ra.LocalMatrix(); B.CloneFrom(A); B.ILU0Factorize(); B.LUAnalyse(); B.LUAnalyseClear()
+        mp = S.MixedPrecisionDC(); inner = S.CG(np.float32); inner.SetPreconditioner(S.Jacobi())
+        inner.Init(1e-5, 1e-2, 1e20, 100); mp.SetOperator(A); mp.Set(inner); mp.InitMaxIter(2); mp.Build()
+        x.Zeros(); mp.Solve(rhs, x); mp.Clear()
+
+    free = []
+    for i in range(12):
+        cycle()
+        ra.sync()
+        import gc; gc.collect()
+        free.append(free_bytes())
+    assert free[-1] >= free[1] - (1 << 20), [f - free[1] for f in free]
