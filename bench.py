@@ -140,12 +140,15 @@ def main():
 
     dist = None
     comm = C.c_void_p()
-    if world > 1:
+    if world > 1 or args.force_global:
+        # torch.distributed (gloo) is the control plane only: it ships the 128-byte RCCL id and the timing
+        # reduction.  --force-global walks the very same path with one rank (plumbing check on a 1-GPU box).
         import torch
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)  # control plane only
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         uid = C.create_string_buffer(128)
         if rank == 0:
             capi.check(lib.ramd_comm_unique_id(uid))
@@ -153,10 +156,6 @@ def main():
         dist.broadcast(t, src=0)
         uid = C.create_string_buffer(bytes(t.tolist()), 128)
         capi.check(lib.ramd_comm_init_rccl(rank, world, uid, C.byref(comm)))  # data plane: RCCL over xGMI
-    elif args.force_global:
-        uid = C.create_string_buffer(128)
-        capi.check(lib.ramd_comm_unique_id(uid))
-        capi.check(lib.ramd_comm_init_rccl(0, 1, uid, C.byref(comm)))
 
     if comm:
         C.CDLL(None).fflush(None)  # RCCL's version banner sits in C stdio: get it out before the JSON line
@@ -281,6 +280,8 @@ def main():
 
         def run(iters):
             capi.check(lib.ramd_gsolver_init(g, NEVER[0], NEVER[1], NEVER[2], 0, iters))
+            if fmt != ra.CSR:  # preconditioners are built from the CSR state (second run: convert back first)
+                capi.check(lib.ramd_gsolver_convert(g, ra.CSR))
             capi.check(lib.ramd_gsolver_build(g))
             if fmt != ra.CSR:  # converted after Build(), as the reference tests do
                 capi.check(lib.ramd_gsolver_convert(g, fmt))
