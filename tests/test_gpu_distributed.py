@@ -50,3 +50,49 @@ def test_two_ranks_one_gpu(kind, oracle):
     xs3 = np.concatenate([r["xs3"] for r in res])
     assert abs(int(res[0]["it3"]) - refm["iters"]) <= 1 and int(res[0]["st3"]) == refm["status"]
     assert np.linalg.norm(xs3 - refm["x"]) / np.linalg.norm(refm["x"]) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_rccl_halo_and_allreduce_on_a_size_one_communicator(dtype):
+    """RCCL refuses two ranks on one device, so the RCCL data plane is exercised with ONE rank: the halo
+    exchange sends to / receives from itself (grouped ncclSend/ncclRecv on the ghost stream, ordered by
+    events against the compute stream) and the scalar all-reduce runs on the device record."""
+    import ctypes as C
+    import subprocess
+    code = r'''
+import ctypes as C, os, sys
+import numpy as np
+os.environ["RAMD_COMM_FORCE_COLLECTIVES"] = "1"
+sys.path.insert(0, %r)
+import rocalution_amd as ra
+from rocalution_amd import capi
+ra.init_rocalution()
+lib = capi.load()
+dtype = np.%s
+uid = C.create_string_buffer(128)
+capi.check(lib.ramd_comm_unique_id(uid))
+comm = C.c_void_p()
+capi.check(lib.ramd_comm_init_rccl(0, 1, uid, C.byref(comm)))
+n = 300000
+src = np.random.default_rng(1).uniform(-1, 1, n).astype(dtype)
+send = ra.LocalVector(dtype, data=src); recv = ra.LocalVector(dtype); recv.Allocate("", n)
+peers = (C.c_int * 2)(0, 0)              # two "neighbours", both myself: two send/recv pairs in one group
+so = (C.c_int64 * 3)(0, 100000, n); ro = (C.c_int64 * 3)(0, 100000, n)
+for rep in range(3):
+    recv.Zeros()
+    send.Scale(2.0)                      # queued on the compute stream right before the exchange
+    capi.check(lib.ramd_comm_halo_begin(comm, send._h, recv._h, 2, peers, so, ro))
+    capi.check(lib.ramd_comm_halo_end(comm))
+    got = recv.numpy()
+    exp = (src * dtype(2.0) ** (rep + 1)).astype(dtype)
+    assert np.array_equal(got, exp), rep
+capi.check(lib.ramd_scalars_set(3, 1.25)); capi.check(lib.ramd_scalars_set(4, -7.5))
+capi.check(lib.ramd_comm_allreduce_scalars(comm, 3, 2))
+out = (C.c_double * 2)()
+capi.check(lib.ramd_scalars_fetch(out, 3, 2))
+assert (out[0], out[1]) == (1.25, -7.5)
+capi.check(lib.ramd_comm_destroy(comm))
+print("rccl self-exchange ok")
+''' % (ROOT, "float64" if dtype == np.float64 else "float32")
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0 and b"rccl self-exchange ok" in r.stdout, r.stdout.decode()[-2000:]
