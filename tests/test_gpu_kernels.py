@@ -479,3 +479,38 @@ def test_fused_bicgstab_updates(ra, dtype, precond):
     eq(vx.numpy(), rx.numpy()); eq(vr.numpy(), r)
     capi.check(lib.ramd_scalars_fetch(out, 0, 7))
     assert out[S_FLAG] == 1.0
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_csr_long_rows_across_lds_chunks(ra, oracle, dtype):
+    """rows of 20-50 entries: a 256-row workgroup needs several LDS chunks, rows straddle chunk borders;
+    empty rows and one row with every column included.  Apply, ApplyAdd, fused dot: bit-exact."""
+    import ctypes as C
+    from rocalution_amd import capi
+    lib = capi.load()
+    rng = np.random.default_rng(31)
+    n = 3000
+    rows = []
+    for i in range(n):
+        k = int(rng.integers(20, 50))
+        rows.append(sorted(set(np.clip(i + rng.integers(-400, 401, k), 0, n - 1).tolist())))
+    rows[7] = []; rows[8] = []; rows[1500] = list(range(0, n, 1))
+    rp = np.zeros(n + 1, np.int32); rp[1:] = np.cumsum([len(r) for r in rows])
+    ci = np.array([c for r in rows for c in r], np.int32)
+    va = rng.uniform(-1, 1, len(ci)).astype(dtype)
+    xh = rng.uniform(-1, 1, n).astype(dtype); y0 = rng.uniform(-1, 1, n).astype(dtype)
+    A = ra.LocalMatrix(dtype); A.SetDataPtrCSR(rp, ci, va)
+    x = ra.LocalVector(dtype, data=xh)
+    y = ra.LocalVector(dtype); y.Allocate("", n)
+    A.Apply(x, y)
+    ref = oracle.csr_apply(rp, ci, va, xh)
+    eq(y.numpy(), ref)
+    ya = ra.LocalVector(dtype, data=y0)
+    A.ApplyAdd(x, -0.75, ya)
+    eq(ya.numpy(), oracle.csr_apply_add(rp, ci, va, xh, dtype(-0.75), y0))
+    w = ra.LocalVector(dtype); w.Allocate("", n)
+    capi.check(lib.ramd_fused_apply_dot(A._h, x._h, w._h, 11))
+    eq(w.numpy(), ref)
+    out = (C.c_double * 1)()
+    capi.check(lib.ramd_scalars_fetch(out, 11, 1))
+    close(out[0], float(np.dot(xh.astype(np.float64), ref.astype(np.float64))), 1e-12 if dtype == np.float64 else 1e-6)
