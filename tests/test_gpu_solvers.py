@@ -326,3 +326,54 @@ def test_fixedpoint_as_smoother(ra, S, name):
     assert (ls.GetIterationCount(), ls.GetSolverStatus()) == (int(meta[0]), int(meta[1])) == (0, 0)
     assert ls.GetCurrentResidual() == meta[2] == 0.0
     eq(x.numpy(), g["fixedpoint_smoother_mcsgs_x"])
+
+
+def _write_mtx(path, rp, ci, va):
+    n = len(rp) - 1
+    with open(path, "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate real general\n%d %d %d\n" % (n, n, len(ci)))
+        rows = np.repeat(np.arange(n), np.diff(rp))
+        for r, c, v in zip(rows, ci, va):
+            f.write("%d %d %.17g\n" % (r + 1, c + 1, v))
+
+
+DRIVER_RUNS = [("cg", "jacobi", "csr", 0, "cg_jacobi"), ("gmres", "ilu", "csr", 30, "gmres_ilu0"),
+               ("bicgstab", "mcsgs", "ell", 0, "bicgstab_mcsgs_ell"), ("cg", "jacobi", "hyb", 0, "cg_jacobi_hyb"),
+               ("mixed", "jacobi", "csr", 0, "mixed_cg_jacobi"), ("qmrcgstab", "mcsgs", "csr", 0, "qmrcgstab_mcsgs"),
+               ("idr", "none", "csr", 4, "idr_none"), ("fcg", "mcsgs", "csr", 0, "fcg_mcsgs"),
+               ("cr", "jacobi", "csr", 0, "cr_jacobi"), ("fgmres", "ilu", "csr", 30, "fgmres_ilu0"),
+               ("bicgstabl", "none", "csr", 2, "bicgstabl_none"), ("cg", "sgs", "csr", 0, "cg_sgs"),
+               ("gmres", "mcilu", "csr", 30, "gmres_mcilu"), ("bicgstab", "gs", "csr", 0, "bicgstab_gs")]
+
+
+def test_cpp_sample_driver_end_to_end(tmp_path):
+    """samples/krylov_driver.cpp -- plain host C++ on include/rocalution (the call sequence of the reference's
+    samples: ReadFileMTX, MoveToAccelerator, Build, ConvertTo after Build, Solve, Clear) -- built with g++
+    and run on the gr_30_30 operator: iteration counts / status of the genuine library's runs"""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "krylov_driver")
+    libdir = os.path.join(root, "rocalution_amd")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "samples", "krylov_driver.cpp"), "-o", exe, "-L" + libdir,
+                           "-lrocalution_amd", "-Wl,-rpath," + libdir])
+    g = load_golden("gr3030")
+    mtx = str(tmp_path / "gr3030.mtx")
+    _write_mtx(mtx, g["rowptr"], g["col"], g["val"])
+    for solver, pc, fmt, param, tag in DRIVER_RUNS:
+        r = subprocess.run([exe, mtx, solver, pc, fmt] + ([str(param)] if param else []), stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, timeout=300)
+        out = r.stdout.decode()
+        assert r.returncode == 0, out[-2000:]
+        m = re.search(r"RESULT .*iters=(\d+) status=(\d+) residual=(\S+) error=(\S+)", out)
+        assert m, out[-2000:]
+        meta = g[tag + "_meta"]
+        slack = 1 if solver in ("cg", "fcg", "cr", "mixed") else 2
+        assert abs(int(m.group(1)) - int(meta[0])) <= slack and int(m.group(2)) == int(meta[1]), (tag, m.groups(), meta)
+        assert float(m.group(4)) < 1e-3, (tag, m.group(4))  # ||1 - x||_2, the samples' own check
+    # the synthetic operator built on the device
+    r = subprocess.run([exe, "poisson:32", "cg", "jacobi"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    m = re.search(r"RESULT .*iters=(\d+) status=(\d+)", r.stdout.decode())
+    assert r.returncode == 0 and m and abs(int(m.group(1)) - 66) <= 1 and int(m.group(2)) == 2
