@@ -860,6 +860,196 @@ public:
         this->need_accel_("ApplyAdd");
         RAMD_CHECK(ramd_mat_apply_add(this->dev_, in.handle(), (double)scalar, out->handle()));
     }
+    // ---- matrix utilities next to the solver path (local_matrix.cpp / host_matrix_csr.cpp:919-1160, :3465-3630)
+    void Gershgorin(ValueType& lambda_min, ValueType& lambda_max) const
+    {
+        this->need_accel_("Gershgorin");
+        double lo = 0.0, hi = 0.0;
+        RAMD_CHECK(ramd_mat_gershgorin(this->dev_, &lo, &hi));
+        lambda_min = static_cast<ValueType>(lo);
+        lambda_max = static_cast<ValueType>(hi);
+    }
+    void ExtractL(LocalMatrix<ValueType>* L, bool diag) const
+    {
+        this->need_accel_("ExtractL");
+        assert(L != NULL && L != this);
+        L->MoveToAccelerator();
+        RAMD_CHECK(ramd_mat_extract_tri(this->dev_, L->handle(), 0, diag ? 1 : 0));
+    }
+    void ExtractU(LocalMatrix<ValueType>* U, bool diag) const
+    {
+        this->need_accel_("ExtractU");
+        assert(U != NULL && U != this);
+        U->MoveToAccelerator();
+        RAMD_CHECK(ramd_mat_extract_tri(this->dev_, U->handle(), 1, diag ? 1 : 0));
+    }
+    void Scale(ValueType alpha)
+    {
+        this->need_accel_("Scale");
+        RAMD_CHECK(ramd_mat_scale_values(this->dev_, (double)alpha, 0));
+    }
+    void ScaleDiagonal(ValueType alpha)
+    {
+        this->need_accel_("ScaleDiagonal");
+        RAMD_CHECK(ramd_mat_scale_values(this->dev_, (double)alpha, 1));
+    }
+    void ScaleOffDiagonal(ValueType alpha)
+    {
+        this->need_accel_("ScaleOffDiagonal");
+        RAMD_CHECK(ramd_mat_scale_values(this->dev_, (double)alpha, 2));
+    }
+    void AddScalar(ValueType alpha)
+    {
+        this->need_accel_("AddScalar");
+        RAMD_CHECK(ramd_mat_add_scalar_values(this->dev_, (double)alpha, 0));
+    }
+    void AddScalarDiagonal(ValueType alpha)
+    {
+        this->need_accel_("AddScalarDiagonal");
+        RAMD_CHECK(ramd_mat_add_scalar_values(this->dev_, (double)alpha, 1));
+    }
+    void AddScalarOffDiagonal(ValueType alpha)
+    {
+        this->need_accel_("AddScalarOffDiagonal");
+        RAMD_CHECK(ramd_mat_add_scalar_values(this->dev_, (double)alpha, 2));
+    }
+    // new values into the existing CSR pattern (LocalMatrix::UpdateValuesCSR)
+    void UpdateValuesCSR(ValueType* val)
+    {
+        assert(val != NULL || this->GetNnz() == 0);
+        if(this->on_accel_)
+            RAMD_CHECK(ramd_mat_update_values(this->dev_, val));
+        else
+            std::copy(val, val + this->h_val_.size(), this->h_val_.begin());
+    }
+    // LocalMatrix::Check (host_matrix_csr.cpp:137-240): structural sanity of the CSR data, run on the host like
+    // the reference does for both of its backends; false (with a message) instead of garbage later
+    bool Check(void) const
+    {
+        std::vector<PtrType>   rp((size_t)this->GetM() + 1, 0);
+        std::vector<int>       ci((size_t)this->GetNnz());
+        std::vector<ValueType> va((size_t)this->GetNnz());
+        const int64_t          nrow = this->GetM(), ncol = this->GetN(), nnz = this->GetNnz();
+        if(nnz == 0)
+            return true;
+        if(this->GetFormat() != CSR)
+        {
+            LocalMatrix<ValueType> tmp;
+            tmp.CloneFrom(*this);
+            tmp.ConvertTo(CSR);
+            tmp.CopyToCSR(rp.data(), ci.data(), va.data());
+        }
+        else
+            this->CopyToCSR(rp.data(), ci.data(), va.data());
+        auto fail = [](const char* what) {
+            LOG_INFO("*** error: Matrix CSR:Check - " << what);
+            return false;
+        };
+        for(int64_t i = 0; i <= nrow; ++i)
+            if(rp[(size_t)i] < 0 || rp[(size_t)i] > nnz)
+                return fail("problems with matrix row offset pointers");
+        bool sorted = true;
+        for(int64_t i = 0; i < nrow; ++i)
+            for(PtrType j = rp[(size_t)i]; j < rp[(size_t)i + 1]; ++j)
+            {
+                const int col  = ci[(size_t)j];
+                const int prev = (j > rp[(size_t)i]) ? ci[(size_t)j - 1] : -1;
+                if(col < 0 || col > ncol)
+                    return fail("problems with matrix col values");
+                if(col == prev)
+                    return fail("problems with matrix col values - the matrix has duplicated column entries");
+                const ValueType v = va[(size_t)j];
+                if(v == std::numeric_limits<ValueType>::infinity() || v != v)
+                    return fail("problems with matrix values");
+                if(j > rp[(size_t)i] && prev >= col)
+                    sorted = false;
+            }
+        if(!sorted)
+            LOG_INFO("*** warning: Matrix CSR:Check - the matrix has not sorted columns");
+        return true;
+    }
+    // COO input (LocalMatrix::SetDataPtrCOO, local_matrix.cpp:782-850): kept as row-sorted data -- entries are
+    // moved to their rows by a STABLE counting sort, so the products of a row are still added in storage
+    // order (the order of the reference's serial COO loop restricted to that row).  GetFormat() == COO once
+    // the object is on the accelerator.
+    void SetDataPtrCOO(int** row, int** col, ValueType** val, std::string name, int64_t nnz, int64_t nrow,
+                       int64_t ncol)
+    {
+        assert(row != NULL && col != NULL && val != NULL);
+        this->CopyFromCOO_(*row, *col, *val, name, nnz, nrow, ncol);
+        delete[] * row;
+        delete[] * col;
+        delete[] * val;
+        *row = NULL;
+        *col = NULL;
+        *val = NULL;
+    }
+    void LeaveDataPtrCOO(int** row, int** col, ValueType** val)
+    {
+        const int64_t nnz = this->GetNnz();
+        allocate_host(nnz, row);
+        allocate_host(nnz, col);
+        allocate_host(nnz, val);
+        this->CopyToCOO(*row, *col, *val);
+        this->Clear();
+    }
+    void CopyToCOO(int* row, int* col, ValueType* val) const
+    {
+        const int64_t          nrow = this->GetM(), nnz = this->GetNnz();
+        std::vector<PtrType>   rp((size_t)nrow + 1, 0);
+        const LocalMatrix<ValueType>* src = this;
+        LocalMatrix<ValueType>        tmp;
+        if(this->GetFormat() != CSR)
+        {
+            tmp.CloneFrom(*this);
+            tmp.ConvertTo(CSR);
+            src = &tmp;
+        }
+        if(nrow > 0)
+            src->CopyToCSR(rp.data(), col, val);
+        for(int64_t i = 0; i < nrow; ++i)
+            for(PtrType j = rp[(size_t)i]; j < rp[(size_t)i + 1]; ++j)
+                row[j] = (int)i;
+        (void)nnz;
+    }
+
+private:
+    void CopyFromCOO_(const int* row, const int* col, const ValueType* val, const std::string& name, int64_t nnz,
+                      int64_t nrow, int64_t ncol)
+    {
+        const bool was_accel = this->on_accel_;
+        this->Clear();
+        if(was_accel)
+        {
+            RAMD_CHECK(ramd_mat_clear(this->dev_));
+            this->on_accel_ = false;
+        }
+        this->name_ = name;
+        this->h_rp_.assign((size_t)nrow + 1, 0);
+        this->h_ci_.assign((size_t)nnz, 0);
+        this->h_val_.assign((size_t)nnz, ValueType(0));
+        for(int64_t k = 0; k < nnz; ++k)
+        {
+            assert(row[k] >= 0 && row[k] < nrow);
+            ++this->h_rp_[(size_t)row[k] + 1];
+        }
+        for(int64_t i = 0; i < nrow; ++i)
+            this->h_rp_[(size_t)i + 1] += this->h_rp_[(size_t)i];
+        std::vector<PtrType> cur(this->h_rp_.begin(), this->h_rp_.end() - 1);
+        for(int64_t k = 0; k < nnz; ++k) // stable: storage order inside every row is kept
+        {
+            const PtrType p       = cur[(size_t)row[k]]++;
+            this->h_ci_[(size_t)p]  = col[k];
+            this->h_val_[(size_t)p] = val[k];
+        }
+        this->h_nrow_ = nrow;
+        this->h_ncol_ = ncol;
+        this->coo_input_ = true;
+        if(was_accel)
+            this->MoveToAccelerator();
+    }
+
+public:
     void ExtractDiagonal(LocalVector<ValueType>* vec_diag) const
     {
         this->need_accel_("ExtractDiagonal");
@@ -1008,6 +1198,11 @@ private:
         std::vector<int>().swap(this->h_ci_);
         std::vector<ValueType>().swap(this->h_val_);
         this->h_nrow_ = this->h_ncol_ = 0;
+        if(this->coo_input_)
+        {
+            this->coo_input_ = false;
+            RAMD_CHECK(ramd_mat_convert(this->dev_, (int)COO));
+        }
     }
     void dev_info_(int* nr, int* nc, int64_t* nnz, int* fmt) const
     {
@@ -1043,6 +1238,7 @@ private:
     ramd_mat_t             dev_      = NULL;
     bool                   own_      = true;
     bool                   on_accel_ = false;
+    bool                   coo_input_ = false; // host data came in as COO: becomes a COO object on the device
 };
 
 } // namespace rocalution

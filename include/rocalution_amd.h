@@ -236,6 +236,18 @@ int ramd_fused_normalize(ramd_vec_t v, int slot_sq, int slot_norm);
  * HIP-event timing on the stream the kernels are launched on (bench.py): a stopwatch around any
  * region, and an optional per-launch bracket of every SpMV (Apply / fused Apply+dot) so that the
  * kernel's average duration is measured live inside a solver run. */
+/* ---- LocalMatrix utilities next to the solver path (host_matrix_csr.cpp, CSR only; other formats:
+ * RAMD_ERR_UNSUPPORTED, the front end converts).
+ *   Gershgorin (:3465-3506): per row  sum_{j!=i}|a_ij| left to right and the stored diagonal; bounds start at 0.
+ *   ExtractL / ExtractLDiagonal / ExtractU / ExtractUDiagonal (:919-1160): upper != 0 -> U part, with_diag.
+ *   Scale / ScaleDiagonal / ScaleOffDiagonal (:3509-3568), AddScalar* (:3570-3630): which = 0 all, 1 the first
+ *     stored diagonal entry of every row, 2 off-diagonal entries.
+ *   UpdateValuesCSR: new values (host array of nnz entries) into the existing pattern. */
+int ramd_mat_gershgorin(ramd_mat_t m, double* lambda_min, double* lambda_max);
+int ramd_mat_extract_tri(ramd_mat_t m, ramd_mat_t out, int upper, int with_diag);
+int ramd_mat_scale_values(ramd_mat_t m, double alpha, int which);
+int ramd_mat_add_scalar_values(ramd_mat_t m, double alpha, int which);
+int ramd_mat_update_values(ramd_mat_t m, const void* host_val);
 /* free / total device memory in bytes (hipMemGetInfo): leak checks, sizing */
 int ramd_mem_info(uint64_t* free_bytes, uint64_t* total_bytes);
 int ramd_timer_start(void); /* records an event on the current stream */

@@ -242,6 +242,18 @@ class LocalMatrix:
 
     CopyFromCSR = SetDataPtrCSR
 
+    def SetDataPtrCOO(self, row, col, val, name="", nnz=None, nrow=None, ncol=None):
+        """LocalMatrix::SetDataPtrCOO: entries go to their rows by a STABLE sort (a row's products are still
+        added in storage order, as in the reference's serial COO loop); the object is a COO matrix afterwards"""
+        row = np.ascontiguousarray(row, dtype=np.int64)
+        order = np.argsort(row, kind="stable")
+        nrow = int(row.max()) + 1 if nrow is None else int(nrow)
+        rp = np.zeros(nrow + 1, dtype=np.int64)
+        np.cumsum(np.bincount(row, minlength=nrow), out=rp[1:])
+        self.SetDataPtrCSR(rp, np.asarray(col)[order], np.asarray(val)[order], nrow=nrow, ncol=ncol)
+        if len(row):
+            self.ConvertTo(COO)
+
     def CopyToCSR(self):
         nr, nc, nnz, fmt = self._info()
         rp = np.empty(nr + 1, dtype=np.int32)
@@ -321,6 +333,41 @@ class LocalMatrix:
 
     def ExtractInverseDiagonal(self, d):
         capi.check(_lib().ramd_mat_extract_inv_diag(self._h, d._h))
+
+    def Gershgorin(self):
+        """-> (lambda_min, lambda_max): Gershgorin bounds as the reference computes them (both start at 0)"""
+        lo, hi = C.c_double(0), C.c_double(0)
+        capi.check(_lib().ramd_mat_gershgorin(self._h, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def ExtractL(self, out, diag):
+        capi.check(_lib().ramd_mat_extract_tri(self._h, out._h, 0, int(bool(diag))))
+
+    def ExtractU(self, out, diag):
+        capi.check(_lib().ramd_mat_extract_tri(self._h, out._h, 1, int(bool(diag))))
+
+    def Scale(self, alpha):
+        capi.check(_lib().ramd_mat_scale_values(self._h, float(alpha), 0))
+
+    def ScaleDiagonal(self, alpha):
+        capi.check(_lib().ramd_mat_scale_values(self._h, float(alpha), 1))
+
+    def ScaleOffDiagonal(self, alpha):
+        capi.check(_lib().ramd_mat_scale_values(self._h, float(alpha), 2))
+
+    def AddScalar(self, alpha):
+        capi.check(_lib().ramd_mat_add_scalar_values(self._h, float(alpha), 0))
+
+    def AddScalarDiagonal(self, alpha):
+        capi.check(_lib().ramd_mat_add_scalar_values(self._h, float(alpha), 1))
+
+    def AddScalarOffDiagonal(self, alpha):
+        capi.check(_lib().ramd_mat_add_scalar_values(self._h, float(alpha), 2))
+
+    def UpdateValuesCSR(self, val):
+        va = np.ascontiguousarray(val, dtype=self.dtype)
+        assert len(va) == self.GetNnz()
+        capi.check(_lib().ramd_mat_update_values(self._h, va.ctypes.data_as(C.c_void_p)))
 
     def ExtractSubMatrix(self, row_offset, col_offset, row_size, col_size, out):
         capi.check(_lib().ramd_mat_extract_submatrix(self._h, row_offset, col_offset, row_size, col_size,

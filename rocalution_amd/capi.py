@@ -109,6 +109,11 @@ SIGNATURES = {
     "ramd_mat_gen_poisson7": (i32, [mat_t, i32]),
     "ramd_mat_gen_poisson7_slab": (i32, [mat_t, mat_t, i32, i64, i64]),
     # fused ops / scalar records
+    "ramd_mat_gershgorin": (i32, [mat_t, pf64, pf64]),
+    "ramd_mat_extract_tri": (i32, [mat_t, mat_t, i32, i32]),
+    "ramd_mat_scale_values": (i32, [mat_t, f64, i32]),
+    "ramd_mat_add_scalar_values": (i32, [mat_t, f64, i32]),
+    "ramd_mat_update_values": (i32, [mat_t, ptr]),
     "ramd_mem_info": (i32, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ramd_scalars_set": (i32, [i32, f64]),
     "ramd_scalars_fetch": (i32, [pf64, i32, i32]),

@@ -248,3 +248,18 @@ def test_file_io_matches_reference_files(tmp_path):
     assert open(out / "x_from_ascii.dat", "rb").read() == ref_dat
     assert open(out / "x_from_bin.dat", "rb").read() == ref_dat
     _same_but_version(str(out / "x_from_bin.bin"), os.path.join(gold, "ref_x.bin"), b"#rocALUTION binary vector file\n")
+
+
+def test_host_side_matrix_api(tmp_path):
+    """COO input with the reference's ownership rules, Check(), LeaveDataPtrCOO, UpdateValuesCSR on host
+    storage: a plain g++ program linked against the library, no accelerator needed"""
+    import subprocess
+    from rocalution_amd import build as B
+    B.build()
+    exe = str(tmp_path / "api_driver")
+    libdir = os.path.join(ROOT, "rocalution_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "drivers", "api_driver.cpp"), "-o", exe,
+                           "-L", libdir, "-lrocalution_amd", "-Wl,-rpath," + libdir])
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert r.returncode == 0 and b"api_driver ok" in r.stdout, (r.returncode, r.stdout.decode()[-1500:])
