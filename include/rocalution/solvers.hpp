@@ -311,6 +311,17 @@ public:
     }
     virtual void MoveToHost(void) {}
     virtual void MoveToAccelerator(void) {}
+    // Solver::ReBuildNumeric (solver.hpp:214-218): the operator kept its pattern but got new values
+    // (UpdateValuesCSR): redo the numerical part.  Here: a full Clear() + Build() -- same result, and every
+    // analysis of this backend runs on the device in milliseconds.
+    virtual void ReBuildNumeric(void)
+    {
+        if(this->build_)
+        {
+            this->Clear();
+            this->Build();
+        }
+    }
     virtual void Verbose(int verb = 1)
     {
         this->verb_ = verb;
@@ -1054,6 +1065,16 @@ public:
     void InitTol(double abs, double rel, double div)
     {
         this->iter_ctrl_.InitTolerance(abs, rel, div);
+    }
+    virtual void ReBuildNumeric(void)
+    {
+        if(!this->build_)
+            return;
+        Solver<OperatorType, VectorType, ValueType>* pc = this->precond_;
+        this->Clear(); // clears (and detaches) the preconditioner
+        if(pc != NULL)
+            this->precond_ = pc;
+        this->Build();
     }
     void SetResidualNorm(int resnorm)
     {

@@ -324,6 +324,8 @@ int ramd_solver_precond_apply(ramd_solver_t s, ramd_vec_t rhs, ramd_vec_t x); /*
 int ramd_solver_result(ramd_solver_t s, int* iters, int* status, double* final_res);
 int ramd_solver_history(ramd_solver_t s, double* buf, int cap, int* len);
 int ramd_solver_num_colors(ramd_solver_t s, int* ncolors);
+/* Solver::ReBuildNumeric (solver.hpp:214-218): the operator got new values in the same pattern */
+int ramd_solver_rebuild_numeric(ramd_solver_t s);
 int ramd_solver_clear(ramd_solver_t s);
 
 /* LocalMatrix::ReadFileMTX (src/base/local_matrix.cpp:1269-1326, src/base/host/host_io.cpp:51-320):

@@ -156,6 +156,7 @@ SIGNATURES = {
     "ramd_solver_init": (i32, [ptr, f64, f64, f64, i32, i32]),
     "ramd_solver_init_inner": (i32, [ptr, f64, f64, f64, i32]),
     "ramd_solver_set_basis": (i32, [ptr, i32]),
+    "ramd_solver_rebuild_numeric": (i32, [ptr]),
     "ramd_solver_set_seed": (i32, [ptr, C.c_ulonglong]),
     "ramd_solver_set_params": (i32, [ptr, f64, f64]),
     "ramd_solver_set_fused": (i32, [ptr, i32]),

@@ -30,6 +30,10 @@ struct SolverBase
     virtual void set_fused_sweeps(bool) {}
     virtual void set_seed(unsigned long long) {}
     virtual void set_params(double, double) {}
+    virtual bool rebuild_numeric()
+    {
+        return false;
+    }
     virtual void build(ramd_mat_t op)                                    = 0;
     virtual void solve(ramd_vec_t rhs, ramd_vec_t x)                     = 0;
     virtual bool precond_apply(ramd_vec_t, ramd_vec_t)                   = 0;
@@ -239,6 +243,13 @@ struct LocalSolver : SolverBase
         if(built)
             ls()->Clear(); // also clears (and detaches) the preconditioner, like the reference
         built = false;
+    }
+    bool rebuild_numeric() override
+    {
+        if(!built)
+            return false;
+        ls()->ReBuildNumeric();
+        return true;
     }
 };
 
@@ -665,6 +676,15 @@ int ramd_solver_num_colors(ramd_solver_t s, int* n)
         return RAMD_ERR_ARG;
     *n = s->impl->num_colors();
     return RAMD_OK;
+}
+int ramd_solver_rebuild_numeric(ramd_solver_t s)
+{
+    if(!s)
+        return RAMD_ERR_ARG;
+    GUARD_BEGIN
+    if(!s->impl->rebuild_numeric())
+        return RAMD_ERR_STATE;
+    GUARD_END
 }
 int ramd_solver_clear(ramd_solver_t s)
 {

@@ -157,6 +157,9 @@ class _IterativeLinearSolver:
     def PrecondApply(self, rhs, x):
         capi.check(_lib().ramd_solver_precond_apply(self._h, rhs._h, x._h))
 
+    def ReBuildNumeric(self):
+        capi.check(_lib().ramd_solver_rebuild_numeric(self._h))
+
     def Clear(self):
         if self._h:
             capi.check(_lib().ramd_solver_clear(self._h))

@@ -377,3 +377,26 @@ def test_cpp_sample_driver_end_to_end(tmp_path):
     r = subprocess.run([exe, "poisson:32", "cg", "jacobi"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     m = re.search(r"RESULT .*iters=(\d+) status=(\d+)", r.stdout.decode())
     assert r.returncode == 0 and m and abs(int(m.group(1)) - 66) <= 1 and int(m.group(2)) == 2
+
+
+@pytest.mark.parametrize("pcname", ["Jacobi", "ILU", "MultiColoredSGS", "SGS"])
+def test_rebuild_numeric_after_value_update(ra, S, oracle, pcname):
+    """UpdateValuesCSR + ReBuildNumeric: the solver then behaves like a freshly built one on the new values"""
+    rp, ci, va = gen.poisson7(10)
+    n = len(rp) - 1
+    va2 = va * 2.5  # same pattern, new (still SPD) values
+    A = ra.LocalMatrix(); A.SetDataPtrCSR(rp, ci, va)
+    ls = S.CG(); ls.SetOperator(A); ls.SetPreconditioner(getattr(S, pcname)()); ls.Build()
+    rhs = ra.LocalVector(data=oracle.csr_apply(rp, ci, va, np.ones(n))); x = ra.LocalVector(); x.Allocate("", n)
+    ls.Solve(rhs, x)
+    it1 = ls.GetIterationCount()
+    A.UpdateValuesCSR(va2)
+    ls.ReBuildNumeric()
+    rhs2 = ra.LocalVector(data=oracle.csr_apply(rp, ci, va2, np.ones(n))); x.Zeros()
+    ls.Solve(rhs2, x)
+    B = ra.LocalMatrix(); B.SetDataPtrCSR(rp, ci, va2)
+    fresh = S.CG(); fresh.SetOperator(B); fresh.SetPreconditioner(getattr(S, pcname)()); fresh.Build()
+    y = ra.LocalVector(); y.Allocate("", n)
+    fresh.Solve(rhs2, y)
+    assert ls.GetIterationCount() == fresh.GetIterationCount() and abs(ls.GetIterationCount() - it1) <= 1
+    eq(x.numpy(), y.numpy())
