@@ -89,26 +89,32 @@ __global__ __launch_bounds__(kBlock) void k_levels(int nrow, const int* __restri
                                                    const int* __restrict__ ci, int* level,
                                                    unsigned* counter, unsigned base)
 {
-    const unsigned blk = take_ticket(counter, base);
-    const int64_t  t   = (int64_t)blk * kBlock + threadIdx.x;
-    if(t >= nrow)
-        return;
-    const int i   = LOWER ? (int)t : (int)(nrow - 1 - t);
-    int       j   = rp[i];
-    const int end = rp[i + 1];
-    int       lev = 0;
+    const unsigned blk  = take_ticket(counter, base);
+    const int64_t  t    = (int64_t)blk * kBlock + threadIdx.x;
+    const bool     live = t < nrow;
+    const int      lane = threadIdx.x & 63;
+    const int      i    = live ? (LOWER ? (int)t : (int)(nrow - 1 - t)) : 0;
+    // rows handled by my wave: i0 .. (LOWER: ascending, else descending) -- their levels travel through
+    // shuffles (the i-1 / i+1 chain of a stencil never leaves the registers), others through memory
+    const int i0  = LOWER ? i - lane : i + lane;
+    int       j   = live ? rp[i] : 0;
+    const int end = live ? rp[i + 1] : 0;
+    int       lev = 0, mine = 0;
     // SIMT hazard: lanes of one wave may depend on each other, and a lane that has LEFT a loop cannot
     // execute anything until the whole wave leaves it.  So results are published inside the loop and
     // the loop exit is made wave-uniform with a ballot (otherwise the compiler is free to sink the
     // publish into the loop's exit block, which deadlocks).
-    bool fin = false;
+    bool fin   = !live;
     int  spins = 0;
     do
     {
         spin_guard(spins);
+        const int  j_start = j;
+        const bool was_fin = fin;
+        int        want    = lane; // at most one in-wave dependency per turn
         if(!fin)
         {
-            if(j < end)
+            while(j < end) // dependencies held by other waves: take every one that is ready
             {
                 const int c = ci[j];
                 if(LOWER ? (c >= i) : (c <= i))
@@ -117,24 +123,39 @@ __global__ __launch_bounds__(kBlock) void k_levels(int nrow, const int* __restri
                         j = end; // sorted rows: nothing below the diagonal follows
                     else
                         ++j;
+                    continue;
                 }
-                else
+                const int rel = LOWER ? c - i0 : i0 - c; // lane that owns row c, if it is one of mine
+                if(rel >= 0 && rel < 64)
                 {
-                    const int lc
-                        = __hip_atomic_load(level + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if(lc != 0)
-                    {
-                        lev = max(lev, lc);
-                        ++j;
-                    }
+                    want = rel;
+                    break;
                 }
+                const int lc = __hip_atomic_load(level + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if(lc == 0)
+                    break;
+                lev = max(lev, lc);
+                ++j;
             }
-            else
+        }
+        const int got = __shfl(mine, want, 64);
+        if(!fin)
+        {
+            if(want != lane && got != 0)
             {
-                __hip_atomic_store(level + i, lev + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lev = max(lev, got);
+                ++j;
+            }
+            if(j >= end)
+            {
+                mine = lev + 1;
+                __hip_atomic_store(level + i, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 fin = true;
             }
         }
+        // nobody in the wave advanced (all waiting on other waves): back off instead of flooding the L2 with polls
+        if(__ballot(!was_fin && (fin || j != j_start)) == 0ull)
+            __builtin_amdgcn_s_sleep(8);
     } while(__ballot(!fin) != 0ull);
 }
 
@@ -326,14 +347,16 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void k_ilu0(int nrow, const int* __restrict__ rp,
                                                  const int* __restrict__ ci, T* val, int* done,
                                                  int* diag_pos, unsigned* counter,
-                                                 unsigned base)
+                                                 unsigned base, const int* __restrict__ order)
 {
     using B            = typename Sentinel<T>::bits;
     const unsigned blk = take_ticket(counter, base);
     const int64_t  t   = (int64_t)blk * kBlock + threadIdx.x;
     if(t >= nrow)
         return;
-    const int i   = (int)t;
+    // rows are taken in (level, row) order: the rows of a wave are (almost always) independent and every
+    // pivot row belongs to an earlier level, i.e. an earlier or the same workgroup ticket
+    const int i   = order[t];
     const int rs  = rp[i];
     const int re  = rp[i + 1];
     int       j   = rs;
@@ -436,6 +459,10 @@ struct TriState
     int*      lu_rhs_idx = nullptr; // [n]: U position -> L position of the same row
     unsigned* counter    = nullptr; // shared workgroup ticket
     unsigned  ticket     = 0; // host copy of the counter value
+    // rows ordered by (lower-dependency level, row), computed once per pattern: ILU(0) runs in this order
+    // and LAnalyse / LUAnalyse take it over
+    int* l_order_cache = nullptr;
+    int  l_nlev_cache  = 0;
 };
 
 static TriState* tri_state(ramd_mat_s* m)
@@ -452,6 +479,7 @@ void tri_release(ramd_mat_s* m)
     st->U.release();
     dev_free(&st->lu_rhs_idx);
     dev_free(&st->counter);
+    dev_free(&st->l_order_cache);
     delete st;
     m->tri = nullptr;
 }
@@ -485,6 +513,41 @@ static unsigned nblocks_of(int n)
     return (unsigned)((n + kBlock - 1) / kBlock);
 }
 
+// dependency levels (sync-free sweep in natural order) and the rows ordered by (level, row): a stable sort,
+// so rows of one level keep ascending row order and neighbouring positions poll / gather neighbouring memory
+static int level_order(ramd_mat_s* m, TriState* st, bool lower, int** order_out, int* nlev_out)
+{
+    Backend&       b     = backend();
+    const int      n     = m->nrow;
+    int*           level = nullptr;
+    const unsigned nb    = nblocks_of(n);
+    RAMD_TRY(dev_alloc(&level, n));
+    hipError_t e = hipMemsetAsync(level, 0, sizeof(int) * (size_t)n, b.cur);
+    if(lower)
+        hipLaunchKernelGGL((k_levels<true>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, level,
+                           st->counter, st->ticket);
+    else
+        hipLaunchKernelGGL((k_levels<false>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, level,
+                           st->counter, st->ticket);
+    st->ticket += nb;
+    int nlev = 0;
+    int s    = (e == hipSuccess) ? device_max_int(level, n, &nlev) : RAMD_ERR_HIP;
+    int* order = nullptr;
+    if(s == RAMD_OK)
+        s = dev_alloc(&order, n);
+    if(s == RAMD_OK)
+        s = device_stable_sort_by_key(level, n, nlev, order);
+    dev_free(&level);
+    if(s != RAMD_OK)
+    {
+        dev_free(&order);
+        return s;
+    }
+    *order_out = order;
+    *nlev_out  = nlev;
+    return RAMD_OK;
+}
+
 template <typename T>
 static int build_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower)
 {
@@ -495,28 +558,20 @@ static int build_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower)
     P->nslices = (n + 63) / 64;
     if(n == 0)
         return RAMD_OK;
-    int*           level = nullptr;
-    const unsigned nb    = nblocks_of(n);
-    RAMD_TRY(dev_alloc(&level, n));
-    RAMD_HIP(hipMemsetAsync(level, 0, sizeof(int) * (size_t)n, b.cur));
-    if(lower)
-        hipLaunchKernelGGL((k_levels<true>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, level,
-                           st->counter, st->ticket);
+    const unsigned nb   = nblocks_of(n);
+    int            nlev = 0;
+    int            s    = RAMD_OK;
+    if(lower && st->l_order_cache) // computed by ILU0Factorize on the same pattern
+    {
+        P->order          = st->l_order_cache;
+        nlev              = st->l_nlev_cache;
+        st->l_order_cache = nullptr;
+    }
     else
-        hipLaunchKernelGGL((k_levels<false>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, level,
-                           st->counter, st->ticket);
-    st->ticket += nb;
-    int nlev = 0;
-    int s    = device_max_int(level, n, &nlev);
-    // rows ordered by (level, row): stable sort, so rows of one level keep ascending row order and
-    // neighbouring positions poll / gather neighbouring memory
+        s = level_order(m, st, lower, &P->order, &nlev);
     const int grid = ew_grid(n);
     if(s == RAMD_OK)
-        s = dev_alloc(&P->order, n);
-    if(s == RAMD_OK)
         s = dev_alloc(&P->pos, n);
-    if(s == RAMD_OK)
-        s = device_stable_sort_by_key(level, n, nlev, P->order);
     if(s == RAMD_OK)
         hipLaunchKernelGGL(k_invert_perm, dim3(grid), dim3(kBlock), 0, b.cur, n, P->order, P->pos);
     // slice widths -> offsets
@@ -585,7 +640,6 @@ static int build_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower)
         P->nodiag = nd != 0;
     }
     P->nlevels = nlev;
-    dev_free(&level);
     dev_free(&nodiag);
     if(s != RAMD_OK)
         P->release();
@@ -652,8 +706,17 @@ static int ilu0_t(ramd_mat_s* m)
     }
     RAMD_HIP(hipMemsetAsync(done, 0, sizeof(int) * (size_t)n, b.cur));
     const unsigned nb = nblocks_of(n);
+    if(!st->l_order_cache)
+    {
+        int s = level_order(m, st, true, &st->l_order_cache, &st->l_nlev_cache);
+        if(s != RAMD_OK)
+        {
+            dev_free(&done);
+            return s;
+        }
+    }
     hipLaunchKernelGGL((k_ilu0<T>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (T*)m->val, done,
-                       m->diag_pos, st->counter, st->ticket);
+                       m->diag_pos, st->counter, st->ticket, st->l_order_cache);
     st->ticket += nb;
     hipError_t e = hipGetLastError();
     if(e == hipSuccess)

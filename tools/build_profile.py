@@ -5,7 +5,8 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rocalution_amd as ra  # noqa: E402
 from rocalution_amd import capi  # noqa: E402
 
