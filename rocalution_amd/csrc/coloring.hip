@@ -48,9 +48,11 @@ __global__ __launch_bounds__(kBlock) void k_pattern_symmetric(int nrow, const in
 
 __global__ __launch_bounds__(kBlock) void k_greedy_color(int nrow, const int* __restrict__ rp,
                                                          const int* __restrict__ ci, int* color,
-                                                         unsigned* counter, int* overflow)
+                                                         unsigned* counter, int* overflow,
+                                                         const int* __restrict__ block_order)
 {
-    const unsigned blk  = take_ticket(counter, 0u);
+    const unsigned tick = take_ticket(counter, 0u);
+    const unsigned blk  = block_order ? (unsigned)block_order[tick] : tick; // blocksched.hip
     const int64_t  t    = (int64_t)blk * kBlock + threadIdx.x;
     const int      lane = threadIdx.x & 63;
     const bool     live = t < nrow;
@@ -166,12 +168,18 @@ int multicoloring_device(const ramd_mat_s* m, int* num_colors, int* size_colors,
     if(hipMemsetAsync(color, 0, sizeof(int) * ((size_t)n + 1), b.cur) != hipSuccess)
         return cleanup(RAMD_ERR_HIP);
     const int nblk = (n + kBlock - 1) / kBlock;
+    int* border = nullptr;
+    (void)block_schedule(m, true, &border); // hyperplane order of the row blocks (nullptr: natural order)
     hipLaunchKernelGGL(k_greedy_color, dim3(nblk), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, color,
-                       reinterpret_cast<unsigned*>(work + 2), work + 1);
+                       reinterpret_cast<unsigned*>(work + 2), work + 1, border);
     if(hipGetLastError() != hipSuccess)
+    {
+        dev_free(&border);
         return cleanup(RAMD_ERR_HIP);
+    }
     int nc = 0;
-    s      = device_max_int(color, n, &nc);
+    s      = device_max_int(color, n, &nc); // (synchronises)
+    dev_free(&border);
     if(s != RAMD_OK)
         return cleanup(s);
     if(hipMemcpyAsync(h, work, sizeof(int) * 2, hipMemcpyDeviceToHost, b.cur) != hipSuccess

@@ -23,6 +23,9 @@ void prof_spmv_end();
 // trisolve.hip
 void tri_release(ramd_mat_s* m);
 
+// blocksched.hip: hyperplane order of the row blocks for the natural-order sync-free sweeps (nullptr: natural)
+int block_schedule(const ramd_mat_s* m, bool lower, int** order_out);
+
 // coloring.hip: device greedy colouring; RAMD_ERR_UNSUPPORTED -> caller runs the host sweep
 int multicoloring_device(const ramd_mat_s* m, int* num_colors, int* size_colors, ramd_vec_s* perm);
 

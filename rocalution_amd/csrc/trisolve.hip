@@ -87,9 +87,11 @@ __global__ __launch_bounds__(kBlock) void k_fill_sentinel(int64_t n, T* __restri
 template <bool LOWER>
 __global__ __launch_bounds__(kBlock) void k_levels(int nrow, const int* __restrict__ rp,
                                                    const int* __restrict__ ci, int* level,
-                                                   unsigned* counter, unsigned base)
+                                                   unsigned* counter, unsigned base,
+                                                   const int* __restrict__ block_order)
 {
-    const unsigned blk  = take_ticket(counter, base);
+    const unsigned tick = take_ticket(counter, base);
+    const unsigned blk  = block_order ? (unsigned)block_order[tick] : tick; // blocksched.hip
     const int64_t  t    = (int64_t)blk * kBlock + threadIdx.x;
     const bool     live = t < nrow;
     const int      lane = threadIdx.x & 63;
@@ -523,15 +525,18 @@ static int level_order(ramd_mat_s* m, TriState* st, bool lower, int** order_out,
     const unsigned nb    = nblocks_of(n);
     RAMD_TRY(dev_alloc(&level, n));
     hipError_t e = hipMemsetAsync(level, 0, sizeof(int) * (size_t)n, b.cur);
+    int*       border = nullptr;
+    (void)block_schedule(m, lower, &border); // nullptr: natural order
     if(lower)
         hipLaunchKernelGGL((k_levels<true>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, level,
-                           st->counter, st->ticket);
+                           st->counter, st->ticket, border);
     else
         hipLaunchKernelGGL((k_levels<false>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, level,
-                           st->counter, st->ticket);
+                           st->counter, st->ticket, border);
     st->ticket += nb;
     int nlev = 0;
-    int s    = (e == hipSuccess) ? device_max_int(level, n, &nlev) : RAMD_ERR_HIP;
+    int s    = (e == hipSuccess) ? device_max_int(level, n, &nlev) : RAMD_ERR_HIP; // (synchronises)
+    dev_free(&border);
     int* order = nullptr;
     if(s == RAMD_OK)
         s = dev_alloc(&order, n);

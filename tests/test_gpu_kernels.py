@@ -584,3 +584,19 @@ def test_coo_input_unsorted(ra, oracle):
     for r, c, v in zip(row, col, val):
         ref[r] += v * x[c]
     eq(y.numpy(), ref)
+
+
+def test_block_hyperplane_schedule_gives_identical_results():
+    """RAMD_BLOCKSCHED_MIN=1 applies the hyperplane block order (blocksched.hip) to every level sweep and
+    colouring of the kernel / solver tests: colours, permutations, ILU(0) factors and triangular solves must
+    not change by a bit (also on patterns whose dependency sets overflow the per-block table)"""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, RAMD_BLOCKSCHED_MIN="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_kernels.py"),
+                        os.path.join(here, "test_gpu_solvers.py"), "-q", "-m", "gpu", "-x", "-k",
+                        "multicoloring or ilu or trisolve or preconditioner_apply or mcsgs or vs_oracle_larger"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
