@@ -3,6 +3,10 @@
 // streams and the compute_{default,interior,ghost} switches) -- no rocBLAS/rocSPARSE handles.
 #include "common.hpp"
 
+#include <map>
+#include <mutex>
+#include <unordered_map>
+
 #include <mutex>
 
 namespace ramd
@@ -35,6 +39,115 @@ int ensure_init()
 } // namespace ramd
 
 using namespace ramd;
+
+// ---------------------------------------------------------------- caching device allocator
+// hipFree of multi-GB blocks is deferred by the runtime and paid by a LATER hipMalloc (measured: a solver
+// Build() after the Clear() of a 512^3 preconditioner took +2.3..3.2 s at random).  Freed blocks are therefore
+// kept and handed out again to requests of (nearly) the same size -- Build/Clear cycles repeat their sizes
+// exactly.  RAMD_ALLOC_CACHE=0 disables the cache; it is emptied on out-of-memory and by ramd_stop().
+namespace ramd
+{
+namespace
+{
+struct AllocCache
+{
+    std::mutex                       mu;
+    std::multimap<size_t, void*>     free_blocks; // size -> block
+    std::unordered_map<void*, size_t> live;       // block -> size
+    size_t                           cached_bytes = 0;
+    size_t                           cap          = 0; // bytes the cache may hold (set at first use)
+    int                              enabled      = -1;
+    bool on()
+    {
+        if(enabled < 0)
+        {
+            const char* e = getenv("RAMD_ALLOC_CACHE");
+            enabled       = (e && atoi(e) == 0) ? 0 : 1;
+        }
+        return enabled == 1;
+    }
+    void drop_all()
+    {
+        for(auto& kv : free_blocks)
+            (void)hipFree(kv.second);
+        free_blocks.clear();
+        cached_bytes = 0;
+    }
+};
+AllocCache& cache()
+{
+    static AllocCache c;
+    return c;
+}
+} // namespace
+
+hipError_t cached_malloc_bytes(void** p, size_t bytes)
+{
+    AllocCache&                 c = cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    const size_t                need = (bytes + 255) & ~(size_t)255;
+    if(c.on() && need >= (1u << 20)) // small blocks go straight to the runtime (its own pools are fine there)
+    {
+        auto it = c.free_blocks.lower_bound(need);
+        if(it != c.free_blocks.end() && it->first <= need + need / 8)
+        {
+            *p = it->second;
+            c.cached_bytes -= it->first;
+            c.live[*p] = it->first;
+            c.free_blocks.erase(it);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, need);
+    if(e != hipSuccess && !c.free_blocks.empty())
+    {
+        (void)hipGetLastError();
+        c.drop_all(); // out of memory: give the cached blocks back and try again
+        e = hipMalloc(p, need);
+    }
+    if(e == hipSuccess)
+        c.live[*p] = need;
+    return e;
+}
+
+hipError_t cached_free(void* p)
+{
+    if(!p)
+        return hipSuccess;
+    AllocCache&                 c = cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    auto                        it = c.live.find(p);
+    if(it == c.live.end())
+        return hipFree(p); // not ours
+    const size_t sz = it->second;
+    c.live.erase(it);
+    if(c.on() && sz >= (1u << 20))
+    {
+        if(c.cap == 0)
+        {
+            size_t f = 0, t = 0;
+            c.cap    = (hipMemGetInfo(&f, &t) == hipSuccess) ? t / 5 * 2 : ((size_t)64 << 30); // 40 % of the device
+        }
+        if(c.cached_bytes + sz <= c.cap)
+        {
+            // kernels on any stream may still use the block: hipFree would have waited for the device, too
+            (void)hipDeviceSynchronize();
+            c.free_blocks.emplace(sz, p);
+            c.cached_bytes += sz;
+            return hipSuccess;
+        }
+    }
+    return hipFree(p);
+}
+
+void cached_release_all(void)
+{
+    AllocCache&                 c = cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.drop_all();
+}
+
+} // namespace ramd
 
 extern "C" {
 
@@ -99,6 +212,7 @@ int ramd_stop(void)
     if(!b.initialized)
         return RAMD_OK;
     (void)hipDeviceSynchronize();
+    cached_release_all();
     (void)hipFree(b.d_partials);
     (void)hipFree(b.d_ticket);
     (void)hipFree(b.d_scalars);

@@ -84,13 +84,26 @@ int      ensure_init();
 // inside an array may run past its logical end (never dereferenced for results).
 constexpr size_t kPad = 256;
 
+// caching device allocator (backend.hip): every device block of the library goes through these two
+hipError_t cached_malloc_bytes(void** p, size_t bytes);
+hipError_t cached_free(void* p);
+void       cached_release_all(void);
+template <typename X>
+inline hipError_t cached_malloc(X** p, size_t bytes)
+{
+    void*      q = nullptr;
+    hipError_t e = cached_malloc_bytes(&q, bytes);
+    *p           = static_cast<X*>(q);
+    return e;
+}
+
 template <typename X>
 int dev_alloc(X** p, int64_t n)
 {
     *p = nullptr;
     void*  q     = nullptr;
     size_t bytes = (size_t)(n > 0 ? n : 0) * sizeof(X) + kPad;
-    RAMD_HIP(hipMalloc(&q, bytes));
+    RAMD_HIP(cached_malloc_bytes(&q, bytes));
     *p = static_cast<X*>(q);
     return RAMD_OK;
 }
@@ -98,7 +111,7 @@ template <typename X>
 void dev_free(X** p)
 {
     if(*p)
-        (void)hipFree(*p);
+        (void)cached_free(*p);
     *p = nullptr;
 }
 

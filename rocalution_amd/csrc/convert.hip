@@ -357,7 +357,7 @@ static int convert_from_csr(ramd_mat_s* m, int format)
         const int64_t nnz_ell = (int64_t)width * m->nrow;
         RAMD_TRY(dev_alloc(&m->ell_col, nnz_ell));
         void* ev = nullptr;
-        RAMD_HIP(hipMalloc(&ev, (size_t)nnz_ell * sizeof(T) + kPad));
+        RAMD_HIP(cached_malloc(&ev, (size_t)nnz_ell * sizeof(T) + kPad));
         m->ell_val   = ev;
         m->ell_width = width;
         if(nnz_ell > 0)
@@ -392,21 +392,21 @@ static int convert_from_csr(ramd_mat_s* m, int format)
         if(s == RAMD_OK)
             s = dev_alloc(&m->ell_col, nnz_ell);
         void *ev = nullptr, *cv = nullptr;
-        if(s == RAMD_OK && hipMalloc(&ev, (size_t)nnz_ell * sizeof(T) + kPad) != hipSuccess)
+        if(s == RAMD_OK && cached_malloc(&ev, (size_t)nnz_ell * sizeof(T) + kPad) != hipSuccess)
             s = RAMD_ERR_HIP;
         if(s == RAMD_OK)
             s = dev_alloc(&m->coo_row, ncoo);
         if(s == RAMD_OK)
             s = dev_alloc(&m->coo_col, ncoo);
-        if(s == RAMD_OK && hipMalloc(&cv, (size_t)ncoo * sizeof(T) + kPad) != hipSuccess)
+        if(s == RAMD_OK && cached_malloc(&cv, (size_t)ncoo * sizeof(T) + kPad) != hipSuccess)
             s = RAMD_ERR_HIP;
         if(s != RAMD_OK)
         {
             dev_free(&crp);
             if(ev)
-                (void)hipFree(ev);
+                (void)cached_free(ev);
             if(cv)
-                (void)hipFree(cv);
+                (void)cached_free(cv);
             mat_free_ell(m);
             mat_free_coo(m);
             RAMD_FAIL(s, "csr_to_hyb: allocation failed");
@@ -481,7 +481,7 @@ static int convert_to_csr(ramd_mat_s* m)
     void* val = nullptr;
     if(s == RAMD_OK)
         s = dev_alloc(&ci, nnz);
-    if(s == RAMD_OK && hipMalloc(&val, (size_t)nnz * sizeof(T) + kPad) != hipSuccess)
+    if(s == RAMD_OK && cached_malloc(&val, (size_t)nnz * sizeof(T) + kPad) != hipSuccess)
         s = RAMD_ERR_HIP;
     if(s != RAMD_OK)
     {
@@ -688,7 +688,7 @@ int ramd_mat_permute(ramd_mat_t m, ramd_vec_t perm)
     void*    ova = nullptr;
     RAMD_TRY(dev_alloc(&orp, (int64_t)m->nrow + 1));
     int s = dev_alloc(&oci, m->nnz);
-    if(s == RAMD_OK && hipMalloc(&ova, (size_t)m->nnz * val_size(m->dtype) + kPad) != hipSuccess)
+    if(s == RAMD_OK && cached_malloc(&ova, (size_t)m->nnz * val_size(m->dtype) + kPad) != hipSuccess)
         s = RAMD_ERR_HIP;
     if(s == RAMD_OK)
     {
@@ -715,7 +715,7 @@ int ramd_mat_permute(ramd_mat_t m, ramd_vec_t perm)
         dev_free(&orp);
         dev_free(&oci);
         if(ova)
-            (void)hipFree(ova);
+            (void)cached_free(ova);
         RAMD_FAIL(s, "Permute failed");
     }
     mat_free_csr(m);

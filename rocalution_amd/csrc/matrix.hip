@@ -21,14 +21,14 @@ void mat_free_csr(ramd_mat_s* m)
     dev_free(&m->rp);
     dev_free(&m->ci);
     if(m->val)
-        (void)hipFree(m->val);
+        (void)cached_free(m->val);
     m->val = nullptr;
 }
 void mat_free_ell(ramd_mat_s* m)
 {
     dev_free(&m->ell_col);
     if(m->ell_val)
-        (void)hipFree(m->ell_val);
+        (void)cached_free(m->ell_val);
     m->ell_val   = nullptr;
     m->ell_width = 0;
 }
@@ -37,7 +37,7 @@ void mat_free_coo(ramd_mat_s* m)
     dev_free(&m->coo_row);
     dev_free(&m->coo_col);
     if(m->coo_val)
-        (void)hipFree(m->coo_val);
+        (void)cached_free(m->coo_val);
     m->coo_val = nullptr;
     dev_free(&m->coo_grow);
     dev_free(&m->coo_gptr);
@@ -69,7 +69,7 @@ int mat_alloc_csr(ramd_mat_s* m, int nrow, int ncol, int64_t nnz)
     RAMD_TRY(dev_alloc(&m->rp, (int64_t)nrow + 1));
     RAMD_TRY(dev_alloc(&m->ci, nnz));
     void* v = nullptr;
-    RAMD_HIP(hipMalloc(&v, (size_t)(nnz > 0 ? nnz : 0) * val_size(m->dtype) + kPad));
+    RAMD_HIP(cached_malloc(&v, (size_t)(nnz > 0 ? nnz : 0) * val_size(m->dtype) + kPad));
     m->val = v;
     return RAMD_OK;
 }
@@ -311,7 +311,7 @@ int ramd_mat_clone(ramd_mat_t src, ramd_mat_t* out)
     auto dup_v = [&](void** dst, const void* from, int64_t n) {
         if(s != RAMD_OK || !from)
             return;
-        if(hipMalloc(dst, (size_t)(n > 0 ? n : 0) * vs + kPad) != hipSuccess)
+        if(cached_malloc(dst, (size_t)(n > 0 ? n : 0) * vs + kPad) != hipSuccess)
         {
             s = RAMD_ERR_HIP;
             return;

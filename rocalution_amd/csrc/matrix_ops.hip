@@ -157,8 +157,8 @@ int ramd_mat_gershgorin(ramd_mat_t m, double* lambda_min, double* lambda_max)
     double*      part = nullptr;
     const int    grid = reduce_grid(m->nrow);
     int          s    = RAMD_OK;
-    if(hipMalloc(&lo, vs * (size_t)m->nrow) != hipSuccess || hipMalloc(&hi, vs * (size_t)m->nrow) != hipSuccess
-       || hipMalloc((void**)&part, sizeof(double) * 2 * (size_t)grid) != hipSuccess)
+    if(cached_malloc(&lo, vs * (size_t)m->nrow) != hipSuccess || cached_malloc(&hi, vs * (size_t)m->nrow) != hipSuccess
+       || cached_malloc((void**)&part, sizeof(double) * 2 * (size_t)grid) != hipSuccess)
         s = RAMD_ERR_HIP;
     std::vector<double> h((size_t)2 * grid);
     if(s == RAMD_OK)
@@ -181,9 +181,9 @@ int ramd_mat_gershgorin(ramd_mat_t m, double* lambda_min, double* lambda_max)
            || hipStreamSynchronize(b.cur) != hipSuccess)
             s = RAMD_ERR_HIP;
     }
-    (void)hipFree(lo);
-    (void)hipFree(hi);
-    (void)hipFree(part);
+    (void)cached_free(lo);
+    (void)cached_free(hi);
+    (void)cached_free(part);
     if(s != RAMD_OK)
         RAMD_FAIL(s, "Gershgorin: allocation / launch failed");
     double mn = 0.0, mx = 0.0;

@@ -46,7 +46,7 @@ struct McsgsPlan
         for(void** p : ps)
         {
             if(*p)
-                (void)hipFree(*p);
+                (void)cached_free(*p);
             *p = nullptr;
         }
     }
@@ -249,7 +249,7 @@ static int mc_pack(McsgsPlan* P, const ramd_mat_s* m, bool lower, const int* d_o
     RAMD_HIP(hipMemcpyAsync(&total, *soff + nslices, sizeof(int), hipMemcpyDeviceToHost, b.cur));
     RAMD_HIP(hipStreamSynchronize(b.cur));
     RAMD_TRY(dev_alloc(scol, total));
-    RAMD_HIP(hipMalloc(sval, (size_t)total * sizeof(T) + kPad));
+    RAMD_HIP(cached_malloc(sval, (size_t)total * sizeof(T) + kPad));
     const unsigned nbk = (unsigned)((n + kBlock - 1) / kBlock);
     if(lower)
         hipLaunchKernelGGL((k_mc_fill<T, true>), dim3(nbk), dim3(kBlock), 0, b.cur, n, P->nb, m->rp, m->ci,
@@ -305,9 +305,9 @@ static int mc_build(McsgsPlan* P, const ramd_mat_s* m, const int* perm)
     RAMD_HIP(hipMemcpyAsync(d_off, P->off.data(), sizeof(int) * ((size_t)nb + 1), hipMemcpyHostToDevice, b.cur));
     RAMD_TRY(dev_alloc(&P->iperm, n));
     RAMD_TRY(dev_alloc(&P->blk_of, n));
-    RAMD_HIP(hipMalloc(&P->d, (size_t)n * sizeof(T) + kPad));
-    RAMD_HIP(hipMalloc(&P->dinv, (size_t)n * sizeof(T) + kPad));
-    RAMD_HIP(hipMalloc(&P->xp, (size_t)n * sizeof(T) + kPad));
+    RAMD_HIP(cached_malloc(&P->d, (size_t)n * sizeof(T) + kPad));
+    RAMD_HIP(cached_malloc(&P->dinv, (size_t)n * sizeof(T) + kPad));
+    RAMD_HIP(cached_malloc(&P->xp, (size_t)n * sizeof(T) + kPad));
     hipLaunchKernelGGL(k_mc_prepare, dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, nb, d_off, perm, P->iperm,
                        P->blk_of);
     int s = mc_pack<T>(P, m, true, d_off);

@@ -444,11 +444,11 @@ struct TriPlan
         dev_free(&slice_off);
         dev_free(&ecol);
         if(eval)
-            (void)hipFree(eval);
+            (void)cached_free(eval);
         if(diag)
-            (void)hipFree(diag);
+            (void)cached_free(diag);
         if(w)
-            (void)hipFree(w);
+            (void)cached_free(w);
         eval = diag = w = nullptr;
         n               = 0;
     }
@@ -612,11 +612,11 @@ static int build_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower)
     int* nodiag = nullptr;
     if(s == RAMD_OK)
         s = dev_alloc(&P->ecol, total);
-    if(s == RAMD_OK && hipMalloc(&P->eval, (size_t)total * sizeof(T) + kPad) != hipSuccess)
+    if(s == RAMD_OK && cached_malloc(&P->eval, (size_t)total * sizeof(T) + kPad) != hipSuccess)
         s = RAMD_ERR_HIP;
-    if(s == RAMD_OK && hipMalloc(&P->diag, (size_t)n * sizeof(T) + kPad) != hipSuccess)
+    if(s == RAMD_OK && cached_malloc(&P->diag, (size_t)n * sizeof(T) + kPad) != hipSuccess)
         s = RAMD_ERR_HIP;
-    if(s == RAMD_OK && hipMalloc(&P->w, (size_t)n * sizeof(T) + kPad) != hipSuccess)
+    if(s == RAMD_OK && cached_malloc(&P->w, (size_t)n * sizeof(T) + kPad) != hipSuccess)
         s = RAMD_ERR_HIP;
     if(s == RAMD_OK)
         s = dev_alloc(&nodiag, 1);

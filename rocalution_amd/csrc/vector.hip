@@ -417,7 +417,7 @@ int ramd_vec_clear(ramd_vec_t v)
 {
     CHECK_VEC(v);
     if(v->d)
-        (void)hipFree(v->d);
+        (void)cached_free(v->d);
     v->d = nullptr;
     v->n = 0;
     return RAMD_OK;
@@ -441,7 +441,7 @@ int ramd_vec_allocate(ramd_vec_t v, int64_t n)
     if(n > 0)
     {
         size_t bytes = (size_t)n * dtype_size(v->dtype);
-        RAMD_HIP(hipMalloc(&v->d, bytes + kPad));
+        RAMD_HIP(cached_malloc(&v->d, bytes + kPad));
         RAMD_HIP(hipMemsetAsync(v->d, 0, bytes + kPad, backend().cur));
         v->n = n;
     }
@@ -703,8 +703,8 @@ int ramd_vec_amax(ramd_vec_t v, double* value, int64_t* index)
     int        grid = reduce_grid(v->n);
     double*    dval = nullptr;
     long long* didx = nullptr;
-    RAMD_HIP(hipMalloc((void**)&dval, sizeof(double) * grid));
-    RAMD_HIP(hipMalloc((void**)&didx, sizeof(long long) * grid));
+    RAMD_HIP(cached_malloc((void**)&dval, sizeof(double) * grid));
+    RAMD_HIP(cached_malloc((void**)&didx, sizeof(long long) * grid));
     DISPATCH_FP(v, hipLaunchKernelGGL((k_amax_partial<T>), dim3(grid), dim3(kBlock), 0, bk.cur, v->n,
                                       (const T*)v->d, dval, didx));
     double*    hv = (double*)malloc(sizeof(double) * grid);
@@ -722,8 +722,8 @@ int ramd_vec_amax(ramd_vec_t v, double* value, int64_t* index)
         }
     free(hv);
     free(hi);
-    (void)hipFree(dval);
-    (void)hipFree(didx);
+    (void)cached_free(dval);
+    (void)cached_free(didx);
     RAMD_HIP(e1);
     RAMD_HIP(e2);
     RAMD_HIP(e3);
