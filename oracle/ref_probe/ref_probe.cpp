@@ -764,6 +764,12 @@ static int cmd_bench(int argc, char** argv)
     ls->Build();
     _rocalution_sync();
     double t_build = (rocalution_time() - tb0) / 1e6;
+    // untimed warm-up solve (first-use costs of the vendor libraries: kernel loading, lazy allocations) --
+    // the same treatment bench.py gives the own backend (W warm-up steps)
+    ls->InitMaxIter(accel ? 20 : (iters < 3 ? iters : 3));
+    ls->Solve(rhs, &x);
+    ls->InitMaxIter(iters);
+    x.Zeros();
     _rocalution_sync();
     double ts0 = rocalution_time();
     ls->Solve(rhs, &x);
