@@ -462,6 +462,60 @@ private:
     bool         level_;
 };
 
+// ---- IC (incomplete Cholesky, zero fill-in): preconditioner.cpp:826-925
+template <class OperatorType, class VectorType, typename ValueType>
+class IC : public Preconditioner<OperatorType, VectorType, ValueType>
+{
+public:
+    IC() {}
+    virtual ~IC()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("IC preconditioner");
+        if(this->build_)
+            LOG_INFO("IC nnz = " << this->IC_.GetNnz());
+    }
+    virtual void Build(void)
+    {
+        if(this->build_)
+            this->Clear();
+        this->build_ = true;
+        assert(this->op_ != NULL);
+        this->IC_.CloneBackend(*this->op_);
+        this->inv_diag_entries_.CloneBackend(*this->op_);
+        this->op_->ExtractL(&this->IC_, true);
+        this->IC_.ICFactorize(&this->inv_diag_entries_);
+        this->IC_.LLAnalyse();
+    }
+    virtual void Clear(void)
+    {
+        this->IC_.LLAnalyseClear();
+        this->inv_diag_entries_.Clear();
+        this->IC_.Clear();
+        this->build_ = false;
+    }
+    virtual void Solve(const VectorType& rhs, VectorType* x)
+    {
+        assert(this->build_ == true && x != NULL && x != &rhs);
+        this->IC_.LLSolve(rhs, this->inv_diag_entries_, x);
+    }
+    const OperatorType& GetFactor(void) const
+    {
+        return this->IC_;
+    }
+    const VectorType& GetInverseDiagonal(void) const
+    {
+        return this->inv_diag_entries_;
+    }
+
+private:
+    OperatorType IC_;
+    VectorType   inv_diag_entries_;
+};
+
 // ---- GS / SGS: preconditioner.cpp:206-257 / :302-379 (sparse triangular solves on the matrix itself).
 // SGS::Build fills diag_entries_ with the INVERSE diagonal (:318, ExtractInverseDiagonal) -- kept as is.
 template <class OperatorType, class VectorType, typename ValueType>

@@ -149,6 +149,14 @@ int ramd_mat_permute(ramd_mat_t m, ramd_vec_t perm_i32); /* :206  P A P^T */
  * hip_matrix_csr.cpp:3915-4060).  size_colors must hold nrow ints. */
 int ramd_mat_multicoloring(ramd_mat_t m, int* num_colors, int* size_colors, ramd_vec_t perm_i32);
 int ramd_mat_ilu0_factorize(ramd_mat_t m); /* :321 */
+/* Incomplete Cholesky (IC preconditioner, preconditioner.cpp:862-925):
+ *   ICFactorize (host_matrix_csr.cpp:2344-2466) in place on L = ExtractL(A, diag = true); returns the inverse
+ *   diagonal; RAMD_ERR_STATE on the reference's "IC breakdown" conditions.
+ *   LLAnalyse / LLSolve(in, inv_diag, out) (:1294-1341): L y = b, L^T x = y, both scaled by inv_diag. */
+int ramd_mat_ic_factorize(ramd_mat_t m, ramd_vec_t inv_diag);
+int ramd_mat_ll_analyse(ramd_mat_t m);
+int ramd_mat_ll_analyse_clear(ramd_mat_t m);
+int ramd_mat_ll_solve(ramd_mat_t m, ramd_vec_t in, ramd_vec_t inv_diag, ramd_vec_t out);
 int ramd_mat_lu_analyse(ramd_mat_t m); /* :344 */
 int ramd_mat_lu_analyse_clear(ramd_mat_t m); /* :346 */
 int ramd_mat_lu_solve(ramd_mat_t m, ramd_vec_t in, ramd_vec_t out); /* :349 */
@@ -303,7 +311,8 @@ enum { RAMD_SOLVER_CG = 0, RAMD_SOLVER_GMRES = 1, RAMD_SOLVER_BICGSTAB = 2,
        /* solver.cpp:517-775 FixedPoint, chebyshev.cpp; parameters through ramd_solver_set_params */
        RAMD_SOLVER_FIXEDPOINT = 9, RAMD_SOLVER_CHEBYSHEV = 10 };
 enum { RAMD_PC_NONE = 0, RAMD_PC_JACOBI = 1, RAMD_PC_ILU0 = 2, RAMD_PC_MCSGS = 3, RAMD_PC_MCGS = 4, RAMD_PC_MCILU = 5,
-       RAMD_PC_GS = 6, RAMD_PC_SGS = 7 /* preconditioner.cpp:206-257 / :302-379 */ };
+       RAMD_PC_GS = 6, RAMD_PC_SGS = 7, /* preconditioner.cpp:206-257 / :302-379 */
+       RAMD_PC_IC = 8 /* :862-925 */ };
 int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out);
 /* MixedPrecisionDC<fp64 outer, fp32 inner>: inner solver/preconditioner kinds */
 int ramd_solver_create_mixed(int inner_solver, int inner_precond, ramd_solver_t* out);

@@ -12,7 +12,7 @@ enum { ORC_CSR = 1, ORC_ELL = 6, ORC_HYB = 7 }; /* numbering of src/base/matrix_
 enum { ORC_CG = 0, ORC_GMRES = 1, ORC_BICGSTAB = 2, ORC_FCG = 3, ORC_CR = 4, ORC_FGMRES = 5, ORC_BICGSTABL = 6,
        ORC_QMRCGSTAB = 7, ORC_IDR = 8, ORC_FIXEDPOINT = 9, ORC_CHEBYSHEV = 10 };
 enum { ORC_PC_NONE = 0, ORC_PC_JACOBI = 1, ORC_PC_ILU0 = 2, ORC_PC_MCSGS = 3, ORC_PC_MCGS = 4, ORC_PC_MCILU = 5,
-       ORC_PC_GS = 6, ORC_PC_SGS = 7 };
+       ORC_PC_GS = 6, ORC_PC_SGS = 7, ORC_PC_IC = 8 };
 #define ORC_PC_IS_MC(k) ((k) == ORC_PC_MCSGS || (k) == ORC_PC_MCGS || (k) == ORC_PC_MCILU)
 
 typedef struct

@@ -505,6 +505,98 @@ void SUF(orc_csr_usolve)(int nrow, int64_t nnz, const int* row_offset, const int
     }
 }
 
+/* src/base/host/host_matrix_csr.cpp:2344-2466  ICFactorize on L = lower part incl. diagonal (sorted rows,
+ * diagonal last in every row): in place, inverse diagonal returned.  Returns 0 on the reference's breakdowns
+ * (structural / numerical zero diagonal: FATAL_ERROR there). */
+int SUF(orc_csr_ic_factorize)(int nrow, const int* row_offset, const int* col, T* val, T* inv_diag)
+{
+    int* diag_offset = (int*)calloc((size_t)nrow, sizeof(int));
+    int* nnz_entries = (int*)calloc((size_t)nrow, sizeof(int));
+    int  ok          = 1;
+    for(int i = 0; i < nrow && ok; ++i)
+    {
+        int row_begin = row_offset[i], row_end = row_offset[i + 1];
+        for(int j = row_begin; j < row_end; ++j)
+            nnz_entries[col[j]] = j;
+        T   sum      = (T)0;
+        int has_diag = 0;
+        int j;
+        for(j = row_begin; j < row_end; ++j)
+        {
+            int col_j = col[j];
+            T   val_j = val[j];
+            if(col_j == i)
+            {
+                has_diag = 1;
+                break;
+            }
+            if(col_j > i)
+                break;
+            int row_begin_j = row_offset[col_j];
+            int row_diag_j  = diag_offset[col_j];
+            T   local_sum   = (T)0;
+            T   inv_d       = val[row_diag_j];
+            if(inv_d == (T)0)
+            {
+                ok = 0;
+                break;
+            }
+            inv_d = (T)1 / inv_d;
+            for(int k = row_begin_j; k < row_diag_j; ++k)
+            {
+                int col_k = col[k];
+                if(nnz_entries[col_k] != 0)
+                    local_sum += val[k] * val[nnz_entries[col_k]];
+            }
+            val_j = (val_j - local_sum) * inv_d;
+            sum += val_j * val_j;
+            val[j] = val_j;
+        }
+        if(!ok || !has_diag)
+        {
+            ok = 0;
+            break;
+        }
+        T diag_entry = ORC_SQRT(ORC_FABS(val[j] - sum));
+        val[j]       = diag_entry;
+        if(diag_entry == (T)0)
+        {
+            ok = 0;
+            break;
+        }
+        inv_diag[i]    = (T)1 / diag_entry;
+        diag_offset[i] = j;
+        for(j = row_begin; j < row_end; ++j)
+            nnz_entries[col[j]] = 0;
+    }
+    free(diag_offset);
+    free(nnz_entries);
+    return ok;
+}
+
+/* host_matrix_csr.cpp:1294-1341  LLSolve(in, inv_diag, out): forward sweep by rows, backward sweep by COLUMNS
+ * (scatter), both scaled with the stored inverse diagonal */
+void SUF(orc_csr_llsolve)(int nrow, const int* row_offset, const int* col, const T* val, const T* in,
+                          const T* inv_diag, T* out)
+{
+    for(int ai = 0; ai < nrow; ++ai)
+    {
+        T   value    = in[ai];
+        int diag_idx = row_offset[ai + 1] - 1;
+        for(int aj = row_offset[ai]; aj < diag_idx; ++aj)
+            value -= val[aj] * out[col[aj]];
+        out[ai] = value * inv_diag[ai];
+    }
+    for(int ai = nrow - 1; ai >= 0; --ai)
+    {
+        int diag_idx = row_offset[ai + 1] - 1;
+        T   value    = out[ai] * inv_diag[ai];
+        for(int aj = row_offset[ai]; aj < diag_idx; ++aj)
+            out[col[aj]] -= value * val[aj];
+        out[ai] = value;
+    }
+}
+
 /* ---- permutation / extraction --------------------------------------------- */
 
 /* src/base/host/host_matrix_csr.cpp:3848-3958  Permute:  B = P A P^T, rows moved to
@@ -693,6 +785,9 @@ typedef struct
     const int* col;
     T*         lu_val;
     int64_t    nnz;
+    /* IC: own lower-triangular pattern */
+    int* ic_row_offset;
+    int* ic_col;
     /* MC-SGS (decomposed, omega = 1) */
     int   num_blocks;
     int*  block_sizes;
@@ -714,6 +809,8 @@ static void SUF(pc_free)(SUF(orc_pc) * P)
     free(P->lu_val);
     if(P->kind == ORC_PC_SGS)
         free(P->xtmp);
+    free(P->ic_row_offset);
+    free(P->ic_col);
     if(ORC_PC_IS_MC(P->kind))
     {
         int nb = P->num_blocks;
@@ -766,6 +863,34 @@ static int SUF(pc_build)(SUF(orc_pc) * P, int kind, int nrow, int64_t nnz, const
         P->lu_val     = (T*)malloc(sizeof(T) * (size_t)nnz);
         memcpy(P->lu_val, val, sizeof(T) * (size_t)nnz);
         SUF(orc_csr_ilu0)(nrow, row_offset, col, P->lu_val);
+    }
+    else if(kind == ORC_PC_IC)
+    {
+        /* IC::Build (preconditioner.cpp:862-880): IC_ = ExtractL(op, diag = true); ICFactorize(&inv_diag) */
+        int64_t nl = 0;
+        for(int i = 0; i < nrow; ++i)
+            for(int j = row_offset[i]; j < row_offset[i + 1]; ++j)
+                if(col[j] <= i)
+                    ++nl;
+        P->ic_row_offset = (int*)calloc((size_t)nrow + 1, sizeof(int));
+        P->ic_col        = (int*)malloc(sizeof(int) * (size_t)(nl > 0 ? nl : 1));
+        P->lu_val        = (T*)malloc(sizeof(T) * (size_t)(nl > 0 ? nl : 1));
+        int64_t k        = 0;
+        for(int i = 0; i < nrow; ++i)
+        {
+            for(int j = row_offset[i]; j < row_offset[i + 1]; ++j)
+                if(col[j] <= i)
+                {
+                    P->ic_col[k] = col[j];
+                    P->lu_val[k] = val[j];
+                    ++k;
+                }
+            P->ic_row_offset[i + 1] = (int)k;
+        }
+        P->nnz      = nl;
+        P->inv_diag = (T*)calloc((size_t)nrow, sizeof(T));
+        if(!SUF(orc_csr_ic_factorize)(nrow, P->ic_row_offset, P->ic_col, P->lu_val, P->inv_diag))
+            return 0;
     }
     else if(kind == ORC_PC_GS || kind == ORC_PC_SGS)
     {
@@ -879,6 +1004,11 @@ static void SUF(pc_solve)(SUF(orc_pc) * P, const T* rhs, T* x)
     else if(P->kind == ORC_PC_ILU0)
     {
         SUF(orc_csr_lusolve)(n, P->nnz, P->row_offset, P->col, P->lu_val, rhs, x);
+    }
+    else if(P->kind == ORC_PC_IC)
+    {
+        /* IC::Solve (preconditioner.cpp:916-925): LLSolve(rhs, inv_diag_entries_, x) */
+        SUF(orc_csr_llsolve)(n, P->ic_row_offset, P->ic_col, P->lu_val, rhs, P->inv_diag, x);
     }
     else if(P->kind == ORC_PC_GS)
     {

@@ -16,7 +16,7 @@ _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 CSR, ELL, HYB = 1, 6, 7
 CG, GMRES, BICGSTAB, FCG, CR, FGMRES, BICGSTABL, QMRCGSTAB, IDR, FIXEDPOINT, CHEBYSHEV = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
-PC_NONE, PC_JACOBI, PC_ILU0, PC_MCSGS, PC_MCGS, PC_MCILU, PC_GS, PC_SGS = 0, 1, 2, 3, 4, 5, 6, 7
+PC_NONE, PC_JACOBI, PC_ILU0, PC_MCSGS, PC_MCGS, PC_MCILU, PC_GS, PC_SGS, PC_IC = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
 
 def build(force=False):

@@ -121,6 +121,7 @@ static int cmd_gen(const std::string& in, const std::string& out)
     std::vector<double> xin = slurp<double>(in + "/x.bin");
     std::vector<double> yin = slurp<double>(in + "/y.bin");
     int                 do_solvers = (int)hdr[2];
+    const bool          symmetric_spd = do_solvers != 0; // the solver cases are the SPD operators
     int                 basis      = (int)hdr[3];
 
     MatD mat;
@@ -303,6 +304,15 @@ static int cmd_gen(const std::string& in, const std::string& out)
         p.Build();
         p.Solve(x, &y);
         dump_vec("pc_gs", y);
+        p.Clear();
+    }
+    if(symmetric_spd) // incomplete Cholesky needs an SPD operator
+    {
+        IC<MatD, VecD, double> p;
+        p.SetOperator(mat);
+        p.Build();
+        p.Solve(x, &y);
+        dump_vec("pc_ic", y);
         p.Clear();
     }
     {
@@ -584,6 +594,16 @@ static int cmd_gen(const std::string& in, const std::string& out)
             ls.Build();
             sol.Zeros();
             run_solver("chebyshev_jacobi", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            CG<MatD, VecD, double> ls;
+            IC<MatD, VecD, double> p;
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(p);
+            ls.Build();
+            sol.Zeros();
+            run_solver("cg_ic", ls, rhs, sol);
             ls.Clear();
         }
         {

@@ -16,7 +16,7 @@ OK, ERR_HIP, ERR_ARG, ERR_UNSUPPORTED, ERR_REFUSED, ERR_NO_DEVICE, ERR_STATE = r
 SOLVER_CG, SOLVER_GMRES, SOLVER_BICGSTAB = 0, 1, 2
 SOLVER_FCG, SOLVER_CR, SOLVER_FGMRES, SOLVER_BICGSTABL, SOLVER_QMRCGSTAB, SOLVER_IDR = 3, 4, 5, 6, 7, 8
 SOLVER_FIXEDPOINT, SOLVER_CHEBYSHEV = 9, 10
-PC_NONE, PC_JACOBI, PC_ILU0, PC_MCSGS, PC_MCGS, PC_MCILU, PC_GS, PC_SGS = 0, 1, 2, 3, 4, 5, 6, 7
+PC_NONE, PC_JACOBI, PC_ILU0, PC_MCSGS, PC_MCGS, PC_MCILU, PC_GS, PC_SGS, PC_IC = 0, 1, 2, 3, 4, 5, 6, 7, 8
 F64, F32, I32 = 0, 1, 2
 CSR, COO, ELL, HYB = 1, 4, 6, 7
 
@@ -109,6 +109,10 @@ SIGNATURES = {
     "ramd_mat_gen_poisson7": (i32, [mat_t, i32]),
     "ramd_mat_gen_poisson7_slab": (i32, [mat_t, mat_t, i32, i64, i64]),
     # fused ops / scalar records
+    "ramd_mat_ic_factorize": (i32, [mat_t, vec_t]),
+    "ramd_mat_ll_analyse": (i32, [mat_t]),
+    "ramd_mat_ll_analyse_clear": (i32, [mat_t]),
+    "ramd_mat_ll_solve": (i32, [mat_t, vec_t, vec_t, vec_t]),
     "ramd_mat_gershgorin": (i32, [mat_t, pf64, pf64]),
     "ramd_mat_extract_tri": (i32, [mat_t, mat_t, i32, i32]),
     "ramd_mat_scale_values": (i32, [mat_t, f64, i32]),

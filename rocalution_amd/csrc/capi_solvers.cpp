@@ -58,6 +58,7 @@ struct Precs
     MultiColoredILU<M, V, T> mcilu;
     GS<M, V, T>              gs;
     SGS<M, V, T>             sgs;
+    IC<M, V, T>              ic;
     Solver<M, V, T>*         get(int kind)
     {
         switch(kind)
@@ -66,6 +67,8 @@ struct Precs
             return &gs;
         case RAMD_PC_SGS:
             return &sgs;
+        case RAMD_PC_IC:
+            return &ic;
         case RAMD_PC_JACOBI:
             return &jacobi;
         case RAMD_PC_ILU0:
@@ -444,7 +447,7 @@ extern "C" {
 
 int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out)
 {
-    if(!out || solver < 0 || solver > RAMD_SOLVER_CHEBYSHEV || precond < 0 || precond > RAMD_PC_SGS
+    if(!out || solver < 0 || solver > RAMD_SOLVER_CHEBYSHEV || precond < 0 || precond > RAMD_PC_IC
        || (dtype != RAMD_F64 && dtype != RAMD_F32))
         return RAMD_ERR_ARG;
     GUARD_BEGIN
@@ -459,7 +462,7 @@ int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out)
 
 int ramd_solver_create_mixed(int inner_solver, int inner_precond, ramd_solver_t* out)
 {
-    if(!out || inner_solver < 0 || inner_solver > 2 || inner_precond < 0 || inner_precond > RAMD_PC_SGS)
+    if(!out || inner_solver < 0 || inner_solver > 2 || inner_precond < 0 || inner_precond > RAMD_PC_IC)
         return RAMD_ERR_ARG;
     GUARD_BEGIN
     ramd_solver_s* s = new ramd_solver_s;

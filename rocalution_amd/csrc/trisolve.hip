@@ -208,7 +208,8 @@ __global__ __launch_bounds__(kBlock) void k_tri_fill(int nrow, const int* __rest
                                                      const int* __restrict__ pos,
                                                      const int* __restrict__ slice_off,
                                                      int* __restrict__ ecol, T* __restrict__ eval,
-                                                     T* __restrict__ diag, int* __restrict__ nodiag)
+                                                     T* __restrict__ diag, int* __restrict__ nodiag,
+                                                     int reverse)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if(t >= nrow)
@@ -220,8 +221,10 @@ __global__ __launch_bounds__(kBlock) void k_tri_fill(int nrow, const int* __rest
     const int     w    = (slice_off[s + 1] - base) >> 6;
     int           k    = 0;
     bool          have = false;
-    for(int j = rp[i]; j < rp[i + 1]; ++j)
+    const int     rs = rp[i], re = rp[i + 1];
+    for(int q = rs; q < re; ++q)
     {
+        const int j = reverse ? (re - 1 - (q - rs)) : q; // reverse: entries in DESCENDING storage order
         const int c = ci[j];
         if(LOWER ? (c < i) : (c > i))
         {
@@ -252,7 +255,8 @@ __global__ __launch_bounds__(kBlock) void k_tri_fill(int nrow, const int* __rest
 // rhs  = rhs_src[rhs_idx[t]]          (gather: natural-order input, or the L stage's positions)
 // w    = sentinel-initialised scratch in position order (polled + published)
 // out  = optional natural-order output, out[order[t]] = sum
-template <typename T, bool UNIT_DIAG>
+// DMODE 0: unit diagonal   1: sum /= diag (stored diagonal)   2: sum *= diag (an inverse diagonal: LLSolve)
+template <typename T, int DMODE>
 __global__ __launch_bounds__(kBlock) void k_trsv(int nrow, const int* __restrict__ slice_off,
                                                  const int* __restrict__ ecol,
                                                  const T* __restrict__ eval,
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(kBlock) void k_trsv(int nrow, const int* __restrict
     const int     b0   = slice_off[s];
     const int     wd   = (slice_off[s + 1] - b0) >> 6;
     T             sum  = rhs_src[rhs_idx[t]];
-    const T       dg   = UNIT_DIAG ? (T)1 : diag[t]; // fetched before the wait, not after it
+    const T       dg   = (DMODE == 0) ? (T)1 : diag[t]; // fetched before the wait, not after it
     const int     onat = out ? order[t] : 0;
     // A row's dependencies mostly sit in the previous level and become ready together, so they are
     // polled TOGETHER (one L2 round trip per attempt, not one per dependency) and the row's entries are
@@ -322,8 +326,10 @@ __global__ __launch_bounds__(kBlock) void k_trsv(int nrow, const int* __restrict
                     load_chunk(k0);
                 else
                 {
-                    if(!UNIT_DIAG)
+                    if(DMODE == 1)
                         sum /= dg;
+                    else if(DMODE == 2)
+                        sum = sum * dg;
                     publish(w + t, sum);
                     if(out)
                         out[onat] = sum;
@@ -465,6 +471,11 @@ struct TriState
     // and LAnalyse / LUAnalyse take it over
     int* l_order_cache = nullptr;
     int  l_nlev_cache  = 0;
+    // LLSolve (incomplete Cholesky): forward plan on L, backward plan on L^T, both scaled by an inverse diagonal
+    TriPlan     LLf, LLb;
+    bool        haveLL      = false;
+    int*        ll_rhs_idx  = nullptr; // [n]: L^T position -> L position of the same row
+    const void* ll_diag_src = nullptr; // inverse-diagonal vector the plans' diag arrays were gathered from
 };
 
 static TriState* tri_state(ramd_mat_s* m)
@@ -482,6 +493,9 @@ void tri_release(ramd_mat_s* m)
     dev_free(&st->lu_rhs_idx);
     dev_free(&st->counter);
     dev_free(&st->l_order_cache);
+    st->LLf.release();
+    st->LLb.release();
+    dev_free(&st->ll_rhs_idx);
     delete st;
     m->tri = nullptr;
 }
@@ -554,7 +568,7 @@ static int level_order(ramd_mat_s* m, TriState* st, bool lower, int** order_out,
 }
 
 template <typename T>
-static int build_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower)
+static int build_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bool reverse = false)
 {
     Backend&  b = backend();
     const int n = m->nrow;
@@ -631,11 +645,11 @@ static int build_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower)
         if(lower)
             hipLaunchKernelGGL((k_tri_fill<T, true>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci,
                                (const T*)m->val, P->order, P->pos, P->slice_off, P->ecol, (T*)P->eval,
-                               (T*)P->diag, nodiag);
+                               (T*)P->diag, nodiag, reverse ? 1 : 0);
         else
             hipLaunchKernelGGL((k_tri_fill<T, false>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci,
                                (const T*)m->val, P->order, P->pos, P->slice_off, P->ecol, (T*)P->eval,
-                               (T*)P->diag, nodiag);
+                               (T*)P->diag, nodiag, reverse ? 1 : 0);
         int        nd = 0;
         hipError_t e  = hipMemcpyAsync(&nd, nodiag, sizeof(int), hipMemcpyDeviceToHost, b.cur);
         if(e == hipSuccess)
@@ -661,7 +675,8 @@ __global__ __launch_bounds__(kBlock) void k_compose_idx(int n, const int* __rest
 }
 
 template <typename T>
-static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const int* rhs_idx, T* out)
+static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const int* rhs_idx, T* out,
+                    bool mul_inv_diag = false)
 {
     Backend& b = backend();
     if(P->n == 0)
@@ -678,14 +693,17 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
         lds_pad        = e1 ? atoi(e1) : 0;
         sleep_cycles   = e2 ? atoi(e2) : 4;
     }
-    if(unit)
-        hipLaunchKernelGGL((k_trsv<T, true>), dim3(nb), dim3(kBlock), (size_t)lds_pad, b.cur, P->n,
-                           P->slice_off, P->ecol, (const T*)P->eval, (const T*)P->diag, rhs_src, rhs_idx,
-                           (T*)P->w, out, P->order, st->counter, st->ticket, sleep_cycles);
+#define TRSV(DM)                                                                                          \
+    hipLaunchKernelGGL((k_trsv<T, DM>), dim3(nb), dim3(kBlock), (size_t)lds_pad, b.cur, P->n, P->slice_off, \
+                       P->ecol, (const T*)P->eval, (const T*)P->diag, rhs_src, rhs_idx, (T*)P->w, out,     \
+                       P->order, st->counter, st->ticket, sleep_cycles)
+    if(mul_inv_diag)
+        TRSV(2);
+    else if(unit)
+        TRSV(0);
     else
-        hipLaunchKernelGGL((k_trsv<T, false>), dim3(nb), dim3(kBlock), (size_t)lds_pad, b.cur, P->n,
-                           P->slice_off, P->ecol, (const T*)P->eval, (const T*)P->diag, rhs_src, rhs_idx,
-                           (T*)P->w, out, P->order, st->counter, st->ticket, sleep_cycles);
+        TRSV(1);
+#undef TRSV
     st->ticket += nb;
     RAMD_HIP(hipGetLastError());
     return RAMD_OK;
@@ -731,6 +749,268 @@ static int ilu0_t(ramd_mat_s* m)
     return RAMD_OK;
 }
 
+// ---------------------------------------------------------------- IC(0), level order, sync-free
+// host_matrix_csr.cpp:2344-2466 on L = lower part incl. diagonal (sorted rows => the diagonal is the last entry of
+// every row).  Thread per row, rows in (level, row) order; a row waits for every row col_j < i of its pattern:
+//   l_ij = (a_ij - sum_k l_jk l_ik) / l_jj   (k ascending over row j, products added when row i has column k)
+//   l_ii = sqrt(|a_ii - sum_j l_ij^2|),  inv_diag_i = 1 / l_ii
+// err: 1 structural zero diagonal, 2 numerical zero (the reference aborts with "IC breakdown")
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_ic0(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                T* val, T* __restrict__ inv_diag, int* done, int* err,
+                                                unsigned* counter, unsigned base, const int* __restrict__ order)
+{
+    using B            = typename Sentinel<T>::bits;
+    const unsigned blk = take_ticket(counter, base);
+    const int64_t  t   = (int64_t)blk * kBlock + threadIdx.x;
+    if(t >= nrow)
+        return;
+    const int i  = order[t];
+    const int rs = rp[i], re = rp[i + 1];
+    int       j  = rs;
+    T         sum = (T)0;
+    bool      fin = false;
+    int       spins = 0;
+    do
+    {
+        spin_guard(spins);
+        if(!fin)
+        {
+            const int cj = (j < re) ? ci[j] : nrow;
+            if(j < re && cj < i)
+            {
+                if(__hip_atomic_load(done + cj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                {
+                    const int rbj = rp[cj], rdj = rp[cj + 1] - 1; // diagonal of row cj: its last entry
+                    const T   dj  = Sentinel<T>::from_bits(__hip_atomic_load(
+                        reinterpret_cast<const B*>(val + rdj), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    T local_sum = (T)0;
+                    int m = rs; // own entries left of (i, cj), ascending
+                    for(int k = rbj; k < rdj; ++k)
+                    {
+                        const int ck = ci[k];
+                        while(m < j && ci[m] < ck)
+                            ++m;
+                        if(m < j && ci[m] == ck)
+                        {
+                            const T ljk = Sentinel<T>::from_bits(__hip_atomic_load(
+                                reinterpret_cast<const B*>(val + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            local_sum += ljk * val[m];
+                        }
+                    }
+                    if(dj == (T)0)
+                        *err = 2;
+                    const T inv = (T)1 / dj;
+                    const T lij = (val[j] - local_sum) * inv;
+                    sum += lij * lij;
+                    val[j] = lij;
+                    ++j;
+                }
+            }
+            else
+            {
+                // diagonal (or its absence)
+                T dinv = (T)1;
+                if(j < re && cj == i)
+                {
+                    const T a  = val[j] - sum;
+                    const T de = (T)sqrt((double)(a < (T)0 ? -a : a));
+                    val[j]     = de;
+                    if(de == (T)0)
+                        *err = 2;
+                    dinv = (T)1 / de;
+                }
+                else
+                    *err = 1;
+                inv_diag[i] = dinv;
+                for(int q = rs; q < re && q <= j; ++q) // publish the row write-through, then the flag
+                    __hip_atomic_store(reinterpret_cast<B*>(val + q), Sentinel<T>::as_bits(val[q]), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(done + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                fin = true;
+            }
+        }
+    } while(__ballot(!fin) != 0ull);
+}
+
+template <typename T>
+static int ic0_t(ramd_mat_s* m, ramd_vec_s* inv_diag)
+{
+    Backend&  b  = backend();
+    TriState* st = nullptr;
+    RAMD_TRY(tri_get(m, &st));
+    const int n    = m->nrow;
+    int*      done = nullptr;
+    int*      err  = nullptr;
+    RAMD_TRY(dev_alloc(&done, (int64_t)n + 1));
+    err = done + n;
+    hipError_t e = hipMemsetAsync(done, 0, sizeof(int) * ((size_t)n + 1), b.cur);
+    if(!st->l_order_cache)
+    {
+        int s = level_order(m, st, true, &st->l_order_cache, &st->l_nlev_cache);
+        if(s != RAMD_OK)
+        {
+            dev_free(&done);
+            return s;
+        }
+    }
+    const unsigned nb = nblocks_of(n);
+    hipLaunchKernelGGL((k_ic0<T>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (T*)m->val, (T*)inv_diag->d, done,
+                       err, st->counter, st->ticket, st->l_order_cache);
+    st->ticket += nb;
+    int herr = 0;
+    if(e == hipSuccess)
+        e = hipGetLastError();
+    if(e == hipSuccess)
+        e = hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+    if(e == hipSuccess)
+        e = hipStreamSynchronize(b.cur);
+    dev_free(&done);
+    RAMD_HIP(e);
+    if(herr == 1)
+        RAMD_FAIL(RAMD_ERR_STATE, "IC breakdown: structural zero diagonal");
+    if(herr == 2)
+        RAMD_FAIL(RAMD_ERR_STATE, "IC breakdown: division by zero");
+    return RAMD_OK;
+}
+
+// ---------------------------------------------------------------- transpose (pattern + values) for L^T
+__global__ __launch_bounds__(kBlock) void k_tr_count(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                     int* __restrict__ cnt)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += gsz)
+        for(int j = rp[r]; j < rp[r + 1]; ++j)
+            atomicAdd(cnt + ci[j], 1);
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_tr_scatter(int nrow, const int* __restrict__ rp,
+                                                       const int* __restrict__ ci, const T* __restrict__ val,
+                                                       int* __restrict__ cursor, int* __restrict__ tci,
+                                                       T* __restrict__ tval)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += gsz)
+        for(int j = rp[r]; j < rp[r + 1]; ++j)
+        {
+            const int p = atomicAdd(cursor + ci[j], 1);
+            tci[p]      = (int)r;
+            tval[p]     = val[j];
+        }
+}
+// the scatter order inside a row is arbitrary: sort every (short) row by column
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_tr_sort_rows(int nrow, const int* __restrict__ rp, int* __restrict__ ci,
+                                                         T* __restrict__ val)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += gsz)
+        for(int a = rp[r] + 1; a < rp[r + 1]; ++a)
+        {
+            const int c = ci[a];
+            const T   v = val[a];
+            int       q = a - 1;
+            for(; q >= rp[r] && ci[q] > c; --q)
+            {
+                ci[q + 1]  = ci[q];
+                val[q + 1] = val[q];
+            }
+            ci[q + 1]  = c;
+            val[q + 1] = v;
+        }
+}
+
+template <typename T>
+static int transpose_into(const ramd_mat_s* m, ramd_mat_s* t)
+{
+    Backend& b = backend();
+    RAMD_TRY(mat_alloc_csr(t, m->ncol, m->nrow, m->nnz));
+    RAMD_HIP(hipMemsetAsync(t->rp, 0, sizeof(int) * ((size_t)t->nrow + 1), b.cur));
+    const int grid = ew_grid(std::max(m->nrow, 1));
+    hipLaunchKernelGGL(k_tr_count, dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, m->rp, m->ci, t->rp);
+    RAMD_TRY(device_exclusive_scan(t->rp, t->rp, (int64_t)t->nrow + 1));
+    int* cursor = nullptr;
+    RAMD_TRY(dev_alloc(&cursor, (int64_t)t->nrow + 1));
+    hipError_t e = hipMemcpyAsync(cursor, t->rp, sizeof(int) * ((size_t)t->nrow + 1), hipMemcpyDeviceToDevice, b.cur);
+    hipLaunchKernelGGL((k_tr_scatter<T>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, m->rp, m->ci, (const T*)m->val,
+                       cursor, t->ci, (T*)t->val);
+    hipLaunchKernelGGL((k_tr_sort_rows<T>), dim3(ew_grid(std::max(t->nrow, 1))), dim3(kBlock), 0, b.cur, t->nrow, t->rp,
+                       t->ci, (T*)t->val);
+    if(e == hipSuccess)
+        e = hipGetLastError();
+    if(e == hipSuccess)
+        e = hipStreamSynchronize(b.cur);
+    dev_free(&cursor);
+    RAMD_HIP(e);
+    return RAMD_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_gather_diag(int n, const int* __restrict__ order, const T* __restrict__ src,
+                                                        T* __restrict__ dst)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gsz)
+        dst[t] = src[order[t]];
+}
+
+template <typename T>
+static int ll_analyse_t(ramd_mat_s* m)
+{
+    TriState* st = nullptr;
+    RAMD_TRY(tri_get(m, &st));
+    st->haveLL = false;
+    RAMD_TRY(build_plan<T>(m, st, &st->LLf, true)); // forward: row sweep on L
+    ramd_mat_s* lt = new ramd_mat_s;
+    lt->dtype      = m->dtype;
+    int s          = transpose_into<T>(m, lt);
+    if(s == RAMD_OK)
+    {
+        TriState* stt = nullptr;
+        // the backward plan lives in THIS matrix' state; the transposed copy is only its input (own ticket counter)
+        s = tri_get(lt, &stt);
+        if(s == RAMD_OK)
+            s = build_plan<T>(lt, stt, &st->LLb, false, true); // entries of a row of L^T in DESCENDING row order
+    }
+    tri_release(lt);
+    mat_free_csr(lt);
+    delete lt;
+    RAMD_TRY(s);
+    dev_free(&st->ll_rhs_idx);
+    RAMD_TRY(dev_alloc(&st->ll_rhs_idx, m->nrow));
+    if(m->nrow > 0)
+        hipLaunchKernelGGL(k_compose_idx, dim3(ew_grid(m->nrow)), dim3(kBlock), 0, backend().cur, m->nrow, st->LLb.order,
+                           st->LLf.pos, st->ll_rhs_idx);
+    RAMD_HIP(hipGetLastError());
+    st->ll_diag_src = nullptr;
+    st->haveLL      = true;
+    return RAMD_OK;
+}
+
+template <typename T>
+static int ll_solve_t(ramd_mat_s* m, const T* in, const T* inv_diag, T* out)
+{
+    TriState* st = tri_state(m);
+    if(!st || !st->haveLL)
+        RAMD_FAIL(RAMD_ERR_STATE, "LLSolve before LLAnalyse");
+    Backend& b = backend();
+    if(m->nrow == 0)
+        return RAMD_OK;
+    if(st->ll_diag_src != (const void*)inv_diag) // the plans keep the inverse diagonal in position order
+    {
+        const int grid = ew_grid(m->nrow);
+        hipLaunchKernelGGL((k_gather_diag<T>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, st->LLf.order, inv_diag,
+                           (T*)st->LLf.diag);
+        hipLaunchKernelGGL((k_gather_diag<T>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, st->LLb.order, inv_diag,
+                           (T*)st->LLb.diag);
+        st->ll_diag_src = (const void*)inv_diag;
+    }
+    // L y = b with y_i scaled by inv_diag_i, y kept in position order; then L^T x = y, scaled, natural order out
+    RAMD_TRY(run_plan<T>(st, &st->LLf, false, in, st->LLf.order, nullptr, true));
+    return run_plan<T>(st, &st->LLb, false, (const T*)st->LLf.w, st->ll_rhs_idx, out, true);
+}
+
 } // namespace ramd
 
 using namespace ramd;
@@ -760,6 +1040,54 @@ int ramd_mat_ilu0_factorize(ramd_mat_t m)
     if(m->nrow != m->ncol || m->nnz <= 0)
         RAMD_FAIL(RAMD_ERR_ARG, "ILU0Factorize: need a square, non-empty matrix (the reference asserts)");
     return (m->dtype == RAMD_F64) ? ilu0_t<double>(m) : ilu0_t<float>(m);
+}
+
+int ramd_mat_ic_factorize(ramd_mat_t m, ramd_vec_t inv_diag)
+{
+    if(!m || !inv_diag)
+        RAMD_FAIL(RAMD_ERR_ARG, "null handle");
+    if(m->format != RAMD_CSR)
+        return RAMD_ERR_UNSUPPORTED;
+    if(m->nrow != m->ncol || m->nnz <= 0 || inv_diag->dtype != m->dtype)
+        RAMD_FAIL(RAMD_ERR_ARG, "ICFactorize: need a square, non-empty lower-triangular matrix and a vector of its type");
+    RAMD_TRY(ramd_vec_allocate(inv_diag, m->nrow));
+    return (m->dtype == RAMD_F64) ? ic0_t<double>(m, inv_diag) : ic0_t<float>(m, inv_diag);
+}
+
+int ramd_mat_ll_analyse(ramd_mat_t m)
+{
+    if(!m)
+        RAMD_FAIL(RAMD_ERR_ARG, "null matrix handle");
+    if(m->format != RAMD_CSR)
+        return RAMD_ERR_UNSUPPORTED;
+    if(m->nrow != m->ncol)
+        RAMD_FAIL(RAMD_ERR_ARG, "LLAnalyse: square matrix expected");
+    return (m->dtype == RAMD_F64) ? ll_analyse_t<double>(m) : ll_analyse_t<float>(m);
+}
+
+int ramd_mat_ll_analyse_clear(ramd_mat_t m)
+{
+    if(!m)
+        RAMD_FAIL(RAMD_ERR_ARG, "null matrix handle");
+    TriState* st = tri_state(m);
+    if(st)
+    {
+        st->LLf.release();
+        st->LLb.release();
+        dev_free(&st->ll_rhs_idx);
+        st->haveLL = false;
+    }
+    return RAMD_OK;
+}
+
+int ramd_mat_ll_solve(ramd_mat_t m, ramd_vec_t in, ramd_vec_t inv_diag, ramd_vec_t out)
+{
+    RAMD_TRY(check_tri(m, in, out));
+    if(!inv_diag || inv_diag->dtype != m->dtype || inv_diag->n != m->nrow)
+        RAMD_FAIL(RAMD_ERR_ARG, "LLSolve: inverse diagonal vector of the matrix' size and type expected");
+    if(m->dtype == RAMD_F64)
+        return ll_solve_t<double>(m, (const double*)in->d, (const double*)inv_diag->d, (double*)out->d);
+    return ll_solve_t<float>(m, (const float*)in->d, (const float*)inv_diag->d, (float*)out->d);
 }
 
 int ramd_mat_lu_analyse(ramd_mat_t m)

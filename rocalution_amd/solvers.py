@@ -11,7 +11,8 @@ import ctypes as C
 import numpy as np
 
 from . import capi
-from .capi import (PC_GS, PC_ILU0, PC_JACOBI, PC_MCGS, PC_MCILU, PC_MCSGS, PC_NONE, PC_SGS, SOLVER_BICGSTAB, SOLVER_BICGSTABL,
+from .capi import (PC_GS, PC_IC, PC_ILU0, PC_JACOBI, PC_MCGS, PC_MCILU, PC_MCSGS, PC_NONE, PC_SGS, SOLVER_BICGSTAB,
+                   SOLVER_BICGSTABL,
                    SOLVER_CG, SOLVER_CHEBYSHEV, SOLVER_CR, SOLVER_FCG, SOLVER_FGMRES, SOLVER_FIXEDPOINT, SOLVER_GMRES,
                    SOLVER_IDR, SOLVER_QMRCGSTAB)
 
@@ -50,6 +51,11 @@ class GS(_Precond):
 class SGS(_Precond):
     """symmetric Gauss-Seidel: LSolve, diagonal scaling, USolve (preconditioner.cpp:302-379)"""
     kind = PC_SGS
+
+
+class IC(_Precond):
+    """incomplete Cholesky, zero fill-in (preconditioner.cpp:826-925): ICFactorize on ExtractL, LLSolve"""
+    kind = PC_IC
 
 
 class MultiColoredSGS(_Precond):

@@ -26,6 +26,7 @@ static std::unique_ptr<AnySolver> make_precond(const std::string& p)
     if(p == "jacobi") return std::unique_ptr<AnySolver>(new Jacobi<Mat, Vec, double>);
     if(p == "gs") return std::unique_ptr<AnySolver>(new GS<Mat, Vec, double>);
     if(p == "sgs") return std::unique_ptr<AnySolver>(new SGS<Mat, Vec, double>);
+    if(p == "ic") return std::unique_ptr<AnySolver>(new IC<Mat, Vec, double>);
     if(p == "ilu") return std::unique_ptr<AnySolver>(new ILU<Mat, Vec, double>);
     if(p == "mcgs") return std::unique_ptr<AnySolver>(new MultiColoredGS<Mat, Vec, double>);
     if(p == "mcsgs") return std::unique_ptr<AnySolver>(new MultiColoredSGS<Mat, Vec, double>);

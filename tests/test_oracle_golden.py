@@ -141,6 +141,8 @@ def test_preconditioner_apply(oracle, name):
     eq(oracle.precond_apply(oracle.PC_MCILU, rp, ci, va, x), g["pc_mcilu"])
     eq(oracle.precond_apply(oracle.PC_GS, rp, ci, va, x), g["pc_gs"])
     eq(oracle.precond_apply(oracle.PC_SGS, rp, ci, va, x), g["pc_sgs"])
+    if "pc_ic" in g:  # SPD cases only
+        eq(oracle.precond_apply(oracle.PC_IC, rp, ci, va, x), g["pc_ic"])
 
 
 SOLVER_TABLE = {
@@ -171,6 +173,7 @@ SOLVER_TABLE = {
     "idr2_jacobi": ("IDR", "PC_JACOBI", "CSR", dict(basis=2, seed=777)),
     "cg_sgs": ("CG", "PC_SGS", "CSR", {}),
     "bicgstab_gs": ("BICGSTAB", "PC_GS", "CSR", {}),
+    "cg_ic": ("CG", "PC_IC", "CSR", {}),
     "fixedpoint_jacobi": ("FIXEDPOINT", "PC_JACOBI", "CSR", dict(p0=0.8, max_iter=40)),
     "fixedpoint_smoother_mcsgs": ("FIXEDPOINT", "PC_MCSGS", "CSR", dict(p0=1.0, p1=1.0, max_iter=3)),
     "chebyshev_none": ("CHEBYSHEV", "PC_NONE", "CSR", dict(p0=0.05, p1=16.0, max_iter=60)),
