@@ -32,6 +32,18 @@
 /* ---- OpenMP policy: src/base/backend_manager.cpp:78 (threshold 10000), :590-607 ---- */
 static int g_threads   = 1;
 static int g_threshold = 10000;
+/* SolverDescr of the preconditioners built next (src/solvers/solver.hpp:82-148): defaults direct, 30, 1e-3, tol on */
+static int    g_tri_iterative = 0;
+static int    g_it_max_iter   = 30;
+static double g_it_tol        = 1e-3;
+static int    g_it_use_tol    = 1;
+void          orc_set_solver_descr(int iterative, int max_iter, double tol, int use_tol)
+{
+    g_tri_iterative = iterative;
+    g_it_max_iter   = max_iter;
+    g_it_tol        = tol;
+    g_it_use_tol    = use_tol;
+}
 
 void orc_set_threads(int n)
 {

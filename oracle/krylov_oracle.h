@@ -38,6 +38,9 @@ typedef struct
 void orc_set_threads(int n);
 int  orc_get_threads(void);
 int  orc_max_threads(void);
+/* SolverDescr applied to every preconditioner built afterwards: TriSolverAlg_Iterative on/off, max sweeps,
+ * tolerance, tolerance used (solver.hpp:82-148; defaults 0, 30, 1e-3, 1) */
+void orc_set_solver_descr(int iterative, int max_iter, double tol, int use_tol);
 
 int     orc_csr_ell_width(int nrow, int64_t nnz, const int* row_offset);
 int     orc_csr_hyb_width(int nrow, int64_t nnz);
@@ -76,11 +79,21 @@ int     orc_csr_multicoloring(int nrow, int64_t nnz, const int* row_offset, cons
     void orc_csr_lusolve##S(int, int64_t, const int*, const int*, const T*, const T*, T*);         \
     void orc_csr_lsolve##S(int, const int*, const int*, const T*, int, const T*, T*);              \
     void orc_csr_usolve##S(int, int64_t, const int*, const int*, const T*, int, const T*, T*);     \
+    void orc_csr_itlusolve##S(int, double, int, int, int64_t, const int*, const int*, const T*,    \
+                              const T*, T*, T*, T*);                                               \
+    void orc_csr_itllsolve##S(int, double, int, int, int64_t, const int*, const int*, const T*,    \
+                              const T*, T*, T*, T*);                                               \
+    void orc_csr_itlsolve##S(int, double, int, int, int64_t, const int*, const int*, const T*,     \
+                             int, const T*, T*, T*);                                               \
+    void orc_csr_itusolve##S(int, double, int, int, int64_t, const int*, const int*, const T*,     \
+                             int, const T*, T*, T*);                                               \
     void orc_csr_permute##S(int, int64_t, const int*, const int*, const T*, const int*, int*,      \
                             int*, T*);                                                             \
     int64_t orc_csr_extract_submatrix##S(const int*, const int*, const T*, int, int, int, int,     \
                                          int*, int*, T*);                                          \
     int orc_precond_apply##S(int, int, int64_t, const int*, const int*, const T*, const T*, T*);   \
+    int orc_precond_apply_rep##S(int, int, int64_t, const int*, const int*, const T*, const T*,   \
+                                 T*, int);                                                         \
     int orc_solve##S(int, int64_t, const int*, const int*, const T*, const T*, T*, orc_solve_cfg*);
 
 ORC_DECL(double, _f64)

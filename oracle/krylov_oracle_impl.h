@@ -597,6 +597,174 @@ void SUF(orc_csr_llsolve)(int nrow, const int* row_offset, const int* col, const
     }
 }
 
+/* ---- iterative triangular solves (TriSolverAlg_Iterative) --------------------------------
+ * src/base/host/host_sparse.cpp:195-530 host_csritsv_solve, matrix_type general, alpha = 1:
+ * Jacobi sweeps  y <- y + D^-1 (x - (D + T) y)  on one triangle of a CSR matrix with sorted rows, started from
+ * whatever y holds, stopped after *nmaxiter sweeps or when the sweep's max-norm figure drops to tol (tol == NULL:
+ * never); *nmaxiter is overwritten with the sweeps done when the tolerance stops it.
+ *   lower: entries [row begin, first col >= i)            (+ the diagonal, last, when non-unit)
+ *   upper: entries (diagonal, row end)                    (+ the diagonal, FIRST, when non-unit)
+ *   transposed (lower, non-unit only here): column sums of the lower triangle incl. diagonal, rows ascending
+ * A missing or zero diagonal (non-unit) leaves y untouched (:388-391, :425-429).  work: 2*m values. */
+static void SUF(orc_csritsv)(int* nmaxiter, const T* tol, int transposed, int m, int64_t nnz, int lower,
+                             int unit, const T* val, const int* rp, const int* col, const T* x, T* y, T* work)
+{
+    if(m == 0 || nnz == 0)
+    {
+        if(nnz == 0 && unit)
+        {
+            for(int i = 0; i < m; ++i)
+                y[i] = (T)1 * x[i];
+            *nmaxiter = 1;
+        }
+        return;
+    }
+    T*   yp  = work;
+    T*   idg = work + m;
+    int* b   = (int*)malloc(sizeof(int) * (size_t)m);
+    int* e   = (int*)malloc(sizeof(int) * (size_t)m);
+    int  bad = 0;
+    for(int i = 0; i < m && !bad; ++i)
+    {
+        int k = rp[i], end = rp[i + 1];
+        if(unit)
+        {
+            /* first entry with col >= i (lower) resp. col > i (upper) */
+            while(k < end && (lower ? col[k] < i : col[k] <= i))
+                ++k;
+            b[i] = lower ? rp[i] : k;
+            e[i] = lower ? k : end;
+        }
+        else
+        {
+            while(k < end && col[k] != i)
+                ++k;
+            if(k == end)
+                bad = 1; /* structural zero pivot */
+            else if(val[k] == (T)0)
+                bad = 1; /* numerical zero pivot */
+            else
+                idg[i] = (T)1 / val[k];
+            b[i] = lower ? rp[i] : k;
+            e[i] = lower ? k + 1 : end;
+        }
+    }
+    if(!bad)
+        for(int iter = 0; iter < *nmaxiter; ++iter)
+        {
+            for(int i = 0; i < m; ++i)
+                yp[i] = y[i];
+            T mx = (T)0, mxr = (T)0;
+            if(!transposed && !unit)
+                for(int i = 0; i < m; ++i)
+                {
+                    if(e[i] > b[i] + 1)
+                    {
+                        T sum = (T)0;
+                        for(int k = b[i]; k < e[i]; ++k)
+                            sum += val[k] * yp[col[k]];
+                        T r = (T)1 * x[i] - sum;
+                        T h = idg[i] * r;
+                        if(mx < ORC_FABS(h))
+                            mx = ORC_FABS(h);
+                        if(mxr < ORC_FABS(r))
+                            mxr = ORC_FABS(r);
+                        y[i] = yp[i] + h;
+                    }
+                    else
+                    {
+                        y[i] = idg[i] * (T)1 * x[i];
+                        T d  = ORC_FABS(y[i] - yp[i]);
+                        if(mx < d)
+                            mx = d;
+                        T r = ORC_FABS((T)1 * x[i] - yp[i] / idg[i]);
+                        if(mxr < r)
+                            mxr = r;
+                    }
+                }
+            else if(!transposed)
+                for(int i = 0; i < m; ++i)
+                {
+                    T sum = (T)0;
+                    for(int k = b[i]; k < e[i]; ++k)
+                        sum += val[k] * yp[col[k]];
+                    y[i] = (T)1 * x[i] - sum;
+                    T h  = ORC_FABS(y[i] - yp[i]);
+                    if(mx < h)
+                        mx = h;
+                    mxr = mx;
+                }
+            else
+            {
+                for(int i = 0; i < m; ++i)
+                    y[i] = (T)0;
+                for(int i = 0; i < m; ++i)
+                    for(int k = b[i]; k < e[i]; ++k)
+                        y[col[k]] += val[k] * yp[i];
+                for(int i = 0; i < m; ++i)
+                {
+                    /* as written in the reference (:487): the residual figure is max(mx so far, this row) */
+                    T r = ORC_FABS((T)1 * x[i] - y[i]);
+                    mxr = (mx < r) ? r : mx;
+                    T h = idg[i] * ((T)1 * x[i] - y[i]);
+                    if(mx < ORC_FABS(h))
+                        mx = ORC_FABS(h);
+                    y[i] = h + yp[i];
+                }
+            }
+            if(tol && mxr <= *tol)
+            {
+                *nmaxiter = iter + 1;
+                break;
+            }
+        }
+    free(b);
+    free(e);
+}
+
+/* host_matrix_csr.cpp:1565-1650 ItLUSolve: L (unit) into the persistent tmp vector, then U (non-unit) into out;
+ * ONE max_iter variable serves both calls, so a tolerance stop of the L stage caps the U stage */
+void SUF(orc_csr_itlusolve)(int max_iter, double tolerance, int use_tol, int nrow, int64_t nnz, const int* rp,
+                            const int* col, const T* val, const T* in, T* tmp, T* out, T* work)
+{
+    if(nnz <= 0)
+        return;
+    T        t   = (T)tolerance;
+    const T* tol = use_tol ? &t : NULL;
+    SUF(orc_csritsv)(&max_iter, tol, 0, nrow, nnz, 1, 1, val, rp, col, in, tmp, work);
+    SUF(orc_csritsv)(&max_iter, tol, 0, nrow, nnz, 0, 0, val, rp, col, tmp, out, work);
+}
+/* :1748-1833 ItLLSolve: L (non-unit), then L^T */
+void SUF(orc_csr_itllsolve)(int max_iter, double tolerance, int use_tol, int nrow, int64_t nnz, const int* rp,
+                            const int* col, const T* val, const T* in, T* tmp, T* out, T* work)
+{
+    if(nnz <= 0)
+        return;
+    T        t   = (T)tolerance;
+    const T* tol = use_tol ? &t : NULL;
+    SUF(orc_csritsv)(&max_iter, tol, 0, nrow, nnz, 1, 0, val, rp, col, in, tmp, work);
+    SUF(orc_csritsv)(&max_iter, tol, 1, nrow, nnz, 1, 0, val, rp, col, tmp, out, work);
+}
+/* :1909-1968 ItLSolve / :2033-2092 ItUSolve */
+void SUF(orc_csr_itlsolve)(int max_iter, double tolerance, int use_tol, int nrow, int64_t nnz, const int* rp,
+                           const int* col, const T* val, int diag_unit, const T* in, T* out, T* work)
+{
+    if(nnz <= 0)
+        return;
+    T        t   = (T)tolerance;
+    const T* tol = use_tol ? &t : NULL;
+    SUF(orc_csritsv)(&max_iter, tol, 0, nrow, nnz, 1, diag_unit, val, rp, col, in, out, work);
+}
+void SUF(orc_csr_itusolve)(int max_iter, double tolerance, int use_tol, int nrow, int64_t nnz, const int* rp,
+                           const int* col, const T* val, int diag_unit, const T* in, T* out, T* work)
+{
+    if(nnz <= 0)
+        return;
+    T        t   = (T)tolerance;
+    const T* tol = use_tol ? &t : NULL;
+    SUF(orc_csritsv)(&max_iter, tol, 0, nrow, nnz, 0, diag_unit, val, rp, col, in, out, work);
+}
+
 /* ---- permutation / extraction --------------------------------------------- */
 
 /* src/base/host/host_matrix_csr.cpp:3848-3958  Permute:  B = P A P^T, rows moved to
@@ -801,10 +969,17 @@ typedef struct
     T**   blk_diag; /* diag_block_[i] */
     T*    xperm; /* x_ */
     T*    xtmp;
+    /* TriSolverAlg_Iterative (descriptor captured at build): persistent tmp_vec_ and the csritsv buffer */
+    int    it_on, it_max_iter, it_use_tol;
+    double it_tol;
+    T*     it_tmp;
+    T*     it_work;
 } SUF(orc_pc);
 
 static void SUF(pc_free)(SUF(orc_pc) * P)
 {
+    free(P->it_tmp);
+    free(P->it_work);
     free(P->inv_diag);
     free(P->lu_val);
     if(P->kind == ORC_PC_SGS)
@@ -850,6 +1025,16 @@ static int SUF(pc_build)(SUF(orc_pc) * P, int kind, int nrow, int64_t nnz, const
     memset(P, 0, sizeof(*P));
     P->kind = kind;
     P->n    = nrow;
+    if(g_tri_iterative && (kind == ORC_PC_ILU0 || kind == ORC_PC_IC || kind == ORC_PC_GS || kind == ORC_PC_SGS))
+    {
+        /* ItLUAnalyse / ItLLAnalyse allocate tmp_vec_ zero-filled (host_matrix_csr.cpp:1469-1543, :1652-1726) */
+        P->it_on       = 1;
+        P->it_max_iter = g_it_max_iter;
+        P->it_tol      = g_it_tol;
+        P->it_use_tol  = g_it_use_tol;
+        P->it_tmp      = (T*)calloc((size_t)(nrow > 0 ? nrow : 1), sizeof(T));
+        P->it_work     = (T*)calloc((size_t)(nrow > 0 ? 2 * nrow : 1), sizeof(T));
+    }
     if(kind == ORC_PC_JACOBI)
     {
         P->inv_diag = (T*)calloc((size_t)nrow, sizeof(T)); /* Allocate() zero-fills */
@@ -1001,6 +1186,23 @@ static void SUF(pc_solve)(SUF(orc_pc) * P, const T* rhs, T* x)
         else
             SUF(orc_pointwise_mult)(n, x, P->inv_diag);
     }
+    else if(P->it_on && P->kind == ORC_PC_ILU0)
+        SUF(orc_csr_itlusolve)(P->it_max_iter, P->it_tol, P->it_use_tol, n, P->nnz, P->row_offset, P->col,
+                               P->lu_val, rhs, P->it_tmp, x, P->it_work);
+    else if(P->it_on && P->kind == ORC_PC_IC)
+        SUF(orc_csr_itllsolve)(P->it_max_iter, P->it_tol, P->it_use_tol, n, P->nnz, P->ic_row_offset, P->ic_col,
+                               P->lu_val, rhs, P->it_tmp, x, P->it_work);
+    else if(P->it_on && P->kind == ORC_PC_GS)
+        SUF(orc_csr_itlsolve)(P->it_max_iter, P->it_tol, P->it_use_tol, n, P->nnz, P->row_offset, P->col, P->lu_val,
+                              0, rhs, x, P->it_work);
+    else if(P->it_on && P->kind == ORC_PC_SGS)
+    {
+        SUF(orc_csr_itlsolve)(P->it_max_iter, P->it_tol, P->it_use_tol, n, P->nnz, P->row_offset, P->col, P->lu_val,
+                              0, rhs, P->xtmp, P->it_work);
+        SUF(orc_pointwise_mult)(n, P->xtmp, P->inv_diag);
+        SUF(orc_csr_itusolve)(P->it_max_iter, P->it_tol, P->it_use_tol, n, P->nnz, P->row_offset, P->col, P->lu_val,
+                              0, P->xtmp, x, P->it_work);
+    }
     else if(P->kind == ORC_PC_ILU0)
     {
         SUF(orc_csr_lusolve)(n, P->nnz, P->row_offset, P->col, P->lu_val, rhs, x);
@@ -1082,6 +1284,24 @@ int SUF(orc_precond_apply)(int kind, int nrow, int64_t nnz, const int* row_offse
     }
     SUF(pc_build)(&P, kind, nrow, nnz, row_offset, col, val);
     SUF(pc_solve)(&P, rhs, x);
+    SUF(pc_free)(&P);
+    return 1;
+}
+
+/* the same preconditioner applied `reps` times to rhs, x carried over (x is in/out): the iterative triangular
+ * solves start from x's content and keep their intermediate vector between applies */
+int SUF(orc_precond_apply_rep)(int kind, int nrow, int64_t nnz, const int* row_offset, const int* col,
+                               const T* val, const T* rhs, T* x, int reps)
+{
+    SUF(orc_pc) P;
+    if(kind == ORC_PC_NONE)
+    {
+        memcpy(x, rhs, sizeof(T) * (size_t)nrow);
+        return 1;
+    }
+    SUF(pc_build)(&P, kind, nrow, nnz, row_offset, col, val);
+    for(int r = 0; r < reps; ++r)
+        SUF(pc_solve)(&P, rhs, x);
     SUF(pc_free)(&P);
     return 1;
 }

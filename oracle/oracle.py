@@ -63,6 +63,14 @@ def set_threads(n):
     lib().orc_set_threads(int(n))
 
 
+def set_solver_descr(iterative=False, max_iter=30, tol=1e-3, use_tol=True):
+    """SolverDescr for the preconditioners built afterwards (TriSolverAlg_Iterative; solver.hpp:82-148)"""
+    f = lib().orc_set_solver_descr
+    f.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int]
+    f.restype = None
+    f(int(bool(iterative)), int(max_iter), float(tol), int(bool(use_tol)))
+
+
 def max_threads():
     return lib().orc_max_threads()
 
@@ -336,6 +344,16 @@ def precond_apply(kind, rp, ci, va, rhs):
     x = np.zeros(len(rp) - 1, dtype=va.dtype)
     f(C.c_int(kind), C.c_int(len(rp) - 1), C.c_int64(len(va)), _p(rp), _p(ci), _p(va),
       _p(np.ascontiguousarray(rhs, dtype=va.dtype)), _p(x))
+    return x
+
+
+def precond_apply_rep(kind, rp, ci, va, rhs, reps, x0=None):
+    """`reps` applies of one built preconditioner, x carried over (starts from x0 or zeros)"""
+    rp, ci = _i32(rp), _i32(ci)
+    f, _ = _fn("orc_precond_apply_rep", va.dtype)
+    x = np.zeros(len(rp) - 1, dtype=va.dtype) if x0 is None else np.array(x0, dtype=va.dtype)
+    f(C.c_int(kind), C.c_int(len(rp) - 1), C.c_int64(len(va)), _p(rp), _p(ci), _p(va),
+      _p(np.ascontiguousarray(rhs, dtype=va.dtype)), _p(x), C.c_int(reps))
     return x
 
 

@@ -323,6 +323,69 @@ static int cmd_gen(const std::string& in, const std::string& out)
         dump_vec("pc_sgs", y);
         p.Clear();
     }
+    // --- TriSolverAlg_Iterative: Jacobi-sweep triangular solves; applied twice (the second apply starts from
+    //     the first one's output and intermediate vector)
+    {
+        SolverDescr d;
+        d.SetTriSolverAlg(TriSolverAlg_Iterative); // defaults: 30 sweeps, tolerance 1e-3 on
+        ILU<MatD, VecD, double> p;
+        p.SetSolverDescriptor(d);
+        p.SetOperator(mat);
+        p.Build();
+        y.Zeros();
+        p.Solve(x, &y);
+        dump_vec("pc_itilu0", y);
+        p.Solve(x, &y);
+        dump_vec("pc_itilu0_2", y);
+        p.Clear();
+    }
+    {
+        SolverDescr d;
+        d.SetTriSolverAlg(TriSolverAlg_Iterative);
+        d.SetIterativeSolverMaxIteration(12);
+        d.SetIterativeSolverTolerance(1e-2);
+        SGS<MatD, VecD, double> p;
+        p.SetSolverDescriptor(d);
+        p.SetOperator(mat);
+        p.Build();
+        y.Zeros();
+        p.Solve(x, &y);
+        dump_vec("pc_itsgs", y);
+        p.Solve(x, &y);
+        dump_vec("pc_itsgs_2", y);
+        p.Clear();
+    }
+    {
+        SolverDescr d;
+        d.SetTriSolverAlg(TriSolverAlg_Iterative);
+        d.SetIterativeSolverMaxIteration(5);
+        d.DisableIterativeSolverTolerance();
+        GS<MatD, VecD, double> p;
+        p.SetSolverDescriptor(d);
+        p.SetOperator(mat);
+        p.Build();
+        y.Zeros();
+        p.Solve(x, &y);
+        dump_vec("pc_itgs", y);
+        p.Clear();
+    }
+    if(symmetric_spd)
+    {
+        SolverDescr d;
+        d.SetTriSolverAlg(TriSolverAlg_Iterative);
+        d.SetIterativeSolverMaxIteration(8);
+        d.DisableIterativeSolverTolerance();
+        IC<MatD, VecD, double> p;
+        p.SetSolverDescriptor(d);
+        p.SetOperator(mat);
+        p.Build();
+        y.Zeros();
+        p.Solve(x, &y);
+        dump_vec("pc_itic", y);
+        p.Solve(x, &y);
+        dump_vec("pc_itic_2", y);
+        p.Clear();
+    }
     {
         MultiColoredILU<MatD, VecD, double> p; // default ILU(0,1)
         p.SetOperator(mat);
@@ -604,6 +667,39 @@ static int cmd_gen(const std::string& in, const std::string& out)
             ls.Build();
             sol.Zeros();
             run_solver("cg_ic", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            SolverDescr d;
+            d.SetTriSolverAlg(TriSolverAlg_Iterative);
+            d.SetIterativeSolverMaxIteration(20);
+            d.SetIterativeSolverTolerance(1e-6);
+            GMRES<MatD, VecD, double> ls;
+            ILU<MatD, VecD, double>   p;
+            p.SetSolverDescriptor(d);
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(p);
+            ls.SetBasisSize(basis);
+            ls.InitMaxIter(300); // the sweeps need not converge on every case (gr_30_30 stagnates)
+            ls.Build();
+            sol.Zeros();
+            run_solver("gmres_itilu0", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            SolverDescr d;
+            d.SetTriSolverAlg(TriSolverAlg_Iterative);
+            d.SetIterativeSolverMaxIteration(10);
+            d.DisableIterativeSolverTolerance();
+            CG<MatD, VecD, double> ls;
+            IC<MatD, VecD, double> p;
+            p.SetSolverDescriptor(d);
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(p);
+            ls.InitMaxIter(300);
+            ls.Build();
+            sol.Zeros();
+            run_solver("cg_itic", ls, rhs, sol);
             ls.Clear();
         }
         {

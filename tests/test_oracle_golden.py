@@ -145,6 +145,29 @@ def test_preconditioner_apply(oracle, name):
         eq(oracle.precond_apply(oracle.PC_IC, rp, ci, va, x), g["pc_ic"])
 
 
+IT_DESCR = {  # tag: (precond, SolverDescr(max_iter, tol, use_tol)) -- as set in oracle/ref_probe
+    "pc_itilu0": ("PC_ILU0", (30, 1e-3, True)), "pc_itsgs": ("PC_SGS", (12, 1e-2, True)),
+    "pc_itgs": ("PC_GS", (5, 1e-3, False)), "pc_itic": ("PC_IC", (8, 1e-3, False)),
+}
+
+
+@pytest.mark.parametrize("name", KERNEL_CASES)
+def test_iterative_triangular_solves(oracle, name):
+    """TriSolverAlg_Iterative (host_sparse.cpp csritsv): first apply from zero, second apply warm-started"""
+    g = load_golden(name)
+    rp, ci, va, x, y = _inputs(name, g)
+    try:
+        for key, (pc, (mi, tol, ut)) in IT_DESCR.items():
+            if key not in g:
+                continue
+            oracle.set_solver_descr(True, mi, tol, ut)
+            eq(oracle.precond_apply_rep(getattr(oracle, pc), rp, ci, va, x, 1), g[key])
+            if key + "_2" in g:
+                eq(oracle.precond_apply_rep(getattr(oracle, pc), rp, ci, va, x, 2), g[key + "_2"])
+    finally:
+        oracle.set_solver_descr(False)
+
+
 SOLVER_TABLE = {
     # tag: (solver, precond, format, kwargs)
     "cg_none": ("CG", "PC_NONE", "CSR", {}),
@@ -174,6 +197,8 @@ SOLVER_TABLE = {
     "cg_sgs": ("CG", "PC_SGS", "CSR", {}),
     "bicgstab_gs": ("BICGSTAB", "PC_GS", "CSR", {}),
     "cg_ic": ("CG", "PC_IC", "CSR", {}),
+    "gmres_itilu0": ("GMRES", "PC_ILU0", "CSR", dict(descr=(20, 1e-6, True), max_iter=300)),
+    "cg_itic": ("CG", "PC_IC", "CSR", dict(descr=(10, 1e-3, False), max_iter=300)),
     "fixedpoint_jacobi": ("FIXEDPOINT", "PC_JACOBI", "CSR", dict(p0=0.8, max_iter=40)),
     "fixedpoint_smoother_mcsgs": ("FIXEDPOINT", "PC_MCSGS", "CSR", dict(p0=1.0, p1=1.0, max_iter=3)),
     "chebyshev_none": ("CHEBYSHEV", "PC_NONE", "CSR", dict(p0=0.05, p1=16.0, max_iter=60)),
@@ -192,8 +217,14 @@ def test_solver_history_bit_exact(oracle, name, tag):
     x0 = x if tag.endswith("_x0") else None
     kw = dict(kw)
     basis = kw.pop("basis", int(g["basis"][0]))
-    r = oracle.solve(rp, ci, va, rhs, x0=x0, solver=getattr(oracle, s), precond=getattr(oracle, p),
-                     fmt=getattr(oracle, f), basis=basis, **kw)
+    descr = kw.pop("descr", None)
+    if descr:
+        oracle.set_solver_descr(True, *descr)
+    try:
+        r = oracle.solve(rp, ci, va, rhs, x0=x0, solver=getattr(oracle, s), precond=getattr(oracle, p),
+                         fmt=getattr(oracle, f), basis=basis, **kw)
+    finally:
+        oracle.set_solver_descr(False)
     meta = g[tag + "_meta"]
     assert r["iters"] == int(meta[0])
     assert r["status"] == int(meta[1])

@@ -15,3 +15,5 @@ run bicgstab_mcgs_512 --grid 512 --solver bicgstab --precond mcgs --steps 60
 run c5_mixed_512 --grid 512 --solver mixed --steps 10 --warmup 2
 run cg_jacobi_512_ell --grid 512 --format ell
 run cg_jacobi_512_hyb --grid 512 --format hyb
+run cg_ic_256 --grid 256 --precond ic --steps 60
+run cg_ic_512 --grid 512 --precond ic --steps 60
