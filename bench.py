@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--solver", default="cg", choices=["cg", "gmres", "bicgstab", "mixed"],
                     help="headline = cg; the others run the remaining BASELINE.json configs through the same harness")
     ap.add_argument("--precond", default="jacobi", choices=["none", "jacobi", "ilu0", "mcsgs", "mcgs", "mcilu", "ic", "sgs"])
+    ap.add_argument("--itsolve", type=int, default=0,
+                    help="ILU / IC / SGS: iterative triangular solves (TriSolverAlg_Iterative) with this many sweeps")
     ap.add_argument("--force-global", action="store_true",
                     help="1 process: still go through the GlobalMatrix/RCCL code path (communicator of size 1, "
                          "collectives not skipped) - a check of the N>1 plumbing on a 1-GPU box")
@@ -187,7 +189,12 @@ def main():
             ls = solver_cls()
             ls.SetOperator(A)
             if pc_cls is not None:
-                ls.SetPreconditioner(pc_cls())
+                pc = pc_cls()
+                if args.itsolve > 0 and pc_cls in (S.ILU, S.IC, S.SGS):  # TriSolverAlg_Iterative, fixed sweep count
+                    d = S.SolverDescr(); d.SetTriSolverAlg(S.TriSolverAlg_Iterative)
+                    d.SetIterativeSolverMaxIteration(args.itsolve); d.DisableIterativeSolverTolerance()
+                    pc.SetSolverDescriptor(d)
+                ls.SetPreconditioner(pc)
             if basis:
                 ls.SetBasisSize(basis)
             ls.Init(NEVER[0], NEVER[1], NEVER[2], iters)

@@ -1126,6 +1126,77 @@ public:
         this->need_accel_("LUSolve");
         RAMD_CHECK(ramd_mat_lu_solve(this->dev_, in.handle(), out->handle()));
     }
+    // TriSolverAlg_Iterative: Jacobi-sweep triangular solves (local_matrix.cpp ItLU* / ItLL* / ItL* / ItU*)
+    void ItLUAnalyse(void)
+    {
+        this->need_accel_("ItLUAnalyse");
+        RAMD_CHECK(ramd_mat_it_lu_analyse(this->dev_));
+    }
+    void ItLUAnalyseClear(void)
+    {
+        if(this->on_accel_ && this->dev_)
+            RAMD_CHECK(ramd_mat_it_lu_analyse_clear(this->dev_));
+    }
+    void ItLUSolve(int max_iter, double tolerance, bool use_tol, const LocalVector<ValueType>& in,
+                   LocalVector<ValueType>* out) const
+    {
+        this->need_accel_("ItLUSolve");
+        RAMD_CHECK(ramd_mat_it_lu_solve(this->dev_, max_iter, tolerance, use_tol ? 1 : 0, in.handle(), out->handle()));
+    }
+    void ItLLAnalyse(void)
+    {
+        this->need_accel_("ItLLAnalyse");
+        RAMD_CHECK(ramd_mat_it_ll_analyse(this->dev_));
+    }
+    void ItLLAnalyseClear(void)
+    {
+        if(this->on_accel_ && this->dev_)
+            RAMD_CHECK(ramd_mat_it_ll_analyse_clear(this->dev_));
+    }
+    void ItLLSolve(int max_iter, double tolerance, bool use_tol, const LocalVector<ValueType>& in,
+                   LocalVector<ValueType>* out) const
+    {
+        this->need_accel_("ItLLSolve");
+        RAMD_CHECK(ramd_mat_it_ll_solve(this->dev_, max_iter, tolerance, use_tol ? 1 : 0, in.handle(), out->handle()));
+    }
+    void ItLLSolve(int max_iter, double tolerance, bool use_tol, const LocalVector<ValueType>& in,
+                   const LocalVector<ValueType>& inv_diag, LocalVector<ValueType>* out) const
+    {
+        (void)inv_diag; // host_matrix_csr.cpp:1835-1843: forwarded, the sweeps invert the stored diagonal themselves
+        this->ItLLSolve(max_iter, tolerance, use_tol, in, out);
+    }
+    void ItLAnalyse(bool diag_unit = false)
+    {
+        this->need_accel_("ItLAnalyse");
+        RAMD_CHECK(ramd_mat_it_l_analyse(this->dev_, diag_unit ? 1 : 0));
+    }
+    void ItLAnalyseClear(void)
+    {
+        if(this->on_accel_ && this->dev_)
+            RAMD_CHECK(ramd_mat_it_l_analyse_clear(this->dev_));
+    }
+    void ItLSolve(int max_iter, double tolerance, bool use_tol, const LocalVector<ValueType>& in,
+                  LocalVector<ValueType>* out) const
+    {
+        this->need_accel_("ItLSolve");
+        RAMD_CHECK(ramd_mat_it_l_solve(this->dev_, max_iter, tolerance, use_tol ? 1 : 0, in.handle(), out->handle()));
+    }
+    void ItUAnalyse(bool diag_unit = false)
+    {
+        this->need_accel_("ItUAnalyse");
+        RAMD_CHECK(ramd_mat_it_u_analyse(this->dev_, diag_unit ? 1 : 0));
+    }
+    void ItUAnalyseClear(void)
+    {
+        if(this->on_accel_ && this->dev_)
+            RAMD_CHECK(ramd_mat_it_u_analyse_clear(this->dev_));
+    }
+    void ItUSolve(int max_iter, double tolerance, bool use_tol, const LocalVector<ValueType>& in,
+                  LocalVector<ValueType>* out) const
+    {
+        this->need_accel_("ItUSolve");
+        RAMD_CHECK(ramd_mat_it_u_solve(this->dev_, max_iter, tolerance, use_tol ? 1 : 0, in.handle(), out->handle()));
+    }
     // incomplete Cholesky on the lower part incl. diagonal (local_matrix.cpp ICFactorize / LLAnalyse / LLSolve)
     void ICFactorize(LocalVector<ValueType>* inv_diag)
     {

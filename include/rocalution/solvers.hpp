@@ -267,6 +267,100 @@ private:
     int                 minimum_iter_, maximum_iter_;
 };
 
+// ============================================================================ SolverDescr
+// solver.hpp:33-148: which triangular-solve algorithm the preconditioners use, and the iterative one's limits
+#define DISPATCH_OPERATOR_SOLVE_STRATEGY(descr_, op_, func_, ...)                                             \
+    switch(descr_.GetTriSolverAlg())                                                                          \
+    {                                                                                                         \
+    case TriSolverAlg_Default:                                                                                \
+        op_.func_(__VA_ARGS__);                                                                               \
+        break;                                                                                                \
+    case TriSolverAlg_Iterative:                                                                              \
+        op_.It##func_(descr_.GetIterativeSolverMaxIteration(), descr_.GetIterativeSolverTolerance(),          \
+                      descr_.GetIterativeSolverUseTolerance(), __VA_ARGS__);                                  \
+        break;                                                                                                \
+    }
+#define DISPATCH_OPERATOR_ANALYSE_STRATEGY(descr_, op_, func_, ...) \
+    switch(descr_.GetTriSolverAlg())                                \
+    {                                                               \
+    case TriSolverAlg_Default:                                      \
+        op_.func_(__VA_ARGS__);                                     \
+        break;                                                      \
+    case TriSolverAlg_Iterative:                                    \
+        op_.It##func_(__VA_ARGS__);                                 \
+        break;                                                      \
+    }
+
+typedef enum _tri_solver_alg : unsigned int
+{
+    TriSolverAlg_Default   = 0, // level-scheduled direct solve
+    TriSolverAlg_Iterative = 1 // Jacobi sweeps
+} TriSolverAlg;
+
+class SolverDescr
+{
+public:
+    SolverDescr()
+        : tri_solver_alg_(TriSolverAlg_Default)
+        , itsolver_max_iter_(30)
+        , itsolver_tol_(1e-3)
+        , itsolver_use_tol_(true)
+    {
+    }
+    virtual ~SolverDescr() {}
+    void SetTriSolverAlg(TriSolverAlg alg)
+    {
+        this->tri_solver_alg_ = alg;
+    }
+    TriSolverAlg GetTriSolverAlg(void) const
+    {
+        return this->tri_solver_alg_;
+    }
+    void SetIterativeSolverMaxIteration(int max_iter)
+    {
+        this->itsolver_max_iter_ = max_iter;
+    }
+    int GetIterativeSolverMaxIteration(void) const
+    {
+        return this->itsolver_max_iter_;
+    }
+    void SetIterativeSolverTolerance(double tol)
+    {
+        this->itsolver_tol_ = tol;
+    }
+    double GetIterativeSolverTolerance(void) const
+    {
+        return this->itsolver_tol_;
+    }
+    void EnableIterativeSolverTolerance(void)
+    {
+        this->itsolver_use_tol_ = true;
+    }
+    void DisableIterativeSolverTolerance(void)
+    {
+        this->itsolver_use_tol_ = false;
+    }
+    bool GetIterativeSolverUseTolerance(void) const
+    {
+        return this->itsolver_use_tol_;
+    }
+    void Print(void) const
+    {
+        if(this->tri_solver_alg_ != TriSolverAlg_Iterative)
+            return; // nothing is printed in the default direct case (solver.cpp:96-115)
+        if(this->itsolver_use_tol_)
+            LOG_INFO("TriSolverAlg = iterative (" << this->itsolver_max_iter_ << ", " << this->itsolver_tol_ << ")");
+        else
+            LOG_INFO("TriSolverAlg = iterative (" << this->itsolver_max_iter_ << ")");
+    }
+
+protected:
+    TriSolverAlg tri_solver_alg_;
+    int          itsolver_max_iter_;
+    double       itsolver_tol_;
+    bool         itsolver_use_tol_;
+};
+
 // ============================================================================ Solver
 template <class OperatorType, class VectorType, typename ValueType>
 class Solver
@@ -334,8 +428,15 @@ public:
     {
         this->is_smoother_ = true;
     }
+    // solver.cpp:293-301: the strategy cannot change once the solver is built
+    virtual void SetSolverDescriptor(const SolverDescr& descr)
+    {
+        assert(this->build_ == false);
+        this->solver_descr_ = descr;
+    }
 
 protected:
+    SolverDescr                                  solver_descr_;
     const OperatorType*                          op_;
     Solver<OperatorType, VectorType, ValueType>* precond_;
     bool                                         build_;
@@ -438,18 +539,18 @@ public:
         assert(this->op_ != NULL);
         this->ILU_.CloneFrom(*this->op_);
         this->ILU_.ILUpFactorize(this->p_, this->level_);
-        this->ILU_.LUAnalyse();
+        DISPATCH_OPERATOR_ANALYSE_STRATEGY(this->solver_descr_, this->ILU_, LUAnalyse);
     }
     virtual void Clear(void)
     {
-        this->ILU_.LUAnalyseClear();
+        DISPATCH_OPERATOR_ANALYSE_STRATEGY(this->solver_descr_, this->ILU_, LUAnalyseClear);
         this->ILU_.Clear();
         this->build_ = false;
     }
     virtual void Solve(const VectorType& rhs, VectorType* x)
     {
         assert(this->build_ == true && x != NULL && x != &rhs);
-        this->ILU_.LUSolve(rhs, x);
+        DISPATCH_OPERATOR_SOLVE_STRATEGY(this->solver_descr_, this->ILU_, LUSolve, rhs, x);
     }
     const OperatorType& GetFactors(void) const
     {
@@ -488,11 +589,11 @@ public:
         this->inv_diag_entries_.CloneBackend(*this->op_);
         this->op_->ExtractL(&this->IC_, true);
         this->IC_.ICFactorize(&this->inv_diag_entries_);
-        this->IC_.LLAnalyse();
+        DISPATCH_OPERATOR_ANALYSE_STRATEGY(this->solver_descr_, this->IC_, LLAnalyse);
     }
     virtual void Clear(void)
     {
-        this->IC_.LLAnalyseClear();
+        DISPATCH_OPERATOR_ANALYSE_STRATEGY(this->solver_descr_, this->IC_, LLAnalyseClear);
         this->inv_diag_entries_.Clear();
         this->IC_.Clear();
         this->build_ = false;
@@ -500,7 +601,7 @@ public:
     virtual void Solve(const VectorType& rhs, VectorType* x)
     {
         assert(this->build_ == true && x != NULL && x != &rhs);
-        this->IC_.LLSolve(rhs, this->inv_diag_entries_, x);
+        DISPATCH_OPERATOR_SOLVE_STRATEGY(this->solver_descr_, this->IC_, LLSolve, rhs, this->inv_diag_entries_, x);
     }
     const OperatorType& GetFactor(void) const
     {
@@ -538,18 +639,18 @@ public:
         this->build_ = true;
         assert(this->op_ != NULL);
         this->GS_.CloneFrom(*this->op_);
-        this->GS_.LAnalyse(false);
+        DISPATCH_OPERATOR_ANALYSE_STRATEGY(this->solver_descr_, this->GS_, LAnalyse, false);
     }
     virtual void Clear(void)
     {
-        this->GS_.LAnalyseClear();
+        DISPATCH_OPERATOR_ANALYSE_STRATEGY(this->solver_descr_, this->GS_, LAnalyseClear);
         this->GS_.Clear();
         this->build_ = false;
     }
     virtual void Solve(const VectorType& rhs, VectorType* x)
     {
         assert(this->build_ == true && x != NULL);
-        this->GS_.LSolve(rhs, x);
+        DISPATCH_OPERATOR_SOLVE_STRATEGY(this->solver_descr_, this->GS_, LSolve, rhs, x);
     }
 
 private:
@@ -576,8 +677,8 @@ public:
         this->build_ = true;
         assert(this->op_ != NULL);
         this->SGS_.CloneFrom(*this->op_);
-        this->SGS_.LAnalyse(false);
-        this->SGS_.UAnalyse(false);
+        DISPATCH_OPERATOR_ANALYSE_STRATEGY(this->solver_descr_, this->SGS_, LAnalyse, false);
+        DISPATCH_OPERATOR_ANALYSE_STRATEGY(this->solver_descr_, this->SGS_, UAnalyse, false);
         this->diag_entries_.CloneBackend(*this->op_);
         this->diag_entries_.Allocate("diag", this->op_->GetM());
         this->SGS_.ExtractInverseDiagonal(&this->diag_entries_);
@@ -586,8 +687,8 @@ public:
     }
     virtual void Clear(void)
     {
-        this->SGS_.LAnalyseClear();
-        this->SGS_.UAnalyseClear();
+        DISPATCH_OPERATOR_ANALYSE_STRATEGY(this->solver_descr_, this->SGS_, LAnalyseClear);
+        DISPATCH_OPERATOR_ANALYSE_STRATEGY(this->solver_descr_, this->SGS_, UAnalyseClear);
         this->SGS_.Clear();
         this->diag_entries_.Clear();
         this->v_.Clear();
@@ -596,9 +697,9 @@ public:
     virtual void Solve(const VectorType& rhs, VectorType* x)
     {
         assert(this->build_ == true && x != NULL);
-        this->SGS_.LSolve(rhs, &this->v_);
+        DISPATCH_OPERATOR_SOLVE_STRATEGY(this->solver_descr_, this->SGS_, LSolve, rhs, &this->v_);
         this->v_.PointWiseMult(this->diag_entries_);
-        this->SGS_.USolve(this->v_, x);
+        DISPATCH_OPERATOR_SOLVE_STRATEGY(this->solver_descr_, this->SGS_, USolve, this->v_, x);
     }
 
 private:

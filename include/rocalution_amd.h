@@ -157,6 +157,23 @@ int ramd_mat_ic_factorize(ramd_mat_t m, ramd_vec_t inv_diag);
 int ramd_mat_ll_analyse(ramd_mat_t m);
 int ramd_mat_ll_analyse_clear(ramd_mat_t m);
 int ramd_mat_ll_solve(ramd_mat_t m, ramd_vec_t in, ramd_vec_t inv_diag, ramd_vec_t out);
+/* Iterative triangular solves, TriSolverAlg_Iterative (solver.hpp:33-64; host_matrix_csr.cpp:1469-2092 ItLU* / ItLL* /
+ * ItL* / ItU*; sweeps host_sparse.cpp:195-530): Jacobi sweeps started from the content of `out`, at most max_iter per
+ * triangle, stopped when the sweep's max-norm figure is <= tol (use_tol != 0); the sweep count a tolerance stop leaves
+ * behind caps the second triangle (one max_iter variable in the reference).  ItLU / ItLL keep their intermediate
+ * vector between solves (zero after the analysis). */
+int ramd_mat_it_lu_analyse(ramd_mat_t m);
+int ramd_mat_it_lu_analyse_clear(ramd_mat_t m);
+int ramd_mat_it_lu_solve(ramd_mat_t m, int max_iter, double tol, int use_tol, ramd_vec_t in, ramd_vec_t out);
+int ramd_mat_it_ll_analyse(ramd_mat_t m);
+int ramd_mat_it_ll_analyse_clear(ramd_mat_t m);
+int ramd_mat_it_ll_solve(ramd_mat_t m, int max_iter, double tol, int use_tol, ramd_vec_t in, ramd_vec_t out);
+int ramd_mat_it_l_analyse(ramd_mat_t m, int diag_unit);
+int ramd_mat_it_l_analyse_clear(ramd_mat_t m);
+int ramd_mat_it_l_solve(ramd_mat_t m, int max_iter, double tol, int use_tol, ramd_vec_t in, ramd_vec_t out);
+int ramd_mat_it_u_analyse(ramd_mat_t m, int diag_unit);
+int ramd_mat_it_u_analyse_clear(ramd_mat_t m);
+int ramd_mat_it_u_solve(ramd_mat_t m, int max_iter, double tol, int use_tol, ramd_vec_t in, ramd_vec_t out);
 int ramd_mat_lu_analyse(ramd_mat_t m); /* :344 */
 int ramd_mat_lu_analyse_clear(ramd_mat_t m); /* :346 */
 int ramd_mat_lu_solve(ramd_mat_t m, ramd_vec_t in, ramd_vec_t out); /* :349 */
@@ -324,6 +341,9 @@ int ramd_solver_set_basis(ramd_solver_t s, int size_basis); /* GMRES::SetBasisSi
 int ramd_solver_set_seed(ramd_solver_t s, unsigned long long seed); /* IDR::SetRandomSeed (idr.cpp:277-285) */
 /* FixedPoint: p0 = SetRelaxation(omega), p1 != 0 -> FlagSmoother();  Chebyshev: Set(lambda_min = p0, lambda_max = p1) */
 int ramd_solver_set_params(ramd_solver_t s, double p0, double p1);
+/* Solver::SetSolverDescriptor on the preconditioner (solver.cpp:293-301, SolverDescr solver.hpp:82-148): iterative != 0
+ * selects TriSolverAlg_Iterative with the given sweep limit / tolerance / tolerance switch; before build */
+int ramd_solver_set_tri_solver(ramd_solver_t s, int iterative, int max_iter, double tol, int use_tol);
 int ramd_solver_set_fused(ramd_solver_t s, int on); /* fused device loops on/off (default on) */
 int ramd_solver_set_verbose(ramd_solver_t s, int verb);
 int ramd_solver_set_precond_format(ramd_solver_t s, int format); /* MultiColored::SetPrecondMatrixFormat */

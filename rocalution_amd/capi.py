@@ -113,6 +113,18 @@ SIGNATURES = {
     "ramd_mat_ll_analyse": (i32, [mat_t]),
     "ramd_mat_ll_analyse_clear": (i32, [mat_t]),
     "ramd_mat_ll_solve": (i32, [mat_t, vec_t, vec_t, vec_t]),
+    "ramd_mat_it_lu_analyse": (i32, [mat_t]),
+    "ramd_mat_it_lu_analyse_clear": (i32, [mat_t]),
+    "ramd_mat_it_lu_solve": (i32, [mat_t, i32, f64, i32, vec_t, vec_t]),
+    "ramd_mat_it_ll_analyse": (i32, [mat_t]),
+    "ramd_mat_it_ll_analyse_clear": (i32, [mat_t]),
+    "ramd_mat_it_ll_solve": (i32, [mat_t, i32, f64, i32, vec_t, vec_t]),
+    "ramd_mat_it_l_analyse": (i32, [mat_t, i32]),
+    "ramd_mat_it_l_analyse_clear": (i32, [mat_t]),
+    "ramd_mat_it_l_solve": (i32, [mat_t, i32, f64, i32, vec_t, vec_t]),
+    "ramd_mat_it_u_analyse": (i32, [mat_t, i32]),
+    "ramd_mat_it_u_analyse_clear": (i32, [mat_t]),
+    "ramd_mat_it_u_solve": (i32, [mat_t, i32, f64, i32, vec_t, vec_t]),
     "ramd_mat_gershgorin": (i32, [mat_t, pf64, pf64]),
     "ramd_mat_extract_tri": (i32, [mat_t, mat_t, i32, i32]),
     "ramd_mat_scale_values": (i32, [mat_t, f64, i32]),
@@ -162,6 +174,7 @@ SIGNATURES = {
     "ramd_solver_set_basis": (i32, [ptr, i32]),
     "ramd_solver_rebuild_numeric": (i32, [ptr]),
     "ramd_solver_set_seed": (i32, [ptr, C.c_ulonglong]),
+    "ramd_solver_set_tri_solver": (i32, [ptr, i32, i32, f64, i32]),
     "ramd_solver_set_params": (i32, [ptr, f64, f64]),
     "ramd_solver_set_fused": (i32, [ptr, i32]),
     "ramd_solver_set_verbose": (i32, [ptr, i32]),

@@ -30,6 +30,7 @@ struct SolverBase
     virtual void set_fused_sweeps(bool) {}
     virtual void set_seed(unsigned long long) {}
     virtual void set_params(double, double) {}
+    virtual void set_tri_solver(int, int, double, int) {}
     virtual bool rebuild_numeric()
     {
         return false;
@@ -177,6 +178,19 @@ struct LocalSolver : SolverBase
         }
         else if(solver_kind == RAMD_SOLVER_CHEBYSHEV)
             cheb.Set((T)p0, (T)p1);
+    }
+    void set_tri_solver(int alg, int max_iter, double tol, int use_tol) override
+    {
+        SolverDescr d;
+        d.SetTriSolverAlg(alg ? TriSolverAlg_Iterative : TriSolverAlg_Default);
+        d.SetIterativeSolverMaxIteration(max_iter);
+        d.SetIterativeSolverTolerance(tol);
+        if(use_tol)
+            d.EnableIterativeSolverTolerance();
+        else
+            d.DisableIterativeSolverTolerance();
+        if(Solver<LocalMatrix<T>, LocalVector<T>, T>* p = pcs.get(pc_kind))
+            p->SetSolverDescriptor(d);
     }
     void set_fused(bool f) override
     {
@@ -501,6 +515,14 @@ int ramd_solver_set_params(ramd_solver_t s, double p0, double p1)
         return RAMD_ERR_ARG;
     GUARD_BEGIN
     s->impl->set_params(p0, p1);
+    GUARD_END
+}
+int ramd_solver_set_tri_solver(ramd_solver_t s, int iterative, int max_iter, double tol, int use_tol)
+{
+    if(!s || max_iter < 0)
+        return RAMD_ERR_ARG;
+    GUARD_BEGIN
+    s->impl->set_tri_solver(iterative, max_iter, tol, use_tol);
     GUARD_END
 }
 int ramd_solver_set_seed(ramd_solver_t s, unsigned long long seed)

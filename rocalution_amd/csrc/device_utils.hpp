@@ -158,6 +158,16 @@ __device__ __forceinline__ void spin_guard(int& spins)
         __builtin_trap();
 }
 
+// polling loops: sleep when no lane of the wave advanced, doubling up to 64 x 64 cycles; returns the next back-off
+__device__ __forceinline__ int poll_backoff(bool wave_advanced, int backoff)
+{
+    if(wave_advanced)
+        return 1;
+    for(int z = 0; z < backoff; ++z)
+        __builtin_amdgcn_s_sleep(1);
+    return backoff < 64 ? backoff * 2 : 64;
+}
+
 // workgroup ticket: the k-th workgroup to START works on block k (deadlock freedom does not depend
 // on the dispatch order).  `base` is the counter value before this launch.
 __device__ __forceinline__ unsigned take_ticket(unsigned* counter, unsigned base)

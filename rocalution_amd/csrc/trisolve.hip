@@ -374,9 +374,12 @@ __global__ __launch_bounds__(kBlock) void k_ilu0(int nrow, const int* __restrict
         ++dj;
     bool fin = false; // wave-uniform loop exit, see k_levels
     int  spins = 0;
+    int  backoff = 1;
     do
     {
         spin_guard(spins);
+        const int  j_before   = j;
+        const bool fin_before = fin;
         if(!fin)
         {
             if(j < dj)
@@ -426,6 +429,9 @@ __global__ __launch_bounds__(kBlock) void k_ilu0(int nrow, const int* __restrict
                 fin = true;
             }
         }
+        // nobody in the wave advanced: back off (exponentially) instead of flooding the fabric with polls -- without
+        // it a few thousand resident waves polling at full rate can slow the producers down by orders of magnitude
+        backoff = poll_backoff(__ballot(!fin_before && (fin || j != j_before)) != 0ull, backoff);
     } while(__ballot(!fin) != 0ull);
 }
 
@@ -476,7 +482,47 @@ struct TriState
     bool        haveLL      = false;
     int*        ll_rhs_idx  = nullptr; // [n]: L^T position -> L position of the same row
     const void* ll_diag_src = nullptr; // inverse-diagonal vector the plans' diag arrays were gathered from
+    // iterative (Jacobi-sweep) triangular solves, TriSolverAlg_Iterative: natural-order sliced-ELL triangles
+    struct ItSlot
+    {
+        TriPlan A, B; // LU: L, U    LL: L, L^T    L / U alone: A
+        int     kind      = 0; // 0 none, 1 LU, 2 LL, 3 L, 4 U
+        bool    unit      = false; // L / U alone: unit diagonal
+        bool    zero_diag = false; // a non-unit stage has a zero pivot: the reference leaves the output untouched
+    } it[3]; // [0] LU or LL, [1] L alone, [2] U alone (SGS analyses L and U of one matrix)
+    void*   it_tmp       = nullptr; // [n] persistent intermediate vector (tmp_vec_), zero at analysis
+    void*   it_buf       = nullptr; // [n] previous-iterate buffer of the sweeps
+    void*   it_ctl       = nullptr; // ItCtl
 };
+
+static int it_slot_of(int kind)
+{
+    return kind <= 2 ? 0 : kind - 2;
+}
+// idx < 0: everything
+static void it_release(TriState* st, int idx = -1)
+{
+    for(int i = 0; i < 3; ++i)
+        if(idx < 0 || idx == i)
+        {
+            st->it[i].A.release();
+            st->it[i].B.release();
+            st->it[i].kind = 0;
+        }
+    if(st->it[0].kind == 0 && st->it_tmp)
+    {
+        (void)cached_free(st->it_tmp);
+        st->it_tmp = nullptr;
+    }
+    if(st->it[0].kind == 0 && st->it[1].kind == 0 && st->it[2].kind == 0)
+    {
+        if(st->it_buf)
+            (void)cached_free(st->it_buf);
+        if(st->it_ctl)
+            (void)hipFree(st->it_ctl);
+        st->it_buf = st->it_ctl = nullptr;
+    }
+}
 
 static TriState* tri_state(ramd_mat_s* m)
 {
@@ -496,6 +542,7 @@ void tri_release(ramd_mat_s* m)
     st->LLf.release();
     st->LLb.release();
     dev_free(&st->ll_rhs_idx);
+    it_release(st);
     delete st;
     m->tri = nullptr;
 }
@@ -567,8 +614,16 @@ static int level_order(ramd_mat_s* m, TriState* st, bool lower, int** order_out,
     return RAMD_OK;
 }
 
+__global__ __launch_bounds__(kBlock) void k_natural_order(int n, int* __restrict__ v)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gsz)
+        v[t] = (int)t;
+}
+
+// natural = true: rows stay in matrix order (no level analysis) -- the packing of the iterative (Jacobi-sweep) solves
 template <typename T>
-static int build_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bool reverse = false)
+static int build_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bool reverse = false, bool natural = false)
 {
     Backend&  b = backend();
     const int n = m->nrow;
@@ -580,7 +635,13 @@ static int build_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bool 
     const unsigned nb   = nblocks_of(n);
     int            nlev = 0;
     int            s    = RAMD_OK;
-    if(lower && st->l_order_cache) // computed by ILU0Factorize on the same pattern
+    if(natural)
+    {
+        s = dev_alloc(&P->order, n);
+        if(s == RAMD_OK)
+            hipLaunchKernelGGL(k_natural_order, dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, P->order);
+    }
+    else if(lower && st->l_order_cache) // computed by ILU0Factorize on the same pattern
     {
         P->order          = st->l_order_cache;
         nlev              = st->l_nlev_cache;
@@ -771,9 +832,12 @@ __global__ __launch_bounds__(kBlock) void k_ic0(int nrow, const int* __restrict_
     T         sum = (T)0;
     bool      fin = false;
     int       spins = 0;
+    int       backoff = 1;
     do
     {
         spin_guard(spins);
+        const int  j_before   = j;
+        const bool fin_before = fin;
         if(!fin)
         {
             const int cj = (j < re) ? ci[j] : nrow;
@@ -831,6 +895,7 @@ __global__ __launch_bounds__(kBlock) void k_ic0(int nrow, const int* __restrict_
                 fin = true;
             }
         }
+        backoff = poll_backoff(__ballot(!fin_before && (fin || j != j_before)) != 0ull, backoff);
     } while(__ballot(!fin) != 0ull);
 }
 
@@ -876,24 +941,28 @@ static int ic0_t(ramd_mat_s* m, ramd_vec_s* inv_diag)
 }
 
 // ---------------------------------------------------------------- transpose (pattern + values) for L^T
+// lower_only: entries right of the diagonal are left out (L^T of a matrix that also stores an upper part)
 __global__ __launch_bounds__(kBlock) void k_tr_count(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
-                                                     int* __restrict__ cnt)
+                                                     int* __restrict__ cnt, int lower_only)
 {
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
     for(int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += gsz)
         for(int j = rp[r]; j < rp[r + 1]; ++j)
-            atomicAdd(cnt + ci[j], 1);
+            if(!lower_only || ci[j] <= r)
+                atomicAdd(cnt + ci[j], 1);
 }
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_tr_scatter(int nrow, const int* __restrict__ rp,
                                                        const int* __restrict__ ci, const T* __restrict__ val,
                                                        int* __restrict__ cursor, int* __restrict__ tci,
-                                                       T* __restrict__ tval)
+                                                       T* __restrict__ tval, int lower_only)
 {
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
     for(int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += gsz)
         for(int j = rp[r]; j < rp[r + 1]; ++j)
         {
+            if(lower_only && ci[j] > r)
+                continue;
             const int p = atomicAdd(cursor + ci[j], 1);
             tci[p]      = (int)r;
             tval[p]     = val[j];
@@ -922,19 +991,19 @@ __global__ __launch_bounds__(kBlock) void k_tr_sort_rows(int nrow, const int* __
 }
 
 template <typename T>
-static int transpose_into(const ramd_mat_s* m, ramd_mat_s* t)
+static int transpose_into(const ramd_mat_s* m, ramd_mat_s* t, bool lower_only = false)
 {
     Backend& b = backend();
-    RAMD_TRY(mat_alloc_csr(t, m->ncol, m->nrow, m->nnz));
+    RAMD_TRY(mat_alloc_csr(t, m->ncol, m->nrow, m->nnz)); // lower_only: an upper bound, the tail stays unused
     RAMD_HIP(hipMemsetAsync(t->rp, 0, sizeof(int) * ((size_t)t->nrow + 1), b.cur));
     const int grid = ew_grid(std::max(m->nrow, 1));
-    hipLaunchKernelGGL(k_tr_count, dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, m->rp, m->ci, t->rp);
+    hipLaunchKernelGGL(k_tr_count, dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, m->rp, m->ci, t->rp, lower_only ? 1 : 0);
     RAMD_TRY(device_exclusive_scan(t->rp, t->rp, (int64_t)t->nrow + 1));
     int* cursor = nullptr;
     RAMD_TRY(dev_alloc(&cursor, (int64_t)t->nrow + 1));
     hipError_t e = hipMemcpyAsync(cursor, t->rp, sizeof(int) * ((size_t)t->nrow + 1), hipMemcpyDeviceToDevice, b.cur);
     hipLaunchKernelGGL((k_tr_scatter<T>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, m->rp, m->ci, (const T*)m->val,
-                       cursor, t->ci, (T*)t->val);
+                       cursor, t->ci, (T*)t->val, lower_only ? 1 : 0);
     hipLaunchKernelGGL((k_tr_sort_rows<T>), dim3(ew_grid(std::max(t->nrow, 1))), dim3(kBlock), 0, b.cur, t->nrow, t->rp,
                        t->ci, (T*)t->val);
     if(e == hipSuccess)
@@ -944,6 +1013,12 @@ static int transpose_into(const ramd_mat_s* m, ramd_mat_s* t)
     dev_free(&cursor);
     RAMD_HIP(e);
     return RAMD_OK;
+}
+
+template <typename T>
+static int transpose_lower_into(const ramd_mat_s* m, ramd_mat_s* t)
+{
+    return transpose_into<T>(m, t, true);
 }
 
 template <typename T>
@@ -1009,6 +1084,335 @@ static int ll_solve_t(ramd_mat_s* m, const T* in, const T* inv_diag, T* out)
     // L y = b with y_i scaled by inv_diag_i, y kept in position order; then L^T x = y, scaled, natural order out
     RAMD_TRY(run_plan<T>(st, &st->LLf, false, in, st->LLf.order, nullptr, true));
     return run_plan<T>(st, &st->LLb, false, (const T*)st->LLf.w, st->ll_rhs_idx, out, true);
+}
+
+// ---------------------------------------------------------------- iterative triangular solves
+// TriSolverAlg_Iterative (solver.hpp:33-64): host_sparse.cpp:195-530 csritsv, Jacobi sweeps
+//     y <- y + D^-1 (x - (D + T) y)
+// on one triangle, started from the content of y, until `cap` sweeps are done or the sweep's max-norm figure is
+// <= tol.  Every sweep is one bandwidth-bound pass (lane per row over a natural-order sliced-ELL triangle); the
+// stopping test runs on the device (last workgroup of a sweep), so a solve is a fixed sequence of launches without
+// host round trips: sweeps after the stop return at once.
+struct ItCtl
+{
+    int                cap; // sweeps allowed ("max_iter", shared by both stages as in the reference)
+    int                sweeps; // sweeps done in the current stage
+    unsigned           blocks_done;
+    int                pad;
+    unsigned long long mx; // bits of the running max (as double, >= 0)
+};
+
+__global__ void k_it_begin(ItCtl* c, int cap, int first_stage)
+{
+    if(first_stage)
+        c->cap = cap;
+    c->sweeps      = 0;
+    c->blocks_done = 0u;
+    c->mx          = 0ull;
+}
+
+// MODE 0 unit diagonal                       y = x - sum                                  figure: max |y - y_p|
+// MODE 1 non-unit, diagonal LAST  (lower)    r = x - sum, y = y_p + r/d ... (see below)   figure: max |r|
+// MODE 2 non-unit, diagonal FIRST (upper)
+// MODE 3 transposed lower (its rows = columns of L, diagonal first): no single-entry branch, and the figure is
+//        max(max_{i<n-1} |h_i|, |r_{n-1}|) exactly as the reference computes it (host_sparse.cpp:487)
+template <typename T, int MODE>
+__global__ __launch_bounds__(kBlock) void k_itsv(int n, const int* __restrict__ slice_off,
+                                                 const int* __restrict__ ecol, const T* __restrict__ eval,
+                                                 const T* __restrict__ diag, const T* __restrict__ x,
+                                                 const T* __restrict__ yp, T* __restrict__ y, ItCtl* ctl, int sweep,
+                                                 int use_tol, double tol)
+{
+    if(sweep >= __hip_atomic_load(&ctl->cap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        return;
+    double fig = 0.0;
+    // a bounded grid walks the row chunks: one closing atomic pair per workgroup, not per 256 rows
+    for(int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < n; t += (int64_t)gridDim.x * kBlock)
+    {
+        const int64_t s    = t >> 6;
+        const int     lane = (int)(t & 63);
+        const int     b0   = slice_off[s];
+        const int     wd   = (slice_off[s + 1] - b0) >> 6;
+        const T       xi   = x[t];
+        const T       ypi  = yp[t];
+        T             sum  = (T)0;
+        T             idg  = (T)1;
+        bool          off  = false;
+        if(MODE != 0)
+        {
+            const T d = diag[t];
+            idg       = (T)1 / d;
+            if(MODE != 1)
+                sum += d * ypi;
+        }
+        constexpr int W = 4;
+        for(int k0 = 0; k0 < wd; k0 += W)
+        {
+            int c[W];
+            T   a[W];
+#pragma unroll
+            for(int e = 0; e < W; ++e)
+            {
+                const bool in = k0 + e < wd;
+                c[e]          = in ? nt_load(ecol + b0 + (k0 + e) * 64 + lane) : -1;
+                a[e]          = in ? nt_load(eval + b0 + (k0 + e) * 64 + lane) : (T)0;
+            }
+            T g[W];
+#pragma unroll
+            for(int e = 0; e < W; ++e)
+                g[e] = (c[e] >= 0) ? yp[c[e]] : (T)0;
+#pragma unroll
+            for(int e = 0; e < W; ++e)
+                if(c[e] >= 0)
+                {
+                    sum += a[e] * g[e];
+                    off = true;
+                }
+        }
+        T yi;
+        T f;
+        if(MODE == 0)
+        {
+            yi = xi - sum;
+            f  = yi - ypi;
+        }
+        else if(MODE == 3)
+        {
+            const T r = xi - sum;
+            const T h = idg * r;
+            yi        = h + ypi;
+            f         = (t < n - 1) ? h : r;
+        }
+        else
+        {
+            if(MODE == 1)
+                sum += diag[t] * ypi;
+            if(off)
+            {
+                const T r = xi - sum;
+                yi        = ypi + idg * r;
+                f         = r;
+            }
+            else
+            {
+                yi = idg * xi;
+                f  = xi - ypi / idg;
+            }
+        }
+        nt_store(yi, y + t);
+        f = f < (T)0 ? -f : f;
+        if(f == f) // std::max keeps the old value against a NaN
+            fig = fmax(fig, (double)f);
+    }
+    // workgroup max -> device max -> the last workgroup closes the sweep
+#pragma unroll
+    for(int o = 32; o > 0; o >>= 1)
+        fig = fmax(fig, __shfl_xor(fig, o, 64));
+    __shared__ double wmax[kBlock / 64];
+    if((threadIdx.x & 63) == 0)
+        wmax[threadIdx.x >> 6] = fig;
+    __syncthreads();
+    if(threadIdx.x == 0)
+    {
+#pragma unroll
+        for(int w = 1; w < kBlock / 64; ++w)
+            fig = fmax(fig, wmax[w]);
+        atomicMax(&ctl->mx, (unsigned long long)__double_as_longlong(fig));
+        __threadfence();
+        const unsigned done = atomicAdd(&ctl->blocks_done, 1u);
+        if(done == gridDim.x - 1)
+        {
+            const double mx = __longlong_as_double(
+                (long long)__hip_atomic_load(&ctl->mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if(use_tol && mx <= tol)
+                __hip_atomic_store(&ctl->cap, sweep + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ctl->sweeps      = sweep + 1;
+            ctl->blocks_done = 0u;
+            ctl->mx          = 0ull;
+        }
+    }
+}
+
+// an odd number of sweeps leaves the result in the scratch buffer
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_it_finish(int n, const ItCtl* ctl, const T* __restrict__ buf,
+                                                      T* __restrict__ y)
+{
+    if((ctl->sweeps & 1) == 0)
+        return;
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gsz)
+        y[t] = buf[t];
+}
+
+__global__ __launch_bounds__(kBlock) void k_any_zero(int n, const double* d64, const float* d32, int* flag)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gsz)
+        if(d64 ? (d64[t] == 0.0) : (d32[t] == 0.0f))
+            *flag = 1;
+}
+
+template <typename T>
+static int it_stage(TriState* st, TriPlan* P, int mode, int max_iter, double tol, bool use_tol, bool first, const T* x,
+                    T* y)
+{
+    Backend&  b   = backend();
+    const int n   = P->n;
+    ItCtl*    ctl = (ItCtl*)st->it_ctl;
+    T*        buf = (T*)st->it_buf;
+    hipLaunchKernelGGL(k_it_begin, dim3(1), dim3(1), 0, b.cur, ctl, max_iter, first ? 1 : 0);
+    const unsigned nb = std::min(nblocks_of(n), 256u * 16u);
+    // the tolerance is compared in the value type (numeric_traits_t<T>), the figure travels as double
+    const double tol_t = (double)(T)tol;
+    for(int k = 0; k < max_iter; ++k)
+    {
+        const T* src = (k & 1) ? buf : y;
+        T*       dst = (k & 1) ? y : buf;
+#define ITSV(M)                                                                                                  \
+    hipLaunchKernelGGL((k_itsv<T, M>), dim3(nb), dim3(kBlock), 0, b.cur, n, P->slice_off, P->ecol, (const T*)P->eval, \
+                       (const T*)P->diag, x, src, dst, ctl, k, use_tol ? 1 : 0, tol_t)
+        switch(mode)
+        {
+        case 0: ITSV(0); break;
+        case 1: ITSV(1); break;
+        case 2: ITSV(2); break;
+        default: ITSV(3); break;
+        }
+#undef ITSV
+    }
+    hipLaunchKernelGGL((k_it_finish<T>), dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, ctl, (const T*)buf, y);
+    RAMD_HIP(hipGetLastError());
+    return RAMD_OK;
+}
+
+template <typename T>
+static int it_zero_check(TriState::ItSlot* sl, TriPlan* P)
+{
+    Backend& b = backend();
+    if(P->nodiag)
+    {
+        sl->zero_diag = true;
+        return RAMD_OK;
+    }
+    int* flag = nullptr;
+    RAMD_TRY(dev_alloc(&flag, 1));
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), b.cur);
+    hipLaunchKernelGGL(k_any_zero, dim3(ew_grid(P->n)), dim3(kBlock), 0, b.cur, P->n,
+                       sizeof(T) == 8 ? (const double*)P->diag : nullptr, sizeof(T) == 4 ? (const float*)P->diag : nullptr,
+                       flag);
+    int h = 0;
+    if(e == hipSuccess)
+        e = hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+    if(e == hipSuccess)
+        e = hipStreamSynchronize(b.cur);
+    dev_free(&flag);
+    RAMD_HIP(e);
+    if(h)
+        sl->zero_diag = true;
+    return RAMD_OK;
+}
+
+// kind 1 LU (L unit, U non-unit) | 2 LL (L non-unit, L^T) | 3 L | 4 U     (host_matrix_csr.cpp:1469-1543, :1652-1726,
+// :1846-1894, :1970-2018: the reference only sizes a buffer and zero-fills tmp_vec_; the triangles are packed here)
+template <typename T>
+static int it_analyse_t(ramd_mat_s* m, int kind, bool unit)
+{
+    Backend&  b  = backend();
+    TriState* st = nullptr;
+    RAMD_TRY(tri_get(m, &st));
+    const int idx = it_slot_of(kind);
+    it_release(st, idx);
+    TriState::ItSlot* sl = &st->it[idx];
+    const int         n  = m->nrow;
+    sl->unit             = unit;
+    sl->zero_diag        = false;
+    if(n == 0 || m->nnz == 0)
+    {
+        sl->kind = kind;
+        return RAMD_OK;
+    }
+    int s = RAMD_OK;
+    if(kind == 1)
+    {
+        s = build_plan<T>(m, st, &sl->A, true, false, true);
+        if(s == RAMD_OK)
+            s = build_plan<T>(m, st, &sl->B, false, false, true);
+        if(s == RAMD_OK)
+            s = it_zero_check<T>(sl, &sl->B);
+    }
+    else if(kind == 2)
+    {
+        s = build_plan<T>(m, st, &sl->A, true, false, true);
+        if(s == RAMD_OK)
+            s = it_zero_check<T>(sl, &sl->A);
+        if(s == RAMD_OK)
+        {
+            // L^T from the lower triangle of m only (the reference's transposed sweep runs over [row begin, diagonal])
+            ramd_mat_s* lt = new ramd_mat_s;
+            lt->dtype      = m->dtype;
+            s              = transpose_lower_into<T>(m, lt);
+            if(s == RAMD_OK)
+            {
+                TriState* stt = nullptr;
+                s             = tri_get(lt, &stt);
+                if(s == RAMD_OK)
+                    s = build_plan<T>(lt, stt, &sl->B, false, false, true);
+            }
+            tri_release(lt);
+            mat_free_csr(lt);
+            delete lt;
+        }
+    }
+    else
+    {
+        s = build_plan<T>(m, st, &sl->A, kind == 3, false, true);
+        if(s == RAMD_OK && !unit)
+            s = it_zero_check<T>(sl, &sl->A);
+    }
+    if(s == RAMD_OK && !st->it_ctl && hipMalloc(&st->it_ctl, sizeof(ItCtl)) != hipSuccess)
+        s = RAMD_ERR_HIP;
+    if(s == RAMD_OK && !st->it_buf && cached_malloc(&st->it_buf, (size_t)n * sizeof(T) + kPad) != hipSuccess)
+        s = RAMD_ERR_HIP;
+    if(s == RAMD_OK && (kind == 1 || kind == 2))
+    {
+        if(cached_malloc(&st->it_tmp, (size_t)n * sizeof(T) + kPad) != hipSuccess)
+            s = RAMD_ERR_HIP;
+        else if(hipMemsetAsync(st->it_tmp, 0, (size_t)n * sizeof(T), b.cur) != hipSuccess)
+            s = RAMD_ERR_HIP;
+    }
+    if(s != RAMD_OK)
+    {
+        it_release(st, idx);
+        return s;
+    }
+    sl->kind = kind;
+    return RAMD_OK;
+}
+
+template <typename T>
+static int it_solve_t(ramd_mat_s* m, int kind, int max_iter, double tol, bool use_tol, const T* in, T* out)
+{
+    TriState*         st = tri_state(m);
+    TriState::ItSlot* sl = st ? &st->it[it_slot_of(kind)] : nullptr;
+    if(!sl || sl->kind != kind)
+        RAMD_FAIL(RAMD_ERR_STATE, "iterative triangular solve before its analysis");
+    if(m->nnz <= 0 || m->nrow == 0 || max_iter <= 0)
+        return RAMD_OK; // nnz == 0: the reference leaves out untouched (host_matrix_csr.cpp:1571)
+    if(sl->zero_diag)
+        return RAMD_OK; // zero pivot: csritsv returns without touching y (host_sparse.cpp:388-391, :425-429)
+    T* tmp = (T*)st->it_tmp;
+    switch(kind)
+    {
+    case 1:
+        RAMD_TRY(it_stage<T>(st, &sl->A, 0, max_iter, tol, use_tol, true, in, tmp));
+        return it_stage<T>(st, &sl->B, 2, max_iter, tol, use_tol, false, (const T*)tmp, out);
+    case 2:
+        RAMD_TRY(it_stage<T>(st, &sl->A, 1, max_iter, tol, use_tol, true, in, tmp));
+        return it_stage<T>(st, &sl->B, 3, max_iter, tol, use_tol, false, (const T*)tmp, out);
+    case 3: return it_stage<T>(st, &sl->A, sl->unit ? 0 : 1, max_iter, tol, use_tol, true, in, out);
+    default: return it_stage<T>(st, &sl->A, sl->unit ? 0 : 2, max_iter, tol, use_tol, true, in, out);
+    }
 }
 
 } // namespace ramd
@@ -1088,6 +1492,60 @@ int ramd_mat_ll_solve(ramd_mat_t m, ramd_vec_t in, ramd_vec_t inv_diag, ramd_vec
     if(m->dtype == RAMD_F64)
         return ll_solve_t<double>(m, (const double*)in->d, (const double*)inv_diag->d, (double*)out->d);
     return ll_solve_t<float>(m, (const float*)in->d, (const float*)inv_diag->d, (float*)out->d);
+}
+
+// ---- TriSolverAlg_Iterative entry points (one per backend virtual of the reference)
+static int it_analyse(ramd_mat_t m, int kind, int unit)
+{
+    if(!m)
+        RAMD_FAIL(RAMD_ERR_ARG, "null matrix handle");
+    if(m->format != RAMD_CSR)
+        return RAMD_ERR_UNSUPPORTED;
+    if(m->nrow != m->ncol)
+        RAMD_FAIL(RAMD_ERR_ARG, "iterative triangular analysis: square matrix expected");
+    return (m->dtype == RAMD_F64) ? it_analyse_t<double>(m, kind, unit != 0) : it_analyse_t<float>(m, kind, unit != 0);
+}
+static int it_clear(ramd_mat_t m, int kind)
+{
+    if(!m)
+        RAMD_FAIL(RAMD_ERR_ARG, "null matrix handle");
+    TriState* st = tri_state(m);
+    if(st && st->it[it_slot_of(kind)].kind == kind)
+        it_release(st, it_slot_of(kind));
+    return RAMD_OK;
+}
+static int it_solve(ramd_mat_t m, int kind, int max_iter, double tol, int use_tol, ramd_vec_t in, ramd_vec_t out)
+{
+    RAMD_TRY(check_tri(m, in, out));
+    if(in == out)
+        RAMD_FAIL(RAMD_ERR_ARG, "iterative triangular solve: in and out must differ");
+    if(m->dtype == RAMD_F64)
+        return it_solve_t<double>(m, kind, max_iter, tol, use_tol != 0, (const double*)in->d, (double*)out->d);
+    return it_solve_t<float>(m, kind, max_iter, tol, use_tol != 0, (const float*)in->d, (float*)out->d);
+}
+int ramd_mat_it_lu_analyse(ramd_mat_t m) { return it_analyse(m, 1, 0); }
+int ramd_mat_it_lu_analyse_clear(ramd_mat_t m) { return it_clear(m, 1); }
+int ramd_mat_it_lu_solve(ramd_mat_t m, int max_iter, double tol, int use_tol, ramd_vec_t in, ramd_vec_t out)
+{
+    return it_solve(m, 1, max_iter, tol, use_tol, in, out);
+}
+int ramd_mat_it_ll_analyse(ramd_mat_t m) { return it_analyse(m, 2, 0); }
+int ramd_mat_it_ll_analyse_clear(ramd_mat_t m) { return it_clear(m, 2); }
+int ramd_mat_it_ll_solve(ramd_mat_t m, int max_iter, double tol, int use_tol, ramd_vec_t in, ramd_vec_t out)
+{
+    return it_solve(m, 2, max_iter, tol, use_tol, in, out);
+}
+int ramd_mat_it_l_analyse(ramd_mat_t m, int diag_unit) { return it_analyse(m, 3, diag_unit); }
+int ramd_mat_it_l_analyse_clear(ramd_mat_t m) { return it_clear(m, 3); }
+int ramd_mat_it_l_solve(ramd_mat_t m, int max_iter, double tol, int use_tol, ramd_vec_t in, ramd_vec_t out)
+{
+    return it_solve(m, 3, max_iter, tol, use_tol, in, out);
+}
+int ramd_mat_it_u_analyse(ramd_mat_t m, int diag_unit) { return it_analyse(m, 4, diag_unit); }
+int ramd_mat_it_u_analyse_clear(ramd_mat_t m) { return it_clear(m, 4); }
+int ramd_mat_it_u_solve(ramd_mat_t m, int max_iter, double tol, int use_tol, ramd_vec_t in, ramd_vec_t out)
+{
+    return it_solve(m, 4, max_iter, tol, use_tol, in, out);
 }
 
 int ramd_mat_lu_analyse(ramd_mat_t m)

@@ -21,11 +21,40 @@ def _lib():
     return capi.load()
 
 
+TriSolverAlg_Default, TriSolverAlg_Iterative = 0, 1
+
+
+class SolverDescr:
+    """triangular-solve strategy of a preconditioner (solver.hpp:82-148): defaults direct, 30 sweeps, 1e-3, tol on"""
+
+    def __init__(self):
+        self.alg, self.max_iter, self.tol, self.use_tol = TriSolverAlg_Default, 30, 1e-3, True
+
+    def SetTriSolverAlg(self, alg):
+        self.alg = int(alg)
+
+    def SetIterativeSolverMaxIteration(self, n):
+        self.max_iter = int(n)
+
+    def SetIterativeSolverTolerance(self, tol):
+        self.tol = float(tol)
+
+    def EnableIterativeSolverTolerance(self):
+        self.use_tol = True
+
+    def DisableIterativeSolverTolerance(self):
+        self.use_tol = False
+
+
 class _Precond:
     kind = PC_NONE
 
     def __init__(self):
         self.precond_format = None
+        self.descr = None
+
+    def SetSolverDescriptor(self, descr):
+        self.descr = descr
 
     def SetPrecondMatrixFormat(self, fmt):
         self.precond_format = int(fmt)
@@ -149,6 +178,9 @@ class _IterativeLinearSolver:
             capi.check(_lib().ramd_solver_set_decomposition(self._h, 0))
         if self._precond is not None and getattr(self._precond, "fused_sweeps", True) is False:
             capi.check(_lib().ramd_solver_set_fused_sweeps(self._h, 0))
+        if self._precond is not None and getattr(self._precond, "descr", None) is not None:
+            d = self._precond.descr
+            capi.check(_lib().ramd_solver_set_tri_solver(self._h, d.alg, d.max_iter, d.tol, int(d.use_tol)))
         capi.check(_lib().ramd_solver_set_fused(self._h, int(self._fused)))
         capi.check(_lib().ramd_solver_set_verbose(self._h, self._verbose))
         self._configure_extra()
