@@ -64,10 +64,13 @@ __global__ __launch_bounds__(kBlock) void k_greedy_color(int nrow, const int* __
     int  mine  = 0;
     bool fin   = !live;
     int  spins = 0;
+    int  backoff = 1;
     // wave-uniform loop (SIMT rule of trisolve.hip): publish inside, leave together
     do
     {
         spin_guard(spins);
+        const int  j_before   = j;
+        const bool fin_before = fin;
         // (1) neighbours coloured by other waves: consume every one that is ready
         int want = lane; // (2) at most one neighbour inside my wave per turn, through a shuffle
         if(!fin)
@@ -113,6 +116,8 @@ __global__ __launch_bounds__(kBlock) void k_greedy_color(int nrow, const int* __
                 fin = true;
             }
         }
+        // nobody in the wave advanced: exponential back-off (device_utils.hpp) instead of polling at full rate
+        backoff = poll_backoff(__ballot(!fin_before && (fin || j != j_before)) != 0ull, backoff);
     } while(__ballot(!fin) != 0ull);
 }
 
