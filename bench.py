@@ -106,7 +106,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--grid", type=int, default=512, help="Poisson grid edge N (operator is N^3 x N^3)")
-    ap.add_argument("--format", default="csr", choices=["csr", "ell", "hyb"])
+    ap.add_argument("--format", default="csr", choices=["csr", "ell", "hyb", "dia"])
     ap.add_argument("--cpu-grid", type=int, default=256)
     ap.add_argument("--cpu-iters", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -169,7 +169,7 @@ def main():
 
     N = args.grid
     n, nnz = N ** 3, 7 * N ** 3 - 6 * N ** 2
-    fmt = {"csr": ra.CSR, "ell": ra.ELL, "hyb": ra.HYB}[args.format]
+    fmt = {"csr": ra.CSR, "ell": ra.ELL, "hyb": ra.HYB, "dia": ra.DIA}[args.format]
     K, W = args.steps, args.warmup
     NEVER = (0.0, 0.0, 1e300)  # abs / rel / div tolerances that cannot trigger: exactly max_iter steps
 
@@ -248,6 +248,8 @@ def main():
         mixed = args.solver == "mixed"
         vb = 4 if mixed else 8  # the launches of a mixed-precision run are (all but a handful) the fp32 inner SpMVs
         bytes_alg = spmv_bytes(n, nnz, vb) if args.format == "csr" else 4 * nnz_fmt + vb * (2 * n + nnz_fmt)
+        if args.format == "dia":  # values only (7 diagonals x n), x and y once
+            bytes_alg = vb * (2 * n + nnz_fmt)
         ach = bytes_alg / (avg.value * 1e-3) / 1e9 if avg.value > 0 else 0.0
         traffic = None  # HBM bytes per launch from the PMC counters: measured offline with rocprofv3
         tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")  # (separate --pmc passes), see that file
@@ -257,7 +259,8 @@ def main():
                  "in the average)" if mixed else "k_csr_tr<double,0,true> (CSR SpMV + fused <p,q>)")
         prof = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
                     frac=round(ach / HBM_PEAK_GBPS, 4), traffic=traffic, kernel=kname
-                    if args.format == "csr" else "k_ell<%s>" % ("float" if mixed else "double"), launches=cnt.value,
+                    if args.format == "csr" else "k_%s<%s>" % ("dia" if args.format == "dia" else "ell",
+                                                                "float" if mixed else "double"), launches=cnt.value,
                     avg_ms=round(avg.value, 5), min_ms=round(mn.value, 5), max_ms=round(mx.value, 5),
                     algorithmic_bytes=bytes_alg)
         extras = {}

@@ -844,6 +844,10 @@ public:
     {
         this->ConvertTo(HYB);
     }
+    void ConvertToDIA(void)
+    {
+        this->ConvertTo(DIA);
+    }
     void ConvertToCOO(void)
     {
         this->ConvertTo(COO);

@@ -8,7 +8,7 @@
 extern "C" {
 #endif
 
-enum { ORC_CSR = 1, ORC_ELL = 6, ORC_HYB = 7 }; /* numbering of src/base/matrix_formats.hpp */
+enum { ORC_CSR = 1, ORC_DIA = 5, ORC_ELL = 6, ORC_HYB = 7 }; /* numbering of src/base/matrix_formats.hpp */
 enum { ORC_CG = 0, ORC_GMRES = 1, ORC_BICGSTAB = 2, ORC_FCG = 3, ORC_CR = 4, ORC_FGMRES = 5, ORC_BICGSTABL = 6,
        ORC_QMRCGSTAB = 7, ORC_IDR = 8, ORC_FIXEDPOINT = 9, ORC_CHEBYSHEV = 10 };
 enum { ORC_PC_NONE = 0, ORC_PC_JACOBI = 1, ORC_PC_ILU0 = 2, ORC_PC_MCSGS = 3, ORC_PC_MCGS = 4, ORC_PC_MCILU = 5,
@@ -59,6 +59,10 @@ int     orc_csr_multicoloring(int nrow, int64_t nnz, const int* row_offset, cons
                           const T*, const T*, T*);                                                 \
     void orc_hyb_apply_add##S(int, int, int, const int*, const T*, int64_t, const int*,            \
                               const int*, const T*, const T*, T, T*);                              \
+    int  orc_csr_to_dia##S(int, int, int64_t, const int*, const int*, const T*, int*, T*);         \
+    void orc_dia_apply##S(int, int, const int*, const T*, const T*, T*);                           \
+    void orc_dia_apply_add##S(int, int, const int*, const T*, const T*, T, T*);                    \
+    int64_t orc_dia_to_csr##S(int, int, int, const int*, const T*, int*, int*, T*);                \
     int  orc_csr_to_ell_fill##S(int, int64_t, const int*, const int*, const T*, int, int*, T*);    \
     int  orc_csr_to_hyb_fill##S(int, const int*, const int*, const T*, int, int*, T*, int*, int*,  \
                                T*);                                                                \

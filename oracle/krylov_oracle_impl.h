@@ -597,6 +597,114 @@ void SUF(orc_csr_llsolve)(int nrow, const int* row_offset, const int* col, const
     }
 }
 
+/* ---- DIA ------------------------------------------------------------------------------------
+ * host_conversion.cpp:958-1038 csr_to_dia: one slot per populated diagonal (col - row), offsets ascending, values
+ * column-major d*nrow + row (matrix_formats_ind.hpp:43-45), absent entries zero; refused (-1) when the number of
+ * diagonals exceeds 5 * (nnz / min(nrow, ncol)).  offset / val may be NULL (count only). */
+int SUF(orc_csr_to_dia)(int nrow, int ncol, int64_t nnz, const int* row_offset, const int* col, const T* val,
+                        int* offset, T* dval)
+{
+    int* slot = (int*)calloc((size_t)nrow + ncol + 1, sizeof(int));
+    int  nd   = 0;
+    for(int i = 0; i < nrow; ++i)
+        for(int j = row_offset[i]; j < row_offset[i + 1]; ++j)
+        {
+            int o = col[j] - i + nrow;
+            if(!slot[o])
+            {
+                slot[o] = 1;
+                ++nd;
+            }
+        }
+    int size = nrow < ncol ? nrow : ncol;
+    if(size <= 0 || nd > 5 * (nnz / size))
+    {
+        free(slot);
+        return -1;
+    }
+    if(offset && dval)
+    {
+        for(int64_t k = 0; k < (int64_t)size * nd; ++k)
+            dval[k] = (T)0;
+        for(int i = 0, d = 0; i < nrow + ncol; ++i)
+            if(slot[i])
+            {
+                slot[i]     = d;
+                offset[d++] = i - nrow;
+            }
+        for(int i = 0; i < nrow; ++i)
+            for(int j = row_offset[i]; j < row_offset[i + 1]; ++j)
+                dval[(int64_t)slot[col[j] - i + nrow] * nrow + i] = val[j];
+    }
+    free(slot);
+    return nd;
+}
+
+/* host_matrix_dia.cpp:300-356 Apply / :359-412 ApplyAdd: diagonal j covers rows [max(0,-off), nrow - max(0,off));
+ * a row past the end of a diagonal leaves the loop (offsets ascend, so nothing is lost) */
+void SUF(orc_dia_apply)(int nrow, int ndiag, const int* offset, const T* dval, const T* in, T* out)
+{
+    for(int i = 0; i < nrow; ++i)
+    {
+        T sum = (T)0;
+        for(int j = 0; j < ndiag; ++j)
+        {
+            int off = offset[j], start = 0, end = nrow;
+            if(off < 0)
+                start = -off;
+            else
+                end = nrow - off;
+            if(i >= start && i < end)
+                sum += dval[(int64_t)j * nrow + i] * in[i + off];
+            else if(i >= end)
+                break;
+        }
+        out[i] = sum;
+    }
+}
+void SUF(orc_dia_apply_add)(int nrow, int ndiag, const int* offset, const T* dval, const T* in, T scalar, T* out)
+{
+    for(int i = 0; i < nrow; ++i)
+        for(int j = 0; j < ndiag; ++j)
+        {
+            int off = offset[j], start = 0, end = nrow;
+            if(off < 0)
+                start = -off;
+            else
+                end = nrow - off;
+            if(i >= start && i < end)
+                out[i] += scalar * dval[(int64_t)j * nrow + i] * in[i + off];
+            else if(i >= end)
+                break;
+        }
+}
+/* host_conversion.cpp:1040-1113 dia_to_csr: valid columns with a non-zero value, diagonal order; returns nnz
+ * (col / val may be NULL: row offsets only) */
+int64_t SUF(orc_dia_to_csr)(int nrow, int ncol, int ndiag, const int* offset, const T* dval, int* row_offset,
+                            int* col, T* val)
+{
+    row_offset[0] = 0;
+    for(int i = 0; i < nrow; ++i)
+    {
+        int idx = row_offset[i];
+        for(int n = 0; n < ndiag; ++n)
+        {
+            int j = i + offset[n];
+            if(j >= 0 && j < ncol && dval[(int64_t)n * nrow + i] != (T)0)
+            {
+                if(col && val)
+                {
+                    col[idx] = j;
+                    val[idx] = dval[(int64_t)n * nrow + i];
+                }
+                ++idx;
+            }
+        }
+        row_offset[i + 1] = idx;
+    }
+    return row_offset[nrow];
+}
+
 /* ---- iterative triangular solves (TriSolverAlg_Iterative) --------------------------------
  * src/base/host/host_sparse.cpp:195-530 host_csritsv_solve, matrix_type general, alpha = 1:
  * Jacobi sweeps  y <- y + D^-1 (x - (D + T) y)  on one triangle of a CSR matrix with sorted rows, started from
@@ -874,6 +982,9 @@ typedef struct
     int64_t coo_nnz;
     int *   coo_row, *coo_col;
     T*      coo_val;
+    int     dia_ndiag;
+    int*    dia_offset;
+    T*      dia_val;
 } SUF(orc_op);
 
 static void SUF(op_apply)(const SUF(orc_op) * A, const T* in, T* out)
@@ -885,7 +996,9 @@ static void SUF(op_apply)(const SUF(orc_op) * A, const T* in, T* out)
             out[i] = (T)0;
         return;
     }
-    if(A->format == ORC_ELL)
+    if(A->format == ORC_DIA)
+        SUF(orc_dia_apply)(A->nrow, A->dia_ndiag, A->dia_offset, A->dia_val, in, out);
+    else if(A->format == ORC_ELL)
         SUF(orc_ell_apply)(A->nrow, A->ell_max_row, A->ell_col, A->ell_val, in, out);
     else if(A->format == ORC_HYB)
         SUF(orc_hyb_apply)(A->nrow, A->nrow, A->ell_max_row, A->ell_col, A->ell_val, A->coo_nnz,
@@ -915,6 +1028,17 @@ static int SUF(op_build)(SUF(orc_op) * A, int format, int nrow, int64_t nnz, con
         SUF(orc_csr_to_ell_fill)(nrow, nnz, row_offset, col, val, w, A->ell_col, A->ell_val);
         A->format = ORC_ELL;
     }
+    else if(format == ORC_DIA)
+    {
+        int nd = SUF(orc_csr_to_dia)(nrow, nrow, nnz, row_offset, col, val, NULL, NULL);
+        if(nd < 0) /* refused: stays CSR */
+            return 1;
+        A->dia_ndiag  = nd;
+        A->dia_offset = (int*)malloc(sizeof(int) * (size_t)nd + 16);
+        A->dia_val    = (T*)malloc(sizeof(T) * (size_t)nd * nrow + 16);
+        SUF(orc_csr_to_dia)(nrow, nrow, nnz, row_offset, col, val, A->dia_offset, A->dia_val);
+        A->format = ORC_DIA;
+    }
     else if(format == ORC_HYB)
     {
         int     w = orc_csr_hyb_width(nrow, nnz);
@@ -940,6 +1064,8 @@ static void SUF(op_free)(SUF(orc_op) * A)
     free(A->coo_row);
     free(A->coo_col);
     free(A->coo_val);
+    free(A->dia_offset);
+    free(A->dia_val);
 }
 
 typedef struct

@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
-CSR, ELL, HYB = 1, 6, 7
+CSR, DIA, ELL, HYB = 1, 5, 6, 7
 CG, GMRES, BICGSTAB, FCG, CR, FGMRES, BICGSTABL, QMRCGSTAB, IDR, FIXEDPOINT, CHEBYSHEV = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 PC_NONE, PC_JACOBI, PC_ILU0, PC_MCSGS, PC_MCGS, PC_MCILU, PC_GS, PC_SGS, PC_IC = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
@@ -142,6 +142,46 @@ def csr_to_hyb(rp, ci, va):
     f, _ = _fn("orc_csr_to_hyb_fill", va.dtype)
     f(C.c_int(n), _p(rp), _p(ci), _p(va), C.c_int(w), _p(ec), _p(ev), _p(cr), _p(cc), _p(cv))
     return w, ec, ev, cr, cc, cv
+
+
+def csr_to_dia(rp, ci, va):
+    """-> (offsets[num_diag], values[num_diag * n]) or None when the reference refuses the conversion."""
+    rp, ci = _i32(rp), _i32(ci)
+    n = len(rp) - 1
+    f, _ = _fn("orc_csr_to_dia", va.dtype)
+    f.restype = C.c_int
+    nd = f(C.c_int(n), C.c_int(n), C.c_int64(len(va)), _p(rp), _p(ci), _p(va), None, None)
+    if nd < 0:
+        return None
+    off = np.zeros(nd, dtype=np.int32)
+    dv = np.zeros(nd * n, dtype=va.dtype)
+    f(C.c_int(n), C.c_int(n), C.c_int64(len(va)), _p(rp), _p(ci), _p(va), _p(off), _p(dv))
+    return off, dv
+
+
+def dia_apply(n, off, dv, x):
+    f, _ = _fn("orc_dia_apply", dv.dtype)
+    y = np.zeros(n, dtype=dv.dtype)
+    f(C.c_int(n), C.c_int(len(off)), _p(_i32(off)), _p(dv), _p(np.ascontiguousarray(x, dtype=dv.dtype)), _p(y))
+    return y
+
+
+def dia_apply_add(n, off, dv, x, scalar, y):
+    f, ct = _fn("orc_dia_apply_add", dv.dtype)
+    y = np.array(y, dtype=dv.dtype, copy=True)
+    f(C.c_int(n), C.c_int(len(off)), _p(_i32(off)), _p(dv), _p(np.ascontiguousarray(x, dtype=dv.dtype)), ct(scalar), _p(y))
+    return y
+
+
+def dia_to_csr(n, off, dv):
+    f, _ = _fn("orc_dia_to_csr", dv.dtype)
+    f.restype = C.c_int64
+    rp = np.zeros(n + 1, dtype=np.int32)
+    nnz = f(C.c_int(n), C.c_int(n), C.c_int(len(off)), _p(_i32(off)), _p(dv), _p(rp), None, None)
+    ci = np.zeros(nnz, dtype=np.int32)
+    va = np.zeros(nnz, dtype=dv.dtype)
+    f(C.c_int(n), C.c_int(n), C.c_int(len(off)), _p(_i32(off)), _p(dv), _p(rp), _p(ci), _p(va))
+    return rp, ci, va
 
 
 def ell_apply(n, w, ec, ev, x):

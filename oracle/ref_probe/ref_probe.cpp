@@ -169,6 +169,43 @@ static int cmd_gen(const std::string& in, const std::string& out)
         }
     }
     {
+        MatD d;
+        d.CloneFrom(mat);
+        d.ConvertToDIA(); // refused (too many diagonals): falls back to CSR
+        int fmt = d.GetFormat();
+        dump("dia_format", &fmt, 1);
+        if(fmt == DIA)
+        {
+            d.Apply(x, &y);
+            dump_vec("spmv_dia", y);
+            y.CopyFromHostData(yin.data());
+            d.ApplyAdd(x, -0.75, &y);
+            dump_vec("spmv_dia_add", y);
+            MatD back;
+            back.CloneFrom(d);
+            back.ConvertToCSR(); // DIA -> CSR drops the padded zeros (and stored zeros)
+            int*    rp = NULL;
+            int*    ci = NULL;
+            double* va = NULL;
+            int64_t bn = back.GetNnz();
+            back.LeaveDataPtrCSR(&rp, &ci, &va);
+            dump("dia_back_rowptr", rp, (size_t)A.n + 1);
+            dump("dia_back_col", ci, (size_t)bn);
+            dump("dia_back_val", va, (size_t)bn);
+            delete[] rp;
+            delete[] ci;
+            delete[] va;
+            int*    off = NULL;
+            double* dv  = NULL;
+            int     nd  = 0;
+            d.LeaveDataPtrDIA(&off, &dv, nd);
+            dump("dia_offset", off, (size_t)nd);
+            dump("dia_val", dv, (size_t)nd * A.n);
+            delete[] off;
+            delete[] dv;
+        }
+    }
+    {
         MatD h;
         h.CloneFrom(mat);
         h.ConvertToHYB();
@@ -748,6 +785,19 @@ static int cmd_gen(const std::string& in, const std::string& out)
             e.ConvertToHYB();
             sol.Zeros();
             run_solver("cg_jacobi_hyb", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            MatD e;
+            e.CloneFrom(mat);
+            CG<MatD, VecD, double>     ls;
+            Jacobi<MatD, VecD, double> p;
+            ls.SetOperator(e);
+            ls.SetPreconditioner(p);
+            ls.Build();
+            e.ConvertToDIA();
+            sol.Zeros();
+            run_solver("cg_jacobi_dia", ls, rhs, sol);
             ls.Clear();
         }
         {

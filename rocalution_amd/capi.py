@@ -18,7 +18,7 @@ SOLVER_FCG, SOLVER_CR, SOLVER_FGMRES, SOLVER_BICGSTABL, SOLVER_QMRCGSTAB, SOLVER
 SOLVER_FIXEDPOINT, SOLVER_CHEBYSHEV = 9, 10
 PC_NONE, PC_JACOBI, PC_ILU0, PC_MCSGS, PC_MCGS, PC_MCILU, PC_GS, PC_SGS, PC_IC = 0, 1, 2, 3, 4, 5, 6, 7, 8
 F64, F32, I32 = 0, 1, 2
-CSR, COO, ELL, HYB = 1, 4, 6, 7
+CSR, COO, DIA, ELL, HYB = 1, 4, 5, 6, 7
 
 vec_t = C.c_void_p
 mat_t = C.c_void_p
@@ -86,6 +86,8 @@ SIGNATURES = {
     "ramd_mat_clone": (i32, [mat_t, C.POINTER(mat_t)]),
     "ramd_mat_cast": (i32, [mat_t, C.POINTER(mat_t)]),
     "ramd_mat_convert": (i32, [mat_t, i32]),
+    "ramd_mat_dia_info": (i32, [mat_t, pi32]),
+    "ramd_mat_copy_dia_to_host": (i32, [mat_t, ptr, ptr]),
     "ramd_mat_ell_info": (i32, [mat_t, pi32, pi64]),
     "ramd_mat_copy_ell_to_host": (i32, [mat_t, ptr, ptr]),
     "ramd_mat_copy_coo_to_host": (i32, [mat_t, ptr, ptr, ptr]),

@@ -83,6 +83,23 @@ def test_spmv_formats(oracle, name):
     eq(oracle.coo_apply_add(row, ci, va, x, -0.75, y), g["spmv_coo_add"])
 
 
+@pytest.mark.parametrize("name", KERNEL_CASES)
+def test_dia_conversion_and_spmv(oracle, name):
+    g = load_golden(name)
+    rp, ci, va, x, y = _inputs(name, g)
+    n = len(rp) - 1
+    dia = oracle.csr_to_dia(rp, ci, va)
+    if int(g["dia_format"][0]) != oracle.DIA:
+        assert dia is None  # refused: more than 5 * (nnz / n) diagonals
+        return
+    off, dv = dia
+    eq(off, g["dia_offset"]); eq(dv, g["dia_val"])
+    eq(oracle.dia_apply(n, off, dv, x), g["spmv_dia"])
+    eq(oracle.dia_apply_add(n, off, dv, x, -0.75, y), g["spmv_dia_add"])
+    brp, bci, bva = oracle.dia_to_csr(n, off, dv)
+    eq(brp, g["dia_back_rowptr"]); eq(bci, g["dia_back_col"]); eq(bva, g["dia_back_val"])
+
+
 def test_ell_refusal_case_present():
     # rand300 has rows 12x longer than average: the reference must have refused ELL there
     assert int(load_golden("rand300")["ell_format"][0]) != 6
@@ -179,6 +196,7 @@ SOLVER_TABLE = {
     "bicgstab_mcsgs": ("BICGSTAB", "PC_MCSGS", "CSR", {}),
     "bicgstab_mcsgs_ell": ("BICGSTAB", "PC_MCSGS", "ELL", {}),
     "cg_jacobi_hyb": ("CG", "PC_JACOBI", "HYB", {}),
+    "cg_jacobi_dia": ("CG", "PC_JACOBI", "DIA", {}),
     "bicgstab_mcgs": ("BICGSTAB", "PC_MCGS", "CSR", {}),
     "gmres_mcilu": ("GMRES", "PC_MCILU", "CSR", {}),
     "fcg_none": ("FCG", "PC_NONE", "CSR", {}),

@@ -17,3 +17,5 @@ run cg_jacobi_512_ell --grid 512 --format ell
 run cg_jacobi_512_hyb --grid 512 --format hyb
 run cg_ic_256 --grid 256 --precond ic --steps 60
 run cg_ic_512 --grid 512 --precond ic --steps 60
+run cg_jacobi_512_dia --grid 512 --format dia
+run cg_jacobi_256_dia --grid 256 --format dia
