@@ -8,6 +8,10 @@ minutes: size-independent properties of the domain instead of element-wise compa
     (kappa ~ N^2 -> iterations ~ N), residual history monotone in the A-norm sense (checked via <r,z> > 0)
   * M^-1 = (LU)^-1 of ILU(0): L U (LUSolve(b)) == b on the pattern  (factor * solve round trip)
   * MC-SGS: the fused colour sweeps and the block form agree bit-for-bit at full size
+  * iterative triangular solves: a triangular Jacobi iteration is exact after (number of levels) sweeps, so ILU(0)
+    with 3N sweeps must reproduce the level-scheduled solve to round-off; the device stopping test must end a run
+    with a loose tolerance early (far cheaper) without changing more than that tolerance allows
+  * CG+IC reaches the known solution in fewer iterations than CG+Jacobi
 """
 import ctypes as C
 
@@ -54,10 +58,12 @@ def test_spmv_closed_form_and_formats_bit_identical(ra, N):
     x = ra.LocalVector(data=xh)
     A.Apply(x, y)
     y_csr = y.numpy().copy()
-    for fmt in (ra.ELL, ra.HYB):
+    for fmt in (ra.ELL, ra.HYB, ra.DIA):  # DIA also multiplies its padded zeros: +-0 added, same values
         assert A.ConvertTo(fmt) == fmt
         A.Apply(x, y)
         assert np.array_equal(y.numpy(), y_csr)
+    off, _ = A.GetDIA() if N == 256 else (np.array([-N * N, -N, -1, 0, 1, N, N * N]), None)
+    assert list(off) == [-N * N, -N, -1, 0, 1, N, N * N]
     # closed form on a sample of rows (7-point stencil evaluated on the host in the same order)
     idx = rng.integers(0, n, 2000)
     N2 = N * N
@@ -164,3 +170,50 @@ def test_mcsgs_forms_agree_at_full_size_256(ra, S):
         res.append(z.numpy().copy())
         ls.Clear()
     assert np.array_equal(res[0], res[1])
+
+
+def test_iterative_triangular_solve_is_exact_after_level_count_sweeps_256(ra, S):
+    N = 256
+    n = N ** 3
+    A = ra.LocalMatrix(); A.GenPoisson7(N)
+    rng = np.random.default_rng(11)
+    b = ra.LocalVector(data=rng.uniform(-1, 1, n))
+    out = {}
+    for key, descr in (("direct", None), ("it_full", (3 * N, 0.0, False)), ("it_tol", (3 * N, 1e-3, True))):
+        pc = S.ILU()
+        if descr:
+            d = S.SolverDescr(); d.SetTriSolverAlg(S.TriSolverAlg_Iterative)
+            d.SetIterativeSolverMaxIteration(descr[0]); d.SetIterativeSolverTolerance(descr[1])
+            d.EnableIterativeSolverTolerance() if descr[2] else d.DisableIterativeSolverTolerance()
+            pc.SetSolverDescriptor(d)
+        ls = S.GMRES(); ls.SetOperator(A); ls.SetPreconditioner(pc); ls.Build()
+        z = ra.LocalVector(); z.Allocate("", n)
+        ra.sync()
+        import time
+        t = time.perf_counter(); ls.PrecondApply(b, z); ra.sync(); dt = time.perf_counter() - t
+        out[key] = (z.numpy().copy(), dt)
+        ls.Clear()
+    ref = out["direct"][0]
+    scale = np.max(np.abs(ref))
+    assert np.max(np.abs(out["it_full"][0] - ref)) <= 1e-11 * scale  # nilpotent iteration: exact after 3N-2 sweeps
+    # tolerance 1e-3 on the max-norm update/residual figure: close to the exact solve, and stopped long before 3N sweeps
+    assert np.max(np.abs(out["it_tol"][0] - ref)) <= 5e-2 * scale
+    assert out["it_tol"][1] < 0.25 * out["it_full"][1]
+
+
+def test_cg_ic_beats_cg_jacobi_256(ra, S):
+    N = 256
+    n = N ** 3
+    A = ra.LocalMatrix(); A.GenPoisson7(N)
+    ones = ra.LocalVector(); ones.Allocate("", n); ones.Ones()
+    rhs = ra.LocalVector(); rhs.Allocate("", n); A.Apply(ones, rhs)
+    its = {}
+    for name, pc in (("jacobi", S.Jacobi()), ("ic", S.IC())):
+        ls = S.CG(); ls.SetOperator(A); ls.SetPreconditioner(pc); ls.Init(1e-15, 1e-8, 1e8, 5000); ls.Build()
+        x = ra.LocalVector(); x.Allocate("", n)
+        ls.Solve(rhs, x)
+        assert ls.GetSolverStatus() == 2  # relative tolerance reached
+        assert np.linalg.norm(x.numpy() - 1.0) / np.sqrt(n) < 1e-5
+        its[name] = ls.GetIterationCount()
+        ls.Clear()
+    assert its["ic"] < 0.6 * its["jacobi"], its
