@@ -123,7 +123,15 @@ constexpr int kBlock = 256;
 inline int ew_grid(int64_t n_vec_items)
 {
     int64_t g   = (n_vec_items + kBlock - 1) / kBlock;
-    int64_t cap = (int64_t)backend().num_cu * 16;
+    static int mult = -1; // workgroups per CU (RAMD_EW_GRID_MULT: experiments only)
+    if(mult < 0)
+    {
+        const char* e = getenv("RAMD_EW_GRID_MULT");
+        mult          = e ? atoi(e) : 16;
+        if(mult < 1)
+            mult = 16;
+    }
+    int64_t cap = (int64_t)backend().num_cu * mult;
     if(g > cap)
         g = cap;
     if(g < 1)
