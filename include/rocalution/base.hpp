@@ -1130,6 +1130,45 @@ public:
         this->need_accel_("LUSolve");
         RAMD_CHECK(ramd_mat_lu_solve(this->dev_, in.handle(), out->handle()));
     }
+    // ---- CSR matrix algebra (local_matrix.cpp Transpose / Sort / MatrixAdd / MatrixMult)
+    void Sort(void)
+    {
+        this->need_accel_("Sort");
+        RAMD_CHECK(ramd_mat_sort(this->dev_));
+    }
+    void Transpose(LocalMatrix<ValueType>* T) const
+    {
+        this->need_accel_("Transpose");
+        assert(T != NULL && T != this);
+        T->MoveToAccelerator();
+        if(this->GetNnz() > 0)
+            RAMD_CHECK(ramd_mat_transpose(this->dev_, T->dev_));
+    }
+    void Transpose(void)
+    {
+        if(this->GetNnz() > 0)
+        {
+            LocalMatrix<ValueType> tmp;
+            tmp.CloneFrom(*this);
+            tmp.Transpose(this);
+        }
+    }
+    // this = alpha*this + beta*mat; structure == false: pattern(mat) is a subset of pattern(this)
+    void MatrixAdd(const LocalMatrix<ValueType>& mat, ValueType alpha = static_cast<ValueType>(1),
+                   ValueType beta = static_cast<ValueType>(1), bool structure = false)
+    {
+        this->need_accel_("MatrixAdd");
+        assert(&mat != this);
+        RAMD_CHECK(ramd_mat_matrix_add(this->dev_, mat.dev_, (double)alpha, (double)beta, structure ? 1 : 0));
+    }
+    // this = A * B
+    void MatrixMult(const LocalMatrix<ValueType>& A, const LocalMatrix<ValueType>& B)
+    {
+        assert(&A != this && &B != this);
+        A.need_accel_("MatrixMult");
+        this->MoveToAccelerator();
+        RAMD_CHECK(ramd_mat_mat_mult(this->dev_, A.dev_, B.dev_));
+    }
     // TriSolverAlg_Iterative: Jacobi-sweep triangular solves (local_matrix.cpp ItLU* / ItLL* / ItL* / ItU*)
     void ItLUAnalyse(void)
     {

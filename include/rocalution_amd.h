@@ -274,6 +274,13 @@ int ramd_fused_normalize(ramd_vec_t v, int slot_sq, int slot_norm);
  *   UpdateValuesCSR: new values (host array of nnz entries) into the existing pattern. */
 int ramd_mat_gershgorin(ramd_mat_t m, double* lambda_min, double* lambda_max);
 int ramd_mat_extract_tri(ramd_mat_t m, ramd_mat_t out, int upper, int with_diag);
+/* CSR matrix algebra (host_matrix_csr.cpp): Sort :3812-3846 (stable, by column), Transpose(T) :3757-3806,
+ * MatrixAdd :3324-3462 (this = alpha*this + beta*other; structure == 0: pattern of other is a subset; != 0: union
+ * pattern; rows sorted), MatMatMult :2805-2938 (C = A*B, products summed in the host's order, rows sorted) */
+int ramd_mat_sort(ramd_mat_t m);
+int ramd_mat_transpose(ramd_mat_t m, ramd_mat_t out);
+int ramd_mat_matrix_add(ramd_mat_t m, ramd_mat_t other, double alpha, double beta, int structure);
+int ramd_mat_mat_mult(ramd_mat_t c, ramd_mat_t a, ramd_mat_t b);
 int ramd_mat_scale_values(ramd_mat_t m, double alpha, int which);
 int ramd_mat_add_scalar_values(ramd_mat_t m, double alpha, int which);
 int ramd_mat_update_values(ramd_mat_t m, const void* host_val);

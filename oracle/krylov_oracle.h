@@ -59,6 +59,13 @@ int     orc_csr_multicoloring(int nrow, int64_t nnz, const int* row_offset, cons
                           const T*, const T*, T*);                                                 \
     void orc_hyb_apply_add##S(int, int, int, const int*, const T*, int64_t, const int*,            \
                               const int*, const T*, const T*, T, T*);                              \
+    void orc_csr_transpose##S(int, int, int64_t, const int*, const int*, const T*, int*, int*, T*); \
+    int64_t orc_csr_matmult##S(int, int, const int*, const int*, const T*, const int*, const int*, \
+                               const T*, int*, int*, T*);                                          \
+    void orc_csr_matrix_add_subset##S(int, const int*, const int*, T*, const int*, const int*,     \
+                                      const T*, T, T);                                             \
+    int64_t orc_csr_matrix_add_union##S(int, const int*, const int*, const T*, const int*,         \
+                                        const int*, const T*, T, T, int*, int*, T*);               \
     int  orc_csr_to_dia##S(int, int, int64_t, const int*, const int*, const T*, int*, T*);         \
     void orc_dia_apply##S(int, int, const int*, const T*, const T*, T*);                           \
     void orc_dia_apply_add##S(int, int, const int*, const T*, const T*, T, T*);                    \

@@ -597,6 +597,171 @@ void SUF(orc_csr_llsolve)(int nrow, const int* row_offset, const int* col, const
     }
 }
 
+/* ---- CSR matrix algebra ---------------------------------------------------------------------
+ * host_matrix_csr.cpp:3757-3806 Transpose: counting sort by column, entries of a transposed row in ascending
+ * original-row order (out arrays sized by the caller: ncol+1, nnz, nnz) */
+void SUF(orc_csr_transpose)(int nrow, int ncol, int64_t nnz, const int* rp, const int* col, const T* val, int* trp,
+                            int* tcol, T* tval)
+{
+    for(int i = 0; i <= ncol; ++i)
+        trp[i] = 0;
+    for(int64_t k = 0; k < nnz; ++k)
+        trp[col[k] + 1] += 1;
+    for(int i = 0; i < ncol; ++i)
+        trp[i + 1] += trp[i];
+    int* cur = (int*)malloc(sizeof(int) * (size_t)(ncol > 0 ? ncol : 1));
+    for(int i = 0; i < ncol; ++i)
+        cur[i] = trp[i];
+    for(int ai = 0; ai < nrow; ++ai)
+        for(int aj = rp[ai]; aj < rp[ai + 1]; ++aj)
+        {
+            int p   = cur[col[aj]]++;
+            tcol[p] = ai;
+            tval[p] = val[aj];
+        }
+    free(cur);
+}
+
+/* :2805-2938 MatMatMult C = A*B: Gustavson with a column marker, products added in (ja, jb) order; then Sort
+ * (:3812-3846, stable by column).  Two calls: ccol == NULL counts (crp filled), else fills. */
+int64_t SUF(orc_csr_matmult)(int n, int m, const int* arp, const int* acol, const T* aval, const int* brp,
+                             const int* bcol, const T* bval, int* crp, int* ccol, T* cval)
+{
+    int* marker = (int*)malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
+    for(int i = 0; i < m; ++i)
+        marker[i] = -1;
+    if(!ccol)
+    {
+        crp[0] = 0;
+        for(int ia = 0; ia < n; ++ia)
+        {
+            int c = 0;
+            for(int ja = arp[ia]; ja < arp[ia + 1]; ++ja)
+                for(int jb = brp[acol[ja]]; jb < brp[acol[ja] + 1]; ++jb)
+                    if(marker[bcol[jb]] != ia)
+                    {
+                        marker[bcol[jb]] = ia;
+                        ++c;
+                    }
+            crp[ia + 1] = crp[ia] + c;
+        }
+        free(marker);
+        return crp[n];
+    }
+    for(int ia = 0; ia < n; ++ia)
+    {
+        int row_begin = crp[ia], row_end = row_begin;
+        for(int ja = arp[ia]; ja < arp[ia + 1]; ++ja)
+        {
+            int ca = acol[ja];
+            T   va = aval[ja];
+            for(int jb = brp[ca]; jb < brp[ca + 1]; ++jb)
+            {
+                int cb = bcol[jb];
+                T   vb = bval[jb];
+                if(marker[cb] < row_begin)
+                {
+                    marker[cb]    = row_end;
+                    ccol[row_end] = cb;
+                    cval[row_end] = va * vb;
+                    ++row_end;
+                }
+                else
+                    cval[marker[cb]] += va * vb;
+            }
+        }
+        /* Sort(): bubble sort of the row by column */
+        for(int j = crp[ia]; j < crp[ia + 1]; ++j)
+            for(int jj = crp[ia]; jj < crp[ia + 1] - 1; ++jj)
+                if(ccol[jj] > ccol[jj + 1])
+                {
+                    int ti        = ccol[jj];
+                    T   tv        = cval[jj];
+                    ccol[jj]      = ccol[jj + 1];
+                    cval[jj]      = cval[jj + 1];
+                    ccol[jj + 1]  = ti;
+                    cval[jj + 1]  = tv;
+                }
+    }
+    free(marker);
+    return crp[n];
+}
+
+/* :3324-3365 MatrixAdd, structure == false: this = alpha*this + beta*mat on the entries of mat (subset pattern) */
+void SUF(orc_csr_matrix_add_subset)(int nrow, const int* rp, const int* col, T* val, const int* brp, const int* bcol,
+                                    const T* bval, T alpha, T beta)
+{
+    for(int ai = 0; ai < nrow; ++ai)
+    {
+        int first_col = brp[ai];
+        for(int ajj = rp[ai]; ajj < rp[ai + 1]; ++ajj)
+            for(int aj = first_col; aj < brp[ai + 1]; ++aj)
+                if(bcol[aj] == col[ajj])
+                {
+                    val[ajj] = alpha * val[ajj] + beta * bval[aj];
+                    ++first_col;
+                    break;
+                }
+    }
+}
+/* :3366-3459 structure == true: union pattern (sorted, unique), zero-filled, += alpha*A then += beta*B.
+ * ccol == NULL: count only (crp filled). */
+int64_t SUF(orc_csr_matrix_add_union)(int nrow, const int* arp, const int* acol, const T* aval, const int* brp,
+                                      const int* bcol, const T* bval, T alpha, T beta, int* crp, int* ccol, T* cval)
+{
+    if(!ccol)
+        crp[0] = 0;
+    for(int i = 0; i < nrow; ++i)
+    {
+        int na = arp[i + 1] - arp[i], nb = brp[i + 1] - brp[i];
+        int* u = (int*)malloc(sizeof(int) * (size_t)(na + nb + 1));
+        int  k = 0;
+        for(int j = arp[i]; j < arp[i + 1]; ++j)
+            u[k++] = acol[j];
+        for(int j = brp[i]; j < brp[i + 1]; ++j)
+            u[k++] = bcol[j];
+        for(int a = 1; a < k; ++a) /* std::sort */
+        {
+            int c = u[a], q = a - 1;
+            for(; q >= 0 && u[q] > c; --q)
+                u[q + 1] = u[q];
+            u[q + 1] = c;
+        }
+        int w = 0;
+        for(int a = 0; a < k; ++a) /* std::unique */
+            if(a == 0 || u[a] != u[a - 1])
+                u[w++] = u[a];
+        if(!ccol)
+            crp[i + 1] = crp[i] + w;
+        else
+        {
+            int Aj = arp[i], Bj = brp[i];
+            for(int j = 0; j < w; ++j)
+            {
+                int o   = crp[i] + j;
+                ccol[o] = u[j];
+                cval[o] = (T)0;
+                for(int jj = Aj; jj < arp[i + 1]; ++jj)
+                    if(ccol[o] == acol[jj])
+                    {
+                        cval[o] += alpha * aval[jj];
+                        ++Aj;
+                        break;
+                    }
+                for(int jj = Bj; jj < brp[i + 1]; ++jj)
+                    if(ccol[o] == bcol[jj])
+                    {
+                        cval[o] += beta * bval[jj];
+                        ++Bj;
+                        break;
+                    }
+            }
+        }
+        free(u);
+    }
+    return crp[nrow];
+}
+
 /* ---- DIA ------------------------------------------------------------------------------------
  * host_conversion.cpp:958-1038 csr_to_dia: one slot per populated diagonal (col - row), offsets ascending, values
  * column-major d*nrow + row (matrix_formats_ind.hpp:43-45), absent entries zero; refused (-1) when the number of

@@ -144,6 +144,48 @@ def csr_to_hyb(rp, ci, va):
     return w, ec, ev, cr, cc, cv
 
 
+def csr_transpose(rp, ci, va, ncol=None):
+    rp, ci = _i32(rp), _i32(ci)
+    n = len(rp) - 1
+    m = n if ncol is None else ncol
+    f, _ = _fn("orc_csr_transpose", va.dtype)
+    trp = np.zeros(m + 1, dtype=np.int32); tci = np.zeros(len(va), dtype=np.int32); tva = np.zeros(len(va), dtype=va.dtype)
+    f(C.c_int(n), C.c_int(m), C.c_int64(len(va)), _p(rp), _p(ci), _p(va), _p(trp), _p(tci), _p(tva))
+    return trp, tci, tva
+
+
+def csr_matmult(a, b, ncol_b=None):
+    (arp, aci, ava), (brp, bci, bva) = a, b
+    arp, aci, brp, bci = _i32(arp), _i32(aci), _i32(brp), _i32(bci)
+    n = len(arp) - 1
+    m = (len(brp) - 1) if ncol_b is None else ncol_b
+    f, _ = _fn("orc_csr_matmult", ava.dtype)
+    f.restype = C.c_int64
+    crp = np.zeros(n + 1, dtype=np.int32)
+    nnz = f(C.c_int(n), C.c_int(m), _p(arp), _p(aci), _p(ava), _p(brp), _p(bci), _p(bva), _p(crp), None, None)
+    cci = np.zeros(nnz, dtype=np.int32); cva = np.zeros(nnz, dtype=ava.dtype)
+    f(C.c_int(n), C.c_int(m), _p(arp), _p(aci), _p(ava), _p(brp), _p(bci), _p(bva), _p(crp), _p(cci), _p(cva))
+    return crp, cci, cva
+
+
+def csr_matrix_add(a, b, alpha, beta, structure):
+    (arp, aci, ava), (brp, bci, bva) = a, b
+    arp, aci, brp, bci = _i32(arp), _i32(aci), _i32(brp), _i32(bci)
+    n = len(arp) - 1
+    if not structure:
+        f, ct = _fn("orc_csr_matrix_add_subset", ava.dtype)
+        out = np.array(ava, copy=True)
+        f(C.c_int(n), _p(arp), _p(aci), _p(out), _p(brp), _p(bci), _p(bva), ct(alpha), ct(beta))
+        return arp, aci, out
+    f, ct = _fn("orc_csr_matrix_add_union", ava.dtype)
+    f.restype = C.c_int64
+    crp = np.zeros(n + 1, dtype=np.int32)
+    nnz = f(C.c_int(n), _p(arp), _p(aci), _p(ava), _p(brp), _p(bci), _p(bva), ct(alpha), ct(beta), _p(crp), None, None)
+    cci = np.zeros(nnz, dtype=np.int32); cva = np.zeros(nnz, dtype=ava.dtype)
+    f(C.c_int(n), _p(arp), _p(aci), _p(ava), _p(brp), _p(bci), _p(bva), ct(alpha), ct(beta), _p(crp), _p(cci), _p(cva))
+    return crp, cci, cva
+
+
 def csr_to_dia(rp, ci, va):
     """-> (offsets[num_diag], values[num_diag * n]) or None when the reference refuses the conversion."""
     rp, ci = _i32(rp), _i32(ci)

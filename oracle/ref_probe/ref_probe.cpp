@@ -226,6 +226,39 @@ static int cmd_gen(const std::string& in, const std::string& out)
         dump_vec("spmv_coo_add", y);
     }
 
+    // --- CSR matrix algebra: Transpose, MatrixMult, MatrixAdd (subset and union patterns) ---------
+    {
+        auto dump_csr = [&](const std::string& tag, MatD& m) {
+            int*    rp = NULL;
+            int*    ci = NULL;
+            double* va = NULL;
+            int64_t nz = m.GetNnz();
+            int     nr = (int)m.GetM();
+            m.LeaveDataPtrCSR(&rp, &ci, &va);
+            dump(tag + "_rowptr", rp, (size_t)nr + 1);
+            dump(tag + "_col", ci, (size_t)nz);
+            dump(tag + "_val", va, (size_t)nz);
+            delete[] rp;
+            delete[] ci;
+            delete[] va;
+        };
+        MatD t;
+        t.CloneFrom(mat);
+        t.Transpose();
+        MatD aa;
+        aa.MatrixMult(mat, t); // A * A^T
+        MatD sub;
+        sub.CloneFrom(aa);
+        sub.MatrixAdd(mat, 0.5, -2.0, false); // pattern(A) is a subset of pattern(A A^T) (full diagonal)
+        MatD uni;
+        uni.CloneFrom(mat);
+        uni.MatrixAdd(aa, 1.5, 0.25, true); // union pattern
+        dump_csr("alg_transpose", t);
+        dump_csr("alg_matmult", aa);
+        dump_csr("alg_add_subset", sub);
+        dump_csr("alg_add_union", uni);
+    }
+
     // --- BLAS-1 ----------------------------------------------------------------------------
     {
         VecD a, b;

@@ -278,6 +278,24 @@ class LocalMatrix:
         self._h = h
         self.dtype = np.dtype(np.float32 if src.dtype == np.float64 else np.float64)
 
+    # ---- CSR matrix algebra (host_matrix_csr.cpp Sort / Transpose / MatrixAdd / MatMatMult)
+    def Sort(self):
+        capi.check(_lib().ramd_mat_sort(self._h))
+
+    def Transpose(self, out=None):
+        """out = self^T (out given) or in place"""
+        if out is not None:
+            capi.check(_lib().ramd_mat_transpose(self._h, out._h))
+            return
+        tmp = LocalMatrix(self.dtype); tmp.CloneFrom(self)
+        capi.check(_lib().ramd_mat_transpose(tmp._h, self._h))
+
+    def MatrixAdd(self, mat, alpha=1.0, beta=1.0, structure=False):
+        capi.check(_lib().ramd_mat_matrix_add(self._h, mat._h, float(alpha), float(beta), int(bool(structure))))
+
+    def MatrixMult(self, A, B):
+        capi.check(_lib().ramd_mat_mat_mult(self._h, A._h, B._h))
+
     def ConvertTo(self, fmt):
         """LocalMatrix::ConvertTo (src/base/local_matrix.cpp:2064-2151): a refused ELL conversion
         leaves the matrix in CSR (level-2 warning in the reference); returns the resulting format."""

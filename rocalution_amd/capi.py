@@ -127,6 +127,10 @@ SIGNATURES = {
     "ramd_mat_it_u_analyse": (i32, [mat_t, i32]),
     "ramd_mat_it_u_analyse_clear": (i32, [mat_t]),
     "ramd_mat_it_u_solve": (i32, [mat_t, i32, f64, i32, vec_t, vec_t]),
+    "ramd_mat_sort": (i32, [mat_t]),
+    "ramd_mat_transpose": (i32, [mat_t, mat_t]),
+    "ramd_mat_matrix_add": (i32, [mat_t, mat_t, f64, f64, i32]),
+    "ramd_mat_mat_mult": (i32, [mat_t, mat_t, mat_t]),
     "ramd_mat_gershgorin": (i32, [mat_t, pf64, pf64]),
     "ramd_mat_extract_tri": (i32, [mat_t, mat_t, i32, i32]),
     "ramd_mat_scale_values": (i32, [mat_t, f64, i32]),

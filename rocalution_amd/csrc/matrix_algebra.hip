@@ -1,0 +1,439 @@
+// matrix_algebra.hip -- CSR matrix algebra of the LocalMatrix API (the building blocks of the reference's coarse-grid
+// construction): Transpose, Sort, MatrixAdd, MatrixMult.  Reference: src/base/host/host_matrix_csr.cpp
+//   Transpose :3743-3806 | Sort :3812-3846 | MatrixAdd :3324-3462 | MatMatMult :2805-2938
+// Every result entry is produced by the same operations in the same order as the host loops (bit-exact values);
+// rows are one thread each, the intermediate product list of MatrixMult lives in device memory.
+#include "device_utils.hpp"
+#include "matrix_impl.hpp"
+
+#include <algorithm>
+
+namespace ramd
+{
+
+// stable insertion sort of every row by column (host: bubble sort, also stable)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_sort_rows(int nrow, const int* __restrict__ rp, int* __restrict__ ci,
+                                                      T* __restrict__ val)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += gsz)
+        for(int a = rp[r] + 1; a < rp[r + 1]; ++a)
+        {
+            const int c = ci[a];
+            const T   v = val[a];
+            int       q = a - 1;
+            for(; q >= rp[r] && ci[q] > c; --q)
+            {
+                ci[q + 1]  = ci[q];
+                val[q + 1] = val[q];
+            }
+            ci[q + 1]  = c;
+            val[q + 1] = v;
+        }
+}
+
+// ---- MatrixAdd, pattern of `mat` a subset of this (structure == false): this = alpha*this + beta*mat on the matches
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_add_subset(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                       T* __restrict__ val, const int* __restrict__ brp,
+                                                       const int* __restrict__ bci, const T* __restrict__ bval, T alpha,
+                                                       T beta)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+    {
+        int       first = brp[i];
+        const int bend  = brp[i + 1];
+        for(int ajj = rp[i]; ajj < rp[i + 1]; ++ajj)
+            for(int aj = first; aj < bend; ++aj)
+                if(bci[aj] == ci[ajj])
+                {
+                    val[ajj] = alpha * val[ajj] + beta * bval[aj];
+                    ++first; // as the host loop: advanced by one per match (rows sorted)
+                    break;
+                }
+    }
+}
+
+// ---- MatrixAdd with the union pattern (structure == true); rows sorted, columns unique
+__global__ __launch_bounds__(kBlock) void k_union_count(int nrow, const int* __restrict__ arp,
+                                                        const int* __restrict__ aci, const int* __restrict__ brp,
+                                                        const int* __restrict__ bci, int* __restrict__ cnt)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= nrow; i += gsz)
+    {
+        int c = 0;
+        if(i < nrow)
+        {
+            int a = arp[i], b = brp[i];
+            const int ae = arp[i + 1], be = brp[i + 1];
+            while(a < ae || b < be)
+            {
+                const int ca = a < ae ? aci[a] : 0x7fffffff;
+                const int cb = b < be ? bci[b] : 0x7fffffff;
+                const int m  = min(ca, cb);
+                if(ca == m)
+                    ++a;
+                if(cb == m)
+                    ++b;
+                ++c;
+            }
+        }
+        cnt[i] = c;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_union_fill(int nrow, const int* __restrict__ arp,
+                                                       const int* __restrict__ aci, const T* __restrict__ aval,
+                                                       const int* __restrict__ brp, const int* __restrict__ bci,
+                                                       const T* __restrict__ bval, T alpha, T beta,
+                                                       const int* __restrict__ crp, int* __restrict__ cci,
+                                                       T* __restrict__ cval)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+    {
+        int       a = arp[i], b = brp[i], o = crp[i];
+        const int ae = arp[i + 1], be = brp[i + 1];
+        while(a < ae || b < be)
+        {
+            const int ca = a < ae ? aci[a] : 0x7fffffff;
+            const int cb = b < be ? bci[b] : 0x7fffffff;
+            const int m  = min(ca, cb);
+            T         v  = (T)0; // AllocateCSR zero-fills; then += alpha*A, += beta*B (host :3421-3447)
+            if(ca == m)
+                v += alpha * aval[a++];
+            if(cb == m)
+                v += beta * bval[b++];
+            cci[o]  = m;
+            cval[o] = v;
+            ++o;
+        }
+    }
+}
+
+// ---- MatrixMult: C = A * B
+// upper bound of products per row of C
+__global__ __launch_bounds__(kBlock) void k_mm_bound(int nrow, const int* __restrict__ arp, const int* __restrict__ aci,
+                                                     const int* __restrict__ brp, long long* __restrict__ ub)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= nrow; i += gsz)
+    {
+        long long c = 0;
+        if(i < nrow)
+            for(int ja = arp[i]; ja < arp[i + 1]; ++ja)
+                c += brp[aci[ja] + 1] - brp[aci[ja]];
+        ub[i] = c;
+    }
+}
+__global__ void k_scan_ll(int64_t n, long long* v) // exclusive scan, single thread per 1 block (n+1 small vs nnz work)
+{
+    // one workgroup, sequential over tiles: the array has nrow+1 entries and is touched once
+    __shared__ long long carry;
+    __shared__ long long tile[kBlock];
+    if(threadIdx.x == 0)
+        carry = 0;
+    __syncthreads();
+    for(int64_t base = 0; base < n; base += kBlock)
+    {
+        const int64_t i = base + threadIdx.x;
+        const long long x = i < n ? v[i] : 0;
+        tile[threadIdx.x] = x;
+        __syncthreads();
+        for(int o = 1; o < kBlock; o <<= 1) // Hillis-Steele inclusive scan
+        {
+            const long long y = threadIdx.x >= o ? tile[threadIdx.x - o] : 0;
+            __syncthreads();
+            tile[threadIdx.x] += y;
+            __syncthreads();
+        }
+        if(i < n)
+            v[i] = carry + tile[threadIdx.x] - x;
+        __syncthreads();
+        if(threadIdx.x == 0)
+            carry += tile[kBlock - 1];
+        __syncthreads();
+    }
+}
+// products of row i in the host's order (ja ascending, jb ascending), then a stable insertion sort by column and the
+// in-order sum of equal columns (= val[marker] = first product, += the later ones); cnt[i] = distinct columns
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_mm_products(int nrow, const int* __restrict__ arp,
+                                                        const int* __restrict__ aci, const T* __restrict__ aval,
+                                                        const int* __restrict__ brp, const int* __restrict__ bci,
+                                                        const T* __restrict__ bval, const long long* __restrict__ off,
+                                                        int* __restrict__ pcol, T* __restrict__ pval,
+                                                        int* __restrict__ cnt)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= nrow; i += gsz)
+    {
+        if(i == nrow)
+        {
+            cnt[i] = 0;
+            continue;
+        }
+        const long long s = off[i];
+        long long       e = s;
+        for(int ja = arp[i]; ja < arp[i + 1]; ++ja)
+        {
+            const int ca = aci[ja];
+            const T   va = aval[ja];
+            for(int jb = brp[ca]; jb < brp[ca + 1]; ++jb)
+            {
+                // insert (cb, va*vb) behind every entry with column <= cb: stable
+                const int cb = bci[jb];
+                const T   pv = va * bval[jb];
+                long long q  = e - 1;
+                for(; q >= s && pcol[q] > cb; --q)
+                {
+                    pcol[q + 1] = pcol[q];
+                    pval[q + 1] = pval[q];
+                }
+                pcol[q + 1] = cb;
+                pval[q + 1] = pv;
+                ++e;
+            }
+        }
+        // merge equal columns in place
+        long long o = s;
+        for(long long q = s; q < e;)
+        {
+            const int c = pcol[q];
+            T         v = pval[q];
+            ++q;
+            while(q < e && pcol[q] == c)
+                v += pval[q++];
+            pcol[o] = c;
+            pval[o] = v;
+            ++o;
+        }
+        cnt[i] = (int)(o - s);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_mm_compact(int nrow, const long long* __restrict__ off,
+                                                       const int* __restrict__ pcol, const T* __restrict__ pval,
+                                                       const int* __restrict__ crp, int* __restrict__ cci,
+                                                       T* __restrict__ cval)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+    {
+        const long long s = off[i];
+        const int       n = crp[i + 1] - crp[i];
+        for(int k = 0; k < n; ++k)
+        {
+            cci[crp[i] + k]  = pcol[s + k];
+            cval[crp[i] + k] = pval[s + k];
+        }
+    }
+}
+
+static int scan_to_rowptr(int* rp, int nrow, int* total)
+{
+    Backend& b = backend();
+    RAMD_TRY(device_exclusive_scan(rp, rp, (int64_t)nrow + 1));
+    RAMD_HIP(hipMemcpyAsync(total, rp + nrow, sizeof(int), hipMemcpyDeviceToHost, b.cur));
+    RAMD_HIP(hipStreamSynchronize(b.cur));
+    return RAMD_OK;
+}
+
+template <typename T>
+static int matrix_add_t(ramd_mat_s* m, const ramd_mat_s* o, T alpha, T beta, bool structure)
+{
+    Backend&  b    = backend();
+    const int grid = ew_grid(std::max(m->nrow, 1));
+    if(!structure)
+    {
+        if(m->nnz > 0 && o->nnz > 0)
+            hipLaunchKernelGGL((k_add_subset<T>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, m->rp, m->ci, (T*)m->val,
+                               o->rp, o->ci, (const T*)o->val, alpha, beta);
+        RAMD_HIP(hipGetLastError());
+        return RAMD_OK;
+    }
+    int* crp = nullptr;
+    RAMD_TRY(dev_alloc(&crp, (int64_t)m->nrow + 1));
+    hipLaunchKernelGGL(k_union_count, dim3(ew_grid((int64_t)m->nrow + 1)), dim3(kBlock), 0, b.cur, m->nrow, m->rp, m->ci,
+                       o->rp, o->ci, crp);
+    int nnz = 0;
+    int s   = scan_to_rowptr(crp, m->nrow, &nnz);
+    int*  cci = nullptr;
+    void* cv  = nullptr;
+    if(s == RAMD_OK)
+        s = dev_alloc(&cci, nnz);
+    if(s == RAMD_OK && cached_malloc(&cv, (size_t)nnz * sizeof(T) + kPad) != hipSuccess)
+        s = RAMD_ERR_HIP;
+    if(s != RAMD_OK)
+    {
+        dev_free(&crp);
+        dev_free(&cci);
+        return s;
+    }
+    hipLaunchKernelGGL((k_union_fill<T>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, m->rp, m->ci, (const T*)m->val,
+                       o->rp, o->ci, (const T*)o->val, alpha, beta, crp, cci, (T*)cv);
+    hipError_t e = hipGetLastError();
+    if(e == hipSuccess)
+        e = hipStreamSynchronize(b.cur);
+    const int nrow = m->nrow, ncol = m->ncol;
+    mat_free_csr(m);
+    mat_free_analysis(m);
+    m->rp   = crp;
+    m->ci   = cci;
+    m->val  = cv;
+    m->nnz  = nnz;
+    m->nrow = nrow;
+    m->ncol = ncol;
+    RAMD_HIP(e);
+    return RAMD_OK;
+}
+
+template <typename T>
+static int mat_mult_t(ramd_mat_s* c, const ramd_mat_s* a, const ramd_mat_s* bm)
+{
+    Backend&   b    = backend();
+    const int  n    = a->nrow;
+    long long* off  = nullptr;
+    int*       cnt  = nullptr;
+    int*       pcol = nullptr;
+    void*      pval = nullptr;
+    RAMD_TRY(dev_alloc(&off, (int64_t)n + 1));
+    int s = dev_alloc(&cnt, (int64_t)n + 1);
+    if(s == RAMD_OK)
+    {
+        hipLaunchKernelGGL(k_mm_bound, dim3(ew_grid((int64_t)n + 1)), dim3(kBlock), 0, b.cur, n, a->rp, a->ci, bm->rp, off);
+        hipLaunchKernelGGL(k_scan_ll, dim3(1), dim3(kBlock), 0, b.cur, (int64_t)n + 1, off);
+    }
+    long long total = 0;
+    if(s == RAMD_OK)
+    {
+        hipError_t e = hipMemcpyAsync(&total, off + n, sizeof(long long), hipMemcpyDeviceToHost, b.cur);
+        if(e == hipSuccess)
+            e = hipStreamSynchronize(b.cur);
+        if(e != hipSuccess)
+            s = RAMD_ERR_HIP;
+    }
+    if(s == RAMD_OK)
+        s = dev_alloc(&pcol, total);
+    if(s == RAMD_OK && cached_malloc(&pval, (size_t)total * sizeof(T) + kPad) != hipSuccess)
+        s = RAMD_ERR_HIP;
+    int nnz = 0;
+    if(s == RAMD_OK)
+    {
+        hipLaunchKernelGGL((k_mm_products<T>), dim3(ew_grid((int64_t)n + 1)), dim3(kBlock), 0, b.cur, n, a->rp, a->ci,
+                           (const T*)a->val, bm->rp, bm->ci, (const T*)bm->val, off, pcol, (T*)pval, cnt);
+        s = scan_to_rowptr(cnt, n, &nnz);
+    }
+    int*  cci = nullptr;
+    void* cv  = nullptr;
+    if(s == RAMD_OK)
+        s = dev_alloc(&cci, nnz);
+    if(s == RAMD_OK && cached_malloc(&cv, (size_t)nnz * sizeof(T) + kPad) != hipSuccess)
+        s = RAMD_ERR_HIP;
+    if(s == RAMD_OK)
+    {
+        hipLaunchKernelGGL((k_mm_compact<T>), dim3(ew_grid(std::max(n, 1))), dim3(kBlock), 0, b.cur, n, off, pcol,
+                           (const T*)pval, cnt, cci, (T*)cv);
+        hipError_t e = hipGetLastError();
+        if(e == hipSuccess)
+            e = hipStreamSynchronize(b.cur);
+        if(e != hipSuccess)
+            s = RAMD_ERR_HIP;
+    }
+    dev_free(&off);
+    dev_free(&pcol);
+    if(pval)
+        (void)cached_free(pval);
+    if(s != RAMD_OK)
+    {
+        dev_free(&cnt);
+        dev_free(&cci);
+        if(cv)
+            (void)cached_free(cv);
+        return s;
+    }
+    mat_free_csr(c);
+    mat_free_ell(c);
+    mat_free_coo(c);
+    mat_free_dia(c);
+    mat_free_analysis(c);
+    c->format = RAMD_CSR;
+    c->nrow   = a->nrow;
+    c->ncol   = bm->ncol;
+    c->nnz    = nnz;
+    c->rp     = cnt;
+    c->ci     = cci;
+    c->val    = cv;
+    return RAMD_OK;
+}
+
+} // namespace ramd
+
+using namespace ramd;
+
+static int need_csr(const ramd_mat_s* m, const char* what)
+{
+    if(!m)
+        RAMD_FAIL(RAMD_ERR_ARG, "null matrix handle");
+    if(m->format != RAMD_CSR)
+    {
+        (void)what;
+        return RAMD_ERR_UNSUPPORTED; // the front end converts to CSR first (local_matrix.cpp), as for the host backend
+    }
+    return RAMD_OK;
+}
+
+extern "C" {
+
+int ramd_mat_sort(ramd_mat_t m)
+{
+    RAMD_TRY(need_csr(m, "Sort"));
+    if(m->nnz <= 0)
+        return RAMD_OK;
+    Backend&  b    = backend();
+    const int grid = ew_grid(std::max(m->nrow, 1));
+    if(m->dtype == RAMD_F64)
+        hipLaunchKernelGGL((k_sort_rows<double>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, m->rp, m->ci, (double*)m->val);
+    else
+        hipLaunchKernelGGL((k_sort_rows<float>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, m->rp, m->ci, (float*)m->val);
+    RAMD_HIP(hipGetLastError());
+    mat_free_analysis(m);
+    return RAMD_OK;
+}
+
+int ramd_mat_transpose(ramd_mat_t m, ramd_mat_t out)
+{
+    RAMD_TRY(need_csr(m, "Transpose"));
+    if(!out || out == m || out->dtype != m->dtype)
+        RAMD_FAIL(RAMD_ERR_ARG, "Transpose: a distinct output matrix of the same value type expected");
+    if(m->nnz <= 0) // host_matrix_csr.cpp:3765: nothing happens for an empty matrix
+        return RAMD_OK;
+    return mat_transpose(m, out);
+}
+
+int ramd_mat_matrix_add(ramd_mat_t m, ramd_mat_t other, double alpha, double beta, int structure)
+{
+    RAMD_TRY(need_csr(m, "MatrixAdd"));
+    RAMD_TRY(need_csr(other, "MatrixAdd"));
+    if(other == m || other->dtype != m->dtype || other->nrow != m->nrow || other->ncol != m->ncol)
+        RAMD_FAIL(RAMD_ERR_ARG, "MatrixAdd: a second matrix of the same shape and value type expected");
+    if(m->dtype == RAMD_F64)
+        return matrix_add_t<double>(m, other, alpha, beta, structure != 0);
+    return matrix_add_t<float>(m, other, (float)alpha, (float)beta, structure != 0);
+}
+
+int ramd_mat_mat_mult(ramd_mat_t c, ramd_mat_t a, ramd_mat_t b)
+{
+    RAMD_TRY(need_csr(a, "MatrixMult"));
+    RAMD_TRY(need_csr(b, "MatrixMult"));
+    if(!c || c == a || c == b || a->dtype != b->dtype || c->dtype != a->dtype || a->ncol != b->nrow)
+        RAMD_FAIL(RAMD_ERR_ARG, "MatrixMult: C distinct from A and B, A.ncol == B.nrow, one value type");
+    if(a->dtype == RAMD_F64)
+        return mat_mult_t<double>(c, a, b);
+    return mat_mult_t<float>(c, a, b);
+}
+
+} // extern "C"

@@ -23,6 +23,7 @@ void prof_spmv_end();
 
 // trisolve.hip
 void tri_release(ramd_mat_s* m);
+int  mat_transpose(const ramd_mat_s* m, ramd_mat_s* t); // t = m^T, rows sorted
 
 // blocksched.hip: hyperplane order of the row blocks for the natural-order sync-free sweeps (nullptr: natural)
 int block_schedule(const ramd_mat_s* m, bool lower, int** order_out);

@@ -1415,6 +1415,12 @@ static int it_solve_t(ramd_mat_s* m, int kind, int max_iter, double tol, bool us
     }
 }
 
+// matrix_algebra.hip: LocalMatrix::Transpose
+int mat_transpose(const ramd_mat_s* m, ramd_mat_s* t)
+{
+    return (m->dtype == RAMD_F64) ? transpose_into<double>(m, t) : transpose_into<float>(m, t);
+}
+
 } // namespace ramd
 
 using namespace ramd;

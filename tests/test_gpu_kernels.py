@@ -147,6 +147,44 @@ def test_spmv_all_formats_vs_golden(ra, name):
 
 
 @pytest.mark.parametrize("name", CASES)
+def test_csr_matrix_algebra_vs_golden(ra, name):
+    """Transpose, MatrixMult (A * A^T), MatrixAdd with subset and union patterns: arrays bit-exact vs the genuine library"""
+    g = load_golden(name)
+    A = _mat(ra, g)
+
+    def check(M, tag):
+        rp, ci, va = M.CopyToCSR()
+        eq(rp, g[tag + "_rowptr"]); eq(ci, g[tag + "_col"]); eq(va, g[tag + "_val"])
+
+    T = ra.LocalMatrix(); T.CloneFrom(A); T.Transpose()
+    check(T, "alg_transpose")
+    T2 = ra.LocalMatrix(); A.Transpose(T2)
+    check(T2, "alg_transpose")
+    AA = ra.LocalMatrix(); AA.MatrixMult(A, T)
+    check(AA, "alg_matmult")
+    S_ = ra.LocalMatrix(); S_.CloneFrom(AA); S_.MatrixAdd(A, 0.5, -2.0, False)
+    check(S_, "alg_add_subset")
+    U = ra.LocalMatrix(); U.CloneFrom(A); U.MatrixAdd(AA, 1.5, 0.25, True)
+    check(U, "alg_add_union")
+    # Sort: rows scrambled on the host come back sorted, values following their columns
+    rp, ci, va = g["rowptr"], g["col"].copy(), g["val"].copy()
+    rng = np.random.default_rng(5)
+    for i in range(len(rp) - 1):
+        p = rng.permutation(rp[i + 1] - rp[i]) + rp[i]
+        ci[rp[i]:rp[i + 1]] = ci[p]; va[rp[i]:rp[i + 1]] = va[p]
+    B = ra.LocalMatrix(); B.SetDataPtrCSR(rp, ci, va); B.Sort()
+    brp, bci, bva = B.CopyToCSR()
+    eq(bci, g["col"]); eq(bva, g["val"])
+    # y = (A A^T) x through the product equals A (A^T x) to round-off
+    n = len(rp) - 1
+    x = ra.LocalVector(data=g["x"])
+    y1 = ra.LocalVector(); y1.Allocate("", n); AA.Apply(x, y1)
+    t = ra.LocalVector(); t.Allocate("", n); T.Apply(x, t)
+    y2 = ra.LocalVector(); y2.Allocate("", n); A.Apply(t, y2)
+    assert np.allclose(y1.numpy(), y2.numpy(), rtol=1e-12, atol=1e-10 * np.max(np.abs(y2.numpy())))
+
+
+@pytest.mark.parametrize("name", CASES)
 def test_dia_format_vs_golden(ra, name):
     """CSR -> DIA (diagonals, offsets, padded values), DIA SpMV (the padded zeros are multiplied, as on the host),
     DIA -> CSR (stored zeros dropped), fused Apply+dot, and the refusal rule -- all against the genuine library"""

@@ -100,6 +100,26 @@ def test_dia_conversion_and_spmv(oracle, name):
     eq(brp, g["dia_back_rowptr"]); eq(bci, g["dia_back_col"]); eq(bva, g["dia_back_val"])
 
 
+@pytest.mark.parametrize("name", KERNEL_CASES)
+def test_csr_matrix_algebra(oracle, name):
+    """Transpose, A*A^T, MatrixAdd with a subset pattern and with the union pattern (host_matrix_csr.cpp)"""
+    g = load_golden(name)
+    rp, ci, va, x, y = _inputs(name, g)
+    A = (rp, ci, va)
+    t = oracle.csr_transpose(rp, ci, va)
+    for got, key in zip(t, ("rowptr", "col", "val")):
+        eq(got, g["alg_transpose_" + key])
+    aa = oracle.csr_matmult(A, t)
+    for got, key in zip(aa, ("rowptr", "col", "val")):
+        eq(got, g["alg_matmult_" + key])
+    sub = oracle.csr_matrix_add(aa, A, 0.5, -2.0, False)
+    for got, key in zip(sub, ("rowptr", "col", "val")):
+        eq(got, g["alg_add_subset_" + key])
+    uni = oracle.csr_matrix_add(A, aa, 1.5, 0.25, True)
+    for got, key in zip(uni, ("rowptr", "col", "val")):
+        eq(got, g["alg_add_union_" + key])
+
+
 def test_ell_refusal_case_present():
     # rand300 has rows 12x longer than average: the reference must have refused ELL there
     assert int(load_golden("rand300")["ell_format"][0]) != 6
