@@ -428,6 +428,12 @@ public:
     {
         this->is_smoother_ = true;
     }
+    // true: Solve() runs reductions of its own (nested Krylov solvers, multigrid cycles), i.e. it overwrites the
+    // device scalar record -- an outer fused loop that keeps alpha/beta/rho there across the call must not be used
+    virtual bool SolveUsesScalarRecord(void) const
+    {
+        return true;
+    }
     // solver.cpp:293-301: the strategy cannot change once the solver is built
     virtual void SetSolverDescriptor(const SolverDescr& descr)
     {
@@ -454,6 +460,10 @@ public:
     virtual void SolveZeroSol(const VectorType& rhs, VectorType* x)
     {
         this->Solve(rhs, x);
+    }
+    virtual bool SolveUsesScalarRecord(void) const // sweeps / triangular solves / SpMV only
+    {
+        return false;
     }
 };
 
@@ -1501,6 +1511,8 @@ private:
         if(jac != NULL && jac->GetInverseDiagonal().GetSize() == r->GetSize())
             dinv = _fh(jac->GetInverseDiagonal());
         const bool  generic_pc = precond && dinv == NULL;
+        if(generic_pc && this->precond_->SolveUsesScalarRecord())
+            return false; // e.g. a multigrid cycle as preconditioner: the plain loop keeps its scalars on the host
         VectorType* zdir       = precond ? z : r;
 
         // scalar slots: <p,q> = 0, ||r||^2 = 2, rho alternates between 1 and 3 (always adjacent to
@@ -1935,6 +1947,8 @@ private:
     {
         if(!this->op_->is_accel_() || !x->is_accel_())
             return false;
+        if(precond && this->precond_->SolveUsesScalarRecord())
+            return false; // a preconditioner with reductions of its own would overwrite alpha / omega / rho on the device
         const OperatorType& A = *this->op_;
         VectorType *r = &this->r_, *r0 = &this->r0_, *p = &this->p_, *q = &this->q_, *t = &this->t_;
         VectorType *v = &this->v_, *z = &this->z_;
@@ -3306,6 +3320,434 @@ private:
     OperatorTypeL*                                  op_l_;
     VectorTypeH                                     r_h_, d_h_;
     VectorTypeL                                     r_l_, d_l_;
+};
+
+// ============================================================================ multigrid
+// BaseMultiGrid (src/solvers/multigrid/base_multigrid.cpp): V / W / K cycles over a user- or AMG-built hierarchy of
+// operators, restriction / prolongation operators, per-level smoothers and a coarse solver; optional scaling of the
+// coarse correction (:790-812, :873-905).  Host levels (SetHostLevels) do not exist here: every level lives on the GPU.
+enum _cycle
+{
+    Vcycle = 0,
+    Wcycle = 1,
+    Kcycle = 2,
+    Fcycle = 3
+};
+
+template <class OperatorType, class VectorType, typename ValueType>
+class BaseMultiGrid : public IterativeLinearSolver<OperatorType, VectorType, ValueType>
+{
+public:
+    BaseMultiGrid()
+        : levels_(-1)
+        , current_level_(0)
+        , scaling_(false)
+        , iter_pre_smooth_(1)
+        , iter_post_smooth_(1)
+        , cycle_(Vcycle)
+        , kcycle_full_(true)
+        , op_level_(NULL)
+        , restrict_op_level_(NULL)
+        , prolong_op_level_(NULL)
+        , d_level_(NULL)
+        , r_level_(NULL)
+        , t_level_(NULL)
+        , s_level_(NULL)
+        , q_level_(NULL)
+        , solver_coarse_(NULL)
+        , smoother_level_(NULL)
+        , res_norm_(static_cast<ValueType>(0))
+    {
+    }
+    virtual ~BaseMultiGrid()
+    {
+        this->Clear();
+    }
+    virtual void InitLevels(int levels)
+    {
+        assert(this->build_ == false && levels > 0);
+        this->levels_ = levels;
+    }
+    virtual void SetPreconditioner(Solver<OperatorType, VectorType, ValueType>&)
+    {
+        LOG_INFO("BaseMultiGrid::SetPreconditioner() Perhaps you want to set the smoothers on all levels? use "
+                 "SetSmootherLevel() instead of SetPreconditioner!");
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+    virtual void SetSmoother(IterativeLinearSolver<OperatorType, VectorType, ValueType>** smoother)
+    {
+        assert(smoother != NULL);
+        this->smoother_level_ = smoother;
+    }
+    virtual void SetSmootherPreIter(int iter)
+    {
+        this->iter_pre_smooth_ = iter;
+    }
+    virtual void SetSmootherPostIter(int iter)
+    {
+        this->iter_post_smooth_ = iter;
+    }
+    virtual void SetSolver(Solver<OperatorType, VectorType, ValueType>& solver)
+    {
+        this->solver_coarse_ = &solver;
+    }
+    virtual void SetScaling(bool scaling)
+    {
+        if(this->build_ == false) // needs extra storage: before Build only (base_multigrid.cpp:144-158)
+            this->scaling_ = scaling;
+    }
+    virtual void SetHostLevels(int)
+    {
+        LOG_INFO("BaseMultiGrid::SetHostLevels(): this backend keeps every level on the accelerator");
+    }
+    virtual void SetCycle(unsigned int cycle)
+    {
+        this->cycle_ = cycle;
+    }
+    virtual void SetKcycleFull(bool kcycle_full)
+    {
+        this->kcycle_full_ = kcycle_full;
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("MultiGrid solver");
+    }
+    virtual void Build(void)
+    {
+        if(this->build_)
+            this->Clear();
+        for(int i = 0; i < this->levels_ - 1; ++i)
+            assert(this->op_level_[i] != NULL && this->smoother_level_[i] != NULL && this->restrict_op_level_[i] != NULL
+                   && this->prolong_op_level_[i] != NULL);
+        assert(this->op_ != NULL && this->solver_coarse_ != NULL && this->levels_ > 0);
+        this->Initialize();
+        this->build_ = true;
+    }
+    virtual void Clear(void)
+    {
+        if(this->build_)
+        {
+            this->Finalize();
+            this->levels_ = -1;
+            this->build_  = false;
+        }
+    }
+
+protected:
+    // base_multigrid.cpp:219-311
+    virtual void Initialize(void)
+    {
+        assert(this->build_ == false && this->smoother_level_ != NULL);
+        this->smoother_level_[0]->SetOperator(*this->op_);
+        this->smoother_level_[0]->Build();
+        this->smoother_level_[0]->FlagSmoother();
+        for(int i = 1; i < this->levels_ - 1; ++i)
+        {
+            this->smoother_level_[i]->SetOperator(*this->op_level_[i - 1]);
+            this->smoother_level_[i]->Build();
+            this->smoother_level_[i]->FlagSmoother();
+        }
+        this->solver_coarse_->SetOperator(*this->op_level_[this->levels_ - 2]);
+        this->solver_coarse_->Build();
+        this->d_level_ = new VectorType*[this->levels_];
+        this->r_level_ = new VectorType*[this->levels_];
+        this->t_level_ = new VectorType*[this->levels_];
+        this->d_level_[0] = NULL;
+        if(this->scaling_)
+        {
+            this->s_level_ = new VectorType*[this->levels_];
+            for(int i = 0; i < this->levels_; ++i)
+                this->s_level_[i] = this->new_vec_(i, "temporary");
+        }
+        if(this->cycle_ == Kcycle)
+        {
+            this->q_level_ = new VectorType*[this->levels_ > 2 ? this->levels_ - 2 : 1];
+            for(int i = 0; i < this->levels_ - 2; ++i)
+                this->q_level_[i] = this->new_vec_(i + 1, "q");
+        }
+        for(int i = 1; i < this->levels_; ++i)
+        {
+            this->d_level_[i] = this->new_vec_(i, "defect correction");
+            this->r_level_[i] = this->new_vec_(i, "residual");
+            this->t_level_[i] = this->new_vec_(i, "temporary");
+        }
+        this->r_level_[0] = this->new_vec_(0, "residual");
+        this->t_level_[0] = this->new_vec_(0, "temporary");
+    }
+    // base_multigrid.cpp:360-425
+    virtual void Finalize(void)
+    {
+        for(int i = 0; i < this->levels_; ++i)
+        {
+            if(i > 0 && this->d_level_)
+                delete this->d_level_[i];
+            if(this->r_level_)
+                delete this->r_level_[i];
+            if(this->t_level_)
+                delete this->t_level_[i];
+            if(this->s_level_)
+                delete this->s_level_[i];
+        }
+        if(this->q_level_)
+            for(int i = 0; i < this->levels_ - 2; ++i)
+                delete this->q_level_[i];
+        delete[] this->d_level_;
+        delete[] this->r_level_;
+        delete[] this->t_level_;
+        delete[] this->s_level_;
+        delete[] this->q_level_;
+        this->d_level_ = this->r_level_ = this->t_level_ = this->s_level_ = this->q_level_ = NULL;
+        for(int i = 0; i < this->levels_ - 1; ++i)
+            this->smoother_level_[i]->Clear();
+        this->solver_coarse_->Clear();
+        this->iter_ctrl_.Clear();
+    }
+
+public:
+    // base_multigrid.cpp:605-699
+    virtual void Solve(const VectorType& rhs, VectorType* x)
+    {
+        assert(this->levels_ > 1 && x != NULL && x != &rhs && this->op_ != NULL && this->build_ == true);
+        assert(this->precond_ == NULL && this->solver_coarse_ != NULL);
+        if(this->verb_ > 0)
+        {
+            this->PrintStart_();
+            this->iter_ctrl_.PrintInit();
+        }
+        if(this->is_precond_ == false)
+        {
+            this->op_->Apply(*x, this->r_level_[0]);
+            this->r_level_[0]->ScaleAdd(static_cast<ValueType>(-1), rhs);
+            this->res_norm_ = std::abs(this->Norm_(*this->r_level_[0]));
+            if(this->iter_ctrl_.InitResidual(this->res_norm_) == false)
+                return;
+        }
+        else
+            this->iter_ctrl_.InitResidual(1.0);
+        this->Vcycle_(rhs, x);
+        if(this->is_precond_ == false)
+            while(!this->iter_ctrl_.CheckResidual(this->res_norm_, this->index_))
+                this->Vcycle_(rhs, x);
+        if(this->verb_ > 0)
+        {
+            this->iter_ctrl_.PrintStatus();
+            this->PrintEnd_();
+        }
+    }
+
+protected:
+    virtual void PrintStart_(void) const
+    {
+        assert(this->levels_ > 0);
+        LOG_INFO("MultiGrid solver starts");
+        LOG_INFO("MultiGrid Number of levels " << this->levels_);
+    }
+    virtual void PrintEnd_(void) const
+    {
+        LOG_INFO("MultiGrid ends");
+    }
+    virtual void SolveNonPrecond_(const VectorType&, VectorType*)
+    {
+        LOG_INFO("BaseMultiGrid:SolveNonPrecond_() this function is disabled");
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+    virtual void SolvePrecond_(const VectorType&, VectorType*)
+    {
+        LOG_INFO("BaseMultiGrid:SolvePrecond_() this function is disabled");
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+    virtual void Restrict_(const VectorType& fine, VectorType* coarse)
+    {
+        this->restrict_op_level_[this->current_level_]->Apply(fine, coarse);
+    }
+    virtual void Prolong_(const VectorType& coarse, VectorType* fine)
+    {
+        this->prolong_op_level_[this->current_level_]->Apply(coarse, fine);
+    }
+    // base_multigrid.cpp:720-916
+    void Vcycle_(const VectorType& rhs, VectorType* x)
+    {
+        if(this->current_level_ == this->levels_ - 1)
+        {
+            this->solver_coarse_->SolveZeroSol(rhs, x);
+            return;
+        }
+        IterativeLinearSolver<OperatorType, VectorType, ValueType>* smoother = this->smoother_level_[this->current_level_];
+        const OperatorType* op = (this->current_level_ == 0) ? this->op_ : this->op_level_[this->current_level_ - 1];
+        VectorType*         r  = this->r_level_[this->current_level_];
+        VectorType*         rc = this->t_level_[this->current_level_ + 1];
+        VectorType*         rf = this->t_level_[this->current_level_];
+        VectorType*         xc = this->d_level_[this->current_level_ + 1];
+        VectorType*         s  = (this->scaling_) ? this->s_level_[this->current_level_] : NULL;
+        ValueType           factor, divisor;
+        smoother->InitMaxIter(this->iter_pre_smooth_);
+        if(this->is_precond_ || this->current_level_ != 0)
+            smoother->SolveZeroSol(rhs, x);
+        else
+            smoother->Solve(rhs, x);
+        if(this->scaling_ == true)
+            if(this->current_level_ > 0 && this->current_level_ < this->levels_ - 2 && this->iter_pre_smooth_ > 0)
+            {
+                s->PointWiseMult(rhs, *x);
+                factor = s->Reduce();
+                op->Apply(*x, s);
+                s->PointWiseMult(*x);
+                divisor = s->Reduce();
+                if(divisor == static_cast<ValueType>(0))
+                    factor = static_cast<ValueType>(1);
+                else
+                    factor /= divisor;
+                x->Scale(factor);
+            }
+        op->Apply(*x, r);
+        r->ScaleAdd(static_cast<ValueType>(-1), rhs);
+        if(this->scaling_ && this->current_level_ == 0)
+            s->CopyFrom(*r);
+        this->Restrict_(*r, rc);
+        ++this->current_level_;
+        switch(this->cycle_)
+        {
+        case Vcycle: this->Vcycle_(*rc, xc); break;
+        case Wcycle: this->Wcycle_(*rc, xc); break;
+        case Kcycle: this->Kcycle_(*rc, xc); break;
+        case Fcycle: this->Fcycle_(*rc, xc); break;
+        default: FATAL_ERROR(__FILE__, __LINE__); break;
+        }
+        --this->current_level_;
+        this->Prolong_(*xc, r);
+        if(this->scaling_ == true && this->current_level_ < this->levels_ - 2)
+        {
+            if(this->current_level_ == 0)
+                s->PointWiseMult(*r);
+            else
+                s->PointWiseMult(*r, *rf);
+            factor = s->Reduce();
+            op->Apply(*r, s);
+            s->PointWiseMult(*r);
+            divisor = s->Reduce();
+            if(divisor == static_cast<ValueType>(0))
+                factor = static_cast<ValueType>(1);
+            else
+                factor /= divisor;
+            x->AddScale(*r, factor);
+        }
+        else
+            x->AddScale(*r, static_cast<ValueType>(1));
+        smoother->InitMaxIter(this->iter_post_smooth_);
+        smoother->Solve(rhs, x);
+        if(this->current_level_ == 0 && this->is_precond_ == false)
+        {
+            op->Apply(*x, r);
+            r->ScaleAdd(static_cast<ValueType>(-1), rhs);
+            this->res_norm_ = std::abs(this->Norm_(*r));
+        }
+    }
+    void Wcycle_(const VectorType& rhs, VectorType* x)
+    {
+        for(int i = 0; i < 2; ++i) // gamma = 2 hardcoded (base_multigrid.cpp:919-927)
+            this->Vcycle_(rhs, x);
+    }
+    void Fcycle_(const VectorType&, VectorType*)
+    {
+        LOG_INFO("BaseMultiGrid:Fcycle_() not implemented yet"); // nor in the reference (:930-935)
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+    // base_multigrid.cpp:938-1011: two steps of CG around the cycle on the coarse levels
+    void Kcycle_(const VectorType& rhs, VectorType* x)
+    {
+        if(this->current_level_ != 1 && this->kcycle_full_ == false)
+            this->Vcycle_(rhs, x);
+        else if(this->current_level_ < this->levels_ - 1)
+        {
+            VectorType*         q  = this->q_level_[this->current_level_ - 1];
+            VectorType*         r  = this->t_level_[this->current_level_];
+            const OperatorType* op = this->op_level_[this->current_level_ - 1];
+            ValueType           rho, rho_old, alpha;
+            this->Vcycle_(rhs, x);
+            if(r != &rhs)
+                r->CopyFrom(rhs);
+            rho = r->DotNonConj(*x);
+            op->Apply(*x, q);
+            alpha = rho / x->DotNonConj(*q);
+            r->AddScale(*q, -alpha);
+            this->Vcycle_(*r, q);
+            rho_old = rho;
+            rho     = r->DotNonConj(*q);
+            r->CopyFrom(*x);
+            r->ScaleAdd(rho / rho_old, *q);
+            op->Apply(*r, q);
+            x->Scale(alpha);
+            alpha = rho / r->DotNonConj(*q);
+            x->AddScale(*r, alpha);
+        }
+        else
+            this->solver_coarse_->SolveZeroSol(rhs, x);
+    }
+    VectorType* new_vec_(int level, const char* name)
+    {
+        const OperatorType* op = (level == 0) ? this->op_ : this->op_level_[level - 1];
+        VectorType*         v  = new VectorType;
+        v->CloneBackend(*op);
+        v->Allocate(name, op->GetM());
+        return v;
+    }
+
+    int          levels_;
+    int          current_level_;
+    bool         scaling_;
+    int          iter_pre_smooth_;
+    int          iter_post_smooth_;
+    unsigned int cycle_;
+    bool         kcycle_full_;
+    OperatorType** op_level_; // [levels-1]: operators of levels 1 .. levels-1 (level 0 is op_)
+    OperatorType** restrict_op_level_;
+    OperatorType** prolong_op_level_;
+    VectorType**   d_level_;
+    VectorType**   r_level_;
+    VectorType**   t_level_;
+    VectorType**   s_level_;
+    VectorType**   q_level_;
+    Solver<OperatorType, VectorType, ValueType>*                 solver_coarse_;
+    IterativeLinearSolver<OperatorType, VectorType, ValueType>** smoother_level_;
+    ValueType                                                    res_norm_;
+};
+
+// MultiGrid (src/solvers/multigrid/multigrid.cpp): the hierarchy is handed in by the user; scaling on by default
+template <class OperatorType, class VectorType, typename ValueType>
+class MultiGrid : public BaseMultiGrid<OperatorType, VectorType, ValueType>
+{
+public:
+    MultiGrid()
+    {
+        this->scaling_ = true;
+    }
+    virtual ~MultiGrid()
+    {
+        this->Clear();
+        delete[] this->restrict_op_level_;
+        delete[] this->prolong_op_level_;
+    }
+    virtual void SetRestrictOperator(OperatorType** op)
+    {
+        assert(this->build_ == false && op != NULL && this->levels_ > 0);
+        delete[] this->restrict_op_level_;
+        this->restrict_op_level_ = new OperatorType*[this->levels_];
+        for(int i = 0; i < this->levels_ - 1; ++i)
+            this->restrict_op_level_[i] = op[i];
+    }
+    virtual void SetProlongOperator(OperatorType** op)
+    {
+        assert(this->build_ == false && op != NULL && this->levels_ > 0);
+        delete[] this->prolong_op_level_;
+        this->prolong_op_level_ = new OperatorType*[this->levels_];
+        for(int i = 0; i < this->levels_ - 1; ++i)
+            this->prolong_op_level_[i] = op[i];
+    }
+    virtual void SetOperatorHierarchy(OperatorType** op)
+    {
+        assert(this->build_ == false && op != NULL);
+        this->op_level_ = op;
+    }
 };
 
 } // namespace rocalution

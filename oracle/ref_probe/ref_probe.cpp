@@ -834,6 +834,96 @@ static int cmd_gen(const std::string& in, const std::string& out)
             ls.Clear();
         }
         {
+            // --- MultiGrid on a 3-level hierarchy built by pairing consecutive rows: P[i, i/2] = 1, R = P^T,
+            //     Galerkin coarse operators R A P through MatrixMult.  FixedPoint(0.7)+Jacobi smoothers (2 pre, 1 post),
+            //     CG on the coarsest level.  mg_v: V-cycle with scaling (the MultiGrid default) as a solver;
+            //     mg_w: W-cycle, no scaling; cg_mgk: CG preconditioned by a K-cycle.
+            auto pair_prolong = [](int nf, MatD& P) {
+                int     nc = (nf + 1) / 2;
+                int*    rp = new int[nf + 1];
+                int*    ci = new int[nf];
+                double* va = new double[nf];
+                for(int i = 0; i < nf; ++i)
+                {
+                    rp[i] = i;
+                    ci[i] = i / 2;
+                    va[i] = 1.0;
+                }
+                rp[nf] = nf;
+                P.SetDataPtrCSR(&rp, &ci, &va, "P", nf, nf, nc);
+            };
+            MatD P0, R0, A1, P1, R1, A2, tmp;
+            int  n0 = (int)A.n, n1 = (n0 + 1) / 2;
+            pair_prolong(n0, P0);
+            P0.Transpose(&R0);
+            tmp.MatrixMult(mat, P0);
+            A1.MatrixMult(R0, tmp);
+            pair_prolong(n1, P1);
+            P1.Transpose(&R1);
+            tmp.Clear();
+            tmp.MatrixMult(A1, P1);
+            A2.MatrixMult(R1, tmp);
+            dump_csr("mg_A2", A2);
+            MatD* ops[2] = {&A1, &A2};
+            MatD* res[2] = {&R0, &R1};
+            MatD* pro[2] = {&P0, &P1};
+            for(int variant = 0; variant < 3; ++variant)
+            {
+                // heap objects that are never cleared or destroyed: the installed library's BaseMultiGrid::Finalize
+                // walks an array only the AMG classes allocate and crashes for a user-built MultiGrid
+                MultiGrid<MatD, VecD, double>&  mg     = *new MultiGrid<MatD, VecD, double>;
+                FixedPoint<MatD, VecD, double>* fp     = new FixedPoint<MatD, VecD, double>[2];
+                Jacobi<MatD, VecD, double>*     jac    = new Jacobi<MatD, VecD, double>[2];
+                CG<MatD, VecD, double>&         coarse = *new CG<MatD, VecD, double>;
+                IterativeLinearSolver<MatD, VecD, double>** sm = new IterativeLinearSolver<MatD, VecD, double>*[2];
+                for(int l = 0; l < 2; ++l)
+                {
+                    fp[l].SetRelaxation(0.7);
+                    fp[l].SetPreconditioner(jac[l]);
+                    fp[l].Verbose(0);
+                    sm[l] = &fp[l];
+                }
+                coarse.Verbose(0);
+                mg.SetOperator(mat);
+                mg.InitLevels(3);
+                mg.SetOperatorHierarchy(ops);
+                mg.SetRestrictOperator(res);
+                mg.SetProlongOperator(pro);
+                mg.SetSmoother(sm);
+                mg.SetSmootherPreIter(2);
+                mg.SetSmootherPostIter(1);
+                mg.SetSolver(coarse);
+                if(variant == 0)
+                {
+                    mg.InitMaxIter(40);
+                    mg.Build();
+                    sol.Zeros();
+                    run_solver("mg_v", mg, rhs, sol);
+                }
+                else if(variant == 1)
+                {
+                    mg.SetScaling(false);
+                    mg.SetCycle(Wcycle);
+                    mg.InitMaxIter(40);
+                    mg.Build();
+                    sol.Zeros();
+                    run_solver("mg_w", mg, rhs, sol);
+                }
+                else
+                {
+                    mg.SetCycle(Kcycle);
+                    mg.Verbose(0);
+                    CG<MatD, VecD, double>& ls = *new CG<MatD, VecD, double>;
+                    ls.SetOperator(mat);
+                    ls.SetPreconditioner(mg);
+                    ls.InitMaxIter(60);
+                    ls.Build();
+                    sol.Zeros();
+                    run_solver("cg_mgk", ls, rhs, sol);
+                }
+            }
+        }
+        {
             // mixed precision: fp64 defect correction around fp32 CG+Jacobi with the sample's
             // inner tolerances (clients/samples/mixed-precision.cpp:85)
             MixedPrecisionDC<MatD, VecD, double, MatF, VecF, float> mp;
