@@ -1169,6 +1169,38 @@ public:
         this->MoveToAccelerator();
         RAMD_CHECK(ramd_mat_mat_mult(this->dev_, A.dev_, B.dev_));
     }
+    // this = R * A * P as (R * A) * P, two MatrixMult (local_matrix.cpp:5515-5594)
+    void TripleMatrixProduct(const LocalMatrix<ValueType>& R, const LocalMatrix<ValueType>& A,
+                             const LocalMatrix<ValueType>& P)
+    {
+        assert(&R != this && &A != this && &P != this);
+        LocalMatrix<ValueType> tmp;
+        tmp.CloneBackend(*this);
+        tmp.MatrixMult(R, A);
+        this->MatrixMult(tmp, P);
+    }
+    // ---- unsmoothed-aggregation AMG setup, CoarseningStrategy PMIS (local_matrix.cpp:6519-6640, :6852-6930).
+    // Element type of the index vectors: int (the reference: LocalVector<bool> / LocalVector<int64_t>).
+    void AMGPMISAggregate(ValueType eps, LocalVector<int>* connections, LocalVector<int>* aggregates,
+                          LocalVector<int>* aggregate_root_nodes) const
+    {
+        this->need_accel_("AMGPMISAggregate");
+        assert(connections != NULL && aggregates != NULL && aggregate_root_nodes != NULL);
+        connections->MoveToAccelerator();
+        aggregates->MoveToAccelerator();
+        aggregate_root_nodes->MoveToAccelerator();
+        RAMD_CHECK(ramd_mat_amg_pmis_aggregate(this->dev_, (double)eps, connections->handle(), aggregates->handle(),
+                                               aggregate_root_nodes->handle()));
+    }
+    void AMGUnsmoothedAggregation(const LocalVector<int>& aggregates, const LocalVector<int>& aggregate_root_nodes,
+                                  LocalMatrix<ValueType>* prolong) const
+    {
+        this->need_accel_("AMGUnsmoothedAggregation");
+        assert(prolong != NULL && prolong != this);
+        prolong->MoveToAccelerator();
+        RAMD_CHECK(ramd_mat_amg_unsmoothed_prolong(this->dev_, aggregates.handle(), aggregate_root_nodes.handle(),
+                                                   prolong->dev_));
+    }
     // TriSolverAlg_Iterative: Jacobi-sweep triangular solves (local_matrix.cpp ItLU* / ItLL* / ItL* / ItU*)
     void ItLUAnalyse(void)
     {

@@ -3750,4 +3750,286 @@ public:
     }
 };
 
+// ============================================================================ AMG
+// BaseAMG (src/solvers/multigrid/base_amg.cpp): builds the hierarchy level by level through Aggregate_ until the
+// coarse operator has at most coarse_size_ rows; default smoothers FixedPoint(2/3) + Jacobi, default coarse solver
+// CG(0, 1e-6, 1e8, 1000).
+typedef enum _coarsening_strategy
+{
+    Greedy = 0,
+    PMIS   = 1
+} CoarseningStrategy;
+
+template <class OperatorType, class VectorType, typename ValueType>
+class BaseAMG : public BaseMultiGrid<OperatorType, VectorType, ValueType>
+{
+public:
+    BaseAMG()
+        : coarse_size_(300)
+        , set_sm_(false)
+        , set_s_(false)
+        , hierarchy_(false)
+        , op_format_(CSR)
+        , sm_default_(NULL)
+    {
+    }
+    virtual ~BaseAMG()
+    {
+        this->Clear();
+    }
+    virtual void SetCoarsestLevel(int coarse_size)
+    {
+        this->coarse_size_ = coarse_size;
+    }
+    virtual void SetManualSmoothers(bool sm_manual)
+    {
+        this->set_sm_ = sm_manual;
+    }
+    virtual void SetManualSolver(bool s_manual)
+    {
+        this->set_s_ = s_manual;
+    }
+    virtual void SetOperatorFormat(unsigned int op_format, int op_blockdim = 1)
+    {
+        (void)op_blockdim;
+        this->op_format_ = op_format;
+    }
+    virtual int GetNumLevels(void)
+    {
+        return this->levels_;
+    }
+    // base_amg.cpp:119-170
+    virtual void Build(void)
+    {
+        if(this->build_)
+            this->Clear();
+        this->BuildHierarchy();
+        if(this->set_sm_ == false)
+            this->BuildSmoothers();
+        if(this->set_s_ == false)
+        {
+            CG<OperatorType, VectorType, ValueType>* cgs = new CG<OperatorType, VectorType, ValueType>;
+            cgs->Init(0.0, 1e-6, 1e+8, 1000);
+            cgs->Verbose(0);
+            this->solver_coarse_ = cgs;
+        }
+        this->Initialize();
+        if(this->op_format_ != CSR)
+            for(int i = 0; i < this->levels_ - 1; ++i)
+                this->op_level_[i]->ConvertTo(this->op_format_);
+        this->build_ = true;
+    }
+    // base_amg.cpp:173-310
+    virtual void BuildHierarchy(void)
+    {
+        if(this->hierarchy_)
+            return;
+        this->hierarchy_ = true;
+        if(this->op_->GetM() <= static_cast<int64_t>(this->coarse_size_))
+        {
+            LOG_INFO("Problem size too small for AMG, use Krylov solver instead");
+            FATAL_ERROR(__FILE__, __LINE__);
+        }
+        std::vector<OperatorType*> ops, res, pro;
+        this->levels_ = 1;
+        const OperatorType* prev = this->op_;
+        while(true)
+        {
+            OperatorType* c = new OperatorType;
+            OperatorType* r = new OperatorType;
+            OperatorType* p = new OperatorType;
+            c->CloneBackend(*this->op_);
+            r->CloneBackend(*this->op_);
+            p->CloneBackend(*this->op_);
+            const bool ok = this->Aggregate_(*prev, p, r, c);
+            if(!ok)
+            {
+                delete c;
+                delete r;
+                delete p;
+                if(ops.empty())
+                {
+                    LOG_INFO("Could not build initial AMG level");
+                    FATAL_ERROR(__FILE__, __LINE__);
+                }
+                break;
+            }
+            ops.push_back(c);
+            res.push_back(r);
+            pro.push_back(p);
+            ++this->levels_;
+            prev = c;
+            if(!(c->GetM() > static_cast<int64_t>(this->coarse_size_)))
+                break;
+        }
+        this->op_level_          = new OperatorType*[this->levels_ - 1];
+        this->restrict_op_level_ = new OperatorType*[this->levels_ - 1];
+        this->prolong_op_level_  = new OperatorType*[this->levels_ - 1];
+        for(int i = 0; i < this->levels_ - 1; ++i)
+        {
+            this->op_level_[i]          = ops[i];
+            this->restrict_op_level_[i] = res[i];
+            this->prolong_op_level_[i]  = pro[i];
+        }
+    }
+    // base_amg.cpp:313-338
+    virtual void BuildSmoothers(void)
+    {
+        this->smoother_level_ = new IterativeLinearSolver<OperatorType, VectorType, ValueType>*[this->levels_ - 1];
+        this->sm_default_     = new Solver<OperatorType, VectorType, ValueType>*[this->levels_ - 1];
+        for(int i = 0; i < this->levels_ - 1; ++i)
+        {
+            FixedPoint<OperatorType, VectorType, ValueType>* sm  = new FixedPoint<OperatorType, VectorType, ValueType>;
+            Jacobi<OperatorType, VectorType, ValueType>*     jac = new Jacobi<OperatorType, VectorType, ValueType>;
+            sm->SetRelaxation(static_cast<ValueType>(2.f / 3.f));
+            sm->SetPreconditioner(*jac);
+            sm->Verbose(0);
+            this->smoother_level_[i] = sm;
+            this->sm_default_[i]     = jac;
+        }
+    }
+    // base_amg.cpp:341-395
+    virtual void Clear(void)
+    {
+        if(this->build_)
+        {
+            this->Finalize();
+            for(int i = 0; i < this->levels_ - 1; ++i)
+            {
+                delete this->op_level_[i];
+                delete this->restrict_op_level_[i];
+                delete this->prolong_op_level_[i];
+            }
+            delete[] this->op_level_;
+            delete[] this->restrict_op_level_;
+            delete[] this->prolong_op_level_;
+            this->op_level_ = this->restrict_op_level_ = this->prolong_op_level_ = NULL;
+            if(this->set_sm_ == false)
+            {
+                for(int i = 0; i < this->levels_ - 1; ++i)
+                {
+                    delete this->smoother_level_[i];
+                    delete this->sm_default_[i];
+                }
+                delete[] this->smoother_level_;
+                delete[] this->sm_default_;
+                this->smoother_level_ = NULL;
+                this->sm_default_     = NULL;
+            }
+            if(this->set_s_ == false)
+            {
+                delete this->solver_coarse_;
+                this->solver_coarse_ = NULL;
+            }
+            this->levels_    = -1;
+            this->build_     = false;
+            this->hierarchy_ = false;
+        }
+    }
+    virtual void SetRestrictOperator(OperatorType**)
+    {
+        LOG_INFO("BaseAMG::SetRestrictOperator() Perhaps you want to use the MultiGrid class to set external "
+                 "restriction operators");
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+    virtual void SetProlongOperator(OperatorType**)
+    {
+        LOG_INFO("BaseAMG::SetProlongOperator() Perhaps you want to use the MultiGrid class to set external "
+                 "prolongation operators");
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+    virtual void SetOperatorHierarchy(OperatorType**)
+    {
+        LOG_INFO("BaseAMG::SetOperatorHierarchy() Perhaps you want to use the MultiGrid class to set external operators");
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
+
+protected:
+    virtual bool Aggregate_(const OperatorType& op, OperatorType* pro, OperatorType* res, OperatorType* coarse) = 0;
+
+    int          coarse_size_;
+    bool         set_sm_;
+    bool         set_s_;
+    bool         hierarchy_;
+    unsigned int op_format_;
+    Solver<OperatorType, VectorType, ValueType>** sm_default_;
+};
+
+// UAAMG (src/solvers/multigrid/unsmoothed_amg.cpp): unsmoothed aggregation.  The aggregation runs on the device with
+// the PMIS strategy; the reference's sequential Greedy strategy is not provided by this backend.
+template <class OperatorType, class VectorType, typename ValueType>
+class UAAMG : public BaseAMG<OperatorType, VectorType, ValueType>
+{
+public:
+    UAAMG()
+        : eps_(static_cast<ValueType>(0.01f))
+        , over_interp_(static_cast<ValueType>(1.5f))
+        , strat_(Greedy)
+    {
+    }
+    virtual ~UAAMG()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("UAAMG solver");
+        LOG_INFO("UAAMG number of levels " << this->levels_);
+        LOG_INFO("UAAMG using unsmoothed aggregation");
+    }
+    virtual void SetOverInterp(ValueType overInterp)
+    {
+        this->over_interp_ = overInterp;
+    }
+    virtual void SetCouplingStrength(ValueType eps)
+    {
+        this->eps_ = eps;
+    }
+    virtual void SetCoarseningStrategy(CoarseningStrategy strat)
+    {
+        this->strat_ = strat;
+    }
+
+protected:
+    virtual void PrintStart_(void) const
+    {
+        LOG_INFO("UAAMG solver starts");
+        LOG_INFO("UAAMG number of levels " << this->levels_);
+    }
+    virtual void PrintEnd_(void) const
+    {
+        LOG_INFO("UAAMG ends");
+    }
+    // unsmoothed_amg.cpp:204-263
+    virtual bool Aggregate_(const OperatorType& op, OperatorType* pro, OperatorType* res, OperatorType* coarse)
+    {
+        assert(pro != NULL && res != NULL && coarse != NULL);
+        LocalVector<int> connections, aggregates, aggregate_root_nodes;
+        ValueType        eps = this->eps_;
+        for(int i = 0; i < this->levels_ - 1; ++i)
+            eps *= static_cast<ValueType>(0.5);
+        if(this->strat_ != PMIS)
+        {
+            LOG_INFO("UAAMG: CoarseningStrategy Greedy (a sequential sweep) is not provided by this backend; use "
+                     "SetCoarseningStrategy(PMIS)");
+            FATAL_ERROR(__FILE__, __LINE__);
+        }
+        op.AMGPMISAggregate(eps, &connections, &aggregates, &aggregate_root_nodes);
+        op.AMGUnsmoothedAggregation(aggregates, aggregate_root_nodes, pro);
+        connections.Clear();
+        aggregates.Clear();
+        aggregate_root_nodes.Clear();
+        pro->Transpose(res);
+        coarse->CloneBackend(op);
+        coarse->TripleMatrixProduct(*res, op, *pro);
+        if(this->over_interp_ > static_cast<ValueType>(1))
+            coarse->Scale(static_cast<ValueType>(1) / this->over_interp_);
+        return true;
+    }
+
+    ValueType          eps_;
+    ValueType          over_interp_;
+    CoarseningStrategy strat_;
+};
+
 } // namespace rocalution

@@ -277,6 +277,13 @@ int ramd_mat_extract_tri(ramd_mat_t m, ramd_mat_t out, int upper, int with_diag)
 /* CSR matrix algebra (host_matrix_csr.cpp): Sort :3812-3846 (stable, by column), Transpose(T) :3757-3806,
  * MatrixAdd :3324-3462 (this = alpha*this + beta*other; structure == 0: pattern of other is a subset; != 0: union
  * pattern; rows sorted), MatMatMult :2805-2938 (C = A*B, products summed in the host's order, rows sorted) */
+/* Unsmoothed-aggregation AMG setup, CoarseningStrategy PMIS (local_matrix.cpp:6519-6640 AMGPMISAggregate: strong
+ * connections, PMIS rounds, root nodes, aggregate ranks, two passes for the unassigned rows; :6852-6930
+ * AMGUnsmoothedAggregation: P with one entry per aggregated row).  Int vectors (the reference: bool / int64_t). */
+int ramd_mat_amg_pmis_aggregate(ramd_mat_t m, double eps, ramd_vec_t connections, ramd_vec_t aggregates,
+                                ramd_vec_t aggregate_root_nodes);
+int ramd_mat_amg_unsmoothed_prolong(ramd_mat_t m, ramd_vec_t aggregates, ramd_vec_t aggregate_root_nodes,
+                                    ramd_mat_t prolong);
 int ramd_mat_sort(ramd_mat_t m);
 int ramd_mat_transpose(ramd_mat_t m, ramd_mat_t out);
 int ramd_mat_matrix_add(ramd_mat_t m, ramd_mat_t other, double alpha, double beta, int structure);

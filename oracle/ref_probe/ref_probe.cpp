@@ -924,6 +924,63 @@ static int cmd_gen(const std::string& in, const std::string& out)
             }
         }
         {
+            // --- unsmoothed-aggregation AMG, PMIS coarsening: the setup arrays of the first level and two runs
+            LocalVector<bool>    conn;
+            LocalVector<int64_t> agg, roots;
+            mat.AMGPMISAggregate(0.01, &conn, &agg, &roots);
+            MatD P;
+            mat.AMGUnsmoothedAggregation(agg, roots, &P);
+            std::vector<int32_t> ic((size_t)mat.GetNnz()), ia((size_t)A.n), ir((size_t)A.n);
+            {
+                std::vector<char> hb((size_t)mat.GetNnz()); // LocalVector<bool> -> bytes
+                bool*             tmp = new bool[mat.GetNnz()];
+                conn.CopyToHostData(tmp);
+                for(size_t k = 0; k < ic.size(); ++k)
+                    ic[k] = tmp[k] ? 1 : 0;
+                delete[] tmp;
+                std::vector<int64_t> h64((size_t)A.n);
+                agg.CopyToHostData(h64.data());
+                for(size_t k = 0; k < ia.size(); ++k)
+                    ia[k] = (int32_t)h64[k];
+                roots.CopyToHostData(h64.data());
+                for(size_t k = 0; k < ir.size(); ++k)
+                    ir[k] = (int32_t)h64[k];
+            }
+            dump("amg_conn", ic.data(), ic.size());
+            dump("amg_agg", ia.data(), ia.size());
+            dump("amg_roots", ir.data(), ir.size());
+            dump_csr("amg_P", P);
+            for(int variant = 0; variant < 2; ++variant)
+            {
+                UAAMG<MatD, VecD, double>& amg = *new UAAMG<MatD, VecD, double>;
+                amg.SetOperator(mat);
+                amg.SetCoarseningStrategy(PMIS);
+                amg.SetCoarsestLevel(20);
+                amg.Verbose(0);
+                if(variant == 0)
+                {
+                    amg.InitMaxIter(60);
+                    amg.Build();
+                    double lv = (double)amg.GetNumLevels();
+                    dump("uaamg_levels", &lv, 1);
+                    sol.Zeros();
+                    run_solver("uaamg_pmis", amg, rhs, sol);
+                    amg.Clear();
+                }
+                else
+                {
+                    CG<MatD, VecD, double> ls;
+                    ls.SetOperator(mat);
+                    ls.SetPreconditioner(amg);
+                    ls.InitMaxIter(100);
+                    ls.Build();
+                    sol.Zeros();
+                    run_solver("cg_uaamg", ls, rhs, sol);
+                    ls.Clear();
+                }
+            }
+        }
+        {
             // mixed precision: fp64 defect correction around fp32 CG+Jacobi with the sample's
             // inner tolerances (clients/samples/mixed-precision.cpp:85)
             MixedPrecisionDC<MatD, VecD, double, MatF, VecF, float> mp;

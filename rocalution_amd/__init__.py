@@ -278,6 +278,21 @@ class LocalMatrix:
         self._h = h
         self.dtype = np.dtype(np.float32 if src.dtype == np.float64 else np.float64)
 
+    # ---- unsmoothed-aggregation AMG setup, PMIS coarsening (local_matrix.cpp:6519-6640, :6852-6930)
+    def AMGPMISAggregate(self, eps):
+        """-> (connections, aggregates, aggregate_root_nodes) as int LocalVectors"""
+        conn, agg, roots = LocalVector(np.int32), LocalVector(np.int32), LocalVector(np.int32)
+        capi.check(_lib().ramd_mat_amg_pmis_aggregate(self._h, float(eps), conn._h, agg._h, roots._h))
+        return conn, agg, roots
+
+    def AMGUnsmoothedAggregation(self, aggregates, aggregate_root_nodes, prolong):
+        capi.check(_lib().ramd_mat_amg_unsmoothed_prolong(self._h, aggregates._h, aggregate_root_nodes._h, prolong._h))
+
+    def TripleMatrixProduct(self, R, A, P):
+        tmp = LocalMatrix(self.dtype)
+        tmp.MatrixMult(R, A)
+        self.MatrixMult(tmp, P)
+
     # ---- CSR matrix algebra (host_matrix_csr.cpp Sort / Transpose / MatrixAdd / MatMatMult)
     def Sort(self):
         capi.check(_lib().ramd_mat_sort(self._h))

@@ -1,0 +1,404 @@
+// amg.hip -- aggregation kernels of the unsmoothed-aggregation AMG setup (UAAMG with CoarseningStrategy PMIS).
+// Reference (host backend): src/base/host/host_matrix_csr.cpp
+//   AMGComputeStrongConnections :5098-5160 | hash1 :5162-5168 | AMGPMISInitializeState :5171-5222
+//   AMGPMISFindMaxNeighbourNode :5340-5533 | AMGPMISInitializeAggregateGlobalIndices :5642-5660
+//   AMGPMISAddUnassignedNodesToAggregations :5536-5640 | AMGUnsmoothedAggregationProlongNnz/Fill :6331-6512
+// and the driver sequence of LocalMatrix::AMGPMISAggregate / AMGUnsmoothedAggregation (local_matrix.cpp:6519-6640,
+// :6852-6930).  Every step of the reference is a row-parallel loop reading the previous step's arrays only, so each
+// one is a kernel with the same per-row code; the only host decisions are the "any row undecided?" flag per PMIS round
+// and the scan totals.  Single-process (Local) form: no ghost part.
+#include "device_utils.hpp"
+#include "matrix_impl.hpp"
+
+#include <algorithm>
+
+namespace ramd
+{
+
+__device__ __forceinline__ unsigned pmis_hash(unsigned x)
+{
+    x = ((x >> 16) ^ x) * 0x45d9f3bu;
+    x = ((x >> 16) ^ x) * 0x45d9f3bu;
+    x = (x >> 16) ^ x;
+    return x / 2u;
+}
+
+// ExtractDiagonal (host_matrix_csr.cpp:772-800): first matching column; rows without a diagonal keep the zero fill
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_extract_diag_plain(int nrow, const int* __restrict__ rp,
+                                                               const int* __restrict__ ci, const T* __restrict__ val,
+                                                               T* __restrict__ d)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+        for(int j = rp[i]; j < rp[i + 1]; ++j)
+            if(ci[j] == (int)i)
+            {
+                d[i] = val[j];
+                break;
+            }
+}
+
+// conn[j] = (c != i) && (v*v > eps^2 * d_i * d_c)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_amg_connections(int nrow, const int* __restrict__ rp,
+                                                            const int* __restrict__ ci, const T* __restrict__ val,
+                                                            const T* __restrict__ diag, T eps2, int* __restrict__ conn)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+    {
+        const T eps_dia_i = eps2 * diag[i];
+        for(int j = rp[i]; j < rp[i + 1]; ++j)
+        {
+            const int c = ci[j];
+            const T   v = val[j];
+            conn[j]     = (c != (int)i) && (v * v > eps_dia_i * diag[c]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_pmis_init(int nrow, const int* __restrict__ rp, const int* __restrict__ conn,
+                                                      int* __restrict__ state, int* __restrict__ hash)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+    {
+        int s = -2;
+        for(int j = rp[i]; j < rp[i + 1]; ++j)
+            if(conn[j])
+            {
+                s = 0;
+                break;
+            }
+        state[i] = s;
+        hash[i]  = (int)pmis_hash((unsigned)i);
+    }
+}
+
+struct MisTuple
+{
+    int s, v, i;
+};
+// lexographical_max(&neighbour, &t_max) of the reference: t_max stays only when strictly larger in (s, v)
+__device__ __forceinline__ MisTuple mis_max(const MisTuple& nb, const MisTuple& tm)
+{
+    if(tm.s > nb.s)
+        return tm;
+    if(tm.s == nb.s && tm.v > nb.v)
+        return tm;
+    return nb;
+}
+
+__global__ __launch_bounds__(kBlock) void k_pmis_find_max(int nrow, const int* __restrict__ rp,
+                                                          const int* __restrict__ ci, const int* __restrict__ conn,
+                                                          const int* __restrict__ state, const int* __restrict__ hash,
+                                                          int* __restrict__ max_state, int* __restrict__ agg,
+                                                          int* __restrict__ undecided)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+    {
+        MisTuple t = {state[i], hash[i], (int)i};
+        for(int j = rp[i]; j < rp[i + 1]; ++j)
+            if(conn[j])
+            {
+                const int      c  = ci[j];
+                const MisTuple tj = {state[c], hash[c], c};
+                t                 = mis_max(tj, t);
+            }
+        const int row = t.i; // distance two, through the distance-one maximum
+        for(int j = rp[row]; j < rp[row + 1]; ++j)
+            if(conn[j])
+            {
+                const int      c  = ci[j];
+                const MisTuple tj = {state[c], hash[c], c};
+                t                 = mis_max(tj, t);
+            }
+        if(state[i] == 0)
+        {
+            if(t.i == (int)i)
+            {
+                max_state[i] = 1;
+                agg[i]       = 1;
+            }
+            else if(t.s == 1)
+            {
+                max_state[i] = -1;
+                agg[i]       = 0;
+            }
+            else
+                *undecided = 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_pmis_roots(int nrow, const int* __restrict__ agg, int* __restrict__ roots)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+        roots[i] = (agg[i] == 1) ? (int)i : -1;
+}
+
+// rows in state -1 join the aggregate of their first strongly connected neighbour in state 1 (state: copy taken before
+// the pass; the rows written here are in state -1, the rows read are in state 1: no overlap)
+__global__ __launch_bounds__(kBlock) void k_pmis_add_unassigned(int nrow, const int* __restrict__ rp,
+                                                                const int* __restrict__ ci,
+                                                                const int* __restrict__ conn,
+                                                                const int* __restrict__ state,
+                                                                int* __restrict__ max_state, int* agg, int* roots)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+    {
+        const int s = state[i];
+        if(s == -1)
+        {
+            for(int j = rp[i]; j < rp[i + 1]; ++j)
+                if(conn[j])
+                {
+                    const int c = ci[j];
+                    if(state[c] == 1)
+                    {
+                        agg[i]       = agg[c];
+                        max_state[i] = 1;
+                        roots[i]     = roots[c];
+                        break;
+                    }
+                }
+        }
+        else if(s == -2)
+            agg[i] = -2;
+    }
+}
+
+// ---- P of the unsmoothed aggregation: one entry 1 per aggregated row, column = rank of the aggregate's root node
+__global__ __launch_bounds__(kBlock) void k_ua_count(int nrow, const int* __restrict__ agg, const int* __restrict__ roots,
+                                                     int* __restrict__ prp, int* __restrict__ f2c)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= nrow; i += gsz)
+    {
+        int c = 0;
+        if(i < nrow && agg[i] >= 0)
+        {
+            c             = 1;
+            f2c[roots[i]] = 1; // same value from every member of the aggregate
+        }
+        prp[i] = c;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_ua_fill(int nrow, const int* __restrict__ agg, const int* __restrict__ roots,
+                                                    const int* __restrict__ prp, const int* __restrict__ f2c,
+                                                    int* __restrict__ pci, T* __restrict__ pval)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+        if(agg[i] >= 0)
+        {
+            pci[prp[i]]  = f2c[roots[i]];
+            pval[prp[i]] = (T)1;
+        }
+}
+
+template <typename T>
+static int pmis_aggregate_t(ramd_mat_s* m, T eps, ramd_vec_s* vconn, ramd_vec_s* vagg, ramd_vec_s* vroots)
+{
+    Backend&  b    = backend();
+    const int n    = m->nrow;
+    const int grid = ew_grid(std::max(n, 1));
+    RAMD_TRY(ramd_vec_allocate(vconn, m->nnz));
+    RAMD_TRY(ramd_vec_allocate(vagg, n)); // zero-filled, as LocalVector::Allocate
+    RAMD_TRY(ramd_vec_allocate(vroots, n));
+    int* conn  = (int*)vconn->d;
+    int* agg   = (int*)vagg->d;
+    int* roots = (int*)vroots->d;
+    T*   diag  = nullptr;
+    int *state = nullptr, *max_state = nullptr, *hash = nullptr, *flag = nullptr;
+    int  s = dev_alloc(&diag, n);
+    if(s == RAMD_OK)
+        s = dev_alloc(&state, n);
+    if(s == RAMD_OK)
+        s = dev_alloc(&max_state, n);
+    if(s == RAMD_OK)
+        s = dev_alloc(&hash, n);
+    if(s == RAMD_OK)
+        s = dev_alloc(&flag, 1);
+    hipError_t e = hipSuccess;
+    if(s == RAMD_OK)
+    {
+        e = hipMemsetAsync(diag, 0, sizeof(T) * (size_t)n, b.cur); // ExtractDiagonal into a zero-filled vector
+        hipLaunchKernelGGL((k_extract_diag_plain<T>), dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, m->ci,
+                           (const T*)m->val, diag);
+        hipLaunchKernelGGL((k_amg_connections<T>), dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const T*)m->val,
+                           (const T*)diag, eps * eps, conn);
+        hipLaunchKernelGGL(k_pmis_init, dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, (const int*)conn, max_state, hash);
+        for(int iter = 0; e == hipSuccess; ++iter)
+        {
+            e = hipMemcpyAsync(state, max_state, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, b.cur);
+            if(e == hipSuccess)
+                e = hipMemsetAsync(flag, 0, sizeof(int), b.cur);
+            hipLaunchKernelGGL(k_pmis_find_max, dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const int*)conn,
+                               (const int*)state, (const int*)hash, max_state, agg, flag);
+            int undecided = 0;
+            if(e == hipSuccess)
+                e = hipMemcpyAsync(&undecided, flag, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+            if(e == hipSuccess)
+                e = hipStreamSynchronize(b.cur);
+            if(!undecided)
+                break;
+            if(iter > 10000)
+            {
+                s = RAMD_ERR_STATE;
+                break;
+            }
+        }
+        if(e == hipSuccess && s == RAMD_OK)
+        {
+            hipLaunchKernelGGL(k_pmis_roots, dim3(grid), dim3(kBlock), 0, b.cur, n, (const int*)agg, roots);
+            // aggregates->ExclusiveSum(): rank of every root (the other rows are overwritten below)
+            int* tmp = nullptr;
+            s        = dev_alloc(&tmp, (int64_t)n + 1);
+            if(s == RAMD_OK)
+            {
+                e = hipMemcpyAsync(tmp, agg, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, b.cur);
+                if(e == hipSuccess)
+                    e = hipMemsetAsync(tmp + n, 0, sizeof(int), b.cur);
+                s = device_exclusive_scan(tmp, tmp, (int64_t)n + 1);
+                if(s == RAMD_OK && e == hipSuccess)
+                    e = hipMemcpyAsync(agg, tmp, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, b.cur);
+                if(e == hipSuccess)
+                    e = hipStreamSynchronize(b.cur);
+            }
+            dev_free(&tmp);
+            for(int k = 0; k < 2 && s == RAMD_OK && e == hipSuccess; ++k)
+            {
+                e = hipMemcpyAsync(state, max_state, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, b.cur);
+                hipLaunchKernelGGL(k_pmis_add_unassigned, dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, m->ci,
+                                   (const int*)conn, (const int*)state, max_state, agg, roots);
+            }
+            if(e == hipSuccess)
+                e = hipGetLastError();
+            if(e == hipSuccess)
+                e = hipStreamSynchronize(b.cur);
+        }
+    }
+    dev_free(&diag);
+    dev_free(&state);
+    dev_free(&max_state);
+    dev_free(&hash);
+    dev_free(&flag);
+    RAMD_TRY(s);
+    RAMD_HIP(e);
+    return RAMD_OK;
+}
+
+template <typename T>
+static int ua_prolong_t(const ramd_mat_s* m, const ramd_vec_s* vagg, const ramd_vec_s* vroots, ramd_mat_s* p)
+{
+    Backend&   b     = backend();
+    const int  n     = m->nrow;
+    const int* agg   = (const int*)vagg->d;
+    const int* roots = (const int*)vroots->d;
+    int *      prp = nullptr, *f2c = nullptr;
+    RAMD_TRY(dev_alloc(&prp, (int64_t)n + 1));
+    int s = dev_alloc(&f2c, (int64_t)n + 1);
+    if(s != RAMD_OK)
+    {
+        dev_free(&prp);
+        return s;
+    }
+    hipError_t e = hipMemsetAsync(f2c, 0, sizeof(int) * ((size_t)n + 1), b.cur);
+    hipLaunchKernelGGL(k_ua_count, dim3(ew_grid((int64_t)n + 1)), dim3(kBlock), 0, b.cur, n, agg, roots, prp, f2c);
+    s = device_exclusive_scan(prp, prp, (int64_t)n + 1);
+    if(s == RAMD_OK)
+        s = device_exclusive_scan(f2c, f2c, (int64_t)n + 1);
+    int tot[2] = {0, 0};
+    if(s == RAMD_OK && e == hipSuccess)
+        e = hipMemcpyAsync(&tot[0], prp + n, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+    if(s == RAMD_OK && e == hipSuccess)
+        e = hipMemcpyAsync(&tot[1], f2c + n, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+    if(s == RAMD_OK && e == hipSuccess)
+        e = hipStreamSynchronize(b.cur);
+    int*  pci = nullptr;
+    void* pv  = nullptr;
+    if(s == RAMD_OK && e == hipSuccess)
+        s = dev_alloc(&pci, tot[0]);
+    if(s == RAMD_OK && e == hipSuccess && cached_malloc(&pv, (size_t)tot[0] * sizeof(T) + kPad) != hipSuccess)
+        s = RAMD_ERR_HIP;
+    if(s == RAMD_OK && e == hipSuccess)
+    {
+        hipLaunchKernelGGL((k_ua_fill<T>), dim3(ew_grid(std::max(n, 1))), dim3(kBlock), 0, b.cur, n, agg, roots,
+                           (const int*)prp, (const int*)f2c, pci, (T*)pv);
+        e = hipGetLastError();
+        if(e == hipSuccess)
+            e = hipStreamSynchronize(b.cur);
+    }
+    dev_free(&f2c);
+    if(s != RAMD_OK || e != hipSuccess)
+    {
+        dev_free(&prp);
+        dev_free(&pci);
+        if(pv)
+            (void)cached_free(pv);
+        RAMD_TRY(s);
+        RAMD_HIP(e);
+    }
+    mat_free_csr(p);
+    mat_free_ell(p);
+    mat_free_coo(p);
+    mat_free_dia(p);
+    mat_free_analysis(p);
+    p->format = RAMD_CSR;
+    p->nrow   = n;
+    p->ncol   = tot[1];
+    p->nnz    = tot[0];
+    p->rp     = prp;
+    p->ci     = pci;
+    p->val    = pv;
+    return RAMD_OK;
+}
+
+} // namespace ramd
+
+using namespace ramd;
+
+extern "C" {
+
+int ramd_mat_amg_pmis_aggregate(ramd_mat_t m, double eps, ramd_vec_t connections, ramd_vec_t aggregates,
+                                ramd_vec_t aggregate_root_nodes)
+{
+    if(!m || !connections || !aggregates || !aggregate_root_nodes)
+        RAMD_FAIL(RAMD_ERR_ARG, "null handle");
+    if(m->format != RAMD_CSR)
+        return RAMD_ERR_UNSUPPORTED;
+    if(connections->dtype != RAMD_I32 || aggregates->dtype != RAMD_I32 || aggregate_root_nodes->dtype != RAMD_I32)
+        RAMD_FAIL(RAMD_ERR_ARG, "AMGPMISAggregate: int vectors expected");
+    if(m->nrow != m->ncol)
+        RAMD_FAIL(RAMD_ERR_ARG, "AMGPMISAggregate: square matrix expected");
+    if(m->nnz <= 0)
+        return RAMD_OK; // local_matrix.cpp:6545: nothing happens for an empty matrix
+    if(m->dtype == RAMD_F64)
+        return pmis_aggregate_t<double>(m, eps, connections, aggregates, aggregate_root_nodes);
+    return pmis_aggregate_t<float>(m, (float)eps, connections, aggregates, aggregate_root_nodes);
+}
+
+int ramd_mat_amg_unsmoothed_prolong(ramd_mat_t m, ramd_vec_t aggregates, ramd_vec_t aggregate_root_nodes,
+                                    ramd_mat_t prolong)
+{
+    if(!m || !aggregates || !aggregate_root_nodes || !prolong || prolong == m)
+        RAMD_FAIL(RAMD_ERR_ARG, "null handle / prolong aliases the operator");
+    if(m->format != RAMD_CSR)
+        return RAMD_ERR_UNSUPPORTED;
+    if(aggregates->dtype != RAMD_I32 || aggregate_root_nodes->dtype != RAMD_I32 || aggregates->n != m->nrow
+       || aggregate_root_nodes->n != m->nrow || prolong->dtype != m->dtype)
+        RAMD_FAIL(RAMD_ERR_ARG, "AMGUnsmoothedAggregation: int vectors of the operator's size, P of its value type");
+    if(m->nnz <= 0)
+        return RAMD_OK;
+    if(m->dtype == RAMD_F64)
+        return ua_prolong_t<double>(m, aggregates, aggregate_root_nodes, prolong);
+    return ua_prolong_t<float>(m, aggregates, aggregate_root_nodes, prolong);
+}
+
+} // extern "C"

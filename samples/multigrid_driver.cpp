@@ -5,6 +5,8 @@
 // Usage: multigrid_driver <matrix.mtx> <variant>    variant: v (V-cycle + scaling, solver)
 //                                                            w (W-cycle, no scaling, solver)
 //                                                            k (CG preconditioned by a K-cycle)
+//                                                            a (UAAMG, PMIS coarsening, as a solver)
+//                                                            c (CG preconditioned by UAAMG)
 // Prints one RESULT line and the residual history (HIST lines), which tests/test_gpu_solvers.py compares with the
 // genuine library's run of the same setup (oracle/ref_probe).
 #include <cstdlib>
@@ -57,6 +59,44 @@ int main(int argc, char* argv[])
     e.Ones();
     mat.Apply(e, &rhs);
     x.Zeros();
+
+    if(variant == "a" || variant == "c")
+    {
+        // the reference's sample sequence for UAAMG (clients/samples/ua-amg.cpp), PMIS coarsening
+        UAAMG<Mat, Vec, double> amg;
+        CG<Mat, Vec, double>    cg;
+        amg.SetOperator(mat);
+        amg.SetCoarseningStrategy(PMIS);
+        amg.SetCoarsestLevel(20);
+        amg.Verbose(0);
+        IterativeLinearSolver<Mat, Vec, double>* s = &amg;
+        if(variant == "a")
+            amg.InitMaxIter(60);
+        else
+        {
+            cg.SetOperator(mat);
+            cg.SetPreconditioner(amg);
+            cg.InitMaxIter(100);
+            s = &cg;
+        }
+        s->Verbose(0);
+        s->RecordResidualHistory();
+        s->Build();
+        const int levels = amg.GetNumLevels();
+        s->Solve(rhs, &x);
+        _rocalution_sync();
+        std::cout.precision(17);
+        const std::vector<double> h = s->GetResidualHistory();
+        for(size_t i = 0; i < h.size(); ++i)
+            std::cout << "HIST " << h[i] << std::endl;
+        e.ScaleAdd(-1.0, x);
+        std::cout << "RESULT variant=" << variant << " coarse_n=" << levels << " coarse_nnz=0"
+                  << " iters=" << s->GetIterationCount() << " status=" << s->GetSolverStatus()
+                  << " residual=" << s->GetCurrentResidual() << " error=" << e.Norm() << std::endl;
+        s->Clear();
+        stop_rocalution();
+        return 0;
+    }
 
     Mat P0, R0, A1, P1, R1, A2, tmp;
     const int n0 = (int)mat.GetM(), n1 = (n0 + 1) / 2;

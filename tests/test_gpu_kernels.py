@@ -184,6 +184,21 @@ def test_csr_matrix_algebra_vs_golden(ra, name):
     assert np.allclose(y1.numpy(), y2.numpy(), rtol=1e-12, atol=1e-10 * np.max(np.abs(y2.numpy())))
 
 
+@pytest.mark.parametrize("name", ["gr3030", "poisson8", "lap2d7"])
+def test_amg_pmis_aggregation_vs_golden(ra, name):
+    """UA-AMG setup of the first level: strong connections, PMIS aggregates, root nodes, prolongation operator --
+    every array identical to the genuine library's (host backend)"""
+    g = load_golden(name)
+    A = _mat(ra, g)
+    conn, agg, roots = A.AMGPMISAggregate(0.01)
+    eq(conn.numpy(), g["amg_conn"]); eq(agg.numpy(), g["amg_agg"]); eq(roots.numpy(), g["amg_roots"])
+    P = ra.LocalMatrix()
+    A.AMGUnsmoothedAggregation(agg, roots, P)
+    rp, ci, va = P.CopyToCSR()
+    eq(rp, g["amg_P_rowptr"]); eq(ci, g["amg_P_col"]); eq(va, g["amg_P_val"])
+    assert P.GetN() == int(g["amg_P_col"].max()) + 1
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_dia_format_vs_golden(ra, name):
     """CSR -> DIA (diagonals, offsets, padded values), DIA SpMV (the padded zeros are multiplied, as on the host),

@@ -497,3 +497,34 @@ def test_cpp_multigrid_driver_vs_reference(tmp_path, name):
         hist = np.array([float(v) for v in re.findall(r"HIST (\S+)", out)])
         _check_hist(hist, g[tag + "_hist"], False, rtol=1e-5)
         assert float(m.group(6)) < 1e-3, (tag, m.group(6))
+
+
+@pytest.mark.parametrize("name", ["gr3030", "poisson8", "lap2d7"])
+def test_cpp_uaamg_driver_vs_reference(tmp_path, name):
+    """UAAMG (unsmoothed aggregation, PMIS coarsening, default smoothers / coarse solver) through the C++ driver:
+    number of levels, iteration counts and residual histories of the genuine library, as a solver and as CG's
+    preconditioner"""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "multigrid_driver")
+    libdir = os.path.join(root, "rocalution_amd")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "samples", "multigrid_driver.cpp"), "-o", exe, "-L" + libdir,
+                           "-lrocalution_amd", "-Wl,-rpath," + libdir])
+    g = load_golden(name)
+    mtx = str(tmp_path / (name + ".mtx"))
+    _write_mtx(mtx, g["rowptr"], g["col"], g["val"])
+    for variant, tag in (("a", "uaamg_pmis"), ("c", "cg_uaamg")):
+        r = subprocess.run([exe, mtx, variant], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        out = r.stdout.decode()
+        assert r.returncode == 0, out[-2000:]
+        m = re.search(r"RESULT .*coarse_n=(\d+) coarse_nnz=(\d+) iters=(\d+) status=(\d+) residual=(\S+) error=(\S+)", out)
+        assert m, out[-2000:]
+        assert int(m.group(1)) == int(g["uaamg_levels"][0])
+        meta = g[tag + "_meta"]
+        assert abs(int(m.group(3)) - int(meta[0])) <= 1 and int(m.group(4)) == int(meta[1]), (tag, m.groups(), meta)
+        hist = np.array([float(v) for v in re.findall(r"HIST (\S+)", out)])
+        _check_hist(hist, g[tag + "_hist"], False, rtol=1e-5)
+        assert float(m.group(6)) < 1e-3, (tag, m.group(6))
