@@ -48,8 +48,17 @@ int main(int argc, char* argv[])
     init_rocalution();
     Mat mat;
     Vec x, rhs, e;
-    mat.ReadFileMTX(std::string(argv[1]));
-    mat.MoveToAccelerator();
+    const std::string src = argv[1];
+    if(src.compare(0, 8, "poisson:") == 0)
+    {
+        mat.MoveToAccelerator();
+        mat.GeneratePoisson7(atoi(src.c_str() + 8)); // extension: 3-D 7-point operator built on the device
+    }
+    else
+    {
+        mat.ReadFileMTX(src);
+        mat.MoveToAccelerator();
+    }
     x.MoveToAccelerator();
     rhs.MoveToAccelerator();
     e.MoveToAccelerator();
@@ -81,10 +90,21 @@ int main(int argc, char* argv[])
         }
         s->Verbose(0);
         s->RecordResidualHistory();
+        if(argc > 3)
+        {
+            amg.SetCoarsestLevel(atoi(argv[3]));
+            s->Init(1e-15, 1e-8, 1e8, 500);
+        }
+        double t0 = rocalution_time();
         s->Build();
+        _rocalution_sync();
+        double t1 = rocalution_time();
         const int levels = amg.GetNumLevels();
         s->Solve(rhs, &x);
         _rocalution_sync();
+        double t2 = rocalution_time();
+        std::cout << "TIMING build_s=" << (t1 - t0) / 1e6 << " solve_s=" << (t2 - t1) / 1e6 << " levels=" << levels
+                  << std::endl;
         std::cout.precision(17);
         const std::vector<double> h = s->GetResidualHistory();
         for(size_t i = 0; i < h.size(); ++i)

@@ -376,7 +376,6 @@ def test_mcilu_without_decomposition(ra, S, name):
     assert abs(ls.GetIterationCount() - int(g["gmres_mcilu_meta"][0])) <= 2
 
 
-@pytest.mark.parametrize("name", ["gr3030", "poisson8", "lap2d7"])
 def test_fixedpoint_as_smoother(ra, S, name):
     """FlagSmoother(): exactly max_iter sweeps and no residual bookkeeping (solver.cpp:686-720) -- the result
     of 3 MC-SGS sweeps equals the reference's to round-off of nothing: every step is an exact kernel"""
@@ -499,7 +498,7 @@ def test_cpp_multigrid_driver_vs_reference(tmp_path, name):
         assert float(m.group(6)) < 1e-3, (tag, m.group(6))
 
 
-@pytest.mark.parametrize("name", ["gr3030", "poisson8", "lap2d7"])
+@pytest.mark.parametrize("name", ["gr3030", "poisson8", "lap2d7", "poisson16", "poisson32"])
 def test_cpp_uaamg_driver_vs_reference(tmp_path, name):
     """UAAMG (unsmoothed aggregation, PMIS coarsening, default smoothers / coarse solver) through the C++ driver:
     number of levels, iteration counts and residual histories of the genuine library, as a solver and as CG's
@@ -515,16 +514,21 @@ def test_cpp_uaamg_driver_vs_reference(tmp_path, name):
                            "-lrocalution_amd", "-Wl,-rpath," + libdir])
     g = load_golden(name)
     mtx = str(tmp_path / (name + ".mtx"))
-    _write_mtx(mtx, g["rowptr"], g["col"], g["val"])
+    rp, ci, va, _ = _inputs(name, g)
+    _write_mtx(mtx, rp, ci, va)
     for variant, tag in (("a", "uaamg_pmis"), ("c", "cg_uaamg")):
         r = subprocess.run([exe, mtx, variant], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
         out = r.stdout.decode()
         assert r.returncode == 0, out[-2000:]
         m = re.search(r"RESULT .*coarse_n=(\d+) coarse_nnz=(\d+) iters=(\d+) status=(\d+) residual=(\S+) error=(\S+)", out)
         assert m, out[-2000:]
-        assert int(m.group(1)) == int(g["uaamg_levels"][0])
+        if "uaamg_levels" in g:
+            assert int(m.group(1)) == int(g["uaamg_levels"][0])
         meta = g[tag + "_meta"]
         assert abs(int(m.group(3)) - int(meta[0])) <= 1 and int(m.group(4)) == int(meta[1]), (tag, m.groups(), meta)
         hist = np.array([float(v) for v in re.findall(r"HIST (\S+)", out)])
-        _check_hist(hist, g[tag + "_hist"], False, rtol=1e-5)
-        assert float(m.group(6)) < 1e-3, (tag, m.group(6))
+        # the V-cycle of the larger Poisson cases is not a contraction (see the stand-alone run), CG around it
+        # amplifies the summation-order differences of the dots: strict for 8 iterations, then the BiCGStab rule
+        _check_hist(hist, g[tag + "_hist"], tag == "cg_uaamg" and name in ("poisson16", "poisson32"), rtol=1e-5)
+        if int(meta[1]) in (1, 2):  # the stand-alone V-cycle of the reference DIVERGES on the larger Poisson cases
+            assert float(m.group(6)) < 1e-3, (tag, m.group(6))  # (status 3 / 4 in the genuine run as well)
