@@ -1192,6 +1192,16 @@ public:
         RAMD_CHECK(ramd_mat_amg_pmis_aggregate(this->dev_, (double)eps, connections->handle(), aggregates->handle(),
                                                aggregate_root_nodes->handle()));
     }
+    void AMGSmoothedAggregation(ValueType relax, const LocalVector<int>& connections, const LocalVector<int>& aggregates,
+                                const LocalVector<int>& aggregate_root_nodes, LocalMatrix<ValueType>* prolong,
+                                int lumping_strat = 0) const
+    {
+        this->need_accel_("AMGSmoothedAggregation");
+        assert(prolong != NULL && prolong != this && relax > static_cast<ValueType>(0));
+        prolong->MoveToAccelerator();
+        RAMD_CHECK(ramd_mat_amg_smoothed_prolong(this->dev_, (double)relax, lumping_strat, connections.handle(),
+                                                 aggregates.handle(), aggregate_root_nodes.handle(), prolong->dev_));
+    }
     void AMGUnsmoothedAggregation(const LocalVector<int>& aggregates, const LocalVector<int>& aggregate_root_nodes,
                                   LocalMatrix<ValueType>* prolong) const
     {

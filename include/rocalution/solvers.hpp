@@ -4032,4 +4032,93 @@ protected:
     CoarseningStrategy strat_;
 };
 
+typedef enum _lumping_strategy
+{
+    AddWeakConnections      = 0,
+    SubtractWeakConnections = 1
+} LumpingStrategy;
+
+// SAAMG (src/solvers/multigrid/smoothed_amg.cpp): smoothed aggregation; aggregation on the device with PMIS
+template <class OperatorType, class VectorType, typename ValueType>
+class SAAMG : public BaseAMG<OperatorType, VectorType, ValueType>
+{
+public:
+    SAAMG()
+        : eps_(static_cast<ValueType>(0.01f))
+        , relax_(static_cast<ValueType>(2.f / 3.f))
+        , strat_(Greedy)
+        , lumping_strat_(AddWeakConnections)
+    {
+    }
+    virtual ~SAAMG()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("SAAMG solver");
+        LOG_INFO("SAAMG number of levels " << this->levels_);
+        LOG_INFO("SAAMG using PMIS smoothed aggregation");
+    }
+    virtual void SetCouplingStrength(ValueType eps)
+    {
+        this->eps_ = eps;
+    }
+    virtual void SetInterpRelax(ValueType relax)
+    {
+        this->relax_ = relax;
+    }
+    virtual void SetCoarseningStrategy(CoarseningStrategy strat)
+    {
+        this->strat_ = strat;
+    }
+    virtual void SetLumpingStrategy(LumpingStrategy lumping_strat)
+    {
+        this->lumping_strat_ = lumping_strat;
+    }
+
+protected:
+    virtual void PrintStart_(void) const
+    {
+        LOG_INFO("SAAMG solver starts");
+        LOG_INFO("SAAMG number of levels " << this->levels_);
+    }
+    virtual void PrintEnd_(void) const
+    {
+        LOG_INFO("SAAMG ends");
+    }
+    // smoothed_amg.cpp:244-316
+    virtual bool Aggregate_(const OperatorType& op, OperatorType* pro, OperatorType* res, OperatorType* coarse)
+    {
+        assert(pro != NULL && res != NULL && coarse != NULL);
+        LocalVector<int> connections, aggregates, aggregate_root_nodes;
+        ValueType        eps = this->eps_;
+        for(int i = 0; i < this->levels_ - 1; ++i)
+            eps *= static_cast<ValueType>(0.5);
+        if(this->strat_ != PMIS)
+        {
+            LOG_INFO("SAAMG: CoarseningStrategy Greedy (a sequential sweep) is not provided by this backend; use "
+                     "SetCoarseningStrategy(PMIS)");
+            FATAL_ERROR(__FILE__, __LINE__);
+        }
+        op.AMGPMISAggregate(eps, &connections, &aggregates, &aggregate_root_nodes);
+        op.AMGSmoothedAggregation(this->relax_, connections, aggregates, aggregate_root_nodes, pro,
+                                  this->lumping_strat_ == AddWeakConnections ? 0 : 1);
+        connections.Clear();
+        aggregates.Clear();
+        aggregate_root_nodes.Clear();
+        if(pro->GetN() == 0) // R would have no rows: the level is reverted by the caller
+            return false;
+        pro->Transpose(res);
+        coarse->CloneBackend(op);
+        coarse->TripleMatrixProduct(*res, op, *pro);
+        return true;
+    }
+
+    ValueType          eps_;
+    ValueType          relax_;
+    CoarseningStrategy strat_;
+    LumpingStrategy    lumping_strat_;
+};
+
 } // namespace rocalution

@@ -284,6 +284,10 @@ int ramd_mat_amg_pmis_aggregate(ramd_mat_t m, double eps, ramd_vec_t connections
                                 ramd_vec_t aggregate_root_nodes);
 int ramd_mat_amg_unsmoothed_prolong(ramd_mat_t m, ramd_vec_t aggregates, ramd_vec_t aggregate_root_nodes,
                                     ramd_mat_t prolong);
+/* AMGSmoothedAggregation (local_matrix.cpp:6642-6760; host_matrix_csr.cpp:5936-6330): P = (I - relax D_f^-1 A_f) P_tent
+ * on the strength-filtered matrix, lumping_strat 0 adds / 1 subtracts the weak couplings to the diagonal */
+int ramd_mat_amg_smoothed_prolong(ramd_mat_t m, double relax, int lumping_strat, ramd_vec_t connections,
+                                  ramd_vec_t aggregates, ramd_vec_t aggregate_root_nodes, ramd_mat_t prolong);
 int ramd_mat_sort(ramd_mat_t m);
 int ramd_mat_transpose(ramd_mat_t m, ramd_mat_t out);
 int ramd_mat_matrix_add(ramd_mat_t m, ramd_mat_t other, double alpha, double beta, int structure);

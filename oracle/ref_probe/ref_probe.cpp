@@ -950,6 +950,43 @@ static int cmd_gen(const std::string& in, const std::string& out)
             dump("amg_agg", ia.data(), ia.size());
             dump("amg_roots", ir.data(), ir.size());
             dump_csr("amg_P", P);
+            {
+                MatD Ps;
+                mat.AMGSmoothedAggregation(2.0 / 3.0, conn, agg, roots, &Ps, 0);
+                dump_csr("amg_Ps", Ps);
+                MatD Ps1;
+                mat.AMGSmoothedAggregation(0.5, conn, agg, roots, &Ps1, 1); // SubtractWeakConnections
+                dump_csr("amg_Ps1", Ps1);
+            }
+            for(int variant = 0; variant < 2; ++variant)
+            {
+                SAAMG<MatD, VecD, double>& amg = *new SAAMG<MatD, VecD, double>;
+                amg.SetOperator(mat);
+                amg.SetCoarseningStrategy(PMIS);
+                amg.SetCoarsestLevel(20);
+                amg.Verbose(0);
+                if(variant == 0)
+                {
+                    amg.InitMaxIter(60);
+                    amg.Build();
+                    double lv = (double)amg.GetNumLevels();
+                    dump("saamg_levels", &lv, 1);
+                    sol.Zeros();
+                    run_solver("saamg_pmis", amg, rhs, sol);
+                    amg.Clear();
+                }
+                else
+                {
+                    CG<MatD, VecD, double> ls;
+                    ls.SetOperator(mat);
+                    ls.SetPreconditioner(amg);
+                    ls.InitMaxIter(100);
+                    ls.Build();
+                    sol.Zeros();
+                    run_solver("cg_saamg", ls, rhs, sol);
+                    ls.Clear();
+                }
+            }
             for(int variant = 0; variant < 2; ++variant)
             {
                 UAAMG<MatD, VecD, double>& amg = *new UAAMG<MatD, VecD, double>;

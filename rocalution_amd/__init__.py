@@ -288,6 +288,10 @@ class LocalMatrix:
     def AMGUnsmoothedAggregation(self, aggregates, aggregate_root_nodes, prolong):
         capi.check(_lib().ramd_mat_amg_unsmoothed_prolong(self._h, aggregates._h, aggregate_root_nodes._h, prolong._h))
 
+    def AMGSmoothedAggregation(self, relax, connections, aggregates, aggregate_root_nodes, prolong, lumping_strat=0):
+        capi.check(_lib().ramd_mat_amg_smoothed_prolong(self._h, float(relax), int(lumping_strat), connections._h,
+                                                        aggregates._h, aggregate_root_nodes._h, prolong._h))
+
     def TripleMatrixProduct(self, R, A, P):
         tmp = LocalMatrix(self.dtype)
         tmp.MatrixMult(R, A)

@@ -202,6 +202,169 @@ __global__ __launch_bounds__(kBlock) void k_ua_fill(int nrow, const int* __restr
         }
 }
 
+// ---- P of the smoothed aggregation (host_matrix_csr.cpp:5936-6330, local part): row i of (I - relax D_f^-1 A_f) P_tent,
+// A_f the strength-filtered matrix with the weak couplings lumped into the diagonal.  Per row: the diagonal entry
+// contributes 1 - relax, a strong entry -relax * (1/dia) * a_ij, keyed by the root node of the neighbour's aggregate;
+// equal keys are summed in row order, keys ascend (std::map) -- here a stable insertion into the row's own scratch
+// segment (its range of the operator's entries) followed by the in-order sum.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_sa_row(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                   const T* __restrict__ val, const int* __restrict__ conn,
+                                                   const int* __restrict__ agg, const int* __restrict__ roots, T relax,
+                                                   int lumping, int* __restrict__ tkey, T* __restrict__ tval,
+                                                   int* __restrict__ cnt, int* __restrict__ f2c)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= nrow; i += gsz)
+    {
+        if(i == nrow)
+        {
+            cnt[i] = 0;
+            continue;
+        }
+        const int rs = rp[i], re = rp[i + 1];
+        T         dia = (T)0;
+        for(int j = rs; j < re; ++j)
+        {
+            if(ci[j] == (int)i)
+                dia += val[j];
+            else if(!conn[j])
+            {
+                if(lumping == 0)
+                    dia += val[j];
+                else
+                    dia -= val[j];
+            }
+        }
+        dia = (T)1 / dia;
+        int e = rs; // entries [rs, e) of the scratch segment are filled, sorted by key, stable
+        for(int j = rs; j < re; ++j)
+        {
+            const int c = ci[j];
+            if(c != (int)i && !conn[j])
+                continue;
+            if(agg[c] < 0)
+                continue;
+            const T   v   = (c == (int)i) ? (T)1 - relax : -relax * dia * val[j];
+            const int key = roots[c];
+            f2c[key]      = 1;
+            int q         = e - 1;
+            for(; q >= rs && tkey[q] > key; --q)
+            {
+                tkey[q + 1] = tkey[q];
+                tval[q + 1] = tval[q];
+            }
+            tkey[q + 1] = key;
+            tval[q + 1] = v;
+            ++e;
+        }
+        int o = rs;
+        for(int q = rs; q < e;)
+        {
+            const int k = tkey[q];
+            T         v = tval[q];
+            ++q;
+            while(q < e && tkey[q] == k)
+                v += tval[q++];
+            tkey[o] = k;
+            tval[o] = v;
+            ++o;
+        }
+        cnt[i] = o - rs;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_sa_compact(int nrow, const int* __restrict__ rp, const int* __restrict__ tkey,
+                                                       const T* __restrict__ tval, const int* __restrict__ prp,
+                                                       const int* __restrict__ f2c, int* __restrict__ pci,
+                                                       T* __restrict__ pval)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+    {
+        const int n = prp[i + 1] - prp[i];
+        for(int k = 0; k < n; ++k)
+        {
+            pci[prp[i] + k]  = f2c[tkey[rp[i] + k]];
+            pval[prp[i] + k] = tval[rp[i] + k];
+        }
+    }
+}
+
+template <typename T>
+static int sa_prolong_t(const ramd_mat_s* m, T relax, int lumping, const ramd_vec_s* vconn, const ramd_vec_s* vagg,
+                        const ramd_vec_s* vroots, ramd_mat_s* p)
+{
+    Backend&  b = backend();
+    const int n = m->nrow;
+    int *     tkey = nullptr, *cnt = nullptr, *f2c = nullptr;
+    void*     tval = nullptr;
+    RAMD_TRY(dev_alloc(&tkey, m->nnz));
+    int s = dev_alloc(&cnt, (int64_t)n + 1);
+    if(s == RAMD_OK)
+        s = dev_alloc(&f2c, (int64_t)n + 1);
+    if(s == RAMD_OK && cached_malloc(&tval, (size_t)m->nnz * sizeof(T) + kPad) != hipSuccess)
+        s = RAMD_ERR_HIP;
+    hipError_t e = hipSuccess;
+    int        tot[2] = {0, 0};
+    if(s == RAMD_OK)
+    {
+        e = hipMemsetAsync(f2c, 0, sizeof(int) * ((size_t)n + 1), b.cur);
+        hipLaunchKernelGGL((k_sa_row<T>), dim3(ew_grid((int64_t)n + 1)), dim3(kBlock), 0, b.cur, n, m->rp, m->ci,
+                           (const T*)m->val, (const int*)vconn->d, (const int*)vagg->d, (const int*)vroots->d, relax,
+                           lumping, tkey, (T*)tval, cnt, f2c);
+        s = device_exclusive_scan(cnt, cnt, (int64_t)n + 1);
+        if(s == RAMD_OK)
+            s = device_exclusive_scan(f2c, f2c, (int64_t)n + 1);
+        if(s == RAMD_OK && e == hipSuccess)
+            e = hipMemcpyAsync(&tot[0], cnt + n, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+        if(s == RAMD_OK && e == hipSuccess)
+            e = hipMemcpyAsync(&tot[1], f2c + n, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+        if(s == RAMD_OK && e == hipSuccess)
+            e = hipStreamSynchronize(b.cur);
+    }
+    int*  pci = nullptr;
+    void* pv  = nullptr;
+    if(s == RAMD_OK && e == hipSuccess)
+        s = dev_alloc(&pci, tot[0]);
+    if(s == RAMD_OK && e == hipSuccess && cached_malloc(&pv, (size_t)tot[0] * sizeof(T) + kPad) != hipSuccess)
+        s = RAMD_ERR_HIP;
+    if(s == RAMD_OK && e == hipSuccess)
+    {
+        hipLaunchKernelGGL((k_sa_compact<T>), dim3(ew_grid(std::max(n, 1))), dim3(kBlock), 0, b.cur, n, m->rp,
+                           (const int*)tkey, (const T*)tval, (const int*)cnt, (const int*)f2c, pci, (T*)pv);
+        e = hipGetLastError();
+        if(e == hipSuccess)
+            e = hipStreamSynchronize(b.cur);
+    }
+    dev_free(&tkey);
+    dev_free(&f2c);
+    if(tval)
+        (void)cached_free(tval);
+    if(s != RAMD_OK || e != hipSuccess)
+    {
+        dev_free(&cnt);
+        dev_free(&pci);
+        if(pv)
+            (void)cached_free(pv);
+        RAMD_TRY(s);
+        RAMD_HIP(e);
+    }
+    mat_free_csr(p);
+    mat_free_ell(p);
+    mat_free_coo(p);
+    mat_free_dia(p);
+    mat_free_analysis(p);
+    p->format = RAMD_CSR;
+    p->nrow   = n;
+    p->ncol   = tot[1];
+    p->nnz    = tot[0];
+    p->rp     = cnt;
+    p->ci     = pci;
+    p->val    = pv;
+    return RAMD_OK;
+}
+
 template <typename T>
 static int pmis_aggregate_t(ramd_mat_s* m, T eps, ramd_vec_s* vconn, ramd_vec_s* vagg, ramd_vec_s* vroots)
 {
@@ -382,6 +545,24 @@ int ramd_mat_amg_pmis_aggregate(ramd_mat_t m, double eps, ramd_vec_t connections
     if(m->dtype == RAMD_F64)
         return pmis_aggregate_t<double>(m, eps, connections, aggregates, aggregate_root_nodes);
     return pmis_aggregate_t<float>(m, (float)eps, connections, aggregates, aggregate_root_nodes);
+}
+
+int ramd_mat_amg_smoothed_prolong(ramd_mat_t m, double relax, int lumping_strat, ramd_vec_t connections,
+                                  ramd_vec_t aggregates, ramd_vec_t aggregate_root_nodes, ramd_mat_t prolong)
+{
+    if(!m || !connections || !aggregates || !aggregate_root_nodes || !prolong || prolong == m)
+        RAMD_FAIL(RAMD_ERR_ARG, "null handle / prolong aliases the operator");
+    if(m->format != RAMD_CSR)
+        return RAMD_ERR_UNSUPPORTED;
+    if(connections->dtype != RAMD_I32 || aggregates->dtype != RAMD_I32 || aggregate_root_nodes->dtype != RAMD_I32
+       || connections->n != m->nnz || aggregates->n != m->nrow || aggregate_root_nodes->n != m->nrow
+       || prolong->dtype != m->dtype || !(relax > 0.0))
+        RAMD_FAIL(RAMD_ERR_ARG, "AMGSmoothedAggregation: relax > 0, int vectors of the operator's sizes, P of its type");
+    if(m->nnz <= 0)
+        return RAMD_OK;
+    if(m->dtype == RAMD_F64)
+        return sa_prolong_t<double>(m, relax, lumping_strat, connections, aggregates, aggregate_root_nodes, prolong);
+    return sa_prolong_t<float>(m, (float)relax, lumping_strat, connections, aggregates, aggregate_root_nodes, prolong);
 }
 
 int ramd_mat_amg_unsmoothed_prolong(ramd_mat_t m, ramd_vec_t aggregates, ramd_vec_t aggregate_root_nodes,

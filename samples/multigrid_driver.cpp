@@ -7,6 +7,8 @@
 //                                                            k (CG preconditioned by a K-cycle)
 //                                                            a (UAAMG, PMIS coarsening, as a solver)
 //                                                            c (CG preconditioned by UAAMG)
+//                                                            s (SAAMG, PMIS coarsening, as a solver)
+//                                                            d (CG preconditioned by SAAMG)
 // Prints one RESULT line and the residual history (HIST lines), which tests/test_gpu_solvers.py compares with the
 // genuine library's run of the same setup (oracle/ref_probe).
 #include <cstdlib>
@@ -69,17 +71,22 @@ int main(int argc, char* argv[])
     mat.Apply(e, &rhs);
     x.Zeros();
 
-    if(variant == "a" || variant == "c")
+    if(variant == "a" || variant == "c" || variant == "s" || variant == "d")
     {
-        // the reference's sample sequence for UAAMG (clients/samples/ua-amg.cpp), PMIS coarsening
-        UAAMG<Mat, Vec, double> amg;
-        CG<Mat, Vec, double>    cg;
+        // the reference's sample sequence for UAAMG / SAAMG (clients/samples/ua-amg.cpp, sa-amg.cpp), PMIS coarsening
+        UAAMG<Mat, Vec, double>    ua;
+        SAAMG<Mat, Vec, double>    sa;
+        const bool                 smoothed = (variant == "s" || variant == "d");
+        BaseAMG<Mat, Vec, double>& amg      = smoothed ? static_cast<BaseAMG<Mat, Vec, double>&>(sa)
+                                                       : static_cast<BaseAMG<Mat, Vec, double>&>(ua);
+        CG<Mat, Vec, double>       cg;
         amg.SetOperator(mat);
-        amg.SetCoarseningStrategy(PMIS);
+        ua.SetCoarseningStrategy(PMIS);
+        sa.SetCoarseningStrategy(PMIS);
         amg.SetCoarsestLevel(20);
         amg.Verbose(0);
         IterativeLinearSolver<Mat, Vec, double>* s = &amg;
-        if(variant == "a")
+        if(variant == "a" || variant == "s")
             amg.InitMaxIter(60);
         else
         {

@@ -197,6 +197,12 @@ def test_amg_pmis_aggregation_vs_golden(ra, name):
     rp, ci, va = P.CopyToCSR()
     eq(rp, g["amg_P_rowptr"]); eq(ci, g["amg_P_col"]); eq(va, g["amg_P_val"])
     assert P.GetN() == int(g["amg_P_col"].max()) + 1
+    # smoothed aggregation: (I - relax D_f^-1 A_f) P_tent, both lumping strategies
+    for key, relax, lump in (("amg_Ps", 2.0 / 3.0, 0), ("amg_Ps1", 0.5, 1)):
+        Ps = ra.LocalMatrix()
+        A.AMGSmoothedAggregation(relax, conn, agg, roots, Ps, lump)
+        rp, ci, va = Ps.CopyToCSR()
+        eq(rp, g[key + "_rowptr"]); eq(ci, g[key + "_col"]); eq(va, g[key + "_val"])
 
 
 @pytest.mark.parametrize("name", CASES)

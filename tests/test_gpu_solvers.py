@@ -516,14 +516,15 @@ def test_cpp_uaamg_driver_vs_reference(tmp_path, name):
     mtx = str(tmp_path / (name + ".mtx"))
     rp, ci, va, _ = _inputs(name, g)
     _write_mtx(mtx, rp, ci, va)
-    for variant, tag in (("a", "uaamg_pmis"), ("c", "cg_uaamg")):
+    for variant, tag in (("a", "uaamg_pmis"), ("c", "cg_uaamg"), ("s", "saamg_pmis"), ("d", "cg_saamg")):
         r = subprocess.run([exe, mtx, variant], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
         out = r.stdout.decode()
         assert r.returncode == 0, out[-2000:]
         m = re.search(r"RESULT .*coarse_n=(\d+) coarse_nnz=(\d+) iters=(\d+) status=(\d+) residual=(\S+) error=(\S+)", out)
         assert m, out[-2000:]
-        if "uaamg_levels" in g:
-            assert int(m.group(1)) == int(g["uaamg_levels"][0])
+        lv = ("saamg" if "saamg" in tag else "uaamg") + "_levels"
+        if lv in g:
+            assert int(m.group(1)) == int(g[lv][0])
         meta = g[tag + "_meta"]
         assert abs(int(m.group(3)) - int(meta[0])) <= 1 and int(m.group(4)) == int(meta[1]), (tag, m.groups(), meta)
         hist = np.array([float(v) for v in re.findall(r"HIST (\S+)", out)])
