@@ -7,6 +7,7 @@
 #include "matrix_impl.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace ramd
 {
@@ -233,6 +234,100 @@ __global__ __launch_bounds__(kBlock) void k_mm_compact(int nrow, const long long
     }
 }
 
+// ---- MatrixMult, long rows: products in generation order, two stable sorts (by column, then by row) keep that order
+// among equal (row, column) pairs, one thread per distinct pair sums its run left to right
+__global__ __launch_bounds__(kBlock) void k_mm_any_long(int nrow, const long long* __restrict__ off, int limit,
+                                                        int* __restrict__ flag)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+        if(off[i + 1] - off[i] > limit)
+            *flag = 1;
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_mm_generate(int nrow, const int* __restrict__ arp,
+                                                        const int* __restrict__ aci, const T* __restrict__ aval,
+                                                        const int* __restrict__ brp, const int* __restrict__ bci,
+                                                        const T* __restrict__ bval, const long long* __restrict__ off,
+                                                        int* __restrict__ prow, int* __restrict__ pcol,
+                                                        T* __restrict__ pval)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+    {
+        long long q = off[i];
+        for(int ja = arp[i]; ja < arp[i + 1]; ++ja)
+        {
+            const int ca = aci[ja];
+            const T   va = aval[ja];
+            for(int jb = brp[ca]; jb < brp[ca + 1]; ++jb, ++q)
+            {
+                prow[q] = (int)i;
+                pcol[q] = bci[jb];
+                pval[q] = va * bval[jb];
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_gather_int(int64_t n, const int* __restrict__ idx, const int* __restrict__ src,
+                                                       int* __restrict__ dst)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gsz)
+        dst[k] = src[idx[k]];
+}
+// perm[k] = o1[o2[k]]; head[k] = 1 where the (row, col) pair differs from the previous one; cnt[row] += heads
+__global__ __launch_bounds__(kBlock) void k_mm_heads(int64_t n, const int* __restrict__ o1, const int* __restrict__ o2,
+                                                     const int* __restrict__ prow, const int* __restrict__ pcol,
+                                                     int* __restrict__ perm, int* __restrict__ head, int* __restrict__ cnt)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k <= n; k += gsz)
+    {
+        if(k == n)
+        {
+            head[k] = 0;
+            continue;
+        }
+        const int p = o1[o2[k]];
+        perm[k]     = p;
+        bool h      = true;
+        if(k > 0)
+        {
+            const int pp = o1[o2[k - 1]];
+            h            = prow[pp] != prow[p] || pcol[pp] != pcol[p];
+        }
+        head[k] = h ? 1 : 0;
+        if(h)
+            atomicAdd(cnt + prow[p], 1);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_mm_reduce(int64_t n, const int* __restrict__ perm,
+                                                      const int* __restrict__ headpos, const int* __restrict__ prow,
+                                                      const int* __restrict__ pcol, const T* __restrict__ pval,
+                                                      int* __restrict__ cci, T* __restrict__ cval)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gsz)
+    {
+        if(headpos[k + 1] == headpos[k]) // not the first product of its (row, col) pair
+            continue;
+        const int p = perm[k];
+        const int r = prow[p], c = pcol[p];
+        T         v = pval[p];
+        for(int64_t q = k + 1; q < n; ++q)
+        {
+            const int pq = perm[q];
+            if(prow[pq] != r || pcol[pq] != c)
+                break;
+            v += pval[pq];
+        }
+        cci[headpos[k]]  = c;
+        cval[headpos[k]] = v;
+    }
+}
+
 static int scan_to_rowptr(int* rp, int nrow, int* total)
 {
     Backend& b = backend();
@@ -292,6 +387,104 @@ static int matrix_add_t(ramd_mat_s* m, const ramd_mat_s* o, T alpha, T beta, boo
 }
 
 template <typename T>
+static int mat_mult_sorted_t(ramd_mat_s* c, const ramd_mat_s* a, const ramd_mat_s* bm, const long long* off,
+                             long long total)
+{
+    Backend&  b = backend();
+    const int n = a->nrow;
+    if(total >= 0x7fffffffLL)
+        RAMD_FAIL(RAMD_ERR_UNSUPPORTED, "MatrixMult: more than 2^31 intermediate products");
+    const int64_t P    = (int64_t)total;
+    int *         prow = nullptr, *pcol = nullptr, *o1 = nullptr, *o2 = nullptr, *k2 = nullptr, *head = nullptr;
+    int*          cnt  = nullptr;
+    void*         pval = nullptr;
+    int           s    = dev_alloc(&prow, P);
+    if(s == RAMD_OK)
+        s = dev_alloc(&pcol, P);
+    if(s == RAMD_OK)
+        s = dev_alloc(&o1, P);
+    if(s == RAMD_OK)
+        s = dev_alloc(&o2, P);
+    if(s == RAMD_OK)
+        s = dev_alloc(&k2, P);
+    if(s == RAMD_OK)
+        s = dev_alloc(&head, P + 1);
+    if(s == RAMD_OK)
+        s = dev_alloc(&cnt, (int64_t)n + 1);
+    if(s == RAMD_OK && cached_malloc(&pval, (size_t)P * sizeof(T) + kPad) != hipSuccess)
+        s = RAMD_ERR_HIP;
+    int   nnz = 0;
+    int*  cci = nullptr;
+    void* cv  = nullptr;
+    if(s == RAMD_OK)
+    {
+        const int gp = ew_grid(std::max<int64_t>(P, 1));
+        hipLaunchKernelGGL((k_mm_generate<T>), dim3(ew_grid(std::max(n, 1))), dim3(kBlock), 0, b.cur, n, a->rp, a->ci,
+                           (const T*)a->val, bm->rp, bm->ci, (const T*)bm->val, off, prow, pcol, (T*)pval);
+        s = device_stable_sort_by_key(pcol, P, std::max(bm->ncol - 1, 0), o1);
+        if(s == RAMD_OK)
+        {
+            hipLaunchKernelGGL(k_gather_int, dim3(gp), dim3(kBlock), 0, b.cur, P, (const int*)o1, (const int*)prow, k2);
+            s = device_stable_sort_by_key(k2, P, std::max(n - 1, 0), o2);
+        }
+        if(s == RAMD_OK && hipMemsetAsync(cnt, 0, sizeof(int) * ((size_t)n + 1), b.cur) != hipSuccess)
+            s = RAMD_ERR_HIP;
+        if(s == RAMD_OK)
+        {
+            // k2 is reused as the composed permutation
+            hipLaunchKernelGGL(k_mm_heads, dim3(ew_grid(P + 1)), dim3(kBlock), 0, b.cur, P, (const int*)o1, (const int*)o2,
+                               (const int*)prow, (const int*)pcol, k2, head, cnt);
+            s = device_exclusive_scan(head, head, P + 1);
+        }
+        if(s == RAMD_OK)
+            s = scan_to_rowptr(cnt, n, &nnz);
+        if(s == RAMD_OK)
+            s = dev_alloc(&cci, nnz);
+        if(s == RAMD_OK && cached_malloc(&cv, (size_t)nnz * sizeof(T) + kPad) != hipSuccess)
+            s = RAMD_ERR_HIP;
+        if(s == RAMD_OK)
+        {
+            hipLaunchKernelGGL((k_mm_reduce<T>), dim3(gp), dim3(kBlock), 0, b.cur, P, (const int*)k2, (const int*)head,
+                               (const int*)prow, (const int*)pcol, (const T*)pval, cci, (T*)cv);
+            hipError_t e = hipGetLastError();
+            if(e == hipSuccess)
+                e = hipStreamSynchronize(b.cur);
+            if(e != hipSuccess)
+                s = RAMD_ERR_HIP;
+        }
+    }
+    dev_free(&prow);
+    dev_free(&pcol);
+    dev_free(&o1);
+    dev_free(&o2);
+    dev_free(&k2);
+    dev_free(&head);
+    if(pval)
+        (void)cached_free(pval);
+    if(s != RAMD_OK)
+    {
+        dev_free(&cnt);
+        dev_free(&cci);
+        if(cv)
+            (void)cached_free(cv);
+        return s;
+    }
+    mat_free_csr(c);
+    mat_free_ell(c);
+    mat_free_coo(c);
+    mat_free_dia(c);
+    mat_free_analysis(c);
+    c->format = RAMD_CSR;
+    c->nrow   = a->nrow;
+    c->ncol   = bm->ncol;
+    c->nnz    = nnz;
+    c->rp     = cnt;
+    c->ci     = cci;
+    c->val    = cv;
+    return RAMD_OK;
+}
+
+template <typename T>
 static int mat_mult_t(ramd_mat_s* c, const ramd_mat_s* a, const ramd_mat_s* bm)
 {
     Backend&   b    = backend();
@@ -315,6 +508,38 @@ static int mat_mult_t(ramd_mat_s* c, const ramd_mat_s* a, const ramd_mat_s* bm)
             e = hipStreamSynchronize(b.cur);
         if(e != hipSuccess)
             s = RAMD_ERR_HIP;
+    }
+    if(s == RAMD_OK)
+    {
+        // rows with many products: the per-thread insertion below is quadratic in the row length
+        static int limit = -1;
+        if(limit < 0)
+        {
+            const char* e = getenv("RAMD_MM_INSERT_LIMIT");
+            limit         = e ? atoi(e) : 64;
+        }
+        int  any  = 0;
+        int* flag = nullptr;
+        s         = dev_alloc(&flag, 1);
+        if(s == RAMD_OK)
+        {
+            hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), b.cur);
+            hipLaunchKernelGGL(k_mm_any_long, dim3(ew_grid(std::max(n, 1))), dim3(kBlock), 0, b.cur, n, off, limit, flag);
+            if(e == hipSuccess)
+                e = hipMemcpyAsync(&any, flag, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+            if(e == hipSuccess)
+                e = hipStreamSynchronize(b.cur);
+            if(e != hipSuccess)
+                s = RAMD_ERR_HIP;
+        }
+        dev_free(&flag);
+        if(s == RAMD_OK && any)
+        {
+            s = mat_mult_sorted_t<T>(c, a, bm, off, total);
+            dev_free(&off);
+            dev_free(&cnt);
+            return s;
+        }
     }
     if(s == RAMD_OK)
         s = dev_alloc(&pcol, total);

@@ -184,6 +184,21 @@ def test_csr_matrix_algebra_vs_golden(ra, name):
     assert np.allclose(y1.numpy(), y2.numpy(), rtol=1e-12, atol=1e-10 * np.max(np.abs(y2.numpy())))
 
 
+def test_matmult_long_row_path_in_a_fresh_process():
+    """MatrixMult switches to products + two stable sorts + run sums when a row has many products; forced here on the
+    small golden matrices (RAMD_MM_INSERT_LIMIT=0 is read once per process) -- same bit-exact arrays"""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, RAMD_MM_INSERT_LIMIT="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-q", "-x",
+                        "-m", "gpu", "-k", "csr_matrix_algebra_vs_golden"], env=env, cwd=root, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "5 passed" in out, out[-3000:]
+
+
 @pytest.mark.parametrize("name", ["gr3030", "poisson8", "lap2d7"])
 def test_amg_pmis_aggregation_vs_golden(ra, name):
     """UA-AMG setup of the first level: strong connections, PMIS aggregates, root nodes, prolongation operator --
