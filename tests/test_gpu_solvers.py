@@ -376,6 +376,7 @@ def test_mcilu_without_decomposition(ra, S, name):
     assert abs(ls.GetIterationCount() - int(g["gmres_mcilu_meta"][0])) <= 2
 
 
+@pytest.mark.parametrize("name", ["gr3030", "poisson8", "lap2d7"])
 def test_fixedpoint_as_smoother(ra, S, name):
     """FlagSmoother(): exactly max_iter sweeps and no residual bookkeeping (solver.cpp:686-720) -- the result
     of 3 MC-SGS sweeps equals the reference's to round-off of nothing: every step is an exact kernel"""
