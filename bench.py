@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--no-reference-gpu", action="store_true")
     ap.add_argument("--solver", default="cg", choices=["cg", "gmres", "bicgstab", "mixed"],
                     help="headline = cg; the others run the remaining BASELINE.json configs through the same harness")
-    ap.add_argument("--precond", default="jacobi", choices=["none", "jacobi", "ilu0", "mcsgs", "mcgs", "mcilu", "ic", "sgs"])
+    ap.add_argument("--precond", default="jacobi", choices=["none", "jacobi", "ilu0", "mcsgs", "mcgs", "mcilu", "ic", "sgs", "uaamg", "saamg"])
     ap.add_argument("--itsolve", type=int, default=0,
                     help="ILU / IC / SGS: iterative triangular solves (TriSolverAlg_Iterative) with this many sweeps")
     ap.add_argument("--force-global", action="store_true",
@@ -217,7 +217,7 @@ def main():
 
         HEAD = {"cg": S.CG, "gmres": S.GMRES, "bicgstab": S.BiCGStab}.get(args.solver, S.CG)
         HPC = {"none": None, "jacobi": S.Jacobi, "ilu0": S.ILU, "mcsgs": S.MultiColoredSGS,
-               "mcgs": S.MultiColoredGS, "mcilu": S.MultiColoredILU, "ic": S.IC, "sgs": S.SGS}[args.precond]
+               "mcgs": S.MultiColoredGS, "mcilu": S.MultiColoredILU, "ic": S.IC, "sgs": S.SGS, "uaamg": S.UAAMG, "saamg": S.SAAMG}[args.precond]
         if args.solver == "mixed":
             def run(iters, *_a):  # noqa: F811  (config 5 on one GPU)
                 inner = S.CG(np.float32)
@@ -320,7 +320,7 @@ def main():
             "metric": "%s iterations/s, 3D 7-pt Poisson %d^3 %s fp64" % (
                 {"cg": "CG", "gmres": "GMRES(30)", "bicgstab": "BiCGStab", "mixed": "MixedPrecisionDC(fp64/fp32 CG)"}[args.solver]
                 + "+" + {"none": "none", "jacobi": "Jacobi", "ilu0": "ILU(0)", "mcsgs": "MC-SGS", "mcgs": "MC-GS",
-                         "mcilu": "MC-ILU(0,1)", "ic": "IC", "sgs": "SGS"}[args.precond], N,
+                         "mcilu": "MC-ILU(0,1)", "ic": "IC", "sgs": "SGS", "uaamg": "UAAMG(PMIS)", "saamg": "SAAMG(PMIS)"}[args.precond], N,
                 args.format.upper()),
             "value": round(it / dt, 3), "unit": "iters/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / it * 1e3, 5), "higher_is_better": True,

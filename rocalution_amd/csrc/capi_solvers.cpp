@@ -60,10 +60,24 @@ struct Precs
     GS<M, V, T>              gs;
     SGS<M, V, T>             sgs;
     IC<M, V, T>              ic;
+    UAAMG<M, V, T>           uaamg;
+    SAAMG<M, V, T>           saamg;
+    Precs()
+    {
+        // the aggregation runs on the device with the PMIS strategy (the Greedy default is a sequential host sweep)
+        uaamg.SetCoarseningStrategy(PMIS);
+        saamg.SetCoarseningStrategy(PMIS);
+        uaamg.Verbose(0);
+        saamg.Verbose(0);
+    }
     Solver<M, V, T>*         get(int kind)
     {
         switch(kind)
         {
+        case RAMD_PC_UAAMG:
+            return &uaamg;
+        case RAMD_PC_SAAMG:
+            return &saamg;
         case RAMD_PC_GS:
             return &gs;
         case RAMD_PC_SGS:
@@ -461,7 +475,7 @@ extern "C" {
 
 int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out)
 {
-    if(!out || solver < 0 || solver > RAMD_SOLVER_CHEBYSHEV || precond < 0 || precond > RAMD_PC_IC
+    if(!out || solver < 0 || solver > RAMD_SOLVER_CHEBYSHEV || precond < 0 || precond > RAMD_PC_SAAMG
        || (dtype != RAMD_F64 && dtype != RAMD_F32))
         return RAMD_ERR_ARG;
     GUARD_BEGIN
@@ -476,7 +490,7 @@ int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out)
 
 int ramd_solver_create_mixed(int inner_solver, int inner_precond, ramd_solver_t* out)
 {
-    if(!out || inner_solver < 0 || inner_solver > 2 || inner_precond < 0 || inner_precond > RAMD_PC_IC)
+    if(!out || inner_solver < 0 || inner_solver > 2 || inner_precond < 0 || inner_precond > RAMD_PC_SAAMG)
         return RAMD_ERR_ARG;
     GUARD_BEGIN
     ramd_solver_s* s = new ramd_solver_s;

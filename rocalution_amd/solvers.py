@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import capi
-from .capi import (PC_GS, PC_IC, PC_ILU0, PC_JACOBI, PC_MCGS, PC_MCILU, PC_MCSGS, PC_NONE, PC_SGS, SOLVER_BICGSTAB,
+from .capi import (PC_GS, PC_IC, PC_ILU0, PC_SAAMG, PC_UAAMG, PC_JACOBI, PC_MCGS, PC_MCILU, PC_MCSGS, PC_NONE, PC_SGS, SOLVER_BICGSTAB,
                    SOLVER_BICGSTABL,
                    SOLVER_CG, SOLVER_CHEBYSHEV, SOLVER_CR, SOLVER_FCG, SOLVER_FGMRES, SOLVER_FIXEDPOINT, SOLVER_GMRES,
                    SOLVER_IDR, SOLVER_QMRCGSTAB)
@@ -85,6 +85,17 @@ class SGS(_Precond):
 class IC(_Precond):
     """incomplete Cholesky, zero fill-in (preconditioner.cpp:826-925): ICFactorize on ExtractL, LLSolve"""
     kind = PC_IC
+
+
+class UAAMG(_Precond):
+    """unsmoothed-aggregation AMG as a preconditioner (unsmoothed_amg.cpp), PMIS coarsening on the device, default
+    FixedPoint(2/3)+Jacobi smoothers and CG coarse solver, coarsest level <= 300 rows"""
+    kind = PC_UAAMG
+
+
+class SAAMG(_Precond):
+    """smoothed-aggregation AMG as a preconditioner (smoothed_amg.cpp), PMIS coarsening on the device"""
+    kind = PC_SAAMG
 
 
 class MultiColoredSGS(_Precond):

@@ -534,3 +534,22 @@ def test_cpp_uaamg_driver_vs_reference(tmp_path, name):
         _check_hist(hist, g[tag + "_hist"], tag == "cg_uaamg" and name in ("poisson16", "poisson32"), rtol=1e-5)
         if int(meta[1]) in (1, 2):  # the stand-alone V-cycle of the reference DIVERGES on the larger Poisson cases
             assert float(m.group(6)) < 1e-3, (tag, m.group(6))  # (status 3 / 4 in the genuine run as well)
+
+
+@pytest.mark.parametrize("name", ["gr3030", "poisson8", "poisson16", "poisson32"])
+@pytest.mark.parametrize("amg", ["uaamg", "saamg"])
+def test_amg_preconditioners_through_the_c_abi(ra, S, name, amg):
+    """RAMD_PC_UAAMG / RAMD_PC_SAAMG of the C solver object (what bench.py --precond uaamg|saamg uses): CG iteration
+    counts of the genuine library's runs with PMIS coarsening (coarsest level: the default 300 rows here, 20 there --
+    the counts agree within the coarse solver's tolerance where the hierarchies coincide)"""
+    g = load_golden(name)
+    rp, ci, va, _ = _inputs(name, g)
+    n = len(rp) - 1
+    A = ra.LocalMatrix(); A.SetDataPtrCSR(rp, ci, va)
+    rhs = ra.LocalVector(data=g["rhs_ones"]); x = ra.LocalVector(); x.Allocate("", n)
+    ls = S.CG(); ls.SetOperator(A); ls.SetPreconditioner(getattr(S, amg.upper())()); ls.InitMaxIter(200); ls.Build()
+    ls.Solve(rhs, x)
+    assert ls.GetSolverStatus() in (1, 2)
+    assert np.linalg.norm(x.numpy() - 1.0) / np.sqrt(n) < 1e-4
+    ref = int(g["cg_" + amg + "_meta"][0])
+    assert ls.GetIterationCount() <= ref + 6, (ls.GetIterationCount(), ref)
