@@ -328,6 +328,129 @@ __global__ __launch_bounds__(kBlock) void k_mm_reduce(int64_t n, const int* __re
     }
 }
 
+// ---- MatrixMult, medium rows (<= kMmCap products): one workgroup per row; products into LDS in generation order with
+// the key (column, generation index), bitonic sort, one thread per distinct column sums its run in generation order.
+// Writes the compacted row into the scratch segment like k_mm_products (same k_mm_compact afterwards).
+constexpr int kMmCap = 2048;
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_mm_row_lds(int nrow, const int* __restrict__ arp,
+                                                       const int* __restrict__ aci, const T* __restrict__ aval,
+                                                       const int* __restrict__ brp, const int* __restrict__ bci,
+                                                       const T* __restrict__ bval, const long long* __restrict__ off,
+                                                       int* __restrict__ pcol, T* __restrict__ pval,
+                                                       int* __restrict__ cnt, int* __restrict__ toolong)
+{
+    __shared__ unsigned long long key[kMmCap];
+    __shared__ T                  val[kMmCap];
+    __shared__ int                aux[kMmCap + 1]; // prefix of the B-row lengths, later the output positions
+    const int tid = threadIdx.x;
+    for(int i = blockIdx.x; i <= nrow; i += gridDim.x)
+    {
+        if(i == nrow)
+        {
+            if(tid == 0)
+                cnt[i] = 0;
+            continue;
+        }
+        const long long s  = off[i];
+        const long long ul = off[i + 1] - s;
+        const int       ra = arp[i], na = arp[i + 1] - ra;
+        if(ul > kMmCap || na > kMmCap)
+        {
+            if(tid == 0)
+            {
+                *toolong = 1;
+                cnt[i]   = 0;
+            }
+            continue;
+        }
+        const int ub = (int)ul;
+        int       m  = 1;
+        while(m < ub)
+            m <<= 1;
+        for(int t = tid; t < na; t += kBlock)
+            aux[t] = brp[aci[ra + t] + 1] - brp[aci[ra + t]];
+        __syncthreads();
+        if(tid == 0) // exclusive prefix (rows of A are short)
+        {
+            int run = 0;
+            for(int t = 0; t < na; ++t)
+            {
+                const int l = aux[t];
+                aux[t]      = run;
+                run += l;
+            }
+        }
+        __syncthreads();
+        for(int t = tid; t < na; t += kBlock)
+        {
+            const int ca = aci[ra + t];
+            const T   va = aval[ra + t];
+            int       q  = aux[t];
+            for(int jb = brp[ca]; jb < brp[ca + 1]; ++jb, ++q)
+            {
+                key[q] = ((unsigned long long)(unsigned)bci[jb] << 32) | (unsigned)q;
+                val[q] = va * bval[jb];
+            }
+        }
+        for(int q = ub + tid; q < m; q += kBlock)
+        {
+            key[q] = ~0ull;
+            val[q] = (T)0;
+        }
+        __syncthreads();
+        for(int k = 2; k <= m; k <<= 1)
+            for(int j = k >> 1; j > 0; j >>= 1)
+            {
+                for(int idx = tid; idx < m; idx += kBlock)
+                {
+                    const int ixj = idx ^ j;
+                    if(ixj > idx)
+                    {
+                        const bool               up = (idx & k) == 0;
+                        const unsigned long long a = key[idx], c = key[ixj];
+                        if((a > c) == up)
+                        {
+                            key[idx] = c;
+                            key[ixj] = a;
+                            const T v = val[idx];
+                            val[idx]  = val[ixj];
+                            val[ixj]  = v;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        // heads of the runs of equal columns -> output positions
+        for(int idx = tid; idx < ub; idx += kBlock)
+            aux[idx] = (idx == 0 || (unsigned)(key[idx - 1] >> 32) != (unsigned)(key[idx] >> 32)) ? 1 : 0;
+        __syncthreads();
+        if(tid == 0)
+        {
+            int run = 0;
+            for(int idx = 0; idx < ub; ++idx)
+            {
+                const int h = aux[idx];
+                aux[idx]    = h ? run : -1;
+                run += h;
+            }
+            cnt[i] = run;
+        }
+        __syncthreads();
+        for(int idx = tid; idx < ub; idx += kBlock)
+            if(aux[idx] >= 0)
+            {
+                const unsigned c = (unsigned)(key[idx] >> 32);
+                T              v = val[idx];
+                for(int q = idx + 1; q < ub && (unsigned)(key[q] >> 32) == c; ++q)
+                    v += val[q];
+                pcol[s + aux[idx]] = (int)c;
+                pval[s + aux[idx]] = v;
+            }
+        __syncthreads();
+    }
+}
+
 static int scan_to_rowptr(int* rp, int nrow, int* total)
 {
     Backend& b = backend();
@@ -532,13 +655,96 @@ static int mat_mult_t(ramd_mat_s* c, const ramd_mat_s* a, const ramd_mat_s* bm)
             if(e != hipSuccess)
                 s = RAMD_ERR_HIP;
         }
+        static int use_lds = -1;
+        if(use_lds < 0)
+        {
+            const char* e2 = getenv("RAMD_MM_LDS");
+            use_lds        = e2 ? atoi(e2) : 1;
+        }
+        bool lds_done = false;
+        if(s == RAMD_OK && any && use_lds)
+        {
+            // medium rows: workgroup per row, sorted in LDS; a row beyond the cap sends the whole product to the global sort
+            s = dev_alloc(&pcol, total);
+            if(s == RAMD_OK && cached_malloc(&pval, (size_t)total * sizeof(T) + kPad) != hipSuccess)
+                s = RAMD_ERR_HIP;
+            int toolong = 0;
+            if(s == RAMD_OK)
+            {
+                hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), b.cur);
+                const int  g = (int)std::min<int64_t>((int64_t)n + 1, (int64_t)backend().num_cu * 8);
+                hipLaunchKernelGGL((k_mm_row_lds<T>), dim3(g), dim3(kBlock), 0, b.cur, n, a->rp, a->ci, (const T*)a->val,
+                                   bm->rp, bm->ci, (const T*)bm->val, off, pcol, (T*)pval, cnt, flag);
+                if(e == hipSuccess)
+                    e = hipMemcpyAsync(&toolong, flag, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+                if(e == hipSuccess)
+                    e = hipStreamSynchronize(b.cur);
+                if(e != hipSuccess)
+                    s = RAMD_ERR_HIP;
+            }
+            if(s == RAMD_OK && !toolong)
+                lds_done = true;
+            else
+            {
+                dev_free(&pcol);
+                if(pval)
+                    (void)cached_free(pval);
+                pval = nullptr;
+            }
+        }
         dev_free(&flag);
-        if(s == RAMD_OK && any)
+        if(s == RAMD_OK && any && !lds_done)
         {
             s = mat_mult_sorted_t<T>(c, a, bm, off, total);
             dev_free(&off);
             dev_free(&cnt);
             return s;
+        }
+        if(lds_done)
+        {
+            int nnz2 = 0;
+            s        = scan_to_rowptr(cnt, n, &nnz2);
+            int*  cci2 = nullptr;
+            void* cv2  = nullptr;
+            if(s == RAMD_OK)
+                s = dev_alloc(&cci2, nnz2);
+            if(s == RAMD_OK && cached_malloc(&cv2, (size_t)nnz2 * sizeof(T) + kPad) != hipSuccess)
+                s = RAMD_ERR_HIP;
+            if(s == RAMD_OK)
+            {
+                hipLaunchKernelGGL((k_mm_compact<T>), dim3(ew_grid(std::max(n, 1))), dim3(kBlock), 0, b.cur, n, off, pcol,
+                                   (const T*)pval, cnt, cci2, (T*)cv2);
+                hipError_t e = hipGetLastError();
+                if(e == hipSuccess)
+                    e = hipStreamSynchronize(b.cur);
+                if(e != hipSuccess)
+                    s = RAMD_ERR_HIP;
+            }
+            dev_free(&off);
+            dev_free(&pcol);
+            if(pval)
+                (void)cached_free(pval);
+            if(s != RAMD_OK)
+            {
+                dev_free(&cnt);
+                dev_free(&cci2);
+                if(cv2)
+                    (void)cached_free(cv2);
+                return s;
+            }
+            mat_free_csr(c);
+            mat_free_ell(c);
+            mat_free_coo(c);
+            mat_free_dia(c);
+            mat_free_analysis(c);
+            c->format = RAMD_CSR;
+            c->nrow   = a->nrow;
+            c->ncol   = bm->ncol;
+            c->nnz    = nnz2;
+            c->rp     = cnt;
+            c->ci     = cci2;
+            c->val    = cv2;
+            return RAMD_OK;
         }
     }
     if(s == RAMD_OK)

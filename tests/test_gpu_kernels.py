@@ -184,13 +184,16 @@ def test_csr_matrix_algebra_vs_golden(ra, name):
     assert np.allclose(y1.numpy(), y2.numpy(), rtol=1e-12, atol=1e-10 * np.max(np.abs(y2.numpy())))
 
 
-def test_matmult_long_row_path_in_a_fresh_process():
-    """MatrixMult switches to products + two stable sorts + run sums when a row has many products; forced here on the
-    small golden matrices (RAMD_MM_INSERT_LIMIT=0 is read once per process) -- same bit-exact arrays"""
+@pytest.mark.parametrize("lds", ["1", "0"])
+def test_matmult_long_row_paths_in_a_fresh_process(lds):
+    """MatrixMult leaves the per-thread insertion when a row has many products: (lds=1) one workgroup per row sorts the
+    products by (column, generation index) in LDS, (lds=0 / rows beyond 2048 products) two global stable sorts; both
+    followed by in-order run sums.  Forced here on the small golden matrices (the switches are read once per
+    process) -- same bit-exact arrays as the reference"""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, RAMD_MM_INSERT_LIMIT="0")
+    env = dict(os.environ, RAMD_MM_INSERT_LIMIT="0", RAMD_MM_LDS=lds)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-q", "-x",
                         "-m", "gpu", "-k", "csr_matrix_algebra_vs_golden"], env=env, cwd=root, stdout=subprocess.PIPE,
