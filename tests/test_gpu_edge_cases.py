@@ -194,6 +194,41 @@ def test_fp32_solvers_vs_oracle(ra, S, oracle, sname):
     assert np.max(np.abs(x.numpy() - 1.0)) < 1e-3
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_ic_and_iterative_triangular_solves_vs_oracle_both_precisions(ra, S, oracle, dtype):
+    """IC (factorisation + L L^T solve) and the Jacobi-sweep triangular solves of ILU / IC / GS / SGS in fp32 and fp64
+    against the oracle on a 3-D Poisson operator: bit-exact applies, incl. the warm-started second apply"""
+    rp, ci, va = gen.poisson7(9, dtype)
+    n = len(rp) - 1
+    x = np.random.default_rng(7).uniform(-1, 1, n).astype(dtype)
+    A = ra.LocalMatrix(dtype); A.SetDataPtrCSR(rp, ci, va)
+    vx = ra.LocalVector(dtype, data=x)
+
+    def apply(pc, reps):
+        ls = S.CG(dtype); ls.SetOperator(A); ls.SetPreconditioner(pc); ls.Build()
+        z = ra.LocalVector(dtype); z.Allocate("", n)
+        for _ in range(reps):
+            ls.PrecondApply(vx, z)
+        out = z.numpy().copy()
+        ls.Clear()
+        return out
+
+    eq(apply(S.IC(), 1), oracle.precond_apply(oracle.PC_IC, rp, ci, va, x))
+    for cls, kind, descr in ((S.ILU, "PC_ILU0", (30, 1e-3, True)), (S.IC, "PC_IC", (6, 1e-3, False)),
+                             (S.GS, "PC_GS", (7, 1e-2, True)), (S.SGS, "PC_SGS", (4, 1e-3, False))):
+        for reps in (1, 2):
+            d = S.SolverDescr(); d.SetTriSolverAlg(S.TriSolverAlg_Iterative)
+            d.SetIterativeSolverMaxIteration(descr[0]); d.SetIterativeSolverTolerance(descr[1])
+            d.EnableIterativeSolverTolerance() if descr[2] else d.DisableIterativeSolverTolerance()
+            pc = cls(); pc.SetSolverDescriptor(d)
+            try:
+                oracle.set_solver_descr(True, *descr)
+                ref = oracle.precond_apply_rep(getattr(oracle, kind), rp, ci, va, x, reps)
+            finally:
+                oracle.set_solver_descr(False)
+            eq(apply(pc, reps), ref)
+
+
 def test_build_clear_cycles_do_not_leak_device_memory(ra, S):
     """every Build()/Clear() pair (preconditioner plans, analysis data, work vectors, format conversions) gives
     its device memory back: free memory after 12 cycles == after 2 cycles"""
