@@ -1192,6 +1192,25 @@ public:
         RAMD_CHECK(ramd_mat_amg_pmis_aggregate(this->dev_, (double)eps, connections->handle(), aggregates->handle(),
                                                aggregate_root_nodes->handle()));
     }
+    // the reference's default strategy: its sequential sweep restated as a sync-free device sweep with the same result;
+    // needs a symmetric strong-connection graph
+    void AMGGreedyAggregate(ValueType eps, LocalVector<int>* connections, LocalVector<int>* aggregates,
+                            LocalVector<int>* aggregate_root_nodes) const
+    {
+        this->need_accel_("AMGGreedyAggregate");
+        assert(connections != NULL && aggregates != NULL && aggregate_root_nodes != NULL);
+        connections->MoveToAccelerator();
+        aggregates->MoveToAccelerator();
+        aggregate_root_nodes->MoveToAccelerator();
+        int s = ramd_mat_amg_greedy_aggregate(this->dev_, (double)eps, connections->handle(), aggregates->handle(),
+                                              aggregate_root_nodes->handle());
+        if(s == RAMD_ERR_UNSUPPORTED)
+        {
+            LOG_INFO("LocalMatrix::AMGGreedyAggregate(): " << ramd_last_error());
+            FATAL_ERROR(__FILE__, __LINE__);
+        }
+        RAMD_CHECK(s);
+    }
     void AMGSmoothedAggregation(ValueType relax, const LocalVector<int>& connections, const LocalVector<int>& aggregates,
                                 const LocalVector<int>& aggregate_root_nodes, LocalMatrix<ValueType>* prolong,
                                 int lumping_strat = 0) const

@@ -3955,8 +3955,8 @@ protected:
     Solver<OperatorType, VectorType, ValueType>** sm_default_;
 };
 
-// UAAMG (src/solvers/multigrid/unsmoothed_amg.cpp): unsmoothed aggregation.  The aggregation runs on the device with
-// the PMIS strategy; the reference's sequential Greedy strategy is not provided by this backend.
+// UAAMG (src/solvers/multigrid/unsmoothed_amg.cpp): unsmoothed aggregation; both coarsening strategies run on the
+// device (Greedy: the sequential sweep of the reference as a sync-free sweep with the same aggregates).
 template <class OperatorType, class VectorType, typename ValueType>
 class UAAMG : public BaseAMG<OperatorType, VectorType, ValueType>
 {
@@ -4008,13 +4008,10 @@ protected:
         ValueType        eps = this->eps_;
         for(int i = 0; i < this->levels_ - 1; ++i)
             eps *= static_cast<ValueType>(0.5);
-        if(this->strat_ != PMIS)
-        {
-            LOG_INFO("UAAMG: CoarseningStrategy Greedy (a sequential sweep) is not provided by this backend; use "
-                     "SetCoarseningStrategy(PMIS)");
-            FATAL_ERROR(__FILE__, __LINE__);
-        }
-        op.AMGPMISAggregate(eps, &connections, &aggregates, &aggregate_root_nodes);
+        if(this->strat_ == PMIS)
+            op.AMGPMISAggregate(eps, &connections, &aggregates, &aggregate_root_nodes);
+        else
+            op.AMGGreedyAggregate(eps, &connections, &aggregates, &aggregate_root_nodes);
         op.AMGUnsmoothedAggregation(aggregates, aggregate_root_nodes, pro);
         connections.Clear();
         aggregates.Clear();
@@ -4058,7 +4055,7 @@ public:
     {
         LOG_INFO("SAAMG solver");
         LOG_INFO("SAAMG number of levels " << this->levels_);
-        LOG_INFO("SAAMG using PMIS smoothed aggregation");
+        LOG_INFO(((this->strat_ == PMIS) ? "SAAMG using PMIS smoothed aggregation" : "SAAMG using greedy smoothed aggregation"));
     }
     virtual void SetCouplingStrength(ValueType eps)
     {
@@ -4095,13 +4092,10 @@ protected:
         ValueType        eps = this->eps_;
         for(int i = 0; i < this->levels_ - 1; ++i)
             eps *= static_cast<ValueType>(0.5);
-        if(this->strat_ != PMIS)
-        {
-            LOG_INFO("SAAMG: CoarseningStrategy Greedy (a sequential sweep) is not provided by this backend; use "
-                     "SetCoarseningStrategy(PMIS)");
-            FATAL_ERROR(__FILE__, __LINE__);
-        }
-        op.AMGPMISAggregate(eps, &connections, &aggregates, &aggregate_root_nodes);
+        if(this->strat_ == PMIS)
+            op.AMGPMISAggregate(eps, &connections, &aggregates, &aggregate_root_nodes);
+        else
+            op.AMGGreedyAggregate(eps, &connections, &aggregates, &aggregate_root_nodes);
         op.AMGSmoothedAggregation(this->relax_, connections, aggregates, aggregate_root_nodes, pro,
                                   this->lumping_strat_ == AddWeakConnections ? 0 : 1);
         connections.Clear();

@@ -282,6 +282,10 @@ int ramd_mat_extract_tri(ramd_mat_t m, ramd_mat_t out, int upper, int with_diag)
  * AMGUnsmoothedAggregation: P with one entry per aggregated row).  Int vectors (the reference: bool / int64_t). */
 int ramd_mat_amg_pmis_aggregate(ramd_mat_t m, double eps, ramd_vec_t connections, ramd_vec_t aggregates,
                                 ramd_vec_t aggregate_root_nodes);
+/* AMGGreedyAggregate (local_matrix.cpp:6409-6517; host sweep host_matrix_csr.cpp:4841-4938), the reference's default
+ * CoarseningStrategy: same aggregates as the sequential sweep; RAMD_ERR_UNSUPPORTED for a non-symmetric strength graph */
+int ramd_mat_amg_greedy_aggregate(ramd_mat_t m, double eps, ramd_vec_t connections, ramd_vec_t aggregates,
+                                  ramd_vec_t aggregate_root_nodes);
 int ramd_mat_amg_unsmoothed_prolong(ramd_mat_t m, ramd_vec_t aggregates, ramd_vec_t aggregate_root_nodes,
                                     ramd_mat_t prolong);
 /* AMGSmoothedAggregation (local_matrix.cpp:6642-6760; host_matrix_csr.cpp:5936-6330): P = (I - relax D_f^-1 A_f) P_tent

@@ -951,6 +951,44 @@ static int cmd_gen(const std::string& in, const std::string& out)
             dump("amg_roots", ir.data(), ir.size());
             dump_csr("amg_P", P);
             {
+                // the default coarsening strategy: the sequential greedy sweep
+                LocalVector<bool>    gconn;
+                LocalVector<int64_t> gagg, groots;
+                mat.AMGGreedyAggregate(0.01, &gconn, &gagg, &groots);
+                std::vector<int64_t> h64((size_t)A.n);
+                std::vector<int32_t> h32((size_t)A.n);
+                gagg.CopyToHostData(h64.data());
+                for(size_t k = 0; k < h32.size(); ++k)
+                    h32[k] = (int32_t)h64[k];
+                dump("amg_gagg", h32.data(), h32.size());
+                groots.CopyToHostData(h64.data());
+                for(size_t k = 0; k < h32.size(); ++k)
+                    h32[k] = (int32_t)h64[k];
+                dump("amg_groots", h32.data(), h32.size());
+                for(int variant = 0; variant < 2; ++variant)
+                {
+                    CG<MatD, VecD, double> ls;
+                    UAAMG<MatD, VecD, double>& ua = *new UAAMG<MatD, VecD, double>; // default strategy: Greedy
+                    SAAMG<MatD, VecD, double>& sa = *new SAAMG<MatD, VecD, double>;
+                    ua.SetCoarsestLevel(20);
+                    sa.SetCoarsestLevel(20);
+                    ua.Verbose(0);
+                    sa.Verbose(0);
+                    ls.SetOperator(mat);
+                    if(variant == 0)
+                        ls.SetPreconditioner(ua);
+                    else
+                        ls.SetPreconditioner(sa);
+                    ls.InitMaxIter(100);
+                    ls.Build();
+                    double lv = (double)(variant == 0 ? ua.GetNumLevels() : sa.GetNumLevels());
+                    dump(variant == 0 ? "uaamg_greedy_levels" : "saamg_greedy_levels", &lv, 1);
+                    sol.Zeros();
+                    run_solver(variant == 0 ? "cg_uaamg_greedy" : "cg_saamg_greedy", ls, rhs, sol);
+                    ls.Clear();
+                }
+            }
+            {
                 MatD Ps;
                 mat.AMGSmoothedAggregation(2.0 / 3.0, conn, agg, roots, &Ps, 0);
                 dump_csr("amg_Ps", Ps);

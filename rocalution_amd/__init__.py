@@ -285,6 +285,12 @@ class LocalMatrix:
         capi.check(_lib().ramd_mat_amg_pmis_aggregate(self._h, float(eps), conn._h, agg._h, roots._h))
         return conn, agg, roots
 
+    def AMGGreedyAggregate(self, eps):
+        """-> (connections, aggregates, aggregate_root_nodes): the reference's sequential greedy sweep, same result"""
+        conn, agg, roots = LocalVector(np.int32), LocalVector(np.int32), LocalVector(np.int32)
+        capi.check(_lib().ramd_mat_amg_greedy_aggregate(self._h, float(eps), conn._h, agg._h, roots._h))
+        return conn, agg, roots
+
     def AMGUnsmoothedAggregation(self, aggregates, aggregate_root_nodes, prolong):
         capi.check(_lib().ramd_mat_amg_unsmoothed_prolong(self._h, aggregates._h, aggregate_root_nodes._h, prolong._h))
 

@@ -457,6 +457,247 @@ static int pmis_aggregate_t(ramd_mat_s* m, T eps, ramd_vec_s* vconn, ramd_vec_s*
     return RAMD_OK;
 }
 
+// ---- Greedy aggregation (host_matrix_csr.cpp:4841-4938): the reference's sequential sweep -- row i becomes the seed of a
+// new aggregate when it is still unassigned at its turn, claims its strong neighbours (overwriting earlier claims) and
+// tentatively the unassigned strong neighbours of those -- restated as three parallel steps with the same result:
+//  1. seeds = greedy distance-2 independent set in index order: i is a seed iff no seed s < i has i among its strong
+//     neighbours or their strong neighbours.  Sync-free: a row polls the decisions of the lower-index rows of its 2-hop
+//     neighbourhood (workgroups in natural order by ticket, so every awaited row is resident or done).
+//  2. aggregate number = rank of the seed (device scan).
+//  3. owner of a non-seed row: the LARGEST seed among its strong neighbours (direct claims overwrite in sweep order),
+//     else the SMALLEST seed two strong hops away (the first tentative claim sticks).
+// Needs a symmetric strong-connection graph (checked; RAMD_ERR_UNSUPPORTED otherwise).
+__global__ __launch_bounds__(kBlock) void k_conn_symmetric(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                           const int* __restrict__ conn, int* __restrict__ asym)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+        for(int j = rp[i]; j < rp[i + 1]; ++j)
+            if(conn[j])
+            {
+                const int c     = ci[j];
+                bool      found = false;
+                for(int k = rp[c]; k < rp[c + 1]; ++k)
+                    if(ci[k] == (int)i && conn[k])
+                    {
+                        found = true;
+                        break;
+                    }
+                if(!found)
+                    *asym = 1;
+            }
+}
+// dec: 0 undecided, 1 seed, 2 covered, 3 removed (no strong connection)
+__global__ __launch_bounds__(kBlock) void k_greedy_init(int nrow, const int* __restrict__ rp, const int* __restrict__ conn,
+                                                        int* __restrict__ dec)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+    {
+        int d = 3;
+        for(int j = rp[i]; j < rp[i + 1]; ++j)
+            if(conn[j])
+            {
+                d = 0;
+                break;
+            }
+        dec[i] = d;
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_greedy_seeds(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                         const int* __restrict__ conn, int* dec, unsigned* counter)
+{
+    const unsigned blk  = take_ticket(counter, 0u);
+    const int64_t  t    = (int64_t)blk * kBlock + threadIdx.x;
+    const bool     live = t < nrow;
+    const int      i    = live ? (int)t : 0;
+    bool           fin  = !live;
+    if(live && __hip_atomic_load(dec + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3)
+        fin = true;
+    const int rs = live ? rp[i] : 0, re = live ? rp[i + 1] : 0;
+    int       j  = rs; // cursor over my strong neighbours c
+    int       k  = -1; // -1: c itself is the candidate; >= 0: cursor over the strong neighbours of c
+    int       spins = 0, backoff = 1;
+    do
+    {
+        spin_guard(spins);
+        bool advanced = false;
+        if(!fin)
+        {
+            // walk the candidates until one is undecided (retry later), one is a seed (covered) or none is left (seed)
+            while(true)
+            {
+                if(j >= re)
+                {
+                    __hip_atomic_store(dec + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    fin = advanced = true;
+                    break;
+                }
+                if(!conn[j])
+                {
+                    ++j;
+                    k = -1;
+                    continue;
+                }
+                const int c = ci[j];
+                int       u; // candidate
+                if(k < 0)
+                    u = c;
+                else
+                {
+                    if(k >= rp[c + 1])
+                    {
+                        ++j;
+                        k = -1;
+                        continue;
+                    }
+                    if(!conn[k])
+                    {
+                        ++k;
+                        continue;
+                    }
+                    u = ci[k];
+                }
+                if(u < i)
+                {
+                    const int d = __hip_atomic_load(dec + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if(d == 0)
+                        break; // not decided yet: poll again
+                    if(d == 1)
+                    {
+                        __hip_atomic_store(dec + i, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        fin = advanced = true;
+                        break;
+                    }
+                }
+                advanced = true;
+                if(k < 0)
+                    k = rp[c];
+                else
+                    ++k;
+            }
+        }
+        backoff = poll_backoff(__ballot(advanced) != 0ull, backoff);
+    } while(__ballot(!fin) != 0ull);
+}
+__global__ __launch_bounds__(kBlock) void k_greedy_flags(int nrow, const int* __restrict__ dec, int* __restrict__ flag)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= nrow; i += gsz)
+        flag[i] = (i < nrow && dec[i] == 1) ? 1 : 0;
+}
+__global__ __launch_bounds__(kBlock) void k_greedy_assign(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                          const int* __restrict__ conn, const int* __restrict__ dec,
+                                                          const int* __restrict__ rank, int* __restrict__ agg,
+                                                          int* __restrict__ roots)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+    {
+        const int d = dec[i];
+        if(d == 3)
+        {
+            agg[i] = -2; // removed; the root entry keeps the zero of Allocate
+            continue;
+        }
+        int owner = -1;
+        if(d == 1)
+            owner = (int)i;
+        else
+        {
+            for(int j = rp[i]; j < rp[i + 1]; ++j) // direct claims: the last one in sweep order = the largest seed
+                if(conn[j] && dec[ci[j]] == 1)
+                    owner = max(owner, ci[j]);
+            if(owner < 0)
+            {
+                int best = 0x7fffffff; // tentative claims: the first one = the smallest seed two hops away
+                for(int j = rp[i]; j < rp[i + 1]; ++j)
+                    if(conn[j])
+                    {
+                        const int c = ci[j];
+                        for(int k = rp[c]; k < rp[c + 1]; ++k)
+                            if(conn[k] && dec[ci[k]] == 1)
+                                best = min(best, ci[k]);
+                    }
+                owner = best;
+            }
+        }
+        agg[i]   = rank[owner];
+        roots[i] = owner;
+    }
+}
+
+template <typename T>
+static int greedy_aggregate_t(ramd_mat_s* m, T eps, ramd_vec_s* vconn, ramd_vec_s* vagg, ramd_vec_s* vroots)
+{
+    Backend&  b    = backend();
+    const int n    = m->nrow;
+    const int grid = ew_grid(std::max(n, 1));
+    RAMD_TRY(ramd_vec_allocate(vconn, m->nnz));
+    RAMD_TRY(ramd_vec_allocate(vagg, n));
+    RAMD_TRY(ramd_vec_allocate(vroots, n));
+    int*      conn  = (int*)vconn->d;
+    int*      agg   = (int*)vagg->d;
+    int*      roots = (int*)vroots->d;
+    T*        diag  = nullptr;
+    int *     dec = nullptr, *rank = nullptr, *flag = nullptr;
+    unsigned* counter = nullptr;
+    int       s = dev_alloc(&diag, n);
+    if(s == RAMD_OK)
+        s = dev_alloc(&dec, n);
+    if(s == RAMD_OK)
+        s = dev_alloc(&rank, (int64_t)n + 1);
+    if(s == RAMD_OK)
+        s = dev_alloc(&flag, 1);
+    if(s == RAMD_OK)
+        s = dev_alloc(&counter, 1);
+    hipError_t e = hipSuccess;
+    int        asym = 0;
+    if(s == RAMD_OK)
+    {
+        e = hipMemsetAsync(diag, 0, sizeof(T) * (size_t)n, b.cur);
+        if(e == hipSuccess)
+            e = hipMemsetAsync(flag, 0, sizeof(int), b.cur);
+        if(e == hipSuccess)
+            e = hipMemsetAsync(counter, 0, sizeof(unsigned), b.cur);
+        hipLaunchKernelGGL((k_extract_diag_plain<T>), dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, m->ci,
+                           (const T*)m->val, diag);
+        hipLaunchKernelGGL((k_amg_connections<T>), dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const T*)m->val,
+                           (const T*)diag, eps * eps, conn);
+        hipLaunchKernelGGL(k_conn_symmetric, dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const int*)conn, flag);
+        if(e == hipSuccess)
+            e = hipMemcpyAsync(&asym, flag, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+        if(e == hipSuccess)
+            e = hipStreamSynchronize(b.cur);
+    }
+    if(s == RAMD_OK && e == hipSuccess && !asym)
+    {
+        hipLaunchKernelGGL(k_greedy_init, dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, (const int*)conn, dec);
+        const unsigned nb = (unsigned)((n + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(k_greedy_seeds, dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const int*)conn, dec,
+                           counter);
+        hipLaunchKernelGGL(k_greedy_flags, dim3(ew_grid((int64_t)n + 1)), dim3(kBlock), 0, b.cur, n, (const int*)dec, rank);
+        s = device_exclusive_scan(rank, rank, (int64_t)n + 1);
+        if(s == RAMD_OK)
+            hipLaunchKernelGGL(k_greedy_assign, dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const int*)conn,
+                               (const int*)dec, (const int*)rank, agg, roots);
+        e = hipGetLastError();
+        if(e == hipSuccess)
+            e = hipStreamSynchronize(b.cur);
+    }
+    dev_free(&diag);
+    dev_free(&dec);
+    dev_free(&rank);
+    dev_free(&flag);
+    dev_free(&counter);
+    RAMD_TRY(s);
+    RAMD_HIP(e);
+    if(asym)
+        RAMD_FAIL(RAMD_ERR_UNSUPPORTED,
+                  "AMGGreedyAggregate: the strong-connection graph is not symmetric (use CoarseningStrategy PMIS)");
+    return RAMD_OK;
+}
+
 template <typename T>
 static int ua_prolong_t(const ramd_mat_s* m, const ramd_vec_s* vagg, const ramd_vec_s* vroots, ramd_mat_s* p)
 {
@@ -545,6 +786,24 @@ int ramd_mat_amg_pmis_aggregate(ramd_mat_t m, double eps, ramd_vec_t connections
     if(m->dtype == RAMD_F64)
         return pmis_aggregate_t<double>(m, eps, connections, aggregates, aggregate_root_nodes);
     return pmis_aggregate_t<float>(m, (float)eps, connections, aggregates, aggregate_root_nodes);
+}
+
+int ramd_mat_amg_greedy_aggregate(ramd_mat_t m, double eps, ramd_vec_t connections, ramd_vec_t aggregates,
+                                  ramd_vec_t aggregate_root_nodes)
+{
+    if(!m || !connections || !aggregates || !aggregate_root_nodes)
+        RAMD_FAIL(RAMD_ERR_ARG, "null handle");
+    if(m->format != RAMD_CSR)
+        return RAMD_ERR_UNSUPPORTED;
+    if(connections->dtype != RAMD_I32 || aggregates->dtype != RAMD_I32 || aggregate_root_nodes->dtype != RAMD_I32)
+        RAMD_FAIL(RAMD_ERR_ARG, "AMGGreedyAggregate: int vectors expected");
+    if(m->nrow != m->ncol)
+        RAMD_FAIL(RAMD_ERR_ARG, "AMGGreedyAggregate: square matrix expected");
+    if(m->nnz <= 0)
+        return RAMD_OK;
+    if(m->dtype == RAMD_F64)
+        return greedy_aggregate_t<double>(m, eps, connections, aggregates, aggregate_root_nodes);
+    return greedy_aggregate_t<float>(m, (float)eps, connections, aggregates, aggregate_root_nodes);
 }
 
 int ramd_mat_amg_smoothed_prolong(ramd_mat_t m, double relax, int lumping_strat, ramd_vec_t connections,

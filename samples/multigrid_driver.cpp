@@ -9,6 +9,7 @@
 //                                                            c (CG preconditioned by UAAMG)
 //                                                            s (SAAMG, PMIS coarsening, as a solver)
 //                                                            d (CG preconditioned by SAAMG)
+//                                                            g / h (as c / d with the default Greedy coarsening)
 // Prints one RESULT line and the residual history (HIST lines), which tests/test_gpu_solvers.py compares with the
 // genuine library's run of the same setup (oracle/ref_probe).
 #include <cstdlib>
@@ -71,18 +72,22 @@ int main(int argc, char* argv[])
     mat.Apply(e, &rhs);
     x.Zeros();
 
-    if(variant == "a" || variant == "c" || variant == "s" || variant == "d")
+    if(variant == "a" || variant == "c" || variant == "s" || variant == "d" || variant == "g" || variant == "h")
     {
         // the reference's sample sequence for UAAMG / SAAMG (clients/samples/ua-amg.cpp, sa-amg.cpp), PMIS coarsening
         UAAMG<Mat, Vec, double>    ua;
         SAAMG<Mat, Vec, double>    sa;
-        const bool                 smoothed = (variant == "s" || variant == "d");
+        const bool                 smoothed = (variant == "s" || variant == "d" || variant == "h");
+        const bool                 greedy   = (variant == "g" || variant == "h");
         BaseAMG<Mat, Vec, double>& amg      = smoothed ? static_cast<BaseAMG<Mat, Vec, double>&>(sa)
                                                        : static_cast<BaseAMG<Mat, Vec, double>&>(ua);
         CG<Mat, Vec, double>       cg;
         amg.SetOperator(mat);
-        ua.SetCoarseningStrategy(PMIS);
-        sa.SetCoarseningStrategy(PMIS);
+        if(!greedy) // (Greedy is the default of both classes)
+        {
+            ua.SetCoarseningStrategy(PMIS);
+            sa.SetCoarseningStrategy(PMIS);
+        }
         amg.SetCoarsestLevel(20);
         amg.Verbose(0);
         IterativeLinearSolver<Mat, Vec, double>* s = &amg;

@@ -215,6 +215,9 @@ def test_amg_pmis_aggregation_vs_golden(ra, name):
     rp, ci, va = P.CopyToCSR()
     eq(rp, g["amg_P_rowptr"]); eq(ci, g["amg_P_col"]); eq(va, g["amg_P_val"])
     assert P.GetN() == int(g["amg_P_col"].max()) + 1
+    # the default strategy: the reference's sequential greedy sweep, restated as a sync-free device sweep
+    gconn, gagg, groots = A.AMGGreedyAggregate(0.01)
+    eq(gconn.numpy(), g["amg_conn"]); eq(gagg.numpy(), g["amg_gagg"]); eq(groots.numpy(), g["amg_groots"])
     # smoothed aggregation: (I - relax D_f^-1 A_f) P_tent, both lumping strategies
     for key, relax, lump in (("amg_Ps", 2.0 / 3.0, 0), ("amg_Ps1", 0.5, 1)):
         Ps = ra.LocalMatrix()

@@ -517,13 +517,14 @@ def test_cpp_uaamg_driver_vs_reference(tmp_path, name):
     mtx = str(tmp_path / (name + ".mtx"))
     rp, ci, va, _ = _inputs(name, g)
     _write_mtx(mtx, rp, ci, va)
-    for variant, tag in (("a", "uaamg_pmis"), ("c", "cg_uaamg"), ("s", "saamg_pmis"), ("d", "cg_saamg")):
+    for variant, tag in (("a", "uaamg_pmis"), ("c", "cg_uaamg"), ("s", "saamg_pmis"), ("d", "cg_saamg"),
+                         ("g", "cg_uaamg_greedy"), ("h", "cg_saamg_greedy")):
         r = subprocess.run([exe, mtx, variant], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
         out = r.stdout.decode()
         assert r.returncode == 0, out[-2000:]
         m = re.search(r"RESULT .*coarse_n=(\d+) coarse_nnz=(\d+) iters=(\d+) status=(\d+) residual=(\S+) error=(\S+)", out)
         assert m, out[-2000:]
-        lv = ("saamg" if "saamg" in tag else "uaamg") + "_levels"
+        lv = ("saamg" if "saamg" in tag else "uaamg") + ("_greedy" if "greedy" in tag else "") + "_levels"
         if lv in g:
             assert int(m.group(1)) == int(g[lv][0])
         meta = g[tag + "_meta"]
@@ -531,7 +532,7 @@ def test_cpp_uaamg_driver_vs_reference(tmp_path, name):
         hist = np.array([float(v) for v in re.findall(r"HIST (\S+)", out)])
         # the V-cycle of the larger Poisson cases is not a contraction (see the stand-alone run), CG around it
         # amplifies the summation-order differences of the dots: strict for 8 iterations, then the BiCGStab rule
-        _check_hist(hist, g[tag + "_hist"], tag == "cg_uaamg" and name in ("poisson16", "poisson32"), rtol=1e-5)
+        _check_hist(hist, g[tag + "_hist"], tag.startswith("cg_uaamg") and name in ("poisson16", "poisson32"), rtol=1e-5)
         if int(meta[1]) in (1, 2):  # the stand-alone V-cycle of the reference DIVERGES on the larger Poisson cases
             assert float(m.group(6)) < 1e-3, (tag, m.group(6))  # (status 3 / 4 in the genuine run as well)
 
