@@ -504,8 +504,11 @@ __global__ __launch_bounds__(kBlock) void k_greedy_init(int nrow, const int* __r
         dec[i] = d;
     }
 }
+// cov[h] = 1: a seed marked h as lying within two strong hops (an accelerator: the rows it covers stop walking their
+// candidate lists, which are quadratic in the row length on the dense coarse operators of smoothed aggregation)
 __global__ __launch_bounds__(kBlock) void k_greedy_seeds(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
-                                                         const int* __restrict__ conn, int* dec, unsigned* counter)
+                                                         const int* __restrict__ conn, int* dec, int* cov,
+                                                         unsigned* counter)
 {
     const unsigned blk  = take_ticket(counter, 0u);
     const int64_t  t    = (int64_t)blk * kBlock + threadIdx.x;
@@ -522,6 +525,11 @@ __global__ __launch_bounds__(kBlock) void k_greedy_seeds(int nrow, const int* __
     {
         spin_guard(spins);
         bool advanced = false;
+        if(!fin && __hip_atomic_load(cov + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+        {
+            __hip_atomic_store(dec + i, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            fin = advanced = true;
+        }
         if(!fin)
         {
             // walk the candidates until one is undecided (retry later), one is a seed (covered) or none is left (seed)
@@ -531,6 +539,16 @@ __global__ __launch_bounds__(kBlock) void k_greedy_seeds(int nrow, const int* __
                 {
                     __hip_atomic_store(dec + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     fin = advanced = true;
+                    for(int a = rs; a < re; ++a) // mark my two-hop neighbourhood
+                        if(conn[a])
+                        {
+                            const int c = ci[a];
+                            if(c > i)
+                                __hip_atomic_store(cov + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            for(int q = rp[c]; q < rp[c + 1]; ++q)
+                                if(conn[q] && ci[q] > i)
+                                    __hip_atomic_store(cov + ci[q], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                     break;
                 }
                 if(!conn[j])
@@ -640,11 +658,13 @@ static int greedy_aggregate_t(ramd_mat_s* m, T eps, ramd_vec_s* vconn, ramd_vec_
     int*      agg   = (int*)vagg->d;
     int*      roots = (int*)vroots->d;
     T*        diag  = nullptr;
-    int *     dec = nullptr, *rank = nullptr, *flag = nullptr;
+    int *     dec = nullptr, *rank = nullptr, *flag = nullptr, *cov = nullptr;
     unsigned* counter = nullptr;
     int       s = dev_alloc(&diag, n);
     if(s == RAMD_OK)
         s = dev_alloc(&dec, n);
+    if(s == RAMD_OK)
+        s = dev_alloc(&cov, n);
     if(s == RAMD_OK)
         s = dev_alloc(&rank, (int64_t)n + 1);
     if(s == RAMD_OK)
@@ -673,8 +693,9 @@ static int greedy_aggregate_t(ramd_mat_s* m, T eps, ramd_vec_s* vconn, ramd_vec_
     if(s == RAMD_OK && e == hipSuccess && !asym)
     {
         hipLaunchKernelGGL(k_greedy_init, dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, (const int*)conn, dec);
+        e = hipMemsetAsync(cov, 0, sizeof(int) * (size_t)n, b.cur);
         const unsigned nb = (unsigned)((n + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL(k_greedy_seeds, dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const int*)conn, dec,
+        hipLaunchKernelGGL(k_greedy_seeds, dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const int*)conn, dec, cov,
                            counter);
         hipLaunchKernelGGL(k_greedy_flags, dim3(ew_grid((int64_t)n + 1)), dim3(kBlock), 0, b.cur, n, (const int*)dec, rank);
         s = device_exclusive_scan(rank, rank, (int64_t)n + 1);
@@ -687,6 +708,7 @@ static int greedy_aggregate_t(ramd_mat_s* m, T eps, ramd_vec_s* vconn, ramd_vec_
     }
     dev_free(&diag);
     dev_free(&dec);
+    dev_free(&cov);
     dev_free(&rank);
     dev_free(&flag);
     dev_free(&counter);

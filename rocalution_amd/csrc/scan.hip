@@ -3,6 +3,8 @@
 #include "device_utils.hpp"
 #include "matrix_impl.hpp"
 
+#include <cstdlib>
+
 #include <utility>
 #include <vector>
 
@@ -118,7 +120,155 @@ __global__ __launch_bounds__(kBlock) void k_sort_scatter(int64_t n, const int* _
     }
 }
 
+// ---- stable LSD radix sort by key, 4 bits per pass: per-tile digit histograms (bin-major) -> one scan -> scatter with
+// the in-tile rank of every element among the equal digits (thread-private LDS counters, blocked arrangement, so
+// ranks follow the input order).  A pass moves ~20 bytes per element; 21-bit keys take 6 passes instead of 21.
+constexpr int kRadixItems = 8;
+constexpr int kRadixTile  = kBlock * kRadixItems;
+__global__ __launch_bounds__(kBlock) void k_radix_hist(int64_t n, const int* __restrict__ keys, int shift,
+                                                       int nblocks, int* __restrict__ hist)
+{
+    __shared__ int h[16];
+    if(threadIdx.x < 16)
+        h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kRadixTile + (int64_t)threadIdx.x * kRadixItems;
+#pragma unroll
+    for(int e = 0; e < kRadixItems; ++e)
+        if(base + e < n)
+            atomicAdd(&h[(keys[base + e] >> shift) & 15], 1);
+    __syncthreads();
+    if(threadIdx.x < 16)
+        hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+__global__ __launch_bounds__(kBlock) void k_radix_scatter(int64_t n, const int* __restrict__ keys,
+                                                          const int* __restrict__ vals, int shift, int nblocks,
+                                                          const int* __restrict__ hist, int* __restrict__ okeys,
+                                                          int* __restrict__ ovals)
+{
+    __shared__ int cnt[16][kBlock];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for(int d = 0; d < 16; ++d)
+        cnt[d][tid] = 0;
+    const int64_t base = (int64_t)blockIdx.x * kRadixTile + (int64_t)tid * kRadixItems;
+    int           k[kRadixItems];
+#pragma unroll
+    for(int e = 0; e < kRadixItems; ++e)
+    {
+        k[e] = (base + e < n) ? keys[base + e] : 0;
+        if(base + e < n)
+            cnt[(k[e] >> shift) & 15][tid] += 1; // my own column: no conflicts
+    }
+    __syncthreads();
+    if(tid < 16) // exclusive prefix over the threads, one digit per thread
+    {
+        int run = 0;
+        for(int t = 0; t < kBlock; ++t)
+        {
+            const int c = cnt[tid][t];
+            cnt[tid][t] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for(int e = 0; e < kRadixItems; ++e)
+        if(base + e < n)
+        {
+            const int d   = (k[e] >> shift) & 15;
+            const int r   = cnt[d][tid]++;
+            const int pos = hist[(int64_t)d * nblocks + blockIdx.x] + r;
+            okeys[pos]    = k[e];
+            ovals[pos]    = vals ? vals[base + e] : (int)(base + e);
+        }
+}
+
+static int device_stable_sort_radix4(const int* keys, int64_t n, int max_key, int* order_out)
+{
+    Backend& b    = backend();
+    int      bits = 0;
+    while((1ll << bits) <= (long long)max_key)
+        ++bits;
+    const int64_t nblk64 = (n + kRadixTile - 1) / kRadixTile;
+    if(nblk64 * 16 + 1 >= 0x7fffffffLL)
+        return RAMD_ERR_UNSUPPORTED;
+    const int nblocks = (int)nblk64;
+    int *     ka = nullptr, *kb = nullptr, *va = nullptr, *vb = nullptr, *hist = nullptr;
+    int       s = dev_alloc(&ka, n);
+    if(s == RAMD_OK)
+        s = dev_alloc(&kb, n);
+    if(s == RAMD_OK)
+        s = dev_alloc(&va, n);
+    if(s == RAMD_OK)
+        s = dev_alloc(&vb, n);
+    if(s == RAMD_OK)
+        s = dev_alloc(&hist, (int64_t)nblocks * 16 + 1);
+    if(s == RAMD_OK && hipMemcpyAsync(ka, keys, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, b.cur) != hipSuccess)
+        s = RAMD_ERR_HIP;
+    bool first = true;
+    for(int shift = 0; shift < bits && s == RAMD_OK; shift += 4)
+    {
+        hipLaunchKernelGGL(k_radix_hist, dim3((unsigned)nblocks), dim3(kBlock), 0, b.cur, n, (const int*)ka, shift,
+                           nblocks, hist);
+        s = device_exclusive_scan(hist, hist, (int64_t)nblocks * 16 + 1);
+        if(s != RAMD_OK)
+            break;
+        hipLaunchKernelGGL(k_radix_scatter, dim3((unsigned)nblocks), dim3(kBlock), 0, b.cur, n, (const int*)ka,
+                           first ? (const int*)nullptr : (const int*)va, shift, nblocks, (const int*)hist, kb, vb);
+        std::swap(ka, kb);
+        std::swap(va, vb);
+        first = false;
+    }
+    if(s == RAMD_OK)
+    {
+        hipError_t e = hipSuccess;
+        if(first) // all keys zero: identity order
+        {
+            std::vector<int> iota((size_t)n);
+            for(int64_t i = 0; i < n; ++i)
+                iota[(size_t)i] = (int)i;
+            e = hipMemcpy(order_out, iota.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice);
+        }
+        else
+            e = hipMemcpyAsync(order_out, va, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, b.cur);
+        if(e == hipSuccess)
+            e = hipGetLastError();
+        if(e == hipSuccess)
+            e = hipStreamSynchronize(b.cur);
+        if(e != hipSuccess)
+            s = RAMD_ERR_HIP;
+    }
+    dev_free(&ka);
+    dev_free(&kb);
+    dev_free(&va);
+    dev_free(&vb);
+    dev_free(&hist);
+    return s;
+}
+
+static int device_stable_sort_bitwise(const int* keys, int64_t n, int max_key, int* order_out);
+
 int device_stable_sort_by_key(const int* keys, int64_t n, int max_key, int* order_out)
+{
+    if(n <= 0)
+        return RAMD_OK;
+    static int bitwise = -1; // RAMD_SORT_BITWISE=1: the one-bit-per-pass variant (A/B experiments)
+    if(bitwise < 0)
+    {
+        const char* e = getenv("RAMD_SORT_BITWISE");
+        bitwise       = e ? atoi(e) : 0;
+    }
+    if(!bitwise)
+    {
+        int s = device_stable_sort_radix4(keys, n, max_key, order_out);
+        if(s != RAMD_ERR_UNSUPPORTED)
+            return s;
+    }
+    return device_stable_sort_bitwise(keys, n, max_key, order_out);
+}
+
+static int device_stable_sort_bitwise(const int* keys, int64_t n, int max_key, int* order_out)
 {
     if(n <= 0)
         return RAMD_OK;
