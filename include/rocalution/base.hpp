@@ -1169,6 +1169,20 @@ public:
         this->MoveToAccelerator();
         RAMD_CHECK(ramd_mat_mat_mult(this->dev_, A.dev_, B.dev_));
     }
+    void DiagonalMatrixMultR(const LocalVector<ValueType>& diag)
+    {
+        this->need_accel_("DiagonalMatrixMultR");
+        RAMD_CHECK(ramd_mat_diag_mult(this->dev_, diag.handle(), 0));
+    }
+    void DiagonalMatrixMultL(const LocalVector<ValueType>& diag)
+    {
+        this->need_accel_("DiagonalMatrixMultL");
+        RAMD_CHECK(ramd_mat_diag_mult(this->dev_, diag.handle(), 1));
+    }
+    void DiagonalMatrixMult(const LocalVector<ValueType>& diag) // deprecated alias of ...R in the reference
+    {
+        this->DiagonalMatrixMultR(diag);
+    }
     // this = R * A * P as (R * A) * P, two MatrixMult (local_matrix.cpp:5515-5594)
     void TripleMatrixProduct(const LocalMatrix<ValueType>& R, const LocalMatrix<ValueType>& A,
                              const LocalMatrix<ValueType>& P)

@@ -627,6 +627,200 @@ private:
     VectorType   inv_diag_entries_;
 };
 
+// ---- approximate-inverse preconditioners whose Solve is a sparse matrix-vector product (preconditioner_ai.cpp)
+// AIChebyshev :41-215: Chebyshev polynomial of the shifted operator built with MatrixMult / MatrixAdd
+template <class OperatorType, class VectorType, typename ValueType>
+class AIChebyshev : public Preconditioner<OperatorType, VectorType, ValueType>
+{
+public:
+    AIChebyshev()
+        : p_(0)
+        , lambda_min_(static_cast<ValueType>(0))
+        , lambda_max_(static_cast<ValueType>(0))
+    {
+    }
+    virtual ~AIChebyshev()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("Approximate Inverse Chebyshev(" << this->p_ << ") preconditioner");
+    }
+    virtual void Set(int p, ValueType lambda_min, ValueType lambda_max)
+    {
+        assert(p > 0 && lambda_min != static_cast<ValueType>(0) && lambda_max != static_cast<ValueType>(0)
+               && this->build_ == false);
+        this->p_          = p;
+        this->lambda_min_ = lambda_min;
+        this->lambda_max_ = lambda_max;
+    }
+    virtual void Build(void)
+    {
+        if(this->build_)
+            this->Clear();
+        this->build_ = true;
+        assert(this->op_ != NULL);
+        const ValueType one = static_cast<ValueType>(1);
+        this->AIChebyshev_.CloneFrom(*this->op_);
+        ValueType q = (one - std::sqrt(this->lambda_min_ / this->lambda_max_))
+                      / (one + std::sqrt(this->lambda_min_ / this->lambda_max_));
+        ValueType c = one / std::sqrt(this->lambda_min_ * this->lambda_max_);
+        OperatorType Z; // Z = 2/(beta-alpha) [A - (beta+alpha)/2]
+        Z.CloneFrom(*this->op_);
+        Z.AddScalarDiagonal(static_cast<ValueType>(-1) * (this->lambda_max_ + this->lambda_min_) / (static_cast<ValueType>(2)));
+        Z.ScaleDiagonal(static_cast<ValueType>(2) / (this->lambda_max_ - this->lambda_min_));
+        this->AIChebyshev_.AddScalarDiagonal(c / static_cast<ValueType>(2));
+        OperatorType Tkm2;
+        Tkm2.CloneFrom(Z);
+        c = c * static_cast<ValueType>(-1) * q;
+        this->AIChebyshev_.MatrixAdd(Tkm2, one, c, true);
+        OperatorType Tkm1;
+        Tkm1.CloneBackend(*this->op_);
+        Tkm1.MatrixMult(Z, Z);
+        Tkm1.Scale(static_cast<ValueType>(2));
+        Tkm1.AddScalarDiagonal(static_cast<ValueType>(-1));
+        c = c * static_cast<ValueType>(-1) * q;
+        this->AIChebyshev_.MatrixAdd(Tkm1, one, c, true);
+        OperatorType Tk;
+        Tk.CloneBackend(*this->op_);
+        for(int i = 2; i <= this->p_; ++i)
+        {
+            Tk.MatrixMult(Z, Tkm1);
+            Tk.MatrixAdd(Tkm2, static_cast<ValueType>(2), static_cast<ValueType>(-1), true);
+            c = c * static_cast<ValueType>(-1) * q;
+            this->AIChebyshev_.MatrixAdd(Tk, one, c, true);
+            if(i + 1 <= this->p_)
+            {
+                Tkm2.CloneFrom(Tkm1);
+                Tkm1.CloneFrom(Tk);
+            }
+        }
+    }
+    virtual void Clear(void)
+    {
+        this->AIChebyshev_.Clear();
+        this->build_ = false;
+    }
+    virtual void Solve(const VectorType& rhs, VectorType* x)
+    {
+        assert(this->build_ == true && x != NULL && x != &rhs);
+        this->AIChebyshev_.Apply(rhs, x);
+    }
+
+private:
+    OperatorType AIChebyshev_;
+    int          p_;
+    ValueType    lambda_min_, lambda_max_;
+};
+
+// TNS :477-713: truncated Neumann series, (I - L D^-1 + (L D^-1)^2) D^-1 (I - D^-1 L^T + (D^-1 L^T)^2), applied
+// implicitly (default: four triangular SpMVs) or as one explicit matrix
+template <class OperatorType, class VectorType, typename ValueType>
+class TNS : public Preconditioner<OperatorType, VectorType, ValueType>
+{
+public:
+    TNS()
+        : impl_(true)
+    {
+    }
+    virtual ~TNS()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("Truncated Neumann Series (TNS) Preconditioner");
+        LOG_INFO((this->impl_ ? "Implicit TNS L" : "Explicit TNS"));
+    }
+    virtual void Set(bool imp)
+    {
+        assert(this->build_ == false);
+        this->impl_ = imp;
+    }
+    virtual void Build(void)
+    {
+        if(this->build_)
+            this->Clear();
+        this->build_ = true;
+        assert(this->op_ != NULL);
+        if(this->impl_)
+        {
+            this->L_.CloneBackend(*this->op_);
+            this->LT_.CloneBackend(*this->op_);
+            this->tmp1_.CloneBackend(*this->op_);
+            this->tmp2_.CloneBackend(*this->op_);
+            this->Dinv_.CloneBackend(*this->op_);
+            this->op_->ExtractInverseDiagonal(&this->Dinv_);
+            this->op_->ExtractL(&this->L_, false);
+            this->L_.DiagonalMatrixMultR(this->Dinv_);
+            this->L_.Transpose(&this->LT_);
+            this->tmp1_.Allocate("tmp1 vec for TNS", this->op_->GetM());
+            this->tmp2_.Allocate("tmp2 vec for TNS", this->op_->GetM());
+        }
+        else
+        {
+            OperatorType K, KT;
+            this->L_.CloneBackend(*this->op_);
+            this->Dinv_.CloneBackend(*this->op_);
+            this->TNS_.CloneBackend(*this->op_);
+            K.CloneBackend(*this->op_);
+            KT.CloneBackend(*this->op_);
+            this->op_->ExtractInverseDiagonal(&this->Dinv_);
+            this->op_->ExtractL(&this->L_, true); // the diagonal entries stay in the pattern, flushed to zero
+            this->L_.ScaleDiagonal(static_cast<ValueType>(0));
+            this->L_.DiagonalMatrixMultR(this->Dinv_);
+            K.MatrixMult(this->L_, this->L_);
+            this->L_.AddScalarDiagonal(static_cast<ValueType>(-1));
+            K.MatrixAdd(this->L_, static_cast<ValueType>(1), static_cast<ValueType>(-1), true);
+            K.Transpose(&KT);
+            KT.DiagonalMatrixMultR(this->Dinv_);
+            this->TNS_.MatrixMult(KT, K);
+            K.Clear();
+            KT.Clear();
+            this->L_.Clear();
+            this->Dinv_.Clear();
+        }
+    }
+    virtual void Clear(void)
+    {
+        if(this->build_)
+        {
+            this->TNS_.Clear();
+            this->L_.Clear();
+            this->LT_.Clear();
+            this->Dinv_.Clear();
+            this->tmp1_.Clear();
+            this->tmp2_.Clear();
+            this->build_ = false;
+        }
+    }
+    virtual void Solve(const VectorType& rhs, VectorType* x)
+    {
+        assert(this->build_ == true && x != NULL && x != &rhs);
+        if(this->impl_)
+        {
+            this->L_.Apply(rhs, &this->tmp1_);
+            this->L_.Apply(this->tmp1_, &this->tmp2_);
+            this->tmp1_.AddScale(this->tmp2_, static_cast<ValueType>(-1));
+            x->CopyFrom(rhs);
+            x->AddScale(this->tmp1_, static_cast<ValueType>(-1));
+            x->PointWiseMult(this->Dinv_);
+            this->LT_.Apply(*x, &this->tmp1_);
+            this->LT_.Apply(this->tmp1_, &this->tmp2_);
+            x->ScaleAdd2(static_cast<ValueType>(1), this->tmp1_, static_cast<ValueType>(-1), this->tmp2_,
+                         static_cast<ValueType>(1));
+        }
+        else
+            this->TNS_.Apply(rhs, x);
+    }
+
+private:
+    OperatorType L_, LT_, TNS_;
+    VectorType   Dinv_, tmp1_, tmp2_;
+    bool         impl_;
+};
+
 // ---- GS / SGS: preconditioner.cpp:206-257 / :302-379 (sparse triangular solves on the matrix itself).
 // SGS::Build fills diag_entries_ with the INVERSE diagonal (:318, ExtractInverseDiagonal) -- kept as is.
 template <class OperatorType, class VectorType, typename ValueType>

@@ -292,6 +292,7 @@ int ramd_mat_amg_unsmoothed_prolong(ramd_mat_t m, ramd_vec_t aggregates, ramd_ve
  * on the strength-filtered matrix, lumping_strat 0 adds / 1 subtracts the weak couplings to the diagonal */
 int ramd_mat_amg_smoothed_prolong(ramd_mat_t m, double relax, int lumping_strat, ramd_vec_t connections,
                                   ramd_vec_t aggregates, ramd_vec_t aggregate_root_nodes, ramd_mat_t prolong);
+int ramd_mat_diag_mult(ramd_mat_t m, ramd_vec_t diag, int left); /* DiagonalMatrixMultL (1) / R (0), :3631-3676 */
 int ramd_mat_sort(ramd_mat_t m);
 int ramd_mat_transpose(ramd_mat_t m, ramd_mat_t out);
 int ramd_mat_matrix_add(ramd_mat_t m, ramd_mat_t other, double alpha, double beta, int structure);
@@ -357,7 +358,9 @@ enum { RAMD_PC_NONE = 0, RAMD_PC_JACOBI = 1, RAMD_PC_ILU0 = 2, RAMD_PC_MCSGS = 3
        RAMD_PC_GS = 6, RAMD_PC_SGS = 7, /* preconditioner.cpp:206-257 / :302-379 */
        RAMD_PC_IC = 8, /* :862-925 */
        /* unsmoothed_amg.cpp / smoothed_amg.cpp with CoarseningStrategy PMIS, default smoothers and coarse solver */
-       RAMD_PC_UAAMG = 9, RAMD_PC_SAAMG = 10 };
+       RAMD_PC_UAAMG = 9, RAMD_PC_SAAMG = 10,
+       /* preconditioner_ai.cpp: AIChebyshev :41-215 (params p, lambda_min, lambda_max), TNS :477-713 (param implicit) */
+       RAMD_PC_AICHEBYSHEV = 11, RAMD_PC_TNS = 12 };
 int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out);
 /* MixedPrecisionDC<fp64 outer, fp32 inner>: inner solver/preconditioner kinds */
 int ramd_solver_create_mixed(int inner_solver, int inner_precond, ramd_solver_t* out);
@@ -372,6 +375,8 @@ int ramd_solver_set_params(ramd_solver_t s, double p0, double p1);
 /* Solver::SetSolverDescriptor on the preconditioner (solver.cpp:293-301, SolverDescr solver.hpp:82-148): iterative != 0
  * selects TriSolverAlg_Iterative with the given sweep limit / tolerance / tolerance switch; before build */
 int ramd_solver_set_tri_solver(ramd_solver_t s, int iterative, int max_iter, double tol, int use_tol);
+/* parameters of the preconditioner: AIChebyshev::Set(p0 = p, p1 = lambda_min, p2 = lambda_max), TNS::Set(p0 != 0: implicit) */
+int ramd_solver_set_precond_params(ramd_solver_t s, double p0, double p1, double p2);
 int ramd_solver_set_fused(ramd_solver_t s, int on); /* fused device loops on/off (default on) */
 int ramd_solver_set_verbose(ramd_solver_t s, int verb);
 int ramd_solver_set_precond_format(ramd_solver_t s, int format); /* MultiColored::SetPrecondMatrixFormat */

@@ -456,6 +456,33 @@ static int cmd_gen(const std::string& in, const std::string& out)
         dump_vec("pc_itic_2", y);
         p.Clear();
     }
+    // --- approximate-inverse preconditioners built with matrix algebra (preconditioner_ai.cpp)
+    {
+        AIChebyshev<MatD, VecD, double> p;
+        p.Set(3, 0.05, 16.0);
+        p.SetOperator(mat);
+        p.Build();
+        p.Solve(x, &y);
+        dump_vec("pc_aicheb", y);
+        p.Clear();
+    }
+    {
+        TNS<MatD, VecD, double> p; // implicit (default)
+        p.SetOperator(mat);
+        p.Build();
+        p.Solve(x, &y);
+        dump_vec("pc_tns", y);
+        p.Clear();
+    }
+    {
+        TNS<MatD, VecD, double> p;
+        p.Set(false); // explicit matrix
+        p.SetOperator(mat);
+        p.Build();
+        p.Solve(x, &y);
+        dump_vec("pc_tns_expl", y);
+        p.Clear();
+    }
     {
         MultiColoredILU<MatD, VecD, double> p; // default ILU(0,1)
         p.SetOperator(mat);
@@ -770,6 +797,28 @@ static int cmd_gen(const std::string& in, const std::string& out)
             ls.Build();
             sol.Zeros();
             run_solver("cg_itic", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            CG<MatD, VecD, double>  ls;
+            TNS<MatD, VecD, double> p;
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(p);
+            ls.Build();
+            sol.Zeros();
+            run_solver("cg_tns", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            CG<MatD, VecD, double>          ls;
+            AIChebyshev<MatD, VecD, double> p;
+            p.Set(3, 0.05, 16.0);
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(p);
+            ls.InitMaxIter(300);
+            ls.Build();
+            sol.Zeros();
+            run_solver("cg_aicheb", ls, rhs, sol);
             ls.Clear();
         }
         {

@@ -31,6 +31,7 @@ struct SolverBase
     virtual void set_seed(unsigned long long) {}
     virtual void set_params(double, double) {}
     virtual void set_tri_solver(int, int, double, int) {}
+    virtual void set_precond_params(double, double, double) {}
     virtual bool rebuild_numeric()
     {
         return false;
@@ -62,6 +63,8 @@ struct Precs
     IC<M, V, T>              ic;
     UAAMG<M, V, T>           uaamg;
     SAAMG<M, V, T>           saamg;
+    AIChebyshev<M, V, T>     aicheb;
+    TNS<M, V, T>             tns;
     Precs()
     {
         // the aggregation runs on the device with the PMIS strategy (the Greedy default is a sequential host sweep)
@@ -74,6 +77,10 @@ struct Precs
     {
         switch(kind)
         {
+        case RAMD_PC_AICHEBYSHEV:
+            return &aicheb;
+        case RAMD_PC_TNS:
+            return &tns;
         case RAMD_PC_UAAMG:
             return &uaamg;
         case RAMD_PC_SAAMG:
@@ -205,6 +212,13 @@ struct LocalSolver : SolverBase
             d.DisableIterativeSolverTolerance();
         if(Solver<LocalMatrix<T>, LocalVector<T>, T>* p = pcs.get(pc_kind))
             p->SetSolverDescriptor(d);
+    }
+    void set_precond_params(double p0, double p1, double p2) override
+    {
+        if(pc_kind == RAMD_PC_AICHEBYSHEV)
+            pcs.aicheb.Set((int)p0, (T)p1, (T)p2);
+        else if(pc_kind == RAMD_PC_TNS)
+            pcs.tns.Set(p0 != 0.0);
     }
     void set_fused(bool f) override
     {
@@ -475,7 +489,7 @@ extern "C" {
 
 int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out)
 {
-    if(!out || solver < 0 || solver > RAMD_SOLVER_CHEBYSHEV || precond < 0 || precond > RAMD_PC_SAAMG
+    if(!out || solver < 0 || solver > RAMD_SOLVER_CHEBYSHEV || precond < 0 || precond > RAMD_PC_TNS
        || (dtype != RAMD_F64 && dtype != RAMD_F32))
         return RAMD_ERR_ARG;
     GUARD_BEGIN
@@ -490,7 +504,7 @@ int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out)
 
 int ramd_solver_create_mixed(int inner_solver, int inner_precond, ramd_solver_t* out)
 {
-    if(!out || inner_solver < 0 || inner_solver > 2 || inner_precond < 0 || inner_precond > RAMD_PC_SAAMG)
+    if(!out || inner_solver < 0 || inner_solver > 2 || inner_precond < 0 || inner_precond > RAMD_PC_TNS)
         return RAMD_ERR_ARG;
     GUARD_BEGIN
     ramd_solver_s* s = new ramd_solver_s;
@@ -537,6 +551,14 @@ int ramd_solver_set_tri_solver(ramd_solver_t s, int iterative, int max_iter, dou
         return RAMD_ERR_ARG;
     GUARD_BEGIN
     s->impl->set_tri_solver(iterative, max_iter, tol, use_tol);
+    GUARD_END
+}
+int ramd_solver_set_precond_params(ramd_solver_t s, double p0, double p1, double p2)
+{
+    if(!s)
+        return RAMD_ERR_ARG;
+    GUARD_BEGIN
+    s->impl->set_precond_params(p0, p1, p2);
     GUARD_END
 }
 int ramd_solver_set_seed(ramd_solver_t s, unsigned long long seed)

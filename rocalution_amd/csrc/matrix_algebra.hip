@@ -34,6 +34,17 @@ __global__ __launch_bounds__(kBlock) void k_sort_rows(int nrow, const int* __res
         }
 }
 
+// DiagonalMatrixMultR / L (host_matrix_csr.cpp:3631-3676): val[j] *= diag[col[j]] resp. diag[row]
+template <typename T, bool LEFT>
+__global__ __launch_bounds__(kBlock) void k_diag_mult(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                      T* __restrict__ val, const T* __restrict__ diag)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+        for(int j = rp[i]; j < rp[i + 1]; ++j)
+            val[j] *= LEFT ? diag[i] : diag[ci[j]];
+}
+
 // ---- MatrixAdd, pattern of `mat` a subset of this (structure == false): this = alpha*this + beta*mat on the matches
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_add_subset(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
@@ -830,6 +841,38 @@ int ramd_mat_sort(ramd_mat_t m)
         hipLaunchKernelGGL((k_sort_rows<double>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, m->rp, m->ci, (double*)m->val);
     else
         hipLaunchKernelGGL((k_sort_rows<float>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, m->rp, m->ci, (float*)m->val);
+    RAMD_HIP(hipGetLastError());
+    mat_free_analysis(m);
+    return RAMD_OK;
+}
+
+int ramd_mat_diag_mult(ramd_mat_t m, ramd_vec_t diag, int left)
+{
+    RAMD_TRY(need_csr(m, "DiagonalMatrixMult"));
+    if(!diag || diag->dtype != m->dtype || diag->n != (left ? m->nrow : m->ncol))
+        RAMD_FAIL(RAMD_ERR_ARG, "DiagonalMatrixMult: diagonal vector of the matrix' value type and size expected");
+    if(m->nnz <= 0)
+        return RAMD_OK;
+    Backend&  b    = backend();
+    const int grid = ew_grid(std::max(m->nrow, 1));
+#define GO(T, L)                                                                                                  \
+    hipLaunchKernelGGL((k_diag_mult<T, L>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, m->rp, m->ci, (T*)m->val, \
+                       (const T*)diag->d)
+    if(m->dtype == RAMD_F64)
+    {
+        if(left)
+            GO(double, true);
+        else
+            GO(double, false);
+    }
+    else
+    {
+        if(left)
+            GO(float, true);
+        else
+            GO(float, false);
+    }
+#undef GO
     RAMD_HIP(hipGetLastError());
     mat_free_analysis(m);
     return RAMD_OK;

@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import capi
-from .capi import (PC_GS, PC_IC, PC_ILU0, PC_SAAMG, PC_UAAMG, PC_JACOBI, PC_MCGS, PC_MCILU, PC_MCSGS, PC_NONE, PC_SGS, SOLVER_BICGSTAB,
+from .capi import (PC_AICHEBYSHEV, PC_GS, PC_IC, PC_ILU0, PC_SAAMG, PC_TNS, PC_UAAMG, PC_JACOBI, PC_MCGS, PC_MCILU, PC_MCSGS, PC_NONE, PC_SGS, SOLVER_BICGSTAB,
                    SOLVER_BICGSTABL,
                    SOLVER_CG, SOLVER_CHEBYSHEV, SOLVER_CR, SOLVER_FCG, SOLVER_FGMRES, SOLVER_FIXEDPOINT, SOLVER_GMRES,
                    SOLVER_IDR, SOLVER_QMRCGSTAB)
@@ -85,6 +85,26 @@ class SGS(_Precond):
 class IC(_Precond):
     """incomplete Cholesky, zero fill-in (preconditioner.cpp:826-925): ICFactorize on ExtractL, LLSolve"""
     kind = PC_IC
+
+
+class AIChebyshev(_Precond):
+    """approximate inverse by a Chebyshev polynomial of the operator (preconditioner_ai.cpp:41-215); Solve = one SpMV"""
+    kind = PC_AICHEBYSHEV
+
+    def Set(self, p, lambda_min, lambda_max):
+        self.params = (float(p), float(lambda_min), float(lambda_max))
+
+
+class TNS(_Precond):
+    """truncated Neumann series (preconditioner_ai.cpp:477-713): implicit (four triangular SpMVs) or explicit matrix"""
+    kind = PC_TNS
+
+    def __init__(self):
+        super().__init__()
+        self.params = (1.0, 0.0, 0.0)
+
+    def Set(self, imp):
+        self.params = (1.0 if imp else 0.0, 0.0, 0.0)
 
 
 class UAAMG(_Precond):
@@ -192,6 +212,8 @@ class _IterativeLinearSolver:
         if self._precond is not None and getattr(self._precond, "descr", None) is not None:
             d = self._precond.descr
             capi.check(_lib().ramd_solver_set_tri_solver(self._h, d.alg, d.max_iter, d.tol, int(d.use_tol)))
+        if self._precond is not None and getattr(self._precond, "params", None) is not None:
+            capi.check(_lib().ramd_solver_set_precond_params(self._h, *self._precond.params))
         capi.check(_lib().ramd_solver_set_fused(self._h, int(self._fused)))
         capi.check(_lib().ramd_solver_set_verbose(self._h, self._verbose))
         self._configure_extra()

@@ -61,9 +61,15 @@ def _mk(S, tag, dtype=np.float64):
     if tag == "chebyshev_jacobi":
         solver.Set(0.01, 2.0); solver.InitMaxIter(60)
     pc = {"none": None, "jacobi": S.Jacobi, "ilu0": S.ILU, "mcsgs": S.MultiColoredSGS, "mcgs": S.MultiColoredGS,
-          "mcilu": S.MultiColoredILU, "gs": S.GS, "sgs": S.SGS, "ic": S.IC}[tag.split("_")[1]]
+          "mcilu": S.MultiColoredILU, "gs": S.GS, "sgs": S.SGS, "ic": S.IC, "tns": S.TNS, "tnsx": S.TNS,
+          "aicheb": S.AIChebyshev}[tag.split("_")[1]]
     if pc is not None:
-        solver.SetPreconditioner(pc())
+        p = pc()
+        if tag.split("_")[1] == "aicheb":
+            p.Set(3, 0.05, 16.0); solver.InitMaxIter(300)
+        if tag.split("_")[1] == "tnsx":
+            p.Set(False)  # explicit matrix
+        solver.SetPreconditioner(p)
     return solver
 
 
@@ -96,7 +102,8 @@ def test_preconditioner_apply_bit_exact(ra, S, name):
     n = A.GetM()
     x = ra.LocalVector(data=g["x"])
     for tag, key in (("cg_jacobi", "pc_jacobi"), ("cg_ilu0", "pc_ilu0"), ("cg_mcsgs", "pc_mcsgs"), ("cg_gs", "pc_gs"),
-                     ("cg_sgs", "pc_sgs"), ("cg_ic", "pc_ic")):
+                     ("cg_sgs", "pc_sgs"), ("cg_ic", "pc_ic"), ("cg_aicheb", "pc_aicheb"), ("cg_tns", "pc_tns"),
+                     ("cg_tnsx", "pc_tns_expl")):
         if key not in g:  # IC only on the SPD cases (the reference asserts on a breakdown)
             continue
         ls = _mk(S, tag); ls.SetOperator(A); ls.Build()
@@ -172,7 +179,7 @@ def test_solvers_with_iterative_triangular_solves(ra, S, name, tag):
 SOLVER_TAGS = ["cg_none", "cg_jacobi", "gmres_none", "gmres_ilu0", "bicgstab_none", "bicgstab_mcsgs", "bicgstab_mcgs",
                "gmres_mcilu", "fcg_none", "fcg_jacobi", "fcg_mcsgs", "cr_none", "cr_jacobi", "fgmres_none",
                "fgmres_ilu0", "bicgstabl_none", "bicgstabl3_jacobi", "qmrcgstab_none", "qmrcgstab_mcsgs", "idr_none",
-               "idr2_jacobi", "cg_sgs", "cg_ic", "bicgstab_gs", "fixedpoint_jacobi", "chebyshev_none", "chebyshev_jacobi"]
+               "idr2_jacobi", "cg_sgs", "cg_ic", "cg_tns", "cg_aicheb", "bicgstab_gs", "fixedpoint_jacobi", "chebyshev_none", "chebyshev_jacobi"]
 SOLVER_CASES = ["gr3030", "poisson8", "lap2d7", "poisson16", "poisson32"]
 
 
@@ -227,6 +234,11 @@ def test_solvers_vs_golden(ra, S, name, tag, fused):
     meta = g[tag + "_meta"]
     slack = 1 if tag.split("_")[0] in ("cg", "fcg", "cr") else 2
     bicg = tag.split("_")[0] in ("bicgstab", "bicgstabl", "bicgstabl3", "qmrcgstab", "idr", "idr2")  # see _check_hist
+    # the reference's AIChebyshev (A + c/2 I + ... as written there) is not a definite preconditioner: CG around it
+    # amplifies the summation-order differences of the dots like BiCGStab does (its applies are bit-exact, see above)
+    bicg = bicg or tag == "cg_aicheb"
+    if tag == "cg_aicheb":
+        slack = 4  # ... and the iteration count moves with it (39 against 41 on poisson8)
     _check_run(ls.GetResidualHistory(), g[tag + "_hist"], ls.GetIterationCount(), int(meta[0]),
                ls.GetSolverStatus(), int(meta[1]), slack, bicg)
     if ls.GetIterationCount() == int(meta[0]) and not bicg:
