@@ -1169,6 +1169,17 @@ public:
         this->MoveToAccelerator();
         RAMD_CHECK(ramd_mat_mat_mult(this->dev_, A.dev_, B.dev_));
     }
+    // factorised sparse approximate inverse on the lower pattern of this matrix (this becomes the factor)
+    void FSAI(int power, const LocalMatrix<ValueType>* pattern)
+    {
+        this->need_accel_("FSAI");
+        if(pattern != NULL || power > 1)
+        {
+            LOG_INFO("LocalMatrix::FSAI(): only the pattern of the operator itself (power 1) is provided by this backend");
+            FATAL_ERROR(__FILE__, __LINE__);
+        }
+        RAMD_CHECK(ramd_mat_fsai(this->dev_, 1));
+    }
     void DiagonalMatrixMultR(const LocalVector<ValueType>& diag)
     {
         this->need_accel_("DiagonalMatrixMultR");

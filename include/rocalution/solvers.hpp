@@ -714,6 +714,79 @@ private:
     ValueType    lambda_min_, lambda_max_;
 };
 
+// FSAI :217-361: factorised sparse approximate inverse, M^-1 = G^T G with G on the lower pattern of A; Solve = two SpMVs
+template <class OperatorType, class VectorType, typename ValueType>
+class FSAI : public Preconditioner<OperatorType, VectorType, ValueType>
+{
+public:
+    FSAI()
+        : matrix_power_(1)
+        , external_pattern_(false)
+        , matrix_pattern_(NULL)
+    {
+    }
+    virtual ~FSAI()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("Factorized Sparse Approximate Inverse preconditioner");
+        if(this->build_)
+            LOG_INFO("FSAI matrix nnz = " << this->FSAI_L_.GetNnz() + this->FSAI_LT_.GetNnz() - this->FSAI_L_.GetM());
+    }
+    virtual void Set(int power)
+    {
+        assert(this->build_ == false && power > 0);
+        this->matrix_power_ = power;
+    }
+    virtual void Set(const OperatorType& pattern)
+    {
+        assert(this->build_ == false);
+        this->matrix_pattern_ = &pattern;
+    }
+    virtual void Build(void)
+    {
+        if(this->build_)
+            this->Clear();
+        this->build_ = true;
+        assert(this->op_ != NULL);
+        this->FSAI_L_.CloneFrom(*this->op_);
+        this->FSAI_L_.FSAI(this->matrix_power_, this->matrix_pattern_);
+        this->FSAI_LT_.CloneBackend(*this->op_);
+        this->FSAI_L_.Transpose(&this->FSAI_LT_);
+        this->t_.CloneBackend(*this->op_);
+        this->t_.Allocate("temporary", this->op_->GetM());
+    }
+    virtual void Clear(void)
+    {
+        if(this->build_)
+        {
+            this->FSAI_L_.Clear();
+            this->FSAI_LT_.Clear();
+            this->t_.Clear();
+            this->build_ = false;
+        }
+    }
+    virtual void Solve(const VectorType& rhs, VectorType* x)
+    {
+        assert(this->build_ == true && x != NULL && x != &rhs);
+        this->FSAI_L_.Apply(rhs, &this->t_);
+        this->FSAI_LT_.Apply(this->t_, x);
+    }
+    const OperatorType& GetFactor(void) const
+    {
+        return this->FSAI_L_;
+    }
+
+private:
+    OperatorType        FSAI_L_, FSAI_LT_;
+    VectorType          t_;
+    int                 matrix_power_;
+    bool                external_pattern_;
+    const OperatorType* matrix_pattern_;
+};
+
 // TNS :477-713: truncated Neumann series, (I - L D^-1 + (L D^-1)^2) D^-1 (I - D^-1 L^T + (D^-1 L^T)^2), applied
 // implicitly (default: four triangular SpMVs) or as one explicit matrix
 template <class OperatorType, class VectorType, typename ValueType>

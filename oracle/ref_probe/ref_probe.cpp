@@ -466,6 +466,19 @@ static int cmd_gen(const std::string& in, const std::string& out)
         dump_vec("pc_aicheb", y);
         p.Clear();
     }
+    if(symmetric_spd) // the dense sub-systems are factorised without pivoting: SPD operators
+    {
+        FSAI<MatD, VecD, double> p;
+        p.SetOperator(mat);
+        p.Build();
+        p.Solve(x, &y);
+        dump_vec("pc_fsai", y);
+        p.Clear();
+        MatD G;
+        G.CloneFrom(mat);
+        G.FSAI(1, NULL);
+        dump_csr("fsai_G", G);
+    }
     {
         TNS<MatD, VecD, double> p; // implicit (default)
         p.SetOperator(mat);
@@ -797,6 +810,16 @@ static int cmd_gen(const std::string& in, const std::string& out)
             ls.Build();
             sol.Zeros();
             run_solver("cg_itic", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            CG<MatD, VecD, double>   ls;
+            FSAI<MatD, VecD, double> p;
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(p);
+            ls.Build();
+            sol.Zeros();
+            run_solver("cg_fsai", ls, rhs, sol);
             ls.Clear();
         }
         {

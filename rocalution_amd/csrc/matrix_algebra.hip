@@ -45,6 +45,97 @@ __global__ __launch_bounds__(kBlock) void k_diag_mult(int nrow, const int* __res
             val[j] *= LEFT ? diag[i] : diag[ci[j]];
 }
 
+// ---- FSAI(1) factor (host_matrix_csr.cpp:6514-6662): for every row the dense system of the operator restricted to the
+// row's lower pattern is factorised (in-place LU without pivoting, the host's loop order) and solved for the last unit
+// vector; the row is then scaled by sqrt(1 / |last entry|).  One thread per row, dense scratch in device memory.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_fsai(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                 const T* __restrict__ val, const int* __restrict__ lrp,
+                                                 const int* __restrict__ lci, T* __restrict__ lval,
+                                                 const long long* __restrict__ soff, T* __restrict__ scratch)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t ai = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ai < nrow; ai += gsz)
+    {
+        const int base = lrp[ai];
+        const int nr   = lrp[ai + 1] - base;
+        if(nr == 1)
+        {
+            const int aj = rp[ai];
+            if(ci[aj] == (int)ai)
+                lval[base] = (T)1 / val[aj];
+        }
+        else if(nr > 1)
+        {
+            T* Asub = scratch + soff[ai];
+            T* mk   = Asub + (long long)nr * nr;
+            for(int q = 0; q < nr * nr; ++q)
+                Asub[q] = (T)0;
+            for(int k = 0; k < nr; ++k)
+            {
+                const int rk = lci[base + k];
+                for(int aj = rp[rk]; aj < rp[rk + 1]; ++aj)
+                {
+                    for(int j = 0; j < nr; ++j)
+                    {
+                        const int ac = lci[base + j];
+                        if(ci[aj] < ac)
+                            break;
+                        if(ci[aj] == ac)
+                        {
+                            Asub[j + k * nr] = val[aj];
+                            break;
+                        }
+                    }
+                    if(ci[aj] == (int)ai)
+                        break;
+                }
+            }
+            for(int q = 0; q < nr; ++q)
+                mk[q] = (T)0;
+            mk[nr - 1] = (T)1;
+            for(int i = 0; i < nr - 1; ++i)
+                for(int k = i + 1; k < nr; ++k)
+                {
+                    Asub[i + k * nr] /= Asub[i + i * nr];
+                    for(int j = i + 1; j < nr; ++j)
+                        Asub[j + k * nr] -= Asub[i + k * nr] * Asub[j + i * nr];
+                }
+            for(int i = nr - 1; i >= 0; --i)
+            {
+                mk[i] /= Asub[i + i * nr];
+                for(int j = 0; j < i; ++j)
+                    mk[j] -= mk[i] * Asub[i + j * nr];
+            }
+            for(int k = 0; k < nr; ++k)
+                lval[base + k] = mk[k];
+        }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_fsai_scale(int nrow, const int* __restrict__ lrp, T* __restrict__ lval)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t ai = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ai < nrow; ai += gsz)
+    {
+        if(lrp[ai + 1] == lrp[ai])
+            continue;
+        const T last = lval[lrp[ai + 1] - 1];
+        const T fac  = (T)sqrt((double)((T)1 / (last < (T)0 ? -last : last)));
+        for(int aj = lrp[ai]; aj < lrp[ai + 1]; ++aj)
+            lval[aj] *= fac;
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_fsai_sizes(int nrow, const int* __restrict__ lrp, long long* __restrict__ sz)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= nrow; i += gsz)
+    {
+        long long nr = (i < nrow) ? (lrp[i + 1] - lrp[i]) : 0;
+        sz[i]        = nr > 1 ? nr * nr + nr : 0;
+    }
+}
+
 // ---- MatrixAdd, pattern of `mat` a subset of this (structure == false): this = alpha*this + beta*mat on the matches
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_add_subset(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
@@ -844,6 +935,79 @@ int ramd_mat_sort(ramd_mat_t m)
     RAMD_HIP(hipGetLastError());
     mat_free_analysis(m);
     return RAMD_OK;
+}
+
+int ramd_mat_fsai(ramd_mat_t m, int power)
+{
+    RAMD_TRY(need_csr(m, "FSAI"));
+    if(power != 1)
+        RAMD_FAIL(RAMD_ERR_UNSUPPORTED, "FSAI: only the pattern of the operator itself (power 1) is provided");
+    if(m->nrow != m->ncol || m->nnz <= 0)
+        RAMD_FAIL(RAMD_ERR_ARG, "FSAI: square, non-empty matrix expected");
+    Backend&   b = backend();
+    ramd_mat_t L = nullptr;
+    RAMD_TRY(ramd_mat_create(m->dtype, &L));
+    int s = ramd_mat_extract_tri(m, L, 0, 1); // ExtractLDiagonal
+    long long* soff    = nullptr;
+    void*      scratch = nullptr;
+    long long  total   = 0;
+    const int  n       = m->nrow;
+    if(s == RAMD_OK)
+        s = dev_alloc(&soff, (int64_t)n + 1);
+    if(s == RAMD_OK)
+    {
+        hipLaunchKernelGGL(k_fsai_sizes, dim3(ew_grid((int64_t)n + 1)), dim3(kBlock), 0, b.cur, n, (const int*)L->rp, soff);
+        hipLaunchKernelGGL(k_scan_ll, dim3(1), dim3(kBlock), 0, b.cur, (int64_t)n + 1, soff);
+        hipError_t e = hipMemcpyAsync(&total, soff + n, sizeof(long long), hipMemcpyDeviceToHost, b.cur);
+        if(e == hipSuccess)
+            e = hipStreamSynchronize(b.cur);
+        if(e != hipSuccess)
+            s = RAMD_ERR_HIP;
+    }
+    if(s == RAMD_OK && cached_malloc(&scratch, (size_t)total * val_size(m->dtype) + kPad) != hipSuccess)
+        s = RAMD_ERR_HIP;
+    if(s == RAMD_OK)
+    {
+        const int grid = ew_grid(std::max(n, 1));
+        if(m->dtype == RAMD_F64)
+        {
+            hipLaunchKernelGGL((k_fsai<double>), dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const double*)m->val,
+                               (const int*)L->rp, (const int*)L->ci, (double*)L->val, (const long long*)soff,
+                               (double*)scratch);
+            hipLaunchKernelGGL((k_fsai_scale<double>), dim3(grid), dim3(kBlock), 0, b.cur, n, (const int*)L->rp,
+                               (double*)L->val);
+        }
+        else
+        {
+            hipLaunchKernelGGL((k_fsai<float>), dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const float*)m->val,
+                               (const int*)L->rp, (const int*)L->ci, (float*)L->val, (const long long*)soff, (float*)scratch);
+            hipLaunchKernelGGL((k_fsai_scale<float>), dim3(grid), dim3(kBlock), 0, b.cur, n, (const int*)L->rp,
+                               (float*)L->val);
+        }
+        hipError_t e = hipGetLastError();
+        if(e == hipSuccess)
+            e = hipStreamSynchronize(b.cur);
+        if(e != hipSuccess)
+            s = RAMD_ERR_HIP;
+    }
+    dev_free(&soff);
+    if(scratch)
+        (void)cached_free(scratch);
+    if(s == RAMD_OK)
+    {
+        // this becomes the factor (host: Clear(); SetDataPtrCSR(L arrays))
+        mat_free_csr(m);
+        mat_free_analysis(m);
+        m->rp  = L->rp;
+        m->ci  = L->ci;
+        m->val = L->val;
+        m->nnz = L->nnz;
+        L->rp = L->ci = nullptr;
+        L->val        = nullptr;
+        L->nnz        = 0;
+    }
+    ramd_mat_destroy(L);
+    return s;
 }
 
 int ramd_mat_diag_mult(ramd_mat_t m, ramd_vec_t diag, int left)

@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import capi
-from .capi import (PC_AICHEBYSHEV, PC_GS, PC_IC, PC_ILU0, PC_SAAMG, PC_TNS, PC_UAAMG, PC_JACOBI, PC_MCGS, PC_MCILU, PC_MCSGS, PC_NONE, PC_SGS, SOLVER_BICGSTAB,
+from .capi import (PC_AICHEBYSHEV, PC_FSAI, PC_GS, PC_IC, PC_ILU0, PC_SAAMG, PC_TNS, PC_UAAMG, PC_JACOBI, PC_MCGS, PC_MCILU, PC_MCSGS, PC_NONE, PC_SGS, SOLVER_BICGSTAB,
                    SOLVER_BICGSTABL,
                    SOLVER_CG, SOLVER_CHEBYSHEV, SOLVER_CR, SOLVER_FCG, SOLVER_FGMRES, SOLVER_FIXEDPOINT, SOLVER_GMRES,
                    SOLVER_IDR, SOLVER_QMRCGSTAB)
@@ -93,6 +93,11 @@ class AIChebyshev(_Precond):
 
     def Set(self, p, lambda_min, lambda_max):
         self.params = (float(p), float(lambda_min), float(lambda_max))
+
+
+class FSAI(_Precond):
+    """factorised sparse approximate inverse on the lower pattern of the operator (preconditioner_ai.cpp:217-361)"""
+    kind = PC_FSAI
 
 
 class TNS(_Precond):

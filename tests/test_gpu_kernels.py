@@ -184,6 +184,16 @@ def test_csr_matrix_algebra_vs_golden(ra, name):
     assert np.allclose(y1.numpy(), y2.numpy(), rtol=1e-12, atol=1e-10 * np.max(np.abs(y2.numpy())))
 
 
+def test_fsai_factor_vs_golden(ra):
+    """FSAI(1): per-row dense LU on the lower pattern and the scaling -- factor arrays identical to the genuine library"""
+    for name in ("gr3030", "poisson8", "lap2d7"):
+        g = load_golden(name)
+        A = _mat(ra, g)
+        A.FSAI(1)
+        rp, ci, va = A.CopyToCSR()
+        eq(rp, g["fsai_G_rowptr"]); eq(ci, g["fsai_G_col"]); eq(va, g["fsai_G_val"])
+
+
 @pytest.mark.parametrize("lds", ["1", "0"])
 def test_matmult_long_row_paths_in_a_fresh_process(lds):
     """MatrixMult leaves the per-thread insertion when a row has many products: (lds=1) one workgroup per row sorts the
