@@ -336,6 +336,62 @@ __global__ __launch_bounds__(kBlock) void k_mm_compact(int nrow, const long long
     }
 }
 
+// exclusive scan of 64-bit counts: the multi-block 32-bit scan whenever the total fits (the usual case), else one block
+__global__ __launch_bounds__(kBlock) void k_ll_total(int64_t n, const long long* __restrict__ v, unsigned long long* tot)
+{
+    unsigned long long acc = 0;
+    const int64_t      gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gsz)
+        acc += (unsigned long long)v[i];
+    for(int o = 32; o > 0; o >>= 1)
+        acc += __shfl_xor(acc, o, 64);
+    if((threadIdx.x & 63) == 0 && acc)
+        atomicAdd(tot, acc); // integer sum: order does not matter
+}
+__global__ __launch_bounds__(kBlock) void k_ll_to_int(int64_t n, const long long* __restrict__ v, int* __restrict__ o)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gsz)
+        o[i] = (int)v[i];
+}
+__global__ __launch_bounds__(kBlock) void k_int_to_ll(int64_t n, const int* __restrict__ v, long long* __restrict__ o)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gsz)
+        o[i] = (long long)v[i];
+}
+static int scan_ll(long long* v, int64_t n)
+{
+    Backend&            b   = backend();
+    unsigned long long* tot = nullptr;
+    RAMD_TRY(dev_alloc(&tot, 1));
+    unsigned long long h = 0;
+    hipError_t         e = hipMemsetAsync(tot, 0, sizeof(unsigned long long), b.cur);
+    hipLaunchKernelGGL(k_ll_total, dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, (const long long*)v, tot);
+    if(e == hipSuccess)
+        e = hipMemcpyAsync(&h, tot, sizeof(h), hipMemcpyDeviceToHost, b.cur);
+    if(e == hipSuccess)
+        e = hipStreamSynchronize(b.cur);
+    dev_free(&tot);
+    RAMD_HIP(e);
+    if(h >= 0x7fffffffULL)
+    {
+        hipLaunchKernelGGL(k_scan_ll, dim3(1), dim3(kBlock), 0, b.cur, n, v);
+        RAMD_HIP(hipGetLastError());
+        return RAMD_OK;
+    }
+    int* tmp = nullptr;
+    RAMD_TRY(dev_alloc(&tmp, n));
+    hipLaunchKernelGGL(k_ll_to_int, dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, (const long long*)v, tmp);
+    int s = device_exclusive_scan(tmp, tmp, n);
+    if(s == RAMD_OK)
+        hipLaunchKernelGGL(k_int_to_ll, dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, (const int*)tmp, v);
+    if(s == RAMD_OK && hipStreamSynchronize(b.cur) != hipSuccess)
+        s = RAMD_ERR_HIP;
+    dev_free(&tmp);
+    return s;
+}
+
 // ---- MatrixMult, long rows: products in generation order, two stable sorts (by column, then by row) keep that order
 // among equal (row, column) pairs, one thread per distinct pair sums its run left to right
 __global__ __launch_bounds__(kBlock) void k_mm_any_long(int nrow, const long long* __restrict__ off, int limit,
@@ -723,7 +779,7 @@ static int mat_mult_t(ramd_mat_s* c, const ramd_mat_s* a, const ramd_mat_s* bm)
     if(s == RAMD_OK)
     {
         hipLaunchKernelGGL(k_mm_bound, dim3(ew_grid((int64_t)n + 1)), dim3(kBlock), 0, b.cur, n, a->rp, a->ci, bm->rp, off);
-        hipLaunchKernelGGL(k_scan_ll, dim3(1), dim3(kBlock), 0, b.cur, (int64_t)n + 1, off);
+        s = scan_ll(off, (int64_t)n + 1);
     }
     long long total = 0;
     if(s == RAMD_OK)
@@ -957,8 +1013,10 @@ int ramd_mat_fsai(ramd_mat_t m, int power)
     if(s == RAMD_OK)
     {
         hipLaunchKernelGGL(k_fsai_sizes, dim3(ew_grid((int64_t)n + 1)), dim3(kBlock), 0, b.cur, n, (const int*)L->rp, soff);
-        hipLaunchKernelGGL(k_scan_ll, dim3(1), dim3(kBlock), 0, b.cur, (int64_t)n + 1, soff);
-        hipError_t e = hipMemcpyAsync(&total, soff + n, sizeof(long long), hipMemcpyDeviceToHost, b.cur);
+        s            = scan_ll(soff, (int64_t)n + 1);
+        hipError_t e = (s == RAMD_OK) ? hipSuccess : hipErrorUnknown;
+        if(e == hipSuccess)
+            e = hipMemcpyAsync(&total, soff + n, sizeof(long long), hipMemcpyDeviceToHost, b.cur);
         if(e == hipSuccess)
             e = hipStreamSynchronize(b.cur);
         if(e != hipSuccess)
