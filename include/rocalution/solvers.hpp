@@ -3325,6 +3325,8 @@ protected:
             if(steps < 1)
                 return;
             this->iter_ctrl_.InitResidual(1.0); // dummy: the smoother never looks at a residual
+            if(this->fused_ && this->FusedJacobiSweeps_(rhs, x, steps))
+                return;
             for(int iter = 0; iter < steps; ++iter)
             {
                 this->op_->Apply(*x, &this->x_res_);
@@ -3356,6 +3358,39 @@ protected:
     }
 
 private:
+    // FixedPoint + Jacobi as a smoother on a Local CSR operator: every sweep is ONE pass (SpMV with the update as its
+    // epilogue, ramd_fused_jacobi_sweep) plus the copy back, instead of SpMV + three vector kernels; same operations
+    template <class O = OperatorType, class V = VectorType>
+    typename std::enable_if<_fusable<O, V, ValueType>::value, bool>::type
+        FusedJacobiSweeps_(const VectorType& rhs, VectorType* x, int steps)
+    {
+        typedef Jacobi<OperatorType, VectorType, ValueType> JacobiType;
+        JacobiType* jac = dynamic_cast<JacobiType*>(this->precond_);
+        if(jac == NULL || !this->op_->is_accel_() || !x->is_accel_() || this->op_->GetFormat() != CSR
+           || jac->GetInverseDiagonal().GetSize() != x->GetSize())
+            return false;
+        for(int iter = 0; iter < steps; ++iter)
+        {
+            int s = ramd_fused_jacobi_sweep(this->op_->handle(), _fh(jac->GetInverseDiagonal()), _fh(rhs), _fh(*x),
+                                            _fh(this->x_res_), (double)this->omega_);
+            if(s == RAMD_ERR_UNSUPPORTED)
+            {
+                if(iter == 0)
+                    return false;
+                FATAL_ERROR(__FILE__, __LINE__);
+            }
+            RAMD_CHECK(s);
+            x->CopyFrom(this->x_res_);
+        }
+        return true;
+    }
+    template <class O = OperatorType, class V = VectorType>
+    typename std::enable_if<!_fusable<O, V, ValueType>::value, bool>::type
+        FusedJacobiSweeps_(const VectorType&, VectorType*, int)
+    {
+        return false;
+    }
+
     ValueType  omega_;
     VectorType x_old_, x_res_;
 };

@@ -212,6 +212,9 @@ int ramd_scalars_fetch_async_end(int record, double* host, int count);
 int ramd_fused_apply_dot(ramd_mat_t m, ramd_vec_t x, ramd_vec_t y, int slot_dot);
 /* y = A x  and  s[slot_dot] = <w, y>   (bicgstab.cpp:397-400: q = A z ; r0.q) */
 int ramd_fused_apply_dotv(ramd_mat_t m, ramd_vec_t x, ramd_vec_t y, ramd_vec_t w, int slot_dot);
+/* one sweep of FixedPoint(omega) + Jacobi (solver.cpp:686-720 with preconditioner.cpp:137-166): xnew = x + omega * dinv * (rhs - A x)
+ * in one pass, the same operations as Apply, ScaleAdd(-1, rhs), PointWiseMult, AddScale; CSR only (else RAMD_ERR_UNSUPPORTED) */
+int ramd_fused_jacobi_sweep(ramd_mat_t m, ramd_vec_t dinv, ramd_vec_t rhs, ramd_vec_t x, ramd_vec_t xnew, double omega);
 /* y += scalar * A x  and  s[slot_dot] = <p, y>, GIVEN that s[slot_dot] already holds <p, y> of the
  * incoming y: only the rows A touches are corrected (the ghost part of GlobalMatrix::Apply,
  * global_matrix.cpp:1001-1007, followed by the interior part of GlobalVector::Dot,

@@ -149,6 +149,7 @@ SIGNATURES = {
     "ramd_scalars_fetch_async_end": (i32, [i32, pf64, i32]),
     "ramd_fused_apply_dot": (i32, [mat_t, vec_t, vec_t, i32]),
     "ramd_fused_apply_add_dot": (i32, [mat_t, vec_t, f64, vec_t, vec_t, i32]),
+    "ramd_fused_jacobi_sweep": (i32, [mat_t, vec_t, vec_t, vec_t, vec_t, f64]),
     "ramd_fused_apply_dotv": (i32, [mat_t, vec_t, vec_t, vec_t, i32]),
     "ramd_fused_bicg_r_update": (i32, [vec_t, vec_t, i32, i32]),
     "ramd_fused_bicg_xr_update": (i32, [vec_t, vec_t, vec_t, vec_t, vec_t, vec_t, vec_t, i32, i32, i32, i32, i32, i32]),

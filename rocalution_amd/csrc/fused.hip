@@ -445,6 +445,20 @@ int ramd_fused_apply_dotv(ramd_mat_t m, ramd_vec_t x, ramd_vec_t y, ramd_vec_t w
     return ramd_fused_multi_dot(vs, 1, y, slot_dot);
 }
 
+int ramd_fused_jacobi_sweep(ramd_mat_t m, ramd_vec_t dinv, ramd_vec_t rhs, ramd_vec_t x, ramd_vec_t xnew, double omega)
+{
+    if(!m || !dinv || !rhs || !x || !xnew || x == xnew || rhs == xnew || dinv == xnew)
+        RAMD_FAIL(RAMD_ERR_ARG, "fused_jacobi_sweep: bad arguments");
+    if(dinv->dtype != m->dtype || rhs->dtype != m->dtype || x->dtype != m->dtype || xnew->dtype != m->dtype
+       || dinv->n != m->nrow || rhs->n != m->nrow || x->n != m->ncol || xnew->n != m->nrow)
+        RAMD_FAIL(RAMD_ERR_ARG, "fused_jacobi_sweep: vector sizes/types do not match the matrix");
+    if(m->dtype == RAMD_F64)
+        return mat_jacobi_sweep_impl<double>(m, (const double*)dinv->d, (const double*)rhs->d, (const double*)x->d,
+                                             (double*)xnew->d, omega);
+    return mat_jacobi_sweep_impl<float>(m, (const float*)dinv->d, (const float*)rhs->d, (const float*)x->d,
+                                        (float*)xnew->d, (float)omega);
+}
+
 int ramd_fused_bicg_r_update(ramd_vec_t r, ramd_vec_t q, int slot_rho, int slot_r0q)
 {
     CHECK_SAMEV(r, q);

@@ -37,6 +37,8 @@ int mat_apply_impl(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar);
 template <typename T>
 int mat_apply_dot_impl(const ramd_mat_s* m, const T* x, T* y, int slot, const T* dotv = nullptr);
 template <typename T>
+int mat_jacobi_sweep_impl(const ramd_mat_s* m, const T* dinv, const T* rhs, const T* x, T* xnew, T omega);
+template <typename T>
 int mat_apply_add_dot_impl(const ramd_mat_s* m, const T* x, T* y, T scalar, const T* p, int slot);
 
 // vector.hip: scalars[slot] = sum(a[0..n)) in one launch, fixed order

@@ -76,6 +76,8 @@ struct CsrDotWs
 {
     double*     part1; // [4 * nblk] one partial per wave
     const void* dotv; // the dot runs against this vector (nullptr: against x)
+    const void* jdinv; // MODE 2 (Jacobi sweep): inverse diagonal and right-hand side
+    const void* jrhs;
 };
 
 // CSR SpMV, "LDS transpose" layout.  Measured on MI355X (tools/spmv_lab.py): the kernel is bound by
@@ -88,6 +90,8 @@ struct CsrDotWs
 //   3. the row sum runs left to right in storage order (bit-identical to the host backend);
 //      y is written once, non-temporal.
 // MODE 0: y = A x      MODE 1: y += scalar * A x (term by term into y, as the host ApplyAdd)
+// MODE 2: one damped-Jacobi sweep  y = x + scalar * (dinv * (-(A x) + rhs))  -- the four vector kernels of the
+//         FixedPoint(omega)+Jacobi smoother (Apply, ScaleAdd(-1, rhs), PointWiseMult, AddScale) as the epilogue, same operations
 // DOT   : additionally reduce <x, y> into scalar slot `slot` (square matrix)
 // LDS (24 KiB per workgroup) allows 6 workgroups = 6 waves per SIMD: keep the register budget inside
 // 512/6 VGPRs (the fused-dot variant sat at 86 and lost a whole wave per SIMD: -4%)
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) 
                 for(int e = 0; e < kGatherW; ++e)
                     if(j + e < hi)
                     {
-                        if(MODE == 0)
+                        if(MODE != 1)
                             sum += v[e] * xv[e];
                         else
                             sum += scalar * v[e] * xv[e];
@@ -187,6 +191,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) 
         }
         if(row < nrow)
         {
+            if(MODE == 2)
+            {
+                T t = (T)(-1) * sum + static_cast<const T*>(ws.jrhs)[row];
+                t   = static_cast<const T*>(ws.jdinv)[row] * t;
+                sum = x[row] + scalar * t;
+            }
             // non-temporal, unconditionally: a run-time switch here let the compiler merge both branches
             // into ONE plain store (the hint was lost and the kernel ran 15% slower at 256^3)
             nt_store(sum, y + row);
@@ -441,7 +451,7 @@ static BandMap band_map_for(const ramd_mat_s* m, int per_xcd);
 
 template <typename T>
 static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar, bool dot, int slot,
-                      const T* dotv = nullptr)
+                      const T* dotv = nullptr, const T* jdinv = nullptr, const T* jrhs = nullptr)
 {
     Backend&  b       = backend();
     const int nblk    = (m->nrow + kCsrRows - 1) / kCsrRows;
@@ -468,7 +478,11 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
 #define LAUNCH(MODE, DOT)                                                                          \
     hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
                        per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm)
-    if(mode == 0 && !dot)
+    ws.jdinv = jdinv;
+    ws.jrhs  = jrhs;
+    if(mode == 2)
+        LAUNCH(2, false);
+    else if(mode == 0 && !dot)
         LAUNCH(0, false);
     else if(mode == 0 && dot)
         LAUNCH(0, true);
@@ -701,6 +715,19 @@ int mat_apply_add_dot_impl(const ramd_mat_s* m, const T* x, T* y, T scalar, cons
 }
 template int mat_apply_add_dot_impl<double>(const ramd_mat_s*, const double*, double*, double, const double*, int);
 template int mat_apply_add_dot_impl<float>(const ramd_mat_s*, const float*, float*, float, const float*, int);
+// one damped-Jacobi sweep xnew = x + omega * dinv * (rhs - A x), CSR only
+template <typename T>
+int mat_jacobi_sweep_impl(const ramd_mat_s* m, const T* dinv, const T* rhs, const T* x, T* xnew, T omega)
+{
+    if(m->format != RAMD_CSR || m->nnz <= 0 || m->nrow != m->ncol)
+        return RAMD_ERR_UNSUPPORTED;
+    prof_spmv_begin();
+    int s = launch_csr<T>(m, x, xnew, 2, omega, false, 0, nullptr, dinv, rhs);
+    prof_spmv_end();
+    return s;
+}
+template int mat_jacobi_sweep_impl<double>(const ramd_mat_s*, const double*, const double*, const double*, double*, double);
+template int mat_jacobi_sweep_impl<float>(const ramd_mat_s*, const float*, const float*, const float*, float*, float);
 template int mat_apply_dot_impl<double>(const ramd_mat_s*, const double*, double*, int, const double*);
 template int mat_apply_dot_impl<float>(const ramd_mat_s*, const float*, float*, int, const float*);
 

@@ -566,3 +566,24 @@ def test_amg_preconditioners_through_the_c_abi(ra, S, name, amg):
     assert np.linalg.norm(x.numpy() - 1.0) / np.sqrt(n) < 1e-4
     ref = int(g["cg_" + amg + "_meta"][0])
     assert ls.GetIterationCount() <= ref + 6, (ls.GetIterationCount(), ref)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_fused_jacobi_smoother_sweeps_bit_identical(ra, S, dtype):
+    """FixedPoint(omega)+Jacobi flagged as a smoother (the default smoother of the AMG classes): the one-pass sweep
+    (SpMV with the update in its epilogue) against the four-kernel sequence -- bitwise the same iterate"""
+    rp, ci, va = gen.poisson7(14, dtype)
+    n = len(rp) - 1
+    rng = np.random.default_rng(3)
+    b = rng.uniform(-1, 1, n).astype(dtype); x0 = rng.uniform(-1, 1, n).astype(dtype)
+    A = ra.LocalMatrix(dtype); A.SetDataPtrCSR(rp, ci, va)
+    out = []
+    for fused in (True, False):
+        ls = S.FixedPoint(dtype); ls.SetOperator(A); ls.SetPreconditioner(S.Jacobi()); ls.SetRelaxation(2.0 / 3.0)
+        ls.FlagSmoother(); ls.InitMaxIter(5); ls.SetFused(fused); ls.Build()
+        x = ra.LocalVector(dtype, data=x0)
+        ls.Solve(ra.LocalVector(dtype, data=b), x)
+        out.append(x.numpy().copy())
+        ls.Clear()
+    assert np.array_equal(out[0], out[1])
+    assert not np.array_equal(out[0], x0)
