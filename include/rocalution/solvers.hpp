@@ -627,6 +627,88 @@ private:
     VectorType   inv_diag_entries_;
 };
 
+// ---- VariablePreconditioner (preconditioner.cpp:594-673): a different preconditioner on every call, round robin --
+// for the flexible Krylov methods (FGMRES, FCG)
+template <class OperatorType, class VectorType, typename ValueType>
+class VariablePreconditioner : public Preconditioner<OperatorType, VectorType, ValueType>
+{
+public:
+    VariablePreconditioner()
+        : num_precond_(0)
+        , preconds_(NULL)
+        , counter_(0)
+    {
+    }
+    virtual ~VariablePreconditioner()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        if(this->build_)
+        {
+            LOG_INFO("VariablePreconditioner with " << this->num_precond_ << " preconditioners:");
+            for(int i = 0; i < this->num_precond_; ++i)
+                this->preconds_[i]->Print();
+        }
+        else
+            LOG_INFO("VariablePreconditioner preconditioner");
+    }
+    virtual void SetPreconditioner(int n, Solver<OperatorType, VectorType, ValueType>** precond)
+    {
+        assert(this->preconds_ == NULL && n > 0 && precond != NULL);
+        this->preconds_ = new Solver<OperatorType, VectorType, ValueType>*[n];
+        for(int i = 0; i < n; ++i)
+            this->preconds_[i] = precond[i];
+        this->num_precond_ = n;
+    }
+    virtual void Build(void)
+    {
+        if(this->build_)
+            this->Clear();
+        assert(this->op_ != NULL && this->preconds_ != NULL);
+        this->build_ = true;
+        for(int i = 0; i < this->num_precond_; ++i)
+        {
+            this->preconds_[i]->SetOperator(*this->op_);
+            this->preconds_[i]->Build();
+        }
+    }
+    virtual void Clear(void)
+    {
+        if(this->preconds_ != NULL && this->build_)
+        {
+            for(int i = 0; i < this->num_precond_; ++i)
+                this->preconds_[i]->Clear();
+            delete[] this->preconds_;
+            this->preconds_    = NULL;
+            this->num_precond_ = 0;
+        }
+        this->counter_ = 0;
+        this->build_   = false;
+    }
+    virtual void Solve(const VectorType& rhs, VectorType* x)
+    {
+        assert(this->build_ == true && x != NULL && x != &rhs);
+        this->preconds_[this->counter_]->Solve(rhs, x);
+        ++this->counter_;
+        if(this->counter_ >= this->num_precond_)
+            this->counter_ = 0;
+    }
+    virtual bool SolveUsesScalarRecord(void) const
+    {
+        for(int i = 0; i < this->num_precond_; ++i)
+            if(this->preconds_[i]->SolveUsesScalarRecord())
+                return true;
+        return false;
+    }
+
+private:
+    int                                           num_precond_;
+    Solver<OperatorType, VectorType, ValueType>** preconds_;
+    int                                           counter_;
+};
+
 // ---- approximate-inverse preconditioners whose Solve is a sparse matrix-vector product (preconditioner_ai.cpp)
 // AIChebyshev :41-215: Chebyshev polynomial of the shifted operator built with MatrixMult / MatrixAdd
 template <class OperatorType, class VectorType, typename ValueType>

@@ -813,6 +813,23 @@ static int cmd_gen(const std::string& in, const std::string& out)
             ls.Clear();
         }
         {
+            // a different preconditioner on every application, round robin (flexible GMRES)
+            FGMRES<MatD, VecD, double>                 ls;
+            VariablePreconditioner<MatD, VecD, double> vp;
+            Jacobi<MatD, VecD, double>                 v0;
+            MultiColoredSGS<MatD, VecD, double>        v1;
+            ILU<MatD, VecD, double>                    v2;
+            Solver<MatD, VecD, double>*                list[3] = {&v0, &v1, &v2};
+            vp.SetPreconditioner(3, list);
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(vp);
+            ls.SetBasisSize(basis);
+            ls.Build();
+            sol.Zeros();
+            run_solver("fgmres_variable", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
             CG<MatD, VecD, double>   ls;
             FSAI<MatD, VecD, double> p;
             ls.SetOperator(mat);

@@ -31,6 +31,18 @@ static std::unique_ptr<AnySolver> make_precond(const std::string& p)
     if(p == "mcgs") return std::unique_ptr<AnySolver>(new MultiColoredGS<Mat, Vec, double>);
     if(p == "mcsgs") return std::unique_ptr<AnySolver>(new MultiColoredSGS<Mat, Vec, double>);
     if(p == "mcilu") return std::unique_ptr<AnySolver>(new MultiColoredILU<Mat, Vec, double>);
+    if(p == "fsai") return std::unique_ptr<AnySolver>(new FSAI<Mat, Vec, double>);
+    if(p == "tns") return std::unique_ptr<AnySolver>(new TNS<Mat, Vec, double>);
+    if(p == "variable") // Jacobi, MC-SGS, ILU(0) in turn (for the flexible methods)
+    {
+        static Jacobi<Mat, Vec, double>          v0;
+        static MultiColoredSGS<Mat, Vec, double> v1;
+        static ILU<Mat, Vec, double>             v2;
+        static AnySolver*                        list[3] = {&v0, &v1, &v2};
+        VariablePreconditioner<Mat, Vec, double>* vp      = new VariablePreconditioner<Mat, Vec, double>;
+        vp->SetPreconditioner(3, list);
+        return std::unique_ptr<AnySolver>(vp);
+    }
     if(p != "none")
     {
         std::cerr << "unknown preconditioner " << p << std::endl;
