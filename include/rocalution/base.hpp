@@ -453,6 +453,13 @@ public:
         this->need_accel_("ScaleAdd");
         RAMD_CHECK(ramd_vec_scale_add(this->dev_, (double)alpha, x.dev_));
     }
+    void ScaleAddScale(ValueType alpha, const LocalVector<ValueType>& x, ValueType beta, int64_t src_offset,
+                       int64_t dst_offset, int64_t size)
+    {
+        this->need_accel_("ScaleAddScale");
+        RAMD_CHECK(ramd_vec_scale_add_scale_offset(this->dev_, (double)alpha, x.handle(), (double)beta, src_offset,
+                                                   dst_offset, size));
+    }
     void ScaleAddScale(ValueType alpha, const LocalVector<ValueType>& x, ValueType beta)
     {
         this->need_accel_("ScaleAddScale");

@@ -627,6 +627,182 @@ private:
     VectorType   inv_diag_entries_;
 };
 
+// ---- AS / RAS (preconditioner_as.cpp): (restricted) additive Schwarz over nb contiguous row blocks with `overlap`
+// rows on each side; the local operators come from ExtractSubMatrix, the local solvers from the caller
+template <class OperatorType, class VectorType, typename ValueType>
+class AS : public Preconditioner<OperatorType, VectorType, ValueType>
+{
+public:
+    AS()
+        : num_blocks_(0)
+        , overlap_(-1)
+        , pos_(NULL)
+        , sizes_(NULL)
+        , local_mat_(NULL)
+        , local_precond_(NULL)
+        , r_(NULL)
+        , z_(NULL)
+    {
+    }
+    virtual ~AS()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("Additive Schwarz preconditioner");
+    }
+    virtual void Set(int nb, int overlap, Solver<OperatorType, VectorType, ValueType>** preconds)
+    {
+        if(this->build_ || this->local_precond_ != NULL)
+            this->Clear();
+        assert(nb > 0 && overlap >= 0 && preconds != NULL);
+        this->num_blocks_    = nb;
+        this->overlap_       = overlap;
+        this->local_precond_ = new Solver<OperatorType, VectorType, ValueType>*[nb];
+        this->pos_           = new int[nb];
+        this->sizes_         = new int[nb];
+        for(int i = 0; i < nb; ++i)
+            this->local_precond_[i] = preconds[i];
+    }
+    // preconditioner_as.cpp:101-186
+    virtual void Build(void)
+    {
+        assert(this->op_ != NULL && this->num_blocks_ > 0 && this->overlap_ >= 0);
+        const int size   = static_cast<int>(this->op_->GetLocalM() / this->num_blocks_);
+        int       offset = 0;
+        for(int i = 0; i < this->num_blocks_; ++i)
+        {
+            this->pos_[i] = offset - this->overlap_;
+            offset += size;
+            this->sizes_[i] = size + 2 * this->overlap_;
+        }
+        this->pos_[0]                       = 0;
+        this->sizes_[0]                     = size + this->overlap_;
+        this->sizes_[this->num_blocks_ - 1] = size + this->overlap_;
+        std::vector<ValueType> w((size_t)this->op_->GetM(), static_cast<ValueType>(1));
+        for(int i = 0; i < this->num_blocks_; ++i)
+            for(int j = 0; j < this->overlap_; ++j)
+            {
+                if(i != 0)
+                    w[(size_t)(this->pos_[i] + j)] = static_cast<ValueType>(0.5);
+                if(i != this->num_blocks_ - 1)
+                    w[(size_t)(this->pos_[i] + size + j)] = static_cast<ValueType>(0.5);
+            }
+        this->weight_.CloneBackend(*this->op_);
+        this->weight_.Allocate("Overlapping weights", this->op_->GetM());
+        this->weight_.CopyFromData(w.data());
+        this->local_mat_ = new OperatorType*[this->num_blocks_];
+        this->r_         = new VectorType*[this->num_blocks_];
+        this->z_         = new VectorType*[this->num_blocks_];
+        for(int i = 0; i < this->num_blocks_; ++i)
+        {
+            this->r_[i] = new VectorType;
+            this->r_[i]->CloneBackend(*this->op_);
+            this->r_[i]->Allocate("AS residual vector", this->sizes_[i]);
+            this->z_[i] = new VectorType;
+            this->z_[i]->CloneBackend(*this->op_);
+            this->z_[i]->Allocate("AS residual vector", this->sizes_[i]);
+            this->local_mat_[i] = new OperatorType;
+            this->local_mat_[i]->CloneBackend(*this->op_);
+            this->op_->ExtractSubMatrix(this->pos_[i], this->pos_[i], this->sizes_[i], this->sizes_[i], this->local_mat_[i]);
+            this->local_precond_[i]->SetOperator(*this->local_mat_[i]);
+            this->local_precond_[i]->Build();
+        }
+        this->build_ = true;
+    }
+    virtual void Clear(void)
+    {
+        if(this->build_)
+        {
+            this->weight_.Clear();
+            for(int i = 0; i < this->num_blocks_; ++i)
+            {
+                if(this->local_precond_[i] != NULL)
+                {
+                    this->local_precond_[i]->Clear();
+                    this->local_precond_[i] = NULL;
+                }
+                delete this->r_[i];
+                delete this->z_[i];
+                delete this->local_mat_[i];
+            }
+            delete[] this->r_;
+            delete[] this->z_;
+            delete[] this->local_mat_;
+            this->r_ = this->z_ = NULL;
+            this->local_mat_    = NULL;
+            this->build_        = false;
+        }
+        delete[] this->local_precond_;
+        delete[] this->pos_;
+        delete[] this->sizes_;
+        this->local_precond_ = NULL;
+        this->pos_ = this->sizes_ = NULL;
+        this->num_blocks_         = 0;
+        this->overlap_            = -1;
+    }
+    // preconditioner_as.cpp:232-262
+    virtual void Solve(const VectorType& rhs, VectorType* x)
+    {
+        assert(this->build_ == true && x != NULL && x != &rhs);
+        this->LocalSolves_(rhs);
+        x->Zeros();
+        for(int i = 0; i < this->num_blocks_; ++i)
+            x->ScaleAddScale(static_cast<ValueType>(1), *this->z_[i], static_cast<ValueType>(1), 0, this->pos_[i],
+                             this->sizes_[i]);
+        x->PointWiseMult(this->weight_);
+    }
+    virtual bool SolveUsesScalarRecord(void) const
+    {
+        for(int i = 0; i < this->num_blocks_; ++i)
+            if(this->local_precond_[i] != NULL && this->local_precond_[i]->SolveUsesScalarRecord())
+                return true;
+        return false;
+    }
+
+protected:
+    void LocalSolves_(const VectorType& rhs)
+    {
+        for(int i = 0; i < this->num_blocks_; ++i)
+            this->r_[i]->CopyFrom(rhs, this->pos_[i], 0, this->sizes_[i]);
+        for(int i = 0; i < this->num_blocks_; ++i)
+            this->local_precond_[i]->SolveZeroSol(*this->r_[i], this->z_[i]);
+    }
+    int            num_blocks_;
+    int            overlap_;
+    int*           pos_;
+    int*           sizes_;
+    OperatorType** local_mat_;
+    Solver<OperatorType, VectorType, ValueType>** local_precond_;
+    VectorType** r_;
+    VectorType** z_;
+    VectorType   weight_;
+};
+
+template <class OperatorType, class VectorType, typename ValueType>
+class RAS : public AS<OperatorType, VectorType, ValueType>
+{
+public:
+    virtual void Print(void) const
+    {
+        LOG_INFO("Restricted Additive Schwarz preconditioner");
+    }
+    // preconditioner_as.cpp:330-355: every block keeps only its own (non-overlapping) part of the local solution
+    virtual void Solve(const VectorType& rhs, VectorType* x)
+    {
+        assert(this->build_ == true && x != NULL && x != &rhs);
+        this->LocalSolves_(rhs);
+        const int size     = static_cast<int>(this->op_->GetLocalM() / this->num_blocks_);
+        int       z_offset = 0;
+        for(int i = 0; i < this->num_blocks_; ++i)
+        {
+            x->CopyFrom(*this->z_[i], z_offset, this->pos_[i] + z_offset, size);
+            z_offset = this->overlap_;
+        }
+    }
+};
+
 // ---- VariablePreconditioner (preconditioner.cpp:594-673): a different preconditioner on every call, round robin --
 // for the flexible Krylov methods (FGMRES, FCG)
 template <class OperatorType, class VectorType, typename ValueType>

@@ -104,6 +104,9 @@ int ramd_vec_copy_from_permute_backward(ramd_vec_t v, ramd_vec_t src, ramd_vec_t
 int ramd_vec_add_scale(ramd_vec_t v, ramd_vec_t x, double alpha); /* AddScale :126  v = v + alpha*x */
 int ramd_vec_scale_add(ramd_vec_t v, double alpha, ramd_vec_t x); /* ScaleAdd :128  v = alpha*v + x */
 int ramd_vec_scale_add_scale(ramd_vec_t v, double alpha, ramd_vec_t x, double beta); /* :130 */
+/* the sub-range form (host_vector.cpp:693-720): v[dst+i] = alpha*v[dst+i] + beta*x[src+i], i < size */
+int ramd_vec_scale_add_scale_offset(ramd_vec_t v, double alpha, ramd_vec_t x, double beta, int64_t src_offset,
+                                    int64_t dst_offset, int64_t size);
 int ramd_vec_scale_add2(ramd_vec_t v, double alpha, ramd_vec_t x, double beta, ramd_vec_t y,
                         double gamma); /* ScaleAdd2 :142 */
 int ramd_vec_scale(ramd_vec_t v, double alpha); /* Scale :149 */

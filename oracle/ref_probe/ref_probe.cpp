@@ -829,6 +829,29 @@ static int cmd_gen(const std::string& in, const std::string& out)
             run_solver("fgmres_variable", ls, rhs, sol);
             ls.Clear();
         }
+        for(int variant = 0; variant < 2; ++variant)
+        {
+            // (restricted) additive Schwarz: 3 blocks, overlap 4, ILU(0) on every block
+            GMRES<MatD, VecD, double> ls;
+            AS<MatD, VecD, double>    as;
+            RAS<MatD, VecD, double>   ras;
+            ILU<MatD, VecD, double>   loc[3];
+            Solver<MatD, VecD, double>* list[3] = {&loc[0], &loc[1], &loc[2]};
+            if(variant == 0)
+                as.Set(3, 4, list);
+            else
+                ras.Set(3, 4, list);
+            ls.SetOperator(mat);
+            if(variant == 0)
+                ls.SetPreconditioner(as);
+            else
+                ls.SetPreconditioner(ras);
+            ls.SetBasisSize(basis);
+            ls.Build();
+            sol.Zeros();
+            run_solver(variant == 0 ? "gmres_as" : "gmres_ras", ls, rhs, sol);
+            ls.Clear();
+        }
         {
             CG<MatD, VecD, double>   ls;
             FSAI<MatD, VecD, double> p;

@@ -65,6 +65,7 @@ SIGNATURES = {
     "ramd_vec_copy_from_permute_backward": (i32, [vec_t, vec_t, vec_t]),
     "ramd_vec_add_scale": (i32, [vec_t, vec_t, f64]),
     "ramd_vec_scale_add": (i32, [vec_t, f64, vec_t]),
+    "ramd_vec_scale_add_scale_offset": (i32, [vec_t, f64, vec_t, f64, i64, i64, i64]),
     "ramd_vec_scale_add_scale": (i32, [vec_t, f64, vec_t, f64]),
     "ramd_vec_scale_add2": (i32, [vec_t, f64, vec_t, f64, vec_t, f64]),
     "ramd_vec_scale": (i32, [vec_t, f64]),

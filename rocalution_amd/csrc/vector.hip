@@ -104,6 +104,16 @@ struct FScaleAdd
     }
 };
 
+// host_vector.cpp:693-720  ScaleAddScale on a sub-range (element loop: the ranges need not be packet aligned)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_scale_add_scale_offset(int64_t n, T* __restrict__ v, const T* __restrict__ x,
+                                                                   T alpha, T beta)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gsz)
+        v[i] = alpha * v[i] + beta * x[i];
+}
+
 // host_vector.cpp:672-690  ScaleAddScale: v = alpha*v + beta*x
 template <typename T>
 struct FScaleAddScale
@@ -643,6 +653,28 @@ int ramd_vec_scale_add_scale(ramd_vec_t v, double alpha, ramd_vec_t x, double be
     CHECK_SAME(v, x);
     DISPATCH_FP(
         v, return launch_map<T>(v->n, FScaleAddScale<T>{(T*)v->d, (const T*)x->d, (T)alpha, (T)beta}));
+}
+int ramd_vec_scale_add_scale_offset(ramd_vec_t v, double alpha, ramd_vec_t x, double beta, int64_t src_offset,
+                                    int64_t dst_offset, int64_t size)
+{
+    CHECK_VEC(v);
+    CHECK_VEC(x);
+    if(v->dtype != x->dtype || size < 0 || src_offset < 0 || dst_offset < 0 || src_offset + size > x->n
+       || dst_offset + size > v->n)
+        RAMD_FAIL(RAMD_ERR_ARG, "ScaleAddScale(offsets): range outside the vectors / type mismatch");
+    if(size == 0)
+        return RAMD_OK;
+    const int grid = ew_grid(size);
+    if(v->dtype == RAMD_F64)
+        hipLaunchKernelGGL((k_scale_add_scale_offset<double>), dim3(grid), dim3(kBlock), 0, backend().cur, size,
+                           (double*)v->d + dst_offset, (const double*)x->d + src_offset, alpha, beta);
+    else if(v->dtype == RAMD_F32)
+        hipLaunchKernelGGL((k_scale_add_scale_offset<float>), dim3(grid), dim3(kBlock), 0, backend().cur, size,
+                           (float*)v->d + dst_offset, (const float*)x->d + src_offset, (float)alpha, (float)beta);
+    else
+        RAMD_FAIL(RAMD_ERR_ARG, "ScaleAddScale(offsets): real vectors expected");
+    RAMD_HIP(hipGetLastError());
+    return RAMD_OK;
 }
 int ramd_vec_scale_add2(ramd_vec_t v, double alpha, ramd_vec_t x, double beta, ramd_vec_t y, double gamma)
 {

@@ -33,6 +33,14 @@ static std::unique_ptr<AnySolver> make_precond(const std::string& p)
     if(p == "mcilu") return std::unique_ptr<AnySolver>(new MultiColoredILU<Mat, Vec, double>);
     if(p == "fsai") return std::unique_ptr<AnySolver>(new FSAI<Mat, Vec, double>);
     if(p == "tns") return std::unique_ptr<AnySolver>(new TNS<Mat, Vec, double>);
+    if(p == "as" || p == "ras") // (restricted) additive Schwarz: 3 blocks, overlap 4, ILU(0) on every block
+    {
+        static ILU<Mat, Vec, double> loc[3];
+        static AnySolver*            list[3] = {&loc[0], &loc[1], &loc[2]};
+        AS<Mat, Vec, double>*        s       = (p == "as") ? new AS<Mat, Vec, double> : new RAS<Mat, Vec, double>;
+        s->Set(3, 4, list);
+        return std::unique_ptr<AnySolver>(s);
+    }
     if(p == "variable") // Jacobi, MC-SGS, ILU(0) in turn (for the flexible methods)
     {
         static Jacobi<Mat, Vec, double>          v0;
