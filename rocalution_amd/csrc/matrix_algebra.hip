@@ -7,6 +7,7 @@
 #include "matrix_impl.hpp"
 
 #include <algorithm>
+#include <vector>
 #include <cstdlib>
 
 namespace ramd
@@ -321,12 +322,12 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void k_mm_compact(int nrow, const long long* __restrict__ off,
                                                        const int* __restrict__ pcol, const T* __restrict__ pval,
                                                        const int* __restrict__ crp, int* __restrict__ cci,
-                                                       T* __restrict__ cval)
+                                                       T* __restrict__ cval, long long base = 0)
 {
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
     for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
     {
-        const long long s = off[i];
+        const long long s = off[i] - base;
         const int       n = crp[i + 1] - crp[i];
         for(int k = 0; k < n; ++k)
         {
@@ -403,24 +404,24 @@ __global__ __launch_bounds__(kBlock) void k_mm_any_long(int nrow, const long lon
             *flag = 1;
 }
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_mm_generate(int nrow, const int* __restrict__ arp,
+__global__ __launch_bounds__(kBlock) void k_mm_generate(int r0, int r1, const int* __restrict__ arp,
                                                         const int* __restrict__ aci, const T* __restrict__ aval,
                                                         const int* __restrict__ brp, const int* __restrict__ bci,
                                                         const T* __restrict__ bval, const long long* __restrict__ off,
-                                                        int* __restrict__ prow, int* __restrict__ pcol,
+                                                        long long base, int* __restrict__ prow, int* __restrict__ pcol,
                                                         T* __restrict__ pval)
 {
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
-    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+    for(int64_t i = r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < r1; i += gsz)
     {
-        long long q = off[i];
+        long long q = off[i] - base;
         for(int ja = arp[i]; ja < arp[i + 1]; ++ja)
         {
             const int ca = aci[ja];
             const T   va = aval[ja];
             for(int jb = brp[ca]; jb < brp[ca + 1]; ++jb, ++q)
             {
-                prow[q] = (int)i;
+                prow[q] = (int)(i - r0);
                 pcol[q] = bci[jb];
                 pval[q] = va * bval[jb];
             }
@@ -491,27 +492,22 @@ __global__ __launch_bounds__(kBlock) void k_mm_reduce(int64_t n, const int* __re
 // Writes the compacted row into the scratch segment like k_mm_products (same k_mm_compact afterwards).
 constexpr int kMmCap = 2048;
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_mm_row_lds(int nrow, const int* __restrict__ arp,
+__global__ __launch_bounds__(kBlock) void k_mm_row_lds(int r0, int nrow, const int* __restrict__ arp,
                                                        const int* __restrict__ aci, const T* __restrict__ aval,
                                                        const int* __restrict__ brp, const int* __restrict__ bci,
                                                        const T* __restrict__ bval, const long long* __restrict__ off,
-                                                       int* __restrict__ pcol, T* __restrict__ pval,
+                                                       long long base, int* __restrict__ pcol, T* __restrict__ pval,
                                                        int* __restrict__ cnt, int* __restrict__ toolong)
 {
     __shared__ unsigned long long key[kMmCap];
     __shared__ T                  val[kMmCap];
     __shared__ int                aux[kMmCap + 1]; // prefix of the B-row lengths, later the output positions
     const int tid = threadIdx.x;
-    for(int i = blockIdx.x; i <= nrow; i += gridDim.x)
+    // rows [r0, nrow): scratch positions relative to `base`, counts into cnt[row]
+    for(int i = r0 + blockIdx.x; i < nrow; i += gridDim.x)
     {
-        if(i == nrow)
-        {
-            if(tid == 0)
-                cnt[i] = 0;
-            continue;
-        }
-        const long long s  = off[i];
-        const long long ul = off[i + 1] - s;
+        const long long s  = off[i] - base;
+        const long long ul = off[i + 1] - off[i];
         const int       ra = arp[i], na = arp[i + 1] - ra;
         if(ul > kMmCap || na > kMmCap)
         {
@@ -667,19 +663,22 @@ static int matrix_add_t(ramd_mat_s* m, const ramd_mat_s* o, T alpha, T beta, boo
     return RAMD_OK;
 }
 
+// one chunk of rows [r0, r1) of C through the sorted path; the rows' counts go to cnt[r0..r1), the compacted entries of
+// the chunk (contiguous in C, rows being contiguous) to freshly allocated arrays
 template <typename T>
-static int mat_mult_sorted_t(ramd_mat_s* c, const ramd_mat_s* a, const ramd_mat_s* bm, const long long* off,
-                             long long total)
+static int mat_mult_sorted_chunk(const ramd_mat_s* a, const ramd_mat_s* bm, const long long* off, int r0, int r1,
+                                 long long base, int64_t P, int* cnt, int** cci_out, void** cv_out, int* nnz_out)
 {
-    Backend&  b = backend();
-    const int n = a->nrow;
-    if(total >= 0x7fffffffLL)
-        RAMD_FAIL(RAMD_ERR_UNSUPPORTED, "MatrixMult: more than 2^31 intermediate products");
-    const int64_t P    = (int64_t)total;
-    int *         prow = nullptr, *pcol = nullptr, *o1 = nullptr, *o2 = nullptr, *k2 = nullptr, *head = nullptr;
-    int*          cnt  = nullptr;
-    void*         pval = nullptr;
-    int           s    = dev_alloc(&prow, P);
+    Backend&  b  = backend();
+    const int nr = r1 - r0;
+    *cci_out     = nullptr;
+    *cv_out      = nullptr;
+    *nnz_out     = 0;
+    if(P <= 0 || nr <= 0)
+        return RAMD_OK;
+    int * prow = nullptr, *pcol = nullptr, *o1 = nullptr, *o2 = nullptr, *k2 = nullptr, *head = nullptr;
+    void* pval = nullptr;
+    int   s    = dev_alloc(&prow, P);
     if(s == RAMD_OK)
         s = dev_alloc(&pcol, P);
     if(s == RAMD_OK)
@@ -690,8 +689,6 @@ static int mat_mult_sorted_t(ramd_mat_s* c, const ramd_mat_s* a, const ramd_mat_
         s = dev_alloc(&k2, P);
     if(s == RAMD_OK)
         s = dev_alloc(&head, P + 1);
-    if(s == RAMD_OK)
-        s = dev_alloc(&cnt, (int64_t)n + 1);
     if(s == RAMD_OK && cached_malloc(&pval, (size_t)P * sizeof(T) + kPad) != hipSuccess)
         s = RAMD_ERR_HIP;
     int   nnz = 0;
@@ -700,25 +697,29 @@ static int mat_mult_sorted_t(ramd_mat_s* c, const ramd_mat_s* a, const ramd_mat_
     if(s == RAMD_OK)
     {
         const int gp = ew_grid(std::max<int64_t>(P, 1));
-        hipLaunchKernelGGL((k_mm_generate<T>), dim3(ew_grid(std::max(n, 1))), dim3(kBlock), 0, b.cur, n, a->rp, a->ci,
-                           (const T*)a->val, bm->rp, bm->ci, (const T*)bm->val, off, prow, pcol, (T*)pval);
+        hipLaunchKernelGGL((k_mm_generate<T>), dim3(ew_grid(nr)), dim3(kBlock), 0, b.cur, r0, r1, a->rp, a->ci,
+                           (const T*)a->val, bm->rp, bm->ci, (const T*)bm->val, off, base, prow, pcol, (T*)pval);
         s = device_stable_sort_by_key(pcol, P, std::max(bm->ncol - 1, 0), o1);
         if(s == RAMD_OK)
         {
             hipLaunchKernelGGL(k_gather_int, dim3(gp), dim3(kBlock), 0, b.cur, P, (const int*)o1, (const int*)prow, k2);
-            s = device_stable_sort_by_key(k2, P, std::max(n - 1, 0), o2);
+            s = device_stable_sort_by_key(k2, P, std::max(nr - 1, 0), o2);
         }
-        if(s == RAMD_OK && hipMemsetAsync(cnt, 0, sizeof(int) * ((size_t)n + 1), b.cur) != hipSuccess)
-            s = RAMD_ERR_HIP;
         if(s == RAMD_OK)
         {
             // k2 is reused as the composed permutation
             hipLaunchKernelGGL(k_mm_heads, dim3(ew_grid(P + 1)), dim3(kBlock), 0, b.cur, P, (const int*)o1, (const int*)o2,
-                               (const int*)prow, (const int*)pcol, k2, head, cnt);
+                               (const int*)prow, (const int*)pcol, k2, head, cnt + r0);
             s = device_exclusive_scan(head, head, P + 1);
         }
         if(s == RAMD_OK)
-            s = scan_to_rowptr(cnt, n, &nnz);
+        {
+            hipError_t e = hipMemcpyAsync(&nnz, head + P, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+            if(e == hipSuccess)
+                e = hipStreamSynchronize(b.cur);
+            if(e != hipSuccess)
+                s = RAMD_ERR_HIP;
+        }
         if(s == RAMD_OK)
             s = dev_alloc(&cci, nnz);
         if(s == RAMD_OK && cached_malloc(&cv, (size_t)nnz * sizeof(T) + kPad) != hipSuccess)
@@ -744,10 +745,239 @@ static int mat_mult_sorted_t(ramd_mat_s* c, const ramd_mat_s* a, const ramd_mat_
         (void)cached_free(pval);
     if(s != RAMD_OK)
     {
+        dev_free(&cci);
+        if(cv)
+            (void)cached_free(cv);
+        return s;
+    }
+    *cci_out = cci;
+    *cv_out  = cv;
+    *nnz_out = nnz;
+    return RAMD_OK;
+}
+
+// one chunk through the LDS kernel: compacted rows into a scratch of P entries, then into a piece; *toolong: a row of
+// the chunk exceeds the LDS capacity (the caller sends the chunk through the global sort instead)
+template <typename T>
+static int mat_mult_lds_chunk(const ramd_mat_s* a, const ramd_mat_s* bm, const long long* off, int r0, int r1,
+                              long long base, int64_t P, int* cnt, int** cci_out, void** cv_out, int* nnz_out,
+                              int* toolong)
+{
+    Backend&  b  = backend();
+    const int nr = r1 - r0;
+    *cci_out     = nullptr;
+    *cv_out      = nullptr;
+    *nnz_out     = 0;
+    *toolong     = 0;
+    if(P <= 0 || nr <= 0)
+        return RAMD_OK;
+    int * pcol = nullptr, *flag = nullptr, *crp = nullptr;
+    void* pval = nullptr;
+    int   s    = dev_alloc(&pcol, P);
+    if(s == RAMD_OK)
+        s = dev_alloc(&flag, 1);
+    if(s == RAMD_OK)
+        s = dev_alloc(&crp, (int64_t)nr + 1);
+    if(s == RAMD_OK && cached_malloc(&pval, (size_t)P * sizeof(T) + kPad) != hipSuccess)
+        s = RAMD_ERR_HIP;
+    int*  cci = nullptr;
+    void* cv  = nullptr;
+    int   nnz = 0;
+    if(s == RAMD_OK)
+    {
+        hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), b.cur);
+        const int  g = (int)std::min<int64_t>((int64_t)nr, (int64_t)backend().num_cu * 8);
+        hipLaunchKernelGGL((k_mm_row_lds<T>), dim3(g), dim3(kBlock), 0, b.cur, r0, r1, a->rp, a->ci, (const T*)a->val,
+                           bm->rp, bm->ci, (const T*)bm->val, off, base, pcol, (T*)pval, cnt, flag);
+        if(e == hipSuccess)
+            e = hipMemcpyAsync(toolong, flag, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+        if(e == hipSuccess)
+            e = hipStreamSynchronize(b.cur);
+        if(e != hipSuccess)
+            s = RAMD_ERR_HIP;
+    }
+    if(s == RAMD_OK && !*toolong)
+    {
+        hipError_t e = hipMemcpyAsync(crp, cnt + r0, sizeof(int) * (size_t)nr, hipMemcpyDeviceToDevice, b.cur);
+        if(e == hipSuccess)
+            e = hipMemsetAsync(crp + nr, 0, sizeof(int), b.cur);
+        if(e != hipSuccess)
+            s = RAMD_ERR_HIP;
+        if(s == RAMD_OK)
+            s = scan_to_rowptr(crp, nr, &nnz);
+        if(s == RAMD_OK)
+            s = dev_alloc(&cci, nnz);
+        if(s == RAMD_OK && cached_malloc(&cv, (size_t)nnz * sizeof(T) + kPad) != hipSuccess)
+            s = RAMD_ERR_HIP;
+        if(s == RAMD_OK)
+        {
+            hipLaunchKernelGGL((k_mm_compact<T>), dim3(ew_grid(nr)), dim3(kBlock), 0, b.cur, nr, off + r0, (const int*)pcol,
+                               (const T*)pval, (const int*)crp, cci, (T*)cv, base);
+            e = hipGetLastError();
+            if(e == hipSuccess)
+                e = hipStreamSynchronize(b.cur);
+            if(e != hipSuccess)
+                s = RAMD_ERR_HIP;
+        }
+    }
+    dev_free(&pcol);
+    dev_free(&flag);
+    dev_free(&crp);
+    if(pval)
+        (void)cached_free(pval);
+    if(s != RAMD_OK || *toolong)
+    {
+        dev_free(&cci);
+        if(cv)
+            (void)cached_free(cv);
+        return s;
+    }
+    *cci_out = cci;
+    *cv_out  = cv;
+    *nnz_out = nnz;
+    return RAMD_OK;
+}
+
+// long rows: row chunks of at most RAMD_MM_CHUNK products (bounded, reusable scratch; int32 sort indices); every chunk
+// goes through the LDS kernel, or through the global sort when one of its rows exceeds the LDS capacity
+template <typename T>
+static int mat_mult_chunked_t(ramd_mat_s* c, const ramd_mat_s* a, const ramd_mat_s* bm, const long long* off)
+{
+    Backend&  b = backend();
+    const int n = a->nrow;
+    static long long chunk_products = -1;
+    if(chunk_products < 0)
+    {
+        const char* e  = getenv("RAMD_MM_CHUNK"); // products per chunk (tests force tiny chunks)
+        chunk_products = e ? atoll(e) : (1ll << 28);
+        if(chunk_products < 1)
+            chunk_products = 1;
+    }
+    static int use_lds = -1;
+    if(use_lds < 0)
+    {
+        const char* e2 = getenv("RAMD_MM_LDS");
+        use_lds        = e2 ? atoi(e2) : 1;
+    }
+    auto read_off = [&](int i, long long* v) -> int {
+        RAMD_HIP(hipMemcpyAsync(v, off + i, sizeof(long long), hipMemcpyDeviceToHost, b.cur));
+        RAMD_HIP(hipStreamSynchronize(b.cur));
+        return RAMD_OK;
+    };
+    int* cnt = nullptr;
+    RAMD_TRY(dev_alloc(&cnt, (int64_t)n + 1));
+    int s = RAMD_OK;
+    if(hipMemsetAsync(cnt, 0, sizeof(int) * ((size_t)n + 1), b.cur) != hipSuccess)
+        s = RAMD_ERR_HIP;
+    struct Piece
+    {
+        int*  ci;
+        void* val;
+        int   nnz;
+    };
+    std::vector<Piece> pieces;
+    int                r0   = 0;
+    long long          base = 0;
+    long long          nnz_total = 0;
+    while(s == RAMD_OK && r0 < n)
+    {
+        // largest r1 with off[r1] - base <= chunk_products (at least one row)
+        int lo = r0 + 1, hi = n;
+        long long v = 0;
+        s = read_off(hi, &v);
+        if(s != RAMD_OK)
+            break;
+        if(v - base > chunk_products)
+        {
+            while(lo < hi)
+            {
+                const int mid = lo + (hi - lo + 1) / 2;
+                s             = read_off(mid, &v);
+                if(s != RAMD_OK)
+                    break;
+                if(v - base <= chunk_products)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+            if(s != RAMD_OK)
+                break;
+            hi = lo;
+            s  = read_off(hi, &v);
+            if(s != RAMD_OK)
+                break;
+        }
+        const int       r1 = hi;
+        const long long P  = v - base;
+        if(P >= 0x7fffffffLL)
+        {
+            s = RAMD_ERR_UNSUPPORTED; // a single row with more than 2^31 products
+            break;
+        }
+        Piece pc      = {nullptr, nullptr, 0};
+        int   toolong = 1;
+        if(use_lds)
+            s = mat_mult_lds_chunk<T>(a, bm, off, r0, r1, base, (int64_t)P, cnt, &pc.ci, &pc.val, &pc.nnz, &toolong);
+        if(s == RAMD_OK && toolong)
+        {
+            if(hipMemsetAsync(cnt + r0, 0, sizeof(int) * (size_t)(r1 - r0), b.cur) != hipSuccess)
+                s = RAMD_ERR_HIP;
+            if(s == RAMD_OK)
+                s = mat_mult_sorted_chunk<T>(a, bm, off, r0, r1, base, (int64_t)P, cnt, &pc.ci, &pc.val, &pc.nnz);
+        }
+        if(s == RAMD_OK)
+        {
+            pieces.push_back(pc);
+            nnz_total += pc.nnz;
+        }
+        r0   = r1;
+        base = v;
+    }
+    if(s == RAMD_OK && nnz_total >= 0x7fffffffLL)
+        s = RAMD_ERR_UNSUPPORTED;
+    int   nnz = 0;
+    int*  cci = nullptr;
+    void* cv  = nullptr;
+    if(s == RAMD_OK)
+        s = scan_to_rowptr(cnt, n, &nnz);
+    if(s == RAMD_OK)
+        s = dev_alloc(&cci, nnz);
+    if(s == RAMD_OK && cached_malloc(&cv, (size_t)nnz * sizeof(T) + kPad) != hipSuccess)
+        s = RAMD_ERR_HIP;
+    if(s == RAMD_OK)
+    {
+        size_t     at = 0;
+        hipError_t e  = hipSuccess;
+        for(size_t k = 0; k < pieces.size() && e == hipSuccess; ++k)
+        {
+            if(pieces[k].nnz > 0)
+            {
+                e = hipMemcpyAsync(cci + at, pieces[k].ci, sizeof(int) * (size_t)pieces[k].nnz, hipMemcpyDeviceToDevice, b.cur);
+                if(e == hipSuccess)
+                    e = hipMemcpyAsync((char*)cv + at * sizeof(T), pieces[k].val, sizeof(T) * (size_t)pieces[k].nnz,
+                                       hipMemcpyDeviceToDevice, b.cur);
+            }
+            at += (size_t)pieces[k].nnz;
+        }
+        if(e == hipSuccess)
+            e = hipStreamSynchronize(b.cur);
+        if(e != hipSuccess)
+            s = RAMD_ERR_HIP;
+    }
+    for(size_t k = 0; k < pieces.size(); ++k)
+    {
+        dev_free(&pieces[k].ci);
+        if(pieces[k].val)
+            (void)cached_free(pieces[k].val);
+    }
+    if(s != RAMD_OK)
+    {
         dev_free(&cnt);
         dev_free(&cci);
         if(cv)
             (void)cached_free(cv);
+        if(s == RAMD_ERR_UNSUPPORTED)
+            RAMD_FAIL(RAMD_ERR_UNSUPPORTED, "MatrixMult: result or a single row beyond the 32-bit index range");
         return s;
     }
     mat_free_csr(c);
@@ -813,96 +1043,13 @@ static int mat_mult_t(ramd_mat_s* c, const ramd_mat_s* a, const ramd_mat_s* bm)
             if(e != hipSuccess)
                 s = RAMD_ERR_HIP;
         }
-        static int use_lds = -1;
-        if(use_lds < 0)
-        {
-            const char* e2 = getenv("RAMD_MM_LDS");
-            use_lds        = e2 ? atoi(e2) : 1;
-        }
-        bool lds_done = false;
-        if(s == RAMD_OK && any && use_lds)
-        {
-            // medium rows: workgroup per row, sorted in LDS; a row beyond the cap sends the whole product to the global sort
-            s = dev_alloc(&pcol, total);
-            if(s == RAMD_OK && cached_malloc(&pval, (size_t)total * sizeof(T) + kPad) != hipSuccess)
-                s = RAMD_ERR_HIP;
-            int toolong = 0;
-            if(s == RAMD_OK)
-            {
-                hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), b.cur);
-                const int  g = (int)std::min<int64_t>((int64_t)n + 1, (int64_t)backend().num_cu * 8);
-                hipLaunchKernelGGL((k_mm_row_lds<T>), dim3(g), dim3(kBlock), 0, b.cur, n, a->rp, a->ci, (const T*)a->val,
-                                   bm->rp, bm->ci, (const T*)bm->val, off, pcol, (T*)pval, cnt, flag);
-                if(e == hipSuccess)
-                    e = hipMemcpyAsync(&toolong, flag, sizeof(int), hipMemcpyDeviceToHost, b.cur);
-                if(e == hipSuccess)
-                    e = hipStreamSynchronize(b.cur);
-                if(e != hipSuccess)
-                    s = RAMD_ERR_HIP;
-            }
-            if(s == RAMD_OK && !toolong)
-                lds_done = true;
-            else
-            {
-                dev_free(&pcol);
-                if(pval)
-                    (void)cached_free(pval);
-                pval = nullptr;
-            }
-        }
         dev_free(&flag);
-        if(s == RAMD_OK && any && !lds_done)
+        if(s == RAMD_OK && any)
         {
-            s = mat_mult_sorted_t<T>(c, a, bm, off, total);
+            s = mat_mult_chunked_t<T>(c, a, bm, off);
             dev_free(&off);
             dev_free(&cnt);
             return s;
-        }
-        if(lds_done)
-        {
-            int nnz2 = 0;
-            s        = scan_to_rowptr(cnt, n, &nnz2);
-            int*  cci2 = nullptr;
-            void* cv2  = nullptr;
-            if(s == RAMD_OK)
-                s = dev_alloc(&cci2, nnz2);
-            if(s == RAMD_OK && cached_malloc(&cv2, (size_t)nnz2 * sizeof(T) + kPad) != hipSuccess)
-                s = RAMD_ERR_HIP;
-            if(s == RAMD_OK)
-            {
-                hipLaunchKernelGGL((k_mm_compact<T>), dim3(ew_grid(std::max(n, 1))), dim3(kBlock), 0, b.cur, n, off, pcol,
-                                   (const T*)pval, cnt, cci2, (T*)cv2);
-                hipError_t e = hipGetLastError();
-                if(e == hipSuccess)
-                    e = hipStreamSynchronize(b.cur);
-                if(e != hipSuccess)
-                    s = RAMD_ERR_HIP;
-            }
-            dev_free(&off);
-            dev_free(&pcol);
-            if(pval)
-                (void)cached_free(pval);
-            if(s != RAMD_OK)
-            {
-                dev_free(&cnt);
-                dev_free(&cci2);
-                if(cv2)
-                    (void)cached_free(cv2);
-                return s;
-            }
-            mat_free_csr(c);
-            mat_free_ell(c);
-            mat_free_coo(c);
-            mat_free_dia(c);
-            mat_free_analysis(c);
-            c->format = RAMD_CSR;
-            c->nrow   = a->nrow;
-            c->ncol   = bm->ncol;
-            c->nnz    = nnz2;
-            c->rp     = cnt;
-            c->ci     = cci2;
-            c->val    = cv2;
-            return RAMD_OK;
         }
     }
     if(s == RAMD_OK)

@@ -194,7 +194,7 @@ def test_fsai_factor_vs_golden(ra):
         eq(rp, g["fsai_G_rowptr"]); eq(ci, g["fsai_G_col"]); eq(va, g["fsai_G_val"])
 
 
-@pytest.mark.parametrize("lds", ["1", "0"])
+@pytest.mark.parametrize("lds", ["1", "0", "0+chunks"])
 def test_matmult_long_row_paths_in_a_fresh_process(lds):
     """MatrixMult leaves the per-thread insertion when a row has many products: (lds=1) one workgroup per row sorts the
     products by (column, generation index) in LDS, (lds=0 / rows beyond 2048 products) two global stable sorts; both
@@ -203,7 +203,9 @@ def test_matmult_long_row_paths_in_a_fresh_process(lds):
     import os
     import subprocess
     import sys
-    env = dict(os.environ, RAMD_MM_INSERT_LIMIT="0", RAMD_MM_LDS=lds)
+    env = dict(os.environ, RAMD_MM_INSERT_LIMIT="0", RAMD_MM_LDS=lds[0])
+    if lds.endswith("chunks"):  # the global sort runs over row chunks of bounded product count: force many chunks
+        env["RAMD_MM_CHUNK"] = "700"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-q", "-x",
                         "-m", "gpu", "-k", "csr_matrix_algebra_vs_golden"], env=env, cwd=root, stdout=subprocess.PIPE,
