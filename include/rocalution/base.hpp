@@ -1224,6 +1224,22 @@ public:
         RAMD_CHECK(ramd_mat_amg_pmis_aggregate(this->dev_, (double)eps, connections->handle(), aggregates->handle(),
                                                aggregate_root_nodes->handle()));
     }
+    // ---- Ruge-Stueben AMG setup: PMIS C/F splitting and direct interpolation (int vectors instead of bool)
+    void RSPMISCoarsening(float eps, LocalVector<int>* CFmap, LocalVector<int>* S) const
+    {
+        this->need_accel_("RSPMISCoarsening");
+        assert(CFmap != NULL && S != NULL);
+        CFmap->MoveToAccelerator();
+        S->MoveToAccelerator();
+        RAMD_CHECK(ramd_mat_rs_pmis_coarsening(this->dev_, eps, CFmap->handle(), S->handle()));
+    }
+    void RSDirectInterpolation(const LocalVector<int>& CFmap, const LocalVector<int>& S, LocalMatrix<ValueType>* prolong) const
+    {
+        this->need_accel_("RSDirectInterpolation");
+        assert(prolong != NULL && prolong != this);
+        prolong->MoveToAccelerator();
+        RAMD_CHECK(ramd_mat_rs_direct_interpolation(this->dev_, CFmap.handle(), S.handle(), prolong->dev_));
+    }
     // the reference's default strategy: its sequential sweep restated as a sync-free device sweep with the same result;
     // needs a symmetric strong-connection graph
     void AMGGreedyAggregate(ValueType eps, LocalVector<int>* connections, LocalVector<int>* aggregates,

@@ -4675,4 +4675,94 @@ protected:
     LumpingStrategy    lumping_strat_;
 };
 
+typedef enum _interpolation_type
+{
+    Direct = 0,
+    ExtPI  = 1
+} InterpolationType;
+
+// RugeStuebenAMG (src/solvers/multigrid/ruge_stueben_amg.cpp): classical AMG.  Built here: PMIS C/F splitting with
+// direct interpolation; the sequential Greedy splitting (the reference's default) and Ext+i interpolation are not.
+template <class OperatorType, class VectorType, typename ValueType>
+class RugeStuebenAMG : public BaseAMG<OperatorType, VectorType, ValueType>
+{
+public:
+    RugeStuebenAMG()
+        : eps_(0.25f)
+        , FF1_(false)
+        , coarsening_(Greedy)
+        , interpolation_(Direct)
+    {
+        this->scaling_ = false;
+    }
+    virtual ~RugeStuebenAMG()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("AMG solver");
+        LOG_INFO("AMG number of levels " << this->levels_);
+        LOG_INFO("AMG Ruge-Stuben coarsening");
+    }
+    virtual void SetStrengthThreshold(float eps)
+    {
+        this->eps_ = eps;
+    }
+    virtual void SetCouplingStrength(ValueType eps) // older name of the same parameter
+    {
+        this->eps_ = (float)eps;
+    }
+    virtual void SetCoarseningStrategy(CoarseningStrategy strat)
+    {
+        this->coarsening_ = strat;
+    }
+    virtual void SetInterpolationType(InterpolationType type)
+    {
+        this->interpolation_ = type;
+    }
+    virtual void SetInterpolationFF1Limit(bool FF1)
+    {
+        this->FF1_ = FF1;
+    }
+
+protected:
+    virtual void PrintStart_(void) const
+    {
+        LOG_INFO("AMG solver starts");
+        LOG_INFO("AMG number of levels " << this->levels_);
+    }
+    virtual void PrintEnd_(void) const
+    {
+        LOG_INFO("AMG ends");
+    }
+    // ruge_stueben_amg.cpp:277-342
+    virtual bool Aggregate_(const OperatorType& op, OperatorType* pro, OperatorType* res, OperatorType* coarse)
+    {
+        assert(pro != NULL && res != NULL && coarse != NULL);
+        if(this->coarsening_ != PMIS || this->interpolation_ != Direct)
+        {
+            LOG_INFO("RugeStuebenAMG: this backend provides CoarseningStrategy PMIS with InterpolationType Direct "
+                     "(SetCoarseningStrategy(PMIS)); the sequential Greedy splitting and Ext+i interpolation are not built");
+            FATAL_ERROR(__FILE__, __LINE__);
+        }
+        LocalVector<int> CFmap, S;
+        op.RSPMISCoarsening(this->eps_, &CFmap, &S);
+        op.RSDirectInterpolation(CFmap, S, pro);
+        CFmap.Clear();
+        S.Clear();
+        if(pro->GetN() == 0)
+            return false;
+        pro->Transpose(res);
+        coarse->CloneBackend(op);
+        coarse->TripleMatrixProduct(*res, op, *pro);
+        return true;
+    }
+
+    float              eps_;
+    bool               FF1_;
+    CoarseningStrategy coarsening_;
+    InterpolationType  interpolation_;
+};
+
 } // namespace rocalution

@@ -288,6 +288,10 @@ int ramd_mat_extract_tri(ramd_mat_t m, ramd_mat_t out, int upper, int with_diag)
  * AMGUnsmoothedAggregation: P with one entry per aggregated row).  Int vectors (the reference: bool / int64_t). */
 int ramd_mat_amg_pmis_aggregate(ramd_mat_t m, double eps, ramd_vec_t connections, ramd_vec_t aggregates,
                                 ramd_vec_t aggregate_root_nodes);
+/* Ruge-Stueben AMG (local_matrix.cpp RSPMISCoarsening / RSDirectInterpolation): C/F splitting by PMIS (cfmap: 1 coarse,
+ * 2 fine; S: strong influences per entry) and direct interpolation */
+int ramd_mat_rs_pmis_coarsening(ramd_mat_t m, float eps, ramd_vec_t cfmap, ramd_vec_t S);
+int ramd_mat_rs_direct_interpolation(ramd_mat_t m, ramd_vec_t cfmap, ramd_vec_t S, ramd_mat_t prolong);
 /* AMGGreedyAggregate (local_matrix.cpp:6409-6517; host sweep host_matrix_csr.cpp:4841-4938), the reference's default
  * CoarseningStrategy: same aggregates as the sequential sweep; RAMD_ERR_UNSUPPORTED for a non-symmetric strength graph */
 int ramd_mat_amg_greedy_aggregate(ramd_mat_t m, double eps, ramd_vec_t connections, ramd_vec_t aggregates,

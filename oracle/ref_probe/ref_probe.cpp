@@ -1108,6 +1108,53 @@ static int cmd_gen(const std::string& in, const std::string& out)
                 mat.AMGSmoothedAggregation(0.5, conn, agg, roots, &Ps1, 1); // SubtractWeakConnections
                 dump_csr("amg_Ps1", Ps1);
             }
+            {
+                // classical (Ruge-Stueben) AMG: PMIS C/F splitting, direct interpolation
+                LocalVector<int>  cf;
+                LocalVector<bool> S;
+                mat.RSPMISCoarsening(0.25f, &cf, &S);
+                MatD Prs;
+                mat.RSDirectInterpolation(cf, S, &Prs);
+                std::vector<int32_t> hcf((size_t)A.n), hs((size_t)mat.GetNnz());
+                cf.CopyToHostData(hcf.data());
+                bool* tb = new bool[mat.GetNnz()];
+                S.CopyToHostData(tb);
+                for(size_t k = 0; k < hs.size(); ++k)
+                    hs[k] = tb[k] ? 1 : 0;
+                delete[] tb;
+                dump("rs_cf", hcf.data(), hcf.size());
+                dump("rs_S", hs.data(), hs.size());
+                dump_csr("rs_P", Prs);
+                for(int variant = 0; variant < 2; ++variant)
+                {
+                    RugeStuebenAMG<MatD, VecD, double>& amg = *new RugeStuebenAMG<MatD, VecD, double>;
+                    amg.SetOperator(mat);
+                    amg.SetCoarseningStrategy(PMIS);
+                    amg.SetCoarsestLevel(20);
+                    amg.Verbose(0);
+                    if(variant == 0)
+                    {
+                        amg.InitMaxIter(60);
+                        amg.Build();
+                        double lv = (double)amg.GetNumLevels();
+                        dump("rsamg_levels", &lv, 1);
+                        sol.Zeros();
+                        run_solver("rsamg_pmis", amg, rhs, sol);
+                        amg.Clear();
+                    }
+                    else
+                    {
+                        CG<MatD, VecD, double> ls;
+                        ls.SetOperator(mat);
+                        ls.SetPreconditioner(amg);
+                        ls.InitMaxIter(100);
+                        ls.Build();
+                        sol.Zeros();
+                        run_solver("cg_rsamg", ls, rhs, sol);
+                        ls.Clear();
+                    }
+                }
+            }
             for(int variant = 0; variant < 2; ++variant)
             {
                 SAAMG<MatD, VecD, double>& amg = *new SAAMG<MatD, VecD, double>;

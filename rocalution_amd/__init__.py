@@ -285,6 +285,15 @@ class LocalMatrix:
         capi.check(_lib().ramd_mat_amg_pmis_aggregate(self._h, float(eps), conn._h, agg._h, roots._h))
         return conn, agg, roots
 
+    def RSPMISCoarsening(self, eps):
+        """-> (CFmap, S) int LocalVectors: 1 coarse / 2 fine per row, strong influence flag per entry"""
+        cf, S = LocalVector(np.int32), LocalVector(np.int32)
+        capi.check(_lib().ramd_mat_rs_pmis_coarsening(self._h, C.c_float(eps), cf._h, S._h))
+        return cf, S
+
+    def RSDirectInterpolation(self, CFmap, S, prolong):
+        capi.check(_lib().ramd_mat_rs_direct_interpolation(self._h, CFmap._h, S._h, prolong._h))
+
     def AMGGreedyAggregate(self, eps):
         """-> (connections, aggregates, aggregate_root_nodes): the reference's sequential greedy sweep, same result"""
         conn, agg, roots = LocalVector(np.int32), LocalVector(np.int32), LocalVector(np.int32)

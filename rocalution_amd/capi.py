@@ -129,6 +129,8 @@ SIGNATURES = {
     "ramd_mat_it_u_analyse_clear": (i32, [mat_t]),
     "ramd_mat_it_u_solve": (i32, [mat_t, i32, f64, i32, vec_t, vec_t]),
     "ramd_mat_amg_pmis_aggregate": (i32, [mat_t, f64, vec_t, vec_t, vec_t]),
+    "ramd_mat_rs_pmis_coarsening": (i32, [mat_t, C.c_float, vec_t, vec_t]),
+    "ramd_mat_rs_direct_interpolation": (i32, [mat_t, vec_t, vec_t, mat_t]),
     "ramd_mat_amg_greedy_aggregate": (i32, [mat_t, f64, vec_t, vec_t, vec_t]),
     "ramd_mat_amg_unsmoothed_prolong": (i32, [mat_t, vec_t, vec_t, mat_t]),
     "ramd_mat_amg_smoothed_prolong": (i32, [mat_t, f64, i32, vec_t, vec_t, vec_t, mat_t]),

@@ -720,6 +720,384 @@ static int greedy_aggregate_t(ramd_mat_s* m, T eps, ramd_vec_s* vconn, ramd_vec_
     return RAMD_OK;
 }
 
+// ---- Ruge-Stueben AMG, PMIS coarsening + direct interpolation (host_matrix_csr.cpp: hash :7060-7071,
+// RSPMISStrongInfluences :7074-7209, RSPMISUnassignedToCoarse :7212-7259, RSPMISCorrectCoarse :7262-7381,
+// RSPMISCoarseEdgesToFine :7384-7459, RSPMISCheckUndecided :7462-7487, RSDirectProlongNnz :7501-7660,
+// RSDirectProlongFill :7678-7930; drivers local_matrix.cpp RSPMISCoarsening / RSDirectInterpolation).  Every step of
+// the reference is a row loop whose writes are idempotent (states only move one way inside a step), so each one is a
+// kernel; omega = hash + number of strong in-edges is accumulated with float atomics of +1.0f (all increments equal:
+// the sum does not depend on their order).
+__device__ __forceinline__ float rs_hash(unsigned long long key)
+{
+    key = (~key) + (key << 21);
+    key = key ^ (key >> 24);
+    key = (key + (key << 3)) + (key << 8);
+    key = key ^ (key >> 14);
+    key = (key + (key << 2)) + (key << 4);
+    key = key ^ (key >> 28);
+    key = key + (key << 31);
+    return (float)key / (float)0xffffffffffffffffULL;
+}
+__global__ __launch_bounds__(kBlock) void k_rs_omega_init(int nrow, float* __restrict__ omega, int* __restrict__ S,
+                                                          int64_t nnz)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz || i < nrow; i += gsz)
+    {
+        if(i < nrow)
+            omega[i] = rs_hash((unsigned long long)i);
+        if(i < nnz)
+            S[i] = 0;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_rs_strong(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                      const T* __restrict__ val, float eps, int* __restrict__ S,
+                                                      float* omega)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+    {
+        T    mn = (T)0, mx = (T)0;
+        bool sign = false;
+        for(int j = rp[i]; j < rp[i + 1]; ++j)
+        {
+            const T v = val[j];
+            if(ci[j] == (int)i)
+                sign = v < (T)0;
+            else
+            {
+                mn = (mn < v) ? mn : v;
+                mx = (mx > v) ? mx : v;
+            }
+        }
+        const T cond = (sign ? mx : mn) * (T)eps;
+        for(int j = rp[i]; j < rp[i + 1]; ++j)
+            if(ci[j] != (int)i && val[j] < cond)
+            {
+                S[j] = 1;
+                atomicAdd(omega + ci[j], 1.0f);
+            }
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_rs_unassigned_to_coarse(int nrow, int* __restrict__ cf,
+                                                                    int* __restrict__ marked,
+                                                                    const float* __restrict__ omega)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+    {
+        int m = 0;
+        if(cf[i] == 0)
+        {
+            if(omega[i] >= 1.0f)
+            {
+                cf[i] = 1;
+                m     = 1;
+            }
+            else
+                cf[i] = 2;
+        }
+        marked[i] = m;
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_rs_correct_coarse(int nrow, const int* __restrict__ rp,
+                                                              const int* __restrict__ ci, const int* __restrict__ S,
+                                                              const int* __restrict__ marked,
+                                                              const float* __restrict__ omega, int* cf)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+        if(marked[i])
+        {
+            const float wr = omega[i];
+            for(int j = rp[i]; j < rp[i + 1]; ++j)
+                if(S[j])
+                {
+                    const int c = ci[j];
+                    if(marked[c])
+                    {
+                        const float wc = omega[c];
+                        if(wr > wc)
+                            cf[c] = 0; // only zeros are written in this step: the order of the rows does not matter
+                        else if(wr < wc)
+                            cf[i] = 0;
+                    }
+                }
+        }
+}
+__global__ __launch_bounds__(kBlock) void k_rs_coarse_edges_to_fine(int nrow, const int* __restrict__ rp,
+                                                                    const int* __restrict__ ci,
+                                                                    const int* __restrict__ S, int* cf)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+        if(cf[i] == 0)
+            for(int j = rp[i]; j < rp[i + 1]; ++j)
+                if(S[j] && cf[ci[j]] == 1) // (rows turn 0 -> 2 concurrently: the test for 1 is not affected)
+                {
+                    cf[i] = 2;
+                    break;
+                }
+}
+__global__ __launch_bounds__(kBlock) void k_rs_any_undecided(int nrow, const int* __restrict__ cf, int* __restrict__ flag)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+        if(cf[i] == 0)
+            *flag = 1;
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_rs_direct_nnz(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                          const T* __restrict__ val, const int* __restrict__ cf,
+                                                          const int* __restrict__ S, T* __restrict__ Amin,
+                                                          T* __restrict__ Amax, int* __restrict__ f2c,
+                                                          int* __restrict__ prp)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row <= nrow; row += gsz)
+    {
+        if(row == nrow)
+        {
+            f2c[row] = 0;
+            prp[row] = 0;
+            continue;
+        }
+        if(cf[row] == 1)
+        {
+            f2c[row] = 1;
+            prp[row] = 1;
+            continue;
+        }
+        f2c[row] = 0;
+        T amin = (T)0, amax = (T)0;
+        for(int j = rp[row]; j < rp[row + 1]; ++j)
+        {
+            if(!S[j] || cf[ci[j]] != 1)
+                continue;
+            amin = (amin < val[j]) ? amin : val[j];
+            amax = (amax > val[j]) ? amax : val[j];
+        }
+        Amin[row] = amin = amin * (T)0.2f;
+        Amax[row] = amax = amax * (T)0.2f;
+        int nnz = 0;
+        for(int j = rp[row]; j < rp[row + 1]; ++j)
+            if(S[j] && cf[ci[j]] == 1)
+                if(val[j] <= amin || val[j] >= amax)
+                    ++nnz;
+        prp[row] = nnz;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_rs_direct_fill(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                           const T* __restrict__ val, const int* __restrict__ cf,
+                                                           const int* __restrict__ S, const T* __restrict__ Amin,
+                                                           const T* __restrict__ Amax, const int* __restrict__ f2c,
+                                                           const int* __restrict__ prp, int* __restrict__ pci,
+                                                           T* __restrict__ pval)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < nrow; row += gsz)
+    {
+        int row_P = prp[row];
+        if(cf[row] == 1)
+        {
+            pci[row_P]  = f2c[row];
+            pval[row_P] = (T)1;
+            continue;
+        }
+        T diag = (T)0, a_num = (T)0, a_den = (T)0, b_num = (T)0, b_den = (T)0, d_neg = (T)0, d_pos = (T)0;
+        const T amin = Amin[row], amax = Amax[row];
+        for(int j = rp[row]; j < rp[row + 1]; ++j)
+        {
+            const int c = ci[j];
+            const T   v = val[j];
+            if(c == (int)row)
+            {
+                diag = v;
+                continue;
+            }
+            if(v < (T)0)
+            {
+                a_num += v;
+                if(S[j] && cf[c] == 1)
+                {
+                    a_den += v;
+                    if(v > amin)
+                        d_neg += v;
+                }
+            }
+            else
+            {
+                b_num += v;
+                if(S[j] && cf[c] == 1)
+                {
+                    b_den += v;
+                    if(v < amax)
+                        d_pos += v;
+                }
+            }
+        }
+        T cf_neg = (T)1, cf_pos = (T)1;
+        {
+            const T t1 = a_den - d_neg, t2 = b_den - d_pos;
+            if((t1 < (T)0 ? -t1 : t1) > 1e-32)
+                cf_neg = a_den / t1;
+            if((t2 < (T)0 ? -t2 : t2) > 1e-32)
+                cf_pos = b_den / t2;
+        }
+        if(b_num > (T)0 && (b_den < (T)0 ? -b_den : b_den) < 1e-32)
+            diag += b_num;
+        const T alpha = ((a_den < (T)0 ? -a_den : a_den) > 1e-32) ? -cf_neg * a_num / (diag * a_den) : (T)0;
+        const T beta  = ((b_den < (T)0 ? -b_den : b_den) > 1e-32) ? -cf_pos * b_num / (diag * b_den) : (T)0;
+        for(int j = rp[row]; j < rp[row + 1]; ++j)
+        {
+            const int c = ci[j];
+            const T   v = val[j];
+            if(S[j] && cf[c] == 1)
+            {
+                if(v > amin && v < amax)
+                    continue;
+                pci[row_P]  = f2c[c];
+                pval[row_P] = (v < (T)0 ? alpha : beta) * v;
+                ++row_P;
+            }
+        }
+    }
+}
+
+template <typename T>
+static int rs_pmis_t(ramd_mat_s* m, float eps, ramd_vec_s* vcf, ramd_vec_s* vS)
+{
+    Backend&  b    = backend();
+    const int n    = m->nrow;
+    const int grid = ew_grid(std::max(n, 1));
+    RAMD_TRY(ramd_vec_allocate(vS, m->nnz));
+    RAMD_TRY(ramd_vec_allocate(vcf, n)); // CFmap->Zeros()
+    int*   S      = (int*)vS->d;
+    int*   cf     = (int*)vcf->d;
+    float* omega  = nullptr;
+    int *  marked = nullptr, *flag = nullptr;
+    int    s      = dev_alloc(&omega, n);
+    if(s == RAMD_OK)
+        s = dev_alloc(&marked, n);
+    if(s == RAMD_OK)
+        s = dev_alloc(&flag, 1);
+    hipError_t e = hipSuccess;
+    if(s == RAMD_OK)
+    {
+        hipLaunchKernelGGL(k_rs_omega_init, dim3(ew_grid(std::max<int64_t>(m->nnz, n))), dim3(kBlock), 0, b.cur, n, omega, S,
+                           m->nnz);
+        hipLaunchKernelGGL((k_rs_strong<T>), dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const T*)m->val, eps, S,
+                           omega);
+        for(int iter = 0; e == hipSuccess; ++iter)
+        {
+            hipLaunchKernelGGL(k_rs_unassigned_to_coarse, dim3(grid), dim3(kBlock), 0, b.cur, n, cf, marked,
+                               (const float*)omega);
+            hipLaunchKernelGGL(k_rs_correct_coarse, dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const int*)S,
+                               (const int*)marked, (const float*)omega, cf);
+            hipLaunchKernelGGL(k_rs_coarse_edges_to_fine, dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, m->ci,
+                               (const int*)S, cf);
+            e = hipMemsetAsync(flag, 0, sizeof(int), b.cur);
+            hipLaunchKernelGGL(k_rs_any_undecided, dim3(grid), dim3(kBlock), 0, b.cur, n, (const int*)cf, flag);
+            int undecided = 0;
+            if(e == hipSuccess)
+                e = hipMemcpyAsync(&undecided, flag, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+            if(e == hipSuccess)
+                e = hipStreamSynchronize(b.cur);
+            if(!undecided)
+                break;
+            if(iter > 10000)
+            {
+                s = RAMD_ERR_STATE;
+                break;
+            }
+        }
+        if(e == hipSuccess)
+            e = hipGetLastError();
+    }
+    dev_free(&omega);
+    dev_free(&marked);
+    dev_free(&flag);
+    RAMD_TRY(s);
+    RAMD_HIP(e);
+    return RAMD_OK;
+}
+
+template <typename T>
+static int rs_direct_t(const ramd_mat_s* m, const ramd_vec_s* vcf, const ramd_vec_s* vS, ramd_mat_s* p)
+{
+    Backend&   b  = backend();
+    const int  n  = m->nrow;
+    const int* cf = (const int*)vcf->d;
+    const int* S  = (const int*)vS->d;
+    T *        Amin = nullptr, *Amax = nullptr;
+    int *      f2c = nullptr, *prp = nullptr;
+    int        s = dev_alloc(&Amin, n);
+    if(s == RAMD_OK)
+        s = dev_alloc(&Amax, n);
+    if(s == RAMD_OK)
+        s = dev_alloc(&f2c, (int64_t)n + 1);
+    if(s == RAMD_OK)
+        s = dev_alloc(&prp, (int64_t)n + 1);
+    int        tot[2] = {0, 0};
+    int*       pci    = nullptr;
+    void*      pv     = nullptr;
+    hipError_t e      = hipSuccess;
+    if(s == RAMD_OK)
+    {
+        hipLaunchKernelGGL((k_rs_direct_nnz<T>), dim3(ew_grid((int64_t)n + 1)), dim3(kBlock), 0, b.cur, n, m->rp, m->ci,
+                           (const T*)m->val, cf, S, Amin, Amax, f2c, prp);
+        s = device_exclusive_scan(f2c, f2c, (int64_t)n + 1);
+        if(s == RAMD_OK)
+            s = device_exclusive_scan(prp, prp, (int64_t)n + 1);
+        if(s == RAMD_OK)
+            e = hipMemcpyAsync(&tot[0], prp + n, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+        if(s == RAMD_OK && e == hipSuccess)
+            e = hipMemcpyAsync(&tot[1], f2c + n, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+        if(s == RAMD_OK && e == hipSuccess)
+            e = hipStreamSynchronize(b.cur);
+    }
+    if(s == RAMD_OK && e == hipSuccess)
+        s = dev_alloc(&pci, tot[0]);
+    if(s == RAMD_OK && e == hipSuccess && cached_malloc(&pv, (size_t)tot[0] * sizeof(T) + kPad) != hipSuccess)
+        s = RAMD_ERR_HIP;
+    if(s == RAMD_OK && e == hipSuccess)
+    {
+        hipLaunchKernelGGL((k_rs_direct_fill<T>), dim3(ew_grid(std::max(n, 1))), dim3(kBlock), 0, b.cur, n, m->rp, m->ci,
+                           (const T*)m->val, cf, S, (const T*)Amin, (const T*)Amax, (const int*)f2c, (const int*)prp, pci,
+                           (T*)pv);
+        e = hipGetLastError();
+        if(e == hipSuccess)
+            e = hipStreamSynchronize(b.cur);
+    }
+    dev_free(&Amin);
+    dev_free(&Amax);
+    dev_free(&f2c);
+    if(s != RAMD_OK || e != hipSuccess)
+    {
+        dev_free(&prp);
+        dev_free(&pci);
+        if(pv)
+            (void)cached_free(pv);
+        RAMD_TRY(s);
+        RAMD_HIP(e);
+    }
+    mat_free_csr(p);
+    mat_free_ell(p);
+    mat_free_coo(p);
+    mat_free_dia(p);
+    mat_free_analysis(p);
+    p->format = RAMD_CSR;
+    p->nrow   = n;
+    p->ncol   = tot[1];
+    p->nnz    = tot[0];
+    p->rp     = prp;
+    p->ci     = pci;
+    p->val    = pv;
+    return RAMD_OK;
+}
+
 template <typename T>
 static int ua_prolong_t(const ramd_mat_s* m, const ramd_vec_s* vagg, const ramd_vec_s* vroots, ramd_mat_s* p)
 {
@@ -826,6 +1204,33 @@ int ramd_mat_amg_greedy_aggregate(ramd_mat_t m, double eps, ramd_vec_t connectio
     if(m->dtype == RAMD_F64)
         return greedy_aggregate_t<double>(m, eps, connections, aggregates, aggregate_root_nodes);
     return greedy_aggregate_t<float>(m, (float)eps, connections, aggregates, aggregate_root_nodes);
+}
+
+int ramd_mat_rs_pmis_coarsening(ramd_mat_t m, float eps, ramd_vec_t cfmap, ramd_vec_t S)
+{
+    if(!m || !cfmap || !S)
+        RAMD_FAIL(RAMD_ERR_ARG, "null handle");
+    if(m->format != RAMD_CSR)
+        return RAMD_ERR_UNSUPPORTED;
+    if(cfmap->dtype != RAMD_I32 || S->dtype != RAMD_I32 || m->nrow != m->ncol)
+        RAMD_FAIL(RAMD_ERR_ARG, "RSPMISCoarsening: square matrix and int vectors expected");
+    if(m->nnz <= 0)
+        return RAMD_OK;
+    return (m->dtype == RAMD_F64) ? rs_pmis_t<double>(m, eps, cfmap, S) : rs_pmis_t<float>(m, eps, cfmap, S);
+}
+
+int ramd_mat_rs_direct_interpolation(ramd_mat_t m, ramd_vec_t cfmap, ramd_vec_t S, ramd_mat_t prolong)
+{
+    if(!m || !cfmap || !S || !prolong || prolong == m)
+        RAMD_FAIL(RAMD_ERR_ARG, "null handle / prolong aliases the operator");
+    if(m->format != RAMD_CSR)
+        return RAMD_ERR_UNSUPPORTED;
+    if(cfmap->dtype != RAMD_I32 || S->dtype != RAMD_I32 || cfmap->n != m->nrow || S->n != m->nnz
+       || prolong->dtype != m->dtype)
+        RAMD_FAIL(RAMD_ERR_ARG, "RSDirectInterpolation: int vectors of the operator's sizes, P of its value type");
+    if(m->nnz <= 0)
+        return RAMD_OK;
+    return (m->dtype == RAMD_F64) ? rs_direct_t<double>(m, cfmap, S, prolong) : rs_direct_t<float>(m, cfmap, S, prolong);
 }
 
 int ramd_mat_amg_smoothed_prolong(ramd_mat_t m, double relax, int lumping_strat, ramd_vec_t connections,

@@ -230,6 +230,13 @@ def test_amg_pmis_aggregation_vs_golden(ra, name):
     # the default strategy: the reference's sequential greedy sweep, restated as a sync-free device sweep
     gconn, gagg, groots = A.AMGGreedyAggregate(0.01)
     eq(gconn.numpy(), g["amg_conn"]); eq(gagg.numpy(), g["amg_gagg"]); eq(groots.numpy(), g["amg_groots"])
+    # classical AMG: PMIS C/F splitting (hash + strong in-degree weights) and direct interpolation
+    cf, S_ = A.RSPMISCoarsening(0.25)
+    eq(cf.numpy(), g["rs_cf"]); eq(S_.numpy(), g["rs_S"])
+    Prs = ra.LocalMatrix()
+    A.RSDirectInterpolation(cf, S_, Prs)
+    rp, ci, va = Prs.CopyToCSR()
+    eq(rp, g["rs_P_rowptr"]); eq(ci, g["rs_P_col"]); eq(va, g["rs_P_val"])
     # smoothed aggregation: (I - relax D_f^-1 A_f) P_tent, both lumping strategies
     for key, relax, lump in (("amg_Ps", 2.0 / 3.0, 0), ("amg_Ps1", 0.5, 1)):
         Ps = ra.LocalMatrix()

@@ -533,13 +533,14 @@ def test_cpp_uaamg_driver_vs_reference(tmp_path, name):
     rp, ci, va, _ = _inputs(name, g)
     _write_mtx(mtx, rp, ci, va)
     for variant, tag in (("a", "uaamg_pmis"), ("c", "cg_uaamg"), ("s", "saamg_pmis"), ("d", "cg_saamg"),
-                         ("g", "cg_uaamg_greedy"), ("h", "cg_saamg_greedy")):
+                         ("g", "cg_uaamg_greedy"), ("h", "cg_saamg_greedy"), ("r", "rsamg_pmis"), ("q", "cg_rsamg")):
         r = subprocess.run([exe, mtx, variant], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
         out = r.stdout.decode()
         assert r.returncode == 0, out[-2000:]
         m = re.search(r"RESULT .*coarse_n=(\d+) coarse_nnz=(\d+) iters=(\d+) status=(\d+) residual=(\S+) error=(\S+)", out)
         assert m, out[-2000:]
-        lv = ("saamg" if "saamg" in tag else "uaamg") + ("_greedy" if "greedy" in tag else "") + "_levels"
+        lv = ("rsamg" if "rsamg" in tag else "saamg" if "saamg" in tag else "uaamg") + \
+             ("_greedy" if "greedy" in tag else "") + "_levels"
         if lv in g:
             assert int(m.group(1)) == int(g[lv][0])
         meta = g[tag + "_meta"]
