@@ -373,7 +373,8 @@ enum { RAMD_PC_NONE = 0, RAMD_PC_JACOBI = 1, RAMD_PC_ILU0 = 2, RAMD_PC_MCSGS = 3
        /* unsmoothed_amg.cpp / smoothed_amg.cpp with CoarseningStrategy PMIS, default smoothers and coarse solver */
        RAMD_PC_UAAMG = 9, RAMD_PC_SAAMG = 10,
        /* preconditioner_ai.cpp: AIChebyshev :41-215 (params p, lambda_min, lambda_max), TNS :477-713 (param implicit) */
-       RAMD_PC_AICHEBYSHEV = 11, RAMD_PC_TNS = 12, RAMD_PC_FSAI = 13 /* :217-361 */ };
+       RAMD_PC_AICHEBYSHEV = 11, RAMD_PC_TNS = 12, RAMD_PC_FSAI = 13, /* :217-361 */
+       RAMD_PC_ITILU0 = 14 /* preconditioner.cpp:520-700; factors = exact ILU(0) as on the reference's host backend */ };
 int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out);
 /* MixedPrecisionDC<fp64 outer, fp32 inner>: inner solver/preconditioner kinds */
 int ramd_solver_create_mixed(int inner_solver, int inner_precond, ramd_solver_t* out);

@@ -16,7 +16,7 @@ OK, ERR_HIP, ERR_ARG, ERR_UNSUPPORTED, ERR_REFUSED, ERR_NO_DEVICE, ERR_STATE = r
 SOLVER_CG, SOLVER_GMRES, SOLVER_BICGSTAB = 0, 1, 2
 SOLVER_FCG, SOLVER_CR, SOLVER_FGMRES, SOLVER_BICGSTABL, SOLVER_QMRCGSTAB, SOLVER_IDR = 3, 4, 5, 6, 7, 8
 SOLVER_FIXEDPOINT, SOLVER_CHEBYSHEV = 9, 10
-PC_NONE, PC_JACOBI, PC_ILU0, PC_MCSGS, PC_MCGS, PC_MCILU, PC_GS, PC_SGS, PC_IC, PC_UAAMG, PC_SAAMG, PC_AICHEBYSHEV, PC_TNS, PC_FSAI = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13
+PC_NONE, PC_JACOBI, PC_ILU0, PC_MCSGS, PC_MCGS, PC_MCILU, PC_GS, PC_SGS, PC_IC, PC_UAAMG, PC_SAAMG, PC_AICHEBYSHEV, PC_TNS, PC_FSAI, PC_ITILU0 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14
 F64, F32, I32 = 0, 1, 2
 CSR, COO, DIA, ELL, HYB = 1, 4, 5, 6, 7
 

@@ -66,6 +66,7 @@ struct Precs
     AIChebyshev<M, V, T>     aicheb;
     TNS<M, V, T>             tns;
     FSAI<M, V, T>            fsai;
+    ItILU0<M, V, T>          itilu0;
     Precs()
     {
         // the aggregation runs on the device with the PMIS strategy (the Greedy default is a sequential host sweep)
@@ -84,6 +85,8 @@ struct Precs
             return &tns;
         case RAMD_PC_FSAI:
             return &fsai;
+        case RAMD_PC_ITILU0:
+            return &itilu0;
         case RAMD_PC_UAAMG:
             return &uaamg;
         case RAMD_PC_SAAMG:
@@ -492,7 +495,7 @@ extern "C" {
 
 int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out)
 {
-    if(!out || solver < 0 || solver > RAMD_SOLVER_CHEBYSHEV || precond < 0 || precond > RAMD_PC_FSAI
+    if(!out || solver < 0 || solver > RAMD_SOLVER_CHEBYSHEV || precond < 0 || precond > RAMD_PC_ITILU0
        || (dtype != RAMD_F64 && dtype != RAMD_F32))
         return RAMD_ERR_ARG;
     GUARD_BEGIN
@@ -507,7 +510,7 @@ int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out)
 
 int ramd_solver_create_mixed(int inner_solver, int inner_precond, ramd_solver_t* out)
 {
-    if(!out || inner_solver < 0 || inner_solver > 2 || inner_precond < 0 || inner_precond > RAMD_PC_FSAI)
+    if(!out || inner_solver < 0 || inner_solver > 2 || inner_precond < 0 || inner_precond > RAMD_PC_ITILU0)
         return RAMD_ERR_ARG;
     GUARD_BEGIN
     ramd_solver_s* s = new ramd_solver_s;

@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import capi
-from .capi import (PC_AICHEBYSHEV, PC_FSAI, PC_GS, PC_IC, PC_ILU0, PC_SAAMG, PC_TNS, PC_UAAMG, PC_JACOBI, PC_MCGS, PC_MCILU, PC_MCSGS, PC_NONE, PC_SGS, SOLVER_BICGSTAB,
+from .capi import (PC_AICHEBYSHEV, PC_FSAI, PC_GS, PC_ITILU0, PC_IC, PC_ILU0, PC_SAAMG, PC_TNS, PC_UAAMG, PC_JACOBI, PC_MCGS, PC_MCILU, PC_MCSGS, PC_NONE, PC_SGS, SOLVER_BICGSTAB,
                    SOLVER_BICGSTABL,
                    SOLVER_CG, SOLVER_CHEBYSHEV, SOLVER_CR, SOLVER_FCG, SOLVER_FGMRES, SOLVER_FIXEDPOINT, SOLVER_GMRES,
                    SOLVER_IDR, SOLVER_QMRCGSTAB)
@@ -93,6 +93,24 @@ class AIChebyshev(_Precond):
 
     def Set(self, p, lambda_min, lambda_max):
         self.params = (float(p), float(lambda_min), float(lambda_max))
+
+
+class ItILU0(_Precond):
+    """ItILU0 (preconditioner.cpp:520-700): ILU(0) factors computed exactly (as the reference's host backend does), triangular
+    solves per SolverDescr; the sweep parameters of the HIP backend's iterative factorisation are accepted and unused"""
+    kind = PC_ITILU0
+
+    def SetTolerance(self, tol):
+        pass
+
+    def SetMaxIter(self, n):
+        pass
+
+    def SetOptions(self, opt):
+        pass
+
+    def SetAlgorithm(self, alg):
+        pass
 
 
 class FSAI(_Precond):

@@ -150,6 +150,25 @@ def test_iterative_triangular_solves_bit_exact(ra, S, name):
         ls.Clear()
 
 
+@pytest.mark.parametrize("name", PC_CASES)
+def test_itilu0_preconditioner(ra, S, name):
+    """ItILU0 with direct and with iterative triangular solves: the applies of ILU(0) (what the reference's host backend
+    computes for ItILU0: its iterative factorisation falls back to the exact one there)"""
+    g = load_golden(name)
+    A = ra.LocalMatrix(); A.SetDataPtrCSR(g["rowptr"], g["col"], g["val"])
+    n = A.GetM()
+    x = ra.LocalVector(data=g["x"])
+    for key, descr in (("pc_ilu0", None), ("pc_itilu0", (30, 1e-3, True))):
+        pc = S.ItILU0(); pc.SetTolerance(1e-8); pc.SetMaxIter(50)
+        if descr:
+            pc.SetSolverDescriptor(_descr(S, *descr))
+        ls = S.CG(); ls.SetOperator(A); ls.SetPreconditioner(pc); ls.Build()
+        z = ra.LocalVector(); z.Allocate("", n)
+        ls.PrecondApply(x, z)
+        eq(z.numpy(), g[key])
+        ls.Clear()
+
+
 @pytest.mark.parametrize("name", SOLVER_CASES_IT)
 @pytest.mark.parametrize("tag", ["gmres_itilu0", "cg_itic"])
 def test_solvers_with_iterative_triangular_solves(ra, S, name, tag):
