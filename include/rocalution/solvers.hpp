@@ -627,6 +627,214 @@ private:
     VectorType   inv_diag_entries_;
 };
 
+// ---- BlockPreconditioner (preconditioner_blockprecond.cpp): the operator cut into n x n blocks (optionally after a
+// permutation); block-diagonal solve or block forward substitution (default) with one caller-supplied solver per
+// diagonal block
+template <class OperatorType, class VectorType, typename ValueType>
+class BlockPreconditioner : public Preconditioner<OperatorType, VectorType, ValueType>
+{
+public:
+    BlockPreconditioner()
+        : num_blocks_(0)
+        , block_sizes_(NULL)
+        , diag_solve_(false)
+        , A_last_(NULL)
+        , A_block_(NULL)
+        , x_block_(NULL)
+        , tmp_block_(NULL)
+        , D_solver_(NULL)
+    {
+    }
+    virtual ~BlockPreconditioner()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("BlockPreconditioner with " << this->num_blocks_ << " blocks");
+    }
+    virtual void Set(int n, const int* size, Solver<OperatorType, VectorType, ValueType>** D_solver)
+    {
+        assert(this->build_ == false && n > 0 && size != NULL && D_solver != NULL);
+        delete[] this->block_sizes_;
+        delete[] this->D_solver_;
+        this->num_blocks_  = n;
+        this->block_sizes_ = new int[n];
+        this->D_solver_    = new Solver<OperatorType, VectorType, ValueType>*[n];
+        for(int i = 0; i < n; ++i)
+        {
+            this->block_sizes_[i] = size[i];
+            this->D_solver_[i]    = D_solver[i];
+        }
+    }
+    virtual void SetDiagonalSolver(void)
+    {
+        this->diag_solve_ = true;
+    }
+    virtual void SetLSolver(void)
+    {
+        this->diag_solve_ = false;
+    }
+    virtual void SetExternalLastMatrix(const OperatorType& mat)
+    {
+        this->A_last_ = new OperatorType;
+        this->A_last_->CloneFrom(mat);
+    }
+    virtual void SetPermutation(const LocalVector<int>& perm)
+    {
+        this->permutation_.CopyFrom(perm);
+    }
+    // preconditioner_blockprecond.cpp:157-262
+    virtual void Build(void)
+    {
+        if(this->build_)
+            this->Clear();
+        assert(this->op_ != NULL && this->num_blocks_ > 0);
+        this->build_     = true;
+        const int nb     = this->num_blocks_;
+        this->x_block_   = new VectorType*[nb];
+        this->tmp_block_ = new VectorType*[nb];
+        std::vector<int> offsets((size_t)nb + 1, 0);
+        for(int i = 0; i < nb; ++i)
+        {
+            this->x_block_[i] = new VectorType;
+            this->x_block_[i]->CloneBackend(*this->op_);
+            this->x_block_[i]->Allocate("Diagonal preconditioners", this->block_sizes_[i]);
+            this->tmp_block_[i] = new VectorType;
+            this->tmp_block_[i]->CloneBackend(*this->op_);
+            this->tmp_block_[i]->Allocate("Diagonal preconditioners", this->block_sizes_[i]);
+            offsets[(size_t)i + 1] = offsets[(size_t)i] + this->block_sizes_[i];
+        }
+        this->A_block_ = new OperatorType**[nb];
+        for(int k = 0; k < nb; ++k)
+        {
+            this->A_block_[k] = new OperatorType*[nb];
+            for(int j = 0; j < nb; ++j)
+            {
+                this->A_block_[k][j] = new OperatorType;
+                this->A_block_[k][j]->CloneBackend(*this->op_);
+            }
+        }
+        if(this->permutation_.GetSize() > 0)
+        {
+            this->permutation_.CloneBackend(*this->op_);
+            OperatorType perm_op;
+            perm_op.CloneFrom(*this->op_);
+            perm_op.Permute(this->permutation_);
+            perm_op.ExtractSubMatrices(nb, nb, offsets.data(), offsets.data(), this->A_block_);
+            this->x_.CloneBackend(*this->op_);
+            this->x_.Allocate("x (not permuted)", this->op_->GetM());
+        }
+        else
+            this->op_->ExtractSubMatrices(nb, nb, offsets.data(), offsets.data(), this->A_block_);
+        if(this->A_last_ != NULL)
+        {
+            assert(this->A_block_[nb - 1][nb - 1]->GetM() == this->A_last_->GetM());
+            delete this->A_block_[nb - 1][nb - 1];
+            this->A_block_[nb - 1][nb - 1] = this->A_last_;
+            this->A_last_                  = NULL;
+        }
+        for(int i = 0; i < nb; ++i)
+        {
+            this->D_solver_[i]->SetOperator(*this->A_block_[i][i]);
+            this->D_solver_[i]->Build();
+        }
+        for(int i = 0; i < nb; ++i)
+        {
+            for(int j = i + 1; j < nb; ++j)
+                this->A_block_[i][j]->Clear();
+            if(this->diag_solve_)
+                for(int j = 0; j < i; ++j)
+                    this->A_block_[i][j]->Clear();
+        }
+    }
+    virtual void Clear(void)
+    {
+        if(this->build_)
+        {
+            for(int i = 0; i < this->num_blocks_; ++i)
+            {
+                delete this->x_block_[i];
+                delete this->tmp_block_[i];
+                if(this->D_solver_[i] != NULL)
+                {
+                    this->D_solver_[i]->Clear();
+                    this->D_solver_[i] = NULL;
+                }
+                for(int j = 0; j < this->num_blocks_; ++j)
+                    delete this->A_block_[i][j];
+                delete[] this->A_block_[i];
+            }
+            delete[] this->x_block_;
+            delete[] this->tmp_block_;
+            delete[] this->A_block_;
+            this->x_block_ = this->tmp_block_ = NULL;
+            this->A_block_                    = NULL;
+            this->permutation_.Clear();
+            this->x_.Clear();
+            this->build_ = false;
+        }
+        delete[] this->D_solver_;
+        delete[] this->block_sizes_;
+        this->D_solver_    = NULL;
+        this->block_sizes_ = NULL;
+        this->num_blocks_  = 0;
+    }
+    // preconditioner_blockprecond.cpp:265-340
+    virtual void Solve(const VectorType& rhs, VectorType* x)
+    {
+        assert(this->build_ == true && x != NULL && x != &rhs);
+        const bool permuted = this->permutation_.GetSize() > 0;
+        if(permuted)
+            this->x_.CopyFromPermute(rhs, this->permutation_);
+        else
+            x->CopyFrom(rhs);
+        const VectorType& src = permuted ? this->x_ : *x;
+        int               off = 0;
+        for(int i = 0; i < this->num_blocks_; ++i)
+        {
+            this->x_block_[i]->CopyFrom(src, off, 0, this->block_sizes_[i]);
+            off += this->block_sizes_[i];
+        }
+        for(int i = 0; i < this->num_blocks_; ++i)
+        {
+            if(this->diag_solve_ == false)
+                for(int j = 0; j < i; ++j)
+                    this->A_block_[i][j]->ApplyAdd(*this->x_block_[j], static_cast<ValueType>(-1), this->x_block_[i]);
+            this->D_solver_[i]->SolveZeroSol(*this->x_block_[i], this->tmp_block_[i]);
+            this->x_block_[i]->CopyFrom(*this->tmp_block_[i]);
+        }
+        VectorType* dst = permuted ? &this->x_ : x;
+        off             = 0;
+        for(int i = 0; i < this->num_blocks_; ++i)
+        {
+            dst->CopyFrom(*this->x_block_[i], 0, off, this->block_sizes_[i]);
+            off += this->block_sizes_[i];
+        }
+        if(permuted)
+            x->CopyFromPermuteBackward(this->x_, this->permutation_);
+    }
+    virtual bool SolveUsesScalarRecord(void) const
+    {
+        for(int i = 0; i < this->num_blocks_; ++i)
+            if(this->D_solver_ != NULL && this->D_solver_[i] != NULL && this->D_solver_[i]->SolveUsesScalarRecord())
+                return true;
+        return false;
+    }
+
+private:
+    int             num_blocks_;
+    int*            block_sizes_;
+    bool            diag_solve_;
+    OperatorType*   A_last_;
+    OperatorType*** A_block_;
+    VectorType**    x_block_;
+    VectorType**    tmp_block_;
+    VectorType      x_;
+    LocalVector<int> permutation_;
+    Solver<OperatorType, VectorType, ValueType>** D_solver_;
+};
+
 // ---- AS / RAS (preconditioner_as.cpp): (restricted) additive Schwarz over nb contiguous row blocks with `overlap`
 // rows on each side; the local operators come from ExtractSubMatrix, the local solvers from the caller
 template <class OperatorType, class VectorType, typename ValueType>

@@ -831,6 +831,27 @@ static int cmd_gen(const std::string& in, const std::string& out)
         }
         for(int variant = 0; variant < 2; ++variant)
         {
+            // block preconditioner: 3 row blocks (n/3, n/3, rest), ILU(0) per diagonal block; block forward substitution
+            // (variant 0) or block-diagonal solve (variant 1)
+            GMRES<MatD, VecD, double>               ls;
+            BlockPreconditioner<MatD, VecD, double> bp;
+            ILU<MatD, VecD, double>                 loc[3];
+            Solver<MatD, VecD, double>*             list[3] = {&loc[0], &loc[1], &loc[2]};
+            const int nn    = (int)A.n;
+            const int sz[3] = {nn / 3, nn / 3, nn - 2 * (nn / 3)};
+            bp.Set(3, sz, list);
+            if(variant == 1)
+                bp.SetDiagonalSolver();
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(bp);
+            ls.SetBasisSize(basis);
+            ls.Build();
+            sol.Zeros();
+            run_solver(variant == 0 ? "gmres_block" : "gmres_blockdiag", ls, rhs, sol);
+            ls.Clear();
+        }
+        for(int variant = 0; variant < 2; ++variant)
+        {
             // (restricted) additive Schwarz: 3 blocks, overlap 4, ILU(0) on every block
             GMRES<MatD, VecD, double> ls;
             AS<MatD, VecD, double>    as;

@@ -21,6 +21,8 @@ typedef LocalMatrix<double> Mat;
 typedef LocalVector<double> Vec;
 typedef Solver<Mat, Vec, double> AnySolver;
 
+static int g_nrow = 0; // rows of the operator (block sizes of the block preconditioner)
+
 static std::unique_ptr<AnySolver> make_precond(const std::string& p)
 {
     if(p == "jacobi") return std::unique_ptr<AnySolver>(new Jacobi<Mat, Vec, double>);
@@ -40,6 +42,18 @@ static std::unique_ptr<AnySolver> make_precond(const std::string& p)
         AS<Mat, Vec, double>*        s       = (p == "as") ? new AS<Mat, Vec, double> : new RAS<Mat, Vec, double>;
         s->Set(3, 4, list);
         return std::unique_ptr<AnySolver>(s);
+    }
+    if(p == "block" || p == "blockdiag") // 3 row blocks (n/3, n/3, rest), ILU(0) per diagonal block; L or diagonal solve
+    {
+        static ILU<Mat, Vec, double> loc[3];
+        static AnySolver*            list[3] = {&loc[0], &loc[1], &loc[2]};
+        BlockPreconditioner<Mat, Vec, double>* bp = new BlockPreconditioner<Mat, Vec, double>;
+        const int n  = g_nrow;
+        const int sz[3] = {n / 3, n / 3, n - 2 * (n / 3)};
+        bp->Set(3, sz, list);
+        if(p == "blockdiag")
+            bp->SetDiagonalSolver();
+        return std::unique_ptr<AnySolver>(bp);
     }
     if(p == "variable") // Jacobi, MC-SGS, ILU(0) in turn (for the flexible methods)
     {
@@ -129,7 +143,8 @@ int main(int argc, char* argv[])
             std::cerr << "unknown solver " << sname << std::endl;
             return 2;
         }
-        pc = make_precond(pname);
+        g_nrow = (int)mat.GetM();
+        pc     = make_precond(pname);
         if(pc)
             ls->SetPreconditioner(*pc);
     }

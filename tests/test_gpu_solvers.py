@@ -438,7 +438,8 @@ DRIVER_RUNS = [("cg", "jacobi", "csr", 0, "cg_jacobi"), ("gmres", "ilu", "csr", 
                ("cg", "jacobi", "dia", 0, "cg_jacobi_dia"), ("cg", "ic", "csr", 0, "cg_ic"),
                ("fgmres", "variable", "csr", 30, "fgmres_variable"), ("cg", "fsai", "csr", 0, "cg_fsai"),
                ("cg", "tns", "csr", 0, "cg_tns"), ("gmres", "as", "csr", 30, "gmres_as"),
-               ("gmres", "ras", "csr", 30, "gmres_ras"),
+               ("gmres", "ras", "csr", 30, "gmres_ras"), ("gmres", "block", "csr", 30, "gmres_block"),
+               ("gmres", "blockdiag", "csr", 30, "gmres_blockdiag"),
                ("mixed", "jacobi", "csr", 0, "mixed_cg_jacobi"), ("qmrcgstab", "mcsgs", "csr", 0, "qmrcgstab_mcsgs"),
                ("idr", "none", "csr", 4, "idr_none"), ("fcg", "mcsgs", "csr", 0, "fcg_mcsgs"),
                ("cr", "jacobi", "csr", 0, "cr_jacobi"), ("fgmres", "ilu", "csr", 30, "fgmres_ilu0"),
