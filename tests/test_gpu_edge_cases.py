@@ -229,6 +229,45 @@ def test_ic_and_iterative_triangular_solves_vs_oracle_both_precisions(ra, S, ora
             eq(apply(pc, reps), ref)
 
 
+@pytest.mark.parametrize("pcname", ["UAAMG", "SAAMG", "FSAI", "TNS", "ItILU0", "IC"])
+def test_new_preconditioners_in_single_precision(ra, S, pcname):
+    """fp32 instantiations of the widened preconditioners: CG converges to fp32 accuracy on a 3-D Poisson operator"""
+    rp, ci, va = gen.poisson7(12, np.float32)
+    n = len(rp) - 1
+    A = ra.LocalMatrix(np.float32); A.SetDataPtrCSR(rp, ci, va)
+    ones = ra.LocalVector(np.float32, data=np.ones(n, np.float32))
+    rhs = ra.LocalVector(np.float32); rhs.Allocate("", n); A.Apply(ones, rhs)
+    ls = S.CG(np.float32); ls.SetOperator(A); ls.SetPreconditioner(getattr(S, pcname)())
+    ls.Init(1e-6, 1e-5, 1e8, 500); ls.Build()
+    x = ra.LocalVector(np.float32); x.Allocate("", n)
+    ls.Solve(rhs, x)
+    assert ls.GetSolverStatus() in (1, 2), ls.GetSolverStatus()
+    assert np.max(np.abs(x.numpy() - 1.0)) < 2e-3
+
+
+def test_dia_operator_under_every_krylov_solver(ra, S):
+    """solvers only see Apply(): a DIA operator gives the iteration counts of the CSR one"""
+    rp, ci, va = gen.poisson7(10)
+    n = len(rp) - 1
+    counts = {}
+    for fmt in ("CSR", "DIA"):
+        A = ra.LocalMatrix(); A.SetDataPtrCSR(rp, ci, va)
+        ones = ra.LocalVector(data=np.ones(n)); rhs = ra.LocalVector(); rhs.Allocate("", n); A.Apply(ones, rhs)
+        for sname in ("CG", "BiCGStab", "GMRES", "CR", "QMRCGStab"):
+            ls = getattr(S, sname)(); ls.SetOperator(A); ls.SetPreconditioner(S.Jacobi()); ls.Build()
+            if fmt == "DIA":
+                assert A.ConvertTo(ra.DIA) == ra.DIA
+            x = ra.LocalVector(); x.Allocate("", n)
+            ls.Solve(rhs, x)
+            counts[(fmt, sname)] = ls.GetIterationCount()
+            assert np.max(np.abs(x.numpy() - 1.0)) < 1e-4
+            ls.Clear()
+            if fmt == "DIA":
+                assert A.ConvertTo(ra.CSR) == ra.CSR
+    for sname in ("CG", "BiCGStab", "GMRES", "CR", "QMRCGStab"):
+        assert abs(counts[("CSR", sname)] - counts[("DIA", sname)]) <= 1, (sname, counts)
+
+
 def test_build_clear_cycles_do_not_leak_device_memory(ra, S):
     """every Build()/Clear() pair (preconditioner plans, analysis data, work vectors, format conversions) gives
     its device memory back: free memory after 12 cycles == after 2 cycles"""
