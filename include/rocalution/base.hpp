@@ -1187,6 +1187,12 @@ public:
         }
         RAMD_CHECK(ramd_mat_fsai(this->dev_, 1));
     }
+    // sparse approximate inverse on the pattern of this matrix (this becomes M ~ A^-1)
+    void SPAI(void)
+    {
+        this->need_accel_("SPAI");
+        RAMD_CHECK(ramd_mat_spai(this->dev_));
+    }
     void DiagonalMatrixMultR(const LocalVector<ValueType>& diag)
     {
         this->need_accel_("DiagonalMatrixMultR");

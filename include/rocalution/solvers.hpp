@@ -1253,6 +1253,52 @@ private:
     const OperatorType* matrix_pattern_;
 };
 
+// SPAI :363-475: sparse approximate inverse on the pattern of A; Solve = one SpMV
+template <class OperatorType, class VectorType, typename ValueType>
+class SPAI : public Preconditioner<OperatorType, VectorType, ValueType>
+{
+public:
+    virtual ~SPAI()
+    {
+        this->Clear();
+    }
+    virtual void Print(void) const
+    {
+        LOG_INFO("SParse Approximate Inverse preconditioner");
+        if(this->build_)
+            LOG_INFO("SPAI matrix nnz = " << this->SPAI_.GetNnz());
+    }
+    virtual void Build(void)
+    {
+        if(this->build_)
+            this->Clear();
+        this->build_ = true;
+        assert(this->op_ != NULL);
+        this->SPAI_.CloneFrom(*this->op_);
+        this->SPAI_.SPAI();
+    }
+    virtual void Clear(void)
+    {
+        if(this->build_)
+        {
+            this->SPAI_.Clear();
+            this->build_ = false;
+        }
+    }
+    virtual void Solve(const VectorType& rhs, VectorType* x)
+    {
+        assert(this->build_ == true && x != NULL && x != &rhs);
+        this->SPAI_.Apply(rhs, x);
+    }
+    const OperatorType& GetMatrix(void) const
+    {
+        return this->SPAI_;
+    }
+
+private:
+    OperatorType SPAI_;
+};
+
 // TNS :477-713: truncated Neumann series, (I - L D^-1 + (L D^-1)^2) D^-1 (I - D^-1 L^T + (D^-1 L^T)^2), applied
 // implicitly (default: four triangular SpMVs) or as one explicit matrix
 template <class OperatorType, class VectorType, typename ValueType>

@@ -305,6 +305,9 @@ int ramd_mat_amg_smoothed_prolong(ramd_mat_t m, double relax, int lumping_strat,
 /* FSAI (host_matrix_csr.cpp:6514-6662): m becomes the factorised sparse approximate inverse factor on the lower pattern
  * of the operator (power 1; larger powers / external patterns: RAMD_ERR_UNSUPPORTED) */
 int ramd_mat_fsai(ramd_mat_t m, int power);
+/* SPAI (host_matrix_csr.cpp:6665-6780): m becomes the sparse approximate inverse on its own pattern (per row a dense
+ * least-squares problem solved by Householder QR, host_matrix_dense.cpp:361-520) */
+int ramd_mat_spai(ramd_mat_t m);
 int ramd_mat_diag_mult(ramd_mat_t m, ramd_vec_t diag, int left); /* DiagonalMatrixMultL (1) / R (0), :3631-3676 */
 int ramd_mat_sort(ramd_mat_t m);
 int ramd_mat_transpose(ramd_mat_t m, ramd_mat_t out);
@@ -374,6 +377,7 @@ enum { RAMD_PC_NONE = 0, RAMD_PC_JACOBI = 1, RAMD_PC_ILU0 = 2, RAMD_PC_MCSGS = 3
        RAMD_PC_UAAMG = 9, RAMD_PC_SAAMG = 10,
        /* preconditioner_ai.cpp: AIChebyshev :41-215 (params p, lambda_min, lambda_max), TNS :477-713 (param implicit) */
        RAMD_PC_AICHEBYSHEV = 11, RAMD_PC_TNS = 12, RAMD_PC_FSAI = 13, /* :217-361 */
+       RAMD_PC_SPAI = 15, /* preconditioner_ai.cpp SPAI */
        RAMD_PC_ITILU0 = 14 /* preconditioner.cpp:520-700; factors = exact ILU(0) as on the reference's host backend */ };
 int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out);
 /* MixedPrecisionDC<fp64 outer, fp32 inner>: inner solver/preconditioner kinds */

@@ -480,6 +480,18 @@ static int cmd_gen(const std::string& in, const std::string& out)
         dump_csr("fsai_G", G);
     }
     {
+        SPAI<MatD, VecD, double> p;
+        p.SetOperator(mat);
+        p.Build();
+        p.Solve(x, &y);
+        dump_vec("pc_spai", y);
+        p.Clear();
+        MatD Ms;
+        Ms.CloneFrom(mat);
+        Ms.SPAI();
+        dump_csr("spai_M", Ms);
+    }
+    {
         TNS<MatD, VecD, double> p; // implicit (default)
         p.SetOperator(mat);
         p.Build();
@@ -871,6 +883,16 @@ static int cmd_gen(const std::string& in, const std::string& out)
             ls.Build();
             sol.Zeros();
             run_solver(variant == 0 ? "gmres_as" : "gmres_ras", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            BiCGStab<MatD, VecD, double> ls;
+            SPAI<MatD, VecD, double>     p;
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(p);
+            ls.Build();
+            sol.Zeros();
+            run_solver("bicgstab_spai", ls, rhs, sol);
             ls.Clear();
         }
         {

@@ -307,6 +307,10 @@ class LocalMatrix:
         capi.check(_lib().ramd_mat_amg_smoothed_prolong(self._h, float(relax), int(lumping_strat), connections._h,
                                                         aggregates._h, aggregate_root_nodes._h, prolong._h))
 
+    def SPAI(self):
+        """this becomes the sparse approximate inverse on its own pattern (host_matrix_csr.cpp:6665-6780)"""
+        capi.check(_lib().ramd_mat_spai(self._h))
+
     def FSAI(self, power=1):
         """this becomes the FSAI factor on its own lower pattern (host_matrix_csr.cpp:6514-6662)"""
         capi.check(_lib().ramd_mat_fsai(self._h, int(power)))

@@ -16,7 +16,7 @@ OK, ERR_HIP, ERR_ARG, ERR_UNSUPPORTED, ERR_REFUSED, ERR_NO_DEVICE, ERR_STATE = r
 SOLVER_CG, SOLVER_GMRES, SOLVER_BICGSTAB = 0, 1, 2
 SOLVER_FCG, SOLVER_CR, SOLVER_FGMRES, SOLVER_BICGSTABL, SOLVER_QMRCGSTAB, SOLVER_IDR = 3, 4, 5, 6, 7, 8
 SOLVER_FIXEDPOINT, SOLVER_CHEBYSHEV = 9, 10
-PC_NONE, PC_JACOBI, PC_ILU0, PC_MCSGS, PC_MCGS, PC_MCILU, PC_GS, PC_SGS, PC_IC, PC_UAAMG, PC_SAAMG, PC_AICHEBYSHEV, PC_TNS, PC_FSAI, PC_ITILU0 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14
+PC_NONE, PC_JACOBI, PC_ILU0, PC_MCSGS, PC_MCGS, PC_MCILU, PC_GS, PC_SGS, PC_IC, PC_UAAMG, PC_SAAMG, PC_AICHEBYSHEV, PC_TNS, PC_FSAI, PC_ITILU0, PC_SPAI = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15
 F64, F32, I32 = 0, 1, 2
 CSR, COO, DIA, ELL, HYB = 1, 4, 5, 6, 7
 
@@ -135,6 +135,7 @@ SIGNATURES = {
     "ramd_mat_amg_unsmoothed_prolong": (i32, [mat_t, vec_t, vec_t, mat_t]),
     "ramd_mat_amg_smoothed_prolong": (i32, [mat_t, f64, i32, vec_t, vec_t, vec_t, mat_t]),
     "ramd_mat_fsai": (i32, [mat_t, i32]),
+    "ramd_mat_spai": (i32, [mat_t]),
     "ramd_mat_diag_mult": (i32, [mat_t, vec_t, i32]),
     "ramd_mat_sort": (i32, [mat_t]),
     "ramd_mat_transpose": (i32, [mat_t, mat_t]),

@@ -67,6 +67,7 @@ struct Precs
     TNS<M, V, T>             tns;
     FSAI<M, V, T>            fsai;
     ItILU0<M, V, T>          itilu0;
+    SPAI<M, V, T>            spai;
     Precs()
     {
         // the aggregation runs on the device with the PMIS strategy (the Greedy default is a sequential host sweep)
@@ -87,6 +88,8 @@ struct Precs
             return &fsai;
         case RAMD_PC_ITILU0:
             return &itilu0;
+        case RAMD_PC_SPAI:
+            return &spai;
         case RAMD_PC_UAAMG:
             return &uaamg;
         case RAMD_PC_SAAMG:
@@ -495,7 +498,7 @@ extern "C" {
 
 int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out)
 {
-    if(!out || solver < 0 || solver > RAMD_SOLVER_CHEBYSHEV || precond < 0 || precond > RAMD_PC_ITILU0
+    if(!out || solver < 0 || solver > RAMD_SOLVER_CHEBYSHEV || precond < 0 || precond > RAMD_PC_SPAI
        || (dtype != RAMD_F64 && dtype != RAMD_F32))
         return RAMD_ERR_ARG;
     GUARD_BEGIN
@@ -510,7 +513,7 @@ int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out)
 
 int ramd_solver_create_mixed(int inner_solver, int inner_precond, ramd_solver_t* out)
 {
-    if(!out || inner_solver < 0 || inner_solver > 2 || inner_precond < 0 || inner_precond > RAMD_PC_ITILU0)
+    if(!out || inner_solver < 0 || inner_solver > 2 || inner_precond < 0 || inner_precond > RAMD_PC_SPAI)
         return RAMD_ERR_ARG;
     GUARD_BEGIN
     ramd_solver_s* s = new ramd_solver_s;

@@ -137,6 +137,187 @@ __global__ __launch_bounds__(kBlock) void k_fsai_sizes(int nrow, const int* __re
     }
 }
 
+// ---- SPAI (host_matrix_csr.cpp:6665-6780 with the dense QR of host_matrix_dense.cpp:361-520): on the pattern of A^T,
+// row i of M^T minimises || e_i - A(I, J) m ||_2 with J = pattern of row i of A^T and I = the rows of A meeting J (in
+// order of first appearance); Householder QR and back substitution in the host's loop order, one thread per row, dense
+// scratch in device memory.  at* = CSR of A^T (the pattern that is filled), a* = CSR of A.
+struct SpaiDims
+{
+    int nI, nJ;
+};
+// candidate k of the traversal "for idx in J: for j in row J[idx] of A^T" is new iff it did not occur earlier
+__device__ __forceinline__ int spai_collect(int i, const int* __restrict__ atrp, const int* __restrict__ atci,
+                                            int* __restrict__ Iout)
+{
+    int       nI = 0;
+    const int rs = atrp[i], re = atrp[i + 1];
+    for(int a = rs; a < re; ++a)
+    {
+        const int Ja = atci[a];
+        for(int j = atrp[Ja]; j < atrp[Ja + 1]; ++j)
+        {
+            const int c    = atci[j];
+            bool      seen = false;
+            if(Iout)
+            {
+                for(int q = 0; q < nI; ++q)
+                    if(Iout[q] == c)
+                    {
+                        seen = true;
+                        break;
+                    }
+            }
+            else
+            {
+                // no list yet: replay the traversal up to this position
+                for(int a2 = rs; a2 <= a && !seen; ++a2)
+                {
+                    const int J2  = atci[a2];
+                    const int end = (a2 == a) ? j : atrp[J2 + 1];
+                    for(int j2 = atrp[J2]; j2 < end; ++j2)
+                        if(atci[j2] == c)
+                        {
+                            seen = true;
+                            break;
+                        }
+                }
+            }
+            if(!seen)
+            {
+                if(Iout)
+                    Iout[nI] = c;
+                ++nI;
+            }
+        }
+    }
+    return nI;
+}
+__device__ __forceinline__ long long spai_index_slots(long long nI, int tsz)
+{
+    return (nI * 4 + tsz - 1) / tsz + 1; // value-type slots holding the nI row indices
+}
+__global__ __launch_bounds__(kBlock) void k_spai_sizes(int r0, int r1, const int* __restrict__ atrp,
+                                                       const int* __restrict__ atci, long long* __restrict__ sz, int tsz)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= r1; i += gsz)
+    {
+        long long v = 0;
+        if(i < r1)
+        {
+            const long long nJ = atrp[i + 1] - atrp[i];
+            const long long nI = spai_collect((int)i, atrp, atci, nullptr);
+            v                  = nI * nJ + 2 * nI + nJ + spai_index_slots(nI, tsz); // Asub, v, ek, mk, I
+        }
+        sz[i - r0] = v;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_spai_rows(int r0, int r1, const int* __restrict__ atrp,
+                                                      const int* __restrict__ atci, const int* __restrict__ arp,
+                                                      const int* __restrict__ aci, const T* __restrict__ aval,
+                                                      const long long* __restrict__ soff, T* __restrict__ scratch,
+                                                      T* __restrict__ mval)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < r1; i += gsz)
+    {
+        const int rs = atrp[i];
+        const int nJ = atrp[i + 1] - rs;
+        if(nJ == 0)
+            continue;
+        T*   base = scratch + soff[i - r0];
+        // layout: [I ints | Asub nI*nJ | v nI | ek nI | mk nJ]; nI known after collecting into the head of the segment
+        int* I  = reinterpret_cast<int*>(base);
+        const int nI = spai_collect((int)i, atrp, atci, I);
+        T*   Asub = base + spai_index_slots(nI, (int)sizeof(T));
+        T*   v    = Asub + (long long)nI * nJ;
+        T*   ek   = v + nI;
+        T*   mk   = ek + nI;
+        for(int q = 0; q < nI * nJ; ++q)
+            Asub[q] = (T)0;
+        for(int k = 0; k < nI; ++k) // Asub(k, j) = A(I[k], J[j]), DENSE_IND(k, j) = k + j * nI
+            for(int aj = arp[I[k]]; aj < arp[I[k] + 1]; ++aj)
+                for(int j = 0; j < nJ; ++j)
+                    if(aci[aj] == atci[rs + j])
+                        Asub[k + j * nI] = aval[aj];
+        const int size = nI < nJ ? nI : nJ;
+        for(int q = 0; q < nI; ++q)
+            v[q] = (T)0;
+        // QRDecompose
+        for(int c = 0; c < size; ++c)
+        {
+            T beta;
+            T s = (T)0;
+            for(int r = 1; r < nI - c; ++r)
+                v[r] = Asub[(r + c) + c * nI];
+            for(int r = c + 1; r < nI; ++r)
+                s += v[r - c] * v[r - c];
+            if(s == (T)0)
+                beta = (T)0;
+            else
+            {
+                T aii = Asub[c + c * nI];
+                if(aii <= (T)0)
+                    aii -= (T)sqrt((double)(aii * aii + s));
+                else
+                    aii += (T)sqrt((double)(aii * aii + s));
+                const T squared = aii * aii;
+                beta            = (T)2 * squared / (s + squared);
+                aii             = (T)1 / aii;
+                for(int r = 1; r < nI - c; ++r)
+                    v[r] *= aii;
+            }
+            if(beta != (T)0)
+            {
+                for(int aj = c; aj < nJ; ++aj)
+                {
+                    T sum = Asub[c + aj * nI];
+                    for(int ai = c + 1; ai < nI; ++ai)
+                        sum += v[ai - c] * Asub[ai + aj * nI];
+                    sum *= beta;
+                    Asub[c + aj * nI] -= sum;
+                    for(int ai = c + 1; ai < nI; ++ai)
+                        Asub[ai + aj * nI] -= sum * v[ai - c];
+                }
+                for(int k = c + 1; k < nI; ++k)
+                    Asub[k + c * nI] = v[k - c];
+            }
+        }
+        // QRSolve(e_k, mk)
+        for(int q = 0; q < nI; ++q)
+            ek[q] = (I[q] == (int)i) ? (T)1 : (T)0;
+        for(int q = 0; q < nJ; ++q)
+            mk[q] = (T)0;
+        for(int c = 0; c < size; ++c)
+        {
+            T sum = (T)1;
+            for(int j = c + 1; j < nI; ++j)
+                sum += Asub[j + c * nI] * Asub[j + c * nI];
+            sum = (T)2 / sum;
+            if(sum != (T)2)
+            {
+                T sum2 = ek[c];
+                for(int j = c + 1; j < nI; ++j)
+                    sum2 += Asub[j + c * nI] * ek[j];
+                sum2 *= sum;
+                ek[c] -= sum2;
+                for(int j = c + 1; j < nI; ++j)
+                    ek[j] -= sum2 * Asub[j + c * nI];
+            }
+        }
+        for(int c = size - 1; c >= 0; --c)
+        {
+            T sum = (T)0;
+            for(int j = c + 1; j < nJ; ++j)
+                sum += Asub[c + j * nI] * mk[j];
+            mk[c] = (ek[c] - sum) / Asub[c + c * nI];
+        }
+        for(int j = 0; j < nJ; ++j)
+            mval[rs + j] = mk[j];
+    }
+}
+
 // ---- MatrixAdd, pattern of `mat` a subset of this (structure == false): this = alpha*this + beta*mat on the matches
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_add_subset(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
@@ -1212,6 +1393,99 @@ int ramd_mat_fsai(ramd_mat_t m, int power)
         L->nnz        = 0;
     }
     ramd_mat_destroy(L);
+    return s;
+}
+
+int ramd_mat_spai(ramd_mat_t m)
+{
+    RAMD_TRY(need_csr(m, "SPAI"));
+    if(m->nrow != m->ncol || m->nnz <= 0)
+        RAMD_FAIL(RAMD_ERR_ARG, "SPAI: square, non-empty matrix expected");
+    Backend&   b  = backend();
+    const int  n  = m->nrow;
+    ramd_mat_t AT = nullptr;
+    RAMD_TRY(ramd_mat_create(m->dtype, &AT));
+    int s = mat_transpose(m, AT); // the pattern that is filled; rows sorted
+    void* mval = nullptr;
+    if(s == RAMD_OK && cached_malloc(&mval, (size_t)AT->nnz * val_size(m->dtype) + kPad) != hipSuccess)
+        s = RAMD_ERR_HIP;
+    if(s == RAMD_OK && hipMemsetAsync(mval, 0, (size_t)AT->nnz * val_size(m->dtype), b.cur) != hipSuccess)
+        s = RAMD_ERR_HIP;
+    const int chunk = 1 << 18; // rows per pass: bounds the dense scratch
+    for(int r0 = 0; r0 < n && s == RAMD_OK; r0 += chunk)
+    {
+        const int  r1   = std::min(n, r0 + chunk);
+        const int  nr   = r1 - r0;
+        long long* soff = nullptr;
+        void*      scr  = nullptr;
+        long long  tot  = 0;
+        s               = dev_alloc(&soff, (int64_t)nr + 1);
+        if(s == RAMD_OK)
+        {
+            hipLaunchKernelGGL(k_spai_sizes, dim3(ew_grid((int64_t)nr + 1)), dim3(kBlock), 0, b.cur, r0, r1,
+                               (const int*)AT->rp, (const int*)AT->ci, soff, (int)val_size(m->dtype));
+            s = scan_ll(soff, (int64_t)nr + 1);
+        }
+        if(s == RAMD_OK)
+        {
+            hipError_t e = hipMemcpyAsync(&tot, soff + nr, sizeof(long long), hipMemcpyDeviceToHost, b.cur);
+            if(e == hipSuccess)
+                e = hipStreamSynchronize(b.cur);
+            if(e != hipSuccess)
+                s = RAMD_ERR_HIP;
+        }
+        if(s == RAMD_OK && cached_malloc(&scr, (size_t)tot * val_size(m->dtype) + kPad) != hipSuccess)
+            s = RAMD_ERR_HIP;
+        if(s == RAMD_OK)
+        {
+            const int grid = ew_grid(nr);
+            if(m->dtype == RAMD_F64)
+                hipLaunchKernelGGL((k_spai_rows<double>), dim3(grid), dim3(kBlock), 0, b.cur, r0, r1, (const int*)AT->rp,
+                                   (const int*)AT->ci, (const int*)m->rp, (const int*)m->ci, (const double*)m->val,
+                                   (const long long*)soff, (double*)scr, (double*)mval);
+            else
+                hipLaunchKernelGGL((k_spai_rows<float>), dim3(grid), dim3(kBlock), 0, b.cur, r0, r1, (const int*)AT->rp,
+                                   (const int*)AT->ci, (const int*)m->rp, (const int*)m->ci, (const float*)m->val,
+                                   (const long long*)soff, (float*)scr, (float*)mval);
+            hipError_t e = hipGetLastError();
+            if(e == hipSuccess)
+                e = hipStreamSynchronize(b.cur);
+            if(e != hipSuccess)
+                s = RAMD_ERR_HIP;
+        }
+        dev_free(&soff);
+        if(scr)
+            (void)cached_free(scr);
+    }
+    if(s == RAMD_OK)
+    {
+        // M^T = (pattern of A^T, new values); this = its transpose
+        if(AT->val)
+            (void)cached_free(AT->val);
+        AT->val = mval;
+        mval    = nullptr;
+        ramd_mat_t M = nullptr;
+        s            = ramd_mat_create(m->dtype, &M);
+        if(s == RAMD_OK)
+            s = mat_transpose(AT, M);
+        if(s == RAMD_OK)
+        {
+            mat_free_csr(m);
+            mat_free_analysis(m);
+            m->rp  = M->rp;
+            m->ci  = M->ci;
+            m->val = M->val;
+            m->nnz = M->nnz;
+            M->rp = M->ci = nullptr;
+            M->val        = nullptr;
+            M->nnz        = 0;
+        }
+        if(M)
+            ramd_mat_destroy(M);
+    }
+    if(mval)
+        (void)cached_free(mval);
+    ramd_mat_destroy(AT);
     return s;
 }
 

@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import capi
-from .capi import (PC_AICHEBYSHEV, PC_FSAI, PC_GS, PC_ITILU0, PC_IC, PC_ILU0, PC_SAAMG, PC_TNS, PC_UAAMG, PC_JACOBI, PC_MCGS, PC_MCILU, PC_MCSGS, PC_NONE, PC_SGS, SOLVER_BICGSTAB,
+from .capi import (PC_AICHEBYSHEV, PC_FSAI, PC_GS, PC_ITILU0, PC_SPAI, PC_IC, PC_ILU0, PC_SAAMG, PC_TNS, PC_UAAMG, PC_JACOBI, PC_MCGS, PC_MCILU, PC_MCSGS, PC_NONE, PC_SGS, SOLVER_BICGSTAB,
                    SOLVER_BICGSTABL,
                    SOLVER_CG, SOLVER_CHEBYSHEV, SOLVER_CR, SOLVER_FCG, SOLVER_FGMRES, SOLVER_FIXEDPOINT, SOLVER_GMRES,
                    SOLVER_IDR, SOLVER_QMRCGSTAB)
@@ -111,6 +111,12 @@ class ItILU0(_Precond):
 
     def SetAlgorithm(self, alg):
         pass
+
+
+class SPAI(_Precond):
+    """sparse approximate inverse on the pattern of the operator (preconditioner_ai.cpp:363-475): per row a dense
+    least-squares problem solved by Householder QR on the device; Solve = one SpMV"""
+    kind = PC_SPAI
 
 
 class FSAI(_Precond):

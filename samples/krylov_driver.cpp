@@ -34,6 +34,7 @@ static std::unique_ptr<AnySolver> make_precond(const std::string& p)
     if(p == "mcsgs") return std::unique_ptr<AnySolver>(new MultiColoredSGS<Mat, Vec, double>);
     if(p == "mcilu") return std::unique_ptr<AnySolver>(new MultiColoredILU<Mat, Vec, double>);
     if(p == "fsai") return std::unique_ptr<AnySolver>(new FSAI<Mat, Vec, double>);
+    if(p == "spai") return std::unique_ptr<AnySolver>(new SPAI<Mat, Vec, double>);
     if(p == "tns") return std::unique_ptr<AnySolver>(new TNS<Mat, Vec, double>);
     if(p == "as" || p == "ras") // (restricted) additive Schwarz: 3 blocks, overlap 4, ILU(0) on every block
     {

@@ -184,6 +184,23 @@ def test_csr_matrix_algebra_vs_golden(ra, name):
     assert np.allclose(y1.numpy(), y2.numpy(), rtol=1e-12, atol=1e-10 * np.max(np.abs(y2.numpy())))
 
 
+@pytest.mark.parametrize("name", CASES)
+def test_spai_matrix_vs_golden(ra, name):
+    """SPAI: per-row least squares by Householder QR on the device -- pattern identical, values identical on the
+    integer-valued operators and within 1e-13 on the random ones"""
+    g = load_golden(name)
+    A = _mat(ra, g)
+    A.SPAI()
+    rp, ci, va = A.CopyToCSR()
+    eq(rp, g["spai_M_rowptr"]); eq(ci, g["spai_M_col"])
+    if name.startswith("rand"):
+        # general real values: the installed 4.1 library is one ulp away from the loops of the 3.2 source in 30 % of the
+        # entries (a host restatement of that source shows the same one-ulp picture), so: 1e-13 relative
+        assert np.allclose(va, g["spai_M_val"], rtol=1e-13, atol=1e-15)
+    else:
+        eq(va, g["spai_M_val"])
+
+
 def test_fsai_factor_vs_golden(ra):
     """FSAI(1): per-row dense LU on the lower pattern and the scaling -- factor arrays identical to the genuine library"""
     for name in ("gr3030", "poisson8", "lap2d7"):
