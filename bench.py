@@ -293,7 +293,9 @@ def main():
         z0, z1 = (N * rank) // world, (N * (rank + 1)) // world
         g = C.c_void_p()
         SK = {"cg": capi.SOLVER_CG, "gmres": capi.SOLVER_GMRES, "bicgstab": capi.SOLVER_BICGSTAB}
-        PK = {"none": capi.PC_NONE, "jacobi": capi.PC_JACOBI, "ilu0": capi.PC_ILU0, "mcsgs": capi.PC_MCSGS}
+        PK = {"none": capi.PC_NONE, "jacobi": capi.PC_JACOBI, "ilu0": capi.PC_ILU0, "mcsgs": capi.PC_MCSGS,
+              "mcgs": capi.PC_MCGS, "mcilu": capi.PC_MCILU, "ic": capi.PC_IC, "sgs": capi.PC_SGS,
+              "uaamg": capi.PC_UAAMG, "saamg": capi.PC_SAAMG}  # all but Jacobi: BlockJacobi over the ranks
         if args.precond not in PK:
             raise SystemExit("--precond %s: not wired into the distributed driver" % args.precond)
         if args.solver == "mixed":  # config 5: fp64 defect correction around fp32 CG + Jacobi

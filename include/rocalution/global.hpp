@@ -648,6 +648,11 @@ public:
     {
         this->local_precond_->Solve(rhs.GetInterior(), &x->GetInterior());
     }
+    // a local multigrid cycle / nested solver runs reductions of its own: the outer fused loop steps aside
+    virtual bool SolveUsesScalarRecord(void) const
+    {
+        return this->local_precond_ != NULL && this->local_precond_->SolveUsesScalarRecord();
+    }
 
 private:
     Solver<LocalMatrix<ValueType>, LocalVector<ValueType>, ValueType>* local_precond_;

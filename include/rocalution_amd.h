@@ -429,7 +429,9 @@ int ramd_solver_set_fused_sweeps(ramd_solver_t s, int on); /* MultiColored::SetF
 
 /* distributed driver: GlobalMatrix/GlobalVector + Solver<GlobalMatrix,GlobalVector> on one rank of a
  * row-block decomposition (clients/samples/cg_mpi.cpp, bicgstab_mpi.cpp of the reference).  The local
- * preconditioner of MC-SGS / ILU(0) is wrapped in BlockJacobi as the reference samples do. */
+ * preconditioner (any RAMD_PC_* kind but Jacobi, which is the global diagonal: ILU(0), MC-SGS, IC, SA-/UA-AMG on
+ * the interior block, ...) is wrapped in BlockJacobi as the reference samples do
+ * (preconditioner_blockjacobi.cpp:80-141). */
 typedef struct ramd_gsolver_s* ramd_gsolver_t;
 int ramd_gsolver_create(ramd_comm_t comm, int solver, int precond, ramd_gsolver_t* out);
 /* MixedPrecisionDC<fp64 Global outer, fp32 Global inner> (config 5 of BASELINE.json); inner

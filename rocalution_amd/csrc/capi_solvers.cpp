@@ -421,8 +421,7 @@ struct ramd_gsolver_s
     BiCGStab<GM, GV, double>     bicg;
     Jacobi<GM, GV, double>       jacobi; // global Jacobi == interior diagonal
     BlockJacobi<GM, GV, double>  bj;
-    ILU<LM, LV, double>          ilu;
-    MultiColoredSGS<LM, LV, double> mcsgs;
+    Precs<double>                precs; // local preconditioners for BlockJacobi (any RAMD_PC_* kind)
     // mixed precision: fp64 defect correction around an fp32 Global solver
     typedef GlobalMatrix<float>  GMF;
     typedef GlobalVector<float>  GVF;
@@ -767,7 +766,7 @@ int ramd_solver_clear(ramd_solver_t s)
 // ------------------------------------------------------------------------------------ distributed
 int ramd_gsolver_create(ramd_comm_t comm, int solver, int precond, ramd_gsolver_t* out)
 {
-    if(!out || solver < 0 || solver > 2 || precond < 0 || precond > 3)
+    if(!out || solver < 0 || solver > 2 || precond < 0 || precond > RAMD_PC_SPAI)
         return RAMD_ERR_ARG;
     GUARD_BEGIN
     ramd_gsolver_s* g = new ramd_gsolver_s;
@@ -952,14 +951,9 @@ int ramd_gsolver_build(ramd_gsolver_t g)
     }
     if(g->pc_kind == RAMD_PC_JACOBI)
         g->ls()->SetPreconditioner(g->jacobi);
-    else if(g->pc_kind == RAMD_PC_ILU0)
+    else if(g->pc_kind != RAMD_PC_NONE) // BlockJacobi over ranks: the local preconditioner on the interior block
     {
-        g->bj.Set(g->ilu);
-        g->ls()->SetPreconditioner(g->bj);
-    }
-    else if(g->pc_kind == RAMD_PC_MCSGS)
-    {
-        g->bj.Set(g->mcsgs);
+        g->bj.Set(*g->precs.get(g->pc_kind));
         g->ls()->SetPreconditioner(g->bj);
     }
     g->ls()->Build();

@@ -169,6 +169,22 @@ def gpu_worker(rank, world, initfile, kind, outdir):
     g3.build()
     out["xs3"] = g3.solve(None, np.zeros(hi - lo))
     it3, st3, res3 = g3.result()
+    # BlockJacobi around the wider local preconditioners: SA-AMG / IC on the interior block under CG (the symmetric
+    # operators), ILU(0) / FSAI-free SPAI under BiCGStab (the random one)
+    its4 = []
+    for sk, pk in ([(capi.SOLVER_BICGSTAB, capi.PC_ILU0), (capi.SOLVER_BICGSTAB, capi.PC_SPAI)] if kind == "random"
+                   else [(capi.SOLVER_CG, capi.PC_SAAMG), (capi.SOLVER_CG, capi.PC_IC), (capi.SOLVER_CG, capi.PC_UAAMG)]):
+        g4 = D.DistributedSolver(comm, sk, pk)
+        if kind == "poisson_slab":
+            g4.setup_poisson(N, z0, z1)
+        else:
+            g4.setup_csr(n, piece, plan)
+        g4.init(1e-15, 1e-8, 1e8, 500)
+        g4.build()
+        out["xs4_%d" % len(its4)] = g4.solve(None, np.zeros(hi - lo))
+        it4, st4, res4 = g4.result()
+        its4.append((it4, st4))
+    out["its4"] = np.array(its4)
     np.savez(os.path.join(outdir, "r%d.npz" % rank), lo=lo, hi=hi, it=it, res=res, st=st, it2=it2, st2=st2,
              res2=res2, it3=it3, st3=st3, res3=res3, **out)
     dist.barrier()

@@ -42,6 +42,14 @@ def test_two_ranks_one_gpu(kind, oracle):
     xs2 = np.concatenate([r["xs2"] for r in res])
     assert int(res[0]["st2"]) == 2
     assert np.linalg.norm(xs2 - 1.0) / np.sqrt(n) < 1e-4
+    # BlockJacobi around SA-AMG / IC / UA-AMG (CG) or ILU(0) / SPAI (BiCGStab) on the interior block: converged to the
+    # same solution, and in fewer iterations than the Jacobi run above
+    its4 = res[0]["its4"]
+    for k in range(len(its4)):
+        xs4 = np.concatenate([r["xs4_%d" % k] for r in res])
+        assert int(its4[k][1]) == 2, (k, its4)
+        assert np.linalg.norm(xs4 - 1.0) / np.sqrt(n) < 1e-6
+        assert int(its4[k][0]) < int(res[0]["it"]) * (2 if kind == "random" else 1) + 2, (k, its4, res[0]["it"])
     # mixed precision on Global objects (no reference counterpart, SURVEY.md headline 6): pinned by the
     # 1-process MixedPrecisionDC oracle -- same outer iteration count +-1, same solution
     refm = oracle.solve_mixed(rp, ci, va, b, outer={}, inner=dict(solver=oracle.CG, precond=oracle.PC_JACOBI,
