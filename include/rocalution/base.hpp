@@ -1112,15 +1112,12 @@ public:
         this->need_accel_("ILU0Factorize");
         RAMD_CHECK(ramd_mat_ilu0_factorize(this->dev_));
     }
+    // local_matrix.cpp:3910-4040: p = 0 -> ILU(0); level: fill levels on pattern(A^(p+1)), else ILU(0) on that pattern
     void ILUpFactorize(int p, bool level = true)
     {
-        (void)level;
-        if(p != 0)
-        {
-            LOG_INFO("LocalMatrix::ILUpFactorize(): only p = 0 is provided by this backend");
-            FATAL_ERROR(__FILE__, __LINE__);
-        }
-        this->ILU0Factorize();
+        this->need_accel_("ILUpFactorize");
+        assert(p >= 0);
+        RAMD_CHECK(ramd_mat_ilup_factorize(this->dev_, p, level ? 1 : 0));
     }
     void LUAnalyse(void)
     {

@@ -156,6 +156,9 @@ int ramd_mat_permute(ramd_mat_t m, ramd_vec_t perm_i32); /* :206  P A P^T */
  * hip_matrix_csr.cpp:3915-4060).  size_colors must hold nrow ints. */
 int ramd_mat_multicoloring(ramd_mat_t m, int* num_colors, int* size_colors, ramd_vec_t perm_i32);
 int ramd_mat_ilu0_factorize(ramd_mat_t m); /* :321 */
+/* LocalMatrix::ILUpFactorize(p, level) (local_matrix.cpp:3910-4040): p = 0 is ILU(0); level != 0: fill levels on the
+ * pattern of A^(p+1) (host_matrix_csr.cpp:3149-3312), level == 0: ILU(0) on that whole pattern.  In place, CSR. */
+int ramd_mat_ilup_factorize(ramd_mat_t m, int p, int level);
 /* Incomplete Cholesky (IC preconditioner, preconditioner.cpp:862-925):
  *   ICFactorize (host_matrix_csr.cpp:2344-2466) in place on L = ExtractL(A, diag = true); returns the inverse
  *   diagonal; RAMD_ERR_STATE on the reference's "IC breakdown" conditions.

@@ -87,6 +87,7 @@ int     orc_csr_multicoloring(int nrow, int64_t nnz, const int* row_offset, cons
     void orc_copy_permute##S(int64_t, T*, const T*, const int*);                                   \
     void orc_copy_permute_backward##S(int64_t, T*, const T*, const int*);                          \
     int  orc_csr_ilu0##S(int, const int*, const int*, T*);                                         \
+    int  orc_csr_ilup_numeric##S(int, int, const int*, const int*, const int*, const int*, const T*, T*, int*); \
     void orc_csr_lusolve##S(int, int64_t, const int*, const int*, const T*, const T*, T*);         \
     void orc_csr_lsolve##S(int, const int*, const int*, const T*, int, const T*, T*);              \
     void orc_csr_usolve##S(int, int64_t, const int*, const int*, const T*, int, const T*, T*);     \

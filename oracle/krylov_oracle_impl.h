@@ -429,6 +429,72 @@ int SUF(orc_csr_ilu0)(int nrow, const int* row_offset, const int* col, T* val)
     return 1;
 }
 
+/* src/base/host/host_matrix_csr.cpp:3149-3312  ILUpFactorizeNumeric(p, structure): the level-controlled IKJ sweep on
+ * the pattern S (= pattern of A^(p+1), local_matrix.cpp:3929-3935).  val/lev are S-sized work arrays: on return the
+ * entries with lev <= p are the factor's entries (the caller compacts them, host :3276-3300). */
+int SUF(orc_csr_ilup_numeric)(int nrow, int p, const int* s_row_offset, const int* s_col, const int* a_row_offset,
+                              const int* a_col, const T* a_val, T* val, int* levels)
+{
+    const int inf_level = 99999; /* :3171 */
+    int*      ind_diag  = (int*)calloc((size_t)nrow, sizeof(int));
+    if(!ind_diag)
+        return 0;
+    for(int ai = 0; ai < nrow; ++ai) /* :3178-3190 */
+        for(int aj = s_row_offset[ai]; aj < s_row_offset[ai + 1]; ++aj)
+            if(ai == s_col[aj])
+            {
+                ind_diag[ai] = aj;
+                break;
+            }
+    for(int ai = 0; ai < nrow; ++ai) /* :3199-3226: A's values at level 0, the rest 0 at "infinity" */
+        for(int aj = s_row_offset[ai]; aj < s_row_offset[ai + 1]; ++aj)
+        {
+            levels[aj] = inf_level;
+            val[aj]    = (T)0;
+            for(int ajj = a_row_offset[ai]; ajj < a_row_offset[ai + 1]; ++ajj)
+                if(s_col[aj] == a_col[ajj])
+                {
+                    val[aj]    = a_val[ajj];
+                    levels[aj] = 0;
+                    break;
+                }
+        }
+    for(int ai = 1; ai < nrow; ++ai) /* :3229-3273 */
+    {
+        for(int ak = s_row_offset[ai]; ai > s_col[ak]; ++ak)
+        {
+            if(levels[ak] <= p)
+            {
+                val[ak] /= val[ind_diag[s_col[ak]]];
+                for(int aj = ak + 1; aj < s_row_offset[ai + 1]; ++aj)
+                {
+                    T   val_kj   = (T)0;
+                    int level_kj = inf_level;
+                    for(int kj = s_row_offset[s_col[ak]]; kj < s_row_offset[s_col[ak] + 1]; ++kj)
+                        if(s_col[aj] == s_col[kj])
+                        {
+                            level_kj = levels[kj];
+                            val_kj   = val[kj];
+                            break;
+                        }
+                    int lev = level_kj + levels[ak] + 1;
+                    if(levels[aj] > lev)
+                        levels[aj] = lev;
+                    val[aj] -= val[ak] * val_kj;
+                }
+            }
+        }
+        for(int ak = s_row_offset[ai]; ak < s_row_offset[ai + 1]; ++ak)
+            if(levels[ak] > p)
+            {
+                levels[ak] = inf_level;
+                val[ak]    = (T)0;
+            }
+    }
+    free(ind_diag);
+    return 1;
+}
+
 /* src/base/host/host_matrix_csr.cpp:1163-1221  LUSolve (serial): unit-lower forward
  * sweep that stops at the first col >= row, then backward sweep dividing by the diagonal
  * found by equality scan (falls back to the previously found position). */

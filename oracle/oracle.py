@@ -358,6 +358,50 @@ def ilu0(rp, ci, va):
     return lu
 
 
+def symbolic_power(rp, ci, q):
+    """pattern of A^q, rows sorted (host_matrix_csr.cpp:2718-2790 SymbolicMatMatMult, :3073-3146 SymbolicPower --
+    beyond 8 the reference's loop multiplies once more)"""
+    if q > 8:
+        q += 1
+    ones = np.ones(len(ci), dtype=np.float64)
+    a = (_i32(rp), _i32(ci), ones)
+    s = a
+    for _ in range(q - 1):
+        crp, cci, _v = csr_matmult(s, a)
+        for i in range(len(crp) - 1):
+            cci[crp[i]:crp[i + 1]].sort()
+        s = (crp, cci, np.ones(len(cci), dtype=np.float64))
+    return s[0], s[1]
+
+
+def ilup(rp, ci, va, p, level=True):
+    """LocalMatrix::ILUpFactorize (local_matrix.cpp:3910-4040) -> (rowptr, col, val) of the factors"""
+    rp, ci = _i32(rp), _i32(ci)
+    if p == 0:
+        return rp, ci, ilu0(rp, ci, va)
+    srp, sci = symbolic_power(rp, ci, p + 1)
+    f, _ = _fn("orc_csr_ilup_numeric", va.dtype)
+    val = np.zeros(len(sci), dtype=va.dtype)
+    lev = np.zeros(len(sci), dtype=np.int32)
+    # p = -1: nothing is eliminated, the call only places A's values on the pattern
+    f(C.c_int(len(rp) - 1), C.c_int(p if level else -1), _p(srp), _p(sci), _p(rp), _p(ci), _p(va), _p(val), _p(lev))
+    if not level:  # :3985-3993: values on the whole power pattern, then ILU(0)
+        a0 = np.zeros(len(sci), dtype=va.dtype)
+        row = np.repeat(np.arange(len(rp) - 1), np.diff(rp))
+        pos = {}
+        srow = np.repeat(np.arange(len(srp) - 1), np.diff(srp))
+        for k in range(len(sci)):
+            pos[(int(srow[k]), int(sci[k]))] = k
+        for k in range(len(ci)):
+            a0[pos[(int(row[k]), int(ci[k]))]] = va[k]
+        return srp, sci, ilu0(srp, sci, a0)
+    keep = lev <= p
+    nrp = np.zeros(len(srp), dtype=np.int32)
+    srow = np.repeat(np.arange(len(srp) - 1), np.diff(srp))
+    np.add.at(nrp, srow[keep] + 1, 1)
+    return np.cumsum(nrp).astype(np.int32), sci[keep].copy(), val[keep].copy()
+
+
 def lusolve(rp, ci, lu, b):
     rp, ci = _i32(rp), _i32(ci)
     f, _ = _fn("orc_csr_lusolve", lu.dtype)

@@ -352,6 +352,26 @@ static int cmd_gen(const std::string& in, const std::string& out)
         dump_vec("pc_ilu0", y);
         p.Clear();
     }
+    // ILU(p): fill levels on the pattern of A^(p+1) (p = 1, 2), and ILU(0) on that whole pattern (level = false)
+    {
+        const int  ps[3]  = {1, 2, 1};
+        const bool lv[3]  = {true, true, false};
+        const char* nm[3] = {"ilu1", "ilu2", "ilu1n"};
+        for(int k = 0; k < 3; ++k)
+        {
+            MatD lu;
+            lu.CloneFrom(mat);
+            lu.ILUpFactorize(ps[k], lv[k]);
+            dump_csr(nm[k], lu);
+        }
+        ILU<MatD, VecD, double> p;
+        p.Set(1);
+        p.SetOperator(mat);
+        p.Build();
+        p.Solve(x, &y);
+        dump_vec("pc_ilu1", y);
+        p.Clear();
+    }
     {
         MultiColoredSGS<MatD, VecD, double> p;
         p.SetOperator(mat);
@@ -570,6 +590,18 @@ static int cmd_gen(const std::string& in, const std::string& out)
             ls.Build();
             sol.Zeros();
             run_solver("gmres_ilu0", ls, rhs, sol);
+            ls.Clear();
+        }
+        {
+            GMRES<MatD, VecD, double> ls;
+            ILU<MatD, VecD, double>   p;
+            p.Set(1);
+            ls.SetOperator(mat);
+            ls.SetPreconditioner(p);
+            ls.SetBasisSize(basis);
+            ls.Build();
+            sol.Zeros();
+            run_solver("gmres_ilu1", ls, rhs, sol);
             ls.Clear();
         }
         {

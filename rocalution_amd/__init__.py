@@ -461,6 +461,9 @@ class LocalMatrix:
     def ILU0Factorize(self):
         capi.check(_lib().ramd_mat_ilu0_factorize(self._h))
 
+    def ILUpFactorize(self, p, level=True):
+        capi.check(_lib().ramd_mat_ilup_factorize(self._h, int(p), 1 if level else 0))
+
     def LUAnalyse(self):
         capi.check(_lib().ramd_mat_lu_analyse(self._h))
 

@@ -100,6 +100,7 @@ SIGNATURES = {
     "ramd_mat_permute": (i32, [mat_t, vec_t]),
     "ramd_mat_multicoloring": (i32, [mat_t, pi32, ptr, vec_t]),
     "ramd_mat_ilu0_factorize": (i32, [mat_t]),
+    "ramd_mat_ilup_factorize": (i32, [mat_t, i32, i32]),
     "ramd_mat_lu_analyse": (i32, [mat_t]),
     "ramd_mat_lu_analyse_clear": (i32, [mat_t]),
     "ramd_mat_lu_solve": (i32, [mat_t, vec_t, vec_t]),

@@ -810,6 +810,379 @@ static int ilu0_t(ramd_mat_s* m)
     return RAMD_OK;
 }
 
+// ---------------------------------------------------------------- ILU(p) with fill levels, sync-free
+// host_matrix_csr.cpp:3149-3312 (ILUpFactorizeNumeric) on the pattern S = pattern(A^(p+1)) (local_matrix.cpp:3929-3935).
+// Entries of S start with A's value and level 0, or 0 and level "infinite".
+constexpr int kIlupInf = 99999; // host :3171
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_ilup_init(int nrow, const int* __restrict__ srp, const int* __restrict__ sci,
+                                                      const int* __restrict__ arp, const int* __restrict__ aci,
+                                                      const T* __restrict__ aval, T* __restrict__ val,
+                                                      int* __restrict__ lev)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < nrow; row += gsz)
+    {
+        int       a  = arp[row];
+        const int ae = arp[row + 1];
+        for(int j = srp[row]; j < srp[row + 1]; ++j)
+        {
+            const int c = sci[j];
+            while(a < ae && aci[a] < c)
+                ++a;
+            const bool hit = (a < ae && aci[a] == c);
+            val[j]         = hit ? aval[a] : (T)0;
+            if(lev)
+                lev[j] = hit ? 0 : kIlupInf;
+        }
+    }
+}
+
+// Thread per row, rows in (level, row) order of S's lower part.  Row i walks its lower entries a_ik in ascending k; an
+// entry whose level (as updated so far) exceeds p is skipped, otherwise the row waits for row k, scales by its pivot
+// and visits EVERY own entry right of it: level = min(level, lev_kj + lev_ik + 1), a_ij -= a_ik * a_kj (entries of row
+// k that were dropped are published as 0 / infinite).  Afterwards the entries above level p are zeroed and the kept
+// ones counted.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_ilup(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                 T* val, int* lev, int* done, int* diag_pos, int* __restrict__ cnt,
+                                                 int p, unsigned* counter, unsigned base,
+                                                 const int* __restrict__ order)
+{
+    using B            = typename Sentinel<T>::bits;
+    const unsigned blk = take_ticket(counter, base);
+    const int64_t  t   = (int64_t)blk * kBlock + threadIdx.x;
+    if(t >= nrow)
+        return;
+    const int i  = order[t];
+    const int rs = rp[i], re = rp[i + 1];
+    int       j  = rs;
+    int       dj = rs;
+    while(dj < re && ci[dj] < i)
+        ++dj;
+    bool fin = false;
+    int  spins = 0, backoff = 1;
+    do
+    {
+        spin_guard(spins);
+        const int  j_before   = j;
+        const bool fin_before = fin;
+        if(!fin)
+        {
+            if(j < dj)
+            {
+                const int lj = lev[j];
+                if(lj > p)
+                    ++j;
+                else
+                {
+                    const int k = ci[j];
+                    if(__hip_atomic_load(done + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                    {
+                        const int kd  = __hip_atomic_load(diag_pos + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const int kre = rp[k + 1];
+                        const T   pivot = Sentinel<T>::from_bits(__hip_atomic_load(
+                            reinterpret_cast<const B*>(val + kd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        const T f = val[j] / pivot;
+                        val[j]    = f;
+                        int q     = kd + 1;
+                        for(int m = j + 1; m < re; ++m)
+                        {
+                            const int cm = ci[m];
+                            while(q < kre && ci[q] < cm)
+                                ++q;
+                            if(q >= kre)
+                                break;
+                            if(ci[q] == cm)
+                            {
+                                const int lkq = __hip_atomic_load(lev + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const T   akq = Sentinel<T>::from_bits(__hip_atomic_load(
+                                    reinterpret_cast<const B*>(val + q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                                const int l   = lkq + lj + 1;
+                                if(lev[m] > l)
+                                    lev[m] = l;
+                                val[m] -= f * akq;
+                            }
+                        }
+                        ++j;
+                    }
+                }
+            }
+            else
+            {
+                int c = 0;
+                for(int q = rs; q < re; ++q)
+                {
+                    const bool keep = lev[q] <= p;
+                    c += keep ? 1 : 0;
+                    __hip_atomic_store(reinterpret_cast<B*>(val + q), Sentinel<T>::as_bits(keep ? val[q] : (T)0),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(lev + q, keep ? lev[q] : kIlupInf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                cnt[i] = c;
+                __hip_atomic_store(diag_pos + i, dj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(done + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                fin = true;
+            }
+        }
+        backoff = poll_backoff(__ballot(!fin_before && (fin || j != j_before)) != 0ull, backoff);
+    } while(__ballot(!fin) != 0ull);
+}
+
+// The same sweep with one WAVE per row (rows of S up to 64*K entries): lane e % 64 keeps entry e of the row (column,
+// value, level) in registers, the lower entries are taken in ascending order (their value / level broadcast from the
+// owning lane), and every lane right of the pivot entry finds its column in row k by bisection -- per lower entry one
+// parallel step instead of a serial merge over the whole row.  Same operations per entry in the same order.
+__global__ __launch_bounds__(kBlock) void k_row_lengths(int nrow, const int* __restrict__ rp, int* __restrict__ len)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < nrow; row += gsz)
+        len[row] = rp[row + 1] - rp[row];
+}
+
+template <typename T, int K>
+__global__ __launch_bounds__(kBlock) void k_ilup_wave(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                      T* val, int* lev, int* done, int* diag_pos,
+                                                      int* __restrict__ cnt, int p, unsigned* counter, unsigned base,
+                                                      const int* __restrict__ order)
+{
+    using B              = typename Sentinel<T>::bits;
+    constexpr int  WPB   = kBlock / 64;
+    const unsigned blk   = take_ticket(counter, base);
+    const int      lane  = threadIdx.x & 63;
+    const int64_t  t     = (int64_t)blk * WPB + (threadIdx.x >> 6);
+    if(t >= nrow)
+        return;
+    const int i  = order[t];
+    const int rs = rp[i], re = rp[i + 1];
+    const int len = re - rs;
+    int c[K], l[K];
+    T   v[K];
+    int nlow = 0;
+#pragma unroll
+    for(int k = 0; k < K; ++k)
+    {
+        const int  e  = k * 64 + lane;
+        const bool ok = e < len;
+        c[k]          = ok ? ci[rs + e] : 0x7fffffff;
+        v[k]          = ok ? val[rs + e] : (T)0;
+        l[k]          = ok ? lev[rs + e] : kIlupInf;
+        nlow += __popcll(__ballot(ok && c[k] < i));
+    }
+    for(int a = 0; a < nlow; ++a)
+    {
+        const int ak = a >> 6, al = a & 63;
+        int       la = 0, krow = 0;
+        T         va = (T)0;
+#pragma unroll
+        for(int k = 0; k < K; ++k)
+            if(k == ak)
+            {
+                la   = __shfl(l[k], al);
+                krow = __shfl(c[k], al);
+                va   = __shfl(v[k], al);
+            }
+        if(la > p)
+            continue;
+        int spins = 0, backoff = 1;
+        while(__hip_atomic_load(done + krow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+        {
+            spin_guard(spins);
+            backoff = poll_backoff(false, backoff);
+        }
+        const int kd    = __hip_atomic_load(diag_pos + krow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int kre   = rp[krow + 1];
+        const T   pivot = Sentinel<T>::from_bits(
+            __hip_atomic_load(reinterpret_cast<const B*>(val + kd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const T f = va / pivot;
+#pragma unroll
+        for(int k = 0; k < K; ++k)
+        {
+            const int e = k * 64 + lane;
+            if(e == a)
+                v[k] = f;
+            if(e > a && e < len)
+            {
+                int lo = kd + 1, hi = kre; // first position with ci >= c[k]
+                while(lo < hi)
+                {
+                    const int mid = (lo + hi) >> 1;
+                    if(ci[mid] < c[k])
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                if(lo < kre && ci[lo] == c[k])
+                {
+                    const int lkq = __hip_atomic_load(lev + lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const T   akq = Sentinel<T>::from_bits(__hip_atomic_load(
+                        reinterpret_cast<const B*>(val + lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    const int ln  = lkq + la + 1;
+                    if(l[k] > ln)
+                        l[k] = ln;
+                    v[k] -= f * akq;
+                }
+            }
+        }
+    }
+    int kept = 0;
+#pragma unroll
+    for(int k = 0; k < K; ++k)
+    {
+        const int  e    = k * 64 + lane;
+        const bool keep = e < len && l[k] <= p;
+        kept += __popcll(__ballot(keep));
+        if(e < len)
+        {
+            __hip_atomic_store(reinterpret_cast<B*>(val + rs + e), Sentinel<T>::as_bits(keep ? v[k] : (T)0),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(lev + rs + e, keep ? l[k] : kIlupInf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if(lane == 0)
+    {
+        cnt[i] = kept;
+        __hip_atomic_store(diag_pos + i, rs + nlow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(done + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_ilup_compact(int nrow, const int* __restrict__ srp,
+                                                         const int* __restrict__ sci, const T* __restrict__ sval,
+                                                         const int* __restrict__ lev, int p,
+                                                         const int* __restrict__ rp, int* __restrict__ ci,
+                                                         T* __restrict__ val)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < nrow; row += gsz)
+    {
+        int o = rp[row];
+        for(int j = srp[row]; j < srp[row + 1]; ++j)
+            if(lev[j] <= p)
+            {
+                ci[o]  = sci[j];
+                val[o] = sval[j];
+                ++o;
+            }
+    }
+}
+
+template <typename T>
+static int ilup_t(ramd_mat_s* m, int p, bool level)
+{
+    Backend&  b = backend();
+    const int n = m->nrow;
+    // S = pattern(A^q), sorted rows: SymbolicPower(p + 1) (host :3073-3146 -- beyond 8 its loop multiplies once more).
+    // The numeric product kernels give exactly that pattern (they keep cancelled zeros); its values are not used.
+    const int   q = (p + 1 > 8) ? p + 2 : p + 1;
+    ramd_mat_s* S = nullptr;
+    RAMD_TRY(ramd_mat_clone(m, &S));
+    for(int i = 1; i < q; ++i)
+    {
+        ramd_mat_s* nx = nullptr;
+        int         s  = ramd_mat_create(m->dtype, &nx);
+        if(s == RAMD_OK)
+            s = ramd_mat_mat_mult(nx, S, m);
+        ramd_mat_destroy(S);
+        S = nx;
+        if(s != RAMD_OK)
+        {
+            if(S)
+                ramd_mat_destroy(S);
+            return s;
+        }
+    }
+    int*           lev  = nullptr;
+    int*           done = nullptr;
+    int*           cnt  = nullptr;
+    int            s    = RAMD_OK;
+    const unsigned nb   = nblocks_of(n);
+    auto           fail = [&](int code) {
+        dev_free(&lev);
+        dev_free(&done);
+        dev_free(&cnt);
+        ramd_mat_destroy(S);
+        return code;
+    };
+    if(level && (s = dev_alloc(&lev, S->nnz)) != RAMD_OK)
+        return fail(s);
+    hipLaunchKernelGGL((k_ilup_init<T>), dim3(nb), dim3(kBlock), 0, b.cur, n, S->rp, S->ci, m->rp, m->ci,
+                       (const T*)m->val, (T*)S->val, lev);
+    if(hipGetLastError() != hipSuccess)
+        return fail(RAMD_ERR_HIP);
+    if(!level)
+    {
+        // local_matrix.cpp:3985-3993: A's values on the power pattern, then ILU(0)
+        std::swap(m->rp, S->rp);
+        std::swap(m->ci, S->ci);
+        std::swap(m->val, S->val);
+        std::swap(m->nnz, S->nnz);
+        mat_free_analysis(m);
+        m->band_dist = -1;
+        (void)fail(RAMD_OK);
+        return ilu0_t<T>(m);
+    }
+    TriState* st = nullptr;
+    if((s = tri_get(S, &st)) != RAMD_OK || (s = dev_alloc(&done, n)) != RAMD_OK
+       || (s = dev_alloc(&cnt, (int64_t)n + 1)) != RAMD_OK
+       || (!S->diag_pos && (s = dev_alloc(&S->diag_pos, n)) != RAMD_OK))
+        return fail(s);
+    if(hipMemsetAsync(done, 0, sizeof(int) * (size_t)n, b.cur) != hipSuccess
+       || hipMemsetAsync(cnt, 0, sizeof(int) * ((size_t)n + 1), b.cur) != hipSuccess)
+        return fail(RAMD_ERR_HIP);
+    if(!st->l_order_cache && (s = level_order(S, st, true, &st->l_order_cache, &st->l_nlev_cache)) != RAMD_OK)
+        return fail(s);
+    // longest row of S decides: wave per row (<= 256 entries) or thread per row
+    int maxlen = 0;
+    hipLaunchKernelGGL(k_row_lengths, dim3(nb), dim3(kBlock), 0, b.cur, n, S->rp, cnt);
+    if((s = device_max_int(cnt, n, &maxlen)) != RAMD_OK)
+        return fail(s);
+    static const bool wave_rows = !(getenv("RAMD_ILUP_WAVE") && atoi(getenv("RAMD_ILUP_WAVE")) == 0);
+    if(wave_rows && maxlen <= 256)
+    {
+        const unsigned nbw = (unsigned)(((int64_t)n + kBlock / 64 - 1) / (kBlock / 64));
+#define ILUP_WAVE(K)                                                                                             \
+    hipLaunchKernelGGL((k_ilup_wave<T, K>), dim3(nbw), dim3(kBlock), 0, b.cur, n, S->rp, S->ci, (T*)S->val, lev, \
+                       done, S->diag_pos, cnt, p, st->counter, st->ticket, st->l_order_cache)
+        if(maxlen <= 64)
+            ILUP_WAVE(1);
+        else if(maxlen <= 128)
+            ILUP_WAVE(2);
+        else
+            ILUP_WAVE(4);
+#undef ILUP_WAVE
+        st->ticket += nbw;
+    }
+    else
+    {
+        hipLaunchKernelGGL((k_ilup<T>), dim3(nb), dim3(kBlock), 0, b.cur, n, S->rp, S->ci, (T*)S->val, lev, done,
+                           S->diag_pos, cnt, p, st->counter, st->ticket, st->l_order_cache);
+        st->ticket += nb;
+    }
+    if(hipGetLastError() != hipSuccess || hipStreamSynchronize(b.cur) != hipSuccess)
+        return fail(RAMD_ERR_HIP);
+    if((s = device_exclusive_scan(cnt, cnt, (int64_t)n + 1)) != RAMD_OK)
+        return fail(s);
+    int total = 0;
+    if(hipMemcpyAsync(&total, cnt + n, sizeof(int), hipMemcpyDeviceToHost, b.cur) != hipSuccess
+       || hipStreamSynchronize(b.cur) != hipSuccess)
+        return fail(RAMD_ERR_HIP);
+    if((s = mat_alloc_csr(m, n, n, total)) != RAMD_OK) // A's arrays are no longer needed
+        return fail(s);
+    if(hipMemcpyAsync(m->rp, cnt, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToDevice, b.cur) != hipSuccess)
+        return fail(RAMD_ERR_HIP);
+    hipLaunchKernelGGL((k_ilup_compact<T>), dim3(nb), dim3(kBlock), 0, b.cur, n, S->rp, S->ci, (const T*)S->val, lev,
+                       p, m->rp, m->ci, (T*)m->val);
+    if(hipGetLastError() != hipSuccess || hipStreamSynchronize(b.cur) != hipSuccess)
+        return fail(RAMD_ERR_HIP);
+    return fail(RAMD_OK);
+}
+
 // ---------------------------------------------------------------- IC(0), level order, sync-free
 // host_matrix_csr.cpp:2344-2466 on L = lower part incl. diagonal (sorted rows => the diagonal is the last entry of
 // every row).  Thread per row, rows in (level, row) order; a row waits for every row col_j < i of its pattern:
@@ -1450,6 +1823,19 @@ int ramd_mat_ilu0_factorize(ramd_mat_t m)
     if(m->nrow != m->ncol || m->nnz <= 0)
         RAMD_FAIL(RAMD_ERR_ARG, "ILU0Factorize: need a square, non-empty matrix (the reference asserts)");
     return (m->dtype == RAMD_F64) ? ilu0_t<double>(m) : ilu0_t<float>(m);
+}
+
+int ramd_mat_ilup_factorize(ramd_mat_t m, int p, int level)
+{
+    if(!m || p < 0)
+        RAMD_FAIL(RAMD_ERR_ARG, "ILUpFactorize: matrix handle, p >= 0");
+    if(p == 0)
+        return ramd_mat_ilu0_factorize(m); // local_matrix.cpp:3920-3923
+    if(m->format != RAMD_CSR)
+        return RAMD_ERR_UNSUPPORTED;
+    if(m->nrow != m->ncol || m->nnz <= 0)
+        RAMD_FAIL(RAMD_ERR_ARG, "ILUpFactorize: need a square, non-empty matrix");
+    return (m->dtype == RAMD_F64) ? ilup_t<double>(m, p, level != 0) : ilup_t<float>(m, p, level != 0);
 }
 
 int ramd_mat_ic_factorize(ramd_mat_t m, ramd_vec_t inv_diag)

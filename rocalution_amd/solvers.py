@@ -68,8 +68,10 @@ class ILU(_Precond):
     kind = PC_ILU0
 
     def Set(self, p, level=True):
-        if p != 0:
-            raise ValueError("only ILU(0) is provided by this backend")
+        """ILU(p) (preconditioner.cpp:420-447): fill levels on the pattern of A^(p+1), or (level=False) that whole pattern"""
+        if p < 0:
+            raise ValueError("ILU(p): p >= 0")
+        self.params = (float(p), 1.0 if level else 0.0, 0.0)
 
 
 class GS(_Precond):

@@ -5,7 +5,7 @@
 //
 //   krylov_driver <matrix.mtx | poisson:N> <solver> [precond] [format] [param]
 //     solver : cg fcg cr gmres fgmres bicgstab bicgstabl qmrcgstab idr chebyshev fixedpoint mixed
-//     precond: none jacobi gs sgs ilu mcgs mcsgs mcilu          (default jacobi; "mixed" accepts none|jacobi)
+//     precond: none jacobi gs sgs ilu ilu1 ilu2 ic fsai spai tns as ras block blockdiag variable mcgs mcsgs mcilu          (default jacobi; "mixed" accepts none|jacobi)
 //     format : csr ell hyb dia      (the operator is converted AFTER Build(), as the reference's tests do)
 //     param  : restart length (gmres/fgmres), l (bicgstabl), s (idr)
 // Prints the reference's solver log and one machine-readable RESULT line.
@@ -30,6 +30,12 @@ static std::unique_ptr<AnySolver> make_precond(const std::string& p)
     if(p == "sgs") return std::unique_ptr<AnySolver>(new SGS<Mat, Vec, double>);
     if(p == "ic") return std::unique_ptr<AnySolver>(new IC<Mat, Vec, double>);
     if(p == "ilu") return std::unique_ptr<AnySolver>(new ILU<Mat, Vec, double>);
+    if(p == "ilu1" || p == "ilu2") // ILU(p) with fill levels
+    {
+        ILU<Mat, Vec, double>* q = new ILU<Mat, Vec, double>;
+        q->Set(p == "ilu1" ? 1 : 2);
+        return std::unique_ptr<AnySolver>(q);
+    }
     if(p == "mcgs") return std::unique_ptr<AnySolver>(new MultiColoredGS<Mat, Vec, double>);
     if(p == "mcsgs") return std::unique_ptr<AnySolver>(new MultiColoredSGS<Mat, Vec, double>);
     if(p == "mcilu") return std::unique_ptr<AnySolver>(new MultiColoredILU<Mat, Vec, double>);

@@ -201,6 +201,32 @@ def test_spai_matrix_vs_golden(ra, name):
         eq(va, g["spai_M_val"])
 
 
+@pytest.mark.parametrize("name", CASES)
+def test_ilup_factors_vs_golden(ra, name):
+    """ILU(p): fill levels on the pattern of A^(p+1) (p = 1, 2) and ILU(0) on that whole pattern (level=False) --
+    pattern and values identical to the genuine library's host factorisation"""
+    g = load_golden(name)
+    for key, p, level in (("ilu1", 1, True), ("ilu2", 2, True), ("ilu1n", 1, False)):
+        LU = _mat(ra, g)
+        LU.ILUpFactorize(p, level)
+        rp, ci, va = LU.CopyToCSR()
+        eq(rp, g[key + "_rowptr"]); eq(ci, g[key + "_col"]); eq(va, g[key + "_val"])
+
+
+def test_ilup_thread_per_row_path_in_a_fresh_process():
+    """rows of the power pattern beyond 256 entries take the thread-per-row sweep; forced here (switch read once per
+    process) on the golden matrices -- same arrays"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-q", "-x",
+                        "-m", "gpu", "-k", "ilup_factors_vs_golden"], env=dict(os.environ, RAMD_ILUP_WAVE="0"),
+                       cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "5 passed" in out, out[-3000:]
+
+
 def test_fsai_factor_vs_golden(ra):
     """FSAI(1): per-row dense LU on the lower pattern and the scaling -- factor arrays identical to the genuine library"""
     for name in ("gr3030", "poisson8", "lap2d7"):

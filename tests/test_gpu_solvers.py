@@ -60,7 +60,7 @@ def _mk(S, tag, dtype=np.float64):
         solver.Set(0.05, 16.0); solver.InitMaxIter(60)
     if tag == "chebyshev_jacobi":
         solver.Set(0.01, 2.0); solver.InitMaxIter(60)
-    pc = {"none": None, "jacobi": S.Jacobi, "ilu0": S.ILU, "mcsgs": S.MultiColoredSGS, "mcgs": S.MultiColoredGS,
+    pc = {"none": None, "jacobi": S.Jacobi, "ilu0": S.ILU, "ilu1": S.ILU, "mcsgs": S.MultiColoredSGS, "mcgs": S.MultiColoredGS,
           "mcilu": S.MultiColoredILU, "gs": S.GS, "sgs": S.SGS, "ic": S.IC, "tns": S.TNS, "tnsx": S.TNS, "fsai": S.FSAI, "spai": S.SPAI,
           "aicheb": S.AIChebyshev}[tag.split("_")[1]]
     if pc is not None:
@@ -69,6 +69,8 @@ def _mk(S, tag, dtype=np.float64):
             p.Set(3, 0.05, 16.0); solver.InitMaxIter(300)
         if tag.split("_")[1] == "tnsx":
             p.Set(False)  # explicit matrix
+        if tag.split("_")[1] == "ilu1":
+            p.Set(1)
         solver.SetPreconditioner(p)
     return solver
 
@@ -101,7 +103,7 @@ def test_preconditioner_apply_bit_exact(ra, S, name):
     A = ra.LocalMatrix(); A.SetDataPtrCSR(g["rowptr"], g["col"], g["val"])
     n = A.GetM()
     x = ra.LocalVector(data=g["x"])
-    for tag, key in (("cg_jacobi", "pc_jacobi"), ("cg_ilu0", "pc_ilu0"), ("cg_mcsgs", "pc_mcsgs"), ("cg_gs", "pc_gs"),
+    for tag, key in (("cg_jacobi", "pc_jacobi"), ("cg_ilu0", "pc_ilu0"), ("cg_ilu1", "pc_ilu1"), ("cg_mcsgs", "pc_mcsgs"), ("cg_gs", "pc_gs"),
                      ("cg_sgs", "pc_sgs"), ("cg_ic", "pc_ic"), ("cg_aicheb", "pc_aicheb"), ("cg_tns", "pc_tns"),
                      ("cg_tnsx", "pc_tns_expl"), ("cg_fsai", "pc_fsai"), ("bicgstab_spai", "pc_spai")):
         if key not in g:  # IC only on the SPD cases (the reference asserts on a breakdown)
@@ -198,7 +200,7 @@ def test_solvers_with_iterative_triangular_solves(ra, S, name, tag):
     ls.Clear()
 
 
-SOLVER_TAGS = ["cg_none", "cg_jacobi", "gmres_none", "gmres_ilu0", "bicgstab_none", "bicgstab_mcsgs", "bicgstab_mcgs",
+SOLVER_TAGS = ["cg_none", "cg_jacobi", "gmres_none", "gmres_ilu0", "gmres_ilu1", "bicgstab_none", "bicgstab_mcsgs", "bicgstab_mcgs",
                "gmres_mcilu", "fcg_none", "fcg_jacobi", "fcg_mcsgs", "cr_none", "cr_jacobi", "fgmres_none",
                "fgmres_ilu0", "bicgstabl_none", "bicgstabl3_jacobi", "qmrcgstab_none", "qmrcgstab_mcsgs", "idr_none",
                "idr2_jacobi", "cg_sgs", "cg_ic", "cg_tns", "cg_aicheb", "cg_fsai", "bicgstab_spai", "bicgstab_gs", "fixedpoint_jacobi", "chebyshev_none", "chebyshev_jacobi"]

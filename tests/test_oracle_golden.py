@@ -150,6 +150,11 @@ def test_diag_ilu_trisolve(oracle, name):
     eq(g["ilu0_rowptr"], rp); eq(g["ilu0_col"], ci)
     eq(lu, g["ilu0_val"])
     eq(oracle.lusolve(rp, ci, lu, x), g["lusolve"])
+    for key, p, level in (("ilu1", 1, True), ("ilu2", 2, True), ("ilu1n", 1, False)):  # ILU(p) on the power pattern
+        prp, pci, pva = oracle.ilup(rp, ci, va, p, level)
+        eq(prp, g[key + "_rowptr"]); eq(pci, g[key + "_col"]); eq(pva, g[key + "_val"])
+    prp, pci, pva = oracle.ilup(rp, ci, va, 1)
+    eq(oracle.lusolve(prp, pci, pva, x), g["pc_ilu1"])
     eq(oracle.lsolve(rp, ci, va, x, False), g["lsolve_nonunit"])
     eq(oracle.usolve(rp, ci, va, x, False), g["usolve_nonunit"])
 
