@@ -1173,16 +1173,16 @@ public:
         this->MoveToAccelerator();
         RAMD_CHECK(ramd_mat_mat_mult(this->dev_, A.dev_, B.dev_));
     }
-    // factorised sparse approximate inverse on the lower pattern of this matrix (this becomes the factor)
+    // factorised sparse approximate inverse on the lower pattern of this matrix^power (this becomes the factor)
     void FSAI(int power, const LocalMatrix<ValueType>* pattern)
     {
         this->need_accel_("FSAI");
-        if(pattern != NULL || power > 1)
+        if(pattern != NULL)
         {
-            LOG_INFO("LocalMatrix::FSAI(): only the pattern of the operator itself (power 1) is provided by this backend");
+            LOG_INFO("LocalMatrix::FSAI(): an external pattern is not provided by this backend (power >= 1 is)");
             FATAL_ERROR(__FILE__, __LINE__);
         }
-        RAMD_CHECK(ramd_mat_fsai(this->dev_, 1));
+        RAMD_CHECK(ramd_mat_fsai(this->dev_, power));
     }
     // sparse approximate inverse on the pattern of this matrix (this becomes M ~ A^-1)
     void SPAI(void)

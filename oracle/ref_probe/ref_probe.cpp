@@ -498,6 +498,10 @@ static int cmd_gen(const std::string& in, const std::string& out)
         G.CloneFrom(mat);
         G.FSAI(1, NULL);
         dump_csr("fsai_G", G);
+        MatD G2; // pattern of A^2
+        G2.CloneFrom(mat);
+        G2.FSAI(2, NULL);
+        dump_csr("fsai2_G", G2);
     }
     {
         SPAI<MatD, VecD, double> p;

@@ -228,6 +228,8 @@ struct LocalSolver : SolverBase
             pcs.aicheb.Set((int)p0, (T)p1, (T)p2);
         else if(pc_kind == RAMD_PC_TNS)
             pcs.tns.Set(p0 != 0.0);
+        else if(pc_kind == RAMD_PC_FSAI) // FSAI::Set(power)
+            pcs.fsai.Set((int)p0);
         else if(pc_kind == RAMD_PC_ILU0) // ILU::Set(p, level)
             pcs.ilu.Set((int)p0, p1 != 0.0);
     }

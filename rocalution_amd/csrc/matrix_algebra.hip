@@ -1287,6 +1287,33 @@ static int mat_mult_t(ramd_mat_s* c, const ramd_mat_s* a, const ramd_mat_s* bm)
     return RAMD_OK;
 }
 
+// pattern of A^q with sorted rows: SymbolicPower(q) (host_matrix_csr.cpp:3073-3146 -- beyond 8 its loop multiplies once
+// more).  The numeric product kernels give exactly that pattern (cancelled zeros stay); the values are not meaningful.
+int mat_symbolic_power(const ramd_mat_s* a, int q, ramd_mat_s** out)
+{
+    ramd_mat_s* A = const_cast<ramd_mat_s*>(a);
+    const int   nmul = (q > 8) ? q : q - 1;
+    ramd_mat_s* S    = nullptr;
+    RAMD_TRY(ramd_mat_clone(A, &S));
+    for(int i = 0; i < nmul; ++i)
+    {
+        ramd_mat_s* nx = nullptr;
+        int         s  = ramd_mat_create(a->dtype, &nx);
+        if(s == RAMD_OK)
+            s = ramd_mat_mat_mult(nx, S, A);
+        ramd_mat_destroy(S);
+        S = nx;
+        if(s != RAMD_OK)
+        {
+            if(S)
+                ramd_mat_destroy(S);
+            return s;
+        }
+    }
+    *out = S;
+    return RAMD_OK;
+}
+
 } // namespace ramd
 
 using namespace ramd;
@@ -1324,14 +1351,28 @@ int ramd_mat_sort(ramd_mat_t m)
 int ramd_mat_fsai(ramd_mat_t m, int power)
 {
     RAMD_TRY(need_csr(m, "FSAI"));
-    if(power != 1)
-        RAMD_FAIL(RAMD_ERR_UNSUPPORTED, "FSAI: only the pattern of the operator itself (power 1) is provided");
+    if(power < 1)
+        RAMD_FAIL(RAMD_ERR_ARG, "FSAI: power >= 1");
     if(m->nrow != m->ncol || m->nnz <= 0)
         RAMD_FAIL(RAMD_ERR_ARG, "FSAI: square, non-empty matrix expected");
     Backend&   b = backend();
     ramd_mat_t L = nullptr;
     RAMD_TRY(ramd_mat_create(m->dtype, &L));
-    int s = ramd_mat_extract_tri(m, L, 0, 1); // ExtractLDiagonal
+    int s = RAMD_OK;
+    if(power > 1) // host_matrix_csr.cpp:6532-6538: the lower part of the pattern of A^power, values zero
+    {
+        ramd_mat_s* structure = nullptr;
+        s                     = ramd::mat_symbolic_power(m, power, &structure);
+        if(s == RAMD_OK)
+            s = ramd_mat_extract_tri(structure, L, 0, 1);
+        if(structure)
+            ramd_mat_destroy(structure);
+        if(s == RAMD_OK
+           && hipMemsetAsync(L->val, 0, (size_t)L->nnz * val_size(m->dtype), b.cur) != hipSuccess)
+            s = RAMD_ERR_HIP;
+    }
+    else
+        s = ramd_mat_extract_tri(m, L, 0, 1); // ExtractLDiagonal
     long long* soff    = nullptr;
     void*      scratch = nullptr;
     long long  total   = 0;

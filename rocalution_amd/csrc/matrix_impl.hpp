@@ -25,6 +25,9 @@ void prof_spmv_end();
 void tri_release(ramd_mat_s* m);
 int  mat_transpose(const ramd_mat_s* m, ramd_mat_s* t); // t = m^T, rows sorted
 
+// matrix_algebra.hip: *out = new matrix with the (row-sorted) pattern of a^q, SymbolicPower(q)
+int mat_symbolic_power(const ramd_mat_s* a, int q, ramd_mat_s** out);
+
 // blocksched.hip: hyperplane order of the row blocks for the natural-order sync-free sweeps (nullptr: natural)
 int block_schedule(const ramd_mat_s* m, bool lower, int** order_out);
 

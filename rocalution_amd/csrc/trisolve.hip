@@ -1077,26 +1077,9 @@ static int ilup_t(ramd_mat_s* m, int p, bool level)
 {
     Backend&  b = backend();
     const int n = m->nrow;
-    // S = pattern(A^q), sorted rows: SymbolicPower(p + 1) (host :3073-3146 -- beyond 8 its loop multiplies once more).
-    // The numeric product kernels give exactly that pattern (they keep cancelled zeros); its values are not used.
-    const int   q = (p + 1 > 8) ? p + 2 : p + 1;
+    // S = pattern(A^(p+1)), sorted rows (local_matrix.cpp:3931-3933)
     ramd_mat_s* S = nullptr;
-    RAMD_TRY(ramd_mat_clone(m, &S));
-    for(int i = 1; i < q; ++i)
-    {
-        ramd_mat_s* nx = nullptr;
-        int         s  = ramd_mat_create(m->dtype, &nx);
-        if(s == RAMD_OK)
-            s = ramd_mat_mat_mult(nx, S, m);
-        ramd_mat_destroy(S);
-        S = nx;
-        if(s != RAMD_OK)
-        {
-            if(S)
-                ramd_mat_destroy(S);
-            return s;
-        }
-    }
+    RAMD_TRY(mat_symbolic_power(m, p + 1, &S));
     int*           lev  = nullptr;
     int*           done = nullptr;
     int*           cnt  = nullptr;

@@ -125,6 +125,12 @@ class FSAI(_Precond):
     """factorised sparse approximate inverse on the lower pattern of the operator (preconditioner_ai.cpp:217-361)"""
     kind = PC_FSAI
 
+    def Set(self, power):
+        """pattern of the factor: lower part of the pattern of A^power (preconditioner_ai.cpp:253-262)"""
+        if power < 1:
+            raise ValueError("FSAI: power >= 1")
+        self.params = (float(power), 0.0, 0.0)
+
 
 class TNS(_Precond):
     """truncated Neumann series (preconditioner_ai.cpp:477-713): implicit (four triangular SpMVs) or explicit matrix"""

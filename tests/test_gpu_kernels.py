@@ -235,6 +235,10 @@ def test_fsai_factor_vs_golden(ra):
         A.FSAI(1)
         rp, ci, va = A.CopyToCSR()
         eq(rp, g["fsai_G_rowptr"]); eq(ci, g["fsai_G_col"]); eq(va, g["fsai_G_val"])
+        A2 = _mat(ra, g)
+        A2.FSAI(2)  # lower part of the pattern of A^2
+        rp, ci, va = A2.CopyToCSR()
+        eq(rp, g["fsai2_G_rowptr"]); eq(ci, g["fsai2_G_col"]); eq(va, g["fsai2_G_val"])
 
 
 @pytest.mark.parametrize("lds", ["1", "0", "0+chunks"])
