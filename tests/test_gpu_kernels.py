@@ -213,6 +213,34 @@ def test_ilup_factors_vs_golden(ra, name):
         eq(rp, g[key + "_rowptr"]); eq(ci, g[key + "_col"]); eq(va, g[key + "_val"])
 
 
+@pytest.mark.parametrize("p", [1, 2])
+def test_ilup_product_property_poisson48(ra, p):
+    """size-independent property of an incomplete factorisation with fill levels: (L U)_ij = a_ij on the retained
+    pattern (0 on the fill entries), checked on the 48^3 Poisson operator with the host's sparse product"""
+    import scipy.sparse as sp
+    A = ra.LocalMatrix(); A.GenPoisson7(48)
+    n = A.GetM()
+    arp, aci, ava = A.CopyToCSR()
+    F = ra.LocalMatrix(); F.CloneFrom(A)
+    F.ILUpFactorize(p)
+    rp, ci, va = F.CopyToCSR()
+    assert len(ci) > len(aci) and np.all(np.diff(rp) > 0)
+    Fm = sp.csr_matrix((va, ci, rp), shape=(n, n))
+    L = sp.tril(Fm, -1).tocsr() + sp.identity(n, format="csr")
+    U = sp.triu(Fm, 0).tocsr()
+    P = (L @ U).tocsr()
+    Am = sp.csr_matrix((ava, aci, arp), shape=(n, n))
+    mask = sp.csr_matrix((np.ones(len(ci)), ci, rp), shape=(n, n))
+    D = (P - Am).multiply(mask)
+    assert abs(D).max() < 1e-12
+    # the factor has more entries than the pattern of A and fewer than the whole power pattern
+    S = Am.copy(); S.data[:] = 1.0
+    Sp = S
+    for _ in range(p):
+        Sp = (Sp @ S).tocsr()
+    assert len(ci) <= Sp.nnz
+
+
 def test_ilup_thread_per_row_path_in_a_fresh_process():
     """rows of the power pattern beyond 256 entries take the thread-per-row sweep; forced here (switch read once per
     process) on the golden matrices -- same arrays"""
