@@ -1179,8 +1179,8 @@ public:
         this->need_accel_("FSAI");
         if(pattern != NULL)
         {
-            LOG_INFO("LocalMatrix::FSAI(): an external pattern is not provided by this backend (power >= 1 is)");
-            FATAL_ERROR(__FILE__, __LINE__);
+            RAMD_CHECK(ramd_mat_fsai_pattern(this->dev_, pattern->dev_));
+            return;
         }
         RAMD_CHECK(ramd_mat_fsai(this->dev_, power));
     }

@@ -306,8 +306,9 @@ int ramd_mat_amg_unsmoothed_prolong(ramd_mat_t m, ramd_vec_t aggregates, ramd_ve
 int ramd_mat_amg_smoothed_prolong(ramd_mat_t m, double relax, int lumping_strat, ramd_vec_t connections,
                                   ramd_vec_t aggregates, ramd_vec_t aggregate_root_nodes, ramd_mat_t prolong);
 /* FSAI (host_matrix_csr.cpp:6514-6662): m becomes the factorised sparse approximate inverse factor on the lower pattern
- * of the operator's power (power >= 1: pattern of A^power, :6532-6538; external patterns are not provided) */
+ * of the operator's power (power >= 1: pattern of A^power, :6532-6538), or of a pattern matrix handed in */
 int ramd_mat_fsai(ramd_mat_t m, int power);
+int ramd_mat_fsai_pattern(ramd_mat_t m, ramd_mat_t pattern); /* FSAI(power, pattern != NULL), :6525-6531 */
 /* SPAI (host_matrix_csr.cpp:6665-6780): m becomes the sparse approximate inverse on its own pattern (per row a dense
  * least-squares problem solved by Householder QR, host_matrix_dense.cpp:361-520) */
 int ramd_mat_spai(ramd_mat_t m);

@@ -502,6 +502,12 @@ static int cmd_gen(const std::string& in, const std::string& out)
         G2.CloneFrom(mat);
         G2.FSAI(2, NULL);
         dump_csr("fsai2_G", G2);
+        MatD pat, G3; // external pattern: the ILU(1) factor's
+        pat.CloneFrom(mat);
+        pat.ILUpFactorize(1, true);
+        G3.CloneFrom(mat);
+        G3.FSAI(1, &pat);
+        dump_csr("fsai3_G", G3);
     }
     {
         SPAI<MatD, VecD, double> p;

@@ -311,9 +311,12 @@ class LocalMatrix:
         """this becomes the sparse approximate inverse on its own pattern (host_matrix_csr.cpp:6665-6780)"""
         capi.check(_lib().ramd_mat_spai(self._h))
 
-    def FSAI(self, power=1):
-        """this becomes the FSAI factor on its own lower pattern (host_matrix_csr.cpp:6514-6662)"""
-        capi.check(_lib().ramd_mat_fsai(self._h, int(power)))
+    def FSAI(self, power=1, pattern=None):
+        """this becomes the FSAI factor on the lower pattern of A^power, or of `pattern` (host_matrix_csr.cpp:6514-6662)"""
+        if pattern is not None:
+            capi.check(_lib().ramd_mat_fsai_pattern(self._h, pattern._h))
+        else:
+            capi.check(_lib().ramd_mat_fsai(self._h, int(power)))
 
     def TripleMatrixProduct(self, R, A, P):
         tmp = LocalMatrix(self.dtype)

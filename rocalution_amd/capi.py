@@ -136,6 +136,7 @@ SIGNATURES = {
     "ramd_mat_amg_unsmoothed_prolong": (i32, [mat_t, vec_t, vec_t, mat_t]),
     "ramd_mat_amg_smoothed_prolong": (i32, [mat_t, f64, i32, vec_t, vec_t, vec_t, mat_t]),
     "ramd_mat_fsai": (i32, [mat_t, i32]),
+    "ramd_mat_fsai_pattern": (i32, [mat_t, mat_t]),
     "ramd_mat_spai": (i32, [mat_t]),
     "ramd_mat_diag_mult": (i32, [mat_t, vec_t, i32]),
     "ramd_mat_sort": (i32, [mat_t]),

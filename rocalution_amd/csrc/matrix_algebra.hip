@@ -1348,7 +1348,22 @@ int ramd_mat_sort(ramd_mat_t m)
     return RAMD_OK;
 }
 
+static int fsai_impl(ramd_mat_t m, int power, ramd_mat_t pattern);
+
 int ramd_mat_fsai(ramd_mat_t m, int power)
+{
+    return fsai_impl(m, power, nullptr);
+}
+
+int ramd_mat_fsai_pattern(ramd_mat_t m, ramd_mat_t pattern)
+{
+    RAMD_TRY(need_csr(pattern, "FSAI pattern"));
+    if(!m || pattern == m || pattern->nrow != m->nrow || pattern->ncol != m->ncol || pattern->dtype != m->dtype)
+        RAMD_FAIL(RAMD_ERR_ARG, "FSAI: pattern of the operator's shape and value type, distinct from it");
+    return fsai_impl(m, 1, pattern);
+}
+
+static int fsai_impl(ramd_mat_t m, int power, ramd_mat_t pattern)
 {
     RAMD_TRY(need_csr(m, "FSAI"));
     if(power < 1)
@@ -1359,7 +1374,9 @@ int ramd_mat_fsai(ramd_mat_t m, int power)
     ramd_mat_t L = nullptr;
     RAMD_TRY(ramd_mat_create(m->dtype, &L));
     int s = RAMD_OK;
-    if(power > 1) // host_matrix_csr.cpp:6532-6538: the lower part of the pattern of A^power, values zero
+    if(pattern) // host_matrix_csr.cpp:6525-6531: the lower part of the caller's pattern (its values stay where no row system is solved)
+        s = ramd_mat_extract_tri(pattern, L, 0, 1);
+    else if(power > 1) // host_matrix_csr.cpp:6532-6538: the lower part of the pattern of A^power, values zero
     {
         ramd_mat_s* structure = nullptr;
         s                     = ramd::mat_symbolic_power(m, power, &structure);

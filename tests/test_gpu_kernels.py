@@ -267,6 +267,11 @@ def test_fsai_factor_vs_golden(ra):
         A2.FSAI(2)  # lower part of the pattern of A^2
         rp, ci, va = A2.CopyToCSR()
         eq(rp, g["fsai2_G_rowptr"]); eq(ci, g["fsai2_G_col"]); eq(va, g["fsai2_G_val"])
+        pat = _mat(ra, g); pat.ILUpFactorize(1)  # an external pattern: the ILU(1) factor's
+        A3 = _mat(ra, g)
+        A3.FSAI(1, pat)
+        rp, ci, va = A3.CopyToCSR()
+        eq(rp, g["fsai3_G_rowptr"]); eq(ci, g["fsai3_G_col"]); eq(va, g["fsai3_G_val"])
 
 
 @pytest.mark.parametrize("lds", ["1", "0", "0+chunks"])
