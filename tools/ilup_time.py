@@ -9,7 +9,7 @@ ra.init_rocalution()
 A = ra.LocalMatrix(); A.GenPoisson7(N)
 n = A.GetM()
 ones = ra.LocalVector(data=np.ones(n)); rhs = ra.LocalVector(); rhs.Allocate("", n); A.Apply(ones, rhs)
-for rep in range(2):
+for rep in range(int(os.environ.get("REPS", "2"))):
     ls = S.GMRES(); pc = S.ILU(); pc.Set(p, level); ls.SetPreconditioner(pc); ls.SetOperator(A)
     ls.Init(1e-15, 1e-8, 1e8, 300)
     t0 = time.time(); ls.Build(); ra.sync(); tb = time.time() - t0
