@@ -942,7 +942,7 @@ __global__ __launch_bounds__(kBlock) void k_row_lengths(int nrow, const int* __r
         len[row] = rp[row + 1] - rp[row];
 }
 
-template <typename T, int K>
+template <typename T, int K, bool ILU0 = false> // ILU0: no levels (lev == nullptr), zero pivots skipped (host :2132)
 __global__ __launch_bounds__(kBlock) void k_ilup_wave(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
                                                       T* val, int* lev, int* done, int* diag_pos,
                                                       int* __restrict__ cnt, int p, unsigned* counter, unsigned base,
@@ -968,7 +968,7 @@ __global__ __launch_bounds__(kBlock) void k_ilup_wave(int nrow, const int* __res
         const bool ok = e < len;
         c[k]          = ok ? ci[rs + e] : 0x7fffffff;
         v[k]          = ok ? val[rs + e] : (T)0;
-        l[k]          = ok ? lev[rs + e] : kIlupInf;
+        l[k]          = ILU0 ? 0 : (ok ? lev[rs + e] : kIlupInf);
         nlow += __popcll(__ballot(ok && c[k] < i));
     }
     for(int a = 0; a < nlow; ++a)
@@ -996,6 +996,8 @@ __global__ __launch_bounds__(kBlock) void k_ilup_wave(int nrow, const int* __res
         const int kre   = rp[krow + 1];
         const T   pivot = Sentinel<T>::from_bits(
             __hip_atomic_load(reinterpret_cast<const B*>(val + kd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if(ILU0 && pivot == (T)0)
+            continue;
         const T f = va / pivot;
 #pragma unroll
         for(int k = 0; k < K; ++k)
@@ -1016,12 +1018,14 @@ __global__ __launch_bounds__(kBlock) void k_ilup_wave(int nrow, const int* __res
                 }
                 if(lo < kre && ci[lo] == c[k])
                 {
-                    const int lkq = __hip_atomic_load(lev + lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const T   akq = Sentinel<T>::from_bits(__hip_atomic_load(
+                    const T akq = Sentinel<T>::from_bits(__hip_atomic_load(
                         reinterpret_cast<const B*>(val + lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    const int ln  = lkq + la + 1;
-                    if(l[k] > ln)
-                        l[k] = ln;
+                    if(!ILU0)
+                    {
+                        const int ln = __hip_atomic_load(lev + lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + la + 1;
+                        if(l[k] > ln)
+                            l[k] = ln;
+                    }
                     v[k] -= f * akq;
                 }
             }
@@ -1038,13 +1042,15 @@ __global__ __launch_bounds__(kBlock) void k_ilup_wave(int nrow, const int* __res
         {
             __hip_atomic_store(reinterpret_cast<B*>(val + rs + e), Sentinel<T>::as_bits(keep ? v[k] : (T)0),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(lev + rs + e, keep ? l[k] : kIlupInf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if(!ILU0)
+                __hip_atomic_store(lev + rs + e, keep ? l[k] : kIlupInf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if(lane == 0)
     {
-        cnt[i] = kept;
+        if(!ILU0)
+            cnt[i] = kept;
         __hip_atomic_store(diag_pos + i, rs + nlow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(done + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1070,6 +1076,55 @@ __global__ __launch_bounds__(kBlock) void k_ilup_compact(int nrow, const int* __
                 ++o;
             }
     }
+}
+
+// ILU(0) on a pattern with long rows (the power pattern of ILU(p, level = false)): the wave-per-row sweep without
+// levels; rows beyond 256 entries -> the thread-per-row kernel
+template <typename T>
+static int ilu0_long_rows_t(ramd_mat_s* m)
+{
+    Backend&       b   = backend();
+    const int      n   = m->nrow;
+    const unsigned nb  = nblocks_of(n);
+    int*           len = nullptr;
+    int            maxlen = 0;
+    RAMD_TRY(dev_alloc(&len, n));
+    hipLaunchKernelGGL(k_row_lengths, dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, len);
+    int s = device_max_int(len, n, &maxlen);
+    static const bool wave_rows = !(getenv("RAMD_ILUP_WAVE") && atoi(getenv("RAMD_ILUP_WAVE")) == 0);
+    if(s != RAMD_OK || !wave_rows || maxlen > 256)
+    {
+        dev_free(&len);
+        return s != RAMD_OK ? s : ilu0_t<T>(m);
+    }
+    int*      done = len; // reused as the flags
+    TriState* st   = nullptr;
+    if((s = tri_get(m, &st)) != RAMD_OK || (!m->diag_pos && (s = dev_alloc(&m->diag_pos, n)) != RAMD_OK)
+       || (!st->l_order_cache && (s = level_order(m, st, true, &st->l_order_cache, &st->l_nlev_cache)) != RAMD_OK))
+    {
+        dev_free(&done);
+        return s;
+    }
+    hipError_t     e   = hipMemsetAsync(done, 0, sizeof(int) * (size_t)n, b.cur);
+    const unsigned nbw = (unsigned)(((int64_t)n + kBlock / 64 - 1) / (kBlock / 64));
+#define ILU0_WAVE(K)                                                                                                 \
+    hipLaunchKernelGGL((k_ilup_wave<T, K, true>), dim3(nbw), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (T*)m->val,    \
+                       (int*)nullptr, done, m->diag_pos, (int*)nullptr, 0, st->counter, st->ticket, st->l_order_cache)
+    if(maxlen <= 64)
+        ILU0_WAVE(1);
+    else if(maxlen <= 128)
+        ILU0_WAVE(2);
+    else
+        ILU0_WAVE(4);
+#undef ILU0_WAVE
+    st->ticket += nbw;
+    if(e == hipSuccess)
+        e = hipGetLastError();
+    if(e == hipSuccess)
+        e = hipStreamSynchronize(b.cur);
+    dev_free(&done);
+    RAMD_HIP(e);
+    return RAMD_OK;
 }
 
 template <typename T>
@@ -1108,7 +1163,7 @@ static int ilup_t(ramd_mat_s* m, int p, bool level)
         mat_free_analysis(m);
         m->band_dist = -1;
         (void)fail(RAMD_OK);
-        return ilu0_t<T>(m);
+        return ilu0_long_rows_t<T>(m);
     }
     TriState* st = nullptr;
     if((s = tri_get(S, &st)) != RAMD_OK || (s = dev_alloc(&done, n)) != RAMD_OK
