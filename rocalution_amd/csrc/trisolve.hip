@@ -935,6 +935,7 @@ __global__ __launch_bounds__(kBlock) void k_ilup(int nrow, const int* __restrict
 // value, level) in registers, the lower entries are taken in ascending order (their value / level broadcast from the
 // owning lane), and every lane right of the pivot entry finds its column in row k by bisection -- per lower entry one
 // parallel step instead of a serial merge over the whole row.  Same operations per entry in the same order.
+constexpr unsigned kIlupWaveChunk = 1u << 23; // workgroups per launch of the wave-per-row sweeps (2^31 threads)
 __global__ __launch_bounds__(kBlock) void k_row_lengths(int nrow, const int* __restrict__ rp, int* __restrict__ len)
 {
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
@@ -946,13 +947,13 @@ template <typename T, int K, bool ILU0 = false> // ILU0: no levels (lev == nullp
 __global__ __launch_bounds__(kBlock) void k_ilup_wave(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
                                                       T* val, int* lev, int* done, int* diag_pos,
                                                       int* __restrict__ cnt, int p, unsigned* counter, unsigned base,
-                                                      const int* __restrict__ order)
+                                                      const int* __restrict__ order, int64_t row_base)
 {
     using B              = typename Sentinel<T>::bits;
     constexpr int  WPB   = kBlock / 64;
     const unsigned blk   = take_ticket(counter, base);
     const int      lane  = threadIdx.x & 63;
-    const int64_t  t     = (int64_t)blk * WPB + (threadIdx.x >> 6);
+    const int64_t  t     = row_base + (int64_t)blk * WPB + (threadIdx.x >> 6); // launches of <= 2^23 workgroups
     if(t >= nrow)
         return;
     const int i  = order[t];
@@ -1107,17 +1108,22 @@ static int ilu0_long_rows_t(ramd_mat_s* m)
     }
     hipError_t     e   = hipMemsetAsync(done, 0, sizeof(int) * (size_t)n, b.cur);
     const unsigned nbw = (unsigned)(((int64_t)n + kBlock / 64 - 1) / (kBlock / 64));
-#define ILU0_WAVE(K)                                                                                                 \
-    hipLaunchKernelGGL((k_ilup_wave<T, K, true>), dim3(nbw), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (T*)m->val,    \
-                       (int*)nullptr, done, m->diag_pos, (int*)nullptr, 0, st->counter, st->ticket, st->l_order_cache)
-    if(maxlen <= 64)
-        ILU0_WAVE(1);
-    else if(maxlen <= 128)
-        ILU0_WAVE(2);
-    else
-        ILU0_WAVE(4);
+#define ILU0_WAVE(K)                                                                                               \
+    hipLaunchKernelGGL((k_ilup_wave<T, K, true>), dim3(nbc), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (T*)m->val,  \
+                       (int*)nullptr, done, m->diag_pos, (int*)nullptr, 0, st->counter, st->ticket,                \
+                       st->l_order_cache, (int64_t)b0 * (kBlock / 64))
+    for(unsigned b0 = 0; b0 < nbw; b0 += kIlupWaveChunk) // a launch holds < 2^32 threads
+    {
+        const unsigned nbc = std::min(kIlupWaveChunk, nbw - b0);
+        if(maxlen <= 64)
+            ILU0_WAVE(1);
+        else if(maxlen <= 128)
+            ILU0_WAVE(2);
+        else
+            ILU0_WAVE(4);
+        st->ticket += nbc;
+    }
 #undef ILU0_WAVE
-    st->ticket += nbw;
     if(e == hipSuccess)
         e = hipGetLastError();
     if(e == hipSuccess)
@@ -1185,16 +1191,21 @@ static int ilup_t(ramd_mat_s* m, int p, bool level)
     {
         const unsigned nbw = (unsigned)(((int64_t)n + kBlock / 64 - 1) / (kBlock / 64));
 #define ILUP_WAVE(K)                                                                                             \
-    hipLaunchKernelGGL((k_ilup_wave<T, K>), dim3(nbw), dim3(kBlock), 0, b.cur, n, S->rp, S->ci, (T*)S->val, lev, \
-                       done, S->diag_pos, cnt, p, st->counter, st->ticket, st->l_order_cache)
-        if(maxlen <= 64)
-            ILUP_WAVE(1);
-        else if(maxlen <= 128)
-            ILUP_WAVE(2);
-        else
-            ILUP_WAVE(4);
+    hipLaunchKernelGGL((k_ilup_wave<T, K>), dim3(nbc), dim3(kBlock), 0, b.cur, n, S->rp, S->ci, (T*)S->val, lev, \
+                       done, S->diag_pos, cnt, p, st->counter, st->ticket, st->l_order_cache,                    \
+                       (int64_t)b0 * (kBlock / 64))
+        for(unsigned b0 = 0; b0 < nbw; b0 += kIlupWaveChunk)
+        {
+            const unsigned nbc = std::min(kIlupWaveChunk, nbw - b0);
+            if(maxlen <= 64)
+                ILUP_WAVE(1);
+            else if(maxlen <= 128)
+                ILUP_WAVE(2);
+            else
+                ILUP_WAVE(4);
+            st->ticket += nbc;
+        }
 #undef ILUP_WAVE
-        st->ticket += nbw;
     }
     else
     {
@@ -1860,6 +1871,9 @@ int ramd_mat_ilu0_factorize(ramd_mat_t m)
         return RAMD_ERR_UNSUPPORTED;
     if(m->nrow != m->ncol || m->nnz <= 0)
         RAMD_FAIL(RAMD_ERR_ARG, "ILU0Factorize: need a square, non-empty matrix (the reference asserts)");
+    static const bool wave_rows = getenv("RAMD_ILU0_WAVE") && atoi(getenv("RAMD_ILU0_WAVE")) != 0;
+    if(wave_rows) // experiment: one wave per row also for short rows
+        return (m->dtype == RAMD_F64) ? ilu0_long_rows_t<double>(m) : ilu0_long_rows_t<float>(m);
     return (m->dtype == RAMD_F64) ? ilu0_t<double>(m) : ilu0_t<float>(m);
 }
 
