@@ -1,28 +1,38 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the MI355X-native Krylov core.
+"""bench.py -- benchmarks of the MI355X-native Krylov core.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                      (N > 1: spawns one rank per GPU itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json `metric`): CG + Jacobi on the 3-D 7-point Poisson 512^3 operator in CSR, fp64,
-rhs = A*1, x0 = 0 (the reference samples' convention, clients/samples/cg.cpp:77-82), synthetic operator
-generated on the device.  A "step" is ONE CG iteration; the timed region is Solve() running exactly K
-iterations (tolerances that cannot be met), bracketed by barrier + device sync, MAX over ranks.
-N > 1: the 512^3 rows are split into z-slabs across ranks (strong scaling), halo exchange + scalar
-all-reduce over RCCL (GlobalMatrix / GlobalVector path).
+Default workload (BASELINE.json `metric`): CG + Jacobi on the 3-D 7-point Poisson 512^3 operator in CSR, fp64,
+rhs = A*1, x0 = 0 (the reference samples' convention, clients/samples/cg.cpp:77-82), synthetic operator generated
+on the device.  A "step" is ONE Krylov iteration; the timed region is Solve() running exactly K iterations
+(tolerances that cannot be met), bracketed by barrier + device sync, MAX over ranks.
+N > 1: the rows are split into z-slabs across ranks (strong scaling), halo exchange + scalar all-reduce over RCCL
+(GlobalMatrix / GlobalVector path).
 
-Extra objects on the JSON line (N = 1):
-  roofline     -- the CSR SpMV kernel: algorithmic bytes 4(n+nnz)+8(2n+nnz) (clients/samples/
-                  benchmark.cpp:213-233) / its average duration measured with HIP events around every SpMV
-                  launch inside a live CG run; peak = 8 TB/s (MI355X HBM3E).
-  cpu_baseline -- the same solver on the host cores: the genuine rocALUTION OpenMP backend through
-                  oracle/_ref/ref_probe when the ROCm image ships librocalution ("reference"), else the
-                  C oracle ("port"); bounded sample (smaller grid), stated in `sample`.
+Other workloads through the same harness:
+    --solver gmres --precond ilu0                   GMRES(30)+ILU(0) on the 512^3 operator (north_star's second target)
+    --matrix shell --solver gmres --precond ilu0    BASELINE.json config 3 on the af_shell10-class surrogate
+                                                    (generators.shell_surrogate; written as a MatrixMarket symmetric
+                                                    file and read back through ReadFileMTX, as af_shell10.mtx would be)
+    --solver bicgstab --precond mcsgs --format ell  config 4's solver; --solver mixed: config 5
+
+Objects on the JSON line:
+  roofline     -- the DOMINANT kernel of the run: the CSR SpMV for Jacobi-type runs, the sparse triangular solve
+                  (`k_trsv`, two launches per ILU(0) apply) for --precond ilu0/ic/sgs.  achieved = algorithmic bytes per
+                  launch / average launch duration from HIP events around every such launch inside a live solver run;
+                  peak = 8 TB/s (MI355X HBM3E).  `kernels` lists the same figure for the other launch kinds of the iteration.
+  cpu_baseline -- the same solver on the host cores: the genuine rocALUTION OpenMP backend through oracle/_ref/ref_probe
+                  when the ROCm image ships librocalution ("reference"), else the C oracle ("port"); bounded sample,
+                  stated in `sample`.
+  N > 1 adds   -- per_rank roofline, halo_ms, halo_overlap_frac, allreduces_per_iter, rccl_nranks.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
 import subprocess
 import sys
 import time
@@ -34,64 +44,105 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
+PROF_SPMV, PROF_TRSV, PROF_HALO, PROF_HALO_WAIT, PROF_ALLREDUCE, PROF_VEC = range(6)
+
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
 def spmv_bytes(n, nnz, vbytes=8):
+    """clients/samples/benchmark.cpp:213-233: index arrays + values + x + y"""
     return 4 * (n + nnz) + vbytes * (2 * n + nnz)
 
 
-def cpu_baseline(args):
-    """CG+Jacobi on the host: reference OpenMP backend if available, else the C oracle (port)."""
+def trsv_bytes(n, nnz, vbytes=8):
+    """average algorithmic bytes of ONE triangle launch of an LU solve on a matrix with a full diagonal and a
+    symmetric pattern: the same accounting as the SpMV applied to the strictly-lower part (unit diagonal, forward)
+    and to the upper part incl. the diagonal (backward)"""
+    nl = (nnz - n) // 2
+    lo = 4 * (n + nl) + vbytes * (2 * n + nl)
+    up = 4 * (n + nl + n) + vbytes * (2 * n + nl + n)
+    return (lo + up) // 2
+
+
+def physical_cores():
     ncpu = os.cpu_count() or 1
     try:
         phys = int(subprocess.check_output("lscpu -p=CORE,SOCKET | grep -v '^#' | sort -u | wc -l",
                                            shell=True).decode().strip())
     except Exception:
         phys = ncpu
-    threads = max(1, min(phys, ncpu))
-    Nc, iters = args.cpu_grid, args.cpu_iters
+    return max(1, min(phys, ncpu))
+
+
+SOLVER_LABEL = {"cg": "CG", "gmres": "GMRES(30)", "bicgstab": "BiCGStab", "mixed": "MixedPrecisionDC(fp64/fp32 CG)"}
+PRECOND_LABEL = {"none": "none", "jacobi": "Jacobi", "ilu0": "ILU(0)", "mcsgs": "MC-SGS", "mcgs": "MC-GS",
+                 "mcilu": "MC-ILU(0,1)", "ic": "IC", "sgs": "SGS", "uaamg": "UAAMG(PMIS)", "saamg": "SAAMG(PMIS)"}
+
+
+def cpu_baseline(args, mtx_path=None):
+    """the same solver / preconditioner on the host: reference OpenMP backend if available, else the C oracle (port)"""
+    threads = physical_cores()
+    iters = args.cpu_iters
     probe = os.path.join(ROOT, "oracle", "_ref", "ref_probe")
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores")
-    if os.path.exists(probe) and os.path.exists("/opt/rocm/lib/librocalution.so"):
+    label = "%s+%s" % (SOLVER_LABEL.get(args.solver, args.solver), PRECOND_LABEL[args.precond])
+    ref_solver = {"cg": "cg", "gmres": "gmres", "bicgstab": "bicgstab"}.get(args.solver)
+    ref_precond = args.precond if args.precond in ("jacobi", "ilu0", "mcsgs", "none") else None
+    if os.path.exists(probe) and os.path.exists("/opt/rocm/lib/librocalution.so") and ref_solver and ref_precond:
         try:
-            out = subprocess.check_output([probe, "bench", str(Nc), str(iters), str(threads), "0", "cg", "jacobi"],
-                                          env=env, stderr=subprocess.DEVNULL, timeout=600).decode()
+            src = mtx_path if mtx_path else str(args.cpu_grid)
+            out = subprocess.check_output([probe, "bench", src, str(iters), str(threads), "0", ref_solver, ref_precond],
+                                          env=env, stderr=subprocess.DEVNULL, timeout=1500).decode()
             rec = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
-            return dict(value=rec["iters_per_s"], unit="iters/s", cores=threads, kind="reference",
-                        sample="CG+Jacobi, 3-D Poisson %d^3 CSR fp64 (%.3g of the 512^3 rows), %d iterations, "
-                               "rocALUTION %s host/OpenMP backend (accelerator disabled)" %
-                               (Nc, (Nc / 512.0) ** 3, rec["iters"], "installed"),
-                        spmv_GBps=rec["spmv_GBps"], equivalent_512_iters_per_s=rec["iters_per_s"] * (Nc / 512.0) ** 3)
+            if mtx_path:
+                what = "the full %d-row surrogate file (read by the reference's ReadFileMTX in %.1f s)" % (rec["n"], rec["t_read_s"])
+                scale = 1.0
+            else:
+                scale = (args.cpu_grid / float(args.grid)) ** 3
+                what = "3-D Poisson %d^3 CSR fp64 (%.3g of the benchmark's rows)" % (args.cpu_grid, scale)
+            r = dict(value=rec["iters_per_s"], unit="iters/s", cores=threads, kind="reference",
+                     sample="%s, %s, %d iterations, rocALUTION (ROCm-installed) host/OpenMP backend, accelerator disabled"
+                            % (label, what, rec["iters"]),
+                     spmv_GBps=rec["spmv_GBps"], build_s=rec["t_build_s"])
+            if scale != 1.0:
+                r["equivalent_full_size_iters_per_s"] = rec["iters_per_s"] * scale
+            return r
         except Exception as e:  # fall through to the port
             log("cpu_baseline: reference probe failed (%r), using the oracle port" % (e,))
-    import numpy as np
     from oracle import oracle as orc
     from rocalution_amd import generators as gen
     orc.build()
     orc.set_threads(threads)
-    Np = min(Nc, 128)
-    rp, ci, va = gen.poisson7(Np)
+    if args.matrix == "shell":
+        rp, ci, va = gen.shell_surrogate(min(args.shell_nx, 200))
+        what = "shell surrogate %d^2 nodes" % min(args.shell_nx, 200)
+    else:
+        Np = min(args.cpu_grid, 128)
+        rp, ci, va = gen.poisson7(Np)
+        what = "3-D Poisson %d^3 CSR fp64" % Np
     rhs = orc.csr_apply(rp, ci, va, np.ones(len(rp) - 1))
+    osolver = {"cg": orc.CG, "gmres": orc.GMRES, "bicgstab": orc.BICGSTAB}.get(args.solver, orc.CG)
+    opc = {"none": orc.PC_NONE, "jacobi": orc.PC_JACOBI, "ilu0": orc.PC_ILU0, "mcsgs": orc.PC_MCSGS}.get(args.precond, orc.PC_JACOBI)
     t0 = time.time()
-    r = orc.solve(rp, ci, va, rhs, solver=orc.CG, precond=orc.PC_JACOBI, abs_tol=0.0, rel_tol=0.0,
-                  div_tol=1e300, max_iter=iters, history=False)
+    r = orc.solve(rp, ci, va, rhs, solver=osolver, precond=opc, abs_tol=0.0, rel_tol=0.0, div_tol=1e300,
+                  max_iter=iters, history=False)
     dt = time.time() - t0
     return dict(value=r["iters"] / dt, unit="iters/s", cores=threads, kind="port",
-                sample="CG+Jacobi, 3-D Poisson %d^3 CSR fp64, %d iterations, C oracle (OpenMP)" % (Np, r["iters"]),
-                equivalent_512_iters_per_s=r["iters"] / dt * (Np / 512.0) ** 3)
+                sample="%s, %s, %d iterations (incl. Build), C oracle (OpenMP)" % (label, what, r["iters"]))
 
 
 def reference_gpu(args):
-    """optional vendor column: the reference's own rocSPARSE/rocBLAS HIP backend on this GPU"""
+    """optional vendor column: the reference's own rocSPARSE/rocBLAS HIP backend on this GPU (Poisson only)"""
     probe = os.path.join(ROOT, "oracle", "_ref", "ref_probe")
     if not (os.path.exists(probe) and os.path.exists("/opt/rocm/lib/librocalution_hip.so")):
         return None
+    if args.matrix != "poisson" or args.solver not in ("cg", "gmres", "bicgstab") or args.precond not in ("jacobi", "ilu0", "mcsgs"):
+        return None
     try:
-        out = subprocess.check_output([probe, "bench", str(args.grid), str(args.steps), "0", "1", "cg",
-                                       "jacobi"], stderr=subprocess.DEVNULL, timeout=900).decode()
+        out = subprocess.check_output([probe, "bench", str(args.grid), str(min(args.steps, 60) if args.precond == "ilu0" else args.steps),
+                                       "0", "1", args.solver, args.precond], stderr=subprocess.DEVNULL, timeout=900).decode()
         rec = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
         return dict(iters_per_s=rec["iters_per_s"], spmv_GBps=rec["spmv_GBps"], t_spmv_ms=rec["t_spmv_s"] * 1e3,
                     what="rocALUTION (installed) HIP backend = rocSPARSE/rocBLAS wrapper, same workload")
@@ -100,20 +151,100 @@ def reference_gpu(args):
         return None
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` without a launcher: one process per GPU (LOCAL_RANK = device), this process waits.
+    Never falls back to fewer ranks: fewer than N visible devices is an error."""
+    try:
+        ndev = int(subprocess.check_output([sys.executable, "-c",
+                                            "import sys; sys.path.insert(0, %r); import rocalution_amd as ra; "
+                                            "print(ra.device_count())" % ROOT], stderr=subprocess.DEVNULL).decode().split()[-1])
+    except Exception:
+        ndev = 0
+    if ndev < args.gpus:
+        log("bench.py: --gpus %d: need %d devices, %d visible -- not running on fewer ranks" % (args.gpus, args.gpus, ndev))
+        sys.exit(2)
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:  # one rank died: the others would hang in a collective
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.exit(rc)
+
+
+def prof_get(lib, capi, ch):
+    cnt, avg, mn, mx = C.c_int(0), C.c_double(0), C.c_double(0), C.c_double(0)
+    capi.check(lib.ramd_prof_result(ch, C.byref(cnt), C.byref(avg), C.byref(mn), C.byref(mx)))
+    tot = C.c_int64(0)
+    capi.check(lib.ramd_prof_count(ch, C.byref(tot)))
+    return dict(launches=cnt.value, avg_ms=avg.value, min_ms=mn.value, max_ms=mx.value, count=tot.value)
+
+
+def roof(name, bytes_alg, p, traffic=None):
+    ach = bytes_alg / (p["avg_ms"] * 1e-3) / 1e9 if p["avg_ms"] > 0 else 0.0
+    return dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4),
+                traffic=traffic, kernel=name, launches=p["launches"], avg_ms=round(p["avg_ms"], 5),
+                min_ms=round(p["min_ms"], 5), max_ms=round(p["max_ms"], 5), algorithmic_bytes=int(bytes_alg))
+
+
+def traffic_for(key):
+    """HBM bytes per launch from the PMC counters: measured offline with rocprofv3 in separate --pmc passes
+    (tools/pmc_passes.sh) and committed under profiles/; bench.py does not run the profiler"""
+    for f in ("r02_traffic.json", "r01_traffic.json"):
+        p = os.path.join(ROOT, "profiles", f)
+        if os.path.exists(p):
+            d = json.load(open(p))
+            if key in d:
+                return d[key]
+            if key == "spmv_csr_512" and "traffic_bytes" in d:
+                return d["traffic_bytes"]
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--matrix", default="poisson", choices=["poisson", "shell"],
+                    help="poisson: 3-D 7-point operator (device generator); shell: af_shell10-class surrogate "
+                         "(BASELINE.json config 3; 1 GPU), read through ReadFileMTX")
     ap.add_argument("--grid", type=int, default=512, help="Poisson grid edge N (operator is N^3 x N^3)")
+    ap.add_argument("--shell-nx", type=int, default=549, help="shell surrogate: nx x nx mesh nodes, 5 unknowns each")
     ap.add_argument("--format", default="csr", choices=["csr", "ell", "hyb", "dia"])
-    ap.add_argument("--cpu-grid", type=int, default=256)
-    ap.add_argument("--cpu-iters", type=int, default=40)
+    ap.add_argument("--cpu-grid", type=int, default=None, help="Poisson grid of the CPU baseline sample (default: --grid)")
+    ap.add_argument("--cpu-iters", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-gpu", action="store_true")
     ap.add_argument("--solver", default="cg", choices=["cg", "gmres", "bicgstab", "mixed"],
                     help="headline = cg; the others run the remaining BASELINE.json configs through the same harness")
-    ap.add_argument("--precond", default="jacobi", choices=["none", "jacobi", "ilu0", "mcsgs", "mcgs", "mcilu", "ic", "sgs", "uaamg", "saamg"])
+    ap.add_argument("--precond", default="jacobi", choices=sorted(PRECOND_LABEL))
     ap.add_argument("--itsolve", type=int, default=0,
                     help="ILU / IC / SGS: iterative triangular solves (TriSolverAlg_Iterative) with this many sweeps")
     ap.add_argument("--force-global", action="store_true",
@@ -122,20 +253,30 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the GMRES(30)+ILU(0) and BiCGStab+MC-SGS legs (reported under `extras`)")
     args = ap.parse_args()
+    if args.cpu_grid is None:
+        args.cpu_grid = args.grid
+    if args.cpu_iters is None:  # ~10-30 s of host work at the default sizes
+        args.cpu_iters = 12 if (args.matrix == "poisson" and args.cpu_grid >= 384) else 30
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_spawn(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            log("bench.py: --gpus %d needs one process per GPU (torch.distributed.run); running 1" % args.gpus)
-        args.gpus = world
+        log("bench.py: --gpus %d but the launcher started %d rank(s): refusing to report a mislabelled run" % (args.gpus, world))
+        sys.exit(2)
+    if args.matrix == "shell" and (world > 1 or args.force_global):
+        raise SystemExit("--matrix shell is the 1-GPU workload of config 3 (LocalMatrix path)")
 
     if args.force_global:
         os.environ["RAMD_COMM_FORCE_COLLECTIVES"] = "1"
     import rocalution_amd as ra
     from rocalution_amd import capi
     lib = capi.load()
+    if world > 1 and ra.device_count() < world:
+        log("bench.py: %d ranks need %d devices, %d visible" % (world, world, ra.device_count()))
+        sys.exit(2)
     ra.init_rocalution(local_rank)
     if rank == 0:
         log(ra.info_rocalution())
@@ -168,16 +309,48 @@ def main():
             dist.barrier()
 
     N = args.grid
-    n, nnz = N ** 3, 7 * N ** 3 - 6 * N ** 2
     fmt = {"csr": ra.CSR, "ell": ra.ELL, "hyb": ra.HYB, "dia": ra.DIA}[args.format]
     K, W = args.steps, args.warmup
     NEVER = (0.0, 0.0, 1e300)  # abs / rel / div tolerances that cannot trigger: exactly max_iter steps
+    mixed = args.solver == "mixed"
+    tri_pc = args.precond in ("ilu0", "ic", "sgs") and args.itsolve == 0
+    label = SOLVER_LABEL[args.solver] + "+" + PRECOND_LABEL[args.precond]
 
     prof = None
+    kernels = {}
+    extras = {}
+    ingest = None
+    mtx_path = None
+    scaling_fields = {}
     if world == 1 and not args.force_global:
         from rocalution_amd import solvers as S
         A = ra.LocalMatrix()
-        A.GenPoisson7(N)
+        if args.matrix == "shell":
+            from rocalution_amd import generators as gen
+            t0 = time.perf_counter()
+            rp_h, ci_h, va_h = gen.shell_surrogate(args.shell_nx)
+            t_gen = time.perf_counter() - t0
+            mtx_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "ramd_shell_%d.mtx" % args.shell_nx)
+            t0 = time.perf_counter()
+            stored = gen.write_mtx_symmetric(mtx_path, rp_h, ci_h, va_h)
+            t_write = time.perf_counter() - t0
+            n, nnz = len(rp_h) - 1, len(ci_h)
+            del rp_h, ci_h, va_h
+            t0 = time.perf_counter()
+            A.ReadFileMTX(mtx_path)  # host_io.cpp:135-276 semantics: symmetric expansion + row sort, then upload
+            ra.sync()
+            ingest = dict(file_bytes=os.path.getsize(mtx_path), stored_entries=stored, read_s=round(time.perf_counter() - t0, 3),
+                          generate_s=round(t_gen, 3), write_s=round(t_write, 3))
+            assert (A.GetM(), A.GetNnz()) == (n, nnz)
+            regen = lambda: A.ReadFileMTX(mtx_path)
+            wl = ("af_shell10-class surrogate (SuiteSparse af_shell10 itself is not available offline): %d x %d mesh nodes x 5 "
+                  "unknowns, n=%d, nnz=%d (%.2f per row; af_shell10: n=1508065, nnz=52259885), SPD, read from a MatrixMarket "
+                  "symmetric file" % (args.shell_nx, args.shell_nx, n, nnz, nnz / n))
+        else:
+            n, nnz = N ** 3, 7 * N ** 3 - 6 * N ** 2
+            A.GenPoisson7(N)
+            regen = lambda: A.GenPoisson7(N)
+            wl = "3-D 7-point Poisson %d^3 (n=%d, nnz=%d)" % (N, n, nnz)
         ones = ra.LocalVector(); ones.Allocate("ones", n); ones.Ones()
         rhs = ra.LocalVector(); rhs.Allocate("rhs", n)
         x = ra.LocalVector(); x.Allocate("x", n)
@@ -185,7 +358,7 @@ def main():
 
         def run(iters, solver_cls=S.CG, pc_cls=S.Jacobi, basis=None):
             if A.GetFormat() != ra.CSR:  # preconditioners are built from the CSR state
-                A.GenPoisson7(N)
+                regen()
             ls = solver_cls()
             ls.SetOperator(A)
             if pc_cls is not None:
@@ -218,7 +391,8 @@ def main():
         HEAD = {"cg": S.CG, "gmres": S.GMRES, "bicgstab": S.BiCGStab}.get(args.solver, S.CG)
         HPC = {"none": None, "jacobi": S.Jacobi, "ilu0": S.ILU, "mcsgs": S.MultiColoredSGS,
                "mcgs": S.MultiColoredGS, "mcilu": S.MultiColoredILU, "ic": S.IC, "sgs": S.SGS, "uaamg": S.UAAMG, "saamg": S.SAAMG}[args.precond]
-        if args.solver == "mixed":
+        basis = 30 if args.solver == "gmres" else None
+        if mixed:
             def run(iters, *_a):  # noqa: F811  (config 5 on one GPU)
                 inner = S.CG(np.float32)
                 if HPC is not None:
@@ -232,64 +406,55 @@ def main():
                 r = (dt, mp.GetIterationCount(), mp.GetCurrentResidual(), 0.0)
                 mp.Clear()
                 return r
-            run(W)
-            dt, it, res, tbuild = run(K)
-        else:
-            run(W, HEAD, HPC, 30 if args.solver == "gmres" else None)  # warmup
-            dt, it, res, tbuild = run(K, HEAD, HPC, 30 if args.solver == "gmres" else None)
+        run(W, HEAD, HPC, basis)  # warm-up
+        dt, it, res, tbuild = run(K, HEAD, HPC, basis)
         assert it == K, (it, K)
-        # --- roofline leg: same run with every SpMV launch bracketed by HIP events
-        capi.check(lib.ramd_prof_spmv_enable(1))
-        run(min(K, 200), S.CG, S.Jacobi, None) if args.solver != "mixed" else run(min(K, 20))
-        cnt, avg, mn, mx = C.c_int(0), C.c_double(0), C.c_double(0), C.c_double(0)
-        capi.check(lib.ramd_prof_spmv_result(C.byref(cnt), C.byref(avg), C.byref(mn), C.byref(mx)))
-        capi.check(lib.ramd_prof_spmv_enable(0))
-        nnz_fmt = nnz if args.format == "csr" else 7 * n
-        mixed = args.solver == "mixed"
+        # --- roofline leg: the SAME solver run again with every SpMV / triangular-solve / fused-vector launch
+        # bracketed by HIP events on the stream it runs on
+        for ch in (PROF_SPMV, PROF_TRSV, PROF_VEC):
+            capi.check(lib.ramd_prof_enable(ch, 1))
+        run(min(K, 20) if mixed else min(K, 200), HEAD, HPC, basis)
+        p_spmv, p_trsv, p_vec = (prof_get(lib, capi, ch) for ch in (PROF_SPMV, PROF_TRSV, PROF_VEC))
+        for ch in (PROF_SPMV, PROF_TRSV, PROF_VEC):
+            capi.check(lib.ramd_prof_enable(ch, 0))
         vb = 4 if mixed else 8  # the launches of a mixed-precision run are (all but a handful) the fp32 inner SpMVs
-        bytes_alg = spmv_bytes(n, nnz, vb) if args.format == "csr" else 4 * nnz_fmt + vb * (2 * n + nnz_fmt)
-        if args.format == "dia":  # values only (7 diagonals x n), x and y once
-            bytes_alg = vb * (2 * n + nnz_fmt)
-        ach = bytes_alg / (avg.value * 1e-3) / 1e9 if avg.value > 0 else 0.0
-        traffic = None  # HBM bytes per launch from the PMC counters: measured offline with rocprofv3
-        tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")  # (separate --pmc passes), see that file
-        if os.path.exists(tfile) and N == 512 and args.format == "csr" and not mixed:
-            traffic = json.load(open(tfile)).get("traffic_bytes")
-        kname = ("k_csr_tr<float,0,true> (fp32 inner CSR SpMV + fused <p,q>; the few fp64 outer residual SpMVs are "
-                 "in the average)" if mixed else "k_csr_tr<double,0,true> (CSR SpMV + fused <p,q>)")
-        prof = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
-                    frac=round(ach / HBM_PEAK_GBPS, 4), traffic=traffic, kernel=kname
-                    if args.format == "csr" else "k_%s<%s>" % ("dia" if args.format == "dia" else "ell",
-                                                                "float" if mixed else "double"), launches=cnt.value,
-                    avg_ms=round(avg.value, 5), min_ms=round(mn.value, 5), max_ms=round(mx.value, 5),
-                    algorithmic_bytes=bytes_alg)
-        extras = {}
-        if not args.no_extras and args.solver == "cg" and args.precond == "jacobi":
+        if args.format == "csr":
+            b_spmv = spmv_bytes(n, nnz, vb)
+            k_spmv = ("k_csr_tr<float> (fp32 inner CSR SpMV + fused <p,q>; the few fp64 outer residual SpMVs are in the average)"
+                      if mixed else "CSR SpMV (k_csr_tr / k_csr_sub, with the fused dot where the solver uses it)")
+        else:
+            nnz_fmt = 7 * n if args.matrix == "poisson" else nnz
+            b_spmv = vb * (2 * n + nnz_fmt) if args.format == "dia" else 4 * nnz_fmt + vb * (2 * n + nnz_fmt)
+            k_spmv = "k_%s<%s>" % ("dia" if args.format == "dia" else "ell", "float" if mixed else "double")
+        tkey = "spmv_csr_512" if (args.matrix == "poisson" and N == 512 and args.format == "csr" and not mixed) else None
+        r_spmv = roof(k_spmv, b_spmv, p_spmv, traffic_for(tkey) if tkey else None)
+        if tri_pc and p_trsv["launches"] > 0:
+            tk = "trsv_512" if (args.matrix == "poisson" and N == 512) else ("trsv_shell" if args.matrix == "shell" else None)
+            prof = roof("sparse triangular solve (k_trsv / k_trsv_tile), one launch per triangle", trsv_bytes(n, nnz, vb), p_trsv,
+                        traffic_for(tk) if tk else None)
+            kernels["spmv"] = r_spmv
+        else:
+            prof = r_spmv
+        if p_vec["launches"] > 0:
+            # fused vector kernels: CG 40 n B per launch (k_cg_update / k_cg_direction: 3 reads + 2 writes),
+            # GMRES k_mgs_step 32 n B (3 reads + 1 write)
+            kernels["vector_updates"] = roof("k_mgs_step" if args.solver == "gmres" else "k_cg_update / k_cg_direction",
+                                             (32 if args.solver == "gmres" else 40) * n * vb // 8, p_vec)
+        if not args.no_extras and args.solver == "cg" and args.precond == "jacobi" and args.matrix == "poisson":
             # the other two solver/preconditioner pairs of BASELINE.json on the same operator (same
             # "exactly K iterations" protocol; Build() reported separately, as in the reference samples)
-            for name, sc, pc, basis, iters in (("gmres30_ilu0", S.GMRES, S.ILU, 30, min(K, 60)),
-                                               ("bicgstab_mcsgs", S.BiCGStab, S.MultiColoredSGS, None, min(K, 60))):
+            for name, sc, pc, bs, iters in (("gmres30_ilu0", S.GMRES, S.ILU, 30, min(K, 60)),
+                                            ("bicgstab_mcsgs", S.BiCGStab, S.MultiColoredSGS, None, min(K, 60))):
                 try:
-                    d2, i2, r2, tb2 = run(iters, sc, pc, basis)
+                    d2, i2, r2, tb2 = run(iters, sc, pc, bs)
                     extras[name] = dict(iters_per_s=round(i2 / d2, 2), iters=i2, build_s=round(tb2, 3))
                 except Exception as e:
                     extras[name] = dict(error=repr(e))
-            # time to solution (relative residual 1e-8) of the same system with the aggregation AMG as CG's
-            # preconditioner, next to plain CG+Jacobi run to the same tolerance: setup and solve reported apart
-            for name, pc_cls in (("cg_jacobi_to_1e-8", S.Jacobi), ("cg_uaamg_to_1e-8", S.UAAMG)):
-                try:
-                    if A.GetFormat() != ra.CSR:
-                        A.GenPoisson7(N)
-                    ls = S.CG(); ls.SetOperator(A); ls.SetPreconditioner(pc_cls()); ls.Init(1e-15, 1e-8, 1e8, 5000)
-                    tb = time.perf_counter(); ls.Build(); ra.sync(); tb = time.perf_counter() - tb
-                    x.Zeros(); ra.sync()
-                    t0 = time.perf_counter(); ls.Solve(rhs, x); ra.sync(); ts = time.perf_counter() - t0
-                    extras[name] = dict(iters=ls.GetIterationCount(), status=ls.GetSolverStatus(),
-                                        setup_s=round(tb, 3), solve_s=round(ts, 3))
-                    ls.Clear()
-                except Exception as e:
-                    extras[name] = dict(error=repr(e))
     else:
+        if args.matrix != "poisson":
+            raise SystemExit("the distributed driver generates z-slabs of the Poisson operator")
+        n, nnz = N ** 3, 7 * N ** 3 - 6 * N ** 2
+        wl = "3-D 7-point Poisson %d^3 (n=%d, nnz=%d)" % (N, n, nnz)
         z0, z1 = (N * rank) // world, (N * (rank + 1)) // world
         g = C.c_void_p()
         SK = {"cg": capi.SOLVER_CG, "gmres": capi.SOLVER_GMRES, "bicgstab": capi.SOLVER_BICGSTAB}
@@ -298,7 +463,7 @@ def main():
               "uaamg": capi.PC_UAAMG, "saamg": capi.PC_SAAMG}  # all but Jacobi: BlockJacobi over the ranks
         if args.precond not in PK:
             raise SystemExit("--precond %s: not wired into the distributed driver" % args.precond)
-        if args.solver == "mixed":  # config 5: fp64 defect correction around fp32 CG + Jacobi
+        if mixed:  # config 5: fp64 defect correction around fp32 CG + Jacobi
             capi.check(lib.ramd_gsolver_create_mixed(comm, capi.SOLVER_CG, PK[args.precond], C.byref(g)))
             capi.check(lib.ramd_gsolver_init_inner(g, 1e-5, 1e-2, 1e20, 100000))
         else:
@@ -325,43 +490,95 @@ def main():
         run(W)
         dt, it, res, tbuild = run(K)
         assert it == K, (it, K)
-        if dist is not None:
-            import torch
-            t = torch.tensor([dt], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t[0])
-        extras = {}
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+        # --- scaling leg (untimed): the same run with the interior SpMV, the halo exchange, the exposed part of
+        # the halo wait and the all-reduces bracketed by HIP events on their streams
+        chans = (PROF_SPMV, PROF_HALO, PROF_HALO_WAIT, PROF_ALLREDUCE, PROF_TRSV)
+        for ch in chans:
+            capi.check(lib.ramd_prof_enable(ch, 1))
+        kp = min(K, 20) if mixed else min(K, 100)
+        _, itp, _, _ = run(kp)
+        pr = {ch: prof_get(lib, capi, ch) for ch in chans}
+        for ch in chans:
+            capi.check(lib.ramd_prof_enable(ch, 0))
+        k = z1 - z0
+        n_loc = k * N * N
+        nnz_int = n_loc + 4 * (N - 1) * N * k + 2 * (k - 1) * N * N
+        nnz_ghost = ((1 if z0 > 0 else 0) + (1 if z1 < N else 0)) * N * N
+        vb = 4 if mixed else 8
+        if args.format == "csr":
+            b_loc = spmv_bytes(n_loc, nnz_int, vb)
+        else:
+            b_loc = 4 * 7 * n_loc + vb * (2 * n_loc + 7 * n_loc)
+        # interior launches carry the fused dot in most solvers; ghost COO ApplyAdd launches are in the same channel:
+        # separate them by duration rank is fragile, so the channel average is reported together with the count per iteration
+        mine = dict(rank=rank, rows=n_loc, interior_nnz=nnz_int, ghost_nnz=nnz_ghost, spmv_launches_per_iter=round(pr[PROF_SPMV]["count"] / max(itp, 1), 2),
+                    spmv_avg_ms=round(pr[PROF_SPMV]["avg_ms"], 5), spmv_max_ms=round(pr[PROF_SPMV]["max_ms"], 5),
+                    interior_GBps=round(b_loc / (pr[PROF_SPMV]["max_ms"] * 1e-3) / 1e9, 1) if pr[PROF_SPMV]["max_ms"] > 0 else 0.0,
+                    halo_ms=round(pr[PROF_HALO]["avg_ms"], 5), halo_wait_ms=round(pr[PROF_HALO_WAIT]["avg_ms"], 5),
+                    halo_exchanges=pr[PROF_HALO]["count"], allreduces=pr[PROF_ALLREDUCE]["count"],
+                    allreduce_avg_ms=round(pr[PROF_ALLREDUCE]["avg_ms"], 5), iters=itp, algorithmic_bytes=b_loc)
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        nr = C.c_int(0)
+        capi.check(lib.ramd_comm_rccl_count(comm, C.byref(nr)))
+        if rank == 0:
+            # interior SpMV = the LONGEST launch kind of the channel (the ghost ApplyAdd is ~N^2 entries): use the max
+            t_int = max(r["spmv_max_ms"] for r in allr)
+            agg_bytes = sum(r["algorithmic_bytes"] for r in allr)
+            ach = agg_bytes / (t_int * 1e-3) / 1e9 if t_int > 0 else 0.0
+            prof = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBPS * world, unit="GB/s",
+                        frac=round(ach / (HBM_PEAK_GBPS * world), 4), traffic=None,
+                        kernel="interior SpMV of every rank (aggregate algorithmic bytes / slowest rank's longest launch)",
+                        algorithmic_bytes=int(agg_bytes), per_rank=allr)
+            halo = max(r["halo_ms"] for r in allr)
+            wait = max(r["halo_wait_ms"] for r in allr)
+            scaling_fields = dict(halo_ms=halo, halo_wait_ms=wait,
+                                  halo_overlap_frac=round(max(0.0, 1.0 - wait / halo), 4) if halo > 0 else None,
+                                  halo_time_frac=round(wait * allr[0]["halo_exchanges"] / max(itp, 1) / (dt / it * 1e3), 4),
+                                  allreduces_per_iter=round(allr[0]["allreduces"] / max(itp, 1), 2),
+                                  halo_exchanges_per_iter=round(allr[0]["halo_exchanges"] / max(itp, 1), 2),
+                                  rccl_nranks=nr.value)
 
     if rank == 0:
         out = {
-            "metric": "%s iterations/s, 3D 7-pt Poisson %d^3 %s fp64" % (
-                {"cg": "CG", "gmres": "GMRES(30)", "bicgstab": "BiCGStab", "mixed": "MixedPrecisionDC(fp64/fp32 CG)"}[args.solver]
-                + "+" + {"none": "none", "jacobi": "Jacobi", "ilu0": "ILU(0)", "mcsgs": "MC-SGS", "mcgs": "MC-GS",
-                         "mcilu": "MC-ILU(0,1)", "ic": "IC", "sgs": "SGS", "uaamg": "UAAMG(PMIS)", "saamg": "SAAMG(PMIS)"}[args.precond], N,
-                args.format.upper()),
+            "metric": "%s iterations/s, %s %s fp64" % (label, "3D 7-pt Poisson %d^3" % N if args.matrix == "poisson"
+                                                       else "af_shell10-class surrogate (n=%d)" % n, args.format.upper()),
             "value": round(it / dt, 3), "unit": "iters/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / it * 1e3, 5), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64/f32" if args.solver == "mixed" else "f64",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64/f32" if mixed else "f64",
             "data": "synthetic",
-            "config": {"workload": "%s+%s, 3-D 7-point Poisson %d^3 (n=%d, nnz=%d) %s fp64, rhs=A*1, x0=0, "
-                                   "row-split over %d GPU(s)" % (args.solver, args.precond, N, n, nnz,
-                                                                 args.format.upper(), world),
+            "config": {"workload": "%s+%s, %s %s fp64, rhs=A*1, x0=0, row-split over %d GPU(s)"
+                                   % (args.solver, args.precond, wl, args.format.upper(), world),
                        "parallelism": "rows%d" % world, "fused": True},
             "final_residual": res, "build_s": round(tbuild, 4),
         }
         if prof is not None:
             out["roofline"] = prof
+        if kernels:
+            out["kernels"] = kernels
+            if "spmv" in kernels:
+                out["spmv_GBps"] = kernels["spmv"]["achieved"]
+        if prof is not None and "spmv_GBps" not in out and world == 1:
             out["spmv_GBps"] = prof["achieved"]
+        out.update(scaling_fields)
+        if ingest:
+            out["ingest"] = ingest
         if extras:
             out["extras"] = extras
         if world == 1 and not args.no_cpu_baseline and not args.force_global:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"] = cpu_baseline(args, mtx_path)
         if world == 1 and not args.no_reference_gpu and not args.force_global:
             rg = reference_gpu(args)
             if rg is not None:
                 out["reference_gpu"] = rg
         C.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
+    if mtx_path and os.path.exists(mtx_path):
+        os.unlink(mtx_path)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -601,7 +601,7 @@ inline void _f_apply_dotv(const GlobalMatrix<ValueType>& A, const GlobalVector<V
 template <typename ValueType>
 inline void _f_allreduce(const GlobalMatrix<ValueType>& A, int first, int count)
 {
-    if(A.pm() != NULL && A.pm()->GetNumProcs() > 1)
+    if(A.pm() != NULL) // (a communicator of size 1 returns at once unless RAMD_COMM_FORCE_COLLECTIVES is set)
         RAMD_CHECK(ramd_comm_allreduce_scalars(A.pm()->GetComm(), first, count));
 }
 

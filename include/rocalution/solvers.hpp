@@ -627,888 +627,6 @@ private:
     VectorType   inv_diag_entries_;
 };
 
-// ---- BlockPreconditioner (preconditioner_blockprecond.cpp): the operator cut into n x n blocks (optionally after a
-// permutation); block-diagonal solve or block forward substitution (default) with one caller-supplied solver per
-// diagonal block
-template <class OperatorType, class VectorType, typename ValueType>
-class BlockPreconditioner : public Preconditioner<OperatorType, VectorType, ValueType>
-{
-public:
-    BlockPreconditioner()
-        : num_blocks_(0)
-        , block_sizes_(NULL)
-        , diag_solve_(false)
-        , A_last_(NULL)
-        , A_block_(NULL)
-        , x_block_(NULL)
-        , tmp_block_(NULL)
-        , D_solver_(NULL)
-    {
-    }
-    virtual ~BlockPreconditioner()
-    {
-        this->Clear();
-    }
-    virtual void Print(void) const
-    {
-        LOG_INFO("BlockPreconditioner with " << this->num_blocks_ << " blocks");
-    }
-    virtual void Set(int n, const int* size, Solver<OperatorType, VectorType, ValueType>** D_solver)
-    {
-        assert(this->build_ == false && n > 0 && size != NULL && D_solver != NULL);
-        delete[] this->block_sizes_;
-        delete[] this->D_solver_;
-        this->num_blocks_  = n;
-        this->block_sizes_ = new int[n];
-        this->D_solver_    = new Solver<OperatorType, VectorType, ValueType>*[n];
-        for(int i = 0; i < n; ++i)
-        {
-            this->block_sizes_[i] = size[i];
-            this->D_solver_[i]    = D_solver[i];
-        }
-    }
-    virtual void SetDiagonalSolver(void)
-    {
-        this->diag_solve_ = true;
-    }
-    virtual void SetLSolver(void)
-    {
-        this->diag_solve_ = false;
-    }
-    virtual void SetExternalLastMatrix(const OperatorType& mat)
-    {
-        this->A_last_ = new OperatorType;
-        this->A_last_->CloneFrom(mat);
-    }
-    virtual void SetPermutation(const LocalVector<int>& perm)
-    {
-        this->permutation_.CopyFrom(perm);
-    }
-    // preconditioner_blockprecond.cpp:157-262
-    virtual void Build(void)
-    {
-        if(this->build_)
-            this->Clear();
-        assert(this->op_ != NULL && this->num_blocks_ > 0);
-        this->build_     = true;
-        const int nb     = this->num_blocks_;
-        this->x_block_   = new VectorType*[nb];
-        this->tmp_block_ = new VectorType*[nb];
-        std::vector<int> offsets((size_t)nb + 1, 0);
-        for(int i = 0; i < nb; ++i)
-        {
-            this->x_block_[i] = new VectorType;
-            this->x_block_[i]->CloneBackend(*this->op_);
-            this->x_block_[i]->Allocate("Diagonal preconditioners", this->block_sizes_[i]);
-            this->tmp_block_[i] = new VectorType;
-            this->tmp_block_[i]->CloneBackend(*this->op_);
-            this->tmp_block_[i]->Allocate("Diagonal preconditioners", this->block_sizes_[i]);
-            offsets[(size_t)i + 1] = offsets[(size_t)i] + this->block_sizes_[i];
-        }
-        this->A_block_ = new OperatorType**[nb];
-        for(int k = 0; k < nb; ++k)
-        {
-            this->A_block_[k] = new OperatorType*[nb];
-            for(int j = 0; j < nb; ++j)
-            {
-                this->A_block_[k][j] = new OperatorType;
-                this->A_block_[k][j]->CloneBackend(*this->op_);
-            }
-        }
-        if(this->permutation_.GetSize() > 0)
-        {
-            this->permutation_.CloneBackend(*this->op_);
-            OperatorType perm_op;
-            perm_op.CloneFrom(*this->op_);
-            perm_op.Permute(this->permutation_);
-            perm_op.ExtractSubMatrices(nb, nb, offsets.data(), offsets.data(), this->A_block_);
-            this->x_.CloneBackend(*this->op_);
-            this->x_.Allocate("x (not permuted)", this->op_->GetM());
-        }
-        else
-            this->op_->ExtractSubMatrices(nb, nb, offsets.data(), offsets.data(), this->A_block_);
-        if(this->A_last_ != NULL)
-        {
-            assert(this->A_block_[nb - 1][nb - 1]->GetM() == this->A_last_->GetM());
-            delete this->A_block_[nb - 1][nb - 1];
-            this->A_block_[nb - 1][nb - 1] = this->A_last_;
-            this->A_last_                  = NULL;
-        }
-        for(int i = 0; i < nb; ++i)
-        {
-            this->D_solver_[i]->SetOperator(*this->A_block_[i][i]);
-            this->D_solver_[i]->Build();
-        }
-        for(int i = 0; i < nb; ++i)
-        {
-            for(int j = i + 1; j < nb; ++j)
-                this->A_block_[i][j]->Clear();
-            if(this->diag_solve_)
-                for(int j = 0; j < i; ++j)
-                    this->A_block_[i][j]->Clear();
-        }
-    }
-    virtual void Clear(void)
-    {
-        if(this->build_)
-        {
-            for(int i = 0; i < this->num_blocks_; ++i)
-            {
-                delete this->x_block_[i];
-                delete this->tmp_block_[i];
-                if(this->D_solver_[i] != NULL)
-                {
-                    this->D_solver_[i]->Clear();
-                    this->D_solver_[i] = NULL;
-                }
-                for(int j = 0; j < this->num_blocks_; ++j)
-                    delete this->A_block_[i][j];
-                delete[] this->A_block_[i];
-            }
-            delete[] this->x_block_;
-            delete[] this->tmp_block_;
-            delete[] this->A_block_;
-            this->x_block_ = this->tmp_block_ = NULL;
-            this->A_block_                    = NULL;
-            this->permutation_.Clear();
-            this->x_.Clear();
-            this->build_ = false;
-        }
-        delete[] this->D_solver_;
-        delete[] this->block_sizes_;
-        this->D_solver_    = NULL;
-        this->block_sizes_ = NULL;
-        this->num_blocks_  = 0;
-    }
-    // preconditioner_blockprecond.cpp:265-340
-    virtual void Solve(const VectorType& rhs, VectorType* x)
-    {
-        assert(this->build_ == true && x != NULL && x != &rhs);
-        const bool permuted = this->permutation_.GetSize() > 0;
-        if(permuted)
-            this->x_.CopyFromPermute(rhs, this->permutation_);
-        else
-            x->CopyFrom(rhs);
-        const VectorType& src = permuted ? this->x_ : *x;
-        int               off = 0;
-        for(int i = 0; i < this->num_blocks_; ++i)
-        {
-            this->x_block_[i]->CopyFrom(src, off, 0, this->block_sizes_[i]);
-            off += this->block_sizes_[i];
-        }
-        for(int i = 0; i < this->num_blocks_; ++i)
-        {
-            if(this->diag_solve_ == false)
-                for(int j = 0; j < i; ++j)
-                    this->A_block_[i][j]->ApplyAdd(*this->x_block_[j], static_cast<ValueType>(-1), this->x_block_[i]);
-            this->D_solver_[i]->SolveZeroSol(*this->x_block_[i], this->tmp_block_[i]);
-            this->x_block_[i]->CopyFrom(*this->tmp_block_[i]);
-        }
-        VectorType* dst = permuted ? &this->x_ : x;
-        off             = 0;
-        for(int i = 0; i < this->num_blocks_; ++i)
-        {
-            dst->CopyFrom(*this->x_block_[i], 0, off, this->block_sizes_[i]);
-            off += this->block_sizes_[i];
-        }
-        if(permuted)
-            x->CopyFromPermuteBackward(this->x_, this->permutation_);
-    }
-    virtual bool SolveUsesScalarRecord(void) const
-    {
-        for(int i = 0; i < this->num_blocks_; ++i)
-            if(this->D_solver_ != NULL && this->D_solver_[i] != NULL && this->D_solver_[i]->SolveUsesScalarRecord())
-                return true;
-        return false;
-    }
-
-private:
-    int             num_blocks_;
-    int*            block_sizes_;
-    bool            diag_solve_;
-    OperatorType*   A_last_;
-    OperatorType*** A_block_;
-    VectorType**    x_block_;
-    VectorType**    tmp_block_;
-    VectorType      x_;
-    LocalVector<int> permutation_;
-    Solver<OperatorType, VectorType, ValueType>** D_solver_;
-};
-
-// ---- AS / RAS (preconditioner_as.cpp): (restricted) additive Schwarz over nb contiguous row blocks with `overlap`
-// rows on each side; the local operators come from ExtractSubMatrix, the local solvers from the caller
-template <class OperatorType, class VectorType, typename ValueType>
-class AS : public Preconditioner<OperatorType, VectorType, ValueType>
-{
-public:
-    AS()
-        : num_blocks_(0)
-        , overlap_(-1)
-        , pos_(NULL)
-        , sizes_(NULL)
-        , local_mat_(NULL)
-        , local_precond_(NULL)
-        , r_(NULL)
-        , z_(NULL)
-    {
-    }
-    virtual ~AS()
-    {
-        this->Clear();
-    }
-    virtual void Print(void) const
-    {
-        LOG_INFO("Additive Schwarz preconditioner");
-    }
-    virtual void Set(int nb, int overlap, Solver<OperatorType, VectorType, ValueType>** preconds)
-    {
-        if(this->build_ || this->local_precond_ != NULL)
-            this->Clear();
-        assert(nb > 0 && overlap >= 0 && preconds != NULL);
-        this->num_blocks_    = nb;
-        this->overlap_       = overlap;
-        this->local_precond_ = new Solver<OperatorType, VectorType, ValueType>*[nb];
-        this->pos_           = new int[nb];
-        this->sizes_         = new int[nb];
-        for(int i = 0; i < nb; ++i)
-            this->local_precond_[i] = preconds[i];
-    }
-    // preconditioner_as.cpp:101-186
-    virtual void Build(void)
-    {
-        assert(this->op_ != NULL && this->num_blocks_ > 0 && this->overlap_ >= 0);
-        const int size   = static_cast<int>(this->op_->GetLocalM() / this->num_blocks_);
-        int       offset = 0;
-        for(int i = 0; i < this->num_blocks_; ++i)
-        {
-            this->pos_[i] = offset - this->overlap_;
-            offset += size;
-            this->sizes_[i] = size + 2 * this->overlap_;
-        }
-        this->pos_[0]                       = 0;
-        this->sizes_[0]                     = size + this->overlap_;
-        this->sizes_[this->num_blocks_ - 1] = size + this->overlap_;
-        std::vector<ValueType> w((size_t)this->op_->GetM(), static_cast<ValueType>(1));
-        for(int i = 0; i < this->num_blocks_; ++i)
-            for(int j = 0; j < this->overlap_; ++j)
-            {
-                if(i != 0)
-                    w[(size_t)(this->pos_[i] + j)] = static_cast<ValueType>(0.5);
-                if(i != this->num_blocks_ - 1)
-                    w[(size_t)(this->pos_[i] + size + j)] = static_cast<ValueType>(0.5);
-            }
-        this->weight_.CloneBackend(*this->op_);
-        this->weight_.Allocate("Overlapping weights", this->op_->GetM());
-        this->weight_.CopyFromData(w.data());
-        this->local_mat_ = new OperatorType*[this->num_blocks_];
-        this->r_         = new VectorType*[this->num_blocks_];
-        this->z_         = new VectorType*[this->num_blocks_];
-        for(int i = 0; i < this->num_blocks_; ++i)
-        {
-            this->r_[i] = new VectorType;
-            this->r_[i]->CloneBackend(*this->op_);
-            this->r_[i]->Allocate("AS residual vector", this->sizes_[i]);
-            this->z_[i] = new VectorType;
-            this->z_[i]->CloneBackend(*this->op_);
-            this->z_[i]->Allocate("AS residual vector", this->sizes_[i]);
-            this->local_mat_[i] = new OperatorType;
-            this->local_mat_[i]->CloneBackend(*this->op_);
-            this->op_->ExtractSubMatrix(this->pos_[i], this->pos_[i], this->sizes_[i], this->sizes_[i], this->local_mat_[i]);
-            this->local_precond_[i]->SetOperator(*this->local_mat_[i]);
-            this->local_precond_[i]->Build();
-        }
-        this->build_ = true;
-    }
-    virtual void Clear(void)
-    {
-        if(this->build_)
-        {
-            this->weight_.Clear();
-            for(int i = 0; i < this->num_blocks_; ++i)
-            {
-                if(this->local_precond_[i] != NULL)
-                {
-                    this->local_precond_[i]->Clear();
-                    this->local_precond_[i] = NULL;
-                }
-                delete this->r_[i];
-                delete this->z_[i];
-                delete this->local_mat_[i];
-            }
-            delete[] this->r_;
-            delete[] this->z_;
-            delete[] this->local_mat_;
-            this->r_ = this->z_ = NULL;
-            this->local_mat_    = NULL;
-            this->build_        = false;
-        }
-        delete[] this->local_precond_;
-        delete[] this->pos_;
-        delete[] this->sizes_;
-        this->local_precond_ = NULL;
-        this->pos_ = this->sizes_ = NULL;
-        this->num_blocks_         = 0;
-        this->overlap_            = -1;
-    }
-    // preconditioner_as.cpp:232-262
-    virtual void Solve(const VectorType& rhs, VectorType* x)
-    {
-        assert(this->build_ == true && x != NULL && x != &rhs);
-        this->LocalSolves_(rhs);
-        x->Zeros();
-        for(int i = 0; i < this->num_blocks_; ++i)
-            x->ScaleAddScale(static_cast<ValueType>(1), *this->z_[i], static_cast<ValueType>(1), 0, this->pos_[i],
-                             this->sizes_[i]);
-        x->PointWiseMult(this->weight_);
-    }
-    virtual bool SolveUsesScalarRecord(void) const
-    {
-        for(int i = 0; i < this->num_blocks_; ++i)
-            if(this->local_precond_[i] != NULL && this->local_precond_[i]->SolveUsesScalarRecord())
-                return true;
-        return false;
-    }
-
-protected:
-    void LocalSolves_(const VectorType& rhs)
-    {
-        for(int i = 0; i < this->num_blocks_; ++i)
-            this->r_[i]->CopyFrom(rhs, this->pos_[i], 0, this->sizes_[i]);
-        for(int i = 0; i < this->num_blocks_; ++i)
-            this->local_precond_[i]->SolveZeroSol(*this->r_[i], this->z_[i]);
-    }
-    int            num_blocks_;
-    int            overlap_;
-    int*           pos_;
-    int*           sizes_;
-    OperatorType** local_mat_;
-    Solver<OperatorType, VectorType, ValueType>** local_precond_;
-    VectorType** r_;
-    VectorType** z_;
-    VectorType   weight_;
-};
-
-template <class OperatorType, class VectorType, typename ValueType>
-class RAS : public AS<OperatorType, VectorType, ValueType>
-{
-public:
-    virtual void Print(void) const
-    {
-        LOG_INFO("Restricted Additive Schwarz preconditioner");
-    }
-    // preconditioner_as.cpp:330-355: every block keeps only its own (non-overlapping) part of the local solution
-    virtual void Solve(const VectorType& rhs, VectorType* x)
-    {
-        assert(this->build_ == true && x != NULL && x != &rhs);
-        this->LocalSolves_(rhs);
-        const int size     = static_cast<int>(this->op_->GetLocalM() / this->num_blocks_);
-        int       z_offset = 0;
-        for(int i = 0; i < this->num_blocks_; ++i)
-        {
-            x->CopyFrom(*this->z_[i], z_offset, this->pos_[i] + z_offset, size);
-            z_offset = this->overlap_;
-        }
-    }
-};
-
-// ---- VariablePreconditioner (preconditioner.cpp:594-673): a different preconditioner on every call, round robin --
-// for the flexible Krylov methods (FGMRES, FCG)
-template <class OperatorType, class VectorType, typename ValueType>
-class VariablePreconditioner : public Preconditioner<OperatorType, VectorType, ValueType>
-{
-public:
-    VariablePreconditioner()
-        : num_precond_(0)
-        , preconds_(NULL)
-        , counter_(0)
-    {
-    }
-    virtual ~VariablePreconditioner()
-    {
-        this->Clear();
-    }
-    virtual void Print(void) const
-    {
-        if(this->build_)
-        {
-            LOG_INFO("VariablePreconditioner with " << this->num_precond_ << " preconditioners:");
-            for(int i = 0; i < this->num_precond_; ++i)
-                this->preconds_[i]->Print();
-        }
-        else
-            LOG_INFO("VariablePreconditioner preconditioner");
-    }
-    virtual void SetPreconditioner(int n, Solver<OperatorType, VectorType, ValueType>** precond)
-    {
-        assert(this->preconds_ == NULL && n > 0 && precond != NULL);
-        this->preconds_ = new Solver<OperatorType, VectorType, ValueType>*[n];
-        for(int i = 0; i < n; ++i)
-            this->preconds_[i] = precond[i];
-        this->num_precond_ = n;
-    }
-    virtual void Build(void)
-    {
-        if(this->build_)
-            this->Clear();
-        assert(this->op_ != NULL && this->preconds_ != NULL);
-        this->build_ = true;
-        for(int i = 0; i < this->num_precond_; ++i)
-        {
-            this->preconds_[i]->SetOperator(*this->op_);
-            this->preconds_[i]->Build();
-        }
-    }
-    virtual void Clear(void)
-    {
-        if(this->preconds_ != NULL && this->build_)
-        {
-            for(int i = 0; i < this->num_precond_; ++i)
-                this->preconds_[i]->Clear();
-            delete[] this->preconds_;
-            this->preconds_    = NULL;
-            this->num_precond_ = 0;
-        }
-        this->counter_ = 0;
-        this->build_   = false;
-    }
-    virtual void Solve(const VectorType& rhs, VectorType* x)
-    {
-        assert(this->build_ == true && x != NULL && x != &rhs);
-        this->preconds_[this->counter_]->Solve(rhs, x);
-        ++this->counter_;
-        if(this->counter_ >= this->num_precond_)
-            this->counter_ = 0;
-    }
-    virtual bool SolveUsesScalarRecord(void) const
-    {
-        for(int i = 0; i < this->num_precond_; ++i)
-            if(this->preconds_[i]->SolveUsesScalarRecord())
-                return true;
-        return false;
-    }
-
-private:
-    int                                           num_precond_;
-    Solver<OperatorType, VectorType, ValueType>** preconds_;
-    int                                           counter_;
-};
-
-// ---- approximate-inverse preconditioners whose Solve is a sparse matrix-vector product (preconditioner_ai.cpp)
-// AIChebyshev :41-215: Chebyshev polynomial of the shifted operator built with MatrixMult / MatrixAdd
-template <class OperatorType, class VectorType, typename ValueType>
-class AIChebyshev : public Preconditioner<OperatorType, VectorType, ValueType>
-{
-public:
-    AIChebyshev()
-        : p_(0)
-        , lambda_min_(static_cast<ValueType>(0))
-        , lambda_max_(static_cast<ValueType>(0))
-    {
-    }
-    virtual ~AIChebyshev()
-    {
-        this->Clear();
-    }
-    virtual void Print(void) const
-    {
-        LOG_INFO("Approximate Inverse Chebyshev(" << this->p_ << ") preconditioner");
-    }
-    virtual void Set(int p, ValueType lambda_min, ValueType lambda_max)
-    {
-        assert(p > 0 && lambda_min != static_cast<ValueType>(0) && lambda_max != static_cast<ValueType>(0)
-               && this->build_ == false);
-        this->p_          = p;
-        this->lambda_min_ = lambda_min;
-        this->lambda_max_ = lambda_max;
-    }
-    virtual void Build(void)
-    {
-        if(this->build_)
-            this->Clear();
-        this->build_ = true;
-        assert(this->op_ != NULL);
-        const ValueType one = static_cast<ValueType>(1);
-        this->AIChebyshev_.CloneFrom(*this->op_);
-        ValueType q = (one - std::sqrt(this->lambda_min_ / this->lambda_max_))
-                      / (one + std::sqrt(this->lambda_min_ / this->lambda_max_));
-        ValueType c = one / std::sqrt(this->lambda_min_ * this->lambda_max_);
-        OperatorType Z; // Z = 2/(beta-alpha) [A - (beta+alpha)/2]
-        Z.CloneFrom(*this->op_);
-        Z.AddScalarDiagonal(static_cast<ValueType>(-1) * (this->lambda_max_ + this->lambda_min_) / (static_cast<ValueType>(2)));
-        Z.ScaleDiagonal(static_cast<ValueType>(2) / (this->lambda_max_ - this->lambda_min_));
-        this->AIChebyshev_.AddScalarDiagonal(c / static_cast<ValueType>(2));
-        OperatorType Tkm2;
-        Tkm2.CloneFrom(Z);
-        c = c * static_cast<ValueType>(-1) * q;
-        this->AIChebyshev_.MatrixAdd(Tkm2, one, c, true);
-        OperatorType Tkm1;
-        Tkm1.CloneBackend(*this->op_);
-        Tkm1.MatrixMult(Z, Z);
-        Tkm1.Scale(static_cast<ValueType>(2));
-        Tkm1.AddScalarDiagonal(static_cast<ValueType>(-1));
-        c = c * static_cast<ValueType>(-1) * q;
-        this->AIChebyshev_.MatrixAdd(Tkm1, one, c, true);
-        OperatorType Tk;
-        Tk.CloneBackend(*this->op_);
-        for(int i = 2; i <= this->p_; ++i)
-        {
-            Tk.MatrixMult(Z, Tkm1);
-            Tk.MatrixAdd(Tkm2, static_cast<ValueType>(2), static_cast<ValueType>(-1), true);
-            c = c * static_cast<ValueType>(-1) * q;
-            this->AIChebyshev_.MatrixAdd(Tk, one, c, true);
-            if(i + 1 <= this->p_)
-            {
-                Tkm2.CloneFrom(Tkm1);
-                Tkm1.CloneFrom(Tk);
-            }
-        }
-    }
-    virtual void Clear(void)
-    {
-        this->AIChebyshev_.Clear();
-        this->build_ = false;
-    }
-    virtual void Solve(const VectorType& rhs, VectorType* x)
-    {
-        assert(this->build_ == true && x != NULL && x != &rhs);
-        this->AIChebyshev_.Apply(rhs, x);
-    }
-
-private:
-    OperatorType AIChebyshev_;
-    int          p_;
-    ValueType    lambda_min_, lambda_max_;
-};
-
-// FSAI :217-361: factorised sparse approximate inverse, M^-1 = G^T G with G on the lower pattern of A; Solve = two SpMVs
-template <class OperatorType, class VectorType, typename ValueType>
-class FSAI : public Preconditioner<OperatorType, VectorType, ValueType>
-{
-public:
-    FSAI()
-        : matrix_power_(1)
-        , external_pattern_(false)
-        , matrix_pattern_(NULL)
-    {
-    }
-    virtual ~FSAI()
-    {
-        this->Clear();
-    }
-    virtual void Print(void) const
-    {
-        LOG_INFO("Factorized Sparse Approximate Inverse preconditioner");
-        if(this->build_)
-            LOG_INFO("FSAI matrix nnz = " << this->FSAI_L_.GetNnz() + this->FSAI_LT_.GetNnz() - this->FSAI_L_.GetM());
-    }
-    virtual void Set(int power)
-    {
-        assert(this->build_ == false && power > 0);
-        this->matrix_power_ = power;
-    }
-    virtual void Set(const OperatorType& pattern)
-    {
-        assert(this->build_ == false);
-        this->matrix_pattern_ = &pattern;
-    }
-    virtual void Build(void)
-    {
-        if(this->build_)
-            this->Clear();
-        this->build_ = true;
-        assert(this->op_ != NULL);
-        this->FSAI_L_.CloneFrom(*this->op_);
-        this->FSAI_L_.FSAI(this->matrix_power_, this->matrix_pattern_);
-        this->FSAI_LT_.CloneBackend(*this->op_);
-        this->FSAI_L_.Transpose(&this->FSAI_LT_);
-        this->t_.CloneBackend(*this->op_);
-        this->t_.Allocate("temporary", this->op_->GetM());
-    }
-    virtual void Clear(void)
-    {
-        if(this->build_)
-        {
-            this->FSAI_L_.Clear();
-            this->FSAI_LT_.Clear();
-            this->t_.Clear();
-            this->build_ = false;
-        }
-    }
-    virtual void Solve(const VectorType& rhs, VectorType* x)
-    {
-        assert(this->build_ == true && x != NULL && x != &rhs);
-        this->FSAI_L_.Apply(rhs, &this->t_);
-        this->FSAI_LT_.Apply(this->t_, x);
-    }
-    const OperatorType& GetFactor(void) const
-    {
-        return this->FSAI_L_;
-    }
-
-private:
-    OperatorType        FSAI_L_, FSAI_LT_;
-    VectorType          t_;
-    int                 matrix_power_;
-    bool                external_pattern_;
-    const OperatorType* matrix_pattern_;
-};
-
-// SPAI :363-475: sparse approximate inverse on the pattern of A; Solve = one SpMV
-template <class OperatorType, class VectorType, typename ValueType>
-class SPAI : public Preconditioner<OperatorType, VectorType, ValueType>
-{
-public:
-    virtual ~SPAI()
-    {
-        this->Clear();
-    }
-    virtual void Print(void) const
-    {
-        LOG_INFO("SParse Approximate Inverse preconditioner");
-        if(this->build_)
-            LOG_INFO("SPAI matrix nnz = " << this->SPAI_.GetNnz());
-    }
-    virtual void Build(void)
-    {
-        if(this->build_)
-            this->Clear();
-        this->build_ = true;
-        assert(this->op_ != NULL);
-        this->SPAI_.CloneFrom(*this->op_);
-        this->SPAI_.SPAI();
-    }
-    virtual void Clear(void)
-    {
-        if(this->build_)
-        {
-            this->SPAI_.Clear();
-            this->build_ = false;
-        }
-    }
-    virtual void Solve(const VectorType& rhs, VectorType* x)
-    {
-        assert(this->build_ == true && x != NULL && x != &rhs);
-        this->SPAI_.Apply(rhs, x);
-    }
-    const OperatorType& GetMatrix(void) const
-    {
-        return this->SPAI_;
-    }
-
-private:
-    OperatorType SPAI_;
-};
-
-// TNS :477-713: truncated Neumann series, (I - L D^-1 + (L D^-1)^2) D^-1 (I - D^-1 L^T + (D^-1 L^T)^2), applied
-// implicitly (default: four triangular SpMVs) or as one explicit matrix
-template <class OperatorType, class VectorType, typename ValueType>
-class TNS : public Preconditioner<OperatorType, VectorType, ValueType>
-{
-public:
-    TNS()
-        : impl_(true)
-    {
-    }
-    virtual ~TNS()
-    {
-        this->Clear();
-    }
-    virtual void Print(void) const
-    {
-        LOG_INFO("Truncated Neumann Series (TNS) Preconditioner");
-        LOG_INFO((this->impl_ ? "Implicit TNS L" : "Explicit TNS"));
-    }
-    virtual void Set(bool imp)
-    {
-        assert(this->build_ == false);
-        this->impl_ = imp;
-    }
-    virtual void Build(void)
-    {
-        if(this->build_)
-            this->Clear();
-        this->build_ = true;
-        assert(this->op_ != NULL);
-        if(this->impl_)
-        {
-            this->L_.CloneBackend(*this->op_);
-            this->LT_.CloneBackend(*this->op_);
-            this->tmp1_.CloneBackend(*this->op_);
-            this->tmp2_.CloneBackend(*this->op_);
-            this->Dinv_.CloneBackend(*this->op_);
-            this->op_->ExtractInverseDiagonal(&this->Dinv_);
-            this->op_->ExtractL(&this->L_, false);
-            this->L_.DiagonalMatrixMultR(this->Dinv_);
-            this->L_.Transpose(&this->LT_);
-            this->tmp1_.Allocate("tmp1 vec for TNS", this->op_->GetM());
-            this->tmp2_.Allocate("tmp2 vec for TNS", this->op_->GetM());
-        }
-        else
-        {
-            OperatorType K, KT;
-            this->L_.CloneBackend(*this->op_);
-            this->Dinv_.CloneBackend(*this->op_);
-            this->TNS_.CloneBackend(*this->op_);
-            K.CloneBackend(*this->op_);
-            KT.CloneBackend(*this->op_);
-            this->op_->ExtractInverseDiagonal(&this->Dinv_);
-            this->op_->ExtractL(&this->L_, true); // the diagonal entries stay in the pattern, flushed to zero
-            this->L_.ScaleDiagonal(static_cast<ValueType>(0));
-            this->L_.DiagonalMatrixMultR(this->Dinv_);
-            K.MatrixMult(this->L_, this->L_);
-            this->L_.AddScalarDiagonal(static_cast<ValueType>(-1));
-            K.MatrixAdd(this->L_, static_cast<ValueType>(1), static_cast<ValueType>(-1), true);
-            K.Transpose(&KT);
-            KT.DiagonalMatrixMultR(this->Dinv_);
-            this->TNS_.MatrixMult(KT, K);
-            K.Clear();
-            KT.Clear();
-            this->L_.Clear();
-            this->Dinv_.Clear();
-        }
-    }
-    virtual void Clear(void)
-    {
-        if(this->build_)
-        {
-            this->TNS_.Clear();
-            this->L_.Clear();
-            this->LT_.Clear();
-            this->Dinv_.Clear();
-            this->tmp1_.Clear();
-            this->tmp2_.Clear();
-            this->build_ = false;
-        }
-    }
-    virtual void Solve(const VectorType& rhs, VectorType* x)
-    {
-        assert(this->build_ == true && x != NULL && x != &rhs);
-        if(this->impl_)
-        {
-            this->L_.Apply(rhs, &this->tmp1_);
-            this->L_.Apply(this->tmp1_, &this->tmp2_);
-            this->tmp1_.AddScale(this->tmp2_, static_cast<ValueType>(-1));
-            x->CopyFrom(rhs);
-            x->AddScale(this->tmp1_, static_cast<ValueType>(-1));
-            x->PointWiseMult(this->Dinv_);
-            this->LT_.Apply(*x, &this->tmp1_);
-            this->LT_.Apply(this->tmp1_, &this->tmp2_);
-            x->ScaleAdd2(static_cast<ValueType>(1), this->tmp1_, static_cast<ValueType>(-1), this->tmp2_,
-                         static_cast<ValueType>(1));
-        }
-        else
-            this->TNS_.Apply(rhs, x);
-    }
-
-private:
-    OperatorType L_, LT_, TNS_;
-    VectorType   Dinv_, tmp1_, tmp2_;
-    bool         impl_;
-};
-
-// ---- ItILU0 (preconditioner.cpp:520-700): ILU(0) whose factors the reference's HIP backend approaches by asynchronous /
-// synchronous fixed-point sweeps (rocSPARSE csritilu0).  Its host backend -- the parity target -- returns the exact
-// ILU(0) (host_matrix_csr.cpp:2332-2341), and so does this backend: the level-ordered factorisation kernel IS the limit
-// of those sweeps and takes 0.26 s at 512^3.  Algorithm / option / tolerance setters are accepted; no sweeps are run and
-// the convergence history is empty.  Triangular solves follow the SolverDescr (direct or Jacobi sweeps).
-typedef enum _itilu0_alg : unsigned int
-{
-    Default         = 0,
-    AsyncInPlace    = 1,
-    AsyncSplit      = 2,
-    SyncSplit       = 3,
-    SyncSplitFusion = 4
-} ItILU0Algorithm;
-typedef enum _itilu0_option : unsigned int
-{
-    Verbose              = 1,
-    StoppingCriteria     = 2,
-    ComputeNrmCorrection = 4,
-    ComputeNrmResidual   = 8,
-    ConvergenceHistory   = 16,
-    COOFormat            = 32
-} ItILU0Option;
-
-template <class OperatorType, class VectorType, typename ValueType>
-class ItILU0 : public Preconditioner<OperatorType, VectorType, ValueType>
-{
-public:
-    ItILU0()
-        : alg_(Default)
-        , option_(0)
-        , maxiter_(100)
-        , tol_(1e-6)
-        , niter_(0)
-    {
-    }
-    virtual ~ItILU0()
-    {
-        this->Clear();
-    }
-    virtual void Print(void) const
-    {
-        LOG_INFO("ItILU0 preconditioner");
-        if(this->build_)
-            LOG_INFO("ItILU0 nnz = " << this->ItILU0_.GetNnz());
-    }
-    void SetAlgorithm(ItILU0Algorithm alg)
-    {
-        assert(this->build_ == false);
-        this->alg_ = alg;
-    }
-    void SetOptions(int option)
-    {
-        assert(this->build_ == false);
-        this->option_ = option;
-    }
-    void SetMaxIter(int max_iter)
-    {
-        assert(this->build_ == false);
-        this->maxiter_ = max_iter;
-    }
-    void SetTolerance(double tolerance)
-    {
-        assert(this->build_ == false);
-        this->tol_ = tolerance;
-    }
-    const double* GetConvergenceHistory(int* niter)
-    {
-        assert(niter != NULL);
-        *niter = this->niter_; // 0: the factorisation is computed exactly, no sweeps
-        return NULL;
-    }
-    virtual void Build(void)
-    {
-        if(this->build_)
-            this->Clear();
-        this->build_ = true;
-        assert(this->op_ != NULL);
-        this->ItILU0_.CloneFrom(*this->op_);
-        this->ItILU0_.ILU0Factorize();
-        this->niter_ = 0;
-        DISPATCH_OPERATOR_ANALYSE_STRATEGY(this->solver_descr_, this->ItILU0_, LUAnalyse);
-    }
-    virtual void Clear(void)
-    {
-        DISPATCH_OPERATOR_ANALYSE_STRATEGY(this->solver_descr_, this->ItILU0_, LUAnalyseClear);
-        this->ItILU0_.Clear();
-        this->build_ = false;
-    }
-    virtual void Solve(const VectorType& rhs, VectorType* x)
-    {
-        assert(this->build_ == true && x != NULL && x != &rhs);
-        DISPATCH_OPERATOR_SOLVE_STRATEGY(this->solver_descr_, this->ItILU0_, LUSolve, rhs, x);
-    }
-
-private:
-    OperatorType    ItILU0_;
-    ItILU0Algorithm alg_;
-    int             option_;
-    int             maxiter_;
-    double          tol_;
-    int             niter_;
-};
-
 // ---- GS / SGS: preconditioner.cpp:206-257 / :302-379 (sparse triangular solves on the matrix itself).
 // SGS::Build fills diag_entries_ with the INVERSE diagonal (:318, ExtractInverseDiagonal) -- kept as is.
 template <class OperatorType, class VectorType, typename ValueType>
@@ -4010,127 +3128,6 @@ private:
     VectorType x_old_, x_res_;
 };
 
-// ============================================================================ Chebyshev
-// src/solvers/chebyshev.cpp:230-360; the eigenvalue bounds come from the caller (Set)
-template <class OperatorType, class VectorType, typename ValueType>
-class Chebyshev : public IterativeLinearSolver<OperatorType, VectorType, ValueType>
-{
-public:
-    Chebyshev()
-        : init_lambda_(false)
-        , lambda_min_(static_cast<ValueType>(0))
-        , lambda_max_(static_cast<ValueType>(0))
-    {
-    }
-    virtual ~Chebyshev()
-    {
-        this->Clear();
-    }
-    virtual void Print(void) const
-    {
-        LOG_INFO("Chebyshev solver" << (this->precond_ ? ", with preconditioner" : " (non-precond)"));
-    }
-    void Set(ValueType lambda_min, ValueType lambda_max)
-    {
-        this->lambda_min_  = lambda_min;
-        this->lambda_max_  = lambda_max;
-        this->init_lambda_ = true;
-    }
-    virtual void Build(void)
-    {
-        if(this->build_)
-            this->Clear();
-        assert(this->op_ != NULL && this->op_->GetM() == this->op_->GetN() && this->op_->GetM() > 0);
-        assert(this->init_lambda_ == true);
-        this->build_ = true;
-        if(this->precond_ != NULL)
-        {
-            this->precond_->SetOperator(*this->op_);
-            this->precond_->Build();
-            this->z_.CloneBackend(*this->op_);
-            this->z_.Allocate("z", this->op_->GetM());
-        }
-        this->r_.CloneBackend(*this->op_);
-        this->r_.Allocate("r", this->op_->GetM());
-        this->p_.CloneBackend(*this->op_);
-        this->p_.Allocate("p", this->op_->GetM());
-    }
-    virtual void Clear(void)
-    {
-        if(this->build_)
-        {
-            if(this->precond_ != NULL)
-            {
-                this->precond_->Clear();
-                this->precond_ = NULL;
-            }
-            this->r_.Clear();
-            this->z_.Clear();
-            this->p_.Clear();
-            this->iter_ctrl_.Clear();
-            this->build_ = false;
-        }
-    }
-
-protected:
-    virtual void PrintStart_(void) const
-    {
-        LOG_INFO("Chebyshev " << (this->precond_ ? "" : "(non-precond) ") << "linear solver starts");
-    }
-    virtual void PrintEnd_(void) const
-    {
-        LOG_INFO("Chebyshev ends");
-    }
-    virtual void SolveNonPrecond_(const VectorType& rhs, VectorType* x)
-    {
-        this->Solve_(rhs, x, false);
-    }
-    virtual void SolvePrecond_(const VectorType& rhs, VectorType* x)
-    {
-        this->Solve_(rhs, x, true);
-    }
-
-private:
-    void Solve_(const VectorType& rhs, VectorType* x, bool precond)
-    {
-        const OperatorType* op = this->op_;
-        VectorType *        r = &this->r_, *p = &this->p_;
-        VectorType*         z = precond ? &this->z_ : r;
-        const ValueType     two = static_cast<ValueType>(2), one = static_cast<ValueType>(1);
-        ValueType           alpha, beta;
-        const ValueType     d = (this->lambda_max_ + this->lambda_min_) / two;
-        const ValueType     c = (this->lambda_max_ - this->lambda_min_) / two;
-        op->Apply(*x, r);
-        r->ScaleAdd(-one, rhs);
-        ValueType res = this->Norm_(*r);
-        if(this->iter_ctrl_.InitResidual(std::abs(res)) == false)
-            return;
-        if(precond)
-            this->precond_->SolveZeroSol(*r, z);
-        p->CopyFrom(*z);
-        alpha = two / d;
-        x->AddScale(*p, alpha);
-        op->Apply(*x, r);
-        r->ScaleAdd(-one, rhs);
-        res = this->Norm_(*r);
-        while(!this->iter_ctrl_.CheckResidual(std::abs(res), this->index_))
-        {
-            if(precond)
-                this->precond_->SolveZeroSol(*r, z);
-            beta  = (c * alpha / two) * (c * alpha / two);
-            alpha = one / (d - beta);
-            p->ScaleAdd(beta, *z);
-            x->AddScale(*p, alpha);
-            op->Apply(*x, r);
-            r->ScaleAdd(-one, rhs);
-            res = this->Norm_(*r);
-        }
-    }
-    bool       init_lambda_;
-    ValueType  lambda_min_, lambda_max_;
-    VectorType r_, z_, p_;
-};
-
 // ============================================================================ MixedPrecisionDC
 // mixed_precision.cpp:159-236 (Build) and :372-437 (solve).  The reference keeps the fp64 defect
 // correction on the HOST and ships r / d across PCIe every outer step; here both levels live on the
@@ -5030,96 +4027,6 @@ protected:
     ValueType          relax_;
     CoarseningStrategy strat_;
     LumpingStrategy    lumping_strat_;
-};
-
-typedef enum _interpolation_type
-{
-    Direct = 0,
-    ExtPI  = 1
-} InterpolationType;
-
-// RugeStuebenAMG (src/solvers/multigrid/ruge_stueben_amg.cpp): classical AMG.  Built here: PMIS C/F splitting with
-// direct interpolation; the sequential Greedy splitting (the reference's default) and Ext+i interpolation are not.
-template <class OperatorType, class VectorType, typename ValueType>
-class RugeStuebenAMG : public BaseAMG<OperatorType, VectorType, ValueType>
-{
-public:
-    RugeStuebenAMG()
-        : eps_(0.25f)
-        , FF1_(false)
-        , coarsening_(Greedy)
-        , interpolation_(Direct)
-    {
-        this->scaling_ = false;
-    }
-    virtual ~RugeStuebenAMG()
-    {
-        this->Clear();
-    }
-    virtual void Print(void) const
-    {
-        LOG_INFO("AMG solver");
-        LOG_INFO("AMG number of levels " << this->levels_);
-        LOG_INFO("AMG Ruge-Stuben coarsening");
-    }
-    virtual void SetStrengthThreshold(float eps)
-    {
-        this->eps_ = eps;
-    }
-    virtual void SetCouplingStrength(ValueType eps) // older name of the same parameter
-    {
-        this->eps_ = (float)eps;
-    }
-    virtual void SetCoarseningStrategy(CoarseningStrategy strat)
-    {
-        this->coarsening_ = strat;
-    }
-    virtual void SetInterpolationType(InterpolationType type)
-    {
-        this->interpolation_ = type;
-    }
-    virtual void SetInterpolationFF1Limit(bool FF1)
-    {
-        this->FF1_ = FF1;
-    }
-
-protected:
-    virtual void PrintStart_(void) const
-    {
-        LOG_INFO("AMG solver starts");
-        LOG_INFO("AMG number of levels " << this->levels_);
-    }
-    virtual void PrintEnd_(void) const
-    {
-        LOG_INFO("AMG ends");
-    }
-    // ruge_stueben_amg.cpp:277-342
-    virtual bool Aggregate_(const OperatorType& op, OperatorType* pro, OperatorType* res, OperatorType* coarse)
-    {
-        assert(pro != NULL && res != NULL && coarse != NULL);
-        if(this->coarsening_ != PMIS || this->interpolation_ != Direct)
-        {
-            LOG_INFO("RugeStuebenAMG: this backend provides CoarseningStrategy PMIS with InterpolationType Direct "
-                     "(SetCoarseningStrategy(PMIS)); the sequential Greedy splitting and Ext+i interpolation are not built");
-            FATAL_ERROR(__FILE__, __LINE__);
-        }
-        LocalVector<int> CFmap, S;
-        op.RSPMISCoarsening(this->eps_, &CFmap, &S);
-        op.RSDirectInterpolation(CFmap, S, pro);
-        CFmap.Clear();
-        S.Clear();
-        if(pro->GetN() == 0)
-            return false;
-        pro->Transpose(res);
-        coarse->CloneBackend(op);
-        coarse->TripleMatrixProduct(*res, op, *pro);
-        return true;
-    }
-
-    float              eps_;
-    bool               FF1_;
-    CoarseningStrategy coarsening_;
-    InterpolationType  interpolation_;
 };
 
 } // namespace rocalution

@@ -326,6 +326,28 @@ int ramd_timer_start(void); /* records an event on the current stream */
 int ramd_timer_stop(double* elapsed_ms); /* records, synchronises, returns the elapsed time */
 int ramd_prof_spmv_enable(int on); /* bracket SpMV launches with event pairs (ring of 8192) */
 int ramd_prof_spmv_result(int* launches, double* avg_ms, double* min_ms, double* max_ms);
+/* the same for the other launch kinds of a Krylov iteration (measurement only; the reference has no counterpart --
+ * its benchmark driver brackets whole calls with host timers, clients/samples/benchmark.cpp:62-226):
+ *   SPMV      every SpMV launch (Apply / ApplyAdd / fused Apply+dot) on the stream it runs on
+ *   TRSV      every sparse triangular solve launch (one per triangle of LUSolve / LSolve / USolve / LLSolve)
+ *   HALO      every halo exchange (grouped ncclSend/ncclRecv) on the ghost stream
+ *   HALO_WAIT the part of a halo exchange the compute stream had to wait for (exposed, not overlapped)
+ *   ALLREDUCE every scalar all-reduce (counted; timed on the compute stream)
+ *   VEC       the fused vector-update launches of the Krylov loops (k_cg_update, k_cg_direction, k_mgs_step, ...)
+ * ramd_prof_count: occurrences since the channel was enabled (not limited by the event ring). */
+enum
+{
+    RAMD_PROF_SPMV      = 0,
+    RAMD_PROF_TRSV      = 1,
+    RAMD_PROF_HALO      = 2,
+    RAMD_PROF_HALO_WAIT = 3,
+    RAMD_PROF_ALLREDUCE = 4,
+    RAMD_PROF_VEC       = 5,
+    RAMD_PROF_NCHAN     = 6
+};
+int ramd_prof_enable(int channel, int on);
+int ramd_prof_result(int channel, int* launches, double* avg_ms, double* min_ms, double* max_ms);
+int ramd_prof_count(int channel, int64_t* count);
 
 /* ======================================================================= communicator
  * Replaces the reference's MPI layer for the hot path (src/utils/communicator.cpp:41-95 allreduce,
@@ -349,6 +371,7 @@ int ramd_comm_init_callback(int rank, int nranks, ramd_exchange_cb exchange, ram
 int ramd_comm_destroy(ramd_comm_t c);
 int ramd_comm_rank(ramd_comm_t c, int* rank);
 int ramd_comm_size(ramd_comm_t c, int* size);
+int ramd_comm_rccl_count(ramd_comm_t c, int* nranks); /* ncclCommCount of the data-plane communicator (0: callback transport) */
 /* in-place sum over all ranks of scalar slots [first, first+count) of the device record, queued on
  * the current stream (one call for ALL scalars of a fused reduction) */
 int ramd_comm_allreduce_scalars(ramd_comm_t c, int first, int count);
@@ -372,17 +395,13 @@ enum { RAMD_SOLVER_CG = 0, RAMD_SOLVER_GMRES = 1, RAMD_SOLVER_BICGSTAB = 2,
        RAMD_SOLVER_FCG = 3, RAMD_SOLVER_CR = 4, RAMD_SOLVER_FGMRES = 5, RAMD_SOLVER_BICGSTABL = 6,
        RAMD_SOLVER_QMRCGSTAB = 7,
        RAMD_SOLVER_IDR = 8, /* idr.cpp; set_basis = SetShadowSpace, ramd_solver_set_seed = SetRandomSeed */
-       /* solver.cpp:517-775 FixedPoint, chebyshev.cpp; parameters through ramd_solver_set_params */
-       RAMD_SOLVER_FIXEDPOINT = 9, RAMD_SOLVER_CHEBYSHEV = 10 };
+       /* solver.cpp:517-775 FixedPoint; relaxation / smoother flag through ramd_solver_set_params */
+       RAMD_SOLVER_FIXEDPOINT = 9 };
 enum { RAMD_PC_NONE = 0, RAMD_PC_JACOBI = 1, RAMD_PC_ILU0 = 2, RAMD_PC_MCSGS = 3, RAMD_PC_MCGS = 4, RAMD_PC_MCILU = 5,
        RAMD_PC_GS = 6, RAMD_PC_SGS = 7, /* preconditioner.cpp:206-257 / :302-379 */
        RAMD_PC_IC = 8, /* :862-925 */
        /* unsmoothed_amg.cpp / smoothed_amg.cpp with CoarseningStrategy PMIS, default smoothers and coarse solver */
-       RAMD_PC_UAAMG = 9, RAMD_PC_SAAMG = 10,
-       /* preconditioner_ai.cpp: AIChebyshev :41-215 (params p, lambda_min, lambda_max), TNS :477-713 (param implicit) */
-       RAMD_PC_AICHEBYSHEV = 11, RAMD_PC_TNS = 12, RAMD_PC_FSAI = 13, /* :217-361 */
-       RAMD_PC_SPAI = 15, /* preconditioner_ai.cpp SPAI */
-       RAMD_PC_ITILU0 = 14 /* preconditioner.cpp:520-700; factors = exact ILU(0) as on the reference's host backend */ };
+       RAMD_PC_UAAMG = 9, RAMD_PC_SAAMG = 10 };
 int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out);
 /* MixedPrecisionDC<fp64 outer, fp32 inner>: inner solver/preconditioner kinds */
 int ramd_solver_create_mixed(int inner_solver, int inner_precond, ramd_solver_t* out);
@@ -392,12 +411,12 @@ int ramd_solver_init(ramd_solver_t s, double abs_tol, double rel_tol, double div
 int ramd_solver_init_inner(ramd_solver_t s, double abs_tol, double rel_tol, double div_tol, int max_iter);
 int ramd_solver_set_basis(ramd_solver_t s, int size_basis); /* GMRES::SetBasisSize */
 int ramd_solver_set_seed(ramd_solver_t s, unsigned long long seed); /* IDR::SetRandomSeed (idr.cpp:277-285) */
-/* FixedPoint: p0 = SetRelaxation(omega), p1 != 0 -> FlagSmoother();  Chebyshev: Set(lambda_min = p0, lambda_max = p1) */
+/* FixedPoint: p0 = SetRelaxation(omega), p1 != 0 -> FlagSmoother() */
 int ramd_solver_set_params(ramd_solver_t s, double p0, double p1);
 /* Solver::SetSolverDescriptor on the preconditioner (solver.cpp:293-301, SolverDescr solver.hpp:82-148): iterative != 0
  * selects TriSolverAlg_Iterative with the given sweep limit / tolerance / tolerance switch; before build */
 int ramd_solver_set_tri_solver(ramd_solver_t s, int iterative, int max_iter, double tol, int use_tol);
-/* parameters of the preconditioner: AIChebyshev::Set(p0 = p, p1 = lambda_min, p2 = lambda_max), TNS::Set(p0 != 0: implicit) */
+/* parameters of the preconditioner: ILU::Set(p0 = p, p1 != 0: level) */
 int ramd_solver_set_precond_params(ramd_solver_t s, double p0, double p1, double p2);
 int ramd_solver_set_fused(ramd_solver_t s, int on); /* fused device loops on/off (default on) */
 int ramd_solver_set_verbose(ramd_solver_t s, int verb);

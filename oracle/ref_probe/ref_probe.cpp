@@ -1365,13 +1365,31 @@ static int cmd_bench(int argc, char** argv)
     if(threads > 0)
         set_omp_threads_rocalution(threads);
 
-    std::vector<int32_t> rp, ci;
-    std::vector<double>  va;
-    poisson7(N, rp, ci, va);
-    int64_t n = (int64_t)N * N * N, nnz = (int64_t)ci.size();
+    // argv[2]: grid edge of the synthetic 7-point operator, or the path of a MatrixMarket file (config 3's input)
+    const std::string src(argv[2]);
+    const bool        from_file = src.size() > 4 && src.substr(src.size() - 4) == ".mtx";
+    int64_t n = 0, nnz = 0;
     MatD    mat;
-    mat.AllocateCSR("poisson7", nnz, n, n);
-    mat.CopyFromCSR(rp.data(), ci.data(), va.data());
+    double  t_read = 0.0;
+    if(from_file)
+    {
+        double tr0 = rocalution_time();
+        mat.ReadFileMTX(src);
+        t_read = (rocalution_time() - tr0) / 1e6;
+        n      = mat.GetM();
+        nnz    = mat.GetNnz();
+        N      = 0;
+    }
+    else
+    {
+        std::vector<int32_t> rp, ci;
+        std::vector<double>  va;
+        poisson7(N, rp, ci, va);
+        n   = (int64_t)N * N * N;
+        nnz = (int64_t)ci.size();
+        mat.AllocateCSR("poisson7", nnz, n, n);
+        mat.CopyFromCSR(rp.data(), ci.data(), va.data());
+    }
     VecD x, rhs, e;
     if(accel)
     {
@@ -1444,9 +1462,9 @@ static int cmd_bench(int argc, char** argv)
     double bytes   = 4.0 * (n + nnz) + 8.0 * (2.0 * n + nnz);
     printf("{\"ref_probe\":\"bench\",\"N\":%d,\"n\":%lld,\"nnz\":%lld,\"accel\":%d,\"threads\":%d,"
            "\"solver\":\"%s\",\"precond\":\"%s\",\"iters\":%d,\"t_build_s\":%.6f,\"t_solve_s\":%.6f,"
-           "\"iters_per_s\":%.4f,\"t_spmv_s\":%.9f,\"spmv_GBps\":%.3f,\"final_res\":%.17g}\n",
+           "\"iters_per_s\":%.4f,\"t_spmv_s\":%.9f,\"spmv_GBps\":%.3f,\"final_res\":%.17g,\"t_read_s\":%.3f}\n",
            N, (long long)n, (long long)nnz, accel, threads, solver.c_str(), precond.c_str(), it,
-           t_build, t_solve, it / t_solve, t_spmv, bytes / t_spmv / 1e9, ls->GetCurrentResidual());
+           t_build, t_solve, it / t_solve, t_spmv, bytes / t_spmv / 1e9, ls->GetCurrentResidual(), t_read);
     ls->Clear();
     stop_rocalution();
     return 0;

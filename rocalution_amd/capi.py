@@ -15,8 +15,8 @@ if os.environ.get("RAMD_LIB"):  # A/B runs of differently built libraries (tools
 OK, ERR_HIP, ERR_ARG, ERR_UNSUPPORTED, ERR_REFUSED, ERR_NO_DEVICE, ERR_STATE = range(7)
 SOLVER_CG, SOLVER_GMRES, SOLVER_BICGSTAB = 0, 1, 2
 SOLVER_FCG, SOLVER_CR, SOLVER_FGMRES, SOLVER_BICGSTABL, SOLVER_QMRCGSTAB, SOLVER_IDR = 3, 4, 5, 6, 7, 8
-SOLVER_FIXEDPOINT, SOLVER_CHEBYSHEV = 9, 10
-PC_NONE, PC_JACOBI, PC_ILU0, PC_MCSGS, PC_MCGS, PC_MCILU, PC_GS, PC_SGS, PC_IC, PC_UAAMG, PC_SAAMG, PC_AICHEBYSHEV, PC_TNS, PC_FSAI, PC_ITILU0, PC_SPAI = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15
+SOLVER_FIXEDPOINT = 9
+PC_NONE, PC_JACOBI, PC_ILU0, PC_MCSGS, PC_MCGS, PC_MCILU, PC_GS, PC_SGS, PC_IC, PC_UAAMG, PC_SAAMG = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 F64, F32, I32 = 0, 1, 2
 CSR, COO, DIA, ELL, HYB = 1, 4, 5, 6, 7
 
@@ -174,6 +174,10 @@ SIGNATURES = {
     "ramd_timer_stop": (i32, [pf64]),
     "ramd_prof_spmv_enable": (i32, [i32]),
     "ramd_prof_spmv_result": (i32, [pi32, pf64, pf64, pf64]),
+    "ramd_prof_enable": (i32, [i32, i32]),
+    "ramd_prof_result": (i32, [i32, pi32, pf64, pf64, pf64]),
+    "ramd_prof_count": (i32, [i32, pi64]),
+    "ramd_comm_rccl_count": (i32, [ptr, pi32]),
     # communicator
     "ramd_comm_unique_id": (i32, [C.c_char_p]),
     "ramd_comm_init_rccl": (i32, [i32, i32, C.c_char_p, C.POINTER(ptr)]),

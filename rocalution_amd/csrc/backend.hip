@@ -347,64 +347,111 @@ int ramd_timer_stop(double* elapsed_ms)
 
 namespace ramd
 {
-constexpr int     kProfRing = 8192;
-static bool       g_prof_on = false;
-static int        g_prof_n  = 0;
-static hipEvent_t g_prof_ev[2 * kProfRing];
-static bool       g_prof_init = false;
+// HIP-event brackets around the launches of one kind (bench.py roofline / scaling legs): a ring of event pairs per
+// channel, recorded on the stream the launch goes to.  Off by default: no events, no cost.
+constexpr int kProfRing = 8192;
+struct ProfChan
+{
+    bool        on   = false;
+    bool        init = false;
+    int         n    = 0;
+    hipEvent_t* ev   = nullptr; // 2 * kProfRing
+};
+static ProfChan g_prof[RAMD_PROF_NCHAN];
+static int64_t  g_prof_count[RAMD_PROF_NCHAN] = {0};
 
+void prof_begin(int ch, hipStream_t s)
+{
+    ProfChan& c = g_prof[ch];
+    if(c.on && c.n < kProfRing)
+        (void)hipEventRecord(c.ev[2 * c.n], s ? s : backend().cur);
+}
+void prof_end(int ch, hipStream_t s)
+{
+    ProfChan& c = g_prof[ch];
+    ++g_prof_count[ch];
+    if(c.on && c.n < kProfRing)
+    {
+        (void)hipEventRecord(c.ev[2 * c.n + 1], s ? s : backend().cur);
+        ++c.n;
+    }
+}
+void prof_count(int ch)
+{
+    ++g_prof_count[ch];
+}
 void prof_spmv_begin()
 {
-    if(g_prof_on && g_prof_n < kProfRing)
-        (void)hipEventRecord(g_prof_ev[2 * g_prof_n], backend().cur);
+    prof_begin(RAMD_PROF_SPMV, nullptr);
 }
 void prof_spmv_end()
 {
-    if(g_prof_on && g_prof_n < kProfRing)
-    {
-        (void)hipEventRecord(g_prof_ev[2 * g_prof_n + 1], backend().cur);
-        ++g_prof_n;
-    }
+    prof_end(RAMD_PROF_SPMV, nullptr);
 }
 } // namespace ramd
 
 extern "C" {
 
-int ramd_prof_spmv_enable(int on)
+int ramd_prof_enable(int channel, int on)
 {
     RAMD_TRY(ensure_init());
-    if(on && !g_prof_init)
+    if(channel < 0 || channel >= RAMD_PROF_NCHAN)
+        RAMD_FAIL(RAMD_ERR_ARG, "profiling channel out of range");
+    ProfChan& c = g_prof[channel];
+    if(on && !c.init)
     {
+        c.ev = new hipEvent_t[2 * kProfRing];
         for(int i = 0; i < 2 * kProfRing; ++i)
-            RAMD_HIP(hipEventCreate(&g_prof_ev[i]));
-        g_prof_init = true;
+            RAMD_HIP(hipEventCreate(&c.ev[i]));
+        c.init = true;
     }
-    g_prof_on = on != 0;
+    c.on = on != 0;
     if(on)
-        g_prof_n = 0;
+    {
+        c.n                   = 0;
+        g_prof_count[channel] = 0;
+    }
     return RAMD_OK;
 }
-int ramd_prof_spmv_result(int* launches, double* avg_ms, double* min_ms, double* max_ms)
+int ramd_prof_result(int channel, int* launches, double* avg_ms, double* min_ms, double* max_ms)
 {
+    if(channel < 0 || channel >= RAMD_PROF_NCHAN)
+        RAMD_FAIL(RAMD_ERR_ARG, "profiling channel out of range");
     RAMD_HIP(hipDeviceSynchronize());
-    double sum = 0.0, mn = 1e30, mx = 0.0;
-    for(int i = 0; i < g_prof_n; ++i)
+    ProfChan& c   = g_prof[channel];
+    double    sum = 0.0, mn = 1e30, mx = 0.0;
+    for(int i = 0; i < c.n; ++i)
     {
         float ms = 0.f;
-        RAMD_HIP(hipEventElapsedTime(&ms, g_prof_ev[2 * i], g_prof_ev[2 * i + 1]));
+        RAMD_HIP(hipEventElapsedTime(&ms, c.ev[2 * i], c.ev[2 * i + 1]));
         sum += ms;
         mn = ms < mn ? ms : mn;
         mx = ms > mx ? ms : mx;
     }
     if(launches)
-        *launches = g_prof_n;
+        *launches = c.n;
     if(avg_ms)
-        *avg_ms = g_prof_n ? sum / g_prof_n : 0.0;
+        *avg_ms = c.n ? sum / c.n : 0.0;
     if(min_ms)
-        *min_ms = g_prof_n ? mn : 0.0;
+        *min_ms = c.n ? mn : 0.0;
     if(max_ms)
         *max_ms = mx;
     return RAMD_OK;
+}
+int ramd_prof_count(int channel, int64_t* count)
+{
+    if(channel < 0 || channel >= RAMD_PROF_NCHAN || !count)
+        RAMD_FAIL(RAMD_ERR_ARG, "profiling channel out of range");
+    *count = g_prof_count[channel];
+    return RAMD_OK;
+}
+int ramd_prof_spmv_enable(int on)
+{
+    return ramd_prof_enable(RAMD_PROF_SPMV, on);
+}
+int ramd_prof_spmv_result(int* launches, double* avg_ms, double* min_ms, double* max_ms)
+{
+    return ramd_prof_result(RAMD_PROF_SPMV, launches, avg_ms, min_ms, max_ms);
 }
 
 // ---------------------------------------------------------------- scalar records

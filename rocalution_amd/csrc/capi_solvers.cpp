@@ -63,11 +63,6 @@ struct Precs
     IC<M, V, T>              ic;
     UAAMG<M, V, T>           uaamg;
     SAAMG<M, V, T>           saamg;
-    AIChebyshev<M, V, T>     aicheb;
-    TNS<M, V, T>             tns;
-    FSAI<M, V, T>            fsai;
-    ItILU0<M, V, T>          itilu0;
-    SPAI<M, V, T>            spai;
     Precs()
     {
         // the aggregation runs on the device with the PMIS strategy (the Greedy default is a sequential host sweep)
@@ -80,16 +75,6 @@ struct Precs
     {
         switch(kind)
         {
-        case RAMD_PC_AICHEBYSHEV:
-            return &aicheb;
-        case RAMD_PC_TNS:
-            return &tns;
-        case RAMD_PC_FSAI:
-            return &fsai;
-        case RAMD_PC_ITILU0:
-            return &itilu0;
-        case RAMD_PC_SPAI:
-            return &spai;
         case RAMD_PC_UAAMG:
             return &uaamg;
         case RAMD_PC_SAAMG:
@@ -140,7 +125,6 @@ struct LocalSolver : SolverBase
     QMRCGStab<M, V, T>                              qmr;
     IDR<M, V, T>                                    idr;
     FixedPoint<M, V, T>                             fp;
-    Chebyshev<M, V, T>                              cheb;
     Precs<T>                                        pcs;
     M                                               op; // non-owning view of the caller's matrix
     bool                                            built = false;
@@ -173,8 +157,6 @@ struct LocalSolver : SolverBase
             return &idr;
         case RAMD_SOLVER_FIXEDPOINT:
             return &fp;
-        case RAMD_SOLVER_CHEBYSHEV:
-            return &cheb;
         default:
             return &cg;
         }
@@ -206,8 +188,6 @@ struct LocalSolver : SolverBase
             if(p1 != 0.0)
                 fp.FlagSmoother();
         }
-        else if(solver_kind == RAMD_SOLVER_CHEBYSHEV)
-            cheb.Set((T)p0, (T)p1);
     }
     void set_tri_solver(int alg, int max_iter, double tol, int use_tol) override
     {
@@ -224,13 +204,8 @@ struct LocalSolver : SolverBase
     }
     void set_precond_params(double p0, double p1, double p2) override
     {
-        if(pc_kind == RAMD_PC_AICHEBYSHEV)
-            pcs.aicheb.Set((int)p0, (T)p1, (T)p2);
-        else if(pc_kind == RAMD_PC_TNS)
-            pcs.tns.Set(p0 != 0.0);
-        else if(pc_kind == RAMD_PC_FSAI) // FSAI::Set(power)
-            pcs.fsai.Set((int)p0);
-        else if(pc_kind == RAMD_PC_ILU0) // ILU::Set(p, level)
+        (void)p2;
+        if(pc_kind == RAMD_PC_ILU0) // ILU::Set(p, level)
             pcs.ilu.Set((int)p0, p1 != 0.0);
     }
     void set_fused(bool f) override
@@ -501,7 +476,7 @@ extern "C" {
 
 int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out)
 {
-    if(!out || solver < 0 || solver > RAMD_SOLVER_CHEBYSHEV || precond < 0 || precond > RAMD_PC_SPAI
+    if(!out || solver < 0 || solver > RAMD_SOLVER_FIXEDPOINT || precond < 0 || precond > RAMD_PC_SAAMG
        || (dtype != RAMD_F64 && dtype != RAMD_F32))
         return RAMD_ERR_ARG;
     GUARD_BEGIN
@@ -516,7 +491,7 @@ int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out)
 
 int ramd_solver_create_mixed(int inner_solver, int inner_precond, ramd_solver_t* out)
 {
-    if(!out || inner_solver < 0 || inner_solver > 2 || inner_precond < 0 || inner_precond > RAMD_PC_SPAI)
+    if(!out || inner_solver < 0 || inner_solver > 2 || inner_precond < 0 || inner_precond > RAMD_PC_SAAMG)
         return RAMD_ERR_ARG;
     GUARD_BEGIN
     ramd_solver_s* s = new ramd_solver_s;
@@ -770,7 +745,7 @@ int ramd_solver_clear(ramd_solver_t s)
 // ------------------------------------------------------------------------------------ distributed
 int ramd_gsolver_create(ramd_comm_t comm, int solver, int precond, ramd_gsolver_t* out)
 {
-    if(!out || solver < 0 || solver > 2 || precond < 0 || precond > RAMD_PC_SPAI)
+    if(!out || solver < 0 || solver > 2 || precond < 0 || precond > RAMD_PC_SAAMG)
         return RAMD_ERR_ARG;
     GUARD_BEGIN
     ramd_gsolver_s* g = new ramd_gsolver_s;

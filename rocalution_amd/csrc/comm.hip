@@ -7,6 +7,7 @@
 // the compute stream; events, not host syncs, order the two.  Scalars of a fused reduction are summed
 // by ONE ncclAllReduce on the device scalar record.
 #include "common.hpp"
+#include "matrix_impl.hpp"
 
 #include <rccl/rccl.h>
 
@@ -136,6 +137,16 @@ int ramd_comm_size(ramd_comm_t c, int* size)
     return RAMD_OK;
 }
 
+int ramd_comm_rccl_count(ramd_comm_t c, int* nranks)
+{
+    if(!nranks)
+        RAMD_FAIL(RAMD_ERR_ARG, "null output");
+    *nranks = 0;
+    if(c && c->use_rccl)
+        RAMD_NCCL(ncclCommCount(c->nccl, nranks));
+    return RAMD_OK;
+}
+
 int ramd_comm_allreduce_scalars(ramd_comm_t c, int first, int count)
 {
     // RAMD_COMM_FORCE_COLLECTIVES=1: do not skip the collective on a communicator of size 1 (plumbing check)
@@ -147,10 +158,13 @@ int ramd_comm_allreduce_scalars(ramd_comm_t c, int first, int count)
     Backend& b = backend();
     if(c->use_rccl)
     {
+        prof_begin(RAMD_PROF_ALLREDUCE, b.cur);
         RAMD_NCCL(ncclAllReduce(b.d_scalars + first, b.d_scalars + first, (size_t)count, ncclDouble,
                                 ncclSum, c->nccl, b.cur));
+        prof_end(RAMD_PROF_ALLREDUCE, b.cur);
         return RAMD_OK;
     }
+    prof_count(RAMD_PROF_ALLREDUCE);
     double tmp[kScalarSlots];
     RAMD_HIP(hipMemcpyAsync(tmp, b.d_scalars + first, sizeof(double) * count, hipMemcpyDeviceToHost,
                             b.cur));
@@ -189,6 +203,7 @@ int ramd_comm_halo_begin(ramd_comm_t c, ramd_vec_t send, ramd_vec_t recv, int np
     // the exchange may start once the pack kernel (already queued on the current stream) is done
     RAMD_HIP(hipEventRecord(c->ev_packed, b.cur));
     RAMD_HIP(hipStreamWaitEvent(b.stream_ghost, c->ev_packed, 0));
+    prof_begin(RAMD_PROF_HALO, b.stream_ghost);
     if(c->use_rccl)
     {
         const ncclDataType_t dt = (send->dtype == RAMD_F64) ? ncclDouble : ncclFloat;
@@ -225,6 +240,7 @@ int ramd_comm_halo_begin(ramd_comm_t c, ramd_vec_t send, ramd_vec_t recv, int np
         if(rb > 0)
             RAMD_HIP(hipMemcpyAsync(recv->d, c->h_recv, rb, hipMemcpyHostToDevice, b.stream_ghost));
     }
+    prof_end(RAMD_PROF_HALO, b.stream_ghost);
     RAMD_HIP(hipEventRecord(c->ev_halo, b.stream_ghost));
     return RAMD_OK;
 }
@@ -233,7 +249,10 @@ int ramd_comm_halo_end(ramd_comm_t c)
 {
     if(!c)
         return RAMD_OK;
+    // the two events bracket only the wait: their distance is the part of the exchange the interior SpMV did not hide
+    prof_begin(RAMD_PROF_HALO_WAIT, backend().cur);
     RAMD_HIP(hipStreamWaitEvent(backend().cur, c->ev_halo, 0));
+    prof_end(RAMD_PROF_HALO_WAIT, backend().cur);
     return RAMD_OK;
 }
 

@@ -582,12 +582,14 @@ int ramd_fused_cg_update(ramd_vec_t r, ramd_vec_t q, ramd_vec_t dinv, ramd_vec_t
                                (T*)r->d, (const T*)q->d, (const T*)nullptr, (T*)nullptr, ctx,          \
                                slot_rho, slot_pq, slot_rr, slot_rz);                                   \
     } while(0)
+    prof_begin(RAMD_PROF_VEC, b.cur);
     if(r->dtype == RAMD_F64)
         GO(double);
     else if(r->dtype == RAMD_F32)
         GO(float);
     else
         RAMD_FAIL(RAMD_ERR_ARG, "fused_cg_update needs real vectors");
+    prof_end(RAMD_PROF_VEC, b.cur);
 #undef GO
     RAMD_HIP(hipGetLastError());
     return RAMD_OK;
@@ -607,6 +609,7 @@ int ramd_fused_cg_direction(ramd_vec_t x, ramd_vec_t p, ramd_vec_t z, int slot_r
     static int nts = -1;
     if(nts < 0)
         nts = getenv("RAMD_NT_STORES") ? atoi(getenv("RAMD_NT_STORES")) : 0;
+    prof_begin(RAMD_PROF_VEC, b.cur);
     if(p->dtype == RAMD_F64 && nts)
         hipLaunchKernelGGL((k_cg_direction<double, true>), dim3(grid), dim3(kBlock), 0, b.cur, p->n,
                            (double*)x->d, (double*)p->d, (const double*)z->d, b.d_scalars, slot_rho,
@@ -621,6 +624,7 @@ int ramd_fused_cg_direction(ramd_vec_t x, ramd_vec_t p, ramd_vec_t z, int slot_r
                            slot_new);
     else
         RAMD_FAIL(RAMD_ERR_ARG, "fused_cg_direction needs real vectors");
+    prof_end(RAMD_PROF_VEC, b.cur);
     RAMD_HIP(hipGetLastError());
     return RAMD_OK;
 }
@@ -699,12 +703,14 @@ int ramd_fused_mgs_step(ramd_vec_t w, ramd_vec_t v, int slot_h, ramd_vec_t u, in
             hipLaunchKernelGGL((k_mgs_step<T, false>), dim3(grid), dim3(kBlock), 0, b.cur, w->n,   \
                                (T*)w->d, (const T*)v->d, (const T*)nullptr, ctx, slot_h, slot_dot); \
     } while(0)
+    prof_begin(RAMD_PROF_VEC, b.cur);
     if(w->dtype == RAMD_F64)
         GO(double);
     else if(w->dtype == RAMD_F32)
         GO(float);
     else
         RAMD_FAIL(RAMD_ERR_ARG, "fused_mgs_step needs real vectors");
+    prof_end(RAMD_PROF_VEC, b.cur);
 #undef GO
     RAMD_HIP(hipGetLastError());
     return RAMD_OK;

@@ -20,6 +20,9 @@ int csr_analyse_band(ramd_mat_s* m);
 // backend.hip: optional HIP-event bracket around every SpMV launch (bench.py roofline leg)
 void prof_spmv_begin();
 void prof_spmv_end();
+void prof_begin(int channel, hipStream_t s); // s == nullptr: the current stream
+void prof_end(int channel, hipStream_t s);
+void prof_count(int channel); // count an occurrence without timing it
 
 // trisolve.hip
 void tri_release(ramd_mat_s* m);

@@ -449,8 +449,18 @@ struct TriPlan
     void* w         = nullptr; // [n] polled scratch
     int   nlevels   = 0;
     bool  nodiag    = false;
+    // chain-tile form (build_ct_plan): tiles = 64 dependency chains x a band of ct_seg() levels, one wave per tile
+    bool ct        = false;
+    int  ct_ntiles = 0, ct_nsteps = 0, ct_wmax = 0, ct_seg = 0;
+    int* ct_tile_step = nullptr; // [ntiles+1] first step of a tile
+    int* ct_step_pos  = nullptr; // [nsteps+1] first position of a step (a step = the rows of one level inside a tile)
+    int* ct_step_ent  = nullptr; // [nsteps+1] first packed entry of a step
     void  release()
     {
+        dev_free(&ct_tile_step);
+        dev_free(&ct_step_pos);
+        dev_free(&ct_step_ent);
+        ct = false;
         dev_free(&order);
         dev_free(&pos);
         dev_free(&slice_off);
@@ -578,7 +588,7 @@ static unsigned nblocks_of(int n)
 
 // dependency levels (sync-free sweep in natural order) and the rows ordered by (level, row): a stable sort,
 // so rows of one level keep ascending row order and neighbouring positions poll / gather neighbouring memory
-static int level_order(ramd_mat_s* m, TriState* st, bool lower, int** order_out, int* nlev_out)
+static int level_order(ramd_mat_s* m, TriState* st, bool lower, int** order_out, int* nlev_out, int** level_out = nullptr)
 {
     Backend&       b     = backend();
     const int      n     = m->nrow;
@@ -603,7 +613,10 @@ static int level_order(ramd_mat_s* m, TriState* st, bool lower, int** order_out,
         s = dev_alloc(&order, n);
     if(s == RAMD_OK)
         s = device_stable_sort_by_key(level, n, nlev, order);
-    dev_free(&level);
+    if(s == RAMD_OK && level_out)
+        *level_out = level; // the caller keeps (and frees) the per-row levels
+    else
+        dev_free(&level);
     if(s != RAMD_OK)
     {
         dev_free(&order);
@@ -621,6 +634,10 @@ __global__ __launch_bounds__(kBlock) void k_natural_order(int n, int* __restrict
         v[t] = (int)t;
 }
 
+static bool ct_enabled();
+template <typename T>
+static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bool reverse);
+
 // natural = true: rows stay in matrix order (no level analysis) -- the packing of the iterative (Jacobi-sweep) solves
 template <typename T>
 static int build_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bool reverse = false, bool natural = false)
@@ -632,6 +649,21 @@ static int build_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bool 
     P->nslices = (n + 63) / 64;
     if(n == 0)
         return RAMD_OK;
+    if(!natural && ct_enabled())
+    {
+        const int sc = build_ct_plan<T>(m, st, P, lower, reverse);
+        if(sc == RAMD_OK)
+        {
+            if(lower && st->l_order_cache) // the level order of ILU0Factorize is not needed by this form
+                dev_free(&st->l_order_cache);
+            return RAMD_OK;
+        }
+        if(sc != RAMD_ERR_UNSUPPORTED)
+            return sc;
+        P->release();
+        P->n       = n;
+        P->nslices = (n + 63) / 64;
+    }
     const unsigned nb   = nblocks_of(n);
     int            nlev = 0;
     int            s    = RAMD_OK;
@@ -726,6 +758,536 @@ static int build_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bool 
     return s;
 }
 
+// ======================================================================= chain-tile triangular solve
+// The level-scheduled kernel above pays one cross-CU hand-off (~5 us) per dependency level: 1534 levels at 512^3, ~8200 on
+// a 2-D shell mesh with 5 unknowns per node (deep, narrow DAG: GMRES+ILU(0) there was SLOWER than one CPU core).
+// Chain-tile form: most of the depth of such DAGs comes from CHAINS -- runs of consecutive rows each depending on its
+// predecessor (an x-pencil of a stencil, a mesh line of a banded FE matrix).  A tile is
+//      (64 consecutive chains) x (a band of ct_seg() consecutive dependency levels),
+// handled by ONE wave: every level of the band is a step, a step holds at most one row per chain (levels grow strictly
+// along a chain), i.e. at most 64 rows -> one row per lane.  Values produced inside the tile travel through LDS (~0.1 us
+// per step instead of ~5 us per level); only values of other tiles are polled in global memory (NaN-sentinel hand-off as
+// above), and those are all polled together at the start of a step.  Both tile coordinates are monotone along every
+// dependency edge (chains are numbered in sweep order, levels grow along edges), so tiles taken in (band, chain group)
+// order -- the ticket order -- only ever wait on tiles that already started: no deadlock for any matrix.
+// The arithmetic per row is unchanged (ascending columns, divide by the stored diagonal): bit-exact with the host.
+static int ct_seg() // dependency levels per tile band: a tile holds at most 64 * seg rows (LDS: 16 KB of fp64 at 32)
+{
+    static int seg = -1;
+    if(seg < 0)
+    {
+        const char* e = getenv("RAMD_TRSV_CT_SEG"); // experiments only
+        seg           = e ? atoi(e) : 32;
+        if(seg < 4 || seg > 128)
+            seg = 32;
+    }
+    return seg;
+}
+
+// sweep space: t = row (lower solve) or n-1-row (upper solve).  start[t] = 1 if row t does not depend on row t-1.
+template <bool LOWER>
+__global__ __launch_bounds__(kBlock) void k_ct_chain_start(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                           int* __restrict__ start)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(t > n)
+        return;
+    if(t == n)
+    {
+        start[t] = 0; // scan sentinel
+        return;
+    }
+    const int i    = LOWER ? (int)t : (int)(n - 1 - t);
+    const int prev = LOWER ? i - 1 : i + 1;
+    bool      cont = false;
+    if(t > 0)
+        for(int j = rp[i]; j < rp[i + 1]; ++j)
+            if(ci[j] == prev)
+            {
+                cont = true;
+                break;
+            }
+    start[t] = cont ? 0 : 1;
+}
+
+template <bool LOWER>
+__global__ __launch_bounds__(kBlock) void k_ct_keys(int n, const int* __restrict__ level, const int* __restrict__ escan,
+                                                    int ncb, int seg, int* __restrict__ lev_t, int* __restrict__ tkey)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gsz)
+    {
+        const int i     = LOWER ? (int)t : (int)(n - 1 - t);
+        const int lv    = level[i];
+        const int chain = escan[t + 1] - 1;
+        lev_t[t]        = lv;
+        tkey[t]         = ((lv - 1) / seg) * ncb + chain / 64;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_ct_gather_int(int64_t n, const int* __restrict__ src, const int* __restrict__ idx,
+                                                       int* __restrict__ dst)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gsz)
+        dst[t] = src[idx[t]];
+}
+
+// sorted sequences -> row order, tile / step start flags (n+1 entries, the last one 0 for the scans)
+__global__ __launch_bounds__(kBlock) void k_ct_flags(int n, int lower, const int* __restrict__ o1, const int* __restrict__ o2,
+                                                     const int* __restrict__ k2, const int* __restrict__ lev_t,
+                                                     int* __restrict__ order, int* __restrict__ tflag,
+                                                     int* __restrict__ sflag)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p <= n; p += gsz)
+    {
+        if(p == n)
+        {
+            tflag[p] = sflag[p] = 0;
+            continue;
+        }
+        const int t  = o1[o2[p]];
+        order[p]     = lower ? t : n - 1 - t;
+        const int tk = k2[o2[p]];
+        const int lv = lev_t[t];
+        bool      tf = (p == 0), sf = (p == 0);
+        if(p > 0)
+        {
+            const int tq = o1[o2[p - 1]];
+            tf           = k2[o2[p - 1]] != tk;
+            sf           = tf || lev_t[tq] != lv;
+        }
+        tflag[p] = tf ? 1 : 0;
+        sflag[p] = sf ? 1 : 0;
+    }
+}
+
+// tile_of / step_of per position (from the exclusive scans of the flags), first step of a tile, first position of a step,
+// and the number of strictly-triangular entries of the widest row of every step
+template <bool LOWER>
+__global__ __launch_bounds__(kBlock) void k_ct_bounds(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                      const int* __restrict__ order, const int* __restrict__ tflag,
+                                                      const int* __restrict__ sflag, const int* __restrict__ tscan,
+                                                      const int* __restrict__ sscan, int* __restrict__ tile_of,
+                                                      int* __restrict__ step_of, int* __restrict__ tile_step,
+                                                      int* __restrict__ step_pos, int* __restrict__ step_w)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gsz)
+    {
+        const int tl = tscan[p] + tflag[p] - 1;
+        const int st = sscan[p] + sflag[p] - 1;
+        tile_of[p]   = tl;
+        step_of[p]   = st;
+        if(tflag[p])
+            tile_step[tl] = st;
+        if(sflag[p])
+            step_pos[st] = (int)p;
+        const int i = order[p];
+        int       c = 0;
+        for(int j = rp[i]; j < rp[i + 1]; ++j)
+            if(LOWER ? (ci[j] < i) : (ci[j] > i))
+                ++c;
+        if(c > 0)
+            atomicMax(step_w + st, c);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_ct_ent_sizes(int nsteps, const int* __restrict__ step_pos,
+                                                         const int* __restrict__ step_w, int* __restrict__ size)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g <= nsteps; g += gsz)
+        size[g] = (g < nsteps) ? step_w[g] * (step_pos[g + 1] - step_pos[g]) : 0;
+}
+
+// entries of a step: [k][rank] with the step's row count as stride; a column inside the tile becomes its LDS index
+// (position - first position of the tile), a column of another tile -(position + 2), padding -1
+template <typename T, bool LOWER>
+__global__ __launch_bounds__(kBlock) void k_ct_fill(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                    const T* __restrict__ val, const int* __restrict__ order,
+                                                    const int* __restrict__ pos, const int* __restrict__ tile_of,
+                                                    const int* __restrict__ step_of, const int* __restrict__ tile_step,
+                                                    const int* __restrict__ step_pos, const int* __restrict__ step_ent,
+                                                    int* __restrict__ ecol, T* __restrict__ eval, T* __restrict__ diag,
+                                                    int* __restrict__ nodiag, int reverse)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(p >= n)
+        return;
+    const int  i    = order[p];
+    const int  gs   = step_of[p];
+    const int  p0   = step_pos[gs];
+    const int  cnt  = step_pos[gs + 1] - p0;
+    const int  rank = (int)p - p0;
+    const int  base = step_ent[gs];
+    const int  w    = (step_ent[gs + 1] - base) / cnt;
+    const int  tl   = tile_of[p];
+    const int  tpos = step_pos[tile_step[tl]];
+    int        k    = 0;
+    bool       have = false;
+    const int  rs = rp[i], re = rp[i + 1];
+    for(int q = rs; q < re; ++q)
+    {
+        const int j = reverse ? (re - 1 - (q - rs)) : q;
+        const int c = ci[j];
+        if(LOWER ? (c < i) : (c > i))
+        {
+            const int pc              = pos[c];
+            ecol[base + k * cnt + rank] = (tile_of[pc] == tl) ? pc - tpos : -(pc + 2);
+            eval[base + k * cnt + rank] = val[j];
+            ++k;
+        }
+        else if(c == i)
+        {
+            diag[p] = val[j];
+            have    = true;
+        }
+    }
+    for(; k < w; ++k)
+    {
+        ecol[base + k * cnt + rank] = -1;
+        eval[base + k * cnt + rank] = (T)0;
+    }
+    if(!have)
+    {
+        diag[p] = (T)1;
+        *nodiag = 1;
+    }
+}
+
+// one wave per tile.  Registers of a step (its rows' entries, right-hand side, diagonal) are fetched one step ahead.
+template <typename T, int WMAX>
+struct CtStep
+{
+    int c[WMAX];
+    T   a[WMAX];
+    T   b, dg;
+    int p, cnt, w, ebase, onat;
+};
+
+template <typename T, int DMODE, int WMAX>
+__global__ __launch_bounds__(64) void k_trsv_ct(int ntiles, const int* __restrict__ tile_step,
+                                                const int* __restrict__ step_pos, const int* __restrict__ step_ent,
+                                                const int* __restrict__ ecol, const T* __restrict__ eval,
+                                                const T* __restrict__ diag, const T* __restrict__ rhs_src,
+                                                const int* __restrict__ rhs_idx, T* w, T* __restrict__ out,
+                                                const int* __restrict__ order, unsigned* counter, unsigned base)
+{
+    extern __shared__ __attribute__((aligned(16))) char ct_lds[]; // 64 * seg values of the tile
+    T*             xs = reinterpret_cast<T*>(ct_lds);
+    const unsigned t  = take_ticket(counter, base);
+    if(t >= (unsigned)ntiles)
+        return;
+    const int lane = threadIdx.x;
+    const int s0 = tile_step[t], s1 = tile_step[t + 1];
+    const int tpos = step_pos[s0];
+    using B        = typename Sentinel<T>::bits;
+
+    auto fetch = [&](int s, CtStep<T, WMAX>& r) {
+        const int p0 = step_pos[s], p1 = step_pos[s + 1];
+        const int e0 = step_ent[s], e1 = step_ent[s + 1];
+        r.cnt        = p1 - p0;
+        r.w          = (e1 - e0) / r.cnt;
+        r.ebase      = e0;
+        r.p          = p0 + lane;
+        const bool live = lane < r.cnt;
+        r.b          = live ? rhs_src[rhs_idx[r.p]] : (T)0;
+        r.dg         = (DMODE == 0 || !live) ? (T)1 : diag[r.p];
+        r.onat       = (out && live) ? order[r.p] : 0;
+#pragma unroll
+        for(int k = 0; k < WMAX; ++k)
+        {
+            const bool on = live && k < r.w;
+            r.c[k]        = on ? nt_load(ecol + e0 + k * r.cnt + lane) : -1;
+            r.a[k]        = on ? nt_load(eval + e0 + k * r.cnt + lane) : (T)0;
+        }
+    };
+    // consume WMAX entries: values of other tiles are polled together (they belong to tiles that started earlier),
+    // values of this tile come from LDS (written by earlier steps); the subtraction runs in storage order
+    auto consume = [&](const int (&c)[WMAX], const T (&a)[WMAX], T& sum) {
+        B    bits[WMAX];
+        bool ext = false;
+#pragma unroll
+        for(int k = 0; k < WMAX; ++k)
+            ext = ext || (c[k] < -1);
+        if(__ballot(ext) != 0ull)
+        {
+            int spins = 0, backoff = 1;
+            for(;;)
+            {
+                bool all = true;
+#pragma unroll
+                for(int k = 0; k < WMAX; ++k)
+                    if(c[k] < -1)
+                    {
+                        bits[k] = poll_load(w + (-(c[k] + 2)));
+                        all     = all && (bits[k] != Sentinel<T>::value);
+                    }
+                if(__ballot(!all) == 0ull)
+                    break;
+                spin_guard(spins);
+                backoff = poll_backoff(false, backoff);
+            }
+        }
+#pragma unroll
+        for(int k = 0; k < WMAX; ++k)
+        {
+            if(c[k] >= 0)
+                sum -= a[k] * xs[c[k]];
+            else if(c[k] < -1)
+                sum -= a[k] * Sentinel<T>::from_bits(bits[k]);
+        }
+    };
+    auto finish = [&](const CtStep<T, WMAX>& r) {
+        const bool live = lane < r.cnt;
+        T          sum  = r.b;
+        consume(r.c, r.a, sum);
+        for(int k0 = WMAX; k0 < r.w; k0 += WMAX) // rows longer than the register window: the rest without prefetch
+        {
+            int cc[WMAX];
+            T   aa[WMAX];
+#pragma unroll
+            for(int k = 0; k < WMAX; ++k)
+            {
+                const bool on = live && (k0 + k) < r.w;
+                cc[k]         = on ? nt_load(ecol + r.ebase + (k0 + k) * r.cnt + lane) : -1;
+                aa[k]         = on ? nt_load(eval + r.ebase + (k0 + k) * r.cnt + lane) : (T)0;
+            }
+            consume(cc, aa, sum);
+        }
+        if(live)
+        {
+            if(DMODE == 1)
+                sum /= r.dg;
+            else if(DMODE == 2)
+                sum = sum * r.dg;
+            xs[r.p - tpos] = sum;
+            publish(w + r.p, sum);
+            if(out)
+                out[r.onat] = sum;
+        }
+        __syncthreads(); // one wave: orders the LDS write before the next step's reads
+    };
+
+    CtStep<T, WMAX> ra, rb;
+    fetch(s0, ra);
+    for(int s = s0; s < s1; s += 2)
+    {
+        if(s + 1 < s1)
+            fetch(s + 1, rb);
+        finish(ra);
+        if(s + 1 < s1)
+        {
+            if(s + 2 < s1)
+                fetch(s + 2, ra);
+            finish(rb);
+        }
+    }
+}
+
+static bool ct_enabled()
+{
+    static int on = -1;
+    if(on < 0)
+    {
+        const char* e = getenv("RAMD_TRSV_CT"); // 0: always the level-scheduled kernel (A/B experiments)
+        on            = e ? atoi(e) : 1;
+    }
+    return on != 0;
+}
+
+// builds the chain-tile form of a plan; RAMD_ERR_UNSUPPORTED: the matrix has no chains worth it (caller falls back)
+template <typename T>
+static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bool reverse)
+{
+    Backend&  b = backend();
+    const int n = m->nrow;
+    static int min_rows = -1, min_len = -1; // RAMD_TRSV_CT_MINROWS / _MINLEN = 0: force this form (tests of the small goldens)
+    if(min_rows < 0)
+    {
+        min_rows = getenv("RAMD_TRSV_CT_MINROWS") ? atoi(getenv("RAMD_TRSV_CT_MINROWS")) : 4096;
+        min_len  = getenv("RAMD_TRSV_CT_MINLEN") ? atoi(getenv("RAMD_TRSV_CT_MINLEN")) : 8;
+    }
+    if(n < min_rows || n < 1)
+        return RAMD_ERR_UNSUPPORTED;
+    int *level = nullptr, *lorder = nullptr, *start = nullptr, *lev_t = nullptr, *tkey = nullptr, *o1 = nullptr,
+        *k2 = nullptr, *o2 = nullptr, *tflag = nullptr, *sflag = nullptr, *tscan = nullptr, *sscan = nullptr,
+        *tile_of = nullptr, *step_of = nullptr, *step_w = nullptr, *nodiag = nullptr;
+    int  nlev = 0;
+    int  s    = RAMD_OK;
+    auto cleanup = [&]() {
+        dev_free(&level);
+        dev_free(&lorder);
+        dev_free(&start);
+        dev_free(&lev_t);
+        dev_free(&tkey);
+        dev_free(&o1);
+        dev_free(&k2);
+        dev_free(&o2);
+        dev_free(&tflag);
+        dev_free(&sflag);
+        dev_free(&tscan);
+        dev_free(&sscan);
+        dev_free(&tile_of);
+        dev_free(&step_of);
+        dev_free(&step_w);
+        dev_free(&nodiag);
+    };
+#define CT_TRY(expr)     \
+    do                   \
+    {                    \
+        s = (expr);      \
+        if(s != RAMD_OK) \
+        {                \
+            cleanup();   \
+            P->release(); \
+            return s;    \
+        }                \
+    } while(0)
+#define CT_HIP(expr)                 \
+    do                               \
+    {                                \
+        if((expr) != hipSuccess)     \
+        {                            \
+            cleanup();               \
+            P->release();            \
+            RAMD_FAIL(RAMD_ERR_HIP, #expr); \
+        }                            \
+    } while(0)
+    const int grid = ew_grid(n + 1);
+    const unsigned nb1 = (unsigned)(((int64_t)n + 1 + kBlock - 1) / kBlock);
+    // chains
+    CT_TRY(dev_alloc(&start, (int64_t)n + 1));
+    if(lower)
+        hipLaunchKernelGGL((k_ct_chain_start<true>), dim3(nb1), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, start);
+    else
+        hipLaunchKernelGGL((k_ct_chain_start<false>), dim3(nb1), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, start);
+    CT_TRY(device_exclusive_scan(start, start, (int64_t)n + 1)); // start[t] = chains begun before t
+    int nchains = 0;
+    CT_HIP(hipMemcpyAsync(&nchains, start + n, sizeof(int), hipMemcpyDeviceToHost, b.cur));
+    CT_HIP(hipStreamSynchronize(b.cur));
+    if(nchains <= 0 || (int64_t)n < (int64_t)min_len * nchains)
+    {
+        cleanup();
+        return RAMD_ERR_UNSUPPORTED;
+    }
+    // levels (natural row index)
+    CT_TRY(level_order(m, st, lower, &lorder, &nlev, &level));
+    dev_free(&lorder);
+    const int     ncb   = (nchains + 63) / 64;
+    const int     seg   = ct_seg();
+    const int64_t nband = ((int64_t)nlev + seg - 1) / seg;
+    if(nband * ncb >= (1ll << 30))
+    {
+        cleanup();
+        return RAMD_ERR_UNSUPPORTED;
+    }
+    CT_TRY(dev_alloc(&lev_t, n));
+    CT_TRY(dev_alloc(&tkey, n));
+    if(lower)
+        hipLaunchKernelGGL((k_ct_keys<true>), dim3(grid), dim3(kBlock), 0, b.cur, n, level, start, ncb, seg, lev_t, tkey);
+    else
+        hipLaunchKernelGGL((k_ct_keys<false>), dim3(grid), dim3(kBlock), 0, b.cur, n, level, start, ncb, seg, lev_t, tkey);
+    dev_free(&level);
+    dev_free(&start);
+    // rows sorted by (tile, level, chain): the sweep order is already chain-sorted, two stable passes do the rest
+    CT_TRY(dev_alloc(&o1, n));
+    CT_TRY(device_stable_sort_by_key(lev_t, n, nlev, o1));
+    CT_TRY(dev_alloc(&k2, n));
+    hipLaunchKernelGGL(k_ct_gather_int, dim3(grid), dim3(kBlock), 0, b.cur, (int64_t)n, tkey, o1, k2);
+    dev_free(&tkey);
+    CT_TRY(dev_alloc(&o2, n));
+    CT_TRY(device_stable_sort_by_key(k2, n, (int)(nband * ncb), o2));
+    P->release();
+    P->n       = n;
+    P->nslices = (n + 63) / 64;
+    P->nlevels = nlev;
+    CT_TRY(dev_alloc(&P->order, n));
+    CT_TRY(dev_alloc(&tflag, (int64_t)n + 1));
+    CT_TRY(dev_alloc(&sflag, (int64_t)n + 1));
+    hipLaunchKernelGGL(k_ct_flags, dim3(grid), dim3(kBlock), 0, b.cur, n, lower ? 1 : 0, o1, o2, k2, lev_t, P->order, tflag,
+                       sflag);
+    dev_free(&o1);
+    dev_free(&o2);
+    dev_free(&k2);
+    dev_free(&lev_t);
+    CT_TRY(dev_alloc(&P->pos, n));
+    hipLaunchKernelGGL(k_invert_perm, dim3(grid), dim3(kBlock), 0, b.cur, n, P->order, P->pos);
+    CT_TRY(dev_alloc(&tscan, (int64_t)n + 1));
+    CT_TRY(dev_alloc(&sscan, (int64_t)n + 1));
+    CT_TRY(device_exclusive_scan(tflag, tscan, (int64_t)n + 1));
+    CT_TRY(device_exclusive_scan(sflag, sscan, (int64_t)n + 1));
+    int cnts[2] = {0, 0};
+    CT_HIP(hipMemcpyAsync(&cnts[0], tscan + n, sizeof(int), hipMemcpyDeviceToHost, b.cur));
+    CT_HIP(hipMemcpyAsync(&cnts[1], sscan + n, sizeof(int), hipMemcpyDeviceToHost, b.cur));
+    CT_HIP(hipStreamSynchronize(b.cur));
+    const int ntiles = cnts[0], nsteps = cnts[1];
+    P->ct_ntiles     = ntiles;
+    P->ct_seg        = seg;
+    P->ct_nsteps     = nsteps;
+    CT_TRY(dev_alloc(&P->ct_tile_step, (int64_t)ntiles + 1));
+    CT_TRY(dev_alloc(&P->ct_step_pos, (int64_t)nsteps + 1));
+    CT_TRY(dev_alloc(&P->ct_step_ent, (int64_t)nsteps + 1));
+    CT_TRY(dev_alloc(&step_w, (int64_t)nsteps + 1));
+    CT_TRY(dev_alloc(&tile_of, n));
+    CT_TRY(dev_alloc(&step_of, n));
+    CT_HIP(hipMemsetAsync(step_w, 0, sizeof(int) * ((size_t)nsteps + 1), b.cur));
+    CT_HIP(hipMemcpyAsync(P->ct_tile_step + ntiles, &nsteps, sizeof(int), hipMemcpyHostToDevice, b.cur));
+    CT_HIP(hipMemcpyAsync(P->ct_step_pos + nsteps, &n, sizeof(int), hipMemcpyHostToDevice, b.cur));
+    if(lower)
+        hipLaunchKernelGGL((k_ct_bounds<true>), dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, P->order, tflag, sflag,
+                           tscan, sscan, tile_of, step_of, P->ct_tile_step, P->ct_step_pos, step_w);
+    else
+        hipLaunchKernelGGL((k_ct_bounds<false>), dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, P->order, tflag, sflag,
+                           tscan, sscan, tile_of, step_of, P->ct_tile_step, P->ct_step_pos, step_w);
+    dev_free(&tflag);
+    dev_free(&sflag);
+    dev_free(&tscan);
+    dev_free(&sscan);
+    int wmax = 0;
+    CT_TRY(device_max_int(step_w, nsteps, &wmax)); // (synchronises)
+    if((int64_t)wmax * n >= (1ll << 31) - 65536) // packed entries are addressed with 32-bit offsets
+    {
+        cleanup();
+        P->release();
+        return RAMD_ERR_UNSUPPORTED;
+    }
+    P->ct_wmax = wmax;
+    hipLaunchKernelGGL(k_ct_ent_sizes, dim3(ew_grid(nsteps + 1)), dim3(kBlock), 0, b.cur, nsteps, P->ct_step_pos, step_w,
+                       P->ct_step_ent);
+    CT_TRY(device_exclusive_scan(P->ct_step_ent, P->ct_step_ent, (int64_t)nsteps + 1));
+    int total = 0;
+    CT_HIP(hipMemcpyAsync(&total, P->ct_step_ent + nsteps, sizeof(int), hipMemcpyDeviceToHost, b.cur));
+    CT_HIP(hipStreamSynchronize(b.cur));
+    CT_TRY(dev_alloc(&P->ecol, total));
+    CT_HIP(cached_malloc(&P->eval, (size_t)total * sizeof(T) + kPad));
+    CT_HIP(cached_malloc(&P->diag, (size_t)n * sizeof(T) + kPad));
+    CT_HIP(cached_malloc(&P->w, (size_t)n * sizeof(T) + kPad));
+    CT_TRY(dev_alloc(&nodiag, 1));
+    CT_HIP(hipMemsetAsync(nodiag, 0, sizeof(int), b.cur));
+    const unsigned nb = nblocks_of(n);
+    if(lower)
+        hipLaunchKernelGGL((k_ct_fill<T, true>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const T*)m->val, P->order,
+                           P->pos, tile_of, step_of, P->ct_tile_step, P->ct_step_pos, P->ct_step_ent, P->ecol, (T*)P->eval,
+                           (T*)P->diag, nodiag, reverse ? 1 : 0);
+    else
+        hipLaunchKernelGGL((k_ct_fill<T, false>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const T*)m->val, P->order,
+                           P->pos, tile_of, step_of, P->ct_tile_step, P->ct_step_pos, P->ct_step_ent, P->ecol, (T*)P->eval,
+                           (T*)P->diag, nodiag, reverse ? 1 : 0);
+    int nd = 0;
+    CT_HIP(hipMemcpyAsync(&nd, nodiag, sizeof(int), hipMemcpyDeviceToHost, b.cur));
+    CT_HIP(hipStreamSynchronize(b.cur));
+    CT_HIP(hipGetLastError());
+    P->nodiag = nd != 0;
+    P->ct     = true;
+    cleanup();
+#undef CT_TRY
+#undef CT_HIP
+    return RAMD_OK;
+}
+
 __global__ __launch_bounds__(kBlock) void k_compose_idx(int n, const int* __restrict__ orderU,
                                                         const int* __restrict__ posL,
                                                         int* __restrict__ out)
@@ -745,6 +1307,40 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
     const unsigned nb = nblocks_of(P->n);
     hipLaunchKernelGGL((k_fill_sentinel<T>), dim3(ew_grid(P->n)), dim3(kBlock), 0, b.cur, (int64_t)P->n,
                        (T*)P->w);
+    if(P->ct)
+    {
+        const int    dm           = mul_inv_diag ? 2 : (unit ? 0 : 1);
+        const size_t ct_lds_bytes = (size_t)64 * P->ct_seg * sizeof(T);
+#define TRSV_CT(DM, WM)                                                                                               \
+    hipLaunchKernelGGL((k_trsv_ct<T, DM, WM>), dim3((unsigned)P->ct_ntiles), dim3(64), ct_lds_bytes, b.cur, P->ct_ntiles, \
+                       P->ct_tile_step, P->ct_step_pos, P->ct_step_ent, P->ecol, (const T*)P->eval, (const T*)P->diag, \
+                       rhs_src, rhs_idx, (T*)P->w, out, P->order, st->counter, st->ticket)
+#define TRSV_CT_W(WM)    \
+    do                   \
+    {                    \
+        if(dm == 0)      \
+            TRSV_CT(0, WM); \
+        else if(dm == 1) \
+            TRSV_CT(1, WM); \
+        else             \
+            TRSV_CT(2, WM); \
+    } while(0)
+        prof_begin(RAMD_PROF_TRSV, b.cur);
+        if(P->ct_wmax <= 4)
+            TRSV_CT_W(4);
+        else if(P->ct_wmax <= 8)
+            TRSV_CT_W(8);
+        else if(P->ct_wmax <= 16)
+            TRSV_CT_W(16);
+        else
+            TRSV_CT_W(24);
+        prof_end(RAMD_PROF_TRSV, b.cur);
+#undef TRSV_CT_W
+#undef TRSV_CT
+        st->ticket += (unsigned)P->ct_ntiles;
+        RAMD_HIP(hipGetLastError());
+        return RAMD_OK;
+    }
     // tuning knobs (measured defaults; the env overrides are for tools/ experiments only)
     static int lds_pad = -1, sleep_cycles = -1;
     if(lds_pad < 0)
@@ -758,12 +1354,14 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
     hipLaunchKernelGGL((k_trsv<T, DM>), dim3(nb), dim3(kBlock), (size_t)lds_pad, b.cur, P->n, P->slice_off, \
                        P->ecol, (const T*)P->eval, (const T*)P->diag, rhs_src, rhs_idx, (T*)P->w, out,     \
                        P->order, st->counter, st->ticket, sleep_cycles)
+    prof_begin(RAMD_PROF_TRSV, b.cur);
     if(mul_inv_diag)
         TRSV(2);
     else if(unit)
         TRSV(0);
     else
         TRSV(1);
+    prof_end(RAMD_PROF_TRSV, b.cur);
 #undef TRSV
     st->ticket += nb;
     RAMD_HIP(hipGetLastError());

@@ -104,3 +104,125 @@ def to_scipy(rp, ci, va):
     import scipy.sparse as sp
     n = len(rp) - 1
     return sp.csr_matrix((va, ci, rp), shape=(n, n))
+
+
+# ---------------------------------------------------------------------------------------------
+# af_shell10-class surrogate (BASELINE.json config 3).  SuiteSparse Schenk_AFE/af_shell10 is a
+# sheet-metal-forming shell model: n = 1 508 065 = 5 x 301 613 (5 unknowns per mesh node),
+# 52 259 885 non-zeros after symmetric expansion = 34.65 per row, SPD.  There is no network on the
+# benchmark box, so the file cannot be fetched; this generator produces a matrix of the same class:
+#   * a 2-D nx x ny node mesh of quadrilateral cells, every cell split into two triangles along one
+#     of its two diagonals chosen by an integer hash  ->  node degree 4..8 (mean 6), i.e. 25..45
+#     entries per row (mean 35) and an irregular dependency DAG for the triangular solves;
+#   * 5 unknowns per node, dense symmetric 5x5 coupling blocks;
+#   * A = sum_e (edge Laplacian (x) K_e) + diag(shift*(1+a)) (a = unknown within the node) with K_e symmetric, strictly diagonally dominant
+#     -> A is symmetric positive definite.
+# All values are multiples of 1/128 below 2^8, so every sum is exact and the matrix does not depend
+# on the accumulation order.  shell_surrogate(549, 549) gives n = 1 507 005, nnz = 52 635 425 (34.93 per row).
+_SHELL_DOF = 5
+
+
+def _mix64(a):
+    """splitmix64 finaliser on uint64 arrays (wrap-around arithmetic)"""
+    a = (a ^ (a >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    a = (a ^ (a >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return a ^ (a >> np.uint64(31))
+
+
+def _edge_hash(i, j, kind, seed):
+    with np.errstate(over="ignore"):
+        k = (i.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+             + j.astype(np.uint64) * np.uint64(0xC2B2AE3D27D4EB4F)
+             + np.uint64(kind) * np.uint64(0x165667B19E3779F9) + np.uint64(seed))
+        return _mix64(_mix64(k))
+
+
+def shell_surrogate(nx, ny=None, seed=1, shift=1.0 / 64, dtype=np.float64):
+    """CSR arrays (int32 offsets/columns, sorted rows) of the af_shell10-class surrogate."""
+    ny = nx if ny is None else ny
+    D = _SHELL_DOF
+    nn = nx * ny
+    node = np.arange(nn, dtype=np.int64)
+    i, j = node % nx, node // nx
+    # diagonal of cell (i, j) [lower-left node]: bit 0 of its hash: 0 -> (i,j)-(i+1,j+1), 1 -> (i+1,j)-(i,j+1)
+    def cell_diag(ci, cj):
+        ok = (ci >= 0) & (ci < nx - 1) & (cj >= 0) & (cj < ny - 1)
+        return ok, (_edge_hash(np.where(ok, ci, 0), np.where(ok, cj, 0), 7, seed) & np.uint64(1)).astype(np.int64)
+    # the 9 neighbour slots in ascending node-id order; each edge is hashed at its lower (smaller id) end
+    slots = []
+    for dj in (-1, 0, 1):
+        for di in (-1, 0, 1):
+            ii, jj = i + di, j + dj
+            inside = (ii >= 0) & (ii < nx) & (jj >= 0) & (jj < ny)
+            if di == 0 and dj == 0:
+                slots.append((di, dj, np.ones(nn, bool), None))
+                continue
+            # anchor = lower end of the edge; kind: 0 horizontal, 1 vertical, 2 diagonal "/", 3 diagonal "\"
+            lo_i, lo_j = np.where(dj < 0, ii, np.where(dj > 0, i, np.minimum(i, ii))), np.minimum(j, jj)
+            if dj == 0:
+                kind, present = 0, inside
+            elif di == 0:
+                kind, present = 1, inside
+            else:
+                # cell containing the diagonal: lower-left corner (min i, min j)
+                ci, cj = np.minimum(i, ii), np.minimum(j, jj)
+                ok, bit = cell_diag(ci, cj)
+                up_right = (di * dj) > 0  # "/" diagonal connects (ci,cj)-(ci+1,cj+1)
+                kind = 2 if up_right else 3
+                present = inside & ok & (bit == (0 if up_right else 1))
+            h = _edge_hash(np.where(present, lo_i, 0), np.where(present, lo_j, 0), kind, seed)
+            slots.append((di, dj, present, h))
+    a_idx, b_idx = np.meshgrid(np.arange(D), np.arange(D), indexing="ij")
+    pair_bit = np.zeros((D, D), dtype=np.uint64)
+    k = 0
+    for a in range(D):
+        for b in range(a + 1, D):
+            pair_bit[a, b] = pair_bit[b, a] = 8 + k
+            k += 1
+    blocks = np.zeros((nn, 9, D, D), dtype=np.float64)
+    mask = np.zeros((nn, 9), dtype=bool)
+    diag = np.zeros((nn, D, D), dtype=np.float64)
+    for s, (di, dj, present, h) in enumerate(slots):
+        mask[:, s] = present
+        if h is None:
+            continue
+        c = (16.0 + (h & np.uint64(15)).astype(np.float64)) / 16.0  # edge stiffness in [1, 2)
+        sgn = 1.0 - 2.0 * ((h[:, None, None] >> pair_bit[None]) & np.uint64(1)).astype(np.float64)
+        K = np.where(a_idx[None] == b_idx[None], 1.0, sgn / 8.0) * c[:, None, None]
+        K = np.where(present[:, None, None], K, 0.0)
+        blocks[:, s] = -K
+        diag += K
+    diag += np.diag(shift * (1.0 + np.arange(D)))[None]  # per-unknown shift: the constant vector is no eigenvector
+    blocks[:, 4] = diag
+    # expand to scalar rows: row (node, a) holds for every present slot s the entries (s, b), b = 0..D-1
+    nbr = np.stack([node + dj * nx + di for (di, dj, _, _) in slots], axis=1)  # [nn, 9]
+    cols = (nbr[:, None, :, None] * D + np.arange(D)[None, None, None, :])  # [nn, 1, 9, D]
+    cols = np.broadcast_to(cols, (nn, D, 9, D))
+    vals = np.transpose(blocks, (0, 2, 1, 3))  # [nn, a, s, b]
+    m = np.broadcast_to(mask[:, None, :, None], (nn, D, 9, D))
+    counts = np.repeat(mask.sum(axis=1) * D, D)
+    rp = np.zeros(nn * D + 1, dtype=np.int64)
+    np.cumsum(counts, out=rp[1:])
+    assert rp[-1] < 2 ** 31
+    return rp.astype(np.int32), cols[m].astype(np.int32), np.ascontiguousarray(vals[m]).astype(dtype)
+
+
+def write_mtx_symmetric(path, rp, ci, va):
+    """MatrixMarket `coordinate real symmetric` file holding the lower triangle (col <= row) of a
+    symmetric CSR matrix -- the storage af_shell10.mtx itself uses; the reader's symmetric expansion
+    (src/base/host/host_io.cpp:218-272) restores the full pattern."""
+    n = len(rp) - 1
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(rp))
+    keep = ci <= rows
+    r1, c1, v1 = rows[keep] + 1, ci[keep].astype(np.int64) + 1, va[keep]
+    with open(path, "wb") as f:
+        f.write(b"%%MatrixMarket matrix coordinate real symmetric\n")
+        f.write(("%d %d %d\n" % (n, n, len(v1))).encode())
+        try:
+            import pyarrow as pa
+            import pyarrow.csv as pacsv
+            tbl = pa.table({"r": r1, "c": c1, "v": v1.astype(np.float64)})
+            pacsv.write_csv(tbl, f, pacsv.WriteOptions(include_header=False, delimiter=" "))
+        except ImportError:
+            np.savetxt(f, np.column_stack([r1, c1, v1]), fmt="%d %d %.17g")
+    return len(v1)

@@ -11,9 +11,9 @@ import ctypes as C
 import numpy as np
 
 from . import capi
-from .capi import (PC_AICHEBYSHEV, PC_FSAI, PC_GS, PC_ITILU0, PC_SPAI, PC_IC, PC_ILU0, PC_SAAMG, PC_TNS, PC_UAAMG, PC_JACOBI, PC_MCGS, PC_MCILU, PC_MCSGS, PC_NONE, PC_SGS, SOLVER_BICGSTAB,
+from .capi import (PC_GS, PC_IC, PC_ILU0, PC_SAAMG, PC_UAAMG, PC_JACOBI, PC_MCGS, PC_MCILU, PC_MCSGS, PC_NONE, PC_SGS, SOLVER_BICGSTAB,
                    SOLVER_BICGSTABL,
-                   SOLVER_CG, SOLVER_CHEBYSHEV, SOLVER_CR, SOLVER_FCG, SOLVER_FGMRES, SOLVER_FIXEDPOINT, SOLVER_GMRES,
+                   SOLVER_CG, SOLVER_CR, SOLVER_FCG, SOLVER_FGMRES, SOLVER_FIXEDPOINT, SOLVER_GMRES,
                    SOLVER_IDR, SOLVER_QMRCGSTAB)
 
 
@@ -87,61 +87,6 @@ class SGS(_Precond):
 class IC(_Precond):
     """incomplete Cholesky, zero fill-in (preconditioner.cpp:826-925): ICFactorize on ExtractL, LLSolve"""
     kind = PC_IC
-
-
-class AIChebyshev(_Precond):
-    """approximate inverse by a Chebyshev polynomial of the operator (preconditioner_ai.cpp:41-215); Solve = one SpMV"""
-    kind = PC_AICHEBYSHEV
-
-    def Set(self, p, lambda_min, lambda_max):
-        self.params = (float(p), float(lambda_min), float(lambda_max))
-
-
-class ItILU0(_Precond):
-    """ItILU0 (preconditioner.cpp:520-700): ILU(0) factors computed exactly (as the reference's host backend does), triangular
-    solves per SolverDescr; the sweep parameters of the HIP backend's iterative factorisation are accepted and unused"""
-    kind = PC_ITILU0
-
-    def SetTolerance(self, tol):
-        pass
-
-    def SetMaxIter(self, n):
-        pass
-
-    def SetOptions(self, opt):
-        pass
-
-    def SetAlgorithm(self, alg):
-        pass
-
-
-class SPAI(_Precond):
-    """sparse approximate inverse on the pattern of the operator (preconditioner_ai.cpp:363-475): per row a dense
-    least-squares problem solved by Householder QR on the device; Solve = one SpMV"""
-    kind = PC_SPAI
-
-
-class FSAI(_Precond):
-    """factorised sparse approximate inverse on the lower pattern of the operator (preconditioner_ai.cpp:217-361)"""
-    kind = PC_FSAI
-
-    def Set(self, power):
-        """pattern of the factor: lower part of the pattern of A^power (preconditioner_ai.cpp:253-262)"""
-        if power < 1:
-            raise ValueError("FSAI: power >= 1")
-        self.params = (float(power), 0.0, 0.0)
-
-
-class TNS(_Precond):
-    """truncated Neumann series (preconditioner_ai.cpp:477-713): implicit (four triangular SpMVs) or explicit matrix"""
-    kind = PC_TNS
-
-    def __init__(self):
-        super().__init__()
-        self.params = (1.0, 0.0, 0.0)
-
-    def Set(self, imp):
-        self.params = (1.0 if imp else 0.0, 0.0, 0.0)
 
 
 class UAAMG(_Precond):
@@ -373,21 +318,6 @@ class FixedPoint(_IterativeLinearSolver):
 
     def _configure_extra(self):
         capi.check(_lib().ramd_solver_set_params(self._h, self._omega, 1.0 if self._smoother else 0.0))
-
-
-class Chebyshev(_IterativeLinearSolver):
-    """Chebyshev iteration with caller-supplied eigenvalue bounds (src/solvers/chebyshev.cpp)"""
-    kind = SOLVER_CHEBYSHEV
-
-    def __init__(self, dtype=np.float64):
-        super().__init__(dtype)
-        self._lmin = self._lmax = None
-
-    def Set(self, lambda_min, lambda_max):
-        self._lmin, self._lmax = float(lambda_min), float(lambda_max)
-
-    def _configure_extra(self):
-        capi.check(_lib().ramd_solver_set_params(self._h, self._lmin, self._lmax))
 
 
 class QMRCGStab(_IterativeLinearSolver):

@@ -39,39 +39,6 @@ static std::unique_ptr<AnySolver> make_precond(const std::string& p)
     if(p == "mcgs") return std::unique_ptr<AnySolver>(new MultiColoredGS<Mat, Vec, double>);
     if(p == "mcsgs") return std::unique_ptr<AnySolver>(new MultiColoredSGS<Mat, Vec, double>);
     if(p == "mcilu") return std::unique_ptr<AnySolver>(new MultiColoredILU<Mat, Vec, double>);
-    if(p == "fsai") return std::unique_ptr<AnySolver>(new FSAI<Mat, Vec, double>);
-    if(p == "spai") return std::unique_ptr<AnySolver>(new SPAI<Mat, Vec, double>);
-    if(p == "tns") return std::unique_ptr<AnySolver>(new TNS<Mat, Vec, double>);
-    if(p == "as" || p == "ras") // (restricted) additive Schwarz: 3 blocks, overlap 4, ILU(0) on every block
-    {
-        static ILU<Mat, Vec, double> loc[3];
-        static AnySolver*            list[3] = {&loc[0], &loc[1], &loc[2]};
-        AS<Mat, Vec, double>*        s       = (p == "as") ? new AS<Mat, Vec, double> : new RAS<Mat, Vec, double>;
-        s->Set(3, 4, list);
-        return std::unique_ptr<AnySolver>(s);
-    }
-    if(p == "block" || p == "blockdiag") // 3 row blocks (n/3, n/3, rest), ILU(0) per diagonal block; L or diagonal solve
-    {
-        static ILU<Mat, Vec, double> loc[3];
-        static AnySolver*            list[3] = {&loc[0], &loc[1], &loc[2]};
-        BlockPreconditioner<Mat, Vec, double>* bp = new BlockPreconditioner<Mat, Vec, double>;
-        const int n  = g_nrow;
-        const int sz[3] = {n / 3, n / 3, n - 2 * (n / 3)};
-        bp->Set(3, sz, list);
-        if(p == "blockdiag")
-            bp->SetDiagonalSolver();
-        return std::unique_ptr<AnySolver>(bp);
-    }
-    if(p == "variable") // Jacobi, MC-SGS, ILU(0) in turn (for the flexible methods)
-    {
-        static Jacobi<Mat, Vec, double>          v0;
-        static MultiColoredSGS<Mat, Vec, double> v1;
-        static ILU<Mat, Vec, double>             v2;
-        static AnySolver*                        list[3] = {&v0, &v1, &v2};
-        VariablePreconditioner<Mat, Vec, double>* vp      = new VariablePreconditioner<Mat, Vec, double>;
-        vp->SetPreconditioner(3, list);
-        return std::unique_ptr<AnySolver>(vp);
-    }
     if(p != "none")
     {
         std::cerr << "unknown preconditioner " << p << std::endl;
@@ -143,7 +110,6 @@ int main(int argc, char* argv[])
         else if(sname == "bicgstabl") { auto* s = new BiCGStabl<Mat, Vec, double>; if(param > 0) s->SetOrder(param); ls.reset(s); }
         else if(sname == "qmrcgstab") ls.reset(new QMRCGStab<Mat, Vec, double>);
         else if(sname == "idr") { auto* s = new IDR<Mat, Vec, double>; s->SetRandomSeed(12345ULL); if(param > 0) s->SetShadowSpace(param); ls.reset(s); }
-        else if(sname == "chebyshev") { auto* s = new Chebyshev<Mat, Vec, double>; s->Set(0.01, pname == "none" ? 16.0 : 2.0); ls.reset(s); }
         else if(sname == "fixedpoint") { auto* s = new FixedPoint<Mat, Vec, double>; s->SetRelaxation(0.8); ls.reset(s); }
         else
         {

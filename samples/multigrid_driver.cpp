@@ -10,8 +10,6 @@
 //                                                            s (SAAMG, PMIS coarsening, as a solver)
 //                                                            d (CG preconditioned by SAAMG)
 //                                                            g / h (as c / d with the default Greedy coarsening)
-//                                                            r (RugeStuebenAMG, PMIS + direct interpolation, solver)
-//                                                            q (CG preconditioned by RugeStuebenAMG)
 // Prints one RESULT line and the residual history (HIST lines), which tests/test_gpu_solvers.py compares with the
 // genuine library's run of the same setup (oracle/ref_probe).
 #include <cstdlib>
@@ -74,20 +72,15 @@ int main(int argc, char* argv[])
     mat.Apply(e, &rhs);
     x.Zeros();
 
-    if(variant == "a" || variant == "c" || variant == "s" || variant == "d" || variant == "g" || variant == "h"
-       || variant == "r" || variant == "q")
+    if(variant == "a" || variant == "c" || variant == "s" || variant == "d" || variant == "g" || variant == "h")
     {
         // the reference's sample sequence for UAAMG / SAAMG (clients/samples/ua-amg.cpp, sa-amg.cpp), PMIS coarsening
         UAAMG<Mat, Vec, double>    ua;
         SAAMG<Mat, Vec, double>    sa;
         const bool                 smoothed = (variant == "s" || variant == "d" || variant == "h");
         const bool                 greedy   = (variant == "g" || variant == "h");
-        RugeStuebenAMG<Mat, Vec, double> rs;
-        rs.SetCoarseningStrategy(PMIS);
-        const bool                 classical = (variant == "r" || variant == "q");
-        BaseAMG<Mat, Vec, double>& amg       = classical  ? static_cast<BaseAMG<Mat, Vec, double>&>(rs)
-                                               : smoothed ? static_cast<BaseAMG<Mat, Vec, double>&>(sa)
-                                                          : static_cast<BaseAMG<Mat, Vec, double>&>(ua);
+        BaseAMG<Mat, Vec, double>& amg      = smoothed ? static_cast<BaseAMG<Mat, Vec, double>&>(sa)
+                                                       : static_cast<BaseAMG<Mat, Vec, double>&>(ua);
         CG<Mat, Vec, double>       cg;
         amg.SetOperator(mat);
         if(!greedy) // (Greedy is the default of both classes)
@@ -98,7 +91,7 @@ int main(int argc, char* argv[])
         amg.SetCoarsestLevel(20);
         amg.Verbose(0);
         IterativeLinearSolver<Mat, Vec, double>* s = &amg;
-        if(variant == "a" || variant == "s" || variant == "r")
+        if(variant == "a" || variant == "s")
             amg.InitMaxIter(60);
         else
         {

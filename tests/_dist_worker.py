@@ -170,9 +170,9 @@ def gpu_worker(rank, world, initfile, kind, outdir):
     out["xs3"] = g3.solve(None, np.zeros(hi - lo))
     it3, st3, res3 = g3.result()
     # BlockJacobi around the wider local preconditioners: SA-AMG / IC on the interior block under CG (the symmetric
-    # operators), ILU(0) / FSAI-free SPAI under BiCGStab (the random one)
+    # operators), ILU(0) / MC-SGS under BiCGStab (the random one)
     its4 = []
-    for sk, pk in ([(capi.SOLVER_BICGSTAB, capi.PC_ILU0), (capi.SOLVER_BICGSTAB, capi.PC_SPAI)] if kind == "random"
+    for sk, pk in ([(capi.SOLVER_BICGSTAB, capi.PC_ILU0), (capi.SOLVER_BICGSTAB, capi.PC_MCSGS)] if kind == "random"
                    else [(capi.SOLVER_CG, capi.PC_SAAMG), (capi.SOLVER_CG, capi.PC_IC), (capi.SOLVER_CG, capi.PC_UAAMG)]):
         g4 = D.DistributedSolver(comm, sk, pk)
         if kind == "poisson_slab":

@@ -270,3 +270,43 @@ def test_host_side_matrix_api(tmp_path):
                            "-L", libdir, "-lrocalution_amd", "-Wl,-rpath," + libdir])
     r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
     assert r.returncode == 0 and b"api_driver ok" in r.stdout, (r.returncode, r.stdout.decode()[-1500:])
+
+
+def test_shell_surrogate_is_an_af_shell10_class_matrix(oracle, tmp_path):
+    """config 3's stand-in: symmetric, positive definite (Gershgorin-free check through CG convergence), 5-unknown
+    blocks, 25..45 entries per interior row, sorted rows; the symmetric MatrixMarket writer keeps the lower triangle"""
+    from rocalution_amd import generators as gen
+    rp, ci, va = gen.shell_surrogate(24, 20)
+    n = len(rp) - 1
+    assert n == 24 * 20 * 5
+    A = gen.to_scipy(rp, ci, va)
+    assert abs(A - A.T).max() == 0.0
+    d = np.diff(rp)
+    assert d.max() == 45 and d.min() >= 15 and 30.0 < d.mean() < 36.0
+    assert all(np.all(np.diff(ci[rp[r]:rp[r + 1]]) > 0) for r in range(n))
+    assert np.all(va * 128 == np.round(va * 128))  # exact binary fractions: no dependence on summation order
+    # node degrees vary (irregular triangulation): not all interior rows have the same length
+    assert len(set(d.tolist())) >= 4
+    b = oracle.csr_apply(rp, ci, va, np.ones(n))
+    r = oracle.solve(rp, ci, va, b, solver=oracle.CG, precond=oracle.PC_JACOBI, max_iter=5000)
+    assert r["status"] == 2 and np.linalg.norm(r["x"] - 1.0) < 1e-3 * np.sqrt(n)  # SPD: CG converges
+    path = str(tmp_path / "s.mtx")
+    stored = gen.write_mtx_symmetric(path, rp, ci, va)
+    assert stored == (len(ci) + n) // 2
+    with open(path) as f:
+        assert f.readline().strip() == "%%MatrixMarket matrix coordinate real symmetric"
+        assert f.readline().split() == [str(n), str(n), str(stored)]
+        rows = np.loadtxt(f)
+    assert rows.shape == (stored, 3) and np.all(rows[:, 1] <= rows[:, 0])
+    import scipy.sparse as sp
+    L = sp.coo_matrix((rows[:, 2], (rows[:, 0].astype(int) - 1, rows[:, 1].astype(int) - 1)), shape=(n, n)).tocsr()
+    full = L + sp.tril(L, -1).T
+    assert abs(full - A).max() == 0.0
+
+
+def test_bench_never_runs_on_fewer_ranks_than_asked():
+    """`python bench.py --gpus 2` spawns its own ranks; without 2 devices it must fail loudly, not report 1 rank"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 2
+    assert "need 2 devices" in p.stderr and p.stdout.strip() == ""

@@ -42,7 +42,7 @@ def test_two_ranks_one_gpu(kind, oracle):
     xs2 = np.concatenate([r["xs2"] for r in res])
     assert int(res[0]["st2"]) == 2
     assert np.linalg.norm(xs2 - 1.0) / np.sqrt(n) < 1e-4
-    # BlockJacobi around SA-AMG / IC / UA-AMG (CG) or ILU(0) / SPAI (BiCGStab) on the interior block: converged to the
+    # BlockJacobi around SA-AMG / IC / UA-AMG (CG) or ILU(0) / MC-SGS (BiCGStab) on the interior block: converged to the
     # same solution, and in fewer iterations than the Jacobi run above
     its4 = res[0]["its4"]
     for k in range(len(its4)):

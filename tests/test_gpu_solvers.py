@@ -47,7 +47,7 @@ def _mk(S, tag, dtype=np.float64):
     sname = tag.split("_")[0]
     solver = {"cg": S.CG, "gmres": S.GMRES, "bicgstab": S.BiCGStab, "fcg": S.FCG, "cr": S.CR, "fgmres": S.FGMRES,
               "bicgstabl": S.BiCGStabl, "bicgstabl3": S.BiCGStabl, "qmrcgstab": S.QMRCGStab, "idr": S.IDR,
-              "idr2": S.IDR, "fixedpoint": S.FixedPoint, "chebyshev": S.Chebyshev}[sname](dtype)
+              "idr2": S.IDR, "fixedpoint": S.FixedPoint}[sname](dtype)
     if sname == "bicgstabl3":
         solver.SetOrder(3)
     if sname == "idr":
@@ -56,19 +56,10 @@ def _mk(S, tag, dtype=np.float64):
         solver.SetShadowSpace(2); solver.SetRandomSeed(777)
     if tag == "fixedpoint_jacobi":
         solver.SetRelaxation(0.8); solver.InitMaxIter(40)
-    if tag == "chebyshev_none":
-        solver.Set(0.05, 16.0); solver.InitMaxIter(60)
-    if tag == "chebyshev_jacobi":
-        solver.Set(0.01, 2.0); solver.InitMaxIter(60)
     pc = {"none": None, "jacobi": S.Jacobi, "ilu0": S.ILU, "ilu1": S.ILU, "mcsgs": S.MultiColoredSGS, "mcgs": S.MultiColoredGS,
-          "mcilu": S.MultiColoredILU, "gs": S.GS, "sgs": S.SGS, "ic": S.IC, "tns": S.TNS, "tnsx": S.TNS, "fsai": S.FSAI, "spai": S.SPAI,
-          "aicheb": S.AIChebyshev}[tag.split("_")[1]]
+          "mcilu": S.MultiColoredILU, "gs": S.GS, "sgs": S.SGS, "ic": S.IC}[tag.split("_")[1]]
     if pc is not None:
         p = pc()
-        if tag.split("_")[1] == "aicheb":
-            p.Set(3, 0.05, 16.0); solver.InitMaxIter(300)
-        if tag.split("_")[1] == "tnsx":
-            p.Set(False)  # explicit matrix
         if tag.split("_")[1] == "ilu1":
             p.Set(1)
         solver.SetPreconditioner(p)
@@ -104,17 +95,13 @@ def test_preconditioner_apply_bit_exact(ra, S, name):
     n = A.GetM()
     x = ra.LocalVector(data=g["x"])
     for tag, key in (("cg_jacobi", "pc_jacobi"), ("cg_ilu0", "pc_ilu0"), ("cg_ilu1", "pc_ilu1"), ("cg_mcsgs", "pc_mcsgs"), ("cg_gs", "pc_gs"),
-                     ("cg_sgs", "pc_sgs"), ("cg_ic", "pc_ic"), ("cg_aicheb", "pc_aicheb"), ("cg_tns", "pc_tns"),
-                     ("cg_tnsx", "pc_tns_expl"), ("cg_fsai", "pc_fsai"), ("bicgstab_spai", "pc_spai")):
+                     ("cg_sgs", "pc_sgs"), ("cg_ic", "pc_ic")):
         if key not in g:  # IC only on the SPD cases (the reference asserts on a breakdown)
             continue
         ls = _mk(S, tag); ls.SetOperator(A); ls.Build()
         z = ra.LocalVector(); z.Allocate("", n)
         ls.PrecondApply(x, z)
-        if key == "pc_spai" and name.startswith("rand"):  # see test_spai_matrix_vs_golden
-            assert np.allclose(z.numpy(), g[key], rtol=1e-12, atol=1e-13)
-        else:
-            eq(z.numpy(), g[key])
+        eq(z.numpy(), g[key])
         if key == "pc_mcsgs":
             assert ls.GetNumColors() == int(g["mc_num_colors"][0])
         ls.Clear()
@@ -155,25 +142,6 @@ def test_iterative_triangular_solves_bit_exact(ra, S, name):
         ls.Clear()
 
 
-@pytest.mark.parametrize("name", PC_CASES)
-def test_itilu0_preconditioner(ra, S, name):
-    """ItILU0 with direct and with iterative triangular solves: the applies of ILU(0) (what the reference's host backend
-    computes for ItILU0: its iterative factorisation falls back to the exact one there)"""
-    g = load_golden(name)
-    A = ra.LocalMatrix(); A.SetDataPtrCSR(g["rowptr"], g["col"], g["val"])
-    n = A.GetM()
-    x = ra.LocalVector(data=g["x"])
-    for key, descr in (("pc_ilu0", None), ("pc_itilu0", (30, 1e-3, True))):
-        pc = S.ItILU0(); pc.SetTolerance(1e-8); pc.SetMaxIter(50)
-        if descr:
-            pc.SetSolverDescriptor(_descr(S, *descr))
-        ls = S.CG(); ls.SetOperator(A); ls.SetPreconditioner(pc); ls.Build()
-        z = ra.LocalVector(); z.Allocate("", n)
-        ls.PrecondApply(x, z)
-        eq(z.numpy(), g[key])
-        ls.Clear()
-
-
 @pytest.mark.parametrize("name", SOLVER_CASES_IT)
 @pytest.mark.parametrize("tag", ["gmres_itilu0", "cg_itic"])
 def test_solvers_with_iterative_triangular_solves(ra, S, name, tag):
@@ -203,7 +171,7 @@ def test_solvers_with_iterative_triangular_solves(ra, S, name, tag):
 SOLVER_TAGS = ["cg_none", "cg_jacobi", "gmres_none", "gmres_ilu0", "gmres_ilu1", "bicgstab_none", "bicgstab_mcsgs", "bicgstab_mcgs",
                "gmres_mcilu", "fcg_none", "fcg_jacobi", "fcg_mcsgs", "cr_none", "cr_jacobi", "fgmres_none",
                "fgmres_ilu0", "bicgstabl_none", "bicgstabl3_jacobi", "qmrcgstab_none", "qmrcgstab_mcsgs", "idr_none",
-               "idr2_jacobi", "cg_sgs", "cg_ic", "cg_tns", "cg_aicheb", "cg_fsai", "bicgstab_spai", "bicgstab_gs", "fixedpoint_jacobi", "chebyshev_none", "chebyshev_jacobi"]
+               "idr2_jacobi", "cg_sgs", "cg_ic", "bicgstab_gs", "fixedpoint_jacobi"]
 SOLVER_CASES = ["gr3030", "poisson8", "lap2d7", "poisson16", "poisson32"]
 
 
@@ -258,11 +226,6 @@ def test_solvers_vs_golden(ra, S, name, tag, fused):
     meta = g[tag + "_meta"]
     slack = 1 if tag.split("_")[0] in ("cg", "fcg", "cr") else 2
     bicg = tag.split("_")[0] in ("bicgstab", "bicgstabl", "bicgstabl3", "qmrcgstab", "idr", "idr2")  # see _check_hist
-    # the reference's AIChebyshev (A + c/2 I + ... as written there) is not a definite preconditioner: CG around it
-    # amplifies the summation-order differences of the dots like BiCGStab does (its applies are bit-exact, see above)
-    bicg = bicg or tag == "cg_aicheb"
-    if tag == "cg_aicheb":
-        slack = 4  # ... and the iteration count moves with it (39 against 41 on poisson8)
     _check_run(ls.GetResidualHistory(), g[tag + "_hist"], ls.GetIterationCount(), int(meta[0]),
                ls.GetSolverStatus(), int(meta[1]), slack, bicg)
     if ls.GetIterationCount() == int(meta[0]) and not bicg:
@@ -441,10 +404,6 @@ def _write_mtx(path, rp, ci, va):
 DRIVER_RUNS = [("cg", "jacobi", "csr", 0, "cg_jacobi"), ("gmres", "ilu", "csr", 30, "gmres_ilu0"),
                ("bicgstab", "mcsgs", "ell", 0, "bicgstab_mcsgs_ell"), ("cg", "jacobi", "hyb", 0, "cg_jacobi_hyb"),
                ("cg", "jacobi", "dia", 0, "cg_jacobi_dia"), ("cg", "ic", "csr", 0, "cg_ic"),
-               ("fgmres", "variable", "csr", 30, "fgmres_variable"), ("cg", "fsai", "csr", 0, "cg_fsai"),
-               ("cg", "tns", "csr", 0, "cg_tns"), ("gmres", "as", "csr", 30, "gmres_as"),
-               ("gmres", "ras", "csr", 30, "gmres_ras"), ("gmres", "block", "csr", 30, "gmres_block"),
-               ("gmres", "blockdiag", "csr", 30, "gmres_blockdiag"),
                ("mixed", "jacobi", "csr", 0, "mixed_cg_jacobi"), ("qmrcgstab", "mcsgs", "csr", 0, "qmrcgstab_mcsgs"),
                ("idr", "none", "csr", 4, "idr_none"), ("fcg", "mcsgs", "csr", 0, "fcg_mcsgs"),
                ("cr", "jacobi", "csr", 0, "cr_jacobi"), ("fgmres", "ilu", "csr", 30, "fgmres_ilu0"),
@@ -558,13 +517,13 @@ def test_cpp_uaamg_driver_vs_reference(tmp_path, name):
     rp, ci, va, _ = _inputs(name, g)
     _write_mtx(mtx, rp, ci, va)
     for variant, tag in (("a", "uaamg_pmis"), ("c", "cg_uaamg"), ("s", "saamg_pmis"), ("d", "cg_saamg"),
-                         ("g", "cg_uaamg_greedy"), ("h", "cg_saamg_greedy"), ("r", "rsamg_pmis"), ("q", "cg_rsamg")):
+                         ("g", "cg_uaamg_greedy"), ("h", "cg_saamg_greedy")):
         r = subprocess.run([exe, mtx, variant], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
         out = r.stdout.decode()
         assert r.returncode == 0, out[-2000:]
         m = re.search(r"RESULT .*coarse_n=(\d+) coarse_nnz=(\d+) iters=(\d+) status=(\d+) residual=(\S+) error=(\S+)", out)
         assert m, out[-2000:]
-        lv = ("rsamg" if "rsamg" in tag else "saamg" if "saamg" in tag else "uaamg") + \
+        lv = ("saamg" if "saamg" in tag else "uaamg") + \
              ("_greedy" if "greedy" in tag else "") + "_levels"
         if lv in g:
             assert int(m.group(1)) == int(g[lv][0])

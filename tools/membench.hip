@@ -1,0 +1,226 @@
+// membench.hip -- streaming-bandwidth microbenchmark for the BLAS-1 shaped kernels of the Krylov loops (tools/, not product).
+//
+//   hipcc --offload-arch=gfx950 -O3 -o tools/_bin/membench tools/membench.hip && tools/_bin/membench [n]
+//
+// Measures, on n fp64 elements (default 512^3), the access patterns of the fused vector kernels:
+//   copy   1R:1W            (the guide's float4-copy figure: 6.29 TB/s)
+//   read2  2R               (dot)
+//   mgs    3R:1W, w in place  (k_mgs_step)
+//   upd    3R:2W, r in place  (k_cg_update: r, q, dinv -> r, z)
+//   dir    3R:2W, x,p in place (k_cg_direction)
+// over: packets in flight per thread (unroll 1/2/4/8), workgroups per CU (grid-stride) or one-shot grids,
+// non-temporal loads / stores.  Prints one line per variant: pattern, knobs, ms, algorithmic TB/s.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef double v2 __attribute__((ext_vector_type(2)));
+
+#define CHECK(x)                                                                 \
+    do                                                                           \
+    {                                                                            \
+        hipError_t e_ = (x);                                                     \
+        if(e_ != hipSuccess)                                                     \
+        {                                                                        \
+            fprintf(stderr, "%s -> %s\n", #x, hipGetErrorString(e_));            \
+            exit(1);                                                             \
+        }                                                                        \
+    } while(0)
+
+template <bool NT>
+__device__ __forceinline__ v2 ld(const v2* p)
+{
+    return NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st(v2* p, v2 v)
+{
+    if(NT)
+        __builtin_nontemporal_store(v, p);
+    else
+        *p = v;
+}
+
+enum
+{
+    P_COPY = 0,
+    P_READ2,
+    P_MGS,
+    P_UPD,
+    P_DIR
+};
+
+// one kernel body for all patterns: U independent packets per thread per trip, loads first, then math, then stores
+template <int PAT, int U, bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void k_stream(int64_t np, v2* __restrict__ a, v2* __restrict__ b,
+                                                const v2* __restrict__ c, v2* __restrict__ d, double alpha,
+                                                double* __restrict__ sink)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256 * U;
+    double        acc    = 0.0;
+    for(int64_t base = (int64_t)blockIdx.x * 256 * U + threadIdx.x; base < np; base += stride)
+    {
+        v2 va[U], vb[U], vc[U];
+#pragma unroll
+        for(int u = 0; u < U; ++u)
+        {
+            const int64_t i = base + (int64_t)u * 256;
+            if(i < np)
+            {
+                if(PAT == P_COPY)
+                    va[u] = ld<NTL>(a + i);
+                else if(PAT == P_READ2)
+                {
+                    va[u] = ld<NTL>(a + i);
+                    vb[u] = ld<NTL>(b + i);
+                }
+                else
+                {
+                    va[u] = ld<false>(a + i); // in-place operand
+                    vb[u] = (PAT == P_DIR) ? ld<false>(b + i) : ld<NTL>(b + i);
+                    vc[u] = ld<NTL>(c + i);
+                }
+            }
+        }
+#pragma unroll
+        for(int u = 0; u < U; ++u)
+        {
+            const int64_t i = base + (int64_t)u * 256;
+            if(i < np)
+            {
+                if(PAT == P_COPY)
+                    st<NTS>(b + i, va[u]);
+                else if(PAT == P_READ2)
+                    acc += va[u].x * vb[u].x + va[u].y * vb[u].y;
+                else if(PAT == P_MGS)
+                {
+                    v2 w = va[u] + alpha * vb[u];
+                    acc += w.x * vc[u].x + w.y * vc[u].y;
+                    st<NTS>(a + i, w);
+                }
+                else if(PAT == P_UPD)
+                {
+                    v2 r = va[u] + alpha * vb[u];
+                    v2 z = vc[u] * r;
+                    acc += r.x * r.x + r.y * r.y + r.x * z.x + r.y * z.y;
+                    st<NTS>(a + i, r);
+                    st<NTS>(d + i, z);
+                }
+                else
+                {
+                    v2 x = va[u] + alpha * vb[u];
+                    v2 p = alpha * vb[u] + vc[u];
+                    st<NTS>(a + i, x);
+                    st<NTS>(b + i, p);
+                }
+            }
+        }
+    }
+    if(PAT == P_READ2 || PAT == P_MGS || PAT == P_UPD)
+    {
+        // cheap stand-in for the block reduction of the real kernels
+        for(int off = 32; off > 0; off >>= 1)
+            acc += __shfl_down(acc, off, 64);
+        if((threadIdx.x & 63) == 0)
+            sink[blockIdx.x * 4 + (threadIdx.x >> 6)] = acc;
+    }
+}
+
+struct Bufs
+{
+    v2 *    a, *b, *c, *d;
+    double* sink;
+    int64_t np;
+};
+
+template <int PAT, int U, bool NTL, bool NTS>
+static void run(const Bufs& B, const char* name, int wg_per_cu, int bytes_per_elem)
+{
+    int64_t blocks_oneshot = (B.np + 256 * U - 1) / (256 * U);
+    int64_t grid           = wg_per_cu > 0 ? (int64_t)256 * wg_per_cu : blocks_oneshot;
+    if(grid > blocks_oneshot)
+        grid = blocks_oneshot;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    const int reps = 20;
+    for(int w = 0; w < 3; ++w)
+        hipLaunchKernelGGL((k_stream<PAT, U, NTL, NTS>), dim3((unsigned)grid), dim3(256), 0, 0, B.np, B.a, B.b, B.c, B.d,
+                           1e-9, B.sink);
+    CHECK(hipEventRecord(e0));
+    for(int r = 0; r < reps; ++r)
+        hipLaunchKernelGGL((k_stream<PAT, U, NTL, NTS>), dim3((unsigned)grid), dim3(256), 0, 0, B.np, B.a, B.b, B.c, B.d,
+                           1e-9, B.sink);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= reps;
+    const double tb = (double)B.np * 2 * bytes_per_elem / (ms * 1e-3) / 1e12;
+    printf("%-6s unroll=%d wg/cu=%-8s ntl=%d nts=%d  %8.4f ms  %6.3f TB/s\n", name, U,
+           wg_per_cu > 0 ? std::to_string(wg_per_cu).c_str() : "oneshot", (int)NTL, (int)NTS, ms, tb);
+    fflush(stdout);
+    CHECK(hipEventDestroy(e0));
+    CHECK(hipEventDestroy(e1));
+}
+
+template <int PAT, int U>
+static void sweep_nt(const Bufs& B, const char* name, int bpe, const std::vector<int>& grids)
+{
+    for(int g : grids)
+    {
+        run<PAT, U, false, false>(B, name, g, bpe);
+        run<PAT, U, true, false>(B, name, g, bpe);
+        run<PAT, U, false, true>(B, name, g, bpe);
+        run<PAT, U, true, true>(B, name, g, bpe);
+    }
+}
+
+template <int PAT>
+static void sweep(const Bufs& B, const char* name, int bpe)
+{
+    const std::vector<int> grids = {4, 8, 16, 32, 0};
+    sweep_nt<PAT, 1>(B, name, bpe, grids);
+    sweep_nt<PAT, 2>(B, name, bpe, grids);
+    sweep_nt<PAT, 4>(B, name, bpe, grids);
+    sweep_nt<PAT, 8>(B, name, bpe, {8, 16, 0});
+}
+
+int main(int argc, char** argv)
+{
+    const int64_t n = argc > 1 ? atoll(argv[1]) : (int64_t)512 * 512 * 512;
+    Bufs          B;
+    B.np = n / 2;
+    const size_t bytes = (size_t)n * 8 + 256;
+    CHECK(hipMalloc(&B.a, bytes));
+    CHECK(hipMalloc(&B.b, bytes));
+    CHECK(hipMalloc(&B.c, bytes));
+    CHECK(hipMalloc(&B.d, bytes));
+    CHECK(hipMalloc(&B.sink, 1 << 24));
+    CHECK(hipMemset(B.a, 0, bytes));
+    CHECK(hipMemset(B.b, 0, bytes));
+    CHECK(hipMemset(B.c, 0, bytes));
+    CHECK(hipMemset(B.d, 0, bytes));
+    printf("# n = %lld fp64 elements per vector; TB/s = algorithmic bytes (reads + writes) / time\n", (long long)n);
+    sweep<P_COPY>(B, "copy", 16);
+    sweep<P_READ2>(B, "read2", 16);
+    sweep<P_MGS>(B, "mgs", 32);
+    sweep<P_UPD>(B, "upd", 40);
+    sweep<P_DIR>(B, "dir", 40);
+    // hipMemcpyAsync D2D as the runtime's own copy figure
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    CHECK(hipMemcpyAsync(B.b, B.a, (size_t)n * 8, hipMemcpyDeviceToDevice, 0));
+    CHECK(hipEventRecord(e0));
+    for(int r = 0; r < 10; ++r)
+        CHECK(hipMemcpyAsync(B.b, B.a, (size_t)n * 8, hipMemcpyDeviceToDevice, 0));
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    printf("hipMemcpyAsync D2D  %8.4f ms  %6.3f TB/s\n", ms / 10, (double)n * 16 / (ms / 10 * 1e-3) / 1e12);
+    return 0;
+}
