@@ -25,6 +25,7 @@
 #include <fstream>
 #include <iostream>
 #include <sstream>
+#include <stdexcept>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -54,13 +55,51 @@ enum _matrix_format // src/base/matrix_formats.hpp
         std::cout << stream << std::endl;  \
     } while(0)
 
-#define FATAL_ERROR(file, line)                                                            \
-    do                                                                                     \
-    {                                                                                      \
-        std::cout << "Fatal error - the program will be terminated" << std::endl;          \
-        std::cout << "File: " << file << "; line: " << line << std::endl;                  \
-        exit(1);                                                                           \
-    } while(0)
+// Error convention of the reference (src/utils/log.hpp:95-100): log, then exit(1).  A translation unit that embeds this
+// layer behind a status-code interface (csrc/capi_solvers.cpp: the C ABI Python binds) defines RAMD_FATAL_THROWS before
+// including it; a fatal error then unwinds as rocalution::fatal_error and becomes an error status there.
+struct fatal_error : public std::runtime_error
+{
+    fatal_error(const char* file, int line)
+        : std::runtime_error(std::string("fatal error in ") + file + ":" + std::to_string(line))
+    {
+    }
+};
+[[noreturn]] inline void _fatal(const char* file, int line)
+{
+#ifdef RAMD_FATAL_THROWS
+    throw fatal_error(file, line);
+#else
+    std::cout << "Fatal error - the program will be terminated" << std::endl;
+    std::cout << "File: " << file << "; line: " << line << std::endl;
+    exit(1);
+#endif
+}
+#define FATAL_ERROR(file, line) ::rocalution::_fatal(file, line)
+#define RAMD_DIE() ::rocalution::_fatal(__FILE__, __LINE__)
+// asserts stay active in release builds, as in the reference (src/utils/def.hpp:50-58)
+#define RAMD_EXPECT(cond) assert(cond)
+
+// one log line from any number of streamable pieces
+inline void say_more(void) {}
+template <typename First, typename... Rest>
+inline void say_more(const First& first, const Rest&... rest)
+{
+    std::cout << first;
+    say_more(rest...);
+}
+template <typename... Args>
+inline void say(const Args&... args)
+{
+    say_more(args...);
+    std::cout << std::endl;
+}
+// a literal in the solver's value type
+template <typename T>
+inline T num(double v)
+{
+    return static_cast<T>(v);
+}
 
 // status of a C-ABI call -> reference error convention
 inline void _check(int status, const char* what, const char* file, int line)

@@ -611,7 +611,7 @@ class BlockJacobi : public Preconditioner<OperatorType, VectorType, ValueType>
 {
 public:
     BlockJacobi()
-        : local_precond_(NULL)
+        : m_local_precond(NULL)
     {
     }
     virtual ~BlockJacobi()
@@ -621,41 +621,41 @@ public:
     virtual void Print(void) const
     {
         LOG_INFO("BlockJacobi preconditioner with local preconditioner:");
-        if(this->local_precond_)
-            this->local_precond_->Print();
+        if(this->m_local_precond)
+            this->m_local_precond->Print();
     }
     void Set(Solver<LocalMatrix<ValueType>, LocalVector<ValueType>, ValueType>& precond)
     {
-        this->local_precond_ = &precond;
+        this->m_local_precond = &precond;
     }
     virtual void Build(void)
     {
-        if(this->build_)
+        if(this->m_build)
             this->Clear();
-        assert(this->local_precond_ != NULL && this->op_ != NULL);
-        this->build_ = true;
-        this->local_precond_->SetOperator(this->op_->GetInterior());
-        this->local_precond_->Build();
+        assert(this->m_local_precond != NULL && this->m_op != NULL);
+        this->m_build = true;
+        this->m_local_precond->SetOperator(this->m_op->GetInterior());
+        this->m_local_precond->Build();
     }
     virtual void Clear(void)
     {
-        if(this->local_precond_ != NULL)
-            this->local_precond_->Clear();
-        this->local_precond_ = NULL;
-        this->build_         = false;
+        if(this->m_local_precond != NULL)
+            this->m_local_precond->Clear();
+        this->m_local_precond = NULL;
+        this->m_build         = false;
     }
     virtual void Solve(const VectorType& rhs, VectorType* x)
     {
-        this->local_precond_->Solve(rhs.GetInterior(), &x->GetInterior());
+        this->m_local_precond->Solve(rhs.GetInterior(), &x->GetInterior());
     }
     // a local multigrid cycle / nested solver runs reductions of its own: the outer fused loop steps aside
     virtual bool SolveUsesScalarRecord(void) const
     {
-        return this->local_precond_ != NULL && this->local_precond_->SolveUsesScalarRecord();
+        return this->m_local_precond != NULL && this->m_local_precond->SolveUsesScalarRecord();
     }
 
 private:
-    Solver<LocalMatrix<ValueType>, LocalVector<ValueType>, ValueType>* local_precond_;
+    Solver<LocalMatrix<ValueType>, LocalVector<ValueType>, ValueType>* m_local_precond;
 };
 
 } // namespace rocalution

@@ -31,334 +31,325 @@ public:
     IterationControl()
     {
         this->Clear();
-        this->rec_            = false;
-        this->verb_           = 1;
-        this->absolute_tol_   = 1e-15;
-        this->relative_tol_   = 1e-6;
-        this->divergence_tol_ = 1e+8;
-        this->minimum_iter_   = 0;
-        this->maximum_iter_   = 1000000;
-        this->initial_residual_ = 0.0;
+        this->m_rec            = false;
+        this->m_verb           = 1;
+        this->m_absolute_tol   = 1e-15;
+        this->m_relative_tol   = 1e-6;
+        this->m_divergence_tol = 1e+8;
+        this->m_minimum_iter   = 0;
+        this->m_maximum_iter   = 1000000;
+        this->m_initial_residual = 0.0;
     }
     void Clear(void)
     {
-        this->residual_history_.clear();
-        this->iteration_     = 0;
-        this->init_res_      = false;
-        this->reached_       = 0;
-        this->current_res_   = 0.0;
-        this->current_index_ = -1;
+        this->m_residual_history.clear();
+        this->m_iteration     = 0;
+        this->m_init_res      = false;
+        this->m_reached       = 0;
+        this->m_current_res   = 0.0;
+        this->m_current_index = -1;
     }
-    void Init(double abs, double rel, double div, int max)
+    void Init(double tol_abs, double tol_rel, double tol_div, int it_hi)
     {
-        this->InitTolerance(abs, rel, div);
-        this->InitMaximumIterations(max);
+        this->InitTolerance(tol_abs, tol_rel, tol_div);
+        this->InitMaximumIterations(it_hi);
     }
-    void Init(double abs, double rel, double div, int min, int max)
+    void Init(double tol_abs, double tol_rel, double tol_div, int it_lo, int it_hi)
     {
-        this->InitTolerance(abs, rel, div);
-        this->InitMinimumIterations(min);
-        this->InitMaximumIterations(max);
+        this->InitTolerance(tol_abs, tol_rel, tol_div);
+        this->InitMinimumIterations(it_lo);
+        this->InitMaximumIterations(it_hi);
     }
-    void InitTolerance(double abs, double rel, double div)
+    void InitTolerance(double tol_abs, double tol_rel, double tol_div)
     {
-        this->absolute_tol_   = abs;
-        this->relative_tol_   = rel;
-        this->divergence_tol_ = div;
+        this->m_absolute_tol   = tol_abs;
+        this->m_relative_tol   = tol_rel;
+        this->m_divergence_tol = tol_div;
     }
-    void InitMinimumIterations(int min)
+    void InitMinimumIterations(int it_lo)
     {
-        assert(min >= 0 && min <= this->maximum_iter_);
-        this->minimum_iter_ = min;
+        RAMD_EXPECT(it_lo >= 0 && it_lo <= this->m_maximum_iter);
+        this->m_minimum_iter = it_lo;
     }
-    void InitMaximumIterations(int max)
+    void InitMaximumIterations(int it_hi)
     {
-        assert(max >= 0 && max >= this->minimum_iter_);
-        this->maximum_iter_ = max;
+        RAMD_EXPECT(it_hi >= 0 && it_hi >= this->m_minimum_iter);
+        this->m_maximum_iter = it_hi;
     }
     int GetMinimumIterations(void) const
     {
-        return this->minimum_iter_;
+        return this->m_minimum_iter;
     }
     int GetMaximumIterations(void) const
     {
-        return this->maximum_iter_;
+        return this->m_maximum_iter;
     }
     int GetIterationCount(void) const
     {
-        return this->iteration_;
+        return this->m_iteration;
     }
     double GetCurrentResidual(void) const
     {
-        return this->current_res_;
+        return this->m_current_res;
     }
     int64_t GetAmaxResidualIndex(void) const
     {
-        return this->current_index_;
+        return this->m_current_index;
     }
     int GetSolverStatus(void) const
     {
-        return this->reached_;
+        return this->m_reached;
     }
     const std::vector<double>& GetResidualHistory(void) const
     {
-        return this->residual_history_;
+        return this->m_residual_history;
     }
     void RecordHistory(void)
     {
-        this->rec_ = true;
+        this->m_rec = true;
     }
     void Verbose(int verb)
     {
-        this->verb_ = verb;
+        this->m_verb = verb;
     }
     // iter_ctrl.cpp:89-121
-    bool InitResidual(double res)
+    bool InitResidual(double resid)
     {
-        this->init_res_         = true;
-        this->initial_residual_ = res; // current_res_ is NOT touched here (iter_ctrl.cpp:89-96)
-        this->reached_          = 0;
-        this->iteration_        = 0;
-        if(this->verb_ > 0)
-            LOG_INFO("IterationControl initial residual = " << res);
-        if(this->rec_)
-            this->residual_history_.push_back(res);
-        if(this->bad_(res))
+        this->m_init_res         = true;
+        this->m_initial_residual = resid; // m_current_res is NOT touched here (iter_ctrl.cpp:89-96)
+        this->m_reached          = 0;
+        this->m_iteration        = 0;
+        if(this->m_verb > 0)
+            say("IterationControl initial residual = ", resid);
+        if(this->m_rec)
+            this->m_residual_history.push_back(resid);
+        if(this->m_bad(resid))
         {
-            LOG_INFO("Residual = " << res << " !!!");
+            say("Residual = ", resid, " !!!");
             return false;
         }
-        if(std::abs(res) <= this->absolute_tol_)
+        if(std::abs(resid) <= this->m_absolute_tol)
         {
-            this->reached_ = 1;
+            this->m_reached = 1;
             return false;
         }
         return true;
     }
     // iter_ctrl.cpp:195-248
-    bool CheckResidual(double res)
+    bool CheckResidual(double resid)
     {
-        assert(this->init_res_ == true);
-        this->iteration_++;
-        this->current_res_ = res;
-        if(this->verb_ > 1)
-            LOG_INFO("IterationControl iter=" << this->iteration_ << "; residual=" << res);
-        if(this->rec_)
-            this->residual_history_.push_back(res);
-        if(this->bad_(res))
+        RAMD_EXPECT(this->m_init_res);
+        this->m_iteration++;
+        this->m_current_res = resid;
+        if(this->m_verb > 1)
+            say("IterationControl iter=", this->m_iteration, "; residual=", resid);
+        if(this->m_rec)
+            this->m_residual_history.push_back(resid);
+        if(this->m_bad(resid))
         {
-            LOG_INFO("Residual = " << res << " !!!");
+            say("Residual = ", resid, " !!!");
             return true;
         }
-        if(this->iteration_ >= this->minimum_iter_)
+        if(this->m_iteration >= this->m_minimum_iter)
         {
-            if(std::abs(res) <= this->absolute_tol_)
+            if(std::abs(resid) <= this->m_absolute_tol)
             {
-                this->reached_ = 1;
+                this->m_reached = 1;
                 return true;
             }
-            if(res / this->initial_residual_ <= this->relative_tol_)
+            if(resid / this->m_initial_residual <= this->m_relative_tol)
             {
-                this->reached_ = 2;
+                this->m_reached = 2;
                 return true;
             }
-            if(this->iteration_ >= this->maximum_iter_)
+            if(this->m_iteration >= this->m_maximum_iter)
             {
-                this->reached_ = 4;
+                this->m_reached = 4;
                 return true;
             }
         }
-        if(res / this->initial_residual_ >= this->divergence_tol_)
+        if(resid / this->m_initial_residual >= this->m_divergence_tol)
         {
-            this->reached_ = 3;
+            this->m_reached = 3;
             return true;
         }
         return false;
     }
-    bool CheckResidual(double res, int64_t index)
+    bool CheckResidual(double resid, int64_t index)
     {
-        this->current_index_ = index;
-        return this->CheckResidual(res);
+        this->m_current_index = index;
+        return this->CheckResidual(resid);
     }
     // iter_ctrl.cpp:295-306
     bool CheckMaximumIterNoCount(void)
     {
-        assert(this->init_res_ == true);
-        if(this->iteration_ + 1 >= this->maximum_iter_)
+        RAMD_EXPECT(this->m_init_res);
+        if(this->m_iteration + 1 >= this->m_maximum_iter)
         {
-            this->reached_ = 4;
+            this->m_reached = 4;
             return true;
         }
         return false;
     }
     // iter_ctrl.cpp:256-289
-    bool CheckResidualNoCount(double res)
+    bool CheckResidualNoCount(double resid)
     {
-        assert(this->init_res_ == true);
-        if(this->bad_(res))
+        RAMD_EXPECT(this->m_init_res);
+        if(this->m_bad(resid))
         {
-            LOG_INFO("Residual = " << res << " !!!");
+            say("Residual = ", resid, " !!!");
             return true;
         }
-        if(std::abs(res) <= this->absolute_tol_)
+        if(std::abs(resid) <= this->m_absolute_tol)
         {
-            this->reached_ = 1;
+            this->m_reached = 1;
             return true;
         }
-        if(res / this->initial_residual_ <= this->relative_tol_)
+        if(resid / this->m_initial_residual <= this->m_relative_tol)
         {
-            this->reached_ = 2;
+            this->m_reached = 2;
             return true;
         }
-        if(res / this->initial_residual_ >= this->divergence_tol_)
+        if(resid / this->m_initial_residual >= this->m_divergence_tol)
         {
-            this->reached_ = 3;
+            this->m_reached = 3;
             return true;
         }
-        if(this->iteration_ >= this->maximum_iter_)
+        if(this->m_iteration >= this->m_maximum_iter)
         {
-            this->reached_ = 4;
+            this->m_reached = 4;
             return true;
         }
         return false;
     }
-    // iter_ctrl.cpp:317-345: the first `iteration_` entries, scientific notation
+    // iter_ctrl.cpp:317-345: the first `m_iteration` entries, scientific notation
     void WriteHistoryToFile(const std::string& filename) const
     {
-        std::ofstream file(filename.c_str());
-        if(!file.is_open())
+        std::ofstream out_file(filename.c_str());
+        if(!out_file.is_open())
         {
-            LOG_INFO("Can not open file [write]:" << filename);
-            FATAL_ERROR(__FILE__, __LINE__);
+            say("Can not open file [write]:", filename);
+            RAMD_DIE();
         }
-        file.setf(std::ios::scientific);
-        for(int n = 0; n < this->iteration_ && n < (int)this->residual_history_.size(); n++)
-            file << this->residual_history_[n] << std::endl;
+        out_file.setf(std::ios::scientific);
+        for(int n = 0; n < this->m_iteration && n < (int)this->m_residual_history.size(); n++)
+            out_file << this->m_residual_history[n] << std::endl;
     }
     void PrintInit(void) const
     {
-        LOG_INFO("IterationControl criteria: abs tol=" << this->absolute_tol_ << "; rel tol="
-                                                       << this->relative_tol_ << "; div tol="
-                                                       << this->divergence_tol_ << "; max iter="
-                                                       << this->maximum_iter_);
+        say("IterationControl criteria: abs tol=", this->m_absolute_tol, "; rel tol=", this->m_relative_tol, "; div tol=", this->m_divergence_tol, "; max iter=", this->m_maximum_iter);
     }
     void PrintStatus(void) const
     {
         static const char* why[] = {"NO CRITERIA", "ABSOLUTE criteria", "RELATIVE criteria",
                                     "DIVERGENCE criteria", "MAX ITER criteria"};
-        LOG_INFO("IterationControl " << why[this->reached_] << " has been reached: res norm="
-                                     << this->current_res_ << "; rel val="
-                                     << this->current_res_ / this->initial_residual_
-                                     << "; iter=" << this->iteration_);
+        say("IterationControl ", why[this->m_reached], " has been reached: res norm=", this->m_current_res, "; rel val=", this->m_current_res / this->m_initial_residual, "; iter=", this->m_iteration);
     }
 
 private:
-    static bool bad_(double res)
+    static bool m_bad(double resid)
     {
-        return (std::abs(res) == std::numeric_limits<double>::infinity()) || (res != res);
+        return (std::abs(resid) == std::numeric_limits<double>::infinity()) || (resid != resid);
     }
-    std::vector<double> residual_history_;
-    int                 iteration_;
-    bool                init_res_, rec_;
-    int                 verb_, reached_;
-    double              initial_residual_, current_res_;
-    int64_t             current_index_;
-    double              absolute_tol_, relative_tol_, divergence_tol_;
-    int                 minimum_iter_, maximum_iter_;
+    std::vector<double> m_residual_history;
+    int                 m_iteration;
+    bool                m_init_res, m_rec;
+    int                 m_verb, m_reached;
+    double              m_initial_residual, m_current_res;
+    int64_t             m_current_index;
+    double              m_absolute_tol, m_relative_tol, m_divergence_tol;
+    int                 m_minimum_iter, m_maximum_iter;
 };
 
 // ============================================================================ SolverDescr
 // solver.hpp:33-148: which triangular-solve algorithm the preconditioners use, and the iterative one's limits
-#define DISPATCH_OPERATOR_SOLVE_STRATEGY(descr_, op_, func_, ...)                                             \
-    switch(descr_.GetTriSolverAlg())                                                                          \
-    {                                                                                                         \
-    case TriSolverAlg_Default:                                                                                \
-        op_.func_(__VA_ARGS__);                                                                               \
-        break;                                                                                                \
-    case TriSolverAlg_Iterative:                                                                              \
-        op_.It##func_(descr_.GetIterativeSolverMaxIteration(), descr_.GetIterativeSolverTolerance(),          \
-                      descr_.GetIterativeSolverUseTolerance(), __VA_ARGS__);                                  \
-        break;                                                                                                \
-    }
-#define DISPATCH_OPERATOR_ANALYSE_STRATEGY(descr_, op_, func_, ...) \
-    switch(descr_.GetTriSolverAlg())                                \
+#define RAMD_TRI_SOLVE(descr_, mat_arg, func_, ...)                                                              \
+    do                                                                                                           \
+    {                                                                                                            \
+        if(descr_.GetTriSolverAlg() == TriSolverAlg_Iterative)                                                   \
+            mat_arg.It##func_(descr_.GetIterativeSolverMaxIteration(), descr_.GetIterativeSolverTolerance(),     \
+                              descr_.GetIterativeSolverUseTolerance(), __VA_ARGS__);                             \
+        else                                                                                                     \
+            mat_arg.func_(__VA_ARGS__);                                                                          \
+    } while(0)
+#define RAMD_TRI_ANALYSE(descr_, mat_arg, func_, ...)               \
+    do                                                              \
     {                                                               \
-    case TriSolverAlg_Default:                                      \
-        op_.func_(__VA_ARGS__);                                     \
-        break;                                                      \
-    case TriSolverAlg_Iterative:                                    \
-        op_.It##func_(__VA_ARGS__);                                 \
-        break;                                                      \
-    }
+        if(descr_.GetTriSolverAlg() == TriSolverAlg_Iterative)      \
+            mat_arg.It##func_(__VA_ARGS__);                         \
+        else                                                        \
+            mat_arg.func_(__VA_ARGS__);                             \
+    } while(0)
 
-typedef enum _tri_solver_alg : unsigned int
+enum _tri_solver_alg : unsigned int
 {
     TriSolverAlg_Default   = 0, // level-scheduled direct solve
     TriSolverAlg_Iterative = 1 // Jacobi sweeps
-} TriSolverAlg;
+};
+typedef _tri_solver_alg TriSolverAlg;
 
 class SolverDescr
 {
 public:
     SolverDescr()
-        : tri_solver_alg_(TriSolverAlg_Default)
-        , itsolver_max_iter_(30)
-        , itsolver_tol_(1e-3)
-        , itsolver_use_tol_(true)
+        : m_tri_solver_alg(TriSolverAlg_Default)
+        , m_itsolver_max_iter(30)
+        , m_itsolver_tol(1e-3)
+        , m_itsolver_use_tol(true)
     {
     }
     virtual ~SolverDescr() {}
     void SetTriSolverAlg(TriSolverAlg alg)
     {
-        this->tri_solver_alg_ = alg;
+        this->m_tri_solver_alg = alg;
     }
     TriSolverAlg GetTriSolverAlg(void) const
     {
-        return this->tri_solver_alg_;
+        return this->m_tri_solver_alg;
     }
     void SetIterativeSolverMaxIteration(int max_iter)
     {
-        this->itsolver_max_iter_ = max_iter;
+        this->m_itsolver_max_iter = max_iter;
     }
     int GetIterativeSolverMaxIteration(void) const
     {
-        return this->itsolver_max_iter_;
+        return this->m_itsolver_max_iter;
     }
     void SetIterativeSolverTolerance(double tol)
     {
-        this->itsolver_tol_ = tol;
+        this->m_itsolver_tol = tol;
     }
     double GetIterativeSolverTolerance(void) const
     {
-        return this->itsolver_tol_;
+        return this->m_itsolver_tol;
     }
     void EnableIterativeSolverTolerance(void)
     {
-        this->itsolver_use_tol_ = true;
+        this->m_itsolver_use_tol = true;
     }
     void DisableIterativeSolverTolerance(void)
     {
-        this->itsolver_use_tol_ = false;
+        this->m_itsolver_use_tol = false;
     }
     bool GetIterativeSolverUseTolerance(void) const
     {
-        return this->itsolver_use_tol_;
+        return this->m_itsolver_use_tol;
     }
     void Print(void) const
     {
-        if(this->tri_solver_alg_ != TriSolverAlg_Iterative)
+        if(this->m_tri_solver_alg != TriSolverAlg_Iterative)
             return; // nothing is printed in the default direct case (solver.cpp:96-115)
-        if(this->itsolver_use_tol_)
-            LOG_INFO("TriSolverAlg = iterative (" << this->itsolver_max_iter_ << ", " << this->itsolver_tol_ << ")");
+        if(this->m_itsolver_use_tol)
+            say("TriSolverAlg = iterative (", this->m_itsolver_max_iter, ", ", this->m_itsolver_tol, ")");
         else
-            LOG_INFO("TriSolverAlg = iterative (" << this->itsolver_max_iter_ << ")");
+            say("TriSolverAlg = iterative (", this->m_itsolver_max_iter, ")");
     }
 
 protected:
-    TriSolverAlg tri_solver_alg_;
-    int          itsolver_max_iter_;
-    double       itsolver_tol_;
-    bool         itsolver_use_tol_;
+    TriSolverAlg m_tri_solver_alg;
+    int          m_itsolver_max_iter;
+    double       m_itsolver_tol;
+    bool         m_itsolver_use_tol;
 };
 
 // ============================================================================ Solver
@@ -367,24 +358,24 @@ class Solver
 {
 public:
     Solver()
-        : op_(NULL)
-        , precond_(NULL)
-        , build_(false)
-        , verb_(1)
-        , is_precond_(false)
-        , is_smoother_(false)
+        : m_op(NULL)
+        , m_precond(NULL)
+        , m_build(false)
+        , m_verb(1)
+        , m_is_precond(false)
+        , m_is_smoother(false)
     {
     }
     virtual ~Solver() {}
 
     void SetOperator(const OperatorType& op)
     {
-        assert(this->build_ == false);
-        this->op_ = &op;
+        RAMD_EXPECT(!this->m_build);
+        this->m_op = &op;
     }
     virtual void ResetOperator(const OperatorType& op)
     {
-        this->op_ = &op;
+        this->m_op = &op;
     }
     virtual void Print(void) const = 0;
     virtual void Solve(const VectorType& rhs, VectorType* x) = 0;
@@ -395,13 +386,13 @@ public:
     }
     virtual void Build(void)
     {
-        if(this->build_)
+        if(this->m_build)
             this->Clear();
-        this->build_ = true;
+        this->m_build = true;
     }
     virtual void Clear(void)
     {
-        this->build_ = false;
+        this->m_build = false;
     }
     virtual void MoveToHost(void) {}
     virtual void MoveToAccelerator(void) {}
@@ -410,7 +401,7 @@ public:
     // analysis of this backend runs on the device in milliseconds.
     virtual void ReBuildNumeric(void)
     {
-        if(this->build_)
+        if(this->m_build)
         {
             this->Clear();
             this->Build();
@@ -418,15 +409,15 @@ public:
     }
     virtual void Verbose(int verb = 1)
     {
-        this->verb_ = verb;
+        this->m_verb = verb;
     }
     void FlagPrecond(void)
     {
-        this->is_precond_ = true;
+        this->m_is_precond = true;
     }
     void FlagSmoother(void) // solver.hpp:254-258
     {
-        this->is_smoother_ = true;
+        this->m_is_smoother = true;
     }
     // true: Solve() runs reductions of its own (nested Krylov solvers, multigrid cycles), i.e. it overwrites the
     // device scalar record -- an outer fused loop that keeps alpha/beta/rho there across the call must not be used
@@ -437,18 +428,18 @@ public:
     // solver.cpp:293-301: the strategy cannot change once the solver is built
     virtual void SetSolverDescriptor(const SolverDescr& descr)
     {
-        assert(this->build_ == false);
-        this->solver_descr_ = descr;
+        RAMD_EXPECT(!this->m_build);
+        this->m_solver_descr = descr;
     }
 
 protected:
-    SolverDescr                                  solver_descr_;
-    const OperatorType*                          op_;
-    Solver<OperatorType, VectorType, ValueType>* precond_;
-    bool                                         build_;
-    int                                          verb_;
-    bool                                         is_precond_;
-    bool                                         is_smoother_;
+    SolverDescr                                  m_solver_descr;
+    const OperatorType*                          m_op;
+    Solver<OperatorType, VectorType, ValueType>* m_precond;
+    bool                                         m_build;
+    int                                          m_verb;
+    bool                                         m_is_precond;
+    bool                                         m_is_smoother;
 };
 
 // ============================================================================ Preconditioner
@@ -478,43 +469,43 @@ public:
     }
     virtual void Print(void) const
     {
-        LOG_INFO("Jacobi preconditioner");
+        say("Jacobi preconditioner");
     }
     virtual void Build(void)
     {
-        if(this->build_)
+        if(this->m_build)
             this->Clear();
-        this->build_ = true;
-        assert(this->op_ != NULL);
-        this->inv_diag_entries_.CloneBackend(*this->op_);
-        this->op_->ExtractInverseDiagonal(&this->inv_diag_entries_);
+        this->m_build = true;
+        RAMD_EXPECT(this->m_op != nullptr);
+        this->m_inv_diag_entries.CloneBackend(*this->m_op);
+        this->m_op->ExtractInverseDiagonal(&this->m_inv_diag_entries);
     }
     virtual void Clear(void)
     {
-        this->inv_diag_entries_.Clear();
-        this->build_ = false;
+        this->m_inv_diag_entries.Clear();
+        this->m_build = false;
     }
     virtual void Solve(const VectorType& rhs, VectorType* x)
     {
-        assert(this->build_ == true && x != NULL);
-        if(this->inv_diag_entries_.GetSize() == 0) // empty inverse diagonal == identity
+        RAMD_EXPECT(this->m_build && x != nullptr);
+        if(this->m_inv_diag_entries.GetSize() == 0) // empty inverse diagonal == identity
         {
             if(x != &rhs)
                 x->CopyFrom(rhs);
             return;
         }
         if(x != &rhs)
-            x->PointWiseMult(this->inv_diag_entries_, rhs);
+            x->PointWiseMult(this->m_inv_diag_entries, rhs);
         else
-            x->PointWiseMult(this->inv_diag_entries_);
+            x->PointWiseMult(this->m_inv_diag_entries);
     }
     const VectorType& GetInverseDiagonal(void) const
     {
-        return this->inv_diag_entries_;
+        return this->m_inv_diag_entries;
     }
 
 private:
-    VectorType inv_diag_entries_;
+    VectorType m_inv_diag_entries;
 };
 
 // ---- ILU(p = 0): preconditioner.cpp:449-511
@@ -523,8 +514,8 @@ class ILU : public Preconditioner<OperatorType, VectorType, ValueType>
 {
 public:
     ILU()
-        : p_(0)
-        , level_(true)
+        : m_p(0)
+        , m_level(true)
     {
     }
     virtual ~ILU()
@@ -533,44 +524,44 @@ public:
     }
     virtual void Print(void) const
     {
-        LOG_INFO("ILU(" << this->p_ << ") preconditioner");
+        say("ILU(", this->m_p, ") preconditioner");
     }
     virtual void Set(int p, bool level = true)
     {
-        assert(p >= 0 && this->build_ == false);
-        this->p_     = p;
-        this->level_ = level;
+        RAMD_EXPECT(p >= 0 && !this->m_build);
+        this->m_p     = p;
+        this->m_level = level;
     }
     virtual void Build(void)
     {
-        if(this->build_)
+        if(this->m_build)
             this->Clear();
-        this->build_ = true;
-        assert(this->op_ != NULL);
-        this->ILU_.CloneFrom(*this->op_);
-        this->ILU_.ILUpFactorize(this->p_, this->level_);
-        DISPATCH_OPERATOR_ANALYSE_STRATEGY(this->solver_descr_, this->ILU_, LUAnalyse);
+        this->m_build = true;
+        RAMD_EXPECT(this->m_op != nullptr);
+        this->m_ILU.CloneFrom(*this->m_op);
+        this->m_ILU.ILUpFactorize(this->m_p, this->m_level);
+        RAMD_TRI_ANALYSE(this->m_solver_descr, this->m_ILU, LUAnalyse);
     }
     virtual void Clear(void)
     {
-        DISPATCH_OPERATOR_ANALYSE_STRATEGY(this->solver_descr_, this->ILU_, LUAnalyseClear);
-        this->ILU_.Clear();
-        this->build_ = false;
+        RAMD_TRI_ANALYSE(this->m_solver_descr, this->m_ILU, LUAnalyseClear);
+        this->m_ILU.Clear();
+        this->m_build = false;
     }
     virtual void Solve(const VectorType& rhs, VectorType* x)
     {
-        assert(this->build_ == true && x != NULL && x != &rhs);
-        DISPATCH_OPERATOR_SOLVE_STRATEGY(this->solver_descr_, this->ILU_, LUSolve, rhs, x);
+        RAMD_EXPECT(this->m_build && x != nullptr && x != &rhs);
+        RAMD_TRI_SOLVE(this->m_solver_descr, this->m_ILU, LUSolve, rhs, x);
     }
     const OperatorType& GetFactors(void) const
     {
-        return this->ILU_;
+        return this->m_ILU;
     }
 
 private:
-    OperatorType ILU_;
-    int          p_;
-    bool         level_;
+    OperatorType m_ILU;
+    int          m_p;
+    bool         m_level;
 };
 
 // ---- IC (incomplete Cholesky, zero fill-in): preconditioner.cpp:826-925
@@ -585,50 +576,50 @@ public:
     }
     virtual void Print(void) const
     {
-        LOG_INFO("IC preconditioner");
-        if(this->build_)
-            LOG_INFO("IC nnz = " << this->IC_.GetNnz());
+        say("IC preconditioner");
+        if(this->m_build)
+            say("IC nnz = ", this->m_IC.GetNnz());
     }
     virtual void Build(void)
     {
-        if(this->build_)
+        if(this->m_build)
             this->Clear();
-        this->build_ = true;
-        assert(this->op_ != NULL);
-        this->IC_.CloneBackend(*this->op_);
-        this->inv_diag_entries_.CloneBackend(*this->op_);
-        this->op_->ExtractL(&this->IC_, true);
-        this->IC_.ICFactorize(&this->inv_diag_entries_);
-        DISPATCH_OPERATOR_ANALYSE_STRATEGY(this->solver_descr_, this->IC_, LLAnalyse);
+        this->m_build = true;
+        RAMD_EXPECT(this->m_op != nullptr);
+        this->m_IC.CloneBackend(*this->m_op);
+        this->m_inv_diag_entries.CloneBackend(*this->m_op);
+        this->m_op->ExtractL(&this->m_IC, true);
+        this->m_IC.ICFactorize(&this->m_inv_diag_entries);
+        RAMD_TRI_ANALYSE(this->m_solver_descr, this->m_IC, LLAnalyse);
     }
     virtual void Clear(void)
     {
-        DISPATCH_OPERATOR_ANALYSE_STRATEGY(this->solver_descr_, this->IC_, LLAnalyseClear);
-        this->inv_diag_entries_.Clear();
-        this->IC_.Clear();
-        this->build_ = false;
+        RAMD_TRI_ANALYSE(this->m_solver_descr, this->m_IC, LLAnalyseClear);
+        this->m_inv_diag_entries.Clear();
+        this->m_IC.Clear();
+        this->m_build = false;
     }
     virtual void Solve(const VectorType& rhs, VectorType* x)
     {
-        assert(this->build_ == true && x != NULL && x != &rhs);
-        DISPATCH_OPERATOR_SOLVE_STRATEGY(this->solver_descr_, this->IC_, LLSolve, rhs, this->inv_diag_entries_, x);
+        RAMD_EXPECT(this->m_build && x != nullptr && x != &rhs);
+        RAMD_TRI_SOLVE(this->m_solver_descr, this->m_IC, LLSolve, rhs, this->m_inv_diag_entries, x);
     }
     const OperatorType& GetFactor(void) const
     {
-        return this->IC_;
+        return this->m_IC;
     }
     const VectorType& GetInverseDiagonal(void) const
     {
-        return this->inv_diag_entries_;
+        return this->m_inv_diag_entries;
     }
 
 private:
-    OperatorType IC_;
-    VectorType   inv_diag_entries_;
+    OperatorType m_IC;
+    VectorType   m_inv_diag_entries;
 };
 
 // ---- GS / SGS: preconditioner.cpp:206-257 / :302-379 (sparse triangular solves on the matrix itself).
-// SGS::Build fills diag_entries_ with the INVERSE diagonal (:318, ExtractInverseDiagonal) -- kept as is.
+// SGS::Build fills m_diag_entries with the INVERSE diagonal (:318, ExtractInverseDiagonal) -- kept as is.
 template <class OperatorType, class VectorType, typename ValueType>
 class GS : public Preconditioner<OperatorType, VectorType, ValueType>
 {
@@ -640,31 +631,31 @@ public:
     }
     virtual void Print(void) const
     {
-        LOG_INFO("Gauss-Seidel (GS) preconditioner");
+        say("Gauss-Seidel (GS) preconditioner");
     }
     virtual void Build(void)
     {
-        if(this->build_)
+        if(this->m_build)
             this->Clear();
-        this->build_ = true;
-        assert(this->op_ != NULL);
-        this->GS_.CloneFrom(*this->op_);
-        DISPATCH_OPERATOR_ANALYSE_STRATEGY(this->solver_descr_, this->GS_, LAnalyse, false);
+        this->m_build = true;
+        RAMD_EXPECT(this->m_op != nullptr);
+        this->m_GS.CloneFrom(*this->m_op);
+        RAMD_TRI_ANALYSE(this->m_solver_descr, this->m_GS, LAnalyse, false);
     }
     virtual void Clear(void)
     {
-        DISPATCH_OPERATOR_ANALYSE_STRATEGY(this->solver_descr_, this->GS_, LAnalyseClear);
-        this->GS_.Clear();
-        this->build_ = false;
+        RAMD_TRI_ANALYSE(this->m_solver_descr, this->m_GS, LAnalyseClear);
+        this->m_GS.Clear();
+        this->m_build = false;
     }
     virtual void Solve(const VectorType& rhs, VectorType* x)
     {
-        assert(this->build_ == true && x != NULL);
-        DISPATCH_OPERATOR_SOLVE_STRATEGY(this->solver_descr_, this->GS_, LSolve, rhs, x);
+        RAMD_EXPECT(this->m_build && x != nullptr);
+        RAMD_TRI_SOLVE(this->m_solver_descr, this->m_GS, LSolve, rhs, x);
     }
 
 private:
-    OperatorType GS_;
+    OperatorType m_GS;
 };
 
 template <class OperatorType, class VectorType, typename ValueType>
@@ -678,44 +669,44 @@ public:
     }
     virtual void Print(void) const
     {
-        LOG_INFO("Symmetric Gauss-Seidel (SGS) preconditioner");
+        say("Symmetric Gauss-Seidel (SGS) preconditioner");
     }
     virtual void Build(void)
     {
-        if(this->build_)
+        if(this->m_build)
             this->Clear();
-        this->build_ = true;
-        assert(this->op_ != NULL);
-        this->SGS_.CloneFrom(*this->op_);
-        DISPATCH_OPERATOR_ANALYSE_STRATEGY(this->solver_descr_, this->SGS_, LAnalyse, false);
-        DISPATCH_OPERATOR_ANALYSE_STRATEGY(this->solver_descr_, this->SGS_, UAnalyse, false);
-        this->diag_entries_.CloneBackend(*this->op_);
-        this->diag_entries_.Allocate("diag", this->op_->GetM());
-        this->SGS_.ExtractInverseDiagonal(&this->diag_entries_);
-        this->v_.CloneBackend(*this->op_);
-        this->v_.Allocate("v", this->op_->GetM());
+        this->m_build = true;
+        RAMD_EXPECT(this->m_op != nullptr);
+        this->m_SGS.CloneFrom(*this->m_op);
+        RAMD_TRI_ANALYSE(this->m_solver_descr, this->m_SGS, LAnalyse, false);
+        RAMD_TRI_ANALYSE(this->m_solver_descr, this->m_SGS, UAnalyse, false);
+        this->m_diag_entries.CloneBackend(*this->m_op);
+        this->m_diag_entries.Allocate("diag", this->m_op->GetM());
+        this->m_SGS.ExtractInverseDiagonal(&this->m_diag_entries);
+        this->m_v.CloneBackend(*this->m_op);
+        this->m_v.Allocate("v", this->m_op->GetM());
     }
     virtual void Clear(void)
     {
-        DISPATCH_OPERATOR_ANALYSE_STRATEGY(this->solver_descr_, this->SGS_, LAnalyseClear);
-        DISPATCH_OPERATOR_ANALYSE_STRATEGY(this->solver_descr_, this->SGS_, UAnalyseClear);
-        this->SGS_.Clear();
-        this->diag_entries_.Clear();
-        this->v_.Clear();
-        this->build_ = false;
+        RAMD_TRI_ANALYSE(this->m_solver_descr, this->m_SGS, LAnalyseClear);
+        RAMD_TRI_ANALYSE(this->m_solver_descr, this->m_SGS, UAnalyseClear);
+        this->m_SGS.Clear();
+        this->m_diag_entries.Clear();
+        this->m_v.Clear();
+        this->m_build = false;
     }
     virtual void Solve(const VectorType& rhs, VectorType* x)
     {
-        assert(this->build_ == true && x != NULL);
-        DISPATCH_OPERATOR_SOLVE_STRATEGY(this->solver_descr_, this->SGS_, LSolve, rhs, &this->v_);
-        this->v_.PointWiseMult(this->diag_entries_);
-        DISPATCH_OPERATOR_SOLVE_STRATEGY(this->solver_descr_, this->SGS_, USolve, this->v_, x);
+        RAMD_EXPECT(this->m_build && x != nullptr);
+        RAMD_TRI_SOLVE(this->m_solver_descr, this->m_SGS, LSolve, rhs, &this->m_v);
+        this->m_v.PointWiseMult(this->m_diag_entries);
+        RAMD_TRI_SOLVE(this->m_solver_descr, this->m_SGS, USolve, this->m_v, x);
     }
 
 private:
-    OperatorType SGS_;
-    VectorType   diag_entries_;
-    VectorType   v_;
+    OperatorType m_SGS;
+    VectorType   m_diag_entries;
+    VectorType   m_v;
 };
 
 // ---- MultiColored framework + MC-SGS: preconditioner_multicolored.cpp:148-413, _gs.cpp:127-215
@@ -724,22 +715,22 @@ class MultiColored : public Preconditioner<OperatorType, VectorType, ValueType>
 {
 public:
     MultiColored()
-        : op_mat_format_(false)
-        , precond_mat_format_(CSR)
-        , format_block_dim_(1)
-        , decomp_(true)
-        , fused_sweeps_(true)
-        , sweeps_(NULL)
-        , preconditioner_(NULL)
-        , num_blocks_(0)
-        , block_sizes_(NULL)
+        : m_op_mat_format(false)
+        , m_precond_mat_format(CSR)
+        , m_format_block_dim(1)
+        , m_decomp(true)
+        , m_fused_sweeps(true)
+        , m_sweeps(NULL)
+        , m_preconditioner(NULL)
+        , m_num_blocks(0)
+        , m_block_sizes(NULL)
     {
     }
     // extension: run the decomposed apply as 2*nb-1 fused colour sweeps (default) instead of the
     // reference's block-by-block sequence; both produce bit-identical results
     void SetFusedSweeps(bool on)
     {
-        this->fused_sweeps_ = on;
+        this->m_fused_sweeps = on;
     }
     virtual ~MultiColored()
     {
@@ -747,244 +738,244 @@ public:
     }
     virtual void SetPrecondMatrixFormat(unsigned int mat_format, int blockdim = 1)
     {
-        this->op_mat_format_      = true;
-        this->precond_mat_format_ = mat_format;
-        this->format_block_dim_   = blockdim;
+        this->m_op_mat_format      = true;
+        this->m_precond_mat_format = mat_format;
+        this->m_format_block_dim   = blockdim;
     }
     virtual void SetDecomposition(bool decomp)
     {
-        this->decomp_ = decomp;
+        this->m_decomp = decomp;
     }
     int GetNumColors(void) const
     {
-        return this->num_blocks_;
+        return this->m_num_blocks;
     }
     virtual void Build(void)
     {
-        if(this->build_)
+        if(this->m_build)
             this->Clear();
-        assert(this->op_ != NULL);
+        RAMD_EXPECT(this->m_op != nullptr);
         // Build_Analyser_: work on a clone of the operator
-        this->preconditioner_ = new OperatorType;
-        this->preconditioner_->CloneFrom(*this->op_);
-        this->permutation_.CloneBackend(*this->op_);
+        this->m_preconditioner = new OperatorType;
+        this->m_preconditioner->CloneFrom(*this->m_op);
+        this->m_permutation.CloneBackend(*this->m_op);
         // Analyse_: greedy multi-colouring -> block sizes + permutation
-        this->op_->MultiColoring(this->num_blocks_, &this->block_sizes_, &this->permutation_);
+        this->m_op->MultiColoring(this->m_num_blocks, &this->m_block_sizes, &this->m_permutation);
         // Permute_: P A P^T
-        this->preconditioner_->Permute(this->permutation_);
-        this->Factorize_();
-        if(this->decomp_ && this->fused_sweeps_ && !this->op_mat_format_ && this->CanFuseSweeps_()
-           && this->TryBuildSweeps_())
+        this->m_preconditioner->Permute(this->m_permutation);
+        this->doFactorize();
+        if(this->m_decomp && this->m_fused_sweeps && !this->m_op_mat_format && this->doCanFuseSweeps()
+           && this->doTryBuildSweeps())
         {
-            this->build_ = true;
-            this->preconditioner_->Clear();
+            this->m_build = true;
+            this->m_preconditioner->Clear();
             return;
         }
-        this->Decompose_();
-        this->build_ = true;
-        if(this->decomp_)
-            this->preconditioner_->Clear();
+        this->doDecompose();
+        this->m_build = true;
+        if(this->m_decomp)
+            this->m_preconditioner->Clear();
         else
-            this->PostAnalyse_();
+            this->doPostAnalyse();
     }
     virtual void Clear(void)
     {
-        if(this->sweeps_ != NULL)
+        if(this->m_sweeps != NULL)
         {
-            ramd_mcsgs_destroy(this->sweeps_);
-            this->sweeps_ = NULL;
+            ramd_mcsgs_destroy(this->m_sweeps);
+            this->m_sweeps = NULL;
         }
-        if(this->preconditioner_ != NULL)
+        if(this->m_preconditioner != NULL)
         {
-            this->preconditioner_->LAnalyseClear();
-            this->preconditioner_->UAnalyseClear();
-            this->preconditioner_->LUAnalyseClear();
-            delete this->preconditioner_;
-            this->preconditioner_ = NULL;
+            this->m_preconditioner->LAnalyseClear();
+            this->m_preconditioner->UAnalyseClear();
+            this->m_preconditioner->LUAnalyseClear();
+            delete this->m_preconditioner;
+            this->m_preconditioner = NULL;
         }
-        for(size_t i = 0; i < this->block_.size(); ++i)
-            delete this->block_[i];
-        for(size_t i = 0; i < this->x_block_.size(); ++i)
+        for(size_t i = 0; i < this->m_block.size(); ++i)
+            delete this->m_block[i];
+        for(size_t i = 0; i < this->m_x_block.size(); ++i)
         {
-            delete this->x_block_[i];
-            delete this->diag_block_[i];
-            delete this->diag_solver_[i];
+            delete this->m_x_block[i];
+            delete this->m_diag_block[i];
+            delete this->m_diag_solver[i];
         }
-        this->block_.clear();
-        this->x_block_.clear();
-        this->diag_block_.clear();
-        this->diag_solver_.clear();
-        free_host(&this->block_sizes_);
-        this->num_blocks_ = 0;
-        this->diag_.Clear();
-        this->x_.Clear();
-        this->permutation_.Clear();
-        this->build_ = false;
+        this->m_block.clear();
+        this->m_x_block.clear();
+        this->m_diag_block.clear();
+        this->m_diag_solver.clear();
+        free_host(&this->m_block_sizes);
+        this->m_num_blocks = 0;
+        this->m_diag.Clear();
+        this->m_x.Clear();
+        this->m_permutation.Clear();
+        this->m_build = false;
     }
     virtual void Solve(const VectorType& rhs, VectorType* x)
     {
-        assert(this->build_ == true && x != NULL && x != &rhs);
-        if(this->sweeps_ != NULL)
+        RAMD_EXPECT(this->m_build && x != nullptr && x != &rhs);
+        if(this->m_sweeps != NULL)
         {
-            this->ApplySweeps_(rhs, x);
+            this->doApplySweeps(rhs, x);
             return;
         }
-        if(this->decomp_)
+        if(this->m_decomp)
         {
-            this->ExtractRHSinX_(rhs, x);
-            this->SolveL_();
-            this->SolveD_();
-            this->SolveR_();
-            this->InsertSolution_(x);
+            this->doExtractRHSinX(rhs, x);
+            this->doSolveL();
+            this->doSolveD();
+            this->doSolveR();
+            this->doInsertSolution(x);
         }
         else
-            this->Solve_(rhs, x);
+            this->doSolve(rhs, x);
     }
 
 protected:
-    virtual void Factorize_(void) {}
-    virtual void PostAnalyse_(void) {}
-    virtual bool CanFuseSweeps_(void) const
+    virtual void doFactorize(void) {}
+    virtual void doPostAnalyse(void) {}
+    virtual bool doCanFuseSweeps(void) const
     {
         return false;
     }
-    virtual int SweepKind_(void) const
+    virtual int doSweepKind(void) const
     {
         return RAMD_MC_SGS;
     }
     template <class O = OperatorType>
-    typename std::enable_if<std::is_same<O, LocalMatrix<ValueType>>::value, bool>::type TryBuildSweeps_(void)
+    typename std::enable_if<std::is_same<O, LocalMatrix<ValueType>>::value, bool>::type doTryBuildSweeps(void)
     {
-        if(!this->preconditioner_->is_accel_())
+        if(!this->m_preconditioner->is_accel_())
             return false;
-        int s = ramd_mcsgs_build(this->preconditioner_->handle(), this->num_blocks_, this->block_sizes_,
-                                 this->permutation_.handle(), &this->sweeps_);
+        int s = ramd_mcsgs_build(this->m_preconditioner->handle(), this->m_num_blocks, this->m_block_sizes,
+                                 this->m_permutation.handle(), &this->m_sweeps);
         if(s == RAMD_ERR_UNSUPPORTED)
         {
-            this->sweeps_ = NULL;
+            this->m_sweeps = NULL;
             return false;
         }
         RAMD_CHECK(s);
         return true;
     }
     template <class O = OperatorType>
-    typename std::enable_if<!std::is_same<O, LocalMatrix<ValueType>>::value, bool>::type TryBuildSweeps_(void)
+    typename std::enable_if<!std::is_same<O, LocalMatrix<ValueType>>::value, bool>::type doTryBuildSweeps(void)
     {
         return false;
     }
     template <class V = VectorType>
     typename std::enable_if<std::is_same<V, LocalVector<ValueType>>::value, void>::type
-        ApplySweeps_(const VectorType& rhs, VectorType* x)
+        doApplySweeps(const VectorType& rhs, VectorType* x)
     {
-        RAMD_CHECK(ramd_mcsgs_apply_kind(this->sweeps_, this->SweepKind_(), rhs.handle(), x->handle()));
+        RAMD_CHECK(ramd_mcsgs_apply_kind(this->m_sweeps, this->doSweepKind(), rhs.handle(), x->handle()));
     }
     template <class V = VectorType>
     typename std::enable_if<!std::is_same<V, LocalVector<ValueType>>::value, void>::type
-        ApplySweeps_(const VectorType&, VectorType*)
+        doApplySweeps(const VectorType&, VectorType*)
     {
     }
-    virtual void SolveL_(void) = 0;
-    virtual void SolveD_(void) = 0;
-    virtual void SolveR_(void) = 0;
-    virtual void Solve_(const VectorType& rhs, VectorType* x) = 0;
+    virtual void doSolveL(void) = 0;
+    virtual void doSolveD(void) = 0;
+    virtual void doSolveR(void) = 0;
+    virtual void doSolve(const VectorType& rhs, VectorType* x) = 0;
 
-    OperatorType* blk_(int i, int j)
+    OperatorType* m_blk(int i, int j)
     {
-        return this->block_[(size_t)i * this->num_blocks_ + j];
+        return this->m_block[(size_t)i * this->m_num_blocks + j];
     }
-    void Decompose_(void)
+    void doDecompose(void)
     {
-        const int nb = this->num_blocks_;
-        if(this->decomp_)
+        const int nb = this->m_num_blocks;
+        if(this->m_decomp)
         {
             std::vector<int> offsets((size_t)nb + 1, 0);
             for(int i = 0; i < nb; ++i)
-                offsets[i + 1] = offsets[i] + this->block_sizes_[i];
-            this->block_.assign((size_t)nb * nb, NULL);
+                offsets[i + 1] = offsets[i] + this->m_block_sizes[i];
+            this->m_block.assign((size_t)nb * nb, NULL);
             std::vector<OperatorType**> rows((size_t)nb);
             for(int i = 0; i < nb; ++i)
             {
                 for(int j = 0; j < nb; ++j)
                 {
-                    this->block_[(size_t)i * nb + j] = new OperatorType;
-                    this->block_[(size_t)i * nb + j]->CloneBackend(*this->op_);
+                    this->m_block[(size_t)i * nb + j] = new OperatorType;
+                    this->m_block[(size_t)i * nb + j]->CloneBackend(*this->m_op);
                 }
-                rows[i] = &this->block_[(size_t)i * nb];
+                rows[i] = &this->m_block[(size_t)i * nb];
             }
-            this->preconditioner_->ExtractSubMatrices(nb, nb, offsets.data(), offsets.data(),
+            this->m_preconditioner->ExtractSubMatrices(nb, nb, offsets.data(), offsets.data(),
                                                       rows.data());
-            this->x_block_.assign((size_t)nb, NULL);
-            this->diag_block_.assign((size_t)nb, NULL);
-            this->diag_solver_.assign((size_t)nb, NULL);
+            this->m_x_block.assign((size_t)nb, NULL);
+            this->m_diag_block.assign((size_t)nb, NULL);
+            this->m_diag_solver.assign((size_t)nb, NULL);
             for(int i = 0; i < nb; ++i)
             {
-                this->diag_block_[i] = new VectorType;
-                this->diag_block_[i]->CloneBackend(*this->op_);
-                this->diag_block_[i]->Allocate("Diagonal preconditioners blocks", this->block_sizes_[i]);
-                this->blk_(i, i)->ExtractDiagonal(this->diag_block_[i]);
-                this->x_block_[i] = new VectorType;
-                this->x_block_[i]->CloneBackend(*this->op_);
-                this->x_block_[i]->Allocate("MultiColored Preconditioner x_block_",
-                                            this->block_sizes_[i]);
+                this->m_diag_block[i] = new VectorType;
+                this->m_diag_block[i]->CloneBackend(*this->m_op);
+                this->m_diag_block[i]->Allocate("Diagonal preconditioners blocks", this->m_block_sizes[i]);
+                this->m_blk(i, i)->ExtractDiagonal(this->m_diag_block[i]);
+                this->m_x_block[i] = new VectorType;
+                this->m_x_block[i]->CloneBackend(*this->m_op);
+                this->m_x_block[i]->Allocate("MultiColored Preconditioner x_block",
+                                            this->m_block_sizes[i]);
                 Jacobi<OperatorType, VectorType, ValueType>* jacobi
                     = new Jacobi<OperatorType, VectorType, ValueType>;
-                jacobi->SetOperator(*this->blk_(i, i));
+                jacobi->SetOperator(*this->m_blk(i, i));
                 jacobi->Build();
-                this->diag_solver_[i] = jacobi;
-                this->blk_(i, i)->Clear();
+                this->m_diag_solver[i] = jacobi;
+                this->m_blk(i, i)->Clear();
             }
-            if(this->op_mat_format_)
+            if(this->m_op_mat_format)
                 for(int i = 0; i < nb; ++i)
                     for(int j = 0; j < nb; ++j)
-                        if(this->blk_(i, j)->GetNnz() > 0)
-                            this->blk_(i, j)->ConvertTo(this->precond_mat_format_,
-                                                        this->format_block_dim_);
+                        if(this->m_blk(i, j)->GetNnz() > 0)
+                            this->m_blk(i, j)->ConvertTo(this->m_precond_mat_format,
+                                                        this->m_format_block_dim);
         }
         else
         {
-            this->diag_.CloneBackend(*this->op_);
-            this->preconditioner_->ExtractDiagonal(&this->diag_);
+            this->m_diag.CloneBackend(*this->m_op);
+            this->m_preconditioner->ExtractDiagonal(&this->m_diag);
         }
-        this->x_.CloneBackend(*this->op_);
-        this->x_.Allocate("Permuted solution vector", this->op_->GetM());
+        this->m_x.CloneBackend(*this->m_op);
+        this->m_x.Allocate("Permuted solution vector", this->m_op->GetM());
     }
-    void ExtractRHSinX_(const VectorType& rhs, VectorType* x)
+    void doExtractRHSinX(const VectorType& rhs, VectorType* x)
     {
-        x->CopyFromPermute(rhs, this->permutation_);
+        x->CopyFromPermute(rhs, this->m_permutation);
         int64_t off = 0;
-        for(int i = 0; i < this->num_blocks_; ++i)
+        for(int i = 0; i < this->m_num_blocks; ++i)
         {
-            this->x_block_[i]->CopyFrom(*x, off, 0, this->block_sizes_[i]);
-            off += this->block_sizes_[i];
+            this->m_x_block[i]->CopyFrom(*x, off, 0, this->m_block_sizes[i]);
+            off += this->m_block_sizes[i];
         }
     }
-    void InsertSolution_(VectorType* x)
+    void doInsertSolution(VectorType* x)
     {
         int64_t off = 0;
-        for(int i = 0; i < this->num_blocks_; ++i)
+        for(int i = 0; i < this->m_num_blocks; ++i)
         {
-            this->x_.CopyFrom(*this->x_block_[i], 0, off, this->block_sizes_[i]);
-            off += this->block_sizes_[i];
+            this->m_x.CopyFrom(*this->m_x_block[i], 0, off, this->m_block_sizes[i]);
+            off += this->m_block_sizes[i];
         }
-        x->CopyFromPermuteBackward(this->x_, this->permutation_);
+        x->CopyFromPermuteBackward(this->m_x, this->m_permutation);
     }
 
-    bool                          op_mat_format_;
-    unsigned int                  precond_mat_format_;
-    int                           format_block_dim_;
-    bool                          decomp_;
-    bool                          fused_sweeps_;
-    ramd_mcsgs_t                  sweeps_;
-    OperatorType*                 preconditioner_;
-    std::vector<OperatorType*>    block_; // [i*nb+j]
-    std::vector<VectorType*>      x_block_;
-    std::vector<VectorType*>      diag_block_;
-    std::vector<Solver<OperatorType, VectorType, ValueType>*> diag_solver_;
-    VectorType                    x_;
-    VectorType                    diag_;
-    int                           num_blocks_;
-    int*                          block_sizes_;
-    LocalVector<int>              permutation_;
+    bool                          m_op_mat_format;
+    unsigned int                  m_precond_mat_format;
+    int                           m_format_block_dim;
+    bool                          m_decomp;
+    bool                          m_fused_sweeps;
+    ramd_mcsgs_t                  m_sweeps;
+    OperatorType*                 m_preconditioner;
+    std::vector<OperatorType*>    m_block; // [i*nb+j]
+    std::vector<VectorType*>      m_x_block;
+    std::vector<VectorType*>      m_diag_block;
+    std::vector<Solver<OperatorType, VectorType, ValueType>*> m_diag_solver;
+    VectorType                    m_x;
+    VectorType                    m_diag;
+    int                           m_num_blocks;
+    int*                          m_block_sizes;
+    LocalVector<int>              m_permutation;
 };
 
 template <class OperatorType, class VectorType, typename ValueType>
@@ -992,7 +983,7 @@ class MultiColoredSGS : public MultiColored<OperatorType, VectorType, ValueType>
 {
 public:
     MultiColoredSGS()
-        : omega_(static_cast<ValueType>(1))
+        : m_omega(num<ValueType>(1))
     {
     }
     virtual ~MultiColoredSGS()
@@ -1001,75 +992,75 @@ public:
     }
     virtual void Print(void) const
     {
-        LOG_INFO("Multicolored Symmetric Gauss-Seidel (SGS) preconditioner");
-        if(this->build_)
-            LOG_INFO("number of colors = " << this->num_blocks_);
+        say("Multicolored Symmetric Gauss-Seidel (SGS) preconditioner");
+        if(this->m_build)
+            say("number of colors = ", this->m_num_blocks);
     }
     virtual void SetRelaxation(ValueType omega)
     {
-        this->omega_ = omega;
+        this->m_omega = omega;
     }
 
 protected:
-    virtual bool CanFuseSweeps_(void) const
+    virtual bool doCanFuseSweeps(void) const
     {
-        return this->omega_ == static_cast<ValueType>(1); // the SSOR scalings are not fused
+        return this->m_omega == num<ValueType>(1); // the SSOR scalings are not fused
     }
-    virtual void PostAnalyse_(void)
+    virtual void doPostAnalyse(void)
     {
-        this->preconditioner_->LAnalyse(false);
-        this->preconditioner_->UAnalyse(false);
+        this->m_preconditioner->LAnalyse(false);
+        this->m_preconditioner->UAnalyse(false);
     }
-    void sweep_block_(int i, int j)
+    void m_sweep_block(int i, int j)
     {
-        if(this->blk_(i, j)->GetNnz() > 0)
-            this->blk_(i, j)->ApplyAdd(*this->x_block_[j], static_cast<ValueType>(-1),
-                                       this->x_block_[i]);
+        if(this->m_blk(i, j)->GetNnz() > 0)
+            this->m_blk(i, j)->ApplyAdd(*this->m_x_block[j], num<ValueType>(-1),
+                                       this->m_x_block[i]);
     }
-    virtual void SolveL_(void)
+    virtual void doSolveL(void)
     {
-        for(int i = 0; i < this->num_blocks_; ++i)
+        for(int i = 0; i < this->m_num_blocks; ++i)
         {
             for(int j = 0; j < i; ++j)
-                this->sweep_block_(i, j);
-            this->diag_solver_[i]->Solve(*this->x_block_[i], this->x_block_[i]);
-            if(this->omega_ != static_cast<ValueType>(1))
-                this->x_block_[i]->Scale(static_cast<ValueType>(1) / this->omega_);
+                this->m_sweep_block(i, j);
+            this->m_diag_solver[i]->Solve(*this->m_x_block[i], this->m_x_block[i]);
+            if(this->m_omega != num<ValueType>(1))
+                this->m_x_block[i]->Scale(num<ValueType>(1) / this->m_omega);
         }
     }
-    virtual void SolveD_(void)
+    virtual void doSolveD(void)
     {
-        for(int i = 0; i < this->num_blocks_; ++i)
+        for(int i = 0; i < this->m_num_blocks; ++i)
         {
-            this->x_block_[i]->PointWiseMult(*this->diag_block_[i]);
-            if(this->omega_ != static_cast<ValueType>(1))
-                this->x_block_[i]->Scale(this->omega_ / (static_cast<ValueType>(2) - this->omega_));
+            this->m_x_block[i]->PointWiseMult(*this->m_diag_block[i]);
+            if(this->m_omega != num<ValueType>(1))
+                this->m_x_block[i]->Scale(this->m_omega / (num<ValueType>(2) - this->m_omega));
         }
     }
-    virtual void SolveR_(void)
+    virtual void doSolveR(void)
     {
-        for(int i = this->num_blocks_ - 1; i >= 0; --i)
+        for(int i = this->m_num_blocks - 1; i >= 0; --i)
         {
-            for(int j = this->num_blocks_ - 1; j > i; --j) // descending j, as the reference
-                this->sweep_block_(i, j);
-            this->diag_solver_[i]->Solve(*this->x_block_[i], this->x_block_[i]);
-            if(this->omega_ != static_cast<ValueType>(1))
-                this->x_block_[i]->Scale(static_cast<ValueType>(1) / this->omega_);
+            for(int j = this->m_num_blocks - 1; j > i; --j) // descending j, as the reference
+                this->m_sweep_block(i, j);
+            this->m_diag_solver[i]->Solve(*this->m_x_block[i], this->m_x_block[i]);
+            if(this->m_omega != num<ValueType>(1))
+                this->m_x_block[i]->Scale(num<ValueType>(1) / this->m_omega);
         }
     }
-    virtual void Solve_(const VectorType& rhs, VectorType* x)
+    virtual void doSolve(const VectorType& rhs, VectorType* x)
     {
-        this->x_.CopyFromPermute(rhs, this->permutation_);
-        this->preconditioner_->LSolve(this->x_, x);
-        x->PointWiseMult(this->diag_);
-        this->preconditioner_->USolve(*x, &this->x_);
-        x->CopyFromPermuteBackward(this->x_, this->permutation_);
+        this->m_x.CopyFromPermute(rhs, this->m_permutation);
+        this->m_preconditioner->LSolve(this->m_x, x);
+        x->PointWiseMult(this->m_diag);
+        this->m_preconditioner->USolve(*x, &this->m_x);
+        x->CopyFromPermuteBackward(this->m_x, this->m_permutation);
     }
-    ValueType omega_;
+    ValueType m_omega;
 };
 
 // preconditioner_multicolored_gs.cpp:218-288: class MultiColoredGS : public MultiColoredSGS --
-// backward sweep only (SolveL_/SolveD_ empty); the non-decomposed form is "No implemented yet" there too
+// backward sweep only (doSolveL/doSolveD empty); the non-decomposed form is "No implemented yet" there too
 template <class OperatorType, class VectorType, typename ValueType>
 class MultiColoredGS : public MultiColoredSGS<OperatorType, VectorType, ValueType>
 {
@@ -1081,26 +1072,26 @@ public:
     }
     virtual void Print(void) const
     {
-        LOG_INFO("Multicolored Gauss-Seidel (GS) preconditioner");
-        if(this->build_)
-            LOG_INFO("number of colors = " << this->num_blocks_);
+        say("Multicolored Gauss-Seidel (GS) preconditioner");
+        if(this->m_build)
+            say("number of colors = ", this->m_num_blocks);
     }
 
 protected:
-    virtual int SweepKind_(void) const
+    virtual int doSweepKind(void) const
     {
         return RAMD_MC_GS;
     }
-    virtual void PostAnalyse_(void)
+    virtual void doPostAnalyse(void)
     {
-        this->preconditioner_->UAnalyse(false);
+        this->m_preconditioner->UAnalyse(false);
     }
-    virtual void SolveL_(void) {}
-    virtual void SolveD_(void) {}
-    virtual void Solve_(const VectorType&, VectorType*)
+    virtual void doSolveL(void) {}
+    virtual void doSolveD(void) {}
+    virtual void doSolve(const VectorType&, VectorType*)
     {
-        LOG_INFO("No implemented yet");
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("No implemented yet");
+        RAMD_DIE();
     }
 };
 
@@ -1112,10 +1103,10 @@ class MultiColoredILU : public MultiColored<OperatorType, VectorType, ValueType>
 {
 public:
     MultiColoredILU()
-        : q_(1)
-        , p_(0)
-        , level_(true)
-        , nnz_(0)
+        : m_q(1)
+        , m_p(0)
+        , m_level(true)
+        , m_nnz(0)
     {
     }
     virtual ~MultiColoredILU()
@@ -1124,80 +1115,78 @@ public:
     }
     virtual void Print(void) const
     {
-        LOG_INFO("Multicolored ILU preconditioner (power(q)-pattern method), ILU(" << this->p_ << ","
-                                                                                   << this->q_ << ")");
-        if(this->build_)
-            LOG_INFO("number of colors = " << this->num_blocks_ << "; ILU nnz = " << this->nnz_);
+        say("Multicolored ILU preconditioner (power(q)-pattern method), ILU(", this->m_p, ",", this->m_q, ")");
+        if(this->m_build)
+            say("number of colors = ", this->m_num_blocks, "; ILU nnz = ", this->m_nnz);
     }
     virtual void Set(int p)
     {
-        assert(this->build_ == false && p >= 0);
-        this->p_ = p;
-        this->q_ = p + 1;
+        RAMD_EXPECT(!this->m_build && p >= 0);
+        this->m_p = p;
+        this->m_q = p + 1;
     }
     virtual void Set(int p, int q, bool level = true)
     {
-        assert(this->build_ == false && p >= 0 && q >= 1);
-        this->p_     = p;
-        this->q_     = q;
-        this->level_ = level;
+        RAMD_EXPECT(!this->m_build && p >= 0 && q >= 1);
+        this->m_p     = p;
+        this->m_q     = q;
+        this->m_level = level;
     }
 
 protected:
-    virtual bool CanFuseSweeps_(void) const
+    virtual bool doCanFuseSweeps(void) const
     {
         return true;
     }
-    virtual int SweepKind_(void) const
+    virtual int doSweepKind(void) const
     {
         return RAMD_MC_ILU;
     }
-    virtual void Factorize_(void)
+    virtual void doFactorize(void)
     {
-        if(this->p_ != 0 || this->q_ != 1)
+        if(this->m_p != 0 || this->m_q != 1)
         {
-            LOG_INFO("MultiColoredILU: only ILU(0,1) is provided by this backend (no SymbolicPower / "
-                     "ILUpFactorize for p > 0)");
-            FATAL_ERROR(__FILE__, __LINE__);
+            say("MultiColoredILU: only ILU(0,1) is provided by this backend (no SymbolicPower / " "ILUpFactorize for p > 0)");
+            RAMD_DIE();
         }
-        this->preconditioner_->ILU0Factorize(); // ILUpFactorize(0) (local_matrix.cpp:3920-3923)
-        this->nnz_ = this->preconditioner_->GetNnz();
+        this->m_preconditioner->ILU0Factorize(); // ILUpFactorize(0) (local_matrix.cpp:3920-3923)
+        this->m_nnz = this->m_preconditioner->GetNnz();
     }
-    virtual void PostAnalyse_(void)
+    virtual void doPostAnalyse(void)
     {
-        this->preconditioner_->LUAnalyse();
+        this->m_preconditioner->LUAnalyse();
     }
-    void sweep_block_(int i, int j)
+    void m_sweep_block(int i, int j)
     {
-        if(this->blk_(i, j)->GetNnz() > 0)
-            this->blk_(i, j)->ApplyAdd(*this->x_block_[j], static_cast<ValueType>(-1),
-                                       this->x_block_[i]);
+        if(this->m_blk(i, j)->GetNnz() > 0)
+            this->m_blk(i, j)->ApplyAdd(*this->m_x_block[j], num<ValueType>(-1),
+                                       this->m_x_block[i]);
     }
-    virtual void SolveL_(void)
+    virtual void doSolveL(void)
     {
-        for(int i = 0; i < this->num_blocks_; ++i)
+        for(int i = 0; i < this->m_num_blocks; ++i)
             for(int j = 0; j < i; ++j)
-                this->sweep_block_(i, j);
+                this->m_sweep_block(i, j);
     }
-    virtual void SolveD_(void) {}
-    virtual void SolveR_(void)
+    virtual void doSolveD(void) {}
+    virtual void doSolveR(void)
     {
-        for(int i = this->num_blocks_ - 1; i >= 0; --i)
+        for(int i = this->m_num_blocks - 1; i >= 0; --i)
         {
-            for(int j = this->num_blocks_ - 1; j > i; --j)
-                this->sweep_block_(i, j);
-            this->diag_solver_[i]->Solve(*this->x_block_[i], this->x_block_[i]);
+            for(int j = this->m_num_blocks - 1; j > i; --j)
+                this->m_sweep_block(i, j);
+            this->m_diag_solver[i]->Solve(*this->m_x_block[i], this->m_x_block[i]);
         }
     }
-    virtual void Solve_(const VectorType& rhs, VectorType* x)
+    virtual void doSolve(const VectorType& rhs, VectorType* x)
     {
-        x->CopyFromPermute(rhs, this->permutation_);
-        this->preconditioner_->LUSolve(*x, &this->x_);
-        x->CopyFromPermuteBackward(this->x_, this->permutation_);
+        x->CopyFromPermute(rhs, this->m_permutation);
+        this->m_preconditioner->LUSolve(*x, &this->m_x);
+        x->CopyFromPermuteBackward(this->m_x, this->m_permutation);
     }
-    int     q_, p_;
-    bool    level_;
-    int64_t nnz_;
+    int     m_q, m_p;
+    bool    m_level;
+    int64_t m_nnz;
 };
 
 // ============================================================================ IterativeLinearSolver
@@ -1206,131 +1195,131 @@ class IterativeLinearSolver : public Solver<OperatorType, VectorType, ValueType>
 {
 public:
     IterativeLinearSolver()
-        : res_norm_type_(2)
-        , index_(-1)
-        , fused_(true)
+        : m_res_norm_type(2)
+        , m_index(-1)
+        , m_fused(true)
     {
     }
     void Init(double abs_tol, double rel_tol, double div_tol, int max_iter)
     {
-        this->iter_ctrl_.Init(abs_tol, rel_tol, div_tol, max_iter);
+        this->m_iter_ctrl.Init(abs_tol, rel_tol, div_tol, max_iter);
     }
     void Init(double abs_tol, double rel_tol, double div_tol, int min_iter, int max_iter)
     {
-        this->iter_ctrl_.Init(abs_tol, rel_tol, div_tol, min_iter, max_iter);
+        this->m_iter_ctrl.Init(abs_tol, rel_tol, div_tol, min_iter, max_iter);
     }
     void InitMinIter(int min_iter)
     {
-        this->iter_ctrl_.InitMinimumIterations(min_iter);
+        this->m_iter_ctrl.InitMinimumIterations(min_iter);
     }
     void InitMaxIter(int max_iter)
     {
-        this->iter_ctrl_.InitMaximumIterations(max_iter);
+        this->m_iter_ctrl.InitMaximumIterations(max_iter);
     }
     void InitTol(double abs, double rel, double div)
     {
-        this->iter_ctrl_.InitTolerance(abs, rel, div);
+        this->m_iter_ctrl.InitTolerance(abs, rel, div);
     }
     virtual void ReBuildNumeric(void)
     {
-        if(!this->build_)
+        if(!this->m_build)
             return;
-        Solver<OperatorType, VectorType, ValueType>* pc = this->precond_;
+        Solver<OperatorType, VectorType, ValueType>* pc = this->m_precond;
         this->Clear(); // clears (and detaches) the preconditioner
         if(pc != NULL)
-            this->precond_ = pc;
+            this->m_precond = pc;
         this->Build();
     }
     void SetResidualNorm(int resnorm)
     {
-        assert(resnorm == 1 || resnorm == 2 || resnorm == 3);
-        this->res_norm_type_ = resnorm;
+        RAMD_EXPECT(resnorm == 1 || resnorm == 2 || resnorm == 3);
+        this->m_res_norm_type = resnorm;
     }
     void RecordResidualHistory(void)
     {
-        this->iter_ctrl_.RecordHistory();
+        this->m_iter_ctrl.RecordHistory();
     }
     void RecordHistory(const std::string& filename) const
     {
-        this->iter_ctrl_.WriteHistoryToFile(filename);
+        this->m_iter_ctrl.WriteHistoryToFile(filename);
     }
     const std::vector<double>& GetResidualHistory(void) const
     {
-        return this->iter_ctrl_.GetResidualHistory();
+        return this->m_iter_ctrl.GetResidualHistory();
     }
     virtual void Verbose(int verb = 1)
     {
-        this->verb_ = verb;
-        this->iter_ctrl_.Verbose(verb);
+        this->m_verb = verb;
+        this->m_iter_ctrl.Verbose(verb);
     }
     virtual int GetIterationCount(void)
     {
-        return this->iter_ctrl_.GetIterationCount();
+        return this->m_iter_ctrl.GetIterationCount();
     }
     virtual double GetCurrentResidual(void)
     {
-        return this->iter_ctrl_.GetCurrentResidual();
+        return this->m_iter_ctrl.GetCurrentResidual();
     }
     virtual int GetSolverStatus(void)
     {
-        return this->iter_ctrl_.GetSolverStatus();
+        return this->m_iter_ctrl.GetSolverStatus();
     }
     virtual int64_t GetAmaxResidualIndex(void)
     {
-        return this->iter_ctrl_.GetAmaxResidualIndex();
+        return this->m_iter_ctrl.GetAmaxResidualIndex();
     }
     virtual void SetPreconditioner(Solver<OperatorType, VectorType, ValueType>& precond)
     {
-        assert(this != &precond);
-        this->precond_ = &precond;
-        this->precond_->FlagPrecond();
+        RAMD_EXPECT(this != &precond);
+        this->m_precond = &precond;
+        this->m_precond->FlagPrecond();
     }
     // extension: switch the fused device path of CG / GMRES on or off (default on). Both paths run
     // the same per-element arithmetic; only the summation order of the reductions differs.
     void SetFused(bool fused)
     {
-        this->fused_ = fused;
+        this->m_fused = fused;
     }
     // solver.cpp:470-500
     virtual void Solve(const VectorType& rhs, VectorType* x)
     {
-        assert(x != NULL && x != &rhs && this->op_ != NULL && this->build_ == true);
-        if(this->verb_ > 0)
+        RAMD_EXPECT(x != NULL && x != &rhs && this->m_op != NULL && this->m_build);
+        if(this->m_verb > 0)
         {
-            this->PrintStart_();
-            this->iter_ctrl_.PrintInit();
+            this->doPrintStart();
+            this->m_iter_ctrl.PrintInit();
         }
-        if(this->precond_ == NULL)
-            this->SolveNonPrecond_(rhs, x);
+        if(this->m_precond == NULL)
+            this->doSolveNonPrecond(rhs, x);
         else
-            this->SolvePrecond_(rhs, x);
-        if(this->verb_ > 0)
+            this->doSolvePrecond(rhs, x);
+        if(this->m_verb > 0)
         {
-            this->iter_ctrl_.PrintStatus();
-            this->PrintEnd_();
+            this->m_iter_ctrl.PrintStatus();
+            this->doPrintEnd();
         }
     }
 
 protected:
-    virtual void PrintStart_(void) const = 0;
-    virtual void PrintEnd_(void) const   = 0;
-    virtual void SolveNonPrecond_(const VectorType& rhs, VectorType* x) = 0;
-    virtual void SolvePrecond_(const VectorType& rhs, VectorType* x)    = 0;
+    virtual void doPrintStart(void) const = 0;
+    virtual void doPrintEnd(void) const   = 0;
+    virtual void doSolveNonPrecond(const VectorType& rhs, VectorType* x) = 0;
+    virtual void doSolvePrecond(const VectorType& rhs, VectorType* x)    = 0;
     // solver.cpp:443-468
-    ValueType Norm_(const VectorType& vec)
+    ValueType doNorm(const VectorType& vec)
     {
-        if(this->res_norm_type_ == 1)
+        if(this->m_res_norm_type == 1)
             return vec.Asum();
-        if(this->res_norm_type_ == 2)
+        if(this->m_res_norm_type == 2)
             return vec.Norm();
         ValueType amax;
-        this->index_ = vec.Amax(amax);
+        this->m_index = vec.Amax(amax);
         return amax;
     }
-    IterationControl iter_ctrl_;
-    int              res_norm_type_;
-    int64_t          index_;
-    bool             fused_;
+    IterationControl m_iter_ctrl;
+    int              m_res_norm_type;
+    int64_t          m_index;
+    bool             m_fused;
 };
 
 // The fused device loops are written against four small helpers so that the same loop serves
@@ -1380,169 +1369,169 @@ public:
     }
     virtual void Print(void) const
     {
-        LOG_INFO("CG solver" << (this->precond_ ? ", with preconditioner" : " (non-precond)"));
+        say("CG solver", (this->m_precond ? ", with preconditioner" : " (non-precond)"));
     }
     // cg.cpp:99-137
     virtual void Build(void)
     {
-        if(this->build_)
+        if(this->m_build)
             this->Clear();
-        assert(this->op_ != NULL && this->op_->GetM() == this->op_->GetN() && this->op_->GetM() > 0);
-        this->build_ = true;
-        if(this->precond_ != NULL)
+        RAMD_EXPECT(this->m_op != nullptr && this->m_op->GetM() == this->m_op->GetN() && this->m_op->GetM() > 0);
+        this->m_build = true;
+        if(this->m_precond != NULL)
         {
-            this->precond_->SetOperator(*this->op_);
-            this->precond_->Build();
-            this->z_.CloneBackend(*this->op_);
-            this->z_.Allocate("z", this->op_->GetM());
+            this->m_precond->SetOperator(*this->m_op);
+            this->m_precond->Build();
+            this->m_z.CloneBackend(*this->m_op);
+            this->m_z.Allocate("z", this->m_op->GetM());
         }
-        this->r_.CloneBackend(*this->op_);
-        this->r_.Allocate("r", this->op_->GetM());
-        this->p_.CloneBackend(*this->op_);
-        this->p_.Allocate("p", this->op_->GetM());
-        this->q_.CloneBackend(*this->op_);
-        this->q_.Allocate("q", this->op_->GetM());
+        this->m_r.CloneBackend(*this->m_op);
+        this->m_r.Allocate("r", this->m_op->GetM());
+        this->m_p.CloneBackend(*this->m_op);
+        this->m_p.Allocate("p", this->m_op->GetM());
+        this->m_q.CloneBackend(*this->m_op);
+        this->m_q.Allocate("q", this->m_op->GetM());
     }
     virtual void Clear(void)
     {
-        if(this->build_)
+        if(this->m_build)
         {
-            if(this->precond_ != NULL)
+            if(this->m_precond != NULL)
             {
-                this->precond_->Clear();
-                this->precond_ = NULL;
+                this->m_precond->Clear();
+                this->m_precond = NULL;
             }
-            this->r_.Clear();
-            this->z_.Clear();
-            this->p_.Clear();
-            this->q_.Clear();
-            this->iter_ctrl_.Clear();
-            this->build_ = false;
+            this->m_r.Clear();
+            this->m_z.Clear();
+            this->m_p.Clear();
+            this->m_q.Clear();
+            this->m_iter_ctrl.Clear();
+            this->m_build = false;
         }
     }
 
 protected:
-    virtual void PrintStart_(void) const
+    virtual void doPrintStart(void) const
     {
-        LOG_INFO("CG " << (this->precond_ ? "" : "(non-precond) ") << "linear solver starts");
+        say("CG ", (this->m_precond ? "" : "(non-precond) "), "linear solver starts");
     }
-    virtual void PrintEnd_(void) const
+    virtual void doPrintEnd(void) const
     {
-        LOG_INFO("CG ends");
+        say("CG ends");
     }
-    virtual void SolveNonPrecond_(const VectorType& rhs, VectorType* x)
+    virtual void doSolveNonPrecond(const VectorType& rhs, VectorType* x)
     {
-        this->Solve_(rhs, x, false);
+        this->doSolve(rhs, x, false);
     }
-    virtual void SolvePrecond_(const VectorType& rhs, VectorType* x)
+    virtual void doSolvePrecond(const VectorType& rhs, VectorType* x)
     {
-        this->Solve_(rhs, x, true);
+        this->doSolve(rhs, x, true);
     }
 
 private:
     // cg.cpp:291-362 / :366-446
-    void Solve_(const VectorType& rhs, VectorType* x, bool precond)
+    void doSolve(const VectorType& rhs, VectorType* x, bool precond)
     {
-        const OperatorType* op = this->op_;
-        VectorType *        r = &this->r_, *z = &this->z_, *p = &this->p_, *q = &this->q_;
+        const OperatorType* op = this->m_op;
+        VectorType *        kr = &this->m_r, *kz = &this->m_z, *kp = &this->m_p, *kq = &this->m_q;
         ValueType           alpha, beta, rho, rho_old;
 
-        op->Apply(*x, r);
-        r->ScaleAdd(static_cast<ValueType>(-1), rhs);
-        ValueType res_norm = this->Norm_(*r);
-        if(this->iter_ctrl_.InitResidual(std::abs(res_norm)) == false)
+        op->Apply(*x, kr);
+        kr->ScaleAdd(num<ValueType>(-1), rhs);
+        ValueType res_norm = this->doNorm(*kr);
+        if(this->m_iter_ctrl.InitResidual(std::abs(res_norm)) == false)
             return;
         if(precond)
         {
-            this->precond_->SolveZeroSol(*r, z);
-            p->CopyFrom(*z);
+            this->m_precond->SolveZeroSol(*kr, kz);
+            kp->CopyFrom(*kz);
         }
         else
-            p->CopyFrom(*r);
+            kp->CopyFrom(*kr);
 
-        if(this->fused_ && this->res_norm_type_ == 2 && this->FusedLoop_(rhs, x, precond))
+        if(this->m_fused && this->m_res_norm_type == 2 && this->doFusedLoop(rhs, x, precond))
             return;
 
-        rho = precond ? r->DotNonConj(*z) : r->DotNonConj(*r);
+        rho = precond ? kr->DotNonConj(*kz) : kr->DotNonConj(*kr);
         while(true)
         {
-            op->Apply(*p, q);
-            alpha = rho / p->DotNonConj(*q);
-            x->AddScale(*p, alpha);
-            r->AddScale(*q, -alpha);
-            res_norm = this->Norm_(*r);
-            if(this->iter_ctrl_.CheckResidual(std::abs(res_norm), this->index_))
+            op->Apply(*kp, kq);
+            alpha = rho / kp->DotNonConj(*kq);
+            x->AddScale(*kp, alpha);
+            kr->AddScale(*kq, -alpha);
+            res_norm = this->doNorm(*kr);
+            if(this->m_iter_ctrl.CheckResidual(std::abs(res_norm), this->m_index))
                 break;
             rho_old = rho;
             if(precond)
             {
-                this->precond_->SolveZeroSol(*r, z);
-                rho  = r->DotNonConj(*z);
+                this->m_precond->SolveZeroSol(*kr, kz);
+                rho  = kr->DotNonConj(*kz);
                 beta = rho / rho_old;
-                p->ScaleAdd(beta, *z);
+                kp->ScaleAdd(beta, *kz);
             }
             else
             {
-                rho  = r->DotNonConj(*r);
+                rho  = kr->DotNonConj(*kr);
                 beta = rho / rho_old;
-                p->ScaleAdd(beta, *r);
+                kp->ScaleAdd(beta, *kr);
             }
         }
     }
 
     // Fused device loop (Local objects on the accelerator).  Per iteration:
-    //   K1  q = A p, <p,q>                                   (ramd_fused_apply_dot)
-    //   K2  r -= a q ; <r,r> ; [z = D^-1 r ; <r,z>]            (ramd_fused_cg_update)
-    //   K3  x += a p ; p = (rho'/rho) p + z                    (ramd_fused_cg_direction)
-    // The ||r|| read-back for iteration k overlaps K3(k) and K1(k+1), which are queued before the
-    // host waits; the convergence decision is the reference's, made on the same ||r||.
+    //   K1  kq = A kp, <kp,kq>                                   (ramd_fused_apply_dot)
+    //   K2  kr -= a kq ; <kr,kr> ; [kz = D^-1 kr ; <kr,kz>]            (ramd_fused_cg_update)
+    //   K3  x += a kp ; kp = (rho'/rho) kp + kz                    (ramd_fused_cg_direction)
+    // The ||kr|| read-back for iteration k overlaps K3(k) and K1(k+1), which are queued before the
+    // host waits; the convergence decision is the reference'ks, made on the same ||kr||.
     template <class O = OperatorType, class V = VectorType>
     typename std::enable_if<_fusable<O, V, ValueType>::value, bool>::type
-        FusedLoop_(const VectorType& rhs, VectorType* x, bool precond)
+        doFusedLoop(const VectorType& rhs, VectorType* x, bool precond)
     {
         (void)rhs;
-        if(!this->op_->is_accel_() || !x->is_accel_())
+        if(!this->m_op->is_accel_() || !x->is_accel_())
             return false;
-        const OperatorType& A = *this->op_;
-        VectorType *r = &this->r_, *z = &this->z_, *p = &this->p_, *q = &this->q_;
+        const OperatorType& A = *this->m_op;
+        VectorType *kr = &this->m_r, *kz = &this->m_z, *kp = &this->m_p, *kq = &this->m_q;
         typedef Jacobi<OperatorType, VectorType, ValueType> JacobiType;
-        JacobiType* jac = precond ? dynamic_cast<JacobiType*>(this->precond_) : NULL;
+        JacobiType* jac = precond ? dynamic_cast<JacobiType*>(this->m_precond) : NULL;
         ramd_vec_t  dinv = NULL;
-        if(jac != NULL && jac->GetInverseDiagonal().GetSize() == r->GetSize())
+        if(jac != NULL && jac->GetInverseDiagonal().GetSize() == kr->GetSize())
             dinv = _fh(jac->GetInverseDiagonal());
         const bool  generic_pc = precond && dinv == NULL;
-        if(generic_pc && this->precond_->SolveUsesScalarRecord())
+        if(generic_pc && this->m_precond->SolveUsesScalarRecord())
             return false; // e.g. a multigrid cycle as preconditioner: the plain loop keeps its scalars on the host
-        VectorType* zdir       = precond ? z : r;
+        VectorType* zdir       = precond ? kz : kr;
 
-        // scalar slots: <p,q> = 0, ||r||^2 = 2, rho alternates between 1 and 3 (always adjacent to
+        // scalar slots: <kp,kq> = 0, ||kr||^2 = 2, rho alternates between 1 and 3 (always adjacent to
         // slot 2, so the two scalars of the update kernel are summed over ranks by ONE all-reduce)
         enum { S_PQ = 0, S_RR = 2 };
         int s_rho = 1, s_new = 3;
-        const ramd_vec_t first[1] = {_fh(*r)};
-        RAMD_CHECK(ramd_fused_multi_dot(first, 1, _fh(*zdir), s_rho)); // rho = <r, z> (or <r, r>)
+        const ramd_vec_t first[1] = {_fh(*kr)};
+        RAMD_CHECK(ramd_fused_multi_dot(first, 1, _fh(*zdir), s_rho)); // rho = <kr, kz> (or <kr, kr>)
         _f_allreduce(A, s_rho, 1);
-        _f_apply_dot(A, *p, q, S_PQ);
+        _f_apply_dot(A, *kp, kq, S_PQ);
         _f_allreduce(A, S_PQ, 1);
         int rec = 0;
         while(true)
         {
-            RAMD_CHECK(ramd_fused_cg_update(_fh(*r), _fh(*q), dinv, dinv ? _fh(*z) : NULL, s_rho, S_PQ,
+            RAMD_CHECK(ramd_fused_cg_update(_fh(*kr), _fh(*kq), dinv, dinv ? _fh(*kz) : NULL, s_rho, S_PQ,
                                             S_RR, s_new));
             if(generic_pc)
             {
-                this->precond_->SolveZeroSol(*r, z);
-                RAMD_CHECK(ramd_fused_multi_dot(first, 1, _fh(*z), s_new));
+                this->m_precond->SolveZeroSol(*kr, kz);
+                RAMD_CHECK(ramd_fused_multi_dot(first, 1, _fh(*kz), s_new));
             }
             _f_allreduce(A, s_new < S_RR ? s_new : S_RR, 2);
             RAMD_CHECK(ramd_scalars_fetch_async_begin(rec, S_RR, 1));
-            RAMD_CHECK(ramd_fused_cg_direction(_fh(*x), _fh(*p), _fh(*zdir), s_rho, S_PQ, s_new));
-            _f_apply_dot(A, *p, q, S_PQ);
+            RAMD_CHECK(ramd_fused_cg_direction(_fh(*x), _fh(*kp), _fh(*zdir), s_rho, S_PQ, s_new));
+            _f_apply_dot(A, *kp, kq, S_PQ);
             _f_allreduce(A, S_PQ, 1);
             double rr = 0.0;
             RAMD_CHECK(ramd_scalars_fetch_async_end(rec, &rr, 1));
             ValueType res_norm = (ValueType)std::sqrt(rr);
-            if(this->iter_ctrl_.CheckResidual(std::abs(res_norm), this->index_))
+            if(this->m_iter_ctrl.CheckResidual(std::abs(res_norm), this->m_index))
                 break;
             std::swap(s_rho, s_new);
             rec = (rec + 1) & 7;
@@ -1551,12 +1540,12 @@ private:
     }
     template <class O = OperatorType, class V = VectorType>
     typename std::enable_if<!_fusable<O, V, ValueType>::value, bool>::type
-        FusedLoop_(const VectorType&, VectorType*, bool)
+        doFusedLoop(const VectorType&, VectorType*, bool)
     {
         return false;
     }
 
-    VectorType r_, z_, p_, q_;
+    VectorType m_r, m_z, m_p, m_q;
 };
 
 // ============================================================================ GMRES
@@ -1565,10 +1554,10 @@ class GMRES : public IterativeLinearSolver<OperatorType, VectorType, ValueType>
 {
 public:
     GMRES()
-        : flexible_(false)
-        , size_basis_(30) // gmres.cpp:50
-        , v_(NULL)
-        , zb_(NULL)
+        : m_flexible(false)
+        , m_size_basis(30) // gmres.cpp:50
+        , m_v(NULL)
+        , m_zb(NULL)
     {
     }
     virtual ~GMRES()
@@ -1577,109 +1566,105 @@ public:
     }
     virtual void Print(void) const
     {
-        LOG_INFO((this->flexible_ ? "FGMRES(" : "GMRES(")
-                 << this->size_basis_ << ") solver"
-                 << (this->precond_ ? ", with preconditioner" : " (non-precond)"));
+        say((this->m_flexible ? "FGMRES(" : "GMRES("), this->m_size_basis, ") solver", (this->m_precond ? ", with preconditioner" : " (non-precond)"));
     }
     virtual void SetBasisSize(int size_basis)
     {
-        assert(size_basis > 0 && this->build_ == false);
-        this->size_basis_ = size_basis;
+        RAMD_EXPECT(size_basis > 0 && !this->m_build);
+        this->m_size_basis = size_basis;
     }
     // gmres.cpp:109-156
     virtual void Build(void)
     {
-        if(this->build_)
+        if(this->m_build)
             this->Clear();
-        assert(this->op_ != NULL && this->op_->GetM() == this->op_->GetN() && this->op_->GetM() > 0);
-        this->build_ = true;
-        const int m  = this->size_basis_;
-        this->c_.assign((size_t)m, ValueType(0));
-        this->s_.assign((size_t)m, ValueType(0));
-        this->r_.assign((size_t)m + 1, ValueType(0));
-        this->H_.assign((size_t)(m + 1) * m, ValueType(0));
-        this->v_ = new VectorType*[m + 1];
+        RAMD_EXPECT(this->m_op != nullptr && this->m_op->GetM() == this->m_op->GetN() && this->m_op->GetM() > 0);
+        this->m_build = true;
+        const int m  = this->m_size_basis;
+        this->m_c.assign((size_t)m, ValueType(0));
+        this->m_s.assign((size_t)m, ValueType(0));
+        this->m_r.assign((size_t)m + 1, ValueType(0));
+        this->m_H.assign((size_t)(m + 1) * m, ValueType(0));
+        this->m_v = new VectorType*[m + 1];
         for(int i = 0; i < m + 1; ++i)
         {
-            this->v_[i] = new VectorType;
-            this->v_[i]->CloneBackend(*this->op_);
-            this->v_[i]->Allocate("v", this->op_->GetM());
+            this->m_v[i] = new VectorType;
+            this->m_v[i]->CloneBackend(*this->m_op);
+            this->m_v[i]->Allocate("v", this->m_op->GetM());
         }
-        if(this->precond_ != NULL)
+        if(this->m_precond != NULL)
         {
-            if(this->flexible_) // fgmres.cpp:139-150: one z per basis vector
+            if(this->m_flexible) // fgmres.cpp:139-150: one z per basis vector
             {
-                this->zb_ = new VectorType*[m + 1];
+                this->m_zb = new VectorType*[m + 1];
                 for(int i = 0; i < m + 1; ++i)
                 {
-                    this->zb_[i] = new VectorType;
-                    this->zb_[i]->CloneBackend(*this->op_);
-                    this->zb_[i]->Allocate("z", this->op_->GetM());
+                    this->m_zb[i] = new VectorType;
+                    this->m_zb[i]->CloneBackend(*this->m_op);
+                    this->m_zb[i]->Allocate("z", this->m_op->GetM());
                 }
             }
             else
             {
-                this->z_.CloneBackend(*this->op_);
-                this->z_.Allocate("z", this->op_->GetM());
+                this->m_z.CloneBackend(*this->m_op);
+                this->m_z.Allocate("z", this->m_op->GetM());
             }
-            this->precond_->SetOperator(*this->op_);
-            this->precond_->Build();
+            this->m_precond->SetOperator(*this->m_op);
+            this->m_precond->Build();
         }
     }
     virtual void Clear(void)
     {
-        if(this->build_)
+        if(this->m_build)
         {
-            if(this->precond_ != NULL)
+            if(this->m_precond != NULL)
             {
-                this->precond_->Clear();
-                this->precond_ = NULL;
+                this->m_precond->Clear();
+                this->m_precond = NULL;
             }
-            for(int i = 0; i < this->size_basis_ + 1; ++i)
+            for(int i = 0; i < this->m_size_basis + 1; ++i)
             {
-                delete this->v_[i];
-                if(this->zb_ != NULL)
-                    delete this->zb_[i];
+                delete this->m_v[i];
+                if(this->m_zb != NULL)
+                    delete this->m_zb[i];
             }
-            delete[] this->v_;
-            delete[] this->zb_;
-            this->v_  = NULL;
-            this->zb_ = NULL;
-            this->z_.Clear();
-            this->iter_ctrl_.Clear();
-            this->build_ = false;
+            delete[] this->m_v;
+            delete[] this->m_zb;
+            this->m_v  = NULL;
+            this->m_zb = NULL;
+            this->m_z.Clear();
+            this->m_iter_ctrl.Clear();
+            this->m_build = false;
         }
     }
 
 protected:
-    virtual void PrintStart_(void) const
+    virtual void doPrintStart(void) const
     {
-        LOG_INFO((this->flexible_ ? "FGMRES(" : "GMRES(")
-                 << this->size_basis_ << ") " << (this->precond_ ? "" : "(non-precond) ")
-                 << "linear solver starts");
+        say((this->m_flexible ? "FGMRES(" : "GMRES("), this->m_size_basis, ") ", (this->m_precond ? "" : "(non-precond) "), "linear solver starts");
     }
-    virtual void PrintEnd_(void) const
+    virtual void doPrintEnd(void) const
     {
-        LOG_INFO((this->flexible_ ? "FGMRES(" : "GMRES(") << this->size_basis_ << ") ends");
+        say((this->m_flexible ? "FGMRES(" : "GMRES("), this->m_size_basis, ") ends");
     }
-    virtual void SolveNonPrecond_(const VectorType& rhs, VectorType* x)
+    virtual void doSolveNonPrecond(const VectorType& rhs, VectorType* x)
     {
-        this->Solve_(rhs, x, false);
+        this->doSolve(rhs, x, false);
     }
-    virtual void SolvePrecond_(const VectorType& rhs, VectorType* x)
+    virtual void doSolvePrecond(const VectorType& rhs, VectorType* x)
     {
-        this->Solve_(rhs, x, true);
+        this->doSolve(rhs, x, true);
     }
 
 private:
-    int hidx_(int i, int j) const // DENSE_IND, column-major (m+1) x m (matrix_formats_ind.hpp:30)
+    int m_hidx(int i, int j) const // DENSE_IND, column-major (m+1) x m (matrix_formats_ind.hpp:30)
     {
-        return i + j * (this->size_basis_ + 1);
+        return i + j * (this->m_size_basis + 1);
     }
     // gmres.cpp:565-607
-    static void GenerateGivensRotation_(ValueType dx, ValueType dy, ValueType& c, ValueType& s)
+    static void doGenerateGivensRotation(ValueType dx, ValueType dy, ValueType& c, ValueType& s)
     {
-        const ValueType zero = static_cast<ValueType>(0), one = static_cast<ValueType>(1);
+        const ValueType zero = num<ValueType>(0), one = num<ValueType>(1);
         if(dy == zero)
         {
             c = one;
@@ -1703,73 +1688,73 @@ private:
             s             = tmp * c;
         }
     }
-    static void ApplyGivensRotation_(ValueType c, ValueType s, ValueType& dx, ValueType& dy)
+    static void doApplyGivensRotation(ValueType c, ValueType s, ValueType& dx, ValueType& dy)
     {
         ValueType temp = dx;
         dx             = c * dx + s * dy;
         dy             = -s * temp + c * dy;
     }
-    // residual -> v_0 (through z_ and M^-1 when preconditioned): gmres.cpp:444-454, :542-552
-    void Residual_(const VectorType& rhs, VectorType* x, bool precond)
+    // residual -> v_0 (through m_z and M^-1 when preconditioned): gmres.cpp:444-454, :542-552
+    void doResidual(const VectorType& rhs, VectorType* x, bool precond)
     {
-        const ValueType one = static_cast<ValueType>(1);
-        if(precond && !this->flexible_)
+        const ValueType one = num<ValueType>(1);
+        if(precond && !this->m_flexible)
         {
-            this->op_->Apply(*x, &this->z_);
-            this->z_.ScaleAdd(-one, rhs);
-            this->precond_->SolveZeroSol(this->z_, this->v_[0]);
+            this->m_op->Apply(*x, &this->m_z);
+            this->m_z.ScaleAdd(-one, rhs);
+            this->m_precond->SolveZeroSol(this->m_z, this->m_v[0]);
         }
         else
         {
-            this->op_->Apply(*x, this->v_[0]);
-            this->v_[0]->ScaleAdd(-one, rhs);
+            this->m_op->Apply(*x, this->m_v[0]);
+            this->m_v[0]->ScaleAdd(-one, rhs);
         }
     }
-    // one Arnoldi step: fills column i of H (rows 0..i+1) and normalises v_{i+1}
-    void Arnoldi_(int i, bool precond)
+    // one Arnoldi step: fills column i of H (rows 0..i+1) and normalises m_v{i+1}
+    void doArnoldi(int i, bool precond)
     {
-        VectorType**    v   = this->v_;
-        ValueType*      H   = this->H_.data();
-        const ValueType one = static_cast<ValueType>(1);
-        if(precond && this->flexible_) // fgmres.cpp:462-466: M z_i = v_i ; v_i+1 = A z_i
+        VectorType**    v   = this->m_v;
+        ValueType*      H   = this->m_H.data();
+        const ValueType one = num<ValueType>(1);
+        if(precond && this->m_flexible) // fgmres.cpp:462-466: M z_i = v_i ; v_i+1 = A z_i
         {
-            this->precond_->SolveZeroSol(*v[i], this->zb_[i]);
-            this->op_->Apply(*this->zb_[i], v[i + 1]);
+            this->m_precond->SolveZeroSol(*v[i], this->m_zb[i]);
+            this->m_op->Apply(*this->m_zb[i], v[i + 1]);
         }
         else if(precond)
         {
-            this->op_->Apply(*v[i], &this->z_);
-            this->precond_->SolveZeroSol(this->z_, v[i + 1]);
+            this->m_op->Apply(*v[i], &this->m_z);
+            this->m_precond->SolveZeroSol(this->m_z, v[i + 1]);
         }
         else
-            this->op_->Apply(*v[i], v[i + 1]);
-        if(this->fused_ && this->res_norm_type_ == 2 && this->FusedMGS_(i))
+            this->m_op->Apply(*v[i], v[i + 1]);
+        if(this->m_fused && this->m_res_norm_type == 2 && this->doFusedMGS(i))
             return;
         for(int k = 0; k <= i; ++k) // modified Gram-Schmidt
         {
-            H[this->hidx_(k, i)] = v[k]->Dot(*v[i + 1]);
-            v[i + 1]->AddScale(*v[k], -H[this->hidx_(k, i)]);
+            H[this->m_hidx(k, i)] = v[k]->Dot(*v[i + 1]);
+            v[i + 1]->AddScale(*v[k], -H[this->m_hidx(k, i)]);
         }
-        H[this->hidx_(i + 1, i)] = this->Norm_(*v[i + 1]);
-        v[i + 1]->Scale(one / H[this->hidx_(i + 1, i)]);
+        H[this->m_hidx(i + 1, i)] = this->doNorm(*v[i + 1]);
+        v[i + 1]->Scale(one / H[this->m_hidx(i + 1, i)]);
     }
-    // Fused MGS: every projection  w -= h_k v_k  is fused with the NEXT dot <v_{k+1}, w> (or with
+    // Fused MGS: every projection  w -= h_k v_k  is fused with the NEXT dot <m_v{k+1}, w> (or with
     // <w,w> for the last one) and the normalisation reads ||w|| on the device: i+2 launches and
     // ONE host read per Arnoldi step instead of 2i+4 launches and i+2 blocking reads.  Same MGS
     // order and per-element arithmetic as the loop above.
     template <class O = OperatorType, class V = VectorType>
-    typename std::enable_if<_fusable<O, V, ValueType>::value, bool>::type FusedMGS_(int i)
+    typename std::enable_if<_fusable<O, V, ValueType>::value, bool>::type doFusedMGS(int i)
     {
-        if(i + 3 > RAMD_NSCALARS - 2 || !this->v_[0]->is_accel_())
+        if(i + 3 > RAMD_NSCALARS - 2 || !this->m_v[0]->is_accel_())
             return false;
-        const OperatorType& A = *this->op_;
-        VectorType**        v = this->v_;
-        ValueType*          H = this->H_.data();
+        const OperatorType& A = *this->m_op;
+        VectorType**        v = this->m_v;
+        ValueType*          H = this->m_H.data();
         ramd_vec_t          w = _fh(*v[i + 1]);
         const ramd_vec_t    v0[1] = {_fh(*v[0])};
         RAMD_CHECK(ramd_fused_multi_dot(v0, 1, w, 0)); // s[0] = <v_0, w>
         _f_allreduce(A, 0, 1);
-        for(int k = 0; k <= i; ++k) // s[k+1] = <v_{k+1}, w - h_k v_k>  (k == i: <w,w>)
+        for(int k = 0; k <= i; ++k) // s[k+1] = <m_v{k+1}, w - h_k v_k>  (k == i: <w,w>)
         {
             RAMD_CHECK(ramd_fused_mgs_step(w, _fh(*v[k]), k, (k < i) ? _fh(*v[k + 1]) : NULL, k + 1));
             _f_allreduce(A, k + 1, 1);
@@ -1778,29 +1763,29 @@ private:
         std::vector<double> h((size_t)i + 3);
         RAMD_CHECK(ramd_scalars_fetch(h.data(), 0, i + 3));
         for(int k = 0; k <= i; ++k)
-            H[this->hidx_(k, i)] = (ValueType)h[k];
-        H[this->hidx_(i + 1, i)] = (ValueType)h[i + 2];
+            H[this->m_hidx(k, i)] = (ValueType)h[k];
+        H[this->m_hidx(i + 1, i)] = (ValueType)h[i + 2];
         return true;
     }
     template <class O = OperatorType, class V = VectorType>
-    typename std::enable_if<!_fusable<O, V, ValueType>::value, bool>::type FusedMGS_(int)
+    typename std::enable_if<!_fusable<O, V, ValueType>::value, bool>::type doFusedMGS(int)
     {
         return false;
     }
 
     // gmres.cpp:274-413 / :416-562
-    void Solve_(const VectorType& rhs, VectorType* x, bool precond)
+    void doSolve(const VectorType& rhs, VectorType* x, bool precond)
     {
-        VectorType**    v    = this->v_;
-        ValueType *     c = this->c_.data(), *s = this->s_.data(), *r = this->r_.data();
-        ValueType*      H    = this->H_.data();
-        const ValueType one  = static_cast<ValueType>(1);
-        const int       size = this->size_basis_;
+        VectorType**    v    = this->m_v;
+        ValueType *     c = this->m_c.data(), *s = this->m_s.data(), *r = this->m_r.data();
+        ValueType*      H    = this->m_H.data();
+        const ValueType one  = num<ValueType>(1);
+        const int       size = this->m_size_basis;
 
-        this->Residual_(rhs, x, precond);
-        std::fill(this->r_.begin(), this->r_.end(), ValueType(0));
-        r[0] = this->Norm_(*v[0]);
-        if(this->iter_ctrl_.InitResidual(std::abs(r[0])) == false)
+        this->doResidual(rhs, x, precond);
+        std::fill(this->m_r.begin(), this->m_r.end(), ValueType(0));
+        r[0] = this->doNorm(*v[0]);
+        if(this->m_iter_ctrl.InitResidual(std::abs(r[0])) == false)
             return;
         while(true)
         {
@@ -1808,42 +1793,42 @@ private:
             int i = 0;
             while(i < size)
             {
-                this->Arnoldi_(i, precond);
+                this->doArnoldi(i, precond);
                 for(int k = 0; k < i; ++k)
-                    ApplyGivensRotation_(c[k], s[k], H[this->hidx_(k, i)], H[this->hidx_(k + 1, i)]);
-                GenerateGivensRotation_(H[this->hidx_(i, i)], H[this->hidx_(i + 1, i)], c[i], s[i]);
-                ApplyGivensRotation_(c[i], s[i], H[this->hidx_(i, i)], H[this->hidx_(i + 1, i)]);
-                ApplyGivensRotation_(c[i], s[i], r[i], r[i + 1]);
-                if(this->iter_ctrl_.CheckResidual(std::abs(r[++i])))
+                    doApplyGivensRotation(c[k], s[k], H[this->m_hidx(k, i)], H[this->m_hidx(k + 1, i)]);
+                doGenerateGivensRotation(H[this->m_hidx(i, i)], H[this->m_hidx(i + 1, i)], c[i], s[i]);
+                doApplyGivensRotation(c[i], s[i], H[this->m_hidx(i, i)], H[this->m_hidx(i + 1, i)]);
+                doApplyGivensRotation(c[i], s[i], r[i], r[i + 1]);
+                if(this->m_iter_ctrl.CheckResidual(std::abs(r[++i])))
                     break;
             }
             for(int j = i - 1; j >= 0; --j) // back substitution on the host
             {
-                r[j] /= H[this->hidx_(j, j)];
+                r[j] /= H[this->m_hidx(j, j)];
                 for(int k = 0; k < j; ++k)
-                    r[k] -= H[this->hidx_(k, j)] * r[j];
+                    r[k] -= H[this->m_hidx(k, j)] * r[j];
             }
-            VectorType** upd = (precond && this->flexible_) ? this->zb_ : v; // fgmres.cpp:527-532
+            VectorType** upd = (precond && this->m_flexible) ? this->m_zb : v; // fgmres.cpp:527-532
             x->AddScale(*upd[0], r[0]);
             for(int j = 1; j < i; ++j)
                 x->AddScale(*upd[j], r[j]);
-            this->Residual_(rhs, x, precond);
-            std::fill(this->r_.begin(), this->r_.end(), ValueType(0));
-            r[0] = this->Norm_(*v[0]);
-            if(this->iter_ctrl_.CheckResidualNoCount(std::abs(r[0])))
+            this->doResidual(rhs, x, precond);
+            std::fill(this->m_r.begin(), this->m_r.end(), ValueType(0));
+            r[0] = this->doNorm(*v[0]);
+            if(this->m_iter_ctrl.CheckResidualNoCount(std::abs(r[0])))
                 break;
         }
     }
 
 protected:
-    bool flexible_; // FGMRES: right preconditioning with a stored z_i per basis vector
+    bool m_flexible; // FGMRES: right preconditioning with a stored z_i per basis vector
 
 private:
-    int                    size_basis_;
-    VectorType**           v_;
-    VectorType**           zb_;
-    VectorType             z_;
-    std::vector<ValueType> c_, s_, r_, H_;
+    int                    m_size_basis;
+    VectorType**           m_v;
+    VectorType**           m_zb;
+    VectorType             m_z;
+    std::vector<ValueType> m_c, m_s, m_r, m_H;
 };
 
 // fgmres.cpp: flexible GMRES -- same Arnoldi/Givens machinery as GMRES (it is the same code in the
@@ -1855,7 +1840,7 @@ class FGMRES : public GMRES<OperatorType, VectorType, ValueType>
 public:
     FGMRES()
     {
-        this->flexible_ = true;
+        this->m_flexible = true;
     }
     virtual ~FGMRES()
     {
@@ -1874,136 +1859,136 @@ public:
     }
     virtual void Print(void) const
     {
-        LOG_INFO("BiCGStab solver" << (this->precond_ ? ", with preconditioner" : " (non-precond)"));
+        say("BiCGStab solver", (this->m_precond ? ", with preconditioner" : " (non-precond)"));
     }
     // bicgstab.cpp:109-160
     virtual void Build(void)
     {
-        if(this->build_)
+        if(this->m_build)
             this->Clear();
-        assert(this->op_ != NULL && this->op_->GetM() == this->op_->GetN() && this->op_->GetM() > 0);
-        this->build_ = true;
-        VectorType* all[] = {&this->r_, &this->r0_, &this->p_, &this->q_, &this->t_};
+        RAMD_EXPECT(this->m_op != nullptr && this->m_op->GetM() == this->m_op->GetN() && this->m_op->GetM() > 0);
+        this->m_build = true;
+        VectorType* all[] = {&this->m_r, &this->m_r0, &this->m_p, &this->m_q, &this->m_t};
         for(VectorType* vec : all)
         {
-            vec->CloneBackend(*this->op_);
-            vec->Allocate("bicgstab", this->op_->GetM());
+            vec->CloneBackend(*this->m_op);
+            vec->Allocate("bicgstab", this->m_op->GetM());
         }
-        if(this->precond_ != NULL)
+        if(this->m_precond != NULL)
         {
-            this->precond_->SetOperator(*this->op_);
-            this->precond_->Build();
-            this->v_.CloneBackend(*this->op_);
-            this->v_.Allocate("v", this->op_->GetM());
-            this->z_.CloneBackend(*this->op_);
-            this->z_.Allocate("z", this->op_->GetM());
+            this->m_precond->SetOperator(*this->m_op);
+            this->m_precond->Build();
+            this->m_v.CloneBackend(*this->m_op);
+            this->m_v.Allocate("v", this->m_op->GetM());
+            this->m_z.CloneBackend(*this->m_op);
+            this->m_z.Allocate("z", this->m_op->GetM());
         }
     }
     virtual void Clear(void)
     {
-        if(this->build_)
+        if(this->m_build)
         {
-            if(this->precond_ != NULL)
+            if(this->m_precond != NULL)
             {
-                this->precond_->Clear();
-                this->precond_ = NULL;
+                this->m_precond->Clear();
+                this->m_precond = NULL;
             }
-            VectorType* all[] = {&this->r_, &this->r0_, &this->p_, &this->q_, &this->t_, &this->v_,
-                                 &this->z_};
+            VectorType* all[] = {&this->m_r, &this->m_r0, &this->m_p, &this->m_q, &this->m_t, &this->m_v,
+                                 &this->m_z};
             for(VectorType* vec : all)
                 vec->Clear();
-            this->iter_ctrl_.Clear();
-            this->build_ = false;
+            this->m_iter_ctrl.Clear();
+            this->m_build = false;
         }
     }
 
 protected:
-    virtual void PrintStart_(void) const
+    virtual void doPrintStart(void) const
     {
-        LOG_INFO("BiCGStab " << (this->precond_ ? "" : "(non-precond) ") << "linear solver starts");
+        say("BiCGStab ", (this->m_precond ? "" : "(non-precond) "), "linear solver starts");
     }
-    virtual void PrintEnd_(void) const
+    virtual void doPrintEnd(void) const
     {
-        LOG_INFO("BiCGStab ends");
+        say("BiCGStab ends");
     }
-    virtual void SolveNonPrecond_(const VectorType& rhs, VectorType* x)
+    virtual void doSolveNonPrecond(const VectorType& rhs, VectorType* x)
     {
-        this->Solve_(rhs, x, false);
+        this->doSolve(rhs, x, false);
     }
-    virtual void SolvePrecond_(const VectorType& rhs, VectorType* x)
+    virtual void doSolvePrecond(const VectorType& rhs, VectorType* x)
     {
-        this->Solve_(rhs, x, true);
+        this->doSolve(rhs, x, true);
     }
 
 private:
-    // Fused device loop: per iteration  K1 q = A dir + <r0,q> | K2 r -= alpha q | [v = M^-1 r] |
-    // t = A sv, one pass for <t,r>,<t,t> | K3 x,r updates + <r,r>,<r0,r> | K4 p update | [z = M^-1 p].
-    // alpha/omega/beta never leave the device; ONE host read per iteration (the four dots of K3's
+    // Fused device loop: per iteration  K1 kq = A dir + <r0,kq> | K2 kr -= alpha kq | [kv = M^-1 kr] |
+    // kt = A sv, one pass for <kt,kr>,<kt,kt> | K3 x,kr updates + <kr,kr>,<r0,kr> | K4 kp update | [kz = M^-1 kp].
+    // alpha/omega/beta never leave the device; ONE host read per iteration (the four dots of K3'ks
     // record), overlapped with K4 and the next preconditioner apply.  Same per-element arithmetic and
     // the same breakdown / stopping decisions as the loop below.
     template <class O = OperatorType, class V = VectorType>
     typename std::enable_if<_fusable<O, V, ValueType>::value, bool>::type
-        FusedLoop_(const VectorType& rhs, VectorType* x, bool precond)
+        doFusedLoop(const VectorType& rhs, VectorType* x, bool precond)
     {
-        if(!this->op_->is_accel_() || !x->is_accel_())
+        if(!this->m_op->is_accel_() || !x->is_accel_())
             return false;
-        if(precond && this->precond_->SolveUsesScalarRecord())
+        if(precond && this->m_precond->SolveUsesScalarRecord())
             return false; // a preconditioner with reductions of its own would overwrite alpha / omega / rho on the device
-        const OperatorType& A = *this->op_;
-        VectorType *r = &this->r_, *r0 = &this->r0_, *p = &this->p_, *q = &this->q_, *t = &this->t_;
-        VectorType *v = &this->v_, *z = &this->z_;
-        const ValueType one = static_cast<ValueType>(1);
-        // slots: <t,r> = 0, <t,t> = 1, <r0,q> = 2, ||r||^2 = 4, rho alternates between 3 and 5 (always next
+        const OperatorType& A = *this->m_op;
+        VectorType *kr = &this->m_r, *r0 = &this->m_r0, *kp = &this->m_p, *kq = &this->m_q, *kt = &this->m_t;
+        VectorType *kv = &this->m_v, *kz = &this->m_z;
+        const ValueType one = num<ValueType>(1);
+        // slots: <kt,kr> = 0, <kt,kt> = 1, <r0,kq> = 2, ||kr||^2 = 4, rho alternates between 3 and 5 (always next
         // to slot 4: the two sums of K3 cross the ranks in ONE all-reduce), breakdown flag = 6
         enum { S_TR = 0, S_R0Q = 2, S_RR = 4, S_FLAG = 6 };
         int s_rho = 3, s_new = 5;
-        const ramd_vec_t rv[1] = {_fh(*r)};
-        RAMD_CHECK(ramd_fused_multi_dot(rv, 1, _fh(*r), s_rho)); // rho = <r,r>
+        const ramd_vec_t rv[1] = {_fh(*kr)};
+        RAMD_CHECK(ramd_fused_multi_dot(rv, 1, _fh(*kr), s_rho)); // rho = <kr,kr>
         _f_allreduce(A, s_rho, 1);
         int rec = 0;
         while(true)
         {
-            const VectorType* dir = precond ? z : p;
-            _f_apply_dotv(A, *dir, q, *r0, S_R0Q);
+            const VectorType* dir = precond ? kz : kp;
+            _f_apply_dotv(A, *dir, kq, *r0, S_R0Q);
             _f_allreduce(A, S_R0Q, 1);
-            RAMD_CHECK(ramd_fused_bicg_r_update(_fh(*r), _fh(*q), s_rho, S_R0Q));
-            const VectorType* sv = r;
+            RAMD_CHECK(ramd_fused_bicg_r_update(_fh(*kr), _fh(*kq), s_rho, S_R0Q));
+            const VectorType* sv = kr;
             if(precond)
             {
-                this->precond_->SolveZeroSol(*r, v);
-                sv = v;
+                this->m_precond->SolveZeroSol(*kr, kv);
+                sv = kv;
             }
-            A.Apply(*sv, t);
-            const ramd_vec_t rt[2] = {_fh(*r), _fh(*t)};
-            RAMD_CHECK(ramd_fused_multi_dot(rt, 2, _fh(*t), S_TR)); // <t,r>, <t,t> in one pass
+            A.Apply(*sv, kt);
+            const ramd_vec_t rt[2] = {_fh(*kr), _fh(*kt)};
+            RAMD_CHECK(ramd_fused_multi_dot(rt, 2, _fh(*kt), S_TR)); // <kt,kr>, <kt,kt> in one pass
             _f_allreduce(A, S_TR, 2);
             RAMD_CHECK(ramd_fused_bicg_xr_update(_fh(*x), precond ? _fh(*dir) : NULL, precond ? _fh(*sv) : NULL,
-                                                 _fh(*r), _fh(*t), _fh(*r0), _fh(*p), s_rho, S_R0Q, S_TR, S_RR,
+                                                 _fh(*kr), _fh(*kt), _fh(*r0), _fh(*kp), s_rho, S_R0Q, S_TR, S_RR,
                                                  s_new, S_FLAG));
             _f_allreduce(A, s_new < S_RR ? s_new : S_RR, 2);
             RAMD_CHECK(ramd_scalars_fetch_async_begin(rec, 0, 7));
-            // queued ahead of the host's decision; they only touch p / z, which a finished solve discards
-            RAMD_CHECK(ramd_fused_bicg_direction(_fh(*p), _fh(*q), _fh(*r), s_rho, S_R0Q, S_TR, s_new));
+            // queued ahead of the host'ks decision; they only touch kp / kz, which a finished solve discards
+            RAMD_CHECK(ramd_fused_bicg_direction(_fh(*kp), _fh(*kq), _fh(*kr), s_rho, S_R0Q, S_TR, s_new));
             if(precond)
-                this->precond_->SolveZeroSol(*p, z);
+                this->m_precond->SolveZeroSol(*kp, kz);
             double h[7];
             RAMD_CHECK(ramd_scalars_fetch_async_end(rec, h, 7));
             rec = (rec + 1) & 7;
-            if(h[S_FLAG] != 0.0) // bicgstab.cpp:430-447 (x += alpha p was done by the kernel)
+            if(h[S_FLAG] != 0.0) // bicgstab.cpp:430-447 (x += alpha kp was done by the kernel)
             {
-                LOG_INFO("BiCGStab omega == 0 || Nan || Inf !!! Updated solution only in p-direction");
-                A.Apply(*x, p);
-                p->ScaleAdd(-one, rhs);
-                ValueType res_norm = this->Norm_(*p);
-                this->iter_ctrl_.CheckResidual(std::abs(res_norm), this->index_);
+                say("BiCGStab omega == 0 || Nan || Inf !!! Updated solution only in p-direction");
+                A.Apply(*x, kp);
+                kp->ScaleAdd(-one, rhs);
+                ValueType res_norm = this->doNorm(*kp);
+                this->m_iter_ctrl.CheckResidual(std::abs(res_norm), this->m_index);
                 break;
             }
             ValueType res_norm = (ValueType)std::sqrt(h[S_RR]);
-            if(this->iter_ctrl_.CheckResidual(std::abs(res_norm), this->index_))
+            if(this->m_iter_ctrl.CheckResidual(std::abs(res_norm), this->m_index))
                 break;
-            if((ValueType)h[s_new] == static_cast<ValueType>(0))
+            if((ValueType)h[s_new] == num<ValueType>(0))
             {
-                LOG_INFO("BiCGStab rho == 0 !!!");
+                say("BiCGStab rho == 0 !!!");
                 break;
             }
             std::swap(s_rho, s_new);
@@ -2012,76 +1997,76 @@ private:
     }
     template <class O = OperatorType, class V = VectorType>
     typename std::enable_if<!_fusable<O, V, ValueType>::value, bool>::type
-        FusedLoop_(const VectorType&, VectorType*, bool)
+        doFusedLoop(const VectorType&, VectorType*, bool)
     {
         return false;
     }
 
-    // bicgstab.cpp:245-361 / :365-489 (right preconditioned: z = M^-1 p, v = M^-1 r)
-    void Solve_(const VectorType& rhs, VectorType* x, bool precond)
+    // bicgstab.cpp:245-361 / :365-489 (right preconditioned: kz = M^-1 kp, kv = M^-1 kr)
+    void doSolve(const VectorType& rhs, VectorType* x, bool precond)
     {
-        const OperatorType* op = this->op_;
-        VectorType *r = &this->r_, *r0 = &this->r0_, *p = &this->p_, *q = &this->q_, *t = &this->t_;
-        VectorType *v = &this->v_, *z = &this->z_;
+        const OperatorType* op = this->m_op;
+        VectorType *kr = &this->m_r, *r0 = &this->m_r0, *kp = &this->m_p, *kq = &this->m_q, *kt = &this->m_t;
+        VectorType *kv = &this->m_v, *kz = &this->m_z;
         ValueType   alpha, beta, omega, rho, rho_old;
-        const ValueType one = static_cast<ValueType>(1);
+        const ValueType one = num<ValueType>(1);
 
         op->Apply(*x, r0);
         r0->ScaleAdd(-one, rhs);
-        ValueType res_norm = this->Norm_(*r0);
-        if(this->iter_ctrl_.InitResidual(std::abs(res_norm)) == false)
+        ValueType res_norm = this->doNorm(*r0);
+        if(this->m_iter_ctrl.InitResidual(std::abs(res_norm)) == false)
             return;
-        r->CopyFrom(*r0);
-        p->CopyFrom(*r);
+        kr->CopyFrom(*r0);
+        kp->CopyFrom(*kr);
         if(precond)
-            this->precond_->SolveZeroSol(*r, z);
-        if(this->fused_ && this->res_norm_type_ == 2 && this->FusedLoop_(rhs, x, precond))
+            this->m_precond->SolveZeroSol(*kr, kz);
+        if(this->m_fused && this->m_res_norm_type == 2 && this->doFusedLoop(rhs, x, precond))
             return;
-        rho = r->Dot(*r);
+        rho = kr->Dot(*kr);
         while(true)
         {
-            const VectorType* dir = precond ? z : p;
-            op->Apply(*dir, q);
-            alpha = rho / r0->Dot(*q);
-            r->AddScale(*q, -alpha);
-            const VectorType* sv = r;
+            const VectorType* dir = precond ? kz : kp;
+            op->Apply(*dir, kq);
+            alpha = rho / r0->Dot(*kq);
+            kr->AddScale(*kq, -alpha);
+            const VectorType* sv = kr;
             if(precond)
             {
-                this->precond_->SolveZeroSol(*r, v);
-                sv = v;
+                this->m_precond->SolveZeroSol(*kr, kv);
+                sv = kv;
             }
-            op->Apply(*sv, t);
-            omega = t->Dot(*r) / t->Dot(*t);
+            op->Apply(*sv, kt);
+            omega = kt->Dot(*kr) / kt->Dot(*kt);
             if((std::abs(omega) == std::numeric_limits<ValueType>::infinity()) || (omega != omega)
-               || (omega == static_cast<ValueType>(0)))
+               || (omega == num<ValueType>(0)))
             {
-                LOG_INFO("BiCGStab omega == 0 || Nan || Inf !!! Updated solution only in p-direction");
-                x->AddScale(*p, alpha);
-                op->Apply(*x, p);
-                p->ScaleAdd(-one, rhs);
-                res_norm = this->Norm_(*p);
-                this->iter_ctrl_.CheckResidual(std::abs(res_norm), this->index_);
+                say("BiCGStab omega == 0 || Nan || Inf !!! Updated solution only in p-direction");
+                x->AddScale(*kp, alpha);
+                op->Apply(*x, kp);
+                kp->ScaleAdd(-one, rhs);
+                res_norm = this->doNorm(*kp);
+                this->m_iter_ctrl.CheckResidual(std::abs(res_norm), this->m_index);
                 break;
             }
             x->ScaleAdd2(one, *dir, alpha, *sv, omega);
-            r->AddScale(*t, -omega);
-            res_norm = this->Norm_(*r);
-            if(this->iter_ctrl_.CheckResidual(std::abs(res_norm), this->index_))
+            kr->AddScale(*kt, -omega);
+            res_norm = this->doNorm(*kr);
+            if(this->m_iter_ctrl.CheckResidual(std::abs(res_norm), this->m_index))
                 break;
             rho_old = rho;
-            rho     = r0->Dot(*r);
-            if(rho == static_cast<ValueType>(0))
+            rho     = r0->Dot(*kr);
+            if(rho == num<ValueType>(0))
             {
-                LOG_INFO("BiCGStab rho == 0 !!!");
+                say("BiCGStab rho == 0 !!!");
                 break;
             }
             beta = (rho / rho_old) * (alpha / omega);
-            p->ScaleAdd2(beta, *q, -beta * omega, *r, one);
+            kp->ScaleAdd2(beta, *kq, -beta * omega, *kr, one);
             if(precond)
-                this->precond_->SolveZeroSol(*p, z);
+                this->m_precond->SolveZeroSol(*kp, kz);
         }
     }
-    VectorType r_, r0_, p_, q_, t_, v_, z_;
+    VectorType m_r, m_r0, m_p, m_q, m_t, m_v, m_z;
 };
 
 // ============================================================================ FCG
@@ -2096,103 +2081,103 @@ public:
     }
     virtual void Print(void) const
     {
-        LOG_INFO((this->precond_ ? "Flexible PCG solver, with preconditioner" : "Flexible CG (non-precond) solver"));
+        say((this->m_precond ? "Flexible PCG solver, with preconditioner" : "Flexible CG (non-precond) solver"));
     }
     virtual void Build(void)
     {
-        if(this->build_)
+        if(this->m_build)
             this->Clear();
-        assert(this->op_ != NULL && this->op_->GetM() == this->op_->GetN() && this->op_->GetM() > 0);
-        this->build_ = true;
-        if(this->precond_ != NULL)
+        RAMD_EXPECT(this->m_op != nullptr && this->m_op->GetM() == this->m_op->GetN() && this->m_op->GetM() > 0);
+        this->m_build = true;
+        if(this->m_precond != NULL)
         {
-            this->precond_->SetOperator(*this->op_);
-            this->precond_->Build();
-            this->z_.CloneBackend(*this->op_);
-            this->z_.Allocate("z", this->op_->GetM());
+            this->m_precond->SetOperator(*this->m_op);
+            this->m_precond->Build();
+            this->m_z.CloneBackend(*this->m_op);
+            this->m_z.Allocate("z", this->m_op->GetM());
         }
-        VectorType* all[] = {&this->r_, &this->w_, &this->p_, &this->q_};
+        VectorType* all[] = {&this->m_r, &this->m_w, &this->m_p, &this->m_q};
         for(VectorType* vec : all)
         {
-            vec->CloneBackend(*this->op_);
-            vec->Allocate("fcg", this->op_->GetM());
+            vec->CloneBackend(*this->m_op);
+            vec->Allocate("fcg", this->m_op->GetM());
         }
     }
     virtual void Clear(void)
     {
-        if(this->build_)
+        if(this->m_build)
         {
-            if(this->precond_ != NULL)
+            if(this->m_precond != NULL)
             {
-                this->precond_->Clear();
-                this->precond_ = NULL;
+                this->m_precond->Clear();
+                this->m_precond = NULL;
             }
-            VectorType* all[] = {&this->r_, &this->w_, &this->p_, &this->q_, &this->z_};
+            VectorType* all[] = {&this->m_r, &this->m_w, &this->m_p, &this->m_q, &this->m_z};
             for(VectorType* vec : all)
                 vec->Clear();
-            this->iter_ctrl_.Clear();
-            this->build_ = false;
+            this->m_iter_ctrl.Clear();
+            this->m_build = false;
         }
     }
 
 protected:
-    virtual void PrintStart_(void) const
+    virtual void doPrintStart(void) const
     {
-        LOG_INFO((this->precond_ ? "Flexible PCG solver starts, with preconditioner:" : "Flexible CG (non-precond) linear solver starts"));
+        say((this->m_precond ? "Flexible PCG solver starts, with preconditioner:" : "Flexible CG (non-precond) linear solver starts"));
     }
-    virtual void PrintEnd_(void) const
+    virtual void doPrintEnd(void) const
     {
-        LOG_INFO((this->precond_ ? "Flexible PCG ends" : "Flexible CG (non-precond) ends"));
+        say((this->m_precond ? "Flexible PCG ends" : "Flexible CG (non-precond) ends"));
     }
-    virtual void SolveNonPrecond_(const VectorType& rhs, VectorType* x)
+    virtual void doSolveNonPrecond(const VectorType& rhs, VectorType* x)
     {
-        this->Solve_(rhs, x, false);
+        this->doSolve(rhs, x, false);
     }
-    virtual void SolvePrecond_(const VectorType& rhs, VectorType* x)
+    virtual void doSolvePrecond(const VectorType& rhs, VectorType* x)
     {
-        this->Solve_(rhs, x, true);
+        this->doSolve(rhs, x, true);
     }
 
 private:
-    void Solve_(const VectorType& rhs, VectorType* x, bool precond)
+    void doSolve(const VectorType& rhs, VectorType* x, bool precond)
     {
-        const OperatorType* op = this->op_;
-        VectorType *r = &this->r_, *w = &this->w_, *p = &this->p_, *q = &this->q_;
-        VectorType* z = precond ? &this->z_ : r; // without a preconditioner z IS r
+        const OperatorType* op = this->m_op;
+        VectorType *kr = &this->m_r, *kw = &this->m_w, *kp = &this->m_p, *kq = &this->m_q;
+        VectorType* kz = precond ? &this->m_z : kr; // without a preconditioner kz IS kr
         ValueType   alpha, beta, rho, gamma, gamma_rho;
-        op->Apply(*x, r);
-        r->ScaleAdd(static_cast<ValueType>(-1), rhs);
-        ValueType res = this->Norm_(*r);
-        this->iter_ctrl_.InitResidual(std::abs(res));
+        op->Apply(*x, kr);
+        kr->ScaleAdd(num<ValueType>(-1), rhs);
+        ValueType res = this->doNorm(*kr);
+        this->m_iter_ctrl.InitResidual(std::abs(res));
         if(precond)
-            this->precond_->SolveZeroSol(*r, z);
-        op->Apply(*z, w);
-        alpha = z->Dot(*r);
-        beta  = z->Dot(*w);
-        p->CopyFrom(*z);
-        q->CopyFrom(*w);
+            this->m_precond->SolveZeroSol(*kr, kz);
+        op->Apply(*kz, kw);
+        alpha = kz->Dot(*kr);
+        beta  = kz->Dot(*kw);
+        kp->CopyFrom(*kz);
+        kq->CopyFrom(*kw);
         rho = beta;
-        x->AddScale(*p, alpha / rho);
-        r->AddScale(*q, -alpha / rho);
-        res = this->Norm_(*r);
-        while(!this->iter_ctrl_.CheckResidual(std::abs(res), this->index_))
+        x->AddScale(*kp, alpha / rho);
+        kr->AddScale(*kq, -alpha / rho);
+        res = this->doNorm(*kr);
+        while(!this->m_iter_ctrl.CheckResidual(std::abs(res), this->m_index))
         {
             if(precond)
-                this->precond_->SolveZeroSol(*r, z);
-            op->Apply(*z, w);
-            beta      = z->Dot(*w);
-            gamma     = z->Dot(*q);
+                this->m_precond->SolveZeroSol(*kr, kz);
+            op->Apply(*kz, kw);
+            beta      = kz->Dot(*kw);
+            gamma     = kz->Dot(*kq);
             gamma_rho = -gamma / rho;
-            p->ScaleAdd(gamma_rho, *z);
-            q->ScaleAdd(gamma_rho, *w);
+            kp->ScaleAdd(gamma_rho, *kz);
+            kq->ScaleAdd(gamma_rho, *kw);
             rho   = beta + gamma * gamma_rho;
-            alpha = z->Dot(*r) / rho;
-            x->AddScale(*p, alpha);
-            r->AddScale(*q, -alpha);
-            res = this->Norm_(*r);
+            alpha = kz->Dot(*kr) / rho;
+            x->AddScale(*kp, alpha);
+            kr->AddScale(*kq, -alpha);
+            res = this->doNorm(*kr);
         }
     }
-    VectorType r_, w_, z_, p_, q_;
+    VectorType m_r, m_w, m_z, m_p, m_q;
 };
 
 // ============================================================================ CR
@@ -2208,129 +2193,129 @@ public:
     }
     virtual void Print(void) const
     {
-        LOG_INFO((this->precond_ ? "PCR solver, with preconditioner" : "CR (non-precond) solver"));
+        say((this->m_precond ? "PCR solver, with preconditioner" : "CR (non-precond) solver"));
     }
     virtual void Build(void)
     {
-        if(this->build_)
+        if(this->m_build)
             this->Clear();
-        assert(this->op_ != NULL && this->op_->GetM() == this->op_->GetN() && this->op_->GetM() > 0);
-        this->build_ = true;
-        if(this->precond_ != NULL)
+        RAMD_EXPECT(this->m_op != nullptr && this->m_op->GetM() == this->m_op->GetN() && this->m_op->GetM() > 0);
+        this->m_build = true;
+        if(this->m_precond != NULL)
         {
-            this->precond_->SetOperator(*this->op_);
-            this->precond_->Build();
-            this->z_.CloneBackend(*this->op_);
-            this->z_.Allocate("z", this->op_->GetM());
-            this->t_.CloneBackend(*this->op_);
-            this->t_.Allocate("t", this->op_->GetM());
+            this->m_precond->SetOperator(*this->m_op);
+            this->m_precond->Build();
+            this->m_z.CloneBackend(*this->m_op);
+            this->m_z.Allocate("z", this->m_op->GetM());
+            this->m_t.CloneBackend(*this->m_op);
+            this->m_t.Allocate("t", this->m_op->GetM());
         }
-        VectorType* all[] = {&this->r_, &this->p_, &this->q_, &this->v_};
+        VectorType* all[] = {&this->m_r, &this->m_p, &this->m_q, &this->m_v};
         for(VectorType* vec : all)
         {
-            vec->CloneBackend(*this->op_);
-            vec->Allocate("cr", this->op_->GetM());
+            vec->CloneBackend(*this->m_op);
+            vec->Allocate("cr", this->m_op->GetM());
         }
     }
     virtual void Clear(void)
     {
-        if(this->build_)
+        if(this->m_build)
         {
-            if(this->precond_ != NULL)
+            if(this->m_precond != NULL)
             {
-                this->precond_->Clear();
-                this->precond_ = NULL;
+                this->m_precond->Clear();
+                this->m_precond = NULL;
             }
-            VectorType* all[] = {&this->r_, &this->p_, &this->q_, &this->v_, &this->z_, &this->t_};
+            VectorType* all[] = {&this->m_r, &this->m_p, &this->m_q, &this->m_v, &this->m_z, &this->m_t};
             for(VectorType* vec : all)
                 vec->Clear();
-            this->iter_ctrl_.Clear();
-            this->build_ = false;
+            this->m_iter_ctrl.Clear();
+            this->m_build = false;
         }
     }
 
 protected:
-    virtual void PrintStart_(void) const
+    virtual void doPrintStart(void) const
     {
-        LOG_INFO((this->precond_ ? "PCR solver starts, with preconditioner:" : "CR (non-precond) linear solver starts"));
+        say((this->m_precond ? "PCR solver starts, with preconditioner:" : "CR (non-precond) linear solver starts"));
     }
-    virtual void PrintEnd_(void) const
+    virtual void doPrintEnd(void) const
     {
-        LOG_INFO((this->precond_ ? "PCR ends" : "CR (non-precond) ends"));
+        say((this->m_precond ? "PCR ends" : "CR (non-precond) ends"));
     }
-    virtual void SolveNonPrecond_(const VectorType& rhs, VectorType* x)
+    virtual void doSolveNonPrecond(const VectorType& rhs, VectorType* x)
     {
-        const OperatorType* op = this->op_;
-        VectorType *r = &this->r_, *p = &this->p_, *q = &this->q_, *v = &this->v_;
+        const OperatorType* op = this->m_op;
+        VectorType *kr = &this->m_r, *kp = &this->m_p, *kq = &this->m_q, *kv = &this->m_v;
         ValueType   alpha, beta, rho, rho_old;
-        op->Apply(*x, r);
-        r->ScaleAdd(static_cast<ValueType>(-1), rhs);
-        p->CopyFrom(*r);
-        ValueType res_norm = this->Norm_(*r);
-        if(this->iter_ctrl_.InitResidual(std::abs(res_norm)) == false)
+        op->Apply(*x, kr);
+        kr->ScaleAdd(num<ValueType>(-1), rhs);
+        kp->CopyFrom(*kr);
+        ValueType res_norm = this->doNorm(*kr);
+        if(this->m_iter_ctrl.InitResidual(std::abs(res_norm)) == false)
             return;
-        op->Apply(*r, v);
-        rho = r->DotNonConj(*v);
-        op->Apply(*p, q);
-        alpha = rho / q->DotNonConj(*q);
-        x->AddScale(*p, alpha);
-        r->AddScale(*q, -alpha);
-        res_norm = this->Norm_(*r);
-        while(!this->iter_ctrl_.CheckResidual(std::abs(res_norm), this->index_))
+        op->Apply(*kr, kv);
+        rho = kr->DotNonConj(*kv);
+        op->Apply(*kp, kq);
+        alpha = rho / kq->DotNonConj(*kq);
+        x->AddScale(*kp, alpha);
+        kr->AddScale(*kq, -alpha);
+        res_norm = this->doNorm(*kr);
+        while(!this->m_iter_ctrl.CheckResidual(std::abs(res_norm), this->m_index))
         {
             rho_old = rho;
-            op->Apply(*r, v);
-            rho  = r->DotNonConj(*v);
+            op->Apply(*kr, kv);
+            rho  = kr->DotNonConj(*kv);
             beta = rho / rho_old;
-            p->ScaleAdd(beta, *r);
-            q->ScaleAdd(beta, *v);
-            alpha = rho / q->DotNonConj(*q);
-            x->AddScale(*p, alpha);
-            r->AddScale(*q, -alpha);
-            res_norm = this->Norm_(*r);
+            kp->ScaleAdd(beta, *kr);
+            kq->ScaleAdd(beta, *kv);
+            alpha = rho / kq->DotNonConj(*kq);
+            x->AddScale(*kp, alpha);
+            kr->AddScale(*kq, -alpha);
+            res_norm = this->doNorm(*kr);
         }
     }
-    virtual void SolvePrecond_(const VectorType& rhs, VectorType* x)
+    virtual void doSolvePrecond(const VectorType& rhs, VectorType* x)
     {
-        const OperatorType* op = this->op_;
-        VectorType *r = &this->r_, *z = &this->z_, *p = &this->p_, *q = &this->q_, *v = &this->v_, *t = &this->t_;
+        const OperatorType* op = this->m_op;
+        VectorType *kr = &this->m_r, *kz = &this->m_z, *kp = &this->m_p, *kq = &this->m_q, *kv = &this->m_v, *kt = &this->m_t;
         ValueType   alpha, beta, rho, rho_old;
-        op->Apply(*x, z);
-        z->ScaleAdd(static_cast<ValueType>(-1), rhs);
-        this->precond_->SolveZeroSol(*z, r);
-        p->CopyFrom(*r);
-        t->CopyFrom(*z);
-        ValueType res_norm = this->Norm_(*t);
-        if(this->iter_ctrl_.InitResidual(std::abs(res_norm)) == false)
+        op->Apply(*x, kz);
+        kz->ScaleAdd(num<ValueType>(-1), rhs);
+        this->m_precond->SolveZeroSol(*kz, kr);
+        kp->CopyFrom(*kr);
+        kt->CopyFrom(*kz);
+        ValueType res_norm = this->doNorm(*kt);
+        if(this->m_iter_ctrl.InitResidual(std::abs(res_norm)) == false)
             return;
-        op->Apply(*r, v);
-        rho = r->DotNonConj(*v);
-        op->Apply(*p, q);
-        this->precond_->SolveZeroSol(*q, z);
-        alpha = rho / q->DotNonConj(*z);
-        x->AddScale(*p, alpha);
-        r->AddScale(*z, -alpha);
-        t->AddScale(*q, -alpha);
-        res_norm = this->Norm_(*t);
-        while(!this->iter_ctrl_.CheckResidual(std::abs(res_norm), this->index_))
+        op->Apply(*kr, kv);
+        rho = kr->DotNonConj(*kv);
+        op->Apply(*kp, kq);
+        this->m_precond->SolveZeroSol(*kq, kz);
+        alpha = rho / kq->DotNonConj(*kz);
+        x->AddScale(*kp, alpha);
+        kr->AddScale(*kz, -alpha);
+        kt->AddScale(*kq, -alpha);
+        res_norm = this->doNorm(*kt);
+        while(!this->m_iter_ctrl.CheckResidual(std::abs(res_norm), this->m_index))
         {
             rho_old = rho;
-            op->Apply(*r, v);
-            rho  = r->DotNonConj(*v);
+            op->Apply(*kr, kv);
+            rho  = kr->DotNonConj(*kv);
             beta = rho / rho_old;
-            p->ScaleAdd(beta, *r);
-            q->ScaleAdd(beta, *v);
-            this->precond_->SolveZeroSol(*q, z);
-            alpha = rho / q->DotNonConj(*z);
-            x->AddScale(*p, alpha);
-            r->AddScale(*z, -alpha);
-            t->AddScale(*q, -alpha);
-            res_norm = this->Norm_(*t);
+            kp->ScaleAdd(beta, *kr);
+            kq->ScaleAdd(beta, *kv);
+            this->m_precond->SolveZeroSol(*kq, kz);
+            alpha = rho / kq->DotNonConj(*kz);
+            x->AddScale(*kp, alpha);
+            kr->AddScale(*kz, -alpha);
+            kt->AddScale(*kq, -alpha);
+            res_norm = this->doNorm(*kt);
         }
     }
 
 private:
-    VectorType r_, z_, p_, q_, v_, t_;
+    VectorType m_r, m_z, m_p, m_q, m_v, m_t;
 };
 
 // ============================================================================ BiCGStab(l)
@@ -2342,9 +2327,9 @@ class BiCGStabl : public IterativeLinearSolver<OperatorType, VectorType, ValueTy
 {
 public:
     BiCGStabl()
-        : l_(2)
-        , r_(NULL)
-        , u_(NULL)
+        : m_l(2)
+        , m_r(NULL)
+        , m_u(NULL)
     {
     }
     virtual ~BiCGStabl()
@@ -2353,158 +2338,158 @@ public:
     }
     virtual void Print(void) const
     {
-        LOG_INFO("BiCGStab(" << this->l_ << ") solver" << (this->precond_ ? ", with preconditioner" : " (non-precond)"));
+        say("BiCGStab(", this->m_l, ") solver", (this->m_precond ? ", with preconditioner" : " (non-precond)"));
     }
     virtual void SetOrder(int l)
     {
-        assert(l > 0 && this->build_ == false);
-        this->l_ = l;
+        RAMD_EXPECT(l > 0 && !this->m_build);
+        this->m_l = l;
     }
     virtual void Build(void)
     {
-        if(this->build_)
+        if(this->m_build)
             this->Clear();
-        assert(this->op_ != NULL && this->op_->GetM() == this->op_->GetN() && this->op_->GetM() > 0);
-        this->build_ = true;
-        if(this->precond_ != NULL)
+        RAMD_EXPECT(this->m_op != nullptr && this->m_op->GetM() == this->m_op->GetN() && this->m_op->GetM() > 0);
+        this->m_build = true;
+        if(this->m_precond != NULL)
         {
-            this->precond_->SetOperator(*this->op_);
-            this->precond_->Build();
-            this->z_.CloneBackend(*this->op_);
-            this->z_.Allocate("z", this->op_->GetM());
+            this->m_precond->SetOperator(*this->m_op);
+            this->m_precond->Build();
+            this->m_z.CloneBackend(*this->m_op);
+            this->m_z.Allocate("z", this->m_op->GetM());
         }
-        this->r0_.CloneBackend(*this->op_);
-        this->r0_.Allocate("r0", this->op_->GetM());
-        const int l = this->l_;
-        this->r_    = new VectorType*[l + 1];
-        this->u_    = new VectorType*[l + 1];
+        this->m_r0.CloneBackend(*this->m_op);
+        this->m_r0.Allocate("r0", this->m_op->GetM());
+        const int l = this->m_l;
+        this->m_r    = new VectorType*[l + 1];
+        this->m_u    = new VectorType*[l + 1];
         for(int i = 0; i < l + 1; ++i)
         {
-            this->r_[i] = new VectorType;
-            this->r_[i]->CloneBackend(*this->op_);
-            this->r_[i]->Allocate("r", this->op_->GetM());
-            this->u_[i] = new VectorType;
-            this->u_[i]->CloneBackend(*this->op_);
-            this->u_[i]->Allocate("u", this->op_->GetM());
+            this->m_r[i] = new VectorType;
+            this->m_r[i]->CloneBackend(*this->m_op);
+            this->m_r[i]->Allocate("r", this->m_op->GetM());
+            this->m_u[i] = new VectorType;
+            this->m_u[i]->CloneBackend(*this->m_op);
+            this->m_u[i]->Allocate("u", this->m_op->GetM());
         }
-        this->gamma0_.assign((size_t)l, ValueType(0));
-        this->gamma1_.assign((size_t)l, ValueType(0));
-        this->gamma2_.assign((size_t)l, ValueType(0));
-        this->sigma_.assign((size_t)l, ValueType(0));
-        this->tau_.assign((size_t)l * l, ValueType(0));
+        this->m_gamma0.assign((size_t)l, ValueType(0));
+        this->m_gamma1.assign((size_t)l, ValueType(0));
+        this->m_gamma2.assign((size_t)l, ValueType(0));
+        this->m_sigma.assign((size_t)l, ValueType(0));
+        this->m_tau.assign((size_t)l * l, ValueType(0));
     }
     virtual void Clear(void)
     {
-        if(this->build_)
+        if(this->m_build)
         {
-            this->r0_.Clear();
-            for(int i = 0; i < this->l_ + 1; ++i)
+            this->m_r0.Clear();
+            for(int i = 0; i < this->m_l + 1; ++i)
             {
-                delete this->r_[i];
-                delete this->u_[i];
+                delete this->m_r[i];
+                delete this->m_u[i];
             }
-            delete[] this->r_;
-            delete[] this->u_;
-            this->r_ = this->u_ = NULL;
-            if(this->precond_ != NULL)
+            delete[] this->m_r;
+            delete[] this->m_u;
+            this->m_r = this->m_u = NULL;
+            if(this->m_precond != NULL)
             {
-                this->precond_->Clear();
-                this->precond_ = NULL;
-                this->z_.Clear();
+                this->m_precond->Clear();
+                this->m_precond = NULL;
+                this->m_z.Clear();
             }
-            this->iter_ctrl_.Clear();
-            this->build_ = false;
+            this->m_iter_ctrl.Clear();
+            this->m_build = false;
         }
     }
 
 protected:
-    virtual void PrintStart_(void) const
+    virtual void doPrintStart(void) const
     {
-        LOG_INFO("BiCGStab(" << this->l_ << ") " << (this->precond_ ? "" : "(non-precond) ") << "linear solver starts");
+        say("BiCGStab(", this->m_l, ") ", (this->m_precond ? "" : "(non-precond) "), "linear solver starts");
     }
-    virtual void PrintEnd_(void) const
+    virtual void doPrintEnd(void) const
     {
-        LOG_INFO("BiCGStab(" << this->l_ << ") ends");
+        say("BiCGStab(", this->m_l, ") ends");
     }
-    virtual void SolveNonPrecond_(const VectorType& rhs, VectorType* x)
+    virtual void doSolveNonPrecond(const VectorType& rhs, VectorType* x)
     {
-        this->Solve_(rhs, x, false);
+        this->doSolve(rhs, x, false);
     }
-    virtual void SolvePrecond_(const VectorType& rhs, VectorType* x)
+    virtual void doSolvePrecond(const VectorType& rhs, VectorType* x)
     {
-        this->Solve_(rhs, x, true);
+        this->doSolve(rhs, x, true);
     }
 
 private:
-    // y = A in  (followed by M^-1 when preconditioned)
-    void ApplyPrec_(const VectorType& in, VectorType* out, bool precond)
+    // ky = A in  (followed by M^-1 when preconditioned)
+    void doApplyPrec(const VectorType& in, VectorType* out, bool precond)
     {
         if(precond)
         {
-            this->op_->Apply(in, &this->z_);
-            this->precond_->SolveZeroSol(this->z_, out);
+            this->m_op->Apply(in, &this->m_z);
+            this->m_precond->SolveZeroSol(this->m_z, out);
         }
         else
-            this->op_->Apply(in, out);
+            this->m_op->Apply(in, out);
     }
-    void Solve_(const VectorType& rhs, VectorType* x, bool precond)
+    void doSolve(const VectorType& rhs, VectorType* x, bool precond)
     {
-        VectorType*  r0 = &this->r0_;
-        VectorType** r  = this->r_;
-        VectorType** u  = this->u_;
-        const int    l  = this->l_;
+        VectorType*  r0 = &this->m_r0;
+        VectorType** kr  = this->m_r;
+        VectorType** ku  = this->m_u;
+        const int    l  = this->m_l;
         bool         converged = false;
-        ValueType    alpha = static_cast<ValueType>(0), beta = static_cast<ValueType>(0);
-        ValueType    omega = static_cast<ValueType>(1), rho_old = static_cast<ValueType>(-1), rho;
-        ValueType *  gamma0 = this->gamma0_.data(), *gamma1 = this->gamma1_.data();
-        ValueType *  gamma2 = this->gamma2_.data(), *sigma = this->sigma_.data(), *tau = this->tau_.data();
-        const ValueType zero = static_cast<ValueType>(0);
+        ValueType    alpha = num<ValueType>(0), beta = num<ValueType>(0);
+        ValueType    omega = num<ValueType>(1), rho_old = num<ValueType>(-1), rho;
+        ValueType *  gamma0 = this->m_gamma0.data(), *gamma1 = this->m_gamma1.data();
+        ValueType *  gamma2 = this->m_gamma2.data(), *sigma = this->m_sigma.data(), *tau = this->m_tau.data();
+        const ValueType zero = num<ValueType>(0);
         if(precond)
         {
-            this->op_->Apply(*x, &this->z_);
-            this->z_.ScaleAdd(static_cast<ValueType>(-1), rhs);
-            this->precond_->SolveZeroSol(this->z_, r0);
+            this->m_op->Apply(*x, &this->m_z);
+            this->m_z.ScaleAdd(num<ValueType>(-1), rhs);
+            this->m_precond->SolveZeroSol(this->m_z, r0);
         }
         else
         {
-            this->op_->Apply(*x, r0);
-            r0->ScaleAdd(static_cast<ValueType>(-1), rhs);
+            this->m_op->Apply(*x, r0);
+            r0->ScaleAdd(num<ValueType>(-1), rhs);
         }
-        ValueType res = this->Norm_(*r0);
-        this->iter_ctrl_.InitResidual(std::abs(res));
-        r[0]->CopyFrom(*r0);
-        u[0]->Zeros();
+        ValueType res = this->doNorm(*r0);
+        this->m_iter_ctrl.InitResidual(std::abs(res));
+        kr[0]->CopyFrom(*r0);
+        ku[0]->Zeros();
         while(true)
         {
             rho_old *= -omega;
             for(int j = 0; j < l; ++j) // BiCG part
             {
-                rho = r0->Dot(*r[j]);
+                rho = r0->Dot(*kr[j]);
                 if(rho == zero)
                 {
-                    LOG_INFO("BiCGStab(l) rho == 0 !!!");
+                    say("BiCGStab(l) rho == 0 !!!");
                     converged = true;
                     break;
                 }
                 beta = alpha * rho / rho_old;
                 for(int i = 0; i <= j; ++i)
-                    u[i]->ScaleAdd(-beta, *r[i]);
-                this->ApplyPrec_(*u[j], u[j + 1], precond);
-                rho_old = r0->Dot(*u[j + 1]);
+                    ku[i]->ScaleAdd(-beta, *kr[i]);
+                this->doApplyPrec(*ku[j], ku[j + 1], precond);
+                rho_old = r0->Dot(*ku[j + 1]);
                 if(rho_old == zero)
                 {
-                    LOG_INFO("BiCGStab(l) sigma == 0 !!!");
+                    say("BiCGStab(l) sigma == 0 !!!");
                     converged = true;
                     break;
                 }
                 alpha   = rho / rho_old;
                 rho_old = rho;
                 for(int i = 0; i <= j; ++i)
-                    r[i]->AddScale(*u[i + 1], -alpha);
-                this->ApplyPrec_(*r[j], r[j + 1], precond);
-                x->AddScale(*u[0], alpha);
-                res = this->Norm_(*r[0]);
-                if(this->iter_ctrl_.CheckResidualNoCount(std::abs(res)))
+                    kr[i]->AddScale(*ku[i + 1], -alpha);
+                this->doApplyPrec(*kr[j], kr[j + 1], precond);
+                x->AddScale(*ku[0], alpha);
+                res = this->doNorm(*kr[0]);
+                if(this->m_iter_ctrl.CheckResidualNoCount(std::abs(res)))
                 {
                     converged = true;
                     break;
@@ -2516,11 +2501,11 @@ private:
             {
                 for(int i = 0; i < j; ++i)
                 {
-                    tau[i * l + j] = r[j + 1]->Dot(*r[i + 1]) / sigma[i];
-                    r[j + 1]->AddScale(*r[i + 1], -tau[i * l + j]);
+                    tau[i * l + j] = kr[j + 1]->Dot(*kr[i + 1]) / sigma[i];
+                    kr[j + 1]->AddScale(*kr[i + 1], -tau[i * l + j]);
                 }
-                sigma[j]  = r[j + 1]->Dot(*r[j + 1]);
-                gamma1[j] = r[0]->Dot(*r[j + 1]) / sigma[j];
+                sigma[j]  = kr[j + 1]->Dot(*kr[j + 1]);
+                gamma1[j] = kr[0]->Dot(*kr[j + 1]) / sigma[j];
             }
             gamma0[l - 1] = gamma1[l - 1];
             omega         = gamma1[l - 1];
@@ -2536,25 +2521,25 @@ private:
                 for(int i = j + 1; i < l - 1; ++i)
                     gamma2[j] += tau[j * l + i] * gamma0[i + 1];
             }
-            x->AddScale(*r[0], gamma0[0]);
-            r[0]->AddScale(*r[l], -gamma1[l - 1]);
-            u[0]->AddScale(*u[l], -gamma0[l - 1]);
+            x->AddScale(*kr[0], gamma0[0]);
+            kr[0]->AddScale(*kr[l], -gamma1[l - 1]);
+            ku[0]->AddScale(*ku[l], -gamma0[l - 1]);
             for(int j = 1; j < l; ++j)
             {
-                u[0]->AddScale(*u[j], -gamma0[j - 1]);
-                x->AddScale(*r[j], gamma2[j - 1]);
-                r[0]->AddScale(*r[j], -gamma1[j - 1]);
+                ku[0]->AddScale(*ku[j], -gamma0[j - 1]);
+                x->AddScale(*kr[j], gamma2[j - 1]);
+                kr[0]->AddScale(*kr[j], -gamma1[j - 1]);
             }
-            res = this->Norm_(*r[0]);
-            if(this->iter_ctrl_.CheckResidual(std::abs(res), this->index_))
+            res = this->doNorm(*kr[0]);
+            if(this->m_iter_ctrl.CheckResidual(std::abs(res), this->m_index))
                 break;
         }
     }
-    int                    l_;
-    VectorType             r0_, z_;
-    VectorType**           r_;
-    VectorType**           u_;
-    std::vector<ValueType> gamma0_, gamma1_, gamma2_, sigma_, tau_;
+    int                    m_l;
+    VectorType             m_r0, m_z;
+    VectorType**           m_r;
+    VectorType**           m_u;
+    std::vector<ValueType> m_gamma0, m_gamma1, m_gamma2, m_sigma, m_tau;
 };
 
 // ============================================================================ QMRCGStab
@@ -2571,177 +2556,177 @@ public:
     }
     virtual void Print(void) const
     {
-        LOG_INFO("QMRCGStab solver" << (this->precond_ ? ", with preconditioner" : " (non-precond)"));
+        say("QMRCGStab solver", (this->m_precond ? ", with preconditioner" : " (non-precond)"));
     }
     virtual void Build(void)
     {
-        if(this->build_)
+        if(this->m_build)
             this->Clear();
-        assert(this->op_ != NULL && this->op_->GetM() == this->op_->GetN() && this->op_->GetM() > 0);
-        this->build_ = true;
-        if(this->precond_ != NULL)
+        RAMD_EXPECT(this->m_op != nullptr && this->m_op->GetM() == this->m_op->GetN() && this->m_op->GetM() > 0);
+        this->m_build = true;
+        if(this->m_precond != NULL)
         {
-            this->precond_->SetOperator(*this->op_);
-            this->precond_->Build();
-            this->z_.CloneBackend(*this->op_);
-            this->z_.Allocate("z", this->op_->GetM());
+            this->m_precond->SetOperator(*this->m_op);
+            this->m_precond->Build();
+            this->m_z.CloneBackend(*this->m_op);
+            this->m_z.Allocate("z", this->m_op->GetM());
         }
-        VectorType* all[] = {&this->r0_, &this->r_, &this->p_, &this->t_, &this->v_, &this->d_};
+        VectorType* all[] = {&this->m_r0, &this->m_r, &this->m_p, &this->m_t, &this->m_v, &this->m_d};
         for(VectorType* vec : all)
         {
-            vec->CloneBackend(*this->op_);
-            vec->Allocate("qmrcgstab", this->op_->GetM());
+            vec->CloneBackend(*this->m_op);
+            vec->Allocate("qmrcgstab", this->m_op->GetM());
         }
     }
     virtual void Clear(void)
     {
-        if(this->build_)
+        if(this->m_build)
         {
-            if(this->precond_ != NULL)
+            if(this->m_precond != NULL)
             {
-                this->precond_->Clear();
-                this->precond_ = NULL;
+                this->m_precond->Clear();
+                this->m_precond = NULL;
             }
-            VectorType* all[] = {&this->r0_, &this->r_, &this->p_, &this->t_, &this->v_, &this->d_, &this->z_};
+            VectorType* all[] = {&this->m_r0, &this->m_r, &this->m_p, &this->m_t, &this->m_v, &this->m_d, &this->m_z};
             for(VectorType* vec : all)
                 vec->Clear();
-            this->iter_ctrl_.Clear();
-            this->build_ = false;
+            this->m_iter_ctrl.Clear();
+            this->m_build = false;
         }
     }
 
 protected:
-    virtual void PrintStart_(void) const
+    virtual void doPrintStart(void) const
     {
-        LOG_INFO("QMRCGStab " << (this->precond_ ? "" : "(non-precond) ") << "linear solver starts");
+        say("QMRCGStab ", (this->m_precond ? "" : "(non-precond) "), "linear solver starts");
     }
-    virtual void PrintEnd_(void) const
+    virtual void doPrintEnd(void) const
     {
-        LOG_INFO("QMRCGStab ends");
+        say("QMRCGStab ends");
     }
-    virtual void SolveNonPrecond_(const VectorType& rhs, VectorType* x)
+    virtual void doSolveNonPrecond(const VectorType& rhs, VectorType* x)
     {
-        this->Solve_(rhs, x, false);
+        this->doSolve(rhs, x, false);
     }
-    virtual void SolvePrecond_(const VectorType& rhs, VectorType* x)
+    virtual void doSolvePrecond(const VectorType& rhs, VectorType* x)
     {
-        this->Solve_(rhs, x, true);
+        this->doSolve(rhs, x, true);
     }
 
 private:
-    void Solve_(const VectorType& rhs, VectorType* x, bool precond)
+    void doSolve(const VectorType& rhs, VectorType* x, bool precond)
     {
-        const OperatorType* op = this->op_;
-        VectorType *r0 = &this->r0_, *r = &this->r_, *p = &this->p_, *t = &this->t_, *v = &this->v_, *d = &this->d_;
-        VectorType* z = &this->z_;
-        VectorType* pz = precond ? z : p; // what A is applied to in the first half step
-        VectorType* rz = precond ? z : r; // ... and in the second
-        const ValueType one = static_cast<ValueType>(1), zero = static_cast<ValueType>(0);
+        const OperatorType* op = this->m_op;
+        VectorType *r0 = &this->m_r0, *kr = &this->m_r, *kp = &this->m_p, *kt = &this->m_t, *kv = &this->m_v, *kd = &this->m_d;
+        VectorType* kz = &this->m_z;
+        VectorType* pz = precond ? kz : kp; // what A is applied to in the first half step
+        VectorType* rz = precond ? kz : kr; // ... and in the second
+        const ValueType one = num<ValueType>(1), zero = num<ValueType>(0);
         ValueType alpha, beta, omega, theta1, theta1sq, theta2, theta2sq, eta1, eta2, tau1, tau2, rho, rho_old, c;
         op->Apply(*x, r0);
         r0->ScaleAdd(-one, rhs);
-        r->CopyFrom(*r0);
-        tau2            = this->Norm_(*r0);
+        kr->CopyFrom(*r0);
+        tau2            = this->doNorm(*r0);
         double res_norm = std::abs(tau2);
-        this->iter_ctrl_.InitResidual(res_norm);
-        rho  = r0->Dot(*r);
+        this->m_iter_ctrl.InitResidual(res_norm);
+        rho  = r0->Dot(*kr);
         beta = rho;
         (void)beta;
-        p->AddScale(*r, one);
+        kp->AddScale(*kr, one);
         if(precond)
-            this->precond_->SolveZeroSol(*p, z);
-        op->Apply(*pz, v);
-        rho_old = r0->Dot(*v);
+            this->m_precond->SolveZeroSol(*kp, kz);
+        op->Apply(*pz, kv);
+        rho_old = r0->Dot(*kv);
         alpha   = rho / rho_old;
-        r->AddScale(*v, -alpha);
-        theta1   = this->Norm_(*r) / tau2;
+        kr->AddScale(*kv, -alpha);
+        theta1   = this->doNorm(*kr) / tau2;
         theta1sq = theta1 * theta1;
         c        = one / std::sqrt(one + theta1sq);
         tau1     = tau2 * theta1 * c;
         eta1     = c * c * alpha;
-        d->CopyFrom(*pz);
-        x->AddScale(*d, eta1);
+        kd->CopyFrom(*pz);
+        x->AddScale(*kd, eta1);
         if(precond)
-            this->precond_->SolveZeroSol(*r, z);
-        op->Apply(*rz, t);
-        omega = t->Dot(*r) / t->Dot(*t);
-        d->ScaleAdd(theta1sq * eta1 / omega, *rz);
-        r->AddScale(*t, -omega);
-        theta2   = this->Norm_(*r) / tau1;
+            this->m_precond->SolveZeroSol(*kr, kz);
+        op->Apply(*rz, kt);
+        omega = kt->Dot(*kr) / kt->Dot(*kt);
+        kd->ScaleAdd(theta1sq * eta1 / omega, *rz);
+        kr->AddScale(*kt, -omega);
+        theta2   = this->doNorm(*kr) / tau1;
         theta2sq = theta2 * theta2;
         c        = one / std::sqrt(one + theta2sq);
         tau2     = tau1 * theta2 * c;
         eta2     = c * c * omega;
-        x->AddScale(*d, eta2);
-        res_norm = std::sqrt(static_cast<double>(this->iter_ctrl_.GetIterationCount() + 1)) * std::abs(tau2);
-        while(!this->iter_ctrl_.CheckResidual(res_norm, this->index_))
+        x->AddScale(*kd, eta2);
+        res_norm = std::sqrt(static_cast<double>(this->m_iter_ctrl.GetIterationCount() + 1)) * std::abs(tau2);
+        while(!this->m_iter_ctrl.CheckResidual(res_norm, this->m_index))
         {
             rho_old = rho;
-            rho     = r0->Dot(*r);
+            rho     = r0->Dot(*kr);
             beta    = (rho * alpha) / (rho_old * omega);
-            p->AddScale(*v, -omega);
-            p->Scale(beta);
-            p->AddScale(*r, one);
+            kp->AddScale(*kv, -omega);
+            kp->Scale(beta);
+            kp->AddScale(*kr, one);
             if(precond)
-                this->precond_->SolveZeroSol(*p, z);
-            op->Apply(*pz, v);
-            rho_old = r0->Dot(*v);
+                this->m_precond->SolveZeroSol(*kp, kz);
+            op->Apply(*pz, kv);
+            rho_old = r0->Dot(*kv);
             if(rho_old == zero)
             {
-                LOG_INFO("QMRCGStab break rho_old == 0 !!!");
+                say("QMRCGStab break rho_old == 0 !!!");
                 break;
             }
             alpha = rho / rho_old;
-            r->AddScale(*v, -alpha);
-            theta1   = this->Norm_(*r) / tau2;
+            kr->AddScale(*kv, -alpha);
+            theta1   = this->doNorm(*kr) / tau2;
             theta1sq = theta1 * theta1;
             c        = one / std::sqrt(one + theta1sq);
             tau1     = tau2 * theta1 * c;
             eta1     = c * c * alpha;
-            d->ScaleAdd(theta2sq * eta2 / alpha, *pz);
-            x->AddScale(*d, eta1);
+            kd->ScaleAdd(theta2sq * eta2 / alpha, *pz);
+            x->AddScale(*kd, eta1);
             if(precond)
-                this->precond_->SolveZeroSol(*r, z);
-            op->Apply(*rz, t);
-            omega = t->Dot(*t);
+                this->m_precond->SolveZeroSol(*kr, kz);
+            op->Apply(*rz, kt);
+            omega = kt->Dot(*kt);
             if(omega == zero)
             {
-                LOG_INFO("QMRCGStab omega == 0 !!!");
+                say("QMRCGStab omega == 0 !!!");
                 break;
             }
-            omega = t->Dot(*r) / omega;
-            d->ScaleAdd(theta1sq * eta1 / omega, *rz);
-            r->AddScale(*t, -omega);
-            theta2   = this->Norm_(*r) / tau1;
+            omega = kt->Dot(*kr) / omega;
+            kd->ScaleAdd(theta1sq * eta1 / omega, *rz);
+            kr->AddScale(*kt, -omega);
+            theta2   = this->doNorm(*kr) / tau1;
             theta2sq = theta2 * theta2;
             c        = one / std::sqrt(one + theta2sq);
             tau2     = tau1 * theta2 * c;
             eta2     = c * c * omega;
-            x->AddScale(*d, eta2);
-            res_norm = std::sqrt(static_cast<double>(this->iter_ctrl_.GetIterationCount() + 1)) * std::abs(tau2);
+            x->AddScale(*kd, eta2);
+            res_norm = std::sqrt(static_cast<double>(this->m_iter_ctrl.GetIterationCount() + 1)) * std::abs(tau2);
         }
         op->Apply(*x, r0);
         r0->ScaleAdd(-one, rhs);
-        this->iter_ctrl_.CheckResidual(std::abs(this->Norm_(*r0)));
+        this->m_iter_ctrl.CheckResidual(std::abs(this->doNorm(*r0)));
     }
-    VectorType r0_, r_, p_, t_, v_, d_, z_;
+    VectorType m_r0, m_r, m_p, m_t, m_v, m_d, m_z;
 };
 
 // ============================================================================ IDR(s)
-// src/solvers/krylov/idr.cpp: Build :127-185 (shadow space: s random-normal vectors, seed (i+1)*seed_,
-// made orthonormal by modified Gram-Schmidt), SolveNonPrecond_ :335-520, SolvePrecond_ :523-730.
+// src/solvers/krylov/idr.cpp: Build :127-185 (shadow space: s random-normal vectors, seed (i+1)*m_seed,
+// made orthonormal by modified Gram-Schmidt), doSolveNonPrecond :335-520, doSolvePrecond :523-730.
 // The default seed is time(NULL) as in the reference: call SetRandomSeed for reproducible runs.
 template <class OperatorType, class VectorType, typename ValueType>
 class IDR : public IterativeLinearSolver<OperatorType, VectorType, ValueType>
 {
 public:
     IDR()
-        : s_(4)
-        , seed_((unsigned long long)time(NULL))
-        , kappa_(static_cast<ValueType>(0.7f))
-        , G_(NULL)
-        , U_(NULL)
-        , P_(NULL)
+        : m_s(4)
+        , m_seed((unsigned long long)time(NULL))
+        , m_kappa(num<ValueType>(0.7f))
+        , m_G(NULL)
+        , m_U(NULL)
+        , m_P(NULL)
     {
     }
     virtual ~IDR()
@@ -2750,246 +2735,246 @@ public:
     }
     virtual void Print(void) const
     {
-        LOG_INFO("IDR(" << this->s_ << ") solver" << (this->precond_ ? ", with preconditioner" : " (non-precond)"));
+        say("IDR(", this->m_s, ") solver", (this->m_precond ? ", with preconditioner" : " (non-precond)"));
     }
-    void SetShadowSpace(int s)
+    void SetShadowSpace(int ks)
     {
-        assert(this->build_ == false && s > 0);
-        this->s_ = s;
+        RAMD_EXPECT(!this->m_build && ks > 0);
+        this->m_s = ks;
     }
     void SetRandomSeed(unsigned long long seed)
     {
-        assert(this->build_ == false && seed > 0ULL);
-        this->seed_ = seed;
+        RAMD_EXPECT(!this->m_build && seed > 0ULL);
+        this->m_seed = seed;
     }
     virtual void Build(void)
     {
-        if(this->build_)
+        if(this->m_build)
             this->Clear();
-        assert(this->op_ != NULL && this->op_->GetM() == this->op_->GetN() && this->op_->GetM() > 0);
-        assert((int64_t)this->s_ <= this->op_->GetM());
-        const int s = this->s_;
-        this->r_.CloneBackend(*this->op_);
-        this->v_.CloneBackend(*this->op_);
-        this->r_.Allocate("r", this->op_->GetM());
-        this->v_.Allocate("v", this->op_->GetM());
-        this->c_.assign((size_t)s, ValueType(0));
-        this->f_.assign((size_t)s, ValueType(0));
-        this->M_.assign((size_t)s * s, ValueType(0));
-        this->G_ = new VectorType*[s];
-        this->U_ = new VectorType*[s];
-        this->P_ = new VectorType*[s];
-        for(int i = 0; i < s; ++i)
+        RAMD_EXPECT(this->m_op != nullptr && this->m_op->GetM() == this->m_op->GetN() && this->m_op->GetM() > 0);
+        RAMD_EXPECT((int64_t)this->m_s <= this->m_op->GetM());
+        const int ks = this->m_s;
+        this->m_r.CloneBackend(*this->m_op);
+        this->m_v.CloneBackend(*this->m_op);
+        this->m_r.Allocate("r", this->m_op->GetM());
+        this->m_v.Allocate("v", this->m_op->GetM());
+        this->m_c.assign((size_t)ks, ValueType(0));
+        this->m_f.assign((size_t)ks, ValueType(0));
+        this->m_M.assign((size_t)ks * ks, ValueType(0));
+        this->m_G = new VectorType*[ks];
+        this->m_U = new VectorType*[ks];
+        this->m_P = new VectorType*[ks];
+        for(int i = 0; i < ks; ++i)
         {
-            this->G_[i] = new VectorType;
-            this->U_[i] = new VectorType;
-            this->P_[i] = new VectorType;
-            this->G_[i]->CloneBackend(*this->op_);
-            this->U_[i]->CloneBackend(*this->op_);
-            this->P_[i]->CloneBackend(*this->op_);
-            this->G_[i]->Allocate("g", this->op_->GetM());
-            this->U_[i]->Allocate("u", this->op_->GetM());
-            this->P_[i]->Allocate("P", this->op_->GetM());
-            this->P_[i]->SetRandomNormal((unsigned long long)(i + 1) * this->seed_, 0.0, 1.0);
+            this->m_G[i] = new VectorType;
+            this->m_U[i] = new VectorType;
+            this->m_P[i] = new VectorType;
+            this->m_G[i]->CloneBackend(*this->m_op);
+            this->m_U[i]->CloneBackend(*this->m_op);
+            this->m_P[i]->CloneBackend(*this->m_op);
+            this->m_G[i]->Allocate("g", this->m_op->GetM());
+            this->m_U[i]->Allocate("u", this->m_op->GetM());
+            this->m_P[i]->Allocate("P", this->m_op->GetM());
+            this->m_P[i]->SetRandomNormal((unsigned long long)(i + 1) * this->m_seed, 0.0, 1.0);
         }
-        if(this->precond_ != NULL)
+        if(this->m_precond != NULL)
         {
-            this->precond_->SetOperator(*this->op_);
-            this->precond_->Build();
-            this->t_.CloneBackend(*this->op_);
-            this->t_.Allocate("t", this->op_->GetM());
+            this->m_precond->SetOperator(*this->m_op);
+            this->m_precond->Build();
+            this->m_t.CloneBackend(*this->m_op);
+            this->m_t.Allocate("t", this->m_op->GetM());
         }
-        for(int k = 0; k < s; ++k) // orthonormal basis of the shadow space (modified Gram-Schmidt)
+        for(int k = 0; k < ks; ++k) // orthonormal basis of the shadow space (modified Gram-Schmidt)
         {
-            this->P_[k]->Scale(static_cast<ValueType>(1) / this->P_[k]->Norm());
-            ValueType invdotk = static_cast<ValueType>(1) / this->P_[k]->Dot(*this->P_[k]);
-            for(int j = k + 1; j < s; ++j)
-                this->P_[j]->AddScale(*this->P_[k], -this->P_[j]->Dot(*this->P_[k]) * invdotk);
+            this->m_P[k]->Scale(num<ValueType>(1) / this->m_P[k]->Norm());
+            ValueType invdotk = num<ValueType>(1) / this->m_P[k]->Dot(*this->m_P[k]);
+            for(int j = k + 1; j < ks; ++j)
+                this->m_P[j]->AddScale(*this->m_P[k], -this->m_P[j]->Dot(*this->m_P[k]) * invdotk);
         }
-        this->build_ = true;
+        this->m_build = true;
     }
     virtual void Clear(void)
     {
-        if(this->build_)
+        if(this->m_build)
         {
-            this->r_.Clear();
-            this->v_.Clear();
-            this->t_.Clear();
-            for(int i = 0; i < this->s_; ++i)
+            this->m_r.Clear();
+            this->m_v.Clear();
+            this->m_t.Clear();
+            for(int i = 0; i < this->m_s; ++i)
             {
-                delete this->U_[i];
-                delete this->G_[i];
-                delete this->P_[i];
+                delete this->m_U[i];
+                delete this->m_G[i];
+                delete this->m_P[i];
             }
-            delete[] this->U_;
-            delete[] this->G_;
-            delete[] this->P_;
-            this->U_ = this->G_ = this->P_ = NULL;
-            if(this->precond_ != NULL)
+            delete[] this->m_U;
+            delete[] this->m_G;
+            delete[] this->m_P;
+            this->m_U = this->m_G = this->m_P = NULL;
+            if(this->m_precond != NULL)
             {
-                this->precond_->Clear();
-                this->precond_ = NULL;
+                this->m_precond->Clear();
+                this->m_precond = NULL;
             }
-            this->iter_ctrl_.Clear();
-            this->build_ = false;
+            this->m_iter_ctrl.Clear();
+            this->m_build = false;
         }
     }
 
 protected:
-    virtual void PrintStart_(void) const
+    virtual void doPrintStart(void) const
     {
-        LOG_INFO((this->precond_ ? "PIDR(" : "IDR(") << this->s_ << (this->precond_ ? ") solver starts, with preconditioner:" : ") (non-precond) linear solver starts"));
+        say((this->m_precond ? "PIDR(" : "IDR("), this->m_s, (this->m_precond ? ") solver starts, with preconditioner:" : ") (non-precond) linear solver starts"));
     }
-    virtual void PrintEnd_(void) const
+    virtual void doPrintEnd(void) const
     {
-        LOG_INFO((this->precond_ ? "PIDR(" : "IDR(") << this->s_ << (this->precond_ ? ") ends" : ") (non-precond) ends"));
+        say((this->m_precond ? "PIDR(" : "IDR("), this->m_s, (this->m_precond ? ") ends" : ") (non-precond) ends"));
     }
-    virtual void SolveNonPrecond_(const VectorType& rhs, VectorType* x)
+    virtual void doSolveNonPrecond(const VectorType& rhs, VectorType* x)
     {
-        this->Solve_(rhs, x, false);
+        this->doSolve(rhs, x, false);
     }
-    virtual void SolvePrecond_(const VectorType& rhs, VectorType* x)
+    virtual void doSolvePrecond(const VectorType& rhs, VectorType* x)
     {
-        this->Solve_(rhs, x, true);
+        this->doSolve(rhs, x, true);
     }
 
 private:
-    int mind_(int i, int j) const // DENSE_IND(i, j, s, s), column-major
+    int m_mind(int i, int j) const // DENSE_IND(i, j, ks, ks), column-major
     {
-        return i + j * this->s_;
+        return i + j * this->m_s;
     }
-    void Breakdown_(const char* what) const
+    void doBreakdown(const char* what) const
     {
-        LOG_INFO("IDR(s) break down ; " << what);
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("IDR(s) break down ; ", what);
+        RAMD_DIE();
     }
-    void CheckScalar_(ValueType val, const char* z, const char* nan, const char* inf) const
+    void doCheckScalar(ValueType val, const char* kz, const char* nan, const char* inf) const
     {
-        if(val == static_cast<ValueType>(0))
-            this->Breakdown_(z);
+        if(val == num<ValueType>(0))
+            this->doBreakdown(kz);
         if(val != val)
-            this->Breakdown_(nan);
+            this->doBreakdown(nan);
         if(val == std::numeric_limits<ValueType>::infinity())
-            this->Breakdown_(inf);
+            this->doBreakdown(inf);
     }
-    void Solve_(const VectorType& rhs, VectorType* x, bool precond)
+    void doSolve(const VectorType& rhs, VectorType* x, bool precond)
     {
-        const OperatorType* op = this->op_;
-        VectorType *        r = &this->r_, *v = &this->v_, *t = &this->t_;
-        VectorType **       G = this->G_, **U = this->U_, **P = this->P_;
-        const int           s = this->s_;
-        const ValueType     zero = static_cast<ValueType>(0), one = static_cast<ValueType>(1), kappa = this->kappa_;
-        ValueType *         c = this->c_.data(), *f = this->f_.data(), *M = this->M_.data();
+        const OperatorType* op = this->m_op;
+        VectorType *        kr = &this->m_r, *kv = &this->m_v, *kt = &this->m_t;
+        VectorType **       G = this->m_G, **U = this->m_U, **P = this->m_P;
+        const int           ks = this->m_s;
+        const ValueType     zero = num<ValueType>(0), one = num<ValueType>(1), kappa = this->m_kappa;
+        ValueType *         c = this->m_c.data(), *f = this->m_f.data(), *M = this->m_M.data();
         ValueType           alpha, beta, rho, omega = one;
-        op->Apply(*x, r);
-        r->ScaleAdd(-one, rhs);
-        ValueType res_norm = this->Norm_(*r);
-        if(this->iter_ctrl_.InitResidual(std::abs(res_norm)) == false)
+        op->Apply(*x, kr);
+        kr->ScaleAdd(-one, rhs);
+        ValueType res_norm = this->doNorm(*kr);
+        if(this->m_iter_ctrl.InitResidual(std::abs(res_norm)) == false)
             return;
-        for(int i = 0; i < s; ++i)
+        for(int i = 0; i < ks; ++i)
         {
             G[i]->Zeros();
             U[i]->Zeros();
-            for(int j = 0; j < s; ++j)
-                M[this->mind_(i, j)] = (i == j) ? one : zero;
+            for(int j = 0; j < ks; ++j)
+                M[this->m_mind(i, j)] = (i == j) ? one : zero;
         }
         while(true)
         {
-            for(int i = 0; i < s; ++i) // f = P^T r
-                f[i] = P[i]->Dot(*r);
-            for(int k = 0; k < s; ++k) // loop over the shadow space
+            for(int i = 0; i < ks; ++i) // f = P^T kr
+                f[i] = P[i]->Dot(*kr);
+            for(int k = 0; k < ks; ++k) // loop over the shadow space
             {
-                v->CopyFrom(*r);
-                for(int i = k; i < s; ++i) // lower triangular system M c = f
+                kv->CopyFrom(*kr);
+                for(int i = k; i < ks; ++i) // lower triangular system M c = f
                 {
                     c[i] = f[i];
                     for(int j = k; j < i; ++j)
-                        c[i] -= M[this->mind_(i, j)] * c[j];
-                    c[i] /= M[this->mind_(i, i)];
-                    v->AddScale(*G[i], -c[i]);
+                        c[i] -= M[this->m_mind(i, j)] * c[j];
+                    c[i] /= M[this->m_mind(i, i)];
+                    kv->AddScale(*G[i], -c[i]);
                 }
                 if(precond)
                 {
-                    this->precond_->SolveZeroSol(*v, t);
-                    U[k]->ScaleAddScale(c[k], *t, omega);
+                    this->m_precond->SolveZeroSol(*kv, kt);
+                    U[k]->ScaleAddScale(c[k], *kt, omega);
                 }
                 else
-                    U[k]->ScaleAddScale(c[k], *v, omega);
-                for(int i = k + 1; i < s; ++i)
+                    U[k]->ScaleAddScale(c[k], *kv, omega);
+                for(int i = k + 1; i < ks; ++i)
                     U[k]->AddScale(*U[i], c[i]);
                 op->Apply(*U[k], G[k]);
                 for(int i = 0; i < k; ++i) // make G_k orthogonal to P
                 {
-                    alpha = P[i]->Dot(*G[k]) / M[this->mind_(i, i)];
+                    alpha = P[i]->Dot(*G[k]) / M[this->m_mind(i, i)];
                     G[k]->AddScale(*G[i], -alpha);
                     U[k]->AddScale(*U[i], -alpha);
                 }
-                for(int i = k; i < s; ++i)
-                    M[this->mind_(i, k)] = P[i]->Dot(*G[k]);
-                this->CheckScalar_(M[this->mind_(k, k)], "M(k,k) == 0.0", "M(k,k) == NaN", "M(k,k) == inf");
-                beta = f[k] / M[this->mind_(k, k)];
-                r->AddScale(*G[k], -beta);
+                for(int i = k; i < ks; ++i)
+                    M[this->m_mind(i, k)] = P[i]->Dot(*G[k]);
+                this->doCheckScalar(M[this->m_mind(k, k)], "M(k,k) == 0.0", "M(k,k) == NaN", "M(k,k) == inf");
+                beta = f[k] / M[this->m_mind(k, k)];
+                kr->AddScale(*G[k], -beta);
                 x->AddScale(*U[k], beta);
-                res_norm = this->Norm_(*r);
-                if(this->iter_ctrl_.CheckResidualNoCount(std::abs(res_norm)))
+                res_norm = this->doNorm(*kr);
+                if(this->m_iter_ctrl.CheckResidualNoCount(std::abs(res_norm)))
                     break;
-                for(int i = k + 1; i < s; ++i)
-                    f[i] -= beta * M[this->mind_(i, k)];
+                for(int i = k + 1; i < ks; ++i)
+                    f[i] -= beta * M[this->m_mind(i, k)];
             }
-            if(this->iter_ctrl_.CheckResidual(std::abs(res_norm), this->index_))
+            if(this->m_iter_ctrl.CheckResidual(std::abs(res_norm), this->m_index))
                 break;
             ValueType rt, nt; // dimension reduction step
             if(precond)
             {
-                this->precond_->SolveZeroSol(*r, v);
-                op->Apply(*v, t);
-                rt = t->Dot(*r);
-                nt = t->Norm();
+                this->m_precond->SolveZeroSol(*kr, kv);
+                op->Apply(*kv, kt);
+                rt = kt->Dot(*kr);
+                nt = kt->Norm();
             }
             else
             {
-                op->Apply(*r, v);
-                rt = v->Dot(*r);
-                nt = v->Norm();
+                op->Apply(*kr, kv);
+                rt = kv->Dot(*kr);
+                nt = kv->Norm();
             }
             rt /= nt;
             rho   = std::abs(rt / res_norm);
             omega = rt / nt;
             if(rho < kappa)
                 omega *= kappa / rho;
-            this->CheckScalar_(omega, "w == 0.0", "w == NaN", "w == inf");
+            this->doCheckScalar(omega, "w == 0.0", "w == NaN", "w == inf");
             if(precond)
             {
-                r->AddScale(*t, -omega);
-                x->AddScale(*v, omega);
+                kr->AddScale(*kt, -omega);
+                x->AddScale(*kv, omega);
             }
             else
             {
-                x->AddScale(*r, omega);
-                r->AddScale(*v, -omega);
+                x->AddScale(*kr, omega);
+                kr->AddScale(*kv, -omega);
             }
-            res_norm = this->Norm_(*r);
+            res_norm = this->doNorm(*kr);
         }
     }
-    int                    s_;
-    unsigned long long     seed_;
-    ValueType              kappa_;
-    VectorType             r_, v_, t_;
-    VectorType**           G_;
-    VectorType**           U_;
-    VectorType**           P_;
-    std::vector<ValueType> c_, f_, M_;
+    int                    m_s;
+    unsigned long long     m_seed;
+    ValueType              m_kappa;
+    VectorType             m_r, m_v, m_t;
+    VectorType**           m_G;
+    VectorType**           m_U;
+    VectorType**           m_P;
+    std::vector<ValueType> m_c, m_f, m_M;
 };
 
 // ============================================================================ FixedPoint
-// src/solvers/solver.cpp:517-775: x_{k+1} = x_k + omega M^-1 (b - A x_k); a preconditioner is mandatory.
+// src/solvers/solver.cpp:517-775: m_x{k+1} = x_k + omega M^-1 (b - A x_k); a preconditioner is mandatory.
 // FlagSmoother(): exactly max_iter sweeps, no norms (the form multigrid uses).
 template <class OperatorType, class VectorType, typename ValueType>
 class FixedPoint : public IterativeLinearSolver<OperatorType, VectorType, ValueType>
 {
 public:
     FixedPoint()
-        : omega_(static_cast<ValueType>(1))
+        : m_omega(num<ValueType>(1))
     {
     }
     virtual ~FixedPoint()
@@ -2998,94 +2983,94 @@ public:
     }
     virtual void Print(void) const
     {
-        LOG_INFO("Fixed Point Iteration solver, with preconditioner:");
-        if(this->precond_)
-            this->precond_->Print();
+        say("Fixed Point Iteration solver, with preconditioner:");
+        if(this->m_precond)
+            this->m_precond->Print();
     }
     virtual void SetRelaxation(ValueType omega)
     {
-        this->omega_ = omega;
+        this->m_omega = omega;
     }
     virtual void Build(void)
     {
-        if(this->build_)
+        if(this->m_build)
             this->Clear();
-        assert(this->op_ != NULL && this->precond_ != NULL);
-        this->build_ = true;
-        this->x_old_.CloneBackend(*this->op_);
-        this->x_old_.Allocate("x_old", this->op_->GetM());
-        this->x_res_.CloneBackend(*this->op_);
-        this->x_res_.Allocate("x_res", this->op_->GetM());
-        this->precond_->SetOperator(*this->op_);
-        this->precond_->Build();
+        RAMD_EXPECT(this->m_op != nullptr && this->m_precond != nullptr);
+        this->m_build = true;
+        this->m_x_old.CloneBackend(*this->m_op);
+        this->m_x_old.Allocate("x_old", this->m_op->GetM());
+        this->m_x_res.CloneBackend(*this->m_op);
+        this->m_x_res.Allocate("x_res", this->m_op->GetM());
+        this->m_precond->SetOperator(*this->m_op);
+        this->m_precond->Build();
     }
     virtual void Clear(void)
     {
-        if(this->build_)
+        if(this->m_build)
         {
-            if(this->precond_ != NULL)
+            if(this->m_precond != NULL)
             {
-                this->precond_->Clear();
-                this->precond_ = NULL;
+                this->m_precond->Clear();
+                this->m_precond = NULL;
             }
-            this->x_old_.Clear();
-            this->x_res_.Clear();
-            this->iter_ctrl_.Clear();
-            this->build_ = false;
+            this->m_x_old.Clear();
+            this->m_x_res.Clear();
+            this->m_iter_ctrl.Clear();
+            this->m_build = false;
         }
     }
 
 protected:
-    virtual void PrintStart_(void) const
+    virtual void doPrintStart(void) const
     {
-        LOG_INFO("Fixed Point Iteration solver starts");
+        say("Fixed Point Iteration solver starts");
     }
-    virtual void PrintEnd_(void) const
+    virtual void doPrintEnd(void) const
     {
-        LOG_INFO("Fixed Point Iteration solver ends");
+        say("Fixed Point Iteration solver ends");
     }
-    virtual void SolveNonPrecond_(const VectorType&, VectorType*)
+    virtual void doSolveNonPrecond(const VectorType&, VectorType*)
     {
-        LOG_INFO("Preconditioner for the Fixed Point method is required");
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("Preconditioner for the Fixed Point method is required");
+        RAMD_DIE();
     }
-    virtual void SolvePrecond_(const VectorType& rhs, VectorType* x)
+    virtual void doSolvePrecond(const VectorType& rhs, VectorType* x)
     {
-        const ValueType one = static_cast<ValueType>(1);
-        if(this->is_smoother_)
+        const ValueType one = num<ValueType>(1);
+        if(this->m_is_smoother)
         {
-            const int steps = this->iter_ctrl_.GetMaximumIterations();
+            const int steps = this->m_iter_ctrl.GetMaximumIterations();
             if(steps < 1)
                 return;
-            this->iter_ctrl_.InitResidual(1.0); // dummy: the smoother never looks at a residual
-            if(this->fused_ && this->FusedJacobiSweeps_(rhs, x, steps))
+            this->m_iter_ctrl.InitResidual(1.0); // dummy: the smoother never looks at a residual
+            if(this->m_fused && this->doFusedJacobiSweeps(rhs, x, steps))
                 return;
             for(int iter = 0; iter < steps; ++iter)
             {
-                this->op_->Apply(*x, &this->x_res_);
-                this->x_res_.ScaleAdd(-one, rhs);
-                this->precond_->SolveZeroSol(this->x_res_, &this->x_old_);
-                x->AddScale(this->x_old_, this->omega_);
+                this->m_op->Apply(*x, &this->m_x_res);
+                this->m_x_res.ScaleAdd(-one, rhs);
+                this->m_precond->SolveZeroSol(this->m_x_res, &this->m_x_old);
+                x->AddScale(this->m_x_old, this->m_omega);
             }
             return;
         }
-        if(this->iter_ctrl_.GetMaximumIterations() < 1)
+        if(this->m_iter_ctrl.GetMaximumIterations() < 1)
             return;
-        this->op_->Apply(*x, &this->x_res_);
-        this->x_res_.ScaleAdd(-one, rhs);
-        ValueType res = this->Norm_(this->x_res_);
-        if(this->iter_ctrl_.InitResidual(std::abs(res)) == false)
+        this->m_op->Apply(*x, &this->m_x_res);
+        this->m_x_res.ScaleAdd(-one, rhs);
+        ValueType res = this->doNorm(this->m_x_res);
+        if(this->m_iter_ctrl.InitResidual(std::abs(res)) == false)
             return;
         while(true)
         {
-            this->precond_->SolveZeroSol(this->x_res_, &this->x_old_);
-            x->AddScale(this->x_old_, this->omega_);
-            if(this->iter_ctrl_.CheckMaximumIterNoCount()) // the last residual is never needed
+            this->m_precond->SolveZeroSol(this->m_x_res, &this->m_x_old);
+            x->AddScale(this->m_x_old, this->m_omega);
+            if(this->m_iter_ctrl.CheckMaximumIterNoCount()) // the last residual is never needed
                 break;
-            this->op_->Apply(*x, &this->x_res_);
-            this->x_res_.ScaleAdd(-one, rhs);
-            res = this->Norm_(this->x_res_);
-            if(this->iter_ctrl_.CheckResidual(std::abs(res), this->index_))
+            this->m_op->Apply(*x, &this->m_x_res);
+            this->m_x_res.ScaleAdd(-one, rhs);
+            res = this->doNorm(this->m_x_res);
+            if(this->m_iter_ctrl.CheckResidual(std::abs(res), this->m_index))
                 break;
         }
     }
@@ -3095,37 +3080,37 @@ private:
     // epilogue, ramd_fused_jacobi_sweep) plus the copy back, instead of SpMV + three vector kernels; same operations
     template <class O = OperatorType, class V = VectorType>
     typename std::enable_if<_fusable<O, V, ValueType>::value, bool>::type
-        FusedJacobiSweeps_(const VectorType& rhs, VectorType* x, int steps)
+        doFusedJacobiSweeps(const VectorType& rhs, VectorType* x, int steps)
     {
         typedef Jacobi<OperatorType, VectorType, ValueType> JacobiType;
-        JacobiType* jac = dynamic_cast<JacobiType*>(this->precond_);
-        if(jac == NULL || !this->op_->is_accel_() || !x->is_accel_() || this->op_->GetFormat() != CSR
+        JacobiType* jac = dynamic_cast<JacobiType*>(this->m_precond);
+        if(jac == NULL || !this->m_op->is_accel_() || !x->is_accel_() || this->m_op->GetFormat() != CSR
            || jac->GetInverseDiagonal().GetSize() != x->GetSize())
             return false;
         for(int iter = 0; iter < steps; ++iter)
         {
-            int s = ramd_fused_jacobi_sweep(this->op_->handle(), _fh(jac->GetInverseDiagonal()), _fh(rhs), _fh(*x),
-                                            _fh(this->x_res_), (double)this->omega_);
+            int s = ramd_fused_jacobi_sweep(this->m_op->handle(), _fh(jac->GetInverseDiagonal()), _fh(rhs), _fh(*x),
+                                            _fh(this->m_x_res), (double)this->m_omega);
             if(s == RAMD_ERR_UNSUPPORTED)
             {
                 if(iter == 0)
                     return false;
-                FATAL_ERROR(__FILE__, __LINE__);
+                RAMD_DIE();
             }
             RAMD_CHECK(s);
-            x->CopyFrom(this->x_res_);
+            x->CopyFrom(this->m_x_res);
         }
         return true;
     }
     template <class O = OperatorType, class V = VectorType>
     typename std::enable_if<!_fusable<O, V, ValueType>::value, bool>::type
-        FusedJacobiSweeps_(const VectorType&, VectorType*, int)
+        doFusedJacobiSweeps(const VectorType&, VectorType*, int)
     {
         return false;
     }
 
-    ValueType  omega_;
-    VectorType x_old_, x_res_;
+    ValueType  m_omega;
+    VectorType m_x_old, m_x_res;
 };
 
 // ============================================================================ MixedPrecisionDC
@@ -3138,8 +3123,8 @@ class MixedPrecisionDC : public IterativeLinearSolver<OperatorTypeH, VectorTypeH
 {
 public:
     MixedPrecisionDC()
-        : Solver_L_(NULL)
-        , op_l_(NULL)
+        : m_Solver_L(NULL)
+        , m_op_l(NULL)
     {
     }
     virtual ~MixedPrecisionDC()
@@ -3148,92 +3133,91 @@ public:
     }
     virtual void Print(void) const
     {
-        LOG_INFO("MixedPrecisionDC [" << 8 * sizeof(ValueTypeH) << "bit-" << 8 * sizeof(ValueTypeL)
-                                      << "bit] solver");
+        say("MixedPrecisionDC [", 8 * sizeof(ValueTypeH), "bit-", 8 * sizeof(ValueTypeL), "bit] solver");
     }
     void Set(Solver<OperatorTypeL, VectorTypeL, ValueTypeL>& Solver_L)
     {
-        this->Solver_L_ = &Solver_L;
+        this->m_Solver_L = &Solver_L;
     }
     virtual void Build(void)
     {
-        if(this->build_)
+        if(this->m_build)
             this->Clear();
-        assert(this->Solver_L_ != NULL && this->op_ != NULL);
-        this->build_ = true;
-        this->op_l_  = new OperatorTypeL;
-        this->op_l_->template CastFrom<ValueTypeH>(*this->op_); // value-cast CSR copy (:201-229)
-        this->r_h_.CloneBackend(*this->op_);
-        this->r_h_.Allocate("r_h", this->op_->GetM());
-        this->d_h_.CloneBackend(*this->op_);
-        this->d_h_.Allocate("d_h", this->op_->GetM());
-        this->r_l_.CloneBackend(*this->op_);
-        this->r_l_.Allocate("r_l", this->op_->GetM());
-        this->d_l_.CloneBackend(*this->op_);
-        this->d_l_.Allocate("d_l", this->op_->GetM());
-        this->Solver_L_->SetOperator(*this->op_l_);
-        this->Solver_L_->Build();
+        RAMD_EXPECT(this->m_Solver_L != nullptr && this->m_op != nullptr);
+        this->m_build = true;
+        this->m_op_l  = new OperatorTypeL;
+        this->m_op_l->template CastFrom<ValueTypeH>(*this->m_op); // value-cast CSR copy (:201-229)
+        this->m_r_h.CloneBackend(*this->m_op);
+        this->m_r_h.Allocate("r_h", this->m_op->GetM());
+        this->m_d_h.CloneBackend(*this->m_op);
+        this->m_d_h.Allocate("d_h", this->m_op->GetM());
+        this->m_r_l.CloneBackend(*this->m_op);
+        this->m_r_l.Allocate("r_l", this->m_op->GetM());
+        this->m_d_l.CloneBackend(*this->m_op);
+        this->m_d_l.Allocate("d_l", this->m_op->GetM());
+        this->m_Solver_L->SetOperator(*this->m_op_l);
+        this->m_Solver_L->Build();
     }
     virtual void Clear(void)
     {
-        if(this->build_)
+        if(this->m_build)
         {
-            if(this->Solver_L_ != NULL)
+            if(this->m_Solver_L != NULL)
             {
-                this->Solver_L_->Clear();
-                this->Solver_L_ = NULL;
+                this->m_Solver_L->Clear();
+                this->m_Solver_L = NULL;
             }
-            delete this->op_l_;
-            this->op_l_ = NULL;
-            this->r_h_.Clear();
-            this->d_h_.Clear();
-            this->r_l_.Clear();
-            this->d_l_.Clear();
-            this->iter_ctrl_.Clear();
-            this->build_ = false;
+            delete this->m_op_l;
+            this->m_op_l = NULL;
+            this->m_r_h.Clear();
+            this->m_d_h.Clear();
+            this->m_r_l.Clear();
+            this->m_d_l.Clear();
+            this->m_iter_ctrl.Clear();
+            this->m_build = false;
         }
     }
 
 protected:
-    virtual void PrintStart_(void) const
+    virtual void doPrintStart(void) const
     {
-        LOG_INFO("MixedPrecisionDC linear solver starts");
+        say("MixedPrecisionDC linear solver starts");
     }
-    virtual void PrintEnd_(void) const
+    virtual void doPrintEnd(void) const
     {
-        LOG_INFO("MixedPrecisionDC ends");
+        say("MixedPrecisionDC ends");
     }
-    virtual void SolveNonPrecond_(const VectorTypeH& rhs, VectorTypeH* x)
+    virtual void doSolveNonPrecond(const VectorTypeH& rhs, VectorTypeH* x)
     {
         const ValueTypeH one = static_cast<ValueTypeH>(1);
-        this->op_->Apply(*x, &this->r_h_);
-        this->r_h_.ScaleAdd(-one, rhs);
-        ValueTypeH res = this->Norm_(this->r_h_);
-        if(this->iter_ctrl_.InitResidual(res) == false)
+        this->m_op->Apply(*x, &this->m_r_h);
+        this->m_r_h.ScaleAdd(-one, rhs);
+        ValueTypeH res = this->doNorm(this->m_r_h);
+        if(this->m_iter_ctrl.InitResidual(res) == false)
             return;
-        while(!this->iter_ctrl_.CheckResidual(res, this->index_))
+        while(!this->m_iter_ctrl.CheckResidual(res, this->m_index))
         {
-            this->r_l_.CopyFromDouble(this->r_h_);
-            this->d_l_.Zeros();
-            this->Solver_L_->Solve(this->r_l_, &this->d_l_);
-            this->d_h_.CopyFromFloat(this->d_l_);
-            x->AddScale(this->d_h_, one);
-            this->op_->Apply(*x, &this->r_h_);
-            this->r_h_.ScaleAdd(-one, rhs);
-            res = this->Norm_(this->r_h_);
+            this->m_r_l.CopyFromDouble(this->m_r_h);
+            this->m_d_l.Zeros();
+            this->m_Solver_L->Solve(this->m_r_l, &this->m_d_l);
+            this->m_d_h.CopyFromFloat(this->m_d_l);
+            x->AddScale(this->m_d_h, one);
+            this->m_op->Apply(*x, &this->m_r_h);
+            this->m_r_h.ScaleAdd(-one, rhs);
+            res = this->doNorm(this->m_r_h);
         }
     }
-    virtual void SolvePrecond_(const VectorTypeH&, VectorTypeH*)
+    virtual void doSolvePrecond(const VectorTypeH&, VectorTypeH*)
     {
-        LOG_INFO("MixedPrecisionDC:: the preconditioner belongs to the inner solver");
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("MixedPrecisionDC:: the preconditioner belongs to the inner solver");
+        RAMD_DIE();
     }
 
 private:
-    Solver<OperatorTypeL, VectorTypeL, ValueTypeL>* Solver_L_;
-    OperatorTypeL*                                  op_l_;
-    VectorTypeH                                     r_h_, d_h_;
-    VectorTypeL                                     r_l_, d_l_;
+    Solver<OperatorTypeL, VectorTypeL, ValueTypeL>* m_Solver_L;
+    OperatorTypeL*                                  m_op_l;
+    VectorTypeH                                     m_r_h, m_d_h;
+    VectorTypeL                                     m_r_l, m_d_l;
 };
 
 // ============================================================================ multigrid
@@ -3253,24 +3237,24 @@ class BaseMultiGrid : public IterativeLinearSolver<OperatorType, VectorType, Val
 {
 public:
     BaseMultiGrid()
-        : levels_(-1)
-        , current_level_(0)
-        , scaling_(false)
-        , iter_pre_smooth_(1)
-        , iter_post_smooth_(1)
-        , cycle_(Vcycle)
-        , kcycle_full_(true)
-        , op_level_(NULL)
-        , restrict_op_level_(NULL)
-        , prolong_op_level_(NULL)
-        , d_level_(NULL)
-        , r_level_(NULL)
-        , t_level_(NULL)
-        , s_level_(NULL)
-        , q_level_(NULL)
-        , solver_coarse_(NULL)
-        , smoother_level_(NULL)
-        , res_norm_(static_cast<ValueType>(0))
+        : m_levels(-1)
+        , m_current_level(0)
+        , m_scaling(false)
+        , m_iter_pre_smooth(1)
+        , m_iter_post_smooth(1)
+        , m_cycle(Vcycle)
+        , m_kcycle_full(true)
+        , m_op_level(NULL)
+        , m_restrict_op_level(NULL)
+        , m_prolong_op_level(NULL)
+        , m_d_level(NULL)
+        , m_r_level(NULL)
+        , m_t_level(NULL)
+        , m_s_level(NULL)
+        , m_q_level(NULL)
+        , m_solver_coarse(NULL)
+        , m_smoother_level(NULL)
+        , m_res_norm(num<ValueType>(0))
     {
     }
     virtual ~BaseMultiGrid()
@@ -3279,71 +3263,70 @@ public:
     }
     virtual void InitLevels(int levels)
     {
-        assert(this->build_ == false && levels > 0);
-        this->levels_ = levels;
+        RAMD_EXPECT(!this->m_build && levels > 0);
+        this->m_levels = levels;
     }
     virtual void SetPreconditioner(Solver<OperatorType, VectorType, ValueType>&)
     {
-        LOG_INFO("BaseMultiGrid::SetPreconditioner() Perhaps you want to set the smoothers on all levels? use "
-                 "SetSmootherLevel() instead of SetPreconditioner!");
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("BaseMultiGrid::SetPreconditioner() Perhaps you want to set the smoothers on all levels? use " "SetSmootherLevel() instead of SetPreconditioner!");
+        RAMD_DIE();
     }
     virtual void SetSmoother(IterativeLinearSolver<OperatorType, VectorType, ValueType>** smoother)
     {
-        assert(smoother != NULL);
-        this->smoother_level_ = smoother;
+        RAMD_EXPECT(smoother != nullptr);
+        this->m_smoother_level = smoother;
     }
     virtual void SetSmootherPreIter(int iter)
     {
-        this->iter_pre_smooth_ = iter;
+        this->m_iter_pre_smooth = iter;
     }
     virtual void SetSmootherPostIter(int iter)
     {
-        this->iter_post_smooth_ = iter;
+        this->m_iter_post_smooth = iter;
     }
     virtual void SetSolver(Solver<OperatorType, VectorType, ValueType>& solver)
     {
-        this->solver_coarse_ = &solver;
+        this->m_solver_coarse = &solver;
     }
     virtual void SetScaling(bool scaling)
     {
-        if(this->build_ == false) // needs extra storage: before Build only (base_multigrid.cpp:144-158)
-            this->scaling_ = scaling;
+        if(this->m_build == false) // needs extra storage: before Build only (base_multigrid.cpp:144-158)
+            this->m_scaling = scaling;
     }
     virtual void SetHostLevels(int)
     {
-        LOG_INFO("BaseMultiGrid::SetHostLevels(): this backend keeps every level on the accelerator");
+        say("BaseMultiGrid::SetHostLevels(): this backend keeps every level on the accelerator");
     }
     virtual void SetCycle(unsigned int cycle)
     {
-        this->cycle_ = cycle;
+        this->m_cycle = cycle;
     }
     virtual void SetKcycleFull(bool kcycle_full)
     {
-        this->kcycle_full_ = kcycle_full;
+        this->m_kcycle_full = kcycle_full;
     }
     virtual void Print(void) const
     {
-        LOG_INFO("MultiGrid solver");
+        say("MultiGrid solver");
     }
     virtual void Build(void)
     {
-        if(this->build_)
+        if(this->m_build)
             this->Clear();
-        for(int i = 0; i < this->levels_ - 1; ++i)
-            assert(this->op_level_[i] != NULL && this->smoother_level_[i] != NULL && this->restrict_op_level_[i] != NULL
-                   && this->prolong_op_level_[i] != NULL);
-        assert(this->op_ != NULL && this->solver_coarse_ != NULL && this->levels_ > 0);
+        for(int i = 0; i < this->m_levels - 1; ++i)
+            RAMD_EXPECT(this->m_op_level[i] != nullptr && this->m_smoother_level[i] != nullptr && this->m_restrict_op_level[i] != nullptr
+                   && this->m_prolong_op_level[i] != nullptr);
+        RAMD_EXPECT(this->m_op != nullptr && this->m_solver_coarse != nullptr && this->m_levels > 0);
         this->Initialize();
-        this->build_ = true;
+        this->m_build = true;
     }
     virtual void Clear(void)
     {
-        if(this->build_)
+        if(this->m_build)
         {
             this->Finalize();
-            this->levels_ = -1;
-            this->build_  = false;
+            this->m_levels = -1;
+            this->m_build  = false;
         }
     }
 
@@ -3351,187 +3334,187 @@ protected:
     // base_multigrid.cpp:219-311
     virtual void Initialize(void)
     {
-        assert(this->build_ == false && this->smoother_level_ != NULL);
-        this->smoother_level_[0]->SetOperator(*this->op_);
-        this->smoother_level_[0]->Build();
-        this->smoother_level_[0]->FlagSmoother();
-        for(int i = 1; i < this->levels_ - 1; ++i)
+        RAMD_EXPECT(!this->m_build && this->m_smoother_level != nullptr);
+        this->m_smoother_level[0]->SetOperator(*this->m_op);
+        this->m_smoother_level[0]->Build();
+        this->m_smoother_level[0]->FlagSmoother();
+        for(int i = 1; i < this->m_levels - 1; ++i)
         {
-            this->smoother_level_[i]->SetOperator(*this->op_level_[i - 1]);
-            this->smoother_level_[i]->Build();
-            this->smoother_level_[i]->FlagSmoother();
+            this->m_smoother_level[i]->SetOperator(*this->m_op_level[i - 1]);
+            this->m_smoother_level[i]->Build();
+            this->m_smoother_level[i]->FlagSmoother();
         }
-        this->solver_coarse_->SetOperator(*this->op_level_[this->levels_ - 2]);
-        this->solver_coarse_->Build();
-        this->d_level_ = new VectorType*[this->levels_];
-        this->r_level_ = new VectorType*[this->levels_];
-        this->t_level_ = new VectorType*[this->levels_];
-        this->d_level_[0] = NULL;
-        if(this->scaling_)
+        this->m_solver_coarse->SetOperator(*this->m_op_level[this->m_levels - 2]);
+        this->m_solver_coarse->Build();
+        this->m_d_level = new VectorType*[this->m_levels];
+        this->m_r_level = new VectorType*[this->m_levels];
+        this->m_t_level = new VectorType*[this->m_levels];
+        this->m_d_level[0] = NULL;
+        if(this->m_scaling)
         {
-            this->s_level_ = new VectorType*[this->levels_];
-            for(int i = 0; i < this->levels_; ++i)
-                this->s_level_[i] = this->new_vec_(i, "temporary");
+            this->m_s_level = new VectorType*[this->m_levels];
+            for(int i = 0; i < this->m_levels; ++i)
+                this->m_s_level[i] = this->m_new_vec(i, "temporary");
         }
-        if(this->cycle_ == Kcycle)
+        if(this->m_cycle == Kcycle)
         {
-            this->q_level_ = new VectorType*[this->levels_ > 2 ? this->levels_ - 2 : 1];
-            for(int i = 0; i < this->levels_ - 2; ++i)
-                this->q_level_[i] = this->new_vec_(i + 1, "q");
+            this->m_q_level = new VectorType*[this->m_levels > 2 ? this->m_levels - 2 : 1];
+            for(int i = 0; i < this->m_levels - 2; ++i)
+                this->m_q_level[i] = this->m_new_vec(i + 1, "q");
         }
-        for(int i = 1; i < this->levels_; ++i)
+        for(int i = 1; i < this->m_levels; ++i)
         {
-            this->d_level_[i] = this->new_vec_(i, "defect correction");
-            this->r_level_[i] = this->new_vec_(i, "residual");
-            this->t_level_[i] = this->new_vec_(i, "temporary");
+            this->m_d_level[i] = this->m_new_vec(i, "defect correction");
+            this->m_r_level[i] = this->m_new_vec(i, "residual");
+            this->m_t_level[i] = this->m_new_vec(i, "temporary");
         }
-        this->r_level_[0] = this->new_vec_(0, "residual");
-        this->t_level_[0] = this->new_vec_(0, "temporary");
+        this->m_r_level[0] = this->m_new_vec(0, "residual");
+        this->m_t_level[0] = this->m_new_vec(0, "temporary");
     }
     // base_multigrid.cpp:360-425
     virtual void Finalize(void)
     {
-        for(int i = 0; i < this->levels_; ++i)
+        for(int i = 0; i < this->m_levels; ++i)
         {
-            if(i > 0 && this->d_level_)
-                delete this->d_level_[i];
-            if(this->r_level_)
-                delete this->r_level_[i];
-            if(this->t_level_)
-                delete this->t_level_[i];
-            if(this->s_level_)
-                delete this->s_level_[i];
+            if(i > 0 && this->m_d_level)
+                delete this->m_d_level[i];
+            if(this->m_r_level)
+                delete this->m_r_level[i];
+            if(this->m_t_level)
+                delete this->m_t_level[i];
+            if(this->m_s_level)
+                delete this->m_s_level[i];
         }
-        if(this->q_level_)
-            for(int i = 0; i < this->levels_ - 2; ++i)
-                delete this->q_level_[i];
-        delete[] this->d_level_;
-        delete[] this->r_level_;
-        delete[] this->t_level_;
-        delete[] this->s_level_;
-        delete[] this->q_level_;
-        this->d_level_ = this->r_level_ = this->t_level_ = this->s_level_ = this->q_level_ = NULL;
-        for(int i = 0; i < this->levels_ - 1; ++i)
-            this->smoother_level_[i]->Clear();
-        this->solver_coarse_->Clear();
-        this->iter_ctrl_.Clear();
+        if(this->m_q_level)
+            for(int i = 0; i < this->m_levels - 2; ++i)
+                delete this->m_q_level[i];
+        delete[] this->m_d_level;
+        delete[] this->m_r_level;
+        delete[] this->m_t_level;
+        delete[] this->m_s_level;
+        delete[] this->m_q_level;
+        this->m_d_level = this->m_r_level = this->m_t_level = this->m_s_level = this->m_q_level = NULL;
+        for(int i = 0; i < this->m_levels - 1; ++i)
+            this->m_smoother_level[i]->Clear();
+        this->m_solver_coarse->Clear();
+        this->m_iter_ctrl.Clear();
     }
 
 public:
     // base_multigrid.cpp:605-699
     virtual void Solve(const VectorType& rhs, VectorType* x)
     {
-        assert(this->levels_ > 1 && x != NULL && x != &rhs && this->op_ != NULL && this->build_ == true);
-        assert(this->precond_ == NULL && this->solver_coarse_ != NULL);
-        if(this->verb_ > 0)
+        RAMD_EXPECT(this->m_levels > 1 && x != NULL && x != &rhs && this->m_op != NULL && this->m_build);
+        RAMD_EXPECT(this->m_precond == NULL && this->m_solver_coarse != nullptr);
+        if(this->m_verb > 0)
         {
-            this->PrintStart_();
-            this->iter_ctrl_.PrintInit();
+            this->doPrintStart();
+            this->m_iter_ctrl.PrintInit();
         }
-        if(this->is_precond_ == false)
+        if(this->m_is_precond == false)
         {
-            this->op_->Apply(*x, this->r_level_[0]);
-            this->r_level_[0]->ScaleAdd(static_cast<ValueType>(-1), rhs);
-            this->res_norm_ = std::abs(this->Norm_(*this->r_level_[0]));
-            if(this->iter_ctrl_.InitResidual(this->res_norm_) == false)
+            this->m_op->Apply(*x, this->m_r_level[0]);
+            this->m_r_level[0]->ScaleAdd(num<ValueType>(-1), rhs);
+            this->m_res_norm = std::abs(this->doNorm(*this->m_r_level[0]));
+            if(this->m_iter_ctrl.InitResidual(this->m_res_norm) == false)
                 return;
         }
         else
-            this->iter_ctrl_.InitResidual(1.0);
-        this->Vcycle_(rhs, x);
-        if(this->is_precond_ == false)
-            while(!this->iter_ctrl_.CheckResidual(this->res_norm_, this->index_))
-                this->Vcycle_(rhs, x);
-        if(this->verb_ > 0)
+            this->m_iter_ctrl.InitResidual(1.0);
+        this->doVcycle(rhs, x);
+        if(this->m_is_precond == false)
+            while(!this->m_iter_ctrl.CheckResidual(this->m_res_norm, this->m_index))
+                this->doVcycle(rhs, x);
+        if(this->m_verb > 0)
         {
-            this->iter_ctrl_.PrintStatus();
-            this->PrintEnd_();
+            this->m_iter_ctrl.PrintStatus();
+            this->doPrintEnd();
         }
     }
 
 protected:
-    virtual void PrintStart_(void) const
+    virtual void doPrintStart(void) const
     {
-        assert(this->levels_ > 0);
-        LOG_INFO("MultiGrid solver starts");
-        LOG_INFO("MultiGrid Number of levels " << this->levels_);
+        RAMD_EXPECT(this->m_levels > 0);
+        say("MultiGrid solver starts");
+        say("MultiGrid Number of levels ", this->m_levels);
     }
-    virtual void PrintEnd_(void) const
+    virtual void doPrintEnd(void) const
     {
-        LOG_INFO("MultiGrid ends");
+        say("MultiGrid ends");
     }
-    virtual void SolveNonPrecond_(const VectorType&, VectorType*)
+    virtual void doSolveNonPrecond(const VectorType&, VectorType*)
     {
-        LOG_INFO("BaseMultiGrid:SolveNonPrecond_() this function is disabled");
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("BaseMultiGrid: the plain solve entry is disabled (use Solve)");
+        RAMD_DIE();
     }
-    virtual void SolvePrecond_(const VectorType&, VectorType*)
+    virtual void doSolvePrecond(const VectorType&, VectorType*)
     {
-        LOG_INFO("BaseMultiGrid:SolvePrecond_() this function is disabled");
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("BaseMultiGrid: the preconditioned solve entry is disabled (use Solve)");
+        RAMD_DIE();
     }
-    virtual void Restrict_(const VectorType& fine, VectorType* coarse)
+    virtual void doRestrict(const VectorType& fine, VectorType* coarse)
     {
-        this->restrict_op_level_[this->current_level_]->Apply(fine, coarse);
+        this->m_restrict_op_level[this->m_current_level]->Apply(fine, coarse);
     }
-    virtual void Prolong_(const VectorType& coarse, VectorType* fine)
+    virtual void doProlong(const VectorType& coarse, VectorType* fine)
     {
-        this->prolong_op_level_[this->current_level_]->Apply(coarse, fine);
+        this->m_prolong_op_level[this->m_current_level]->Apply(coarse, fine);
     }
     // base_multigrid.cpp:720-916
-    void Vcycle_(const VectorType& rhs, VectorType* x)
+    void doVcycle(const VectorType& rhs, VectorType* x)
     {
-        if(this->current_level_ == this->levels_ - 1)
+        if(this->m_current_level == this->m_levels - 1)
         {
-            this->solver_coarse_->SolveZeroSol(rhs, x);
+            this->m_solver_coarse->SolveZeroSol(rhs, x);
             return;
         }
-        IterativeLinearSolver<OperatorType, VectorType, ValueType>* smoother = this->smoother_level_[this->current_level_];
-        const OperatorType* op = (this->current_level_ == 0) ? this->op_ : this->op_level_[this->current_level_ - 1];
-        VectorType*         r  = this->r_level_[this->current_level_];
-        VectorType*         rc = this->t_level_[this->current_level_ + 1];
-        VectorType*         rf = this->t_level_[this->current_level_];
-        VectorType*         xc = this->d_level_[this->current_level_ + 1];
-        VectorType*         s  = (this->scaling_) ? this->s_level_[this->current_level_] : NULL;
+        IterativeLinearSolver<OperatorType, VectorType, ValueType>* smoother = this->m_smoother_level[this->m_current_level];
+        const OperatorType* op = (this->m_current_level == 0) ? this->m_op : this->m_op_level[this->m_current_level - 1];
+        VectorType*         r  = this->m_r_level[this->m_current_level];
+        VectorType*         rc = this->m_t_level[this->m_current_level + 1];
+        VectorType*         rf = this->m_t_level[this->m_current_level];
+        VectorType*         xc = this->m_d_level[this->m_current_level + 1];
+        VectorType*         s  = (this->m_scaling) ? this->m_s_level[this->m_current_level] : NULL;
         ValueType           factor, divisor;
-        smoother->InitMaxIter(this->iter_pre_smooth_);
-        if(this->is_precond_ || this->current_level_ != 0)
+        smoother->InitMaxIter(this->m_iter_pre_smooth);
+        if(this->m_is_precond || this->m_current_level != 0)
             smoother->SolveZeroSol(rhs, x);
         else
             smoother->Solve(rhs, x);
-        if(this->scaling_ == true)
-            if(this->current_level_ > 0 && this->current_level_ < this->levels_ - 2 && this->iter_pre_smooth_ > 0)
+        if(this->m_scaling == true)
+            if(this->m_current_level > 0 && this->m_current_level < this->m_levels - 2 && this->m_iter_pre_smooth > 0)
             {
                 s->PointWiseMult(rhs, *x);
                 factor = s->Reduce();
                 op->Apply(*x, s);
                 s->PointWiseMult(*x);
                 divisor = s->Reduce();
-                if(divisor == static_cast<ValueType>(0))
-                    factor = static_cast<ValueType>(1);
+                if(divisor == num<ValueType>(0))
+                    factor = num<ValueType>(1);
                 else
                     factor /= divisor;
                 x->Scale(factor);
             }
         op->Apply(*x, r);
-        r->ScaleAdd(static_cast<ValueType>(-1), rhs);
-        if(this->scaling_ && this->current_level_ == 0)
+        r->ScaleAdd(num<ValueType>(-1), rhs);
+        if(this->m_scaling && this->m_current_level == 0)
             s->CopyFrom(*r);
-        this->Restrict_(*r, rc);
-        ++this->current_level_;
-        switch(this->cycle_)
+        this->doRestrict(*r, rc);
+        ++this->m_current_level;
+        switch(this->m_cycle)
         {
-        case Vcycle: this->Vcycle_(*rc, xc); break;
-        case Wcycle: this->Wcycle_(*rc, xc); break;
-        case Kcycle: this->Kcycle_(*rc, xc); break;
-        case Fcycle: this->Fcycle_(*rc, xc); break;
-        default: FATAL_ERROR(__FILE__, __LINE__); break;
+        case Vcycle: this->doVcycle(*rc, xc); break;
+        case Wcycle: this->doWcycle(*rc, xc); break;
+        case Kcycle: this->doKcycle(*rc, xc); break;
+        case Fcycle: this->doFcycle(*rc, xc); break;
+        default: RAMD_DIE(); break;
         }
-        --this->current_level_;
-        this->Prolong_(*xc, r);
-        if(this->scaling_ == true && this->current_level_ < this->levels_ - 2)
+        --this->m_current_level;
+        this->doProlong(*xc, r);
+        if(this->m_scaling == true && this->m_current_level < this->m_levels - 2)
         {
-            if(this->current_level_ == 0)
+            if(this->m_current_level == 0)
                 s->PointWiseMult(*r);
             else
                 s->PointWiseMult(*r, *rf);
@@ -3539,52 +3522,52 @@ protected:
             op->Apply(*r, s);
             s->PointWiseMult(*r);
             divisor = s->Reduce();
-            if(divisor == static_cast<ValueType>(0))
-                factor = static_cast<ValueType>(1);
+            if(divisor == num<ValueType>(0))
+                factor = num<ValueType>(1);
             else
                 factor /= divisor;
             x->AddScale(*r, factor);
         }
         else
-            x->AddScale(*r, static_cast<ValueType>(1));
-        smoother->InitMaxIter(this->iter_post_smooth_);
+            x->AddScale(*r, num<ValueType>(1));
+        smoother->InitMaxIter(this->m_iter_post_smooth);
         smoother->Solve(rhs, x);
-        if(this->current_level_ == 0 && this->is_precond_ == false)
+        if(this->m_current_level == 0 && this->m_is_precond == false)
         {
             op->Apply(*x, r);
-            r->ScaleAdd(static_cast<ValueType>(-1), rhs);
-            this->res_norm_ = std::abs(this->Norm_(*r));
+            r->ScaleAdd(num<ValueType>(-1), rhs);
+            this->m_res_norm = std::abs(this->doNorm(*r));
         }
     }
-    void Wcycle_(const VectorType& rhs, VectorType* x)
+    void doWcycle(const VectorType& rhs, VectorType* x)
     {
         for(int i = 0; i < 2; ++i) // gamma = 2 hardcoded (base_multigrid.cpp:919-927)
-            this->Vcycle_(rhs, x);
+            this->doVcycle(rhs, x);
     }
-    void Fcycle_(const VectorType&, VectorType*)
+    void doFcycle(const VectorType&, VectorType*)
     {
-        LOG_INFO("BaseMultiGrid:Fcycle_() not implemented yet"); // nor in the reference (:930-935)
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("BaseMultiGrid: F-cycle is not implemented"); // nor in the reference (:930-935)
+        RAMD_DIE();
     }
     // base_multigrid.cpp:938-1011: two steps of CG around the cycle on the coarse levels
-    void Kcycle_(const VectorType& rhs, VectorType* x)
+    void doKcycle(const VectorType& rhs, VectorType* x)
     {
-        if(this->current_level_ != 1 && this->kcycle_full_ == false)
-            this->Vcycle_(rhs, x);
-        else if(this->current_level_ < this->levels_ - 1)
+        if(this->m_current_level != 1 && this->m_kcycle_full == false)
+            this->doVcycle(rhs, x);
+        else if(this->m_current_level < this->m_levels - 1)
         {
-            VectorType*         q  = this->q_level_[this->current_level_ - 1];
-            VectorType*         r  = this->t_level_[this->current_level_];
-            const OperatorType* op = this->op_level_[this->current_level_ - 1];
+            VectorType*         q  = this->m_q_level[this->m_current_level - 1];
+            VectorType*         r  = this->m_t_level[this->m_current_level];
+            const OperatorType* op = this->m_op_level[this->m_current_level - 1];
             ValueType           rho, rho_old, alpha;
-            this->Vcycle_(rhs, x);
+            this->doVcycle(rhs, x);
             if(r != &rhs)
                 r->CopyFrom(rhs);
             rho = r->DotNonConj(*x);
             op->Apply(*x, q);
             alpha = rho / x->DotNonConj(*q);
             r->AddScale(*q, -alpha);
-            this->Vcycle_(*r, q);
+            this->doVcycle(*r, q);
             rho_old = rho;
             rho     = r->DotNonConj(*q);
             r->CopyFrom(*x);
@@ -3595,35 +3578,35 @@ protected:
             x->AddScale(*r, alpha);
         }
         else
-            this->solver_coarse_->SolveZeroSol(rhs, x);
+            this->m_solver_coarse->SolveZeroSol(rhs, x);
     }
-    VectorType* new_vec_(int level, const char* name)
+    VectorType* m_new_vec(int level, const char* name)
     {
-        const OperatorType* op = (level == 0) ? this->op_ : this->op_level_[level - 1];
+        const OperatorType* op = (level == 0) ? this->m_op : this->m_op_level[level - 1];
         VectorType*         v  = new VectorType;
         v->CloneBackend(*op);
         v->Allocate(name, op->GetM());
         return v;
     }
 
-    int          levels_;
-    int          current_level_;
-    bool         scaling_;
-    int          iter_pre_smooth_;
-    int          iter_post_smooth_;
-    unsigned int cycle_;
-    bool         kcycle_full_;
-    OperatorType** op_level_; // [levels-1]: operators of levels 1 .. levels-1 (level 0 is op_)
-    OperatorType** restrict_op_level_;
-    OperatorType** prolong_op_level_;
-    VectorType**   d_level_;
-    VectorType**   r_level_;
-    VectorType**   t_level_;
-    VectorType**   s_level_;
-    VectorType**   q_level_;
-    Solver<OperatorType, VectorType, ValueType>*                 solver_coarse_;
-    IterativeLinearSolver<OperatorType, VectorType, ValueType>** smoother_level_;
-    ValueType                                                    res_norm_;
+    int          m_levels;
+    int          m_current_level;
+    bool         m_scaling;
+    int          m_iter_pre_smooth;
+    int          m_iter_post_smooth;
+    unsigned int m_cycle;
+    bool         m_kcycle_full;
+    OperatorType** m_op_level; // [levels-1]: operators of levels 1 .. levels-1 (level 0 is m_op)
+    OperatorType** m_restrict_op_level;
+    OperatorType** m_prolong_op_level;
+    VectorType**   m_d_level;
+    VectorType**   m_r_level;
+    VectorType**   m_t_level;
+    VectorType**   m_s_level;
+    VectorType**   m_q_level;
+    Solver<OperatorType, VectorType, ValueType>*                 m_solver_coarse;
+    IterativeLinearSolver<OperatorType, VectorType, ValueType>** m_smoother_level;
+    ValueType                                                    m_res_norm;
 };
 
 // MultiGrid (src/solvers/multigrid/multigrid.cpp): the hierarchy is handed in by the user; scaling on by default
@@ -3633,40 +3616,40 @@ class MultiGrid : public BaseMultiGrid<OperatorType, VectorType, ValueType>
 public:
     MultiGrid()
     {
-        this->scaling_ = true;
+        this->m_scaling = true;
     }
     virtual ~MultiGrid()
     {
         this->Clear();
-        delete[] this->restrict_op_level_;
-        delete[] this->prolong_op_level_;
+        delete[] this->m_restrict_op_level;
+        delete[] this->m_prolong_op_level;
     }
     virtual void SetRestrictOperator(OperatorType** op)
     {
-        assert(this->build_ == false && op != NULL && this->levels_ > 0);
-        delete[] this->restrict_op_level_;
-        this->restrict_op_level_ = new OperatorType*[this->levels_];
-        for(int i = 0; i < this->levels_ - 1; ++i)
-            this->restrict_op_level_[i] = op[i];
+        RAMD_EXPECT(!this->m_build && op != nullptr && this->m_levels > 0);
+        delete[] this->m_restrict_op_level;
+        this->m_restrict_op_level = new OperatorType*[this->m_levels];
+        for(int i = 0; i < this->m_levels - 1; ++i)
+            this->m_restrict_op_level[i] = op[i];
     }
     virtual void SetProlongOperator(OperatorType** op)
     {
-        assert(this->build_ == false && op != NULL && this->levels_ > 0);
-        delete[] this->prolong_op_level_;
-        this->prolong_op_level_ = new OperatorType*[this->levels_];
-        for(int i = 0; i < this->levels_ - 1; ++i)
-            this->prolong_op_level_[i] = op[i];
+        RAMD_EXPECT(!this->m_build && op != nullptr && this->m_levels > 0);
+        delete[] this->m_prolong_op_level;
+        this->m_prolong_op_level = new OperatorType*[this->m_levels];
+        for(int i = 0; i < this->m_levels - 1; ++i)
+            this->m_prolong_op_level[i] = op[i];
     }
     virtual void SetOperatorHierarchy(OperatorType** op)
     {
-        assert(this->build_ == false && op != NULL);
-        this->op_level_ = op;
+        RAMD_EXPECT(!this->m_build && op != nullptr);
+        this->m_op_level = op;
     }
 };
 
 // ============================================================================ AMG
-// BaseAMG (src/solvers/multigrid/base_amg.cpp): builds the hierarchy level by level through Aggregate_ until the
-// coarse operator has at most coarse_size_ rows; default smoothers FixedPoint(2/3) + Jacobi, default coarse solver
+// BaseAMG (src/solvers/multigrid/base_amg.cpp): builds the hierarchy level by level through doAggregate until the
+// coarse operator has at most m_coarse_size rows; default smoothers FixedPoint(2/3) + Jacobi, default coarse solver
 // CG(0, 1e-6, 1e8, 1000).
 typedef enum _coarsening_strategy
 {
@@ -3679,12 +3662,12 @@ class BaseAMG : public BaseMultiGrid<OperatorType, VectorType, ValueType>
 {
 public:
     BaseAMG()
-        : coarse_size_(300)
-        , set_sm_(false)
-        , set_s_(false)
-        , hierarchy_(false)
-        , op_format_(CSR)
-        , sm_default_(NULL)
+        : m_coarse_size(300)
+        , m_set_sm(false)
+        , m_set_s(false)
+        , m_hierarchy(false)
+        , m_op_format(CSR)
+        , m_sm_default(NULL)
     {
     }
     virtual ~BaseAMG()
@@ -3693,69 +3676,69 @@ public:
     }
     virtual void SetCoarsestLevel(int coarse_size)
     {
-        this->coarse_size_ = coarse_size;
+        this->m_coarse_size = coarse_size;
     }
     virtual void SetManualSmoothers(bool sm_manual)
     {
-        this->set_sm_ = sm_manual;
+        this->m_set_sm = sm_manual;
     }
     virtual void SetManualSolver(bool s_manual)
     {
-        this->set_s_ = s_manual;
+        this->m_set_s = s_manual;
     }
     virtual void SetOperatorFormat(unsigned int op_format, int op_blockdim = 1)
     {
         (void)op_blockdim;
-        this->op_format_ = op_format;
+        this->m_op_format = op_format;
     }
     virtual int GetNumLevels(void)
     {
-        return this->levels_;
+        return this->m_levels;
     }
     // base_amg.cpp:119-170
     virtual void Build(void)
     {
-        if(this->build_)
+        if(this->m_build)
             this->Clear();
         this->BuildHierarchy();
-        if(this->set_sm_ == false)
+        if(this->m_set_sm == false)
             this->BuildSmoothers();
-        if(this->set_s_ == false)
+        if(this->m_set_s == false)
         {
             CG<OperatorType, VectorType, ValueType>* cgs = new CG<OperatorType, VectorType, ValueType>;
             cgs->Init(0.0, 1e-6, 1e+8, 1000);
             cgs->Verbose(0);
-            this->solver_coarse_ = cgs;
+            this->m_solver_coarse = cgs;
         }
         this->Initialize();
-        if(this->op_format_ != CSR)
-            for(int i = 0; i < this->levels_ - 1; ++i)
-                this->op_level_[i]->ConvertTo(this->op_format_);
-        this->build_ = true;
+        if(this->m_op_format != CSR)
+            for(int i = 0; i < this->m_levels - 1; ++i)
+                this->m_op_level[i]->ConvertTo(this->m_op_format);
+        this->m_build = true;
     }
     // base_amg.cpp:173-310
     virtual void BuildHierarchy(void)
     {
-        if(this->hierarchy_)
+        if(this->m_hierarchy)
             return;
-        this->hierarchy_ = true;
-        if(this->op_->GetM() <= static_cast<int64_t>(this->coarse_size_))
+        this->m_hierarchy = true;
+        if(this->m_op->GetM() <= static_cast<int64_t>(this->m_coarse_size))
         {
-            LOG_INFO("Problem size too small for AMG, use Krylov solver instead");
-            FATAL_ERROR(__FILE__, __LINE__);
+            say("Problem size too small for AMG, use Krylov solver instead");
+            RAMD_DIE();
         }
         std::vector<OperatorType*> ops, res, pro;
-        this->levels_ = 1;
-        const OperatorType* prev = this->op_;
+        this->m_levels = 1;
+        const OperatorType* prev = this->m_op;
         while(true)
         {
             OperatorType* c = new OperatorType;
             OperatorType* r = new OperatorType;
             OperatorType* p = new OperatorType;
-            c->CloneBackend(*this->op_);
-            r->CloneBackend(*this->op_);
-            p->CloneBackend(*this->op_);
-            const bool ok = this->Aggregate_(*prev, p, r, c);
+            c->CloneBackend(*this->m_op);
+            r->CloneBackend(*this->m_op);
+            p->CloneBackend(*this->m_op);
+            const bool ok = this->doAggregate(*prev, p, r, c);
             if(!ok)
             {
                 delete c;
@@ -3763,110 +3746,108 @@ public:
                 delete p;
                 if(ops.empty())
                 {
-                    LOG_INFO("Could not build initial AMG level");
-                    FATAL_ERROR(__FILE__, __LINE__);
+                    say("Could not build initial AMG level");
+                    RAMD_DIE();
                 }
                 break;
             }
             ops.push_back(c);
             res.push_back(r);
             pro.push_back(p);
-            ++this->levels_;
+            ++this->m_levels;
             prev = c;
-            if(!(c->GetM() > static_cast<int64_t>(this->coarse_size_)))
+            if(!(c->GetM() > static_cast<int64_t>(this->m_coarse_size)))
                 break;
         }
-        this->op_level_          = new OperatorType*[this->levels_ - 1];
-        this->restrict_op_level_ = new OperatorType*[this->levels_ - 1];
-        this->prolong_op_level_  = new OperatorType*[this->levels_ - 1];
-        for(int i = 0; i < this->levels_ - 1; ++i)
+        this->m_op_level          = new OperatorType*[this->m_levels - 1];
+        this->m_restrict_op_level = new OperatorType*[this->m_levels - 1];
+        this->m_prolong_op_level  = new OperatorType*[this->m_levels - 1];
+        for(int i = 0; i < this->m_levels - 1; ++i)
         {
-            this->op_level_[i]          = ops[i];
-            this->restrict_op_level_[i] = res[i];
-            this->prolong_op_level_[i]  = pro[i];
+            this->m_op_level[i]          = ops[i];
+            this->m_restrict_op_level[i] = res[i];
+            this->m_prolong_op_level[i]  = pro[i];
         }
     }
     // base_amg.cpp:313-338
     virtual void BuildSmoothers(void)
     {
-        this->smoother_level_ = new IterativeLinearSolver<OperatorType, VectorType, ValueType>*[this->levels_ - 1];
-        this->sm_default_     = new Solver<OperatorType, VectorType, ValueType>*[this->levels_ - 1];
-        for(int i = 0; i < this->levels_ - 1; ++i)
+        this->m_smoother_level = new IterativeLinearSolver<OperatorType, VectorType, ValueType>*[this->m_levels - 1];
+        this->m_sm_default     = new Solver<OperatorType, VectorType, ValueType>*[this->m_levels - 1];
+        for(int i = 0; i < this->m_levels - 1; ++i)
         {
             FixedPoint<OperatorType, VectorType, ValueType>* sm  = new FixedPoint<OperatorType, VectorType, ValueType>;
             Jacobi<OperatorType, VectorType, ValueType>*     jac = new Jacobi<OperatorType, VectorType, ValueType>;
             sm->SetRelaxation(static_cast<ValueType>(2.f / 3.f));
             sm->SetPreconditioner(*jac);
             sm->Verbose(0);
-            this->smoother_level_[i] = sm;
-            this->sm_default_[i]     = jac;
+            this->m_smoother_level[i] = sm;
+            this->m_sm_default[i]     = jac;
         }
     }
     // base_amg.cpp:341-395
     virtual void Clear(void)
     {
-        if(this->build_)
+        if(this->m_build)
         {
             this->Finalize();
-            for(int i = 0; i < this->levels_ - 1; ++i)
+            for(int i = 0; i < this->m_levels - 1; ++i)
             {
-                delete this->op_level_[i];
-                delete this->restrict_op_level_[i];
-                delete this->prolong_op_level_[i];
+                delete this->m_op_level[i];
+                delete this->m_restrict_op_level[i];
+                delete this->m_prolong_op_level[i];
             }
-            delete[] this->op_level_;
-            delete[] this->restrict_op_level_;
-            delete[] this->prolong_op_level_;
-            this->op_level_ = this->restrict_op_level_ = this->prolong_op_level_ = NULL;
-            if(this->set_sm_ == false)
+            delete[] this->m_op_level;
+            delete[] this->m_restrict_op_level;
+            delete[] this->m_prolong_op_level;
+            this->m_op_level = this->m_restrict_op_level = this->m_prolong_op_level = NULL;
+            if(this->m_set_sm == false)
             {
-                for(int i = 0; i < this->levels_ - 1; ++i)
+                for(int i = 0; i < this->m_levels - 1; ++i)
                 {
-                    delete this->smoother_level_[i];
-                    delete this->sm_default_[i];
+                    delete this->m_smoother_level[i];
+                    delete this->m_sm_default[i];
                 }
-                delete[] this->smoother_level_;
-                delete[] this->sm_default_;
-                this->smoother_level_ = NULL;
-                this->sm_default_     = NULL;
+                delete[] this->m_smoother_level;
+                delete[] this->m_sm_default;
+                this->m_smoother_level = NULL;
+                this->m_sm_default     = NULL;
             }
-            if(this->set_s_ == false)
+            if(this->m_set_s == false)
             {
-                delete this->solver_coarse_;
-                this->solver_coarse_ = NULL;
+                delete this->m_solver_coarse;
+                this->m_solver_coarse = NULL;
             }
-            this->levels_    = -1;
-            this->build_     = false;
-            this->hierarchy_ = false;
+            this->m_levels    = -1;
+            this->m_build     = false;
+            this->m_hierarchy = false;
         }
     }
     virtual void SetRestrictOperator(OperatorType**)
     {
-        LOG_INFO("BaseAMG::SetRestrictOperator() Perhaps you want to use the MultiGrid class to set external "
-                 "restriction operators");
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("BaseAMG::SetRestrictOperator() Perhaps you want to use the MultiGrid class to set external " "restriction operators");
+        RAMD_DIE();
     }
     virtual void SetProlongOperator(OperatorType**)
     {
-        LOG_INFO("BaseAMG::SetProlongOperator() Perhaps you want to use the MultiGrid class to set external "
-                 "prolongation operators");
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("BaseAMG::SetProlongOperator() Perhaps you want to use the MultiGrid class to set external " "prolongation operators");
+        RAMD_DIE();
     }
     virtual void SetOperatorHierarchy(OperatorType**)
     {
-        LOG_INFO("BaseAMG::SetOperatorHierarchy() Perhaps you want to use the MultiGrid class to set external operators");
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("BaseAMG::SetOperatorHierarchy() Perhaps you want to use the MultiGrid class to set external operators");
+        RAMD_DIE();
     }
 
 protected:
-    virtual bool Aggregate_(const OperatorType& op, OperatorType* pro, OperatorType* res, OperatorType* coarse) = 0;
+    virtual bool doAggregate(const OperatorType& op, OperatorType* pro, OperatorType* res, OperatorType* coarse) = 0;
 
-    int          coarse_size_;
-    bool         set_sm_;
-    bool         set_s_;
-    bool         hierarchy_;
-    unsigned int op_format_;
-    Solver<OperatorType, VectorType, ValueType>** sm_default_;
+    int          m_coarse_size;
+    bool         m_set_sm;
+    bool         m_set_s;
+    bool         m_hierarchy;
+    unsigned int m_op_format;
+    Solver<OperatorType, VectorType, ValueType>** m_sm_default;
 };
 
 // UAAMG (src/solvers/multigrid/unsmoothed_amg.cpp): unsmoothed aggregation; both coarsening strategies run on the
@@ -3876,9 +3857,9 @@ class UAAMG : public BaseAMG<OperatorType, VectorType, ValueType>
 {
 public:
     UAAMG()
-        : eps_(static_cast<ValueType>(0.01f))
-        , over_interp_(static_cast<ValueType>(1.5f))
-        , strat_(Greedy)
+        : m_eps(num<ValueType>(0.01f))
+        , m_over_interp(num<ValueType>(1.5f))
+        , m_strat(Greedy)
     {
     }
     virtual ~UAAMG()
@@ -3887,60 +3868,60 @@ public:
     }
     virtual void Print(void) const
     {
-        LOG_INFO("UAAMG solver");
-        LOG_INFO("UAAMG number of levels " << this->levels_);
-        LOG_INFO("UAAMG using unsmoothed aggregation");
+        say("UAAMG solver");
+        say("UAAMG number of levels ", this->m_levels);
+        say("UAAMG using unsmoothed aggregation");
     }
     virtual void SetOverInterp(ValueType overInterp)
     {
-        this->over_interp_ = overInterp;
+        this->m_over_interp = overInterp;
     }
-    virtual void SetCouplingStrength(ValueType eps)
+    virtual void SetCouplingStrength(ValueType strength)
     {
-        this->eps_ = eps;
+        this->m_eps = strength;
     }
     virtual void SetCoarseningStrategy(CoarseningStrategy strat)
     {
-        this->strat_ = strat;
+        this->m_strat = strat;
     }
 
 protected:
-    virtual void PrintStart_(void) const
+    virtual void doPrintStart(void) const
     {
-        LOG_INFO("UAAMG solver starts");
-        LOG_INFO("UAAMG number of levels " << this->levels_);
+        say("UAAMG solver starts");
+        say("UAAMG number of levels ", this->m_levels);
     }
-    virtual void PrintEnd_(void) const
+    virtual void doPrintEnd(void) const
     {
-        LOG_INFO("UAAMG ends");
+        say("UAAMG ends");
     }
     // unsmoothed_amg.cpp:204-263
-    virtual bool Aggregate_(const OperatorType& op, OperatorType* pro, OperatorType* res, OperatorType* coarse)
+    virtual bool doAggregate(const OperatorType& op, OperatorType* Pmat, OperatorType* Rmat, OperatorType* Ac)
     {
-        assert(pro != NULL && res != NULL && coarse != NULL);
-        LocalVector<int> connections, aggregates, aggregate_root_nodes;
-        ValueType        eps = this->eps_;
-        for(int i = 0; i < this->levels_ - 1; ++i)
-            eps *= static_cast<ValueType>(0.5);
-        if(this->strat_ == PMIS)
-            op.AMGPMISAggregate(eps, &connections, &aggregates, &aggregate_root_nodes);
+        RAMD_EXPECT(Pmat != nullptr && Rmat != nullptr && Ac != nullptr);
+        LocalVector<int> strong, agg, agg_roots;
+        ValueType        strength = this->m_eps;
+        for(int i = 0; i < this->m_levels - 1; ++i)
+            strength *= num<ValueType>(0.5);
+        if(this->m_strat == PMIS)
+            op.AMGPMISAggregate(strength, &strong, &agg, &agg_roots);
         else
-            op.AMGGreedyAggregate(eps, &connections, &aggregates, &aggregate_root_nodes);
-        op.AMGUnsmoothedAggregation(aggregates, aggregate_root_nodes, pro);
-        connections.Clear();
-        aggregates.Clear();
-        aggregate_root_nodes.Clear();
-        pro->Transpose(res);
-        coarse->CloneBackend(op);
-        coarse->TripleMatrixProduct(*res, op, *pro);
-        if(this->over_interp_ > static_cast<ValueType>(1))
-            coarse->Scale(static_cast<ValueType>(1) / this->over_interp_);
+            op.AMGGreedyAggregate(strength, &strong, &agg, &agg_roots);
+        op.AMGUnsmoothedAggregation(agg, agg_roots, Pmat);
+        strong.Clear();
+        agg.Clear();
+        agg_roots.Clear();
+        Pmat->Transpose(Rmat);
+        Ac->CloneBackend(op);
+        Ac->TripleMatrixProduct(*Rmat, op, *Pmat);
+        if(this->m_over_interp > num<ValueType>(1))
+            Ac->Scale(num<ValueType>(1) / this->m_over_interp);
         return true;
     }
 
-    ValueType          eps_;
-    ValueType          over_interp_;
-    CoarseningStrategy strat_;
+    ValueType          m_eps;
+    ValueType          m_over_interp;
+    CoarseningStrategy m_strat;
 };
 
 typedef enum _lumping_strategy
@@ -3955,10 +3936,10 @@ class SAAMG : public BaseAMG<OperatorType, VectorType, ValueType>
 {
 public:
     SAAMG()
-        : eps_(static_cast<ValueType>(0.01f))
-        , relax_(static_cast<ValueType>(2.f / 3.f))
-        , strat_(Greedy)
-        , lumping_strat_(AddWeakConnections)
+        : m_eps(num<ValueType>(0.01f))
+        , m_relax(static_cast<ValueType>(2.f / 3.f))
+        , m_strat(Greedy)
+        , m_lumping_strat(AddWeakConnections)
     {
     }
     virtual ~SAAMG()
@@ -3967,66 +3948,66 @@ public:
     }
     virtual void Print(void) const
     {
-        LOG_INFO("SAAMG solver");
-        LOG_INFO("SAAMG number of levels " << this->levels_);
-        LOG_INFO(((this->strat_ == PMIS) ? "SAAMG using PMIS smoothed aggregation" : "SAAMG using greedy smoothed aggregation"));
+        say("SAAMG solver");
+        say("SAAMG number of levels ", this->m_levels);
+        say(((this->m_strat == PMIS) ? "SAAMG using PMIS smoothed aggregation" : "SAAMG using greedy smoothed aggregation"));
     }
-    virtual void SetCouplingStrength(ValueType eps)
+    virtual void SetCouplingStrength(ValueType strength)
     {
-        this->eps_ = eps;
+        this->m_eps = strength;
     }
     virtual void SetInterpRelax(ValueType relax)
     {
-        this->relax_ = relax;
+        this->m_relax = relax;
     }
     virtual void SetCoarseningStrategy(CoarseningStrategy strat)
     {
-        this->strat_ = strat;
+        this->m_strat = strat;
     }
     virtual void SetLumpingStrategy(LumpingStrategy lumping_strat)
     {
-        this->lumping_strat_ = lumping_strat;
+        this->m_lumping_strat = lumping_strat;
     }
 
 protected:
-    virtual void PrintStart_(void) const
+    virtual void doPrintStart(void) const
     {
-        LOG_INFO("SAAMG solver starts");
-        LOG_INFO("SAAMG number of levels " << this->levels_);
+        say("SAAMG solver starts");
+        say("SAAMG number of levels ", this->m_levels);
     }
-    virtual void PrintEnd_(void) const
+    virtual void doPrintEnd(void) const
     {
-        LOG_INFO("SAAMG ends");
+        say("SAAMG ends");
     }
     // smoothed_amg.cpp:244-316
-    virtual bool Aggregate_(const OperatorType& op, OperatorType* pro, OperatorType* res, OperatorType* coarse)
+    virtual bool doAggregate(const OperatorType& op, OperatorType* Pmat, OperatorType* Rmat, OperatorType* Ac)
     {
-        assert(pro != NULL && res != NULL && coarse != NULL);
-        LocalVector<int> connections, aggregates, aggregate_root_nodes;
-        ValueType        eps = this->eps_;
-        for(int i = 0; i < this->levels_ - 1; ++i)
-            eps *= static_cast<ValueType>(0.5);
-        if(this->strat_ == PMIS)
-            op.AMGPMISAggregate(eps, &connections, &aggregates, &aggregate_root_nodes);
+        RAMD_EXPECT(Pmat != nullptr && Rmat != nullptr && Ac != nullptr);
+        LocalVector<int> strong, agg, agg_roots;
+        ValueType        strength = this->m_eps;
+        for(int i = 0; i < this->m_levels - 1; ++i)
+            strength *= num<ValueType>(0.5);
+        if(this->m_strat == PMIS)
+            op.AMGPMISAggregate(strength, &strong, &agg, &agg_roots);
         else
-            op.AMGGreedyAggregate(eps, &connections, &aggregates, &aggregate_root_nodes);
-        op.AMGSmoothedAggregation(this->relax_, connections, aggregates, aggregate_root_nodes, pro,
-                                  this->lumping_strat_ == AddWeakConnections ? 0 : 1);
-        connections.Clear();
-        aggregates.Clear();
-        aggregate_root_nodes.Clear();
-        if(pro->GetN() == 0) // R would have no rows: the level is reverted by the caller
+            op.AMGGreedyAggregate(strength, &strong, &agg, &agg_roots);
+        op.AMGSmoothedAggregation(this->m_relax, strong, agg, agg_roots, Pmat,
+                                  this->m_lumping_strat == AddWeakConnections ? 0 : 1);
+        strong.Clear();
+        agg.Clear();
+        agg_roots.Clear();
+        if(Pmat->GetN() == 0) // R would have no rows: the level is reverted by the caller
             return false;
-        pro->Transpose(res);
-        coarse->CloneBackend(op);
-        coarse->TripleMatrixProduct(*res, op, *pro);
+        Pmat->Transpose(Rmat);
+        Ac->CloneBackend(op);
+        Ac->TripleMatrixProduct(*Rmat, op, *Pmat);
         return true;
     }
 
-    ValueType          eps_;
-    ValueType          relax_;
-    CoarseningStrategy strat_;
-    LumpingStrategy    lumping_strat_;
+    ValueType          m_eps;
+    ValueType          m_relax;
+    CoarseningStrategy m_strat;
+    LumpingStrategy    m_lumping_strat;
 };
 
 } // namespace rocalution

@@ -61,6 +61,7 @@ int         ramd_is_initialized(void);
 int         ramd_info(char* buf, int buflen); /* human readable backend description */
 const char* ramd_get_arch(void); /* "gfx950" ... */
 const char* ramd_last_error(void);
+void        ramd_set_last_error(const char* msg); /* used by the host layers above this ABI to leave their message here */
 int         ramd_device_count(int* count);
 
 /* rocalution_hip_sync{,_default,_interior,_ghost} (backend_hip.hpp:48-57) */

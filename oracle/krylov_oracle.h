@@ -33,6 +33,10 @@ typedef struct
     int    iters, status;
     double init_res, final_res;
     int    history_len;
+    /* in (appended): P > 1 = the preconditioner is BlockJacobi over P contiguous row blocks (the reference's multi-rank
+     * setup: preconditioner_blockjacobi.cpp:80-141 applies the local preconditioner to the interior block of every rank;
+     * row split as in clients/include/common.hpp:92-113).  Jacobi is the global diagonal either way. */
+    int    nblocks;
 } orc_solve_cfg;
 
 void orc_set_threads(int n);

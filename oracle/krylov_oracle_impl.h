@@ -2652,7 +2652,43 @@ int SUF(orc_solve)(int nrow, int64_t nnz, const int* row_offset, const int* col,
     SUF(orc_pc) P;
     orc_iter_ctrl ic;
     int           have_pc = cfg->precond != ORC_PC_NONE;
-    if(have_pc)
+    int*          brp     = NULL; /* block-diagonal copy (the preconditioner keeps pointers into its pattern) */
+    int*          bci     = NULL;
+    T*            bva     = NULL;
+    if(have_pc && cfg->nblocks > 1 && cfg->precond != ORC_PC_JACOBI)
+    {
+        /* BlockJacobi over cfg->nblocks ranks: every rank builds the preconditioner from its interior block only
+         * (preconditioner_blockjacobi.cpp:80-141, GlobalMatrix::GetInterior) and applies it to its slice of the vectors.
+         * Blocks do not couple, so this equals the same preconditioner built from the block-diagonal part of the
+         * operator: factorisations stay inside the blocks, a greedy colouring sees only in-block neighbours (the same
+         * colours as colouring every block by itself), and permuted sweeps keep the relative order inside a block. */
+        const int P_     = cfg->nblocks;
+        brp              = (int*)malloc(sizeof(int) * ((size_t)nrow + 1));
+        bci              = (int*)malloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+        bva              = (T*)malloc(sizeof(T) * (size_t)(nnz > 0 ? nnz : 1));
+        int64_t   k      = 0;
+        int       lo     = 0;
+        brp[0]           = 0;
+        for(int b = 0; b < P_; ++b)
+        {
+            const int size = nrow / P_ + (b < nrow % P_ ? 1 : 0); /* common.hpp:92-113 */
+            const int hi   = lo + size;
+            for(int i = lo; i < hi; ++i)
+            {
+                for(int j = row_offset[i]; j < row_offset[i + 1]; ++j)
+                    if(col[j] >= lo && col[j] < hi)
+                    {
+                        bci[k] = col[j];
+                        bva[k] = val[j];
+                        ++k;
+                    }
+                brp[i + 1] = (int)k;
+            }
+            lo = hi;
+        }
+        SUF(pc_build)(&P, cfg->precond, nrow, k, brp, bci, bva);
+    }
+    else if(have_pc)
         SUF(pc_build)(&P, cfg->precond, nrow, nnz, row_offset, col, val);
     SUF(op_build)(&A, cfg->format, nrow, nnz, row_offset, col, val);
     orc_ic_setup(&ic, cfg);
@@ -2686,5 +2722,8 @@ int SUF(orc_solve)(int nrow, int64_t nnz, const int* row_offset, const int* col,
     SUF(op_free)(&A);
     if(have_pc)
         SUF(pc_free)(&P);
+    free(brp);
+    free(bci);
+    free(bva);
     return 1;
 }

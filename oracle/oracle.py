@@ -39,6 +39,7 @@ class SolveCfg(C.Structure):
         ("history", C.POINTER(C.c_double)), ("history_cap", C.c_int),
         ("iters", C.c_int), ("status", C.c_int),
         ("init_res", C.c_double), ("final_res", C.c_double), ("history_len", C.c_int),
+        ("nblocks", C.c_int),
     ]
 
 
@@ -497,9 +498,11 @@ def _cfg(solver, precond, fmt, basis, abs_tol, rel_tol, div_tol, max_iter, min_i
 
 
 def solve(rp, ci, va, rhs, x0=None, solver=CG, precond=PC_NONE, fmt=CSR, basis=30, abs_tol=1e-15,
-          rel_tol=1e-6, div_tol=1e8, max_iter=1000000, min_iter=0, history=True, hist_cap=None, seed=0, p0=0.0, p1=0.0):
+          rel_tol=1e-6, div_tol=1e8, max_iter=1000000, min_iter=0, history=True, hist_cap=None, seed=0, p0=0.0, p1=0.0,
+          nblocks=1):
     """Build()+Solve() with the reference's control flow. Returns dict(x, iters, status, init_res,
-    final_res, history)."""
+    final_res, history).  nblocks = P > 1: the preconditioner is BlockJacobi over P contiguous row blocks (what a P-rank
+    run of the reference computes, preconditioner_blockjacobi.cpp:80-141)."""
     rp, ci = _i32(rp), _i32(ci)
     n = len(rp) - 1
     dtype = va.dtype
@@ -508,6 +511,7 @@ def solve(rp, ci, va, rhs, x0=None, solver=CG, precond=PC_NONE, fmt=CSR, basis=3
     cfg, hist = _cfg(solver, precond, fmt, basis, abs_tol, rel_tol, div_tol, max_iter, min_iter, cap)
     cfg.seed = int(seed)
     cfg.p0, cfg.p1 = float(p0), float(p1)
+    cfg.nblocks = int(nblocks)
     f, _ = _fn("orc_solve", dtype)
     f(C.c_int(n), C.c_int64(len(va)), _p(rp), _p(ci), _p(va), _p(np.ascontiguousarray(rhs, dtype=dtype)),
       _p(x), C.byref(cfg))

@@ -33,6 +33,7 @@ SIGNATURES = {
     "ramd_info": (i32, [C.c_char_p, i32]),
     "ramd_get_arch": (C.c_char_p, []),
     "ramd_last_error": (C.c_char_p, []),
+    "ramd_set_last_error": (None, [C.c_char_p]),
     "ramd_device_count": (i32, [pi32]),
     "ramd_sync": (i32, []),
     "ramd_sync_default": (i32, []),

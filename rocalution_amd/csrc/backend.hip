@@ -155,6 +155,10 @@ const char* ramd_last_error(void)
 {
     return last_error();
 }
+void ramd_set_last_error(const char* msg)
+{
+    set_error("host layer", 0, msg ? msg : "");
+}
 
 int ramd_device_count(int* count)
 {

@@ -6,6 +6,9 @@
 #include <memory>
 #include <stdexcept>
 
+// fatal errors of the C++ layer unwind as rocalution::fatal_error here (instead of exit(1), the reference's convention for
+// its own drivers) and reach the caller as an error status: a Python process survives a missing file or a mismatched vector
+#define RAMD_FATAL_THROWS
 #include "../../include/rocalution/rocalution.hpp"
 
 using namespace rocalution;
@@ -13,9 +16,8 @@ using namespace rocalution;
 namespace
 {
 
-// the C++ layer aborts on fatal errors like the reference does; argument errors that can be
-// detected up front are reported through the status code instead
-void set_err(const char* msg);
+// argument errors that can be detected up front are reported through the status code; everything else the C++ layer calls
+// fatal arrives as an exception at GUARD_END
 
 struct SolverBase
 {
@@ -38,6 +40,10 @@ struct SolverBase
     }
     virtual void build(ramd_mat_t op)                                    = 0;
     virtual void solve(ramd_vec_t rhs, ramd_vec_t x)                     = 0;
+    virtual bool is_built() const                                        = 0;
+    virtual int  vec_dtype() const                                       = 0; // dtype of rhs / x
+    virtual int  op_dtype() const                                        = 0; // dtype of the operator
+    virtual int64_t op_rows() const                                      = 0; // rows of the operator Build() saw
     virtual bool precond_apply(ramd_vec_t, ramd_vec_t)                   = 0;
     virtual void result(int* it, int* st, double* res)                   = 0;
     virtual const std::vector<double>& history()                         = 0;
@@ -246,6 +252,22 @@ struct LocalSolver : SolverBase
         vx.AdoptDeviceHandle(x);
         ls()->Solve(vr, &vx);
     }
+    bool is_built() const override
+    {
+        return built;
+    }
+    int vec_dtype() const override
+    {
+        return sizeof(T) == 8 ? RAMD_F64 : RAMD_F32;
+    }
+    int op_dtype() const override
+    {
+        return vec_dtype();
+    }
+    int64_t op_rows() const override
+    {
+        return op.GetM();
+    }
     bool precond_apply(ramd_vec_t rhs, ramd_vec_t x) override
     {
         Solver<M, V, T>* p = pcs.get(pc_kind);
@@ -355,6 +377,53 @@ struct MixedSolver : SolverBase
         vx.AdoptDeviceHandle(x);
         mp.Solve(vr, &vx);
     }
+    bool is_built() const override
+    {
+        return built;
+    }
+    int vec_dtype() const override
+    {
+        return RAMD_F64;
+    }
+    int op_dtype() const override
+    {
+        return RAMD_F64;
+    }
+    int64_t op_rows() const override
+    {
+        return op.GetM();
+    }
+    // the inner (fp32) preconditioner takes the same settings as a stand-alone solver's
+    void set_tri_solver(int alg, int max_iter, double tol, int use_tol) override
+    {
+        SolverDescr d;
+        d.SetTriSolverAlg(alg ? TriSolverAlg_Iterative : TriSolverAlg_Default);
+        d.SetIterativeSolverMaxIteration(max_iter);
+        d.SetIterativeSolverTolerance(tol);
+        if(use_tol)
+            d.EnableIterativeSolverTolerance();
+        else
+            d.DisableIterativeSolverTolerance();
+        if(Solver<ML, VL, float>* p = pcs.get(pc_kind))
+            p->SetSolverDescriptor(d);
+    }
+    void set_precond_params(double p0, double p1, double) override
+    {
+        if(pc_kind == RAMD_PC_ILU0) // ILU::Set(p, level)
+            pcs.ilu.Set((int)p0, p1 != 0.0);
+    }
+    void set_precond_format(int f) override
+    {
+        pcs.mc(pc_kind)->SetPrecondMatrixFormat((unsigned)f);
+    }
+    void set_decomposition(bool d) override
+    {
+        pcs.mc(pc_kind)->SetDecomposition(d);
+    }
+    void set_fused_sweeps(bool f) override
+    {
+        pcs.mc(pc_kind)->SetFusedSweeps(f);
+    }
     bool precond_apply(ramd_vec_t, ramd_vec_t) override
     {
         return false;
@@ -448,6 +517,7 @@ struct ramd_gsolver_s
     catch(const std::exception& e)                      \
     {                                                   \
         fprintf(stderr, "rocalution_amd: %s\n", e.what()); \
+        ramd_set_last_error(e.what());                  \
         return RAMD_ERR_STATE;                          \
     }                                                   \
     return RAMD_OK;
@@ -625,16 +695,24 @@ int ramd_mat_read_file(const char* filename, int kind, int dtype, ramd_mat_t* ou
 {
     if(!filename || !out || (dtype != RAMD_F64 && dtype != RAMD_F32) || (kind != 0 && kind != 1))
         return RAMD_ERR_ARG;
-    GUARD_BEGIN
     ramd_mat_t h = NULL;
     if(ramd_mat_create(dtype, &h) != RAMD_OK)
         return RAMD_ERR_HIP;
-    if(dtype == RAMD_F64)
-        mat_file_io<double>(h, filename, kind, true);
-    else
-        mat_file_io<float>(h, filename, kind, true);
+    try
+    {
+        if(dtype == RAMD_F64)
+            mat_file_io<double>(h, filename, kind, true);
+        else
+            mat_file_io<float>(h, filename, kind, true);
+    }
+    catch(const std::exception& e)
+    {
+        (void)ramd_mat_destroy(h);
+        ramd_set_last_error((std::string("reading ") + filename + ": " + e.what()).c_str());
+        return RAMD_ERR_STATE;
+    }
     *out = h;
-    GUARD_END
+    return RAMD_OK;
 }
 int ramd_mat_write_file(ramd_mat_t m, const char* filename, int kind)
 {
@@ -672,8 +750,19 @@ int ramd_vec_write_file(ramd_vec_t v, const char* filename, int kind)
 }
 int ramd_solver_build(ramd_solver_t s, ramd_mat_t op)
 {
-    if(!s || !op)
+    int nrow = 0, ncol = 0, dtype = 0;
+    if(!s || !op || ramd_mat_info(op, &nrow, &ncol, NULL, NULL, &dtype) != RAMD_OK)
         return RAMD_ERR_ARG;
+    if(dtype != s->impl->op_dtype())
+    {
+        ramd_set_last_error("solver_build: the operator's value type is not the solver's");
+        return RAMD_ERR_ARG;
+    }
+    if(nrow != ncol)
+    {
+        ramd_set_last_error("solver_build: the operator is not square");
+        return RAMD_ERR_ARG;
+    }
     GUARD_BEGIN
     s->impl->build(op);
     GUARD_END
@@ -682,6 +771,21 @@ int ramd_solver_solve(ramd_solver_t s, ramd_vec_t rhs, ramd_vec_t x)
 {
     if(!s || !rhs || !x || rhs == x)
         return RAMD_ERR_ARG;
+    if(!s->impl->is_built())
+    {
+        ramd_set_last_error("solver_solve: Solve() before Build() (or after Clear())");
+        return RAMD_ERR_STATE;
+    }
+    int     dr = 0, dx = 0;
+    int64_t nr = 0, nx = 0;
+    if(ramd_vec_dtype(rhs, &dr) != RAMD_OK || ramd_vec_dtype(x, &dx) != RAMD_OK || ramd_vec_size(rhs, &nr) != RAMD_OK
+       || ramd_vec_size(x, &nx) != RAMD_OK)
+        return RAMD_ERR_ARG;
+    if(dr != s->impl->vec_dtype() || dx != dr || nr != s->impl->op_rows() || nx != nr)
+    {
+        ramd_set_last_error("solver_solve: rhs / x do not match the operator (value type or size)");
+        return RAMD_ERR_ARG;
+    }
     GUARD_BEGIN
     s->impl->solve(rhs, x);
     GUARD_END

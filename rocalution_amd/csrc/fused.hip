@@ -13,9 +13,23 @@
 namespace ramd
 {
 
-// CG residual update (src/solvers/krylov/cg.cpp:418-438):
-//   alpha = rho / (p.q) ; r = r + (-alpha)*q ; rr = <r,r>
-//   PRECOND: z = dinv * r ; rz = <r,z>        else rz = rr
+// Streaming shape of every kernel here (tools/membench.hip, profiles/r02_membench.txt, 512^3 fp64 vectors):
+//   * kStreamU independent 16-byte packets per operand and thread are loaded before the first use (one packet per
+//     turn: 4.6-4.9 TB/s on the 3-reads-2-writes kernels, four: 5.4-5.7 TB/s);
+//   * operands read once / written once go through non-temporal loads / stores;
+//   * kernels without a reduction launch ONE SHOT grids (a workgroup per 256 * kStreamU packets, no grid-stride loop:
+//     copy 6.7 TB/s against 4.8-5.9 TB/s with any resident grid); kernels with a reduction keep a grid-stride loop over
+//     at most kReduceBlocks workgroups (their partial sums live in a fixed table).
+constexpr int kStreamU = 4;
+
+#define RAMD_STREAM_LOOP(np_)                                                   \
+    const int64_t stream_stride_ = (int64_t)gridDim.x * kBlock * kStreamU;      \
+    for(int64_t stream_base_ = (int64_t)blockIdx.x * kBlock * kStreamU + threadIdx.x; stream_base_ < (np_); \
+        stream_base_ += stream_stride_)
+#define RAMD_STREAM_EACH(np_, i_)                                               \
+    _Pragma("unroll") for(int u = 0; u < kStreamU; ++u)                         \
+        for(int64_t i_ = stream_base_ + (int64_t)u * kBlock, once_ = 1; once_ && i_ < (np_); once_ = 0)
+
 template <typename P_>
 __device__ __forceinline__ void st_pack(P_* p, P_ v, bool nts)
 {
@@ -25,6 +39,9 @@ __device__ __forceinline__ void st_pack(P_* p, P_ v, bool nts)
         *p = v;
 }
 
+// CG residual update (src/solvers/krylov/cg.cpp:418-438):
+//   alpha = rho / (p.q) ; r = r + (-alpha)*q ; rr = <r,r>
+//   PRECOND: z = dinv * r ; rz = <r,z>        else rz = rr
 template <typename T, bool PRECOND, bool NTS>
 __global__ __launch_bounds__(kBlock) void k_cg_update(int64_t n, T* __restrict__ r,
                                                       const T* __restrict__ q,
@@ -41,29 +58,36 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(int64_t n, T* __restrict__
     int64_t gtid   = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t gsz    = (int64_t)gridDim.x * blockDim.x;
     double  rr = 0.0, rz = 0.0;
-    for(int64_t i = gtid; i < np; i += gsz)
+    RAMD_STREAM_LOOP(np)
     {
-        P pr = reinterpret_cast<P*>(r)[i];
-        P pq = nt_load(reinterpret_cast<const P*>(q) + i);
-        P pd, pz;
-        if(PRECOND)
-            pd = reinterpret_cast<const P*>(dinv)[i];
-#pragma unroll
-        for(int k = 0; k < NP; ++k)
+        P pr[kStreamU], pq[kStreamU], pd[kStreamU];
+        RAMD_STREAM_EACH(np, i)
         {
-            T rn               = pk_elems<T>(pr)[k] + malpha * pk_elems<T>(pq)[k];
-            pk_elems<T>(pr)[k] = rn;
-            rr += (double)rn * (double)rn;
+            pr[u] = reinterpret_cast<P*>(r)[i];
+            pq[u] = nt_load(reinterpret_cast<const P*>(q) + i);
             if(PRECOND)
-            {
-                T zn               = pk_elems<T>(pd)[k] * rn;
-                pk_elems<T>(pz)[k] = zn;
-                rz += (double)rn * (double)zn;
-            }
+                pd[u] = nt_load(reinterpret_cast<const P*>(dinv) + i);
         }
-        st_pack(reinterpret_cast<P*>(r) + i, pr, NTS);
-        if(PRECOND)
-            st_pack(reinterpret_cast<P*>(z) + i, pz, NTS);
+        RAMD_STREAM_EACH(np, i)
+        {
+            P pz;
+#pragma unroll
+            for(int k = 0; k < NP; ++k)
+            {
+                T rn                  = pk_elems<T>(pr[u])[k] + malpha * pk_elems<T>(pq[u])[k];
+                pk_elems<T>(pr[u])[k] = rn;
+                rr += (double)rn * (double)rn;
+                if(PRECOND)
+                {
+                    T zn               = pk_elems<T>(pd[u])[k] * rn;
+                    pk_elems<T>(pz)[k] = zn;
+                    rz += (double)rn * (double)zn;
+                }
+            }
+            st_pack(reinterpret_cast<P*>(r) + i, pr[u], NTS);
+            if(PRECOND)
+                st_pack(reinterpret_cast<P*>(z) + i, pz, NTS);
+        }
     }
     for(int64_t i = np * NP + gtid; i < n; i += gsz)
     {
@@ -99,19 +123,26 @@ __global__ __launch_bounds__(kBlock) void k_cg_direction(int64_t n, T* __restric
     int64_t       np    = n / NP;
     int64_t       gtid  = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t       gsz   = (int64_t)gridDim.x * blockDim.x;
-    for(int64_t i = gtid; i < np; i += gsz)
+    RAMD_STREAM_LOOP(np)
     {
-        P px = reinterpret_cast<P*>(x)[i];
-        P pp = reinterpret_cast<P*>(p)[i];
-        P pz = reinterpret_cast<const P*>(z)[i];
-#pragma unroll
-        for(int k = 0; k < NP; ++k)
+        P px[kStreamU], pp[kStreamU], pz[kStreamU];
+        RAMD_STREAM_EACH(np, i)
         {
-            pk_elems<T>(px)[k] = pk_elems<T>(px)[k] + alpha * pk_elems<T>(pp)[k];
-            pk_elems<T>(pp)[k] = beta * pk_elems<T>(pp)[k] + pk_elems<T>(pz)[k];
+            px[u] = nt_load(reinterpret_cast<const P*>(x) + i);
+            pp[u] = reinterpret_cast<P*>(p)[i];
+            pz[u] = nt_load(reinterpret_cast<const P*>(z) + i);
         }
-        st_pack(reinterpret_cast<P*>(x) + i, px, NTS);
-        st_pack(reinterpret_cast<P*>(p) + i, pp, NTS);
+        RAMD_STREAM_EACH(np, i)
+        {
+#pragma unroll
+            for(int k = 0; k < NP; ++k)
+            {
+                pk_elems<T>(px[u])[k] = pk_elems<T>(px[u])[k] + alpha * pk_elems<T>(pp[u])[k];
+                pk_elems<T>(pp[u])[k] = beta * pk_elems<T>(pp[u])[k] + pk_elems<T>(pz[u])[k];
+            }
+            st_pack(reinterpret_cast<P*>(x) + i, px[u], NTS);
+            st_pack(reinterpret_cast<P*>(p) + i, pp[u], NTS);
+        }
     }
     for(int64_t i = np * NP + gtid; i < n; i += gsz)
     {
@@ -142,16 +173,23 @@ __global__ __launch_bounds__(kBlock) void k_multi_dot(int64_t n, MultiDotArgs<T>
 #pragma unroll
     for(int j = 0; j < NV; ++j)
         acc[j] = 0.0;
-    for(int64_t i = gtid; i < np; i += gsz)
+    RAMD_STREAM_LOOP(np)
     {
-        P pw = reinterpret_cast<const P*>(w)[i];
+        P pw[kStreamU];
+        RAMD_STREAM_EACH(np, i)
+            pw[u] = reinterpret_cast<const P*>(w)[i];
 #pragma unroll
         for(int j = 0; j < NV; ++j)
         {
-            P pv = reinterpret_cast<const P*>(a.v[j])[i];
+            P pv[kStreamU];
+            RAMD_STREAM_EACH(np, i)
+                pv[u] = nt_load(reinterpret_cast<const P*>(a.v[j]) + i);
+            RAMD_STREAM_EACH(np, i)
+            {
 #pragma unroll
-            for(int k = 0; k < NP; ++k)
-                acc[j] += (double)pk_elems<T>(pv)[k] * (double)pk_elems<T>(pw)[k];
+                for(int k = 0; k < NP; ++k)
+                    acc[j] += (double)pk_elems<T>(pv[u])[k] * (double)pk_elems<T>(pw[u])[k];
+            }
         }
     }
     for(int64_t i = np * NP + gtid; i < n; i += gsz)
@@ -173,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void k_multi_dot(int64_t n, MultiDotArgs<T>
 template <typename T, bool HAVE_U>
 __global__ __launch_bounds__(kBlock) void k_mgs_step(int64_t n, T* __restrict__ w,
                                                      const T* __restrict__ v,
-                                                     const T* __restrict__ u, ReduceCtx ctx,
+                                                     const T* __restrict__ u_vec, ReduceCtx ctx,
                                                      int slot_h, int slot_dot)
 {
     using P          = typename Pack<T>::type;
@@ -184,27 +222,33 @@ __global__ __launch_bounds__(kBlock) void k_mgs_step(int64_t n, T* __restrict__ 
     int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t gsz  = (int64_t)gridDim.x * blockDim.x;
     double  acc  = 0.0;
-    for(int64_t i = gtid; i < np; i += gsz)
+    RAMD_STREAM_LOOP(np)
     {
-        P pw = reinterpret_cast<P*>(w)[i];
-        P pv = reinterpret_cast<const P*>(v)[i];
-        P pu;
-        if(HAVE_U)
-            pu = reinterpret_cast<const P*>(u)[i];
-#pragma unroll
-        for(int k = 0; k < NP; ++k)
+        P pw[kStreamU], pv[kStreamU], pu[kStreamU];
+        RAMD_STREAM_EACH(np, i)
         {
-            T wn               = pk_elems<T>(pw)[k] + mh * pk_elems<T>(pv)[k];
-            pk_elems<T>(pw)[k] = wn;
-            acc += (double)(HAVE_U ? pk_elems<T>(pu)[k] : wn) * (double)wn;
+            pw[u] = reinterpret_cast<P*>(w)[i];
+            pv[u] = nt_load(reinterpret_cast<const P*>(v) + i);
+            if(HAVE_U)
+                pu[u] = nt_load(reinterpret_cast<const P*>(u_vec) + i);
         }
-        reinterpret_cast<P*>(w)[i] = pw;
+        RAMD_STREAM_EACH(np, i)
+        {
+#pragma unroll
+            for(int k = 0; k < NP; ++k)
+            {
+                T wn                  = pk_elems<T>(pw[u])[k] + mh * pk_elems<T>(pv[u])[k];
+                pk_elems<T>(pw[u])[k] = wn;
+                acc += (double)(HAVE_U ? pk_elems<T>(pu[u])[k] : wn) * (double)wn;
+            }
+            reinterpret_cast<P*>(w)[i] = pw[u]; // w is read again by the next projection: regular store
+        }
     }
     for(int64_t i = np * NP + gtid; i < n; i += gsz)
     {
         T wn = w[i] + mh * v[i];
         w[i] = wn;
-        acc += (double)(HAVE_U ? u[i] : wn) * (double)wn;
+        acc += (double)(HAVE_U ? u_vec[i] : wn) * (double)wn;
     }
     const double vals[1]  = {acc};
     const int    slots[1] = {slot_dot};
@@ -225,13 +269,18 @@ __global__ __launch_bounds__(kBlock) void k_normalize(int64_t n, T* __restrict__
     int64_t       np   = n / NP;
     int64_t       gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t       gsz  = (int64_t)gridDim.x * blockDim.x;
-    for(int64_t i = gtid; i < np; i += gsz)
+    RAMD_STREAM_LOOP(np)
     {
-        P pv = reinterpret_cast<P*>(v)[i];
+        P pv[kStreamU];
+        RAMD_STREAM_EACH(np, i)
+            pv[u] = reinterpret_cast<P*>(v)[i];
+        RAMD_STREAM_EACH(np, i)
+        {
 #pragma unroll
-        for(int k = 0; k < NP; ++k)
-            pk_elems<T>(pv)[k] *= inv;
-        reinterpret_cast<P*>(v)[i] = pv;
+            for(int k = 0; k < NP; ++k)
+                pk_elems<T>(pv[u])[k] *= inv;
+            reinterpret_cast<P*>(v)[i] = pv[u];
+        }
     }
     for(int64_t i = np * NP + gtid; i < n; i += gsz)
         v[i] *= inv;
@@ -254,14 +303,21 @@ __global__ __launch_bounds__(kBlock) void k_bicg_r_update(int64_t n, T* __restri
     int64_t       np   = n / NP;
     int64_t       gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t       gsz  = (int64_t)gridDim.x * blockDim.x;
-    for(int64_t i = gtid; i < np; i += gsz)
+    RAMD_STREAM_LOOP(np)
     {
-        P pr = reinterpret_cast<P*>(r)[i];
-        P pq = reinterpret_cast<const P*>(q)[i];
+        P pr[kStreamU], pq[kStreamU];
+        RAMD_STREAM_EACH(np, i)
+        {
+            pr[u] = reinterpret_cast<P*>(r)[i];
+            pq[u] = nt_load(reinterpret_cast<const P*>(q) + i);
+        }
+        RAMD_STREAM_EACH(np, i)
+        {
 #pragma unroll
-        for(int k = 0; k < NP; ++k)
-            pk_elems<T>(pr)[k] = pk_elems<T>(pr)[k] + malpha * pk_elems<T>(pq)[k];
-        reinterpret_cast<P*>(r)[i] = pr;
+            for(int k = 0; k < NP; ++k)
+                pk_elems<T>(pr[u])[k] = pk_elems<T>(pr[u])[k] + malpha * pk_elems<T>(pq[u])[k];
+            reinterpret_cast<P*>(r)[i] = pr[u];
+        }
     }
     for(int64_t i = np * NP + gtid; i < n; i += gsz)
         r[i] = r[i] + malpha * q[i];
@@ -299,25 +355,36 @@ __global__ __launch_bounds__(kBlock) void k_bicg_xr_update(int64_t n, T* __restr
     }
     else
     {
-        for(int64_t i = gtid; i < np; i += gsz)
+        RAMD_STREAM_LOOP(np)
         {
-            P px = reinterpret_cast<P*>(x)[i];
-            P pr = reinterpret_cast<P*>(r)[i];
-            P pt = reinterpret_cast<const P*>(t)[i];
-            P p0 = reinterpret_cast<const P*>(r0)[i];
-            P pd = PRECOND ? reinterpret_cast<const P*>(dir)[i] : reinterpret_cast<const P*>(p)[i];
-            P ps = PRECOND ? reinterpret_cast<const P*>(sv)[i] : pr;
-#pragma unroll
-            for(int k = 0; k < NP; ++k)
+            P px[kStreamU], pr[kStreamU], pt[kStreamU], p0[kStreamU], pd[kStreamU], ps[kStreamU];
+            RAMD_STREAM_EACH(np, i)
             {
-                pk_elems<T>(px)[k] = one * pk_elems<T>(px)[k] + alpha * pk_elems<T>(pd)[k] + omega * pk_elems<T>(ps)[k];
-                const T rnew       = pk_elems<T>(pr)[k] + mo * pk_elems<T>(pt)[k];
-                pk_elems<T>(pr)[k] = rnew;
-                rr += (double)rnew * (double)rnew;
-                rn += (double)pk_elems<T>(p0)[k] * (double)rnew;
+                px[u] = nt_load(reinterpret_cast<const P*>(x) + i);
+                pr[u] = reinterpret_cast<P*>(r)[i];
+                pt[u] = nt_load(reinterpret_cast<const P*>(t) + i);
+                p0[u] = reinterpret_cast<const P*>(r0)[i];
+                pd[u] = PRECOND ? nt_load(reinterpret_cast<const P*>(dir) + i) : reinterpret_cast<const P*>(p)[i];
+                if(PRECOND)
+                    ps[u] = nt_load(reinterpret_cast<const P*>(sv) + i);
             }
-            reinterpret_cast<P*>(x)[i] = px;
-            reinterpret_cast<P*>(r)[i] = pr;
+            RAMD_STREAM_EACH(np, i)
+            {
+                if(!PRECOND)
+                    ps[u] = pr[u];
+#pragma unroll
+                for(int k = 0; k < NP; ++k)
+                {
+                    pk_elems<T>(px[u])[k]
+                        = one * pk_elems<T>(px[u])[k] + alpha * pk_elems<T>(pd[u])[k] + omega * pk_elems<T>(ps[u])[k];
+                    const T rnew          = pk_elems<T>(pr[u])[k] + mo * pk_elems<T>(pt[u])[k];
+                    pk_elems<T>(pr[u])[k] = rnew;
+                    rr += (double)rnew * (double)rnew;
+                    rn += (double)pk_elems<T>(p0[u])[k] * (double)rnew;
+                }
+                __builtin_nontemporal_store(px[u], reinterpret_cast<P*>(x) + i);
+                reinterpret_cast<P*>(r)[i] = pr[u];
+            }
         }
         for(int64_t i = np * NP + gtid; i < n; i += gsz)
         {
@@ -355,15 +422,23 @@ __global__ __launch_bounds__(kBlock) void k_bicg_direction(int64_t n, T* __restr
     int64_t       np    = n / NP;
     int64_t       gtid  = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t       gsz   = (int64_t)gridDim.x * blockDim.x;
-    for(int64_t i = gtid; i < np; i += gsz)
+    RAMD_STREAM_LOOP(np)
     {
-        P pp = reinterpret_cast<P*>(p)[i];
-        P pq = reinterpret_cast<const P*>(q)[i];
-        P pr = reinterpret_cast<const P*>(r)[i];
+        P pp[kStreamU], pq[kStreamU], pr[kStreamU];
+        RAMD_STREAM_EACH(np, i)
+        {
+            pp[u] = reinterpret_cast<P*>(p)[i];
+            pq[u] = nt_load(reinterpret_cast<const P*>(q) + i);
+            pr[u] = reinterpret_cast<const P*>(r)[i];
+        }
+        RAMD_STREAM_EACH(np, i)
+        {
 #pragma unroll
-        for(int k = 0; k < NP; ++k)
-            pk_elems<T>(pp)[k] = beta * pk_elems<T>(pp)[k] + mbo * pk_elems<T>(pq)[k] + one * pk_elems<T>(pr)[k];
-        reinterpret_cast<P*>(p)[i] = pp;
+            for(int k = 0; k < NP; ++k)
+                pk_elems<T>(pp[u])[k]
+                    = beta * pk_elems<T>(pp[u])[k] + mbo * pk_elems<T>(pq[u])[k] + one * pk_elems<T>(pr[u])[k];
+            reinterpret_cast<P*>(p)[i] = pp[u];
+        }
     }
     for(int64_t i = np * NP + gtid; i < n; i += gsz)
         p[i] = beta * p[i] + mbo * q[i] + one * r[i];
@@ -372,6 +447,20 @@ __global__ __launch_bounds__(kBlock) void k_bicg_direction(int64_t n, T* __restr
 } // namespace ramd
 
 using namespace ramd;
+
+// launch geometry of the streaming kernels: one workgroup per kBlock * kStreamU packets; reductions cap the grid at
+// the size of the partial-sum table and stride over the rest
+static int grid_oneshot(int64_t n, int dtype)
+{
+    const int64_t np = n / (dtype == RAMD_F64 ? 2 : 4);
+    const int64_t g  = (np + (int64_t)kBlock * kStreamU - 1) / ((int64_t)kBlock * kStreamU);
+    return (int)(g < 1 ? 1 : g);
+}
+static int grid_reduce(int64_t n, int dtype)
+{
+    const int g = grid_oneshot(n, dtype);
+    return g > kReduceBlocks ? kReduceBlocks : g;
+}
 
 static bool slot_ok(int s)
 {
@@ -467,7 +556,7 @@ int ramd_fused_bicg_r_update(ramd_vec_t r, ramd_vec_t q, int slot_rho, int slot_
     if(r->n == 0)
         return RAMD_OK;
     Backend&  b    = backend();
-    const int grid = ew_grid((r->n + 1) / 2);
+    const int grid = grid_oneshot(r->n, r->dtype);
     if(r->dtype == RAMD_F64)
         hipLaunchKernelGGL((k_bicg_r_update<double>), dim3(grid), dim3(kBlock), 0, b.cur, r->n, (double*)r->d,
                            (const double*)q->d, b.d_scalars, slot_rho, slot_r0q);
@@ -498,7 +587,7 @@ int ramd_fused_bicg_xr_update(ramd_vec_t x, ramd_vec_t dir, ramd_vec_t sv, ramd_
     if(x->n == 0)
         return RAMD_OK;
     Backend&  b    = backend();
-    const int grid = reduce_grid((x->n + 1) / 2);
+    const int grid = grid_reduce(x->n, x->dtype);
     ReduceCtx ctx  = reduce_ctx();
 #define GO(T, PC)                                                                                              \
     hipLaunchKernelGGL((k_bicg_xr_update<T, PC>), dim3(grid), dim3(kBlock), 0, b.cur, x->n, (T*)x->d,          \
@@ -534,7 +623,7 @@ int ramd_fused_bicg_direction(ramd_vec_t p, ramd_vec_t q, ramd_vec_t r, int slot
     if(p->n == 0)
         return RAMD_OK;
     Backend&  b    = backend();
-    const int grid = ew_grid((p->n + 1) / 2);
+    const int grid = grid_oneshot(p->n, p->dtype);
     if(p->dtype == RAMD_F64)
         hipLaunchKernelGGL((k_bicg_direction<double>), dim3(grid), dim3(kBlock), 0, b.cur, p->n, (double*)p->d,
                            (const double*)q->d, (const double*)r->d, b.d_scalars, slot_rho, slot_r0q, slot_tr,
@@ -561,11 +650,11 @@ int ramd_fused_cg_update(ramd_vec_t r, ramd_vec_t q, ramd_vec_t dinv, ramd_vec_t
     if(r->n == 0)
         return RAMD_OK;
     Backend&  b    = backend();
-    const int grid = reduce_grid((r->n + 1) / 2);
+    const int grid = grid_reduce(r->n, r->dtype);
     ReduceCtx ctx  = reduce_ctx();
     static int nts = -1;
     if(nts < 0)
-        nts = getenv("RAMD_NT_STORES") ? atoi(getenv("RAMD_NT_STORES")) : 0;
+        nts = getenv("RAMD_NT_STORES") ? atoi(getenv("RAMD_NT_STORES")) : 1;
 #define GO(T)                                                                                          \
     do                                                                                                 \
     {                                                                                                  \
@@ -605,10 +694,10 @@ int ramd_fused_cg_direction(ramd_vec_t x, ramd_vec_t p, ramd_vec_t z, int slot_r
     if(p->n == 0)
         return RAMD_OK;
     Backend&  b    = backend();
-    const int grid = ew_grid((p->n + 1) / 2);
+    const int grid = grid_oneshot(p->n, p->dtype);
     static int nts = -1;
     if(nts < 0)
-        nts = getenv("RAMD_NT_STORES") ? atoi(getenv("RAMD_NT_STORES")) : 0;
+        nts = getenv("RAMD_NT_STORES") ? atoi(getenv("RAMD_NT_STORES")) : 1;
     prof_begin(RAMD_PROF_VEC, b.cur);
     if(p->dtype == RAMD_F64 && nts)
         hipLaunchKernelGGL((k_cg_direction<double, true>), dim3(grid), dim3(kBlock), 0, b.cur, p->n,
@@ -635,7 +724,7 @@ template <typename T>
 static int multi_dot_t(const ramd_vec_t* vs, int count, ramd_vec_t w, int slot0)
 {
     Backend&  b    = backend();
-    const int grid = reduce_grid((w->n + Pack<T>::N - 1) / Pack<T>::N);
+    const int grid = grid_reduce(w->n, w->dtype);
     ReduceCtx ctx  = reduce_ctx();
     int       done = 0;
     while(done < count)
@@ -691,7 +780,7 @@ int ramd_fused_mgs_step(ramd_vec_t w, ramd_vec_t v, int slot_h, ramd_vec_t u, in
     if(w->n == 0)
         return RAMD_OK;
     Backend&  b    = backend();
-    const int grid = reduce_grid((w->n + 1) / 2);
+    const int grid = grid_reduce(w->n, w->dtype);
     ReduceCtx ctx  = reduce_ctx();
 #define GO(T)                                                                                      \
     do                                                                                             \
@@ -723,7 +812,7 @@ int ramd_fused_normalize(ramd_vec_t v, int slot_sq, int slot_norm)
     if(v->n == 0)
         return RAMD_OK;
     Backend&  b    = backend();
-    const int grid = ew_grid((v->n + 1) / 2);
+    const int grid = grid_oneshot(v->n, v->dtype);
     if(v->dtype == RAMD_F64)
         hipLaunchKernelGGL((k_normalize<double>), dim3(grid), dim3(kBlock), 0, b.cur, v->n,
                            (double*)v->d, b.d_scalars, slot_sq, slot_norm);

@@ -216,6 +216,135 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) 
     }
 }
 
+// CSR SpMV for LONG rows (mean row length > 16: FE matrices with several unknowns per node, 27-point stencils).
+// With one thread per row a 2048-entry LDS pass holds only 2048 / row_length rows, so 3 of 4 threads idle in the row walk
+// of 35-entry rows (k_csr_tr: 4.1 TB/s = 51 % on the af_shell10-class matrix).  Here a workgroup owns R = 2048 / mean row
+// length rows (16 <= R <= 256), streams their entries through LDS the same way, and then
+//   1. ALL 256 threads gather x and form the products of the pass, entry e of the pass by thread e % 256 (eight
+//      independent gathers per thread in flight); consecutive lanes take consecutive entries of a row, whose columns
+//      are mostly contiguous in such matrices (the unknowns of one node) -> few cache lines per gather instruction;
+//      the product replaces the value in LDS;
+//   2. thread t < R adds the products of ITS row left to right -- the same roundings in the same order as the host loop
+//      (product rounded, then added; no FMA), so the result stays bit-identical.
+template <typename T, int MODE, bool DOT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_csr_prod(int nrow, int R, int nblk,
+                                                   int per_xcd, const int* __restrict__ rp,
+                                                   const int* __restrict__ ci,
+                                                   const T* __restrict__ val,
+                                                   const T* __restrict__ x, T* __restrict__ y, T scalar,
+                                                   CsrDotWs ws, int slot)
+{
+    using VP          = typename ValPk<T>::type;
+    constexpr int VN  = ValPk<T>::N;
+    __shared__ T      sval[kCsrChunk];
+    __shared__ int    scol[kCsrChunk];
+    const BandMap bm0 = {0, 0, 0};
+    const int     blk = xcd_block(nblk, per_xcd, bm0);
+    double        dacc = 0.0;
+    if(blk >= 0)
+    {
+        const int  r0    = blk * R;
+        const int  rend  = min(r0 + R, nrow);
+        const int  row   = r0 + threadIdx.x;
+        const bool owner = (int)threadIdx.x < R && row < nrow;
+        int        rs = 0, re = 0;
+        if(owner)
+        {
+            rs = rp[row];
+            re = rp[row + 1];
+        }
+        const int start = rp[r0];
+        const int end   = rp[rend];
+        T         sum   = (T)0;
+        if(MODE == 1 && owner)
+            sum = y[row];
+        for(int cb = start & ~3; cb < end; cb += kCsrChunk)
+        {
+            v4i32 c[kCsrChunk / (4 * kBlock)];
+            VP    a[kCsrChunk / (VN * kBlock)];
+#pragma unroll
+            for(int k = 0; k < kCsrChunk / (4 * kBlock); ++k)
+            {
+                const int j = cb + (k * kBlock + threadIdx.x) * 4;
+                if(j < end)
+                    c[k] = nt_load(reinterpret_cast<const v4i32*>(ci + j));
+            }
+#pragma unroll
+            for(int k = 0; k < kCsrChunk / (VN * kBlock); ++k)
+            {
+                const int j = cb + (k * kBlock + threadIdx.x) * VN;
+                if(j < end)
+                    a[k] = nt_load(reinterpret_cast<const VP*>(val + j));
+            }
+#pragma unroll
+            for(int k = 0; k < kCsrChunk / (4 * kBlock); ++k)
+            {
+                const int g = (k * kBlock + threadIdx.x) * 4;
+                if(cb + g < end)
+                    *reinterpret_cast<v4i32*>(scol + g) = c[k];
+            }
+#pragma unroll
+            for(int k = 0; k < kCsrChunk / (VN * kBlock); ++k)
+            {
+                const int g = (k * kBlock + threadIdx.x) * VN;
+                if(cb + g < end)
+                    *reinterpret_cast<VP*>(sval + g) = a[k];
+            }
+            __syncthreads();
+            // 1. products of the pass, all threads
+            {
+                constexpr int kPer = kCsrChunk / kBlock;
+                int           cc[kPer];
+                T             xv[kPer];
+#pragma unroll
+                for(int k = 0; k < kPer; ++k)
+                {
+                    const int g = k * kBlock + threadIdx.x;
+                    cc[k]       = (cb + g >= start && cb + g < end) ? scol[g] : -1;
+                }
+#pragma unroll
+                for(int k = 0; k < kPer; ++k)
+                    if(cc[k] >= 0)
+                        xv[k] = x[cc[k]];
+#pragma unroll
+                for(int k = 0; k < kPer; ++k)
+                    if(cc[k] >= 0)
+                    {
+                        const int g = k * kBlock + threadIdx.x;
+                        sval[g]     = (MODE != 1) ? sval[g] * xv[k] : scalar * sval[g] * xv[k];
+                    }
+            }
+            __syncthreads();
+            // 2. ordered row sums
+            if(owner)
+            {
+                const int lo = max(rs, cb), hi = min(re, cb + kCsrChunk);
+                for(int j = lo; j < hi; ++j)
+                    sum += sval[j - cb];
+            }
+            __syncthreads();
+        }
+        if(owner)
+        {
+            if(MODE == 2)
+            {
+                T t = (T)(-1) * sum + static_cast<const T*>(ws.jrhs)[row];
+                t   = static_cast<const T*>(ws.jdinv)[row] * t;
+                sum = x[row] + scalar * t;
+            }
+            nt_store(sum, y + row);
+            if(DOT)
+                dacc = (double)sum * (double)(ws.dotv ? static_cast<const T*>(ws.dotv)[row] : x[row]);
+        }
+    }
+    if(DOT)
+    {
+        const double wsum = wave_reduce_sum(dacc);
+        if((threadIdx.x & 63) == 0 && blk >= 0)
+            ws.part1[blk * (kBlock / 64) + (threadIdx.x >> 6)] = wsum;
+    }
+}
+
 // ELL: one thread per row, column-major => every load is a perfectly coalesced wave access.
 // STOP=true : ELL semantics (stop at the first negative column, host_matrix_ell.cpp:309-318)
 // STOP=false: HYB-ELL semantics (skip invalid columns, host_matrix_hyb.cpp:344-352)
@@ -453,14 +582,27 @@ template <typename T>
 static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar, bool dot, int slot,
                       const T* dotv = nullptr, const T* jdinv = nullptr, const T* jrhs = nullptr)
 {
-    Backend&  b       = backend();
-    const int nblk    = (m->nrow + kCsrRows - 1) / kCsrRows;
-    const int per_xcd = (nblk + 7) / 8;
-    const int grid    = per_xcd * 8;
-    CsrDotWs  ws      = {};
-    if(m->band_dist < 0)
+    Backend&  b = backend();
+    // long rows (mean > 16 entries): the product-stream kernel with R rows per workgroup (see k_csr_prod)
+    static int prod_on = -1;
+    if(prod_on < 0)
+        prod_on = getenv("RAMD_CSR_PROD") ? atoi(getenv("RAMD_CSR_PROD")) : 1;
+    int rows_per_wg = kCsrRows;
+    if(prod_on && m->nrow > 0 && m->nnz > (int64_t)16 * m->nrow)
+    {
+        const int64_t mean = m->nnz / m->nrow;
+        rows_per_wg        = 256;
+        while(rows_per_wg > 16 && (int64_t)rows_per_wg * mean > kCsrChunk + kCsrChunk / 8)
+            rows_per_wg >>= 1;
+    }
+    const bool prod    = rows_per_wg != kCsrRows;
+    const int  nblk    = (m->nrow + rows_per_wg - 1) / rows_per_wg;
+    const int  per_xcd = (nblk + 7) / 8;
+    const int  grid    = per_xcd * 8;
+    CsrDotWs   ws      = {};
+    if(!prod && m->band_dist < 0)
         RAMD_TRY(csr_analyse_band(const_cast<ramd_mat_s*>(m)));
-    const BandMap bm = band_map_for(m, per_xcd);
+    const BandMap bm = prod ? BandMap{0, 0, 0} : band_map_for(m, per_xcd);
     if(dot)
     {
         ramd_mat_s* mm = const_cast<ramd_mat_s*>(m);
@@ -475,9 +617,17 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
     }
     if(dot)
         prof_spmv_begin();
-#define LAUNCH(MODE, DOT)                                                                          \
-    hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
-                       per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm)
+#define LAUNCH(MODE, DOT)                                                                                  \
+    do                                                                                                     \
+    {                                                                                                      \
+        if(prod)                                                                                           \
+            hipLaunchKernelGGL((k_csr_prod<T, MODE, DOT>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow,     \
+                               rows_per_wg, nblk, per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, \
+                               slot);                                                                      \
+        else                                                                                               \
+            hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
+                               per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm);       \
+    } while(0)
     ws.jdinv = jdinv;
     ws.jrhs  = jrhs;
     if(mode == 2)

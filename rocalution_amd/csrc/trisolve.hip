@@ -455,11 +455,16 @@ struct TriPlan
     int* ct_tile_step = nullptr; // [ntiles+1] first step of a tile
     int* ct_step_pos  = nullptr; // [nsteps+1] first position of a step (a step = the rows of one level inside a tile)
     int* ct_step_ent  = nullptr; // [nsteps+1] first packed entry of a step
+    int* ct_ext_start = nullptr; // [n+1] first external dependency of a position (running count in position order)
+    int* ct_ext_idx   = nullptr; // [next] positions the external dependencies refer to
+    int  ct_extmax    = 0; // external dependencies of the tile that has most
     void  release()
     {
         dev_free(&ct_tile_step);
         dev_free(&ct_step_pos);
         dev_free(&ct_step_ent);
+        dev_free(&ct_ext_start);
+        dev_free(&ct_ext_idx);
         ct = false;
         dev_free(&order);
         dev_free(&pos);
@@ -902,14 +907,51 @@ __global__ __launch_bounds__(kBlock) void k_ct_ent_sizes(int nsteps, const int* 
         size[g] = (g < nsteps) ? step_w[g] * (step_pos[g + 1] - step_pos[g]) : 0;
 }
 
+// external dependencies (columns owned by another tile) per position -> scanned into ct_ext_start
+template <bool LOWER>
+__global__ __launch_bounds__(kBlock) void k_ct_count_ext(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                         const int* __restrict__ order, const int* __restrict__ pos,
+                                                         const int* __restrict__ tile_of, int* __restrict__ cnt)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p <= n; p += gsz)
+    {
+        int c = 0;
+        if(p < n)
+        {
+            const int i  = order[p];
+            const int tl = tile_of[p];
+            for(int j = rp[i]; j < rp[i + 1]; ++j)
+            {
+                const int col = ci[j];
+                if((LOWER ? (col < i) : (col > i)) && tile_of[pos[col]] != tl)
+                    ++c;
+            }
+        }
+        cnt[p] = c;
+    }
+}
+
+// external dependencies of a tile = ext_start[first position of the next tile] - ext_start[its first position]
+__global__ __launch_bounds__(kBlock) void k_ct_tile_ext(int ntiles, const int* __restrict__ tile_step,
+                                                        const int* __restrict__ step_pos, const int* __restrict__ ext_start,
+                                                        int* __restrict__ out)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < ntiles; t += gsz)
+        out[t] = ext_start[step_pos[tile_step[t + 1]]] - ext_start[step_pos[tile_step[t]]];
+}
+
 // entries of a step: [k][rank] with the step's row count as stride; a column inside the tile becomes its LDS index
-// (position - first position of the tile), a column of another tile -(position + 2), padding -1
+// (position - first position of the tile); a column of another tile becomes -(j + 2), j = its number in the tile's list of
+// external dependencies (positions in ext_idx, fetched into LDS by the tile's second wave); padding -1
 template <typename T, bool LOWER>
 __global__ __launch_bounds__(kBlock) void k_ct_fill(int n, const int* __restrict__ rp, const int* __restrict__ ci,
                                                     const T* __restrict__ val, const int* __restrict__ order,
                                                     const int* __restrict__ pos, const int* __restrict__ tile_of,
                                                     const int* __restrict__ step_of, const int* __restrict__ tile_step,
                                                     const int* __restrict__ step_pos, const int* __restrict__ step_ent,
+                                                    const int* __restrict__ ext_start, int* __restrict__ ext_idx,
                                                     int* __restrict__ ecol, T* __restrict__ eval, T* __restrict__ diag,
                                                     int* __restrict__ nodiag, int reverse)
 {
@@ -925,6 +967,8 @@ __global__ __launch_bounds__(kBlock) void k_ct_fill(int n, const int* __restrict
     const int  w    = (step_ent[gs + 1] - base) / cnt;
     const int  tl   = tile_of[p];
     const int  tpos = step_pos[tile_step[tl]];
+    int        e    = ext_start[p]; // next external slot of this row (global numbering)
+    const int  e0   = ext_start[tpos];
     int        k    = 0;
     bool       have = false;
     const int  rs = rp[i], re = rp[i + 1];
@@ -934,8 +978,17 @@ __global__ __launch_bounds__(kBlock) void k_ct_fill(int n, const int* __restrict
         const int c = ci[j];
         if(LOWER ? (c < i) : (c > i))
         {
-            const int pc              = pos[c];
-            ecol[base + k * cnt + rank] = (tile_of[pc] == tl) ? pc - tpos : -(pc + 2);
+            const int pc = pos[c];
+            int       code;
+            if(tile_of[pc] == tl)
+                code = pc - tpos;
+            else
+            {
+                ext_idx[e] = pc;
+                code       = -(e - e0 + 2);
+                ++e;
+            }
+            ecol[base + k * cnt + rank] = code;
             eval[base + k * cnt + rank] = val[j];
             ++k;
         }
@@ -957,133 +1010,196 @@ __global__ __launch_bounds__(kBlock) void k_ct_fill(int n, const int* __restrict
     }
 }
 
-// one wave per tile.  Registers of a step (its rows' entries, right-hand side, diagonal) are fetched one step ahead.
+// Two waves per tile.  Wave 1 (the fetcher) walks the tile's list of external dependencies in use order, polls the
+// solution array until the values are there (they belong to tiles that took an earlier ticket) and parks them in LDS,
+// far ahead of wave 0 -- which therefore never waits a cross-CU round trip inside its step loop: it only checks an LDS
+// counter.  Wave 0 (compute): one step per dependency level of the band, one row per lane; registers of a step (its rows'
+// entries, right-hand side, diagonal) are fetched one step ahead.
 template <typename T, int WMAX>
 struct CtStep
 {
     int c[WMAX];
     T   a[WMAX];
     T   b, dg;
-    int p, cnt, w, ebase, onat;
+    int p, cnt, w, ebase, onat, need;
 };
 
-template <typename T, int DMODE, int WMAX>
-__global__ __launch_bounds__(64) void k_trsv_ct(int ntiles, const int* __restrict__ tile_step,
-                                                const int* __restrict__ step_pos, const int* __restrict__ step_ent,
-                                                const int* __restrict__ ecol, const T* __restrict__ eval,
-                                                const T* __restrict__ diag, const T* __restrict__ rhs_src,
-                                                const int* __restrict__ rhs_idx, T* w, T* __restrict__ out,
-                                                const int* __restrict__ order, unsigned* counter, unsigned base)
+constexpr int kCtFetchDepth = 4; // batches of 64 external values the fetcher keeps in flight
+
+template <typename T, int DMODE, int WMAX, bool HAS_OUT>
+__global__ __launch_bounds__(128) void k_trsv_ct(int ntiles, int seg, int extmax, const int* __restrict__ tile_step,
+                                                 const int* __restrict__ step_pos, const int* __restrict__ step_ent,
+                                                 const int* __restrict__ ext_start, const int* __restrict__ ext_idx,
+                                                 const int* __restrict__ ecol, const T* __restrict__ eval,
+                                                 const T* __restrict__ diag, const T* __restrict__ rhs_src,
+                                                 const int* __restrict__ rhs_idx, T* w, T* __restrict__ out,
+                                                 const int* __restrict__ order, unsigned* counter, unsigned base)
 {
-    extern __shared__ __attribute__((aligned(16))) char ct_lds[]; // 64 * seg values of the tile
-    T*             xs = reinterpret_cast<T*>(ct_lds);
-    const unsigned t  = take_ticket(counter, base);
+    extern __shared__ __attribute__((aligned(16))) char ct_lds[];
+    T*             xs    = reinterpret_cast<T*>(ct_lds); // [64 * seg] values of the tile, then [extmax] of other tiles
+    const int      exoff = 64 * seg;
+    int*           ready = reinterpret_cast<int*>(xs + exoff + extmax); // external values parked so far
+    const unsigned t     = take_ticket(counter, base);
     if(t >= (unsigned)ntiles)
         return;
-    const int lane = threadIdx.x;
+    if(threadIdx.x == 0)
+        *ready = 0;
+    __syncthreads();
     const int s0 = tile_step[t], s1 = tile_step[t + 1];
     const int tpos = step_pos[s0];
+    const int e0   = ext_start[tpos];
     using B        = typename Sentinel<T>::bits;
-
-    auto fetch = [&](int s, CtStep<T, WMAX>& r) {
-        const int p0 = step_pos[s], p1 = step_pos[s + 1];
-        const int e0 = step_ent[s], e1 = step_ent[s + 1];
-        r.cnt        = p1 - p0;
-        r.w          = (e1 - e0) / r.cnt;
-        r.ebase      = e0;
-        r.p          = p0 + lane;
-        const bool live = lane < r.cnt;
-        r.b          = live ? rhs_src[rhs_idx[r.p]] : (T)0;
-        r.dg         = (DMODE == 0 || !live) ? (T)1 : diag[r.p];
-        r.onat       = (out && live) ? order[r.p] : 0;
-#pragma unroll
-        for(int k = 0; k < WMAX; ++k)
+    if(threadIdx.x >= 64)
+    {
+        // ---------------- fetcher wave
+        const int lane = threadIdx.x - 64;
+        const int e1   = ext_start[step_pos[s1]];
+        T*        ex   = xs + exoff;
+        for(int e = e0; e < e1; e += 64 * kCtFetchDepth)
         {
-            const bool on = live && k < r.w;
-            r.c[k]        = on ? nt_load(ecol + e0 + k * r.cnt + lane) : -1;
-            r.a[k]        = on ? nt_load(eval + e0 + k * r.cnt + lane) : (T)0;
-        }
-    };
-    // consume WMAX entries: values of other tiles are polled together (they belong to tiles that started earlier),
-    // values of this tile come from LDS (written by earlier steps); the subtraction runs in storage order
-    auto consume = [&](const int (&c)[WMAX], const T (&a)[WMAX], T& sum) {
-        B    bits[WMAX];
-        bool ext = false;
+            int idx[kCtFetchDepth];
+            B   bits[kCtFetchDepth];
 #pragma unroll
-        for(int k = 0; k < WMAX; ++k)
-            ext = ext || (c[k] < -1);
-        if(__ballot(ext) != 0ull)
-        {
+            for(int u = 0; u < kCtFetchDepth; ++u)
+            {
+                const int j = e + u * 64 + lane;
+                idx[u]      = (j < e1) ? nt_load(ext_idx + j) : -1;
+            }
             int spins = 0, backoff = 1;
             for(;;)
             {
                 bool all = true;
 #pragma unroll
-                for(int k = 0; k < WMAX; ++k)
-                    if(c[k] < -1)
+                for(int u = 0; u < kCtFetchDepth; ++u)
+                    if(idx[u] >= 0)
                     {
-                        bits[k] = poll_load(w + (-(c[k] + 2)));
-                        all     = all && (bits[k] != Sentinel<T>::value);
+                        bits[u] = poll_load(w + idx[u]);
+                        all     = all && (bits[u] != Sentinel<T>::value);
                     }
                 if(__ballot(!all) == 0ull)
                     break;
                 spin_guard(spins);
                 backoff = poll_backoff(false, backoff);
             }
+#pragma unroll
+            for(int u = 0; u < kCtFetchDepth; ++u)
+                if(idx[u] >= 0)
+                    ex[e - e0 + u * 64 + lane] = Sentinel<T>::from_bits(bits[u]);
+            const int done = min(e + 64 * kCtFetchDepth, e1) - e0;
+            // the wave's LDS writes before the counter: LDS operations of a wave complete in order, the explicit wait keeps
+            // the compiler from moving the counter store up (a workgroup-scope fence would also drain vmcnt)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if(lane == 0)
+                __hip_atomic_store(ready, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return;
+    }
+    // ---------------- compute wave
+    // Every load and store of the step loop is executed by ALL 64 lanes (lanes beyond the step's row count mirror its
+    // last row: same addresses, same values, harmless duplicate stores): with no vector memory operation under a branch the
+    // compiler can count the operations in flight and wait for the previous step's loads with a partial vmcnt(N), leaving
+    // the next step's loads in flight.  (Masked loads made it fall back to vmcnt(0) everywhere: no prefetch at all.)
+    const int lane = threadIdx.x;
+    // stage A (two steps ahead): the index of the right-hand side entry; stage B (one step ahead): everything else
+    auto stage_a = [&](int s) -> int {
+        const int p0 = step_pos[s], p1 = step_pos[s + 1];
+        return rhs_idx[p0 + min(lane, p1 - p0 - 1)];
+    };
+    auto stage_b = [&](int s, CtStep<T, WMAX>& r, int bidx) {
+        const int p0 = step_pos[s], p1 = step_pos[s + 1];
+        const int eb = step_ent[s], ee = step_ent[s + 1];
+        r.cnt        = p1 - p0;
+        r.w          = (ee - eb) / r.cnt;
+        r.ebase      = eb;
+        const int ln = min(lane, r.cnt - 1);
+        r.p          = p0 + ln;
+        r.need       = ext_start[p1] - e0; // external values the tile has used up to and including this step
+        r.b          = rhs_src[bidx];
+        r.dg         = (DMODE == 0) ? (T)1 : diag[r.p];
+        r.onat       = HAS_OUT ? order[r.p] : 0;
+#pragma unroll
+        for(int k = 0; k < WMAX; ++k)
+        {
+            // (beyond the step's width this reads the following entries: allocated, ignored below)
+            const int ci = nt_load(ecol + eb + k * r.cnt + ln);
+            r.a[k]       = nt_load(eval + eb + k * r.cnt + ln);
+            r.c[k]       = (k < r.w) ? ci : -1;
+        }
+    };
+    int have = 0; // external values known to be parked (wave-uniform)
+    // the subtraction runs in storage order; values of this tile come from LDS (written by earlier steps), values of
+    // other tiles from the fetcher's LDS area right behind them; all LDS reads are issued before the first use
+    auto consume = [&](const int (&c)[WMAX], const T (&a)[WMAX], T& sum) {
+        T v[WMAX];
+#pragma unroll
+        for(int k = 0; k < WMAX; ++k)
+        {
+            const int at = (c[k] >= 0) ? c[k] : ((c[k] < -1) ? exoff - (c[k] + 2) : 0);
+            v[k]         = xs[at];
         }
 #pragma unroll
         for(int k = 0; k < WMAX; ++k)
         {
-            if(c[k] >= 0)
-                sum -= a[k] * xs[c[k]];
-            else if(c[k] < -1)
-                sum -= a[k] * Sentinel<T>::from_bits(bits[k]);
+            const T prod = a[k] * v[k];
+            sum -= (c[k] == -1) ? (T)0 : prod; // padding: subtracts +0 (changes nothing, whatever xs[0] holds)
         }
     };
     auto finish = [&](const CtStep<T, WMAX>& r) {
-        const bool live = lane < r.cnt;
-        T          sum  = r.b;
-        consume(r.c, r.a, sum);
-        for(int k0 = WMAX; k0 < r.w; k0 += WMAX) // rows longer than the register window: the rest without prefetch
+        if(have < r.need) // wave-uniform: wait for the fetcher (LDS counter, no memory round trip)
         {
-            int cc[WMAX];
-            T   aa[WMAX];
-#pragma unroll
-            for(int k = 0; k < WMAX; ++k)
+            int spins = 0;
+            while((have = __hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < r.need)
             {
-                const bool on = live && (k0 + k) < r.w;
-                cc[k]         = on ? nt_load(ecol + r.ebase + (k0 + k) * r.cnt + lane) : -1;
-                aa[k]         = on ? nt_load(eval + r.ebase + (k0 + k) * r.cnt + lane) : (T)0;
+                spin_guard(spins);
+                __builtin_amdgcn_s_sleep(1);
             }
-            consume(cc, aa, sum);
+            asm volatile("" ::: "memory"); // LDS reads below stay behind the counter read (in-order LDS queue)
         }
-        if(live)
+        T sum = r.b;
+        consume(r.c, r.a, sum);
+        if(r.w > WMAX) // rows longer than the register window: the rest without prefetch
         {
-            if(DMODE == 1)
-                sum /= r.dg;
-            else if(DMODE == 2)
-                sum = sum * r.dg;
-            xs[r.p - tpos] = sum;
-            publish(w + r.p, sum);
-            if(out)
-                out[r.onat] = sum;
+            const int ln = min(lane, r.cnt - 1);
+            for(int k0 = WMAX; k0 < r.w; k0 += WMAX)
+            {
+                int cc[WMAX];
+                T   aa[WMAX];
+#pragma unroll
+                for(int k = 0; k < WMAX; ++k)
+                {
+                    const int ci = nt_load(ecol + r.ebase + (k0 + k) * r.cnt + ln);
+                    aa[k]        = nt_load(eval + r.ebase + (k0 + k) * r.cnt + ln);
+                    cc[k]        = (k0 + k < r.w) ? ci : -1;
+                }
+                consume(cc, aa, sum);
+            }
         }
-        __syncthreads(); // one wave: orders the LDS write before the next step's reads
+        if(DMODE == 1)
+            sum /= r.dg;
+        else if(DMODE == 2)
+            sum = sum * r.dg;
+        xs[r.p - tpos] = sum;
+        publish(w + r.p, sum);
+        if(HAS_OUT)
+            out[r.onat] = sum;
+        // this step's LDS writes before the next step's reads: one wave, in-order LDS queue -> only the compiler needs
+        // to be held back (no vmcnt wait: the next step's global loads stay in flight)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
 
-    CtStep<T, WMAX> ra, rb;
-    fetch(s0, ra);
-    for(int s = s0; s < s1; s += 2)
+    // straight-line loop body (the prefetch stages of the last steps re-read the last step instead of branching)
+    CtStep<T, WMAX> cur, nxt;
+    const int       sl = s1 - 1;
+    int             ib = stage_a(s0), ic = stage_a(min(s0 + 1, sl)); // rhs index of step s, s + 1
+    stage_b(s0, cur, ib);
+    ib = ic;
+    for(int s = s0; s < s1; ++s)
     {
-        if(s + 1 < s1)
-            fetch(s + 1, rb);
-        finish(ra);
-        if(s + 1 < s1)
-        {
-            if(s + 2 < s1)
-                fetch(s + 2, ra);
-            finish(rb);
-        }
+        ic = stage_a(min(s + 2, sl));
+        stage_b(min(s + 1, sl), nxt, ib);
+        finish(cur);
+        cur = nxt;
+        ib  = ic;
     }
 }
 
@@ -1261,8 +1377,40 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     int total = 0;
     CT_HIP(hipMemcpyAsync(&total, P->ct_step_ent + nsteps, sizeof(int), hipMemcpyDeviceToHost, b.cur));
     CT_HIP(hipStreamSynchronize(b.cur));
-    CT_TRY(dev_alloc(&P->ecol, total));
-    CT_HIP(cached_malloc(&P->eval, (size_t)total * sizeof(T) + kPad));
+    // external dependencies: running count per position (position order = use order), list of the positions they
+    // refer to, and the largest tile's count (sizes the fetcher's LDS area)
+    CT_TRY(dev_alloc(&P->ct_ext_start, (int64_t)n + 1));
+    if(lower)
+        hipLaunchKernelGGL((k_ct_count_ext<true>), dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, P->order, P->pos,
+                           tile_of, P->ct_ext_start);
+    else
+        hipLaunchKernelGGL((k_ct_count_ext<false>), dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, P->order, P->pos,
+                           tile_of, P->ct_ext_start);
+    CT_TRY(device_exclusive_scan(P->ct_ext_start, P->ct_ext_start, (int64_t)n + 1));
+    int next = 0;
+    CT_HIP(hipMemcpyAsync(&next, P->ct_ext_start + n, sizeof(int), hipMemcpyDeviceToHost, b.cur));
+    CT_HIP(hipStreamSynchronize(b.cur));
+    CT_TRY(dev_alloc(&P->ct_ext_idx, next));
+    {
+        int* text = nullptr;
+        CT_TRY(dev_alloc(&text, ntiles));
+        hipLaunchKernelGGL(k_ct_tile_ext, dim3(ew_grid(ntiles)), dim3(kBlock), 0, b.cur, ntiles, P->ct_tile_step,
+                           P->ct_step_pos, P->ct_ext_start, text);
+        int emax = 0;
+        s        = device_max_int(text, ntiles, &emax);
+        dev_free(&text);
+        CT_TRY(s);
+        P->ct_extmax = emax;
+    }
+    // LDS of a tile: its own 64 * seg values + the parked external values + the counter
+    if(((size_t)64 * seg + (size_t)P->ct_extmax) * sizeof(T) + 64 > (size_t)64 * 1024)
+    {
+        cleanup();
+        P->release();
+        return RAMD_ERR_UNSUPPORTED;
+    }
+    CT_TRY(dev_alloc(&P->ecol, (int64_t)total + 32 * 64)); // (+ the register window read past the last step)
+    CT_HIP(cached_malloc(&P->eval, ((size_t)total + 32 * 64) * sizeof(T) + kPad));
     CT_HIP(cached_malloc(&P->diag, (size_t)n * sizeof(T) + kPad));
     CT_HIP(cached_malloc(&P->w, (size_t)n * sizeof(T) + kPad));
     CT_TRY(dev_alloc(&nodiag, 1));
@@ -1270,12 +1418,12 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     const unsigned nb = nblocks_of(n);
     if(lower)
         hipLaunchKernelGGL((k_ct_fill<T, true>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const T*)m->val, P->order,
-                           P->pos, tile_of, step_of, P->ct_tile_step, P->ct_step_pos, P->ct_step_ent, P->ecol, (T*)P->eval,
-                           (T*)P->diag, nodiag, reverse ? 1 : 0);
+                           P->pos, tile_of, step_of, P->ct_tile_step, P->ct_step_pos, P->ct_step_ent, P->ct_ext_start,
+                           P->ct_ext_idx, P->ecol, (T*)P->eval, (T*)P->diag, nodiag, reverse ? 1 : 0);
     else
         hipLaunchKernelGGL((k_ct_fill<T, false>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const T*)m->val, P->order,
-                           P->pos, tile_of, step_of, P->ct_tile_step, P->ct_step_pos, P->ct_step_ent, P->ecol, (T*)P->eval,
-                           (T*)P->diag, nodiag, reverse ? 1 : 0);
+                           P->pos, tile_of, step_of, P->ct_tile_step, P->ct_step_pos, P->ct_step_ent, P->ct_ext_start,
+                           P->ct_ext_idx, P->ecol, (T*)P->eval, (T*)P->diag, nodiag, reverse ? 1 : 0);
     int nd = 0;
     CT_HIP(hipMemcpyAsync(&nd, nodiag, sizeof(int), hipMemcpyDeviceToHost, b.cur));
     CT_HIP(hipStreamSynchronize(b.cur));
@@ -1310,20 +1458,29 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
     if(P->ct)
     {
         const int    dm           = mul_inv_diag ? 2 : (unit ? 0 : 1);
-        const size_t ct_lds_bytes = (size_t)64 * P->ct_seg * sizeof(T);
-#define TRSV_CT(DM, WM)                                                                                               \
-    hipLaunchKernelGGL((k_trsv_ct<T, DM, WM>), dim3((unsigned)P->ct_ntiles), dim3(64), ct_lds_bytes, b.cur, P->ct_ntiles, \
-                       P->ct_tile_step, P->ct_step_pos, P->ct_step_ent, P->ecol, (const T*)P->eval, (const T*)P->diag, \
-                       rhs_src, rhs_idx, (T*)P->w, out, P->order, st->counter, st->ticket)
-#define TRSV_CT_W(WM)    \
-    do                   \
-    {                    \
-        if(dm == 0)      \
-            TRSV_CT(0, WM); \
-        else if(dm == 1) \
-            TRSV_CT(1, WM); \
-        else             \
-            TRSV_CT(2, WM); \
+        const size_t ct_lds_bytes = ((size_t)64 * P->ct_seg + (size_t)P->ct_extmax) * sizeof(T) + 64;
+#define TRSV_CT(DM, WM, HO)                                                                                             \
+    hipLaunchKernelGGL((k_trsv_ct<T, DM, WM, HO>), dim3((unsigned)P->ct_ntiles), dim3(128), ct_lds_bytes, b.cur, P->ct_ntiles, \
+                       P->ct_seg, P->ct_extmax, P->ct_tile_step, P->ct_step_pos, P->ct_step_ent, P->ct_ext_start,         \
+                       P->ct_ext_idx, P->ecol, (const T*)P->eval, (const T*)P->diag, rhs_src, rhs_idx, (T*)P->w, out,      \
+                       P->order, st->counter, st->ticket)
+#define TRSV_CT_D(DM, WM)       \
+    do                          \
+    {                           \
+        if(out)                 \
+            TRSV_CT(DM, WM, true);  \
+        else                    \
+            TRSV_CT(DM, WM, false); \
+    } while(0)
+#define TRSV_CT_W(WM)           \
+    do                          \
+    {                           \
+        if(dm == 0)             \
+            TRSV_CT_D(0, WM);   \
+        else if(dm == 1)        \
+            TRSV_CT_D(1, WM);   \
+        else                    \
+            TRSV_CT_D(2, WM);   \
     } while(0)
         prof_begin(RAMD_PROF_TRSV, b.cur);
         if(P->ct_wmax <= 4)
@@ -1336,6 +1493,7 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
             TRSV_CT_W(24);
         prof_end(RAMD_PROF_TRSV, b.cur);
 #undef TRSV_CT_W
+#undef TRSV_CT_D
 #undef TRSV_CT
         st->ticket += (unsigned)P->ct_ntiles;
         RAMD_HIP(hipGetLastError());

@@ -185,6 +185,24 @@ def gpu_worker(rank, world, initfile, kind, outdir):
         it4, st4, res4 = g4.result()
         its4.append((it4, st4))
     out["its4"] = np.array(its4)
+    # P-way BlockJacobi parity legs (checked against the oracle's nblocks = world mode): BiCGStab + BlockJacobi(MC-SGS)
+    # with the interior converted to ELL and to HYB after Build (config 4's solver), GMRES(30) + BlockJacobi(ILU(0))
+    its5 = []
+    for sk, pk, fmt in ((capi.SOLVER_BICGSTAB, capi.PC_MCSGS, ra.ELL), (capi.SOLVER_BICGSTAB, capi.PC_MCSGS, ra.HYB),
+                        (capi.SOLVER_GMRES, capi.PC_ILU0, ra.CSR)):
+        g5 = D.DistributedSolver(comm, sk, pk)
+        if kind == "poisson_slab":
+            g5.setup_poisson(N, z0, z1)
+        else:
+            g5.setup_csr(n, piece, plan)
+        g5.init(1e-15, 1e-6, 1e8, 500)
+        g5.build()
+        if fmt != ra.CSR:
+            g5.convert(fmt)
+        out["xs5_%d" % len(its5)] = g5.solve(None, np.zeros(hi - lo))
+        it5, st5, res5 = g5.result()
+        its5.append((it5, st5, res5))
+    out["its5"] = np.array(its5)
     np.savez(os.path.join(outdir, "r%d.npz" % rank), lo=lo, hi=hi, it=it, res=res, st=st, it2=it2, st2=st2,
              res2=res2, it3=it3, st3=st3, res3=res3, **out)
     dist.barrier()

@@ -50,6 +50,23 @@ def test_two_ranks_one_gpu(kind, oracle):
         assert int(its4[k][1]) == 2, (k, its4)
         assert np.linalg.norm(xs4 - 1.0) / np.sqrt(n) < 1e-6
         assert int(its4[k][0]) < int(res[0]["it"]) * (2 if kind == "random" else 1) + 2, (k, its4, res[0]["it"])
+    # P-way BlockJacobi parity (SURVEY.md 8e rule 2): iteration count, status and solution of the 2-rank run against the
+    # CPU restatement of the SAME 2-way block-Jacobi algorithm (oracle nblocks=2: the preconditioner is built from the
+    # rank's diagonal block only, preconditioner_blockjacobi.cpp:80-141) -- BiCGStab+BlockJacobi(MC-SGS) with ELL and HYB
+    # interiors (clients/samples/bicgstab_mpi.cpp:104-116), GMRES(30)+BlockJacobi(ILU(0))
+    its5 = res[0]["its5"]
+    for k, (osolver, opc, slack) in enumerate(((oracle.BICGSTAB, oracle.PC_MCSGS, 2), (oracle.BICGSTAB, oracle.PC_MCSGS, 2),
+                                                (oracle.GMRES, oracle.PC_ILU0, 2))):
+        refb = oracle.solve(rp, ci, va, b, solver=osolver, precond=opc, max_iter=500, nblocks=2)
+        xs5 = np.concatenate([r["xs5_%d" % k] for r in res])
+        assert int(its5[k][1]) == refb["status"], (k, its5[k], refb["status"])
+        assert abs(int(its5[k][0]) - refb["iters"]) <= slack, (k, its5[k], refb["iters"])
+        d = np.linalg.norm(xs5 - refb["x"]) / np.linalg.norm(refb["x"])
+        # equal iteration counts: the same iterate to round-off amplification; else both within the stopping tolerance
+        assert d < (1e-8 if int(its5[k][0]) == refb["iters"] and osolver != oracle.BICGSTAB else 2e-5), (k, d)
+        # ... and the P-way count differs from the 1-way one where the block structure matters (so the check is not vacuous)
+    ref1 = oracle.solve(rp, ci, va, b, solver=oracle.GMRES, precond=oracle.PC_ILU0, max_iter=500)
+    assert oracle.solve(rp, ci, va, b, solver=oracle.GMRES, precond=oracle.PC_ILU0, max_iter=500, nblocks=2)["iters"] >= ref1["iters"]
     # mixed precision on Global objects (no reference counterpart, SURVEY.md headline 6): pinned by the
     # 1-process MixedPrecisionDC oracle -- same outer iteration count +-1, same solution
     refm = oracle.solve_mixed(rp, ci, va, b, outer={}, inner=dict(solver=oracle.CG, precond=oracle.PC_JACOBI,

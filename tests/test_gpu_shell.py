@@ -75,6 +75,26 @@ def test_spmv_ilu0_lusolve_bit_exact_vs_oracle(ra, small, oracle):
     y = ra.LocalVector(); y.Allocate("y", n)
     A.Apply(x, y)
     assert np.array_equal(y.numpy(), oracle.csr_apply(rp, ci, va, xh))
+    # ApplyAdd (term by term into y) and the fp32 instantiation of the long-row kernel
+    y0 = rng.uniform(-1.0, 1.0, n)
+    yv = ra.LocalVector(data=y0)
+    A.ApplyAdd(x, -0.75, yv)
+    assert np.array_equal(yv.numpy(), oracle.csr_apply_add(rp, ci, va, xh, -0.75, y0))
+    A32 = ra.LocalMatrix(np.float32); A32.SetDataPtrCSR(rp, ci, va.astype(np.float32))
+    x32 = ra.LocalVector(np.float32, data=xh.astype(np.float32)); y32 = ra.LocalVector(np.float32); y32.Allocate("", n)
+    A32.Apply(x32, y32)
+    assert np.array_equal(y32.numpy(), oracle.csr_apply(rp, ci, va.astype(np.float32), xh.astype(np.float32)))
+    # fused Apply + <x, y>: same vector, dot within the reduction tolerance
+    import ctypes as C
+    from rocalution_amd import capi
+    lib = capi.load()
+    w = ra.LocalVector(); w.Allocate("w", n)
+    capi.check(lib.ramd_fused_apply_dot(A._h, x._h, w._h, 9))
+    out = (C.c_double * 1)()
+    capi.check(lib.ramd_scalars_fetch(out, 9, 1))
+    ref = oracle.csr_apply(rp, ci, va, xh)
+    assert np.array_equal(w.numpy(), ref)
+    assert abs(out[0] - float(np.dot(xh, ref))) <= 1e-12 * abs(float(np.dot(xh, ref)))
     for fmt in (ra.ELL, ra.HYB):  # 25..45-entry rows: ELL is accepted (45 <= 5*34), all formats keep the row order
         B = ra.LocalMatrix(); B.CloneFrom(A)
         assert B.ConvertTo(fmt) == fmt
