@@ -115,7 +115,11 @@ __device__ __forceinline__ void grid_reduce_finish(const ReduceCtx& ctx, const d
         for(int k = 0; k < NS; ++k)
             __hip_atomic_store(&ctx.partials[(size_t)slot[k] * kReduceBlocks + blockIdx.x], bsum[k],
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        // The partials travel as 8-byte agent-scope atomics on both sides (write-through store here, L1/L2-bypassing
+        // load in the last workgroup): the valid hand-off form that needs NO release fence.  An agent-scope release
+        // fence is a write-back of the XCD L2's dirty lines -- in a streaming kernel that is megabytes, once per
+        // workgroup (measured: the fused update kernels got slower when the grid grew from 2048 to 8192 workgroups).
+        // Only the completion of the stores has to precede the ticket.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned int t = __hip_atomic_fetch_add(ctx.ticket, 1u, __ATOMIC_RELAXED,
                                                 __HIP_MEMORY_SCOPE_AGENT);

@@ -30,10 +30,11 @@ constexpr int kStreamU = 4;
     _Pragma("unroll") for(int u = 0; u < kStreamU; ++u)                         \
         for(int64_t i_ = stream_base_ + (int64_t)u * kBlock, once_ = 1; once_ && i_ < (np_); once_ = 0)
 
-template <typename P_>
-__device__ __forceinline__ void st_pack(P_* p, P_ v, bool nts)
+// (a compile-time switch: with a run-time flag the compiler once merged both branches into one plain store)
+template <bool NTS_, typename P_>
+__device__ __forceinline__ void st_pack(P_* p, P_ v)
 {
-    if(nts)
+    if constexpr(NTS_)
         __builtin_nontemporal_store(v, p);
     else
         *p = v;
@@ -84,9 +85,9 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(int64_t n, T* __restrict__
                     rz += (double)rn * (double)zn;
                 }
             }
-            st_pack(reinterpret_cast<P*>(r) + i, pr[u], NTS);
+            st_pack<NTS>(reinterpret_cast<P*>(r) + i, pr[u]);
             if(PRECOND)
-                st_pack(reinterpret_cast<P*>(z) + i, pz, NTS);
+                st_pack<NTS>(reinterpret_cast<P*>(z) + i, pz);
         }
     }
     for(int64_t i = np * NP + gtid; i < n; i += gsz)
@@ -140,8 +141,8 @@ __global__ __launch_bounds__(kBlock) void k_cg_direction(int64_t n, T* __restric
                 pk_elems<T>(px[u])[k] = pk_elems<T>(px[u])[k] + alpha * pk_elems<T>(pp[u])[k];
                 pk_elems<T>(pp[u])[k] = beta * pk_elems<T>(pp[u])[k] + pk_elems<T>(pz[u])[k];
             }
-            st_pack(reinterpret_cast<P*>(x) + i, px[u], NTS);
-            st_pack(reinterpret_cast<P*>(p) + i, pp[u], NTS);
+            st_pack<NTS>(reinterpret_cast<P*>(x) + i, px[u]);
+            st_pack<NTS>(reinterpret_cast<P*>(p) + i, pp[u]);
         }
     }
     for(int64_t i = np * NP + gtid; i < n; i += gsz)

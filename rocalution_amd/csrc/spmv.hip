@@ -586,7 +586,7 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
     // long rows (mean > 16 entries): the product-stream kernel with R rows per workgroup (see k_csr_prod)
     static int prod_on = -1;
     if(prod_on < 0)
-        prod_on = getenv("RAMD_CSR_PROD") ? atoi(getenv("RAMD_CSR_PROD")) : 1;
+        prod_on = getenv("RAMD_CSR_PROD") ? atoi(getenv("RAMD_CSR_PROD")) : 0; // measured slower so far (r02d): off
     int rows_per_wg = kCsrRows;
     if(prod_on && m->nrow > 0 && m->nnz > (int64_t)16 * m->nrow)
     {

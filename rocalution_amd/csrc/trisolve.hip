@@ -449,15 +449,17 @@ struct TriPlan
     void* w         = nullptr; // [n] polled scratch
     int   nlevels   = 0;
     bool  nodiag    = false;
-    // chain-tile form (build_ct_plan): tiles = 64 dependency chains x a band of ct_seg() levels, one wave per tile
+    // box-tile form (build_ct_plan): tiles = boxes in three monotone dependency coordinates, one workgroup per tile
     bool ct        = false;
-    int  ct_ntiles = 0, ct_nsteps = 0, ct_wmax = 0, ct_seg = 0;
+    int  ct_ntiles = 0, ct_nsteps = 0, ct_wmax = 0;
+    int  ct_dims[4] = {0, 0, 0, 0}; // max rows / steps / packed entries / external dependencies of a tile
     int* ct_tile_step = nullptr; // [ntiles+1] first step of a tile
     int* ct_step_pos  = nullptr; // [nsteps+1] first position of a step (a step = the rows of one level inside a tile)
     int* ct_step_ent  = nullptr; // [nsteps+1] first packed entry of a step
     int* ct_ext_start = nullptr; // [n+1] first external dependency of a position (running count in position order)
     int* ct_ext_idx   = nullptr; // [next] positions the external dependencies refer to
-    int  ct_extmax    = 0; // external dependencies of the tile that has most
+    int* ct_tile_desc = nullptr; // [8 * ntiles] k_ct_tile_desc
+    int* ct_step_rec  = nullptr; // [4 * (nsteps + 1)] k_ct_step_rec
     void  release()
     {
         dev_free(&ct_tile_step);
@@ -465,6 +467,8 @@ struct TriPlan
         dev_free(&ct_step_ent);
         dev_free(&ct_ext_start);
         dev_free(&ct_ext_idx);
+        dev_free(&ct_tile_desc);
+        dev_free(&ct_step_rec);
         ct = false;
         dev_free(&order);
         dev_free(&pos);
@@ -763,31 +767,29 @@ static int build_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bool 
     return s;
 }
 
-// ======================================================================= chain-tile triangular solve
+// ======================================================================= box-tile triangular solve
 // The level-scheduled kernel above pays one cross-CU hand-off (~5 us) per dependency level: 1534 levels at 512^3, ~8200 on
-// a 2-D shell mesh with 5 unknowns per node (deep, narrow DAG: GMRES+ILU(0) there was SLOWER than one CPU core).
-// Chain-tile form: most of the depth of such DAGs comes from CHAINS -- runs of consecutive rows each depending on its
-// predecessor (an x-pencil of a stencil, a mesh line of a banded FE matrix).  A tile is
-//      (64 consecutive chains) x (a band of ct_seg() consecutive dependency levels),
-// handled by ONE wave: every level of the band is a step, a step holds at most one row per chain (levels grow strictly
-// along a chain), i.e. at most 64 rows -> one row per lane.  Values produced inside the tile travel through LDS (~0.1 us
-// per step instead of ~5 us per level); only values of other tiles are polled in global memory (NaN-sentinel hand-off as
-// above), and those are all polled together at the start of a step.  Both tile coordinates are monotone along every
-// dependency edge (chains are numbered in sweep order, levels grow along edges), so tiles taken in (band, chain group)
-// order -- the ticket order -- only ever wait on tiles that already started: no deadlock for any matrix.
+// a 2-D shell mesh with 5 unknowns per node (deep, narrow DAG: GMRES+ILU(0) there was SLOWER than one CPU core).  Making
+// the hand-off itself cheaper does not help: tiles that stay one level apart run in lockstep at that latency whatever the
+// tile shape (measured: chains x level bands with per-step polling 5.4 ms, with a run-ahead fetcher wave 55 ms at 512^3).
+// What helps is a tile that is SMALL IN EVERY DEPENDENCY DIRECTION and is finished as a unit before its successors
+// start: the solve then costs (depth of the tile DAG) x (time of one tile), and a tile is a few microseconds of LDS work.
+//
+// Tiles for any matrix -- three MONOTONE coordinates per row, propagated along the dependency DAG:
+//      c0(v) = max over dependencies u of c0(u) + [u is v's chain predecessor]   (chain: v depends on the row right before it)
+//      c1(v) = max ... c1(u) + [u lies in the chain right before v's chain]
+//      c2(v) = max ... c2(u) + [u lies in an earlier chain than that]
+// Every coordinate is non-decreasing along EVERY edge, so boxes (c0 / b0, c1 / b1, c2 / b2) form an acyclic tile graph for
+// any matrix, and tiles taken in order of (t0 + t1 + t2, t2, t1, t0) -- the ticket order -- only wait on tiles that
+// already started.  On a lexicographic 3-D stencil the coordinates are the grid coordinates (boxes = cubes), on a
+// banded 2-D FE matrix they are (skewed position along the mesh line, mesh line): parallelograms.
+// Inside a tile the rows run in order of their global dependency level (one step per level present in the tile).
+//
+// One workgroup of two waves per tile.  Everything static the tile needs (packed entries, diagonal, scatter index) and
+// its right-hand side values are copied into LDS in ONE bulk phase with all loads in flight; wave 1 meanwhile polls the
+// values of other tiles the tile depends on (NaN-sentinel hand-off as above) and parks them in LDS; wave 0 then walks the
+// steps touching only LDS, publishes every finished value with one agent-scope store, and is done.
 // The arithmetic per row is unchanged (ascending columns, divide by the stored diagonal): bit-exact with the host.
-static int ct_seg() // dependency levels per tile band: a tile holds at most 64 * seg rows (LDS: 16 KB of fp64 at 32)
-{
-    static int seg = -1;
-    if(seg < 0)
-    {
-        const char* e = getenv("RAMD_TRSV_CT_SEG"); // experiments only
-        seg           = e ? atoi(e) : 32;
-        if(seg < 4 || seg > 128)
-            seg = 32;
-    }
-    return seg;
-}
 
 // sweep space: t = row (lower solve) or n-1-row (upper solve).  start[t] = 1 if row t does not depend on row t-1.
 template <bool LOWER>
@@ -815,23 +817,123 @@ __global__ __launch_bounds__(kBlock) void k_ct_chain_start(int n, const int* __r
     start[t] = cont ? 0 : 1;
 }
 
+// packed coordinates: bit 63 = computed, c0 24 bits, c1 20 bits, c2 19 bits, each saturating (a clamped monotone
+// coordinate is still monotone: far-out tiles just get coarser)
+constexpr unsigned long long kCtReady = 1ull << 63;
+constexpr int                kCtC0Bits = 24, kCtC1Bits = 20, kCtC2Bits = 19;
+__device__ __forceinline__ unsigned long long ct_pack(int c0, int c1, int c2)
+{
+    c0 = min(c0, (1 << kCtC0Bits) - 1);
+    c1 = min(c1, (1 << kCtC1Bits) - 1);
+    c2 = min(c2, (1 << kCtC2Bits) - 1);
+    return kCtReady | (unsigned long long)c0 | ((unsigned long long)c1 << kCtC0Bits)
+           | ((unsigned long long)c2 << (kCtC0Bits + kCtC1Bits));
+}
+__device__ __forceinline__ int ct_c0(unsigned long long w)
+{
+    return (int)(w & ((1ull << kCtC0Bits) - 1));
+}
+__device__ __forceinline__ int ct_c1(unsigned long long w)
+{
+    return (int)((w >> kCtC0Bits) & ((1ull << kCtC1Bits) - 1));
+}
+__device__ __forceinline__ int ct_c2(unsigned long long w)
+{
+    return (int)((w >> (kCtC0Bits + kCtC1Bits)) & ((1ull << kCtC2Bits) - 1));
+}
+
+// sync-free sweep in sweep order (as k_levels): a row polls the packed words of its dependencies; the word is the flag
+// (one 8-byte agent-scope store per row).  ext[0..2] = maxima of the three coordinates.
 template <bool LOWER>
-__global__ __launch_bounds__(kBlock) void k_ct_keys(int n, const int* __restrict__ level, const int* __restrict__ escan,
-                                                    int ncb, int seg, int* __restrict__ lev_t, int* __restrict__ tkey)
+__global__ __launch_bounds__(kBlock) void k_ct_coords(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                      const int* __restrict__ escan, unsigned long long* word,
+                                                      int* __restrict__ ext, unsigned* counter, unsigned base)
+{
+    const unsigned blk  = take_ticket(counter, base);
+    const int64_t  t    = (int64_t)blk * kBlock + threadIdx.x;
+    const bool     live = t < n;
+    const int      i    = live ? (LOWER ? (int)t : (int)(n - 1 - t)) : 0;
+    int            j    = live ? rp[i] : 0;
+    const int      end  = live ? rp[i + 1] : 0;
+    const int      mych = live ? escan[t + 1] - 1 : 0;
+    int            c0 = 0, c1 = 0, c2 = 0;
+    bool           fin     = !live;
+    int            spins   = 0;
+    int            backoff = 1;
+    do
+    {
+        spin_guard(spins);
+        const int  j_start = j;
+        const bool was_fin = fin;
+        if(!fin)
+        {
+            while(j < end)
+            {
+                const int c = ci[j];
+                if(LOWER ? (c >= i) : (c <= i))
+                {
+                    if(LOWER)
+                        j = end; // sorted rows: nothing below the diagonal follows
+                    else
+                        ++j;
+                    continue;
+                }
+                const int                tc = LOWER ? c : n - 1 - c;
+                const unsigned long long w
+                    = __hip_atomic_load(word + tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if(!(w & kCtReady))
+                    break;
+                const int chc = escan[tc + 1] - 1;
+                c0            = max(c0, ct_c0(w) + ((tc == (int)t - 1 && chc == mych) ? 1 : 0));
+                c1            = max(c1, ct_c1(w) + ((chc == mych - 1) ? 1 : 0));
+                c2            = max(c2, ct_c2(w) + ((chc < mych - 1) ? 1 : 0));
+                ++j;
+            }
+            if(j >= end)
+            {
+                __hip_atomic_store(word + t, ct_pack(c0, c1, c2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                fin = true;
+            }
+        }
+        backoff = poll_backoff(__ballot(!was_fin && (fin || j != j_start)) != 0ull, backoff);
+    } while(__ballot(!fin) != 0ull);
+    // maxima: one atomic per wave and coordinate
+    int m0 = live ? min(c0, (1 << kCtC0Bits) - 1) : 0, m1 = live ? min(c1, (1 << kCtC1Bits) - 1) : 0,
+        m2 = live ? min(c2, (1 << kCtC2Bits) - 1) : 0;
+#pragma unroll
+    for(int off = 32; off > 0; off >>= 1)
+    {
+        m0 = max(m0, __shfl_xor(m0, off, 64));
+        m1 = max(m1, __shfl_xor(m1, off, 64));
+        m2 = max(m2, __shfl_xor(m2, off, 64));
+    }
+    if((threadIdx.x & 63) == 0)
+    {
+        atomicMax(ext + 0, m0);
+        atomicMax(ext + 1, m1);
+        atomicMax(ext + 2, m2);
+    }
+}
+
+// tile key of every row (sweep space): boxes of b0 x b1 x b2 in coordinate space, ordered by (t0+t1+t2, t2, t1, t0)
+template <bool LOWER>
+__global__ __launch_bounds__(kBlock) void k_ct_keys(int n, const int* __restrict__ level,
+                                                    const unsigned long long* __restrict__ word, int b0, int b1, int b2,
+                                                    int T0, int T1, int T2, int* __restrict__ lev_t, int* __restrict__ tkey)
 {
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
     for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gsz)
     {
-        const int i     = LOWER ? (int)t : (int)(n - 1 - t);
-        const int lv    = level[i];
-        const int chain = escan[t + 1] - 1;
-        lev_t[t]        = lv;
-        tkey[t]         = ((lv - 1) / seg) * ncb + chain / 64;
+        const int                i = LOWER ? (int)t : (int)(n - 1 - t);
+        const unsigned long long w = word[t];
+        const int                t0 = ct_c0(w) / b0, t1 = ct_c1(w) / b1, t2 = ct_c2(w) / b2;
+        lev_t[t] = level[i];
+        tkey[t]  = (((t0 + t1 + t2) * T2 + t2) * T1 + t1) * T0 + t0;
     }
 }
 
 __global__ __launch_bounds__(kBlock) void k_ct_gather_int(int64_t n, const int* __restrict__ src, const int* __restrict__ idx,
-                                                       int* __restrict__ dst)
+                                                          int* __restrict__ dst)
 {
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
     for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gsz)
@@ -932,14 +1034,22 @@ __global__ __launch_bounds__(kBlock) void k_ct_count_ext(int n, const int* __res
     }
 }
 
-// external dependencies of a tile = ext_start[first position of the next tile] - ext_start[its first position]
-__global__ __launch_bounds__(kBlock) void k_ct_tile_ext(int ntiles, const int* __restrict__ tile_step,
-                                                        const int* __restrict__ step_pos, const int* __restrict__ ext_start,
-                                                        int* __restrict__ out)
+// per tile: rows, steps, packed entries, external dependencies (sizes of the LDS areas)
+__global__ __launch_bounds__(kBlock) void k_ct_tile_sizes(int ntiles, const int* __restrict__ tile_step,
+                                                          const int* __restrict__ step_pos, const int* __restrict__ step_ent,
+                                                          const int* __restrict__ ext_start, int* __restrict__ rows,
+                                                          int* __restrict__ steps, int* __restrict__ ents,
+                                                          int* __restrict__ exts)
 {
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
     for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < ntiles; t += gsz)
-        out[t] = ext_start[step_pos[tile_step[t + 1]]] - ext_start[step_pos[tile_step[t]]];
+    {
+        const int s0 = tile_step[t], s1 = tile_step[t + 1];
+        rows[t]  = step_pos[s1] - step_pos[s0];
+        steps[t] = s1 - s0;
+        ents[t]  = step_ent[s1] - step_ent[s0];
+        exts[t]  = ext_start[step_pos[s1]] - ext_start[step_pos[s0]];
+    }
 }
 
 // entries of a step: [k][rank] with the step's row count as stride; a column inside the tile becomes its LDS index
@@ -1010,51 +1120,131 @@ __global__ __launch_bounds__(kBlock) void k_ct_fill(int n, const int* __restrict
     }
 }
 
-// Two waves per tile.  Wave 1 (the fetcher) walks the tile's list of external dependencies in use order, polls the
-// solution array until the values are there (they belong to tiles that took an earlier ticket) and parks them in LDS,
-// far ahead of wave 0 -- which therefore never waits a cross-CU round trip inside its step loop: it only checks an LDS
-// counter.  Wave 0 (compute): one step per dependency level of the band, one row per lane; registers of a step (its rows'
-// entries, right-hand side, diagonal) are fetched one step ahead.
-template <typename T, int WMAX>
-struct CtStep
+// everything a workgroup needs to know about its tile in one 32-byte record:
+// {first step, steps, first position, rows | first packed entry, packed entries, first external slot, external slots}
+__global__ __launch_bounds__(kBlock) void k_ct_tile_desc(int ntiles, const int* __restrict__ tile_step,
+                                                         const int* __restrict__ step_pos, const int* __restrict__ step_ent,
+                                                         const int* __restrict__ ext_start, int* __restrict__ desc)
 {
-    int c[WMAX];
-    T   a[WMAX];
-    T   b, dg;
-    int p, cnt, w, ebase, onat, need;
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < ntiles; t += gsz)
+    {
+        const int s0 = tile_step[t], s1 = tile_step[t + 1];
+        const int p0 = step_pos[s0], p1 = step_pos[s1];
+        desc[8 * t + 0] = s0;
+        desc[8 * t + 1] = s1 - s0;
+        desc[8 * t + 2] = p0;
+        desc[8 * t + 3] = p1 - p0;
+        desc[8 * t + 4] = step_ent[s0];
+        desc[8 * t + 5] = step_ent[s1] - step_ent[s0];
+        desc[8 * t + 6] = ext_start[p0];
+        desc[8 * t + 7] = ext_start[p1] - ext_start[p0];
+    }
+}
+
+// per step: {first position, first packed entry, external slots used before the step, 0} -- one 16-byte load per step
+// in the bulk phase instead of three dependent ones
+__global__ __launch_bounds__(kBlock) void k_ct_step_rec(int nsteps, const int* __restrict__ step_pos,
+                                                        const int* __restrict__ step_ent, const int* __restrict__ ext_start,
+                                                        int* __restrict__ rec)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g <= nsteps; g += gsz)
+    {
+        const int p    = step_pos[g];
+        rec[4 * g + 0] = p;
+        rec[4 * g + 1] = step_ent[g];
+        rec[4 * g + 2] = ext_start[p];
+        rec[4 * g + 3] = 0;
+    }
+}
+
+// LDS areas of a tile (element counts, the plan's maxima)
+struct CtDims
+{
+    int rows, steps, ents, exts;
 };
+template <typename T>
+static size_t ct_lds_bytes(const CtDims& d, bool with_diag, bool with_out, int lanes_per_row)
+{
+    size_t tvals = (size_t)d.rows /*xs*/ + d.exts /*ex*/ + d.ents /*values*/ + d.rows /*rhs*/ + (with_diag ? d.rows : 0)
+                   + (lanes_per_row > 1 ? 64 * 4 : 0) /*products of a pass*/;
+    size_t ivals = (size_t)d.ents /*columns*/ + (with_out ? d.rows : 0) + 3 * ((size_t)d.steps + 1) + 4;
+    return tvals * sizeof(T) + ivals * sizeof(int) + 32;
+}
 
 constexpr int kCtFetchDepth = 4; // batches of 64 external values the fetcher keeps in flight
 
-template <typename T, int DMODE, int WMAX, bool HAS_OUT>
-__global__ __launch_bounds__(128) void k_trsv_ct(int ntiles, int seg, int extmax, const int* __restrict__ tile_step,
-                                                 const int* __restrict__ step_pos, const int* __restrict__ step_ent,
-                                                 const int* __restrict__ ext_start, const int* __restrict__ ext_idx,
-                                                 const int* __restrict__ ecol, const T* __restrict__ eval,
-                                                 const T* __restrict__ diag, const T* __restrict__ rhs_src,
-                                                 const int* __restrict__ rhs_idx, T* w, T* __restrict__ out,
-                                                 const int* __restrict__ order, unsigned* counter, unsigned base)
+// LPR = lanes per row: 1 (short rows: the lane walks its row) or 8 (long rows: eight lanes form the products of a row,
+// parked in LDS, the first lane subtracts them in storage order)
+template <typename T, int DMODE, bool HAS_OUT, int LPR>
+__global__ __launch_bounds__(128) void k_trsv_box(int ntiles, int group, CtDims dims, const int* __restrict__ tile_desc,
+                                                  const int* __restrict__ step_rec, const int* __restrict__ ext_idx,
+                                                  const int* __restrict__ ecol, const T* __restrict__ eval,
+                                                  const T* __restrict__ diag, const T* __restrict__ rhs_src,
+                                                  const int* __restrict__ rhs_idx, T* w, T* __restrict__ out,
+                                                  const int* __restrict__ order, unsigned* counter, unsigned base)
 {
     extern __shared__ __attribute__((aligned(16))) char ct_lds[];
-    T*             xs    = reinterpret_cast<T*>(ct_lds); // [64 * seg] values of the tile, then [extmax] of other tiles
-    const int      exoff = 64 * seg;
-    int*           ready = reinterpret_cast<int*>(xs + exoff + extmax); // external values parked so far
-    const unsigned t     = take_ticket(counter, base);
-    if(t >= (unsigned)ntiles)
-        return;
-    if(threadIdx.x == 0)
-        *ready = 0;
-    __syncthreads();
-    const int s0 = tile_step[t], s1 = tile_step[t + 1];
-    const int tpos = step_pos[s0];
-    const int e0   = ext_start[tpos];
-    using B        = typename Sentinel<T>::bits;
-    if(threadIdx.x >= 64)
+    T*   xs   = reinterpret_cast<T*>(ct_lds); // [rows] values of the tile
+    T*   ex   = xs + dims.rows; // [exts] values of other tiles
+    T*   lval = ex + dims.exts; // [ents] packed values
+    T*   lb   = lval + dims.ents; // [rows] right-hand side
+    T*   ldg  = lb + dims.rows; // [rows] diagonal (DMODE != 0)
+    T*   prod = ldg + (DMODE != 0 ? dims.rows : 0); // [64 * 4] products of a pass (LPR > 1)
+    int* lcol = reinterpret_cast<int*>(prod + (LPR > 1 ? 64 * 4 : 0)); // [ents] packed columns
+    int* lnat = lcol + dims.ents; // [rows] scatter index of the output
+    int* spos = lnat + (HAS_OUT ? dims.rows : 0); // [steps+1] first row of a step (tile-relative)
+    int* sent = spos + dims.steps + 1; // [steps+1] first entry of a step (tile-relative)
+    int* sneed = sent + dims.steps + 1; // [steps+1] external values used before the step
+    int* ready = sneed + dims.steps + 1; // external values parked so far
+
+    const int      tid    = threadIdx.x;
+    const unsigned ticket = take_ticket(counter, base);
+    // a ticket covers `group` consecutive tiles (one atomic on the shared counter per group: a single word hands out
+    // only ~90 tickets per microsecond); they run one after the other -- each only waits on tiles with smaller numbers,
+    // which belong to earlier tickets or to this workgroup's own past
+    for(int g = 0; g < group; ++g)
     {
-        // ---------------- fetcher wave
-        const int lane = threadIdx.x - 64;
-        const int e1   = ext_start[step_pos[s1]];
-        T*        ex   = xs + exoff;
+    const int64_t t64 = (int64_t)ticket * group + g;
+    if(t64 >= ntiles)
+        break;
+    const int  t  = (int)t64;
+    const v4i32 d0 = reinterpret_cast<const v4i32*>(tile_desc)[2 * t];
+    const v4i32 d1 = reinterpret_cast<const v4i32*>(tile_desc)[2 * t + 1];
+    const int  s0 = d0.x, nsteps = d0.y, tpos = d0.z, nrows = d0.w;
+    const int  E0 = d1.x, nent = d1.y, e0 = d1.z, e1 = d1.z + d1.w;
+    using B       = typename Sentinel<T>::bits;
+    // ---------------- bulk phase: all threads, every load independent of the others
+    if(tid == 0)
+        *ready = 0;
+    for(int i = tid; i < nent; i += 128)
+    {
+        lcol[i] = nt_load(ecol + E0 + i);
+        lval[i] = nt_load(eval + E0 + i);
+    }
+    for(int i = tid; i < nrows; i += 128)
+    {
+        lb[i] = rhs_src[rhs_idx[tpos + i]];
+        if(DMODE != 0)
+            ldg[i] = diag[tpos + i];
+        if(HAS_OUT)
+            lnat[i] = order[tpos + i];
+    }
+    for(int i = tid; i <= nsteps; i += 128)
+    {
+        const v4i32 r = reinterpret_cast<const v4i32*>(step_rec)[s0 + i];
+        spos[i]       = r.x - tpos;
+        sent[i]       = r.y - E0;
+        sneed[i]      = r.z - e0;
+    }
+    __syncthreads();
+    if(tid >= 64)
+    {
+        // ---------------- fetcher wave: the values of other tiles, in use order.  Batches of 64; the polls of up to
+        // kCtFetchDepth batches are in flight together, a batch is handed to the compute wave as soon as it and all
+        // batches before it are complete (the compute wave starts on the first steps while producers still work).
+        const int lane = tid - 64;
         for(int e = e0; e < e1; e += 64 * kCtFetchDepth)
         {
             int idx[kCtFetchDepth];
@@ -1065,142 +1255,148 @@ __global__ __launch_bounds__(128) void k_trsv_ct(int ntiles, int seg, int extmax
                 const int j = e + u * 64 + lane;
                 idx[u]      = (j < e1) ? nt_load(ext_idx + j) : -1;
             }
-            int spins = 0, backoff = 1;
-            for(;;)
+            const int nbatch = min(kCtFetchDepth, (e1 - e + 63) / 64);
+            int       next = 0, spins = 0, backoff = 1;
+            while(next < nbatch)
             {
-                bool all = true;
 #pragma unroll
                 for(int u = 0; u < kCtFetchDepth; ++u)
-                    if(idx[u] >= 0)
-                    {
+                    if(u >= next && idx[u] >= 0)
                         bits[u] = poll_load(w + idx[u]);
-                        all     = all && (bits[u] != Sentinel<T>::value);
+                bool advanced = false;
+#pragma unroll
+                for(int u = 0; u < kCtFetchDepth; ++u)
+                    if(u == next && u < nbatch)
+                    {
+                        const bool missing = idx[u] >= 0 && bits[u] == Sentinel<T>::value;
+                        if(__ballot(missing) == 0ull)
+                        {
+                            if(idx[u] >= 0)
+                                ex[e - e0 + u * 64 + lane] = Sentinel<T>::from_bits(bits[u]);
+                            // the wave's LDS writes before the counter (in-order LDS queue; the wait also pins the compiler)
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            if(lane == 0)
+                                __hip_atomic_store(ready, min(e + (u + 1) * 64, e1) - e0, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                            ++next;
+                            advanced = true;
+                        }
                     }
-                if(__ballot(!all) == 0ull)
-                    break;
-                spin_guard(spins);
-                backoff = poll_backoff(false, backoff);
+                if(!advanced)
+                {
+                    spin_guard(spins);
+                    backoff = poll_backoff(false, backoff);
+                }
             }
-#pragma unroll
-            for(int u = 0; u < kCtFetchDepth; ++u)
-                if(idx[u] >= 0)
-                    ex[e - e0 + u * 64 + lane] = Sentinel<T>::from_bits(bits[u]);
-            const int done = min(e + 64 * kCtFetchDepth, e1) - e0;
-            // the wave's LDS writes before the counter: LDS operations of a wave complete in order, the explicit wait keeps
-            // the compiler from moving the counter store up (a workgroup-scope fence would also drain vmcnt)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if(lane == 0)
-                __hip_atomic_store(ready, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        return;
     }
-    // ---------------- compute wave
-    // Every load and store of the step loop is executed by ALL 64 lanes (lanes beyond the step's row count mirror its
-    // last row: same addresses, same values, harmless duplicate stores): with no vector memory operation under a branch the
-    // compiler can count the operations in flight and wait for the previous step's loads with a partial vmcnt(N), leaving
-    // the next step's loads in flight.  (Masked loads made it fall back to vmcnt(0) everywhere: no prefetch at all.)
-    const int lane = threadIdx.x;
-    // stage A (two steps ahead): the index of the right-hand side entry; stage B (one step ahead): everything else
-    auto stage_a = [&](int s) -> int {
-        const int p0 = step_pos[s], p1 = step_pos[s + 1];
-        return rhs_idx[p0 + min(lane, p1 - p0 - 1)];
-    };
-    auto stage_b = [&](int s, CtStep<T, WMAX>& r, int bidx) {
-        const int p0 = step_pos[s], p1 = step_pos[s + 1];
-        const int eb = step_ent[s], ee = step_ent[s + 1];
-        r.cnt        = p1 - p0;
-        r.w          = (ee - eb) / r.cnt;
-        r.ebase      = eb;
-        const int ln = min(lane, r.cnt - 1);
-        r.p          = p0 + ln;
-        r.need       = ext_start[p1] - e0; // external values the tile has used up to and including this step
-        r.b          = rhs_src[bidx];
-        r.dg         = (DMODE == 0) ? (T)1 : diag[r.p];
-        r.onat       = HAS_OUT ? order[r.p] : 0;
-#pragma unroll
-        for(int k = 0; k < WMAX; ++k)
-        {
-            // (beyond the step's width this reads the following entries: allocated, ignored below)
-            const int ci = nt_load(ecol + eb + k * r.cnt + ln);
-            r.a[k]       = nt_load(eval + eb + k * r.cnt + ln);
-            r.c[k]       = (k < r.w) ? ci : -1;
-        }
-    };
-    int have = 0; // external values known to be parked (wave-uniform)
-    // the subtraction runs in storage order; values of this tile come from LDS (written by earlier steps), values of
-    // other tiles from the fetcher's LDS area right behind them; all LDS reads are issued before the first use
-    auto consume = [&](const int (&c)[WMAX], const T (&a)[WMAX], T& sum) {
-        T v[WMAX];
-#pragma unroll
-        for(int k = 0; k < WMAX; ++k)
-        {
-            const int at = (c[k] >= 0) ? c[k] : ((c[k] < -1) ? exoff - (c[k] + 2) : 0);
-            v[k]         = xs[at];
-        }
-#pragma unroll
-        for(int k = 0; k < WMAX; ++k)
-        {
-            const T prod = a[k] * v[k];
-            sum -= (c[k] == -1) ? (T)0 : prod; // padding: subtracts +0 (changes nothing, whatever xs[0] holds)
-        }
-    };
-    auto finish = [&](const CtStep<T, WMAX>& r) {
-        if(have < r.need) // wave-uniform: wait for the fetcher (LDS counter, no memory round trip)
+    else
+    {
+    // ---------------- compute wave: steps out of LDS
+    const int     lane = tid;
+    constexpr int RPP  = 64 / LPR; // rows per pass
+    const int     sub  = lane % LPR; // my share of the row's entries: k = sub, sub + LPR, ...
+    const int     slot = lane / LPR; // row of the pass
+    int           have = 0;
+    for(int s = 0; s < nsteps; ++s)
+    {
+        const int r0s = spos[s], cnt = spos[s + 1] - r0s;
+        const int eb  = sent[s];
+        const int wd  = (sent[s + 1] - eb) / cnt;
+        const int need = sneed[s + 1];
+        if(have < need) // wave-uniform: wait for the fetcher (LDS counter, no memory round trip)
         {
             int spins = 0;
-            while((have = __hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < r.need)
+            while((have = __hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need)
             {
                 spin_guard(spins);
                 __builtin_amdgcn_s_sleep(1);
             }
-            asm volatile("" ::: "memory"); // LDS reads below stay behind the counter read (in-order LDS queue)
+            asm volatile("" ::: "memory");
         }
-        T sum = r.b;
-        consume(r.c, r.a, sum);
-        if(r.w > WMAX) // rows longer than the register window: the rest without prefetch
+        for(int rb = 0; rb < cnt; rb += RPP)
         {
-            const int ln = min(lane, r.cnt - 1);
-            for(int k0 = WMAX; k0 < r.w; k0 += WMAX)
+            const int  row  = rb + slot;
+            const bool live = row < cnt;
+            T          sum  = (T)0;
+            if(LPR == 1)
             {
-                int cc[WMAX];
-                T   aa[WMAX];
-#pragma unroll
-                for(int k = 0; k < WMAX; ++k)
+                if(live)
                 {
-                    const int ci = nt_load(ecol + r.ebase + (k0 + k) * r.cnt + ln);
-                    aa[k]        = nt_load(eval + r.ebase + (k0 + k) * r.cnt + ln);
-                    cc[k]        = (k0 + k < r.w) ? ci : -1;
+                    sum = lb[r0s + row];
+                    for(int k0 = 0; k0 < wd; k0 += 4) // four entries at a time: LDS reads first, then the ordered subtraction
+                    {
+                        int c[4];
+                        T   a[4], v[4];
+#pragma unroll
+                        for(int q = 0; q < 4; ++q)
+                        {
+                            const bool on = k0 + q < wd;
+                            c[q]          = on ? lcol[eb + (k0 + q) * cnt + row] : -1;
+                            a[q]          = on ? lval[eb + (k0 + q) * cnt + row] : (T)0;
+                        }
+#pragma unroll
+                        for(int q = 0; q < 4; ++q)
+                            v[q] = (c[q] >= 0) ? xs[c[q]] : ((c[q] < -1) ? ex[-(c[q] + 2)] : (T)0);
+#pragma unroll
+                        for(int q = 0; q < 4; ++q)
+                            if(c[q] != -1)
+                                sum -= a[q] * v[q];
+                    }
                 }
-                consume(cc, aa, sum);
+            }
+            else
+            {
+                // products of the row by its LPR lanes, four rounds at a time (LPR * 4 entries), parked in LDS;
+                // then the row's first lane subtracts them in storage order
+                if(live && sub == 0)
+                    sum = lb[r0s + row];
+                for(int k0 = 0; k0 < wd; k0 += LPR * 4)
+                {
+#pragma unroll
+                    for(int q = 0; q < 4; ++q)
+                    {
+                        const int k = k0 + q * LPR + sub;
+                        if(live && k < wd)
+                        {
+                            const int c = lcol[eb + k * cnt + row];
+                            const T   a = lval[eb + k * cnt + row];
+                            const T   v = (c >= 0) ? xs[c] : ((c < -1) ? ex[-(c + 2)] : (T)0);
+                            prod[slot * (LPR * 4) + q * LPR + sub] = (c != -1) ? a * v : (T)0;
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if(live && sub == 0)
+                    {
+                        const int m = min(LPR * 4, wd - k0);
+                        for(int q = 0; q < m; ++q)
+                        {
+                            const int c = lcol[eb + (k0 + q) * cnt + row];
+                            if(c != -1) // padding is not an operation of the host loop
+                                sum -= prod[slot * (LPR * 4) + q];
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            }
+            if(live && sub == 0)
+            {
+                if(DMODE == 1)
+                    sum /= ldg[r0s + row];
+                else if(DMODE == 2)
+                    sum = sum * ldg[r0s + row];
+                xs[r0s + row] = sum;
+                publish(w + tpos + r0s + row, sum);
+                if(HAS_OUT)
+                    out[lnat[r0s + row]] = sum;
             }
         }
-        if(DMODE == 1)
-            sum /= r.dg;
-        else if(DMODE == 2)
-            sum = sum * r.dg;
-        xs[r.p - tpos] = sum;
-        publish(w + r.p, sum);
-        if(HAS_OUT)
-            out[r.onat] = sum;
-        // this step's LDS writes before the next step's reads: one wave, in-order LDS queue -> only the compiler needs
-        // to be held back (no vmcnt wait: the next step's global loads stay in flight)
+        // this step's LDS writes before the next step's reads: one wave, in-order LDS queue
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    };
-
-    // straight-line loop body (the prefetch stages of the last steps re-read the last step instead of branching)
-    CtStep<T, WMAX> cur, nxt;
-    const int       sl = s1 - 1;
-    int             ib = stage_a(s0), ic = stage_a(min(s0 + 1, sl)); // rhs index of step s, s + 1
-    stage_b(s0, cur, ib);
-    ib = ic;
-    for(int s = s0; s < s1; ++s)
-    {
-        ic = stage_a(min(s + 2, sl));
-        stage_b(min(s + 1, sl), nxt, ib);
-        finish(cur);
-        cur = nxt;
-        ib  = ic;
     }
+    } // compute wave
+    __syncthreads(); // both waves are done with the LDS areas before the next tile of the group overwrites them
+    } // tiles of the group
 }
 
 static bool ct_enabled()
@@ -1214,23 +1410,28 @@ static bool ct_enabled()
     return on != 0;
 }
 
-// builds the chain-tile form of a plan; RAMD_ERR_UNSUPPORTED: the matrix has no chains worth it (caller falls back)
+// builds the box-tile form of a plan; RAMD_ERR_UNSUPPORTED: the matrix has no chains worth it, or its tiles do not fit
+// the LDS budget (caller falls back to the level-scheduled form)
 template <typename T>
 static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bool reverse)
 {
     Backend&  b = backend();
     const int n = m->nrow;
-    static int min_rows = -1, min_len = -1; // RAMD_TRSV_CT_MINROWS / _MINLEN = 0: force this form (tests of the small goldens)
+    static int min_rows = -1, min_len = -1, rows_target = -1; // RAMD_TRSV_CT_MINROWS / _MINLEN = 0: force this form (tests)
     if(min_rows < 0)
     {
-        min_rows = getenv("RAMD_TRSV_CT_MINROWS") ? atoi(getenv("RAMD_TRSV_CT_MINROWS")) : 4096;
-        min_len  = getenv("RAMD_TRSV_CT_MINLEN") ? atoi(getenv("RAMD_TRSV_CT_MINLEN")) : 8;
+        min_rows    = getenv("RAMD_TRSV_CT_MINROWS") ? atoi(getenv("RAMD_TRSV_CT_MINROWS")) : 4096;
+        min_len     = getenv("RAMD_TRSV_CT_MINLEN") ? atoi(getenv("RAMD_TRSV_CT_MINLEN")) : 8;
+        rows_target = getenv("RAMD_TRSV_CT_ROWS") ? atoi(getenv("RAMD_TRSV_CT_ROWS")) : 512;
     }
+    static const bool verbose    = getenv("RAMD_TRSV_CT_VERBOSE") != nullptr;
+    static const int  lds_budget = getenv("RAMD_TRSV_CT_LDS") ? atoi(getenv("RAMD_TRSV_CT_LDS")) : 40 * 1024;
     if(n < min_rows || n < 1)
         return RAMD_ERR_UNSUPPORTED;
     int *level = nullptr, *lorder = nullptr, *start = nullptr, *lev_t = nullptr, *tkey = nullptr, *o1 = nullptr,
         *k2 = nullptr, *o2 = nullptr, *tflag = nullptr, *sflag = nullptr, *tscan = nullptr, *sscan = nullptr,
-        *tile_of = nullptr, *step_of = nullptr, *step_w = nullptr, *nodiag = nullptr;
+        *tile_of = nullptr, *step_of = nullptr, *step_w = nullptr, *nodiag = nullptr, *cext = nullptr, *tsz = nullptr;
+    unsigned long long* word = nullptr;
     int  nlev = 0;
     int  s    = RAMD_OK;
     auto cleanup = [&]() {
@@ -1250,6 +1451,9 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
         dev_free(&step_of);
         dev_free(&step_w);
         dev_free(&nodiag);
+        dev_free(&cext);
+        dev_free(&tsz);
+        dev_free(&word);
     };
 #define CT_TRY(expr)     \
     do                   \
@@ -1272,8 +1476,18 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
             RAMD_FAIL(RAMD_ERR_HIP, #expr); \
         }                            \
     } while(0)
-    const int grid = ew_grid(n + 1);
-    const unsigned nb1 = (unsigned)(((int64_t)n + 1 + kBlock - 1) / kBlock);
+#define CT_GIVE_UP()                                                                       \
+    do                                                                                     \
+    {                                                                                      \
+        if(verbose)                                                                        \
+            fprintf(stderr, "box-tile plan: not used for this matrix (trisolve.hip:%d)\n", __LINE__); \
+        cleanup();                                                                         \
+        P->release();                                                                      \
+        return RAMD_ERR_UNSUPPORTED;                                                       \
+    } while(0)
+    const int      grid = ew_grid(n + 1);
+    const unsigned nb1  = (unsigned)(((int64_t)n + 1 + kBlock - 1) / kBlock);
+    const unsigned nb   = nblocks_of(n);
     // chains
     CT_TRY(dev_alloc(&start, (int64_t)n + 1));
     if(lower)
@@ -1285,37 +1499,75 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     CT_HIP(hipMemcpyAsync(&nchains, start + n, sizeof(int), hipMemcpyDeviceToHost, b.cur));
     CT_HIP(hipStreamSynchronize(b.cur));
     if(nchains <= 0 || (int64_t)n < (int64_t)min_len * nchains)
+        CT_GIVE_UP();
+    // monotone coordinates (sync-free sweep) and their extents
+    CT_TRY(dev_alloc(&word, n));
+    CT_TRY(dev_alloc(&cext, 4));
+    CT_HIP(hipMemsetAsync(word, 0, sizeof(unsigned long long) * (size_t)n, b.cur));
+    CT_HIP(hipMemsetAsync(cext, 0, sizeof(int) * 4, b.cur));
+    if(lower)
+        hipLaunchKernelGGL((k_ct_coords<true>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, start, word, cext,
+                           st->counter, st->ticket);
+    else
+        hipLaunchKernelGGL((k_ct_coords<false>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, start, word, cext,
+                           st->counter, st->ticket);
+    st->ticket += nb;
+    int hext[3] = {0, 0, 0};
+    CT_HIP(hipMemcpyAsync(hext, cext, sizeof(int) * 3, hipMemcpyDeviceToHost, b.cur));
+    CT_HIP(hipStreamSynchronize(b.cur));
+    dev_free(&start);
+    // box sizes: b_k proportional to the extent E_k of every non-trivial coordinate (equal depth of the tile DAG in
+    // every direction), about `rows` rows per tile; rows = what the LDS budget (~40 KB) allows for this row length
+    int64_t ntri = 0;
     {
-        cleanup();
-        return RAMD_ERR_UNSUPPORTED;
+        // strictly-triangular entries: (nnz - diagonal) / 2 for a symmetric pattern; nnz as the safe estimate otherwise
+        ntri = (m->nnz > n) ? (m->nnz - n) / 2 : m->nnz;
     }
-    // levels (natural row index)
+    const double wbar = (double)ntri / (double)n;
+    int          rows = (int)(40.0 * 1024.0 / (wbar * (sizeof(T) + 4) + 3 * sizeof(T) + 8));
+    rows              = rows > rows_target ? rows_target : rows;
+    rows              = rows < 32 ? 32 : rows;
+    const int64_t E[3] = {(int64_t)hext[0] + 1, (int64_t)hext[1] + 1, (int64_t)hext[2] + 1};
+    int           dnz  = 0;
+    for(int k = 0; k < 3; ++k)
+        dnz += E[k] > 1 ? 1 : 0;
+    if(dnz == 0)
+        CT_GIVE_UP();
+    int     bs[3] = {1, 1, 1}, Ts[3] = {1, 1, 1};
+    int     ntiles = 0, nsteps = 0, wmax = 0, total = 0;
+    int64_t keymax = 0;
+    // levels (natural row index): once
     CT_TRY(level_order(m, st, lower, &lorder, &nlev, &level));
     dev_free(&lorder);
-    const int     ncb   = (nchains + 63) / 64;
-    const int     seg   = ct_seg();
-    const int64_t nband = ((int64_t)nlev + seg - 1) / seg;
-    if(nband * ncb >= (1ll << 30))
+    bool fits = false;
+    for(int attempt = 0; attempt < 5 && !fits; ++attempt)
     {
-        cleanup();
-        return RAMD_ERR_UNSUPPORTED;
+    const double f = pow((double)rows / (double)n, 1.0 / dnz);
+    for(int k = 0; k < 3; ++k)
+    {
+        double bk = E[k] > 1 ? (double)E[k] * f : 1.0;
+        bs[k]     = bk < 1.0 ? 1 : (int)(bk + 0.5);
+        Ts[k]     = (int)((E[k] + bs[k] - 1) / bs[k]);
     }
+    keymax = (int64_t)(Ts[0] + Ts[1] + Ts[2]) * Ts[2] * Ts[1] * Ts[0];
+    if(keymax >= (1ll << 30))
+        CT_GIVE_UP();
+    // keys, sort by (tile, level, sweep index)
     CT_TRY(dev_alloc(&lev_t, n));
     CT_TRY(dev_alloc(&tkey, n));
     if(lower)
-        hipLaunchKernelGGL((k_ct_keys<true>), dim3(grid), dim3(kBlock), 0, b.cur, n, level, start, ncb, seg, lev_t, tkey);
+        hipLaunchKernelGGL((k_ct_keys<true>), dim3(grid), dim3(kBlock), 0, b.cur, n, level, word, bs[0], bs[1], bs[2], Ts[0],
+                           Ts[1], Ts[2], lev_t, tkey);
     else
-        hipLaunchKernelGGL((k_ct_keys<false>), dim3(grid), dim3(kBlock), 0, b.cur, n, level, start, ncb, seg, lev_t, tkey);
-    dev_free(&level);
-    dev_free(&start);
-    // rows sorted by (tile, level, chain): the sweep order is already chain-sorted, two stable passes do the rest
+        hipLaunchKernelGGL((k_ct_keys<false>), dim3(grid), dim3(kBlock), 0, b.cur, n, level, word, bs[0], bs[1], bs[2], Ts[0],
+                           Ts[1], Ts[2], lev_t, tkey);
     CT_TRY(dev_alloc(&o1, n));
     CT_TRY(device_stable_sort_by_key(lev_t, n, nlev, o1));
     CT_TRY(dev_alloc(&k2, n));
     hipLaunchKernelGGL(k_ct_gather_int, dim3(grid), dim3(kBlock), 0, b.cur, (int64_t)n, tkey, o1, k2);
     dev_free(&tkey);
     CT_TRY(dev_alloc(&o2, n));
-    CT_TRY(device_stable_sort_by_key(k2, n, (int)(nband * ncb), o2));
+    CT_TRY(device_stable_sort_by_key(k2, n, (int)keymax, o2));
     P->release();
     P->n       = n;
     P->nslices = (n + 63) / 64;
@@ -1339,9 +1591,9 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     CT_HIP(hipMemcpyAsync(&cnts[0], tscan + n, sizeof(int), hipMemcpyDeviceToHost, b.cur));
     CT_HIP(hipMemcpyAsync(&cnts[1], sscan + n, sizeof(int), hipMemcpyDeviceToHost, b.cur));
     CT_HIP(hipStreamSynchronize(b.cur));
-    const int ntiles = cnts[0], nsteps = cnts[1];
+    ntiles = cnts[0];
+    nsteps = cnts[1];
     P->ct_ntiles     = ntiles;
-    P->ct_seg        = seg;
     P->ct_nsteps     = nsteps;
     CT_TRY(dev_alloc(&P->ct_tile_step, (int64_t)ntiles + 1));
     CT_TRY(dev_alloc(&P->ct_step_pos, (int64_t)nsteps + 1));
@@ -1362,23 +1614,16 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     dev_free(&sflag);
     dev_free(&tscan);
     dev_free(&sscan);
-    int wmax = 0;
     CT_TRY(device_max_int(step_w, nsteps, &wmax)); // (synchronises)
     if((int64_t)wmax * n >= (1ll << 31) - 65536) // packed entries are addressed with 32-bit offsets
-    {
-        cleanup();
-        P->release();
-        return RAMD_ERR_UNSUPPORTED;
-    }
+        CT_GIVE_UP();
     P->ct_wmax = wmax;
     hipLaunchKernelGGL(k_ct_ent_sizes, dim3(ew_grid(nsteps + 1)), dim3(kBlock), 0, b.cur, nsteps, P->ct_step_pos, step_w,
                        P->ct_step_ent);
     CT_TRY(device_exclusive_scan(P->ct_step_ent, P->ct_step_ent, (int64_t)nsteps + 1));
-    int total = 0;
     CT_HIP(hipMemcpyAsync(&total, P->ct_step_ent + nsteps, sizeof(int), hipMemcpyDeviceToHost, b.cur));
     CT_HIP(hipStreamSynchronize(b.cur));
-    // external dependencies: running count per position (position order = use order), list of the positions they
-    // refer to, and the largest tile's count (sizes the fetcher's LDS area)
+    // external dependencies: running count per position (position order = use order) and the positions they refer to
     CT_TRY(dev_alloc(&P->ct_ext_start, (int64_t)n + 1));
     if(lower)
         hipLaunchKernelGGL((k_ct_count_ext<true>), dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, P->order, P->pos,
@@ -1391,31 +1636,53 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     CT_HIP(hipMemcpyAsync(&next, P->ct_ext_start + n, sizeof(int), hipMemcpyDeviceToHost, b.cur));
     CT_HIP(hipStreamSynchronize(b.cur));
     CT_TRY(dev_alloc(&P->ct_ext_idx, next));
+    // the largest tile in every respect sizes the LDS areas
+    CT_TRY(dev_alloc(&tsz, (int64_t)4 * ntiles));
+    hipLaunchKernelGGL(k_ct_tile_sizes, dim3(ew_grid(ntiles)), dim3(kBlock), 0, b.cur, ntiles, P->ct_tile_step, P->ct_step_pos,
+                       P->ct_step_ent, P->ct_ext_start, tsz, tsz + ntiles, tsz + 2 * (size_t)ntiles, tsz + 3 * (size_t)ntiles);
+    CT_TRY(device_max_int(tsz, ntiles, &P->ct_dims[0]));
+    CT_TRY(device_max_int(tsz + ntiles, ntiles, &P->ct_dims[1]));
+    CT_TRY(device_max_int(tsz + 2 * (size_t)ntiles, ntiles, &P->ct_dims[2]));
+    CT_TRY(device_max_int(tsz + 3 * (size_t)ntiles, ntiles, &P->ct_dims[3]));
     {
-        int* text = nullptr;
-        CT_TRY(dev_alloc(&text, ntiles));
-        hipLaunchKernelGGL(k_ct_tile_ext, dim3(ew_grid(ntiles)), dim3(kBlock), 0, b.cur, ntiles, P->ct_tile_step,
-                           P->ct_step_pos, P->ct_ext_start, text);
-        int emax = 0;
-        s        = device_max_int(text, ntiles, &emax);
-        dev_free(&text);
-        CT_TRY(s);
-        P->ct_extmax = emax;
+        const CtDims d    = {P->ct_dims[0], P->ct_dims[1], P->ct_dims[2], P->ct_dims[3]};
+        const size_t need = ct_lds_bytes<T>(d, true, true, wmax > 8 ? 8 : 1);
+        if(need <= (size_t)lds_budget)
+            fits = true;
+        else
+        {
+            // the occupied part of the coordinate lattice is denser than its bounding box (skewed meshes): smaller boxes
+            if(verbose)
+                fprintf(stderr, "box-tile plan: box=(%d,%d,%d) needs %zu B of LDS per tile (max rows %d): shrinking\n", bs[0],
+                        bs[1], bs[2], need, d.rows);
+            const int nrows_next = (int)((double)rows * (double)lds_budget / (double)need * 0.85);
+            rows                 = nrows_next < rows - 1 ? nrows_next : rows - 1;
+            if(rows < 16)
+                CT_GIVE_UP();
+            dev_free(&P->order);
+            dev_free(&P->pos);
+            dev_free(&P->ct_tile_step);
+            dev_free(&P->ct_step_pos);
+            dev_free(&P->ct_step_ent);
+            dev_free(&P->ct_ext_start);
+            dev_free(&P->ct_ext_idx);
+            dev_free(&tile_of);
+            dev_free(&step_of);
+            dev_free(&step_w);
+            dev_free(&tsz);
+        }
     }
-    // LDS of a tile: its own 64 * seg values + the parked external values + the counter
-    if(((size_t)64 * seg + (size_t)P->ct_extmax) * sizeof(T) + 64 > (size_t)64 * 1024)
-    {
-        cleanup();
-        P->release();
-        return RAMD_ERR_UNSUPPORTED;
-    }
-    CT_TRY(dev_alloc(&P->ecol, (int64_t)total + 32 * 64)); // (+ the register window read past the last step)
-    CT_HIP(cached_malloc(&P->eval, ((size_t)total + 32 * 64) * sizeof(T) + kPad));
+    } // attempts
+    dev_free(&level);
+    dev_free(&word);
+    if(!fits)
+        CT_GIVE_UP();
+    CT_TRY(dev_alloc(&P->ecol, total));
+    CT_HIP(cached_malloc(&P->eval, (size_t)total * sizeof(T) + kPad));
     CT_HIP(cached_malloc(&P->diag, (size_t)n * sizeof(T) + kPad));
     CT_HIP(cached_malloc(&P->w, (size_t)n * sizeof(T) + kPad));
     CT_TRY(dev_alloc(&nodiag, 1));
     CT_HIP(hipMemsetAsync(nodiag, 0, sizeof(int), b.cur));
-    const unsigned nb = nblocks_of(n);
     if(lower)
         hipLaunchKernelGGL((k_ct_fill<T, true>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const T*)m->val, P->order,
                            P->pos, tile_of, step_of, P->ct_tile_step, P->ct_step_pos, P->ct_step_ent, P->ct_ext_start,
@@ -1424,15 +1691,28 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
         hipLaunchKernelGGL((k_ct_fill<T, false>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const T*)m->val, P->order,
                            P->pos, tile_of, step_of, P->ct_tile_step, P->ct_step_pos, P->ct_step_ent, P->ct_ext_start,
                            P->ct_ext_idx, P->ecol, (T*)P->eval, (T*)P->diag, nodiag, reverse ? 1 : 0);
+    CT_TRY(dev_alloc(&P->ct_tile_desc, (int64_t)8 * ntiles));
+    hipLaunchKernelGGL(k_ct_tile_desc, dim3(ew_grid(ntiles)), dim3(kBlock), 0, b.cur, ntiles, P->ct_tile_step, P->ct_step_pos,
+                       P->ct_step_ent, P->ct_ext_start, P->ct_tile_desc);
+    CT_TRY(dev_alloc(&P->ct_step_rec, (int64_t)4 * ((int64_t)nsteps + 1)));
+    hipLaunchKernelGGL(k_ct_step_rec, dim3(ew_grid(nsteps + 1)), dim3(kBlock), 0, b.cur, nsteps, P->ct_step_pos, P->ct_step_ent,
+                       P->ct_ext_start, P->ct_step_rec);
     int nd = 0;
     CT_HIP(hipMemcpyAsync(&nd, nodiag, sizeof(int), hipMemcpyDeviceToHost, b.cur));
     CT_HIP(hipStreamSynchronize(b.cur));
     CT_HIP(hipGetLastError());
     P->nodiag = nd != 0;
     P->ct     = true;
+    if(verbose)
+        fprintf(stderr,
+                "box-tile plan (%s): n=%d chains=%d levels=%d extents=(%lld,%lld,%lld) box=(%d,%d,%d) tiles=%d steps=%d "
+                "wmax=%d max rows/steps/entries/ext per tile = %d/%d/%d/%d\n",
+                lower ? "lower" : "upper", n, nchains, nlev, (long long)E[0], (long long)E[1], (long long)E[2], bs[0], bs[1],
+                bs[2], ntiles, nsteps, wmax, P->ct_dims[0], P->ct_dims[1], P->ct_dims[2], P->ct_dims[3]);
     cleanup();
 #undef CT_TRY
 #undef CT_HIP
+#undef CT_GIVE_UP
     return RAMD_OK;
 }
 
@@ -1457,45 +1737,50 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
                        (T*)P->w);
     if(P->ct)
     {
-        const int    dm           = mul_inv_diag ? 2 : (unit ? 0 : 1);
-        const size_t ct_lds_bytes = ((size_t)64 * P->ct_seg + (size_t)P->ct_extmax) * sizeof(T) + 64;
-#define TRSV_CT(DM, WM, HO)                                                                                             \
-    hipLaunchKernelGGL((k_trsv_ct<T, DM, WM, HO>), dim3((unsigned)P->ct_ntiles), dim3(128), ct_lds_bytes, b.cur, P->ct_ntiles, \
-                       P->ct_seg, P->ct_extmax, P->ct_tile_step, P->ct_step_pos, P->ct_step_ent, P->ct_ext_start,         \
-                       P->ct_ext_idx, P->ecol, (const T*)P->eval, (const T*)P->diag, rhs_src, rhs_idx, (T*)P->w, out,      \
-                       P->order, st->counter, st->ticket)
-#define TRSV_CT_D(DM, WM)       \
+        const int    dm  = mul_inv_diag ? 2 : (unit ? 0 : 1);
+        const int    lpr = P->ct_wmax > 8 ? 8 : 1;
+        const CtDims dims = {P->ct_dims[0], P->ct_dims[1], P->ct_dims[2], P->ct_dims[3]};
+        const size_t lds  = ct_lds_bytes<T>(dims, dm != 0, out != nullptr, lpr);
+        static int   group = -1; // tiles per ticket
+        if(group < 0)
+        {
+            group = getenv("RAMD_TRSV_CT_GROUP") ? atoi(getenv("RAMD_TRSV_CT_GROUP")) : 1; // (measured: 1 is best)
+            group = group < 1 ? 1 : group;
+        }
+        const unsigned nwg = (unsigned)((P->ct_ntiles + group - 1) / group);
+#define TRSV_BOX(DM, HO, LP)                                                                                            \
+    hipLaunchKernelGGL((k_trsv_box<T, DM, HO, LP>), dim3(nwg), dim3(128), lds, b.cur, P->ct_ntiles, group,               \
+                       dims, P->ct_tile_desc, P->ct_step_rec, P->ct_ext_idx, P->ecol,                                   \
+                       (const T*)P->eval, (const T*)P->diag, rhs_src, rhs_idx, (T*)P->w, out, P->order, st->counter,  \
+                       st->ticket)
+#define TRSV_BOX_L(DM, HO)      \
     do                          \
     {                           \
-        if(out)                 \
-            TRSV_CT(DM, WM, true);  \
+        if(lpr == 1)            \
+            TRSV_BOX(DM, HO, 1); \
         else                    \
-            TRSV_CT(DM, WM, false); \
+            TRSV_BOX(DM, HO, 8); \
     } while(0)
-#define TRSV_CT_W(WM)           \
-    do                          \
-    {                           \
-        if(dm == 0)             \
-            TRSV_CT_D(0, WM);   \
-        else if(dm == 1)        \
-            TRSV_CT_D(1, WM);   \
-        else                    \
-            TRSV_CT_D(2, WM);   \
+#define TRSV_BOX_O(DM)             \
+    do                             \
+    {                              \
+        if(out)                    \
+            TRSV_BOX_L(DM, true);  \
+        else                       \
+            TRSV_BOX_L(DM, false); \
     } while(0)
         prof_begin(RAMD_PROF_TRSV, b.cur);
-        if(P->ct_wmax <= 4)
-            TRSV_CT_W(4);
-        else if(P->ct_wmax <= 8)
-            TRSV_CT_W(8);
-        else if(P->ct_wmax <= 16)
-            TRSV_CT_W(16);
+        if(dm == 0)
+            TRSV_BOX_O(0);
+        else if(dm == 1)
+            TRSV_BOX_O(1);
         else
-            TRSV_CT_W(24);
+            TRSV_BOX_O(2);
         prof_end(RAMD_PROF_TRSV, b.cur);
-#undef TRSV_CT_W
-#undef TRSV_CT_D
-#undef TRSV_CT
-        st->ticket += (unsigned)P->ct_ntiles;
+#undef TRSV_BOX_O
+#undef TRSV_BOX_L
+#undef TRSV_BOX
+        st->ticket += nwg;
         RAMD_HIP(hipGetLastError());
         return RAMD_OK;
     }

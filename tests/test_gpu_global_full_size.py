@@ -1,0 +1,111 @@
+"""BASELINE.json configs 4 and 5 at FULL size (3-D Poisson 512^3) through the GlobalMatrix / GlobalVector path on one GPU:
+a size-1 RCCL communicator with the collectives forced on (RAMD_COMM_FORCE_COLLECTIVES=1), i.e. the code path of the
+multi-GPU run with every ncclAllReduce really issued.  The oracle cannot run 134M rows in test time; checked instead:
+  * C4: BiCGStab + BlockJacobi(MultiColoredSGS), interior converted to ELL and to HYB after Build() (the reference's
+    test order, clients/include/testing_cg.hpp:151-155; solver set-up of clients/samples/bicgstab_mpi.cpp:104-116):
+    converges to x = 1, iteration count in the range the 32^3 / 48^3 oracle runs extrapolate to (25 / 36 iterations:
+    ~0.75 N), and the SAME iteration count, final residual and solution as the LocalMatrix path at one rank
+    (SURVEY.md 8e rule 3: P = 1 Global == Local)
+  * C5: MixedPrecisionDC (fp64 defect correction around fp32 CG + Jacobi, inner Init(1e-5, 1e-2, 1e20, 100000) as
+    clients/samples/mixed-precision.cpp:85) converges to x = 1 in a handful of outer iterations.
+Runs in a subprocess: the force switch is read once per process.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_PRELUDE = r'''
+import ctypes as C, os, sys
+import numpy as np
+os.environ["RAMD_COMM_FORCE_COLLECTIVES"] = "1"
+sys.path.insert(0, %r)
+import rocalution_amd as ra
+from rocalution_amd import capi, solvers as S
+ra.init_rocalution()
+lib = capi.load()
+N = 512
+n = N ** 3
+uid = C.create_string_buffer(128)
+capi.check(lib.ramd_comm_unique_id(uid))
+comm = C.c_void_p()
+capi.check(lib.ramd_comm_init_rccl(0, 1, uid, C.byref(comm)))
+nr = C.c_int(0); capi.check(lib.ramd_comm_rccl_count(comm, C.byref(nr))); assert nr.value == 1
+
+def gsolve(g, fmt):
+    capi.check(lib.ramd_gsolver_setup_poisson(g, N, 0, N))
+    capi.check(lib.ramd_gsolver_build(g))
+    if fmt != ra.CSR:
+        capi.check(lib.ramd_gsolver_convert(g, fmt))
+    capi.check(lib.ramd_prof_enable(4, 1))  # count the all-reduces of the run
+    x = np.zeros(n)
+    capi.check(lib.ramd_gsolver_solve(g, None, x.ctypes.data_as(C.c_void_p)))  # rhs = A*1, x0 = 0
+    it, st, rs = C.c_int(0), C.c_int(0), C.c_double(0)
+    capi.check(lib.ramd_gsolver_result(g, C.byref(it), C.byref(st), C.byref(rs)))
+    cnt = C.c_int64(0); capi.check(lib.ramd_prof_count(4, C.byref(cnt)))
+    return x, it.value, st.value, rs.value, cnt.value
+''' % ROOT
+
+
+def _run(body, timeout=1500):
+    r = subprocess.run([sys.executable, "-c", _PRELUDE + body], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "FULL-SIZE OK" in out, out[-3000:]
+    return out
+
+
+@pytest.mark.parametrize("fmt", ["ELL", "HYB"])
+def test_config4_bicgstab_blockjacobi_mcsgs_512_global_equals_local(fmt):
+    _run(r'''
+fmt = ra.%s
+g = C.c_void_p()
+capi.check(lib.ramd_gsolver_create(comm, capi.SOLVER_BICGSTAB, capi.PC_MCSGS, C.byref(g)))
+capi.check(lib.ramd_gsolver_init(g, 1e-15, 1e-6, 1e8, 0, 5000))
+xg, itg, stg, rsg, nred = gsolve(g, fmt)
+assert stg == 2 and 250 <= itg <= 700, (itg, stg)      # 32^3: 25, 48^3: 36 iterations -> ~0.75 N
+assert nred >= 3 * itg, (nred, itg)                     # the scalar all-reduces really went through RCCL
+assert np.sqrt(np.mean((xg - 1.0) ** 2)) < 1e-4
+capi.check(lib.ramd_gsolver_destroy(g))
+# the LocalMatrix path on the same operator: same iterates
+A = ra.LocalMatrix(); A.GenPoisson7(N)
+ones = ra.LocalVector(); ones.Allocate("", n); ones.Ones()
+rhs = ra.LocalVector(); rhs.Allocate("", n); A.Apply(ones, rhs)
+ls = S.BiCGStab(); ls.SetOperator(A); ls.SetPreconditioner(S.MultiColoredSGS()); ls.Init(1e-15, 1e-6, 1e8, 5000); ls.Build()
+assert A.ConvertTo(fmt) == fmt
+x = ra.LocalVector(); x.Allocate("", n)
+ls.Solve(rhs, x)
+assert ls.GetSolverStatus() == 2
+assert ls.GetIterationCount() == itg, (ls.GetIterationCount(), itg)
+assert abs(ls.GetCurrentResidual() - rsg) <= 1e-9 * rsg, (ls.GetCurrentResidual(), rsg)
+assert np.max(np.abs(x.numpy() - xg)) <= 1e-9
+print("FULL-SIZE OK", itg, rsg, nred)
+''' % fmt)
+
+
+def test_config5_mixed_precision_512_global():
+    _run(r'''
+g = C.c_void_p()
+capi.check(lib.ramd_gsolver_create_mixed(comm, capi.SOLVER_CG, capi.PC_JACOBI, C.byref(g)))
+capi.check(lib.ramd_gsolver_init(g, 1e-15, 1e-6, 1e8, 0, 100))
+capi.check(lib.ramd_gsolver_init_inner(g, 1e-5, 1e-2, 1e20, 100000))
+xg, itg, stg, rsg, nred = gsolve(g, ra.CSR)
+assert stg == 2 and 2 <= itg <= 8, (itg, stg)           # 32^3 .. 128^3 oracle runs: 3-4 outer iterations
+assert nred > 100                                        # inner fp32 CG: two all-reduces per iteration
+assert np.sqrt(np.mean((xg - 1.0) ** 2)) < 1e-4
+capi.check(lib.ramd_gsolver_destroy(g))
+# the LocalMatrix MixedPrecisionDC on the same operator: same outer iteration count
+A = ra.LocalMatrix(); A.GenPoisson7(N)
+ones = ra.LocalVector(); ones.Allocate("", n); ones.Ones()
+rhs = ra.LocalVector(); rhs.Allocate("", n); A.Apply(ones, rhs)
+inner = S.CG(np.float32); inner.SetPreconditioner(S.Jacobi()); inner.Init(1e-5, 1e-2, 1e20, 100000)
+mp = S.MixedPrecisionDC(); mp.SetOperator(A); mp.Set(inner); mp.Init(1e-15, 1e-6, 1e8, 100); mp.Build()
+x = ra.LocalVector(); x.Allocate("", n)
+mp.Solve(rhs, x)
+assert mp.GetSolverStatus() == 2 and abs(mp.GetIterationCount() - itg) <= 1, (mp.GetIterationCount(), itg)
+assert np.sqrt(np.mean((x.numpy() - 1.0) ** 2)) < 1e-4
+print("FULL-SIZE OK", itg, rsg, nred)
+''')
