@@ -98,6 +98,12 @@ bool LocalMatrix<ValueType>::ReadFileMTX(const std::string& filename)
         if(sscanf(line.c_str(), "%lld %lld %lld", &nrow, &ncol, &nnz) == 3)
             break;
     }
+    // sizes must be usable as 32-bit row / column indices (and a negative count must not become a huge allocation)
+    if(nrow < 0 || ncol < 0 || nnz < 0 || nrow > 2147483646LL || ncol > 2147483646LL)
+    {
+        LOG_INFO("ReadFileMTX: invalid matrix data (sizes " << nrow << " x " << ncol << ", " << nnz << " entries)");
+        FATAL_ERROR(__FILE__, __LINE__);
+    }
     std::vector<int>       row((size_t)nnz), col((size_t)nnz);
     std::vector<ValueType> val((size_t)nnz);
     char*                  q = const_cast<char*>(p);
@@ -112,12 +118,19 @@ bool LocalMatrix<ValueType>::ReadFileMTX(const std::string& filename)
         }
         q      = e;
         long c = strtol(q, &e, 10);
-        q      = e;
+        bool bad = (e == q); // the reference reads every entry with fscanf(...) != 3 -> error (host_io.cpp:200-216)
+        q        = e;
         double v = 1.0;
         if(!is_pattern)
         {
-            v = strtod(q, &e);
-            q = e;
+            v   = strtod(q, &e);
+            bad = bad || (e == q);
+            q   = e;
+        }
+        if(bad || r < 1 || r > nrow || c < 1 || c > ncol)
+        {
+            LOG_INFO("ReadFileMTX: invalid matrix data (entry " << i + 1 << ")");
+            FATAL_ERROR(__FILE__, __LINE__);
         }
         row[(size_t)i] = (int)r - 1;
         col[(size_t)i] = (int)c - 1;

@@ -670,26 +670,7 @@ int ramd_solver_set_fused_sweeps(ramd_solver_t s, int on)
 }
 int ramd_mat_read_mtx(const char* filename, int dtype, ramd_mat_t* out)
 {
-    if(!filename || !out || (dtype != RAMD_F64 && dtype != RAMD_F32))
-        return RAMD_ERR_ARG;
-    GUARD_BEGIN
-    ramd_mat_t h = NULL;
-    if(ramd_mat_create(dtype, &h) != RAMD_OK)
-        return RAMD_ERR_HIP;
-    if(dtype == RAMD_F64)
-    {
-        LocalMatrix<double> m;
-        m.AdoptDeviceHandle(h);
-        m.ReadFileMTX(filename);
-    }
-    else
-    {
-        LocalMatrix<float> m;
-        m.AdoptDeviceHandle(h);
-        m.ReadFileMTX(filename);
-    }
-    *out = h;
-    GUARD_END
+    return ramd_mat_read_file(filename, RAMD_FILE_MTX, dtype, out);
 }
 int ramd_mat_read_file(const char* filename, int kind, int dtype, ramd_mat_t* out)
 {

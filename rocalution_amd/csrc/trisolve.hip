@@ -449,6 +449,7 @@ struct TriPlan
     void* w         = nullptr; // [n] polled scratch
     int   nlevels   = 0;
     bool  nodiag    = false;
+    bool  filled_once = false;
     // box-tile form (build_ct_plan): tiles = boxes in three monotone dependency coordinates, one workgroup per tile
     bool ct        = false;
     int  ct_ntiles = 0, ct_nsteps = 0, ct_wmax = 0;
@@ -588,6 +589,18 @@ static int tri_get(ramd_mat_s* m, TriState** out)
     }
     *out = tri_state(m);
     return RAMD_OK;
+}
+
+// after a failed launch of a ticketed kernel the device counter and its host copy may disagree (every later sync-free
+// kernel on this matrix would then map its workgroups to the wrong blocks): bring both back to zero
+static void tri_resync(TriState* st)
+{
+    (void)hipDeviceSynchronize();
+    (void)hipGetLastError();
+    if(st && st->counter)
+        (void)hipMemset(st->counter, 0, sizeof(unsigned) * 4);
+    if(st)
+        st->ticket = 0;
 }
 
 static unsigned nblocks_of(int n)
@@ -1142,10 +1155,11 @@ __global__ __launch_bounds__(kBlock) void k_ct_tile_desc(int ntiles, const int* 
     }
 }
 
-// per step: {first position, first packed entry, external slots used before the step, 0} -- one 16-byte load per step
-// in the bulk phase instead of three dependent ones
-__global__ __launch_bounds__(kBlock) void k_ct_step_rec(int nsteps, const int* __restrict__ step_pos,
+// per step: {first position, first packed entry, external slots used before the step, first position of its tile} -- one
+// 16-byte record per step, fetched in bulk when a workgroup starts
+__global__ __launch_bounds__(kBlock) void k_ct_step_rec(int n, int nsteps, const int* __restrict__ step_pos,
                                                         const int* __restrict__ step_ent, const int* __restrict__ ext_start,
+                                                        const int* __restrict__ tile_of, const int* __restrict__ tile_step,
                                                         int* __restrict__ rec)
 {
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
@@ -1155,96 +1169,145 @@ __global__ __launch_bounds__(kBlock) void k_ct_step_rec(int nsteps, const int* _
         rec[4 * g + 0] = p;
         rec[4 * g + 1] = step_ent[g];
         rec[4 * g + 2] = ext_start[p];
-        rec[4 * g + 3] = 0;
+        rec[4 * g + 3] = (p < n) ? step_pos[tile_step[tile_of[p]]] : n;
     }
 }
 
-// LDS areas of a tile (element counts, the plan's maxima)
+// longest strictly-triangular row part
+template <bool LOWER>
+__global__ __launch_bounds__(kBlock) void k_ct_row_wmax(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                        int* __restrict__ out)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    int           m   = 0;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gsz)
+    {
+        int c = 0;
+        for(int j = rp[i]; j < rp[i + 1]; ++j)
+            if(LOWER ? (ci[j] < i) : (ci[j] > i))
+                ++c;
+        m = max(m, c);
+    }
+#pragma unroll
+    for(int off = 32; off > 0; off >>= 1)
+        m = max(m, __shfl_xor(m, off, 64));
+    if((threadIdx.x & 63) == 0)
+        atomicMax(out, m);
+}
+
+// a (tile, level) group of more than `rpp` rows becomes several steps (its rows are independent of each other)
+__global__ __launch_bounds__(kBlock) void k_ct_split(int n, int rpp, const int* __restrict__ gflag, const int* __restrict__ gscan,
+                                                     const int* __restrict__ gpos, int* __restrict__ sflag)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p <= n; p += gsz)
+    {
+        if(p == n)
+        {
+            sflag[p] = 0;
+            continue;
+        }
+        const int gid = gscan[p] + gflag[p] - 1;
+        sflag[p]      = ((p - gpos[gid]) % rpp == 0) ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_ct_scatter_starts(int n, const int* __restrict__ flag, const int* __restrict__ scan,
+                                                              int* __restrict__ start)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gsz)
+        if(flag[p])
+            start[scan[p]] = (int)p;
+}
+
+// LDS areas of a workgroup (element counts, the plan's maxima over tiles)
 struct CtDims
 {
     int rows, steps, ents, exts;
 };
+constexpr int kCtFetchDepth = 4; // batches of 64 external values the fetcher keeps in flight
+constexpr int kCtDepth      = 6; // steps the compute wave's global loads run ahead of its arithmetic
+
 template <typename T>
-static size_t ct_lds_bytes(const CtDims& d, bool with_diag, bool with_out, int lanes_per_row)
+static size_t ct_lds_bytes(const CtDims& d, int group, int lanes_per_row, int wl)
 {
-    size_t tvals = (size_t)d.rows /*xs*/ + d.exts /*ex*/ + d.ents /*values*/ + d.rows /*rhs*/ + (with_diag ? d.rows : 0)
-                   + (lanes_per_row > 1 ? 64 * 4 : 0) /*products of a pass*/;
-    size_t ivals = (size_t)d.ents /*columns*/ + (with_out ? d.rows : 0) + 3 * ((size_t)d.steps + 1) + 4;
-    return tvals * sizeof(T) + ivals * sizeof(int) + 32;
+    size_t tvals = (size_t)d.rows /*xs*/ + 2 * (size_t)d.exts /*ex, two tiles*/
+                   + (lanes_per_row > 1 ? (size_t)64 * wl : 0) /*products of a step*/;
+    size_t ivals = 4 * ((size_t)group * d.steps + 1) /*step records*/ + (size_t)group * d.rows /*rhs index*/ + 8;
+    return tvals * sizeof(T) + ivals * sizeof(int) + 64;
 }
 
-constexpr int kCtFetchDepth = 4; // batches of 64 external values the fetcher keeps in flight
+// registers of one step of the compute wave (loaded kCtDepth steps before they are used)
+template <typename T, int WL>
+struct CtRegs
+{
+    int c[WL];
+    T   a[WL];
+    T   b, dg;
+    int onat;
+};
 
-// LPR = lanes per row: 1 (short rows: the lane walks its row) or 8 (long rows: eight lanes form the products of a row,
-// parked in LDS, the first lane subtracts them in storage order)
-template <typename T, int DMODE, bool HAS_OUT, int LPR>
-__global__ __launch_bounds__(128) void k_trsv_box(int ntiles, int group, CtDims dims, const int* __restrict__ tile_desc,
-                                                  const int* __restrict__ step_rec, const int* __restrict__ ext_idx,
-                                                  const int* __restrict__ ecol, const T* __restrict__ eval,
-                                                  const T* __restrict__ diag, const T* __restrict__ rhs_src,
-                                                  const int* __restrict__ rhs_idx, T* w, T* __restrict__ out,
-                                                  const int* __restrict__ order, unsigned* counter, unsigned base)
+// One workgroup (two waves) per `group` consecutive tiles.
+//   wave 1 (fetcher): per tile, the values of other tiles in use order -> LDS (two tiles' worth of space, so it runs one
+//                     tile ahead); hands them over through a running count.
+//   wave 0 (compute): walks the steps of all its tiles as ONE stream.  The packed entries, right-hand side, diagonal and
+//                     scatter index of a step are loaded kCtDepth steps ahead into registers (the steps of consecutive
+//                     tiles are contiguous in memory, so the pipeline never drains at a tile boundary); a step itself
+//                     touches only LDS (the tile's own values, the parked external ones) and issues its stores.
+// Every vector memory operation of the step loop is executed unconditionally by all 64 lanes -- lanes beyond the step's
+// rows mirror its last row, steps beyond the last one repeat it (same addresses, same values: harmless duplicates) -- so
+// the compiler can count what is in flight and wait with a partial vmcnt(N) instead of draining the prefetch.
+// LPR lanes per row: 1 (W <= WL entries per row) or 8 (W <= 8 * WL): each lane forms WL products of the row, they meet in
+// LDS, and every lane of the row subtracts all of them in storage order (the same roundings as the host loop).
+template <typename T, int DMODE, bool HAS_OUT, int LPR, int WL, bool FETCHER, int DEPTH>
+__global__ __launch_bounds__(FETCHER ? 128 : 64) void k_trsv_stream(int ntiles, int group, CtDims dims, const int* __restrict__ tile_desc,
+                                                     const int* __restrict__ step_rec, const int* __restrict__ ext_idx,
+                                                     const int* __restrict__ ecol, const T* __restrict__ eval,
+                                                     const T* __restrict__ diag, const T* __restrict__ rhs_src,
+                                                     const int* __restrict__ rhs_idx, T* w, T* __restrict__ out,
+                                                     const int* __restrict__ order, unsigned* counter, unsigned base)
 {
     extern __shared__ __attribute__((aligned(16))) char ct_lds[];
-    T*   xs   = reinterpret_cast<T*>(ct_lds); // [rows] values of the tile
-    T*   ex   = xs + dims.rows; // [exts] values of other tiles
-    T*   lval = ex + dims.exts; // [ents] packed values
-    T*   lb   = lval + dims.ents; // [rows] right-hand side
-    T*   ldg  = lb + dims.rows; // [rows] diagonal (DMODE != 0)
-    T*   prod = ldg + (DMODE != 0 ? dims.rows : 0); // [64 * 4] products of a pass (LPR > 1)
-    int* lcol = reinterpret_cast<int*>(prod + (LPR > 1 ? 64 * 4 : 0)); // [ents] packed columns
-    int* lnat = lcol + dims.ents; // [rows] scatter index of the output
-    int* spos = lnat + (HAS_OUT ? dims.rows : 0); // [steps+1] first row of a step (tile-relative)
-    int* sent = spos + dims.steps + 1; // [steps+1] first entry of a step (tile-relative)
-    int* sneed = sent + dims.steps + 1; // [steps+1] external values used before the step
-    int* ready = sneed + dims.steps + 1; // external values parked so far
+    T*     xs   = reinterpret_cast<T*>(ct_lds); // [rows] values of the current tile
+    T*     ex   = xs + dims.rows; // [2][exts] values of other tiles (tile parity)
+    T*     prod = ex + 2 * dims.exts; // [64 * WL] products of a step (LPR > 1)
+    v4i32* recs = reinterpret_cast<v4i32*>(prod + (LPR > 1 ? 64 * WL : 0)); // [group * steps + 1] step records
+    int*   lidx = reinterpret_cast<int*>(recs + (group * dims.steps + 1)); // [group * rows] right-hand side index
+    int*   fetched = lidx + group * dims.rows; // external values parked so far (all tiles of the group)
+    int*   tdone   = fetched + 1; // tiles the compute wave has finished
 
     const int      tid    = threadIdx.x;
     const unsigned ticket = take_ticket(counter, base);
-    // a ticket covers `group` consecutive tiles (one atomic on the shared counter per group: a single word hands out
-    // only ~90 tickets per microsecond); they run one after the other -- each only waits on tiles with smaller numbers,
-    // which belong to earlier tickets or to this workgroup's own past
-    for(int g = 0; g < group; ++g)
-    {
-    const int64_t t64 = (int64_t)ticket * group + g;
-    if(t64 >= ntiles)
-        break;
-    const int  t  = (int)t64;
-    const v4i32 d0 = reinterpret_cast<const v4i32*>(tile_desc)[2 * t];
-    const v4i32 d1 = reinterpret_cast<const v4i32*>(tile_desc)[2 * t + 1];
-    const int  s0 = d0.x, nsteps = d0.y, tpos = d0.z, nrows = d0.w;
-    const int  E0 = d1.x, nent = d1.y, e0 = d1.z, e1 = d1.z + d1.w;
-    using B       = typename Sentinel<T>::bits;
-    // ---------------- bulk phase: all threads, every load independent of the others
+    const int64_t  t0_64  = (int64_t)ticket * group;
+    if(t0_64 >= ntiles)
+        return;
+    const int   t0  = (int)t0_64;
+    const int   ntl = min(group, ntiles - t0);
+    const v4i32 dA0 = reinterpret_cast<const v4i32*>(tile_desc)[2 * t0];
+    const v4i32 dA1 = reinterpret_cast<const v4i32*>(tile_desc)[2 * t0 + 1];
+    const v4i32 dZ0 = reinterpret_cast<const v4i32*>(tile_desc)[2 * (t0 + ntl - 1)];
+    const int   S0 = dA0.x, nst = dZ0.x + dZ0.y - dA0.x; // steps of the group
+    const int   P0 = dA0.z, npos = dZ0.z + dZ0.w - dA0.z; // positions of the group
+    const int   X0 = dA1.z; // first external slot of the group
+    using B        = typename Sentinel<T>::bits;
+    // ---------------- start-up: step records and right-hand side indices of the whole group
     if(tid == 0)
-        *ready = 0;
-    for(int i = tid; i < nent; i += 128)
     {
-        lcol[i] = nt_load(ecol + E0 + i);
-        lval[i] = nt_load(eval + E0 + i);
+        *fetched = 0;
+        *tdone   = 0;
     }
-    for(int i = tid; i < nrows; i += 128)
+    constexpr int NT = FETCHER ? 128 : 64;
+    for(int i = tid; i <= nst; i += NT)
+        recs[i] = reinterpret_cast<const v4i32*>(step_rec)[S0 + i];
+    for(int i = tid; i < npos; i += NT)
+        lidx[i] = rhs_idx[P0 + i];
+    if(!FETCHER)
     {
-        lb[i] = rhs_src[rhs_idx[tpos + i]];
-        if(DMODE != 0)
-            ldg[i] = diag[tpos + i];
-        if(HAS_OUT)
-            lnat[i] = order[tpos + i];
-    }
-    for(int i = tid; i <= nsteps; i += 128)
-    {
-        const v4i32 r = reinterpret_cast<const v4i32*>(step_rec)[s0 + i];
-        spos[i]       = r.x - tpos;
-        sent[i]       = r.y - E0;
-        sneed[i]      = r.z - e0;
-    }
-    __syncthreads();
-    if(tid >= 64)
-    {
-        // ---------------- fetcher wave: the values of other tiles, in use order.  Batches of 64; the polls of up to
-        // kCtFetchDepth batches are in flight together, a batch is handed to the compute wave as soon as it and all
-        // batches before it are complete (the compute wave starts on the first steps while producers still work).
-        const int lane = tid - 64;
+        // single-wave form (one tile per workgroup): the wave parks all external values of its tile itself, all polls
+        // of a round in flight together, before it starts on the steps.  Twice as many tiles fit a CU; a tile whose
+        // producers are still at work simply waits here (in ticket order they started earlier).
+        const int e0 = dA1.z, e1 = dA1.z + dA1.w;
         for(int e = e0; e < e1; e += 64 * kCtFetchDepth)
         {
             int idx[kCtFetchDepth];
@@ -1252,151 +1315,209 @@ __global__ __launch_bounds__(128) void k_trsv_box(int ntiles, int group, CtDims 
 #pragma unroll
             for(int u = 0; u < kCtFetchDepth; ++u)
             {
-                const int j = e + u * 64 + lane;
+                const int j = e + u * 64 + tid;
                 idx[u]      = (j < e1) ? nt_load(ext_idx + j) : -1;
             }
-            const int nbatch = min(kCtFetchDepth, (e1 - e + 63) / 64);
-            int       next = 0, spins = 0, backoff = 1;
-            while(next < nbatch)
+            int spins = 0, backoff = 1;
+            for(;;)
             {
+                bool all = true;
 #pragma unroll
                 for(int u = 0; u < kCtFetchDepth; ++u)
-                    if(u >= next && idx[u] >= 0)
-                        bits[u] = poll_load(w + idx[u]);
-                bool advanced = false;
-#pragma unroll
-                for(int u = 0; u < kCtFetchDepth; ++u)
-                    if(u == next && u < nbatch)
+                    if(idx[u] >= 0)
                     {
-                        const bool missing = idx[u] >= 0 && bits[u] == Sentinel<T>::value;
-                        if(__ballot(missing) == 0ull)
-                        {
-                            if(idx[u] >= 0)
-                                ex[e - e0 + u * 64 + lane] = Sentinel<T>::from_bits(bits[u]);
-                            // the wave's LDS writes before the counter (in-order LDS queue; the wait also pins the compiler)
-                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            if(lane == 0)
-                                __hip_atomic_store(ready, min(e + (u + 1) * 64, e1) - e0, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
-                            ++next;
-                            advanced = true;
-                        }
+                        bits[u] = poll_load(w + idx[u]);
+                        all     = all && (bits[u] != Sentinel<T>::value);
                     }
-                if(!advanced)
+                if(__ballot(!all) == 0ull)
+                    break;
+                spin_guard(spins);
+                backoff = poll_backoff(false, backoff);
+            }
+#pragma unroll
+            for(int u = 0; u < kCtFetchDepth; ++u)
+                if(idx[u] >= 0)
+                    ex[e - e0 + u * 64 + tid] = Sentinel<T>::from_bits(bits[u]);
+        }
+    }
+    __syncthreads();
+    if(FETCHER && tid >= 64)
+    {
+        // ---------------- fetcher wave
+        const int lane = tid - 64;
+        for(int g = 0; g < ntl; ++g)
+        {
+            const v4i32 d1 = reinterpret_cast<const v4i32*>(tile_desc)[2 * (t0 + g) + 1];
+            const int   e0 = d1.z, e1 = d1.z + d1.w;
+            T*          exb = ex + (g & 1) * dims.exts;
+            if(g >= 2) // the buffer of tile g was used by tile g - 2: wait until the compute wave is done with it
+            {
+                int spins = 0;
+                while(__hip_atomic_load(tdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < g - 1)
                 {
                     spin_guard(spins);
-                    backoff = poll_backoff(false, backoff);
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            for(int e = e0; e < e1; e += 64 * kCtFetchDepth)
+            {
+                int idx[kCtFetchDepth];
+                B   bits[kCtFetchDepth];
+#pragma unroll
+                for(int u = 0; u < kCtFetchDepth; ++u)
+                {
+                    const int j = e + u * 64 + lane;
+                    idx[u]      = (j < e1) ? nt_load(ext_idx + j) : -1;
+                }
+                const int nbatch = min(kCtFetchDepth, (e1 - e + 63) / 64);
+                int       next = 0, spins = 0, backoff = 1;
+                while(next < nbatch)
+                {
+#pragma unroll
+                    for(int u = 0; u < kCtFetchDepth; ++u)
+                        if(u >= next && idx[u] >= 0)
+                            bits[u] = poll_load(w + idx[u]);
+                    bool advanced = false;
+#pragma unroll
+                    for(int u = 0; u < kCtFetchDepth; ++u)
+                        if(u == next && u < nbatch)
+                        {
+                            const bool missing = idx[u] >= 0 && bits[u] == Sentinel<T>::value;
+                            if(__ballot(missing) == 0ull)
+                            {
+                                if(idx[u] >= 0)
+                                    exb[e - e0 + u * 64 + lane] = Sentinel<T>::from_bits(bits[u]);
+                                // the wave's LDS writes before the count (in-order LDS queue; the wait pins the compiler)
+                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                                if(lane == 0)
+                                    __hip_atomic_store(fetched, min(e + (u + 1) * 64, e1) - X0, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                                ++next;
+                                advanced = true;
+                            }
+                        }
+                    if(!advanced)
+                    {
+                        spin_guard(spins);
+                        backoff = poll_backoff(false, backoff);
+                    }
                 }
             }
         }
+        return;
     }
-    else
-    {
-    // ---------------- compute wave: steps out of LDS
+    // ---------------- compute wave
     const int     lane = tid;
-    constexpr int RPP  = 64 / LPR; // rows per pass
-    const int     sub  = lane % LPR; // my share of the row's entries: k = sub, sub + LPR, ...
-    const int     slot = lane / LPR; // row of the pass
-    int           have = 0;
-    for(int s = 0; s < nsteps; ++s)
-    {
-        const int r0s = spos[s], cnt = spos[s + 1] - r0s;
-        const int eb  = sent[s];
-        const int wd  = (sent[s + 1] - eb) / cnt;
-        const int need = sneed[s + 1];
-        if(have < need) // wave-uniform: wait for the fetcher (LDS counter, no memory round trip)
+    constexpr int RPP  = 64 / LPR; // rows per step at most
+    const int     sub  = lane % LPR;
+    const int     slot = lane / LPR;
+    const int     last = nst - 1;
+    // record of step i: {first position, first packed entry, external slots used before the step, first position of its tile}
+    auto fetch = [&](int i, CtRegs<T, WL>& r) {
+        const v4i32 a = recs[i], bnext = recs[i + 1];
+        const int   cnt = bnext.x - a.x;
+        const int   wd  = (bnext.y - a.y) / cnt;
+        const int   row = min(slot, cnt - 1);
+        const int   p   = a.x + row;
+        r.b             = rhs_src[lidx[p - P0]];
+        r.dg            = (DMODE == 0) ? (T)1 : diag[p];
+        r.onat          = HAS_OUT ? order[p] : 0;
+#pragma unroll
+        for(int k = 0; k < WL; ++k)
+        {
+            const int ke = k * LPR + sub; // (beyond the row's width this reads following entries: allocated, ignored)
+            const int ci = nt_load(ecol + a.y + ke * cnt + row);
+            r.a[k]       = nt_load(eval + a.y + ke * cnt + row);
+            r.c[k]       = (ke < wd) ? ci : -1;
+        }
+    };
+    int have = 0, tile_no = 0;
+    auto step = [&](int i, const CtRegs<T, WL>& r) {
+        const v4i32 a = recs[i], bnext = recs[i + 1];
+        const int   cnt  = bnext.x - a.x;
+        const int   row  = min(slot, cnt - 1);
+        const int   need = bnext.z - X0; // external values used up to and including this step (running over the group)
+        if(FETCHER && have < need) // wave-uniform: wait for the fetcher (LDS count, no memory round trip)
         {
             int spins = 0;
-            while((have = __hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need)
+            while((have = __hip_atomic_load(fetched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need)
             {
                 spin_guard(spins);
                 __builtin_amdgcn_s_sleep(1);
             }
             asm volatile("" ::: "memory");
         }
-        for(int rb = 0; rb < cnt; rb += RPP)
+        const int exo = dims.rows + (tile_no & 1) * dims.exts; // xs and ex are contiguous: one base for both kinds
+        T         v[WL];
+#pragma unroll
+        for(int k = 0; k < WL; ++k)
         {
-            const int  row  = rb + slot;
-            const bool live = row < cnt;
-            T          sum  = (T)0;
-            if(LPR == 1)
+            const int at = (r.c[k] >= 0) ? r.c[k] : ((r.c[k] < -1) ? exo - (r.c[k] + 2) : 0);
+            v[k]         = xs[at];
+        }
+        T sum = r.b;
+        if(LPR == 1)
+        {
+#pragma unroll
+            for(int k = 0; k < WL; ++k)
             {
-                if(live)
-                {
-                    sum = lb[r0s + row];
-                    for(int k0 = 0; k0 < wd; k0 += 4) // four entries at a time: LDS reads first, then the ordered subtraction
-                    {
-                        int c[4];
-                        T   a[4], v[4];
-#pragma unroll
-                        for(int q = 0; q < 4; ++q)
-                        {
-                            const bool on = k0 + q < wd;
-                            c[q]          = on ? lcol[eb + (k0 + q) * cnt + row] : -1;
-                            a[q]          = on ? lval[eb + (k0 + q) * cnt + row] : (T)0;
-                        }
-#pragma unroll
-                        for(int q = 0; q < 4; ++q)
-                            v[q] = (c[q] >= 0) ? xs[c[q]] : ((c[q] < -1) ? ex[-(c[q] + 2)] : (T)0);
-#pragma unroll
-                        for(int q = 0; q < 4; ++q)
-                            if(c[q] != -1)
-                                sum -= a[q] * v[q];
-                    }
-                }
-            }
-            else
-            {
-                // products of the row by its LPR lanes, four rounds at a time (LPR * 4 entries), parked in LDS;
-                // then the row's first lane subtracts them in storage order
-                if(live && sub == 0)
-                    sum = lb[r0s + row];
-                for(int k0 = 0; k0 < wd; k0 += LPR * 4)
-                {
-#pragma unroll
-                    for(int q = 0; q < 4; ++q)
-                    {
-                        const int k = k0 + q * LPR + sub;
-                        if(live && k < wd)
-                        {
-                            const int c = lcol[eb + k * cnt + row];
-                            const T   a = lval[eb + k * cnt + row];
-                            const T   v = (c >= 0) ? xs[c] : ((c < -1) ? ex[-(c + 2)] : (T)0);
-                            prod[slot * (LPR * 4) + q * LPR + sub] = (c != -1) ? a * v : (T)0;
-                        }
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if(live && sub == 0)
-                    {
-                        const int m = min(LPR * 4, wd - k0);
-                        for(int q = 0; q < m; ++q)
-                        {
-                            const int c = lcol[eb + (k0 + q) * cnt + row];
-                            if(c != -1) // padding is not an operation of the host loop
-                                sum -= prod[slot * (LPR * 4) + q];
-                        }
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-            }
-            if(live && sub == 0)
-            {
-                if(DMODE == 1)
-                    sum /= ldg[r0s + row];
-                else if(DMODE == 2)
-                    sum = sum * ldg[r0s + row];
-                xs[r0s + row] = sum;
-                publish(w + tpos + r0s + row, sum);
-                if(HAS_OUT)
-                    out[lnat[r0s + row]] = sum;
+                const T pr = r.a[k] * v[k];
+                sum -= (r.c[k] == -1) ? (T)0 : pr; // padding subtracts +0: changes nothing
             }
         }
-        // this step's LDS writes before the next step's reads: one wave, in-order LDS queue
+        else
+        {
+            // the row's products meet in LDS ([slot][entry]); every lane of the row then subtracts them in storage order
+            const int wd = (bnext.y - a.y) / cnt;
+#pragma unroll
+            for(int k = 0; k < WL; ++k)
+                prod[slot * (LPR * WL) + k * LPR + sub] = (r.c[k] == -1) ? (T)0 : r.a[k] * v[k];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for(int q = 0; q < wd; ++q)
+                sum -= prod[slot * (LPR * WL) + q];
+        }
+        if(DMODE == 1)
+            sum /= r.dg;
+        else if(DMODE == 2)
+            sum = sum * r.dg;
+        xs[a.x + row - a.w] = sum;
+        publish(w + a.x + row, sum);
+        if(HAS_OUT)
+            out[r.onat] = sum;
+        // this step's LDS traffic before the next step's: one wave, in-order LDS queue
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if(FETCHER && bnext.w != a.w && i < last) // the tile is finished: the fetcher may reuse the buffer of the tile before it
+        {
+            ++tile_no;
+            if(lane == 0)
+                __hip_atomic_store(tdone, tile_no, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    CtRegs<T, WL> st[DEPTH];
+#pragma unroll
+    for(int j = 0; j < DEPTH; ++j)
+        fetch(min(j, last), st[j]);
+    for(int i0 = 0; i0 < nst; i0 += DEPTH)
+    {
+#pragma unroll
+        for(int j = 0; j < DEPTH; ++j)
+        {
+            const int i = i0 + j;
+            step(min(i, last), st[j]); // (beyond the last step: the last one again, its registers were re-fetched)
+            fetch(min(i + DEPTH, last), st[j]);
+        }
     }
-    } // compute wave
-    __syncthreads(); // both waves are done with the LDS areas before the next tile of the group overwrites them
-    } // tiles of the group
+}
+
+static int ct_group() // tiles per workgroup (one ticket, one pipeline start-up)
+{
+    static int group = -1;
+    if(group < 0)
+    {
+        group = getenv("RAMD_TRSV_CT_GROUP") ? atoi(getenv("RAMD_TRSV_CT_GROUP")) : 1; // (measured: grouping tiles serialises the wavefront)
+        group = group < 1 ? 1 : (group > 64 ? 64 : group);
+    }
+    return group;
 }
 
 static bool ct_enabled()
@@ -1523,18 +1644,30 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
         // strictly-triangular entries: (nnz - diagonal) / 2 for a symmetric pattern; nnz as the safe estimate otherwise
         ntri = (m->nnz > n) ? (m->nnz - n) / 2 : m->nnz;
     }
-    const double wbar = (double)ntri / (double)n;
-    int          rows = (int)(40.0 * 1024.0 / (wbar * (sizeof(T) + 4) + 3 * sizeof(T) + 8));
-    rows              = rows > rows_target ? rows_target : rows;
-    rows              = rows < 32 ? 32 : rows;
+    (void)ntri;
+    int rows = rows_target < 32 ? 32 : rows_target; // (LDS holds only the tile's own values and its external ones)
     const int64_t E[3] = {(int64_t)hext[0] + 1, (int64_t)hext[1] + 1, (int64_t)hext[2] + 1};
     int           dnz  = 0;
     for(int k = 0; k < 3; ++k)
         dnz += E[k] > 1 ? 1 : 0;
     if(dnz == 0)
         CT_GIVE_UP();
-    int     bs[3] = {1, 1, 1}, Ts[3] = {1, 1, 1};
-    int     ntiles = 0, nsteps = 0, wmax = 0, total = 0;
+    // longest strictly-triangular row: decides how many lanes share a row (and so how many rows a step may hold)
+    int wmax = 0;
+    CT_HIP(hipMemsetAsync(cext + 3, 0, sizeof(int), b.cur));
+    if(lower)
+        hipLaunchKernelGGL((k_ct_row_wmax<true>), dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, cext + 3);
+    else
+        hipLaunchKernelGGL((k_ct_row_wmax<false>), dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, cext + 3);
+    CT_HIP(hipMemcpyAsync(&wmax, cext + 3, sizeof(int), hipMemcpyDeviceToHost, b.cur));
+    CT_HIP(hipStreamSynchronize(b.cur));
+    if(wmax > 32) // (8 lanes x 4 entries per row and step)
+        CT_GIVE_UP();
+    const int lpr = wmax > 8 ? 8 : 1;
+    const int wl  = lpr == 1 ? (wmax <= 4 ? 4 : 8) : 4;
+    const int rpp = 64 / lpr;
+    int       bs[3] = {1, 1, 1}, Ts[3] = {1, 1, 1};
+    int       ntiles = 0, nsteps = 0, total = 0;
     int64_t keymax = 0;
     // levels (natural row index): once
     CT_TRY(level_order(m, st, lower, &lorder, &nlev, &level));
@@ -1587,6 +1720,26 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     CT_TRY(dev_alloc(&sscan, (int64_t)n + 1));
     CT_TRY(device_exclusive_scan(tflag, tscan, (int64_t)n + 1));
     CT_TRY(device_exclusive_scan(sflag, sscan, (int64_t)n + 1));
+    {
+        // a step holds at most rpp rows: cut the (tile, level) groups (sflag so far) into pieces of rpp rows
+        int ngroups = 0;
+        CT_HIP(hipMemcpyAsync(&ngroups, sscan + n, sizeof(int), hipMemcpyDeviceToHost, b.cur));
+        CT_HIP(hipStreamSynchronize(b.cur));
+        int* gpos = nullptr;
+        CT_TRY(dev_alloc(&gpos, (int64_t)ngroups + 1));
+        hipLaunchKernelGGL(k_ct_scatter_starts, dim3(grid), dim3(kBlock), 0, b.cur, n, sflag, sscan, gpos);
+        int* sflag2 = nullptr;
+        s           = dev_alloc(&sflag2, (int64_t)n + 1);
+        if(s == RAMD_OK)
+        {
+            hipLaunchKernelGGL(k_ct_split, dim3(grid), dim3(kBlock), 0, b.cur, n, rpp, sflag, sscan, gpos, sflag2);
+            s = device_exclusive_scan(sflag2, sscan, (int64_t)n + 1);
+        }
+        dev_free(&gpos);
+        dev_free(&sflag);
+        sflag = sflag2;
+        CT_TRY(s);
+    }
     int cnts[2] = {0, 0};
     CT_HIP(hipMemcpyAsync(&cnts[0], tscan + n, sizeof(int), hipMemcpyDeviceToHost, b.cur));
     CT_HIP(hipMemcpyAsync(&cnts[1], sscan + n, sizeof(int), hipMemcpyDeviceToHost, b.cur));
@@ -1614,7 +1767,6 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     dev_free(&sflag);
     dev_free(&tscan);
     dev_free(&sscan);
-    CT_TRY(device_max_int(step_w, nsteps, &wmax)); // (synchronises)
     if((int64_t)wmax * n >= (1ll << 31) - 65536) // packed entries are addressed with 32-bit offsets
         CT_GIVE_UP();
     P->ct_wmax = wmax;
@@ -1646,7 +1798,7 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     CT_TRY(device_max_int(tsz + 3 * (size_t)ntiles, ntiles, &P->ct_dims[3]));
     {
         const CtDims d    = {P->ct_dims[0], P->ct_dims[1], P->ct_dims[2], P->ct_dims[3]};
-        const size_t need = ct_lds_bytes<T>(d, true, true, wmax > 8 ? 8 : 1);
+        const size_t need = ct_lds_bytes<T>(d, ct_group(), lpr, wl);
         if(need <= (size_t)lds_budget)
             fits = true;
         else
@@ -1677,8 +1829,8 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     dev_free(&word);
     if(!fits)
         CT_GIVE_UP();
-    CT_TRY(dev_alloc(&P->ecol, total));
-    CT_HIP(cached_malloc(&P->eval, (size_t)total * sizeof(T) + kPad));
+    CT_TRY(dev_alloc(&P->ecol, (int64_t)total + 64 * 64)); // (+ what the register window reads past the last step)
+    CT_HIP(cached_malloc(&P->eval, ((size_t)total + 64 * 64) * sizeof(T) + kPad));
     CT_HIP(cached_malloc(&P->diag, (size_t)n * sizeof(T) + kPad));
     CT_HIP(cached_malloc(&P->w, (size_t)n * sizeof(T) + kPad));
     CT_TRY(dev_alloc(&nodiag, 1));
@@ -1695,8 +1847,8 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     hipLaunchKernelGGL(k_ct_tile_desc, dim3(ew_grid(ntiles)), dim3(kBlock), 0, b.cur, ntiles, P->ct_tile_step, P->ct_step_pos,
                        P->ct_step_ent, P->ct_ext_start, P->ct_tile_desc);
     CT_TRY(dev_alloc(&P->ct_step_rec, (int64_t)4 * ((int64_t)nsteps + 1)));
-    hipLaunchKernelGGL(k_ct_step_rec, dim3(ew_grid(nsteps + 1)), dim3(kBlock), 0, b.cur, nsteps, P->ct_step_pos, P->ct_step_ent,
-                       P->ct_ext_start, P->ct_step_rec);
+    hipLaunchKernelGGL(k_ct_step_rec, dim3(ew_grid(nsteps + 1)), dim3(kBlock), 0, b.cur, n, nsteps, P->ct_step_pos,
+                       P->ct_step_ent, P->ct_ext_start, tile_of, P->ct_tile_step, P->ct_step_rec);
     int nd = 0;
     CT_HIP(hipMemcpyAsync(&nd, nodiag, sizeof(int), hipMemcpyDeviceToHost, b.cur));
     CT_HIP(hipStreamSynchronize(b.cur));
@@ -1733,53 +1885,77 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
     if(P->n == 0)
         return RAMD_OK;
     const unsigned nb = nblocks_of(P->n);
-    hipLaunchKernelGGL((k_fill_sentinel<T>), dim3(ew_grid(P->n)), dim3(kBlock), 0, b.cur, (int64_t)P->n,
-                       (T*)P->w);
+    static const bool nofill = getenv("RAMD_TRSV_NOFILL") != nullptr; // diagnostic only (tools/): no dependency waits
+    if(!nofill || !P->filled_once)
+        hipLaunchKernelGGL((k_fill_sentinel<T>), dim3(ew_grid(P->n)), dim3(kBlock), 0, b.cur, (int64_t)P->n,
+                           (T*)P->w);
+    P->filled_once = true;
     if(P->ct)
     {
-        const int    dm  = mul_inv_diag ? 2 : (unit ? 0 : 1);
-        const int    lpr = P->ct_wmax > 8 ? 8 : 1;
-        const CtDims dims = {P->ct_dims[0], P->ct_dims[1], P->ct_dims[2], P->ct_dims[3]};
-        const size_t lds  = ct_lds_bytes<T>(dims, dm != 0, out != nullptr, lpr);
-        static int   group = -1; // tiles per ticket
-        if(group < 0)
-        {
-            group = getenv("RAMD_TRSV_CT_GROUP") ? atoi(getenv("RAMD_TRSV_CT_GROUP")) : 1; // (measured: 1 is best)
-            group = group < 1 ? 1 : group;
-        }
+        const int    dm    = mul_inv_diag ? 2 : (unit ? 0 : 1);
+        const int    lpr   = P->ct_wmax > 8 ? 8 : 1;
+        const int    wl    = lpr == 1 ? (P->ct_wmax <= 4 ? 4 : 8) : 4;
+        static int fetcher = -1; // 1: second wave parks the external values progressively; 0: one wave per tile
+        if(fetcher < 0)
+            fetcher = getenv("RAMD_TRSV_CT_FETCHER") ? atoi(getenv("RAMD_TRSV_CT_FETCHER")) : -2;
+        const bool   fw    = fetcher == -2 ? (lpr == 8) : (fetcher != 0); // long rows / narrow DAGs profit from the overlap
+        static int   depth = -1; // steps of prefetch (experiments: 4 / 6 / 8)
+        if(depth < 0)
+            depth = getenv("RAMD_TRSV_CT_DEPTH") ? atoi(getenv("RAMD_TRSV_CT_DEPTH")) : 6;
+        const int    group = fw ? ct_group() : 1;
+        const CtDims dims  = {P->ct_dims[0], P->ct_dims[1], P->ct_dims[2], P->ct_dims[3]};
+        const size_t lds   = ct_lds_bytes<T>(dims, group, lpr, wl);
         const unsigned nwg = (unsigned)((P->ct_ntiles + group - 1) / group);
-#define TRSV_BOX(DM, HO, LP)                                                                                            \
-    hipLaunchKernelGGL((k_trsv_box<T, DM, HO, LP>), dim3(nwg), dim3(128), lds, b.cur, P->ct_ntiles, group,               \
-                       dims, P->ct_tile_desc, P->ct_step_rec, P->ct_ext_idx, P->ecol,                                   \
-                       (const T*)P->eval, (const T*)P->diag, rhs_src, rhs_idx, (T*)P->w, out, P->order, st->counter,  \
-                       st->ticket)
-#define TRSV_BOX_L(DM, HO)      \
-    do                          \
-    {                           \
-        if(lpr == 1)            \
-            TRSV_BOX(DM, HO, 1); \
-        else                    \
-            TRSV_BOX(DM, HO, 8); \
+#define TRSV_ST_K(DM, HO, LP, WLL, FW, DP, NTH)                                                                         \
+    hipLaunchKernelGGL((k_trsv_stream<T, DM, HO, LP, WLL, FW, DP>), dim3(nwg), dim3(NTH), lds, b.cur, P->ct_ntiles, group, \
+                       dims, P->ct_tile_desc, P->ct_step_rec, P->ct_ext_idx, P->ecol, (const T*)P->eval,                \
+                       (const T*)P->diag, rhs_src, rhs_idx, (T*)P->w, out, P->order, st->counter, st->ticket)
+#define TRSV_ST(DM, HO, LP, WLL)                                                                                        \
+    do                                                                                                                  \
+    {                                                                                                                   \
+        if(fw && depth == 4)                                                                                            \
+            TRSV_ST_K(DM, HO, LP, WLL, true, 4, 128);                                                                   \
+        else if(fw && depth == 8)                                                                                       \
+            TRSV_ST_K(DM, HO, LP, WLL, true, 8, 128);                                                                   \
+        else if(fw)                                                                                                     \
+            TRSV_ST_K(DM, HO, LP, WLL, true, 6, 128);                                                                   \
+        else if(depth == 4)                                                                                             \
+            TRSV_ST_K(DM, HO, LP, WLL, false, 4, 64);                                                                   \
+        else if(depth == 8)                                                                                             \
+            TRSV_ST_K(DM, HO, LP, WLL, false, 8, 64);                                                                   \
+        else                                                                                                            \
+            TRSV_ST_K(DM, HO, LP, WLL, false, 6, 64);                                                                   \
     } while(0)
-#define TRSV_BOX_O(DM)             \
+#define TRSV_ST_L(DM, HO)          \
     do                             \
     {                              \
-        if(out)                    \
-            TRSV_BOX_L(DM, true);  \
+        if(lpr == 8)               \
+            TRSV_ST(DM, HO, 8, 4); \
+        else if(wl == 4)           \
+            TRSV_ST(DM, HO, 1, 4); \
         else                       \
-            TRSV_BOX_L(DM, false); \
+            TRSV_ST(DM, HO, 1, 8); \
+    } while(0)
+#define TRSV_ST_O(DM)             \
+    do                            \
+    {                             \
+        if(out)                   \
+            TRSV_ST_L(DM, true);  \
+        else                      \
+            TRSV_ST_L(DM, false); \
     } while(0)
         prof_begin(RAMD_PROF_TRSV, b.cur);
         if(dm == 0)
-            TRSV_BOX_O(0);
+            TRSV_ST_O(0);
         else if(dm == 1)
-            TRSV_BOX_O(1);
+            TRSV_ST_O(1);
         else
-            TRSV_BOX_O(2);
+            TRSV_ST_O(2);
         prof_end(RAMD_PROF_TRSV, b.cur);
-#undef TRSV_BOX_O
-#undef TRSV_BOX_L
-#undef TRSV_BOX
+#undef TRSV_ST_O
+#undef TRSV_ST_L
+#undef TRSV_ST
+#undef TRSV_ST_K
         st->ticket += nwg;
         RAMD_HIP(hipGetLastError());
         return RAMD_OK;
@@ -2153,7 +2329,7 @@ static int ilu0_long_rows_t(ramd_mat_s* m)
     hipLaunchKernelGGL((k_ilup_wave<T, K, true>), dim3(nbc), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (T*)m->val,  \
                        (int*)nullptr, done, m->diag_pos, (int*)nullptr, 0, st->counter, st->ticket,                \
                        st->l_order_cache, (int64_t)b0 * (kBlock / 64))
-    for(unsigned b0 = 0; b0 < nbw; b0 += kIlupWaveChunk) // a launch holds < 2^32 threads
+    for(unsigned b0 = 0; b0 < nbw && e == hipSuccess; b0 += kIlupWaveChunk) // a launch holds < 2^32 threads
     {
         const unsigned nbc = std::min(kIlupWaveChunk, nbw - b0);
         if(maxlen <= 64)
@@ -2162,14 +2338,16 @@ static int ilu0_long_rows_t(ramd_mat_s* m)
             ILU0_WAVE(2);
         else
             ILU0_WAVE(4);
-        st->ticket += nbc;
+        e = hipGetLastError(); // per chunk: the ticket only advances past launches that went out
+        if(e == hipSuccess)
+            st->ticket += nbc;
     }
 #undef ILU0_WAVE
     if(e == hipSuccess)
-        e = hipGetLastError();
-    if(e == hipSuccess)
         e = hipStreamSynchronize(b.cur);
     dev_free(&done);
+    if(e != hipSuccess)
+        tri_resync(st);
     RAMD_HIP(e);
     return RAMD_OK;
 }
@@ -2235,7 +2413,8 @@ static int ilup_t(ramd_mat_s* m, int p, bool level)
     hipLaunchKernelGGL((k_ilup_wave<T, K>), dim3(nbc), dim3(kBlock), 0, b.cur, n, S->rp, S->ci, (T*)S->val, lev, \
                        done, S->diag_pos, cnt, p, st->counter, st->ticket, st->l_order_cache,                    \
                        (int64_t)b0 * (kBlock / 64))
-        for(unsigned b0 = 0; b0 < nbw; b0 += kIlupWaveChunk)
+        hipError_t le = hipSuccess;
+        for(unsigned b0 = 0; b0 < nbw && le == hipSuccess; b0 += kIlupWaveChunk)
         {
             const unsigned nbc = std::min(kIlupWaveChunk, nbw - b0);
             if(maxlen <= 64)
@@ -2244,18 +2423,33 @@ static int ilup_t(ramd_mat_s* m, int p, bool level)
                 ILUP_WAVE(2);
             else
                 ILUP_WAVE(4);
-            st->ticket += nbc;
+            le = hipGetLastError(); // per chunk: the ticket only advances past launches that went out
+            if(le == hipSuccess)
+                st->ticket += nbc;
         }
 #undef ILUP_WAVE
+        if(le != hipSuccess)
+        {
+            tri_resync(st);
+            return fail(RAMD_ERR_HIP);
+        }
     }
     else
     {
         hipLaunchKernelGGL((k_ilup<T>), dim3(nb), dim3(kBlock), 0, b.cur, n, S->rp, S->ci, (T*)S->val, lev, done,
                            S->diag_pos, cnt, p, st->counter, st->ticket, st->l_order_cache);
+        if(hipGetLastError() != hipSuccess)
+        {
+            tri_resync(st);
+            return fail(RAMD_ERR_HIP);
+        }
         st->ticket += nb;
     }
-    if(hipGetLastError() != hipSuccess || hipStreamSynchronize(b.cur) != hipSuccess)
+    if(hipStreamSynchronize(b.cur) != hipSuccess)
+    {
+        tri_resync(st);
         return fail(RAMD_ERR_HIP);
+    }
     if((s = device_exclusive_scan(cnt, cnt, (int64_t)n + 1)) != RAMD_OK)
         return fail(s);
     int total = 0;

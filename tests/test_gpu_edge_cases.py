@@ -307,3 +307,43 @@ def test_build_clear_cycles_do_not_leak_device_memory(ra, S):
         import gc; gc.collect()
         free.append(free_bytes())
     assert free[-1] >= free[1] - (1 << 20), [f - free[1] for f in free]
+
+
+def test_errors_reach_python_as_exceptions_not_as_exit(ra, S, tmp_path):
+    """the C++ layer's fatal errors (exit(1) in a reference driver) unwind to the C ABI as an error status: a missing or
+    damaged MatrixMarket file, a Solve() after Clear() or with mismatched vectors raise RamdError and leave the process
+    (and the library) usable"""
+    A = ra.LocalMatrix()
+    with pytest.raises(ra.RamdError):
+        A.ReadFileMTX(str(tmp_path / "does_not_exist.mtx"))
+    bad = tmp_path / "bad.mtx"
+    bad.write_text("%%MatrixMarket matrix coordinate real general\n3 3 3\n1 1 2.0\n2 2\n")  # truncated entry
+    with pytest.raises(ra.RamdError):
+        A.ReadFileMTX(str(bad))
+    bad.write_text("%%MatrixMarket matrix coordinate real general\n3 3 2\n1 1 2.0\n4 2 1.0\n")  # row index out of range
+    with pytest.raises(ra.RamdError):
+        A.ReadFileMTX(str(bad))
+    bad.write_text("%%MatrixMarket matrix coordinate real general\n3 3 -2\n")  # negative entry count
+    with pytest.raises(ra.RamdError):
+        A.ReadFileMTX(str(bad))
+    rp, ci, va = gen.poisson7(6)
+    n = len(rp) - 1
+    A.SetDataPtrCSR(rp, ci, va)
+    ls = S.CG(); ls.SetOperator(A); ls.SetPreconditioner(S.Jacobi()); ls.Build()
+    rhs = ra.LocalVector(data=np.ones(n)); x = ra.LocalVector(); x.Allocate("", n)
+    ls.Solve(rhs, x)
+    short = ra.LocalVector(); short.Allocate("", n - 1)
+    with pytest.raises(ra.RamdError):
+        ls.Solve(rhs, short)  # size mismatch
+    xf = ra.LocalVector(np.float32); xf.Allocate("", n)
+    with pytest.raises(ra.RamdError):
+        ls.Solve(rhs, xf)  # value type mismatch
+    ls.Clear()
+    with pytest.raises(ra.RamdError):
+        ls.Solve(rhs, x)  # Solve() after Clear()
+    A32 = ra.LocalMatrix(np.float32); A32.SetDataPtrCSR(rp, ci, va.astype(np.float32))
+    ls2 = S.CG(); ls2.SetOperator(A32)
+    with pytest.raises(ra.RamdError):
+        ls2.Build()  # fp64 solver on an fp32 operator
+    ls.Build(); x.Zeros(); ls.Solve(rhs, x)  # still alive
+    assert ls.GetSolverStatus() in (1, 2)

@@ -182,8 +182,10 @@ def _check_hist(hist, ref_hist, bicgstab, rtol=2e-6):
     difference of every dot product (its residual is not monotone and rho/omega are ratios of small
     numbers), so only its first 8 iterations are held to 1e-6; afterwards the two runs must stay within
     a factor of 30 of each other (single spikes of the erratic phase differ by up to ~16x with the
-    nonsymmetric GS preconditioner) -- the reference's own OpenMP backend moves by as much between thread
-    counts."""
+    nonsymmetric GS preconditioner).  That bound is the reference algorithm's own spread, measured:
+    tests/test_oracle_golden.py::test_bicgstab_residual_history_moves_with_the_summation_order runs the oracle with
+    1..8 OpenMP threads (only the partial-sum order of the dots changes) and finds x198 (BiCGStab), x18 (BiCGStab+GS),
+    x6 (QMRCGStab) between the histories on the 32^3 system."""
     m = min(len(hist), len(ref_hist)) - 2
     if m <= 0:  # runs of one or two iterations: nothing between start and end to compare
         return
