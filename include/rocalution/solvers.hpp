@@ -1772,6 +1772,29 @@ private:
     {
         return false;
     }
+    // the solution update of a cycle as ONE pass over x per eight basis vectors (same order of additions per element)
+    template <class O = OperatorType, class V = VectorType>
+    typename std::enable_if<_fusable<O, V, ValueType>::value, bool>::type doFusedUpdate(VectorType* x, VectorType** upd,
+                                                                                        const ValueType* coef, int count)
+    {
+        if(!this->m_fused || count < 1 || !x->is_accel_())
+            return false;
+        std::vector<ramd_vec_t> hs((size_t)count);
+        std::vector<double>     cs((size_t)count);
+        for(int j = 0; j < count; ++j)
+        {
+            hs[(size_t)j] = _fh(*upd[j]);
+            cs[(size_t)j] = (double)coef[j];
+        }
+        RAMD_CHECK(ramd_fused_multi_axpy(_fh(*x), hs.data(), cs.data(), count));
+        return true;
+    }
+    template <class O = OperatorType, class V = VectorType>
+    typename std::enable_if<!_fusable<O, V, ValueType>::value, bool>::type doFusedUpdate(VectorType*, VectorType**,
+                                                                                         const ValueType*, int)
+    {
+        return false;
+    }
 
     // gmres.cpp:274-413 / :416-562
     void doSolve(const VectorType& rhs, VectorType* x, bool precond)
@@ -1809,9 +1832,9 @@ private:
                     r[k] -= H[this->m_hidx(k, j)] * r[j];
             }
             VectorType** upd = (precond && this->m_flexible) ? this->m_zb : v; // fgmres.cpp:527-532
-            x->AddScale(*upd[0], r[0]);
-            for(int j = 1; j < i; ++j)
-                x->AddScale(*upd[j], r[j]);
+            if(!this->doFusedUpdate(x, upd, r, i)) // x += r_0 upd_0, then r_1 upd_1, ... (one AddScale per basis vector)
+                for(int j = 0; j < i; ++j)
+                    x->AddScale(*upd[j], r[j]);
             this->doResidual(rhs, x, precond);
             std::fill(this->m_r.begin(), this->m_r.end(), ValueType(0));
             r[0] = this->doNorm(*v[0]);

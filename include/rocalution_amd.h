@@ -265,6 +265,9 @@ int ramd_mcsgs_apply_kind(ramd_mcsgs_t h, int kind, ramd_vec_t rhs, ramd_vec_t x
 int ramd_mcsgs_destroy(ramd_mcsgs_t h);
 /* several dot products against one vector in one pass: s[slot0+k] = <v_k, w>, k < count */
 int ramd_fused_multi_dot(const ramd_vec_t* vs, int count, ramd_vec_t w, int slot0);
+/* x = x + coef[0] vs[0]; x = x + coef[1] vs[1]; ... in this order per element: a sequence of AddScale calls
+ * (src/base/base_vector.hpp AddScale; the GMRES solution update, gmres.cpp:522-532) with x read and written once */
+int ramd_fused_multi_axpy(ramd_vec_t x, const ramd_vec_t* vs, const double* coef, int count);
 /* w += (-h) v ; s[slot_dot] = <u, w>   (one MGS step fused with the next dot, gmres.cpp:480-486);
  * h is read from s[slot_h]; u may be NULL (then only the update and s[slot_dot]=<w,w>) */
 int ramd_fused_mgs_step(ramd_vec_t w, ramd_vec_t v, int slot_h, ramd_vec_t u, int slot_dot);

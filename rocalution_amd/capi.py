@@ -168,6 +168,7 @@ SIGNATURES = {
     "ramd_mcsgs_apply_kind": (i32, [ptr, i32, vec_t, vec_t]),
     "ramd_mcsgs_destroy": (i32, [ptr]),
     "ramd_fused_multi_dot": (i32, [C.POINTER(vec_t), i32, vec_t, i32]),
+    "ramd_fused_multi_axpy": (i32, [vec_t, C.POINTER(vec_t), pf64, i32]),
     "ramd_fused_mgs_step": (i32, [vec_t, vec_t, i32, vec_t, i32]),
     "ramd_fused_normalize": (i32, [vec_t, i32, i32]),
     # measurement hooks

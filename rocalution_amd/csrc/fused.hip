@@ -207,6 +207,47 @@ __global__ __launch_bounds__(kBlock) void k_multi_dot(int64_t n, MultiDotArgs<T>
     grid_reduce_finish<NV>(ctx, acc, slots, ops, lds);
 }
 
+// x = x + c_0 v_0 ; x = x + c_1 v_1 ; ... in THIS order per element (the solution update of a GMRES cycle,
+// gmres.cpp:522-532: one AddScale per basis vector), up to kMaxMultiDot vectors per launch: x is read and written once
+// instead of once per vector (24 n bytes per AddScale -> 8 n + 16 n / count)
+template <typename T>
+struct MultiAxpyArgs
+{
+    const T* v[kMaxMultiDot];
+    T        c[kMaxMultiDot];
+};
+template <typename T, int NV>
+__global__ __launch_bounds__(kBlock) void k_multi_axpy(int64_t n, T* __restrict__ x, MultiAxpyArgs<T> a)
+{
+    using P          = typename Pack<T>::type;
+    constexpr int NP = Pack<T>::N;
+    int64_t       np   = n / NP;
+    int64_t       gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t       gsz  = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = gtid; i < np; i += gsz) // (one-shot grid: one turn)
+    {
+        P px = reinterpret_cast<P*>(x)[i];
+        P pv[NV];
+#pragma unroll
+        for(int j = 0; j < NV; ++j)
+            pv[j] = nt_load(reinterpret_cast<const P*>(a.v[j]) + i);
+#pragma unroll
+        for(int j = 0; j < NV; ++j)
+#pragma unroll
+            for(int k = 0; k < NP; ++k)
+                pk_elems<T>(px)[k] = pk_elems<T>(px)[k] + a.c[j] * pk_elems<T>(pv[j])[k];
+        reinterpret_cast<P*>(x)[i] = px;
+    }
+    for(int64_t i = np * NP + gtid; i < n; i += gsz)
+    {
+        T xv = x[i];
+#pragma unroll
+        for(int j = 0; j < NV; ++j)
+            xv = xv + a.c[j] * a.v[j][i];
+        x[i] = xv;
+    }
+}
+
 // one modified-Gram-Schmidt step fused with the NEXT projection's dot (gmres.cpp:480-486):
 //   w = w + (-h)*v ; s[slot_dot] = <u, w>   (u == nullptr: <w, w>)
 template <typename T, bool HAVE_U>
@@ -827,3 +868,52 @@ int ramd_fused_normalize(ramd_vec_t v, int slot_sq, int slot_norm)
 }
 
 } // extern "C"
+
+template <typename T>
+static int multi_axpy_t(ramd_vec_t x, const ramd_vec_t* vs, const double* coef, int count)
+{
+    Backend& b = backend();
+    for(int j0 = 0; j0 < count; j0 += kMaxMultiDot)
+    {
+        const int        nv = (count - j0 < kMaxMultiDot) ? count - j0 : kMaxMultiDot;
+        MultiAxpyArgs<T> a;
+        for(int j = 0; j < kMaxMultiDot; ++j)
+        {
+            a.v[j] = (const T*)vs[j0 + (j < nv ? j : 0)]->d;
+            a.c[j] = (T)coef[j0 + (j < nv ? j : 0)];
+        }
+        const int64_t np   = x->n / Pack<T>::N;
+        const int64_t g    = (np + kBlock - 1) / kBlock;
+        const int     grid = (int)(g < 1 ? 1 : g);
+#define GO(NV)                                                                                              \
+    case NV:                                                                                                \
+        hipLaunchKernelGGL((k_multi_axpy<T, NV>), dim3(grid), dim3(kBlock), 0, b.cur, x->n, (T*)x->d, a); \
+        break;
+        switch(nv)
+        {
+            GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8)
+        }
+#undef GO
+    }
+    RAMD_HIP(hipGetLastError());
+    return RAMD_OK;
+}
+
+extern "C" int ramd_fused_multi_axpy(ramd_vec_t x, const ramd_vec_t* vs, const double* coef, int count)
+{
+    if(!x || !vs || !coef || count < 1)
+        RAMD_FAIL(RAMD_ERR_ARG, "fused_multi_axpy: bad arguments");
+    for(int j = 0; j < count; ++j)
+    {
+        CHECK_SAMEV(vs[j], x);
+        if(vs[j] == x)
+            RAMD_FAIL(RAMD_ERR_ARG, "fused_multi_axpy: a vector aliases the target");
+    }
+    if(x->n == 0)
+        return RAMD_OK;
+    if(x->dtype == RAMD_F64)
+        return multi_axpy_t<double>(x, vs, coef, count);
+    if(x->dtype == RAMD_F32)
+        return multi_axpy_t<float>(x, vs, coef, count);
+    RAMD_FAIL(RAMD_ERR_ARG, "fused_multi_axpy needs real vectors");
+}

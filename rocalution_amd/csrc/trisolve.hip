@@ -1260,8 +1260,8 @@ struct CtRegs
 // the compiler can count what is in flight and wait with a partial vmcnt(N) instead of draining the prefetch.
 // LPR lanes per row: 1 (W <= WL entries per row) or 8 (W <= 8 * WL): each lane forms WL products of the row, they meet in
 // LDS, and every lane of the row subtracts all of them in storage order (the same roundings as the host loop).
-template <typename T, int DMODE, bool HAS_OUT, int LPR, int WL, bool FETCHER, int DEPTH>
-__global__ __launch_bounds__(FETCHER ? 128 : 64) void k_trsv_stream(int ntiles, int group, CtDims dims, const int* __restrict__ tile_desc,
+template <typename T, int DMODE, bool HAS_OUT, int LPR, int WL, int DEPTH>
+__global__ __launch_bounds__(128) void k_trsv_stream(int ntiles, int group, CtDims dims, const int* __restrict__ tile_desc,
                                                      const int* __restrict__ step_rec, const int* __restrict__ ext_idx,
                                                      const int* __restrict__ ecol, const T* __restrict__ eval,
                                                      const T* __restrict__ diag, const T* __restrict__ rhs_src,
@@ -1297,51 +1297,13 @@ __global__ __launch_bounds__(FETCHER ? 128 : 64) void k_trsv_stream(int ntiles, 
         *fetched = 0;
         *tdone   = 0;
     }
-    constexpr int NT = FETCHER ? 128 : 64;
+    constexpr int NT = 128;
     for(int i = tid; i <= nst; i += NT)
         recs[i] = reinterpret_cast<const v4i32*>(step_rec)[S0 + i];
     for(int i = tid; i < npos; i += NT)
         lidx[i] = rhs_idx[P0 + i];
-    if(!FETCHER)
-    {
-        // single-wave form (one tile per workgroup): the wave parks all external values of its tile itself, all polls
-        // of a round in flight together, before it starts on the steps.  Twice as many tiles fit a CU; a tile whose
-        // producers are still at work simply waits here (in ticket order they started earlier).
-        const int e0 = dA1.z, e1 = dA1.z + dA1.w;
-        for(int e = e0; e < e1; e += 64 * kCtFetchDepth)
-        {
-            int idx[kCtFetchDepth];
-            B   bits[kCtFetchDepth];
-#pragma unroll
-            for(int u = 0; u < kCtFetchDepth; ++u)
-            {
-                const int j = e + u * 64 + tid;
-                idx[u]      = (j < e1) ? nt_load(ext_idx + j) : -1;
-            }
-            int spins = 0, backoff = 1;
-            for(;;)
-            {
-                bool all = true;
-#pragma unroll
-                for(int u = 0; u < kCtFetchDepth; ++u)
-                    if(idx[u] >= 0)
-                    {
-                        bits[u] = poll_load(w + idx[u]);
-                        all     = all && (bits[u] != Sentinel<T>::value);
-                    }
-                if(__ballot(!all) == 0ull)
-                    break;
-                spin_guard(spins);
-                backoff = poll_backoff(false, backoff);
-            }
-#pragma unroll
-            for(int u = 0; u < kCtFetchDepth; ++u)
-                if(idx[u] >= 0)
-                    ex[e - e0 + u * 64 + tid] = Sentinel<T>::from_bits(bits[u]);
-        }
-    }
     __syncthreads();
-    if(FETCHER && tid >= 64)
+    if(tid >= 64)
     {
         // ---------------- fetcher wave
         const int lane = tid - 64;
@@ -1437,7 +1399,7 @@ __global__ __launch_bounds__(FETCHER ? 128 : 64) void k_trsv_stream(int ntiles, 
         const int   cnt  = bnext.x - a.x;
         const int   row  = min(slot, cnt - 1);
         const int   need = bnext.z - X0; // external values used up to and including this step (running over the group)
-        if(FETCHER && have < need) // wave-uniform: wait for the fetcher (LDS count, no memory round trip)
+        if(have < need) // wave-uniform: wait for the fetcher (LDS count, no memory round trip)
         {
             int spins = 0;
             while((have = __hip_atomic_load(fetched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need)
@@ -1473,6 +1435,7 @@ __global__ __launch_bounds__(FETCHER ? 128 : 64) void k_trsv_stream(int ntiles, 
             for(int k = 0; k < WL; ++k)
                 prod[slot * (LPR * WL) + k * LPR + sub] = (r.c[k] == -1) ? (T)0 : r.a[k] * v[k];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // (reading all 32 slots into registers first and subtracting them unrolled was measured slower: 9.9 vs 8.9 ms)
             for(int q = 0; q < wd; ++q)
                 sum -= prod[slot * (LPR * WL) + q];
         }
@@ -1486,7 +1449,7 @@ __global__ __launch_bounds__(FETCHER ? 128 : 64) void k_trsv_stream(int ntiles, 
             out[r.onat] = sum;
         // this step's LDS traffic before the next step's: one wave, in-order LDS queue
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if(FETCHER && bnext.w != a.w && i < last) // the tile is finished: the fetcher may reuse the buffer of the tile before it
+        if(bnext.w != a.w && i < last) // the tile is finished: the fetcher may reuse the buffer of the tile before it
         {
             ++tile_no;
             if(lane == 0)
@@ -1895,46 +1858,24 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
         const int    dm    = mul_inv_diag ? 2 : (unit ? 0 : 1);
         const int    lpr   = P->ct_wmax > 8 ? 8 : 1;
         const int    wl    = lpr == 1 ? (P->ct_wmax <= 4 ? 4 : 8) : 4;
-        static int fetcher = -1; // 1: second wave parks the external values progressively; 0: one wave per tile
-        if(fetcher < 0)
-            fetcher = getenv("RAMD_TRSV_CT_FETCHER") ? atoi(getenv("RAMD_TRSV_CT_FETCHER")) : -2;
-        const bool   fw    = fetcher == -2 ? (lpr == 8) : (fetcher != 0); // long rows / narrow DAGs profit from the overlap
-        static int   depth = -1; // steps of prefetch (experiments: 4 / 6 / 8)
-        if(depth < 0)
-            depth = getenv("RAMD_TRSV_CT_DEPTH") ? atoi(getenv("RAMD_TRSV_CT_DEPTH")) : 6;
-        const int    group = fw ? ct_group() : 1;
+        const int    group = ct_group();
         const CtDims dims  = {P->ct_dims[0], P->ct_dims[1], P->ct_dims[2], P->ct_dims[3]};
         const size_t lds   = ct_lds_bytes<T>(dims, group, lpr, wl);
         const unsigned nwg = (unsigned)((P->ct_ntiles + group - 1) / group);
-#define TRSV_ST_K(DM, HO, LP, WLL, FW, DP, NTH)                                                                         \
-    hipLaunchKernelGGL((k_trsv_stream<T, DM, HO, LP, WLL, FW, DP>), dim3(nwg), dim3(NTH), lds, b.cur, P->ct_ntiles, group, \
-                       dims, P->ct_tile_desc, P->ct_step_rec, P->ct_ext_idx, P->ecol, (const T*)P->eval,                \
-                       (const T*)P->diag, rhs_src, rhs_idx, (T*)P->w, out, P->order, st->counter, st->ticket)
-#define TRSV_ST(DM, HO, LP, WLL)                                                                                        \
-    do                                                                                                                  \
-    {                                                                                                                   \
-        if(fw && depth == 4)                                                                                            \
-            TRSV_ST_K(DM, HO, LP, WLL, true, 4, 128);                                                                   \
-        else if(fw && depth == 8)                                                                                       \
-            TRSV_ST_K(DM, HO, LP, WLL, true, 8, 128);                                                                   \
-        else if(fw)                                                                                                     \
-            TRSV_ST_K(DM, HO, LP, WLL, true, 6, 128);                                                                   \
-        else if(depth == 4)                                                                                             \
-            TRSV_ST_K(DM, HO, LP, WLL, false, 4, 64);                                                                   \
-        else if(depth == 8)                                                                                             \
-            TRSV_ST_K(DM, HO, LP, WLL, false, 8, 64);                                                                   \
-        else                                                                                                            \
-            TRSV_ST_K(DM, HO, LP, WLL, false, 6, 64);                                                                   \
-    } while(0)
+// prefetch depth: 8 steps for short rows (12 small loads per step), 6 for the 8-lanes-per-row form (measured)
+#define TRSV_ST(DM, HO, LP, WLL, DP)                                                                                     \
+    hipLaunchKernelGGL((k_trsv_stream<T, DM, HO, LP, WLL, DP>), dim3(nwg), dim3(128), lds, b.cur, P->ct_ntiles, group, dims, \
+                       P->ct_tile_desc, P->ct_step_rec, P->ct_ext_idx, P->ecol, (const T*)P->eval, (const T*)P->diag,    \
+                       rhs_src, rhs_idx, (T*)P->w, out, P->order, st->counter, st->ticket)
 #define TRSV_ST_L(DM, HO)          \
     do                             \
     {                              \
-        if(lpr == 8)               \
-            TRSV_ST(DM, HO, 8, 4); \
-        else if(wl == 4)           \
-            TRSV_ST(DM, HO, 1, 4); \
-        else                       \
-            TRSV_ST(DM, HO, 1, 8); \
+        if(lpr == 8)                  \
+            TRSV_ST(DM, HO, 8, 4, 6); \
+        else if(wl == 4)              \
+            TRSV_ST(DM, HO, 1, 4, 8); \
+        else                          \
+            TRSV_ST(DM, HO, 1, 8, 6); \
     } while(0)
 #define TRSV_ST_O(DM)             \
     do                            \
@@ -1955,7 +1896,6 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
 #undef TRSV_ST_O
 #undef TRSV_ST_L
 #undef TRSV_ST
-#undef TRSV_ST_K
         st->ticket += nwg;
         RAMD_HIP(hipGetLastError());
         return RAMD_OK;

@@ -32,7 +32,11 @@ int launch_map(int64_t n, F f)
 {
     if(n <= 0)
         return RAMD_OK;
-    int grid = ew_grid((n + Pack<T>::N - 1) / Pack<T>::N);
+    // one-shot grid (a packet per thread, no grid-stride loop): 5.3-6.7 TB/s against 4.6-4.9 TB/s with a resident
+    // grid on these streaming patterns (tools/membench.hip, profiles/r02_membench.txt)
+    const int64_t np   = (n + Pack<T>::N - 1) / Pack<T>::N;
+    int64_t       g    = (np + kBlock - 1) / kBlock;
+    const int     grid = (int)(g < 1 ? 1 : (g > 0x7fffffff ? 0x7fffffff : g));
     hipLaunchKernelGGL((k_map<T, F>), dim3(grid), dim3(kBlock), 0, backend().cur, n, f);
     RAMD_HIP(hipGetLastError());
     return RAMD_OK;

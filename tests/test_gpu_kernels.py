@@ -823,3 +823,26 @@ def test_block_hyperplane_schedule_gives_identical_results():
                         "multicoloring or ilu or trisolve or preconditioner_apply or mcsgs or vs_oracle_larger"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("count", [1, 3, 8, 13, 30])
+def test_fused_multi_axpy_equals_the_addscale_sequence(ra, dtype, count):
+    """ramd_fused_multi_axpy (the GMRES solution update in one pass per eight basis vectors): the same additions per
+    element in the same order as `count` AddScale calls -> bit-identical"""
+    import ctypes as C
+    from rocalution_amd import capi
+    lib = capi.load()
+    n = 100003
+    rng = np.random.default_rng(count)
+    x0 = rng.uniform(-1, 1, n).astype(dtype)
+    vs = [ra.LocalVector(dtype, data=rng.uniform(-1, 1, n).astype(dtype)) for _ in range(count)]
+    coef = rng.uniform(-2, 2, count)
+    a = ra.LocalVector(dtype, data=x0)
+    for v, c in zip(vs, coef):
+        a.AddScale(v, float(dtype(c)))
+    b = ra.LocalVector(dtype, data=x0)
+    hs = (capi.vec_t * count)(*[v._h for v in vs])
+    cs = (C.c_double * count)(*[float(dtype(c)) for c in coef])
+    capi.check(lib.ramd_fused_multi_axpy(b._h, hs, cs, count))
+    assert np.array_equal(a.numpy(), b.numpy())

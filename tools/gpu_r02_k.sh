@@ -1,0 +1,13 @@
+#!/bin/bash
+mkdir -p gpurun_out/r02k
+cd /root/repo
+export TMPDIR=/tmp
+timeout 3000 python -m pytest tests -x -q -m gpu > gpurun_out/r02k/full_gpu.log 2>&1; echo "full gpu suite rc=$?"; tail -4 gpurun_out/r02k/full_gpu.log
+timeout 900 python bench.py > gpurun_out/r02k/bench_cg.json 2> gpurun_out/r02k/bench_cg.err; echo "bench cg rc=$?"
+timeout 900 python bench.py --solver gmres --precond ilu0 --steps 60 --warmup 10 --cpu-grid 256 --cpu-iters 20 > gpurun_out/r02k/bench_gmres.json 2> gpurun_out/r02k/bench_gmres.err; echo "bench gmres rc=$?"
+timeout 900 python bench.py --matrix shell --solver gmres --precond ilu0 --steps 60 --warmup 10 > gpurun_out/r02k/bench_shell.json 2> gpurun_out/r02k/bench_shell.err; echo "bench shell rc=$?"
+timeout 900 python bench.py --solver bicgstab --precond mcsgs --format ell --steps 60 --warmup 10 --no-cpu-baseline --no-reference-gpu > gpurun_out/r02k/bench_c4.json 2> gpurun_out/r02k/bench_c4.err; echo "bench c4 rc=$?"
+timeout 900 python bench.py --solver mixed --steps 10 --warmup 2 --no-cpu-baseline --no-reference-gpu > gpurun_out/r02k/bench_c5.json 2> gpurun_out/r02k/bench_c5.err; echo "bench c5 rc=$?"
+timeout 600 python bench.py --force-global --steps 100 --warmup 10 > gpurun_out/r02k/bench_global1.json 2> gpurun_out/r02k/bench_global1.err; echo "bench global rc=$?"
+cd /tmp; timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /root/repo/gpurun_out/r02k/calib -o c --output-format csv -- /root/repo/tools/_bin/membench calib > /root/repo/gpurun_out/r02k/calib.log 2>&1; echo "calib rc=$?"
+cd /root/repo; python __graft_entry__.py smoke > gpurun_out/r02k/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 gpurun_out/r02k/smoke.log

@@ -14,6 +14,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 typedef double v2 __attribute__((ext_vector_type(2)));
@@ -188,8 +189,46 @@ static void sweep(const Bufs& B, const char* name, int bpe)
     sweep_nt<PAT, 8>(B, name, bpe, {8, 16, 0});
 }
 
+// calibration of the FETCH_SIZE counter against known byte counts: the same 1 GiB read with 16, 8 and 4 bytes per lane
+//   rocprofv3 --pmc FETCH_SIZE --kernel-trace -- tools/_bin/membench calib
+template <typename X>
+__global__ __launch_bounds__(256) void k_calib_read(int64_t nx, const X* __restrict__ a, double* __restrict__ sink)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if(i < nx)
+    {
+        X      v = a[i];
+        double s = 0.0;
+        for(unsigned k = 0; k < sizeof(X) / 4; ++k)
+            s += (double)reinterpret_cast<const int*>(&v)[k];
+        if(s == 1.2345e300)
+            sink[0] = s;
+    }
+}
+
 int main(int argc, char** argv)
 {
+    if(argc > 1 && std::string(argv[1]) == "calib")
+    {
+        const size_t bytes = (size_t)1 << 30;
+        void*        a     = nullptr;
+        double*      sink  = nullptr;
+        CHECK(hipMalloc(&a, bytes));
+        CHECK(hipMalloc(&sink, 64));
+        CHECK(hipMemset(a, 0, bytes));
+        for(int rep = 0; rep < 3; ++rep)
+        {
+            hipLaunchKernelGGL((k_calib_read<v2>), dim3((unsigned)(bytes / 16 / 256)), dim3(256), 0, 0, (int64_t)(bytes / 16),
+                               (const v2*)a, sink);
+            hipLaunchKernelGGL((k_calib_read<double>), dim3((unsigned)(bytes / 8 / 256)), dim3(256), 0, 0, (int64_t)(bytes / 8),
+                               (const double*)a, sink);
+            hipLaunchKernelGGL((k_calib_read<int>), dim3((unsigned)(bytes / 4 / 256)), dim3(256), 0, 0, (int64_t)(bytes / 4),
+                               (const int*)a, sink);
+        }
+        CHECK(hipDeviceSynchronize());
+        printf("calib: 3 x (16 B, 8 B, 4 B per lane) reads of %zu bytes each\n", bytes);
+        return 0;
+    }
     const int64_t n = argc > 1 ? atoll(argv[1]) : (int64_t)512 * 512 * 512;
     Bufs          B;
     B.np = n / 2;
