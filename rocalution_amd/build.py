@@ -23,7 +23,7 @@ HIPCC = os.path.join(ROCM, "bin", "hipcc")
 # so FMA contraction would buy nothing.
 CXXFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
             "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
-            "-I" + os.path.join(os.path.dirname(HERE), "include")]
+            "-I" + os.path.join(os.path.dirname(HERE), "include")] + os.environ.get("RAMD_EXTRA_CXXFLAGS", "").split()
 LDFLAGS = ["-shared", "-fPIC", "--offload-arch=gfx950", "-L" + os.path.join(ROCM, "lib"), "-lrccl",
            "-Wl,-rpath," + os.path.join(ROCM, "lib")]
 

@@ -452,6 +452,7 @@ struct TriPlan
     bool  filled_once = false;
     // box-tile form (build_ct_plan): tiles = boxes in three monotone dependency coordinates, one workgroup per tile
     bool ct        = false;
+    bool ct_rec    = false; // rows of <= 8 entries: record form (k_trsv_rec), `eval` holds the quads
     int  ct_ntiles = 0, ct_nsteps = 0, ct_wmax = 0;
     int  ct_dims[4] = {0, 0, 0, 0}; // max rows / steps / packed entries / external dependencies of a tile
     int* ct_tile_step = nullptr; // [ntiles+1] first step of a tile
@@ -461,6 +462,11 @@ struct TriPlan
     int* ct_ext_idx   = nullptr; // [next] positions the external dependencies refer to
     int* ct_tile_desc = nullptr; // [8 * ntiles] k_ct_tile_desc
     int* ct_step_rec  = nullptr; // [4 * (nsteps + 1)] k_ct_step_rec
+    // record form: the rows of every tile sorted by where their right-hand side comes from (source index, row number inside
+    // the tile), so that the fetch wave reads a tile's right-hand side with line-sized runs; valid for the index array `ct_in_key`
+    int*            ct_in_src = nullptr; // [n]
+    unsigned short* ct_in_loc = nullptr; // [n]
+    const int*      ct_in_key = nullptr;
     void  release()
     {
         dev_free(&ct_tile_step);
@@ -470,7 +476,10 @@ struct TriPlan
         dev_free(&ct_ext_idx);
         dev_free(&ct_tile_desc);
         dev_free(&ct_step_rec);
-        ct = false;
+        dev_free(&ct_in_src);
+        dev_free(&ct_in_loc);
+        ct_in_key = nullptr;
+        ct = ct_rec = false;
         dev_free(&order);
         dev_free(&pos);
         dev_free(&slice_off);
@@ -493,6 +502,11 @@ struct TriState
     int*      lu_rhs_idx = nullptr; // [n]: U position -> L position of the same row
     unsigned* counter    = nullptr; // shared workgroup ticket
     unsigned  ticket     = 0; // host copy of the counter value
+    // ticket streams of the persistent box-tile solve: one counter word serves ~88 tickets per microsecond (262144 tiles at
+    // 512^3 = 3 ms of tickets alone); tile k belongs to stream k % streams, every stream has its own word (own 4 KB page)
+    static constexpr int kStreams = 16, kStreamStride = 1024;
+    unsigned* stream_counter = nullptr; // [kStreams * kStreamStride]
+    unsigned  stream_ticket[kStreams] = {0}; // host copies
     // rows ordered by (lower-dependency level, row), computed once per pattern: ILU(0) runs in this order
     // and LAnalyse / LUAnalyse take it over
     int* l_order_cache = nullptr;
@@ -558,6 +572,7 @@ void tri_release(ramd_mat_s* m)
     st->U.release();
     dev_free(&st->lu_rhs_idx);
     dev_free(&st->counter);
+    dev_free(&st->stream_counter);
     dev_free(&st->l_order_cache);
     st->LLf.release();
     st->LLb.release();
@@ -599,8 +614,14 @@ static void tri_resync(TriState* st)
     (void)hipGetLastError();
     if(st && st->counter)
         (void)hipMemset(st->counter, 0, sizeof(unsigned) * 4);
+    if(st && st->stream_counter)
+        (void)hipMemset(st->stream_counter, 0, sizeof(unsigned) * TriState::kStreams * TriState::kStreamStride);
     if(st)
+    {
         st->ticket = 0;
+        for(int i = 0; i < TriState::kStreams; ++i)
+            st->stream_ticket[i] = 0;
+    }
 }
 
 static unsigned nblocks_of(int n)
@@ -1375,30 +1396,43 @@ __global__ __launch_bounds__(128) void k_trsv_stream(int ntiles, int group, CtDi
     const int     slot = lane / LPR;
     const int     last = nst - 1;
     // record of step i: {first position, first packed entry, external slots used before the step, first position of its tile}
+    // The step records come out of LDS into vector registers although every lane reads the same record: pin them to
+    // scalar registers (readfirstlane), so that addresses are a scalar base per array plus a small per-lane offset --
+    // the counters of r02 showed the kernel ISSUE bound (284 instructions per step, half of them 64-bit address
+    // arithmetic on the vector ALU), not memory bound.
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
     auto fetch = [&](int i, CtRegs<T, WL>& r) {
         const v4i32 a = recs[i], bnext = recs[i + 1];
-        const int   cnt = bnext.x - a.x;
-        const int   wd  = (bnext.y - a.y) / cnt;
-        const int   row = min(slot, cnt - 1);
-        const int   p   = a.x + row;
-        r.b             = rhs_src[lidx[p - P0]];
-        r.dg            = (DMODE == 0) ? (T)1 : diag[p];
-        r.onat          = HAS_OUT ? order[p] : 0;
+        const int   apos = uni(a.x), aent = uni(a.y);
+        const int   cnt  = uni(bnext.x) - apos;
+        const int   wd   = (uni(bnext.y) - aent) / cnt;
+        const int   row  = min(slot, cnt - 1);
+        const int*  colb = ecol + aent; // scalar bases of this step
+        const T*    valb = eval + aent;
+        const int   p    = apos + row;
+        r.b              = rhs_src[lidx[p - P0]];
+        r.dg             = (DMODE == 0) ? (T)1 : (diag + apos)[row];
+        r.onat           = HAS_OUT ? (order + apos)[row] : 0;
 #pragma unroll
         for(int k = 0; k < WL; ++k)
         {
-            const int ke = k * LPR + sub; // (beyond the row's width this reads following entries: allocated, ignored)
-            const int ci = nt_load(ecol + a.y + ke * cnt + row);
-            r.a[k]       = nt_load(eval + a.y + ke * cnt + row);
-            r.c[k]       = (ke < wd) ? ci : -1;
+            const int ke  = k * LPR + sub; // (beyond the row's width this reads following entries: allocated, ignored)
+            const int off = ke * cnt + row;
+            const int ci  = nt_load(colb + off);
+            r.a[k]        = nt_load(valb + off);
+            r.c[k]        = (ke < wd) ? ci : -1;
         }
     };
     int have = 0, tile_no = 0;
     auto step = [&](int i, const CtRegs<T, WL>& r) {
-        const v4i32 a = recs[i], bnext = recs[i + 1];
-        const int   cnt  = bnext.x - a.x;
-        const int   row  = min(slot, cnt - 1);
-        const int   need = bnext.z - X0; // external values used up to and including this step (running over the group)
+        const v4i32 a0 = recs[i], b0 = recs[i + 1];
+        struct
+        {
+            int x, y, z, w;
+        } a = {uni(a0.x), uni(a0.y), uni(a0.z), uni(a0.w)}, bnext = {uni(b0.x), uni(b0.y), uni(b0.z), uni(b0.w)};
+        const int cnt  = bnext.x - a.x;
+        const int row  = min(slot, cnt - 1);
+        const int need = bnext.z - X0; // external values used up to and including this step (running over the group)
         if(have < need) // wave-uniform: wait for the fetcher (LDS count, no memory round trip)
         {
             int spins = 0;
@@ -1443,7 +1477,7 @@ __global__ __launch_bounds__(128) void k_trsv_stream(int ntiles, int group, CtDi
             sum /= r.dg;
         else if(DMODE == 2)
             sum = sum * r.dg;
-        xs[a.x + row - a.w] = sum;
+        xs[a.x - a.w + row] = sum;
         publish(w + a.x + row, sum);
         if(HAS_OUT)
             out[r.onat] = sum;
@@ -1469,6 +1503,616 @@ __global__ __launch_bounds__(128) void k_trsv_stream(int ntiles, int group, CtDi
             step(min(i, last), st[j]); // (beyond the last step: the last one again, its registers were re-fetched)
             fetch(min(i + DEPTH, last), st[j]);
         }
+    }
+}
+
+// ======================================================================= record form of the box-tile solve (rows of <= 8 entries)
+// Counters of the stream kernel above (profiles/r02_trsv_counters.txt): the solve is bound by the NUMBER of vector memory
+// instructions a step issues (13 per step of ~23 rows: the CU's address path and the 6-bit vmcnt window both count
+// instructions, not bytes) and by the start-up chain of a tile (ticket -> descriptor -> step records -> first loads, ~5 us
+// of a ~20 us tile).  The record form attacks both:
+//   * everything static a row needs is ONE record of 16-byte quads -- {column codes as 16-bit LDS indices | values | diagonal |
+//     scatter index} -- stored quad-major per step, so a step loads it with 2-3 fully coalesced 16-byte loads instead
+//     of 8-11 narrow ones; a unit-diagonal solve without natural-order output skips the quad(s) holding diagonal and index;
+//   * workgroups are PERSISTENT: the second wave takes the tickets, posts the tile descriptor into an LDS ring and parks the
+//     tile's external values up to two tiles ahead, so the compute wave walks the steps of tile after tile as one stream
+//     whose prefetch never drains (ticket order still guarantees progress: a tile only waits on lower tickets, all held
+//     by running workgroups whose earlier tiles are finished first);
+//   * step records are uniform: fetched through the scalar cache one step ahead, not through LDS.
+// Column codes: 0 = padding (LDS slot 0 holds 0.0 and the padded value is 0: subtracts +0), 1 + q = row q of the tile,
+// 1 + rows_max + j = external value j of the tile.
+constexpr int kCtRing = 3; // tiles the ticket/fetch wave may be ahead of the compute wave (+1)
+
+template <typename T, int WL>
+struct CtRec
+{
+    static constexpr int WLC      = (WL + 3) / 4 * 4; // 16-bit codes, padded to whole 8-byte slots
+    static constexpr int off_val  = WLC * 2;
+    static constexpr int off_diag = off_val + WL * (int)sizeof(T);
+    static constexpr int off_ord  = off_diag + (int)sizeof(T);
+    static constexpr int NQ       = (off_ord + 4 + 15) / 16; // quads of a row (storage stride)
+    static constexpr int NQL      = (off_diag + 15) / 16; // quads without diagonal and scatter index
+};
+
+template <typename T>
+static size_t ct_rec_lds_bytes(const CtDims& d)
+{
+    return ((size_t)1 + (size_t)kCtRing * d.rows + (size_t)kCtRing * d.exts) * sizeof(T)
+           + (size_t)(2 + 5 * kCtRing) * sizeof(int) + 64;
+}
+
+// per step: {first position, rows, external values of the tile used up to and including this step, first row's index in the tile}
+__global__ __launch_bounds__(kBlock) void k_ct_step_rec2(int n, int nsteps, const int* __restrict__ step_pos,
+                                                         const int* __restrict__ ext_start, const int* __restrict__ tile_of,
+                                                         const int* __restrict__ tile_step, int* __restrict__ rec)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g <= nsteps; g += gsz)
+    {
+        const int p = step_pos[g];
+        if(g == nsteps)
+        {
+            rec[4 * g + 0] = p;
+            rec[4 * g + 1] = 1;
+            rec[4 * g + 2] = 0;
+            rec[4 * g + 3] = 0;
+            continue;
+        }
+        const int p1   = step_pos[g + 1];
+        const int tpos = step_pos[tile_step[tile_of[p]]];
+        rec[4 * g + 0] = p;
+        rec[4 * g + 1] = p1 - p;
+        rec[4 * g + 2] = ext_start[p1] - ext_start[tpos];
+        rec[4 * g + 3] = p - tpos;
+    }
+}
+
+template <typename T, bool LOWER, int WL>
+__global__ __launch_bounds__(kBlock) void k_ct_fill_rec(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                        const T* __restrict__ val, const int* __restrict__ order,
+                                                        const int* __restrict__ pos, const int* __restrict__ tile_of,
+                                                        const int* __restrict__ step_of, const int* __restrict__ tile_step,
+                                                        const int* __restrict__ step_pos, const int* __restrict__ ext_start,
+                                                        int* __restrict__ ext_idx, char* __restrict__ erec,
+                                                        int* __restrict__ nodiag, int reverse, int rows_max)
+{
+    using L         = CtRec<T, WL>;
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(p >= n)
+        return;
+    const int i    = order[p];
+    const int gs   = step_of[p];
+    const int p0   = step_pos[gs];
+    const int cnt  = step_pos[gs + 1] - p0;
+    const int rank = (int)p - p0;
+    const int tl   = tile_of[p];
+    const int tpos = step_pos[tile_step[tl]];
+    int       e    = ext_start[p];
+    const int e0   = ext_start[tpos];
+    auto      field = [&](int off) -> char* {
+        return erec + ((size_t)L::NQ * p0 + (size_t)(off / 16) * cnt + rank) * 16 + (off % 16);
+    };
+    int       k    = 0;
+    bool      have = false;
+    const int rs = rp[i], re = rp[i + 1];
+    for(int q = rs; q < re; ++q)
+    {
+        const int j = reverse ? (re - 1 - (q - rs)) : q;
+        const int c = ci[j];
+        if(LOWER ? (c < i) : (c > i))
+        {
+            const int pc = pos[c];
+            int       code;
+            if(tile_of[pc] == tl)
+                code = 1 + (pc - tpos);
+            else
+            {
+                ext_idx[e] = pc;
+                code       = 1 + rows_max + (e - e0);
+                ++e;
+            }
+            if(k < WL)
+            {
+                *reinterpret_cast<unsigned short*>(field(2 * k))                 = (unsigned short)code;
+                *reinterpret_cast<T*>(field(L::off_val + k * (int)sizeof(T))) = val[j];
+            }
+            ++k;
+        }
+        else if(c == i)
+        {
+            *reinterpret_cast<T*>(field(L::off_diag)) = val[j];
+            have                                      = true;
+        }
+    }
+    // (padding codes / values stay 0: the array is zeroed before the fill)
+    *reinterpret_cast<int*>(field(L::off_ord)) = i;
+    if(!have)
+    {
+        *reinterpret_cast<T*>(field(L::off_diag)) = (T)1;
+        *nodiag                                   = 1;
+    }
+}
+
+// The compute wave's loads are issued by hand (inline asm) and waited for by hand: left to the compiler, the counter waits
+// of a software pipeline with scalar control flow in the loop body come out as drains (vmcnt(0) at the loop header, the
+// state of the prologue merged into every trip).  The hardware retires vector memory operations in order, so with a fixed
+// number of operations per step "the record issued D steps ago has arrived" is exactly s_waitcnt vmcnt(D * operations);
+// tying the registers through an empty asm after the wait keeps the compiler from using them earlier.
+__device__ __forceinline__ const void* ct_uniform(const void* p) // (a wave-uniform pointer the compiler may not recognise as one)
+{
+    const unsigned long long v  = (unsigned long long)p;
+    const unsigned           lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned           hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (const void*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ v4i32 ct_load_quad(const void* sbase, unsigned voff)
+{
+    sbase = ct_uniform(sbase);
+    v4i32 r;
+    asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+    return r;
+}
+__device__ __forceinline__ int ct_load_int(const void* sbase, unsigned voff)
+{
+    sbase = ct_uniform(sbase);
+    int r;
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+    return r;
+}
+__device__ __forceinline__ double ct_load_val(const double* p)
+{
+    double r;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+__device__ __forceinline__ float ct_load_val(const float* p)
+{
+    float r;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void ct_wait_vm()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+struct CtBases // counter values of the ticket streams before the launch
+{
+    unsigned v[16];
+};
+
+template <typename T, int NQ>
+struct CtStage
+{
+    v4i32 q[NQ]; // the row's record
+    int   g, tf; // uniform: index of the step's record; its tile number * 4 + flags (1 = a new step, 2 = last step of its tile)
+};
+
+template <typename T, int DMODE, bool HAS_OUT, int WL, int DEPTH, bool PROF>
+__global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const v4i32* __restrict__ tile_desc,
+                                                  const v4i32* __restrict__ step_rec, const int* __restrict__ ext_idx,
+                                                  const v4i32* __restrict__ erec, const T* __restrict__ rhs_src,
+                                                  const int* __restrict__ in_src,
+                                                  const unsigned short* __restrict__ in_loc, T* w, T* __restrict__ out,
+                                                  unsigned* counter, CtBases bases, int nstreams, unsigned long long* prof_arg)
+{
+    using L           = CtRec<T, WL>;
+    using B           = typename Sentinel<T>::bits;
+    constexpr int NQ  = (DMODE != 0 || HAS_OUT) ? L::NQ : L::NQL;
+    constexpr int R   = kCtRing;
+    unsigned long long* const prof = PROF ? prof_arg : nullptr; // (diagnostic instantiation only: the counters cost scalar registers)
+    extern __shared__ __attribute__((aligned(16))) char ct_lds[];
+    // xs[0] = 0; xs[1 + slot * rows + q] = row q of the tile in ring slot `slot`: its right-hand side value until the row's
+    // step has run (parked by the fetch wave), its solution afterwards
+    T*   xs      = reinterpret_cast<T*>(ct_lds);
+    T*   ex      = xs + 1 + R * dims.rows; // [R][exts] external values, one buffer per ring slot
+    int* posted  = reinterpret_cast<int*>(ex + R * dims.exts); // tiles whose descriptor is in the ring
+    int* tdone   = posted + 1; // tiles the compute wave has finished
+    int* fetched = tdone + 1; // [R] external values parked so far
+    int* tdesc   = fetched + R; // [R][4] {first step, steps, -, -}
+    const int tid = threadIdx.x;
+    auto      uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    if(tid == 0)
+    {
+        *posted = 0;
+        *tdone  = 0;
+        xs[0]   = (T)0;
+    }
+    __syncthreads();
+    if(tid >= 64)
+    {
+        // ---------------- ticket / fetch wave
+        const int lane = tid - 64;
+        // ticket stream of this workgroup: tiles stream, stream + nstreams, ... in this order
+        const int      stream = (int)(blockIdx.x % (unsigned)nstreams);
+        unsigned*      cword  = counter + (size_t)stream * 1024;
+        const unsigned base   = bases.v[stream];
+        // (prof != nullptr: cycle counts per phase, tools/ diagnostics)
+        unsigned long long pf_t0 = prof ? __builtin_amdgcn_s_memtime() : 0, pf_ring = 0, pf_ticket = 0, pf_idx = 0, pf_poll = 0;
+        auto pf_flush = [&]() {
+            if(prof && lane == 0)
+            {
+                atomicAdd(prof + 20 + (__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11)) & 3), 1ull);
+                atomicAdd(prof + 8, __builtin_amdgcn_s_memtime() - pf_t0);
+                atomicAdd(prof + 9, pf_ring);
+                atomicAdd(prof + 10, pf_ticket);
+                atomicAdd(prof + 11, pf_idx);
+                atomicAdd(prof + 12, pf_poll);
+            }
+        };
+        for(int n = 0;; ++n)
+        {
+            const int slot = n % R;
+            unsigned long long pf_a = prof ? __builtin_amdgcn_s_memtime() : 0;
+            if(n >= R) // the slot was used by tile n - R
+            {
+                int spins = 0;
+                while(uni(__hip_atomic_load(tdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < n - R + 1)
+                {
+                    spin_guard(spins);
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            unsigned long long pf_b = prof ? __builtin_amdgcn_s_memtime() : 0;
+            pf_ring += pf_b - pf_a;
+            unsigned tk = 0;
+            if(lane == 0)
+                tk = __hip_atomic_fetch_add(cword, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base;
+            const long long t64 = (long long)(unsigned)uni((int)tk) * nstreams + stream;
+            const bool      end = t64 >= (long long)ntiles;
+            const int       t   = end ? 0 : (int)t64;
+            v4i32      d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0};
+            if(!end)
+            {
+                d0 = tile_desc[2 * (size_t)t];
+                d1 = tile_desc[2 * (size_t)t + 1];
+            }
+            if(lane == 0)
+            {
+                tdesc[4 * slot + 0] = d0.x;
+                tdesc[4 * slot + 1] = end ? 0 : d0.y;
+                fetched[slot]       = -1; // (-1: the tile's right-hand side is not in LDS yet)
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if(lane == 0)
+                __hip_atomic_store(posted, n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if(end)
+            {
+                pf_flush();
+                return;
+            }
+            const int e0 = uni(d1.z), e1 = e0 + uni(d1.w);
+            if(prof)
+                pf_ticket += __builtin_amdgcn_s_memtime() - pf_b;
+            T*        exb = ex + slot * dims.exts;
+            {
+                // the tile's right-hand side: rows sorted by source index -> neighbouring lanes read neighbouring addresses
+                // (whole lines where the tile covers contiguous pieces of the source vector); parked in row order
+                const int p0 = uni(d0.z), nr = uni(d0.w);
+                T*        rbb = xs + 1 + slot * dims.rows;
+                for(int q0 = 0; q0 < nr; q0 += 4 * 64)
+                {
+                    int src[4], loc[4];
+                    T   v[4];
+#pragma unroll
+                    for(int u = 0; u < 4; ++u)
+                    {
+                        const int q = q0 + u * 64 + lane;
+                        src[u]      = (q < nr) ? nt_load(in_src + p0 + q) : -1;
+                        loc[u]      = (q < nr) ? (int)nt_load(in_loc + p0 + q) : 0;
+                    }
+#pragma unroll
+                    for(int u = 0; u < 4; ++u)
+                        if(src[u] >= 0)
+                            v[u] = rhs_src[src[u]];
+#pragma unroll
+                    for(int u = 0; u < 4; ++u)
+                        if(src[u] >= 0)
+                            rbb[loc[u]] = v[u];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if(lane == 0)
+                    __hip_atomic_store(fetched + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            for(int e = e0; e < e1; e += 64 * kCtFetchDepth)
+            {
+                int idx[kCtFetchDepth];
+                B   bits[kCtFetchDepth];
+#pragma unroll
+                for(int u = 0; u < kCtFetchDepth; ++u)
+                {
+                    const int j = e + u * 64 + lane;
+                    idx[u]      = (j < e1) ? nt_load(ext_idx + j) : -1;
+                }
+                const int nbatch = min(kCtFetchDepth, (e1 - e + 63) / 64);
+                int       next = 0, spins = 0, backoff = 1;
+                unsigned long long pf_c = 0;
+                if(prof)
+                {
+                    pf_c = __builtin_amdgcn_s_memtime();
+                    int keep = idx[0];
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(keep)::"memory");
+                    idx[0] = keep;
+                    pf_idx += __builtin_amdgcn_s_memtime() - pf_c;
+                    pf_c = __builtin_amdgcn_s_memtime();
+                }
+                int done = 0; // values of batch `next` already handed over
+                while(next < nbatch)
+                {
+#pragma unroll
+                    for(int u = 0; u < kCtFetchDepth; ++u)
+                        if(u >= next && idx[u] >= 0)
+                            bits[u] = poll_load(w + idx[u]);
+                    bool advanced = false;
+#pragma unroll
+                    for(int u = 0; u < kCtFetchDepth; ++u)
+                        if(u == next && u < nbatch)
+                        {
+                            // hand over every value up to the first missing one (use order): the tile starts as soon as what its
+                            // first steps need is there, not when 64 values -- several steps' worth -- are complete
+                            const bool               missing = idx[u] >= 0 && bits[u] == Sentinel<T>::value;
+                            const unsigned long long mm      = __ballot(missing);
+                            const int                nb      = min(64, e1 - (e + u * 64));
+                            const int                ready   = min(nb, mm ? (int)__builtin_ctzll(mm) : 64);
+                            if(ready > done)
+                            {
+                                if(lane >= done && lane < ready)
+                                {
+                                    exb[e - e0 + u * 64 + lane] = Sentinel<T>::from_bits(bits[u]);
+                                    idx[u]                      = -1; // parked: not polled again
+                                }
+                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                                if(lane == 0)
+                                    __hip_atomic_store(fetched + slot, e - e0 + u * 64 + ready, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                                done     = ready;
+                                advanced = true;
+                            }
+                            if(ready == nb)
+                            {
+                                ++next;
+                                done = 0;
+                            }
+                        }
+                    if(!advanced)
+                    {
+                        spin_guard(spins);
+                        backoff = poll_backoff(false, backoff);
+                    }
+                }
+                if(prof)
+                    pf_poll += __builtin_amdgcn_s_memtime() - pf_c;
+            }
+        }
+    }
+    // ---------------- compute wave: one stream of steps over all the tiles this workgroup gets
+    const int lane = tid;
+    // iterator over the steps: `cur` is the record of the next step to fetch (loaded one fetch ahead through the scalar cache)
+    unsigned long long pc_t0 = prof ? __builtin_amdgcn_s_memtime() : 0, pc_ext = 0, pc_post = 0, pc_steps = 0, pc_dups = 0;
+    int   g = 0, gend = 0, tn = 0, pending = 0, done_tiles = 0;
+    bool  ending = false, cur_fresh = false, cur_last = false;
+    v4i32 cur = {0, 1, 0, 0};
+    auto  wait_posted = [&](int want) {
+        int spins = 0;
+        while(uni(__hip_atomic_load(posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < want)
+        {
+            spin_guard(spins);
+            __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+    };
+    auto load_cur = [&]() {
+        const v4i32 r = step_rec[g];
+        cur           = v4i32{uni(r.x), uni(r.y), uni(r.z), uni(r.w)};
+        cur_last      = (g + 1 == gend);
+    };
+    // moves to the next step; false: nothing new (the next tile is not posted yet and real steps are still in flight, or
+    // there are no more tiles) -- the caller then repeats the current step as a harmless duplicate
+    auto try_advance = [&]() -> bool {
+        if(ending)
+            return false;
+        if(g + 1 < gend)
+        {
+            g = uni(g + 1);
+            load_cur();
+            return true;
+        }
+        if(uni(__hip_atomic_load(posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < tn + 2)
+        {
+            if(pending > 0)
+                return false;
+            const unsigned long long a = prof ? __builtin_amdgcn_s_memtime() : 0;
+            wait_posted(tn + 2);
+            if(prof)
+                pc_post += __builtin_amdgcn_s_memtime() - a;
+        }
+        asm volatile("" ::: "memory");
+        const int s   = (tn + 1) % R;
+        const int S0  = uni(tdesc[4 * s + 0]);
+        const int nst = uni(tdesc[4 * s + 1]);
+        if(nst == 0)
+        {
+            ending = true;
+            return false;
+        }
+        tn   = uni(tn + 1);
+        g    = S0;
+        gend = S0 + nst;
+        load_cur();
+        return true;
+    };
+    // vector memory operations of one step of the stream, in issue order: the stores of the step (value, natural-order copy),
+    // then the quads of the record DEPTH steps ahead
+    constexpr int OPS = (HAS_OUT ? 2 : 1) + NQ;
+    static_assert(DEPTH * OPS < 64, "the whole prefetch window has to fit the 6-bit counter");
+    auto fetch_rec = [&](CtStage<T, NQ>& st) {
+        st.g  = g; // (the record itself comes back through the scalar cache when the step runs: scalar registers are scarce)
+        st.tf = tn * 4 + ((cur_fresh ? 1 : 0) | (cur_last ? 2 : 0));
+        const int      row = min(lane, cur.y - 1);
+        const v4i32*   qb  = erec + (size_t)L::NQ * (size_t)cur.x; // scalar base of the step + 32-bit lane offsets
+        const unsigned ro  = (unsigned)row * 16u;
+        // (lanes beyond the step's rows mirror its last row -- same addresses, same values: every operation is issued, and
+        //  counted, in every step; switching those lanes off instead was measured no faster)
+#pragma unroll
+        for(int q = 0; q < NQ; ++q)
+            st.q[q] = ct_load_quad(qb, ro + (unsigned)(q * cur.y) * 16u);
+        if(cur_fresh)
+            pending = uni(pending + 1);
+        cur_fresh = try_advance();
+    };
+    auto arrived = [&](CtStage<T, NQ>& st) { // (after the wait) the registers of the stage may be used from here on
+#pragma unroll
+        for(int q = 0; q < NQ; ++q)
+            asm volatile("" : "+v"(st.q[q]));
+    };
+    int  have = -1, have_tn = -1;
+    auto step = [&](const CtStage<T, NQ>& stq, const v4i32 rec) {
+        struct
+        {
+            int pos, cnt, need, lbase, tn, flags;
+        } st = {uni(rec.x), uni(rec.y), uni(rec.z), uni(rec.w), uni(stq.tf) >> 2, uni(stq.tf) & 3};
+        const int row  = min(lane, st.cnt - 1);
+        const int slot = st.tn % R;
+        if(st.tn != have_tn)
+        {
+            have_tn = st.tn;
+            have    = -1; // (until the fetch wave has parked the tile's right-hand side)
+        }
+        if(prof)
+        {
+            if(st.flags & 1)
+                ++pc_steps;
+            else
+                ++pc_dups;
+        }
+        if(have < st.need) // wave-uniform: wait for the fetch wave (an LDS count, no memory round trip)
+        {
+            const unsigned long long a = prof ? __builtin_amdgcn_s_memtime() : 0;
+            int spins = 0;
+            while((have = uni(__hip_atomic_load(fetched + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) < st.need)
+            {
+                spin_guard(spins);
+                __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+            if(prof)
+                pc_ext += __builtin_amdgcn_s_memtime() - a;
+        }
+        {
+        // every dword of the record counts as used here: a dword nobody reads would be handed out as a temporary while
+        // its load is still in flight, and the write-after-write hazard costs a drain of the prefetch
+#pragma unroll
+        for(int q = 0; q < NQ; ++q)
+            asm volatile("" ::"v"(stq.q[q]));
+        const int  xso  = slot * dims.rows; // shifts of the column codes into this tile's buffers
+        const int  exo  = (R - 1) * dims.rows + slot * dims.exts;
+        const int  rmax = dims.rows;
+        const int  own  = 1 + xso + st.lbase + row;
+        const T    bval = xs[own]; // right-hand side (a repeated step finds its result there)
+        T          v[WL], a[WL];
+#pragma unroll
+        for(int k = 0; k < WL; ++k)
+        {
+            const int word = stq.q[(k / 2) / 4][(k / 2) % 4];
+            const int c    = (k & 1) ? (int)((unsigned)word >> 16) : (word & 0xffff);
+            const int at   = (c == 0) ? 0 : c + ((c > rmax) ? exo : xso);
+            v[k]           = xs[at];
+            if(sizeof(T) == 8)
+            {
+                const int wi = (L::off_val + 8 * k) / 4;
+                a[k]         = (T)__hiloint2double(stq.q[(wi + 1) / 4][(wi + 1) % 4], stq.q[wi / 4][wi % 4]);
+            }
+            else
+            {
+                const int wi = (L::off_val + 4 * k) / 4;
+                a[k]         = (T)__int_as_float(stq.q[wi / 4][wi % 4]);
+            }
+        }
+        T sum = bval;
+        if(st.flags & 1) // (a repeated step only re-issues its stores)
+        {
+#pragma unroll
+        for(int k = 0; k < WL; ++k)
+            sum -= a[k] * v[k]; // (padding: 0 * xs[0] = 0 * 0)
+        if(DMODE != 0)
+        {
+            T dg;
+            if(sizeof(T) == 8)
+            {
+                const int wi = L::off_diag / 4;
+                dg           = (T)__hiloint2double(stq.q[(wi + 1) / 4][(wi + 1) % 4], stq.q[wi / 4][wi % 4]);
+            }
+            else
+                dg = (T)__int_as_float(stq.q[(L::off_diag / 4) / 4][(L::off_diag / 4) % 4]);
+            if(DMODE == 1)
+                sum /= dg;
+            else
+                sum = sum * dg;
+        }
+        xs[own] = sum;
+        }
+        publish(w + st.pos + row, sum);
+        if(HAS_OUT)
+            out[stq.q[(L::off_ord / 4) / 4][(L::off_ord / 4) % 4]] = sum;
+        }
+        // this step's LDS traffic before the next step's: one wave, in-order LDS queue
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if(st.flags & 1)
+        {
+            pending = uni(pending - 1);
+            if(st.flags & 2) // the tile is finished: its ring slot may be reused
+            {
+                done_tiles = uni(done_tiles + 1);
+                if(lane == 0)
+                    __hip_atomic_store(tdone, done_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    };
+    // first tile
+    wait_posted(1);
+    {
+        const int S0  = uni(tdesc[0]);
+        const int nst = uni(tdesc[1]);
+        if(nst == 0)
+            return;
+        g    = S0;
+        gend = S0 + nst;
+        load_cur();
+        cur_fresh = true;
+    }
+    CtStage<T, NQ> st[DEPTH];
+#pragma unroll
+    for(int j = 0; j < DEPTH; ++j)
+        fetch_rec(st[j]);
+    ct_wait_vm<0>(); // (the stream starts with nothing in flight: every steady-state wait below is then sufficient)
+    v4i32 rec_next = step_rec[uni(st[0].g)];
+    for(;;)
+    {
+#pragma unroll
+        for(int j = 0; j < DEPTH; ++j)
+        {
+            const v4i32 rec = rec_next; // (requested during the step before)
+            rec_next        = step_rec[uni(st[(j + 1) % DEPTH].g)];
+            // this step's quads were loaded DEPTH steps ago: DEPTH - 1 steps' operations were issued after them
+            ct_wait_vm<(DEPTH - 1) * OPS>();
+            arrived(st[j]);
+            step(st[j], rec);
+            fetch_rec(st[j]);
+        }
+        if(ending && pending == 0)
+            break;
+    }
+    if(prof && lane == 0)
+    {
+        atomicAdd(prof + 16 + (__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11)) & 3), 1ull); // SIMD of the compute wave
+        atomicAdd(prof + 0, __builtin_amdgcn_s_memtime() - pc_t0);
+        atomicAdd(prof + 1, pc_ext);
+        atomicAdd(prof + 2, pc_post);
+        atomicAdd(prof + 3, pc_steps);
+        atomicAdd(prof + 4, pc_dups);
+        atomicAdd(prof + 5, 1ull);
     }
 }
 
@@ -1627,7 +2271,7 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     if(wmax > 32) // (8 lanes x 4 entries per row and step)
         CT_GIVE_UP();
     const int lpr = wmax > 8 ? 8 : 1;
-    const int wl  = lpr == 1 ? (wmax <= 4 ? 4 : 8) : 4;
+    const int wl  = lpr == 1 ? (wmax <= 3 ? 3 : (wmax <= 4 ? 4 : 8)) : 4;
     const int rpp = 64 / lpr;
     int       bs[3] = {1, 1, 1}, Ts[3] = {1, 1, 1};
     int       ntiles = 0, nsteps = 0, total = 0;
@@ -1761,8 +2405,8 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     CT_TRY(device_max_int(tsz + 3 * (size_t)ntiles, ntiles, &P->ct_dims[3]));
     {
         const CtDims d    = {P->ct_dims[0], P->ct_dims[1], P->ct_dims[2], P->ct_dims[3]};
-        const size_t need = ct_lds_bytes<T>(d, ct_group(), lpr, wl);
-        if(need <= (size_t)lds_budget)
+        const size_t need = lpr == 1 ? ct_rec_lds_bytes<T>(d) : ct_lds_bytes<T>(d, ct_group(), lpr, wl);
+        if(need <= (size_t)lds_budget && (lpr != 1 || 1 + d.rows + d.exts < 65536)) // (record form: 16-bit column codes)
             fits = true;
         else
         {
@@ -1792,26 +2436,63 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     dev_free(&word);
     if(!fits)
         CT_GIVE_UP();
-    CT_TRY(dev_alloc(&P->ecol, (int64_t)total + 64 * 64)); // (+ what the register window reads past the last step)
-    CT_HIP(cached_malloc(&P->eval, ((size_t)total + 64 * 64) * sizeof(T) + kPad));
-    CT_HIP(cached_malloc(&P->diag, (size_t)n * sizeof(T) + kPad));
     CT_HIP(cached_malloc(&P->w, (size_t)n * sizeof(T) + kPad));
     CT_TRY(dev_alloc(&nodiag, 1));
     CT_HIP(hipMemsetAsync(nodiag, 0, sizeof(int), b.cur));
-    if(lower)
-        hipLaunchKernelGGL((k_ct_fill<T, true>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const T*)m->val, P->order,
-                           P->pos, tile_of, step_of, P->ct_tile_step, P->ct_step_pos, P->ct_step_ent, P->ct_ext_start,
-                           P->ct_ext_idx, P->ecol, (T*)P->eval, (T*)P->diag, nodiag, reverse ? 1 : 0);
-    else
-        hipLaunchKernelGGL((k_ct_fill<T, false>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const T*)m->val, P->order,
-                           P->pos, tile_of, step_of, P->ct_tile_step, P->ct_step_pos, P->ct_step_ent, P->ct_ext_start,
-                           P->ct_ext_idx, P->ecol, (T*)P->eval, (T*)P->diag, nodiag, reverse ? 1 : 0);
     CT_TRY(dev_alloc(&P->ct_tile_desc, (int64_t)8 * ntiles));
     hipLaunchKernelGGL(k_ct_tile_desc, dim3(ew_grid(ntiles)), dim3(kBlock), 0, b.cur, ntiles, P->ct_tile_step, P->ct_step_pos,
                        P->ct_step_ent, P->ct_ext_start, P->ct_tile_desc);
     CT_TRY(dev_alloc(&P->ct_step_rec, (int64_t)4 * ((int64_t)nsteps + 1)));
-    hipLaunchKernelGGL(k_ct_step_rec, dim3(ew_grid(nsteps + 1)), dim3(kBlock), 0, b.cur, n, nsteps, P->ct_step_pos,
-                       P->ct_step_ent, P->ct_ext_start, tile_of, P->ct_tile_step, P->ct_step_rec);
+    P->ct_rec = (lpr == 1);
+    if(P->ct_rec)
+    {
+        // record form: one array of 16-byte quads (CtRec), zeroed = padded
+        const size_t nq    = wl == 3 ? CtRec<T, 3>::NQ : (wl == 4 ? CtRec<T, 4>::NQ : CtRec<T, 8>::NQ);
+        const size_t bytes = nq * 16 * (size_t)n + kPad;
+        CT_HIP(cached_malloc(&P->eval, bytes));
+        CT_HIP(hipMemsetAsync(P->eval, 0, bytes, b.cur));
+#define CT_FILL_REC(LOW, WLL)                                                                                                \
+    hipLaunchKernelGGL((k_ct_fill_rec<T, LOW, WLL>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const T*)m->val,   \
+                       P->order, P->pos, tile_of, step_of, P->ct_tile_step, P->ct_step_pos, P->ct_ext_start, P->ct_ext_idx, \
+                       (char*)P->eval, nodiag, reverse ? 1 : 0, P->ct_dims[0])
+        if(lower)
+        {
+            if(wl == 3)
+                CT_FILL_REC(true, 3);
+            else if(wl == 4)
+                CT_FILL_REC(true, 4);
+            else
+                CT_FILL_REC(true, 8);
+        }
+        else
+        {
+            if(wl == 3)
+                CT_FILL_REC(false, 3);
+            else if(wl == 4)
+                CT_FILL_REC(false, 4);
+            else
+                CT_FILL_REC(false, 8);
+        }
+#undef CT_FILL_REC
+        hipLaunchKernelGGL(k_ct_step_rec2, dim3(ew_grid(nsteps + 1)), dim3(kBlock), 0, b.cur, n, nsteps, P->ct_step_pos,
+                           P->ct_ext_start, tile_of, P->ct_tile_step, P->ct_step_rec);
+    }
+    else
+    {
+        CT_TRY(dev_alloc(&P->ecol, (int64_t)total + 64 * 64)); // (+ what the register window reads past the last step)
+        CT_HIP(cached_malloc(&P->eval, ((size_t)total + 64 * 64) * sizeof(T) + kPad));
+        CT_HIP(cached_malloc(&P->diag, (size_t)n * sizeof(T) + kPad));
+        if(lower)
+            hipLaunchKernelGGL((k_ct_fill<T, true>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const T*)m->val,
+                               P->order, P->pos, tile_of, step_of, P->ct_tile_step, P->ct_step_pos, P->ct_step_ent,
+                               P->ct_ext_start, P->ct_ext_idx, P->ecol, (T*)P->eval, (T*)P->diag, nodiag, reverse ? 1 : 0);
+        else
+            hipLaunchKernelGGL((k_ct_fill<T, false>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const T*)m->val,
+                               P->order, P->pos, tile_of, step_of, P->ct_tile_step, P->ct_step_pos, P->ct_step_ent,
+                               P->ct_ext_start, P->ct_ext_idx, P->ecol, (T*)P->eval, (T*)P->diag, nodiag, reverse ? 1 : 0);
+        hipLaunchKernelGGL(k_ct_step_rec, dim3(ew_grid(nsteps + 1)), dim3(kBlock), 0, b.cur, n, nsteps, P->ct_step_pos,
+                           P->ct_step_ent, P->ct_ext_start, tile_of, P->ct_tile_step, P->ct_step_rec);
+    }
     int nd = 0;
     CT_HIP(hipMemcpyAsync(&nd, nodiag, sizeof(int), hipMemcpyDeviceToHost, b.cur));
     CT_HIP(hipStreamSynchronize(b.cur));
@@ -1840,6 +2521,86 @@ __global__ __launch_bounds__(kBlock) void k_compose_idx(int n, const int* __rest
         out[t] = posL[orderU[t]];
 }
 
+// ---- rows of every tile sorted by the source index of their right-hand side (record form; once per index array)
+__global__ __launch_bounds__(kBlock) void k_ct_tile_of_pos(int n, int ntiles, const int* __restrict__ tile_desc,
+                                                           int* __restrict__ tile_of)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gsz)
+    {
+        int lo = 0, hi = ntiles - 1; // last tile whose first position is <= p
+        while(lo < hi)
+        {
+            const int mid = (lo + hi + 1) >> 1;
+            if(tile_desc[8 * (size_t)mid + 2] <= (int)p)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        tile_of[p] = lo;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_ct_in_lists(int n, const int* __restrict__ o1, const int* __restrict__ o2,
+                                                        const int* __restrict__ rhs_idx, const int* __restrict__ tile_of,
+                                                        const int* __restrict__ tile_desc, int* __restrict__ in_src,
+                                                        unsigned short* __restrict__ in_loc)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gsz)
+    {
+        const int p = o1[o2[q]]; // position: q-th of its tile in source order
+        in_src[q]   = rhs_idx[p];
+        in_loc[q]   = (unsigned short)(p - tile_desc[8 * (size_t)tile_of[p] + 2]);
+    }
+}
+
+static int ct_build_in_lists(TriPlan* P, const int* rhs_idx)
+{
+    Backend&  b = backend();
+    const int n = P->n;
+    dev_free(&P->ct_in_src);
+    dev_free(&P->ct_in_loc);
+    P->ct_in_key = nullptr;
+    int *o1 = nullptr, *o2 = nullptr, *tile_of = nullptr, *k2 = nullptr;
+    int  s  = RAMD_OK;
+    auto done = [&](int rc) {
+        dev_free(&o1);
+        dev_free(&o2);
+        dev_free(&tile_of);
+        dev_free(&k2);
+        return rc;
+    };
+    const int grid = ew_grid(n);
+    if((s = dev_alloc(&o1, n)) != RAMD_OK)
+        return done(s);
+    if((s = device_stable_sort_by_key(rhs_idx, n, n, o1)) != RAMD_OK) // (source indices are positions / rows: < n)
+        return done(s);
+    if((s = dev_alloc(&tile_of, n)) != RAMD_OK)
+        return done(s);
+    hipLaunchKernelGGL(k_ct_tile_of_pos, dim3(grid), dim3(kBlock), 0, b.cur, n, P->ct_ntiles, P->ct_tile_desc, tile_of);
+    if((s = dev_alloc(&k2, n)) != RAMD_OK)
+        return done(s);
+    hipLaunchKernelGGL(k_ct_gather_int, dim3(grid), dim3(kBlock), 0, b.cur, (int64_t)n, tile_of, o1, k2);
+    if((s = dev_alloc(&o2, n)) != RAMD_OK)
+        return done(s);
+    if((s = device_stable_sort_by_key(k2, n, P->ct_ntiles, o2)) != RAMD_OK)
+        return done(s);
+    if((s = dev_alloc(&P->ct_in_src, n)) != RAMD_OK)
+        return done(s);
+    if((s = dev_alloc(&P->ct_in_loc, n)) != RAMD_OK)
+        return done(s);
+    hipLaunchKernelGGL(k_ct_in_lists, dim3(grid), dim3(kBlock), 0, b.cur, n, o1, o2, rhs_idx, tile_of, P->ct_tile_desc,
+                       P->ct_in_src, P->ct_in_loc);
+    if(hipStreamSynchronize(b.cur) != hipSuccess || hipGetLastError() != hipSuccess)
+    {
+        done(RAMD_OK);
+        RAMD_FAIL(RAMD_ERR_HIP, "sorted right-hand-side lists of the box-tile plan");
+    }
+    P->ct_in_key = rhs_idx;
+    return done(RAMD_OK);
+}
+
 template <typename T>
 static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const int* rhs_idx, T* out,
                     bool mul_inv_diag = false)
@@ -1857,9 +2618,115 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
     {
         const int    dm    = mul_inv_diag ? 2 : (unit ? 0 : 1);
         const int    lpr   = P->ct_wmax > 8 ? 8 : 1;
-        const int    wl    = lpr == 1 ? (P->ct_wmax <= 4 ? 4 : 8) : 4;
+        const int    wl    = lpr == 1 ? (P->ct_wmax <= 3 ? 3 : (P->ct_wmax <= 4 ? 4 : 8)) : 4;
         const int    group = ct_group();
         const CtDims dims  = {P->ct_dims[0], P->ct_dims[1], P->ct_dims[2], P->ct_dims[3]};
+        if(P->ct_rec)
+        {
+            if(P->ct_in_key != rhs_idx)
+                RAMD_TRY(ct_build_in_lists(P, rhs_idx));
+            const size_t lds = ct_rec_lds_bytes<T>(dims);
+            unsigned     nwg = 0;
+            int          nstreams = 1;
+            CtBases      bases;
+            if(!st->stream_counter)
+            {
+                RAMD_TRY(dev_alloc(&st->stream_counter, (int64_t)TriState::kStreams * TriState::kStreamStride));
+                RAMD_HIP(hipMemsetAsync(st->stream_counter, 0, sizeof(unsigned) * TriState::kStreams * TriState::kStreamStride,
+                                        b.cur));
+            }
+            // RAMD_TRSV_PROF=1 (tools/ diagnostics): cycle counts per phase of the two waves, printed after every solve
+            static const bool      pf_on  = getenv("RAMD_TRSV_PROF") != nullptr;
+            static unsigned long long* pf_buf = nullptr;
+            if(pf_on)
+            {
+                if(!pf_buf)
+                    RAMD_HIP(hipMalloc(&pf_buf, 32 * sizeof(unsigned long long)));
+                RAMD_HIP(hipMemsetAsync(pf_buf, 0, 32 * sizeof(unsigned long long), b.cur));
+            }
+// persistent workgroups: as many as the device holds at once (more would only queue), never more than tiles
+#define TRSV_RC(DM, HO, WLL, DP)                                                                                            \
+    do                                                                                                                      \
+    {                                                                                                                       \
+        static int occ = 0;                                                                                                 \
+        static size_t occ_lds = (size_t)-1;                                                                                 \
+        if(occ_lds != lds)                                                                                                  \
+        {                                                                                                                   \
+            int nb_cu = 0;                                                                                                  \
+            RAMD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_cu, k_trsv_rec<T, DM, HO, WLL, DP, false>, 128, lds));       \
+            occ     = nb_cu < 1 ? 1 : nb_cu;                                                                                \
+            occ_lds = lds;                                                                                                  \
+        }                                                                                                                   \
+        const int64_t cap = (int64_t)occ * b.num_cu;                                                                        \
+        nwg               = (unsigned)(P->ct_ntiles < cap ? P->ct_ntiles : cap);                                            \
+        nstreams          = nwg < (unsigned)TriState::kStreams ? (int)nwg : TriState::kStreams;                             \
+        for(int i = 0; i < TriState::kStreams; ++i)                                                                         \
+            bases.v[i] = st->stream_ticket[i];                                                                              \
+        if(pf_on && WLL == 3 && sizeof(T) == 8)                                                                             \
+            hipLaunchKernelGGL((k_trsv_rec<T, DM, HO, (WLL == 3 ? 3 : 3), 8, true>), dim3(nwg), dim3(128), lds, b.cur,         \
+                               P->ct_ntiles, dims, (const v4i32*)P->ct_tile_desc, (const v4i32*)P->ct_step_rec,             \
+                               P->ct_ext_idx, (const v4i32*)P->eval, rhs_src, P->ct_in_src, P->ct_in_loc, (T*)P->w, out,    \
+                               st->stream_counter, bases, nstreams, pf_buf);                                                \
+        else                                                                                                                \
+            hipLaunchKernelGGL((k_trsv_rec<T, DM, HO, WLL, DP, false>), dim3(nwg), dim3(128), lds, b.cur, P->ct_ntiles,     \
+                               dims, (const v4i32*)P->ct_tile_desc, (const v4i32*)P->ct_step_rec, P->ct_ext_idx,            \
+                               (const v4i32*)P->eval, rhs_src, P->ct_in_src, P->ct_in_loc, (T*)P->w, out,                   \
+                               st->stream_counter, bases, nstreams, pf_buf);                                                \
+    } while(0)
+#define TRSV_RC_L(DM, HO)            \
+    do                               \
+    {                                \
+        if(wl == 3)                  \
+            TRSV_RC(DM, HO, 3, 8);   \
+        else if(wl == 4)             \
+            TRSV_RC(DM, HO, 4, 8);   \
+        else                         \
+            TRSV_RC(DM, HO, 8, 6);   \
+    } while(0)
+#define TRSV_RC_O(DM)                \
+    do                               \
+    {                                \
+        if(out)                      \
+            TRSV_RC_L(DM, true);     \
+        else                         \
+            TRSV_RC_L(DM, false);    \
+    } while(0)
+            prof_begin(RAMD_PROF_TRSV, b.cur);
+            if(dm == 0)
+                TRSV_RC_O(0);
+            else if(dm == 1)
+                TRSV_RC_O(1);
+            else
+                TRSV_RC_O(2);
+            prof_end(RAMD_PROF_TRSV, b.cur);
+#undef TRSV_RC_O
+#undef TRSV_RC_L
+#undef TRSV_RC
+            // per stream: its tiles, plus one ticket beyond the last tile for every workgroup bound to it
+            for(int i = 0; i < nstreams; ++i)
+            {
+                const unsigned tiles_i = (unsigned)P->ct_ntiles > (unsigned)i ? ((unsigned)P->ct_ntiles - i + nstreams - 1) / nstreams : 0u;
+                const unsigned wgs_i   = nwg > (unsigned)i ? (nwg - i + nstreams - 1) / nstreams : 0u;
+                st->stream_ticket[i] += tiles_i + wgs_i;
+            }
+            RAMD_HIP(hipGetLastError());
+            if(pf_on)
+            {
+                unsigned long long h[32];
+                RAMD_HIP(hipMemcpyAsync(h, pf_buf, sizeof(h), hipMemcpyDeviceToHost, b.cur));
+                RAMD_HIP(hipStreamSynchronize(b.cur));
+                const double wg = h[5] ? (double)h[5] : 1.0;
+                fprintf(stderr,
+                        "trsv prof (dm=%d out=%d): wgs=%u tiles=%d | compute wave: %.0f cyc/wg, ext-wait %.1f%%, posted-wait %.1f%%, "
+                        "steps %llu dups %llu | fetch wave: %.0f cyc/wg, ring-wait %.1f%%, ticket+desc %.1f%%, idx %.1f%%, poll %.1f%%\n",
+                        dm, out ? 1 : 0, nwg, P->ct_ntiles, h[0] / wg, 100.0 * h[1] / (h[0] + 1.0), 100.0 * h[2] / (h[0] + 1.0),
+                        h[3], h[4], h[8] / wg, 100.0 * h[9] / (h[8] + 1.0), 100.0 * h[10] / (h[8] + 1.0),
+                        100.0 * h[11] / (h[8] + 1.0), 100.0 * h[12] / (h[8] + 1.0));
+                fprintf(stderr, "trsv prof: SIMD of the compute waves %llu/%llu/%llu/%llu, of the fetch waves %llu/%llu/%llu/%llu\n", h[16],
+                        h[17], h[18], h[19], h[20], h[21], h[22], h[23]);
+            }
+            return RAMD_OK;
+        }
         const size_t lds   = ct_lds_bytes<T>(dims, group, lpr, wl);
         const unsigned nwg = (unsigned)((P->ct_ntiles + group - 1) / group);
 // prefetch depth: 8 steps for short rows (12 small loads per step), 6 for the 8-lanes-per-row form (measured)
@@ -1872,6 +2739,8 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
     {                              \
         if(lpr == 8)                  \
             TRSV_ST(DM, HO, 8, 4, 6); \
+        else if(wl == 3)              \
+            TRSV_ST(DM, HO, 1, 3, 8); \
         else if(wl == 4)              \
             TRSV_ST(DM, HO, 1, 4, 8); \
         else                          \
@@ -2627,6 +3496,50 @@ __global__ __launch_bounds__(kBlock) void k_gather_diag(int n, const int* __rest
         dst[t] = src[order[t]];
 }
 
+// record form: the diagonal lives inside the rows' records; one wave per step
+template <typename T, int WL>
+__global__ __launch_bounds__(kBlock) void k_ct_rec_set_diag(int nsteps, const int* __restrict__ step_rec,
+                                                            const int* __restrict__ order, const T* __restrict__ src,
+                                                            char* __restrict__ erec)
+{
+    using L            = CtRec<T, WL>;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int     lane = threadIdx.x & 63;
+    if(wave >= nsteps)
+        return;
+    const int p0 = step_rec[4 * wave], cnt = step_rec[4 * wave + 1];
+    if(lane < cnt)
+        *reinterpret_cast<T*>(erec + ((size_t)L::NQ * p0 + (size_t)(L::off_diag / 16) * cnt + lane) * 16 + (L::off_diag % 16))
+            = src[order[p0 + lane]];
+}
+
+// diagonal of a plan <- src (natural order): LLSolve keeps the inverse diagonal of the factor there
+template <typename T>
+static int plan_set_diag(TriPlan* P, const T* src)
+{
+    Backend& b = backend();
+    if(P->n == 0)
+        return RAMD_OK;
+    if(P->ct && P->ct_rec)
+    {
+        const int      wl = P->ct_wmax <= 3 ? 3 : (P->ct_wmax <= 4 ? 4 : 8);
+        const unsigned nb = (unsigned)(((int64_t)P->ct_nsteps * 64 + kBlock - 1) / kBlock);
+        if(wl == 3)
+            hipLaunchKernelGGL((k_ct_rec_set_diag<T, 3>), dim3(nb), dim3(kBlock), 0, b.cur, P->ct_nsteps, P->ct_step_rec,
+                               P->order, src, (char*)P->eval);
+        else if(wl == 4)
+            hipLaunchKernelGGL((k_ct_rec_set_diag<T, 4>), dim3(nb), dim3(kBlock), 0, b.cur, P->ct_nsteps, P->ct_step_rec,
+                               P->order, src, (char*)P->eval);
+        else
+            hipLaunchKernelGGL((k_ct_rec_set_diag<T, 8>), dim3(nb), dim3(kBlock), 0, b.cur, P->ct_nsteps, P->ct_step_rec,
+                               P->order, src, (char*)P->eval);
+    }
+    else
+        hipLaunchKernelGGL((k_gather_diag<T>), dim3(ew_grid(P->n)), dim3(kBlock), 0, b.cur, P->n, P->order, src, (T*)P->diag);
+    RAMD_HIP(hipGetLastError());
+    return RAMD_OK;
+}
+
 template <typename T>
 static int ll_analyse_t(ramd_mat_s* m)
 {
@@ -2671,11 +3584,8 @@ static int ll_solve_t(ramd_mat_s* m, const T* in, const T* inv_diag, T* out)
         return RAMD_OK;
     if(st->ll_diag_src != (const void*)inv_diag) // the plans keep the inverse diagonal in position order
     {
-        const int grid = ew_grid(m->nrow);
-        hipLaunchKernelGGL((k_gather_diag<T>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, st->LLf.order, inv_diag,
-                           (T*)st->LLf.diag);
-        hipLaunchKernelGGL((k_gather_diag<T>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, st->LLb.order, inv_diag,
-                           (T*)st->LLb.diag);
+        RAMD_TRY(plan_set_diag<T>(&st->LLf, inv_diag));
+        RAMD_TRY(plan_set_diag<T>(&st->LLb, inv_diag));
         st->ll_diag_src = (const void*)inv_diag;
     }
     // L y = b with y_i scaled by inv_diag_i, y kept in position order; then L^T x = y, scaled, natural order out

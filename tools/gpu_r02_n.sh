@@ -1,0 +1,10 @@
+#!/bin/bash
+mkdir -p gpurun_out/r02n
+cd /root/repo
+export TMPDIR=/tmp
+for cfg in "1024 40960" "2048 49152" "4096 81920" "256 40960"; do
+  set -- $cfg
+  RAMD_TRSV_CT_VERBOSE=1 RAMD_TRSV_CT_ROWS=$1 RAMD_TRSV_CT_LDS=$2 timeout 600 python bench.py --solver gmres --precond ilu0 --steps 30 --warmup 5 --no-cpu-baseline --no-reference-gpu > gpurun_out/r02n/b_$1.json 2> gpurun_out/r02n/b_$1.err
+  echo "rows=$1 lds=$2 rc=$?"; grep "box-tile plan" gpurun_out/r02n/b_$1.err | tail -2
+  python -c "import sys,json; d=json.loads(open('gpurun_out/r02n/b_$1.json').read().strip().splitlines()[-1]); print(d['value'], d['roofline']['avg_ms'], d['roofline']['min_ms'])"
+done
