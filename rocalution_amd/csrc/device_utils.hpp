@@ -10,6 +10,7 @@ namespace ramd
 typedef double v2f64 __attribute__((ext_vector_type(2)));
 typedef float  v4f32 __attribute__((ext_vector_type(4)));
 typedef int    v4i32 __attribute__((ext_vector_type(4)));
+typedef int    v2i32 __attribute__((ext_vector_type(2)));
 
 template <typename T>
 struct Pack;

@@ -464,9 +464,9 @@ struct TriPlan
     int* ct_step_rec  = nullptr; // [4 * (nsteps + 1)] k_ct_step_rec
     // record form: the rows of every tile sorted by where their right-hand side comes from (source index, row number inside
     // the tile), so that the fetch wave reads a tile's right-hand side with line-sized runs; valid for the index array `ct_in_key`
-    int*            ct_in_src = nullptr; // [n]
-    unsigned short* ct_in_loc = nullptr; // [n]
-    const int*      ct_in_key = nullptr;
+    int*       ct_in_pairs  = nullptr; // [2 n] {source index, row number inside the tile}
+    const int* ct_in_key    = nullptr;
+    int*       ct_out_pairs = nullptr; // [2 n] the same for the natural-order output: {row of the matrix, row number inside the tile}
     void  release()
     {
         dev_free(&ct_tile_step);
@@ -476,8 +476,8 @@ struct TriPlan
         dev_free(&ct_ext_idx);
         dev_free(&ct_tile_desc);
         dev_free(&ct_step_rec);
-        dev_free(&ct_in_src);
-        dev_free(&ct_in_loc);
+        dev_free(&ct_in_pairs);
+        dev_free(&ct_out_pairs);
         ct_in_key = nullptr;
         ct = ct_rec = false;
         dev_free(&order);
@@ -1529,9 +1529,8 @@ struct CtRec
     static constexpr int WLC      = (WL + 3) / 4 * 4; // 16-bit codes, padded to whole 8-byte slots
     static constexpr int off_val  = WLC * 2;
     static constexpr int off_diag = off_val + WL * (int)sizeof(T);
-    static constexpr int off_ord  = off_diag + (int)sizeof(T);
-    static constexpr int NQ       = (off_ord + 4 + 15) / 16; // quads of a row (storage stride)
-    static constexpr int NQL      = (off_diag + 15) / 16; // quads without diagonal and scatter index
+    static constexpr int NQ       = (off_diag + (int)sizeof(T) + 15) / 16; // quads of a row (storage stride)
+    static constexpr int NQL      = (off_diag + 15) / 16; // quads without the diagonal
 };
 
 template <typename T>
@@ -1625,7 +1624,6 @@ __global__ __launch_bounds__(kBlock) void k_ct_fill_rec(int n, const int* __rest
         }
     }
     // (padding codes / values stay 0: the array is zeroed before the fill)
-    *reinterpret_cast<int*>(field(L::off_ord)) = i;
     if(!have)
     {
         *reinterpret_cast<T*>(field(L::off_diag)) = (T)1;
@@ -1694,13 +1692,13 @@ template <typename T, int DMODE, bool HAS_OUT, int WL, int DEPTH, bool PROF>
 __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const v4i32* __restrict__ tile_desc,
                                                   const v4i32* __restrict__ step_rec, const int* __restrict__ ext_idx,
                                                   const v4i32* __restrict__ erec, const T* __restrict__ rhs_src,
-                                                  const int* __restrict__ in_src,
-                                                  const unsigned short* __restrict__ in_loc, T* w, T* __restrict__ out,
+                                                  const int* __restrict__ in_pairs,
+                                                  const int* __restrict__ out_pairs, T* w, T* __restrict__ out,
                                                   unsigned* counter, CtBases bases, int nstreams, unsigned long long* prof_arg)
 {
     using L           = CtRec<T, WL>;
     using B           = typename Sentinel<T>::bits;
-    constexpr int NQ  = (DMODE != 0 || HAS_OUT) ? L::NQ : L::NQL;
+    constexpr int NQ  = (DMODE != 0) ? L::NQ : L::NQL;
     constexpr int R   = kCtRing;
     unsigned long long* const prof = PROF ? prof_arg : nullptr; // (diagnostic instantiation only: the counters cost scalar registers)
     extern __shared__ __attribute__((aligned(16))) char ct_lds[];
@@ -1711,7 +1709,7 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
     int* posted  = reinterpret_cast<int*>(ex + R * dims.exts); // tiles whose descriptor is in the ring
     int* tdone   = posted + 1; // tiles the compute wave has finished
     int* fetched = tdone + 1; // [R] external values parked so far
-    int* tdesc   = fetched + R; // [R][4] {first step, steps, -, -}
+    int* tdesc   = fetched + R; // [R][4] {first step, steps, first position, rows}
     const int tid = threadIdx.x;
     auto      uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
     if(tid == 0)
@@ -1742,6 +1740,26 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
                 atomicAdd(prof + 12, pf_poll);
             }
         };
+        // natural-order output of a finished tile: rows sorted by destination -> neighbouring lanes write neighbouring addresses
+        auto write_back = [&](int sl) {
+            const int p0 = uni(tdesc[4 * sl + 2]), nr = uni(tdesc[4 * sl + 3]);
+            const T*  xb = xs + 1 + sl * dims.rows;
+            const v2i32* pr = reinterpret_cast<const v2i32*>(out_pairs) + p0;
+            for(int q0 = 0; q0 < nr; q0 += 4 * 64)
+            {
+                v2i32 d[4];
+#pragma unroll
+                for(int u = 0; u < 4; ++u)
+                {
+                    const int q = q0 + u * 64 + lane;
+                    d[u]        = (q < nr) ? nt_load(pr + q) : v2i32{-1, 0};
+                }
+#pragma unroll
+                for(int u = 0; u < 4; ++u)
+                    if(d[u].x >= 0)
+                        out[d[u].x] = xb[d[u].y];
+            }
+        };
         for(int n = 0;; ++n)
         {
             const int slot = n % R;
@@ -1755,6 +1773,8 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
                     __builtin_amdgcn_s_sleep(2);
                 }
             }
+            if(HAS_OUT && n >= R)
+                write_back(slot); // tile n - R is finished (ring wait above): its values leave before the slot is reused
             unsigned long long pf_b = prof ? __builtin_amdgcn_s_memtime() : 0;
             pf_ring += pf_b - pf_a;
             unsigned tk = 0;
@@ -1773,6 +1793,11 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
             {
                 tdesc[4 * slot + 0] = d0.x;
                 tdesc[4 * slot + 1] = end ? 0 : d0.y;
+                if(!end)
+                {
+                    tdesc[4 * slot + 2] = d0.z;
+                    tdesc[4 * slot + 3] = d0.w;
+                }
                 fetched[slot]       = -1; // (-1: the tile's right-hand side is not in LDS yet)
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1780,6 +1805,18 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
                 __hip_atomic_store(posted, n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if(end)
             {
+                if(HAS_OUT) // the last tiles of this workgroup (their slots were never reused)
+                    for(int m = max(0, n - R + 1); m < n; ++m)
+                    {
+                        int spins = 0;
+                        while(uni(__hip_atomic_load(tdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < m + 1)
+                        {
+                            spin_guard(spins);
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                        asm volatile("" ::: "memory");
+                        write_back(m % R);
+                    }
                 pf_flush();
                 return;
             }
@@ -1792,25 +1829,25 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
                 // (whole lines where the tile covers contiguous pieces of the source vector); parked in row order
                 const int p0 = uni(d0.z), nr = uni(d0.w);
                 T*        rbb = xs + 1 + slot * dims.rows;
+                const v2i32* pr = reinterpret_cast<const v2i32*>(in_pairs) + p0;
                 for(int q0 = 0; q0 < nr; q0 += 4 * 64)
                 {
-                    int src[4], loc[4];
-                    T   v[4];
+                    v2i32 d[4];
+                    T     v[4];
 #pragma unroll
                     for(int u = 0; u < 4; ++u)
                     {
                         const int q = q0 + u * 64 + lane;
-                        src[u]      = (q < nr) ? nt_load(in_src + p0 + q) : -1;
-                        loc[u]      = (q < nr) ? (int)nt_load(in_loc + p0 + q) : 0;
+                        d[u]        = (q < nr) ? nt_load(pr + q) : v2i32{-1, 0};
                     }
 #pragma unroll
                     for(int u = 0; u < 4; ++u)
-                        if(src[u] >= 0)
-                            v[u] = rhs_src[src[u]];
+                        if(d[u].x >= 0)
+                            v[u] = rhs_src[d[u].x];
 #pragma unroll
                     for(int u = 0; u < 4; ++u)
-                        if(src[u] >= 0)
-                            rbb[loc[u]] = v[u];
+                        if(d[u].x >= 0)
+                            rbb[d[u].y] = v[u];
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if(lane == 0)
@@ -1943,9 +1980,9 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
         load_cur();
         return true;
     };
-    // vector memory operations of one step of the stream, in issue order: the stores of the step (value, natural-order copy),
-    // then the quads of the record DEPTH steps ahead
-    constexpr int OPS = (HAS_OUT ? 2 : 1) + NQ;
+    // vector memory operations of one step of the stream, in issue order: the store of the step's values, then the quads of
+    // the record DEPTH steps ahead
+    constexpr int OPS = 1 + NQ;
     static_assert(DEPTH * OPS < 64, "the whole prefetch window has to fit the 6-bit counter");
     auto fetch_rec = [&](CtStage<T, NQ>& st) {
         st.g  = g; // (the record itself comes back through the scalar cache when the step runs: scalar registers are scarce)
@@ -2054,8 +2091,6 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
         xs[own] = sum;
         }
         publish(w + st.pos + row, sum);
-        if(HAS_OUT)
-            out[stq.q[(L::off_ord / 4) / 4][(L::off_ord / 4) % 4]] = sum;
         }
         // this step's LDS traffic before the next step's: one wave, in-order LDS queue
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -2541,27 +2576,25 @@ __global__ __launch_bounds__(kBlock) void k_ct_tile_of_pos(int n, int ntiles, co
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_ct_in_lists(int n, const int* __restrict__ o1, const int* __restrict__ o2,
-                                                        const int* __restrict__ rhs_idx, const int* __restrict__ tile_of,
-                                                        const int* __restrict__ tile_desc, int* __restrict__ in_src,
-                                                        unsigned short* __restrict__ in_loc)
+__global__ __launch_bounds__(kBlock) void k_ct_pair_lists(int n, const int* __restrict__ o1, const int* __restrict__ o2,
+                                                          const int* __restrict__ key, const int* __restrict__ tile_of,
+                                                          const int* __restrict__ tile_desc, int* __restrict__ pairs)
 {
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
     for(int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gsz)
     {
-        const int p = o1[o2[q]]; // position: q-th of its tile in source order
-        in_src[q]   = rhs_idx[p];
-        in_loc[q]   = (unsigned short)(p - tile_desc[8 * (size_t)tile_of[p] + 2]);
+        const int p      = o1[o2[q]]; // position: q-th of its tile in key order
+        pairs[2 * q]     = key[p];
+        pairs[2 * q + 1] = p - tile_desc[8 * (size_t)tile_of[p] + 2];
     }
 }
 
-static int ct_build_in_lists(TriPlan* P, const int* rhs_idx)
+// pairs[q] = {key[p], row number of p inside its tile}, the positions p of every tile sorted by key[p]
+static int ct_build_pair_lists(TriPlan* P, const int* key, int** pairs_out)
 {
     Backend&  b = backend();
     const int n = P->n;
-    dev_free(&P->ct_in_src);
-    dev_free(&P->ct_in_loc);
-    P->ct_in_key = nullptr;
+    dev_free(pairs_out);
     int *o1 = nullptr, *o2 = nullptr, *tile_of = nullptr, *k2 = nullptr;
     int  s  = RAMD_OK;
     auto done = [&](int rc) {
@@ -2574,7 +2607,7 @@ static int ct_build_in_lists(TriPlan* P, const int* rhs_idx)
     const int grid = ew_grid(n);
     if((s = dev_alloc(&o1, n)) != RAMD_OK)
         return done(s);
-    if((s = device_stable_sort_by_key(rhs_idx, n, n, o1)) != RAMD_OK) // (source indices are positions / rows: < n)
+    if((s = device_stable_sort_by_key(key, n, n, o1)) != RAMD_OK) // (keys are positions / rows: < n)
         return done(s);
     if((s = dev_alloc(&tile_of, n)) != RAMD_OK)
         return done(s);
@@ -2586,18 +2619,15 @@ static int ct_build_in_lists(TriPlan* P, const int* rhs_idx)
         return done(s);
     if((s = device_stable_sort_by_key(k2, n, P->ct_ntiles, o2)) != RAMD_OK)
         return done(s);
-    if((s = dev_alloc(&P->ct_in_src, n)) != RAMD_OK)
+    if((s = dev_alloc(pairs_out, (int64_t)2 * n)) != RAMD_OK)
         return done(s);
-    if((s = dev_alloc(&P->ct_in_loc, n)) != RAMD_OK)
-        return done(s);
-    hipLaunchKernelGGL(k_ct_in_lists, dim3(grid), dim3(kBlock), 0, b.cur, n, o1, o2, rhs_idx, tile_of, P->ct_tile_desc,
-                       P->ct_in_src, P->ct_in_loc);
+    hipLaunchKernelGGL(k_ct_pair_lists, dim3(grid), dim3(kBlock), 0, b.cur, n, o1, o2, key, tile_of, P->ct_tile_desc,
+                       *pairs_out);
     if(hipStreamSynchronize(b.cur) != hipSuccess || hipGetLastError() != hipSuccess)
     {
         done(RAMD_OK);
-        RAMD_FAIL(RAMD_ERR_HIP, "sorted right-hand-side lists of the box-tile plan");
+        RAMD_FAIL(RAMD_ERR_HIP, "sorted index lists of the box-tile plan");
     }
-    P->ct_in_key = rhs_idx;
     return done(RAMD_OK);
 }
 
@@ -2624,7 +2654,13 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
         if(P->ct_rec)
         {
             if(P->ct_in_key != rhs_idx)
-                RAMD_TRY(ct_build_in_lists(P, rhs_idx));
+            {
+                P->ct_in_key = nullptr;
+                RAMD_TRY(ct_build_pair_lists(P, rhs_idx, &P->ct_in_pairs));
+                P->ct_in_key = rhs_idx;
+            }
+            if(out && !P->ct_out_pairs)
+                RAMD_TRY(ct_build_pair_lists(P, P->order, &P->ct_out_pairs));
             const size_t lds = ct_rec_lds_bytes<T>(dims);
             unsigned     nwg = 0;
             int          nstreams = 1;
@@ -2665,12 +2701,12 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
         if(pf_on && WLL == 3 && sizeof(T) == 8)                                                                             \
             hipLaunchKernelGGL((k_trsv_rec<T, DM, HO, (WLL == 3 ? 3 : 3), 8, true>), dim3(nwg), dim3(128), lds, b.cur,         \
                                P->ct_ntiles, dims, (const v4i32*)P->ct_tile_desc, (const v4i32*)P->ct_step_rec,             \
-                               P->ct_ext_idx, (const v4i32*)P->eval, rhs_src, P->ct_in_src, P->ct_in_loc, (T*)P->w, out,    \
+                               P->ct_ext_idx, (const v4i32*)P->eval, rhs_src, P->ct_in_pairs, P->ct_out_pairs, (T*)P->w, out, \
                                st->stream_counter, bases, nstreams, pf_buf);                                                \
         else                                                                                                                \
             hipLaunchKernelGGL((k_trsv_rec<T, DM, HO, WLL, DP, false>), dim3(nwg), dim3(128), lds, b.cur, P->ct_ntiles,     \
                                dims, (const v4i32*)P->ct_tile_desc, (const v4i32*)P->ct_step_rec, P->ct_ext_idx,            \
-                               (const v4i32*)P->eval, rhs_src, P->ct_in_src, P->ct_in_loc, (T*)P->w, out,                   \
+                               (const v4i32*)P->eval, rhs_src, P->ct_in_pairs, P->ct_out_pairs, (T*)P->w, out,               \
                                st->stream_counter, bases, nstreams, pf_buf);                                                \
     } while(0)
 #define TRSV_RC_L(DM, HO)            \
