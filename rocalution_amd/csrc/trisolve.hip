@@ -1566,7 +1566,9 @@ __global__ __launch_bounds__(kBlock) void k_ct_step_rec2(int n, int nsteps, cons
     }
 }
 
-template <typename T, bool LOWER, int WL>
+// LPR lanes share a row (LPR = 8: rows of up to 8 * WL entries): the row's record is LPR lane records of WL consecutive
+// entries each; the diagonal sits in the last lane's record (the lane that finishes the row)
+template <typename T, bool LOWER, int WL, int LPR>
 __global__ __launch_bounds__(kBlock) void k_ct_fill_rec(int n, const int* __restrict__ rp, const int* __restrict__ ci,
                                                         const T* __restrict__ val, const int* __restrict__ order,
                                                         const int* __restrict__ pos, const int* __restrict__ tile_of,
@@ -1588,8 +1590,9 @@ __global__ __launch_bounds__(kBlock) void k_ct_fill_rec(int n, const int* __rest
     const int tpos = step_pos[tile_step[tl]];
     int       e    = ext_start[p];
     const int e0   = ext_start[tpos];
-    auto      field = [&](int off) -> char* {
-        return erec + ((size_t)L::NQ * p0 + (size_t)(off / 16) * cnt + rank) * 16 + (off % 16);
+    // byte `off` of the record of lane `sub` of this row: quad-major over the step's cnt * LPR lane records
+    auto field = [&](int sub, int off) -> char* {
+        return erec + ((size_t)L::NQ * LPR * p0 + (size_t)(off / 16) * (cnt * LPR) + (rank * LPR + sub)) * 16 + (off % 16);
     };
     int       k    = 0;
     bool      have = false;
@@ -1610,24 +1613,25 @@ __global__ __launch_bounds__(kBlock) void k_ct_fill_rec(int n, const int* __rest
                 code       = 1 + rows_max + (e - e0);
                 ++e;
             }
-            if(k < WL)
+            if(k < WL * LPR)
             {
-                *reinterpret_cast<unsigned short*>(field(2 * k))                 = (unsigned short)code;
-                *reinterpret_cast<T*>(field(L::off_val + k * (int)sizeof(T))) = val[j];
+                const int sub = k / WL, kk = k % WL;
+                *reinterpret_cast<unsigned short*>(field(sub, 2 * kk))                 = (unsigned short)code;
+                *reinterpret_cast<T*>(field(sub, L::off_val + kk * (int)sizeof(T))) = val[j];
             }
             ++k;
         }
         else if(c == i)
         {
-            *reinterpret_cast<T*>(field(L::off_diag)) = val[j];
-            have                                      = true;
+            *reinterpret_cast<T*>(field(LPR - 1, L::off_diag)) = val[j];
+            have                                               = true;
         }
     }
     // (padding codes / values stay 0: the array is zeroed before the fill)
     if(!have)
     {
-        *reinterpret_cast<T*>(field(L::off_diag)) = (T)1;
-        *nodiag                                   = 1;
+        *reinterpret_cast<T*>(field(LPR - 1, L::off_diag)) = (T)1;
+        *nodiag                                            = 1;
     }
 }
 
@@ -1669,6 +1673,17 @@ __device__ __forceinline__ float ct_load_val(const float* p)
     asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(p) : "memory");
     return r;
 }
+// value of the lane below (row_shr:1 inside a row of 16 lanes; lane 0 of a row gets 0)
+__device__ __forceinline__ double ct_from_lane_below(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x111, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x111, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float ct_from_lane_below(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, false));
+}
 template <int N>
 __device__ __forceinline__ void ct_wait_vm()
 {
@@ -1688,7 +1703,7 @@ struct CtStage
     int   g, tf; // uniform: index of the step's record; its tile number * 4 + flags (1 = a new step, 2 = last step of its tile)
 };
 
-template <typename T, int DMODE, bool HAS_OUT, int WL, int DEPTH, bool PROF>
+template <typename T, int DMODE, bool HAS_OUT, int LPR, int WL, int DEPTH, bool PROF>
 __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const v4i32* __restrict__ tile_desc,
                                                   const v4i32* __restrict__ step_rec, const int* __restrict__ ext_idx,
                                                   const v4i32* __restrict__ erec, const T* __restrict__ rhs_src,
@@ -1987,14 +2002,15 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
     auto fetch_rec = [&](CtStage<T, NQ>& st) {
         st.g  = g; // (the record itself comes back through the scalar cache when the step runs: scalar registers are scarce)
         st.tf = tn * 4 + ((cur_fresh ? 1 : 0) | (cur_last ? 2 : 0));
-        const int      row = min(lane, cur.y - 1);
-        const v4i32*   qb  = erec + (size_t)L::NQ * (size_t)cur.x; // scalar base of the step + 32-bit lane offsets
+        const int      nl  = cur.y * LPR; // lane records of the step
+        const int      row = min(lane, nl - 1);
+        const v4i32*   qb  = erec + (size_t)(L::NQ * LPR) * (size_t)cur.x; // scalar base of the step + 32-bit lane offsets
         const unsigned ro  = (unsigned)row * 16u;
         // (lanes beyond the step's rows mirror its last row -- same addresses, same values: every operation is issued, and
         //  counted, in every step; switching those lanes off instead was measured no faster)
 #pragma unroll
         for(int q = 0; q < NQ; ++q)
-            st.q[q] = ct_load_quad(qb, ro + (unsigned)(q * cur.y) * 16u);
+            st.q[q] = ct_load_quad(qb, ro + (unsigned)(q * nl) * 16u);
         if(cur_fresh)
             pending = uni(pending + 1);
         cur_fresh = try_advance();
@@ -2010,7 +2026,10 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
         {
             int pos, cnt, need, lbase, tn, flags;
         } st = {uni(rec.x), uni(rec.y), uni(rec.z), uni(rec.w), uni(stq.tf) >> 2, uni(stq.tf) & 3};
-        const int row  = min(lane, st.cnt - 1);
+        const int nl   = st.cnt * LPR; // lane records of the step
+        const int lrec = min(lane, nl - 1);
+        const int row  = lrec / LPR; // row of the step this lane works for
+        const int sub  = lrec % LPR; // its place among the row's lanes
         const int slot = st.tn % R;
         if(st.tn != have_tn)
         {
@@ -2070,9 +2089,31 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
         T sum = bval;
         if(st.flags & 1) // (a repeated step only re-issues its stores)
         {
+        if(LPR == 1)
+        {
 #pragma unroll
-        for(int k = 0; k < WL; ++k)
-            sum -= a[k] * v[k]; // (padding: 0 * xs[0] = 0 * 0)
+            for(int k = 0; k < WL; ++k)
+                sum -= a[k] * v[k]; // (padding: 0 * xs[0] = 0 * 0)
+        }
+        else
+        {
+            // the row's entries are subtracted in storage order, as the host loop does: lane 0 of the row starts from the
+            // right-hand side and takes its WL entries, hands the running value to lane 1 (DPP, no LDS), ... -- every lane
+            // runs every round, the value that counts is the one of lane `t` in round t; the last lane ends up with the row
+            T pr[WL];
+#pragma unroll
+            for(int k = 0; k < WL; ++k)
+                pr[k] = a[k] * v[k];
+#pragma unroll
+            for(int t = 0; t < LPR; ++t)
+            {
+                T acc = (t == 0) ? bval : ct_from_lane_below(sum);
+#pragma unroll
+                for(int k = 0; k < WL; ++k)
+                    acc -= pr[k];
+                sum = acc;
+            }
+        }
         if(DMODE != 0)
         {
             T dg;
@@ -2088,9 +2129,12 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
             else
                 sum = sum * dg;
         }
-        xs[own] = sum;
+        if(LPR == 1 || (sub == LPR - 1 && lane < nl))
+            xs[own] = sum;
         }
-        publish(w + st.pos + row, sum);
+        // (LPR = 1: lanes beyond the step's rows repeat its last row; LPR > 1: only the last lane of a row holds it)
+        if(LPR == 1 || (sub == LPR - 1 && lane < nl))
+            publish(w + st.pos + row, sum);
         }
         // this step's LDS traffic before the next step's: one wave, in-order LDS queue
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -2440,8 +2484,8 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     CT_TRY(device_max_int(tsz + 3 * (size_t)ntiles, ntiles, &P->ct_dims[3]));
     {
         const CtDims d    = {P->ct_dims[0], P->ct_dims[1], P->ct_dims[2], P->ct_dims[3]};
-        const size_t need = lpr == 1 ? ct_rec_lds_bytes<T>(d) : ct_lds_bytes<T>(d, ct_group(), lpr, wl);
-        if(need <= (size_t)lds_budget && (lpr != 1 || 1 + d.rows + d.exts < 65536)) // (record form: 16-bit column codes)
+        const size_t need = ct_rec_lds_bytes<T>(d);
+        if(need <= (size_t)lds_budget && 1 + d.rows + d.exts < 65536) // (16-bit column codes)
             fits = true;
         else
         {
@@ -2478,55 +2522,37 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     hipLaunchKernelGGL(k_ct_tile_desc, dim3(ew_grid(ntiles)), dim3(kBlock), 0, b.cur, ntiles, P->ct_tile_step, P->ct_step_pos,
                        P->ct_step_ent, P->ct_ext_start, P->ct_tile_desc);
     CT_TRY(dev_alloc(&P->ct_step_rec, (int64_t)4 * ((int64_t)nsteps + 1)));
-    P->ct_rec = (lpr == 1);
-    if(P->ct_rec)
+    P->ct_rec = true;
     {
-        // record form: one array of 16-byte quads (CtRec), zeroed = padded
+        // record form: one array of 16-byte quads (CtRec), lpr lane records per row, zeroed = padded
         const size_t nq    = wl == 3 ? CtRec<T, 3>::NQ : (wl == 4 ? CtRec<T, 4>::NQ : CtRec<T, 8>::NQ);
-        const size_t bytes = nq * 16 * (size_t)n + kPad;
+        const size_t bytes = nq * 16 * (size_t)lpr * (size_t)n + kPad;
         CT_HIP(cached_malloc(&P->eval, bytes));
         CT_HIP(hipMemsetAsync(P->eval, 0, bytes, b.cur));
-#define CT_FILL_REC(LOW, WLL)                                                                                                \
-    hipLaunchKernelGGL((k_ct_fill_rec<T, LOW, WLL>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const T*)m->val,   \
-                       P->order, P->pos, tile_of, step_of, P->ct_tile_step, P->ct_step_pos, P->ct_ext_start, P->ct_ext_idx, \
-                       (char*)P->eval, nodiag, reverse ? 1 : 0, P->ct_dims[0])
+#define CT_FILL_REC(LOW, WLL, LP)                                                                                            \
+    hipLaunchKernelGGL((k_ct_fill_rec<T, LOW, WLL, LP>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci,                  \
+                       (const T*)m->val, P->order, P->pos, tile_of, step_of, P->ct_tile_step, P->ct_step_pos,               \
+                       P->ct_ext_start, P->ct_ext_idx, (char*)P->eval, nodiag, reverse ? 1 : 0, P->ct_dims[0])
+#define CT_FILL_REC_W(LOW)           \
+    do                               \
+    {                                \
+        if(lpr == 8)                 \
+            CT_FILL_REC(LOW, 4, 8);  \
+        else if(wl == 3)             \
+            CT_FILL_REC(LOW, 3, 1);  \
+        else if(wl == 4)             \
+            CT_FILL_REC(LOW, 4, 1);  \
+        else                         \
+            CT_FILL_REC(LOW, 8, 1);  \
+    } while(0)
         if(lower)
-        {
-            if(wl == 3)
-                CT_FILL_REC(true, 3);
-            else if(wl == 4)
-                CT_FILL_REC(true, 4);
-            else
-                CT_FILL_REC(true, 8);
-        }
+            CT_FILL_REC_W(true);
         else
-        {
-            if(wl == 3)
-                CT_FILL_REC(false, 3);
-            else if(wl == 4)
-                CT_FILL_REC(false, 4);
-            else
-                CT_FILL_REC(false, 8);
-        }
+            CT_FILL_REC_W(false);
+#undef CT_FILL_REC_W
 #undef CT_FILL_REC
         hipLaunchKernelGGL(k_ct_step_rec2, dim3(ew_grid(nsteps + 1)), dim3(kBlock), 0, b.cur, n, nsteps, P->ct_step_pos,
                            P->ct_ext_start, tile_of, P->ct_tile_step, P->ct_step_rec);
-    }
-    else
-    {
-        CT_TRY(dev_alloc(&P->ecol, (int64_t)total + 64 * 64)); // (+ what the register window reads past the last step)
-        CT_HIP(cached_malloc(&P->eval, ((size_t)total + 64 * 64) * sizeof(T) + kPad));
-        CT_HIP(cached_malloc(&P->diag, (size_t)n * sizeof(T) + kPad));
-        if(lower)
-            hipLaunchKernelGGL((k_ct_fill<T, true>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const T*)m->val,
-                               P->order, P->pos, tile_of, step_of, P->ct_tile_step, P->ct_step_pos, P->ct_step_ent,
-                               P->ct_ext_start, P->ct_ext_idx, P->ecol, (T*)P->eval, (T*)P->diag, nodiag, reverse ? 1 : 0);
-        else
-            hipLaunchKernelGGL((k_ct_fill<T, false>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const T*)m->val,
-                               P->order, P->pos, tile_of, step_of, P->ct_tile_step, P->ct_step_pos, P->ct_step_ent,
-                               P->ct_ext_start, P->ct_ext_idx, P->ecol, (T*)P->eval, (T*)P->diag, nodiag, reverse ? 1 : 0);
-        hipLaunchKernelGGL(k_ct_step_rec, dim3(ew_grid(nsteps + 1)), dim3(kBlock), 0, b.cur, n, nsteps, P->ct_step_pos,
-                           P->ct_step_ent, P->ct_ext_start, tile_of, P->ct_tile_step, P->ct_step_rec);
     }
     int nd = 0;
     CT_HIP(hipMemcpyAsync(&nd, nodiag, sizeof(int), hipMemcpyDeviceToHost, b.cur));
@@ -2681,7 +2707,7 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
                 RAMD_HIP(hipMemsetAsync(pf_buf, 0, 32 * sizeof(unsigned long long), b.cur));
             }
 // persistent workgroups: as many as the device holds at once (more would only queue), never more than tiles
-#define TRSV_RC(DM, HO, WLL, DP)                                                                                            \
+#define TRSV_RC(DM, HO, LP, WLL, DP)                                                                                        \
     do                                                                                                                      \
     {                                                                                                                       \
         static int occ = 0;                                                                                                 \
@@ -2689,7 +2715,7 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
         if(occ_lds != lds)                                                                                                  \
         {                                                                                                                   \
             int nb_cu = 0;                                                                                                  \
-            RAMD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_cu, k_trsv_rec<T, DM, HO, WLL, DP, false>, 128, lds));       \
+            RAMD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_cu, k_trsv_rec<T, DM, HO, LP, WLL, DP, false>, 128, lds));       \
             occ     = nb_cu < 1 ? 1 : nb_cu;                                                                                \
             occ_lds = lds;                                                                                                  \
         }                                                                                                                   \
@@ -2699,12 +2725,12 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
         for(int i = 0; i < TriState::kStreams; ++i)                                                                         \
             bases.v[i] = st->stream_ticket[i];                                                                              \
         if(pf_on && WLL == 3 && sizeof(T) == 8)                                                                             \
-            hipLaunchKernelGGL((k_trsv_rec<T, DM, HO, (WLL == 3 ? 3 : 3), 8, true>), dim3(nwg), dim3(128), lds, b.cur,         \
+            hipLaunchKernelGGL((k_trsv_rec<T, DM, HO, 1, 3, 8, true>), dim3(nwg), dim3(128), lds, b.cur,                        \
                                P->ct_ntiles, dims, (const v4i32*)P->ct_tile_desc, (const v4i32*)P->ct_step_rec,             \
                                P->ct_ext_idx, (const v4i32*)P->eval, rhs_src, P->ct_in_pairs, P->ct_out_pairs, (T*)P->w, out, \
                                st->stream_counter, bases, nstreams, pf_buf);                                                \
         else                                                                                                                \
-            hipLaunchKernelGGL((k_trsv_rec<T, DM, HO, WLL, DP, false>), dim3(nwg), dim3(128), lds, b.cur, P->ct_ntiles,     \
+            hipLaunchKernelGGL((k_trsv_rec<T, DM, HO, LP, WLL, DP, false>), dim3(nwg), dim3(128), lds, b.cur, P->ct_ntiles, \
                                dims, (const v4i32*)P->ct_tile_desc, (const v4i32*)P->ct_step_rec, P->ct_ext_idx,            \
                                (const v4i32*)P->eval, rhs_src, P->ct_in_pairs, P->ct_out_pairs, (T*)P->w, out,               \
                                st->stream_counter, bases, nstreams, pf_buf);                                                \
@@ -2712,12 +2738,14 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
 #define TRSV_RC_L(DM, HO)            \
     do                               \
     {                                \
-        if(wl == 3)                  \
-            TRSV_RC(DM, HO, 3, 8);   \
-        else if(wl == 4)             \
-            TRSV_RC(DM, HO, 4, 8);   \
-        else                         \
-            TRSV_RC(DM, HO, 8, 6);   \
+        if(lpr == 8)                    \
+            TRSV_RC(DM, HO, 8, 4, 8);   \
+        else if(wl == 3)                \
+            TRSV_RC(DM, HO, 1, 3, 8);   \
+        else if(wl == 4)                \
+            TRSV_RC(DM, HO, 1, 4, 8);   \
+        else                            \
+            TRSV_RC(DM, HO, 1, 8, 6);   \
     } while(0)
 #define TRSV_RC_O(DM)                \
     do                               \
@@ -3532,8 +3560,8 @@ __global__ __launch_bounds__(kBlock) void k_gather_diag(int n, const int* __rest
         dst[t] = src[order[t]];
 }
 
-// record form: the diagonal lives inside the rows' records; one wave per step
-template <typename T, int WL>
+// record form: the diagonal lives inside the rows' records (last lane record of the row); one wave per step
+template <typename T, int WL, int LPR>
 __global__ __launch_bounds__(kBlock) void k_ct_rec_set_diag(int nsteps, const int* __restrict__ step_rec,
                                                             const int* __restrict__ order, const T* __restrict__ src,
                                                             char* __restrict__ erec)
@@ -3545,7 +3573,9 @@ __global__ __launch_bounds__(kBlock) void k_ct_rec_set_diag(int nsteps, const in
         return;
     const int p0 = step_rec[4 * wave], cnt = step_rec[4 * wave + 1];
     if(lane < cnt)
-        *reinterpret_cast<T*>(erec + ((size_t)L::NQ * p0 + (size_t)(L::off_diag / 16) * cnt + lane) * 16 + (L::off_diag % 16))
+        *reinterpret_cast<T*>(erec
+                              + ((size_t)L::NQ * LPR * p0 + (size_t)(L::off_diag / 16) * (cnt * LPR) + (lane * LPR + LPR - 1)) * 16
+                              + (L::off_diag % 16))
             = src[order[p0 + lane]];
 }
 
@@ -3558,17 +3588,21 @@ static int plan_set_diag(TriPlan* P, const T* src)
         return RAMD_OK;
     if(P->ct && P->ct_rec)
     {
-        const int      wl = P->ct_wmax <= 3 ? 3 : (P->ct_wmax <= 4 ? 4 : 8);
-        const unsigned nb = (unsigned)(((int64_t)P->ct_nsteps * 64 + kBlock - 1) / kBlock);
-        if(wl == 3)
-            hipLaunchKernelGGL((k_ct_rec_set_diag<T, 3>), dim3(nb), dim3(kBlock), 0, b.cur, P->ct_nsteps, P->ct_step_rec,
-                               P->order, src, (char*)P->eval);
+        const int      lpr = P->ct_wmax > 8 ? 8 : 1;
+        const int      wl  = lpr == 8 ? 4 : (P->ct_wmax <= 3 ? 3 : (P->ct_wmax <= 4 ? 4 : 8));
+        const unsigned nb  = (unsigned)(((int64_t)P->ct_nsteps * 64 + kBlock - 1) / kBlock);
+#define CT_SET_DIAG(WLL, LP)                                                                                                \
+    hipLaunchKernelGGL((k_ct_rec_set_diag<T, WLL, LP>), dim3(nb), dim3(kBlock), 0, b.cur, P->ct_nsteps, P->ct_step_rec,     \
+                       P->order, src, (char*)P->eval)
+        if(lpr == 8)
+            CT_SET_DIAG(4, 8);
+        else if(wl == 3)
+            CT_SET_DIAG(3, 1);
         else if(wl == 4)
-            hipLaunchKernelGGL((k_ct_rec_set_diag<T, 4>), dim3(nb), dim3(kBlock), 0, b.cur, P->ct_nsteps, P->ct_step_rec,
-                               P->order, src, (char*)P->eval);
+            CT_SET_DIAG(4, 1);
         else
-            hipLaunchKernelGGL((k_ct_rec_set_diag<T, 8>), dim3(nb), dim3(kBlock), 0, b.cur, P->ct_nsteps, P->ct_step_rec,
-                               P->order, src, (char*)P->eval);
+            CT_SET_DIAG(8, 1);
+#undef CT_SET_DIAG
     }
     else
         hipLaunchKernelGGL((k_gather_diag<T>), dim3(ew_grid(P->n)), dim3(kBlock), 0, b.cur, P->n, P->order, src, (T*)P->diag);
