@@ -430,7 +430,7 @@ def main():
         r_spmv = roof(k_spmv, b_spmv, p_spmv, traffic_for(tkey) if tkey else None)
         if tri_pc and p_trsv["launches"] > 0:
             tk = "trsv_512" if (args.matrix == "poisson" and N == 512) else ("trsv_shell" if args.matrix == "shell" else None)
-            prof = roof("sparse triangular solve (k_trsv / k_trsv_tile), one launch per triangle", trsv_bytes(n, nnz, vb), p_trsv,
+            prof = roof("sparse triangular solve (k_trsv_rec: record-form box tiles; k_trsv where a matrix has no chains), one launch per triangle", trsv_bytes(n, nnz, vb), p_trsv,
                         traffic_for(tk) if tk else None)
             kernels["spmv"] = r_spmv
         else:

@@ -806,8 +806,8 @@ static int build_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bool 
 // a 2-D shell mesh with 5 unknowns per node (deep, narrow DAG: GMRES+ILU(0) there was SLOWER than one CPU core).  Making
 // the hand-off itself cheaper does not help: tiles that stay one level apart run in lockstep at that latency whatever the
 // tile shape (measured: chains x level bands with per-step polling 5.4 ms, with a run-ahead fetcher wave 55 ms at 512^3).
-// What helps is a tile that is SMALL IN EVERY DEPENDENCY DIRECTION and is finished as a unit before its successors
-// start: the solve then costs (depth of the tile DAG) x (time of one tile), and a tile is a few microseconds of LDS work.
+// What helps is a tile that is SMALL IN EVERY DEPENDENCY DIRECTION: its own dependencies are resolved in LDS, and a
+// successor tile only trails it by the few steps its first rows need.
 //
 // Tiles for any matrix -- three MONOTONE coordinates per row, propagated along the dependency DAG:
 //      c0(v) = max over dependencies u of c0(u) + [u is v's chain predecessor]   (chain: v depends on the row right before it)
@@ -817,12 +817,8 @@ static int build_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bool 
 // any matrix, and tiles taken in order of (t0 + t1 + t2, t2, t1, t0) -- the ticket order -- only wait on tiles that
 // already started.  On a lexicographic 3-D stencil the coordinates are the grid coordinates (boxes = cubes), on a
 // banded 2-D FE matrix they are (skewed position along the mesh line, mesh line): parallelograms.
-// Inside a tile the rows run in order of their global dependency level (one step per level present in the tile).
-//
-// One workgroup of two waves per tile.  Everything static the tile needs (packed entries, diagonal, scatter index) and
-// its right-hand side values are copied into LDS in ONE bulk phase with all loads in flight; wave 1 meanwhile polls the
-// values of other tiles the tile depends on (NaN-sentinel hand-off as above) and parks them in LDS; wave 0 then walks the
-// steps touching only LDS, publishes every finished value with one agent-scope store, and is done.
+// Inside a tile the rows run in order of their global dependency level (one step per level present in the tile, at most
+// 64 / lanes-per-row rows per step).  The solve kernel is k_trsv_rec further down ("record form").
 // The arithmetic per row is unchanged (ascending columns, divide by the stored diagonal): bit-exact with the host.
 
 // sweep space: t = row (lower solve) or n-1-row (upper solve).  start[t] = 1 if row t does not depend on row t-1.
@@ -1086,74 +1082,6 @@ __global__ __launch_bounds__(kBlock) void k_ct_tile_sizes(int ntiles, const int*
     }
 }
 
-// entries of a step: [k][rank] with the step's row count as stride; a column inside the tile becomes its LDS index
-// (position - first position of the tile); a column of another tile becomes -(j + 2), j = its number in the tile's list of
-// external dependencies (positions in ext_idx, fetched into LDS by the tile's second wave); padding -1
-template <typename T, bool LOWER>
-__global__ __launch_bounds__(kBlock) void k_ct_fill(int n, const int* __restrict__ rp, const int* __restrict__ ci,
-                                                    const T* __restrict__ val, const int* __restrict__ order,
-                                                    const int* __restrict__ pos, const int* __restrict__ tile_of,
-                                                    const int* __restrict__ step_of, const int* __restrict__ tile_step,
-                                                    const int* __restrict__ step_pos, const int* __restrict__ step_ent,
-                                                    const int* __restrict__ ext_start, int* __restrict__ ext_idx,
-                                                    int* __restrict__ ecol, T* __restrict__ eval, T* __restrict__ diag,
-                                                    int* __restrict__ nodiag, int reverse)
-{
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if(p >= n)
-        return;
-    const int  i    = order[p];
-    const int  gs   = step_of[p];
-    const int  p0   = step_pos[gs];
-    const int  cnt  = step_pos[gs + 1] - p0;
-    const int  rank = (int)p - p0;
-    const int  base = step_ent[gs];
-    const int  w    = (step_ent[gs + 1] - base) / cnt;
-    const int  tl   = tile_of[p];
-    const int  tpos = step_pos[tile_step[tl]];
-    int        e    = ext_start[p]; // next external slot of this row (global numbering)
-    const int  e0   = ext_start[tpos];
-    int        k    = 0;
-    bool       have = false;
-    const int  rs = rp[i], re = rp[i + 1];
-    for(int q = rs; q < re; ++q)
-    {
-        const int j = reverse ? (re - 1 - (q - rs)) : q;
-        const int c = ci[j];
-        if(LOWER ? (c < i) : (c > i))
-        {
-            const int pc = pos[c];
-            int       code;
-            if(tile_of[pc] == tl)
-                code = pc - tpos;
-            else
-            {
-                ext_idx[e] = pc;
-                code       = -(e - e0 + 2);
-                ++e;
-            }
-            ecol[base + k * cnt + rank] = code;
-            eval[base + k * cnt + rank] = val[j];
-            ++k;
-        }
-        else if(c == i)
-        {
-            diag[p] = val[j];
-            have    = true;
-        }
-    }
-    for(; k < w; ++k)
-    {
-        ecol[base + k * cnt + rank] = -1;
-        eval[base + k * cnt + rank] = (T)0;
-    }
-    if(!have)
-    {
-        diag[p] = (T)1;
-        *nodiag = 1;
-    }
-}
-
 // everything a workgroup needs to know about its tile in one 32-byte record:
 // {first step, steps, first position, rows | first packed entry, packed entries, first external slot, external slots}
 __global__ __launch_bounds__(kBlock) void k_ct_tile_desc(int ntiles, const int* __restrict__ tile_step,
@@ -1173,24 +1101,6 @@ __global__ __launch_bounds__(kBlock) void k_ct_tile_desc(int ntiles, const int* 
         desc[8 * t + 5] = step_ent[s1] - step_ent[s0];
         desc[8 * t + 6] = ext_start[p0];
         desc[8 * t + 7] = ext_start[p1] - ext_start[p0];
-    }
-}
-
-// per step: {first position, first packed entry, external slots used before the step, first position of its tile} -- one
-// 16-byte record per step, fetched in bulk when a workgroup starts
-__global__ __launch_bounds__(kBlock) void k_ct_step_rec(int n, int nsteps, const int* __restrict__ step_pos,
-                                                        const int* __restrict__ step_ent, const int* __restrict__ ext_start,
-                                                        const int* __restrict__ tile_of, const int* __restrict__ tile_step,
-                                                        int* __restrict__ rec)
-{
-    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
-    for(int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g <= nsteps; g += gsz)
-    {
-        const int p    = step_pos[g];
-        rec[4 * g + 0] = p;
-        rec[4 * g + 1] = step_ent[g];
-        rec[4 * g + 2] = ext_start[p];
-        rec[4 * g + 3] = (p < n) ? step_pos[tile_step[tile_of[p]]] : n;
     }
 }
 
@@ -1247,278 +1157,32 @@ struct CtDims
 {
     int rows, steps, ents, exts;
 };
-constexpr int kCtFetchDepth = 4; // batches of 64 external values the fetcher keeps in flight
-constexpr int kCtDepth      = 6; // steps the compute wave's global loads run ahead of its arithmetic
+constexpr int kCtFetchDepth = 4; // batches of 64 external values the fetch wave keeps in flight
 
-template <typename T>
-static size_t ct_lds_bytes(const CtDims& d, int group, int lanes_per_row, int wl)
-{
-    size_t tvals = (size_t)d.rows /*xs*/ + 2 * (size_t)d.exts /*ex, two tiles*/
-                   + (lanes_per_row > 1 ? (size_t)64 * wl : 0) /*products of a step*/;
-    size_t ivals = 4 * ((size_t)group * d.steps + 1) /*step records*/ + (size_t)group * d.rows /*rhs index*/ + 8;
-    return tvals * sizeof(T) + ivals * sizeof(int) + 64;
-}
-
-// registers of one step of the compute wave (loaded kCtDepth steps before they are used)
-template <typename T, int WL>
-struct CtRegs
-{
-    int c[WL];
-    T   a[WL];
-    T   b, dg;
-    int onat;
-};
-
-// One workgroup (two waves) per `group` consecutive tiles.
-//   wave 1 (fetcher): per tile, the values of other tiles in use order -> LDS (two tiles' worth of space, so it runs one
-//                     tile ahead); hands them over through a running count.
-//   wave 0 (compute): walks the steps of all its tiles as ONE stream.  The packed entries, right-hand side, diagonal and
-//                     scatter index of a step are loaded kCtDepth steps ahead into registers (the steps of consecutive
-//                     tiles are contiguous in memory, so the pipeline never drains at a tile boundary); a step itself
-//                     touches only LDS (the tile's own values, the parked external ones) and issues its stores.
-// Every vector memory operation of the step loop is executed unconditionally by all 64 lanes -- lanes beyond the step's
-// rows mirror its last row, steps beyond the last one repeat it (same addresses, same values: harmless duplicates) -- so
-// the compiler can count what is in flight and wait with a partial vmcnt(N) instead of draining the prefetch.
-// LPR lanes per row: 1 (W <= WL entries per row) or 8 (W <= 8 * WL): each lane forms WL products of the row, they meet in
-// LDS, and every lane of the row subtracts all of them in storage order (the same roundings as the host loop).
-template <typename T, int DMODE, bool HAS_OUT, int LPR, int WL, int DEPTH>
-__global__ __launch_bounds__(128) void k_trsv_stream(int ntiles, int group, CtDims dims, const int* __restrict__ tile_desc,
-                                                     const int* __restrict__ step_rec, const int* __restrict__ ext_idx,
-                                                     const int* __restrict__ ecol, const T* __restrict__ eval,
-                                                     const T* __restrict__ diag, const T* __restrict__ rhs_src,
-                                                     const int* __restrict__ rhs_idx, T* w, T* __restrict__ out,
-                                                     const int* __restrict__ order, unsigned* counter, unsigned base)
-{
-    extern __shared__ __attribute__((aligned(16))) char ct_lds[];
-    T*     xs   = reinterpret_cast<T*>(ct_lds); // [rows] values of the current tile
-    T*     ex   = xs + dims.rows; // [2][exts] values of other tiles (tile parity)
-    T*     prod = ex + 2 * dims.exts; // [64 * WL] products of a step (LPR > 1)
-    v4i32* recs = reinterpret_cast<v4i32*>(prod + (LPR > 1 ? 64 * WL : 0)); // [group * steps + 1] step records
-    int*   lidx = reinterpret_cast<int*>(recs + (group * dims.steps + 1)); // [group * rows] right-hand side index
-    int*   fetched = lidx + group * dims.rows; // external values parked so far (all tiles of the group)
-    int*   tdone   = fetched + 1; // tiles the compute wave has finished
-
-    const int      tid    = threadIdx.x;
-    const unsigned ticket = take_ticket(counter, base);
-    const int64_t  t0_64  = (int64_t)ticket * group;
-    if(t0_64 >= ntiles)
-        return;
-    const int   t0  = (int)t0_64;
-    const int   ntl = min(group, ntiles - t0);
-    const v4i32 dA0 = reinterpret_cast<const v4i32*>(tile_desc)[2 * t0];
-    const v4i32 dA1 = reinterpret_cast<const v4i32*>(tile_desc)[2 * t0 + 1];
-    const v4i32 dZ0 = reinterpret_cast<const v4i32*>(tile_desc)[2 * (t0 + ntl - 1)];
-    const int   S0 = dA0.x, nst = dZ0.x + dZ0.y - dA0.x; // steps of the group
-    const int   P0 = dA0.z, npos = dZ0.z + dZ0.w - dA0.z; // positions of the group
-    const int   X0 = dA1.z; // first external slot of the group
-    using B        = typename Sentinel<T>::bits;
-    // ---------------- start-up: step records and right-hand side indices of the whole group
-    if(tid == 0)
-    {
-        *fetched = 0;
-        *tdone   = 0;
-    }
-    constexpr int NT = 128;
-    for(int i = tid; i <= nst; i += NT)
-        recs[i] = reinterpret_cast<const v4i32*>(step_rec)[S0 + i];
-    for(int i = tid; i < npos; i += NT)
-        lidx[i] = rhs_idx[P0 + i];
-    __syncthreads();
-    if(tid >= 64)
-    {
-        // ---------------- fetcher wave
-        const int lane = tid - 64;
-        for(int g = 0; g < ntl; ++g)
-        {
-            const v4i32 d1 = reinterpret_cast<const v4i32*>(tile_desc)[2 * (t0 + g) + 1];
-            const int   e0 = d1.z, e1 = d1.z + d1.w;
-            T*          exb = ex + (g & 1) * dims.exts;
-            if(g >= 2) // the buffer of tile g was used by tile g - 2: wait until the compute wave is done with it
-            {
-                int spins = 0;
-                while(__hip_atomic_load(tdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < g - 1)
-                {
-                    spin_guard(spins);
-                    __builtin_amdgcn_s_sleep(2);
-                }
-            }
-            for(int e = e0; e < e1; e += 64 * kCtFetchDepth)
-            {
-                int idx[kCtFetchDepth];
-                B   bits[kCtFetchDepth];
-#pragma unroll
-                for(int u = 0; u < kCtFetchDepth; ++u)
-                {
-                    const int j = e + u * 64 + lane;
-                    idx[u]      = (j < e1) ? nt_load(ext_idx + j) : -1;
-                }
-                const int nbatch = min(kCtFetchDepth, (e1 - e + 63) / 64);
-                int       next = 0, spins = 0, backoff = 1;
-                while(next < nbatch)
-                {
-#pragma unroll
-                    for(int u = 0; u < kCtFetchDepth; ++u)
-                        if(u >= next && idx[u] >= 0)
-                            bits[u] = poll_load(w + idx[u]);
-                    bool advanced = false;
-#pragma unroll
-                    for(int u = 0; u < kCtFetchDepth; ++u)
-                        if(u == next && u < nbatch)
-                        {
-                            const bool missing = idx[u] >= 0 && bits[u] == Sentinel<T>::value;
-                            if(__ballot(missing) == 0ull)
-                            {
-                                if(idx[u] >= 0)
-                                    exb[e - e0 + u * 64 + lane] = Sentinel<T>::from_bits(bits[u]);
-                                // the wave's LDS writes before the count (in-order LDS queue; the wait pins the compiler)
-                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                                if(lane == 0)
-                                    __hip_atomic_store(fetched, min(e + (u + 1) * 64, e1) - X0, __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-                                ++next;
-                                advanced = true;
-                            }
-                        }
-                    if(!advanced)
-                    {
-                        spin_guard(spins);
-                        backoff = poll_backoff(false, backoff);
-                    }
-                }
-            }
-        }
-        return;
-    }
-    // ---------------- compute wave
-    const int     lane = tid;
-    constexpr int RPP  = 64 / LPR; // rows per step at most
-    const int     sub  = lane % LPR;
-    const int     slot = lane / LPR;
-    const int     last = nst - 1;
-    // record of step i: {first position, first packed entry, external slots used before the step, first position of its tile}
-    // The step records come out of LDS into vector registers although every lane reads the same record: pin them to
-    // scalar registers (readfirstlane), so that addresses are a scalar base per array plus a small per-lane offset --
-    // the counters of r02 showed the kernel ISSUE bound (284 instructions per step, half of them 64-bit address
-    // arithmetic on the vector ALU), not memory bound.
-    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
-    auto fetch = [&](int i, CtRegs<T, WL>& r) {
-        const v4i32 a = recs[i], bnext = recs[i + 1];
-        const int   apos = uni(a.x), aent = uni(a.y);
-        const int   cnt  = uni(bnext.x) - apos;
-        const int   wd   = (uni(bnext.y) - aent) / cnt;
-        const int   row  = min(slot, cnt - 1);
-        const int*  colb = ecol + aent; // scalar bases of this step
-        const T*    valb = eval + aent;
-        const int   p    = apos + row;
-        r.b              = rhs_src[lidx[p - P0]];
-        r.dg             = (DMODE == 0) ? (T)1 : (diag + apos)[row];
-        r.onat           = HAS_OUT ? (order + apos)[row] : 0;
-#pragma unroll
-        for(int k = 0; k < WL; ++k)
-        {
-            const int ke  = k * LPR + sub; // (beyond the row's width this reads following entries: allocated, ignored)
-            const int off = ke * cnt + row;
-            const int ci  = nt_load(colb + off);
-            r.a[k]        = nt_load(valb + off);
-            r.c[k]        = (ke < wd) ? ci : -1;
-        }
-    };
-    int have = 0, tile_no = 0;
-    auto step = [&](int i, const CtRegs<T, WL>& r) {
-        const v4i32 a0 = recs[i], b0 = recs[i + 1];
-        struct
-        {
-            int x, y, z, w;
-        } a = {uni(a0.x), uni(a0.y), uni(a0.z), uni(a0.w)}, bnext = {uni(b0.x), uni(b0.y), uni(b0.z), uni(b0.w)};
-        const int cnt  = bnext.x - a.x;
-        const int row  = min(slot, cnt - 1);
-        const int need = bnext.z - X0; // external values used up to and including this step (running over the group)
-        if(have < need) // wave-uniform: wait for the fetcher (LDS count, no memory round trip)
-        {
-            int spins = 0;
-            while((have = __hip_atomic_load(fetched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need)
-            {
-                spin_guard(spins);
-                __builtin_amdgcn_s_sleep(1);
-            }
-            asm volatile("" ::: "memory");
-        }
-        const int exo = dims.rows + (tile_no & 1) * dims.exts; // xs and ex are contiguous: one base for both kinds
-        T         v[WL];
-#pragma unroll
-        for(int k = 0; k < WL; ++k)
-        {
-            const int at = (r.c[k] >= 0) ? r.c[k] : ((r.c[k] < -1) ? exo - (r.c[k] + 2) : 0);
-            v[k]         = xs[at];
-        }
-        T sum = r.b;
-        if(LPR == 1)
-        {
-#pragma unroll
-            for(int k = 0; k < WL; ++k)
-            {
-                const T pr = r.a[k] * v[k];
-                sum -= (r.c[k] == -1) ? (T)0 : pr; // padding subtracts +0: changes nothing
-            }
-        }
-        else
-        {
-            // the row's products meet in LDS ([slot][entry]); every lane of the row then subtracts them in storage order
-            const int wd = (bnext.y - a.y) / cnt;
-#pragma unroll
-            for(int k = 0; k < WL; ++k)
-                prod[slot * (LPR * WL) + k * LPR + sub] = (r.c[k] == -1) ? (T)0 : r.a[k] * v[k];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            // (reading all 32 slots into registers first and subtracting them unrolled was measured slower: 9.9 vs 8.9 ms)
-            for(int q = 0; q < wd; ++q)
-                sum -= prod[slot * (LPR * WL) + q];
-        }
-        if(DMODE == 1)
-            sum /= r.dg;
-        else if(DMODE == 2)
-            sum = sum * r.dg;
-        xs[a.x - a.w + row] = sum;
-        publish(w + a.x + row, sum);
-        if(HAS_OUT)
-            out[r.onat] = sum;
-        // this step's LDS traffic before the next step's: one wave, in-order LDS queue
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if(bnext.w != a.w && i < last) // the tile is finished: the fetcher may reuse the buffer of the tile before it
-        {
-            ++tile_no;
-            if(lane == 0)
-                __hip_atomic_store(tdone, tile_no, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    };
-    CtRegs<T, WL> st[DEPTH];
-#pragma unroll
-    for(int j = 0; j < DEPTH; ++j)
-        fetch(min(j, last), st[j]);
-    for(int i0 = 0; i0 < nst; i0 += DEPTH)
-    {
-#pragma unroll
-        for(int j = 0; j < DEPTH; ++j)
-        {
-            const int i = i0 + j;
-            step(min(i, last), st[j]); // (beyond the last step: the last one again, its registers were re-fetched)
-            fetch(min(i + DEPTH, last), st[j]);
-        }
-    }
-}
-
-// ======================================================================= record form of the box-tile solve (rows of <= 8 entries)
-// Counters of the stream kernel above (profiles/r02_trsv_counters.txt): the solve is bound by the NUMBER of vector memory
-// instructions a step issues (13 per step of ~23 rows: the CU's address path and the 6-bit vmcnt window both count
-// instructions, not bytes) and by the start-up chain of a tile (ticket -> descriptor -> step records -> first loads, ~5 us
-// of a ~20 us tile).  The record form attacks both:
-//   * everything static a row needs is ONE record of 16-byte quads -- {column codes as 16-bit LDS indices | values | diagonal |
-//     scatter index} -- stored quad-major per step, so a step loads it with 2-3 fully coalesced 16-byte loads instead
-//     of 8-11 narrow ones; a unit-diagonal solve without natural-order output skips the quad(s) holding diagonal and index;
-//   * workgroups are PERSISTENT: the second wave takes the tickets, posts the tile descriptor into an LDS ring and parks the
-//     tile's external values up to two tiles ahead, so the compute wave walks the steps of tile after tile as one stream
-//     whose prefetch never drains (ticket order still guarantees progress: a tile only waits on lower tickets, all held
-//     by running workgroups whose earlier tiles are finished first);
-//   * step records are uniform: fetched through the scalar cache one step ahead, not through LDS.
+// ======================================================================= record form of the box-tile solve
+// What the counters and the phase timers of round 2 said about the first box-tile kernels (one workgroup per tile, narrow
+// per-array loads, everything of a step gathered per step; profiles/r02_trsv_*):
+//   * ONE ticket word serves ~88 atomics per microsecond: 262144 tiles at 512^3 cost 3 ms of tickets alone, whatever the
+//     kernel did otherwise;
+//   * below that, the solve is bound by the NUMBER of vector memory instructions a CU issues (~45 cycles each, 23 rows of 64
+//     lanes or not), and by the start-up chain of a tile (ticket -> descriptor -> step records -> first loads);
+//   * with dependencies on, the critical path is (tile hops) x (steps a successor trails its predecessor) x (time of a step).
+// The record form:
+//   * everything static a row needs is ONE record of 16-byte quads -- {column codes as 16-bit LDS indices | values |
+//     diagonal} -- stored quad-major per step: 2-3 fully coalesced 16-byte loads per step instead of 8-11 narrow ones
+//     (a unit-diagonal solve skips the quad holding the diagonal); rows of 9-32 entries take 8 lanes, each with a record
+//     of 4 consecutive entries, and the running value of the row passes from lane to lane through DPP in storage order;
+//   * workgroups are PERSISTENT, tickets come from 16 streams (tile k belongs to stream k % 16, every stream its own
+//     word on its own page).  The second wave of the workgroup takes the tickets, posts the tile descriptor into an LDS
+//     ring and works up to two tiles ahead: it reads the tile's right-hand side -- rows sorted by source index, so that
+//     neighbouring lanes read neighbouring addresses -- into the tile's LDS slot, parks the values of other tiles in use
+//     order (handing over every value up to the first missing one), and writes the natural-order output of a finished
+//     tile back in destination order.  Ticket order still guarantees progress: a tile only waits on lower tickets, all
+//     held by running workgroups whose earlier tiles are finished first;
+//   * the compute wave walks the steps of tile after tile as one stream whose prefetch never drains: quads DEPTH steps ahead
+//     into registers (hand-issued loads, hand-counted vmcnt), step records through the scalar cache, a step itself only
+//     touches LDS (right-hand side and solution share a slot per row) and issues one store: the agent-scope publication of
+//     its values, which doubles as the position-order result the next stage reads.
 // Column codes: 0 = padding (LDS slot 0 holds 0.0 and the padded value is 0: subtracts +0), 1 + q = row q of the tile,
 // 1 + rows_max + j = external value j of the tile.
 constexpr int kCtRing = 3; // tiles the ticket/fetch wave may be ahead of the compute wave (+1)
@@ -2195,17 +1859,6 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
     }
 }
 
-static int ct_group() // tiles per workgroup (one ticket, one pipeline start-up)
-{
-    static int group = -1;
-    if(group < 0)
-    {
-        group = getenv("RAMD_TRSV_CT_GROUP") ? atoi(getenv("RAMD_TRSV_CT_GROUP")) : 1; // (measured: grouping tiles serialises the wavefront)
-        group = group < 1 ? 1 : (group > 64 ? 64 : group);
-    }
-    return group;
-}
-
 static bool ct_enabled()
 {
     static int on = -1;
@@ -2675,7 +2328,6 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
         const int    dm    = mul_inv_diag ? 2 : (unit ? 0 : 1);
         const int    lpr   = P->ct_wmax > 8 ? 8 : 1;
         const int    wl    = lpr == 1 ? (P->ct_wmax <= 3 ? 3 : (P->ct_wmax <= 4 ? 4 : 8)) : 4;
-        const int    group = ct_group();
         const CtDims dims  = {P->ct_dims[0], P->ct_dims[1], P->ct_dims[2], P->ct_dims[3]};
         if(P->ct_rec)
         {
@@ -2791,47 +2443,6 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
             }
             return RAMD_OK;
         }
-        const size_t lds   = ct_lds_bytes<T>(dims, group, lpr, wl);
-        const unsigned nwg = (unsigned)((P->ct_ntiles + group - 1) / group);
-// prefetch depth: 8 steps for short rows (12 small loads per step), 6 for the 8-lanes-per-row form (measured)
-#define TRSV_ST(DM, HO, LP, WLL, DP)                                                                                     \
-    hipLaunchKernelGGL((k_trsv_stream<T, DM, HO, LP, WLL, DP>), dim3(nwg), dim3(128), lds, b.cur, P->ct_ntiles, group, dims, \
-                       P->ct_tile_desc, P->ct_step_rec, P->ct_ext_idx, P->ecol, (const T*)P->eval, (const T*)P->diag,    \
-                       rhs_src, rhs_idx, (T*)P->w, out, P->order, st->counter, st->ticket)
-#define TRSV_ST_L(DM, HO)          \
-    do                             \
-    {                              \
-        if(lpr == 8)                  \
-            TRSV_ST(DM, HO, 8, 4, 6); \
-        else if(wl == 3)              \
-            TRSV_ST(DM, HO, 1, 3, 8); \
-        else if(wl == 4)              \
-            TRSV_ST(DM, HO, 1, 4, 8); \
-        else                          \
-            TRSV_ST(DM, HO, 1, 8, 6); \
-    } while(0)
-#define TRSV_ST_O(DM)             \
-    do                            \
-    {                             \
-        if(out)                   \
-            TRSV_ST_L(DM, true);  \
-        else                      \
-            TRSV_ST_L(DM, false); \
-    } while(0)
-        prof_begin(RAMD_PROF_TRSV, b.cur);
-        if(dm == 0)
-            TRSV_ST_O(0);
-        else if(dm == 1)
-            TRSV_ST_O(1);
-        else
-            TRSV_ST_O(2);
-        prof_end(RAMD_PROF_TRSV, b.cur);
-#undef TRSV_ST_O
-#undef TRSV_ST_L
-#undef TRSV_ST
-        st->ticket += nwg;
-        RAMD_HIP(hipGetLastError());
-        return RAMD_OK;
     }
     // tuning knobs (measured defaults; the env overrides are for tools/ experiments only)
     static int lds_pad = -1, sleep_cycles = -1;
