@@ -1064,6 +1064,98 @@ __global__ __launch_bounds__(kBlock) void k_ct_count_ext(int n, const int* __res
     }
 }
 
+// ---- external values of a tile, each ONCE.  Rows of FE matrices share their external columns (the 5 unknowns of a mesh
+// node are referenced by ~10 rows of the neighbouring tile): listed per reference, a 350-row tile of the shell surrogate
+// carried 1300 external values -- LDS, and through it the tile size, was set by the duplicates.  A reference r (numbered in
+// use order: position, then entry) OWNS its value if no earlier reference of the same tile names the same position; slots
+// are numbered over the owners in use order, every other reference takes the slot of its owner.
+template <bool LOWER>
+__global__ __launch_bounds__(kBlock) void k_ct_enum_refs(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                         const int* __restrict__ order, const int* __restrict__ pos,
+                                                         const int* __restrict__ tile_of, const int* __restrict__ ref_start,
+                                                         int* __restrict__ ref_pc, int* __restrict__ ref_tile)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gsz)
+    {
+        const int i  = order[p];
+        const int tl = tile_of[p];
+        int       r  = ref_start[p];
+        for(int j = rp[i]; j < rp[i + 1]; ++j)
+        {
+            const int col = ci[j];
+            if(LOWER ? (col < i) : (col > i))
+            {
+                const int pc = pos[col];
+                if(tile_of[pc] != tl)
+                {
+                    ref_pc[r]   = pc;
+                    ref_tile[r] = tl;
+                    ++r;
+                }
+            }
+        }
+    }
+}
+
+// sorted by (tile, position), references in use order inside a group: the first of a group owns the value
+__global__ __launch_bounds__(kBlock) void k_ct_ref_heads(int nr, const int* __restrict__ o1, const int* __restrict__ o2,
+                                                         const int* __restrict__ ref_pc, const int* __restrict__ ref_tile,
+                                                         int* __restrict__ head, int* __restrict__ is_owner)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q <= nr; q += gsz)
+    {
+        if(q == nr)
+        {
+            head[q]     = 0;
+            is_owner[q] = 0;
+            continue;
+        }
+        const int r = o1[o2[q]];
+        int       h = 1;
+        if(q > 0)
+        {
+            const int rb = o1[o2[q - 1]];
+            h            = (ref_pc[r] != ref_pc[rb] || ref_tile[r] != ref_tile[rb]) ? 1 : 0;
+        }
+        head[q]     = h;
+        is_owner[r] = h;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_ct_group_slots(int nr, const int* __restrict__ o1, const int* __restrict__ o2,
+                                                           const int* __restrict__ head, const int* __restrict__ hscan,
+                                                           const int* __restrict__ uniq, const int* __restrict__ ref_pc,
+                                                           int* __restrict__ group_slot, int* __restrict__ ext_idx)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nr; q += gsz)
+        if(head[q])
+        {
+            const int r          = o1[o2[q]];
+            group_slot[hscan[q]] = uniq[r];
+            ext_idx[uniq[r]]     = ref_pc[r];
+        }
+}
+
+__global__ __launch_bounds__(kBlock) void k_ct_ref_slots(int nr, const int* __restrict__ o1, const int* __restrict__ o2,
+                                                         const int* __restrict__ head, const int* __restrict__ hscan,
+                                                         const int* __restrict__ group_slot, int* __restrict__ slot_of_ref)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nr; q += gsz)
+        slot_of_ref[o1[o2[q]]] = group_slot[hscan[q] + head[q] - 1];
+}
+
+__global__ __launch_bounds__(kBlock) void k_ct_ext_start_unique(int n, const int* __restrict__ ref_start,
+                                                                const int* __restrict__ uniq, int* __restrict__ ext_start)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p <= n; p += gsz)
+        ext_start[p] = uniq[ref_start[p]];
+}
+
 // per tile: rows, steps, packed entries, external dependencies (sizes of the LDS areas)
 __global__ __launch_bounds__(kBlock) void k_ct_tile_sizes(int ntiles, const int* __restrict__ tile_step,
                                                           const int* __restrict__ step_pos, const int* __restrict__ step_ent,
@@ -1239,7 +1331,9 @@ __global__ __launch_bounds__(kBlock) void k_ct_fill_rec(int n, const int* __rest
                                                         const int* __restrict__ step_of, const int* __restrict__ tile_step,
                                                         const int* __restrict__ step_pos, const int* __restrict__ ext_start,
                                                         int* __restrict__ ext_idx, char* __restrict__ erec,
-                                                        int* __restrict__ nodiag, int reverse, int rows_max)
+                                                        int* __restrict__ nodiag, int reverse, int rows_max,
+                                                        const int* __restrict__ ref_start,
+                                                        const int* __restrict__ slot_of_ref)
 {
     using L         = CtRec<T, WL>;
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1254,6 +1348,17 @@ __global__ __launch_bounds__(kBlock) void k_ct_fill_rec(int n, const int* __rest
     const int tpos = step_pos[tile_step[tl]];
     int       e    = ext_start[p];
     const int e0   = ext_start[tpos];
+    // (de-duplicated external values: the j-th external reference of the row, in ascending column order, has the slot
+    //  slot_of_ref[ref_start[p] + j]; otherwise every reference has its own slot, numbered in storage order)
+    const int rbase = slot_of_ref ? ref_start[p] : 0;
+    int       nref  = 0;
+    for(int q = rp[i]; slot_of_ref && reverse && q < rp[i + 1]; ++q) // storage order is descending: count first
+    {
+        const int c = ci[q];
+        if((LOWER ? (c < i) : (c > i)) && tile_of[pos[c]] != tl)
+            ++nref;
+    }
+    int jref = 0;
     // byte `off` of the record of lane `sub` of this row: quad-major over the step's cnt * LPR lane records
     auto field = [&](int sub, int off) -> char* {
         return erec + ((size_t)L::NQ * LPR * p0 + (size_t)(off / 16) * (cnt * LPR) + (rank * LPR + sub)) * 16 + (off % 16);
@@ -1271,6 +1376,12 @@ __global__ __launch_bounds__(kBlock) void k_ct_fill_rec(int n, const int* __rest
             int       code;
             if(tile_of[pc] == tl)
                 code = 1 + (pc - tpos);
+            else if(slot_of_ref)
+            {
+                const int r = rbase + (reverse ? (nref - 1 - jref) : jref); // (references are numbered in ascending columns)
+                code        = 1 + rows_max + (slot_of_ref[r] - e0);
+                ++jref;
+            }
             else
             {
                 ext_idx[e] = pc;
@@ -1890,7 +2001,8 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
         return RAMD_ERR_UNSUPPORTED;
     int *level = nullptr, *lorder = nullptr, *start = nullptr, *lev_t = nullptr, *tkey = nullptr, *o1 = nullptr,
         *k2 = nullptr, *o2 = nullptr, *tflag = nullptr, *sflag = nullptr, *tscan = nullptr, *sscan = nullptr,
-        *tile_of = nullptr, *step_of = nullptr, *step_w = nullptr, *nodiag = nullptr, *cext = nullptr, *tsz = nullptr;
+        *tile_of = nullptr, *step_of = nullptr, *step_w = nullptr, *nodiag = nullptr, *cext = nullptr, *tsz = nullptr,
+        *ref_start = nullptr, *slot_of_ref = nullptr;
     unsigned long long* word = nullptr;
     int  nlev = 0;
     int  s    = RAMD_OK;
@@ -1914,6 +2026,8 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
         dev_free(&cext);
         dev_free(&tsz);
         dev_free(&word);
+        dev_free(&ref_start);
+        dev_free(&slot_of_ref);
     };
 #define CT_TRY(expr)     \
     do                   \
@@ -2126,7 +2240,79 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     int next = 0;
     CT_HIP(hipMemcpyAsync(&next, P->ct_ext_start + n, sizeof(int), hipMemcpyDeviceToHost, b.cur));
     CT_HIP(hipStreamSynchronize(b.cur));
-    CT_TRY(dev_alloc(&P->ct_ext_idx, next));
+    dev_free(&ref_start);
+    dev_free(&slot_of_ref);
+    static const int dedup_env = getenv("RAMD_TRSV_CT_DEDUP") ? atoi(getenv("RAMD_TRSV_CT_DEDUP")) : -1; // (0 / 1: force)
+    if(next > 0 && (dedup_env >= 0 ? dedup_env != 0 : next > n)) // (more references than rows: values are shared)
+    {
+        // every external value of a tile once (see k_ct_enum_refs)
+        const int nr = next;
+        int *ref_pc = nullptr, *ref_tile = nullptr, *o1r = nullptr, *o2r = nullptr, *k2r = nullptr, *head = nullptr,
+            *is_owner = nullptr, *hscan = nullptr, *uniq = nullptr, *group_slot = nullptr;
+        auto drop = [&]() {
+            dev_free(&ref_pc);
+            dev_free(&ref_tile);
+            dev_free(&o1r);
+            dev_free(&o2r);
+            dev_free(&k2r);
+            dev_free(&head);
+            dev_free(&is_owner);
+            dev_free(&hscan);
+            dev_free(&uniq);
+            dev_free(&group_slot);
+        };
+#define CT_TRY2(expr)    \
+    do                   \
+    {                    \
+        s = (expr);      \
+        if(s != RAMD_OK) \
+        {                \
+            drop();      \
+            CT_TRY(s);   \
+        }                \
+    } while(0)
+        ref_start        = P->ct_ext_start; // (the running count per reference stays: the fill kernel numbers references with it)
+        P->ct_ext_start  = nullptr;
+        const int gridr = ew_grid(nr + 1);
+        CT_TRY2(dev_alloc(&ref_pc, nr));
+        CT_TRY2(dev_alloc(&ref_tile, nr));
+        if(lower)
+            hipLaunchKernelGGL((k_ct_enum_refs<true>), dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, P->order, P->pos,
+                               tile_of, ref_start, ref_pc, ref_tile);
+        else
+            hipLaunchKernelGGL((k_ct_enum_refs<false>), dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, P->order, P->pos,
+                               tile_of, ref_start, ref_pc, ref_tile);
+        CT_TRY2(dev_alloc(&o1r, nr));
+        CT_TRY2(device_stable_sort_by_key(ref_pc, nr, n, o1r));
+        CT_TRY2(dev_alloc(&k2r, nr));
+        hipLaunchKernelGGL(k_ct_gather_int, dim3(gridr), dim3(kBlock), 0, b.cur, (int64_t)nr, ref_tile, o1r, k2r);
+        CT_TRY2(dev_alloc(&o2r, nr));
+        CT_TRY2(device_stable_sort_by_key(k2r, nr, ntiles, o2r));
+        CT_TRY2(dev_alloc(&head, (int64_t)nr + 1));
+        CT_TRY2(dev_alloc(&is_owner, (int64_t)nr + 1));
+        hipLaunchKernelGGL(k_ct_ref_heads, dim3(gridr), dim3(kBlock), 0, b.cur, nr, o1r, o2r, ref_pc, ref_tile, head, is_owner);
+        CT_TRY2(dev_alloc(&hscan, (int64_t)nr + 1));
+        CT_TRY2(dev_alloc(&uniq, (int64_t)nr + 1));
+        CT_TRY2(device_exclusive_scan(head, hscan, (int64_t)nr + 1));
+        CT_TRY2(device_exclusive_scan(is_owner, uniq, (int64_t)nr + 1));
+        CT_HIP(hipMemcpyAsync(&next, uniq + nr, sizeof(int), hipMemcpyDeviceToHost, b.cur));
+        CT_HIP(hipStreamSynchronize(b.cur));
+        CT_TRY2(dev_alloc(&group_slot, next));
+        CT_TRY2(dev_alloc(&P->ct_ext_idx, next));
+        CT_TRY2(dev_alloc(&slot_of_ref, nr));
+        hipLaunchKernelGGL(k_ct_group_slots, dim3(gridr), dim3(kBlock), 0, b.cur, nr, o1r, o2r, head, hscan, uniq, ref_pc,
+                           group_slot, P->ct_ext_idx);
+        hipLaunchKernelGGL(k_ct_ref_slots, dim3(gridr), dim3(kBlock), 0, b.cur, nr, o1r, o2r, head, hscan, group_slot,
+                           slot_of_ref);
+        CT_TRY2(dev_alloc(&P->ct_ext_start, (int64_t)n + 1));
+        hipLaunchKernelGGL(k_ct_ext_start_unique, dim3(grid), dim3(kBlock), 0, b.cur, n, ref_start, uniq, P->ct_ext_start);
+        if(verbose)
+            fprintf(stderr, "box-tile plan: %d external references -> %d distinct values\n", nr, next);
+        drop();
+#undef CT_TRY2
+    }
+    else
+        CT_TRY(dev_alloc(&P->ct_ext_idx, next));
     // the largest tile in every respect sizes the LDS areas
     CT_TRY(dev_alloc(&tsz, (int64_t)4 * ntiles));
     hipLaunchKernelGGL(k_ct_tile_sizes, dim3(ew_grid(ntiles)), dim3(kBlock), 0, b.cur, ntiles, P->ct_tile_step, P->ct_step_pos,
@@ -2138,15 +2324,20 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     {
         const CtDims d    = {P->ct_dims[0], P->ct_dims[1], P->ct_dims[2], P->ct_dims[3]};
         const size_t need = ct_rec_lds_bytes<T>(d);
-        if(need <= (size_t)lds_budget && 1 + d.rows + d.exts < 65536) // (16-bit column codes)
+        // the occupied part of the coordinate lattice is denser than its bounding box on skewed meshes: the largest tile
+        // may hold several times the rows asked for, and big tiles cost more hops' worth of waiting than they save
+        const bool too_many_rows = (int64_t)d.rows * 2 > (int64_t)rows_target * 3 && attempt < 3;
+        if(need <= (size_t)lds_budget && 1 + d.rows + d.exts < 65536 && !too_many_rows) // (16-bit column codes)
             fits = true;
         else
         {
-            // the occupied part of the coordinate lattice is denser than its bounding box (skewed meshes): smaller boxes
             if(verbose)
                 fprintf(stderr, "box-tile plan: box=(%d,%d,%d) needs %zu B of LDS per tile (max rows %d): shrinking\n", bs[0],
                         bs[1], bs[2], need, d.rows);
-            const int nrows_next = (int)((double)rows * (double)lds_budget / (double)need * 0.85);
+            double shrink = (double)lds_budget / (double)need * 0.85;
+            if(too_many_rows && (double)rows_target / (double)d.rows < shrink)
+                shrink = (double)rows_target / (double)d.rows;
+            const int nrows_next = (int)((double)rows * shrink);
             rows                 = nrows_next < rows - 1 ? nrows_next : rows - 1;
             if(rows < 16)
                 CT_GIVE_UP();
@@ -2185,7 +2376,8 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
 #define CT_FILL_REC(LOW, WLL, LP)                                                                                            \
     hipLaunchKernelGGL((k_ct_fill_rec<T, LOW, WLL, LP>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci,                  \
                        (const T*)m->val, P->order, P->pos, tile_of, step_of, P->ct_tile_step, P->ct_step_pos,               \
-                       P->ct_ext_start, P->ct_ext_idx, (char*)P->eval, nodiag, reverse ? 1 : 0, P->ct_dims[0])
+                       P->ct_ext_start, P->ct_ext_idx, (char*)P->eval, nodiag, reverse ? 1 : 0, P->ct_dims[0], ref_start, \
+                       slot_of_ref)
 #define CT_FILL_REC_W(LOW)           \
     do                               \
     {                                \
@@ -3637,8 +3829,12 @@ int ramd_mat_ilu0_factorize(ramd_mat_t m)
         return RAMD_ERR_UNSUPPORTED;
     if(m->nrow != m->ncol || m->nnz <= 0)
         RAMD_FAIL(RAMD_ERR_ARG, "ILU0Factorize: need a square, non-empty matrix (the reference asserts)");
-    static const bool wave_rows = getenv("RAMD_ILU0_WAVE") && atoi(getenv("RAMD_ILU0_WAVE")) != 0;
-    if(wave_rows) // experiment: one wave per row also for short rows
+    // one wave per row (every lane keeps an entry of the row, pivot rows are searched by bisection) pays for rows of FE
+    // size: measured on the shell surrogate (35 entries per row) 2.9 s -> 0.1 s per factorisation, on the 7-point operator
+    // 8 % slower than the thread-per-row sweep.  Same operations per entry in the same order: bit-identical factors.
+    static const int wave_env = getenv("RAMD_ILU0_WAVE") ? atoi(getenv("RAMD_ILU0_WAVE")) : -1; // (0 / 1: force, A/B experiments)
+    const bool       wave_rows = wave_env >= 0 ? wave_env != 0 : (m->nnz >= (int64_t)12 * m->nrow);
+    if(wave_rows)
         return (m->dtype == RAMD_F64) ? ilu0_long_rows_t<double>(m) : ilu0_long_rows_t<float>(m);
     return (m->dtype == RAMD_F64) ? ilu0_t<double>(m) : ilu0_t<float>(m);
 }
