@@ -1275,6 +1275,10 @@ constexpr int kCtFetchDepth = 4; // batches of 64 external values the fetch wave
 //     into registers (hand-issued loads, hand-counted vmcnt), step records through the scalar cache, a step itself only
 //     touches LDS (right-hand side and solution share a slot per row) and issues one store: the agent-scope publication of
 //     its values, which doubles as the position-order result the next stage reads.
+// Measured and dropped: a compact EXPORT array (only rows other tiles wait for are published, slots in position order, the
+// position-order result written per tile by the fetch wave; external traffic 25 -> ~10 bytes per row, sentinel fill three
+// times smaller) -- 2.66 -> 2.76 ms per triangle at 512^3, 5.8 -> 6.5 ms on the shell surrogate: the per-step rank
+// computation and the scratch stores of lanes without an exported row cost more than the bytes saved.
 // Column codes: 0 = padding (LDS slot 0 holds 0.0 and the padded value is 0: subtracts +0), 1 + q = row q of the tile,
 // 1 + rows_max + j = external value j of the tile.
 constexpr int kCtRing = 3; // tiles the ticket/fetch wave may be ahead of the compute wave (+1)
