@@ -250,7 +250,8 @@ __global__ __launch_bounds__(kBlock) void k_multi_axpy(int64_t n, T* __restrict_
 
 // one modified-Gram-Schmidt step fused with the NEXT projection's dot (gmres.cpp:480-486):
 //   w = w + (-h)*v ; s[slot_dot] = <u, w>   (u == nullptr: <w, w>)
-template <typename T, bool HAVE_U>
+// NTW: w streams (non-temporal load and store) -- vectors far beyond the caches, where keeping w's lines only evicts others
+template <typename T, bool HAVE_U, bool NTW>
 __global__ __launch_bounds__(kBlock) void k_mgs_step(int64_t n, T* __restrict__ w,
                                                      const T* __restrict__ v,
                                                      const T* __restrict__ u_vec, ReduceCtx ctx,
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(kBlock) void k_mgs_step(int64_t n, T* __restrict__ 
         P pw[kStreamU], pv[kStreamU], pu[kStreamU];
         RAMD_STREAM_EACH(np, i)
         {
-            pw[u] = reinterpret_cast<P*>(w)[i];
+            pw[u] = NTW ? nt_load(reinterpret_cast<const P*>(w) + i) : reinterpret_cast<P*>(w)[i];
             pv[u] = nt_load(reinterpret_cast<const P*>(v) + i);
             if(HAVE_U)
                 pu[u] = nt_load(reinterpret_cast<const P*>(u_vec) + i);
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(kBlock) void k_mgs_step(int64_t n, T* __restrict__ 
                 pk_elems<T>(pw[u])[k] = wn;
                 acc += (double)(HAVE_U ? pk_elems<T>(pu[u])[k] : wn) * (double)wn;
             }
-            reinterpret_cast<P*>(w)[i] = pw[u]; // w is read again by the next projection: regular store
+            st_pack<NTW>(reinterpret_cast<P*>(w) + i, pw[u]); // (w is read again by the next projection: cached while it fits)
         }
     }
     for(int64_t i = np * NP + gtid; i < n; i += gsz)
@@ -824,14 +825,23 @@ int ramd_fused_mgs_step(ramd_vec_t w, ramd_vec_t v, int slot_h, ramd_vec_t u, in
     Backend&  b    = backend();
     const int grid = grid_reduce(w->n, w->dtype);
     ReduceCtx ctx  = reduce_ctx();
+    // w streams when the working set of a projection (w, v, u) is far beyond the 256 MB last-level cache
+    static const int ntw_env = getenv("RAMD_MGS_NT") ? atoi(getenv("RAMD_MGS_NT")) : -1; // (0 / 1: force, A/B experiments)
+    const bool       ntw     = ntw_env >= 0 ? ntw_env != 0 : (int64_t)w->n * 8 > (int64_t)256 * 1024 * 1024;
 #define GO(T)                                                                                      \
     do                                                                                             \
     {                                                                                              \
-        if(u)                                                                                      \
-            hipLaunchKernelGGL((k_mgs_step<T, true>), dim3(grid), dim3(kBlock), 0, b.cur, w->n,    \
+        if(u && ntw)                                                                               \
+            hipLaunchKernelGGL((k_mgs_step<T, true, true>), dim3(grid), dim3(kBlock), 0, b.cur, w->n, \
                                (T*)w->d, (const T*)v->d, (const T*)u->d, ctx, slot_h, slot_dot);   \
+        else if(u)                                                                                 \
+            hipLaunchKernelGGL((k_mgs_step<T, true, false>), dim3(grid), dim3(kBlock), 0, b.cur, w->n, \
+                               (T*)w->d, (const T*)v->d, (const T*)u->d, ctx, slot_h, slot_dot);   \
+        else if(ntw)                                                                               \
+            hipLaunchKernelGGL((k_mgs_step<T, false, true>), dim3(grid), dim3(kBlock), 0, b.cur, w->n, \
+                               (T*)w->d, (const T*)v->d, (const T*)nullptr, ctx, slot_h, slot_dot); \
         else                                                                                       \
-            hipLaunchKernelGGL((k_mgs_step<T, false>), dim3(grid), dim3(kBlock), 0, b.cur, w->n,   \
+            hipLaunchKernelGGL((k_mgs_step<T, false, false>), dim3(grid), dim3(kBlock), 0, b.cur, w->n, \
                                (T*)w->d, (const T*)v->d, (const T*)nullptr, ctx, slot_h, slot_dot); \
     } while(0)
     prof_begin(RAMD_PROF_VEC, b.cur);
