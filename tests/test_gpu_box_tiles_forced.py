@@ -36,3 +36,57 @@ def test_parity_suite_with_box_tiles_forced(dedup):
     assert "box-tile plan (lower)" in p.stdout and "box-tile plan (upper)" in p.stdout, tail
     if dedup == "1":
         assert "distinct values" in p.stdout, tail
+
+
+_CROSS = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+import rocalution_amd as ra
+from rocalution_amd import generators as gen
+ra.init_rocalution()
+out = {}
+for tag, (rp, ci, va) in (("poisson20", gen.poisson7(20)), ("shell16", gen.shell_surrogate(16, 16))):
+    n = len(rp) - 1
+    for dt in (np.float64, np.float32):
+        A = ra.LocalMatrix(dt); A.SetDataPtrCSR(rp, ci, va.astype(dt))
+        A.ILU0Factorize(); A.LUAnalyse()
+        b = np.random.default_rng(7).uniform(-1, 1, n).astype(dt)
+        y = ra.LocalVector(dt); y.Allocate("", n)
+        for rep in range(3):
+            A.LUSolve(ra.LocalVector(dt, data=b), y)
+        out["%%s_%%s_lu" %% (tag, np.dtype(dt).name)] = y.numpy().copy()
+        B = ra.LocalMatrix(dt); B.SetDataPtrCSR(rp, ci, va.astype(dt))
+        B.LAnalyse(False); B.LSolve(ra.LocalVector(dt, data=b), y)
+        out["%%s_%%s_l" %% (tag, np.dtype(dt).name)] = y.numpy().copy()
+        B.UAnalyse(False); B.USolve(ra.LocalVector(dt, data=b), y)
+        out["%%s_%%s_u" %% (tag, np.dtype(dt).name)] = y.numpy().copy()
+np.savez(sys.argv[1], **out)
+"""
+
+
+@pytest.mark.gpu
+def test_fp32_and_fp64_box_tiles_equal_the_level_scheduled_kernel(tmp_path):
+    """Both kernels perform the host loop's operations per row in the same order (host_matrix_csr.cpp:1163-1221), so their
+    results are bit-identical -- in fp32 as in fp64, one lane per row (7-point operator) and eight (shell surrogate).  The
+    fp32 instantiations have no golden of their own; this pins them to the form the goldens pin."""
+    import numpy as np
+    script = tmp_path / "cross.py"
+    script.write_text(_CROSS % {"root": ROOT})
+    res = {}
+    for tag, env in (("level", {"RAMD_TRSV_CT": "0"}),
+                     ("tiles", {"RAMD_TRSV_CT_MINROWS": "0", "RAMD_TRSV_CT_MINLEN": "0", "RAMD_TRSV_CT_DEDUP": "1",
+                                "RAMD_TRSV_CT_VERBOSE": "1"})):
+        out = str(tmp_path / (tag + ".npz"))
+        p = subprocess.run([sys.executable, str(script), out], cwd=ROOT, env=dict(os.environ, **env), stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout[-3000:]
+        if tag == "tiles":
+            assert "box-tile plan (lower)" in p.stdout, p.stdout[-3000:]
+        else:
+            assert "box-tile plan" not in p.stdout
+        res[tag] = dict(np.load(out))
+    assert sorted(res["level"]) == sorted(res["tiles"]) and len(res["level"]) == 12
+    for k in res["level"]:
+        a, b = res["level"][k], res["tiles"][k]
+        assert a.dtype == b.dtype and np.isfinite(a).all(), k
+        assert np.array_equal(a, b), (k, float(np.abs(a - b).max()))
