@@ -510,6 +510,7 @@ struct TriState
     // rows ordered by (lower-dependency level, row), computed once per pattern: ILU(0) runs in this order
     // and LAnalyse / LUAnalyse take it over
     int* l_order_cache = nullptr;
+    int* l_level_cache = nullptr; // per-row levels of the same sweep (the box-tile plan of L takes them over)
     int  l_nlev_cache  = 0;
     // LLSolve (incomplete Cholesky): forward plan on L, backward plan on L^T, both scaled by an inverse diagonal
     TriPlan     LLf, LLb;
@@ -574,6 +575,7 @@ void tri_release(ramd_mat_s* m)
     dev_free(&st->counter);
     dev_free(&st->stream_counter);
     dev_free(&st->l_order_cache);
+    dev_free(&st->l_level_cache);
     st->LLf.release();
     st->LLb.release();
     dev_free(&st->ll_rhs_idx);
@@ -699,6 +701,8 @@ static int build_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bool 
         {
             if(lower && st->l_order_cache) // the level order of ILU0Factorize is not needed by this form
                 dev_free(&st->l_order_cache);
+            if(lower)
+                dev_free(&st->l_level_cache);
             return RAMD_OK;
         }
         if(sc != RAMD_ERR_UNSUPPORTED)
@@ -877,9 +881,11 @@ __device__ __forceinline__ int ct_c2(unsigned long long w)
 template <bool LOWER>
 __global__ __launch_bounds__(kBlock) void k_ct_coords(int n, const int* __restrict__ rp, const int* __restrict__ ci,
                                                       const int* __restrict__ escan, unsigned long long* word,
-                                                      int* __restrict__ ext, unsigned* counter, unsigned base)
+                                                      int* __restrict__ ext, unsigned* counter, unsigned base,
+                                                      const int* __restrict__ block_order)
 {
-    const unsigned blk  = take_ticket(counter, base);
+    const unsigned tick = take_ticket(counter, base);
+    const unsigned blk  = block_order ? (unsigned)block_order[tick] : tick; // hyperplane order of the blocks (blocksched.hip)
     const int64_t  t    = (int64_t)blk * kBlock + threadIdx.x;
     const bool     live = t < n;
     const int      i    = live ? (LOWER ? (int)t : (int)(n - 1 - t)) : 0;
@@ -2083,13 +2089,24 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     CT_TRY(dev_alloc(&cext, 4));
     CT_HIP(hipMemsetAsync(word, 0, sizeof(unsigned long long) * (size_t)n, b.cur));
     CT_HIP(hipMemsetAsync(cext, 0, sizeof(int) * 4, b.cur));
-    if(lower)
-        hipLaunchKernelGGL((k_ct_coords<true>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, start, word, cext,
-                           st->counter, st->ticket);
-    else
-        hipLaunchKernelGGL((k_ct_coords<false>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, start, word, cext,
-                           st->counter, st->ticket);
-    st->ticket += nb;
+    {
+        // same block graph as the level sweep: blocks in hyperplane order fill the machine (natural order: only the ~2048
+        // resident blocks -- two grid planes at 512^3 -- are in flight, the lines of a plane a serial chain inside that window)
+        int* border = nullptr;
+        (void)block_schedule(m, lower, &border); // nullptr: natural order
+        if(lower)
+            hipLaunchKernelGGL((k_ct_coords<true>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, start, word, cext,
+                               st->counter, st->ticket, border);
+        else
+            hipLaunchKernelGGL((k_ct_coords<false>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, start, word, cext,
+                               st->counter, st->ticket, border);
+        st->ticket += nb;
+        if(border)
+        {
+            (void)hipStreamSynchronize(b.cur);
+            dev_free(&border);
+        }
+    }
     int hext[3] = {0, 0, 0};
     CT_HIP(hipMemcpyAsync(hext, cext, sizeof(int) * 3, hipMemcpyDeviceToHost, b.cur));
     CT_HIP(hipStreamSynchronize(b.cur));
@@ -2127,8 +2144,17 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     int       ntiles = 0, nsteps = 0, total = 0;
     int64_t keymax = 0;
     // levels (natural row index): once
-    CT_TRY(level_order(m, st, lower, &lorder, &nlev, &level));
-    dev_free(&lorder);
+    if(lower && st->l_level_cache) // the sweep ILU0Factorize ran on the same pattern
+    {
+        level             = st->l_level_cache;
+        st->l_level_cache = nullptr;
+        nlev              = st->l_nlev_cache;
+    }
+    else
+    {
+        CT_TRY(level_order(m, st, lower, &lorder, &nlev, &level));
+        dev_free(&lorder);
+    }
     bool fits = false;
     for(int attempt = 0; attempt < 5 && !fits; ++attempt)
     {
@@ -2689,7 +2715,8 @@ static int ilu0_t(ramd_mat_s* m)
     const unsigned nb = nblocks_of(n);
     if(!st->l_order_cache)
     {
-        int s = level_order(m, st, true, &st->l_order_cache, &st->l_nlev_cache);
+        dev_free(&st->l_level_cache);
+        int s = level_order(m, st, true, &st->l_order_cache, &st->l_nlev_cache, &st->l_level_cache);
         if(s != RAMD_OK)
         {
             dev_free(&done);
@@ -2998,7 +3025,9 @@ static int ilu0_long_rows_t(ramd_mat_s* m)
     int*      done = len; // reused as the flags
     TriState* st   = nullptr;
     if((s = tri_get(m, &st)) != RAMD_OK || (!m->diag_pos && (s = dev_alloc(&m->diag_pos, n)) != RAMD_OK)
-       || (!st->l_order_cache && (s = level_order(m, st, true, &st->l_order_cache, &st->l_nlev_cache)) != RAMD_OK))
+       || (!st->l_order_cache
+           && (dev_free(&st->l_level_cache),
+               (s = level_order(m, st, true, &st->l_order_cache, &st->l_nlev_cache, &st->l_level_cache)) != RAMD_OK)))
     {
         dev_free(&done);
         return s;
