@@ -90,3 +90,71 @@ def test_fp32_and_fp64_box_tiles_equal_the_level_scheduled_kernel(tmp_path):
         a, b = res["level"][k], res["tiles"][k]
         assert a.dtype == b.dtype and np.isfinite(a).all(), k
         assert np.array_equal(a, b), (k, float(np.abs(a - b).max()))
+
+
+_RAGGED = r"""
+import sys, numpy as np, scipy.sparse as sp
+sys.path.insert(0, %(root)r)
+import rocalution_amd as ra
+from oracle import oracle
+ra.init_rocalution()
+rng = np.random.default_rng(11)
+
+
+def banded(n, wmax, reach):
+    # symmetric pattern, row i linked to i-1 (chains) and to a random number of rows within `reach`; diagonally dominant
+    rows, cols = [], []
+    for i in range(1, n):
+        k = int(rng.integers(0, wmax))
+        js = set([i - 1]) | set(int(j) for j in rng.integers(max(0, i - reach), i, size=k))
+        for j in js:
+            rows += [i, j]; cols += [j, i]
+    v = rng.uniform(-1, -0.05, len(rows))
+    A = sp.coo_matrix((v, (rows, cols)), shape=(n, n)).tocsr(); A.sum_duplicates()
+    A = (A + A.T) * 0.5
+    A = A + sp.diags(np.asarray(abs(A).sum(axis=1)).ravel() + 1.0)
+    A = A.tocsr(); A.sort_indices()
+    return A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+
+
+checked = 0
+for n, wmax, reach in ((1, 1, 1), (2, 1, 1), (65, 2, 8), (777, 3, 40), (3000, 8, 100), (3000, 20, 64), (2500, 31, 200),
+                       (1500, 60, 300)):
+    rp, ci, va = banded(n, wmax, reach)
+    low = max(int(((ci[rp[i]:rp[i + 1]]) < i).sum()) for i in range(n))
+    A = ra.LocalMatrix(); A.SetDataPtrCSR(rp, ci, va)
+    A.ILU0Factorize()
+    lu = oracle.ilu0(rp, ci, va)
+    assert np.array_equal(A.CopyToCSR()[2], lu), ("ilu0", n, wmax)
+    A.LUAnalyse()
+    y = ra.LocalVector(); y.Allocate("", n)
+    for rep in range(2):
+        b = rng.uniform(-1, 1, n)
+        A.LUSolve(ra.LocalVector(data=b), y)
+        assert np.array_equal(y.numpy(), oracle.lusolve(rp, ci, lu, b)), ("lusolve", n, wmax, low)
+    B = ra.LocalMatrix(); B.SetDataPtrCSR(rp, ci, va)
+    B.LAnalyse(False); B.LSolve(ra.LocalVector(data=b), y)
+    assert np.array_equal(y.numpy(), oracle.lsolve(rp, ci, va, b, False)), ("lsolve", n, wmax, low)
+    B.UAnalyse(False); B.USolve(ra.LocalVector(data=b), y)
+    assert np.array_equal(y.numpy(), oracle.usolve(rp, ci, va, b, False)), ("usolve", n, wmax, low)
+    print("ok n=%%d longest lower row %%d" %% (n, low), flush=True)
+    checked += 1
+print("checked", checked)
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dedup", ["0", "1"])
+def test_ragged_rows_from_1_to_60_entries_bit_exact(tmp_path, dedup):
+    """Random banded systems with rows of 1 .. 60 strictly-triangular entries: one lane per row (<= 8 entries), eight lanes
+    per row (<= 32), and the level-scheduled fallback beyond; n = 1, 2, a partial wave, several tiles.  ILU(0) factors,
+    LUSolve, LSolve and USolve against the oracle (host_matrix_csr.cpp:1163-1221, :1344-1466, :2096-2171), bit for bit."""
+    script = tmp_path / "ragged.py"
+    script.write_text(_RAGGED % {"root": ROOT})
+    env = dict(os.environ, RAMD_TRSV_CT_MINROWS="0", RAMD_TRSV_CT_MINLEN="0", RAMD_TRSV_CT_DEDUP=dedup,
+               RAMD_TRSV_CT_VERBOSE="1")
+    p = subprocess.run([sys.executable, str(script)], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-4000:]
+    assert "checked 8" in p.stdout, p.stdout[-4000:]
+    assert "wmax=" in p.stdout and "box-tile plan (lower)" in p.stdout, p.stdout[-2000:]
