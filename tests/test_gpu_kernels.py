@@ -460,9 +460,11 @@ def test_extract_submatrix_vs_oracle(ra, oracle):
         eq(rp, orp); eq(ci, oci); eq(va, ova)
 
 
-@pytest.mark.parametrize("N", [24, 40])
+@pytest.mark.parametrize("N", [24, 40, 168])
 def test_ilu_lusolve_poisson_vs_oracle(ra, oracle, N):
-    """deep dependency DAG (3N-2 levels), exercised repeatedly to shake out stale hand-offs"""
+    """deep dependency DAG (3N-2 levels), exercised repeatedly to shake out stale hand-offs.  N = 168: 4.7 M rows = 9261
+    box tiles on ~2000 persistent workgroups, so every workgroup walks several tiles (LDS ring reuse, per-tile write-back
+    of the natural-order output, all 16 ticket streams) -- still bit for bit"""
     from rocalution_amd import generators as gen
     rp, ci, va = gen.poisson7(N)
     n = len(rp) - 1
