@@ -124,6 +124,165 @@ public:
         return this->global_nrow_ > 0 && this->local_nrow_ >= 0 && this->recvs_ == this->sends_
                && (int)this->boundary_index_.size() == this->GetNumSenders();
     }
+    // File IO of the communication pattern (parallel_manager.cpp:441-743): a head file naming one "<file>.rank.<r>" file
+    // per rank, each a list of "#KEY" sections.  Files written here are read by the reference and vice versa; every rank
+    // writes / reads its own file, rank 0 also writes the head file.
+    void WriteFileASCII(const std::string& filename) const
+    {
+        RAMD_EXPECT(this->Status());
+        if(this->rank_ == 0)
+        {
+            std::ofstream head(filename.c_str());
+            if(!head.is_open())
+                {
+                say("cannot open ParallelManager file [write]: " + filename);
+                RAMD_DIE();
+            }
+            for(int r = 0; r < this->num_procs_; ++r)
+                head << filename << ".rank." << r << "\n";
+        }
+        const std::string name = filename + ".rank." + std::to_string(this->rank_);
+        std::ofstream     out(name.c_str());
+        if(!out.is_open())
+            {
+                say("cannot open ParallelManager file [write]: " + name);
+                RAMD_DIE();
+            }
+        static const char* const bar = "%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%";
+        const int nrecv = (int)this->recvs_.size(), nsend = (int)this->sends_.size();
+        out << bar << "\n%% ROCALUTION MPI ParallelManager output %%\n" << bar << "\n";
+        out << "#RANK\n" << this->rank_ << "\n" << bar << "\n";
+        out << "#GLOBAL_NROW\n" << this->global_nrow_ << "\n" << bar << "\n";
+        out << "#GLOBAL_NCOL\n" << this->global_ncol_ << "\n" << bar << "\n";
+        out << "#LOCAL_NROW\n" << this->local_nrow_ << "\n" << bar << "\n";
+        out << "#LOCAL_NCOL\n" << this->local_ncol_ << "\n" << bar << "\n";
+        out << "#BOUNDARY_SIZE\n" << this->boundary_index_.size() << "\n" << bar << "\n";
+        out << "#NUMBER_OF_RECEIVERS\n" << nrecv << "\n" << bar << "\n";
+        out << "#NUMBER_OF_SENDERS\n" << nsend << "\n" << bar << "\n";
+        out << "#RECEIVERS_RANK\n";
+        for(int i = 0; i < nrecv; ++i)
+            out << this->recvs_[(size_t)i] << "\n";
+        out << bar << "\n#SENDERS_RANK\n";
+        for(int i = 0; i < nsend; ++i)
+            out << this->sends_[(size_t)i] << "\n";
+        out << bar << "\n#RECEIVERS_INDEX_OFFSET\n";
+        for(size_t i = 0; i < this->recv_offset_.size(); ++i)
+            out << this->recv_offset_[i] << "\n";
+        out << bar << "\n#SENDERS_INDEX_OFFSET\n";
+        for(size_t i = 0; i < this->send_offset_.size(); ++i)
+            out << this->send_offset_[i] << "\n";
+        out << bar << "\n#BOUNDARY_INDEX\n";
+        for(size_t i = 0; i < this->boundary_index_.size(); ++i)
+            out << this->boundary_index_[i] << "\n";
+        if(!out.good())
+            {
+                say("write error on ParallelManager file: " + name);
+                RAMD_DIE();
+            }
+    }
+    // needs the communicator (rank) first; the sub-files are looked up in the directory of the head file
+    void ReadFileASCII(const std::string& filename)
+    {
+        RAMD_EXPECT(this->comm_ != NULL);
+        std::ifstream head(filename.c_str());
+        if(!head.is_open())
+            {
+                say("cannot open ParallelManager file [read]: " + filename);
+                RAMD_DIE();
+            }
+        std::string name;
+        for(int r = 0; r <= this->rank_; ++r)
+            if(!std::getline(head, name))
+                {
+                say("ParallelManager head file names fewer ranks than this communicator has: " + filename);
+                RAMD_DIE();
+            }
+        std::string trimmed;
+        for(size_t i = 0; i < name.size(); ++i)
+            if(!std::isspace((unsigned char)name[i]))
+                trimmed += name[i];
+        // (the reference prepends the head file's directory to the name as it stands in the head file)
+        const size_t cut = filename.find_last_of("\\/");
+        name             = (cut == std::string::npos ? std::string() : filename.substr(0, cut + 1)) + trimmed;
+        std::ifstream in(name.c_str());
+        if(!in.is_open())
+        {
+            in.open(trimmed.c_str()); // a head file that already carries the path (written with a path, read from elsewhere)
+            if(!in.is_open())
+                {
+                say("cannot open ParallelManager file [read]: " + name);
+                RAMD_DIE();
+            }
+        }
+        this->Clear();
+        int     rank = -1, nrecv = -1, nsend = -1;
+        int64_t bsize = -1;
+        std::string line;
+        auto ints = [&](std::vector<int>& v, int64_t count) {
+            v.resize((size_t)(count > 0 ? count : 0));
+            for(size_t i = 0; i < v.size(); ++i)
+                in >> v[i];
+        };
+        auto longs = [&](std::vector<int64_t>& v, int64_t count) {
+            v.resize((size_t)(count > 0 ? count : 0));
+            for(size_t i = 0; i < v.size(); ++i)
+                in >> v[i];
+        };
+        while(std::getline(in, line))
+        {
+            if(line.find("#RANK") != std::string::npos)
+                in >> rank;
+            else if(line.find("#GLOBAL_SIZE") != std::string::npos)
+            {
+                in >> this->global_nrow_;
+                this->global_ncol_ = this->global_nrow_;
+            }
+            else if(line.find("#GLOBAL_NROW") != std::string::npos)
+                in >> this->global_nrow_;
+            else if(line.find("#GLOBAL_NCOL") != std::string::npos)
+                in >> this->global_ncol_;
+            else if(line.find("#LOCAL_SIZE") != std::string::npos)
+            {
+                in >> this->local_nrow_;
+                this->local_ncol_ = this->local_nrow_;
+            }
+            else if(line.find("#LOCAL_NROW") != std::string::npos)
+                in >> this->local_nrow_;
+            else if(line.find("#LOCAL_NCOL") != std::string::npos)
+                in >> this->local_ncol_;
+            else if(line.find("#BOUNDARY_SIZE") != std::string::npos)
+                in >> bsize;
+            else if(line.find("#NUMBER_OF_RECEIVERS") != std::string::npos)
+                in >> nrecv;
+            else if(line.find("#NUMBER_OF_SENDERS") != std::string::npos)
+                in >> nsend;
+            else if(line.find("#RECEIVERS_RANK") != std::string::npos)
+                ints(this->recvs_, nrecv);
+            else if(line.find("#SENDERS_RANK") != std::string::npos)
+                ints(this->sends_, nsend);
+            else if(line.find("#RECEIVERS_INDEX_OFFSET") != std::string::npos)
+                longs(this->recv_offset_, (int64_t)nrecv + 1);
+            else if(line.find("#SENDERS_INDEX_OFFSET") != std::string::npos)
+                longs(this->send_offset_, (int64_t)nsend + 1);
+            else if(line.find("#BOUNDARY_INDEX") != std::string::npos)
+                ints(this->boundary_index_, bsize);
+            if(in.fail() && !in.eof())
+                {
+                say("malformed ParallelManager file: " + name);
+                RAMD_DIE();
+            }
+        }
+        if(rank != this->rank_)
+        {
+            say("ParallelManager file " + name + " belongs to another rank");
+            RAMD_DIE();
+        }
+        if(nrecv < 0 || nsend < 0 || bsize < 0 || !this->Status())
+            {
+                say("incomplete ParallelManager file: " + name);
+                RAMD_DIE();
+            }
+    }
     const std::vector<int>& peers(void) const
     {
         return this->sends_;

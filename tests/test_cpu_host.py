@@ -115,6 +115,12 @@ def test_reference_style_driver_compiles_with_plain_gxx():
         subprocess.check_call(["g++", "-std=c++14", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), src])
 
 
+def test_parallel_manager_io_driver_compiles_with_plain_gxx():
+    """tests/drivers/pm_io_driver.cpp (run by the GPU suite: a communicator needs an initialised device) is host C++"""
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "drivers", "pm_io_driver.cpp")])
+
+
 @pytest.mark.parametrize("sample", ["krylov_driver.cpp", "multigrid_driver.cpp"])
 def test_sample_drivers_compile_with_plain_gxx(sample):
     """samples/*.cpp (run end to end by the GPU suite) are plain host C++ on include/rocalution: no hipcc, no device"""
