@@ -1287,7 +1287,14 @@ constexpr int kCtFetchDepth = 4; // batches of 64 external values the fetch wave
 // computation and the scratch stores of lanes without an exported row cost more than the bytes saved.
 // Column codes: 0 = padding (LDS slot 0 holds 0.0 and the padded value is 0: subtracts +0), 1 + q = row q of the tile,
 // 1 + rows_max + j = external value j of the tile.
-constexpr int kCtRing = 3; // tiles the ticket/fetch wave may be ahead of the compute wave (+1)
+// (compile-time tuning hooks; measured at 512^3: prefetch depth 6 / 8 equal, 12 slower (registers); ring 2 / 3 equal, 4 slower (LDS))
+#ifndef RAMD_CT_RING
+#define RAMD_CT_RING 3
+#endif
+#ifndef RAMD_CT_DEPTH3
+#define RAMD_CT_DEPTH3 8
+#endif
+constexpr int kCtRing = RAMD_CT_RING; // tiles the ticket/fetch wave may be ahead of the compute wave (+1)
 
 template <typename T, int WL>
 struct CtRec
@@ -2615,7 +2622,7 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
         if(lpr == 8)                    \
             TRSV_RC(DM, HO, 8, 4, 8);   \
         else if(wl == 3)                \
-            TRSV_RC(DM, HO, 1, 3, 8);   \
+            TRSV_RC(DM, HO, 1, 3, RAMD_CT_DEPTH3);   \
         else if(wl == 4)                \
             TRSV_RC(DM, HO, 1, 4, 8);   \
         else                            \
