@@ -481,6 +481,31 @@ def test_ilu_lusolve_poisson_vs_oracle(ra, oracle, N):
         eq(y.numpy(), oracle.lusolve(rp, ci, lu, b))
 
 
+def test_ilu_lusolve_27_point_stencil_vs_oracle(ra, oracle):
+    """13 strictly-lower entries per row: the eight-lanes-per-row form of the box-tile solve on cubic tiles (the shell
+    surrogate exercises it on 2-D parallelograms), ILU(0) by the wave-per-row sweep -- factors and solutions bit for bit"""
+    import scipy.sparse as sp
+    N = 36
+    t = sp.diags([np.ones(N - 1), np.ones(N), np.ones(N - 1)], [-1, 0, 1])
+    P = sp.kron(sp.kron(t, t), t).tocsr()  # 27-point pattern
+    P.data[:] = -1.0
+    A = (P + sp.diags(np.full(N ** 3, 28.0))).tocsr()  # diagonal 27 (= 28 - 1): strictly dominant
+    A.sort_indices()
+    rp, ci, va = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+    n = N ** 3
+    M = ra.LocalMatrix(); M.SetDataPtrCSR(rp, ci, va)
+    M.ILU0Factorize()
+    lu = oracle.ilu0(rp, ci, va)
+    eq(M.CopyToCSR()[2], lu)
+    M.LUAnalyse()
+    rng = np.random.default_rng(27)
+    y = ra.LocalVector(); y.Allocate("", n)
+    for rep in range(3):
+        b = rng.uniform(-1, 1, n)
+        M.LUSolve(ra.LocalVector(data=b), y)
+        eq(y.numpy(), oracle.lusolve(rp, ci, lu, b))
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_convert_back_to_csr_and_clone(ra, name):
     """ELL/HYB/COO -> CSR (host_conversion.cpp:690-960) restores the CSR arrays (golden matrices have

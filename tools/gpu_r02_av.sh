@@ -2,4 +2,4 @@
 mkdir -p gpurun_out/r02av
 cd /root/repo
 export TMPDIR=/tmp
-timeout 1200 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "ilu_lusolve_poisson" > gpurun_out/r02av/t.log 2>&1; echo "rc=$?"; tail -4 gpurun_out/r02av/t.log
+RAMD_TRSV_CT_VERBOSE=1 timeout 1200 python -m pytest tests/test_gpu_kernels.py -x -q -s -m gpu -k "27_point" > gpurun_out/r02av/t.log 2>&1; echo "rc=$?"; grep "box-tile plan (" gpurun_out/r02av/t.log | tail -2 | cut -c1-260; tail -3 gpurun_out/r02av/t.log
