@@ -1291,6 +1291,9 @@ constexpr int kCtFetchDepth = 4; // batches of 64 external values the fetch wave
 #ifndef RAMD_CT_RING
 #define RAMD_CT_RING 3
 #endif
+#ifndef RAMD_CT_PRIO
+#define RAMD_CT_PRIO 3
+#endif
 #ifndef RAMD_CT_DEPTH3
 #define RAMD_CT_DEPTH3 8
 #endif
@@ -1732,6 +1735,8 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
         }
     }
     // ---------------- compute wave: one stream of steps over all the tiles this workgroup gets
+    // (its steps are the critical path of the solve: issue priority over the polling waves that share the SIMD)
+    __builtin_amdgcn_s_setprio(RAMD_CT_PRIO);
     const int lane = tid;
     // iterator over the steps: `cur` is the record of the next step to fetch (loaded one fetch ahead through the scalar cache)
     unsigned long long pc_t0 = prof ? __builtin_amdgcn_s_memtime() : 0, pc_ext = 0, pc_post = 0, pc_steps = 0, pc_dups = 0;
