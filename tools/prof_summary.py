@@ -40,7 +40,7 @@ for name in WHAT:
         if not os.path.exists(db):
             continue
         rows = q(db, "select kernel_name,counter_name,count(*),avg(value),min(value),max(value) from counters_collection "
-                     "group by kernel_name,counter_name order by avg(value) desc limit 16")
+                     "group by kernel_name,counter_name order by avg(value) desc limit 48")
         with open(os.path.join(out, "%s_pmc_%s_%s.txt" % (tag, ctr, name)), "w") as f:
             f.write("# rocprofv3 --pmc %s --kernel-trace -- %s   (one counter per pass)\n" % (ctr, WHAT[name].split(" (")[0].replace("--steps 100 --warmup 10", "--steps 20 --warmup 2").replace("--steps 60 --warmup 10", "--steps 20 --warmup 2")))
             f.write("# KiB per dispatch as reported.  gfx950: FETCH_SIZE counts 64 B per 128-B request for 16-byte-per-lane streaming\n"
