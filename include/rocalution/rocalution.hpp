@@ -9,3 +9,4 @@
 #include "io.hpp"
 #include "solvers.hpp"
 #include "global.hpp"
+#include "distribute.hpp"

@@ -194,3 +194,16 @@ def test_parallel_manager_file_io(tmp_path):
     base = str(d / "pattern.pm")
     assert open(base).read().splitlines() == [base + ".rank.%d" % k for k in range(3)]
     assert open(base + ".rank.1").read() == _PM_RANK1
+
+
+def test_distribute_matrix_one_rank_end_to_end(tmp_path):
+    """distribute_matrix (include/rocalution/distribute.hpp) in the call sequence of the reference's cg_mpi sample, through a
+    real RCCL communicator of size 1: same iteration count and residual as the LocalMatrix solve"""
+    import subprocess
+    exe = str(tmp_path / "distribute_driver")
+    libdir = os.path.join(ROOT, "rocalution_amd")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "drivers", "distribute_driver.cpp"), "-o", exe, "-L" + libdir,
+                           "-lrocalution_amd", "-Wl,-rpath," + libdir])
+    r = subprocess.run([exe, "20"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0 and b"distribute_driver ok" in r.stdout, r.stdout.decode()[-2000:]
