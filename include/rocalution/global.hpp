@@ -330,15 +330,15 @@ public:
     }
     bool is_accel_(void) const
     {
-        return this->vector_interior_.is_accel_();
+        return this->m_owned.is_accel_();
     }
     void MoveToAccelerator(void)
     {
-        this->vector_interior_.MoveToAccelerator();
+        this->m_owned.MoveToAccelerator();
     }
     void MoveToHost(void)
     {
-        this->vector_interior_.MoveToHost();
+        this->m_owned.MoveToHost();
     }
     template <class Obj>
     void CloneBackend(const Obj& src) // also adopts the parallel manager (base_rocalution.cpp:109)
@@ -359,27 +359,27 @@ public:
             local = (this->pm_->GetGlobalNrow() == size) ? this->pm_->GetLocalNrow()
                                                          : this->pm_->GetLocalNcol();
         }
-        this->vector_interior_.Allocate("Interior of " + name, local);
+        this->m_owned.Allocate("Interior of " + name, local);
     }
     void Clear(void)
     {
-        this->vector_interior_.Clear();
+        this->m_owned.Clear();
     }
     int64_t GetSize(void) const
     {
-        return this->pm_ ? this->pm_->GetGlobalNrow() : this->vector_interior_.GetSize();
+        return this->pm_ ? this->pm_->GetGlobalNrow() : this->m_owned.GetSize();
     }
     int64_t GetLocalSize(void) const
     {
-        return this->vector_interior_.GetSize();
+        return this->m_owned.GetSize();
     }
     LocalVector<ValueType>& GetInterior(void)
     {
-        return this->vector_interior_;
+        return this->m_owned;
     }
     const LocalVector<ValueType>& GetInterior(void) const
     {
-        return this->vector_interior_;
+        return this->m_owned;
     }
     void Info(void) const
     {
@@ -387,72 +387,72 @@ public:
     }
     void Zeros(void)
     {
-        this->vector_interior_.Zeros();
+        this->m_owned.Zeros();
     }
     void Ones(void)
     {
-        this->vector_interior_.Ones();
+        this->m_owned.Ones();
     }
     void SetValues(ValueType val)
     {
-        this->vector_interior_.SetValues(val);
+        this->m_owned.SetValues(val);
     }
     // global_vector.cpp:317-330: every rank fills its interior part from the same seed
     void SetRandomUniform(unsigned long long seed, ValueType a = static_cast<ValueType>(-1),
                           ValueType b = static_cast<ValueType>(1))
     {
-        this->vector_interior_.SetRandomUniform(seed, a, b);
+        this->m_owned.SetRandomUniform(seed, a, b);
     }
     void SetRandomNormal(unsigned long long seed, ValueType mean = static_cast<ValueType>(0),
                          ValueType var = static_cast<ValueType>(1))
     {
-        this->vector_interior_.SetRandomNormal(seed, mean, var);
+        this->m_owned.SetRandomNormal(seed, mean, var);
     }
     void CopyFrom(const GlobalVector<ValueType>& src)
     {
-        this->vector_interior_.CopyFrom(src.vector_interior_);
+        this->m_owned.CopyFrom(src.m_owned);
     }
     void AddScale(const GlobalVector<ValueType>& x, ValueType alpha)
     {
-        this->vector_interior_.AddScale(x.vector_interior_, alpha);
+        this->m_owned.AddScale(x.m_owned, alpha);
     }
     void ScaleAdd(ValueType alpha, const GlobalVector<ValueType>& x)
     {
-        this->vector_interior_.ScaleAdd(alpha, x.vector_interior_);
+        this->m_owned.ScaleAdd(alpha, x.m_owned);
     }
     void ScaleAdd2(ValueType alpha, const GlobalVector<ValueType>& x, ValueType beta,
                    const GlobalVector<ValueType>& y, ValueType gamma)
     {
-        this->vector_interior_.ScaleAdd2(alpha, x.vector_interior_, beta, y.vector_interior_, gamma);
+        this->m_owned.ScaleAdd2(alpha, x.m_owned, beta, y.m_owned, gamma);
     }
     void ScaleAddScale(ValueType alpha, const GlobalVector<ValueType>& x, ValueType beta)
     {
-        this->vector_interior_.ScaleAddScale(alpha, x.vector_interior_, beta);
+        this->m_owned.ScaleAddScale(alpha, x.m_owned, beta);
     }
     void Scale(ValueType alpha)
     {
-        this->vector_interior_.Scale(alpha);
+        this->m_owned.Scale(alpha);
     }
     void PointWiseMult(const GlobalVector<ValueType>& x)
     {
-        this->vector_interior_.PointWiseMult(x.vector_interior_);
+        this->m_owned.PointWiseMult(x.m_owned);
     }
     void PointWiseMult(const GlobalVector<ValueType>& x, const GlobalVector<ValueType>& y)
     {
-        this->vector_interior_.PointWiseMult(x.vector_interior_, y.vector_interior_);
+        this->m_owned.PointWiseMult(x.m_owned, y.m_owned);
     }
     void CopyFromFloat(const GlobalVector<float>& src)
     {
-        this->vector_interior_.CopyFromFloat(src.GetInterior());
+        this->m_owned.CopyFromFloat(src.GetInterior());
     }
     void CopyFromDouble(const GlobalVector<double>& src)
     {
-        this->vector_interior_.CopyFromDouble(src.GetInterior());
+        this->m_owned.CopyFromDouble(src.GetInterior());
     }
     // global_vector.cpp:547-588: local reduction, then sum over ranks; Norm = sqrt(allreduce(dot))
     ValueType Dot(const GlobalVector<ValueType>& x) const
     {
-        return (ValueType)this->reduce_(x.vector_interior_.handle(), false);
+        return (ValueType)this->reduce_(x.m_owned.handle(), false);
     }
     ValueType DotNonConj(const GlobalVector<ValueType>& x) const
     {
@@ -460,11 +460,11 @@ public:
     }
     ValueType Norm(void) const
     {
-        return (ValueType)std::sqrt(this->reduce_(this->vector_interior_.handle(), false));
+        return (ValueType)std::sqrt(this->reduce_(this->m_owned.handle(), false));
     }
     ValueType Asum(void) const
     {
-        double     local = (double)this->vector_interior_.Asum();
+        double     local = (double)this->m_owned.Asum();
         return (ValueType)this->sum_ranks_(local);
     }
     int64_t Amax(ValueType& value) const
@@ -479,7 +479,7 @@ private:
     double reduce_(ramd_vec_t other, bool) const
     {
         const int        slot  = RAMD_NSCALARS - 2;
-        const ramd_vec_t vs[1] = {this->vector_interior_.handle()};
+        const ramd_vec_t vs[1] = {this->m_owned.handle()};
         RAMD_CHECK(ramd_fused_multi_dot(vs, 1, other, slot));
         if(this->pm_ != NULL && this->pm_->GetNumProcs() > 1)
             RAMD_CHECK(ramd_comm_allreduce_scalars(this->pm_->GetComm(), slot, 1));
@@ -499,7 +499,7 @@ private:
         return r;
     }
     const ParallelManager* pm_;
-    LocalVector<ValueType> vector_interior_;
+    LocalVector<ValueType> m_owned;
     friend class GlobalMatrix<ValueType>;
 };
 
@@ -525,47 +525,47 @@ public:
     }
     bool is_accel_(void) const
     {
-        return this->matrix_interior_.is_accel_();
+        return this->m_interior.is_accel_();
     }
     int64_t GetM(void) const
     {
-        return this->pm_ ? this->pm_->GetGlobalNrow() : this->matrix_interior_.GetM();
+        return this->pm_ ? this->pm_->GetGlobalNrow() : this->m_interior.GetM();
     }
     int64_t GetN(void) const
     {
-        return this->pm_ ? this->pm_->GetGlobalNcol() : this->matrix_interior_.GetN();
+        return this->pm_ ? this->pm_->GetGlobalNcol() : this->m_interior.GetN();
     }
     int64_t GetLocalM(void) const
     {
-        return this->matrix_interior_.GetM();
+        return this->m_interior.GetM();
     }
     int64_t GetLocalN(void) const
     {
-        return this->matrix_interior_.GetN();
+        return this->m_interior.GetN();
     }
     int64_t GetLocalNnz(void) const
     {
-        return this->matrix_interior_.GetNnz();
+        return this->m_interior.GetNnz();
     }
     int64_t GetGhostNnz(void) const
     {
-        return this->matrix_ghost_.GetNnz();
+        return this->m_ghost.GetNnz();
     }
     LocalMatrix<ValueType>& GetInterior(void)
     {
-        return this->matrix_interior_;
+        return this->m_interior;
     }
     const LocalMatrix<ValueType>& GetInterior(void) const
     {
-        return this->matrix_interior_;
+        return this->m_interior;
     }
     LocalMatrix<ValueType>& GetGhost(void)
     {
-        return this->matrix_ghost_;
+        return this->m_ghost;
     }
     const LocalMatrix<ValueType>& GetGhost(void) const
     {
-        return this->matrix_ghost_;
+        return this->m_ghost;
     }
     void Info(void) const
     {
@@ -577,35 +577,35 @@ public:
                             int64_t nnz)
     {
         assert(this->pm_ != NULL);
-        this->matrix_interior_.SetDataPtrCSR(row_offset, col, val, "Interior of " + name, nnz,
+        this->m_interior.SetDataPtrCSR(row_offset, col, val, "Interior of " + name, nnz,
                                              this->pm_->GetLocalNrow(), this->pm_->GetLocalNcol());
     }
     void SetGhostDataPtrCSR(PtrType** row_offset, int** col, ValueType** val, std::string name,
                             int64_t nnz)
     {
         assert(this->pm_ != NULL);
-        this->matrix_ghost_.SetDataPtrCSR(row_offset, col, val, "Ghost of " + name, nnz,
+        this->m_ghost.SetDataPtrCSR(row_offset, col, val, "Ghost of " + name, nnz,
                                           this->pm_->GetLocalNrow(), this->pm_->GetNumReceivers());
     }
     void MoveToAccelerator(void)
     {
-        this->matrix_interior_.MoveToAccelerator();
-        this->matrix_ghost_.MoveToAccelerator();
-        this->InitCommPattern_();
+        this->m_interior.MoveToAccelerator();
+        this->m_ghost.MoveToAccelerator();
+        this->doInitHalo();
     }
     // global_matrix.cpp:913-921: interior in the requested format, ghost part always COO
     void ConvertTo(unsigned int matrix_format, int blockdim = 1)
     {
-        this->matrix_interior_.ConvertTo(matrix_format, blockdim);
-        if(this->matrix_ghost_.GetNnz() > 0)
-            this->matrix_ghost_.ConvertTo(COO);
+        this->m_interior.ConvertTo(matrix_format, blockdim);
+        if(this->m_ghost.GetNnz() > 0)
+            this->m_ghost.ConvertTo(COO);
     }
     // extension: only the ghost part to (row-grouped) COO -- a CSR ghost part is walked over ALL local rows
     // although only the boundary rows have entries.  Results are bit-identical (same per-row order).
     void CompactGhost(void)
     {
-        if(this->matrix_ghost_.GetNnz() > 0 && this->matrix_ghost_.GetFormat() == CSR)
-            this->matrix_ghost_.ConvertTo(COO);
+        if(this->m_ghost.GetNnz() > 0 && this->m_ghost.GetFormat() == CSR)
+            this->m_ghost.ConvertTo(COO);
     }
     void ConvertToCSR(void)
     {
@@ -621,7 +621,7 @@ public:
     }
     void ExtractInverseDiagonal(GlobalVector<ValueType>* vec_inv_diag) const
     {
-        this->matrix_interior_.ExtractInverseDiagonal(&vec_inv_diag->vector_interior_);
+        this->m_interior.ExtractInverseDiagonal(&vec_inv_diag->m_owned);
     }
     // extension: value-cast copy (interior + ghost, same parallel manager) for MixedPrecisionDC on
     // Global objects -- the reference instantiates MixedPrecisionDC for LocalMatrix only
@@ -630,28 +630,28 @@ public:
     void CastFrom(const GlobalMatrix<OtherType>& src)
     {
         this->pm_ = src.pm();
-        this->matrix_interior_.template CastFrom<OtherType>(src.GetInterior());
+        this->m_interior.template CastFrom<OtherType>(src.GetInterior());
         const unsigned int gfmt = src.GetGhost().GetFormat();
         if(gfmt == CSR)
-            this->matrix_ghost_.template CastFrom<OtherType>(src.GetGhost());
+            this->m_ghost.template CastFrom<OtherType>(src.GetGhost());
         else // the value cast is defined on CSR (mixed_precision.cpp:201); keep the source's ghost format
         {
             LocalMatrix<OtherType> tmp;
             tmp.CloneFrom(src.GetGhost());
             tmp.ConvertTo(CSR);
-            this->matrix_ghost_.template CastFrom<OtherType>(tmp);
-            this->matrix_ghost_.ConvertTo(gfmt);
+            this->m_ghost.template CastFrom<OtherType>(tmp);
+            this->m_ghost.ConvertTo(gfmt);
         }
-        this->InitCommPattern_();
+        this->doInitHalo();
     }
     // extension: per-rank slab of the synthetic 3-D Poisson operator, built on the device
     void GeneratePoisson7Slab(int N, int64_t row_begin, int64_t row_end)
     {
-        this->matrix_interior_.MoveToAccelerator();
-        this->matrix_ghost_.MoveToAccelerator();
-        RAMD_CHECK(ramd_mat_gen_poisson7_slab(this->matrix_interior_.handle(), this->matrix_ghost_.handle(),
+        this->m_interior.MoveToAccelerator();
+        this->m_ghost.MoveToAccelerator();
+        RAMD_CHECK(ramd_mat_gen_poisson7_slab(this->m_interior.handle(), this->m_ghost.handle(),
                                               N, row_begin, row_end));
-        this->InitCommPattern_();
+        this->doInitHalo();
     }
 
     // global_matrix.cpp:924-1009, device-resident: pack | halo over xGMI || interior SpMV | ghost +=
@@ -660,18 +660,18 @@ public:
         const bool comm = this->pm_ != NULL && !this->pm_->peers().empty();
         if(comm)
         {
-            in.vector_interior_.GetIndexValues(this->halo_, &this->send_buffer_);
-            RAMD_CHECK(ramd_comm_halo_begin(this->pm_->GetComm(), this->send_buffer_.handle(),
-                                            this->recv_buffer_.handle(), (int)this->pm_->peers().size(),
+            in.m_owned.GetIndexValues(this->m_halo_rows, &this->m_send);
+            RAMD_CHECK(ramd_comm_halo_begin(this->pm_->GetComm(), this->m_send.handle(),
+                                            this->m_recv.handle(), (int)this->pm_->peers().size(),
                                             this->pm_->peers().data(), this->pm_->send_offset().data(),
                                             this->pm_->recv_offset().data()));
         }
-        this->matrix_interior_.Apply(in.vector_interior_, &out->vector_interior_);
+        this->m_interior.Apply(in.m_owned, &out->m_owned);
         if(comm)
         {
             RAMD_CHECK(ramd_comm_halo_end(this->pm_->GetComm()));
-            this->matrix_ghost_.ApplyAdd(this->recv_buffer_, static_cast<ValueType>(1),
-                                         &out->vector_interior_);
+            this->m_ghost.ApplyAdd(this->m_recv, static_cast<ValueType>(1),
+                                         &out->m_owned);
         }
     }
 
@@ -688,50 +688,50 @@ public:
         const bool comm = this->pm_ != NULL && !this->pm_->peers().empty();
         if(comm)
         {
-            in.vector_interior_.GetIndexValues(this->halo_, &this->send_buffer_);
-            RAMD_CHECK(ramd_comm_halo_begin(this->pm_->GetComm(), this->send_buffer_.handle(),
-                                            this->recv_buffer_.handle(), (int)this->pm_->peers().size(),
+            in.m_owned.GetIndexValues(this->m_halo_rows, &this->m_send);
+            RAMD_CHECK(ramd_comm_halo_begin(this->pm_->GetComm(), this->m_send.handle(),
+                                            this->m_recv.handle(), (int)this->pm_->peers().size(),
                                             this->pm_->peers().data(), this->pm_->send_offset().data(),
                                             this->pm_->recv_offset().data()));
         }
         if(&w == &in)
-            RAMD_CHECK(ramd_fused_apply_dot(this->matrix_interior_.handle(), in.vector_interior_.handle(),
-                                            out->vector_interior_.handle(), slot));
+            RAMD_CHECK(ramd_fused_apply_dot(this->m_interior.handle(), in.m_owned.handle(),
+                                            out->m_owned.handle(), slot));
         else
-            RAMD_CHECK(ramd_fused_apply_dotv(this->matrix_interior_.handle(), in.vector_interior_.handle(),
-                                             out->vector_interior_.handle(), w.vector_interior_.handle(),
+            RAMD_CHECK(ramd_fused_apply_dotv(this->m_interior.handle(), in.m_owned.handle(),
+                                             out->m_owned.handle(), w.m_owned.handle(),
                                              slot));
         if(comm)
         {
             RAMD_CHECK(ramd_comm_halo_end(this->pm_->GetComm()));
-            RAMD_CHECK(ramd_fused_apply_add_dot(this->matrix_ghost_.handle(), this->recv_buffer_.handle(), 1.0,
-                                                out->vector_interior_.handle(),
-                                                w.vector_interior_.handle(), slot));
+            RAMD_CHECK(ramd_fused_apply_add_dot(this->m_ghost.handle(), this->m_recv.handle(), 1.0,
+                                                out->m_owned.handle(),
+                                                w.m_owned.handle(), slot));
         }
     }
 
 private:
     // global_matrix.cpp:4476-4513: halo index vector + device send/recv buffers
-    void InitCommPattern_(void)
+    void doInitHalo(void)
     {
         if(this->pm_ == NULL || this->pm_->peers().empty())
             return;
         const int nb = this->pm_->GetBoundarySize();
-        this->halo_.MoveToAccelerator();
-        this->halo_.Allocate("halo", nb);
+        this->m_halo_rows.MoveToAccelerator();
+        this->m_halo_rows.Allocate("halo", nb);
         if(nb > 0)
-            this->halo_.CopyFromHostData(this->pm_->GetBoundaryIndex());
-        this->send_buffer_.MoveToAccelerator();
-        this->send_buffer_.Allocate("send buffer", this->pm_->GetNumSenders());
-        this->recv_buffer_.MoveToAccelerator();
-        this->recv_buffer_.Allocate("recv buffer", this->pm_->GetNumReceivers());
+            this->m_halo_rows.CopyFromHostData(this->pm_->GetBoundaryIndex());
+        this->m_send.MoveToAccelerator();
+        this->m_send.Allocate("send buffer", this->pm_->GetNumSenders());
+        this->m_recv.MoveToAccelerator();
+        this->m_recv.Allocate("recv buffer", this->pm_->GetNumReceivers());
     }
     const ParallelManager*         pm_;
-    LocalMatrix<ValueType>         matrix_interior_;
-    LocalMatrix<ValueType>         matrix_ghost_;
-    LocalVector<int>               halo_;
-    mutable LocalVector<ValueType> send_buffer_;
-    mutable LocalVector<ValueType> recv_buffer_;
+    LocalMatrix<ValueType>         m_interior;
+    LocalMatrix<ValueType>         m_ghost;
+    LocalVector<int>               m_halo_rows;
+    mutable LocalVector<ValueType> m_send;
+    mutable LocalVector<ValueType> m_recv;
 };
 
 // ---- fused-loop helpers for Global objects (see solvers.hpp: _fusable / _fh / _f_apply_dot / _f_allreduce)

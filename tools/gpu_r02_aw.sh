@@ -2,4 +2,4 @@
 mkdir -p gpurun_out/r02aw
 cd /root/repo
 export TMPDIR=/tmp
-timeout 1200 python -m pytest tests/test_gpu_distributed.py -x -q -m gpu -k "parallel_manager or distribute_matrix" > gpurun_out/r02aw/t.log 2>&1; echo "rc=$?"; tail -15 gpurun_out/r02aw/t.log
+timeout 2400 python -m pytest tests/test_gpu_distributed.py tests/test_gpu_global_full_size.py -x -q -m gpu > gpurun_out/r02aw/t.log 2>&1; echo "rc=$?"; tail -6 gpurun_out/r02aw/t.log
