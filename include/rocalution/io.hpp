@@ -26,12 +26,12 @@ namespace rocalution
 template <typename ValueType>
 bool LocalMatrix<ValueType>::ReadFileMTX(const std::string& filename)
 {
-    LOG_INFO("ReadFileMTX: filename=" << filename << "; reading...");
+    say("ReadFileMTX: filename=", filename, "; reading...");
     std::ifstream f(filename.c_str(), std::ios::binary | std::ios::ate);
     if(!f)
     {
-        LOG_INFO("ReadFileMTX: cannot open file " << filename);
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("ReadFileMTX: cannot open file ", filename);
+        RAMD_DIE();
     }
     std::string buf((size_t)f.tellg(), '\0');
     f.seekg(0);
@@ -52,8 +52,8 @@ bool LocalMatrix<ValueType>::ReadFileMTX(const std::string& filename)
     std::string line;
     if(!next_line(line))
     {
-        LOG_INFO("ReadFileMTX: invalid matrix market banner");
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("ReadFileMTX: invalid matrix market banner");
+        RAMD_DIE();
     }
     std::istringstream bs(line);
     std::string        banner, mtx, array_type, matrix_type, storage_type;
@@ -76,13 +76,13 @@ bool LocalMatrix<ValueType>::ReadFileMTX(const std::string& filename)
     if(banner.compare(0, 14, "%%MatrixMarket") != 0 || mtx.compare(0, 6, "matrix") != 0
        || array_type.compare(0, 10, "coordinate") != 0 || !sym_ok || (!val_ok && !is_complex))
     {
-        LOG_INFO("ReadFileMTX: invalid matrix market banner");
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("ReadFileMTX: invalid matrix market banner");
+        RAMD_DIE();
     }
     if(is_complex)
     {
-        LOG_INFO("ReadFileMTX: complex matrices are not provided by this backend");
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("ReadFileMTX: complex matrices are not provided by this backend");
+        RAMD_DIE();
     }
     // skip comments, read "m n nnz"
     long long nrow = 0, ncol = 0, nnz = 0;
@@ -90,8 +90,8 @@ bool LocalMatrix<ValueType>::ReadFileMTX(const std::string& filename)
     {
         if(!next_line(line))
         {
-            LOG_INFO("ReadFileMTX: invalid matrix data");
-            FATAL_ERROR(__FILE__, __LINE__);
+            say("ReadFileMTX: invalid matrix data");
+            RAMD_DIE();
         }
         if(!line.empty() && line[0] == '%')
             continue;
@@ -101,8 +101,8 @@ bool LocalMatrix<ValueType>::ReadFileMTX(const std::string& filename)
     // sizes must be usable as 32-bit row / column indices (and a negative count must not become a huge allocation)
     if(nrow < 0 || ncol < 0 || nnz < 0 || nrow > 2147483646LL || ncol > 2147483646LL)
     {
-        LOG_INFO("ReadFileMTX: invalid matrix data (sizes " << nrow << " x " << ncol << ", " << nnz << " entries)");
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("ReadFileMTX: invalid matrix data (sizes ", nrow, " x ", ncol, ", ", nnz, " entries)");
+        RAMD_DIE();
     }
     std::vector<int>       row((size_t)nnz), col((size_t)nnz);
     std::vector<ValueType> val((size_t)nnz);
@@ -113,8 +113,8 @@ bool LocalMatrix<ValueType>::ReadFileMTX(const std::string& filename)
         long  r = strtol(q, &e, 10);
         if(e == q)
         {
-            LOG_INFO("ReadFileMTX: invalid matrix data");
-            FATAL_ERROR(__FILE__, __LINE__);
+            say("ReadFileMTX: invalid matrix data");
+            RAMD_DIE();
         }
         q      = e;
         long c = strtol(q, &e, 10);
@@ -129,8 +129,8 @@ bool LocalMatrix<ValueType>::ReadFileMTX(const std::string& filename)
         }
         if(bad || r < 1 || r > nrow || c < 1 || c > ncol)
         {
-            LOG_INFO("ReadFileMTX: invalid matrix data (entry " << i + 1 << ")");
-            FATAL_ERROR(__FILE__, __LINE__);
+            say("ReadFileMTX: invalid matrix data (entry ", i + 1, ")");
+            RAMD_DIE();
         }
         row[(size_t)i] = (int)r - 1;
         col[(size_t)i] = (int)c - 1;
@@ -208,7 +208,7 @@ bool LocalMatrix<ValueType>::ReadFileMTX(const std::string& filename)
     this->h_ncol_ = ncol;
     if(was_accel)
         this->MoveToAccelerator();
-    LOG_INFO("ReadFileMTX: filename=" << filename << "; done");
+    say("ReadFileMTX: filename=", filename, "; done");
     return true;
 }
 
@@ -243,7 +243,7 @@ inline void csr_on_host(const LocalMatrix<ValueType>& A, std::vector<PtrType>& r
 template <typename ValueType>
 bool LocalMatrix<ValueType>::WriteFileMTX(const std::string& filename) const
 {
-    LOG_INFO("WriteFileMTX: filename=" << filename << "; writing...");
+    say("WriteFileMTX: filename=", filename, "; writing...");
     std::vector<PtrType>   rp;
     std::vector<int>       ci;
     std::vector<ValueType> va;
@@ -251,8 +251,8 @@ bool LocalMatrix<ValueType>::WriteFileMTX(const std::string& filename) const
     FILE* file = fopen(filename.c_str(), "w");
     if(!file)
     {
-        LOG_INFO("WriteFileMTX: cannot open file " << filename);
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("WriteFileMTX: cannot open file ", filename);
+        RAMD_DIE();
     }
     fprintf(file, "%%%%MatrixMarket matrix coordinate real general\n");
     fprintf(file, "%d %d %lld\n", (int)this->GetM(), (int)this->GetN(), (long long)ci.size());
@@ -260,14 +260,14 @@ bool LocalMatrix<ValueType>::WriteFileMTX(const std::string& filename) const
         for(PtrType j = rp[i]; j < rp[i + 1]; ++j)
             fprintf(file, "%d %d %0.12g\n", (int)i + 1, ci[j] + 1, (double)va[j]);
     fclose(file);
-    LOG_INFO("WriteFileMTX: filename=" << filename << "; done");
+    say("WriteFileMTX: filename=", filename, "; done");
     return true;
 }
 
 template <typename ValueType>
 bool LocalMatrix<ValueType>::WriteFileCSR(const std::string& filename) const
 {
-    LOG_INFO("WriteFileCSR: filename=" << filename << "; writing...");
+    say("WriteFileCSR: filename=", filename, "; writing...");
     std::vector<PtrType>   rp;
     std::vector<int>       ci;
     std::vector<ValueType> va;
@@ -275,8 +275,8 @@ bool LocalMatrix<ValueType>::WriteFileCSR(const std::string& filename) const
     std::ofstream out(filename.c_str(), std::ios::out | std::ios::binary);
     if(!out.is_open())
     {
-        LOG_INFO("WriteFileCSR: cannot open file " << filename);
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("WriteFileCSR: cannot open file ", filename);
+        RAMD_DIE();
     }
     out << "#rocALUTION binary csr file" << std::endl;
     const int     version = __ROCALUTION_VER;
@@ -292,30 +292,30 @@ bool LocalMatrix<ValueType>::WriteFileCSR(const std::string& filename) const
     out.write((const char*)dv.data(), sizeof(double) * dv.size());
     if(!out)
     {
-        LOG_INFO("WriteFileCSR: filename=" << filename << "; could not write to file");
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("WriteFileCSR: filename=", filename, "; could not write to file");
+        RAMD_DIE();
     }
     out.close();
-    LOG_INFO("WriteFileCSR: filename=" << filename << "; done");
+    say("WriteFileCSR: filename=", filename, "; done");
     return true;
 }
 
 template <typename ValueType>
 bool LocalMatrix<ValueType>::ReadFileCSR(const std::string& filename)
 {
-    LOG_INFO("ReadFileCSR: filename=" << filename << "; reading...");
+    say("ReadFileCSR: filename=", filename, "; reading...");
     std::ifstream in(filename.c_str(), std::ios::in | std::ios::binary);
     if(!in.is_open())
     {
-        LOG_INFO("ReadFileCSR: cannot open file " << filename);
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("ReadFileCSR: cannot open file ", filename);
+        RAMD_DIE();
     }
     std::string header;
     std::getline(in, header);
     if(header != "#rocALUTION binary csr file")
     {
-        LOG_INFO("ReadFileCSR: invalid rocALUTION matrix header");
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("ReadFileCSR: invalid rocALUTION matrix header");
+        RAMD_DIE();
     }
     int     version = 0;
     int64_t nrow = 0, ncol = 0, nnz = 0;
@@ -336,13 +336,13 @@ bool LocalMatrix<ValueType>::ReadFileCSR(const std::string& filename)
     }
     if(!in || nrow < 0 || ncol < 0 || nnz < 0)
     {
-        LOG_INFO("ReadFileCSR: invalid matrix data");
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("ReadFileCSR: invalid matrix data");
+        RAMD_DIE();
     }
     if(version >= 30000 && nnz >= std::numeric_limits<int>::max())
     {
-        LOG_INFO("ReadFileCSR: cannot read 64 bit sparsity pattern into 32 bit structure");
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("ReadFileCSR: cannot read 64 bit sparsity pattern into 32 bit structure");
+        RAMD_DIE();
     }
     std::vector<PtrType>   rp((size_t)nrow + 1);
     std::vector<int>       ci((size_t)nnz);
@@ -357,8 +357,8 @@ bool LocalMatrix<ValueType>::ReadFileCSR(const std::string& filename)
     }
     if(!in)
     {
-        LOG_INFO("ReadFileCSR: invalid matrix data");
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("ReadFileCSR: invalid matrix data");
+        RAMD_DIE();
     }
     const bool was_accel = this->on_accel_;
     this->Clear();
@@ -373,7 +373,7 @@ bool LocalMatrix<ValueType>::ReadFileCSR(const std::string& filename)
     this->h_ncol_ = ncol;
     if(was_accel)
         this->MoveToAccelerator();
-    LOG_INFO("ReadFileCSR: filename=" << filename << "; done");
+    say("ReadFileCSR: filename=", filename, "; done");
     return true;
 }
 
@@ -381,12 +381,12 @@ bool LocalMatrix<ValueType>::ReadFileCSR(const std::string& filename)
 template <typename ValueType>
 void LocalVector<ValueType>::ReadFileASCII(const std::string& filename)
 {
-    LOG_INFO("ReadFileASCII: filename=" << filename << "; reading...");
+    say("ReadFileASCII: filename=", filename, "; reading...");
     std::ifstream file(filename.c_str(), std::ifstream::in);
     if(!file.is_open())
     {
-        LOG_INFO("Can not open vector file [read]:" << filename);
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("Can not open vector file [read]:", filename);
+        RAMD_DIE();
     }
     int64_t     n = 0; // the size is the number of LINES (host_vector.cpp:433-437)
     std::string line;
@@ -400,44 +400,44 @@ void LocalVector<ValueType>::ReadFileASCII(const std::string& filename)
     file.close();
     this->Allocate(filename, n);
     this->CopyFromHostData(data.data());
-    LOG_INFO("ReadFileASCII: filename=" << filename << "; done");
+    say("ReadFileASCII: filename=", filename, "; done");
 }
 
 template <typename ValueType>
 void LocalVector<ValueType>::WriteFileASCII(const std::string& filename) const
 {
-    LOG_INFO("WriteFileASCII: filename=" << filename << "; writing...");
+    say("WriteFileASCII: filename=", filename, "; writing...");
     std::vector<ValueType> data((size_t)this->GetSize());
     this->CopyToHostData(data.data());
     std::ofstream file(filename.c_str(), std::ifstream::out);
     if(!file.is_open())
     {
-        LOG_INFO("Can not open vector file [write]:" << filename);
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("Can not open vector file [write]:", filename);
+        RAMD_DIE();
     }
     file.setf(std::ios::scientific);
     for(size_t i = 0; i < data.size(); ++i)
         file << data[i] << std::endl;
     file.close();
-    LOG_INFO("WriteFileASCII: filename=" << filename << "; done");
+    say("WriteFileASCII: filename=", filename, "; done");
 }
 
 template <typename ValueType>
 void LocalVector<ValueType>::ReadFileBinary(const std::string& filename)
 {
-    LOG_INFO("ReadFileBinary: filename=" << filename << "; reading...");
+    say("ReadFileBinary: filename=", filename, "; reading...");
     std::ifstream in(filename.c_str(), std::ios::in | std::ios::binary);
     if(!in.is_open())
     {
-        LOG_INFO("ReadFileBinary: filename=" << filename << "; cannot open file");
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("ReadFileBinary: filename=", filename, "; cannot open file");
+        RAMD_DIE();
     }
     std::string header;
     std::getline(in, header);
     if(header != "#rocALUTION binary vector file")
     {
-        LOG_INFO("ReadFileBinary: filename=" << filename << " is not a rocALUTION vector");
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("ReadFileBinary: filename=", filename, " is not a rocALUTION vector");
+        RAMD_DIE();
     }
     int     version = 0;
     int64_t n       = 0;
@@ -452,8 +452,8 @@ void LocalVector<ValueType>::ReadFileBinary(const std::string& filename)
         in.read((char*)&n, sizeof(int64_t));
     if(!in || n < 0)
     {
-        LOG_INFO("ReadFileBinary: filename=" << filename << "; could not read from file");
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("ReadFileBinary: filename=", filename, "; could not read from file");
+        RAMD_DIE();
     }
     std::vector<ValueType> data((size_t)n);
     if(std::is_floating_point<ValueType>::value) // real data is always stored in double precision
@@ -467,26 +467,26 @@ void LocalVector<ValueType>::ReadFileBinary(const std::string& filename)
         in.read((char*)data.data(), sizeof(ValueType) * data.size());
     if(!in)
     {
-        LOG_INFO("ReadFileBinary: filename=" << filename << "; could not read from file");
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("ReadFileBinary: filename=", filename, "; could not read from file");
+        RAMD_DIE();
     }
     this->Allocate(filename, n);
     this->CopyFromHostData(data.data());
-    LOG_INFO("ReadFileBinary: filename=" << filename << "; done");
+    say("ReadFileBinary: filename=", filename, "; done");
 }
 
 template <typename ValueType>
 void LocalVector<ValueType>::WriteFileBinary(const std::string& filename) const
 {
-    LOG_INFO("WriteFileBinary: filename=" << filename << "; writing...");
+    say("WriteFileBinary: filename=", filename, "; writing...");
     const int64_t          n = this->GetSize();
     std::vector<ValueType> data((size_t)n);
     this->CopyToHostData(data.data());
     std::ofstream out(filename.c_str(), std::ios::out | std::ios::binary);
     if(!out.is_open())
     {
-        LOG_INFO("WriteFileBinary: filename=" << filename << "; cannot open file");
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("WriteFileBinary: filename=", filename, "; cannot open file");
+        RAMD_DIE();
     }
     out << "#rocALUTION binary vector file" << std::endl;
     const int version = __ROCALUTION_VER;
@@ -501,11 +501,11 @@ void LocalVector<ValueType>::WriteFileBinary(const std::string& filename) const
         out.write((const char*)data.data(), sizeof(ValueType) * data.size());
     if(!out)
     {
-        LOG_INFO("WriteFileBinary: filename=" << filename << "; could not write to file");
-        FATAL_ERROR(__FILE__, __LINE__);
+        say("WriteFileBinary: filename=", filename, "; could not write to file");
+        RAMD_DIE();
     }
     out.close();
-    LOG_INFO("WriteFileBinary: filename=" << filename << "; done");
+    say("WriteFileBinary: filename=", filename, "; done");
 }
 
 } // namespace rocalution
