@@ -1,4 +1,4 @@
 #!/bin/bash
 cd /root/repo
-bash tools/gpu_r02_aq.sh 2>&1 | head -6
-bash tools/gpu_r02_an.sh 2>&1 | grep -v "box-tile plan"
+bash tools/r02_runs/gpu_r02_aq.sh 2>&1 | head -6
+bash tools/r02_runs/gpu_r02_an.sh 2>&1 | grep -v "box-tile plan"
