@@ -1294,6 +1294,9 @@ constexpr int kCtFetchDepth = 4; // batches of 64 external values the fetch wave
 #ifndef RAMD_CT_PRIO
 #define RAMD_CT_PRIO 3
 #endif
+#ifndef RAMD_CT_POLL_CAP
+#define RAMD_CT_POLL_CAP 8 // (measured: 64 -> 8 gives 2.5 % at 512^3, 6 % at 256^3, 2.4 % on the shell; 2 is no better)
+#endif
 #ifndef RAMD_CT_DEPTH3
 #define RAMD_CT_DEPTH3 8
 #endif
@@ -1726,7 +1729,11 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
                     if(!advanced)
                     {
                         spin_guard(spins);
-                        backoff = poll_backoff(false, backoff);
+                        // (sleep between polls: doubling, capped low -- the wait for a neighbour tile's values is on the critical
+                        //  path of the solve, half a back-off period of it on average per tile hop)
+                        for(int z = 0; z < backoff; ++z)
+                            __builtin_amdgcn_s_sleep(1);
+                        backoff = backoff < RAMD_CT_POLL_CAP ? backoff * 2 : RAMD_CT_POLL_CAP;
                     }
                 }
                 if(prof)
