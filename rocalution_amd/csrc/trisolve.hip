@@ -1835,11 +1835,8 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
         const int row  = lrec / LPR; // row of the step this lane works for
         const int sub  = lrec % LPR; // its place among the row's lanes
         const int slot = st.tn % R;
-        if(st.tn != have_tn)
-        {
-            have_tn = st.tn;
-            have    = -1; // (until the fetch wave has parked the tile's right-hand side)
-        }
+        have    = (st.tn != have_tn) ? -1 : have; // (-1: until the fetch wave has parked the tile's right-hand side)
+        have_tn = st.tn;
         if(prof)
         {
             if(st.flags & 1)
@@ -1847,7 +1844,7 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
             else
                 ++pc_dups;
         }
-        if(have < st.need) // wave-uniform: wait for the fetch wave (an LDS count, no memory round trip)
+        if(__builtin_expect(have < st.need, 0)) // wave-uniform: wait for the fetch wave (an LDS count, no memory round trip)
         {
             const unsigned long long a = prof ? __builtin_amdgcn_s_memtime() : 0;
             int spins = 0;
@@ -1891,7 +1888,6 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
             }
         }
         T sum = bval;
-        if(st.flags & 1) // (a repeated step only re-issues its stores)
         {
         if(LPR == 1)
         {
@@ -1933,6 +1929,7 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
             else
                 sum = sum * dg;
         }
+        sum = (st.flags & 1) ? sum : bval; // (a repeated step finds its result in place of the right-hand side: re-store it)
         if(LPR == 1 || (sub == LPR - 1 && lane < nl))
             xs[own] = sum;
         }
@@ -1942,10 +1939,9 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
         }
         // this step's LDS traffic before the next step's: one wave, in-order LDS queue
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if(st.flags & 1)
+        pending = uni(pending - (st.flags & 1));
         {
-            pending = uni(pending - 1);
-            if(st.flags & 2) // the tile is finished: its ring slot may be reused
+            if(__builtin_expect((st.flags & 3) == 3, 0)) // the tile is finished: its ring slot may be reused
             {
                 done_tiles = uni(done_tiles + 1);
                 if(lane == 0)
