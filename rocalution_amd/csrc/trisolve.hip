@@ -1315,8 +1315,7 @@ struct CtRec
 template <typename T>
 static size_t ct_rec_lds_bytes(const CtDims& d)
 {
-    return ((size_t)1 + (size_t)kCtRing * d.rows + (size_t)kCtRing * d.exts) * sizeof(T)
-           + (size_t)(2 + 5 * kCtRing) * sizeof(int) + 64;
+    return (size_t)kCtRing * ((size_t)1 + d.rows + d.exts) * sizeof(T) + (size_t)(2 + 5 * kCtRing) * sizeof(int) + 64;
 }
 
 // per step: {first position, rows, external values of the tile used up to and including this step, first row's index in the tile}
@@ -1516,11 +1515,12 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
     constexpr int R   = kCtRing;
     unsigned long long* const prof = PROF ? prof_arg : nullptr; // (diagnostic instantiation only: the counters cost scalar registers)
     extern __shared__ __attribute__((aligned(16))) char ct_lds[];
-    // xs[0] = 0; xs[1 + slot * rows + q] = row q of the tile in ring slot `slot`: its right-hand side value until the row's
-    // step has run (parked by the fetch wave), its solution afterwards
-    T*   xs      = reinterpret_cast<T*>(ct_lds);
-    T*   ex      = xs + 1 + R * dims.rows; // [R][exts] external values, one buffer per ring slot
-    int* posted  = reinterpret_cast<int*>(ex + R * dims.exts); // tiles whose descriptor is in the ring
+    // One region per ring slot: xs[slot * S] = 0 (the padding column), then row q of the tile at [1 + q] -- its right-hand side
+    // value until the row's step has run (parked by the fetch wave), its solution afterwards --, then the tile's external
+    // values at [1 + rows + j].  A column code c is therefore the element slot * S + c, whatever its kind: one add.
+    T*        xs     = reinterpret_cast<T*>(ct_lds);
+    const int S      = 1 + dims.rows + dims.exts;
+    int*      posted = reinterpret_cast<int*>(xs + R * S); // tiles whose descriptor is in the ring
     int* tdone   = posted + 1; // tiles the compute wave has finished
     int* fetched = tdone + 1; // [R] external values parked so far
     int* tdesc   = fetched + R; // [R][4] {first step, steps, first position, rows}
@@ -1530,7 +1530,8 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
     {
         *posted = 0;
         *tdone  = 0;
-        xs[0]   = (T)0;
+        for(int r = 0; r < R; ++r)
+            xs[r * S] = (T)0;
     }
     __syncthreads();
     if(tid >= 64)
@@ -1557,7 +1558,7 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
         // natural-order output of a finished tile: rows sorted by destination -> neighbouring lanes write neighbouring addresses
         auto write_back = [&](int sl) {
             const int p0 = uni(tdesc[4 * sl + 2]), nr = uni(tdesc[4 * sl + 3]);
-            const T*  xb = xs + 1 + sl * dims.rows;
+            const T*  xb = xs + sl * S + 1;
             const v2i32* pr = reinterpret_cast<const v2i32*>(out_pairs) + p0;
             for(int q0 = 0; q0 < nr; q0 += 4 * 64)
             {
@@ -1637,12 +1638,12 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
             const int e0 = uni(d1.z), e1 = e0 + uni(d1.w);
             if(prof)
                 pf_ticket += __builtin_amdgcn_s_memtime() - pf_b;
-            T*        exb = ex + slot * dims.exts;
+            T*        exb = xs + slot * S + 1 + dims.rows;
             {
                 // the tile's right-hand side: rows sorted by source index -> neighbouring lanes read neighbouring addresses
                 // (whole lines where the tile covers contiguous pieces of the source vector); parked in row order
                 const int p0 = uni(d0.z), nr = uni(d0.w);
-                T*        rbb = xs + 1 + slot * dims.rows;
+                T*        rbb = xs + slot * S + 1;
                 const v2i32* pr = reinterpret_cast<const v2i32*>(in_pairs) + p0;
                 for(int q0 = 0; q0 < nr; q0 += 4 * 64)
                 {
@@ -1864,10 +1865,8 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
 #pragma unroll
         for(int q = 0; q < NQ; ++q)
             asm volatile("" ::"v"(stq.q[q]));
-        const int  xso  = slot * dims.rows; // shifts of the column codes into this tile's buffers
-        const int  exo  = (R - 1) * dims.rows + slot * dims.exts;
-        const int  rmax = dims.rows;
-        const int  own  = 1 + xso + st.lbase + row;
+        const int  sbase = slot * S; // this tile's region
+        const int  own   = sbase + 1 + st.lbase + row;
         const T    bval = xs[own]; // right-hand side (a repeated step finds its result there)
         T          v[WL], a[WL];
 #pragma unroll
@@ -1875,7 +1874,7 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
         {
             const int word = stq.q[(k / 2) / 4][(k / 2) % 4];
             const int c    = (k & 1) ? (int)((unsigned)word >> 16) : (word & 0xffff);
-            const int at   = (c == 0) ? 0 : c + ((c > rmax) ? exo : xso);
+            const int at   = sbase + c;
             v[k]           = xs[at];
             if(sizeof(T) == 8)
             {
@@ -1894,7 +1893,7 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
         {
 #pragma unroll
             for(int k = 0; k < WL; ++k)
-                sum -= a[k] * v[k]; // (padding: 0 * xs[0] = 0 * 0)
+                sum -= a[k] * v[k]; // (padding: value 0 * the slot's zero element)
         }
         else
         {
