@@ -1834,8 +1834,8 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
         } st = {uni(rec.x), uni(rec.y), uni(rec.z), uni(rec.w), uni(stq.tf) >> 2, uni(stq.tf) & 3};
         const int nl   = st.cnt * LPR; // lane records of the step
         const int lrec = min(lane, nl - 1);
-        const int row  = lrec / LPR; // row of the step this lane works for
-        const int sub  = lrec % LPR; // its place among the row's lanes
+        const int row  = (int)((unsigned)lrec / (unsigned)LPR); // row of the step this lane works for
+        const int sub  = (int)((unsigned)lrec % (unsigned)LPR); // its place among the row's lanes
         const int slot = st.tn % R;
         have    = (st.tn != have_tn) ? -1 : have; // (-1: until the fetch wave has parked the tile's right-hand side)
         have_tn = st.tn;
