@@ -1287,7 +1287,8 @@ constexpr int kCtFetchDepth = 4; // batches of 64 external values the fetch wave
 // computation and the scratch stores of lanes without an exported row cost more than the bytes saved.
 // Column codes: 0 = padding (LDS slot 0 holds 0.0 and the padded value is 0: subtracts +0), 1 + q = row q of the tile,
 // 1 + rows_max + j = external value j of the tile.
-// (compile-time tuning hooks; measured at 512^3: prefetch depth 6 / 8 equal, 12 slower (registers); ring 2 / 3 equal, 4 slower (LDS))
+// (compile-time tuning hooks; measured: prefetch depth 3 .. 8 equal on 512^3 / 256^3 / the shell surrogate, 12 slower (registers);
+//  ring 2 / 3 equal, 4 slower (LDS))
 #ifndef RAMD_CT_RING
 #define RAMD_CT_RING 3
 #endif
@@ -1299,6 +1300,9 @@ constexpr int kCtFetchDepth = 4; // batches of 64 external values the fetch wave
 #endif
 #ifndef RAMD_CT_DEPTH3
 #define RAMD_CT_DEPTH3 8
+#endif
+#ifndef RAMD_CT_DEPTH8L
+#define RAMD_CT_DEPTH8L 8 // (eight lanes per row)
 #endif
 constexpr int kCtRing = RAMD_CT_RING; // tiles the ticket/fetch wave may be ahead of the compute wave (+1)
 
@@ -2628,7 +2632,7 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
     do                               \
     {                                \
         if(lpr == 8)                    \
-            TRSV_RC(DM, HO, 8, 4, 8);   \
+            TRSV_RC(DM, HO, 8, 4, RAMD_CT_DEPTH8L);   \
         else if(wl == 3)                \
             TRSV_RC(DM, HO, 1, 3, RAMD_CT_DEPTH3);   \
         else if(wl == 4)                \
