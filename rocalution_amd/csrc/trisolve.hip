@@ -1312,8 +1312,12 @@ struct CtRec
     static constexpr int WLC      = (WL + 3) / 4 * 4; // 16-bit codes, padded to whole 8-byte slots
     static constexpr int off_val  = WLC * 2;
     static constexpr int off_diag = off_val + WL * (int)sizeof(T);
-    static constexpr int NQ       = (off_diag + (int)sizeof(T) + 15) / 16; // quads of a row (storage stride)
+    static constexpr int NQ       = (off_diag + (int)sizeof(T) + 15) / 16; // quads of a record with the diagonal in it
     static constexpr int NQL      = (off_diag + 15) / 16; // quads without the diagonal
+    // codes + values fill whole quads and the diagonal would sit alone in a half-used one (fp64 rows of <= 3 entries: 48
+    // bytes stored for 40): the diagonal then lives in its own position-order array and a step loads it with one 8-byte access
+    static constexpr bool DSEP = (off_diag % 16 == 0) && sizeof(T) == 8;
+    static constexpr int  NQS  = DSEP ? NQL : NQ; // quads stored per record
 };
 
 template <typename T>
@@ -1359,7 +1363,7 @@ __global__ __launch_bounds__(kBlock) void k_ct_fill_rec(int n, const int* __rest
                                                         int* __restrict__ ext_idx, char* __restrict__ erec,
                                                         int* __restrict__ nodiag, int reverse, int rows_max,
                                                         const int* __restrict__ ref_start,
-                                                        const int* __restrict__ slot_of_ref)
+                                                        const int* __restrict__ slot_of_ref, T* __restrict__ diag_sep)
 {
     using L         = CtRec<T, WL>;
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1387,7 +1391,8 @@ __global__ __launch_bounds__(kBlock) void k_ct_fill_rec(int n, const int* __rest
     int jref = 0;
     // byte `off` of the record of lane `sub` of this row: quad-major over the step's cnt * LPR lane records
     auto field = [&](int sub, int off) -> char* {
-        return erec + ((size_t)L::NQ * LPR * p0 + (size_t)(off / 16) * (cnt * LPR) + (rank * LPR + sub)) * 16 + (off % 16);
+        constexpr int stride = (L::DSEP && LPR == 1) ? L::NQS : L::NQ; // quads stored per lane record
+        return erec + ((size_t)stride * LPR * p0 + (size_t)(off / 16) * (cnt * LPR) + (rank * LPR + sub)) * 16 + (off % 16);
     };
     int       k    = 0;
     bool      have = false;
@@ -1424,15 +1429,21 @@ __global__ __launch_bounds__(kBlock) void k_ct_fill_rec(int n, const int* __rest
         }
         else if(c == i)
         {
-            *reinterpret_cast<T*>(field(LPR - 1, L::off_diag)) = val[j];
-            have                                               = true;
+            if(L::DSEP && LPR == 1)
+                diag_sep[p] = val[j];
+            else
+                *reinterpret_cast<T*>(field(LPR - 1, L::off_diag)) = val[j];
+            have = true;
         }
     }
     // (padding codes / values stay 0: the array is zeroed before the fill)
     if(!have)
     {
-        *reinterpret_cast<T*>(field(LPR - 1, L::off_diag)) = (T)1;
-        *nodiag                                            = 1;
+        if(L::DSEP && LPR == 1)
+            diag_sep[p] = (T)1;
+        else
+            *reinterpret_cast<T*>(field(LPR - 1, L::off_diag)) = (T)1;
+        *nodiag = 1;
     }
 }
 
@@ -1453,6 +1464,20 @@ __device__ __forceinline__ v4i32 ct_load_quad(const void* sbase, unsigned voff)
     sbase = ct_uniform(sbase);
     v4i32 r;
     asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+    return r;
+}
+__device__ __forceinline__ double ct_load_T(const double* sbase, unsigned voff)
+{
+    const void* b = ct_uniform(sbase);
+    double      r;
+    asm volatile("global_load_dwordx2 %0, %1, %2 nt" : "=v"(r) : "v"(voff), "s"(b) : "memory");
+    return r;
+}
+__device__ __forceinline__ float ct_load_T(const float* sbase, unsigned voff)
+{
+    const void* b = ct_uniform(sbase);
+    float       r;
+    asm volatile("global_load_dword %0, %1, %2 nt" : "=v"(r) : "v"(voff), "s"(b) : "memory");
     return r;
 }
 __device__ __forceinline__ int ct_load_int(const void* sbase, unsigned voff)
@@ -1502,20 +1527,23 @@ template <typename T, int NQ>
 struct CtStage
 {
     v4i32 q[NQ]; // the row's record
+    T     dg; // the diagonal, where it is kept outside the record
     int   g, tf; // uniform: index of the step's record; its tile number * 4 + flags (1 = a new step, 2 = last step of its tile)
 };
 
 template <typename T, int DMODE, bool HAS_OUT, int LPR, int WL, int DEPTH, bool PROF>
 __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const v4i32* __restrict__ tile_desc,
                                                   const v4i32* __restrict__ step_rec, const int* __restrict__ ext_idx,
-                                                  const v4i32* __restrict__ erec, const T* __restrict__ rhs_src,
+                                                  const v4i32* __restrict__ erec, const T* __restrict__ diag_sep,
+                                                  const T* __restrict__ rhs_src,
                                                   const int* __restrict__ in_pairs,
                                                   const int* __restrict__ out_pairs, T* w, T* __restrict__ out,
                                                   unsigned* counter, CtBases bases, int nstreams, unsigned long long* prof_arg)
 {
     using L           = CtRec<T, WL>;
     using B           = typename Sentinel<T>::bits;
-    constexpr int NQ  = (DMODE != 0) ? L::NQ : L::NQL;
+    constexpr bool DSEP = L::DSEP && LPR == 1; // the diagonal in its own array (CtRec)
+    constexpr int  NQ   = (DMODE != 0 && !DSEP) ? L::NQ : L::NQL;
     constexpr int R   = kCtRing;
     unsigned long long* const prof = PROF ? prof_arg : nullptr; // (diagnostic instantiation only: the counters cost scalar registers)
     extern __shared__ __attribute__((aligned(16))) char ct_lds[];
@@ -1807,20 +1835,22 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
     };
     // vector memory operations of one step of the stream, in issue order: the store of the step's values, then the quads of
     // the record DEPTH steps ahead
-    constexpr int OPS = 1 + NQ;
+    constexpr int OPS = 1 + NQ + ((DSEP && DMODE != 0) ? 1 : 0);
     static_assert(DEPTH * OPS < 64, "the whole prefetch window has to fit the 6-bit counter");
     auto fetch_rec = [&](CtStage<T, NQ>& st) {
         st.g  = g; // (the record itself comes back through the scalar cache when the step runs: scalar registers are scarce)
         st.tf = tn * 4 + ((cur_fresh ? 1 : 0) | (cur_last ? 2 : 0));
         const int      nl  = cur.y * LPR; // lane records of the step
         const int      row = min(lane, nl - 1);
-        const v4i32*   qb  = erec + (size_t)(L::NQ * LPR) * (size_t)cur.x; // scalar base of the step + 32-bit lane offsets
+        const v4i32*   qb  = erec + (size_t)((DSEP ? L::NQS : L::NQ) * LPR) * (size_t)cur.x; // scalar base of the step + lane offsets
         const unsigned ro  = (unsigned)row * 16u;
         // (lanes beyond the step's rows mirror its last row -- same addresses, same values: every operation is issued, and
         //  counted, in every step; switching those lanes off instead was measured no faster)
 #pragma unroll
         for(int q = 0; q < NQ; ++q)
             st.q[q] = ct_load_quad(qb, ro + (unsigned)(q * nl) * 16u);
+        if(DSEP && DMODE != 0)
+            st.dg = ct_load_T(diag_sep + cur.x, (unsigned)row * (unsigned)sizeof(T));
         if(cur_fresh)
             pending = uni(pending + 1);
         cur_fresh = try_advance();
@@ -1829,6 +1859,8 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
 #pragma unroll
         for(int q = 0; q < NQ; ++q)
             asm volatile("" : "+v"(st.q[q]));
+        if(DSEP && DMODE != 0)
+            asm volatile("" : "+v"(st.dg));
     };
     int  have = -1, have_tn = -1;
     auto step = [&](const CtStage<T, NQ>& stq, const v4i32 rec) {
@@ -1921,7 +1953,9 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
         if(DMODE != 0)
         {
             T dg;
-            if(sizeof(T) == 8)
+            if(DSEP)
+                dg = stq.dg;
+            else if(sizeof(T) == 8)
             {
                 const int wi = L::off_diag / 4;
                 dg           = (T)__hiloint2double(stq.q[(wi + 1) / 4][(wi + 1) % 4], stq.q[wi / 4][wi % 4]);
@@ -2418,7 +2452,8 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     P->ct_rec = true;
     {
         // record form: one array of 16-byte quads (CtRec), lpr lane records per row, zeroed = padded
-        const size_t nq    = wl == 3 ? CtRec<T, 3>::NQ : (wl == 4 ? CtRec<T, 4>::NQ : CtRec<T, 8>::NQ);
+        const size_t nq    = lpr == 8 ? CtRec<T, 4>::NQ : (wl == 3 ? CtRec<T, 3>::NQS : (wl == 4 ? CtRec<T, 4>::NQS : CtRec<T, 8>::NQS));
+        CT_HIP(cached_malloc(&P->diag, (size_t)n * sizeof(T) + kPad)); // (used where the record keeps no diagonal: CtRec::DSEP)
         const size_t bytes = nq * 16 * (size_t)lpr * (size_t)n + kPad;
         CT_HIP(cached_malloc(&P->eval, bytes));
         CT_HIP(hipMemsetAsync(P->eval, 0, bytes, b.cur));
@@ -2426,7 +2461,7 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     hipLaunchKernelGGL((k_ct_fill_rec<T, LOW, WLL, LP>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci,                  \
                        (const T*)m->val, P->order, P->pos, tile_of, step_of, P->ct_tile_step, P->ct_step_pos,               \
                        P->ct_ext_start, P->ct_ext_idx, (char*)P->eval, nodiag, reverse ? 1 : 0, P->ct_dims[0], ref_start, \
-                       slot_of_ref)
+                       slot_of_ref, (T*)P->diag)
 #define CT_FILL_REC_W(LOW)           \
     do                               \
     {                                \
@@ -2620,12 +2655,14 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
         if(pf_on && WLL == 3 && sizeof(T) == 8)                                                                             \
             hipLaunchKernelGGL((k_trsv_rec<T, DM, HO, 1, 3, 8, true>), dim3(nwg), dim3(128), lds, b.cur,                        \
                                P->ct_ntiles, dims, (const v4i32*)P->ct_tile_desc, (const v4i32*)P->ct_step_rec,             \
-                               P->ct_ext_idx, (const v4i32*)P->eval, rhs_src, P->ct_in_pairs, P->ct_out_pairs, (T*)P->w, out, \
+                               P->ct_ext_idx, (const v4i32*)P->eval, (const T*)P->diag, rhs_src, P->ct_in_pairs,            \
+                               P->ct_out_pairs, (T*)P->w, out,                                                              \
                                st->stream_counter, bases, nstreams, pf_buf);                                                \
         else                                                                                                                \
             hipLaunchKernelGGL((k_trsv_rec<T, DM, HO, LP, WLL, DP, false>), dim3(nwg), dim3(128), lds, b.cur, P->ct_ntiles, \
                                dims, (const v4i32*)P->ct_tile_desc, (const v4i32*)P->ct_step_rec, P->ct_ext_idx,            \
-                               (const v4i32*)P->eval, rhs_src, P->ct_in_pairs, P->ct_out_pairs, (T*)P->w, out,               \
+                               (const v4i32*)P->eval, (const T*)P->diag, rhs_src, P->ct_in_pairs, P->ct_out_pairs,           \
+                               (T*)P->w, out,                                                                               \
                                st->stream_counter, bases, nstreams, pf_buf);                                                \
     } while(0)
 #define TRSV_RC_L(DM, HO)            \
@@ -3446,6 +3483,13 @@ static int plan_set_diag(TriPlan* P, const T* src)
         const int      lpr = P->ct_wmax > 8 ? 8 : 1;
         const int      wl  = lpr == 8 ? 4 : (P->ct_wmax <= 3 ? 3 : (P->ct_wmax <= 4 ? 4 : 8));
         const unsigned nb  = (unsigned)(((int64_t)P->ct_nsteps * 64 + kBlock - 1) / kBlock);
+        const bool     dsep = lpr == 1 && (wl == 3 ? CtRec<T, 3>::DSEP : (wl == 4 ? CtRec<T, 4>::DSEP : CtRec<T, 8>::DSEP));
+        if(dsep) // the diagonal has its own position-order array
+        {
+            hipLaunchKernelGGL((k_gather_diag<T>), dim3(ew_grid(P->n)), dim3(kBlock), 0, b.cur, P->n, P->order, src, (T*)P->diag);
+            RAMD_HIP(hipGetLastError());
+            return RAMD_OK;
+        }
 #define CT_SET_DIAG(WLL, LP)                                                                                                \
     hipLaunchKernelGGL((k_ct_rec_set_diag<T, WLL, LP>), dim3(nb), dim3(kBlock), 0, b.cur, P->ct_nsteps, P->ct_step_rec,     \
                        P->order, src, (char*)P->eval)
