@@ -1751,6 +1751,38 @@ private:
         VectorType**        v = this->m_v;
         ValueType*          H = this->m_H.data();
         ramd_vec_t          w = _fh(*v[i + 1]);
+        // Blocks of four projections per pass (ramd_fused_mgs_block: the same recurrence with the block's Gram entries
+        // measured in the pass, h by forward substitution on the device): 2 + 2*4 vector streams per four projections
+        // instead of 16, and one all-reduce per block.  RAMD_MGS_BLOCK=0: one projection per pass (below).
+        static const bool blocked = !(std::getenv("RAMD_MGS_BLOCK") && std::atoi(std::getenv("RAMD_MGS_BLOCK")) == 0);
+        constexpr int     K = 4, area0 = 40, area1 = 52; // sums of a pass: <= 4 + 6 slots, two areas in turn
+        if(blocked && i + 3 <= area0)
+        {
+            const int               m = i + 1;
+            std::vector<ramd_vec_t> vh((size_t)m);
+            for(int k = 0; k < m; ++k)
+                vh[(size_t)k] = _fh(*v[k]);
+            const int nb = (m + K - 1) / K;
+            for(int b = 0; b < nb; ++b)
+            {
+                const int nc   = std::min(K, m - b * K);
+                const int area = (b & 1) ? area1 : area0, parea = (b & 1) ? area0 : area1;
+                RAMD_CHECK(ramd_fused_mgs_block(w, b > 0 ? &vh[(size_t)(b - 1) * K] : NULL, b > 0 ? K : 0, (b - 1) * K, parea,
+                                                &vh[(size_t)b * K], nc, area));
+                _f_allreduce(A, area, nc + nc * (nc - 1) / 2);
+            }
+            const int nl = m - (nb - 1) * K; // last block: applied, and s[i+1] = <w,w>
+            RAMD_CHECK(ramd_fused_mgs_block(w, &vh[(size_t)(nb - 1) * K], nl, (nb - 1) * K, ((nb - 1) & 1) ? area1 : area0, NULL, 0,
+                                            i + 1));
+            _f_allreduce(A, i + 1, 1);
+            RAMD_CHECK(ramd_fused_normalize(w, i + 1, i + 2)); // s[i+2] = ||w|| ; w /= ||w||
+            std::vector<double> h((size_t)i + 3);
+            RAMD_CHECK(ramd_scalars_fetch(h.data(), 0, i + 3));
+            for(int k = 0; k <= i; ++k)
+                H[this->m_hidx(k, i)] = (ValueType)h[k];
+            H[this->m_hidx(i + 1, i)] = (ValueType)h[i + 2];
+            return true;
+        }
         const ramd_vec_t    v0[1] = {_fh(*v[0])};
         RAMD_CHECK(ramd_fused_multi_dot(v0, 1, w, 0)); // s[0] = <v_0, w>
         _f_allreduce(A, 0, 1);

@@ -299,6 +299,138 @@ __global__ __launch_bounds__(kBlock) void k_mgs_step(int64_t n, T* __restrict__ 
     grid_reduce_finish<1>(ctx, vals, slots, ops, lds);
 }
 
+// Modified Gram-Schmidt in blocks of up to kMgsBlock basis vectors (gmres.cpp:480-486, the same recurrence):
+//   h_m = <v_m, w - sum_{k<m} h_k v_k> = <v_m, w> - sum_{k<m} h_k <v_k, v_m>
+// so ONE pass yields the block's e_m = <v_m, w> and its Gram entries g_km = <v_k, v_m> (measured, not assumed 0), the h_m
+// follow by forward substitution in the prologue of the NEXT pass, which applies  w -= h_0 v_0; w -= h_1 v_1; ...  (the
+// sequential per-element arithmetic of the MGS loop) while it gathers the next block's sums: 2 + 2K vector streams per K
+// projections instead of 4K.  Slots: e_c at slot_e + c, g_cd (c < d) behind them in row-major order of the strict upper
+// triangle; NC == 0: s[slot_e] = <w, w> of the updated w (the norm of the new basis vector).
+constexpr int kMgsBlock = 4;
+template <typename T>
+struct MgsBlockArgs
+{
+    const T* vp[kMgsBlock]; // previous block: applied
+    const T* vc[kMgsBlock]; // current block: projected on
+};
+template <typename T, int NPV, int NC, bool NTW>
+__global__ __launch_bounds__(kBlock) void k_mgs_block(int64_t n, T* __restrict__ w, MgsBlockArgs<T> a, ReduceCtx ctx,
+                                                      int slot_h, int slot_eprev, int slot_e)
+{
+    using P           = typename Pack<T>::type;
+    constexpr int NPK = Pack<T>::N;
+    constexpr int NG  = NC * (NC - 1) / 2;
+    constexpr int NS  = NC == 0 ? 1 : NC + NG;
+    constexpr int U   = (NPV + NC > 5) ? 2 : 4;
+    __shared__ double lds[4 * NS + 4];
+    T mh[NPV > 0 ? NPV : 1];
+    if constexpr(NPV > 0)
+    {
+        double h[NPV];
+        int    g = slot_eprev + NPV;
+#pragma unroll
+        for(int m = 0; m < NPV; ++m)
+            h[m] = ctx.scalars[slot_eprev + m];
+#pragma unroll
+        for(int k = 0; k < NPV; ++k) // column sweep of the forward substitution: row k of the triangle is contiguous
+#pragma unroll
+            for(int m = k + 1; m < NPV; ++m)
+                h[m] -= h[k] * ctx.scalars[g++];
+#pragma unroll
+        for(int m = 0; m < NPV; ++m)
+            mh[m] = -(T)h[m];
+        if(blockIdx.x == 0 && threadIdx.x == 0)
+#pragma unroll
+            for(int m = 0; m < NPV; ++m)
+                ctx.scalars[slot_h + m] = h[m];
+    }
+    double acc[NS];
+#pragma unroll
+    for(int j = 0; j < NS; ++j)
+        acc[j] = 0.0;
+    const int64_t np     = n / NPK;
+    const int64_t stride = (int64_t)gridDim.x * kBlock * U;
+    for(int64_t base = (int64_t)blockIdx.x * kBlock * U + threadIdx.x; base < np; base += stride)
+    {
+        P pw[U], pp[NPV > 0 ? NPV : 1][U], pc[NC > 0 ? NC : 1][U];
+#pragma unroll
+        for(int u = 0; u < U; ++u)
+        {
+            const int64_t i = base + (int64_t)u * kBlock;
+            if(i < np)
+            {
+                pw[u] = (NTW || NPV == 0) ? nt_load(reinterpret_cast<const P*>(w) + i) : reinterpret_cast<P*>(w)[i];
+#pragma unroll
+                for(int q = 0; q < NPV; ++q)
+                    pp[q][u] = nt_load(reinterpret_cast<const P*>(a.vp[q]) + i);
+#pragma unroll
+                for(int c = 0; c < NC; ++c)
+                    pc[c][u] = nt_load(reinterpret_cast<const P*>(a.vc[c]) + i);
+            }
+        }
+#pragma unroll
+        for(int u = 0; u < U; ++u)
+        {
+            const int64_t i = base + (int64_t)u * kBlock;
+            if(i < np)
+            {
+#pragma unroll
+                for(int k = 0; k < NPK; ++k)
+                {
+                    T wn = pk_elems<T>(pw[u])[k];
+#pragma unroll
+                    for(int q = 0; q < NPV; ++q)
+                        wn = wn + mh[q] * pk_elems<T>(pp[q][u])[k];
+                    pk_elems<T>(pw[u])[k] = wn;
+                    if constexpr(NC == 0)
+                        acc[0] += (double)wn * (double)wn;
+                    int g = NC;
+#pragma unroll
+                    for(int c = 0; c < NC; ++c)
+                    {
+                        acc[c] += (double)pk_elems<T>(pc[c][u])[k] * (double)wn;
+#pragma unroll
+                        for(int d = c + 1; d < NC; ++d)
+                            acc[g++] += (double)pk_elems<T>(pc[c][u])[k] * (double)pk_elems<T>(pc[d][u])[k];
+                    }
+                }
+                if constexpr(NPV > 0)
+                    st_pack<NTW>(reinterpret_cast<P*>(w) + i, pw[u]);
+            }
+        }
+    }
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t gsz  = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = np * NPK + gtid; i < n; i += gsz)
+    {
+        T wn = w[i];
+#pragma unroll
+        for(int q = 0; q < NPV; ++q)
+            wn = wn + mh[q] * a.vp[q][i];
+        if constexpr(NPV > 0)
+            w[i] = wn;
+        if constexpr(NC == 0)
+            acc[0] += (double)wn * (double)wn;
+        int g = NC;
+#pragma unroll
+        for(int c = 0; c < NC; ++c)
+        {
+            acc[c] += (double)a.vc[c][i] * (double)wn;
+#pragma unroll
+            for(int d = c + 1; d < NC; ++d)
+                acc[g++] += (double)a.vc[c][i] * (double)a.vc[d][i];
+        }
+    }
+    int slots[NS], ops[NS];
+#pragma unroll
+    for(int j = 0; j < NS; ++j)
+    {
+        slots[j] = slot_e + j;
+        ops[j]   = RED_SUM;
+    }
+    grid_reduce_finish<NS>(ctx, acc, slots, ops, lds);
+}
+
 // v *= 1/sqrt(s[slot_sq]); the norm itself is left in s[slot_norm]   (gmres.cpp:493-496)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_normalize(int64_t n, T* __restrict__ v,
@@ -792,6 +924,74 @@ static int multi_dot_t(const ramd_vec_t* vs, int count, ramd_vec_t w, int slot0)
     return RAMD_OK;
 }
 
+template <typename T>
+static int mgs_block_t(ramd_vec_t w, const ramd_vec_t* vprev, int nprev, int slot_h, int slot_eprev, const ramd_vec_t* vcur,
+                       int ncur, int slot_e, bool ntw)
+{
+    Backend&        b    = backend();
+    const int       grid = grid_reduce(w->n, w->dtype);
+    ReduceCtx       ctx  = reduce_ctx();
+    MgsBlockArgs<T> a;
+    for(int j = 0; j < kMgsBlock; ++j)
+    {
+        a.vp[j] = nprev > 0 ? (const T*)vprev[std::min(j, nprev - 1)]->d : nullptr;
+        a.vc[j] = ncur > 0 ? (const T*)vcur[std::min(j, ncur - 1)]->d : nullptr;
+    }
+#define GO2(NPV, NC)                                                                                              \
+    do                                                                                                            \
+    {                                                                                                             \
+        if(ntw)                                                                                                   \
+            hipLaunchKernelGGL((k_mgs_block<T, NPV, NC, true>), dim3(grid), dim3(kBlock), 0, b.cur, w->n, (T*)w->d, a, ctx, \
+                               slot_h, slot_eprev, slot_e);                                                       \
+        else                                                                                                      \
+            hipLaunchKernelGGL((k_mgs_block<T, NPV, NC, false>), dim3(grid), dim3(kBlock), 0, b.cur, w->n, (T*)w->d, a, ctx, \
+                               slot_h, slot_eprev, slot_e);                                                       \
+    } while(0)
+#define GO_NC(NPV)      \
+    switch(ncur)        \
+    {                   \
+    case 1:             \
+        GO2(NPV, 1);    \
+        break;          \
+    case 2:             \
+        GO2(NPV, 2);    \
+        break;          \
+    case 3:             \
+        GO2(NPV, 3);    \
+        break;          \
+    default:            \
+        GO2(NPV, 4);    \
+        break;          \
+    }
+    prof_begin(RAMD_PROF_VEC, b.cur);
+    if(nprev == 0)
+        GO_NC(0)
+    else if(ncur > 0) // (a block before another one is always full)
+        GO_NC(4)
+    else
+        switch(nprev)
+        {
+        case 1:
+            GO2(1, 0);
+            break;
+        case 2:
+            GO2(2, 0);
+            break;
+        case 3:
+            GO2(3, 0);
+            break;
+        default:
+            GO2(4, 0);
+            break;
+        }
+    prof_end(RAMD_PROF_VEC, b.cur);
+#undef GO_NC
+#undef GO2
+    RAMD_HIP(hipGetLastError());
+    return RAMD_OK;
+}
+
+
 extern "C" {
 
 int ramd_fused_multi_dot(const ramd_vec_t* vs, int count, ramd_vec_t w, int slot0)
@@ -855,6 +1055,43 @@ int ramd_fused_mgs_step(ramd_vec_t w, ramd_vec_t v, int slot_h, ramd_vec_t u, in
 #undef GO
     RAMD_HIP(hipGetLastError());
     return RAMD_OK;
+}
+
+int ramd_fused_mgs_block(ramd_vec_t w, const ramd_vec_t* vprev, int nprev, int slot_h, int slot_eprev,
+                         const ramd_vec_t* vcur, int ncur, int slot_e)
+{
+    if(!w || nprev < 0 || ncur < 0 || nprev > kMgsBlock || ncur > kMgsBlock || (nprev == 0 && ncur == 0)
+       || (nprev > 0 && !vprev) || (ncur > 0 && !vcur) || (nprev > 0 && ncur > 0 && nprev != kMgsBlock))
+        RAMD_FAIL(RAMD_ERR_ARG, "fused_mgs_block: bad arguments (blocks of 1..4 vectors; a block followed by another is full)");
+    const int nsum = ncur == 0 ? 1 : ncur + ncur * (ncur - 1) / 2;
+    if(!slot_ok(slot_e) || !slot_ok(slot_e + nsum - 1))
+        RAMD_FAIL(RAMD_ERR_ARG, "scalar slot out of range");
+    if(nprev > 0)
+    {
+        const int nprevsum = nprev + nprev * (nprev - 1) / 2;
+        if(!slot_ok(slot_h) || !slot_ok(slot_h + nprev - 1) || !slot_ok(slot_eprev) || !slot_ok(slot_eprev + nprevsum - 1))
+            RAMD_FAIL(RAMD_ERR_ARG, "scalar slot out of range");
+        // (the sums of this pass must not land on what its prologue still reads)
+        if(slot_e < slot_eprev + nprevsum && slot_eprev < slot_e + nsum)
+            RAMD_FAIL(RAMD_ERR_ARG, "fused_mgs_block: the two slot areas overlap");
+    }
+    for(int j = 0; j < nprev; ++j)
+        CHECK_SAMEV(vprev[j], w);
+    for(int j = 0; j < ncur; ++j)
+        CHECK_SAMEV(vcur[j], w);
+    if(w->n == 0)
+    {
+        for(int j = 0; j < nsum; ++j)
+            RAMD_TRY(ramd_scalars_set(slot_e + j, 0.0));
+        return RAMD_OK;
+    }
+    static const int ntw_env = getenv("RAMD_MGS_NT") ? atoi(getenv("RAMD_MGS_NT")) : -1; // (0 / 1: force, A/B experiments)
+    const bool       ntw     = ntw_env >= 0 ? ntw_env != 0 : (int64_t)w->n * 8 > (int64_t)256 * 1024 * 1024;
+    if(w->dtype == RAMD_F64)
+        return mgs_block_t<double>(w, vprev, nprev, slot_h, slot_eprev, vcur, ncur, slot_e, ntw);
+    if(w->dtype == RAMD_F32)
+        return mgs_block_t<float>(w, vprev, nprev, slot_h, slot_eprev, vcur, ncur, slot_e, ntw);
+    RAMD_FAIL(RAMD_ERR_ARG, "fused_mgs_block needs real vectors");
 }
 
 int ramd_fused_normalize(ramd_vec_t v, int slot_sq, int slot_norm)

@@ -873,3 +873,85 @@ def test_fused_multi_axpy_equals_the_addscale_sequence(ra, dtype, count):
     cs = (C.c_double * count)(*[float(dtype(c)) for c in coef])
     capi.check(lib.ramd_fused_multi_axpy(b._h, hs, cs, count))
     assert np.array_equal(a.numpy(), b.numpy())
+
+
+def _mgs_sequential(lib, capi, w, vs, m):
+    """the one-projection-per-pass path: multi_dot + m mgs_step launches; returns h[0..m-1], <w,w>"""
+    first = (capi.vec_t * 1)(vs[0]._h)
+    capi.check(lib.ramd_fused_multi_dot(first, 1, w._h, 0))
+    for k in range(m):
+        capi.check(lib.ramd_fused_mgs_step(w._h, vs[k]._h, k, vs[k + 1]._h if k + 1 < m else None, k + 1))
+    out = np.zeros(m + 1)
+    capi.check(lib.ramd_scalars_fetch(out.ctypes.data_as(capi.pf64), 0, m + 1))
+    return out
+
+
+def _mgs_blocked(lib, capi, w, vs, m):
+    """ramd_fused_mgs_block exactly as GMRES::doFusedMGS drives it (include/rocalution/solvers.hpp)"""
+    K, areas = 4, (40, 52)
+    hs = (capi.vec_t * m)(*[v._h for v in vs[:m]])
+    import ctypes as C
+    at = lambda k: C.cast(C.byref(hs, k * C.sizeof(capi.vec_t)), C.POINTER(capi.vec_t))
+    nb = (m + K - 1) // K
+    for b in range(nb):
+        nc = min(K, m - b * K)
+        capi.check(lib.ramd_fused_mgs_block(w._h, at((b - 1) * K) if b else None, K if b else 0, (b - 1) * K,
+                                            areas[(b - 1) & 1], at(b * K), nc, areas[b & 1]))
+    nl = m - (nb - 1) * K
+    capi.check(lib.ramd_fused_mgs_block(w._h, at((nb - 1) * K), nl, (nb - 1) * K, areas[(nb - 1) & 1], None, 0, m))
+    out = np.zeros(m + 1)
+    capi.check(lib.ramd_scalars_fetch(out.ctypes.data_as(capi.pf64), 0, m + 1))
+    return out
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("m", [1, 2, 4, 5, 8, 11, 30])
+@pytest.mark.parametrize("basis", ["orthonormal", "oblique"])
+def test_fused_mgs_block_is_the_mgs_recurrence(ra, dtype, m, basis):
+    """ramd_fused_mgs_block (four projections per pass; GMRES Arnoldi, gmres.cpp:480-486) against the one-projection-
+    per-pass kernels and a float64 numpy MGS.  `oblique`: basis vectors far from orthogonal -- the block form measures
+    their Gram entries, it does not assume an orthonormal basis.  Tolerance: the h of the two forms differ by rounding
+    only, a few ulp of ||w|| (1e-13 / 2e-5 relative to ||w|| for fp64 / fp32, fp32 sums being accumulated in fp64)."""
+    from rocalution_amd import capi
+    lib = capi.load()
+    n = 100003
+    rng = np.random.default_rng(100 * m + (basis == "oblique"))
+    V = rng.uniform(-1, 1, (n, m))
+    if basis == "orthonormal":
+        V, _ = np.linalg.qr(V)
+    else:
+        V /= np.linalg.norm(V, axis=0)
+    w0 = rng.uniform(-1, 1, n)
+    vs = [ra.LocalVector(dtype, data=np.ascontiguousarray(V[:, k]).astype(dtype)) for k in range(m)]
+    wa = ra.LocalVector(dtype, data=w0.astype(dtype))
+    wb = ra.LocalVector(dtype, data=w0.astype(dtype))
+    ha = _mgs_sequential(lib, capi, wa, vs, m)
+    hb = _mgs_blocked(lib, capi, wb, vs, m)
+    # numpy MGS on the rounded inputs
+    wr = w0.astype(dtype).astype(np.float64)
+    href = np.zeros(m + 1)
+    for k in range(m):
+        vk = vs[k].numpy().astype(np.float64)
+        href[k] = vk @ wr
+        wr = wr - href[k] * vk
+    href[m] = wr @ wr
+    scale = np.linalg.norm(w0)
+    tol = (1e-13 if dtype == np.float64 else 2e-5) * (1.0 if basis == "orthonormal" else 20.0)
+    assert np.max(np.abs(hb[:m] - ha[:m])) <= tol * scale, (hb, ha)
+    assert np.max(np.abs(hb[:m] - href[:m])) <= tol * scale
+    assert abs(hb[m] - ha[m]) <= 4 * tol * scale * scale and abs(hb[m] - href[m]) <= 4 * tol * scale * scale
+    assert np.max(np.abs(wb.numpy().astype(np.float64) - wa.numpy().astype(np.float64))) <= tol * scale
+    assert np.max(np.abs(wb.numpy().astype(np.float64) - wr)) <= tol * scale
+
+
+def test_fused_mgs_block_rejects_bad_arguments(ra):
+    from rocalution_amd import capi
+    lib = capi.load()
+    v = [ra.LocalVector(np.float64, data=np.ones(64)) for _ in range(5)]
+    w = ra.LocalVector(np.float64, data=np.ones(64))
+    hs = (capi.vec_t * 5)(*[x._h for x in v])
+    assert lib.ramd_fused_mgs_block(w._h, None, 0, 0, 0, None, 0, 0) != 0           # nothing to do
+    assert lib.ramd_fused_mgs_block(w._h, None, 0, 0, 0, hs, 5, 0) != 0             # block too long
+    assert lib.ramd_fused_mgs_block(w._h, hs, 3, 0, 40, hs, 2, 52) != 0             # a followed block must be full
+    assert lib.ramd_fused_mgs_block(w._h, hs, 4, 0, 40, hs, 4, 44) != 0             # overlapping slot areas
+    assert lib.ramd_fused_mgs_block(w._h, None, 0, 0, 0, hs, 4, 60) != 0            # sums beyond the record
