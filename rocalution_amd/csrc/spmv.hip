@@ -217,47 +217,61 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) 
 }
 
 // CSR SpMV for LONG rows (mean row length > 16: FE matrices with several unknowns per node, 27-point stencils).
-// With one thread per row a 2048-entry LDS pass holds only 2048 / row_length rows, so 3 of 4 threads idle in the row walk
-// of 35-entry rows (k_csr_tr: 4.1 TB/s = 51 % on the af_shell10-class matrix).  Here a workgroup owns R = 2048 / mean row
-// length rows (16 <= R <= 256), streams their entries through LDS the same way, and then
-//   1. ALL 256 threads gather x and form the products of the pass, entry e of the pass by thread e % 256 (eight
-//      independent gathers per thread in flight); consecutive lanes take consecutive entries of a row, whose columns
-//      are mostly contiguous in such matrices (the unknowns of one node) -> few cache lines per gather instruction;
-//      the product replaces the value in LDS;
-//   2. thread t < R adds the products of ITS row left to right -- the same roundings in the same order as the host loop
-//      (product rounded, then added; no FMA), so the result stays bit-identical.
-template <typename T, int MODE, bool DOT>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_csr_prod(int nrow, int R, int nblk,
-                                                   int per_xcd, const int* __restrict__ rp,
-                                                   const int* __restrict__ ci,
-                                                   const T* __restrict__ val,
-                                                   const T* __restrict__ x, T* __restrict__ y, T scalar,
-                                                   CsrDotWs ws, int slot)
+// With one thread per row a 2048-entry LDS pass holds only 2048 / row_length rows, so 3 of 4 lanes idle in the row walk
+// of 35-entry rows and every gather instruction carries 16 addresses (k_csr_tr: 4.1 TB/s = 51 % on the af_shell10-class
+// matrix).  Here FOUR lanes share a row: the same raw stream of the workgroup's entries through LDS, then quad q walks the
+// rows q, q+64, ... that intersect the pass; lane l gathers x for the entries l, l+4, ... of its row (consecutive lanes =
+// consecutive entries, whose columns are mostly the unknowns of one node: few lines per gather instruction, all 64 lanes
+// busy) and forms the rounded product; the row sum is then taken IN STORAGE ORDER by every lane of the quad from the
+// quad-broadcast products (DPP quad_perm: no LDS round trip) -- the same roundings in the same order as the host loop.
+// A row that straddles two passes carries its running sum in LDS.
+template <int E, typename T>
+__device__ __forceinline__ T quad_bcast(T v)
 {
-    using VP          = typename ValPk<T>::type;
-    constexpr int VN  = ValPk<T>::N;
-    __shared__ T      sval[kCsrChunk];
-    __shared__ int    scol[kCsrChunk];
-    const BandMap bm0 = {0, 0, 0};
-    const int     blk = xcd_block(nblk, per_xcd, bm0);
+    constexpr int ctrl = E * 85; // quad_perm [E, E, E, E]
+    if constexpr(sizeof(T) == 8)
+    {
+        const long long b  = __builtin_bit_cast(long long, v);
+        const int       lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffll), ctrl, 0xf, 0xf, true);
+        const int       hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), ctrl, 0xf, 0xf, true);
+        return __builtin_bit_cast(T, ((long long)hi << 32) | (long long)(unsigned)lo);
+    }
+    else
+        return __builtin_bit_cast(T, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true));
+}
+constexpr int kQ4Batch = 4; // gathers in flight per lane (16 entries of a row per batch)
+template <typename T, int MODE, bool DOT>
+__global__ __launch_bounds__(kBlock) void k_csr_q4(int nrow, int nblk, int per_xcd, const int* __restrict__ rp,
+                                                   const int* __restrict__ ci, const T* __restrict__ val,
+                                                   const T* __restrict__ x, T* __restrict__ y, T scalar, CsrDotWs ws,
+                                                   int slot)
+{
+    using VP         = typename ValPk<T>::type;
+    constexpr int VN = ValPk<T>::N;
+    __shared__ T   sval[kCsrChunk];
+    __shared__ int scol[kCsrChunk];
+    __shared__ int srp[kCsrRows + 1];
+    __shared__ T   ssum[kCsrRows];
+    const BandMap bm0  = {0, 0, 0};
+    const int     blk  = xcd_block(nblk, per_xcd, bm0);
     double        dacc = 0.0;
     if(blk >= 0)
     {
-        const int  r0    = blk * R;
-        const int  rend  = min(r0 + R, nrow);
-        const int  row   = r0 + threadIdx.x;
-        const bool owner = (int)threadIdx.x < R && row < nrow;
-        int        rs = 0, re = 0;
-        if(owner)
+        const int r0   = blk * kCsrRows;
+        const int rend = min(r0 + kCsrRows, nrow);
+        const int nr   = rend - r0;
+        const int row  = r0 + threadIdx.x;
+        if((int)threadIdx.x < nr)
         {
-            rs = rp[row];
-            re = rp[row + 1];
+            srp[threadIdx.x]  = rp[row];
+            ssum[threadIdx.x] = (MODE == 1) ? y[row] : (T)0;
         }
-        const int start = rp[r0];
-        const int end   = rp[rend];
-        T         sum   = (T)0;
-        if(MODE == 1 && owner)
-            sum = y[row];
+        if(threadIdx.x == 0)
+            srp[nr] = rp[rend];
+        __syncthreads();
+        const int start = srp[0];
+        const int end   = srp[nr];
+        const int q = threadIdx.x >> 2, l = threadIdx.x & 3;
         for(int cb = start & ~3; cb < end; cb += kCsrChunk)
         {
             v4i32 c[kCsrChunk / (4 * kBlock)];
@@ -291,41 +305,63 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) 
                     *reinterpret_cast<VP*>(sval + g) = a[k];
             }
             __syncthreads();
-            // 1. products of the pass, all threads
+            for(int r = q; r < nr; r += kBlock / 4)
             {
-                constexpr int kPer = kCsrChunk / kBlock;
-                int           cc[kPer];
-                T             xv[kPer];
-#pragma unroll
-                for(int k = 0; k < kPer; ++k)
+                const int lo = max(srp[r], cb), hi = min(srp[r + 1], cb + kCsrChunk);
+                if(lo >= hi)
+                    continue;
+                T sum = ssum[r];
+                for(int j = lo; j < hi; j += 4 * kQ4Batch)
                 {
-                    const int g = k * kBlock + threadIdx.x;
-                    cc[k]       = (cb + g >= start && cb + g < end) ? scol[g] : -1;
-                }
+                    int cc[kQ4Batch];
+                    T   p[kQ4Batch], xv[kQ4Batch];
 #pragma unroll
-                for(int k = 0; k < kPer; ++k)
-                    if(cc[k] >= 0)
-                        xv[k] = x[cc[k]];
-#pragma unroll
-                for(int k = 0; k < kPer; ++k)
-                    if(cc[k] >= 0)
+                    for(int e = 0; e < kQ4Batch; ++e)
                     {
-                        const int g = k * kBlock + threadIdx.x;
-                        sval[g]     = (MODE != 1) ? sval[g] * xv[k] : scalar * sval[g] * xv[k];
+                        const int jj = j + 4 * e + l;
+                        cc[e]        = -1;
+                        if(jj < hi)
+                        {
+                            cc[e] = scol[jj - cb];
+                            p[e]  = sval[jj - cb];
+                        }
                     }
-            }
-            __syncthreads();
-            // 2. ordered row sums
-            if(owner)
-            {
-                const int lo = max(rs, cb), hi = min(re, cb + kCsrChunk);
-                for(int j = lo; j < hi; ++j)
-                    sum += sval[j - cb];
+#pragma unroll
+                    for(int e = 0; e < kQ4Batch; ++e)
+                        if(cc[e] >= 0)
+                            xv[e] = x[cc[e]];
+#pragma unroll
+                    for(int e = 0; e < kQ4Batch; ++e)
+                    {
+                        if(cc[e] >= 0)
+                            p[e] = (MODE != 1) ? p[e] * xv[e] : scalar * p[e] * xv[e];
+                        const int left = hi - (j + 4 * e); // entries of this group of four (quad-uniform)
+                        if(left >= 4)
+                        {
+                            sum += quad_bcast<0>(p[e]);
+                            sum += quad_bcast<1>(p[e]);
+                            sum += quad_bcast<2>(p[e]);
+                            sum += quad_bcast<3>(p[e]);
+                        }
+                        else if(left > 0)
+                        {
+                            const T b0 = quad_bcast<0>(p[e]), b1 = quad_bcast<1>(p[e]), b2 = quad_bcast<2>(p[e]);
+                            sum += b0;
+                            if(left > 1)
+                                sum += b1;
+                            if(left > 2)
+                                sum += b2;
+                        }
+                    }
+                }
+                if(l == 0)
+                    ssum[r] = sum;
             }
             __syncthreads();
         }
-        if(owner)
+        if((int)threadIdx.x < nr)
         {
+            T sum = ssum[threadIdx.x];
             if(MODE == 2)
             {
                 T t = (T)(-1) * sum + static_cast<const T*>(ws.jrhs)[row];
@@ -418,6 +454,8 @@ __global__ __launch_bounds__(kBlock) void k_ell(int nrow, int ncol, int width,
             part1[blk * (kBlock / 64) + (threadIdx.x >> 6)] = wsum;
     }
 }
+
+
 
 // DIA (host_matrix_dia.cpp:300-412): one thread per row, diagonal d contributes val[d*nrow + row] * x[row + offset_d]
 // when 0 <= row + offset_d < nrow (the host's start/end/break tests for ascending offsets); padded zeros ARE
@@ -583,26 +621,17 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
                       const T* dotv = nullptr, const T* jdinv = nullptr, const T* jrhs = nullptr)
 {
     Backend&  b = backend();
-    // long rows (mean > 16 entries): the product-stream kernel with R rows per workgroup (see k_csr_prod)
-    static int prod_on = -1;
-    if(prod_on < 0)
-        prod_on = getenv("RAMD_CSR_PROD") ? atoi(getenv("RAMD_CSR_PROD")) : 0; // measured slower so far (r02d): off
-    int rows_per_wg = kCsrRows;
-    if(prod_on && m->nrow > 0 && m->nnz > (int64_t)16 * m->nrow)
-    {
-        const int64_t mean = m->nnz / m->nrow;
-        rows_per_wg        = 256;
-        while(rows_per_wg > 16 && (int64_t)rows_per_wg * mean > kCsrChunk + kCsrChunk / 8)
-            rows_per_wg >>= 1;
-    }
-    const bool prod    = rows_per_wg != kCsrRows;
+    // long rows (mean > 16 entries): four lanes per row (see k_csr_q4)
+    static const int q4_env = getenv("RAMD_CSR_Q4") ? atoi(getenv("RAMD_CSR_Q4")) : -1; // (0 / 1: force, A/B experiments)
+    const int        rows_per_wg = kCsrRows;
+    const bool q4      = q4_env > 0; // measured EQUAL to k_csr_tr on the shell surrogate (0.162 vs 0.160 ms): opt-in
     const int  nblk    = (m->nrow + rows_per_wg - 1) / rows_per_wg;
     const int  per_xcd = (nblk + 7) / 8;
     const int  grid    = per_xcd * 8;
     CsrDotWs   ws      = {};
-    if(!prod && m->band_dist < 0)
+    if(!q4 && m->band_dist < 0)
         RAMD_TRY(csr_analyse_band(const_cast<ramd_mat_s*>(m)));
-    const BandMap bm = prod ? BandMap{0, 0, 0} : band_map_for(m, per_xcd);
+    const BandMap bm = q4 ? BandMap{0, 0, 0} : band_map_for(m, per_xcd);
     if(dot)
     {
         ramd_mat_s* mm = const_cast<ramd_mat_s*>(m);
@@ -620,10 +649,9 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
 #define LAUNCH(MODE, DOT)                                                                                  \
     do                                                                                                     \
     {                                                                                                      \
-        if(prod)                                                                                           \
-            hipLaunchKernelGGL((k_csr_prod<T, MODE, DOT>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow,     \
-                               rows_per_wg, nblk, per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, \
-                               slot);                                                                      \
+        if(q4)                                                                                             \
+            hipLaunchKernelGGL((k_csr_q4<T, MODE, DOT>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
+                               per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot);           \
         else                                                                                               \
             hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
                                per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm);       \

@@ -955,3 +955,20 @@ def test_fused_mgs_block_rejects_bad_arguments(ra):
     assert lib.ramd_fused_mgs_block(w._h, hs, 3, 0, 40, hs, 2, 52) != 0             # a followed block must be full
     assert lib.ramd_fused_mgs_block(w._h, hs, 4, 0, 40, hs, 4, 44) != 0             # overlapping slot areas
     assert lib.ramd_fused_mgs_block(w._h, None, 0, 0, 0, hs, 4, 60) != 0            # sums beyond the record
+
+
+@pytest.mark.parametrize("variant", ["RAMD_CSR_Q4=1"])
+def test_csr_spmv_variants_forced_in_a_fresh_process(variant):
+    """the CSR SpMV has an opt-in four-lanes-per-row walk (k_csr_q4); forced on for EVERY matrix of the SpMV / ApplyAdd /
+    fused-dot / Jacobi-sweep tests: results must not change (bit-exact: the row sum stays in storage order)"""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ)
+    env[variant.split("=")[0]] = variant.split("=")[1]
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_kernels.py"),
+                        os.path.join(here, "test_gpu_edge_cases.py"), "-q", "-m", "gpu", "-x", "-k",
+                        "(spmv or csr or apply or fused_bicgstab or golden) and not fresh_process"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
