@@ -439,20 +439,21 @@ def main():
             # fused vector kernels: CG 40 n B per launch (k_cg_update / k_cg_direction: 3 reads + 2 writes),
             # GMRES k_mgs_step 32 n B (3 reads + 1 write)
             if args.solver == "gmres" and os.environ.get("RAMD_MGS_BLOCK", "1") != "0":
-                # k_mgs_block, four projections per pass (GMRES::doFusedMGS): Arnoldi step with m basis vectors =
-                # first pass 1 + nc streams (w only read), later passes 2 + 4 + nc, last pass 2 + nl (+ <w,w>);
+                # k_mgs_block, KB projections per pass (GMRES::doFusedMGS): Arnoldi step with m basis vectors =
+                # first pass 1 + nc streams (w only read), later passes 2 + KB + nc, last pass 2 + nl (+ <w,w>);
                 # the bracketed run did it_prof iterations of restart cycles of `basis`
+                KB = lib.ramd_fused_mgs_block_max()
                 it_prof, streams, launches = (min(K, 20) if mixed else min(K, 200)), 0, 0
                 for j in range(it_prof):
                     m = j % basis + 1
-                    nb = (m + 3) // 4
+                    nb = (m + KB - 1) // KB
                     for b in range(nb):
-                        nc = min(4, m - 4 * b)
-                        streams += (1 + nc) if b == 0 else (6 + nc)
-                    streams += 2 + (m - 4 * (nb - 1))
+                        nc = min(KB, m - KB * b)
+                        streams += (1 + nc) if b == 0 else (2 + KB + nc)
+                    streams += 2 + (m - KB * (nb - 1))
                     launches += nb + 1
                 launches = p_vec["launches"] or launches  # (the same count unless the iteration control stopped early)
-                kernels["vector_updates"] = roof("k_mgs_block (modified Gram-Schmidt, four projections per pass; average over the "
+                kernels["vector_updates"] = roof("k_mgs_block (modified Gram-Schmidt, %d projections per pass; average over the " % KB +
                                                  "passes of the restart cycles)", streams * n * vb // launches, p_vec)
             else:
                 kernels["vector_updates"] = roof("k_mgs_step" if args.solver == "gmres" else "k_cg_update / k_cg_direction",

@@ -1751,11 +1751,13 @@ private:
         VectorType**        v = this->m_v;
         ValueType*          H = this->m_H.data();
         ramd_vec_t          w = _fh(*v[i + 1]);
-        // Blocks of four projections per pass (ramd_fused_mgs_block: the same recurrence with the block's Gram entries
-        // measured in the pass, h by forward substitution on the device): 2 + 2*4 vector streams per four projections
-        // instead of 16, and one all-reduce per block.  RAMD_MGS_BLOCK=0: one projection per pass (below).
+        // Blocks of K (= 4) projections per pass (ramd_fused_mgs_block: the same recurrence with the block's Gram entries
+        // measured in the pass, h by forward substitution on the device): 2 + 2K vector streams per K projections instead
+        // of 4K, and one all-reduce per block.  RAMD_MGS_BLOCK=0: one projection per pass (below).
         static const bool blocked = !(std::getenv("RAMD_MGS_BLOCK") && std::atoi(std::getenv("RAMD_MGS_BLOCK")) == 0);
-        constexpr int     K = 4, area0 = 40, area1 = 52; // sums of a pass: <= 4 + 6 slots, two areas in turn
+        static const int  K       = ramd_fused_mgs_block_max();
+        const int         nsum    = K + K * (K - 1) / 2; // sums of a pass; two areas in turn at the top of the record
+        const int         area1 = RAMD_NSCALARS - 4 - nsum, area0 = area1 - nsum;
         if(blocked && i + 3 <= area0)
         {
             const int               m = i + 1;

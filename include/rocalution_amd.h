@@ -209,7 +209,7 @@ int ramd_mat_gen_poisson7_slab(ramd_mat_t interior, ramd_mat_t ghost, int N, int
  * RAMD_NSCALARS doubles; ramd_scalars_fetch copies a record to the host (blocking on the
  * stream).  Element-wise arithmetic is the reference's expression for each op, so results
  * equal the unfused sequence except for the summation order of the reductions. */
-enum { RAMD_NSCALARS = 64 };
+enum { RAMD_NSCALARS = 128 };
 int ramd_scalars_set(int slot, double value);
 int ramd_scalars_fetch(double* host, int first, int count);
 int ramd_scalars_fetch_async_begin(int record, int first, int count); /* record in 0..7 */
@@ -271,13 +271,15 @@ int ramd_fused_multi_axpy(ramd_vec_t x, const ramd_vec_t* vs, const double* coef
 /* w += (-h) v ; s[slot_dot] = <u, w>   (one MGS step fused with the next dot, gmres.cpp:480-486);
  * h is read from s[slot_h]; u may be NULL (then only the update and s[slot_dot]=<w,w>) */
 int ramd_fused_mgs_step(ramd_vec_t w, ramd_vec_t v, int slot_h, ramd_vec_t u, int slot_dot);
-/* the same MGS recurrence (gmres.cpp:480-486) in blocks of up to 4 basis vectors, one pass per block:
+/* the same MGS recurrence (gmres.cpp:480-486) in blocks of up to ramd_fused_mgs_block_max() (4 in the shipped build, at most 8) basis vectors, one pass
+ * per block:
  *   h_m = <v_m, w - sum_{k<m} h_k v_k> = <v_m, w> - sum_{k<m} h_k <v_k, v_m>
  * The pass first solves the PREVIOUS block's h from the sums its pass left at s[slot_eprev ...] (e_0..e_{nprev-1}, then
  * the strict upper triangle of the block's Gram matrix, row-major), stores them at s[slot_h ...] and applies
  * w -= h_0 vprev_0; w -= h_1 vprev_1; ... (per element, in this order); then it leaves the sums of the CURRENT block at
  * s[slot_e ...] in the same layout (ncur + ncur(ncur-1)/2 slots).  nprev == 0: first block (w is only read);
- * ncur == 0: last pass, s[slot_e] = <w, w> of the updated w.  A block that is followed by another holds 4 vectors. */
+ * ncur == 0: last pass, s[slot_e] = <w, w> of the updated w.  A block that is followed by another is full. */
+int ramd_fused_mgs_block_max(void);
 int ramd_fused_mgs_block(ramd_vec_t w, const ramd_vec_t* vprev, int nprev, int slot_h, int slot_eprev,
                          const ramd_vec_t* vcur, int ncur, int slot_e);
 /* v = v * (1/s[slot]) with s[slot] = sqrt(s[slot_sq]) computed on device (gmres.cpp:493-496) */

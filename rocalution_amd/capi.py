@@ -170,6 +170,7 @@ SIGNATURES = {
     "ramd_fused_multi_dot": (i32, [C.POINTER(vec_t), i32, vec_t, i32]),
     "ramd_fused_multi_axpy": (i32, [vec_t, C.POINTER(vec_t), pf64, i32]),
     "ramd_fused_mgs_step": (i32, [vec_t, vec_t, i32, vec_t, i32]),
+    "ramd_fused_mgs_block_max": (i32, []),
     "ramd_fused_mgs_block": (i32, [vec_t, C.POINTER(vec_t), i32, i32, i32, C.POINTER(vec_t), i32, i32]),
     "ramd_fused_normalize": (i32, [vec_t, i32, i32]),
     # measurement hooks

@@ -54,7 +54,7 @@ const char* last_error();
 // Three streams mirror the reference's default / interior / ghost choreography
 // (src/base/hip/backend_hip.cpp:358-410); `cur` is what every op launches on.
 constexpr int kReduceBlocks  = 8192; // partial sums per reduction launch (32 workgroups per CU: tools/membench.hip)
-constexpr int kScalarSlots   = 64; // doubles per scalar record
+constexpr int kScalarSlots   = 128; // doubles per scalar record
 constexpr int kScalarRecords = 8; // ring of records in host-mapped memory
 
 struct Backend

@@ -305,8 +305,16 @@ __global__ __launch_bounds__(kBlock) void k_mgs_step(int64_t n, T* __restrict__ 
 // follow by forward substitution in the prologue of the NEXT pass, which applies  w -= h_0 v_0; w -= h_1 v_1; ...  (the
 // sequential per-element arithmetic of the MGS loop) while it gathers the next block's sums: 2 + 2K vector streams per K
 // projections instead of 4K.  Slots: e_c at slot_e + c, g_cd (c < d) behind them in row-major order of the strict upper
-// triangle; NC == 0: s[slot_e] = <w, w> of the updated w (the norm of the new basis vector).
-constexpr int kMgsBlock = 4;
+// triangle; NC == 0: s[slot_e] = <w, w> of the updated w (the norm of the new basis vector).  The sums are accumulated with
+// fused multiply-adds (the 44 products per element of a block of 8 are otherwise 88 fp64 operations); the update of w is
+// NOT fused: it is the AddScale expression of the host loop, rounded as there.
+// Block size: measured at 512^3 (GMRES(30), iterations/s) 4: 56.5, 5: 55.2, 6: 55.9, 8: 56.3 -- longer blocks move fewer
+// bytes (38.8 instead of 42.5 vector streams per Arnoldi step on average at 8) but their passes run at 4.9 instead of
+// 5.3 TB/s (17 read streams at once, 164 VGPRs), which cancels the saving; 4 keeps the kernels small.
+#ifndef RAMD_MGS_K
+#define RAMD_MGS_K 4
+#endif
+constexpr int kMgsBlock = RAMD_MGS_K; // (<= 8; 36 sums per pass at 8)
 template <typename T>
 struct MgsBlockArgs
 {
@@ -321,7 +329,7 @@ __global__ __launch_bounds__(kBlock) void k_mgs_block(int64_t n, T* __restrict__
     constexpr int NPK = Pack<T>::N;
     constexpr int NG  = NC * (NC - 1) / 2;
     constexpr int NS  = NC == 0 ? 1 : NC + NG;
-    constexpr int U   = (NPV + NC > 5) ? 2 : 4;
+    constexpr int U   = (NPV + NC > 9) ? 1 : (NPV + NC > 5) ? 2 : 4;
     __shared__ double lds[4 * NS + 4];
     T mh[NPV > 0 ? NPV : 1];
     if constexpr(NPV > 0)
@@ -383,15 +391,18 @@ __global__ __launch_bounds__(kBlock) void k_mgs_block(int64_t n, T* __restrict__
                         wn = wn + mh[q] * pk_elems<T>(pp[q][u])[k];
                     pk_elems<T>(pw[u])[k] = wn;
                     if constexpr(NC == 0)
-                        acc[0] += (double)wn * (double)wn;
+                        acc[0] = __builtin_fma((double)wn, (double)wn, acc[0]);
                     int g = NC;
 #pragma unroll
                     for(int c = 0; c < NC; ++c)
                     {
-                        acc[c] += (double)pk_elems<T>(pc[c][u])[k] * (double)wn;
+                        acc[c] = __builtin_fma((double)pk_elems<T>(pc[c][u])[k], (double)wn, acc[c]);
 #pragma unroll
                         for(int d = c + 1; d < NC; ++d)
-                            acc[g++] += (double)pk_elems<T>(pc[c][u])[k] * (double)pk_elems<T>(pc[d][u])[k];
+                            {
+                            acc[g] = __builtin_fma((double)pk_elems<T>(pc[c][u])[k], (double)pk_elems<T>(pc[d][u])[k], acc[g]);
+                            ++g;
+                        }
                     }
                 }
                 if constexpr(NPV > 0)
@@ -410,7 +421,7 @@ __global__ __launch_bounds__(kBlock) void k_mgs_block(int64_t n, T* __restrict__
         if constexpr(NPV > 0)
             w[i] = wn;
         if constexpr(NC == 0)
-            acc[0] += (double)wn * (double)wn;
+            acc[0] = __builtin_fma((double)wn, (double)wn, acc[0]);
         int g = NC;
 #pragma unroll
         for(int c = 0; c < NC; ++c)
@@ -937,56 +948,49 @@ static int mgs_block_t(ramd_vec_t w, const ramd_vec_t* vprev, int nprev, int slo
         a.vp[j] = nprev > 0 ? (const T*)vprev[std::min(j, nprev - 1)]->d : nullptr;
         a.vc[j] = ncur > 0 ? (const T*)vcur[std::min(j, ncur - 1)]->d : nullptr;
     }
-#define GO2(NPV, NC)                                                                                              \
-    do                                                                                                            \
-    {                                                                                                             \
-        if(ntw)                                                                                                   \
-            hipLaunchKernelGGL((k_mgs_block<T, NPV, NC, true>), dim3(grid), dim3(kBlock), 0, b.cur, w->n, (T*)w->d, a, ctx, \
-                               slot_h, slot_eprev, slot_e);                                                       \
-        else                                                                                                      \
-            hipLaunchKernelGGL((k_mgs_block<T, NPV, NC, false>), dim3(grid), dim3(kBlock), 0, b.cur, w->n, (T*)w->d, a, ctx, \
-                               slot_h, slot_eprev, slot_e);                                                       \
-    } while(0)
-#define GO_NC(NPV)      \
-    switch(ncur)        \
-    {                   \
-    case 1:             \
-        GO2(NPV, 1);    \
-        break;          \
-    case 2:             \
-        GO2(NPV, 2);    \
-        break;          \
-    case 3:             \
-        GO2(NPV, 3);    \
-        break;          \
-    default:            \
-        GO2(NPV, 4);    \
-        break;          \
-    }
     prof_begin(RAMD_PROF_VEC, b.cur);
-    if(nprev == 0)
-        GO_NC(0)
-    else if(ncur > 0) // (a block before another one is always full)
-        GO_NC(4)
-    else
-        switch(nprev)
+    bool launched = false;
+    auto go       = [&](auto npv, auto nc) {
+        constexpr int NPV = decltype(npv)::value, NC = decltype(nc)::value;
+        if constexpr(NPV <= kMgsBlock && NC <= kMgsBlock)
         {
-        case 1:
-            GO2(1, 0);
-            break;
-        case 2:
-            GO2(2, 0);
-            break;
-        case 3:
-            GO2(3, 0);
-            break;
-        default:
-            GO2(4, 0);
-            break;
+            if(ntw)
+                hipLaunchKernelGGL((k_mgs_block<T, NPV, NC, true>), dim3(grid), dim3(kBlock), 0, b.cur, w->n, (T*)w->d, a, ctx,
+                                   slot_h, slot_eprev, slot_e);
+            else
+                hipLaunchKernelGGL((k_mgs_block<T, NPV, NC, false>), dim3(grid), dim3(kBlock), 0, b.cur, w->n, (T*)w->d, a, ctx,
+                                   slot_h, slot_eprev, slot_e);
+            launched = true;
         }
+    };
+    using std::integral_constant;
+#define MGS_EACH(M) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8)
+    if(ncur > 0)
+    {
+        // first block (w only read) or a full block applied while the next one is projected on
+#define M(NC)                                                                        \
+    if(ncur == NC)                                                                   \
+    {                                                                                \
+        if(nprev == 0)                                                               \
+            go(integral_constant<int, 0>{}, integral_constant<int, NC>{});           \
+        else                                                                         \
+            go(integral_constant<int, kMgsBlock>{}, integral_constant<int, NC>{});   \
+    }
+        MGS_EACH(M)
+#undef M
+    }
+    else
+    {
+#define M(NP) \
+    if(nprev == NP) \
+        go(integral_constant<int, NP>{}, integral_constant<int, 0>{});
+        MGS_EACH(M)
+#undef M
+    }
+#undef MGS_EACH
     prof_end(RAMD_PROF_VEC, b.cur);
-#undef GO_NC
-#undef GO2
+    if(!launched)
+        RAMD_FAIL(RAMD_ERR_ARG, "fused_mgs_block: block longer than this build's block size");
     RAMD_HIP(hipGetLastError());
     return RAMD_OK;
 }
@@ -1057,12 +1061,17 @@ int ramd_fused_mgs_step(ramd_vec_t w, ramd_vec_t v, int slot_h, ramd_vec_t u, in
     return RAMD_OK;
 }
 
+int ramd_fused_mgs_block_max(void)
+{
+    return kMgsBlock;
+}
+
 int ramd_fused_mgs_block(ramd_vec_t w, const ramd_vec_t* vprev, int nprev, int slot_h, int slot_eprev,
                          const ramd_vec_t* vcur, int ncur, int slot_e)
 {
     if(!w || nprev < 0 || ncur < 0 || nprev > kMgsBlock || ncur > kMgsBlock || (nprev == 0 && ncur == 0)
        || (nprev > 0 && !vprev) || (ncur > 0 && !vcur) || (nprev > 0 && ncur > 0 && nprev != kMgsBlock))
-        RAMD_FAIL(RAMD_ERR_ARG, "fused_mgs_block: bad arguments (blocks of 1..4 vectors; a block followed by another is full)");
+        RAMD_FAIL(RAMD_ERR_ARG, "fused_mgs_block: bad arguments (blocks of 1..ramd_fused_mgs_block_max() vectors; a block followed by another is full)");
     const int nsum = ncur == 0 ? 1 : ncur + ncur * (ncur - 1) / 2;
     if(!slot_ok(slot_e) || !slot_ok(slot_e + nsum - 1))
         RAMD_FAIL(RAMD_ERR_ARG, "scalar slot out of range");

@@ -888,7 +888,9 @@ def _mgs_sequential(lib, capi, w, vs, m):
 
 def _mgs_blocked(lib, capi, w, vs, m):
     """ramd_fused_mgs_block exactly as GMRES::doFusedMGS drives it (include/rocalution/solvers.hpp)"""
-    K, areas = 4, (40, 52)
+    K = lib.ramd_fused_mgs_block_max()
+    nsum = K + K * (K - 1) // 2
+    areas = (124 - 2 * nsum, 124 - nsum)
     hs = (capi.vec_t * m)(*[v._h for v in vs[:m]])
     import ctypes as C
     at = lambda k: C.cast(C.byref(hs, k * C.sizeof(capi.vec_t)), C.POINTER(capi.vec_t))
@@ -905,10 +907,10 @@ def _mgs_blocked(lib, capi, w, vs, m):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("m", [1, 2, 4, 5, 8, 11, 30])
+@pytest.mark.parametrize("m", [1, 2, 4, 5, 8, 9, 11, 16, 17, 30])
 @pytest.mark.parametrize("basis", ["orthonormal", "oblique"])
 def test_fused_mgs_block_is_the_mgs_recurrence(ra, dtype, m, basis):
-    """ramd_fused_mgs_block (four projections per pass; GMRES Arnoldi, gmres.cpp:480-486) against the one-projection-
+    """ramd_fused_mgs_block (up to eight projections per pass; GMRES Arnoldi, gmres.cpp:480-486) against the one-projection-
     per-pass kernels and a float64 numpy MGS.  `oblique`: basis vectors far from orthogonal -- the block form measures
     their Gram entries, it does not assume an orthonormal basis.  Tolerance: the h of the two forms differ by rounding
     only, a few ulp of ||w|| (1e-13 / 2e-5 relative to ||w|| for fp64 / fp32, fp32 sums being accumulated in fp64)."""
@@ -947,28 +949,12 @@ def test_fused_mgs_block_is_the_mgs_recurrence(ra, dtype, m, basis):
 def test_fused_mgs_block_rejects_bad_arguments(ra):
     from rocalution_amd import capi
     lib = capi.load()
-    v = [ra.LocalVector(np.float64, data=np.ones(64)) for _ in range(5)]
+    v = [ra.LocalVector(np.float64, data=np.ones(64)) for _ in range(9)]
     w = ra.LocalVector(np.float64, data=np.ones(64))
-    hs = (capi.vec_t * 5)(*[x._h for x in v])
+    K = lib.ramd_fused_mgs_block_max()
+    hs = (capi.vec_t * (K + 1))(*[x._h for x in v])
     assert lib.ramd_fused_mgs_block(w._h, None, 0, 0, 0, None, 0, 0) != 0           # nothing to do
-    assert lib.ramd_fused_mgs_block(w._h, None, 0, 0, 0, hs, 5, 0) != 0             # block too long
-    assert lib.ramd_fused_mgs_block(w._h, hs, 3, 0, 40, hs, 2, 52) != 0             # a followed block must be full
-    assert lib.ramd_fused_mgs_block(w._h, hs, 4, 0, 40, hs, 4, 44) != 0             # overlapping slot areas
-    assert lib.ramd_fused_mgs_block(w._h, None, 0, 0, 0, hs, 4, 60) != 0            # sums beyond the record
-
-
-@pytest.mark.parametrize("variant", ["RAMD_CSR_Q4=1"])
-def test_csr_spmv_variants_forced_in_a_fresh_process(variant):
-    """the CSR SpMV has an opt-in four-lanes-per-row walk (k_csr_q4); forced on for EVERY matrix of the SpMV / ApplyAdd /
-    fused-dot / Jacobi-sweep tests: results must not change (bit-exact: the row sum stays in storage order)"""
-    import os
-    import subprocess
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ)
-    env[variant.split("=")[0]] = variant.split("=")[1]
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_kernels.py"),
-                        os.path.join(here, "test_gpu_edge_cases.py"), "-q", "-m", "gpu", "-x", "-k",
-                        "(spmv or csr or apply or fused_bicgstab or golden) and not fresh_process"],
-                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
-    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    assert lib.ramd_fused_mgs_block(w._h, None, 0, 0, 0, hs, K + 1, 0) != 0         # block too long
+    assert lib.ramd_fused_mgs_block(w._h, hs, K - 1, 0, 40, hs, 2, 90) != 0         # a followed block must be full
+    assert lib.ramd_fused_mgs_block(w._h, hs, K, 0, 40, hs, K, 44) != 0             # overlapping slot areas
+    assert lib.ramd_fused_mgs_block(w._h, None, 0, 0, 0, hs, K, 120) != 0           # sums beyond the record
