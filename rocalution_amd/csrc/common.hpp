@@ -53,7 +53,10 @@ const char* last_error();
 // One host thread drives the backend (as in the reference, SURVEY.md §8b "Threading").
 // Three streams mirror the reference's default / interior / ghost choreography
 // (src/base/hip/backend_hip.cpp:358-410); `cur` is what every op launches on.
-constexpr int kReduceBlocks  = 8192; // partial sums per reduction launch (32 workgroups per CU: tools/membench.hip)
+#ifndef RAMD_REDUCE_BLOCKS
+#define RAMD_REDUCE_BLOCKS 8192
+#endif
+constexpr int kReduceBlocks  = RAMD_REDUCE_BLOCKS; // partial sums per reduction launch (32 workgroups per CU: tools/membench.hip)
 constexpr int kScalarSlots   = 128; // doubles per scalar record
 constexpr int kScalarRecords = 8; // ring of records in host-mapped memory
 

@@ -329,7 +329,10 @@ __global__ __launch_bounds__(kBlock) void k_mgs_block(int64_t n, T* __restrict__
     constexpr int NPK = Pack<T>::N;
     constexpr int NG  = NC * (NC - 1) / 2;
     constexpr int NS  = NC == 0 ? 1 : NC + NG;
-    constexpr int U   = (NPV + NC > 9) ? 1 : (NPV + NC > 5) ? 2 : 4;
+#ifndef RAMD_MGS_U
+#define RAMD_MGS_U 2
+#endif
+    constexpr int U   = (NPV + NC > 9) ? 1 : (NPV + NC > 5) ? RAMD_MGS_U : 4;
     __shared__ double lds[4 * NS + 4];
     T mh[NPV > 0 ? NPV : 1];
     if constexpr(NPV > 0)

@@ -949,12 +949,34 @@ def test_fused_mgs_block_is_the_mgs_recurrence(ra, dtype, m, basis):
 def test_fused_mgs_block_rejects_bad_arguments(ra):
     from rocalution_amd import capi
     lib = capi.load()
-    v = [ra.LocalVector(np.float64, data=np.ones(64)) for _ in range(9)]
-    w = ra.LocalVector(np.float64, data=np.ones(64))
     K = lib.ramd_fused_mgs_block_max()
+    v = [ra.LocalVector(np.float64, data=np.ones(64)) for _ in range(K + 1)]
+    w = ra.LocalVector(np.float64, data=np.ones(64))
     hs = (capi.vec_t * (K + 1))(*[x._h for x in v])
     assert lib.ramd_fused_mgs_block(w._h, None, 0, 0, 0, None, 0, 0) != 0           # nothing to do
     assert lib.ramd_fused_mgs_block(w._h, None, 0, 0, 0, hs, K + 1, 0) != 0         # block too long
     assert lib.ramd_fused_mgs_block(w._h, hs, K - 1, 0, 40, hs, 2, 90) != 0         # a followed block must be full
     assert lib.ramd_fused_mgs_block(w._h, hs, K, 0, 40, hs, K, 44) != 0             # overlapping slot areas
     assert lib.ramd_fused_mgs_block(w._h, None, 0, 0, 0, hs, K, 120) != 0           # sums beyond the record
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 255, 257, 1023])
+def test_fused_mgs_block_tiny_vectors(ra, n):
+    """vectors shorter than a 16-byte packet / a workgroup: only the scalar tail loop (or a partial packet pass) runs"""
+    from rocalution_amd import capi
+    lib = capi.load()
+    rng = np.random.default_rng(n)
+    for dtype in (np.float64, np.float32):
+        m = min(n, 6)
+        V = rng.uniform(-1, 1, (n, m))
+        V /= np.linalg.norm(V, axis=0)
+        w0 = rng.uniform(-1, 1, n)
+        vs = [ra.LocalVector(dtype, data=np.ascontiguousarray(V[:, k]).astype(dtype)) for k in range(m)]
+        wa = ra.LocalVector(dtype, data=w0.astype(dtype))
+        wb = ra.LocalVector(dtype, data=w0.astype(dtype))
+        ha = _mgs_sequential(lib, capi, wa, vs, m)
+        hb = _mgs_blocked(lib, capi, wb, vs, m)
+        tol = (1e-13 if dtype == np.float64 else 2e-5) * 20.0 * max(1.0, np.linalg.norm(w0))
+        assert np.max(np.abs(hb[:m] - ha[:m])) <= tol
+        assert abs(hb[m] - ha[m]) <= 4 * tol * max(1.0, np.linalg.norm(w0))
+        assert np.max(np.abs(wb.numpy().astype(np.float64) - wa.numpy().astype(np.float64))) <= tol
