@@ -427,6 +427,8 @@ def main():
             b_spmv = vb * (2 * n + nnz_fmt) if args.format == "dia" else 4 * nnz_fmt + vb * (2 * n + nnz_fmt)
             k_spmv = "k_%s<%s>" % ("dia" if args.format == "dia" else "ell", "float" if mixed else "double")
         tkey = "spmv_csr_512" if (args.matrix == "poisson" and N == 512 and args.format == "csr" and not mixed) else None
+        if args.matrix == "shell" and args.format == "csr" and not mixed:
+            tkey = "spmv_csr_shell"
         r_spmv = roof(k_spmv, b_spmv, p_spmv, traffic_for(tkey) if tkey else None)
         if tri_pc and p_trsv["launches"] > 0:
             tk = "trsv_512" if (args.matrix == "poisson" and N == 512) else ("trsv_shell" if args.matrix == "shell" else None)
