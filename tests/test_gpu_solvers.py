@@ -577,3 +577,17 @@ def test_fused_jacobi_smoother_sweeps_bit_identical(ra, S, dtype):
         ls.Clear()
     assert np.array_equal(out[0], out[1])
     assert not np.array_equal(out[0], x0)
+
+
+def test_gmres_one_projection_per_pass_in_a_fresh_process():
+    """RAMD_MGS_BLOCK=0: GMRES / FGMRES orthogonalise with one Gram-Schmidt projection per pass (k_mgs_step) instead of
+    blocks of four (k_mgs_block); every GMRES parity test of this file must hold for that form too"""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, RAMD_MGS_BLOCK="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_solvers.py"), "-q", "-m", "gpu", "-x",
+                        "-k", "gmres and not fresh_process"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       timeout=1500)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
