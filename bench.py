@@ -6,8 +6,11 @@
 
 Default workload (BASELINE.json `metric`): CG + Jacobi on the 3-D 7-point Poisson 512^3 operator in CSR, fp64,
 rhs = A*1, x0 = 0 (the reference samples' convention, clients/samples/cg.cpp:77-82), synthetic operator generated
-on the device.  A "step" is ONE Krylov iteration; the timed region is Solve() running exactly K iterations
-(tolerances that cannot be met), bracketed by barrier + device sync, MAX over ranks.
+on the device.  A "step" is ONE Krylov iteration.  ONE Solve() runs W + K iterations (tolerances that cannot be met):
+the W warm-up iterations are untimed, the clock starts when the solver has checked iteration W with the device drained
+(ramd_solver_set_time_mark) and stops after barrier + device sync behind the Solve: exactly K iterations, all of their
+work included, MAX over ranks.  (--warmup 0 times the whole Solve, i.e. also the initial residual and first direction:
+at K = 20 that is 192 instead of 225 it/s.)
 N > 1: the rows are split into z-slabs across ranks (strong scaling), halo exchange + scalar all-reduce over RCCL
 (GlobalMatrix / GlobalVector path).
 
@@ -356,7 +359,10 @@ def main():
         x = ra.LocalVector(); x.Allocate("x", n)
         A.Apply(ones, rhs)
 
-        def run(iters, solver_cls=S.CG, pc_cls=S.Jacobi, basis=None):
+        def run(iters, solver_cls=S.CG, pc_cls=S.Jacobi, basis=None, warm=0):
+            """one Solve of warm + iters iterations; warm > 0: the clock starts when iteration `warm` has been checked
+            and the device drained (ramd_solver_set_time_mark), so the timed region is exactly `iters` iterations and
+            the solver's preamble (initial residual, first direction) falls into the warm-up"""
             if A.GetFormat() != ra.CSR:  # preconditioners are built from the CSR state
                 regen()
             ls = solver_cls()
@@ -370,20 +376,23 @@ def main():
                 ls.SetPreconditioner(pc)
             if basis:
                 ls.SetBasisSize(basis)
-            ls.Init(NEVER[0], NEVER[1], NEVER[2], iters)
+            ls.Init(NEVER[0], NEVER[1], NEVER[2], warm + iters)
             tb = time.perf_counter()
             ls.Build()
             ra.sync()
             tb = time.perf_counter() - tb
             if fmt != ra.CSR and A.GetFormat() == ra.CSR:
                 A.ConvertTo(fmt)
+            if warm > 0:
+                ls.SetTimeMark(warm)
             x.Zeros()
             barrier()
             t0 = time.perf_counter()
             ls.Solve(rhs, x)
             barrier()
-            dt = time.perf_counter() - t0
-            it = ls.GetIterationCount()
+            dt = ls.GetSecondsSinceTimeMark() if warm > 0 else time.perf_counter() - t0
+            assert dt > 0, "the marked iteration was not reached"
+            it = ls.GetIterationCount() - warm
             res = ls.GetCurrentResidual()
             ls.Clear()
             return dt, it, res, tb
@@ -393,21 +402,25 @@ def main():
                "mcgs": S.MultiColoredGS, "mcilu": S.MultiColoredILU, "ic": S.IC, "sgs": S.SGS, "uaamg": S.UAAMG, "saamg": S.SAAMG}[args.precond]
         basis = 30 if args.solver == "gmres" else None
         if mixed:
-            def run(iters, *_a):  # noqa: F811  (config 5 on one GPU)
+            def run(iters, *_a, warm=0):  # noqa: F811  (config 5 on one GPU)
                 inner = S.CG(np.float32)
                 if HPC is not None:
                     inner.SetPreconditioner(HPC())
                 inner.Init(1e-5, 1e-2, 1e20, 100000)
                 mp = S.MixedPrecisionDC(); mp.SetOperator(A); mp.Set(inner)
-                mp.Init(NEVER[0], NEVER[1], NEVER[2], iters)
-                mp.Build(); x.Zeros(); barrier()
+                mp.Init(NEVER[0], NEVER[1], NEVER[2], warm + iters)
+                mp.Build()
+                if warm > 0:
+                    mp.SetTimeMark(warm)
+                x.Zeros(); barrier()
                 t0 = time.perf_counter(); mp.Solve(rhs, x); barrier()
-                dt = time.perf_counter() - t0
-                r = (dt, mp.GetIterationCount(), mp.GetCurrentResidual(), 0.0)
+                dt = mp.GetSecondsSinceTimeMark() if warm > 0 else time.perf_counter() - t0
+                assert dt > 0, "the marked iteration was not reached"
+                r = (dt, mp.GetIterationCount() - warm, mp.GetCurrentResidual(), 0.0)
                 mp.Clear()
                 return r
-        run(W, HEAD, HPC, basis)  # warm-up
-        dt, it, res, tbuild = run(K, HEAD, HPC, basis)
+        # W untimed warm-up iterations, then EXACTLY K timed ones, in one Solve (see run); --warmup 0 times the whole Solve
+        dt, it, res, tbuild = run(K, HEAD, HPC, basis, warm=W)
         assert it == K, (it, K)
         # --- roofline leg: the SAME solver run again with every SpMV / triangular-solve / fused-vector launch
         # bracketed by HIP events on the stream it runs on
@@ -490,8 +503,9 @@ def main():
             capi.check(lib.ramd_gsolver_create(comm, SK[args.solver], PK[args.precond], C.byref(g)))
         capi.check(lib.ramd_gsolver_setup_poisson(g, N, z0, z1))
 
-        def run(iters):
-            capi.check(lib.ramd_gsolver_init(g, NEVER[0], NEVER[1], NEVER[2], 0, iters))
+        def run(iters, warm=0):
+            capi.check(lib.ramd_gsolver_init(g, NEVER[0], NEVER[1], NEVER[2], 0, warm + iters))
+            capi.check(lib.ramd_gsolver_set_time_mark(g, warm if warm > 0 else -1))
             if fmt != ra.CSR:  # preconditioners are built from the CSR state (second run: convert back first)
                 capi.check(lib.ramd_gsolver_convert(g, ra.CSR))
             capi.check(lib.ramd_gsolver_build(g))
@@ -503,12 +517,17 @@ def main():
             capi.check(lib.ramd_gsolver_solve_device(g))
             barrier()
             dt = time.perf_counter() - t0
+            if warm > 0:  # the clock of every rank started when it had checked iteration `warm` (ranks are in step: two
+                sec = C.c_double(0)  # all-reduces per iteration), device drained; max over ranks below
+                capi.check(lib.ramd_gsolver_seconds_since_time_mark(g, C.byref(sec)))
+                dt = sec.value
+                assert dt > 0, "the marked iteration was not reached"
             itc, st, rs = C.c_int(0), C.c_int(0), C.c_double(0)
             capi.check(lib.ramd_gsolver_result(g, C.byref(itc), C.byref(st), C.byref(rs)))
-            return dt, itc.value, rs.value, 0.0
+            return dt, itc.value - warm, rs.value, 0.0
 
-        run(W)
-        dt, it, res, tbuild = run(K)
+        # W untimed warm-up iterations, then EXACTLY K timed ones, in one Solve; --warmup 0 times the whole Solve
+        dt, it, res, tbuild = run(K, warm=W)
         assert it == K, (it, K)
         import torch
         t = torch.tensor([dt], dtype=torch.float64)

@@ -16,6 +16,7 @@
 
 #include <ctime>
 
+#include <chrono>
 #include <cmath>
 #include <limits>
 
@@ -136,10 +137,29 @@ public:
         return true;
     }
     // iter_ctrl.cpp:195-248
+    // measurement hook (bench.py: W warm-up iterations, then exactly K timed ones inside ONE Solve): the wall-clock
+    // instant at which iteration `iteration` was checked, with the device drained.  Not part of the reference's class.
+    void SetTimeMark(int iteration)
+    {
+        this->m_mark_iter = iteration;
+        this->m_mark_set  = false;
+    }
+    double GetSecondsSinceTimeMark(void) const // < 0: the marked iteration was never reached
+    {
+        if(!this->m_mark_set)
+            return -1.0;
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - this->m_mark_time).count();
+    }
     bool CheckResidual(double resid)
     {
         RAMD_EXPECT(this->m_init_res);
         this->m_iteration++;
+        if(this->m_iteration == this->m_mark_iter)
+        {
+            _rocalution_sync();
+            this->m_mark_time = std::chrono::steady_clock::now();
+            this->m_mark_set  = true;
+        }
         this->m_current_res = resid;
         if(this->m_verb > 1)
             say("IterationControl iter=", this->m_iteration, "; residual=", resid);
@@ -252,6 +272,9 @@ private:
         return (std::abs(resid) == std::numeric_limits<double>::infinity()) || (resid != resid);
     }
     std::vector<double> m_residual_history;
+    int                                   m_mark_iter = -1; // (survives Clear(): set once per measurement)
+    bool                                  m_mark_set  = false;
+    std::chrono::steady_clock::time_point m_mark_time;
     int                 m_iteration;
     bool                m_init_res, m_rec;
     int                 m_verb, m_reached;
@@ -1255,6 +1278,15 @@ public:
     virtual int GetIterationCount(void)
     {
         return this->m_iter_ctrl.GetIterationCount();
+    }
+    // measurement hook, see IterationControl::SetTimeMark
+    virtual void SetTimeMark(int iteration)
+    {
+        this->m_iter_ctrl.SetTimeMark(iteration);
+    }
+    virtual double GetSecondsSinceTimeMark(void)
+    {
+        return this->m_iter_ctrl.GetSecondsSinceTimeMark();
     }
     virtual double GetCurrentResidual(void)
     {

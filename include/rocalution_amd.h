@@ -440,6 +440,11 @@ int ramd_solver_build(ramd_solver_t s, ramd_mat_t op); /* SetOperator + [SetPrec
 int ramd_solver_solve(ramd_solver_t s, ramd_vec_t rhs, ramd_vec_t x);
 int ramd_solver_precond_apply(ramd_solver_t s, ramd_vec_t rhs, ramd_vec_t x); /* M^-1 rhs (test hook) */
 int ramd_solver_result(ramd_solver_t s, int* iters, int* status, double* final_res);
+/* measurement hook (bench.py: W warm-up iterations and exactly K timed ones inside ONE Solve): the solver drains the device
+ * and notes the wall clock when it has checked iteration `iteration`; seconds_since: now minus that instant (< 0: the
+ * iteration was never reached).  Not a reference entry point. */
+int ramd_solver_set_time_mark(ramd_solver_t s, int iteration);
+int ramd_solver_seconds_since_time_mark(ramd_solver_t s, double* seconds);
 int ramd_solver_history(ramd_solver_t s, double* buf, int cap, int* len);
 int ramd_solver_num_colors(ramd_solver_t s, int* ncolors);
 /* Solver::ReBuildNumeric (solver.hpp:214-218): the operator got new values in the same pattern */
@@ -498,6 +503,8 @@ int ramd_gsolver_solve_ones(ramd_gsolver_t g); /* rhs = A*1, x0 = 0, everything 
 int ramd_gsolver_prepare_ones(ramd_gsolver_t g); /* rhs = A*1, x = 0 (on the device) */
 int ramd_gsolver_solve_device(ramd_gsolver_t g); /* Solve(rhs, &x) on the prepared device vectors */
 int ramd_gsolver_result(ramd_gsolver_t g, int* iters, int* status, double* final_res);
+int ramd_gsolver_set_time_mark(ramd_gsolver_t g, int iteration); /* as ramd_solver_set_time_mark */
+int ramd_gsolver_seconds_since_time_mark(ramd_gsolver_t g, double* seconds);
 int ramd_gsolver_dot_check(ramd_gsolver_t g, double* x_dot_x); /* <x,x> over all ranks after a solve */
 
 #ifdef __cplusplus

@@ -218,6 +218,8 @@ SIGNATURES = {
     "ramd_solver_solve": (i32, [ptr, vec_t, vec_t]),
     "ramd_solver_precond_apply": (i32, [ptr, vec_t, vec_t]),
     "ramd_solver_result": (i32, [ptr, pi32, pi32, pf64]),
+    "ramd_solver_set_time_mark": (i32, [ptr, i32]),
+    "ramd_solver_seconds_since_time_mark": (i32, [ptr, pf64]),
     "ramd_solver_history": (i32, [ptr, pf64, i32, pi32]),
     "ramd_solver_num_colors": (i32, [ptr, pi32]),
     "ramd_solver_clear": (i32, [ptr]),
@@ -240,6 +242,8 @@ SIGNATURES = {
     "ramd_gsolver_prepare_ones": (i32, [ptr]),
     "ramd_gsolver_solve_device": (i32, [ptr]),
     "ramd_gsolver_result": (i32, [ptr, pi32, pi32, pf64]),
+    "ramd_gsolver_set_time_mark": (i32, [ptr, i32]),
+    "ramd_gsolver_seconds_since_time_mark": (i32, [ptr, pf64]),
     "ramd_gsolver_dot_check": (i32, [ptr, pf64]),
 }
 

@@ -46,6 +46,8 @@ struct SolverBase
     virtual int64_t op_rows() const                                      = 0; // rows of the operator Build() saw
     virtual bool precond_apply(ramd_vec_t, ramd_vec_t)                   = 0;
     virtual void result(int* it, int* st, double* res)                   = 0;
+    virtual void   set_time_mark(int iteration)                          = 0;
+    virtual double seconds_since_time_mark()                             = 0;
     virtual const std::vector<double>& history()                         = 0;
     virtual int                        num_colors()
     {
@@ -285,6 +287,14 @@ struct LocalSolver : SolverBase
         *st  = ls()->GetSolverStatus();
         *res = ls()->GetCurrentResidual();
     }
+    void set_time_mark(int iteration) override
+    {
+        ls()->SetTimeMark(iteration);
+    }
+    double seconds_since_time_mark() override
+    {
+        return ls()->GetSecondsSinceTimeMark();
+    }
     const std::vector<double>& history() override
     {
         return ls()->GetResidualHistory();
@@ -433,6 +443,14 @@ struct MixedSolver : SolverBase
         *it  = mp.GetIterationCount();
         *st  = mp.GetSolverStatus();
         *res = mp.GetCurrentResidual();
+    }
+    void set_time_mark(int iteration) override
+    {
+        mp.SetTimeMark(iteration);
+    }
+    double seconds_since_time_mark() override
+    {
+        return mp.GetSecondsSinceTimeMark();
     }
     const std::vector<double>& history() override
     {
@@ -777,6 +795,20 @@ int ramd_solver_precond_apply(ramd_solver_t s, ramd_vec_t rhs, ramd_vec_t x)
         return RAMD_ERR_ARG;
     return s->impl->precond_apply(rhs, x) ? RAMD_OK : RAMD_ERR_STATE;
 }
+int ramd_solver_set_time_mark(ramd_solver_t s, int iteration)
+{
+    if(!s)
+        return RAMD_ERR_ARG;
+    s->impl->set_time_mark(iteration);
+    return RAMD_OK;
+}
+int ramd_solver_seconds_since_time_mark(ramd_solver_t s, double* seconds)
+{
+    if(!s || !seconds)
+        return RAMD_ERR_ARG;
+    *seconds = s->impl->seconds_since_time_mark();
+    return RAMD_OK;
+}
 int ramd_solver_result(ramd_solver_t s, int* iters, int* status, double* final_res)
 {
     if(!s)
@@ -1079,6 +1111,20 @@ int ramd_gsolver_solve_device(ramd_gsolver_t g)
     GUARD_BEGIN
     g->ls()->Solve(g->rhs, &g->x);
     GUARD_END
+}
+int ramd_gsolver_set_time_mark(ramd_gsolver_t g, int iteration)
+{
+    if(!g)
+        return RAMD_ERR_ARG;
+    g->ls()->SetTimeMark(iteration);
+    return RAMD_OK;
+}
+int ramd_gsolver_seconds_since_time_mark(ramd_gsolver_t g, double* seconds)
+{
+    if(!g || !seconds)
+        return RAMD_ERR_ARG;
+    *seconds = g->ls()->GetSecondsSinceTimeMark();
+    return RAMD_OK;
 }
 int ramd_gsolver_result(ramd_gsolver_t g, int* iters, int* status, double* final_res)
 {

@@ -225,6 +225,15 @@ class _IterativeLinearSolver:
     def GetIterationCount(self):
         return self._result()[0]
 
+    def SetTimeMark(self, iteration):
+        """measurement hook: note the wall clock (device drained) when iteration `iteration` has been checked"""
+        capi.check(_lib().ramd_solver_set_time_mark(self._h, int(iteration)))
+
+    def GetSecondsSinceTimeMark(self):
+        s = C.c_double(0)
+        capi.check(_lib().ramd_solver_seconds_since_time_mark(self._h, C.byref(s)))
+        return s.value
+
     def GetSolverStatus(self):
         return self._result()[1]
 

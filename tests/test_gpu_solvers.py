@@ -591,3 +591,31 @@ def test_gmres_one_projection_per_pass_in_a_fresh_process():
                         "-k", "gmres and not fresh_process"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        timeout=1500)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
+
+
+def test_time_mark_hook_does_not_change_the_solve(ra, S):
+    """ramd_solver_set_time_mark (bench.py's clock: starts when iteration W has been checked): the iterate and the
+    iteration count are bit-identical with and without it; a mark that is never reached reports -1"""
+    import time
+    rp, ci, va = gen.poisson7(20, np.float64)
+    n = len(rp) - 1
+    A = ra.LocalMatrix(np.float64); A.SetDataPtrCSR(rp, ci, va)
+    ones = ra.LocalVector(np.float64); ones.Allocate("", n); ones.Ones()
+    b = ra.LocalVector(np.float64); b.Allocate("", n); A.Apply(ones, b)
+    out = []
+    for mark in (None, 4, 500):
+        ls = S.CG(); ls.SetOperator(A); ls.SetPreconditioner(S.Jacobi()); ls.Init(0.0, 0.0, 1e300, 12); ls.Build()
+        if mark is not None:
+            ls.SetTimeMark(mark)
+        x = ra.LocalVector(np.float64); x.Allocate("", n); x.Zeros()
+        t0 = time.perf_counter()
+        ls.Solve(b, x)
+        ra.sync()
+        wall = time.perf_counter() - t0
+        since = ls.GetSecondsSinceTimeMark()
+        out.append((x.numpy().copy(), ls.GetIterationCount(), since, wall))
+        ls.Clear()
+    assert out[0][1] == out[1][1] == out[2][1] == 12
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][0], out[2][0])
+    assert out[0][2] == -1.0 and out[2][2] == -1.0
+    assert 0.0 < out[1][2] <= out[1][3] + 1e-3
