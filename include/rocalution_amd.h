@@ -148,6 +148,10 @@ int ramd_mat_copy_coo_to_host(ramd_mat_t m, int32_t* row, int32_t* col, void* va
 /* Apply :450 / ApplyAdd :452 -- y = A x ; y += scalar * A x, in the matrix' current format */
 int ramd_mat_apply(ramd_mat_t m, ramd_vec_t x, ramd_vec_t y);
 int ramd_mat_apply_add(ramd_mat_t m, ramd_vec_t x, double scalar, ramd_vec_t y);
+/* what the CSR product learned about the matrix on its first call (no reference counterpart): state 0 = not analysed yet,
+ * 1 = the rows fall into `entries` patterns of column offsets (col - row) of at most `width` entries, the kernel rebuilds the
+ * columns from one byte per row; -1 = not structured (too many patterns or rows longer than 16): columns are read */
+int ramd_mat_pattern_info(ramd_mat_t m, int* state, int* entries, int* width);
 int ramd_mat_extract_diag(ramd_mat_t m, ramd_vec_t d); /* :193 */
 int ramd_mat_extract_inv_diag(ramd_mat_t m, ramd_vec_t d); /* :195 ; *d resized to min(nrow,ncol) */
 int ramd_mat_extract_submatrix(ramd_mat_t m, int row_offset, int col_offset, int row_size, int col_size,

@@ -187,6 +187,12 @@ struct ramd_mat_s
     void* tri      = nullptr; // ramd::TriState* (level-ordered solve plans), trisolve.hip
     // workspace of the fused CSR SpMV + <x,y> (spmv.hip)
     int     band_dist = -1; // far-band distance in rows for the band-aware traversal (-1 unknown, 0 none)
+    // row patterns of the CSR SpMV (spmv.hip, csr_analyse_pattern): rows whose column offsets col - row coincide share a
+    // dictionary entry, and the kernel rebuilds the columns from one byte per row instead of reading 4 bytes per entry
+    int            pat_state = 0; // 0 unknown, 1 usable, -1 not usable (too many patterns / rows too long)
+    int            pat_n = 0, pat_w = 0; // dictionary entries, padded row length
+    unsigned char* pat_id   = nullptr; // [nrow]
+    int*           pat_dict = nullptr; // [pat_n * pat_w] column offsets in storage order
     double* dot_part1 = nullptr; // [dot_nblk] per-workgroup partials
     int     dot_nblk  = 0;
 };

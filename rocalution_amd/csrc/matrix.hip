@@ -58,6 +58,9 @@ void mat_free_analysis(ramd_mat_s* m)
     dev_free(&m->dot_part1);
     m->dot_nblk  = 0;
     m->band_dist = -1;
+    dev_free(&m->pat_id);
+    dev_free(&m->pat_dict);
+    m->pat_state = m->pat_n = m->pat_w = 0;
     tri_release(m);
     m->lu_analysed = m->l_analysed = m->u_analysed = false;
     m->l_diag_unit                                 = true;
@@ -372,6 +375,18 @@ int ramd_mat_clone(ramd_mat_t src, ramd_mat_t* out)
     return RAMD_OK;
 }
 
+int ramd_mat_pattern_info(ramd_mat_t m, int* state, int* entries, int* width)
+{
+    if(!m)
+        RAMD_FAIL(RAMD_ERR_ARG, "null matrix handle");
+    if(state)
+        *state = m->pat_state;
+    if(entries)
+        *entries = m->pat_n;
+    if(width)
+        *width = m->pat_w;
+    return RAMD_OK;
+}
 int ramd_mat_apply(ramd_mat_t m, ramd_vec_t x, ramd_vec_t y)
 {
     RAMD_TRY(check_apply_args(m, x, y));

@@ -95,18 +95,28 @@ struct CsrDotWs
 // DOT   : additionally reduce <x, y> into scalar slot `slot` (square matrix)
 // LDS (24 KiB per workgroup) allows 6 workgroups = 6 waves per SIMD: keep the register budget inside
 // 512/6 VGPRs (the fused-dot variant sat at 86 and lost a whole wave per SIMD: -4%)
-template <typename T, int MODE, bool DOT>
+// row patterns: see ramd_mat_s::pat_* and csr_analyse_pattern below
+constexpr int kPatMaxW = 16; // longest row a pattern may have
+constexpr int kPatMax  = 64; // dictionary entries
+struct CsrPattern
+{
+    const unsigned char* id; // [nrow]
+    const int*           dict; // [n * w]
+    int                  n, w;
+};
+
+template <typename T, int MODE, bool DOT, bool PAT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_csr_tr(int nrow, int nblk, int per_xcd,
                                                    const int* __restrict__ rp,
                                                    const int* __restrict__ ci,
                                                    const T* __restrict__ val,
                                                    const T* __restrict__ x, T* __restrict__ y, T scalar,
-                                                   CsrDotWs ws, int slot, BandMap bm)
+                                                   CsrDotWs ws, int slot, BandMap bm, CsrPattern pat)
 {
     using VP          = typename ValPk<T>::type;
     constexpr int VN  = ValPk<T>::N;
     __shared__ T      sval[kCsrChunk];
-    __shared__ int    scol[kCsrChunk];
+    __shared__ int    scol[PAT ? kPatMax * kPatMaxW : kCsrChunk]; // PAT: the dictionary of column offsets instead
     const int blk  = xcd_block(nblk, per_xcd, bm);
     double    dacc = 0.0;
     if(blk >= 0)
@@ -115,10 +125,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) 
         const int rend = min(r0 + kCsrRows, nrow);
         const int row  = r0 + threadIdx.x;
         int       rs = 0, re = 0;
+        int       dbase = 0; // PAT: where this row's offsets start in the dictionary, minus rs
+        if(PAT)
+            for(int i = threadIdx.x; i < pat.n * pat.w; i += kBlock)
+                scol[i] = pat.dict[i];
         if(row < nrow)
         {
             rs = rp[row];
             re = rp[row + 1];
+            if(PAT)
+                dbase = (int)pat.id[row] * pat.w - rs;
         }
         const int start = rp[r0];
         const int end   = rp[rend];
@@ -130,7 +146,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) 
             v4i32 c[kCsrChunk / (4 * kBlock)];
             VP    a[kCsrChunk / (VN * kBlock)];
 #pragma unroll
-            for(int k = 0; k < kCsrChunk / (4 * kBlock); ++k)
+            for(int k = 0; k < (PAT ? 0 : kCsrChunk / (4 * kBlock)); ++k)
             {
                 const int j = cb + (k * kBlock + threadIdx.x) * 4;
                 if(j < end)
@@ -144,7 +160,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) 
                     a[k] = nt_load(reinterpret_cast<const VP*>(val + j));
             }
 #pragma unroll
-            for(int k = 0; k < kCsrChunk / (4 * kBlock); ++k)
+            for(int k = 0; k < (PAT ? 0 : kCsrChunk / (4 * kBlock)); ++k)
             {
                 const int g = (k * kBlock + threadIdx.x) * 4;
                 if(cb + g < end)
@@ -170,7 +186,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) 
                 for(int e = 0; e < kGatherW; ++e)
                     if(j + e < hi)
                     {
-                        cc[e] = scol[j - cb + e];
+                        cc[e] = PAT ? row + scol[dbase + j + e] : scol[j - cb + e];
                         v[e]  = sval[j - cb + e];
                     }
 #pragma unroll
@@ -614,6 +630,202 @@ int csr_analyse_band(ramd_mat_s* m)
     return RAMD_OK;
 }
 
+// ------------------------------------------------------------------------------------------ row patterns
+// Structured operators repeat a handful of rows: every interior row of a stencil has the same column offsets col - row.
+// The analysis hashes (length, offsets) of every row into a 256-slot table, gives up beyond kPatMax distinct rows or rows
+// longer than kPatMaxW, builds the dictionary from one representative row per slot and then VERIFIES every row against its
+// dictionary entry entry by entry (a hash collision makes the matrix "not usable", never a wrong column).  The SpMV then
+// reads one byte per row instead of four per entry: 9.9 instead of 13.9 GB per launch at 512^3, same values, same order.
+constexpr int kPatTable = 256;
+__device__ __forceinline__ unsigned long long pat_hash(int len, const int* __restrict__ ci, int rs, int row)
+{
+    unsigned long long h = 0x9E3779B97F4A7C15ull ^ (unsigned long long)(unsigned)len;
+    for(int k = 0; k < len; ++k)
+    {
+        const unsigned long long o = (unsigned long long)(unsigned)(ci[rs + k] - row);
+        h ^= o + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+        h *= 0xD6E8FEB86659FD93ull;
+    }
+    return h | 1ull; // (0 marks an empty slot)
+}
+__global__ __launch_bounds__(kBlock) void k_pat_insert(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                       unsigned long long* table, int* rep, int* fail)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += gsz)
+    {
+        const int rs = rp[r], len = rp[r + 1] - rs;
+        if(len > kPatMaxW)
+        {
+            *fail = 1;
+            continue;
+        }
+        const unsigned long long h = pat_hash(len, ci, rs, (int)r);
+        int                      s = (int)(h % kPatTable);
+        int                      probes = 0;
+        for(; probes < kPatTable; ++probes, s = (s + 1) % kPatTable)
+        {
+            unsigned long long cur = __hip_atomic_load(table + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if(cur == 0)
+            {
+                cur = atomicCAS(table + s, 0ull, h);
+                if(cur == 0)
+                {
+                    rep[s] = (int)r;
+                    break;
+                }
+            }
+            if(cur == h)
+                break;
+        }
+        if(probes == kPatTable)
+            *fail = 1;
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_pat_assign(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                       const unsigned long long* __restrict__ table,
+                                                       const int* __restrict__ slot_id, const int* __restrict__ dict,
+                                                       const int* __restrict__ dlen, int w, unsigned char* __restrict__ id,
+                                                       int* fail)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += gsz)
+    {
+        const int                rs = rp[r], len = rp[r + 1] - rs;
+        const unsigned long long h = pat_hash(len, ci, rs, (int)r);
+        int                      s = (int)(h % kPatTable), probes = 0;
+        while(probes < kPatTable && table[s] != h)
+        {
+            s = (s + 1) % kPatTable;
+            ++probes;
+        }
+        bool ok = probes < kPatTable;
+        int  p  = 0;
+        if(ok)
+        {
+            p  = slot_id[s];
+            ok = dlen[p] == len;
+            for(int k = 0; ok && k < len; ++k)
+                ok = dict[p * w + k] == ci[rs + k] - (int)r;
+        }
+        if(!ok)
+            *fail = 1;
+        id[r] = (unsigned char)p;
+    }
+}
+
+int csr_analyse_pattern(ramd_mat_s* m)
+{
+    m->pat_state = -1;
+    if(m->format != RAMD_CSR || m->nrow <= 0 || m->nnz <= 0)
+        return RAMD_OK;
+    Backend&            b = backend();
+    unsigned long long* table = nullptr;
+    int *               rep = nullptr, *flag = nullptr, *d_slot = nullptr, *d_len = nullptr;
+    auto                cleanup = [&]() {
+        dev_free(&table);
+        dev_free(&rep);
+        dev_free(&flag);
+        dev_free(&d_slot);
+        dev_free(&d_len);
+    };
+#define PAT_TRY(expr)          \
+    do                         \
+    {                          \
+        const int s_ = (expr); \
+        if(s_ != RAMD_OK)      \
+        {                      \
+            cleanup();         \
+            return s_;         \
+        }                      \
+    } while(0)
+#define PAT_HIP(expr)                                  \
+    do                                                 \
+    {                                                  \
+        if((expr) != hipSuccess)                       \
+        {                                              \
+            cleanup();                                 \
+            RAMD_FAIL(RAMD_ERR_HIP, "pattern analysis"); \
+        }                                              \
+    } while(0)
+    PAT_TRY(dev_alloc(&table, kPatTable));
+    PAT_TRY(dev_alloc(&rep, kPatTable));
+    PAT_TRY(dev_alloc(&flag, 2));
+    PAT_HIP(hipMemsetAsync(table, 0, sizeof(unsigned long long) * kPatTable, b.cur));
+    PAT_HIP(hipMemsetAsync(rep, 0, sizeof(int) * kPatTable, b.cur));
+    PAT_HIP(hipMemsetAsync(flag, 0, sizeof(int) * 2, b.cur));
+    const int grid = ew_grid(m->nrow);
+    hipLaunchKernelGGL(k_pat_insert, dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, m->rp, m->ci, table, rep, flag);
+    unsigned long long h_table[kPatTable];
+    int                h_rep[kPatTable], h_flag[2] = {0, 0};
+    PAT_HIP(hipMemcpyAsync(h_table, table, sizeof(h_table), hipMemcpyDeviceToHost, b.cur));
+    PAT_HIP(hipMemcpyAsync(h_rep, rep, sizeof(h_rep), hipMemcpyDeviceToHost, b.cur));
+    PAT_HIP(hipMemcpyAsync(h_flag, flag, sizeof(int) * 2, hipMemcpyDeviceToHost, b.cur));
+    PAT_HIP(hipStreamSynchronize(b.cur));
+    int np = 0, h_slot[kPatTable];
+    for(int s = 0; s < kPatTable; ++s)
+    {
+        h_slot[s] = -1;
+        if(h_table[s] != 0)
+            h_slot[s] = np++;
+    }
+    if(h_flag[0] != 0 || np == 0 || np > kPatMax)
+    {
+        cleanup();
+        return RAMD_OK; // not usable: stays -1
+    }
+    // dictionary: the representative row of every slot
+    std::vector<int> h_len((size_t)np), rows((size_t)np);
+    int              w = 1;
+    for(int s = 0; s < kPatTable; ++s)
+        if(h_slot[s] >= 0)
+        {
+            int pair[2] = {0, 0};
+            PAT_HIP(hipMemcpy(pair, m->rp + h_rep[s], sizeof(int) * 2, hipMemcpyDeviceToHost));
+            rows[(size_t)h_slot[s]]  = h_rep[s];
+            h_len[(size_t)h_slot[s]] = pair[1] - pair[0];
+            w                        = std::max(w, pair[1] - pair[0]);
+        }
+    std::vector<int> h_dict((size_t)np * w, 0);
+    for(int s = 0; s < kPatTable; ++s)
+        if(h_slot[s] >= 0 && h_len[(size_t)h_slot[s]] > 0)
+        {
+            const int p = h_slot[s];
+            int       start = 0;
+            PAT_HIP(hipMemcpy(&start, m->rp + rows[(size_t)p], sizeof(int), hipMemcpyDeviceToHost));
+            PAT_HIP(hipMemcpy(h_dict.data() + (size_t)p * w, m->ci + start, sizeof(int) * (size_t)h_len[(size_t)p],
+                              hipMemcpyDeviceToHost));
+            for(int k = 0; k < h_len[(size_t)p]; ++k)
+                h_dict[(size_t)p * w + k] -= rows[(size_t)p];
+        }
+    dev_free(&m->pat_id);
+    dev_free(&m->pat_dict);
+    PAT_TRY(dev_alloc(&m->pat_id, m->nrow));
+    PAT_TRY(dev_alloc(&m->pat_dict, (int64_t)np * w));
+    PAT_TRY(dev_alloc(&d_slot, kPatTable));
+    PAT_TRY(dev_alloc(&d_len, np));
+    PAT_HIP(hipMemcpyAsync(m->pat_dict, h_dict.data(), sizeof(int) * (size_t)np * w, hipMemcpyHostToDevice, b.cur));
+    PAT_HIP(hipMemcpyAsync(d_slot, h_slot, sizeof(int) * kPatTable, hipMemcpyHostToDevice, b.cur));
+    PAT_HIP(hipMemcpyAsync(d_len, h_len.data(), sizeof(int) * (size_t)np, hipMemcpyHostToDevice, b.cur));
+    hipLaunchKernelGGL(k_pat_assign, dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, m->rp, m->ci, table, d_slot, m->pat_dict,
+                       d_len, w, m->pat_id, flag + 1);
+    PAT_HIP(hipMemcpyAsync(h_flag, flag, sizeof(int) * 2, hipMemcpyDeviceToHost, b.cur));
+    PAT_HIP(hipStreamSynchronize(b.cur));
+    cleanup();
+#undef PAT_TRY
+#undef PAT_HIP
+    if(h_flag[1] != 0) // two different rows behind one hash
+    {
+        dev_free(&m->pat_id);
+        dev_free(&m->pat_dict);
+        return RAMD_OK;
+    }
+    m->pat_n     = np;
+    m->pat_w     = w;
+    m->pat_state = 1;
+    return RAMD_OK;
+}
+
 static BandMap band_map_for(const ramd_mat_s* m, int per_xcd);
 
 template <typename T>
@@ -624,7 +836,14 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
     // long rows (mean > 16 entries): four lanes per row (see k_csr_q4)
     static const int q4_env = getenv("RAMD_CSR_Q4") ? atoi(getenv("RAMD_CSR_Q4")) : -1; // (0 / 1: force, A/B experiments)
     const int        rows_per_wg = kCsrRows;
-    const bool q4      = q4_env > 0; // measured EQUAL to k_csr_tr on the shell surrogate (0.162 vs 0.160 ms): opt-in
+    // structured operators: columns from a row-pattern dictionary (csr_analyse_pattern); analysed once, on the first
+    // product of a matrix with >= 2^20 entries (RAMD_CSR_PAT=1: every matrix, =0: never)
+    static const int pat_env = getenv("RAMD_CSR_PAT") ? atoi(getenv("RAMD_CSR_PAT")) : -1;
+    if(m->pat_state == 0 && pat_env != 0 && (pat_env > 0 || m->nnz >= (1 << 20)))
+        RAMD_TRY(csr_analyse_pattern(const_cast<ramd_mat_s*>(m)));
+    const bool       use_pat = pat_env != 0 && m->pat_state == 1;
+    const CsrPattern pat     = {use_pat ? m->pat_id : nullptr, use_pat ? m->pat_dict : nullptr, m->pat_n, m->pat_w};
+    const bool q4      = !use_pat && q4_env > 0; // measured EQUAL to k_csr_tr on the shell surrogate (0.162 vs 0.160 ms): opt-in
     const int  nblk    = (m->nrow + rows_per_wg - 1) / rows_per_wg;
     const int  per_xcd = (nblk + 7) / 8;
     const int  grid    = per_xcd * 8;
@@ -652,9 +871,12 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
         if(q4)                                                                                             \
             hipLaunchKernelGGL((k_csr_q4<T, MODE, DOT>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
                                per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot);           \
+        else if(use_pat)                                                                                   \
+            hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT, true>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
+                               per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat);  \
         else                                                                                               \
-            hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
-                               per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm);       \
+            hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT, false>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
+                               per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat);  \
     } while(0)
     ws.jdinv = jdinv;
     ws.jrhs  = jrhs;

@@ -980,3 +980,66 @@ def test_fused_mgs_block_tiny_vectors(ra, n):
         assert np.max(np.abs(hb[:m] - ha[:m])) <= tol
         assert abs(hb[m] - ha[m]) <= 4 * tol * max(1.0, np.linalg.norm(w0))
         assert np.max(np.abs(wb.numpy().astype(np.float64) - wa.numpy().astype(np.float64))) <= tol
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_csr_row_patterns_in_a_fresh_process(dtype):
+    """row-pattern SpMV (csr_analyse_pattern): a 3-D stencil falls into <= 27 patterns and takes the dictionary kernel, a
+    random matrix and a matrix with a 17-entry row do not; results bit-exact against the oracle either way, also after the
+    values were replaced and for a rectangular block"""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import rocalution_amd as ra
+from rocalution_amd import capi, generators as gen
+from oracle import oracle
+oracle.build(); oracle.set_threads(1); lib = capi.load(); ra.init_rocalution()
+dtype = np.%s
+def info(A):
+    s, n, w = C.c_int(9), C.c_int(0), C.c_int(0)
+    capi.check(lib.ramd_mat_pattern_info(A._h, C.byref(s), C.byref(n), C.byref(w))); return s.value, n.value, w.value
+def check(rp, ci, va, nrow, ncol, want):
+    rng = np.random.default_rng(5)
+    A = ra.LocalMatrix(dtype); A.SetDataPtrCSR(rp, ci, va.astype(dtype), nrow=nrow, ncol=ncol)
+    assert info(A)[0] == 0
+    xh = rng.uniform(-1, 1, ncol).astype(dtype); y0 = rng.uniform(-1, 1, nrow).astype(dtype)
+    x = ra.LocalVector(dtype, data=xh); y = ra.LocalVector(dtype); y.Allocate("", nrow)
+    A.Apply(x, y)
+    st = info(A); assert st[0] == want, (st, want)
+    assert np.array_equal(y.numpy(), oracle.csr_apply(rp, ci, va.astype(dtype), xh))
+    ya = ra.LocalVector(dtype, data=y0); A.ApplyAdd(x, 0.375, ya)
+    assert np.array_equal(ya.numpy(), oracle.csr_apply_add(rp, ci, va.astype(dtype), xh, dtype(0.375), y0))
+    return A, st
+rp, ci, va = gen.poisson7(21, np.float64)
+n = len(rp) - 1
+va = va * np.random.default_rng(1).uniform(0.5, 1.5, len(va))       # values play no role in the pattern
+A, st = check(rp, ci, va, n, n, 1)
+assert st[1] <= 27 and st[2] == 7, st
+# a rectangular row block of the same operator (columns keep their global numbering): offsets relative to the local row
+r0, r1 = 3 * 441, 9 * 441
+rpb = (rp[r0:r1 + 1] - rp[r0]).astype(np.int32); cib = ci[rp[r0]:rp[r1]]; vab = va[rp[r0]:rp[r1]]
+check(rpb, cib, vab, r1 - r0, n, 1)
+# random pattern: far more than 64 different rows
+rng = np.random.default_rng(2); m = 3000
+rows = [sorted(set(rng.integers(0, m, 5).tolist())) for _ in range(m)]
+rpr = np.zeros(m + 1, np.int32); rpr[1:] = np.cumsum([len(r) for r in rows])
+cir = np.array([c for r in rows for c in r], np.int32); var = rng.uniform(-1, 1, len(cir))
+check(rpr, cir, var, m, m, -1)
+# one row of 17 entries in an otherwise structured matrix
+rows = [[i] for i in range(m)]; rows[77] = list(range(60, 77)) ; rows[78] = []
+rpl = np.zeros(m + 1, np.int32); rpl[1:] = np.cumsum([len(r) for r in rows])
+cil = np.array([c for r in rows for c in r], np.int32); val = rng.uniform(-1, 1, len(cil))
+check(rpl, cil, val, m, m, -1)
+rows[77] = list(range(61, 77))                                         # 16 entries: fits; an empty row is a pattern too
+rpl = np.zeros(m + 1, np.int32); rpl[1:] = np.cumsum([len(r) for r in rows])
+cil = np.array([c for r in rows for c in r], np.int32); val = rng.uniform(-1, 1, len(cil))
+A2, st = check(rpl, cil, val, m, m, 1)
+assert st[1] == 3 and st[2] == 16, st
+print("OK")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), np.dtype(dtype).name)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RAMD_CSR_PAT="1"), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0 and b"OK" in r.stdout, r.stdout.decode()[-3000:]
