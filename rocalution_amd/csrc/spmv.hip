@@ -96,6 +96,9 @@ struct CsrDotWs
 // LDS (24 KiB per workgroup) allows 6 workgroups = 6 waves per SIMD: keep the register budget inside
 // 512/6 VGPRs (the fused-dot variant sat at 86 and lost a whole wave per SIMD: -4%)
 // row patterns: see ramd_mat_s::pat_* and csr_analyse_pattern below
+#ifndef RAMD_CSR_PAT_WAVES
+#define RAMD_CSR_PAT_WAVES 6
+#endif
 constexpr int kPatMaxW = 16; // longest row a pattern may have
 constexpr int kPatMax  = 64; // dictionary entries
 struct CsrPattern
@@ -106,7 +109,7 @@ struct CsrPattern
 };
 
 template <typename T, int MODE, bool DOT, bool PAT>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_csr_tr(int nrow, int nblk, int per_xcd,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PAT ? RAMD_CSR_PAT_WAVES : 6, 8))) void k_csr_tr(int nrow, int nblk, int per_xcd,
                                                    const int* __restrict__ rp,
                                                    const int* __restrict__ ci,
                                                    const T* __restrict__ val,
