@@ -657,11 +657,14 @@ __global__ __launch_bounds__(kBlock) void k_pat_insert(int nrow, const int* __re
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
     for(int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += gsz)
     {
+        // (an unstructured matrix is recognised after a few thousand rows: the rest of the sweep only looks at the flag)
+        if(__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+            return;
         const int rs = rp[r], len = rp[r + 1] - rs;
         if(len > kPatMaxW)
         {
-            *fail = 1;
-            continue;
+            __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
         }
         const unsigned long long h = pat_hash(len, ci, rs, (int)r);
         int                      s = (int)(h % kPatTable);
@@ -675,6 +678,8 @@ __global__ __launch_bounds__(kBlock) void k_pat_insert(int nrow, const int* __re
                 if(cur == 0)
                 {
                     rep[s] = (int)r;
+                    if(atomicAdd(fail + 1, 1) >= kPatMax) // (fail[1] counts the distinct rows during this pass)
+                        __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
             }
@@ -682,7 +687,7 @@ __global__ __launch_bounds__(kBlock) void k_pat_insert(int nrow, const int* __re
                 break;
         }
         if(probes == kPatTable)
-            *fail = 1;
+            __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 __global__ __launch_bounds__(kBlock) void k_pat_assign(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
@@ -810,6 +815,7 @@ int csr_analyse_pattern(ramd_mat_s* m)
     PAT_HIP(hipMemcpyAsync(m->pat_dict, h_dict.data(), sizeof(int) * (size_t)np * w, hipMemcpyHostToDevice, b.cur));
     PAT_HIP(hipMemcpyAsync(d_slot, h_slot, sizeof(int) * kPatTable, hipMemcpyHostToDevice, b.cur));
     PAT_HIP(hipMemcpyAsync(d_len, h_len.data(), sizeof(int) * (size_t)np, hipMemcpyHostToDevice, b.cur));
+    PAT_HIP(hipMemsetAsync(flag + 1, 0, sizeof(int), b.cur));
     hipLaunchKernelGGL(k_pat_assign, dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, m->rp, m->ci, table, d_slot, m->pat_dict,
                        d_len, w, m->pat_id, flag + 1);
     PAT_HIP(hipMemcpyAsync(h_flag, flag, sizeof(int) * 2, hipMemcpyDeviceToHost, b.cur));

@@ -3,6 +3,7 @@ same seeded inputs, plus the committed golden fixtures (outputs of the genuine r
 backend).  Bar: element-wise ops, SpMV in all formats, layouts, ILU(0) factors,
 triangular solves, permutations: BIT-EXACT; reductions: relative 1e-13 (tree vs. sequential sum).
 """
+import os
 import numpy as np
 import pytest
 
@@ -1043,3 +1044,32 @@ print("OK")
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RAMD_CSR_PAT="1"), stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0 and b"OK" in r.stdout, r.stdout.decode()[-3000:]
+
+
+def test_csr_row_patterns_give_up_quickly_on_a_large_unstructured_matrix(ra, oracle):
+    """2^20 rows of four random columns each (4.2 M entries: above the default threshold of the analysis): thousands of
+    distinct rows, so the pattern sweep must stop after the first few thousand rows instead of probing a full table for
+    every row; the product is the ordinary one, bit-exact"""
+    import ctypes as C
+    import time
+    from rocalution_amd import capi
+    lib = capi.load()
+    n = 1 << 20
+    rng = np.random.default_rng(8)
+    ci = np.sort(rng.integers(0, n, (n, 4)), axis=1).astype(np.int32).ravel()
+    rp = (np.arange(n + 1, dtype=np.int64) * 4).astype(np.int32)
+    va = rng.uniform(-1, 1, 4 * n)
+    xh = rng.uniform(-1, 1, n)
+    A = ra.LocalMatrix(np.float64); A.SetDataPtrCSR(rp, ci, va)
+    x = ra.LocalVector(np.float64, data=xh); y = ra.LocalVector(np.float64); y.Allocate("", n)
+    ra.sync()
+    t0 = time.perf_counter()
+    A.Apply(x, y)
+    ra.sync()
+    dt = time.perf_counter() - t0
+    st = C.c_int(9)
+    capi.check(lib.ramd_mat_pattern_info(A._h, C.byref(st), None, None))
+    if os.environ.get("RAMD_CSR_PAT", "-1") != "0":
+        assert st.value == -1
+    assert dt < 1.0, dt
+    eq(y.numpy(), oracle.csr_apply(rp, ci, va, xh))
