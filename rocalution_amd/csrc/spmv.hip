@@ -14,6 +14,7 @@
 #include "matrix_impl.hpp"
 
 #include <algorithm>
+#include <climits>
 #include <vector>
 
 namespace ramd
@@ -101,6 +102,7 @@ struct CsrDotWs
 #endif
 constexpr int kPatMaxW = 16; // longest row a pattern may have
 constexpr int kPatMax  = 64; // dictionary entries
+constexpr int kPatEnd  = INT_MIN; // dictionary entry of an ELL slot that holds no column (col < 0)
 struct CsrPattern
 {
     const unsigned char* id; // [nrow]
@@ -403,20 +405,29 @@ __global__ __launch_bounds__(kBlock) void k_csr_q4(int nrow, int nblk, int per_x
 // ELL: one thread per row, column-major => every load is a perfectly coalesced wave access.
 // STOP=true : ELL semantics (stop at the first negative column, host_matrix_ell.cpp:309-318)
 // STOP=false: HYB-ELL semantics (skip invalid columns, host_matrix_hyb.cpp:344-352)
-template <typename T, int MODE, bool STOP, bool DOT>
+// PAT: the slot tuple of a row comes from the row-pattern dictionary (one byte per row instead of four per slot)
+template <typename T, int MODE, bool STOP, bool DOT, bool PAT>
 __global__ __launch_bounds__(kBlock) void k_ell(int nrow, int ncol, int width,
                                                 const int* __restrict__ ecol,
                                                 const T* __restrict__ eval,
                                                 const T* __restrict__ x, T* __restrict__ y, T scalar,
                                                 double* __restrict__ part1, const T* __restrict__ dotv,
-                                                int nblk, int per_xcd, BandMap bm)
+                                                int nblk, int per_xcd, BandMap bm, CsrPattern pat)
 {
+    __shared__ int sdict[PAT ? kPatMax * kPatMaxW : 1];
     double dacc = 0.0;
     // one workgroup per 256 rows, XCD- and band-aware order (same mapping as the CSR kernel)
     const int     blk = xcd_block(nblk, per_xcd, bm);
     const int64_t row = (int64_t)blk * kCsrRows + threadIdx.x;
+    if(PAT)
+    {
+        for(int i = threadIdx.x; i < pat.n * kPatMaxW; i += kBlock)
+            sdict[i] = pat.dict[i];
+        __syncthreads();
+    }
     if(blk >= 0 && row < nrow)
     {
+        const int dbase = PAT ? (int)pat.id[row] * kPatMaxW : 0;
         T sum = (T)0;
         if(MODE == 1)
             sum = y[row];
@@ -433,7 +444,13 @@ __global__ __launch_bounds__(kBlock) void k_ell(int nrow, int ncol, int width,
                 c[e] = -1;
                 if(el + e < width)
                 {
-                    c[e] = nt_load(ecol + (int64_t)(el + e) * nrow + row);
+                    if(PAT)
+                    {
+                        const int o = sdict[dbase + el + e];
+                        c[e]        = o == kPatEnd ? -1 : (int)row + o;
+                    }
+                    else
+                        c[e] = nt_load(ecol + (int64_t)(el + e) * nrow + row);
                     v[e] = nt_load(eval + (int64_t)(el + e) * nrow + row);
                 }
             }
@@ -640,19 +657,49 @@ int csr_analyse_band(ramd_mat_s* m)
 // dictionary entry entry by entry (a hash collision makes the matrix "not usable", never a wrong column).  The SpMV then
 // reads one byte per row instead of four per entry: 9.9 instead of 13.9 GB per launch at 512^3, same values, same order.
 constexpr int kPatTable = 256;
-__device__ __forceinline__ unsigned long long pat_hash(int len, const int* __restrict__ ci, int rs, int row)
+// where the columns of row r live: CSR rows, or the column-major slots of an ELL block (negative column = no entry)
+struct PatCsr
+{
+    const int* rp;
+    const int* ci;
+    __device__ int len(int r) const
+    {
+        return rp[r + 1] - rp[r];
+    }
+    __device__ int off(int r, int k) const
+    {
+        return ci[rp[r] + k] - r;
+    }
+};
+struct PatEll
+{
+    const int* ecol;
+    int        nrow, width;
+    __device__ int len(int) const
+    {
+        return width;
+    }
+    __device__ int off(int r, int k) const
+    {
+        const int c = ecol[(int64_t)k * nrow + r];
+        return c < 0 ? kPatEnd : c - r;
+    }
+};
+template <class Acc>
+__device__ __forceinline__ unsigned long long pat_hash(const Acc& a, int r, int len)
 {
     unsigned long long h = 0x9E3779B97F4A7C15ull ^ (unsigned long long)(unsigned)len;
     for(int k = 0; k < len; ++k)
     {
-        const unsigned long long o = (unsigned long long)(unsigned)(ci[rs + k] - row);
+        const unsigned long long o = (unsigned long long)(unsigned)a.off(r, k);
         h ^= o + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
         h *= 0xD6E8FEB86659FD93ull;
     }
     return h | 1ull; // (0 marks an empty slot)
 }
-__global__ __launch_bounds__(kBlock) void k_pat_insert(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
-                                                       unsigned long long* table, int* rep, int* fail)
+// fail[0]: not usable; fail[1]: distinct rows so far (pass 1) / a row differs from its dictionary entry (pass 2)
+template <class Acc>
+__global__ __launch_bounds__(kBlock) void k_pat_insert(int nrow, Acc a, unsigned long long* table, int* rep, int* fail)
 {
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
     for(int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += gsz)
@@ -660,13 +707,13 @@ __global__ __launch_bounds__(kBlock) void k_pat_insert(int nrow, const int* __re
         // (an unstructured matrix is recognised after a few thousand rows: the rest of the sweep only looks at the flag)
         if(__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
             return;
-        const int rs = rp[r], len = rp[r + 1] - rs;
+        const int len = a.len((int)r);
         if(len > kPatMaxW)
         {
             __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
-        const unsigned long long h = pat_hash(len, ci, rs, (int)r);
+        const unsigned long long h = pat_hash(a, (int)r, len);
         int                      s = (int)(h % kPatTable);
         int                      probes = 0;
         for(; probes < kPatTable; ++probes, s = (s + 1) % kPatTable)
@@ -678,7 +725,7 @@ __global__ __launch_bounds__(kBlock) void k_pat_insert(int nrow, const int* __re
                 if(cur == 0)
                 {
                     rep[s] = (int)r;
-                    if(atomicAdd(fail + 1, 1) >= kPatMax) // (fail[1] counts the distinct rows during this pass)
+                    if(atomicAdd(fail + 1, 1) >= kPatMax)
                         __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
@@ -690,17 +737,28 @@ __global__ __launch_bounds__(kBlock) void k_pat_insert(int nrow, const int* __re
             __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-__global__ __launch_bounds__(kBlock) void k_pat_assign(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
-                                                       const unsigned long long* __restrict__ table,
+// the dictionary: entry p = the offsets of its representative row, kPatMaxW slots each
+template <class Acc>
+__global__ void k_pat_dict(int np, Acc a, const int* __restrict__ rows, int* __restrict__ dict, int* __restrict__ dlen)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if(p >= np)
+        return;
+    const int r = rows[p], len = a.len(r);
+    dlen[p] = len;
+    for(int k = 0; k < kPatMaxW; ++k)
+        dict[p * kPatMaxW + k] = k < len ? a.off(r, k) : 0;
+}
+template <class Acc>
+__global__ __launch_bounds__(kBlock) void k_pat_assign(int nrow, Acc a, const unsigned long long* __restrict__ table,
                                                        const int* __restrict__ slot_id, const int* __restrict__ dict,
-                                                       const int* __restrict__ dlen, int w, unsigned char* __restrict__ id,
-                                                       int* fail)
+                                                       const int* __restrict__ dlen, unsigned char* __restrict__ id, int* fail)
 {
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
     for(int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += gsz)
     {
-        const int                rs = rp[r], len = rp[r + 1] - rs;
-        const unsigned long long h = pat_hash(len, ci, rs, (int)r);
+        const int                len = a.len((int)r);
+        const unsigned long long h = pat_hash(a, (int)r, len);
         int                      s = (int)(h % kPatTable), probes = 0;
         while(probes < kPatTable && table[s] != h)
         {
@@ -714,7 +772,7 @@ __global__ __launch_bounds__(kBlock) void k_pat_assign(int nrow, const int* __re
             p  = slot_id[s];
             ok = dlen[p] == len;
             for(int k = 0; ok && k < len; ++k)
-                ok = dict[p * w + k] == ci[rs + k] - (int)r;
+                ok = dict[p * kPatMaxW + k] == a.off((int)r, k);
         }
         if(!ok)
             *fail = 1;
@@ -722,20 +780,20 @@ __global__ __launch_bounds__(kBlock) void k_pat_assign(int nrow, const int* __re
     }
 }
 
-int csr_analyse_pattern(ramd_mat_s* m)
+template <class Acc>
+static int analyse_pattern(ramd_mat_s* m, Acc acc)
 {
     m->pat_state = -1;
-    if(m->format != RAMD_CSR || m->nrow <= 0 || m->nnz <= 0)
-        return RAMD_OK;
     Backend&            b = backend();
     unsigned long long* table = nullptr;
-    int *               rep = nullptr, *flag = nullptr, *d_slot = nullptr, *d_len = nullptr;
+    int *               rep = nullptr, *flag = nullptr, *d_slot = nullptr, *d_len = nullptr, *d_rows = nullptr;
     auto                cleanup = [&]() {
         dev_free(&table);
         dev_free(&rep);
         dev_free(&flag);
         dev_free(&d_slot);
         dev_free(&d_len);
+        dev_free(&d_rows);
     };
 #define PAT_TRY(expr)          \
     do                         \
@@ -747,14 +805,14 @@ int csr_analyse_pattern(ramd_mat_s* m)
             return s_;         \
         }                      \
     } while(0)
-#define PAT_HIP(expr)                                  \
-    do                                                 \
-    {                                                  \
-        if((expr) != hipSuccess)                       \
-        {                                              \
-            cleanup();                                 \
+#define PAT_HIP(expr)                                    \
+    do                                                   \
+    {                                                    \
+        if((expr) != hipSuccess)                         \
+        {                                                \
+            cleanup();                                   \
             RAMD_FAIL(RAMD_ERR_HIP, "pattern analysis"); \
-        }                                              \
+        }                                                \
     } while(0)
     PAT_TRY(dev_alloc(&table, kPatTable));
     PAT_TRY(dev_alloc(&rep, kPatTable));
@@ -763,63 +821,44 @@ int csr_analyse_pattern(ramd_mat_s* m)
     PAT_HIP(hipMemsetAsync(rep, 0, sizeof(int) * kPatTable, b.cur));
     PAT_HIP(hipMemsetAsync(flag, 0, sizeof(int) * 2, b.cur));
     const int grid = ew_grid(m->nrow);
-    hipLaunchKernelGGL(k_pat_insert, dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, m->rp, m->ci, table, rep, flag);
+    hipLaunchKernelGGL((k_pat_insert<Acc>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, acc, table, rep, flag);
     unsigned long long h_table[kPatTable];
     int                h_rep[kPatTable], h_flag[2] = {0, 0};
     PAT_HIP(hipMemcpyAsync(h_table, table, sizeof(h_table), hipMemcpyDeviceToHost, b.cur));
     PAT_HIP(hipMemcpyAsync(h_rep, rep, sizeof(h_rep), hipMemcpyDeviceToHost, b.cur));
     PAT_HIP(hipMemcpyAsync(h_flag, flag, sizeof(int) * 2, hipMemcpyDeviceToHost, b.cur));
     PAT_HIP(hipStreamSynchronize(b.cur));
-    int np = 0, h_slot[kPatTable];
+    int np = 0, h_slot[kPatTable], h_rows[kPatMax];
     for(int s = 0; s < kPatTable; ++s)
     {
         h_slot[s] = -1;
         if(h_table[s] != 0)
+        {
+            if(np < kPatMax)
+                h_rows[np] = h_rep[s];
             h_slot[s] = np++;
+        }
     }
     if(h_flag[0] != 0 || np == 0 || np > kPatMax)
     {
         cleanup();
         return RAMD_OK; // not usable: stays -1
     }
-    // dictionary: the representative row of every slot
-    std::vector<int> h_len((size_t)np), rows((size_t)np);
-    int              w = 1;
-    for(int s = 0; s < kPatTable; ++s)
-        if(h_slot[s] >= 0)
-        {
-            int pair[2] = {0, 0};
-            PAT_HIP(hipMemcpy(pair, m->rp + h_rep[s], sizeof(int) * 2, hipMemcpyDeviceToHost));
-            rows[(size_t)h_slot[s]]  = h_rep[s];
-            h_len[(size_t)h_slot[s]] = pair[1] - pair[0];
-            w                        = std::max(w, pair[1] - pair[0]);
-        }
-    std::vector<int> h_dict((size_t)np * w, 0);
-    for(int s = 0; s < kPatTable; ++s)
-        if(h_slot[s] >= 0 && h_len[(size_t)h_slot[s]] > 0)
-        {
-            const int p = h_slot[s];
-            int       start = 0;
-            PAT_HIP(hipMemcpy(&start, m->rp + rows[(size_t)p], sizeof(int), hipMemcpyDeviceToHost));
-            PAT_HIP(hipMemcpy(h_dict.data() + (size_t)p * w, m->ci + start, sizeof(int) * (size_t)h_len[(size_t)p],
-                              hipMemcpyDeviceToHost));
-            for(int k = 0; k < h_len[(size_t)p]; ++k)
-                h_dict[(size_t)p * w + k] -= rows[(size_t)p];
-        }
     dev_free(&m->pat_id);
     dev_free(&m->pat_dict);
     PAT_TRY(dev_alloc(&m->pat_id, m->nrow));
-    PAT_TRY(dev_alloc(&m->pat_dict, (int64_t)np * w));
+    PAT_TRY(dev_alloc(&m->pat_dict, (int64_t)np * kPatMaxW));
     PAT_TRY(dev_alloc(&d_slot, kPatTable));
     PAT_TRY(dev_alloc(&d_len, np));
-    PAT_HIP(hipMemcpyAsync(m->pat_dict, h_dict.data(), sizeof(int) * (size_t)np * w, hipMemcpyHostToDevice, b.cur));
+    PAT_TRY(dev_alloc(&d_rows, np));
     PAT_HIP(hipMemcpyAsync(d_slot, h_slot, sizeof(int) * kPatTable, hipMemcpyHostToDevice, b.cur));
-    PAT_HIP(hipMemcpyAsync(d_len, h_len.data(), sizeof(int) * (size_t)np, hipMemcpyHostToDevice, b.cur));
+    PAT_HIP(hipMemcpyAsync(d_rows, h_rows, sizeof(int) * (size_t)np, hipMemcpyHostToDevice, b.cur));
     PAT_HIP(hipMemsetAsync(flag + 1, 0, sizeof(int), b.cur));
-    hipLaunchKernelGGL(k_pat_assign, dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, m->rp, m->ci, table, d_slot, m->pat_dict,
-                       d_len, w, m->pat_id, flag + 1);
+    hipLaunchKernelGGL((k_pat_dict<Acc>), dim3(1), dim3(kPatMax), 0, b.cur, np, acc, d_rows, m->pat_dict, d_len);
+    hipLaunchKernelGGL((k_pat_assign<Acc>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, acc, table, d_slot, m->pat_dict,
+                       d_len, m->pat_id, flag + 1);
     PAT_HIP(hipMemcpyAsync(h_flag, flag, sizeof(int) * 2, hipMemcpyDeviceToHost, b.cur));
-    PAT_HIP(hipStreamSynchronize(b.cur));
+    PAT_HIP(hipStreamSynchronize(b.cur)); // (also: the host arrays above were read by the copies)
     cleanup();
 #undef PAT_TRY
 #undef PAT_HIP
@@ -830,9 +869,25 @@ int csr_analyse_pattern(ramd_mat_s* m)
         return RAMD_OK;
     }
     m->pat_n     = np;
-    m->pat_w     = w;
+    m->pat_w     = kPatMaxW;
     m->pat_state = 1;
     return RAMD_OK;
+}
+
+int csr_analyse_pattern(ramd_mat_s* m)
+{
+    m->pat_state = -1;
+    if(m->format != RAMD_CSR || m->nrow <= 0 || m->nnz <= 0)
+        return RAMD_OK;
+    return analyse_pattern(m, PatCsr{m->rp, m->ci});
+}
+// the ELL block of an ELL / HYB matrix: a pattern is the whole slot tuple, empty slots (col < 0) included
+int ell_analyse_pattern(ramd_mat_s* m)
+{
+    m->pat_state = -1;
+    if((m->format != RAMD_ELL && m->format != RAMD_HYB) || m->nrow <= 0 || m->ell_width <= 0 || m->ell_width > kPatMaxW)
+        return RAMD_OK;
+    return analyse_pattern(m, PatEll{m->ell_col, m->nrow, m->ell_width});
 }
 
 static BandMap band_map_for(const ramd_mat_s* m, int per_xcd);
@@ -944,10 +999,24 @@ static int launch_ell(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
         }
         part1 = mm->dot_part1;
     }
-#define LAUNCH(MODE, STOP, DOT)                                                                        \
-    hipLaunchKernelGGL((k_ell<T, MODE, STOP, DOT>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow,       \
-                       m->ncol, m->ell_width, m->ell_col, (const T*)m->ell_val, x, y, scalar, part1, \
-                       dotv, nblk, per_xcd, bm)
+    // structured operators: the slot tuples from a row-pattern dictionary (see csr_analyse_pattern / launch_csr)
+    static const int pat_env = getenv("RAMD_CSR_PAT") ? atoi(getenv("RAMD_CSR_PAT")) : -1;
+    if(m->pat_state == 0 && pat_env != 0 && (pat_env > 0 || (int64_t)m->nrow * m->ell_width >= (1 << 20)))
+        RAMD_TRY(ell_analyse_pattern(const_cast<ramd_mat_s*>(m)));
+    const bool       use_pat = pat_env != 0 && m->pat_state == 1;
+    const CsrPattern pat     = {use_pat ? m->pat_id : nullptr, use_pat ? m->pat_dict : nullptr, m->pat_n, m->pat_w};
+#define LAUNCH(MODE, STOP, DOT)                                                                          \
+    do                                                                                                   \
+    {                                                                                                    \
+        if(use_pat)                                                                                      \
+            hipLaunchKernelGGL((k_ell<T, MODE, STOP, DOT, true>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, \
+                               m->ncol, m->ell_width, m->ell_col, (const T*)m->ell_val, x, y, scalar, part1, \
+                               dotv, nblk, per_xcd, bm, pat);                                            \
+        else                                                                                             \
+            hipLaunchKernelGGL((k_ell<T, MODE, STOP, DOT, false>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, \
+                               m->ncol, m->ell_width, m->ell_col, (const T*)m->ell_val, x, y, scalar, part1, \
+                               dotv, nblk, per_xcd, bm, pat);                                            \
+    } while(0)
     if(dot && stop)
         LAUNCH(0, true, true);
     else if(dot)

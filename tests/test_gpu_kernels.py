@@ -1018,7 +1018,18 @@ rp, ci, va = gen.poisson7(21, np.float64)
 n = len(rp) - 1
 va = va * np.random.default_rng(1).uniform(0.5, 1.5, len(va))       # values play no role in the pattern
 A, st = check(rp, ci, va, n, n, 1)
-assert st[1] <= 27 and st[2] == 7, st
+assert st[1] <= 27 and st[2] == 16, st
+# the same operator as ELL and as HYB: the analysis runs on the slot tuples of the ELL block (empty slots included)
+for fmt in (ra.ELL, ra.HYB):
+    B = ra.LocalMatrix(dtype); B.SetDataPtrCSR(rp, ci, va.astype(dtype))
+    assert B.ConvertTo(fmt) == fmt and info(B)[0] == 0
+    xh = np.random.default_rng(6).uniform(-1, 1, n).astype(dtype); y0 = np.random.default_rng(7).uniform(-1, 1, n).astype(dtype)
+    x = ra.LocalVector(dtype, data=xh); y = ra.LocalVector(dtype); y.Allocate("", n)
+    B.Apply(x, y)
+    assert info(B)[0] == 1 and info(B)[1] <= 27, info(B)
+    assert np.array_equal(y.numpy(), oracle.csr_apply(rp, ci, va.astype(dtype), xh))
+    ya = ra.LocalVector(dtype, data=y0); B.ApplyAdd(x, -1.25, ya)
+    assert np.array_equal(ya.numpy(), oracle.csr_apply_add(rp, ci, va.astype(dtype), xh, dtype(-1.25), y0))
 # a rectangular row block of the same operator (columns keep their global numbering): offsets relative to the local row
 r0, r1 = 3 * 441, 9 * 441
 rpb = (rp[r0:r1 + 1] - rp[r0]).astype(np.int32); cib = ci[rp[r0]:rp[r1]]; vab = va[rp[r0]:rp[r1]]
@@ -1073,3 +1084,21 @@ def test_csr_row_patterns_give_up_quickly_on_a_large_unstructured_matrix(ra, ora
         assert st.value == -1
     assert dt < 1.0, dt
     eq(y.numpy(), oracle.csr_apply(rp, ci, va, xh))
+
+
+@pytest.mark.parametrize("variant", ["RAMD_CSR_Q4=1", "RAMD_CSR_PAT=1", "RAMD_CSR_PAT=0"])
+def test_spmv_variants_forced_in_a_fresh_process(variant):
+    """the CSR SpMV has an opt-in four-lanes-per-row walk (k_csr_q4), and CSR / ELL / HYB rebuild the columns of structured
+    matrices from row patterns (by default only from 2^20 entries on); each forced on (or off) for EVERY matrix of the
+    SpMV / ApplyAdd / fused-dot / Jacobi-sweep / format tests: results must not change (bit-exact: same values, same order)"""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ)
+    env[variant.split("=")[0]] = variant.split("=")[1]
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_kernels.py"),
+                        os.path.join(here, "test_gpu_edge_cases.py"), os.path.join(here, "test_gpu_solvers.py"), "-q", "-m", "gpu",
+                        "-x", "-k", "(spmv or csr or apply or fused_bicgstab or golden or smoother or dia_format or convert) "
+                                    "and not fresh_process"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
