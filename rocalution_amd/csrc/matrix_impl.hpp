@@ -16,6 +16,19 @@ int    mat_alloc_csr(ramd_mat_s* m, int nrow, int ncol, int64_t nnz);
 
 // spmv.hip: detect a far band (3-D stencil plane distance) for the band-aware row-block traversal
 int csr_analyse_band(ramd_mat_s* m);
+// row patterns (spmv.hip): rows whose column offsets col - row coincide share a dictionary entry of kPatMaxW slots
+constexpr int kPatMaxW = 16; // longest row a pattern may have
+constexpr int kPatMax  = 64; // dictionary entries
+constexpr int kPatEnd  = -2147483647 - 1; // dictionary entry of an ELL slot that holds no column (col < 0)
+struct CsrPattern
+{
+    const unsigned char* id; // [nrow]
+    const int*           dict; // [n * kPatMaxW]
+    int                  n, w;
+};
+// the same analysis for a wave-sliced ELL (slices of 64 rows, column-major inside a slice: the MC-SGS sweeps); on success
+// *state = 1 and *id / *dict are device arrays the caller owns, else *state = -1
+int sell_analyse_pattern(int nrow, const int* slice_off, const int* ecol, int* state, int* n, unsigned char** id, int** dict);
 
 // backend.hip: optional HIP-event bracket around every SpMV launch (bench.py roofline leg)
 void prof_spmv_begin();

@@ -34,6 +34,11 @@ struct McsgsPlan
     // sliced ELL of the strictly lower / upper colour parts (slice = 64 consecutive positions)
     int * l_off = nullptr, *l_col = nullptr, *u_off = nullptr, *u_col = nullptr;
     void *l_val = nullptr, *u_val = nullptr;
+    // row patterns of the two parts (spmv.hip: sell_analyse_pattern): the sweeps of a structured operator rebuild their
+    // columns from one byte per row instead of reading four per slot
+    int            l_pat = 0, u_pat = 0, l_pat_n = 0, u_pat_n = 0; // state: 1 usable
+    unsigned char *l_pat_id = nullptr, *u_pat_id = nullptr;
+    int *          l_pat_dict = nullptr, *u_pat_dict = nullptr;
     void  release()
     {
         dev_free(&iperm);
@@ -42,6 +47,11 @@ struct McsgsPlan
         dev_free(&l_col);
         dev_free(&u_off);
         dev_free(&u_col);
+        dev_free(&l_pat_id);
+        dev_free(&u_pat_id);
+        dev_free(&l_pat_dict);
+        dev_free(&u_pat_dict);
+        l_pat = u_pat = 0;
         void** ps[] = {&d, &dinv, &xp, &l_val, &u_val};
         for(void** p : ps)
         {
@@ -163,18 +173,27 @@ __global__ __launch_bounds__(kBlock) void k_mc_fill(int n, int nb, const int* __
 //   !ident   : s = s * dinv[t]            (diag_solver_[i]->Solve in place)
 //   BOTH     : last colour: L sweep, D and R sweep of the same row in one go (it has no U part)
 //   TO_OUT   : out[iperm[t]] = s          (folds x = P^T x_)
-template <typename T, bool FROM_RHS, bool MULT_D, bool BOTH, bool TO_OUT>
+//   PAT      : the columns come from the row-pattern dictionary (one byte per row; -1 slots are dictionary entries too)
+template <typename T, bool FROM_RHS, bool MULT_D, bool BOTH, bool TO_OUT, bool PAT>
 __global__ __launch_bounds__(kBlock) void k_mc_sweep(int p0, int p1, const int* __restrict__ slice_off,
                                                      const int* __restrict__ ecol,
                                                      const T* __restrict__ eval,
                                                      const T* __restrict__ d, const T* __restrict__ dinv,
                                                      const int* __restrict__ iperm,
                                                      const T* __restrict__ rhs, T* xp,
-                                                     T* __restrict__ out, int identity)
+                                                     T* __restrict__ out, int identity, CsrPattern pat)
 {
+    __shared__ int sdict[PAT ? kPatMax * kPatMaxW : 1];
+    if(PAT)
+    {
+        for(int i = threadIdx.x; i < pat.n * kPatMaxW; i += kBlock)
+            sdict[i] = pat.dict[i];
+        __syncthreads();
+    }
     const int64_t t = (int64_t)p0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if(t >= p1)
         return;
+    const int dbase = PAT ? (int)pat.id[t] * kPatMaxW : 0;
     const int lane = (int)(t & 63);
     const int base = slice_off[t >> 6];
     const int w    = (slice_off[(t >> 6) + 1] - base) >> 6;
@@ -194,7 +213,13 @@ __global__ __launch_bounds__(kBlock) void k_mc_sweep(int p0, int p1, const int* 
             c[e] = -1;
             if(k0 + e < w)
             {
-                c[e] = nt_load(ecol + base + (k0 + e) * 64 + lane);
+                if(PAT)
+                {
+                    const int o = sdict[dbase + k0 + e];
+                    c[e]        = o == kPatEnd ? -1 : (int)t + o;
+                }
+                else
+                    c[e] = nt_load(ecol + base + (k0 + e) * 64 + lane);
                 a[e] = nt_load(eval + base + (k0 + e) * 64 + lane);
             }
         }
@@ -313,6 +338,14 @@ static int mc_build(McsgsPlan* P, const ramd_mat_s* m, const int* perm)
     int s = mc_pack<T>(P, m, true, d_off);
     if(s == RAMD_OK)
         s = mc_pack<T>(P, m, false, d_off);
+    // structured operators: row patterns of both parts (same switch and threshold as the SpMV: RAMD_CSR_PAT, 2^20 entries)
+    static const int pat_env = getenv("RAMD_CSR_PAT") ? atoi(getenv("RAMD_CSR_PAT")) : -1;
+    if(s == RAMD_OK && pat_env != 0 && (pat_env > 0 || m->nnz >= (1 << 20)))
+    {
+        s = sell_analyse_pattern(n, P->l_off, P->l_col, &P->l_pat, &P->l_pat_n, &P->l_pat_id, &P->l_pat_dict);
+        if(s == RAMD_OK)
+            s = sell_analyse_pattern(n, P->u_off, P->u_col, &P->u_pat, &P->u_pat_n, &P->u_pat_id, &P->u_pat_dict);
+    }
     int* cnt = nullptr;
     if(s == RAMD_OK)
         s = dev_alloc(&cnt, nb);
@@ -342,15 +375,24 @@ static int mc_apply(McsgsPlan* P, int kind, const T* rhs, T* out)
 {
     Backend&  b  = backend();
     const int nb = P->nb;
+    const CsrPattern lpat = {P->l_pat_id, P->l_pat_dict, P->l_pat_n, kPatMaxW};
+    const CsrPattern upat = {P->u_pat_id, P->u_pat_dict, P->u_pat_n, kPatMaxW};
 #define SWEEP_ID(FR, MD, BO, TO, i, OFFP, COLP, VALP, IDENT)                                             \
     do                                                                                                   \
     {                                                                                                    \
-        const int p0 = P->off[(size_t)(i)], p1 = P->off[(size_t)(i) + 1];                                \
-        if(p1 > p0)                                                                                      \
-            hipLaunchKernelGGL((k_mc_sweep<T, FR, MD, BO, TO>), dim3((p1 - p0 + kBlock - 1) / kBlock),   \
+        const int  p0 = P->off[(size_t)(i)], p1 = P->off[(size_t)(i) + 1];                               \
+        const bool lower_part = (OFFP) == P->l_off;                                                      \
+        const bool use_pat    = lower_part ? P->l_pat == 1 : P->u_pat == 1;                              \
+        if(p1 > p0 && use_pat)                                                                           \
+            hipLaunchKernelGGL((k_mc_sweep<T, FR, MD, BO, TO, true>), dim3((p1 - p0 + kBlock - 1) / kBlock), \
                                dim3(kBlock), 0, b.cur, p0, p1, OFFP, COLP, (const T*)VALP,               \
                                (const T*)P->d, (const T*)P->dinv, P->iperm, rhs, (T*)P->xp, out,         \
-                               (int)(IDENT));                                                            \
+                               (int)(IDENT), lower_part ? lpat : upat);                                  \
+        else if(p1 > p0)                                                                                 \
+            hipLaunchKernelGGL((k_mc_sweep<T, FR, MD, BO, TO, false>), dim3((p1 - p0 + kBlock - 1) / kBlock), \
+                               dim3(kBlock), 0, b.cur, p0, p1, OFFP, COLP, (const T*)VALP,               \
+                               (const T*)P->d, (const T*)P->dinv, P->iperm, rhs, (T*)P->xp, out,         \
+                               (int)(IDENT), lpat);                                                      \
     } while(0)
 #define SWEEP(FR, MD, BO, TO, i, OFFP, COLP, VALP)                                                       \
     SWEEP_ID(FR, MD, BO, TO, i, OFFP, COLP, VALP, P->identity[(size_t)(i)])

@@ -100,16 +100,6 @@ struct CsrDotWs
 #ifndef RAMD_CSR_PAT_WAVES
 #define RAMD_CSR_PAT_WAVES 6
 #endif
-constexpr int kPatMaxW = 16; // longest row a pattern may have
-constexpr int kPatMax  = 64; // dictionary entries
-constexpr int kPatEnd  = INT_MIN; // dictionary entry of an ELL slot that holds no column (col < 0)
-struct CsrPattern
-{
-    const unsigned char* id; // [nrow]
-    const int*           dict; // [n * w]
-    int                  n, w;
-};
-
 template <typename T, int MODE, bool DOT, bool PAT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PAT ? RAMD_CSR_PAT_WAVES : 6, 8))) void k_csr_tr(int nrow, int nblk, int per_xcd,
                                                    const int* __restrict__ rp,
@@ -685,6 +675,20 @@ struct PatEll
         return c < 0 ? kPatEnd : c - r;
     }
 };
+struct PatSell // slices of 64 rows, column-major inside the slice, width = slice length / 64
+{
+    const int* slice_off;
+    const int* ecol;
+    __device__ int len(int r) const
+    {
+        return (slice_off[(r >> 6) + 1] - slice_off[r >> 6]) >> 6;
+    }
+    __device__ int off(int r, int k) const
+    {
+        const int c = ecol[slice_off[r >> 6] + k * 64 + (r & 63)];
+        return c < 0 ? kPatEnd : c - r;
+    }
+};
 template <class Acc>
 __device__ __forceinline__ unsigned long long pat_hash(const Acc& a, int r, int len)
 {
@@ -781,9 +785,9 @@ __global__ __launch_bounds__(kBlock) void k_pat_assign(int nrow, Acc a, const un
 }
 
 template <class Acc>
-static int analyse_pattern(ramd_mat_s* m, Acc acc)
+static int analyse_pattern(int nrow, Acc acc, int* out_state, int* out_n, unsigned char** out_id, int** out_dict)
 {
-    m->pat_state = -1;
+    *out_state = -1;
     Backend&            b = backend();
     unsigned long long* table = nullptr;
     int *               rep = nullptr, *flag = nullptr, *d_slot = nullptr, *d_len = nullptr, *d_rows = nullptr;
@@ -820,8 +824,8 @@ static int analyse_pattern(ramd_mat_s* m, Acc acc)
     PAT_HIP(hipMemsetAsync(table, 0, sizeof(unsigned long long) * kPatTable, b.cur));
     PAT_HIP(hipMemsetAsync(rep, 0, sizeof(int) * kPatTable, b.cur));
     PAT_HIP(hipMemsetAsync(flag, 0, sizeof(int) * 2, b.cur));
-    const int grid = ew_grid(m->nrow);
-    hipLaunchKernelGGL((k_pat_insert<Acc>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, acc, table, rep, flag);
+    const int grid = ew_grid(nrow);
+    hipLaunchKernelGGL((k_pat_insert<Acc>), dim3(grid), dim3(kBlock), 0, b.cur, nrow, acc, table, rep, flag);
     unsigned long long h_table[kPatTable];
     int                h_rep[kPatTable], h_flag[2] = {0, 0};
     PAT_HIP(hipMemcpyAsync(h_table, table, sizeof(h_table), hipMemcpyDeviceToHost, b.cur));
@@ -844,19 +848,19 @@ static int analyse_pattern(ramd_mat_s* m, Acc acc)
         cleanup();
         return RAMD_OK; // not usable: stays -1
     }
-    dev_free(&m->pat_id);
-    dev_free(&m->pat_dict);
-    PAT_TRY(dev_alloc(&m->pat_id, m->nrow));
-    PAT_TRY(dev_alloc(&m->pat_dict, (int64_t)np * kPatMaxW));
+    dev_free(out_id);
+    dev_free(out_dict);
+    PAT_TRY(dev_alloc(out_id, nrow));
+    PAT_TRY(dev_alloc(out_dict, (int64_t)np * kPatMaxW));
     PAT_TRY(dev_alloc(&d_slot, kPatTable));
     PAT_TRY(dev_alloc(&d_len, np));
     PAT_TRY(dev_alloc(&d_rows, np));
     PAT_HIP(hipMemcpyAsync(d_slot, h_slot, sizeof(int) * kPatTable, hipMemcpyHostToDevice, b.cur));
     PAT_HIP(hipMemcpyAsync(d_rows, h_rows, sizeof(int) * (size_t)np, hipMemcpyHostToDevice, b.cur));
     PAT_HIP(hipMemsetAsync(flag + 1, 0, sizeof(int), b.cur));
-    hipLaunchKernelGGL((k_pat_dict<Acc>), dim3(1), dim3(kPatMax), 0, b.cur, np, acc, d_rows, m->pat_dict, d_len);
-    hipLaunchKernelGGL((k_pat_assign<Acc>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, acc, table, d_slot, m->pat_dict,
-                       d_len, m->pat_id, flag + 1);
+    hipLaunchKernelGGL((k_pat_dict<Acc>), dim3(1), dim3(kPatMax), 0, b.cur, np, acc, d_rows, *out_dict, d_len);
+    hipLaunchKernelGGL((k_pat_assign<Acc>), dim3(grid), dim3(kBlock), 0, b.cur, nrow, acc, table, d_slot, *out_dict, d_len,
+                       *out_id, flag + 1);
     PAT_HIP(hipMemcpyAsync(h_flag, flag, sizeof(int) * 2, hipMemcpyDeviceToHost, b.cur));
     PAT_HIP(hipStreamSynchronize(b.cur)); // (also: the host arrays above were read by the copies)
     cleanup();
@@ -864,13 +868,12 @@ static int analyse_pattern(ramd_mat_s* m, Acc acc)
 #undef PAT_HIP
     if(h_flag[1] != 0) // two different rows behind one hash
     {
-        dev_free(&m->pat_id);
-        dev_free(&m->pat_dict);
+        dev_free(out_id);
+        dev_free(out_dict);
         return RAMD_OK;
     }
-    m->pat_n     = np;
-    m->pat_w     = kPatMaxW;
-    m->pat_state = 1;
+    *out_n     = np;
+    *out_state = 1;
     return RAMD_OK;
 }
 
@@ -879,7 +882,8 @@ int csr_analyse_pattern(ramd_mat_s* m)
     m->pat_state = -1;
     if(m->format != RAMD_CSR || m->nrow <= 0 || m->nnz <= 0)
         return RAMD_OK;
-    return analyse_pattern(m, PatCsr{m->rp, m->ci});
+    m->pat_w = kPatMaxW;
+    return analyse_pattern(m->nrow, PatCsr{m->rp, m->ci}, &m->pat_state, &m->pat_n, &m->pat_id, &m->pat_dict);
 }
 // the ELL block of an ELL / HYB matrix: a pattern is the whole slot tuple, empty slots (col < 0) included
 int ell_analyse_pattern(ramd_mat_s* m)
@@ -887,7 +891,16 @@ int ell_analyse_pattern(ramd_mat_s* m)
     m->pat_state = -1;
     if((m->format != RAMD_ELL && m->format != RAMD_HYB) || m->nrow <= 0 || m->ell_width <= 0 || m->ell_width > kPatMaxW)
         return RAMD_OK;
-    return analyse_pattern(m, PatEll{m->ell_col, m->nrow, m->ell_width});
+    m->pat_w = kPatMaxW;
+    return analyse_pattern(m->nrow, PatEll{m->ell_col, m->nrow, m->ell_width}, &m->pat_state, &m->pat_n, &m->pat_id,
+                           &m->pat_dict);
+}
+int sell_analyse_pattern(int nrow, const int* slice_off, const int* ecol, int* state, int* n, unsigned char** id, int** dict)
+{
+    *state = -1;
+    if(nrow <= 0)
+        return RAMD_OK;
+    return analyse_pattern(nrow, PatSell{slice_off, ecol}, state, n, id, dict);
 }
 
 static BandMap band_map_for(const ramd_mat_s* m, int per_xcd);

@@ -1088,9 +1088,10 @@ def test_csr_row_patterns_give_up_quickly_on_a_large_unstructured_matrix(ra, ora
 
 @pytest.mark.parametrize("variant", ["RAMD_CSR_Q4=1", "RAMD_CSR_PAT=1", "RAMD_CSR_PAT=0"])
 def test_spmv_variants_forced_in_a_fresh_process(variant):
-    """the CSR SpMV has an opt-in four-lanes-per-row walk (k_csr_q4), and CSR / ELL / HYB rebuild the columns of structured
-    matrices from row patterns (by default only from 2^20 entries on); each forced on (or off) for EVERY matrix of the
-    SpMV / ApplyAdd / fused-dot / Jacobi-sweep / format tests: results must not change (bit-exact: same values, same order)"""
+    """the CSR SpMV has an opt-in four-lanes-per-row walk (k_csr_q4), and CSR / ELL / HYB products and the multi-colour
+    sweeps rebuild the columns of structured matrices from row patterns (by default only from 2^20 entries on); each forced
+    on (or off) for EVERY matrix of the SpMV / ApplyAdd / fused-dot / Jacobi-sweep / format / multi-colour / solver-history
+    tests: results must not change (bit-exact: same values, same order)"""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
@@ -1098,7 +1099,8 @@ def test_spmv_variants_forced_in_a_fresh_process(variant):
     env[variant.split("=")[0]] = variant.split("=")[1]
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_kernels.py"),
                         os.path.join(here, "test_gpu_edge_cases.py"), os.path.join(here, "test_gpu_solvers.py"), "-q", "-m", "gpu",
-                        "-x", "-k", "(spmv or csr or apply or fused_bicgstab or golden or smoother or dia_format or convert) "
+                        "-x", "-k", "(spmv or csr or apply or fused_bicgstab or golden or smoother or dia_format or convert or mcsgs or mcgs or mcilu "
+                                    "or multicolor or history) "
                                     "and not fresh_process"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
