@@ -708,8 +708,12 @@ __global__ __launch_bounds__(kBlock) void k_pat_insert(int nrow, Acc a, unsigned
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
     for(int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += gsz)
     {
-        // (an unstructured matrix is recognised after a few thousand rows: the rest of the sweep only looks at the flag)
-        if(__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+        // (an unstructured matrix is recognised after a few thousand rows: the rest of the sweep only looks at the flag --
+        // one lane per wave: a load of ONE word by every row is served by one L2 channel, 0.5 s at 512^3)
+        int stop = 0;
+        if((threadIdx.x & 63) == 0)
+            stop = __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if(__shfl(stop, 0) != 0)
             return;
         const int len = a.len((int)r);
         if(len > kPatMaxW)
