@@ -479,7 +479,7 @@ def main():
             for name, sc, pc, bs, iters in (("gmres30_ilu0", S.GMRES, S.ILU, 30, min(K, 60)),
                                             ("bicgstab_mcsgs", S.BiCGStab, S.MultiColoredSGS, None, min(K, 60))):
                 try:
-                    d2, i2, r2, tb2 = run(iters, sc, pc, bs)
+                    d2, i2, r2, tb2 = run(iters, sc, pc, bs, warm=min(W, 10))
                     extras[name] = dict(iters_per_s=round(i2 / d2, 2), iters=i2, build_s=round(tb2, 3))
                 except Exception as e:
                     extras[name] = dict(error=repr(e))
