@@ -368,3 +368,37 @@ def test_bench_never_runs_on_fewer_ranks_than_asked():
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert p.returncode == 2
     assert "need 2 devices" in p.stderr and p.stdout.strip() == ""
+
+
+def test_blocked_mgs_recurrence_numpy_model():
+    """the algebra behind ramd_fused_mgs_block (include/rocalution_amd.h; GMRES::doFusedMGS): with e_m = <v_m, w> and the
+    block's Gram entries g_km = <v_k, v_m> taken in ONE pass over the un-updated w, forward substitution
+    h_m = e_m - sum_{k<m} h_k g_km gives the modified Gram-Schmidt coefficients -- for an oblique basis too (the Gram
+    entries are measured, not assumed zero).  numpy model of the device passes, blocks of 4, against the sequential loop."""
+    import numpy as np
+    rng = np.random.default_rng(11)
+    n, m, K = 5000, 11, 4
+    for oblique in (False, True):
+        V = rng.uniform(-1, 1, (n, m))
+        V = V / np.linalg.norm(V, axis=0) if oblique else np.linalg.qr(V)[0]
+        w0 = rng.uniform(-1, 1, n)
+        w = w0.copy(); href = np.zeros(m)
+        for k in range(m):  # gmres.cpp:480-486
+            href[k] = V[:, k] @ w
+            w = w - href[k] * V[:, k]
+        wb = w0.copy(); h = np.zeros(m); prev = None
+        for b in range(0, m, K):
+            blk = list(range(b, min(b + K, m)))
+            if prev is not None:  # prologue of the pass: solve the previous block, apply it in MGS order
+                for k in prev[0]:
+                    wb = wb - h[k] * V[:, k]
+            e = np.array([V[:, k] @ wb for k in blk])
+            G = np.array([[V[:, a] @ V[:, c] for c in blk] for a in blk])
+            for i, k in enumerate(blk):
+                h[k] = e[i] - sum(h[blk[j]] * G[j, i] for j in range(i))
+            prev = (blk,)
+        for k in prev[0]:
+            wb = wb - h[k] * V[:, k]
+        tol = (1e-13 if not oblique else 2e-12) * np.linalg.norm(w0)
+        assert np.max(np.abs(h - href)) <= tol
+        assert np.max(np.abs(wb - w)) <= tol
