@@ -47,7 +47,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
-PROF_SPMV, PROF_TRSV, PROF_HALO, PROF_HALO_WAIT, PROF_ALLREDUCE, PROF_VEC = range(6)
+PROF_SPMV, PROF_TRSV, PROF_HALO, PROF_HALO_WAIT, PROF_ALLREDUCE, PROF_VEC, PROF_PRECOND = range(7)
 
 
 def log(*a):
@@ -67,6 +67,13 @@ def trsv_bytes(n, nnz, vbytes=8):
     lo = 4 * (n + nl) + vbytes * (2 * n + nl)
     up = 4 * (n + nl + n) + vbytes * (2 * n + nl + n)
     return (lo + up) // 2
+
+
+def mcsgs_bytes(n, nnz, vbytes=8):
+    """algorithmic bytes of ONE multi-coloured SGS apply (preconditioner_multicolored_gs.cpp:127-215): every off-diagonal
+    entry once (column index + value: the lower part in SolveL_, the upper part in SolveR_) and five vector streams
+    (rhs in, the inverse diagonal twice, the diagonal, x out)"""
+    return (4 + vbytes) * (nnz - n) + 5 * vbytes * n
 
 
 def physical_cores():
@@ -100,7 +107,8 @@ def cpu_baseline(args, mtx_path=None):
                                           env=env, stderr=subprocess.DEVNULL, timeout=1500).decode()
             rec = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
             if mtx_path:
-                what = "the full %d-row surrogate file (read by the reference's ReadFileMTX in %.1f s)" % (rec["n"], rec["t_read_s"])
+                what = "the full %d-row %s (read by the reference's ReadFileMTX in %.1f s)" % (
+                    rec["n"], "surrogate file" if args.matrix == "shell" else "file " + os.path.basename(mtx_path), rec["t_read_s"])
                 scale = 1.0
             else:
                 scale = (args.cpu_grid / float(args.grid)) ** 3
@@ -118,7 +126,14 @@ def cpu_baseline(args, mtx_path=None):
     from rocalution_amd import generators as gen
     orc.build()
     orc.set_threads(threads)
-    if args.matrix == "shell":
+    if args.matrix == "file":
+        import scipy.io
+        import scipy.sparse as sp
+        M = sp.csr_matrix(scipy.io.mmread(mtx_path))
+        M.sort_indices()
+        rp, ci, va = M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data.astype(np.float64)
+        what = "file " + os.path.basename(mtx_path)
+    elif args.matrix == "shell":
         rp, ci, va = gen.shell_surrogate(min(args.shell_nx, 200))
         what = "shell surrogate %d^2 nodes" % min(args.shell_nx, 200)
     else:
@@ -219,7 +234,7 @@ def roof(name, bytes_alg, p, traffic=None):
 def traffic_for(key):
     """HBM bytes per launch from the PMC counters: measured offline with rocprofv3 in separate --pmc passes
     (tools/pmc_passes.sh) and committed under profiles/; bench.py does not run the profiler"""
-    for f in ("r02_traffic.json", "r01_traffic.json"):
+    for f in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         p = os.path.join(ROOT, "profiles", f)
         if os.path.exists(p):
             d = json.load(open(p))
@@ -235,9 +250,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--matrix", default="poisson", choices=["poisson", "shell"],
+    ap.add_argument("--matrix", default="poisson", choices=["poisson", "shell", "file"],
                     help="poisson: 3-D 7-point operator (device generator); shell: af_shell10-class surrogate "
-                         "(BASELINE.json config 3; 1 GPU), read through ReadFileMTX")
+                         "(BASELINE.json config 3; 1 GPU), read through ReadFileMTX; file: the MatrixMarket file given with --mtx")
+    ap.add_argument("--mtx", default=None, metavar="PATH",
+                    help="MatrixMarket file supplied on the box (e.g. SuiteSparse af_shell10.mtx for config 3): read with the "
+                         "reference's ReadFileMTX semantics (host_io.cpp:135-276); implies --matrix file")
     ap.add_argument("--grid", type=int, default=512, help="Poisson grid edge N (operator is N^3 x N^3)")
     ap.add_argument("--shell-nx", type=int, default=549, help="shell surrogate: nx x nx mesh nodes, 5 unknowns each")
     ap.add_argument("--format", default="csr", choices=["csr", "ell", "hyb", "dia"])
@@ -256,6 +274,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the GMRES(30)+ILU(0) and BiCGStab+MC-SGS legs (reported under `extras`)")
     args = ap.parse_args()
+    if args.mtx:
+        args.matrix = "file"
+    if args.matrix == "file" and not (args.mtx and os.path.exists(args.mtx)):
+        raise SystemExit("--matrix file needs --mtx PATH of an existing MatrixMarket file")
     if args.cpu_grid is None:
         args.cpu_grid = args.grid
     if args.cpu_iters is None:  # ~10-30 s of host work at the default sizes
@@ -269,8 +291,8 @@ def main():
     if world != args.gpus:
         log("bench.py: --gpus %d but the launcher started %d rank(s): refusing to report a mislabelled run" % (args.gpus, world))
         sys.exit(2)
-    if args.matrix == "shell" and (world > 1 or args.force_global):
-        raise SystemExit("--matrix shell is the 1-GPU workload of config 3 (LocalMatrix path)")
+    if args.matrix in ("shell", "file") and (world > 1 or args.force_global):
+        raise SystemExit("--matrix shell / --mtx is the 1-GPU workload of config 3 (LocalMatrix path)")
 
     if args.force_global:
         os.environ["RAMD_COMM_FORCE_COLLECTIVES"] = "1"
@@ -324,6 +346,8 @@ def main():
     extras = {}
     ingest = None
     mtx_path = None
+    mtx_generated = False
+    cols_read = None
     scaling_fields = {}
     if world == 1 and not args.force_global:
         from rocalution_amd import solvers as S
@@ -334,6 +358,7 @@ def main():
             rp_h, ci_h, va_h = gen.shell_surrogate(args.shell_nx)
             t_gen = time.perf_counter() - t0
             mtx_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "ramd_shell_%d.mtx" % args.shell_nx)
+            mtx_generated = True
             t0 = time.perf_counter()
             stored = gen.write_mtx_symmetric(mtx_path, rp_h, ci_h, va_h)
             t_write = time.perf_counter() - t0
@@ -349,6 +374,17 @@ def main():
             wl = ("af_shell10-class surrogate (SuiteSparse af_shell10 itself is not available offline): %d x %d mesh nodes x 5 "
                   "unknowns, n=%d, nnz=%d (%.2f per row; af_shell10: n=1508065, nnz=52259885), SPD, read from a MatrixMarket "
                   "symmetric file" % (args.shell_nx, args.shell_nx, n, nnz, nnz / n))
+        elif args.matrix == "file":
+            mtx_path = os.path.abspath(args.mtx)
+            t0 = time.perf_counter()
+            A.ReadFileMTX(mtx_path)
+            ra.sync()
+            n, nnz = A.GetM(), A.GetNnz()
+            if A.GetN() != n:
+                raise SystemExit("--mtx: the Krylov drivers need a square matrix (%d x %d)" % (n, A.GetN()))
+            ingest = dict(file_bytes=os.path.getsize(mtx_path), read_s=round(time.perf_counter() - t0, 3))
+            regen = lambda: A.ReadFileMTX(mtx_path)
+            wl = "%s (n=%d, nnz=%d, %.2f per row), read through ReadFileMTX" % (os.path.basename(mtx_path), n, nnz, nnz / max(n, 1))
         else:
             n, nnz = N ** 3, 7 * N ** 3 - 6 * N ** 2
             A.GenPoisson7(N)
@@ -424,12 +460,20 @@ def main():
         assert it == K, (it, K)
         # --- roofline leg: the SAME solver run again with every SpMV / triangular-solve / fused-vector launch
         # bracketed by HIP events on the stream it runs on
-        for ch in (PROF_SPMV, PROF_TRSV, PROF_VEC):
-            capi.check(lib.ramd_prof_enable(ch, 1))
-        run(min(K, 20) if mixed else min(K, 200), HEAD, HPC, basis)
-        p_spmv, p_trsv, p_vec = (prof_get(lib, capi, ch) for ch in (PROF_SPMV, PROF_TRSV, PROF_VEC))
-        for ch in (PROF_SPMV, PROF_TRSV, PROF_VEC):
-            capi.check(lib.ramd_prof_enable(ch, 0))
+        CH = (PROF_SPMV, PROF_TRSV, PROF_VEC, PROF_PRECOND)
+
+        def profiled(iters, *a):
+            """the solver run again with every launch of the channels bracketed by HIP events on its stream"""
+            for ch in CH:
+                capi.check(lib.ramd_prof_enable(ch, 1))
+            run(iters, *a)
+            r = {ch: prof_get(lib, capi, ch) for ch in CH}
+            for ch in CH:
+                capi.check(lib.ramd_prof_enable(ch, 0))
+            return r
+
+        pr0 = profiled(min(K, 20) if mixed else min(K, 200), HEAD, HPC, basis)
+        p_spmv, p_trsv, p_vec = pr0[PROF_SPMV], pr0[PROF_TRSV], pr0[PROF_VEC]
         vb = 4 if mixed else 8  # the launches of a mixed-precision run are (all but a handful) the fp32 inner SpMVs
         if args.format == "csr":
             b_spmv = spmv_bytes(n, nnz, vb)
@@ -473,6 +517,19 @@ def main():
             else:
                 kernels["vector_updates"] = roof("k_mgs_step" if args.solver == "gmres" else "k_cg_update / k_cg_direction",
                                                  (32 if args.solver == "gmres" else 40) * n * vb // 8, p_vec)
+        st_pat = C.c_int(0)
+        capi.check(lib.ramd_mat_pattern_info(A._h, C.byref(st_pat), None, None))
+        if st_pat.value == 1 and not mixed and args.format in ("csr", "ell", "hyb"):
+            # the SAME run with the columns read (the general path every unstructured matrix takes): its own timed
+            # K iterations and its own HIP-event average; the row-pattern figure above stays the headline
+            A.UseRowPatterns(False)
+            d3, i3, _, _ = run(K, HEAD, HPC, basis, warm=W)
+            pr3 = profiled(min(K, 200), HEAD, HPC, basis)
+            A.UseRowPatterns(True)
+            ck = "spmv_csr_512_columns_read" if tkey == "spmv_csr_512" else None
+            cols_read = dict(iters_per_s=round(i3 / d3, 3), ms_per_step=round(d3 / i3 * 1e3, 5),
+                             roofline=roof(k_spmv.split(" (")[0] + " with the stored columns read (ramd_mat_pattern_use(m, 0))",
+                                           b_spmv, pr3[PROF_SPMV], traffic_for(ck) if ck else None))
         if not args.no_extras and args.solver == "cg" and args.precond == "jacobi" and args.matrix == "poisson":
             # the other two solver/preconditioner pairs of BASELINE.json on the same operator (same
             # "exactly K iterations" protocol; Build() reported separately, as in the reference samples)
@@ -480,7 +537,18 @@ def main():
                                             ("bicgstab_mcsgs", S.BiCGStab, S.MultiColoredSGS, None, min(K, 60))):
                 try:
                     d2, i2, r2, tb2 = run(iters, sc, pc, bs, warm=min(W, 10))
-                    extras[name] = dict(iters_per_s=round(i2 / d2, 2), iters=i2, build_s=round(tb2, 3))
+                    extras[name] = dict(iters_per_s=round(i2 / d2, 2), iters=i2, ms_per_step=round(d2 / i2 * 1e3, 4),
+                                        build_s=round(tb2, 3))
+                    # first-class evidence: the dominant kernel of the leg with its own HIP-event average
+                    pe = profiled(iters, sc, pc, bs)
+                    big = (args.matrix == "poisson" and N == 512)
+                    if name == "gmres30_ilu0" and pe[PROF_TRSV]["launches"] > 0:
+                        extras[name]["roofline"] = roof("sparse triangular solve (k_trsv_rec), one launch per triangle",
+                                                        trsv_bytes(n, nnz, 8), pe[PROF_TRSV], traffic_for("trsv_512") if big else None)
+                    if name == "bicgstab_mcsgs" and pe[PROF_PRECOND]["launches"] > 0:
+                        extras[name]["roofline"] = roof("multi-coloured SGS apply (k_mc_sweep: all colour sweeps of one apply)",
+                                                        mcsgs_bytes(n, nnz, 8), pe[PROF_PRECOND], traffic_for("mcsgs_512") if big else None)
+                    extras[name]["kernels"] = {"spmv": roof("CSR SpMV (k_csr_tr)", spmv_bytes(n, nnz, 8), pe[PROF_SPMV])}
                 except Exception as e:
                     extras[name] = dict(error=repr(e))
     else:
@@ -585,7 +653,8 @@ def main():
     if rank == 0:
         out = {
             "metric": "%s iterations/s, %s %s fp64" % (label, "3D 7-pt Poisson %d^3" % N if args.matrix == "poisson"
-                                                       else "af_shell10-class surrogate (n=%d)" % n, args.format.upper()),
+                                                       else ("af_shell10-class surrogate (n=%d)" % n if args.matrix == "shell"
+                                                             else "%s (n=%d)" % (os.path.basename(args.mtx), n)), args.format.upper()),
             "value": round(it / dt, 3), "unit": "iters/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / it * 1e3, 5), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64/f32" if mixed else "f64",
@@ -597,6 +666,9 @@ def main():
         }
         if prof is not None:
             out["roofline"] = prof
+        if cols_read is not None:
+            out["roofline_columns_read"] = cols_read["roofline"]
+            out["columns_read"] = {k: cols_read[k] for k in ("iters_per_s", "ms_per_step")}
         if kernels:
             out["kernels"] = kernels
             if "spmv" in kernels:
@@ -616,7 +688,7 @@ def main():
                 out["reference_gpu"] = rg
         C.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
-    if mtx_path and os.path.exists(mtx_path):
+    if mtx_generated and mtx_path and os.path.exists(mtx_path):
         os.unlink(mtx_path)
     if dist is not None:
         dist.barrier()

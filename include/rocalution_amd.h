@@ -152,6 +152,10 @@ int ramd_mat_apply_add(ramd_mat_t m, ramd_vec_t x, double scalar, ramd_vec_t y);
  * 1 = the rows fall into `entries` patterns of column offsets (col - row) of at most `width` entries, the kernel rebuilds the
  * columns from one byte per row; -1 = not structured (too many patterns or rows longer than 16): columns are read */
 int ramd_mat_pattern_info(ramd_mat_t m, int* state, int* entries, int* width);
+/* on = 0: the products of this matrix read its stored columns even where a dictionary exists (the general CSR / ELL path:
+ * bench.py reports both figures); on != 0 (default): use the dictionary where the matrix is structured.  Results are
+ * bit-identical either way (same values, same order of additions). */
+int ramd_mat_pattern_use(ramd_mat_t m, int on);
 int ramd_mat_extract_diag(ramd_mat_t m, ramd_vec_t d); /* :193 */
 int ramd_mat_extract_inv_diag(ramd_mat_t m, ramd_vec_t d); /* :195 ; *d resized to min(nrow,ncol) */
 int ramd_mat_extract_submatrix(ramd_mat_t m, int row_offset, int col_offset, int row_size, int col_size,
@@ -362,7 +366,8 @@ enum
     RAMD_PROF_HALO_WAIT = 3,
     RAMD_PROF_ALLREDUCE = 4,
     RAMD_PROF_VEC       = 5,
-    RAMD_PROF_NCHAN     = 6
+    RAMD_PROF_PRECOND   = 6, /* one multi-colour preconditioner apply (all its colour sweeps) */
+    RAMD_PROF_NCHAN     = 7
 };
 int ramd_prof_enable(int channel, int on);
 int ramd_prof_result(int channel, int* launches, double* avg_ms, double* min_ms, double* max_ms);

@@ -400,6 +400,10 @@ class LocalMatrix:
     def Apply(self, x, y):
         capi.check(_lib().ramd_mat_apply(self._h, x._h, y._h))
 
+    def UseRowPatterns(self, on=True):
+        """False: products read the stored columns even where a row-pattern dictionary exists (ramd_mat_pattern_use)"""
+        capi.check(_lib().ramd_mat_pattern_use(self._h, 1 if on else 0))
+
     def ApplyAdd(self, x, scalar, y):
         capi.check(_lib().ramd_mat_apply_add(self._h, x._h, float(scalar), y._h))
 

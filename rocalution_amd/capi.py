@@ -95,6 +95,7 @@ SIGNATURES = {
     "ramd_mat_copy_coo_to_host": (i32, [mat_t, ptr, ptr, ptr]),
     "ramd_mat_apply": (i32, [mat_t, vec_t, vec_t]),
     "ramd_mat_pattern_info": (i32, [mat_t, pi32, pi32, pi32]),
+    "ramd_mat_pattern_use": (i32, [mat_t, i32]),
     "ramd_mat_apply_add": (i32, [mat_t, vec_t, f64, vec_t]),
     "ramd_mat_extract_diag": (i32, [mat_t, vec_t]),
     "ramd_mat_extract_inv_diag": (i32, [mat_t, vec_t]),

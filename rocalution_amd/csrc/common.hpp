@@ -190,6 +190,12 @@ struct ramd_mat_s
     // row patterns of the CSR SpMV (spmv.hip, csr_analyse_pattern): rows whose column offsets col - row coincide share a
     // dictionary entry, and the kernel rebuilds the columns from one byte per row instead of reading 4 bytes per entry
     int            pat_state = 0; // 0 unknown, 1 usable, -1 not usable (too many patterns / rows too long)
+    bool           pat_off   = false; // ramd_mat_pattern_use(m, 0): the products of this matrix read its columns
+    int            pat_len[64] = {0}; // row length of every dictionary entry (host copy)
+    // x tiles in LDS (spmv.hip, csr_analyse_xl): 0 unknown, 1 usable, -1 not usable
+    int            xl_state = 0;
+    int*           xl_dict  = nullptr; // [pat_n * pat_w] LDS element of x for thread 0, per dictionary entry and slot
+    int            xl_segs[2 + 3 * 8] = {0}; // XlSegs (matrix_impl.hpp), kept as plain ints here
     int            pat_n = 0, pat_w = 0; // dictionary entries, padded row length
     unsigned char* pat_id   = nullptr; // [nrow]
     int*           pat_dict = nullptr; // [pat_n * pat_w] column offsets in storage order

@@ -60,6 +60,8 @@ void mat_free_analysis(ramd_mat_s* m)
     m->band_dist = -1;
     dev_free(&m->pat_id);
     dev_free(&m->pat_dict);
+    dev_free(&m->xl_dict);
+    m->xl_state = 0;
     m->pat_state = m->pat_n = m->pat_w = 0;
     tri_release(m);
     m->lu_analysed = m->l_analysed = m->u_analysed = false;
@@ -385,6 +387,13 @@ int ramd_mat_pattern_info(ramd_mat_t m, int* state, int* entries, int* width)
         *entries = m->pat_n;
     if(width)
         *width = m->pat_w;
+    return RAMD_OK;
+}
+int ramd_mat_pattern_use(ramd_mat_t m, int on)
+{
+    if(!m)
+        RAMD_FAIL(RAMD_ERR_ARG, "null matrix handle");
+    m->pat_off = (on == 0);
     return RAMD_OK;
 }
 int ramd_mat_apply(ramd_mat_t m, ramd_vec_t x, ramd_vec_t y)

@@ -20,6 +20,17 @@ int csr_analyse_band(ramd_mat_s* m);
 constexpr int kPatMaxW = 16; // longest row a pattern may have
 constexpr int kPatMax  = 64; // dictionary entries
 constexpr int kPatEnd  = -2147483647 - 1; // dictionary entry of an ELL slot that holds no column (col < 0)
+// x tiles of a structured CSR product (spmv.hip, k_csr_xl): the distinct column offsets of the dictionary fall into a few
+// clusters; a 256-row block needs, per cluster, ONE contiguous piece of x -- loaded into LDS with 16-byte packets
+constexpr int kXlSegs = 8; // clusters
+struct XlSegs
+{
+    int nseg;
+    int omin[kXlSegs]; // first element of the piece relative to the block's first row (a multiple of the packet size)
+    int npk[kXlSegs]; // 16-byte packets of the piece
+    int base[kXlSegs]; // where the piece starts in the LDS area (elements)
+    int total; // elements of the LDS area in use (a multiple of the packet size)
+};
 struct CsrPattern
 {
     const unsigned char* id; // [nrow]

@@ -377,6 +377,12 @@ static int mc_apply(McsgsPlan* P, int kind, const T* rhs, T* out)
     const int nb = P->nb;
     const CsrPattern lpat = {P->l_pat_id, P->l_pat_dict, P->l_pat_n, kPatMaxW};
     const CsrPattern upat = {P->u_pat_id, P->u_pat_dict, P->u_pat_n, kPatMaxW};
+    struct ProfScope // (HIP events around the whole apply when the channel is on: bench.py)
+    {
+        hipStream_t s;
+        explicit ProfScope(hipStream_t st) : s(st) { prof_begin(RAMD_PROF_PRECOND, s); }
+        ~ProfScope() { prof_end(RAMD_PROF_PRECOND, s); }
+    } prof_scope(b.cur);
 #define SWEEP_ID(FR, MD, BO, TO, i, OFFP, COLP, VALP, IDENT)                                             \
     do                                                                                                   \
     {                                                                                                    \

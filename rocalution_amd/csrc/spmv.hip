@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cstring>
 #include <vector>
 
 namespace ramd
@@ -26,6 +27,7 @@ constexpr int kCsrRows  = 256; // rows per workgroup (one per thread)
 #endif
 constexpr int kGatherW = RAMD_GATHER_W; // x gathers in flight per row and batch
 constexpr int kCsrChunk = 2048; // entries staged in LDS per pass (16 KiB values + 8 KiB columns)
+constexpr int kXlElems  = 2048; // k_csr_xl: LDS elements of the x area (16 KiB fp64)
 
 // XCD-aware mapping: hardware places workgroup b on XCD b % 8 (observed, used for speed only).
 // Every XCD gets one contiguous eighth of the row blocks and walks it in dispatch order, so rows that
@@ -221,6 +223,118 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PAT ? RA
         // launch (reduce_sum_to_slot) adds the partials in a fixed order.  (A ticketed in-kernel finish
         // was measured 9% slower: every workgroup would have to drain its partial store before taking
         // the ticket, which holds its wave slots for a full memory round trip.)
+        const double wsum = wave_reduce_sum(dacc);
+        if((threadIdx.x & 63) == 0 && blk >= 0)
+            ws.part1[blk * (kBlock / 64) + (threadIdx.x >> 6)] = wsum;
+    }
+}
+
+// CSR SpMV of a STRUCTURED matrix with x tiles in LDS (row patterns, csr_analyse_xl).  k_csr_tr<PAT> no longer reads the
+// columns, so what it moves per row is the values (7 x 8 B on the 7-point operator) -- and 7 x 8 B of x through the gather
+// path: 28 wave-level 8-byte loads per 256 rows, each 4-5 lines (the +-1 neighbours straddle), 4.6-4.9 TB/s of the bytes
+// moved.  With the dictionary known a block needs, per CLUSTER of column offsets, one contiguous piece of x (the 7-point
+// operator: 5 pieces of 2 KiB instead of 7 gathers).  The pieces and the block's values go straight into LDS with 16-byte
+// packets (global_load_lds: no staging registers, no ds_write pass); the row walk then only touches LDS.  Same products,
+// same left-to-right sums.
+template <typename T, int MODE, bool DOT>
+__global__ __launch_bounds__(kBlock) void k_csr_xl(int nrow, int nblk, int per_xcd, const int* __restrict__ rp,
+                                                   const T* __restrict__ val, const T* __restrict__ x, T* __restrict__ y,
+                                                   T scalar, CsrDotWs ws, int slot, BandMap bm, CsrPattern pat, XlSegs sg)
+{
+    constexpr int VN = 16 / (int)sizeof(T);
+    // LDS (dynamic: what this matrix needs decides how many workgroups a CU holds): values of a pass | x pieces | dictionary
+    extern __shared__ __attribute__((aligned(16))) char xl_lds[];
+    T*   sval  = reinterpret_cast<T*>(xl_lds);
+    T*   sx    = sval + kCsrChunk;
+    int* sdict = reinterpret_cast<int*>(sx + sg.total);
+    using GP = const __attribute__((address_space(1))) void*;
+    using LP = __attribute__((address_space(3))) void*;
+    const int blk  = xcd_block(nblk, per_xcd, bm);
+    const int tid  = threadIdx.x;
+    const int wtid = tid & ~63; // first thread of my wave
+    double    dacc = 0.0;
+    if(blk >= 0)
+    {
+        const int r0   = blk * kCsrRows;
+        const int rend = min(r0 + kCsrRows, nrow);
+        const int row  = r0 + tid;
+        // x pieces: packet q of piece s holds x[r0 + omin + q * VN ...]; packets outside [0, nrow) are skipped (nothing
+        // reads them: a column that exists lies inside), the vector is padded by 256 B beyond nrow
+#pragma unroll 1
+        for(int s = 0; s < sg.nseg; ++s)
+        {
+            const int64_t g0 = (int64_t)r0 + sg.omin[s];
+            for(int q0 = 0; q0 < sg.npk[s]; q0 += kBlock)
+            {
+                const int     q = q0 + tid;
+                const int64_t g = g0 + (int64_t)q * VN;
+                if(q < sg.npk[s] && g >= 0 && g < nrow)
+                    __builtin_amdgcn_global_load_lds((GP)(x + g), (LP)(sx + sg.base[s] + (q0 + wtid) * VN), 16, 0, 0);
+            }
+        }
+        for(int i = tid; i < pat.n * pat.w; i += kBlock)
+            sdict[i] = pat.dict[i];
+        int rs = 0, re = 0, dbase = 0;
+        if(row < nrow)
+        {
+            rs    = rp[row];
+            re    = rp[row + 1];
+            dbase = (int)pat.id[row] * pat.w - rs;
+        }
+        const int start = rp[r0];
+        const int end   = rp[rend];
+        T         sum   = (T)0;
+        if(MODE == 1 && row < nrow)
+            sum = y[row];
+        for(int cb = start & ~3; cb < end; cb += kCsrChunk)
+        {
+#pragma unroll
+            for(int k = 0; k < kCsrChunk / (VN * kBlock); ++k)
+            {
+                const int j = cb + (k * kBlock + tid) * VN;
+                if(j < end)
+                    __builtin_amdgcn_global_load_lds((GP)(val + j), (LP)(sval + (k * kBlock + wtid) * VN), 16, 0, 2);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int lo = max(rs, cb), hi = min(re, cb + kCsrChunk);
+            for(int j = lo; j < hi; j += kGatherW)
+            {
+                T v[kGatherW], xv[kGatherW];
+#pragma unroll
+                for(int e = 0; e < kGatherW; ++e)
+                    if(j + e < hi)
+                    {
+                        v[e]  = sval[j - cb + e];
+                        xv[e] = sx[sdict[dbase + j + e] + tid];
+                    }
+#pragma unroll
+                for(int e = 0; e < kGatherW; ++e)
+                    if(j + e < hi)
+                    {
+                        if(MODE != 1)
+                            sum += v[e] * xv[e];
+                        else
+                            sum += scalar * v[e] * xv[e];
+                    }
+            }
+            __syncthreads();
+        }
+        if(row < nrow)
+        {
+            if(MODE == 2)
+            {
+                T t = (T)(-1) * sum + static_cast<const T*>(ws.jrhs)[row];
+                t   = static_cast<const T*>(ws.jdinv)[row] * t;
+                sum = x[row] + scalar * t;
+            }
+            nt_store(sum, y + row);
+            if(DOT)
+                dacc = (double)sum * (double)(ws.dotv ? static_cast<const T*>(ws.dotv)[row] : x[row]);
+        }
+    }
+    if(DOT)
+    {
         const double wsum = wave_reduce_sum(dacc);
         if((threadIdx.x & 63) == 0 && blk >= 0)
             ws.part1[blk * (kBlock / 64) + (threadIdx.x >> 6)] = wsum;
@@ -789,7 +903,8 @@ __global__ __launch_bounds__(kBlock) void k_pat_assign(int nrow, Acc a, const un
 }
 
 template <class Acc>
-static int analyse_pattern(int nrow, Acc acc, int* out_state, int* out_n, unsigned char** out_id, int** out_dict)
+static int analyse_pattern(int nrow, Acc acc, int* out_state, int* out_n, unsigned char** out_id, int** out_dict,
+                           int* out_len_host = nullptr)
 {
     *out_state = -1;
     Backend&            b = backend();
@@ -866,6 +981,8 @@ static int analyse_pattern(int nrow, Acc acc, int* out_state, int* out_n, unsign
     hipLaunchKernelGGL((k_pat_assign<Acc>), dim3(grid), dim3(kBlock), 0, b.cur, nrow, acc, table, d_slot, *out_dict, d_len,
                        *out_id, flag + 1);
     PAT_HIP(hipMemcpyAsync(h_flag, flag, sizeof(int) * 2, hipMemcpyDeviceToHost, b.cur));
+    if(out_len_host)
+        PAT_HIP(hipMemcpyAsync(out_len_host, d_len, sizeof(int) * (size_t)np, hipMemcpyDeviceToHost, b.cur));
     PAT_HIP(hipStreamSynchronize(b.cur)); // (also: the host arrays above were read by the copies)
     cleanup();
 #undef PAT_TRY
@@ -887,7 +1004,78 @@ int csr_analyse_pattern(ramd_mat_s* m)
     if(m->format != RAMD_CSR || m->nrow <= 0 || m->nnz <= 0)
         return RAMD_OK;
     m->pat_w = kPatMaxW;
-    return analyse_pattern(m->nrow, PatCsr{m->rp, m->ci}, &m->pat_state, &m->pat_n, &m->pat_id, &m->pat_dict);
+    m->xl_state = 0;
+    return analyse_pattern(m->nrow, PatCsr{m->rp, m->ci}, &m->pat_state, &m->pat_n, &m->pat_id, &m->pat_dict, m->pat_len);
+}
+
+// x tiles (k_csr_xl): clusters of the dictionary's distinct column offsets -> pieces of x a 256-row block stages in LDS
+template <typename T>
+static int csr_analyse_xl(ramd_mat_s* m)
+{
+    m->xl_state = -1;
+    if(m->pat_state != 1 || m->pat_n <= 0 || m->nrow != m->ncol)
+        return RAMD_OK;
+    constexpr int EP = 16 / (int)sizeof(T); // elements per packet
+    const int     np = m->pat_n;
+    std::vector<int> dict((size_t)np * kPatMaxW);
+    RAMD_HIP(hipMemcpy(dict.data(), m->pat_dict, sizeof(int) * dict.size(), hipMemcpyDeviceToHost));
+    std::vector<int> offs;
+    for(int p = 0; p < np; ++p)
+        for(int k = 0; k < m->pat_len[p] && k < kPatMaxW; ++k)
+            offs.push_back(dict[(size_t)p * kPatMaxW + k]);
+    if(offs.empty())
+        return RAMD_OK;
+    std::sort(offs.begin(), offs.end());
+    offs.erase(std::unique(offs.begin(), offs.end()), offs.end());
+    auto floor_to = [](int v, int q) { return v >= 0 ? v / q * q : -((-v + q - 1) / q * q); };
+    XlSegs sg   = {};
+    int    lo   = offs[0], hi = offs[0];
+    int    used = 0;
+    auto   close_seg = [&]() -> bool {
+        if(sg.nseg >= kXlSegs)
+            return false;
+        const int al  = floor_to(lo, EP);
+        const int len = hi - al + kCsrRows; // elements al .. hi + 255 relative to the block's first row
+        const int npk = (len + EP - 1) / EP;
+        if(used + npk * EP > kXlElems)
+            return false;
+        sg.omin[sg.nseg] = al;
+        sg.npk[sg.nseg]  = npk;
+        sg.base[sg.nseg] = used;
+        used += npk * EP;
+        ++sg.nseg;
+        return true;
+    };
+    for(size_t i = 1; i < offs.size(); ++i)
+    {
+        if((int64_t)offs[i] - floor_to(lo, EP) > kCsrRows) // (a gap this wide: two pieces are cheaper than one)
+        {
+            if(!close_seg())
+                return RAMD_OK;
+            lo = offs[i];
+        }
+        hi = offs[i];
+    }
+    if(!close_seg())
+        return RAMD_OK;
+    sg.total = used;
+    std::vector<int> xd((size_t)np * kPatMaxW, 0);
+    for(int p = 0; p < np; ++p)
+        for(int k = 0; k < m->pat_len[p] && k < kPatMaxW; ++k)
+        {
+            const int o = dict[(size_t)p * kPatMaxW + k];
+            int       s = sg.nseg - 1;
+            while(s > 0 && o < sg.omin[s])
+                --s;
+            xd[(size_t)p * kPatMaxW + k] = sg.base[s] + (o - sg.omin[s]);
+        }
+    dev_free(&m->xl_dict);
+    RAMD_TRY(dev_alloc(&m->xl_dict, (int64_t)xd.size()));
+    RAMD_HIP(hipMemcpy(m->xl_dict, xd.data(), sizeof(int) * xd.size(), hipMemcpyHostToDevice));
+    static_assert(sizeof(XlSegs) <= sizeof(m->xl_segs), "ramd_mat_s::xl_segs holds an XlSegs");
+    memcpy(m->xl_segs, &sg, sizeof(sg));
+    m->xl_state = 1;
+    return RAMD_OK;
 }
 // the ELL block of an ELL / HYB matrix: a pattern is the whole slot tuple, empty slots (col < 0) included
 int ell_analyse_pattern(ramd_mat_s* m)
@@ -922,8 +1110,17 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
     static const int pat_env = getenv("RAMD_CSR_PAT") ? atoi(getenv("RAMD_CSR_PAT")) : -1;
     if(m->pat_state == 0 && pat_env != 0 && (pat_env > 0 || m->nnz >= (1 << 20)))
         RAMD_TRY(csr_analyse_pattern(const_cast<ramd_mat_s*>(m)));
-    const bool       use_pat = pat_env != 0 && m->pat_state == 1;
-    const CsrPattern pat     = {use_pat ? m->pat_id : nullptr, use_pat ? m->pat_dict : nullptr, m->pat_n, m->pat_w};
+    const bool       use_pat = pat_env != 0 && m->pat_state == 1 && !m->pat_off;
+    // ... and their x tiles in LDS (RAMD_CSR_XL=0: the gather form k_csr_tr<PAT>)
+    static const int xl_env = getenv("RAMD_CSR_XL") ? atoi(getenv("RAMD_CSR_XL")) : 1;
+    if(use_pat && xl_env != 0 && m->xl_state == 0)
+        RAMD_TRY(csr_analyse_xl<T>(const_cast<ramd_mat_s*>(m)));
+    const bool       use_xl  = use_pat && xl_env != 0 && m->xl_state == 1;
+    const CsrPattern pat     = {use_pat ? m->pat_id : nullptr, use_pat ? (use_xl ? m->xl_dict : m->pat_dict) : nullptr, m->pat_n,
+                                m->pat_w};
+    XlSegs           xsg     = {};
+    if(use_xl)
+        memcpy(&xsg, m->xl_segs, sizeof(xsg));
     const bool q4      = !use_pat && q4_env > 0; // measured EQUAL to k_csr_tr on the shell surrogate (0.162 vs 0.160 ms): opt-in
     const int  nblk    = (m->nrow + rows_per_wg - 1) / rows_per_wg;
     const int  per_xcd = (nblk + 7) / 8;
@@ -952,6 +1149,11 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
         if(q4)                                                                                             \
             hipLaunchKernelGGL((k_csr_q4<T, MODE, DOT>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
                                per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot);           \
+        else if(use_xl)                                                                                    \
+            hipLaunchKernelGGL((k_csr_xl<T, MODE, DOT>), dim3(grid), dim3(kBlock),                         \
+                               sizeof(T) * (size_t)(kCsrChunk + xsg.total) + sizeof(int) * (size_t)(pat.n * pat.w), b.cur, \
+                               m->nrow, nblk, per_xcd, \
+                               m->rp, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, xsg);             \
         else if(use_pat)                                                                                   \
             hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT, true>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
                                per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat);  \
@@ -1020,7 +1222,7 @@ static int launch_ell(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
     static const int pat_env = getenv("RAMD_CSR_PAT") ? atoi(getenv("RAMD_CSR_PAT")) : -1;
     if(m->pat_state == 0 && pat_env != 0 && (pat_env > 0 || (int64_t)m->nrow * m->ell_width >= (1 << 20)))
         RAMD_TRY(ell_analyse_pattern(const_cast<ramd_mat_s*>(m)));
-    const bool       use_pat = pat_env != 0 && m->pat_state == 1;
+    const bool       use_pat = pat_env != 0 && m->pat_state == 1 && !m->pat_off;
     const CsrPattern pat     = {use_pat ? m->pat_id : nullptr, use_pat ? m->pat_dict : nullptr, m->pat_n, m->pat_w};
 #define LAUNCH(MODE, STOP, DOT)                                                                          \
     do                                                                                                   \

@@ -23,6 +23,8 @@
 #include "device_utils.hpp"
 #include "matrix_impl.hpp"
 
+#include <type_traits>
+
 namespace ramd
 {
 
@@ -456,6 +458,8 @@ struct TriPlan
     bool ct        = false;
     bool ct_rec    = false; // rows of <= 8 entries: record form (k_trsv_rec), `eval` holds the quads
     int  ct_ntiles = 0, ct_nsteps = 0, ct_wmax = 0;
+    bool ct_grp     = false; // grouped form: row groups (supernodes) are one step each, kGrpLPR lanes per row
+    bool ct_infirst = false; // ... whose in-group entries come first in the order of the host loop (upper solve)
     int  ct_dims[4] = {0, 0, 0, 0}; // max rows / steps / packed entries / external dependencies of a tile
     int* ct_tile_step = nullptr; // [ntiles+1] first step of a tile
     int* ct_step_pos  = nullptr; // [nsteps+1] first position of a step (a step = the rows of one level inside a tile)
@@ -481,7 +485,7 @@ struct TriPlan
         dev_free(&ct_in_pairs);
         dev_free(&ct_out_pairs);
         ct_in_key = nullptr;
-        ct = ct_rec = false;
+        ct = ct_rec = ct_grp = ct_infirst = false;
         dev_free(&order);
         dev_free(&pos);
         dev_free(&slice_off);
@@ -853,6 +857,169 @@ __global__ __launch_bounds__(kBlock) void k_ct_chain_start(int n, const int* __r
     start[t] = cont ? 0 : 1;
 }
 
+// ---- row groups (supernodes).  The unknowns of one mesh node of an FE matrix form a dense diagonal block: row t of the
+// sweep depends on row t-1 AND shares every other dependency with it (lower part of t = lower part of t-1 plus {t-1}).  Such
+// rows are a serial chain -- one dependency level each, 5 levels per node of a shell mesh, ~8200 levels on the af_shell10-class
+// matrix -- but their in-group entries are the LAST entries of the row in the order of the host loop (lower solve; the FIRST
+// ones in the upper solve).  A group (<= kGrpMax consecutive rows of one supernode) is therefore ONE vertex of the tile DAG and
+// ONE step of the solve: the step sums the out-of-group entries of all its rows at once and finishes the in-group ones in
+// rounds through lane permutes (k_trsv_rec, grouped form) -- the same subtractions in the same order as the host loop.
+// brk[t] = 1: sweep row t does not continue the supernode of row t-1.
+constexpr int kGrpMax = 8, kGrpLPR = 4, kGrpWL = 6;
+template <bool LOWER>
+__global__ __launch_bounds__(kBlock) void k_ct_sn_breaks(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                         int* __restrict__ brk)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(t > n)
+        return;
+    if(t == n)
+    {
+        brk[t] = 0; // scan sentinel
+        return;
+    }
+    bool same = false;
+    if(t > 0)
+    {
+        const int i = LOWER ? (int)t : (int)(n - 1 - t);
+        const int p = LOWER ? i - 1 : i + 1; // the row before i in the sweep
+        if(LOWER)
+        {
+            // lower(i) == lower(p) followed by p  (sorted rows)
+            int a = rp[p], b = rp[i];
+            const int ae = rp[p + 1], be = rp[i + 1];
+            same = true;
+            while(a < ae && ci[a] < p)
+            {
+                if(b >= be || ci[b] != ci[a])
+                {
+                    same = false;
+                    break;
+                }
+                ++a;
+                ++b;
+            }
+            if(same)
+                same = (b < be && ci[b] == p) && (b + 1 >= be || ci[b + 1] >= i);
+        }
+        else
+        {
+            // upper(i) == p followed by upper(p)
+            int a = rp[p], b = rp[i];
+            const int ae = rp[p + 1], be = rp[i + 1];
+            while(a < ae && ci[a] <= p)
+                ++a;
+            while(b < be && ci[b] <= i)
+                ++b;
+            same = (b < be && ci[b] == p);
+            if(same)
+            {
+                ++b;
+                same = (ae - a) == (be - b);
+                for(; same && a < ae; ++a, ++b)
+                    same = ci[a] == ci[b];
+            }
+        }
+    }
+    brk[t] = same ? 0 : 1;
+}
+
+// supernode runs are cut into groups of at most kGrpMax rows: gs[t] = 1 where a group starts (n + 1 entries, the last 0)
+__global__ __launch_bounds__(kBlock) void k_ct_group_starts(int n, const int* __restrict__ brk, const int* __restrict__ bscan,
+                                                            const int* __restrict__ run_start, int* __restrict__ gs)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t <= n; t += gsz)
+    {
+        if(t == n)
+        {
+            gs[t] = 0;
+            continue;
+        }
+        const int run = bscan[t] + brk[t] - 1;
+        gs[t]         = ((t - run_start[run]) % kGrpMax == 0) ? 1 : 0;
+    }
+}
+
+// first / last sweep row of the group of every sweep row
+__global__ __launch_bounds__(kBlock) void k_ct_group_bounds(int n, const int* __restrict__ gs, const int* __restrict__ gscan,
+                                                            const int* __restrict__ gstart, int* __restrict__ gf,
+                                                            int* __restrict__ gl)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gsz)
+    {
+        const int g = gscan[t] + gs[t] - 1;
+        gf[t]       = gstart[g];
+        gl[t]       = gstart[g + 1] - 1; // (gstart[ngroups] = n)
+    }
+}
+
+// group levels, sync-free sweep in sweep order: level of a group = 1 + max level of the groups its rows depend on.  A row
+// publishes max(own external dependencies, the row before it in the group) + [it is the group's first row]; readers take
+// the word of the LAST row of a dependency's group.  0 = not computed yet.
+template <bool LOWER>
+__global__ __launch_bounds__(kBlock) void k_ct_glevels(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                       const int* __restrict__ gf, const int* __restrict__ gl, int* glev,
+                                                       unsigned* counter, unsigned base, const int* __restrict__ block_order)
+{
+    const unsigned tick = take_ticket(counter, base);
+    const unsigned blk  = block_order ? (unsigned)block_order[tick] : tick;
+    const int64_t  t    = (int64_t)blk * kBlock + threadIdx.x;
+    const bool     live = t < n;
+    const int      i    = live ? (LOWER ? (int)t : (int)(n - 1 - t)) : 0;
+    const int      dir  = LOWER ? 1 : -1; // far-to-near in sweep order, as k_levels
+    int            j    = live ? (LOWER ? rp[i] : rp[i + 1] - 1) : 0;
+    const int      end  = live ? (LOWER ? rp[i + 1] : rp[i] - 1) : 0;
+    const int      myf  = live ? gf[t] : 0;
+    int            lev  = 0;
+    bool           fin     = !live;
+    int            spins   = 0;
+    int            backoff = 1;
+    do
+    {
+        spin_guard(spins);
+        const int  j_start = j;
+        const bool was_fin = fin;
+        if(!fin)
+        {
+            while(j != end)
+            {
+                const int c = ci[j];
+                if(LOWER ? (c >= i) : (c <= i))
+                {
+                    j = end;
+                    continue;
+                }
+                const int tc = LOWER ? c : n - 1 - c;
+                if(tc >= myf) // in-group: only the row right before this one carries the group's running maximum
+                {
+                    if(tc == (int)t - 1)
+                    {
+                        const int lc = __hip_atomic_load(glev + tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if(lc == 0)
+                            break;
+                        lev = max(lev, lc - 1);
+                    }
+                    j += dir;
+                    continue;
+                }
+                const int lc = __hip_atomic_load(glev + gl[tc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if(lc == 0)
+                    break;
+                lev = max(lev, lc);
+                j += dir;
+            }
+            if(j == end)
+            {
+                __hip_atomic_store(glev + t, lev + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                fin = true;
+            }
+        }
+        backoff = poll_backoff(__ballot(!was_fin && (fin || j != j_start)) != 0ull, backoff);
+    } while(__ballot(!fin) != 0ull);
+}
+
 // packed coordinates: bit 63 = computed, c0 24 bits, c1 20 bits, c2 19 bits, each saturating (a clamped monotone
 // coordinate is still monotone: far-out tiles just get coarser)
 constexpr unsigned long long kCtReady = 1ull << 63;
@@ -884,8 +1051,12 @@ template <bool LOWER>
 __global__ __launch_bounds__(kBlock) void k_ct_coords(int n, const int* __restrict__ rp, const int* __restrict__ ci,
                                                       const int* __restrict__ escan, unsigned long long* word,
                                                       int* __restrict__ ext, unsigned* counter, unsigned base,
-                                                      const int* __restrict__ block_order)
+                                                      const int* __restrict__ block_order, const int* __restrict__ gf,
+                                                      const int* __restrict__ gl)
 {
+    // gf / gl != nullptr: row groups (k_ct_sn_breaks) -- the coordinates are those of the QUOTIENT graph (a group is one
+    // vertex: contiguous pieces of a topological order, so the quotient is acyclic): in-group dependencies add nothing, the
+    // word of a dependency is the word of the last row of its group (the maximum over the group, handed from row to row)
     const unsigned tick = take_ticket(counter, base);
     const unsigned blk  = block_order ? (unsigned)block_order[tick] : tick; // hyperplane order of the blocks (blocksched.hip)
     const int64_t  t    = (int64_t)blk * kBlock + threadIdx.x;
@@ -895,6 +1066,7 @@ __global__ __launch_bounds__(kBlock) void k_ct_coords(int n, const int* __restri
     int            j    = live ? (LOWER ? rp[i] : rp[i + 1] - 1) : 0;
     const int      end  = live ? (LOWER ? rp[i + 1] : rp[i] - 1) : 0;
     const int      mych = live ? escan[t + 1] - 1 : 0;
+    const int      myf  = (live && gf) ? gf[t] : (int)t; // first row of my group
     int            c0 = 0, c1 = 0, c2 = 0;
     bool           fin     = !live;
     int            spins   = 0;
@@ -915,12 +1087,27 @@ __global__ __launch_bounds__(kBlock) void k_ct_coords(int n, const int* __restri
                     continue;
                 }
                 const int                tc = LOWER ? c : n - 1 - c;
+                if(tc >= myf) // in-group (grouped form only): the row before this one carries the group's maxima so far
+                {
+                    if(tc == (int)t - 1)
+                    {
+                        const unsigned long long wp
+                            = __hip_atomic_load(word + tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if(!(wp & kCtReady))
+                            break;
+                        c0 = max(c0, ct_c0(wp));
+                        c1 = max(c1, ct_c1(wp));
+                        c2 = max(c2, ct_c2(wp));
+                    }
+                    j += dir;
+                    continue;
+                }
                 const unsigned long long w
-                    = __hip_atomic_load(word + tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    = __hip_atomic_load(word + (gl ? gl[tc] : tc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if(!(w & kCtReady))
                     break;
                 const int chc = escan[tc + 1] - 1;
-                c0            = max(c0, ct_c0(w) + ((tc == (int)t - 1 && chc == mych) ? 1 : 0));
+                c0            = max(c0, ct_c0(w) + ((tc == myf - 1 && chc == mych) ? 1 : 0));
                 c1            = max(c1, ct_c1(w) + ((chc == mych - 1) ? 1 : 0));
                 c2            = max(c2, ct_c2(w) + ((chc < mych - 1) ? 1 : 0));
                 j += dir;
@@ -955,15 +1142,18 @@ __global__ __launch_bounds__(kBlock) void k_ct_coords(int n, const int* __restri
 template <bool LOWER>
 __global__ __launch_bounds__(kBlock) void k_ct_keys(int n, const int* __restrict__ level,
                                                     const unsigned long long* __restrict__ word, int b0, int b1, int b2,
-                                                    int T0, int T1, int T2, int* __restrict__ lev_t, int* __restrict__ tkey)
+                                                    int T0, int T1, int T2, int* __restrict__ lev_t, int* __restrict__ tkey,
+                                                    const int* __restrict__ gl)
 {
+    // gl != nullptr (row groups): `level` holds the group levels in SWEEP order; every row takes the word and the level of
+    // the last row of its group, so a group stays together in one tile and one step
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
     for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gsz)
     {
         const int                i = LOWER ? (int)t : (int)(n - 1 - t);
-        const unsigned long long w = word[t];
+        const unsigned long long w = word[gl ? gl[t] : t];
         const int                t0 = ct_c0(w) / b0, t1 = ct_c1(w) / b1, t2 = ct_c2(w) / b2;
-        lev_t[t] = level[i];
+        lev_t[t] = gl ? level[gl[t]] : level[i];
         tkey[t]  = (((t0 + t1 + t2) * T2 + t2) * T1 + t1) * T0 + t0;
     }
 }
@@ -1241,6 +1431,92 @@ __global__ __launch_bounds__(kBlock) void k_ct_split(int n, int rpp, const int* 
     }
 }
 
+// row groups: a step holds whole groups, at most rpp rows -- one thread walks the rows of a tile (a few hundred) and packs
+// the groups of every (tile, level) piece into steps in position order
+__global__ __launch_bounds__(kBlock) void k_ct_split_groups(int ntiles, int n, int lower, int rpp, const int* __restrict__ tpos,
+                                                            const int* __restrict__ sflag, const int* __restrict__ order,
+                                                            const int* __restrict__ gf, const int* __restrict__ gl,
+                                                            int* __restrict__ sflag2)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t tl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; tl < ntiles; tl += gsz)
+    {
+        int fill = 0;
+        for(int p = tpos[tl]; p < tpos[tl + 1]; ++p)
+        {
+            const int t  = lower ? order[p] : n - 1 - order[p];
+            int       st = 0;
+            if(sflag[p])
+            {
+                st   = 1;
+                fill = 0;
+            }
+            if(gf[t] == t) // first row of its group
+            {
+                const int gsize = gl[t] - t + 1;
+                if(fill + gsize > rpp)
+                {
+                    st   = 1;
+                    fill = 0;
+                }
+                fill += gsize;
+            }
+            sflag2[p] = st;
+        }
+        if(tl == ntiles - 1)
+            sflag2[n] = 0;
+    }
+}
+
+// largest group of every step (rows)
+__global__ __launch_bounds__(kBlock) void k_ct_step_maxg(int n, int lower, const int* __restrict__ order,
+                                                         const int* __restrict__ step_of, const int* __restrict__ gf,
+                                                         const int* __restrict__ gl, int* __restrict__ step_maxg)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gsz)
+    {
+        const int t = lower ? order[p] : n - 1 - order[p];
+        if(gf[t] == t && gl[t] > t)
+            atomicMax(step_maxg + step_of[p], gl[t] - t + 1);
+    }
+}
+
+// longest strictly-triangular row part OUTSIDE the row's group
+template <bool LOWER>
+__global__ __launch_bounds__(kBlock) void k_ct_row_wmax_out(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                            const int* __restrict__ gf, const int* __restrict__ gl,
+                                                            int* __restrict__ out, int* __restrict__ out_gsize)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    int           m = 0, mg = 0;
+    for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gsz)
+    {
+        const int i = LOWER ? (int)t : (int)(n - 1 - t);
+        int       c = 0;
+        mg          = max(mg, gl[t] - gf[t] + 1);
+        for(int j = rp[i]; j < rp[i + 1]; ++j)
+        {
+            const int col = ci[j];
+            if(LOWER ? (col < i) : (col > i))
+                if((LOWER ? col : n - 1 - col) < gf[t])
+                    ++c;
+        }
+        m = max(m, c);
+    }
+#pragma unroll
+    for(int off = 32; off > 0; off >>= 1)
+    {
+        m  = max(m, __shfl_xor(m, off, 64));
+        mg = max(mg, __shfl_xor(mg, off, 64));
+    }
+    if((threadIdx.x & 63) == 0)
+    {
+        atomicMax(out, m);
+        atomicMax(out_gsize, mg);
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_ct_scatter_starts(int n, const int* __restrict__ flag, const int* __restrict__ scan,
                                                               int* __restrict__ start)
 {
@@ -1254,6 +1530,7 @@ __global__ __launch_bounds__(kBlock) void k_ct_scatter_starts(int n, const int* 
 struct CtDims
 {
     int rows, steps, ents, exts;
+    int infirst; // grouped form: the in-group entries of a row come FIRST in the order of the host loop (upper solve)
 };
 constexpr int kCtFetchDepth = 4; // batches of 64 external values the fetch wave keeps in flight
 
@@ -1304,6 +1581,9 @@ constexpr int kCtFetchDepth = 4; // batches of 64 external values the fetch wave
 #ifndef RAMD_CT_DEPTH8L
 #define RAMD_CT_DEPTH8L 8 // (eight lanes per row)
 #endif
+#ifndef RAMD_CT_DEPTHG
+#define RAMD_CT_DEPTHG 4 // (grouped form: a step is several times longer, the records twice as wide)
+#endif
 constexpr int kCtRing = RAMD_CT_RING; // tiles the ticket/fetch wave may be ahead of the compute wave (+1)
 
 template <typename T, int WL>
@@ -1326,10 +1606,12 @@ static size_t ct_rec_lds_bytes(const CtDims& d)
     return (size_t)kCtRing * ((size_t)1 + d.rows + d.exts) * sizeof(T) + (size_t)(2 + 5 * kCtRing) * sizeof(int) + 64;
 }
 
-// per step: {first position, rows, external values of the tile used up to and including this step, first row's index in the tile}
+// per step: {first position, rows (| largest row group << 8), external values of the tile used up to and including this step,
+// first row's index in the tile}
 __global__ __launch_bounds__(kBlock) void k_ct_step_rec2(int n, int nsteps, const int* __restrict__ step_pos,
                                                          const int* __restrict__ ext_start, const int* __restrict__ tile_of,
-                                                         const int* __restrict__ tile_step, int* __restrict__ rec)
+                                                         const int* __restrict__ tile_step, int* __restrict__ rec,
+                                                         const int* __restrict__ step_maxg)
 {
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
     for(int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g <= nsteps; g += gsz)
@@ -1346,7 +1628,7 @@ __global__ __launch_bounds__(kBlock) void k_ct_step_rec2(int n, int nsteps, cons
         const int p1   = step_pos[g + 1];
         const int tpos = step_pos[tile_step[tile_of[p]]];
         rec[4 * g + 0] = p;
-        rec[4 * g + 1] = p1 - p;
+        rec[4 * g + 1] = (p1 - p) | ((step_maxg ? max(step_maxg[g], 1) : 1) << 8); // rows | largest group of the step << 8
         rec[4 * g + 2] = ext_start[p1] - ext_start[tpos];
         rec[4 * g + 3] = p - tpos;
     }
@@ -1447,6 +1729,122 @@ __global__ __launch_bounds__(kBlock) void k_ct_fill_rec(int n, const int* __rest
     }
 }
 
+// Grouped form (row groups, k_ct_sn_breaks): kGrpLPR lanes per row with kGrpWL out-of-group entries each.
+//   lane record  : {kGrpWL 16-bit column codes | meta (4 bytes: index of the row in its group, << 8: which in-group
+//                  coefficients exist) | kGrpWL values}, quad-major per step like CtRec
+//   row record   : {kGrpMax - 1 in-group coefficients, indexed by the group row they multiply | diagonal}, position order
+template <typename T>
+struct CtGRec
+{
+    static constexpr int WLC      = kGrpWL;
+    static constexpr int off_meta = 12;
+    static constexpr int off_val  = 16;
+    static constexpr int off_diag = 0; // (not in the lane record)
+    static constexpr int NQ       = (off_val + kGrpWL * (int)sizeof(T) + 15) / 16;
+    static constexpr int NQL      = NQ;
+    static constexpr int NQS      = NQ;
+    static constexpr bool DSEP    = false;
+    static constexpr int  NGQ     = kGrpMax * (int)sizeof(T) / 16; // quads of a row record
+};
+
+template <typename T, bool LOWER>
+__global__ __launch_bounds__(kBlock) void k_ct_fill_grec(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                         const T* __restrict__ val, const int* __restrict__ order,
+                                                         const int* __restrict__ pos, const int* __restrict__ tile_of,
+                                                         const int* __restrict__ step_of, const int* __restrict__ tile_step,
+                                                         const int* __restrict__ step_pos, const int* __restrict__ ext_start,
+                                                         int* __restrict__ ext_idx, char* __restrict__ erec,
+                                                         int* __restrict__ nodiag, int reverse, int rows_max,
+                                                         const int* __restrict__ ref_start,
+                                                         const int* __restrict__ slot_of_ref, T* __restrict__ grec,
+                                                         const int* __restrict__ gf)
+{
+    using L           = CtGRec<T>;
+    constexpr int LPR = kGrpLPR, WL = kGrpWL;
+    const int64_t p   = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(p >= n)
+        return;
+    const int i    = order[p];
+    const int t    = LOWER ? i : n - 1 - i;
+    const int tf   = gf[t]; // first sweep row of the group
+    const int gi   = t - tf;
+    const int gs   = step_of[p];
+    const int p0   = step_pos[gs];
+    const int cnt  = step_pos[gs + 1] - p0;
+    const int rank = (int)p - p0;
+    const int tl   = tile_of[p];
+    const int tpos = step_pos[tile_step[tl]];
+    int       e    = ext_start[p];
+    const int e0   = ext_start[tpos];
+    const int rbase = slot_of_ref ? ref_start[p] : 0;
+    int       nref  = 0;
+    for(int q = rp[i]; slot_of_ref && reverse && q < rp[i + 1]; ++q) // storage order is descending: count first
+    {
+        const int c = ci[q];
+        if((LOWER ? (c < i) : (c > i)) && tile_of[pos[c]] != tl)
+            ++nref;
+    }
+    int  jref  = 0;
+    auto field = [&](int sub, int off) -> char* {
+        return erec + ((size_t)L::NQ * LPR * p0 + (size_t)(off / 16) * (cnt * LPR) + (rank * LPR + sub)) * 16 + (off % 16);
+    };
+    T*        rr   = grec + (size_t)kGrpMax * p;
+    int       k    = 0;
+    int       mask = 0;
+    bool      have = false;
+    const int rs = rp[i], re = rp[i + 1];
+    for(int q = rs; q < re; ++q)
+    {
+        const int j = reverse ? (re - 1 - (q - rs)) : q;
+        const int c = ci[j];
+        if(LOWER ? (c < i) : (c > i))
+        {
+            const int tc = LOWER ? c : n - 1 - c;
+            if(tc >= tf) // in-group: coefficient of group row tc - tf
+            {
+                rr[tc - tf] = val[j];
+                mask |= 1 << (tc - tf);
+                continue;
+            }
+            const int pc = pos[c];
+            int       code;
+            if(tile_of[pc] == tl)
+                code = 1 + (pc - tpos);
+            else if(slot_of_ref)
+            {
+                const int r = rbase + (reverse ? (nref - 1 - jref) : jref);
+                code        = 1 + rows_max + (slot_of_ref[r] - e0);
+                ++jref;
+            }
+            else
+            {
+                ext_idx[e] = pc;
+                code       = 1 + rows_max + (e - e0);
+                ++e;
+            }
+            if(k < WL * LPR)
+            {
+                const int sub = k / WL, kk = k % WL;
+                *reinterpret_cast<unsigned short*>(field(sub, 2 * kk))            = (unsigned short)code;
+                *reinterpret_cast<T*>(field(sub, L::off_val + kk * (int)sizeof(T))) = val[j];
+            }
+            ++k;
+        }
+        else if(c == i)
+        {
+            rr[kGrpMax - 1] = val[j];
+            have            = true;
+        }
+    }
+    for(int sub = 0; sub < LPR; ++sub)
+        *reinterpret_cast<int*>(field(sub, L::off_meta)) = gi | (mask << 8);
+    if(!have)
+    {
+        rr[kGrpMax - 1] = (T)1;
+        *nodiag         = 1;
+    }
+}
+
 // The compute wave's loads are issued by hand (inline asm) and waited for by hand: left to the compiler, the counter waits
 // of a software pipeline with scalar control flow in the loop body come out as drains (vmcnt(0) at the loop header, the
 // state of the prologue merged into every trip).  The hardware retires vector memory operations in order, so with a fixed
@@ -1523,10 +1921,11 @@ struct CtBases // counter values of the ticket streams before the launch
     unsigned v[16];
 };
 
-template <typename T, int NQ>
+template <typename T, int NQ, int NGQ = 0>
 struct CtStage
 {
     v4i32 q[NQ]; // the row's record
+    v4i32 gq[NGQ > 0 ? NGQ : 1]; // grouped form: the row record (in-group coefficients, diagonal)
     T     dg; // the diagonal, where it is kept outside the record
     int   g, tf; // uniform: index of the step's record; its tile number * 4 + flags (1 = a new step, 2 = last step of its tile)
 };
@@ -1540,10 +1939,13 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
                                                   const int* __restrict__ out_pairs, T* w, T* __restrict__ out,
                                                   unsigned* counter, CtBases bases, int nstreams, unsigned long long* prof_arg)
 {
-    using L           = CtRec<T, WL>;
+    constexpr bool GRP = (LPR == kGrpLPR); // grouped form (row groups; CtGRec): `diag_sep` holds the row records
+    using L           = typename std::conditional<GRP, CtGRec<T>, CtRec<T, WL>>::type;
     using B           = typename Sentinel<T>::bits;
+    static_assert(!GRP || WL == kGrpWL, "the grouped form has one lane-record shape");
     constexpr bool DSEP = L::DSEP && LPR == 1; // the diagonal in its own array (CtRec)
     constexpr int  NQ   = (DMODE != 0 && !DSEP) ? L::NQ : L::NQL;
+    constexpr int  NGQ  = GRP ? CtGRec<T>::NGQ : 0;
     constexpr int R   = kCtRing;
     unsigned long long* const prof = PROF ? prof_arg : nullptr; // (diagnostic instantiation only: the counters cost scalar registers)
     extern __shared__ __attribute__((aligned(16))) char ct_lds[];
@@ -1835,12 +2237,12 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
     };
     // vector memory operations of one step of the stream, in issue order: the store of the step's values, then the quads of
     // the record DEPTH steps ahead
-    constexpr int OPS = 1 + NQ + ((DSEP && DMODE != 0) ? 1 : 0);
+    constexpr int OPS = 1 + NQ + NGQ + ((DSEP && DMODE != 0) ? 1 : 0);
     static_assert(DEPTH * OPS < 64, "the whole prefetch window has to fit the 6-bit counter");
-    auto fetch_rec = [&](CtStage<T, NQ>& st) {
+    auto fetch_rec = [&](CtStage<T, NQ, NGQ>& st) {
         st.g  = g; // (the record itself comes back through the scalar cache when the step runs: scalar registers are scarce)
         st.tf = tn * 4 + ((cur_fresh ? 1 : 0) | (cur_last ? 2 : 0));
-        const int      nl  = cur.y * LPR; // lane records of the step
+        const int      nl  = (cur.y & 0xff) * LPR; // lane records of the step
         const int      row = min(lane, nl - 1);
         const v4i32*   qb  = erec + (size_t)((DSEP ? L::NQS : L::NQ) * LPR) * (size_t)cur.x; // scalar base of the step + lane offsets
         const unsigned ro  = (unsigned)row * 16u;
@@ -1851,23 +2253,34 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
             st.q[q] = ct_load_quad(qb, ro + (unsigned)(q * nl) * 16u);
         if(DSEP && DMODE != 0)
             st.dg = ct_load_T(diag_sep + cur.x, (unsigned)row * (unsigned)sizeof(T));
+        if(GRP) // the row record: the lanes of a row read the same 16-byte words
+        {
+            const unsigned go = ((unsigned)row / (unsigned)LPR) * (unsigned)(kGrpMax * sizeof(T));
+#pragma unroll
+            for(int q = 0; q < NGQ; ++q)
+                st.gq[q] = ct_load_quad(diag_sep + (size_t)kGrpMax * (size_t)cur.x, go + (unsigned)q * 16u);
+        }
         if(cur_fresh)
             pending = uni(pending + 1);
         cur_fresh = try_advance();
     };
-    auto arrived = [&](CtStage<T, NQ>& st) { // (after the wait) the registers of the stage may be used from here on
+    auto arrived = [&](CtStage<T, NQ, NGQ>& st) { // (after the wait) the registers of the stage may be used from here on
 #pragma unroll
         for(int q = 0; q < NQ; ++q)
             asm volatile("" : "+v"(st.q[q]));
+#pragma unroll
+        for(int q = 0; q < NGQ; ++q)
+            asm volatile("" : "+v"(st.gq[q]));
         if(DSEP && DMODE != 0)
             asm volatile("" : "+v"(st.dg));
     };
     int  have = -1, have_tn = -1;
-    auto step = [&](const CtStage<T, NQ>& stq, const v4i32 rec) {
+    auto step = [&](const CtStage<T, NQ, NGQ>& stq, const v4i32 rec) {
         struct
         {
             int pos, cnt, need, lbase, tn, flags;
-        } st = {uni(rec.x), uni(rec.y), uni(rec.z), uni(rec.w), uni(stq.tf) >> 2, uni(stq.tf) & 3};
+        } st = {uni(rec.x), uni(rec.y) & 0xff, uni(rec.z), uni(rec.w), uni(stq.tf) >> 2, uni(stq.tf) & 3};
+        const int maxg = uni(rec.y) >> 8; // grouped form: rows of the step's largest group
         const int nl   = st.cnt * LPR; // lane records of the step
         const int lrec = min(lane, nl - 1);
         const int row  = (int)((unsigned)lrec / (unsigned)LPR); // row of the step this lane works for
@@ -1901,6 +2314,9 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
 #pragma unroll
         for(int q = 0; q < NQ; ++q)
             asm volatile("" ::"v"(stq.q[q]));
+#pragma unroll
+        for(int q = 0; q < NGQ; ++q)
+            asm volatile("" ::"v"(stq.gq[q]));
         const int  sbase = slot * S; // this tile's region
         const int  own   = sbase + 1 + st.lbase + row;
         const T    bval = xs[own]; // right-hand side (a repeated step finds its result there)
@@ -1925,7 +2341,95 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
         }
         T sum = bval;
         {
-        if(LPR == 1)
+        if constexpr(GRP)
+        {
+            // One step = whole row groups.  The out-of-group entries of a row are summed by its LPR lanes exactly as in the
+            // ungrouped form (lane chain in storage order); the in-group entries -- coefficients gq[r] of the group's row r --
+            // are subtracted in the order of the host loop with the FINAL value of row r, fetched from that row's last lane by
+            // a lane permute.  The value that counts is the one of the row's last lane (in-last) / first lane (in-first).
+            const int meta = stq.q[0][3];
+            const int gi   = meta & 0xff; // this row's index in its group
+            const int gm   = meta >> 8; // bit r: the row has a coefficient for group row r
+            auto coef = [&](int r) -> T {
+                if(sizeof(T) == 8)
+                    return (T)__hiloint2double(stq.gq[(2 * r + 1) / 4][(2 * r + 1) % 4], stq.gq[(2 * r) / 4][(2 * r) % 4]);
+                return (T)__int_as_float(stq.gq[r / 4][r % 4]);
+            };
+            const T dg = coef(kGrpMax - 1);
+            auto finalize = [&](T s) -> T { return DMODE == 0 ? s : (DMODE == 1 ? s / dg : s * dg); };
+            // last lane of group row r of this lane's group
+            auto from_group_row = [&](int r, T v) -> T {
+                const int src = ((row - gi + r) * LPR + (LPR - 1)) * 4;
+                if(sizeof(T) == 8)
+                {
+                    const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint((double)v));
+                    const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint((double)v));
+                    return (T)__hiloint2double(hi, lo);
+                }
+                return (T)__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int((float)v)));
+            };
+            T pr[WL];
+#pragma unroll
+            for(int k = 0; k < WL; ++k)
+                pr[k] = a[k] * v[k];
+            auto chain = [&](T first) -> T { // the row's out-of-group entries in storage order, starting from `first` in lane 0
+                T s = first;
+#pragma unroll
+                for(int t = 0; t < LPR; ++t)
+                {
+                    T acc = (t == 0) ? first : ct_from_lane_below(s);
+#pragma unroll
+                    for(int k = 0; k < WL; ++k)
+                        acc -= pr[k];
+                    s = acc;
+                }
+                return s;
+            };
+            if(!dims.infirst)
+            {
+                // lower solve: out-of-group entries first (all rows of the step at once), then round r hands the finished
+                // row r of every group to the rows behind it
+                sum = chain(bval);
+#pragma unroll
+                for(int r = 0; r < kGrpMax - 1; ++r)
+                {
+                    if(r + 1 < maxg) // (wave-uniform)
+                    {
+                        const T y = from_group_row(r, finalize(sum));
+                        const T d = sum - coef(r) * y;
+                        sum       = (gi > r && ((gm >> r) & 1)) ? d : sum;
+                    }
+                }
+                sum = finalize(sum);
+            }
+            else
+            {
+                // upper solve: a row starts with its in-group entries (nearest row first), so the rows of a group run one
+                // after the other; the groups of the step side by side
+                T yr[kGrpMax - 1];
+                T fin = bval;
+#pragma unroll
+                for(int g2 = 0; g2 < kGrpMax; ++g2)
+                {
+                    if(g2 < maxg) // (wave-uniform)
+                    {
+                        if(g2 > 0)
+                            yr[g2 - 1] = from_group_row(g2 - 1, fin);
+                        T acc0 = bval;
+#pragma unroll
+                        for(int r = g2 - 1; r >= 0; --r)
+                        {
+                            const T d = acc0 - coef(r) * yr[r];
+                            acc0      = ((gm >> r) & 1) ? d : acc0;
+                        }
+                        const T f = finalize(chain(acc0));
+                        fin       = (gi == g2) ? f : fin;
+                    }
+                }
+                sum = fin;
+            }
+        }
+        else if(LPR == 1)
         {
 #pragma unroll
             for(int k = 0; k < WL; ++k)
@@ -1950,7 +2454,7 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
                 sum = acc;
             }
         }
-        if(DMODE != 0)
+        if(DMODE != 0 && !GRP)
         {
             T dg;
             if(DSEP)
@@ -1999,7 +2503,7 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
         load_cur();
         cur_fresh = true;
     }
-    CtStage<T, NQ> st[DEPTH];
+    CtStage<T, NQ, NGQ> st[DEPTH];
 #pragma unroll
     for(int j = 0; j < DEPTH; ++j)
         fetch_rec(st[j]);
@@ -2065,7 +2569,7 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     int *level = nullptr, *lorder = nullptr, *start = nullptr, *lev_t = nullptr, *tkey = nullptr, *o1 = nullptr,
         *k2 = nullptr, *o2 = nullptr, *tflag = nullptr, *sflag = nullptr, *tscan = nullptr, *sscan = nullptr,
         *tile_of = nullptr, *step_of = nullptr, *step_w = nullptr, *nodiag = nullptr, *cext = nullptr, *tsz = nullptr,
-        *ref_start = nullptr, *slot_of_ref = nullptr;
+        *ref_start = nullptr, *slot_of_ref = nullptr, *gf = nullptr, *gl = nullptr, *tposv = nullptr, *step_maxg = nullptr;
     unsigned long long* word = nullptr;
     int  nlev = 0;
     int  s    = RAMD_OK;
@@ -2091,6 +2595,10 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
         dev_free(&word);
         dev_free(&ref_start);
         dev_free(&slot_of_ref);
+        dev_free(&gf);
+        dev_free(&gl);
+        dev_free(&tposv);
+        dev_free(&step_maxg);
     };
 #define CT_TRY(expr)     \
     do                   \
@@ -2137,9 +2645,103 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     CT_HIP(hipStreamSynchronize(b.cur));
     if(nchains <= 0 || (int64_t)n < (int64_t)min_len * nchains)
         CT_GIVE_UP();
+    // longest strictly-triangular row: decides how many lanes share a row (and so how many rows a step may hold)
+    int wmax = 0;
+    CT_TRY(dev_alloc(&cext, 4));
+    CT_HIP(hipMemsetAsync(cext, 0, sizeof(int) * 4, b.cur));
+    if(lower)
+        hipLaunchKernelGGL((k_ct_row_wmax<true>), dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, cext + 3);
+    else
+        hipLaunchKernelGGL((k_ct_row_wmax<false>), dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, cext + 3);
+    CT_HIP(hipMemcpyAsync(&wmax, cext + 3, sizeof(int), hipMemcpyDeviceToHost, b.cur));
+    CT_HIP(hipStreamSynchronize(b.cur));
+    // row groups (supernodes): only where several lanes share a row anyway (long rows), and not for the descending-order
+    // sweep over the lower part (no caller)
+    static const int grp_env = getenv("RAMD_TRSV_CT_GROUPS") ? atoi(getenv("RAMD_TRSV_CT_GROUPS")) : 1; // (0: off; A/B experiments)
+    bool grp = false;
+    int  grp_count = 0, grp_maxsize = 1;
+    if(grp_env != 0 && wmax > 8 && wmax <= kGrpLPR * kGrpWL + kGrpMax - 1 && !(lower && reverse))
+    {
+        int *brk = nullptr, *bscan = nullptr, *rstart = nullptr, *gs = nullptr, *gscan = nullptr, *gstart = nullptr;
+        auto drop = [&]() {
+            dev_free(&brk);
+            dev_free(&bscan);
+            dev_free(&rstart);
+            dev_free(&gs);
+            dev_free(&gscan);
+            dev_free(&gstart);
+        };
+#define CT_TRYG(expr)    \
+    do                   \
+    {                    \
+        s = (expr);      \
+        if(s != RAMD_OK) \
+        {                \
+            drop();      \
+            CT_TRY(s);   \
+        }                \
+    } while(0)
+        CT_TRYG(dev_alloc(&brk, (int64_t)n + 1));
+        CT_TRYG(dev_alloc(&bscan, (int64_t)n + 1));
+        if(lower)
+            hipLaunchKernelGGL((k_ct_sn_breaks<true>), dim3(nb1), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, brk);
+        else
+            hipLaunchKernelGGL((k_ct_sn_breaks<false>), dim3(nb1), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, brk);
+        CT_TRYG(device_exclusive_scan(brk, bscan, (int64_t)n + 1));
+        int nruns = 0;
+        if(hipMemcpyAsync(&nruns, bscan + n, sizeof(int), hipMemcpyDeviceToHost, b.cur) != hipSuccess
+           || hipStreamSynchronize(b.cur) != hipSuccess)
+            CT_TRYG(RAMD_ERR_HIP);
+        if(nruns > 0 && (int64_t)nruns * 3 <= (int64_t)n * 2) // (mean run of at least 1.5 rows: otherwise not worth the wider records)
+        {
+            CT_TRYG(dev_alloc(&rstart, (int64_t)nruns + 1));
+            hipLaunchKernelGGL(k_ct_scatter_starts, dim3(grid), dim3(kBlock), 0, b.cur, n, brk, bscan, rstart);
+            CT_TRYG(dev_alloc(&gs, (int64_t)n + 1));
+            CT_TRYG(dev_alloc(&gscan, (int64_t)n + 1));
+            hipLaunchKernelGGL(k_ct_group_starts, dim3(grid), dim3(kBlock), 0, b.cur, n, brk, bscan, rstart, gs);
+            CT_TRYG(device_exclusive_scan(gs, gscan, (int64_t)n + 1));
+            int ngroups = 0;
+            if(hipMemcpyAsync(&ngroups, gscan + n, sizeof(int), hipMemcpyDeviceToHost, b.cur) != hipSuccess
+               || hipStreamSynchronize(b.cur) != hipSuccess)
+                CT_TRYG(RAMD_ERR_HIP);
+            CT_TRYG(dev_alloc(&gstart, (int64_t)ngroups + 1));
+            hipLaunchKernelGGL(k_ct_scatter_starts, dim3(grid), dim3(kBlock), 0, b.cur, n, gs, gscan, gstart);
+            if(hipMemcpyAsync(gstart + ngroups, &n, sizeof(int), hipMemcpyHostToDevice, b.cur) != hipSuccess)
+                CT_TRYG(RAMD_ERR_HIP);
+            CT_TRYG(dev_alloc(&gf, n));
+            CT_TRYG(dev_alloc(&gl, n));
+            hipLaunchKernelGGL(k_ct_group_bounds, dim3(grid), dim3(kBlock), 0, b.cur, n, gs, gscan, gstart, gf, gl);
+            // the out-of-group part of every row has to fit kGrpLPR x kGrpWL entries
+            int wout = 0;
+            CT_HIP(hipMemsetAsync(cext + 2, 0, 2 * sizeof(int), b.cur));
+            if(lower)
+                hipLaunchKernelGGL((k_ct_row_wmax_out<true>), dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, gf, gl,
+                                   cext + 3, cext + 2);
+            else
+                hipLaunchKernelGGL((k_ct_row_wmax_out<false>), dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, gf, gl,
+                                   cext + 3, cext + 2);
+            int two[2] = {0, 0};
+            if(hipMemcpyAsync(two, cext + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, b.cur) != hipSuccess
+               || hipStreamSynchronize(b.cur) != hipSuccess)
+                CT_TRYG(RAMD_ERR_HIP);
+            wout        = two[1];
+            grp_maxsize = two[0] < 1 ? 1 : two[0];
+            grp_count   = ngroups;
+            grp = wout <= kGrpLPR * kGrpWL;
+            if(verbose)
+                fprintf(stderr, "box-tile plan: %d supernode runs, %d row groups of <= %d rows, longest out-of-group part %d%s\n",
+                        nruns, ngroups, kGrpMax, wout, grp ? "" : " (too long: ungrouped form)");
+            if(!grp)
+            {
+                dev_free(&gf);
+                dev_free(&gl);
+            }
+        }
+        drop();
+#undef CT_TRYG
+    }
     // monotone coordinates (sync-free sweep) and their extents
     CT_TRY(dev_alloc(&word, n));
-    CT_TRY(dev_alloc(&cext, 4));
     CT_HIP(hipMemsetAsync(word, 0, sizeof(unsigned long long) * (size_t)n, b.cur));
     CT_HIP(hipMemsetAsync(cext, 0, sizeof(int) * 4, b.cur));
     {
@@ -2149,10 +2751,10 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
         (void)block_schedule(m, lower, &border); // nullptr: natural order
         if(lower)
             hipLaunchKernelGGL((k_ct_coords<true>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, start, word, cext,
-                               st->counter, st->ticket, border);
+                               st->counter, st->ticket, border, gf, gl);
         else
             hipLaunchKernelGGL((k_ct_coords<false>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, start, word, cext,
-                               st->counter, st->ticket, border);
+                               st->counter, st->ticket, border, gf, gl);
         st->ticket += nb;
         if(border)
         {
@@ -2179,25 +2781,34 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
         dnz += E[k] > 1 ? 1 : 0;
     if(dnz == 0)
         CT_GIVE_UP();
-    // longest strictly-triangular row: decides how many lanes share a row (and so how many rows a step may hold)
-    int wmax = 0;
-    CT_HIP(hipMemsetAsync(cext + 3, 0, sizeof(int), b.cur));
-    if(lower)
-        hipLaunchKernelGGL((k_ct_row_wmax<true>), dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, cext + 3);
-    else
-        hipLaunchKernelGGL((k_ct_row_wmax<false>), dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, cext + 3);
-    CT_HIP(hipMemcpyAsync(&wmax, cext + 3, sizeof(int), hipMemcpyDeviceToHost, b.cur));
-    CT_HIP(hipStreamSynchronize(b.cur));
-    if(wmax > 32) // (8 lanes x 4 entries per row and step)
+    if(wmax > 32 && !grp) // (8 lanes x 4 entries per row and step)
         CT_GIVE_UP();
-    const int lpr = wmax > 8 ? 8 : 1;
-    const int wl  = lpr == 1 ? (wmax <= 3 ? 3 : (wmax <= 4 ? 4 : 8)) : 4;
+    const int lpr = grp ? kGrpLPR : (wmax > 8 ? 8 : 1);
+    const int wl  = grp ? kGrpWL : (lpr == 1 ? (wmax <= 3 ? 3 : (wmax <= 4 ? 4 : 8)) : 4);
     const int rpp = 64 / lpr;
     int       bs[3] = {1, 1, 1}, Ts[3] = {1, 1, 1};
     int       ntiles = 0, nsteps = 0, total = 0;
     int64_t keymax = 0;
     // levels (natural row index): once
-    if(lower && st->l_level_cache) // the sweep ILU0Factorize ran on the same pattern
+    if(grp)
+    {
+        // levels of the quotient graph, in sweep order
+        CT_TRY(dev_alloc(&level, n));
+        CT_HIP(hipMemsetAsync(level, 0, sizeof(int) * (size_t)n, b.cur));
+        int* border = nullptr;
+        (void)block_schedule(m, lower, &border);
+        if(lower)
+            hipLaunchKernelGGL((k_ct_glevels<true>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, gf, gl, level,
+                               st->counter, st->ticket, border);
+        else
+            hipLaunchKernelGGL((k_ct_glevels<false>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, gf, gl, level,
+                               st->counter, st->ticket, border);
+        st->ticket += nb;
+        s = device_max_int(level, n, &nlev); // (synchronises)
+        dev_free(&border);
+        CT_TRY(s);
+    }
+    else if(lower && st->l_level_cache) // the sweep ILU0Factorize ran on the same pattern
     {
         level             = st->l_level_cache;
         st->l_level_cache = nullptr;
@@ -2216,8 +2827,28 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     {
         double bk = E[k] > 1 ? (double)E[k] * f : 1.0;
         bs[k]     = bk < 1.0 ? 1 : (int)(bk + 0.5);
-        Ts[k]     = (int)((E[k] + bs[k] - 1) / bs[k]);
     }
+    static const int grp_shape = getenv("RAMD_TRSV_CT_GSHAPE") ? atoi(getenv("RAMD_TRSV_CT_GSHAPE")) : 1; // (0: proportional boxes)
+    if(grp && grp_shape != 0 && grp_count > 0)
+    {
+        // grouped form: the rows of one dependency level inside a tile are its cross-section over the non-chain coordinates;
+        // a cross-section that fits ONE step (64 / lanes-per-row rows = rpp / largest group whole groups) lets a tile advance
+        // one level per step -- the critical path of the solve -- instead of one level per several steps.  The box is as long
+        // along the chain coordinate as the row budget allows (hops along it trail the predecessor by one step).
+        // (the typical group: the mean, rounded -- a few longer runs, e.g. the first mesh nodes whose rows have nothing below
+        //  them, only split a step now and then)
+        const double gavg  = (double)n / (double)grp_count;
+        int          gtyp  = (int)(gavg + 0.5);
+        gtyp               = gtyp < 1 ? 1 : (gtyp > grp_maxsize ? grp_maxsize : gtyp);
+        static const int cross_env = getenv("RAMD_TRSV_CT_GCROSS") ? atoi(getenv("RAMD_TRSV_CT_GCROSS")) : 0; // (experiments)
+        const int    cross = cross_env > 0 ? cross_env : (rpp / gtyp < 1 ? 1 : rpp / gtyp);
+        bs[1]              = E[1] > 1 ? (int)(E[1] < cross ? E[1] : cross) : 1;
+        bs[2]              = E[2] > 1 ? (cross / bs[1] < 1 ? 1 : cross / bs[1]) : 1;
+        double b0          = (double)rows / (gavg * bs[1] * bs[2]);
+        bs[0]              = E[0] > 1 ? (b0 < 1.0 ? 1 : (int)(b0 + 0.5)) : 1;
+    }
+    for(int k = 0; k < 3; ++k)
+        Ts[k] = (int)((E[k] + bs[k] - 1) / bs[k]);
     keymax = (int64_t)(Ts[0] + Ts[1] + Ts[2]) * Ts[2] * Ts[1] * Ts[0];
     if(keymax >= (1ll << 30))
         CT_GIVE_UP();
@@ -2226,10 +2857,10 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     CT_TRY(dev_alloc(&tkey, n));
     if(lower)
         hipLaunchKernelGGL((k_ct_keys<true>), dim3(grid), dim3(kBlock), 0, b.cur, n, level, word, bs[0], bs[1], bs[2], Ts[0],
-                           Ts[1], Ts[2], lev_t, tkey);
+                           Ts[1], Ts[2], lev_t, tkey, gl);
     else
         hipLaunchKernelGGL((k_ct_keys<false>), dim3(grid), dim3(kBlock), 0, b.cur, n, level, word, bs[0], bs[1], bs[2], Ts[0],
-                           Ts[1], Ts[2], lev_t, tkey);
+                           Ts[1], Ts[2], lev_t, tkey, gl);
     CT_TRY(dev_alloc(&o1, n));
     CT_TRY(device_stable_sort_by_key(lev_t, n, nlev, o1));
     CT_TRY(dev_alloc(&k2, n));
@@ -2266,7 +2897,28 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
         hipLaunchKernelGGL(k_ct_scatter_starts, dim3(grid), dim3(kBlock), 0, b.cur, n, sflag, sscan, gpos);
         int* sflag2 = nullptr;
         s           = dev_alloc(&sflag2, (int64_t)n + 1);
-        if(s == RAMD_OK)
+        if(s == RAMD_OK && grp)
+        {
+            // whole groups per step: one thread per tile packs them
+            int nt = 0;
+            if(hipMemcpyAsync(&nt, tscan + n, sizeof(int), hipMemcpyDeviceToHost, b.cur) != hipSuccess
+               || hipStreamSynchronize(b.cur) != hipSuccess)
+                s = RAMD_ERR_HIP;
+            dev_free(&tposv);
+            if(s == RAMD_OK)
+                s = dev_alloc(&tposv, (int64_t)nt + 1);
+            if(s == RAMD_OK)
+            {
+                hipLaunchKernelGGL(k_ct_scatter_starts, dim3(grid), dim3(kBlock), 0, b.cur, n, tflag, tscan, tposv);
+                if(hipMemcpyAsync(tposv + nt, &n, sizeof(int), hipMemcpyHostToDevice, b.cur) != hipSuccess)
+                    s = RAMD_ERR_HIP;
+                hipLaunchKernelGGL(k_ct_split_groups, dim3(ew_grid(nt)), dim3(kBlock), 0, b.cur, nt, n, lower ? 1 : 0, rpp, tposv,
+                                   sflag, P->order, gf, gl, sflag2);
+                if(s == RAMD_OK)
+                    s = device_exclusive_scan(sflag2, sscan, (int64_t)n + 1);
+            }
+        }
+        else if(s == RAMD_OK)
         {
             hipLaunchKernelGGL(k_ct_split, dim3(grid), dim3(kBlock), 0, b.cur, n, rpp, sflag, sscan, gpos, sflag2);
             s = device_exclusive_scan(sflag2, sscan, (int64_t)n + 1);
@@ -2452,11 +3104,28 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     P->ct_rec = true;
     {
         // record form: one array of 16-byte quads (CtRec), lpr lane records per row, zeroed = padded
-        const size_t nq    = lpr == 8 ? CtRec<T, 4>::NQ : (wl == 3 ? CtRec<T, 3>::NQS : (wl == 4 ? CtRec<T, 4>::NQS : CtRec<T, 8>::NQS));
-        CT_HIP(cached_malloc(&P->diag, (size_t)n * sizeof(T) + kPad)); // (used where the record keeps no diagonal: CtRec::DSEP)
+        const size_t nq    = grp ? CtGRec<T>::NQ
+                                 : (lpr == 8 ? CtRec<T, 4>::NQ
+                                             : (wl == 3 ? CtRec<T, 3>::NQS : (wl == 4 ? CtRec<T, 4>::NQS : CtRec<T, 8>::NQS)));
+        // (the diagonal where the record keeps none: CtRec::DSEP; grouped form: the row records)
+        const size_t dbytes = (size_t)n * sizeof(T) * (grp ? (size_t)kGrpMax : (size_t)1) + kPad;
+        CT_HIP(cached_malloc(&P->diag, dbytes));
+        if(grp)
+            CT_HIP(hipMemsetAsync(P->diag, 0, dbytes, b.cur));
         const size_t bytes = nq * 16 * (size_t)lpr * (size_t)n + kPad;
         CT_HIP(cached_malloc(&P->eval, bytes));
         CT_HIP(hipMemsetAsync(P->eval, 0, bytes, b.cur));
+        if(grp)
+        {
+            CT_TRY(dev_alloc(&step_maxg, (int64_t)nsteps + 1));
+            CT_HIP(hipMemsetAsync(step_maxg, 0, sizeof(int) * ((size_t)nsteps + 1), b.cur));
+            hipLaunchKernelGGL(k_ct_step_maxg, dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, lower ? 1 : 0, P->order, step_of, gf,
+                               gl, step_maxg);
+        }
+#define CT_FILL_GREC(LOW)                                                                                                    \
+    hipLaunchKernelGGL((k_ct_fill_grec<T, LOW>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const T*)m->val,        \
+                       P->order, P->pos, tile_of, step_of, P->ct_tile_step, P->ct_step_pos, P->ct_ext_start, P->ct_ext_idx, \
+                       (char*)P->eval, nodiag, reverse ? 1 : 0, P->ct_dims[0], ref_start, slot_of_ref, (T*)P->diag, gf)
 #define CT_FILL_REC(LOW, WLL, LP)                                                                                            \
     hipLaunchKernelGGL((k_ct_fill_rec<T, LOW, WLL, LP>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci,                  \
                        (const T*)m->val, P->order, P->pos, tile_of, step_of, P->ct_tile_step, P->ct_step_pos,               \
@@ -2474,14 +3143,21 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
         else                         \
             CT_FILL_REC(LOW, 8, 1);  \
     } while(0)
-        if(lower)
+        if(grp && lower)
+            CT_FILL_GREC(true);
+        else if(grp)
+            CT_FILL_GREC(false);
+        else if(lower)
             CT_FILL_REC_W(true);
         else
             CT_FILL_REC_W(false);
 #undef CT_FILL_REC_W
 #undef CT_FILL_REC
+#undef CT_FILL_GREC
         hipLaunchKernelGGL(k_ct_step_rec2, dim3(ew_grid(nsteps + 1)), dim3(kBlock), 0, b.cur, n, nsteps, P->ct_step_pos,
-                           P->ct_ext_start, tile_of, P->ct_tile_step, P->ct_step_rec);
+                           P->ct_ext_start, tile_of, P->ct_tile_step, P->ct_step_rec, step_maxg);
+        P->ct_grp     = grp;
+        P->ct_infirst = grp && (lower == reverse);
     }
     int nd = 0;
     CT_HIP(hipMemcpyAsync(&nd, nodiag, sizeof(int), hipMemcpyDeviceToHost, b.cur));
@@ -2492,9 +3168,10 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     if(verbose)
         fprintf(stderr,
                 "box-tile plan (%s): n=%d chains=%d levels=%d extents=(%lld,%lld,%lld) box=(%d,%d,%d) tiles=%d steps=%d "
-                "wmax=%d max rows/steps/entries/ext per tile = %d/%d/%d/%d\n",
+                "wmax=%d max rows/steps/entries/ext per tile = %d/%d/%d/%d%s\n",
                 lower ? "lower" : "upper", n, nchains, nlev, (long long)E[0], (long long)E[1], (long long)E[2], bs[0], bs[1],
-                bs[2], ntiles, nsteps, wmax, P->ct_dims[0], P->ct_dims[1], P->ct_dims[2], P->ct_dims[3]);
+                bs[2], ntiles, nsteps, wmax, P->ct_dims[0], P->ct_dims[1], P->ct_dims[2], P->ct_dims[3],
+                grp ? " [row groups]" : "");
     cleanup();
 #undef CT_TRY
 #undef CT_HIP
@@ -2602,9 +3279,9 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
     if(P->ct)
     {
         const int    dm    = mul_inv_diag ? 2 : (unit ? 0 : 1);
-        const int    lpr   = P->ct_wmax > 8 ? 8 : 1;
-        const int    wl    = lpr == 1 ? (P->ct_wmax <= 3 ? 3 : (P->ct_wmax <= 4 ? 4 : 8)) : 4;
-        const CtDims dims  = {P->ct_dims[0], P->ct_dims[1], P->ct_dims[2], P->ct_dims[3]};
+        const int    lpr   = P->ct_grp ? kGrpLPR : (P->ct_wmax > 8 ? 8 : 1);
+        const int    wl    = P->ct_grp ? kGrpWL : (lpr == 1 ? (P->ct_wmax <= 3 ? 3 : (P->ct_wmax <= 4 ? 4 : 8)) : 4);
+        const CtDims dims  = {P->ct_dims[0], P->ct_dims[1], P->ct_dims[2], P->ct_dims[3], P->ct_infirst ? 1 : 0};
         if(P->ct_rec)
         {
             if(P->ct_in_key != rhs_idx)
@@ -2668,7 +3345,9 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
 #define TRSV_RC_L(DM, HO)            \
     do                               \
     {                                \
-        if(lpr == 8)                    \
+        if(lpr == kGrpLPR)              \
+            TRSV_RC(DM, HO, kGrpLPR, kGrpWL, RAMD_CT_DEPTHG); \
+        else if(lpr == 8)               \
             TRSV_RC(DM, HO, 8, 4, RAMD_CT_DEPTH8L);   \
         else if(wl == 3)                \
             TRSV_RC(DM, HO, 1, 3, RAMD_CT_DEPTH3);   \

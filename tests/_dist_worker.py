@@ -113,14 +113,16 @@ def cpu_worker(rank, world, initfile, kind, outdir):
     dist.destroy_process_group()
 
 
-def gpu_worker(rank, world, initfile, kind, outdir):
+def gpu_worker(rank, world, initfile, kind, outdir, rccl=False):
     """2 ranks sharing ONE GPU: the real GlobalMatrix / GlobalVector / CG path of the library with the
-    host-staged callback transport (RCCL refuses two ranks on one device)."""
+    host-staged callback transport (RCCL refuses two ranks on one device).
+    rccl=True: one GPU per rank, halo exchange and scalar sums over RCCL (ramd_comm_init_rccl) -- the transport of the
+    multi-GPU bench; needs `world` visible devices."""
     from rocalution_amd import capi, distributed as D
     import rocalution_amd as ra
     dist = _init(rank, world, initfile)
-    ra.init_rocalution(0)
-    comm = D.make_callback_comm(rank, world, dist)
+    ra.init_rocalution(rank if rccl else 0)
+    comm = D.init_rccl_comm(rank, world, dist) if rccl else D.make_callback_comm(rank, world, dist)
     out = {}
     if kind == "poisson_slab":
         N = 12
@@ -211,4 +213,7 @@ def gpu_worker(rank, world, initfile, kind, outdir):
 
 if __name__ == "__main__":
     mode, rank, world, initfile, kind, outdir = sys.argv[1:7]
-    (cpu_worker if mode == "cpu" else gpu_worker)(int(rank), int(world), initfile, kind, outdir)
+    if mode == "cpu":
+        cpu_worker(int(rank), int(world), initfile, kind, outdir)
+    else:
+        gpu_worker(int(rank), int(world), initfile, kind, outdir, rccl=(mode == "rccl"))

@@ -13,8 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-@pytest.mark.parametrize("kind", ["poisson_slab", "gr3030", "random"])
-def test_two_ranks_one_gpu(kind, oracle):
+def _check_two_ranks(kind, oracle, mode):
     from test_cpu_host import _spawn
     import _dist_worker as W
     from rocalution_amd import generators as gen
@@ -29,7 +28,7 @@ def test_two_ranks_one_gpu(kind, oracle):
     yref = oracle.csr_apply(rp, ci, va, x)
     b = oracle.csr_apply(rp, ci, va, np.ones(n))
     ref = oracle.solve(rp, ci, va, b, solver=oracle.CG, precond=oracle.PC_JACOBI, max_iter=500)
-    res = _spawn("gpu", kind)
+    res = _spawn(mode, kind)
     y = np.concatenate([r["y"] for r in res])
     assert np.array_equal(y, yref) or np.allclose(y, yref, rtol=1e-13, atol=1e-13)
     y_ell = np.concatenate([r["y_ell"] for r in res])
@@ -75,6 +74,24 @@ def test_two_ranks_one_gpu(kind, oracle):
     xs3 = np.concatenate([r["xs3"] for r in res])
     assert abs(int(res[0]["it3"]) - refm["iters"]) <= 1 and int(res[0]["st3"]) == refm["status"]
     assert np.linalg.norm(xs3 - refm["x"]) / np.linalg.norm(refm["x"]) < 1e-5
+
+
+@pytest.mark.parametrize("kind", ["poisson_slab", "gr3030", "random"])
+def test_two_ranks_one_gpu(kind, oracle):
+    _check_two_ranks(kind, oracle, "gpu")
+
+
+@pytest.mark.parametrize("kind", ["poisson_slab", "gr3030", "random"])
+def test_two_rccl_ranks_on_two_gpus(kind, oracle):
+    """The same checks with ONE GPU PER RANK and the RCCL data plane (grouped ncclSend/ncclRecv halo on the ghost stream
+    overlapped with the interior SpMV, ncclAllReduce on the device scalar record): CG+Jacobi on a slab / general row split,
+    BiCGStab+BlockJacobi(MC-SGS) with ELL and HYB interiors and GMRES(30)+BlockJacobi(ILU(0)) against the oracle's
+    nblocks=2 mode, MixedPrecisionDC on Global objects (global_matrix.cpp:948-1008 is the choreography replaced).  Runs
+    wherever at least two devices are visible (any multi-GPU driver box), skips on a 1-GPU box."""
+    import rocalution_amd as ra
+    if ra.device_count() < 2:
+        pytest.skip("needs two GPUs (one RCCL rank per device)")
+    _check_two_ranks(kind, oracle, "rccl")
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])

@@ -1086,17 +1086,19 @@ def test_csr_row_patterns_give_up_quickly_on_a_large_unstructured_matrix(ra, ora
     eq(y.numpy(), oracle.csr_apply(rp, ci, va, xh))
 
 
-@pytest.mark.parametrize("variant", ["RAMD_CSR_Q4=1", "RAMD_CSR_PAT=1", "RAMD_CSR_PAT=0"])
+@pytest.mark.parametrize("variant", ["RAMD_CSR_Q4=1", "RAMD_CSR_PAT=1", "RAMD_CSR_PAT=1,RAMD_CSR_XL=0", "RAMD_CSR_PAT=0"])
 def test_spmv_variants_forced_in_a_fresh_process(variant):
     """the CSR SpMV has an opt-in four-lanes-per-row walk (k_csr_q4), and CSR / ELL / HYB products and the multi-colour
-    sweeps rebuild the columns of structured matrices from row patterns (by default only from 2^20 entries on); each forced
+    sweeps rebuild the columns of structured matrices from row patterns (by default only from 2^20 entries on; the CSR
+    product then stages the x pieces its 256-row blocks need in LDS, k_csr_xl, or -- RAMD_CSR_XL=0 -- gathers x); each forced
     on (or off) for EVERY matrix of the SpMV / ApplyAdd / fused-dot / Jacobi-sweep / format / multi-colour / solver-history
     tests: results must not change (bit-exact: same values, same order)"""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ)
-    env[variant.split("=")[0]] = variant.split("=")[1]
+    for kv in variant.split(","):
+        env[kv.split("=")[0]] = kv.split("=")[1]
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_kernels.py"),
                         os.path.join(here, "test_gpu_edge_cases.py"), os.path.join(here, "test_gpu_solvers.py"), "-q", "-m", "gpu",
                         "-x", "-k", "(spmv or csr or apply or fused_bicgstab or golden or smoother or dia_format or convert or mcsgs or mcgs or mcilu "
