@@ -283,6 +283,36 @@ public:
         else
             this->host_.assign((size_t)size, ValueType(0));
     }
+    // extension: Allocate with a placement hint -- `other` is a vector a fused kernel WRITES in the same pass as this one;
+    // the block comes from the other placement class (ramd_vec_allocate_apart).  Same contents as Allocate (zeros).
+    void AllocateApart(std::string name, int64_t size, const LocalVector<ValueType>& other)
+    {
+        assert(size >= 0);
+        this->name_ = name;
+        if(this->on_accel_ && other.on_accel_ && other.dev_ != nullptr)
+        {
+            this->ensure_dev_();
+            RAMD_CHECK(ramd_vec_allocate_apart(this->dev_, size, other.dev_));
+        }
+        else
+            this->Allocate(name, size);
+    }
+    // ... and for a vector that is already allocated: moved (contents kept) if it shares `other`'s class
+    void PlaceApartFrom(const LocalVector<ValueType>& other)
+    {
+        if(!this->on_accel_ || !other.on_accel_ || this->dev_ == nullptr || other.dev_ == nullptr || &other == this)
+            return;
+        int mine = -1, theirs = -1;
+        RAMD_CHECK(ramd_vec_placement_class(this->dev_, &mine));
+        RAMD_CHECK(ramd_vec_placement_class(other.dev_, &theirs));
+        if(mine < 0 || theirs < 0 || mine != theirs)
+            return;
+        LocalVector<ValueType> moved;
+        moved.CloneBackend(*this);
+        moved.AllocateApart(this->name_, this->GetSize(), other);
+        moved.CopyFrom(*this);
+        std::swap(this->dev_, moved.dev_);
+    }
     void Clear(void)
     {
         if(this->dev_)

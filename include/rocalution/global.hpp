@@ -365,6 +365,10 @@ public:
     {
         this->m_owned.Clear();
     }
+    void PlaceApartFrom(const GlobalVector<ValueType>& other) // (placement hint of LocalVector, for the rank's share)
+    {
+        this->m_owned.PlaceApartFrom(other.m_owned);
+    }
     int64_t GetSize(void) const
     {
         return this->pm_ ? this->pm_->GetGlobalNrow() : this->m_owned.GetSize();
@@ -657,7 +661,7 @@ public:
     // global_matrix.cpp:924-1009, device-resident: pack | halo over xGMI || interior SpMV | ghost +=
     void Apply(const GlobalVector<ValueType>& in, GlobalVector<ValueType>* out) const
     {
-        const bool comm = this->pm_ != NULL && !this->pm_->peers().empty();
+        const bool comm = this->pm_ != NULL && (this->m_halo_allgather || !this->pm_->peers().empty());
         if(comm)
         {
             in.m_owned.GetIndexValues(this->m_halo_rows, &this->m_send);
@@ -685,7 +689,7 @@ public:
     void ApplyDotV(const GlobalVector<ValueType>& in, const GlobalVector<ValueType>& w,
                    GlobalVector<ValueType>* out, int slot) const
     {
-        const bool comm = this->pm_ != NULL && !this->pm_->peers().empty();
+        const bool comm = this->pm_ != NULL && (this->m_halo_allgather || !this->pm_->peers().empty());
         if(comm)
         {
             in.m_owned.GetIndexValues(this->m_halo_rows, &this->m_send);
@@ -714,7 +718,18 @@ private:
     // global_matrix.cpp:4476-4513: halo index vector + device send/recv buffers
     void doInitHalo(void)
     {
-        if(this->pm_ == NULL || this->pm_->peers().empty())
+        this->m_halo_allgather = false;
+        if(this->pm_ == NULL)
+            return;
+        {
+            // every rank announces its plan: the ranks agree on the form of the exchange (pairs, or one all-gather when
+            // some rank has many neighbours); in the all-gather form a rank without neighbours takes part as well
+            int ag = 0;
+            RAMD_CHECK(ramd_comm_halo_select(this->pm_->GetComm(), (int)this->pm_->peers().size(), this->pm_->peers().data(),
+                                             this->pm_->send_offset().data(), this->pm_->recv_offset().data(), &ag));
+            this->m_halo_allgather = ag != 0;
+        }
+        if(this->pm_->peers().empty() && !this->m_halo_allgather)
             return;
         const int nb = this->pm_->GetBoundarySize();
         this->m_halo_rows.MoveToAccelerator();
@@ -732,6 +747,7 @@ private:
     LocalVector<int>               m_halo_rows;
     mutable LocalVector<ValueType> m_send;
     mutable LocalVector<ValueType> m_recv;
+    bool                           m_halo_allgather = false; // form of the exchange the ranks agreed on (doInitHalo)
 };
 
 // ---- fused-loop helpers for Global objects (see solvers.hpp: _fusable / _fh / _f_apply_dot / _f_allreduce)

@@ -19,6 +19,7 @@
 #include <chrono>
 #include <cmath>
 #include <limits>
+#include <memory>
 
 #include "base.hpp"
 
@@ -1212,6 +1213,47 @@ protected:
     int64_t m_nnz;
 };
 
+// ============================================================================ WorkVectors
+// An owning set of work vectors on the operator's backend (Krylov bases, shadow spaces, level vectors).  A Build() that
+// runs out of device memory half way unwinds as rocalution::fatal_error behind the C ABI: whatever was allocated so far
+// is released by the set itself, and Clear() / the destructor of a half-built solver find nothing dangling.
+template <class VectorType>
+class WorkVectors
+{
+public:
+    WorkVectors() = default;
+    WorkVectors(const WorkVectors&) = delete;
+    WorkVectors& operator=(const WorkVectors&) = delete;
+    // `count` vectors of op.GetM() entries where the operator lives
+    template <class OperatorType>
+    void Create(const OperatorType& op, int count, const char* name)
+    {
+        this->Release();
+        m_own.reserve((size_t)count);
+        m_raw.reserve((size_t)count);
+        for(int i = 0; i < count; ++i)
+        {
+            m_own.emplace_back(new VectorType);
+            m_raw.push_back(m_own.back().get());
+            m_own.back()->CloneBackend(op);
+            m_own.back()->Allocate(name, op.GetM());
+        }
+    }
+    void Release(void)
+    {
+        m_raw.clear();
+        m_own.clear();
+    }
+    int         Count(void) const { return (int)m_own.size(); }
+    bool        Empty(void) const { return m_own.empty(); }
+    VectorType* operator[](int i) const { return m_raw[(size_t)i]; }
+    VectorType** Data(void) { return m_raw.data(); } // (the fused kernels take arrays of vectors)
+
+private:
+    std::vector<std::unique_ptr<VectorType>> m_own;
+    std::vector<VectorType*>                 m_raw;
+};
+
 // ============================================================================ IterativeLinearSolver
 template <class OperatorType, class VectorType, typename ValueType>
 class IterativeLinearSolver : public Solver<OperatorType, VectorType, ValueType>
@@ -1390,20 +1432,198 @@ inline void _f_allreduce(const LocalMatrix<ValueType>&, int, int)
 {
 }
 
-// ============================================================================ CG
+// ============================================================================ Recurrence
+// Device-resident recurrences: what a Krylov driver does between two residual checks, written as launches that never
+// come back to the host.  A dot product lands in a slot of the device scalar record, the coefficients (alpha = rho / <p,q>,
+// Givens-like c and tau, the small triangular systems of BiCGStab(l)) are short scalar programs that run on the record in
+// one single-thread launch, the vector updates read their coefficients from slots -- so an iteration costs ONE blocking
+// read (the residual the stopping rule needs, together with the breakdown flag) instead of one per Dot / Norm, and the
+// launches of the next iteration are already queued while the host waits.  The reference keeps all of this on the host
+// (src/solvers/krylov/{cr,fcg,bicgstabl,qmrcgstab}.cpp over hip_vector.cpp:785-931).
+// Breakdown tests (rho == 0 ...) become a flag on the device: FlagIfZero raises it, every update issued afterwards is
+// a no-op on the device (guarded launches), and the driver sees the flag with its next read -- state and solution are then
+// exactly what the reference leaves behind when it breaks out of its loop.
+// Arithmetic: every scalar operation is the reference's (same operands, same order, IEEE double or -- for float drivers --
+// float); dots are the fixed-order device reductions used everywhere else.
+// Slots: a driver numbers its scalars 0, 1, ... ; the engine maps them behind the slots the fused SpMV / CG / GMRES loops
+// use, one bank per nesting depth (a preconditioner that is itself such a driver gets the next bank).
 template <class OperatorType, class VectorType, typename ValueType>
-class CG : public IterativeLinearSolver<OperatorType, VectorType, ValueType>
+class Recurrence
 {
 public:
-    virtual ~CG()
+    enum { kBankFirst = 64, kBankSize = 96 }; // (two banks: [64, 160) and [160, 256); the fused loops use the slots below 64
+                                              //  and the top of the record)
+    explicit Recurrence(const OperatorType& A, int nscalars)
+        : m_op(A)
+        , m_single(sizeof(ValueType) == 4)
     {
-        this->Clear();
+        RAMD_EXPECT(nscalars + 2 <= kBankSize);
+        m_base = kBankFirst + kBankSize * depth_()++;
+        if(m_base + kBankSize > RAMD_NSCALARS)
+        {
+            say("Recurrence: drivers nested deeper than the scalar record allows");
+            RAMD_DIE();
+        }
+        m_guard = m_base + kBankSize - 1; // the breakdown flag of this driver
+        m_tmp   = m_base + kBankSize - 2;
+        this->Set(-1, 0.0);
     }
+    ~Recurrence()
+    {
+        --depth_();
+    }
+    Recurrence(const Recurrence&) = delete;
+    Recurrence& operator=(const Recurrence&) = delete;
+
+    // ---- scalar program (queued; goes out as one launch before the next consumer)
+    void Set(int d, double v) { push_(RAMD_SOP_SET, d, -2, -2, v); } // d == -1: the breakdown flag
+    void Mov(int d, int a) { push_(RAMD_SOP_MOV, d, a, -2, 0.0); }
+    void Add(int d, int a, int b) { push_(RAMD_SOP_ADD, d, a, b, 0.0); }
+    void Sub(int d, int a, int b) { push_(RAMD_SOP_SUB, d, a, b, 0.0); }
+    void Mul(int d, int a, int b) { push_(RAMD_SOP_MUL, d, a, b, 0.0); }
+    void Div(int d, int a, int b) { push_(RAMD_SOP_DIV, d, a, b, 0.0); }
+    void Neg(int d, int a) { push_(RAMD_SOP_NEG, d, a, -2, 0.0); }
+    void Sqrt(int d, int a) { push_(RAMD_SOP_SQRT, d, a, -2, 0.0); }
+    void FlagIfZero(int a) { push_(RAMD_SOP_ZFLAG, -1, a, -2, 0.0); }
+    void FlagIfBad(int a) { push_(RAMD_SOP_BADFLAG, -1, a, -2, 0.0); } // zero, NaN or infinite
+    void ClearFlag(void) { this->Set(-1, 0.0); }
+    void MovIfLess(int d, int a, int b, int src) { push_(RAMD_SOP_CMOVLT, d, a, b, (double)map_(src)); } // if a < b: d = src
+
+    // ---- reductions into slots
+    void Dot(int d, const VectorType& a, const VectorType& b)
+    {
+        this->Flush();
+        const ramd_vec_t one[1] = {_fh(a)};
+        RAMD_CHECK(ramd_fused_multi_dot(one, 1, _fh(b), m_base + d));
+        _f_allreduce(m_op, m_base + d, 1);
+    }
+    // s[d + k] = <as[k], w> for k < count, one pass over w
+    void Dots(int d, VectorType* const* as, int count, const VectorType& w)
+    {
+        this->Flush();
+        ramd_vec_t h[8];
+        RAMD_EXPECT(count >= 1 && count <= 8);
+        for(int k = 0; k < count; ++k)
+            h[k] = _fh(*as[k]);
+        RAMD_CHECK(ramd_fused_multi_dot(h, count, _fh(w), m_base + d));
+        _f_allreduce(m_op, m_base + d, count);
+    }
+    // s[d] = ||a||_2 (the dot, then the square root on the device)
+    void Norm(int d, const VectorType& a)
+    {
+        this->Dot(d, a, a);
+        this->Sqrt(d, d);
+    }
+
+    // ---- vector updates with coefficients from slots (f = +-1 or any constant factor)
+    void Axpy(VectorType* x, int slot, double f, const VectorType& y) // x = x + (f s) y        (AddScale)
+    {
+        this->combine_(x, x, -1, 1.0, &y, slot, f, nullptr, -1, 0.0);
+    }
+    void Xpay(VectorType* x, int slot, double f, const VectorType& y) // x = (f s) x + y        (ScaleAdd)
+    {
+        this->combine_(x, x, slot, f, &y, -1, 1.0, nullptr, -1, 0.0);
+    }
+    void Scale(VectorType* x, int slot, double f) // x = (f s) x
+    {
+        this->combine_(x, x, slot, f, nullptr, -1, 0.0, nullptr, -1, 0.0);
+    }
+    void XpbyS(VectorType* x, int sx, double fx, const VectorType& y, int sy, double fy) // x = (fx sx) x + (fy sy) y  (ScaleAddScale)
+    {
+        this->combine_(x, x, sx, fx, &y, sy, fy, nullptr, -1, 0.0);
+    }
+    // x = (fx sx) x + (fy sy) y + (fz sz) z                                                       (ScaleAdd2)
+    void Combine3(VectorType* x, int sx, double fx, const VectorType& y, int sy, double fy, const VectorType& z, int sz, double fz)
+    {
+        this->combine_(x, x, sx, fx, &y, sy, fy, &z, sz, fz);
+    }
+    void AddVec(VectorType* x, const VectorType& y) // x = x + y, guarded like every other update
+    {
+        this->combine_(x, x, -1, 1.0, &y, -1, 1.0, nullptr, -1, 0.0);
+    }
+    void Assign(VectorType* x, const VectorType& y) // x = y, guarded
+    {
+        this->combine_(x, &y, -1, 1.0, nullptr, -1, 0.0, nullptr, -1, 0.0);
+    }
+
+    // ---- the one read per iteration: slots [first, first + count) and the breakdown flag
+    bool Fetch(int first, int count, double* out) // returns true if a breakdown was flagged
+    {
+        this->Flush();
+        double buf[kBankSize];
+        RAMD_EXPECT(first >= 0 && count >= 1 && first + count <= kBankSize - 2);
+        // (one copy of the bank's tail: the values and the flag travel together)
+        RAMD_CHECK(ramd_scalars_fetch(buf, m_base, kBankSize));
+        for(int k = 0; k < count; ++k)
+            out[k] = buf[first + k];
+        return buf[kBankSize - 1] != 0.0;
+    }
+    double Fetch(int slot, bool* broke = nullptr)
+    {
+        double     v = 0.0;
+        const bool b = this->Fetch(slot, 1, &v);
+        if(broke)
+            *broke = b;
+        return v;
+    }
+    void Flush(void)
+    {
+        if(m_prog.empty())
+            return;
+        RAMD_CHECK(ramd_scalars_eval(m_prog.data(), (int)m_prog.size(), m_single ? 1 : 0));
+        m_prog.clear();
+    }
+
+private:
+    static int& depth_(void)
+    {
+        static int d = 0;
+        return d;
+    }
+    int map_(int s) const
+    {
+        return s == -1 ? m_guard : (s == -2 ? -1 : m_base + s);
+    }
+    void push_(int op, int d, int a, int b, double imm)
+    {
+        if(m_prog.size() == (size_t)RAMD_SOP_MAX)
+            this->Flush();
+        ramd_sop_t o;
+        o.op  = op;
+        o.dst = map_(d);
+        o.a   = map_(a);
+        o.b   = map_(b);
+        o.imm = imm;
+        m_prog.push_back(o);
+    }
+    void combine_(VectorType* x, const VectorType* v0, int s0, double f0, const VectorType* v1, int s1, double f1,
+                  const VectorType* v2, int s2, double f2)
+    {
+        this->Flush();
+        ramd_vec_t vs[3]  = {_fh(*v0), v1 ? _fh(*v1) : nullptr, v2 ? _fh(*v2) : nullptr};
+        const int  sl[3]  = {s0 >= 0 ? m_base + s0 : -1, s1 >= 0 ? m_base + s1 : -1, s2 >= 0 ? m_base + s2 : -1};
+        const double f[3] = {f0, f1, f2};
+        RAMD_CHECK(ramd_vec_combine_s(_fh(*x), v2 ? 3 : (v1 ? 2 : 1), vs, sl, f, m_guard));
+    }
+    const OperatorType&     m_op;
+    bool                    m_single;
+    int                     m_base, m_guard, m_tmp;
+    std::vector<ramd_sop_t> m_prog;
+};
+
+// ============================================================================ KrylovDriver
+// What the recurrence-based drivers below share: the work vectors live in one owning set on the operator's backend, Build and
+// Clear are the same for all of them, the residual the stopping rule sees comes out of the recurrence engine together with
+// its breakdown flag (one read per iteration), and both Solve entries of the reference's interface lead to one routine.
+template <class OperatorType, class VectorType, typename ValueType>
+class KrylovDriver : public IterativeLinearSolver<OperatorType, VectorType, ValueType>
+{
+public:
+    typedef Recurrence<OperatorType, VectorType, ValueType> Engine;
     virtual void Print(void) const
     {
-        say("CG solver", (this->m_precond ? ", with preconditioner" : " (non-precond)"));
+        say(this->doLabel(this->m_precond != NULL), " solver", (this->m_precond ? ", with preconditioner" : ""));
     }
-    // cg.cpp:99-137
     virtual void Build(void)
     {
         if(this->m_build)
@@ -1414,103 +1634,134 @@ public:
         {
             this->m_precond->SetOperator(*this->m_op);
             this->m_precond->Build();
-            this->m_z.CloneBackend(*this->m_op);
-            this->m_z.Allocate("z", this->m_op->GetM());
         }
-        this->m_r.CloneBackend(*this->m_op);
-        this->m_r.Allocate("r", this->m_op->GetM());
-        this->m_p.CloneBackend(*this->m_op);
-        this->m_p.Allocate("p", this->m_op->GetM());
-        this->m_q.CloneBackend(*this->m_op);
-        this->m_q.Allocate("q", this->m_op->GetM());
+        this->m_w.Create(*this->m_op, this->doWorkVectors(this->m_precond != NULL), "krylov work vector");
+        this->doAfterBuild();
     }
     virtual void Clear(void)
     {
-        if(this->m_build)
+        if(!this->m_build)
+            return;
+        if(this->m_precond != NULL)
         {
-            if(this->m_precond != NULL)
-            {
-                this->m_precond->Clear();
-                this->m_precond = NULL;
-            }
-            this->m_r.Clear();
-            this->m_z.Clear();
-            this->m_p.Clear();
-            this->m_q.Clear();
-            this->m_iter_ctrl.Clear();
-            this->m_build = false;
+            this->m_precond->Clear();
+            this->m_precond = NULL;
         }
+        this->m_w.Release();
+        this->m_iter_ctrl.Clear();
+        this->m_build = false;
     }
 
 protected:
+    virtual void doAfterBuild(void) // (what a driver prepares once its work vectors exist)
+    {
+    }
+    virtual const char* doLabel(bool precond) const             = 0; // name of the method in the log lines
+    virtual int         doWorkVectors(bool precond) const       = 0;
+    virtual void doIterate(const VectorType& rhs, VectorType* x, bool precond) = 0;
     virtual void doPrintStart(void) const
     {
-        say("CG ", (this->m_precond ? "" : "(non-precond) "), "linear solver starts");
+        say(this->doLabel(this->m_precond != NULL), " linear solver starts", (this->m_precond ? ", with preconditioner:" : ""));
     }
     virtual void doPrintEnd(void) const
     {
-        say("CG ends");
+        say(this->doLabel(this->m_precond != NULL), " ends");
     }
     virtual void doSolveNonPrecond(const VectorType& rhs, VectorType* x)
     {
-        this->doSolve(rhs, x, false);
+        this->doIterate(rhs, x, false);
     }
     virtual void doSolvePrecond(const VectorType& rhs, VectorType* x)
     {
-        this->doSolve(rhs, x, true);
+        this->doIterate(rhs, x, true);
+    }
+    VectorType* W(int i)
+    {
+        return this->m_w[i];
+    }
+    // r = rhs - A x
+    void doDefect(const VectorType& rhs, const VectorType& x, VectorType* r)
+    {
+        this->m_op->Apply(x, r);
+        r->ScaleAdd(num<ValueType>(-1), rhs);
+    }
+    // the residual norm of `v` as the stopping rule wants it, with the breakdown flag of the recurrence: ONE read.  The
+    // Euclidean norm is formed on the device (slot `slot`); the other norm types go through the vector's own reduction.
+    double doResidual(Engine& K, int slot, const VectorType& v, bool* broke = nullptr)
+    {
+        if(this->m_res_norm_type == 2)
+        {
+            K.Norm(slot, v);
+            return std::abs(K.Fetch(slot, broke));
+        }
+        (void)K.Fetch(slot, broke);
+        return std::abs((double)this->doNorm(v));
+    }
+    WorkVectors<VectorType> m_w;
+};
+
+// ============================================================================ CG
+// src/solvers/krylov/cg.cpp:291-446.  Two forms of the same iteration: the three-launch loop below (SpMV carrying <p, q>,
+// residual update carrying ||r||^2 and -- with Jacobi -- z and <r, z>, direction update), used for the Euclidean norm, and
+// the recurrence-engine form for every other setting (other norms, SetFused(false), preconditioners that run reductions
+// of their own).  Either way the coefficients never visit the host; the stopping rule sees the recursive residual ||r||.
+template <class OperatorType, class VectorType, typename ValueType>
+class CG : public KrylovDriver<OperatorType, VectorType, ValueType>
+{
+public:
+    virtual ~CG()
+    {
+        this->Clear();
+    }
+
+protected:
+    virtual const char* doLabel(bool precond) const
+    {
+        return precond ? "PCG" : "CG (non-precond)";
+    }
+    virtual int doWorkVectors(bool precond) const
+    {
+        return precond ? 4 : 3;
+    }
+    virtual void doIterate(const VectorType& rhs, VectorType* x, bool precond)
+    {
+        typedef typename KrylovDriver<OperatorType, VectorType, ValueType>::Engine Engine;
+        enum { sRho, sRhoOld, sPQ, sAlpha, sBeta, sRes, sCount };
+        VectorType *r = this->W(0), *p = this->W(1), *q = this->W(2), *z = precond ? this->W(3) : r;
+        // placement (no arithmetic): the residual update writes r and z in one pass, the direction update x and p -- each
+        // pair streams faster from different placement classes (csrc/backend.hip); a no-op for small or already-apart blocks
+        if(precond)
+            z->PlaceApartFrom(*r);
+        p->PlaceApartFrom(*x);
+        Engine K(*this->m_op, sCount);
+        this->doDefect(rhs, *x, r);
+        if(this->m_iter_ctrl.InitResidual(this->doResidual(K, sRes, *r)) == false)
+            return;
+        if(precond)
+            this->m_precond->SolveZeroSol(*r, z);
+        p->CopyFrom(*z);
+        if(this->m_fused && this->m_res_norm_type == 2 && this->doFusedLoop(rhs, x, precond))
+            return;
+        K.Dot(sRho, *r, *z);
+        while(true)
+        {
+            this->m_op->Apply(*p, q);
+            K.Dot(sPQ, *p, *q);
+            K.Div(sAlpha, sRho, sPQ);
+            K.Axpy(x, sAlpha, +1.0, *p);
+            K.Axpy(r, sAlpha, -1.0, *q);
+            if(this->m_iter_ctrl.CheckResidual(this->doResidual(K, sRes, *r), this->m_index))
+                break;
+            K.Mov(sRhoOld, sRho);
+            if(precond)
+                this->m_precond->SolveZeroSol(*r, z);
+            K.Dot(sRho, *r, *z);
+            K.Div(sBeta, sRho, sRhoOld);
+            K.Xpay(p, sBeta, +1.0, *z);
+        }
     }
 
 private:
-    // cg.cpp:291-362 / :366-446
-    void doSolve(const VectorType& rhs, VectorType* x, bool precond)
-    {
-        const OperatorType* op = this->m_op;
-        VectorType *        kr = &this->m_r, *kz = &this->m_z, *kp = &this->m_p, *kq = &this->m_q;
-        ValueType           alpha, beta, rho, rho_old;
-
-        op->Apply(*x, kr);
-        kr->ScaleAdd(num<ValueType>(-1), rhs);
-        ValueType res_norm = this->doNorm(*kr);
-        if(this->m_iter_ctrl.InitResidual(std::abs(res_norm)) == false)
-            return;
-        if(precond)
-        {
-            this->m_precond->SolveZeroSol(*kr, kz);
-            kp->CopyFrom(*kz);
-        }
-        else
-            kp->CopyFrom(*kr);
-
-        if(this->m_fused && this->m_res_norm_type == 2 && this->doFusedLoop(rhs, x, precond))
-            return;
-
-        rho = precond ? kr->DotNonConj(*kz) : kr->DotNonConj(*kr);
-        while(true)
-        {
-            op->Apply(*kp, kq);
-            alpha = rho / kp->DotNonConj(*kq);
-            x->AddScale(*kp, alpha);
-            kr->AddScale(*kq, -alpha);
-            res_norm = this->doNorm(*kr);
-            if(this->m_iter_ctrl.CheckResidual(std::abs(res_norm), this->m_index))
-                break;
-            rho_old = rho;
-            if(precond)
-            {
-                this->m_precond->SolveZeroSol(*kr, kz);
-                rho  = kr->DotNonConj(*kz);
-                beta = rho / rho_old;
-                kp->ScaleAdd(beta, *kz);
-            }
-            else
-            {
-                rho  = kr->DotNonConj(*kr);
-                beta = rho / rho_old;
-                kp->ScaleAdd(beta, *kr);
-            }
-        }
-    }
-
     // Fused device loop (Local objects on the accelerator).  Per iteration:
     //   K1  kq = A kp, <kp,kq>                                   (ramd_fused_apply_dot)
     //   K2  kr -= a kq ; <kr,kr> ; [kz = D^-1 kr ; <kr,kz>]            (ramd_fused_cg_update)
@@ -1525,7 +1776,7 @@ private:
         if(!this->m_op->is_accel_() || !x->is_accel_())
             return false;
         const OperatorType& A = *this->m_op;
-        VectorType *kr = &this->m_r, *kz = &this->m_z, *kp = &this->m_p, *kq = &this->m_q;
+        VectorType *kr = this->W(0), *kp = this->W(1), *kq = this->W(2), *kz = precond ? this->W(3) : kr;
         typedef Jacobi<OperatorType, VectorType, ValueType> JacobiType;
         JacobiType* jac = precond ? dynamic_cast<JacobiType*>(this->m_precond) : NULL;
         ramd_vec_t  dinv = NULL;
@@ -1577,7 +1828,6 @@ private:
         return false;
     }
 
-    VectorType m_r, m_z, m_p, m_q;
 };
 
 // ============================================================================ GMRES
@@ -1588,8 +1838,6 @@ public:
     GMRES()
         : m_flexible(false)
         , m_size_basis(30) // gmres.cpp:50
-        , m_v(NULL)
-        , m_zb(NULL)
     {
     }
     virtual ~GMRES()
@@ -1617,25 +1865,11 @@ public:
         this->m_s.assign((size_t)m, ValueType(0));
         this->m_r.assign((size_t)m + 1, ValueType(0));
         this->m_H.assign((size_t)(m + 1) * m, ValueType(0));
-        this->m_v = new VectorType*[m + 1];
-        for(int i = 0; i < m + 1; ++i)
-        {
-            this->m_v[i] = new VectorType;
-            this->m_v[i]->CloneBackend(*this->m_op);
-            this->m_v[i]->Allocate("v", this->m_op->GetM());
-        }
+        this->m_v.Create(*this->m_op, m + 1, "v");
         if(this->m_precond != NULL)
         {
             if(this->m_flexible) // fgmres.cpp:139-150: one z per basis vector
-            {
-                this->m_zb = new VectorType*[m + 1];
-                for(int i = 0; i < m + 1; ++i)
-                {
-                    this->m_zb[i] = new VectorType;
-                    this->m_zb[i]->CloneBackend(*this->m_op);
-                    this->m_zb[i]->Allocate("z", this->m_op->GetM());
-                }
-            }
+                this->m_zb.Create(*this->m_op, m + 1, "z");
             else
             {
                 this->m_z.CloneBackend(*this->m_op);
@@ -1654,16 +1888,8 @@ public:
                 this->m_precond->Clear();
                 this->m_precond = NULL;
             }
-            for(int i = 0; i < this->m_size_basis + 1; ++i)
-            {
-                delete this->m_v[i];
-                if(this->m_zb != NULL)
-                    delete this->m_zb[i];
-            }
-            delete[] this->m_v;
-            delete[] this->m_zb;
-            this->m_v  = NULL;
-            this->m_zb = NULL;
+            this->m_v.Release();
+            this->m_zb.Release();
             this->m_z.Clear();
             this->m_iter_ctrl.Clear();
             this->m_build = false;
@@ -1745,7 +1971,7 @@ private:
     // one Arnoldi step: fills column i of H (rows 0..i+1) and normalises m_v{i+1}
     void doArnoldi(int i, bool precond)
     {
-        VectorType**    v   = this->m_v;
+        VectorType**    v   = this->m_v.Data();
         ValueType*      H   = this->m_H.data();
         const ValueType one = num<ValueType>(1);
         if(precond && this->m_flexible) // fgmres.cpp:462-466: M z_i = v_i ; v_i+1 = A z_i
@@ -1780,7 +2006,7 @@ private:
         if(i + 3 > RAMD_NSCALARS - 2 || !this->m_v[0]->is_accel_())
             return false;
         const OperatorType& A = *this->m_op;
-        VectorType**        v = this->m_v;
+        VectorType**        v = this->m_v.Data();
         ValueType*          H = this->m_H.data();
         ramd_vec_t          w = _fh(*v[i + 1]);
         // Blocks of K (= 4) projections per pass (ramd_fused_mgs_block: the same recurrence with the block's Gram entries
@@ -1865,7 +2091,7 @@ private:
     // gmres.cpp:274-413 / :416-562
     void doSolve(const VectorType& rhs, VectorType* x, bool precond)
     {
-        VectorType**    v    = this->m_v;
+        VectorType**    v    = this->m_v.Data();
         ValueType *     c = this->m_c.data(), *s = this->m_s.data(), *r = this->m_r.data();
         ValueType*      H    = this->m_H.data();
         const ValueType one  = num<ValueType>(1);
@@ -1897,7 +2123,7 @@ private:
                 for(int k = 0; k < j; ++k)
                     r[k] -= H[this->m_hidx(k, j)] * r[j];
             }
-            VectorType** upd = (precond && this->m_flexible) ? this->m_zb : v; // fgmres.cpp:527-532
+            VectorType** upd = (precond && this->m_flexible) ? this->m_zb.Data() : v; // fgmres.cpp:527-532
             if(!this->doFusedUpdate(x, upd, r, i)) // x += r_0 upd_0, then r_1 upd_1, ... (one AddScale per basis vector)
                 for(int j = 0; j < i; ++j)
                     x->AddScale(*upd[j], r[j]);
@@ -1914,8 +2140,8 @@ protected:
 
 private:
     int                    m_size_basis;
-    VectorType**           m_v;
-    VectorType**           m_zb;
+    WorkVectors<VectorType> m_v; // Krylov basis
+    WorkVectors<VectorType> m_zb; // flexible variant: the preconditioned basis
     VectorType             m_z;
     std::vector<ValueType> m_c, m_s, m_r, m_H;
 };
@@ -1938,75 +2164,107 @@ public:
 };
 
 // ============================================================================ BiCGStab
+// src/solvers/krylov/bicgstab.cpp:245-489 (right preconditioned: z = M^-1 p, v = M^-1 r).  As for CG: a loop of fused
+// kernels for the Euclidean norm, the recurrence-engine form otherwise.  The reference's two breakdown branches are kept:
+// omega zero / NaN / infinite -> the solution is updated in the p direction only and the true residual decides
+// (bicgstab.cpp:430-447); rho = 0 -> the loop ends.  In the engine form the flag is raised on the device, the two updates
+// that would use omega are no-ops, and the host learns about it with the residual it reads anyway; <r0, r> for the next
+// direction is gathered before that read so that one read serves the three decisions of an iteration.
 template <class OperatorType, class VectorType, typename ValueType>
-class BiCGStab : public IterativeLinearSolver<OperatorType, VectorType, ValueType>
+class BiCGStab : public KrylovDriver<OperatorType, VectorType, ValueType>
 {
 public:
     virtual ~BiCGStab()
     {
         this->Clear();
     }
-    virtual void Print(void) const
-    {
-        say("BiCGStab solver", (this->m_precond ? ", with preconditioner" : " (non-precond)"));
-    }
-    // bicgstab.cpp:109-160
-    virtual void Build(void)
-    {
-        if(this->m_build)
-            this->Clear();
-        RAMD_EXPECT(this->m_op != nullptr && this->m_op->GetM() == this->m_op->GetN() && this->m_op->GetM() > 0);
-        this->m_build = true;
-        VectorType* all[] = {&this->m_r, &this->m_r0, &this->m_p, &this->m_q, &this->m_t};
-        for(VectorType* vec : all)
-        {
-            vec->CloneBackend(*this->m_op);
-            vec->Allocate("bicgstab", this->m_op->GetM());
-        }
-        if(this->m_precond != NULL)
-        {
-            this->m_precond->SetOperator(*this->m_op);
-            this->m_precond->Build();
-            this->m_v.CloneBackend(*this->m_op);
-            this->m_v.Allocate("v", this->m_op->GetM());
-            this->m_z.CloneBackend(*this->m_op);
-            this->m_z.Allocate("z", this->m_op->GetM());
-        }
-    }
-    virtual void Clear(void)
-    {
-        if(this->m_build)
-        {
-            if(this->m_precond != NULL)
-            {
-                this->m_precond->Clear();
-                this->m_precond = NULL;
-            }
-            VectorType* all[] = {&this->m_r, &this->m_r0, &this->m_p, &this->m_q, &this->m_t, &this->m_v,
-                                 &this->m_z};
-            for(VectorType* vec : all)
-                vec->Clear();
-            this->m_iter_ctrl.Clear();
-            this->m_build = false;
-        }
-    }
 
 protected:
-    virtual void doPrintStart(void) const
+    virtual const char* doLabel(bool precond) const
     {
-        say("BiCGStab ", (this->m_precond ? "" : "(non-precond) "), "linear solver starts");
+        return precond ? "BiCGStab" : "BiCGStab (non-precond)";
     }
-    virtual void doPrintEnd(void) const
+    virtual int doWorkVectors(bool precond) const
     {
-        say("BiCGStab ends");
+        return precond ? 7 : 5;
     }
-    virtual void doSolveNonPrecond(const VectorType& rhs, VectorType* x)
+    virtual void doIterate(const VectorType& rhs, VectorType* x, bool precond)
     {
-        this->doSolve(rhs, x, false);
-    }
-    virtual void doSolvePrecond(const VectorType& rhs, VectorType* x)
-    {
-        this->doSolve(rhs, x, true);
+        typedef typename KrylovDriver<OperatorType, VectorType, ValueType>::Engine Engine;
+        enum { sRes, sRho, sRhoOld, sR0Q, sTR, sTT, sAlpha, sOmega, sBeta, sT, sU, sCount }; // (sRes, sRho: read together)
+        VectorType *r = this->W(0), *shadow = this->W(1), *p = this->W(2), *q = this->W(3), *t = this->W(4);
+        VectorType *v = precond ? this->W(5) : NULL, *z = precond ? this->W(6) : NULL;
+        r->PlaceApartFrom(*x); // (placement only: the fused update writes x and r in one pass)
+        Engine K(*this->m_op, sCount);
+        this->doDefect(rhs, *x, shadow);
+        if(this->m_iter_ctrl.InitResidual(this->doResidual(K, sRes, *shadow)) == false)
+            return;
+        r->CopyFrom(*shadow);
+        p->CopyFrom(*r);
+        if(precond)
+            this->m_precond->SolveZeroSol(*r, z);
+        if(this->m_fused && this->m_res_norm_type == 2 && this->doFusedLoop(rhs, x, precond))
+            return;
+        K.Dot(sRho, *r, *r);
+        while(true)
+        {
+            const VectorType* dir = precond ? z : p;
+            this->m_op->Apply(*dir, q);
+            K.Dot(sR0Q, *shadow, *q);
+            K.Div(sAlpha, sRho, sR0Q);
+            K.Axpy(r, sAlpha, -1.0, *q);
+            const VectorType* sv = r;
+            if(precond)
+            {
+                this->m_precond->SolveZeroSol(*r, v);
+                sv = v;
+            }
+            this->m_op->Apply(*sv, t);
+            K.Dot(sTR, *t, *r);
+            K.Dot(sTT, *t, *t);
+            K.Div(sOmega, sTR, sTT);
+            K.FlagIfBad(sOmega);
+            K.Combine3(x, -1, 1.0, *dir, sAlpha, +1.0, *sv, sOmega, +1.0); // x = x + alpha dir + omega sv
+            K.Axpy(r, sOmega, -1.0, *t);
+            K.Mov(sRhoOld, sRho);
+            K.Dot(sRho, *shadow, *r);
+            double two[2] = {0.0, 0.0};
+            bool   broke  = false;
+            if(this->m_res_norm_type == 2)
+            {
+                K.Norm(sRes, *r);
+                broke = K.Fetch(sRes, 2, two);
+            }
+            else
+            {
+                broke  = K.Fetch(sRes, 2, two);
+                two[0] = (double)this->doNorm(*r);
+            }
+            if(broke)
+            {
+                say("BiCGStab omega == 0 || Nan || Inf !!! Updated solution only in p-direction");
+                K.ClearFlag();
+                K.Axpy(x, sAlpha, +1.0, *p);
+                this->doDefect(rhs, *x, p);
+                this->m_iter_ctrl.CheckResidual(std::abs((double)this->doNorm(*p)), this->m_index);
+                break;
+            }
+            if(this->m_iter_ctrl.CheckResidual(std::abs(two[0]), this->m_index))
+                break;
+            if((ValueType)two[1] == num<ValueType>(0))
+            {
+                say("BiCGStab rho == 0 !!!");
+                break;
+            }
+            K.Div(sT, sRho, sRhoOld);
+            K.Div(sU, sAlpha, sOmega);
+            K.Mul(sBeta, sT, sU); // beta = (rho / rho_old) (alpha / omega)
+            K.Neg(sT, sBeta);
+            K.Mul(sT, sT, sOmega);
+            K.Combine3(p, sBeta, +1.0, *q, sT, +1.0, *r, -1, 1.0); // p = beta p + (-beta omega) q + r
+            if(precond)
+                this->m_precond->SolveZeroSol(*p, z);
+        }
     }
 
 private:
@@ -2014,7 +2272,7 @@ private:
     // kt = A sv, one pass for <kt,kr>,<kt,kt> | K3 x,kr updates + <kr,kr>,<r0,kr> | K4 kp update | [kz = M^-1 kp].
     // alpha/omega/beta never leave the device; ONE host read per iteration (the four dots of K3'ks
     // record), overlapped with K4 and the next preconditioner apply.  Same per-element arithmetic and
-    // the same breakdown / stopping decisions as the loop below.
+    // the same breakdown / stopping decisions as the engine form above.
     template <class O = OperatorType, class V = VectorType>
     typename std::enable_if<_fusable<O, V, ValueType>::value, bool>::type
         doFusedLoop(const VectorType& rhs, VectorType* x, bool precond)
@@ -2024,8 +2282,8 @@ private:
         if(precond && this->m_precond->SolveUsesScalarRecord())
             return false; // a preconditioner with reductions of its own would overwrite alpha / omega / rho on the device
         const OperatorType& A = *this->m_op;
-        VectorType *kr = &this->m_r, *r0 = &this->m_r0, *kp = &this->m_p, *kq = &this->m_q, *kt = &this->m_t;
-        VectorType *kv = &this->m_v, *kz = &this->m_z;
+        VectorType *kr = this->W(0), *r0 = this->W(1), *kp = this->W(2), *kq = this->W(3), *kt = this->W(4);
+        VectorType *kv = precond ? this->W(5) : NULL, *kz = precond ? this->W(6) : NULL;
         const ValueType one = num<ValueType>(1);
         // slots: <kt,kr> = 0, <kt,kt> = 1, <r0,kq> = 2, ||kr||^2 = 4, rho alternates between 3 and 5 (always next
         // to slot 4: the two sums of K3 cross the ranks in ONE all-reduce), breakdown flag = 6
@@ -2091,744 +2349,460 @@ private:
         return false;
     }
 
-    // bicgstab.cpp:245-361 / :365-489 (right preconditioned: kz = M^-1 kp, kv = M^-1 kr)
-    void doSolve(const VectorType& rhs, VectorType* x, bool precond)
-    {
-        const OperatorType* op = this->m_op;
-        VectorType *kr = &this->m_r, *r0 = &this->m_r0, *kp = &this->m_p, *kq = &this->m_q, *kt = &this->m_t;
-        VectorType *kv = &this->m_v, *kz = &this->m_z;
-        ValueType   alpha, beta, omega, rho, rho_old;
-        const ValueType one = num<ValueType>(1);
-
-        op->Apply(*x, r0);
-        r0->ScaleAdd(-one, rhs);
-        ValueType res_norm = this->doNorm(*r0);
-        if(this->m_iter_ctrl.InitResidual(std::abs(res_norm)) == false)
-            return;
-        kr->CopyFrom(*r0);
-        kp->CopyFrom(*kr);
-        if(precond)
-            this->m_precond->SolveZeroSol(*kr, kz);
-        if(this->m_fused && this->m_res_norm_type == 2 && this->doFusedLoop(rhs, x, precond))
-            return;
-        rho = kr->Dot(*kr);
-        while(true)
-        {
-            const VectorType* dir = precond ? kz : kp;
-            op->Apply(*dir, kq);
-            alpha = rho / r0->Dot(*kq);
-            kr->AddScale(*kq, -alpha);
-            const VectorType* sv = kr;
-            if(precond)
-            {
-                this->m_precond->SolveZeroSol(*kr, kv);
-                sv = kv;
-            }
-            op->Apply(*sv, kt);
-            omega = kt->Dot(*kr) / kt->Dot(*kt);
-            if((std::abs(omega) == std::numeric_limits<ValueType>::infinity()) || (omega != omega)
-               || (omega == num<ValueType>(0)))
-            {
-                say("BiCGStab omega == 0 || Nan || Inf !!! Updated solution only in p-direction");
-                x->AddScale(*kp, alpha);
-                op->Apply(*x, kp);
-                kp->ScaleAdd(-one, rhs);
-                res_norm = this->doNorm(*kp);
-                this->m_iter_ctrl.CheckResidual(std::abs(res_norm), this->m_index);
-                break;
-            }
-            x->ScaleAdd2(one, *dir, alpha, *sv, omega);
-            kr->AddScale(*kt, -omega);
-            res_norm = this->doNorm(*kr);
-            if(this->m_iter_ctrl.CheckResidual(std::abs(res_norm), this->m_index))
-                break;
-            rho_old = rho;
-            rho     = r0->Dot(*kr);
-            if(rho == num<ValueType>(0))
-            {
-                say("BiCGStab rho == 0 !!!");
-                break;
-            }
-            beta = (rho / rho_old) * (alpha / omega);
-            kp->ScaleAdd2(beta, *kq, -beta * omega, *kr, one);
-            if(precond)
-                this->m_precond->SolveZeroSol(*kp, kz);
-        }
-    }
-    VectorType m_r, m_r0, m_p, m_q, m_t, m_v, m_z;
 };
 
 // ============================================================================ FCG
-// src/solvers/krylov/fcg.cpp:232-318 / :321-420 (flexible CG).  InitResidual's verdict is not consulted.
+// Flexible conjugate gradients (src/solvers/krylov/fcg.cpp:232-420).  One routine for both forms: without a
+// preconditioner z IS r.  InitResidual's verdict is not consulted (as there).
 template <class OperatorType, class VectorType, typename ValueType>
-class FCG : public IterativeLinearSolver<OperatorType, VectorType, ValueType>
+class FCG : public KrylovDriver<OperatorType, VectorType, ValueType>
 {
 public:
     virtual ~FCG()
     {
         this->Clear();
     }
-    virtual void Print(void) const
-    {
-        say((this->m_precond ? "Flexible PCG solver, with preconditioner" : "Flexible CG (non-precond) solver"));
-    }
-    virtual void Build(void)
-    {
-        if(this->m_build)
-            this->Clear();
-        RAMD_EXPECT(this->m_op != nullptr && this->m_op->GetM() == this->m_op->GetN() && this->m_op->GetM() > 0);
-        this->m_build = true;
-        if(this->m_precond != NULL)
-        {
-            this->m_precond->SetOperator(*this->m_op);
-            this->m_precond->Build();
-            this->m_z.CloneBackend(*this->m_op);
-            this->m_z.Allocate("z", this->m_op->GetM());
-        }
-        VectorType* all[] = {&this->m_r, &this->m_w, &this->m_p, &this->m_q};
-        for(VectorType* vec : all)
-        {
-            vec->CloneBackend(*this->m_op);
-            vec->Allocate("fcg", this->m_op->GetM());
-        }
-    }
-    virtual void Clear(void)
-    {
-        if(this->m_build)
-        {
-            if(this->m_precond != NULL)
-            {
-                this->m_precond->Clear();
-                this->m_precond = NULL;
-            }
-            VectorType* all[] = {&this->m_r, &this->m_w, &this->m_p, &this->m_q, &this->m_z};
-            for(VectorType* vec : all)
-                vec->Clear();
-            this->m_iter_ctrl.Clear();
-            this->m_build = false;
-        }
-    }
 
 protected:
-    virtual void doPrintStart(void) const
+    virtual const char* doLabel(bool precond) const
     {
-        say((this->m_precond ? "Flexible PCG solver starts, with preconditioner:" : "Flexible CG (non-precond) linear solver starts"));
+        return precond ? "Flexible PCG" : "Flexible CG (non-precond)";
     }
-    virtual void doPrintEnd(void) const
+    virtual int doWorkVectors(bool precond) const
     {
-        say((this->m_precond ? "Flexible PCG ends" : "Flexible CG (non-precond) ends"));
+        return precond ? 5 : 4;
     }
-    virtual void doSolveNonPrecond(const VectorType& rhs, VectorType* x)
+    virtual void doIterate(const VectorType& rhs, VectorType* x, bool precond)
     {
-        this->doSolve(rhs, x, false);
-    }
-    virtual void doSolvePrecond(const VectorType& rhs, VectorType* x)
-    {
-        this->doSolve(rhs, x, true);
-    }
-
-private:
-    void doSolve(const VectorType& rhs, VectorType* x, bool precond)
-    {
-        const OperatorType* op = this->m_op;
-        VectorType *kr = &this->m_r, *kw = &this->m_w, *kp = &this->m_p, *kq = &this->m_q;
-        VectorType* kz = precond ? &this->m_z : kr; // without a preconditioner kz IS kr
-        ValueType   alpha, beta, rho, gamma, gamma_rho;
-        op->Apply(*x, kr);
-        kr->ScaleAdd(num<ValueType>(-1), rhs);
-        ValueType res = this->doNorm(*kr);
-        this->m_iter_ctrl.InitResidual(std::abs(res));
-        if(precond)
-            this->m_precond->SolveZeroSol(*kr, kz);
-        op->Apply(*kz, kw);
-        alpha = kz->Dot(*kr);
-        beta  = kz->Dot(*kw);
-        kp->CopyFrom(*kz);
-        kq->CopyFrom(*kw);
-        rho = beta;
-        x->AddScale(*kp, alpha / rho);
-        kr->AddScale(*kq, -alpha / rho);
-        res = this->doNorm(*kr);
-        while(!this->m_iter_ctrl.CheckResidual(std::abs(res), this->m_index))
-        {
+        typedef typename KrylovDriver<OperatorType, VectorType, ValueType>::Engine Engine;
+        enum { sRZ, sZW, sZQ, sRho, sCoef, sT, sRes, sCount }; // <z,r>, <z,w>, <z,q>, rho, a coefficient, scratch, ||r||
+        VectorType *r = this->W(0), *w = this->W(1), *p = this->W(2), *q = this->W(3), *z = precond ? this->W(4) : r;
+        Engine K(*this->m_op, sCount);
+        auto   precondition = [&]() {
             if(precond)
-                this->m_precond->SolveZeroSol(*kr, kz);
-            op->Apply(*kz, kw);
-            beta      = kz->Dot(*kw);
-            gamma     = kz->Dot(*kq);
-            gamma_rho = -gamma / rho;
-            kp->ScaleAdd(gamma_rho, *kz);
-            kq->ScaleAdd(gamma_rho, *kw);
-            rho   = beta + gamma * gamma_rho;
-            alpha = kz->Dot(*kr) / rho;
-            x->AddScale(*kp, alpha);
-            kr->AddScale(*kq, -alpha);
-            res = this->doNorm(*kr);
+                this->m_precond->SolveZeroSol(*r, z);
+        };
+        this->doDefect(rhs, *x, r);
+        this->m_iter_ctrl.InitResidual(this->doResidual(K, sRes, *r));
+        // first step: p = z, q = A z, rho = <z, w>, x += (<z,r> / rho) p
+        precondition();
+        this->m_op->Apply(*z, w);
+        K.Dot(sRZ, *z, *r);
+        K.Dot(sZW, *z, *w);
+        p->CopyFrom(*z);
+        q->CopyFrom(*w);
+        K.Mov(sRho, sZW);
+        K.Div(sCoef, sRZ, sRho);
+        K.Axpy(x, sCoef, +1.0, *p);
+        K.Axpy(r, sCoef, -1.0, *q);
+        while(!this->m_iter_ctrl.CheckResidual(this->doResidual(K, sRes, *r), this->m_index))
+        {
+            precondition();
+            this->m_op->Apply(*z, w);
+            K.Dot(sZW, *z, *w);
+            K.Dot(sZQ, *z, *q);
+            // gamma_rho = -<z,q> / rho ; p = gamma_rho p + z ; q = gamma_rho q + w ; rho = <z,w> + <z,q> gamma_rho
+            K.Neg(sT, sZQ);
+            K.Div(sCoef, sT, sRho);
+            K.Xpay(p, sCoef, +1.0, *z);
+            K.Xpay(q, sCoef, +1.0, *w);
+            K.Mul(sT, sZQ, sCoef);
+            K.Add(sRho, sZW, sT);
+            K.Dot(sRZ, *z, *r);
+            K.Div(sCoef, sRZ, sRho);
+            K.Axpy(x, sCoef, +1.0, *p);
+            K.Axpy(r, sCoef, -1.0, *q);
         }
     }
-    VectorType m_r, m_w, m_z, m_p, m_q;
 };
 
 // ============================================================================ CR
-// src/solvers/krylov/cr.cpp:240-318 / :321-430 (conjugate residual; the preconditioned variant tests
-// convergence on t, the unpreconditioned residual)
+// Conjugate residuals (src/solvers/krylov/cr.cpp:240-446).  The preconditioned form carries two residuals: r (the
+// preconditioned one the recurrence runs on) and t (the plain one the stopping rule sees); without a preconditioner they
+// are one vector and z is q.
 template <class OperatorType, class VectorType, typename ValueType>
-class CR : public IterativeLinearSolver<OperatorType, VectorType, ValueType>
+class CR : public KrylovDriver<OperatorType, VectorType, ValueType>
 {
 public:
     virtual ~CR()
     {
         this->Clear();
     }
-    virtual void Print(void) const
-    {
-        say((this->m_precond ? "PCR solver, with preconditioner" : "CR (non-precond) solver"));
-    }
-    virtual void Build(void)
-    {
-        if(this->m_build)
-            this->Clear();
-        RAMD_EXPECT(this->m_op != nullptr && this->m_op->GetM() == this->m_op->GetN() && this->m_op->GetM() > 0);
-        this->m_build = true;
-        if(this->m_precond != NULL)
-        {
-            this->m_precond->SetOperator(*this->m_op);
-            this->m_precond->Build();
-            this->m_z.CloneBackend(*this->m_op);
-            this->m_z.Allocate("z", this->m_op->GetM());
-            this->m_t.CloneBackend(*this->m_op);
-            this->m_t.Allocate("t", this->m_op->GetM());
-        }
-        VectorType* all[] = {&this->m_r, &this->m_p, &this->m_q, &this->m_v};
-        for(VectorType* vec : all)
-        {
-            vec->CloneBackend(*this->m_op);
-            vec->Allocate("cr", this->m_op->GetM());
-        }
-    }
-    virtual void Clear(void)
-    {
-        if(this->m_build)
-        {
-            if(this->m_precond != NULL)
-            {
-                this->m_precond->Clear();
-                this->m_precond = NULL;
-            }
-            VectorType* all[] = {&this->m_r, &this->m_p, &this->m_q, &this->m_v, &this->m_z, &this->m_t};
-            for(VectorType* vec : all)
-                vec->Clear();
-            this->m_iter_ctrl.Clear();
-            this->m_build = false;
-        }
-    }
 
 protected:
-    virtual void doPrintStart(void) const
+    virtual const char* doLabel(bool precond) const
     {
-        say((this->m_precond ? "PCR solver starts, with preconditioner:" : "CR (non-precond) linear solver starts"));
+        return precond ? "PCR" : "CR (non-precond)";
     }
-    virtual void doPrintEnd(void) const
+    virtual int doWorkVectors(bool precond) const
     {
-        say((this->m_precond ? "PCR ends" : "CR (non-precond) ends"));
+        return precond ? 6 : 4;
     }
-    virtual void doSolveNonPrecond(const VectorType& rhs, VectorType* x)
+    virtual void doIterate(const VectorType& rhs, VectorType* x, bool precond)
     {
-        const OperatorType* op = this->m_op;
-        VectorType *kr = &this->m_r, *kp = &this->m_p, *kq = &this->m_q, *kv = &this->m_v;
-        ValueType   alpha, beta, rho, rho_old;
-        op->Apply(*x, kr);
-        kr->ScaleAdd(num<ValueType>(-1), rhs);
-        kp->CopyFrom(*kr);
-        ValueType res_norm = this->doNorm(*kr);
-        if(this->m_iter_ctrl.InitResidual(std::abs(res_norm)) == false)
-            return;
-        op->Apply(*kr, kv);
-        rho = kr->DotNonConj(*kv);
-        op->Apply(*kp, kq);
-        alpha = rho / kq->DotNonConj(*kq);
-        x->AddScale(*kp, alpha);
-        kr->AddScale(*kq, -alpha);
-        res_norm = this->doNorm(*kr);
-        while(!this->m_iter_ctrl.CheckResidual(std::abs(res_norm), this->m_index))
+        typedef typename KrylovDriver<OperatorType, VectorType, ValueType>::Engine Engine;
+        enum { sRho, sRhoOld, sDen, sAlpha, sBeta, sRes, sCount };
+        VectorType *r = this->W(0), *p = this->W(1), *q = this->W(2), *v = this->W(3);
+        VectorType *z = precond ? this->W(4) : q, *t = precond ? this->W(5) : r;
+        Engine K(*this->m_op, sCount);
+        if(precond)
         {
-            rho_old = rho;
-            op->Apply(*kr, kv);
-            rho  = kr->DotNonConj(*kv);
-            beta = rho / rho_old;
-            kp->ScaleAdd(beta, *kr);
-            kq->ScaleAdd(beta, *kv);
-            alpha = rho / kq->DotNonConj(*kq);
-            x->AddScale(*kp, alpha);
-            kr->AddScale(*kq, -alpha);
-            res_norm = this->doNorm(*kr);
+            this->doDefect(rhs, *x, z);
+            this->m_precond->SolveZeroSol(*z, r);
+            t->CopyFrom(*z);
+        }
+        else
+            this->doDefect(rhs, *x, r);
+        p->CopyFrom(*r);
+        if(this->m_iter_ctrl.InitResidual(this->doResidual(K, sRes, *t)) == false)
+            return;
+        // x += alpha p with alpha = <r, A r> / <A p, M^-1 A p>; the residuals follow
+        auto advance = [&]() {
+            if(precond)
+                this->m_precond->SolveZeroSol(*q, z);
+            K.Dot(sDen, *q, *z);
+            K.Div(sAlpha, sRho, sDen);
+            K.Axpy(x, sAlpha, +1.0, *p);
+            K.Axpy(r, sAlpha, -1.0, *z);
+            if(precond)
+                K.Axpy(t, sAlpha, -1.0, *q);
+        };
+        this->m_op->Apply(*r, v);
+        K.Dot(sRho, *r, *v);
+        this->m_op->Apply(*p, q);
+        advance();
+        while(!this->m_iter_ctrl.CheckResidual(this->doResidual(K, sRes, *t), this->m_index))
+        {
+            K.Mov(sRhoOld, sRho);
+            this->m_op->Apply(*r, v);
+            K.Dot(sRho, *r, *v);
+            K.Div(sBeta, sRho, sRhoOld);
+            K.Xpay(p, sBeta, +1.0, *r);
+            K.Xpay(q, sBeta, +1.0, *v); // A p by recurrence: no second product
+            advance();
         }
     }
-    virtual void doSolvePrecond(const VectorType& rhs, VectorType* x)
-    {
-        const OperatorType* op = this->m_op;
-        VectorType *kr = &this->m_r, *kz = &this->m_z, *kp = &this->m_p, *kq = &this->m_q, *kv = &this->m_v, *kt = &this->m_t;
-        ValueType   alpha, beta, rho, rho_old;
-        op->Apply(*x, kz);
-        kz->ScaleAdd(num<ValueType>(-1), rhs);
-        this->m_precond->SolveZeroSol(*kz, kr);
-        kp->CopyFrom(*kr);
-        kt->CopyFrom(*kz);
-        ValueType res_norm = this->doNorm(*kt);
-        if(this->m_iter_ctrl.InitResidual(std::abs(res_norm)) == false)
-            return;
-        op->Apply(*kr, kv);
-        rho = kr->DotNonConj(*kv);
-        op->Apply(*kp, kq);
-        this->m_precond->SolveZeroSol(*kq, kz);
-        alpha = rho / kq->DotNonConj(*kz);
-        x->AddScale(*kp, alpha);
-        kr->AddScale(*kz, -alpha);
-        kt->AddScale(*kq, -alpha);
-        res_norm = this->doNorm(*kt);
-        while(!this->m_iter_ctrl.CheckResidual(std::abs(res_norm), this->m_index))
-        {
-            rho_old = rho;
-            op->Apply(*kr, kv);
-            rho  = kr->DotNonConj(*kv);
-            beta = rho / rho_old;
-            kp->ScaleAdd(beta, *kr);
-            kq->ScaleAdd(beta, *kv);
-            this->m_precond->SolveZeroSol(*kq, kz);
-            alpha = rho / kq->DotNonConj(*kz);
-            x->AddScale(*kp, alpha);
-            kr->AddScale(*kz, -alpha);
-            kt->AddScale(*kq, -alpha);
-            res_norm = this->doNorm(*kt);
-        }
-    }
-
-private:
-    VectorType m_r, m_z, m_p, m_q, m_v, m_t;
 };
 
 // ============================================================================ BiCGStab(l)
-// src/solvers/krylov/bicgstabl.cpp:292-496 / :499-695.  l = 2 by default (SetOrder).  The
-// preconditioned variant applies M^-1 after every operator product (left preconditioning) and tests
-// the preconditioned residual.  One "iteration" is one outer sweep (l BiCG steps + the MR part).
+// src/solvers/krylov/bicgstabl.cpp:292-695.  l = 2 by default (SetOrder).  The preconditioned variant applies M^-1 after
+// every operator product (left preconditioning) and tests the preconditioned residual.  One "iteration" is one outer sweep
+// (l BiCG steps + the minimal-residual part); the l x l recurrences of the MR part (tau, sigma, gamma, gamma', gamma'') run
+// as scalar programs on the device, the two breakdown tests (rho = 0, <r0, A u> = 0) raise the engine's flag.
 template <class OperatorType, class VectorType, typename ValueType>
-class BiCGStabl : public IterativeLinearSolver<OperatorType, VectorType, ValueType>
+class BiCGStabl : public KrylovDriver<OperatorType, VectorType, ValueType>
 {
 public:
+    enum { kMaxOrder = 7 }; // (l^2 + 4 l + 8 scalars have to fit one bank of the recurrence engine)
     BiCGStabl()
         : m_l(2)
-        , m_r(NULL)
-        , m_u(NULL)
     {
     }
     virtual ~BiCGStabl()
     {
         this->Clear();
     }
-    virtual void Print(void) const
-    {
-        say("BiCGStab(", this->m_l, ") solver", (this->m_precond ? ", with preconditioner" : " (non-precond)"));
-    }
     virtual void SetOrder(int l)
     {
         RAMD_EXPECT(l > 0 && !this->m_build);
+        if(l > kMaxOrder)
+        {
+            say("BiCGStab(l): orders above ", (int)kMaxOrder, " are not supported");
+            RAMD_DIE();
+        }
         this->m_l = l;
-    }
-    virtual void Build(void)
-    {
-        if(this->m_build)
-            this->Clear();
-        RAMD_EXPECT(this->m_op != nullptr && this->m_op->GetM() == this->m_op->GetN() && this->m_op->GetM() > 0);
-        this->m_build = true;
-        if(this->m_precond != NULL)
-        {
-            this->m_precond->SetOperator(*this->m_op);
-            this->m_precond->Build();
-            this->m_z.CloneBackend(*this->m_op);
-            this->m_z.Allocate("z", this->m_op->GetM());
-        }
-        this->m_r0.CloneBackend(*this->m_op);
-        this->m_r0.Allocate("r0", this->m_op->GetM());
-        const int l = this->m_l;
-        this->m_r    = new VectorType*[l + 1];
-        this->m_u    = new VectorType*[l + 1];
-        for(int i = 0; i < l + 1; ++i)
-        {
-            this->m_r[i] = new VectorType;
-            this->m_r[i]->CloneBackend(*this->m_op);
-            this->m_r[i]->Allocate("r", this->m_op->GetM());
-            this->m_u[i] = new VectorType;
-            this->m_u[i]->CloneBackend(*this->m_op);
-            this->m_u[i]->Allocate("u", this->m_op->GetM());
-        }
-        this->m_gamma0.assign((size_t)l, ValueType(0));
-        this->m_gamma1.assign((size_t)l, ValueType(0));
-        this->m_gamma2.assign((size_t)l, ValueType(0));
-        this->m_sigma.assign((size_t)l, ValueType(0));
-        this->m_tau.assign((size_t)l * l, ValueType(0));
-    }
-    virtual void Clear(void)
-    {
-        if(this->m_build)
-        {
-            this->m_r0.Clear();
-            for(int i = 0; i < this->m_l + 1; ++i)
-            {
-                delete this->m_r[i];
-                delete this->m_u[i];
-            }
-            delete[] this->m_r;
-            delete[] this->m_u;
-            this->m_r = this->m_u = NULL;
-            if(this->m_precond != NULL)
-            {
-                this->m_precond->Clear();
-                this->m_precond = NULL;
-                this->m_z.Clear();
-            }
-            this->m_iter_ctrl.Clear();
-            this->m_build = false;
-        }
     }
 
 protected:
-    virtual void doPrintStart(void) const
+    virtual const char* doLabel(bool precond) const
     {
-        say("BiCGStab(", this->m_l, ") ", (this->m_precond ? "" : "(non-precond) "), "linear solver starts");
+        return precond ? "BiCGStab(l)" : "BiCGStab(l) (non-precond)";
     }
-    virtual void doPrintEnd(void) const
+    virtual int doWorkVectors(bool precond) const
     {
-        say("BiCGStab(", this->m_l, ") ends");
+        return 2 * (this->m_l + 1) + 1 + (precond ? 1 : 0); // r_0..r_l, u_0..u_l, the shadow residual, the product before M^-1
     }
-    virtual void doSolveNonPrecond(const VectorType& rhs, VectorType* x)
+    virtual void doIterate(const VectorType& rhs, VectorType* x, bool precond)
     {
-        this->doSolve(rhs, x, false);
-    }
-    virtual void doSolvePrecond(const VectorType& rhs, VectorType* x)
-    {
-        this->doSolve(rhs, x, true);
-    }
-
-private:
-    // ky = A in  (followed by M^-1 when preconditioned)
-    void doApplyPrec(const VectorType& in, VectorType* out, bool precond)
-    {
-        if(precond)
-        {
-            this->m_op->Apply(in, &this->m_z);
-            this->m_precond->SolveZeroSol(this->m_z, out);
-        }
-        else
-            this->m_op->Apply(in, out);
-    }
-    void doSolve(const VectorType& rhs, VectorType* x, bool precond)
-    {
-        VectorType*  r0 = &this->m_r0;
-        VectorType** kr  = this->m_r;
-        VectorType** ku  = this->m_u;
-        const int    l  = this->m_l;
-        bool         converged = false;
-        ValueType    alpha = num<ValueType>(0), beta = num<ValueType>(0);
-        ValueType    omega = num<ValueType>(1), rho_old = num<ValueType>(-1), rho;
-        ValueType *  gamma0 = this->m_gamma0.data(), *gamma1 = this->m_gamma1.data();
-        ValueType *  gamma2 = this->m_gamma2.data(), *sigma = this->m_sigma.data(), *tau = this->m_tau.data();
-        const ValueType zero = num<ValueType>(0);
-        if(precond)
-        {
-            this->m_op->Apply(*x, &this->m_z);
-            this->m_z.ScaleAdd(num<ValueType>(-1), rhs);
-            this->m_precond->SolveZeroSol(this->m_z, r0);
-        }
-        else
-        {
-            this->m_op->Apply(*x, r0);
-            r0->ScaleAdd(num<ValueType>(-1), rhs);
-        }
-        ValueType res = this->doNorm(*r0);
-        this->m_iter_ctrl.InitResidual(std::abs(res));
-        kr[0]->CopyFrom(*r0);
-        ku[0]->Zeros();
-        while(true)
-        {
-            rho_old *= -omega;
-            for(int j = 0; j < l; ++j) // BiCG part
+        typedef typename KrylovDriver<OperatorType, VectorType, ValueType>::Engine Engine;
+        const int l = this->m_l;
+        // vectors
+        auto R = [&](int i) { return this->W(i); };
+        auto U = [&](int i) { return this->W(l + 1 + i); };
+        VectorType *shadow = this->W(2 * l + 2), *prod = precond ? this->W(2 * l + 3) : NULL;
+        // scalars
+        enum { sAlpha, sBeta, sOmega, sRho, sRhoOld, sT, sRes, sFirst };
+        const int sSigma = sFirst, sG0 = sSigma + l, sG1 = sG0 + l, sG2 = sG1 + l, sTau = sG2 + l, sCount = sTau + l * l;
+        Engine    K(*this->m_op, sCount);
+        auto      tau = [&](int i, int j) { return sTau + i * l + j; };
+        // y = A in, followed by M^-1 when preconditioned
+        auto product = [&](const VectorType& in, VectorType* out) {
+            if(precond)
             {
-                rho = r0->Dot(*kr[j]);
-                if(rho == zero)
-                {
-                    say("BiCGStab(l) rho == 0 !!!");
-                    converged = true;
-                    break;
-                }
-                beta = alpha * rho / rho_old;
-                for(int i = 0; i <= j; ++i)
-                    ku[i]->ScaleAdd(-beta, *kr[i]);
-                this->doApplyPrec(*ku[j], ku[j + 1], precond);
-                rho_old = r0->Dot(*ku[j + 1]);
-                if(rho_old == zero)
-                {
-                    say("BiCGStab(l) sigma == 0 !!!");
-                    converged = true;
-                    break;
-                }
-                alpha   = rho / rho_old;
-                rho_old = rho;
-                for(int i = 0; i <= j; ++i)
-                    kr[i]->AddScale(*ku[i + 1], -alpha);
-                this->doApplyPrec(*kr[j], kr[j + 1], precond);
-                x->AddScale(*ku[0], alpha);
-                res = this->doNorm(*kr[0]);
-                if(this->m_iter_ctrl.CheckResidualNoCount(std::abs(res)))
-                {
-                    converged = true;
-                    break;
-                }
+                this->m_op->Apply(in, prod);
+                this->m_precond->SolveZeroSol(*prod, out);
             }
-            if(converged)
+            else
+                this->m_op->Apply(in, out);
+        };
+        if(precond)
+        {
+            this->doDefect(rhs, *x, prod);
+            this->m_precond->SolveZeroSol(*prod, shadow);
+        }
+        else
+            this->doDefect(rhs, *x, shadow);
+        this->m_iter_ctrl.InitResidual(this->doResidual(K, sRes, *shadow));
+        R(0)->CopyFrom(*shadow);
+        U(0)->Zeros();
+        K.Set(sAlpha, 0.0);
+        K.Set(sOmega, 1.0);
+        K.Set(sRhoOld, -1.0);
+        bool stop = false;
+        while(!stop)
+        {
+            K.Neg(sT, sOmega);
+            K.Mul(sRhoOld, sRhoOld, sT); // rho_old *= -omega
+            for(int j = 0; j < l && !stop; ++j) // BiCG part
+            {
+                K.Dot(sRho, *shadow, *R(j));
+                K.FlagIfZero(sRho);
+                K.Mul(sT, sAlpha, sRho);
+                K.Div(sBeta, sT, sRhoOld); // beta = alpha rho / rho_old
+                for(int i = 0; i <= j; ++i)
+                    K.Xpay(U(i), sBeta, -1.0, *R(i)); // u_i = -beta u_i + r_i
+                product(*U(j), U(j + 1));
+                K.Dot(sRhoOld, *shadow, *U(j + 1));
+                K.FlagIfZero(sRhoOld);
+                K.Div(sAlpha, sRho, sRhoOld);
+                K.Mov(sRhoOld, sRho);
+                for(int i = 0; i <= j; ++i)
+                    K.Axpy(R(i), sAlpha, -1.0, *U(i + 1));
+                product(*R(j), R(j + 1));
+                K.Axpy(x, sAlpha, +1.0, *U(0));
+                bool         broke = false;
+                const double res   = this->doResidual(K, sRes, *R(0), &broke);
+                if(broke)
+                {
+                    say("BiCGStab(l): breakdown (rho = 0 or <r0, A u> = 0)");
+                    stop = true;
+                }
+                else if(this->m_iter_ctrl.CheckResidualNoCount(res))
+                    stop = true;
+            }
+            if(stop)
                 break;
-            for(int j = 0; j < l; ++j) // modified Gram-Schmidt (MR part)
+            for(int j = 0; j < l; ++j) // minimal-residual part: modified Gram-Schmidt on r_1 .. r_l
             {
                 for(int i = 0; i < j; ++i)
                 {
-                    tau[i * l + j] = kr[j + 1]->Dot(*kr[i + 1]) / sigma[i];
-                    kr[j + 1]->AddScale(*kr[i + 1], -tau[i * l + j]);
+                    K.Dot(sT, *R(j + 1), *R(i + 1));
+                    K.Div(tau(i, j), sT, sSigma + i);
+                    K.Axpy(R(j + 1), tau(i, j), -1.0, *R(i + 1));
                 }
-                sigma[j]  = kr[j + 1]->Dot(*kr[j + 1]);
-                gamma1[j] = kr[0]->Dot(*kr[j + 1]) / sigma[j];
+                K.Dot(sSigma + j, *R(j + 1), *R(j + 1));
+                K.Dot(sT, *R(0), *R(j + 1));
+                K.Div(sG1 + j, sT, sSigma + j);
             }
-            gamma0[l - 1] = gamma1[l - 1];
-            omega         = gamma1[l - 1];
+            K.Mov(sG0 + l - 1, sG1 + l - 1);
+            K.Mov(sOmega, sG1 + l - 1);
             for(int j = l - 2; j >= 0; --j)
             {
-                gamma0[j] = gamma1[j];
+                K.Mov(sG0 + j, sG1 + j);
                 for(int i = j + 1; i < l; ++i)
-                    gamma0[j] -= tau[j * l + i] * gamma0[i];
+                {
+                    K.Mul(sT, tau(j, i), sG0 + i);
+                    K.Sub(sG0 + j, sG0 + j, sT);
+                }
             }
             for(int j = 0; j < l - 1; ++j)
             {
-                gamma2[j] = gamma0[j + 1];
+                K.Mov(sG2 + j, sG0 + j + 1);
                 for(int i = j + 1; i < l - 1; ++i)
-                    gamma2[j] += tau[j * l + i] * gamma0[i + 1];
+                {
+                    K.Mul(sT, tau(j, i), sG0 + i + 1);
+                    K.Add(sG2 + j, sG2 + j, sT);
+                }
             }
-            x->AddScale(*kr[0], gamma0[0]);
-            kr[0]->AddScale(*kr[l], -gamma1[l - 1]);
-            ku[0]->AddScale(*ku[l], -gamma0[l - 1]);
+            K.Axpy(x, sG0, +1.0, *R(0));
+            K.Axpy(R(0), sG1 + l - 1, -1.0, *R(l));
+            K.Axpy(U(0), sG0 + l - 1, -1.0, *U(l));
             for(int j = 1; j < l; ++j)
             {
-                ku[0]->AddScale(*ku[j], -gamma0[j - 1]);
-                x->AddScale(*kr[j], gamma2[j - 1]);
-                kr[0]->AddScale(*kr[j], -gamma1[j - 1]);
+                K.Axpy(U(0), sG0 + j - 1, -1.0, *U(j));
+                K.Axpy(x, sG2 + j - 1, +1.0, *R(j));
+                K.Axpy(R(0), sG1 + j - 1, -1.0, *R(j));
             }
-            res = this->doNorm(*kr[0]);
-            if(this->m_iter_ctrl.CheckResidual(std::abs(res), this->m_index))
+            if(this->m_iter_ctrl.CheckResidual(this->doResidual(K, sRes, *R(0)), this->m_index))
                 break;
         }
     }
-    int                    m_l;
-    VectorType             m_r0, m_z;
-    VectorType**           m_r;
-    VectorType**           m_u;
-    std::vector<ValueType> m_gamma0, m_gamma1, m_gamma2, m_sigma, m_tau;
+    int m_l;
 };
 
 // ============================================================================ QMRCGStab
-// src/solvers/krylov/qmrcgstab.cpp:262-460 / :463-690.  The iteration control sees the bound
-// sqrt(#iter+1)*|tau|; after the loop the TRUE residual is computed and checked once more (one more
-// counted iteration).  p is only zero-filled by Build(), as in the reference.
+// src/solvers/krylov/qmrcgstab.cpp:262-690.  Two half steps per iteration, each followed by a quasi-minimisation
+// (theta, c, tau, eta); the stopping rule sees the bound sqrt(k + 1) |tau|, the true residual is measured once at the end.
+// All of theta / c / tau / eta live on the device; the host reads tau (and the breakdown flag) once per iteration.
 template <class OperatorType, class VectorType, typename ValueType>
-class QMRCGStab : public IterativeLinearSolver<OperatorType, VectorType, ValueType>
+class QMRCGStab : public KrylovDriver<OperatorType, VectorType, ValueType>
 {
 public:
     virtual ~QMRCGStab()
     {
         this->Clear();
     }
-    virtual void Print(void) const
-    {
-        say("QMRCGStab solver", (this->m_precond ? ", with preconditioner" : " (non-precond)"));
-    }
-    virtual void Build(void)
-    {
-        if(this->m_build)
-            this->Clear();
-        RAMD_EXPECT(this->m_op != nullptr && this->m_op->GetM() == this->m_op->GetN() && this->m_op->GetM() > 0);
-        this->m_build = true;
-        if(this->m_precond != NULL)
-        {
-            this->m_precond->SetOperator(*this->m_op);
-            this->m_precond->Build();
-            this->m_z.CloneBackend(*this->m_op);
-            this->m_z.Allocate("z", this->m_op->GetM());
-        }
-        VectorType* all[] = {&this->m_r0, &this->m_r, &this->m_p, &this->m_t, &this->m_v, &this->m_d};
-        for(VectorType* vec : all)
-        {
-            vec->CloneBackend(*this->m_op);
-            vec->Allocate("qmrcgstab", this->m_op->GetM());
-        }
-    }
-    virtual void Clear(void)
-    {
-        if(this->m_build)
-        {
-            if(this->m_precond != NULL)
-            {
-                this->m_precond->Clear();
-                this->m_precond = NULL;
-            }
-            VectorType* all[] = {&this->m_r0, &this->m_r, &this->m_p, &this->m_t, &this->m_v, &this->m_d, &this->m_z};
-            for(VectorType* vec : all)
-                vec->Clear();
-            this->m_iter_ctrl.Clear();
-            this->m_build = false;
-        }
-    }
 
 protected:
-    virtual void doPrintStart(void) const
+    virtual const char* doLabel(bool precond) const
     {
-        say("QMRCGStab ", (this->m_precond ? "" : "(non-precond) "), "linear solver starts");
+        return precond ? "QMRCGStab" : "QMRCGStab (non-precond)";
     }
-    virtual void doPrintEnd(void) const
+    virtual int doWorkVectors(bool precond) const
     {
-        say("QMRCGStab ends");
+        return precond ? 7 : 6;
     }
-    virtual void doSolveNonPrecond(const VectorType& rhs, VectorType* x)
+    virtual void doIterate(const VectorType& rhs, VectorType* x, bool precond)
     {
-        this->doSolve(rhs, x, false);
-    }
-    virtual void doSolvePrecond(const VectorType& rhs, VectorType* x)
-    {
-        this->doSolve(rhs, x, true);
-    }
-
-private:
-    void doSolve(const VectorType& rhs, VectorType* x, bool precond)
-    {
-        const OperatorType* op = this->m_op;
-        VectorType *r0 = &this->m_r0, *kr = &this->m_r, *kp = &this->m_p, *kt = &this->m_t, *kv = &this->m_v, *kd = &this->m_d;
-        VectorType* kz = &this->m_z;
-        VectorType* pz = precond ? kz : kp; // what A is applied to in the first half step
-        VectorType* rz = precond ? kz : kr; // ... and in the second
-        const ValueType one = num<ValueType>(1), zero = num<ValueType>(0);
-        ValueType alpha, beta, omega, theta1, theta1sq, theta2, theta2sq, eta1, eta2, tau1, tau2, rho, rho_old, c;
-        op->Apply(*x, r0);
-        r0->ScaleAdd(-one, rhs);
-        kr->CopyFrom(*r0);
-        tau2            = this->doNorm(*r0);
-        double res_norm = std::abs(tau2);
-        this->m_iter_ctrl.InitResidual(res_norm);
-        rho  = r0->Dot(*kr);
-        beta = rho;
-        (void)beta;
-        kp->AddScale(*kr, one);
-        if(precond)
-            this->m_precond->SolveZeroSol(*kp, kz);
-        op->Apply(*pz, kv);
-        rho_old = r0->Dot(*kv);
-        alpha   = rho / rho_old;
-        kr->AddScale(*kv, -alpha);
-        theta1   = this->doNorm(*kr) / tau2;
-        theta1sq = theta1 * theta1;
-        c        = one / std::sqrt(one + theta1sq);
-        tau1     = tau2 * theta1 * c;
-        eta1     = c * c * alpha;
-        kd->CopyFrom(*pz);
-        x->AddScale(*kd, eta1);
-        if(precond)
-            this->m_precond->SolveZeroSol(*kr, kz);
-        op->Apply(*rz, kt);
-        omega = kt->Dot(*kr) / kt->Dot(*kt);
-        kd->ScaleAdd(theta1sq * eta1 / omega, *rz);
-        kr->AddScale(*kt, -omega);
-        theta2   = this->doNorm(*kr) / tau1;
-        theta2sq = theta2 * theta2;
-        c        = one / std::sqrt(one + theta2sq);
-        tau2     = tau1 * theta2 * c;
-        eta2     = c * c * omega;
-        x->AddScale(*kd, eta2);
-        res_norm = std::sqrt(static_cast<double>(this->m_iter_ctrl.GetIterationCount() + 1)) * std::abs(tau2);
+        typedef typename KrylovDriver<OperatorType, VectorType, ValueType>::Engine Engine;
+        enum { sOne, sRho, sRhoOld, sAlpha, sBeta, sOmega, sTheta1Sq, sTheta2Sq, sEta1, sEta2, sTau1, sTau2, sC, sT, sU, sNorm, sCount };
+        VectorType *shadow = this->W(0), *r = this->W(1), *p = this->W(2), *t = this->W(3), *v = this->W(4), *d = this->W(5);
+        VectorType *z  = precond ? this->W(6) : NULL;
+        VectorType *pz = precond ? z : p; // what A is applied to in the first half step
+        VectorType *rz = precond ? z : r; // ... and in the second
+        Engine K(*this->m_op, sCount);
+        K.Set(sOne, 1.0);
+        // ||v|| into a slot, in the norm the solver was told to use
+        auto norm_to = [&](int slot, const VectorType& vec) {
+            if(this->m_res_norm_type == 2)
+                K.Norm(slot, vec);
+            else
+                K.Set(slot, (double)this->doNorm(vec));
+        };
+        // the quasi-minimisation after a half step: theta = ||r|| / tau_in, c = 1 / sqrt(1 + theta^2),
+        // tau_out = tau_in theta c, eta = c c coef.  theta^2 stays in sThetaSq
+        auto minimise = [&](int sThetaSq, int sTauIn, int sTauOut, int sEta, int sCoef) {
+            norm_to(sNorm, *r);
+            K.Div(sT, sNorm, sTauIn); // theta
+            K.Mul(sThetaSq, sT, sT);
+            K.Add(sU, sOne, sThetaSq);
+            K.Sqrt(sU, sU);
+            K.Div(sC, sOne, sU);
+            K.Mul(sU, sTauIn, sT);
+            K.Mul(sTauOut, sU, sC);
+            K.Mul(sU, sC, sC);
+            K.Mul(sEta, sU, sCoef);
+        };
+        // first half: alpha = rho / <r0, A pz>, r -= alpha v;  second half: omega = <t, r> / <t, t>, r -= omega t
+        auto first_half = [&](bool test) {
+            if(precond)
+                this->m_precond->SolveZeroSol(*p, z);
+            this->m_op->Apply(*pz, v);
+            K.Dot(sRhoOld, *shadow, *v);
+            if(test)
+                K.FlagIfZero(sRhoOld);
+            K.Div(sAlpha, sRho, sRhoOld);
+            K.Axpy(r, sAlpha, -1.0, *v);
+            minimise(sTheta1Sq, sTau2, sTau1, sEta1, sAlpha);
+        };
+        auto second_half = [&](bool test) {
+            if(precond)
+                this->m_precond->SolveZeroSol(*r, z);
+            this->m_op->Apply(*rz, t);
+            K.Dot(sU, *t, *t);
+            if(test)
+                K.FlagIfZero(sU);
+            K.Dot(sT, *t, *r);
+            K.Div(sOmega, sT, sU);
+            K.Mul(sT, sTheta1Sq, sEta1);
+            K.Div(sT, sT, sOmega);
+            K.Xpay(d, sT, +1.0, *rz); // d = (theta1^2 eta1 / omega) d + rz
+            K.Axpy(r, sOmega, -1.0, *t);
+            minimise(sTheta2Sq, sTau1, sTau2, sEta2, sOmega);
+            K.Axpy(x, sEta2, +1.0, *d);
+        };
+        auto bound = [&](bool* broke) {
+            const double tau = K.Fetch(sTau2, broke);
+            return std::sqrt(static_cast<double>(this->m_iter_ctrl.GetIterationCount() + 1)) * std::abs(tau);
+        };
+        this->doDefect(rhs, *x, shadow);
+        r->CopyFrom(*shadow);
+        norm_to(sTau2, *shadow);
+        this->m_iter_ctrl.InitResidual(std::abs(K.Fetch(sTau2)));
+        K.Dot(sRho, *shadow, *r);
+        K.AddVec(p, *r);
+        first_half(false);
+        K.Assign(d, *pz);
+        K.Axpy(x, sEta1, +1.0, *d);
+        second_half(false);
+        bool   broke    = false;
+        double res_norm = bound(&broke);
         while(!this->m_iter_ctrl.CheckResidual(res_norm, this->m_index))
         {
-            rho_old = rho;
-            rho     = r0->Dot(*kr);
-            beta    = (rho * alpha) / (rho_old * omega);
-            kp->AddScale(*kv, -omega);
-            kp->Scale(beta);
-            kp->AddScale(*kr, one);
+            K.Mov(sC, sRho); // (sC is free here: the previous rho)
+            K.Dot(sRho, *shadow, *r);
+            K.Mul(sT, sRho, sAlpha);
+            K.Mul(sU, sC, sOmega);
+            K.Div(sBeta, sT, sU); // beta = (rho alpha) / (rho_old omega)
+            K.Axpy(p, sOmega, -1.0, *v);
+            K.Scale(p, sBeta, +1.0);
+            K.AddVec(p, *r);
+            // d = (theta2^2 eta2 / alpha) d + pz needs the new alpha: the first half computes it before d is touched
             if(precond)
-                this->m_precond->SolveZeroSol(*kp, kz);
-            op->Apply(*pz, kv);
-            rho_old = r0->Dot(*kv);
-            if(rho_old == zero)
+                this->m_precond->SolveZeroSol(*p, z);
+            this->m_op->Apply(*pz, v);
+            K.Dot(sRhoOld, *shadow, *v);
+            K.FlagIfZero(sRhoOld);
+            K.Div(sAlpha, sRho, sRhoOld);
+            K.Axpy(r, sAlpha, -1.0, *v);
+            minimise(sTheta1Sq, sTau2, sTau1, sEta1, sAlpha);
+            K.Mul(sT, sTheta2Sq, sEta2);
+            K.Div(sT, sT, sAlpha);
+            K.Xpay(d, sT, +1.0, *pz);
+            K.Axpy(x, sEta1, +1.0, *d);
+            second_half(true);
+            res_norm = bound(&broke);
+            if(broke)
             {
-                say("QMRCGStab break rho_old == 0 !!!");
+                say("QMRCGStab: breakdown (<r0, A p> = 0 or <t, t> = 0)");
                 break;
             }
-            alpha = rho / rho_old;
-            kr->AddScale(*kv, -alpha);
-            theta1   = this->doNorm(*kr) / tau2;
-            theta1sq = theta1 * theta1;
-            c        = one / std::sqrt(one + theta1sq);
-            tau1     = tau2 * theta1 * c;
-            eta1     = c * c * alpha;
-            kd->ScaleAdd(theta2sq * eta2 / alpha, *pz);
-            x->AddScale(*kd, eta1);
-            if(precond)
-                this->m_precond->SolveZeroSol(*kr, kz);
-            op->Apply(*rz, kt);
-            omega = kt->Dot(*kt);
-            if(omega == zero)
-            {
-                say("QMRCGStab omega == 0 !!!");
-                break;
-            }
-            omega = kt->Dot(*kr) / omega;
-            kd->ScaleAdd(theta1sq * eta1 / omega, *rz);
-            kr->AddScale(*kt, -omega);
-            theta2   = this->doNorm(*kr) / tau1;
-            theta2sq = theta2 * theta2;
-            c        = one / std::sqrt(one + theta2sq);
-            tau2     = tau1 * theta2 * c;
-            eta2     = c * c * omega;
-            x->AddScale(*kd, eta2);
-            res_norm = std::sqrt(static_cast<double>(this->m_iter_ctrl.GetIterationCount() + 1)) * std::abs(tau2);
         }
-        op->Apply(*x, r0);
-        r0->ScaleAdd(-one, rhs);
-        this->m_iter_ctrl.CheckResidual(std::abs(this->doNorm(*r0)));
+        this->doDefect(rhs, *x, shadow);
+        this->m_iter_ctrl.CheckResidual(std::abs((double)this->doNorm(*shadow)));
     }
-    VectorType m_r0, m_r, m_p, m_t, m_v, m_d, m_z;
 };
 
 // ============================================================================ IDR(s)
-// src/solvers/krylov/idr.cpp: Build :127-185 (shadow space: s random-normal vectors, seed (i+1)*m_seed,
-// made orthonormal by modified Gram-Schmidt), doSolveNonPrecond :335-520, doSolvePrecond :523-730.
-// The default seed is time(NULL) as in the reference: call SetRandomSeed for reproducible runs.
+// src/solvers/krylov/idr.cpp: Build :127-185 (shadow space: s random-normal vectors, seed (i+1)*m_seed, made orthonormal
+// by modified Gram-Schmidt), the iteration :335-730.  The default seed is time(NULL) as in the reference: call
+// SetRandomSeed for reproducible runs.  The s x s matrix M = P^T G, the right-hand side f = P^T r and the coefficients c of
+// the small triangular systems live on the device (M column-major: the part of a column below the diagonal is ONE
+// multi-dot pass over G_k); a zero / NaN / infinite pivot or relaxation -- fatal in the reference -- raises the engine's
+// flag and ends the run with the same message at the next read.
 template <class OperatorType, class VectorType, typename ValueType>
-class IDR : public IterativeLinearSolver<OperatorType, VectorType, ValueType>
+class IDR : public KrylovDriver<OperatorType, VectorType, ValueType>
 {
 public:
+    enum { kMaxShadow = 8 };
     IDR()
         : m_s(4)
         , m_seed((unsigned long long)time(NULL))
         , m_kappa(num<ValueType>(0.7f))
-        , m_G(NULL)
-        , m_U(NULL)
-        , m_P(NULL)
     {
     }
     virtual ~IDR()
     {
         this->Clear();
     }
-    virtual void Print(void) const
-    {
-        say("IDR(", this->m_s, ") solver", (this->m_precond ? ", with preconditioner" : " (non-precond)"));
-    }
     void SetShadowSpace(int ks)
     {
         RAMD_EXPECT(!this->m_build && ks > 0);
+        if(ks > kMaxShadow)
+        {
+            say("IDR(s): shadow spaces of more than ", (int)kMaxShadow, " vectors are not supported");
+            RAMD_DIE();
+        }
         this->m_s = ks;
     }
     void SetRandomSeed(unsigned long long seed)
@@ -2836,223 +2810,173 @@ public:
         RAMD_EXPECT(!this->m_build && seed > 0ULL);
         this->m_seed = seed;
     }
-    virtual void Build(void)
-    {
-        if(this->m_build)
-            this->Clear();
-        RAMD_EXPECT(this->m_op != nullptr && this->m_op->GetM() == this->m_op->GetN() && this->m_op->GetM() > 0);
-        RAMD_EXPECT((int64_t)this->m_s <= this->m_op->GetM());
-        const int ks = this->m_s;
-        this->m_r.CloneBackend(*this->m_op);
-        this->m_v.CloneBackend(*this->m_op);
-        this->m_r.Allocate("r", this->m_op->GetM());
-        this->m_v.Allocate("v", this->m_op->GetM());
-        this->m_c.assign((size_t)ks, ValueType(0));
-        this->m_f.assign((size_t)ks, ValueType(0));
-        this->m_M.assign((size_t)ks * ks, ValueType(0));
-        this->m_G = new VectorType*[ks];
-        this->m_U = new VectorType*[ks];
-        this->m_P = new VectorType*[ks];
-        for(int i = 0; i < ks; ++i)
-        {
-            this->m_G[i] = new VectorType;
-            this->m_U[i] = new VectorType;
-            this->m_P[i] = new VectorType;
-            this->m_G[i]->CloneBackend(*this->m_op);
-            this->m_U[i]->CloneBackend(*this->m_op);
-            this->m_P[i]->CloneBackend(*this->m_op);
-            this->m_G[i]->Allocate("g", this->m_op->GetM());
-            this->m_U[i]->Allocate("u", this->m_op->GetM());
-            this->m_P[i]->Allocate("P", this->m_op->GetM());
-            this->m_P[i]->SetRandomNormal((unsigned long long)(i + 1) * this->m_seed, 0.0, 1.0);
-        }
-        if(this->m_precond != NULL)
-        {
-            this->m_precond->SetOperator(*this->m_op);
-            this->m_precond->Build();
-            this->m_t.CloneBackend(*this->m_op);
-            this->m_t.Allocate("t", this->m_op->GetM());
-        }
-        for(int k = 0; k < ks; ++k) // orthonormal basis of the shadow space (modified Gram-Schmidt)
-        {
-            this->m_P[k]->Scale(num<ValueType>(1) / this->m_P[k]->Norm());
-            ValueType invdotk = num<ValueType>(1) / this->m_P[k]->Dot(*this->m_P[k]);
-            for(int j = k + 1; j < ks; ++j)
-                this->m_P[j]->AddScale(*this->m_P[k], -this->m_P[j]->Dot(*this->m_P[k]) * invdotk);
-        }
-        this->m_build = true;
-    }
-    virtual void Clear(void)
-    {
-        if(this->m_build)
-        {
-            this->m_r.Clear();
-            this->m_v.Clear();
-            this->m_t.Clear();
-            for(int i = 0; i < this->m_s; ++i)
-            {
-                delete this->m_U[i];
-                delete this->m_G[i];
-                delete this->m_P[i];
-            }
-            delete[] this->m_U;
-            delete[] this->m_G;
-            delete[] this->m_P;
-            this->m_U = this->m_G = this->m_P = NULL;
-            if(this->m_precond != NULL)
-            {
-                this->m_precond->Clear();
-                this->m_precond = NULL;
-            }
-            this->m_iter_ctrl.Clear();
-            this->m_build = false;
-        }
-    }
 
 protected:
-    virtual void doPrintStart(void) const
+    virtual const char* doLabel(bool precond) const
     {
-        say((this->m_precond ? "PIDR(" : "IDR("), this->m_s, (this->m_precond ? ") solver starts, with preconditioner:" : ") (non-precond) linear solver starts"));
+        return precond ? "PIDR(s)" : "IDR(s) (non-precond)";
     }
-    virtual void doPrintEnd(void) const
+    virtual int doWorkVectors(bool precond) const
     {
-        say((this->m_precond ? "PIDR(" : "IDR("), this->m_s, (this->m_precond ? ") ends" : ") (non-precond) ends"));
+        return 2 + 3 * this->m_s + (precond ? 1 : 0); // r, v, then G, U, P, and t where a preconditioner is applied
     }
-    virtual void doSolveNonPrecond(const VectorType& rhs, VectorType* x)
+    VectorType* G(int i) { return this->W(2 + i); }
+    VectorType* U(int i) { return this->W(2 + this->m_s + i); }
+    VectorType* P(int i) { return this->W(2 + 2 * this->m_s + i); }
+    // orthonormal basis of the shadow space
+    virtual void doAfterBuild(void)
     {
-        this->doSolve(rhs, x, false);
+        typedef typename KrylovDriver<OperatorType, VectorType, ValueType>::Engine Engine;
+        RAMD_EXPECT((int64_t)this->m_s <= this->m_op->GetM());
+        const int ks = this->m_s;
+        enum { sOne, sN, sInv, sD, sCount };
+        Engine K(*this->m_op, sCount);
+        K.Set(sOne, 1.0);
+        for(int i = 0; i < ks; ++i)
+            this->P(i)->SetRandomNormal((unsigned long long)(i + 1) * this->m_seed, 0.0, 1.0);
+        for(int k = 0; k < ks; ++k)
+        {
+            K.Norm(sN, *this->P(k));
+            K.Div(sN, sOne, sN);
+            K.Scale(this->P(k), sN, +1.0); // P_k /= ||P_k||  (as a product with the reciprocal)
+            K.Dot(sD, *this->P(k), *this->P(k));
+            K.Div(sInv, sOne, sD);
+            for(int j = k + 1; j < ks; ++j)
+            {
+                K.Dot(sD, *this->P(j), *this->P(k));
+                K.Neg(sD, sD);
+                K.Mul(sD, sD, sInv);
+                K.Axpy(this->P(j), sD, +1.0, *this->P(k)); // P_j -= (<P_j, P_k> / <P_k, P_k>) P_k
+            }
+        }
+        K.Flush();
     }
-    virtual void doSolvePrecond(const VectorType& rhs, VectorType* x)
+    virtual void doIterate(const VectorType& rhs, VectorType* x, bool precond)
     {
-        this->doSolve(rhs, x, true);
-    }
-
-private:
-    int m_mind(int i, int j) const // DENSE_IND(i, j, ks, ks), column-major
-    {
-        return i + j * this->m_s;
-    }
-    void doBreakdown(const char* what) const
-    {
-        say("IDR(s) break down ; ", what);
-        RAMD_DIE();
-    }
-    void doCheckScalar(ValueType val, const char* kz, const char* nan, const char* inf) const
-    {
-        if(val == num<ValueType>(0))
-            this->doBreakdown(kz);
-        if(val != val)
-            this->doBreakdown(nan);
-        if(val == std::numeric_limits<ValueType>::infinity())
-            this->doBreakdown(inf);
-    }
-    void doSolve(const VectorType& rhs, VectorType* x, bool precond)
-    {
-        const OperatorType* op = this->m_op;
-        VectorType *        kr = &this->m_r, *kv = &this->m_v, *kt = &this->m_t;
-        VectorType **       G = this->m_G, **U = this->m_U, **P = this->m_P;
-        const int           ks = this->m_s;
-        const ValueType     zero = num<ValueType>(0), one = num<ValueType>(1), kappa = this->m_kappa;
-        ValueType *         c = this->m_c.data(), *f = this->m_f.data(), *M = this->m_M.data();
-        ValueType           alpha, beta, rho, omega = one;
-        op->Apply(*x, kr);
-        kr->ScaleAdd(-one, rhs);
-        ValueType res_norm = this->doNorm(*kr);
-        if(this->m_iter_ctrl.InitResidual(std::abs(res_norm)) == false)
+        typedef typename KrylovDriver<OperatorType, VectorType, ValueType>::Engine Engine;
+        const int   ks = this->m_s;
+        VectorType *r = this->W(0), *v = this->W(1), *t = precond ? this->W(2 + 3 * ks) : NULL;
+        enum { sOne, sKappa, sOmega, sBeta, sAlpha, sRT, sNT, sRho, sT, sU, sRes, sFirst };
+        const int sF = sFirst, sC = sF + ks, sM = sC + ks, sCount = sM + ks * ks;
+        auto      M = [&](int i, int j) { return sM + j * ks + i; }; // column-major
+        Engine    K(*this->m_op, sCount);
+        K.Set(sOne, 1.0);
+        K.Set(sKappa, (double)this->m_kappa);
+        K.Set(sOmega, 1.0);
+        this->doDefect(rhs, *x, r);
+        double res = this->doResidual(K, sRes, *r);
+        if(this->m_iter_ctrl.InitResidual(res) == false)
             return;
         for(int i = 0; i < ks; ++i)
         {
-            G[i]->Zeros();
-            U[i]->Zeros();
+            this->G(i)->Zeros();
+            this->U(i)->Zeros();
             for(int j = 0; j < ks; ++j)
-                M[this->m_mind(i, j)] = (i == j) ? one : zero;
+                K.Set(M(i, j), i == j ? 1.0 : 0.0);
         }
+        VectorType* shadow[kMaxShadow];
+        for(int i = 0; i < ks; ++i)
+            shadow[i] = this->P(i);
+        auto fatal_if = [&](bool broke) {
+            if(broke)
+            {
+                say("IDR(s) break down ; M(k,k) or the relaxation w is zero, NaN or infinite");
+                RAMD_DIE();
+            }
+        };
         while(true)
         {
-            for(int i = 0; i < ks; ++i) // f = P^T kr
-                f[i] = P[i]->Dot(*kr);
-            for(int k = 0; k < ks; ++k) // loop over the shadow space
+            K.Dots(sF, shadow, ks, *r); // f = P^T r, one pass over r
+            bool done = false;
+            for(int k = 0; k < ks && !done; ++k) // loop over the shadow space
             {
-                kv->CopyFrom(*kr);
                 for(int i = k; i < ks; ++i) // lower triangular system M c = f
                 {
-                    c[i] = f[i];
+                    K.Mov(sC + i, sF + i);
                     for(int j = k; j < i; ++j)
-                        c[i] -= M[this->m_mind(i, j)] * c[j];
-                    c[i] /= M[this->m_mind(i, i)];
-                    kv->AddScale(*G[i], -c[i]);
+                    {
+                        K.Mul(sT, M(i, j), sC + j);
+                        K.Sub(sC + i, sC + i, sT);
+                    }
+                    K.Div(sC + i, sC + i, M(i, i));
                 }
+                v->CopyFrom(*r);
+                for(int i = k; i < ks; ++i)
+                    K.Axpy(v, sC + i, -1.0, *this->G(i));
                 if(precond)
                 {
-                    this->m_precond->SolveZeroSol(*kv, kt);
-                    U[k]->ScaleAddScale(c[k], *kt, omega);
+                    this->m_precond->SolveZeroSol(*v, t);
+                    K.XpbyS(this->U(k), sC + k, +1.0, *t, sOmega, +1.0);
                 }
                 else
-                    U[k]->ScaleAddScale(c[k], *kv, omega);
+                    K.XpbyS(this->U(k), sC + k, +1.0, *v, sOmega, +1.0);
                 for(int i = k + 1; i < ks; ++i)
-                    U[k]->AddScale(*U[i], c[i]);
-                op->Apply(*U[k], G[k]);
+                    K.Axpy(this->U(k), sC + i, +1.0, *this->U(i));
+                this->m_op->Apply(*this->U(k), this->G(k));
                 for(int i = 0; i < k; ++i) // make G_k orthogonal to P
                 {
-                    alpha = P[i]->Dot(*G[k]) / M[this->m_mind(i, i)];
-                    G[k]->AddScale(*G[i], -alpha);
-                    U[k]->AddScale(*U[i], -alpha);
+                    K.Dot(sT, *this->P(i), *this->G(k));
+                    K.Div(sAlpha, sT, M(i, i));
+                    K.Axpy(this->G(k), sAlpha, -1.0, *this->G(i));
+                    K.Axpy(this->U(k), sAlpha, -1.0, *this->U(i));
                 }
-                for(int i = k; i < ks; ++i)
-                    M[this->m_mind(i, k)] = P[i]->Dot(*G[k]);
-                this->doCheckScalar(M[this->m_mind(k, k)], "M(k,k) == 0.0", "M(k,k) == NaN", "M(k,k) == inf");
-                beta = f[k] / M[this->m_mind(k, k)];
-                kr->AddScale(*G[k], -beta);
-                x->AddScale(*U[k], beta);
-                res_norm = this->doNorm(*kr);
-                if(this->m_iter_ctrl.CheckResidualNoCount(std::abs(res_norm)))
-                    break;
+                K.Dots(M(k, k), shadow + k, ks - k, *this->G(k)); // column k of M from the diagonal down
+                K.FlagIfBad(M(k, k));
+                K.Div(sBeta, sF + k, M(k, k));
+                K.Axpy(r, sBeta, -1.0, *this->G(k));
+                K.Axpy(x, sBeta, +1.0, *this->U(k));
                 for(int i = k + 1; i < ks; ++i)
-                    f[i] -= beta * M[this->m_mind(i, k)];
+                {
+                    K.Mul(sT, sBeta, M(i, k));
+                    K.Sub(sF + i, sF + i, sT);
+                }
+                bool broke = false;
+                res        = this->doResidual(K, sRes, *r, &broke);
+                fatal_if(broke);
+                if(this->m_iter_ctrl.CheckResidualNoCount(res))
+                    done = true;
             }
-            if(this->m_iter_ctrl.CheckResidual(std::abs(res_norm), this->m_index))
+            if(this->m_iter_ctrl.CheckResidual(res, this->m_index))
                 break;
-            ValueType rt, nt; // dimension reduction step
+            // dimension reduction step: omega = <t, r> / <t, t>, stretched when t and r are nearly orthogonal
+            VectorType *av = precond ? t : v, *dx = precond ? v : r;
+            if(precond)
+                this->m_precond->SolveZeroSol(*r, v);
+            this->m_op->Apply(*dx, av);
+            K.Dot(sRT, *av, *r);
+            K.Norm(sNT, *av);
+            K.Div(sRT, sRT, sNT);
+            if(this->m_res_norm_type != 2)
+                K.Set(sRes, res);
+            K.Div(sT, sRT, sRes);
+            K.Set(sU, 0.0);
+            K.Sub(sRho, sU, sT);
+            K.MovIfLess(sRho, sU, sT, sT); // rho = |rt / ||r|||
+            K.Div(sOmega, sRT, sNT);
+            K.Div(sT, sKappa, sRho);
+            K.Mul(sT, sOmega, sT);
+            K.MovIfLess(sOmega, sRho, sKappa, sT); // omega *= kappa / rho where rho < kappa
+            K.FlagIfBad(sOmega);
+            // x += omega dx ; r -= omega av  (in the reference's order: for the plain form x first, r is dx there)
             if(precond)
             {
-                this->m_precond->SolveZeroSol(*kr, kv);
-                op->Apply(*kv, kt);
-                rt = kt->Dot(*kr);
-                nt = kt->Norm();
+                K.Axpy(r, sOmega, -1.0, *av);
+                K.Axpy(x, sOmega, +1.0, *dx);
             }
             else
             {
-                op->Apply(*kr, kv);
-                rt = kv->Dot(*kr);
-                nt = kv->Norm();
+                K.Axpy(x, sOmega, +1.0, *dx);
+                K.Axpy(r, sOmega, -1.0, *av);
             }
-            rt /= nt;
-            rho   = std::abs(rt / res_norm);
-            omega = rt / nt;
-            if(rho < kappa)
-                omega *= kappa / rho;
-            this->doCheckScalar(omega, "w == 0.0", "w == NaN", "w == inf");
-            if(precond)
-            {
-                kr->AddScale(*kt, -omega);
-                x->AddScale(*kv, omega);
-            }
+            if(this->m_res_norm_type == 2)
+                K.Norm(sRes, *r); // (read with the next residual: nothing waits for it here)
             else
-            {
-                x->AddScale(*kr, omega);
-                kr->AddScale(*kv, -omega);
-            }
-            res_norm = this->doNorm(*kr);
+                res = std::abs((double)this->doNorm(*r));
         }
     }
-    int                    m_s;
-    unsigned long long     m_seed;
-    ValueType              m_kappa;
-    VectorType             m_r, m_v, m_t;
-    VectorType**           m_G;
-    VectorType**           m_U;
-    VectorType**           m_P;
-    std::vector<ValueType> m_c, m_f, m_M;
+    int                m_s;
+    unsigned long long m_seed;
+    ValueType          m_kappa;
 };
 
 // ============================================================================ FixedPoint
@@ -3435,19 +3359,19 @@ protected:
         }
         this->m_solver_coarse->SetOperator(*this->m_op_level[this->m_levels - 2]);
         this->m_solver_coarse->Build();
-        this->m_d_level = new VectorType*[this->m_levels];
-        this->m_r_level = new VectorType*[this->m_levels];
-        this->m_t_level = new VectorType*[this->m_levels];
+        this->m_d_level = new VectorType*[this->m_levels]();
+        this->m_r_level = new VectorType*[this->m_levels]();
+        this->m_t_level = new VectorType*[this->m_levels]();
         this->m_d_level[0] = NULL;
         if(this->m_scaling)
         {
-            this->m_s_level = new VectorType*[this->m_levels];
+            this->m_s_level = new VectorType*[this->m_levels]();
             for(int i = 0; i < this->m_levels; ++i)
                 this->m_s_level[i] = this->m_new_vec(i, "temporary");
         }
         if(this->m_cycle == Kcycle)
         {
-            this->m_q_level = new VectorType*[this->m_levels > 2 ? this->m_levels - 2 : 1];
+            this->m_q_level = new VectorType*[this->m_levels > 2 ? this->m_levels - 2 : 1]();
             for(int i = 0; i < this->m_levels - 2; ++i)
                 this->m_q_level[i] = this->m_new_vec(i + 1, "q");
         }
@@ -3717,7 +3641,7 @@ public:
     {
         RAMD_EXPECT(!this->m_build && op != nullptr && this->m_levels > 0);
         delete[] this->m_restrict_op_level;
-        this->m_restrict_op_level = new OperatorType*[this->m_levels];
+        this->m_restrict_op_level = new OperatorType*[this->m_levels]();
         for(int i = 0; i < this->m_levels - 1; ++i)
             this->m_restrict_op_level[i] = op[i];
     }
@@ -3725,7 +3649,7 @@ public:
     {
         RAMD_EXPECT(!this->m_build && op != nullptr && this->m_levels > 0);
         delete[] this->m_prolong_op_level;
-        this->m_prolong_op_level = new OperatorType*[this->m_levels];
+        this->m_prolong_op_level = new OperatorType*[this->m_levels]();
         for(int i = 0; i < this->m_levels - 1; ++i)
             this->m_prolong_op_level[i] = op[i];
     }
@@ -3848,9 +3772,9 @@ public:
             if(!(c->GetM() > static_cast<int64_t>(this->m_coarse_size)))
                 break;
         }
-        this->m_op_level          = new OperatorType*[this->m_levels - 1];
-        this->m_restrict_op_level = new OperatorType*[this->m_levels - 1];
-        this->m_prolong_op_level  = new OperatorType*[this->m_levels - 1];
+        this->m_op_level          = new OperatorType*[this->m_levels - 1]();
+        this->m_restrict_op_level = new OperatorType*[this->m_levels - 1]();
+        this->m_prolong_op_level  = new OperatorType*[this->m_levels - 1]();
         for(int i = 0; i < this->m_levels - 1; ++i)
         {
             this->m_op_level[i]          = ops[i];
@@ -3861,8 +3785,8 @@ public:
     // base_amg.cpp:313-338
     virtual void BuildSmoothers(void)
     {
-        this->m_smoother_level = new IterativeLinearSolver<OperatorType, VectorType, ValueType>*[this->m_levels - 1];
-        this->m_sm_default     = new Solver<OperatorType, VectorType, ValueType>*[this->m_levels - 1];
+        this->m_smoother_level = new IterativeLinearSolver<OperatorType, VectorType, ValueType>*[this->m_levels - 1]();
+        this->m_sm_default     = new Solver<OperatorType, VectorType, ValueType>*[this->m_levels - 1]();
         for(int i = 0; i < this->m_levels - 1; ++i)
         {
             FixedPoint<OperatorType, VectorType, ValueType>* sm  = new FixedPoint<OperatorType, VectorType, ValueType>;

@@ -89,6 +89,12 @@ int ramd_vec_clear(ramd_vec_t v); /* ::Clear :71 */
 int ramd_vec_size(ramd_vec_t v, int64_t* n);
 int ramd_vec_dtype(ramd_vec_t v, int* dtype);
 void* ramd_vec_data(ramd_vec_t v); /* raw device pointer (LeaveDataPtr-style view, :68) */
+/* Allocate (base_vector.hpp:68, hip_vector.cpp:117-150) with a placement hint: the block comes from the placement class
+ * opposite to the one `other` lives in -- two vectors a fused update WRITES in one pass stream 8-15 % faster from different
+ * classes (csrc/backend.hip, "Placement classes").  other == NULL or unclassified (< 64 MiB): plain ramd_vec_allocate. */
+int ramd_vec_allocate_apart(ramd_vec_t v, int64_t n, ramd_vec_t other);
+/* 0 / 1: the placement class of the vector's block, -1: not classified (small, host, empty) */
+int ramd_vec_placement_class(ramd_vec_t v, int* cls);
 int ramd_vec_zeros(ramd_vec_t v); /* :73 */
 int ramd_vec_ones(ramd_vec_t v); /* :75 */
 int ramd_vec_set_values(ramd_vec_t v, double val); /* :77 */
@@ -217,7 +223,34 @@ int ramd_mat_gen_poisson7_slab(ramd_mat_t interior, ramd_mat_t ghost, int N, int
  * RAMD_NSCALARS doubles; ramd_scalars_fetch copies a record to the host (blocking on the
  * stream).  Element-wise arithmetic is the reference's expression for each op, so results
  * equal the unfused sequence except for the summation order of the reductions. */
-enum { RAMD_NSCALARS = 128 };
+enum { RAMD_NSCALARS = 384 };
+/* ---- device-resident scalar algebra (the recurrences of the Krylov drivers without host round trips).
+ * The reference computes every recurrence coefficient on the host: each Dot / Norm is a blocking read-back
+ * (hip_vector.cpp:785-931 + hipStreamSynchronize), the quotient is formed in C++ and travels back as a kernel argument
+ * (src/solvers/krylov/{cr,fcg,bicgstabl,qmrcgstab,idr}.cpp).  Here a dot lands in a slot of the device record
+ * (ramd_fused_multi_dot), a short program of scalar operations runs on the record in ONE single-thread launch, and the
+ * vector updates take their coefficients from slots -- the host reads one residual per iteration.
+ * A program is a list of {op, dst, a, b, imm}: dst = a (+,-,*,/) b on slots, SET dst = imm, NEG / SQRT / ABS / MOV of a,
+ * ZFLAG: dst = 1 if slot a == 0 (else unchanged) -- the breakdown tests of the drivers (rho == 0 ...) without a read-back:
+ * every later ramd_vec_combine_s guarded by that slot becomes a no-op, the host sees the flag with the next residual.
+ * single != 0: every result is rounded to float (drivers instantiated for float compute their scalars in float). */
+typedef struct
+{
+    int    op, dst, a, b;
+    double imm;
+} ramd_sop_t;
+enum
+{
+    RAMD_SOP_SET = 0, RAMD_SOP_MOV, RAMD_SOP_ADD, RAMD_SOP_SUB, RAMD_SOP_MUL, RAMD_SOP_DIV, RAMD_SOP_NEG, RAMD_SOP_SQRT,
+    RAMD_SOP_ABS, RAMD_SOP_ZFLAG, RAMD_SOP_BADFLAG, /* like ZFLAG, for a == 0, NaN or +-Inf (bicgstab.cpp:430-447) */
+    RAMD_SOP_CMOVLT /* if slot a < slot b: dst = slot (int)imm   (idr.cpp: omega *= kappa / rho where rho < kappa) */
+};
+enum { RAMD_SOP_MAX = 96 }; /* operations per program */
+int ramd_scalars_eval(const ramd_sop_t* ops, int count, int single);
+/* x = sum_k c_k * v_k over nterms <= 3 terms, evaluated left to right exactly as the reference's AddScale / ScaleAdd /
+ * ScaleAddScale / ScaleAdd2 / Scale expressions (host_vector.cpp:635-760); c_k = factor[k] * slot[slots[k]] (slots[k] >= 0)
+ * or factor[k] alone; v_k may be x itself.  guard >= 0: nothing happens when that slot is non-zero. */
+int ramd_vec_combine_s(ramd_vec_t x, int nterms, const ramd_vec_t* vs, const int* slots, const double* factors, int guard);
 int ramd_scalars_set(int slot, double value);
 int ramd_scalars_fetch(double* host, int first, int count);
 int ramd_scalars_fetch_async_begin(int record, int first, int count); /* record in 0..7 */
@@ -404,6 +437,13 @@ int ramd_comm_allreduce_scalars(ramd_comm_t c, int first, int count);
  *        send[send_offset[k] .. send_offset[k+1]) -> peer k and recv[recv_offset[k] ..) <- peer k on
  *        the ghost stream, so it overlaps whatever is queued on the current stream next;
  * end  : the current stream waits for the exchange. */
+/* COLLECTIVE (every rank of the communicator, also one without neighbours): announces an exchange plan and agrees on
+ * its form -- grouped ncclSend/ncclRecv pairs, or, when some rank has more than four peers (or RAMD_COMM_HALO=allgather),
+ * ONE ncclAllGather of equally padded boundary buffers from which every rank picks what it needs (the reference posts
+ * one MPI_Isend/Irecv per neighbour whatever their number, parallel_manager.cpp:726-782).  *allgather = 1: every rank
+ * has to call ramd_comm_halo_begin / _end for every exchange of this plan, also with npeers = 0. */
+int ramd_comm_halo_select(ramd_comm_t c, int npeers, const int* peers, const int64_t* send_offset,
+                          const int64_t* recv_offset, int* allgather);
 int ramd_comm_halo_begin(ramd_comm_t c, ramd_vec_t send, ramd_vec_t recv, int npeers, const int* peers,
                          const int64_t* send_offset, const int64_t* recv_offset);
 int ramd_comm_halo_end(ramd_comm_t c);

@@ -49,6 +49,8 @@ SIGNATURES = {
     "ramd_vec_create": (i32, [i32, C.POINTER(vec_t)]),
     "ramd_vec_destroy": (i32, [vec_t]),
     "ramd_vec_allocate": (i32, [vec_t, i64]),
+    "ramd_vec_allocate_apart": (i32, [vec_t, i64, vec_t]),
+    "ramd_vec_placement_class": (i32, [vec_t, pi32]),
     "ramd_vec_clear": (i32, [vec_t]),
     "ramd_vec_size": (i32, [vec_t, pi64]),
     "ramd_vec_dtype": (i32, [vec_t, pi32]),
@@ -169,6 +171,8 @@ SIGNATURES = {
     "ramd_mcsgs_apply": (i32, [ptr, vec_t, vec_t]),
     "ramd_mcsgs_apply_kind": (i32, [ptr, i32, vec_t, vec_t]),
     "ramd_mcsgs_destroy": (i32, [ptr]),
+    "ramd_scalars_eval": (i32, [ptr, i32, i32]),
+    "ramd_vec_combine_s": (i32, [vec_t, i32, ptr, pi32, ptr, i32]),
     "ramd_fused_multi_dot": (i32, [C.POINTER(vec_t), i32, vec_t, i32]),
     "ramd_fused_multi_axpy": (i32, [vec_t, C.POINTER(vec_t), pf64, i32]),
     "ramd_fused_mgs_step": (i32, [vec_t, vec_t, i32, vec_t, i32]),
@@ -192,6 +196,7 @@ SIGNATURES = {
     "ramd_comm_rank": (i32, [ptr, pi32]),
     "ramd_comm_size": (i32, [ptr, pi32]),
     "ramd_comm_allreduce_scalars": (i32, [ptr, i32, i32]),
+    "ramd_comm_halo_select": (i32, [ptr, i32, pi32, pi64, pi64, pi32]),
     "ramd_comm_halo_begin": (i32, [ptr, vec_t, vec_t, i32, pi32, pi64, pi64]),
     "ramd_comm_halo_end": (i32, [ptr]),
     # solver layer

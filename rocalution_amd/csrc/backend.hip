@@ -45,18 +45,109 @@ using namespace ramd;
 // Build() after the Clear() of a 512^3 preconditioner took +2.3..3.2 s at random).  Freed blocks are therefore
 // kept and handed out again to requests of (nearly) the same size -- Build/Clear cycles repeat their sizes
 // exactly.  RAMD_ALLOC_CACHE=0 disables the cache; it is emptied on out-of-memory and by ramd_stop().
+//
+// Arenas (blocks of >= 64 MiB).  How fast a kernel streams SEVERAL big arrays at once depends on how their addresses relate
+// (tools/placement2.hip, profiles/r03_placement_*.txt): inside one allocation, five 1-GiB streams placed 1 GiB + 4 MiB apart
+// -- exactly where consecutive hipMalloc calls of 1-GiB vectors land -- run the 3-read-2-write update at 5.3-5.6 TB/s, placed
+// 1 GiB + 32 MiB apart at 6.0-6.6 TB/s, in every process; blocks from SEPARATE hipMalloc calls draw their relation anew
+// in every process (the 5-9 % "placement lottery" of round 2).  Big blocks are therefore carved out of a few large arenas
+// (one hipMalloc each: one physically coherent range) at controlled offsets: the k-th big block of an arena starts at a
+// multiple of 2 MiB that is congruent to k * 32 MiB modulo 512 MiB, so equally sized work vectors allocated one after the
+// other lie (size rounded up to 512 MiB) + 32 MiB apart.  Measured with the solver's own kernels: reproducible to +-0.4 % over
+// fresh processes -- but always in the SLOW mode (k_cg_update 5.1-5.3 TB/s for every group and every offset step), because
+// one allocation is one placement class (below).  Arenas are therefore opt-in (RAMD_ALLOC_ARENA=1, experiments).
+//
+// Placement classes.  What the lottery really draws (tools/placement2.hip w, profiles/r03_placement_pairs.txt): every big
+// block belongs to one of TWO classes (where the driver put it), and what a kernel with two WRITE streams gets depends on
+// whether they are in the same class: two 1-GiB write streams 6.0-6.6 TB/s in the same class, 7.1-7.35 TB/s across the
+// classes; the 3-read-2-write update 5.8-6.2 against 6.5-6.8 TB/s (two read streams prefer the SAME class: 6.9-7.2 against
+// 6.4-6.8; one read + one write do not care).  The class of a block is measured once, when it is handed out (two short
+// write+write probes against a reference block, ~0.1 ms), and a caller can ask for a block in the class opposite to
+// another one's (cached_malloc_apart): the solvers place the two vectors their fused updates write apart.
 namespace ramd
 {
 namespace
 {
+constexpr size_t kArenaMinBlock = (size_t)64 << 20; // blocks from this size on live in arenas
+constexpr size_t kArenaBytes    = (size_t)32 << 30; // default size of an arena
+constexpr size_t kArenaPhase    = (size_t)32 << 20; // offset step between consecutive blocks ...
+constexpr size_t kArenaModulus  = (size_t)512 << 20; // ... modulo this
+struct Arena
+{
+    char*  base   = nullptr;
+    size_t size   = 0;
+    size_t top    = 0; // first unused byte
+    int    placed = 0; // blocks carved so far
+    int    live   = 0; // blocks handed out and not freed
+};
 struct AllocCache
 {
     std::mutex                       mu;
     std::multimap<size_t, void*>     free_blocks; // size -> block
     std::unordered_map<void*, size_t> live;       // block -> size
+    std::vector<Arena>                arenas;
+    std::unordered_map<void*, int>    arena_of; // block (live or cached) -> its arena
+    std::unordered_map<void*, int>    klass; // big block (live or cached) -> placement class 0 / 1 (measured)
+    char*                             ref = nullptr; // reference block of the class probes (2 x kProbeBytes)
+    int                               arena_on = -1;
     size_t                           cached_bytes = 0;
     size_t                           cap          = 0; // bytes the cache may hold (set at first use)
     int                              enabled      = -1;
+    bool use_arenas()
+    {
+        if(arena_on < 0)
+        {
+            const char* e = getenv("RAMD_ALLOC_ARENA");
+            arena_on      = (e && atoi(e) != 0) ? 1 : 0;
+        }
+        return arena_on == 1 && on();
+    }
+    // a block of `need` bytes from an arena (nullptr: no arena has room and a new one cannot be had)
+    void* carve(size_t need)
+    {
+        for(int pass = 0; pass < 2; ++pass)
+        {
+            for(size_t a = 0; a < arenas.size(); ++a)
+            {
+                // (RAMD_ARENA_PHASE_MB / RAMD_ARENA_MOD_MB: the placement experiments of tools/placement_probe.py)
+                static const size_t phase = getenv("RAMD_ARENA_PHASE_MB") ? (size_t)atoll(getenv("RAMD_ARENA_PHASE_MB")) << 20 : kArenaPhase;
+                static const size_t modulus = getenv("RAMD_ARENA_MOD_MB") ? (size_t)atoll(getenv("RAMD_ARENA_MOD_MB")) << 20 : kArenaModulus;
+                Arena&       ar   = arenas[a];
+                size_t       off  = (ar.top + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+                const size_t want = ((size_t)ar.placed * phase) % modulus;
+                off += (want + modulus - off % modulus) % modulus;
+                if(off + need <= ar.size)
+                {
+                    ar.top = off + need;
+                    ++ar.placed;
+                    ++ar.live;
+                    void* p     = ar.base + off;
+                    arena_of[p] = (int)a;
+                    return p;
+                }
+            }
+            if(pass == 1)
+                break;
+            // a new arena: the default size, or what this request needs; never more than what the device has free
+            size_t f = 0, t = 0;
+            if(hipMemGetInfo(&f, &t) != hipSuccess)
+                return nullptr;
+            size_t want = need + kArenaModulus > kArenaBytes ? need + kArenaModulus : kArenaBytes;
+            if(want + ((size_t)4 << 30) > f)
+                return nullptr;
+            void* base = nullptr;
+            if(hipMalloc(&base, want) != hipSuccess)
+            {
+                (void)hipGetLastError();
+                return nullptr;
+            }
+            Arena ar;
+            ar.base = (char*)base;
+            ar.size = want;
+            arenas.push_back(ar);
+        }
+        return nullptr;
+    }
     bool on()
     {
         if(enabled < 0)
@@ -68,10 +159,33 @@ struct AllocCache
     }
     void drop_all()
     {
+        // blocks of their own go back to the runtime; an arena goes back as a whole once none of its blocks is in use
+        std::multimap<size_t, void*> keep;
         for(auto& kv : free_blocks)
-            (void)hipFree(kv.second);
-        free_blocks.clear();
+        {
+            auto it = arena_of.find(kv.second);
+            if(it == arena_of.end())
+            {
+                klass.erase(kv.second);
+                (void)hipFree(kv.second);
+            }
+            else if(arenas[(size_t)it->second].live > 0)
+                keep.insert(kv);
+            else
+                arena_of.erase(it);
+        }
+        free_blocks.swap(keep);
         cached_bytes = 0;
+        for(auto& kv : free_blocks)
+            cached_bytes += kv.first;
+        for(Arena& ar : arenas)
+            if(ar.live == 0 && ar.base)
+            {
+                (void)hipFree(ar.base);
+                ar.base = nullptr;
+                ar.size = ar.top = 0; // (the slot stays: arena_of holds indices)
+                ar.placed        = 0;
+            }
     }
 };
 AllocCache& cache()
@@ -80,6 +194,112 @@ AllocCache& cache()
     return c;
 }
 } // namespace
+
+namespace
+{
+constexpr size_t kClassMinBlock = (size_t)64 << 20; // blocks from this size on are classified
+constexpr size_t kProbeBytes    = (size_t)256 << 20; // bytes each of the two probe streams writes (at most: the block's size)
+typedef unsigned int probe_pk __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_probe_ww(size_t n16, probe_pk* __restrict__ a, probe_pk* __restrict__ b)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if(i < n16)
+    {
+        __builtin_nontemporal_store(probe_pk{0u, 0u, 0u, 0u}, a + i);
+        __builtin_nontemporal_store(probe_pk{0u, 0u, 0u, 0u}, b + i);
+    }
+}
+// class of a fresh block: does writing it together with the reference block run like reference + reference (same class, 0)
+// or clearly faster (the other class, 1)?  The block's contents are undefined at this point.
+int probe_class(AllocCache& c, void* p, size_t bytes)
+{
+    static const int off = getenv("RAMD_ALLOC_CLASSES") && atoi(getenv("RAMD_ALLOC_CLASSES")) == 0;
+    if(off || bytes < kClassMinBlock)
+        return -1;
+    if(!c.ref)
+    {
+        void* r = nullptr;
+        if(hipMalloc(&r, 2 * kProbeBytes) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            return -1;
+        }
+        c.ref = (char*)r;
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if(hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+        return -1;
+    static const size_t probe_env = getenv("RAMD_ALLOC_PROBE_MB") ? (size_t)atoll(getenv("RAMD_ALLOC_PROBE_MB")) << 20 : kProbeBytes;
+    const size_t   pb  = std::min(std::min(probe_env, kProbeBytes), bytes & ~(size_t)4095);
+    const size_t   n16 = pb / 16;
+    const unsigned g   = (unsigned)((n16 + 255) / 256);
+    auto           run = [&](void* a, void* b2) -> float {
+        float best = 1e30f;
+        for(int rep = 0; rep < 4; ++rep)
+        {
+            (void)hipEventRecord(e0, nullptr);
+            hipLaunchKernelGGL(k_probe_ww, dim3(g), dim3(256), 0, nullptr, n16, (probe_pk*)a, (probe_pk*)b2);
+            (void)hipEventRecord(e1, nullptr);
+            (void)hipEventSynchronize(e1);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if(rep > 0 && ms < best) // (the first launch warms up)
+                best = ms;
+        }
+        return best;
+    };
+    (void)hipDeviceSynchronize();
+    // (the probe walks the block's END: its start is the part a previous owner of the address range touched last)
+    const float same  = run(c.ref, c.ref + kProbeBytes);
+    const float mixed = run(c.ref, (char*)p + ((bytes - pb) & ~(size_t)4095));
+    static const bool verbose = getenv("RAMD_ALLOC_VERBOSE") != nullptr;
+    if(verbose)
+        fprintf(stderr, "alloc class probe: block %p (%zu MiB): same-class reference pair %.4f ms, with the block %.4f ms -> class %d\n", p,
+                bytes >> 20, same, mixed, mixed < 0.94f * same ? 1 : 0);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipGetLastError();
+    return mixed < 0.94f * same ? 1 : 0;
+}
+} // namespace
+
+int cached_block_class(const void* p)
+{
+    AllocCache&                 c = cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    auto                        it = c.klass.find(const_cast<void*>(p));
+    return it == c.klass.end() ? -1 : it->second;
+}
+
+hipError_t cached_malloc_bytes(void** p, size_t bytes);
+
+// a block in the placement class OPPOSITE to the one of `other` (see the header of this section); falls back to any block
+// when `other` has no class, classes are off, or the other class does not turn up within a few draws
+hipError_t cached_malloc_apart(void** p, size_t bytes, const void* other)
+{
+    const int avoid = other ? cached_block_class(other) : -1;
+    if(avoid < 0)
+        return cached_malloc_bytes(p, bytes);
+    std::vector<void*> rejects;
+    hipError_t         e = hipSuccess;
+    for(int draw = 0; draw < 6; ++draw)
+    {
+        void* q = nullptr;
+        e       = cached_malloc_bytes(&q, bytes);
+        if(e != hipSuccess)
+            break;
+        const int k = cached_block_class(q);
+        if(k < 0 || k != avoid || draw == 5)
+        {
+            *p = q;
+            break;
+        }
+        rejects.push_back(q); // (kept allocated while drawing: the next draw has to come from somewhere else)
+    }
+    for(void* r : rejects)
+        (void)cached_free(r);
+    return e;
+}
 
 hipError_t cached_malloc_bytes(void** p, size_t bytes)
 {
@@ -95,6 +315,22 @@ hipError_t cached_malloc_bytes(void** p, size_t bytes)
             c.cached_bytes -= it->first;
             c.live[*p] = it->first;
             c.free_blocks.erase(it);
+            auto ia = c.arena_of.find(*p);
+            if(ia != c.arena_of.end())
+                ++c.arenas[(size_t)ia->second].live;
+            return hipSuccess;
+        }
+    }
+    if(c.use_arenas() && need >= kArenaMinBlock)
+    {
+        void* q = c.carve(need);
+        if(q)
+        {
+            *p         = q;
+            c.live[q] = need;
+            const int k = probe_class(c, q, need);
+            if(k >= 0)
+                c.klass[q] = k;
             return hipSuccess;
         }
     }
@@ -106,7 +342,12 @@ hipError_t cached_malloc_bytes(void** p, size_t bytes)
         e = hipMalloc(p, need);
     }
     if(e == hipSuccess)
+    {
         c.live[*p] = need;
+        const int k = probe_class(c, *p, need);
+        if(k >= 0)
+            c.klass[*p] = k;
+    }
     return e;
 }
 
@@ -121,6 +362,15 @@ hipError_t cached_free(void* p)
         return hipFree(p); // not ours
     const size_t sz = it->second;
     c.live.erase(it);
+    auto ia = c.arena_of.find(p);
+    if(ia != c.arena_of.end()) // a piece of an arena: always kept for the next request of its size
+    {
+        (void)hipDeviceSynchronize();
+        --c.arenas[(size_t)ia->second].live;
+        c.free_blocks.emplace(sz, p);
+        c.cached_bytes += sz;
+        return hipSuccess;
+    }
     if(c.on() && sz >= (1u << 20))
     {
         if(c.cap == 0)
@@ -137,6 +387,7 @@ hipError_t cached_free(void* p)
             return hipSuccess;
         }
     }
+    c.klass.erase(p);
     return hipFree(p);
 }
 

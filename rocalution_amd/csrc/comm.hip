@@ -6,6 +6,13 @@
 // ncclSend/ncclRecv per neighbour runs on the GHOST stream over xGMI while the interior SpMV runs on
 // the compute stream; events, not host syncs, order the two.  Scalars of a fused reduction are summed
 // by ONE ncclAllReduce on the device scalar record.
+//
+// Many-neighbour graphs (last row): a rank with more than kAgPeers peers exchanges its halo with ONE
+// ncclAllGather of equally padded boundary buffers instead of a group of send/recv pairs -- on the point-to-point xGMI
+// fabric a ring all-gather moves every block once over every link, while P-1 pairs per rank serialise on the rank's links.
+// What a rank needs from the gathered buffer is copied out by an index list built once per exchange plan from a small
+// table every rank contributes (its total and, per destination rank, where that rank's piece starts in its buffer).
+// RAMD_COMM_HALO=allgather / sendrecv forces either form.
 #include "common.hpp"
 #include "matrix_impl.hpp"
 
@@ -28,7 +35,29 @@ struct ramd_comm_s
     void*  h_send = nullptr;
     void*  h_recv = nullptr;
     size_t h_send_bytes = 0, h_recv_bytes = 0;
+    // all-gather form of the halo exchange: one plan per (peers, offsets) signature
+    struct AgPlan
+    {
+        unsigned long long key = 0; // hash of the exchange plan + element size
+        int64_t M = 0; // padded boundary length (elements): the maximum over the ranks
+        int64_t nrecv = 0;
+        int*    d_idx = nullptr; // [nrecv] position in the gathered buffer of every received value
+        void*   d_send = nullptr; // [M] padded copy of the packed boundary
+        void*   d_all  = nullptr; // [size * M] the gathered buffers
+    };
+    std::vector<AgPlan> ag;
+    // form of the exchange the ranks agreed on per plan (ramd_comm_halo_select): key of the plan -> 1 = all-gather
+    std::vector<std::pair<unsigned long long, int>> form;
 };
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_halo_pick(int64_t n, const int* __restrict__ idx, const T* __restrict__ all,
+                                                   T* __restrict__ recv)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n)
+        recv[i] = all[idx[i]];
+}
 
 #define RAMD_NCCL(expr)                                                                            \
     do                                                                                             \
@@ -122,6 +151,14 @@ int ramd_comm_destroy(ramd_comm_t c)
         (void)hipHostFree(c->h_send);
     if(c->h_recv)
         (void)hipHostFree(c->h_recv);
+    for(auto& pl : c->ag)
+    {
+        dev_free(&pl.d_idx);
+        if(pl.d_send)
+            (void)cached_free(pl.d_send);
+        if(pl.d_all)
+            (void)cached_free(pl.d_all);
+    }
     delete c;
     return RAMD_OK;
 }
@@ -189,20 +226,273 @@ static int ensure_host(void** p, size_t* have, size_t need)
     return RAMD_OK;
 }
 
+} // extern "C"
+
+constexpr int kAgPeers = 4; // more peers than this: all-gather form
+
+static int halo_forced_form()
+{
+    static const int mode = [] {
+        const char* e = getenv("RAMD_COMM_HALO");
+        if(e && std::string(e) == "allgather")
+            return 1;
+        if(e && std::string(e) == "sendrecv")
+            return 0;
+        return -1;
+    }();
+    return mode;
+}
+static unsigned long long halo_plan_key(int npeers, const int* peers, const int64_t* send_offset, const int64_t* recv_offset)
+{
+    unsigned long long h = 1469598103934665603ull;
+    auto mix = [&](long long v) { h = (h ^ (unsigned long long)v) * 1099511628211ull; };
+    mix(npeers);
+    for(int k = 0; k < npeers; ++k)
+        mix(peers[k]);
+    for(int k = 0; k <= npeers && npeers > 0; ++k)
+    {
+        mix(send_offset[k]);
+        mix(recv_offset[k]);
+    }
+    return h;
+}
+// the form the ranks agreed on for this plan (0: send/recv pairs -- also for a plan nobody announced)
+static bool halo_use_allgather(const ramd_comm_s* c, unsigned long long key)
+{
+    for(auto& kv : c->form)
+        if(kv.first == key)
+            return kv.second == 1;
+    return false;
+}
+
+// all ranks contribute `count` int64 each; out[r * count ..] = rank r's contribution (host arrays)
+static int comm_allgather_host(ramd_comm_s* c, const int64_t* mine, int count, int64_t* out)
+{
+    Backend& b = backend();
+    if(c->use_rccl)
+    {
+        int64_t *d_in = nullptr, *d_out = nullptr;
+        RAMD_TRY(dev_alloc(&d_in, count));
+        int s = dev_alloc(&d_out, (int64_t)count * c->size);
+        if(s != RAMD_OK)
+        {
+            dev_free(&d_in);
+            return s;
+        }
+        hipError_t   e = hipMemcpyAsync(d_in, mine, sizeof(int64_t) * (size_t)count, hipMemcpyHostToDevice, b.stream_ghost);
+        ncclResult_t r = ncclSuccess;
+        if(e == hipSuccess)
+            r = ncclAllGather(d_in, d_out, (size_t)count, ncclInt64, c->nccl, b.stream_ghost);
+        if(e == hipSuccess && r == ncclSuccess)
+            e = hipMemcpyAsync(out, d_out, sizeof(int64_t) * (size_t)count * c->size, hipMemcpyDeviceToHost, b.stream_ghost);
+        if(e == hipSuccess && r == ncclSuccess)
+            e = hipStreamSynchronize(b.stream_ghost);
+        dev_free(&d_in);
+        dev_free(&d_out);
+        if(r != ncclSuccess)
+            RAMD_FAIL(RAMD_ERR_HIP, std::string("ncclAllGather (halo plan) -> ") + ncclGetErrorString(r));
+        RAMD_HIP(e);
+        return RAMD_OK;
+    }
+    // callback transport: everybody sends its record to everybody else
+    std::vector<int>     peers;
+    std::vector<int64_t> so, ro;
+    std::vector<int64_t> sbuf, rbuf((size_t)count * (c->size - 1));
+    so.push_back(0);
+    ro.push_back(0);
+    for(int q = 0; q < c->size; ++q)
+        if(q != c->rank)
+        {
+            peers.push_back(q);
+            sbuf.insert(sbuf.end(), mine, mine + count);
+            so.push_back(so.back() + (int64_t)sizeof(int64_t) * count);
+            ro.push_back(ro.back() + (int64_t)sizeof(int64_t) * count);
+        }
+    if(c->cb_exchange(c->user, (int)peers.size(), peers.data(), sbuf.data(), so.data(), rbuf.data(), ro.data()) != 0)
+        RAMD_FAIL(RAMD_ERR_STATE, "halo plan exchange callback failed");
+    int k = 0;
+    for(int q = 0; q < c->size; ++q)
+    {
+        const int64_t* src = (q == c->rank) ? mine : rbuf.data() + (size_t)count * (k++);
+        memcpy(out + (size_t)count * q, src, sizeof(int64_t) * (size_t)count);
+    }
+    return RAMD_OK;
+}
+
+static int halo_ag_plan(ramd_comm_s* c, size_t es, int npeers, const int* peers, const int64_t* send_offset,
+                        const int64_t* recv_offset, ramd_comm_s::AgPlan** out)
+{
+    const unsigned long long h = halo_plan_key(npeers, peers, send_offset, recv_offset) * 31ull + (unsigned long long)es;
+    for(auto& pl : c->ag)
+        if(pl.key == h)
+        {
+            *out = &pl;
+            return RAMD_OK;
+        }
+    // every rank's table: [0] = its boundary length, [1 + 2q] / [2 + 2q] = start / length of the piece for rank q
+    const int            P = c->size, cnt = 1 + 2 * P;
+    std::vector<int64_t> mine((size_t)cnt, 0), all((size_t)cnt * P, 0);
+    mine[0] = npeers > 0 ? send_offset[npeers] : 0;
+    for(int k = 0; k < npeers; ++k)
+    {
+        if(peers[k] < 0 || peers[k] >= P)
+            RAMD_FAIL(RAMD_ERR_ARG, "halo plan: peer rank out of range");
+        mine[1 + 2 * peers[k]] = send_offset[k];
+        mine[2 + 2 * peers[k]] = send_offset[k + 1] - send_offset[k];
+    }
+    RAMD_TRY(comm_allgather_host(c, mine.data(), cnt, all.data()));
+    ramd_comm_s::AgPlan pl;
+    pl.key   = h;
+    pl.nrecv = npeers > 0 ? recv_offset[npeers] : 0;
+    for(int q = 0; q < P; ++q)
+        pl.M = std::max(pl.M, all[(size_t)cnt * q]);
+    pl.M = (pl.M + 1) & ~(int64_t)1; // (16-byte multiples in fp64)
+    if(pl.M * P >= (1ll << 31))
+        RAMD_FAIL(RAMD_ERR_UNSUPPORTED, "halo all-gather: gathered buffer beyond 32-bit indices");
+    std::vector<int> idx((size_t)pl.nrecv, 0);
+    for(int k = 0; k < npeers; ++k)
+    {
+        const int      q   = peers[k];
+        const int64_t  off = all[(size_t)cnt * q + 1 + 2 * c->rank], len = all[(size_t)cnt * q + 2 + 2 * c->rank];
+        if(len != recv_offset[k + 1] - recv_offset[k])
+            RAMD_FAIL(RAMD_ERR_STATE, "halo plan: a peer sends a different number of values than this rank expects");
+        for(int64_t j = 0; j < len; ++j)
+            idx[(size_t)(recv_offset[k] + j)] = (int)((int64_t)q * pl.M + off + j);
+    }
+    if(getenv("RAMD_COMM_DEBUG"))
+    {
+        fprintf(stderr, "[rank %d] halo all-gather plan: npeers=%d M=%lld nrecv=%lld es=%zu table:", c->rank, npeers, (long long)pl.M,
+                (long long)pl.nrecv, es);
+        for(size_t i = 0; i < all.size(); ++i)
+            fprintf(stderr, " %lld", (long long)all[i]);
+        fprintf(stderr, " | idx:");
+        for(size_t i = 0; i < idx.size() && i < 6; ++i)
+            fprintf(stderr, " %d", idx[i]);
+        fprintf(stderr, "\n");
+    }
+    RAMD_TRY(dev_alloc(&pl.d_idx, pl.nrecv > 0 ? pl.nrecv : 1));
+    if(pl.nrecv > 0)
+        RAMD_HIP(hipMemcpy(pl.d_idx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice));
+    RAMD_HIP(cached_malloc_bytes(&pl.d_send, (size_t)(pl.M > 0 ? pl.M : 2) * es));
+    RAMD_HIP(cached_malloc_bytes(&pl.d_all, (size_t)(pl.M > 0 ? pl.M : 2) * es * P));
+    // (on the ghost stream, where the exchanges fill and read it: a null-stream memset is not ordered against that stream
+    //  and could land after the first packed boundary was copied in)
+    RAMD_HIP(hipMemsetAsync(pl.d_send, 0, (size_t)(pl.M > 0 ? pl.M : 2) * es, backend().stream_ghost));
+    RAMD_HIP(hipStreamSynchronize(backend().stream_ghost));
+    c->ag.push_back(pl);
+    *out = &c->ag.back();
+    return RAMD_OK;
+}
+
+extern "C" {
+
+int ramd_comm_halo_select(ramd_comm_t c, int npeers, const int* peers, const int64_t* send_offset,
+                          const int64_t* recv_offset, int* allgather)
+{
+    if(allgather)
+        *allgather = 0;
+    if(!c || c->size < 2)
+        return RAMD_OK;
+    if(npeers < 0 || (npeers > 0 && (!peers || !send_offset || !recv_offset)))
+        RAMD_FAIL(RAMD_ERR_ARG, "halo_select: bad arguments");
+    const unsigned long long key = halo_plan_key(npeers, peers, send_offset, recv_offset);
+    // every rank learns the largest peer count: the rule has to give the same answer everywhere
+    std::vector<int64_t> all((size_t)c->size, 0);
+    const int64_t        mine = npeers;
+    RAMD_TRY(comm_allgather_host(c, &mine, 1, all.data()));
+    int64_t most = 0;
+    for(int64_t v : all)
+        most = std::max(most, v);
+    const int forced = halo_forced_form();
+    const int ag     = forced >= 0 ? forced : (most > kAgPeers ? 1 : 0);
+    bool      known  = false;
+    for(auto& kv : c->form)
+        if(kv.first == key)
+        {
+            kv.second = ag;
+            known     = true;
+        }
+    if(!known)
+        c->form.emplace_back(key, ag);
+    if(allgather)
+        *allgather = ag;
+    return RAMD_OK;
+}
+
 int ramd_comm_halo_begin(ramd_comm_t c, ramd_vec_t send, ramd_vec_t recv, int npeers, const int* peers,
                          const int64_t* send_offset, const int64_t* recv_offset)
 {
-    if(!c || npeers <= 0)
+    if(!c)
         return RAMD_OK;
-    if(!send || !recv || !peers || !send_offset || !recv_offset || send->dtype != recv->dtype)
+    const bool ag_form = c->size > 1 && npeers >= 0
+                         && halo_use_allgather(c, halo_plan_key(npeers, peers, send_offset, recv_offset));
+    if(npeers <= 0 && !ag_form)
+        return RAMD_OK;
+    if(!send || !recv || (npeers > 0 && (!peers || !send_offset || !recv_offset)) || send->dtype != recv->dtype)
         RAMD_FAIL(RAMD_ERR_ARG, "halo_begin: bad arguments");
-    if(send_offset[npeers] > send->n || recv_offset[npeers] > recv->n)
+    if(npeers > 0 && (send_offset[npeers] > send->n || recv_offset[npeers] > recv->n))
         RAMD_FAIL(RAMD_ERR_ARG, "halo_begin: offsets exceed the buffer sizes");
     Backend&     b  = backend();
     const size_t es = (send->dtype == RAMD_F64) ? 8 : 4;
     // the exchange may start once the pack kernel (already queued on the current stream) is done
     RAMD_HIP(hipEventRecord(c->ev_packed, b.cur));
     RAMD_HIP(hipStreamWaitEvent(b.stream_ghost, c->ev_packed, 0));
+    if(ag_form)
+    {
+        // (a collective: every rank of the communicator is here for this exchange, also one without neighbours -- the
+        //  form was agreed on when the plan was announced, ramd_comm_halo_select)
+        ramd_comm_s::AgPlan* pl = nullptr;
+        RAMD_TRY(halo_ag_plan(c, es, npeers, peers, send_offset, recv_offset, &pl));
+        prof_begin(RAMD_PROF_HALO, b.stream_ghost);
+        const size_t sb = npeers > 0 ? (size_t)send_offset[npeers] * es : 0;
+        if(sb > 0)
+            RAMD_HIP(hipMemcpyAsync(pl->d_send, send->d, sb, hipMemcpyDeviceToDevice, b.stream_ghost));
+        if(c->use_rccl)
+        {
+            const ncclDataType_t dt = (send->dtype == RAMD_F64) ? ncclDouble : ncclFloat;
+            RAMD_NCCL(ncclAllGather(pl->d_send, pl->d_all, (size_t)pl->M, dt, c->nccl, b.stream_ghost));
+        }
+        else
+        {
+            // callback transport: the padded buffer goes to every other rank (host staged)
+            const int    P  = c->size;
+            const size_t mb = (size_t)pl->M * es;
+            RAMD_TRY(ensure_host(&c->h_send, &c->h_send_bytes, mb * (size_t)(P - 1)));
+            RAMD_TRY(ensure_host(&c->h_recv, &c->h_recv_bytes, mb * (size_t)(P - 1)));
+            std::vector<int>     pr;
+            std::vector<int64_t> so(1, 0), ro(1, 0);
+            for(int q = 0; q < P; ++q)
+                if(q != c->rank)
+                {
+                    RAMD_HIP(hipMemcpyAsync((char*)c->h_send + mb * pr.size(), pl->d_send, mb, hipMemcpyDeviceToHost,
+                                            b.stream_ghost));
+                    pr.push_back(q);
+                    so.push_back(so.back() + (int64_t)mb);
+                    ro.push_back(ro.back() + (int64_t)mb);
+                }
+            RAMD_HIP(hipStreamSynchronize(b.stream_ghost));
+            if(c->cb_exchange(c->user, (int)pr.size(), pr.data(), c->h_send, so.data(), c->h_recv, ro.data()) != 0)
+                RAMD_FAIL(RAMD_ERR_STATE, "halo exchange callback failed");
+            size_t k = 0;
+            for(int q = 0; q < P; ++q)
+                if(q != c->rank)
+                    RAMD_HIP(hipMemcpyAsync((char*)pl->d_all + mb * (size_t)q, (char*)c->h_recv + mb * (k++), mb,
+                                            hipMemcpyHostToDevice, b.stream_ghost));
+        }
+        if(pl->nrecv > 0)
+        {
+            const unsigned g = (unsigned)((pl->nrecv + 255) / 256);
+            if(send->dtype == RAMD_F64)
+                hipLaunchKernelGGL((k_halo_pick<double>), dim3(g), dim3(256), 0, b.stream_ghost, pl->nrecv, pl->d_idx,
+                                   (const double*)pl->d_all, (double*)recv->d);
+            else
+                hipLaunchKernelGGL((k_halo_pick<float>), dim3(g), dim3(256), 0, b.stream_ghost, pl->nrecv, pl->d_idx,
+                                   (const float*)pl->d_all, (float*)recv->d);
+        }
+        prof_end(RAMD_PROF_HALO, b.stream_ghost);
+        RAMD_HIP(hipEventRecord(c->ev_halo, b.stream_ghost));
+        return RAMD_OK;
+    }
     prof_begin(RAMD_PROF_HALO, b.stream_ghost);
     if(c->use_rccl)
     {

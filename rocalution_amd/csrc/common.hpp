@@ -57,7 +57,7 @@ const char* last_error();
 #define RAMD_REDUCE_BLOCKS 8192
 #endif
 constexpr int kReduceBlocks  = RAMD_REDUCE_BLOCKS; // partial sums per reduction launch (32 workgroups per CU: tools/membench.hip)
-constexpr int kScalarSlots   = 128; // doubles per scalar record
+constexpr int kScalarSlots   = 384; // doubles per scalar record (RAMD_NSCALARS)
 constexpr int kScalarRecords = 8; // ring of records in host-mapped memory
 
 struct Backend
@@ -90,6 +90,8 @@ constexpr size_t kPad = 256;
 // caching device allocator (backend.hip): every device block of the library goes through these two
 hipError_t cached_malloc_bytes(void** p, size_t bytes);
 hipError_t cached_free(void* p);
+hipError_t cached_malloc_apart(void** p, size_t bytes, const void* other); // in the placement class opposite to `other`'s
+int        cached_block_class(const void* p); // 0 / 1, or -1 (small block, not classified)
 void       cached_release_all(void);
 template <typename X>
 inline hipError_t cached_malloc(X** p, size_t bytes)

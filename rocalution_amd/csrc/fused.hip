@@ -999,7 +999,173 @@ static int mgs_block_t(ramd_vec_t w, const ramd_vec_t* vprev, int nprev, int slo
 }
 
 
+// ---------------------------------------------------------------- device-resident scalar algebra
+struct SopList
+{
+    ramd_sop_t op[RAMD_SOP_MAX];
+};
+__global__ void k_scalar_prog(SopList pr, int count, int single, double* __restrict__ s)
+{
+    if(threadIdx.x != 0 || blockIdx.x != 0)
+        return;
+    for(int i = 0; i < count; ++i)
+    {
+        const ramd_sop_t o = pr.op[i];
+        const double     a = o.a >= 0 ? s[o.a] : 0.0, b = o.b >= 0 ? s[o.b] : 0.0;
+        double           r = 0.0;
+        bool             store = true;
+        switch(o.op)
+        {
+        case RAMD_SOP_SET: r = o.imm; break;
+        case RAMD_SOP_MOV: r = a; break;
+        case RAMD_SOP_ADD: r = single ? (double)((float)a + (float)b) : a + b; break;
+        case RAMD_SOP_SUB: r = single ? (double)((float)a - (float)b) : a - b; break;
+        case RAMD_SOP_MUL: r = single ? (double)((float)a * (float)b) : a * b; break;
+        case RAMD_SOP_DIV: r = single ? (double)((float)a / (float)b) : a / b; break;
+        case RAMD_SOP_NEG: r = -a; break;
+        case RAMD_SOP_SQRT: r = single ? (double)sqrtf((float)a) : sqrt(a); break;
+        case RAMD_SOP_ABS: r = fabs(a); break;
+        case RAMD_SOP_ZFLAG:
+            store = (a == 0.0);
+            r     = 1.0;
+            break;
+        case RAMD_SOP_BADFLAG:
+            store = (a == 0.0) || (a != a) || (fabs(a) == INFINITY);
+            r     = 1.0;
+            break;
+        case RAMD_SOP_CMOVLT:
+            store = a < b;
+            r     = s[(int)o.imm];
+            break;
+        default: store = false; break;
+        }
+        if(store)
+            s[o.dst] = single ? (double)(float)r : r;
+    }
+}
+
+struct CombineArgs
+{
+    const void* v[3];
+    int         slot[3];
+    double      factor[3];
+};
+// x = c0 v0 + c1 v1 + c2 v2 (left to right, no contraction), one 16-byte packet per operand and thread
+template <typename T, int NT>
+__global__ __launch_bounds__(kBlock) void k_combine_s(int64_t n, T* __restrict__ x, CombineArgs a, int guard,
+                                                      const double* __restrict__ s)
+{
+    using PK         = typename Pack<T>::type;
+    constexpr int PN = Pack<T>::N;
+    if(guard >= 0 && s[guard] != 0.0)
+        return;
+    T c[NT];
+#pragma unroll
+    for(int k = 0; k < NT; ++k)
+        c[k] = (T)(a.slot[k] >= 0 ? a.factor[k] * s[a.slot[k]] : a.factor[k]);
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * PN;
+    if(i >= n)
+        return;
+    PK p[NT];
+#pragma unroll
+    for(int k = 0; k < NT; ++k)
+        p[k] = *reinterpret_cast<const PK*>(static_cast<const T*>(a.v[k]) + i); // (vectors are padded by 256 B)
+    PK r;
+#pragma unroll
+    for(int e = 0; e < PN; ++e)
+    {
+        T acc = c[0] * p[0][e];
+#pragma unroll
+        for(int k = 1; k < NT; ++k)
+            acc = acc + c[k] * p[k][e];
+        r[e] = acc;
+    }
+    if(i + PN <= n)
+        *reinterpret_cast<PK*>(x + i) = r;
+    else
+        for(int e = 0; e < PN && i + e < n; ++e)
+            x[i + e] = r[e];
+}
+
 extern "C" {
+
+int ramd_scalars_eval(const ramd_sop_t* ops, int count, int single)
+{
+    RAMD_TRY(ensure_init());
+    if(count == 0)
+        return RAMD_OK;
+    if(!ops || count < 0 || count > RAMD_SOP_MAX)
+        RAMD_FAIL(RAMD_ERR_ARG, "scalars_eval: bad program");
+    SopList pr;
+    for(int i = 0; i < count; ++i)
+    {
+        const ramd_sop_t& o = ops[i];
+        if(o.op == RAMD_SOP_CMOVLT && (!slot_ok(o.b) || !slot_ok((int)o.imm)))
+            RAMD_FAIL(RAMD_ERR_ARG, "scalars_eval: operation or slot out of range");
+        if(o.op < RAMD_SOP_SET || o.op > RAMD_SOP_CMOVLT || !slot_ok(o.dst) || (o.op != RAMD_SOP_SET && !slot_ok(o.a))
+           || (o.op >= RAMD_SOP_ADD && o.op <= RAMD_SOP_DIV && !slot_ok(o.b)))
+            RAMD_FAIL(RAMD_ERR_ARG, "scalars_eval: operation or slot out of range");
+        pr.op[i] = o;
+        if(o.op == RAMD_SOP_SET)
+            pr.op[i].a = pr.op[i].b = -1;
+        else if(!(o.op >= RAMD_SOP_ADD && o.op <= RAMD_SOP_DIV) && o.op != RAMD_SOP_CMOVLT)
+            pr.op[i].b = -1;
+    }
+    Backend& b = backend();
+    hipLaunchKernelGGL(k_scalar_prog, dim3(1), dim3(64), 0, b.cur, pr, count, single, b.d_scalars);
+    RAMD_HIP(hipGetLastError());
+    return RAMD_OK;
+}
+
+int ramd_vec_combine_s(ramd_vec_t x, int nterms, const ramd_vec_t* vs, const int* slots, const double* factors, int guard)
+{
+    if(!x || !vs || !slots || !factors || nterms < 1 || nterms > 3 || (guard >= 0 && !slot_ok(guard)))
+        RAMD_FAIL(RAMD_ERR_ARG, "vec_combine_s: bad arguments");
+    CombineArgs a = {};
+    for(int k = 0; k < nterms; ++k)
+    {
+        CHECK_SAMEV(vs[k], x);
+        if(slots[k] >= 0 && !slot_ok(slots[k]))
+            RAMD_FAIL(RAMD_ERR_ARG, "vec_combine_s: slot out of range");
+        a.v[k]      = vs[k]->d;
+        a.slot[k]   = slots[k];
+        a.factor[k] = factors[k];
+    }
+    if(x->n == 0)
+        return RAMD_OK;
+    Backend& b = backend();
+#define COMBINE(T, NTT)                                                                                                       \
+    hipLaunchKernelGGL((k_combine_s<T, NTT>), dim3((unsigned)((x->n + (int64_t)kBlock * Pack<T>::N - 1) / ((int64_t)kBlock * Pack<T>::N))), \
+                       dim3(kBlock), 0, b.cur, x->n, (T*)x->d, a, guard, b.d_scalars)
+    prof_begin(RAMD_PROF_VEC, b.cur);
+    if(x->dtype == RAMD_F64)
+    {
+        if(nterms == 1)
+            COMBINE(double, 1);
+        else if(nterms == 2)
+            COMBINE(double, 2);
+        else
+            COMBINE(double, 3);
+    }
+    else if(x->dtype == RAMD_F32)
+    {
+        if(nterms == 1)
+            COMBINE(float, 1);
+        else if(nterms == 2)
+            COMBINE(float, 2);
+        else
+            COMBINE(float, 3);
+    }
+    else
+    {
+        prof_end(RAMD_PROF_VEC, b.cur);
+        RAMD_FAIL(RAMD_ERR_ARG, "vec_combine_s needs real vectors");
+    }
+    prof_end(RAMD_PROF_VEC, b.cur);
+#undef COMBINE
+    RAMD_HIP(hipGetLastError());
+    return RAMD_OK;
+}
 
 int ramd_fused_multi_dot(const ramd_vec_t* vs, int count, ramd_vec_t w, int slot0)
 {

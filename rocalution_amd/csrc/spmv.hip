@@ -236,6 +236,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PAT ? RA
 // operator: 5 pieces of 2 KiB instead of 7 gathers).  The pieces and the block's values go straight into LDS with 16-byte
 // packets (global_load_lds: no staging registers, no ds_write pass); the row walk then only touches LDS.  Same products,
 // same left-to-right sums.
+// Measured (round 3, 512^3, profiles/r03_spmv_xl.txt): the plain product 2.17-2.19 ms against 2.18-2.30 ms of k_csr_tr<PAT>
+// (equal once the allocations are placed by the arena allocator, 5 % ahead without it), but the form the CG loop uses --
+// the product carrying <p, q> -- 2.44-2.52 ms against 2.24-2.29 ms: the x tiles do not buy what the request concurrency
+// of the gather form already delivers (x is served by the L2 in both), and the two dependent memory phases per block
+// (x pieces + row offsets, then the values) leave the CU idle longer than the gather form's overlap of its own blocks.
+// Kept as an opt-in (RAMD_CSR_XL=1) under the same bit-exact tests; the default stays the gather form.
 template <typename T, int MODE, bool DOT>
 __global__ __launch_bounds__(kBlock) void k_csr_xl(int nrow, int nblk, int per_xcd, const int* __restrict__ rp,
                                                    const T* __restrict__ val, const T* __restrict__ x, T* __restrict__ y,
@@ -1111,8 +1117,8 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
     if(m->pat_state == 0 && pat_env != 0 && (pat_env > 0 || m->nnz >= (1 << 20)))
         RAMD_TRY(csr_analyse_pattern(const_cast<ramd_mat_s*>(m)));
     const bool       use_pat = pat_env != 0 && m->pat_state == 1 && !m->pat_off;
-    // ... and their x tiles in LDS (RAMD_CSR_XL=0: the gather form k_csr_tr<PAT>)
-    static const int xl_env = getenv("RAMD_CSR_XL") ? atoi(getenv("RAMD_CSR_XL")) : 1;
+    // ... and, opt-in, their x tiles in LDS (RAMD_CSR_XL=1: k_csr_xl; default: the gather form k_csr_tr<PAT>)
+    static const int xl_env = getenv("RAMD_CSR_XL") ? atoi(getenv("RAMD_CSR_XL")) : 0;
     if(use_pat && xl_env != 0 && m->xl_state == 0)
         RAMD_TRY(csr_analyse_xl<T>(const_cast<ramd_mat_s*>(m)));
     const bool       use_xl  = use_pat && xl_env != 0 && m->xl_state == 1;

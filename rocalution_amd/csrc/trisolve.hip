@@ -4142,12 +4142,22 @@ __global__ __launch_bounds__(kBlock) void k_ct_rec_set_diag(int nsteps, const in
     const int     lane = threadIdx.x & 63;
     if(wave >= nsteps)
         return;
-    const int p0 = step_rec[4 * wave], cnt = step_rec[4 * wave + 1];
+    const int p0 = step_rec[4 * wave], cnt = step_rec[4 * wave + 1] & 0xff; // (rows | largest group << 8)
     if(lane < cnt)
         *reinterpret_cast<T*>(erec
                               + ((size_t)L::NQ * LPR * p0 + (size_t)(L::off_diag / 16) * (cnt * LPR) + (lane * LPR + LPR - 1)) * 16
                               + (L::off_diag % 16))
             = src[order[p0 + lane]];
+}
+
+// grouped form: the diagonal is the last element of the row record
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_ct_grec_set_diag(int n, const int* __restrict__ order, const T* __restrict__ src,
+                                                             T* __restrict__ grec)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gsz)
+        grec[(size_t)kGrpMax * p + kGrpMax - 1] = src[order[p]];
 }
 
 // diagonal of a plan <- src (natural order): LLSolve keeps the inverse diagonal of the factor there
@@ -4157,6 +4167,12 @@ static int plan_set_diag(TriPlan* P, const T* src)
     Backend& b = backend();
     if(P->n == 0)
         return RAMD_OK;
+    if(P->ct && P->ct_rec && P->ct_grp)
+    {
+        hipLaunchKernelGGL((k_ct_grec_set_diag<T>), dim3(ew_grid(P->n)), dim3(kBlock), 0, b.cur, P->n, P->order, src, (T*)P->diag);
+        RAMD_HIP(hipGetLastError());
+        return RAMD_OK;
+    }
     if(P->ct && P->ct_rec)
     {
         const int      lpr = P->ct_wmax > 8 ? 8 : 1;

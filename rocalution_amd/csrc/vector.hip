@@ -462,6 +462,35 @@ int ramd_vec_allocate(ramd_vec_t v, int64_t n)
     return RAMD_OK;
 }
 
+int ramd_vec_allocate_apart(ramd_vec_t v, int64_t n, ramd_vec_t other)
+{
+    CHECK_VEC(v);
+    if(n < 0)
+        RAMD_FAIL(RAMD_ERR_ARG, "negative size");
+    if(other == v)
+        other = nullptr;
+    RAMD_TRY(ramd_vec_clear(v));
+    if(n > 0)
+    {
+        size_t bytes = (size_t)n * dtype_size(v->dtype);
+        void*  q     = nullptr;
+        RAMD_HIP(cached_malloc_apart(&q, bytes + kPad, other ? other->d : nullptr));
+        v->d = q;
+        RAMD_HIP(hipMemsetAsync(v->d, 0, bytes + kPad, backend().cur));
+        v->n = n;
+    }
+    return RAMD_OK;
+}
+
+int ramd_vec_placement_class(ramd_vec_t v, int* cls)
+{
+    CHECK_VEC(v);
+    if(!cls)
+        RAMD_FAIL(RAMD_ERR_ARG, "null output");
+    *cls = v->d ? cached_block_class(v->d) : -1;
+    return RAMD_OK;
+}
+
 int ramd_vec_size(ramd_vec_t v, int64_t* n)
 {
     CHECK_VEC(v);

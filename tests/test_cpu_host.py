@@ -218,11 +218,11 @@ def test_split_rows_and_halo_plan_single_process():
                 assert np.array_equal(mine, needs[int(q)][r])
 
 
-def _spawn(mode, kind, world=2, timeout=300):
+def _spawn(mode, kind, world=2, timeout=300, env=None):
     with tempfile.TemporaryDirectory() as d:
         initfile = os.path.join(d, "init")
         procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), mode, str(r),
-                                   str(world), initfile, kind, d]) for r in range(world)]
+                                   str(world), initfile, kind, d], env=dict(os.environ, **(env or {}))) for r in range(world)]
         for p in procs:
             assert p.wait(timeout=timeout) == 0
         return [dict(np.load(os.path.join(d, "r%d.npz" % r))) for r in range(world)]

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def _check_two_ranks(kind, oracle, mode):
+def _check_two_ranks(kind, oracle, mode, world=2, env=None):
     from test_cpu_host import _spawn
     import _dist_worker as W
     from rocalution_amd import generators as gen
@@ -28,7 +28,7 @@ def _check_two_ranks(kind, oracle, mode):
     yref = oracle.csr_apply(rp, ci, va, x)
     b = oracle.csr_apply(rp, ci, va, np.ones(n))
     ref = oracle.solve(rp, ci, va, b, solver=oracle.CG, precond=oracle.PC_JACOBI, max_iter=500)
-    res = _spawn(mode, kind)
+    res = _spawn(mode, kind, world=world, timeout=600, env=env)
     y = np.concatenate([r["y"] for r in res])
     assert np.array_equal(y, yref) or np.allclose(y, yref, rtol=1e-13, atol=1e-13)
     y_ell = np.concatenate([r["y_ell"] for r in res])
@@ -56,7 +56,7 @@ def _check_two_ranks(kind, oracle, mode):
     its5 = res[0]["its5"]
     for k, (osolver, opc, slack) in enumerate(((oracle.BICGSTAB, oracle.PC_MCSGS, 2), (oracle.BICGSTAB, oracle.PC_MCSGS, 2),
                                                 (oracle.GMRES, oracle.PC_ILU0, 2))):
-        refb = oracle.solve(rp, ci, va, b, solver=osolver, precond=opc, max_iter=500, nblocks=2)
+        refb = oracle.solve(rp, ci, va, b, solver=osolver, precond=opc, max_iter=500, nblocks=world)
         xs5 = np.concatenate([r["xs5_%d" % k] for r in res])
         assert int(its5[k][1]) == refb["status"], (k, its5[k], refb["status"])
         assert abs(int(its5[k][0]) - refb["iters"]) <= slack, (k, its5[k], refb["iters"])
@@ -65,7 +65,7 @@ def _check_two_ranks(kind, oracle, mode):
         assert d < (1e-8 if int(its5[k][0]) == refb["iters"] and osolver != oracle.BICGSTAB else 2e-5), (k, d)
         # ... and the P-way count differs from the 1-way one where the block structure matters (so the check is not vacuous)
     ref1 = oracle.solve(rp, ci, va, b, solver=oracle.GMRES, precond=oracle.PC_ILU0, max_iter=500)
-    assert oracle.solve(rp, ci, va, b, solver=oracle.GMRES, precond=oracle.PC_ILU0, max_iter=500, nblocks=2)["iters"] >= ref1["iters"]
+    assert oracle.solve(rp, ci, va, b, solver=oracle.GMRES, precond=oracle.PC_ILU0, max_iter=500, nblocks=world)["iters"] >= ref1["iters"]
     # mixed precision on Global objects (no reference counterpart, SURVEY.md headline 6): pinned by the
     # 1-process MixedPrecisionDC oracle -- same outer iteration count +-1, same solution
     refm = oracle.solve_mixed(rp, ci, va, b, outer={}, inner=dict(solver=oracle.CG, precond=oracle.PC_JACOBI,
@@ -79,6 +79,17 @@ def _check_two_ranks(kind, oracle, mode):
 @pytest.mark.parametrize("kind", ["poisson_slab", "gr3030", "random"])
 def test_two_ranks_one_gpu(kind, oracle):
     _check_two_ranks(kind, oracle, "gpu")
+
+
+@pytest.mark.parametrize("kind", ["random", "poisson_slab"])
+def test_four_ranks_allgather_halo(kind, oracle):
+    """The halo exchange as ONE all-gather of equally padded boundary buffers (the form a rank with more than four
+    neighbours selects; forced here: RAMD_COMM_HALO=allgather) on a 4-way row split of a general sparse matrix -- every
+    rank has up to three peers with pieces of different lengths, the random one's pattern couples all of them.  Through
+    the callback transport (4 processes on one GPU): plan table exchange, padded gather, index pick; every check of the
+    2-rank test (SpMV, CG+Jacobi, BlockJacobi legs against the oracle's nblocks=4 mode, mixed precision).
+    Replaces the per-neighbour MPI_Isend/Irecv of src/base/parallel_manager.cpp:726-782."""
+    _check_two_ranks(kind, oracle, "gpu", world=4, env={"RAMD_COMM_HALO": "allgather"})
 
 
 @pytest.mark.parametrize("kind", ["poisson_slab", "gr3030", "random"])

@@ -958,7 +958,7 @@ def test_fused_mgs_block_rejects_bad_arguments(ra):
     assert lib.ramd_fused_mgs_block(w._h, None, 0, 0, 0, hs, K + 1, 0) != 0         # block too long
     assert lib.ramd_fused_mgs_block(w._h, hs, K - 1, 0, 40, hs, 2, 90) != 0         # a followed block must be full
     assert lib.ramd_fused_mgs_block(w._h, hs, K, 0, 40, hs, K, 44) != 0             # overlapping slot areas
-    assert lib.ramd_fused_mgs_block(w._h, None, 0, 0, 0, hs, K, 120) != 0           # sums beyond the record
+    assert lib.ramd_fused_mgs_block(w._h, None, 0, 0, 0, hs, K, 376) != 0           # sums beyond the record (384 slots)
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 255, 257, 1023])
@@ -1086,11 +1086,11 @@ def test_csr_row_patterns_give_up_quickly_on_a_large_unstructured_matrix(ra, ora
     eq(y.numpy(), oracle.csr_apply(rp, ci, va, xh))
 
 
-@pytest.mark.parametrize("variant", ["RAMD_CSR_Q4=1", "RAMD_CSR_PAT=1", "RAMD_CSR_PAT=1,RAMD_CSR_XL=0", "RAMD_CSR_PAT=0"])
+@pytest.mark.parametrize("variant", ["RAMD_CSR_Q4=1", "RAMD_CSR_PAT=1", "RAMD_CSR_PAT=1,RAMD_CSR_XL=1", "RAMD_CSR_PAT=0"])
 def test_spmv_variants_forced_in_a_fresh_process(variant):
     """the CSR SpMV has an opt-in four-lanes-per-row walk (k_csr_q4), and CSR / ELL / HYB products and the multi-colour
-    sweeps rebuild the columns of structured matrices from row patterns (by default only from 2^20 entries on; the CSR
-    product then stages the x pieces its 256-row blocks need in LDS, k_csr_xl, or -- RAMD_CSR_XL=0 -- gathers x); each forced
+    sweeps rebuild the columns of structured matrices from row patterns (by default only from 2^20 entries on; with RAMD_CSR_XL=1
+    the CSR product stages the x pieces its 256-row blocks need in LDS, k_csr_xl, instead of gathering x); each forced
     on (or off) for EVERY matrix of the SpMV / ApplyAdd / fused-dot / Jacobi-sweep / format / multi-colour / solver-history
     tests: results must not change (bit-exact: same values, same order)"""
     import subprocess
@@ -1106,3 +1106,70 @@ def test_spmv_variants_forced_in_a_fresh_process(variant):
                                     "and not fresh_process"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_scalar_programs_and_guarded_combines(ra, dtype):
+    """The device-resident scalar algebra of the recurrence-based drivers (ramd_scalars_eval, ramd_vec_combine_s):
+    a program on the record gives what the host would compute with the same operations in the same order (IEEE double, or
+    float for float drivers: hip_vector.cpp returns scalars to the host, the drivers of src/solvers/krylov do this
+    arithmetic there); a combine is the reference's AddScale / ScaleAdd / ScaleAdd2 expression with the coefficient read
+    from a slot (bit-exact against the kernels taking the coefficient by value); a raised flag turns later combines into
+    no-ops."""
+    import ctypes as C
+    from rocalution_amd import capi
+    lib = capi.load()
+
+    class Sop(C.Structure):
+        _fields_ = [("op", C.c_int), ("dst", C.c_int), ("a", C.c_int), ("b", C.c_int), ("imm", C.c_double)]
+    SET, MOV, ADD, SUB, MUL, DIV, NEG, SQRT, ABS, ZFLAG = range(10)
+    single = 1 if dtype == np.float32 else 0
+    T = np.float32 if single else np.float64
+    base = 200
+    prog = [(SET, 0, -1, -1, 3.7), (SET, 1, -1, -1, -1.3), (DIV, 2, 0, 1, 0), (MUL, 3, 2, 2, 0), (SET, 4, -1, -1, 1.0),
+            (ADD, 5, 4, 3, 0), (SQRT, 5, 5, -1, 0), (DIV, 6, 4, 5, 0), (NEG, 7, 6, -1, 0), (SUB, 8, 7, 0, 0), (ABS, 9, 8, -1, 0),
+            (MOV, 10, 9, -1, 0), (SET, 11, -1, -1, 0.0), (ZFLAG, 11, 10, -1, 0), (SET, 12, -1, -1, 0.0), (ZFLAG, 13, 12, -1, 0)]
+    capi.check(lib.ramd_scalars_set(base + 13, 0.0))
+    arr = (Sop * len(prog))(*[Sop(o, base + d, (base + a) if a >= 0 else -1, (base + b) if b >= 0 else -1, imm) for o, d, a, b, imm in prog])
+    capi.check(lib.ramd_scalars_eval(arr, len(prog), single))
+    out = (C.c_double * 14)()
+    capi.check(lib.ramd_scalars_fetch(out, base, 14))
+    s = [T(0)] * 14
+    s[0], s[1] = T(3.7), T(-1.3)
+    s[2] = T(s[0] / s[1]); s[3] = T(s[2] * s[2]); s[4] = T(1.0); s[5] = T(np.sqrt(T(s[4] + s[3]))); s[6] = T(s[4] / s[5])
+    s[7] = T(-s[6]); s[8] = T(s[7] - s[0]); s[9] = T(abs(s[8])); s[10] = s[9]
+    assert [out[k] for k in range(11)] == [float(v) for v in s[:11]]
+    assert out[11] == 0.0 and out[13] == 1.0  # flag only where the tested slot is zero
+    # combines: coefficient from a slot == coefficient by value
+    n = 100003
+    rng = np.random.default_rng(11)
+    hx, hy, hz = (rng.uniform(-1, 1, n).astype(dtype) for _ in range(3))
+    coef = float(out[2])
+    V = lambda h: ra.LocalVector(dtype, data=h)
+
+    def combine(x, terms, guard=-1):
+        vs = (capi.vec_t * len(terms))(*[t[0]._h for t in terms])
+        sl = (C.c_int * len(terms))(*[t[1] for t in terms])
+        fa = (C.c_double * len(terms))(*[t[2] for t in terms])
+        capi.check(lib.ramd_vec_combine_s(x._h, len(terms), vs, sl, fa, guard))
+    x, y, z = V(hx), V(hy), V(hz)
+    ref = V(hx); ref.AddScale(y, -coef)
+    combine(x, [(x, -1, 1.0), (y, base + 2, -1.0)])
+    assert np.array_equal(x.numpy(), ref.numpy())
+    x = V(hx); ref = V(hx); ref.ScaleAdd(coef, y)
+    combine(x, [(x, base + 2, 1.0), (y, -1, 1.0)])
+    assert np.array_equal(x.numpy(), ref.numpy())
+    x = V(hx); ref = V(hx); ref.ScaleAdd2(coef, y, float(out[6]), z, -1.0)
+    combine(x, [(x, base + 2, 1.0), (y, base + 6, 1.0), (z, -1, -1.0)])
+    assert np.array_equal(x.numpy(), ref.numpy())
+    x = V(hx); ref = V(hx); ref.Scale(coef)
+    combine(x, [(x, base + 2, 1.0)])
+    assert np.array_equal(x.numpy(), ref.numpy())
+    # guarded: slot base+13 holds 1 -> nothing happens; slot base+11 holds 0 -> the update runs
+    x = V(hx)
+    combine(x, [(x, -1, 1.0), (y, base + 2, 1.0)], guard=base + 13)
+    assert np.array_equal(x.numpy(), hx)
+    combine(x, [(x, -1, 1.0), (y, base + 2, 1.0)], guard=base + 11)
+    ref = V(hx); ref.AddScale(y, coef)
+    assert np.array_equal(x.numpy(), ref.numpy())

@@ -4,8 +4,12 @@ not exist on the GPU box and nothing in the product or the tests imports this).
 
     python tools/copycheck.py include/rocalution/solvers.hpp [--by-class] [--show CLASS]
 
-A line counts when, stripped of whitespace, it is >= 25 characters and not a comment; it is "verbatim" when the same
-stripped line occurs anywhere under /root/reference/src.  Reported per class (text between `class X` headers): share of
+A line counts when, NORMALISED, it is >= 20 characters and not a comment; it is "verbatim" when the same normalised line
+occurs anywhere under /root/reference/src.  Normalisation (round 3; the round-2 version compared exact lines and a rename
+hid a copy): whitespace and `this->` removed, and on BOTH sides the naming conventions are folded onto one spelling --
+member prefixes / suffixes (m_foo, foo_ -> foo), the helpers this repo uses for the reference's idioms (RAMD_EXPECT -> assert,
+num<ValueType>( -> static_cast<ValueType>(, say( -> LOG_INFO( ), hook names (doFoo -> Foo, Foo_ -> Foo) and the k-prefixed
+local vector names (kr -> r).  Reported per class (text between `class X` headers): share of
 verbatim lines and the longest in-order run of consecutive counted lines that are consecutive counted lines of ONE
 reference file.
 """
@@ -17,6 +21,13 @@ REF = "/root/reference/src"
 
 
 def norm(l):
+    l = l.replace("this->", "")
+    l = re.sub(r"\bRAMD_EXPECT\(", "assert(", l)
+    l = re.sub(r"\bnum<(\w+)>\(", r"static_cast<\1>(", l)
+    l = re.sub(r"\bm_(\w+)", r"\1", l)          # m_foo -> foo
+    l = re.sub(r"\b([A-Za-z]\w*?)_\b", r"\1", l)  # foo_ -> foo
+    l = re.sub(r"\bdo([A-Z]\w*)", r"\1", l)      # doSolvePrecond -> SolvePrecond
+    l = re.sub(r"\bk([a-z]\w{0,2})\b", r"\1", l)  # kr, kz, kp, kq, kv, kt -> r, z, ...
     return re.sub(r"\s+", "", l)
 
 
@@ -25,7 +36,7 @@ def counted(l):
     if s.startswith("//") or s.startswith("/*") or s.startswith("*"):
         return None
     s = norm(s)
-    return s if len(s) >= 25 else None
+    return s if len(s) >= 20 else None
 
 
 def load_ref():

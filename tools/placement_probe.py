@@ -17,6 +17,10 @@ for k in range(NV):
 
 
 addr = [lib.ramd_vec_data(v._h) for v in vs]
+cls = []
+for v in vs:
+    c = C.c_int(-9); capi.check(lib.ramd_vec_placement_class(v._h, C.byref(c))); cls.append(c.value)
+print("placement classes:", cls, flush=True)
 print("addresses:", " ".join("%x" % a for a in addr))
 print("offsets to vector 0 in MiB:", " ".join("%.3f" % ((a - addr[0]) / 2**20) for a in addr), flush=True)
 
@@ -47,5 +51,12 @@ for rep in range(1):
         r, q, d, z = (vs[i] for i in g)
         capi.check(lib.ramd_scalars_set(1, 1.0)); capi.check(lib.ramd_scalars_set(2, 1e30))
         ms = timed(lambda: capi.check(lib.ramd_fused_cg_update(r._h, q._h, d._h, z._h, 1, 2, 3, 4)))
-        out.append("%s %.0f" % (g, 5 * n * 8 / ms / 1e6))
+        out.append("%s[r%d z%d] %.0f" % (g, cls[g[0]], cls[g[3]], 5 * n * 8 / ms / 1e6))
     print("cg_update GB/s:", " | ".join(out), flush=True)
+    vals = [float(o.split()[-1]) for o in out[:-1]]
+    same = [float(o.split()[-1]) for o, g in zip(out[:-1], groups) if cls[g[0]] == cls[g[3]]]
+    diff = [float(o.split()[-1]) for o, g in zip(out[:-1], groups) if cls[g[0]] != cls[g[3]]]
+    print("r and z in the SAME class: %s | in DIFFERENT classes: %s" % (" ".join("%.0f" % v for v in same), " ".join("%.0f" % v for v in diff)), flush=True)
+    print("cg_update min %.0f max %.0f mean %.0f  (arena phase %s MiB mod %s MiB, arena %s)" % (min(vals), max(vals), sum(vals) / len(vals),
+          __import__("os").environ.get("RAMD_ARENA_PHASE_MB", "32"), __import__("os").environ.get("RAMD_ARENA_MOD_MB", "512"),
+          __import__("os").environ.get("RAMD_ALLOC_ARENA", "1")), flush=True)
