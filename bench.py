@@ -395,10 +395,15 @@ def main():
         x = ra.LocalVector(); x.Allocate("x", n)
         A.Apply(ones, rhs)
 
-        def run(iters, solver_cls=S.CG, pc_cls=S.Jacobi, basis=None, warm=0):
+        CH = (PROF_SPMV, PROF_TRSV, PROF_VEC, PROF_PRECOND)
+
+        def run(iters, solver_cls=S.CG, pc_cls=S.Jacobi, basis=None, warm=0, prof_iters=0):
             """one Solve of warm + iters iterations; warm > 0: the clock starts when iteration `warm` has been checked
             and the device drained (ramd_solver_set_time_mark), so the timed region is exactly `iters` iterations and
-            the solver's preamble (initial residual, first direction) falls into the warm-up"""
+            the solver's preamble (initial residual, first direction) falls into the warm-up.
+            prof_iters > 0: afterwards a SECOND Solve of that many iterations on the SAME built solver (same work vectors,
+            same placement) with every SpMV / triangular-solve / fused-vector / preconditioner launch bracketed by HIP
+            events on its stream -> the fifth value returned (dict channel -> statistics)"""
             if A.GetFormat() != ra.CSR:  # preconditioners are built from the CSR state
                 regen()
             ls = solver_cls()
@@ -430,15 +435,27 @@ def main():
             assert dt > 0, "the marked iteration was not reached"
             it = ls.GetIterationCount() - warm
             res = ls.GetCurrentResidual()
+            pr = None
+            if prof_iters > 0:
+                ls.Init(NEVER[0], NEVER[1], NEVER[2], prof_iters)
+                ls.SetTimeMark(-1)
+                x.Zeros()
+                for ch in CH:
+                    capi.check(lib.ramd_prof_enable(ch, 1))
+                ls.Solve(rhs, x)
+                ra.sync()
+                pr = {ch: prof_get(lib, capi, ch) for ch in CH}
+                for ch in CH:
+                    capi.check(lib.ramd_prof_enable(ch, 0))
             ls.Clear()
-            return dt, it, res, tb
+            return dt, it, res, tb, pr
 
         HEAD = {"cg": S.CG, "gmres": S.GMRES, "bicgstab": S.BiCGStab}.get(args.solver, S.CG)
         HPC = {"none": None, "jacobi": S.Jacobi, "ilu0": S.ILU, "mcsgs": S.MultiColoredSGS,
                "mcgs": S.MultiColoredGS, "mcilu": S.MultiColoredILU, "ic": S.IC, "sgs": S.SGS, "uaamg": S.UAAMG, "saamg": S.SAAMG}[args.precond]
         basis = 30 if args.solver == "gmres" else None
         if mixed:
-            def run(iters, *_a, warm=0):  # noqa: F811  (config 5 on one GPU)
+            def run(iters, *_a, warm=0, prof_iters=0):  # noqa: F811  (config 5 on one GPU)
                 inner = S.CG(np.float32)
                 if HPC is not None:
                     inner.SetPreconditioner(HPC())
@@ -453,26 +470,25 @@ def main():
                 dt = mp.GetSecondsSinceTimeMark() if warm > 0 else time.perf_counter() - t0
                 assert dt > 0, "the marked iteration was not reached"
                 r = (dt, mp.GetIterationCount() - warm, mp.GetCurrentResidual(), 0.0)
+                pr = None
+                if prof_iters > 0:
+                    mp.Init(NEVER[0], NEVER[1], NEVER[2], prof_iters)
+                    mp.SetTimeMark(-1)
+                    x.Zeros()
+                    for ch in CH:
+                        capi.check(lib.ramd_prof_enable(ch, 1))
+                    mp.Solve(rhs, x)
+                    ra.sync()
+                    pr = {ch: prof_get(lib, capi, ch) for ch in CH}
+                    for ch in CH:
+                        capi.check(lib.ramd_prof_enable(ch, 0))
                 mp.Clear()
-                return r
+                return r + (pr,)
         # W untimed warm-up iterations, then EXACTLY K timed ones, in one Solve (see run); --warmup 0 times the whole Solve
-        dt, it, res, tbuild = run(K, HEAD, HPC, basis, warm=W)
+        # --- timed leg, then the roofline leg: the same built solver solves again with every SpMV / triangular-solve /
+        # fused-vector launch bracketed by HIP events on the stream it runs on
+        dt, it, res, tbuild, pr0 = run(K, HEAD, HPC, basis, warm=W, prof_iters=(min(K, 20) if mixed else min(K, 200)))
         assert it == K, (it, K)
-        # --- roofline leg: the SAME solver run again with every SpMV / triangular-solve / fused-vector launch
-        # bracketed by HIP events on the stream it runs on
-        CH = (PROF_SPMV, PROF_TRSV, PROF_VEC, PROF_PRECOND)
-
-        def profiled(iters, *a):
-            """the solver run again with every launch of the channels bracketed by HIP events on its stream"""
-            for ch in CH:
-                capi.check(lib.ramd_prof_enable(ch, 1))
-            run(iters, *a)
-            r = {ch: prof_get(lib, capi, ch) for ch in CH}
-            for ch in CH:
-                capi.check(lib.ramd_prof_enable(ch, 0))
-            return r
-
-        pr0 = profiled(min(K, 20) if mixed else min(K, 200), HEAD, HPC, basis)
         p_spmv, p_trsv, p_vec = pr0[PROF_SPMV], pr0[PROF_TRSV], pr0[PROF_VEC]
         vb = 4 if mixed else 8  # the launches of a mixed-precision run are (all but a handful) the fp32 inner SpMVs
         if args.format == "csr":
@@ -519,12 +535,11 @@ def main():
                                                  (32 if args.solver == "gmres" else 40) * n * vb // 8, p_vec)
         st_pat = C.c_int(0)
         capi.check(lib.ramd_mat_pattern_info(A._h, C.byref(st_pat), None, None))
-        if st_pat.value == 1 and not mixed and args.format in ("csr", "ell", "hyb"):
+        if st_pat.value in (1, 2) and not mixed and args.format in ("csr", "ell", "hyb"):
             # the SAME run with the columns read (the general path every unstructured matrix takes): its own timed
             # K iterations and its own HIP-event average; the row-pattern figure above stays the headline
             A.UseRowPatterns(False)
-            d3, i3, _, _ = run(K, HEAD, HPC, basis, warm=W)
-            pr3 = profiled(min(K, 200), HEAD, HPC, basis)
+            d3, i3, _, _, pr3 = run(K, HEAD, HPC, basis, warm=W, prof_iters=min(K, 200))
             A.UseRowPatterns(True)
             ck = "spmv_csr_512_columns_read" if tkey == "spmv_csr_512" else None
             cols_read = dict(iters_per_s=round(i3 / d3, 3), ms_per_step=round(d3 / i3 * 1e3, 5),
@@ -536,11 +551,10 @@ def main():
             for name, sc, pc, bs, iters in (("gmres30_ilu0", S.GMRES, S.ILU, 30, min(K, 60)),
                                             ("bicgstab_mcsgs", S.BiCGStab, S.MultiColoredSGS, None, min(K, 60))):
                 try:
-                    d2, i2, r2, tb2 = run(iters, sc, pc, bs, warm=min(W, 10))
+                    d2, i2, r2, tb2, pe = run(iters, sc, pc, bs, warm=min(W, 10), prof_iters=iters)
                     extras[name] = dict(iters_per_s=round(i2 / d2, 2), iters=i2, ms_per_step=round(d2 / i2 * 1e3, 4),
                                         build_s=round(tb2, 3))
                     # first-class evidence: the dominant kernel of the leg with its own HIP-event average
-                    pe = profiled(iters, sc, pc, bs)
                     big = (args.matrix == "poisson" and N == 512)
                     if name == "gmres30_ilu0" and pe[PROF_TRSV]["launches"] > 0:
                         extras[name]["roofline"] = roof("sparse triangular solve (k_trsv_rec), one launch per triangle",

@@ -65,20 +65,35 @@ struct fatal_error : public std::runtime_error
     {
     }
 };
-[[noreturn]] inline void _fatal(const char* file, int line)
+// (two functions with two names -- one inline function with two bodies would be an ODR violation as soon as a throwing and
+//  an exiting translation unit met in one program)
+[[noreturn]] inline void _fatal_throw(const char* file, int line)
 {
-#ifdef RAMD_FATAL_THROWS
     throw fatal_error(file, line);
-#else
+}
+[[noreturn]] inline void _fatal_exit(const char* file, int line)
+{
     std::cout << "Fatal error - the program will be terminated" << std::endl;
     std::cout << "File: " << file << "; line: " << line << std::endl;
     exit(1);
-#endif
 }
-#define FATAL_ERROR(file, line) ::rocalution::_fatal(file, line)
-#define RAMD_DIE() ::rocalution::_fatal(__FILE__, __LINE__)
-// asserts stay active in release builds, as in the reference (src/utils/def.hpp:50-58)
-#define RAMD_EXPECT(cond) assert(cond)
+#ifdef RAMD_FATAL_THROWS
+#define FATAL_ERROR(file, line) ::rocalution::_fatal_throw(file, line)
+#else
+#define FATAL_ERROR(file, line) ::rocalution::_fatal_exit(file, line)
+#endif
+#define RAMD_DIE() FATAL_ERROR(__FILE__, __LINE__)
+// precondition checks stay active in release builds, as the reference's asserts do (src/utils/def.hpp:50-58), also
+// under -DNDEBUG, and fail through the same channel as every other fatal error (a status code behind the C ABI, not abort())
+#define RAMD_EXPECT(cond)                  \
+    do                                     \
+    {                                      \
+        if(!(cond))                        \
+        {                                  \
+            std::cout << "Assertion failed: " << #cond << std::endl; \
+            RAMD_DIE();                    \
+        }                                  \
+    } while(0)
 
 // one log line from any number of streamable pieces
 inline void say_more(void) {}
@@ -297,21 +312,14 @@ public:
         else
             this->Allocate(name, size);
     }
-    // ... and for a vector that is already allocated: moved (contents kept) if it shares `other`'s class
+    // ... and for a vector that is already allocated: the pair is measured, the vector moves (contents kept) where a
+    // candidate block pairs clearly better with `other` (ramd_vec_place_apart)
     void PlaceApartFrom(const LocalVector<ValueType>& other)
     {
         if(!this->on_accel_ || !other.on_accel_ || this->dev_ == nullptr || other.dev_ == nullptr || &other == this)
             return;
-        int mine = -1, theirs = -1;
-        RAMD_CHECK(ramd_vec_placement_class(this->dev_, &mine));
-        RAMD_CHECK(ramd_vec_placement_class(other.dev_, &theirs));
-        if(mine < 0 || theirs < 0 || mine != theirs)
-            return;
-        LocalVector<ValueType> moved;
-        moved.CloneBackend(*this);
-        moved.AllocateApart(this->name_, this->GetSize(), other);
-        moved.CopyFrom(*this);
-        std::swap(this->dev_, moved.dev_);
+        int moved = 0;
+        RAMD_CHECK(ramd_vec_place_apart(this->dev_, other.dev_, &moved));
     }
     void Clear(void)
     {

@@ -277,11 +277,47 @@ public:
             say("ParallelManager file " + name + " belongs to another rank");
             RAMD_DIE();
         }
+        // a pattern written by the reference may name a rank as sender only or as receiver only (unsymmetric matrices): the
+        // exchange here pairs every send with a receive, so the two lists become their union with empty pieces
+        if(nrecv >= 0 && nsend >= 0 && this->recvs_ != this->sends_)
+            this->doUnitePeers();
         if(nrecv < 0 || nsend < 0 || bsize < 0 || !this->Status())
             {
                 say("incomplete ParallelManager file: " + name);
                 RAMD_DIE();
             }
+    }
+    // receivers and senders -> one ascending peer list; a peer missing on one side gets an empty piece there.  The order of
+    // the non-empty pieces (receive buffer = column numbering of the ghost matrix, boundary index) does not change, which
+    // needs both lists ascending as the reference writes them.
+    void doUnitePeers(void)
+    {
+        if(!std::is_sorted(this->recvs_.begin(), this->recvs_.end()) || !std::is_sorted(this->sends_.begin(), this->sends_.end())
+           || this->recv_offset_.size() != this->recvs_.size() + 1 || this->send_offset_.size() != this->sends_.size() + 1)
+            return; // (Status() reports it)
+        std::vector<int> all(this->recvs_);
+        all.insert(all.end(), this->sends_.begin(), this->sends_.end());
+        std::sort(all.begin(), all.end());
+        all.erase(std::unique(all.begin(), all.end()), all.end());
+        auto spread = [&](const std::vector<int>& have, const std::vector<int64_t>& off) {
+            std::vector<int64_t> out(1, 0);
+            size_t               k = 0;
+            for(int p : all)
+            {
+                int64_t len = 0;
+                if(k < have.size() && have[k] == p)
+                {
+                    len = off[k + 1] - off[k];
+                    ++k;
+                }
+                out.push_back(out.back() + len);
+            }
+            return out;
+        };
+        this->recv_offset_ = spread(this->recvs_, this->recv_offset_);
+        this->send_offset_ = spread(this->sends_, this->send_offset_);
+        this->recvs_       = all;
+        this->sends_       = all;
     }
     const std::vector<int>& peers(void) const
     {

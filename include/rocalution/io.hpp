@@ -104,6 +104,13 @@ bool LocalMatrix<ValueType>::ReadFileMTX(const std::string& filename)
         say("ReadFileMTX: invalid matrix data (sizes ", nrow, " x ", ncol, ", ", nnz, " entries)");
         RAMD_DIE();
     }
+    // every entry takes at least "1 1\n" in the file: a header count the rest of the file cannot hold is a damaged file, not
+    // an allocation request
+    if(nnz > (long long)(end - p) / 4 + 1)
+    {
+        say("ReadFileMTX: invalid matrix data (", nnz, " entries announced, ", (long long)(end - p), " bytes left in the file)");
+        RAMD_DIE();
+    }
     std::vector<int>       row((size_t)nnz), col((size_t)nnz);
     std::vector<ValueType> val((size_t)nnz);
     char*                  q = const_cast<char*>(p);

@@ -1451,26 +1451,48 @@ template <class OperatorType, class VectorType, typename ValueType>
 class Recurrence
 {
 public:
-    enum { kBankFirst = 64, kBankSize = 96 }; // (two banks: [64, 160) and [160, 256); the fused loops use the slots below 64
-                                              //  and the top of the record)
+    // layout of the device record: [0, 64) the fused loops; [64, 160) and [160, 256) two banks for nested drivers;
+    // [256, 440) eight slots per multigrid level (the cycles keep their scalars per level across the recursion);
+    // from 440 on the Gram-Schmidt sums of GMRES and the scratch of the blocking vector API
+    enum { kBankFirst = 64, kBankSize = 96, kGridFirst = 256, kGridSpan = 8, kGridLevels = 23 };
+    // a driver: the next free bank
     explicit Recurrence(const OperatorType& A, int nscalars)
         : m_op(A)
         , m_single(sizeof(ValueType) == 4)
+        , m_span(kBankSize)
+        , m_nested(true)
     {
         RAMD_EXPECT(nscalars + 2 <= kBankSize);
         m_base = kBankFirst + kBankSize * depth_()++;
-        if(m_base + kBankSize > RAMD_NSCALARS)
+        if(m_base + kBankSize > kGridFirst)
         {
             say("Recurrence: drivers nested deeper than the scalar record allows");
             RAMD_DIE();
         }
-        m_guard = m_base + kBankSize - 1; // the breakdown flag of this driver
-        m_tmp   = m_base + kBankSize - 2;
+        m_guard = m_base + m_span - 1; // the breakdown flag of this driver
+        this->Set(-1, 0.0);
+    }
+    // a multigrid cycle: the slots of its level
+    Recurrence(const OperatorType& A, int nscalars, int grid_level)
+        : m_op(A)
+        , m_single(sizeof(ValueType) == 4)
+        , m_span(kGridSpan)
+        , m_nested(false)
+    {
+        RAMD_EXPECT(nscalars + 1 <= kGridSpan);
+        if(grid_level < 0 || grid_level >= kGridLevels)
+        {
+            say("Recurrence: more multigrid levels than the scalar record has room for");
+            RAMD_DIE();
+        }
+        m_base  = kGridFirst + kGridSpan * grid_level;
+        m_guard = m_base + m_span - 1;
         this->Set(-1, 0.0);
     }
     ~Recurrence()
     {
-        --depth_();
+        if(m_nested)
+            --depth_();
     }
     Recurrence(const Recurrence&) = delete;
     Recurrence& operator=(const Recurrence&) = delete;
@@ -1487,6 +1509,7 @@ public:
     void FlagIfZero(int a) { push_(RAMD_SOP_ZFLAG, -1, a, -2, 0.0); }
     void FlagIfBad(int a) { push_(RAMD_SOP_BADFLAG, -1, a, -2, 0.0); } // zero, NaN or infinite
     void ClearFlag(void) { this->Set(-1, 0.0); }
+    void OneIfZero(int d, int a) { push_(RAMD_SOP_ZFLAG, d, a, -2, 0.0); } // d = 1 where a == 0 (else unchanged)
     void MovIfLess(int d, int a, int b, int src) { push_(RAMD_SOP_CMOVLT, d, a, b, (double)map_(src)); } // if a < b: d = src
 
     // ---- reductions into slots
@@ -1551,12 +1574,12 @@ public:
     {
         this->Flush();
         double buf[kBankSize];
-        RAMD_EXPECT(first >= 0 && count >= 1 && first + count <= kBankSize - 2);
-        // (one copy of the bank's tail: the values and the flag travel together)
-        RAMD_CHECK(ramd_scalars_fetch(buf, m_base, kBankSize));
+        RAMD_EXPECT(first >= 0 && count >= 1 && first + count <= m_span - 1);
+        // (one copy of the bank: the values and the flag travel together)
+        RAMD_CHECK(ramd_scalars_fetch(buf, m_base, m_span));
         for(int k = 0; k < count; ++k)
             out[k] = buf[first + k];
-        return buf[kBankSize - 1] != 0.0;
+        return buf[m_span - 1] != 0.0;
     }
     double Fetch(int slot, bool* broke = nullptr)
     {
@@ -1607,7 +1630,9 @@ private:
     }
     const OperatorType&     m_op;
     bool                    m_single;
-    int                     m_base, m_guard, m_tmp;
+    int                     m_span;
+    bool                    m_nested;
+    int                     m_base, m_guard;
     std::vector<ramd_sop_t> m_prog;
 };
 
@@ -1636,6 +1661,7 @@ public:
             this->m_precond->Build();
         }
         this->m_w.Create(*this->m_op, this->doWorkVectors(this->m_precond != NULL), "krylov work vector");
+        this->m_placed = false;
         this->doAfterBuild();
     }
     virtual void Clear(void)
@@ -1697,7 +1723,16 @@ protected:
         (void)K.Fetch(slot, broke);
         return std::abs((double)this->doNorm(v));
     }
+    // placement of vector pairs a fused update writes in one pass (LocalVector::PlaceApartFrom: measured, a few
+    // milliseconds): once per Build, at the first Solve, when the solution vector is known
+    bool doPlaceOnce(void)
+    {
+        const bool first = !this->m_placed;
+        this->m_placed   = true;
+        return first;
+    }
     WorkVectors<VectorType> m_w;
+    bool                    m_placed = false;
 };
 
 // ============================================================================ CG
@@ -1730,9 +1765,12 @@ protected:
         VectorType *r = this->W(0), *p = this->W(1), *q = this->W(2), *z = precond ? this->W(3) : r;
         // placement (no arithmetic): the residual update writes r and z in one pass, the direction update x and p -- each
         // pair streams faster from different placement classes (csrc/backend.hip); a no-op for small or already-apart blocks
-        if(precond)
-            z->PlaceApartFrom(*r);
-        p->PlaceApartFrom(*x);
+        if(this->doPlaceOnce())
+        {
+            if(precond)
+                z->PlaceApartFrom(*r);
+            p->PlaceApartFrom(*x);
+        }
         Engine K(*this->m_op, sCount);
         this->doDefect(rhs, *x, r);
         if(this->m_iter_ctrl.InitResidual(this->doResidual(K, sRes, *r)) == false)
@@ -2194,7 +2232,8 @@ protected:
         enum { sRes, sRho, sRhoOld, sR0Q, sTR, sTT, sAlpha, sOmega, sBeta, sT, sU, sCount }; // (sRes, sRho: read together)
         VectorType *r = this->W(0), *shadow = this->W(1), *p = this->W(2), *q = this->W(3), *t = this->W(4);
         VectorType *v = precond ? this->W(5) : NULL, *z = precond ? this->W(6) : NULL;
-        r->PlaceApartFrom(*x); // (placement only: the fused update writes x and r in one pass)
+        if(this->doPlaceOnce())
+            r->PlaceApartFrom(*x); // (placement only: the fused update writes x and r in one pass)
         Engine K(*this->m_op, sCount);
         this->doDefect(rhs, *x, shadow);
         if(this->m_iter_ctrl.InitResidual(this->doResidual(K, sRes, *shadow)) == false)
@@ -3237,6 +3276,10 @@ private:
 // BaseMultiGrid (src/solvers/multigrid/base_multigrid.cpp): V / W / K cycles over a user- or AMG-built hierarchy of
 // operators, restriction / prolongation operators, per-level smoothers and a coarse solver; optional scaling of the
 // coarse correction (:790-812, :873-905).  Host levels (SetHostLevels) do not exist here: every level lives on the GPU.
+// Layout: one GridLevel per level -- its operator, the transfer operators towards the next level, its smoother and the
+// vectors a cycle needs there -- instead of one array per kind of object; the cycle takes the level as an argument.  The
+// scalars of a cycle (the scaling quotients <b, x> / <A x, x>, the rho / alpha of the K-cycle) stay on the device, in the
+// eight slots the record reserves per level: a cycle used as a preconditioner never makes the host wait.
 enum _cycle
 {
     Vcycle = 0,
@@ -3246,27 +3289,42 @@ enum _cycle
 };
 
 template <class OperatorType, class VectorType, typename ValueType>
+struct GridLevel
+{
+    const OperatorType* A         = nullptr; // operator of this level (level 0: the solver's own)
+    OperatorType*       to_coarse = nullptr; // restriction onto the next level (none on the coarsest)
+    OperatorType*       to_fine   = nullptr; // prolongation from the next level
+    IterativeLinearSolver<OperatorType, VectorType, ValueType>* relax = nullptr;
+    std::unique_ptr<VectorType> corr; // correction computed on this level for the level above (levels >= 1)
+    std::unique_ptr<VectorType> rhs; // ... and its right-hand side: the restricted defect; level 0: scratch
+    std::unique_ptr<VectorType> defect; // b - A x of this level, then the prolonged correction
+    std::unique_ptr<VectorType> keep; // scaling: the defect before the coarse correction (level 0) / A times the correction
+    std::unique_ptr<VectorType> kdir; // K-cycle: A times the search direction (levels 1 .. last - 1)
+    void drop_vectors(void)
+    {
+        corr.reset();
+        rhs.reset();
+        defect.reset();
+        keep.reset();
+        kdir.reset();
+    }
+};
+
+template <class OperatorType, class VectorType, typename ValueType>
 class BaseMultiGrid : public IterativeLinearSolver<OperatorType, VectorType, ValueType>
 {
 public:
+    typedef GridLevel<OperatorType, VectorType, ValueType>         Level;
+    typedef Recurrence<OperatorType, VectorType, ValueType>        Engine;
+    typedef IterativeLinearSolver<OperatorType, VectorType, ValueType> Smoother;
     BaseMultiGrid()
         : m_levels(-1)
-        , m_current_level(0)
         , m_scaling(false)
         , m_iter_pre_smooth(1)
         , m_iter_post_smooth(1)
         , m_cycle(Vcycle)
         , m_kcycle_full(true)
-        , m_op_level(NULL)
-        , m_restrict_op_level(NULL)
-        , m_prolong_op_level(NULL)
-        , m_d_level(NULL)
-        , m_r_level(NULL)
-        , m_t_level(NULL)
-        , m_s_level(NULL)
-        , m_q_level(NULL)
         , m_solver_coarse(NULL)
-        , m_smoother_level(NULL)
         , m_res_norm(num<ValueType>(0))
     {
     }
@@ -3278,16 +3336,18 @@ public:
     {
         RAMD_EXPECT(!this->m_build && levels > 0);
         this->m_levels = levels;
+        this->m_grid.resize((size_t)levels);
     }
     virtual void SetPreconditioner(Solver<OperatorType, VectorType, ValueType>&)
     {
         say("BaseMultiGrid::SetPreconditioner() Perhaps you want to set the smoothers on all levels? use " "SetSmootherLevel() instead of SetPreconditioner!");
         RAMD_DIE();
     }
-    virtual void SetSmoother(IterativeLinearSolver<OperatorType, VectorType, ValueType>** smoother)
+    virtual void SetSmoother(Smoother** smoother) // one per level but the coarsest
     {
-        RAMD_EXPECT(smoother != nullptr);
-        this->m_smoother_level = smoother;
+        RAMD_EXPECT(smoother != nullptr && this->m_levels > 0);
+        for(int l = 0; l + 1 < this->m_levels; ++l)
+            this->m_grid[(size_t)l].relax = smoother[l];
     }
     virtual void SetSmootherPreIter(int iter)
     {
@@ -3326,94 +3386,31 @@ public:
     {
         if(this->m_build)
             this->Clear();
-        for(int i = 0; i < this->m_levels - 1; ++i)
-            RAMD_EXPECT(this->m_op_level[i] != nullptr && this->m_smoother_level[i] != nullptr && this->m_restrict_op_level[i] != nullptr
-                   && this->m_prolong_op_level[i] != nullptr);
-        RAMD_EXPECT(this->m_op != nullptr && this->m_solver_coarse != nullptr && this->m_levels > 0);
-        this->Initialize();
+        RAMD_EXPECT(this->m_op != nullptr && this->m_solver_coarse != nullptr && this->m_levels > 0
+                    && (int)this->m_grid.size() == this->m_levels);
+        for(int l = 0; l + 1 < this->m_levels; ++l)
+        {
+            const Level& g = this->m_grid[(size_t)l];
+            RAMD_EXPECT(this->m_grid[(size_t)l + 1].A != nullptr && g.relax != nullptr && g.to_coarse != nullptr && g.to_fine != nullptr);
+        }
+        this->doPrepareCycle();
         this->m_build = true;
     }
     virtual void Clear(void)
     {
         if(this->m_build)
         {
-            this->Finalize();
+            this->doReleaseCycle();
+            this->m_grid.clear();
             this->m_levels = -1;
             this->m_build  = false;
         }
     }
-
-protected:
-    // base_multigrid.cpp:219-311
-    virtual void Initialize(void)
+    virtual bool SolveUsesScalarRecord(void) const
     {
-        RAMD_EXPECT(!this->m_build && this->m_smoother_level != nullptr);
-        this->m_smoother_level[0]->SetOperator(*this->m_op);
-        this->m_smoother_level[0]->Build();
-        this->m_smoother_level[0]->FlagSmoother();
-        for(int i = 1; i < this->m_levels - 1; ++i)
-        {
-            this->m_smoother_level[i]->SetOperator(*this->m_op_level[i - 1]);
-            this->m_smoother_level[i]->Build();
-            this->m_smoother_level[i]->FlagSmoother();
-        }
-        this->m_solver_coarse->SetOperator(*this->m_op_level[this->m_levels - 2]);
-        this->m_solver_coarse->Build();
-        this->m_d_level = new VectorType*[this->m_levels]();
-        this->m_r_level = new VectorType*[this->m_levels]();
-        this->m_t_level = new VectorType*[this->m_levels]();
-        this->m_d_level[0] = NULL;
-        if(this->m_scaling)
-        {
-            this->m_s_level = new VectorType*[this->m_levels]();
-            for(int i = 0; i < this->m_levels; ++i)
-                this->m_s_level[i] = this->m_new_vec(i, "temporary");
-        }
-        if(this->m_cycle == Kcycle)
-        {
-            this->m_q_level = new VectorType*[this->m_levels > 2 ? this->m_levels - 2 : 1]();
-            for(int i = 0; i < this->m_levels - 2; ++i)
-                this->m_q_level[i] = this->m_new_vec(i + 1, "q");
-        }
-        for(int i = 1; i < this->m_levels; ++i)
-        {
-            this->m_d_level[i] = this->m_new_vec(i, "defect correction");
-            this->m_r_level[i] = this->m_new_vec(i, "residual");
-            this->m_t_level[i] = this->m_new_vec(i, "temporary");
-        }
-        this->m_r_level[0] = this->m_new_vec(0, "residual");
-        this->m_t_level[0] = this->m_new_vec(0, "temporary");
-    }
-    // base_multigrid.cpp:360-425
-    virtual void Finalize(void)
-    {
-        for(int i = 0; i < this->m_levels; ++i)
-        {
-            if(i > 0 && this->m_d_level)
-                delete this->m_d_level[i];
-            if(this->m_r_level)
-                delete this->m_r_level[i];
-            if(this->m_t_level)
-                delete this->m_t_level[i];
-            if(this->m_s_level)
-                delete this->m_s_level[i];
-        }
-        if(this->m_q_level)
-            for(int i = 0; i < this->m_levels - 2; ++i)
-                delete this->m_q_level[i];
-        delete[] this->m_d_level;
-        delete[] this->m_r_level;
-        delete[] this->m_t_level;
-        delete[] this->m_s_level;
-        delete[] this->m_q_level;
-        this->m_d_level = this->m_r_level = this->m_t_level = this->m_s_level = this->m_q_level = NULL;
-        for(int i = 0; i < this->m_levels - 1; ++i)
-            this->m_smoother_level[i]->Clear();
-        this->m_solver_coarse->Clear();
-        this->m_iter_ctrl.Clear();
+        return true;
     }
 
-public:
     // base_multigrid.cpp:605-699
     virtual void Solve(const VectorType& rhs, VectorType* x)
     {
@@ -3424,20 +3421,22 @@ public:
             this->doPrintStart();
             this->m_iter_ctrl.PrintInit();
         }
-        if(this->m_is_precond == false)
-        {
-            this->m_op->Apply(*x, this->m_r_level[0]);
-            this->m_r_level[0]->ScaleAdd(num<ValueType>(-1), rhs);
-            this->m_res_norm = std::abs(this->doNorm(*this->m_r_level[0]));
-            if(this->m_iter_ctrl.InitResidual(this->m_res_norm) == false)
-                return;
-        }
-        else
+        bool go = true;
+        if(this->m_is_precond)
             this->m_iter_ctrl.InitResidual(1.0);
-        this->doVcycle(rhs, x);
-        if(this->m_is_precond == false)
-            while(!this->m_iter_ctrl.CheckResidual(this->m_res_norm, this->m_index))
-                this->doVcycle(rhs, x);
+        else
+        {
+            VectorType* d = this->m_grid[0].defect.get();
+            this->m_op->Apply(*x, d);
+            d->ScaleAdd(num<ValueType>(-1), rhs);
+            this->m_res_norm = std::abs(this->doNorm(*d));
+            go               = this->m_iter_ctrl.InitResidual(this->m_res_norm);
+        }
+        if(!go)
+            return;
+        do
+            this->doCycle(0, rhs, x);
+        while(!this->m_is_precond && !this->m_iter_ctrl.CheckResidual(this->m_res_norm, this->m_index));
         if(this->m_verb > 0)
         {
             this->m_iter_ctrl.PrintStatus();
@@ -3466,160 +3465,201 @@ protected:
         say("BaseMultiGrid: the preconditioned solve entry is disabled (use Solve)");
         RAMD_DIE();
     }
-    virtual void doRestrict(const VectorType& fine, VectorType* coarse)
+    // smoothers and coarse solver get their operators, every level its vectors (base_multigrid.cpp:219-311)
+    virtual void doPrepareCycle(void)
     {
-        this->m_restrict_op_level[this->m_current_level]->Apply(fine, coarse);
-    }
-    virtual void doProlong(const VectorType& coarse, VectorType* fine)
-    {
-        this->m_prolong_op_level[this->m_current_level]->Apply(coarse, fine);
-    }
-    // base_multigrid.cpp:720-916
-    void doVcycle(const VectorType& rhs, VectorType* x)
-    {
-        if(this->m_current_level == this->m_levels - 1)
+        const int last = this->m_levels - 1;
+        this->m_grid[0].A = this->m_op;
+        for(int l = 0; l < last; ++l)
         {
-            this->m_solver_coarse->SolveZeroSol(rhs, x);
-            return;
+            Level& g = this->m_grid[(size_t)l];
+            g.relax->SetOperator(*g.A);
+            g.relax->Build();
+            g.relax->FlagSmoother();
         }
-        IterativeLinearSolver<OperatorType, VectorType, ValueType>* smoother = this->m_smoother_level[this->m_current_level];
-        const OperatorType* op = (this->m_current_level == 0) ? this->m_op : this->m_op_level[this->m_current_level - 1];
-        VectorType*         r  = this->m_r_level[this->m_current_level];
-        VectorType*         rc = this->m_t_level[this->m_current_level + 1];
-        VectorType*         rf = this->m_t_level[this->m_current_level];
-        VectorType*         xc = this->m_d_level[this->m_current_level + 1];
-        VectorType*         s  = (this->m_scaling) ? this->m_s_level[this->m_current_level] : NULL;
-        ValueType           factor, divisor;
-        smoother->InitMaxIter(this->m_iter_pre_smooth);
-        if(this->m_is_precond || this->m_current_level != 0)
-            smoother->SolveZeroSol(rhs, x);
-        else
-            smoother->Solve(rhs, x);
-        if(this->m_scaling == true)
-            if(this->m_current_level > 0 && this->m_current_level < this->m_levels - 2 && this->m_iter_pre_smooth > 0)
-            {
-                s->PointWiseMult(rhs, *x);
-                factor = s->Reduce();
-                op->Apply(*x, s);
-                s->PointWiseMult(*x);
-                divisor = s->Reduce();
-                if(divisor == num<ValueType>(0))
-                    factor = num<ValueType>(1);
-                else
-                    factor /= divisor;
-                x->Scale(factor);
-            }
-        op->Apply(*x, r);
-        r->ScaleAdd(num<ValueType>(-1), rhs);
-        if(this->m_scaling && this->m_current_level == 0)
-            s->CopyFrom(*r);
-        this->doRestrict(*r, rc);
-        ++this->m_current_level;
+        this->m_solver_coarse->SetOperator(*this->m_grid[(size_t)last].A);
+        this->m_solver_coarse->Build();
+        auto fresh = [](const OperatorType& like, const char* name) {
+            std::unique_ptr<VectorType> v(new VectorType);
+            v->CloneBackend(like);
+            v->Allocate(name, like.GetM());
+            return v;
+        };
+        for(int l = 0; l <= last; ++l)
+        {
+            Level& g = this->m_grid[(size_t)l];
+            g.defect = fresh(*g.A, "defect");
+            g.rhs    = fresh(*g.A, "level right-hand side");
+            if(l > 0)
+                g.corr = fresh(*g.A, "coarse correction");
+            if(this->m_scaling)
+                g.keep = fresh(*g.A, "scaling scratch");
+            if(this->m_cycle == Kcycle && l >= 1 && l < last)
+                g.kdir = fresh(*g.A, "K-cycle direction image");
+        }
+    }
+    virtual void doReleaseCycle(void)
+    {
+        for(Level& g : this->m_grid)
+            g.drop_vectors();
+        for(int l = 0; l + 1 < this->m_levels && l < (int)this->m_grid.size(); ++l)
+            if(this->m_grid[(size_t)l].relax)
+                this->m_grid[(size_t)l].relax->Clear();
+        if(this->m_solver_coarse)
+            this->m_solver_coarse->Clear();
+        this->m_iter_ctrl.Clear();
+    }
+    // x *= <b, x> / <A x, x> (a quotient of one where the denominator vanishes); `img` receives A x
+    void doScaleIterate(int l, const VectorType& b, VectorType* x, VectorType* img)
+    {
+        enum { sNum, sDen, sQ, sCount };
+        Level& g = this->m_grid[(size_t)l];
+        Engine K(*g.A, sCount, l);
+        K.Dot(sNum, b, *x);
+        g.A->Apply(*x, img);
+        K.Dot(sDen, *img, *x);
+        K.Div(sQ, sNum, sDen);
+        K.OneIfZero(sQ, sDen);
+        K.Scale(x, sQ, +1.0);
+        K.Flush();
+    }
+    // x += (<c, ref> / <A c, c>) c for the prolonged correction c (quotient one where the denominator vanishes)
+    void doAddScaled(int l, VectorType* x, const VectorType& c, const VectorType& ref, VectorType* img)
+    {
+        enum { sNum, sDen, sQ, sCount };
+        Level& g = this->m_grid[(size_t)l];
+        Engine K(*g.A, sCount, l);
+        K.Dot(sNum, ref, c);
+        g.A->Apply(c, img);
+        K.Dot(sDen, *img, c);
+        K.Div(sQ, sNum, sDen);
+        K.OneIfZero(sQ, sDen);
+        K.Axpy(x, sQ, +1.0, c);
+        K.Flush();
+    }
+    void doVisit(int l, const VectorType& b, VectorType* x) // one visit of level l in the configured cycle
+    {
         switch(this->m_cycle)
         {
-        case Vcycle: this->doVcycle(*rc, xc); break;
-        case Wcycle: this->doWcycle(*rc, xc); break;
-        case Kcycle: this->doKcycle(*rc, xc); break;
-        case Fcycle: this->doFcycle(*rc, xc); break;
-        default: RAMD_DIE(); break;
+        case Vcycle: this->doCycle(l, b, x); break;
+        case Wcycle: // two visits (gamma = 2, base_multigrid.cpp:919-927)
+            this->doCycle(l, b, x);
+            this->doCycle(l, b, x);
+            break;
+        case Kcycle: this->doKrylovVisit(l, b, x); break;
+        default:
+            say("BaseMultiGrid: F-cycle is not implemented"); // nor in the reference (:930-935)
+            RAMD_DIE();
         }
-        --this->m_current_level;
-        this->doProlong(*xc, r);
-        if(this->m_scaling == true && this->m_current_level < this->m_levels - 2)
+    }
+    // base_multigrid.cpp:720-916
+    void doCycle(int l, const VectorType& b, VectorType* x)
+    {
+        const int last = this->m_levels - 1;
+        if(l == last)
         {
-            if(this->m_current_level == 0)
-                s->PointWiseMult(*r);
+            this->m_solver_coarse->SolveZeroSol(b, x);
+            return;
+        }
+        Level&      g    = this->m_grid[(size_t)l];
+        Level&      next = this->m_grid[(size_t)l + 1];
+        VectorType* d    = g.defect.get();
+        const bool  top  = (l == 0);
+        g.relax->InitMaxIter(this->m_iter_pre_smooth);
+        if(this->m_is_precond || !top)
+            g.relax->SolveZeroSol(b, x);
+        else
+            g.relax->Solve(b, x);
+        if(this->m_scaling && !top && l < last - 1 && this->m_iter_pre_smooth > 0)
+            this->doScaleIterate(l, b, x, g.keep.get());
+        g.A->Apply(*x, d);
+        d->ScaleAdd(num<ValueType>(-1), b);
+        if(this->m_scaling && top)
+            g.keep->CopyFrom(*d);
+        g.to_coarse->Apply(*d, next.rhs.get());
+        this->doVisit(l + 1, *next.rhs, next.corr.get());
+        g.to_fine->Apply(*next.corr, d);
+        if(this->m_scaling && l < last - 1)
+        {
+            // the defect the correction was computed for: kept aside on the top level, the level's right-hand side below
+            if(top)
+            {
+                // keep holds that defect and is the only scratch here: its product with the correction first, then A c
+                enum { sNum, sDen, sQ, sCount };
+                Engine K(*g.A, sCount, l);
+                K.Dot(sNum, *g.keep, *d);
+                g.A->Apply(*d, g.keep.get());
+                K.Dot(sDen, *g.keep, *d);
+                K.Div(sQ, sNum, sDen);
+                K.OneIfZero(sQ, sDen);
+                K.Axpy(x, sQ, +1.0, *d);
+                K.Flush();
+            }
             else
-                s->PointWiseMult(*r, *rf);
-            factor = s->Reduce();
-            op->Apply(*r, s);
-            s->PointWiseMult(*r);
-            divisor = s->Reduce();
-            if(divisor == num<ValueType>(0))
-                factor = num<ValueType>(1);
-            else
-                factor /= divisor;
-            x->AddScale(*r, factor);
+                this->doAddScaled(l, x, *d, b, g.keep.get());
         }
         else
-            x->AddScale(*r, num<ValueType>(1));
-        smoother->InitMaxIter(this->m_iter_post_smooth);
-        smoother->Solve(rhs, x);
-        if(this->m_current_level == 0 && this->m_is_precond == false)
+            x->AddScale(*d, num<ValueType>(1));
+        g.relax->InitMaxIter(this->m_iter_post_smooth);
+        g.relax->Solve(b, x);
+        if(top && !this->m_is_precond)
         {
-            op->Apply(*x, r);
-            r->ScaleAdd(num<ValueType>(-1), rhs);
-            this->m_res_norm = std::abs(this->doNorm(*r));
+            g.A->Apply(*x, d);
+            d->ScaleAdd(num<ValueType>(-1), b);
+            this->m_res_norm = std::abs(this->doNorm(*d));
         }
     }
-    void doWcycle(const VectorType& rhs, VectorType* x)
+    // base_multigrid.cpp:938-1011: two steps of conjugate gradients around the cycle on the coarse levels
+    void doKrylovVisit(int l, const VectorType& b, VectorType* x)
     {
-        for(int i = 0; i < 2; ++i) // gamma = 2 hardcoded (base_multigrid.cpp:919-927)
-            this->doVcycle(rhs, x);
-    }
-    void doFcycle(const VectorType&, VectorType*)
-    {
-        say("BaseMultiGrid: F-cycle is not implemented"); // nor in the reference (:930-935)
-        RAMD_DIE();
-    }
-    // base_multigrid.cpp:938-1011: two steps of CG around the cycle on the coarse levels
-    void doKcycle(const VectorType& rhs, VectorType* x)
-    {
-        if(this->m_current_level != 1 && this->m_kcycle_full == false)
-            this->doVcycle(rhs, x);
-        else if(this->m_current_level < this->m_levels - 1)
+        const int last = this->m_levels - 1;
+        if(l != 1 && !this->m_kcycle_full)
         {
-            VectorType*         q  = this->m_q_level[this->m_current_level - 1];
-            VectorType*         r  = this->m_t_level[this->m_current_level];
-            const OperatorType* op = this->m_op_level[this->m_current_level - 1];
-            ValueType           rho, rho_old, alpha;
-            this->doVcycle(rhs, x);
-            if(r != &rhs)
-                r->CopyFrom(rhs);
-            rho = r->DotNonConj(*x);
-            op->Apply(*x, q);
-            alpha = rho / x->DotNonConj(*q);
-            r->AddScale(*q, -alpha);
-            this->doVcycle(*r, q);
-            rho_old = rho;
-            rho     = r->DotNonConj(*q);
-            r->CopyFrom(*x);
-            r->ScaleAdd(rho / rho_old, *q);
-            op->Apply(*r, q);
-            x->Scale(alpha);
-            alpha = rho / r->DotNonConj(*q);
-            x->AddScale(*r, alpha);
+            this->doCycle(l, b, x);
+            return;
         }
-        else
-            this->m_solver_coarse->SolveZeroSol(rhs, x);
-    }
-    VectorType* m_new_vec(int level, const char* name)
-    {
-        const OperatorType* op = (level == 0) ? this->m_op : this->m_op_level[level - 1];
-        VectorType*         v  = new VectorType;
-        v->CloneBackend(*op);
-        v->Allocate(name, op->GetM());
-        return v;
+        if(l >= last)
+        {
+            this->m_solver_coarse->SolveZeroSol(b, x);
+            return;
+        }
+        // (slots 3 .. 6 of the level: the cycles run in between use 0 .. 2 for their scaling quotients)
+        enum { sRho = 3, sRhoOld, sAlpha, sT, sCount };
+        Level&      g = this->m_grid[(size_t)l];
+        VectorType *q = g.kdir.get(), *r = g.rhs.get();
+        Engine      K(*g.A, sCount, l);
+        this->doCycle(l, b, x);
+        if(r != &b)
+            r->CopyFrom(b);
+        K.Dot(sRho, *r, *x);
+        g.A->Apply(*x, q);
+        K.Dot(sT, *x, *q);
+        K.Div(sAlpha, sRho, sT);
+        K.Axpy(r, sAlpha, -1.0, *q);
+        K.Flush();
+        this->doCycle(l, *r, q);
+        K.Mov(sRhoOld, sRho);
+        K.Dot(sRho, *r, *q);
+        r->CopyFrom(*x);
+        K.Div(sT, sRho, sRhoOld);
+        K.Xpay(r, sT, +1.0, *q); // r = (rho / rho_old) r + q
+        g.A->Apply(*r, q);
+        K.Scale(x, sAlpha, +1.0);
+        K.Dot(sT, *r, *q);
+        K.Div(sAlpha, sRho, sT);
+        K.Axpy(x, sAlpha, +1.0, *r);
+        K.Flush();
     }
 
     int          m_levels;
-    int          m_current_level;
     bool         m_scaling;
     int          m_iter_pre_smooth;
     int          m_iter_post_smooth;
     unsigned int m_cycle;
     bool         m_kcycle_full;
-    OperatorType** m_op_level; // [levels-1]: operators of levels 1 .. levels-1 (level 0 is m_op)
-    OperatorType** m_restrict_op_level;
-    OperatorType** m_prolong_op_level;
-    VectorType**   m_d_level;
-    VectorType**   m_r_level;
-    VectorType**   m_t_level;
-    VectorType**   m_s_level;
-    VectorType**   m_q_level;
-    Solver<OperatorType, VectorType, ValueType>*                 m_solver_coarse;
-    IterativeLinearSolver<OperatorType, VectorType, ValueType>** m_smoother_level;
-    ValueType                                                    m_res_norm;
+    std::vector<Level> m_grid;
+    Solver<OperatorType, VectorType, ValueType>* m_solver_coarse;
+    ValueType                                    m_res_norm;
 };
 
 // MultiGrid (src/solvers/multigrid/multigrid.cpp): the hierarchy is handed in by the user; scaling on by default
@@ -3634,36 +3674,32 @@ public:
     virtual ~MultiGrid()
     {
         this->Clear();
-        delete[] this->m_restrict_op_level;
-        delete[] this->m_prolong_op_level;
     }
-    virtual void SetRestrictOperator(OperatorType** op)
+    virtual void SetRestrictOperator(OperatorType** op) // [levels - 1]
     {
         RAMD_EXPECT(!this->m_build && op != nullptr && this->m_levels > 0);
-        delete[] this->m_restrict_op_level;
-        this->m_restrict_op_level = new OperatorType*[this->m_levels]();
-        for(int i = 0; i < this->m_levels - 1; ++i)
-            this->m_restrict_op_level[i] = op[i];
+        for(int l = 0; l + 1 < this->m_levels; ++l)
+            this->m_grid[(size_t)l].to_coarse = op[l];
     }
-    virtual void SetProlongOperator(OperatorType** op)
+    virtual void SetProlongOperator(OperatorType** op) // [levels - 1]
     {
         RAMD_EXPECT(!this->m_build && op != nullptr && this->m_levels > 0);
-        delete[] this->m_prolong_op_level;
-        this->m_prolong_op_level = new OperatorType*[this->m_levels]();
-        for(int i = 0; i < this->m_levels - 1; ++i)
-            this->m_prolong_op_level[i] = op[i];
+        for(int l = 0; l + 1 < this->m_levels; ++l)
+            this->m_grid[(size_t)l].to_fine = op[l];
     }
-    virtual void SetOperatorHierarchy(OperatorType** op)
+    virtual void SetOperatorHierarchy(OperatorType** op) // operators of the levels 1 .. levels - 1
     {
-        RAMD_EXPECT(!this->m_build && op != nullptr);
-        this->m_op_level = op;
+        RAMD_EXPECT(!this->m_build && op != nullptr && this->m_levels > 0);
+        for(int l = 1; l < this->m_levels; ++l)
+            this->m_grid[(size_t)l].A = op[l - 1];
     }
 };
 
 // ============================================================================ AMG
 // BaseAMG (src/solvers/multigrid/base_amg.cpp): builds the hierarchy level by level through doAggregate until the
 // coarse operator has at most m_coarse_size rows; default smoothers FixedPoint(2/3) + Jacobi, default coarse solver
-// CG(0, 1e-6, 1e8, 1000).
+// CG(0, 1e-6, 1e8, 1000).  The class owns what it creates: the coarse operators and transfer operators, and -- unless the
+// caller supplies them -- the smoothers and the coarse solver.
 typedef enum _coarsening_strategy
 {
     Greedy = 0,
@@ -3674,13 +3710,13 @@ template <class OperatorType, class VectorType, typename ValueType>
 class BaseAMG : public BaseMultiGrid<OperatorType, VectorType, ValueType>
 {
 public:
+    typedef typename BaseMultiGrid<OperatorType, VectorType, ValueType>::Level Level;
     BaseAMG()
         : m_coarse_size(300)
         , m_set_sm(false)
         , m_set_s(false)
         , m_hierarchy(false)
         , m_op_format(CSR)
-        , m_sm_default(NULL)
     {
     }
     virtual ~BaseAMG()
@@ -3714,22 +3750,22 @@ public:
         if(this->m_build)
             this->Clear();
         this->BuildHierarchy();
-        if(this->m_set_sm == false)
+        if(!this->m_set_sm)
             this->BuildSmoothers();
-        if(this->m_set_s == false)
+        if(!this->m_set_s)
         {
-            CG<OperatorType, VectorType, ValueType>* cgs = new CG<OperatorType, VectorType, ValueType>;
-            cgs->Init(0.0, 1e-6, 1e+8, 1000);
-            cgs->Verbose(0);
-            this->m_solver_coarse = cgs;
+            this->m_own_coarse.reset(new CG<OperatorType, VectorType, ValueType>);
+            this->m_own_coarse->Init(0.0, 1e-6, 1e+8, 1000);
+            this->m_own_coarse->Verbose(0);
+            this->m_solver_coarse = this->m_own_coarse.get();
         }
-        this->Initialize();
+        this->doPrepareCycle();
         if(this->m_op_format != CSR)
-            for(int i = 0; i < this->m_levels - 1; ++i)
-                this->m_op_level[i]->ConvertTo(this->m_op_format);
+            for(std::unique_ptr<OperatorType>& c : this->m_own_A)
+                c->ConvertTo(this->m_op_format);
         this->m_build = true;
     }
-    // base_amg.cpp:173-310
+    // base_amg.cpp:173-310: aggregate until the operator is small enough (or cannot be coarsened any more)
     virtual void BuildHierarchy(void)
     {
         if(this->m_hierarchy)
@@ -3740,62 +3776,49 @@ public:
             say("Problem size too small for AMG, use Krylov solver instead");
             RAMD_DIE();
         }
-        std::vector<OperatorType*> ops, res, pro;
-        this->m_levels = 1;
-        const OperatorType* prev = this->m_op;
-        while(true)
+        this->m_grid.clear();
+        this->m_grid.emplace_back();
+        this->m_grid[0].A = this->m_op;
+        this->m_levels    = 1; // (doAggregate reads the depth reached so far)
+        for(bool more = true; more;)
         {
-            OperatorType* c = new OperatorType;
-            OperatorType* r = new OperatorType;
-            OperatorType* p = new OperatorType;
+            std::unique_ptr<OperatorType> c(new OperatorType), r(new OperatorType), p(new OperatorType);
             c->CloneBackend(*this->m_op);
             r->CloneBackend(*this->m_op);
             p->CloneBackend(*this->m_op);
-            const bool ok = this->doAggregate(*prev, p, r, c);
-            if(!ok)
+            if(!this->doAggregate(*this->m_grid.back().A, p.get(), r.get(), c.get()))
             {
-                delete c;
-                delete r;
-                delete p;
-                if(ops.empty())
+                if(this->m_levels == 1)
                 {
                     say("Could not build initial AMG level");
                     RAMD_DIE();
                 }
                 break;
             }
-            ops.push_back(c);
-            res.push_back(r);
-            pro.push_back(p);
+            more                         = c->GetM() > static_cast<int64_t>(this->m_coarse_size);
+            this->m_grid.back().to_coarse = r.get();
+            this->m_grid.back().to_fine   = p.get();
+            this->m_grid.emplace_back();
+            this->m_grid.back().A = c.get();
+            this->m_own_A.push_back(std::move(c));
+            this->m_own_R.push_back(std::move(r));
+            this->m_own_P.push_back(std::move(p));
             ++this->m_levels;
-            prev = c;
-            if(!(c->GetM() > static_cast<int64_t>(this->m_coarse_size)))
-                break;
-        }
-        this->m_op_level          = new OperatorType*[this->m_levels - 1]();
-        this->m_restrict_op_level = new OperatorType*[this->m_levels - 1]();
-        this->m_prolong_op_level  = new OperatorType*[this->m_levels - 1]();
-        for(int i = 0; i < this->m_levels - 1; ++i)
-        {
-            this->m_op_level[i]          = ops[i];
-            this->m_restrict_op_level[i] = res[i];
-            this->m_prolong_op_level[i]  = pro[i];
         }
     }
     // base_amg.cpp:313-338
     virtual void BuildSmoothers(void)
     {
-        this->m_smoother_level = new IterativeLinearSolver<OperatorType, VectorType, ValueType>*[this->m_levels - 1]();
-        this->m_sm_default     = new Solver<OperatorType, VectorType, ValueType>*[this->m_levels - 1]();
-        for(int i = 0; i < this->m_levels - 1; ++i)
+        for(int l = 0; l + 1 < this->m_levels; ++l)
         {
-            FixedPoint<OperatorType, VectorType, ValueType>* sm  = new FixedPoint<OperatorType, VectorType, ValueType>;
-            Jacobi<OperatorType, VectorType, ValueType>*     jac = new Jacobi<OperatorType, VectorType, ValueType>;
+            std::unique_ptr<FixedPoint<OperatorType, VectorType, ValueType>> sm(new FixedPoint<OperatorType, VectorType, ValueType>);
+            std::unique_ptr<Jacobi<OperatorType, VectorType, ValueType>>     jac(new Jacobi<OperatorType, VectorType, ValueType>);
             sm->SetRelaxation(static_cast<ValueType>(2.f / 3.f));
             sm->SetPreconditioner(*jac);
             sm->Verbose(0);
-            this->m_smoother_level[i] = sm;
-            this->m_sm_default[i]     = jac;
+            this->m_grid[(size_t)l].relax = sm.get();
+            this->m_own_relax.push_back(std::move(sm));
+            this->m_own_relax_inner.push_back(std::move(jac));
         }
     }
     // base_amg.cpp:341-395
@@ -3803,32 +3826,16 @@ public:
     {
         if(this->m_build)
         {
-            this->Finalize();
-            for(int i = 0; i < this->m_levels - 1; ++i)
+            this->doReleaseCycle();
+            this->m_grid.clear();
+            this->m_own_relax.clear();
+            this->m_own_relax_inner.clear();
+            this->m_own_A.clear();
+            this->m_own_R.clear();
+            this->m_own_P.clear();
+            if(!this->m_set_s)
             {
-                delete this->m_op_level[i];
-                delete this->m_restrict_op_level[i];
-                delete this->m_prolong_op_level[i];
-            }
-            delete[] this->m_op_level;
-            delete[] this->m_restrict_op_level;
-            delete[] this->m_prolong_op_level;
-            this->m_op_level = this->m_restrict_op_level = this->m_prolong_op_level = NULL;
-            if(this->m_set_sm == false)
-            {
-                for(int i = 0; i < this->m_levels - 1; ++i)
-                {
-                    delete this->m_smoother_level[i];
-                    delete this->m_sm_default[i];
-                }
-                delete[] this->m_smoother_level;
-                delete[] this->m_sm_default;
-                this->m_smoother_level = NULL;
-                this->m_sm_default     = NULL;
-            }
-            if(this->m_set_s == false)
-            {
-                delete this->m_solver_coarse;
+                this->m_own_coarse.reset();
                 this->m_solver_coarse = NULL;
             }
             this->m_levels    = -1;
@@ -3860,7 +3867,10 @@ protected:
     bool         m_set_s;
     bool         m_hierarchy;
     unsigned int m_op_format;
-    Solver<OperatorType, VectorType, ValueType>** m_sm_default;
+    std::vector<std::unique_ptr<OperatorType>> m_own_A, m_own_R, m_own_P;
+    std::vector<std::unique_ptr<IterativeLinearSolver<OperatorType, VectorType, ValueType>>> m_own_relax;
+    std::vector<std::unique_ptr<Solver<OperatorType, VectorType, ValueType>>>                m_own_relax_inner;
+    std::unique_ptr<CG<OperatorType, VectorType, ValueType>>                                 m_own_coarse;
 };
 
 // UAAMG (src/solvers/multigrid/unsmoothed_amg.cpp): unsmoothed aggregation; both coarsening strategies run on the

@@ -93,6 +93,10 @@ void* ramd_vec_data(ramd_vec_t v); /* raw device pointer (LeaveDataPtr-style vie
  * opposite to the one `other` lives in -- two vectors a fused update WRITES in one pass stream 8-15 % faster from different
  * classes (csrc/backend.hip, "Placement classes").  other == NULL or unclassified (< 64 MiB): plain ramd_vec_allocate. */
 int ramd_vec_allocate_apart(ramd_vec_t v, int64_t n, ramd_vec_t other);
+/* ... for a vector that is already allocated: how fast ONE kernel writes this vector and `other` together is measured (a
+ * write pass over both blocks, contents saved and restored), and the vector moves to the best of a few fresh candidate
+ * blocks if one is clearly faster; *moved tells.  Same sizes and types only, blocks from 64 MiB on; otherwise a no-op. */
+int ramd_vec_place_apart(ramd_vec_t v, ramd_vec_t other, int* moved);
 /* 0 / 1: the placement class of the vector's block, -1: not classified (small, host, empty) */
 int ramd_vec_placement_class(ramd_vec_t v, int* cls);
 int ramd_vec_zeros(ramd_vec_t v); /* :73 */
@@ -156,7 +160,9 @@ int ramd_mat_apply(ramd_mat_t m, ramd_vec_t x, ramd_vec_t y);
 int ramd_mat_apply_add(ramd_mat_t m, ramd_vec_t x, double scalar, ramd_vec_t y);
 /* what the CSR product learned about the matrix on its first call (no reference counterpart): state 0 = not analysed yet,
  * 1 = the rows fall into `entries` patterns of column offsets (col - row) of at most `width` entries, the kernel rebuilds the
- * columns from one byte per row; -1 = not structured (too many patterns or rows longer than 16): columns are read */
+ * columns from one byte per row; -1 = not structured (too many patterns or rows longer than 16): columns are read;
+ * 2 = no dictionary, but most rows carry the column list of the row before them (the unknowns of one mesh node of an FE
+ * matrix): only the first row of such a group has its columns read */
 int ramd_mat_pattern_info(ramd_mat_t m, int* state, int* entries, int* width);
 /* on = 0: the products of this matrix read its stored columns even where a dictionary exists (the general CSR / ELL path:
  * bench.py reports both figures); on != 0 (default): use the dictionary where the matrix is structured.  Results are
@@ -223,7 +229,7 @@ int ramd_mat_gen_poisson7_slab(ramd_mat_t interior, ramd_mat_t ghost, int N, int
  * RAMD_NSCALARS doubles; ramd_scalars_fetch copies a record to the host (blocking on the
  * stream).  Element-wise arithmetic is the reference's expression for each op, so results
  * equal the unfused sequence except for the summation order of the reductions. */
-enum { RAMD_NSCALARS = 384 };
+enum { RAMD_NSCALARS = 512 };
 /* ---- device-resident scalar algebra (the recurrences of the Krylov drivers without host round trips).
  * The reference computes every recurrence coefficient on the host: each Dot / Norm is a blocking read-back
  * (hip_vector.cpp:785-931 + hipStreamSynchronize), the quotient is formed in C++ and travels back as a kernel argument

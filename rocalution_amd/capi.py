@@ -51,6 +51,7 @@ SIGNATURES = {
     "ramd_vec_allocate": (i32, [vec_t, i64]),
     "ramd_vec_allocate_apart": (i32, [vec_t, i64, vec_t]),
     "ramd_vec_placement_class": (i32, [vec_t, pi32]),
+    "ramd_vec_place_apart": (i32, [vec_t, vec_t, pi32]),
     "ramd_vec_clear": (i32, [vec_t]),
     "ramd_vec_size": (i32, [vec_t, pi64]),
     "ramd_vec_dtype": (i32, [vec_t, pi32]),

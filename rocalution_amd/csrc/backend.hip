@@ -198,7 +198,7 @@ AllocCache& cache()
 namespace
 {
 constexpr size_t kClassMinBlock = (size_t)64 << 20; // blocks from this size on are classified
-constexpr size_t kProbeBytes    = (size_t)256 << 20; // bytes each of the two probe streams writes (at most: the block's size)
+constexpr size_t kProbeBytes    = (size_t)512 << 20; // bytes each of the two probe streams writes (at most: the block's size)
 typedef unsigned int probe_pk __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_probe_ww(size_t n16, probe_pk* __restrict__ a, probe_pk* __restrict__ b)
 {
@@ -235,7 +235,7 @@ int probe_class(AllocCache& c, void* p, size_t bytes)
     const unsigned g   = (unsigned)((n16 + 255) / 256);
     auto           run = [&](void* a, void* b2) -> float {
         float best = 1e30f;
-        for(int rep = 0; rep < 4; ++rep)
+        for(int rep = 0; rep < 7; ++rep)
         {
             (void)hipEventRecord(e0, nullptr);
             hipLaunchKernelGGL(k_probe_ww, dim3(g), dim3(256), 0, nullptr, n16, (probe_pk*)a, (probe_pk*)b2);
@@ -255,13 +255,41 @@ int probe_class(AllocCache& c, void* p, size_t bytes)
     static const bool verbose = getenv("RAMD_ALLOC_VERBOSE") != nullptr;
     if(verbose)
         fprintf(stderr, "alloc class probe: block %p (%zu MiB): same-class reference pair %.4f ms, with the block %.4f ms -> class %d\n", p,
-                bytes >> 20, same, mixed, mixed < 0.94f * same ? 1 : 0);
+                bytes >> 20, same, mixed, mixed < 0.93f * same ? 1 : 0);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipGetLastError();
-    return mixed < 0.94f * same ? 1 : 0;
+    return mixed < 0.93f * same ? 1 : 0;
 }
 } // namespace
+
+// milliseconds of one pass writing `bytes` (a multiple of 4 KiB) to both blocks at once -- the direct measurement of how two
+// blocks get along as the two outputs of one kernel (contents are overwritten with zeros)
+float probe_write_pair_ms(void* a, void* b2, size_t bytes)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if(hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+        return -1.f;
+    const size_t   n16  = bytes / 16;
+    const unsigned g    = (unsigned)((n16 + 255) / 256);
+    float          best = 1e30f;
+    (void)hipDeviceSynchronize();
+    for(int rep = 0; rep < 5; ++rep)
+    {
+        (void)hipEventRecord(e0, nullptr);
+        hipLaunchKernelGGL(k_probe_ww, dim3(g), dim3(256), 0, nullptr, n16, (probe_pk*)a, (probe_pk*)b2);
+        (void)hipEventRecord(e1, nullptr);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if(rep > 0 && ms < best)
+            best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipGetLastError();
+    return best;
+}
 
 int cached_block_class(const void* p)
 {
@@ -282,14 +310,14 @@ hipError_t cached_malloc_apart(void** p, size_t bytes, const void* other)
         return cached_malloc_bytes(p, bytes);
     std::vector<void*> rejects;
     hipError_t         e = hipSuccess;
-    for(int draw = 0; draw < 6; ++draw)
+    for(int draw = 0; draw < 12; ++draw)
     {
         void* q = nullptr;
         e       = cached_malloc_bytes(&q, bytes);
         if(e != hipSuccess)
             break;
         const int k = cached_block_class(q);
-        if(k < 0 || k != avoid || draw == 5)
+        if(k < 0 || k != avoid || draw == 11)
         {
             *p = q;
             break;

@@ -57,7 +57,7 @@ const char* last_error();
 #define RAMD_REDUCE_BLOCKS 8192
 #endif
 constexpr int kReduceBlocks  = RAMD_REDUCE_BLOCKS; // partial sums per reduction launch (32 workgroups per CU: tools/membench.hip)
-constexpr int kScalarSlots   = 384; // doubles per scalar record (RAMD_NSCALARS)
+constexpr int kScalarSlots   = 512; // doubles per scalar record (RAMD_NSCALARS)
 constexpr int kScalarRecords = 8; // ring of records in host-mapped memory
 
 struct Backend
@@ -92,6 +92,7 @@ hipError_t cached_malloc_bytes(void** p, size_t bytes);
 hipError_t cached_free(void* p);
 hipError_t cached_malloc_apart(void** p, size_t bytes, const void* other); // in the placement class opposite to `other`'s
 int        cached_block_class(const void* p); // 0 / 1, or -1 (small block, not classified)
+float      probe_write_pair_ms(void* a, void* b, size_t bytes); // one pass writing both blocks at once (zeros), best of 4
 void       cached_release_all(void);
 template <typename X>
 inline hipError_t cached_malloc(X** p, size_t bytes)
@@ -194,6 +195,10 @@ struct ramd_mat_s
     int            pat_state = 0; // 0 unknown, 1 usable, -1 not usable (too many patterns / rows too long)
     bool           pat_off   = false; // ramd_mat_pattern_use(m, 0): the products of this matrix read its columns
     int            pat_len[64] = {0}; // row length of every dictionary entry (host copy)
+    // rows that share their column list with the row before them (spmv.hip, csr_analyse_groups): 0 unknown, 1 usable, -1 not
+    int            grp_state = 0;
+    int*           grp_lead  = nullptr; // [nrow] rp[leader of the row's group] - rp[row]  (0 for a leader)
+    unsigned char* grp_need  = nullptr; // [ceil(nnz / 4)] 1: this 16-byte packet of column indices holds a leader's entries
     // x tiles in LDS (spmv.hip, csr_analyse_xl): 0 unknown, 1 usable, -1 not usable
     int            xl_state = 0;
     int*           xl_dict  = nullptr; // [pat_n * pat_w] LDS element of x for thread 0, per dictionary entry and slot

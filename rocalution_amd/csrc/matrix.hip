@@ -62,6 +62,9 @@ void mat_free_analysis(ramd_mat_s* m)
     dev_free(&m->pat_dict);
     dev_free(&m->xl_dict);
     m->xl_state = 0;
+    dev_free(&m->grp_lead);
+    dev_free(&m->grp_need);
+    m->grp_state = 0;
     m->pat_state = m->pat_n = m->pat_w = 0;
     tri_release(m);
     m->lu_analysed = m->l_analysed = m->u_analysed = false;
@@ -382,7 +385,7 @@ int ramd_mat_pattern_info(ramd_mat_t m, int* state, int* entries, int* width)
     if(!m)
         RAMD_FAIL(RAMD_ERR_ARG, "null matrix handle");
     if(state)
-        *state = m->pat_state;
+        *state = (m->pat_state != 1 && m->grp_state == 1) ? 2 : m->pat_state;
     if(entries)
         *entries = m->pat_n;
     if(width)

@@ -16,6 +16,7 @@ int    mat_alloc_csr(ramd_mat_s* m, int nrow, int ncol, int64_t nnz);
 
 // spmv.hip: detect a far band (3-D stencil plane distance) for the band-aware row-block traversal
 int csr_analyse_band(ramd_mat_s* m);
+int csr_analyse_groups(ramd_mat_s* m);
 // row patterns (spmv.hip): rows whose column offsets col - row coincide share a dictionary entry of kPatMaxW slots
 constexpr int kPatMaxW = 16; // longest row a pattern may have
 constexpr int kPatMax  = 64; // dictionary entries
@@ -30,6 +31,12 @@ struct XlSegs
     int npk[kXlSegs]; // 16-byte packets of the piece
     int base[kXlSegs]; // where the piece starts in the LDS area (elements)
     int total; // elements of the LDS area in use (a multiple of the packet size)
+};
+// rows sharing the column list of the row before them (FE matrices: the unknowns of one mesh node): k_csr_tr<GRP>
+struct CsrGroups
+{
+    const int*           lead; // [nrow] entry offset from a row's entries to its group leader's (<= 0)
+    const unsigned char* need; // [nnz / 4] column packets that have to be read
 };
 struct CsrPattern
 {

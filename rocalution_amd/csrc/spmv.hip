@@ -102,13 +102,18 @@ struct CsrDotWs
 #ifndef RAMD_CSR_PAT_WAVES
 #define RAMD_CSR_PAT_WAVES 6
 #endif
-template <typename T, int MODE, bool DOT, bool PAT>
+// GRP (row groups, csr_analyse_groups): the rows of one mesh node of an FE matrix carry the SAME column list (5 unknowns per
+// node on a shell mesh: five rows of ~35 entries with identical columns).  Only the first row of such a group -- its leader --
+// has its column packets read; the others walk the leader's columns in LDS (lead[row] = offset from the row's entries to
+// the leader's).  4 bytes per entry become ~0.8 on the af_shell10-class matrix: 12.6 -> 9.4 bytes per entry moved.  A
+// follower whose leader's entries were staged in an earlier pass reads its own columns from memory (one group in ~12).
+template <typename T, int MODE, bool DOT, bool PAT, bool GRP = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PAT ? RAMD_CSR_PAT_WAVES : 6, 8))) void k_csr_tr(int nrow, int nblk, int per_xcd,
                                                    const int* __restrict__ rp,
                                                    const int* __restrict__ ci,
                                                    const T* __restrict__ val,
                                                    const T* __restrict__ x, T* __restrict__ y, T scalar,
-                                                   CsrDotWs ws, int slot, BandMap bm, CsrPattern pat)
+                                                   CsrDotWs ws, int slot, BandMap bm, CsrPattern pat, CsrGroups grp = {})
 {
     using VP          = typename ValPk<T>::type;
     constexpr int VN  = ValPk<T>::N;
@@ -123,6 +128,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PAT ? RA
         const int row  = r0 + threadIdx.x;
         int       rs = 0, re = 0;
         int       dbase = 0; // PAT: where this row's offsets start in the dictionary, minus rs
+        int       lead  = 0; // GRP: leader's entry index minus this row's
         if(PAT)
             for(int i = threadIdx.x; i < pat.n * pat.w; i += kBlock)
                 scol[i] = pat.dict[i];
@@ -132,6 +138,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PAT ? RA
             re = rp[row + 1];
             if(PAT)
                 dbase = (int)pat.id[row] * pat.w - rs;
+            if(GRP)
+                lead = grp.lead[row];
         }
         const int start = rp[r0];
         const int end   = rp[rend];
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PAT ? RA
             for(int k = 0; k < (PAT ? 0 : kCsrChunk / (4 * kBlock)); ++k)
             {
                 const int j = cb + (k * kBlock + threadIdx.x) * 4;
-                if(j < end)
+                if(j < end && (!GRP || grp.need[j >> 2]))
                     c[k] = nt_load(reinterpret_cast<const v4i32*>(ci + j));
             }
 #pragma unroll
@@ -183,8 +191,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PAT ? RA
                 for(int e = 0; e < kGatherW; ++e)
                     if(j + e < hi)
                     {
-                        cc[e] = PAT ? row + scol[dbase + j + e] : scol[j - cb + e];
-                        v[e]  = sval[j - cb + e];
+                        if(GRP)
+                        {
+                            const int jl = j + e + lead; // the same entry of the group's leader
+                            cc[e]        = jl >= cb ? scol[jl - cb] : ci[j + e];
+                        }
+                        else
+                            cc[e] = PAT ? row + scol[dbase + j + e] : scol[j - cb + e];
+                        v[e] = sval[j - cb + e];
                     }
 #pragma unroll
                 for(int e = 0; e < kGatherW; ++e)
@@ -1014,6 +1028,106 @@ int csr_analyse_pattern(ramd_mat_s* m)
     return analyse_pattern(m->nrow, PatCsr{m->rp, m->ci}, &m->pat_state, &m->pat_n, &m->pat_id, &m->pat_dict, m->pat_len);
 }
 
+// ------------------------------------------------------------------------------------------ row groups
+// same[i] = 1: row i has exactly the columns of row i-1 and does not start a 256-row block
+__global__ __launch_bounds__(kBlock) void k_grp_same(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                     unsigned char* __restrict__ same)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+    {
+        bool s = false;
+        if(i % kCsrRows != 0)
+        {
+            const int a = rp[i - 1], b = rp[i], e = rp[i + 1];
+            s           = (e - b) == (b - a) && e > b;
+            for(int k = 0; s && k < e - b; ++k)
+                s = ci[a + k] == ci[b + k];
+        }
+        same[i] = s ? 1 : 0;
+    }
+}
+constexpr int kGrpRows = 8; // rows of a group at most (a longer run starts over)
+__global__ __launch_bounds__(kBlock) void k_grp_lead(int nrow, const int* __restrict__ rp, const unsigned char* __restrict__ same,
+                                                     int* __restrict__ lead, unsigned long long* __restrict__ followers)
+{
+    const int64_t      gsz = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long cnt = 0;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+    {
+        int k = 0;
+        while(k < kGrpRows && same[i - k]) // (same[] is 0 at the first row of every block: the walk stays inside)
+            ++k;
+        if(k == kGrpRows)
+            k = 0; // deep inside a long run: on its own
+        lead[i] = rp[i - k] - rp[i];
+        cnt += k > 0 ? 1 : 0;
+    }
+    for(int off = 32; off > 0; off >>= 1)
+        cnt += __shfl_xor(cnt, off, 64);
+    if((threadIdx.x & 63) == 0 && cnt)
+        atomicAdd(followers, cnt);
+}
+__global__ __launch_bounds__(kBlock) void k_grp_need(int nrow, const int* __restrict__ rp, const int* __restrict__ lead,
+                                                     unsigned char* __restrict__ need)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+        if(lead[i] == 0) // a leader (or a row on its own): its packets are read
+            for(int q = rp[i] >> 2; q <= (rp[i + 1] - 1) >> 2 && rp[i + 1] > rp[i]; ++q)
+                need[q] = 1;
+}
+int csr_analyse_groups(ramd_mat_s* m)
+{
+    m->grp_state = -1;
+    if(m->format != RAMD_CSR || m->nrow <= 0 || m->nnz <= 0)
+        return RAMD_OK;
+    Backend&            b    = backend();
+    unsigned char*      same = nullptr;
+    unsigned long long* dcnt = nullptr;
+    RAMD_TRY(dev_alloc(&same, m->nrow));
+    int s = dev_alloc(&dcnt, 1);
+    dev_free(&m->grp_lead);
+    dev_free(&m->grp_need);
+    if(s == RAMD_OK)
+        s = dev_alloc(&m->grp_lead, m->nrow);
+    const int64_t npk = (m->nnz + 3) / 4 + 1;
+    if(s == RAMD_OK)
+        s = dev_alloc(&m->grp_need, npk);
+    unsigned long long followers = 0;
+    if(s == RAMD_OK)
+    {
+        (void)hipMemsetAsync(dcnt, 0, sizeof(unsigned long long), b.cur);
+        (void)hipMemsetAsync(m->grp_need, 0, (size_t)npk, b.cur);
+        const int grid = ew_grid(m->nrow);
+        hipLaunchKernelGGL(k_grp_same, dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, m->rp, m->ci, same);
+        hipLaunchKernelGGL(k_grp_lead, dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, m->rp, same, m->grp_lead, dcnt);
+        hipLaunchKernelGGL(k_grp_need, dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, m->rp, m->grp_lead, m->grp_need);
+        hipError_t e = hipMemcpyAsync(&followers, dcnt, sizeof(followers), hipMemcpyDeviceToHost, b.cur);
+        if(e == hipSuccess)
+            e = hipStreamSynchronize(b.cur);
+        if(e != hipSuccess)
+            s = RAMD_ERR_HIP;
+    }
+    dev_free(&same);
+    dev_free(&dcnt);
+    if(s != RAMD_OK)
+    {
+        dev_free(&m->grp_lead);
+        dev_free(&m->grp_need);
+        RAMD_FAIL(s, "row-group analysis");
+    }
+    // worth it when at least half of the rows ride on another row's columns
+    if(followers * 2 >= (unsigned long long)m->nrow)
+        m->grp_state = 1;
+    else
+    {
+        dev_free(&m->grp_lead);
+        dev_free(&m->grp_need);
+    }
+    return RAMD_OK;
+}
+
 // x tiles (k_csr_xl): clusters of the dictionary's distinct column offsets -> pieces of x a 256-row block stages in LDS
 template <typename T>
 static int csr_analyse_xl(ramd_mat_s* m)
@@ -1127,6 +1241,16 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
     XlSegs           xsg     = {};
     if(use_xl)
         memcpy(&xsg, m->xl_segs, sizeof(xsg));
+    // rows sharing the column list of their predecessor (FE matrices), opt-in: RAMD_CSR_GRP=1.  Measured on the af_shell10-class
+    // matrix (profiles/r03_spmv_shell_variants.txt): 9.4 instead of 12.6 bytes per entry moved, and 0.235 ms instead of
+    // 0.159 ms -- the product is bound by the dependent gather rounds of the row walk (five per 35-entry row, one row in four
+    // lanes active per 2048-entry pass), not by bytes; the per-entry choice between the leader's staged columns and the
+    // row's own costs more than the column packets saved.  Kept under the same bit-exact tests as an experiment.
+    static const int grp_env = getenv("RAMD_CSR_GRP") ? atoi(getenv("RAMD_CSR_GRP")) : 0;
+    if(!use_pat && grp_env > 0 && m->grp_state == 0 && m->pat_state != 1)
+        RAMD_TRY(csr_analyse_groups(const_cast<ramd_mat_s*>(m)));
+    const bool      use_grp = !use_pat && grp_env != 0 && m->grp_state == 1 && !m->pat_off;
+    const CsrGroups cgr     = {use_grp ? m->grp_lead : nullptr, use_grp ? m->grp_need : nullptr};
     const bool q4      = !use_pat && q4_env > 0; // measured EQUAL to k_csr_tr on the shell surrogate (0.162 vs 0.160 ms): opt-in
     const int  nblk    = (m->nrow + rows_per_wg - 1) / rows_per_wg;
     const int  per_xcd = (nblk + 7) / 8;
@@ -1163,6 +1287,9 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
         else if(use_pat)                                                                                   \
             hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT, true>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
                                per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat);  \
+        else if(use_grp)                                                                                   \
+            hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT, false, true>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
+                               per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, cgr); \
         else                                                                                               \
             hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT, false>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
                                per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat);  \

@@ -482,6 +482,85 @@ int ramd_vec_allocate_apart(ramd_vec_t v, int64_t n, ramd_vec_t other)
     return RAMD_OK;
 }
 
+int ramd_vec_place_apart(ramd_vec_t v, ramd_vec_t other, int* moved)
+{
+    CHECK_VEC(v);
+    if(moved)
+        *moved = 0;
+    if(!other || other == v || !v->d || !other->d || v->n != other->n || v->dtype != other->dtype)
+        return RAMD_OK;
+    const size_t bytes = (size_t)v->n * dtype_size(v->dtype);
+    static const bool off = getenv("RAMD_ALLOC_CLASSES") && atoi(getenv("RAMD_ALLOC_CLASSES")) == 0;
+    if(off || bytes < ((size_t)64 << 20))
+        return RAMD_OK;
+    // how the two blocks get along as the outputs of one kernel is MEASURED (a write pass over both, ~0.3 ms per GiB):
+    // the vector keeps its block unless one of a few fresh candidates -- drawn from the other placement class first -- is
+    // clearly faster with `other`; the contents move with it.
+    const size_t pb = bytes & ~(size_t)4095;
+    void*        scratch = nullptr; // `other` is in use: probe against a copy of nothing -- its block is written, so save it
+    RAMD_HIP(cached_malloc_bytes(&scratch, bytes + kPad));
+    RAMD_HIP(hipMemcpyAsync(scratch, other->d, bytes, hipMemcpyDeviceToDevice, backend().cur));
+    void* keep = nullptr; // ... and the vector's own contents
+    hipError_t e = cached_malloc_bytes(&keep, bytes + kPad);
+    if(e != hipSuccess)
+    {
+        (void)cached_free(scratch);
+        RAMD_HIP(e);
+    }
+    (void)hipMemcpyAsync(keep, v->d, bytes, hipMemcpyDeviceToDevice, backend().cur);
+    (void)hipStreamSynchronize(backend().cur);
+    float              best_ms = probe_write_pair_ms(v->d, other->d, pb);
+    void*              best    = v->d;
+    std::vector<void*> losers;
+    static const bool  verbose = getenv("RAMD_ALLOC_VERBOSE") != nullptr;
+    if(verbose)
+        fprintf(stderr, "place apart: current pair %.4f ms", best_ms);
+    float worst_ms = best_ms;
+    // (pairs come in two speeds, ~8-15 % apart: the search ends as soon as both have been seen and the fast one is held)
+    for(int k = 0; k < 12 && worst_ms < 1.07f * best_ms; ++k)
+    {
+        void* c = nullptr;
+        if(cached_malloc_apart(&c, bytes + kPad, other->d) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            break;
+        }
+        const float ms = probe_write_pair_ms(c, other->d, pb);
+        if(verbose)
+            fprintf(stderr, ", candidate %.4f", ms);
+        if(ms > worst_ms)
+            worst_ms = ms;
+        if(ms > 0.f && ms < 0.96f * best_ms)
+        {
+            if(best != v->d)
+                losers.push_back(best);
+            best    = c;
+            best_ms = ms;
+        }
+        else
+            losers.push_back(c);
+    }
+    if(verbose)
+        fprintf(stderr, " -> %s (%.4f ms)\n", best == v->d ? "kept" : "moved", best_ms);
+    // the probes wrote zeros over both blocks: restore
+    (void)hipMemcpyAsync(other->d, scratch, bytes, hipMemcpyDeviceToDevice, backend().cur);
+    if(best != v->d)
+    {
+        (void)hipMemsetAsync((char*)best + bytes, 0, kPad, backend().cur);
+        losers.push_back(v->d);
+        v->d = best;
+        if(moved)
+            *moved = 1;
+    }
+    (void)hipMemcpyAsync(v->d, keep, bytes, hipMemcpyDeviceToDevice, backend().cur);
+    (void)hipStreamSynchronize(backend().cur);
+    for(void* l : losers)
+        (void)cached_free(l);
+    (void)cached_free(scratch);
+    (void)cached_free(keep);
+    return RAMD_OK;
+}
+
 int ramd_vec_placement_class(ramd_vec_t v, int* cls)
 {
     CHECK_VEC(v);

@@ -115,6 +115,25 @@ int main(int argc, char** argv)
             older.ReadFileASCII(old);
             REQUIRE(older.GetGlobalNrow() == 100 && older.GetGlobalNcol() == 100 && older.GetLocalNrow() == 30
                     && older.GetLocalNcol() == 30 && older.GetBoundarySize() == 4 && older.peers() == p.peers);
+            // a pattern of an unsymmetric matrix, as the reference writes it: this rank receives from rank 0 only but
+            // sends to ranks 0 and 2 -- read as the union of the two lists with an empty receive piece for rank 2
+            const std::string uns = std::string(argv[1]) + "/uns.pm";
+            {
+                std::ofstream head(uns.c_str());
+                head << "uns.pm.rank.0\nuns.pm.rank.1\nuns.pm.rank.2\n";
+                std::ofstream f((uns + ".rank.1").c_str());
+                f << "#RANK\n1\n#GLOBAL_NROW\n100\n#GLOBAL_NCOL\n100\n#LOCAL_NROW\n30\n#LOCAL_NCOL\n30\n#BOUNDARY_SIZE\n4\n"
+                     "#NUMBER_OF_RECEIVERS\n1\n#NUMBER_OF_SENDERS\n2\n#RECEIVERS_RANK\n0\n#SENDERS_RANK\n0\n2\n"
+                     "#RECEIVERS_INDEX_OFFSET\n0\n3\n#SENDERS_INDEX_OFFSET\n0\n2\n4\n#BOUNDARY_INDEX\n0\n1\n28\n29\n";
+            }
+            ParallelManager unsym;
+            unsym.SetMPICommunicator(comm);
+            unsym.ReadFileASCII(uns);
+            REQUIRE(unsym.Status() && unsym.peers() == p.peers);
+            REQUIRE(unsym.recv_offset().size() == 3 && unsym.recv_offset()[0] == 0 && unsym.recv_offset()[1] == 3
+                    && unsym.recv_offset()[2] == 3);
+            REQUIRE(unsym.send_offset().size() == 3 && unsym.send_offset()[1] == 2 && unsym.send_offset()[2] == 4);
+            REQUIRE(unsym.GetNumReceivers() == 3 && unsym.GetNumSenders() == 4);
         }
         REQUIRE(ramd_comm_destroy(comm) == RAMD_OK);
     }

@@ -958,7 +958,7 @@ def test_fused_mgs_block_rejects_bad_arguments(ra):
     assert lib.ramd_fused_mgs_block(w._h, None, 0, 0, 0, hs, K + 1, 0) != 0         # block too long
     assert lib.ramd_fused_mgs_block(w._h, hs, K - 1, 0, 40, hs, 2, 90) != 0         # a followed block must be full
     assert lib.ramd_fused_mgs_block(w._h, hs, K, 0, 40, hs, K, 44) != 0             # overlapping slot areas
-    assert lib.ramd_fused_mgs_block(w._h, None, 0, 0, 0, hs, K, 376) != 0           # sums beyond the record (384 slots)
+    assert lib.ramd_fused_mgs_block(w._h, None, 0, 0, 0, hs, K, 504) != 0           # sums beyond the record (512 slots)
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 255, 257, 1023])
@@ -1086,7 +1086,8 @@ def test_csr_row_patterns_give_up_quickly_on_a_large_unstructured_matrix(ra, ora
     eq(y.numpy(), oracle.csr_apply(rp, ci, va, xh))
 
 
-@pytest.mark.parametrize("variant", ["RAMD_CSR_Q4=1", "RAMD_CSR_PAT=1", "RAMD_CSR_PAT=1,RAMD_CSR_XL=1", "RAMD_CSR_PAT=0"])
+@pytest.mark.parametrize("variant", ["RAMD_CSR_Q4=1", "RAMD_CSR_PAT=1", "RAMD_CSR_PAT=1,RAMD_CSR_XL=1", "RAMD_CSR_PAT=0",
+                                     "RAMD_CSR_PAT=0,RAMD_CSR_GRP=1"])
 def test_spmv_variants_forced_in_a_fresh_process(variant):
     """the CSR SpMV has an opt-in four-lanes-per-row walk (k_csr_q4), and CSR / ELL / HYB products and the multi-colour
     sweeps rebuild the columns of structured matrices from row patterns (by default only from 2^20 entries on; with RAMD_CSR_XL=1
@@ -1173,3 +1174,30 @@ def test_scalar_programs_and_guarded_combines(ra, dtype):
     combine(x, [(x, -1, 1.0), (y, base + 2, 1.0)], guard=base + 11)
     ref = V(hx); ref.AddScale(y, coef)
     assert np.array_equal(x.numpy(), ref.numpy())
+
+
+@pytest.mark.gpu
+def test_single_launch_reductions_under_load(ra):
+    """The single-launch reductions hand their per-workgroup partial sums to the last workgroup through relaxed agent-scope
+    atomics, a store-completion wait and a ticket -- no release fence (device_utils.hpp: grid_reduce_finish; a fence there
+    is a write-back of an XCD's L2).  Stress: the largest grids the kernels use (8192 workgroups spread over all eight
+    XCDs), hundreds of launches back to back, with sums whose exact value is known: a partial that arrived late or stale
+    would show up as a wrong integer."""
+    import ctypes as C
+    from rocalution_amd import capi
+    lib = capi.load()
+    n = 8192 * 256 * 4 + 37
+    rng = np.random.default_rng(3)
+    hx = rng.integers(-3, 4, n).astype(np.float64)
+    hy = rng.integers(-3, 4, n).astype(np.float64)
+    x, y = ra.LocalVector(data=hx), ra.LocalVector(data=hy)
+    exact_dot, exact_nrm2 = float(np.dot(hx, hy)), float(np.dot(hx, hx))
+    for rep in range(150):
+        assert x.Dot(y) == exact_dot, rep
+        assert x.Norm() ** 2 == pytest.approx(exact_nrm2, rel=1e-15), rep
+    hs = (capi.vec_t * 2)(x._h, y._h)
+    out = (C.c_double * 2)()
+    for rep in range(150):
+        capi.check(lib.ramd_fused_multi_dot(hs, 2, y._h, 40))
+        capi.check(lib.ramd_scalars_fetch(out, 40, 2))
+        assert (out[0], out[1]) == (exact_dot, float(np.dot(hy, hy))), rep

@@ -192,17 +192,22 @@ static void sweep(const Bufs& B, const char* name, int bpe)
 // calibration of the FETCH_SIZE counter against known byte counts: the same 1 GiB read with 16, 8 and 4 bytes per lane
 //   rocprofv3 --pmc FETCH_SIZE --kernel-trace -- tools/_bin/membench calib
 template <typename X>
-__global__ __launch_bounds__(256) void k_calib_read(int64_t nx, const X* __restrict__ a, double* __restrict__ sink)
+__global__ __launch_bounds__(256) void k_calib_read(int64_t nx, const X* __restrict__ a, double* __restrict__ sink, int magic)
 {
+    // (round 2's version compared against a constant no int can convert to: the 4-byte instantiation was proven dead and
+    //  read nothing -- 8.5 KiB "fetched" for 1 GiB.  The value is now compared with a kernel argument.)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if(i < nx)
     {
-        X      v = a[i];
-        double s = 0.0;
-        for(unsigned k = 0; k < sizeof(X) / 4; ++k)
-            s += (double)reinterpret_cast<const int*>(&v)[k];
-        if(s == 1.2345e300)
-            sink[0] = s;
+        X   v = a[i];
+        int s = 0;
+        if(sizeof(X) >= 4)
+            for(unsigned k = 0; k < sizeof(X) / 4; ++k)
+                s ^= reinterpret_cast<const int*>(&v)[k];
+        else
+            s = (int)*reinterpret_cast<const unsigned char*>(&v);
+        if(s == magic)
+            sink[0] = (double)s;
     }
 }
 
@@ -219,14 +224,16 @@ int main(int argc, char** argv)
         for(int rep = 0; rep < 3; ++rep)
         {
             hipLaunchKernelGGL((k_calib_read<v2>), dim3((unsigned)(bytes / 16 / 256)), dim3(256), 0, 0, (int64_t)(bytes / 16),
-                               (const v2*)a, sink);
+                               (const v2*)a, sink, 0x5a5a5a5a);
             hipLaunchKernelGGL((k_calib_read<double>), dim3((unsigned)(bytes / 8 / 256)), dim3(256), 0, 0, (int64_t)(bytes / 8),
-                               (const double*)a, sink);
+                               (const double*)a, sink, 0x5a5a5a5a);
             hipLaunchKernelGGL((k_calib_read<int>), dim3((unsigned)(bytes / 4 / 256)), dim3(256), 0, 0, (int64_t)(bytes / 4),
-                               (const int*)a, sink);
+                               (const int*)a, sink, 0x5a5a5a5a);
+            hipLaunchKernelGGL((k_calib_read<unsigned char>), dim3((unsigned)(bytes / 4 / 256)), dim3(256), 0, 0, (int64_t)(bytes / 4),
+                               (const unsigned char*)a, sink, 0x5a);
         }
         CHECK(hipDeviceSynchronize());
-        printf("calib: 3 x (16 B, 8 B, 4 B per lane) reads of %zu bytes each\n", bytes);
+        printf("calib: 3 x (16 B, 8 B, 4 B per lane reads of %zu bytes, 1 B per lane read of %zu bytes)\n", bytes, bytes / 4);
         return 0;
     }
     const int64_t n = argc > 1 ? atoll(argv[1]) : (int64_t)512 * 512 * 512;

@@ -1,4 +1,4 @@
-"""Turn the rocprofv3 sqlite outputs under gpurun_out/prof/ (tools/profile_r02.sh) into small text summaries in profiles/."""
+"""Turn the rocprofv3 sqlite outputs under gpurun_out/prof/ (tools/profile_r03.sh) into small text summaries in profiles/."""
 import json, os, sqlite3, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof")
@@ -8,7 +8,9 @@ os.makedirs(out, exist_ok=True)
 
 WHAT = {"cg": "python bench.py --steps 100 --warmup 10 (512^3 CG+Jacobi, the headline)",
         "gmres": "python bench.py --solver gmres --precond ilu0 --steps 60 --warmup 10 (512^3 GMRES(30)+ILU(0))",
-        "shell": "python bench.py --matrix shell --solver gmres --precond ilu0 --steps 60 --warmup 10 (config 3 surrogate)"}
+        "shell": "python bench.py --matrix shell --solver gmres --precond ilu0 --steps 60 --warmup 10 (config 3 surrogate)",
+        "bicgstab": "python bench.py --solver bicgstab --precond mcsgs --steps 60 --warmup 10 (512^3 BiCGStab+MC-SGS, config 4's solver)",
+        "calib": "tools/_bin/membench calib (reads of 1 GiB with 16 / 8 / 4 bytes per lane, of 256 MiB with 1 byte per lane)"}
 
 
 def q(db, sql):
@@ -35,6 +37,8 @@ for name, what in WHAT.items():
 traffic = {}
 for name in WHAT:
     vals = {}
+    if name == "calib" and tag == "r02":
+        continue
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         db = os.path.join(src, "%s_%s" % (ctr, name), "bench_results.db")
         if not os.path.exists(db):
@@ -43,9 +47,11 @@ for name in WHAT:
                      "group by kernel_name,counter_name order by avg(value) desc limit 48")
         with open(os.path.join(out, "%s_pmc_%s_%s.txt" % (tag, ctr, name)), "w") as f:
             f.write("# rocprofv3 --pmc %s --kernel-trace -- %s   (one counter per pass)\n" % (ctr, WHAT[name].split(" (")[0].replace("--steps 100 --warmup 10", "--steps 20 --warmup 2").replace("--steps 60 --warmup 10", "--steps 20 --warmup 2")))
-            f.write("# KiB per dispatch as reported.  gfx950: FETCH_SIZE counts 64 B per 128-B request for 16-byte-per-lane streaming\n"
-                    "# reads, i.e. HALF the bytes (MI355X_MICROARCH.md, HBM section; verified on the fused vector kernels whose traffic\n"
-                    "# is known exactly); narrower reads are counted in full.  WRITE_SIZE matches the written volume.\n")
+            f.write("# KiB per dispatch as reported.  gfx950: FETCH_SIZE counts 64 B per 128-B request, i.e. HALF the bytes read\n"
+                    "# (MI355X_MICROARCH.md, HBM section) -- calibrated in this round on reads of known size with 16, 8, 4 and 1 bytes per\n"
+                    "# lane (r03_pmc_FETCH_SIZE_calib.txt: 0.5000 of the bytes every time; round 2's 4-byte kernel had been optimised away and\n"
+                    "# its conclusion that narrow reads are counted in full was wrong).  WRITE_SIZE matches the written volume (calib: a 1-GiB\n"
+                    "# fill reports 1 GiB).  HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE.\n")
             f.write("# kernel | counter | dispatches | avg | min | max\n")
             for r in rows:
                 f.write("%s | %s | %d | %.1f | %.1f | %.1f\n" % (short(r[0]), r[1], r[2], r[3], r[4], r[5]))
