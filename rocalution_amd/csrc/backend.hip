@@ -3,6 +3,7 @@
 // streams and the compute_{default,interior,ghost} switches) -- no rocBLAS/rocSPARSE handles.
 #include "common.hpp"
 
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <unordered_map>
@@ -265,6 +266,20 @@ int probe_class(AllocCache& c, void* p, size_t bytes)
 
 // milliseconds of one pass writing `bytes` (a multiple of 4 KiB) to both blocks at once -- the direct measurement of how two
 // blocks get along as the two outputs of one kernel (contents are overwritten with zeros)
+// Build-phase stopwatch for tools/ (RAMD_BUILD_VERBOSE=1): synchronises the device, so only for diagnosis
+void build_mark(const char* what)
+{
+    static const bool on = getenv("RAMD_BUILD_VERBOSE") != nullptr;
+    if(!on)
+        return;
+    static std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    (void)hipDeviceSynchronize();
+    const auto now = std::chrono::steady_clock::now();
+    if(what)
+        fprintf(stderr, "build phase %-34s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+    last = now;
+}
+
 float probe_write_pair_ms(void* a, void* b2, size_t bytes)
 {
     hipEvent_t e0 = nullptr, e1 = nullptr;

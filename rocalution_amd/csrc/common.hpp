@@ -92,6 +92,7 @@ hipError_t cached_malloc_bytes(void** p, size_t bytes);
 hipError_t cached_free(void* p);
 hipError_t cached_malloc_apart(void** p, size_t bytes, const void* other); // in the placement class opposite to `other`'s
 int        cached_block_class(const void* p); // 0 / 1, or -1 (small block, not classified)
+void       build_mark(const char* what); // RAMD_BUILD_VERBOSE: device-synchronised wall time since the previous mark (stderr)
 float      probe_write_pair_ms(void* a, void* b, size_t bytes); // one pass writing both blocks at once (zeros), best of 4
 void       cached_release_all(void);
 template <typename X>

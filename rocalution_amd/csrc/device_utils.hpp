@@ -163,14 +163,19 @@ __device__ __forceinline__ void spin_guard(int& spins)
         __builtin_trap();
 }
 
+// poll_turn (the sweeps in 64-row units, trisolve.hip / blocksched.hip): a wave none of whose lanes advanced in the last
+// turn waits with ONE polling lane -- its first unfinished one -- instead of 64; everybody polls again once that lane gets
+// through.  On a dependency graph with little parallelism (an FE shell: ~20 units per level) nearly all of the ~8000
+// resident waves wait, and 64 polls per wave and turn saturate the L2 the few productive waves need: measured 0.37 s for
+// the level sweep of the 1.5 M-row shell surrogate before, 0.19 s after (the rest was the unit structure, blocksched.hip).
 // polling loops: sleep when no lane of the wave advanced, doubling up to 64 x 64 cycles; returns the next back-off
-__device__ __forceinline__ int poll_backoff(bool wave_advanced, int backoff)
+__device__ __forceinline__ int poll_backoff(bool wave_advanced, int backoff, int cap = 64)
 {
     if(wave_advanced)
         return 1;
     for(int z = 0; z < backoff; ++z)
         __builtin_amdgcn_s_sleep(1);
-    return backoff < 64 ? backoff * 2 : 64;
+    return backoff < cap ? backoff * 2 : cap;
 }
 
 // workgroup ticket: the k-th workgroup to START works on block k (deadlock freedom does not depend
@@ -182,6 +187,15 @@ __device__ __forceinline__ unsigned take_ticket(unsigned* counter, unsigned base
         s_t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base;
     __syncthreads();
     return s_t;
+}
+
+// ... per wave: the k-th WAVE to start works on unit k (sweeps in units of 64 rows)
+__device__ __forceinline__ unsigned take_wave_ticket(unsigned* counter, unsigned base)
+{
+    unsigned v = 0;
+    if((threadIdx.x & 63) == 0)
+        v = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base;
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
 }
 
 inline ReduceCtx reduce_ctx(int ticket_id = 0)

@@ -64,6 +64,26 @@ int mat_symbolic_power(const ramd_mat_s* a, int q, ramd_mat_s** out);
 
 // blocksched.hip: hyperplane order of the row blocks for the natural-order sync-free sweeps (nullptr: natural)
 int block_schedule(const ramd_mat_s* m, bool lower, int** order_out);
+// ... and the wave units (<= 64 consecutive sweep rows that belong together) of the sweeps with in-wave register resolution
+// (trisolve.hip), with their order by level of the unit graph, all computed on the device
+struct UnitPlan
+{
+    int  nunits = 0;
+    int* ustart = nullptr; // [nunits + 1] first sweep row of every unit
+    int* order  = nullptr; // [nunits] or nullptr: natural order
+    void release();
+};
+struct UnitView // (kernel argument)
+{
+    const int* ustart;
+    const int* order;
+    int        nunits;
+};
+inline UnitView unit_view(const UnitPlan& p)
+{
+    return UnitView{p.ustart, p.order, p.nunits};
+}
+int unit_schedule(const ramd_mat_s* m, bool lower, UnitPlan* out);
 
 // coloring.hip: device greedy colouring; RAMD_ERR_UNSUPPORTED -> caller runs the host sweep
 int multicoloring_device(const ramd_mat_s* m, int* num_colors, int* size_colors, ramd_vec_s* perm);

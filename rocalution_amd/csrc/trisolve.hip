@@ -83,47 +83,65 @@ __global__ __launch_bounds__(kBlock) void k_fill_sentinel(int64_t n, T* __restri
         w[i] = s;
 }
 
+__device__ __forceinline__ bool lane_bit(unsigned long long mask, int b) // (b wave-uniform: 32-bit shifts)
+{
+    const unsigned half = b < 32 ? (unsigned)mask : (unsigned)(mask >> 32);
+    return (half >> (b & 31)) & 1u;
+}
+
+// workgroup size of the sweeps that take their rows in 64-row wave units (k_levels, k_ct_glevels, k_ct_coords, k_ilu0_rows):
+// one ticket per workgroup -- ~10 ns per atomic on the one counter, 1.3 ms for the 131 072 workgroups of 512^3 (a ticket per
+// wave: 21 ms, per 256 rows: 5 ms, both more than the level sweep itself).  The 16 waves of workgroup k take the units
+// order[16 k .. 16 k + 15]: every unit a unit waits for sits at an earlier place of that order, i.e. in a workgroup that
+// started earlier or in this one.
+constexpr int kSweepBlock = 1024;
+
 // ---------------------------------------------------------------- levels (natural order, once)
 // level[i] = 1 + max(level[dep]); 0 means "not computed yet" and doubles as the poll flag.
 // LOWER: deps are columns < i, rows taken in ascending order; else columns > i, descending order.
+//
+// A wave holds 64 consecutive rows of the sweep, so a dependency is either a row of an EARLIER wave (polled in memory) or a
+// row of a lower lane of this wave.  The two kinds are separated: (A) every lane consumes its out-of-wave dependencies and
+// notes the in-wave ones in a 64-bit lane mask; (B) the in-wave part -- a longest path over the lanes in ascending order --
+// is resolved in registers: at step b lane b is final (its in-wave dependencies are lower lanes), its value is broadcast
+// with one v_readlane and the lanes that hold bit b take it.  A chain link inside the wave costs a handful of ALU
+// instructions instead of a trip through the L2 (~0.4 us: the i-1 chain of a 512-row grid line used to take ~100 us per
+// 256-row block, 0.11 s per sweep at 512^3); the wave publishes its 64 levels together.
 template <bool LOWER>
-__global__ __launch_bounds__(kBlock) void k_levels(int nrow, const int* __restrict__ rp,
+__global__ __launch_bounds__(kSweepBlock) void k_levels(int nrow, const int* __restrict__ rp,
                                                    const int* __restrict__ ci, int* level,
                                                    unsigned* counter, unsigned base,
-                                                   const int* __restrict__ block_order)
+                                                   UnitView uv, int poll_cap)
 {
-    const unsigned tick = take_ticket(counter, base);
-    const unsigned blk  = block_order ? (unsigned)block_order[tick] : tick; // blocksched.hip
-    const int64_t  t    = (int64_t)blk * kBlock + threadIdx.x;
-    const bool     live = t < nrow;
+    const unsigned slot = take_ticket(counter, base) * (blockDim.x >> 6) + (threadIdx.x >> 6); // (one ticket per workgroup)
     const int      lane = threadIdx.x & 63;
+    const bool     have = slot < (unsigned)uv.nunits; // unit_schedule: the rows of my unit
+    const int      unit = have ? (uv.order ? uv.order[slot] : (int)slot) : 0;
+    const int      ufirst = have ? uv.ustart[unit] : 0;
+    const int64_t  t    = (int64_t)ufirst + lane;
+    const bool     live = have && t < uv.ustart[unit + 1];
     const int      i    = live ? (LOWER ? (int)t : (int)(nrow - 1 - t)) : 0;
-    // rows handled by my wave: i0 .. (LOWER: ascending, else descending) -- their levels travel through
-    // shuffles (the i-1 / i+1 chain of a stencil never leaves the registers), others through memory
-    const int i0  = LOWER ? i - lane : i + lane;
-    // dependencies are taken far-to-near in sweep order (LOWER: ascending columns, else descending): the nearest one -- the
-    // chain predecessor, the last to become ready -- comes last, when everything else is consumed.  (Scanning the upper
-    // part in ascending columns blocked on the predecessor FIRST and took the other in-wave dependencies, one per turn,
-    // only after it: 4-5x the sweep time on FE matrices with ~10 in-wave dependencies per row.)
-    const int dir = LOWER ? 1 : -1;
-    int       j   = live ? (LOWER ? rp[i] : rp[i + 1] - 1) : 0;
-    const int end = live ? (LOWER ? rp[i + 1] : rp[i] - 1) : 0; // one past the last entry in scan direction
-    int       lev = 0, mine = 0;
-    // SIMT hazard: lanes of one wave may depend on each other, and a lane that has LEFT a loop cannot
-    // execute anything until the whole wave leaves it.  So results are published inside the loop and
-    // the loop exit is made wave-uniform with a ballot (otherwise the compiler is free to sink the
-    // publish into the loop's exit block, which deadlocks).
-    bool fin   = !live;
-    int  spins = 0;
+    const int      i0   = LOWER ? i - lane : i + lane; // the row of lane 0
+    const int      dir  = LOWER ? 1 : -1;
+    int            j    = live ? (LOWER ? rp[i] : rp[i + 1] - 1) : 0;
+    const int      end  = live ? (LOWER ? rp[i + 1] : rp[i] - 1) : 0; // one past the last entry in scan direction
+    int            lev  = 0;
+    unsigned long long inwave = 0ull;
+    // (A) SIMT hazard: a lane that has LEFT a loop cannot execute anything until the whole wave leaves it, so the loop
+    // exit is made wave-uniform with a ballot
+    bool fin     = !live;
+    int  spins   = 0;
+    int  backoff = 1;
+    bool stalled = false; // nobody of the wave advanced last turn
     do
     {
         spin_guard(spins);
         const int  j_start = j;
         const bool was_fin = fin;
-        int        want    = lane; // at most one in-wave dependency per turn
-        if(!fin)
+        const bool my_turn = !stalled || lane == (int)__ffsll((long long)__ballot(!fin)) - 1; // (see poll_turn)
+        if(!fin && my_turn)
         {
-            while(j != end) // dependencies held by other waves: take every one that is ready
+            while(j != end)
             {
                 const int c = ci[j];
                 if(LOWER ? (c >= i) : (c <= i))
@@ -132,10 +150,11 @@ __global__ __launch_bounds__(kBlock) void k_levels(int nrow, const int* __restri
                     continue;
                 }
                 const int rel = LOWER ? c - i0 : i0 - c; // lane that owns row c, if it is one of mine
-                if(rel >= 0 && rel < 64)
+                if(rel >= 0)
                 {
-                    want = rel;
-                    break;
+                    inwave |= 1ull << rel; // (rel < lane)
+                    j += dir;
+                    continue;
                 }
                 const int lc = __hip_atomic_load(level + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if(lc == 0)
@@ -143,26 +162,23 @@ __global__ __launch_bounds__(kBlock) void k_levels(int nrow, const int* __restri
                 lev = max(lev, lc);
                 j += dir;
             }
-        }
-        const int got = __shfl(mine, want, 64);
-        if(!fin)
-        {
-            if(want != lane && got != 0)
-            {
-                lev = max(lev, got);
-                j += dir;
-            }
-            if(j == end)
-            {
-                mine = lev + 1;
-                __hip_atomic_store(level + i, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                fin = true;
-            }
+            fin = (j == end);
         }
         // nobody in the wave advanced (all waiting on other waves): back off instead of flooding the L2 with polls
-        if(__ballot(!was_fin && (fin || j != j_start)) == 0ull)
-            __builtin_amdgcn_s_sleep(8);
+        const bool advanced = __ballot(!was_fin && (fin || j != j_start)) != 0ull;
+        stalled             = !advanced;
+        backoff             = poll_backoff(advanced, backoff, poll_cap);
     } while(__ballot(!fin) != 0ull);
+    // (B)
+    if(__ballot(inwave != 0ull) != 0ull)
+        for(int b = 0; b < 63; ++b)
+        {
+            const int lb = __builtin_amdgcn_readlane(lev, b) + 1;
+            if(lane_bit(inwave, b))
+                lev = max(lev, lb);
+        }
+    if(live)
+        __hip_atomic_store(level + i, lev + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ __launch_bounds__(kBlock) void k_invert_perm(int n, const int* __restrict__ order,
@@ -439,6 +455,219 @@ __global__ __launch_bounds__(kBlock) void k_ilu0(int nrow, const int* __restrict
     } while(__ballot(!fin) != 0ull);
 }
 
+// ... the same factorisation for rows of at most kIluW entries, in NATURAL order (blocks in hyperplane order, blocksched.hip):
+// a lane keeps its whole row in registers; pivot rows of earlier waves are read from memory as above, pivot rows held by a
+// lower lane of the same wave -- they are the LAST pivots of the row, the columns being sorted -- are taken from that
+// lane's registers, lane by lane in ascending order (at step b lane b is final; see k_levels).  The i-1 chain of a grid
+// line never leaves the wave: a link costs ~200 ALU instructions instead of a flag, a pivot and a row fetched through the
+// L2, and the sweep reads and writes the matrix in storage order (the level order above touches ~25 scattered 64-byte
+// lines per row: 0.26 s at 512^3).  Same operations per entry in the same ascending-pivot order: bit-identical factors.
+constexpr int kIluW = 8;
+
+template <typename T>
+__device__ __forceinline__ T bcast_lane(T v, int lane_id);
+template <>
+__device__ __forceinline__ float bcast_lane<float>(float v, int lane_id)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_id));
+}
+template <>
+__device__ __forceinline__ double bcast_lane<double>(double v, int lane_id)
+{
+    const long long bits = __double_as_longlong(v);
+    const int       lo   = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), lane_id);
+    const int       hi   = __builtin_amdgcn_readlane((int)(bits >> 32), lane_id);
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+
+template <typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_ilu0_rows(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                      T* val, int* done, int* diag_pos, unsigned* counter, unsigned base,
+                                                      UnitView uv, int poll_cap)
+{
+    using B             = typename Sentinel<T>::bits;
+    constexpr int  NO   = kIluW - 1; // entries besides the pivot entry
+    const unsigned slot = take_ticket(counter, base) * (BLOCK / 64) + (threadIdx.x >> 6); // (one ticket per workgroup)
+    const int      lane = threadIdx.x & 63;
+    const bool     have = slot < (unsigned)uv.nunits; // unit_schedule: the rows of my unit
+    const int      unit = have ? (uv.order ? uv.order[slot] : (int)slot) : 0;
+    const int      ufirst = have ? uv.ustart[unit] : 0;
+    const int64_t  t    = (int64_t)ufirst + lane;
+    const bool     live = have && t < uv.ustart[unit + 1];
+    const int      i    = live ? (int)t : 0;
+    const int      i0   = (int)t - lane; // the row of lane 0
+    const int      rs   = live ? rp[i] : 0;
+    const int      len  = live ? rp[i + 1] - rs : 0; // <= kIluW (caller)
+    // the row in registers: the pivot entry -- the first one at or right of the diagonal ("diag_offset", host :2162) -- apart
+    // (dcol, dg), the other entries in storage order (oc, ov): [0, dp) left of it, [dp, len - 1) right of it
+    int dp = 0, dcol = 0x7fffffff;
+    T   dg = (T)0;
+    int oc[NO];
+    T   ov[NO];
+    {
+        int cols[kIluW];
+        T   vals[kIluW];
+#pragma unroll
+        for(int m = 0; m < kIluW; ++m)
+        {
+            cols[m] = m < len ? ci[rs + m] : 0x7fffffff;
+            vals[m] = m < len ? val[rs + m] : (T)0;
+            dp += (cols[m] < i) ? 1 : 0;
+        }
+#pragma unroll
+        for(int m = 0; m < kIluW; ++m)
+        {
+            dcol = (m == dp) ? cols[m] : dcol;
+            dg   = (m == dp) ? vals[m] : dg;
+        }
+#pragma unroll
+        for(int m = 0; m < NO; ++m)
+        {
+            oc[m] = m < dp ? cols[m] : cols[m + 1];
+            ov[m] = m < dp ? vals[m] : vals[m + 1];
+        }
+    }
+    const int          nup     = len - 1 - dp; // entries right of the pivot entry (< 0: there is none)
+    unsigned long long inwave  = 0ull;
+    int                a       = 0; // next pivot of the row
+    bool               fin     = !live;
+    int                spins   = 0;
+    int                backoff = 1;
+    bool stalled = false; // nobody of the wave advanced last turn
+    do // (A) pivot rows held by earlier waves; wave-uniform exit as in k_levels
+    {
+        spin_guard(spins);
+        const int  a_before   = a;
+        const bool fin_before = fin;
+        const bool my_turn = !stalled || lane == (int)__ffsll((long long)__ballot(!fin)) - 1; // (see poll_turn)
+        if(!fin && my_turn)
+        {
+            if(a < dp)
+            {
+                int k = 0;
+#pragma unroll
+                for(int m = 0; m < NO; ++m)
+                    k = (m == a) ? oc[m] : k;
+                if(k >= i0)
+                {
+                    inwave |= 1ull << (k - i0);
+                    ++a;
+                }
+                else if(__hip_atomic_load(done + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                {
+                    const int kd    = __hip_atomic_load(diag_pos + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int kre   = rp[k + 1];
+                    const T   pivot = Sentinel<T>::from_bits(__hip_atomic_load(
+                        reinterpret_cast<const B*>(val + kd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if(pivot != (T)0)
+                    {
+                        T x = (T)0;
+#pragma unroll
+                        for(int m = 0; m < NO; ++m)
+                            x = (m == a) ? ov[m] : x;
+                        const T f = x / pivot;
+#pragma unroll
+                        for(int m = 0; m < NO; ++m)
+                            ov[m] = (m == a) ? f : ov[m];
+                        for(int q = kd + 1; q < kre; ++q)
+                        {
+                            const int cq  = ci[q];
+                            const T   akq = Sentinel<T>::from_bits(__hip_atomic_load(
+                                reinterpret_cast<const B*>(val + q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            if(cq == dcol)
+                                dg -= f * akq;
+#pragma unroll
+                            for(int m = 0; m < NO; ++m) // (cq > k: a match lies right of (i, k))
+                                if(oc[m] == cq)
+                                    ov[m] -= f * akq;
+                        }
+                    }
+                    ++a;
+                }
+            }
+            else
+                fin = true;
+        }
+        const bool advanced = __ballot(!fin_before && (fin || a != a_before)) != 0ull;
+        stalled             = !advanced;
+        backoff             = poll_backoff(advanced, backoff, poll_cap);
+    } while(__ballot(!fin) != 0ull);
+    if(__ballot(inwave != 0ull) != 0ull) // (B) pivot rows held by lower lanes
+    {
+        const int meta = (dp & 0xff) | ((nup & 0xff) << 8); // (nup = -1 -> 0xff)
+        for(int b = 0; b < 63; ++b)
+        {
+            const bool mine = lane_bit(inwave, b);
+            if(__ballot(mine) == 0ull)
+                continue;
+            const int metab = __builtin_amdgcn_readlane(meta, b);
+            const int dpb = metab & 0xff, nupb = (metab >> 8) & 0xff;
+            const T   pivot = bcast_lane<T>(dg, b);
+            if(nupb == 0xff || pivot == (T)0) // (no entry at or right of the diagonal: nothing to eliminate with)
+                continue;
+            const int kb = i0 + b;
+            T         x  = (T)0;
+#pragma unroll
+            for(int m = 0; m < NO; ++m)
+                x = (oc[m] == kb) ? ov[m] : x;
+            const T f = x / pivot;
+#pragma unroll
+            for(int m = 0; m < NO; ++m)
+                ov[m] = (mine && oc[m] == kb) ? f : ov[m];
+#pragma unroll
+            for(int mb = 0; mb < NO; ++mb)
+                if(mb >= dpb && mb < dpb + nupb) // (wave-uniform)
+                {
+                    const int cb = __builtin_amdgcn_readlane(oc[mb], b);
+                    const T   vb = bcast_lane<T>(ov[mb], b);
+                    const int cm = mine ? cb : -1; // (no column is -1)
+                    // (most entries of a pivot row meet nothing in the rows that use it -- on a 7-point grid two of three:
+                    //  the column tests alone, 8 of the ~35 instructions, tell)
+                    bool hit = (dcol == cm);
+#pragma unroll
+                    for(int m = 0; m < NO; ++m)
+                        hit = hit || (oc[m] == cm);
+                    if(__ballot(hit) == 0ull)
+                        continue;
+                    if(dcol == cm)
+                        dg -= f * vb;
+#pragma unroll
+                    for(int m = 0; m < NO; ++m)
+                        if(oc[m] == cm)
+                            ov[m] -= f * vb;
+                }
+        }
+    }
+    if(live)
+    {
+        // publish the finished row write-through, then the flag
+#pragma unroll
+        for(int m = 0; m < kIluW; ++m)
+            if(m < len)
+            {
+                const T v = m == dp ? dg : (m < dp ? ov[m < NO ? m : 0] : ov[m > 0 ? m - 1 : 0]);
+                __hip_atomic_store(reinterpret_cast<B*>(val + rs + m), Sentinel<T>::as_bits(v), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        __hip_atomic_store(diag_pos + i, rs + dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(done + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_max_row_len(int n, const int* __restrict__ rp, int* __restrict__ out)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    int           mx  = 0;
+    for(int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gsz)
+        mx = max(mx, rp[r + 1] - rp[r]);
+#pragma unroll
+    for(int off = 32; off > 0; off >>= 1)
+        mx = max(mx, __shfl_xor(mx, off, 64));
+    if((threadIdx.x & 63) == 0 && mx > 0)
+        atomicMax(out, mx);
+}
+
 // ---------------------------------------------------------------- plans
 struct TriPlan
 {
@@ -636,10 +865,28 @@ static unsigned nblocks_of(int n)
 {
     return (unsigned)((n + kBlock - 1) / kBlock);
 }
+static int sweep_poll_cap()
+{
+    // longest sleep between two polls of a stalled wave, in units of 64 cycles (device_utils.hpp poll_backoff)
+    static const int v = getenv("RAMD_SWEEP_POLLCAP") ? atoi(getenv("RAMD_SWEEP_POLLCAP")) : 64;
+    return v;
+}
+static int sweep_block_size()
+{
+    static const int v = getenv("RAMD_SWEEP_BLOCK") ? atoi(getenv("RAMD_SWEEP_BLOCK")) : kSweepBlock; // (64 .. 1024, experiments)
+    return v;
+}
+static unsigned sweep_blocks(int nunits) // workgroups for that many wave units
+{
+    const int per = sweep_block_size() / 64;
+    return (unsigned)((nunits + per - 1) / per);
+}
 
 // dependency levels (sync-free sweep in natural order) and the rows ordered by (level, row): a stable sort,
 // so rows of one level keep ascending row order and neighbouring positions poll / gather neighbouring memory
-static int level_order(ramd_mat_s* m, TriState* st, bool lower, int** order_out, int* nlev_out, int** level_out = nullptr)
+// (order_out == nullptr: only the levels are wanted; units: a unit order the caller holds already, see unit_schedule)
+static int level_order(ramd_mat_s* m, TriState* st, bool lower, int** order_out, int* nlev_out, int** level_out = nullptr,
+                       const UnitPlan* units = nullptr)
 {
     Backend&       b     = backend();
     const int      n     = m->nrow;
@@ -647,23 +894,37 @@ static int level_order(ramd_mat_s* m, TriState* st, bool lower, int** order_out,
     const unsigned nb    = nblocks_of(n);
     RAMD_TRY(dev_alloc(&level, n));
     hipError_t e = hipMemsetAsync(level, 0, sizeof(int) * (size_t)n, b.cur);
-    int*       border = nullptr;
-    (void)block_schedule(m, lower, &border); // nullptr: natural order
+    UnitPlan own;
+    build_mark(nullptr);
+    if(!units)
+    {
+        int su = unit_schedule(m, lower, &own);
+        if(su != RAMD_OK)
+        {
+            dev_free(&level);
+            return su;
+        }
+        units = &own;
+    }
+    build_mark("levels: unit schedule");
+    const unsigned nbs = sweep_blocks(units->nunits);
     if(lower)
-        hipLaunchKernelGGL((k_levels<true>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, level,
-                           st->counter, st->ticket, border);
+        hipLaunchKernelGGL((k_levels<true>), dim3(nbs), dim3(sweep_block_size()), 0, b.cur, n, m->rp, m->ci, level,
+                           st->counter, st->ticket, unit_view(*units), sweep_poll_cap());
     else
-        hipLaunchKernelGGL((k_levels<false>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, level,
-                           st->counter, st->ticket, border);
-    st->ticket += nb;
+        hipLaunchKernelGGL((k_levels<false>), dim3(nbs), dim3(sweep_block_size()), 0, b.cur, n, m->rp, m->ci, level,
+                           st->counter, st->ticket, unit_view(*units), sweep_poll_cap());
+    st->ticket += nbs;
     int nlev = 0;
     int s    = (e == hipSuccess) ? device_max_int(level, n, &nlev) : RAMD_ERR_HIP; // (synchronises)
-    dev_free(&border);
+    build_mark("levels: sweep");
+    own.release();
     int* order = nullptr;
-    if(s == RAMD_OK)
+    if(s == RAMD_OK && order_out)
         s = dev_alloc(&order, n);
-    if(s == RAMD_OK)
+    if(s == RAMD_OK && order_out)
         s = device_stable_sort_by_key(level, n, nlev, order);
+    build_mark("levels: sort by level");
     if(s == RAMD_OK && level_out)
         *level_out = level; // the caller keeps (and frees) the per-row levels
     else
@@ -673,8 +934,9 @@ static int level_order(ramd_mat_s* m, TriState* st, bool lower, int** order_out,
         dev_free(&order);
         return s;
     }
-    *order_out = order;
-    *nlev_out  = nlev;
+    if(order_out)
+        *order_out = order;
+    *nlev_out = nlev;
     return RAMD_OK;
 }
 
@@ -957,31 +1219,40 @@ __global__ __launch_bounds__(kBlock) void k_ct_group_bounds(int n, const int* __
 
 // group levels, sync-free sweep in sweep order: level of a group = 1 + max level of the groups its rows depend on.  A row
 // publishes max(own external dependencies, the row before it in the group) + [it is the group's first row]; readers take
-// the word of the LAST row of a dependency's group.  0 = not computed yet.
+// the word of the LAST row of a dependency's group.  0 = not computed yet.  In-wave dependencies are resolved in registers
+// (see k_levels): `near` notes the lanes whose published value is taken as it is, `prev` the row before this one in its group.
 template <bool LOWER>
-__global__ __launch_bounds__(kBlock) void k_ct_glevels(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+__global__ __launch_bounds__(kSweepBlock) void k_ct_glevels(int n, const int* __restrict__ rp, const int* __restrict__ ci,
                                                        const int* __restrict__ gf, const int* __restrict__ gl, int* glev,
-                                                       unsigned* counter, unsigned base, const int* __restrict__ block_order)
+                                                       unsigned* counter, unsigned base, UnitView uv, int poll_cap)
 {
-    const unsigned tick = take_ticket(counter, base);
-    const unsigned blk  = block_order ? (unsigned)block_order[tick] : tick;
-    const int64_t  t    = (int64_t)blk * kBlock + threadIdx.x;
-    const bool     live = t < n;
+    const unsigned slot = take_ticket(counter, base) * (blockDim.x >> 6) + (threadIdx.x >> 6); // (one ticket per workgroup)
+    const int      lane = threadIdx.x & 63;
+    const bool     have = slot < (unsigned)uv.nunits; // unit_schedule: the rows of my unit
+    const int      unit = have ? (uv.order ? uv.order[slot] : (int)slot) : 0;
+    const int      ufirst = have ? uv.ustart[unit] : 0;
+    const int64_t  t    = (int64_t)ufirst + lane;
+    const bool     live = have && t < uv.ustart[unit + 1];
+    const int      t0   = (int)t - lane; // sweep index of lane 0
     const int      i    = live ? (LOWER ? (int)t : (int)(n - 1 - t)) : 0;
     const int      dir  = LOWER ? 1 : -1; // far-to-near in sweep order, as k_levels
     int            j    = live ? (LOWER ? rp[i] : rp[i + 1] - 1) : 0;
     const int      end  = live ? (LOWER ? rp[i + 1] : rp[i] - 1) : 0;
     const int      myf  = live ? gf[t] : 0;
     int            lev  = 0;
+    unsigned long long near = 0ull;
+    bool           prev    = false;
     bool           fin     = !live;
     int            spins   = 0;
     int            backoff = 1;
+    bool stalled = false; // nobody of the wave advanced last turn
     do
     {
         spin_guard(spins);
         const int  j_start = j;
         const bool was_fin = fin;
-        if(!fin)
+        const bool my_turn = !stalled || lane == (int)__ffsll((long long)__ballot(!fin)) - 1; // (see poll_turn)
+        if(!fin && my_turn)
         {
             while(j != end)
             {
@@ -996,28 +1267,49 @@ __global__ __launch_bounds__(kBlock) void k_ct_glevels(int n, const int* __restr
                 {
                     if(tc == (int)t - 1)
                     {
-                        const int lc = __hip_atomic_load(glev + tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if(lc == 0)
-                            break;
-                        lev = max(lev, lc - 1);
+                        if(lane > 0)
+                            prev = true;
+                        else
+                        {
+                            const int lc = __hip_atomic_load(glev + tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if(lc == 0)
+                                break;
+                            lev = max(lev, lc - 1);
+                        }
                     }
                     j += dir;
                     continue;
                 }
-                const int lc = __hip_atomic_load(glev + gl[tc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int tg = gl[tc];
+                if(tg >= t0)
+                {
+                    near |= 1ull << (tg - t0);
+                    j += dir;
+                    continue;
+                }
+                const int lc = __hip_atomic_load(glev + tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if(lc == 0)
                     break;
                 lev = max(lev, lc);
                 j += dir;
             }
-            if(j == end)
-            {
-                __hip_atomic_store(glev + t, lev + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                fin = true;
-            }
+            fin = (j == end);
         }
-        backoff = poll_backoff(__ballot(!was_fin && (fin || j != j_start)) != 0ull, backoff);
+        const bool advanced = __ballot(!was_fin && (fin || j != j_start)) != 0ull;
+        stalled             = !advanced;
+        backoff             = poll_backoff(advanced, backoff, poll_cap);
     } while(__ballot(!fin) != 0ull);
+    if(__ballot(near != 0ull || prev) != 0ull)
+        for(int b = 0; b < 63; ++b)
+        {
+            const int pb = __builtin_amdgcn_readlane(lev, b) + 1; // what lane b publishes
+            if(lane_bit(near, b))
+                lev = max(lev, pb);
+            if(prev && lane == b + 1)
+                lev = max(lev, pb - 1);
+        }
+    if(live)
+        __hip_atomic_store(glev + t, lev + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // packed coordinates: bit 63 = computed, c0 24 bits, c1 20 bits, c2 19 bits, each saturating (a clamped monotone
@@ -1045,22 +1337,27 @@ __device__ __forceinline__ int ct_c2(unsigned long long w)
     return (int)((w >> (kCtC0Bits + kCtC1Bits)) & ((1ull << kCtC2Bits) - 1));
 }
 
-// sync-free sweep in sweep order (as k_levels): a row polls the packed words of its dependencies; the word is the flag
-// (one 8-byte agent-scope store per row).  ext[0..2] = maxima of the three coordinates.
+// sync-free sweep in sweep order (as k_levels): a row polls the packed words of its out-of-wave dependencies; the word is the
+// flag (one 8-byte agent-scope store per row); in-wave dependencies are resolved in registers, lane by lane (k_levels): a
+// lane mask per coordinate notes where the +1 applies.  ext[0..2] = maxima of the three coordinates.
 template <bool LOWER>
-__global__ __launch_bounds__(kBlock) void k_ct_coords(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+__global__ __launch_bounds__(kSweepBlock) void k_ct_coords(int n, const int* __restrict__ rp, const int* __restrict__ ci,
                                                       const int* __restrict__ escan, unsigned long long* word,
-                                                      int* __restrict__ ext, unsigned* counter, unsigned base,
-                                                      const int* __restrict__ block_order, const int* __restrict__ gf,
-                                                      const int* __restrict__ gl)
+                                                      int* ext, unsigned* counter, unsigned base,
+                                                      UnitView uv, const int* __restrict__ gf,
+                                                      const int* __restrict__ gl, int poll_cap)
 {
     // gf / gl != nullptr: row groups (k_ct_sn_breaks) -- the coordinates are those of the QUOTIENT graph (a group is one
     // vertex: contiguous pieces of a topological order, so the quotient is acyclic): in-group dependencies add nothing, the
     // word of a dependency is the word of the last row of its group (the maximum over the group, handed from row to row)
-    const unsigned tick = take_ticket(counter, base);
-    const unsigned blk  = block_order ? (unsigned)block_order[tick] : tick; // hyperplane order of the blocks (blocksched.hip)
-    const int64_t  t    = (int64_t)blk * kBlock + threadIdx.x;
-    const bool     live = t < n;
+    const unsigned slot = take_ticket(counter, base) * (blockDim.x >> 6) + (threadIdx.x >> 6); // (one ticket per workgroup)
+    const int      lane = threadIdx.x & 63;
+    const bool     have = slot < (unsigned)uv.nunits; // unit_schedule: the rows of my unit
+    const int      unit = have ? (uv.order ? uv.order[slot] : (int)slot) : 0;
+    const int      ufirst = have ? uv.ustart[unit] : 0;
+    const int64_t  t    = (int64_t)ufirst + lane;
+    const bool     live = have && t < uv.ustart[unit + 1];
+    const int      t0   = (int)t - lane; // sweep index of lane 0
     const int      i    = live ? (LOWER ? (int)t : (int)(n - 1 - t)) : 0;
     const int      dir  = LOWER ? 1 : -1; // far-to-near in sweep order, as k_levels
     int            j    = live ? (LOWER ? rp[i] : rp[i + 1] - 1) : 0;
@@ -1068,15 +1365,18 @@ __global__ __launch_bounds__(kBlock) void k_ct_coords(int n, const int* __restri
     const int      mych = live ? escan[t + 1] - 1 : 0;
     const int      myf  = (live && gf) ? gf[t] : (int)t; // first row of my group
     int            c0 = 0, c1 = 0, c2 = 0;
+    unsigned long long near = 0ull, up0 = 0ull, up1 = 0ull, up2 = 0ull; // in-wave dependencies; where a coordinate steps
     bool           fin     = !live;
     int            spins   = 0;
     int            backoff = 1;
+    bool stalled = false; // nobody of the wave advanced last turn
     do
     {
         spin_guard(spins);
         const int  j_start = j;
         const bool was_fin = fin;
-        if(!fin)
+        const bool my_turn = !stalled || lane == (int)__ffsll((long long)__ballot(!fin)) - 1; // (see poll_turn)
+        if(!fin && my_turn)
         {
             while(j != end)
             {
@@ -1086,40 +1386,70 @@ __global__ __launch_bounds__(kBlock) void k_ct_coords(int n, const int* __restri
                     j = end; // sorted rows: no dependency follows in scan direction
                     continue;
                 }
-                const int                tc = LOWER ? c : n - 1 - c;
+                const int tc = LOWER ? c : n - 1 - c;
                 if(tc >= myf) // in-group (grouped form only): the row before this one carries the group's maxima so far
                 {
                     if(tc == (int)t - 1)
                     {
-                        const unsigned long long wp
-                            = __hip_atomic_load(word + tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if(!(wp & kCtReady))
-                            break;
-                        c0 = max(c0, ct_c0(wp));
-                        c1 = max(c1, ct_c1(wp));
-                        c2 = max(c2, ct_c2(wp));
+                        if(lane > 0)
+                            near |= 1ull << (lane - 1);
+                        else
+                        {
+                            const unsigned long long wp
+                                = __hip_atomic_load(word + tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if(!(wp & kCtReady))
+                                break;
+                            c0 = max(c0, ct_c0(wp));
+                            c1 = max(c1, ct_c1(wp));
+                            c2 = max(c2, ct_c2(wp));
+                        }
                     }
                     j += dir;
                     continue;
                 }
-                const unsigned long long w
-                    = __hip_atomic_load(word + (gl ? gl[tc] : tc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int  tg  = gl ? gl[tc] : tc;
+                const int  chc = escan[tc + 1] - 1;
+                const bool s0 = (tc == myf - 1 && chc == mych), s1 = (chc == mych - 1), s2 = (chc < mych - 1);
+                if(tg >= t0)
+                {
+                    const unsigned long long bit = 1ull << (tg - t0);
+                    near |= bit;
+                    up0 |= s0 ? bit : 0ull; // (several rows of one group: the maximum of the steps)
+                    up1 |= s1 ? bit : 0ull;
+                    up2 |= s2 ? bit : 0ull;
+                    j += dir;
+                    continue;
+                }
+                const unsigned long long w = __hip_atomic_load(word + tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if(!(w & kCtReady))
                     break;
-                const int chc = escan[tc + 1] - 1;
-                c0            = max(c0, ct_c0(w) + ((tc == myf - 1 && chc == mych) ? 1 : 0));
-                c1            = max(c1, ct_c1(w) + ((chc == mych - 1) ? 1 : 0));
-                c2            = max(c2, ct_c2(w) + ((chc < mych - 1) ? 1 : 0));
+                c0 = max(c0, ct_c0(w) + (s0 ? 1 : 0));
+                c1 = max(c1, ct_c1(w) + (s1 ? 1 : 0));
+                c2 = max(c2, ct_c2(w) + (s2 ? 1 : 0));
                 j += dir;
             }
-            if(j == end)
+            fin = (j == end);
+        }
+        const bool advanced = __ballot(!was_fin && (fin || j != j_start)) != 0ull;
+        stalled             = !advanced;
+        backoff             = poll_backoff(advanced, backoff, poll_cap);
+    } while(__ballot(!fin) != 0ull);
+    if(__ballot(near != 0ull) != 0ull)
+        for(int b = 0; b < 63; ++b)
+        {
+            // what lane b publishes (saturated like the packed word)
+            const int p0 = min(__builtin_amdgcn_readlane(c0, b), (1 << kCtC0Bits) - 1);
+            const int p1 = min(__builtin_amdgcn_readlane(c1, b), (1 << kCtC1Bits) - 1);
+            const int p2 = min(__builtin_amdgcn_readlane(c2, b), (1 << kCtC2Bits) - 1);
+            if(lane_bit(near, b))
             {
-                __hip_atomic_store(word + t, ct_pack(c0, c1, c2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                fin = true;
+                c0 = max(c0, p0 + (lane_bit(up0, b) ? 1 : 0));
+                c1 = max(c1, p1 + (lane_bit(up1, b) ? 1 : 0));
+                c2 = max(c2, p2 + (lane_bit(up2, b) ? 1 : 0));
             }
         }
-        backoff = poll_backoff(__ballot(!was_fin && (fin || j != j_start)) != 0ull, backoff);
-    } while(__ballot(!fin) != 0ull);
+    if(live)
+        __hip_atomic_store(word + t, ct_pack(c0, c1, c2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // maxima: one atomic per wave and coordinate
     int m0 = live ? min(c0, (1 << kCtC0Bits) - 1) : 0, m1 = live ? min(c1, (1 << kCtC1Bits) - 1) : 0,
         m2 = live ? min(c2, (1 << kCtC2Bits) - 1) : 0;
@@ -1130,11 +1460,16 @@ __global__ __launch_bounds__(kBlock) void k_ct_coords(int n, const int* __restri
         m1 = max(m1, __shfl_xor(m1, off, 64));
         m2 = max(m2, __shfl_xor(m2, off, 64));
     }
+    // (one address for every wave: an RMW costs ~10 ns there, 63 ms for the 6.3 M of a 512^3 sweep -- so only where it raises
+    //  the maximum, which a plain agent-scope load tells)
     if((threadIdx.x & 63) == 0)
     {
-        atomicMax(ext + 0, m0);
-        atomicMax(ext + 1, m1);
-        atomicMax(ext + 2, m2);
+        if(m0 > __hip_atomic_load(ext + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(ext + 0, m0);
+        if(m1 > __hip_atomic_load(ext + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(ext + 1, m1);
+        if(m2 > __hip_atomic_load(ext + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(ext + 2, m2);
     }
 }
 
@@ -2570,6 +2905,7 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
         *k2 = nullptr, *o2 = nullptr, *tflag = nullptr, *sflag = nullptr, *tscan = nullptr, *sscan = nullptr,
         *tile_of = nullptr, *step_of = nullptr, *step_w = nullptr, *nodiag = nullptr, *cext = nullptr, *tsz = nullptr,
         *ref_start = nullptr, *slot_of_ref = nullptr, *gf = nullptr, *gl = nullptr, *tposv = nullptr, *step_maxg = nullptr;
+    UnitPlan units;
     unsigned long long* word = nullptr;
     int  nlev = 0;
     int  s    = RAMD_OK;
@@ -2599,6 +2935,7 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
         dev_free(&gl);
         dev_free(&tposv);
         dev_free(&step_maxg);
+        units.release();
     };
 #define CT_TRY(expr)     \
     do                   \
@@ -2633,6 +2970,7 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     const int      grid = ew_grid(n + 1);
     const unsigned nb1  = (unsigned)(((int64_t)n + 1 + kBlock - 1) / kBlock);
     const unsigned nb   = nblocks_of(n);
+    build_mark(nullptr);
     // chains
     CT_TRY(dev_alloc(&start, (int64_t)n + 1));
     if(lower)
@@ -2740,6 +3078,7 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
         drop();
 #undef CT_TRYG
     }
+    build_mark("plan: chains, row widths, groups");
     // monotone coordinates (sync-free sweep) and their extents
     CT_TRY(dev_alloc(&word, n));
     CT_HIP(hipMemsetAsync(word, 0, sizeof(unsigned long long) * (size_t)n, b.cur));
@@ -2747,24 +3086,21 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     {
         // same block graph as the level sweep: blocks in hyperplane order fill the machine (natural order: only the ~2048
         // resident blocks -- two grid planes at 512^3 -- are in flight, the lines of a plane a serial chain inside that window)
-        int* border = nullptr;
-        (void)block_schedule(m, lower, &border); // nullptr: natural order
+        CT_TRY(unit_schedule(m, lower, &units)); // (kept for the level sweep below)
+        build_mark("plan: unit schedule");
+        const unsigned nbs = sweep_blocks(units.nunits);
         if(lower)
-            hipLaunchKernelGGL((k_ct_coords<true>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, start, word, cext,
-                               st->counter, st->ticket, border, gf, gl);
+            hipLaunchKernelGGL((k_ct_coords<true>), dim3(nbs), dim3(sweep_block_size()), 0, b.cur, n, m->rp, m->ci, start, word,
+                               cext, st->counter, st->ticket, unit_view(units), gf, gl, sweep_poll_cap());
         else
-            hipLaunchKernelGGL((k_ct_coords<false>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, start, word, cext,
-                               st->counter, st->ticket, border, gf, gl);
-        st->ticket += nb;
-        if(border)
-        {
-            (void)hipStreamSynchronize(b.cur);
-            dev_free(&border);
-        }
+            hipLaunchKernelGGL((k_ct_coords<false>), dim3(nbs), dim3(sweep_block_size()), 0, b.cur, n, m->rp, m->ci, start, word,
+                               cext, st->counter, st->ticket, unit_view(units), gf, gl, sweep_poll_cap());
+        st->ticket += nbs;
     }
     int hext[3] = {0, 0, 0};
     CT_HIP(hipMemcpyAsync(hext, cext, sizeof(int) * 3, hipMemcpyDeviceToHost, b.cur));
     CT_HIP(hipStreamSynchronize(b.cur));
+    build_mark("plan: coordinates sweep");
     dev_free(&start);
     // box sizes: b_k proportional to the extent E_k of every non-trivial coordinate (equal depth of the tile DAG in
     // every direction), about `rows` rows per tile; rows = what the LDS budget (~40 KB) allows for this row length
@@ -2795,17 +3131,15 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
         // levels of the quotient graph, in sweep order
         CT_TRY(dev_alloc(&level, n));
         CT_HIP(hipMemsetAsync(level, 0, sizeof(int) * (size_t)n, b.cur));
-        int* border = nullptr;
-        (void)block_schedule(m, lower, &border);
+        const unsigned nbs = sweep_blocks(units.nunits);
         if(lower)
-            hipLaunchKernelGGL((k_ct_glevels<true>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, gf, gl, level,
-                               st->counter, st->ticket, border);
+            hipLaunchKernelGGL((k_ct_glevels<true>), dim3(nbs), dim3(sweep_block_size()), 0, b.cur, n, m->rp, m->ci, gf, gl, level,
+                               st->counter, st->ticket, unit_view(units), sweep_poll_cap());
         else
-            hipLaunchKernelGGL((k_ct_glevels<false>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, gf, gl, level,
-                               st->counter, st->ticket, border);
-        st->ticket += nb;
+            hipLaunchKernelGGL((k_ct_glevels<false>), dim3(nbs), dim3(sweep_block_size()), 0, b.cur, n, m->rp, m->ci, gf, gl, level,
+                               st->counter, st->ticket, unit_view(units), sweep_poll_cap());
+        st->ticket += nbs;
         s = device_max_int(level, n, &nlev); // (synchronises)
-        dev_free(&border);
         CT_TRY(s);
     }
     else if(lower && st->l_level_cache) // the sweep ILU0Factorize ran on the same pattern
@@ -2816,12 +3150,15 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     }
     else
     {
-        CT_TRY(level_order(m, st, lower, &lorder, &nlev, &level));
-        dev_free(&lorder);
+        CT_TRY(level_order(m, st, lower, nullptr, &nlev, &level, &units));
     }
+    CT_HIP(hipStreamSynchronize(b.cur));
+    units.release();
+    build_mark("plan: levels");
     bool fits = false;
     for(int attempt = 0; attempt < 5 && !fits; ++attempt)
     {
+    build_mark(nullptr);
     const double f = pow((double)rows / (double)n, 1.0 / dnz);
     for(int k = 0; k < 3; ++k)
     {
@@ -2868,6 +3205,7 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     dev_free(&tkey);
     CT_TRY(dev_alloc(&o2, n));
     CT_TRY(device_stable_sort_by_key(k2, n, (int)keymax, o2));
+    build_mark("plan: keys and two sorts");
     P->release();
     P->n       = n;
     P->nslices = (n + 63) / 64;
@@ -2934,6 +3272,7 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     CT_HIP(hipStreamSynchronize(b.cur));
     ntiles = cnts[0];
     nsteps = cnts[1];
+    build_mark("plan: flags, scans, step split");
     P->ct_ntiles     = ntiles;
     P->ct_nsteps     = nsteps;
     CT_TRY(dev_alloc(&P->ct_tile_step, (int64_t)ntiles + 1));
@@ -2975,6 +3314,7 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     int next = 0;
     CT_HIP(hipMemcpyAsync(&next, P->ct_ext_start + n, sizeof(int), hipMemcpyDeviceToHost, b.cur));
     CT_HIP(hipStreamSynchronize(b.cur));
+    build_mark("plan: bounds, entry sizes, externals count");
     dev_free(&ref_start);
     dev_free(&slot_of_ref);
     static const int dedup_env = getenv("RAMD_TRSV_CT_DEDUP") ? atoi(getenv("RAMD_TRSV_CT_DEDUP")) : -1; // (0 / 1: force)
@@ -3090,6 +3430,7 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
         }
     }
     } // attempts
+    build_mark("plan: externals, dedup, fit check");
     dev_free(&level);
     dev_free(&word);
     if(!fits)
@@ -3165,6 +3506,7 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     CT_HIP(hipGetLastError());
     P->nodiag = nd != 0;
     P->ct     = true;
+    build_mark("plan: records");
     if(verbose)
         fprintf(stderr,
                 "box-tile plan (%s): n=%d chains=%d levels=%d extents=(%lld,%lld,%lld) box=(%d,%d,%d) tiles=%d steps=%d "
@@ -3448,6 +3790,48 @@ static int ilu0_t(ramd_mat_s* m)
     }
     RAMD_HIP(hipMemsetAsync(done, 0, sizeof(int) * (size_t)n, b.cur));
     const unsigned nb = nblocks_of(n);
+    // rows that fit a lane's registers: the natural-order sweep with in-wave pivots (k_ilu0_rows)
+    static const int rows_env = getenv("RAMD_ILU0_ROWS") ? atoi(getenv("RAMD_ILU0_ROWS")) : 1; // (0: off; A/B experiments)
+    if(rows_env != 0)
+    {
+        int  maxlen = 0;
+        int* dmax   = done; // (borrowed: zeroed above, zeroed again below)
+        hipLaunchKernelGGL(k_max_row_len, dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, m->rp, dmax);
+        hipError_t e = hipMemcpyAsync(&maxlen, dmax, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+        if(e == hipSuccess)
+            e = hipMemsetAsync(dmax, 0, sizeof(int), b.cur);
+        if(e == hipSuccess)
+            e = hipStreamSynchronize(b.cur);
+        if(e != hipSuccess)
+        {
+            dev_free(&done);
+            RAMD_HIP(e);
+        }
+        if(maxlen <= kIluW)
+        {
+            UnitPlan up;
+            int      su = unit_schedule(m, true, &up);
+            if(su != RAMD_OK)
+            {
+                dev_free(&done);
+                return su;
+            }
+            // (workgroups of 256: the waves of this sweep run for tens of microseconds, and a workgroup of 16 holds its CU
+            //  slots until the last of them is done -- measured 101 ms against 77 ms at 512^3)
+            const unsigned nbi = (unsigned)((up.nunits + 3) / 4);
+            hipLaunchKernelGGL((k_ilu0_rows<T, 256>), dim3(nbi), dim3(256), 0, b.cur, n, m->rp, m->ci, (T*)m->val, done,
+                               m->diag_pos, st->counter, st->ticket, unit_view(up), sweep_poll_cap());
+            st->ticket += nbi;
+            e = hipGetLastError();
+            if(e == hipSuccess)
+                e = hipStreamSynchronize(b.cur);
+            up.release();
+            build_mark("ilu0: factorisation sweep (rows in registers)");
+            dev_free(&done);
+            RAMD_HIP(e);
+            return RAMD_OK;
+        }
+    }
     if(!st->l_order_cache)
     {
         dev_free(&st->l_level_cache);
@@ -3464,6 +3848,7 @@ static int ilu0_t(ramd_mat_s* m)
     hipError_t e = hipGetLastError();
     if(e == hipSuccess)
         e = hipStreamSynchronize(b.cur);
+    build_mark("ilu0: factorisation sweep");
     dev_free(&done);
     RAMD_HIP(e);
     return RAMD_OK;

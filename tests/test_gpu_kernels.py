@@ -482,6 +482,44 @@ def test_ilu_lusolve_poisson_vs_oracle(ra, oracle, N):
         eq(y.numpy(), oracle.lusolve(rp, ci, lu, b))
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("reach", [3, 40, 700])
+def test_ilu0_rows_in_registers_irregular_vs_oracle(ra, oracle, dtype, reach):
+    """ILU(0) of rows with at most 8 entries runs in natural order with the row in registers; pivot rows held by a lower
+    lane of the same wave come from that lane's registers (k_ilu0_rows).  Random unsymmetric patterns whose lower entries
+    reach 3 / 40 / 700 rows back: in-wave pivots at every lane distance, several per row, mixed with out-of-wave ones, a
+    missing diagonal neighbour here and there -- factors bit for bit, fp64 and fp32"""
+    rng = np.random.default_rng(reach)
+    n = 1 << 20  # 4096 blocks of 256 rows: the hyperplane block order is in use
+    rows, cols = [], []
+    i = np.arange(n)
+    for s in range(3):
+        d = rng.integers(1, reach + 1, n)
+        keep = rng.random(n) < 0.8
+        lo = i - d
+        ok = keep & (lo >= 0)
+        rows.append(i[ok]); cols.append(lo[ok])
+        d = rng.integers(1, reach + 1, n)
+        keep = rng.random(n) < 0.8
+        hi = i + d
+        ok = keep & (hi < n)
+        rows.append(i[ok]); cols.append(hi[ok])
+    rows.append(i); cols.append(i)
+    import scipy.sparse as sp
+    r = np.concatenate(rows); c = np.concatenate(cols)
+    P = sp.csr_matrix((np.ones(len(r)), (r, c)), shape=(n, n))
+    P.sum_duplicates(); P.sort_indices()
+    assert np.diff(P.indptr).max() <= 7
+    P.data[:] = rng.uniform(-1.0, 1.0, len(P.data))
+    diag = np.asarray(abs(P).sum(axis=1)).ravel() + 1.0
+    A = (P - sp.diags(P.diagonal()) + sp.diags(diag)).tocsr(); A.sort_indices()
+    rp, ci, va = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(dtype)
+    M = ra.LocalMatrix(dtype=dtype)
+    M.SetDataPtrCSR(rp, ci, va)
+    M.ILU0Factorize()
+    eq(M.CopyToCSR()[2], oracle.ilu0(rp, ci, va))
+
+
 def test_ilu_lusolve_27_point_stencil_vs_oracle(ra, oracle):
     """13 strictly-lower entries per row: the eight-lanes-per-row form of the box-tile solve on cubic tiles (the shell
     surrogate exercises it on 2-D parallelograms), ILU(0) by the wave-per-row sweep -- factors and solutions bit for bit"""
