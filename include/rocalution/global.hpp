@@ -710,8 +710,8 @@ public:
         if(comm)
         {
             RAMD_CHECK(ramd_comm_halo_end(this->pm_->GetComm()));
-            this->m_ghost.ApplyAdd(this->m_recv, static_cast<ValueType>(1),
-                                         &out->m_owned);
+            if(this->m_ghost.GetNnz() > 0)
+                this->m_ghost.ApplyAdd(this->m_recv, static_cast<ValueType>(1), &out->m_owned);
         }
     }
 
@@ -744,13 +744,319 @@ public:
         if(comm)
         {
             RAMD_CHECK(ramd_comm_halo_end(this->pm_->GetComm()));
-            RAMD_CHECK(ramd_fused_apply_add_dot(this->m_ghost.handle(), this->m_recv.handle(), 1.0,
+            if(this->m_ghost.GetNnz() > 0)
+                RAMD_CHECK(ramd_fused_apply_add_dot(this->m_ghost.handle(), this->m_recv.handle(), 1.0,
                                                 out->m_owned.handle(),
                                                 w.m_owned.handle(), slot));
         }
     }
 
+    // ---- aggregation AMG on the row-block decomposition (global_matrix.cpp:1038-1880 Transpose / TripleMatrixProduct,
+    // :2607-3558 AMG*Aggregate / AMG*Aggregation).  MI355X-first form: the aggregates of a rank stay inside its row block
+    // ("decoupled" aggregation), so the prolongation and restriction operators are block-diagonal -- no ghost part, no
+    // communication when a cycle applies them -- and only the Galerkin product exchanges data, once per level at Build:
+    // the prolongation rows of the boundary rows travel to the neighbours through the same halo exchange the SpMV uses.
+    // The coarse operator is again interior + ghost with a ParallelManager of its own (coarse boundary = the aggregates
+    // the boundary rows belong to).  On one rank this IS the LocalMatrix algorithm, kernel for kernel; over P ranks it is
+    // the P-way decoupled algorithm (the reference lets aggregates cross ranks: its hierarchy differs for P > 1).
+    template <class Obj>
+    void CloneBackend(const Obj& src)
+    {
+        if(src.is_accel_())
+        {
+            this->m_interior.MoveToAccelerator();
+            this->m_ghost.MoveToAccelerator();
+        }
+    }
+    void Scale(ValueType alpha)
+    {
+        this->m_interior.Scale(alpha);
+        if(this->m_ghost.GetNnz() > 0)
+            this->m_ghost.Scale(alpha);
+    }
+    void AMGPMISAggregate(ValueType eps, LocalVector<int>* connections, LocalVector<int>* aggregates,
+                          LocalVector<int>* aggregate_root_nodes) const
+    {
+        this->m_interior.AMGPMISAggregate(eps, connections, aggregates, aggregate_root_nodes);
+    }
+    void AMGGreedyAggregate(ValueType eps, LocalVector<int>* connections, LocalVector<int>* aggregates,
+                            LocalVector<int>* aggregate_root_nodes) const
+    {
+        this->m_interior.AMGGreedyAggregate(eps, connections, aggregates, aggregate_root_nodes);
+    }
+    void AMGUnsmoothedAggregation(const LocalVector<int>& aggregates, const LocalVector<int>& aggregate_root_nodes,
+                                  GlobalMatrix<ValueType>* prolong) const
+    {
+        assert(prolong != NULL && prolong != this);
+        this->m_interior.AMGUnsmoothedAggregation(aggregates, aggregate_root_nodes, &prolong->m_interior);
+        prolong->doBlockDiagonal(this->pm_, this->GetM(), -1);
+    }
+    void AMGSmoothedAggregation(ValueType relax, const LocalVector<int>& connections, const LocalVector<int>& aggregates,
+                                const LocalVector<int>& aggregate_root_nodes, GlobalMatrix<ValueType>* prolong,
+                                int lumping_strat = 0) const
+    {
+        assert(prolong != NULL && prolong != this);
+        // The smoothing step I - w D^-1 A_F uses the interior block: couplings across ranks do not widen the rows of P.  They
+        // are treated the way the filtered matrix A_F treats weak connections -- lumped onto the diagonal -- so that the
+        // rows of A_F next to a rank boundary keep their row sum and P still reproduces what the tentative prolongation
+        // reproduces there (without it CG + SA-AMG needed twice the iterations on two ranks).
+        if(this->m_ghost.GetNnz() > 0)
+        {
+            const int64_t          n = this->m_interior.GetM();
+            LocalVector<ValueType> ones, lump;
+            ones.MoveToAccelerator();
+            lump.MoveToAccelerator();
+            ones.Allocate("ones", this->m_ghost.GetN());
+            ones.Ones();
+            lump.Allocate("ghost row sums", n);
+            this->m_ghost.Apply(ones, &lump);
+            std::vector<ValueType> h((size_t)n);
+            lump.CopyToHostData(h.data());
+            std::vector<PtrType> rp((size_t)n + 1);
+            std::vector<int>     ci((size_t)n);
+            for(int64_t i = 0; i <= n; ++i)
+                rp[(size_t)i] = (PtrType)i;
+            for(int64_t i = 0; i < n; ++i)
+            {
+                ci[(size_t)i] = (int)i;
+                if(lumping_strat == 1) // (SubtractWeakConnections)
+                    h[(size_t)i] = -h[(size_t)i];
+            }
+            LocalMatrix<ValueType> D, Al;
+            D.MoveToAccelerator();
+            D.AllocateCSR("lumped ghost couplings", n, n, n);
+            D.CopyFromCSR(rp.data(), ci.data(), h.data());
+            Al.CloneFrom(this->m_interior);
+            Al.MatrixAdd(D, static_cast<ValueType>(1), static_cast<ValueType>(1), false);
+            Al.AMGSmoothedAggregation(relax, connections, aggregates, aggregate_root_nodes, &prolong->m_interior, lumping_strat);
+        }
+        else
+            this->m_interior.AMGSmoothedAggregation(relax, connections, aggregates, aggregate_root_nodes, &prolong->m_interior,
+                                                    lumping_strat);
+        prolong->doBlockDiagonal(this->pm_, this->GetM(), -1);
+    }
+    // of a block-diagonal operator (a prolongation / restriction of this class)
+    void Transpose(GlobalMatrix<ValueType>* T) const
+    {
+        assert(T != NULL && T != this);
+        RAMD_EXPECT(this->m_ghost.GetNnz() == 0);
+        this->m_interior.Transpose(&T->m_interior);
+        if(this->m_interior.GetNnz() == 0) // (nothing to transpose: an empty operator of the transposed shape)
+            T->m_interior.AllocateCSR("transposed", 0, this->m_interior.GetN(), this->m_interior.GetM());
+        T->doBlockDiagonal(this->pm_, this->GetN(), this->GetM());
+    }
+    // this = R A P for block-diagonal R and P: interior = R_i A_i P_i; ghost = R_i A_g P_g, where P_g holds the
+    // prolongation rows of the ghost columns of A (the neighbours' boundary rows), received here
+    void TripleMatrixProduct(const GlobalMatrix<ValueType>& R, const GlobalMatrix<ValueType>& A,
+                             const GlobalMatrix<ValueType>& P)
+    {
+        assert(&R != this && &A != this && &P != this);
+        RAMD_EXPECT(R.m_ghost.GetNnz() == 0 && P.m_ghost.GetNnz() == 0);
+        this->m_interior.CloneBackend(A.m_interior);
+        this->m_ghost.CloneBackend(A.m_interior);
+        this->m_interior.TripleMatrixProduct(R.m_interior, A.m_interior, P.m_interior);
+        const ParallelManager* fpm = A.pm_;
+        const int64_t          nc  = P.m_interior.GetN();
+        RAMD_EXPECT(sizeof(ValueType) > 4 || nc < (1 << 24)); // (aggregate numbers travel as values of the matrix type)
+        if(fpm == NULL)
+        {
+            this->pm_ = NULL;
+            this->m_own_pm.reset();
+            return;
+        }
+        std::shared_ptr<ParallelManager> cpm(new ParallelManager);
+        cpm->SetMPICommunicator(fpm->GetComm());
+        cpm->SetLocalNrow(nc);
+        cpm->SetLocalNcol(nc);
+        cpm->SetGlobalNrow(P.GetN());
+        cpm->SetGlobalNcol(P.GetN());
+        const std::vector<int>&     peers = fpm->peers();
+        const std::vector<int64_t>& soff  = fpm->send_offset();
+        const std::vector<int64_t>& roff  = fpm->recv_offset();
+        const int                   np    = (int)peers.size();
+        const int64_t               nsend = fpm->GetNumSenders(), nrecv = fpm->GetNumReceivers();
+        std::vector<int>            c_boundary, c_soff(1, 0), c_roff(1, 0);
+        const bool                  talk = np > 0 || A.m_halo_allgather;
+        if(talk)
+        {
+            // prolongation rows of my boundary rows, on the host (k-th entry of every row per exchange)
+            std::vector<PtrType>   prp((size_t)P.m_interior.GetM() + 1, 0);
+            std::vector<int>       pci((size_t)P.m_interior.GetNnz());
+            std::vector<ValueType> pva((size_t)P.m_interior.GetNnz());
+            if(P.m_interior.GetNnz() > 0)
+                P.m_interior.CopyToCSR(prp.data(), pci.data(), pva.data());
+            const int* bidx = fpm->GetBoundaryIndex();
+            int        kloc = 0;
+            for(int64_t s2 = 0; s2 < nsend; ++s2)
+                kloc = std::max(kloc, (int)(prp[(size_t)bidx[s2] + 1] - prp[(size_t)bidx[s2]]));
+            const int kmax = A.doMaxRanks(kloc);
+            std::vector<std::vector<int>>       gcol((size_t)kmax);
+            std::vector<std::vector<ValueType>> gval((size_t)kmax);
+            LocalVector<ValueType> sbuf, rbuf;
+            sbuf.MoveToAccelerator();
+            rbuf.MoveToAccelerator();
+            sbuf.Allocate("prolongation rows out", nsend);
+            rbuf.Allocate("prolongation rows in", nrecv);
+            std::vector<ValueType> hs((size_t)nsend), hr((size_t)nrecv);
+            for(int k = 0; k < kmax; ++k)
+                for(int what = 0; what < 2; ++what) // column (as a number: exact below 2^53 / 2^24), then value
+                {
+                    for(int64_t s2 = 0; s2 < nsend; ++s2)
+                    {
+                        const int     b   = bidx[s2];
+                        const PtrType at  = prp[(size_t)b] + k;
+                        const bool    has = at < prp[(size_t)b + 1];
+                        hs[(size_t)s2]    = what == 0 ? (has ? static_cast<ValueType>(pci[(size_t)at]) : static_cast<ValueType>(-1))
+                                                      : (has ? pva[(size_t)at] : static_cast<ValueType>(0));
+                    }
+                    if(nsend > 0)
+                        sbuf.CopyFromHostData(hs.data());
+                    A.doExchange(sbuf, &rbuf);
+                    if(nrecv > 0)
+                        rbuf.CopyToHostData(hr.data());
+                    if(what == 0)
+                    {
+                        gcol[(size_t)k].resize((size_t)nrecv);
+                        for(int64_t g = 0; g < nrecv; ++g)
+                            gcol[(size_t)k][(size_t)g] = (int)hr[(size_t)g];
+                    }
+                    else
+                        gval[(size_t)k] = hr;
+                }
+            // coarse boundary towards every peer: the distinct aggregates under the boundary rows sent to it, ascending --
+            // the receiver numbers its coarse ghost columns by the same rule from what it was sent
+            std::vector<int> seen;
+            for(int q = 0; q < np; ++q)
+            {
+                seen.clear();
+                for(int64_t s2 = soff[(size_t)q]; s2 < soff[(size_t)q + 1]; ++s2)
+                    for(PtrType at = prp[(size_t)bidx[s2]]; at < prp[(size_t)bidx[s2] + 1]; ++at)
+                        seen.push_back(pci[(size_t)at]);
+                std::sort(seen.begin(), seen.end());
+                seen.erase(std::unique(seen.begin(), seen.end()), seen.end());
+                c_boundary.insert(c_boundary.end(), seen.begin(), seen.end());
+                c_soff.push_back((int)c_boundary.size());
+            }
+            // P_g: one row per ghost column of A, columns = coarse ghost columns
+            std::vector<PtrType>   grp((size_t)nrecv + 1, 0);
+            std::vector<int>       gci;
+            std::vector<ValueType> gva;
+            int                    ncg = 0;
+            for(int q = 0; q < np; ++q)
+            {
+                seen.clear();
+                for(int64_t g = roff[(size_t)q]; g < roff[(size_t)q + 1]; ++g)
+                    for(int k = 0; k < kmax; ++k)
+                        if(gcol[(size_t)k][(size_t)g] >= 0)
+                            seen.push_back(gcol[(size_t)k][(size_t)g]);
+                std::sort(seen.begin(), seen.end());
+                seen.erase(std::unique(seen.begin(), seen.end()), seen.end());
+                for(int64_t g = roff[(size_t)q]; g < roff[(size_t)q + 1]; ++g)
+                {
+                    for(int k = 0; k < kmax; ++k)
+                        if(gcol[(size_t)k][(size_t)g] >= 0)
+                        {
+                            const int at = (int)(std::lower_bound(seen.begin(), seen.end(), gcol[(size_t)k][(size_t)g]) - seen.begin());
+                            gci.push_back(ncg + at);
+                            gva.push_back(gval[(size_t)k][(size_t)g]);
+                        }
+                    grp[(size_t)g + 1] = (PtrType)gci.size();
+                }
+                ncg += (int)seen.size();
+                c_roff.push_back(ncg);
+            }
+            this->m_ghost.Clear();
+            if(A.m_ghost.GetNnz() > 0 && !gci.empty() && nc > 0)
+            {
+                LocalMatrix<ValueType> Pg, Ag, AgPg;
+                Pg.CloneBackend(A.m_interior);
+                Pg.AllocateCSR("prolongation rows of the ghost columns", (int64_t)gci.size(), nrecv, ncg);
+                Pg.CopyFromCSR(grp.data(), gci.data(), gva.data());
+                Ag.CloneFrom(A.m_ghost);
+                if(Ag.GetFormat() != CSR)
+                    Ag.ConvertTo(CSR);
+                AgPg.CloneBackend(A.m_interior);
+                AgPg.MatrixMult(Ag, Pg);
+                this->m_ghost.MatrixMult(R.m_interior, AgPg);
+            }
+            if(this->m_ghost.GetNnz() == 0)
+                this->m_ghost.AllocateCSR("Ghost of the coarse operator", 0, nc, ncg);
+        }
+        else
+            for(int q = 0; q < np; ++q)
+            {
+                c_soff.push_back(0);
+                c_roff.push_back(0);
+            }
+        cpm->SetBoundaryIndex((int)c_boundary.size(), c_boundary.data());
+        cpm->SetReceivers(np, peers.data(), c_roff.data());
+        cpm->SetSenders(np, peers.data(), c_soff.data());
+        this->m_own_pm = cpm;
+        this->pm_      = cpm.get();
+        this->doInitHalo();
+    }
+
 private:
+    // a block-diagonal operator between two row-block distributions: a ParallelManager of its own without neighbours
+    // (ncol < 0: the global column count is the sum of the local ones)
+    void doBlockDiagonal(const ParallelManager* like, int64_t global_nrow, int64_t global_ncol)
+    {
+        this->m_ghost.Clear();
+        this->m_halo_allgather = false;
+        if(like == NULL)
+        {
+            this->pm_ = NULL;
+            this->m_own_pm.reset();
+            return;
+        }
+        std::shared_ptr<ParallelManager> pm(new ParallelManager);
+        pm->SetMPICommunicator(like->GetComm());
+        pm->SetLocalNrow(this->m_interior.GetM());
+        pm->SetLocalNcol(this->m_interior.GetN());
+        pm->SetGlobalNrow(global_nrow);
+        if(global_ncol < 0)
+            global_ncol = (int64_t)std::llround(doSumRanks(like, (double)this->m_interior.GetN()));
+        pm->SetGlobalNcol(global_ncol);
+        this->m_own_pm = pm;
+        this->pm_      = pm.get();
+    }
+    static double doSumRanks(const ParallelManager* pm, double local)
+    {
+        if(pm == NULL || pm->GetNumProcs() == 1)
+            return local;
+        const int slot = RAMD_NSCALARS - 2;
+        RAMD_CHECK(ramd_scalars_set(slot, local));
+        RAMD_CHECK(ramd_comm_allreduce_scalars(pm->GetComm(), slot, 1));
+        double r = 0.0;
+        RAMD_CHECK(ramd_scalars_fetch(&r, slot, 1));
+        return r;
+    }
+    // max over ranks of a small non-negative count (the all-reduce sums: one indicator slot per value)
+    int doMaxRanks(int local) const
+    {
+        if(this->pm_ == NULL || this->pm_->GetNumProcs() == 1)
+            return local;
+        const int cap = 48, first = RAMD_NSCALARS - 8 - cap;
+        RAMD_EXPECT(local <= cap);
+        for(int k = 0; k < cap; ++k)
+            RAMD_CHECK(ramd_scalars_set(first + k, k < local ? 1.0 : 0.0));
+        RAMD_CHECK(ramd_comm_allreduce_scalars(this->pm_->GetComm(), first, cap));
+        double v[48];
+        RAMD_CHECK(ramd_scalars_fetch(v, first, cap));
+        int r = 0;
+        for(int k = 0; k < cap; ++k)
+            if(v[k] > 0.5)
+                r = k + 1;
+        return r;
+    }
+    // one halo exchange of per-boundary-row values with the pattern of this matrix (device buffers)
+    void doExchange(const LocalVector<ValueType>& send, LocalVector<ValueType>* recv) const
+    {
+        RAMD_CHECK(ramd_comm_halo_begin(this->pm_->GetComm(), send.handle(), recv->handle(), (int)this->pm_->peers().size(),
+                                        this->pm_->peers().data(), this->pm_->send_offset().data(),
+                                        this->pm_->recv_offset().data()));
+        RAMD_CHECK(ramd_comm_halo_end(this->pm_->GetComm()));
+    }
     // global_matrix.cpp:4476-4513: halo index vector + device send/recv buffers
     void doInitHalo(void)
     {
@@ -778,6 +1084,7 @@ private:
         this->m_recv.Allocate("recv buffer", this->pm_->GetNumReceivers());
     }
     const ParallelManager*         pm_;
+    std::shared_ptr<ParallelManager> m_own_pm; // coarse levels and transfer operators own theirs
     LocalMatrix<ValueType>         m_interior;
     LocalMatrix<ValueType>         m_ghost;
     LocalVector<int>               m_halo_rows;

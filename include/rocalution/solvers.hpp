@@ -1410,6 +1410,17 @@ struct _fusable<LocalMatrix<ValueType>, LocalVector<ValueType>, ValueType>
 {
     static constexpr bool value = true;
 };
+// ... and the operators that are ONE device matrix (kernels fused around their SpMV take the matrix handle itself)
+template <class OperatorType, class VectorType, typename ValueType>
+struct _one_block
+{
+    static constexpr bool value = false;
+};
+template <typename ValueType>
+struct _one_block<LocalMatrix<ValueType>, LocalVector<ValueType>, ValueType>
+{
+    static constexpr bool value = true;
+};
 template <typename ValueType>
 inline ramd_vec_t _fh(const LocalVector<ValueType>& v)
 {
@@ -3131,7 +3142,7 @@ private:
     // FixedPoint + Jacobi as a smoother on a Local CSR operator: every sweep is ONE pass (SpMV with the update as its
     // epilogue, ramd_fused_jacobi_sweep) plus the copy back, instead of SpMV + three vector kernels; same operations
     template <class O = OperatorType, class V = VectorType>
-    typename std::enable_if<_fusable<O, V, ValueType>::value, bool>::type
+    typename std::enable_if<_one_block<O, V, ValueType>::value, bool>::type
         doFusedJacobiSweeps(const VectorType& rhs, VectorType* x, int steps)
     {
         typedef Jacobi<OperatorType, VectorType, ValueType> JacobiType;
@@ -3155,7 +3166,7 @@ private:
         return true;
     }
     template <class O = OperatorType, class V = VectorType>
-    typename std::enable_if<!_fusable<O, V, ValueType>::value, bool>::type
+    typename std::enable_if<!_one_block<O, V, ValueType>::value, bool>::type
         doFusedJacobiSweeps(const VectorType&, VectorType*, int)
     {
         return false;
@@ -3409,6 +3420,43 @@ public:
     virtual bool SolveUsesScalarRecord(void) const
     {
         return true;
+    }
+    // extension (tests, diagnostics): how far the hierarchy is from the Galerkin identity A_c = R A_f P, measured on a vector
+    // the caller fills (x_c of level l + 1): min over a of || A_c x_c - a R A_f P x_c || / || A_c x_c ||.  For Global operators it exercises
+    // the ghost part of the coarse operator and its halo plan against those of the fine one.
+    ValueType GalerkinDefect(int l, const VectorType& xc)
+    {
+        RAMD_EXPECT(this->m_build && l >= 0 && l + 1 < this->m_levels);
+        Level&      f = this->m_grid[(size_t)l];
+        const Level& c = this->m_grid[(size_t)l + 1];
+        VectorType  yc, zc, xf, yf;
+        VectorType* cs[2] = {&yc, &zc};
+        VectorType* fs[2] = {&xf, &yf};
+        for(VectorType* v : cs)
+        {
+            v->CloneBackend(*c.A);
+            v->Allocate("coarse", c.A->GetM());
+        }
+        for(VectorType* v : fs)
+        {
+            v->CloneBackend(*f.A);
+            v->Allocate("fine", f.A->GetM());
+        }
+        c.A->Apply(xc, &yc);
+        f.to_fine->Apply(xc, &xf);
+        f.A->Apply(xf, &yf);
+        f.to_coarse->Apply(yf, &zc);
+        // (UAAMG divides the coarse operator by its over-interpolation factor: the identity holds up to that one scalar)
+        const ValueType zz = zc.Dot(zc);
+        const ValueType a  = zz > num<ValueType>(0) ? yc.Dot(zc) / zz : num<ValueType>(1);
+        zc.ScaleAdd(-a, yc);
+        const ValueType den = yc.Norm();
+        return den > num<ValueType>(0) ? zc.Norm() / den : zc.Norm();
+    }
+    const OperatorType* GetLevelOperator(int l) const
+    {
+        RAMD_EXPECT(this->m_build && l >= 0 && l < this->m_levels);
+        return this->m_grid[(size_t)l].A;
     }
 
     // base_multigrid.cpp:605-699

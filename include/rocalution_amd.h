@@ -471,7 +471,10 @@ enum { RAMD_PC_NONE = 0, RAMD_PC_JACOBI = 1, RAMD_PC_ILU0 = 2, RAMD_PC_MCSGS = 3
        RAMD_PC_GS = 6, RAMD_PC_SGS = 7, /* preconditioner.cpp:206-257 / :302-379 */
        RAMD_PC_IC = 8, /* :862-925 */
        /* unsmoothed_amg.cpp / smoothed_amg.cpp with CoarseningStrategy PMIS, default smoothers and coarse solver */
-       RAMD_PC_UAAMG = 9, RAMD_PC_SAAMG = 10 };
+       RAMD_PC_UAAMG = 9, RAMD_PC_SAAMG = 10,
+       /* ramd_gsolver_create only: UAAMG / SAAMG on the GlobalMatrix itself (coarse levels coupled across the ranks; the
+        * aggregates stay inside a rank's row block) instead of BlockJacobi around a local AMG */
+       RAMD_PC_GLOBAL_UAAMG = 11, RAMD_PC_GLOBAL_SAAMG = 12 };
 int ramd_solver_create(int solver, int precond, int dtype, ramd_solver_t* out);
 /* MixedPrecisionDC<fp64 outer, fp32 inner>: inner solver/preconditioner kinds */
 int ramd_solver_create_mixed(int inner_solver, int inner_precond, ramd_solver_t* out);
@@ -552,6 +555,10 @@ int ramd_gsolver_init(ramd_gsolver_t g, double abs_tol, double rel_tol, double d
 int ramd_gsolver_set_basis(ramd_gsolver_t g, int size_basis);
 int ramd_gsolver_set_verbose(ramd_gsolver_t g, int verb);
 int ramd_gsolver_build(ramd_gsolver_t g);
+/* RAMD_PC_GLOBAL_* after Build: depth of the hierarchy, global rows of the coarsest operator, and the largest relative
+ * defect of the Galerkin identity A_c x = R A_f P x over the levels, x random per rank (test hook: exercises the ghost
+ * parts and halo plans of the coarse operators) */
+int ramd_gsolver_amg_info(ramd_gsolver_t g, int* levels, int64_t* coarsest_rows, double* worst_galerkin_defect);
 int ramd_gsolver_apply(ramd_gsolver_t g, const double* x_local, double* y_local); /* y = A x (test hook) */
 int ramd_gsolver_solve(ramd_gsolver_t g, const double* rhs_local, double* x_local); /* NULL rhs: A*1 ; x0 = x_local or 0 */
 int ramd_gsolver_solve_ones(ramd_gsolver_t g); /* rhs = A*1, x0 = 0, everything stays on the device */

@@ -17,6 +17,7 @@ SOLVER_CG, SOLVER_GMRES, SOLVER_BICGSTAB = 0, 1, 2
 SOLVER_FCG, SOLVER_CR, SOLVER_FGMRES, SOLVER_BICGSTABL, SOLVER_QMRCGSTAB, SOLVER_IDR = 3, 4, 5, 6, 7, 8
 SOLVER_FIXEDPOINT = 9
 PC_NONE, PC_JACOBI, PC_ILU0, PC_MCSGS, PC_MCGS, PC_MCILU, PC_GS, PC_SGS, PC_IC, PC_UAAMG, PC_SAAMG = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+PC_GLOBAL_UAAMG, PC_GLOBAL_SAAMG = 11, 12
 F64, F32, I32 = 0, 1, 2
 CSR, COO, DIA, ELL, HYB = 1, 4, 5, 6, 7
 
@@ -245,6 +246,7 @@ SIGNATURES = {
     "ramd_gsolver_set_verbose": (i32, [ptr, i32]),
     "ramd_gsolver_build": (i32, [ptr]),
     "ramd_gsolver_apply": (i32, [ptr, ptr, ptr]),
+    "ramd_gsolver_amg_info": (i32, [ptr, ptr, ptr, ptr]),
     "ramd_gsolver_solve": (i32, [ptr, ptr, ptr]),
     "ramd_gsolver_solve_ones": (i32, [ptr]),
     "ramd_gsolver_prepare_ones": (i32, [ptr]),

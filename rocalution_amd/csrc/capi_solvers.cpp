@@ -488,6 +488,8 @@ struct ramd_gsolver_s
     Jacobi<GM, GV, double>       jacobi; // global Jacobi == interior diagonal
     BlockJacobi<GM, GV, double>  bj;
     Precs<double>                precs; // local preconditioners for BlockJacobi (any RAMD_PC_* kind)
+    UAAMG<GM, GV, double>        guaamg; // aggregation AMG on the GlobalMatrix itself (RAMD_PC_GLOBAL_*)
+    SAAMG<GM, GV, double>        gsaamg;
     // mixed precision: fp64 defect correction around an fp32 Global solver
     typedef GlobalMatrix<float>  GMF;
     typedef GlobalVector<float>  GVF;
@@ -862,7 +864,7 @@ int ramd_solver_clear(ramd_solver_t s)
 // ------------------------------------------------------------------------------------ distributed
 int ramd_gsolver_create(ramd_comm_t comm, int solver, int precond, ramd_gsolver_t* out)
 {
-    if(!out || solver < 0 || solver > 2 || precond < 0 || precond > RAMD_PC_SAAMG)
+    if(!out || solver < 0 || solver > 2 || precond < 0 || precond > RAMD_PC_GLOBAL_SAAMG)
         return RAMD_ERR_ARG;
     GUARD_BEGIN
     ramd_gsolver_s* g = new ramd_gsolver_s;
@@ -1047,6 +1049,17 @@ int ramd_gsolver_build(ramd_gsolver_t g)
     }
     if(g->pc_kind == RAMD_PC_JACOBI)
         g->ls()->SetPreconditioner(g->jacobi);
+    else if(g->pc_kind == RAMD_PC_GLOBAL_UAAMG || g->pc_kind == RAMD_PC_GLOBAL_SAAMG)
+    {
+        g->guaamg.SetCoarseningStrategy(PMIS);
+        g->gsaamg.SetCoarseningStrategy(PMIS);
+        g->guaamg.Verbose(0);
+        g->gsaamg.Verbose(0);
+        if(g->pc_kind == RAMD_PC_GLOBAL_UAAMG)
+            g->ls()->SetPreconditioner(g->guaamg);
+        else
+            g->ls()->SetPreconditioner(g->gsaamg);
+    }
     else if(g->pc_kind != RAMD_PC_NONE) // BlockJacobi over ranks: the local preconditioner on the interior block
     {
         g->bj.Set(*g->precs.get(g->pc_kind));
@@ -1054,6 +1067,31 @@ int ramd_gsolver_build(ramd_gsolver_t g)
     }
     g->ls()->Build();
     g->built = true;
+    GUARD_END
+}
+int ramd_gsolver_amg_info(ramd_gsolver_t g, int* levels, int64_t* coarsest_rows, double* worst_galerkin_defect)
+{
+    if(!g || !g->built || (g->pc_kind != RAMD_PC_GLOBAL_UAAMG && g->pc_kind != RAMD_PC_GLOBAL_SAAMG))
+        return RAMD_ERR_STATE;
+    GUARD_BEGIN
+    BaseAMG<ramd_gsolver_s::GM, ramd_gsolver_s::GV, double>* amg
+        = g->pc_kind == RAMD_PC_GLOBAL_UAAMG ? (BaseAMG<ramd_gsolver_s::GM, ramd_gsolver_s::GV, double>*)&g->guaamg : &g->gsaamg;
+    const int L = amg->GetNumLevels();
+    double    worst = 0.0;
+    for(int l = 0; l + 1 < L; ++l)
+    {
+        ramd_gsolver_s::GV xc;
+        xc.CloneBackend(*amg->GetLevelOperator(l + 1));
+        xc.Allocate("probe", amg->GetLevelOperator(l + 1)->GetM());
+        xc.GetInterior().SetRandomUniform(1234ull + 77ull * (unsigned)g->pm.GetRank() + (unsigned)l, -1.0, 1.0);
+        worst = std::max(worst, (double)amg->GalerkinDefect(l, xc));
+    }
+    if(levels)
+        *levels = L;
+    if(coarsest_rows)
+        *coarsest_rows = amg->GetLevelOperator(L - 1)->GetM();
+    if(worst_galerkin_defect)
+        *worst_galerkin_defect = worst;
     GUARD_END
 }
 int ramd_gsolver_apply(ramd_gsolver_t g, const double* x_local, double* y_local)

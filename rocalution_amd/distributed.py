@@ -225,6 +225,12 @@ class DistributedSolver:
                                                       x.ctypes.data_as(C.c_void_p)))
         return x
 
+    def amg_info(self):
+        """RAMD_PC_GLOBAL_* after build(): (levels, global rows of the coarsest operator, worst Galerkin defect)"""
+        lv, rows, worst = C.c_int(0), C.c_int64(0), C.c_double(0)
+        self._capi.check(self._lib.ramd_gsolver_amg_info(self._g, C.byref(lv), C.byref(rows), C.byref(worst)))
+        return lv.value, rows.value, worst.value
+
     def result(self):
         it, st, res = C.c_int(0), C.c_int(0), C.c_double(0)
         self._capi.check(self._lib.ramd_gsolver_result(self._g, C.byref(it), C.byref(st), C.byref(res)))

@@ -211,9 +211,58 @@ def gpu_worker(rank, world, initfile, kind, outdir, rccl=False):
     dist.destroy_process_group()
 
 
+def amg_worker(rank, world, initfile, kind, outdir):
+    """aggregation AMG on the GlobalMatrix (RAMD_PC_GLOBAL_*): CG preconditioned by UA-AMG and by SA-AMG on `world` ranks
+    sharing one GPU (callback transport).  kind: "poisson_slab" (24^3, z-slabs) or "gr3030x" (the 2-D 9-point gr_30_30
+    pattern repeated on a 120 x 120 grid, general CSR split with an unstructured halo plan)"""
+    from rocalution_amd import capi, distributed as D
+    import rocalution_amd as ra
+    dist = _init(rank, world, initfile)
+    ra.init_rocalution(0)
+    comm = D.make_callback_comm(rank, world, dist)
+    out = {}
+    for tag, pk in (("ua", capi.PC_GLOBAL_UAAMG), ("sa", capi.PC_GLOBAL_SAAMG)):
+        g = D.DistributedSolver(comm, capi.SOLVER_CG, pk)
+        if kind == "poisson_slab":
+            N = 24
+            z0, z1 = (N * rank) // world, (N * (rank + 1)) // world
+            lo, hi = z0 * N * N, z1 * N * N
+            g.setup_poisson(N, z0, z1)
+        else:
+            rp, ci, va = amg_matrix(kind)
+            n = len(rp) - 1
+            off = D.partition_rows(n, world)
+            piece = D.split_rows(rp, ci, va, off, rank)
+            plan = D.build_halo_plan(piece, off, rank, _gather_obj(dist, world))
+            lo, hi = piece["row_begin"], piece["row_end"]
+            g.setup_csr(n, piece, plan)
+        g.init(1e-15, 1e-8, 1e8, 200)
+        g.build()
+        out["info_" + tag] = np.array(g.amg_info(), dtype=np.float64)
+        out["x_" + tag] = g.solve(None, np.zeros(hi - lo))
+        out["res_" + tag] = np.array(g.result(), dtype=np.float64)
+    np.savez(os.path.join(outdir, "r%d.npz" % rank), lo=lo, hi=hi, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def amg_matrix(kind):
+    import scipy.sparse as sp
+    if kind == "gr3030x":
+        # 9-point stencil of gr_30_30 (8 on the diagonal, -1 to the 8 neighbours) on a 120 x 120 grid
+        N = 120
+        t = sp.diags([np.ones(N - 1), np.ones(N), np.ones(N - 1)], [-1, 0, 1])
+        A = (-sp.kron(t, t) + sp.diags(np.full(N * N, 9.0))).tocsr()
+        A.sort_indices()
+        return A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+    raise ValueError(kind)
+
+
 if __name__ == "__main__":
     mode, rank, world, initfile, kind, outdir = sys.argv[1:7]
-    if mode == "cpu":
+    if mode == "amg":
+        amg_worker(int(rank), int(world), initfile, kind, outdir)
+    elif mode == "cpu":
         cpu_worker(int(rank), int(world), initfile, kind, outdir)
     else:
         gpu_worker(int(rank), int(world), initfile, kind, outdir, rccl=(mode == "rccl"))
