@@ -88,7 +88,9 @@ def physical_cores():
 
 SOLVER_LABEL = {"cg": "CG", "gmres": "GMRES(30)", "bicgstab": "BiCGStab", "mixed": "MixedPrecisionDC(fp64/fp32 CG)"}
 PRECOND_LABEL = {"none": "none", "jacobi": "Jacobi", "ilu0": "ILU(0)", "mcsgs": "MC-SGS", "mcgs": "MC-GS",
-                 "mcilu": "MC-ILU(0,1)", "ic": "IC", "sgs": "SGS", "uaamg": "UAAMG(PMIS)", "saamg": "SAAMG(PMIS)"}
+                 "mcilu": "MC-ILU(0,1)", "ic": "IC", "sgs": "SGS", "uaamg": "UAAMG(PMIS)", "saamg": "SAAMG(PMIS)",
+                 # the distributed driver only: AMG on the GlobalMatrix itself (coarse levels coupled across the ranks)
+                 "global-uaamg": "UAAMG(PMIS) on the GlobalMatrix", "global-saamg": "SAAMG(PMIS) on the GlobalMatrix"}
 
 
 def cpu_baseline(args, mtx_path=None):
@@ -291,6 +293,8 @@ def main():
     if world != args.gpus:
         log("bench.py: --gpus %d but the launcher started %d rank(s): refusing to report a mislabelled run" % (args.gpus, world))
         sys.exit(2)
+    if args.precond.startswith("global-"):
+        args.force_global = True  # (the preconditioner of the GlobalMatrix path)
     if args.matrix in ("shell", "file") and (world > 1 or args.force_global):
         raise SystemExit("--matrix shell / --mtx is the 1-GPU workload of config 3 (LocalMatrix path)")
 
@@ -487,7 +491,11 @@ def main():
         # W untimed warm-up iterations, then EXACTLY K timed ones, in one Solve (see run); --warmup 0 times the whole Solve
         # --- timed leg, then the roofline leg: the same built solver solves again with every SpMV / triangular-solve /
         # fused-vector launch bracketed by HIP events on the stream it runs on
+        capi.check(lib.ramd_placement_seconds(None, 1))
         dt, it, res, tbuild, pr0 = run(K, HEAD, HPC, basis, warm=W, prof_iters=(min(K, 20) if mixed else min(K, 200)))
+        placement_s = C.c_double(0.0)
+        capi.check(lib.ramd_placement_seconds(C.byref(placement_s), 0))
+        placement_s = placement_s.value
         assert it == K, (it, K)
         p_spmv, p_trsv, p_vec = pr0[PROF_SPMV], pr0[PROF_TRSV], pr0[PROF_VEC]
         vb = 4 if mixed else 8  # the launches of a mixed-precision run are (all but a handful) the fp32 inner SpMVs
@@ -575,7 +583,8 @@ def main():
         SK = {"cg": capi.SOLVER_CG, "gmres": capi.SOLVER_GMRES, "bicgstab": capi.SOLVER_BICGSTAB}
         PK = {"none": capi.PC_NONE, "jacobi": capi.PC_JACOBI, "ilu0": capi.PC_ILU0, "mcsgs": capi.PC_MCSGS,
               "mcgs": capi.PC_MCGS, "mcilu": capi.PC_MCILU, "ic": capi.PC_IC, "sgs": capi.PC_SGS,
-              "uaamg": capi.PC_UAAMG, "saamg": capi.PC_SAAMG}  # all but Jacobi: BlockJacobi over the ranks
+              "uaamg": capi.PC_UAAMG, "saamg": capi.PC_SAAMG,  # all but Jacobi: BlockJacobi over the ranks
+              "global-uaamg": capi.PC_GLOBAL_UAAMG, "global-saamg": capi.PC_GLOBAL_SAAMG}
         if args.precond not in PK:
             raise SystemExit("--precond %s: not wired into the distributed driver" % args.precond)
         if mixed:  # config 5: fp64 defect correction around fp32 CG + Jacobi
@@ -609,7 +618,11 @@ def main():
             return dt, itc.value - warm, rs.value, 0.0
 
         # W untimed warm-up iterations, then EXACTLY K timed ones, in one Solve; --warmup 0 times the whole Solve
+        capi.check(lib.ramd_placement_seconds(None, 1))
         dt, it, res, tbuild = run(K, warm=W)
+        placement_s = C.c_double(0.0)
+        capi.check(lib.ramd_placement_seconds(C.byref(placement_s), 0))
+        placement_s = placement_s.value
         assert it == K, (it, K)
         import torch
         t = torch.tensor([dt], dtype=torch.float64)
@@ -677,6 +690,9 @@ def main():
                                    % (args.solver, args.precond, wl, args.format.upper(), world),
                        "parallelism": "rows%d" % world, "fused": True},
             "final_residual": res, "build_s": round(tbuild, 4),
+            # wall time of the placement measurements at the first Solve of the timed solver (before the timed window:
+            # work vectors of the fused loops are placed by trial, once per Build; RAMD_PLACE_TRIES=0 switches it off)
+            "placement_s": round(placement_s, 4),
         }
         if prof is not None:
             out["roofline"] = prof

@@ -28,6 +28,7 @@
 #include <stdexcept>
 #include <string>
 #include <type_traits>
+#include <functional>
 #include <vector>
 
 #include "../rocalution_amd.h"
@@ -320,6 +321,23 @@ public:
             return;
         int moved = 0;
         RAMD_CHECK(ramd_vec_place_apart(this->dev_, other.dev_, &moved));
+    }
+    // ... and by trial: `run` launches the kernels that use this vector; the vector moves to the fastest of its own block
+    // and `tries` fresh ones (ramd_vec_place_by_trial).  `run` is executed 3 (tries + 1) times.
+    void PlaceByTrial(const std::function<void()>& run, int tries)
+    {
+        if(!this->on_accel_ || this->dev_ == nullptr)
+            return;
+        struct Hop
+        {
+            static int call(void* ctx)
+            {
+                (*static_cast<const std::function<void()>*>(ctx))();
+                return RAMD_OK;
+            }
+        };
+        int moved = 0;
+        RAMD_CHECK(ramd_vec_place_by_trial(this->dev_, &Hop::call, const_cast<std::function<void()>*>(&run), tries, &moved));
     }
     void Clear(void)
     {

@@ -405,6 +405,15 @@ public:
     {
         this->m_owned.PlaceApartFrom(other.m_owned);
     }
+    void PlaceByTrial(const std::function<void()>& run, int tries)
+    {
+        // every rank has to run `run` equally often (it exchanges halos): all of them take part, or none
+        const double mine = (double)this->m_owned.GetSize() * sizeof(ValueType) >= (double)(64 << 20) ? 1.0 : 0.0;
+        if(this->pm_ != NULL && this->pm_->GetNumProcs() > 1
+           && this->sum_ranks_(mine) < (double)this->pm_->GetNumProcs() - 0.5)
+            return;
+        this->m_owned.PlaceByTrial(run, tries);
+    }
     int64_t GetSize(void) const
     {
         return this->pm_ ? this->pm_->GetGlobalNrow() : this->m_owned.GetSize();

@@ -1781,6 +1781,8 @@ protected:
             if(precond)
                 z->PlaceApartFrom(*r);
             p->PlaceApartFrom(*x);
+            if(this->m_fused && this->m_res_norm_type == 2)
+                this->doPlaceByTrial(x, precond);
         }
         Engine K(*this->m_op, sCount);
         this->doDefect(rhs, *x, r);
@@ -1876,7 +1878,51 @@ private:
     {
         return false;
     }
-
+    // Placement of the work vectors of the fused loop by trial (LocalVector::PlaceByTrial), OPT-IN (RAMD_PLACE_TRIES=k): one
+    // whole iteration -- update, direction, product -- is timed with z, p, q, r in turn in their own block and in k fresh
+    // ones; no arithmetic of the solve is involved (the work vectors are overwritten before they are used, the iterate is
+    // saved and restored).  Measured at 512^3 over fresh processes (gpurun_out/r03al, r03am, r03an): the trial times do
+    // predict the loop (4.05 ... 4.45 ms per iteration depending on the blocks), but the fast combination is not reliably
+    // among a handful of fresh blocks -- medians 244 / 247 / 241 it/s with 3 / 6-10 / 6 tries against 240-244 without, for
+    // 0.4-1.5 s at the first Solve (ramd_placement_seconds).  Not worth it by default.
+    template <class O = OperatorType, class V = VectorType>
+    typename std::enable_if<_fusable<O, V, ValueType>::value, void>::type doPlaceByTrial(VectorType* x, bool precond)
+    {
+        if(!this->m_op->is_accel_() || !x->is_accel_())
+            return;
+        const OperatorType& A = *this->m_op;
+        VectorType *kr = this->W(0), *kp = this->W(1), *kq = this->W(2), *kz = precond ? this->W(3) : kr;
+        typedef Jacobi<OperatorType, VectorType, ValueType> JacobiType;
+        JacobiType* jac  = precond ? dynamic_cast<JacobiType*>(this->m_precond) : NULL;
+        ramd_vec_t  dinv = NULL;
+        if(jac != NULL && jac->GetInverseDiagonal().GetSize() == kr->GetSize())
+            dinv = _fh(jac->GetInverseDiagonal());
+        if(precond && dinv == NULL)
+            return; // (a general preconditioner sits between the kernels: its own vectors decide)
+        static const int tries = getenv("RAMD_PLACE_TRIES") ? atoi(getenv("RAMD_PLACE_TRIES")) : 0; // (0: off)
+        if(tries <= 0)
+            return;
+        VectorType keep;
+        keep.CloneBackend(*x);
+        keep.Allocate("iterate", x->GetSize());
+        keep.CopyFrom(*x);
+        VectorType* zdir = precond ? kz : kr;
+        auto iteration   = [&]() {
+            RAMD_CHECK(ramd_fused_cg_update(_fh(*kr), _fh(*kq), dinv, dinv ? _fh(*kz) : NULL, 1, 0, 2, 3));
+            RAMD_CHECK(ramd_fused_cg_direction(_fh(*x), _fh(*kp), _fh(*zdir), 1, 0, 3));
+            _f_apply_dot(A, *kp, kq, 0);
+        };
+        if(precond)
+            kz->PlaceByTrial(iteration, tries);
+        kp->PlaceByTrial(iteration, tries);
+        kq->PlaceByTrial(iteration, tries);
+        kr->PlaceByTrial(iteration, tries);
+        x->CopyFrom(keep);
+    }
+    template <class O = OperatorType, class V = VectorType>
+    typename std::enable_if<!_fusable<O, V, ValueType>::value, void>::type doPlaceByTrial(VectorType*, bool)
+    {
+    }
 };
 
 // ============================================================================ GMRES

@@ -455,14 +455,14 @@ __global__ __launch_bounds__(kBlock) void k_ilu0(int nrow, const int* __restrict
     } while(__ballot(!fin) != 0ull);
 }
 
-// ... the same factorisation for rows of at most kIluW entries, in NATURAL order (blocks in hyperplane order, blocksched.hip):
+// ... the same factorisation for rows of at most W entries (W = 8: 5- / 7-point operators; W = 16: 9-point ones), in NATURAL order (blocks in hyperplane order, blocksched.hip):
 // a lane keeps its whole row in registers; pivot rows of earlier waves are read from memory as above, pivot rows held by a
 // lower lane of the same wave -- they are the LAST pivots of the row, the columns being sorted -- are taken from that
 // lane's registers, lane by lane in ascending order (at step b lane b is final; see k_levels).  The i-1 chain of a grid
 // line never leaves the wave: a link costs ~200 ALU instructions instead of a flag, a pivot and a row fetched through the
 // L2, and the sweep reads and writes the matrix in storage order (the level order above touches ~25 scattered 64-byte
 // lines per row: 0.26 s at 512^3).  Same operations per entry in the same ascending-pivot order: bit-identical factors.
-constexpr int kIluW = 8;
+constexpr int kIluWMax = 16;
 
 template <typename T>
 __device__ __forceinline__ T bcast_lane(T v, int lane_id);
@@ -480,7 +480,7 @@ __device__ __forceinline__ double bcast_lane<double>(double v, int lane_id)
     return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
 }
 
-template <typename T, int BLOCK>
+template <typename T, int BLOCK, int kIluW>
 __global__ __launch_bounds__(BLOCK) void k_ilu0_rows(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
                                                       T* val, int* done, int* diag_pos, unsigned* counter, unsigned base,
                                                       UnitView uv, int poll_cap)
@@ -3807,7 +3807,7 @@ static int ilu0_t(ramd_mat_s* m)
             dev_free(&done);
             RAMD_HIP(e);
         }
-        if(maxlen <= kIluW)
+        if(maxlen <= kIluWMax)
         {
             UnitPlan up;
             int      su = unit_schedule(m, true, &up);
@@ -3819,8 +3819,12 @@ static int ilu0_t(ramd_mat_s* m)
             // (workgroups of 256: the waves of this sweep run for tens of microseconds, and a workgroup of 16 holds its CU
             //  slots until the last of them is done -- measured 101 ms against 77 ms at 512^3)
             const unsigned nbi = (unsigned)((up.nunits + 3) / 4);
-            hipLaunchKernelGGL((k_ilu0_rows<T, 256>), dim3(nbi), dim3(256), 0, b.cur, n, m->rp, m->ci, (T*)m->val, done,
-                               m->diag_pos, st->counter, st->ticket, unit_view(up), sweep_poll_cap());
+            if(maxlen <= 8)
+                hipLaunchKernelGGL((k_ilu0_rows<T, 256, 8>), dim3(nbi), dim3(256), 0, b.cur, n, m->rp, m->ci, (T*)m->val, done,
+                                   m->diag_pos, st->counter, st->ticket, unit_view(up), sweep_poll_cap());
+            else
+                hipLaunchKernelGGL((k_ilu0_rows<T, 256, kIluWMax>), dim3(nbi), dim3(256), 0, b.cur, n, m->rp, m->ci, (T*)m->val,
+                                   done, m->diag_pos, st->counter, st->ticket, unit_view(up), sweep_poll_cap());
             st->ticket += nbi;
             e = hipGetLastError();
             if(e == hipSuccess)

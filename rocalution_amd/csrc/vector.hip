@@ -6,6 +6,7 @@
 // -ffp-contract=off so that updates are bit-identical to the OpenMP backend; reductions use a
 // fixed-order tree (the reference's OpenMP reduction order is itself thread-count dependent).
 #include "device_utils.hpp"
+#include <chrono>
 #include "matrix_impl.hpp"
 
 namespace ramd
@@ -482,9 +483,32 @@ int ramd_vec_allocate_apart(ramd_vec_t v, int64_t n, ramd_vec_t other)
     return RAMD_OK;
 }
 
+namespace
+{
+double g_placement_seconds = 0.0; // wall time spent measuring placements (ramd_placement_seconds)
+struct PlacementClock
+{
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~PlacementClock()
+    {
+        g_placement_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+};
+} // namespace
+
+int ramd_placement_seconds(double* seconds, int reset)
+{
+    if(seconds)
+        *seconds = g_placement_seconds;
+    if(reset)
+        g_placement_seconds = 0.0;
+    return RAMD_OK;
+}
+
 int ramd_vec_place_apart(ramd_vec_t v, ramd_vec_t other, int* moved)
 {
     CHECK_VEC(v);
+    PlacementClock clock;
     if(moved)
         *moved = 0;
     if(!other || other == v || !v->d || !other->d || v->n != other->n || v->dtype != other->dtype)
@@ -559,6 +583,108 @@ int ramd_vec_place_apart(ramd_vec_t v, ramd_vec_t other, int* moved)
     (void)cached_free(scratch);
     (void)cached_free(keep);
     return RAMD_OK;
+}
+
+// Placement by trial: `run` launches the kernels that use the vector (on the current stream, any number of them); it is
+// timed with the vector in its own block and in `tries` fresh ones, and the vector moves to the fastest (contents kept).
+// Always the same number of trials -- `run` may contain exchanges with other ranks, which then run it equally often.
+int ramd_vec_place_by_trial(ramd_vec_t v, ramd_trial_cb run, void* ctx, int tries, int* moved)
+{
+    CHECK_VEC(v);
+    PlacementClock clock;
+    if(moved)
+        *moved = 0;
+    if(!run || tries < 1 || !v->d)
+        return RAMD_OK;
+    const size_t      bytes = (size_t)v->n * dtype_size(v->dtype);
+    static const bool off   = getenv("RAMD_ALLOC_CLASSES") && atoi(getenv("RAMD_ALLOC_CLASSES")) == 0;
+    if(off || bytes < ((size_t)64 << 20))
+        return RAMD_OK;
+    static const bool verbose = getenv("RAMD_ALLOC_VERBOSE") != nullptr;
+    hipStream_t       st      = backend().cur;
+    hipEvent_t        e0, e1;
+    RAMD_HIP(hipEventCreate(&e0));
+    RAMD_HIP(hipEventCreate(&e1));
+    void* const own  = v->d;
+    void*       keep = nullptr;
+    if(cached_malloc_bytes(&keep, bytes + kPad) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        return RAMD_OK; // no room to try: stay
+    }
+    (void)hipMemcpyAsync(keep, own, bytes, hipMemcpyDeviceToDevice, st);
+    int  rc        = RAMD_OK;
+    auto time_with = [&](void* block, float* ms) { // one warm run, then the faster of two
+        v->d       = block;
+        float best = 1e30f;
+        for(int rep = 0; rep < 3 && rc == RAMD_OK; ++rep)
+        {
+            (void)hipEventRecord(e0, st);
+            rc = run(ctx);
+            (void)hipEventRecord(e1, st);
+            (void)hipEventSynchronize(e1);
+            float t = 0.f;
+            (void)hipEventElapsedTime(&t, e0, e1);
+            if(rep > 0 && t < best)
+                best = t;
+        }
+        v->d = own;
+        *ms  = best;
+    };
+    float best_ms = 0.f;
+    time_with(own, &best_ms);
+    void*              best = own;
+    std::vector<void*> losers;
+    if(verbose)
+        fprintf(stderr, "place by trial: own block %.4f ms", best_ms);
+    for(int k = 0; k < tries && rc == RAMD_OK; ++k)
+    {
+        void* c = nullptr;
+        if(cached_malloc_bytes(&c, bytes + kPad) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            c = nullptr;
+        }
+        float ms = 1e30f;
+        if(c)
+        {
+            (void)hipMemcpyAsync(c, keep, bytes, hipMemcpyDeviceToDevice, st);
+            (void)hipMemsetAsync((char*)c + bytes, 0, kPad, st);
+            time_with(c, &ms);
+        }
+        else
+            time_with(own, &ms); // (keeps the number of runs the same on every rank)
+        if(verbose)
+            fprintf(stderr, ", candidate %.4f", ms);
+        if(c && rc == RAMD_OK && ms < 0.995f * best_ms)
+        {
+            if(best != own)
+                losers.push_back(best);
+            best    = c;
+            best_ms = ms;
+        }
+        else if(c)
+            losers.push_back(c);
+    }
+    if(verbose)
+        fprintf(stderr, " -> %s (%.4f ms)\n", best == own ? "kept" : "moved", best_ms);
+    if(best != own)
+    {
+        losers.push_back(own);
+        v->d = best;
+        if(moved)
+            *moved = 1;
+    }
+    (void)hipMemcpyAsync(v->d, keep, bytes, hipMemcpyDeviceToDevice, st);
+    (void)hipStreamSynchronize(st);
+    for(void* l : losers)
+        (void)cached_free(l);
+    (void)cached_free(keep);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
 }
 
 int ramd_vec_placement_class(ramd_vec_t v, int* cls)

@@ -211,15 +211,15 @@ def gpu_worker(rank, world, initfile, kind, outdir, rccl=False):
     dist.destroy_process_group()
 
 
-def amg_worker(rank, world, initfile, kind, outdir):
+def amg_worker(rank, world, initfile, kind, outdir, rccl=False):
     """aggregation AMG on the GlobalMatrix (RAMD_PC_GLOBAL_*): CG preconditioned by UA-AMG and by SA-AMG on `world` ranks
     sharing one GPU (callback transport).  kind: "poisson_slab" (24^3, z-slabs) or "gr3030x" (the 2-D 9-point gr_30_30
     pattern repeated on a 120 x 120 grid, general CSR split with an unstructured halo plan)"""
     from rocalution_amd import capi, distributed as D
     import rocalution_amd as ra
     dist = _init(rank, world, initfile)
-    ra.init_rocalution(0)
-    comm = D.make_callback_comm(rank, world, dist)
+    ra.init_rocalution(rank if rccl else 0)
+    comm = D.init_rccl_comm(rank, world, dist) if rccl else D.make_callback_comm(rank, world, dist)
     out = {}
     for tag, pk in (("ua", capi.PC_GLOBAL_UAAMG), ("sa", capi.PC_GLOBAL_SAAMG)):
         g = D.DistributedSolver(comm, capi.SOLVER_CG, pk)
@@ -260,8 +260,8 @@ def amg_matrix(kind):
 
 if __name__ == "__main__":
     mode, rank, world, initfile, kind, outdir = sys.argv[1:7]
-    if mode == "amg":
-        amg_worker(int(rank), int(world), initfile, kind, outdir)
+    if mode in ("amg", "amg_rccl"):
+        amg_worker(int(rank), int(world), initfile, kind, outdir, rccl=(mode == "amg_rccl"))
     elif mode == "cpu":
         cpu_worker(int(rank), int(world), initfile, kind, outdir)
     else:

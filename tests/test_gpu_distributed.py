@@ -118,6 +118,23 @@ def test_two_rccl_ranks_on_two_gpus(kind, oracle):
     _check_two_ranks(kind, oracle, "rccl")
 
 
+def test_two_rccl_ranks_global_amg_on_two_gpus():
+    """... and the aggregation AMG on the GlobalMatrix over RCCL (prolongation rows and coarse halos through grouped
+    ncclSend/ncclRecv): the Galerkin identity on every level, convergence to the solution.  Skips on a 1-GPU box."""
+    import rocalution_amd as ra
+    if ra.device_count() < 2:
+        pytest.skip("needs two GPUs (one RCCL rank per device)")
+    from test_cpu_host import _spawn
+    res = _spawn("amg_rccl", "poisson_slab", world=2, timeout=900)
+    n = 24 ** 3
+    for tag in ("ua", "sa"):
+        x = np.concatenate([r["x_" + tag] for r in res])
+        assert int(res[0]["res_" + tag][1]) == 2
+        assert np.linalg.norm(x - 1.0) / np.sqrt(n) < 1e-6
+        for r in res:
+            assert r["info_" + tag][2] < 1e-12
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_rccl_halo_and_allreduce_on_a_size_one_communicator(dtype):
     """RCCL refuses two ranks on one device, so the RCCL data plane is exercised with ONE rank: the halo

@@ -483,8 +483,8 @@ def test_ilu_lusolve_poisson_vs_oracle(ra, oracle, N):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("reach", [3, 40, 700])
-def test_ilu0_rows_in_registers_irregular_vs_oracle(ra, oracle, dtype, reach):
+@pytest.mark.parametrize("reach,side", [(3, 3), (40, 3), (700, 3), (40, 7)])
+def test_ilu0_rows_in_registers_irregular_vs_oracle(ra, oracle, dtype, reach, side):
     """ILU(0) of rows with at most 8 entries runs in natural order with the row in registers; pivot rows held by a lower
     lane of the same wave come from that lane's registers (k_ilu0_rows).  Random unsymmetric patterns whose lower entries
     reach 3 / 40 / 700 rows back: in-wave pivots at every lane distance, several per row, mixed with out-of-wave ones, a
@@ -493,7 +493,7 @@ def test_ilu0_rows_in_registers_irregular_vs_oracle(ra, oracle, dtype, reach):
     n = 1 << 20  # 4096 blocks of 256 rows: the hyperplane block order is in use
     rows, cols = [], []
     i = np.arange(n)
-    for s in range(3):
+    for s in range(side):  # (side = 7: rows of up to 15 entries, the 16-entry form of the kernel)
         d = rng.integers(1, reach + 1, n)
         keep = rng.random(n) < 0.8
         lo = i - d
@@ -509,7 +509,7 @@ def test_ilu0_rows_in_registers_irregular_vs_oracle(ra, oracle, dtype, reach):
     r = np.concatenate(rows); c = np.concatenate(cols)
     P = sp.csr_matrix((np.ones(len(r)), (r, c)), shape=(n, n))
     P.sum_duplicates(); P.sort_indices()
-    assert np.diff(P.indptr).max() <= 7
+    assert np.diff(P.indptr).max() <= 2 * side + 1
     P.data[:] = rng.uniform(-1.0, 1.0, len(P.data))
     diag = np.asarray(abs(P).sum(axis=1)).ravel() + 1.0
     A = (P - sp.diags(P.diagonal()) + sp.diags(diag)).tocsr(); A.sort_indices()
