@@ -7,8 +7,8 @@
 // colour(i) depends only on the neighbours j < i, so the sweep is a DAG like a triangular solve.  For a
 // structurally symmetric pattern (checked here) the row entries are all the neighbours and the sweep
 // runs sync-free: thread per row, workgroups in ticket order, a row polls the colour array itself
-// (0 = not yet) for neighbours in other waves and takes the colours of its own wave through shuffles
-// (the x-1 chain of a stencil never leaves the registers).  Unsymmetric patterns, or more than 64
+// (0 = not yet) for neighbours in other waves and takes the colours of its own wave in registers
+// (the x-1 chain of a stencil never leaves them; see k_greedy_color).  Unsymmetric patterns, or more than 64
 // colours, return RAMD_ERR_UNSUPPORTED and the caller runs the host sweep (host_analysis.hip).
 // At 512^3 the serial host sweep takes 6.3 s (+ 4.3 GB over PCIe); this one is bandwidth/latency bound.
 #include "device_utils.hpp"
@@ -46,34 +46,41 @@ __global__ __launch_bounds__(kBlock) void k_pattern_symmetric(int nrow, const in
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_greedy_color(int nrow, const int* __restrict__ rp,
-                                                         const int* __restrict__ ci, int* color,
-                                                         unsigned* counter, int* overflow,
-                                                         const int* __restrict__ block_order)
+// The sweep takes its rows in the wave units of blocksched.hip (unit_schedule: <= 64 consecutive rows that belong
+// together, units in hyperplane order): a neighbour is a row of an EARLIER wave -- its colour is polled in memory -- or of
+// a lower lane of this wave, noted in a lane mask and resolved in registers in one ascending pass (at step b lane b has
+// seen all its neighbours, picks its colour, v_readlane broadcasts it to the lanes that hold bit b).  The x-1 chain of a
+// grid line costs a handful of ALU instructions per link instead of a turn of a divergent loop with a memory poll in it:
+// 186 -> 13 ms at 512^3 (the 256-row blocks of round 2 were half an x-pencil each, 256 serial links).
+constexpr int kColorBlock = 1024;
+__global__ __launch_bounds__(kColorBlock) void k_greedy_color(int nrow, const int* __restrict__ rp,
+                                                              const int* __restrict__ ci, int* color, unsigned* counter,
+                                                              int* overflow, UnitView uv)
 {
-    const unsigned tick = take_ticket(counter, 0u);
-    const unsigned blk  = block_order ? (unsigned)block_order[tick] : tick; // blocksched.hip
-    const int64_t  t    = (int64_t)blk * kBlock + threadIdx.x;
+    const unsigned slot = take_ticket(counter, 0u) * (kColorBlock / 64) + (threadIdx.x >> 6); // (one ticket per workgroup)
     const int      lane = threadIdx.x & 63;
-    const bool     live = t < nrow;
+    const bool     have = slot < (unsigned)uv.nunits;
+    const int      unit = have ? (uv.order ? uv.order[slot] : (int)slot) : 0;
+    const int      w0   = have ? uv.ustart[unit] : 0; // first row of my wave
+    const int64_t  t    = (int64_t)w0 + lane;
+    const bool     live = have && t < uv.ustart[unit + 1];
     const int      row  = live ? (int)t : 0;
-    const int      w0   = (int)(t - lane); // first row of my wave
     int            j    = live ? rp[row] : 0;
     const int      end  = live ? rp[row + 1] : 0;
     unsigned long long used = 0ull; // bit c-1 <-> colour c
-    int  mine  = 0;
-    bool fin   = !live;
-    int  spins = 0;
+    unsigned long long inwave = 0ull; // neighbours held by lower lanes
+    bool fin     = !live;
+    int  spins   = 0;
     int  backoff = 1;
-    // wave-uniform loop (SIMT rule of trisolve.hip): publish inside, leave together
+    bool stalled = false;
+    // (A) neighbours coloured by other waves; wave-uniform loop (SIMT rule of trisolve.hip); a stalled wave polls with one lane
     do
     {
         spin_guard(spins);
         const int  j_before   = j;
         const bool fin_before = fin;
-        // (1) neighbours coloured by other waves: consume every one that is ready
-        int want = lane; // (2) at most one neighbour inside my wave per turn, through a shuffle
-        if(!fin)
+        const bool my_turn    = !stalled || lane == (int)__ffsll((long long)__ballot(!fin)) - 1;
+        if(!fin && my_turn)
         {
             while(j < end)
             {
@@ -85,8 +92,9 @@ __global__ __launch_bounds__(kBlock) void k_greedy_color(int nrow, const int* __
                 }
                 if(c >= w0)
                 {
-                    want = c - w0;
-                    break;
+                    inwave |= 1ull << (c - w0);
+                    ++j;
+                    continue;
                 }
                 const int cc = __hip_atomic_load(color + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if(cc == 0)
@@ -94,31 +102,34 @@ __global__ __launch_bounds__(kBlock) void k_greedy_color(int nrow, const int* __
                 used |= 1ull << (cc - 1);
                 ++j;
             }
+            fin = (j >= end);
         }
-        const int got = __shfl(mine, want, 64);
-        if(!fin)
-        {
-            if(want != lane && got != 0)
-            {
-                used |= 1ull << (got - 1);
-                ++j;
-            }
-            if(j >= end)
-            {
-                if(used == ~0ull)
-                {
-                    *overflow = 1; // > 64 colours: result discarded by the caller
-                    mine      = 64;
-                }
-                else
-                    mine = __ffsll((long long)~used);
-                __hip_atomic_store(color + row, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                fin = true;
-            }
-        }
-        // nobody in the wave advanced: exponential back-off (device_utils.hpp) instead of polling at full rate
-        backoff = poll_backoff(__ballot(!fin_before && (fin || j != j_before)) != 0ull, backoff);
+        const bool advanced = __ballot(!fin_before && (fin || j != j_before)) != 0ull;
+        stalled             = !advanced;
+        backoff             = poll_backoff(advanced, backoff);
     } while(__ballot(!fin) != 0ull);
+    // (B) neighbours held by lower lanes
+    if(__ballot(inwave != 0ull) != 0ull)
+        for(int b = 0; b < 63; ++b)
+        {
+            const int pick = used == ~0ull ? 64 : __ffsll((long long)~used); // what lane b takes (it is final at step b)
+            const int cb   = __builtin_amdgcn_readlane(pick, b);
+            const unsigned half = b < 32 ? (unsigned)inwave : (unsigned)(inwave >> 32);
+            if((half >> (b & 31)) & 1u)
+                used |= 1ull << (cb - 1);
+        }
+    if(live)
+    {
+        int mine;
+        if(used == ~0ull)
+        {
+            *overflow = 1; // > 64 colours: result discarded by the caller
+            mine      = 64;
+        }
+        else
+            mine = __ffsll((long long)~used);
+        __hip_atomic_store(color + row, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void k_color_flag(int nrow, const int* __restrict__ color, int c,
@@ -145,6 +156,7 @@ int multicoloring_device(const ramd_mat_s* m, int* num_colors, int* size_colors,
     const int n = m->nrow;
     if(n <= 0 || m->nnz <= 0)
         return RAMD_ERR_UNSUPPORTED;
+    build_mark(nullptr);
     if(m->nnz / n > 256) // the symmetry check walks the mirror row per entry
         return RAMD_ERR_UNSUPPORTED;
     int* color = nullptr;
@@ -172,19 +184,24 @@ int multicoloring_device(const ramd_mat_s* m, int* num_colors, int* size_colors,
         return cleanup(RAMD_ERR_UNSUPPORTED);
     if(hipMemsetAsync(color, 0, sizeof(int) * ((size_t)n + 1), b.cur) != hipSuccess)
         return cleanup(RAMD_ERR_HIP);
-    const int nblk = (n + kBlock - 1) / kBlock;
-    int* border = nullptr;
-    (void)block_schedule(m, true, &border); // hyperplane order of the row blocks (nullptr: natural order)
-    hipLaunchKernelGGL(k_greedy_color, dim3(nblk), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, color,
-                       reinterpret_cast<unsigned*>(work + 2), work + 1, border);
+    build_mark("colouring: symmetry check");
+    UnitPlan units; // wave units of the lower-neighbour graph, in hyperplane order (blocksched.hip)
+    s = unit_schedule(m, true, &units);
+    build_mark("colouring: unit schedule");
+    if(s != RAMD_OK)
+        return cleanup(s);
+    const int per = kColorBlock / 64;
+    hipLaunchKernelGGL(k_greedy_color, dim3((unsigned)((units.nunits + per - 1) / per)), dim3(kColorBlock), 0, b.cur, n, m->rp,
+                       m->ci, color, reinterpret_cast<unsigned*>(work + 2), work + 1, unit_view(units));
     if(hipGetLastError() != hipSuccess)
     {
-        dev_free(&border);
+        units.release();
         return cleanup(RAMD_ERR_HIP);
     }
     int nc = 0;
     s      = device_max_int(color, n, &nc); // (synchronises)
-    dev_free(&border);
+    build_mark("colouring: greedy sweep");
+    units.release();
     if(s != RAMD_OK)
         return cleanup(s);
     if(hipMemcpyAsync(h, work, sizeof(int) * 2, hipMemcpyDeviceToHost, b.cur) != hipSuccess
@@ -217,6 +234,7 @@ int multicoloring_device(const ramd_mat_s* m, int* num_colors, int* size_colors,
     }
     if(s == RAMD_OK && hipStreamSynchronize(b.cur) != hipSuccess)
         s = RAMD_ERR_HIP;
+    build_mark("colouring: permutation");
     if(s == RAMD_OK)
         *num_colors = nc;
     return cleanup(s);

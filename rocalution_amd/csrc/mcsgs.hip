@@ -288,12 +288,12 @@ static int mc_pack(McsgsPlan* P, const ramd_mat_s* m, bool lower, const int* d_o
     return RAMD_OK;
 }
 
-// number of stored entries of the diagonal colour block (i,i): 0 -> Jacobi inverse diagonal empty
+// does the diagonal colour block (i,i) store any entry?  cnt[i] = 0: no -> Jacobi inverse diagonal empty
 __global__ __launch_bounds__(kBlock) void k_mc_block_nnz(int n, const int* __restrict__ rp,
                                                          const int* __restrict__ ci,
                                                          const int* __restrict__ off,
                                                          const int* __restrict__ blk_of,
-                                                         int* __restrict__ cnt)
+                                                         int* cnt)
 {
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
     for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gsz)
@@ -303,20 +303,11 @@ __global__ __launch_bounds__(kBlock) void k_mc_block_nnz(int n, const int* __res
         for(int j = rp[t]; j < rp[t + 1]; ++j)
             if(ci[j] >= off[b] && ci[j] < off[b + 1])
                 ++c;
-        // one atomic per wave when the whole wave sits in one colour (the common case): 67M
-        // same-address atomics took 1.5 s at 512^3
-        const int b0 = __shfl(b, 0, 64);
-        if(__ballot(b != b0) == 0ull)
-        {
-            int w = c;
-#pragma unroll
-            for(int o = 32; o > 0; o >>= 1)
-                w += __shfl_xor(w, o, 64);
-            if((threadIdx.x & 63) == 0 && w)
-                atomicAdd(cnt + b0, w);
-        }
-        else if(c)
-            atomicAdd(cnt + b, c);
+        // only "none at all" matters to the caller, so cnt[b] is a flag: raised by a plain agent-scope store, and only
+        // where a load says it is not raised yet (67 M same-address atomic adds took 1.5 s at 512^3, one per wave still
+        // 24 ms: an RMW on one address costs ~10 ns whoever issues it)
+        if(c && __hip_atomic_load(cnt + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+            __hip_atomic_store(cnt + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
