@@ -243,6 +243,150 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PAT ? RA
     }
 }
 
+// Row-pattern product, TWO row blocks per workgroup (k_csr_tr<PAT> with its memory phases overlapped).  k_csr_tr<PAT> at
+// 512^3 moves 10.3 GB in 2.2-2.3 ms = 4.6 TB/s where two plain read streams reach 7.1 TB/s (profiles/r02_membench.txt): a
+// workgroup there is one chain -- value packets from HBM (~2.5 us), LDS, barrier, two rounds of x gathers through the L2
+// (~1.2 us), store -- and with six workgroups of 14 KB per CU only ~84 KB are in flight per CU and chain: Little's law, not
+// HBM, is the bound.  Here the value packets of BOTH row blocks are requested first; block 0 is staged and walked while block
+// 1's packets are still on their way, then block 1: twice the bytes in flight per wave for 16 more registers.  Same
+// products in the same order per row, the same per-wave partials of the fused dot in the same places: results identical to
+// k_csr_tr<PAT> bit for bit.  Needs every row block's entries to fit one LDS pass (256 x width + 3 <= kCsrChunk).
+// MEASURED (gpurun_out/r03aq) and therefore opt-in (RAMD_CSR_PAT2=1): the plain product 2.27 ms against 2.11 ms of
+// k_csr_tr<PAT> at 512^3 (500^3: 2.06 vs 1.97; 256^3: 0.242 vs 0.252), the product + dot 2.31 vs 2.30 ms, CG 242-244 vs
+// 239-249 it/s -- the bytes in flight were not the bound after all; the reasoning above is kept because it is the
+// obvious one and it is wrong.
+__device__ __forceinline__ int xcd_block_at(int i, int nblk, int per_xcd, BandMap bm)
+{
+    int l = i;
+    if(bm.P > 0 && i < bm.Z * bm.P)
+    {
+        const int tile   = i / (bm.W * bm.Z);
+        const int within = i - tile * (bm.W * bm.Z);
+        const int z      = within / bm.W;
+        const int w      = within - z * bm.W;
+        l                = z * bm.P + tile * bm.W + w;
+    }
+    const int b = (blockIdx.x & 7) * per_xcd + l;
+    return (i < per_xcd && b < nblk) ? b : -1;
+}
+
+template <typename T, int MODE, bool DOT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RAMD_CSR_PAT_WAVES, 8))) void k_csr_pat2(
+    int nrow, int nblk, int per_xcd, const int* __restrict__ rp, const T* __restrict__ val, const T* __restrict__ x,
+    T* __restrict__ y, T scalar, CsrDotWs ws, int slot, BandMap bm, CsrPattern pat)
+{
+    using VP           = typename ValPk<T>::type;
+    constexpr int VN   = ValPk<T>::N;
+    constexpr int NPKT = kCsrChunk / (VN * kBlock);
+    __shared__ T   sval[kCsrChunk];
+    __shared__ int sdict[kPatMax * kPatMaxW];
+    for(int i = threadIdx.x; i < pat.n * pat.w; i += kBlock)
+        sdict[i] = pat.dict[i];
+    int blk[2], rs[2], re[2], dbase[2], cb[2], end[2];
+    VP  a[2][NPKT];
+    T   sum[2];
+#pragma unroll
+    for(int h = 0; h < 2; ++h)
+    {
+        blk[h]        = xcd_block_at(2 * (int)(blockIdx.x >> 3) + h, nblk, per_xcd, bm);
+        rs[h] = re[h] = dbase[h] = cb[h] = end[h] = 0;
+        sum[h]                                    = (T)0;
+        if(blk[h] >= 0)
+        {
+            const int r0   = blk[h] * kCsrRows;
+            const int rend = min(r0 + kCsrRows, nrow);
+            const int row  = r0 + threadIdx.x;
+            if(row < nrow)
+            {
+                rs[h]    = rp[row];
+                re[h]    = rp[row + 1];
+                dbase[h] = (int)pat.id[row] * pat.w - rs[h];
+                if(MODE == 1)
+                    sum[h] = y[row];
+            }
+            cb[h]  = rp[r0] & ~3;
+            end[h] = rp[rend];
+#pragma unroll
+            for(int k = 0; k < NPKT; ++k)
+            {
+                const int j = cb[h] + (k * kBlock + threadIdx.x) * VN;
+                if(j < end[h])
+                    a[h][k] = nt_load(reinterpret_cast<const VP*>(val + j));
+            }
+        }
+    }
+    double dacc[2] = {0.0, 0.0};
+#pragma unroll
+    for(int h = 0; h < 2; ++h)
+    {
+        if(h == 1)
+            __syncthreads(); // (block 0's values have been read by everybody)
+        if(blk[h] >= 0)
+        {
+#pragma unroll
+            for(int k = 0; k < NPKT; ++k)
+            {
+                const int g = (k * kBlock + threadIdx.x) * VN;
+                if(cb[h] + g < end[h])
+                    *reinterpret_cast<VP*>(sval + g) = a[h][k];
+            }
+        }
+        __syncthreads();
+        if(blk[h] >= 0)
+        {
+            const int row = blk[h] * kCsrRows + threadIdx.x;
+            T         sm  = sum[h];
+            for(int j = rs[h]; j < re[h]; j += kGatherW)
+            {
+                int cc[kGatherW];
+                T   v[kGatherW], xv[kGatherW];
+#pragma unroll
+                for(int e = 0; e < kGatherW; ++e)
+                    if(j + e < re[h])
+                    {
+                        cc[e] = row + sdict[dbase[h] + j + e];
+                        v[e]  = sval[j - cb[h] + e];
+                    }
+#pragma unroll
+                for(int e = 0; e < kGatherW; ++e)
+                    if(j + e < re[h])
+                        xv[e] = x[cc[e]];
+#pragma unroll
+                for(int e = 0; e < kGatherW; ++e)
+                    if(j + e < re[h])
+                    {
+                        if(MODE != 1)
+                            sm += v[e] * xv[e];
+                        else
+                            sm += scalar * v[e] * xv[e];
+                    }
+            }
+            if(row < nrow)
+            {
+                if(MODE == 2)
+                {
+                    T t = (T)(-1) * sm + static_cast<const T*>(ws.jrhs)[row];
+                    t   = static_cast<const T*>(ws.jdinv)[row] * t;
+                    sm  = x[row] + scalar * t;
+                }
+                nt_store(sm, y + row);
+                if(DOT)
+                    dacc[h] = (double)sm * (double)(ws.dotv ? static_cast<const T*>(ws.dotv)[row] : x[row]);
+            }
+        }
+    }
+    if(DOT)
+    {
+#pragma unroll
+        for(int h = 0; h < 2; ++h)
+        {
+            const double wsum = wave_reduce_sum(dacc[h]);
+            if((threadIdx.x & 63) == 0 && blk[h] >= 0)
+                ws.part1[blk[h] * (kBlock / 64) + (threadIdx.x >> 6)] = wsum;
+        }
+    }
+}
+
 // CSR SpMV of a STRUCTURED matrix with x tiles in LDS (row patterns, csr_analyse_xl).  k_csr_tr<PAT> no longer reads the
 // columns, so what it moves per row is the values (7 x 8 B on the 7-point operator) -- and 7 x 8 B of x through the gather
 // path: 28 wave-level 8-byte loads per 256 rows, each 4-5 lines (the +-1 neighbours straddle), 4.6-4.9 TB/s of the bytes
@@ -1251,6 +1395,9 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
         RAMD_TRY(csr_analyse_groups(const_cast<ramd_mat_s*>(m)));
     const bool      use_grp = !use_pat && grp_env != 0 && m->grp_state == 1 && !m->pat_off;
     const CsrGroups cgr     = {use_grp ? m->grp_lead : nullptr, use_grp ? m->grp_need : nullptr};
+    // two row blocks per workgroup with their memory phases overlapped (k_csr_pat2), where a row block fits one LDS pass
+    static const int pat2_env = getenv("RAMD_CSR_PAT2") ? atoi(getenv("RAMD_CSR_PAT2")) : 0; // (opt-in experiment, see k_csr_pat2)
+    const bool       use_pat2 = use_pat && !use_xl && pat2_env != 0 && kCsrRows * m->pat_w + 3 <= kCsrChunk;
     const bool q4      = !use_pat && q4_env > 0; // measured EQUAL to k_csr_tr on the shell surrogate (0.162 vs 0.160 ms): opt-in
     const int  nblk    = (m->nrow + rows_per_wg - 1) / rows_per_wg;
     const int  per_xcd = (nblk + 7) / 8;
@@ -1284,6 +1431,9 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
                                sizeof(T) * (size_t)(kCsrChunk + xsg.total) + sizeof(int) * (size_t)(pat.n * pat.w), b.cur, \
                                m->nrow, nblk, per_xcd, \
                                m->rp, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, xsg);             \
+        else if(use_pat2)                                                                                  \
+            hipLaunchKernelGGL((k_csr_pat2<T, MODE, DOT>), dim3(((per_xcd + 1) / 2) * 8), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
+                               per_xcd, m->rp, (const T*)m->val, x, y, scalar, ws, slot, bm, pat);         \
         else if(use_pat)                                                                                   \
             hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT, true>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
                                per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat);  \
