@@ -144,6 +144,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PAT ? RA
         const int start = rp[r0];
         const int end   = rp[rend];
         T         sum   = (T)0;
+        // x[row] for the epilogues (fused dot against x, Jacobi sweep): the row's own diagonal entry gathers it anyway, so
+        // the row-pattern product takes it from there (one gather per row less).  What the fused dot costs on top of the
+        // plain product differs from box to box by more than this saves (tools/spmv_time.py at 512^3: +0.20 ms before,
+        // +0.004 and +0.12 ms after, gpurun_out/r03aq / r03ar / r03as).  Only for row patterns: with the stored columns
+        // read the same test costs registers that kernel does not have (2.5 -> 2.97 ms).
+        T    xrow      = (T)0;
+        bool have_xrow = false;
         if(MODE == 1 && row < nrow)
             sum = y[row];
         for(int cb = start & ~3; cb < end; cb += kCsrChunk)
@@ -212,23 +219,31 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PAT ? RA
                             sum += v[e] * xv[e];
                         else
                             sum += scalar * v[e] * xv[e];
+                        if(PAT && (DOT || MODE == 2) && cc[e] == row)
+                        {
+                            xrow      = xv[e];
+                            have_xrow = true;
+                        }
                     }
             }
             __syncthreads();
         }
         if(row < nrow)
         {
+            if((DOT && !ws.dotv) || MODE == 2)
+                if(!have_xrow) // (a row without a stored diagonal entry)
+                    xrow = x[row];
             if(MODE == 2)
             {
                 T t = (T)(-1) * sum + static_cast<const T*>(ws.jrhs)[row];
                 t   = static_cast<const T*>(ws.jdinv)[row] * t;
-                sum = x[row] + scalar * t;
+                sum = xrow + scalar * t;
             }
             // non-temporal, unconditionally: a run-time switch here let the compiler merge both branches
             // into ONE plain store (the hint was lost and the kernel ran 15% slower at 256^3)
             nt_store(sum, y + row);
-            if(DOT) // w_row is fetched last: no live register across the stream (x[row] is an L1/L2 hit by now)
-                dacc = (double)sum * (double)(ws.dotv ? static_cast<const T*>(ws.dotv)[row] : x[row]);
+            if(DOT)
+                dacc = (double)sum * (double)(ws.dotv ? static_cast<const T*>(ws.dotv)[row] : xrow);
         }
     }
     if(DOT)
@@ -336,6 +351,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RAMD_CSR
         {
             const int row = blk[h] * kCsrRows + threadIdx.x;
             T         sm  = sum[h];
+            T         xrow      = (T)0;
+            bool      have_xrow = false;
             for(int j = rs[h]; j < re[h]; j += kGatherW)
             {
                 int cc[kGatherW];
@@ -359,19 +376,27 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RAMD_CSR
                             sm += v[e] * xv[e];
                         else
                             sm += scalar * v[e] * xv[e];
+                        if((DOT || MODE == 2) && cc[e] == row)
+                        {
+                            xrow      = xv[e];
+                            have_xrow = true;
+                        }
                     }
             }
             if(row < nrow)
             {
+                if((DOT && !ws.dotv) || MODE == 2)
+                    if(!have_xrow)
+                        xrow = x[row];
                 if(MODE == 2)
                 {
                     T t = (T)(-1) * sm + static_cast<const T*>(ws.jrhs)[row];
                     t   = static_cast<const T*>(ws.jdinv)[row] * t;
-                    sm  = x[row] + scalar * t;
+                    sm  = xrow + scalar * t;
                 }
                 nt_store(sm, y + row);
                 if(DOT)
-                    dacc[h] = (double)sm * (double)(ws.dotv ? static_cast<const T*>(ws.dotv)[row] : x[row]);
+                    dacc[h] = (double)sm * (double)(ws.dotv ? static_cast<const T*>(ws.dotv)[row] : xrow);
             }
         }
     }
