@@ -325,14 +325,16 @@ hipError_t cached_malloc_apart(void** p, size_t bytes, const void* other)
         return cached_malloc_bytes(p, bytes);
     std::vector<void*> rejects;
     hipError_t         e = hipSuccess;
-    for(int draw = 0; draw < 12; ++draw)
+    // (a fresh GiB costs 1 ... 100 ms of hipMalloc depending on the box: few draws)
+    constexpr int kDraws = 4;
+    for(int draw = 0; draw < kDraws; ++draw)
     {
         void* q = nullptr;
         e       = cached_malloc_bytes(&q, bytes);
         if(e != hipSuccess)
             break;
         const int k = cached_block_class(q);
-        if(k < 0 || k != avoid || draw == 11)
+        if(k < 0 || k != avoid || draw == kDraws - 1)
         {
             *p = q;
             break;

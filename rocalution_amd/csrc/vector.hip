@@ -541,7 +541,7 @@ int ramd_vec_place_apart(ramd_vec_t v, ramd_vec_t other, int* moved)
         fprintf(stderr, "place apart: current pair %.4f ms", best_ms);
     float worst_ms = best_ms;
     // (pairs come in two speeds, ~8-15 % apart: the search ends as soon as both have been seen and the fast one is held)
-    for(int k = 0; k < 12 && worst_ms < 1.07f * best_ms; ++k)
+    for(int k = 0; k < 5 && worst_ms < 1.07f * best_ms; ++k) // (each candidate is a fresh allocation: 1 ... 100 ms per GiB)
     {
         void* c = nullptr;
         if(cached_malloc_apart(&c, bytes + kPad, other->d) != hipSuccess)
