@@ -324,7 +324,8 @@ public:
     }
     // ... and by trial: `run` launches the kernels that use this vector; the vector moves to the fastest of its own block
     // and `tries` fresh ones (ramd_vec_place_by_trial).  `run` is executed 3 (tries + 1) times.
-    void PlaceByTrial(const std::function<void()>& run, int tries)
+    void PlaceByTrial(const std::function<void()>& run, int tries, double stop_ratio = 0.0,
+                      const LocalVector<ValueType>* apart_from = nullptr)
     {
         if(!this->on_accel_ || this->dev_ == nullptr)
             return;
@@ -337,7 +338,8 @@ public:
             }
         };
         int moved = 0;
-        RAMD_CHECK(ramd_vec_place_by_trial(this->dev_, &Hop::call, const_cast<std::function<void()>*>(&run), tries, &moved));
+        RAMD_CHECK(ramd_vec_place_by_trial(this->dev_, &Hop::call, const_cast<std::function<void()>*>(&run), tries, stop_ratio,
+                                           (apart_from && apart_from->on_accel_) ? apart_from->dev_ : nullptr, &moved));
     }
     void Clear(void)
     {

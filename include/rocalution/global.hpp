@@ -405,8 +405,14 @@ public:
     {
         this->m_owned.PlaceApartFrom(other.m_owned);
     }
-    void PlaceByTrial(const std::function<void()>& run, int tries)
+    void PlaceByTrial(const std::function<void()>& run, int tries, double stop_ratio = 0.0,
+                      const GlobalVector<ValueType>* apart_from = nullptr)
     {
+        if(stop_ratio > 0.0) // (a `run` without exchanges: every rank places its share by itself)
+        {
+            this->m_owned.PlaceByTrial(run, tries, stop_ratio, apart_from ? &apart_from->m_owned : nullptr);
+            return;
+        }
         // every rank has to run `run` equally often (it exchanges halos): all of them take part, or none
         const double mine = (double)this->m_owned.GetSize() * sizeof(ValueType) >= (double)(64 << 20) ? 1.0 : 0.0;
         if(this->pm_ != NULL && this->pm_->GetNumProcs() > 1

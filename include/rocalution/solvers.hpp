@@ -1776,13 +1776,11 @@ protected:
         VectorType *r = this->W(0), *p = this->W(1), *q = this->W(2), *z = precond ? this->W(3) : r;
         // placement (no arithmetic): the residual update writes r and z in one pass, the direction update x and p -- each
         // pair streams faster from different placement classes (csrc/backend.hip); a no-op for small or already-apart blocks
-        if(this->doPlaceOnce())
+        if(this->doPlaceOnce() && !(this->m_fused && this->m_res_norm_type == 2 && this->doPlaceByTrial(x, precond)))
         {
             if(precond)
                 z->PlaceApartFrom(*r);
             p->PlaceApartFrom(*x);
-            if(this->m_fused && this->m_res_norm_type == 2)
-                this->doPlaceByTrial(x, precond);
         }
         Engine K(*this->m_op, sCount);
         this->doDefect(rhs, *x, r);
@@ -1878,18 +1876,20 @@ private:
     {
         return false;
     }
-    // Placement of the work vectors of the fused loop by trial (LocalVector::PlaceByTrial), OPT-IN (RAMD_PLACE_TRIES=k): one
-    // whole iteration -- update, direction, product -- is timed with z, p, q, r in turn in their own block and in k fresh
-    // ones; no arithmetic of the solve is involved (the work vectors are overwritten before they are used, the iterate is
-    // saved and restored).  Measured at 512^3 over fresh processes (gpurun_out/r03al, r03am, r03an): the trial times do
-    // predict the loop (4.05 ... 4.45 ms per iteration depending on the blocks), but the fast combination is not reliably
-    // among a handful of fresh blocks -- medians 244 / 247 / 241 it/s with 3 / 6-10 / 6 tries against 240-244 without, for
-    // 0.4-1.5 s at the first Solve (ramd_placement_seconds).  Not worth it by default.
+    // Placement of the work vectors of the fused loop with its OWN kernels as the probe (LocalVector::PlaceByTrial): the
+    // residual update (3 reads, 2 writes) runs at 0.85 or at 0.97 ms at 512^3 depending on the blocks of its vectors, the
+    // direction update likewise; the generic write-pair probe of PlaceApartFrom finds the fast case only two times in three
+    // (profiles/r03_bench_repeats_cg.txt: 0.85 / 0.92 / 0.97 ms average).  So z is placed by timing the residual update, p
+    // by timing the direction update, each in its own block and in up to 8 fresh ones, until the time seen is clearly the
+    // fast one.  No arithmetic of the solve is involved (the work vectors are overwritten before they are used, the iterate
+    // is saved and restored); once per Build, at its first Solve (ramd_placement_seconds; bench.py reports it).
+    // RAMD_PLACE_TRIES=k additionally times a whole iteration with k fresh blocks for q and r (measured not to pay:
+    // medians 244 / 247 / 241 it/s over three series against 240-244 without, for 0.4-1.5 s).
     template <class O = OperatorType, class V = VectorType>
-    typename std::enable_if<_fusable<O, V, ValueType>::value, void>::type doPlaceByTrial(VectorType* x, bool precond)
+    typename std::enable_if<_fusable<O, V, ValueType>::value, bool>::type doPlaceByTrial(VectorType* x, bool precond)
     {
         if(!this->m_op->is_accel_() || !x->is_accel_())
-            return;
+            return false;
         const OperatorType& A = *this->m_op;
         VectorType *kr = this->W(0), *kp = this->W(1), *kq = this->W(2), *kz = precond ? this->W(3) : kr;
         typedef Jacobi<OperatorType, VectorType, ValueType> JacobiType;
@@ -1898,30 +1898,48 @@ private:
         if(jac != NULL && jac->GetInverseDiagonal().GetSize() == kr->GetSize())
             dinv = _fh(jac->GetInverseDiagonal());
         if(precond && dinv == NULL)
-            return; // (a general preconditioner sits between the kernels: its own vectors decide)
-        static const int tries = getenv("RAMD_PLACE_TRIES") ? atoi(getenv("RAMD_PLACE_TRIES")) : 0; // (0: off)
-        if(tries <= 0)
-            return;
+            return false; // (a general preconditioner sits between the kernels: the pair probes)
         VectorType keep;
         keep.CloneBackend(*x);
         keep.Allocate("iterate", x->GetSize());
         keep.CopyFrom(*x);
         VectorType* zdir = precond ? kz : kr;
-        auto iteration   = [&]() {
-            RAMD_CHECK(ramd_fused_cg_update(_fh(*kr), _fh(*kq), dinv, dinv ? _fh(*kz) : NULL, 1, 0, 2, 3));
-            RAMD_CHECK(ramd_fused_cg_direction(_fh(*x), _fh(*kp), _fh(*zdir), 1, 0, 3));
-            _f_apply_dot(A, *kp, kq, 0);
-        };
+        auto update    = [&]() { RAMD_CHECK(ramd_fused_cg_update(_fh(*kr), _fh(*kq), dinv, dinv ? _fh(*kz) : NULL, 1, 0, 2, 3)); };
+        auto direction = [&]() { RAMD_CHECK(ramd_fused_cg_direction(_fh(*x), _fh(*kp), _fh(*zdir), 1, 0, 3)); };
         if(precond)
-            kz->PlaceByTrial(iteration, tries);
-        kp->PlaceByTrial(iteration, tries);
-        kq->PlaceByTrial(iteration, tries);
-        kr->PlaceByTrial(iteration, tries);
+            kz->PlaceByTrial(update, 8, 0.94, kr);
+        kp->PlaceByTrial(direction, 8, 0.94, x);
+        // (RAMD_PLACE_Q=k: q, the output of the product, by timing the product with k fresh blocks -- measured without
+        //  gain for the product, 2.27-2.28 ms either way, and q is read by the residual update, which then lost its fast
+        //  placement in half the runs: gpurun_out/r03av, third series.  A Global product exchanges halos, so every rank
+        //  runs the same fixed number of trials there.)
+        static const int qtries = getenv("RAMD_PLACE_Q") ? atoi(getenv("RAMD_PLACE_Q")) : 0; // (0: off)
+        if(qtries > 0)
+        {
+            auto product = [&]() { _f_apply_dot(A, *kp, kq, 0); };
+            if(_one_block<OperatorType, VectorType, ValueType>::value)
+                kq->PlaceByTrial(product, qtries, 0.975);
+            else
+                kq->PlaceByTrial(product, qtries < 3 ? qtries : 3);
+        }
+        static const int tries = getenv("RAMD_PLACE_TRIES") ? atoi(getenv("RAMD_PLACE_TRIES")) : 0; // (0: off)
+        if(tries > 0)
+        {
+            auto iteration = [&]() {
+                update();
+                direction();
+                _f_apply_dot(A, *kp, kq, 0);
+            };
+            kq->PlaceByTrial(iteration, tries);
+            kr->PlaceByTrial(iteration, tries);
+        }
         x->CopyFrom(keep);
+        return true;
     }
     template <class O = OperatorType, class V = VectorType>
-    typename std::enable_if<!_fusable<O, V, ValueType>::value, void>::type doPlaceByTrial(VectorType*, bool)
+    typename std::enable_if<!_fusable<O, V, ValueType>::value, bool>::type doPlaceByTrial(VectorType*, bool)
     {
+        return false;
     }
 };
 

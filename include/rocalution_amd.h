@@ -98,16 +98,18 @@ int ramd_vec_allocate_apart(ramd_vec_t v, int64_t n, ramd_vec_t other);
  * blocks if one is clearly faster; *moved tells.  Same sizes and types only, blocks from 64 MiB on; otherwise a no-op. */
 int ramd_vec_place_apart(ramd_vec_t v, ramd_vec_t other, int* moved);
 /* ... and by trial: `run(ctx)` launches the kernels that use the vector on the current stream (return RAMD_OK); it is timed
- * with the vector in its own block and in `tries` fresh ones -- always that many, `run` may talk to other ranks -- and the
- * vector moves to the fastest (contents kept; what `run` does to other vectors is the caller's business).  No-op below
- * 64 MiB.  Which pairs and triples of big blocks stream well together is decided by their physical placement and is only
+ * with the vector in its own block and in up to `tries` fresh ones, and the vector moves to the fastest (contents kept; what
+ * `run` does to other vectors is the caller's business).  stop_ratio = 0: always `tries` trials (`run` may talk to other
+ * ranks); stop_ratio in (0, 1): stop once the best time is below stop_ratio x the worst one seen.  apart_from != NULL: the
+ * first candidates are drawn from the placement class that vector is not in.  No-op below 64 MiB.  Which pairs and triples of big blocks stream well together is decided by their physical placement and is only
  * partly predicted by the placement class.  The fused CG loop can place its work vectors this way at its first Solve
  * (opt-in, RAMD_PLACE_TRIES=k: measured not to pay by default, see solvers.hpp). */
 /* wall time this process has spent measuring placements so far (ramd_vec_place_apart, ramd_vec_place_by_trial); reset != 0
  * sets it back to zero */
 int ramd_placement_seconds(double* seconds, int reset);
 typedef int (*ramd_trial_cb)(void* ctx);
-int ramd_vec_place_by_trial(ramd_vec_t v, ramd_trial_cb run, void* ctx, int tries, int* moved);
+int ramd_vec_place_by_trial(ramd_vec_t v, ramd_trial_cb run, void* ctx, int tries, double stop_ratio, ramd_vec_t apart_from,
+                            int* moved);
 /* 0 / 1: the placement class of the vector's block, -1: not classified (small, host, empty) */
 int ramd_vec_placement_class(ramd_vec_t v, int* cls);
 int ramd_vec_zeros(ramd_vec_t v); /* :73 */

@@ -53,7 +53,7 @@ SIGNATURES = {
     "ramd_vec_allocate_apart": (i32, [vec_t, i64, vec_t]),
     "ramd_vec_placement_class": (i32, [vec_t, pi32]),
     "ramd_vec_place_apart": (i32, [vec_t, vec_t, pi32]),
-    "ramd_vec_place_by_trial": (i32, [vec_t, C.c_void_p, C.c_void_p, i32, pi32]),
+    "ramd_vec_place_by_trial": (i32, [vec_t, C.c_void_p, C.c_void_p, i32, C.c_double, vec_t, pi32]),
     "ramd_placement_seconds": (i32, [C.POINTER(C.c_double), i32]),
     "ramd_vec_clear": (i32, [vec_t]),
     "ramd_vec_size": (i32, [vec_t, pi64]),

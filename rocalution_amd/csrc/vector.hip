@@ -586,9 +586,12 @@ int ramd_vec_place_apart(ramd_vec_t v, ramd_vec_t other, int* moved)
 }
 
 // Placement by trial: `run` launches the kernels that use the vector (on the current stream, any number of them); it is
-// timed with the vector in its own block and in `tries` fresh ones, and the vector moves to the fastest (contents kept).
-// Always the same number of trials -- `run` may contain exchanges with other ranks, which then run it equally often.
-int ramd_vec_place_by_trial(ramd_vec_t v, ramd_trial_cb run, void* ctx, int tries, int* moved)
+// timed with the vector in its own block and in up to `tries` fresh ones, and the vector moves to the fastest (contents
+// kept).  stop_ratio = 0: always `tries` trials -- `run` may contain exchanges with other ranks, which then run it equally
+// often.  stop_ratio in (0, 1), for a `run` without such exchanges: the kernels run at one of a few discrete speeds, and
+// the search ends as soon as the best time is below stop_ratio x the worst one seen (a fresh GiB costs up to 100 ms).
+int ramd_vec_place_by_trial(ramd_vec_t v, ramd_trial_cb run, void* ctx, int tries, double stop_ratio, ramd_vec_t apart_from,
+                            int* moved)
 {
     CHECK_VEC(v);
     PlacementClock clock;
@@ -635,14 +638,21 @@ int ramd_vec_place_by_trial(ramd_vec_t v, ramd_trial_cb run, void* ctx, int trie
     };
     float best_ms = 0.f;
     time_with(own, &best_ms);
-    void*              best = own;
+    float              worst_ms = best_ms;
+    void*              best     = own;
     std::vector<void*> losers;
     if(verbose)
         fprintf(stderr, "place by trial: own block %.4f ms", best_ms);
     for(int k = 0; k < tries && rc == RAMD_OK; ++k)
     {
+        if(stop_ratio > 0.0 && best_ms < (float)stop_ratio * worst_ms)
+            break;
         void* c = nullptr;
-        if(cached_malloc_bytes(&c, bytes + kPad) != hipSuccess)
+        // (apart_from: the first candidates come from the placement class that vector's block is NOT in -- fresh blocks of
+        //  one process tend to share a class, and for two vectors a kernel writes the other class is the likely fast one)
+        const hipError_t ea = (apart_from && apart_from->d && k < 3) ? cached_malloc_apart(&c, bytes + kPad, apart_from->d)
+                                                                     : cached_malloc_bytes(&c, bytes + kPad);
+        if(ea != hipSuccess)
         {
             (void)hipGetLastError();
             c = nullptr;
@@ -658,6 +668,8 @@ int ramd_vec_place_by_trial(ramd_vec_t v, ramd_trial_cb run, void* ctx, int trie
             time_with(own, &ms); // (keeps the number of runs the same on every rank)
         if(verbose)
             fprintf(stderr, ", candidate %.4f", ms);
+        if(ms < 1e29f && ms > worst_ms)
+            worst_ms = ms;
         if(c && rc == RAMD_OK && ms < 0.995f * best_ms)
         {
             if(best != own)
