@@ -1239,3 +1239,53 @@ def test_single_launch_reductions_under_load(ra):
         capi.check(lib.ramd_fused_multi_dot(hs, 2, y._h, 40))
         capi.check(lib.ramd_scalars_fetch(out, 40, 2))
         assert (out[0], out[1]) == (exact_dot, float(np.dot(hy, hy))), rep
+
+
+def test_placement_entry_points_keep_contents_and_count_trials(ra):
+    """ramd_vec_allocate_apart / ramd_vec_place_apart / ramd_vec_place_by_trial / ramd_vec_placement_class move a vector
+    between device blocks and never change what it holds; the trial callback runs 3 x (1 + tries) times when no stop ratio
+    is given (a warm run and two timed ones per placement -- ranks that exchange halos inside it rely on the count), fewer
+    with one; vectors below 64 MiB are left alone; ramd_placement_seconds accounts for the time."""
+    import ctypes as C
+    from rocalution_amd import capi
+    lib = capi.load()
+    n = (96 << 20) // 8  # 96 MiB of fp64: above the 64-MiB threshold
+    rng = np.random.default_rng(11)
+    a = rng.uniform(-1, 1, n)
+    b = rng.uniform(-1, 1, n)
+    va = ra.LocalVector(data=a)
+    vz = ra.LocalVector()
+    capi.check(lib.ramd_vec_allocate_apart(vz._h, n, va._h))
+    assert vz.GetSize() == n and not vz.numpy().any()  # (zero-filled like Allocate)
+    vb = ra.LocalVector(data=b)
+    cls = C.c_int(-7)
+    capi.check(lib.ramd_vec_placement_class(va._h, C.byref(cls)))
+    assert cls.value in (0, 1)
+    capi.check(lib.ramd_placement_seconds(None, 1))
+    moved = C.c_int(0)
+    capi.check(lib.ramd_vec_place_apart(vb._h, va._h, C.byref(moved)))
+    assert np.array_equal(va.numpy(), a) and np.array_equal(vb.numpy(), b)
+    calls = []
+    CB = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+    def run(_ctx):
+        calls.append(1)
+        vb.Scale(1.0)  # some kernel that touches the vector
+        return 0
+    cb_keep = CB(run)
+    cb = C.cast(cb_keep, C.c_void_p)
+    capi.check(lib.ramd_vec_place_by_trial(vb._h, cb, None, 2, 0.0, None, C.byref(moved)))
+    assert len(calls) == 3 * (1 + 2)
+    assert np.array_equal(vb.numpy(), b)
+    del calls[:]
+    capi.check(lib.ramd_vec_place_by_trial(vb._h, cb, None, 6, 0.5, va._h, C.byref(moved)))  # (no block is twice as fast)
+    assert len(calls) == 3 * (1 + 6) and np.array_equal(vb.numpy(), b)
+    secs = C.c_double(0.0)
+    capi.check(lib.ramd_placement_seconds(C.byref(secs), 0))
+    assert secs.value > 0.0
+    small = ra.LocalVector(data=np.arange(1000.0))
+    del calls[:]
+    capi.check(lib.ramd_vec_place_by_trial(small._h, cb, None, 3, 0.0, None, C.byref(moved)))
+    assert len(calls) == 0 and moved.value == 0 and np.array_equal(small.numpy(), np.arange(1000.0))
+    capi.check(lib.ramd_vec_placement_class(small._h, C.byref(cls)))
+    assert cls.value == -1
