@@ -207,6 +207,7 @@ struct ramd_mat_s
     int            pat_n = 0, pat_w = 0; // dictionary entries, padded row length
     unsigned char* pat_id   = nullptr; // [nrow]
     int*           pat_dict = nullptr; // [pat_n * pat_w] column offsets in storage order
+    int*           blk_rp   = nullptr; // [ceil(nrow / 256) + 1] row offsets of the 256-row blocks (k_csr_pat2: a compact, cache-resident copy)
     double* dot_part1 = nullptr; // [dot_nblk] per-workgroup partials
     int     dot_nblk  = 0;
 };

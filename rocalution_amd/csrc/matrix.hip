@@ -60,6 +60,7 @@ void mat_free_analysis(ramd_mat_s* m)
     m->band_dist = -1;
     dev_free(&m->pat_id);
     dev_free(&m->pat_dict);
+    dev_free(&m->blk_rp);
     dev_free(&m->xl_dict);
     m->xl_state = 0;
     dev_free(&m->grp_lead);

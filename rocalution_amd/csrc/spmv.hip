@@ -258,18 +258,31 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PAT ? RA
     }
 }
 
-// Row-pattern product, TWO row blocks per workgroup (k_csr_tr<PAT> with its memory phases overlapped).  k_csr_tr<PAT> at
-// 512^3 moves 10.3 GB in 2.2-2.3 ms = 4.6 TB/s where two plain read streams reach 7.1 TB/s (profiles/r02_membench.txt): a
-// workgroup there is one chain -- value packets from HBM (~2.5 us), LDS, barrier, two rounds of x gathers through the L2
-// (~1.2 us), store -- and with six workgroups of 14 KB per CU only ~84 KB are in flight per CU and chain: Little's law, not
-// HBM, is the bound.  Here the value packets of BOTH row blocks are requested first; block 0 is staged and walked while block
-// 1's packets are still on their way, then block 1: twice the bytes in flight per wave for 16 more registers.  Same
-// products in the same order per row, the same per-wave partials of the fused dot in the same places: results identical to
-// k_csr_tr<PAT> bit for bit.  Needs every row block's entries to fit one LDS pass (256 x width + 3 <= kCsrChunk).
-// MEASURED (gpurun_out/r03aq) and therefore opt-in (RAMD_CSR_PAT2=1): the plain product 2.27 ms against 2.11 ms of
-// k_csr_tr<PAT> at 512^3 (500^3: 2.06 vs 1.97; 256^3: 0.242 vs 0.252), the product + dot 2.31 vs 2.30 ms, CG 242-244 vs
-// 239-249 it/s -- the bytes in flight were not the bound after all; the reasoning above is kept because it is the
-// obvious one and it is wrong.
+// Row-pattern product, TWO row blocks per workgroup and a shorter dependency chain (k_csr_tr<PAT> reworked).  PMC passes on
+// k_csr_tr<PAT> at 512^3 (tools/pmc_spmv.sh, gpurun_out/r03bc): 82 % of the wave cycles are SQ_WAIT_ANY (parked at a
+// waitcnt or the barrier), 13 % issue; a wave lives 7.2 us -- the product is bound by the latency chain of a workgroup
+// times the waves a CU holds, not by HBM (10.3 GB in 2.2-2.3 ms = 4.6 TB/s where two read streams reach 7.1 TB/s).  The
+// chain was: dictionary fetched and staged (an L2 round trip before anything else) -> rp[r0] (a MISS of a 0.5-GB stream:
+// the addresses of the value packets hang on it) -> value packets (HBM) -> LDS, barrier -> two rounds of x gathers -> store.
+// Here: the value packets of BOTH row blocks are requested at once, their addresses come from a compact copy of the block
+// offsets (blk_rp: 2 MB at 512^3, cache-resident), the dictionary is requested first but staged last, and block 0 is walked
+// while block 1's packets are still on their way.  Same products in the same order per row, the same per-wave partials
+// of the fused dot in the same places: results identical to k_csr_tr<PAT> bit for bit.  Needs every row block's entries to
+// fit one LDS pass (256 x longest pattern + 3 <= kCsrChunk).  Measured, alternating with k_csr_tr<PAT> on one box
+// (gpurun_out/r03bd, r03be): plain product 2.19-2.27 -> 1.95-1.98 ms, product + dot 2.23-2.33 -> 1.93-2.08 ms (0.84-0.90 of
+// 8 TB/s on algorithmic CSR bytes), inside the CG loop 2.36 -> 1.93-2.15 ms.  (A first measurement of this kernel reported
+// "slower": its switch tested the dictionary stride instead of the longest pattern and the kernel never ran -- the
+// difference it showed was box-to-box noise, which says how large that is.)  RAMD_CSR_PAT2=0: the old kernel.
+__global__ __launch_bounds__(kBlock) void k_blk_rp(int nrow, int nblk, const int* __restrict__ rp, int* __restrict__ blk_rp)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b <= nblk; b += gsz)
+    {
+        const int64_t r = b * kCsrRows;
+        blk_rp[b]       = rp[r < nrow ? r : nrow];
+    }
+}
+
 __device__ __forceinline__ int xcd_block_at(int i, int nblk, int per_xcd, BandMap bm)
 {
     int l = i;
@@ -288,15 +301,23 @@ __device__ __forceinline__ int xcd_block_at(int i, int nblk, int per_xcd, BandMa
 template <typename T, int MODE, bool DOT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RAMD_CSR_PAT_WAVES, 8))) void k_csr_pat2(
     int nrow, int nblk, int per_xcd, const int* __restrict__ rp, const T* __restrict__ val, const T* __restrict__ x,
-    T* __restrict__ y, T scalar, CsrDotWs ws, int slot, BandMap bm, CsrPattern pat)
+    T* __restrict__ y, T scalar, CsrDotWs ws, int slot, BandMap bm, CsrPattern pat, const int* __restrict__ blk_rp)
 {
     using VP           = typename ValPk<T>::type;
     constexpr int VN   = ValPk<T>::N;
     constexpr int NPKT = kCsrChunk / (VN * kBlock);
+    constexpr int NDW  = kPatMax * kPatMaxW / kBlock; // dictionary words per thread
     __shared__ T   sval[kCsrChunk];
     __shared__ int sdict[kPatMax * kPatMaxW];
-    for(int i = threadIdx.x; i < pat.n * pat.w; i += kBlock)
-        sdict[i] = pat.dict[i];
+    // the dictionary is requested first and staged LAST, after the value packets are on their way: its round trip (an L2
+    // hit) overlaps theirs instead of preceding them
+    int dreg[NDW];
+#pragma unroll
+    for(int q = 0; q < NDW; ++q)
+    {
+        const int i = q * kBlock + threadIdx.x;
+        dreg[q]     = i < pat.n * pat.w ? pat.dict[i] : 0;
+    }
     int blk[2], rs[2], re[2], dbase[2], cb[2], end[2];
     VP  a[2][NPKT];
     T   sum[2];
@@ -319,8 +340,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RAMD_CSR
                 if(MODE == 1)
                     sum[h] = y[row];
             }
-            cb[h]  = rp[r0] & ~3;
-            end[h] = rp[rend];
+            // (block offsets from the compact copy: 2 MB at 512^3, cache-resident, where rp[r0] is a miss of a 0.5-GB
+            //  stream -- the value packets' addresses hang on it)
+            (void)rend;
+            cb[h]  = blk_rp[blk[h]] & ~3;
+            end[h] = blk_rp[blk[h] + 1];
 #pragma unroll
             for(int k = 0; k < NPKT; ++k)
             {
@@ -329,6 +353,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RAMD_CSR
                     a[h][k] = nt_load(reinterpret_cast<const VP*>(val + j));
             }
         }
+    }
+#pragma unroll
+    for(int q = 0; q < NDW; ++q)
+    {
+        const int i = q * kBlock + threadIdx.x;
+        if(i < pat.n * pat.w)
+            sdict[i] = dreg[q];
     }
     double dacc[2] = {0.0, 0.0};
 #pragma unroll
@@ -1421,8 +1452,18 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
     const bool      use_grp = !use_pat && grp_env != 0 && m->grp_state == 1 && !m->pat_off;
     const CsrGroups cgr     = {use_grp ? m->grp_lead : nullptr, use_grp ? m->grp_need : nullptr};
     // two row blocks per workgroup with their memory phases overlapped (k_csr_pat2), where a row block fits one LDS pass
-    static const int pat2_env = getenv("RAMD_CSR_PAT2") ? atoi(getenv("RAMD_CSR_PAT2")) : 0; // (opt-in experiment, see k_csr_pat2)
-    const bool       use_pat2 = use_pat && !use_xl && pat2_env != 0 && kCsrRows * m->pat_w + 3 <= kCsrChunk;
+    static const int pat2_env = getenv("RAMD_CSR_PAT2") ? atoi(getenv("RAMD_CSR_PAT2")) : 1; // (0: k_csr_tr<PAT>; A/B experiments)
+    int              pat_maxlen = 0;
+    for(int p2 = 0; p2 < m->pat_n && p2 < 64; ++p2)
+        pat_maxlen = m->pat_len[p2] > pat_maxlen ? m->pat_len[p2] : pat_maxlen;
+    const bool use_pat2 = use_pat && !use_xl && pat2_env != 0 && pat_maxlen > 0 && kCsrRows * pat_maxlen + 3 <= kCsrChunk;
+    if(use_pat2 && !m->blk_rp)
+    {
+        ramd_mat_s* mm  = const_cast<ramd_mat_s*>(m);
+        const int   nb2 = (m->nrow + kCsrRows - 1) / kCsrRows;
+        RAMD_TRY(dev_alloc(&mm->blk_rp, (int64_t)nb2 + 1));
+        hipLaunchKernelGGL(k_blk_rp, dim3(ew_grid((int64_t)nb2 + 1)), dim3(kBlock), 0, b.cur, m->nrow, nb2, m->rp, mm->blk_rp);
+    }
     const bool q4      = !use_pat && q4_env > 0; // measured EQUAL to k_csr_tr on the shell surrogate (0.162 vs 0.160 ms): opt-in
     const int  nblk    = (m->nrow + rows_per_wg - 1) / rows_per_wg;
     const int  per_xcd = (nblk + 7) / 8;
@@ -1458,7 +1499,7 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
                                m->rp, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, xsg);             \
         else if(use_pat2)                                                                                  \
             hipLaunchKernelGGL((k_csr_pat2<T, MODE, DOT>), dim3(((per_xcd + 1) / 2) * 8), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
-                               per_xcd, m->rp, (const T*)m->val, x, y, scalar, ws, slot, bm, pat);         \
+                               per_xcd, m->rp, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, m->blk_rp); \
         else if(use_pat)                                                                                   \
             hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT, true>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
                                per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat);  \
