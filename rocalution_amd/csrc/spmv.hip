@@ -113,7 +113,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PAT ? RA
                                                    const int* __restrict__ ci,
                                                    const T* __restrict__ val,
                                                    const T* __restrict__ x, T* __restrict__ y, T scalar,
-                                                   CsrDotWs ws, int slot, BandMap bm, CsrPattern pat, CsrGroups grp = {})
+                                                   CsrDotWs ws, int slot, BandMap bm, CsrPattern pat, CsrGroups grp = {},
+                                                   const int* __restrict__ blk_rp = nullptr)
 {
     using VP          = typename ValPk<T>::type;
     constexpr int VN  = ValPk<T>::N;
@@ -141,8 +142,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PAT ? RA
             if(GRP)
                 lead = grp.lead[row];
         }
-        const int start = rp[r0];
-        const int end   = rp[rend];
+        // (blk_rp: a compact, cache-resident copy of the block offsets -- the addresses of the first packets hang on them,
+        //  and rp[r0] itself is a miss of a stream as long as the row count; see k_csr_pat2)
+        const int start = blk_rp ? blk_rp[blk] : rp[r0];
+        const int end   = blk_rp ? blk_rp[blk + 1] : rp[rend];
         T         sum   = (T)0;
         // x[row] for the epilogues (fused dot against x, Jacobi sweep): the row's own diagonal entry gathers it anyway, so
         // the row-pattern product takes it from there (one gather per row less).  What the fused dot costs on top of the
@@ -1457,7 +1460,11 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
     for(int p2 = 0; p2 < m->pat_n && p2 < 64; ++p2)
         pat_maxlen = m->pat_len[p2] > pat_maxlen ? m->pat_len[p2] : pat_maxlen;
     const bool use_pat2 = use_pat && !use_xl && pat2_env != 0 && pat_maxlen > 0 && kCsrRows * pat_maxlen + 3 <= kCsrChunk;
-    if(use_pat2 && !m->blk_rp)
+    // (RAMD_CSR_BLKRP=1: the compact block offsets for the general kernel too -- measured without effect there, 2.36-2.52 vs
+    //  2.45-2.52 ms with the columns read at 512^3 and 0.157 vs 0.157 ms on the shell surrogate, gpurun_out/r03bg: that kernel
+    //  runs at the stream rate of its bytes already)
+    static const int blkrp_env = getenv("RAMD_CSR_BLKRP") ? atoi(getenv("RAMD_CSR_BLKRP")) : 0;
+    if((use_pat2 || (blkrp_env != 0 && !(!use_pat && q4_env > 0) && m->nrow >= (1 << 16))) && !m->blk_rp)
     {
         ramd_mat_s* mm  = const_cast<ramd_mat_s*>(m);
         const int   nb2 = (m->nrow + kCsrRows - 1) / kCsrRows;
@@ -1502,13 +1509,13 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
                                per_xcd, m->rp, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, m->blk_rp); \
         else if(use_pat)                                                                                   \
             hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT, true>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
-                               per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat);  \
+                               per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, CsrGroups{}, m->blk_rp);  \
         else if(use_grp)                                                                                   \
             hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT, false, true>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
-                               per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, cgr); \
+                               per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, cgr, m->blk_rp); \
         else                                                                                               \
             hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT, false>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
-                               per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat);  \
+                               per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, CsrGroups{}, m->blk_rp);  \
     } while(0)
     ws.jdinv = jdinv;
     ws.jrhs  = jrhs;
