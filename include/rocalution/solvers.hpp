@@ -1908,6 +1908,9 @@ private:
         auto direction = [&]() { RAMD_CHECK(ramd_fused_cg_direction(_fh(*x), _fh(*kp), _fh(*zdir), 1, 0, 3)); };
         if(precond)
             kz->PlaceByTrial(update, 8, 0.94, kr);
+        // (r is the other vector the residual update writes: where no block for z made it fast -- all ten runs of one series,
+        //  gpurun_out/r03bi -- another block for r may; where it is fast already this costs one candidate)
+        kr->PlaceByTrial(update, 6, 0.94, precond ? kz : kq);
         kp->PlaceByTrial(direction, 8, 0.94, x);
         // (RAMD_PLACE_Q=k: q, the output of the product, by timing the product with k fresh blocks -- measured without
         //  gain for the product, 2.27-2.28 ms either way, and q is read by the residual update, which then lost its fast

@@ -275,7 +275,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PAT ? RA
 // (gpurun_out/r03bd, r03be): plain product 2.19-2.27 -> 1.95-1.98 ms, product + dot 2.23-2.33 -> 1.93-2.08 ms (0.84-0.90 of
 // 8 TB/s on algorithmic CSR bytes), inside the CG loop 2.36 -> 1.93-2.15 ms.  (A first measurement of this kernel reported
 // "slower": its switch tested the dictionary stride instead of the longest pattern and the kernel never ran -- the
-// difference it showed was box-to-box noise, which says how large that is.)  RAMD_CSR_PAT2=0: the old kernel.
+// difference it showed was box-to-box noise, which says how large that is.)  Three and four row blocks per workgroup:
+// plain product equal (1.94-2.15 ms), product + dot clearly slower (2.26-2.41 vs 2.05 ms; gpurun_out/r03bh).
+// RAMD_CSR_PAT2=0: the old kernel.
 __global__ __launch_bounds__(kBlock) void k_blk_rp(int nrow, int nblk, const int* __restrict__ rp, int* __restrict__ blk_rp)
 {
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
@@ -301,8 +303,8 @@ __device__ __forceinline__ int xcd_block_at(int i, int nblk, int per_xcd, BandMa
     return (i < per_xcd && b < nblk) ? b : -1;
 }
 
-template <typename T, int MODE, bool DOT>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RAMD_CSR_PAT_WAVES, 8))) void k_csr_pat2(
+template <typename T, int MODE, bool DOT, int NB>
+__global__ __launch_bounds__(kBlock) void k_csr_pat2(
     int nrow, int nblk, int per_xcd, const int* __restrict__ rp, const T* __restrict__ val, const T* __restrict__ x,
     T* __restrict__ y, T scalar, CsrDotWs ws, int slot, BandMap bm, CsrPattern pat, const int* __restrict__ blk_rp)
 {
@@ -321,13 +323,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RAMD_CSR
         const int i = q * kBlock + threadIdx.x;
         dreg[q]     = i < pat.n * pat.w ? pat.dict[i] : 0;
     }
-    int blk[2], rs[2], re[2], dbase[2], cb[2], end[2];
-    VP  a[2][NPKT];
-    T   sum[2];
+    int blk[NB], rs[NB], re[NB], dbase[NB], cb[NB], end[NB];
+    VP  a[NB][NPKT];
+    T   sum[NB];
 #pragma unroll
-    for(int h = 0; h < 2; ++h)
+    for(int h = 0; h < NB; ++h)
     {
-        blk[h]        = xcd_block_at(2 * (int)(blockIdx.x >> 3) + h, nblk, per_xcd, bm);
+        blk[h]        = xcd_block_at(NB * (int)(blockIdx.x >> 3) + h, nblk, per_xcd, bm);
         rs[h] = re[h] = dbase[h] = cb[h] = end[h] = 0;
         sum[h]                                    = (T)0;
         if(blk[h] >= 0)
@@ -364,12 +366,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RAMD_CSR
         if(i < pat.n * pat.w)
             sdict[i] = dreg[q];
     }
-    double dacc[2] = {0.0, 0.0};
+    double dacc[NB];
 #pragma unroll
-    for(int h = 0; h < 2; ++h)
+    for(int h = 0; h < NB; ++h)
+        dacc[h] = 0.0;
+#pragma unroll
+    for(int h = 0; h < NB; ++h)
     {
-        if(h == 1)
-            __syncthreads(); // (block 0's values have been read by everybody)
+        if(h > 0)
+            __syncthreads(); // (the previous block's values have been read by everybody)
         if(blk[h] >= 0)
         {
 #pragma unroll
@@ -437,7 +442,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RAMD_CSR
     if(DOT)
     {
 #pragma unroll
-        for(int h = 0; h < 2; ++h)
+        for(int h = 0; h < NB; ++h)
         {
             const double wsum = wave_reduce_sum(dacc[h]);
             if((threadIdx.x & 63) == 0 && blk[h] >= 0)
@@ -1505,7 +1510,7 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
                                m->nrow, nblk, per_xcd, \
                                m->rp, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, xsg);             \
         else if(use_pat2)                                                                                  \
-            hipLaunchKernelGGL((k_csr_pat2<T, MODE, DOT>), dim3(((per_xcd + 1) / 2) * 8), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
+            hipLaunchKernelGGL((k_csr_pat2<T, MODE, DOT, 2>), dim3(((per_xcd + 1) / 2) * 8), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
                                per_xcd, m->rp, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, m->blk_rp); \
         else if(use_pat)                                                                                   \
             hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT, true>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
