@@ -321,7 +321,7 @@ struct MgsBlockArgs
     const T* vp[kMgsBlock]; // previous block: applied
     const T* vc[kMgsBlock]; // current block: projected on
 };
-template <typename T, int NPV, int NC, bool NTW>
+template <typename T, int NPV, int NC, bool NTW, int UO = 0>
 __global__ __launch_bounds__(kBlock) void k_mgs_block(int64_t n, T* __restrict__ w, MgsBlockArgs<T> a, ReduceCtx ctx,
                                                       int slot_h, int slot_eprev, int slot_e)
 {
@@ -330,9 +330,9 @@ __global__ __launch_bounds__(kBlock) void k_mgs_block(int64_t n, T* __restrict__
     constexpr int NG  = NC * (NC - 1) / 2;
     constexpr int NS  = NC == 0 ? 1 : NC + NG;
 #ifndef RAMD_MGS_U
-#define RAMD_MGS_U 2
+#define RAMD_MGS_U 4 // (packets per thread and pass; full block at 512^3: 1.71 / 1.53 / 1.53 / 1.49 ms with 1 / 2 / 3 / 4, gpurun_out/r03bk)
 #endif
-    constexpr int U   = (NPV + NC > 9) ? 1 : (NPV + NC > 5) ? RAMD_MGS_U : 4;
+    constexpr int U   = UO > 0 ? UO : ((NPV + NC > 9) ? 1 : (NPV + NC > 5) ? RAMD_MGS_U : 4); // (UO: tools/ experiments)
     __shared__ double lds[4 * NS + 4];
     T mh[NPV > 0 ? NPV : 1];
     if constexpr(NPV > 0)
@@ -957,6 +957,24 @@ static int mgs_block_t(ramd_vec_t w, const ramd_vec_t* vprev, int nprev, int slo
         constexpr int NPV = decltype(npv)::value, NC = decltype(nc)::value;
         if constexpr(NPV <= kMgsBlock && NC <= kMgsBlock)
         {
+            static const int uo = getenv("RAMD_MGS_UO") ? atoi(getenv("RAMD_MGS_UO")) : 0; // (packets per thread and pass of the full block, experiments)
+            if constexpr(NPV == 4 && NC == 4)
+            {
+                if(uo == 1 || uo == 3 || uo == 4)
+                {
+                    if(uo == 1)
+                        hipLaunchKernelGGL((k_mgs_block<T, NPV, NC, true, 1>), dim3(grid), dim3(kBlock), 0, b.cur, w->n, (T*)w->d, a, ctx,
+                                           slot_h, slot_eprev, slot_e);
+                    else if(uo == 3)
+                        hipLaunchKernelGGL((k_mgs_block<T, NPV, NC, true, 3>), dim3(grid), dim3(kBlock), 0, b.cur, w->n, (T*)w->d, a, ctx,
+                                           slot_h, slot_eprev, slot_e);
+                    else
+                        hipLaunchKernelGGL((k_mgs_block<T, NPV, NC, true, 4>), dim3(grid), dim3(kBlock), 0, b.cur, w->n, (T*)w->d, a, ctx,
+                                           slot_h, slot_eprev, slot_e);
+                    launched = true;
+                    return;
+                }
+            }
             if(ntw)
                 hipLaunchKernelGGL((k_mgs_block<T, NPV, NC, true>), dim3(grid), dim3(kBlock), 0, b.cur, w->n, (T*)w->d, a, ctx,
                                    slot_h, slot_eprev, slot_e);
