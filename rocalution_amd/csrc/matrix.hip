@@ -61,6 +61,7 @@ void mat_free_analysis(ramd_mat_s* m)
     dev_free(&m->pat_id);
     dev_free(&m->pat_dict);
     dev_free(&m->blk_rp);
+    m->blk_span = 0;
     dev_free(&m->xl_dict);
     m->xl_state = 0;
     dev_free(&m->grp_lead);

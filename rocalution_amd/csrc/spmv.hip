@@ -303,29 +303,34 @@ __device__ __forceinline__ int xcd_block_at(int i, int nblk, int per_xcd, BandMa
     return (i < per_xcd && b < nblk) ? b : -1;
 }
 
-template <typename T, int MODE, bool DOT, int NB>
+// PAT = false: the same two-block structure with the stored columns read (their packets travel with the value packets):
+// matrices whose 256-row blocks all fit one LDS pass (short rows: 5- / 7-point operators, unstructured graphs of low degree).
+template <typename T, int MODE, bool DOT, int NB, bool PAT = true>
 __global__ __launch_bounds__(kBlock) void k_csr_pat2(
-    int nrow, int nblk, int per_xcd, const int* __restrict__ rp, const T* __restrict__ val, const T* __restrict__ x,
-    T* __restrict__ y, T scalar, CsrDotWs ws, int slot, BandMap bm, CsrPattern pat, const int* __restrict__ blk_rp)
+    int nrow, int nblk, int per_xcd, const int* __restrict__ rp, const int* __restrict__ ci, const T* __restrict__ val,
+    const T* __restrict__ x, T* __restrict__ y, T scalar, CsrDotWs ws, int slot, BandMap bm, CsrPattern pat,
+    const int* __restrict__ blk_rp)
 {
     using VP           = typename ValPk<T>::type;
     constexpr int VN   = ValPk<T>::N;
     constexpr int NPKT = kCsrChunk / (VN * kBlock);
-    constexpr int NDW  = kPatMax * kPatMaxW / kBlock; // dictionary words per thread
+    constexpr int NCPK = PAT ? 0 : kCsrChunk / (4 * kBlock); // column packets per thread and block
+    constexpr int NDW  = PAT ? kPatMax * kPatMaxW / kBlock : 0; // dictionary words per thread
     __shared__ T   sval[kCsrChunk];
-    __shared__ int sdict[kPatMax * kPatMaxW];
+    __shared__ int scol[PAT ? kPatMax * kPatMaxW : kCsrChunk]; // PAT: the dictionary of column offsets
     // the dictionary is requested first and staged LAST, after the value packets are on their way: its round trip (an L2
     // hit) overlaps theirs instead of preceding them
-    int dreg[NDW];
+    int dreg[NDW > 0 ? NDW : 1];
 #pragma unroll
     for(int q = 0; q < NDW; ++q)
     {
         const int i = q * kBlock + threadIdx.x;
         dreg[q]     = i < pat.n * pat.w ? pat.dict[i] : 0;
     }
-    int blk[NB], rs[NB], re[NB], dbase[NB], cb[NB], end[NB];
-    VP  a[NB][NPKT];
-    T   sum[NB];
+    int   blk[NB], rs[NB], re[NB], dbase[NB], cb[NB], end[NB];
+    VP    a[NB][NPKT];
+    v4i32 c[NB][NCPK > 0 ? NCPK : 1];
+    T     sum[NB];
 #pragma unroll
     for(int h = 0; h < NB; ++h)
     {
@@ -334,22 +339,28 @@ __global__ __launch_bounds__(kBlock) void k_csr_pat2(
         sum[h]                                    = (T)0;
         if(blk[h] >= 0)
         {
-            const int r0   = blk[h] * kCsrRows;
-            const int rend = min(r0 + kCsrRows, nrow);
-            const int row  = r0 + threadIdx.x;
+            const int r0  = blk[h] * kCsrRows;
+            const int row = r0 + threadIdx.x;
             if(row < nrow)
             {
-                rs[h]    = rp[row];
-                re[h]    = rp[row + 1];
-                dbase[h] = (int)pat.id[row] * pat.w - rs[h];
+                rs[h] = rp[row];
+                re[h] = rp[row + 1];
+                if(PAT)
+                    dbase[h] = (int)pat.id[row] * pat.w - rs[h];
                 if(MODE == 1)
                     sum[h] = y[row];
             }
             // (block offsets from the compact copy: 2 MB at 512^3, cache-resident, where rp[r0] is a miss of a 0.5-GB
             //  stream -- the value packets' addresses hang on it)
-            (void)rend;
             cb[h]  = blk_rp[blk[h]] & ~3;
             end[h] = blk_rp[blk[h] + 1];
+#pragma unroll
+            for(int k = 0; k < NCPK; ++k)
+            {
+                const int j = cb[h] + (k * kBlock + threadIdx.x) * 4;
+                if(j < end[h])
+                    c[h][k] = nt_load(reinterpret_cast<const v4i32*>(ci + j));
+            }
 #pragma unroll
             for(int k = 0; k < NPKT; ++k)
             {
@@ -364,7 +375,7 @@ __global__ __launch_bounds__(kBlock) void k_csr_pat2(
     {
         const int i = q * kBlock + threadIdx.x;
         if(i < pat.n * pat.w)
-            sdict[i] = dreg[q];
+            scol[i] = dreg[q];
     }
     double dacc[NB];
 #pragma unroll
@@ -377,6 +388,13 @@ __global__ __launch_bounds__(kBlock) void k_csr_pat2(
             __syncthreads(); // (the previous block's values have been read by everybody)
         if(blk[h] >= 0)
         {
+#pragma unroll
+            for(int k = 0; k < NCPK; ++k)
+            {
+                const int g = (k * kBlock + threadIdx.x) * 4;
+                if(cb[h] + g < end[h])
+                    *reinterpret_cast<v4i32*>(scol + g) = c[h][k];
+            }
 #pragma unroll
             for(int k = 0; k < NPKT; ++k)
             {
@@ -400,7 +418,7 @@ __global__ __launch_bounds__(kBlock) void k_csr_pat2(
                 for(int e = 0; e < kGatherW; ++e)
                     if(j + e < re[h])
                     {
-                        cc[e] = row + sdict[dbase[h] + j + e];
+                        cc[e] = PAT ? row + scol[dbase[h] + j + e] : scol[j - cb[h] + e];
                         v[e]  = sval[j - cb[h] + e];
                     }
 #pragma unroll
@@ -415,7 +433,7 @@ __global__ __launch_bounds__(kBlock) void k_csr_pat2(
                             sm += v[e] * xv[e];
                         else
                             sm += scalar * v[e] * xv[e];
-                        if((DOT || MODE == 2) && cc[e] == row)
+                        if(PAT && (DOT || MODE == 2) && cc[e] == row)
                         {
                             xrow      = xv[e];
                             have_xrow = true;
@@ -449,6 +467,20 @@ __global__ __launch_bounds__(kBlock) void k_csr_pat2(
                 ws.part1[blk[h] * (kBlock / 64) + (threadIdx.x >> 6)] = wsum;
         }
     }
+}
+
+// largest number of entries (from the 4-aligned start) a 256-row block stages: decides whether a matrix takes k_csr_pat2
+__global__ __launch_bounds__(kBlock) void k_blk_span_max(int nblk, const int* __restrict__ blk_rp, int* __restrict__ out)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    int           mx  = 0;
+    for(int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += gsz)
+        mx = max(mx, blk_rp[b + 1] - (blk_rp[b] & ~3));
+#pragma unroll
+    for(int o = 32; o > 0; o >>= 1)
+        mx = max(mx, __shfl_xor(mx, o, 64));
+    if((threadIdx.x & 63) == 0 && mx > 0)
+        atomicMax(out, mx);
 }
 
 // CSR SpMV of a STRUCTURED matrix with x tiles in LDS (row patterns, csr_analyse_xl).  k_csr_tr<PAT> no longer reads the
@@ -1469,13 +1501,38 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
     //  2.45-2.52 ms with the columns read at 512^3 and 0.157 vs 0.157 ms on the shell surrogate, gpurun_out/r03bg: that kernel
     //  runs at the stream rate of its bytes already)
     static const int blkrp_env = getenv("RAMD_CSR_BLKRP") ? atoi(getenv("RAMD_CSR_BLKRP")) : 0;
-    if((use_pat2 || (blkrp_env != 0 && !(!use_pat && q4_env > 0) && m->nrow >= (1 << 16))) && !m->blk_rp)
+    // ... and the same structure with the columns read, for matrices of short rows (every row block fits one LDS pass)
+    // (measured SLOWER than k_csr_tr, 2.52-2.55 vs 2.38-2.40 ms at 512^3 in alternating runs, gpurun_out/r03bm: with the columns
+    //  read the product runs at the stream rate of its 14.2 GB and the extra registers only cost occupancy -- opt-in:
+    //  RAMD_CSR_COL2=1; 2: also small matrices, for the tests)
+    static const int col2_env = getenv("RAMD_CSR_COL2") ? atoi(getenv("RAMD_CSR_COL2")) : 0;
+    const bool col2_candidate = !use_pat && !use_grp && !(q4_env > 0) && col2_env != 0 && (m->nrow >= (1 << 16) || col2_env == 2)
+                                && m->nnz <= (int64_t)8 * m->nrow && m->blk_span >= 0;
+    if((use_pat2 || col2_candidate || (blkrp_env != 0 && !(!use_pat && q4_env > 0) && m->nrow >= (1 << 16))) && !m->blk_rp)
     {
         ramd_mat_s* mm  = const_cast<ramd_mat_s*>(m);
         const int   nb2 = (m->nrow + kCsrRows - 1) / kCsrRows;
         RAMD_TRY(dev_alloc(&mm->blk_rp, (int64_t)nb2 + 1));
         hipLaunchKernelGGL(k_blk_rp, dim3(ew_grid((int64_t)nb2 + 1)), dim3(kBlock), 0, b.cur, m->nrow, nb2, m->rp, mm->blk_rp);
     }
+    if(col2_candidate && m->blk_span == 0) // measured once per matrix
+    {
+        ramd_mat_s* mm  = const_cast<ramd_mat_s*>(m);
+        const int   nb2 = (m->nrow + kCsrRows - 1) / kCsrRows;
+        int*        d   = nullptr;
+        RAMD_TRY(dev_alloc(&d, 1));
+        hipError_t e = hipMemsetAsync(d, 0, sizeof(int), b.cur);
+        hipLaunchKernelGGL(k_blk_span_max, dim3(ew_grid(nb2)), dim3(kBlock), 0, b.cur, nb2, m->blk_rp, d);
+        int span = 0;
+        if(e == hipSuccess)
+            e = hipMemcpyAsync(&span, d, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+        if(e == hipSuccess)
+            e = hipStreamSynchronize(b.cur);
+        dev_free(&d);
+        RAMD_HIP(e);
+        mm->blk_span = span > 0 ? span : -1;
+    }
+    const bool use_col2 = col2_candidate && m->blk_span > 0 && m->blk_span <= kCsrChunk;
     const bool q4      = !use_pat && q4_env > 0; // measured EQUAL to k_csr_tr on the shell surrogate (0.162 vs 0.160 ms): opt-in
     const int  nblk    = (m->nrow + rows_per_wg - 1) / rows_per_wg;
     const int  per_xcd = (nblk + 7) / 8;
@@ -1510,8 +1567,11 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
                                m->nrow, nblk, per_xcd, \
                                m->rp, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, xsg);             \
         else if(use_pat2)                                                                                  \
-            hipLaunchKernelGGL((k_csr_pat2<T, MODE, DOT, 2>), dim3(((per_xcd + 1) / 2) * 8), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
-                               per_xcd, m->rp, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, m->blk_rp); \
+            hipLaunchKernelGGL((k_csr_pat2<T, MODE, DOT, 2, true>), dim3(((per_xcd + 1) / 2) * 8), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
+                               per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, m->blk_rp); \
+        else if(use_col2)                                                                                  \
+            hipLaunchKernelGGL((k_csr_pat2<T, MODE, DOT, 2, false>), dim3(((per_xcd + 1) / 2) * 8), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
+                               per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, m->blk_rp); \
         else if(use_pat)                                                                                   \
             hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT, true>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
                                per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, CsrGroups{}, m->blk_rp);  \
