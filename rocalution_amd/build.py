@@ -13,8 +13,14 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(CSRC, "_obj")
-LIB = os.path.join(HERE, "librocalution_amd.so")
+# RAMD_BUILD_FLAVOUR=asan: a second, separate library (librocalution_amd_asan.so, objects under csrc/_obj_asan) whose HOST code
+# -- the ABI layer and the C++ API layer of include/rocalution behind it -- is instrumented by AddressSanitizer; device code is
+# left alone (-fno-gpu-sanitize).  The counterpart of the reference's BUILD_ADDRESS_SANITIZER option (CMakeLists.txt:83-90).
+# Use:  RAMD_BUILD_FLAVOUR=asan python -m rocalution_amd.build ;  RAMD_LIB=.../librocalution_amd_asan.so
+#       LD_PRELOAD=$(hipcc --print-file-name=libclang_rt.asan-x86_64.so) ASAN_OPTIONS=detect_leaks=0 python -m pytest tests -m gpu
+FLAVOUR = os.environ.get("RAMD_BUILD_FLAVOUR", "")
+OBJ = os.path.join(CSRC, "_obj" + ("_" + FLAVOUR if FLAVOUR else ""))
+LIB = os.path.join(HERE, "librocalution_amd" + ("_" + FLAVOUR if FLAVOUR else "") + ".so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 
@@ -26,6 +32,12 @@ CXXFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contrac
             "-I" + os.path.join(os.path.dirname(HERE), "include")] + os.environ.get("RAMD_EXTRA_CXXFLAGS", "").split()
 LDFLAGS = ["-shared", "-fPIC", "--offload-arch=gfx950", "-L" + os.path.join(ROCM, "lib"), "-lrccl",
            "-Wl,-rpath," + os.path.join(ROCM, "lib")]
+if FLAVOUR == "asan":
+    _SAN = ["-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan", "-g", "-fno-omit-frame-pointer"]
+    CXXFLAGS = [f for f in CXXFLAGS if f != "-O3"] + ["-O1"] + _SAN
+    LDFLAGS = LDFLAGS + _SAN
+elif FLAVOUR:
+    raise SystemExit("RAMD_BUILD_FLAVOUR: only 'asan' is known")
 
 
 def _sources():

@@ -9,6 +9,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librocalution_amd.so")
+# RAMD_LIB: another build of the same library (the ASAN flavour of rocalution_amd/build.py)
+LIB_PATH = os.environ.get("RAMD_LIB", LIB_PATH)
 if os.environ.get("RAMD_LIB"):  # A/B runs of differently built libraries (tools/)
     LIB_PATH = os.environ["RAMD_LIB"]
 
