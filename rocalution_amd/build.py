@@ -18,6 +18,9 @@ CSRC = os.path.join(HERE, "csrc")
 # left alone (-fno-gpu-sanitize).  The counterpart of the reference's BUILD_ADDRESS_SANITIZER option (CMakeLists.txt:83-90).
 # Use:  RAMD_BUILD_FLAVOUR=asan python -m rocalution_amd.build ;  RAMD_LIB=.../librocalution_amd_asan.so
 #       LD_PRELOAD=$(hipcc --print-file-name=libclang_rt.asan-x86_64.so) ASAN_OPTIONS=detect_leaks=0 python -m pytest tests -m gpu
+# State: builds and loads (python under the preloaded runtime imports it); on this image the first device allocation then
+# fails inside the sanitizer's hsa_amd_memory_pool_allocate interceptor ("out of memory", gpurun_out/r03bn) -- the ROCm
+# installation here has no ASAN-instrumented runtime libraries (no /opt/rocm/lib/asan), which that interceptor expects.
 FLAVOUR = os.environ.get("RAMD_BUILD_FLAVOUR", "")
 OBJ = os.path.join(CSRC, "_obj" + ("_" + FLAVOUR if FLAVOUR else ""))
 LIB = os.path.join(HERE, "librocalution_amd" + ("_" + FLAVOUR if FLAVOUR else "") + ".so")
