@@ -502,7 +502,7 @@ def main():
         if args.format == "csr":
             b_spmv = spmv_bytes(n, nnz, vb)
             k_spmv = ("k_csr_tr<float> (fp32 inner CSR SpMV + fused <p,q>; the few fp64 outer residual SpMVs are in the average)"
-                      if mixed else "CSR SpMV (k_csr_tr, with the fused dot where the solver uses it; a structured matrix's columns come from its row-pattern dictionary: traffic below the algorithmic CSR bytes)")
+                      if mixed else "CSR SpMV (k_csr_pat2 for structured matrices -- columns from the row-pattern dictionary, two row blocks per workgroup: traffic below the algorithmic CSR bytes -- else k_csr_tr; with the fused dot where the solver uses it)")
         else:
             nnz_fmt = 7 * n if args.matrix == "poisson" else nnz
             b_spmv = vb * (2 * n + nnz_fmt) if args.format == "dia" else 4 * nnz_fmt + vb * (2 * n + nnz_fmt)
@@ -570,7 +570,7 @@ def main():
                     if name == "bicgstab_mcsgs" and pe[PROF_PRECOND]["launches"] > 0:
                         extras[name]["roofline"] = roof("multi-coloured SGS apply (k_mc_sweep: all colour sweeps of one apply)",
                                                         mcsgs_bytes(n, nnz, 8), pe[PROF_PRECOND], traffic_for("mcsgs_512") if big else None)
-                    extras[name]["kernels"] = {"spmv": roof("CSR SpMV (k_csr_tr)", spmv_bytes(n, nnz, 8), pe[PROF_SPMV])}
+                    extras[name]["kernels"] = {"spmv": roof("CSR SpMV (k_csr_pat2 / k_csr_tr)", spmv_bytes(n, nnz, 8), pe[PROF_SPMV])}
                 except Exception as e:
                     extras[name] = dict(error=repr(e))
     else:
