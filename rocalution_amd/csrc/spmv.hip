@@ -305,12 +305,20 @@ __device__ __forceinline__ int xcd_block_at(int i, int nblk, int per_xcd, BandMa
 
 // PAT = false: the same two-block structure with the stored columns read (their packets travel with the value packets):
 // matrices whose 256-row blocks all fit one LDS pass (short rows: 5- / 7-point operators, unstructured graphs of low degree).
-template <typename T, int MODE, bool DOT, int NB, bool PAT = true>
+// NORP (row patterns only): the row offsets are not read either -- a row's length is its pattern's, its first entry the
+// block's offset plus the lengths of the rows before it in the block (a scan over 256 lengths through DPP and 4 LDS words,
+// done while the value packets are in flight): 4 bytes per row less, 0.54 of 10.6 GB at 512^3.
+struct PatLens
+{
+    unsigned char len[kPatMax];
+};
+template <typename T, int MODE, bool DOT, int NB, bool PAT = true, bool NORP = false>
 __global__ __launch_bounds__(kBlock) void k_csr_pat2(
     int nrow, int nblk, int per_xcd, const int* __restrict__ rp, const int* __restrict__ ci, const T* __restrict__ val,
     const T* __restrict__ x, T* __restrict__ y, T scalar, CsrDotWs ws, int slot, BandMap bm, CsrPattern pat,
-    const int* __restrict__ blk_rp)
+    const int* __restrict__ blk_rp, PatLens pl = {})
 {
+    static_assert(!NORP || PAT, "row offsets can only be rebuilt from row patterns");
     using VP           = typename ValPk<T>::type;
     constexpr int VN   = ValPk<T>::N;
     constexpr int NPKT = kCsrChunk / (VN * kBlock);
@@ -327,7 +335,9 @@ __global__ __launch_bounds__(kBlock) void k_csr_pat2(
         const int i = q * kBlock + threadIdx.x;
         dreg[q]     = i < pat.n * pat.w ? pat.dict[i] : 0;
     }
-    int   blk[NB], rs[NB], re[NB], dbase[NB], cb[NB], end[NB];
+    __shared__ int slen[NORP ? kPatMax : 1];
+    __shared__ int swsum[NORP ? NB * (kBlock / 64) : 1];
+    int   blk[NB], rs[NB], re[NB], dbase[NB], cb[NB], end[NB], pid[NB];
     VP    a[NB][NPKT];
     v4i32 c[NB][NCPK > 0 ? NCPK : 1];
     T     sum[NB];
@@ -336,6 +346,7 @@ __global__ __launch_bounds__(kBlock) void k_csr_pat2(
     {
         blk[h]        = xcd_block_at(NB * (int)(blockIdx.x >> 3) + h, nblk, per_xcd, bm);
         rs[h] = re[h] = dbase[h] = cb[h] = end[h] = 0;
+        pid[h]                                    = -1;
         sum[h]                                    = (T)0;
         if(blk[h] >= 0)
         {
@@ -343,10 +354,15 @@ __global__ __launch_bounds__(kBlock) void k_csr_pat2(
             const int row = r0 + threadIdx.x;
             if(row < nrow)
             {
-                rs[h] = rp[row];
-                re[h] = rp[row + 1];
-                if(PAT)
-                    dbase[h] = (int)pat.id[row] * pat.w - rs[h];
+                if(NORP)
+                    pid[h] = (int)pat.id[row];
+                else
+                {
+                    rs[h] = rp[row];
+                    re[h] = rp[row + 1];
+                    if(PAT)
+                        dbase[h] = (int)pat.id[row] * pat.w - rs[h];
+                }
                 if(MODE == 1)
                     sum[h] = y[row];
             }
@@ -376,6 +392,42 @@ __global__ __launch_bounds__(kBlock) void k_csr_pat2(
         const int i = q * kBlock + threadIdx.x;
         if(i < pat.n * pat.w)
             scol[i] = dreg[q];
+    }
+    if(NORP)
+    {
+        if(threadIdx.x < kPatMax)
+            slen[threadIdx.x] = (int)pl.len[threadIdx.x];
+        __syncthreads();
+        int len[NB], excl[NB];
+#pragma unroll
+        for(int h = 0; h < NB; ++h)
+        {
+            len[h] = pid[h] >= 0 ? slen[pid[h]] : 0;
+            int inc = len[h]; // inclusive scan over the wave
+#pragma unroll
+            for(int o = 1; o < 64; o <<= 1)
+            {
+                const int up = __shfl_up(inc, o, 64);
+                if((int)(threadIdx.x & 63) >= o)
+                    inc += up;
+            }
+            excl[h] = inc - len[h];
+            if((threadIdx.x & 63) == 63)
+                swsum[h * (kBlock / 64) + (threadIdx.x >> 6)] = inc;
+        }
+        __syncthreads();
+#pragma unroll
+        for(int h = 0; h < NB; ++h)
+        {
+            int before = 0;
+#pragma unroll
+            for(int w = 0; w < kBlock / 64; ++w)
+                before += (w < (int)(threadIdx.x >> 6)) ? swsum[h * (kBlock / 64) + w] : 0;
+            const int first = blk[h] >= 0 ? blk_rp[blk[h]] : 0; // (the block's true offset: cb is its 4-aligned floor)
+            rs[h]    = first + before + excl[h];
+            re[h]    = rs[h] + len[h];
+            dbase[h] = pid[h] >= 0 ? pid[h] * pat.w - rs[h] : 0;
+        }
     }
     double dacc[NB];
 #pragma unroll
@@ -1497,6 +1549,14 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
     for(int p2 = 0; p2 < m->pat_n && p2 < 64; ++p2)
         pat_maxlen = m->pat_len[p2] > pat_maxlen ? m->pat_len[p2] : pat_maxlen;
     const bool use_pat2 = use_pat && !use_xl && pat2_env != 0 && pat_maxlen > 0 && kCsrRows * pat_maxlen + 3 <= kCsrChunk;
+    // (measured without gain, 1.80-1.85 vs 1.73-1.92 ms plain and 2.03-2.10 vs 2.02-2.04 ms with the dot in alternating runs,
+    //  gpurun_out/r03bq: 5 % fewer bytes do nothing for a product bound by its latency chain, the scan adds two barriers --
+    //  opt-in: RAMD_CSR_NORP=1)
+    static const int norp_env = getenv("RAMD_CSR_NORP") ? atoi(getenv("RAMD_CSR_NORP")) : 0;
+    const bool       use_norp = use_pat2 && norp_env != 0;
+    PatLens          plens    = {};
+    for(int p2 = 0; p2 < m->pat_n && p2 < kPatMax; ++p2)
+        plens.len[p2] = (unsigned char)m->pat_len[p2];
     // (RAMD_CSR_BLKRP=1: the compact block offsets for the general kernel too -- measured without effect there, 2.36-2.52 vs
     //  2.45-2.52 ms with the columns read at 512^3 and 0.157 vs 0.157 ms on the shell surrogate, gpurun_out/r03bg: that kernel
     //  runs at the stream rate of its bytes already)
@@ -1566,6 +1626,9 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
                                sizeof(T) * (size_t)(kCsrChunk + xsg.total) + sizeof(int) * (size_t)(pat.n * pat.w), b.cur, \
                                m->nrow, nblk, per_xcd, \
                                m->rp, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, xsg);             \
+        else if(use_pat2 && use_norp)                                                                      \
+            hipLaunchKernelGGL((k_csr_pat2<T, MODE, DOT, 2, true, true>), dim3(((per_xcd + 1) / 2) * 8), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
+                               per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, m->blk_rp, plens); \
         else if(use_pat2)                                                                                  \
             hipLaunchKernelGGL((k_csr_pat2<T, MODE, DOT, 2, true>), dim3(((per_xcd + 1) / 2) * 8), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
                                per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, m->blk_rp); \
