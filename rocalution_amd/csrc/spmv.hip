@@ -551,7 +551,8 @@ __global__ __launch_bounds__(kBlock) void k_blk_span_max(int nblk, const int* __
 template <typename T, int MODE, bool DOT>
 __global__ __launch_bounds__(kBlock) void k_csr_xl(int nrow, int nblk, int per_xcd, const int* __restrict__ rp,
                                                    const T* __restrict__ val, const T* __restrict__ x, T* __restrict__ y,
-                                                   T scalar, CsrDotWs ws, int slot, BandMap bm, CsrPattern pat, XlSegs sg)
+                                                   T scalar, CsrDotWs ws, int slot, BandMap bm, CsrPattern pat, XlSegs sg,
+                                                   const int* __restrict__ blk_rp)
 {
     constexpr int VN = 16 / (int)sizeof(T);
     // LDS (dynamic: what this matrix needs decides how many workgroups a CU holds): values of a pass | x pieces | dictionary
@@ -584,6 +585,20 @@ __global__ __launch_bounds__(kBlock) void k_csr_xl(int nrow, int nblk, int per_x
                     __builtin_amdgcn_global_load_lds((GP)(x + g), (LP)(sx + sg.base[s] + (q0 + wtid) * VN), 16, 0, 0);
             }
         }
+        // (block offsets from the compact copy where there is one: the first pass's value packets then hang on nothing but
+        //  an L2 hit and leave together with the x pieces; dictionary and row offsets are requested after them -- k_csr_pat2)
+        const int start = blk_rp ? blk_rp[blk] : rp[r0];
+        const int end   = blk_rp ? blk_rp[blk + 1] : rp[rend];
+        {
+            const int cb0 = start & ~3;
+#pragma unroll
+            for(int k = 0; k < kCsrChunk / (VN * kBlock); ++k)
+            {
+                const int j = cb0 + (k * kBlock + tid) * VN;
+                if(j < end)
+                    __builtin_amdgcn_global_load_lds((GP)(val + j), (LP)(sval + (k * kBlock + wtid) * VN), 16, 0, 2);
+            }
+        }
         for(int i = tid; i < pat.n * pat.w; i += kBlock)
             sdict[i] = pat.dict[i];
         int rs = 0, re = 0, dbase = 0;
@@ -593,19 +608,20 @@ __global__ __launch_bounds__(kBlock) void k_csr_xl(int nrow, int nblk, int per_x
             re    = rp[row + 1];
             dbase = (int)pat.id[row] * pat.w - rs;
         }
-        const int start = rp[r0];
-        const int end   = rp[rend];
-        T         sum   = (T)0;
+        T sum = (T)0;
         if(MODE == 1 && row < nrow)
             sum = y[row];
         for(int cb = start & ~3; cb < end; cb += kCsrChunk)
         {
-#pragma unroll
-            for(int k = 0; k < kCsrChunk / (VN * kBlock); ++k)
+            if(cb != (start & ~3)) // (the first pass is on its way already)
             {
-                const int j = cb + (k * kBlock + tid) * VN;
-                if(j < end)
-                    __builtin_amdgcn_global_load_lds((GP)(val + j), (LP)(sval + (k * kBlock + wtid) * VN), 16, 0, 2);
+#pragma unroll
+                for(int k = 0; k < kCsrChunk / (VN * kBlock); ++k)
+                {
+                    const int j = cb + (k * kBlock + tid) * VN;
+                    if(j < end)
+                        __builtin_amdgcn_global_load_lds((GP)(val + j), (LP)(sval + (k * kBlock + wtid) * VN), 16, 0, 2);
+                }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -1568,7 +1584,7 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
     static const int col2_env = getenv("RAMD_CSR_COL2") ? atoi(getenv("RAMD_CSR_COL2")) : 0;
     const bool col2_candidate = !use_pat && !use_grp && !(q4_env > 0) && col2_env != 0 && (m->nrow >= (1 << 16) || col2_env == 2)
                                 && m->nnz <= (int64_t)8 * m->nrow && m->blk_span >= 0;
-    if((use_pat2 || col2_candidate || (blkrp_env != 0 && !(!use_pat && q4_env > 0) && m->nrow >= (1 << 16))) && !m->blk_rp)
+    if((use_pat2 || use_xl || col2_candidate || (blkrp_env != 0 && !(!use_pat && q4_env > 0) && m->nrow >= (1 << 16))) && !m->blk_rp)
     {
         ramd_mat_s* mm  = const_cast<ramd_mat_s*>(m);
         const int   nb2 = (m->nrow + kCsrRows - 1) / kCsrRows;
@@ -1625,7 +1641,7 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
             hipLaunchKernelGGL((k_csr_xl<T, MODE, DOT>), dim3(grid), dim3(kBlock),                         \
                                sizeof(T) * (size_t)(kCsrChunk + xsg.total) + sizeof(int) * (size_t)(pat.n * pat.w), b.cur, \
                                m->nrow, nblk, per_xcd, \
-                               m->rp, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, xsg);             \
+                               m->rp, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, xsg, m->blk_rp); \
         else if(use_pat2 && use_norp)                                                                      \
             hipLaunchKernelGGL((k_csr_pat2<T, MODE, DOT, 2, true, true>), dim3(((per_xcd + 1) / 2) * 8), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
                                per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, m->blk_rp, plens); \
