@@ -2310,8 +2310,9 @@ protected:
         enum { sRes, sRho, sRhoOld, sR0Q, sTR, sTT, sAlpha, sOmega, sBeta, sT, sU, sCount }; // (sRes, sRho: read together)
         VectorType *r = this->W(0), *shadow = this->W(1), *p = this->W(2), *q = this->W(3), *t = this->W(4);
         VectorType *v = precond ? this->W(5) : NULL, *z = precond ? this->W(6) : NULL;
-        if(this->doPlaceOnce())
-            r->PlaceApartFrom(*x); // (placement only: the fused update writes x and r in one pass)
+        // (placement only: the fused update writes x and r in one pass)
+        if(this->doPlaceOnce() && !(this->m_fused && this->m_res_norm_type == 2 && this->doPlaceByTrial(x, precond)))
+            r->PlaceApartFrom(*x);
         Engine K(*this->m_op, sCount);
         this->doDefect(rhs, *x, shadow);
         if(this->m_iter_ctrl.InitResidual(this->doResidual(K, sRes, *shadow)) == false)
@@ -2465,7 +2466,37 @@ private:
     {
         return false;
     }
-
+    // r placed with the fused x / r update itself as the probe (see CG::doPlaceByTrial): 8 streams, two of them written.
+    // The coefficients of the trial runs are set to one, so that the kernel takes its regular branch (omega finite).
+    template <class O = OperatorType, class V = VectorType>
+    typename std::enable_if<_fusable<O, V, ValueType>::value, bool>::type doPlaceByTrial(VectorType* x, bool precond)
+    {
+        if(!this->m_op->is_accel_() || !x->is_accel_() || (precond && this->m_precond->SolveUsesScalarRecord()))
+            return false;
+        VectorType *kr = this->W(0), *r0 = this->W(1), *kp = this->W(2), *kt = this->W(4);
+        VectorType *kv = precond ? this->W(5) : NULL, *kz = precond ? this->W(6) : NULL;
+        VectorType keep;
+        keep.CloneBackend(*x);
+        keep.Allocate("iterate", x->GetSize());
+        keep.CopyFrom(*x);
+        for(int sl = 0; sl < 6; ++sl)
+            RAMD_CHECK(ramd_scalars_set(sl, 1.0));
+        auto update = [&]() {
+            RAMD_CHECK(ramd_fused_bicg_xr_update(_fh(*x), precond ? _fh(*kz) : NULL, precond ? _fh(*kv) : NULL, _fh(*kr), _fh(*kt),
+                                                 _fh(*r0), _fh(*kp), 3, 2, 0, 4, 5, 6));
+            RAMD_CHECK(ramd_scalars_set(3, 1.0)); // (the kernel moves rho on: keep the coefficients finite)
+            RAMD_CHECK(ramd_scalars_set(5, 1.0));
+        };
+        kr->PlaceByTrial(update, 8, 0.94, x);
+        x->CopyFrom(keep);
+        RAMD_CHECK(ramd_scalars_set(6, 0.0));
+        return true;
+    }
+    template <class O = OperatorType, class V = VectorType>
+    typename std::enable_if<!_fusable<O, V, ValueType>::value, bool>::type doPlaceByTrial(VectorType*, bool)
+    {
+        return false;
+    }
 };
 
 // ============================================================================ FCG
