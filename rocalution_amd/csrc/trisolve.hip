@@ -702,6 +702,7 @@ struct TriPlan
     int*       ct_in_pairs  = nullptr; // [2 n] {source index, row number inside the tile}
     const int* ct_in_key    = nullptr;
     int*       ct_out_pairs = nullptr; // [2 n] the same for the natural-order output: {row of the matrix, row number inside the tile}
+    bool       ct_in_packed = false, ct_out_packed = false; // the lists in 4 bytes per row (see CtDims)
     void  release()
     {
         dev_free(&ct_tile_step);
@@ -714,7 +715,7 @@ struct TriPlan
         dev_free(&ct_in_pairs);
         dev_free(&ct_out_pairs);
         ct_in_key = nullptr;
-        ct = ct_rec = ct_grp = ct_infirst = false;
+        ct = ct_rec = ct_grp = ct_infirst = ct_in_packed = ct_out_packed = false;
         dev_free(&order);
         dev_free(&pos);
         dev_free(&slice_off);
@@ -1493,6 +1494,49 @@ __global__ __launch_bounds__(kBlock) void k_ct_keys(int n, const int* __restrict
     }
 }
 
+// Rows of one level of a tile may come in any order (they do not depend on each other): the rows another tile reads come
+// first, grouped by the direction in which that tile lies (the first box coordinate in which the two tiles differ), then
+// the rows nobody else reads.  The fetch waves read other tiles' values with agent-scope loads that pay whole 64-byte lines
+// per instruction; in plain sweep order a cube's face row sits alone in its line (one line per 8-byte value), this way the
+// face rows of a level are neighbours in w.  cls[t] in sweep space: 0..2 = direction, 3 = not read by another tile.
+template <bool LOWER>
+__global__ __launch_bounds__(kBlock) void k_ct_export_class(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                            const unsigned long long* __restrict__ word,
+                                                            const int* __restrict__ tkey, int b0, int b1, int b2,
+                                                            int* __restrict__ cls)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gsz)
+    {
+        const int i  = LOWER ? (int)t : (int)(n - 1 - t);
+        const int tk = tkey[t];
+        const unsigned long long w = word[t];
+        const int                a0 = ct_c0(w) / b0, a1 = ct_c1(w) / b1;
+        for(int j = rp[i]; j < rp[i + 1]; ++j)
+        {
+            const int c = ci[j];
+            if(LOWER ? (c < i) : (c > i))
+            {
+                const int tc = LOWER ? c : n - 1 - c;
+                if(tkey[tc] != tk)
+                {
+                    const unsigned long long wc = word[tc];
+                    const int d = (ct_c0(wc) / b0 != a0) ? 0 : ((ct_c1(wc) / b1 != a1) ? 1 : 2);
+                    if(cls[tc] > d)
+                        atomicMin(cls + tc, d);
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_ct_class_key(int n, const int* __restrict__ lev_t, int* __restrict__ cls)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gsz)
+        cls[t] = lev_t[t] * 4 + cls[t];
+}
+
 __global__ __launch_bounds__(kBlock) void k_ct_gather_int(int64_t n, const int* __restrict__ src, const int* __restrict__ idx,
                                                           int* __restrict__ dst)
 {
@@ -1593,6 +1637,60 @@ __global__ __launch_bounds__(kBlock) void k_ct_count_ext(int n, const int* __res
         }
         cnt[p] = c;
     }
+}
+
+// ---- where a tile's values sit in w (rows of <= 3 entries, one lane per row).  The fetch waves read other tiles' values with
+// agent-scope loads -- nothing of them is kept in a cache, every load instruction pays whole 64-byte lines -- and in
+// position (= level) order the rows another tile needs are spread over the producer's whole piece of w: one line per
+// 8-byte value (profiles/r02_traffic.json: 19-25 bytes per row at 512^3).  So the rows of a tile take their places in w in
+// the order {rows some other tile reads, by the smallest such tile; rows nobody else reads}, position order inside each
+// class: what one consumer fetches from one producer is a contiguous piece (the face of an 8 x 8 x 8 cube: 8 lines instead
+// of ~50), and a step still stores one short run per class.  The place travels in the record's spare 16-bit code.
+template <bool LOWER>
+__global__ __launch_bounds__(kBlock) void k_ct_min_consumer(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                            const int* __restrict__ order, const int* __restrict__ pos,
+                                                            const int* __restrict__ tile_of, int* __restrict__ cons)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gsz)
+    {
+        const int i  = order[p];
+        const int tl = tile_of[p];
+        for(int j = rp[i]; j < rp[i + 1]; ++j)
+        {
+            const int col = ci[j];
+            if(LOWER ? (col < i) : (col > i))
+            {
+                const int pc = pos[col];
+                if(tile_of[pc] != tl && cons[pc] > tl) // (plain read first: most references find the minimum already there)
+                    atomicMin(cons + pc, tl);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_fill_int(int64_t n, int v, int* __restrict__ out)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gsz)
+        out[t] = v;
+}
+
+// wmap[o1[o2[k]]] = k: the k-th place of w goes to the position that comes k-th in (tile, consumer class, position) order
+__global__ __launch_bounds__(kBlock) void k_ct_wmap(int n, const int* __restrict__ o1, const int* __restrict__ o2,
+                                                    int* __restrict__ wmap)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gsz)
+        wmap[o1[o2[k]]] = (int)k;
+}
+
+// idx[j] = map[idx[j]]
+__global__ __launch_bounds__(kBlock) void k_ct_map_idx(int64_t n, const int* __restrict__ map, int* __restrict__ idx)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gsz)
+        idx[t] = map[idx[t]];
 }
 
 // ---- external values of a tile, each ONCE.  Rows of FE matrices share their external columns (the 5 unknowns of a mesh
@@ -1866,6 +1964,8 @@ struct CtDims
 {
     int rows, steps, ents, exts;
     int infirst; // grouped form: the in-group entries of a row come FIRST in the order of the host loop (upper solve)
+    // sorted index lists in 4 bytes per row: (index - the tile's smallest index) << sbits | row number inside the tile
+    int in_packed, out_packed, sbits;
 };
 constexpr int kCtFetchDepth = 4; // batches of 64 external values the fetch wave keeps in flight
 
@@ -1921,6 +2021,10 @@ constexpr int kCtFetchDepth = 4; // batches of 64 external values the fetch wave
 #endif
 constexpr int kCtRing = RAMD_CT_RING; // tiles the ticket/fetch wave may be ahead of the compute wave (+1)
 
+// records with a spare 16-bit code carry the row's place in its tile's piece of w (see k_ct_min_consumer)
+template <int WL, int LPR>
+constexpr bool kCtWSlot = (WL == 3 && LPR == 1);
+
 template <typename T, int WL>
 struct CtRec
 {
@@ -1938,7 +2042,7 @@ struct CtRec
 template <typename T>
 static size_t ct_rec_lds_bytes(const CtDims& d)
 {
-    return (size_t)kCtRing * ((size_t)1 + d.rows + d.exts) * sizeof(T) + (size_t)(2 + 5 * kCtRing) * sizeof(int) + 64;
+    return (size_t)kCtRing * ((size_t)1 + d.rows + d.exts) * sizeof(T) + (size_t)(2 + 6 * kCtRing) * sizeof(int) + 64;
 }
 
 // per step: {first position, rows (| largest row group << 8), external values of the tile used up to and including this step,
@@ -1980,7 +2084,8 @@ __global__ __launch_bounds__(kBlock) void k_ct_fill_rec(int n, const int* __rest
                                                         int* __restrict__ ext_idx, char* __restrict__ erec,
                                                         int* __restrict__ nodiag, int reverse, int rows_max,
                                                         const int* __restrict__ ref_start,
-                                                        const int* __restrict__ slot_of_ref, T* __restrict__ diag_sep)
+                                                        const int* __restrict__ slot_of_ref, T* __restrict__ diag_sep,
+                                                        const int* __restrict__ wmap)
 {
     using L         = CtRec<T, WL>;
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2054,6 +2159,8 @@ __global__ __launch_bounds__(kBlock) void k_ct_fill_rec(int n, const int* __rest
         }
     }
     // (padding codes / values stay 0: the array is zeroed before the fill)
+    if(kCtWSlot<WL, LPR>) // the row's place in its tile's piece of w (k_ct_min_consumer), in the spare fourth code
+        *reinterpret_cast<unsigned short*>(field(0, 2 * WL)) = (unsigned short)((wmap ? wmap[p] : (int)p) - tpos);
     if(!have)
     {
         if(L::DSEP && LPR == 1)
@@ -2293,6 +2400,8 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
     int* tdone   = posted + 1; // tiles the compute wave has finished
     int* fetched = tdone + 1; // [R] external values parked so far
     int* tdesc   = fetched + R; // [R][4] {first step, steps, first position, rows}
+    int* obase   = tdesc + 4 * R; // [R] smallest destination index of the tile (packed output list)
+    const int smask = (1 << dims.sbits) - 1;
     const int tid = threadIdx.x;
     auto      uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
     if(tid == 0)
@@ -2329,9 +2438,22 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
             const int p0 = uni(tdesc[4 * sl + 2]), nr = uni(tdesc[4 * sl + 3]);
             const T*  xb = xs + sl * S + 1;
             const v2i32* pr = reinterpret_cast<const v2i32*>(out_pairs) + p0;
+            const int*   pk = out_pairs + p0;
+            const int    ob = uni(obase[sl]);
             for(int q0 = 0; q0 < nr; q0 += 4 * 64)
             {
                 v2i32 d[4];
+                if(dims.out_packed)
+                {
+#pragma unroll
+                    for(int u = 0; u < 4; ++u)
+                    {
+                        const int q = q0 + u * 64 + lane;
+                        const int x = (q < nr) ? nt_load(pk + q) : 0;
+                        d[u]        = (q < nr) ? v2i32{ob + (int)((unsigned)x >> dims.sbits), x & smask} : v2i32{-1, 0};
+                    }
+                }
+                else
 #pragma unroll
                 for(int u = 0; u < 4; ++u)
                 {
@@ -2344,21 +2466,40 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
                         out[d[u].x] = xb[d[u].y];
             }
         };
+        // Finished tiles are written back when this wave has nothing better to do -- while it waits for other tiles' values --
+        // and at the latest before their ring slot is reused: done at that point only, the write-back of tile n - R sat in
+        // front of the right-hand side and the external values of tile n, which the compute wave was about to wait for.
+        int  wb_next = 0; // tiles [0, wb_next) of this workgroup are written back
+        auto wait_done = [&](int want) {
+            int spins = 0;
+            while(uni(__hip_atomic_load(tdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < want)
+            {
+                spin_guard(spins);
+                __builtin_amdgcn_s_sleep(2);
+            }
+            asm volatile("" ::: "memory");
+        };
+        auto try_write_back = [&](int posted_tiles) -> bool { // one finished tile, if there is one
+            if(!HAS_OUT || wb_next >= posted_tiles
+               || uni(__hip_atomic_load(tdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) <= wb_next)
+                return false;
+            asm volatile("" ::: "memory");
+            write_back(wb_next % R);
+            wb_next = uni(wb_next + 1);
+            return true;
+        };
         for(int n = 0;; ++n)
         {
             const int slot = n % R;
             unsigned long long pf_a = prof ? __builtin_amdgcn_s_memtime() : 0;
             if(n >= R) // the slot was used by tile n - R
-            {
-                int spins = 0;
-                while(uni(__hip_atomic_load(tdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < n - R + 1)
+                wait_done(n - R + 1);
+            if(HAS_OUT)
+                while(wb_next <= n - R) // (finished: ring wait above) its values leave before the slot is reused
                 {
-                    spin_guard(spins);
-                    __builtin_amdgcn_s_sleep(2);
+                    write_back(wb_next % R);
+                    wb_next = uni(wb_next + 1);
                 }
-            }
-            if(HAS_OUT && n >= R)
-                write_back(slot); // tile n - R is finished (ring wait above): its values leave before the slot is reused
             unsigned long long pf_b = prof ? __builtin_amdgcn_s_memtime() : 0;
             pf_ring += pf_b - pf_a;
             unsigned tk = 0;
@@ -2381,6 +2522,7 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
                 {
                     tdesc[4 * slot + 2] = d0.z;
                     tdesc[4 * slot + 3] = d0.w;
+                    obase[slot]         = d1.y;
                 }
                 fetched[slot]       = -1; // (-1: the tile's right-hand side is not in LDS yet)
             }
@@ -2390,16 +2532,10 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
             if(end)
             {
                 if(HAS_OUT) // the last tiles of this workgroup (their slots were never reused)
-                    for(int m = max(0, n - R + 1); m < n; ++m)
+                    for(; wb_next < n; wb_next = uni(wb_next + 1))
                     {
-                        int spins = 0;
-                        while(uni(__hip_atomic_load(tdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < m + 1)
-                        {
-                            spin_guard(spins);
-                            __builtin_amdgcn_s_sleep(2);
-                        }
-                        asm volatile("" ::: "memory");
-                        write_back(m % R);
+                        wait_done(wb_next + 1);
+                        write_back(wb_next % R);
                     }
                 pf_flush();
                 return;
@@ -2414,10 +2550,23 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
                 const int p0 = uni(d0.z), nr = uni(d0.w);
                 T*        rbb = xs + slot * S + 1;
                 const v2i32* pr = reinterpret_cast<const v2i32*>(in_pairs) + p0;
+                const int*   pk = in_pairs + p0;
+                const int    ib = uni(d1.x);
                 for(int q0 = 0; q0 < nr; q0 += 4 * 64)
                 {
                     v2i32 d[4];
                     T     v[4];
+                    if(dims.in_packed)
+                    {
+#pragma unroll
+                        for(int u = 0; u < 4; ++u)
+                        {
+                            const int q = q0 + u * 64 + lane;
+                            const int x = (q < nr) ? nt_load(pk + q) : 0;
+                            d[u]        = (q < nr) ? v2i32{ib + (int)((unsigned)x >> dims.sbits), x & smask} : v2i32{-1, 0};
+                        }
+                    }
+                    else
 #pragma unroll
                     for(int u = 0; u < 4; ++u)
                     {
@@ -2460,12 +2609,23 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
                     pf_c = __builtin_amdgcn_s_memtime();
                 }
                 int done = 0; // values of batch `next` already handed over
+                // Every poll is a read from memory (agent scope: nothing of it stays in a cache), whole lines per load
+                // instruction: all batches are requested once, afterwards only the lanes of the batch being handed over whose
+                // value has not arrived ask again (re-reading everything on every round was 2/3 of the external traffic).
+#pragma unroll
+                for(int u = 0; u < kCtFetchDepth; ++u)
+                    bits[u] = (idx[u] >= 0) ? poll_load(w + idx[u]) : (B)0;
+                bool first_round = true;
                 while(next < nbatch)
                 {
+                    if(!first_round)
+                    {
 #pragma unroll
-                    for(int u = 0; u < kCtFetchDepth; ++u)
-                        if(u >= next && idx[u] >= 0)
-                            bits[u] = poll_load(w + idx[u]);
+                        for(int u = 0; u < kCtFetchDepth; ++u)
+                            if(u == next && idx[u] >= 0 && bits[u] == Sentinel<T>::value)
+                                bits[u] = poll_load(w + idx[u]);
+                    }
+                    first_round   = false;
                     bool advanced = false;
 #pragma unroll
                     for(int u = 0; u < kCtFetchDepth; ++u)
@@ -2497,6 +2657,8 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
                                 done = 0;
                             }
                         }
+                    if(!advanced && try_write_back(n)) // (tiles 0 .. n - 1 of this workgroup have their slots filled in)
+                        advanced = true;
                     if(!advanced)
                     {
                         spin_guard(spins);
@@ -2811,7 +2973,9 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
             xs[own] = sum;
         }
         // (LPR = 1: lanes beyond the step's rows repeat its last row; LPR > 1: only the last lane of a row holds it)
-        if(LPR == 1 || (sub == LPR - 1 && lane < nl))
+        if(kCtWSlot<WL, LPR>)
+            publish(w + (st.pos - st.lbase) + (int)((unsigned)stq.q[0][1] >> 16), sum);
+        else if(LPR == 1 || (sub == LPR - 1 && lane < nl))
             publish(w + st.pos + row, sum);
         }
         // this step's LDS traffic before the next step's: one wave, in-order LDS queue
@@ -2904,7 +3068,8 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     int *level = nullptr, *lorder = nullptr, *start = nullptr, *lev_t = nullptr, *tkey = nullptr, *o1 = nullptr,
         *k2 = nullptr, *o2 = nullptr, *tflag = nullptr, *sflag = nullptr, *tscan = nullptr, *sscan = nullptr,
         *tile_of = nullptr, *step_of = nullptr, *step_w = nullptr, *nodiag = nullptr, *cext = nullptr, *tsz = nullptr,
-        *ref_start = nullptr, *slot_of_ref = nullptr, *gf = nullptr, *gl = nullptr, *tposv = nullptr, *step_maxg = nullptr;
+        *ref_start = nullptr, *slot_of_ref = nullptr, *gf = nullptr, *gl = nullptr, *tposv = nullptr, *step_maxg = nullptr,
+        *wmap = nullptr;
     UnitPlan units;
     unsigned long long* word = nullptr;
     int  nlev = 0;
@@ -2935,6 +3100,7 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
         dev_free(&gl);
         dev_free(&tposv);
         dev_free(&step_maxg);
+        dev_free(&wmap);
         units.release();
     };
 #define CT_TRY(expr)     \
@@ -3123,7 +3289,7 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     const int wl  = grp ? kGrpWL : (lpr == 1 ? (wmax <= 3 ? 3 : (wmax <= 4 ? 4 : 8)) : 4);
     const int rpp = 64 / lpr;
     int       bs[3] = {1, 1, 1}, Ts[3] = {1, 1, 1};
-    int       ntiles = 0, nsteps = 0, total = 0;
+    int       ntiles = 0, nsteps = 0, total = 0, next = 0;
     int64_t keymax = 0;
     // levels (natural row index): once
     if(grp)
@@ -3165,6 +3331,13 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
         double bk = E[k] > 1 ? (double)E[k] * f : 1.0;
         bs[k]     = bk < 1.0 ? 1 : (int)(bk + 0.5);
     }
+    if(const char* e = getenv("RAMD_TRSV_CT_BOX")) // "b0,b1,b2": the box edges as given (tools/ experiments; first attempt only)
+    {
+        int v[3] = {0, 0, 0};
+        if(attempt == 0 && sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]) == 3 && v[0] > 0 && v[1] > 0 && v[2] > 0)
+            for(int k = 0; k < 3; ++k)
+                bs[k] = v[k];
+    }
     static const int grp_shape = getenv("RAMD_TRSV_CT_GSHAPE") ? atoi(getenv("RAMD_TRSV_CT_GSHAPE")) : 1; // (0: proportional boxes)
     if(grp && grp_shape != 0 && grp_count > 0)
     {
@@ -3199,7 +3372,25 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
         hipLaunchKernelGGL((k_ct_keys<false>), dim3(grid), dim3(kBlock), 0, b.cur, n, level, word, bs[0], bs[1], bs[2], Ts[0],
                            Ts[1], Ts[2], lev_t, tkey, gl);
     CT_TRY(dev_alloc(&o1, n));
-    CT_TRY(device_stable_sort_by_key(lev_t, n, nlev, o1));
+    static const int cls_env = getenv("RAMD_TRSV_CLASSES") ? atoi(getenv("RAMD_TRSV_CLASSES")) : 1; // (0: sweep order inside a level; A/B)
+    if(cls_env != 0 && !grp && (int64_t)nlev * 4 + 4 < (1ll << 31))
+    {
+        int* cls = nullptr;
+        CT_TRY(dev_alloc(&cls, n));
+        hipLaunchKernelGGL(k_fill_int, dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, (int64_t)n, 3, cls);
+        if(lower)
+            hipLaunchKernelGGL((k_ct_export_class<true>), dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, word, tkey, bs[0],
+                               bs[1], bs[2], cls);
+        else
+            hipLaunchKernelGGL((k_ct_export_class<false>), dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, word, tkey, bs[0],
+                               bs[1], bs[2], cls);
+        hipLaunchKernelGGL(k_ct_class_key, dim3(grid), dim3(kBlock), 0, b.cur, n, lev_t, cls);
+        s = device_stable_sort_by_key(cls, n, nlev * 4 + 4, o1);
+        dev_free(&cls);
+        CT_TRY(s);
+    }
+    else
+        CT_TRY(device_stable_sort_by_key(lev_t, n, nlev, o1));
     CT_TRY(dev_alloc(&k2, n));
     hipLaunchKernelGGL(k_ct_gather_int, dim3(grid), dim3(kBlock), 0, b.cur, (int64_t)n, tkey, o1, k2);
     dev_free(&tkey);
@@ -3311,7 +3502,7 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
         hipLaunchKernelGGL((k_ct_count_ext<false>), dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, P->order, P->pos,
                            tile_of, P->ct_ext_start);
     CT_TRY(device_exclusive_scan(P->ct_ext_start, P->ct_ext_start, (int64_t)n + 1));
-    int next = 0;
+    next = 0;
     CT_HIP(hipMemcpyAsync(&next, P->ct_ext_start + n, sizeof(int), hipMemcpyDeviceToHost, b.cur));
     CT_HIP(hipStreamSynchronize(b.cur));
     build_mark("plan: bounds, entry sizes, externals count");
@@ -3436,6 +3627,49 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     if(!fits)
         CT_GIVE_UP();
     CT_HIP(cached_malloc(&P->w, (size_t)n * sizeof(T) + kPad));
+    static const int wslot_env = getenv("RAMD_TRSV_WSLOT") ? atoi(getenv("RAMD_TRSV_WSLOT")) : 0; // (1: the places below; measured, see DESIGN)
+    if(wslot_env != 0 && !grp && lpr == 1 && wl == 3 && next > 0 && ntiles > 1)
+    {
+        // places in w: exported rows of a tile first, grouped by the tile that reads them (k_ct_min_consumer)
+        int *cons = nullptr, *w1 = nullptr, *w2 = nullptr, *wk = nullptr;
+        auto drop = [&]() {
+            dev_free(&cons);
+            dev_free(&w1);
+            dev_free(&w2);
+            dev_free(&wk);
+        };
+#define CT_TRYW(expr)    \
+    do                   \
+    {                    \
+        s = (expr);      \
+        if(s != RAMD_OK) \
+        {                \
+            drop();      \
+            CT_TRY(s);   \
+        }                \
+    } while(0)
+        CT_TRYW(dev_alloc(&cons, n));
+        hipLaunchKernelGGL(k_fill_int, dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, (int64_t)n, ntiles, cons);
+        if(lower)
+            hipLaunchKernelGGL((k_ct_min_consumer<true>), dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, P->order,
+                               P->pos, tile_of, cons);
+        else
+            hipLaunchKernelGGL((k_ct_min_consumer<false>), dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, P->order,
+                               P->pos, tile_of, cons);
+        CT_TRYW(dev_alloc(&w1, n));
+        CT_TRYW(device_stable_sort_by_key(cons, n, ntiles + 1, w1));
+        dev_free(&cons);
+        CT_TRYW(dev_alloc(&wk, n));
+        hipLaunchKernelGGL(k_ct_gather_int, dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, (int64_t)n, tile_of, w1, wk);
+        CT_TRYW(dev_alloc(&w2, n));
+        CT_TRYW(device_stable_sort_by_key(wk, n, ntiles, w2));
+        dev_free(&wk);
+        CT_TRYW(dev_alloc(&wmap, n));
+        hipLaunchKernelGGL(k_ct_wmap, dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, w1, w2, wmap);
+        drop();
+#undef CT_TRYW
+        build_mark("plan: places in w");
+    }
     CT_TRY(dev_alloc(&nodiag, 1));
     CT_HIP(hipMemsetAsync(nodiag, 0, sizeof(int), b.cur));
     CT_TRY(dev_alloc(&P->ct_tile_desc, (int64_t)8 * ntiles));
@@ -3471,7 +3705,7 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     hipLaunchKernelGGL((k_ct_fill_rec<T, LOW, WLL, LP>), dim3(nb), dim3(kBlock), 0, b.cur, n, m->rp, m->ci,                  \
                        (const T*)m->val, P->order, P->pos, tile_of, step_of, P->ct_tile_step, P->ct_step_pos,               \
                        P->ct_ext_start, P->ct_ext_idx, (char*)P->eval, nodiag, reverse ? 1 : 0, P->ct_dims[0], ref_start, \
-                       slot_of_ref, (T*)P->diag)
+                       slot_of_ref, (T*)P->diag, wmap)
 #define CT_FILL_REC_W(LOW)           \
     do                               \
     {                                \
@@ -3497,6 +3731,14 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
 #undef CT_FILL_GREC
         hipLaunchKernelGGL(k_ct_step_rec2, dim3(ew_grid(nsteps + 1)), dim3(kBlock), 0, b.cur, n, nsteps, P->ct_step_pos,
                            P->ct_ext_start, tile_of, P->ct_tile_step, P->ct_step_rec, step_maxg);
+        if(wmap)
+        {
+            // everything that names a value of w by its position now names its place: the external values of the tiles,
+            // and -- through P->pos, which the next stage's index list is composed with -- the rows themselves
+            if(next > 0)
+                hipLaunchKernelGGL(k_ct_map_idx, dim3(ew_grid(next)), dim3(kBlock), 0, b.cur, (int64_t)next, wmap, P->ct_ext_idx);
+            hipLaunchKernelGGL(k_ct_map_idx, dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, (int64_t)n, wmap, P->pos);
+        }
         P->ct_grp     = grp;
         P->ct_infirst = grp && (lower == reverse);
     }
@@ -3563,8 +3805,47 @@ __global__ __launch_bounds__(kBlock) void k_ct_pair_lists(int n, const int* __re
     }
 }
 
+// The lists in 4 bytes per row where the indices of every tile span little enough (rows of a box tile of a grid in natural
+// order: 7 planes; the rows of one tile of the stage before): range[t] = largest - smallest index of tile t, then
+// packed[q] = (index - smallest of the tile) << sbits | row number, the smallest index into the tile descriptor.
+__global__ __launch_bounds__(kBlock) void k_ct_pair_range(int ntiles, const int* __restrict__ tile_desc,
+                                                          const int* __restrict__ pairs, int* __restrict__ range)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < ntiles; t += gsz)
+    {
+        const int p0 = tile_desc[8 * t + 2], nr = tile_desc[8 * t + 3];
+        range[t]     = nr > 0 ? pairs[2 * (size_t)(p0 + nr - 1)] - pairs[2 * (size_t)p0] : 0;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_ct_pack_pairs(int n, int sbits, int which, const int* __restrict__ tile_of,
+                                                          int* __restrict__ tile_desc, const int* __restrict__ pairs,
+                                                          int* __restrict__ packed)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gsz)
+    {
+        const int t    = tile_of[q];
+        const int p0   = tile_desc[8 * (size_t)t + 2];
+        const int base = pairs[2 * (size_t)p0];
+        packed[q]      = (int)(((unsigned)(pairs[2 * q] - base) << sbits) | (unsigned)pairs[2 * q + 1]);
+        if(q == p0)
+            tile_desc[8 * (size_t)t + 4 + which] = base;
+    }
+}
+
+static int ct_sbits(int rows)
+{
+    int sb = 1;
+    while((1 << sb) < rows)
+        ++sb;
+    return sb;
+}
+
 // pairs[q] = {key[p], row number of p inside its tile}, the positions p of every tile sorted by key[p]
-static int ct_build_pair_lists(TriPlan* P, const int* key, int** pairs_out)
+// (which: 0 = the right-hand side list, 1 = the output list; *packed_out: the 4-byte form was possible)
+static int ct_build_pair_lists(TriPlan* P, const int* key, int** pairs_out, int which, bool* packed_out)
 {
     Backend&  b = backend();
     const int n = P->n;
@@ -3597,6 +3878,37 @@ static int ct_build_pair_lists(TriPlan* P, const int* key, int** pairs_out)
         return done(s);
     hipLaunchKernelGGL(k_ct_pair_lists, dim3(grid), dim3(kBlock), 0, b.cur, n, o1, o2, key, tile_of, P->ct_tile_desc,
                        *pairs_out);
+    *packed_out = false;
+    static const int pack_env = getenv("RAMD_TRSV_PACK") ? atoi(getenv("RAMD_TRSV_PACK")) : 1; // (0: 8-byte pairs; A/B)
+    const int sbits = ct_sbits(P->ct_dims[0]);
+    if(pack_env != 0 && sbits < 24)
+    {
+        int maxrange = 0;
+        dev_free(&k2);
+        if((s = dev_alloc(&k2, P->ct_ntiles)) != RAMD_OK)
+            return done(s);
+        hipLaunchKernelGGL(k_ct_pair_range, dim3(ew_grid(P->ct_ntiles)), dim3(kBlock), 0, b.cur, P->ct_ntiles, P->ct_tile_desc,
+                           *pairs_out, k2);
+        if((s = device_max_int(k2, P->ct_ntiles, &maxrange)) != RAMD_OK)
+            return done(s);
+        if(maxrange >= 0 && (int64_t)maxrange < (1ll << (32 - sbits)))
+        {
+            int* packed = nullptr;
+            if((s = dev_alloc(&packed, n)) != RAMD_OK)
+                return done(s);
+            hipLaunchKernelGGL(k_ct_pack_pairs, dim3(grid), dim3(kBlock), 0, b.cur, n, sbits, which, tile_of, P->ct_tile_desc,
+                               *pairs_out, packed);
+            if(hipStreamSynchronize(b.cur) != hipSuccess)
+            {
+                dev_free(&packed);
+                done(RAMD_OK);
+                RAMD_FAIL(RAMD_ERR_HIP, "packed index lists of the box-tile plan");
+            }
+            dev_free(pairs_out);
+            *pairs_out  = packed;
+            *packed_out = true;
+        }
+    }
     if(hipStreamSynchronize(b.cur) != hipSuccess || hipGetLastError() != hipSuccess)
     {
         done(RAMD_OK);
@@ -3623,17 +3935,19 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
         const int    dm    = mul_inv_diag ? 2 : (unit ? 0 : 1);
         const int    lpr   = P->ct_grp ? kGrpLPR : (P->ct_wmax > 8 ? 8 : 1);
         const int    wl    = P->ct_grp ? kGrpWL : (lpr == 1 ? (P->ct_wmax <= 3 ? 3 : (P->ct_wmax <= 4 ? 4 : 8)) : 4);
-        const CtDims dims  = {P->ct_dims[0], P->ct_dims[1], P->ct_dims[2], P->ct_dims[3], P->ct_infirst ? 1 : 0};
+        CtDims dims = {P->ct_dims[0], P->ct_dims[1], P->ct_dims[2], P->ct_dims[3], P->ct_infirst ? 1 : 0, 0, 0, ct_sbits(P->ct_dims[0])};
         if(P->ct_rec)
         {
             if(P->ct_in_key != rhs_idx)
             {
                 P->ct_in_key = nullptr;
-                RAMD_TRY(ct_build_pair_lists(P, rhs_idx, &P->ct_in_pairs));
+                RAMD_TRY(ct_build_pair_lists(P, rhs_idx, &P->ct_in_pairs, 0, &P->ct_in_packed));
                 P->ct_in_key = rhs_idx;
             }
             if(out && !P->ct_out_pairs)
-                RAMD_TRY(ct_build_pair_lists(P, P->order, &P->ct_out_pairs));
+                RAMD_TRY(ct_build_pair_lists(P, P->order, &P->ct_out_pairs, 1, &P->ct_out_packed));
+            dims.in_packed  = P->ct_in_packed ? 1 : 0;
+            dims.out_packed = (out && P->ct_out_packed) ? 1 : 0;
             const size_t lds = ct_rec_lds_bytes<T>(dims);
             unsigned     nwg = 0;
             int          nstreams = 1;
