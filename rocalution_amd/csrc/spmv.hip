@@ -107,7 +107,11 @@ struct CsrDotWs
 // has its column packets read; the others walk the leader's columns in LDS (lead[row] = offset from the row's entries to
 // the leader's).  4 bytes per entry become ~0.8 on the af_shell10-class matrix: 12.6 -> 9.4 bytes per entry moved.  A
 // follower whose leader's entries were staged in an earlier pass reads its own columns from memory (one group in ~12).
-template <typename T, int MODE, bool DOT, bool PAT, bool GRP = false>
+// PIPE (RAMD_CSR_PIPE=1, an experiment for rows of 25-45 entries where a row block takes several LDS passes): the packets of
+// pass k + 1 are requested before the rows of pass k are walked and wait in registers meanwhile.  Measured slower (0.173
+// against 0.154-0.159 ms on the config-3 surrogate): the waves of the other five workgroups of the CU already cover that
+// latency, and the held packets cost registers.
+template <typename T, int MODE, bool DOT, bool PAT, bool GRP = false, bool PIPE = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PAT ? RAMD_CSR_PAT_WAVES : 6, 8))) void k_csr_tr(int nrow, int nblk, int per_xcd,
                                                    const int* __restrict__ rp,
                                                    const int* __restrict__ ci,
@@ -156,10 +160,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PAT ? RA
         bool have_xrow = false;
         if(MODE == 1 && row < nrow)
             sum = y[row];
-        for(int cb = start & ~3; cb < end; cb += kCsrChunk)
-        {
-            v4i32 c[kCsrChunk / (4 * kBlock)];
-            VP    a[kCsrChunk / (VN * kBlock)];
+        v4i32 c[kCsrChunk / (4 * kBlock)];
+        VP    a[kCsrChunk / (VN * kBlock)];
+        auto  request = [&](int cb) { // the packets of the pass that starts at entry cb
 #pragma unroll
             for(int k = 0; k < (PAT ? 0 : kCsrChunk / (4 * kBlock)); ++k)
             {
@@ -174,6 +177,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PAT ? RA
                 if(j < end)
                     a[k] = nt_load(reinterpret_cast<const VP*>(val + j));
             }
+        };
+        if(PIPE)
+            request(start & ~3);
+        for(int cb = start & ~3; cb < end; cb += kCsrChunk)
+        {
+            if(!PIPE)
+                request(cb);
 #pragma unroll
             for(int k = 0; k < (PAT ? 0 : kCsrChunk / (4 * kBlock)); ++k)
             {
@@ -189,6 +199,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PAT ? RA
                     *reinterpret_cast<VP*>(sval + g) = a[k];
             }
             __syncthreads();
+            if(PIPE && cb + kCsrChunk < end)
+                request(cb + kCsrChunk);
             const int lo = max(rs, cb), hi = min(re, cb + kCsrChunk);
             // masked batches of kGatherW entries: all gathers of a batch are issued before the first use,
             // the products are added IN ORDER.  (A row of 7 used to cost one batch of 4 plus three
@@ -1609,6 +1621,9 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
         mm->blk_span = span > 0 ? span : -1;
     }
     const bool use_col2 = col2_candidate && m->blk_span > 0 && m->blk_span <= kCsrChunk;
+    // (measured SLOWER on the config-3 surrogate: 0.173 against 0.154-0.159 ms in alternating runs, gpurun_out/r03cb -- opt-in)
+    static const int pipe_env = getenv("RAMD_CSR_PIPE") ? atoi(getenv("RAMD_CSR_PIPE")) : 0;
+    const bool use_pipe = pipe_env != 0;
     const bool q4      = !use_pat && q4_env > 0; // measured EQUAL to k_csr_tr on the shell surrogate (0.162 vs 0.160 ms): opt-in
     const int  nblk    = (m->nrow + rows_per_wg - 1) / rows_per_wg;
     const int  per_xcd = (nblk + 7) / 8;
@@ -1657,6 +1672,9 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
         else if(use_grp)                                                                                   \
             hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT, false, true>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
                                per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, cgr, m->blk_rp); \
+        else if(use_pipe)                                                                                  \
+            hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT, false, false, true>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
+                               per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, CsrGroups{}, m->blk_rp);  \
         else                                                                                               \
             hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT, false>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
                                per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, CsrGroups{}, m->blk_rp);  \

@@ -1639,7 +1639,8 @@ __global__ __launch_bounds__(kBlock) void k_ct_count_ext(int n, const int* __res
     }
 }
 
-// ---- where a tile's values sit in w (rows of <= 3 entries, one lane per row).  The fetch waves read other tiles' values with
+// ---- where a tile's values sit in w (rows of <= 3 entries, one lane per row; RAMD_TRSV_WSLOT=1 -- measured: 7 bytes per row
+// less traffic at 512^3, 2-4 % slower, because a step's publication store becomes four short runs; off by default).  The fetch waves read other tiles' values with
 // agent-scope loads -- nothing of them is kept in a cache, every load instruction pays whole 64-byte lines -- and in
 // position (= level) order the rows another tile needs are spread over the producer's whole piece of w: one line per
 // 8-byte value (profiles/r02_traffic.json: 19-25 bytes per row at 512^3).  So the rows of a tile take their places in w in
