@@ -846,6 +846,170 @@ __global__ __launch_bounds__(kBlock) void k_csr_q4(int nrow, int nblk, int per_x
     }
 }
 
+// CSR SpMV for rows of 16+ entries, WAVE-PRIVATE passes (k_csr_w4).  Counters on k_csr_tr with the 35-entry rows of the
+// config-3 surrogate (tools/pmc_spmv_shell.sh, profiles/r03_pmc_spmv_shell.txt): 81 % of the wave cycles are waits, on average
+// 0.08 vector memory instructions in flight per wave -- a 2048-entry LDS pass of the workgroup holds the rows of ONE of its
+// four waves, the other three stand at the barrier while that wave walks its rows (five passes, ten barriers per workgroup).
+// Here a wave owns its 64 rows from the first packet to the store: it stages 16 rows at a time (four lanes per row, as in
+// k_csr_q4) through its own piece of LDS, with no workgroup barrier anywhere; the four waves of a workgroup and the
+// workgroups of a CU are in different phases at any time.  Products and sums as in k_csr_q4: lane l of a quad takes the
+// entries l, l + 4, ... of the row, the row sum runs in storage order over the quad-broadcast products -- bit-identical to
+// the host loop.  The finished sums pass through LDS so that lane t ends up with row t of the wave: the epilogue (Jacobi
+// sweep, fused dot with ONE partial per wave) is the one of k_csr_tr, same order of additions.
+constexpr int kW4Chunk = 640; // entries per wave and pass (16 rows of up to 40 entries in one pass)
+constexpr int kW4Batch = 3; // gathers in flight per lane (12 entries of a row per round)
+template <typename T, int MODE, bool DOT, int NWV>
+__global__ __launch_bounds__(64 * NWV) void k_csr_w4(int nrow, int nblk, int per_xcd, const int* __restrict__ rp,
+                                                   const int* __restrict__ ci, const T* __restrict__ val,
+                                                   const T* __restrict__ x, T* __restrict__ y, T scalar, CsrDotWs ws,
+                                                   int slot, BandMap bm)
+{
+    using VP           = typename ValPk<T>::type;
+    constexpr int VN   = ValPk<T>::N;
+    constexpr int CH   = kW4Chunk;
+    constexpr int NCP  = (CH / 4 + 63) / 64; // column packets per lane and pass
+    constexpr int NVP  = (CH / VN + 63) / 64; // value packets per lane and pass
+    __shared__ __attribute__((aligned(16))) T   sval[NWV][CH];
+    __shared__ __attribute__((aligned(16))) int scol[NWV][CH];
+    __shared__ T   ssum[NWV][64];
+    const int blk  = xcd_block(nblk, per_xcd, bm);
+    double    dacc = 0.0;
+    if(blk >= 0)
+    {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const int q = lane >> 2, l = lane & 3;
+        const int wbase = (blk * NWV + wave) * 64;
+        T*        sv    = sval[wave];
+        int*      sc    = scol[wave];
+        for(int s4 = 0; s4 < 4; ++s4)
+        {
+            const int first = wbase + 16 * s4;
+            if(first >= nrow) // (wave-uniform)
+                break;
+            const int row = first + q;
+            int       rs = 0, re = 0;
+            if(row < nrow)
+            {
+                rs = rp[row];
+                re = rp[row + 1];
+            }
+            const int lastq = min(15, nrow - 1 - first);
+            const int S     = __builtin_amdgcn_readlane(rs, 0);
+            const int E     = __shfl(re, 4 * lastq, 64);
+            T         sum   = (MODE == 1 && row < nrow) ? y[row] : (T)0;
+            for(int cb = S & ~3; cb < E; cb += CH)
+            {
+                v4i32 c[NCP];
+                VP    a[NVP];
+#pragma unroll
+                for(int k = 0; k < NCP; ++k)
+                {
+                    const int g = (k * 64 + lane) * 4;
+                    if(g < CH && cb + g < E)
+                        c[k] = nt_load(reinterpret_cast<const v4i32*>(ci + cb + g));
+                }
+#pragma unroll
+                for(int k = 0; k < NVP; ++k)
+                {
+                    const int g = (k * 64 + lane) * VN;
+                    if(g < CH && cb + g < E)
+                        a[k] = nt_load(reinterpret_cast<const VP*>(val + cb + g));
+                }
+#pragma unroll
+                for(int k = 0; k < NCP; ++k)
+                {
+                    const int g = (k * 64 + lane) * 4;
+                    if(g < CH && cb + g < E)
+                        *reinterpret_cast<v4i32*>(sc + g) = c[k];
+                }
+#pragma unroll
+                for(int k = 0; k < NVP; ++k)
+                {
+                    const int g = (k * 64 + lane) * VN;
+                    if(g < CH && cb + g < E)
+                        *reinterpret_cast<VP*>(sv + g) = a[k];
+                }
+                // (one wave: its LDS operations complete in order; the barrier only keeps the compiler from moving reads up)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const int lo = max(rs, cb), hi = min(re, cb + CH);
+                for(int j = lo; j < hi; j += 4 * kW4Batch)
+                {
+                    int cc[kW4Batch];
+                    T   p[kW4Batch], xv[kW4Batch];
+#pragma unroll
+                    for(int e = 0; e < kW4Batch; ++e)
+                    {
+                        const int jj = j + 4 * e + l;
+                        cc[e]        = -1;
+                        if(jj < hi)
+                        {
+                            cc[e] = sc[jj - cb];
+                            p[e]  = sv[jj - cb];
+                        }
+                    }
+#pragma unroll
+                    for(int e = 0; e < kW4Batch; ++e)
+                        if(cc[e] >= 0)
+                            xv[e] = x[cc[e]];
+#pragma unroll
+                    for(int e = 0; e < kW4Batch; ++e)
+                    {
+                        if(cc[e] >= 0)
+                            p[e] = (MODE != 1) ? p[e] * xv[e] : scalar * p[e] * xv[e];
+                        const int left = hi - (j + 4 * e); // entries of this group of four (quad-uniform)
+                        if(left >= 4)
+                        {
+                            sum += quad_bcast<0>(p[e]);
+                            sum += quad_bcast<1>(p[e]);
+                            sum += quad_bcast<2>(p[e]);
+                            sum += quad_bcast<3>(p[e]);
+                        }
+                        else if(left > 0)
+                        {
+                            const T b0 = quad_bcast<0>(p[e]), b1 = quad_bcast<1>(p[e]), b2 = quad_bcast<2>(p[e]);
+                            sum += b0;
+                            if(left > 1)
+                                sum += b1;
+                            if(left > 2)
+                                sum += b2;
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier(); // the next pass overwrites what this one read
+            }
+            if(l == 0)
+                ssum[wave][16 * s4 + q] = sum;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const int row = wbase + lane;
+        if(row < nrow)
+        {
+            T sum = ssum[wave][lane];
+            T xrow = (T)0;
+            if((DOT && !ws.dotv) || MODE == 2)
+                xrow = x[row];
+            if(MODE == 2)
+            {
+                T t = (T)(-1) * sum + static_cast<const T*>(ws.jrhs)[row];
+                t   = static_cast<const T*>(ws.jdinv)[row] * t;
+                sum = xrow + scalar * t;
+            }
+            nt_store(sum, y + row);
+            if(DOT)
+                dacc = (double)sum * (double)(ws.dotv ? static_cast<const T*>(ws.dotv)[row] : xrow);
+        }
+    }
+    if(DOT)
+    {
+        const double wsum = wave_reduce_sum(dacc);
+        if((threadIdx.x & 63) == 0 && blk >= 0)
+            ws.part1[blk * NWV + (threadIdx.x >> 6)] = wsum;
+    }
+}
+
 // ELL: one thread per row, column-major => every load is a perfectly coalesced wave access.
 // STOP=true : ELL semantics (stop at the first negative column, host_matrix_ell.cpp:309-318)
 // STOP=false: HYB-ELL semantics (skip invalid columns, host_matrix_hyb.cpp:344-352)
@@ -1624,6 +1788,10 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
     // (measured SLOWER on the config-3 surrogate: 0.173 against 0.154-0.159 ms in alternating runs, gpurun_out/r03cb -- opt-in)
     static const int pipe_env = getenv("RAMD_CSR_PIPE") ? atoi(getenv("RAMD_CSR_PIPE")) : 0;
     const bool use_pipe = pipe_env != 0;
+    static const int w4_env = getenv("RAMD_CSR_W4") ? atoi(getenv("RAMD_CSR_W4")) : -1; // (0 / 1: force; default: rows of 16+ entries)
+    const bool use_w4  = !use_pat && !use_grp && !(q4_env > 0) && !use_col2
+                         && (w4_env >= 0 ? w4_env != 0 : (int64_t)m->nnz >= (int64_t)16 * m->nrow);
+    static const int w4_waves = getenv("RAMD_CSR_W4_WAVES") ? atoi(getenv("RAMD_CSR_W4_WAVES")) : 4; // (1: one wave per workgroup)
     const bool q4      = !use_pat && q4_env > 0; // measured EQUAL to k_csr_tr on the shell surrogate (0.162 vs 0.160 ms): opt-in
     const int  nblk    = (m->nrow + rows_per_wg - 1) / rows_per_wg;
     const int  per_xcd = (nblk + 7) / 8;
@@ -1672,6 +1840,13 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
         else if(use_grp)                                                                                   \
             hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT, false, true>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
                                per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, cgr, m->blk_rp); \
+        else if(use_w4 && w4_waves == 1)                                                                   \
+            hipLaunchKernelGGL((k_csr_w4<T, MODE, DOT, 1>), dim3(((nblk * 4 + 7) / 8) * 8), dim3(64), 0, b.cur, m->nrow,     \
+                               nblk * 4, (nblk * 4 + 7) / 8, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot,        \
+                               BandMap{0, 0, 0});                                                         \
+        else if(use_w4)                                                                                    \
+            hipLaunchKernelGGL((k_csr_w4<T, MODE, DOT, 4>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk,  \
+                               per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm);        \
         else if(use_pipe)                                                                                  \
             hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT, false, false, true>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
                                per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, CsrGroups{}, m->blk_rp);  \
