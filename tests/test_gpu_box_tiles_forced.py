@@ -21,10 +21,13 @@ SELECT = ("(ilu or lusolve or trisolve or preconditioner_apply or sgs or solvers
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dedup", ["0", "1"])
+@pytest.mark.parametrize("dedup", ["0", "1", "0w"])
 def test_parity_suite_with_box_tiles_forced(dedup):
-    env = dict(os.environ, RAMD_TRSV_CT_MINROWS="0", RAMD_TRSV_CT_MINLEN="0", RAMD_TRSV_CT_DEDUP=dedup,
+    # "0w": additionally the opt-in layout of w (a tile's values placed by consumer, RAMD_TRSV_WSLOT=1) and 8-byte index pairs
+    env = dict(os.environ, RAMD_TRSV_CT_MINROWS="0", RAMD_TRSV_CT_MINLEN="0", RAMD_TRSV_CT_DEDUP=dedup[0],
                RAMD_TRSV_CT_VERBOSE="1")
+    if dedup.endswith("w"):
+        env.update(RAMD_TRSV_WSLOT="1", RAMD_TRSV_PACK="0", RAMD_TRSV_CLASSES="0")
     cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-s", "-m", "gpu", "-p", "no:cacheprovider",
            os.path.join(ROOT, "tests", "test_gpu_kernels.py"), os.path.join(ROOT, "tests", "test_gpu_solvers.py"),
            os.path.join(ROOT, "tests", "test_gpu_shell.py"), "-k", SELECT]
