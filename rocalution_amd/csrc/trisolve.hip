@@ -703,6 +703,7 @@ struct TriPlan
     const int* ct_in_key    = nullptr;
     int*       ct_out_pairs = nullptr; // [2 n] the same for the natural-order output: {row of the matrix, row number inside the tile}
     bool       ct_in_packed = false, ct_out_packed = false; // the lists in 4 bytes per row (see CtDims)
+    bool       prefilled_next = false; // the last run filled the next stage's w with sentinels (run_plan)
     void  release()
     {
         dev_free(&ct_tile_step);
@@ -2380,7 +2381,8 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
                                                   const T* __restrict__ rhs_src,
                                                   const int* __restrict__ in_pairs,
                                                   const int* __restrict__ out_pairs, T* w, T* __restrict__ out,
-                                                  unsigned* counter, CtBases bases, int nstreams, unsigned long long* prof_arg)
+                                                  unsigned* counter, CtBases bases, int nstreams, unsigned long long* prof_arg,
+                                                  T* __restrict__ prefill)
 {
     constexpr bool GRP = (LPR == kGrpLPR); // grouped form (row groups; CtGRec): `diag_sep` holds the row records
     using L           = typename std::conditional<GRP, CtGRec<T>, CtRec<T, WL>>::type;
@@ -2586,6 +2588,15 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if(lane == 0)
                     __hip_atomic_store(fetched + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // the sentinels of the NEXT stage's w (the upper solve after this lower one: same positions, another array):
+                // this kernel waits on its tile wavefront a quarter of its time and has the bandwidth to spare, the fill as a
+                // kernel of its own (0.19 ms at 512^3) has not
+                if(prefill)
+                {
+                    const T sv = Sentinel<T>::from_bits(Sentinel<T>::value);
+                    for(int q = lane; q < nr; q += 64)
+                        nt_store(sv, prefill + p0 + q);
+                }
             }
             for(int e = e0; e < e1; e += 64 * kCtFetchDepth)
             {
@@ -3920,17 +3931,27 @@ static int ct_build_pair_lists(TriPlan* P, const int* key, int** pairs_out, int 
 
 template <typename T>
 static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const int* rhs_idx, T* out,
-                    bool mul_inv_diag = false)
+                    bool mul_inv_diag = false, TriPlan* next_stage = nullptr, bool own_fill_done = false)
 {
+    // next_stage: the plan that runs right after this one on the same stream; a box-tile kernel fills its w with sentinels
+    // on the way (own_fill_done tells that plan so).  Returns with P->prefilled_next set if it did.
     Backend& b = backend();
     if(P->n == 0)
         return RAMD_OK;
     const unsigned nb = nblocks_of(P->n);
     static const bool nofill = getenv("RAMD_TRSV_NOFILL") != nullptr; // diagnostic only (tools/): no dependency waits
-    if(!nofill || !P->filled_once)
+    if((!nofill || !P->filled_once) && !own_fill_done)
         hipLaunchKernelGGL((k_fill_sentinel<T>), dim3(ew_grid(P->n)), dim3(kBlock), 0, b.cur, (int64_t)P->n,
                            (T*)P->w);
-    P->filled_once = true;
+    P->filled_once     = true;
+    P->prefilled_next  = false;
+    static const int prefill_env = getenv("RAMD_TRSV_PREFILL") ? atoi(getenv("RAMD_TRSV_PREFILL")) : 1; // (0: every plan fills its own w)
+    T* prefill = nullptr;
+    if(prefill_env != 0 && !nofill && next_stage && next_stage->n == P->n && next_stage->w && P->ct && P->ct_rec)
+    {
+        prefill           = (T*)next_stage->w;
+        P->prefilled_next = true;
+    }
     if(P->ct)
     {
         const int    dm    = mul_inv_diag ? 2 : (unit ? 0 : 1);
@@ -3991,13 +4012,13 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
                                P->ct_ntiles, dims, (const v4i32*)P->ct_tile_desc, (const v4i32*)P->ct_step_rec,             \
                                P->ct_ext_idx, (const v4i32*)P->eval, (const T*)P->diag, rhs_src, P->ct_in_pairs,            \
                                P->ct_out_pairs, (T*)P->w, out,                                                              \
-                               st->stream_counter, bases, nstreams, pf_buf);                                                \
+                               st->stream_counter, bases, nstreams, pf_buf, prefill);                                       \
         else                                                                                                                \
             hipLaunchKernelGGL((k_trsv_rec<T, DM, HO, LP, WLL, DP, false>), dim3(nwg), dim3(128), lds, b.cur, P->ct_ntiles, \
                                dims, (const v4i32*)P->ct_tile_desc, (const v4i32*)P->ct_step_rec, P->ct_ext_idx,            \
                                (const v4i32*)P->eval, (const T*)P->diag, rhs_src, P->ct_in_pairs, P->ct_out_pairs,           \
                                (T*)P->w, out,                                                                               \
-                               st->stream_counter, bases, nstreams, pf_buf);                                                \
+                               st->stream_counter, bases, nstreams, pf_buf, prefill);                                       \
     } while(0)
 #define TRSV_RC_L(DM, HO)            \
     do                               \
@@ -4957,8 +4978,8 @@ static int ll_solve_t(ramd_mat_s* m, const T* in, const T* inv_diag, T* out)
         st->ll_diag_src = (const void*)inv_diag;
     }
     // L y = b with y_i scaled by inv_diag_i, y kept in position order; then L^T x = y, scaled, natural order out
-    RAMD_TRY(run_plan<T>(st, &st->LLf, false, in, st->LLf.order, nullptr, true));
-    return run_plan<T>(st, &st->LLb, false, (const T*)st->LLf.w, st->ll_rhs_idx, out, true);
+    RAMD_TRY(run_plan<T>(st, &st->LLf, false, in, st->LLf.order, nullptr, true, &st->LLb));
+    return run_plan<T>(st, &st->LLb, false, (const T*)st->LLf.w, st->ll_rhs_idx, out, true, nullptr, st->LLf.prefilled_next);
 }
 
 // ---------------------------------------------------------------- iterative triangular solves
@@ -5496,13 +5517,14 @@ int ramd_mat_lu_solve(ramd_mat_t m, ramd_vec_t in, ramd_vec_t out)
     if(m->dtype == RAMD_F64)
     {
         // L y = b (unit diagonal), y kept in L-position order inside the plan's scratch
-        RAMD_TRY(run_plan<double>(st, &st->L, true, (const double*)in->d, st->L.order, nullptr));
+        RAMD_TRY(run_plan<double>(st, &st->L, true, (const double*)in->d, st->L.order, nullptr, false, &st->U));
         // U x = y (stored diagonal), x written back in natural order
         return run_plan<double>(st, &st->U, false, (const double*)st->L.w, st->lu_rhs_idx,
-                                (double*)out->d);
+                                (double*)out->d, false, nullptr, st->L.prefilled_next);
     }
-    RAMD_TRY(run_plan<float>(st, &st->L, true, (const float*)in->d, st->L.order, nullptr));
-    return run_plan<float>(st, &st->U, false, (const float*)st->L.w, st->lu_rhs_idx, (float*)out->d);
+    RAMD_TRY(run_plan<float>(st, &st->L, true, (const float*)in->d, st->L.order, nullptr, false, &st->U));
+    return run_plan<float>(st, &st->U, false, (const float*)st->L.w, st->lu_rhs_idx, (float*)out->d, false, nullptr,
+                           st->L.prefilled_next);
 }
 
 int ramd_mat_l_analyse(ramd_mat_t m, int diag_unit)
