@@ -342,12 +342,58 @@ __global__ __launch_bounds__(kBlock) void k_amax_partial(int64_t n, const T* a, 
     }
 }
 
+// Sum of a few million partial sums (one per wave of a fused SpMV + dot) into a scalar slot.  With a thread per 16-byte packet
+// this took 4096 workgroups and 55 microseconds at 512^3 -- 41 of them the workgroups' tickets, ~10 ns each on the one ticket
+// word, all at the end of a kernel too short to spread them (profiles/r03_kernel_stats_cg.txt: k_reduce<double, 1>).  Here at most
+// 256 workgroups, every thread with U independent packets in flight per round; the order of the additions is fixed by (n, grid).
+template <int U>
+__global__ __launch_bounds__(kBlock) void k_sum_partials(int64_t n, const double* __restrict__ a, ReduceCtx ctx, int slot)
+{
+    __shared__ double lds[8];
+    const int64_t np   = n / 2;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t gsz  = (int64_t)gridDim.x * blockDim.x;
+    double        acc  = 0.0;
+    for(int64_t i = gtid; i < np; i += U * gsz)
+    {
+        v2f64 v[U];
+#pragma unroll
+        for(int u = 0; u < U; ++u)
+        {
+            const int64_t j = i + u * gsz;
+            v[u]            = j < np ? reinterpret_cast<const v2f64*>(a)[j] : v2f64{0.0, 0.0};
+        }
+#pragma unroll
+        for(int u = 0; u < U; ++u)
+        {
+            acc += v[u].x;
+            acc += v[u].y;
+        }
+    }
+    if((n & 1) && gtid == 0)
+        acc += a[n - 1];
+    const double vals[1]  = {acc};
+    const int    slots[1] = {slot};
+    const int    ops[1]   = {(int)RED_SUM};
+    grid_reduce_finish<1>(ctx, vals, slots, ops, lds);
+}
+
 int reduce_sum_to_slot(const double* a, int64_t n, int slot)
 {
     if(n <= 0)
         return ramd_scalars_set(slot, 0.0);
-    hipLaunchKernelGGL((k_reduce<double, 1>), dim3(reduce_grid((n + 1) / 2)), dim3(kBlock), 0,
-                       backend().cur, n, a, a, reduce_ctx(), slot, (int)RED_SUM);
+    static const bool plain = getenv("RAMD_SUM_PARTIALS") && atoi(getenv("RAMD_SUM_PARTIALS")) == 0; // (A/B: the general kernel)
+    if(plain)
+    {
+        hipLaunchKernelGGL((k_reduce<double, 1>), dim3(reduce_grid((n + 1) / 2)), dim3(kBlock), 0, backend().cur, n, a, a,
+                           reduce_ctx(), slot, (int)RED_SUM);
+        RAMD_HIP(hipGetLastError());
+        return RAMD_OK;
+    }
+    constexpr int U = 8;
+    int64_t       g = (n / 2 + (int64_t)kBlock * U - 1) / ((int64_t)kBlock * U);
+    g               = g < 1 ? 1 : (g > 256 ? 256 : g);
+    hipLaunchKernelGGL((k_sum_partials<U>), dim3((unsigned)g), dim3(kBlock), 0, backend().cur, n, a, reduce_ctx(), slot);
     RAMD_HIP(hipGetLastError());
     return RAMD_OK;
 }
