@@ -461,9 +461,11 @@ def test_extract_submatrix_vs_oracle(ra, oracle):
         eq(rp, orp); eq(ci, oci); eq(va, ova)
 
 
-@pytest.mark.parametrize("N", [24, 40, 168])
+@pytest.mark.parametrize("N", [24, 40, 77, 100, 168])
 def test_ilu_lusolve_poisson_vs_oracle(ra, oracle, N):
-    """deep dependency DAG (3N-2 levels), exercised repeatedly to shake out stale hand-offs.  N = 168: 4.7 M rows = 9261
+    """deep dependency DAG (3N-2 levels), exercised repeatedly to shake out stale hand-offs.  N = 77, 100: grid lines that are
+    no multiple of the tile box (boundary tiles, upper and lower tiles that do not coincide: the 4-byte index lists fall back to
+    pairs where a tile's sources span too much).  N = 168: 4.7 M rows = 9261
     box tiles on ~2000 persistent workgroups, so every workgroup walks several tiles (LDS ring reuse, per-tile write-back
     of the natural-order output, all 16 ticket streams) -- still bit for bit"""
     from rocalution_amd import generators as gen
