@@ -502,7 +502,7 @@ def main():
         if args.format == "csr":
             b_spmv = spmv_bytes(n, nnz, vb)
             k_spmv = ("k_csr_tr<float> (fp32 inner CSR SpMV + fused <p,q>; the few fp64 outer residual SpMVs are in the average)"
-                      if mixed else "CSR SpMV (k_csr_pat2 for structured matrices -- columns from the row-pattern dictionary, two row blocks per workgroup: traffic below the algorithmic CSR bytes -- else k_csr_tr; with the fused dot where the solver uses it)")
+                      if mixed else "CSR SpMV (k_csr_pat2 for structured matrices -- columns from the row-pattern dictionary, two row blocks per workgroup: traffic below the algorithmic CSR bytes -- else k_csr_tr, or k_csr_w4 for rows of 16+ entries; with the fused dot where the solver uses it)")
         else:
             nnz_fmt = 7 * n if args.matrix == "poisson" else nnz
             b_spmv = vb * (2 * n + nnz_fmt) if args.format == "dia" else 4 * nnz_fmt + vb * (2 * n + nnz_fmt)
