@@ -188,7 +188,11 @@ def self_spawn(args):
                                             "print(ra.device_count())" % ROOT], stderr=subprocess.DEVNULL).decode().split()[-1])
     except Exception:
         ndev = 0
-    if ndev < args.gpus:
+    if args.transport == "callback":
+        if ndev < 1:
+            log("bench.py: --transport callback: no device visible")
+            sys.exit(2)
+    elif ndev < args.gpus:
         log("bench.py: --gpus %d: need %d devices, %d visible -- not running on fewer ranks" % (args.gpus, args.gpus, ndev))
         sys.exit(2)
     port = free_port()
@@ -273,6 +277,12 @@ def main():
     ap.add_argument("--force-global", action="store_true",
                     help="1 process: still go through the GlobalMatrix/RCCL code path (communicator of size 1, "
                          "collectives not skipped) - a check of the N>1 plumbing on a 1-GPU box")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "callback"],
+                    help="data plane of the N > 1 run.  rccl (default): one GPU per rank, halo exchange and scalar all-reduce over "
+                         "RCCL/xGMI.  callback: the ranks SHARE the visible device(s) (rank r on device r mod count) and talk "
+                         "through the host-staged callback transport of the tests (gloo underneath) -- a REHEARSAL of the whole "
+                         "N > 1 code path of this file on a 1-GPU box (RCCL refuses two ranks on one device); the line it prints "
+                         "says so (\"transport\", \"rehearsal\": true) and is not a scaling measurement")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the GMRES(30)+ILU(0) and BiCGStab+MC-SGS legs (reported under `extras`)")
     args = ap.parse_args()
@@ -303,10 +313,14 @@ def main():
     import rocalution_amd as ra
     from rocalution_amd import capi
     lib = capi.load()
-    if world > 1 and ra.device_count() < world:
+    rehearsal = args.transport == "callback" and world > 1
+    if world > 1 and not rehearsal and ra.device_count() < world:
         log("bench.py: %d ranks need %d devices, %d visible" % (world, world, ra.device_count()))
         sys.exit(2)
-    ra.init_rocalution(local_rank)
+    if rehearsal and ra.device_count() < 1:
+        log("bench.py: --transport callback: no device visible")
+        sys.exit(2)
+    ra.init_rocalution(local_rank % ra.device_count() if rehearsal else local_rank)
     if rank == 0:
         log(ra.info_rocalution())
 
@@ -321,13 +335,17 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        uid = C.create_string_buffer(128)
-        if rank == 0:
-            capi.check(lib.ramd_comm_unique_id(uid))
-        t = torch.tensor(list(uid.raw), dtype=torch.uint8)
-        dist.broadcast(t, src=0)
-        uid = C.create_string_buffer(bytes(t.tolist()), 128)
-        capi.check(lib.ramd_comm_init_rccl(rank, world, uid, C.byref(comm)))  # data plane: RCCL over xGMI
+        if rehearsal:
+            from rocalution_amd import distributed as D_
+            comm = D_.make_callback_comm(rank, world, dist)  # data plane: host-staged (several ranks per device)
+        else:
+            uid = C.create_string_buffer(128)
+            if rank == 0:
+                capi.check(lib.ramd_comm_unique_id(uid))
+            t = torch.tensor(list(uid.raw), dtype=torch.uint8)
+            dist.broadcast(t, src=0)
+            uid = C.create_string_buffer(bytes(t.tolist()), 128)
+            capi.check(lib.ramd_comm_init_rccl(rank, world, uid, C.byref(comm)))  # data plane: RCCL over xGMI
 
     if comm:
         C.CDLL(None).fflush(None)  # RCCL's version banner sits in C stdio: get it out before the JSON line
@@ -675,7 +693,11 @@ def main():
                                   halo_time_frac=round(wait * allr[0]["halo_exchanges"] / max(itp, 1) / (dt / it * 1e3), 4),
                                   allreduces_per_iter=round(allr[0]["allreduces"] / max(itp, 1), 2),
                                   halo_exchanges_per_iter=round(allr[0]["halo_exchanges"] / max(itp, 1), 2),
-                                  rccl_nranks=nr.value)
+                                  rccl_nranks=nr.value,
+                                  transport="rccl" if not rehearsal else "callback (host-staged through gloo; the ranks share "
+                                                                         "the device(s))")
+            if rehearsal:
+                scaling_fields["rehearsal"] = True  # the N > 1 code path on one box: NOT a scaling measurement
 
     if rank == 0:
         out = {

@@ -570,6 +570,10 @@ public:
         : pm_(&pm)
     {
     }
+    ~GlobalMatrix()
+    {
+        this->doDropHaloPlan();
+    }
     void SetParallelManager(const ParallelManager& pm)
     {
         this->pm_ = &pm;
@@ -712,11 +716,11 @@ public:
     // global_matrix.cpp:924-1009, device-resident: pack | halo over xGMI || interior SpMV | ghost +=
     void Apply(const GlobalVector<ValueType>& in, GlobalVector<ValueType>* out) const
     {
-        const bool comm = this->pm_ != NULL && (this->m_halo_allgather || !this->pm_->peers().empty());
+        const bool comm = this->pm_ != NULL && (this->m_halo_plan > 0 || !this->pm_->peers().empty());
         if(comm)
         {
             in.m_owned.GetIndexValues(this->m_halo_rows, &this->m_send);
-            RAMD_CHECK(ramd_comm_halo_begin(this->pm_->GetComm(), this->m_send.handle(),
+            RAMD_CHECK(ramd_comm_halo_begin_plan(this->pm_->GetComm(), this->m_halo_plan, this->m_send.handle(),
                                             this->m_recv.handle(), (int)this->pm_->peers().size(),
                                             this->pm_->peers().data(), this->pm_->send_offset().data(),
                                             this->pm_->recv_offset().data()));
@@ -740,11 +744,11 @@ public:
     void ApplyDotV(const GlobalVector<ValueType>& in, const GlobalVector<ValueType>& w,
                    GlobalVector<ValueType>* out, int slot) const
     {
-        const bool comm = this->pm_ != NULL && (this->m_halo_allgather || !this->pm_->peers().empty());
+        const bool comm = this->pm_ != NULL && (this->m_halo_plan > 0 || !this->pm_->peers().empty());
         if(comm)
         {
             in.m_owned.GetIndexValues(this->m_halo_rows, &this->m_send);
-            RAMD_CHECK(ramd_comm_halo_begin(this->pm_->GetComm(), this->m_send.handle(),
+            RAMD_CHECK(ramd_comm_halo_begin_plan(this->pm_->GetComm(), this->m_halo_plan, this->m_send.handle(),
                                             this->m_recv.handle(), (int)this->pm_->peers().size(),
                                             this->pm_->peers().data(), this->pm_->send_offset().data(),
                                             this->pm_->recv_offset().data()));
@@ -891,7 +895,9 @@ public:
         const int                   np    = (int)peers.size();
         const int64_t               nsend = fpm->GetNumSenders(), nrecv = fpm->GetNumReceivers();
         std::vector<int>            c_boundary, c_soff(1, 0), c_roff(1, 0);
-        const bool                  talk = np > 0 || A.m_halo_allgather;
+        // (kmax below is an all-reduce: EVERY rank of a multi-rank run enters this block, also one without neighbours --
+        //  its kloc is 0 and its exchanges are empty; only the pairwise exchanges themselves may be skipped per rank)
+        const bool                  talk = np > 0 || A.m_halo_plan > 0 || fpm->GetNumProcs() > 1;
         if(talk)
         {
             // prolongation rows of my boundary rows, on the host (k-th entry of every row per exchange)
@@ -1017,7 +1023,7 @@ private:
     void doBlockDiagonal(const ParallelManager* like, int64_t global_nrow, int64_t global_ncol)
     {
         this->m_ghost.Clear();
-        this->m_halo_allgather = false;
+        this->doDropHaloPlan();
         if(like == NULL)
         {
             this->pm_ = NULL;
@@ -1067,7 +1073,7 @@ private:
     // one halo exchange of per-boundary-row values with the pattern of this matrix (device buffers)
     void doExchange(const LocalVector<ValueType>& send, LocalVector<ValueType>* recv) const
     {
-        RAMD_CHECK(ramd_comm_halo_begin(this->pm_->GetComm(), send.handle(), recv->handle(), (int)this->pm_->peers().size(),
+        RAMD_CHECK(ramd_comm_halo_begin_plan(this->pm_->GetComm(), this->m_halo_plan, send.handle(), recv->handle(), (int)this->pm_->peers().size(),
                                         this->pm_->peers().data(), this->pm_->send_offset().data(),
                                         this->pm_->recv_offset().data()));
         RAMD_CHECK(ramd_comm_halo_end(this->pm_->GetComm()));
@@ -1075,7 +1081,7 @@ private:
     // global_matrix.cpp:4476-4513: halo index vector + device send/recv buffers
     void doInitHalo(void)
     {
-        this->m_halo_allgather = false;
+        this->doDropHaloPlan();
         if(this->pm_ == NULL)
             return;
         {
@@ -1084,9 +1090,10 @@ private:
             int ag = 0;
             RAMD_CHECK(ramd_comm_halo_select(this->pm_->GetComm(), (int)this->pm_->peers().size(), this->pm_->peers().data(),
                                              this->pm_->send_offset().data(), this->pm_->recv_offset().data(), &ag));
-            this->m_halo_allgather = ag != 0;
+            this->m_halo_plan = ag;
+            this->m_halo_comm = ag > 0 ? this->pm_->GetComm() : NULL;
         }
-        if(this->pm_->peers().empty() && !this->m_halo_allgather)
+        if(this->pm_->peers().empty() && this->m_halo_plan == 0)
             return;
         const int nb = this->pm_->GetBoundarySize();
         this->m_halo_rows.MoveToAccelerator();
@@ -1105,7 +1112,17 @@ private:
     LocalVector<int>               m_halo_rows;
     mutable LocalVector<ValueType> m_send;
     mutable LocalVector<ValueType> m_recv;
-    bool                           m_halo_allgather = false; // form of the exchange the ranks agreed on (doInitHalo)
+    // form of the exchange the ranks agreed on (doInitHalo): 0 = send/recv pairs, k > 0 = the all-gather plan number k
+    // handed out by ramd_comm_halo_select (owned by this matrix: released when the plan is replaced or the matrix dies)
+    void doDropHaloPlan(void)
+    {
+        if(this->m_halo_plan > 0 && this->m_halo_comm != NULL)
+            (void)ramd_comm_halo_release(this->m_halo_comm, this->m_halo_plan);
+        this->m_halo_plan = 0;
+        this->m_halo_comm = NULL;
+    }
+    int                            m_halo_plan = 0;
+    ramd_comm_t                    m_halo_comm = NULL;
 };
 
 // ---- fused-loop helpers for Global objects (see solvers.hpp: _fusable / _fh / _f_apply_dot / _f_allreduce)

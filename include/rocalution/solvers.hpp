@@ -1899,6 +1899,10 @@ private:
             dinv = _fh(jac->GetInverseDiagonal());
         if(precond && dinv == NULL)
             return false; // (a general preconditioner sits between the kernels: the pair probes)
+        int room = 0; // the saved iterate, the saved contents of the vector being placed, one candidate
+        RAMD_CHECK(ramd_placement_room((int64_t)x->GetSize() * (int64_t)sizeof(ValueType), 3, &room));
+        if(!room)
+            return true; // (memory is tight: no placement at all, also not by the pair probes)
         VectorType keep;
         keep.CloneBackend(*x);
         keep.Allocate("iterate", x->GetSize());
@@ -2475,6 +2479,10 @@ private:
             return false;
         VectorType *kr = this->W(0), *r0 = this->W(1), *kp = this->W(2), *kt = this->W(4);
         VectorType *kv = precond ? this->W(5) : NULL, *kz = precond ? this->W(6) : NULL;
+        int room = 0; // the saved iterate, the saved contents of r, one candidate
+        RAMD_CHECK(ramd_placement_room((int64_t)x->GetSize() * (int64_t)sizeof(ValueType), 3, &room));
+        if(!room)
+            return true; // (memory is tight: no placement at all)
         VectorType keep;
         keep.CloneBackend(*x);
         keep.Allocate("iterate", x->GetSize());

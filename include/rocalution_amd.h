@@ -101,9 +101,15 @@ int ramd_vec_place_apart(ramd_vec_t v, ramd_vec_t other, int* moved);
  * with the vector in its own block and in up to `tries` fresh ones, and the vector moves to the fastest (contents kept; what
  * `run` does to other vectors is the caller's business).  stop_ratio = 0: always `tries` trials (`run` may talk to other
  * ranks); stop_ratio in (0, 1): stop once the best time is below stop_ratio x the worst one seen.  apart_from != NULL: the
- * first candidates are drawn from the placement class that vector is not in.  No-op below 64 MiB.  Which pairs and triples of big blocks stream well together is decided by their physical placement and is only
- * partly predicted by the placement class.  The fused CG loop can place its work vectors this way at its first Solve
- * (opt-in, RAMD_PLACE_TRIES=k: measured not to pay by default, see solvers.hpp). */
+ * first candidates are drawn from the placement class that vector is not in.  No-op below 64 MiB.  Which pairs and triples
+ * of big blocks stream well together is decided by their physical placement and is only partly predicted by the placement
+ * class.  The fused CG and BiCGStab loops place the vectors their update kernels write this way at their first Solve, by
+ * default, for vectors of 64 MiB and more (RAMD_ALLOC_CLASSES=0 switches every placement measurement off).
+ * Placement is an optimisation and never the reason a solve runs out of memory: every spare block (saved contents,
+ * candidates, the 1-GiB reference block of the class probe) is only taken while it leaves a sixteenth of the device (at
+ * least 2 GiB) free -- ramd_placement_room answers that question for `blocks` blocks of `bytes` -- and a failed allocation
+ * inside a placement call means "stay where you are" (RAMD_OK, *moved = 0). */
+int ramd_placement_room(int64_t bytes, int blocks, int* ok);
 /* wall time this process has spent measuring placements so far (ramd_vec_place_apart, ramd_vec_place_by_trial); reset != 0
  * sets it back to zero */
 int ramd_placement_seconds(double* seconds, int reset);
@@ -459,12 +465,19 @@ int ramd_comm_allreduce_scalars(ramd_comm_t c, int first, int count);
 /* COLLECTIVE (every rank of the communicator, also one without neighbours): announces an exchange plan and agrees on
  * its form -- grouped ncclSend/ncclRecv pairs, or, when some rank has more than four peers (or RAMD_COMM_HALO=allgather),
  * ONE ncclAllGather of equally padded boundary buffers from which every rank picks what it needs (the reference posts
- * one MPI_Isend/Irecv per neighbour whatever their number, parallel_manager.cpp:726-782).  *allgather = 1: every rank
- * has to call ramd_comm_halo_begin / _end for every exchange of this plan, also with npeers = 0. */
+ * one MPI_Isend/Irecv per neighbour whatever their number, parallel_manager.cpp:726-782).
+ * *allgather = 0: pairs (ramd_comm_halo_begin).  *allgather = k > 0: the all-gather form; k is the plan's number -- the
+ * count of this collective call, the same on every rank, NOT a function of this rank's own peers and offsets (two
+ * matrices may look alike from one rank and differ on the others) -- and every rank has to call
+ * ramd_comm_halo_begin_plan(c, k, ...) / _end for every exchange of this plan, also with npeers = 0.
+ * ramd_comm_halo_release gives a plan's device buffers back (the owner of the plan calls it when it goes away). */
 int ramd_comm_halo_select(ramd_comm_t c, int npeers, const int* peers, const int64_t* send_offset,
                           const int64_t* recv_offset, int* allgather);
+int ramd_comm_halo_release(ramd_comm_t c, int plan);
 int ramd_comm_halo_begin(ramd_comm_t c, ramd_vec_t send, ramd_vec_t recv, int npeers, const int* peers,
                          const int64_t* send_offset, const int64_t* recv_offset);
+int ramd_comm_halo_begin_plan(ramd_comm_t c, int plan, ramd_vec_t send, ramd_vec_t recv, int npeers, const int* peers,
+                              const int64_t* send_offset, const int64_t* recv_offset);
 int ramd_comm_halo_end(ramd_comm_t c);
 
 /* ======================================================================= solver layer

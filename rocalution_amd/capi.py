@@ -57,6 +57,7 @@ SIGNATURES = {
     "ramd_vec_place_apart": (i32, [vec_t, vec_t, pi32]),
     "ramd_vec_place_by_trial": (i32, [vec_t, C.c_void_p, C.c_void_p, i32, C.c_double, vec_t, pi32]),
     "ramd_placement_seconds": (i32, [C.POINTER(C.c_double), i32]),
+    "ramd_placement_room": (i32, [i64, i32, pi32]),
     "ramd_vec_clear": (i32, [vec_t]),
     "ramd_vec_size": (i32, [vec_t, pi64]),
     "ramd_vec_dtype": (i32, [vec_t, pi32]),
@@ -204,6 +205,8 @@ SIGNATURES = {
     "ramd_comm_allreduce_scalars": (i32, [ptr, i32, i32]),
     "ramd_comm_halo_select": (i32, [ptr, i32, pi32, pi64, pi64, pi32]),
     "ramd_comm_halo_begin": (i32, [ptr, vec_t, vec_t, i32, pi32, pi64, pi64]),
+    "ramd_comm_halo_begin_plan": (i32, [ptr, i32, vec_t, vec_t, i32, pi32, pi64, pi64]),
+    "ramd_comm_halo_release": (i32, [ptr, i32]),
     "ramd_comm_halo_end": (i32, [ptr]),
     # solver layer
     "ramd_solver_create": (i32, [i32, i32, i32, C.POINTER(ptr)]),

@@ -180,6 +180,11 @@ struct AllocCache
         cached_bytes = 0;
         for(auto& kv : free_blocks)
             cached_bytes += kv.first;
+        if(ref) // the reference block of the class probes (1 GiB): comes back with the next probe
+        {
+            (void)hipFree(ref);
+            ref = nullptr;
+        }
         for(Arena& ar : arenas)
             if(ar.live == 0 && ar.base)
             {
@@ -220,6 +225,12 @@ int probe_class(AllocCache& c, void* p, size_t bytes)
         return -1;
     if(!c.ref)
     {
+        size_t f = 0, t = 0;
+        if(hipMemGetInfo(&f, &t) != hipSuccess || f < 2 * kProbeBytes + std::max(t / 16, (size_t)2 << 30))
+        {
+            (void)hipGetLastError();
+            return -1; // (memory is tight: blocks stay unclassified, placement is skipped)
+        }
         void* r = nullptr;
         if(hipMalloc(&r, 2 * kProbeBytes) != hipSuccess)
         {
@@ -305,6 +316,24 @@ float probe_write_pair_ms(void* a, void* b2, size_t bytes)
     (void)hipEventDestroy(e1);
     (void)hipGetLastError();
     return best;
+}
+
+bool placement_room(size_t bytes, int blocks)
+{
+    size_t f = 0, t = 0;
+    if(hipMemGetInfo(&f, &t) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return false;
+    }
+    size_t cached = 0;
+    {
+        AllocCache&                 c = cache();
+        std::lock_guard<std::mutex> lk(c.mu);
+        cached = c.cached_bytes; // (blocks the cache holds are handed out again or dropped before the runtime says no)
+    }
+    const size_t reserve = std::max(t / 16, (size_t)2 << 30);
+    return f + cached >= (size_t)blocks * (bytes + ((size_t)1 << 20)) + reserve;
 }
 
 int cached_block_class(const void* p)

@@ -296,9 +296,11 @@ __global__ __launch_bounds__(kBlock) void k_unit_deps(int nrow, int nunits, cons
 // publishes.  As long as some lane still waits, the others do not wait with it (64 units that published together would tie
 // the end of one grid plane to the start of the next, the very thing the units avoid): a lane whose dependencies are all
 // there publishes, and the lanes that hold its bit take its level through a shuffle, one per turn.
-__global__ __launch_bounds__(kBlock) void k_unit_levels(int nunits, const int* __restrict__ deps, int* level)
+// Units go to workgroups by TICKET (the k-th workgroup to start takes units [k kBlock, (k + 1) kBlock)): a unit only waits
+// for earlier units, i.e. for workgroups that have started, whatever order the hardware dispatches the grid in.
+__global__ __launch_bounds__(kBlock) void k_unit_levels(int nunits, const int* __restrict__ deps, int* level, unsigned* counter)
 {
-    const int64_t u    = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t u    = (int64_t)take_ticket(counter, 0u) * kBlock + threadIdx.x;
     const bool    live = u < nunits;
     const int     lane = threadIdx.x & 63;
     const int     u0   = (int)u - lane;
@@ -377,8 +379,9 @@ int unit_schedule(const ramd_mat_s* m, bool lower, UnitPlan* out)
     Backend&  b    = backend();
     const int grid = ew_grid(n + 1);
     int *     brk = nullptr, *bscan = nullptr, *hard = nullptr, *hscan = nullptr, *seg = nullptr, *uflag = nullptr,
-        *uscan = nullptr, *deps = nullptr, *over = nullptr, *level = nullptr;
+        *uscan = nullptr, *deps = nullptr, *over = nullptr, *level = nullptr, *tick = nullptr;
     auto drop = [&]() {
+        dev_free(&tick);
         dev_free(&brk);
         dev_free(&bscan);
         dev_free(&hard);
@@ -461,8 +464,10 @@ int unit_schedule(const ramd_mat_s* m, bool lower, UnitPlan* out)
         drop();
         return RAMD_OK;
     }
+    US_TRY(dev_alloc(&tick, 1));
+    US_HIP(hipMemsetAsync(tick, 0, sizeof(int), b.cur));
     hipLaunchKernelGGL(k_unit_levels, dim3((unsigned)((nunits + kBlock - 1) / kBlock)), dim3(kBlock), 0, b.cur, nunits, deps,
-                       level);
+                       level, (unsigned*)tick);
     int nlev = 0;
     US_TRY(device_max_int(level, nunits, &nlev)); // (synchronises)
     US_TRY(dev_alloc(&out->order, nunits));

@@ -18,6 +18,7 @@
 
 #include <rccl/rccl.h>
 
+#include <set>
 #include <vector>
 
 using namespace ramd;
@@ -35,10 +36,15 @@ struct ramd_comm_s
     void*  h_send = nullptr;
     void*  h_recv = nullptr;
     size_t h_send_bytes = 0, h_recv_bytes = 0;
-    // all-gather form of the halo exchange: one plan per (peers, offsets) signature
+    // all-gather form of the halo exchange: one plan per ramd_comm_halo_select call that chose it.  A plan is identified by
+    // the sequence number of that (collective) call -- the same number on every rank -- never by a rank's own (peers,
+    // offsets): the padded length M and the table behind d_idx are properties of ALL ranks' plans, and two matrices whose
+    // plans coincide on one rank (e.g. a rank without neighbours on every AMG level) need not coincide on the others.
     struct AgPlan
     {
-        unsigned long long key = 0; // hash of the exchange plan + element size
+        int     id = 0; // sequence number of the halo_select call that made it (> 0)
+        int     npeers = 0; // this rank's side of the plan, checked at every exchange
+        int64_t nsend = 0;
         int64_t M = 0; // padded boundary length (elements): the maximum over the ranks
         int64_t nrecv = 0;
         int*    d_idx = nullptr; // [nrecv] position in the gathered buffer of every received value
@@ -46,8 +52,7 @@ struct ramd_comm_s
         void*   d_all  = nullptr; // [size * M] the gathered buffers
     };
     std::vector<AgPlan> ag;
-    // form of the exchange the ranks agreed on per plan (ramd_comm_halo_select): key of the plan -> 1 = all-gather
-    std::vector<std::pair<unsigned long long, int>> form;
+    int                 select_calls = 0; // ramd_comm_halo_select calls so far (collective: equal on every rank)
 };
 
 template <typename T>
@@ -70,10 +75,18 @@ __global__ __launch_bounds__(256) void k_halo_pick(int64_t n, const int* __restr
         }                                                                                          \
     } while(0)
 
+// communicators that have not been destroyed yet (a halo plan's owner may ask to release it after the communicator went)
+static std::set<const ramd_comm_s*>& live_comms()
+{
+    static std::set<const ramd_comm_s*> s;
+    return s;
+}
+
 static int comm_common_init(ramd_comm_s* c)
 {
     RAMD_HIP(hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
     RAMD_HIP(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
+    live_comms().insert(c);
     return RAMD_OK;
 }
 
@@ -151,6 +164,7 @@ int ramd_comm_destroy(ramd_comm_t c)
         (void)hipHostFree(c->h_send);
     if(c->h_recv)
         (void)hipHostFree(c->h_recv);
+    live_comms().erase(c);
     for(auto& pl : c->ag)
     {
         dev_free(&pl.d_idx);
@@ -242,29 +256,6 @@ static int halo_forced_form()
     }();
     return mode;
 }
-static unsigned long long halo_plan_key(int npeers, const int* peers, const int64_t* send_offset, const int64_t* recv_offset)
-{
-    unsigned long long h = 1469598103934665603ull;
-    auto mix = [&](long long v) { h = (h ^ (unsigned long long)v) * 1099511628211ull; };
-    mix(npeers);
-    for(int k = 0; k < npeers; ++k)
-        mix(peers[k]);
-    for(int k = 0; k <= npeers && npeers > 0; ++k)
-    {
-        mix(send_offset[k]);
-        mix(recv_offset[k]);
-    }
-    return h;
-}
-// the form the ranks agreed on for this plan (0: send/recv pairs -- also for a plan nobody announced)
-static bool halo_use_allgather(const ramd_comm_s* c, unsigned long long key)
-{
-    for(auto& kv : c->form)
-        if(kv.first == key)
-            return kv.second == 1;
-    return false;
-}
-
 // all ranks contribute `count` int64 each; out[r * count ..] = rank r's contribution (host arrays)
 static int comm_allgather_host(ramd_comm_s* c, const int64_t* mine, int count, int64_t* out)
 {
@@ -319,16 +310,10 @@ static int comm_allgather_host(ramd_comm_s* c, const int64_t* mine, int count, i
     return RAMD_OK;
 }
 
-static int halo_ag_plan(ramd_comm_s* c, size_t es, int npeers, const int* peers, const int64_t* send_offset,
-                        const int64_t* recv_offset, ramd_comm_s::AgPlan** out)
+// builds the all-gather plan `id` (a collective: every rank is inside ramd_comm_halo_select for the same plan)
+static int halo_ag_plan(ramd_comm_s* c, int id, int npeers, const int* peers, const int64_t* send_offset,
+                        const int64_t* recv_offset)
 {
-    const unsigned long long h = halo_plan_key(npeers, peers, send_offset, recv_offset) * 31ull + (unsigned long long)es;
-    for(auto& pl : c->ag)
-        if(pl.key == h)
-        {
-            *out = &pl;
-            return RAMD_OK;
-        }
     // every rank's table: [0] = its boundary length, [1 + 2q] / [2 + 2q] = start / length of the piece for rank q
     const int            P = c->size, cnt = 1 + 2 * P;
     std::vector<int64_t> mine((size_t)cnt, 0), all((size_t)cnt * P, 0);
@@ -342,8 +327,10 @@ static int halo_ag_plan(ramd_comm_s* c, size_t es, int npeers, const int* peers,
     }
     RAMD_TRY(comm_allgather_host(c, mine.data(), cnt, all.data()));
     ramd_comm_s::AgPlan pl;
-    pl.key   = h;
-    pl.nrecv = npeers > 0 ? recv_offset[npeers] : 0;
+    pl.id     = id;
+    pl.npeers = npeers;
+    pl.nsend  = npeers > 0 ? send_offset[npeers] : 0;
+    pl.nrecv  = npeers > 0 ? recv_offset[npeers] : 0;
     for(int q = 0; q < P; ++q)
         pl.M = std::max(pl.M, all[(size_t)cnt * q]);
     pl.M = (pl.M + 1) & ~(int64_t)1; // (16-byte multiples in fp64)
@@ -361,8 +348,8 @@ static int halo_ag_plan(ramd_comm_s* c, size_t es, int npeers, const int* peers,
     }
     if(getenv("RAMD_COMM_DEBUG"))
     {
-        fprintf(stderr, "[rank %d] halo all-gather plan: npeers=%d M=%lld nrecv=%lld es=%zu table:", c->rank, npeers, (long long)pl.M,
-                (long long)pl.nrecv, es);
+        fprintf(stderr, "[rank %d] halo all-gather plan %d: npeers=%d M=%lld nrecv=%lld table:", c->rank, id, npeers, (long long)pl.M,
+                (long long)pl.nrecv);
         for(size_t i = 0; i < all.size(); ++i)
             fprintf(stderr, " %lld", (long long)all[i]);
         fprintf(stderr, " | idx:");
@@ -373,6 +360,7 @@ static int halo_ag_plan(ramd_comm_s* c, size_t es, int npeers, const int* peers,
     RAMD_TRY(dev_alloc(&pl.d_idx, pl.nrecv > 0 ? pl.nrecv : 1));
     if(pl.nrecv > 0)
         RAMD_HIP(hipMemcpy(pl.d_idx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice));
+    const size_t es = 8; // (buffers sized for fp64; fp32 exchanges of the same plan use their first half)
     RAMD_HIP(cached_malloc_bytes(&pl.d_send, (size_t)(pl.M > 0 ? pl.M : 2) * es));
     RAMD_HIP(cached_malloc_bytes(&pl.d_all, (size_t)(pl.M > 0 ? pl.M : 2) * es * P));
     // (on the ghost stream, where the exchanges fill and read it: a null-stream memset is not ordered against that stream
@@ -380,7 +368,6 @@ static int halo_ag_plan(ramd_comm_s* c, size_t es, int npeers, const int* peers,
     RAMD_HIP(hipMemsetAsync(pl.d_send, 0, (size_t)(pl.M > 0 ? pl.M : 2) * es, backend().stream_ghost));
     RAMD_HIP(hipStreamSynchronize(backend().stream_ghost));
     c->ag.push_back(pl);
-    *out = &c->ag.back();
     return RAMD_OK;
 }
 
@@ -395,7 +382,6 @@ int ramd_comm_halo_select(ramd_comm_t c, int npeers, const int* peers, const int
         return RAMD_OK;
     if(npeers < 0 || (npeers > 0 && (!peers || !send_offset || !recv_offset)))
         RAMD_FAIL(RAMD_ERR_ARG, "halo_select: bad arguments");
-    const unsigned long long key = halo_plan_key(npeers, peers, send_offset, recv_offset);
     // every rank learns the largest peer count: the rule has to give the same answer everywhere
     std::vector<int64_t> all((size_t)c->size, 0);
     const int64_t        mine = npeers;
@@ -405,27 +391,48 @@ int ramd_comm_halo_select(ramd_comm_t c, int npeers, const int* peers, const int
         most = std::max(most, v);
     const int forced = halo_forced_form();
     const int ag     = forced >= 0 ? forced : (most > kAgPeers ? 1 : 0);
-    bool      known  = false;
-    for(auto& kv : c->form)
-        if(kv.first == key)
-        {
-            kv.second = ag;
-            known     = true;
-        }
-    if(!known)
-        c->form.emplace_back(key, ag);
+    // the plan's identity: the number of this collective call (every rank counts the same calls in the same order)
+    const int id = ++c->select_calls;
+    if(ag)
+        RAMD_TRY(halo_ag_plan(c, id, npeers, peers, send_offset, recv_offset));
     if(allgather)
-        *allgather = ag;
+        *allgather = ag ? id : 0;
+    return RAMD_OK;
+}
+
+int ramd_comm_halo_release(ramd_comm_t c, int plan)
+{
+    // (the owner of a plan may outlive the communicator: a destroyed one has already given everything back)
+    if(!c || plan <= 0 || !live_comms().count(c))
+        return RAMD_OK;
+    for(size_t i = 0; i < c->ag.size(); ++i)
+        if(c->ag[i].id == plan)
+        {
+            // (an exchange of this plan may still be queued on the ghost stream)
+            (void)hipStreamSynchronize(backend().stream_ghost);
+            dev_free(&c->ag[i].d_idx);
+            if(c->ag[i].d_send)
+                (void)cached_free(c->ag[i].d_send);
+            if(c->ag[i].d_all)
+                (void)cached_free(c->ag[i].d_all);
+            c->ag.erase(c->ag.begin() + (long)i);
+            break;
+        }
     return RAMD_OK;
 }
 
 int ramd_comm_halo_begin(ramd_comm_t c, ramd_vec_t send, ramd_vec_t recv, int npeers, const int* peers,
                          const int64_t* send_offset, const int64_t* recv_offset)
 {
+    return ramd_comm_halo_begin_plan(c, 0, send, recv, npeers, peers, send_offset, recv_offset);
+}
+
+int ramd_comm_halo_begin_plan(ramd_comm_t c, int plan, ramd_vec_t send, ramd_vec_t recv, int npeers, const int* peers,
+                              const int64_t* send_offset, const int64_t* recv_offset)
+{
     if(!c)
         return RAMD_OK;
-    const bool ag_form = c->size > 1 && npeers >= 0
-                         && halo_use_allgather(c, halo_plan_key(npeers, peers, send_offset, recv_offset));
+    const bool ag_form = c->size > 1 && npeers >= 0 && plan > 0;
     if(npeers <= 0 && !ag_form)
         return RAMD_OK;
     if(!send || !recv || (npeers > 0 && (!peers || !send_offset || !recv_offset)) || send->dtype != recv->dtype)
@@ -442,7 +449,14 @@ int ramd_comm_halo_begin(ramd_comm_t c, ramd_vec_t send, ramd_vec_t recv, int np
         // (a collective: every rank of the communicator is here for this exchange, also one without neighbours -- the
         //  form was agreed on when the plan was announced, ramd_comm_halo_select)
         ramd_comm_s::AgPlan* pl = nullptr;
-        RAMD_TRY(halo_ag_plan(c, es, npeers, peers, send_offset, recv_offset, &pl));
+        for(auto& q : c->ag)
+            if(q.id == plan)
+                pl = &q;
+        if(!pl)
+            RAMD_FAIL(RAMD_ERR_STATE, "halo_begin: unknown all-gather plan (ramd_comm_halo_select hands out the number)");
+        if(pl->npeers != npeers || pl->nsend != (npeers > 0 ? send_offset[npeers] : 0)
+           || pl->nrecv != (npeers > 0 ? recv_offset[npeers] : 0))
+            RAMD_FAIL(RAMD_ERR_ARG, "halo_begin: peers / offsets differ from the plan announced under this number");
         prof_begin(RAMD_PROF_HALO, b.stream_ghost);
         const size_t sb = npeers > 0 ? (size_t)send_offset[npeers] * es : 0;
         if(sb > 0)

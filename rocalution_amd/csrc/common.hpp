@@ -94,6 +94,9 @@ hipError_t cached_malloc_apart(void** p, size_t bytes, const void* other); // in
 int        cached_block_class(const void* p); // 0 / 1, or -1 (small block, not classified)
 void       build_mark(const char* what); // RAMD_BUILD_VERBOSE: device-synchronised wall time since the previous mark (stderr)
 float      probe_write_pair_ms(void* a, void* b, size_t bytes); // one pass writing both blocks at once (zeros), best of 4
+// may a placement measurement take `blocks` more blocks of `bytes` each?  Only while that leaves a sixteenth of the device
+// (at least 2 GiB) free: placement is an optimisation and must never be what runs a memory-tight solve out of memory
+bool       placement_room(size_t bytes, int blocks);
 void       cached_release_all(void);
 template <typename X>
 inline hipError_t cached_malloc(X** p, size_t bytes)

@@ -655,12 +655,19 @@ __global__ __launch_bounds__(BLOCK) void k_ilu0_rows(int nrow, const int* __rest
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_max_row_len(int n, const int* __restrict__ rp, int* __restrict__ out)
+// register slots a row needs in k_ilu0_rows: its entries, plus one where NO entry sits at or right of the diagonal (columns
+// are sorted: the last one is left of it) -- such a row has its "pivot entry" one past its end, and a row of exactly W
+// entries of that kind would not fit W slots (its last column would be dropped and a foreign value slot written)
+__global__ __launch_bounds__(kBlock) void k_max_row_len(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                        int* __restrict__ out)
 {
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
     int           mx  = 0;
     for(int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gsz)
-        mx = max(mx, rp[r + 1] - rp[r]);
+    {
+        const int rs = rp[r], re = rp[r + 1];
+        mx = max(mx, re - rs + ((re > rs && ci[re - 1] < (int)r) ? 1 : 0));
+    }
 #pragma unroll
     for(int off = 32; off > 0; off >>= 1)
         mx = max(mx, __shfl_xor(mx, off, 64));
@@ -4132,7 +4139,7 @@ static int ilu0_t(ramd_mat_s* m)
     {
         int  maxlen = 0;
         int* dmax   = done; // (borrowed: zeroed above, zeroed again below)
-        hipLaunchKernelGGL(k_max_row_len, dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, m->rp, dmax);
+        hipLaunchKernelGGL(k_max_row_len, dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, dmax);
         hipError_t e = hipMemcpyAsync(&maxlen, dmax, sizeof(int), hipMemcpyDeviceToHost, b.cur);
         if(e == hipSuccess)
             e = hipMemsetAsync(dmax, 0, sizeof(int), b.cur);

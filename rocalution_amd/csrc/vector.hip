@@ -551,6 +551,14 @@ int ramd_placement_seconds(double* seconds, int reset)
     return RAMD_OK;
 }
 
+int ramd_placement_room(int64_t bytes, int blocks, int* ok)
+{
+    if(!ok || bytes < 0 || blocks < 0)
+        RAMD_FAIL(RAMD_ERR_ARG, "placement_room: bad arguments");
+    *ok = placement_room((size_t)bytes + kPad, blocks) ? 1 : 0;
+    return RAMD_OK;
+}
+
 int ramd_vec_place_apart(ramd_vec_t v, ramd_vec_t other, int* moved)
 {
     CHECK_VEC(v);
@@ -567,16 +575,23 @@ int ramd_vec_place_apart(ramd_vec_t v, ramd_vec_t other, int* moved)
     // the vector keeps its block unless one of a few fresh candidates -- drawn from the other placement class first -- is
     // clearly faster with `other`; the contents move with it.
     const size_t pb = bytes & ~(size_t)4095;
+    // (scratch + keep + one candidate: placement is an optimisation -- without room for it the vector stays where it is)
+    if(!placement_room(bytes + kPad, 3))
+        return RAMD_OK;
     void*        scratch = nullptr; // `other` is in use: probe against a copy of nothing -- its block is written, so save it
-    RAMD_HIP(cached_malloc_bytes(&scratch, bytes + kPad));
-    RAMD_HIP(hipMemcpyAsync(scratch, other->d, bytes, hipMemcpyDeviceToDevice, backend().cur));
-    void* keep = nullptr; // ... and the vector's own contents
-    hipError_t e = cached_malloc_bytes(&keep, bytes + kPad);
-    if(e != hipSuccess)
+    if(cached_malloc_bytes(&scratch, bytes + kPad) != hipSuccess)
     {
-        (void)cached_free(scratch);
-        RAMD_HIP(e);
+        (void)hipGetLastError();
+        return RAMD_OK;
     }
+    void* keep = nullptr; // ... and the vector's own contents
+    if(cached_malloc_bytes(&keep, bytes + kPad) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        (void)cached_free(scratch);
+        return RAMD_OK;
+    }
+    RAMD_HIP(hipMemcpyAsync(scratch, other->d, bytes, hipMemcpyDeviceToDevice, backend().cur));
     (void)hipMemcpyAsync(keep, v->d, bytes, hipMemcpyDeviceToDevice, backend().cur);
     (void)hipStreamSynchronize(backend().cur);
     float              best_ms = probe_write_pair_ms(v->d, other->d, pb);
@@ -590,7 +605,7 @@ int ramd_vec_place_apart(ramd_vec_t v, ramd_vec_t other, int* moved)
     for(int k = 0; k < 5 && worst_ms < 1.07f * best_ms; ++k) // (each candidate is a fresh allocation: 1 ... 100 ms per GiB)
     {
         void* c = nullptr;
-        if(cached_malloc_apart(&c, bytes + kPad, other->d) != hipSuccess)
+        if(!placement_room(bytes + kPad, 1) || cached_malloc_apart(&c, bytes + kPad, other->d) != hipSuccess)
         {
             (void)hipGetLastError();
             break;
@@ -656,7 +671,9 @@ int ramd_vec_place_by_trial(ramd_vec_t v, ramd_trial_cb run, void* ctx, int trie
     RAMD_HIP(hipEventCreate(&e1));
     void* const own  = v->d;
     void*       keep = nullptr;
-    if(cached_malloc_bytes(&keep, bytes + kPad) != hipSuccess)
+    // (the saved contents + one candidate; every further candidate is asked for again below -- losers stay allocated
+    //  until the end so that a draw never returns a block already seen)
+    if(!placement_room(bytes + kPad, 2) || cached_malloc_bytes(&keep, bytes + kPad) != hipSuccess)
     {
         (void)hipGetLastError();
         (void)hipEventDestroy(e0);
@@ -696,8 +713,10 @@ int ramd_vec_place_by_trial(ramd_vec_t v, ramd_trial_cb run, void* ctx, int trie
         void* c = nullptr;
         // (apart_from: the first candidates come from the placement class that vector's block is NOT in -- fresh blocks of
         //  one process tend to share a class, and for two vectors a kernel writes the other class is the likely fast one)
-        const hipError_t ea = (apart_from && apart_from->d && k < 3) ? cached_malloc_apart(&c, bytes + kPad, apart_from->d)
-                                                                     : cached_malloc_bytes(&c, bytes + kPad);
+        const hipError_t ea = !placement_room(bytes + kPad, 1)
+                                  ? hipErrorOutOfMemory
+                                  : ((apart_from && apart_from->d && k < 3) ? cached_malloc_apart(&c, bytes + kPad, apart_from->d)
+                                                                            : cached_malloc_bytes(&c, bytes + kPad));
         if(ea != hipSuccess)
         {
             (void)hipGetLastError();

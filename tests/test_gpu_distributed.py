@@ -314,3 +314,61 @@ def test_aggregation_amg_on_the_global_matrix(ra, S, kind):
             # (aggregates that stop at the rank boundaries cost iterations as the blocks get thinner -- measured 10 / 11 / 16
             #  for SA-AMG on the 120 x 120 nine-point grid over 1 / 2 / 4 ranks; a wrong coarse coupling does not converge at all)
             assert it <= 2 * it1, (tag, w, it, it1)
+
+
+def _bench_line(*flags, timeout=900, env=None):
+    """runs bench.py as the driver does (self-spawning for --gpus N > 1) and returns its ONE JSON line"""
+    import json
+    import subprocess
+    e = dict(os.environ)
+    e.pop("RANK", None); e.pop("WORLD_SIZE", None); e.pop("LOCAL_RANK", None)
+    if env:
+        e.update(env)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + [str(f) for f in flags], env=e, timeout=timeout,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_multi_rank_path_rehearsed_on_one_gpu(world):
+    """The N > 1 branch of bench.py -- per-rank z-slabs, the Global solver, the HIP-event channels of the scaling leg, the
+    per-rank aggregation, the max-over-ranks timing -- executed with N processes on ONE device over the host-staged
+    transport (`--transport callback`), as the driver will execute it with one GPU per rank over RCCL: the JSON line is
+    complete, the slabs add up to the operator, CG costs one halo exchange and two all-reduces per iteration, and the
+    iterates are those of the one-rank run (same residual after the same number of iterations)."""
+    N, K, W = 96, 30, 5
+    one = _bench_line("--gpus", 1, "--grid", N, "--steps", K, "--warmup", W, "--no-cpu-baseline", "--no-reference-gpu",
+                      "--no-extras")
+    assert one["n_gpus"] == 1 and one["steps"] == K and one["value"] > 0
+    out = _bench_line("--gpus", world, "--grid", N, "--steps", K, "--warmup", W, "--transport", "callback")
+    assert out["n_gpus"] == world and out["steps"] == K and out["warmup"] == W
+    assert out["value"] > 0 and abs(out["value"] * out["ms_per_step"] * 1e-3 - 1.0) < 1e-3
+    assert out["scaling"] == "strong" and out["unit"] == "iters/s" and out["higher_is_better"] is True
+    assert out["rehearsal"] is True and out["transport"].startswith("callback") and out["rccl_nranks"] == 0
+    assert out["metric"] == one["metric"]  # the same metric as the 1-GPU line, on the same operator
+    per = out["roofline"]["per_rank"]
+    assert [r["rank"] for r in per] == list(range(world))
+    assert sum(r["rows"] for r in per) == N ** 3
+    assert sum(r["interior_nnz"] + r["ghost_nnz"] for r in per) == 7 * N ** 3 - 6 * N ** 2
+    assert all(r["iters"] == min(K, 100) and r["spmv_avg_ms"] > 0 for r in per)
+    # interior ranks talk to two neighbours, the end ranks to one: everybody exchanges once per product
+    assert out["halo_exchanges_per_iter"] == pytest.approx(1.0, abs=0.1)
+    assert out["allreduces_per_iter"] == pytest.approx(2.0, abs=0.15)  # <p,q> and {||r||^2, <r,z>} (cg.cpp:410-438: three)
+    assert out["roofline"]["peak"] == 8000.0 * world and 0 < out["roofline"]["frac"] < 1
+    assert out["halo_ms"] > 0 and out["halo_overlap_frac"] is not None
+    # the same Krylov iterates: residual after W + K iterations agrees with the one-rank run (dots summed in another order)
+    assert out["final_residual"] == pytest.approx(one["final_residual"], rel=1e-6)
+
+
+@pytest.mark.parametrize("flags", [("--solver", "bicgstab", "--precond", "mcsgs", "--format", "ell"),
+                                   ("--solver", "mixed"),
+                                   ("--solver", "gmres", "--precond", "ilu0")])
+def test_bench_other_configs_multi_rank_rehearsal(flags):
+    """configs 4 / 5 and north_star's second solver through the same N > 1 branch (2 ranks on one device)"""
+    out = _bench_line("--gpus", 2, "--grid", 64, "--steps", 12, "--warmup", 3, "--transport", "callback", *flags)
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["rehearsal"] is True
+    assert sum(r["rows"] for r in out["roofline"]["per_rank"]) == 64 ** 3
+    assert np.isfinite(out["final_residual"])

@@ -522,6 +522,32 @@ def test_ilu0_rows_in_registers_irregular_vs_oracle(ra, oracle, dtype, reach, si
     eq(M.CopyToCSR()[2], oracle.ilu0(rp, ci, va))
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("width", [8, 16])
+def test_ilu0_rows_without_an_entry_at_or_right_of_the_diagonal(ra, oracle, dtype, width):
+    """a row of EXACTLY 8 (16) entries, all of them left of the diagonal, has its pivot position one past its end: it needs
+    one register slot more than it has entries (the 8-entry form would drop its last column and write a foreign value
+    slot).  Such rows take the next wider form / the level-order sweep; factors bit for bit.  (No later row uses such a
+    row as a pivot row: the reference reads past the end of the row there.)"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(width)
+    n = 1 << 14
+    A = sp.diags([rng.uniform(-1, 0, n - 2), rng.uniform(-1, 0, n - 1), np.full(n, 5.0), rng.uniform(-1, 0, n - 1)],
+                 [-2, -1, 0, 1]).tolil()
+    odd = list(range(100, n - 100, 517))
+    for r in odd:
+        A[:, r] = 0.0  # nobody depends on row r
+        A[r, :] = 0.0
+        A[r, r - width:r] = rng.uniform(-1, -0.1, width)  # `width` entries, none at or right of the diagonal
+    A = A.tocsr(); A.eliminate_zeros(); A.sort_indices()
+    rp, ci, va = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(dtype)
+    assert np.diff(rp).max() == width and all(ci[rp[r + 1] - 1] < r for r in odd)
+    M = ra.LocalMatrix(dtype=dtype)
+    M.SetDataPtrCSR(rp, ci, va)
+    M.ILU0Factorize()
+    eq(M.CopyToCSR()[2], oracle.ilu0(rp, ci, va))
+
+
 def test_ilu_lusolve_27_point_stencil_vs_oracle(ra, oracle):
     """13 strictly-lower entries per row: the eight-lanes-per-row form of the box-tile solve on cubic tiles (the shell
     surrogate exercises it on 2-D parallelograms), ILU(0) by the wave-per-row sweep -- factors and solutions bit for bit"""
