@@ -738,6 +738,12 @@ def main():
             rg = reference_gpu(args)
             if rg is not None:
                 out["reference_gpu"] = rg
+            # ... and the same vendor column for the other two legs (rocSPARSE csrsv for ILU(0): hip_matrix_csr.cpp:1756-1821)
+            for name, so, pc in (("gmres30_ilu0", "gmres", "ilu0"), ("bicgstab_mcsgs", "bicgstab", "mcsgs")):
+                if name in extras and "iters" in extras[name]:
+                    rg = reference_gpu(argparse.Namespace(**dict(vars(args), solver=so, precond=pc, steps=extras[name]["iters"])))
+                    if rg is not None:
+                        extras[name]["reference_gpu"] = rg
         C.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
     if mtx_generated and mtx_path and os.path.exists(mtx_path):

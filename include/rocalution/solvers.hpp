@@ -817,25 +817,20 @@ public:
             delete this->m_preconditioner;
             this->m_preconditioner = NULL;
         }
-        for(size_t i = 0; i < this->m_block.size(); ++i)
-            delete this->m_block[i];
-        for(size_t i = 0; i < this->m_x_block.size(); ++i)
-        {
-            delete this->m_x_block[i];
-            delete this->m_diag_block[i];
-            delete this->m_diag_solver[i];
-        }
-        this->m_block.clear();
-        this->m_x_block.clear();
-        this->m_diag_block.clear();
-        this->m_diag_solver.clear();
+        this->m_pieces.clear();
+        this->m_plan.clear();
         free_host(&this->m_block_sizes);
         this->m_num_blocks = 0;
         this->m_diag.Clear();
         this->m_x.Clear();
+        this->m_y.Clear();
         this->m_permutation.Clear();
         this->m_build = false;
     }
+    // The apply outside the fused colour sweeps (relaxation parameter != 1, SetPrecondMatrixFormat, SetFusedSweeps(false),
+    // SetDecomposition(false)): ONE loop over a list of steps the concrete preconditioner wrote down at Build()
+    // (doWritePlan) -- the same operations on the same operands in the same order as the fused sweeps, so both forms give
+    // the same bits (tests: pc_mcsgs / pc_mcgs / pc_mcilu goldens in both forms).
     virtual void Solve(const VectorType& rhs, VectorType* x)
     {
         RAMD_EXPECT(this->m_build && x != nullptr && x != &rhs);
@@ -844,19 +839,118 @@ public:
             this->doApplySweeps(rhs, x);
             return;
         }
+        this->m_x.CopyFromPermute(rhs, this->m_permutation);
+        VectorType* whole = &this->m_x; // (the form without pieces: where the permuted vector currently is)
         if(this->m_decomp)
+            for(size_t c = 0; c < this->m_pieces.size(); ++c)
+                this->m_pieces[c]->x.CopyFrom(this->m_x, this->m_pieces[c]->first, 0, this->m_pieces[c]->size);
+        for(size_t k = 0; k < this->m_plan.size(); ++k)
         {
-            this->doExtractRHSinX(rhs, x);
-            this->doSolveL();
-            this->doSolveD();
-            this->doSolveR();
-            this->doInsertSolution(x);
+            const Step& st = this->m_plan[k];
+            Piece*      pc = st.colour >= 0 ? this->m_pieces[(size_t)st.colour].get() : NULL;
+            VectorType* other = (whole == &this->m_x) ? &this->m_y : &this->m_x;
+            switch(st.what)
+            {
+            case Step::SubtractCoupling: // x_i -= A_ij x_j
+                if(pc->coupling[(size_t)st.with] != nullptr)
+                    pc->coupling[(size_t)st.with]->ApplyAdd(this->m_pieces[(size_t)st.with]->x, num<ValueType>(-1), &pc->x);
+                break;
+            case Step::DivideByDiagonal: // the Jacobi solve with block (i,i): nothing stored there = identity
+                if(pc->inv_diag.GetSize() > 0)
+                    pc->x.PointWiseMult(pc->inv_diag);
+                break;
+            case Step::MultiplyByDiagonal:
+                if(pc != NULL)
+                    pc->x.PointWiseMult(pc->diag);
+                else
+                    whole->PointWiseMult(this->m_diag);
+                break;
+            case Step::Scale:
+                pc->x.Scale(st.factor);
+                break;
+            case Step::WholeLower:
+                this->m_preconditioner->LSolve(*whole, other);
+                whole = other;
+                break;
+            case Step::WholeUpper:
+                this->m_preconditioner->USolve(*whole, other);
+                whole = other;
+                break;
+            case Step::WholeLU:
+                this->m_preconditioner->LUSolve(*whole, other);
+                whole = other;
+                break;
+            case Step::NotProvided:
+                say("No implemented yet");
+                RAMD_DIE();
+                break;
+            }
         }
-        else
-            this->doSolve(rhs, x);
+        if(this->m_decomp)
+            for(size_t c = 0; c < this->m_pieces.size(); ++c)
+                whole->CopyFrom(this->m_pieces[c]->x, 0, this->m_pieces[c]->first, this->m_pieces[c]->size);
+        x->CopyFromPermuteBackward(*whole, this->m_permutation);
     }
 
 protected:
+    // one entry of the apply's step list
+    struct Step
+    {
+        enum What
+        {
+            SubtractCoupling,
+            DivideByDiagonal,
+            MultiplyByDiagonal,
+            Scale,
+            WholeLower,
+            WholeUpper,
+            WholeLU,
+            NotProvided // (a form the reference does not have either: fails when applied, as there)
+        };
+        What      what;
+        int       colour; // the colour the step writes (-1: the whole permuted vector)
+        int       with; // SubtractCoupling: the colour whose values are read
+        ValueType factor; // Scale
+    };
+    // what the apply keeps per colour i: its slice of the permuted vector, the diagonal of block (i,i) and its Jacobi
+    // inverse, and the blocks (i,j), j != i, that couple it to other colours (only those that store entries)
+    struct Piece
+    {
+        int64_t                                    first, size;
+        VectorType                                 x, diag, inv_diag;
+        std::vector<std::unique_ptr<OperatorType>> coupling;
+    };
+    static void note(std::vector<Step>* plan, typename Step::What what, int colour, int with = -1,
+                     ValueType factor = num<ValueType>(1))
+    {
+        Step st = {what, colour, with, factor};
+        plan->push_back(st);
+    }
+    // forward part of a Gauss-Seidel-type apply over the colours: x_i -= sum_{j<i} A_ij x_j [; x_i = D_i^-1 x_i] [; x_i *= f]
+    static void note_forward(std::vector<Step>* plan, int nb, bool divide, bool scale, ValueType f)
+    {
+        for(int i = 0; i < nb; ++i)
+        {
+            for(int j = 0; j < i; ++j)
+                note(plan, Step::SubtractCoupling, i, j);
+            if(divide)
+                note(plan, Step::DivideByDiagonal, i);
+            if(scale)
+                note(plan, Step::Scale, i, -1, f);
+        }
+    }
+    // backward part: colours descending, their couplings descending as well (the order of the reference's sums)
+    static void note_backward(std::vector<Step>* plan, int nb, bool scale, ValueType f)
+    {
+        for(int i = nb - 1; i >= 0; --i)
+        {
+            for(int j = nb - 1; j > i; --j)
+                note(plan, Step::SubtractCoupling, i, j);
+            note(plan, Step::DivideByDiagonal, i);
+            if(scale)
+                note(plan, Step::Scale, i, -1, f);
+        }
+    }
     virtual void doFactorize(void) {}
     virtual void doPostAnalyse(void) {}
     virtual bool doCanFuseSweeps(void) const
@@ -867,6 +961,8 @@ protected:
     {
         return RAMD_MC_SGS;
     }
+    // the steps of one apply: pieces == true for the decomposed form, false for the whole permuted matrix
+    virtual void doWritePlan(std::vector<Step>* plan, bool pieces) const = 0;
     template <class O = OperatorType>
     typename std::enable_if<std::is_same<O, LocalMatrix<ValueType>>::value, bool>::type doTryBuildSweeps(void)
     {
@@ -898,108 +994,72 @@ protected:
         doApplySweeps(const VectorType&, VectorType*)
     {
     }
-    virtual void doSolveL(void) = 0;
-    virtual void doSolveD(void) = 0;
-    virtual void doSolveR(void) = 0;
-    virtual void doSolve(const VectorType& rhs, VectorType* x) = 0;
-
-    OperatorType* m_blk(int i, int j)
-    {
-        return this->m_block[(size_t)i * this->m_num_blocks + j];
-    }
+    // Build(), outside the fused sweeps: cut P A P^T into the colours' pieces (or keep it whole) and write the step list
     void doDecompose(void)
     {
         const int nb = this->m_num_blocks;
-        if(this->m_decomp)
+        this->m_x.CloneBackend(*this->m_op);
+        this->m_x.Allocate("permuted vector", this->m_op->GetM());
+        this->m_plan.clear();
+        this->doWritePlan(&this->m_plan, this->m_decomp);
+        if(!this->m_decomp)
         {
-            std::vector<int> offsets((size_t)nb + 1, 0);
-            for(int i = 0; i < nb; ++i)
-                offsets[i + 1] = offsets[i] + this->m_block_sizes[i];
-            this->m_block.assign((size_t)nb * nb, NULL);
-            std::vector<OperatorType**> rows((size_t)nb);
-            for(int i = 0; i < nb; ++i)
-            {
-                for(int j = 0; j < nb; ++j)
-                {
-                    this->m_block[(size_t)i * nb + j] = new OperatorType;
-                    this->m_block[(size_t)i * nb + j]->CloneBackend(*this->m_op);
-                }
-                rows[i] = &this->m_block[(size_t)i * nb];
-            }
-            this->m_preconditioner->ExtractSubMatrices(nb, nb, offsets.data(), offsets.data(),
-                                                      rows.data());
-            this->m_x_block.assign((size_t)nb, NULL);
-            this->m_diag_block.assign((size_t)nb, NULL);
-            this->m_diag_solver.assign((size_t)nb, NULL);
-            for(int i = 0; i < nb; ++i)
-            {
-                this->m_diag_block[i] = new VectorType;
-                this->m_diag_block[i]->CloneBackend(*this->m_op);
-                this->m_diag_block[i]->Allocate("Diagonal preconditioners blocks", this->m_block_sizes[i]);
-                this->m_blk(i, i)->ExtractDiagonal(this->m_diag_block[i]);
-                this->m_x_block[i] = new VectorType;
-                this->m_x_block[i]->CloneBackend(*this->m_op);
-                this->m_x_block[i]->Allocate("MultiColored Preconditioner x_block",
-                                            this->m_block_sizes[i]);
-                Jacobi<OperatorType, VectorType, ValueType>* jacobi
-                    = new Jacobi<OperatorType, VectorType, ValueType>;
-                jacobi->SetOperator(*this->m_blk(i, i));
-                jacobi->Build();
-                this->m_diag_solver[i] = jacobi;
-                this->m_blk(i, i)->Clear();
-            }
-            if(this->m_op_mat_format)
-                for(int i = 0; i < nb; ++i)
-                    for(int j = 0; j < nb; ++j)
-                        if(this->m_blk(i, j)->GetNnz() > 0)
-                            this->m_blk(i, j)->ConvertTo(this->m_precond_mat_format,
-                                                        this->m_format_block_dim);
-        }
-        else
-        {
+            this->m_y.CloneBackend(*this->m_op);
+            this->m_y.Allocate("permuted vector (second)", this->m_op->GetM());
             this->m_diag.CloneBackend(*this->m_op);
             this->m_preconditioner->ExtractDiagonal(&this->m_diag);
+            return;
         }
-        this->m_x.CloneBackend(*this->m_op);
-        this->m_x.Allocate("Permuted solution vector", this->m_op->GetM());
-    }
-    void doExtractRHSinX(const VectorType& rhs, VectorType* x)
-    {
-        x->CopyFromPermute(rhs, this->m_permutation);
-        int64_t off = 0;
-        for(int i = 0; i < this->m_num_blocks; ++i)
+        int64_t first = 0;
+        for(int i = 0; i < nb; ++i)
         {
-            this->m_x_block[i]->CopyFrom(*x, off, 0, this->m_block_sizes[i]);
-            off += this->m_block_sizes[i];
+            std::unique_ptr<Piece> pc(new Piece);
+            pc->first = first;
+            pc->size  = this->m_block_sizes[i];
+            pc->x.CloneBackend(*this->m_op);
+            pc->x.Allocate("colour slice", pc->size);
+            pc->coupling.resize((size_t)nb);
+            int64_t col = 0;
+            for(int j = 0; j < nb; ++j)
+            {
+                std::unique_ptr<OperatorType> blk(new OperatorType);
+                blk->CloneBackend(*this->m_op);
+                this->m_preconditioner->ExtractSubMatrix(first, col, pc->size, this->m_block_sizes[j], blk.get());
+                col += this->m_block_sizes[j];
+                if(j == i)
+                {
+                    pc->diag.CloneBackend(*this->m_op);
+                    pc->diag.Allocate("colour diagonal", pc->size);
+                    blk->ExtractDiagonal(&pc->diag);
+                    pc->inv_diag.CloneBackend(*this->m_op);
+                    blk->ExtractInverseDiagonal(&pc->inv_diag); // (stays empty for a block without entries)
+                }
+                else if(blk->GetNnz() > 0)
+                {
+                    if(this->m_op_mat_format)
+                        blk->ConvertTo(this->m_precond_mat_format, this->m_format_block_dim);
+                    pc->coupling[(size_t)j] = std::move(blk);
+                }
+            }
+            first += pc->size;
+            this->m_pieces.push_back(std::move(pc));
         }
-    }
-    void doInsertSolution(VectorType* x)
-    {
-        int64_t off = 0;
-        for(int i = 0; i < this->m_num_blocks; ++i)
-        {
-            this->m_x.CopyFrom(*this->m_x_block[i], 0, off, this->m_block_sizes[i]);
-            off += this->m_block_sizes[i];
-        }
-        x->CopyFromPermuteBackward(this->m_x, this->m_permutation);
     }
 
-    bool                          m_op_mat_format;
-    unsigned int                  m_precond_mat_format;
-    int                           m_format_block_dim;
-    bool                          m_decomp;
-    bool                          m_fused_sweeps;
-    ramd_mcsgs_t                  m_sweeps;
-    OperatorType*                 m_preconditioner;
-    std::vector<OperatorType*>    m_block; // [i*nb+j]
-    std::vector<VectorType*>      m_x_block;
-    std::vector<VectorType*>      m_diag_block;
-    std::vector<Solver<OperatorType, VectorType, ValueType>*> m_diag_solver;
-    VectorType                    m_x;
-    VectorType                    m_diag;
-    int                           m_num_blocks;
-    int*                          m_block_sizes;
-    LocalVector<int>              m_permutation;
+    bool                                m_op_mat_format;
+    unsigned int                        m_precond_mat_format;
+    int                                 m_format_block_dim;
+    bool                                m_decomp;
+    bool                                m_fused_sweeps;
+    ramd_mcsgs_t                        m_sweeps;
+    OperatorType*                       m_preconditioner;
+    std::vector<std::unique_ptr<Piece>> m_pieces;
+    std::vector<Step>                   m_plan;
+    VectorType                          m_x, m_y;
+    VectorType                          m_diag;
+    int                                 m_num_blocks;
+    int*                                m_block_sizes;
+    LocalVector<int>                    m_permutation;
 };
 
 template <class OperatorType, class VectorType, typename ValueType>
@@ -1035,56 +1095,35 @@ protected:
         this->m_preconditioner->LAnalyse(false);
         this->m_preconditioner->UAnalyse(false);
     }
-    void m_sweep_block(int i, int j)
+    // SSOR over the colours (preconditioner_multicolored_gs.cpp:127-215): forward Gauss-Seidel part, the diagonal, the
+    // backward part; with a relaxation parameter the three parts carry the factors 1/w, w/(2-w), 1/w
+    virtual void doWritePlan(std::vector<typename MultiColored<OperatorType, VectorType, ValueType>::Step>* plan, bool pieces) const
     {
-        if(this->m_blk(i, j)->GetNnz() > 0)
-            this->m_blk(i, j)->ApplyAdd(*this->m_x_block[j], num<ValueType>(-1),
-                                       this->m_x_block[i]);
-    }
-    virtual void doSolveL(void)
-    {
-        for(int i = 0; i < this->m_num_blocks; ++i)
+        typedef typename MultiColored<OperatorType, VectorType, ValueType>::Step Step;
+        if(!pieces)
         {
-            for(int j = 0; j < i; ++j)
-                this->m_sweep_block(i, j);
-            this->m_diag_solver[i]->Solve(*this->m_x_block[i], this->m_x_block[i]);
-            if(this->m_omega != num<ValueType>(1))
-                this->m_x_block[i]->Scale(num<ValueType>(1) / this->m_omega);
+            this->note(plan, Step::WholeLower, -1);
+            this->note(plan, Step::MultiplyByDiagonal, -1);
+            this->note(plan, Step::WholeUpper, -1);
+            return;
         }
-    }
-    virtual void doSolveD(void)
-    {
-        for(int i = 0; i < this->m_num_blocks; ++i)
+        const int       nb    = this->m_num_blocks;
+        const bool      relax = this->m_omega != num<ValueType>(1);
+        const ValueType f     = num<ValueType>(1) / this->m_omega;
+        this->note_forward(plan, nb, true, relax, f);
+        for(int i = 0; i < nb; ++i)
         {
-            this->m_x_block[i]->PointWiseMult(*this->m_diag_block[i]);
-            if(this->m_omega != num<ValueType>(1))
-                this->m_x_block[i]->Scale(this->m_omega / (num<ValueType>(2) - this->m_omega));
+            this->note(plan, Step::MultiplyByDiagonal, i);
+            if(relax)
+                this->note(plan, Step::Scale, i, -1, this->m_omega / (num<ValueType>(2) - this->m_omega));
         }
-    }
-    virtual void doSolveR(void)
-    {
-        for(int i = this->m_num_blocks - 1; i >= 0; --i)
-        {
-            for(int j = this->m_num_blocks - 1; j > i; --j) // descending j, as the reference
-                this->m_sweep_block(i, j);
-            this->m_diag_solver[i]->Solve(*this->m_x_block[i], this->m_x_block[i]);
-            if(this->m_omega != num<ValueType>(1))
-                this->m_x_block[i]->Scale(num<ValueType>(1) / this->m_omega);
-        }
-    }
-    virtual void doSolve(const VectorType& rhs, VectorType* x)
-    {
-        this->m_x.CopyFromPermute(rhs, this->m_permutation);
-        this->m_preconditioner->LSolve(this->m_x, x);
-        x->PointWiseMult(this->m_diag);
-        this->m_preconditioner->USolve(*x, &this->m_x);
-        x->CopyFromPermuteBackward(this->m_x, this->m_permutation);
+        this->note_backward(plan, nb, relax, f);
     }
     ValueType m_omega;
 };
 
 // preconditioner_multicolored_gs.cpp:218-288: class MultiColoredGS : public MultiColoredSGS --
-// backward sweep only (doSolveL/doSolveD empty); the non-decomposed form is "No implemented yet" there too
+// the backward part only; the form on the whole permuted matrix is "No implemented yet" there too
 template <class OperatorType, class VectorType, typename ValueType>
 class MultiColoredGS : public MultiColoredSGS<OperatorType, VectorType, ValueType>
 {
@@ -1110,12 +1149,16 @@ protected:
     {
         this->m_preconditioner->UAnalyse(false);
     }
-    virtual void doSolveL(void) {}
-    virtual void doSolveD(void) {}
-    virtual void doSolve(const VectorType&, VectorType*)
+    // the backward part alone; the reference has no form on the whole permuted matrix either ("No implemented yet")
+    virtual void doWritePlan(std::vector<typename MultiColored<OperatorType, VectorType, ValueType>::Step>* plan, bool pieces) const
     {
-        say("No implemented yet");
-        RAMD_DIE();
+        if(!pieces)
+        {
+            this->note(plan, MultiColored<OperatorType, VectorType, ValueType>::Step::NotProvided, -1);
+            return;
+        }
+        const bool relax = this->m_omega != num<ValueType>(1);
+        this->note_backward(plan, this->m_num_blocks, relax, num<ValueType>(1) / this->m_omega);
     }
 };
 
@@ -1180,33 +1223,18 @@ protected:
     {
         this->m_preconditioner->LUAnalyse();
     }
-    void m_sweep_block(int i, int j)
+    // unit lower factor: the forward part has no diagonal solve; the backward part divides by U's diagonal
+    // (preconditioner_multicolored_ilu.cpp:187-232)
+    virtual void doWritePlan(std::vector<typename MultiColored<OperatorType, VectorType, ValueType>::Step>* plan, bool pieces) const
     {
-        if(this->m_blk(i, j)->GetNnz() > 0)
-            this->m_blk(i, j)->ApplyAdd(*this->m_x_block[j], num<ValueType>(-1),
-                                       this->m_x_block[i]);
-    }
-    virtual void doSolveL(void)
-    {
-        for(int i = 0; i < this->m_num_blocks; ++i)
-            for(int j = 0; j < i; ++j)
-                this->m_sweep_block(i, j);
-    }
-    virtual void doSolveD(void) {}
-    virtual void doSolveR(void)
-    {
-        for(int i = this->m_num_blocks - 1; i >= 0; --i)
+        typedef typename MultiColored<OperatorType, VectorType, ValueType>::Step Step;
+        if(!pieces)
         {
-            for(int j = this->m_num_blocks - 1; j > i; --j)
-                this->m_sweep_block(i, j);
-            this->m_diag_solver[i]->Solve(*this->m_x_block[i], this->m_x_block[i]);
+            this->note(plan, Step::WholeLU, -1);
+            return;
         }
-    }
-    virtual void doSolve(const VectorType& rhs, VectorType* x)
-    {
-        x->CopyFromPermute(rhs, this->m_permutation);
-        this->m_preconditioner->LUSolve(*x, &this->m_x);
-        x->CopyFromPermuteBackward(this->m_x, this->m_permutation);
+        this->note_forward(plan, this->m_num_blocks, false, false, num<ValueType>(1));
+        this->note_backward(plan, this->m_num_blocks, false, num<ValueType>(1));
     }
     int     m_q, m_p;
     bool    m_level;

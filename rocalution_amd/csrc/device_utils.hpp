@@ -219,4 +219,35 @@ inline int reduce_grid(int64_t n_items)
     return (int)g;
 }
 
+// XCD-aware mapping: hardware places workgroup b on XCD b % 8 (observed, used for speed only).
+// Every XCD gets one contiguous eighth of the row blocks and walks it in dispatch order, so rows that
+// gather the same x planes are in flight on the same L2 at the same time.
+//
+// Band-aware traversal (P > 0): matrices with a far band at distance D rows (3-D stencils: D = one
+// grid plane) gather x[r-D], x[r], x[r+D]; walking the rows plane by plane puts 2 planes (4 MiB of x at
+// 512^3) between the first and the last use of an x entry -- more than an XCD's L2, so x is fetched from
+// HBM three times (measured: +2 GB per SpMV).  Instead the XCD's range is cut into in-plane tiles of W
+// row blocks and every tile is swept through all planes before the next tile starts: the reuse window
+// shrinks to 3 x W x 2 KiB.  P = D / 256 row blocks per plane, Z = planes in the XCD's range.
+struct BandMap
+{
+    int P, W, Z; // P == 0: linear order
+};
+__device__ __forceinline__ int xcd_block(int nblk, int per_xcd, BandMap bm)
+{
+    const int i = blockIdx.x >> 3; // position in this XCD's dispatch sequence
+    int       l = i;
+    if(bm.P > 0 && i < bm.Z * bm.P)
+    {
+        const int tile   = i / (bm.W * bm.Z);
+        const int within = i - tile * (bm.W * bm.Z);
+        const int z      = within / bm.W;
+        const int w      = within - z * bm.W;
+        l                = z * bm.P + tile * bm.W + w;
+    }
+    const int b = (blockIdx.x & 7) * per_xcd + l;
+    return (i < per_xcd && b < nblk) ? b : -1;
+}
+
+
 } // namespace ramd

@@ -15,6 +15,7 @@
 #include "device_utils.hpp"
 #include "matrix_impl.hpp"
 
+#include <algorithm>
 #include <vector>
 
 namespace ramd
@@ -39,8 +40,21 @@ struct McsgsPlan
     int            l_pat = 0, u_pat = 0, l_pat_n = 0, u_pat_n = 0; // state: 1 usable
     unsigned char *l_pat_id = nullptr, *u_pat_id = nullptr;
     int *          l_pat_dict = nullptr, *u_pat_dict = nullptr;
+    // order in which the workgroups of a colour sweep take the 256-row blocks of the colour (device_utils.hpp: every XCD a
+    // contiguous eighth, walked tile by tile through the planes of a far band): per colour, for the L and the U part
+    std::vector<BandMap> l_bm, u_bm;
+    // Output pairs.  out[iperm[t]] of a colour's rows is a store of every nb-th element: 16 bytes leave the L2 for 8 (counters:
+    // WRITE_SIZE 24 bytes per row where xp and out are written).  The LAST sweep of an apply (colour 0) therefore also
+    // stores the neighbour in the aligned 16-byte pair of its row where that neighbour belongs to another colour -- final
+    // by then, in xp -- and that row's own sweep leaves its store out:
+    //   pair_of [t], t < off[1]   : position of the row that shares the 16-byte pair of out with row t, or -1
+    //   covered [t], t >= off[1]  : 1 = out of this row is stored by its partner's sweep
+    int*           pair_of = nullptr;
+    unsigned char* covered = nullptr;
     void  release()
     {
+        dev_free(&pair_of);
+        dev_free(&covered);
         dev_free(&iperm);
         dev_free(&blk_of);
         dev_free(&l_off);
@@ -174,6 +188,12 @@ __global__ __launch_bounds__(kBlock) void k_mc_fill(int n, int nb, const int* __
 //   BOTH     : last colour: L sweep, D and R sweep of the same row in one go (it has no U part)
 //   TO_OUT   : out[iperm[t]] = s          (folds x = P^T x_)
 //   PAT      : the columns come from the row-pattern dictionary (one byte per row; -1 slots are dictionary entries too)
+//   keep_xp  : 0 where no later sweep reads this colour's xp (the last sweep of an apply): the store is left out
+// Block order: a row of colour i gathers xp of OTHER colours at the positions of its grid neighbours -- under the colour
+// permutation the rows of one colour keep their natural order, so those are the same three "planes" a stencil product
+// gathers, at half the pitch.  With workgroup b on block b every line of xp was fetched by three XCDs (blocks b, b +- 1
+// sit on different XCDs; counters: 24 instead of 8 bytes per row); the XCD- and band-aware order of the CSR product
+// (xcd_block) keeps a line's readers on one L2.
 template <typename T, bool FROM_RHS, bool MULT_D, bool BOTH, bool TO_OUT, bool PAT>
 __global__ __launch_bounds__(kBlock) void k_mc_sweep(int p0, int p1, const int* __restrict__ slice_off,
                                                      const int* __restrict__ ecol,
@@ -181,8 +201,13 @@ __global__ __launch_bounds__(kBlock) void k_mc_sweep(int p0, int p1, const int* 
                                                      const T* __restrict__ d, const T* __restrict__ dinv,
                                                      const int* __restrict__ iperm,
                                                      const T* __restrict__ rhs, T* xp,
-                                                     T* __restrict__ out, int identity, CsrPattern pat)
+                                                     T* __restrict__ out, int identity, CsrPattern pat, int nblk, int per_xcd,
+                                                     BandMap bm, int keep_xp, const int* __restrict__ pair_of,
+                                                     const unsigned char* __restrict__ covered)
 {
+    const int blk = xcd_block(nblk, per_xcd, bm); // (uniform in the workgroup)
+    if(blk < 0)
+        return;
     __shared__ int sdict[PAT ? kPatMax * kPatMaxW : 1];
     if(PAT)
     {
@@ -190,7 +215,7 @@ __global__ __launch_bounds__(kBlock) void k_mc_sweep(int p0, int p1, const int* 
             sdict[i] = pat.dict[i];
         __syncthreads();
     }
-    const int64_t t = (int64_t)p0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t t = (int64_t)p0 + (int64_t)blk * kBlock + threadIdx.x;
     if(t >= p1)
         return;
     const int dbase = PAT ? (int)pat.id[t] * kPatMaxW : 0;
@@ -246,9 +271,107 @@ __global__ __launch_bounds__(kBlock) void k_mc_sweep(int p0, int p1, const int* 
         if(!identity)
             s = s * dinv[t];
     }
-    xp[t] = s;
+    if(keep_xp)
+        xp[t] = s;
     if(TO_OUT)
-        out[orow] = s;
+    {
+        if(pair_of) // (the last sweep: rows of colour 0)
+        {
+            const int q = pair_of[t];
+            if(q >= 0)
+            {
+                using P2 = T __attribute__((ext_vector_type(2)));
+                const T other = xp[q]; // final: every other colour is done
+                P2      v;
+                v.x = (orow & 1) ? other : s;
+                v.y = (orow & 1) ? s : other;
+                *reinterpret_cast<P2*>(out + (orow & ~1)) = v;
+            }
+            else
+                out[orow] = s;
+        }
+        else if(!covered || !covered[t])
+            out[orow] = s;
+    }
+}
+
+// pairs of the output (see McsgsPlan): row t of colour 0 takes the row next to it in its aligned pair of out along where that
+// row has another colour
+__global__ __launch_bounds__(kBlock) void k_mc_pairs(int n, int n0, const int* __restrict__ iperm, const int* __restrict__ perm,
+                                                     int* __restrict__ pair_of, unsigned char* __restrict__ covered)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n0; t += gsz)
+    {
+        const int o = iperm[t] ^ 1;
+        int       q = -1;
+        if(o < n)
+        {
+            const int pq = perm[o];
+            if(pq >= n0)
+            {
+                q           = pq;
+                covered[pq] = 1;
+            }
+        }
+        pair_of[t] = q;
+    }
+}
+
+// half the spread of the columns of sampled rows of [p0, p1): the distance between rows that gather the same far line
+__global__ __launch_bounds__(kBlock) void k_mc_band_sample(int p0, int p1, int stride, const int* __restrict__ slice_off,
+                                                           const int* __restrict__ ecol, int* __restrict__ out)
+{
+    const int     s    = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t t    = (int64_t)p0 + ((int64_t)s * stride + stride / 2) % (p1 - p0);
+    const int     base = slice_off[t >> 6];
+    const int     w    = (slice_off[(t >> 6) + 1] - base) >> 6;
+    int           lo = 0x7fffffff, hi = -1;
+    for(int k = 0; k < w; ++k)
+    {
+        const int c = ecol[base + k * 64 + (int)(t & 63)];
+        if(c < 0)
+            break;
+        lo = min(lo, c);
+        hi = max(hi, c);
+    }
+    out[s] = hi >= lo ? (hi - lo) / 2 : 0;
+}
+
+static int mc_band_map(const McsgsPlan* P, int colour, bool lower, BandMap* bm)
+{
+    *bm = BandMap{0, 0, 0};
+    static const int xcd_env = getenv("RAMD_MC_XCD") ? atoi(getenv("RAMD_MC_XCD")) : 1; // 0: linear order inside an XCD's eighth
+    const int p0 = P->off[(size_t)colour], p1 = P->off[(size_t)colour + 1];
+    if(xcd_env == 0 || p1 - p0 < (1 << 20))
+        return RAMD_OK;
+    Backend&  b       = backend();
+    const int samples = 1024;
+    int*      d       = nullptr;
+    RAMD_TRY(dev_alloc(&d, samples));
+    hipLaunchKernelGGL(k_mc_band_sample, dim3(samples / kBlock), dim3(kBlock), 0, b.cur, p0, p1, std::max(1, (p1 - p0) / samples),
+                       lower ? P->l_off : P->u_off, lower ? P->l_col : P->u_col, d);
+    std::vector<int> h((size_t)samples);
+    hipError_t       e = hipMemcpyAsync(h.data(), d, sizeof(int) * samples, hipMemcpyDeviceToHost, b.cur);
+    if(e == hipSuccess)
+        e = hipStreamSynchronize(b.cur);
+    dev_free(&d);
+    RAMD_HIP(e);
+    std::sort(h.begin(), h.end());
+    const int med = h[samples / 2];
+    const int cnt = (int)(std::upper_bound(h.begin(), h.end(), med) - std::lower_bound(h.begin(), h.end(), med));
+    if(cnt * 2 >= samples && med > 0 && med % kBlock == 0 && (int64_t)med * 8 >= (1 << 19) && med < (p1 - p0) / 16)
+    {
+        const int nblk = (p1 - p0 + kBlock - 1) / kBlock, per_xcd = (nblk + 7) / 8;
+        bm->P = med / kBlock;
+        bm->Z = per_xcd / bm->P;
+        bm->W = 32;
+        while(bm->W > 1 && bm->P % bm->W != 0)
+            bm->W >>= 1;
+        if(bm->Z < 3)
+            bm->P = 0;
+    }
+    return RAMD_OK;
 }
 
 template <typename T>
@@ -337,6 +460,32 @@ static int mc_build(McsgsPlan* P, const ramd_mat_s* m, const int* perm)
         if(s == RAMD_OK)
             s = sell_analyse_pattern(n, P->u_off, P->u_col, &P->u_pat, &P->u_pat_n, &P->u_pat_id, &P->u_pat_dict);
     }
+    P->l_bm.assign((size_t)nb, BandMap{0, 0, 0});
+    P->u_bm.assign((size_t)nb, BandMap{0, 0, 0});
+    for(int i = 0; i < nb && s == RAMD_OK; ++i)
+    {
+        s = mc_band_map(P, i, true, &P->l_bm[(size_t)i]);
+        if(s == RAMD_OK)
+            s = mc_band_map(P, i, false, &P->u_bm[(size_t)i]);
+    }
+    // (8-byte values only: a pair of fp32 values is no full 16-byte store; RAMD_MC_PAIR=0: off)
+    static const int pair_env = getenv("RAMD_MC_PAIR") ? atoi(getenv("RAMD_MC_PAIR")) : 1;
+    if(s == RAMD_OK && pair_env != 0 && nb > 1 && sizeof(T) == 8 && (n >= (1 << 16) || pair_env == 2)) // (2: any size -- tests)
+    {
+        s = dev_alloc(&P->pair_of, P->off[1]);
+        unsigned char* cov = nullptr;
+        if(s == RAMD_OK)
+            s = dev_alloc(&cov, n);
+        if(s == RAMD_OK)
+        {
+            P->covered = cov;
+            hipError_t e = hipMemsetAsync(cov, 0, (size_t)n, b.cur);
+            hipLaunchKernelGGL(k_mc_pairs, dim3(ew_grid(P->off[1])), dim3(kBlock), 0, b.cur, n, P->off[1], P->iperm, perm,
+                               P->pair_of, cov);
+            if(e != hipSuccess)
+                s = RAMD_ERR_HIP;
+        }
+    }
     int* cnt = nullptr;
     if(s == RAMD_OK)
         s = dev_alloc(&cnt, nb);
@@ -374,30 +523,40 @@ static int mc_apply(McsgsPlan* P, int kind, const T* rhs, T* out)
         explicit ProfScope(hipStream_t st) : s(st) { prof_begin(RAMD_PROF_PRECOND, s); }
         ~ProfScope() { prof_end(RAMD_PROF_PRECOND, s); }
     } prof_scope(b.cur);
-#define SWEEP_ID(FR, MD, BO, TO, i, OFFP, COLP, VALP, IDENT)                                             \
+    // (pairs: only in the applies whose LAST sweep with an output is colour 0's and in which every colour stores its output --
+    //  all three kinds; the colour-0 sweep of an apply runs after all others)
+    const bool pairs_on = P->pair_of != nullptr && nb > 1;
+    // (KEEP: does a later sweep of this apply read the colour's xp?)
+#define SWEEP_ID(FR, MD, BO, TO, i, OFFP, COLP, VALP, IDENT, KEEP)                                       \
     do                                                                                                   \
     {                                                                                                    \
         const int  p0 = P->off[(size_t)(i)], p1 = P->off[(size_t)(i) + 1];                               \
         const bool lower_part = (OFFP) == P->l_off;                                                      \
         const bool use_pat    = lower_part ? P->l_pat == 1 : P->u_pat == 1;                              \
+        const int  nblk = (p1 - p0 + kBlock - 1) / kBlock, per_xcd = (nblk + 7) / 8;                     \
+        const BandMap bm = lower_part ? P->l_bm[(size_t)(i)] : P->u_bm[(size_t)(i)];                     \
         if(p1 > p0 && use_pat)                                                                           \
-            hipLaunchKernelGGL((k_mc_sweep<T, FR, MD, BO, TO, true>), dim3((p1 - p0 + kBlock - 1) / kBlock), \
+            hipLaunchKernelGGL((k_mc_sweep<T, FR, MD, BO, TO, true>), dim3(per_xcd * 8),                 \
                                dim3(kBlock), 0, b.cur, p0, p1, OFFP, COLP, (const T*)VALP,               \
                                (const T*)P->d, (const T*)P->dinv, P->iperm, rhs, (T*)P->xp, out,         \
-                               (int)(IDENT), lower_part ? lpat : upat);                                  \
+                               (int)(IDENT), lower_part ? lpat : upat, nblk, per_xcd, bm, (int)(KEEP),   \
+                               (const int*)(((TO) && (i) == 0 && pairs_on) ? P->pair_of : nullptr),      \
+                               (const unsigned char*)(((TO) && (i) > 0 && pairs_on) ? P->covered : nullptr)); \
         else if(p1 > p0)                                                                                 \
-            hipLaunchKernelGGL((k_mc_sweep<T, FR, MD, BO, TO, false>), dim3((p1 - p0 + kBlock - 1) / kBlock), \
+            hipLaunchKernelGGL((k_mc_sweep<T, FR, MD, BO, TO, false>), dim3(per_xcd * 8),                \
                                dim3(kBlock), 0, b.cur, p0, p1, OFFP, COLP, (const T*)VALP,               \
                                (const T*)P->d, (const T*)P->dinv, P->iperm, rhs, (T*)P->xp, out,         \
-                               (int)(IDENT), lpat);                                                      \
+                               (int)(IDENT), lpat, nblk, per_xcd, bm, (int)(KEEP),                       \
+                               (const int*)(((TO) && (i) == 0 && pairs_on) ? P->pair_of : nullptr),      \
+                               (const unsigned char*)(((TO) && (i) > 0 && pairs_on) ? P->covered : nullptr)); \
     } while(0)
-#define SWEEP(FR, MD, BO, TO, i, OFFP, COLP, VALP)                                                       \
-    SWEEP_ID(FR, MD, BO, TO, i, OFFP, COLP, VALP, P->identity[(size_t)(i)])
+#define SWEEP(FR, MD, BO, TO, i, OFFP, COLP, VALP, KEEP)                                                 \
+    SWEEP_ID(FR, MD, BO, TO, i, OFFP, COLP, VALP, P->identity[(size_t)(i)], KEEP)
     if(kind == RAMD_MC_GS)
     {
         // MultiColoredGS (preconditioner_multicolored_gs.cpp:250-288): x = P rhs, SolveR_ only
         for(int i = nb - 1; i >= 0; --i)
-            SWEEP(true, false, false, true, i, P->u_off, P->u_col, P->u_val);
+            SWEEP(true, false, false, true, i, P->u_off, P->u_col, P->u_val, i > 0);
         RAMD_HIP(hipGetLastError());
         return RAMD_OK;
     }
@@ -406,21 +565,21 @@ static int mc_apply(McsgsPlan* P, int kind, const T* rhs, T* out)
         // MultiColoredILU on the ILU(0) factors of P A P^T (preconditioner_multicolored_ilu.cpp:187-232):
         // SolveL_ has no diagonal solve (unit L), SolveD_ is empty, SolveR_ divides by the U diagonal
         for(int i = 0; i + 1 < nb; ++i)
-            SWEEP_ID(true, false, false, false, i, P->l_off, P->l_col, P->l_val, 1);
-        SWEEP(true, false, false, true, nb - 1, P->l_off, P->l_col, P->l_val); // last colour: L and R in one
+            SWEEP_ID(true, false, false, false, i, P->l_off, P->l_col, P->l_val, 1, true);
+        SWEEP(true, false, false, true, nb - 1, P->l_off, P->l_col, P->l_val, nb > 1); // last colour: L and R in one
         for(int i = nb - 2; i >= 0; --i)
-            SWEEP(false, false, false, true, i, P->u_off, P->u_col, P->u_val);
+            SWEEP(false, false, false, true, i, P->u_off, P->u_col, P->u_val, i > 0);
         RAMD_HIP(hipGetLastError());
         return RAMD_OK;
     }
     // SolveL_ for colours 0 .. nb-2
     for(int i = 0; i + 1 < nb; ++i)
-        SWEEP(true, false, false, false, i, P->l_off, P->l_col, P->l_val);
+        SWEEP(true, false, false, false, i, P->l_off, P->l_col, P->l_val, true);
     // last colour: SolveL_ + SolveD_ + SolveR_ of its rows in one sweep (no U part)
-    SWEEP(true, false, true, true, nb - 1, P->l_off, P->l_col, P->l_val);
+    SWEEP(true, false, true, true, nb - 1, P->l_off, P->l_col, P->l_val, nb > 1);
     // SolveD_ + SolveR_ for colours nb-2 .. 0
     for(int i = nb - 2; i >= 0; --i)
-        SWEEP(false, true, false, true, i, P->u_off, P->u_col, P->u_val);
+        SWEEP(false, true, false, true, i, P->u_off, P->u_col, P->u_val, i > 0);
 #undef SWEEP
 #undef SWEEP_ID
     RAMD_HIP(hipGetLastError());

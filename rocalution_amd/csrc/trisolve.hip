@@ -1975,6 +1975,9 @@ struct CtDims
     int infirst; // grouped form: the in-group entries of a row come FIRST in the order of the host loop (upper solve)
     // sorted index lists in 4 bytes per row: (index - the tile's smallest index) << sbits | row number inside the tile
     int in_packed, out_packed, sbits;
+    // stages whose result leaves through `out`: w only hands values over to other tiles, and a step publishes just its rows
+    // that some other tile reads (they come first in the step; their number travels in the step record)
+    int mask_pub;
 };
 constexpr int kCtFetchDepth = 4; // batches of 64 external values the fetch wave keeps in flight
 
@@ -2059,7 +2062,7 @@ static size_t ct_rec_lds_bytes(const CtDims& d)
 __global__ __launch_bounds__(kBlock) void k_ct_step_rec2(int n, int nsteps, const int* __restrict__ step_pos,
                                                          const int* __restrict__ ext_start, const int* __restrict__ tile_of,
                                                          const int* __restrict__ tile_step, int* __restrict__ rec,
-                                                         const int* __restrict__ step_maxg)
+                                                         const int* __restrict__ step_maxg, const int* __restrict__ step_nexp)
 {
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
     for(int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g <= nsteps; g += gsz)
@@ -2076,9 +2079,33 @@ __global__ __launch_bounds__(kBlock) void k_ct_step_rec2(int n, int nsteps, cons
         const int p1   = step_pos[g + 1];
         const int tpos = step_pos[tile_step[tile_of[p]]];
         rec[4 * g + 0] = p;
-        rec[4 * g + 1] = (p1 - p) | ((step_maxg ? max(step_maxg[g], 1) : 1) << 8); // rows | largest group of the step << 8
+        // rows | largest group of the step << 8 | rows of the step, counted from its first, up to the last one another tile reads << 16
+        rec[4 * g + 1] = (p1 - p) | ((step_maxg ? max(step_maxg[g], 1) : 1) << 8) | ((step_nexp ? step_nexp[g] : (p1 - p)) << 16);
         rec[4 * g + 2] = ext_start[p1] - ext_start[tpos];
         rec[4 * g + 3] = p - tpos;
+    }
+}
+
+// rows another tile reads (they are some tile's external values), and per step how far they reach into the step: inside a
+// level the exported rows come first (k_ct_export_class), so this is normally their count
+__global__ __launch_bounds__(kBlock) void k_ct_mark_exported(int64_t next, const int* __restrict__ ext_idx, int* __restrict__ mark)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < next; j += gsz)
+        mark[ext_idx[j]] = 1;
+}
+__global__ __launch_bounds__(kBlock) void k_ct_step_nexp(int nsteps, const int* __restrict__ step_pos, const int* __restrict__ mark,
+                                                         int* __restrict__ nexp)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < nsteps; g += gsz)
+    {
+        const int p0 = step_pos[g], p1 = step_pos[g + 1];
+        int       last = 0;
+        for(int p = p0; p < p1; ++p)
+            if(mark[p])
+                last = p - p0 + 1;
+        nexp[g] = last;
     }
 }
 
@@ -2796,7 +2823,9 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
         {
             int pos, cnt, need, lbase, tn, flags;
         } st = {uni(rec.x), uni(rec.y) & 0xff, uni(rec.z), uni(rec.w), uni(stq.tf) >> 2, uni(stq.tf) & 3};
-        const int maxg = uni(rec.y) >> 8; // grouped form: rows of the step's largest group
+        const int maxg = (uni(rec.y) >> 8) & 0xff; // grouped form: rows of the step's largest group
+        // rows of the step whose value another tile reads: [0, nexp) -- all of them where w is also the stage's result
+        const int nexp = dims.mask_pub ? ((uni(rec.y) >> 16) & 0xff) : 64;
         const int nl   = st.cnt * LPR; // lane records of the step
         const int lrec = min(lane, nl - 1);
         const int row  = (int)((unsigned)lrec / (unsigned)LPR); // row of the step this lane works for
@@ -2993,8 +3022,11 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
         }
         // (LPR = 1: lanes beyond the step's rows repeat its last row; LPR > 1: only the last lane of a row holds it)
         if(kCtWSlot<WL, LPR>)
-            publish(w + (st.pos - st.lbase) + (int)((unsigned)stq.q[0][1] >> 16), sum);
-        else if(LPR == 1 || (sub == LPR - 1 && lane < nl))
+        {
+            if(row < nexp)
+                publish(w + (st.pos - st.lbase) + (int)((unsigned)stq.q[0][1] >> 16), sum);
+        }
+        else if((LPR == 1 || (sub == LPR - 1 && lane < nl)) && row < nexp)
             publish(w + st.pos + row, sum);
         }
         // this step's LDS traffic before the next step's: one wave, in-order LDS queue
@@ -3748,8 +3780,28 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
 #undef CT_FILL_REC_W
 #undef CT_FILL_REC
 #undef CT_FILL_GREC
-        hipLaunchKernelGGL(k_ct_step_rec2, dim3(ew_grid(nsteps + 1)), dim3(kBlock), 0, b.cur, n, nsteps, P->ct_step_pos,
-                           P->ct_ext_start, tile_of, P->ct_tile_step, P->ct_step_rec, step_maxg);
+        {
+            // which rows leave their tile (positions named in the external lists, before those are re-mapped to places)
+            int *mark = nullptr, *snexp = nullptr;
+            s = dev_alloc(&mark, n);
+            if(s == RAMD_OK)
+                s = dev_alloc(&snexp, (int64_t)nsteps + 1);
+            if(s == RAMD_OK)
+            {
+                hipError_t e = hipMemsetAsync(mark, 0, sizeof(int) * (size_t)n, b.cur);
+                if(next > 0)
+                    hipLaunchKernelGGL(k_ct_mark_exported, dim3(ew_grid(next)), dim3(kBlock), 0, b.cur, (int64_t)next, P->ct_ext_idx,
+                                       mark);
+                hipLaunchKernelGGL(k_ct_step_nexp, dim3(ew_grid(nsteps)), dim3(kBlock), 0, b.cur, nsteps, P->ct_step_pos, mark, snexp);
+                hipLaunchKernelGGL(k_ct_step_rec2, dim3(ew_grid(nsteps + 1)), dim3(kBlock), 0, b.cur, n, nsteps, P->ct_step_pos,
+                                   P->ct_ext_start, tile_of, P->ct_tile_step, P->ct_step_rec, step_maxg, snexp);
+                if(e != hipSuccess)
+                    s = RAMD_ERR_HIP;
+            }
+            dev_free(&mark);
+            dev_free(&snexp);
+            CT_TRY(s);
+        }
         if(wmap)
         {
             // everything that names a value of w by its position now names its place: the external values of the tiles,
@@ -3977,6 +4029,8 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
                 RAMD_TRY(ct_build_pair_lists(P, P->order, &P->ct_out_pairs, 1, &P->ct_out_packed));
             dims.in_packed  = P->ct_in_packed ? 1 : 0;
             dims.out_packed = (out && P->ct_out_packed) ? 1 : 0;
+            static const int maskpub_env = getenv("RAMD_TRSV_MASKPUB") ? atoi(getenv("RAMD_TRSV_MASKPUB")) : 1; // (0: every row, A/B)
+            dims.mask_pub   = (out && maskpub_env != 0) ? 1 : 0;
             const size_t lds = ct_rec_lds_bytes<T>(dims);
             unsigned     nwg = 0;
             int          nstreams = 1;

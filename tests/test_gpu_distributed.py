@@ -355,8 +355,10 @@ def test_bench_multi_rank_path_rehearsed_on_one_gpu(world):
     assert sum(r["interior_nnz"] + r["ghost_nnz"] for r in per) == 7 * N ** 3 - 6 * N ** 2
     assert all(r["iters"] == min(K, 100) and r["spmv_avg_ms"] > 0 for r in per)
     # interior ranks talk to two neighbours, the end ranks to one: everybody exchanges once per product
-    assert out["halo_exchanges_per_iter"] == pytest.approx(1.0, abs=0.1)
-    assert out["allreduces_per_iter"] == pytest.approx(2.0, abs=0.15)  # <p,q> and {||r||^2, <r,z>} (cg.cpp:410-438: three)
+    # (per iteration of the bracketed run, whose preamble -- initial residual, first direction -- adds a constant few)
+    itp = per[0]["iters"]
+    assert 1.0 <= out["halo_exchanges_per_iter"] <= 1.0 + 4.0 / itp
+    assert 2.0 <= out["allreduces_per_iter"] <= 2.0 + 6.0 / itp  # <p,q> and {||r||^2, <r,z>} (cg.cpp:410-438: three)
     assert out["roofline"]["peak"] == 8000.0 * world and 0 < out["roofline"]["frac"] < 1
     assert out["halo_ms"] > 0 and out["halo_overlap_frac"] is not None
     # the same Krylov iterates: residual after W + K iterations agrees with the one-rank run (dots summed in another order)
