@@ -240,7 +240,7 @@ def roof(name, bytes_alg, p, traffic=None):
 def traffic_for(key):
     """HBM bytes per launch from the PMC counters: measured offline with rocprofv3 in separate --pmc passes
     (tools/pmc_passes.sh) and committed under profiles/; bench.py does not run the profiler"""
-    for f in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for f in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         p = os.path.join(ROOT, "profiles", f)
         if os.path.exists(p):
             d = json.load(open(p))
@@ -559,6 +559,10 @@ def main():
             else:
                 kernels["vector_updates"] = roof("k_mgs_step" if args.solver == "gmres" else "k_cg_update / k_cg_direction",
                                                  (32 if args.solver == "gmres" else 40) * n * vb // 8, p_vec)
+        if args.precond in ("mcsgs", "mcgs", "mcilu") and pr0[PROF_PRECOND]["launches"] > 0:
+            kernels["precond_apply"] = roof("multi-coloured %s apply (k_mc_sweep: all colour sweeps of one apply)" % args.precond.upper()[2:],
+                                            mcsgs_bytes(n, nnz, vb), pr0[PROF_PRECOND],
+                                            traffic_for("mcsgs_512") if (args.matrix == "poisson" and N == 512 and not mixed) else None)
         st_pat = C.c_int(0)
         capi.check(lib.ramd_mat_pattern_info(A._h, C.byref(st_pat), None, None))
         if st_pat.value in (1, 2) and not mixed and args.format in ("csr", "ell", "hyb"):

@@ -112,8 +112,17 @@ __global__ __launch_bounds__(kBlock) void k_mc_width(int n, const int* __restric
 #pragma unroll
     for(int o = 32; o > 0; o >>= 1)
         c = max(c, __shfl_xor(c, o, 64));
+    // (an even number of slots: the sweeps read the values of two slots of a row with one 16-byte access)
     if((threadIdx.x & 63) == 0 && (t >> 6) * 64 < n)
-        slice_w[t >> 6] = c * 64;
+        slice_w[t >> 6] = ((c + 1) & ~1) * 64;
+}
+
+// where slot k of lane `lane` sits in a slice's piece of the value array: slots in pairs, {2j, 2j + 1} of a row next to each other
+// (one 16-byte access per pair: 8-byte accesses stream at 0.54-0.70 of the 16-byte rate, MI355X_MICROARCH.md), lanes
+// consecutive inside a pair.  The column array keeps the slot-major layout (the row-pattern analysis reads it).
+__device__ __forceinline__ int mc_val_at(int k, int lane)
+{
+    return (k >> 1) * 128 + lane * 2 + (k & 1);
 }
 
 // fill; also extracts diag / inverse diagonal (host_matrix_csr.cpp:772-845 semantics)
@@ -141,7 +150,7 @@ __global__ __launch_bounds__(kBlock) void k_mc_fill(int n, int nb, const int* __
         for(int j = rs; j < re && ci[j] < off[b]; ++j, ++k) // ascending columns == ascending blocks
         {
             ecol[base + k * 64 + lane] = ci[j];
-            eval[base + k * 64 + lane] = val[j];
+            eval[base + mc_val_at(k, lane)] = val[j];
         }
         // diagonal of the colour block (first match wins)
         T dv = (T)0, iv = (T)0;
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void k_mc_fill(int n, int nb, const int* __
             for(int j = lo; j < hi_end; ++j, ++k)
             {
                 ecol[base + k * 64 + lane] = ci[j];
-                eval[base + k * 64 + lane] = val[j];
+                eval[base + mc_val_at(k, lane)] = val[j];
             }
             hi_end = lo;
         }
@@ -175,7 +184,7 @@ __global__ __launch_bounds__(kBlock) void k_mc_fill(int n, int nb, const int* __
     for(; k < w; ++k)
     {
         ecol[base + k * 64 + lane] = -1;
-        eval[base + k * 64 + lane] = (T)0;
+        eval[base + mc_val_at(k, lane)] = (T)0;
     }
 }
 
@@ -205,33 +214,66 @@ __global__ __launch_bounds__(kBlock) void k_mc_sweep(int p0, int p1, const int* 
                                                      BandMap bm, int keep_xp, const int* __restrict__ pair_of,
                                                      const unsigned char* __restrict__ covered)
 {
-    const int blk = xcd_block(nblk, per_xcd, bm); // (uniform in the workgroup)
+    // (bm.W < 0: workgroup b takes block b -- the order of rounds 1 to 3, kept for A/B runs)
+    const int blk = bm.W < 0 ? ((int)blockIdx.x < nblk ? (int)blockIdx.x : -1) : xcd_block(nblk, per_xcd, bm); // (uniform)
     if(blk < 0)
         return;
     __shared__ int sdict[PAT ? kPatMax * kPatMaxW : 1];
+    // Everything a row needs that hangs on nothing but its position is requested BEFORE the dictionary is staged (the
+    // barrier would otherwise keep these loads behind the dictionary's round trip): the chain of a workgroup is then
+    // {dictionary, row data} -> {values, gathers} -> store instead of dictionary -> row data -> values -> store.
+    constexpr int NDW = PAT ? kPatMax * kPatMaxW / kBlock : 0;
+    int           dreg[NDW > 0 ? NDW : 1];
+#pragma unroll
+    for(int q = 0; q < NDW; ++q)
+    {
+        const int i = q * kBlock + threadIdx.x;
+        dreg[q]     = i < pat.n * kPatMaxW ? pat.dict[i] : 0;
+    }
+    const int64_t t    = (int64_t)p0 + (int64_t)blk * kBlock + threadIdx.x;
+    const bool    live = t < p1;
+    const int64_t tl   = live ? t : (int64_t)p1 - 1; // (lanes beyond the colour read what its last row reads)
+    const int     pid  = PAT ? (int)pat.id[tl] : 0;
+    const int     lane = (int)(tl & 63);
+    const int     base = slice_off[tl >> 6];
+    const int     w    = (slice_off[(tl >> 6) + 1] - base) >> 6;
+    const int     orow = (FROM_RHS || TO_OUT) ? iperm[tl] : 0;
+    const T       dv   = (MULT_D || BOTH) ? d[tl] : (T)0;
+    const T       iv   = !identity ? dinv[tl] : (T)0;
+    const int     pq   = (TO_OUT && pair_of) ? pair_of[tl] : -1;
+    const bool    skip_out = TO_OUT && !pair_of && covered && covered[tl];
+    T             s    = FROM_RHS ? rhs[orow] : xp[tl];
     if(PAT)
     {
-        for(int i = threadIdx.x; i < pat.n * kPatMaxW; i += kBlock)
-            sdict[i] = pat.dict[i];
+#pragma unroll
+        for(int q = 0; q < NDW; ++q)
+        {
+            const int i = q * kBlock + threadIdx.x;
+            if(i < pat.n * kPatMaxW)
+                sdict[i] = dreg[q];
+        }
         __syncthreads();
     }
-    const int64_t t = (int64_t)p0 + (int64_t)blk * kBlock + threadIdx.x;
-    if(t >= p1)
+    if(!live)
         return;
-    const int dbase = PAT ? (int)pat.id[t] * kPatMaxW : 0;
-    const int lane = (int)(t & 63);
-    const int base = slice_off[t >> 6];
-    const int w    = (slice_off[(t >> 6) + 1] - base) >> 6;
-    const int orow = (FROM_RHS || TO_OUT) ? iperm[t] : 0;
-    T         s    = FROM_RHS ? rhs[orow] : xp[t];
+    const int dbase = pid * kPatMaxW;
     if(MULT_D)
-        s = s * d[t];
+        s = s * dv;
     // masked batches of 8 slots: loads, then gathers, then the updates IN ORDER (padding col = -1 ends a row)
     bool done = false;
     for(int k0 = 0; k0 < w && !done; k0 += 8)
     {
         int c[8];
         T   a[8], xv[8];
+        using P2 = T __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for(int e = 0; e < 8; e += 2) // (w is even: slots come in pairs, mc_val_at)
+            if(k0 + e < w)
+            {
+                const P2 av = nt_load(reinterpret_cast<const P2*>(eval + base + mc_val_at(k0 + e, lane)));
+                a[e]        = av.x;
+                a[e + 1]    = av.y;
+            }
 #pragma unroll
         for(int e = 0; e < 8; ++e)
         {
@@ -245,7 +287,6 @@ __global__ __launch_bounds__(kBlock) void k_mc_sweep(int p0, int p1, const int* 
                 }
                 else
                     c[e] = nt_load(ecol + base + (k0 + e) * 64 + lane);
-                a[e] = nt_load(eval + base + (k0 + e) * 64 + lane);
             }
         }
 #pragma unroll
@@ -264,12 +305,12 @@ __global__ __launch_bounds__(kBlock) void k_mc_sweep(int p0, int p1, const int* 
                 s -= a[e] * xv[e];
     }
     if(!identity)
-        s = s * dinv[t];
+        s = s * iv;
     if(BOTH)
     {
-        s = s * d[t];
+        s = s * dv;
         if(!identity)
-            s = s * dinv[t];
+            s = s * iv;
     }
     if(keep_xp)
         xp[t] = s;
@@ -277,11 +318,10 @@ __global__ __launch_bounds__(kBlock) void k_mc_sweep(int p0, int p1, const int* 
     {
         if(pair_of) // (the last sweep: rows of colour 0)
         {
-            const int q = pair_of[t];
-            if(q >= 0)
+            if(pq >= 0)
             {
                 using P2 = T __attribute__((ext_vector_type(2)));
-                const T other = xp[q]; // final: every other colour is done
+                const T other = xp[pq]; // final: every other colour is done
                 P2      v;
                 v.x = (orow & 1) ? other : s;
                 v.y = (orow & 1) ? s : other;
@@ -290,7 +330,7 @@ __global__ __launch_bounds__(kBlock) void k_mc_sweep(int p0, int p1, const int* 
             else
                 out[orow] = s;
         }
-        else if(!covered || !covered[t])
+        else if(!skip_out)
             out[orow] = s;
     }
 }
@@ -341,9 +381,13 @@ __global__ __launch_bounds__(kBlock) void k_mc_band_sample(int p0, int p1, int s
 static int mc_band_map(const McsgsPlan* P, int colour, bool lower, BandMap* bm)
 {
     *bm = BandMap{0, 0, 0};
-    static const int xcd_env = getenv("RAMD_MC_XCD") ? atoi(getenv("RAMD_MC_XCD")) : 1; // 0: linear order inside an XCD's eighth
+    // RAMD_MC_XCD: 1 (default) band-aware tiles inside every XCD's contiguous eighth; 2: the contiguous eighth in linear
+    // order; 0: workgroup b takes block b (round robin over the XCDs)
+    static const int xcd_env = getenv("RAMD_MC_XCD") ? atoi(getenv("RAMD_MC_XCD")) : 1;
     const int p0 = P->off[(size_t)colour], p1 = P->off[(size_t)colour + 1];
-    if(xcd_env == 0 || p1 - p0 < (1 << 20))
+    if(xcd_env == 0)
+        bm->W = -1;
+    if(xcd_env == 0 || xcd_env == 2 || p1 - p0 < (1 << 20))
         return RAMD_OK;
     Backend&  b       = backend();
     const int samples = 1024;
@@ -365,7 +409,8 @@ static int mc_band_map(const McsgsPlan* P, int colour, bool lower, BandMap* bm)
         const int nblk = (p1 - p0 + kBlock - 1) / kBlock, per_xcd = (nblk + 7) / 8;
         bm->P = med / kBlock;
         bm->Z = per_xcd / bm->P;
-        bm->W = 32;
+        static const int w_env = getenv("RAMD_MC_BANDW") ? atoi(getenv("RAMD_MC_BANDW")) : 32; // (row blocks per plane of a tile)
+        bm->W = w_env > 0 ? w_env : 32;
         while(bm->W > 1 && bm->P % bm->W != 0)
             bm->W >>= 1;
         if(bm->Z < 3)

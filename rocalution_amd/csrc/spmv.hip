@@ -504,6 +504,15 @@ __global__ __launch_bounds__(kBlock) void k_csr_pat2(
     }
 }
 
+// Measured and removed (round 4, alternating runs at 512^3, product + dot inside the CG loop; k_csr_pat2: 2.04-2.09 ms):
+//  * a PERSISTENT form -- workgroups that stay, the XCD's block pairs dealt out with stride "workgroups per XCD", the dictionary
+//    staged once, the packets of pair k + 1 requested before pair k is walked (146 VGPRs, 3 workgroups per CU): 2.61-2.63 ms,
+//    3.36 ms with 2 workgroups per CU (gpurun_out/r04f);
+//  * MORE waves instead: the second block's packets requested into the first block's registers once those are in LDS, 7 / 8
+//    waves per SIMD asked of the compiler: 2.17-2.20 ms / 3.11-3.16 ms (the walk's 40 gather registers spill); both blocks
+//    requested at once with 7 waves: 2.08-2.12 ms (gpurun_out/r04g).
+// Neither a longer stream per workgroup nor more resident waves moves this product: what it moves per row (79 bytes) comes at
+// 5.2 TB/s like the other gather kernels (colour sweeps 5.0-5.4, ELL with patterns 5.0), whichever way it is requested.
 // largest number of entries (from the 4-aligned start) a 256-row block stages: decides whether a matrix takes k_csr_pat2
 __global__ __launch_bounds__(kBlock) void k_blk_span_max(int nblk, const int* __restrict__ blk_rp, int* __restrict__ out)
 {
@@ -827,6 +836,9 @@ __global__ __launch_bounds__(kBlock) void k_csr_q4(int nrow, int nblk, int per_x
 // entries l, l + 4, ... of the row, the row sum runs in storage order over the quad-broadcast products -- bit-identical to
 // the host loop.  The finished sums pass through LDS so that lane t ends up with row t of the wave: the epilogue (Jacobi
 // sweep, fused dot with ONE partial per wave) is the one of k_csr_tr, same order of additions.
+// Measured and removed (round 4): the row offsets of a wave's four 16-row pieces requested at once and the first pass of piece
+// k + 1 requested before piece k is walked (a second packet set in registers) -- 0.58 ms against 0.157 ms on the config-3
+// surrogate (gpurun_out/r04g).
 constexpr int kW4Chunk = 640; // entries per wave and pass (16 rows of up to 40 entries in one pass)
 constexpr int kW4Batch = 3; // gathers in flight per lane (12 entries of a row per round)
 template <typename T, int MODE, bool DOT, int NWV>

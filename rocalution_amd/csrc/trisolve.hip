@@ -711,6 +711,7 @@ struct TriPlan
     int*       ct_out_pairs = nullptr; // [2 n] the same for the natural-order output: {row of the matrix, row number inside the tile}
     bool       ct_in_packed = false, ct_out_packed = false; // the lists in 4 bytes per row (see CtDims)
     bool       prefilled_next = false; // the last run filled the next stage's w with sentinels (run_plan)
+    bool       w_sentinel     = false; // w holds sentinels everywhere (the stage that read it as its right-hand side left them)
     void  release()
     {
         dev_free(&ct_tile_step);
@@ -736,6 +737,7 @@ struct TriPlan
             (void)cached_free(w);
         eval = diag = w = nullptr;
         n               = 0;
+        w_sentinel = prefilled_next = filled_once = false;
     }
 };
 
@@ -2412,11 +2414,11 @@ template <typename T, int DMODE, bool HAS_OUT, int LPR, int WL, int DEPTH, bool 
 __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const v4i32* __restrict__ tile_desc,
                                                   const v4i32* __restrict__ step_rec, const int* __restrict__ ext_idx,
                                                   const v4i32* __restrict__ erec, const T* __restrict__ diag_sep,
-                                                  const T* __restrict__ rhs_src,
+                                                  const T* rhs_src,
                                                   const int* __restrict__ in_pairs,
                                                   const int* __restrict__ out_pairs, T* w, T* __restrict__ out,
                                                   unsigned* counter, CtBases bases, int nstreams, unsigned long long* prof_arg,
-                                                  T* __restrict__ prefill)
+                                                  T* __restrict__ prefill, T* refill)
 {
     constexpr bool GRP = (LPR == kGrpLPR); // grouped form (row groups; CtGRec): `diag_sep` holds the row records
     using L           = typename std::conditional<GRP, CtGRec<T>, CtRec<T, WL>>::type;
@@ -2618,6 +2620,16 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
                     for(int u = 0; u < 4; ++u)
                         if(d[u].x >= 0)
                             rbb[d[u].y] = v[u];
+                    // the right-hand side is the previous stage's w, and this is the one read of the element: the sentinel
+                    // that stage's NEXT run needs goes in behind it (was k_fill_sentinel, a kernel of its own per solve)
+                    if(refill)
+                    {
+                        const T sv = Sentinel<T>::from_bits(Sentinel<T>::value);
+#pragma unroll
+                        for(int u = 0; u < 4; ++u)
+                            if(d[u].x >= 0)
+                                nt_store(sv, refill + d[u].x);
+                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if(lane == 0)
@@ -3990,8 +4002,11 @@ static int ct_build_pair_lists(TriPlan* P, const int* key, int** pairs_out, int 
 
 template <typename T>
 static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const int* rhs_idx, T* out,
-                    bool mul_inv_diag = false, TriPlan* next_stage = nullptr, bool own_fill_done = false)
+                    bool mul_inv_diag = false, TriPlan* next_stage = nullptr, bool own_fill_done = false,
+                    TriPlan* prev_stage = nullptr)
 {
+    // prev_stage: the plan whose w is this run's right-hand side (rhs_src); a box-tile kernel leaves sentinels behind every
+    // element it has read, so that plan's next run needs no fill (TriPlan::w_sentinel).
     // next_stage: the plan that runs right after this one on the same stream; a box-tile kernel fills its w with sentinels
     // on the way (own_fill_done tells that plan so).  Returns with P->prefilled_next set if it did.
     Backend& b = backend();
@@ -3999,10 +4014,15 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
         return RAMD_OK;
     const unsigned nb = nblocks_of(P->n);
     static const bool nofill = getenv("RAMD_TRSV_NOFILL") != nullptr; // diagnostic only (tools/): no dependency waits
-    if((!nofill || !P->filled_once) && !own_fill_done)
+    if((!nofill || !P->filled_once) && !own_fill_done && !P->w_sentinel)
         hipLaunchKernelGGL((k_fill_sentinel<T>), dim3(ew_grid(P->n)), dim3(kBlock), 0, b.cur, (int64_t)P->n,
                            (T*)P->w);
     P->filled_once     = true;
+    P->w_sentinel      = false; // (from here on w holds this run's values)
+    static const int refill_env = getenv("RAMD_TRSV_REFILL") ? atoi(getenv("RAMD_TRSV_REFILL")) : 1; // (0: off; A/B)
+    T* refill = nullptr;
+    if(refill_env != 0 && !nofill && prev_stage && prev_stage->n == P->n && prev_stage->w == (void*)rhs_src && P->ct && P->ct_rec)
+        refill = (T*)prev_stage->w;
     P->prefilled_next  = false;
     static const int prefill_env = getenv("RAMD_TRSV_PREFILL") ? atoi(getenv("RAMD_TRSV_PREFILL")) : 1; // (0: every plan fills its own w)
     T* prefill = nullptr;
@@ -4073,13 +4093,13 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
                                P->ct_ntiles, dims, (const v4i32*)P->ct_tile_desc, (const v4i32*)P->ct_step_rec,             \
                                P->ct_ext_idx, (const v4i32*)P->eval, (const T*)P->diag, rhs_src, P->ct_in_pairs,            \
                                P->ct_out_pairs, (T*)P->w, out,                                                              \
-                               st->stream_counter, bases, nstreams, pf_buf, prefill);                                       \
+                               st->stream_counter, bases, nstreams, pf_buf, prefill, refill);                               \
         else                                                                                                                \
             hipLaunchKernelGGL((k_trsv_rec<T, DM, HO, LP, WLL, DP, false>), dim3(nwg), dim3(128), lds, b.cur, P->ct_ntiles, \
                                dims, (const v4i32*)P->ct_tile_desc, (const v4i32*)P->ct_step_rec, P->ct_ext_idx,            \
                                (const v4i32*)P->eval, (const T*)P->diag, rhs_src, P->ct_in_pairs, P->ct_out_pairs,           \
                                (T*)P->w, out,                                                                               \
-                               st->stream_counter, bases, nstreams, pf_buf, prefill);                                       \
+                               st->stream_counter, bases, nstreams, pf_buf, prefill, refill);                               \
     } while(0)
 #define TRSV_RC_L(DM, HO)            \
     do                               \
@@ -4122,6 +4142,8 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
                 st->stream_ticket[i] += tiles_i + wgs_i;
             }
             RAMD_HIP(hipGetLastError());
+            if(refill)
+                prev_stage->w_sentinel = true;
             if(pf_on)
             {
                 unsigned long long h[32];
@@ -5040,7 +5062,8 @@ static int ll_solve_t(ramd_mat_s* m, const T* in, const T* inv_diag, T* out)
     }
     // L y = b with y_i scaled by inv_diag_i, y kept in position order; then L^T x = y, scaled, natural order out
     RAMD_TRY(run_plan<T>(st, &st->LLf, false, in, st->LLf.order, nullptr, true, &st->LLb));
-    return run_plan<T>(st, &st->LLb, false, (const T*)st->LLf.w, st->ll_rhs_idx, out, true, nullptr, st->LLf.prefilled_next);
+    return run_plan<T>(st, &st->LLb, false, (const T*)st->LLf.w, st->ll_rhs_idx, out, true, nullptr, st->LLf.prefilled_next,
+                       &st->LLf);
 }
 
 // ---------------------------------------------------------------- iterative triangular solves
@@ -5581,11 +5604,11 @@ int ramd_mat_lu_solve(ramd_mat_t m, ramd_vec_t in, ramd_vec_t out)
         RAMD_TRY(run_plan<double>(st, &st->L, true, (const double*)in->d, st->L.order, nullptr, false, &st->U));
         // U x = y (stored diagonal), x written back in natural order
         return run_plan<double>(st, &st->U, false, (const double*)st->L.w, st->lu_rhs_idx,
-                                (double*)out->d, false, nullptr, st->L.prefilled_next);
+                                (double*)out->d, false, nullptr, st->L.prefilled_next, &st->L);
     }
     RAMD_TRY(run_plan<float>(st, &st->L, true, (const float*)in->d, st->L.order, nullptr, false, &st->U));
     return run_plan<float>(st, &st->U, false, (const float*)st->L.w, st->lu_rhs_idx, (float*)out->d, false, nullptr,
-                           st->L.prefilled_next);
+                           st->L.prefilled_next, &st->L);
 }
 
 int ramd_mat_l_analyse(ramd_mat_t m, int diag_unit)
