@@ -49,10 +49,6 @@ def _sources():
         if os.path.basename(root) == "_obj":
             continue
         for f in sorted(files):
-            # lab.hip holds experiment kernels for tools/spmv_lab.py (ramdx_lab_*): not part of the product library
-            # unless asked for (RAMD_BUILD_LAB=1)
-            if f == "lab.hip" and os.environ.get("RAMD_BUILD_LAB", "0") != "1":
-                continue
             if f.endswith((".hip", ".cpp")):
                 srcs.append(os.path.join(root, f))
     return srcs

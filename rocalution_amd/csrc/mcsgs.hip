@@ -243,6 +243,17 @@ __global__ __launch_bounds__(kBlock) void k_mc_sweep(int p0, int p1, const int* 
     const int     pq   = (TO_OUT && pair_of) ? pair_of[tl] : -1;
     const bool    skip_out = TO_OUT && !pair_of && covered && covered[tl];
     T             s    = FROM_RHS ? rhs[orow] : xp[tl];
+    // ... and the values of the first batch of slots (they hang on the slice offset only)
+    using P2 = T __attribute__((ext_vector_type(2)));
+    T a0[8];
+#pragma unroll
+    for(int e = 0; e < 8; e += 2)
+        if(e < w)
+        {
+            const P2 av = nt_load(reinterpret_cast<const P2*>(eval + base + mc_val_at(e, lane)));
+            a0[e]       = av.x;
+            a0[e + 1]   = av.y;
+        }
     if(PAT)
     {
 #pragma unroll
@@ -265,14 +276,21 @@ __global__ __launch_bounds__(kBlock) void k_mc_sweep(int p0, int p1, const int* 
     {
         int c[8];
         T   a[8], xv[8];
-        using P2 = T __attribute__((ext_vector_type(2)));
 #pragma unroll
         for(int e = 0; e < 8; e += 2) // (w is even: slots come in pairs, mc_val_at)
             if(k0 + e < w)
             {
-                const P2 av = nt_load(reinterpret_cast<const P2*>(eval + base + mc_val_at(k0 + e, lane)));
-                a[e]        = av.x;
-                a[e + 1]    = av.y;
+                if(k0 == 0)
+                {
+                    a[e]     = a0[e];
+                    a[e + 1] = a0[e + 1];
+                }
+                else
+                {
+                    const P2 av = nt_load(reinterpret_cast<const P2*>(eval + base + mc_val_at(k0 + e, lane)));
+                    a[e]        = av.x;
+                    a[e + 1]    = av.y;
+                }
             }
 #pragma unroll
         for(int e = 0; e < 8; ++e)

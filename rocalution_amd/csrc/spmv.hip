@@ -54,7 +54,7 @@ struct CsrDotWs
     const void* jrhs;
 };
 
-// CSR SpMV, "LDS transpose" layout.  Measured on MI355X (tools/spmv_lab.py): the kernel is bound by
+// CSR SpMV, "LDS transpose" layout.  Measured on MI355X (round 1, a since-deleted lab of kernel variants): the kernel is bound by
 // HBM *and* by L1/TA line throughput, so every global access is made as line-efficient as possible:
 //   1. the workgroup's contiguous nnz range is streamed RAW into LDS with independent, fully
 //      coalesced 16-byte packets (int4 columns, double2/float4 values; non-temporal: read once);
@@ -836,9 +836,6 @@ __global__ __launch_bounds__(kBlock) void k_csr_q4(int nrow, int nblk, int per_x
 // entries l, l + 4, ... of the row, the row sum runs in storage order over the quad-broadcast products -- bit-identical to
 // the host loop.  The finished sums pass through LDS so that lane t ends up with row t of the wave: the epilogue (Jacobi
 // sweep, fused dot with ONE partial per wave) is the one of k_csr_tr, same order of additions.
-// Measured and removed (round 4): the row offsets of a wave's four 16-row pieces requested at once and the first pass of piece
-// k + 1 requested before piece k is walked (a second packet set in registers) -- 0.58 ms against 0.157 ms on the config-3
-// surrogate (gpurun_out/r04g).
 constexpr int kW4Chunk = 640; // entries per wave and pass (16 rows of up to 40 entries in one pass)
 constexpr int kW4Batch = 3; // gathers in flight per lane (12 entries of a row per round)
 template <typename T, int MODE, bool DOT, int NWV>
@@ -993,6 +990,13 @@ __global__ __launch_bounds__(64 * NWV) void k_csr_w4(int nrow, int nblk, int per
     }
 }
 
+// Measured and removed (round 4): k_csr_w4 with look-ahead -- the row offsets of a wave's four 16-row pieces requested at once,
+// the first pass of piece k + 1 on its way while piece k is walked (two packet sets used alternately, pieces unrolled with
+// compile-time numbers; 142 VGPRs, 3 waves per SIMD, or 128 with 4): 0.1655 / 0.1707 ms against 0.1604 ms of k_csr_w4 on the
+// config-3 surrogate in alternating runs (gpurun_out/r04i; a first version that indexed the sets at run time kept them in
+// scratch memory: 0.58 ms).  With k_csr_tr, k_csr_q4, the PIPE form and one wave per workgroup that makes SIX row walks at
+// 0.155-0.17 ms: the wave's dependency chain is not what bounds this product either.
+
 // ELL: one thread per row, column-major => every load is a perfectly coalesced wave access.
 // STOP=true : ELL semantics (stop at the first negative column, host_matrix_ell.cpp:309-318)
 // STOP=false: HYB-ELL semantics (skip invalid columns, host_matrix_hyb.cpp:344-352)
@@ -1008,19 +1012,49 @@ __global__ __launch_bounds__(kBlock) void k_ell(int nrow, int ncol, int width,
     __shared__ int sdict[PAT ? kPatMax * kPatMaxW : 1];
     double dacc = 0.0;
     // one workgroup per 256 rows, XCD- and band-aware order (same mapping as the CSR kernel)
-    const int     blk = xcd_block(nblk, per_xcd, bm);
-    const int64_t row = (int64_t)blk * kCsrRows + threadIdx.x;
+    const int     blk  = xcd_block(nblk, per_xcd, bm);
+    const int64_t row  = (int64_t)blk * kCsrRows + threadIdx.x;
+    const bool    live = blk >= 0 && row < nrow;
+    // PAT: the dictionary is requested first and staged last; the row's pattern number, its y (ApplyAdd) and the values of
+    // its first batch of slots -- none of which hangs on the dictionary -- are on their way before the barrier (round 4:
+    // the chain of a workgroup was dictionary -> barrier -> values -> gathers)
+    constexpr int NDW = PAT ? kPatMax * kPatMaxW / kBlock : 0;
+    int           dreg[NDW > 0 ? NDW : 1];
+    T             v0[kGatherW];
+    int           pid  = 0;
+    T             sum0 = (T)0;
     if(PAT)
     {
-        for(int i = threadIdx.x; i < pat.n * kPatMaxW; i += kBlock)
-            sdict[i] = pat.dict[i];
+#pragma unroll
+        for(int q = 0; q < NDW; ++q)
+        {
+            const int i = q * kBlock + threadIdx.x;
+            dreg[q]     = i < pat.n * kPatMaxW ? pat.dict[i] : 0;
+        }
+        if(live)
+        {
+            pid = (int)pat.id[row];
+            if(MODE == 1)
+                sum0 = y[row];
+#pragma unroll
+            for(int e = 0; e < kGatherW; ++e)
+                if(e < width)
+                    v0[e] = nt_load(eval + (int64_t)e * nrow + row);
+        }
+#pragma unroll
+        for(int q = 0; q < NDW; ++q)
+        {
+            const int i = q * kBlock + threadIdx.x;
+            if(i < pat.n * kPatMaxW)
+                sdict[i] = dreg[q];
+        }
         __syncthreads();
     }
-    if(blk >= 0 && row < nrow)
+    if(live)
     {
-        const int dbase = PAT ? (int)pat.id[row] * kPatMaxW : 0;
-        T sum = (T)0;
-        if(MODE == 1)
+        const int dbase = PAT ? pid * kPatMaxW : 0;
+        T sum = PAT ? sum0 : (T)0;
+        if(!PAT && MODE == 1)
             sum = y[row];
         // masked batches of kGatherW slots: the independent col/val loads of a batch first, then all its
         // gathers, then the products IN ORDER (a width-7 row is one batch, not 4 + three dependent steps)
@@ -1039,10 +1073,13 @@ __global__ __launch_bounds__(kBlock) void k_ell(int nrow, int ncol, int width,
                     {
                         const int o = sdict[dbase + el + e];
                         c[e]        = o == kPatEnd ? -1 : (int)row + o;
+                        v[e]        = el == 0 ? v0[e] : nt_load(eval + (int64_t)(el + e) * nrow + row);
                     }
                     else
+                    {
                         c[e] = nt_load(ecol + (int64_t)(el + e) * nrow + row);
-                    v[e] = nt_load(eval + (int64_t)(el + e) * nrow + row);
+                        v[e] = nt_load(eval + (int64_t)(el + e) * nrow + row);
+                    }
                 }
             }
             bool use[kGatherW];

@@ -1,15 +1,20 @@
-"""Turn the rocprofv3 sqlite outputs under gpurun_out/prof/ (tools/profile_r03.sh) into small text summaries in profiles/."""
+"""Turn the rocprofv3 sqlite outputs under gpurun_out/prof/ (tools/profile_r04.sh) into small text summaries in profiles/."""
 import json, os, sqlite3, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-out = os.path.join(ROOT, "profiles")
+# "box": run on the GPU box right after the passes -- summaries go to gpurun_out/prof_txt (merged back), databases are deleted
+on_box = len(sys.argv) > 2 and sys.argv[2] == "box"
+out = os.path.join(ROOT, "gpurun_out", "prof_txt") if on_box else os.path.join(ROOT, "profiles")
 os.makedirs(out, exist_ok=True)
 
 WHAT = {"cg": "python bench.py --steps 100 --warmup 10 (512^3 CG+Jacobi, the headline)",
         "gmres": "python bench.py --solver gmres --precond ilu0 --steps 60 --warmup 10 (512^3 GMRES(30)+ILU(0))",
         "shell": "python bench.py --matrix shell --solver gmres --precond ilu0 --steps 60 --warmup 10 (config 3 surrogate)",
         "bicgstab": "python bench.py --solver bicgstab --precond mcsgs --steps 60 --warmup 10 (512^3 BiCGStab+MC-SGS, config 4's solver)",
+        "ell": "python bench.py --format ell --solver bicgstab --precond mcsgs --steps 60 --warmup 10 (config 4: ELL interior)",
+        "hyb": "python bench.py --format hyb --solver bicgstab --precond mcsgs --steps 60 --warmup 10 (config 4: HYB interior)",
+        "mixed": "python bench.py --solver mixed --steps 30 --warmup 3 (config 5: fp64 defect correction around fp32 CG+Jacobi)",
         "calib": "tools/_bin/membench calib (reads of 1 GiB with 16 / 8 / 4 bytes per lane, of 256 MiB with 1 byte per lane)"}
 
 
@@ -46,7 +51,7 @@ for name in WHAT:
         rows = q(db, "select kernel_name,counter_name,count(*),avg(value),min(value),max(value) from counters_collection "
                      "group by kernel_name,counter_name order by avg(value) desc limit 48")
         with open(os.path.join(out, "%s_pmc_%s_%s.txt" % (tag, ctr, name)), "w") as f:
-            f.write("# rocprofv3 --pmc %s --kernel-trace -- %s   (one counter per pass)\n" % (ctr, WHAT[name].split(" (")[0].replace("--steps 100 --warmup 10", "--steps 20 --warmup 2").replace("--steps 60 --warmup 10", "--steps 20 --warmup 2")))
+            f.write("# rocprofv3 --pmc %s --kernel-trace -- %s   (one counter per pass)\n" % (ctr, WHAT[name].split(" (")[0].replace("--steps 100 --warmup 10", "--steps 20 --warmup 2").replace("--steps 60 --warmup 10", "--steps 20 --warmup 2").replace("--steps 30 --warmup 3", "--steps 10 --warmup 2")))
             f.write("# KiB per dispatch as reported.  gfx950: FETCH_SIZE counts 64 B per 128-B request, i.e. HALF the bytes read\n"
                     "# (MI355X_MICROARCH.md, HBM section) -- calibrated in this round on reads of known size with 16, 8, 4 and 1 bytes per\n"
                     "# lane (r03_pmc_FETCH_SIZE_calib.txt: 0.5000 of the bytes every time; round 2's 4-byte kernel had been optimised away and\n"
@@ -59,4 +64,9 @@ for name in WHAT:
             vals.setdefault(short(r[0]), {})[ctr] = (r[3], r[2])
     traffic[name] = vals
 json.dump(traffic, open(os.path.join(out, tag + "_pmc_raw.json"), "w"), indent=1)
+if on_box:
+    import shutil
+    for d in os.listdir(src):
+        if os.path.isdir(os.path.join(src, d)):
+            shutil.rmtree(os.path.join(src, d), ignore_errors=True)
 print(sorted(os.listdir(out)))
