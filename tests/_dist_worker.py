@@ -246,6 +246,60 @@ def amg_worker(rank, world, initfile, kind, outdir, rccl=False):
     dist.destroy_process_group()
 
 
+def plans_matrices(world, m=600):
+    """two operators on world * m rows whose row block of rank 0 couples to no other rank (its exchange plan is the same empty
+    one for both), while the other ranks are coupled in a chain -- by one sub-/super-diagonal pair in A, by three in B: the
+    boundary pieces, and with them the padded length of the all-gather form, differ between the two on every other rank"""
+    import scipy.sparse as sp
+    n = world * m
+    rng = np.random.default_rng(21)
+    def chain(width):
+        d = [sp.diags(rng.uniform(-1.0, -0.1, n - k), k) for k in range(1, width + 1)]
+        L = sum(d)
+        A = (L + L.T).tolil()
+        A[:m, m:] = 0.0  # rank 0 stands alone
+        A[m:, :m] = 0.0
+        A = A.tocsr()
+        A = A + sp.diags(np.asarray(abs(A).sum(axis=1)).ravel() + 1.0)
+        A = A.tocsr(); A.sort_indices(); A.eliminate_zeros()
+        return A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+    return chain(1), chain(3)
+
+
+def plans_worker(rank, world, initfile, kind, outdir):
+    """two GlobalMatrix objects on ONE communicator, products with them in alternation (see plans_matrices)"""
+    from rocalution_amd import capi, distributed as D
+    import rocalution_amd as ra
+    dist = _init(rank, world, initfile)
+    ra.init_rocalution(0)
+    comm = D.make_callback_comm(rank, world, dist)
+    mats = plans_matrices(world)
+    n = len(mats[0][0]) - 1
+    off = D.partition_rows(n, world)
+    gs = []
+    for rp, ci, va in mats:
+        piece = D.split_rows(rp, ci, va, off, rank)
+        plan = D.build_halo_plan(piece, off, rank, _gather_obj(dist, world))
+        g = D.DistributedSolver(comm, capi.SOLVER_CG, capi.PC_JACOBI)
+        g.setup_csr(n, piece, plan)
+        gs.append((g, piece, plan))
+    lo, hi = gs[0][1]["row_begin"], gs[0][1]["row_end"]
+    out = {"npeers": np.array([len(p["peers"]) for _, _, p in gs])}
+    rng = np.random.default_rng(9)
+    for rep in range(3):
+        x = rng.uniform(-1, 1, n)
+        for k, (g, _, _) in enumerate(gs):
+            out["y%d_%d" % (k, rep)] = g.apply(x[lo:hi])
+    # ... and a solve with each (all-reduces between the exchanges)
+    for k, (g, _, _) in enumerate(gs):
+        g.init(1e-15, 1e-8, 1e8, 500)
+        g.build()
+        out["xs%d" % k] = g.solve(None, np.zeros(hi - lo))
+    np.savez(os.path.join(outdir, "r%d.npz" % rank), lo=lo, hi=hi, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def amg_matrix(kind):
     import scipy.sparse as sp
     if kind == "gr3030x":
@@ -264,5 +318,7 @@ if __name__ == "__main__":
         amg_worker(int(rank), int(world), initfile, kind, outdir, rccl=(mode == "amg_rccl"))
     elif mode == "cpu":
         cpu_worker(int(rank), int(world), initfile, kind, outdir)
+    elif mode == "plans":
+        plans_worker(int(rank), int(world), initfile, kind, outdir)
     else:
         gpu_worker(int(rank), int(world), initfile, kind, outdir, rccl=(mode == "rccl"))

@@ -402,3 +402,56 @@ def test_blocked_mgs_recurrence_numpy_model():
         tol = (1e-13 if not oblique else 2e-12) * np.linalg.norm(w0)
         assert np.max(np.abs(h - href)) <= tol
         assert np.max(np.abs(wb - w)) <= tol
+
+
+# ------------------------------------------------------------------ the hand-off forms of the single-launch reductions
+def test_grid_reduction_hand_off_is_emitted_in_the_write_through_forms(tmp_path):
+    """Every dot / norm of every solver ends in grid_reduce_finish (csrc/device_utils.hpp): per-workgroup partials handed to the
+    last workgroup WITHOUT a release fence -- 8-byte agent-scope atomics on both sides, the stores' completion before the
+    ticket.  That is valid only in the forms the ISA gives those operations (MI355X_MICROARCH.md, "Workgroup dispatch, XCD
+    placement & inter-workgroup visibility"): the partial's store write-through (`global_store ... sc1`), `s_waitcnt vmcnt(0)`
+    between it and the ticket's atomic, the last workgroup's loads L1-bypassing (`global_load ... sc1`) behind an acquire
+    (`buffer_inv sc1`).  The kernel's source is compiled for gfx950 with the library's flags and the assembly checked, so a
+    compiler that lowers these operations differently fails here and not as a wrong residual norm under load."""
+    import re
+    import shutil
+    hipcc = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = tmp_path / "probe.hip"
+    src.write_text('''
+#include "device_utils.hpp"
+namespace ramd {
+__global__ __launch_bounds__(kBlock) void k_probe_reduce(int64_t n, const double* __restrict__ a, ReduceCtx ctx, int slot)
+{
+    __shared__ double lds[8];
+    double acc = 0.0;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        acc += a[i];
+    const double vals[1] = {acc};
+    const int slots[1] = {slot};
+    const int ops[1] = {RED_SUM};
+    grid_reduce_finish<1>(ctx, vals, slots, ops, lds);
+}
+}
+''')
+    out = tmp_path / "probe.s"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "rocalution_amd", "csrc"),
+           "--cuda-device-only", "-S", str(src), "-o", str(out)]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:]
+    body = out.read_text()
+    body = body[body.index("k_probe_reduce"):]
+    ops = [l.strip() for l in body.splitlines() if re.match(r"\s*(global_|buffer_|s_waitcnt vmcnt|s_barrier)", l)]
+    st = [i for i, l in enumerate(ops) if l.startswith("global_store_dwordx2") and l.endswith("sc1")]
+    at = [i for i, l in enumerate(ops) if l.startswith("global_atomic_add")]
+    assert st and at and st[0] < at[0], ops
+    # the partial is stored write-through, and the store has completed before the ticket is taken
+    assert any(l.startswith("s_waitcnt vmcnt(0)") for l in ops[st[0] + 1:at[0]]), ops
+    # the last workgroup: acquire, then loads that bypass the L1
+    inv = [i for i, l in enumerate(ops) if l.startswith("buffer_inv") and "sc1" in l]
+    assert inv and inv[0] > at[0], ops
+    assert any(l.startswith("global_load_dwordx2") and l.endswith("sc1") for l in ops[inv[0]:]), ops
+    # ... and nowhere a release fence (write-back of the XCD L2) per workgroup
+    assert not any(l.startswith("buffer_wbl2") for l in ops), ops

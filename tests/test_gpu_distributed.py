@@ -105,6 +105,35 @@ def test_four_ranks_allgather_halo(kind, oracle):
     _check_two_ranks(kind, oracle, "gpu", world=4, env={"RAMD_COMM_HALO": "allgather"})
 
 
+@pytest.mark.parametrize("form", ["allgather", "sendrecv"])
+def test_two_operators_whose_plans_coincide_on_one_rank_only(form):
+    """Halo plans are identified by the number of the collective call that announced them (ramd_comm_halo_select), not by a
+    rank's own peers and offsets: here rank 0 has NO neighbours in either of two operators on one communicator -- the same
+    empty plan -- while the other three ranks exchange pieces of different lengths for the two.  With plans cached per
+    rank-local signature, rank 0 would skip the second plan's table exchange and enter the all-gather with the first plan's
+    padded length: a mismatched collective (hang or wrong halo).  Products with both operators in alternation and a CG
+    solve with each, 4 ranks on one GPU, both forms of the exchange."""
+    import scipy.sparse as sp
+    from test_cpu_host import _spawn
+    import _dist_worker as W
+    world = 4
+    res = _spawn("plans", "x", world=world, timeout=600, env={"RAMD_COMM_HALO": form})
+    assert list(res[0]["npeers"]) == [0, 0] and all(min(r["npeers"]) >= 1 for r in res[1:])
+    mats = W.plans_matrices(world)
+    n = len(mats[0][0]) - 1
+    rng = np.random.default_rng(9)
+    for rep in range(3):
+        x = rng.uniform(-1, 1, n)
+        for k, (rp, ci, va) in enumerate(mats):
+            A = sp.csr_matrix((va, ci, rp), shape=(n, n))
+            y = np.concatenate([r["y%d_%d" % (k, rep)] for r in res])
+            assert np.allclose(y, A @ x, rtol=1e-13, atol=1e-13), (k, rep)
+    for k, (rp, ci, va) in enumerate(mats):
+        A = sp.csr_matrix((va, ci, rp), shape=(n, n))
+        xs = np.concatenate([r["xs%d" % k] for r in res])
+        assert np.linalg.norm(xs - 1.0) / np.sqrt(n) < 1e-6  # (rhs = A * 1)
+
+
 @pytest.mark.parametrize("kind", ["poisson_slab", "gr3030", "random"])
 def test_two_rccl_ranks_on_two_gpus(kind, oracle):
     """The same checks with ONE GPU PER RANK and the RCCL data plane (grouped ncclSend/ncclRecv halo on the ghost stream
