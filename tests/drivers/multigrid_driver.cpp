@@ -1,4 +1,4 @@
-// samples/multigrid_driver.cpp -- MultiGrid on a user-built hierarchy, written against include/rocalution the way a
+// tests/drivers/multigrid_driver.cpp -- MultiGrid on a user-built hierarchy, written against include/rocalution the way a
 // rocALUTION user writes it (the call sequence of the reference's MultiGrid / UAAMG setup code):
 //   transfer operators P (pairs of consecutive rows -> one coarse row) and R = P^T, Galerkin coarse operators
 //   R A P through LocalMatrix::MatrixMult, FixedPoint(0.7)+Jacobi smoothers (2 pre, 1 post), CG on the coarsest level.

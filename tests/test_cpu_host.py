@@ -173,11 +173,11 @@ def test_parallel_manager_io_driver_compiles_with_plain_gxx():
                            os.path.join(ROOT, "tests", "drivers", "pm_io_driver.cpp")])
 
 
-@pytest.mark.parametrize("sample", ["krylov_driver.cpp", "multigrid_driver.cpp"])
+@pytest.mark.parametrize("sample", ["samples/krylov_driver.cpp", "tests/drivers/multigrid_driver.cpp"])
 def test_sample_drivers_compile_with_plain_gxx(sample):
-    """samples/*.cpp (run end to end by the GPU suite) are plain host C++ on include/rocalution: no hipcc, no device"""
+    """the C++ drivers (run end to end by the GPU suite) are plain host C++ on include/rocalution: no hipcc, no device"""
     subprocess.check_call(["g++", "-std=c++14", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "samples", sample)])
+                           os.path.join(ROOT, *sample.split("/"))])
 
 
 def test_partition_matches_reference_rule():

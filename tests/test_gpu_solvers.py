@@ -475,7 +475,7 @@ def test_rebuild_numeric_after_value_update(ra, S, oracle, pcname):
 
 @pytest.mark.parametrize("name", ["gr3030", "poisson8", "lap2d7"])
 def test_cpp_multigrid_driver_vs_reference(tmp_path, name):
-    """samples/multigrid_driver.cpp: MultiGrid (V-cycle with scaling, W-cycle, K-cycle as CG preconditioner) on a
+    """tests/drivers/multigrid_driver.cpp: MultiGrid (V-cycle with scaling, W-cycle, K-cycle as CG preconditioner) on a
     3-level hierarchy whose coarse operators come from the device Transpose / MatrixMult -- against the genuine
     library's run of the same setup: coarse operator size, iteration counts, residual histories"""
     import os
@@ -485,7 +485,7 @@ def test_cpp_multigrid_driver_vs_reference(tmp_path, name):
     exe = str(tmp_path / "multigrid_driver")
     libdir = os.path.join(root, "rocalution_amd")
     subprocess.check_call(["g++", "-std=c++14", "-O1", "-I" + os.path.join(root, "include"),
-                           os.path.join(root, "samples", "multigrid_driver.cpp"), "-o", exe, "-L" + libdir,
+                           os.path.join(root, "tests", "drivers", "multigrid_driver.cpp"), "-o", exe, "-L" + libdir,
                            "-lrocalution_amd", "-Wl,-rpath," + libdir])
     g = load_golden(name)
     mtx = str(tmp_path / (name + ".mtx"))
@@ -516,7 +516,7 @@ def test_cpp_uaamg_driver_vs_reference(tmp_path, name):
     exe = str(tmp_path / "multigrid_driver")
     libdir = os.path.join(root, "rocalution_amd")
     subprocess.check_call(["g++", "-std=c++14", "-O1", "-I" + os.path.join(root, "include"),
-                           os.path.join(root, "samples", "multigrid_driver.cpp"), "-o", exe, "-L" + libdir,
+                           os.path.join(root, "tests", "drivers", "multigrid_driver.cpp"), "-o", exe, "-L" + libdir,
                            "-lrocalution_amd", "-Wl,-rpath," + libdir])
     g = load_golden(name)
     mtx = str(tmp_path / (name + ".mtx"))
