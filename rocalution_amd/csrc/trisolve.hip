@@ -2107,7 +2107,10 @@ __global__ __launch_bounds__(kBlock) void k_ct_step_nexp(int nsteps, const int* 
         for(int p = p0; p < p1; ++p)
             if(mark[p])
                 last = p - p0 + 1;
-        nexp[g] = last;
+        // (never 0: the compute wave counts its vector memory operations per step by hand -- one store, then the record
+        //  loads -- and a step whose store instruction is skipped because no lane has anything to publish would let the
+        //  wait for a record through one operation early; row 0 of a step without exported rows is published for that reason)
+        nexp[g] = last > 0 ? last : 1;
     }
 }
 
@@ -2837,7 +2840,9 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
         } st = {uni(rec.x), uni(rec.y) & 0xff, uni(rec.z), uni(rec.w), uni(stq.tf) >> 2, uni(stq.tf) & 3};
         const int maxg = (uni(rec.y) >> 8) & 0xff; // grouped form: rows of the step's largest group
         // rows of the step whose value another tile reads: [0, nexp) -- all of them where w is also the stage's result
-        const int nexp = dims.mask_pub ? ((uni(rec.y) >> 16) & 0xff) : 64;
+        // (at least 1: the publication store is one of the step's hand-counted vector memory operations -- it has to be ISSUED
+        //  in every step, i.e. with at least one active lane; see k_ct_step_nexp)
+        const int nexp = dims.mask_pub ? max(1, (uni(rec.y) >> 16) & 0xff) : 64;
         const int nl   = st.cnt * LPR; // lane records of the step
         const int lrec = min(lane, nl - 1);
         const int row  = (int)((unsigned)lrec / (unsigned)LPR); // row of the step this lane works for

@@ -403,3 +403,30 @@ def test_bench_other_configs_multi_rank_rehearsal(flags):
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["rehearsal"] is True
     assert sum(r["rows"] for r in out["roofline"]["per_rank"]) == 64 ** 3
     assert np.isfinite(out["final_residual"])
+
+
+def test_bench_under_torch_distributed_run_rehearsed_on_one_gpu():
+    """the launch form the driver uses for N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the launcher, rank 0
+    prints the one JSON line -- with the host-staged transport on one device; a launcher world size that differs from
+    --gpus is refused"""
+    import json
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.join(ROOT, "bench.py")]
+    p = subprocess.run(base + ["--gpus", "2", "--grid", "64", "--steps", "12", "--warmup", "3", "--transport", "callback"], env=e,
+                       timeout=900, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 12 and out["value"] > 0 and out["rehearsal"] is True
+    assert sum(r["rows"] for r in out["roofline"]["per_rank"]) == 64 ** 3
+    p = subprocess.run(base + ["--gpus", "4", "--grid", "64", "--steps", "12", "--warmup", "3", "--transport", "callback"], env=e,
+                       timeout=900, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode != 0 and "refusing" in p.stderr
