@@ -353,35 +353,22 @@ hipError_t cached_malloc_apart(void** p, size_t bytes, const void* other)
     const int avoid = other ? cached_block_class(other) : -1;
     if(avoid < 0)
         return cached_malloc_bytes(p, bytes);
-    std::vector<void*> rejects, spacers;
+    std::vector<void*> rejects;
     hipError_t         e = hipSuccess;
-    // (a fresh GiB costs 1 ... 100 ms of hipMalloc depending on the box: few draws)
-    // Blocks handed out one after the other come in RUNS of one class (tools/class_map.py, round 4: runs of 4 ... 30 GiB over the
-    // whole device memory, the class of the reference block the rarer one): drawing again next to a rejected block mostly
-    // draws the same class.  After two rejects a SPACER (8, then 16, then 32 GiB, never stored to, freed when the search ends;
-    // only while placement_room allows) is put between the draws, so that the next one comes from farther away.
-    // RAMD_ALLOC_SPACER=0: no spacers (A/B).
-    static const bool spacer_on = !(getenv("RAMD_ALLOC_SPACER") && atoi(getenv("RAMD_ALLOC_SPACER")) == 0);
-    constexpr int     kDraws    = 7;
+    // (a fresh GiB costs 1 ... 100 ms of hipMalloc depending on the box: few draws.  Blocks handed out one after the other
+    //  come in RUNS of one class -- tools/class_map.py, round 4: runs of 4 ... 30 GiB over the whole device memory, the
+    //  reference block's class the rarer one -- so a draw next to a rejected block mostly draws the same class; putting
+    //  spacers of 8 / 16 / 32 GiB between the draws was measured: 6-9 s of hipMalloc / hipFree per search, gpurun_out/r04t,
+    //  removed)
+    constexpr int kDraws = 4;
     for(int draw = 0; draw < kDraws; ++draw)
     {
-        if(spacer_on && draw >= 2 && draw <= 4)
-        {
-            const size_t sb = (size_t)8 << (30 + (draw - 2)); // 8, 16, 32 GiB
-            void*        sp = nullptr;
-            if(placement_room(sb + bytes, 1) && hipMalloc(&sp, sb) == hipSuccess)
-                spacers.push_back(sp);
-            else
-                (void)hipGetLastError();
-        }
-        else if(!spacer_on && draw >= 4)
-            break;
         void* q = nullptr;
         e       = cached_malloc_bytes(&q, bytes);
         if(e != hipSuccess)
             break;
         const int k = cached_block_class(q);
-        if(k < 0 || k != avoid || draw == kDraws - 1 || (!spacer_on && draw == 3))
+        if(k < 0 || k != avoid || draw == kDraws - 1)
         {
             *p = q;
             break;
@@ -390,10 +377,6 @@ hipError_t cached_malloc_apart(void** p, size_t bytes, const void* other)
     }
     for(void* r : rejects)
         (void)cached_free(r);
-    for(void* sp : spacers)
-        (void)hipFree(sp);
-    if(e == hipSuccess && *p == nullptr && !rejects.empty())
-        e = cached_malloc_bytes(p, bytes); // (every draw was rejected and given back: any block will do)
     return e;
 }
 
