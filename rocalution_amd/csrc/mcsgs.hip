@@ -353,6 +353,12 @@ __global__ __launch_bounds__(kBlock) void k_mc_sweep(int p0, int p1, const int* 
     }
 }
 
+// Measured and removed (round 4): TWO ROWS PER THREAD for these sweeps (pattern numbers, permutation, diagonal, inverse, work
+// values and the slot pairs of both rows read with accesses of twice the width, twice the gathers in flight per thread --
+// the step that took the ELL product from 2.15 to 1.85 ms, k_ell2): MC-SGS apply 3.30-3.34 ms against 3.17 ms in
+// alternating runs (gpurun_out/r04v).  The sweeps' values already come in 16-byte slot pairs; what the ELL product gained
+// was exactly that.
+
 // pairs of the output (see McsgsPlan): row t of colour 0 takes the row next to it in its aligned pair of out along where that
 // row has another colour
 __global__ __launch_bounds__(kBlock) void k_mc_pairs(int n, int n0, const int* __restrict__ iperm, const int* __restrict__ perm,

@@ -1121,6 +1121,148 @@ __global__ __launch_bounds__(kBlock) void k_ell(int nrow, int ncol, int width,
 
 
 
+// ELL, TWO ROWS PER THREAD (k_ell2; structured operators -- row patterns -- with an even row count of 2^16 rows and more,
+// RAMD_ELL2=0/1: off / any even size).
+// The reference's layout puts slot el of neighbouring rows side by side (ELL_IND = el * nrow + row), so a thread that owns
+// rows 2t and 2t + 1 reads a slot's two values with ONE 16-byte access and its two columns with one 8-byte access, y and the
+// pattern numbers in pairs as well: a third fewer memory instructions per row, and the streamed part of the product in
+// 16-byte accesses (8-byte accesses stream at 0.54-0.70 of that rate, MI355X_MICROARCH.md).  The gathers stay per row.  Each
+// row's products are added in slot order as in k_ell: y is bit-identical; the fused <x, y> sums two rows per lane before
+// the wave reduction (one partial per 128 rows), i.e. differs from k_ell's in the last bits like any other summation order.
+template <typename T, int MODE, bool STOP, bool DOT, bool PAT>
+__global__ __launch_bounds__(kBlock) void k_ell2(int nrow, int ncol, int width, const int* __restrict__ ecol,
+                                                 const T* __restrict__ eval, const T* __restrict__ x, T* __restrict__ y,
+                                                 T scalar, double* __restrict__ part1, const T* __restrict__ dotv, int nblk,
+                                                 int per_xcd, BandMap bm, CsrPattern pat)
+{
+    using P2 = T __attribute__((ext_vector_type(2)));
+    using I2 = int __attribute__((ext_vector_type(2)));
+    __shared__ int sdict[PAT ? kPatMax * kPatMaxW : 1];
+    double         dacc = 0.0;
+    const int      blk  = xcd_block(nblk, per_xcd, bm); // (a block = 2 * kBlock rows)
+    const int64_t  r0   = ((int64_t)blk * kBlock + threadIdx.x) * 2; // rows r0 and r0 + 1 (nrow is even)
+    const bool     live = blk >= 0 && r0 < nrow;
+    constexpr int  NDW  = PAT ? kPatMax * kPatMaxW / kBlock : 0;
+    int            dreg[NDW > 0 ? NDW : 1];
+    P2             v0[kGatherW];
+    int            pidA = 0, pidB = 0;
+    P2             sum  = {(T)0, (T)0};
+    if(PAT)
+    {
+#pragma unroll
+        for(int q = 0; q < NDW; ++q)
+        {
+            const int i = q * kBlock + threadIdx.x;
+            dreg[q]     = i < pat.n * kPatMaxW ? pat.dict[i] : 0;
+        }
+    }
+    if(live)
+    {
+        if(PAT)
+        {
+            const unsigned short pp = *reinterpret_cast<const unsigned short*>(pat.id + r0);
+            pidA                    = pp & 0xff;
+            pidB                    = pp >> 8;
+        }
+        if(MODE == 1)
+            sum = *reinterpret_cast<const P2*>(y + r0);
+#pragma unroll
+        for(int e = 0; e < kGatherW; ++e)
+            if(e < width)
+                v0[e] = nt_load(reinterpret_cast<const P2*>(eval + (int64_t)e * nrow + r0));
+    }
+    if(PAT)
+    {
+#pragma unroll
+        for(int q = 0; q < NDW; ++q)
+        {
+            const int i = q * kBlock + threadIdx.x;
+            if(i < pat.n * kPatMaxW)
+                sdict[i] = dreg[q];
+        }
+        __syncthreads();
+    }
+    if(live)
+    {
+        T    sA = sum.x, sB = sum.y;
+        bool stopA = false, stopB = false;
+        for(int el = 0; el < width && !(stopA && stopB); el += kGatherW)
+        {
+            int cA[kGatherW], cB[kGatherW];
+            P2  v[kGatherW];
+            T   xA[kGatherW], xB[kGatherW];
+#pragma unroll
+            for(int e = 0; e < kGatherW; ++e)
+            {
+                cA[e] = cB[e] = -1;
+                if(el + e < width)
+                {
+                    if(PAT)
+                    {
+                        const int oA = sdict[pidA * kPatMaxW + el + e], oB = sdict[pidB * kPatMaxW + el + e];
+                        cA[e]        = oA == kPatEnd ? -1 : (int)r0 + oA;
+                        cB[e]        = oB == kPatEnd ? -1 : (int)r0 + 1 + oB;
+                    }
+                    else
+                    {
+                        const I2 cc = nt_load(reinterpret_cast<const I2*>(ecol + (int64_t)(el + e) * nrow + r0));
+                        cA[e]       = cc.x;
+                        cB[e]       = cc.y;
+                    }
+                    v[e] = el == 0 ? v0[e] : nt_load(reinterpret_cast<const P2*>(eval + (int64_t)(el + e) * nrow + r0));
+                }
+            }
+            bool useA[kGatherW], useB[kGatherW];
+#pragma unroll
+            for(int e = 0; e < kGatherW; ++e)
+            {
+                if(STOP) // ELL: everything after a row's first negative column is padding
+                {
+                    if(el + e < width && cA[e] < 0)
+                        stopA = true;
+                    if(el + e < width && cB[e] < 0)
+                        stopB = true;
+                    useA[e] = (el + e < width) && !stopA;
+                    useB[e] = (el + e < width) && !stopB;
+                }
+                else // HYB-ELL: skip invalid columns
+                {
+                    useA[e] = (el + e < width) && cA[e] >= 0 && cA[e] < ncol;
+                    useB[e] = (el + e < width) && cB[e] >= 0 && cB[e] < ncol;
+                }
+                if(useA[e])
+                    xA[e] = x[cA[e]];
+                if(useB[e])
+                    xB[e] = x[cB[e]];
+            }
+#pragma unroll
+            for(int e = 0; e < kGatherW; ++e)
+            {
+                if(useA[e])
+                    sA += (MODE == 0) ? v[e].x * xA[e] : scalar * v[e].x * xA[e];
+                if(useB[e])
+                    sB += (MODE == 0) ? v[e].y * xB[e] : scalar * v[e].y * xB[e];
+            }
+        }
+        P2 out;
+        out.x = sA;
+        out.y = sB;
+        nt_store(out, reinterpret_cast<P2*>(y + r0));
+        if(DOT)
+        {
+            const P2 w2 = *reinterpret_cast<const P2*>((dotv ? dotv : x) + r0);
+            dacc += (double)sA * (double)w2.x;
+            dacc += (double)sB * (double)w2.y;
+        }
+    }
+    if(DOT) // one partial per wave (128 rows), summed in fixed order by a second tiny launch
+    {
+        const double wsum = wave_reduce_sum(dacc);
+        if((threadIdx.x & 63) == 0 && blk >= 0)
+            part1[blk * (kBlock / 64) + (threadIdx.x >> 6)] = wsum;
+    }
+}
+
 // DIA (host_matrix_dia.cpp:300-412): one thread per row, diagonal d contributes val[d*nrow + row] * x[row + offset_d]
 // when 0 <= row + offset_d < nrow (the host's start/end/break tests for ascending offsets); padded zeros ARE
 // multiplied, as on the host.  Values stream coalesced with no index array: 8 B per stored entry.
@@ -1937,10 +2079,32 @@ static int launch_ell(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
         RAMD_TRY(ell_analyse_pattern(const_cast<ramd_mat_s*>(m)));
     const bool       use_pat = pat_env != 0 && m->pat_state == 1 && !m->pat_off;
     const CsrPattern pat     = {use_pat ? m->pat_id : nullptr, use_pat ? m->pat_dict : nullptr, m->pat_n, m->pat_w};
+    // two rows per thread (k_ell2) where the pairs are aligned: an even number of rows
+    static const int ell2_env = getenv("RAMD_ELL2") ? atoi(getenv("RAMD_ELL2")) : -1;
+    // (row patterns only: with the columns read the pair kernel needs 206 registers -- 2 waves per SIMD -- and runs at
+    //  3.8-4.0 ms against k_ell's 2.4 ms at 512^3; with patterns 126 registers and 1.81-1.88 against 2.12-2.19 ms, gpurun_out/r04u)
+    const bool       use2     = use_pat && (m->nrow % 2 == 0) && m->nrow > 0 && (ell2_env >= 0 ? ell2_env != 0 : m->nrow >= (1 << 16));
+    const int        nblk2    = (m->nrow + 2 * kCsrRows - 1) / (2 * kCsrRows);
+    const int        per_xcd2 = (nblk2 + 7) / 8;
+    BandMap          bm2      = {0, 0, 0};
+    if(use2 && m->band_dist > 0 && m->band_dist % (2 * kCsrRows) == 0)
+    {
+        bm2.P = m->band_dist / (2 * kCsrRows);
+        bm2.Z = per_xcd2 / bm2.P;
+        bm2.W = 16;
+        while(bm2.W > 1 && bm2.P % bm2.W != 0)
+            bm2.W >>= 1;
+        if(bm2.Z < 3)
+            bm2.P = 0;
+    }
 #define LAUNCH(MODE, STOP, DOT)                                                                          \
     do                                                                                                   \
     {                                                                                                    \
-        if(use_pat)                                                                                      \
+        if(use2)                                                                                         \
+            hipLaunchKernelGGL((k_ell2<T, MODE, STOP, DOT, true>), dim3(per_xcd2 * 8), dim3(kBlock), 0, b.cur, m->nrow, \
+                               m->ncol, m->ell_width, m->ell_col, (const T*)m->ell_val, x, y, scalar, part1, \
+                               dotv, nblk2, per_xcd2, bm2, pat);                                         \
+        else if(use_pat)                                                                                 \
             hipLaunchKernelGGL((k_ell<T, MODE, STOP, DOT, true>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, \
                                m->ncol, m->ell_width, m->ell_col, (const T*)m->ell_val, x, y, scalar, part1, \
                                dotv, nblk, per_xcd, bm, pat);                                            \
@@ -1964,7 +2128,7 @@ static int launch_ell(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
 #undef LAUNCH
     RAMD_HIP(hipGetLastError());
     if(dot)
-        return reduce_sum_to_slot(part1, (int64_t)nblk * (kBlock / 64), slot);
+        return reduce_sum_to_slot(part1, (int64_t)(use2 ? nblk2 : nblk) * (kBlock / 64), slot);
     return RAMD_OK;
 }
 
