@@ -1121,15 +1121,15 @@ __global__ __launch_bounds__(kBlock) void k_ell(int nrow, int ncol, int width,
 
 
 
-// ELL, TWO ROWS PER THREAD (k_ell2; structured operators -- row patterns -- with an even row count of 2^16 rows and more,
-// RAMD_ELL2=0/1: off / any even size).
+// ELL, TWO ROWS PER THREAD (k_ell2; operators with an even row count of 2^16 rows and more, RAMD_ELL2=0/1: off / any even size;
+// GW slots per batch: 8 with row patterns, 4 with the columns read).
 // The reference's layout puts slot el of neighbouring rows side by side (ELL_IND = el * nrow + row), so a thread that owns
 // rows 2t and 2t + 1 reads a slot's two values with ONE 16-byte access and its two columns with one 8-byte access, y and the
 // pattern numbers in pairs as well: a third fewer memory instructions per row, and the streamed part of the product in
 // 16-byte accesses (8-byte accesses stream at 0.54-0.70 of that rate, MI355X_MICROARCH.md).  The gathers stay per row.  Each
 // row's products are added in slot order as in k_ell: y is bit-identical; the fused <x, y> sums two rows per lane before
 // the wave reduction (one partial per 128 rows), i.e. differs from k_ell's in the last bits like any other summation order.
-template <typename T, int MODE, bool STOP, bool DOT, bool PAT>
+template <typename T, int MODE, bool STOP, bool DOT, bool PAT, int GW = kGatherW>
 __global__ __launch_bounds__(kBlock) void k_ell2(int nrow, int ncol, int width, const int* __restrict__ ecol,
                                                  const T* __restrict__ eval, const T* __restrict__ x, T* __restrict__ y,
                                                  T scalar, double* __restrict__ part1, const T* __restrict__ dotv, int nblk,
@@ -1144,7 +1144,7 @@ __global__ __launch_bounds__(kBlock) void k_ell2(int nrow, int ncol, int width, 
     const bool     live = blk >= 0 && r0 < nrow;
     constexpr int  NDW  = PAT ? kPatMax * kPatMaxW / kBlock : 0;
     int            dreg[NDW > 0 ? NDW : 1];
-    P2             v0[kGatherW];
+    P2             v0[GW];
     int            pidA = 0, pidB = 0;
     P2             sum  = {(T)0, (T)0};
     if(PAT)
@@ -1167,7 +1167,7 @@ __global__ __launch_bounds__(kBlock) void k_ell2(int nrow, int ncol, int width, 
         if(MODE == 1)
             sum = *reinterpret_cast<const P2*>(y + r0);
 #pragma unroll
-        for(int e = 0; e < kGatherW; ++e)
+        for(int e = 0; e < GW; ++e)
             if(e < width)
                 v0[e] = nt_load(reinterpret_cast<const P2*>(eval + (int64_t)e * nrow + r0));
     }
@@ -1186,13 +1186,13 @@ __global__ __launch_bounds__(kBlock) void k_ell2(int nrow, int ncol, int width, 
     {
         T    sA = sum.x, sB = sum.y;
         bool stopA = false, stopB = false;
-        for(int el = 0; el < width && !(stopA && stopB); el += kGatherW)
+        for(int el = 0; el < width && !(stopA && stopB); el += GW)
         {
-            int cA[kGatherW], cB[kGatherW];
-            P2  v[kGatherW];
-            T   xA[kGatherW], xB[kGatherW];
+            int cA[GW], cB[GW];
+            P2  v[GW];
+            T   xA[GW], xB[GW];
 #pragma unroll
-            for(int e = 0; e < kGatherW; ++e)
+            for(int e = 0; e < GW; ++e)
             {
                 cA[e] = cB[e] = -1;
                 if(el + e < width)
@@ -1212,9 +1212,9 @@ __global__ __launch_bounds__(kBlock) void k_ell2(int nrow, int ncol, int width, 
                     v[e] = el == 0 ? v0[e] : nt_load(reinterpret_cast<const P2*>(eval + (int64_t)(el + e) * nrow + r0));
                 }
             }
-            bool useA[kGatherW], useB[kGatherW];
+            bool useA[GW], useB[GW];
 #pragma unroll
-            for(int e = 0; e < kGatherW; ++e)
+            for(int e = 0; e < GW; ++e)
             {
                 if(STOP) // ELL: everything after a row's first negative column is padding
                 {
@@ -1236,7 +1236,7 @@ __global__ __launch_bounds__(kBlock) void k_ell2(int nrow, int ncol, int width, 
                     xB[e] = x[cB[e]];
             }
 #pragma unroll
-            for(int e = 0; e < kGatherW; ++e)
+            for(int e = 0; e < GW; ++e)
             {
                 if(useA[e])
                     sA += (MODE == 0) ? v[e].x * xA[e] : scalar * v[e].x * xA[e];
@@ -2081,13 +2081,16 @@ static int launch_ell(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
     const CsrPattern pat     = {use_pat ? m->pat_id : nullptr, use_pat ? m->pat_dict : nullptr, m->pat_n, m->pat_w};
     // two rows per thread (k_ell2) where the pairs are aligned: an even number of rows
     static const int ell2_env = getenv("RAMD_ELL2") ? atoi(getenv("RAMD_ELL2")) : -1;
-    // (row patterns only: with the columns read the pair kernel needs 206 registers -- 2 waves per SIMD -- and runs at
-    //  3.8-4.0 ms against k_ell's 2.4 ms at 512^3; with patterns 126 registers and 1.81-1.88 against 2.12-2.19 ms, gpurun_out/r04u)
+    // (with patterns eight slots per batch: 126 registers, 1.81-1.88 against 2.12-2.19 ms at 512^3, gpurun_out/r04u; eight slots
+    //  per batch with the columns read need 206 registers -- 2 waves per SIMD -- and ran at 3.8-4.0 ms against k_ell's 2.4 ms)
     const bool       use2     = use_pat && (m->nrow % 2 == 0) && m->nrow > 0 && (ell2_env >= 0 ? ell2_env != 0 : m->nrow >= (1 << 16));
+    // ... with the columns read: four slots per batch (76 registers, 6 waves per SIMD) -- 2.27-2.48 ms against k_ell's
+    // 2.42-2.55 ms in alternating runs (gpurun_out/r04x): a few per cent, taken
+    const bool       use2c    = !use_pat && (m->nrow % 2 == 0) && m->nrow > 0 && (ell2_env >= 0 ? ell2_env != 0 : m->nrow >= (1 << 16));
     const int        nblk2    = (m->nrow + 2 * kCsrRows - 1) / (2 * kCsrRows);
     const int        per_xcd2 = (nblk2 + 7) / 8;
     BandMap          bm2      = {0, 0, 0};
-    if(use2 && m->band_dist > 0 && m->band_dist % (2 * kCsrRows) == 0)
+    if((use2 || use2c) && m->band_dist > 0 && m->band_dist % (2 * kCsrRows) == 0)
     {
         bm2.P = m->band_dist / (2 * kCsrRows);
         bm2.Z = per_xcd2 / bm2.P;
@@ -2102,6 +2105,10 @@ static int launch_ell(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
     {                                                                                                    \
         if(use2)                                                                                         \
             hipLaunchKernelGGL((k_ell2<T, MODE, STOP, DOT, true>), dim3(per_xcd2 * 8), dim3(kBlock), 0, b.cur, m->nrow, \
+                               m->ncol, m->ell_width, m->ell_col, (const T*)m->ell_val, x, y, scalar, part1, \
+                               dotv, nblk2, per_xcd2, bm2, pat);                                         \
+        else if(use2c)                                                                                   \
+            hipLaunchKernelGGL((k_ell2<T, MODE, STOP, DOT, false, 4>), dim3(per_xcd2 * 8), dim3(kBlock), 0, b.cur, m->nrow, \
                                m->ncol, m->ell_width, m->ell_col, (const T*)m->ell_val, x, y, scalar, part1, \
                                dotv, nblk2, per_xcd2, bm2, pat);                                         \
         else if(use_pat)                                                                                 \
@@ -2128,7 +2135,7 @@ static int launch_ell(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
 #undef LAUNCH
     RAMD_HIP(hipGetLastError());
     if(dot)
-        return reduce_sum_to_slot(part1, (int64_t)(use2 ? nblk2 : nblk) * (kBlock / 64), slot);
+        return reduce_sum_to_slot(part1, (int64_t)((use2 || use2c) ? nblk2 : nblk) * (kBlock / 64), slot);
     return RAMD_OK;
 }
 

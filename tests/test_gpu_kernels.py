@@ -1153,7 +1153,7 @@ def test_csr_row_patterns_give_up_quickly_on_a_large_unstructured_matrix(ra, ora
 
 
 @pytest.mark.parametrize("variant", ["RAMD_CSR_Q4=1", "RAMD_CSR_PAT=1", "RAMD_CSR_PAT=1,RAMD_CSR_XL=1", "RAMD_CSR_PAT=0",
-                                     "RAMD_CSR_PAT=0,RAMD_CSR_GRP=1", "RAMD_CSR_PAT=1,RAMD_CSR_PAT2=0", "RAMD_ELL2=1,RAMD_CSR_PAT=1", "RAMD_CSR_PAT=0,RAMD_CSR_COL2=2", "RAMD_CSR_PAT=1,RAMD_CSR_NORP=1",
+                                     "RAMD_CSR_PAT=0,RAMD_CSR_GRP=1", "RAMD_CSR_PAT=1,RAMD_CSR_PAT2=0", "RAMD_ELL2=1,RAMD_CSR_PAT=1", "RAMD_ELL2=1,RAMD_CSR_PAT=0", "RAMD_CSR_PAT=0,RAMD_CSR_COL2=2", "RAMD_CSR_PAT=1,RAMD_CSR_NORP=1",
                                      "RAMD_CSR_PAT=0,RAMD_CSR_W4=1", "RAMD_CSR_PAT=0,RAMD_CSR_W4=1,RAMD_CSR_W4_WAVES=1", "RAMD_CSR_PAT=0,RAMD_CSR_PIPE=1"])
 def test_spmv_variants_forced_in_a_fresh_process(variant):
     """the CSR SpMV has an opt-in four-lanes-per-row walk (k_csr_q4), and CSR / ELL / HYB products and the multi-colour
