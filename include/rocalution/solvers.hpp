@@ -1938,12 +1938,17 @@ private:
         VectorType* zdir = precond ? kz : kr;
         auto update    = [&]() { RAMD_CHECK(ramd_fused_cg_update(_fh(*kr), _fh(*kq), dinv, dinv ? _fh(*kz) : NULL, 1, 0, 2, 3)); };
         auto direction = [&]() { RAMD_CHECK(ramd_fused_cg_direction(_fh(*x), _fh(*kp), _fh(*zdir), 1, 0, 3)); };
+        // (candidates per vector: fresh blocks of one process come in runs of one placement class -- tools/class_map.py --, so a
+        //  longer search reaches farther.  Six fresh processes each, alternating, gpurun_out/r04y: with up to 24 candidates both
+        //  update kernels at 0.852-0.857 ms in all six, with up to 8 at 0.90 / 0.93 ms in two of six; the search ends at the
+        //  first fast block, 0.04-0.11 s either way.  RAMD_PLACE_DRAWS overrides.)
+        static const int draws = getenv("RAMD_PLACE_DRAWS") ? atoi(getenv("RAMD_PLACE_DRAWS")) : 24;
         if(precond)
-            kz->PlaceByTrial(update, 8, 0.94, kr);
+            kz->PlaceByTrial(update, draws, 0.94, kr);
         // (r is the other vector the residual update writes: where no block for z made it fast -- all ten runs of one series,
         //  gpurun_out/r03bi -- another block for r may; where it is fast already this costs one candidate)
-        kr->PlaceByTrial(update, 6, 0.94, precond ? kz : kq);
-        kp->PlaceByTrial(direction, 8, 0.94, x);
+        kr->PlaceByTrial(update, draws > 8 ? draws : 6, 0.94, precond ? kz : kq);
+        kp->PlaceByTrial(direction, draws, 0.94, x);
         // (RAMD_PLACE_Q=k: q, the output of the product, by timing the product with k fresh blocks -- measured without
         //  gain for the product, 2.27-2.28 ms either way, and q is read by the residual update, which then lost its fast
         //  placement in half the runs: gpurun_out/r03av, third series.  A Global product exchanges halos, so every rank
