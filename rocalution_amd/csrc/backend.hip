@@ -57,7 +57,7 @@ using namespace ramd;
 // multiple of 2 MiB that is congruent to k * 32 MiB modulo 512 MiB, so equally sized work vectors allocated one after the
 // other lie (size rounded up to 512 MiB) + 32 MiB apart.  Measured with the solver's own kernels: reproducible to +-0.4 % over
 // fresh processes -- but always in the SLOW mode (k_cg_update 5.1-5.3 TB/s for every group and every offset step), because
-// one allocation is one placement class (below).  Arenas are therefore opt-in (RAMD_ALLOC_ARENA=1, experiments).
+// one allocation is one placement class (below).  For the work vectors arenas are therefore out; since round 4 they hold the blocks of 2 GiB and more (matrix arrays, see cached_malloc_bytes).
 //
 // Placement classes.  What the lottery really draws (tools/placement2.hip w, profiles/r03_placement_pairs.txt): every big
 // block belongs to one of TWO classes (where the driver put it), and what a kernel with two WRITE streams gets depends on
@@ -70,7 +70,8 @@ namespace ramd
 {
 namespace
 {
-constexpr size_t kArenaMinBlock = (size_t)64 << 20; // blocks from this size on live in arenas
+constexpr size_t kArenaMinBlock = (size_t)64 << 20; // smallest block an arena may hold (RAMD_ARENA_MIN_MB)
+constexpr size_t kArenaDefaultMin = (size_t)2 << 30; // blocks from this size on live in arenas by default
 constexpr size_t kArenaBytes    = (size_t)32 << 30; // default size of an arena
 constexpr size_t kArenaPhase    = (size_t)32 << 20; // offset step between consecutive blocks ...
 constexpr size_t kArenaModulus  = (size_t)512 << 20; // ... modulo this
@@ -100,7 +101,7 @@ struct AllocCache
         if(arena_on < 0)
         {
             const char* e = getenv("RAMD_ALLOC_ARENA");
-            arena_on      = (e && atoi(e) != 0) ? 1 : 0;
+            arena_on      = (e && atoi(e) == 0) ? 0 : 1; // (on by default since round 4 -- for the blocks of kArenaDefaultMin and more)
         }
         return arena_on == 1 && on();
     }
@@ -400,7 +401,15 @@ hipError_t cached_malloc_bytes(void** p, size_t bytes)
             return hipSuccess;
         }
     }
-    if(c.use_arenas() && need >= kArenaMinBlock)
+    // Which blocks live in arenas: by default those of 2 GiB and more -- at 512^3 the column and value arrays of a matrix, of
+    // its solve plans and colour parts, NOT the 1-GiB work vectors.  One arena is one placement class, and streams that are
+    // only READ together prefer one class: with a matrix' arrays side by side in an arena the CSR product that reads the
+    // stored columns ran at 2.29-2.46 ms against 2.49-2.59 ms, the row-pattern product at 2.05-2.09 against 1.97-2.13 ms
+    // (same mean, a third of the spread), four fresh processes each, alternating (gpurun_out/r04za); vectors a kernel WRITES
+    // in pairs want different classes and stay outside (everything in arenas, RAMD_ARENA_MIN_MB=64: the slow mode of the
+    // update kernels in one run of four, 1-2 s of placement search).  RAMD_ALLOC_ARENA=0: no arenas.
+    static const size_t arena_min = getenv("RAMD_ARENA_MIN_MB") ? (size_t)atoll(getenv("RAMD_ARENA_MIN_MB")) << 20 : kArenaDefaultMin;
+    if(c.use_arenas() && need >= arena_min)
     {
         void* q = c.carve(need);
         if(q)
