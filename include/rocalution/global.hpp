@@ -716,6 +716,11 @@ public:
     // global_matrix.cpp:924-1009, device-resident: pack | halo over xGMI || interior SpMV | ghost +=
     void Apply(const GlobalVector<ValueType>& in, GlobalVector<ValueType>* out) const
     {
+        if(this->m_reverse)
+        {
+            this->doApplyReverse(in, out);
+            return;
+        }
         const bool comm = this->pm_ != NULL && (this->m_halo_plan > 0 || !this->pm_->peers().empty());
         if(comm)
         {
@@ -771,13 +776,20 @@ public:
     }
 
     // ---- aggregation AMG on the row-block decomposition (global_matrix.cpp:1038-1880 Transpose / TripleMatrixProduct,
-    // :2607-3558 AMG*Aggregate / AMG*Aggregation).  MI355X-first form: the aggregates of a rank stay inside its row block
-    // ("decoupled" aggregation), so the prolongation and restriction operators are block-diagonal -- no ghost part, no
-    // communication when a cycle applies them -- and only the Galerkin product exchanges data, once per level at Build:
-    // the prolongation rows of the boundary rows travel to the neighbours through the same halo exchange the SpMV uses.
-    // The coarse operator is again interior + ghost with a ParallelManager of its own (coarse boundary = the aggregates
-    // the boundary rows belong to).  On one rank this IS the LocalMatrix algorithm, kernel for kernel; over P ranks it is
-    // the P-way decoupled algorithm (the reference lets aggregates cross ranks: its hierarchy differs for P > 1).
+    // :2607-3558 AMG*Aggregate / AMG*Aggregation).  Two forms:
+    //  * coupled (PMIS, the reference's only strategy on more than one rank): the aggregates cross the rank boundaries
+    //    exactly as the reference's do -- the aggregation runs on the block [interior | ghost] with every per-node array
+    //    extended over the ghost nodes (ramd_mat_amg_pmis_aggregate_global) and numbers the aggregates as ONE rank would,
+    //    so the hierarchy (aggregates, P, the Galerkin operators) does not depend on the number of ranks.  A coarse row
+    //    lives on the rank that owns the root node of its aggregate.  P is interior + ghost with a halo plan over the
+    //    coarse vector; R = P^T is NOT assembled: it is applied as P_int^T x + the reverse exchange of P_ghost^T x (the
+    //    ghost columns' partial sums travel to their owners and are added there).  The Galerkin product is formed row
+    //    block by row block -- every rank multiplies out P^T (A P) over ITS fine rows (device SpGEMMs) and ships the
+    //    coarse rows it does not own to their owners, who add them up.
+    //  * decoupled (Greedy on more than one rank, an extension: the reference refuses, global_matrix.cpp:2607-2645; or
+    //    RAMD_GLOBAL_AMG=decoupled): the aggregates of a rank stay inside its row block, the prolongation and restriction
+    //    operators are block-diagonal and only the Galerkin product exchanges data.
+    // On one rank both are the LocalMatrix algorithm, kernel for kernel.
     template <class Obj>
     void CloneBackend(const Obj& src)
     {
@@ -796,7 +808,26 @@ public:
     void AMGPMISAggregate(ValueType eps, LocalVector<int>* connections, LocalVector<int>* aggregates,
                           LocalVector<int>* aggregate_root_nodes) const
     {
-        this->m_interior.AMGPMISAggregate(eps, connections, aggregates, aggregate_root_nodes);
+        this->m_amg.reset();
+        if(!this->doCoupled())
+        {
+            this->m_interior.AMGPMISAggregate(eps, connections, aggregates, aggregate_root_nodes);
+            return;
+        }
+        std::shared_ptr<AmgBlock> w(new AmgBlock);
+        this->doRowBlock(&w->block);
+        w->offsets   = doRankOffsets(this->pm_, this->m_interior.GetM());
+        w->first_row = w->offsets[(size_t)this->pm_->GetRank()];
+        connections->MoveToAccelerator();
+        aggregates->MoveToAccelerator();
+        aggregate_root_nodes->MoveToAccelerator();
+        w->numbers.MoveToAccelerator();
+        RAMD_CHECK(ramd_mat_amg_pmis_aggregate_global(
+            w->block.handle(), (double)eps, this->pm_->GetComm(), this->m_halo_plan, (int)this->pm_->peers().size(),
+            this->pm_->peers().data(), this->pm_->send_offset().data(), this->pm_->recv_offset().data(),
+            this->m_halo_rows.handle(), w->first_row, w->numbers.handle(), connections->handle(), aggregates->handle(),
+            aggregate_root_nodes->handle(), &w->agg_first, &w->agg_mine, &w->agg_total));
+        this->m_amg = w;
     }
     void AMGGreedyAggregate(ValueType eps, LocalVector<int>* connections, LocalVector<int>* aggregates,
                             LocalVector<int>* aggregate_root_nodes) const
@@ -807,6 +838,11 @@ public:
                                   GlobalMatrix<ValueType>* prolong) const
     {
         assert(prolong != NULL && prolong != this);
+        if(this->m_amg)
+        {
+            this->doProlongCoupled(0, static_cast<ValueType>(0), 0, aggregates, aggregates, aggregate_root_nodes, prolong);
+            return;
+        }
         this->m_interior.AMGUnsmoothedAggregation(aggregates, aggregate_root_nodes, &prolong->m_interior);
         prolong->doBlockDiagonal(this->pm_, this->GetM(), -1);
     }
@@ -815,6 +851,11 @@ public:
                                 int lumping_strat = 0) const
     {
         assert(prolong != NULL && prolong != this);
+        if(this->m_amg)
+        {
+            this->doProlongCoupled(1, relax, lumping_strat, connections, aggregates, aggregate_root_nodes, prolong);
+            return;
+        }
         // The smoothing step I - w D^-1 A_F uses the interior block: couplings across ranks do not widen the rows of P.  They
         // are treated the way the filtered matrix A_F treats weak connections -- lumped onto the diagonal -- so that the
         // rows of A_F next to a rank boundary keep their row sum and P still reproduces what the tentative prolongation
@@ -858,6 +899,11 @@ public:
     void Transpose(GlobalMatrix<ValueType>* T) const
     {
         assert(T != NULL && T != this);
+        if(this->m_coupled)
+        {
+            this->doTransposeCoupled(T);
+            return;
+        }
         RAMD_EXPECT(this->m_ghost.GetNnz() == 0);
         this->m_interior.Transpose(&T->m_interior);
         if(this->m_interior.GetNnz() == 0) // (nothing to transpose: an empty operator of the transposed shape)
@@ -870,6 +916,11 @@ public:
                              const GlobalMatrix<ValueType>& P)
     {
         assert(&R != this && &A != this && &P != this);
+        if(P.m_coupled)
+        {
+            this->doGalerkinCoupled(A, P);
+            return;
+        }
         RAMD_EXPECT(R.m_ghost.GetNnz() == 0 && P.m_ghost.GetNnz() == 0);
         this->m_interior.CloneBackend(A.m_interior);
         this->m_ghost.CloneBackend(A.m_interior);
@@ -1018,6 +1069,526 @@ public:
     }
 
 private:
+    // ==== the coupled form ================================================================================
+    struct AmgBlock // what AMGPMISAggregate leaves for the AMG*Aggregation call that follows it
+    {
+        LocalMatrix<ValueType> block;   // [interior | ghost]
+        LocalVector<int>       numbers; // global number of every node of the extended block
+        std::vector<int64_t>   offsets; // first row of every rank, and the global size
+        int64_t                first_row = 0, agg_first = 0, agg_mine = 0, agg_total = 0;
+    };
+    bool doCoupled(void) const
+    {
+        static const bool off = [] {
+            const char* e = std::getenv("RAMD_GLOBAL_AMG");
+            return e != NULL && std::string(e) == "decoupled";
+        }();
+        return !off && this->pm_ != NULL && this->pm_->GetNumProcs() > 1;
+    }
+    // [interior | ghost] of this operator as one CSR block on the device
+    void doRowBlock(LocalMatrix<ValueType>* block) const
+    {
+        LocalMatrix<ValueType>        ci, cg;
+        const LocalMatrix<ValueType>* pi = &this->m_interior;
+        const LocalMatrix<ValueType>* pg = &this->m_ghost;
+        if(pi->GetFormat() != CSR)
+        {
+            ci.CloneFrom(*pi);
+            ci.ConvertTo(CSR);
+            pi = &ci;
+        }
+        if(pg->GetNnz() > 0 && pg->GetFormat() != CSR)
+        {
+            cg.CloneFrom(*pg);
+            cg.ConvertTo(CSR);
+            pg = &cg;
+        }
+        block->MoveToAccelerator();
+        // (a ghost part without entries still has its columns: the halo pattern fixes their number)
+        RAMD_CHECK(ramd_mat_merge_columns(pi->handle(), pg->GetNnz() > 0 ? pg->handle() : NULL,
+                                          this->pm_->GetNumReceivers(), block->handle()));
+    }
+    // first entry of every rank's share of `local` items in rank order, and the total (one all-reduce)
+    static std::vector<int64_t> doRankOffsets(const ParallelManager* pm, int64_t local)
+    {
+        const int P = pm->GetNumProcs(), r = pm->GetRank();
+        const int cap = 48, first = RAMD_NSCALARS - 8 - cap;
+        RAMD_EXPECT(P <= cap);
+        for(int k = 0; k < P; ++k)
+            RAMD_CHECK(ramd_scalars_set(first + k, k == r ? (double)local : 0.0));
+        RAMD_CHECK(ramd_comm_allreduce_scalars(pm->GetComm(), first, P));
+        double v[48];
+        RAMD_CHECK(ramd_scalars_fetch(v, first, P));
+        std::vector<int64_t> off((size_t)P + 1, 0);
+        for(int k = 0; k < P; ++k)
+            off[(size_t)k + 1] = off[(size_t)k] + (int64_t)std::llround(v[k]);
+        return off;
+    }
+    // one exchange of this operator's halo pattern with 8-byte entries whatever the value type (setup data: numbers)
+    void doExchangeD(const std::vector<double>& send, std::vector<double>* recv) const
+    {
+        const int64_t ns = this->pm_->GetNumSenders(), nr = this->pm_->GetNumReceivers();
+        RAMD_EXPECT((int64_t)send.size() == ns);
+        LocalVector<double> s, r;
+        s.MoveToAccelerator();
+        r.MoveToAccelerator();
+        s.Allocate("setup data out", ns);
+        r.Allocate("setup data in", nr);
+        if(ns > 0)
+            s.CopyFromHostData(send.data());
+        RAMD_CHECK(ramd_comm_halo_begin_plan(this->pm_->GetComm(), this->m_halo_plan, s.handle(), r.handle(),
+                                             (int)this->pm_->peers().size(), this->pm_->peers().data(),
+                                             this->pm_->send_offset().data(), this->pm_->recv_offset().data()));
+        RAMD_CHECK(ramd_comm_halo_end(this->pm_->GetComm()));
+        recv->assign((size_t)nr, 0.0);
+        if(nr > 0)
+            r.CopyToHostData(recv->data());
+    }
+    // messages of any length between any two ranks (out[q]: what goes to rank q; returns what every rank sent here).
+    // Lengths first -- P - 1 all-reduces of one slot per rank, round k announcing the message for rank + k -- then ONE
+    // exchange in pairs.  A collective: every rank of the communicator calls it.
+    static std::vector<std::vector<double>> doTalk(const ParallelManager* pm, const std::vector<std::vector<double>>& out)
+    {
+        const int P = pm->GetNumProcs(), r = pm->GetRank();
+        const int cap = 48, first = RAMD_NSCALARS - 8 - cap;
+        RAMD_EXPECT(P <= cap && (int)out.size() == P);
+        std::vector<int64_t> nin((size_t)P, 0);
+        for(int k = 1; k < P; ++k)
+        {
+            for(int q = 0; q < P; ++q)
+                RAMD_CHECK(ramd_scalars_set(first + q, q == r ? (double)out[(size_t)((r + k) % P)].size() : 0.0));
+            RAMD_CHECK(ramd_comm_allreduce_scalars(pm->GetComm(), first, P));
+            double v[48];
+            RAMD_CHECK(ramd_scalars_fetch(v, first, P));
+            const int from    = (r - k + P) % P;
+            nin[(size_t)from] = (int64_t)std::llround(v[from]);
+        }
+        std::vector<int>     peers;
+        std::vector<int64_t> so(1, 0), ro(1, 0);
+        for(int q = 0; q < P; ++q)
+            if(q != r && (!out[(size_t)q].empty() || nin[(size_t)q] > 0))
+            {
+                peers.push_back(q);
+                so.push_back(so.back() + (int64_t)out[(size_t)q].size());
+                ro.push_back(ro.back() + nin[(size_t)q]);
+            }
+        std::vector<std::vector<double>> in((size_t)P);
+        if(peers.empty())
+            return in;
+        std::vector<double> hs((size_t)so.back()), hr((size_t)ro.back());
+        for(size_t k = 0; k < peers.size(); ++k)
+            std::copy(out[(size_t)peers[k]].begin(), out[(size_t)peers[k]].end(), hs.begin() + so[k]);
+        LocalVector<double> s, rv;
+        s.MoveToAccelerator();
+        rv.MoveToAccelerator();
+        s.Allocate("messages out", so.back());
+        rv.Allocate("messages in", ro.back());
+        if(!hs.empty())
+            s.CopyFromHostData(hs.data());
+        RAMD_CHECK(ramd_comm_halo_begin(pm->GetComm(), s.handle(), rv.handle(), (int)peers.size(), peers.data(), so.data(),
+                                        ro.data()));
+        RAMD_CHECK(ramd_comm_halo_end(pm->GetComm()));
+        if(!hr.empty())
+            rv.CopyToHostData(hr.data());
+        for(size_t k = 0; k < peers.size(); ++k)
+            in[(size_t)peers[k]].assign(hr.begin() + ro[k], hr.begin() + ro[k + 1]);
+        return in;
+    }
+    static int doOwner(const std::vector<int64_t>& offsets, int64_t id)
+    {
+        return (int)(std::upper_bound(offsets.begin(), offsets.end(), id) - offsets.begin()) - 1;
+    }
+    // this = the rows (rp, gcol, val) of a distributed operator whose columns are GLOBAL numbers of a space distributed
+    // by col_offsets: interior = the columns of this rank, ghost = the others in ascending order (= grouped by owner),
+    // and the halo pattern that brings the ghost columns' vector entries here -- every rank tells the owners which of
+    // their entries it needs (parallel_manager.cpp GenerateFromGhostColumnsWithParent_ and the boundary exchange after
+    // it do this for the reference).  A collective.
+    void doFromGlobalColumns(const ParallelManager* like, int64_t global_nrow, const std::vector<int64_t>& col_offsets,
+                             const std::vector<PtrType>& rp, const std::vector<int64_t>& gcol,
+                             const std::vector<ValueType>& val)
+    {
+        const int     P = like->GetNumProcs(), r = like->GetRank();
+        const int64_t n = (int64_t)rp.size() - 1, c0 = col_offsets[(size_t)r], nc = col_offsets[(size_t)r + 1] - c0;
+        std::vector<int64_t> ghost;
+        for(int64_t g : gcol)
+            if(g < c0 || g >= c0 + nc)
+                ghost.push_back(g);
+        std::sort(ghost.begin(), ghost.end());
+        ghost.erase(std::unique(ghost.begin(), ghost.end()), ghost.end());
+        std::vector<PtrType>   irp((size_t)n + 1, 0), grp((size_t)n + 1, 0);
+        std::vector<int>       ici, gci;
+        std::vector<ValueType> iva, gva;
+        std::vector<std::pair<int, ValueType>> row;
+        for(int64_t i = 0; i < n; ++i)
+        {
+            for(int part = 0; part < 2; ++part)
+            {
+                row.clear();
+                for(PtrType j = rp[(size_t)i]; j < rp[(size_t)i + 1]; ++j)
+                {
+                    const int64_t g   = gcol[(size_t)j];
+                    const bool    own = g >= c0 && g < c0 + nc;
+                    if(own == (part == 0))
+                        row.emplace_back(own ? (int)(g - c0)
+                                             : (int)(std::lower_bound(ghost.begin(), ghost.end(), g) - ghost.begin()),
+                                         val[(size_t)j]);
+                }
+                std::stable_sort(row.begin(), row.end(),
+                                 [](const std::pair<int, ValueType>& a, const std::pair<int, ValueType>& b) { return a.first < b.first; });
+                for(const std::pair<int, ValueType>& e : row)
+                {
+                    (part == 0 ? ici : gci).push_back(e.first);
+                    (part == 0 ? iva : gva).push_back(e.second);
+                }
+            }
+            irp[(size_t)i + 1] = (PtrType)ici.size();
+            grp[(size_t)i + 1] = (PtrType)gci.size();
+        }
+        this->m_interior.MoveToAccelerator();
+        this->m_ghost.MoveToAccelerator();
+        this->m_interior.AllocateCSR("Interior", (int64_t)ici.size(), n, nc);
+        if(!ici.empty())
+            this->m_interior.CopyFromCSR(irp.data(), ici.data(), iva.data());
+        this->m_ghost.AllocateCSR("Ghost", (int64_t)gci.size(), n, (int64_t)ghost.size());
+        if(!gci.empty())
+            this->m_ghost.CopyFromCSR(grp.data(), gci.data(), gva.data());
+        // who owns what I need; the owners learn it from me
+        std::vector<std::vector<double>> ask((size_t)P);
+        for(int64_t g : ghost)
+            ask[(size_t)doOwner(col_offsets, g)].push_back((double)g);
+        const std::vector<std::vector<double>> asked = doTalk(like, ask);
+        std::vector<int> peers, boundary, soff(1, 0), roff(1, 0);
+        for(int q = 0; q < P; ++q)
+            if(!ask[(size_t)q].empty() || !asked[(size_t)q].empty())
+            {
+                RAMD_EXPECT(q != r);
+                peers.push_back(q);
+                for(double g : asked[(size_t)q])
+                {
+                    const int64_t l = (int64_t)std::llround(g) - c0;
+                    RAMD_EXPECT(l >= 0 && l < nc);
+                    boundary.push_back((int)l);
+                }
+                soff.push_back((int)boundary.size());
+                roff.push_back(roff.back() + (int)ask[(size_t)q].size());
+            }
+        std::shared_ptr<ParallelManager> pm(new ParallelManager);
+        pm->SetMPICommunicator(like->GetComm());
+        pm->SetLocalNrow(n);
+        pm->SetLocalNcol(nc);
+        pm->SetGlobalNrow(global_nrow);
+        pm->SetGlobalNcol(col_offsets.back());
+        pm->SetBoundaryIndex((int)boundary.size(), boundary.data());
+        pm->SetReceivers((int)peers.size(), peers.data(), roff.data());
+        pm->SetSenders((int)peers.size(), peers.data(), soff.data());
+        this->m_own_pm      = pm;
+        this->pm_           = pm.get();
+        this->m_coupled     = true;
+        this->m_reverse     = false;
+        this->m_ghost_cols  = ghost;
+        this->m_col_offsets = col_offsets;
+        this->m_amg.reset();
+        this->doInitHalo();
+    }
+    // rows of P for the rows of this rank, columns = global aggregate numbers
+    void doProlongCoupled(int smoothed, ValueType relax, int lumping_strat, const LocalVector<int>& connections,
+                          const LocalVector<int>& aggregates, const LocalVector<int>& aggregate_root_nodes,
+                          GlobalMatrix<ValueType>* prolong) const
+    {
+        const AmgBlock&        w = *this->m_amg;
+        LocalMatrix<ValueType> Pl;
+        Pl.MoveToAccelerator();
+        RAMD_CHECK(ramd_mat_amg_prolong_global(w.block.handle(), smoothed, (double)relax, lumping_strat, connections.handle(),
+                                               aggregates.handle(), aggregate_root_nodes.handle(), w.agg_total, Pl.handle()));
+        const int64_t          n = Pl.GetM(), nnz = Pl.GetNnz();
+        std::vector<PtrType>   rp((size_t)n + 1, 0);
+        std::vector<int>       ci((size_t)nnz);
+        std::vector<ValueType> va((size_t)nnz);
+        if(nnz > 0)
+            Pl.CopyToCSR(rp.data(), ci.data(), va.data());
+        std::vector<int64_t> gc(ci.begin(), ci.end());
+        const std::vector<int64_t> coff = doRankOffsets(this->pm_, w.agg_mine);
+        RAMD_EXPECT(coff[(size_t)this->pm_->GetRank()] == w.agg_first && coff.back() == w.agg_total);
+        prolong->m_interior.CloneBackend(this->m_interior);
+        prolong->doDropHaloPlan();
+        prolong->doFromGlobalColumns(this->pm_, this->GetM(), coff, rp, gc, va);
+        this->m_amg.reset();
+    }
+    // R = P^T in the reverse form: interior = P_int^T, ghost = P_ghost^T (one row per ghost column of P); Apply adds the
+    // ghost rows' results into the rows of their owners -- the exchange of P run backwards
+    void doTransposeCoupled(GlobalMatrix<ValueType>* T) const
+    {
+        const ParallelManager* pp = this->pm_;
+        const int64_t          n = this->m_interior.GetM(), nc = this->m_interior.GetN(), ng = (int64_t)this->m_ghost_cols.size();
+        T->doDropHaloPlan();
+        T->m_interior.CloneBackend(this->m_interior);
+        T->m_ghost.CloneBackend(this->m_interior);
+        if(this->m_interior.GetNnz() > 0)
+            this->m_interior.Transpose(&T->m_interior);
+        else
+            T->m_interior.AllocateCSR("transposed", 0, nc, n);
+        if(this->m_ghost.GetNnz() > 0)
+            this->m_ghost.Transpose(&T->m_ghost);
+        else
+            T->m_ghost.AllocateCSR("transposed ghost", 0, ng, n);
+        // where the received partial sums go: row boundary[s] of the result += entry s (a 0/1 operator, so that equal
+        // targets -- a coarse node needed by two ranks -- add up in a fixed order)
+        const int64_t          ns = pp->GetNumSenders();
+        std::vector<PtrType>   srp((size_t)nc + 1, 0);
+        std::vector<int>       sci((size_t)ns);
+        std::vector<ValueType> sva((size_t)ns, static_cast<ValueType>(1));
+        const int*             b = pp->GetBoundaryIndex();
+        for(int64_t s2 = 0; s2 < ns; ++s2)
+            ++srp[(size_t)b[s2] + 1];
+        for(int64_t i = 0; i < nc; ++i)
+            srp[(size_t)i + 1] += srp[(size_t)i];
+        std::vector<PtrType> at(srp.begin(), srp.end() - 1);
+        for(int64_t s2 = 0; s2 < ns; ++s2)
+            sci[(size_t)at[(size_t)b[s2]]++] = (int)s2;
+        T->m_scatter.CloneBackend(this->m_interior);
+        T->m_scatter.AllocateCSR("reverse halo", ns, nc, ns);
+        if(ns > 0)
+            T->m_scatter.CopyFromCSR(srp.data(), sci.data(), sva.data());
+        // the pattern of P with the two directions swapped
+        std::vector<int> peers(pp->peers()), soff, roff;
+        for(int64_t o : pp->recv_offset())
+            soff.push_back((int)o);
+        for(int64_t o : pp->send_offset())
+            roff.push_back((int)o);
+        if(soff.empty())
+        {
+            soff.push_back(0);
+            roff.push_back(0);
+        }
+        std::shared_ptr<ParallelManager> pm(new ParallelManager);
+        pm->SetMPICommunicator(pp->GetComm());
+        pm->SetLocalNrow(nc);
+        pm->SetLocalNcol(n);
+        pm->SetGlobalNrow(pp->GetGlobalNcol());
+        pm->SetGlobalNcol(pp->GetGlobalNrow());
+        pm->SetReceivers((int)peers.size(), peers.data(), roff.data());
+        pm->SetSenders((int)peers.size(), peers.data(), soff.data());
+        T->m_own_pm  = pm;
+        T->pm_       = pm.get();
+        T->m_coupled = true;
+        T->m_reverse = true;
+        T->m_ghost_cols.clear();
+        T->m_col_offsets.clear();
+        T->m_send.MoveToAccelerator();
+        T->m_send.Allocate("reverse send buffer", ng);
+        T->m_recv.MoveToAccelerator();
+        T->m_recv.Allocate("reverse recv buffer", ns);
+    }
+    void doApplyReverse(const GlobalVector<ValueType>& in, GlobalVector<ValueType>* out) const
+    {
+        const bool comm = !this->pm_->peers().empty();
+        if(comm)
+        {
+            if(this->m_ghost.GetNnz() > 0)
+                this->m_ghost.Apply(in.m_owned, &this->m_send);
+            else if(this->m_send.GetSize() > 0)
+                this->m_send.Zeros();
+            RAMD_CHECK(ramd_comm_halo_begin(this->pm_->GetComm(), this->m_send.handle(), this->m_recv.handle(),
+                                            (int)this->pm_->peers().size(), this->pm_->peers().data(),
+                                            this->pm_->send_offset().data(), this->pm_->recv_offset().data()));
+        }
+        this->m_interior.Apply(in.m_owned, &out->m_owned);
+        if(comm)
+        {
+            RAMD_CHECK(ramd_comm_halo_end(this->pm_->GetComm()));
+            if(this->m_scatter.GetNnz() > 0)
+                this->m_scatter.ApplyAdd(this->m_recv, static_cast<ValueType>(1), &out->m_owned);
+        }
+    }
+    // this = P^T A P, P coupled (see the head of this section)
+    void doGalerkinCoupled(const GlobalMatrix<ValueType>& A, const GlobalMatrix<ValueType>& P)
+    {
+        const ParallelManager*      fpm  = A.pm_;
+        const int                   Pn   = fpm->GetNumProcs(), r = fpm->GetRank();
+        const std::vector<int64_t>& coff = P.m_col_offsets;
+        const int64_t n = A.m_interior.GetM(), ngA = fpm->GetNumReceivers(), ns = fpm->GetNumSenders();
+        const int64_t c0 = coff[(size_t)r], nc = coff[(size_t)r + 1] - c0;
+        RAMD_EXPECT(P.m_interior.GetM() == n && P.m_interior.GetN() == nc);
+        // rows of P on the host, global columns
+        std::vector<PtrType>   prp((size_t)n + 1, 0);
+        std::vector<int64_t>   pgc;
+        std::vector<ValueType> pva;
+        {
+            std::vector<PtrType>   irp((size_t)n + 1, 0), grp((size_t)n + 1, 0);
+            std::vector<int>       ici((size_t)P.m_interior.GetNnz()), gci((size_t)P.m_ghost.GetNnz());
+            std::vector<ValueType> iva(ici.size()), gva(gci.size());
+            if(!ici.empty())
+                P.m_interior.CopyToCSR(irp.data(), ici.data(), iva.data());
+            if(!gci.empty())
+                P.m_ghost.CopyToCSR(grp.data(), gci.data(), gva.data());
+            pgc.reserve(ici.size() + gci.size());
+            pva.reserve(ici.size() + gci.size());
+            for(int64_t i = 0; i < n; ++i)
+            {
+                for(PtrType j = irp[(size_t)i]; j < irp[(size_t)i + 1]; ++j)
+                {
+                    pgc.push_back(c0 + ici[(size_t)j]);
+                    pva.push_back(iva[(size_t)j]);
+                }
+                for(PtrType j = grp[(size_t)i]; j < grp[(size_t)i + 1]; ++j)
+                {
+                    pgc.push_back(P.m_ghost_cols[(size_t)gci[(size_t)j]]);
+                    pva.push_back(gva[(size_t)j]);
+                }
+                prp[(size_t)i + 1] = (PtrType)pgc.size();
+            }
+        }
+        // ... and the rows of P of A's ghost nodes from their owners: the k-th entry of every boundary row per exchange
+        const int* bidx = fpm->GetBoundaryIndex();
+        int        kloc = 0;
+        for(int64_t s2 = 0; s2 < ns; ++s2)
+            kloc = std::max(kloc, (int)(prp[(size_t)bidx[s2] + 1] - prp[(size_t)bidx[s2]]));
+        const int kmax = A.doMaxRanks(kloc);
+        std::vector<std::vector<double>> gcol((size_t)kmax), gval((size_t)kmax);
+        std::vector<double>              hs((size_t)ns);
+        for(int k = 0; k < kmax; ++k)
+            for(int what = 0; what < 2; ++what)
+            {
+                for(int64_t s2 = 0; s2 < ns; ++s2)
+                {
+                    const PtrType at  = prp[(size_t)bidx[s2]] + k;
+                    const bool    has = at < prp[(size_t)bidx[s2] + 1];
+                    hs[(size_t)s2]    = what == 0 ? (has ? (double)pgc[(size_t)at] : -1.0) : (has ? (double)pva[(size_t)at] : 0.0);
+                }
+                A.doExchangeD(hs, what == 0 ? &gcol[(size_t)k] : &gval[(size_t)k]);
+            }
+        // compact numbering of the coarse columns seen here: mine first, then the others ascending
+        std::vector<int64_t> others;
+        for(int64_t g : pgc)
+            if(g < c0 || g >= c0 + nc)
+                others.push_back(g);
+        for(int k = 0; k < kmax; ++k)
+            for(double g : gcol[(size_t)k])
+                if(g >= 0.0 && ((int64_t)g < c0 || (int64_t)g >= c0 + nc))
+                    others.push_back((int64_t)g);
+        std::sort(others.begin(), others.end());
+        others.erase(std::unique(others.begin(), others.end()), others.end());
+        const int64_t ncc = nc + (int64_t)others.size();
+        auto compact = [&](int64_t g) {
+            return (g >= c0 && g < c0 + nc) ? (int)(g - c0)
+                                            : (int)(nc + (std::lower_bound(others.begin(), others.end(), g) - others.begin()));
+        };
+        // P over the extended block (its own rows, then the ghost nodes' rows), rows sorted
+        std::vector<PtrType>   xrp((size_t)(n + ngA) + 1, 0);
+        std::vector<int>       xci;
+        std::vector<ValueType> xva;
+        std::vector<std::pair<int, ValueType>> row;
+        auto flush = [&](int64_t i) {
+            std::stable_sort(row.begin(), row.end(),
+                             [](const std::pair<int, ValueType>& a, const std::pair<int, ValueType>& b) { return a.first < b.first; });
+            for(const std::pair<int, ValueType>& e : row)
+            {
+                xci.push_back(e.first);
+                xva.push_back(e.second);
+            }
+            xrp[(size_t)i + 1] = (PtrType)xci.size();
+            row.clear();
+        };
+        for(int64_t i = 0; i < n; ++i)
+        {
+            for(PtrType j = prp[(size_t)i]; j < prp[(size_t)i + 1]; ++j)
+                row.emplace_back(compact(pgc[(size_t)j]), pva[(size_t)j]);
+            flush(i);
+        }
+        const PtrType nnz_own = xrp[(size_t)n];
+        for(int64_t g = 0; g < ngA; ++g)
+        {
+            for(int k = 0; k < kmax; ++k)
+                if(gcol[(size_t)k][(size_t)g] >= 0.0)
+                    row.emplace_back(compact((int64_t)gcol[(size_t)k][(size_t)g]), static_cast<ValueType>(gval[(size_t)k][(size_t)g]));
+            flush(n + g);
+        }
+        // the products on the device
+        std::vector<PtrType>   crp((size_t)ncc + 1, 0);
+        std::vector<int>       cci;
+        std::vector<ValueType> cva;
+        if(nnz_own > 0)
+        {
+            LocalMatrix<ValueType> Ablk, Px, Pown, Pt, AP, C;
+            A.doRowBlock(&Ablk);
+            const int64_t xrows = Ablk.GetN();
+            RAMD_EXPECT(xrows == n + ngA);
+            Px.MoveToAccelerator();
+            Px.AllocateCSR("P over the extended block", (int64_t)xrp[(size_t)xrows], xrows, ncc);
+            Px.CopyFromCSR(xrp.data(), xci.data(), xva.data());
+            Pown.MoveToAccelerator();
+            Pown.AllocateCSR("P of the own rows", (int64_t)nnz_own, n, ncc);
+            Pown.CopyFromCSR(xrp.data(), xci.data(), xva.data());
+            AP.MoveToAccelerator();
+            AP.MatrixMult(Ablk, Px);
+            Pt.MoveToAccelerator();
+            Pown.Transpose(&Pt);
+            C.MoveToAccelerator();
+            C.MatrixMult(Pt, AP);
+            cci.resize((size_t)C.GetNnz());
+            cva.resize((size_t)C.GetNnz());
+            if(C.GetNnz() > 0)
+                C.CopyToCSR(crp.data(), cci.data(), cva.data());
+        }
+        auto global_of = [&](int c) { return c < nc ? c0 + c : others[(size_t)(c - nc)]; };
+        // coarse rows of other ranks go to their owners as (row, column, value) triplets
+        std::vector<std::vector<double>> out((size_t)Pn);
+        for(int64_t I = nc; I < ncc; ++I)
+        {
+            const int64_t gI = others[(size_t)(I - nc)];
+            const int     q  = doOwner(coff, gI);
+            for(PtrType j = crp[(size_t)I]; j < crp[(size_t)I + 1]; ++j)
+            {
+                out[(size_t)q].push_back((double)gI);
+                out[(size_t)q].push_back((double)global_of(cci[(size_t)j]));
+                out[(size_t)q].push_back((double)cva[(size_t)j]);
+            }
+        }
+        const std::vector<std::vector<double>> in = doTalk(fpm, out);
+        // my rows: what I computed, then what arrived in rank order; equal columns of a row are added in that order
+        std::vector<std::vector<std::pair<int64_t, ValueType>>> rows((size_t)nc);
+        for(int64_t I = 0; I < nc; ++I)
+            for(PtrType j = crp[(size_t)I]; j < crp[(size_t)I + 1]; ++j)
+                rows[(size_t)I].emplace_back(global_of(cci[(size_t)j]), cva[(size_t)j]);
+        for(int q = 0; q < Pn; ++q)
+            for(size_t t = 0; t + 2 < in[(size_t)q].size(); t += 3)
+            {
+                const int64_t I = (int64_t)std::llround(in[(size_t)q][t]) - c0;
+                RAMD_EXPECT(I >= 0 && I < nc);
+                rows[(size_t)I].emplace_back((int64_t)std::llround(in[(size_t)q][t + 1]), static_cast<ValueType>(in[(size_t)q][t + 2]));
+            }
+        std::vector<PtrType>   arp((size_t)nc + 1, 0);
+        std::vector<int64_t>   agc;
+        std::vector<ValueType> ava;
+        for(int64_t I = 0; I < nc; ++I)
+        {
+            std::vector<std::pair<int64_t, ValueType>>& rw = rows[(size_t)I];
+            std::stable_sort(rw.begin(), rw.end(),
+                             [](const std::pair<int64_t, ValueType>& a, const std::pair<int64_t, ValueType>& b) { return a.first < b.first; });
+            for(size_t k = 0; k < rw.size();)
+            {
+                const int64_t g = rw[k].first;
+                ValueType     v = rw[k].second;
+                for(++k; k < rw.size() && rw[k].first == g; ++k)
+                    v += rw[k].second;
+                agc.push_back(g);
+                ava.push_back(v);
+            }
+            arp[(size_t)I + 1] = (PtrType)agc.size();
+            std::vector<std::pair<int64_t, ValueType>>().swap(rw);
+        }
+        this->m_interior.CloneBackend(A.m_interior);
+        this->m_ghost.CloneBackend(A.m_interior);
+        this->doDropHaloPlan();
+        this->doFromGlobalColumns(fpm, coff.back(), coff, arp, agc, ava);
+    }
+    mutable std::shared_ptr<AmgBlock> m_amg;
+    bool                   m_coupled = false; // built by the coupled setup: m_ghost_cols / m_col_offsets are valid
+    bool                   m_reverse = false; // a restriction in the reverse form (doTransposeCoupled)
+    std::vector<int64_t>   m_ghost_cols;      // global number of every ghost column
+    std::vector<int64_t>   m_col_offsets;     // first column of every rank, and the global column count
+    LocalMatrix<ValueType> m_scatter;         // reverse form: received partial sums -> rows
+
     // a block-diagonal operator between two row-block distributions: a ParallelManager of its own without neighbours
     // (ncol < 0: the global column count is the sum of the local ones)
     void doBlockDiagonal(const ParallelManager* like, int64_t global_nrow, int64_t global_ncol)

@@ -480,6 +480,28 @@ int ramd_comm_halo_begin_plan(ramd_comm_t c, int plan, ramd_vec_t send, ramd_vec
                               const int64_t* send_offset, const int64_t* recv_offset);
 int ramd_comm_halo_end(ramd_comm_t c);
 
+/* Aggregation AMG across the row blocks of a distributed matrix (global_matrix.cpp:2647-3121 AMGPMISAggregate, :3123-3558
+ * AMGSmoothedAggregation / AMGUnsmoothedAggregation with the host kernels host_matrix_csr.cpp:5098-5660, :5936-6512).
+ * ramd_mat_merge_columns: out = [interior | ghost], one CSR operator of the block's rows whose ghost_ncol ghost columns
+ * follow the interior ones (ghost may be NULL: a block without ghost entries) (per row: the interior entries, then the ghost entries -- the order the reference's loops visit them in).
+ * ramd_mat_amg_pmis_aggregate_global: the PMIS aggregation on such a block; plan / npeers / peers / offsets / boundary
+ * (device int vector) describe the halo exchange of the matrix (as for ramd_comm_halo_begin_plan), first_row is the
+ * global number of the block's row 0.  Results over the block's nrow + nghost nodes: numbers (global node numbers),
+ * aggregates (global aggregate number, -2 isolated), aggregate_root_nodes (global number of the root node);
+ * connections over the block's entries.  agg_first / agg_mine / agg_total: this rank's range of aggregate numbers and
+ * the global count.  The numbering is the one a single rank produces on the whole matrix.  A collective: every rank of
+ * the communicator calls it.  ramd_mat_amg_prolong_global: this block's rows of the prolongation (smoothed != 0: the
+ * smoothed one) with GLOBAL aggregate numbers as columns (global_ncol = agg_total). */
+int ramd_mat_merge_columns(ramd_mat_t interior, ramd_mat_t ghost, int ghost_ncol, ramd_mat_t out);
+int ramd_mat_amg_pmis_aggregate_global(ramd_mat_t block, double eps, ramd_comm_t comm, int plan, int npeers,
+                                       const int* peers, const int64_t* send_offset, const int64_t* recv_offset,
+                                       ramd_vec_t boundary, int64_t first_row, ramd_vec_t numbers,
+                                       ramd_vec_t connections, ramd_vec_t aggregates, ramd_vec_t aggregate_root_nodes,
+                                       int64_t* agg_first, int64_t* agg_mine, int64_t* agg_total);
+int ramd_mat_amg_prolong_global(ramd_mat_t block, int smoothed, double relax, int lumping_strat, ramd_vec_t connections,
+                                ramd_vec_t aggregates, ramd_vec_t aggregate_root_nodes, int64_t global_ncol,
+                                ramd_mat_t prolong);
+
 /* ======================================================================= solver layer
  * C handles onto the compiled C++ API layer (include/rocalution/: Solver<Operator,Vector>::Build()/
  * Solve(), src/solvers/solver.hpp:179-444 of the reference) for callers without a C++ compiler
@@ -585,6 +607,10 @@ int ramd_gsolver_build(ramd_gsolver_t g);
  * defect of the Galerkin identity A_c x = R A_f P x over the levels, x random per rank (test hook: exercises the ghost
  * parts and halo plans of the coarse operators) */
 int ramd_gsolver_amg_info(ramd_gsolver_t g, int* levels, int64_t* coarsest_rows, double* worst_galerkin_defect);
+/* ... and a fingerprint of the operator of one level that does not depend on how the rows are distributed: its global
+ * row count, this rank's entries (interior + ghost; the caller adds the ranks up) and || A_l 1 ||_2 (a collective) */
+int ramd_gsolver_amg_level(ramd_gsolver_t g, int level, int64_t* global_rows, int64_t* local_entries,
+                           double* norm_of_row_sums);
 int ramd_gsolver_apply(ramd_gsolver_t g, const double* x_local, double* y_local); /* y = A x (test hook) */
 int ramd_gsolver_solve(ramd_gsolver_t g, const double* rhs_local, double* x_local); /* NULL rhs: A*1 ; x0 = x_local or 0 */
 int ramd_gsolver_solve_ones(ramd_gsolver_t g); /* rhs = A*1, x0 = 0, everything stays on the device */

@@ -147,6 +147,10 @@ SIGNATURES = {
     "ramd_mat_amg_greedy_aggregate": (i32, [mat_t, f64, vec_t, vec_t, vec_t]),
     "ramd_mat_amg_unsmoothed_prolong": (i32, [mat_t, vec_t, vec_t, mat_t]),
     "ramd_mat_amg_smoothed_prolong": (i32, [mat_t, f64, i32, vec_t, vec_t, vec_t, mat_t]),
+    "ramd_mat_merge_columns": (i32, [mat_t, mat_t, i32, mat_t]),
+    "ramd_mat_amg_pmis_aggregate_global": (i32, [mat_t, f64, ptr, i32, i32, pi32, pi64, pi64, vec_t, i64, vec_t, vec_t,
+                                                 vec_t, vec_t, pi64, pi64, pi64]),
+    "ramd_mat_amg_prolong_global": (i32, [mat_t, i32, f64, i32, vec_t, vec_t, vec_t, i64, mat_t]),
     "ramd_mat_fsai": (i32, [mat_t, i32]),
     "ramd_mat_fsai_pattern": (i32, [mat_t, mat_t]),
     "ramd_mat_spai": (i32, [mat_t]),
@@ -254,6 +258,7 @@ SIGNATURES = {
     "ramd_gsolver_build": (i32, [ptr]),
     "ramd_gsolver_apply": (i32, [ptr, ptr, ptr]),
     "ramd_gsolver_amg_info": (i32, [ptr, ptr, ptr, ptr]),
+    "ramd_gsolver_amg_level": (i32, [ptr, i32, pi64, pi64, pf64]),
     "ramd_gsolver_solve": (i32, [ptr, ptr, ptr]),
     "ramd_gsolver_solve_ones": (i32, [ptr]),
     "ramd_gsolver_prepare_ones": (i32, [ptr]),

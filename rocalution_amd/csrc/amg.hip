@@ -11,6 +11,7 @@
 #include "matrix_impl.hpp"
 
 #include <algorithm>
+#include <cmath>
 
 namespace ramd
 {
@@ -59,7 +60,8 @@ __global__ __launch_bounds__(kBlock) void k_amg_connections(int nrow, const int*
 }
 
 __global__ __launch_bounds__(kBlock) void k_pmis_init(int nrow, const int* __restrict__ rp, const int* __restrict__ conn,
-                                                      int* __restrict__ state, int* __restrict__ hash)
+                                                      int* __restrict__ state, int* __restrict__ hash,
+                                                      unsigned first_row = 0u) // (global number of row 0)
 {
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
     for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(kBlock) void k_pmis_init(int nrow, const int* __res
                 break;
             }
         state[i] = s;
-        hash[i]  = (int)pmis_hash((unsigned)i);
+        hash[i]  = (int)pmis_hash((unsigned)i + first_row);
     }
 }
 
@@ -182,8 +184,9 @@ __global__ __launch_bounds__(kBlock) void k_ua_count(int nrow, const int* __rest
         int c = 0;
         if(i < nrow && agg[i] >= 0)
         {
-            c             = 1;
-            f2c[roots[i]] = 1; // same value from every member of the aggregate
+            c = 1;
+            if(f2c)
+                f2c[roots[i]] = 1; // same value from every member of the aggregate
         }
         prp[i] = c;
     }
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(kBlock) void k_ua_fill(int nrow, const int* __restr
     for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
         if(agg[i] >= 0)
         {
-            pci[prp[i]]  = f2c[roots[i]];
+            pci[prp[i]]  = f2c ? f2c[roots[i]] : agg[i];
             pval[prp[i]] = (T)1;
         }
 }
@@ -246,8 +249,9 @@ __global__ __launch_bounds__(kBlock) void k_sa_row(int nrow, const int* __restri
             if(agg[c] < 0)
                 continue;
             const T   v   = (c == (int)i) ? (T)1 - relax : -relax * dia * val[j];
-            const int key = roots[c];
-            f2c[key]      = 1;
+            const int key = f2c ? roots[c] : agg[c]; // (no table: the aggregate numbers are the coarse columns)
+            if(f2c)
+                f2c[key] = 1;
             int q         = e - 1;
             for(; q >= rs && tkey[q] > key; --q)
             {
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(kBlock) void k_sa_compact(int nrow, const int* __re
         const int n = prp[i + 1] - prp[i];
         for(int k = 0; k < n; ++k)
         {
-            pci[prp[i] + k]  = f2c[tkey[rp[i] + k]];
+            pci[prp[i] + k]  = f2c ? f2c[tkey[rp[i] + k]] : tkey[rp[i] + k];
             pval[prp[i] + k] = tval[rp[i] + k];
         }
     }
@@ -293,32 +297,36 @@ __global__ __launch_bounds__(kBlock) void k_sa_compact(int nrow, const int* __re
 
 template <typename T>
 static int sa_prolong_t(const ramd_mat_s* m, T relax, int lumping, const ramd_vec_s* vconn, const ramd_vec_s* vagg,
-                        const ramd_vec_s* vroots, ramd_mat_s* p)
+                        const ramd_vec_s* vroots, ramd_mat_s* p, int64_t global_ncol = -1)
 {
+    // global_ncol >= 0: the operator is the row block [interior | ghost] of a distributed matrix, the vectors cover its
+    // columns and the aggregate numbers are global: they ARE the columns of P (no fine-to-coarse table)
+    const bool gk = global_ncol >= 0;
     Backend&  b = backend();
     const int n = m->nrow;
     int *     tkey = nullptr, *cnt = nullptr, *f2c = nullptr;
     void*     tval = nullptr;
     RAMD_TRY(dev_alloc(&tkey, m->nnz));
     int s = dev_alloc(&cnt, (int64_t)n + 1);
-    if(s == RAMD_OK)
+    if(s == RAMD_OK && !gk)
         s = dev_alloc(&f2c, (int64_t)n + 1);
     if(s == RAMD_OK && cached_malloc(&tval, (size_t)m->nnz * sizeof(T) + kPad) != hipSuccess)
         s = RAMD_ERR_HIP;
     hipError_t e = hipSuccess;
-    int        tot[2] = {0, 0};
+    int        tot[2] = {0, (int)global_ncol};
     if(s == RAMD_OK)
     {
-        e = hipMemsetAsync(f2c, 0, sizeof(int) * ((size_t)n + 1), b.cur);
+        if(!gk)
+            e = hipMemsetAsync(f2c, 0, sizeof(int) * ((size_t)n + 1), b.cur);
         hipLaunchKernelGGL((k_sa_row<T>), dim3(ew_grid((int64_t)n + 1)), dim3(kBlock), 0, b.cur, n, m->rp, m->ci,
                            (const T*)m->val, (const int*)vconn->d, (const int*)vagg->d, (const int*)vroots->d, relax,
                            lumping, tkey, (T*)tval, cnt, f2c);
         s = device_exclusive_scan(cnt, cnt, (int64_t)n + 1);
-        if(s == RAMD_OK)
+        if(s == RAMD_OK && !gk)
             s = device_exclusive_scan(f2c, f2c, (int64_t)n + 1);
         if(s == RAMD_OK && e == hipSuccess)
             e = hipMemcpyAsync(&tot[0], cnt + n, sizeof(int), hipMemcpyDeviceToHost, b.cur);
-        if(s == RAMD_OK && e == hipSuccess)
+        if(s == RAMD_OK && e == hipSuccess && !gk)
             e = hipMemcpyAsync(&tot[1], f2c + n, sizeof(int), hipMemcpyDeviceToHost, b.cur);
         if(s == RAMD_OK && e == hipSuccess)
             e = hipStreamSynchronize(b.cur);
@@ -1099,29 +1107,31 @@ static int rs_direct_t(const ramd_mat_s* m, const ramd_vec_s* vcf, const ramd_ve
 }
 
 template <typename T>
-static int ua_prolong_t(const ramd_mat_s* m, const ramd_vec_s* vagg, const ramd_vec_s* vroots, ramd_mat_s* p)
+static int ua_prolong_t(const ramd_mat_s* m, const ramd_vec_s* vagg, const ramd_vec_s* vroots, ramd_mat_s* p,
+                        int64_t global_ncol = -1)
 {
+    const bool gk = global_ncol >= 0; // (as in sa_prolong_t)
     Backend&   b     = backend();
     const int  n     = m->nrow;
     const int* agg   = (const int*)vagg->d;
     const int* roots = (const int*)vroots->d;
     int *      prp = nullptr, *f2c = nullptr;
     RAMD_TRY(dev_alloc(&prp, (int64_t)n + 1));
-    int s = dev_alloc(&f2c, (int64_t)n + 1);
+    int s = gk ? RAMD_OK : dev_alloc(&f2c, (int64_t)n + 1);
     if(s != RAMD_OK)
     {
         dev_free(&prp);
         return s;
     }
-    hipError_t e = hipMemsetAsync(f2c, 0, sizeof(int) * ((size_t)n + 1), b.cur);
+    hipError_t e = gk ? hipSuccess : hipMemsetAsync(f2c, 0, sizeof(int) * ((size_t)n + 1), b.cur);
     hipLaunchKernelGGL(k_ua_count, dim3(ew_grid((int64_t)n + 1)), dim3(kBlock), 0, b.cur, n, agg, roots, prp, f2c);
     s = device_exclusive_scan(prp, prp, (int64_t)n + 1);
-    if(s == RAMD_OK)
+    if(s == RAMD_OK && !gk)
         s = device_exclusive_scan(f2c, f2c, (int64_t)n + 1);
-    int tot[2] = {0, 0};
+    int tot[2] = {0, (int)global_ncol};
     if(s == RAMD_OK && e == hipSuccess)
         e = hipMemcpyAsync(&tot[0], prp + n, sizeof(int), hipMemcpyDeviceToHost, b.cur);
-    if(s == RAMD_OK && e == hipSuccess)
+    if(s == RAMD_OK && e == hipSuccess && !gk)
         e = hipMemcpyAsync(&tot[1], f2c + n, sizeof(int), hipMemcpyDeviceToHost, b.cur);
     if(s == RAMD_OK && e == hipSuccess)
         e = hipStreamSynchronize(b.cur);
@@ -1162,6 +1172,472 @@ static int ua_prolong_t(const ramd_mat_s* m, const ramd_vec_s* vagg, const ramd_
     p->ci     = pci;
     p->val    = pv;
     return RAMD_OK;
+}
+
+
+// ---- aggregation across the row blocks of a distributed matrix (global_matrix.cpp:2647-3121 AMGPMISAggregate; the
+// ghost-aware halves of the kernels cited at the top of this file).  One rank's view: the n rows of its block as ONE
+// operator [interior | ghost] with n + ng columns (k_merge_*: the interior entries of a row, then its ghost entries with
+// their column moved up by n -- the order every reference loop visits them in), and every per-node array extended by the
+// ng ghost nodes, whose entries arrive through the halo exchange of the matrix.  The local kernels above then serve
+// unchanged wherever the reference's loops are "interior part, then ghost part" of the same body; what is new:
+//   * the distance-two step through a ghost node: the reference ships the (state, hash, column) LIST of every boundary
+//     row's strong neighbours and folds it at the receiver (AMGExtractBoundaryState / the bnd_* branch of
+//     AMGPMISFindMaxNeighbourNode); the fold is associative with "the later entry wins a tie", so the owner folds the
+//     list itself and ships ONE tuple per boundary row -- three ints instead of 3 x the row length;
+//   * the tie rule of AMGPMISAddUnassignedNodesToAggregations between the first local root and a ghost root with a
+//     smaller global number.
+// Aggregate numbers and root nodes are GLOBAL (int: the global sizes must stay below 2^31); the numbering -- roots in
+// global row order -- is the one a single rank produces, so the hierarchy does not depend on the number of ranks (equal
+// hashes of two nodes within two hops aside: there the visiting order decides, and it differs at a rank boundary).
+__global__ __launch_bounds__(kBlock) void k_merge_rp(int nrow, const int* __restrict__ rpi, const int* __restrict__ rpg,
+                                                     int* __restrict__ rp)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= nrow; i += gsz)
+        rp[i] = rpi[i] + (rpg ? rpg[i] : 0);
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_merge_fill(int nrow, int ncol_i, const int* __restrict__ rpi,
+                                                       const int* __restrict__ cii, const T* __restrict__ vi,
+                                                       const int* __restrict__ rpg, const int* __restrict__ cig,
+                                                       const T* __restrict__ vg, const int* __restrict__ rp,
+                                                       int* __restrict__ ci, T* __restrict__ val)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+    {
+        int o = rp[i];
+        for(int j = rpi[i]; j < rpi[i + 1]; ++j, ++o)
+        {
+            ci[o]  = cii[j];
+            val[o] = vi[j];
+        }
+        if(rpg)
+            for(int j = rpg[i]; j < rpg[i + 1]; ++j, ++o)
+            {
+                ci[o]  = cig[j] + ncol_i;
+                val[o] = vg[j];
+            }
+    }
+}
+template <typename T>
+static int merge_columns_t(const ramd_mat_s* a, const ramd_mat_s* g, int ghost_ncol, ramd_mat_s* out)
+{
+    Backend&      b   = backend();
+    const int     n   = a->nrow;
+    const bool    hg  = g && g->nnz > 0;
+    const int64_t nnz = a->nnz + (hg ? g->nnz : 0);
+    int *         rp = nullptr, *ci = nullptr;
+    void*         val = nullptr;
+    RAMD_TRY(dev_alloc(&rp, (int64_t)n + 1));
+    int s = dev_alloc(&ci, nnz);
+    if(s == RAMD_OK && cached_malloc(&val, (size_t)nnz * sizeof(T) + kPad) != hipSuccess)
+        s = RAMD_ERR_HIP;
+    hipError_t e = hipSuccess;
+    if(s == RAMD_OK)
+    {
+        hipLaunchKernelGGL(k_merge_rp, dim3(ew_grid((int64_t)n + 1)), dim3(kBlock), 0, b.cur, n, (const int*)a->rp,
+                           hg ? (const int*)g->rp : (const int*)nullptr, rp);
+        hipLaunchKernelGGL((k_merge_fill<T>), dim3(ew_grid(std::max(n, 1))), dim3(kBlock), 0, b.cur, n, a->ncol,
+                           (const int*)a->rp, (const int*)a->ci, (const T*)a->val,
+                           hg ? (const int*)g->rp : (const int*)nullptr, hg ? (const int*)g->ci : (const int*)nullptr,
+                           hg ? (const T*)g->val : (const T*)nullptr, (const int*)rp, ci, (T*)val);
+        e = hipGetLastError();
+        if(e == hipSuccess)
+            e = hipStreamSynchronize(b.cur);
+    }
+    if(s != RAMD_OK || e != hipSuccess)
+    {
+        dev_free(&rp);
+        dev_free(&ci);
+        if(val)
+            (void)cached_free(val);
+        RAMD_TRY(s);
+        RAMD_HIP(e);
+    }
+    mat_free_csr(out);
+    mat_free_ell(out);
+    mat_free_coo(out);
+    mat_free_dia(out);
+    mat_free_analysis(out);
+    out->format = RAMD_CSR;
+    out->nrow   = n;
+    out->ncol   = a->ncol + ghost_ncol;
+    out->nnz    = nnz;
+    out->rp     = rp;
+    out->ci     = ci;
+    out->val    = val;
+    return RAMD_OK;
+}
+
+template <typename U>
+__global__ __launch_bounds__(kBlock) void k_pick(int64_t n, const int* __restrict__ idx, const U* __restrict__ src,
+                                                 U* __restrict__ dst)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gsz)
+        dst[s] = src[idx[s]];
+}
+
+// what one exchange of the operator's halo pattern needs (the arguments of ramd_comm_halo_begin_plan)
+struct HaloArgs
+{
+    ramd_comm_t    comm;
+    int            plan, npeers;
+    const int*     peers;
+    const int64_t *so, *ro;
+    const int*     d_boundary; // device copy of the boundary index (nsend)
+    int64_t        nsend, nrecv;
+    void *         d_send, *d_recv; // 8 bytes per entry
+};
+// the ghost entries [n, n + ng) of a per-node array from the owners of the ghost nodes
+template <typename U>
+static int halo_extend(const HaloArgs& h, U* ext, int n)
+{
+    static_assert(sizeof(U) == 4 || sizeof(U) == 8, "4- or 8-byte entries");
+    Backend& b = backend();
+    if(h.nsend > 0)
+        hipLaunchKernelGGL((k_pick<U>), dim3(ew_grid(h.nsend)), dim3(kBlock), 0, b.cur, h.nsend, h.d_boundary,
+                           (const U*)ext, (U*)h.d_send);
+    ramd_vec_s vs, vr;
+    vs.dtype = vr.dtype = (sizeof(U) == 8) ? RAMD_F64 : RAMD_I32; // (the exchange moves bytes: 8 or 4 per entry)
+    vs.n                = h.nsend;
+    vs.d                = h.d_send;
+    vr.n                = h.nrecv;
+    vr.d                = h.d_recv;
+    RAMD_TRY(ramd_comm_halo_begin_plan(h.comm, h.plan, &vs, &vr, h.npeers, h.peers, h.so, h.ro));
+    RAMD_TRY(ramd_comm_halo_end(h.comm));
+    if(h.nrecv > 0)
+        RAMD_HIP(hipMemcpyAsync(ext + n, h.d_recv, sizeof(U) * (size_t)h.nrecv, hipMemcpyDeviceToDevice, b.cur));
+    return RAMD_OK;
+}
+
+constexpr int kNoTuple = -3; // below every state: "this boundary row has no strong neighbour"
+
+// per boundary row: the fold of (state, hash, global number) over its strong neighbours, in row order
+__global__ __launch_bounds__(kBlock) void k_pmis_boundary_fold(int64_t nb, const int* __restrict__ boundary, int n,
+                                                               const int* __restrict__ rp, const int* __restrict__ ci,
+                                                               const int* __restrict__ conn,
+                                                               const int* __restrict__ state,
+                                                               const int* __restrict__ hash, int first_row,
+                                                               const int* __restrict__ ghost_number,
+                                                               int* __restrict__ out_s, int* __restrict__ out_v,
+                                                               int* __restrict__ out_g)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nb; s += gsz)
+    {
+        const int row = boundary[s];
+        MisTuple  t   = {kNoTuple, 0, -1};
+        for(int j = rp[row]; j < rp[row + 1]; ++j)
+            if(conn[j])
+            {
+                const int      c  = ci[j];
+                const MisTuple tj = {state[c], hash[c], c < n ? first_row + c : ghost_number[c - n]};
+                t                 = (t.s == kNoTuple) ? tj : mis_max(tj, t);
+            }
+        out_s[s] = t.s;
+        out_v[s] = t.v;
+        out_g[s] = t.i;
+    }
+}
+
+// AMGPMISFindMaxNeighbourNode with the ghost branch: gs / gv / gg = the folded tuple of every ghost node
+__global__ __launch_bounds__(kBlock) void k_pmis_find_max_global(int nrow, const int* __restrict__ rp,
+                                                                 const int* __restrict__ ci,
+                                                                 const int* __restrict__ conn,
+                                                                 const int* __restrict__ state,
+                                                                 const int* __restrict__ hash, int first_row,
+                                                                 const int* __restrict__ gs, const int* __restrict__ gv,
+                                                                 const int* __restrict__ gg, int* __restrict__ max_state,
+                                                                 int* __restrict__ agg, int* __restrict__ undecided)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+    {
+        MisTuple t = {state[i], hash[i], (int)i};
+        for(int j = rp[i]; j < rp[i + 1]; ++j)
+            if(conn[j])
+            {
+                const int      c  = ci[j];
+                const MisTuple tj = {state[c], hash[c], c};
+                t                 = mis_max(tj, t);
+            }
+        if(t.i < nrow)
+        {
+            const int row = t.i;
+            for(int j = rp[row]; j < rp[row + 1]; ++j)
+                if(conn[j])
+                {
+                    const int      c  = ci[j];
+                    const MisTuple tj = {state[c], hash[c], c};
+                    t                 = mis_max(tj, t);
+                }
+        }
+        else
+        {
+            const int g = t.i - nrow;
+            if(gs[g] != kNoTuple)
+            {
+                const int      l  = gg[g] - first_row; // a row of this block, or "elsewhere"
+                const MisTuple tj = {gs[g], gv[g], (l >= 0 && l < nrow) ? l : -1};
+                t                 = mis_max(tj, t);
+            }
+        }
+        if(state[i] == 0)
+        {
+            if(t.i == (int)i)
+            {
+                max_state[i] = 1;
+                agg[i]       = 1;
+            }
+            else if(t.s == 1)
+            {
+                max_state[i] = -1;
+                agg[i]       = 0;
+            }
+            else
+                *undecided = 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_pmis_roots_global(int nrow, int first_row, const int* __restrict__ agg,
+                                                              int* __restrict__ roots)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+        roots[i] = (agg[i] == 1) ? first_row + (int)i : -1;
+}
+__global__ __launch_bounds__(kBlock) void k_iota(int64_t n, int* __restrict__ x, int first)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gsz)
+        x[i] = first + (int)i;
+}
+__global__ __launch_bounds__(kBlock) void k_add_const(int64_t n, int* __restrict__ x, int c)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gsz)
+        x[i] += c;
+}
+
+// AMGPMISAddUnassignedNodesToAggregations: the first strongly connected local root, unless a ghost root with a smaller
+// global number follows in the row (then that one); without a local root the first ghost root
+__global__ __launch_bounds__(kBlock) void k_pmis_add_unassigned_global(int nrow, const int* __restrict__ rp,
+                                                                       const int* __restrict__ ci,
+                                                                       const int* __restrict__ conn,
+                                                                       const int* __restrict__ state, int first_row,
+                                                                       const int* __restrict__ ghost_number,
+                                                                       int* __restrict__ max_state, int* agg, int* roots)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gsz)
+    {
+        const int s = state[i];
+        if(s == -1)
+        {
+            int  gcol  = -1;
+            bool local = false;
+            for(int j = rp[i]; j < rp[i + 1]; ++j)
+                if(conn[j])
+                {
+                    const int c = ci[j];
+                    if(state[c] != 1)
+                        continue;
+                    if(c < nrow)
+                    {
+                        if(local)
+                            continue;
+                        local = true;
+                        gcol  = first_row + c;
+                    }
+                    else if(!(gcol == -1 || ghost_number[c - nrow] < gcol))
+                        continue;
+                    agg[i]       = agg[c];
+                    max_state[i] = 1;
+                    roots[i]     = roots[c];
+                    if(c >= nrow)
+                        break;
+                }
+        }
+        else if(s == -2)
+            agg[i] = -2;
+    }
+}
+
+// exclusive prefix of one count per rank (an all-reduce of one indicator slot per rank) and the total
+static int ranks_prefix(ramd_comm_t comm, int64_t mine, int64_t* before, int64_t* total)
+{
+    int rank = 0, size = 1;
+    RAMD_TRY(ramd_comm_rank(comm, &rank));
+    RAMD_TRY(ramd_comm_size(comm, &size));
+    const int cap = 48, first = RAMD_NSCALARS - 8 - cap;
+    if(size > cap)
+        RAMD_FAIL(RAMD_ERR_UNSUPPORTED, "more ranks than scalar slots of the setup exchanges");
+    for(int k = 0; k < size; ++k)
+        RAMD_TRY(ramd_scalars_set(first + k, k == rank ? (double)mine : 0.0));
+    RAMD_TRY(ramd_comm_allreduce_scalars(comm, first, size));
+    double v[48];
+    RAMD_TRY(ramd_scalars_fetch(v, first, size));
+    *before = 0;
+    *total  = 0;
+    for(int k = 0; k < size; ++k)
+    {
+        if(k < rank)
+            *before += (int64_t)std::llround(v[k]);
+        *total += (int64_t)std::llround(v[k]);
+    }
+    return RAMD_OK;
+}
+static int ranks_any(ramd_comm_t comm, int mine, int* any)
+{
+    const int slot = RAMD_NSCALARS - 2;
+    RAMD_TRY(ramd_scalars_set(slot, mine ? 1.0 : 0.0));
+    RAMD_TRY(ramd_comm_allreduce_scalars(comm, slot, 1));
+    double r = 0.0;
+    RAMD_TRY(ramd_scalars_fetch(&r, slot, 1));
+    *any = r > 0.5;
+    return RAMD_OK;
+}
+
+template <typename T>
+static int pmis_aggregate_global_t(const ramd_mat_s* m, T eps, HaloArgs h, int first_row, ramd_vec_s* vnumber,
+                                   ramd_vec_s* vconn, ramd_vec_s* vagg, ramd_vec_s* vroots, int64_t* agg_first,
+                                   int64_t* agg_mine, int64_t* agg_total)
+{
+    Backend&      b    = backend();
+    const int     n    = m->nrow;
+    const int     ng   = m->ncol - n;
+    const int64_t next = (int64_t)n + ng;
+    const int     grid = ew_grid(std::max(n, 1));
+    RAMD_TRY(ramd_vec_allocate(vconn, m->nnz));
+    RAMD_TRY(ramd_vec_allocate(vagg, next)); // zero-filled
+    RAMD_TRY(ramd_vec_allocate(vroots, next));
+    RAMD_TRY(ramd_vec_allocate(vnumber, next)); // global number of every node of the extended block
+    int* conn  = (int*)vconn->d;
+    int* agg   = (int*)vagg->d;
+    int* roots = (int*)vroots->d;
+    int* const number       = (int*)vnumber->d;
+    const int* ghost_number = number + n;
+    T*   diag  = nullptr;
+    int *state = nullptr, *max_state = nullptr, *hash = nullptr, *flag = nullptr, *bt = nullptr, *gt = nullptr,
+        *tmp = nullptr;
+    double *sb = nullptr, *rb = nullptr;
+    int     s  = dev_alloc(&diag, next);
+    if(s == RAMD_OK)
+        s = dev_alloc(&state, next);
+    if(s == RAMD_OK)
+        s = dev_alloc(&max_state, next);
+    if(s == RAMD_OK)
+        s = dev_alloc(&hash, next);
+    if(s == RAMD_OK)
+        s = dev_alloc(&flag, 1);
+    if(s == RAMD_OK)
+        s = dev_alloc(&bt, 3 * h.nsend);
+    if(s == RAMD_OK)
+        s = dev_alloc(&gt, 3 * (int64_t)ng + 3);
+    if(s == RAMD_OK)
+        s = dev_alloc(&sb, h.nsend);
+    if(s == RAMD_OK)
+        s = dev_alloc(&rb, h.nrecv);
+    if(s == RAMD_OK)
+        s = dev_alloc(&tmp, (int64_t)n + 1);
+    h.d_send = sb;
+    h.d_recv = rb;
+    auto body = [&]() -> int {
+        RAMD_HIP(hipMemsetAsync(diag, 0, sizeof(T) * (size_t)next, b.cur));
+        RAMD_HIP(hipMemsetAsync(max_state, 0, sizeof(int) * (size_t)next, b.cur));
+        hipLaunchKernelGGL(k_iota, dim3(grid), dim3(kBlock), 0, b.cur, (int64_t)n, number, first_row);
+        RAMD_TRY(halo_extend<int>(h, number, n));
+        hipLaunchKernelGGL((k_extract_diag_plain<T>), dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, m->ci,
+                           (const T*)m->val, diag);
+        RAMD_TRY(halo_extend<T>(h, diag, n));
+        hipLaunchKernelGGL((k_amg_connections<T>), dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, (const T*)m->val,
+                           (const T*)diag, eps * eps, conn);
+        hipLaunchKernelGGL(k_pmis_init, dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, (const int*)conn, max_state, hash,
+                           (unsigned)first_row);
+        RAMD_TRY(halo_extend<int>(h, max_state, n));
+        RAMD_TRY(halo_extend<int>(h, hash, n));
+        int* const bs = bt, *const bv = bt + h.nsend, *const bg = bt + 2 * h.nsend;
+        int* const gs = gt, *const gv = gt + ng, *const gg = gt + 2 * (int64_t)ng;
+        for(int iter = 0;; ++iter)
+        {
+            RAMD_HIP(hipMemcpyAsync(state, max_state, sizeof(int) * (size_t)next, hipMemcpyDeviceToDevice, b.cur));
+            RAMD_HIP(hipMemsetAsync(flag, 0, sizeof(int), b.cur));
+            if(h.nsend > 0)
+                hipLaunchKernelGGL(k_pmis_boundary_fold, dim3(ew_grid(h.nsend)), dim3(kBlock), 0, b.cur, h.nsend,
+                                   h.d_boundary, n, m->rp, m->ci, (const int*)conn, (const int*)state, (const int*)hash,
+                                   first_row, ghost_number, bs, bv, bg);
+            // (the three fields of the tuples travel as three exchanges of the pattern: the plan fixes the entry count)
+            for(int f = 0; f < 3; ++f)
+            {
+                ramd_vec_s vs, vr;
+                vs.dtype = vr.dtype = RAMD_I32;
+                vs.n                = h.nsend;
+                vs.d                = bt + (int64_t)f * h.nsend;
+                vr.n                = h.nrecv;
+                vr.d                = gt + (int64_t)f * ng;
+                RAMD_TRY(ramd_comm_halo_begin_plan(h.comm, h.plan, &vs, &vr, h.npeers, h.peers, h.so, h.ro));
+                RAMD_TRY(ramd_comm_halo_end(h.comm));
+            }
+            hipLaunchKernelGGL(k_pmis_find_max_global, dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, m->ci,
+                               (const int*)conn, (const int*)state, (const int*)hash, first_row, (const int*)gs,
+                               (const int*)gv, (const int*)gg, max_state, agg, flag);
+            RAMD_TRY(halo_extend<int>(h, max_state, n));
+            int undecided = 0, any = 0;
+            RAMD_HIP(hipMemcpyAsync(&undecided, flag, sizeof(int), hipMemcpyDeviceToHost, b.cur));
+            RAMD_HIP(hipStreamSynchronize(b.cur));
+            RAMD_TRY(ranks_any(h.comm, undecided, &any));
+            if(!any)
+                break;
+            if(iter > 10000)
+                return RAMD_ERR_STATE;
+        }
+        hipLaunchKernelGGL(k_pmis_roots_global, dim3(grid), dim3(kBlock), 0, b.cur, n, first_row, (const int*)agg, roots);
+        RAMD_TRY(halo_extend<int>(h, roots, n));
+        // aggregates: rank of every root among the roots of all ranks, in global row order
+        RAMD_HIP(hipMemcpyAsync(tmp, agg, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, b.cur));
+        RAMD_HIP(hipMemsetAsync(tmp + n, 0, sizeof(int), b.cur));
+        RAMD_TRY(device_exclusive_scan(tmp, tmp, (int64_t)n + 1));
+        int mine = 0;
+        RAMD_HIP(hipMemcpyAsync(&mine, tmp + n, sizeof(int), hipMemcpyDeviceToHost, b.cur));
+        RAMD_HIP(hipStreamSynchronize(b.cur));
+        RAMD_TRY(ranks_prefix(h.comm, mine, agg_first, agg_total));
+        *agg_mine = mine;
+        if(*agg_total >= ((int64_t)1 << 31) - 1)
+            RAMD_FAIL(RAMD_ERR_UNSUPPORTED, "AMGPMISAggregate: 2^31 aggregates and more");
+        RAMD_HIP(hipMemcpyAsync(agg, tmp, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, b.cur));
+        if(n > 0 && *agg_first != 0)
+            hipLaunchKernelGGL(k_add_const, dim3(grid), dim3(kBlock), 0, b.cur, (int64_t)n, agg, (int)*agg_first);
+        RAMD_TRY(halo_extend<int>(h, agg, n));
+        for(int k = 0; k < 2; ++k)
+        {
+            RAMD_HIP(hipMemcpyAsync(state, max_state, sizeof(int) * (size_t)next, hipMemcpyDeviceToDevice, b.cur));
+            hipLaunchKernelGGL(k_pmis_add_unassigned_global, dim3(grid), dim3(kBlock), 0, b.cur, n, m->rp, m->ci,
+                               (const int*)conn, (const int*)state, first_row, ghost_number, max_state, agg, roots);
+            RAMD_TRY(halo_extend<int>(h, agg, n));
+            RAMD_TRY(halo_extend<int>(h, roots, n));
+            RAMD_TRY(halo_extend<int>(h, max_state, n));
+        }
+        RAMD_HIP(hipGetLastError());
+        RAMD_HIP(hipStreamSynchronize(b.cur));
+        return RAMD_OK;
+    };
+    if(s == RAMD_OK)
+        s = body();
+    dev_free(&diag);
+    dev_free(&state);
+    dev_free(&max_state);
+    dev_free(&hash);
+    dev_free(&flag);
+    dev_free(&bt);
+    dev_free(&gt);
+    dev_free(&sb);
+    dev_free(&rb);
+    dev_free(&tmp);
+    return s;
 }
 
 } // namespace ramd
@@ -1266,6 +1742,82 @@ int ramd_mat_amg_unsmoothed_prolong(ramd_mat_t m, ramd_vec_t aggregates, ramd_ve
     if(m->dtype == RAMD_F64)
         return ua_prolong_t<double>(m, aggregates, aggregate_root_nodes, prolong);
     return ua_prolong_t<float>(m, aggregates, aggregate_root_nodes, prolong);
+}
+
+int ramd_mat_merge_columns(ramd_mat_t interior, ramd_mat_t ghost, int ghost_ncol, ramd_mat_t out)
+{
+    if(!interior || !out || out == interior || out == ghost)
+        RAMD_FAIL(RAMD_ERR_ARG, "null handle / the result aliases an operand");
+    if(interior->format != RAMD_CSR || (ghost && ghost->nnz > 0 && ghost->format != RAMD_CSR))
+        return RAMD_ERR_UNSUPPORTED;
+    if(ghost_ncol < 0
+       || (ghost && ghost->nnz > 0
+           && (ghost->nrow != interior->nrow || ghost->dtype != interior->dtype || ghost->ncol > ghost_ncol)))
+        RAMD_FAIL(RAMD_ERR_ARG, "merge_columns: the two parts of one row block expected");
+    if(out->dtype != interior->dtype)
+        RAMD_FAIL(RAMD_ERR_ARG, "merge_columns: result of the operands' value type expected");
+    return (interior->dtype == RAMD_F64) ? merge_columns_t<double>(interior, ghost, ghost_ncol, out)
+                                         : merge_columns_t<float>(interior, ghost, ghost_ncol, out);
+}
+
+int ramd_mat_amg_pmis_aggregate_global(ramd_mat_t block, double eps, ramd_comm_t comm, int plan, int npeers,
+                                       const int* peers, const int64_t* send_offset, const int64_t* recv_offset,
+                                       ramd_vec_t boundary, int64_t first_row, ramd_vec_t numbers,
+                                       ramd_vec_t connections, ramd_vec_t aggregates, ramd_vec_t aggregate_root_nodes,
+                                       int64_t* agg_first, int64_t* agg_mine, int64_t* agg_total)
+{
+    if(!block || !comm || !boundary || !numbers || !connections || !aggregates || !aggregate_root_nodes || !agg_first
+       || !agg_mine || !agg_total)
+        RAMD_FAIL(RAMD_ERR_ARG, "null handle");
+    if(block->format != RAMD_CSR)
+        return RAMD_ERR_UNSUPPORTED;
+    if(boundary->dtype != RAMD_I32 || numbers->dtype != RAMD_I32 || connections->dtype != RAMD_I32
+       || aggregates->dtype != RAMD_I32 || aggregate_root_nodes->dtype != RAMD_I32)
+        RAMD_FAIL(RAMD_ERR_ARG, "AMGPMISAggregate: int vectors expected");
+    const int64_t nsend = npeers > 0 ? send_offset[npeers] : 0, nrecv = npeers > 0 ? recv_offset[npeers] : 0;
+    if(block->ncol - block->nrow != nrecv || boundary->n != nsend)
+        RAMD_FAIL(RAMD_ERR_ARG, "AMGPMISAggregate: the row block [interior | ghost] and the halo pattern do not match");
+    if(first_row + (int64_t)block->nrow >= ((int64_t)1 << 31) - 1)
+        RAMD_FAIL(RAMD_ERR_UNSUPPORTED, "AMGPMISAggregate: global row numbers of 2^31 and more");
+    HaloArgs h;
+    h.comm       = comm;
+    h.plan       = plan;
+    h.npeers     = npeers;
+    h.peers      = peers;
+    h.so         = send_offset;
+    h.ro         = recv_offset;
+    h.d_boundary = (const int*)boundary->d;
+    h.nsend      = nsend;
+    h.nrecv      = nrecv;
+    h.d_send = h.d_recv = nullptr;
+    if(block->dtype == RAMD_F64)
+        return pmis_aggregate_global_t<double>(block, eps, h, (int)first_row, numbers, connections, aggregates,
+                                               aggregate_root_nodes, agg_first, agg_mine, agg_total);
+    return pmis_aggregate_global_t<float>(block, (float)eps, h, (int)first_row, numbers, connections, aggregates,
+                                          aggregate_root_nodes, agg_first, agg_mine, agg_total);
+}
+
+int ramd_mat_amg_prolong_global(ramd_mat_t block, int smoothed, double relax, int lumping_strat, ramd_vec_t connections,
+                                ramd_vec_t aggregates, ramd_vec_t aggregate_root_nodes, int64_t global_ncol,
+                                ramd_mat_t prolong)
+{
+    if(!block || !connections || !aggregates || !aggregate_root_nodes || !prolong || prolong == block)
+        RAMD_FAIL(RAMD_ERR_ARG, "null handle / prolong aliases the operator");
+    if(block->format != RAMD_CSR)
+        return RAMD_ERR_UNSUPPORTED;
+    if(connections->dtype != RAMD_I32 || aggregates->dtype != RAMD_I32 || aggregate_root_nodes->dtype != RAMD_I32
+       || (smoothed && connections->n != block->nnz) || aggregates->n != block->ncol
+       || aggregate_root_nodes->n != block->ncol
+       || prolong->dtype != block->dtype || global_ncol < 0 || global_ncol >= ((int64_t)1 << 31) - 1
+       || (smoothed && !(relax > 0.0)))
+        RAMD_FAIL(RAMD_ERR_ARG, "prolong_global: int vectors over the block's entries / columns, P of its value type");
+    if(block->dtype == RAMD_F64)
+        return smoothed ? sa_prolong_t<double>(block, relax, lumping_strat, connections, aggregates, aggregate_root_nodes,
+                                               prolong, global_ncol)
+                        : ua_prolong_t<double>(block, aggregates, aggregate_root_nodes, prolong, global_ncol);
+    return smoothed ? sa_prolong_t<float>(block, (float)relax, lumping_strat, connections, aggregates,
+                                          aggregate_root_nodes, prolong, global_ncol)
+                    : ua_prolong_t<float>(block, aggregates, aggregate_root_nodes, prolong, global_ncol);
 }
 
 } // extern "C"

@@ -1094,6 +1094,32 @@ int ramd_gsolver_amg_info(ramd_gsolver_t g, int* levels, int64_t* coarsest_rows,
         *worst_galerkin_defect = worst;
     GUARD_END
 }
+int ramd_gsolver_amg_level(ramd_gsolver_t g, int level, int64_t* global_rows, int64_t* local_entries,
+                           double* norm_of_row_sums)
+{
+    if(!g || !g->built || (g->pc_kind != RAMD_PC_GLOBAL_UAAMG && g->pc_kind != RAMD_PC_GLOBAL_SAAMG))
+        return RAMD_ERR_STATE;
+    GUARD_BEGIN
+    BaseAMG<ramd_gsolver_s::GM, ramd_gsolver_s::GV, double>* amg
+        = g->pc_kind == RAMD_PC_GLOBAL_UAAMG ? (BaseAMG<ramd_gsolver_s::GM, ramd_gsolver_s::GV, double>*)&g->guaamg : &g->gsaamg;
+    if(level < 0 || level >= amg->GetNumLevels())
+        return RAMD_ERR_ARG;
+    const ramd_gsolver_s::GM* A = amg->GetLevelOperator(level);
+    ramd_gsolver_s::GV        one, y;
+    one.CloneBackend(*A);
+    y.CloneBackend(*A);
+    one.Allocate("ones", A->GetM());
+    y.Allocate("row sums", A->GetM());
+    one.Ones();
+    A->Apply(one, &y);
+    if(global_rows)
+        *global_rows = A->GetM();
+    if(local_entries)
+        *local_entries = A->GetLocalNnz() + A->GetGhostNnz();
+    if(norm_of_row_sums)
+        *norm_of_row_sums = y.Norm();
+    GUARD_END
+}
 int ramd_gsolver_apply(ramd_gsolver_t g, const double* x_local, double* y_local)
 {
     if(!g || !g->setup || !x_local || !y_local)

@@ -231,6 +231,12 @@ class DistributedSolver:
         self._capi.check(self._lib.ramd_gsolver_amg_info(self._g, C.byref(lv), C.byref(rows), C.byref(worst)))
         return lv.value, rows.value, worst.value
 
+    def amg_level(self, level):
+        """RAMD_PC_GLOBAL_* after build(): (global rows, this rank's entries, || A_level 1 ||) of one level's operator"""
+        rows, ent, nrm = C.c_int64(0), C.c_int64(0), C.c_double(0)
+        self._capi.check(self._lib.ramd_gsolver_amg_level(self._g, int(level), C.byref(rows), C.byref(ent), C.byref(nrm)))
+        return rows.value, ent.value, nrm.value
+
     def result(self):
         it, st, res = C.c_int(0), C.c_int(0), C.c_double(0)
         self._capi.check(self._lib.ramd_gsolver_result(self._g, C.byref(it), C.byref(st), C.byref(res)))

@@ -239,6 +239,7 @@ def amg_worker(rank, world, initfile, kind, outdir, rccl=False):
         g.init(1e-15, 1e-8, 1e8, 200)
         g.build()
         out["info_" + tag] = np.array(g.amg_info(), dtype=np.float64)
+        out["levels_" + tag] = np.array([g.amg_level(l) for l in range(int(out["info_" + tag][0]))], dtype=np.float64)
         out["x_" + tag] = g.solve(None, np.zeros(hi - lo))
         out["res_" + tag] = np.array(g.result(), dtype=np.float64)
     np.savez(os.path.join(outdir, "r%d.npz" % rank), lo=lo, hi=hi, **out)
@@ -307,6 +308,23 @@ def amg_matrix(kind):
         N = 120
         t = sp.diags([np.ones(N - 1), np.ones(N), np.ones(N - 1)], [-1, 0, 1])
         A = (-sp.kron(t, t) + sp.diags(np.full(N * N, 9.0))).tocsr()
+        A.sort_indices()
+        return A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+    if kind == "thin":
+        # the same stencil on a 16 x 60 grid with random symmetric weights: over 8 ranks a row block is two grid lines thick,
+        # so aggregates (two hops) and the columns of the smoothed prolongation (three) reach past the neighbouring rank --
+        # the owner of a coarse column is then a rank this one shares no fine halo with
+        ny, nx = 16, 60
+        rng = np.random.default_rng(33)
+        idx = np.arange(ny * nx).reshape(ny, nx)
+        rows, cols, vals = [], [], []
+        for dy, dx in ((0, 1), (1, -1), (1, 0), (1, 1)):
+            a = idx[max(0, -dy):ny - max(0, dy), max(0, -dx):nx - max(0, dx)].ravel()
+            b = idx[max(0, dy):ny - max(0, -dy), max(0, dx):nx - max(0, -dx)].ravel()
+            w = -rng.uniform(0.5, 1.5, a.size)
+            rows += [a, b]; cols += [b, a]; vals += [w, w]
+        A = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(ny * nx, ny * nx)).tocsr()
+        A = (A + sp.diags(-np.asarray(A.sum(axis=1)).ravel() + 0.05)).tocsr()
         A.sort_indices()
         return A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
     raise ValueError(kind)

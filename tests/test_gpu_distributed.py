@@ -296,16 +296,7 @@ def test_distribute_matrix_one_rank_end_to_end(tmp_path):
     assert r.returncode == 0 and b"distribute_driver ok" in r.stdout, r.stdout.decode()[-2000:]
 
 
-@pytest.mark.parametrize("kind", ["poisson_slab", "gr3030x"])
-def test_aggregation_amg_on_the_global_matrix(ra, S, kind):
-    """UAAMG / SAAMG with OperatorType = GlobalMatrix (global_matrix.cpp:1038-1880, :2607-3558; unsmoothed_amg.cpp /
-    smoothed_amg.cpp): the aggregates stay inside a rank's row block, the Galerkin product exchanges the prolongation rows
-    of the boundary rows, the coarse operators are interior + ghost with halo plans of their own.
-      * 1 rank: Global == Local, iteration for iteration (same kernels: the row block is the whole matrix);
-      * 2 and 4 ranks: every level satisfies A_c x = R A_f P x on a random x to rounding (ghost parts and coarse halo plans
-        against the fine ones), the solves converge to the solution of A x = A 1, and the iteration counts stay within twice
-        the 1-rank count."""
-    from test_cpu_host import _spawn
+def _amg_local_runs(ra, S, kind):
     import _dist_worker as W
     from rocalution_amd import generators as gen
     if kind == "poisson_slab":
@@ -313,7 +304,6 @@ def test_aggregation_amg_on_the_global_matrix(ra, S, kind):
     else:
         rp, ci, va = W.amg_matrix(kind)
     n = len(rp) - 1
-    # the Local run of the same solver
     A = ra.LocalMatrix(); A.SetDataPtrCSR(rp, ci, va)
     b = ra.LocalVector(); b.Allocate("", n); A.Apply(ra.LocalVector(data=np.ones(n)), b)
     local = {}
@@ -324,13 +314,31 @@ def test_aggregation_amg_on_the_global_matrix(ra, S, kind):
         ls.Solve(b, x)
         local[tag] = (ls.GetIterationCount(), x.numpy().copy())
         ls.Clear()
-    runs = {w: _spawn("amg", kind, world=w, timeout=900) for w in (1, 2, 4)}
+    return n, local
+
+
+@pytest.mark.parametrize("kind", ["poisson_slab", "gr3030x", "thin"])
+def test_aggregation_amg_on_the_global_matrix(ra, S, kind):
+    """UAAMG / SAAMG with OperatorType = GlobalMatrix (global_matrix.cpp:1038-1880, :2607-3558; unsmoothed_amg.cpp /
+    smoothed_amg.cpp), PMIS: the aggregates cross the rank boundaries as the reference's do, and -- the reference has no
+    MPI here to compare with -- the property that pins the P-way algorithm is its independence of P: the aggregate
+    numbering is the one a single rank produces, so
+      * 1 rank: Global == Local, iteration for iteration (same kernels: the row block is the whole matrix);
+      * 2 and 4 ranks: the SAME hierarchy as on one rank -- every level has the same global size, the same number of
+        entries and the same || A_l 1 || (to rounding: the Galerkin sums are taken in another order), every level satisfies
+        A_c x = R A_f P x on a random x (ghost parts, the halo plans of P and A_c, the reverse exchange of R), and CG takes
+        the SAME number of iterations to the same solution."""
+    from test_cpu_host import _spawn
+    n, local = _amg_local_runs(ra, S, kind)
+    worlds = (1, 3, 8) if kind == "thin" else (1, 2, 4)  # ("thin": see _dist_worker.amg_matrix)
+    runs = {w: _spawn("amg", kind, world=w, timeout=900) for w in worlds}
     for tag in ("ua", "sa"):
         it1 = int(runs[1][0]["res_" + tag][0])
         x1 = runs[1][0]["x_" + tag]
         assert it1 == local[tag][0], (tag, it1, local[tag][0])
         assert np.max(np.abs(x1 - local[tag][1])) <= 1e-12
-        for w in (1, 2, 4):
+        lv1 = runs[1][0]["levels_" + tag]
+        for w in worlds:
             res = runs[w]
             x = np.concatenate([r["x_" + tag] for r in res])
             it, st = int(res[0]["res_" + tag][0]), int(res[0]["res_" + tag][1])
@@ -340,8 +348,36 @@ def test_aggregation_amg_on_the_global_matrix(ra, S, kind):
             assert levels >= 2 and coarsest < n / 4, (tag, w, levels, coarsest)
             for r in res:  # every rank reports the same (all-reduced) defect
                 assert r["info_" + tag][2] < 1e-12, (tag, w, r["info_" + tag])
-            # (aggregates that stop at the rank boundaries cost iterations as the blocks get thinner -- measured 10 / 11 / 16
-            #  for SA-AMG on the 120 x 120 nine-point grid over 1 / 2 / 4 ranks; a wrong coarse coupling does not converge at all)
+            lv = np.array([r["levels_" + tag] for r in res])  # (rank, level, what)
+            assert lv.shape[1] == lv1.shape[0], (tag, w, lv.shape, lv1.shape)
+            assert np.array_equal(lv[0, :, 0], lv1[:, 0]), (tag, w, lv[0, :, 0], lv1[:, 0])  # global rows per level
+            assert np.array_equal(lv[:, :, 1].sum(axis=0), lv1[:, 1]), (tag, w, lv[:, :, 1].sum(axis=0), lv1[:, 1])
+            assert np.allclose(lv[0, :, 2], lv1[:, 2], rtol=1e-11, atol=0), (tag, w, lv[0, :, 2], lv1[:, 2])
+            assert it == it1, (tag, w, it, it1)
+            assert np.max(np.abs(x - x1)) <= 1e-9, (tag, w)
+
+
+def test_aggregation_amg_on_the_global_matrix_decoupled(ra, S):
+    """... and the form whose aggregates stop at the rank boundaries (RAMD_GLOBAL_AMG=decoupled; what Greedy uses on more
+    than one rank): block-diagonal P and R, the Galerkin identity on every level, convergence to the solution; thinner
+    blocks cost iterations (measured 10 / 11 / 16 for SA-AMG on the 120 x 120 nine-point grid over 1 / 2 / 4 ranks)."""
+    from test_cpu_host import _spawn
+    kind = "gr3030x"
+    n, local = _amg_local_runs(ra, S, kind)
+    runs = {w: _spawn("amg", kind, world=w, timeout=900, env={"RAMD_GLOBAL_AMG": "decoupled"}) for w in (1, 2, 4)}
+    for tag in ("ua", "sa"):
+        it1 = int(runs[1][0]["res_" + tag][0])
+        assert it1 == local[tag][0], (tag, it1, local[tag][0])
+        for w in (2, 4):
+            res = runs[w]
+            x = np.concatenate([r["x_" + tag] for r in res])
+            it, st = int(res[0]["res_" + tag][0]), int(res[0]["res_" + tag][1])
+            levels, coarsest, defect = res[0]["info_" + tag]
+            assert st == 2, (tag, w, st)
+            assert np.linalg.norm(x - 1.0) / np.sqrt(n) < 1e-6, (tag, w)
+            assert levels >= 2 and coarsest < n / 4, (tag, w, levels, coarsest)
+            for r in res:
+                assert r["info_" + tag][2] < 1e-12, (tag, w, r["info_" + tag])
             assert it <= 2 * it1, (tag, w, it, it1)
 
 
