@@ -223,8 +223,8 @@ def amg_worker(rank, world, initfile, kind, outdir, rccl=False):
     out = {}
     for tag, pk in (("ua", capi.PC_GLOBAL_UAAMG), ("sa", capi.PC_GLOBAL_SAAMG)):
         g = D.DistributedSolver(comm, capi.SOLVER_CG, pk)
-        if kind == "poisson_slab":
-            N = 24
+        if kind.startswith("poisson_slab"):
+            N = int(kind[len("poisson_slab"):] or 24)
             z0, z1 = (N * rank) // world, (N * (rank + 1)) // world
             lo, hi = z0 * N * N, z1 * N * N
             g.setup_poisson(N, z0, z1)
@@ -243,6 +243,61 @@ def amg_worker(rank, world, initfile, kind, outdir, rccl=False):
         out["x_" + tag] = g.solve(None, np.zeros(hi - lo))
         out["res_" + tag] = np.array(g.result(), dtype=np.float64)
     np.savez(os.path.join(outdir, "r%d.npz" % rank), lo=lo, hi=hi, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def aggregate_worker(rank, world, initfile, kind, outdir):
+    """the distributed aggregation through the C ABI itself (ramd_mat_merge_columns, ramd_mat_amg_pmis_aggregate_global,
+    ramd_mat_amg_prolong_global) on the row blocks of a golden matrix; kind = "<golden name>:<even|uneven>" """
+    import ctypes as C
+    from conftest import load_golden
+    from rocalution_amd import capi, distributed as D
+    import rocalution_amd as ra
+    dist = _init(rank, world, initfile)
+    ra.init_rocalution(0)
+    lib = capi.load()
+    comm = D.make_callback_comm(rank, world, dist)
+    name, how = kind.split(":")
+    g = load_golden(name)
+    rp, ci, va = g["rowptr"], g["col"], g["val"]
+    n = len(rp) - 1
+    off = D.partition_rows(n, world)
+    if how == "uneven":  # blocks of very different sizes (the first one two rows)
+        cuts = sorted(set([2] + [int(n * f) for f in (0.11, 0.16, 0.55, 0.8, 0.93, 0.97)]))[:world - 1]
+        off = np.array([0] + cuts + [n], dtype=np.int64)
+    piece = D.split_rows(rp, ci, va, off, rank)
+    plan = D.build_halo_plan(piece, off, rank, _gather_obj(dist, world))
+    lo, hi = piece["row_begin"], piece["row_end"]
+    nloc, nrecv = hi - lo, int(plan["recv_offset"][-1])
+    Ai, Ag, blk, Pu, Ps = (ra.LocalMatrix() for _ in range(5))
+    Ai.SetDataPtrCSR(*piece["interior"], nrow=nloc, ncol=nloc)
+    has_ghost = len(piece["ghost"][1]) > 0
+    if has_ghost:
+        Ag.SetDataPtrCSR(*piece["ghost"], nrow=nloc, ncol=nrecv)
+    capi.check(lib.ramd_mat_merge_columns(Ai._h, Ag._h if has_ghost else None, nrecv, blk._h))
+    peers = np.ascontiguousarray(plan["peers"], dtype=np.int32)
+    so = np.ascontiguousarray(plan["send_offset"], dtype=np.int64)
+    ro = np.ascontiguousarray(plan["recv_offset"], dtype=np.int64)
+    bnd = ra.LocalVector(np.int32, data=plan["boundary_index"])
+    numbers, conn, agg, roots = (ra.LocalVector(np.int32) for _ in range(4))
+    first, mine, total = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    pi32, pi64 = C.POINTER(C.c_int), C.POINTER(C.c_int64)
+    capi.check(lib.ramd_mat_amg_pmis_aggregate_global(
+        blk._h, 0.01, comm, 0, len(peers), peers.ctypes.data_as(pi32), so.ctypes.data_as(pi64), ro.ctypes.data_as(pi64),
+        bnd._h, int(lo), numbers._h, conn._h, agg._h, roots._h, C.byref(first), C.byref(mine), C.byref(total)))
+    capi.check(lib.ramd_mat_amg_prolong_global(blk._h, 0, 0.0, 0, conn._h, agg._h, roots._h, total.value, Pu._h))
+    capi.check(lib.ramd_mat_amg_prolong_global(blk._h, 1, 2.0 / 3.0, 0, conn._h, agg._h, roots._h, total.value, Ps._h))
+    out = dict(lo=lo, hi=hi, nrecv=nrecv, numbers=numbers.CopyToHostData(), agg=agg.CopyToHostData(),
+               roots=roots.CopyToHostData(), conn=conn.CopyToHostData(), first=first.value, mine=mine.value,
+               total=total.value, recv_global=piece["recv_global"])
+    for tag, P in (("pu", Pu), ("ps", Ps)):
+        prp, pci, pva = P.CopyToCSR()
+        out[tag + "_rp"], out[tag + "_ci"], out[tag + "_va"], out[tag + "_ncol"] = prp, pci, pva, P.GetN()
+    # the entries of the block in the reference's layout: conn over [interior entries | ghost entries] of the rank
+    brp, bci, _ = blk.CopyToCSR()
+    out["blk_rp"], out["blk_ci"] = brp, bci
+    np.savez(os.path.join(outdir, "r%d.npz" % rank), **out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -336,6 +391,8 @@ if __name__ == "__main__":
         amg_worker(int(rank), int(world), initfile, kind, outdir, rccl=(mode == "amg_rccl"))
     elif mode == "cpu":
         cpu_worker(int(rank), int(world), initfile, kind, outdir)
+    elif mode == "aggregate":
+        aggregate_worker(int(rank), int(world), initfile, kind, outdir)
     elif mode == "plans":
         plans_worker(int(rank), int(world), initfile, kind, outdir)
     else:

@@ -357,6 +357,61 @@ def test_aggregation_amg_on_the_global_matrix(ra, S, kind):
             assert np.max(np.abs(x - x1)) <= 1e-9, (tag, w)
 
 
+@pytest.mark.parametrize("name,world,how", [("gr3030", 2, "even"), ("gr3030", 5, "uneven"), ("poisson8", 3, "even"),
+                                            ("poisson8", 7, "uneven"), ("lap2d7", 4, "uneven")])
+def test_distributed_pmis_aggregation_vs_oracle_and_golden(name, world, how):
+    """ramd_mat_amg_pmis_aggregate_global / ramd_mat_amg_prolong_global called through the C ABI on `world` row blocks
+    (global_matrix.cpp:2647-3121, :3123-3558):
+      * node numbers, aggregates and root nodes over every rank's extended block (own rows, then ghost nodes) are those of
+        the oracle's P-way serial mode (oracle/pmis_pway.py) -- and with it those of the genuine library's single-process
+        run (tests/golden), whatever the number of ranks and wherever the block boundaries fall: bit-exact;
+      * the strong-connection flags are the golden ones, entry for entry;
+      * the rows of the unsmoothed prolongation put together are the golden operator bit for bit; those of the smoothed
+        one agree to rounding (a row next to a block boundary adds its ghost entries after the interior ones)."""
+    from conftest import load_golden
+    from test_cpu_host import _spawn
+    from test_oracle_golden import _pmis_oracle
+    O = _pmis_oracle()
+    g = load_golden(name)
+    rp, ci, va = g["rowptr"], g["col"], g["val"]
+    n = len(rp) - 1
+    res = _spawn("aggregate", name + ":" + how, world=world, timeout=600)
+    off = [int(r["lo"]) for r in res] + [n]
+    oagg, oroots = O.pmis_pway(rp, ci, va, 0.01, off)
+    assert np.array_equal(oagg, g["amg_agg"]) and np.array_equal(oroots, g["amg_roots"])
+    nagg = int(g["amg_agg"].max()) + 1
+    firsts = 0
+    for r in res:
+        lo, hi = int(r["lo"]), int(r["hi"])
+        ext = np.concatenate([np.arange(lo, hi), r["recv_global"]]).astype(np.int64)  # global number of every node
+        assert np.array_equal(r["numbers"], ext)
+        assert np.array_equal(r["agg"], oagg[ext]), (lo, hi)
+        assert np.array_equal(r["roots"], oroots[ext]), (lo, hi)
+        assert int(r["total"]) == nagg and int(r["first"]) == firsts
+        firsts += int(r["mine"])
+        # strong connections: the block's entries against the golden flags of the same (row, column)
+        gconn = {}
+        for i in range(lo, hi):
+            for j in range(rp[i], rp[i + 1]):
+                gconn[(i, int(ci[j]))] = int(g["amg_conn"][j])
+        brp, bci = r["blk_rp"], r["blk_ci"]
+        for i in range(hi - lo):
+            for j in range(brp[i], brp[i + 1]):
+                assert int(r["conn"][j]) == gconn[(lo + i, int(ext[bci[j]]))]
+    assert firsts == nagg
+    for tag, key, exact in (("pu", "amg_P", True), ("ps", "amg_Ps", False)):
+        prp = np.concatenate([[0]] + [r[tag + "_rp"][1:] + sum(len(q[tag + "_ci"]) for q in res[:k])
+                                      for k, r in enumerate(res)])
+        pci = np.concatenate([r[tag + "_ci"] for r in res])
+        pva = np.concatenate([r[tag + "_va"] for r in res])
+        assert all(int(r[tag + "_ncol"]) == nagg for r in res)
+        assert np.array_equal(prp, g[key + "_rowptr"]) and np.array_equal(pci, g[key + "_col"])
+        if exact:
+            assert np.array_equal(pva, g[key + "_val"])
+        else:
+            assert np.allclose(pva, g[key + "_val"], rtol=1e-14, atol=1e-16)
+
+
 def test_aggregation_amg_on_the_global_matrix_decoupled(ra, S):
     """... and the form whose aggregates stop at the rank boundaries (RAMD_GLOBAL_AMG=decoupled; what Greedy uses on more
     than one rank): block-diagonal P and R, the Galerkin identity on every level, convergence to the solution; thinner

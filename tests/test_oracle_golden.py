@@ -396,3 +396,37 @@ def test_bicgstab_residual_history_moves_with_the_summation_order(oracle):
                 assert worst > least, worst  # the spread is real: a 1e-6 bar on the whole history cannot be met by ANY reordering
     finally:
         oracle.set_threads(1)
+
+
+# ------------------------------------------------------------------ PMIS aggregation, single-process and P-way serial mode
+def _pmis_oracle():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("pmis_pway", os.path.join(root, "oracle", "pmis_pway.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("name", ["gr3030", "poisson8", "lap2d7"])
+def test_pmis_restatement_vs_golden_and_its_p_way_mode(name):
+    """oracle/pmis_pway.py: (a) its single-process form returns the strong connections, aggregates and root nodes of the
+    genuine rocALUTION host backend (the arrays the device kernels are checked against), bit for bit; (b) its P-way serial
+    mode -- the reference's GlobalMatrix::AMGPMISAggregate with every message an explicit copy between emulated ranks --
+    returns the SAME aggregates and root nodes for every number of ranks and every position of the block boundaries tried
+    (even blocks, blocks of very different sizes, a block of two rows): the property the `-m gpu` parity tests of the
+    distributed aggregation build on."""
+    O = _pmis_oracle()
+    g = load_golden(name)
+    rp, ci, va = g["rowptr"], g["col"], g["val"]
+    n = len(rp) - 1
+    conn, agg, roots = O.pmis_single(rp, ci, va, 0.01)
+    assert np.array_equal(conn, g["amg_conn"])
+    assert np.array_equal(agg, g["amg_agg"])
+    assert np.array_equal(roots, g["amg_roots"])
+    splits = [[0, n // 2, n], [0, n // 3, 2 * n // 3, n], [0, 2, n // 7, n // 7 + 5, n - n // 5, n],
+              list(np.linspace(0, n, 9).astype(int))]
+    for off in splits:
+        a, r = O.pmis_pway(rp, ci, va, 0.01, off)
+        assert np.array_equal(a, agg), off
+        assert np.array_equal(r, roots), off
