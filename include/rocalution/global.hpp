@@ -1252,7 +1252,15 @@ private:
         this->m_ghost.AllocateCSR("Ghost", (int64_t)gci.size(), n, (int64_t)ghost.size());
         if(!gci.empty())
             this->m_ghost.CopyFromCSR(grp.data(), gci.data(), gva.data());
-        // who owns what I need; the owners learn it from me
+        this->doAdoptGhosts(like, global_nrow, col_offsets, ghost);
+    }
+    // the halo pattern that brings the vector entries of the ghost columns `ghost` (global numbers, ascending) here: who
+    // owns what I need, and the owners learn it from me.  interior / ghost are in place.  A collective.
+    void doAdoptGhosts(const ParallelManager* like, int64_t global_nrow, const std::vector<int64_t>& col_offsets,
+                       const std::vector<int64_t>& ghost)
+    {
+        const int     P = like->GetNumProcs(), r = like->GetRank();
+        const int64_t n = this->m_interior.GetM(), c0 = col_offsets[(size_t)r], nc = col_offsets[(size_t)r + 1] - c0;
         std::vector<std::vector<double>> ask((size_t)P);
         for(int64_t g : ghost)
             ask[(size_t)doOwner(col_offsets, g)].push_back((double)g);
@@ -1503,13 +1511,12 @@ private:
                     row.emplace_back(compact((int64_t)gcol[(size_t)k][(size_t)g]), static_cast<ValueType>(gval[(size_t)k][(size_t)g]));
             flush(n + g);
         }
-        // the products on the device
-        std::vector<PtrType>   crp((size_t)ncc + 1, 0);
-        std::vector<int>       cci;
-        std::vector<ValueType> cva;
+        // the products on the device: C = P_own^T ([A_int | A_ghost] P_ext), rows and columns in the compact numbering
+        LocalMatrix<ValueType> C;
+        C.MoveToAccelerator();
         if(nnz_own > 0)
         {
-            LocalMatrix<ValueType> Ablk, Px, Pown, Pt, AP, C;
+            LocalMatrix<ValueType> Ablk, Px, Pown, Pt, AP;
             A.doRowBlock(&Ablk);
             const int64_t xrows = Ablk.GetN();
             RAMD_EXPECT(xrows == n + ngA);
@@ -1523,15 +1530,17 @@ private:
             AP.MatrixMult(Ablk, Px);
             Pt.MoveToAccelerator();
             Pown.Transpose(&Pt);
-            C.MoveToAccelerator();
             C.MatrixMult(Pt, AP);
-            cci.resize((size_t)C.GetNnz());
-            cva.resize((size_t)C.GetNnz());
-            if(C.GetNnz() > 0)
-                C.CopyToCSR(crp.data(), cci.data(), cva.data());
         }
+        else
+            C.AllocateCSR("empty product", 0, ncc, ncc);
+        // coarse rows of other ranks go to their owners as (row, column, value) triplets -- values as they are
+        std::vector<PtrType>   crp((size_t)ncc + 1, 0);
+        std::vector<int>       cci((size_t)C.GetNnz());
+        std::vector<ValueType> cva((size_t)C.GetNnz());
+        if(C.GetNnz() > 0)
+            C.CopyToCSR(crp.data(), cci.data(), cva.data());
         auto global_of = [&](int c) { return c < nc ? c0 + c : others[(size_t)(c - nc)]; };
-        // coarse rows of other ranks go to their owners as (row, column, value) triplets
         std::vector<std::vector<double>> out((size_t)Pn);
         for(int64_t I = nc; I < ncc; ++I)
         {
@@ -1545,42 +1554,85 @@ private:
             }
         }
         const std::vector<std::vector<double>> in = doTalk(fpm, out);
-        // my rows: what I computed, then what arrived in rank order; equal columns of a row are added in that order
-        std::vector<std::vector<std::pair<int64_t, ValueType>>> rows((size_t)nc);
-        for(int64_t I = 0; I < nc; ++I)
-            for(PtrType j = crp[(size_t)I]; j < crp[(size_t)I + 1]; ++j)
-                rows[(size_t)I].emplace_back(global_of(cci[(size_t)j]), cva[(size_t)j]);
+        // ghost columns of the coarse operator: the foreign columns of my rows, in what I computed and in what arrived
+        std::vector<int64_t> ghost;
+        for(PtrType j = 0; j < crp[(size_t)nc]; ++j)
+            if(cci[(size_t)j] >= nc)
+                ghost.push_back(others[(size_t)(cci[(size_t)j] - nc)]);
         for(int q = 0; q < Pn; ++q)
             for(size_t t = 0; t + 2 < in[(size_t)q].size(); t += 3)
             {
-                const int64_t I = (int64_t)std::llround(in[(size_t)q][t]) - c0;
-                RAMD_EXPECT(I >= 0 && I < nc);
-                rows[(size_t)I].emplace_back((int64_t)std::llround(in[(size_t)q][t + 1]), static_cast<ValueType>(in[(size_t)q][t + 2]));
+                const int64_t J = (int64_t)std::llround(in[(size_t)q][t + 1]);
+                if(J < c0 || J >= c0 + nc)
+                    ghost.push_back(J);
             }
-        std::vector<PtrType>   arp((size_t)nc + 1, 0);
-        std::vector<int64_t>   agc;
-        std::vector<ValueType> ava;
-        for(int64_t I = 0; I < nc; ++I)
+        std::sort(ghost.begin(), ghost.end());
+        ghost.erase(std::unique(ghost.begin(), ghost.end()), ghost.end());
+        const int64_t ngh = (int64_t)ghost.size();
+        auto final_of = [&](int64_t g) {
+            return (g >= c0 && g < c0 + nc) ? (int)(g - c0)
+                                            : (int)(nc + (std::lower_bound(ghost.begin(), ghost.end(), g) - ghost.begin()));
+        };
+        // my rows over [own columns | ghost columns]: the part computed here, then one operator per sending rank; the sums
+        // are device MatrixAdds in that order (entries of one (row, column) are added own part first, then rank by rank)
+        LocalMatrix<ValueType> M;
+        M.MoveToAccelerator();
         {
-            std::vector<std::pair<int64_t, ValueType>>& rw = rows[(size_t)I];
-            std::stable_sort(rw.begin(), rw.end(),
-                             [](const std::pair<int64_t, ValueType>& a, const std::pair<int64_t, ValueType>& b) { return a.first < b.first; });
-            for(size_t k = 0; k < rw.size();)
-            {
-                const int64_t g = rw[k].first;
-                ValueType     v = rw[k].second;
-                for(++k; k < rw.size() && rw[k].first == g; ++k)
-                    v += rw[k].second;
-                agc.push_back(g);
-                ava.push_back(v);
-            }
-            arp[(size_t)I + 1] = (PtrType)agc.size();
-            std::vector<std::pair<int64_t, ValueType>>().swap(rw);
+            std::vector<PtrType>   mrp(crp.begin(), crp.begin() + nc + 1);
+            std::vector<int>       mci((size_t)mrp[(size_t)nc]);
+            std::vector<ValueType> mva(cva.begin(), cva.begin() + mrp[(size_t)nc]);
+            for(size_t j = 0; j < mci.size(); ++j)
+                mci[j] = final_of(global_of(cci[j])); // (ascending in a row: both numberings ascend with the global one)
+            M.AllocateCSR("own part of the coarse rows", (int64_t)mci.size(), nc, nc + ngh);
+            if(!mci.empty())
+                M.CopyFromCSR(mrp.data(), mci.data(), mva.data());
         }
+        for(int q = 0; q < Pn; ++q)
+        {
+            const std::vector<double>& msg = in[(size_t)q];
+            if(msg.empty())
+                continue;
+            const size_t        nt = msg.size() / 3;
+            std::vector<size_t> ord(nt);
+            std::vector<int>    ti(nt), tj(nt);
+            for(size_t t = 0; t < nt; ++t)
+            {
+                ord[t]          = t;
+                const int64_t I = (int64_t)std::llround(msg[3 * t]) - c0;
+                RAMD_EXPECT(I >= 0 && I < nc);
+                ti[t] = (int)I;
+                tj[t] = final_of((int64_t)std::llround(msg[3 * t + 1]));
+            }
+            std::sort(ord.begin(), ord.end(), [&](size_t a2, size_t b2) { return ti[a2] != ti[b2] ? ti[a2] < ti[b2] : tj[a2] < tj[b2]; });
+            std::vector<PtrType>   rrp((size_t)nc + 1, 0);
+            std::vector<int>       rci(nt);
+            std::vector<ValueType> rva(nt);
+            for(size_t k = 0; k < nt; ++k)
+            {
+                ++rrp[(size_t)ti[ord[k]] + 1];
+                rci[k] = tj[ord[k]];
+                rva[k] = static_cast<ValueType>(msg[3 * ord[k] + 2]);
+            }
+            for(int64_t I = 0; I < nc; ++I)
+                rrp[(size_t)I + 1] += rrp[(size_t)I];
+            LocalMatrix<ValueType> Rq;
+            Rq.MoveToAccelerator();
+            Rq.AllocateCSR("coarse rows computed elsewhere", (int64_t)nt, nc, nc + ngh);
+            Rq.CopyFromCSR(rrp.data(), rci.data(), rva.data());
+            M.MatrixAdd(Rq, static_cast<ValueType>(1), static_cast<ValueType>(1), true);
+        }
+        this->doDropHaloPlan();
         this->m_interior.CloneBackend(A.m_interior);
         this->m_ghost.CloneBackend(A.m_interior);
-        this->doDropHaloPlan();
-        this->doFromGlobalColumns(fpm, coff.back(), coff, arp, agc, ava);
+        if(nc > 0 && M.GetNnz() > 0)
+            M.ExtractSubMatrix(0, 0, nc, nc, &this->m_interior);
+        else
+            this->m_interior.AllocateCSR("Interior", 0, nc, nc);
+        if(nc > 0 && ngh > 0 && M.GetNnz() > 0)
+            M.ExtractSubMatrix(0, nc, nc, ngh, &this->m_ghost);
+        else
+            this->m_ghost.AllocateCSR("Ghost", 0, nc, ngh);
+        this->doAdoptGhosts(fpm, coff.back(), coff, ghost);
     }
     mutable std::shared_ptr<AmgBlock> m_amg;
     bool                   m_coupled = false; // built by the coupled setup: m_ghost_cols / m_col_offsets are valid
