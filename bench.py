@@ -639,7 +639,11 @@ def main():
             capi.check(lib.ramd_gsolver_set_time_mark(g, warm if warm > 0 else -1))
             if fmt != ra.CSR:  # preconditioners are built from the CSR state (second run: convert back first)
                 capi.check(lib.ramd_gsolver_convert(g, ra.CSR))
+            barrier()
+            tb0 = time.perf_counter()
             capi.check(lib.ramd_gsolver_build(g))
+            barrier()
+            tb = time.perf_counter() - tb0  # (Build() of solver + preconditioner on this rank, barrier to barrier)
             if fmt != ra.CSR:  # converted after Build(), as the reference tests do
                 capi.check(lib.ramd_gsolver_convert(g, fmt))
             capi.check(lib.ramd_gsolver_prepare_ones(g))
@@ -655,7 +659,7 @@ def main():
                 assert dt > 0, "the marked iteration was not reached"
             itc, st, rs = C.c_int(0), C.c_int(0), C.c_double(0)
             capi.check(lib.ramd_gsolver_result(g, C.byref(itc), C.byref(st), C.byref(rs)))
-            return dt, itc.value - warm, rs.value, 0.0
+            return dt, itc.value - warm, rs.value, tb
 
         # W untimed warm-up iterations, then EXACTLY K timed ones, in one Solve; --warmup 0 times the whole Solve
         capi.check(lib.ramd_placement_seconds(None, 1))
