@@ -1289,7 +1289,7 @@ struct HaloArgs
     const int64_t *so, *ro;
     const int*     d_boundary; // device copy of the boundary index (nsend)
     int64_t        nsend, nrecv;
-    void *         d_send, *d_recv; // 8 bytes per entry
+    void*          d_send; // 8 bytes per entry
 };
 // the ghost entries [n, n + ng) of a per-node array from the owners of the ghost nodes
 template <typename U>
@@ -1305,11 +1305,9 @@ static int halo_extend(const HaloArgs& h, U* ext, int n)
     vs.n                = h.nsend;
     vs.d                = h.d_send;
     vr.n                = h.nrecv;
-    vr.d                = h.d_recv;
+    vr.d                = ext + n; // (the receive buffer IS the ghost part of the array)
     RAMD_TRY(ramd_comm_halo_begin_plan(h.comm, h.plan, &vs, &vr, h.npeers, h.peers, h.so, h.ro));
     RAMD_TRY(ramd_comm_halo_end(h.comm));
-    if(h.nrecv > 0)
-        RAMD_HIP(hipMemcpyAsync(ext + n, h.d_recv, sizeof(U) * (size_t)h.nrecv, hipMemcpyDeviceToDevice, b.cur));
     return RAMD_OK;
 }
 
@@ -1524,7 +1522,7 @@ static int pmis_aggregate_global_t(const ramd_mat_s* m, T eps, HaloArgs h, int f
     T*   diag  = nullptr;
     int *state = nullptr, *max_state = nullptr, *hash = nullptr, *flag = nullptr, *bt = nullptr, *gt = nullptr,
         *tmp = nullptr;
-    double *sb = nullptr, *rb = nullptr;
+    double* sb = nullptr;
     int     s  = dev_alloc(&diag, next);
     if(s == RAMD_OK)
         s = dev_alloc(&state, next);
@@ -1541,11 +1539,8 @@ static int pmis_aggregate_global_t(const ramd_mat_s* m, T eps, HaloArgs h, int f
     if(s == RAMD_OK)
         s = dev_alloc(&sb, h.nsend);
     if(s == RAMD_OK)
-        s = dev_alloc(&rb, h.nrecv);
-    if(s == RAMD_OK)
         s = dev_alloc(&tmp, (int64_t)n + 1);
     h.d_send = sb;
-    h.d_recv = rb;
     auto body = [&]() -> int {
         RAMD_HIP(hipMemsetAsync(diag, 0, sizeof(T) * (size_t)next, b.cur));
         RAMD_HIP(hipMemsetAsync(max_state, 0, sizeof(int) * (size_t)next, b.cur));
@@ -1635,7 +1630,6 @@ static int pmis_aggregate_global_t(const ramd_mat_s* m, T eps, HaloArgs h, int f
     dev_free(&bt);
     dev_free(&gt);
     dev_free(&sb);
-    dev_free(&rb);
     dev_free(&tmp);
     return s;
 }
@@ -1789,7 +1783,7 @@ int ramd_mat_amg_pmis_aggregate_global(ramd_mat_t block, double eps, ramd_comm_t
     h.d_boundary = (const int*)boundary->d;
     h.nsend      = nsend;
     h.nrecv      = nrecv;
-    h.d_send = h.d_recv = nullptr;
+    h.d_send = nullptr;
     if(block->dtype == RAMD_F64)
         return pmis_aggregate_global_t<double>(block, eps, h, (int)first_row, numbers, connections, aggregates,
                                                aggregate_root_nodes, agg_first, agg_mine, agg_total);

@@ -259,8 +259,11 @@ def aggregate_worker(rank, world, initfile, kind, outdir):
     lib = capi.load()
     comm = D.make_callback_comm(rank, world, dist)
     name, how = kind.split(":")
-    g = load_golden(name)
-    rp, ci, va = g["rowptr"], g["col"], g["val"]
+    if name == "iso":
+        rp, ci, va = amg_matrix(name)
+    else:
+        g = load_golden(name)
+        rp, ci, va = g["rowptr"], g["col"], g["val"]
     n = len(rp) - 1
     off = D.partition_rows(n, world)
     if how == "uneven":  # blocks of very different sizes (the first one two rows)
@@ -380,6 +383,23 @@ def amg_matrix(kind):
             rows += [a, b]; cols += [b, a]; vals += [w, w]
         A = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(ny * nx, ny * nx)).tocsr()
         A = (A + sp.diags(-np.asarray(A.sum(axis=1)).ravel() + 0.05)).tocsr()
+        A.sort_indices()
+        return A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+    if kind == "iso":
+        # 400 rows: rows 0..99 a component of their own (over 4 even blocks rank 0 has no neighbour), a random symmetric
+        # pattern on the rest, and every ninth row with a diagonal so large that none of its couplings is strong (such
+        # rows stay outside every aggregate, also where they are boundary rows or ghost nodes)
+        n, m = 400, 100
+        rng = np.random.default_rng(77)
+        def sym(k, dens):
+            B = sp.random(k, k, density=dens, random_state=rng, data_rvs=lambda s: -rng.uniform(0.2, 1.0, s))
+            B = sp.triu(B, 1)
+            return (B + B.T).tocsr()
+        band = sp.diags([-np.ones(n - m - 1), -np.ones(n - m - 1)], [-1, 1])  # (keeps the big component connected)
+        A = sp.block_diag([sym(m, 0.06) + sp.diags([-np.ones(m - 1), -np.ones(m - 1)], [-1, 1]), sym(n - m, 0.02) + band]).tocsr()
+        d = -np.asarray(A.sum(axis=1)).ravel() + 0.1
+        d[::9] *= 1e6
+        A = (A + sp.diags(d)).tocsr()
         A.sort_indices()
         return A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
     raise ValueError(kind)

@@ -412,6 +412,37 @@ def test_distributed_pmis_aggregation_vs_oracle_and_golden(name, world, how):
             assert np.allclose(pva, g[key + "_val"], rtol=1e-14, atol=1e-16)
 
 
+@pytest.mark.parametrize("world,how", [(4, "even"), (6, "uneven")])
+def test_distributed_pmis_aggregation_isolated_rows_and_a_rank_without_neighbours(world, how):
+    """... on a matrix without goldens, against the oracle alone: a component that fills one rank's block exactly (that rank
+    exchanges with nobody while the others do), rows none of whose couplings is strong (aggregate -2, also as boundary rows
+    and as ghost nodes), an irregular pattern.  Aggregates and roots bit-exact against oracle/pmis_pway.py in its P-way and
+    its single-process form; the unsmoothed prolongation has its one entry per aggregated row at the aggregate's number."""
+    import _dist_worker as W
+    from test_cpu_host import _spawn
+    from test_oracle_golden import _pmis_oracle
+    O = _pmis_oracle()
+    rp, ci, va = W.amg_matrix("iso")
+    n = len(rp) - 1
+    res = _spawn("aggregate", "iso:" + how, world=world, timeout=600)
+    off = [int(r["lo"]) for r in res] + [n]
+    oagg, oroots = O.pmis_pway(rp, ci, va, 0.01, off)
+    _, sagg, sroots = O.pmis_single(rp, ci, va, 0.01)
+    assert np.array_equal(oagg, sagg) and np.array_equal(oroots, sroots)
+    assert (oagg == -2).sum() >= n // 9 and oagg.max() > 10
+    if how == "even":
+        assert int(res[0]["nrecv"]) == 0 and all(int(r["nrecv"]) > 0 for r in res[1:])
+    nagg = int(oagg.max()) + 1
+    for r in res:
+        lo, hi = int(r["lo"]), int(r["hi"])
+        ext = np.concatenate([np.arange(lo, hi), r["recv_global"]]).astype(np.int64)
+        assert np.array_equal(r["agg"], oagg[ext]) and np.array_equal(r["roots"], oroots[ext]), (lo, hi)
+        assert int(r["total"]) == nagg and int(r["pu_ncol"]) == nagg
+        own = oagg[lo:hi]
+        assert np.array_equal(np.diff(r["pu_rp"]), (own >= 0).astype(np.int32))
+        assert np.array_equal(r["pu_ci"], own[own >= 0]) and np.all(r["pu_va"] == 1.0)
+
+
 def test_aggregation_amg_on_the_global_matrix_decoupled(ra, S):
     """... and the form whose aggregates stop at the rank boundaries (RAMD_GLOBAL_AMG=decoupled; what Greedy uses on more
     than one rank): block-diagonal P and R, the Galerkin identity on every level, convergence to the solution; thinner
