@@ -2798,7 +2798,12 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
     constexpr int OPS = 1 + NQ + NGQ + ((DSEP && DMODE != 0) ? 1 : 0);
     static_assert(DEPTH * OPS < 64, "the whole prefetch window has to fit the 6-bit counter");
     auto fetch_rec = [&](CtStage<T, NQ, NGQ>& st) {
-        st.g  = g; // (the record itself comes back through the scalar cache when the step runs: scalar registers are scarce)
+        // (the record itself comes back through the scalar cache when the step runs: scalar registers are scarce.  Carrying
+        //  it with the stage in four vector registers instead -- no scalar load left in the step, whose LDS waits are waits on
+        //  lgkmcnt(0) and so wait for that load too -- was measured: 512 x 512 x 64 slab 3.27 vs 3.34 ms per GMRES iteration,
+        //  full cube 60.2 vs 62.1 it/s, FE surrogate 199 vs 200.5: not the step's bottleneck, and the registers cost more
+        //  where the solve is bandwidth-bound; tools/r04_runs/zp.sh)
+        st.g  = g;
         st.tf = tn * 4 + ((cur_fresh ? 1 : 0) | (cur_last ? 2 : 0));
         const int      nl  = (cur.y & 0xff) * LPR; // lane records of the step
         const int      row = min(lane, nl - 1);
@@ -3393,11 +3398,43 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     for(int attempt = 0; attempt < 5 && !fits; ++attempt)
     {
     build_mark(nullptr);
-    const double f = pow((double)rows / (double)n, 1.0 / dnz);
-    for(int k = 0; k < 3; ++k)
+    // boxes as cubic as the extents allow, `rows` rows each: a box of b0 x b1 x b2 has b0 + b1 + b2 - 2 dependency levels, and
+    // every level costs the tile's wave at least one step -- the flatter the box, the emptier its steps.  (Boxes in the
+    // proportion of the extents are the same thing on a cube; on the 512 x 512 x 64 slab of an 8-way row split they were
+    // 16 x 16 x 2 = 34 levels for 512 rows against 22 for 8 x 8 x 8: GMRES(30)+ILU(0) there 3.52 -> 3.30 ms per iteration;
+    // larger cubes lose again -- 10^3: 3.64, 12^3: 4.43, 16^3: 4.85 ms, on the full cube 62.7 / 54.7 / 49.5 / 42.6 it/s for
+    // 8^3 / 10^3 / 12^3 / 16^3; tools/r04_runs/zn.sh.)  An extent shorter than the edge keeps its length and the others share
+    // the rest.
     {
-        double bk = E[k] > 1 ? (double)E[k] * f : 1.0;
-        bs[k]     = bk < 1.0 ? 1 : (int)(bk + 0.5);
+        double vol  = (double)rows * ((double)E[0] * (double)E[1] * (double)E[2] / (double)n); // (coordinate cells per box)
+        bool   done[3] = {E[0] <= 1, E[1] <= 1, E[2] <= 1};
+        for(int k = 0; k < 3; ++k)
+            bs[k] = 1;
+        for(int round = 0; round < 3; ++round)
+        {
+            int free_dims = 0;
+            for(int k = 0; k < 3; ++k)
+                free_dims += done[k] ? 0 : 1;
+            if(free_dims == 0)
+                break;
+            const double edge  = pow(vol < 1.0 ? 1.0 : vol, 1.0 / free_dims);
+            bool         again = false;
+            for(int k = 0; k < 3; ++k)
+                if(!done[k] && (double)E[k] <= edge) // the whole extent: the other edges grow
+                {
+                    bs[k]   = (int)E[k];
+                    vol    /= (double)E[k];
+                    done[k] = true;
+                    again   = true;
+                }
+            if(!again)
+            {
+                for(int k = 0; k < 3; ++k)
+                    if(!done[k])
+                        bs[k] = edge < 1.0 ? 1 : (int)(edge + 0.5);
+                break;
+            }
+        }
     }
     if(const char* e = getenv("RAMD_TRSV_CT_BOX")) // "b0,b1,b2": the box edges as given (tools/ experiments; first attempt only)
     {
