@@ -4112,7 +4112,9 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
                     RAMD_HIP(hipMalloc(&pf_buf, 32 * sizeof(unsigned long long)));
                 RAMD_HIP(hipMemsetAsync(pf_buf, 0, 32 * sizeof(unsigned long long), b.cur));
             }
-// persistent workgroups: as many as the device holds at once (more would only queue), never more than tiles
+// persistent workgroups: as many as the device holds at once (more would only queue), never more than tiles.  (Fewer -- less
+// polling ahead of the tile wavefront -- is no faster: RAMD_TRSV_WGS_PER_CU = 2 / 3 / 4 / 6 / all (9) on the 512 x 512 x 64 slab
+// 3.69 / 3.44 / 3.32 / 3.30 / 3.32 ms per GMRES iteration, on the cube 3 / 4 / 6 / all: 50.2 / 55.5 / 60.9 / 61.9 it/s.)
 #define TRSV_RC(DM, HO, LP, WLL, DP)                                                                                        \
     do                                                                                                                      \
     {                                                                                                                       \
@@ -4123,6 +4125,9 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
             int nb_cu = 0;                                                                                                  \
             RAMD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_cu, k_trsv_rec<T, DM, HO, LP, WLL, DP, false>, 128, lds));       \
             occ     = nb_cu < 1 ? 1 : nb_cu;                                                                                \
+            static const int occ_env = getenv("RAMD_TRSV_WGS_PER_CU") ? atoi(getenv("RAMD_TRSV_WGS_PER_CU")) : 0; /* (experiments) */ \
+            if(occ_env > 0 && occ_env < occ)                                                                                \
+                occ = occ_env;                                                                                              \
             occ_lds = lds;                                                                                                  \
         }                                                                                                                   \
         const int64_t cap = (int64_t)occ * b.num_cu;                                                                        \
