@@ -443,6 +443,30 @@ def test_distributed_pmis_aggregation_isolated_rows_and_a_rank_without_neighbour
         assert np.array_equal(r["pu_ci"], own[own >= 0]) and np.all(r["pu_va"] == 1.0)
 
 
+def test_aggregation_amg_on_the_global_matrix_all_gather_halo(ra, S):
+    """... with the all-gather form of the halo exchange forced (RAMD_COMM_HALO=allgather: what ranks with many neighbours
+    select): the aggregation's 4-byte payloads (states, hashes, aggregate numbers: bit patterns, some of them NaNs when read
+    as floats) travel through the plan's padded buffers, while the reverse exchange of the restriction and the setup messages
+    stay exchanges in pairs -- same hierarchy, same iteration counts as on one rank."""
+    from test_cpu_host import _spawn
+    kind = "gr3030x"
+    n, local = _amg_local_runs(ra, S, kind)
+    runs = {w: _spawn("amg", kind, world=w, timeout=900, env={"RAMD_COMM_HALO": "allgather"}) for w in (1, 4)}
+    for tag in ("ua", "sa"):
+        it1 = int(runs[1][0]["res_" + tag][0])
+        assert it1 == local[tag][0], (tag, it1, local[tag][0])
+        res = runs[4]
+        lv1 = runs[1][0]["levels_" + tag]
+        lv = np.array([r["levels_" + tag] for r in res])
+        assert np.array_equal(lv[0, :, 0], lv1[:, 0]) and np.array_equal(lv[:, :, 1].sum(axis=0), lv1[:, 1]), (tag, lv, lv1)
+        assert np.allclose(lv[0, :, 2], lv1[:, 2], rtol=1e-11, atol=0)
+        assert int(res[0]["res_" + tag][0]) == it1 and int(res[0]["res_" + tag][1]) == 2
+        x = np.concatenate([r["x_" + tag] for r in res])
+        assert np.max(np.abs(x - runs[1][0]["x_" + tag])) <= 1e-9
+        for r in res:
+            assert r["info_" + tag][2] < 1e-12
+
+
 def test_aggregation_amg_on_the_global_matrix_decoupled(ra, S):
     """... and the form whose aggregates stop at the rank boundaries (RAMD_GLOBAL_AMG=decoupled; what Greedy uses on more
     than one rank): block-diagonal P and R, the Galerkin identity on every level, convergence to the solution; thinner
