@@ -1207,7 +1207,7 @@ private:
                              const std::vector<PtrType>& rp, const std::vector<int64_t>& gcol,
                              const std::vector<ValueType>& val)
     {
-        const int     P = like->GetNumProcs(), r = like->GetRank();
+        const int     r = like->GetRank();
         const int64_t n = (int64_t)rp.size() - 1, c0 = col_offsets[(size_t)r], nc = col_offsets[(size_t)r + 1] - c0;
         std::vector<int64_t> ghost;
         for(int64_t g : gcol)
