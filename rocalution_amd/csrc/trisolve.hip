@@ -2802,7 +2802,10 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
         //  it with the stage in four vector registers instead -- no scalar load left in the step, whose LDS waits are waits on
         //  lgkmcnt(0) and so wait for that load too -- was measured: 512 x 512 x 64 slab 3.27 vs 3.34 ms per GMRES iteration,
         //  full cube 60.2 vs 62.1 it/s, FE surrogate 199 vs 200.5: not the step's bottleneck, and the registers cost more
-        //  where the solve is bandwidth-bound; tools/r04_runs/zp.sh)
+        //  where the solve is bandwidth-bound; tools/r04_runs/zp.sh.  Neither does it help to request both of a step's records
+        //  -- this one and the next step's -- in the MIDDLE of the step, behind its LDS reads, so that no scalar load is in
+        //  flight at the step's first LDS wait: slab 3.35 vs 3.33 ms, cube 63.1 vs 63.4 it/s, surrogate 201.4 vs 200.5;
+        //  tools/r04_runs/zx.sh.  The scalar-cache round trips are not what a step waits for.)
         st.g  = g;
         st.tf = tn * 4 + ((cur_fresh ? 1 : 0) | (cur_last ? 2 : 0));
         const int      nl  = (cur.y & 0xff) * LPR; // lane records of the step
