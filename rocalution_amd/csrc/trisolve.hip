@@ -22,6 +22,7 @@
 //     no flags, no fences.
 #include "device_utils.hpp"
 #include "matrix_impl.hpp"
+#include "trsv_lattice.hpp"
 
 #include <type_traits>
 
@@ -712,8 +713,12 @@ struct TriPlan
     bool       ct_in_packed = false, ct_out_packed = false; // the lists in 4 bytes per row (see CtDims)
     bool       prefilled_next = false; // the last run filled the next stage's w with sentinels (run_plan)
     bool       w_sentinel     = false; // w holds sentinels everywhere (the stage that read it as its right-hand side left them)
+    // lattice form (trsv_lattice.hip): the triangle of a 5- / 7-point lattice operator, pencils marched along x; such a plan
+    // has no order / pos / w -- it reads and writes natural-order vectors
+    LatPlan* lat = nullptr;
     void  release()
     {
+        lat_release(&lat);
         dev_free(&ct_tile_step);
         dev_free(&ct_step_pos);
         dev_free(&ct_step_ent);
@@ -5612,6 +5617,28 @@ int ramd_mat_lu_analyse(ramd_mat_t m)
         return RAMD_ERR_UNSUPPORTED;
     TriState* st = nullptr;
     RAMD_TRY(tri_get(m, &st));
+    // both triangles on a lattice: the pencil form, L then U in place on the output vector (no position order, no scratch)
+    {
+        st->L.release();
+        st->U.release();
+        int sl = m->dtype == RAMD_F64 ? lat_build<double>(m, true, true, &st->L.lat) : lat_build<float>(m, true, true, &st->L.lat);
+        if(sl == RAMD_OK)
+            sl = m->dtype == RAMD_F64 ? lat_build<double>(m, false, false, &st->U.lat) : lat_build<float>(m, false, false, &st->U.lat);
+        if(sl == RAMD_OK)
+        {
+            st->L.n = st->U.n = m->nrow;
+            st->haveL = st->haveU = true;
+            dev_free(&st->lu_rhs_idx);
+            dev_free(&st->l_order_cache);
+            dev_free(&st->l_level_cache);
+            m->lu_analysed = true;
+            return RAMD_OK;
+        }
+        st->L.release();
+        st->U.release();
+        if(sl != RAMD_ERR_UNSUPPORTED)
+            return sl;
+    }
     if(m->dtype == RAMD_F64)
     {
         RAMD_TRY(build_plan<double>(m, st, &st->L, true));
@@ -5648,6 +5675,18 @@ int ramd_mat_lu_solve(ramd_mat_t m, ramd_vec_t in, ramd_vec_t out)
     if(!m->lu_analysed)
         RAMD_FAIL(RAMD_ERR_STATE, "LUSolve before LUAnalyse");
     TriState* st = tri_state(m);
+    if(st->L.lat && st->U.lat)
+    {
+        if(!lat_is_unit(st->L.lat) || lat_is_unit(st->U.lat))
+            RAMD_FAIL(RAMD_ERR_STATE, "LUSolve: the plans of LUAnalyse were replaced by LAnalyse / UAnalyse");
+        if(m->dtype == RAMD_F64)
+        {
+            RAMD_TRY(lat_run<double>(st->L.lat, (const double*)in->d, (double*)out->d));
+            return lat_run<double>(st->U.lat, (const double*)out->d, (double*)out->d);
+        }
+        RAMD_TRY(lat_run<float>(st->L.lat, (const float*)in->d, (float*)out->d));
+        return lat_run<float>(st->U.lat, (const float*)out->d, (float*)out->d);
+    }
     if(m->dtype == RAMD_F64)
     {
         // L y = b (unit diagonal), y kept in L-position order inside the plan's scratch
@@ -5669,7 +5708,14 @@ int ramd_mat_l_analyse(ramd_mat_t m, int diag_unit)
         return RAMD_ERR_UNSUPPORTED;
     TriState* st = nullptr;
     RAMD_TRY(tri_get(m, &st));
-    if(m->dtype == RAMD_F64)
+    st->L.release();
+    const int sl = m->dtype == RAMD_F64 ? lat_build<double>(m, true, diag_unit != 0, &st->L.lat)
+                                        : lat_build<float>(m, true, diag_unit != 0, &st->L.lat);
+    if(sl == RAMD_OK)
+        st->L.n = m->nrow;
+    else if(sl != RAMD_ERR_UNSUPPORTED)
+        return sl;
+    else if(m->dtype == RAMD_F64)
         RAMD_TRY(build_plan<double>(m, st, &st->L, true));
     else
         RAMD_TRY(build_plan<float>(m, st, &st->L, true));
@@ -5699,6 +5745,9 @@ int ramd_mat_l_solve(ramd_mat_t m, ramd_vec_t in, ramd_vec_t out)
     if(!m->l_analysed)
         RAMD_FAIL(RAMD_ERR_STATE, "LSolve before LAnalyse");
     TriState* st = tri_state(m);
+    if(st->L.lat)
+        return m->dtype == RAMD_F64 ? lat_run<double>(st->L.lat, (const double*)in->d, (double*)out->d)
+                                    : lat_run<float>(st->L.lat, (const float*)in->d, (float*)out->d);
     if(m->dtype == RAMD_F64)
         return run_plan<double>(st, &st->L, m->l_diag_unit, (const double*)in->d, st->L.order,
                                 (double*)out->d);
@@ -5713,7 +5762,14 @@ int ramd_mat_u_analyse(ramd_mat_t m, int diag_unit)
         return RAMD_ERR_UNSUPPORTED;
     TriState* st = nullptr;
     RAMD_TRY(tri_get(m, &st));
-    if(m->dtype == RAMD_F64)
+    st->U.release();
+    const int sl = m->dtype == RAMD_F64 ? lat_build<double>(m, false, diag_unit != 0, &st->U.lat)
+                                        : lat_build<float>(m, false, diag_unit != 0, &st->U.lat);
+    if(sl == RAMD_OK)
+        st->U.n = m->nrow;
+    else if(sl != RAMD_ERR_UNSUPPORTED)
+        return sl;
+    else if(m->dtype == RAMD_F64)
         RAMD_TRY(build_plan<double>(m, st, &st->U, false));
     else
         RAMD_TRY(build_plan<float>(m, st, &st->U, false));
@@ -5743,6 +5799,9 @@ int ramd_mat_u_solve(ramd_mat_t m, ramd_vec_t in, ramd_vec_t out)
     if(!m->u_analysed)
         RAMD_FAIL(RAMD_ERR_STATE, "USolve before UAnalyse");
     TriState* st = tri_state(m);
+    if(st->U.lat)
+        return m->dtype == RAMD_F64 ? lat_run<double>(st->U.lat, (const double*)in->d, (double*)out->d)
+                                    : lat_run<float>(st->U.lat, (const float*)in->d, (float*)out->d);
     if(m->dtype == RAMD_F64)
         return run_plan<double>(st, &st->U, m->u_diag_unit, (const double*)in->d, st->U.order,
                                 (double*)out->d);
