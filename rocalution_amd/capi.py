@@ -116,6 +116,7 @@ SIGNATURES = {
     "ramd_mat_lu_analyse": (i32, [mat_t]),
     "ramd_mat_lu_analyse_clear": (i32, [mat_t]),
     "ramd_mat_lu_solve": (i32, [mat_t, vec_t, vec_t]),
+    "ramd_tri_plan_stats": (i32, [i32, pi64]),
     "ramd_mat_l_analyse": (i32, [mat_t, i32]),
     "ramd_mat_l_analyse_clear": (i32, [mat_t]),
     "ramd_mat_l_solve": (i32, [mat_t, vec_t, vec_t]),

@@ -716,6 +716,9 @@ struct TriPlan
     // lattice form (trsv_lattice.hip): the triangle of a 5- / 7-point lattice operator, pencils marched along x; such a plan
     // has no order / pos / w -- it reads and writes natural-order vectors
     LatPlan* lat = nullptr;
+    // what the analysis found (ramd_tri_plan_stats): chains, external values of all tiles, box edges
+    int       st_chains = 0, st_box[3] = {0, 0, 0};
+    long long st_ext    = 0;
     void  release()
     {
         lat_release(&lat);
@@ -3881,6 +3884,10 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     CT_HIP(hipGetLastError());
     P->nodiag = nd != 0;
     P->ct     = true;
+    P->nlevels   = nlev;
+    P->st_chains = nchains;
+    P->st_ext    = next;
+    P->st_box[0] = bs[0], P->st_box[1] = bs[1], P->st_box[2] = bs[2];
     build_mark("plan: records");
     if(verbose)
         fprintf(stderr,
@@ -5609,6 +5616,57 @@ int ramd_mat_it_u_solve(ramd_mat_t m, int max_iter, double tol, int use_tol, ram
     return it_solve(m, 4, max_iter, tol, use_tol, in, out);
 }
 
+// statistics of the plans of the most recent LUAnalyse / LAnalyse / UAnalyse of this process (bench.py prints them, so that a run
+// on a matrix nobody here has seen comes back with a diagnosis of its triangular solves, not just a rate)
+static long long g_tri_stats[2][16];
+static void tri_note_stats(const ramd_mat_s* m, const TriPlan* P, int which)
+{
+    long long* o = g_tri_stats[which];
+    for(int i = 0; i < 16; ++i)
+        o[i] = 0;
+    o[1] = m->nrow;
+    if(P->lat)
+    {
+        LatInfo li;
+        lat_info(P->lat, &li);
+        o[0] = 4;
+        o[2] = (long long)li.nx + li.ny + li.nz - 2;
+        o[3] = li.npencil;
+        o[4] = (long long)li.npencil * li.nsteps;
+        o[5] = (long long)(li.face_bytes / val_size(m->dtype));
+        o[6] = 64LL * li.nsteps;
+        o[7] = 3;
+        o[8] = 1;
+        o[9] = li.nx, o[10] = li.ny, o[11] = li.nz;
+        o[12] = (long long)(li.coef_bytes + li.face_bytes);
+        return;
+    }
+    o[0] = !P->ct ? 1 : (P->ct_grp ? 3 : 2);
+    o[2] = P->nlevels;
+    o[7] = P->ct_wmax;
+    if(P->ct)
+    {
+        o[3] = P->ct_ntiles;
+        o[4] = P->ct_nsteps;
+        o[5] = P->st_ext;
+        o[6] = P->ct_dims[0];
+        o[8] = P->ct_grp ? kGrpLPR : (P->ct_wmax > 8 ? 8 : 1);
+        o[9] = P->st_box[0], o[10] = P->st_box[1], o[11] = P->st_box[2];
+        o[13] = P->st_chains;
+        o[14] = P->ct_dims[1];
+        o[15] = P->ct_dims[3];
+    }
+}
+
+int ramd_tri_plan_stats(int which, long long* out16)
+{
+    if(which < 0 || which > 1 || !out16)
+        RAMD_FAIL(RAMD_ERR_ARG, "ramd_tri_plan_stats(which = 0 lower / 1 upper, out[16])");
+    for(int i = 0; i < 16; ++i)
+        out16[i] = g_tri_stats[which][i];
+    return RAMD_OK;
+}
+
 int ramd_mat_lu_analyse(ramd_mat_t m)
 {
     if(!m)
@@ -5632,6 +5690,8 @@ int ramd_mat_lu_analyse(ramd_mat_t m)
             dev_free(&st->l_order_cache);
             dev_free(&st->l_level_cache);
             m->lu_analysed = true;
+            tri_note_stats(m, &st->L, 0);
+            tri_note_stats(m, &st->U, 1);
             return RAMD_OK;
         }
         st->L.release();
@@ -5657,6 +5717,8 @@ int ramd_mat_lu_analyse(ramd_mat_t m)
                            st->U.order, st->L.pos, st->lu_rhs_idx);
     RAMD_HIP(hipGetLastError());
     m->lu_analysed = true;
+    tri_note_stats(m, &st->L, 0);
+    tri_note_stats(m, &st->U, 1);
     return RAMD_OK;
 }
 
@@ -5722,6 +5784,7 @@ int ramd_mat_l_analyse(ramd_mat_t m, int diag_unit)
     st->haveL      = true;
     m->l_analysed  = true;
     m->l_diag_unit = diag_unit != 0;
+    tri_note_stats(m, &st->L, 0);
     return RAMD_OK;
 }
 
@@ -5776,6 +5839,7 @@ int ramd_mat_u_analyse(ramd_mat_t m, int diag_unit)
     st->haveU      = true;
     m->u_analysed  = true;
     m->u_diag_unit = diag_unit != 0;
+    tri_note_stats(m, &st->U, 1);
     return RAMD_OK;
 }
 

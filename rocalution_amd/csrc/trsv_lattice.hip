@@ -76,7 +76,7 @@ struct LatDims
     int nj, nk, npencil; // pencils in y and z
     int nsb; // staging blocks of a pencil: ceil(nx / 16)
     int nbody; // loop bodies (32 steps each) of a pencil: 2 nbody >= nsb + 2
-    int tx; // elements of a face line: 16 nsb
+    int nfb; // face batches (4 columns of both faces = 64 elements) a pencil publishes: columns 0 .. nx + 6
 };
 
 // ---------------------------------------------------------------- detection
@@ -254,6 +254,26 @@ __device__ __forceinline__ float lat_ld_elem(const float* p)
     asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(p) : "memory");
     return r;
 }
+__device__ __forceinline__ double lat_ld_elem_sc1(const double* p)
+{
+    double r;
+    asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+__device__ __forceinline__ float lat_ld_elem_sc1(const float* p)
+{
+    float r;
+    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+__device__ __forceinline__ void lat_st_elem_sc1(double* p, double v)
+{
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lat_st_elem_sc1(float* p, float v)
+{
+    asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
+}
 __device__ __forceinline__ v2f64 lat_ld_pair_sc1(const double* p)
 {
     v2f64 r;
@@ -311,22 +331,61 @@ __device__ __forceinline__ void lat_tie(X& v) // (nothing that reads v may move 
     asm volatile("" : "+v"(v));
 }
 
+// The order in which a loop body (32 steps) issues its vector memory operations.  Before step u:
+//   stage 0  u % 16 == 0: the natural-order stores of block ph - 2                       (IO operations)
+//   stage 1  u % 16 == 0: the natural-order loads of block ph + 1                        (IO)
+//   stage 2  u % 4 == 3:  the publication of face batch (t - 11) / 4                     (1)
+//   stage 3  u % 4 == 0:  the sentinel reset of face batch t / 4, then the poll of batch t / 4 + A / 4   (2)
+// and after step u:
+//   stage 4  u odd: the coefficient loads of step pair u / 2 + D                         (NC)
+// A wait names the operation it needs by (step, stage) and sits in front of a (step, stage); what lies between is counted here.
+template <int NC, int IO>
+struct LatSched
+{
+    static constexpr int ops(int u, int st)
+    {
+        return st == 0 ? (u % 16 == 0 ? IO : 0)
+               : st == 1 ? (u % 16 == 0 ? IO : 0)
+               : st == 2 ? (u % 4 == 3 ? 1 : 0)
+               : st == 3 ? (u % 4 == 0 ? 2 : 0)
+                         : (u % 2 == 1 ? NC : 0);
+    }
+    static constexpr int upto(int u, int st) // operations of the body up to and including stage st of step u
+    {
+        int n = 0;
+        for(int v = 0; v < 32; ++v)
+            for(int t = 0; t < 5; ++t)
+                if(v < u || (v == u && t <= st))
+                    n += ops(v, t);
+        return n;
+    }
+    static constexpr int total = upto(31, 4);
+    // operations issued after the last one of (ut, st) and before stage sw of step uw (ut may be negative: the body before)
+    static constexpr int younger(int ut, int st, int uw, int sw)
+    {
+        const int before_wait = sw == 0 ? (uw == 0 ? 0 : upto(uw - 1, 4)) : upto(uw, sw - 1);
+        const int target      = ut >= 0 ? upto(ut, st) : upto(ut + 32, st) - total;
+        return before_wait - target;
+    }
+};
+
 // NC = 3 (unit diagonal) or 4; D = step pairs the coefficient queue runs ahead (divides 8); W = waves per SIMD the register
-// budget is cut for (2: 256 registers -- the LDS ring allows 7 waves per CU; 1: 512)
+// budget is cut for (2: 256 registers -- the LDS ring allows 7 waves per CU).  W = 1 is NOT an option: beyond 256 registers
+// the compiler parks values in accumulation registers, and a copy of a register whose load is still in flight copies garbage.
 template <typename T, bool LOWER, int NC, bool A16, int D, int W>
 __global__ __launch_bounds__(64, W) void k_trsv_lat(LatDims g, int npair, const int* __restrict__ ptab,
                                                  const typename LatT<T>::V2* __restrict__ coef, const T* in, T* out, T* face,
                                                  const T* __restrict__ zeros, T* __restrict__ dump_all, unsigned* counter,
-                                                 unsigned base)
+                                                 unsigned base, int nodep)
 {
     using V2 = typename LatT<T>::V2;
     using B  = typename LatT<T>::bits;
     static_assert(8 % D == 0, "the queue slot of a step pair has to be a compile-time constant");
-    constexpr bool DIV = NC == 4;
-    // vector memory operations of a block boundary, in issue order: stores of the finished block, the two face
-    // publications, the two sentinel resets, then the loads of the next block and the two face polls
-    constexpr int kOpsIO = A16 ? kLK : 2 * kLK; // natural-order loads (= stores) of a block
-    constexpr int kOpsB  = kOpsIO + 2 + 2 + kOpsIO + 2;
+    static_assert(W == 2, "see above");
+    constexpr bool DIV   = NC == 4;
+    constexpr int  kIO   = A16 ? kLK : 2 * kLK; // natural-order loads (= stores) of a block
+    constexpr int  kPoll = 8; // steps a face batch is polled ahead of its use (a multiple of 4)
+    using Sched          = LatSched<NC, kIO>;
     extern __shared__ __attribute__((aligned(16))) char lat_lds[];
     T*        ring = reinterpret_cast<T*>(lat_lds);
     const int lane = threadIdx.x;
@@ -338,6 +397,11 @@ __global__ __launch_bounds__(64, W) void k_trsv_lat(LatDims g, int npair, const 
     const int a_yn  = cj > 0 ? (lane - 1) * kPitch : (kLines + ck) * kPitch + 1;
     // the staging view: instruction q of a block moves lines (sj, q), the lane takes the element pair sm of its line
     const int sj0 = lane >> 3, sm0 = lane & 7;
+    // the face view: a batch is columns 4 c .. 4 c + 3 of the 8 lines of the y face (lanes 0 - 31) and of the z face (32 - 63),
+    // a column being the step at which the successor's lane (0, k) / (j, 0) uses the value: tau = i + k resp. i + j
+    const int fl = (lane >> 2) & 7, fm = lane & 3;
+    const int a_fin  = (kLines + (lane >> 2)) * kPitch + 1 + fm; // + column: where a polled value goes
+    const int a_fout = (lane < 32 ? (kLJ * fl + kLJ - 1) : (kLJ * (kLK - 1) + fl)) * kPitch + 1 + fm; // + (column + 7): where a face value is
     const B   sent = LatT<T>::sentinel;
     const T*  zsrc = zeros + 2 * lane; // what lanes and phases without data read
     T*        dump = dump_all + (size_t)blockIdx.x * 128 + 2 * lane; // ... and write
@@ -353,7 +417,9 @@ __global__ __launch_bounds__(64, W) void k_trsv_lat(LatDims g, int npair, const 
             break;
         const int  pt = uni(ptab[q]);
         const int  pj = pt & 0xffff, pk = pt >> 16;
-        const bool has_yin = pj > 0, has_zin = pk > 0, has_yout = pj + 1 < g.nj, has_zout = pk + 1 < g.nk;
+        // (nodep: diagnostic runs without the hand-offs -- wrong results, the time of the streams alone)
+        const bool has_yin = pj > 0 && !nodep, has_zin = pk > 0 && !nodep;
+        const bool has_out = (pj + 1 < g.nj || pk + 1 < g.nk) && !nodep;
         const int  sj = sj0, sm = sm0;
         const int  sy  = pj * kLJ + sj; // sweep y of the staging line
         const bool yok = sy < g.ny;
@@ -367,14 +433,15 @@ __global__ __launch_bounds__(64, W) void k_trsv_lat(LatDims g, int npair, const 
             const int gz = LOWER ? sz : g.nz - 1 - sz;
             lineoff[qq]  = (yok && sz < g.nz) ? (gz * g.ny + gy) * g.nx : -1;
         }
-        const T* fy_in  = face + ((size_t)(pk * g.nj + (has_yin ? pj - 1 : 0)) * 2 + 0) * kLJ * g.tx + (size_t)sj * g.tx + 2 * sm;
-        const T* fz_in  = face + ((size_t)((has_zin ? pk - 1 : 0) * g.nj + pj) * 2 + 1) * kLJ * g.tx + (size_t)sj * g.tx + 2 * sm;
-        T*       fy_out = face + ((size_t)(pk * g.nj + pj) * 2 + 0) * kLJ * g.tx + (size_t)sj * g.tx + 2 * sm;
-        T*       fz_out = fy_out + (size_t)kLJ * g.tx;
-        const V2* cpen  = coef + (size_t)q * npair * NC * 64;
+        // face records: [pencil][batch][64]; the y half comes from pencil (pj - 1, pk), the z half from (pj, pk - 1)
+        const bool fvalid = lane < 32 ? has_yin : has_zin;
+        const int  fpen   = lane < 32 ? pk * g.nj + (pj > 0 ? pj - 1 : 0) : (pk > 0 ? pk - 1 : 0) * g.nj + pj;
+        const T*   fin_p  = face + (size_t)fpen * g.nfb * 64 + lane;
+        T*         fout_p = face + (size_t)(pk * g.nj + pj) * g.nfb * 64 + lane;
+        const V2*  cpen   = coef + (size_t)q * npair * NC * 64;
 
-        V2 rin[kLK]; // right-hand side of the next block, in sweep order
-        V2 finy, finz; // polled face values of the next block
+        V2 rin[kLK]; // right-hand side of the next block (memory order)
+        T  fin[kPoll / 4]; // polled face batches
         V2 cq[D][NC];
         T  vprev = (T)0;
 
@@ -400,10 +467,9 @@ __global__ __launch_bounds__(64, W) void k_trsv_lat(LatDims g, int npair, const 
                 }
             }
         };
-        auto poll_faces = [&](int b) __attribute__((always_inline)) { // block b -> finy, finz
-            const bool inb = (unsigned)b < (unsigned)g.nsb;
-            finy           = lat_ld_pair_sc1((has_yin && inb) ? fy_in + kXB * b : zsrc);
-            finz           = lat_ld_pair_sc1((has_zin && inb) ? fz_in + kXB * b : zsrc);
+        auto poll_face = [&](auto slot, int c) __attribute__((always_inline)) { // face batch c -> fin[slot]
+            const bool ok              = fvalid && (unsigned)c < (unsigned)g.nfb;
+            fin[decltype(slot)::value] = lat_ld_elem_sc1(ok ? fin_p + (size_t)c * 64 : zsrc);
         };
         auto load_coef = [&](auto slot, int pair) __attribute__((always_inline)) {
             const int pp = pair < npair ? pair : npair - 1;
@@ -412,11 +478,10 @@ __global__ __launch_bounds__(64, W) void k_trsv_lat(LatDims g, int npair, const 
                 cq[decltype(slot)::value][decltype(c)::value] = lat_ld_coef<decltype(c)::value * 64 * (int)sizeof(V2)>(sb, cvoff);
             });
         };
-        auto is_sent = [&](V2 v) { return LatT<T>::to_bits(v.x) == sent || LatT<T>::to_bits(v.y) == sent; };
 
         // ---- prologue: the first block's loads go out, the ring is zeroed under them, then ONE drain per pencil
         load_rhs(0);
-        poll_faces(0);
+        lat_for<0, kPoll / 4>([&](auto c) __attribute__((always_inline)) { poll_face(c, decltype(c)::value); });
         lat_for<0, D>([&](auto d) __attribute__((always_inline)) { load_coef(d, decltype(d)::value); });
         for(int e = lane; e < kLdsElems; e += 64)
             ring[e] = (T)0; // rows the lattice does not have read +0 from the ring (fill of the skew, column "-1")
@@ -424,137 +489,128 @@ __global__ __launch_bounds__(64, W) void k_trsv_lat(LatDims g, int npair, const 
 
         for(int body = 0; body < g.nbody; ++body)
         {
-            lat_for<0, 2>([&](auto halfc) __attribute__((always_inline)) {
-                constexpr int half = decltype(halfc)::value;
-                const int     ph   = 2 * body + half; // the block whose steps come next
-                // ---- the loads of the previous boundary (right-hand side and faces of block ph) have arrived:
-                //      only the 8 step pairs of coefficient loads are younger
-                lat_wait<8 * NC>();
-#pragma unroll
-                for(int qq = 0; qq < kLK; ++qq)
-                    lat_tie(rin[qq]);
-                lat_tie(finy);
-                lat_tie(finz);
-                // (the staging addresses are recomputed at every boundary from these: hoisted out of the pencil loop they
-                //  would cost ~100 registers, and a spill is a vector memory operation the counts above do not know)
-                int sj = sj0, sm = sm0;
-                asm volatile("" : "+v"(sj), "+v"(sm));
-                const int cl = 2 * sm + sj;
-#pragma unroll
-                for(int qq = 0; qq < kLK; ++qq)
-                    asm volatile("" : "+v"(lineoff[qq]));
-                // ---- results of block ph - 2 leave the ring (every lane is past it since step 14 of block ph - 1)
+            lat_for<0, kRing>([&](auto uc) __attribute__((always_inline)) {
+                constexpr int u = decltype(uc)::value; // column of this step
+                if constexpr(u % kXB == 0)
                 {
-                    const int  b  = ph - 2;
-                    const int  i0 = kXB * b + 2 * sm;
-                    const bool x0 = (unsigned)i0 < (unsigned)g.nx, x1 = (unsigned)(i0 + 1) < (unsigned)g.nx;
-                    T          z0 = (T)0, z1 = (T)0;
+                    constexpr int half = u / kXB;
+                    const int     ph   = 2 * body + half; // the block whose steps come next
+                    // ---- the loads of the previous boundary (right-hand side of block ph) have arrived
+                    lat_wait<Sched::younger(u - kXB, 1, u, 0)>();
+#pragma unroll
+                    for(int qq = 0; qq < kLK; ++qq)
+                        lat_tie(rin[qq]);
+                    // (the staging addresses are recomputed at every boundary from these: hoisted out of the pencil loop they
+                    //  would cost ~100 registers, and a spill is a vector memory operation the counts do not know)
+                    int sj = sj0, sm = sm0;
+                    asm volatile("" : "+v"(sj), "+v"(sm));
+                    const int cl = 2 * sm + sj;
+#pragma unroll
+                    for(int qq = 0; qq < kLK; ++qq)
+                        asm volatile("" : "+v"(lineoff[qq]));
+                    // ---- results of block ph - 2 leave the ring (every lane is past it since step 14 of block ph - 1)
+                    {
+                        const int  i0 = kXB * (ph - 2) + 2 * sm;
+                        const bool x0 = (unsigned)i0 < (unsigned)g.nx, x1 = (unsigned)(i0 + 1) < (unsigned)g.nx;
+#pragma unroll
+                        for(int qq = 0; qq < kLK; ++qq)
+                        {
+                            const int  c0 = (cl + 16 * half + qq) & 31, c1 = (cl + 16 * half + qq + 1) & 31;
+                            const T    r0 = ring[(qq * kLJ + sj) * kPitch + 1 + c0];
+                            const T    r1 = ring[(qq * kLJ + sj) * kPitch + 1 + c1];
+                            const bool lv = lineoff[qq] >= 0;
+                            if(A16)
+                            {
+                                T* p = out + ((size_t)lineoff[qq] + (LOWER ? i0 : g.nx - 2 - i0));
+                                lat_st_pair_nt((lv && x0) ? p : dump, LOWER ? V2{r0, r1} : V2{r1, r0});
+                            }
+                            else
+                            {
+                                T* p0 = out + ((size_t)lineoff[qq] + (LOWER ? i0 : g.nx - 1 - i0));
+                                T* p1 = out + ((size_t)lineoff[qq] + (LOWER ? i0 + 1 : g.nx - 2 - i0));
+                                lat_st_elem_nt((lv && x0) ? p0 : dump, r0);
+                                lat_st_elem_nt((lv && x1) ? p1 : dump + 1, r1);
+                            }
+                        }
+                    }
+                    // ---- the right-hand side of block ph enters; then the requests of block ph + 1
 #pragma unroll
                     for(int qq = 0; qq < kLK; ++qq)
                     {
-                        const int  c0 = (cl + 16 * half + qq) & 31, c1 = (cl + 16 * half + qq + 1) & 31;
-                        const T    r0 = ring[(qq * kLJ + sj) * kPitch + 1 + c0];
-                        const T    r1 = ring[(qq * kLJ + sj) * kPitch + 1 + c1];
-                        const bool lv = lineoff[qq] >= 0;
-                        if(A16)
-                        {
-                            T* p = out + ((size_t)lineoff[qq] + (LOWER ? i0 : g.nx - 2 - i0));
-                            lat_st_pair_nt((lv && x0) ? p : dump, LOWER ? V2{r0, r1} : V2{r1, r0});
-                        }
-                        else
-                        {
-                            T* p0 = out + ((size_t)lineoff[qq] + (LOWER ? i0 : g.nx - 1 - i0));
-                            T* p1 = out + ((size_t)lineoff[qq] + (LOWER ? i0 + 1 : g.nx - 2 - i0));
-                            lat_st_elem_nt((lv && x0) ? p0 : dump, r0);
-                            lat_st_elem_nt((lv && x1) ? p1 : dump + 1, r1);
-                        }
-                        if(qq == kLK - 1) // lines (sj, 7): the z face
-                        {
-                            z0 = x0 ? r0 : (T)0;
-                            z1 = x1 ? r1 : (T)0;
-                        }
+                        const int c0 = (cl + 16 * half + qq) & 31, c1 = (cl + 16 * half + qq + 1) & 31;
+                        const V2  v  = (LOWER || !A16) ? rin[qq] : V2{rin[qq].y, rin[qq].x};
+                        ring[(qq * kLJ + sj) * kPitch + 1 + c0] = v.x;
+                        ring[(qq * kLJ + sj) * kPitch + 1 + c1] = v.y;
                     }
-                    const int  c0 = (cl + 16 * half + 7) & 31, c1 = (cl + 16 * half + 8) & 31; // lines (7, sj): the y face
-                    const T    y0 = ring[(sj * kLJ + 7) * kPitch + 1 + c0];
-                    const T    y1 = ring[(sj * kLJ + 7) * kPitch + 1 + c1];
-                    const bool inb = (unsigned)b < (unsigned)g.nsb;
-                    lat_st_pair_sc1((has_yout && inb) ? fy_out + kXB * b : dump, V2{x0 ? y0 : (T)0, x1 ? y1 : (T)0});
-                    lat_st_pair_sc1((has_zout && inb) ? fz_out + kXB * b : dump, V2{z0, z1});
+                    load_rhs(ph + 1);
                 }
-                // ---- block ph enters: faces of the predecessors (polled a block ago; again until they are there) ...
+                if constexpr(u % 4 == 3)
                 {
-                    int spins = 0, backoff = 1;
-                    while(__any(is_sent(finy) || is_sent(finz)))
-                    {
-                        spin_guard(spins);
-                        backoff = poll_backoff(false, backoff, 8);
-                        poll_faces(ph);
-                        lat_wait<0>();
-                        lat_tie(finy);
-                        lat_tie(finz);
-                    }
-                    const bool inb = (unsigned)ph < (unsigned)g.nsb;
-                    const V2   sv  = {LatT<T>::from_bits(sent), LatT<T>::from_bits(sent)};
-                    lat_st_pair_sc1((has_yin && inb) ? const_cast<T*>(fy_in) + kXB * ph : dump, sv); // the sentinel goes back
-                    lat_st_pair_sc1((has_zin && inb) ? const_cast<T*>(fz_in) + kXB * ph : dump, sv); // behind the read
-                    const int c0 = (cl + 16 * half) & 31, c1 = (cl + 16 * half + 1) & 31;
-                    ring[(kLines + sj) * kPitch + 1 + c0]       = finy.x;
-                    ring[(kLines + sj) * kPitch + 1 + c1]       = finy.y;
-                    ring[(kLines + kLK + sj) * kPitch + 1 + c0] = finz.x;
-                    ring[(kLines + kLK + sj) * kPitch + 1 + c1] = finz.y;
+                    // ---- face batch (t - 11) / 4 is complete: its last column was written by lanes (7, .) / (., 7) at step u - 1
+                    const int  c  = 8 * body + (u - 11) / 4; // (u - 11 is a multiple of 4)
+                    const T    v  = ring[a_fout + (u - 4)];
+                    const bool ok = has_out && (unsigned)c < (unsigned)g.nfb;
+                    lat_st_elem_sc1(ok ? fout_p + (size_t)c * 64 : dump, v);
                 }
-                // ---- ... and its right-hand side; then the requests of block ph + 1
-#pragma unroll
-                for(int qq = 0; qq < kLK; ++qq)
+                if constexpr(u % 4 == 0)
                 {
-                    const int c0 = (cl + 16 * half + qq) & 31, c1 = (cl + 16 * half + qq + 1) & 31;
-                    const V2  v  = (LOWER || !A16) ? rin[qq] : V2{rin[qq].y, rin[qq].x};
-                    ring[(qq * kLJ + sj) * kPitch + 1 + c0] = v.x;
-                    ring[(qq * kLJ + sj) * kPitch + 1 + c1] = v.y;
+                    // ---- face batch t / 4 of the predecessors, polled kPoll steps ago (and again until it is there)
+                    constexpr int slot = (u / 4) % (kPoll / 4);
+                    const int     c    = 8 * body + u / 4;
+                    lat_wait<Sched::younger(u - kPoll, 3, u, 3)>();
+                    lat_tie(fin[slot]);
+                    if(__any(LatT<T>::to_bits(fin[slot]) == sent))
+                    {
+                        int spins = 0, backoff = 1;
+                        do
+                        {
+                            spin_guard(spins);
+                            backoff = poll_backoff(false, backoff, 4);
+                            poll_face(std::integral_constant<int, slot>{}, c);
+                            lat_wait<0>();
+                            lat_tie(fin[slot]);
+                        } while(__any(LatT<T>::to_bits(fin[slot]) == sent));
+                    }
+                    ring[a_fin + u] = fin[slot];
+                    const bool ok   = fvalid && (unsigned)c < (unsigned)g.nfb;
+                    lat_st_elem_sc1(ok ? const_cast<T*>(fin_p) + (size_t)c * 64 : dump, LatT<T>::from_bits(sent)); // the sentinel goes back behind the read
+                    poll_face(std::integral_constant<int, slot>{}, c + kPoll / 4);
                 }
-                load_rhs(ph + 1);
-                poll_faces(ph + 1);
-                // ---- 16 steps
-                lat_for<0, kXB>([&](auto uuc) __attribute__((always_inline)) {
-                    constexpr int u = kXB * half + decltype(uuc)::value; // column of this step
-                    constexpr int p = u >> 1, e = u & 1; // step pair inside the body, element of the pair
-                    constexpr int slot = p % D;
-                    if constexpr(e == 0)
-                    {
-                        // this pair's coefficients were requested D pairs ago: D - 1 pairs of loads are younger, and the block
-                        // boundary's operations where one lies in between
-                        constexpr bool crossed = (p % 8) < D;
-                        lat_wait<(D - 1) * NC + (crossed ? kOpsB : 0)>();
-                        lat_for<0, NC>([&](auto c) __attribute__((always_inline)) { lat_tie(cq[slot][decltype(c)::value]); });
-                    }
-                    const T b  = ring[a_own + u];
-                    const T vz = ring[a_zn + u];
-                    const T vy = ring[a_yn + u];
-                    T       acc;
-                    if(LOWER)
-                    {
-                        acc = b - (e ? cq[slot][0].y : cq[slot][0].x) * vz;
-                        acc = acc - (e ? cq[slot][1].y : cq[slot][1].x) * vy;
-                        acc = acc - (e ? cq[slot][2].y : cq[slot][2].x) * vprev;
-                    }
-                    else
-                    {
-                        acc = b - (e ? cq[slot][0].y : cq[slot][0].x) * vprev;
-                        acc = acc - (e ? cq[slot][1].y : cq[slot][1].x) * vy;
-                        acc = acc - (e ? cq[slot][2].y : cq[slot][2].x) * vz;
-                    }
-                    if(DIV)
-                        acc = acc / (e ? cq[slot][NC - 1].y : cq[slot][NC - 1].x);
-                    vprev           = acc;
-                    ring[a_own + u] = acc;
-                    if(u == kRing - 1)
-                        ring[a_own - 1] = acc;
-                    if constexpr(e == 1)
-                    {
-                        load_coef(std::integral_constant<int, slot>{}, body * 16 + p + D);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                });
+                constexpr int p = u >> 1, e = u & 1; // step pair inside the body, element of the pair
+                constexpr int slot = p % D;
+                if constexpr(e == 0)
+                {
+                    // this pair's coefficients were requested D pairs ago
+                    lat_wait<Sched::younger(u - 2 * D + 1, 4, u, 4)>();
+                    lat_for<0, NC>([&](auto c) __attribute__((always_inline)) { lat_tie(cq[slot][decltype(c)::value]); });
+                }
+                const T b  = ring[a_own + u];
+                const T vz = ring[a_zn + u];
+                const T vy = ring[a_yn + u];
+                T       acc;
+                if(LOWER)
+                {
+                    acc = b - (e ? cq[slot][0].y : cq[slot][0].x) * vz;
+                    acc = acc - (e ? cq[slot][1].y : cq[slot][1].x) * vy;
+                    acc = acc - (e ? cq[slot][2].y : cq[slot][2].x) * vprev;
+                }
+                else
+                {
+                    acc = b - (e ? cq[slot][0].y : cq[slot][0].x) * vprev;
+                    acc = acc - (e ? cq[slot][1].y : cq[slot][1].x) * vy;
+                    acc = acc - (e ? cq[slot][2].y : cq[slot][2].x) * vz;
+                }
+                if(DIV)
+                    acc = acc / (e ? cq[slot][NC - 1].y : cq[slot][NC - 1].x);
+                vprev           = acc;
+                ring[a_own + u] = acc;
+                if(u == kRing - 1)
+                    ring[a_own - 1] = acc;
+                if constexpr(e == 1)
+                {
+                    load_coef(std::integral_constant<int, slot>{}, body * 16 + p + D);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             });
         }
         lat_wait<0>(); // (the registers of the last requests are reused by the next pencil)
@@ -687,7 +743,7 @@ int lat_build(const ramd_mat_s* m, bool lower, bool unit, LatPlan** out)
     g.npencil = g.nj * g.nk;
     g.nsb     = (nx + kXB - 1) / kXB;
     g.nbody   = (g.nsb + 2 + 1) / 2;
-    g.tx      = kXB * g.nsb;
+    g.nfb     = (nx + 6) / 4 + 1;
     P->npair  = 16 * g.nbody;
     if(g.nj > 0xffff || g.nk > 0x7fff)
     {
@@ -712,7 +768,7 @@ int lat_build(const ramd_mat_s* m, bool lower, bool unit, LatPlan** out)
        || hipStreamSynchronize(b.cur) != hipSuccess)
         return bail(RAMD_ERR_HIP);
     P->coef_bytes = (size_t)g.npencil * P->npair * P->nc * 128 * sizeof(T);
-    P->face_bytes = (size_t)g.npencil * 2 * kLJ * g.tx * sizeof(T);
+    P->face_bytes = (size_t)g.npencil * g.nfb * 64 * sizeof(T);
     if(cached_malloc(&P->coef, P->coef_bytes + kPad) != hipSuccess || cached_malloc(&P->face, P->face_bytes + kPad) != hipSuccess)
         return bail(RAMD_ERR_HIP);
     if(dev_alloc(&P->counter, 4) != RAMD_OK || hipMemsetAsync(P->counter, 0, 16, b.cur) != hipSuccess)
@@ -752,6 +808,7 @@ int lat_run(LatPlan* P, const T* in, T* out)
     const bool    a16 = (g.nx % 2 == 0) && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % (2 * sizeof(T)) == 0);
     using V2          = typename LatT<T>::V2;
     unsigned nwg      = 0;
+    static const int nodep = getenv("RAMD_LAT_NODEP") ? atoi(getenv("RAMD_LAT_NODEP")) : 0; // (tools/: timing without hand-offs)
 #define LAT_GO(LO, NCV, A, DV, WV)                                                                                           \
     do                                                                                                                     \
     {                                                                                                                      \
@@ -761,7 +818,10 @@ int lat_run(LatPlan* P, const T* in, T* out)
             int nb_cu = 0;                                                                                                 \
             RAMD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_cu, k_trsv_lat<T, LO, NCV, A, DV, WV>, 64, lds));         \
             occ = nb_cu < 1 ? 1 : nb_cu;                                                                                   \
-            static const int occ_env = getenv("RAMD_LAT_WGS_PER_CU") ? atoi(getenv("RAMD_LAT_WGS_PER_CU")) : 0;            \
+            /* two pencils per CU: measured at 512^3 (LUSolve, ms) 1 / 2 / 3 / 4 / 5 / 7 per CU: 2.74 / 2.38 / 2.49 / 2.53 / 2.65 / \
+               2.78 -- 512 waves with their queues move what the memory system delivers, and every further wave only slows the   \
+               steps of the pencils the others wait for (256^3: 0.57 / 0.56 / 0.60 / 0.65 / 0.65; gpurun_out/r05d.log) */        \
+            static const int occ_env = getenv("RAMD_LAT_WGS_PER_CU") ? atoi(getenv("RAMD_LAT_WGS_PER_CU")) : 2;            \
             if(occ_env > 0 && occ_env < occ)                                                                               \
                 occ = occ_env;                                                                                             \
         }                                                                                                                  \
@@ -770,15 +830,15 @@ int lat_run(LatPlan* P, const T* in, T* out)
         nwg         = (unsigned)(g.npencil < cap ? g.npencil : cap);                                                       \
         hipLaunchKernelGGL((k_trsv_lat<T, LO, NCV, A, DV, WV>), dim3(nwg), dim3(64), lds, b.cur, g, P->npair, P->ptab,          \
                            (const V2*)P->coef, in, out, (T*)P->face, (const T*)P->zeros, (T*)P->dump, P->counter,          \
-                           P->ticket);                                                                                     \
+                           P->ticket, nodep);                                                                              \
     } while(0)
 #define LAT_GO_A(LO, NCV)           \
     do                              \
     {                               \
         if(a16)                     \
-            LAT_GO(LO, NCV, true, (NCV == 3 ? 4 : 2), 2);  \
+            LAT_GO(LO, NCV, true, 4, 2);  \
         else                        \
-            LAT_GO(LO, NCV, false, (NCV == 3 ? 4 : 2), 2); \
+            LAT_GO(LO, NCV, false, 4, 2); \
     } while(0)
     prof_begin(RAMD_PROF_TRSV, b.cur);
     if(P->lower)

@@ -455,3 +455,38 @@ __global__ __launch_bounds__(kBlock) void k_probe_reduce(int64_t n, const double
     assert any(l.startswith("global_load_dwordx2") and l.endswith("sc1") for l in ops[inv[0]:]), ops
     # ... and nowhere a release fence (write-back of the XCD L2) per workgroup
     assert not any(l.startswith("buffer_wbl2") for l in ops), ops
+
+
+# ------------------------------------------------------------------ the hand-counted waits of the lattice triangular solve
+def test_lattice_solve_kernels_have_no_memory_operation_the_counts_do_not_know(tmp_path):
+    """k_trsv_lat (csrc/trsv_lattice.hip) issues every vector memory operation of its pencil loop by hand and waits for loads by
+    COUNTING the operations issued since (LatSched computes the counts at compile time).  That is valid only while the compiler
+    adds no vector memory operation of its own inside the loop -- a register spill to scratch -- and never copies a register
+    whose load is still in flight (values parked in accumulation registers above 256 VGPRs did exactly that: NaNs).  The file
+    is compiled for gfx950 with the library's flags and every instantiation checked: no scratch, no spills, no v_accvgpr
+    moves, at most 256 VGPRs; and the waits in front of the steps are the counts the schedule model predicts, not drains."""
+    import re
+    hipcc = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    out = tmp_path / "lat.s"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "rocalution_amd", "csrc"),
+           "--cuda-device-only", "-S", os.path.join(ROOT, "rocalution_amd", "csrc", "trsv_lattice.hip"), "-o", str(out)]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:]
+    text = out.read_text()
+    meta = text[text.index("amdhsa.kernels:"):]
+    kern = re.findall(r"\.name:\s+(\S*k_trsv_lat\S*).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+)\s+\.vgpr_spill_count:\s+(\d+)",
+                      meta, flags=re.S)
+    assert len(kern) == 16, [k[0] for k in kern]  # {fp64, fp32} x {lower, upper} x {unit, divide} x {16-byte, 8-byte staging}
+    for name, scratch, vgpr, spill in kern:
+        assert int(scratch) == 0 and int(spill) == 0 and int(vgpr) <= 256, (name, scratch, vgpr, spill)
+    for name, _, _, _ in kern:
+        start = text.index("\n" + name + ":")
+        body = text[start:text.index("s_endpgm", start)]
+        assert "v_accvgpr" not in body and "scratch_" not in body and "buffer_store" not in body, name
+        waits = [int(w) for w in re.findall(r"s_waitcnt vmcnt\((\d+)\)", body)]
+        # drains: the prologue / epilogue of a pencil and the re-poll loops of the 8 face batches of a loop body, nothing else
+        assert sum(1 for w in waits if w == 0) <= 2 + 8 + 2, (name, waits)
+        assert sum(1 for w in waits if w > 0) >= 16 + 2 + 8, (name, waits)
