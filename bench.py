@@ -46,6 +46,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_GBPS = 6300.0  # ... and what a device-wide copy achieves there ("~6.3 TB/s"): the practical ceiling of a stream
 
 PROF_SPMV, PROF_TRSV, PROF_HALO, PROF_HALO_WAIT, PROF_ALLREDUCE, PROF_VEC, PROF_PRECOND = range(7)
 
@@ -249,16 +250,55 @@ def prof_get(lib, capi, ch):
 
 
 def roof(name, bytes_alg, p, traffic=None):
+    """frac = ALGORITHMIC bytes (the reference's accounting of the operation) / time / peak.  A kernel that rebuilds its column
+    indices from a dictionary, or a triangular solve that needs none, moves fewer bytes than that: `moved_frac` is what the
+    memory system really delivered (PMC traffic of the same launch, measured offline: profiles/) over the same time and peak,
+    `achievable_frac` prices the algorithmic rate against the guide's copy figure instead of the 8 TB/s of the data sheet"""
     ach = bytes_alg / (p["avg_ms"] * 1e-3) / 1e9 if p["avg_ms"] > 0 else 0.0
-    return dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4),
-                traffic=traffic, kernel=name, launches=p["launches"], avg_ms=round(p["avg_ms"], 5),
-                min_ms=round(p["min_ms"], 5), max_ms=round(p["max_ms"], 5), algorithmic_bytes=int(bytes_alg))
+    r = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4),
+             traffic=traffic, kernel=name, launches=p["launches"], avg_ms=round(p["avg_ms"], 5),
+             min_ms=round(p["min_ms"], 5), max_ms=round(p["max_ms"], 5), algorithmic_bytes=int(bytes_alg),
+             achievable_frac=round(ach / HBM_COPY_GBPS, 4))
+    if traffic and p["avg_ms"] > 0:
+        moved = traffic / (p["avg_ms"] * 1e-3) / 1e9
+        r["moved_GBps"] = round(moved, 1)
+        r["moved_frac"] = round(moved / HBM_PEAK_GBPS, 4)
+        r["traffic_over_algorithmic"] = round(traffic / bytes_alg, 4)
+    return r
+
+
+TRI_FORMS = {0: "none", 1: "level-scheduled rows (k_trsv)", 2: "box tiles, record form (k_trsv_rec)",
+             3: "box tiles with row groups (k_trsv_rec, grouped)", 4: "lattice pencils (k_trsv_lat)"}
+
+
+def tri_plan_stats(lib, capi):
+    """what the last LUAnalyse / LAnalyse / UAnalyse of this process built (ramd_tri_plan_stats): so that a run on a matrix
+    nobody here has seen (--mtx af_shell10.mtx) comes back with a diagnosis of its triangular solves, not just a rate"""
+    out = {}
+    for which, name in ((0, "lower"), (1, "upper")):
+        st = (C.c_int64 * 16)()
+        capi.check(lib.ramd_tri_plan_stats(which, st))
+        if st[0] == 0:
+            continue
+        d = dict(form=TRI_FORMS.get(int(st[0]), str(st[0])), rows=int(st[1]), dependency_levels=int(st[2]),
+                 tiles=int(st[3]), steps=int(st[4]), values_handed_between_tiles=int(st[5]), max_rows_per_tile=int(st[6]),
+                 longest_row=int(st[7]), lanes_per_row=int(st[8]))
+        if st[0] == 4:
+            d["lattice"] = [int(st[9]), int(st[10]), int(st[11])]
+            d["plan_bytes"] = int(st[12])
+        elif st[0] in (2, 3):
+            d["box"] = [int(st[9]), int(st[10]), int(st[11])]
+            d["chains"] = int(st[13])
+            d["max_steps_per_tile"] = int(st[14])
+            d["max_external_values_per_tile"] = int(st[15])
+        out[name] = d
+    return out
 
 
 def traffic_for(key):
     """HBM bytes per launch from the PMC counters: measured offline with rocprofv3 in separate --pmc passes
     (tools/pmc_passes.sh) and committed under profiles/; bench.py does not run the profiler"""
-    for f in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for f in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         p = os.path.join(ROOT, "profiles", f)
         if os.path.exists(p):
             d = json.load(open(p))
@@ -382,6 +422,7 @@ def main():
     label = SOLVER_LABEL[args.solver] + "+" + PRECOND_LABEL[args.precond]
 
     prof = None
+    tri_plan = None
     kernels = {}
     extras = {}
     ingest = None
@@ -543,14 +584,17 @@ def main():
             nnz_fmt = 7 * n if args.matrix == "poisson" else nnz
             b_spmv = vb * (2 * n + nnz_fmt) if args.format == "dia" else 4 * nnz_fmt + vb * (2 * n + nnz_fmt)
             k_spmv = "k_%s<%s>" % ("dia" if args.format == "dia" else "ell", "float" if mixed else "double")
-        tkey = "spmv_csr_512" if (args.matrix == "poisson" and N == 512 and args.format == "csr" and not mixed) else None
+        tkey = None
+        if args.matrix == "poisson" and N == 512 and args.format in ("csr", "ell"):
+            tkey = "spmv_%s_512%s" % (args.format, "_fp32" if mixed else "")
         if args.matrix == "shell" and args.format == "csr" and not mixed:
             tkey = "spmv_csr_shell"
         r_spmv = roof(k_spmv, b_spmv, p_spmv, traffic_for(tkey) if tkey else None)
         if tri_pc and p_trsv["launches"] > 0:
             tk = "trsv_512" if (args.matrix == "poisson" and N == 512) else ("trsv_shell" if args.matrix == "shell" else None)
-            prof = roof("sparse triangular solve (k_trsv_rec: record-form box tiles; k_trsv where a matrix has no chains), one launch per triangle", trsv_bytes(n, nnz, vb), p_trsv,
-                        traffic_for(tk) if tk else None)
+            tri_plan = tri_plan_stats(lib, capi)
+            prof = roof("sparse triangular solve, one launch per triangle: %s" % (tri_plan.get("lower", {}).get("form", "?")),
+                        trsv_bytes(n, nnz, vb), p_trsv, traffic_for(tk) if tk else None)
             kernels["spmv"] = r_spmv
         else:
             prof = r_spmv
@@ -583,13 +627,13 @@ def main():
                                             traffic_for("mcsgs_512") if (args.matrix == "poisson" and N == 512 and not mixed) else None)
         st_pat = C.c_int(0)
         capi.check(lib.ramd_mat_pattern_info(A._h, C.byref(st_pat), None, None))
-        if st_pat.value in (1, 2) and not mixed and args.format in ("csr", "ell", "hyb"):
+        if st_pat.value in (1, 2) and args.format in ("csr", "ell", "hyb"):
             # the SAME run with the columns read (the general path every unstructured matrix takes): its own timed
             # K iterations and its own HIP-event average; the row-pattern figure above stays the headline
             A.UseRowPatterns(False)
-            d3, i3, _, _, pr3 = run(K, HEAD, HPC, basis, warm=W, prof_iters=min(K, 200))
+            d3, i3, _, _, pr3 = run(K, HEAD, HPC, basis, warm=W, prof_iters=(min(K, 20) if mixed else min(K, 200)))
             A.UseRowPatterns(True)
-            ck = "spmv_csr_512_columns_read" if tkey == "spmv_csr_512" else None
+            ck = tkey + "_columns_read" if (tkey and tkey.endswith(("_512", "_512_fp32"))) else None
             cols_read = dict(iters_per_s=round(i3 / d3, 3), ms_per_step=round(d3 / i3 * 1e3, 5),
                              roofline=roof(k_spmv.split(" (")[0] + " with the stored columns read (ramd_mat_pattern_use(m, 0))",
                                            b_spmv, pr3[PROF_SPMV], traffic_for(ck) if ck else None))
@@ -605,8 +649,10 @@ def main():
                     # first-class evidence: the dominant kernel of the leg with its own HIP-event average
                     big = (args.matrix == "poisson" and N == 512)
                     if name == "gmres30_ilu0" and pe[PROF_TRSV]["launches"] > 0:
-                        extras[name]["roofline"] = roof("sparse triangular solve (k_trsv_rec), one launch per triangle",
+                        tp = tri_plan_stats(lib, capi)
+                        extras[name]["roofline"] = roof("sparse triangular solve, one launch per triangle: %s" % tp.get("lower", {}).get("form", "?"),
                                                         trsv_bytes(n, nnz, 8), pe[PROF_TRSV], traffic_for("trsv_512") if big else None)
+                        extras[name]["tri_plan"] = tp
                     if name == "bicgstab_mcsgs" and pe[PROF_PRECOND]["launches"] > 0:
                         extras[name]["roofline"] = roof("multi-coloured SGS apply (k_mc_sweep: all colour sweeps of one apply)",
                                                         mcsgs_bytes(n, nnz, 8), pe[PROF_PRECOND], traffic_for("mcsgs_512") if big else None)
@@ -754,6 +800,8 @@ def main():
         if prof is not None and "spmv_GBps" not in out and world == 1:
             out["spmv_GBps"] = prof["achieved"]
         out.update(scaling_fields)
+        if tri_plan:
+            out["tri_plan"] = tri_plan
         if ingest:
             out["ingest"] = ingest
         if extras:

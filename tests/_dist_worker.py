@@ -405,8 +405,73 @@ def amg_matrix(kind):
     raise ValueError(kind)
 
 
+def slab8_worker(rank, world, initfile, kind, outdir):
+    """BASELINE.json configs 4 / 5 as they are specified -- "row-split across 8 x MI355X": `world` processes on ONE device over
+    the host-staged transport, every rank a z-slab of the Poisson operator (clients/include/common.hpp:92-113 partition rule,
+    choreography of src/base/global_matrix.cpp:924-1009).  kind = "<what>:<N>"."""
+    from rocalution_amd import capi, distributed as D
+    import rocalution_amd as ra
+    what, N = kind.split(":")
+    N = int(N)
+    dist = _init(rank, world, initfile)
+    ra.init_rocalution(0)
+    comm = D.make_callback_comm(rank, world, dist)
+    z0, z1 = (N * rank) // world, (N * (rank + 1)) // world
+    lo, hi = z0 * N * N, z1 * N * N
+    out = dict(lo=lo, hi=hi)
+    if what == "apply":
+        g = D.DistributedSolver(comm, capi.SOLVER_CG, capi.PC_JACOBI)
+        g.setup_poisson(N, z0, z1)
+        y1 = g.apply(np.ones(hi - lo))
+        idx = np.arange(lo, hi, dtype=np.int64)
+        xv = ((idx * 7 + (idx // N) * 3 + (idx // (N * N)) * 5) % 17 - 8).astype(np.float64)  # small integers: every sum exact
+        y2 = g.apply(xv)
+        for fmt in (ra.ELL, ra.HYB):
+            g.convert(fmt)
+            assert np.array_equal(g.apply(xv), y2)
+            g.convert(ra.CSR)
+        # closed form on this slab: 6 x - the neighbours that exist (the halo planes come from the neighbouring ranks)
+        k = np.arange(z0, z1)[:, None, None]; j = np.arange(N)[None, :, None]; i = np.arange(N)[None, None, :]
+
+        def xval(ii, jj, kk):
+            r = (kk * N + jj) * N + ii
+            return ((r * 7 + (r // N) * 3 + (r // (N * N)) * 5) % 17 - 8).astype(np.float64)
+        ref2 = 6.0 * xval(i, j, k)
+        nb = np.zeros((z1 - z0, N, N))
+        for (di, dj, dk) in ((1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)):
+            ii, jj, kk = i + di, j + dj, k + dk
+            ok = (ii >= 0) & (ii < N) & (jj >= 0) & (jj < N) & (kk >= 0) & (kk < N)
+            v = xval(np.clip(ii, 0, N - 1), np.clip(jj, 0, N - 1), np.clip(kk, 0, N - 1))
+            ref2 = ref2 - np.where(ok, v, 0.0)
+            nb = nb + ok
+        out["apply_ones_ok"] = bool(np.array_equal(y1, (6.0 - nb).ravel()))
+        out["apply_x_ok"] = bool(np.array_equal(y2, np.broadcast_to(ref2, (z1 - z0, N, N)).ravel()))
+    else:
+        sk, pk, fmt, mixed = {"c4": (capi.SOLVER_BICGSTAB, capi.PC_MCSGS, ra.ELL, False),
+                              "c4hyb": (capi.SOLVER_BICGSTAB, capi.PC_MCSGS, ra.HYB, False),
+                              "c5": (capi.SOLVER_CG, capi.PC_JACOBI, ra.CSR, True),
+                              "gmres": (capi.SOLVER_GMRES, capi.PC_ILU0, ra.CSR, False)}[what]
+        g = D.DistributedSolver(comm, sk, pk, mixed=mixed)
+        g.setup_poisson(N, z0, z1)
+        g.init(1e-15, 1e-6, 1e8, 5000 if not mixed else 100)
+        if mixed:
+            g.init_inner(1e-5, 1e-2, 1e20, 100000)
+        g.build()
+        if fmt != ra.CSR:
+            g.convert(fmt)
+        xs = g.solve(None, np.zeros(hi - lo))
+        it, st, res = g.result()
+        out.update(it=it, st=st, res=res, err2=float(((xs - 1.0) ** 2).sum()), xmin=float(xs.min()), xmax=float(xs.max()))
+    np.savez(os.path.join(outdir, "r%d.npz" % rank), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 if __name__ == "__main__":
     mode, rank, world, initfile, kind, outdir = sys.argv[1:7]
+    if mode == "slab8":
+        slab8_worker(int(rank), int(world), initfile, kind, outdir)
+        sys.exit(0)
     if mode in ("amg", "amg_rccl"):
         amg_worker(int(rank), int(world), initfile, kind, outdir, rccl=(mode == "amg_rccl"))
     elif mode == "cpu":
