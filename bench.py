@@ -286,6 +286,11 @@ def tri_plan_stats(lib, capi):
         if st[0] == 4:
             d["lattice"] = [int(st[9]), int(st[10]), int(st[11])]
             d["plan_bytes"] = int(st[12])
+        elif st[0] == 1:
+            d["why_not_box_tiles"] = {0: "", 1: "no chains of consecutively numbered dependent rows (mean chain length < 8): the tile coordinates of "
+                                         "the box-tile form are built on such chains", 2: "no dependencies", 3: "triangular rows longer than 32 "
+                                         "entries that do not form row groups", 4: "tile key range", 5: "entry index range",
+                                      6: "the tiles cannot be made to fit the LDS", 7: "too few rows", 8: "switched off"}.get(int(st[12]), str(st[12]))
         elif st[0] in (2, 3):
             d["box"] = [int(st[9]), int(st[10]), int(st[11])]
             d["chains"] = int(st[13])
@@ -322,6 +327,10 @@ def main():
                          "reference's ReadFileMTX semantics (host_io.cpp:135-276); implies --matrix file")
     ap.add_argument("--grid", type=int, default=512, help="Poisson grid edge N (operator is N^3 x N^3)")
     ap.add_argument("--shell-nx", type=int, default=549, help="shell surrogate: nx x nx mesh nodes, 5 unknowns each")
+    ap.add_argument("--shell-variant", default="lex", choices=["lex", "rcm", "delaunay", "random"],
+                    help="node numbering of the config-3-class operator (generators.shell_variant): lex = the surrogate; rcm = the "
+                         "same mesh in reverse Cuthill-McKee order; delaunay = a jittered-point triangulation in RCM order; "
+                         "random = a random node permutation")
     ap.add_argument("--format", default="csr", choices=["csr", "ell", "hyb", "dia"])
     ap.add_argument("--cpu-grid", type=int, default=None, help="Poisson grid of the CPU baseline sample (default: --grid)")
     ap.add_argument("--cpu-iters", type=int, default=None)
@@ -436,9 +445,9 @@ def main():
         if args.matrix == "shell":
             from rocalution_amd import generators as gen
             t0 = time.perf_counter()
-            rp_h, ci_h, va_h = gen.shell_surrogate(args.shell_nx)
+            rp_h, ci_h, va_h = gen.shell_variant(args.shell_nx, args.shell_variant)
             t_gen = time.perf_counter() - t0
-            mtx_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "ramd_shell_%d.mtx" % args.shell_nx)
+            mtx_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "ramd_shell_%d_%s.mtx" % (args.shell_nx, args.shell_variant))
             mtx_generated = True
             t0 = time.perf_counter()
             stored = gen.write_mtx_symmetric(mtx_path, rp_h, ci_h, va_h)
@@ -453,8 +462,8 @@ def main():
             assert (A.GetM(), A.GetNnz()) == (n, nnz)
             regen = lambda: A.ReadFileMTX(mtx_path)
             wl = ("af_shell10-class surrogate (SuiteSparse af_shell10 itself is not available offline): %d x %d mesh nodes x 5 "
-                  "unknowns, n=%d, nnz=%d (%.2f per row; af_shell10: n=1508065, nnz=52259885), SPD, read from a MatrixMarket "
-                  "symmetric file" % (args.shell_nx, args.shell_nx, n, nnz, nnz / n))
+                  "unknowns, node numbering '%s', n=%d, nnz=%d (%.2f per row; af_shell10: n=1508065, nnz=52259885), SPD, read from a "
+                  "MatrixMarket symmetric file" % (args.shell_nx, args.shell_nx, args.shell_variant, n, nnz, nnz / n))
         elif args.matrix == "file":
             mtx_path = os.path.abspath(args.mtx)
             t0 = time.perf_counter()

@@ -231,7 +231,9 @@ int ramd_mat_lu_solve(ramd_mat_t m, ramd_vec_t in, ramd_vec_t out); /* :349 */
  * hook, no reference counterpart; which = 0 lower, 1 upper).  out[0] form: 1 level-scheduled rows, 2 box tiles in record
  * form, 3 box tiles with row groups, 4 lattice pencils; [1] rows; [2] dependency levels; [3] tiles / pencils; [4] steps of all
  * tiles; [5] values handed from tile to tile per solve; [6] most rows of a tile; [7] longest triangular row; [8] lanes per row;
- * [9..11] box edges in the three dependency coordinates (lattice: nx, ny, nz); [12] bytes of the plan (lattice form);
+ * [9..11] box edges in the three dependency coordinates (lattice: nx, ny, nz); [12] bytes of the plan (lattice form) / for
+ * form 1 the reason the box-tile form was not taken: 1 no chains of consecutively numbered dependent rows, 2 no dependencies,
+ * 3 rows longer than 32 entries without row groups, 4 / 5 index ranges, 6 tiles do not fit the LDS, 7 too few rows, 8 switched off;
  * [13] chains; [14] most steps of a tile; [15] most external values of a tile */
 int ramd_tri_plan_stats(int which, long long* out16);
 int ramd_mat_l_analyse(ramd_mat_t m, int diag_unit); /* :365 */

@@ -51,10 +51,24 @@ struct McsgsPlan
     //   covered [t], t >= off[1]  : 1 = out of this row is stored by its partner's sweep
     int*           pair_of = nullptr;
     unsigned char* covered = nullptr;
+    // Colour 0 folded away (SGS apply, structured operators).  The first sweep of an apply has no entries -- colour 0 has no
+    // lower colours -- and only scales: x_0 = Dinv_0 rhs_0, 36 bytes per row of the colour and a launch to leave 8 behind.  Its
+    // readers form that product themselves instead: the forward sweeps of the other colours at their gathers (rhs and the
+    // inverse diagonal in NATURAL order, where a row's neighbours share lines with the row itself), colour 0's backward
+    // sweep for its own row.  Same operands, same product: bit-identical.  Needs the natural-order offset of every slot of
+    // the lower part's row patterns to be one number per pattern (nat_dict; verified row by row at Build()).
+    bool  fold0    = false;
+    void* dinv_nat = nullptr; // [n] inverse diagonal at the ORIGINAL row index (rows of colour 0)
+    int*  nat_dict = nullptr; // [l_pat_n * kPatMaxW] original-index offset of a slot whose column has colour 0
     void  release()
     {
         dev_free(&pair_of);
         dev_free(&covered);
+        dev_free(&nat_dict);
+        if(dinv_nat)
+            (void)cached_free(dinv_nat);
+        dinv_nat = nullptr;
+        fold0    = false;
         dev_free(&iperm);
         dev_free(&blk_of);
         dev_free(&l_off);
@@ -203,7 +217,9 @@ __global__ __launch_bounds__(kBlock) void k_mc_fill(int n, int nb, const int* __
 // gathers, at half the pitch.  With workgroup b on block b every line of xp was fetched by three XCDs (blocks b, b +- 1
 // sit on different XCDs; counters: 24 instead of 8 bytes per row); the XCD- and band-aware order of the CSR product
 // (xcd_block) keeps a line's readers on one L2.
-template <typename T, bool FROM_RHS, bool MULT_D, bool BOTH, bool TO_OUT, bool PAT>
+//   FOLD     : colour 0 is not in xp (McsgsPlan::fold0): a gathered column of colour 0 is rhs * dinv at its original index,
+//              the own value of a colour-0 row (its backward sweep) rhs[orow] * dinv[t]
+template <typename T, bool FROM_RHS, bool MULT_D, bool BOTH, bool TO_OUT, bool PAT, bool FOLD = false>
 __global__ __launch_bounds__(kBlock) void k_mc_sweep(int p0, int p1, const int* __restrict__ slice_off,
                                                      const int* __restrict__ ecol,
                                                      const T* __restrict__ eval,
@@ -212,23 +228,29 @@ __global__ __launch_bounds__(kBlock) void k_mc_sweep(int p0, int p1, const int* 
                                                      const T* __restrict__ rhs, T* xp,
                                                      T* __restrict__ out, int identity, CsrPattern pat, int nblk, int per_xcd,
                                                      BandMap bm, int keep_xp, const int* __restrict__ pair_of,
-                                                     const unsigned char* __restrict__ covered)
+                                                     const unsigned char* __restrict__ covered, int n0 = 0,
+                                                     const int* __restrict__ nat_dict = nullptr,
+                                                     const T* __restrict__ dinv_nat = nullptr)
 {
+    static_assert(!FOLD || PAT, "the natural-order offsets belong to the row patterns");
     // (bm.W < 0: workgroup b takes block b -- the order of rounds 1 to 3, kept for A/B runs)
     const int blk = bm.W < 0 ? ((int)blockIdx.x < nblk ? (int)blockIdx.x : -1) : xcd_block(nblk, per_xcd, bm); // (uniform)
     if(blk < 0)
         return;
     __shared__ int sdict[PAT ? kPatMax * kPatMaxW : 1];
+    __shared__ int snat[(FOLD && !MULT_D) ? kPatMax * kPatMaxW : 1];
     // Everything a row needs that hangs on nothing but its position is requested BEFORE the dictionary is staged (the
     // barrier would otherwise keep these loads behind the dictionary's round trip): the chain of a workgroup is then
     // {dictionary, row data} -> {values, gathers} -> store instead of dictionary -> row data -> values -> store.
     constexpr int NDW = PAT ? kPatMax * kPatMaxW / kBlock : 0;
-    int           dreg[NDW > 0 ? NDW : 1];
+    int           dreg[NDW > 0 ? NDW : 1], nreg[NDW > 0 ? NDW : 1];
 #pragma unroll
     for(int q = 0; q < NDW; ++q)
     {
         const int i = q * kBlock + threadIdx.x;
         dreg[q]     = i < pat.n * kPatMaxW ? pat.dict[i] : 0;
+        if(FOLD && !MULT_D)
+            nreg[q] = i < pat.n * kPatMaxW ? nat_dict[i] : 0;
     }
     const int64_t t    = (int64_t)p0 + (int64_t)blk * kBlock + threadIdx.x;
     const bool    live = t < p1;
@@ -237,12 +259,12 @@ __global__ __launch_bounds__(kBlock) void k_mc_sweep(int p0, int p1, const int* 
     const int     lane = (int)(tl & 63);
     const int     base = slice_off[tl >> 6];
     const int     w    = (slice_off[(tl >> 6) + 1] - base) >> 6;
-    const int     orow = (FROM_RHS || TO_OUT) ? iperm[tl] : 0;
+    const int     orow = (FROM_RHS || TO_OUT || FOLD) ? iperm[tl] : 0;
     const T       dv   = (MULT_D || BOTH) ? d[tl] : (T)0;
-    const T       iv   = !identity ? dinv[tl] : (T)0;
+    const T       iv   = (!identity || (FOLD && MULT_D)) ? dinv[tl] : (T)0;
     const int     pq   = (TO_OUT && pair_of) ? pair_of[tl] : -1;
     const bool    skip_out = TO_OUT && !pair_of && covered && covered[tl];
-    T             s    = FROM_RHS ? rhs[orow] : xp[tl];
+    T             s    = (FROM_RHS || (FOLD && MULT_D)) ? rhs[orow] : xp[tl];
     // ... and the values of the first batch of slots (they hang on the slice offset only)
     using P2 = T __attribute__((ext_vector_type(2)));
     T a0[8];
@@ -261,13 +283,19 @@ __global__ __launch_bounds__(kBlock) void k_mc_sweep(int p0, int p1, const int* 
         {
             const int i = q * kBlock + threadIdx.x;
             if(i < pat.n * kPatMaxW)
+            {
                 sdict[i] = dreg[q];
+                if(FOLD && !MULT_D)
+                    snat[i] = nreg[q];
+            }
         }
         __syncthreads();
     }
     if(!live)
         return;
     const int dbase = pid * kPatMaxW;
+    if(FOLD && MULT_D)
+        s = s * iv; // the forward value of this colour-0 row, formed here instead of read
     if(MULT_D)
         s = s * dv;
     // masked batches of 8 slots: loads, then gathers, then the updates IN ORDER (padding col = -1 ends a row)
@@ -313,7 +341,15 @@ __global__ __launch_bounds__(kBlock) void k_mc_sweep(int p0, int p1, const int* 
             if(c[e] < 0)
                 done = true;
             if(!done)
-                xv[e] = xp[c[e]];
+            {
+                if(FOLD && !MULT_D && c[e] < n0)
+                {
+                    const int o = orow + snat[dbase + k0 + e];
+                    xv[e]       = rhs[o] * dinv_nat[o];
+                }
+                else
+                    xv[e] = xp[c[e]];
+            }
             else
                 c[e] = -1;
         }
@@ -358,6 +394,43 @@ __global__ __launch_bounds__(kBlock) void k_mc_sweep(int p0, int p1, const int* 
 // the step that took the ELL product from 2.15 to 1.85 ms, k_ell2): MC-SGS apply 3.30-3.34 ms against 3.17 ms in
 // alternating runs (gpurun_out/r04v).  The sweeps' values already come in 16-byte slot pairs; what the ELL product gained
 // was exactly that.
+
+// natural-order offsets of the slots of the lower part's patterns that point into colour 0 (McsgsPlan::fold0):
+// pass 0: the first row of a pattern to arrive writes iperm[col] - iperm[row]; pass 1: every row checks its own against it
+constexpr int kNatNone = -2147483647 - 1;
+__global__ __launch_bounds__(kBlock) void k_mc_nat_dict(int p0, int n, int n0, int pass, const unsigned char* __restrict__ pid,
+                                                        const int* __restrict__ dict, const int* __restrict__ iperm,
+                                                        int* nat, int* __restrict__ bad)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t t = (int64_t)p0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gsz)
+    {
+        const int base = (int)pid[t] * kPatMaxW;
+        const int me   = iperm[t];
+        for(int k = 0; k < kPatMaxW; ++k)
+        {
+            const int o = dict[base + k];
+            if(o == kPatEnd)
+                break;
+            const int c = (int)t + o;
+            if(c < 0 || c >= n0)
+                continue; // (a column of another colour: read from the work vector as before)
+            const int dlt = iperm[c] - me;
+            if(pass == 0)
+                atomicCAS(nat + base + k, kNatNone, dlt);
+            else if(__hip_atomic_load(nat + base + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != dlt)
+                *bad = 1;
+        }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_mc_dinv_nat(int n0, const int* __restrict__ iperm, const T* __restrict__ dinv,
+                                                        T* __restrict__ dinv_nat)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n0; t += gsz)
+        dinv_nat[iperm[t]] = dinv[t];
+}
 
 // pairs of the output (see McsgsPlan): row t of colour 0 takes the row next to it in its aligned pair of out along where that
 // row has another colour
@@ -575,6 +648,50 @@ static int mc_build(McsgsPlan* P, const ramd_mat_s* m, const int* perm)
             P->identity[(size_t)i] = (h[(size_t)i] == 0) ? 1 : 0;
     }
     dev_free(&cnt);
+    // colour 0 folded into its readers (see McsgsPlan::fold0): RAMD_MC_FOLD=0 switches it off (A/B, and the tests run both forms)
+    static const int fold_env = getenv("RAMD_MC_FOLD") ? atoi(getenv("RAMD_MC_FOLD")) : 1;
+    if(s == RAMD_OK && fold_env != 0 && nb > 1 && P->l_pat == 1 && P->u_pat == 1 && !P->identity[0] && P->off[1] > 0)
+    {
+        const int n0 = P->off[1];
+        int*      bad = nullptr;
+        s = dev_alloc(&P->nat_dict, (int64_t)P->l_pat_n * kPatMaxW);
+        if(s == RAMD_OK)
+            s = dev_alloc(&bad, 1);
+        if(s == RAMD_OK && cached_malloc(&P->dinv_nat, (size_t)n * sizeof(T) + kPad) != hipSuccess)
+            s = RAMD_ERR_HIP;
+        if(s == RAMD_OK)
+        {
+            std::vector<int> init((size_t)P->l_pat_n * kPatMaxW, kNatNone);
+            hipError_t       e = hipMemcpyAsync(P->nat_dict, init.data(), sizeof(int) * init.size(), hipMemcpyHostToDevice, b.cur);
+            if(e == hipSuccess)
+                e = hipMemsetAsync(bad, 0, sizeof(int), b.cur);
+            if(e == hipSuccess)
+                e = hipMemsetAsync(P->dinv_nat, 0, (size_t)n * sizeof(T), b.cur);
+            if(e == hipSuccess)
+                e = hipStreamSynchronize(b.cur); // (init goes out of scope)
+            for(int pass = 0; pass < 2; ++pass)
+                hipLaunchKernelGGL(k_mc_nat_dict, dim3(ew_grid(n - n0)), dim3(kBlock), 0, b.cur, n0, n, n0, pass, P->l_pat_id,
+                                   P->l_pat_dict, P->iperm, P->nat_dict, bad);
+            hipLaunchKernelGGL((k_mc_dinv_nat<T>), dim3(ew_grid(n0)), dim3(kBlock), 0, b.cur, n0, P->iperm, (const T*)P->dinv,
+                               (T*)P->dinv_nat);
+            int hb = 1;
+            if(e == hipSuccess)
+                e = hipMemcpyAsync(&hb, bad, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+            if(e == hipSuccess)
+                e = hipStreamSynchronize(b.cur);
+            if(e != hipSuccess)
+                s = RAMD_ERR_HIP;
+            P->fold0 = (s == RAMD_OK && hb == 0);
+        }
+        dev_free(&bad);
+        if(!P->fold0)
+        {
+            dev_free(&P->nat_dict);
+            if(P->dinv_nat)
+                (void)cached_free(P->dinv_nat);
+            P->dinv_nat = nullptr;
+        }
+    }
     dev_free(&d_off);
     return s;
 }
@@ -638,6 +755,33 @@ static int mc_apply(McsgsPlan* P, int kind, const T* rhs, T* out)
         SWEEP(true, false, false, true, nb - 1, P->l_off, P->l_col, P->l_val, nb > 1); // last colour: L and R in one
         for(int i = nb - 2; i >= 0; --i)
             SWEEP(false, false, false, true, i, P->u_off, P->u_col, P->u_val, i > 0);
+        RAMD_HIP(hipGetLastError());
+        return RAMD_OK;
+    }
+    if(P->fold0)
+    {
+        // colour 0's forward sweep (a scaling, no entries) is not run: its readers form Dinv_0 rhs_0 themselves
+#define SWEEPF(FR, MD, BO, TO, i, OFFP, COLP, VALP, KEEP, LOWERP)                                            \
+    do                                                                                                       \
+    {                                                                                                        \
+        const int     p0 = P->off[(size_t)(i)], p1 = P->off[(size_t)(i) + 1];                                \
+        const int     nblk = (p1 - p0 + kBlock - 1) / kBlock, per_xcd = (nblk + 7) / 8;                      \
+        const BandMap bm = (LOWERP) ? P->l_bm[(size_t)(i)] : P->u_bm[(size_t)(i)];                           \
+        if(p1 > p0)                                                                                          \
+            hipLaunchKernelGGL((k_mc_sweep<T, FR, MD, BO, TO, true, true>), dim3(per_xcd * 8), dim3(kBlock), 0, b.cur, p0, p1, \
+                               OFFP, COLP, (const T*)VALP, (const T*)P->d, (const T*)P->dinv, P->iperm, rhs, (T*)P->xp, out,   \
+                               (int)P->identity[(size_t)(i)], (LOWERP) ? lpat : upat, nblk, per_xcd, bm, (int)(KEEP),         \
+                               (const int*)(((TO) && (i) == 0 && pairs_on) ? P->pair_of : nullptr),                          \
+                               (const unsigned char*)(((TO) && (i) > 0 && pairs_on) ? P->covered : nullptr), P->off[1],      \
+                               P->nat_dict, (const T*)P->dinv_nat);                                                          \
+    } while(0)
+        for(int i = 1; i + 1 < nb; ++i)
+            SWEEPF(true, false, false, false, i, P->l_off, P->l_col, P->l_val, true, true);
+        SWEEPF(true, false, true, true, nb - 1, P->l_off, P->l_col, P->l_val, nb > 1, true);
+        for(int i = nb - 2; i >= 1; --i)
+            SWEEP(false, true, false, true, i, P->u_off, P->u_col, P->u_val, true);
+        SWEEPF(false, true, false, true, 0, P->u_off, P->u_col, P->u_val, false, false);
+#undef SWEEPF
         RAMD_HIP(hipGetLastError());
         return RAMD_OK;
     }

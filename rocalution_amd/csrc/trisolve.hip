@@ -718,6 +718,7 @@ struct TriPlan
     LatPlan* lat = nullptr;
     // what the analysis found (ramd_tri_plan_stats): chains, external values of all tiles, box edges
     int       st_chains = 0, st_box[3] = {0, 0, 0};
+    int       st_why    = 0; // why this plan is not in box-tile form (ct_why_text)
     long long st_ext    = 0;
     void  release()
     {
@@ -967,6 +968,23 @@ __global__ __launch_bounds__(kBlock) void k_natural_order(int n, int* __restrict
 }
 
 static bool ct_enabled();
+// why the last build_ct_plan returned RAMD_ERR_UNSUPPORTED (ramd_tri_plan_stats reports it: no matrix falls back silently)
+static int         g_ct_gave_up = 0;
+static const char* ct_why_text(int why)
+{
+    switch(why)
+    {
+    case 1: return "no chains: fewer than 8 consecutively numbered dependent rows per chain on average";
+    case 2: return "no dependencies at all";
+    case 3: return "triangular rows longer than 32 entries that do not form row groups";
+    case 4: return "too many tiles for the 30-bit tile keys";
+    case 5: return "more than 2^31 packed entries";
+    case 6: return "the tiles cannot be made to fit the LDS";
+    case 7: return "fewer rows than the box-tile form is worth (RAMD_TRSV_CT_MINROWS)";
+    case 8: return "switched off (RAMD_TRSV_CT=0)";
+    default: return "";
+    }
+}
 template <typename T>
 static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bool reverse);
 
@@ -981,9 +999,11 @@ static int build_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bool 
     P->nslices = (n + 63) / 64;
     if(n == 0)
         return RAMD_OK;
+    P->st_why = (!natural && !ct_enabled()) ? 8 : 0;
     if(!natural && ct_enabled())
     {
         const int sc = build_ct_plan<T>(m, st, P, lower, reverse);
+        P->st_why    = sc == RAMD_ERR_UNSUPPORTED ? g_ct_gave_up : 0;
         if(sc == RAMD_OK)
         {
             if(lower && st->l_order_cache) // the level order of ILU0Factorize is not needed by this form
@@ -3147,8 +3167,12 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     }
     static const bool verbose    = getenv("RAMD_TRSV_CT_VERBOSE") != nullptr;
     static const int  lds_budget = getenv("RAMD_TRSV_CT_LDS") ? atoi(getenv("RAMD_TRSV_CT_LDS")) : 40 * 1024;
+    g_ct_gave_up = 0;
     if(n < min_rows || n < 1)
+    {
+        g_ct_gave_up = 7;
         return RAMD_ERR_UNSUPPORTED;
+    }
     int *level = nullptr, *lorder = nullptr, *start = nullptr, *lev_t = nullptr, *tkey = nullptr, *o1 = nullptr,
         *k2 = nullptr, *o2 = nullptr, *tflag = nullptr, *sflag = nullptr, *tscan = nullptr, *sscan = nullptr,
         *tile_of = nullptr, *step_of = nullptr, *step_w = nullptr, *nodiag = nullptr, *cext = nullptr, *tsz = nullptr,
@@ -3208,11 +3232,12 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
             RAMD_FAIL(RAMD_ERR_HIP, #expr); \
         }                            \
     } while(0)
-#define CT_GIVE_UP()                                                                       \
+#define CT_GIVE_UP(why)                                                                    \
     do                                                                                     \
     {                                                                                      \
+        g_ct_gave_up = (why);                                                              \
         if(verbose)                                                                        \
-            fprintf(stderr, "box-tile plan: not used for this matrix (trisolve.hip:%d)\n", __LINE__); \
+            fprintf(stderr, "box-tile plan: not used for this matrix (%s; trisolve.hip:%d)\n", ct_why_text(why), __LINE__); \
         cleanup();                                                                         \
         P->release();                                                                      \
         return RAMD_ERR_UNSUPPORTED;                                                       \
@@ -3232,7 +3257,7 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     CT_HIP(hipMemcpyAsync(&nchains, start + n, sizeof(int), hipMemcpyDeviceToHost, b.cur));
     CT_HIP(hipStreamSynchronize(b.cur));
     if(nchains <= 0 || (int64_t)n < (int64_t)min_len * nchains)
-        CT_GIVE_UP();
+        CT_GIVE_UP(1);
     // longest strictly-triangular row: decides how many lanes share a row (and so how many rows a step may hold)
     int wmax = 0;
     CT_TRY(dev_alloc(&cext, 4));
@@ -3366,9 +3391,9 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     for(int k = 0; k < 3; ++k)
         dnz += E[k] > 1 ? 1 : 0;
     if(dnz == 0)
-        CT_GIVE_UP();
+        CT_GIVE_UP(2);
     if(wmax > 32 && !grp) // (8 lanes x 4 entries per row and step)
-        CT_GIVE_UP();
+        CT_GIVE_UP(3);
     const int lpr = grp ? kGrpLPR : (wmax > 8 ? 8 : 1);
     const int wl  = grp ? kGrpWL : (lpr == 1 ? (wmax <= 3 ? 3 : (wmax <= 4 ? 4 : 8)) : 4);
     const int rpp = 64 / lpr;
@@ -3477,7 +3502,7 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
         Ts[k] = (int)((E[k] + bs[k] - 1) / bs[k]);
     keymax = (int64_t)(Ts[0] + Ts[1] + Ts[2]) * Ts[2] * Ts[1] * Ts[0];
     if(keymax >= (1ll << 30))
-        CT_GIVE_UP();
+        CT_GIVE_UP(4);
     // keys, sort by (tile, level, sweep index)
     CT_TRY(dev_alloc(&lev_t, n));
     CT_TRY(dev_alloc(&tkey, n));
@@ -3602,7 +3627,7 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     dev_free(&tscan);
     dev_free(&sscan);
     if((int64_t)wmax * n >= (1ll << 31) - 65536) // packed entries are addressed with 32-bit offsets
-        CT_GIVE_UP();
+        CT_GIVE_UP(5);
     P->ct_wmax = wmax;
     hipLaunchKernelGGL(k_ct_ent_sizes, dim3(ew_grid(nsteps + 1)), dim3(kBlock), 0, b.cur, nsteps, P->ct_step_pos, step_w,
                        P->ct_step_ent);
@@ -3722,7 +3747,7 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
             const int nrows_next = (int)((double)rows * shrink);
             rows                 = nrows_next < rows - 1 ? nrows_next : rows - 1;
             if(rows < 16)
-                CT_GIVE_UP();
+                CT_GIVE_UP(6);
             dev_free(&P->order);
             dev_free(&P->pos);
             dev_free(&P->ct_tile_step);
@@ -3741,7 +3766,7 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     dev_free(&level);
     dev_free(&word);
     if(!fits)
-        CT_GIVE_UP();
+        CT_GIVE_UP(6);
     CT_HIP(cached_malloc(&P->w, (size_t)n * sizeof(T) + kPad));
     static const int wslot_env = getenv("RAMD_TRSV_WSLOT") ? atoi(getenv("RAMD_TRSV_WSLOT")) : 0; // (1: the places below; measured, see DESIGN)
     if(wslot_env != 0 && !grp && lpr == 1 && wl == 3 && next > 0 && ntiles > 1)
@@ -5643,6 +5668,7 @@ static void tri_note_stats(const ramd_mat_s* m, const TriPlan* P, int which)
     }
     o[0] = !P->ct ? 1 : (P->ct_grp ? 3 : 2);
     o[2] = P->nlevels;
+    o[12] = P->ct ? 0 : P->st_why;
     o[7] = P->ct_wmax;
     if(P->ct)
     {

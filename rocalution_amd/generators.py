@@ -226,3 +226,105 @@ def write_mtx_symmetric(path, rp, ci, va):
         except ImportError:
             np.savetxt(f, np.column_stack([r1, c1, v1]), fmt="%d %d %.17g")
     return len(v1)
+
+
+# ---------------------------------------------------------------------------------------------
+# Variants of the config-3 class: the same kind of operator -- 5 unknowns per mesh node, ~35 entries per
+# row, SPD -- with the node NUMBERINGS a real file may carry.  The surrogate above numbers its nodes lexicographically, which
+# is exactly what the tile construction of the triangular solves keys on (chains of consecutively numbered, dependent rows);
+# SuiteSparse af_shell10 is an unstructured sheet-metal mesh in whatever order the pre-processor left it.
+#   "lex"       the surrogate as it is
+#   "rcm"       the same mesh, nodes renumbered by reverse Cuthill-McKee (scipy.sparse.csgraph) -- a bandwidth-reducing order,
+#               level sets of a breadth-first search from a corner: consecutive nodes are mostly NOT neighbours
+#   "delaunay"  a Delaunay triangulation of jittered lattice points (valence 4 .. 9), in reverse Cuthill-McKee order
+#   "random"    the surrogate's mesh with a random node permutation (the adversarial case: no locality at all)
+def _fe_from_edges(nn, eu, ev, seed, shift=1.0 / 64, dtype=np.float64):
+    """A = sum over edges (u, v) of [[K, -K], [-K, K]] (K = K_e: symmetric 5 x 5, diagonally dominant, from a hash of the edge)
+    + diag(shift (1 + a)): SPD; all values multiples of 1/128, so every sum is exact"""
+    import scipy.sparse as sp
+    D = _SHELL_DOF
+    lo, hi = np.minimum(eu, ev).astype(np.int64), np.maximum(eu, ev).astype(np.int64)
+    h = _edge_hash(lo, hi, 5, seed)
+    c = (16.0 + (h & np.uint64(15)).astype(np.float64)) / 16.0
+    pair_bit = np.zeros((D, D), dtype=np.uint64)
+    k = 0
+    for a in range(D):
+        for b in range(a + 1, D):
+            pair_bit[a, b] = pair_bit[b, a] = 8 + k
+            k += 1
+    sgn = 1.0 - 2.0 * ((h[:, None, None] >> pair_bit[None]) & np.uint64(1)).astype(np.float64)
+    eye = np.eye(D, dtype=bool)
+    K = np.where(eye[None], 1.0, sgn / 8.0) * c[:, None, None]  # [ne, D, D]
+    a_idx, b_idx = np.meshgrid(np.arange(D), np.arange(D), indexing="ij")
+
+    def block_coo(rn, cn, V):
+        r = (rn[:, None, None] * D + a_idx[None]).ravel()
+        cc = (cn[:, None, None] * D + b_idx[None]).ravel()
+        return r, cc, V.ravel()
+    parts = [block_coo(lo, hi, -K), block_coo(hi, lo, -K), block_coo(lo, lo, K), block_coo(hi, hi, K)]
+    node = np.arange(nn, dtype=np.int64)
+    parts.append(block_coo(node, node, np.broadcast_to(np.diag(shift * (1.0 + np.arange(D)))[None], (nn, D, D)).copy()))
+    r = np.concatenate([p[0] for p in parts]); cc = np.concatenate([p[1] for p in parts]); v = np.concatenate([p[2] for p in parts])
+    A = sp.coo_matrix((v, (r, cc)), shape=(nn * D, nn * D)).tocsr()
+    A.sum_duplicates(); A.sort_indices()
+    # (the zero blocks of node pairs do not occur: every stored block belongs to an edge or to a node's diagonal)
+    return A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(dtype)
+
+
+def _permute_nodes(rp, ci, va, perm_new_of_old):
+    """P A P^T with whole nodes moved: node k becomes node perm_new_of_old[k], its 5 unknowns stay together and in order"""
+    import scipy.sparse as sp
+    D = _SHELL_DOF
+    n = len(rp) - 1
+    A = sp.csr_matrix((va, ci, rp), shape=(n, n))
+    old_of_new = np.empty_like(perm_new_of_old)
+    old_of_new[perm_new_of_old] = np.arange(len(perm_new_of_old))
+    idx = (old_of_new[:, None] * D + np.arange(D)[None]).ravel()
+    B = A[idx][:, idx].tocsr()
+    B.sort_indices()
+    return B.indptr.astype(np.int32), B.indices.astype(np.int32), B.data.astype(va.dtype)
+
+
+def _node_graph(rp, ci):
+    import scipy.sparse as sp
+    D = _SHELL_DOF
+    n = len(rp) - 1
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(rp)) // D
+    G = sp.coo_matrix((np.ones(len(ci), np.int8), (rows, ci.astype(np.int64) // D)), shape=(n // D, n // D)).tocsr()
+    G.sum_duplicates()
+    return G
+
+
+def _rcm_new_of_old(G):
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    order = reverse_cuthill_mckee(G.tocsr(), symmetric_mode=True)  # order[new] = old
+    new_of_old = np.empty(len(order), dtype=np.int64)
+    new_of_old[order] = np.arange(len(order))
+    return new_of_old
+
+
+def shell_variant(nx, kind="lex", seed=1, dtype=np.float64):
+    """CSR arrays of a config-3-class operator with nx x nx mesh nodes in the numbering `kind` (see above)"""
+    if kind == "lex":
+        return shell_surrogate(nx, seed=seed, dtype=dtype)
+    if kind in ("rcm", "random"):
+        rp, ci, va = shell_surrogate(nx, seed=seed, dtype=dtype)
+        if kind == "rcm":
+            p = _rcm_new_of_old(_node_graph(rp, ci))
+        else:
+            p = np.random.default_rng(seed).permutation(nx * nx).astype(np.int64)
+        return _permute_nodes(rp, ci, va, p)
+    if kind == "delaunay":
+        from scipy.spatial import Delaunay
+        rng = np.random.default_rng(seed)
+        gx, gy = np.meshgrid(np.arange(nx, dtype=np.float64), np.arange(nx, dtype=np.float64), indexing="xy")
+        pts = np.column_stack([gx.ravel(), gy.ravel()]) + rng.uniform(-0.35, 0.35, (nx * nx, 2))
+        tri = Delaunay(pts).simplices
+        e = np.concatenate([tri[:, [0, 1]], tri[:, [1, 2]], tri[:, [0, 2]]])
+        e = np.unique(np.sort(e, axis=1), axis=0)
+        # (the hull of a jittered lattice has a few long sliver edges: keep edges of at most 2.5 lattice spacings)
+        keep = np.linalg.norm(pts[e[:, 0]] - pts[e[:, 1]], axis=1) <= 2.5
+        e = e[keep]
+        rp, ci, va = _fe_from_edges(nx * nx, e[:, 0], e[:, 1], seed, dtype=dtype)
+        return _permute_nodes(rp, ci, va, _rcm_new_of_old(_node_graph(rp, ci)))
+    raise ValueError(kind)

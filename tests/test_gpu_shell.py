@@ -215,3 +215,45 @@ def test_full_size_gmres30_ilu0_converges_to_known_solution(ra, S, full):
     x.AddScale(ones, -1.0)
     assert x.Norm() / np.sqrt(n) < 1e-4
     ls.Clear()
+
+
+# ------------------------------------------------------------------ other node numberings of the same class
+@pytest.mark.parametrize("kind", ["rcm", "delaunay", "random"])
+def test_variants_of_the_class_bit_exact_and_plan_reported(ra, S, gen, oracle, kind):
+    """The surrogate numbers its mesh nodes lexicographically -- exactly what the tile construction of the triangular solves
+    keys on.  The same class of operator in reverse Cuthill-McKee order, as a Delaunay mesh in RCM order and in a random
+    node order: ILU(0) factors and LUSolve bit-exact against the oracle, GMRES(30)+ILU(0) iteration count and solution
+    against the oracle, and the plan statistics say which form the triangular solves took and, if not the tiles, why."""
+    import ctypes as C
+    from rocalution_amd import capi
+    lib = capi.load()
+    rp, ci, va = gen.shell_variant(40, kind)  # 8000 rows: above the 4096-row threshold of the box-tile form
+    n = len(rp) - 1
+    A = ra.LocalMatrix(); A.SetDataPtrCSR(rp, ci, va)
+    F = ra.LocalMatrix(); F.CloneFrom(A)
+    F.ILU0Factorize()
+    lu = oracle.ilu0(rp, ci, va)
+    assert np.array_equal(F.CopyToCSR()[2], lu)
+    F.LUAnalyse()
+    st = (C.c_int64 * 16)()
+    forms = []
+    for which in (0, 1):
+        capi.check(lib.ramd_tri_plan_stats(which, st))
+        assert st[0] in (1, 2, 3) and st[1] == n and st[2] > 0, list(st)
+        assert (st[0] == 1) == (st[12] != 0), list(st)  # a plan that is not in tile form says why
+        forms.append((int(st[0]), int(st[12]), int(st[2])))
+    b = np.random.default_rng(5).uniform(-1, 1, n)
+    y = ra.LocalVector(); y.Allocate("", n)
+    for rep in range(2):
+        F.LUSolve(ra.LocalVector(data=b), y)
+        assert np.array_equal(y.numpy(), oracle.lusolve(rp, ci, lu, b))
+    rhs = oracle.csr_apply(rp, ci, va, np.ones(n))
+    ref = oracle.solve(rp, ci, va, rhs, solver=oracle.GMRES, precond=oracle.PC_ILU0, basis=30, max_iter=500)
+    ls = S.GMRES(); ls.SetOperator(A); ls.SetPreconditioner(S.ILU()); ls.SetBasisSize(30); ls.Init(1e-15, 1e-6, 1e8, 500)
+    ls.Build()
+    x = ra.LocalVector(); x.Allocate("", n); x.Zeros()
+    ls.Solve(ra.LocalVector(data=rhs), x)
+    assert ls.GetSolverStatus() == ref["status"] and abs(ls.GetIterationCount() - ref["iters"]) <= 2
+    assert np.linalg.norm(x.numpy() - ref["x"]) / np.linalg.norm(ref["x"]) < 1e-8
+    ls.Clear()
+    print(kind, "plans (form, reason, levels):", forms, "GMRES iterations", ref["iters"])

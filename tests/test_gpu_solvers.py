@@ -625,12 +625,15 @@ def test_time_mark_hook_does_not_change_the_solve(ra, S):
     assert 0.0 < out[1][2] <= out[1][3] + 1e-3
 
 
-def test_multicoloured_sweeps_with_output_pairs_forced():
+@pytest.mark.parametrize("pat", ["-1", "1"])
+def test_multicoloured_sweeps_with_output_pairs_forced(pat):
     """the colour sweeps store out[] in aligned 16-byte pairs from the last sweep (mcsgs.hip, McsgsPlan::pair_of) only for
     operators of 2^16 rows and more; here the bit-exact multi-colour tests (goldens of MC-SGS / MC-GS / MC-ILU applies in
-    both forms, solver histories, 2 to 4 colours, odd sizes) run again in a fresh process with the pairs forced on"""
+    both forms, solver histories, 2 to 4 colours, odd sizes) run again in a fresh process with the pairs forced on -- and once
+    more with the row patterns forced on as well, i.e. with colour 0 of the SGS applies folded into its readers
+    (McsgsPlan::fold0) together with the pairs"""
     import subprocess
-    env = dict(os.environ, RAMD_MC_PAIR="2")
+    env = dict(os.environ, RAMD_MC_PAIR="2", RAMD_CSR_PAT=pat)
     cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", os.path.abspath(__file__),
            "-k", "(mcsgs or mcgs or mcilu or preconditioner_apply or solvers_vs_golden or smoother) and not forced and not full_size"]
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
