@@ -408,17 +408,9 @@ public:
     void PlaceByTrial(const std::function<void()>& run, int tries, double stop_ratio = 0.0,
                       const GlobalVector<ValueType>* apart_from = nullptr)
     {
-        if(stop_ratio > 0.0) // (a `run` without exchanges: every rank places its share by itself)
-        {
-            this->m_owned.PlaceByTrial(run, tries, stop_ratio, apart_from ? &apart_from->m_owned : nullptr);
-            return;
-        }
-        // every rank has to run `run` equally often (it exchanges halos): all of them take part, or none
-        const double mine = (double)this->m_owned.GetSize() * sizeof(ValueType) >= (double)(64 << 20) ? 1.0 : 0.0;
-        if(this->pm_ != NULL && this->pm_->GetNumProcs() > 1
-           && this->sum_ranks_(mine) < (double)this->pm_->GetNumProcs() - 0.5)
-            return;
-        this->m_owned.PlaceByTrial(run, tries);
+        // `run` launches kernels on this rank's vectors only -- never a collective (ramd_vec_place_by_trial): every rank
+        // places its share by itself, with as many candidates as its own memory allows
+        this->m_owned.PlaceByTrial(run, tries, stop_ratio, apart_from ? &apart_from->m_owned : nullptr);
     }
     int64_t GetSize(void) const
     {
@@ -626,6 +618,10 @@ public:
     {
         return this->m_ghost;
     }
+    bool IsTransferOperator(void) const // a coupled prolongation or a reverse-form restriction of the AMG setup
+    {
+        return this->m_coupled || this->m_reverse;
+    }
     void Info(void) const
     {
         LOG_INFO("GlobalMatrix rows=" << this->GetM() << "; cols=" << this->GetN()
@@ -636,6 +632,7 @@ public:
                             int64_t nnz)
     {
         assert(this->pm_ != NULL);
+        this->m_amg.reset(); // (a new operator: the merged block of an earlier aggregation describes the old one)
         this->m_interior.SetDataPtrCSR(row_offset, col, val, "Interior of " + name, nnz,
                                              this->pm_->GetLocalNrow(), this->pm_->GetLocalNcol());
     }
@@ -643,6 +640,7 @@ public:
                             int64_t nnz)
     {
         assert(this->pm_ != NULL);
+        this->m_amg.reset();
         this->m_ghost.SetDataPtrCSR(row_offset, col, val, "Ghost of " + name, nnz,
                                           this->pm_->GetLocalNrow(), this->pm_->GetNumReceivers());
     }
@@ -650,6 +648,13 @@ public:
     {
         this->m_interior.MoveToAccelerator();
         this->m_ghost.MoveToAccelerator();
+        if(this->m_reverse)
+        {
+            // a restriction in the reverse form (doTransposeCoupled) has no halo plan of the forward kind -- announcing one
+            // would be a collective the other ranks' objects do not enter -- and its scatter operator moves with it
+            this->m_scatter.MoveToAccelerator();
+            return;
+        }
         this->doInitHalo();
     }
     // global_matrix.cpp:913-921: interior in the requested format, ghost part always COO
@@ -688,6 +693,8 @@ public:
     template <typename OtherType>
     void CastFrom(const GlobalMatrix<OtherType>& src)
     {
+        // (operators only: the coupled prolongation / reverse-form restriction of the AMG setup carry their own exchange state)
+        RAMD_EXPECT(!src.IsTransferOperator());
         this->pm_ = src.pm();
         this->m_interior.template CastFrom<OtherType>(src.GetInterior());
         const unsigned int gfmt = src.GetGhost().GetFormat();
@@ -749,6 +756,7 @@ public:
     void ApplyDotV(const GlobalVector<ValueType>& in, const GlobalVector<ValueType>& w,
                    GlobalVector<ValueType>* out, int slot) const
     {
+        RAMD_EXPECT(!this->m_reverse); // (a restriction is applied, never the operator of a fused product + dot)
         const bool comm = this->pm_ != NULL && (this->m_halo_plan > 0 || !this->pm_->peers().empty());
         if(comm)
         {
@@ -832,6 +840,7 @@ public:
     void AMGGreedyAggregate(ValueType eps, LocalVector<int>* connections, LocalVector<int>* aggregates,
                             LocalVector<int>* aggregate_root_nodes) const
     {
+        this->m_amg.reset(); // (rank-local aggregates: a coupled block of an earlier PMIS aggregation must not be taken up)
         this->m_interior.AMGGreedyAggregate(eps, connections, aggregates, aggregate_root_nodes);
     }
     void AMGUnsmoothedAggregation(const LocalVector<int>& aggregates, const LocalVector<int>& aggregate_root_nodes,
@@ -840,6 +849,9 @@ public:
         assert(prolong != NULL && prolong != this);
         if(this->m_amg)
         {
+            // (the aggregates of the coupled form cover the rank's rows AND its ghost nodes: anything else was not made by the
+            //  AMGPMISAggregate call this block belongs to)
+            RAMD_EXPECT(aggregates.GetSize() == this->m_amg->block.GetN());
             this->doProlongCoupled(0, static_cast<ValueType>(0), 0, aggregates, aggregates, aggregate_root_nodes, prolong);
             return;
         }
@@ -853,6 +865,7 @@ public:
         assert(prolong != NULL && prolong != this);
         if(this->m_amg)
         {
+            RAMD_EXPECT(aggregates.GetSize() == this->m_amg->block.GetN());
             this->doProlongCoupled(1, relax, lumping_strat, connections, aggregates, aggregate_root_nodes, prolong);
             return;
         }
@@ -1111,17 +1124,12 @@ private:
     // first entry of every rank's share of `local` items in rank order, and the total (one all-reduce)
     static std::vector<int64_t> doRankOffsets(const ParallelManager* pm, int64_t local)
     {
-        const int P = pm->GetNumProcs(), r = pm->GetRank();
-        const int cap = 48, first = RAMD_NSCALARS - 8 - cap;
-        RAMD_EXPECT(P <= cap);
-        for(int k = 0; k < P; ++k)
-            RAMD_CHECK(ramd_scalars_set(first + k, k == r ? (double)local : 0.0));
-        RAMD_CHECK(ramd_comm_allreduce_scalars(pm->GetComm(), first, P));
-        double v[48];
-        RAMD_CHECK(ramd_scalars_fetch(v, first, P));
+        const int            P = pm->GetNumProcs();
+        std::vector<int64_t> all((size_t)P, 0);
+        RAMD_CHECK(ramd_comm_allgather_i64(pm->GetComm(), &local, 1, all.data()));
         std::vector<int64_t> off((size_t)P + 1, 0);
         for(int k = 0; k < P; ++k)
-            off[(size_t)k + 1] = off[(size_t)k] + (int64_t)std::llround(v[k]);
+            off[(size_t)k + 1] = off[(size_t)k] + all[(size_t)k];
         return off;
     }
     // one exchange of this operator's halo pattern with 8-byte entries whatever the value type (setup data: numbers)
@@ -1145,24 +1153,17 @@ private:
             r.CopyToHostData(recv->data());
     }
     // messages of any length between any two ranks (out[q]: what goes to rank q; returns what every rank sent here).
-    // Lengths first -- P - 1 all-reduces of one slot per rank, round k announcing the message for rank + k -- then ONE
-    // exchange in pairs.  A collective: every rank of the communicator calls it.
+    // Lengths first -- one all-gather of every rank's P lengths -- then ONE exchange in pairs.  A collective: every rank of the communicator calls it.
     static std::vector<std::vector<double>> doTalk(const ParallelManager* pm, const std::vector<std::vector<double>>& out)
     {
         const int P = pm->GetNumProcs(), r = pm->GetRank();
-        const int cap = 48, first = RAMD_NSCALARS - 8 - cap;
-        RAMD_EXPECT(P <= cap && (int)out.size() == P);
-        std::vector<int64_t> nin((size_t)P, 0);
-        for(int k = 1; k < P; ++k)
-        {
-            for(int q = 0; q < P; ++q)
-                RAMD_CHECK(ramd_scalars_set(first + q, q == r ? (double)out[(size_t)((r + k) % P)].size() : 0.0));
-            RAMD_CHECK(ramd_comm_allreduce_scalars(pm->GetComm(), first, P));
-            double v[48];
-            RAMD_CHECK(ramd_scalars_fetch(v, first, P));
-            const int from    = (r - k + P) % P;
-            nin[(size_t)from] = (int64_t)std::llround(v[from]);
-        }
+        RAMD_EXPECT((int)out.size() == P);
+        std::vector<int64_t> len((size_t)P, 0), all((size_t)P * P, 0), nin((size_t)P, 0);
+        for(int q = 0; q < P; ++q)
+            len[(size_t)q] = (int64_t)out[(size_t)q].size();
+        RAMD_CHECK(ramd_comm_allgather_i64(pm->GetComm(), len.data(), P, all.data()));
+        for(int q = 0; q < P; ++q)
+            nin[(size_t)q] = q == r ? 0 : all[(size_t)q * P + r];
         std::vector<int>     peers;
         std::vector<int64_t> so(1, 0), ro(1, 0);
         for(int q = 0; q < P; ++q)
@@ -1705,6 +1706,7 @@ private:
     void doInitHalo(void)
     {
         this->doDropHaloPlan();
+        this->m_amg.reset();
         if(this->pm_ == NULL)
             return;
         {
@@ -1715,6 +1717,8 @@ private:
                                              this->pm_->send_offset().data(), this->pm_->recv_offset().data(), &ag));
             this->m_halo_plan = ag;
             this->m_halo_comm = ag > 0 ? this->pm_->GetComm() : NULL;
+            if(ag > 0)
+                RAMD_CHECK(ramd_comm_generation(this->m_halo_comm, &this->m_halo_gen));
         }
         if(this->pm_->peers().empty() && this->m_halo_plan == 0)
             return;
@@ -1740,12 +1744,13 @@ private:
     void doDropHaloPlan(void)
     {
         if(this->m_halo_plan > 0 && this->m_halo_comm != NULL)
-            (void)ramd_comm_halo_release(this->m_halo_comm, this->m_halo_plan);
+            (void)ramd_comm_halo_release(this->m_halo_comm, this->m_halo_plan, this->m_halo_gen);
         this->m_halo_plan = 0;
         this->m_halo_comm = NULL;
     }
     int                            m_halo_plan = 0;
     ramd_comm_t                    m_halo_comm = NULL;
+    long long                      m_halo_gen  = 0; // ramd_comm_generation of m_halo_comm when the plan was announced
 };
 
 // ---- fused-loop helpers for Global objects (see solvers.hpp: _fusable / _fh / _f_apply_dot / _f_allreduce)

@@ -1951,19 +1951,19 @@ private:
         kp->PlaceByTrial(direction, draws, 0.94, x);
         // (RAMD_PLACE_Q=k: q, the output of the product, by timing the product with k fresh blocks -- measured without
         //  gain for the product, 2.27-2.28 ms either way, and q is read by the residual update, which then lost its fast
-        //  placement in half the runs: gpurun_out/r03av, third series.  A Global product exchanges halos, so every rank
-        //  runs the same fixed number of trials there.)
+        //  placement in half the runs: gpurun_out/r03av, third series.  LocalMatrix operators only: a Global product
+        //  exchanges halos and reduces, i.e. the trial itself would be a collective, and whether a rank has the memory for a
+        //  candidate block -- or finds a fast one early -- is that rank's own affair: ranks leaving the trials at different
+        //  points would leave the others hanging in the exchange.  The trials above time kernels on this
+        //  rank's vectors only.)
         static const int qtries = getenv("RAMD_PLACE_Q") ? atoi(getenv("RAMD_PLACE_Q")) : 0; // (0: off)
-        if(qtries > 0)
+        if(qtries > 0 && _one_block<OperatorType, VectorType, ValueType>::value)
         {
             auto product = [&]() { _f_apply_dot(A, *kp, kq, 0); };
-            if(_one_block<OperatorType, VectorType, ValueType>::value)
-                kq->PlaceByTrial(product, qtries, 0.975);
-            else
-                kq->PlaceByTrial(product, qtries < 3 ? qtries : 3);
+            kq->PlaceByTrial(product, qtries, 0.975);
         }
         static const int tries = getenv("RAMD_PLACE_TRIES") ? atoi(getenv("RAMD_PLACE_TRIES")) : 0; // (0: off)
-        if(tries > 0)
+        if(tries > 0 && _one_block<OperatorType, VectorType, ValueType>::value)
         {
             auto iteration = [&]() {
                 update();

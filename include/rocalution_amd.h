@@ -99,8 +99,9 @@ int ramd_vec_allocate_apart(ramd_vec_t v, int64_t n, ramd_vec_t other);
 int ramd_vec_place_apart(ramd_vec_t v, ramd_vec_t other, int* moved);
 /* ... and by trial: `run(ctx)` launches the kernels that use the vector on the current stream (return RAMD_OK); it is timed
  * with the vector in its own block and in up to `tries` fresh ones, and the vector moves to the fastest (contents kept; what
- * `run` does to other vectors is the caller's business).  stop_ratio = 0: always `tries` trials (`run` may talk to other
- * ranks); stop_ratio in (0, 1): stop once the best time is below stop_ratio x the worst one seen.  apart_from != NULL: the
+ * `run` does to other vectors is the caller's business).  `run` must not contain a collective: whether this rank has the
+ * memory for a candidate block is its own affair, and ranks leaving the trials at different points would hang the others
+ * (the solvers time kernels on the rank's own vectors only).  stop_ratio = 0: up to `tries` trials; stop_ratio in (0, 1): stop once the best time is below stop_ratio x the worst one seen.  apart_from != NULL: the
  * first candidates are drawn from the placement class that vector is not in.  No-op below 64 MiB.  Which pairs and triples
  * of big blocks stream well together is decided by their physical placement and is only partly predicted by the placement
  * class.  The fused CG and BiCGStab loops place the vectors their update kernels write this way at their first Solve, by
@@ -462,6 +463,9 @@ int ramd_comm_init_callback(int rank, int nranks, ramd_exchange_cb exchange, ram
 int ramd_comm_destroy(ramd_comm_t c);
 int ramd_comm_rank(ramd_comm_t c, int* rank);
 int ramd_comm_size(ramd_comm_t c, int* size);
+/* all-gather of `count` 64-bit integers per rank between HOST arrays (out[q * count ..] = rank q's): the setup exchanges of the
+ * distributed AMG -- what Communicator::AllGather / MPI_Allgather of src/utils/communicator.cpp do for parallel_manager.cpp */
+int ramd_comm_allgather_i64(ramd_comm_t c, const int64_t* mine, int count, int64_t* out);
 int ramd_comm_rccl_count(ramd_comm_t c, int* nranks); /* ncclCommCount of the data-plane communicator (0: callback transport) */
 /* in-place sum over all ranks of scalar slots [first, first+count) of the device record, queued on
  * the current stream (one call for ALL scalars of a fused reduction) */
@@ -482,7 +486,10 @@ int ramd_comm_allreduce_scalars(ramd_comm_t c, int first, int count);
  * ramd_comm_halo_release gives a plan's device buffers back (the owner of the plan calls it when it goes away). */
 int ramd_comm_halo_select(ramd_comm_t c, int npeers, const int* peers, const int64_t* send_offset,
                           const int64_t* recv_offset, int* allgather);
-int ramd_comm_halo_release(ramd_comm_t c, int plan);
+int ramd_comm_halo_release(ramd_comm_t c, int plan, long long generation);
+/* a number no other communicator of this process has or will have: the owner of a halo plan keeps it next to the plan number,
+ * so that a late release cannot hit a plan of a newer communicator that was allocated at the same address */
+int ramd_comm_generation(ramd_comm_t c, long long* generation);
 int ramd_comm_halo_begin(ramd_comm_t c, ramd_vec_t send, ramd_vec_t recv, int npeers, const int* peers,
                          const int64_t* send_offset, const int64_t* recv_offset);
 int ramd_comm_halo_begin_plan(ramd_comm_t c, int plan, ramd_vec_t send, ramd_vec_t recv, int npeers, const int* peers,

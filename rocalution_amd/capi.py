@@ -207,11 +207,13 @@ SIGNATURES = {
     "ramd_comm_destroy": (i32, [ptr]),
     "ramd_comm_rank": (i32, [ptr, pi32]),
     "ramd_comm_size": (i32, [ptr, pi32]),
+    "ramd_comm_allgather_i64": (i32, [ptr, pi64, i32, pi64]),
     "ramd_comm_allreduce_scalars": (i32, [ptr, i32, i32]),
     "ramd_comm_halo_select": (i32, [ptr, i32, pi32, pi64, pi64, pi32]),
     "ramd_comm_halo_begin": (i32, [ptr, vec_t, vec_t, i32, pi32, pi64, pi64]),
     "ramd_comm_halo_begin_plan": (i32, [ptr, i32, vec_t, vec_t, i32, pi32, pi64, pi64]),
-    "ramd_comm_halo_release": (i32, [ptr, i32]),
+    "ramd_comm_halo_release": (i32, [ptr, i32, i64]),
+    "ramd_comm_generation": (i32, [ptr, pi64]),
     "ramd_comm_halo_end": (i32, [ptr]),
     # solver layer
     "ramd_solver_create": (i32, [i32, i32, i32, C.POINTER(ptr)]),

@@ -1465,27 +1465,21 @@ __global__ __launch_bounds__(kBlock) void k_pmis_add_unassigned_global(int nrow,
     }
 }
 
-// exclusive prefix of one count per rank (an all-reduce of one indicator slot per rank) and the total
+// exclusive prefix of one count per rank (an all-gather) and the total
 static int ranks_prefix(ramd_comm_t comm, int64_t mine, int64_t* before, int64_t* total)
 {
     int rank = 0, size = 1;
     RAMD_TRY(ramd_comm_rank(comm, &rank));
     RAMD_TRY(ramd_comm_size(comm, &size));
-    const int cap = 48, first = RAMD_NSCALARS - 8 - cap;
-    if(size > cap)
-        RAMD_FAIL(RAMD_ERR_UNSUPPORTED, "more ranks than scalar slots of the setup exchanges");
-    for(int k = 0; k < size; ++k)
-        RAMD_TRY(ramd_scalars_set(first + k, k == rank ? (double)mine : 0.0));
-    RAMD_TRY(ramd_comm_allreduce_scalars(comm, first, size));
-    double v[48];
-    RAMD_TRY(ramd_scalars_fetch(v, first, size));
+    std::vector<int64_t> v((size_t)size, 0);
+    RAMD_TRY(ramd_comm_allgather_i64(comm, &mine, 1, v.data()));
     *before = 0;
     *total  = 0;
     for(int k = 0; k < size; ++k)
     {
         if(k < rank)
-            *before += (int64_t)std::llround(v[k]);
-        *total += (int64_t)std::llround(v[k]);
+            *before += v[(size_t)k];
+        *total += v[(size_t)k];
     }
     return RAMD_OK;
 }

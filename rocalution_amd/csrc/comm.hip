@@ -18,6 +18,7 @@
 
 #include <rccl/rccl.h>
 
+#include <mutex>
 #include <set>
 #include <vector>
 
@@ -52,6 +53,7 @@ struct ramd_comm_s
         void*   d_all  = nullptr; // [size * M] the gathered buffers
     };
     std::vector<AgPlan> ag;
+    long long           generation = 0; // unique per communicator of this process (a later one may reuse this one's address)
     int                 select_calls = 0; // ramd_comm_halo_select calls so far (collective: equal on every rank)
 };
 
@@ -81,11 +83,19 @@ static std::set<const ramd_comm_s*>& live_comms()
     static std::set<const ramd_comm_s*> s;
     return s;
 }
+static std::mutex& live_comms_mutex()
+{
+    static std::mutex m;
+    return m;
+}
 
 static int comm_common_init(ramd_comm_s* c)
 {
     RAMD_HIP(hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
     RAMD_HIP(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
+    static long long next_generation = 0;
+    std::lock_guard<std::mutex> lock(live_comms_mutex());
+    c->generation = ++next_generation;
     live_comms().insert(c);
     return RAMD_OK;
 }
@@ -164,7 +174,10 @@ int ramd_comm_destroy(ramd_comm_t c)
         (void)hipHostFree(c->h_send);
     if(c->h_recv)
         (void)hipHostFree(c->h_recv);
-    live_comms().erase(c);
+    {
+        std::lock_guard<std::mutex> lock(live_comms_mutex());
+        live_comms().erase(c);
+    }
     for(auto& pl : c->ag)
     {
         dev_free(&pl.d_idx);
@@ -186,6 +199,23 @@ int ramd_comm_size(ramd_comm_t c, int* size)
 {
     *size = c ? c->size : 1;
     return RAMD_OK;
+}
+
+static int comm_allgather_host(ramd_comm_s* c, const int64_t* mine, int count, int64_t* out);
+// every rank contributes `count` 64-bit integers; out[q * count ..] = rank q's (host arrays).  The setup exchanges of the
+// distributed AMG (row / aggregate offsets in rank order, message lengths between any two ranks) use it: any number of ranks,
+// one collective.
+int ramd_comm_allgather_i64(ramd_comm_t c, const int64_t* mine, int count, int64_t* out)
+{
+    if(!c || !mine || !out || count < 1)
+        RAMD_FAIL(RAMD_ERR_ARG, "ramd_comm_allgather_i64: bad arguments");
+    if(c->size == 1)
+    {
+        for(int k = 0; k < count; ++k)
+            out[k] = mine[k];
+        return RAMD_OK;
+    }
+    return comm_allgather_host(c, mine, count, out);
 }
 
 int ramd_comm_rccl_count(ramd_comm_t c, int* nranks)
@@ -400,11 +430,24 @@ int ramd_comm_halo_select(ramd_comm_t c, int npeers, const int* peers, const int
     return RAMD_OK;
 }
 
-int ramd_comm_halo_release(ramd_comm_t c, int plan)
+int ramd_comm_generation(ramd_comm_t c, long long* generation)
+{
+    if(!c || !generation)
+        RAMD_FAIL(RAMD_ERR_ARG, "ramd_comm_generation: bad arguments");
+    *generation = c->generation;
+    return RAMD_OK;
+}
+
+int ramd_comm_halo_release(ramd_comm_t c, int plan, long long generation)
 {
     // (the owner of a plan may outlive the communicator: a destroyed one has already given everything back)
-    if(!c || plan <= 0 || !live_comms().count(c))
-        return RAMD_OK;
+    // (the owner of a plan may outlive its communicator, and a later communicator may sit at the same address: the plan is
+    //  released only in the communicator it was announced in)
+    {
+        std::lock_guard<std::mutex> lock(live_comms_mutex());
+        if(!c || plan <= 0 || !live_comms().count(c) || c->generation != generation)
+            return RAMD_OK;
+    }
     for(size_t i = 0; i < c->ag.size(); ++i)
         if(c->ag[i].id == plan)
         {

@@ -648,8 +648,8 @@ int ramd_vec_place_apart(ramd_vec_t v, ramd_vec_t other, int* moved)
 
 // Placement by trial: `run` launches the kernels that use the vector (on the current stream, any number of them); it is
 // timed with the vector in its own block and in up to `tries` fresh ones, and the vector moves to the fastest (contents
-// kept).  stop_ratio = 0: always `tries` trials -- `run` may contain exchanges with other ranks, which then run it equally
-// often.  stop_ratio in (0, 1), for a `run` without such exchanges: the kernels run at one of a few discrete speeds, and
+// kept).  `run` must not contain a collective (a rank that is short of memory tries fewer candidates than the others).
+// stop_ratio = 0: up to `tries` trials.  stop_ratio in (0, 1): the kernels run at one of a few discrete speeds, and
 // the search ends as soon as the best time is below stop_ratio x the worst one seen (a fresh GiB costs up to 100 ms).
 int ramd_vec_place_by_trial(ramd_vec_t v, ramd_trial_cb run, void* ctx, int tries, double stop_ratio, ramd_vec_t apart_from,
                             int* moved)
