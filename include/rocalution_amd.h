@@ -230,7 +230,7 @@ int ramd_mat_lu_analyse_clear(ramd_mat_t m); /* :346 */
 int ramd_mat_lu_solve(ramd_mat_t m, ramd_vec_t in, ramd_vec_t out); /* :349 */
 /* statistics of the triangular-solve plans of the most recent LUAnalyse / LAnalyse / UAnalyse of this process (a measurement
  * hook, no reference counterpart; which = 0 lower, 1 upper).  out[0] form: 1 level-scheduled rows, 2 box tiles in record
- * form, 3 box tiles with row groups, 4 lattice pencils; [1] rows; [2] dependency levels; [3] tiles / pencils; [4] steps of all
+ * form, 3 box tiles with row groups, 4 lattice pencils, 5 level-scheduled rows walked by one workgroup (deep, narrow graphs); [1] rows; [2] dependency levels; [3] tiles / pencils; [4] steps of all
  * tiles; [5] values handed from tile to tile per solve; [6] most rows of a tile; [7] longest triangular row; [8] lanes per row;
  * [9..11] box edges in the three dependency coordinates (lattice: nx, ny, nz); [12] bytes of the plan (lattice form) / for
  * form 1 the reason the box-tile form was not taken: 1 no chains of consecutively numbered dependent rows, 2 no dependencies,

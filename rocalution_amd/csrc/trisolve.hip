@@ -367,6 +367,224 @@ __global__ __launch_bounds__(kBlock) void k_trsv(int nrow, const int* __restrict
     } while(__ballot(!fin) != 0ull);
 }
 
+// ---------------------------------------------------------------- band form: ONE workgroup walks the levels
+// The level-scheduled kernel above pays a cross-CU hand-off per dependency level (~9 us with rows of 35 entries).  That is the
+// right trade where a level holds thousands of rows; it is a disaster on a DEEP and NARROW dependency graph that the box tiles
+// cannot take -- a shell mesh numbered by reverse Cuthill-McKee or by an advancing front has ~10 700 levels of ~140 rows and
+// no chains of consecutively numbered rows for the tile coordinates to grow along: 95 ms per triangle, GMRES(30)+ILU(0) at
+// 5 it/s, slower than the host (profiles/r05_shell_variants.json).  A level of 140 rows does not need 256 CUs; it needs the
+// next level to start the moment this one ends.  So ONE workgroup (512 threads, one CU) walks the whole plan in position order:
+//   * rounds of 256 positions, two lanes per row with up to 24 entries each (rows of up to 48 entries); the row data of the
+//     NEXT round is requested into registers while the levels of this round run (what a thread loads does not depend on the
+//     solution, only on its position: the assignment thread -> position is static);
+//   * the levels inside a round (positions are sorted by level) run one after the other behind a workgroup barrier -- ~0.1 us
+//     instead of a trip through the L2 -- every lane forming its products at once and the two lanes of a row subtracting them
+//     in storage order, the second lane continuing the first one's sum (DPP): the operations of the host loop in its order;
+//   * the solution of the last 8192 positions lives in an LDS window (a row's dependencies are gathered there; older ones,
+//     beyond the window, from w in memory -- written by this workgroup itself, visible to it behind the barrier).
+// The plan arrays are those of the level-scheduled form (k_tri_fill), plus the level of every position.
+constexpr int kBandThreads = 512, kBandGroups = 2, kBandRows = kBandThreads / kBandGroups / 2, kBandW = 24, kBandWin = 16384;
+template <typename T>
+__device__ __forceinline__ T band_from_lane_before(T v); // value of lane - 1 (pairs never cross a row of 16 lanes)
+template <>
+__device__ __forceinline__ double band_from_lane_before<double>(double v)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x111, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x111, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <>
+__device__ __forceinline__ float band_from_lane_before<float>(float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x111, 0xf, 0xf, true));
+}
+
+// (two groups of 256 threads take the rounds of 128 positions in turn: while one group runs the levels of its round, the
+//  other one's requests for the next round are in flight -- one register buffer per thread, every index static)
+template <typename T, int DMODE>
+__global__ __launch_bounds__(kBandThreads) void k_trsv_band(int nrow, const int* __restrict__ slice_off, const int* __restrict__ ecol,
+                                                           const T* __restrict__ eval, const T* __restrict__ diag,
+                                                           const int* __restrict__ plev, const T* __restrict__ rhs_src,
+                                                           const int* __restrict__ rhs_idx, T* w, T* __restrict__ out,
+                                                           const int* __restrict__ order, int dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) char band_lds[];
+    T*        win = reinterpret_cast<T*>(band_lds);
+    const int g = threadIdx.x / (kBandThreads / kBandGroups), t = threadIdx.x % (kBandThreads / kBandGroups);
+    const int q = t >> 1, h = t & 1;
+    int       cbuf[kBandW];
+    T         abuf[kBandW];
+    T         rhs = (T)0, dg = (T)1;
+    int       mylev = -1, onat = 0;
+    // what the requests of a row hang on -- its slice's offsets, where its right-hand side sits -- is read one turn earlier
+    // still.  (Macros, not lambdas: captured by reference these scalars were kept in scratch memory, and a scratch store of
+    // a loaded value is a drain of the whole memory queue once per round.)
+    int n_b0 = 0, n_wd = 0, n_ridx = 0, n_lev = -1, n_onat = 0;
+    T   n_dg = (T)1;
+#define BAND_LOOK_AHEAD(ROUND)                                               \
+    do                                                                       \
+    {                                                                        \
+        const int64_t p_ = (int64_t)(ROUND)*kBandRows + q;                   \
+        const bool    in_ = p_ < nrow;                                       \
+        const int64_t pp_ = in_ ? p_ : 0;                                    \
+        n_b0   = slice_off[pp_ >> 6];                                        \
+        n_wd   = in_ ? (slice_off[(pp_ >> 6) + 1] - n_b0) >> 6 : 0;          \
+        n_ridx = rhs_idx[pp_];                                               \
+        n_lev  = in_ ? plev[pp_] : -1;                                       \
+        n_dg   = DMODE == 0 ? (T)1 : diag[pp_];                              \
+        n_onat = out ? order[pp_] : 0;                                       \
+    } while(0)
+#define BAND_REQUEST(ROUND)                                                                              \
+    do                                                                                                   \
+    {                                                                                                    \
+        const int64_t  p_  = (int64_t)(ROUND)*kBandRows + q;                                             \
+        const unsigned o_  = (unsigned)(n_b0 + h * kBandW * 64 + (int)(p_ & 63));                        \
+        const int      nw_ = (dbg & 1) ? 0 : n_wd - h * kBandW; /* entries of my half (0 beyond the last row) */ \
+        mylev = n_lev;                                                                                   \
+        dg    = n_dg;                                                                                    \
+        onat  = n_onat;                                                                                  \
+        _Pragma("unroll") for(int e = 0; e < kBandW; ++e)                                                \
+        {                                                                                                \
+            cbuf[e] = e < nw_ ? nt_load(ecol + (o_ + (unsigned)(e * 64))) : -1;                          \
+            abuf[e] = e < nw_ ? nt_load(eval + (o_ + (unsigned)(e * 64))) : (T)0;                        \
+        }                                                                                                \
+        rhs = rhs_src[n_ridx];                                                                           \
+    } while(0)
+    const int nrounds = (nrow + kBandRows - 1) / kBandRows;
+    if(g < nrounds)
+    {
+        BAND_LOOK_AHEAD(g);
+        BAND_REQUEST(g);
+    }
+    if(g + kBandGroups < nrounds)
+        BAND_LOOK_AHEAD(g + kBandGroups);
+    // (positions are sorted by level: a round's levels are those of its first and last position, read a round ahead)
+    int nlev0 = plev[0], nlev1 = plev[min(kBandRows, nrow) - 1];
+    for(int round = 0; round < nrounds; ++round)
+    {
+        const int  base = round * kBandRows;
+        const int  lev0 = nlev0, lev1 = nlev1;
+        if(round + 1 < nrounds)
+        {
+            nlev0 = plev[base + kBandRows];
+            nlev1 = plev[min(base + 2 * kBandRows, nrow) - 1];
+        }
+        const bool mine = (round % kBandGroups) == g;
+        const int  pl   = base + q;
+        for(int lev = lev0; lev <= lev1; ++lev)
+        {
+            if(mine && mylev == lev && !(dbg & 2))
+            {
+                // (the products overwrite the values: a row is used once; eight gathers at a time)
+                const int thr = base + kBandRows - kBandWin; // older positions have left the window
+#pragma unroll
+                for(int e0 = 0; e0 < kBandW; e0 += 8)
+                {
+                    T    x[8];
+                    bool far = false;
+#pragma unroll
+                    for(int e = 0; e < 8; ++e)
+                    {
+                        const int c = cbuf[e0 + e];
+                        x[e]        = c >= 0 ? win[c & (kBandWin - 1)] : (T)0;
+                        far         = far || (c >= 0 && c < thr);
+                    }
+                    if(__any(far)) // (a dependency farther back than the window: from memory, past the L1)
+                    {
+#pragma unroll
+                        for(int e = 0; e < 8; ++e)
+                        {
+                            const int c = cbuf[e0 + e];
+                            if(c >= 0 && c < thr)
+                                x[e] = Sentinel<T>::from_bits(poll_load(w + c));
+                        }
+                    }
+#pragma unroll
+                    for(int e = 0; e < 8; ++e)
+                        abuf[e0 + e] = abuf[e0 + e] * x[e];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                T sum = rhs;
+                if(h == 0)
+                {
+#pragma unroll
+                    for(int e = 0; e < kBandW; ++e)
+                        if(cbuf[e] >= 0)
+                            sum -= abuf[e];
+                }
+                const T first = band_from_lane_before<T>(sum);
+                if(h == 1)
+                {
+                    sum = first;
+#pragma unroll
+                    for(int e = 0; e < kBandW; ++e)
+                        if(cbuf[e] >= 0)
+                            sum -= abuf[e];
+                    if(DMODE == 1)
+                        sum /= dg;
+                    else if(DMODE == 2)
+                        sum = sum * dg;
+                    win[pl & (kBandWin - 1)] = sum;
+                    w[pl]                    = sum;
+                    if(out)
+                        out[onat] = sum;
+                }
+            }
+            // the waves share the LDS window only: wait for the LDS, not for memory -- __syncthreads() drains the vector memory
+            // queue as well, i.e. every level would wait for the requests of the next round and for its own stores (2 us per
+            // level instead of 0.3).  What is read from w in memory was stored more than 16000 positions ago.
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if(mine && round + kBandGroups < nrounds)
+        {
+            BAND_REQUEST(round + kBandGroups);
+            if(round + 2 * kBandGroups < nrounds)
+                BAND_LOOK_AHEAD(round + 2 * kBandGroups);
+        }
+    }
+#undef BAND_REQUEST
+#undef BAND_LOOK_AHEAD
+}
+
+__global__ void k_ct_gather_int(int64_t n, const int* __restrict__ src, const int* __restrict__ idx, int* __restrict__ dst);
+// entries of a level plan whose dependency lies farther back than the window of k_trsv_band (diagnostics)
+__global__ __launch_bounds__(kBlock) void k_band_far(int n, const int* __restrict__ slice_off, const int* __restrict__ ecol,
+                                                     unsigned long long* __restrict__ out)
+{
+    const int64_t      gsz = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long far = 0, all = 0;
+    for(int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gsz)
+    {
+        const int b0 = slice_off[p >> 6], wd = (slice_off[(p >> 6) + 1] - b0) >> 6;
+        for(int k = 0; k < wd; ++k)
+        {
+            const int c = ecol[b0 + k * 64 + (int)(p & 63)];
+            if(c >= 0)
+            {
+                ++all;
+                far += ((int)p - c > kBandWin - 2 * kBandRows) ? 1 : 0;
+            }
+        }
+    }
+    if(far)
+        atomicAdd(out, far);
+    if(all)
+        atomicAdd(out + 1, all);
+}
+// widest slice (entries per row) of a level plan
+__global__ __launch_bounds__(kBlock) void k_band_maxw(int nslices, const int* __restrict__ slice_off, int* __restrict__ out)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    int           mx  = 0;
+    for(int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nslices; s += gsz)
+        mx = max(mx, (slice_off[s + 1] - slice_off[s]) >> 6);
+#pragma unroll
+    for(int off = 32; off > 0; off >>= 1)
+        mx = max(mx, __shfl_xor(mx, off, 64));
+    if((threadIdx.x & 63) == 0 && mx > 0)
+        atomicMax(out, mx);
+}
+
 // ---------------------------------------------------------------- ILU(0), natural order, sync-free
 // host_matrix_csr.cpp:2096-2171.  Thread per row; a row waits for every pivot row k < i of its
 // pattern (flag done[k]), scales a_ik, and subtracts a_ik * a_kj from its own entries that exist
@@ -716,6 +934,9 @@ struct TriPlan
     // lattice form (trsv_lattice.hip): the triangle of a 5- / 7-point lattice operator, pencils marched along x; such a plan
     // has no order / pos / w -- it reads and writes natural-order vectors
     LatPlan* lat = nullptr;
+    // band form (k_trsv_band): a deep, narrow dependency graph walked by one workgroup; the level of every position
+    bool band      = false;
+    int* band_plev = nullptr;
     // what the analysis found (ramd_tri_plan_stats): chains, external values of all tiles, box edges
     int       st_chains = 0, st_box[3] = {0, 0, 0};
     int       st_why    = 0; // why this plan is not in box-tile form (ct_why_text)
@@ -723,6 +944,8 @@ struct TriPlan
     void  release()
     {
         lat_release(&lat);
+        dev_free(&band_plev);
+        band = false;
         dev_free(&ct_tile_step);
         dev_free(&ct_step_pos);
         dev_free(&ct_step_ent);
@@ -1107,6 +1330,55 @@ static int build_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bool 
     }
     P->nlevels = nlev;
     dev_free(&nodiag);
+    // deep and narrow (fewer than 1024 rows per level on average), rows of at most 48 entries: the band form
+    // (RAMD_TRSV_BAND = 0: off, 2: whatever the shape -- tests)
+    const int band_env = getenv("RAMD_TRSV_BAND") ? atoi(getenv("RAMD_TRSV_BAND")) : 1;
+    if(s == RAMD_OK && !natural && band_env != 0 && nlev > 0 && (band_env == 2 || (n >= 4096 && (int64_t)n < (int64_t)1024 * nlev)))
+    {
+        int* lvl  = nullptr;
+        int  nl2  = 0, maxw = 0;
+        int* dmax = nullptr;
+        s = level_order(m, st, lower, nullptr, &nl2, &lvl);
+        if(s == RAMD_OK)
+            s = dev_alloc(&dmax, 1);
+        if(s == RAMD_OK)
+        {
+            hipError_t e = hipMemsetAsync(dmax, 0, sizeof(int), b.cur);
+            hipLaunchKernelGGL(k_band_maxw, dim3(ew_grid(P->nslices)), dim3(kBlock), 0, b.cur, P->nslices, P->slice_off, dmax);
+            if(e == hipSuccess)
+                e = hipMemcpyAsync(&maxw, dmax, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+            if(e == hipSuccess)
+                e = hipStreamSynchronize(b.cur);
+            if(e != hipSuccess)
+                s = RAMD_ERR_HIP;
+        }
+        if(s == RAMD_OK && maxw <= 2 * kBandW)
+        {
+            s = dev_alloc(&P->band_plev, n);
+            if(s == RAMD_OK)
+            {
+                hipLaunchKernelGGL(k_ct_gather_int, dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, (int64_t)n, lvl, P->order, P->band_plev);
+                P->band = hipGetLastError() == hipSuccess && hipStreamSynchronize(b.cur) == hipSuccess;
+            }
+        }
+        dev_free(&lvl);
+        dev_free(&dmax);
+        static const bool verbose = getenv("RAMD_TRSV_CT_VERBOSE") != nullptr;
+        if(verbose && s == RAMD_OK)
+        {
+            unsigned long long *dfar = nullptr, hfar[2] = {0, 0};
+            if(dev_alloc(&dfar, 2) == RAMD_OK && hipMemsetAsync(dfar, 0, 16, b.cur) == hipSuccess)
+            {
+                hipLaunchKernelGGL(k_band_far, dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, P->slice_off, P->ecol, dfar);
+                (void)hipMemcpyAsync(hfar, dfar, 16, hipMemcpyDeviceToHost, b.cur);
+                (void)hipStreamSynchronize(b.cur);
+            }
+            dev_free(&dfar);
+            fprintf(stderr, "band plan (%s): n=%d levels=%d (%.0f rows per level), longest row %d, %.3f %% of the dependencies beyond the window%s\n",
+                    lower ? "lower" : "upper", n, nlev, (double)n / nlev, maxw, hfar[1] ? 100.0 * (double)hfar[0] / (double)hfar[1] : 0.0,
+                    P->band ? "" : ": rows too long, level-scheduled form");
+        }
+    }
     if(s != RAMD_OK)
         P->release();
     return s;
@@ -4094,6 +4366,27 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
     Backend& b = backend();
     if(P->n == 0)
         return RAMD_OK;
+    if(P->band)
+    {
+        // one workgroup walks the levels (k_trsv_band): nothing is polled, so w needs no sentinels
+        const size_t lds = (size_t)kBandWin * sizeof(T);
+        static const int band_dbg = getenv("RAMD_BAND_DBG") ? atoi(getenv("RAMD_BAND_DBG")) : 0; // (tools/: 1 no entries, 2 no arithmetic)
+        prof_begin(RAMD_PROF_TRSV, b.cur);
+#define TRSV_BAND(DM)                                                                                                          \
+    hipLaunchKernelGGL((k_trsv_band<T, DM>), dim3(1), dim3(kBandThreads), lds, b.cur, P->n, P->slice_off, P->ecol, (const T*)P->eval, \
+                       (const T*)P->diag, P->band_plev, rhs_src, rhs_idx, (T*)P->w, out, P->order, band_dbg)
+        if(mul_inv_diag)
+            TRSV_BAND(2);
+        else if(unit)
+            TRSV_BAND(0);
+        else
+            TRSV_BAND(1);
+#undef TRSV_BAND
+        prof_end(RAMD_PROF_TRSV, b.cur);
+        P->w_sentinel = P->prefilled_next = false;
+        RAMD_HIP(hipGetLastError());
+        return RAMD_OK;
+    }
     const unsigned nb = nblocks_of(P->n);
     static const bool nofill = getenv("RAMD_TRSV_NOFILL") != nullptr; // diagnostic only (tools/): no dependency waits
     if((!nofill || !P->filled_once) && !own_fill_done && !P->w_sentinel)
@@ -5666,7 +5959,7 @@ static void tri_note_stats(const ramd_mat_s* m, const TriPlan* P, int which)
         o[12] = (long long)(li.coef_bytes + li.face_bytes);
         return;
     }
-    o[0] = !P->ct ? 1 : (P->ct_grp ? 3 : 2);
+    o[0] = !P->ct ? (P->band ? 5 : 1) : (P->ct_grp ? 3 : 2);
     o[2] = P->nlevels;
     o[12] = P->ct ? 0 : P->st_why;
     o[7] = P->ct_wmax;
