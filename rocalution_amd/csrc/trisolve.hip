@@ -398,9 +398,48 @@ __device__ __forceinline__ float band_from_lane_before<float>(float v)
 {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x111, 0xf, 0xf, true));
 }
+// The requests of the kernel are issued by hand and waited for by COUNT (as in trsv_lattice.hip): left to the compiler, the
+// loop around them got a vmcnt(0) per round -- every round waited for the requests just issued for the round after next,
+// 1.35 us per step where a barrier step of one workgroup costs 0.1-0.25 us (tools/onewg.hip).
+__device__ __forceinline__ int band_ld(const int* p)
+{
+    int r;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+__device__ __forceinline__ double band_ld(const double* p)
+{
+    double r;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+__device__ __forceinline__ float band_ld(const float* p)
+{
+    float r;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+__device__ __forceinline__ void band_st(double* p, double v)
+{
+    asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void band_st(float* p, float v)
+{
+    asm volatile("global_store_dword %0, %1, off\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void band_wait()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <typename X>
+__device__ __forceinline__ void band_tie(X& v)
+{
+    asm volatile("" : "+v"(v));
+}
 
 // (two groups of 256 threads take the rounds of 128 positions in turn: while one group runs the levels of its round, the
-//  other one's requests for the next round are in flight -- one register buffer per thread, every index static)
+//  other one's requests for its next round are in flight -- one register buffer per thread, every index static)
 template <typename T, int DMODE>
 __global__ __launch_bounds__(kBandThreads) void k_trsv_band(int nrow, const int* __restrict__ slice_off, const int* __restrict__ ecol,
                                                            const T* __restrict__ eval, const T* __restrict__ diag,
@@ -412,65 +451,102 @@ __global__ __launch_bounds__(kBandThreads) void k_trsv_band(int nrow, const int*
     T*        win = reinterpret_cast<T*>(band_lds);
     const int g = threadIdx.x / (kBandThreads / kBandGroups), t = threadIdx.x % (kBandThreads / kBandGroups);
     const int q = t >> 1, h = t & 1;
+    T* const  dump = w + nrow + (threadIdx.x & 15); // (inside the allocation's padding: what lanes without a result store)
     int       cbuf[kBandW];
     T         abuf[kBandW];
-    T         rhs = (T)0, dg = (T)1;
-    int       mylev = -1, onat = 0;
-    // what the requests of a row hang on -- its slice's offsets, where its right-hand side sits -- is read one turn earlier
-    // still.  (Macros, not lambdas: captured by reference these scalars were kept in scratch memory, and a scratch store of
-    // a loaded value is a drain of the whole memory queue once per round.)
-    int n_b0 = 0, n_wd = 0, n_ridx = 0, n_lev = -1, n_onat = 0;
+    T         rhs = (T)0, dg = (T)1, res = (T)0;
+    int       mylev = -1, onat = 0, nw = 0;
+    bool      have = false;
+    // what the requests of a row hang on -- its slice's offsets, where its right-hand side sits -- is read one turn earlier still
+    int n_b0 = 0, n_b1 = 0, n_ridx = 0, n_lev = -1, n_onat = 0;
     T   n_dg = (T)1;
+    // ... and with it the levels of the two rounds before that row's: a round's levels are those of its first and last
+    // position (positions are sorted by level).  Vector loads like the rest: a SCALAR load in flight would be waited for by
+    // the lgkmcnt(0) in front of every barrier (LDS and scalar memory share that counter) -- a round trip per round.
+    int n_l10 = 0, n_l11 = 0, n_l20 = 0, n_l21 = 0;
+    constexpr int kOpsLA = 10; // vector memory operations of a look-ahead
 #define BAND_LOOK_AHEAD(ROUND)                                               \
     do                                                                       \
     {                                                                        \
-        const int64_t p_ = (int64_t)(ROUND)*kBandRows + q;                   \
-        const bool    in_ = p_ < nrow;                                       \
-        const int64_t pp_ = in_ ? p_ : 0;                                    \
-        n_b0   = slice_off[pp_ >> 6];                                        \
-        n_wd   = in_ ? (slice_off[(pp_ >> 6) + 1] - n_b0) >> 6 : 0;          \
-        n_ridx = rhs_idx[pp_];                                               \
-        n_lev  = in_ ? plev[pp_] : -1;                                       \
-        n_dg   = DMODE == 0 ? (T)1 : diag[pp_];                              \
-        n_onat = out ? order[pp_] : 0;                                       \
+        const int64_t p_  = (int64_t)(ROUND)*kBandRows + q;                  \
+        const int64_t pp_ = p_ < nrow ? p_ : 0;                              \
+        n_b0   = band_ld(slice_off + (pp_ >> 6));                            \
+        n_b1   = band_ld(slice_off + (pp_ >> 6) + 1);                        \
+        n_ridx = band_ld(rhs_idx + pp_);                                     \
+        n_lev  = band_ld(plev + pp_);                                        \
+        n_dg   = band_ld(DMODE == 0 ? rhs_src : diag + pp_);                 \
+        n_onat = band_ld(out ? order + pp_ : plev);                          \
+        const int r1_ = max((ROUND)-1, 0), r2_ = (ROUND);                    \
+        n_l10 = band_ld(plev + min((int64_t)r1_ * kBandRows, (int64_t)nrow - 1));        \
+        n_l11 = band_ld(plev + (min(((int64_t)r1_ + 1) * kBandRows, (int64_t)nrow) - 1)); \
+        n_l20 = band_ld(plev + min((int64_t)r2_ * kBandRows, (int64_t)nrow - 1));        \
+        n_l21 = band_ld(plev + (min(((int64_t)r2_ + 1) * kBandRows, (int64_t)nrow) - 1)); \
     } while(0)
+#define BAND_TIE_LA()      \
+    do                     \
+    {                      \
+        band_tie(n_b0);    \
+        band_tie(n_b1);    \
+        band_tie(n_ridx);  \
+        band_tie(n_lev);   \
+        band_tie(n_dg);    \
+        band_tie(n_onat);  \
+        band_tie(n_l10);   \
+        band_tie(n_l11);   \
+        band_tie(n_l20);   \
+        band_tie(n_l21);   \
+    } while(0)
+    // (2 kBandW + 1 operations; entries beyond the row read the row's first one and are masked when the data is taken over)
 #define BAND_REQUEST(ROUND)                                                                              \
     do                                                                                                   \
     {                                                                                                    \
         const int64_t  p_  = (int64_t)(ROUND)*kBandRows + q;                                             \
-        const unsigned o_  = (unsigned)(n_b0 + h * kBandW * 64 + (int)(p_ & 63));                        \
-        const int      nw_ = (dbg & 1) ? 0 : n_wd - h * kBandW; /* entries of my half (0 beyond the last row) */ \
-        mylev = n_lev;                                                                                   \
-        dg    = n_dg;                                                                                    \
+        const unsigned o_  = (unsigned)(n_b0 + (int)(p_ & 63));                                          \
+        nw    = (p_ < nrow && !(dbg & 1)) ? ((n_b1 - n_b0) >> 6) - h * kBandW : 0;                       \
+        have  = p_ < nrow;                                                                               \
+        mylev = have ? n_lev : -1;                                                                       \
+        dg    = DMODE == 0 ? (T)1 : n_dg;                                                                \
         onat  = n_onat;                                                                                  \
         _Pragma("unroll") for(int e = 0; e < kBandW; ++e)                                                \
         {                                                                                                \
-            cbuf[e] = e < nw_ ? nt_load(ecol + (o_ + (unsigned)(e * 64))) : -1;                          \
-            abuf[e] = e < nw_ ? nt_load(eval + (o_ + (unsigned)(e * 64))) : (T)0;                        \
+            const unsigned oe_ = e < nw ? o_ + (unsigned)((h * kBandW + e) * 64) : o_;                   \
+            cbuf[e] = band_ld(ecol + oe_);                                                               \
+            abuf[e] = band_ld(eval + oe_);                                                               \
         }                                                                                                \
-        rhs = rhs_src[n_ridx];                                                                           \
+        rhs = band_ld(rhs_src + n_ridx);                                                                 \
     } while(0)
     const int nrounds = (nrow + kBandRows - 1) / kBandRows;
-    if(g < nrounds)
-    {
-        BAND_LOOK_AHEAD(g);
-        BAND_REQUEST(g);
-    }
-    if(g + kBandGroups < nrounds)
-        BAND_LOOK_AHEAD(g + kBandGroups);
-    // (positions are sorted by level: a round's levels are those of its first and last position, read a round ahead)
-    int nlev0 = plev[0], nlev1 = plev[min(kBandRows, nrow) - 1];
+    BAND_LOOK_AHEAD(g);
+    band_wait<0>();
+    BAND_TIE_LA();
+    BAND_REQUEST(g);
+    BAND_LOOK_AHEAD(g + kBandGroups);
+    int lev0 = plev[0], lev1 = plev[min(kBandRows, nrow) - 1]; // (rounds 0 and 1: read here, before the pipeline starts)
+    int a_lev0 = plev[min(kBandRows, nrow - 1)], a_lev1 = plev[min(2 * kBandRows, nrow) - 1];
+    // (used here, so that the compiler waits for these four loads HERE: carried into the loop as "possibly in flight" they cost
+    //  a vmcnt(0) per round -- which for the idle half is a wait for the requests it has just issued)
+    lev0 = __builtin_amdgcn_readfirstlane(lev0), lev1 = __builtin_amdgcn_readfirstlane(lev1);
+    a_lev0 = __builtin_amdgcn_readfirstlane(a_lev0), a_lev1 = __builtin_amdgcn_readfirstlane(a_lev1);
+    int b_lev0 = a_lev0, b_lev1 = a_lev1;
     for(int round = 0; round < nrounds; ++round)
     {
         const int  base = round * kBandRows;
-        const int  lev0 = nlev0, lev1 = nlev1;
-        if(round + 1 < nrounds)
-        {
-            nlev0 = plev[base + kBandRows];
-            nlev1 = plev[min(base + 2 * kBandRows, nrow) - 1];
-        }
-        const bool mine = (round % kBandGroups) == g;
+        const bool mine = (round % kBandGroups) == g; // (uniform per wave: a group is four whole waves)
         const int  pl   = base + q;
+        if(mine)
+        {
+            // my row of this round has arrived: only the look-ahead behind it is younger
+            band_wait<kOpsLA>();
+#pragma unroll
+            for(int e = 0; e < kBandW; ++e)
+            {
+                band_tie(cbuf[e]);
+                band_tie(abuf[e]);
+                if(e >= nw)
+                    cbuf[e] = -1;
+            }
+            band_tie(rhs);
+        }
         for(int lev = lev0; lev <= lev1; ++lev)
         {
             if(mine && mylev == lev && !(dbg & 2))
@@ -525,24 +601,33 @@ __global__ __launch_bounds__(kBandThreads) void k_trsv_band(int nrow, const int*
                     else if(DMODE == 2)
                         sum = sum * dg;
                     win[pl & (kBandWin - 1)] = sum;
-                    w[pl]                    = sum;
-                    if(out)
-                        out[onat] = sum;
+                    res                      = sum;
                 }
             }
-            // the waves share the LDS window only: wait for the LDS, not for memory -- __syncthreads() drains the vector memory
-            // queue as well, i.e. every level would wait for the requests of the next round and for its own stores (2 us per
-            // level instead of 0.3).  What is read from w in memory was stored more than 16000 positions ago.
+            // the waves share the LDS window only: wait for the LDS, not for memory (__syncthreads() drains the vector memory
+            // queue as well).  What is read from w in memory was stored more than 16000 positions ago.
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
-        if(mine && round + kBandGroups < nrounds)
+        if(mine)
         {
+            // the round's results leave (every lane stores: the ones without a result into the padding), then the requests of
+            // my next round -- what they hang on was looked up a turn ago: only the two stores are younger -- and the next look-ahead
+            const bool st = have && h == 1;
+            band_st(st ? w + pl : dump, res);
+            band_st((st && out) ? out + onat : dump, res);
+            band_wait<2>();
+            BAND_TIE_LA();
+            a_lev0 = n_l10, a_lev1 = n_l11; // (the look-ahead that has just arrived: levels of the next two rounds)
+            b_lev0 = n_l20, b_lev1 = n_l21;
             BAND_REQUEST(round + kBandGroups);
-            if(round + 2 * kBandGroups < nrounds)
-                BAND_LOOK_AHEAD(round + 2 * kBandGroups);
+            BAND_LOOK_AHEAD(round + 2 * kBandGroups);
         }
+        lev0 = __builtin_amdgcn_readfirstlane(a_lev0), lev1 = __builtin_amdgcn_readfirstlane(a_lev1);
+        a_lev0 = b_lev0, a_lev1 = b_lev1;
     }
+    band_wait<0>();
 #undef BAND_REQUEST
+#undef BAND_TIE_LA
 #undef BAND_LOOK_AHEAD
 }
 
