@@ -77,6 +77,22 @@ def mcsgs_bytes(n, nnz, vbytes=8):
     return (4 + vbytes) * (nnz - n) + 5 * vbytes * n
 
 
+def mc_red_black(args, precond=None):
+    """does the MC-SGS apply of this run take the one-pass red-black lattice form (csrc/mcsgs.hip: k_mc_rb)?  SGS on the
+    two-colour lattice operator of the generators, unless RAMD_MC_RB=0"""
+    return ((precond or args.precond) == "mcsgs" and args.matrix == "poisson"
+            and os.environ.get("RAMD_MC_RB", "1") != "0")
+
+
+def mc_form(args, precond=None):
+    return ("k_mc_rb: both colours of a red-black lattice operator in one pass" if mc_red_black(args, precond)
+            else "k_mc_sweep: all colour sweeps of one apply")
+
+
+def mc_traffic_key(args, precond=None):
+    return "mcsgs_512" if mc_red_black(args, precond) else "mcsgs_512_sweeps"
+
+
 def physical_cores():
     ncpu = os.cpu_count() or 1
     try:
@@ -632,9 +648,9 @@ def main():
                 kernels["vector_updates"] = roof("k_mgs_step" if args.solver == "gmres" else "k_cg_update / k_cg_direction",
                                                  (32 if args.solver == "gmres" else 40) * n * vb // 8, p_vec)
         if args.precond in ("mcsgs", "mcgs", "mcilu") and pr0[PROF_PRECOND]["launches"] > 0:
-            kernels["precond_apply"] = roof("multi-coloured %s apply (k_mc_sweep: all colour sweeps of one apply)" % args.precond.upper()[2:],
+            kernels["precond_apply"] = roof("multi-coloured %s apply (%s)" % (args.precond.upper()[2:], mc_form(args)),
                                             mcsgs_bytes(n, nnz, vb), pr0[PROF_PRECOND],
-                                            traffic_for("mcsgs_512") if (args.matrix == "poisson" and N == 512 and not mixed) else None)
+                                            traffic_for(mc_traffic_key(args)) if (args.matrix == "poisson" and N == 512 and not mixed) else None)
         st_pat = C.c_int(0)
         capi.check(lib.ramd_mat_pattern_info(A._h, C.byref(st_pat), None, None))
         if st_pat.value in (1, 2) and args.format in ("csr", "ell", "hyb"):
@@ -664,8 +680,9 @@ def main():
                                                         trsv_bytes(n, nnz, 8), pe[PROF_TRSV], traffic_for("trsv_512") if big else None)
                         extras[name]["tri_plan"] = tp
                     if name == "bicgstab_mcsgs" and pe[PROF_PRECOND]["launches"] > 0:
-                        extras[name]["roofline"] = roof("multi-coloured SGS apply (k_mc_sweep: all colour sweeps of one apply)",
-                                                        mcsgs_bytes(n, nnz, 8), pe[PROF_PRECOND], traffic_for("mcsgs_512") if big else None)
+                        extras[name]["roofline"] = roof("multi-coloured SGS apply (%s)" % mc_form(args, "mcsgs"),
+                                                        mcsgs_bytes(n, nnz, 8), pe[PROF_PRECOND],
+                                                        traffic_for(mc_traffic_key(args, "mcsgs")) if big else None)
                     extras[name]["kernels"] = {"spmv": roof("CSR SpMV (k_csr_pat2 / k_csr_tr)", spmv_bytes(n, nnz, 8), pe[PROF_SPMV])}
                 except Exception as e:
                     extras[name] = dict(error=repr(e))

@@ -60,6 +60,13 @@ struct McsgsPlan
     bool  fold0    = false;
     void* dinv_nat = nullptr; // [n] inverse diagonal at the ORIGINAL row index (rows of colour 0)
     int*  nat_dict = nullptr; // [l_pat_n * kPatMaxW] original-index offset of a slot whose column has colour 0
+    // Red-black lattice form (k_mc_rb, SGS applies): the operator is a 7- / 5-point lattice operator and the two colours are the
+    // two parities of x + y + z.  ONE pass over both colours instead of a sweep per colour: see k_mc_rb.
+    bool  rb = false;
+    int   rb_nx = 0, rb_ny = 0, rb_nz = 0, rb_p0 = 0; // rb_p0: parity of the cells of colour 0
+    void* rb_val[2] = {nullptr, nullptr}; // per colour: [6][lines * hx] off-diagonal values, slot = ascending column offset
+    void* rb_d[2]   = {nullptr, nullptr}; // per colour: [lines * hx] diagonal / inverse diagonal
+    void* rb_di[2]  = {nullptr, nullptr};
     void  release()
     {
         dev_free(&pair_of);
@@ -69,6 +76,17 @@ struct McsgsPlan
             (void)cached_free(dinv_nat);
         dinv_nat = nullptr;
         fold0    = false;
+        for(int c = 0; c < 2; ++c)
+        {
+            void** ps2[] = {&rb_val[c], &rb_d[c], &rb_di[c]};
+            for(void** q : ps2)
+            {
+                if(*q)
+                    (void)cached_free(*q);
+                *q = nullptr;
+            }
+        }
+        rb = false;
         dev_free(&iperm);
         dev_free(&blk_of);
         dev_free(&l_off);
@@ -432,6 +450,315 @@ __global__ __launch_bounds__(kBlock) void k_mc_dinv_nat(int n0, const int* __res
         dinv_nat[iperm[t]] = dinv[t];
 }
 
+// ======================================================================= red-black lattice form
+// A two-colour SGS apply moves every natural-order stream (rhs, d, 1/d, out) twice at half density -- once per colour -- and
+// sends the second colour's values through memory between the sweeps: 15 GB per apply at 512^3 for values 48 + rhs 8 + d 8 +
+// 1/d 8 + out 8 = 80 bytes per row = 10.7 GB.  Where the operator is a 7- / 5-point lattice operator (every row has exactly the
+// neighbours r -+ 1, r -+ nx, r -+ nx ny its position allows) and the colours are the parities of x + y + z, ONE pass does it:
+// a workgroup owns a 128 x 16 (x, y) tile and a run of z planes and marches along z; per plane z it
+//   A. reads rhs of plane z + 2 on the tile + 2 cells around it: colour-0 cells become x0 = rhs * dinv, colour-1 cells keep rhs (LDS)
+//   B. forms the colour-1 values of plane z + 1 on the tile + 1 cell: s = rhs - sum a_k x0_k (ascending columns), s *= dinv, d, dinv
+//   C. forms the colour-0 values of plane z: s = x0 * d - sum a_k y1_k, s *= dinv; stores the plane's rows of out, both colours
+// with three planes of each kind in LDS.  The one-cell ring of colour-1 values around the tile is recomputed by every tile that
+// needs it (they depend on x0 only, which is elementwise): 14 % more colour-1 rows, no exchange between workgroups.  The tile is
+// WIDE because the arrays are read in 128-byte lines: a 32-wide tile reads one line per array and row and a second one for its
+// single ring cell of colour 1 (measured: 32 x 32 3.04 ms, 64 x 16 2.57, 128 x 8 2.43, 128 x 16 2.24 ms per apply at 512^3).
+// The operations per row are those of the two sweeps (preconditioner_multicolored_gs.cpp:127-215) in their order; the
+// values are stored per colour in the order of the cells along x (cell x of a line at x / 2), so that both colours read
+// whole lines.  A cell the lattice does not have contributes no term (masked, not multiplied by zero).
+constexpr int kRbTX = 128, kRbTY = 16, kRbAX = kRbTX + 4, kRbAY = kRbTY + 4, kRbBX = kRbTX + 2, kRbBY = kRbTY + 2, kRbPX = kRbAX + 1,
+              kRbPY = kRbBX + 1, kRbChunkMax = 64, kRbChunkMin = 16, kRbThreads = 512;
+struct RbDims
+{
+    int nx, ny, nz, hx, p0, tiles_x, tiles_y, chunks, chunk;
+};
+// The global loads of a stage do not depend on what the stages before it left in LDS, so they are issued one plane AHEAD, into
+// registers, right after the registers' previous contents were consumed: while a plane is computed, the loads of the next one
+// are in flight (a workgroup has 60 KB of LDS, two fit a CU -- occupancy alone would not hide three dependent round trips per
+// plane).  The barriers wait for LDS only (rb_barrier: __syncthreads() would drain the loads in flight as well).
+__device__ __forceinline__ int rb_clamp(int v, int hi)
+{
+    return min(max(v, 0), hi);
+}
+__device__ __forceinline__ void rb_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+template <typename T>
+__global__ __launch_bounds__(kRbThreads) void k_mc_rb(RbDims g, const T* __restrict__ val0, const T* __restrict__ val1,
+                                               const T* __restrict__ d0, const T* __restrict__ di0, const T* __restrict__ d1,
+                                               const T* __restrict__ di1, const T* __restrict__ rhs, T* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) char rb_lds[];
+    T* XR = reinterpret_cast<T*>(rb_lds); // [3][kRbAY][kRbPX]: x0 on colour-0 cells, rhs on colour-1 cells
+    T* Y1 = XR + 3 * kRbAY * kRbPX; // [3][kRbBY][kRbPY]: finished colour-1 values
+    constexpr int kAC = kRbAX * kRbAY, kBH = kRbBX / 2, kBC = kRbBY * kBH, kCH = kRbTX / 2, kCC = kRbTY * kCH;
+    constexpr int NA = (kAC + kRbThreads - 1) / kRbThreads, NB = (kBC + kRbThreads - 1) / kRbThreads, NC = (kCC + kRbThreads - 1) / kRbThreads;
+    const int tid = threadIdx.x;
+    // workgroup w runs on XCD w % 8: every XCD gets a contiguous run of tiles (the rings of neighbouring tiles meet in one L2)
+    int wg = blockIdx.x;
+    if(gridDim.x % 8 == 0)
+        wg = (wg % 8) * (int)(gridDim.x / 8) + wg / 8;
+    const int tx = wg % g.tiles_x, ty = (wg / g.tiles_x) % g.tiles_y, cz = wg / (g.tiles_x * g.tiles_y);
+    const int x0t = tx * kRbTX, y0t = ty * kRbTY, z0 = cz * g.chunk, z1 = min(z0 + g.chunk, g.nz);
+    const size_t nc = (size_t)g.ny * g.nz * g.hx; // elements of a per-colour array (one slot)
+    const size_t pl = (size_t)g.ny * g.nx, plc = (size_t)g.ny * g.hx;
+    T ra[NA], rd[NA], vb[NB][8], vc[NC][8];
+#define RB_SLOT(p) ((((p) % 3) + 3) % 3)
+#define RB_A_CELL(i)                                                                              \
+    const int  idx = tid + kRbThreads * (i), lx = idx % kRbAX, ly = idx / kRbAX, gx = x0t - 2 + lx, gy = y0t - 2 + ly; \
+    const bool in  = idx < kAC && gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny
+#define RB_B_CELL(i, p)                                                                           \
+    const int  idx = tid + kRbThreads * (i), ly = idx / kBH, gy = y0t - 1 + ly,                          \
+              lx  = 2 * (idx % kBH) + ((1 - g.p0 - gy - (p) - (x0t - 1)) & 1), gx = x0t - 1 + lx; \
+    const bool in  = idx < kBC && (p) >= 0 && (p) < g.nz && gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny
+#define RB_C_CELL(i, p)                                                                           \
+    const int  idx = tid + kRbThreads * (i), ly = idx / kCH, gy = y0t + ly,                              \
+              lx  = 2 * (idx % kCH) + ((g.p0 - gy - (p) - x0t) & 1), gx = x0t + lx;               \
+    const bool in  = idx < kCC && gx < g.nx && gy < g.ny
+    // ---- A: plane p, rhs / x0 on the tile + 2
+#define RB_LOAD_A(p)                                                                \
+    _Pragma("unroll") for(int i = 0; i < NA; ++i)                                   \
+    {                                                                               \
+        RB_A_CELL(i);                                                               \
+        (void)in;                                                                   \
+        const int cx = rb_clamp(gx, g.nx - 1), cy = rb_clamp(gy, g.ny - 1), cp = rb_clamp((p), g.nz - 1); \
+        ra[i] = rhs[(size_t)cp * pl + (size_t)cy * g.nx + cx];                      \
+        rd[i] = di0[(size_t)cp * plc + (size_t)cy * g.hx + (cx >> 1)];              \
+    }
+#define RB_PUT_A(p)                                                                 \
+    _Pragma("unroll") for(int i = 0; i < NA; ++i)                                   \
+    {                                                                               \
+        RB_A_CELL(i);                                                               \
+        T v = (((gx + gy + (p)) & 1) == g.p0) ? ra[i] * rd[i] : ra[i];              \
+        if(!(in && (p) >= 0 && (p) < g.nz))                                         \
+            v = (T)0;                                                               \
+        if(idx < kAC)                                                               \
+            XR[(RB_SLOT(p) * kRbAY + ly) * kRbPX + lx] = v;                         \
+    }
+    // ---- B: plane p, colour-1 values on the tile + 1
+#define RB_LOAD8(dst, vp, dp, ip, ci)                                                                                   \
+    dst[0] = vp[ci], dst[1] = vp[nc + ci], dst[2] = vp[2 * nc + ci], dst[3] = vp[3 * nc + ci], dst[4] = vp[4 * nc + ci], \
+    dst[5] = vp[5 * nc + ci], dst[6] = dp[ci], dst[7] = ip[ci]
+#define RB_LOAD_B(p)                                                                \
+    _Pragma("unroll") for(int i = 0; i < NB; ++i)                                   \
+    {                                                                               \
+        RB_B_CELL(i, p);                                                            \
+        (void)in;                                                                   \
+        const size_t ci = (size_t)rb_clamp((p), g.nz - 1) * plc + (size_t)rb_clamp(gy, g.ny - 1) * g.hx + (rb_clamp(gx, g.nx - 1) >> 1); \
+        RB_LOAD8(vb[i], val1, d1, di1, ci);                                         \
+    }
+#define RB_PUT_B(p)                                                                 \
+    _Pragma("unroll") for(int i = 0; i < NB; ++i)                                   \
+    {                                                                               \
+        RB_B_CELL(i, p);                                                            \
+        T s = (T)0;                                                                 \
+        if(in)                                                                      \
+        {                                                                           \
+            const T* X0 = XR + (RB_SLOT((p)-1) * kRbAY + ly + 1) * kRbPX + lx + 1;  \
+            const T* X1 = XR + (RB_SLOT(p) * kRbAY + ly + 1) * kRbPX + lx + 1;      \
+            const T* X2 = XR + (RB_SLOT((p) + 1) * kRbAY + ly + 1) * kRbPX + lx + 1; \
+            s = X1[0];                                                              \
+            if((p) > 0)                                                             \
+                s -= vb[i][0] * X0[0];                                              \
+            if(gy > 0)                                                              \
+                s -= vb[i][1] * X1[-kRbPX];                                         \
+            if(gx > 0)                                                              \
+                s -= vb[i][2] * X1[-1];                                             \
+            if(gx < g.nx - 1)                                                       \
+                s -= vb[i][3] * X1[1];                                              \
+            if(gy < g.ny - 1)                                                       \
+                s -= vb[i][4] * X1[kRbPX];                                          \
+            if((p) < g.nz - 1)                                                      \
+                s -= vb[i][5] * X2[0];                                              \
+            s = s * vb[i][7];                                                       \
+            s = s * vb[i][6];                                                       \
+            s = s * vb[i][7];                                                       \
+        }                                                                           \
+        if(idx < kBC)                                                               \
+            Y1[(RB_SLOT(p) * kRbBY + ly) * kRbPY + lx] = s;                         \
+    }
+    // ---- C: plane p, colour-0 values on the tile (into the cell's place in XR)
+#define RB_LOAD_C(p)                                                                \
+    _Pragma("unroll") for(int i = 0; i < NC; ++i)                                   \
+    {                                                                               \
+        RB_C_CELL(i, p);                                                            \
+        (void)in;                                                                   \
+        const size_t ci = (size_t)rb_clamp((p), g.nz - 1) * plc + (size_t)rb_clamp(gy, g.ny - 1) * g.hx + (rb_clamp(gx, g.nx - 1) >> 1); \
+        RB_LOAD8(vc[i], val0, d0, di0, ci);                                         \
+    }
+#define RB_PUT_C(p)                                                                 \
+    _Pragma("unroll") for(int i = 0; i < NC; ++i)                                   \
+    {                                                                               \
+        RB_C_CELL(i, p);                                                            \
+        if(in)                                                                      \
+        {                                                                           \
+            T*       X  = XR + (RB_SLOT(p) * kRbAY + ly + 2) * kRbPX + lx + 2;      \
+            const T* W0 = Y1 + (RB_SLOT((p)-1) * kRbBY + ly + 1) * kRbPY + lx + 1;  \
+            const T* W1 = Y1 + (RB_SLOT(p) * kRbBY + ly + 1) * kRbPY + lx + 1;      \
+            const T* W2 = Y1 + (RB_SLOT((p) + 1) * kRbBY + ly + 1) * kRbPY + lx + 1; \
+            T        s  = X[0] * vc[i][6];                                          \
+            if((p) > 0)                                                             \
+                s -= vc[i][0] * W0[0];                                              \
+            if(gy > 0)                                                              \
+                s -= vc[i][1] * W1[-kRbPY];                                         \
+            if(gx > 0)                                                              \
+                s -= vc[i][2] * W1[-1];                                             \
+            if(gx < g.nx - 1)                                                       \
+                s -= vc[i][3] * W1[1];                                              \
+            if(gy < g.ny - 1)                                                       \
+                s -= vc[i][4] * W1[kRbPY];                                          \
+            if((p) < g.nz - 1)                                                      \
+                s -= vc[i][5] * W2[0];                                              \
+            X[0] = s * vc[i][7];                                                    \
+        }                                                                           \
+    }
+    // ---- the rows of out of plane p, both colours, whole lines
+#define RB_STORE(p)                                                                 \
+    for(int idx = tid; idx < kRbTX * kRbTY; idx += kRbThreads)                               \
+    {                                                                               \
+        const int lx = idx % kRbTX, ly = idx / kRbTX, gx = x0t + lx, gy = y0t + ly;   \
+        if(gx < g.nx && gy < g.ny)                                                  \
+        {                                                                           \
+            const T o = ((gx + gy + (p)) & 1) == g.p0 ? XR[(RB_SLOT(p) * kRbAY + ly + 2) * kRbPX + lx + 2]  \
+                                                      : Y1[(RB_SLOT(p) * kRbBY + ly + 1) * kRbPY + lx + 1]; \
+            nt_store(o, out + (size_t)(p)*pl + (size_t)gy * g.nx + gx);             \
+        }                                                                           \
+    }
+    // warm-up: planes z0 - 2 .. z0 + 1 of A, z0 - 1 and z0 of B
+    RB_LOAD_A(z0 - 2);
+    RB_PUT_A(z0 - 2);
+    RB_LOAD_A(z0 - 1);
+    RB_PUT_A(z0 - 1);
+    RB_LOAD_A(z0);
+    RB_PUT_A(z0);
+    RB_LOAD_B(z0 - 1);
+    RB_LOAD_A(z0 + 1);
+    rb_barrier();
+    RB_PUT_B(z0 - 1);
+    RB_LOAD_B(z0);
+    rb_barrier();
+    RB_PUT_A(z0 + 1);
+    RB_LOAD_A(z0 + 2);
+    rb_barrier();
+    RB_PUT_B(z0);
+    RB_LOAD_B(z0 + 1);
+    RB_LOAD_C(z0);
+    rb_barrier();
+    for(int z = z0; z < z1; ++z)
+    {
+        RB_PUT_A(z + 2);
+        RB_LOAD_A(z + 3); // (every load is issued by every lane of every wave, at a clamped address where it has no cell:
+        rb_barrier(); //      the number of loads in flight is then a constant the compiler can count its waits against)
+        RB_PUT_B(z + 1);
+        RB_LOAD_B(z + 2);
+        rb_barrier();
+        RB_PUT_C(z);
+        RB_LOAD_C(z + 1);
+        rb_barrier();
+        RB_STORE(z);
+        rb_barrier();
+    }
+#undef RB_SLOT
+#undef RB_A_CELL
+#undef RB_B_CELL
+#undef RB_C_CELL
+#undef RB_LOAD_A
+#undef RB_PUT_A
+#undef RB_LOAD8
+#undef RB_LOAD_B
+#undef RB_PUT_B
+#undef RB_LOAD_C
+#undef RB_PUT_C
+#undef RB_STORE
+}
+
+// min over the off-diagonal entries of |original index of the column - original index of the row| beyond thr
+__global__ __launch_bounds__(kBlock) void k_rb_min_offset(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                          const int* __restrict__ iperm, int thr, int* __restrict__ out_min)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    int           mn  = 0x7fffffff;
+    for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gsz)
+    {
+        const int r = iperm[t];
+        for(int a = rp[t]; a < rp[t + 1]; ++a)
+        {
+            const int dd = abs(iperm[ci[a]] - r);
+            if(dd > thr)
+                mn = min(mn, dd);
+        }
+    }
+#pragma unroll
+    for(int off = 32; off > 0; off >>= 1)
+        mn = min(mn, __shfl_xor(mn, off, 64));
+    if((threadIdx.x & 63) == 0 && mn != 0x7fffffff)
+        atomicMin(out_min, mn);
+}
+// every row: exactly its lattice neighbours + the diagonal, its colour the parity of its cell; values and diagonals laid out per colour
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_rb_fill(int n, int nx, int ny, int nz, int hx, int p0, const int* __restrict__ rp,
+                                                    const int* __restrict__ ci, const T* __restrict__ val,
+                                                    const int* __restrict__ iperm, const int* __restrict__ blk_of,
+                                                    const T* __restrict__ d, const T* __restrict__ dinv, T* __restrict__ v0,
+                                                    T* __restrict__ v1, T* __restrict__ od0, T* __restrict__ odi0,
+                                                    T* __restrict__ od1, T* __restrict__ odi1, int* __restrict__ bad)
+{
+    const int64_t gsz  = (int64_t)gridDim.x * blockDim.x;
+    const int     nxny = nx * ny;
+    const size_t  nc   = (size_t)ny * nz * hx;
+    for(int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gsz)
+    {
+        const int r = iperm[t], x = r % nx, y = (r / nx) % ny, z = r / nxny;
+        const int c = blk_of[t];
+        bool      ok = (((x + y + z) & 1) == p0) == (c == 0);
+        T         a[6] = {(T)0, (T)0, (T)0, (T)0, (T)0, (T)0};
+        int       seen = 0;
+        bool      diag = false;
+        for(int q = rp[t]; q < rp[t + 1]; ++q)
+        {
+            const int dd = iperm[ci[q]] - r;
+            int       k  = -1;
+            if(dd == 0)
+                diag = true;
+            else if(dd == -nxny && z > 0)
+                k = 0;
+            else if(dd == -nx && y > 0)
+                k = 1;
+            else if(dd == -1 && x > 0)
+                k = 2;
+            else if(dd == 1 && x < nx - 1)
+                k = 3;
+            else if(dd == nx && y < ny - 1)
+                k = 4;
+            else if(dd == nxny && z < nz - 1)
+                k = 5;
+            else
+                ok = false;
+            if(k >= 0)
+            {
+                ok   = ok && !(seen & (1 << k));
+                seen |= 1 << k;
+                a[k] = val[q];
+            }
+        }
+        const int want = (z > 0 ? 1 : 0) | (y > 0 ? 2 : 0) | (x > 0 ? 4 : 0) | (x < nx - 1 ? 8 : 0) | (y < ny - 1 ? 16 : 0)
+                         | (z < nz - 1 ? 32 : 0);
+        ok = ok && diag && seen == want;
+        if(!ok)
+        {
+            *bad = 1;
+            continue;
+        }
+        const size_t cidx = ((size_t)z * ny + y) * hx + (x >> 1);
+        T*           v    = c == 0 ? v0 : v1;
+        for(int k = 0; k < 6; ++k)
+            v[k * nc + cidx] = a[k];
+        (c == 0 ? od0 : od1)[cidx]   = d[t];
+        (c == 0 ? odi0 : odi1)[cidx] = dinv[t];
+    }
+}
+
 // pairs of the output (see McsgsPlan): row t of colour 0 takes the row next to it in its aligned pair of out along where that
 // row has another colour
 __global__ __launch_bounds__(kBlock) void k_mc_pairs(int n, int n0, const int* __restrict__ iperm, const int* __restrict__ perm,
@@ -692,6 +1019,93 @@ static int mc_build(McsgsPlan* P, const ramd_mat_s* m, const int* perm)
             P->dinv_nat = nullptr;
         }
     }
+    // red-black lattice form (k_mc_rb): RAMD_MC_RB = 0 off, 1 (default) operators of 2^16 rows and more, 2 any size (tests)
+    static const int rb_env = getenv("RAMD_MC_RB") ? atoi(getenv("RAMD_MC_RB")) : 1;
+    if(s == RAMD_OK && rb_env != 0 && nb == 2 && !P->identity[0] && !P->identity[1] && (n >= (1 << 16) || rb_env == 2) && n >= 8)
+    {
+        int* dmin = nullptr;
+        int  h2[2] = {0x7fffffff, 0};
+        auto pass  = [&](int thr) -> int {
+            h2[0] = 0x7fffffff;
+            if(hipMemcpyAsync(dmin, h2, sizeof(int), hipMemcpyHostToDevice, b.cur) != hipSuccess)
+                return RAMD_ERR_HIP;
+            hipLaunchKernelGGL(k_rb_min_offset, dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, P->iperm, thr, dmin);
+            if(hipMemcpyAsync(h2, dmin, sizeof(int), hipMemcpyDeviceToHost, b.cur) != hipSuccess || hipStreamSynchronize(b.cur) != hipSuccess)
+                return RAMD_ERR_HIP;
+            return RAMD_OK;
+        };
+        s = dev_alloc(&dmin, 2);
+        int nx = 0, ny = 0, nz = 0;
+        if(s == RAMD_OK)
+            s = pass(1);
+        if(s == RAMD_OK && h2[0] != 0x7fffffff && h2[0] >= 2 && n % h2[0] == 0)
+        {
+            nx = h2[0];
+            s  = pass(nx);
+            const int64_t nxny = (s == RAMD_OK && h2[0] != 0x7fffffff) ? h2[0] : n;
+            if(s == RAMD_OK && nxny % nx == 0 && n % nxny == 0 && nxny / nx >= 2)
+            {
+                ny = (int)(nxny / nx);
+                nz = (int)(n / nxny);
+            }
+        }
+        if(s == RAMD_OK && nz > 0)
+        {
+            const int    hx = (nx + 1) / 2;
+            const size_t nc = (size_t)ny * nz * hx;
+            int          c0 = 0, t0 = 0; // colour of the original row 0 (cell (0, 0, 0): parity 0), its position
+            hipError_t   e  = hipMemcpyAsync(&t0, perm, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+            if(e == hipSuccess)
+                e = hipStreamSynchronize(b.cur);
+            if(e == hipSuccess)
+                e = hipMemcpyAsync(&c0, P->blk_of + t0, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+            if(e == hipSuccess)
+                e = hipStreamSynchronize(b.cur);
+            const int p0 = c0 == 0 ? 0 : 1;
+            for(int c = 0; c < 2 && e == hipSuccess; ++c)
+            {
+                e = cached_malloc(&P->rb_val[c], 6 * nc * sizeof(T) + kPad);
+                if(e == hipSuccess)
+                    e = cached_malloc(&P->rb_d[c], nc * sizeof(T) + kPad);
+                if(e == hipSuccess)
+                    e = cached_malloc(&P->rb_di[c], nc * sizeof(T) + kPad);
+                if(e == hipSuccess)
+                    e = hipMemsetAsync(P->rb_val[c], 0, 6 * nc * sizeof(T), b.cur);
+                if(e == hipSuccess)
+                    e = hipMemsetAsync(P->rb_d[c], 0, nc * sizeof(T), b.cur);
+                if(e == hipSuccess)
+                    e = hipMemsetAsync(P->rb_di[c], 0, nc * sizeof(T), b.cur);
+            }
+            int hb = 1;
+            if(e == hipSuccess)
+                e = hipMemsetAsync(dmin + 1, 0, sizeof(int), b.cur);
+            if(e == hipSuccess)
+            {
+                hipLaunchKernelGGL((k_rb_fill<T>), dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, nx, ny, nz, hx, p0, m->rp, m->ci,
+                                   (const T*)m->val, P->iperm, P->blk_of, (const T*)P->d, (const T*)P->dinv, (T*)P->rb_val[0],
+                                   (T*)P->rb_val[1], (T*)P->rb_d[0], (T*)P->rb_di[0], (T*)P->rb_d[1], (T*)P->rb_di[1], dmin + 1);
+                e = hipMemcpyAsync(&hb, dmin + 1, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+            }
+            if(e == hipSuccess)
+                e = hipStreamSynchronize(b.cur);
+            if(e != hipSuccess)
+                s = RAMD_ERR_HIP;
+            P->rb = (s == RAMD_OK && hb == 0);
+            P->rb_nx = nx, P->rb_ny = ny, P->rb_nz = nz, P->rb_p0 = p0;
+            if(!P->rb)
+                for(int c = 0; c < 2; ++c)
+                {
+                    void** ps2[] = {&P->rb_val[c], &P->rb_d[c], &P->rb_di[c]};
+                    for(void** q : ps2)
+                    {
+                        if(*q)
+                            (void)cached_free(*q);
+                        *q = nullptr;
+                    }
+                }
+        }
+        dev_free(&dmin);
+    }
     dev_free(&d_off);
     return s;
 }
@@ -755,6 +1169,22 @@ static int mc_apply(McsgsPlan* P, int kind, const T* rhs, T* out)
         SWEEP(true, false, false, true, nb - 1, P->l_off, P->l_col, P->l_val, nb > 1); // last colour: L and R in one
         for(int i = nb - 2; i >= 0; --i)
             SWEEP(false, false, false, true, i, P->u_off, P->u_col, P->u_val, i > 0);
+        RAMD_HIP(hipGetLastError());
+        return RAMD_OK;
+    }
+    if(P->rb)
+    {
+        RbDims g;
+        g.nx = P->rb_nx, g.ny = P->rb_ny, g.nz = P->rb_nz, g.hx = (P->rb_nx + 1) / 2, g.p0 = P->rb_p0;
+        g.tiles_x = (g.nx + kRbTX - 1) / kRbTX, g.tiles_y = (g.ny + kRbTY - 1) / kRbTY, g.chunks = 1;
+        // runs of planes: four workgroups per CU where the lattice has them (a run repeats three planes of its predecessor)
+        const int want = (4 * b.num_cu + g.tiles_x * g.tiles_y - 1) / (g.tiles_x * g.tiles_y);
+        g.chunk        = std::min(kRbChunkMax, std::max(kRbChunkMin, (g.nz + want - 1) / want));
+        g.chunks       = (g.nz + g.chunk - 1) / g.chunk;
+        const size_t lds = (size_t)(3 * kRbAY * kRbPX + 3 * kRbBY * kRbPY) * sizeof(T);
+        hipLaunchKernelGGL((k_mc_rb<T>), dim3((unsigned)(g.tiles_x * g.tiles_y * g.chunks)), dim3(kRbThreads), lds, b.cur, g,
+                           (const T*)P->rb_val[0], (const T*)P->rb_val[1], (const T*)P->rb_d[0], (const T*)P->rb_di[0],
+                           (const T*)P->rb_d[1], (const T*)P->rb_di[1], rhs, out);
         RAMD_HIP(hipGetLastError());
         return RAMD_OK;
     }

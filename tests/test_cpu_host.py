@@ -490,3 +490,43 @@ def test_lattice_solve_kernels_have_no_memory_operation_the_counts_do_not_know(t
         # drains: the prologue / epilogue of a pencil and the re-poll loops of the 8 face batches of a loop body, nothing else
         assert sum(1 for w in waits if w == 0) <= 2 + 8 + 2, (name, waits)
         assert sum(1 for w in waits if w > 0) >= 16 + 2 + 8, (name, waits)
+
+
+# ------------------------------------------------------------------ the plane-ahead loads of the red-black SGS kernel
+def test_red_black_sgs_kernel_keeps_its_loads_in_flight_across_the_barriers(tmp_path):
+    """k_mc_rb (csrc/mcsgs.hip) issues the global loads of a stage one plane ahead and relies on the COMPILER counting its waits:
+    every lane issues every load (clamped addresses), so the loads in flight are a constant.  A load under a divergent branch,
+    a __syncthreads() or a spill would turn the counted waits of the plane loop into drains again (3.0 -> 3.4 ms at 512^3).
+    Checked on the ISA of both precisions: no scratch, no spills, and inside the plane loop -- the last loop with four
+    barriers -- every wait in front of the stages leaves loads in flight."""
+    import re
+    hipcc = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    out = tmp_path / "mc.s"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "rocalution_amd", "csrc"),
+           "--cuda-device-only", "-S", os.path.join(ROOT, "rocalution_amd", "csrc", "mcsgs.hip"), "-o", str(out)]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:]
+    text = out.read_text()
+    meta = text[text.index("amdhsa.kernels:"):]
+    kern = re.findall(r"\.name:\s+(\S*k_mc_rb\S*).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+)\s+\.vgpr_spill_count:\s+(\d+)",
+                      meta, flags=re.S)
+    assert len(kern) == 2, [k[0] for k in kern]
+    for name, scratch, vgpr, spill in kern:
+        assert int(scratch) == 0 and int(spill) == 0 and int(vgpr) <= 256, (name, scratch, vgpr, spill)
+        start = text.index("\n" + name + ":")
+        lines = [l.strip() for l in text[start:text.index("s_endpgm", start)].split("\n")]
+        assert not any(l.startswith("scratch_") for l in lines), name
+        labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r"(\.LBB\d+_\d+):", l)] if m}
+        # the plane loop: the widest backward branch
+        back = [(labels[m.group(1)], i) for i, l in enumerate(lines)
+                for m in [re.match(r"s_c?branch\w* (\.LBB\d+_\d+)", l)] if m and labels.get(m.group(1), 1 << 30) < i]
+        lo, hi = max(back, key=lambda b: b[1] - b[0])
+        loop = lines[lo:hi]
+        assert sum(1 for l in loop if l == "s_barrier") == 4, (name, sum(1 for l in loop if l == "s_barrier"))
+        loads = sum(1 for l in loop if l.startswith("global_load"))
+        assert loads >= 30, (name, loads)  # rhs, 1/d and two stages of eight arrays, for every cell a thread has
+        waits = [int(w) for l in loop for w in re.findall(r"vmcnt\((\d+)\)", l)]
+        assert waits and min(waits) >= 8, (name, waits)

@@ -11,9 +11,13 @@ os.makedirs(out, exist_ok=True)
 WHAT = {"cg": "python bench.py --steps 100 --warmup 10 (512^3 CG+Jacobi, the headline)",
         "gmres": "python bench.py --solver gmres --precond ilu0 --steps 60 --warmup 10 (512^3 GMRES(30)+ILU(0))",
         "shell": "python bench.py --matrix shell --solver gmres --precond ilu0 --steps 60 --warmup 10 (config 3 surrogate)",
-        "bicgstab": "python bench.py --solver bicgstab --precond mcsgs --steps 60 --warmup 10 (512^3 BiCGStab+MC-SGS, config 4's solver)",
-        "ell": "python bench.py --format ell --solver bicgstab --precond mcsgs --steps 60 --warmup 10 (config 4: ELL interior)",
-        "hyb": "python bench.py --format hyb --solver bicgstab --precond mcsgs --steps 60 --warmup 10 (config 4: HYB interior)",
+        "bicgstab": "RAMD_MC_RB=0 python bench.py --solver bicgstab --precond mcsgs --steps 60 --warmup 10 (512^3 BiCGStab+MC-SGS, config 4's solver; "
+                    "the colour sweeps, as before the red-black form of round 5)",
+        "ell": "RAMD_MC_RB=0 python bench.py --format ell --solver bicgstab --precond mcsgs --steps 60 --warmup 10 (config 4: ELL interior; colour sweeps)",
+        "hyb": "RAMD_MC_RB=0 python bench.py --format hyb --solver bicgstab --precond mcsgs --steps 60 --warmup 10 (config 4: HYB interior; colour sweeps)",
+        "bicgstab_rb": "python bench.py --solver bicgstab --precond mcsgs --steps 60 --warmup 10 (512^3 BiCGStab+MC-SGS, the default: k_mc_rb)",
+        "ell_rb": "python bench.py --format ell --solver bicgstab --precond mcsgs --steps 60 --warmup 10 (config 4: ELL interior, the default: k_mc_rb)",
+        "hyb_rb": "python bench.py --format hyb --solver bicgstab --precond mcsgs --steps 60 --warmup 10 (config 4: HYB interior, the default: k_mc_rb)",
         "mixed": "python bench.py --solver mixed --steps 30 --warmup 3 (config 5: fp64 defect correction around fp32 CG+Jacobi)",
         "calib": "tools/_bin/membench calib (reads of 1 GiB with 16 / 8 / 4 bytes per lane, of 256 MiB with 1 byte per lane)"}
 
@@ -63,7 +67,14 @@ for name in WHAT:
         for r in rows:
             vals.setdefault(short(r[0]), {})[ctr] = (r[3], r[2])
     traffic[name] = vals
-json.dump(traffic, open(os.path.join(out, tag + "_pmc_raw.json"), "w"), indent=1)
+raw_path = os.path.join(out, tag + "_pmc_raw.json")
+if os.path.exists(raw_path):  # a pass over some legs only keeps the other legs' figures
+    old = json.load(open(raw_path))
+    for k, v in old.items():
+        if not traffic.get(k):
+            traffic[k] = v
+traffic = {k: v for k, v in traffic.items() if v}
+json.dump(traffic, open(raw_path, "w"), indent=1)
 if on_box:
     import shutil
     for d in os.listdir(src):
