@@ -24,7 +24,9 @@
 #include "matrix_impl.hpp"
 #include "trsv_lattice.hpp"
 
+#include <algorithm>
 #include <type_traits>
+#include <vector>
 
 namespace ramd
 {
@@ -980,6 +982,22 @@ __global__ __launch_bounds__(kBlock) void k_max_row_len(int n, const int* __rest
 }
 
 // ---------------------------------------------------------------- plans
+// sync-free grouped form (k_trsv_sf, further down): the plan arrays beyond order / pos / diag / w
+struct SfPlan
+{
+    int   nunits = 0, lpr = 0, maxm = 1, wout = 0, ngroups = 0, nglev = 0;
+    int*  uinfo  = nullptr; // [4 nunits] {first position, rows | entries per lane << 8, first 64-entry plane, last dependency}
+    int*  punit  = nullptr; // [n] unit of a position
+    int*  ufar   = nullptr; // [nunits] a position a few levels back of the unit's dependencies (k_sf_far)
+    int*  pinfo  = nullptr; // [n] per position: row number inside its group | rows of the group << 4
+    int*  ecol   = nullptr; // [64 nplanes] positions the out-of-group entries refer to (-1: no entry)
+    void* eval   = nullptr; // [64 nplanes]
+    void* gcoef  = nullptr; // [8 n] in-group coefficients of a position (groups of more than one row)
+    bool  infirst = false;  // the in-group entries come first in the order of the host loop (upper solve)
+    int64_t nplanes = 0;
+};
+static void sf_release(SfPlan** sp);
+
 struct TriPlan
 {
     int   n         = 0;
@@ -1022,6 +1040,8 @@ struct TriPlan
     // band form (k_trsv_band): a deep, narrow dependency graph walked by one workgroup; the level of every position
     bool band      = false;
     int* band_plev = nullptr;
+    // sync-free grouped form (k_trsv_sf): a deep, narrow dependency graph of long rows, one row group per hand-off
+    SfPlan* sf = nullptr;
     // what the analysis found (ramd_tri_plan_stats): chains, external values of all tiles, box edges
     int       st_chains = 0, st_box[3] = {0, 0, 0};
     int       st_why    = 0; // why this plan is not in box-tile form (ct_why_text)
@@ -1029,6 +1049,7 @@ struct TriPlan
     void  release()
     {
         lat_release(&lat);
+        sf_release(&sf);
         dev_free(&band_plev);
         band = false;
         dev_free(&ct_tile_step);
@@ -1295,6 +1316,8 @@ static const char* ct_why_text(int why)
 }
 template <typename T>
 static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bool reverse);
+template <typename T>
+static int build_sf_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower);
 
 // natural = true: rows stay in matrix order (no level analysis) -- the packing of the iterative (Jacobi-sweep) solves
 template <typename T>
@@ -1325,6 +1348,27 @@ static int build_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bool 
         P->release();
         P->n       = n;
         P->nslices = (n + 63) / 64;
+    }
+    // deep, narrow dependency graphs the tiles could not take: one row group per hand-off (k_trsv_sf)
+    if(!natural && !reverse)
+    {
+        const int why = P->st_why;
+        const int sc  = build_sf_plan<T>(m, st, P, lower);
+        if(sc == RAMD_OK)
+        {
+            P->st_why = why;
+            if(lower && st->l_order_cache)
+                dev_free(&st->l_order_cache);
+            if(lower)
+                dev_free(&st->l_level_cache);
+            return RAMD_OK;
+        }
+        if(sc != RAMD_ERR_UNSUPPORTED)
+            return sc;
+        P->release();
+        P->n       = n;
+        P->nslices = (n + 63) / 64;
+        P->st_why  = why;
     }
     const unsigned nb   = nblocks_of(n);
     int            nlev = 0;
@@ -4439,6 +4483,760 @@ static int ct_build_pair_lists(TriPlan* P, const int* key, int** pairs_out, int 
     return done(RAMD_OK);
 }
 
+// ======================================================================= sync-free grouped triangular solve (round 5)
+// For dependency graphs that are DEEP AND NARROW with LONG rows and no chains for the tile coordinates to grow along -- a shell
+// mesh (5 unknowns per node, ~35 entries per row) numbered by reverse Cuthill-McKee or by an advancing front: ~10 700 row
+// levels of ~140 rows.  The level-scheduled kernel pays ~9 us per level there (one lane per row: the row's entries come in
+// dependent chunks of eight, each behind a poll), the band form ~4 us (one CU's load path).  What such a graph needs per level is
+// ONE hand-off and nothing else on the critical path:
+//   * the unit of work is a ROW GROUP (k_ct_sn_breaks: the rows of one mesh node -- row t depends on row t-1 and shares every
+//     other dependency with it): 2 140 group levels instead of 10 700; the in-group part of a step runs in registers, in the
+//     order of the host loop (lower solve: the in-group entries are the LAST of a row, upper solve: the FIRST);
+//   * LPR = 4 or 8 lanes share a row, kw <= 6 out-of-group entries each; a wave holds 64 / LPR rows = whole groups of ONE group
+//     level (a "unit"); positions are sorted by (group level, group, row), units are contiguous pieces of them;
+//   * persistent waves take the units round-robin: a wave is many levels ahead of the front when it starts on a unit, so the
+//     unit's coefficients, right-hand side and diagonal are in registers long before its dependencies are -- no look-ahead
+//     machinery, the other waves ARE the look-ahead;
+//   * it then waits with ONE load per turn on the unit's LAST dependency (the highest position among them: group level - 1) and
+//     only then gathers all of them (data-tagged granules, as k_trsv): the waves ahead of the front cost the memory system one
+//     request per turn each, not one per entry;
+//   * the out-of-group entries are subtracted one after the other through the row's lanes (DPP hand-over), the in-group ones in
+//     rounds through lane permutes; one publication per row.
+// The operations per row are those of host_matrix_csr.cpp:1163-1221 in their order: bit-exact (forced over the parity suite).
+constexpr int kSfKW = 6;
+
+static void sf_release(SfPlan** sp)
+{
+    SfPlan* q = *sp;
+    if(!q)
+        return;
+    dev_free(&q->uinfo);
+    dev_free(&q->ufar);
+    dev_free(&q->punit);
+    dev_free(&q->pinfo);
+    dev_free(&q->ecol);
+    if(q->eval)
+        (void)cached_free(q->eval);
+    if(q->gcoef)
+        (void)cached_free(q->gcoef);
+    delete q;
+    *sp = nullptr;
+}
+
+// order[p] = row of position p, plev[p] = its group level, pinfo[p] = row number inside the group | rows of the group << 4 |
+// out-of-group entries << 8   (sorted[p] = sweep index of position p)
+template <bool LOWER>
+__global__ __launch_bounds__(kBlock) void k_sf_positions(int n, const int* __restrict__ sorted, const int* __restrict__ key,
+                                                         const int* __restrict__ gf, const int* __restrict__ gl,
+                                                         const int* __restrict__ rp, const int* __restrict__ ci,
+                                                         int* __restrict__ order, int* __restrict__ plev, int* __restrict__ pinfo)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gsz)
+    {
+        const int t = sorted[p];
+        const int i = LOWER ? t : n - 1 - t;
+        int       c = 0;
+        for(int j = rp[i]; j < rp[i + 1]; ++j)
+        {
+            const int col = ci[j];
+            if(LOWER ? (col < i) : (col > i))
+                if((LOWER ? col : n - 1 - col) < gf[t])
+                    ++c;
+        }
+        order[p] = i;
+        plev[p]  = key[t];
+        pinfo[p] = (t - gf[t]) | ((gl[t] - gf[t] + 1) << 4) | (c << 8);
+    }
+}
+
+// one wave per unit: the out-of-group entries of its rows into the unit's planes (entry e of a row -> lane e / kw of the row,
+// plane e % kw), the in-group coefficients and the diagonal per position, the unit's last dependency
+template <typename T, bool LOWER, int LPR>
+__global__ __launch_bounds__(64) void k_sf_fill(int n, int nunits, int* __restrict__ uinfo, const int* __restrict__ pinfo,
+                                                const int* __restrict__ order, const int* __restrict__ pos,
+                                                const int* __restrict__ rp, const int* __restrict__ ci, const T* __restrict__ val,
+                                                int* __restrict__ ecol, T* __restrict__ eval, T* __restrict__ gcoef,
+                                                T* __restrict__ diag, int* __restrict__ nodiag, int* __restrict__ punit)
+{
+    const int u = blockIdx.x;
+    if(u >= nunits)
+        return;
+    const int     lane = threadIdx.x, slot = lane / LPR, l = lane % LPR;
+    const int     p0 = uinfo[4 * u], cnt = uinfo[4 * u + 1] & 255, kw = (uinfo[4 * u + 1] >> 8) & 15;
+    const int64_t e0 = (int64_t)uinfo[4 * u + 2] * 64 + lane;
+    const bool    have = slot < cnt;
+    int           maxdep = -1;
+    int           k      = 0; // planes of this lane filled so far
+    if(have)
+    {
+        const int p = p0 + slot, i = order[p];
+        const int r = pinfo[p] & 15;
+        if(l == 0)
+            punit[p] = u;
+        // (sweep index of the group's first row: rows of a group are consecutive positions AND consecutive sweep rows)
+        const int t = LOWER ? i : n - 1 - i, tf = t - r;
+        int       e = 0;
+        bool      dg = false;
+        for(int j = rp[i]; j < rp[i + 1]; ++j)
+        {
+            const int col = ci[j];
+            if(col == i)
+            {
+                if(l == 0)
+                    diag[p] = val[j];
+                dg = true;
+                continue;
+            }
+            if(!(LOWER ? (col < i) : (col > i)))
+                continue;
+            const int tc = LOWER ? col : n - 1 - col;
+            if(tc >= tf)
+            {
+                if(l == 0 && gcoef)
+                    gcoef[(int64_t)p * 8 + (tc - tf)] = val[j];
+                continue;
+            }
+            if(e / kw == l)
+            {
+                const int pc = pos[col];
+                ecol[e0 + (int64_t)k * 64] = pc;
+                eval[e0 + (int64_t)k * 64] = val[j];
+                maxdep                     = max(maxdep, pc);
+                ++k;
+            }
+            ++e;
+        }
+        if(!dg && l == 0)
+        {
+            diag[p] = (T)1;
+            *nodiag = 1;
+        }
+    }
+    for(; k < kw; ++k)
+    {
+        ecol[e0 + (int64_t)k * 64] = -1;
+        eval[e0 + (int64_t)k * 64] = (T)0;
+    }
+#pragma unroll
+    for(int off = 32; off > 0; off >>= 1)
+        maxdep = max(maxdep, __shfl_xor(maxdep, off, 64));
+    if(lane == 0)
+        uinfo[4 * u + 3] = maxdep;
+}
+
+// ufar[u]: the last dependency of the unit that holds the last dependency of ... (depth times) of unit u, -1: none that far back
+__global__ __launch_bounds__(kBlock) void k_sf_far(int nunits, int depth, const int* __restrict__ uinfo, const int* __restrict__ punit,
+                                                   int* __restrict__ ufar)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < nunits; u += gsz)
+    {
+        int q = uinfo[4 * u + 3];
+        for(int d = 0; d < depth && q >= 0; ++d)
+            q = uinfo[4 * punit[q] + 3];
+        ufar[u] = q;
+    }
+}
+
+template <typename T, int LPR, int NA>
+__device__ __forceinline__ T sf_chain(T s, const T (&prod)[kSfKW], int l, int nl)
+{
+    // the out-of-group entries of a row, one after the other through its lanes: lane 0 starts from s, lane k + 1 continues lane
+    // k's sum; nl (uniform) = lanes per row in use in this unit: the result is in lane nl - 1 of the row.  A slot without an entry
+    // holds the product (+0)(+0) = +0, and s - (+0) is s bit for bit for every s (-0 included): no test per entry, NA (4 or 6)
+    // subtractions per lane in a straight line.  Every lane computes, the lane whose turn it is keeps: one wave runs a unit, and
+    // a taken branch costs it more than the arithmetic it would skip (measured: 44 cycles per entry with a test per entry).
+#pragma unroll
+    for(int step = 0; step < LPR; ++step)
+    {
+        if(step >= nl)
+            break;
+        T t = step > 0 ? band_from_lane_before<T>(s) : s;
+#pragma unroll
+        for(int k = 0; k < NA; ++k)
+            t -= prod[k];
+        s = (l == step) ? t : s;
+    }
+    return s;
+}
+
+// value of lane `src` (uniform) in every lane
+__device__ __forceinline__ double sf_from_lane(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float sf_from_lane(float v, int src)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
+// the arithmetic of a unit once its dependencies are there: result of the row in lane nl - 1 of the row.  NA: subtractions per
+// lane of the chain; ONE: the unit holds one group (the lane a finished row is taken from is uniform: v_readlane, else ds_bpermute);
+// maxm (uniform): rows of the unit's longest group
+template <typename T, int DMODE, bool INFIRST, int LPR, int NA, bool ONE>
+__device__ __forceinline__ T sf_compute(T rhs, T dg, const T (&gc)[7], const T (&prod)[kSfKW], int r, int l, int slot, int nl, int maxm)
+{
+    const int gl0 = (slot - r) * LPR + nl - 1; // where the group's first row ends its chain
+    if(!INFIRST)
+    {
+        T sum = sf_chain<T, LPR, NA>(rhs, prod, l, nl);
+        // in-group entries (the last ones of a row): row j of a group is final once the rows before it have been taken out of it
+#pragma unroll
+        for(int j = 0; j < kGrpMax; ++j)
+        {
+            if(j >= maxm)
+                break;
+            if(DMODE != 0)
+            {
+                const T q = DMODE == 1 ? sum / dg : sum * dg;
+                sum       = (r == j) ? q : sum;
+            }
+            if(j < 7 && j + 1 < maxm)
+            {
+                const T yj = ONE ? sf_from_lane(sum, j * LPR + nl - 1) : __shfl(sum, gl0 + j * LPR, 64);
+                const T t  = sum - gc[j] * yj;
+                sum        = (r > j) ? t : sum;
+            }
+        }
+        return sum;
+    }
+    // in-group entries first: the rows of a group one after the other (nearest row first), each with its chain and its division
+    T y[7];
+#pragma unroll
+    for(int j = 0; j < 7; ++j)
+        y[j] = (T)0;
+    T res = (T)0;
+#pragma unroll
+    for(int j = 0; j < kGrpMax; ++j)
+    {
+        if(j >= maxm)
+            break;
+        T s = rhs;
+#pragma unroll
+        for(int i = 6; i >= 0; --i)
+            if(i < j)
+                s -= gc[i] * y[i];
+        s = sf_chain<T, LPR, NA>(s, prod, l, nl);
+        if(DMODE == 1)
+            s /= dg;
+        else if(DMODE == 2)
+            s = s * dg;
+        res = (r == j) ? s : res;
+        if(j < 7 && j + 1 < maxm)
+            y[j] = ONE ? sf_from_lane(s, j * LPR + nl - 1) : __shfl(s, gl0 + j * LPR, 64);
+    }
+    return res;
+}
+
+// (Tried and removed, round 5: the waves of ONE XCD only -- every wave registers with the XCD its XCC_ID names, the XCD with most
+//  waves goes on -- with values published by stores that keep their line in that XCD's L2 (workgroup scope, sc0) and polled by
+//  the same sc1 loads: bit-exact, and SLOWER -- 2.0 us from publication to "dependencies seen" against 1.5 us through memory with
+//  sc1 stores from all eight XCDs, LUSolve on the RCM shell 12.1 against 10.1 ms; gpurun_out/r05u.)
+template <typename T, int DMODE, bool INFIRST, int LPR>
+__global__ __launch_bounds__(64) void k_trsv_sf(int nunits, const v4i32* __restrict__ uinfo, const int* __restrict__ pinfo,
+                                                const int* __restrict__ ecol, const T* __restrict__ eval,
+                                                const T* __restrict__ gcoef, const T* __restrict__ diag,
+                                                const T* __restrict__ rhs_src, const int* __restrict__ rhs_idx, T* w,
+                                                T* __restrict__ out, const int* __restrict__ order, int poll_cap, int gather_only,
+                                                const int* __restrict__ ufar, unsigned long long* __restrict__ dbg)
+{
+    // (dbg: RAMD_TRSV_SF_DBG, two timestamps per unit -- dependencies there, result published)
+    // gather_only 3 (default): one word per turn for the unit's LAST dependency, then gather; 0: one word per turn for a position
+    // `ufar[u]` two levels back, then gather every turn (one round trip less on paper; measured equal, 4.2 / 6.9 against 4.1 / 6.9 ms
+    // on the RCM shell: what a gathering wave asks of the memory system per turn costs what the second round trip did); 1: gather
+    // from the start (5.4 / 7.6 ms: 2048 waves x 4 gathers a turn); 2: no waits (diagnostic: 0.5 / 0.8 ms, the stream time)
+    using B = typename Sentinel<T>::bits;
+    const int lane = threadIdx.x, slot = lane / LPR, l = lane % LPR;
+    if(dbg && blockIdx.x == 0 && lane == 0) // (shader clock against the 100 MHz counter: what a cycle is worth in this kernel)
+    {
+        dbg[2 * (int64_t)nunits]     = clock64();
+        dbg[2 * (int64_t)nunits + 1] = wall_clock64();
+    }
+    for(int u = blockIdx.x; u < nunits; u += gridDim.x)
+    {
+        const v4i32 ui  = uinfo[u];
+        const int   p0  = __builtin_amdgcn_readfirstlane(ui.x);
+        const int   cnt = __builtin_amdgcn_readfirstlane(ui.y) & 255, kw = (__builtin_amdgcn_readfirstlane(ui.y) >> 8) & 15;
+        const int   ld  = __builtin_amdgcn_readfirstlane(ui.w);
+        const bool  have = slot < cnt;
+        const int   p    = p0 + (have ? slot : 0);
+        int         c[kSfKW];
+        T           a[kSfKW];
+        const int64_t e0 = (int64_t)__builtin_amdgcn_readfirstlane(ui.z) * 64 + lane;
+#pragma unroll
+        for(int k = 0; k < kSfKW; ++k)
+        {
+            c[k] = -1;
+            a[k] = (T)0;
+            if(k < kw)
+            {
+                c[k] = nt_load(ecol + e0 + (int64_t)k * 64);
+                a[k] = nt_load(eval + e0 + (int64_t)k * 64);
+            }
+        }
+        const int info = pinfo[p];
+        const int r    = have ? (info & 15) : 0;
+        const int m    = have ? ((info >> 4) & 15) : 0;
+        const T   rhs  = rhs_src[rhs_idx[p]];
+        const T   dg   = (DMODE == 0) ? (T)1 : diag[p];
+        const int onat = out ? order[p] : 0;
+        const bool grouped = __ballot(m > 1) != 0ull;
+        T          gc[7];
+#pragma unroll
+        for(int j = 0; j < 7; ++j)
+            gc[j] = (T)0;
+        if(grouped)
+        {
+#pragma unroll
+            for(int j = 0; j < 7; ++j)
+                gc[j] = gcoef[(int64_t)p * 8 + j];
+        }
+        // one request per turn while the front is levels away
+        const int far = gather_only == 3 ? ld : (gather_only == 0 ? __builtin_amdgcn_readfirstlane(ufar[u]) : -1);
+        if(far >= 0)
+        {
+            int spins = 0, backoff = 1;
+            while(poll_load(w + far) == Sentinel<T>::value)
+            {
+                spin_guard(spins);
+                backoff = poll_backoff(false, backoff, poll_cap);
+            }
+        }
+        B x[kSfKW];
+        {
+            int  spins = 0, backoff = 1;
+            bool all;
+            while(true)
+            {
+                spin_guard(spins);
+                all = true;
+#pragma unroll
+                for(int k = 0; k < kSfKW; ++k)
+                {
+                    x[k] = 0;
+                    if(c[k] >= 0)
+                    {
+                        x[k] = poll_load(w + c[k]);
+                        all  = all && (x[k] != Sentinel<T>::value);
+                    }
+                }
+                if(__ballot(!all) == 0ull || gather_only == 2) // (2: diagnostic, no dependency waits -- wrong results, timing only)
+                    break;
+                if(gather_only != 3)
+                    backoff = poll_backoff(false, backoff, 2);
+            }
+        }
+        unsigned long long d_w0 = 0, d_c0 = 0, d_c1 = 0, d_c2 = 0;
+        if(dbg)
+        {
+            d_w0 = wall_clock64();
+            d_c0 = d_c1 = clock64();
+        }
+        T prod[kSfKW];
+#pragma unroll
+        for(int k = 0; k < kSfKW; ++k)
+            prod[k] = a[k] * Sentinel<T>::from_bits(x[k]);
+        // lanes per row in use in this unit (a row's entries fill its lanes from lane 0 on), one group only: from the unit record
+        const int  nl   = (__builtin_amdgcn_readfirstlane(ui.y) >> 12) & 15;
+        const bool one  = ((__builtin_amdgcn_readfirstlane(ui.y) >> 16) & 1) != 0;
+        const int  maxm = (__builtin_amdgcn_readfirstlane(ui.y) >> 17) & 15;
+        T          res;
+        // (four straight-line bodies, chosen per unit)
+        if(kw <= 4)
+        {
+            if(one)
+                res = sf_compute<T, DMODE, INFIRST, LPR, 4, true>(rhs, dg, gc, prod, r, l, slot, nl, maxm);
+            else
+                res = sf_compute<T, DMODE, INFIRST, LPR, 4, false>(rhs, dg, gc, prod, r, l, slot, nl, maxm);
+        }
+        else
+        {
+            if(one)
+                res = sf_compute<T, DMODE, INFIRST, LPR, kSfKW, true>(rhs, dg, gc, prod, r, l, slot, nl, maxm);
+            else
+                res = sf_compute<T, DMODE, INFIRST, LPR, kSfKW, false>(rhs, dg, gc, prod, r, l, slot, nl, maxm);
+        }
+        if(dbg)
+        {
+            asm volatile("" : "+v"(res));
+            d_c2 = clock64();
+        }
+        if(have && l == nl - 1)
+        {
+            publish(w + p, res);
+            if(out)
+                out[onat] = res;
+        }
+        if(dbg)
+        {
+            const unsigned long long w1 = wall_clock64(), c3 = clock64();
+            if(lane == 0)
+            {
+                dbg[2 * (int64_t)u]     = d_w0;
+                dbg[2 * (int64_t)u + 1] = w1;
+                // cycles: dependencies seen -> chain done | -> result final | -> publication issued
+                dbg[2 * (int64_t)nunits + 4 + 2 * (int64_t)u]     = ((INFIRST ? 0ull : (d_c1 - d_c0)) & 0xffffffffull) | ((d_c2 - d_c0) << 32);
+                dbg[2 * (int64_t)nunits + 4 + 2 * (int64_t)u + 1] = c3 - d_c0;
+            }
+        }
+    }
+    if(dbg && blockIdx.x == 0 && lane == 0)
+    {
+        dbg[2 * (int64_t)nunits + 2] = clock64();
+        dbg[2 * (int64_t)nunits + 3] = wall_clock64();
+    }
+}
+
+template <typename T>
+static int build_sf_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower)
+{
+    Backend&  b = backend();
+    const int n = m->nrow;
+    // RAMD_TRSV_SF = 0: off, 1 (default): deep and narrow graphs, 2: whatever the shape (tests)
+    static const int  sf_env  = getenv("RAMD_TRSV_SF") ? atoi(getenv("RAMD_TRSV_SF")) : 1;
+    static const bool verbose = getenv("RAMD_TRSV_CT_VERBOSE") != nullptr;
+    static const int  sf_kw_min = getenv("RAMD_TRSV_SF_KW") ? std::min(kSfKW, std::max(1, atoi(getenv("RAMD_TRSV_SF_KW")))) : 4;
+    if(sf_env == 0 || n < 1 || (sf_env == 1 && n < 4096))
+        return RAMD_ERR_UNSUPPORTED;
+    int *brk = nullptr, *bscan = nullptr, *rstart = nullptr, *gs = nullptr, *gscan = nullptr, *gstart = nullptr, *gf = nullptr,
+        *gl = nullptr, *level = nullptr, *key = nullptr, *sorted = nullptr, *plev = nullptr, *nodiag = nullptr, *cext = nullptr,
+        *punit = nullptr;
+    UnitPlan units;
+    SfPlan*  S = nullptr;
+    int      s = RAMD_OK;
+    auto cleanup = [&]() {
+        dev_free(&brk);
+        dev_free(&bscan);
+        dev_free(&rstart);
+        dev_free(&gs);
+        dev_free(&gscan);
+        dev_free(&gstart);
+        dev_free(&gf);
+        dev_free(&gl);
+        dev_free(&level);
+        dev_free(&key);
+        dev_free(&sorted);
+        dev_free(&plev);
+        dev_free(&nodiag);
+        dev_free(&cext);
+        punit = nullptr; // (owned by the plan)
+        units.release();
+    };
+#define SF_TRY(expr)       \
+    do                     \
+    {                      \
+        s = (expr);        \
+        if(s != RAMD_OK)   \
+        {                  \
+            cleanup();     \
+            sf_release(&S); \
+            P->release();  \
+            return s;      \
+        }                  \
+    } while(0)
+#define SF_HIP(expr) SF_TRY(((expr) == hipSuccess) ? RAMD_OK : RAMD_ERR_HIP)
+#define SF_GIVE_UP(text)                                                                              \
+    do                                                                                                \
+    {                                                                                                 \
+        if(verbose)                                                                                   \
+            fprintf(stderr, "sync-free grouped plan (%s): not used (%s)\n", lower ? "lower" : "upper", text); \
+        cleanup();                                                                                    \
+        sf_release(&S);                                                                               \
+        P->release();                                                                                 \
+        return RAMD_ERR_UNSUPPORTED;                                                                  \
+    } while(0)
+    const int      grid = ew_grid(n + 1);
+    const unsigned nb1  = (unsigned)(((int64_t)n + 1 + kBlock - 1) / kBlock);
+    build_mark(nullptr);
+    // row groups: supernode runs cut into pieces of at most kGrpMax rows (every other row is a group of its own)
+    SF_TRY(dev_alloc(&brk, (int64_t)n + 1));
+    SF_TRY(dev_alloc(&bscan, (int64_t)n + 1));
+    if(lower)
+        hipLaunchKernelGGL((k_ct_sn_breaks<true>), dim3(nb1), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, brk);
+    else
+        hipLaunchKernelGGL((k_ct_sn_breaks<false>), dim3(nb1), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, brk);
+    SF_TRY(device_exclusive_scan(brk, bscan, (int64_t)n + 1));
+    int nruns = 0;
+    SF_HIP(hipMemcpyAsync(&nruns, bscan + n, sizeof(int), hipMemcpyDeviceToHost, b.cur));
+    SF_HIP(hipStreamSynchronize(b.cur));
+    if(nruns <= 0)
+        SF_GIVE_UP("no rows");
+    SF_TRY(dev_alloc(&rstart, (int64_t)nruns + 1));
+    hipLaunchKernelGGL(k_ct_scatter_starts, dim3(grid), dim3(kBlock), 0, b.cur, n, brk, bscan, rstart);
+    SF_TRY(dev_alloc(&gs, (int64_t)n + 1));
+    SF_TRY(dev_alloc(&gscan, (int64_t)n + 1));
+    hipLaunchKernelGGL(k_ct_group_starts, dim3(grid), dim3(kBlock), 0, b.cur, n, brk, bscan, rstart, gs);
+    SF_TRY(device_exclusive_scan(gs, gscan, (int64_t)n + 1));
+    int ngroups = 0;
+    SF_HIP(hipMemcpyAsync(&ngroups, gscan + n, sizeof(int), hipMemcpyDeviceToHost, b.cur));
+    SF_HIP(hipStreamSynchronize(b.cur));
+    SF_TRY(dev_alloc(&gstart, (int64_t)ngroups + 1));
+    hipLaunchKernelGGL(k_ct_scatter_starts, dim3(grid), dim3(kBlock), 0, b.cur, n, gs, gscan, gstart);
+    SF_HIP(hipMemcpyAsync(gstart + ngroups, &n, sizeof(int), hipMemcpyHostToDevice, b.cur));
+    SF_TRY(dev_alloc(&gf, n));
+    SF_TRY(dev_alloc(&gl, n));
+    hipLaunchKernelGGL(k_ct_group_bounds, dim3(grid), dim3(kBlock), 0, b.cur, n, gs, gscan, gstart, gf, gl);
+    SF_TRY(dev_alloc(&cext, 4));
+    SF_HIP(hipMemsetAsync(cext, 0, sizeof(int) * 4, b.cur));
+    if(lower)
+        hipLaunchKernelGGL((k_ct_row_wmax_out<true>), dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, gf, gl, cext + 3,
+                           cext + 2);
+    else
+        hipLaunchKernelGGL((k_ct_row_wmax_out<false>), dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, m->rp, m->ci, gf, gl, cext + 3,
+                           cext + 2);
+    int two[2] = {0, 0};
+    SF_HIP(hipMemcpyAsync(two, cext + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, b.cur));
+    SF_HIP(hipStreamSynchronize(b.cur));
+    const int maxm = two[0] < 1 ? 1 : two[0], wout = two[1];
+    dev_free(&brk);
+    dev_free(&bscan);
+    dev_free(&rstart);
+    dev_free(&gs);
+    dev_free(&gscan);
+    dev_free(&gstart);
+    if(wout > 8 * kSfKW)
+        SF_GIVE_UP("rows with more than 48 entries outside their group");
+    const int lpr = wout <= 4 * kSfKW ? 4 : 8, rpw = 64 / lpr;
+    // levels of the quotient graph (sweep order)
+    SF_TRY(unit_schedule(m, lower, &units));
+    SF_TRY(dev_alloc(&level, n));
+    SF_HIP(hipMemsetAsync(level, 0, sizeof(int) * (size_t)n, b.cur));
+    {
+        const unsigned nbs = sweep_blocks(units.nunits);
+        if(lower)
+            hipLaunchKernelGGL((k_ct_glevels<true>), dim3(nbs), dim3(sweep_block_size()), 0, b.cur, n, m->rp, m->ci, gf, gl, level,
+                               st->counter, st->ticket, unit_view(units), sweep_poll_cap());
+        else
+            hipLaunchKernelGGL((k_ct_glevels<false>), dim3(nbs), dim3(sweep_block_size()), 0, b.cur, n, m->rp, m->ci, gf, gl, level,
+                               st->counter, st->ticket, unit_view(units), sweep_poll_cap());
+        st->ticket += nbs;
+    }
+    int nglev = 0;
+    SF_TRY(device_max_int(level, n, &nglev)); // (synchronises)
+    units.release();
+    build_mark("sync-free plan: groups, group levels");
+    // deep and narrow: fewer than 2048 rows per group level on average (wider graphs keep the level-scheduled rows)
+    if(sf_env == 1 && (int64_t)n >= (int64_t)2048 * nglev)
+        SF_GIVE_UP("the dependency graph is wide: level-scheduled rows");
+    // positions: sweep rows sorted by the level of their group (stable: groups stay together, rows in sweep order)
+    SF_TRY(dev_alloc(&key, n));
+    hipLaunchKernelGGL(k_ct_gather_int, dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, (int64_t)n, level, gl, key);
+    SF_TRY(dev_alloc(&sorted, n));
+    SF_TRY(device_stable_sort_by_key(key, n, nglev, sorted));
+    S = new SfPlan;
+    S->lpr = lpr, S->maxm = maxm, S->wout = wout, S->ngroups = ngroups, S->nglev = nglev, S->infirst = !lower;
+    SF_TRY(dev_alloc(&P->order, n));
+    SF_TRY(dev_alloc(&P->pos, n));
+    SF_TRY(dev_alloc(&plev, n));
+    SF_TRY(dev_alloc(&S->pinfo, n));
+    if(lower)
+        hipLaunchKernelGGL((k_sf_positions<true>), dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, sorted, key, gf, gl, m->rp, m->ci,
+                           P->order, plev, S->pinfo);
+    else
+        hipLaunchKernelGGL((k_sf_positions<false>), dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, sorted, key, gf, gl, m->rp, m->ci,
+                           P->order, plev, S->pinfo);
+    hipLaunchKernelGGL(k_invert_perm, dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, P->order, P->pos);
+    // units: whole groups of one level, at most rpw rows -- a short pass over two int arrays on the host
+    std::vector<int> h_lev((size_t)n), h_info((size_t)n), h_u;
+    SF_HIP(hipMemcpyAsync(h_lev.data(), plev, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, b.cur));
+    SF_HIP(hipMemcpyAsync(h_info.data(), S->pinfo, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, b.cur));
+    SF_HIP(hipStreamSynchronize(b.cur));
+    h_u.reserve((size_t)ngroups * 4 / (rpw / maxm > 0 ? rpw / maxm : 1) + 16);
+    int64_t nplanes = 0;
+    for(int p = 0; p < n;)
+    {
+        const int lev = h_lev[p], first = p;
+        int       rows = 0, wmax = 0, ngr = 0, gmax = 1;
+        while(p < n && h_lev[p] == lev)
+        {
+            const int gm = (h_info[p] >> 4) & 15;
+            if((h_info[p] & 15) != 0 || gm < 1 || p + gm > n)
+            {
+                cleanup();
+                sf_release(&S);
+                P->release();
+                RAMD_FAIL(RAMD_ERR_STATE, "sync-free plan: a position that does not start its group");
+            }
+            if(gm > rpw)
+            {
+                cleanup();
+                sf_release(&S);
+                P->release();
+                RAMD_FAIL(RAMD_ERR_STATE, "sync-free plan: a group longer than a unit");
+            }
+            if(rows + gm > rpw)
+                break;
+            for(int q = 0; q < gm; ++q)
+                wmax = std::max(wmax, (h_info[p + q] >> 8) & 255);
+            rows += gm;
+            p += gm;
+            ++ngr;
+            gmax = std::max(gmax, gm);
+        }
+        // entries per lane: as few lanes as the rows need at up to sf_kw_min entries each (every lane in use is a hand-over in the
+        // chain of subtractions), more where the longest row asks for it
+        const int kw = std::max(std::min(std::max(wmax, 1), sf_kw_min), (wmax + lpr - 1) / lpr);
+        if(nplanes + kw > (int64_t)0x7fffffff / 64)
+        {
+            cleanup();
+            sf_release(&S);
+            P->release();
+            return RAMD_ERR_UNSUPPORTED;
+        }
+        h_u.push_back(first);
+        const int nlanes = std::max(1, (wmax + kw - 1) / kw); // lanes per row in use
+        h_u.push_back(rows | (kw << 8) | (nlanes << 12) | ((ngr == 1 ? 1 : 0) << 16) | (gmax << 17));
+        h_u.push_back((int)nplanes);
+        h_u.push_back(-1);
+        nplanes += kw;
+    }
+    S->nunits  = (int)(h_u.size() / 4);
+    S->nplanes = nplanes;
+    SF_TRY(dev_alloc(&S->uinfo, (int64_t)h_u.size()));
+    SF_HIP(hipMemcpyAsync(S->uinfo, h_u.data(), sizeof(int) * h_u.size(), hipMemcpyHostToDevice, b.cur));
+    SF_TRY(dev_alloc(&S->ecol, nplanes * 64));
+    SF_HIP(cached_malloc(&S->eval, (size_t)nplanes * 64 * sizeof(T) + kPad));
+    if(maxm > 1)
+    {
+        SF_HIP(cached_malloc(&S->gcoef, (size_t)n * 8 * sizeof(T) + kPad));
+        SF_HIP(hipMemsetAsync(S->gcoef, 0, (size_t)n * 8 * sizeof(T), b.cur));
+    }
+    SF_HIP(cached_malloc(&P->diag, (size_t)n * sizeof(T) + kPad));
+    SF_HIP(cached_malloc(&P->w, (size_t)n * sizeof(T) + kPad));
+    SF_TRY(dev_alloc(&nodiag, 1));
+    SF_HIP(hipMemsetAsync(nodiag, 0, sizeof(int), b.cur));
+    SF_TRY(dev_alloc(&S->punit, n));
+    punit = S->punit;
+    SF_TRY(dev_alloc(&S->ufar, S->nunits));
+#define SF_FILL(LO, LP)                                                                                                       \
+    hipLaunchKernelGGL((k_sf_fill<T, LO, LP>), dim3(S->nunits), dim3(64), 0, b.cur, n, S->nunits, S->uinfo, S->pinfo, P->order, \
+                       P->pos, m->rp, m->ci, (const T*)m->val, S->ecol, (T*)S->eval, (T*)S->gcoef, (T*)P->diag, nodiag, punit)
+    if(lower && lpr == 4)
+        SF_FILL(true, 4);
+    else if(lower)
+        SF_FILL(true, 8);
+    else if(lpr == 4)
+        SF_FILL(false, 4);
+    else
+        SF_FILL(false, 8);
+#undef SF_FILL
+    {
+        static const int far_depth = getenv("RAMD_TRSV_SF_FAR") ? atoi(getenv("RAMD_TRSV_SF_FAR")) : 1;
+        hipLaunchKernelGGL(k_sf_far, dim3(ew_grid(S->nunits)), dim3(kBlock), 0, b.cur, S->nunits, far_depth, S->uinfo, punit, S->ufar);
+    }
+    int nd = 0;
+    SF_HIP(hipMemcpyAsync(&nd, nodiag, sizeof(int), hipMemcpyDeviceToHost, b.cur));
+    SF_HIP(hipStreamSynchronize(b.cur));
+    SF_HIP(hipGetLastError());
+    P->nodiag  = nd != 0;
+    P->nlevels = nglev;
+    P->sf      = S;
+    S          = nullptr;
+    build_mark("sync-free plan: positions, units, fill");
+    if(verbose)
+        fprintf(stderr,
+                "sync-free grouped plan (%s): n=%d, %d row groups of <= %d rows, %d group levels (%.0f rows per level), longest "
+                "out-of-group part %d -> %d lanes per row, %d units, %.1f MB of planes\n",
+                lower ? "lower" : "upper", n, ngroups, maxm, nglev, (double)n / nglev, wout, lpr, P->sf->nunits,
+                (double)nplanes * 64 * (4 + sizeof(T)) / 1e6);
+    cleanup();
+    return RAMD_OK;
+#undef SF_GIVE_UP
+#undef SF_HIP
+#undef SF_TRY
+}
+
+template <typename T>
+static int run_sf_plan(TriPlan* P, int dm, const T* rhs_src, const int* rhs_idx, T* out)
+{
+    Backend&      b = backend();
+    const SfPlan* S = P->sf;
+    hipLaunchKernelGGL((k_fill_sentinel<T>), dim3(ew_grid(P->n)), dim3(kBlock), 0, b.cur, (int64_t)P->n, (T*)P->w);
+    // persistent waves, all resident (a wave only ever waits for units of lower number: held by resident waves)
+    static const int waves_env = getenv("RAMD_TRSV_SF_WAVES") ? atoi(getenv("RAMD_TRSV_SF_WAVES")) : 0; // (per CU; experiments)
+    static const int cap_env   = getenv("RAMD_TRSV_SF_POLLCAP") ? atoi(getenv("RAMD_TRSV_SF_POLLCAP")) : 8;
+    static const int gat_env   = getenv("RAMD_TRSV_SF_GATHER") ? atoi(getenv("RAMD_TRSV_SF_GATHER")) : 3; // (see k_trsv_sf)
+    unsigned nwg = 0;
+    // RAMD_TRSV_SF_DBG=<file prefix> (tools/ diagnostics): two timestamps per unit, dumped after every solve with the unit table
+    static const char*  dbg_path = getenv("RAMD_TRSV_SF_DBG");
+    unsigned long long* dbg      = nullptr;
+    if(dbg_path)
+    {
+        RAMD_HIP(hipMalloc(&dbg, sizeof(unsigned long long) * (4 * (size_t)S->nunits + 4)));
+        RAMD_HIP(hipMemsetAsync(dbg, 0, sizeof(unsigned long long) * (4 * (size_t)S->nunits + 4), b.cur));
+    }
+#define TRSV_SF(DM, INF, LP)                                                                                                  \
+    do                                                                                                                        \
+    {                                                                                                                         \
+        static int occ = 0;                                                                                                   \
+        if(occ == 0)                                                                                                          \
+        {                                                                                                                     \
+            int nb_cu = 0;                                                                                                    \
+            RAMD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_cu, k_trsv_sf<T, DM, INF, LP>, 64, 0));                \
+            occ = nb_cu < 1 ? 1 : (nb_cu - 2 > 8 ? 8 : (nb_cu > 2 ? nb_cu - 2 : 1));                                          \
+            if(waves_env > 0 && waves_env < occ)                                                                              \
+                occ = waves_env;                                                                                              \
+        }                                                                                                                     \
+        const int64_t cap = (int64_t)occ * b.num_cu;                                                                          \
+        nwg               = (unsigned)(S->nunits < cap ? S->nunits : cap);                                                    \
+        hipLaunchKernelGGL((k_trsv_sf<T, DM, INF, LP>), dim3(nwg), dim3(64), 0, b.cur, S->nunits, (const v4i32*)S->uinfo,     \
+                           S->pinfo, S->ecol, (const T*)S->eval, (const T*)S->gcoef, (const T*)P->diag, rhs_src, rhs_idx,      \
+                           (T*)P->w, out, P->order, cap_env, gat_env, S->ufar, dbg);                                          \
+    } while(0)
+#define TRSV_SF_L(DM, INF)      \
+    do                          \
+    {                           \
+        if(S->lpr == 4)         \
+            TRSV_SF(DM, INF, 4); \
+        else                    \
+            TRSV_SF(DM, INF, 8); \
+    } while(0)
+#define TRSV_SF_I(DM)              \
+    do                             \
+    {                              \
+        if(S->infirst)             \
+            TRSV_SF_L(DM, true);   \
+        else                       \
+            TRSV_SF_L(DM, false);  \
+    } while(0)
+    prof_begin(RAMD_PROF_TRSV, b.cur);
+    if(dm == 0)
+        TRSV_SF_I(0);
+    else if(dm == 1)
+        TRSV_SF_I(1);
+    else
+        TRSV_SF_I(2);
+    prof_end(RAMD_PROF_TRSV, b.cur);
+#undef TRSV_SF_I
+#undef TRSV_SF_L
+#undef TRSV_SF
+    RAMD_HIP(hipGetLastError());
+    if(dbg)
+    {
+        std::vector<unsigned long long> ht(4 * (size_t)S->nunits + 4);
+        std::vector<int>                hu(4 * (size_t)S->nunits), hp((size_t)P->n);
+        RAMD_HIP(hipMemcpy(ht.data(), dbg, sizeof(unsigned long long) * ht.size(), hipMemcpyDeviceToHost));
+        RAMD_HIP(hipMemcpy(hu.data(), S->uinfo, sizeof(int) * hu.size(), hipMemcpyDeviceToHost));
+        RAMD_HIP(hipMemcpy(hp.data(), S->punit, sizeof(int) * hp.size(), hipMemcpyDeviceToHost));
+        (void)hipFree(dbg);
+        const std::string fn = std::string(dbg_path) + (S->infirst ? "_upper.bin" : "_lower.bin");
+        if(FILE* f = fopen(fn.c_str(), "wb"))
+        {
+            const int hdr[4] = {S->nunits, P->n, (int)nwg, S->lpr};
+            fwrite(hdr, sizeof(int), 4, f);
+            fwrite(ht.data(), sizeof(unsigned long long), 2 * (size_t)S->nunits, f);
+            fwrite(hu.data(), sizeof(int), hu.size(), f);
+            fwrite(hp.data(), sizeof(int), hp.size(), f);
+            fwrite(ht.data() + 2 * (size_t)S->nunits, sizeof(unsigned long long), 4 + 2 * (size_t)S->nunits, f);
+            fclose(f);
+        }
+    }
+    return RAMD_OK;
+}
+
 template <typename T>
 static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const int* rhs_idx, T* out,
                     bool mul_inv_diag = false, TriPlan* next_stage = nullptr, bool own_fill_done = false,
@@ -4451,6 +5249,11 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
     Backend& b = backend();
     if(P->n == 0)
         return RAMD_OK;
+    if(P->sf)
+    {
+        P->w_sentinel = P->prefilled_next = false;
+        return run_sf_plan<T>(P, mul_inv_diag ? 2 : (unit ? 0 : 1), rhs_src, rhs_idx, out);
+    }
     if(P->band)
     {
         // one workgroup walks the levels (k_trsv_band): nothing is polled, so w needs no sentinels
@@ -6044,8 +6847,20 @@ static void tri_note_stats(const ramd_mat_s* m, const TriPlan* P, int which)
         o[12] = (long long)(li.coef_bytes + li.face_bytes);
         return;
     }
-    o[0] = !P->ct ? (P->band ? 5 : 1) : (P->ct_grp ? 3 : 2);
+    o[0] = !P->ct ? (P->sf ? 6 : (P->band ? 5 : 1)) : (P->ct_grp ? 3 : 2);
     o[2] = P->nlevels;
+    if(P->sf)
+    {
+        o[3] = P->sf->nunits;  // units = whole row groups of one group level, one wave each
+        o[4] = P->sf->ngroups; // row groups (steps of the dependency graph)
+        o[6] = 64 / P->sf->lpr;
+        o[7] = P->sf->wout;
+        o[8] = P->sf->lpr;
+        o[9] = P->sf->maxm;
+        o[12] = P->st_why;
+        o[14] = (long long)(P->sf->nplanes * 64 * (4 + (long long)val_size(m->dtype)));
+        return;
+    }
     o[12] = P->ct ? 0 : P->st_why;
     o[7] = P->ct_wmax;
     if(P->ct)

@@ -169,7 +169,7 @@ def test_parity_suite_with_the_band_form_forced():
     Cuthill-McKee order takes, tests/test_gpu_shell.py) on every matrix of the parity suite: RAMD_TRSV_BAND=2 with the tiles and
     the lattice form switched off -- ILU(0) / IC factors + LUSolve / LLSolve / LSolve / USolve goldens, preconditioner applies,
     solver histories, the config-3 class in four numberings: bit-exact as the level-scheduled kernel is."""
-    env = dict(os.environ, RAMD_TRSV_BAND="2", RAMD_TRSV_CT="0", RAMD_TRSV_LAT="0", RAMD_TRSV_CT_VERBOSE="1")
+    env = dict(os.environ, RAMD_TRSV_BAND="2", RAMD_TRSV_CT="0", RAMD_TRSV_LAT="0", RAMD_TRSV_SF="0", RAMD_TRSV_CT_VERBOSE="1")
     cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-s", "-m", "gpu", "-p", "no:cacheprovider",
            os.path.join(ROOT, "tests", "test_gpu_kernels.py"), os.path.join(ROOT, "tests", "test_gpu_solvers.py"),
            os.path.join(ROOT, "tests", "test_gpu_shell.py"), "-k", SELECT + " or variants"]

@@ -1,0 +1,166 @@
+"""The sync-free grouped triangular solve (k_trsv_sf, trisolve.hip): the form a deep, narrow dependency graph of long rows takes
+when the tile coordinates find no chains -- a shell mesh (5 unknowns per node) in reverse Cuthill-McKee order.
+
+By default only matrices of >= 4096 rows with fewer than 2048 rows per group level take it; RAMD_TRSV_SF=2 forces it on every
+matrix whose rows have at most 48 entries outside their row group.  The settings are read once per process, hence the
+subprocesses.  Everything is compared bit for bit: the kernel performs the operations of host_matrix_csr.cpp:1163-1221 (LUSolve),
+:1357-1404 (LSolve), :1420-1466 (USolve) per row in their order."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# (the selection of tests/test_gpu_box_tiles_forced.py without the solver histories of every Krylov driver: those run the same
+#  LUSolve / LSolve / USolve applies many times over and take most of that suite's time)
+SELECT = ("(ilu or lusolve or trisolve or preconditioner_apply or sgs or rebuild_numeric or gmres30_ilu0) "
+          "and not full_size and not cpp and not fresh_process")
+FORCED = dict(RAMD_TRSV_SF="2", RAMD_TRSV_CT="0", RAMD_TRSV_LAT="0", RAMD_TRSV_BAND="0", RAMD_TRSV_CT_VERBOSE="1")
+
+
+@pytest.mark.gpu
+def test_parity_suite_with_the_sync_free_grouped_form_forced():
+    """ILU(0) / IC factors + LUSolve / LLSolve / LSolve / USolve goldens, preconditioner applies, solver histories, the config-3
+    class in four numberings -- with every triangular plan that can be in the sync-free grouped form (the descending-order sweep
+    of LLSolve's second stage keeps the level-scheduled rows)."""
+    env = dict(os.environ, **FORCED)
+    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-s", "-m", "gpu", "-p", "no:cacheprovider",
+           os.path.join(ROOT, "tests", "test_gpu_kernels.py"), os.path.join(ROOT, "tests", "test_gpu_solvers.py"),
+           os.path.join(ROOT, "tests", "test_gpu_shell.py"), "-k", SELECT + " or variants"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    tail = p.stdout[-3000:]
+    assert p.returncode == 0, tail
+    assert " passed" in tail and "failed" not in tail, tail
+    assert "sync-free grouped plan (lower)" in p.stdout and "sync-free grouped plan (upper)" in p.stdout, tail
+    assert "8 lanes per row" in p.stdout and "4 lanes per row" in p.stdout, tail
+
+
+_BLOCKS = r"""
+import sys, numpy as np, scipy.sparse as sp
+sys.path.insert(0, %(root)r)
+import rocalution_amd as ra
+from oracle import oracle
+ra.init_rocalution()
+rng = np.random.default_rng(23)
+
+
+def block_matrix(nn, bmax, deg, reach, symmetric):
+    # a node graph (node i linked to up to `deg` nodes within `reach` before it) expanded with b_i unknowns per node and dense
+    # coupling blocks: supernodes of 1 .. bmax rows (runs of more than 8 rows are cut), rows of very different lengths; an
+    # unsymmetric pattern gives the two triangles different row groups
+    b = rng.integers(1, bmax + 1, nn)
+    off = np.concatenate([[0], np.cumsum(b)])
+    n = int(off[-1])
+    rows, cols = [], []
+    for i in range(nn):
+        js = set(int(j) for j in rng.integers(max(0, i - reach), i + 1, size=int(rng.integers(0, deg + 1)))) | {i}
+        for j in js:
+            for a in range(off[i], off[i + 1]):
+                for c in range(off[j], off[j + 1]):
+                    rows.append(a); cols.append(c)
+                    if symmetric or rng.random() < 0.5:
+                        rows.append(c); cols.append(a)
+    v = rng.uniform(-1, -0.05, len(rows))
+    A = sp.coo_matrix((v, (rows, cols)), shape=(n, n)).tocsr(); A.sum_duplicates()
+    A = A + sp.diags(np.asarray(abs(A).sum(axis=1)).ravel() + np.asarray(abs(A).sum(axis=0)).ravel() + 1.0)
+    A = A.tocsr(); A.sort_indices()
+    return A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+
+
+checked = 0
+for nn, bmax, deg, reach, sym in ((1, 1, 0, 1, True), (1, 9, 0, 1, True), (40, 5, 3, 6, True), (700, 5, 4, 30, True), (900, 9, 3, 12, False),
+                                  (400, 12, 2, 5, True), (1500, 3, 6, 200, False), (600, 8, 5, 9, True)):
+    rp, ci, va = block_matrix(nn, bmax, deg, reach, sym)
+    n = len(rp) - 1
+    for dt in (np.float64, np.float32):
+        v = va.astype(dt)
+        A = ra.LocalMatrix(dt); A.SetDataPtrCSR(rp, ci, v)
+        A.ILU0Factorize()
+        lu = oracle.ilu0(rp, ci, v)
+        assert np.array_equal(A.CopyToCSR()[2], lu), ("ilu0", nn, bmax, dt)
+        A.LUAnalyse()
+        y = ra.LocalVector(dt); y.Allocate("", n)
+        for rep in range(2):
+            b = rng.uniform(-1, 1, n).astype(dt)
+            A.LUSolve(ra.LocalVector(dt, data=b), y)
+            assert np.array_equal(y.numpy(), oracle.lusolve(rp, ci, lu, b)), ("lusolve", nn, bmax, dt)
+        for unit in (False, True):
+            B = ra.LocalMatrix(dt); B.SetDataPtrCSR(rp, ci, v)
+            B.LAnalyse(unit); B.LSolve(ra.LocalVector(dt, data=b), y)
+            assert np.array_equal(y.numpy(), oracle.lsolve(rp, ci, v, b, unit)), ("lsolve", nn, bmax, dt, unit)
+            B.UAnalyse(unit); B.USolve(ra.LocalVector(dt, data=b), y)
+            assert np.array_equal(y.numpy(), oracle.usolve(rp, ci, v, b, unit)), ("usolve", nn, bmax, dt, unit)
+    print("ok nodes=%%d n=%%d unknowns per node <= %%d" %% (nn, n, bmax), flush=True)
+    checked += 1
+print("checked", checked)
+"""
+
+
+@pytest.mark.gpu
+def test_row_groups_of_1_to_12_rows_unsymmetric_patterns_fp64_fp32_bit_exact(tmp_path):
+    """Block matrices with 1 .. 12 unknowns per node (row groups of every size, runs cut at 8 rows), symmetric and unsymmetric
+    patterns (the upper triangle's groups differ from the lower one's), rows of a few to beyond 48 entries (those matrices fall
+    back, loudly), n = 1 and a single group: ILU(0), LUSolve, LSolve / USolve with stored and with unit diagonal against the
+    oracle, fp64 and fp32."""
+    script = tmp_path / "blocks.py"
+    script.write_text(_BLOCKS % {"root": ROOT})
+    p = subprocess.run([sys.executable, str(script)], cwd=ROOT, env=dict(os.environ, **FORCED), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-4000:]
+    assert "checked 8" in p.stdout, p.stdout[-4000:]
+    assert "sync-free grouped plan (lower)" in p.stdout and "sync-free grouped plan (upper)" in p.stdout, p.stdout[-2000:]
+    assert "row groups of <= 8 rows" in p.stdout and "row groups of <= 5 rows" in p.stdout, p.stdout[-2000:]
+
+
+@pytest.mark.gpu
+def test_full_size_rcm_shell_takes_the_form_by_default():
+    """The config-3 class at full size (n = 1 507 005) in reverse Cuthill-McKee order: the tiles give up, both triangles take the
+    sync-free grouped form (8 lanes per row, groups of 5 rows = the mesh nodes, ~2 140 group levels instead of 10 700 row levels),
+    L U x = b holds to rounding, twenty solves in a row are bit-identical, GMRES(30)+ILU(0) converges to the known solution."""
+    import ctypes as C
+    import numpy as np
+    import rocalution_amd as ra
+    from rocalution_amd import capi, generators as gen, solvers as S
+    ra.init_rocalution()
+    lib = capi.load()
+    rp, ci, va = gen.shell_variant(549, "rcm")
+    n = len(rp) - 1
+    A = ra.LocalMatrix(); A.SetDataPtrCSR(rp, ci, va)
+    F = ra.LocalMatrix(); F.CloneFrom(A)
+    F.ILU0Factorize(); F.LUAnalyse()
+    st = (C.c_int64 * 16)()
+    default = os.environ.get("RAMD_TRSV_SF", "1") == "1" and os.environ.get("RAMD_TRSV_CT", "1") != "0"
+    for which in (0, 1):
+        capi.check(lib.ramd_tri_plan_stats(which, st))
+        if default:
+            assert st[0] == 6 and st[12] != 0, list(st)  # the sync-free grouped form, and why the tiles were not taken
+            assert st[8] == 8 and st[9] == 5 and st[4] >= n // 5, list(st)
+            assert 2000 <= st[2] <= 2300, list(st)
+    rng = np.random.default_rng(3)
+    bh = rng.uniform(-1.0, 1.0, n)
+    b = ra.LocalVector(data=bh)
+    x = ra.LocalVector(); x.Allocate("", n)
+    F.LUSolve(b, x)
+    xh = x.numpy().copy()
+    frp, fci, fva = F.CopyToCSR()
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(rp))
+    upper = fci >= rows
+    u = np.bincount(rows[upper], weights=fva[upper] * xh[fci[upper]], minlength=n)
+    lower = ~upper
+    bl = u + np.bincount(rows[lower], weights=fva[lower] * u[fci[lower]], minlength=n)
+    assert np.max(np.abs(bl - bh)) <= 1e-11 * max(1.0, np.max(np.abs(u)))
+    for rep in range(20):
+        F.LUSolve(b, x)
+        assert np.array_equal(x.numpy(), xh), rep
+    ones = ra.LocalVector(); ones.Allocate("", n); ones.Ones()
+    rhs = ra.LocalVector(); rhs.Allocate("", n)
+    A.Apply(ones, rhs)
+    x.Zeros()
+    ls = S.GMRES(); ls.SetOperator(A); ls.SetPreconditioner(S.ILU()); ls.SetBasisSize(30)
+    ls.Init(1e-15, 1e-6, 1e8, 2000); ls.Build()
+    ls.Solve(rhs, x)
+    assert ls.GetSolverStatus() == 2 and 40 <= ls.GetIterationCount() <= 160, (ls.GetIterationCount(), ls.GetSolverStatus())
+    x.AddScale(ones, -1.0)
+    assert x.Norm() / np.sqrt(n) < 1e-4
+    ls.Clear()
