@@ -172,7 +172,7 @@ def test_parity_suite_with_the_band_form_forced():
     env = dict(os.environ, RAMD_TRSV_BAND="2", RAMD_TRSV_CT="0", RAMD_TRSV_LAT="0", RAMD_TRSV_SF="0", RAMD_TRSV_CT_VERBOSE="1")
     cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-s", "-m", "gpu", "-p", "no:cacheprovider",
            os.path.join(ROOT, "tests", "test_gpu_kernels.py"), os.path.join(ROOT, "tests", "test_gpu_solvers.py"),
-           os.path.join(ROOT, "tests", "test_gpu_shell.py"), "-k", SELECT + " or variants"]
+           os.path.join(ROOT, "tests", "test_gpu_shell.py"), "-k", SELECT + " or variants_of_the_class"]
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
     tail = p.stdout[-3000:]
     assert p.returncode == 0, tail

@@ -12,22 +12,20 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# (the selection of tests/test_gpu_box_tiles_forced.py without the solver histories of every Krylov driver: those run the same
-#  LUSolve / LSolve / USolve applies many times over and take most of that suite's time)
-SELECT = ("(ilu or lusolve or trisolve or preconditioner_apply or sgs or rebuild_numeric or gmres30_ilu0) "
-          "and not full_size and not cpp and not fresh_process")
+SELECT = ("((ilu or lusolve or trisolve or preconditioner_apply or sgs or solvers_vs_golden or rebuild_numeric or gmres30_ilu0) "
+          "and not full_size and not cpp and not fresh_process) or variants_of_the_class")
 FORCED = dict(RAMD_TRSV_SF="2", RAMD_TRSV_CT="0", RAMD_TRSV_LAT="0", RAMD_TRSV_BAND="0", RAMD_TRSV_CT_VERBOSE="1")
 
 
 @pytest.mark.gpu
 def test_parity_suite_with_the_sync_free_grouped_form_forced():
     """ILU(0) / IC factors + LUSolve / LLSolve / LSolve / USolve goldens, preconditioner applies, solver histories, the config-3
-    class in four numberings -- with every triangular plan that can be in the sync-free grouped form (the descending-order sweep
-    of LLSolve's second stage keeps the level-scheduled rows)."""
+    class in four numberings (factors, LUSolve and GMRES(30)+ILU(0) against the oracle) -- with every triangular plan that can be
+    in the sync-free grouped form (the descending-order sweep of LLSolve's second stage keeps the level-scheduled rows)."""
     env = dict(os.environ, **FORCED)
     cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-s", "-m", "gpu", "-p", "no:cacheprovider",
            os.path.join(ROOT, "tests", "test_gpu_kernels.py"), os.path.join(ROOT, "tests", "test_gpu_solvers.py"),
-           os.path.join(ROOT, "tests", "test_gpu_shell.py"), "-k", SELECT + " or variants"]
+           os.path.join(ROOT, "tests", "test_gpu_shell.py"), "-k", SELECT, "--durations=5"]
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
     tail = p.stdout[-3000:]
     assert p.returncode == 0, tail
@@ -135,7 +133,7 @@ def test_full_size_rcm_shell_takes_the_form_by_default():
         capi.check(lib.ramd_tri_plan_stats(which, st))
         if default:
             assert st[0] == 6 and st[12] != 0, list(st)  # the sync-free grouped form, and why the tiles were not taken
-            assert st[8] == 8 and st[9] == 5 and st[4] >= n // 5, list(st)
+            assert st[8] == 8 and 5 <= st[9] <= 8 and abs(st[4] - n // 5) <= 8, list(st)  # (a few runs of rows reach over two nodes)
             assert 2000 <= st[2] <= 2300, list(st)
     rng = np.random.default_rng(3)
     bh = rng.uniform(-1.0, 1.0, n)
