@@ -619,7 +619,9 @@ def main():
             tkey = "spmv_csr_shell"
         r_spmv = roof(k_spmv, b_spmv, p_spmv, traffic_for(tkey) if tkey else None)
         if tri_pc and p_trsv["launches"] > 0:
-            tk = "trsv_512" if (args.matrix == "poisson" and N == 512) else ("trsv_shell" if args.matrix == "shell" else None)
+            tk = "trsv_512" if (args.matrix == "poisson" and N == 512) else None
+            if args.matrix == "shell":  # (counter passes exist for the surrogate and for its RCM numbering)
+                tk = "trsv_shell" if args.shell_variant == "lex" else "trsv_shell_" + args.shell_variant
             tri_plan = tri_plan_stats(lib, capi)
             prof = roof("sparse triangular solve, one launch per triangle: %s" % (tri_plan.get("lower", {}).get("form", "?")),
                         trsv_bytes(n, nnz, vb), p_trsv, traffic_for(tk) if tk else None)

@@ -4673,7 +4673,42 @@ __device__ __forceinline__ float sf_from_lane(float v, int src)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 
-// the arithmetic of a unit once its dependencies are there: result of the row in lane nl - 1 of the row.  NA: subtractions per
+// value of lane + Q of the same 16-lane row (Q compile-time)
+template <int Q>
+__device__ __forceinline__ double sf_from_lane_after(double v)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x100 + Q, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x100 + Q, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int Q>
+__device__ __forceinline__ float sf_from_lane_after(float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x100 + Q, 0xf, 0xf, true));
+}
+// all[q][k] = product k of lane + q, for q = Q .. nl - 1 (nl uniform)
+template <typename T, int LPR, int NA, int Q>
+__device__ __forceinline__ void sf_pull(T (&all)[LPR][NA], const T (&prod)[kSfKW], int nl)
+{
+    if constexpr(Q < LPR)
+    {
+        if(Q < nl)
+        {
+#pragma unroll
+            for(int k = 0; k < NA; ++k)
+                all[Q][k] = sf_from_lane_after<Q>(prod[k]);
+        }
+        else
+        {
+#pragma unroll
+            for(int k = 0; k < NA; ++k)
+                all[Q][k] = (T)0;
+        }
+        sf_pull<T, LPR, NA, Q + 1>(all, prod, nl);
+    }
+}
+
+// the arithmetic of a unit once its dependencies are there: result of the row in lane nl - 1 of the row (lower) / lane 0 (upper).  NA: subtractions per
 // lane of the chain; ONE: the unit holds one group (the lane a finished row is taken from is uniform: v_readlane, else ds_bpermute);
 // maxm (uniform): rows of the unit's longest group
 template <typename T, int DMODE, bool INFIRST, int LPR, int NA, bool ONE>
@@ -4703,7 +4738,16 @@ __device__ __forceinline__ T sf_compute(T rhs, T dg, const T (&gc)[7], const T (
         }
         return sum;
     }
-    // in-group entries first: the rows of a group one after the other (nearest row first), each with its chain and its division
+    // in-group entries first: the rows of a group one after the other (nearest row first), each with its chain and its division.
+    // Five chains per node instead of one: the products of a row's other lanes are first brought into its lane 0 (DPP row shifts,
+    // once per unit), so that a round's chain is a straight line of subtractions in one lane -- no hand-over per lane and round.
+    // The result of a row is in its lane 0.
+    T all[LPR][NA];
+#pragma unroll
+    for(int k = 0; k < NA; ++k)
+        all[0][k] = prod[k];
+    sf_pull<T, LPR, NA, 1>(all, prod, nl);
+    const int g0 = (slot - r) * LPR; // lane 0 of the group's first row
     T y[7];
 #pragma unroll
     for(int j = 0; j < 7; ++j)
@@ -4719,14 +4763,22 @@ __device__ __forceinline__ T sf_compute(T rhs, T dg, const T (&gc)[7], const T (
         for(int i = 6; i >= 0; --i)
             if(i < j)
                 s -= gc[i] * y[i];
-        s = sf_chain<T, LPR, NA>(s, prod, l, nl);
+#pragma unroll
+        for(int q = 0; q < LPR; ++q)
+        {
+            if(q >= nl)
+                break;
+#pragma unroll
+            for(int k = 0; k < NA; ++k)
+                s -= all[q][k];
+        }
         if(DMODE == 1)
             s /= dg;
         else if(DMODE == 2)
             s = s * dg;
         res = (r == j) ? s : res;
         if(j < 7 && j + 1 < maxm)
-            y[j] = ONE ? sf_from_lane(s, j * LPR + nl - 1) : __shfl(s, gl0 + j * LPR, 64);
+            y[j] = ONE ? sf_from_lane(s, j * LPR) : __shfl(s, g0 + j * LPR, 64);
     }
     return res;
 }
@@ -4864,7 +4916,7 @@ __global__ __launch_bounds__(64) void k_trsv_sf(int nunits, const v4i32* __restr
             asm volatile("" : "+v"(res));
             d_c2 = clock64();
         }
-        if(have && l == nl - 1)
+        if(have && l == (INFIRST ? 0 : nl - 1))
         {
             publish(w + p, res);
             if(out)
@@ -5018,9 +5070,12 @@ static int build_sf_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower)
     SF_TRY(device_max_int(level, n, &nglev)); // (synchronises)
     units.release();
     build_mark("sync-free plan: groups, group levels");
-    // deep and narrow: fewer than 2048 rows per group level on average (wider graphs keep the level-scheduled rows)
-    if(sf_env == 1 && (int64_t)n >= (int64_t)2048 * nglev)
-        SF_GIVE_UP("the dependency graph is wide: level-scheduled rows");
+    // by default: deep and narrow graphs (fewer than 2048 rows per group level on average), and graphs of any shape whose rows are
+    // long enough to keep four lanes busy (more than 8 entries outside their group) -- the random numbering of the config-3 class,
+    // 18 group levels of 16 700 groups: 0.49 / 0.86 ms per triangle against 1.17 / 3.1 ms of the level-scheduled rows, whose lanes
+    // fetch a row's entries in dependent chunks of eight.  Short rows in wide graphs keep the level-scheduled form (64 rows per wave).
+    if(sf_env == 1 && (int64_t)n >= (int64_t)2048 * nglev && wout <= 8)
+        SF_GIVE_UP("a wide dependency graph of short rows: level-scheduled rows");
     // positions: sweep rows sorted by the level of their group (stable: groups stay together, rows in sweep order)
     SF_TRY(dev_alloc(&key, n));
     hipLaunchKernelGGL(k_ct_gather_int, dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, (int64_t)n, level, gl, key);

@@ -11,6 +11,8 @@ os.makedirs(out, exist_ok=True)
 WHAT = {"cg": "python bench.py --steps 100 --warmup 10 (512^3 CG+Jacobi, the headline)",
         "gmres": "python bench.py --solver gmres --precond ilu0 --steps 60 --warmup 10 (512^3 GMRES(30)+ILU(0))",
         "shell": "python bench.py --matrix shell --solver gmres --precond ilu0 --steps 60 --warmup 10 (config 3 surrogate)",
+        "shell_rcm": "python bench.py --matrix shell --shell-variant rcm --solver gmres --precond ilu0 --steps 60 --warmup 10 (the config-3 class in "
+                     "reverse Cuthill-McKee order: the sync-free grouped triangular solve, k_trsv_sf)",
         "bicgstab": "RAMD_MC_RB=0 python bench.py --solver bicgstab --precond mcsgs --steps 60 --warmup 10 (512^3 BiCGStab+MC-SGS, config 4's solver; "
                     "the colour sweeps, as before the red-black form of round 5)",
         "ell": "RAMD_MC_RB=0 python bench.py --format ell --solver bicgstab --precond mcsgs --steps 60 --warmup 10 (config 4: ELL interior; colour sweeps)",

@@ -1,6 +1,6 @@
 # rocprofv3 passes behind profiles/r05_* (run on the GPU box from the repo root; then the text summaries are merged back under
 # gpurun_out/prof_txt and copied to profiles/).  Kernel traces and counter passes are separate runs (gpurun refuses --pmc
-# together with the runtime trace domains).   bash tools/profile_r05.sh [leg ...]   legs: cg gmres shell bicgstab ell hyb bicgstab_rb ell_rb hyb_rb mixed calib
+# together with the runtime trace domains).   bash tools/profile_r05.sh [leg ...]   legs: cg gmres shell shell_rcm bicgstab ell hyb bicgstab_rb ell_rb hyb_rb mixed calib
 # (bicgstab / ell / hyb: the colour sweeps, RAMD_MC_RB=0; *_rb: the default, the one-pass red-black form)
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
@@ -13,6 +13,7 @@ args_of() {
     cg) echo "";;
     gmres) echo "--solver gmres --precond ilu0";;
     shell) echo "--matrix shell --solver gmres --precond ilu0";;
+    shell_rcm) echo "--matrix shell --shell-variant rcm --solver gmres --precond ilu0";;
     bicgstab) echo "--solver bicgstab --precond mcsgs";;
     ell) echo "--format ell --solver bicgstab --precond mcsgs";;
     hyb) echo "--format hyb --solver bicgstab --precond mcsgs";;

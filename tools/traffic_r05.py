@@ -42,6 +42,10 @@ t["trsv_shell_lower"] = find("shell", "k_trsv_rec<double, 0, false")
 t["trsv_shell_upper"] = find("shell", "k_trsv_rec<double, 1, true")
 t["trsv_shell"] = (t["trsv_shell_lower"] + t["trsv_shell_upper"]) // 2
 t["trsv_shell_algorithmic"] = 345952650
+if "shell_rcm" in raw:
+    t["trsv_shell_rcm_lower"] = find("shell_rcm", "k_trsv_sf<double, 0, false")
+    t["trsv_shell_rcm_upper"] = find("shell_rcm", "k_trsv_sf<double, 1, true")
+    t["trsv_shell_rcm"] = (t["trsv_shell_rcm_lower"] + t["trsv_shell_rcm_upper"]) // 2
 t["spmv_csr_shell"] = find("shell", "k_csr_w4<double")
 t["spmv_csr_shell_algorithmic"] = 661765200
 t["mc_sweep_forward_512"] = find("bicgstab", "k_mc_sweep<double, true, false, true, true")
