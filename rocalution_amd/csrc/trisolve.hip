@@ -3755,6 +3755,8 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
 #undef CT_TRYG
     }
     build_mark("plan: chains, row widths, groups");
+    if(wmax > 32 && !grp) // (8 lanes x 4 entries per row and step) -- known before the coordinate sweep, which such a matrix is spared
+        CT_GIVE_UP(3);
     // monotone coordinates (sync-free sweep) and their extents
     CT_TRY(dev_alloc(&word, n));
     CT_HIP(hipMemsetAsync(word, 0, sizeof(unsigned long long) * (size_t)n, b.cur));
@@ -3793,8 +3795,6 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
         dnz += E[k] > 1 ? 1 : 0;
     if(dnz == 0)
         CT_GIVE_UP(2);
-    if(wmax > 32 && !grp) // (8 lanes x 4 entries per row and step)
-        CT_GIVE_UP(3);
     const int lpr = grp ? kGrpLPR : (wmax > 8 ? 8 : 1);
     const int wl  = grp ? kGrpWL : (lpr == 1 ? (wmax <= 3 ? 3 : (wmax <= 4 ? 4 : 8)) : 4);
     const int rpp = 64 / lpr;
@@ -4847,7 +4847,7 @@ __global__ __launch_bounds__(64) void k_trsv_sf(int nunits, const v4i32* __restr
                 gc[j] = gcoef[(int64_t)p * 8 + j];
         }
         // one request per turn while the front is levels away
-        const int far = gather_only == 3 ? ld : (gather_only == 0 ? __builtin_amdgcn_readfirstlane(ufar[u]) : -1);
+        const int far = gather_only == 3 ? ld : ((gather_only == 0 || gather_only == 4) ? __builtin_amdgcn_readfirstlane(ufar[u]) : -1);
         if(far >= 0)
         {
             int spins = 0, backoff = 1;
@@ -4858,6 +4858,32 @@ __global__ __launch_bounds__(64) void k_trsv_sf(int nunits, const v4i32* __restr
             }
         }
         B x[kSfKW];
+        if(gather_only == 4)
+        {
+            // every value is requested once; after that only the lanes whose value was not there yet ask again: the turns of a
+            // unit close to the front are a handful of requests, and the turn that finds the last value is the only trip through
+            // memory on the critical path
+#pragma unroll
+            for(int k = 0; k < kSfKW; ++k)
+                x[k] = c[k] >= 0 ? Sentinel<T>::value : (B)0;
+            int spins = 0;
+            while(true)
+            {
+                spin_guard(spins);
+                bool all = true;
+#pragma unroll
+                for(int k = 0; k < kSfKW; ++k)
+                    if(x[k] == Sentinel<T>::value)
+                    {
+                        x[k] = poll_load(w + c[k]);
+                        all  = all && (x[k] != Sentinel<T>::value);
+                    }
+                if(__ballot(!all) == 0ull)
+                    break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        else
         {
             int  spins = 0, backoff = 1;
             bool all;
@@ -5213,7 +5239,7 @@ static int run_sf_plan(TriPlan* P, int dm, const T* rhs_src, const int* rhs_idx,
     // persistent waves, all resident (a wave only ever waits for units of lower number: held by resident waves)
     static const int waves_env = getenv("RAMD_TRSV_SF_WAVES") ? atoi(getenv("RAMD_TRSV_SF_WAVES")) : 0; // (per CU; experiments)
     static const int cap_env   = getenv("RAMD_TRSV_SF_POLLCAP") ? atoi(getenv("RAMD_TRSV_SF_POLLCAP")) : 8;
-    static const int gat_env   = getenv("RAMD_TRSV_SF_GATHER") ? atoi(getenv("RAMD_TRSV_SF_GATHER")) : 3; // (see k_trsv_sf)
+    static const int gat_env   = getenv("RAMD_TRSV_SF_GATHER") ? atoi(getenv("RAMD_TRSV_SF_GATHER")) : 4; // (see k_trsv_sf)
     unsigned nwg = 0;
     // RAMD_TRSV_SF_DBG=<file prefix> (tools/ diagnostics): two timestamps per unit, dumped after every solve with the unit table
     static const char*  dbg_path = getenv("RAMD_TRSV_SF_DBG");
