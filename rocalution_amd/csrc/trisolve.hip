@@ -4503,7 +4503,7 @@ static int ct_build_pair_lists(TriPlan* P, const int* key, int** pairs_out, int 
 //   * the out-of-group entries are subtracted one after the other through the row's lanes (DPP hand-over), the in-group ones in
 //     rounds through lane permutes; one publication per row.
 // The operations per row are those of host_matrix_csr.cpp:1163-1221 in their order: bit-exact (forced over the parity suite).
-constexpr int kSfKW = 6;
+constexpr int kSfKW = 6, kSfStreams = 8;
 
 static void sf_release(SfPlan** sp)
 {
@@ -4793,8 +4793,13 @@ __global__ __launch_bounds__(64) void k_trsv_sf(int nunits, const v4i32* __restr
                                                 const T* __restrict__ gcoef, const T* __restrict__ diag,
                                                 const T* __restrict__ rhs_src, const int* __restrict__ rhs_idx, T* w,
                                                 T* __restrict__ out, const int* __restrict__ order, int poll_cap, int gather_only,
-                                                const int* __restrict__ ufar, unsigned long long* __restrict__ dbg)
+                                                const int* __restrict__ ufar, unsigned long long* __restrict__ dbg, unsigned* tickets)
 {
+    // Units are taken by TICKET, so that a wave only ever waits for units held by waves that are running -- whatever share of the
+    // device this launch gets (a static round-robin over the grid would wait for waves that may never become resident next to
+    // another process's kernel).  One counter word serves ~88 tickets per microsecond and this solve wants ~75: kSfStreams words (own
+    // 128-byte lines), unit u belongs to stream u % kSfStreams, a wave is bound to the stream its START ticket names (the first
+    // kSfStreams waves to run cover every stream) and asks for its next unit while it works on this one.
     // (dbg: RAMD_TRSV_SF_DBG, two timestamps per unit -- dependencies there, result published)
     // gather_only 3 (default): one word per turn for the unit's LAST dependency, then gather; 0: one word per turn for a position
     // `ufar[u]` two levels back, then gather every turn (one round trip less on paper; measured equal, 4.2 / 6.9 against 4.1 / 6.9 ms
@@ -4807,8 +4812,22 @@ __global__ __launch_bounds__(64) void k_trsv_sf(int nunits, const v4i32* __restr
         dbg[2 * (int64_t)nunits]     = clock64();
         dbg[2 * (int64_t)nunits + 1] = wall_clock64();
     }
-    for(int u = blockIdx.x; u < nunits; u += gridDim.x)
+    unsigned start = 0;
+    if(lane == 0)
+        start = __hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int stream = (int)((unsigned)__builtin_amdgcn_readfirstlane((int)start) % (unsigned)kSfStreams);
+    unsigned* const my_counter = tickets + 32 * (1 + stream);
+    unsigned  tk = 0;
+    if(lane == 0)
+        tk = __hip_atomic_fetch_add(my_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for(;;)
     {
+        const long long uu = (long long)stream + (long long)kSfStreams * (unsigned)__builtin_amdgcn_readfirstlane((int)tk);
+        if(uu >= nunits)
+            break;
+        const int u = (int)uu;
+        if(lane == 0) // (the next unit: asked for now, looked at when this one is done)
+            tk = __hip_atomic_fetch_add(my_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const v4i32 ui  = uinfo[u];
         const int   p0  = __builtin_amdgcn_readfirstlane(ui.x);
         const int   cnt = __builtin_amdgcn_readfirstlane(ui.y) & 255, kw = (__builtin_amdgcn_readfirstlane(ui.y) >> 8) & 15;
@@ -4976,7 +4995,7 @@ static int build_sf_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower)
     // RAMD_TRSV_SF = 0: off, 1 (default): deep and narrow graphs, 2: whatever the shape (tests)
     static const int  sf_env  = getenv("RAMD_TRSV_SF") ? atoi(getenv("RAMD_TRSV_SF")) : 1;
     static const bool verbose = getenv("RAMD_TRSV_CT_VERBOSE") != nullptr;
-    static const int  sf_kw_min = getenv("RAMD_TRSV_SF_KW") ? std::min(kSfKW, std::max(1, atoi(getenv("RAMD_TRSV_SF_KW")))) : 4;
+    static const int  sf_kw_min = getenv("RAMD_TRSV_SF_KW") ? std::min(kSfKW, std::max(1, atoi(getenv("RAMD_TRSV_SF_KW")))) : 2;
     if(sf_env == 0 || n < 1 || (sf_env == 1 && n < 4096))
         return RAMD_ERR_UNSUPPORTED;
     int *brk = nullptr, *bscan = nullptr, *rstart = nullptr, *gs = nullptr, *gscan = nullptr, *gstart = nullptr, *gf = nullptr,
@@ -5157,8 +5176,9 @@ static int build_sf_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower)
             ++ngr;
             gmax = std::max(gmax, gm);
         }
-        // entries per lane: as few lanes as the rows need at up to sf_kw_min entries each (every lane in use is a hand-over in the
-        // chain of subtractions), more where the longest row asks for it
+        // entries per lane: at least sf_kw_min where the rows are that long, more where the longest row asks for it.  (Few per lane:
+        // few planes to fetch and few requests per polling turn, but more lanes in the chain of subtractions -- measured on the
+        // RCM shell, lower / upper ms per triangle: 2 per lane 3.46 / 5.12, 3: 3.71 / 5.19, 4: 4.05 / 5.34, 6: 4.4 / 5.7)
         const int kw = std::max(std::min(std::max(wmax, 1), sf_kw_min), (wmax + lpr - 1) / lpr);
         if(nplanes + kw > (int64_t)0x7fffffff / 64)
         {
@@ -5236,10 +5256,15 @@ static int run_sf_plan(TriPlan* P, int dm, const T* rhs_src, const int* rhs_idx,
     Backend&      b = backend();
     const SfPlan* S = P->sf;
     hipLaunchKernelGGL((k_fill_sentinel<T>), dim3(ew_grid(P->n)), dim3(kBlock), 0, b.cur, (int64_t)P->n, (T*)P->w);
-    // persistent waves, all resident (a wave only ever waits for units of lower number: held by resident waves)
+    // persistent waves, as many as the device holds (units by ticket: see k_trsv_sf)
     static const int waves_env = getenv("RAMD_TRSV_SF_WAVES") ? atoi(getenv("RAMD_TRSV_SF_WAVES")) : 0; // (per CU; experiments)
     static const int cap_env   = getenv("RAMD_TRSV_SF_POLLCAP") ? atoi(getenv("RAMD_TRSV_SF_POLLCAP")) : 8;
     static const int gat_env   = getenv("RAMD_TRSV_SF_GATHER") ? atoi(getenv("RAMD_TRSV_SF_GATHER")) : 4; // (see k_trsv_sf)
+    // ticket words of the launch: [0] start tickets, [32 (1 + s)] units of stream s -- zeroed before every launch
+    static unsigned* tickets = nullptr;
+    if(!tickets)
+        RAMD_HIP(hipMalloc(&tickets, sizeof(unsigned) * 32 * (1 + kSfStreams)));
+    RAMD_HIP(hipMemsetAsync(tickets, 0, sizeof(unsigned) * 32 * (1 + kSfStreams), b.cur));
     unsigned nwg = 0;
     // RAMD_TRSV_SF_DBG=<file prefix> (tools/ diagnostics): two timestamps per unit, dumped after every solve with the unit table
     static const char*  dbg_path = getenv("RAMD_TRSV_SF_DBG");
@@ -5257,7 +5282,8 @@ static int run_sf_plan(TriPlan* P, int dm, const T* rhs_src, const int* rhs_idx,
         {                                                                                                                     \
             int nb_cu = 0;                                                                                                    \
             RAMD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_cu, k_trsv_sf<T, DM, INF, LP>, 64, 0));                \
-            occ = nb_cu < 1 ? 1 : (nb_cu - 2 > 8 ? 8 : (nb_cu > 2 ? nb_cu - 2 : 1));                                          \
+            /* (4 per CU: measured 1 / 2 / 4 / 6 / 8 per CU on the RCM shell 5.3 / 4.3 / 4.4 / 4.4 / 4.5 ms per triangle) */          \
+            occ = nb_cu < 1 ? 1 : (nb_cu - 2 > 4 ? 4 : (nb_cu > 2 ? nb_cu - 2 : 1));                                          \
             if(waves_env > 0 && waves_env < occ)                                                                              \
                 occ = waves_env;                                                                                              \
         }                                                                                                                     \
@@ -5265,7 +5291,7 @@ static int run_sf_plan(TriPlan* P, int dm, const T* rhs_src, const int* rhs_idx,
         nwg               = (unsigned)(S->nunits < cap ? S->nunits : cap);                                                    \
         hipLaunchKernelGGL((k_trsv_sf<T, DM, INF, LP>), dim3(nwg), dim3(64), 0, b.cur, S->nunits, (const v4i32*)S->uinfo,     \
                            S->pinfo, S->ecol, (const T*)S->eval, (const T*)S->gcoef, (const T*)P->diag, rhs_src, rhs_idx,      \
-                           (T*)P->w, out, P->order, cap_env, gat_env, S->ufar, dbg);                                          \
+                           (T*)P->w, out, P->order, cap_env, gat_env, S->ufar, dbg, tickets);                                 \
     } while(0)
 #define TRSV_SF_L(DM, INF)      \
     do                          \
