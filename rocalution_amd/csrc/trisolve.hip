@@ -4941,21 +4941,24 @@ __global__ __launch_bounds__(64) void k_trsv_sf(int nunits, const v4i32* __restr
         const bool one  = ((__builtin_amdgcn_readfirstlane(ui.y) >> 16) & 1) != 0;
         const int  maxm = (__builtin_amdgcn_readfirstlane(ui.y) >> 17) & 15;
         T          res;
-        // (four straight-line bodies, chosen per unit)
-        if(kw <= 4)
-        {
-            if(one)
-                res = sf_compute<T, DMODE, INFIRST, LPR, 4, true>(rhs, dg, gc, prod, r, l, slot, nl, maxm);
-            else
-                res = sf_compute<T, DMODE, INFIRST, LPR, 4, false>(rhs, dg, gc, prod, r, l, slot, nl, maxm);
-        }
+        // (straight-line bodies for 2 / 3 / 4 / 6 subtractions per lane, one group or several: chosen per unit)
+#define SF_BODY(NA_)                                                                                             \
+    do                                                                                                           \
+    {                                                                                                            \
+        if(one)                                                                                                  \
+            res = sf_compute<T, DMODE, INFIRST, LPR, NA_, true>(rhs, dg, gc, prod, r, l, slot, nl, maxm);        \
+        else                                                                                                     \
+            res = sf_compute<T, DMODE, INFIRST, LPR, NA_, false>(rhs, dg, gc, prod, r, l, slot, nl, maxm);       \
+    } while(0)
+        if(kw <= 2)
+            SF_BODY(2);
+        else if(kw == 3)
+            SF_BODY(3);
+        else if(kw == 4)
+            SF_BODY(4);
         else
-        {
-            if(one)
-                res = sf_compute<T, DMODE, INFIRST, LPR, kSfKW, true>(rhs, dg, gc, prod, r, l, slot, nl, maxm);
-            else
-                res = sf_compute<T, DMODE, INFIRST, LPR, kSfKW, false>(rhs, dg, gc, prod, r, l, slot, nl, maxm);
-        }
+            SF_BODY(kSfKW);
+#undef SF_BODY
         if(dbg)
         {
             asm volatile("" : "+v"(res));
@@ -5277,16 +5280,19 @@ static int run_sf_plan(TriPlan* P, int dm, const T* rhs_src, const int* rhs_idx,
 #define TRSV_SF(DM, INF, LP)                                                                                                  \
     do                                                                                                                        \
     {                                                                                                                         \
-        static int occ = 0;                                                                                                   \
-        if(occ == 0)                                                                                                          \
+        static int occ_max = 0;                                                                                               \
+        if(occ_max == 0)                                                                                                      \
         {                                                                                                                     \
             int nb_cu = 0;                                                                                                    \
             RAMD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_cu, k_trsv_sf<T, DM, INF, LP>, 64, 0));                \
-            /* (4 per CU: measured 1 / 2 / 4 / 6 / 8 per CU on the RCM shell 5.3 / 4.3 / 4.4 / 4.4 / 4.5 ms per triangle) */          \
-            occ = nb_cu < 1 ? 1 : (nb_cu - 2 > 4 ? 4 : (nb_cu > 2 ? nb_cu - 2 : 1));                                          \
-            if(waves_env > 0 && waves_env < occ)                                                                              \
-                occ = waves_env;                                                                                              \
+            occ_max = nb_cu < 1 ? 1 : (nb_cu - 2 > 8 ? 8 : (nb_cu > 2 ? nb_cu - 2 : 1));                                      \
         }                                                                                                                     \
+        /* waves per CU: a narrow graph is bound by its chain of hand-offs and runs best with few waves around it (1 / 2 / 4 / */ \
+        /* 6 / 8 per CU on the RCM shell: 5.3 / 4.3 / 4.4 / 4.4 / 4.5 ms per triangle), a wide one by its throughput (the     */ \
+        /* random numbering, 16 700 units per level: 1.10 ms with 4 per CU, 0.67 with 8)                                      */ \
+        int occ = ((int64_t)S->nunits >= (int64_t)1024 * S->nglev) ? occ_max : (occ_max < 4 ? occ_max : 4);                   \
+        if(waves_env > 0 && waves_env < occ_max)                                                                              \
+            occ = waves_env;                                                                                                  \
         const int64_t cap = (int64_t)occ * b.num_cu;                                                                          \
         nwg               = (unsigned)(S->nunits < cap ? S->nunits : cap);                                                    \
         hipLaunchKernelGGL((k_trsv_sf<T, DM, INF, LP>), dim3(nwg), dim3(64), 0, b.cur, S->nunits, (const v4i32*)S->uinfo,     \
