@@ -285,7 +285,6 @@ def roof(name, bytes_alg, p, traffic=None):
 
 TRI_FORMS = {0: "none", 1: "level-scheduled rows (k_trsv)", 2: "box tiles, record form (k_trsv_rec)",
              3: "box tiles with row groups (k_trsv_rec, grouped)", 4: "lattice pencils (k_trsv_lat)",
-             5: "levels walked by one workgroup (k_trsv_band: a deep, narrow dependency graph)",
              6: "row groups handed from wave to wave (k_trsv_sf: a deep, narrow dependency graph of long rows; tiles = units of whole "
                 "row groups of one group level, steps = row groups)"}
 
@@ -305,7 +304,7 @@ def tri_plan_stats(lib, capi):
         if st[0] == 4:
             d["lattice"] = [int(st[9]), int(st[10]), int(st[11])]
             d["plan_bytes"] = int(st[12])
-        elif st[0] in (1, 5, 6):
+        elif st[0] in (1, 6):
             d["why_not_box_tiles"] = {0: "", 1: "no chains of consecutively numbered dependent rows (mean chain length < 8): the tile coordinates of "
                                          "the box-tile form are built on such chains", 2: "no dependencies", 3: "triangular rows longer than 32 "
                                          "entries that do not form row groups", 4: "tile key range", 5: "entry index range",

@@ -369,308 +369,26 @@ __global__ __launch_bounds__(kBlock) void k_trsv(int nrow, const int* __restrict
     } while(__ballot(!fin) != 0ull);
 }
 
-// ---------------------------------------------------------------- band form: ONE workgroup walks the levels
-// The level-scheduled kernel above pays a cross-CU hand-off per dependency level (~9 us with rows of 35 entries).  That is the
-// right trade where a level holds thousands of rows; it is a disaster on a DEEP and NARROW dependency graph that the box tiles
-// cannot take -- a shell mesh numbered by reverse Cuthill-McKee or by an advancing front has ~10 700 levels of ~140 rows and
-// no chains of consecutively numbered rows for the tile coordinates to grow along: 95 ms per triangle, GMRES(30)+ILU(0) at
-// 5 it/s, slower than the host (profiles/r05_shell_variants.json).  A level of 140 rows does not need 256 CUs; it needs the
-// next level to start the moment this one ends.  So ONE workgroup (512 threads, one CU) walks the whole plan in position order:
-//   * rounds of 256 positions, two lanes per row with up to 24 entries each (rows of up to 48 entries); the row data of the
-//     NEXT round is requested into registers while the levels of this round run (what a thread loads does not depend on the
-//     solution, only on its position: the assignment thread -> position is static);
-//   * the levels inside a round (positions are sorted by level) run one after the other behind a workgroup barrier -- ~0.1 us
-//     instead of a trip through the L2 -- every lane forming its products at once and the two lanes of a row subtracting them
-//     in storage order, the second lane continuing the first one's sum (DPP): the operations of the host loop in its order;
-//   * the solution of the last 8192 positions lives in an LDS window (a row's dependencies are gathered there; older ones,
-//     beyond the window, from w in memory -- written by this workgroup itself, visible to it behind the barrier).
-// The plan arrays are those of the level-scheduled form (k_tri_fill), plus the level of every position.
-constexpr int kBandThreads = 512, kBandGroups = 2, kBandRows = kBandThreads / kBandGroups / 2, kBandW = 24, kBandWin = 16384;
+// value of lane - 1 of the same 16-lane row (DPP row_shr:1): the hand-over of a running sum from lane to lane of a row
 template <typename T>
-__device__ __forceinline__ T band_from_lane_before(T v); // value of lane - 1 (pairs never cross a row of 16 lanes)
+__device__ __forceinline__ T lane_before_in_row(T v);
 template <>
-__device__ __forceinline__ double band_from_lane_before<double>(double v)
+__device__ __forceinline__ double lane_before_in_row<double>(double v)
 {
     const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x111, 0xf, 0xf, true);
     const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x111, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 template <>
-__device__ __forceinline__ float band_from_lane_before<float>(float v)
+__device__ __forceinline__ float lane_before_in_row<float>(float v)
 {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x111, 0xf, 0xf, true));
 }
-// The requests of the kernel are issued by hand and waited for by COUNT (as in trsv_lattice.hip): left to the compiler, the
-// loop around them got a vmcnt(0) per round -- every round waited for the requests just issued for the round after next,
-// 1.35 us per step where a barrier step of one workgroup costs 0.1-0.25 us (tools/onewg.hip).
-__device__ __forceinline__ int band_ld(const int* p)
-{
-    int r;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(p) : "memory");
-    return r;
-}
-__device__ __forceinline__ double band_ld(const double* p)
-{
-    double r;
-    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
-    return r;
-}
-__device__ __forceinline__ float band_ld(const float* p)
-{
-    float r;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(p) : "memory");
-    return r;
-}
-__device__ __forceinline__ void band_st(double* p, double v)
-{
-    asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void band_st(float* p, float v)
-{
-    asm volatile("global_store_dword %0, %1, off\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void band_wait()
-{
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-template <typename X>
-__device__ __forceinline__ void band_tie(X& v)
-{
-    asm volatile("" : "+v"(v));
-}
-
-// (two groups of 256 threads take the rounds of 128 positions in turn: while one group runs the levels of its round, the
-//  other one's requests for its next round are in flight -- one register buffer per thread, every index static)
-template <typename T, int DMODE>
-__global__ __launch_bounds__(kBandThreads) void k_trsv_band(int nrow, const int* __restrict__ slice_off, const int* __restrict__ ecol,
-                                                           const T* __restrict__ eval, const T* __restrict__ diag,
-                                                           const int* __restrict__ plev, const T* __restrict__ rhs_src,
-                                                           const int* __restrict__ rhs_idx, T* w, T* __restrict__ out,
-                                                           const int* __restrict__ order, int dbg)
-{
-    extern __shared__ __attribute__((aligned(16))) char band_lds[];
-    T*        win = reinterpret_cast<T*>(band_lds);
-    const int g = threadIdx.x / (kBandThreads / kBandGroups), t = threadIdx.x % (kBandThreads / kBandGroups);
-    const int q = t >> 1, h = t & 1;
-    T* const  dump = w + nrow + (threadIdx.x & 15); // (inside the allocation's padding: what lanes without a result store)
-    int       cbuf[kBandW];
-    T         abuf[kBandW];
-    T         rhs = (T)0, dg = (T)1, res = (T)0;
-    int       mylev = -1, onat = 0, nw = 0;
-    bool      have = false;
-    // what the requests of a row hang on -- its slice's offsets, where its right-hand side sits -- is read one turn earlier still
-    int n_b0 = 0, n_b1 = 0, n_ridx = 0, n_lev = -1, n_onat = 0;
-    T   n_dg = (T)1;
-    // ... and with it the levels of the two rounds before that row's: a round's levels are those of its first and last
-    // position (positions are sorted by level).  Vector loads like the rest: a SCALAR load in flight would be waited for by
-    // the lgkmcnt(0) in front of every barrier (LDS and scalar memory share that counter) -- a round trip per round.
-    int n_l10 = 0, n_l11 = 0, n_l20 = 0, n_l21 = 0;
-    constexpr int kOpsLA = 10; // vector memory operations of a look-ahead
-#define BAND_LOOK_AHEAD(ROUND)                                               \
-    do                                                                       \
-    {                                                                        \
-        const int64_t p_  = (int64_t)(ROUND)*kBandRows + q;                  \
-        const int64_t pp_ = p_ < nrow ? p_ : 0;                              \
-        n_b0   = band_ld(slice_off + (pp_ >> 6));                            \
-        n_b1   = band_ld(slice_off + (pp_ >> 6) + 1);                        \
-        n_ridx = band_ld(rhs_idx + pp_);                                     \
-        n_lev  = band_ld(plev + pp_);                                        \
-        n_dg   = band_ld(DMODE == 0 ? rhs_src : diag + pp_);                 \
-        n_onat = band_ld(out ? order + pp_ : plev);                          \
-        const int r1_ = max((ROUND)-1, 0), r2_ = (ROUND);                    \
-        n_l10 = band_ld(plev + min((int64_t)r1_ * kBandRows, (int64_t)nrow - 1));        \
-        n_l11 = band_ld(plev + (min(((int64_t)r1_ + 1) * kBandRows, (int64_t)nrow) - 1)); \
-        n_l20 = band_ld(plev + min((int64_t)r2_ * kBandRows, (int64_t)nrow - 1));        \
-        n_l21 = band_ld(plev + (min(((int64_t)r2_ + 1) * kBandRows, (int64_t)nrow) - 1)); \
-    } while(0)
-#define BAND_TIE_LA()      \
-    do                     \
-    {                      \
-        band_tie(n_b0);    \
-        band_tie(n_b1);    \
-        band_tie(n_ridx);  \
-        band_tie(n_lev);   \
-        band_tie(n_dg);    \
-        band_tie(n_onat);  \
-        band_tie(n_l10);   \
-        band_tie(n_l11);   \
-        band_tie(n_l20);   \
-        band_tie(n_l21);   \
-    } while(0)
-    // (2 kBandW + 1 operations; entries beyond the row read the row's first one and are masked when the data is taken over)
-#define BAND_REQUEST(ROUND)                                                                              \
-    do                                                                                                   \
-    {                                                                                                    \
-        const int64_t  p_  = (int64_t)(ROUND)*kBandRows + q;                                             \
-        const unsigned o_  = (unsigned)(n_b0 + (int)(p_ & 63));                                          \
-        nw    = (p_ < nrow && !(dbg & 1)) ? ((n_b1 - n_b0) >> 6) - h * kBandW : 0;                       \
-        have  = p_ < nrow;                                                                               \
-        mylev = have ? n_lev : -1;                                                                       \
-        dg    = DMODE == 0 ? (T)1 : n_dg;                                                                \
-        onat  = n_onat;                                                                                  \
-        _Pragma("unroll") for(int e = 0; e < kBandW; ++e)                                                \
-        {                                                                                                \
-            const unsigned oe_ = e < nw ? o_ + (unsigned)((h * kBandW + e) * 64) : o_;                   \
-            cbuf[e] = band_ld(ecol + oe_);                                                               \
-            abuf[e] = band_ld(eval + oe_);                                                               \
-        }                                                                                                \
-        rhs = band_ld(rhs_src + n_ridx);                                                                 \
-    } while(0)
-    const int nrounds = (nrow + kBandRows - 1) / kBandRows;
-    BAND_LOOK_AHEAD(g);
-    band_wait<0>();
-    BAND_TIE_LA();
-    BAND_REQUEST(g);
-    BAND_LOOK_AHEAD(g + kBandGroups);
-    int lev0 = plev[0], lev1 = plev[min(kBandRows, nrow) - 1]; // (rounds 0 and 1: read here, before the pipeline starts)
-    int a_lev0 = plev[min(kBandRows, nrow - 1)], a_lev1 = plev[min(2 * kBandRows, nrow) - 1];
-    // (used here, so that the compiler waits for these four loads HERE: carried into the loop as "possibly in flight" they cost
-    //  a vmcnt(0) per round -- which for the idle half is a wait for the requests it has just issued)
-    lev0 = __builtin_amdgcn_readfirstlane(lev0), lev1 = __builtin_amdgcn_readfirstlane(lev1);
-    a_lev0 = __builtin_amdgcn_readfirstlane(a_lev0), a_lev1 = __builtin_amdgcn_readfirstlane(a_lev1);
-    int b_lev0 = a_lev0, b_lev1 = a_lev1;
-    for(int round = 0; round < nrounds; ++round)
-    {
-        const int  base = round * kBandRows;
-        const bool mine = (round % kBandGroups) == g; // (uniform per wave: a group is four whole waves)
-        const int  pl   = base + q;
-        if(mine)
-        {
-            // my row of this round has arrived: only the look-ahead behind it is younger
-            band_wait<kOpsLA>();
-#pragma unroll
-            for(int e = 0; e < kBandW; ++e)
-            {
-                band_tie(cbuf[e]);
-                band_tie(abuf[e]);
-                if(e >= nw)
-                    cbuf[e] = -1;
-            }
-            band_tie(rhs);
-        }
-        for(int lev = lev0; lev <= lev1; ++lev)
-        {
-            if(mine && mylev == lev && !(dbg & 2))
-            {
-                // (the products overwrite the values: a row is used once; eight gathers at a time)
-                const int thr = base + kBandRows - kBandWin; // older positions have left the window
-#pragma unroll
-                for(int e0 = 0; e0 < kBandW; e0 += 8)
-                {
-                    T    x[8];
-                    bool far = false;
-#pragma unroll
-                    for(int e = 0; e < 8; ++e)
-                    {
-                        const int c = cbuf[e0 + e];
-                        x[e]        = c >= 0 ? win[c & (kBandWin - 1)] : (T)0;
-                        far         = far || (c >= 0 && c < thr);
-                    }
-                    if(__any(far)) // (a dependency farther back than the window: from memory, past the L1)
-                    {
-#pragma unroll
-                        for(int e = 0; e < 8; ++e)
-                        {
-                            const int c = cbuf[e0 + e];
-                            if(c >= 0 && c < thr)
-                                x[e] = Sentinel<T>::from_bits(poll_load(w + c));
-                        }
-                    }
-#pragma unroll
-                    for(int e = 0; e < 8; ++e)
-                        abuf[e0 + e] = abuf[e0 + e] * x[e];
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                T sum = rhs;
-                if(h == 0)
-                {
-#pragma unroll
-                    for(int e = 0; e < kBandW; ++e)
-                        if(cbuf[e] >= 0)
-                            sum -= abuf[e];
-                }
-                const T first = band_from_lane_before<T>(sum);
-                if(h == 1)
-                {
-                    sum = first;
-#pragma unroll
-                    for(int e = 0; e < kBandW; ++e)
-                        if(cbuf[e] >= 0)
-                            sum -= abuf[e];
-                    if(DMODE == 1)
-                        sum /= dg;
-                    else if(DMODE == 2)
-                        sum = sum * dg;
-                    win[pl & (kBandWin - 1)] = sum;
-                    res                      = sum;
-                }
-            }
-            // the waves share the LDS window only: wait for the LDS, not for memory (__syncthreads() drains the vector memory
-            // queue as well).  What is read from w in memory was stored more than 16000 positions ago.
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        }
-        if(mine)
-        {
-            // the round's results leave (every lane stores: the ones without a result into the padding), then the requests of
-            // my next round -- what they hang on was looked up a turn ago: only the two stores are younger -- and the next look-ahead
-            const bool st = have && h == 1;
-            band_st(st ? w + pl : dump, res);
-            band_st((st && out) ? out + onat : dump, res);
-            band_wait<2>();
-            BAND_TIE_LA();
-            a_lev0 = n_l10, a_lev1 = n_l11; // (the look-ahead that has just arrived: levels of the next two rounds)
-            b_lev0 = n_l20, b_lev1 = n_l21;
-            BAND_REQUEST(round + kBandGroups);
-            BAND_LOOK_AHEAD(round + 2 * kBandGroups);
-        }
-        lev0 = __builtin_amdgcn_readfirstlane(a_lev0), lev1 = __builtin_amdgcn_readfirstlane(a_lev1);
-        a_lev0 = b_lev0, a_lev1 = b_lev1;
-    }
-    band_wait<0>();
-#undef BAND_REQUEST
-#undef BAND_TIE_LA
-#undef BAND_LOOK_AHEAD
-}
-
-__global__ void k_ct_gather_int(int64_t n, const int* __restrict__ src, const int* __restrict__ idx, int* __restrict__ dst);
-// entries of a level plan whose dependency lies farther back than the window of k_trsv_band (diagnostics)
-__global__ __launch_bounds__(kBlock) void k_band_far(int n, const int* __restrict__ slice_off, const int* __restrict__ ecol,
-                                                     unsigned long long* __restrict__ out)
-{
-    const int64_t      gsz = (int64_t)gridDim.x * blockDim.x;
-    unsigned long long far = 0, all = 0;
-    for(int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gsz)
-    {
-        const int b0 = slice_off[p >> 6], wd = (slice_off[(p >> 6) + 1] - b0) >> 6;
-        for(int k = 0; k < wd; ++k)
-        {
-            const int c = ecol[b0 + k * 64 + (int)(p & 63)];
-            if(c >= 0)
-            {
-                ++all;
-                far += ((int)p - c > kBandWin - 2 * kBandRows) ? 1 : 0;
-            }
-        }
-    }
-    if(far)
-        atomicAdd(out, far);
-    if(all)
-        atomicAdd(out + 1, all);
-}
-// widest slice (entries per row) of a level plan
-__global__ __launch_bounds__(kBlock) void k_band_maxw(int nslices, const int* __restrict__ slice_off, int* __restrict__ out)
-{
-    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
-    int           mx  = 0;
-    for(int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nslices; s += gsz)
-        mx = max(mx, (slice_off[s + 1] - slice_off[s]) >> 6);
-#pragma unroll
-    for(int off = 32; off > 0; off >>= 1)
-        mx = max(mx, __shfl_xor(mx, off, 64));
-    if((threadIdx.x & 63) == 0 && mx > 0)
-        atomicMax(out, mx);
-}
+// (The band form of round 5 -- k_trsv_band: ONE workgroup walking the levels of a deep, narrow dependency graph behind workgroup
+//  barriers, the last 16 384 values in an LDS window, the row data requested a round ahead by hand-counted loads -- stood here:
+//  46 ms per triangle on the RCM-numbered shell against 95 ms of the level-scheduled rows, bound by the load path of its one CU.
+//  The sync-free grouped form further down (k_trsv_sf) solves the same triangles in 3.4 / 4.7 ms and is asked first for every
+//  matrix the band form took; it was removed with its forced parity test at the end of the round.  DESIGN.md section 9.1a.)
 
 // ---------------------------------------------------------------- ILU(0), natural order, sync-free
 // host_matrix_csr.cpp:2096-2171.  Thread per row; a row waits for every pivot row k < i of its
@@ -1037,9 +755,6 @@ struct TriPlan
     // lattice form (trsv_lattice.hip): the triangle of a 5- / 7-point lattice operator, pencils marched along x; such a plan
     // has no order / pos / w -- it reads and writes natural-order vectors
     LatPlan* lat = nullptr;
-    // band form (k_trsv_band): a deep, narrow dependency graph walked by one workgroup; the level of every position
-    bool band      = false;
-    int* band_plev = nullptr;
     // sync-free grouped form (k_trsv_sf): a deep, narrow dependency graph of long rows, one row group per hand-off
     SfPlan* sf = nullptr;
     // what the analysis found (ramd_tri_plan_stats): chains, external values of all tiles, box edges
@@ -1050,8 +765,6 @@ struct TriPlan
     {
         lat_release(&lat);
         sf_release(&sf);
-        dev_free(&band_plev);
-        band = false;
         dev_free(&ct_tile_step);
         dev_free(&ct_step_pos);
         dev_free(&ct_step_ent);
@@ -1459,55 +1172,6 @@ static int build_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bool 
     }
     P->nlevels = nlev;
     dev_free(&nodiag);
-    // deep and narrow (fewer than 1024 rows per level on average), rows of at most 48 entries: the band form
-    // (RAMD_TRSV_BAND = 0: off, 2: whatever the shape -- tests)
-    const int band_env = getenv("RAMD_TRSV_BAND") ? atoi(getenv("RAMD_TRSV_BAND")) : 1;
-    if(s == RAMD_OK && !natural && band_env != 0 && nlev > 0 && (band_env == 2 || (n >= 4096 && (int64_t)n < (int64_t)1024 * nlev)))
-    {
-        int* lvl  = nullptr;
-        int  nl2  = 0, maxw = 0;
-        int* dmax = nullptr;
-        s = level_order(m, st, lower, nullptr, &nl2, &lvl);
-        if(s == RAMD_OK)
-            s = dev_alloc(&dmax, 1);
-        if(s == RAMD_OK)
-        {
-            hipError_t e = hipMemsetAsync(dmax, 0, sizeof(int), b.cur);
-            hipLaunchKernelGGL(k_band_maxw, dim3(ew_grid(P->nslices)), dim3(kBlock), 0, b.cur, P->nslices, P->slice_off, dmax);
-            if(e == hipSuccess)
-                e = hipMemcpyAsync(&maxw, dmax, sizeof(int), hipMemcpyDeviceToHost, b.cur);
-            if(e == hipSuccess)
-                e = hipStreamSynchronize(b.cur);
-            if(e != hipSuccess)
-                s = RAMD_ERR_HIP;
-        }
-        if(s == RAMD_OK && maxw <= 2 * kBandW)
-        {
-            s = dev_alloc(&P->band_plev, n);
-            if(s == RAMD_OK)
-            {
-                hipLaunchKernelGGL(k_ct_gather_int, dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, (int64_t)n, lvl, P->order, P->band_plev);
-                P->band = hipGetLastError() == hipSuccess && hipStreamSynchronize(b.cur) == hipSuccess;
-            }
-        }
-        dev_free(&lvl);
-        dev_free(&dmax);
-        static const bool verbose = getenv("RAMD_TRSV_CT_VERBOSE") != nullptr;
-        if(verbose && s == RAMD_OK)
-        {
-            unsigned long long *dfar = nullptr, hfar[2] = {0, 0};
-            if(dev_alloc(&dfar, 2) == RAMD_OK && hipMemsetAsync(dfar, 0, 16, b.cur) == hipSuccess)
-            {
-                hipLaunchKernelGGL(k_band_far, dim3(ew_grid(n)), dim3(kBlock), 0, b.cur, n, P->slice_off, P->ecol, dfar);
-                (void)hipMemcpyAsync(hfar, dfar, 16, hipMemcpyDeviceToHost, b.cur);
-                (void)hipStreamSynchronize(b.cur);
-            }
-            dev_free(&dfar);
-            fprintf(stderr, "band plan (%s): n=%d levels=%d (%.0f rows per level), longest row %d, %.3f %% of the dependencies beyond the window%s\n",
-                    lower ? "lower" : "upper", n, nlev, (double)n / nlev, maxw, hfar[1] ? 100.0 * (double)hfar[0] / (double)hfar[1] : 0.0,
-                    P->band ? "" : ": rows too long, level-scheduled form");
-        }
-    }
     if(s != RAMD_OK)
         P->release();
     return s;
@@ -4487,7 +4151,7 @@ static int ct_build_pair_lists(TriPlan* P, const int* key, int** pairs_out, int 
 // For dependency graphs that are DEEP AND NARROW with LONG rows and no chains for the tile coordinates to grow along -- a shell
 // mesh (5 unknowns per node, ~35 entries per row) numbered by reverse Cuthill-McKee or by an advancing front: ~10 700 row
 // levels of ~140 rows.  The level-scheduled kernel pays ~9 us per level there (one lane per row: the row's entries come in
-// dependent chunks of eight, each behind a poll), the band form ~4 us (one CU's load path).  What such a graph needs per level is
+// dependent chunks of eight, each behind a poll), the band form that stood here for a while ~4 us (one CU's load path).  What such a graph needs per level is
 // ONE hand-off and nothing else on the critical path:
 //   * the unit of work is a ROW GROUP (k_ct_sn_breaks: the rows of one mesh node -- row t depends on row t-1 and shares every
 //     other dependency with it): 2 140 group levels instead of 10 700; the in-group part of a step runs in registers, in the
@@ -4652,7 +4316,7 @@ __device__ __forceinline__ T sf_chain(T s, const T (&prod)[kSfKW], int l, int nl
     {
         if(step >= nl)
             break;
-        T t = step > 0 ? band_from_lane_before<T>(s) : s;
+        T t = step > 0 ? lane_before_in_row<T>(s) : s;
 #pragma unroll
         for(int k = 0; k < NA; ++k)
             t -= prod[k];
@@ -5366,27 +5030,6 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
     {
         P->w_sentinel = P->prefilled_next = false;
         return run_sf_plan<T>(P, mul_inv_diag ? 2 : (unit ? 0 : 1), rhs_src, rhs_idx, out);
-    }
-    if(P->band)
-    {
-        // one workgroup walks the levels (k_trsv_band): nothing is polled, so w needs no sentinels
-        const size_t lds = (size_t)kBandWin * sizeof(T);
-        static const int band_dbg = getenv("RAMD_BAND_DBG") ? atoi(getenv("RAMD_BAND_DBG")) : 0; // (tools/: 1 no entries, 2 no arithmetic)
-        prof_begin(RAMD_PROF_TRSV, b.cur);
-#define TRSV_BAND(DM)                                                                                                          \
-    hipLaunchKernelGGL((k_trsv_band<T, DM>), dim3(1), dim3(kBandThreads), lds, b.cur, P->n, P->slice_off, P->ecol, (const T*)P->eval, \
-                       (const T*)P->diag, P->band_plev, rhs_src, rhs_idx, (T*)P->w, out, P->order, band_dbg)
-        if(mul_inv_diag)
-            TRSV_BAND(2);
-        else if(unit)
-            TRSV_BAND(0);
-        else
-            TRSV_BAND(1);
-#undef TRSV_BAND
-        prof_end(RAMD_PROF_TRSV, b.cur);
-        P->w_sentinel = P->prefilled_next = false;
-        RAMD_HIP(hipGetLastError());
-        return RAMD_OK;
     }
     const unsigned nb = nblocks_of(P->n);
     static const bool nofill = getenv("RAMD_TRSV_NOFILL") != nullptr; // diagnostic only (tools/): no dependency waits
@@ -6960,7 +6603,7 @@ static void tri_note_stats(const ramd_mat_s* m, const TriPlan* P, int which)
         o[12] = (long long)(li.coef_bytes + li.face_bytes);
         return;
     }
-    o[0] = !P->ct ? (P->sf ? 6 : (P->band ? 5 : 1)) : (P->ct_grp ? 3 : 2);
+    o[0] = !P->ct ? (P->sf ? 6 : 1) : (P->ct_grp ? 3 : 2); // (5 was the band form of round 5)
     o[2] = P->nlevels;
     if(P->sf)
     {

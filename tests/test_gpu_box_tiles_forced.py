@@ -161,20 +161,3 @@ def test_ragged_rows_from_1_to_60_entries_bit_exact(tmp_path, dedup):
     assert p.returncode == 0, p.stdout[-4000:]
     assert "checked 8" in p.stdout, p.stdout[-4000:]
     assert "wmax=" in p.stdout and "box-tile plan (lower)" in p.stdout, p.stdout[-2000:]
-
-
-@pytest.mark.gpu
-def test_parity_suite_with_the_band_form_forced():
-    """k_trsv_band (one workgroup walks the levels of a deep, narrow dependency graph: the form a shell mesh in reverse
-    Cuthill-McKee order takes, tests/test_gpu_shell.py) on every matrix of the parity suite: RAMD_TRSV_BAND=2 with the tiles and
-    the lattice form switched off -- ILU(0) / IC factors + LUSolve / LLSolve / LSolve / USolve goldens, preconditioner applies,
-    solver histories, the config-3 class in four numberings: bit-exact as the level-scheduled kernel is."""
-    env = dict(os.environ, RAMD_TRSV_BAND="2", RAMD_TRSV_CT="0", RAMD_TRSV_LAT="0", RAMD_TRSV_SF="0", RAMD_TRSV_CT_VERBOSE="1")
-    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-s", "-m", "gpu", "-p", "no:cacheprovider",
-           os.path.join(ROOT, "tests", "test_gpu_kernels.py"), os.path.join(ROOT, "tests", "test_gpu_solvers.py"),
-           os.path.join(ROOT, "tests", "test_gpu_shell.py"), "-k", SELECT + " or variants_of_the_class"]
-    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
-    tail = p.stdout[-3000:]
-    assert p.returncode == 0, tail
-    assert " passed" in tail and "failed" not in tail, tail
-    assert "band plan (lower)" in p.stdout and "band plan (upper)" in p.stdout, tail

@@ -14,7 +14,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SELECT = ("((ilu or lusolve or trisolve or preconditioner_apply or sgs or solvers_vs_golden or rebuild_numeric or gmres30_ilu0) "
           "and not full_size and not cpp and not fresh_process) or variants_of_the_class")
-FORCED = dict(RAMD_TRSV_SF="2", RAMD_TRSV_CT="0", RAMD_TRSV_LAT="0", RAMD_TRSV_BAND="0", RAMD_TRSV_CT_VERBOSE="1")
+FORCED = dict(RAMD_TRSV_SF="2", RAMD_TRSV_CT="0", RAMD_TRSV_LAT="0", RAMD_TRSV_CT_VERBOSE="1")
 
 
 @pytest.mark.gpu
