@@ -308,7 +308,8 @@ def tri_plan_stats(lib, capi):
             d["why_not_box_tiles"] = {0: "", 1: "no chains of consecutively numbered dependent rows (mean chain length < 8): the tile coordinates of "
                                          "the box-tile form are built on such chains", 2: "no dependencies", 3: "triangular rows longer than 32 "
                                          "entries that do not form row groups", 4: "tile key range", 5: "entry index range",
-                                      6: "the tiles cannot be made to fit the LDS", 7: "too few rows", 8: "switched off"}.get(int(st[12]), str(st[12]))
+                                      6: "the tiles cannot be made to fit the LDS", 7: "too few rows", 8: "switched off",
+                                      9: "row groups with more than 24 entries outside the group (the sync-free grouped form takes these)"}.get(int(st[12]), str(st[12]))
         elif st[0] in (2, 3):
             d["box"] = [int(st[9]), int(st[10]), int(st[11])]
             d["chains"] = int(st[13])

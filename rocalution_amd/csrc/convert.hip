@@ -838,6 +838,7 @@ int ramd_mat_cast(ramd_mat_t src, ramd_mat_t* out)
                                (double*)m->val, (const float*)src->val);
         RAMD_HIP(hipGetLastError());
     }
+    m->pat_off = src->pat_off; // (ramd_mat_pattern_use(src, 0) holds for the value-cast copy too: MixedPrecisionDC's inner operator)
     *out = m;
     return RAMD_OK;
 }

@@ -1024,6 +1024,7 @@ static const char* ct_why_text(int why)
     case 6: return "the tiles cannot be made to fit the LDS";
     case 7: return "fewer rows than the box-tile form is worth (RAMD_TRSV_CT_MINROWS)";
     case 8: return "switched off (RAMD_TRSV_CT=0)";
+    case 9: return "row groups with more than 24 entries outside the group: the sync-free grouped form takes these";
     default: return "";
     }
 }
@@ -3413,6 +3414,15 @@ static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
             {
                 dev_free(&gf);
                 dev_free(&gl);
+            }
+            // supernodes whose rows are too long for the grouped record: as single rows they are five times as many levels (the
+            // state of round 2), and the analysis sweeps of that form cost 0.5 s on a front-ordered shell before its tiles turn out
+            // not to fit -- the sync-free grouped form keeps the groups and takes rows of up to 48 entries outside them
+            static const int sf_on = getenv("RAMD_TRSV_SF") ? atoi(getenv("RAMD_TRSV_SF")) : 1;
+            if(!grp && sf_on != 0 && !reverse && wout <= 8 * 6 && n >= 4096)
+            {
+                drop();
+                CT_GIVE_UP(9);
             }
         }
         drop();

@@ -1,6 +1,3 @@
-cd /root/repo
-for N in 512 256; do
-RAMD_LAT_NODEP=1 TAG=nodep timeout 300 python tools/trsv_time.py poisson $N
-for w in 2 4 7; do RAMD_LAT_WGS_PER_CU=$w TAG=wgs$w timeout 300 python tools/trsv_time.py poisson $N; done
-for w in 4 7; do RAMD_LAT_NODEP=1 RAMD_LAT_WGS_PER_CU=$w TAG=nodep_wgs$w timeout 300 python tools/trsv_time.py poisson $N; done
-done
+R=${GRAFT_REPO_ROOT:-$PWD}
+cd $R
+RAMD_BUILD_VERBOSE=1 RAMD_TRSV_CT_VERBOSE=1 TAG=build timeout 600 python tools/sf_check.py rcm 549 2 2>&1 | grep -v "^$" | tail -60 | cut -c1-200
