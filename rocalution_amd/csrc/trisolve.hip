@@ -1031,7 +1031,7 @@ static const char* ct_why_text(int why)
 template <typename T>
 static int build_ct_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bool reverse);
 template <typename T>
-static int build_sf_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower);
+static int build_sf_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bool reverse);
 
 // natural = true: rows stay in matrix order (no level analysis) -- the packing of the iterative (Jacobi-sweep) solves
 template <typename T>
@@ -1064,10 +1064,10 @@ static int build_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bool 
         P->nslices = (n + 63) / 64;
     }
     // deep, narrow dependency graphs the tiles could not take: one row group per hand-off (k_trsv_sf)
-    if(!natural && !reverse)
+    if(!natural && !(reverse && lower))
     {
         const int why = P->st_why;
-        const int sc  = build_sf_plan<T>(m, st, P, lower);
+        const int sc  = build_sf_plan<T>(m, st, P, lower, reverse);
         if(sc == RAMD_OK)
         {
             P->st_why = why;
@@ -4158,25 +4158,30 @@ static int ct_build_pair_lists(TriPlan* P, const int* key, int** pairs_out, int 
 }
 
 // ======================================================================= sync-free grouped triangular solve (round 5)
-// For dependency graphs that are DEEP AND NARROW with LONG rows and no chains for the tile coordinates to grow along -- a shell
-// mesh (5 unknowns per node, ~35 entries per row) numbered by reverse Cuthill-McKee or by an advancing front: ~10 700 row
-// levels of ~140 rows.  The level-scheduled kernel pays ~9 us per level there (one lane per row: the row's entries come in
-// dependent chunks of eight, each behind a poll), the band form that stood here for a while ~4 us (one CU's load path).  What such a graph needs per level is
-// ONE hand-off and nothing else on the critical path:
+// For triangles the tiles cannot take -- no chains of consecutively numbered dependent rows for their coordinates to grow along:
+// a shell mesh (5 unknowns per node, ~35 entries per row) numbered by reverse Cuthill-McKee or by an advancing front has ~10 700
+// row levels of ~140 rows.  The level-scheduled kernel pays ~9 us per level there (one lane per row: the row's entries come in
+// dependent chunks of eight, each behind a poll), the band form that stood here for a while ~4 us (one CU's load path).  What
+// such a graph needs per level is ONE hand-off and nothing else on the critical path:
 //   * the unit of work is a ROW GROUP (k_ct_sn_breaks: the rows of one mesh node -- row t depends on row t-1 and shares every
 //     other dependency with it): 2 140 group levels instead of 10 700; the in-group part of a step runs in registers, in the
 //     order of the host loop (lower solve: the in-group entries are the LAST of a row, upper solve: the FIRST);
 //   * LPR = 4 or 8 lanes share a row, kw <= 6 out-of-group entries each; a wave holds 64 / LPR rows = whole groups of ONE group
 //     level (a "unit"); positions are sorted by (group level, group, row), units are contiguous pieces of them;
-//   * persistent waves take the units round-robin: a wave is many levels ahead of the front when it starts on a unit, so the
-//     unit's coefficients, right-hand side and diagonal are in registers long before its dependencies are -- no look-ahead
-//     machinery, the other waves ARE the look-ahead;
-//   * it then waits with ONE load per turn on the unit's LAST dependency (the highest position among them: group level - 1) and
-//     only then gathers all of them (data-tagged granules, as k_trsv): the waves ahead of the front cost the memory system one
-//     request per turn each, not one per entry;
-//   * the out-of-group entries are subtracted one after the other through the row's lanes (DPP hand-over), the in-group ones in
-//     rounds through lane permutes; one publication per row.
-// The operations per row are those of host_matrix_csr.cpp:1163-1221 in their order: bit-exact (forced over the parity suite).
+//   * persistent waves take the units by ticket (k_trsv_sf): a wave is many levels ahead of the front when it starts on a unit,
+//     so the unit's coefficients, right-hand side and diagonal are in registers long before its dependencies are -- no
+//     look-ahead machinery, the other waves ARE the look-ahead;
+//   * it waits with ONE load per turn on a position two levels back, then asks for every value once and after that only for
+//     the values still missing (data-tagged granules, as k_trsv): the waves ahead of the front cost the memory system one
+//     request per turn each, and the turn that finds the last value is the only trip through memory on the critical path;
+//   * the out-of-group entries are subtracted one after the other through the row's lanes (DPP hand-over; upper solve: in the
+//     row's first lane, into which the products are pulled once), the in-group ones in rounds through lane broadcasts; one
+//     publication per row.
+// The operations per row are those of host_matrix_csr.cpp:1163-1221 (LUSolve), :1294-1341 (LLSolve), :1357-1466 (LSolve / USolve)
+// in their order: bit-exact (forced over the parity suite, tests/test_gpu_syncfree.py).  Measured on the RCM-numbered config-3
+// class (2 140 levels): 1.1 us per hand-off + 0.45 us (lower) / 1.1 us (upper) of arithmetic per level = 3.4 / 4.7 ms per
+// triangle (band form 46 ms, level-scheduled rows 95 ms); wide graphs of long rows run at their stream rate (random numbering:
+// 0.56 / 0.69 ms against 1.17 / 3.1 ms).
 constexpr int kSfKW = 6, kSfStreams = 8;
 
 static void sf_release(SfPlan** sp)
@@ -4231,7 +4236,7 @@ __global__ __launch_bounds__(64) void k_sf_fill(int n, int nunits, int* __restri
                                                 const int* __restrict__ order, const int* __restrict__ pos,
                                                 const int* __restrict__ rp, const int* __restrict__ ci, const T* __restrict__ val,
                                                 int* __restrict__ ecol, T* __restrict__ eval, T* __restrict__ gcoef,
-                                                T* __restrict__ diag, int* __restrict__ nodiag, int* __restrict__ punit)
+                                                T* __restrict__ diag, int* __restrict__ nodiag, int* __restrict__ punit, int reverse)
 {
     const int u = blockIdx.x;
     if(u >= nunits)
@@ -4252,8 +4257,10 @@ __global__ __launch_bounds__(64) void k_sf_fill(int n, int nunits, int* __restri
         const int t = LOWER ? i : n - 1 - i, tf = t - r;
         int       e = 0;
         bool      dg = false;
-        for(int j = rp[i]; j < rp[i + 1]; ++j)
+        const int rs = rp[i], re = rp[i + 1];
+        for(int q = rs; q < re; ++q)
         {
+            const int j   = reverse ? re - 1 - (q - rs) : q; // (reverse: the entries in descending storage order)
             const int col = ci[j];
             if(col == i)
             {
@@ -4475,10 +4482,12 @@ __global__ __launch_bounds__(64) void k_trsv_sf(int nunits, const v4i32* __restr
     // 128-byte lines), unit u belongs to stream u % kSfStreams, a wave is bound to the stream its START ticket names (the first
     // kSfStreams waves to run cover every stream) and asks for its next unit while it works on this one.
     // (dbg: RAMD_TRSV_SF_DBG, two timestamps per unit -- dependencies there, result published)
-    // gather_only 3 (default): one word per turn for the unit's LAST dependency, then gather; 0: one word per turn for a position
-    // `ufar[u]` two levels back, then gather every turn (one round trip less on paper; measured equal, 4.2 / 6.9 against 4.1 / 6.9 ms
-    // on the RCM shell: what a gathering wave asks of the memory system per turn costs what the second round trip did); 1: gather
-    // from the start (5.4 / 7.6 ms: 2048 waves x 4 gathers a turn); 2: no waits (diagnostic: 0.5 / 0.8 ms, the stream time)
+    // gather_only (RAMD_TRSV_SF_GATHER) 4, the default: one word per turn for a position `ufar[u]` two levels back, then every
+    // value once and after that only the lanes still without theirs (3.8 / 5.2 ms on the RCM shell when it was measured against the
+    // others); 3: one word per turn for the unit's LAST dependency, then one gather of everything (4.1 / 5.5 ms: two trips through
+    // memory per level); 0: the far word, then a gather of everything every turn (equal to 3: what a gathering wave asks of the
+    // memory system per turn costs what the second trip did); 1: gathers from the start (5.4 / 7.6 ms: 2048 waves x 4 gathers a
+    // turn); 2: no waits (diagnostic, wrong results: 0.5 / 0.8 ms, the stream time)
     using B = typename Sentinel<T>::bits;
     const int lane = threadIdx.x, slot = lane / LPR, l = lane % LPR;
     if(dbg && blockIdx.x == 0 && lane == 0) // (shader clock against the 100 MHz counter: what a cycle is worth in this kernel)
@@ -4665,8 +4674,13 @@ __global__ __launch_bounds__(64) void k_trsv_sf(int nunits, const v4i32* __restr
 }
 
 template <typename T>
-static int build_sf_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower)
+static int build_sf_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bool reverse)
 {
+    // reverse (the second stage of LLSolve: the upper part of L^T with a row's entries taken in DESCENDING column order,
+    // host_matrix_csr.cpp:1294-1341): the entries outside the group come first then and the in-group ones last, nearest group row
+    // last -- the arithmetic of the lower solve on the plan of an upper one
+    if(reverse && lower)
+        return RAMD_ERR_UNSUPPORTED;
     Backend&  b = backend();
     const int n = m->nrow;
     // RAMD_TRSV_SF = 0: off, 1 (default): deep and narrow graphs, 2: whatever the shape (tests)
@@ -4804,7 +4818,7 @@ static int build_sf_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower)
     SF_TRY(dev_alloc(&sorted, n));
     SF_TRY(device_stable_sort_by_key(key, n, nglev, sorted));
     S = new SfPlan;
-    S->lpr = lpr, S->maxm = maxm, S->wout = wout, S->ngroups = ngroups, S->nglev = nglev, S->infirst = !lower;
+    S->lpr = lpr, S->maxm = maxm, S->wout = wout, S->ngroups = ngroups, S->nglev = nglev, S->infirst = !lower && !reverse;
     SF_TRY(dev_alloc(&P->order, n));
     SF_TRY(dev_alloc(&P->pos, n));
     SF_TRY(dev_alloc(&plev, n));
@@ -4891,7 +4905,8 @@ static int build_sf_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower)
     SF_TRY(dev_alloc(&S->ufar, S->nunits));
 #define SF_FILL(LO, LP)                                                                                                       \
     hipLaunchKernelGGL((k_sf_fill<T, LO, LP>), dim3(S->nunits), dim3(64), 0, b.cur, n, S->nunits, S->uinfo, S->pinfo, P->order, \
-                       P->pos, m->rp, m->ci, (const T*)m->val, S->ecol, (T*)S->eval, (T*)S->gcoef, (T*)P->diag, nodiag, punit)
+                       P->pos, m->rp, m->ci, (const T*)m->val, S->ecol, (T*)S->eval, (T*)S->gcoef, (T*)P->diag, nodiag, punit,   \
+                       reverse ? 1 : 0)
     if(lower && lpr == 4)
         SF_FILL(true, 4);
     else if(lower)

@@ -21,7 +21,7 @@ FORCED = dict(RAMD_TRSV_SF="2", RAMD_TRSV_CT="0", RAMD_TRSV_LAT="0", RAMD_TRSV_C
 def test_parity_suite_with_the_sync_free_grouped_form_forced():
     """ILU(0) / IC factors + LUSolve / LLSolve / LSolve / USolve goldens, preconditioner applies, solver histories, the config-3
     class in four numberings (factors, LUSolve and GMRES(30)+ILU(0) against the oracle) -- with every triangular plan that can be
-    in the sync-free grouped form (the descending-order sweep of LLSolve's second stage keeps the level-scheduled rows)."""
+    in the sync-free grouped form (also the descending-order sweep of LLSolve's second stage)."""
     env = dict(os.environ, **FORCED)
     cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-s", "-m", "gpu", "-p", "no:cacheprovider",
            os.path.join(ROOT, "tests", "test_gpu_kernels.py"), os.path.join(ROOT, "tests", "test_gpu_solvers.py"),
@@ -38,6 +38,7 @@ _BLOCKS = r"""
 import sys, numpy as np, scipy.sparse as sp
 sys.path.insert(0, %(root)r)
 import rocalution_amd as ra
+from rocalution_amd import solvers as S
 from oracle import oracle
 ra.init_rocalution()
 rng = np.random.default_rng(23)
@@ -89,6 +90,13 @@ for nn, bmax, deg, reach, sym in ((1, 1, 0, 1, True), (1, 9, 0, 1, True), (40, 5
             assert np.array_equal(y.numpy(), oracle.lsolve(rp, ci, v, b, unit)), ("lsolve", nn, bmax, dt, unit)
             B.UAnalyse(unit); B.USolve(ra.LocalVector(dt, data=b), y)
             assert np.array_equal(y.numpy(), oracle.usolve(rp, ci, v, b, unit)), ("usolve", nn, bmax, dt, unit)
+        if sym:  # IC: L L^T solve, the second stage takes a row's entries in descending order (host_matrix_csr.cpp:1294-1341)
+            A0 = ra.LocalMatrix(dt); A0.SetDataPtrCSR(rp, ci, v)
+            ls = S.CG(dt); ls.SetOperator(A0); ls.SetPreconditioner(S.IC()); ls.Build()
+            z = ra.LocalVector(dt); z.Allocate("", n)
+            ls.PrecondApply(ra.LocalVector(dt, data=b), z)
+            assert np.array_equal(z.numpy(), oracle.precond_apply(oracle.PC_IC, rp, ci, v, b)), ("ic", nn, bmax, dt)
+            ls.Clear()
     print("ok nodes=%%d n=%%d unknowns per node <= %%d" %% (nn, n, bmax), flush=True)
     checked += 1
 print("checked", checked)
@@ -99,8 +107,8 @@ print("checked", checked)
 def test_row_groups_of_1_to_12_rows_unsymmetric_patterns_fp64_fp32_bit_exact(tmp_path):
     """Block matrices with 1 .. 12 unknowns per node (row groups of every size, runs cut at 8 rows), symmetric and unsymmetric
     patterns (the upper triangle's groups differ from the lower one's), rows of a few to beyond 48 entries (those matrices fall
-    back, loudly), n = 1 and a single group: ILU(0), LUSolve, LSolve / USolve with stored and with unit diagonal against the
-    oracle, fp64 and fp32."""
+    back, loudly), n = 1 and a single group: ILU(0), LUSolve, LSolve / USolve with stored and with unit diagonal, the IC apply
+    (L L^T solve: the second stage in descending order) against the oracle, fp64 and fp32."""
     script = tmp_path / "blocks.py"
     script.write_text(_BLOCKS % {"root": ROOT})
     p = subprocess.run([sys.executable, str(script)], cwd=ROOT, env=dict(os.environ, **FORCED), stdout=subprocess.PIPE,
