@@ -170,3 +170,35 @@ def test_full_size_rcm_shell_takes_the_form_by_default():
     x.AddScale(ones, -1.0)
     assert x.Norm() / np.sqrt(n) < 1e-4
     ls.Clear()
+
+
+@pytest.mark.gpu
+def test_bench_mtx_reports_the_plan_of_a_file_nobody_here_has_seen(tmp_path):
+    """`bench.py --mtx PATH` is what a holder of SuiteSparse af_shell10.mtx would run (config 3; the file cannot be fetched here):
+    a MatrixMarket `symmetric` file of the same class in reverse Cuthill-McKee order goes through ReadFileMTX, and the line comes
+    back with the rate AND the diagnosis of its triangular solves -- the form each triangle took, its dependency levels, and why the
+    tiles were not used."""
+    import json
+    from rocalution_amd import generators as gen
+    rp, ci, va = gen.shell_variant(40, "rcm")  # 8000 rows
+    path = str(tmp_path / "shell40_rcm.mtx")
+    gen.write_mtx_symmetric(path, rp, ci, va)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--mtx", path, "--solver", "gmres", "--precond", "ilu0", "--steps", "12",
+           "--warmup", "3", "--no-cpu-baseline", "--no-reference-gpu"]
+    p = subprocess.run(cmd, cwd=str(tmp_path), env=dict(os.environ, TMPDIR=str(tmp_path)), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["steps"] == 12 and d["value"] > 0 and "shell40_rcm.mtx" in d["config"]["workload"], d["config"]
+    assert d["ingest"]["file_bytes"] == os.path.getsize(path)
+    tp = d["tri_plan"]
+    for which in ("lower", "upper"):
+        assert tp[which]["rows"] == len(rp) - 1 and tp[which]["dependency_levels"] > 0, tp[which]
+        assert tp[which]["form"], tp[which]
+        if "box tiles" not in tp[which]["form"] and "lattice" not in tp[which]["form"]:
+            assert tp[which]["why_not_box_tiles"], tp[which]
+    if os.environ.get("RAMD_TRSV_SF", "1") == "1" and os.environ.get("RAMD_TRSV_CT", "1") != "0":
+        assert "k_trsv_sf" in tp["lower"]["form"] and "k_trsv_sf" in tp["upper"]["form"], tp
+    assert d["roofline"]["kernel"].startswith("sparse triangular solve"), d["roofline"]["kernel"]

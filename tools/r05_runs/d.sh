@@ -1,3 +1,3 @@
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd $R
-timeout 1200 python -m pytest tests/test_gpu_syncfree.py tests/test_gpu_edge_cases.py tests/test_gpu_full_size.py -m gpu -x -q 2>&1 | tail -12
+timeout 1200 python -m pytest tests/test_gpu_syncfree.py -m gpu -x -q 2>&1 | tail -30
