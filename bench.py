@@ -350,7 +350,7 @@ def main():
                     help="node numbering of the config-3-class operator (generators.shell_variant): lex = the surrogate; rcm = the "
                          "same mesh in reverse Cuthill-McKee order; delaunay = a jittered-point triangulation in RCM order; "
                          "random = a random node permutation")
-    ap.add_argument("--format", default="csr", choices=["csr", "ell", "hyb", "dia"])
+    ap.add_argument("--format", default="csr", choices=["csr", "ell", "hyb"])
     ap.add_argument("--cpu-grid", type=int, default=None, help="Poisson grid of the CPU baseline sample (default: --grid)")
     ap.add_argument("--cpu-iters", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -442,7 +442,7 @@ def main():
             dist.barrier()
 
     N = args.grid
-    fmt = {"csr": ra.CSR, "ell": ra.ELL, "hyb": ra.HYB, "dia": ra.DIA}[args.format]
+    fmt = {"csr": ra.CSR, "ell": ra.ELL, "hyb": ra.HYB}[args.format]
     K, W = args.steps, args.warmup
     NEVER = (0.0, 0.0, 1e300)  # abs / rel / div tolerances that cannot trigger: exactly max_iter steps
     mixed = args.solver == "mixed"
@@ -610,8 +610,8 @@ def main():
                       if mixed else "CSR SpMV (k_csr_pat2 for structured matrices -- columns from the row-pattern dictionary, two row blocks per workgroup: traffic below the algorithmic CSR bytes -- else k_csr_tr, or k_csr_w4 for rows of 16+ entries; with the fused dot where the solver uses it)")
         else:
             nnz_fmt = 7 * n if args.matrix == "poisson" else nnz
-            b_spmv = vb * (2 * n + nnz_fmt) if args.format == "dia" else 4 * nnz_fmt + vb * (2 * n + nnz_fmt)
-            k_spmv = "k_%s<%s>" % ("dia" if args.format == "dia" else "ell", "float" if mixed else "double")
+            b_spmv = 4 * nnz_fmt + vb * (2 * n + nnz_fmt)
+            k_spmv = "k_ell<%s>" % ("float" if mixed else "double")
         tkey = None
         if args.matrix == "poisson" and N == 512 and args.format in ("csr", "ell"):
             tkey = "spmv_%s_512%s" % (args.format, "_fp32" if mixed else "")

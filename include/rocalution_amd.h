@@ -46,7 +46,7 @@ enum
 enum { RAMD_F64 = 0, RAMD_F32 = 1, RAMD_I32 = 2 };
 
 /* matrix formats: numbering of src/base/matrix_formats.hpp (CSR=1, COO=4, ELL=6, HYB=7) */
-enum { RAMD_CSR = 1, RAMD_COO = 4, RAMD_DIA = 5, RAMD_ELL = 6, RAMD_HYB = 7 };
+enum { RAMD_CSR = 1, RAMD_COO = 4, RAMD_ELL = 6, RAMD_HYB = 7 }; /* (5 = DIA: not provided, as MCSR / BCSR / DENSE) */
 
 typedef struct ramd_vec_s* ramd_vec_t; /* an AcceleratorVector<T> instance */
 typedef struct ramd_mat_s* ramd_mat_t; /* an AcceleratorMatrix<T> instance (any format) */
@@ -168,10 +168,6 @@ int ramd_mat_cast(ramd_mat_t src_f64, ramd_mat_t* out_f32); /* value-cast CSR co
  * RAMD_ERR_REFUSED and leave the matrix CSR) and :1117-1239 (HYB); COO :582 */
 int ramd_mat_convert(ramd_mat_t m, int format);
 /* ELL/HYB/COO raw views for tests (device -> host) */
-/* DIA (hip_matrix_dia.cpp / host_matrix_dia.cpp): number of diagonals; offsets [num_diag] and values
- * [num_diag * nrow], DIA_IND(row, d) = d * nrow + row (matrix_formats_ind.hpp:43-45) */
-int ramd_mat_dia_info(ramd_mat_t m, int* num_diag);
-int ramd_mat_copy_dia_to_host(ramd_mat_t m, int32_t* offset, void* val);
 int ramd_mat_ell_info(ramd_mat_t m, int* width, int64_t* coo_nnz);
 int ramd_mat_copy_ell_to_host(ramd_mat_t m, int32_t* ell_col, void* ell_val);
 int ramd_mat_copy_coo_to_host(ramd_mat_t m, int32_t* row, int32_t* col, void* val);

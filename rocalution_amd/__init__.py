@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 
 from . import capi
-from .capi import CSR, COO, DIA, ELL, HYB, F32, F64, I32, RamdError  # noqa: F401
+from .capi import CSR, COO, ELL, HYB, F32, F64, I32, RamdError  # noqa: F401
 
 _NP = {F64: np.float64, F32: np.float32, I32: np.int32}
 _DT = {np.dtype(np.float64): F64, np.dtype(np.float32): F32, np.dtype(np.int32): I32}
@@ -361,18 +361,6 @@ class LocalMatrix:
 
     def ConvertToHYB(self):
         return self.ConvertTo(HYB)
-
-    def ConvertToDIA(self):
-        return self.ConvertTo(DIA)
-
-    def GetDIA(self):
-        """(offsets[num_diag], values[num_diag * nrow]) of a DIA matrix, DIA_IND(row, d) = d * nrow + row"""
-        nd = C.c_int(0)
-        capi.check(_lib().ramd_mat_dia_info(self._h, C.byref(nd)))
-        off = np.zeros(nd.value, dtype=np.int32)
-        val = np.zeros(nd.value * self.GetM(), dtype=self.dtype)
-        capi.check(_lib().ramd_mat_copy_dia_to_host(self._h, off.ctypes.data_as(C.c_void_p), val.ctypes.data_as(C.c_void_p)))
-        return off, val
 
     def ConvertToCOO(self):
         return self.ConvertTo(COO)

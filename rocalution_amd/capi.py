@@ -21,7 +21,7 @@ SOLVER_FIXEDPOINT = 9
 PC_NONE, PC_JACOBI, PC_ILU0, PC_MCSGS, PC_MCGS, PC_MCILU, PC_GS, PC_SGS, PC_IC, PC_UAAMG, PC_SAAMG = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 PC_GLOBAL_UAAMG, PC_GLOBAL_SAAMG = 11, 12
 F64, F32, I32 = 0, 1, 2
-CSR, COO, DIA, ELL, HYB = 1, 4, 5, 6, 7
+CSR, COO, ELL, HYB = 1, 4, 6, 7
 
 vec_t = C.c_void_p
 mat_t = C.c_void_p
@@ -97,8 +97,6 @@ SIGNATURES = {
     "ramd_mat_clone": (i32, [mat_t, C.POINTER(mat_t)]),
     "ramd_mat_cast": (i32, [mat_t, C.POINTER(mat_t)]),
     "ramd_mat_convert": (i32, [mat_t, i32]),
-    "ramd_mat_dia_info": (i32, [mat_t, pi32]),
-    "ramd_mat_copy_dia_to_host": (i32, [mat_t, ptr, ptr]),
     "ramd_mat_ell_info": (i32, [mat_t, pi32, pi64]),
     "ramd_mat_copy_ell_to_host": (i32, [mat_t, ptr, ptr]),
     "ramd_mat_copy_coo_to_host": (i32, [mat_t, ptr, ptr, ptr]),

@@ -361,7 +361,6 @@ static int sa_prolong_t(const ramd_mat_s* m, T relax, int lumping, const ramd_ve
     mat_free_csr(p);
     mat_free_ell(p);
     mat_free_coo(p);
-    mat_free_dia(p);
     mat_free_analysis(p);
     p->format = RAMD_CSR;
     p->nrow   = n;
@@ -1094,7 +1093,6 @@ static int rs_direct_t(const ramd_mat_s* m, const ramd_vec_s* vcf, const ramd_ve
     mat_free_csr(p);
     mat_free_ell(p);
     mat_free_coo(p);
-    mat_free_dia(p);
     mat_free_analysis(p);
     p->format = RAMD_CSR;
     p->nrow   = n;
@@ -1162,7 +1160,6 @@ static int ua_prolong_t(const ramd_mat_s* m, const ramd_vec_s* vagg, const ramd_
     mat_free_csr(p);
     mat_free_ell(p);
     mat_free_coo(p);
-    mat_free_dia(p);
     mat_free_analysis(p);
     p->format = RAMD_CSR;
     p->nrow   = n;
@@ -1259,7 +1256,6 @@ static int merge_columns_t(const ramd_mat_s* a, const ramd_mat_s* g, int ghost_n
     mat_free_csr(out);
     mat_free_ell(out);
     mat_free_coo(out);
-    mat_free_dia(out);
     mat_free_analysis(out);
     out->format = RAMD_CSR;
     out->nrow   = n;

@@ -178,10 +178,6 @@ struct ramd_mat_s
     int*    coo_row = nullptr;
     int*    coo_col = nullptr;
     void*   coo_val = nullptr;
-    // DIA: num_diag diagonals, offsets ascending, values column-major DIA_IND(row, d) = d*nrow + row
-    int   dia_ndiag  = 0;
-    int*  dia_offset = nullptr;
-    void* dia_val    = nullptr;
     // COO row grouping (built once): touched rows and their entry ranges in stable row order
     int   coo_ngroups = 0;
     int*  coo_grow    = nullptr; // [ngroups] row index

@@ -32,14 +32,6 @@ void mat_free_ell(ramd_mat_s* m)
     m->ell_val   = nullptr;
     m->ell_width = 0;
 }
-void mat_free_dia(ramd_mat_s* m)
-{
-    dev_free(&m->dia_offset);
-    if(m->dia_val)
-        (void)cached_free(m->dia_val);
-    m->dia_val   = nullptr;
-    m->dia_ndiag = 0;
-}
 void mat_free_coo(ramd_mat_s* m)
 {
     dev_free(&m->coo_row);
@@ -79,7 +71,6 @@ int mat_alloc_csr(ramd_mat_s* m, int nrow, int ncol, int64_t nnz)
     mat_free_csr(m);
     mat_free_ell(m);
     mat_free_coo(m);
-    mat_free_dia(m);
     mat_free_analysis(m);
     m->format = RAMD_CSR;
     m->nrow   = nrow;
@@ -237,7 +228,6 @@ int ramd_mat_clear(ramd_mat_t m)
     mat_free_csr(m);
     mat_free_ell(m);
     mat_free_coo(m);
-    mat_free_dia(m);
     mat_free_analysis(m);
     m->format = RAMD_CSR;
     m->nrow = m->ncol = 0;
@@ -355,12 +345,6 @@ int ramd_mat_clone(ramd_mat_t src, ramd_mat_t* out)
         m->ell_width     = src->ell_width;
         dup_i(&m->ell_col, src->ell_col, ne);
         dup_v(&m->ell_val, src->ell_val, ne);
-    }
-    if(src->format == RAMD_DIA)
-    {
-        m->dia_ndiag = src->dia_ndiag;
-        dup_i(&m->dia_offset, src->dia_offset, src->dia_ndiag);
-        dup_v(&m->dia_val, src->dia_val, (int64_t)src->dia_ndiag * src->nrow);
     }
     if(src->format == RAMD_COO || src->format == RAMD_HYB)
     {

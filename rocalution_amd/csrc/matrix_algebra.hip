@@ -1164,7 +1164,6 @@ static int mat_mult_chunked_t(ramd_mat_s* c, const ramd_mat_s* a, const ramd_mat
     mat_free_csr(c);
     mat_free_ell(c);
     mat_free_coo(c);
-    mat_free_dia(c);
     mat_free_analysis(c);
     c->format = RAMD_CSR;
     c->nrow   = a->nrow;
@@ -1275,7 +1274,6 @@ static int mat_mult_t(ramd_mat_s* c, const ramd_mat_s* a, const ramd_mat_s* bm)
     mat_free_csr(c);
     mat_free_ell(c);
     mat_free_coo(c);
-    mat_free_dia(c);
     mat_free_analysis(c);
     c->format = RAMD_CSR;
     c->nrow   = a->nrow;

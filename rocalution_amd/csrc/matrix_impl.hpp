@@ -10,7 +10,6 @@ size_t val_size(int dtype);
 void   mat_free_csr(ramd_mat_s* m);
 void   mat_free_ell(ramd_mat_s* m);
 void   mat_free_coo(ramd_mat_s* m);
-void   mat_free_dia(ramd_mat_s* m);
 void   mat_free_analysis(ramd_mat_s* m);
 int    mat_alloc_csr(ramd_mat_s* m, int nrow, int ncol, int64_t nnz);
 

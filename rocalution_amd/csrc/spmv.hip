@@ -1263,68 +1263,6 @@ __global__ __launch_bounds__(kBlock) void k_ell2(int nrow, int ncol, int width, 
     }
 }
 
-// DIA (host_matrix_dia.cpp:300-412): one thread per row, diagonal d contributes val[d*nrow + row] * x[row + offset_d]
-// when 0 <= row + offset_d < nrow (the host's start/end/break tests for ascending offsets); padded zeros ARE
-// multiplied, as on the host.  Values stream coalesced with no index array: 8 B per stored entry.
-template <typename T, int MODE, bool DOT>
-__global__ __launch_bounds__(kBlock) void k_dia(int nrow, int ndiag, const int* __restrict__ offset,
-                                                const T* __restrict__ dval, const T* __restrict__ x,
-                                                T* __restrict__ y, T scalar, double* __restrict__ part1,
-                                                const T* __restrict__ dotv, int nblk, int per_xcd, BandMap bm)
-{
-    double        dacc = 0.0;
-    const int     blk  = xcd_block(nblk, per_xcd, bm);
-    const int64_t row  = (int64_t)blk * kCsrRows + threadIdx.x;
-    if(blk >= 0 && row < nrow)
-    {
-        T sum = (T)0;
-        if(MODE == 1)
-            sum = y[row];
-        for(int d0 = 0; d0 < ndiag; d0 += kGatherW)
-        {
-            T    v[kGatherW], xv[kGatherW];
-            bool use[kGatherW];
-#pragma unroll
-            for(int e = 0; e < kGatherW; ++e)
-            {
-                use[e] = false;
-                if(d0 + e < ndiag)
-                {
-                    const int64_t c = row + offset[d0 + e];
-                    use[e]          = c >= 0 && c < nrow;
-                    if(use[e])
-                    {
-                        v[e]  = nt_load(dval + (int64_t)(d0 + e) * nrow + row);
-                        xv[e] = x[c];
-                    }
-                }
-            }
-#pragma unroll
-            for(int e = 0; e < kGatherW; ++e)
-                if(use[e])
-                {
-                    if(MODE == 0)
-                        sum += v[e] * xv[e];
-                    else
-                        sum += scalar * v[e] * xv[e];
-                }
-        }
-        nt_store(sum, y + row);
-        if(DOT)
-            dacc += (double)sum * (double)(dotv ? dotv[row] : x[row]);
-    }
-    if(DOT)
-    {
-        const double wsum = wave_reduce_sum(dacc);
-        if((threadIdx.x & 63) == 0 && blk >= 0)
-            part1[blk * (kBlock / 64) + (threadIdx.x >> 6)] = wsum;
-    }
-}
-
-// COO (ghost part of a GlobalMatrix, HYB tail): COO data in this library always comes from a CSR
-// conversion, i.e. it is sorted by row; the non-empty rows and their ranges are compacted once, so
-// one thread adds up one touched row in storage order -- the order of the reference's serial loop
-// (host_matrix_coo.cpp:368-376, :395-400) restricted to that row.  No atomics, deterministic.
 template <typename T, int MODE>
 __global__ __launch_bounds__(kBlock) void k_coo_grouped(int ngroups, const int* __restrict__ grow,
                                                         const int* __restrict__ gptr,
@@ -2140,43 +2078,6 @@ static int launch_ell(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
 }
 
 template <typename T>
-static int launch_dia(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar, bool dot = false, int slot = 0,
-                      const T* dotv = nullptr)
-{
-    Backend&      b       = backend();
-    const int     nblk    = (m->nrow + kCsrRows - 1) / kCsrRows;
-    const int     per_xcd = (nblk + 7) / 8;
-    const int     grid    = per_xcd * 8;
-    const BandMap bm      = band_map_for(m, per_xcd);
-    double*       part1   = nullptr;
-    if(dot)
-    {
-        ramd_mat_s* mm = const_cast<ramd_mat_s*>(m);
-        if(!mm->dot_part1 || mm->dot_nblk != nblk)
-        {
-            dev_free(&mm->dot_part1);
-            RAMD_TRY(dev_alloc(&mm->dot_part1, (int64_t)nblk * (kBlock / 64)));
-            mm->dot_nblk = nblk;
-        }
-        part1 = mm->dot_part1;
-    }
-#define LAUNCH(MODE, DOT)                                                                                      \
-    hipLaunchKernelGGL((k_dia<T, MODE, DOT>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, m->dia_ndiag,        \
-                       m->dia_offset, (const T*)m->dia_val, x, y, scalar, part1, dotv, nblk, per_xcd, bm)
-    if(dot)
-        LAUNCH(0, true);
-    else if(mode == 0)
-        LAUNCH(0, false);
-    else
-        LAUNCH(1, false);
-#undef LAUNCH
-    RAMD_HIP(hipGetLastError());
-    if(dot)
-        return reduce_sum_to_slot(part1, (int64_t)nblk * (kBlock / 64), slot);
-    return RAMD_OK;
-}
-
-template <typename T>
 static int launch_coo(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar)
 {
     if(m->coo_nnz <= 0)
@@ -2228,8 +2129,6 @@ static int mat_apply_inner(const ramd_mat_s* m, const T* x, T* y, int mode, T sc
         return launch_csr<T>(m, x, y, mode, scalar, false, 0);
     case RAMD_ELL:
         return launch_ell<T>(m, x, y, mode, scalar, true);
-    case RAMD_DIA:
-        return launch_dia<T>(m, x, y, mode, scalar);
     case RAMD_HYB:
         if(m->ell_width > 0)
             RAMD_TRY(launch_ell<T>(m, x, y, mode, scalar, false));
@@ -2253,13 +2152,6 @@ int mat_apply_dot_impl(const ramd_mat_s* m, const T* x, T* y, int slot, const T*
 {
     if(m->format == RAMD_CSR && m->nnz > 0 && m->nrow == m->ncol)
         return launch_csr<T>(m, x, y, 0, (T)1, true, slot, dotv); // bracketed inside (SpMV kernel only)
-    if(m->format == RAMD_DIA && m->nnz > 0 && m->nrow == m->ncol)
-    {
-        prof_spmv_begin();
-        int s = launch_dia<T>(m, x, y, 0, (T)1, true, slot, dotv);
-        prof_spmv_end();
-        return s;
-    }
     if((m->format == RAMD_ELL || m->format == RAMD_HYB) && m->ell_width > 0 && m->nrow == m->ncol && m->nrow > 0)
     {
         prof_spmv_begin();

@@ -6,7 +6,7 @@
 //   krylov_driver <matrix.mtx | poisson:N> <solver> [precond] [format] [param]
 //     solver : cg fcg cr gmres fgmres bicgstab bicgstabl qmrcgstab idr chebyshev fixedpoint mixed
 //     precond: none jacobi gs sgs ilu ilu1 ilu2 ic fsai spai tns as ras block blockdiag variable mcgs mcsgs mcilu          (default jacobi; "mixed" accepts none|jacobi)
-//     format : csr ell hyb dia      (the operator is converted AFTER Build(), as the reference's tests do)
+//     format : csr ell hyb      (the operator is converted AFTER Build(), as the reference's tests do)
 //     param  : restart length (gmres/fgmres), l (bicgstabl), s (idr)
 // Prints the reference's solver log and one machine-readable RESULT line.
 #include <rocalution/rocalution.hpp>
@@ -127,8 +127,6 @@ int main(int argc, char* argv[])
         mat.ConvertToELL();
     else if(fname == "hyb")
         mat.ConvertToHYB();
-    else if(fname == "dia")
-        mat.ConvertToDIA();
     ls->Verbose(1);
     mat.Info();
 

@@ -245,29 +245,6 @@ def test_new_preconditioners_in_single_precision(ra, S, pcname):
     assert np.max(np.abs(x.numpy() - 1.0)) < 2e-3
 
 
-def test_dia_operator_under_every_krylov_solver(ra, S):
-    """solvers only see Apply(): a DIA operator gives the iteration counts of the CSR one"""
-    rp, ci, va = gen.poisson7(10)
-    n = len(rp) - 1
-    counts = {}
-    for fmt in ("CSR", "DIA"):
-        A = ra.LocalMatrix(); A.SetDataPtrCSR(rp, ci, va)
-        ones = ra.LocalVector(data=np.ones(n)); rhs = ra.LocalVector(); rhs.Allocate("", n); A.Apply(ones, rhs)
-        for sname in ("CG", "BiCGStab", "GMRES", "CR", "QMRCGStab"):
-            ls = getattr(S, sname)(); ls.SetOperator(A); ls.SetPreconditioner(S.Jacobi()); ls.Build()
-            if fmt == "DIA":
-                assert A.ConvertTo(ra.DIA) == ra.DIA
-            x = ra.LocalVector(); x.Allocate("", n)
-            ls.Solve(rhs, x)
-            counts[(fmt, sname)] = ls.GetIterationCount()
-            assert np.max(np.abs(x.numpy() - 1.0)) < 1e-4
-            ls.Clear()
-            if fmt == "DIA":
-                assert A.ConvertTo(ra.CSR) == ra.CSR
-    for sname in ("CG", "BiCGStab", "GMRES", "CR", "QMRCGStab"):
-        assert abs(counts[("CSR", sname)] - counts[("DIA", sname)]) <= 1, (sname, counts)
-
-
 def test_build_clear_cycles_do_not_leak_device_memory(ra, S):
     """every Build()/Clear() pair (preconditioner plans, analysis data, work vectors, format conversions) gives
     its device memory back: free memory after 12 cycles == after 2 cycles"""

@@ -326,47 +326,6 @@ def test_amg_pmis_aggregation_vs_golden(ra, name):
         eq(rp, g[key + "_rowptr"]); eq(ci, g[key + "_col"]); eq(va, g[key + "_val"])
 
 
-@pytest.mark.parametrize("name", CASES)
-def test_dia_format_vs_golden(ra, name):
-    """CSR -> DIA (diagonals, offsets, padded values), DIA SpMV (the padded zeros are multiplied, as on the host),
-    DIA -> CSR (stored zeros dropped), fused Apply+dot, and the refusal rule -- all against the genuine library"""
-    import ctypes as C
-    from rocalution_amd import capi
-    g = load_golden(name)
-    n = len(g["rowptr"]) - 1
-    A = _mat(ra, g)
-    got = A.ConvertTo(ra.DIA)
-    if int(g["dia_format"][0]) != ra.DIA:
-        assert got == ra.CSR  # refused where the reference refused: > 5 * (nnz / n) diagonals
-        rp, ci, va = A.CopyToCSR()
-        eq(rp, g["rowptr"]); eq(ci, g["col"]); eq(va, g["val"])
-        return
-    assert got == ra.DIA
-    off, dv = A.GetDIA()
-    eq(off, g["dia_offset"]); eq(dv, g["dia_val"])
-    assert A.GetNnz() == len(off) * n
-    x = ra.LocalVector(data=g["x"])
-    y = ra.LocalVector(); y.Allocate("", n)
-    A.Apply(x, y)
-    eq(y.numpy(), g["spmv_dia"])
-    y2 = ra.LocalVector(data=g["y"])
-    A.ApplyAdd(x, -0.75, y2)
-    eq(y2.numpy(), g["spmv_dia_add"])
-    lib = capi.load()
-    y3 = ra.LocalVector(); y3.Allocate("", n)
-    capi.check(lib.ramd_fused_apply_dot(A._h, x._h, y3._h, 7))
-    eq(y3.numpy(), g["spmv_dia"])
-    out = (C.c_double * 1)()
-    capi.check(lib.ramd_scalars_fetch(out, 7, 1))
-    close(out[0], float(np.dot(g["x"], y3.numpy())), 1e-12)
-    B = ra.LocalMatrix(); B.CloneFrom(A)
-    assert B.GetFormat() == ra.DIA
-    assert B.ConvertTo(ra.CSR) == ra.CSR
-    rp, ci, va = B.CopyToCSR()
-    eq(rp, g["dia_back_rowptr"]); eq(ci, g["dia_back_col"]); eq(va, g["dia_back_val"])
-    assert A.ConvertTo(ra.ELL) in (ra.ELL, ra.CSR)  # X -> CSR -> Y protocol from DIA
-
-
 @pytest.mark.parametrize("N", [5, 16, 33])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_spmv_poisson_vs_oracle(ra, oracle, N, dtype):
@@ -376,14 +335,11 @@ def test_spmv_poisson_vs_oracle(ra, oracle, N, dtype):
     x = np.random.default_rng(N).uniform(-4, 6, n).astype(dtype)
     vx = ra.LocalVector(dtype, data=x)
     ref = oracle.csr_apply(rp, ci, va, x)
-    for fmt in (ra.CSR, ra.ELL, ra.HYB, ra.COO, ra.DIA):
+    for fmt in (ra.CSR, ra.ELL, ra.HYB, ra.COO):
         A = ra.LocalMatrix(dtype); A.SetDataPtrCSR(rp, ci, va)
         assert A.ConvertTo(fmt) == fmt
         y = ra.LocalVector(dtype); y.Allocate("", n)
         A.Apply(vx, y)
-        if fmt == ra.DIA:  # same products in the same (ascending column) order; the padded zeros add +-0
-            off, dv = oracle.csr_to_dia(rp, ci, va)
-            eq(y.numpy(), oracle.dia_apply(n, off, dv, x))
         eq(y.numpy(), ref)
     # device generator == host generator
     G = ra.LocalMatrix(dtype); G.GenPoisson7(N)
@@ -1171,7 +1127,7 @@ def test_spmv_variants_forced_in_a_fresh_process(variant):
         env[kv.split("=")[0]] = kv.split("=")[1]
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_kernels.py"),
                         os.path.join(here, "test_gpu_edge_cases.py"), os.path.join(here, "test_gpu_solvers.py"), "-q", "-m", "gpu",
-                        "-x", "-k", "(spmv or csr or apply or fused_bicgstab or golden or smoother or dia_format or convert or mcsgs or mcgs or mcilu "
+                        "-x", "-k", "(spmv or csr or apply or fused_bicgstab or golden or smoother or convert or mcsgs or mcgs or mcilu "
                                     "or multicolor or history) "
                                     "and not fresh_process"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)

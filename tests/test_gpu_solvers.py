@@ -261,7 +261,7 @@ def test_cg_jacobi_x0_tight_tolerance(ra, S, name):
     assert np.linalg.norm(x.numpy() - 1.0) < 1e-6  # the reference test's own pass criterion
 
 
-@pytest.mark.parametrize("fmt", ["ELL", "HYB", "DIA"])
+@pytest.mark.parametrize("fmt", ["ELL", "HYB"])
 def test_convert_after_build(ra, S, fmt):
     """operator converted AFTER Build(), as the reference tests do (testing_cg.hpp:151-155)"""
     g = load_golden("poisson16")
@@ -269,8 +269,7 @@ def test_convert_after_build(ra, S, fmt):
     n = len(rp) - 1
     A = ra.LocalMatrix(); A.SetDataPtrCSR(rp, ci, va)
     rhs = ra.LocalVector(data=g["rhs_ones"])
-    tag, key = {"ELL": ("bicgstab_mcsgs", "bicgstab_mcsgs_ell"), "HYB": ("cg_jacobi", "cg_jacobi_hyb"),
-                "DIA": ("cg_jacobi", "cg_jacobi_dia")}[fmt]
+    tag, key = {"ELL": ("bicgstab_mcsgs", "bicgstab_mcsgs_ell"), "HYB": ("cg_jacobi", "cg_jacobi_hyb")}[fmt]
     ls = _mk(S, tag); ls.SetOperator(A); ls.Build()
     assert A.ConvertTo(getattr(ra, fmt)) == getattr(ra, fmt)
     x = ra.LocalVector(); x.Allocate("", n)
@@ -409,7 +408,7 @@ def _write_mtx(path, rp, ci, va):
 
 DRIVER_RUNS = [("cg", "jacobi", "csr", 0, "cg_jacobi"), ("gmres", "ilu", "csr", 30, "gmres_ilu0"),
                ("bicgstab", "mcsgs", "ell", 0, "bicgstab_mcsgs_ell"), ("cg", "jacobi", "hyb", 0, "cg_jacobi_hyb"),
-               ("cg", "jacobi", "dia", 0, "cg_jacobi_dia"), ("cg", "ic", "csr", 0, "cg_ic"),
+               ("cg", "ic", "csr", 0, "cg_ic"),
                ("mixed", "jacobi", "csr", 0, "mixed_cg_jacobi"), ("qmrcgstab", "mcsgs", "csr", 0, "qmrcgstab_mcsgs"),
                ("idr", "none", "csr", 4, "idr_none"), ("fcg", "mcsgs", "csr", 0, "fcg_mcsgs"),
                ("cr", "jacobi", "csr", 0, "cr_jacobi"), ("fgmres", "ilu", "csr", 30, "fgmres_ilu0"),
