@@ -346,7 +346,7 @@ def main():
                          "reference's ReadFileMTX semantics (host_io.cpp:135-276); implies --matrix file")
     ap.add_argument("--grid", type=int, default=512, help="Poisson grid edge N (operator is N^3 x N^3)")
     ap.add_argument("--shell-nx", type=int, default=549, help="shell surrogate: nx x nx mesh nodes, 5 unknowns each")
-    ap.add_argument("--shell-variant", default="lex", choices=["lex", "rcm", "delaunay", "random"],
+    ap.add_argument("--shell-variant", default="lex", choices=["lex", "rcm", "delaunay", "random", "morton"],
                     help="node numbering of the config-3-class operator (generators.shell_variant): lex = the surrogate; rcm = the "
                          "same mesh in reverse Cuthill-McKee order; delaunay = a jittered-point triangulation in RCM order; "
                          "random = a random node permutation")

@@ -238,6 +238,7 @@ def write_mtx_symmetric(path, rp, ci, va):
 #               level sets of a breadth-first search from a corner: consecutive nodes are mostly NOT neighbours
 #   "delaunay"  a Delaunay triangulation of jittered lattice points (valence 4 .. 9), in reverse Cuthill-McKee order
 #   "random"    the surrogate's mesh with a random node permutation (the adversarial case: no locality at all)
+#   "morton"    the surrogate's mesh in Z-order (bits of the lattice coordinates interleaved): locality without lines or fronts
 def _fe_from_edges(nn, eu, ev, seed, shift=1.0 / 64, dtype=np.float64):
     """A = sum over edges (u, v) of [[K, -K], [-K, K]] (K = K_e: symmetric 5 x 5, diagonally dominant, from a hash of the edge)
     + diag(shift (1 + a)): SPD; all values multiples of 1/128, so every sum is exact"""
@@ -307,10 +308,20 @@ def shell_variant(nx, kind="lex", seed=1, dtype=np.float64):
     """CSR arrays of a config-3-class operator with nx x nx mesh nodes in the numbering `kind` (see above)"""
     if kind == "lex":
         return shell_surrogate(nx, seed=seed, dtype=dtype)
-    if kind in ("rcm", "random"):
+    if kind in ("rcm", "random", "morton"):
         rp, ci, va = shell_surrogate(nx, seed=seed, dtype=dtype)
         if kind == "rcm":
             p = _rcm_new_of_old(_node_graph(rp, ci))
+        elif kind == "morton":
+            # Z-order of the node lattice (bits of i and j interleaved): what a space-filling-curve partitioner leaves behind
+            node = np.arange(nx * nx, dtype=np.int64)
+            i, j = node % nx, node // nx
+            code = np.zeros(nx * nx, dtype=np.int64)
+            for b in range(int(nx - 1).bit_length()):
+                code |= ((i >> b) & 1) << (2 * b)
+                code |= ((j >> b) & 1) << (2 * b + 1)
+            p = np.empty(nx * nx, dtype=np.int64)
+            p[np.argsort(code, kind="stable")] = node  # new number of every old node
         else:
             p = np.random.default_rng(seed).permutation(nx * nx).astype(np.int64)
         return _permute_nodes(rp, ci, va, p)

@@ -218,7 +218,7 @@ def test_full_size_gmres30_ilu0_converges_to_known_solution(ra, S, full):
 
 
 # ------------------------------------------------------------------ other node numberings of the same class
-@pytest.mark.parametrize("kind", ["rcm", "delaunay", "random"])
+@pytest.mark.parametrize("kind", ["rcm", "delaunay", "random", "morton"])
 def test_variants_of_the_class_bit_exact_and_plan_reported(ra, S, gen, oracle, kind):
     """The surrogate numbers its mesh nodes lexicographically -- exactly what the tile construction of the triangular solves
     keys on.  The same class of operator in reverse Cuthill-McKee order, as a Delaunay mesh in RCM order and in a random
