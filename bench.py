@@ -77,20 +77,28 @@ def mcsgs_bytes(n, nnz, vbytes=8):
     return (4 + vbytes) * (nnz - n) + 5 * vbytes * n
 
 
-def mc_red_black(args, precond=None):
-    """does the MC-SGS apply of this run take the one-pass red-black lattice form (csrc/mcsgs.hip: k_mc_rb)?  SGS on the
-    two-colour lattice operator of the generators, unless RAMD_MC_RB=0"""
-    return ((precond or args.precond) == "mcsgs" and args.matrix == "poisson"
-            and os.environ.get("RAMD_MC_RB", "1") != "0")
+MC_FORMS = {0: "k_mc_sweep: all colour sweeps of one apply",
+            1: "k_mc_sweep: all colour sweeps of one apply, colour 0's forward sweep folded into its readers",
+            2: "k_mc_rb: both colours of a red-black lattice operator in one pass"}
 
 
-def mc_form(args, precond=None):
-    return ("k_mc_rb: both colours of a red-black lattice operator in one pass" if mc_red_black(args, precond)
-            else "k_mc_sweep: all colour sweeps of one apply")
+def mc_plan_info(precond=None):
+    """what the multi-coloured preconditioner built last in this process looks like (ramd_mcsgs_info): the form of the SGS
+    apply is the plan's own answer, not an inference from the command line.  MC-GS / MC-ILU applies always run the sweeps."""
+    from rocalution_amd import capi
+    st = (C.c_int64 * 8)()
+    capi.check(capi.load().ramd_mcsgs_info(None, st))
+    form = int(st[0]) if (precond or "mcsgs") == "mcsgs" else min(int(st[0]), 0)
+    return dict(form=form, colours=int(st[1]), row_patterns=[int(st[2]), int(st[3])],
+                lattice=[int(st[4]), int(st[5]), int(st[6])] if form == 2 else None)
 
 
-def mc_traffic_key(args, precond=None):
-    return "mcsgs_512" if mc_red_black(args, precond) else "mcsgs_512_sweeps"
+def mc_form(precond=None):
+    return MC_FORMS[mc_plan_info(precond)["form"]]
+
+
+def mc_traffic_key(precond=None):
+    return "mcsgs_512" if mc_plan_info(precond)["form"] == 2 else "mcsgs_512_sweeps"
 
 
 def physical_cores():
@@ -168,6 +176,24 @@ def cpu_baseline(args, mtx_path=None):
     dt = time.time() - t0
     return dict(value=r["iters"] / dt, unit="iters/s", cores=threads, kind="port",
                 sample="%s, %s, %d iterations (incl. Build), C oracle (OpenMP)" % (label, what, r["iters"]))
+
+
+def cpu_port_baseline(rp, ci, va, solver, precond, iters, what):
+    """the C restatement of the reference's host path (oracle/, OpenMP where the reference has it) on arrays in memory: the CPU
+    baseline of the extras whose operator exists only in memory (kind "port")"""
+    from oracle import oracle as orc
+    orc.build()
+    threads = physical_cores()
+    orc.set_threads(threads)
+    rhs = orc.csr_apply(rp, ci, va, np.ones(len(rp) - 1))
+    osolver = {"cg": orc.CG, "gmres": orc.GMRES, "bicgstab": orc.BICGSTAB}[solver]
+    opc = {"none": orc.PC_NONE, "jacobi": orc.PC_JACOBI, "ilu0": orc.PC_ILU0, "mcsgs": orc.PC_MCSGS}[precond]
+    t0 = time.time()
+    r = orc.solve(rp, ci, va, rhs, solver=osolver, precond=opc, abs_tol=0.0, rel_tol=0.0, div_tol=1e300, max_iter=iters, history=False)
+    dt = time.time() - t0
+    return dict(value=round(r["iters"] / dt, 3), unit="iters/s", cores=threads, kind="port",
+                sample="%s+%s, %s, %d iterations (incl. Build), C oracle (the reference's host loops restated; OpenMP where the "
+                       "reference has it -- its triangular solves are sequential)" % (SOLVER_LABEL[solver], PRECOND_LABEL[precond], what, r["iters"]))
 
 
 def reference_gpu(args):
@@ -322,7 +348,7 @@ def tri_plan_stats(lib, capi):
 def traffic_for(key):
     """HBM bytes per launch from the PMC counters: measured offline with rocprofv3 in separate --pmc passes
     (tools/pmc_passes.sh) and committed under profiles/; bench.py does not run the profiler"""
-    for f in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for f in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         p = os.path.join(ROOT, "profiles", f)
         if os.path.exists(p):
             d = json.load(open(p))
@@ -505,14 +531,16 @@ def main():
         A.Apply(ones, rhs)
 
         CH = (PROF_SPMV, PROF_TRSV, PROF_VEC, PROF_PRECOND)
+        SYSTEM = (A, rhs, x, regen, fmt)  # the operator of the headline run (the extras bring their own)
 
-        def run(iters, solver_cls=S.CG, pc_cls=S.Jacobi, basis=None, warm=0, prof_iters=0):
+        def run(iters, solver_cls=S.CG, pc_cls=S.Jacobi, basis=None, warm=0, prof_iters=0, system=None):
             """one Solve of warm + iters iterations; warm > 0: the clock starts when iteration `warm` has been checked
             and the device drained (ramd_solver_set_time_mark), so the timed region is exactly `iters` iterations and
             the solver's preamble (initial residual, first direction) falls into the warm-up.
             prof_iters > 0: afterwards a SECOND Solve of that many iterations on the SAME built solver (same work vectors,
             same placement) with every SpMV / triangular-solve / fused-vector / preconditioner launch bracketed by HIP
             events on its stream -> the fifth value returned (dict channel -> statistics)"""
+            A, rhs, x, regen, fmt = system if system is not None else SYSTEM
             if A.GetFormat() != ra.CSR:  # preconditioners are built from the CSR state
                 regen()
             ls = solver_cls()
@@ -563,11 +591,13 @@ def main():
         HPC = {"none": None, "jacobi": S.Jacobi, "ilu0": S.ILU, "mcsgs": S.MultiColoredSGS,
                "mcgs": S.MultiColoredGS, "mcilu": S.MultiColoredILU, "ic": S.IC, "sgs": S.SGS, "uaamg": S.UAAMG, "saamg": S.SAAMG}[args.precond]
         basis = 30 if args.solver == "gmres" else None
-        if mixed:
-            def run(iters, *_a, warm=0, prof_iters=0):  # noqa: F811  (config 5 on one GPU)
+        def run_mixed(iters, *_a, warm=0, prof_iters=0, pc_cls=None):
+            """config 5 on one GPU: MixedPrecisionDC, fp64 outer defect correction around an fp32 CG
+            (clients/samples/mixed-precision.cpp:85: inner tolerances 1e-5 / 1e-2 / 1e+20, 100000 iterations)"""
+            if True:
                 inner = S.CG(np.float32)
-                if HPC is not None:
-                    inner.SetPreconditioner(HPC())
+                if pc_cls is not None:
+                    inner.SetPreconditioner(pc_cls())
                 inner.Init(1e-5, 1e-2, 1e20, 100000)
                 mp = S.MixedPrecisionDC(); mp.SetOperator(A); mp.Set(inner)
                 mp.Init(NEVER[0], NEVER[1], NEVER[2], warm + iters)
@@ -593,6 +623,9 @@ def main():
                         capi.check(lib.ramd_prof_enable(ch, 0))
                 mp.Clear()
                 return r + (pr,)
+        if mixed:
+            def run(iters, *_a, warm=0, prof_iters=0):  # noqa: F811
+                return run_mixed(iters, warm=warm, prof_iters=prof_iters, pc_cls=HPC)
         # W untimed warm-up iterations, then EXACTLY K timed ones, in one Solve (see run); --warmup 0 times the whole Solve
         # --- timed leg, then the roofline leg: the same built solver solves again with every SpMV / triangular-solve /
         # fused-vector launch bracketed by HIP events on the stream it runs on
@@ -652,9 +685,9 @@ def main():
                 kernels["vector_updates"] = roof("k_mgs_step" if args.solver == "gmres" else "k_cg_update / k_cg_direction",
                                                  (32 if args.solver == "gmres" else 40) * n * vb // 8, p_vec)
         if args.precond in ("mcsgs", "mcgs", "mcilu") and pr0[PROF_PRECOND]["launches"] > 0:
-            kernels["precond_apply"] = roof("multi-coloured %s apply (%s)" % (args.precond.upper()[2:], mc_form(args)),
+            kernels["precond_apply"] = roof("multi-coloured %s apply (%s)" % (args.precond.upper()[2:], mc_form(args.precond)),
                                             mcsgs_bytes(n, nnz, vb), pr0[PROF_PRECOND],
-                                            traffic_for(mc_traffic_key(args)) if (args.matrix == "poisson" and N == 512 and not mixed) else None)
+                                            traffic_for(mc_traffic_key(args.precond)) if (args.matrix == "poisson" and N == 512 and not mixed) else None)
         st_pat = C.c_int(0)
         capi.check(lib.ramd_mat_pattern_info(A._h, C.byref(st_pat), None, None))
         if st_pat.value in (1, 2) and args.format in ("csr", "ell", "hyb"):
@@ -684,12 +717,74 @@ def main():
                                                         trsv_bytes(n, nnz, 8), pe[PROF_TRSV], traffic_for("trsv_512") if big else None)
                         extras[name]["tri_plan"] = tp
                     if name == "bicgstab_mcsgs" and pe[PROF_PRECOND]["launches"] > 0:
-                        extras[name]["roofline"] = roof("multi-coloured SGS apply (%s)" % mc_form(args, "mcsgs"),
+                        extras[name]["roofline"] = roof("multi-coloured SGS apply (%s)" % mc_form("mcsgs"),
                                                         mcsgs_bytes(n, nnz, 8), pe[PROF_PRECOND],
-                                                        traffic_for(mc_traffic_key(args, "mcsgs")) if big else None)
+                                                        traffic_for(mc_traffic_key("mcsgs")) if big else None)
                     extras[name]["kernels"] = {"spmv": roof("CSR SpMV (k_csr_pat2 / k_csr_tr)", spmv_bytes(n, nnz, 8), pe[PROF_SPMV])}
                 except Exception as e:
                     extras[name] = dict(error=repr(e))
+            t_x = time.perf_counter()
+            # BASELINE.json config 5 on this GPU: MixedPrecisionDC(fp64 outer / fp32 CG + Jacobi inner) on the same operator.
+            # A "step" is one OUTER iteration (residual in fp64, an fp32 CG solve to 1e-2 relative, correction in fp64); the
+            # dominant kernel is the fp32 inner product, once with the row patterns and once with the stored columns read
+            try:
+                mi, mw = min(K, 20), min(W, 3)
+                d5, i5, r5, _, p5 = run_mixed(mi, warm=mw, prof_iters=min(K, 10), pc_cls=S.Jacobi)
+                big = (args.matrix == "poisson" and N == 512)
+                e5 = dict(outer_iters_per_s=round(i5 / d5, 3), iters=i5, ms_per_step=round(d5 / i5 * 1e3, 4), final_residual=r5,
+                          inner_spmv_per_outer=round(p5[PROF_SPMV]["count"] / max(min(K, 10), 1), 1),
+                          roofline=roof("fp32 inner CSR SpMV + fused <p,q> (k_csr_pat2<float>; the few fp64 outer residual products are in "
+                                        "the average)", spmv_bytes(n, nnz, 4), p5[PROF_SPMV], traffic_for("spmv_csr_512_fp32") if big else None))
+                A.UseRowPatterns(False)
+                try:
+                    d6, i6, _, _, p6 = run_mixed(min(mi, 10), warm=mw, prof_iters=min(K, 5), pc_cls=S.Jacobi)
+                finally:
+                    A.UseRowPatterns(True)
+                e5["roofline_columns_read"] = roof("k_csr_tr<float> + fused <p,q>: the same inner product with the stored columns read "
+                                                   "(ramd_mat_pattern_use(m, 0))", spmv_bytes(n, nnz, 4), p6[PROF_SPMV], None)
+                e5["columns_read"] = dict(outer_iters_per_s=round(i6 / d6, 3), ms_per_step=round(d6 / i6 * 1e3, 4))
+                extras["mixed_cg_jacobi"] = e5
+            except Exception as e:
+                extras["mixed_cg_jacobi"] = dict(error=repr(e))
+            log("extras: mixed_cg_jacobi %.1f s" % (time.perf_counter() - t_x))
+            t_x = time.perf_counter()
+            # BASELINE.json config 3's class: GMRES(30)+ILU(0) on the af_shell10-class operator in reverse Cuthill-McKee order (the
+            # numbering with the deep, narrow dependency graph; generators.shell_variant).  Generated in host memory and handed
+            # over with SetDataPtrCSR -- no MatrixMarket round trip in the default run (bench.py --matrix shell has it).
+            try:
+                from rocalution_amd import generators as gen
+                snx = args.shell_nx
+                t0 = time.perf_counter()
+                rp_h, ci_h, va_h = gen.shell_variant(snx, "rcm")
+                t_gen = time.perf_counter() - t0
+                n3, nnz3 = len(rp_h) - 1, len(ci_h)
+                A3 = ra.LocalMatrix(); A3.SetDataPtrCSR(rp_h, ci_h, va_h)
+                ones3 = ra.LocalVector(); ones3.Allocate("ones", n3); ones3.Ones()
+                rhs3 = ra.LocalVector(); rhs3.Allocate("rhs", n3)
+                x3 = ra.LocalVector(); x3.Allocate("x", n3)
+                A3.Apply(ones3, rhs3)
+                sys3 = (A3, rhs3, x3, lambda: A3.SetDataPtrCSR(rp_h, ci_h, va_h), ra.CSR)
+                i3n = min(max(K, 60), 120)
+                d3, i3, r3, tb3, p3 = run(i3n, S.GMRES, S.ILU, 30, warm=min(W, 10), prof_iters=min(i3n, 60), system=sys3)
+                tp3 = tri_plan_stats(lib, capi)
+                e3 = dict(iters_per_s=round(i3 / d3, 2), iters=i3, ms_per_step=round(d3 / i3 * 1e3, 4), build_s=round(tb3, 3),
+                          final_residual=r3, generate_s=round(t_gen, 2),
+                          workload="af_shell10-class operator (SuiteSparse af_shell10 itself is not available offline): %d x %d mesh "
+                                   "nodes x 5 unknowns in reverse Cuthill-McKee order, n=%d, nnz=%d (%.2f per row; af_shell10: "
+                                   "n=1508065, nnz=52259885), SPD, CSR fp64, rhs=A*1, x0=0" % (snx, snx, n3, nnz3, nnz3 / n3),
+                          roofline=roof("sparse triangular solve, one launch per triangle: %s" % tp3.get("lower", {}).get("form", "?"),
+                                        trsv_bytes(n3, nnz3, 8), p3[PROF_TRSV], traffic_for("trsv_shell_rcm")),
+                          tri_plan=tp3,
+                          kernels={"spmv": roof("CSR SpMV (k_csr_w4: rows of 16+ entries, four rows per wave)", spmv_bytes(n3, nnz3, 8),
+                                                p3[PROF_SPMV], traffic_for("spmv_csr_shell"))})
+                del A3, ones3, rhs3, x3, sys3
+                if not args.no_cpu_baseline:
+                    e3["cpu_baseline"] = cpu_port_baseline(rp_h, ci_h, va_h, "gmres", "ilu0", 30,
+                                                           "the same %d-row operator, in memory" % n3)
+                extras["gmres30_ilu0_shell_rcm"] = e3
+            except Exception as e:
+                extras["gmres30_ilu0_shell_rcm"] = dict(error=repr(e))
+            log("extras: gmres30_ilu0_shell_rcm %.1f s" % (time.perf_counter() - t_x))
     else:
         if args.matrix != "poisson":
             raise SystemExit("the distributed driver generates z-slabs of the Poisson operator")

@@ -329,6 +329,12 @@ typedef struct ramd_mcsgs_s* ramd_mcsgs_t;
 int ramd_mcsgs_build(ramd_mat_t permuted, int num_blocks, const int* block_sizes, ramd_vec_t perm_i32,
                      ramd_mcsgs_t* out);
 int ramd_mcsgs_apply(ramd_mcsgs_t h, ramd_vec_t rhs, ramd_vec_t x);
+/* which form of the SGS apply Build() chose (the counterpart of ramd_tri_plan_stats for the colour sweeps; the reference has no
+ * such query -- its MultiColored::Build, preconditioner_multicolored.cpp:303-340, has one form).  out8[0]: 0 = one sweep per
+ * colour and direction (k_mc_sweep), 1 = the same with colour 0's forward sweep folded into its readers, 2 = both colours of a
+ * red-black lattice operator in one pass (k_mc_rb); [1] colours; [2] / [3] 1 = the lower / upper part runs on row patterns;
+ * [4..6] lattice extents of form 2; [7] rows.  h == NULL: the plan built last in this process (not thread-safe: a diagnostic). */
+int ramd_mcsgs_info(ramd_mcsgs_t h, int64_t* out8);
 /* the same sweep plan applied as MultiColoredGS (backward sweep only,
  * preconditioner_multicolored_gs.cpp:250-288) or, when `permuted` held the ILU(0) factors of P A P^T,
  * as MultiColoredILU(0,1) (preconditioner_multicolored_ilu.cpp:187-232) */

@@ -179,6 +179,7 @@ SIGNATURES = {
     "ramd_fused_cg_direction": (i32, [vec_t, vec_t, vec_t, i32, i32, i32]),
     "ramd_mcsgs_build": (i32, [mat_t, i32, pi32, vec_t, C.POINTER(ptr)]),
     "ramd_mcsgs_apply": (i32, [ptr, vec_t, vec_t]),
+    "ramd_mcsgs_info": (i32, [ptr, pi64]),
     "ramd_mcsgs_apply_kind": (i32, [ptr, i32, vec_t, vec_t]),
     "ramd_mcsgs_destroy": (i32, [ptr]),
     "ramd_scalars_eval": (i32, [ptr, i32, i32]),

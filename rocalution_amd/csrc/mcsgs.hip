@@ -12,6 +12,7 @@
 // descending, column ascending), the permutation gather/scatter and the three diagonal scalings are
 // folded into the sweeps.  Arithmetic per row is the reference's, operation for operation
 // (x + (-1*a)*y == x - a*y exactly), so results are bit-identical to the block form.
+#include <atomic>
 #include "device_utils.hpp"
 #include "matrix_impl.hpp"
 
@@ -435,7 +436,12 @@ __global__ __launch_bounds__(kBlock) void k_mc_nat_dict(int p0, int n, int n0, i
                 continue; // (a column of another colour: read from the work vector as before)
             const int dlt = iperm[c] - me;
             if(pass == 0)
-                atomicCAS(nat + base + k, kNatNone, dlt);
+            {
+                // (one row per pattern slot writes; the others see the word filled and leave it alone: 67 M compare-and-swaps
+                //  on a few dozen words took 1.2 s per launch at 512^3)
+                if(__hip_atomic_load(nat + base + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kNatNone)
+                    atomicCAS(nat + base + k, kNatNone, dlt);
+            }
             else if(__hip_atomic_load(nat + base + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != dlt)
                 *bad = 1;
         }
@@ -713,12 +719,20 @@ __global__ __launch_bounds__(kBlock) void k_rb_fill(int n, int nx, int ny, int n
         const int c = blk_of[t];
         bool      ok = (((x + y + z) & 1) == p0) == (c == 0);
         T         a[6] = {(T)0, (T)0, (T)0, (T)0, (T)0, (T)0};
-        int       seen = 0;
+        int       seen = 0, last = -2147483647;
         bool      diag = false;
         for(int q = rp[t]; q < rp[t + 1]; ++q)
         {
             const int dd = iperm[ci[q]] - r;
             int       k  = -1;
+            // the colour sweeps subtract in the storage order of the permuted row, k_mc_rb in ascending natural offsets: the
+            // two orders must be the same one (a colouring permutation that does not keep the natural order within a colour
+            // would still be a valid one -- the sweeps then remain the form that runs)
+            if(dd != 0)
+            {
+                ok   = ok && dd > last;
+                last = dd;
+            }
             if(dd == 0)
                 diag = true;
             else if(dd == -nxny && z > 0)
@@ -938,7 +952,7 @@ static int mc_build(McsgsPlan* P, const ramd_mat_s* m, const int* perm)
             s = mc_band_map(P, i, false, &P->u_bm[(size_t)i]);
     }
     // (8-byte values only: a pair of fp32 values is no full 16-byte store; RAMD_MC_PAIR=0: off)
-    static const int pair_env = getenv("RAMD_MC_PAIR") ? atoi(getenv("RAMD_MC_PAIR")) : 1;
+    const int pair_env = getenv("RAMD_MC_PAIR") ? atoi(getenv("RAMD_MC_PAIR")) : 1;
     if(s == RAMD_OK && pair_env != 0 && nb > 1 && sizeof(T) == 8 && (n >= (1 << 16) || pair_env == 2)) // (2: any size -- tests)
     {
         s = dev_alloc(&P->pair_of, P->off[1]);
@@ -975,52 +989,9 @@ static int mc_build(McsgsPlan* P, const ramd_mat_s* m, const int* perm)
             P->identity[(size_t)i] = (h[(size_t)i] == 0) ? 1 : 0;
     }
     dev_free(&cnt);
-    // colour 0 folded into its readers (see McsgsPlan::fold0): RAMD_MC_FOLD=0 switches it off (A/B, and the tests run both forms)
-    static const int fold_env = getenv("RAMD_MC_FOLD") ? atoi(getenv("RAMD_MC_FOLD")) : 1;
-    if(s == RAMD_OK && fold_env != 0 && nb > 1 && P->l_pat == 1 && P->u_pat == 1 && !P->identity[0] && P->off[1] > 0)
-    {
-        const int n0 = P->off[1];
-        int*      bad = nullptr;
-        s = dev_alloc(&P->nat_dict, (int64_t)P->l_pat_n * kPatMaxW);
-        if(s == RAMD_OK)
-            s = dev_alloc(&bad, 1);
-        if(s == RAMD_OK && cached_malloc(&P->dinv_nat, (size_t)n * sizeof(T) + kPad) != hipSuccess)
-            s = RAMD_ERR_HIP;
-        if(s == RAMD_OK)
-        {
-            std::vector<int> init((size_t)P->l_pat_n * kPatMaxW, kNatNone);
-            hipError_t       e = hipMemcpyAsync(P->nat_dict, init.data(), sizeof(int) * init.size(), hipMemcpyHostToDevice, b.cur);
-            if(e == hipSuccess)
-                e = hipMemsetAsync(bad, 0, sizeof(int), b.cur);
-            if(e == hipSuccess)
-                e = hipMemsetAsync(P->dinv_nat, 0, (size_t)n * sizeof(T), b.cur);
-            if(e == hipSuccess)
-                e = hipStreamSynchronize(b.cur); // (init goes out of scope)
-            for(int pass = 0; pass < 2; ++pass)
-                hipLaunchKernelGGL(k_mc_nat_dict, dim3(ew_grid(n - n0)), dim3(kBlock), 0, b.cur, n0, n, n0, pass, P->l_pat_id,
-                                   P->l_pat_dict, P->iperm, P->nat_dict, bad);
-            hipLaunchKernelGGL((k_mc_dinv_nat<T>), dim3(ew_grid(n0)), dim3(kBlock), 0, b.cur, n0, P->iperm, (const T*)P->dinv,
-                               (T*)P->dinv_nat);
-            int hb = 1;
-            if(e == hipSuccess)
-                e = hipMemcpyAsync(&hb, bad, sizeof(int), hipMemcpyDeviceToHost, b.cur);
-            if(e == hipSuccess)
-                e = hipStreamSynchronize(b.cur);
-            if(e != hipSuccess)
-                s = RAMD_ERR_HIP;
-            P->fold0 = (s == RAMD_OK && hb == 0);
-        }
-        dev_free(&bad);
-        if(!P->fold0)
-        {
-            dev_free(&P->nat_dict);
-            if(P->dinv_nat)
-                (void)cached_free(P->dinv_nat);
-            P->dinv_nat = nullptr;
-        }
-    }
     // red-black lattice form (k_mc_rb): RAMD_MC_RB = 0 off, 1 (default) operators of 2^16 rows and more, 2 any size (tests)
-    static const int rb_env = getenv("RAMD_MC_RB") ? atoi(getenv("RAMD_MC_RB")) : 1;
+    // (read at every Build(), not once per process: the tests switch it inside one process)
+    const int rb_env = getenv("RAMD_MC_RB") ? atoi(getenv("RAMD_MC_RB")) : 1;
     if(s == RAMD_OK && rb_env != 0 && nb == 2 && !P->identity[0] && !P->identity[1] && (n >= (1 << 16) || rb_env == 2) && n >= 8)
     {
         int* dmin = nullptr;
@@ -1105,6 +1076,51 @@ static int mc_build(McsgsPlan* P, const ramd_mat_s* m, const int* perm)
                 }
         }
         dev_free(&dmin);
+    }
+    // colour 0 folded into its readers (see McsgsPlan::fold0): RAMD_MC_FOLD=0 switches it off (A/B, and the tests run both forms).
+    // Not prepared where the red-black form was taken: k_mc_rb does not use it (round 5 spent 4.7 s of Build() here for nothing).
+    const int fold_env = getenv("RAMD_MC_FOLD") ? atoi(getenv("RAMD_MC_FOLD")) : 1;
+    if(s == RAMD_OK && fold_env != 0 && !P->rb && nb > 1 && P->l_pat == 1 && P->u_pat == 1 && !P->identity[0] && P->off[1] > 0)
+    {
+        const int n0 = P->off[1];
+        int*      bad = nullptr;
+        s = dev_alloc(&P->nat_dict, (int64_t)P->l_pat_n * kPatMaxW);
+        if(s == RAMD_OK)
+            s = dev_alloc(&bad, 1);
+        if(s == RAMD_OK && cached_malloc(&P->dinv_nat, (size_t)n * sizeof(T) + kPad) != hipSuccess)
+            s = RAMD_ERR_HIP;
+        if(s == RAMD_OK)
+        {
+            std::vector<int> init((size_t)P->l_pat_n * kPatMaxW, kNatNone);
+            hipError_t       e = hipMemcpyAsync(P->nat_dict, init.data(), sizeof(int) * init.size(), hipMemcpyHostToDevice, b.cur);
+            if(e == hipSuccess)
+                e = hipMemsetAsync(bad, 0, sizeof(int), b.cur);
+            if(e == hipSuccess)
+                e = hipMemsetAsync(P->dinv_nat, 0, (size_t)n * sizeof(T), b.cur);
+            if(e == hipSuccess)
+                e = hipStreamSynchronize(b.cur); // (init goes out of scope)
+            for(int pass = 0; pass < 2; ++pass)
+                hipLaunchKernelGGL(k_mc_nat_dict, dim3(ew_grid(n - n0)), dim3(kBlock), 0, b.cur, n0, n, n0, pass, P->l_pat_id,
+                                   P->l_pat_dict, P->iperm, P->nat_dict, bad);
+            hipLaunchKernelGGL((k_mc_dinv_nat<T>), dim3(ew_grid(n0)), dim3(kBlock), 0, b.cur, n0, P->iperm, (const T*)P->dinv,
+                               (T*)P->dinv_nat);
+            int hb = 1;
+            if(e == hipSuccess)
+                e = hipMemcpyAsync(&hb, bad, sizeof(int), hipMemcpyDeviceToHost, b.cur);
+            if(e == hipSuccess)
+                e = hipStreamSynchronize(b.cur);
+            if(e != hipSuccess)
+                s = RAMD_ERR_HIP;
+            P->fold0 = (s == RAMD_OK && hb == 0);
+        }
+        dev_free(&bad);
+        if(!P->fold0)
+        {
+            dev_free(&P->nat_dict);
+            if(P->dinv_nat)
+                (void)cached_free(P->dinv_nat);
+            P->dinv_nat = nullptr;
+        }
     }
     dev_free(&d_off);
     return s;
@@ -1238,6 +1254,22 @@ struct ramd_mcsgs_s
     McsgsPlan plan;
 };
 
+namespace
+{
+// what the plan built last in this process looks like (ramd_mcsgs_info with a NULL handle: the Python drivers and bench.py do
+// not hold the handle, the C++ preconditioner object does).  One word per field, written at the end of a Build().
+std::atomic<long long> g_mc_last[8];
+void mc_fill_info(const McsgsPlan& P, long long* o)
+{
+    o[0] = P.rb ? 2 : P.fold0 ? 1 : 0;
+    o[1] = P.nb;
+    o[2] = P.l_pat;
+    o[3] = P.u_pat;
+    o[4] = P.rb_nx, o[5] = P.rb_ny, o[6] = P.rb_nz;
+    o[7] = P.n;
+}
+} // namespace
+
 extern "C" {
 
 int ramd_mcsgs_build(ramd_mat_t permuted, int num_blocks, const int* block_sizes, ramd_vec_t perm,
@@ -1270,7 +1302,26 @@ int ramd_mcsgs_build(ramd_mat_t permuted, int num_blocks, const int* block_sizes
         delete h;
         return s;
     }
+    long long o[8];
+    mc_fill_info(P, o);
+    for(int i = 0; i < 8; ++i)
+        g_mc_last[i].store(o[i], std::memory_order_relaxed);
     *out = h;
+    return RAMD_OK;
+}
+
+int ramd_mcsgs_info(ramd_mcsgs_t h, int64_t* out8)
+{
+    if(!out8)
+        RAMD_FAIL(RAMD_ERR_ARG, "mcsgs_info: bad arguments");
+    long long o[8];
+    if(h)
+        mc_fill_info(h->plan, o);
+    else
+        for(int i = 0; i < 8; ++i)
+            o[i] = g_mc_last[i].load(std::memory_order_relaxed);
+    for(int i = 0; i < 8; ++i)
+        out8[i] = (int64_t)o[i];
     return RAMD_OK;
 }
 

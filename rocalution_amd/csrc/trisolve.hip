@@ -794,7 +794,10 @@ struct TriPlan
 
 struct TriState
 {
-    TriPlan   L, U;
+    // LUAnalyse owns L and U; LAnalyse / UAnalyse own Ls / Us: independent plans, as the analyses are independent calls with
+    // their own diagonal flag (a lattice plan fixes the flag when it is built, and LUSolve chains L into U through lu_rhs_idx
+    // and the shared scratch: interleaved LUAnalyse / LAnalyse / UAnalyse / *Clear must not see each other's plans)
+    TriPlan   L, U, Ls, Us;
     bool      haveL = false, haveU = false;
     int*      lu_rhs_idx = nullptr; // [n]: U position -> L position of the same row
     unsigned* counter    = nullptr; // shared workgroup ticket
@@ -868,6 +871,8 @@ void tri_release(ramd_mat_s* m)
         return;
     st->L.release();
     st->U.release();
+    st->Ls.release();
+    st->Us.release();
     dev_free(&st->lu_rhs_idx);
     dev_free(&st->counter);
     dev_free(&st->stream_counter);
@@ -6675,6 +6680,8 @@ int ramd_mat_lu_analyse(ramd_mat_t m)
         return RAMD_ERR_UNSUPPORTED;
     TriState* st = nullptr;
     RAMD_TRY(tri_get(m, &st));
+    m->lu_analysed = false;
+    st->haveL = st->haveU = false;
     // both triangles on a lattice: the pencil form, L then U in place on the output vector (no position order, no scratch)
     {
         st->L.release();
@@ -6737,10 +6744,13 @@ int ramd_mat_lu_solve(ramd_mat_t m, ramd_vec_t in, ramd_vec_t out)
     if(!m->lu_analysed)
         RAMD_FAIL(RAMD_ERR_STATE, "LUSolve before LUAnalyse");
     TriState* st = tri_state(m);
+    if(!st || !st->haveL || !st->haveU || (st->L.lat != nullptr) != (st->U.lat != nullptr)
+       || (!st->L.lat && (!st->lu_rhs_idx || !st->L.order || !st->U.order)))
+        RAMD_FAIL(RAMD_ERR_STATE, "LUSolve: the plans of LUAnalyse are incomplete");
     if(st->L.lat && st->U.lat)
     {
         if(!lat_is_unit(st->L.lat) || lat_is_unit(st->U.lat))
-            RAMD_FAIL(RAMD_ERR_STATE, "LUSolve: the plans of LUAnalyse were replaced by LAnalyse / UAnalyse");
+            RAMD_FAIL(RAMD_ERR_STATE, "LUSolve: the lattice plans of LUAnalyse carry the wrong diagonal flags");
         if(m->dtype == RAMD_F64)
         {
             RAMD_TRY(lat_run<double>(st->L.lat, (const double*)in->d, (double*)out->d));
@@ -6770,21 +6780,21 @@ int ramd_mat_l_analyse(ramd_mat_t m, int diag_unit)
         return RAMD_ERR_UNSUPPORTED;
     TriState* st = nullptr;
     RAMD_TRY(tri_get(m, &st));
-    st->L.release();
-    const int sl = m->dtype == RAMD_F64 ? lat_build<double>(m, true, diag_unit != 0, &st->L.lat)
-                                        : lat_build<float>(m, true, diag_unit != 0, &st->L.lat);
+    m->l_analysed = false;
+    st->Ls.release();
+    const int sl = m->dtype == RAMD_F64 ? lat_build<double>(m, true, diag_unit != 0, &st->Ls.lat)
+                                        : lat_build<float>(m, true, diag_unit != 0, &st->Ls.lat);
     if(sl == RAMD_OK)
-        st->L.n = m->nrow;
+        st->Ls.n = m->nrow;
     else if(sl != RAMD_ERR_UNSUPPORTED)
         return sl;
     else if(m->dtype == RAMD_F64)
-        RAMD_TRY(build_plan<double>(m, st, &st->L, true));
+        RAMD_TRY(build_plan<double>(m, st, &st->Ls, true));
     else
-        RAMD_TRY(build_plan<float>(m, st, &st->L, true));
-    st->haveL      = true;
+        RAMD_TRY(build_plan<float>(m, st, &st->Ls, true));
     m->l_analysed  = true;
     m->l_diag_unit = diag_unit != 0;
-    tri_note_stats(m, &st->L, 0);
+    tri_note_stats(m, &st->Ls, 0);
     return RAMD_OK;
 }
 
@@ -6793,10 +6803,7 @@ int ramd_mat_l_analyse_clear(ramd_mat_t m)
     if(!m)
         RAMD_FAIL(RAMD_ERR_ARG, "null matrix handle");
     if(TriState* st = tri_state(m))
-    {
-        st->L.release();
-        st->haveL = false;
-    }
+        st->Ls.release();
     m->l_analysed  = false;
     m->l_diag_unit = true; // host LAnalyseClear resets to unit (host_matrix_csr.cpp:1350-1354)
     return RAMD_OK;
@@ -6808,13 +6815,13 @@ int ramd_mat_l_solve(ramd_mat_t m, ramd_vec_t in, ramd_vec_t out)
     if(!m->l_analysed)
         RAMD_FAIL(RAMD_ERR_STATE, "LSolve before LAnalyse");
     TriState* st = tri_state(m);
-    if(st->L.lat)
-        return m->dtype == RAMD_F64 ? lat_run<double>(st->L.lat, (const double*)in->d, (double*)out->d)
-                                    : lat_run<float>(st->L.lat, (const float*)in->d, (float*)out->d);
+    if(st->Ls.lat)
+        return m->dtype == RAMD_F64 ? lat_run<double>(st->Ls.lat, (const double*)in->d, (double*)out->d)
+                                    : lat_run<float>(st->Ls.lat, (const float*)in->d, (float*)out->d);
     if(m->dtype == RAMD_F64)
-        return run_plan<double>(st, &st->L, m->l_diag_unit, (const double*)in->d, st->L.order,
+        return run_plan<double>(st, &st->Ls, m->l_diag_unit, (const double*)in->d, st->Ls.order,
                                 (double*)out->d);
-    return run_plan<float>(st, &st->L, m->l_diag_unit, (const float*)in->d, st->L.order, (float*)out->d);
+    return run_plan<float>(st, &st->Ls, m->l_diag_unit, (const float*)in->d, st->Ls.order, (float*)out->d);
 }
 
 int ramd_mat_u_analyse(ramd_mat_t m, int diag_unit)
@@ -6825,21 +6832,21 @@ int ramd_mat_u_analyse(ramd_mat_t m, int diag_unit)
         return RAMD_ERR_UNSUPPORTED;
     TriState* st = nullptr;
     RAMD_TRY(tri_get(m, &st));
-    st->U.release();
-    const int sl = m->dtype == RAMD_F64 ? lat_build<double>(m, false, diag_unit != 0, &st->U.lat)
-                                        : lat_build<float>(m, false, diag_unit != 0, &st->U.lat);
+    m->u_analysed = false;
+    st->Us.release();
+    const int sl = m->dtype == RAMD_F64 ? lat_build<double>(m, false, diag_unit != 0, &st->Us.lat)
+                                        : lat_build<float>(m, false, diag_unit != 0, &st->Us.lat);
     if(sl == RAMD_OK)
-        st->U.n = m->nrow;
+        st->Us.n = m->nrow;
     else if(sl != RAMD_ERR_UNSUPPORTED)
         return sl;
     else if(m->dtype == RAMD_F64)
-        RAMD_TRY(build_plan<double>(m, st, &st->U, false));
+        RAMD_TRY(build_plan<double>(m, st, &st->Us, false));
     else
-        RAMD_TRY(build_plan<float>(m, st, &st->U, false));
-    st->haveU      = true;
+        RAMD_TRY(build_plan<float>(m, st, &st->Us, false));
     m->u_analysed  = true;
     m->u_diag_unit = diag_unit != 0;
-    tri_note_stats(m, &st->U, 1);
+    tri_note_stats(m, &st->Us, 1);
     return RAMD_OK;
 }
 
@@ -6848,10 +6855,7 @@ int ramd_mat_u_analyse_clear(ramd_mat_t m)
     if(!m)
         RAMD_FAIL(RAMD_ERR_ARG, "null matrix handle");
     if(TriState* st = tri_state(m))
-    {
-        st->U.release();
-        st->haveU = false;
-    }
+        st->Us.release();
     m->u_analysed  = false;
     m->u_diag_unit = false;
     return RAMD_OK;
@@ -6863,13 +6867,13 @@ int ramd_mat_u_solve(ramd_mat_t m, ramd_vec_t in, ramd_vec_t out)
     if(!m->u_analysed)
         RAMD_FAIL(RAMD_ERR_STATE, "USolve before UAnalyse");
     TriState* st = tri_state(m);
-    if(st->U.lat)
-        return m->dtype == RAMD_F64 ? lat_run<double>(st->U.lat, (const double*)in->d, (double*)out->d)
-                                    : lat_run<float>(st->U.lat, (const float*)in->d, (float*)out->d);
+    if(st->Us.lat)
+        return m->dtype == RAMD_F64 ? lat_run<double>(st->Us.lat, (const double*)in->d, (double*)out->d)
+                                    : lat_run<float>(st->Us.lat, (const float*)in->d, (float*)out->d);
     if(m->dtype == RAMD_F64)
-        return run_plan<double>(st, &st->U, m->u_diag_unit, (const double*)in->d, st->U.order,
+        return run_plan<double>(st, &st->Us, m->u_diag_unit, (const double*)in->d, st->Us.order,
                                 (double*)out->d);
-    return run_plan<float>(st, &st->U, m->u_diag_unit, (const float*)in->d, st->U.order, (float*)out->d);
+    return run_plan<float>(st, &st->Us, m->u_diag_unit, (const float*)in->d, st->Us.order, (float*)out->d);
 }
 
 } // extern "C"
