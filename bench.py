@@ -737,7 +737,7 @@ def main():
                                         "the average)", spmv_bytes(n, nnz, 4), p5[PROF_SPMV], traffic_for("spmv_csr_512_fp32") if big else None))
                 A.UseRowPatterns(False)
                 try:
-                    d6, i6, _, _, p6 = run_mixed(min(mi, 10), warm=mw, prof_iters=min(K, 5), pc_cls=S.Jacobi)
+                    d6, i6, _, _, p6 = run_mixed(mi, warm=mw, prof_iters=min(K, 5), pc_cls=S.Jacobi)  # (the same outer iterations: their inner counts differ)
                 finally:
                     A.UseRowPatterns(True)
                 e5["roofline_columns_read"] = roof("k_csr_tr<float> + fused <p,q>: the same inner product with the stored columns read "

@@ -1518,6 +1518,13 @@ public:
         this->MoveToAccelerator();
         RAMD_CHECK(ramd_mat_gen_poisson7(this->dev_, N));
     }
+    // extension: the reference's own 3-D test operator generated on the device (the 27-point Laplacian of gen_3d_laplacian,
+    // clients/include/utility.hpp:110-177, there a cube: nx = ny = nz = ndim)
+    void GenerateLaplace27(int nx, int ny, int nz)
+    {
+        this->MoveToAccelerator();
+        RAMD_CHECK(ramd_mat_gen_laplace27(this->dev_, nx, ny, nz));
+    }
     // extension: value-cast copy used by MixedPrecisionDC (mixed_precision.cpp:201-229)
     template <typename OtherType>
     void CastFrom(const LocalMatrix<OtherType>& src)

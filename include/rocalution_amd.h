@@ -225,14 +225,26 @@ int ramd_mat_lu_analyse(ramd_mat_t m); /* :344 */
 int ramd_mat_lu_analyse_clear(ramd_mat_t m); /* :346 */
 int ramd_mat_lu_solve(ramd_mat_t m, ramd_vec_t in, ramd_vec_t out); /* :349 */
 /* statistics of the triangular-solve plans of the most recent LUAnalyse / LAnalyse / UAnalyse of this process (a measurement
- * hook, no reference counterpart; which = 0 lower, 1 upper).  out[0] form: 1 level-scheduled rows, 2 box tiles in record
- * form, 3 box tiles with row groups, 4 lattice pencils, 5 level-scheduled rows walked by one workgroup (deep, narrow graphs); [1] rows; [2] dependency levels; [3] tiles / pencils; [4] steps of all
- * tiles; [5] values handed from tile to tile per solve; [6] most rows of a tile; [7] longest triangular row; [8] lanes per row;
- * [9..11] box edges in the three dependency coordinates (lattice: nx, ny, nz); [12] bytes of the plan (lattice form) / for
- * form 1 the reason the box-tile form was not taken: 1 no chains of consecutively numbered dependent rows, 2 no dependencies,
- * 3 rows longer than 32 entries without row groups, 4 / 5 index ranges, 6 tiles do not fit the LDS, 7 too few rows, 8 switched off;
- * [13] chains; [14] most steps of a tile; [15] most external values of a tile */
+ * hook, no reference counterpart; which = 0 lower, 1 upper).  Process-global and not thread-safe: analyses running concurrently
+ * in several host threads overwrite each other's record.
+ * out[0] form: 1 level-scheduled rows, 2 box tiles in record form, 3 box tiles with row groups, 4 lattice pencils, 6 row groups
+ * handed from wave to wave (sync-free grouped form, trsv_syncfree.hip; 5 was a form removed in round 5).
+ * Forms 1-4: [1] rows; [2] dependency levels; [3] tiles / pencils; [4] steps of all tiles; [5] values handed from tile to tile
+ * per solve; [6] most rows of a tile; [7] longest triangular row; [8] lanes per row; [9..11] box edges in the three dependency
+ * coordinates (lattice: nx, ny, nz); [12] bytes of the plan (lattice form) / for form 1 the reason the box-tile form was not
+ * taken: 1 no chains of consecutively numbered dependent rows, 2 no dependencies, 3 rows longer than 32 entries without row
+ * groups, 4 / 5 index ranges, 6 tiles do not fit the LDS, 7 too few rows, 8 switched off, 9 row groups with more than 24 entries
+ * outside the group; [13] chains; [14] most steps of a tile; [15] most external values of a tile.
+ * Form 6: [1] rows; [2] GROUP levels (one hand-off each); [3] units (whole row groups of one group level, one wave each);
+ * [4] row groups; [5] 0; [6] rows a unit holds at most (64 / lanes per row); [7] most entries of a row outside its group;
+ * [8] lanes per row; [9] rows of the longest group; [12] the reason the box-tile form was not taken (as above); [14] bytes of the
+ * out-of-group entries as stored (positions + coefficients) */
 int ramd_tri_plan_stats(int which, long long* out16);
+/* test hook of the sync-free grouped form's division (trsv_syncfree.hip sf_div: the fp64 division sequence of gfx950 with the
+ * part that depends on the divisor alone formed once per plan; no reference counterpart -- the reference divides,
+ * host_matrix_csr.cpp:1216).  Device pointers, n elements each: fast[i] = sf_div(a[i], d[i]), plain[i] = a[i] / d[i],
+ * in_window[i] = 1 where the short sequence is what produced fast[i] (both operands inside its exponent window) */
+int ramd_selftest_sf_div(long long n, const double* a, const double* d, double* fast, double* plain, int* in_window);
 int ramd_mat_l_analyse(ramd_mat_t m, int diag_unit); /* :365 */
 int ramd_mat_l_analyse_clear(ramd_mat_t m);
 int ramd_mat_l_solve(ramd_mat_t m, ramd_vec_t in, ramd_vec_t out); /* :370 */
@@ -242,6 +254,10 @@ int ramd_mat_u_solve(ramd_mat_t m, ramd_vec_t in, ramd_vec_t out); /* :380 */
 
 /* device-side synthetic operator: 3-D 7-point Poisson N^3 in CSR */
 int ramd_mat_gen_poisson7(ramd_mat_t m, int N);
+/* the reference's own 3-D test operator, generated on the device: the 27-point Laplacian of gen_3d_laplacian
+ * (clients/include/utility.hpp:110-177: 26 on the diagonal, -1 at every lattice neighbour of the 3 x 3 x 3 box, ascending
+ * columns) on an nx x ny x nz lattice, x fastest (the reference generates cubes: nx = ny = nz = ndim) */
+int ramd_mat_gen_laplace27(ramd_mat_t m, int nx, int ny, int nz);
 /* rows [row_begin,row_end) of the same operator split into interior (local columns) and ghost
  * (remote columns, renumbered into the halo receive buffer) parts -- the per-rank pieces a
  * GlobalMatrix holds (src/base/global_matrix.cpp:913-921). */

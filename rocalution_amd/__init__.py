@@ -508,3 +508,9 @@ class LocalMatrix:
 
     def GenPoisson7(self, N):
         capi.check(_lib().ramd_mat_gen_poisson7(self._h, int(N)))
+
+    def GenLaplace27(self, nx, ny=None, nz=None):
+        """the reference's gen_3d_laplacian (clients/include/utility.hpp:110-177) on the device; ny, nz default to nx"""
+        ny = nx if ny is None else ny
+        nz = nx if nz is None else nz
+        capi.check(_lib().ramd_mat_gen_laplace27(self._h, int(nx), int(ny), int(nz)))

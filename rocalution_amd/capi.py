@@ -115,6 +115,7 @@ SIGNATURES = {
     "ramd_mat_lu_analyse_clear": (i32, [mat_t]),
     "ramd_mat_lu_solve": (i32, [mat_t, vec_t, vec_t]),
     "ramd_tri_plan_stats": (i32, [i32, pi64]),
+    "ramd_selftest_sf_div": (i32, [i64, ptr, ptr, ptr, ptr, ptr]),
     "ramd_mat_l_analyse": (i32, [mat_t, i32]),
     "ramd_mat_l_analyse_clear": (i32, [mat_t]),
     "ramd_mat_l_solve": (i32, [mat_t, vec_t, vec_t]),
@@ -122,6 +123,7 @@ SIGNATURES = {
     "ramd_mat_u_analyse_clear": (i32, [mat_t]),
     "ramd_mat_u_solve": (i32, [mat_t, vec_t, vec_t]),
     "ramd_mat_gen_poisson7": (i32, [mat_t, i32]),
+    "ramd_mat_gen_laplace27": (i32, [mat_t, i32, i32, i32]),
     "ramd_mat_gen_poisson7_slab": (i32, [mat_t, mat_t, i32, i64, i64]),
     # fused ops / scalar records
     "ramd_mat_ic_factorize": (i32, [mat_t, vec_t]),

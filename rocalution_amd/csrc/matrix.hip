@@ -183,6 +183,55 @@ __global__ __launch_bounds__(kBlock) void k_poisson_fill(int N, int64_t lo, int6
     }
 }
 
+// The reference's own 3-D operator (clients/include/utility.hpp:110-177 gen_3d_laplacian): the 27-point stencil on a lattice, row
+// r = (z ny + y) nx + x, the entries of a row in the order of its three nested offset loops (sz, sy, sx = -1 .. 1: ascending
+// columns), 26 on the diagonal and -1 elsewhere, a neighbour the lattice does not have left out.  (nx = ny = nz there.)
+__device__ __forceinline__ int lap27_span(int i, int n)
+{
+    return (i > 0 ? 1 : 0) + 1 + (i < n - 1 ? 1 : 0);
+}
+__global__ __launch_bounds__(kBlock) void k_lap27_count(int nx, int ny, int nz, int* __restrict__ cnt)
+{
+    const int64_t n   = (int64_t)nx * ny * nz;
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gsz)
+    {
+        const int x = (int)(r % nx), y = (int)((r / nx) % ny), z = (int)(r / ((int64_t)nx * ny));
+        cnt[r]      = lap27_span(x, nx) * lap27_span(y, ny) * lap27_span(z, nz);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_lap27_fill(int nx, int ny, int nz, const int* __restrict__ rp, int* __restrict__ ci,
+                                                       T* __restrict__ val)
+{
+    const int64_t n   = (int64_t)nx * ny * nz;
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gsz)
+    {
+        const int x = (int)(r % nx), y = (int)((r / nx) % ny), z = (int)(r / ((int64_t)nx * ny));
+        int       p = rp[r];
+        for(int sz = -1; sz <= 1; ++sz)
+        {
+            if(z + sz < 0 || z + sz >= nz)
+                continue;
+            for(int sy = -1; sy <= 1; ++sy)
+            {
+                if(y + sy < 0 || y + sy >= ny)
+                    continue;
+                for(int sx = -1; sx <= 1; ++sx)
+                {
+                    if(x + sx < 0 || x + sx >= nx)
+                        continue;
+                    const int64_t col = r + ((int64_t)sz * ny + sy) * nx + sx;
+                    ci[p]             = (int)col;
+                    val[p]            = (col == r) ? (T)26 : (T)-1;
+                    ++p;
+                }
+            }
+        }
+    }
+}
+
 } // namespace ramd
 
 using namespace ramd;
@@ -516,6 +565,46 @@ int ramd_mat_gen_poisson7(ramd_mat_t m, int N)
     if(N < 1 || (int64_t)N * N * N >= (1ll << 31) / 7)
         RAMD_FAIL(RAMD_ERR_ARG, "poisson7: N out of the int32 index range");
     return gen_poisson_common(m, N, 0, (int64_t)N * N * N, 0);
+}
+
+int ramd_mat_gen_laplace27(ramd_mat_t m, int nx, int ny, int nz)
+{
+    CHECK_MAT(m);
+    const int64_t n = (int64_t)nx * ny * nz;
+    if(nx < 1 || ny < 1 || nz < 1 || n >= (1ll << 31) / 27)
+        RAMD_FAIL(RAMD_ERR_ARG, "laplace27: extents out of the int32 index range");
+    Backend& b   = backend();
+    int *    cnt = nullptr, *rp = nullptr;
+    RAMD_TRY(dev_alloc(&cnt, n + 1));
+    int s = dev_alloc(&rp, n + 1);
+    if(s == RAMD_OK && hipMemsetAsync(cnt + n, 0, sizeof(int), b.cur) != hipSuccess)
+        s = RAMD_ERR_HIP;
+    const int grid = ew_grid(n);
+    if(s == RAMD_OK)
+    {
+        hipLaunchKernelGGL(k_lap27_count, dim3(grid), dim3(kBlock), 0, b.cur, nx, ny, nz, cnt);
+        s = device_exclusive_scan(cnt, rp, n + 1);
+    }
+    int last = 0;
+    if(s == RAMD_OK
+       && (hipMemcpyAsync(&last, rp + n, sizeof(int), hipMemcpyDeviceToHost, b.cur) != hipSuccess
+           || hipStreamSynchronize(b.cur) != hipSuccess))
+        s = RAMD_ERR_HIP;
+    dev_free(&cnt);
+    if(s == RAMD_OK)
+        s = mat_alloc_csr(m, (int)n, (int)n, (int64_t)last);
+    if(s == RAMD_OK)
+    {
+        hipError_t e = hipMemcpyAsync(m->rp, rp, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToDevice, b.cur);
+        if(m->dtype == RAMD_F64)
+            hipLaunchKernelGGL((k_lap27_fill<double>), dim3(grid), dim3(kBlock), 0, b.cur, nx, ny, nz, m->rp, m->ci, (double*)m->val);
+        else
+            hipLaunchKernelGGL((k_lap27_fill<float>), dim3(grid), dim3(kBlock), 0, b.cur, nx, ny, nz, m->rp, m->ci, (float*)m->val);
+        if(e != hipSuccess || hipGetLastError() != hipSuccess || hipStreamSynchronize(b.cur) != hipSuccess)
+            s = RAMD_ERR_HIP;
+    }
+    dev_free(&rp);
+    return s;
 }
 
 int ramd_mat_gen_poisson7_slab(ramd_mat_t interior, ramd_mat_t ghost, int N, int64_t row_begin,

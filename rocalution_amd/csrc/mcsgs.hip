@@ -1063,6 +1063,9 @@ static int mc_build(McsgsPlan* P, const ramd_mat_s* m, const int* perm)
                 s = RAMD_ERR_HIP;
             P->rb = (s == RAMD_OK && hb == 0);
             P->rb_nx = nx, P->rb_ny = ny, P->rb_nz = nz, P->rb_p0 = p0;
+            if(getenv("RAMD_MC_VERBOSE"))
+                fprintf(stderr, "mc plan: red-black lattice form %s on %d x %d x %d (colour 0 = parity %d)\n", P->rb ? "taken" : "REFUSED by the row check",
+                        nx, ny, nz, p0);
             if(!P->rb)
                 for(int c = 0; c < 2; ++c)
                 {
@@ -1075,8 +1078,13 @@ static int mc_build(McsgsPlan* P, const ramd_mat_s* m, const int* perm)
                     }
                 }
         }
+        else if(getenv("RAMD_MC_VERBOSE"))
+            fprintf(stderr, "mc plan: no lattice found for the red-black form (n = %d, smallest offsets %d / %d)\n", n, nx, h2[0]);
         dev_free(&dmin);
     }
+    else if(getenv("RAMD_MC_VERBOSE"))
+        fprintf(stderr, "mc plan: red-black form not tried (n = %d, %d colours, identity blocks %d %d, RAMD_MC_RB = %d)\n", n, nb,
+                nb > 0 ? (int)P->identity[0] : -1, nb > 1 ? (int)P->identity[1] : -1, rb_env);
     // colour 0 folded into its readers (see McsgsPlan::fold0): RAMD_MC_FOLD=0 switches it off (A/B, and the tests run both forms).
     // Not prepared where the red-black form was taken: k_mc_rb does not use it (round 5 spent 4.7 s of Build() here for nothing).
     const int fold_env = getenv("RAMD_MC_FOLD") ? atoi(getenv("RAMD_MC_FOLD")) : 1;

@@ -22,7 +22,9 @@
 //     no flags, no fences.
 #include "device_utils.hpp"
 #include "matrix_impl.hpp"
+#include "trsv_handoff.hpp"
 #include "trsv_lattice.hpp"
+#include "trsv_syncfree.hpp"
 
 #include <algorithm>
 #include <type_traits>
@@ -30,61 +32,6 @@
 
 namespace ramd
 {
-
-// ---------------------------------------------------------------- sentinel helpers
-template <typename T>
-struct Sentinel;
-template <>
-struct Sentinel<double>
-{
-    using bits = unsigned long long;
-    static constexpr bits value = 0x7FF8DEADBEEF0001ull; // quiet NaN with a private payload
-    __device__ static __forceinline__ bits as_bits(double v)
-    {
-        return (bits)__double_as_longlong(v);
-    }
-    __device__ static __forceinline__ double from_bits(bits b)
-    {
-        return __longlong_as_double((long long)b);
-    }
-};
-template <>
-struct Sentinel<float>
-{
-    using bits = unsigned int;
-    static constexpr bits value = 0x7FDEAD01u;
-    __device__ static __forceinline__ bits as_bits(float v)
-    {
-        return __float_as_uint(v);
-    }
-    __device__ static __forceinline__ float from_bits(bits b)
-    {
-        return __uint_as_float(b);
-    }
-};
-
-template <typename T>
-__device__ __forceinline__ typename Sentinel<T>::bits poll_load(const T* p)
-{
-    using B = typename Sentinel<T>::bits;
-    return __hip_atomic_load(reinterpret_cast<const B*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <typename T>
-__device__ __forceinline__ void publish(T* p, T v)
-{
-    using B = typename Sentinel<T>::bits;
-    __hip_atomic_store(reinterpret_cast<B*>(p), Sentinel<T>::as_bits(v), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-}
-
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_fill_sentinel(int64_t n, T* __restrict__ w)
-{
-    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
-    const T       s   = Sentinel<T>::from_bits(Sentinel<T>::value);
-    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gsz)
-        w[i] = s;
-}
 
 __device__ __forceinline__ bool lane_bit(unsigned long long mask, int b) // (b wave-uniform: 32-bit shifts)
 {
@@ -369,21 +316,6 @@ __global__ __launch_bounds__(kBlock) void k_trsv(int nrow, const int* __restrict
     } while(__ballot(!fin) != 0ull);
 }
 
-// value of lane - 1 of the same 16-lane row (DPP row_shr:1): the hand-over of a running sum from lane to lane of a row
-template <typename T>
-__device__ __forceinline__ T lane_before_in_row(T v);
-template <>
-__device__ __forceinline__ double lane_before_in_row<double>(double v)
-{
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x111, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x111, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-template <>
-__device__ __forceinline__ float lane_before_in_row<float>(float v)
-{
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x111, 0xf, 0xf, true));
-}
 // (The band form of round 5 -- k_trsv_band: ONE workgroup walking the levels of a deep, narrow dependency graph behind workgroup
 //  barriers, the last 16 384 values in an LDS window, the row data requested a round ahead by hand-counted loads -- stood here:
 //  46 ms per triangle on the RCM-numbered shell against 95 ms of the level-scheduled rows, bound by the load path of its one CU.
@@ -700,22 +632,6 @@ __global__ __launch_bounds__(kBlock) void k_max_row_len(int n, const int* __rest
 }
 
 // ---------------------------------------------------------------- plans
-// sync-free grouped form (k_trsv_sf, further down): the plan arrays beyond order / pos / diag / w
-struct SfPlan
-{
-    int   nunits = 0, lpr = 0, maxm = 1, wout = 0, ngroups = 0, nglev = 0;
-    int*  uinfo  = nullptr; // [4 nunits] {first position, rows | entries per lane << 8, first 64-entry plane, last dependency}
-    int*  punit  = nullptr; // [n] unit of a position
-    int*  ufar   = nullptr; // [nunits] a position a few levels back of the unit's dependencies (k_sf_far)
-    int*  pinfo  = nullptr; // [n] per position: row number inside its group | rows of the group << 4
-    int*  ecol   = nullptr; // [64 nplanes] positions the out-of-group entries refer to (-1: no entry)
-    void* eval   = nullptr; // [64 nplanes]
-    void* gcoef  = nullptr; // [8 n] in-group coefficients of a position (groups of more than one row)
-    bool  infirst = false;  // the in-group entries come first in the order of the host loop (upper solve)
-    int64_t nplanes = 0;
-};
-static void sf_release(SfPlan** sp);
-
 struct TriPlan
 {
     int   n         = 0;
@@ -1237,7 +1153,7 @@ __global__ __launch_bounds__(kBlock) void k_ct_chain_start(int n, const int* __r
 // ONE step of the solve: the step sums the out-of-group entries of all its rows at once and finishes the in-group ones in
 // rounds through lane permutes (k_trsv_rec, grouped form) -- the same subtractions in the same order as the host loop.
 // brk[t] = 1: sweep row t does not continue the supernode of row t-1.
-constexpr int kGrpMax = 8, kGrpLPR = 4, kGrpWL = 6;
+constexpr int kGrpLPR = 4, kGrpWL = 6; // (kGrpMax: trsv_syncfree.hpp)
 template <bool LOWER>
 __global__ __launch_bounds__(kBlock) void k_ct_sn_breaks(int n, const int* __restrict__ rp, const int* __restrict__ ci,
                                                          int* __restrict__ brk)
@@ -4162,51 +4078,8 @@ static int ct_build_pair_lists(TriPlan* P, const int* key, int** pairs_out, int 
     return done(RAMD_OK);
 }
 
-// ======================================================================= sync-free grouped triangular solve (round 5)
-// For triangles the tiles cannot take -- no chains of consecutively numbered dependent rows for their coordinates to grow along:
-// a shell mesh (5 unknowns per node, ~35 entries per row) numbered by reverse Cuthill-McKee or by an advancing front has ~10 700
-// row levels of ~140 rows.  The level-scheduled kernel pays ~9 us per level there (one lane per row: the row's entries come in
-// dependent chunks of eight, each behind a poll), the band form that stood here for a while ~4 us (one CU's load path).  What
-// such a graph needs per level is ONE hand-off and nothing else on the critical path:
-//   * the unit of work is a ROW GROUP (k_ct_sn_breaks: the rows of one mesh node -- row t depends on row t-1 and shares every
-//     other dependency with it): 2 140 group levels instead of 10 700; the in-group part of a step runs in registers, in the
-//     order of the host loop (lower solve: the in-group entries are the LAST of a row, upper solve: the FIRST);
-//   * LPR = 4 or 8 lanes share a row, kw <= 6 out-of-group entries each; a wave holds 64 / LPR rows = whole groups of ONE group
-//     level (a "unit"); positions are sorted by (group level, group, row), units are contiguous pieces of them;
-//   * persistent waves take the units by ticket (k_trsv_sf): a wave is many levels ahead of the front when it starts on a unit,
-//     so the unit's coefficients, right-hand side and diagonal are in registers long before its dependencies are -- no
-//     look-ahead machinery, the other waves ARE the look-ahead;
-//   * it waits with ONE load per turn on a position two levels back, then asks for every value once and after that only for
-//     the values still missing (data-tagged granules, as k_trsv): the waves ahead of the front cost the memory system one
-//     request per turn each, and the turn that finds the last value is the only trip through memory on the critical path;
-//   * the out-of-group entries are subtracted one after the other through the row's lanes (DPP hand-over; upper solve: in the
-//     row's first lane, into which the products are pulled once), the in-group ones in rounds through lane broadcasts; one
-//     publication per row.
-// The operations per row are those of host_matrix_csr.cpp:1163-1221 (LUSolve), :1294-1341 (LLSolve), :1357-1466 (LSolve / USolve)
-// in their order: bit-exact (forced over the parity suite, tests/test_gpu_syncfree.py).  Measured on the RCM-numbered config-3
-// class (2 140 levels): 1.1 us per hand-off + 0.45 us (lower) / 1.1 us (upper) of arithmetic per level = 3.4 / 4.7 ms per
-// triangle (band form 46 ms, level-scheduled rows 95 ms); wide graphs of long rows run at their stream rate (random numbering:
-// 0.56 / 0.69 ms against 1.17 / 3.1 ms).
-constexpr int kSfKW = 6, kSfStreams = 8;
-
-static void sf_release(SfPlan** sp)
-{
-    SfPlan* q = *sp;
-    if(!q)
-        return;
-    dev_free(&q->uinfo);
-    dev_free(&q->ufar);
-    dev_free(&q->punit);
-    dev_free(&q->pinfo);
-    dev_free(&q->ecol);
-    if(q->eval)
-        (void)cached_free(q->eval);
-    if(q->gcoef)
-        (void)cached_free(q->gcoef);
-    delete q;
-    *sp = nullptr;
-}
-
+// (the sync-free grouped triangular solve -- k_trsv_sf, its plan fill and its launch -- lives in trsv_syncfree.hip; the analysis
+//  that decides for it and lays out its positions and units is build_sf_plan below)
 // order[p] = row of position p, plev[p] = its group level, pinfo[p] = row number inside the group | rows of the group << 4 |
 // out-of-group entries << 8   (sorted[p] = sweep index of position p)
 template <bool LOWER>
@@ -4231,450 +4104,6 @@ __global__ __launch_bounds__(kBlock) void k_sf_positions(int n, const int* __res
         order[p] = i;
         plev[p]  = key[t];
         pinfo[p] = (t - gf[t]) | ((gl[t] - gf[t] + 1) << 4) | (c << 8);
-    }
-}
-
-// one wave per unit: the out-of-group entries of its rows into the unit's planes (entry e of a row -> lane e / kw of the row,
-// plane e % kw), the in-group coefficients and the diagonal per position, the unit's last dependency
-template <typename T, bool LOWER, int LPR>
-__global__ __launch_bounds__(64) void k_sf_fill(int n, int nunits, int* __restrict__ uinfo, const int* __restrict__ pinfo,
-                                                const int* __restrict__ order, const int* __restrict__ pos,
-                                                const int* __restrict__ rp, const int* __restrict__ ci, const T* __restrict__ val,
-                                                int* __restrict__ ecol, T* __restrict__ eval, T* __restrict__ gcoef,
-                                                T* __restrict__ diag, int* __restrict__ nodiag, int* __restrict__ punit, int reverse)
-{
-    const int u = blockIdx.x;
-    if(u >= nunits)
-        return;
-    const int     lane = threadIdx.x, slot = lane / LPR, l = lane % LPR;
-    const int     p0 = uinfo[4 * u], cnt = uinfo[4 * u + 1] & 255, kw = (uinfo[4 * u + 1] >> 8) & 15;
-    const int64_t e0 = (int64_t)uinfo[4 * u + 2] * 64 + lane;
-    const bool    have = slot < cnt;
-    int           maxdep = -1;
-    int           k      = 0; // planes of this lane filled so far
-    if(have)
-    {
-        const int p = p0 + slot, i = order[p];
-        const int r = pinfo[p] & 15;
-        if(l == 0)
-            punit[p] = u;
-        // (sweep index of the group's first row: rows of a group are consecutive positions AND consecutive sweep rows)
-        const int t = LOWER ? i : n - 1 - i, tf = t - r;
-        int       e = 0;
-        bool      dg = false;
-        const int rs = rp[i], re = rp[i + 1];
-        for(int q = rs; q < re; ++q)
-        {
-            const int j   = reverse ? re - 1 - (q - rs) : q; // (reverse: the entries in descending storage order)
-            const int col = ci[j];
-            if(col == i)
-            {
-                if(l == 0)
-                    diag[p] = val[j];
-                dg = true;
-                continue;
-            }
-            if(!(LOWER ? (col < i) : (col > i)))
-                continue;
-            const int tc = LOWER ? col : n - 1 - col;
-            if(tc >= tf)
-            {
-                if(l == 0 && gcoef)
-                    gcoef[(int64_t)p * 8 + (tc - tf)] = val[j];
-                continue;
-            }
-            if(e / kw == l)
-            {
-                const int pc = pos[col];
-                ecol[e0 + (int64_t)k * 64] = pc;
-                eval[e0 + (int64_t)k * 64] = val[j];
-                maxdep                     = max(maxdep, pc);
-                ++k;
-            }
-            ++e;
-        }
-        if(!dg && l == 0)
-        {
-            diag[p] = (T)1;
-            *nodiag = 1;
-        }
-    }
-    for(; k < kw; ++k)
-    {
-        ecol[e0 + (int64_t)k * 64] = -1;
-        eval[e0 + (int64_t)k * 64] = (T)0;
-    }
-#pragma unroll
-    for(int off = 32; off > 0; off >>= 1)
-        maxdep = max(maxdep, __shfl_xor(maxdep, off, 64));
-    if(lane == 0)
-        uinfo[4 * u + 3] = maxdep;
-}
-
-// ufar[u]: the last dependency of the unit that holds the last dependency of ... (depth times) of unit u, -1: none that far back
-__global__ __launch_bounds__(kBlock) void k_sf_far(int nunits, int depth, const int* __restrict__ uinfo, const int* __restrict__ punit,
-                                                   int* __restrict__ ufar)
-{
-    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
-    for(int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < nunits; u += gsz)
-    {
-        int q = uinfo[4 * u + 3];
-        for(int d = 0; d < depth && q >= 0; ++d)
-            q = uinfo[4 * punit[q] + 3];
-        ufar[u] = q;
-    }
-}
-
-template <typename T, int LPR, int NA>
-__device__ __forceinline__ T sf_chain(T s, const T (&prod)[kSfKW], int l, int nl)
-{
-    // the out-of-group entries of a row, one after the other through its lanes: lane 0 starts from s, lane k + 1 continues lane
-    // k's sum; nl (uniform) = lanes per row in use in this unit: the result is in lane nl - 1 of the row.  A slot without an entry
-    // holds the product (+0)(+0) = +0, and s - (+0) is s bit for bit for every s (-0 included): no test per entry, NA (4 or 6)
-    // subtractions per lane in a straight line.  Every lane computes, the lane whose turn it is keeps: one wave runs a unit, and
-    // a taken branch costs it more than the arithmetic it would skip (measured: 44 cycles per entry with a test per entry).
-#pragma unroll
-    for(int step = 0; step < LPR; ++step)
-    {
-        if(step >= nl)
-            break;
-        T t = step > 0 ? lane_before_in_row<T>(s) : s;
-#pragma unroll
-        for(int k = 0; k < NA; ++k)
-            t -= prod[k];
-        s = (l == step) ? t : s;
-    }
-    return s;
-}
-
-// value of lane `src` (uniform) in every lane
-__device__ __forceinline__ double sf_from_lane(double v, int src)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ float sf_from_lane(float v, int src)
-{
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
-}
-
-// value of lane + Q of the same 16-lane row (Q compile-time)
-template <int Q>
-__device__ __forceinline__ double sf_from_lane_after(double v)
-{
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x100 + Q, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x100 + Q, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-template <int Q>
-__device__ __forceinline__ float sf_from_lane_after(float v)
-{
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x100 + Q, 0xf, 0xf, true));
-}
-// all[q][k] = product k of lane + q, for q = Q .. nl - 1 (nl uniform)
-template <typename T, int LPR, int NA, int Q>
-__device__ __forceinline__ void sf_pull(T (&all)[LPR][NA], const T (&prod)[kSfKW], int nl)
-{
-    if constexpr(Q < LPR)
-    {
-        if(Q < nl)
-        {
-#pragma unroll
-            for(int k = 0; k < NA; ++k)
-                all[Q][k] = sf_from_lane_after<Q>(prod[k]);
-        }
-        else
-        {
-#pragma unroll
-            for(int k = 0; k < NA; ++k)
-                all[Q][k] = (T)0;
-        }
-        sf_pull<T, LPR, NA, Q + 1>(all, prod, nl);
-    }
-}
-
-// the arithmetic of a unit once its dependencies are there: result of the row in lane nl - 1 of the row (lower) / lane 0 (upper).  NA: subtractions per
-// lane of the chain; ONE: the unit holds one group (the lane a finished row is taken from is uniform: v_readlane, else ds_bpermute);
-// maxm (uniform): rows of the unit's longest group
-template <typename T, int DMODE, bool INFIRST, int LPR, int NA, bool ONE>
-__device__ __forceinline__ T sf_compute(T rhs, T dg, const T (&gc)[7], const T (&prod)[kSfKW], int r, int l, int slot, int nl, int maxm)
-{
-    const int gl0 = (slot - r) * LPR + nl - 1; // where the group's first row ends its chain
-    if(!INFIRST)
-    {
-        T sum = sf_chain<T, LPR, NA>(rhs, prod, l, nl);
-        // in-group entries (the last ones of a row): row j of a group is final once the rows before it have been taken out of it
-#pragma unroll
-        for(int j = 0; j < kGrpMax; ++j)
-        {
-            if(j >= maxm)
-                break;
-            if(DMODE != 0)
-            {
-                const T q = DMODE == 1 ? sum / dg : sum * dg;
-                sum       = (r == j) ? q : sum;
-            }
-            if(j < 7 && j + 1 < maxm)
-            {
-                const T yj = ONE ? sf_from_lane(sum, j * LPR + nl - 1) : __shfl(sum, gl0 + j * LPR, 64);
-                const T t  = sum - gc[j] * yj;
-                sum        = (r > j) ? t : sum;
-            }
-        }
-        return sum;
-    }
-    // in-group entries first: the rows of a group one after the other (nearest row first), each with its chain and its division.
-    // Five chains per node instead of one: the products of a row's other lanes are first brought into its lane 0 (DPP row shifts,
-    // once per unit), so that a round's chain is a straight line of subtractions in one lane -- no hand-over per lane and round.
-    // The result of a row is in its lane 0.
-    T all[LPR][NA];
-#pragma unroll
-    for(int k = 0; k < NA; ++k)
-        all[0][k] = prod[k];
-    sf_pull<T, LPR, NA, 1>(all, prod, nl);
-    const int g0 = (slot - r) * LPR; // lane 0 of the group's first row
-    T y[7];
-#pragma unroll
-    for(int j = 0; j < 7; ++j)
-        y[j] = (T)0;
-    T res = (T)0;
-#pragma unroll
-    for(int j = 0; j < kGrpMax; ++j)
-    {
-        if(j >= maxm)
-            break;
-        T s = rhs;
-#pragma unroll
-        for(int i = 6; i >= 0; --i)
-            if(i < j)
-                s -= gc[i] * y[i];
-#pragma unroll
-        for(int q = 0; q < LPR; ++q)
-        {
-            if(q >= nl)
-                break;
-#pragma unroll
-            for(int k = 0; k < NA; ++k)
-                s -= all[q][k];
-        }
-        if(DMODE == 1)
-            s /= dg;
-        else if(DMODE == 2)
-            s = s * dg;
-        res = (r == j) ? s : res;
-        if(j < 7 && j + 1 < maxm)
-            y[j] = ONE ? sf_from_lane(s, j * LPR) : __shfl(s, g0 + j * LPR, 64);
-    }
-    return res;
-}
-
-// (Tried and removed, round 5: the waves of ONE XCD only -- every wave registers with the XCD its XCC_ID names, the XCD with most
-//  waves goes on -- with values published by stores that keep their line in that XCD's L2 (workgroup scope, sc0) and polled by
-//  the same sc1 loads: bit-exact, and SLOWER -- 2.0 us from publication to "dependencies seen" against 1.5 us through memory with
-//  sc1 stores from all eight XCDs, LUSolve on the RCM shell 12.1 against 10.1 ms; gpurun_out/r05u.)
-template <typename T, int DMODE, bool INFIRST, int LPR>
-__global__ __launch_bounds__(64) void k_trsv_sf(int nunits, const v4i32* __restrict__ uinfo, const int* __restrict__ pinfo,
-                                                const int* __restrict__ ecol, const T* __restrict__ eval,
-                                                const T* __restrict__ gcoef, const T* __restrict__ diag,
-                                                const T* __restrict__ rhs_src, const int* __restrict__ rhs_idx, T* w,
-                                                T* __restrict__ out, const int* __restrict__ order, int poll_cap, int gather_only,
-                                                const int* __restrict__ ufar, unsigned long long* __restrict__ dbg, unsigned* tickets)
-{
-    // Units are taken by TICKET, so that a wave only ever waits for units held by waves that are running -- whatever share of the
-    // device this launch gets (a static round-robin over the grid would wait for waves that may never become resident next to
-    // another process's kernel).  One counter word serves ~88 tickets per microsecond and this solve wants ~75: kSfStreams words (own
-    // 128-byte lines), unit u belongs to stream u % kSfStreams, a wave is bound to the stream its START ticket names (the first
-    // kSfStreams waves to run cover every stream) and asks for its next unit while it works on this one.
-    // (dbg: RAMD_TRSV_SF_DBG, two timestamps per unit -- dependencies there, result published)
-    // gather_only (RAMD_TRSV_SF_GATHER) 4, the default: one word per turn for a position `ufar[u]` two levels back, then every
-    // value once and after that only the lanes still without theirs (3.8 / 5.2 ms on the RCM shell when it was measured against the
-    // others); 3: one word per turn for the unit's LAST dependency, then one gather of everything (4.1 / 5.5 ms: two trips through
-    // memory per level); 0: the far word, then a gather of everything every turn (equal to 3: what a gathering wave asks of the
-    // memory system per turn costs what the second trip did); 1: gathers from the start (5.4 / 7.6 ms: 2048 waves x 4 gathers a
-    // turn); 2: no waits (diagnostic, wrong results: 0.5 / 0.8 ms, the stream time)
-    using B = typename Sentinel<T>::bits;
-    const int lane = threadIdx.x, slot = lane / LPR, l = lane % LPR;
-    if(dbg && blockIdx.x == 0 && lane == 0) // (shader clock against the 100 MHz counter: what a cycle is worth in this kernel)
-    {
-        dbg[2 * (int64_t)nunits]     = clock64();
-        dbg[2 * (int64_t)nunits + 1] = wall_clock64();
-    }
-    unsigned start = 0;
-    if(lane == 0)
-        start = __hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int stream = (int)((unsigned)__builtin_amdgcn_readfirstlane((int)start) % (unsigned)kSfStreams);
-    unsigned* const my_counter = tickets + 32 * (1 + stream);
-    unsigned  tk = 0;
-    if(lane == 0)
-        tk = __hip_atomic_fetch_add(my_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for(;;)
-    {
-        const long long uu = (long long)stream + (long long)kSfStreams * (unsigned)__builtin_amdgcn_readfirstlane((int)tk);
-        if(uu >= nunits)
-            break;
-        const int u = (int)uu;
-        if(lane == 0) // (the next unit: asked for now, looked at when this one is done)
-            tk = __hip_atomic_fetch_add(my_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const v4i32 ui  = uinfo[u];
-        const int   p0  = __builtin_amdgcn_readfirstlane(ui.x);
-        const int   cnt = __builtin_amdgcn_readfirstlane(ui.y) & 255, kw = (__builtin_amdgcn_readfirstlane(ui.y) >> 8) & 15;
-        const int   ld  = __builtin_amdgcn_readfirstlane(ui.w);
-        const bool  have = slot < cnt;
-        const int   p    = p0 + (have ? slot : 0);
-        int         c[kSfKW];
-        T           a[kSfKW];
-        const int64_t e0 = (int64_t)__builtin_amdgcn_readfirstlane(ui.z) * 64 + lane;
-#pragma unroll
-        for(int k = 0; k < kSfKW; ++k)
-        {
-            c[k] = -1;
-            a[k] = (T)0;
-            if(k < kw)
-            {
-                c[k] = nt_load(ecol + e0 + (int64_t)k * 64);
-                a[k] = nt_load(eval + e0 + (int64_t)k * 64);
-            }
-        }
-        const int info = pinfo[p];
-        const int r    = have ? (info & 15) : 0;
-        const int m    = have ? ((info >> 4) & 15) : 0;
-        const T   rhs  = rhs_src[rhs_idx[p]];
-        const T   dg   = (DMODE == 0) ? (T)1 : diag[p];
-        const int onat = out ? order[p] : 0;
-        const bool grouped = __ballot(m > 1) != 0ull;
-        T          gc[7];
-#pragma unroll
-        for(int j = 0; j < 7; ++j)
-            gc[j] = (T)0;
-        if(grouped)
-        {
-#pragma unroll
-            for(int j = 0; j < 7; ++j)
-                gc[j] = gcoef[(int64_t)p * 8 + j];
-        }
-        // one request per turn while the front is levels away
-        const int far = gather_only == 3 ? ld : ((gather_only == 0 || gather_only == 4) ? __builtin_amdgcn_readfirstlane(ufar[u]) : -1);
-        if(far >= 0)
-        {
-            int spins = 0, backoff = 1;
-            while(poll_load(w + far) == Sentinel<T>::value)
-            {
-                spin_guard(spins);
-                backoff = poll_backoff(false, backoff, poll_cap);
-            }
-        }
-        B x[kSfKW];
-        if(gather_only == 4)
-        {
-            // every value is requested once; after that only the lanes whose value was not there yet ask again: the turns of a
-            // unit close to the front are a handful of requests, and the turn that finds the last value is the only trip through
-            // memory on the critical path
-#pragma unroll
-            for(int k = 0; k < kSfKW; ++k)
-                x[k] = c[k] >= 0 ? Sentinel<T>::value : (B)0;
-            int spins = 0;
-            while(true)
-            {
-                spin_guard(spins);
-                bool all = true;
-#pragma unroll
-                for(int k = 0; k < kSfKW; ++k)
-                    if(x[k] == Sentinel<T>::value)
-                    {
-                        x[k] = poll_load(w + c[k]);
-                        all  = all && (x[k] != Sentinel<T>::value);
-                    }
-                if(__ballot(!all) == 0ull)
-                    break;
-                __builtin_amdgcn_s_sleep(1);
-            }
-        }
-        else
-        {
-            int  spins = 0, backoff = 1;
-            bool all;
-            while(true)
-            {
-                spin_guard(spins);
-                all = true;
-#pragma unroll
-                for(int k = 0; k < kSfKW; ++k)
-                {
-                    x[k] = 0;
-                    if(c[k] >= 0)
-                    {
-                        x[k] = poll_load(w + c[k]);
-                        all  = all && (x[k] != Sentinel<T>::value);
-                    }
-                }
-                if(__ballot(!all) == 0ull || gather_only == 2) // (2: diagnostic, no dependency waits -- wrong results, timing only)
-                    break;
-                if(gather_only != 3)
-                    backoff = poll_backoff(false, backoff, 2);
-            }
-        }
-        unsigned long long d_w0 = 0, d_c0 = 0, d_c1 = 0, d_c2 = 0;
-        if(dbg)
-        {
-            d_w0 = wall_clock64();
-            d_c0 = d_c1 = clock64();
-        }
-        T prod[kSfKW];
-#pragma unroll
-        for(int k = 0; k < kSfKW; ++k)
-            prod[k] = a[k] * Sentinel<T>::from_bits(x[k]);
-        // lanes per row in use in this unit (a row's entries fill its lanes from lane 0 on), one group only: from the unit record
-        const int  nl   = (__builtin_amdgcn_readfirstlane(ui.y) >> 12) & 15;
-        const bool one  = ((__builtin_amdgcn_readfirstlane(ui.y) >> 16) & 1) != 0;
-        const int  maxm = (__builtin_amdgcn_readfirstlane(ui.y) >> 17) & 15;
-        T          res;
-        // (straight-line bodies for 2 / 3 / 4 / 6 subtractions per lane, one group or several: chosen per unit)
-#define SF_BODY(NA_)                                                                                             \
-    do                                                                                                           \
-    {                                                                                                            \
-        if(one)                                                                                                  \
-            res = sf_compute<T, DMODE, INFIRST, LPR, NA_, true>(rhs, dg, gc, prod, r, l, slot, nl, maxm);        \
-        else                                                                                                     \
-            res = sf_compute<T, DMODE, INFIRST, LPR, NA_, false>(rhs, dg, gc, prod, r, l, slot, nl, maxm);       \
-    } while(0)
-        if(kw <= 2)
-            SF_BODY(2);
-        else if(kw == 3)
-            SF_BODY(3);
-        else if(kw == 4)
-            SF_BODY(4);
-        else
-            SF_BODY(kSfKW);
-#undef SF_BODY
-        if(dbg)
-        {
-            asm volatile("" : "+v"(res));
-            d_c2 = clock64();
-        }
-        if(have && l == (INFIRST ? 0 : nl - 1))
-        {
-            publish(w + p, res);
-            if(out)
-                out[onat] = res;
-        }
-        if(dbg)
-        {
-            const unsigned long long w1 = wall_clock64(), c3 = clock64();
-            if(lane == 0)
-            {
-                dbg[2 * (int64_t)u]     = d_w0;
-                dbg[2 * (int64_t)u + 1] = w1;
-                // cycles: dependencies seen -> chain done | -> result final | -> publication issued
-                dbg[2 * (int64_t)nunits + 4 + 2 * (int64_t)u]     = ((INFIRST ? 0ull : (d_c1 - d_c0)) & 0xffffffffull) | ((d_c2 - d_c0) << 32);
-                dbg[2 * (int64_t)nunits + 4 + 2 * (int64_t)u + 1] = c3 - d_c0;
-            }
-        }
-    }
-    if(dbg && blockIdx.x == 0 && lane == 0)
-    {
-        dbg[2 * (int64_t)nunits + 2] = clock64();
-        dbg[2 * (int64_t)nunits + 3] = wall_clock64();
     }
 }
 
@@ -4841,7 +4270,7 @@ static int build_sf_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     SF_HIP(hipMemcpyAsync(h_info.data(), S->pinfo, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, b.cur));
     SF_HIP(hipStreamSynchronize(b.cur));
     h_u.reserve((size_t)ngroups * 4 / (rpw / maxm > 0 ? rpw / maxm : 1) + 16);
-    int64_t nplanes = 0;
+    int64_t nentries = 0;
     for(int p = 0; p < n;)
     {
         const int lev = h_lev[p], first = p;
@@ -4876,7 +4305,8 @@ static int build_sf_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
         // few planes to fetch and few requests per polling turn, but more lanes in the chain of subtractions -- measured on the
         // RCM shell, lower / upper ms per triangle: 2 per lane 3.46 / 5.12, 3: 3.71 / 5.19, 4: 4.05 / 5.34, 6: 4.4 / 5.7)
         const int kw = std::max(std::min(std::max(wmax, 1), sf_kw_min), (wmax + lpr - 1) / lpr);
-        if(nplanes + kw > (int64_t)0x7fffffff / 64)
+        const int nlanes = std::max(1, (wmax + kw - 1) / kw); // lanes per row in use
+        if(nentries + sf_unit_slots(rows, kw, nlanes) > (int64_t)0x7fffffff)
         {
             cleanup();
             sf_release(&S);
@@ -4884,18 +4314,19 @@ static int build_sf_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
             return RAMD_ERR_UNSUPPORTED;
         }
         h_u.push_back(first);
-        const int nlanes = std::max(1, (wmax + kw - 1) / kw); // lanes per row in use
         h_u.push_back(rows | (kw << 8) | (nlanes << 12) | ((ngr == 1 ? 1 : 0) << 16) | (gmax << 17));
-        h_u.push_back((int)nplanes);
+        h_u.push_back((int)nentries);
         h_u.push_back(-1);
-        nplanes += kw;
+        nentries += sf_unit_slots(rows, kw, nlanes); // (only the lanes that hold entries are stored: round 5 kept 64 per plane)
     }
-    S->nunits  = (int)(h_u.size() / 4);
-    S->nplanes = nplanes;
+    S->nunits   = (int)(h_u.size() / 4);
+    S->nentries = nentries;
     SF_TRY(dev_alloc(&S->uinfo, (int64_t)h_u.size()));
     SF_HIP(hipMemcpyAsync(S->uinfo, h_u.data(), sizeof(int) * h_u.size(), hipMemcpyHostToDevice, b.cur));
-    SF_TRY(dev_alloc(&S->ecol, nplanes * 64));
-    SF_HIP(cached_malloc(&S->eval, (size_t)nplanes * 64 * sizeof(T) + kPad));
+    SF_TRY(dev_alloc(&S->ecol, nentries + 64));
+    SF_HIP(cached_malloc(&S->eval, (size_t)(nentries + 64) * sizeof(T) + kPad));
+    if(sizeof(T) == 8)
+        SF_HIP(cached_malloc(&S->rdiag, (size_t)n * sizeof(T) + kPad));
     if(maxm > 1)
     {
         SF_HIP(cached_malloc(&S->gcoef, (size_t)n * 8 * sizeof(T) + kPad));
@@ -4903,33 +4334,12 @@ static int build_sf_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
     }
     SF_HIP(cached_malloc(&P->diag, (size_t)n * sizeof(T) + kPad));
     SF_HIP(cached_malloc(&P->w, (size_t)n * sizeof(T) + kPad));
-    SF_TRY(dev_alloc(&nodiag, 1));
-    SF_HIP(hipMemsetAsync(nodiag, 0, sizeof(int), b.cur));
     SF_TRY(dev_alloc(&S->punit, n));
     punit = S->punit;
     SF_TRY(dev_alloc(&S->ufar, S->nunits));
-#define SF_FILL(LO, LP)                                                                                                       \
-    hipLaunchKernelGGL((k_sf_fill<T, LO, LP>), dim3(S->nunits), dim3(64), 0, b.cur, n, S->nunits, S->uinfo, S->pinfo, P->order, \
-                       P->pos, m->rp, m->ci, (const T*)m->val, S->ecol, (T*)S->eval, (T*)S->gcoef, (T*)P->diag, nodiag, punit,   \
-                       reverse ? 1 : 0)
-    if(lower && lpr == 4)
-        SF_FILL(true, 4);
-    else if(lower)
-        SF_FILL(true, 8);
-    else if(lpr == 4)
-        SF_FILL(false, 4);
-    else
-        SF_FILL(false, 8);
-#undef SF_FILL
-    {
-        static const int far_depth = getenv("RAMD_TRSV_SF_FAR") ? atoi(getenv("RAMD_TRSV_SF_FAR")) : 1;
-        hipLaunchKernelGGL(k_sf_far, dim3(ew_grid(S->nunits)), dim3(kBlock), 0, b.cur, S->nunits, far_depth, S->uinfo, punit, S->ufar);
-    }
-    int nd = 0;
-    SF_HIP(hipMemcpyAsync(&nd, nodiag, sizeof(int), hipMemcpyDeviceToHost, b.cur));
-    SF_HIP(hipStreamSynchronize(b.cur));
-    SF_HIP(hipGetLastError());
-    P->nodiag  = nd != 0;
+    bool nd = false;
+    SF_TRY(sf_fill<T>(S, n, lower, reverse, P->order, P->pos, m->rp, m->ci, (const T*)m->val, (T*)P->diag, &nd));
+    P->nodiag  = nd;
     P->nlevels = nglev;
     P->sf      = S;
     S          = nullptr;
@@ -4939,109 +4349,12 @@ static int build_sf_plan(ramd_mat_s* m, TriState* st, TriPlan* P, bool lower, bo
                 "sync-free grouped plan (%s): n=%d, %d row groups of <= %d rows, %d group levels (%.0f rows per level), longest "
                 "out-of-group part %d -> %d lanes per row, %d units, %.1f MB of planes\n",
                 lower ? "lower" : "upper", n, ngroups, maxm, nglev, (double)n / nglev, wout, lpr, P->sf->nunits,
-                (double)nplanes * 64 * (4 + sizeof(T)) / 1e6);
+                (double)nentries * (4 + sizeof(T)) / 1e6);
     cleanup();
     return RAMD_OK;
 #undef SF_GIVE_UP
 #undef SF_HIP
 #undef SF_TRY
-}
-
-template <typename T>
-static int run_sf_plan(TriPlan* P, int dm, const T* rhs_src, const int* rhs_idx, T* out)
-{
-    Backend&      b = backend();
-    const SfPlan* S = P->sf;
-    hipLaunchKernelGGL((k_fill_sentinel<T>), dim3(ew_grid(P->n)), dim3(kBlock), 0, b.cur, (int64_t)P->n, (T*)P->w);
-    // persistent waves, as many as the device holds (units by ticket: see k_trsv_sf)
-    static const int waves_env = getenv("RAMD_TRSV_SF_WAVES") ? atoi(getenv("RAMD_TRSV_SF_WAVES")) : 0; // (per CU; experiments)
-    static const int cap_env   = getenv("RAMD_TRSV_SF_POLLCAP") ? atoi(getenv("RAMD_TRSV_SF_POLLCAP")) : 8;
-    static const int gat_env   = getenv("RAMD_TRSV_SF_GATHER") ? atoi(getenv("RAMD_TRSV_SF_GATHER")) : 4; // (see k_trsv_sf)
-    // ticket words of the launch: [0] start tickets, [32 (1 + s)] units of stream s -- zeroed before every launch
-    static unsigned* tickets = nullptr;
-    if(!tickets)
-        RAMD_HIP(hipMalloc(&tickets, sizeof(unsigned) * 32 * (1 + kSfStreams)));
-    RAMD_HIP(hipMemsetAsync(tickets, 0, sizeof(unsigned) * 32 * (1 + kSfStreams), b.cur));
-    unsigned nwg = 0;
-    // RAMD_TRSV_SF_DBG=<file prefix> (tools/ diagnostics): two timestamps per unit, dumped after every solve with the unit table
-    static const char*  dbg_path = getenv("RAMD_TRSV_SF_DBG");
-    unsigned long long* dbg      = nullptr;
-    if(dbg_path)
-    {
-        RAMD_HIP(hipMalloc(&dbg, sizeof(unsigned long long) * (4 * (size_t)S->nunits + 4)));
-        RAMD_HIP(hipMemsetAsync(dbg, 0, sizeof(unsigned long long) * (4 * (size_t)S->nunits + 4), b.cur));
-    }
-#define TRSV_SF(DM, INF, LP)                                                                                                  \
-    do                                                                                                                        \
-    {                                                                                                                         \
-        static int occ_max = 0;                                                                                               \
-        if(occ_max == 0)                                                                                                      \
-        {                                                                                                                     \
-            int nb_cu = 0;                                                                                                    \
-            RAMD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_cu, k_trsv_sf<T, DM, INF, LP>, 64, 0));                \
-            occ_max = nb_cu < 1 ? 1 : (nb_cu - 2 > 8 ? 8 : (nb_cu > 2 ? nb_cu - 2 : 1));                                      \
-        }                                                                                                                     \
-        /* waves per CU: a narrow graph is bound by its chain of hand-offs and runs best with few waves around it (1 / 2 / 4 / */ \
-        /* 6 / 8 per CU on the RCM shell: 5.3 / 4.3 / 4.4 / 4.4 / 4.5 ms per triangle), a wide one by its throughput (the     */ \
-        /* random numbering, 16 700 units per level: 1.10 ms with 4 per CU, 0.67 with 8)                                      */ \
-        int occ = ((int64_t)S->nunits >= (int64_t)1024 * S->nglev) ? occ_max : (occ_max < 4 ? occ_max : 4);                   \
-        if(waves_env > 0 && waves_env < occ_max)                                                                              \
-            occ = waves_env;                                                                                                  \
-        const int64_t cap = (int64_t)occ * b.num_cu;                                                                          \
-        nwg               = (unsigned)(S->nunits < cap ? S->nunits : cap);                                                    \
-        hipLaunchKernelGGL((k_trsv_sf<T, DM, INF, LP>), dim3(nwg), dim3(64), 0, b.cur, S->nunits, (const v4i32*)S->uinfo,     \
-                           S->pinfo, S->ecol, (const T*)S->eval, (const T*)S->gcoef, (const T*)P->diag, rhs_src, rhs_idx,      \
-                           (T*)P->w, out, P->order, cap_env, gat_env, S->ufar, dbg, tickets);                                 \
-    } while(0)
-#define TRSV_SF_L(DM, INF)      \
-    do                          \
-    {                           \
-        if(S->lpr == 4)         \
-            TRSV_SF(DM, INF, 4); \
-        else                    \
-            TRSV_SF(DM, INF, 8); \
-    } while(0)
-#define TRSV_SF_I(DM)              \
-    do                             \
-    {                              \
-        if(S->infirst)             \
-            TRSV_SF_L(DM, true);   \
-        else                       \
-            TRSV_SF_L(DM, false);  \
-    } while(0)
-    prof_begin(RAMD_PROF_TRSV, b.cur);
-    if(dm == 0)
-        TRSV_SF_I(0);
-    else if(dm == 1)
-        TRSV_SF_I(1);
-    else
-        TRSV_SF_I(2);
-    prof_end(RAMD_PROF_TRSV, b.cur);
-#undef TRSV_SF_I
-#undef TRSV_SF_L
-#undef TRSV_SF
-    RAMD_HIP(hipGetLastError());
-    if(dbg)
-    {
-        std::vector<unsigned long long> ht(4 * (size_t)S->nunits + 4);
-        std::vector<int>                hu(4 * (size_t)S->nunits), hp((size_t)P->n);
-        RAMD_HIP(hipMemcpy(ht.data(), dbg, sizeof(unsigned long long) * ht.size(), hipMemcpyDeviceToHost));
-        RAMD_HIP(hipMemcpy(hu.data(), S->uinfo, sizeof(int) * hu.size(), hipMemcpyDeviceToHost));
-        RAMD_HIP(hipMemcpy(hp.data(), S->punit, sizeof(int) * hp.size(), hipMemcpyDeviceToHost));
-        (void)hipFree(dbg);
-        const std::string fn = std::string(dbg_path) + (S->infirst ? "_upper.bin" : "_lower.bin");
-        if(FILE* f = fopen(fn.c_str(), "wb"))
-        {
-            const int hdr[4] = {S->nunits, P->n, (int)nwg, S->lpr};
-            fwrite(hdr, sizeof(int), 4, f);
-            fwrite(ht.data(), sizeof(unsigned long long), 2 * (size_t)S->nunits, f);
-            fwrite(hu.data(), sizeof(int), hu.size(), f);
-            fwrite(hp.data(), sizeof(int), hp.size(), f);
-            fwrite(ht.data() + 2 * (size_t)S->nunits, sizeof(unsigned long long), 4 + 2 * (size_t)S->nunits, f);
-            fclose(f);
-        }
-    }
-    return RAMD_OK;
 }
 
 template <typename T>
@@ -5059,7 +4372,7 @@ static int run_plan(TriState* st, TriPlan* P, bool unit, const T* rhs_src, const
     if(P->sf)
     {
         P->w_sentinel = P->prefilled_next = false;
-        return run_sf_plan<T>(P, mul_inv_diag ? 2 : (unit ? 0 : 1), rhs_src, rhs_idx, out);
+        return sf_run<T>(P->sf, P->n, mul_inv_diag ? 2 : (unit ? 0 : 1), (const T*)P->diag, (T*)P->w, P->order, rhs_src, rhs_idx, out);
     }
     const unsigned nb = nblocks_of(P->n);
     static const bool nofill = getenv("RAMD_TRSV_NOFILL") != nullptr; // diagnostic only (tools/): no dependency waits
@@ -6644,7 +5957,7 @@ static void tri_note_stats(const ramd_mat_s* m, const TriPlan* P, int which)
         o[8] = P->sf->lpr;
         o[9] = P->sf->maxm;
         o[12] = P->st_why;
-        o[14] = (long long)(P->sf->nplanes * 64 * (4 + (long long)val_size(m->dtype)));
+        o[14] = (long long)(P->sf->nentries * (4 + (long long)val_size(m->dtype)));
         return;
     }
     o[12] = P->ct ? 0 : P->st_why;

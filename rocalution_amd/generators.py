@@ -35,6 +35,29 @@ def poisson7(N, dtype=np.float64):
     return rp.astype(np.int32), cols[mask].astype(np.int32), np.ascontiguousarray(vals[mask])
 
 
+def laplace27(nx, ny=None, nz=None, dtype=np.float64):
+    """the reference's own 3-D operator (clients/include/utility.hpp:110-177 ``gen_3d_laplacian``; cubes there): 27-point stencil,
+    row ``r = (z*ny + y)*nx + x``, 26 on the diagonal, -1 at every neighbour of the 3 x 3 x 3 box the lattice has, ascending
+    columns.  The device generator is LocalMatrix.GenLaplace27 (csrc/matrix.hip k_lap27_fill)."""
+    ny = nx if ny is None else ny
+    nz = nx if nz is None else nz
+    n = nx * ny * nz
+    r = np.arange(n, dtype=np.int64)
+    x, y, z = r % nx, (r // nx) % ny, r // (nx * ny)
+    cols, mask = [], []
+    for sz in (-1, 0, 1):
+        for sy in (-1, 0, 1):
+            for sx in (-1, 0, 1):
+                cols.append(r + (sz * ny + sy) * nx + sx)
+                mask.append((x + sx >= 0) & (x + sx < nx) & (y + sy >= 0) & (y + sy < ny) & (z + sz >= 0) & (z + sz < nz))
+    cols, mask = np.stack(cols, axis=1), np.stack(mask, axis=1)
+    vals = np.where(cols == r[:, None], 26.0, -1.0).astype(dtype)
+    rp = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(mask.sum(axis=1), out=rp[1:])
+    assert rp[-1] < 2**31
+    return rp.astype(np.int32), cols[mask].astype(np.int32), np.ascontiguousarray(vals[mask])
+
+
 def laplace2d(ndim, dtype=np.float64):
     n = ndim * ndim
     r = np.arange(n, dtype=np.int64)

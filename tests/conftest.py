@@ -26,3 +26,33 @@ def oracle():
     orc.build()
     orc.set_threads(1)
     return orc
+
+
+# ---------------------------------------------------------------- forced-form suites in fresh processes, several at a time
+# Many settings of the library are read once per process, so the tests that force a kernel form over the parity selection run
+# `pytest -k <selection>` in a subprocess each: 21 of them, ~9-20 s apiece and mostly interpreter start-up and tiny kernels.  They
+# are independent of each other and of the process that runs this suite, so a family of them is started together (at most
+# RAMD_TEST_JOBS at a time, default 5) the first time one of its members is asked for, and every parametrised test only waits
+# for its own member.  Nothing is skipped: each member still has to pass in full ("a suite that fits its budget").
+import concurrent.futures as _cf
+import subprocess as _sp
+
+_POOL = None
+_RUNS = {}
+
+
+def forced_run(family, key, jobs):
+    """jobs: {key: (cmd, env, timeout_s)} -- the whole family; returns (returncode, output) of `key`"""
+    global _POOL
+    if _POOL is None:
+        _POOL = _cf.ThreadPoolExecutor(max_workers=max(1, int(os.environ.get("RAMD_TEST_JOBS", "5"))))
+
+    def run(cmd, env, timeout):
+        p = _sp.run(cmd, cwd=ROOT, env=env, stdout=_sp.PIPE, stderr=_sp.STDOUT, text=True, timeout=timeout)
+        return p.returncode, p.stdout
+
+    if (family, key) not in _RUNS:
+        for k, (cmd, env, timeout) in jobs.items():
+            if (family, k) not in _RUNS:
+                _RUNS[(family, k)] = _POOL.submit(run, cmd, env, timeout)
+    return _RUNS[(family, key)].result()

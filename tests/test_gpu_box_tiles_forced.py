@@ -20,25 +20,39 @@ SELECT = ("(ilu or lusolve or trisolve or preconditioner_apply or sgs or solvers
           "and not full_size and not cpp and not fresh_process")
 
 
+def _tri_family():
+    """the five forced-form passes over the triangular-solve parity selection (box tiles x 3, lattice pencils, sync-free groups):
+    started together, see conftest.forced_run"""
+    jobs = {}
+    for dedup in ("0", "1", "0w"):
+        # "0w": additionally the opt-in layout of w (a tile's values placed by consumer, RAMD_TRSV_WSLOT=1) and 8-byte index pairs
+        env = dict(os.environ, RAMD_TRSV_CT_MINROWS="0", RAMD_TRSV_CT_MINLEN="0", RAMD_TRSV_CT_DEDUP=dedup[0],
+                   RAMD_TRSV_CT_VERBOSE="1")
+        if dedup.endswith("w"):
+            env.update(RAMD_TRSV_WSLOT="1", RAMD_TRSV_PACK="0", RAMD_TRSV_CLASSES="0")
+        cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-s", "-m", "gpu", "-p", "no:cacheprovider",
+               os.path.join(ROOT, "tests", "test_gpu_kernels.py"), os.path.join(ROOT, "tests", "test_gpu_solvers.py"),
+               os.path.join(ROOT, "tests", "test_gpu_shell.py"), "-k", SELECT]
+        jobs["tiles" + dedup] = (cmd, env, 1500)
+    import test_gpu_lattice as TL
+    import test_gpu_syncfree as TS
+    jobs["lattice"] = TL.forced_job()
+    jobs["syncfree"] = TS.forced_job()
+    return jobs
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dedup", ["0", "1", "0w"])
 def test_parity_suite_with_box_tiles_forced(dedup):
-    # "0w": additionally the opt-in layout of w (a tile's values placed by consumer, RAMD_TRSV_WSLOT=1) and 8-byte index pairs
-    env = dict(os.environ, RAMD_TRSV_CT_MINROWS="0", RAMD_TRSV_CT_MINLEN="0", RAMD_TRSV_CT_DEDUP=dedup[0],
-               RAMD_TRSV_CT_VERBOSE="1")
-    if dedup.endswith("w"):
-        env.update(RAMD_TRSV_WSLOT="1", RAMD_TRSV_PACK="0", RAMD_TRSV_CLASSES="0")
-    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-s", "-m", "gpu", "-p", "no:cacheprovider",
-           os.path.join(ROOT, "tests", "test_gpu_kernels.py"), os.path.join(ROOT, "tests", "test_gpu_solvers.py"),
-           os.path.join(ROOT, "tests", "test_gpu_shell.py"), "-k", SELECT]
-    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
-    tail = p.stdout[-3000:]
-    assert p.returncode == 0, tail
+    from conftest import forced_run
+    rc, out = forced_run("tri", "tiles" + dedup, _tri_family())
+    tail = out[-3000:]
+    assert rc == 0, tail
     assert " passed" in tail and "failed" not in tail, tail
     # the forced form was really used (the plan builder reports every box-tile plan it makes)
-    assert "box-tile plan (lower)" in p.stdout and "box-tile plan (upper)" in p.stdout, tail
+    assert "box-tile plan (lower)" in out and "box-tile plan (upper)" in out, tail
     if dedup == "1":
-        assert "distinct values" in p.stdout, tail
+        assert "distinct values" in out, tail
 
 
 _CROSS = r"""

@@ -154,16 +154,26 @@ def test_eight_ranks_config4_iteration_count_is_the_oracles_8_block_count_128(or
     print("8 ranks: %d iterations, oracle nblocks=8: %d, nblocks=1: %d" % (its[0], ref["iters"], ref1["iters"]))
 
 
-@pytest.mark.parametrize("what", ["c4", "c4hyb", "c5", "gmres"])
-def test_eight_ranks_converge_at_512(what):
-    """configs 4 (ELL and HYB interior) and 5, and GMRES(30) + BlockJacobi(ILU(0)), on the 8-way split of 512^3: converge to
+SOAK = os.environ.get("RAMD_TEST_SOAK", "0") not in ("", "0")
+# full convergence of four solver / preconditioner pairs on the 8-way split: config 4 runs at BASELINE's 512^3 in every run; the
+# others converge at 256^3 by default and at 512^3 -- 170 s more of the driver's 1 200-s limit, GMRES alone 110 s -- with
+# RAMD_TEST_SOAK=1 ("soak loops behind an env switch").  The size-independent claims (one iteration count, one
+# all-reduced residual on every rank, x -> 1) are the same at both sizes.
+CONVERGE = [("c4", 512), ("c4hyb", 256), ("c5", 256), ("gmres", 256)] + ([("c4hyb", 512), ("c5", 512), ("gmres", 512)] if SOAK else [])
+
+
+@pytest.mark.parametrize("what,N", CONVERGE)
+def test_eight_ranks_converge_at_512(what, N):
+    """configs 4 (ELL and HYB interior) and 5, and GMRES(30) + BlockJacobi(ILU(0)), on the 8-way split of N^3: converge to
     x = 1, every rank reporting the same iteration count, status and (all-reduced) residual"""
-    res = _spawn8(what + ":512", timeout=2400)
+    res = _spawn8("%s:%d" % (what, N), timeout=2400)
     its = [int(r["it"]) for r in res]
     assert len(set(its)) == 1 and all(int(r["st"]) == 2 for r in res), (its, [int(r["st"]) for r in res])
     assert len(set(float(r["res"]) for r in res)) == 1
-    rms = np.sqrt(sum(float(r["err2"]) for r in res) / 512 ** 3)
+    rms = np.sqrt(sum(float(r["err2"]) for r in res) / N ** 3)
     assert rms < (1e-4 if what == "c5" else 1e-3), rms
     lim = {"c4": (250, 900), "c4hyb": (250, 900), "c5": (2, 8), "gmres": (300, 3000)}[what]
+    if N < 512:
+        lim = (lim[0] // 3, lim[1])
     assert lim[0] <= its[0] <= lim[1], its
-    print(what, "8 ranks at 512^3:", its[0], "iterations, residual", float(res[0]["res"]), "rms error", rms)
+    print(what, "8 ranks at %d^3:" % N, its[0], "iterations, residual", float(res[0]["res"]), "rms error", rms)

@@ -1108,30 +1108,41 @@ def test_csr_row_patterns_give_up_quickly_on_a_large_unstructured_matrix(ra, ora
     eq(y.numpy(), oracle.csr_apply(rp, ci, va, xh))
 
 
-@pytest.mark.parametrize("variant", ["RAMD_CSR_Q4=1", "RAMD_CSR_PAT=1", "RAMD_CSR_PAT=1,RAMD_CSR_XL=1", "RAMD_CSR_PAT=0",
-                                     "RAMD_CSR_PAT=0,RAMD_CSR_GRP=1", "RAMD_CSR_PAT=1,RAMD_CSR_PAT2=0", "RAMD_ELL2=1,RAMD_CSR_PAT=1", "RAMD_ELL2=1,RAMD_CSR_PAT=0", "RAMD_CSR_PAT=0,RAMD_CSR_COL2=2", "RAMD_CSR_PAT=1,RAMD_CSR_NORP=1",
-                                     "RAMD_CSR_PAT=0,RAMD_CSR_W4=1", "RAMD_CSR_PAT=0,RAMD_CSR_W4=1,RAMD_CSR_W4_WAVES=1", "RAMD_CSR_PAT=0,RAMD_CSR_PIPE=1",
-                                     "RAMD_CSR_PAT=1,RAMD_MC_FOLD=0", "RAMD_MC_RB=2", "RAMD_MC_RB=0"])
+SPMV_VARIANTS = ["RAMD_CSR_Q4=1", "RAMD_CSR_PAT=1", "RAMD_CSR_PAT=1,RAMD_CSR_XL=1", "RAMD_CSR_PAT=0",
+                 "RAMD_CSR_PAT=0,RAMD_CSR_GRP=1", "RAMD_CSR_PAT=1,RAMD_CSR_PAT2=0", "RAMD_ELL2=1,RAMD_CSR_PAT=1", "RAMD_ELL2=1,RAMD_CSR_PAT=0",
+                 "RAMD_CSR_PAT=0,RAMD_CSR_COL2=2", "RAMD_CSR_PAT=1,RAMD_CSR_NORP=1", "RAMD_CSR_PAT=0,RAMD_CSR_W4=1",
+                 "RAMD_CSR_PAT=0,RAMD_CSR_W4=1,RAMD_CSR_W4_WAVES=1", "RAMD_CSR_PAT=0,RAMD_CSR_PIPE=1", "RAMD_CSR_PAT=1,RAMD_MC_FOLD=0",
+                 "RAMD_MC_RB=2", "RAMD_MC_RB=0"]
+
+
+def _spmv_family():
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    jobs = {}
+    for variant in SPMV_VARIANTS:
+        env = dict(os.environ)
+        for kv in variant.split(","):
+            env[kv.split("=")[0]] = kv.split("=")[1]
+        cmd = [sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_kernels.py"), os.path.join(here, "test_gpu_edge_cases.py"),
+               os.path.join(here, "test_gpu_solvers.py"), "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider", "-k",
+               "(spmv or csr or apply or fused_bicgstab or golden or smoother or convert or mcsgs or mcgs or mcilu or multicolor or history) "
+               "and not fresh_process"]
+        jobs[variant] = (cmd, env, 1500)
+    return jobs
+
+
+@pytest.mark.parametrize("variant", SPMV_VARIANTS)
 def test_spmv_variants_forced_in_a_fresh_process(variant):
     """the CSR SpMV has an opt-in four-lanes-per-row walk (k_csr_q4), and CSR / ELL / HYB products and the multi-colour
     sweeps rebuild the columns of structured matrices from row patterns (by default only from 2^20 entries on; with RAMD_CSR_XL=1
     the CSR product stages the x pieces its 256-row blocks need in LDS, k_csr_xl, instead of gathering x; RAMD_CSR_W4=1: wave-private passes with four lanes per row, k_csr_w4; RAMD_CSR_PIPE=1: the next
     pass requested before the row walk; with row patterns the SGS sweeps fold colour 0 into its readers, RAMD_MC_FOLD=0: do not; RAMD_MC_RB=2: the one-pass red-black lattice form of the SGS apply, k_mc_rb, on every two-colour lattice operator however small, =0: never); each forced
     on (or off) for EVERY matrix of the SpMV / ApplyAdd / fused-dot / Jacobi-sweep / format / multi-colour / solver-history
-    tests: results must not change (bit-exact: same values, same order)"""
-    import subprocess
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ)
-    for kv in variant.split(","):
-        env[kv.split("=")[0]] = kv.split("=")[1]
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_kernels.py"),
-                        os.path.join(here, "test_gpu_edge_cases.py"), os.path.join(here, "test_gpu_solvers.py"), "-q", "-m", "gpu",
-                        "-x", "-k", "(spmv or csr or apply or fused_bicgstab or golden or smoother or convert or mcsgs or mcgs or mcilu "
-                                    "or multicolor or history) "
-                                    "and not fresh_process"],
-                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
-    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    tests: results must not change (bit-exact: same values, same order).  The sixteen processes run several at a time
+    (conftest.forced_run)."""
+    from conftest import forced_run
+    rc, out = forced_run("spmv", variant, _spmv_family())
+    assert rc == 0, out[-3000:]
 
 
 @pytest.mark.gpu

@@ -131,17 +131,23 @@ SELECT = ("(ilu or lusolve or trisolve or preconditioner_apply or sgs or solvers
           "and not full_size and not cpp and not fresh_process")
 
 
-def test_parity_suite_with_the_lattice_form_forced():
-    """every lattice the suite's matrices contain (the `poisson8` goldens, the Poisson systems of the oracle comparisons) goes
-    through the pencil kernel, whatever its size; everything else keeps its plan"""
+def forced_job():
     env = dict(os.environ, RAMD_TRSV_LAT="2", RAMD_TRSV_CT_VERBOSE="1")
     cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-s", "-m", "gpu", "-p", "no:cacheprovider",
            os.path.join(ROOT, "tests", "test_gpu_kernels.py"), os.path.join(ROOT, "tests", "test_gpu_solvers.py"), "-k", SELECT]
-    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
-    tail = p.stdout[-3000:]
-    assert p.returncode == 0, tail
+    return cmd, env, 1500
+
+
+def test_parity_suite_with_the_lattice_form_forced():
+    """every lattice the suite's matrices contain (the `poisson8` goldens, the Poisson systems of the oracle comparisons) goes
+    through the pencil kernel, whatever its size; everything else keeps its plan"""
+    from conftest import forced_run
+    from test_gpu_box_tiles_forced import _tri_family
+    rc, out = forced_run("tri", "lattice", _tri_family())
+    tail = out[-3000:]
+    assert rc == 0, tail
     assert " passed" in tail and "failed" not in tail, tail
-    assert "lattice plan (lower): 8 x 8 x 8" in p.stdout and "lattice plan (upper): 8 x 8 x 8" in p.stdout, tail
+    assert "lattice plan (lower): 8 x 8 x 8" in out and "lattice plan (upper): 8 x 8 x 8" in out, tail
 
 
 def test_what_is_not_a_lattice_keeps_the_general_plans():

@@ -17,21 +17,27 @@ SELECT = ("((ilu or lusolve or trisolve or preconditioner_apply or sgs or solver
 FORCED = dict(RAMD_TRSV_SF="2", RAMD_TRSV_CT="0", RAMD_TRSV_LAT="0", RAMD_TRSV_CT_VERBOSE="1")
 
 
+def forced_job():
+    env = dict(os.environ, **FORCED)
+    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-s", "-m", "gpu", "-p", "no:cacheprovider",
+           os.path.join(ROOT, "tests", "test_gpu_kernels.py"), os.path.join(ROOT, "tests", "test_gpu_solvers.py"),
+           os.path.join(ROOT, "tests", "test_gpu_shell.py"), "-k", SELECT, "--durations=5"]
+    return cmd, env, 1500
+
+
 @pytest.mark.gpu
 def test_parity_suite_with_the_sync_free_grouped_form_forced():
     """ILU(0) / IC factors + LUSolve / LLSolve / LSolve / USolve goldens, preconditioner applies, solver histories, the config-3
     class in four numberings (factors, LUSolve and GMRES(30)+ILU(0) against the oracle) -- with every triangular plan that can be
     in the sync-free grouped form (also the descending-order sweep of LLSolve's second stage)."""
-    env = dict(os.environ, **FORCED)
-    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-s", "-m", "gpu", "-p", "no:cacheprovider",
-           os.path.join(ROOT, "tests", "test_gpu_kernels.py"), os.path.join(ROOT, "tests", "test_gpu_solvers.py"),
-           os.path.join(ROOT, "tests", "test_gpu_shell.py"), "-k", SELECT, "--durations=5"]
-    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
-    tail = p.stdout[-3000:]
-    assert p.returncode == 0, tail
+    from conftest import forced_run
+    from test_gpu_box_tiles_forced import _tri_family
+    rc, out = forced_run("tri", "syncfree", _tri_family())
+    tail = out[-3000:]
+    assert rc == 0, tail
     assert " passed" in tail and "failed" not in tail, tail
-    assert "sync-free grouped plan (lower)" in p.stdout and "sync-free grouped plan (upper)" in p.stdout, tail
-    assert "8 lanes per row" in p.stdout and "4 lanes per row" in p.stdout, tail
+    assert "sync-free grouped plan (lower)" in out and "sync-free grouped plan (upper)" in out, tail
+    assert "8 lanes per row" in out and "4 lanes per row" in out, tail
 
 
 _BLOCKS = r"""
@@ -202,3 +208,77 @@ def test_bench_mtx_reports_the_plan_of_a_file_nobody_here_has_seen(tmp_path):
     if os.environ.get("RAMD_TRSV_SF", "1") == "1" and os.environ.get("RAMD_TRSV_CT", "1") != "0":
         assert "k_trsv_sf" in tp["lower"]["form"] and "k_trsv_sf" in tp["upper"]["form"], tp
     assert d["roofline"]["kernel"].startswith("sparse triangular solve"), d["roofline"]["kernel"]
+
+
+@pytest.mark.gpu
+def test_short_division_sequence_gives_the_bits_of_the_division(tmp_path):
+    """trsv_syncfree.hip sf_div: inside its exponent window the solve forms a / d with the last three operations of gfx950's fp64
+    division sequence, the divisor-only part (reciprocal, two Newton steps) coming from the plan.  Same instructions on the same
+    operands => the bits of `/` (and of the host's correctly rounded division, which the reference performs:
+    host_matrix_csr.cpp:1216).  Checked here on 12 M operand pairs: random mantissas over the whole window and across its edges,
+    divisors with all-ones / all-zeros mantissas, equal operands, powers of two, zeros / infinities / NaNs / denormals (which must
+    leave the window and take `/`), and every diagonal of the ILU(0) factors of the five numberings of the config-3 class against
+    right-hand sides of the magnitudes a solve meets."""
+    import ctypes as C
+    import numpy as np
+    import rocalution_amd as ra
+    from rocalution_amd import capi, generators as gen
+    ra.init_rocalution()
+    lib = capi.load()
+    rng = np.random.default_rng(11)
+
+    def probe(a, d):
+        n = len(a)
+        va, vd = ra.LocalVector(data=a), ra.LocalVector(data=d)
+        vf = ra.LocalVector(); vf.Allocate("", n)
+        vp = ra.LocalVector(); vp.Allocate("", n)
+        vi = ra.LocalVector(np.int32); vi.Allocate("", n)
+        ptr = lambda v: C.c_void_p(lib.ramd_vec_data(v._h))
+        capi.check(lib.ramd_selftest_sf_div(n, ptr(va), ptr(vd), ptr(vf), ptr(vp), ptr(vi)))
+        return vf.numpy(), vp.numpy(), vi.numpy()
+
+    def rand(n, elo, ehi):
+        m = rng.integers(0, 1 << 52, n, dtype=np.uint64)
+        e = rng.integers(elo, ehi + 1, n, dtype=np.uint64)
+        s = rng.integers(0, 2, n, dtype=np.uint64)
+        return ((s << np.uint64(63)) | (e << np.uint64(52)) | m).view(np.float64)
+
+    n = 4_000_000
+    cases = []
+    cases.append((rand(n, 640, 1407), rand(n, 640, 1407)))            # the whole window
+    cases.append((rand(n, 1000, 1046), rand(n, 1000, 1046)))          # the magnitudes of a solve
+    a, d = rand(n, 600, 1450), rand(n, 600, 1450)                     # across the edges of the window
+    d[: n // 8] = (d[: n // 8].view(np.uint64) | np.uint64((1 << 52) - 1)).view(np.float64)            # mantissa all ones
+    d[n // 8: n // 4] = (d[n // 8: n // 4].view(np.uint64) & ~np.uint64((1 << 52) - 1)).view(np.float64)  # powers of two
+    a[n // 4: n // 2] = d[n // 4: n // 2] * rng.choice([1.0, -1.0, 3.0, 1.0 / 3.0], n // 4)           # equal / simple ratios
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 5e-324, -5e-324, 2.2250738585072014e-308, 1.7976931348623157e308,
+                        1.0, -1.0, 2.0 ** -383, 2.0 ** 384, np.nextafter(2.0 ** 385, 0), 2.0 ** 385, np.nextafter(2.0 ** -383, 0)])
+    k = len(special)
+    a[-k * k:] = np.repeat(special, k); d[-k * k:] = np.tile(special, k)
+    cases.append((a, d))
+    inwin = 0
+    for a, d in cases:
+        fast, plain, win = probe(a, d)
+        assert np.array_equal(fast.view(np.uint64), plain.view(np.uint64)), np.flatnonzero(fast.view(np.uint64) != plain.view(np.uint64))[:5]
+        ok = np.isfinite(a) & np.isfinite(d) & (d != 0)
+        with np.errstate(all="ignore"):
+            host = a[ok] / d[ok]   # (IEEE division of the host: correctly rounded)
+        assert np.array_equal(host.view(np.uint64), plain[ok].view(np.uint64))
+        ea = (a.view(np.uint64) >> np.uint64(52)) & np.uint64(0x7ff)
+        ed = (d.view(np.uint64) >> np.uint64(52)) & np.uint64(0x7ff)
+        want = (ea >= 640) & (ea <= 1407) & (ed >= 640) & (ed <= 1407)
+        assert np.array_equal(win.astype(bool), want)
+        inwin += int(win.sum())
+    assert inwin > 8_000_000
+    # the diagonals of the ILU(0) factors of the class, every numbering
+    from oracle import oracle
+    for kind in ("lex", "rcm", "morton", "random", "delaunay"):
+        rp, ci, va = gen.shell_variant(60, kind)
+        lu = oracle.ilu0(rp, ci, va)
+        dg = lu[np.flatnonzero(ci == np.repeat(np.arange(len(rp) - 1), np.diff(rp)))]
+        assert len(dg) == len(rp) - 1
+        reps = 40
+        d = np.tile(dg, reps)
+        a = rng.standard_normal(len(d)) * 10.0 ** rng.integers(-8, 9, len(d))
+        fast, plain, win = probe(a, d)
+        assert win.all() and np.array_equal(fast.view(np.uint64), plain.view(np.uint64)), kind
