@@ -129,7 +129,7 @@ def cpu_baseline(args, mtx_path=None):
     ref_precond = args.precond if args.precond in ("jacobi", "ilu0", "mcsgs", "none") else None
     if os.path.exists(probe) and os.path.exists("/opt/rocm/lib/librocalution.so") and ref_solver and ref_precond:
         try:
-            src = mtx_path if mtx_path else str(args.cpu_grid)
+            src = mtx_path if mtx_path else (("lap27:%d" % args.cpu_grid) if args.matrix == "lap27" else str(args.cpu_grid))
             out = subprocess.check_output([probe, "bench", src, str(iters), str(threads), "0", ref_solver, ref_precond],
                                           env=env, stderr=subprocess.DEVNULL, timeout=1500).decode()
             rec = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
@@ -139,7 +139,8 @@ def cpu_baseline(args, mtx_path=None):
                 scale = 1.0
             else:
                 scale = (args.cpu_grid / float(args.grid)) ** 3
-                what = "3-D Poisson %d^3 CSR fp64 (%.3g of the benchmark's rows)" % (args.cpu_grid, scale)
+                what = "3-D %s %d^3 CSR fp64 (%.3g of the benchmark's rows)" % ("27-point Laplacian" if args.matrix == "lap27" else "Poisson",
+                                                                                  args.cpu_grid, scale)
             r = dict(value=rec["iters_per_s"], unit="iters/s", cores=threads, kind="reference",
                      sample="%s, %s, %d iterations, rocALUTION (ROCm-installed) host/OpenMP backend, accelerator disabled"
                             % (label, what, rec["iters"]),
@@ -163,6 +164,10 @@ def cpu_baseline(args, mtx_path=None):
     elif args.matrix == "shell":
         rp, ci, va = gen.shell_surrogate(min(args.shell_nx, 200))
         what = "shell surrogate %d^2 nodes" % min(args.shell_nx, 200)
+    elif args.matrix == "lap27":
+        Np = min(args.cpu_grid, 96)
+        rp, ci, va = gen.laplace27(Np)
+        what = "3-D 27-point Laplacian %d^3 CSR fp64" % Np
     else:
         Np = min(args.cpu_grid, 128)
         rp, ci, va = gen.poisson7(Np)
@@ -201,10 +206,11 @@ def reference_gpu(args):
     probe = os.path.join(ROOT, "oracle", "_ref", "ref_probe")
     if not (os.path.exists(probe) and os.path.exists("/opt/rocm/lib/librocalution_hip.so")):
         return None
-    if args.matrix != "poisson" or args.solver not in ("cg", "gmres", "bicgstab") or args.precond not in ("jacobi", "ilu0", "mcsgs"):
+    if args.matrix not in ("poisson", "lap27") or args.solver not in ("cg", "gmres", "bicgstab") or args.precond not in ("jacobi", "ilu0", "mcsgs"):
         return None
     def probe_run(grid, steps):
-        out = subprocess.check_output([probe, "bench", str(grid), str(steps), "0", "1", args.solver, args.precond],
+        out = subprocess.check_output([probe, "bench", ("lap27:%d" % grid) if args.matrix == "lap27" else str(grid), str(steps), "0", "1",
+                                       args.solver, args.precond],
                                       stderr=subprocess.STDOUT, timeout=900).decode()
         rec = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
         return dict(iters_per_s=rec["iters_per_s"], spmv_GBps=rec["spmv_GBps"], t_spmv_ms=rec["t_spmv_s"] * 1e3,
@@ -218,7 +224,7 @@ def reference_gpu(args):
         msg = [l for l in (e.output or b"").decode(errors="replace").splitlines() if l.strip()]
         log("reference_gpu: %s+%s at grid %d failed in the vendor library (%s)" % (args.solver, args.precond, args.grid, msg[-1] if msg else e))
         rg = dict(error="the vendor backend fails on this workload at grid %d: %s" % (args.grid, msg[-1][-160:] if msg else repr(e)))
-        if args.matrix == "poisson" and args.grid > 256:
+        if args.matrix in ("poisson", "lap27") and args.grid > 256:
             try:
                 small = probe_run(256, min(steps, 10))  # (its csrsv takes ~1.3 s per iteration there)
                 small["grid"] = 256
@@ -364,8 +370,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--matrix", default="poisson", choices=["poisson", "shell", "file"],
-                    help="poisson: 3-D 7-point operator (device generator); shell: af_shell10-class surrogate "
+    ap.add_argument("--matrix", default="poisson", choices=["poisson", "lap27", "shell", "file"],
+                    help="poisson: 3-D 7-point operator (device generator); lap27: the reference's own 3-D operator, the 27-point "
+                         "Laplacian of clients/include/utility.hpp:110-177 (device generator, --grid N); shell: af_shell10-class surrogate "
                          "(BASELINE.json config 3; 1 GPU), read through ReadFileMTX; file: the MatrixMarket file given with --mtx")
     ap.add_argument("--mtx", default=None, metavar="PATH",
                     help="MatrixMarket file supplied on the box (e.g. SuiteSparse af_shell10.mtx for config 3): read with the "
@@ -520,6 +527,13 @@ def main():
             ingest = dict(file_bytes=os.path.getsize(mtx_path), read_s=round(time.perf_counter() - t0, 3))
             regen = lambda: A.ReadFileMTX(mtx_path)
             wl = "%s (n=%d, nnz=%d, %.2f per row), read through ReadFileMTX" % (os.path.basename(mtx_path), n, nnz, nnz / max(n, 1))
+        elif args.matrix == "lap27":
+            A.GenLaplace27(N)
+            n, nnz = A.GetM(), A.GetNnz()
+            assert n == N ** 3 and nnz == (3 * N - 2) ** 3
+            regen = lambda: A.GenLaplace27(N)
+            wl = ("3-D 27-point Laplacian %d^3 (the reference's gen_3d_laplacian, clients/include/utility.hpp:110-177; n=%d, nnz=%d)"
+                  % (N, n, nnz))
         else:
             n, nnz = N ** 3, 7 * N ** 3 - 6 * N ** 2
             A.GenPoisson7(N)
@@ -642,7 +656,7 @@ def main():
             k_spmv = ("fp32 inner CSR SpMV + fused <p,q> (k_csr_pat2<float> for structured matrices, else k_csr_tr<float>; the few fp64 outer residual SpMVs are in the average)"
                       if mixed else "CSR SpMV (k_csr_pat2 for structured matrices -- columns from the row-pattern dictionary, two row blocks per workgroup: traffic below the algorithmic CSR bytes -- else k_csr_tr, or k_csr_w4 for rows of 16+ entries; with the fused dot where the solver uses it)")
         else:
-            nnz_fmt = 7 * n if args.matrix == "poisson" else nnz
+            nnz_fmt = 7 * n if args.matrix == "poisson" else (27 * n if args.matrix == "lap27" else nnz)
             b_spmv = 4 * nnz_fmt + vb * (2 * n + nnz_fmt)
             k_spmv = "k_ell<%s>" % ("float" if mixed else "double")
         tkey = None
@@ -900,6 +914,7 @@ def main():
     if rank == 0:
         out = {
             "metric": "%s iterations/s, %s %s fp64" % (label, "3D 7-pt Poisson %d^3" % N if args.matrix == "poisson"
+                                                       else "3D 27-pt Laplacian %d^3" % N if args.matrix == "lap27"
                                                        else ("af_shell10-class surrogate (n=%d)" % n if args.matrix == "shell"
                                                              else "%s (n=%d)" % (os.path.basename(args.mtx), n)), args.format.upper()),
             "value": round(it / dt, 3), "unit": "iters/s", "n_gpus": world, "steps": K, "warmup": W,

@@ -6,7 +6,7 @@
 // rocSPARSE/rocBLAS HIP backend -- on inputs handed over as raw binary files.
 //
 //   ref_probe gen   <indir> <outdir>            golden fixtures (see oracle/gen_golden.py)
-//   ref_probe bench <N> <iters> <threads> <accel 0|1> [solver=cg|gmres|bicgstab] [precond=...]
+//   ref_probe bench <N | lap27:N | file.mtx> <iters> <threads> <accel 0|1> [solver=cg|gmres|bicgstab] [precond=...]
 //                                               CG+Jacobi etc. on 3-D 7-pt Poisson N^3, prints JSON
 //
 // Built by oracle/Makefile into oracle/_ref/ (git-ignored). Used by oracle/gen_golden.py in the
@@ -1350,6 +1350,35 @@ static void poisson7(int N, std::vector<int32_t>& rp, std::vector<int32_t>& ci,
             }
 }
 
+// the reference's own 3-D operator: 27-point stencil, 26 on the diagonal, -1 elsewhere, ascending columns
+// (behaviour of clients/include/utility.hpp:110-177 gen_3d_laplacian; rows filled in order here)
+static void laplace27(int N, std::vector<int32_t>& rp, std::vector<int32_t>& ci, std::vector<double>& va)
+{
+    int64_t n = (int64_t)N * N * N;
+    rp.resize(n + 1);
+    ci.clear();
+    va.clear();
+    ci.reserve(27 * n);
+    va.reserve(27 * n);
+    rp[0] = 0;
+    for(int z = 0; z < N; ++z)
+        for(int y = 0; y < N; ++y)
+            for(int x = 0; x < N; ++x)
+            {
+                int64_t r = ((int64_t)z * N + y) * N + x;
+                for(int sz = -1; sz <= 1; ++sz)
+                    for(int sy = -1; sy <= 1; ++sy)
+                        for(int sx = -1; sx <= 1; ++sx)
+                            if(z + sz >= 0 && z + sz < N && y + sy >= 0 && y + sy < N && x + sx >= 0 && x + sx < N)
+                            {
+                                int64_t c = r + ((int64_t)sz * N + sy) * N + sx;
+                                ci.push_back((int32_t)c);
+                                va.push_back(c == r ? 26.0 : -1.0);
+                            }
+                rp[r + 1] = (int32_t)ci.size();
+            }
+}
+
 static int cmd_bench(int argc, char** argv)
 {
     int         N       = atoi(argv[2]);
@@ -1384,7 +1413,13 @@ static int cmd_bench(int argc, char** argv)
     {
         std::vector<int32_t> rp, ci;
         std::vector<double>  va;
-        poisson7(N, rp, ci, va);
+        if(src.rfind("lap27:", 0) == 0) // "lap27:<N>": the 27-point operator instead of the 7-point one
+        {
+            N = atoi(src.c_str() + 6);
+            laplace27(N, rp, ci, va);
+        }
+        else
+            poisson7(N, rp, ci, va);
         n   = (int64_t)N * N * N;
         nnz = (int64_t)ci.size();
         mat.AllocateCSR("poisson7", nnz, n, n);

@@ -72,16 +72,15 @@ void sf_release(SfPlan** sp)
 // |res| with the sign of a * d, which is res.  The second line depends on d alone: it is formed ONCE, with the same
 // instructions, when the plan is filled (sf_recip_iterate), and the solve runs the third line only -- a multiplication and two
 // fused multiply-adds behind the running sum instead of eleven dependent operations, the same bits by construction.  Operands
-// outside the window (a zero right-hand side, an overflowed sum, a tiny pivot) take `/`.
-constexpr unsigned kDivExpLo = 640u, kDivExpSpan = 768u;
-__device__ __forceinline__ bool sf_div_in_window(double v)
-{
-    const unsigned e = ((unsigned)__double2hiint(v) >> 20) & 0x7ffu;
-    return (e - kDivExpLo) < kDivExpSpan;
-}
+// outside the window (a zero right-hand side, an overflowed sum, a tiny pivot) take `/` -- found out per UNIT, by one look at
+// its quotients (sf_quotient_in_window): a wave issues every instruction in order, and a test per division cost what the
+// short sequence saved (round 6, measured: 2 532 -> 2 492 cycles per five-row unit with a test of every dividend).
+constexpr unsigned kDivDLo = 923u, kDivDSpan = 201u, kDivQLo = 773u, kDivQSpan = 501u;
 __device__ __forceinline__ double sf_recip_iterate(double d)
 {
-    if(!sf_div_in_window(d))
+    // (kept only for divisors in the narrow window of sf_quotient_in_window below)
+    const unsigned ex = ((unsigned)__double2hiint(d) >> 20) & 0x7ffu;
+    if((ex - kDivDLo) >= kDivDSpan)
         return 0.0;
     double y = __builtin_amdgcn_rcp(d);
     double e = __builtin_fma(-d, y, 1.0);
@@ -94,23 +93,38 @@ __device__ __forceinline__ float sf_recip_iterate(float)
 {
     return 0.0f;
 }
-// a / d; y = sf_recip_iterate(d); live: the lanes whose quotient is used (the others may hold anything)
-__device__ __forceinline__ double sf_div(double a, double d, double y, bool live)
+// the third line for an unscaled division: a / d where y = sf_recip_iterate(d) != 0 and a lies inside the window -- the caller's
+// business (sf_unit checks the QUOTIENTS of a unit once, see sf_quotient_in_window)
+__device__ __forceinline__ double sf_div_short(double a, double d, double y)
 {
-    const bool   ok  = sf_div_in_window(a) && y != 0.0;
-    const double q   = a * y;
-    const double r   = __builtin_fma(-d, q, a);
-    double       res = __builtin_fma(r, y, q);
-    if(__ballot(live && !ok) != 0ull)
-    {
-        const double slow = a / d;
-        res               = ok ? res : slow;
-    }
-    return res;
+    const double q = a * y;
+    const double r = __builtin_fma(-d, q, a);
+    return __builtin_fma(r, y, q);
 }
-__device__ __forceinline__ float sf_div(float a, float d, float, bool)
+__device__ __forceinline__ float sf_div_short(float a, float d, float)
 {
     return a / d;
+}
+// One test per RESULT instead of one per dividend.  The plan keeps the reciprocal iterate only for divisors with biased
+// exponents in [923, 1123] (|d| in [2^-100, 2^101); 0 otherwise).  If the short sequence returns a quotient q with biased
+// exponent in [773, 1273] (|q| in [2^-250, 2^251)), the dividend a = q d (1 + O(2^-52)) had its exponent in [672, 1374], inside
+// the window of the short sequence: q is a / d.  Conversely a dividend outside that window cannot produce such a q with such a
+// d: a = +-0 gives q = +-0, an infinity or a NaN gives a NaN, |a| < 2^-383 gives |q| < 2^-281, |a| >= 2^385 gives |q| >= 2^283
+// (or an infinity), and y = 0 gives q = 0.
+__device__ __forceinline__ bool sf_quotient_in_window(double q)
+{
+    const unsigned e = ((unsigned)__double2hiint(q) >> 20) & 0x7ffu;
+    return (e - kDivQLo) < kDivQSpan;
+}
+__device__ __forceinline__ bool sf_quotient_in_window(float)
+{
+    return true;
+}
+// a / d the way a unit does it: short sequence, result checked, `/` otherwise (the probe kernel of the tests)
+__device__ __forceinline__ double sf_div(double a, double d, double y)
+{
+    const double q = sf_div_short(a, d, y);
+    return sf_quotient_in_window(q) ? q : a / d;
 }
 
 // a kernel of its own for the tests (ramd_selftest_sf_div): out[i] = sf_div(a[i], d[i]) next to a[i] / d[i]
@@ -122,9 +136,10 @@ __global__ __launch_bounds__(kBlock) void k_sf_div_probe(int64_t n, const double
     for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gsz)
     {
         const double y = sf_recip_iterate(d[i]);
-        fast[i]        = sf_div(a[i], d[i], y, true);
+        const double q = sf_div_short(a[i], d[i], y);
+        fast[i]        = sf_div(a[i], d[i], y);
         plain[i]       = a[i] / d[i];
-        in_window[i]   = (sf_div_in_window(a[i]) && y != 0.0) ? 1 : 0;
+        in_window[i]   = sf_quotient_in_window(q) ? 1 : 0; // (1: the short sequence's quotient is what fast[i] holds)
     }
 }
 
@@ -345,24 +360,102 @@ __device__ __forceinline__ void sf_pull_ready(T (&all)[LPR][NA], const T (&prod)
 }
 
 // ---------------------------------------------------------------- one unit: wait for the dependencies, compute
+// the arithmetic of a unit once its dependencies are there.  Lower solve (INFIRST false): `sum` has been through the row's
+// chain of out-of-group subtractions (result in lane nl - 1 of the row); the in-group entries are the last of a row: row j of
+// a group is final once the rows before it have been taken out of it.  Upper solve: the in-group entries come first -- the rows
+// of a group one after the other (nearest row first), each with its in-group terms, its chain and its division: five chains
+// per node instead of one; a round's chain is a straight line of subtractions in the row's first lane, whose operands (`all`)
+// the waiting turns have brought there; the result of a row is in its lane 0.
+// r: row number inside its group, nl (uniform): lanes per row in use, maxm (uniform): rows of the unit's longest group, ONE:
+// the unit holds one group (the lane a finished row is taken from is uniform: v_readlane, else ds_bpermute).
+// EXACT false: fp64 divisions by the short sequence, unchecked -- the caller checks the results (sf_unit).
+template <typename T, int DMODE, bool INFIRST, int LPR, int NA, bool ONE, bool EXACT>
+__device__ __forceinline__ T sf_rounds(T sum, const T (&all)[INFIRST ? LPR : 1][NA], T rhs, T dg, T rdg, const T (&gc)[7], int r, int l,
+                                       int slot, int nl, int maxm)
+{
+    if constexpr(!INFIRST)
+    {
+        const int gl0 = (slot - r) * LPR + nl - 1; // where the group's first row ends its chain
+#pragma unroll
+        for(int j = 0; j < kGrpMax; ++j)
+        {
+            if(j >= maxm)
+                break;
+            if(DMODE != 0)
+            {
+                const T q = DMODE == 1 ? (EXACT ? sum / dg : sf_div_short(sum, dg, rdg)) : sum * dg;
+                sum       = (r == j) ? q : sum;
+            }
+            if(j < 7 && j + 1 < maxm)
+            {
+                const T yj = ONE ? sf_from_lane(sum, j * LPR + nl - 1) : __shfl(sum, gl0 + j * LPR, 64);
+                const T t  = sum - gc[j] * yj;
+                sum        = (r > j) ? t : sum;
+            }
+        }
+        return sum;
+    }
+    else
+    {
+        const int g0 = (slot - r) * LPR; // lane 0 of the group's first row
+        T         y[7];
+#pragma unroll
+        for(int j = 0; j < 7; ++j)
+            y[j] = (T)0;
+        T res = (T)0;
+#pragma unroll
+        for(int j = 0; j < kGrpMax; ++j)
+        {
+            if(j >= maxm)
+                break;
+            T s = rhs;
+#pragma unroll
+            for(int i = 6; i >= 0; --i)
+                if(i < j)
+                    s -= gc[i] * y[i];
+            // (two lanes of products per test: a lane beyond nl holds +0 products, and s - (+0) is s -- half the tests of a walk
+            //  lane by lane; one wave runs a unit and issues every instruction in order, tests included)
+#pragma unroll
+            for(int q = 0; q < LPR; q += 2)
+            {
+                if(q >= nl)
+                    break;
+#pragma unroll
+                for(int k = 0; k < NA; ++k)
+                    s -= all[q][k];
+#pragma unroll
+                for(int k = 0; k < NA; ++k)
+                    s -= all[q + 1][k];
+            }
+            if(DMODE == 1)
+                s = EXACT ? s / dg : sf_div_short(s, dg, rdg);
+            else if(DMODE == 2)
+                s = s * dg;
+            res = (r == j) ? s : res;
+            if(j < 7 && j + 1 < maxm)
+                y[j] = ONE ? sf_from_lane(s, j * LPR) : __shfl(s, g0 + j * LPR, 64);
+        }
+        return res;
+    }
+}
+
 // c / a: the lane's out-of-group entries (position, coefficient), NA of them (a slot without an entry: c < 0, coefficient +0: the
 // product (+0)(+0) = +0, and s - (+0) is s bit for bit for every s, -0 included: no test per entry, NA subtractions per lane in
 // a straight line -- every lane computes, the lane whose turn it is keeps: one wave runs a unit, and a taken branch costs it more
-// than the arithmetic it would skip).  r: row number inside its group, nl (uniform): lanes per row in use, maxm (uniform): rows of
-// the unit's longest group, ONE: the unit holds one group (the lane a finished row is taken from is uniform: v_readlane, else
-// ds_bpermute).  Returns the result of the row in lane nl - 1 of the row (lower) / lane 0 (upper).
+// than the arithmetic it would skip).  Waits for the unit's dependencies, does what can be done with the values that are there
+// while it waits, finishes (sf_rounds), publishes the rows' results (w[p], and out[onat] where out is given).
 template <typename T, int DMODE, bool INFIRST, int LPR, int NA, bool ONE>
-__device__ __forceinline__ T sf_unit(const T* w, const int (&c)[kSfKW], const T (&a)[kSfKW], T rhs, T dg, T rdg, const T (&gc)[7], bool have,
-                                     int r, int l, int slot, int nl, int maxm, bool nowait, unsigned long long& d_w0,
-                                     unsigned long long& d_c0, bool dbg)
+__device__ __forceinline__ void sf_unit(T* w, T* __restrict__ out, int p, int onat, int pidle, const int (&c)[kSfKW], const T (&a)[kSfKW],
+                                        T rhs, T dg, T rdg, const T (&gc)[7], bool have, int r, int l, int slot, int nl, int maxm,
+                                        int flags, int stagger, unsigned long long* __restrict__ dbg, int64_t nunits, int u)
 {
     using B = typename Sentinel<T>::bits;
     constexpr unsigned long long LM = SfRowMask<LPR>::value;
+    const bool nowait = (flags & 1) != 0, pipe = (flags & 2) != 0;
     B x[NA];
 #pragma unroll
     for(int k = 0; k < NA; ++k)
         x[k] = c[k] >= 0 ? Sentinel<T>::value : (B)0;
-    T prod[NA];
     // what the waiting turns leave behind: lower solve -- the running sum, advanced through `step` lanes of every row;
     // upper solve -- the products of the lanes in `done`, in the row's first lane
     T        sum  = rhs;
@@ -374,24 +467,29 @@ __device__ __forceinline__ T sf_unit(const T* w, const int (&c)[kSfKW], const T 
 #pragma unroll
         for(int k = 0; k < NA; ++k)
             all[q][k] = (T)0;
-    // every value is requested once; after that only the lanes whose value was not there yet ask again: the turns of a unit close
-    // to the front are a handful of requests, and the turn that finds the last value is the only trip through memory on the
-    // critical path
-    int spins = 0;
-    while(true)
-    {
-        spin_guard(spins);
+    // A turn: ALL its requests are issued before the first answer is looked at -- a lane whose value k is there asks for the unit's
+    // first position instead (one address for the whole wave: one request).  (Round 5 asked only the lanes still missing a
+    // value, behind a test per k: the compiler then waits for every answer before the next request, and the turn that finds the
+    // last values of a level -- on the critical path -- was up to kw trips through memory in a row: 1.04 us per hand-off.)
+    auto issue = [&](B(&v)[NA]) {
+#pragma unroll
+        for(int k = 0; k < NA; ++k)
+            v[k] = poll_load(w + (x[k] == Sentinel<T>::value ? c[k] : pidle));
+        __builtin_amdgcn_sched_barrier(0); // (the scheduler must not sink a request behind the wait for another one's answer)
+    };
+    // the answers of a turn -> which lanes are complete; then everything that can be done with what is there
+    auto take = [&](const B(&v)[NA]) -> unsigned long long {
         bool full = true;
 #pragma unroll
         for(int k = 0; k < NA; ++k)
-            if(x[k] == Sentinel<T>::value)
-            {
-                x[k] = poll_load(w + c[k]);
-                if(nowait && x[k] == Sentinel<T>::value) // (diagnostic, RAMD_TRSV_SF_GATHER=2: no dependency waits -- wrong results)
-                    x[k] = (B)0;
-                full = full && (x[k] != Sentinel<T>::value);
-            }
+        {
+            x[k] = (x[k] == Sentinel<T>::value) ? v[k] : x[k];
+            if(nowait && x[k] == Sentinel<T>::value) // (diagnostic, RAMD_TRSV_SF_GATHER=2: no dependency waits -- wrong results)
+                x[k] = (B)0;
+            full = full && (x[k] != Sentinel<T>::value);
+        }
         const unsigned long long ready = __ballot(full);
+        T                        prod[NA];
 #pragma unroll
         for(int k = 0; k < NA; ++k)
             prod[k] = a[k] * Sentinel<T>::from_bits(x[k]); // (a lane that is not complete holds NaNs here: nobody takes them)
@@ -411,78 +509,92 @@ __device__ __forceinline__ T sf_unit(const T* w, const int (&c)[kSfKW], const T 
         }
         else
             sf_pull_ready<T, LPR, NA, 0>(all, prod, nl, ready, done);
-        if(ready == ~0ull)
-            break;
-        __builtin_amdgcn_s_sleep(1);
+        return ready;
+    };
+    // Two generations of requests in flight, half a trip apart (pipe): a value that lands in memory is seen by the next request
+    // to pass there, and with one generation that is on average half a trip away, with two a quarter.  A generation is asked
+    // again the moment its answers have been looked at; the stagger of the start persists.
+    B   va[NA], vb[NA];
+    int spins = 0;
+    issue(va);
+    if(pipe)
+    {
+        for(int z = 0; z < stagger; ++z)
+            __builtin_amdgcn_s_sleep(1);
+        while(true)
+        {
+            spin_guard(spins);
+            issue(vb);
+            if(take(va) == ~0ull)
+                break;
+            issue(va);
+            if(take(vb) == ~0ull)
+                break;
+        }
     }
+    else
+    {
+#pragma unroll
+        for(int k = 0; k < NA; ++k)
+            vb[k] = (B)0;
+        while(take(va) != ~0ull)
+        {
+            spin_guard(spins);
+            __builtin_amdgcn_s_sleep(1);
+            issue(va);
+        }
+    }
+    unsigned long long d_w0 = 0, d_c0 = 0, d_c2 = 0;
     if(dbg)
     {
         d_w0 = wall_clock64();
         d_c0 = clock64();
     }
-    if constexpr(!INFIRST)
+    const int reslane = INFIRST ? 0 : nl - 1;
+    T         res;
+    if constexpr(DMODE == 1 && sizeof(T) == 8)
     {
-        const int gl0 = (slot - r) * LPR + nl - 1; // where the group's first row ends its chain
-        // in-group entries (the last ones of a row): row j of a group is final once the rows before it have been taken out of it
-#pragma unroll
-        for(int j = 0; j < kGrpMax; ++j)
+        // the divisions by the short sequence, unchecked; then ONE look at the rows' results: a quotient inside its window, by a
+        // divisor inside its own (rdg != 0), came from a dividend inside the window in which the short sequence IS the division
+        // (sf_div_short).  Otherwise -- a zero right-hand side, an overflowed sum, a tiny pivot -- the unit is done again with `/`.
+        res = sf_rounds<T, DMODE, INFIRST, LPR, NA, ONE, false>(sum, all, rhs, dg, rdg, gc, r, l, slot, nl, maxm);
+        if(__ballot(have && l == reslane && !sf_quotient_in_window(res)) != 0ull)
         {
-            if(j >= maxm)
-                break;
-            if(DMODE != 0)
-            {
-                const T q = DMODE == 1 ? sf_div(sum, dg, rdg, have && l == nl - 1 && r == j) : sum * dg;
-                sum       = (r == j) ? q : sum;
-            }
-            if(j < 7 && j + 1 < maxm)
-            {
-                const T yj = ONE ? sf_from_lane(sum, j * LPR + nl - 1) : __shfl(sum, gl0 + j * LPR, 64);
-                const T t  = sum - gc[j] * yj;
-                sum        = (r > j) ? t : sum;
-            }
+            res = sf_rounds<T, DMODE, INFIRST, LPR, NA, ONE, true>(sum, all, rhs, dg, rdg, gc, r, l, slot, nl, maxm);
+            if(dbg && (threadIdx.x & 63) == 0)
+                atomicAdd(dbg + 4 * nunits + 4, 1ull);
         }
-        return sum;
     }
     else
+        res = sf_rounds<T, DMODE, INFIRST, LPR, NA, ONE, true>(sum, all, rhs, dg, rdg, gc, r, l, slot, nl, maxm);
+    if(dbg)
     {
-    // in-group entries first: the rows of a group one after the other (nearest row first), each with its chain and its division.
-    // Five chains per node instead of one; a round's chain is a straight line of subtractions in the row's first lane, whose
-    // operands the waiting turns have brought there.  The result of a row is in its lane 0.
-    const int g0 = (slot - r) * LPR; // lane 0 of the group's first row
-    T         y[7];
-#pragma unroll
-    for(int j = 0; j < 7; ++j)
-        y[j] = (T)0;
-    T res = (T)0;
-#pragma unroll
-    for(int j = 0; j < kGrpMax; ++j)
+        asm volatile("" : "+v"(res));
+        d_c2 = clock64();
+    }
+    if(have && l == reslane)
     {
-        if(j >= maxm)
-            break;
-        T s = rhs;
-#pragma unroll
-        for(int i = 6; i >= 0; --i)
-            if(i < j)
-                s -= gc[i] * y[i];
-#pragma unroll
-        for(int q = 0; q < LPR; ++q)
+        publish(w + p, res);
+        if(out)
+            out[onat] = res;
+    }
+    if(dbg)
+    {
+        const unsigned long long t1 = wall_clock64(), c3 = clock64();
+        if((threadIdx.x & 63) == 0)
         {
-            if(q >= nl)
-                break;
-#pragma unroll
-            for(int k = 0; k < NA; ++k)
-                s -= all[q][k];
+            dbg[2 * (int64_t)u]     = d_w0;
+            dbg[2 * (int64_t)u + 1] = t1;
+            // cycles: dependencies seen -> (unused) | -> result final | -> publication issued
+            dbg[2 * nunits + 4 + 2 * (int64_t)u]     = (d_c2 - d_c0) << 32;
+            dbg[2 * nunits + 4 + 2 * (int64_t)u + 1] = c3 - d_c0;
         }
-        if(DMODE == 1)
-            s = sf_div(s, dg, rdg, have && l == 0 && r == j);
-        else if(DMODE == 2)
-            s = s * dg;
-        res = (r == j) ? s : res;
-        if(j < 7 && j + 1 < maxm)
-            y[j] = ONE ? sf_from_lane(s, j * LPR) : __shfl(s, g0 + j * LPR, 64);
     }
-    return res;
-    }
+    // the generation still in flight when the loop ended lands in these registers: they stay reserved until here, behind the
+    // publication, so that nothing on the way to it has to wait for answers nobody needs
+#pragma unroll
+    for(int k = 0; k < NA; ++k)
+        asm volatile("" ::"v"(va[k]), "v"(vb[k]));
 }
 
 // (Tried and removed, round 5: the waves of ONE XCD only -- every wave registers with the XCD its XCC_ID names, the XCD with most
@@ -496,7 +608,7 @@ __global__ __launch_bounds__(64) void k_trsv_sf(int nunits, const v4i32* __restr
                                                 const int* __restrict__ ecol, const T* __restrict__ eval,
                                                 const T* __restrict__ gcoef, const T* __restrict__ diag, const T* __restrict__ rdiag,
                                                 const T* __restrict__ rhs_src, const int* __restrict__ rhs_idx, T* w,
-                                                T* __restrict__ out, const int* __restrict__ order, int poll_cap, int nowait,
+                                                T* __restrict__ out, const int* __restrict__ order, int poll_cap, int flags, int stagger,
                                                 const int* __restrict__ ufar, unsigned long long* __restrict__ dbg, unsigned* tickets)
 {
     // Units are taken by TICKET, so that a wave only ever waits for units held by waves that are running -- whatever share of the
@@ -505,6 +617,7 @@ __global__ __launch_bounds__(64) void k_trsv_sf(int nunits, const v4i32* __restr
     // 128-byte lines), unit u belongs to stream u % kSfStreams, a wave is bound to the stream its START ticket names (the first
     // kSfStreams waves to run cover every stream) and asks for its next unit while it works on this one.
     // (dbg: RAMD_TRSV_SF_DBG, two timestamps per unit -- dependencies there, result published)
+    // flags: 1 = no dependency waits (diagnostic, wrong results), 2 = two generations of requests in flight
     const int lane = threadIdx.x, slot = lane / LPR, l = lane % LPR;
     if(dbg && blockIdx.x == 0 && lane == 0) // (shader clock against the 100 MHz counter: what a cycle is worth in this kernel)
     {
@@ -573,7 +686,7 @@ __global__ __launch_bounds__(64) void k_trsv_sf(int nunits, const v4i32* __restr
                 gc[j] = gcoef[(int64_t)p * 8 + j];
         }
         // one request per turn while the front is levels away
-        const int far = nowait ? -1 : __builtin_amdgcn_readfirstlane(ufar[u]);
+        const int far = (flags & 1) ? -1 : __builtin_amdgcn_readfirstlane(ufar[u]);
         if(far >= 0)
         {
             int spins = 0, backoff = 1;
@@ -583,18 +696,16 @@ __global__ __launch_bounds__(64) void k_trsv_sf(int nunits, const v4i32* __restr
                 backoff = poll_backoff(false, backoff, poll_cap);
             }
         }
-        unsigned long long d_w0 = 0, d_c0 = 0, d_c2 = 0;
-        T                  res;
         // (straight-line bodies for 2 / 3 / 4 / 6 subtractions per lane, one group or several: chosen per unit)
-#define SF_BODY(NA_)                                                                                                          \
-    do                                                                                                                        \
-    {                                                                                                                         \
-        if(one)                                                                                                               \
-            res = sf_unit<T, DMODE, INFIRST, LPR, NA_, true>(w, c, a, rhs, dg, rdg, gc, have, r, l, slot, nl, maxm, nowait != 0, \
-                                                             d_w0, d_c0, dbg != nullptr);                                     \
-        else                                                                                                                  \
-            res = sf_unit<T, DMODE, INFIRST, LPR, NA_, false>(w, c, a, rhs, dg, rdg, gc, have, r, l, slot, nl, maxm, nowait != 0, \
-                                                              d_w0, d_c0, dbg != nullptr);                                    \
+#define SF_BODY(NA_)                                                                                                               \
+    do                                                                                                                             \
+    {                                                                                                                              \
+        if(one)                                                                                                                    \
+            sf_unit<T, DMODE, INFIRST, LPR, NA_, true>(w, out, p, onat, p0, c, a, rhs, dg, rdg, gc, have, r, l, slot, nl, maxm, flags, \
+                                                       stagger, dbg, (int64_t)nunits, u);                                         \
+        else                                                                                                                       \
+            sf_unit<T, DMODE, INFIRST, LPR, NA_, false>(w, out, p, onat, p0, c, a, rhs, dg, rdg, gc, have, r, l, slot, nl, maxm, flags, \
+                                                        stagger, dbg, (int64_t)nunits, u);                                        \
     } while(0)
         if(kw <= 2)
             SF_BODY(2);
@@ -605,29 +716,6 @@ __global__ __launch_bounds__(64) void k_trsv_sf(int nunits, const v4i32* __restr
         else
             SF_BODY(kSfKW);
 #undef SF_BODY
-        if(dbg)
-        {
-            asm volatile("" : "+v"(res));
-            d_c2 = clock64();
-        }
-        if(have && l == (INFIRST ? 0 : nl - 1))
-        {
-            publish(w + p, res);
-            if(out)
-                out[onat] = res;
-        }
-        if(dbg)
-        {
-            const unsigned long long t1 = wall_clock64(), c3 = clock64();
-            if(lane == 0)
-            {
-                dbg[2 * (int64_t)u]     = d_w0;
-                dbg[2 * (int64_t)u + 1] = t1;
-                // cycles: dependencies seen -> (unused) | -> result final | -> publication issued
-                dbg[2 * (int64_t)nunits + 4 + 2 * (int64_t)u]     = (d_c2 - d_c0) << 32;
-                dbg[2 * (int64_t)nunits + 4 + 2 * (int64_t)u + 1] = c3 - d_c0;
-            }
-        }
     }
     if(dbg && blockIdx.x == 0 && lane == 0)
     {
@@ -645,6 +733,9 @@ int sf_run(const SfPlan* S, int n, int dm, const T* diag, T* w, const int* order
     static const int waves_env = getenv("RAMD_TRSV_SF_WAVES") ? atoi(getenv("RAMD_TRSV_SF_WAVES")) : 0; // (per CU; experiments)
     static const int cap_env   = getenv("RAMD_TRSV_SF_POLLCAP") ? atoi(getenv("RAMD_TRSV_SF_POLLCAP")) : 8;
     static const int gat_env   = getenv("RAMD_TRSV_SF_GATHER") ? atoi(getenv("RAMD_TRSV_SF_GATHER")) : 4; // (2: no waits, diagnostic)
+    // two generations of requests in flight per waiting unit, the second `stagger` x 64 cycles behind the first (0: one generation)
+    static const int stag_env  = getenv("RAMD_TRSV_SF_STAGGER") ? atoi(getenv("RAMD_TRSV_SF_STAGGER")) : 8;
+    const int        flags     = (gat_env == 2 ? 1 : 0) | (stag_env > 0 ? 2 : 0);
     // ticket words of the launch: [0] start tickets, [32 (1 + s)] units of stream s -- the plan's own, zeroed before every launch
     RAMD_HIP(hipMemsetAsync(S->tickets, 0, sizeof(unsigned) * 32 * (1 + kSfStreams), b.cur));
     unsigned nwg = 0;
@@ -653,8 +744,8 @@ int sf_run(const SfPlan* S, int n, int dm, const T* diag, T* w, const int* order
     unsigned long long* dbg      = nullptr;
     if(dbg_path)
     {
-        RAMD_HIP(hipMalloc(&dbg, sizeof(unsigned long long) * (4 * (size_t)S->nunits + 4)));
-        RAMD_HIP(hipMemsetAsync(dbg, 0, sizeof(unsigned long long) * (4 * (size_t)S->nunits + 4), b.cur));
+        RAMD_HIP(hipMalloc(&dbg, sizeof(unsigned long long) * (4 * (size_t)S->nunits + 12)));
+        RAMD_HIP(hipMemsetAsync(dbg, 0, sizeof(unsigned long long) * (4 * (size_t)S->nunits + 12), b.cur));
     }
 #define TRSV_SF(DM, INF, LP)                                                                                                  \
     do                                                                                                                        \
@@ -676,7 +767,7 @@ int sf_run(const SfPlan* S, int n, int dm, const T* diag, T* w, const int* order
         nwg               = (unsigned)(S->nunits < cap ? S->nunits : cap);                                                    \
         hipLaunchKernelGGL((k_trsv_sf<T, DM, INF, LP>), dim3(nwg), dim3(64), 0, b.cur, S->nunits, (const v4i32*)S->uinfo,     \
                            S->pinfo, S->ecol, (const T*)S->eval, (const T*)S->gcoef, diag, (const T*)S->rdiag, rhs_src, rhs_idx, \
-                           w, out, order, cap_env, gat_env == 2 ? 1 : 0, S->ufar, dbg, S->tickets);                           \
+                           w, out, order, cap_env, flags, stag_env, S->ufar, dbg, S->tickets);                                \
     } while(0)
 #define TRSV_SF_L(DM, INF)      \
     do                          \
@@ -708,7 +799,7 @@ int sf_run(const SfPlan* S, int n, int dm, const T* diag, T* w, const int* order
     RAMD_HIP(hipGetLastError());
     if(dbg)
     {
-        std::vector<unsigned long long> ht(4 * (size_t)S->nunits + 4);
+        std::vector<unsigned long long> ht(4 * (size_t)S->nunits + 12);
         std::vector<int>                hu(4 * (size_t)S->nunits), hp((size_t)n);
         RAMD_HIP(hipMemcpy(ht.data(), dbg, sizeof(unsigned long long) * ht.size(), hipMemcpyDeviceToHost));
         RAMD_HIP(hipMemcpy(hu.data(), S->uinfo, sizeof(int) * hu.size(), hipMemcpyDeviceToHost));
@@ -724,6 +815,8 @@ int sf_run(const SfPlan* S, int n, int dm, const T* diag, T* w, const int* order
             fwrite(hp.data(), sizeof(int), hp.size(), f);
             fwrite(ht.data() + 2 * (size_t)S->nunits, sizeof(unsigned long long), 4 + 2 * (size_t)S->nunits, f);
             fclose(f);
+            fprintf(stderr, "k_trsv_sf (%s): %llu wave-level divisions took `/` (outside the window of the short sequence), %d units\n",
+                    S->infirst ? "upper" : "lower", ht[4 * (size_t)S->nunits + 4], S->nunits);
         }
     }
     return RAMD_OK;

@@ -530,3 +530,33 @@ def test_red_black_sgs_kernel_keeps_its_loads_in_flight_across_the_barriers(tmp_
         assert loads >= 30, (name, loads)  # rhs, 1/d and two stages of eight arrays, for every cell a thread has
         waits = [int(w) for l in loop for w in re.findall(r"vmcnt\((\d+)\)", l)]
         assert waits and min(waits) >= 8, (name, waits)
+
+
+# ------------------------------------------------------------------ the reference's own 3-D operator (host restatement)
+def test_laplace27_host_generator_is_the_reference_loop():
+    from rocalution_amd import generators as gen
+    import numpy as np
+    """generators.laplace27 against a literal walk of the reference's three nested offset loops (utility.hpp:134-170)"""
+    nx, ny, nz = 4, 3, 5
+    rp, ci, va = gen.laplace27(nx, ny, nz)
+    cols, vals, ptr = [], [], [0]
+    for iz in range(nz):
+        for iy in range(ny):
+            for ix in range(nx):
+                row = iz * ny * nx + iy * nx + ix
+                for sz in (-1, 0, 1):
+                    if not (-1 < iz + sz < nz):
+                        continue
+                    for sy in (-1, 0, 1):
+                        if not (-1 < iy + sy < ny):
+                            continue
+                        for sx in (-1, 0, 1):
+                            if -1 < ix + sx < nx:
+                                col = row + sz * ny * nx + sy * nx + sx
+                                cols.append(col); vals.append(26.0 if col == row else -1.0)
+                ptr.append(len(cols))
+    assert np.array_equal(rp, ptr) and np.array_equal(ci, cols) and np.array_equal(va, vals)
+    rp, ci, va = gen.laplace27(6)
+    assert len(rp) - 1 == 216 and np.diff(rp).max() == 27 and np.diff(rp).min() == 8
+
+
