@@ -969,6 +969,7 @@ public:
         RAMD_CHECK(ramd_mat_apply_add(this->dev_, in.handle(), (double)scalar, out->handle()));
     }
     // ---- matrix utilities next to the solver path (local_matrix.cpp / host_matrix_csr.cpp:919-1160, :3465-3630)
+#ifdef RAMD_WITH_OFFSCOPE // (Gershgorin: out of scope)
     void Gershgorin(ValueType& lambda_min, ValueType& lambda_max) const
     {
         this->need_accel_("Gershgorin");
@@ -977,6 +978,7 @@ public:
         lambda_min = static_cast<ValueType>(lo);
         lambda_max = static_cast<ValueType>(hi);
     }
+#endif
     void ExtractL(LocalMatrix<ValueType>* L, bool diag) const
     {
         this->need_accel_("ExtractL");
@@ -1271,6 +1273,7 @@ public:
         RAMD_CHECK(ramd_mat_mat_mult(this->dev_, A.dev_, B.dev_));
     }
     // factorised sparse approximate inverse on the lower pattern of this matrix^power (this becomes the factor)
+#ifdef RAMD_WITH_OFFSCOPE // (FSAI: out of scope)
     void FSAI(int power, const LocalMatrix<ValueType>* pattern)
     {
         this->need_accel_("FSAI");
@@ -1281,12 +1284,15 @@ public:
         }
         RAMD_CHECK(ramd_mat_fsai(this->dev_, power));
     }
+#endif
     // sparse approximate inverse on the pattern of this matrix (this becomes M ~ A^-1)
+#ifdef RAMD_WITH_OFFSCOPE // (SPAI: out of scope)
     void SPAI(void)
     {
         this->need_accel_("SPAI");
         RAMD_CHECK(ramd_mat_spai(this->dev_));
     }
+#endif
     void DiagonalMatrixMultR(const LocalVector<ValueType>& diag)
     {
         this->need_accel_("DiagonalMatrixMultR");
@@ -1325,6 +1331,7 @@ public:
                                                aggregate_root_nodes->handle()));
     }
     // ---- Ruge-Stueben AMG setup: PMIS C/F splitting and direct interpolation (int vectors instead of bool)
+#ifdef RAMD_WITH_OFFSCOPE // (RSPMISCoarsening: out of scope)
     void RSPMISCoarsening(float eps, LocalVector<int>* CFmap, LocalVector<int>* S) const
     {
         this->need_accel_("RSPMISCoarsening");
@@ -1333,6 +1340,8 @@ public:
         S->MoveToAccelerator();
         RAMD_CHECK(ramd_mat_rs_pmis_coarsening(this->dev_, eps, CFmap->handle(), S->handle()));
     }
+#endif
+#ifdef RAMD_WITH_OFFSCOPE // (RSDirectInterpolation: out of scope)
     void RSDirectInterpolation(const LocalVector<int>& CFmap, const LocalVector<int>& S, LocalMatrix<ValueType>* prolong) const
     {
         this->need_accel_("RSDirectInterpolation");
@@ -1340,6 +1349,7 @@ public:
         prolong->MoveToAccelerator();
         RAMD_CHECK(ramd_mat_rs_direct_interpolation(this->dev_, CFmap.handle(), S.handle(), prolong->dev_));
     }
+#endif
     // the reference's default strategy: its sequential sweep restated as a sync-free device sweep with the same result;
     // needs a symmetric strong-connection graph
     void AMGGreedyAggregate(ValueType eps, LocalVector<int>* connections, LocalVector<int>* aggregates,

@@ -390,7 +390,9 @@ int ramd_fused_normalize(ramd_vec_t v, int slot_sq, int slot_norm);
  *   Scale / ScaleDiagonal / ScaleOffDiagonal (:3509-3568), AddScalar* (:3570-3630): which = 0 all, 1 the first
  *     stored diagonal entry of every row, 2 off-diagonal entries.
  *   UpdateValuesCSR: new values (host array of nnz entries) into the existing pattern. */
+#ifdef RAMD_WITH_OFFSCOPE /* out of scope: not in the default build of librocalution_amd.so */
 int ramd_mat_gershgorin(ramd_mat_t m, double* lambda_min, double* lambda_max);
+#endif
 int ramd_mat_extract_tri(ramd_mat_t m, ramd_mat_t out, int upper, int with_diag);
 /* CSR matrix algebra (host_matrix_csr.cpp): Sort :3812-3846 (stable, by column), Transpose(T) :3757-3806,
  * MatrixAdd :3324-3462 (this = alpha*this + beta*other; structure == 0: pattern of other is a subset; != 0: union
@@ -402,8 +404,10 @@ int ramd_mat_amg_pmis_aggregate(ramd_mat_t m, double eps, ramd_vec_t connections
                                 ramd_vec_t aggregate_root_nodes);
 /* Ruge-Stueben AMG (local_matrix.cpp RSPMISCoarsening / RSDirectInterpolation): C/F splitting by PMIS (cfmap: 1 coarse,
  * 2 fine; S: strong influences per entry) and direct interpolation */
+#ifdef RAMD_WITH_OFFSCOPE /* out of scope: not in the default build of librocalution_amd.so */
 int ramd_mat_rs_pmis_coarsening(ramd_mat_t m, float eps, ramd_vec_t cfmap, ramd_vec_t S);
 int ramd_mat_rs_direct_interpolation(ramd_mat_t m, ramd_vec_t cfmap, ramd_vec_t S, ramd_mat_t prolong);
+#endif
 /* AMGGreedyAggregate (local_matrix.cpp:6409-6517; host sweep host_matrix_csr.cpp:4841-4938), the reference's default
  * CoarseningStrategy: same aggregates as the sequential sweep; RAMD_ERR_UNSUPPORTED for a non-symmetric strength graph */
 int ramd_mat_amg_greedy_aggregate(ramd_mat_t m, double eps, ramd_vec_t connections, ramd_vec_t aggregates,
@@ -416,11 +420,15 @@ int ramd_mat_amg_smoothed_prolong(ramd_mat_t m, double relax, int lumping_strat,
                                   ramd_vec_t aggregates, ramd_vec_t aggregate_root_nodes, ramd_mat_t prolong);
 /* FSAI (host_matrix_csr.cpp:6514-6662): m becomes the factorised sparse approximate inverse factor on the lower pattern
  * of the operator's power (power >= 1: pattern of A^power, :6532-6538), or of a pattern matrix handed in */
+#ifdef RAMD_WITH_OFFSCOPE /* out of scope: not in the default build of librocalution_amd.so */
 int ramd_mat_fsai(ramd_mat_t m, int power);
 int ramd_mat_fsai_pattern(ramd_mat_t m, ramd_mat_t pattern); /* FSAI(power, pattern != NULL), :6525-6531 */
+#endif
 /* SPAI (host_matrix_csr.cpp:6665-6780): m becomes the sparse approximate inverse on its own pattern (per row a dense
  * least-squares problem solved by Householder QR, host_matrix_dense.cpp:361-520) */
+#ifdef RAMD_WITH_OFFSCOPE /* out of scope: not in the default build of librocalution_amd.so */
 int ramd_mat_spai(ramd_mat_t m);
+#endif
 int ramd_mat_diag_mult(ramd_mat_t m, ramd_vec_t diag, int left); /* DiagonalMatrixMultL (1) / R (0), :3631-3676 */
 int ramd_mat_sort(ramd_mat_t m);
 int ramd_mat_transpose(ramd_mat_t m, ramd_mat_t out);

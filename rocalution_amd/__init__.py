@@ -49,6 +49,14 @@ def sync():
     capi.check(_lib().ramd_sync())
 
 
+def _offscope(name):
+    """entry points outside SURVEY.md's scope exist only in a library built with -DRAMD_WITH_OFFSCOPE (capi.OPTIONAL)"""
+    if not capi.has(name):
+        raise NotImplementedError(name + ": out of scope (SURVEY.md section 2), not in the default build of librocalution_amd.so; "
+                                  "rebuild with RAMD_EXTRA_CXXFLAGS=-DRAMD_WITH_OFFSCOPE")
+    return getattr(_lib(), name)
+
+
 class LocalVector:
     """LocalVector<ValueType> resident on the accelerator (src/base/local_vector.hpp)."""
 
@@ -288,11 +296,11 @@ class LocalMatrix:
     def RSPMISCoarsening(self, eps):
         """-> (CFmap, S) int LocalVectors: 1 coarse / 2 fine per row, strong influence flag per entry"""
         cf, S = LocalVector(np.int32), LocalVector(np.int32)
-        capi.check(_lib().ramd_mat_rs_pmis_coarsening(self._h, C.c_float(eps), cf._h, S._h))
+        capi.check(_offscope("ramd_mat_rs_pmis_coarsening")(self._h, C.c_float(eps), cf._h, S._h))
         return cf, S
 
     def RSDirectInterpolation(self, CFmap, S, prolong):
-        capi.check(_lib().ramd_mat_rs_direct_interpolation(self._h, CFmap._h, S._h, prolong._h))
+        capi.check(_offscope("ramd_mat_rs_direct_interpolation")(self._h, CFmap._h, S._h, prolong._h))
 
     def AMGGreedyAggregate(self, eps):
         """-> (connections, aggregates, aggregate_root_nodes): the reference's sequential greedy sweep, same result"""
@@ -309,14 +317,14 @@ class LocalMatrix:
 
     def SPAI(self):
         """this becomes the sparse approximate inverse on its own pattern (host_matrix_csr.cpp:6665-6780)"""
-        capi.check(_lib().ramd_mat_spai(self._h))
+        capi.check(_offscope("ramd_mat_spai")(self._h))
 
     def FSAI(self, power=1, pattern=None):
         """this becomes the FSAI factor on the lower pattern of A^power, or of `pattern` (host_matrix_csr.cpp:6514-6662)"""
         if pattern is not None:
-            capi.check(_lib().ramd_mat_fsai_pattern(self._h, pattern._h))
+            capi.check(_offscope("ramd_mat_fsai_pattern")(self._h, pattern._h))
         else:
-            capi.check(_lib().ramd_mat_fsai(self._h, int(power)))
+            capi.check(_offscope("ramd_mat_fsai")(self._h, int(power)))
 
     def TripleMatrixProduct(self, R, A, P):
         tmp = LocalMatrix(self.dtype)
@@ -404,7 +412,7 @@ class LocalMatrix:
     def Gershgorin(self):
         """-> (lambda_min, lambda_max): Gershgorin bounds as the reference computes them (both start at 0)"""
         lo, hi = C.c_double(0), C.c_double(0)
-        capi.check(_lib().ramd_mat_gershgorin(self._h, C.byref(lo), C.byref(hi)))
+        capi.check(_offscope("ramd_mat_gershgorin")(self._h, C.byref(lo), C.byref(hi)))
         return lo.value, hi.value
 
     def ExtractL(self, out, diag):

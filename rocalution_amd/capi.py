@@ -143,8 +143,6 @@ SIGNATURES = {
     "ramd_mat_it_u_analyse_clear": (i32, [mat_t]),
     "ramd_mat_it_u_solve": (i32, [mat_t, i32, f64, i32, vec_t, vec_t]),
     "ramd_mat_amg_pmis_aggregate": (i32, [mat_t, f64, vec_t, vec_t, vec_t]),
-    "ramd_mat_rs_pmis_coarsening": (i32, [mat_t, C.c_float, vec_t, vec_t]),
-    "ramd_mat_rs_direct_interpolation": (i32, [mat_t, vec_t, vec_t, mat_t]),
     "ramd_mat_amg_greedy_aggregate": (i32, [mat_t, f64, vec_t, vec_t, vec_t]),
     "ramd_mat_amg_unsmoothed_prolong": (i32, [mat_t, vec_t, vec_t, mat_t]),
     "ramd_mat_amg_smoothed_prolong": (i32, [mat_t, f64, i32, vec_t, vec_t, vec_t, mat_t]),
@@ -152,15 +150,11 @@ SIGNATURES = {
     "ramd_mat_amg_pmis_aggregate_global": (i32, [mat_t, f64, ptr, i32, i32, pi32, pi64, pi64, vec_t, i64, vec_t, vec_t,
                                                  vec_t, vec_t, pi64, pi64, pi64]),
     "ramd_mat_amg_prolong_global": (i32, [mat_t, i32, f64, i32, vec_t, vec_t, vec_t, i64, mat_t]),
-    "ramd_mat_fsai": (i32, [mat_t, i32]),
-    "ramd_mat_fsai_pattern": (i32, [mat_t, mat_t]),
-    "ramd_mat_spai": (i32, [mat_t]),
     "ramd_mat_diag_mult": (i32, [mat_t, vec_t, i32]),
     "ramd_mat_sort": (i32, [mat_t]),
     "ramd_mat_transpose": (i32, [mat_t, mat_t]),
     "ramd_mat_matrix_add": (i32, [mat_t, mat_t, f64, f64, i32]),
     "ramd_mat_mat_mult": (i32, [mat_t, mat_t, mat_t]),
-    "ramd_mat_gershgorin": (i32, [mat_t, pf64, pf64]),
     "ramd_mat_extract_tri": (i32, [mat_t, mat_t, i32, i32]),
     "ramd_mat_scale_values": (i32, [mat_t, f64, i32]),
     "ramd_mat_add_scalar_values": (i32, [mat_t, f64, i32]),
@@ -273,6 +267,17 @@ SIGNATURES = {
     "ramd_gsolver_dot_check": (i32, [ptr, pf64]),
 }
 
+# entry points outside SURVEY.md's scope (SPAI / FSAI / Ruge-Stueben AMG / Gershgorin): only in a library built with
+# RAMD_EXTRA_CXXFLAGS=-DRAMD_WITH_OFFSCOPE (include/rocalution_amd.h keeps them behind the same macro); attached when exported
+OPTIONAL = {
+    "ramd_mat_rs_pmis_coarsening": (i32, [mat_t, C.c_float, vec_t, vec_t]),
+    "ramd_mat_rs_direct_interpolation": (i32, [mat_t, vec_t, vec_t, mat_t]),
+    "ramd_mat_fsai": (i32, [mat_t, i32]),
+    "ramd_mat_fsai_pattern": (i32, [mat_t, mat_t]),
+    "ramd_mat_spai": (i32, [mat_t]),
+    "ramd_mat_gershgorin": (i32, [mat_t, pf64, pf64]),
+}
+
 _lib = None
 
 
@@ -298,8 +303,18 @@ def load(build_if_missing=True):
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in OPTIONAL.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
     return lib
+
+
+def has(name):
+    """is this (optional) entry point in the library?"""
+    return hasattr(load(), name)
 
 
 def check(status):

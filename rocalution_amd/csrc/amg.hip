@@ -727,6 +727,7 @@ static int greedy_aggregate_t(ramd_mat_s* m, T eps, ramd_vec_s* vconn, ramd_vec_
     return RAMD_OK;
 }
 
+#ifdef RAMD_WITH_OFFSCOPE // (Ruge-Stueben AMG kernels: out of scope; built with RAMD_EXTRA_CXXFLAGS=-DRAMD_WITH_OFFSCOPE)
 // ---- Ruge-Stueben AMG, PMIS coarsening + direct interpolation (host_matrix_csr.cpp: hash :7060-7071,
 // RSPMISStrongInfluences :7074-7209, RSPMISUnassignedToCoarse :7212-7259, RSPMISCorrectCoarse :7262-7381,
 // RSPMISCoarseEdgesToFine :7384-7459, RSPMISCheckUndecided :7462-7487, RSDirectProlongNnz :7501-7660,
@@ -1104,6 +1105,7 @@ static int rs_direct_t(const ramd_mat_s* m, const ramd_vec_s* vcf, const ramd_ve
     return RAMD_OK;
 }
 
+#endif // RAMD_WITH_OFFSCOPE
 template <typename T>
 static int ua_prolong_t(const ramd_mat_s* m, const ramd_vec_s* vagg, const ramd_vec_s* vroots, ramd_mat_s* p,
                         int64_t global_ncol = -1)
@@ -1666,6 +1668,7 @@ int ramd_mat_amg_greedy_aggregate(ramd_mat_t m, double eps, ramd_vec_t connectio
     return greedy_aggregate_t<float>(m, (float)eps, connections, aggregates, aggregate_root_nodes);
 }
 
+#ifdef RAMD_WITH_OFFSCOPE // (Ruge-Stueben AMG: out of scope; built with RAMD_EXTRA_CXXFLAGS=-DRAMD_WITH_OFFSCOPE)
 int ramd_mat_rs_pmis_coarsening(ramd_mat_t m, float eps, ramd_vec_t cfmap, ramd_vec_t S)
 {
     if(!m || !cfmap || !S)
@@ -1692,6 +1695,7 @@ int ramd_mat_rs_direct_interpolation(ramd_mat_t m, ramd_vec_t cfmap, ramd_vec_t 
         return RAMD_OK;
     return (m->dtype == RAMD_F64) ? rs_direct_t<double>(m, cfmap, S, prolong) : rs_direct_t<float>(m, cfmap, S, prolong);
 }
+#endif // RAMD_WITH_OFFSCOPE
 
 int ramd_mat_amg_smoothed_prolong(ramd_mat_t m, double relax, int lumping_strat, ramd_vec_t connections,
                                   ramd_vec_t aggregates, ramd_vec_t aggregate_root_nodes, ramd_mat_t prolong)

@@ -46,6 +46,7 @@ __global__ __launch_bounds__(kBlock) void k_diag_mult(int nrow, const int* __res
             val[j] *= LEFT ? diag[i] : diag[ci[j]];
 }
 
+#ifdef RAMD_WITH_OFFSCOPE // (FSAI / SPAI kernels: out of scope; built with RAMD_EXTRA_CXXFLAGS=-DRAMD_WITH_OFFSCOPE)
 // ---- FSAI(1) factor (host_matrix_csr.cpp:6514-6662): for every row the dense system of the operator restricted to the
 // row's lower pattern is factorised (in-place LU without pivoting, the host's loop order) and solved for the last unit
 // vector; the row is then scaled by sqrt(1 / |last entry|).  One thread per row, dense scratch in device memory.
@@ -318,6 +319,7 @@ __global__ __launch_bounds__(kBlock) void k_spai_rows(int r0, int r1, const int*
     }
 }
 
+#endif // RAMD_WITH_OFFSCOPE
 // ---- MatrixAdd, pattern of `mat` a subset of this (structure == false): this = alpha*this + beta*mat on the matches
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_add_subset(int nrow, const int* __restrict__ rp, const int* __restrict__ ci,
@@ -1346,6 +1348,7 @@ int ramd_mat_sort(ramd_mat_t m)
     return RAMD_OK;
 }
 
+#ifdef RAMD_WITH_OFFSCOPE // (FSAI / SPAI: out of scope; built with RAMD_EXTRA_CXXFLAGS=-DRAMD_WITH_OFFSCOPE)
 static int fsai_impl(ramd_mat_t m, int power, ramd_mat_t pattern);
 
 int ramd_mat_fsai(ramd_mat_t m, int power)
@@ -1544,6 +1547,7 @@ int ramd_mat_spai(ramd_mat_t m)
     ramd_mat_destroy(AT);
     return s;
 }
+#endif // RAMD_WITH_OFFSCOPE
 
 int ramd_mat_diag_mult(ramd_mat_t m, ramd_vec_t diag, int left)
 {

@@ -143,6 +143,7 @@ using namespace ramd;
 
 extern "C" {
 
+#ifdef RAMD_WITH_OFFSCOPE // (Gershgorin: out of scope; built with RAMD_EXTRA_CXXFLAGS=-DRAMD_WITH_OFFSCOPE)
 int ramd_mat_gershgorin(ramd_mat_t m, double* lambda_min, double* lambda_max)
 {
     NEED_CSR(m, "Gershgorin");
@@ -196,6 +197,7 @@ int ramd_mat_gershgorin(ramd_mat_t m, double* lambda_min, double* lambda_max)
     *lambda_max = mx;
     return RAMD_OK;
 }
+#endif // RAMD_WITH_OFFSCOPE
 
 int ramd_mat_extract_tri(ramd_mat_t m, ramd_mat_t out, int upper, int with_diag)
 {

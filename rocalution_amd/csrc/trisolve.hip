@@ -276,15 +276,18 @@ __global__ __launch_bounds__(kBlock) void k_trsv(int nrow, const int* __restrict
         bool progress = true;
         if(!fin)
         {
+            // (every request of the attempt is issued before the first answer is looked at: a slot without an entry asks for
+            //  the row's own position, whose answer nobody reads.  With a test around every request -- rounds 1 to 5 -- the
+            //  compiler waited for each answer before the next request: kDepChunk trips through memory per attempt, not one.)
             typename Sentinel<T>::bits bits[kDepChunk];
-            bool                       all = true;
 #pragma unroll
             for(int e = 0; e < kDepChunk; ++e)
-                if(c[e] >= 0)
-                {
-                    bits[e] = poll_load(w + c[e]);
-                    all     = all && (bits[e] != Sentinel<T>::value);
-                }
+                bits[e] = poll_load(w + (c[e] >= 0 ? (int64_t)c[e] : t));
+            __builtin_amdgcn_sched_barrier(0);
+            bool all = true;
+#pragma unroll
+            for(int e = 0; e < kDepChunk; ++e)
+                all = all && (c[e] < 0 || bits[e] != Sentinel<T>::value);
             if(all)
             {
 #pragma unroll

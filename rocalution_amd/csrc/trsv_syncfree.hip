@@ -398,43 +398,48 @@ __device__ __forceinline__ T sf_rounds(T sum, const T (&all)[INFIRST ? LPR : 1][
     else
     {
         const int g0 = (slot - r) * LPR; // lane 0 of the group's first row
-        T         y[7];
-#pragma unroll
-        for(int j = 0; j < 7; ++j)
-            y[j] = (T)0;
+        // gyI = gc[I] * y_I, the in-group term of the rows after row I: formed once, when y_I is there (the same product every
+        // later round would form).  Seven named values, not an array: an array that lives across the early exits of the rounds
+        // travels through them as ONE register tuple, a dozen moves per round (seen in the ISA of round 6's first version).
+        T gy0 = (T)0, gy1 = (T)0, gy2 = (T)0, gy3 = (T)0, gy4 = (T)0, gy5 = (T)0, gy6 = (T)0;
         T res = (T)0;
-#pragma unroll
-        for(int j = 0; j < kGrpMax; ++j)
-        {
-            if(j >= maxm)
-                break;
-            T s = rhs;
-#pragma unroll
-            for(int i = 6; i >= 0; --i)
-                if(i < j)
-                    s -= gc[i] * y[i];
-            // (two lanes of products per test: a lane beyond nl holds +0 products, and s - (+0) is s -- half the tests of a walk
-            //  lane by lane; one wave runs a unit and issues every instruction in order, tests included)
-#pragma unroll
-            for(int q = 0; q < LPR; q += 2)
-            {
-                if(q >= nl)
-                    break;
-#pragma unroll
-                for(int k = 0; k < NA; ++k)
-                    s -= all[q][k];
-#pragma unroll
-                for(int k = 0; k < NA; ++k)
-                    s -= all[q + 1][k];
-            }
-            if(DMODE == 1)
-                s = EXACT ? s / dg : sf_div_short(s, dg, rdg);
-            else if(DMODE == 2)
-                s = s * dg;
-            res = (r == j) ? s : res;
-            if(j < 7 && j + 1 < maxm)
-                y[j] = ONE ? sf_from_lane(s, j * LPR) : __shfl(s, g0 + j * LPR, 64);
-        }
+#define SF_ROUND(J, INGROUP, KEEP)                                                                         \
+    if((J) < maxm)                                                                                         \
+    {                                                                                                      \
+        T s = rhs;                                                                                         \
+        INGROUP;                                                                                           \
+        _Pragma("unroll") for(int q = 0; q < LPR; q += 2)                                                  \
+        {                                                                                                  \
+            if(q >= nl)                                                                                    \
+                break;                                                                                     \
+            _Pragma("unroll") for(int k = 0; k < NA; ++k) s -= all[q][k];                                  \
+            _Pragma("unroll") for(int k = 0; k < NA; ++k) s -= all[q + 1][k];                              \
+        }                                                                                                  \
+        if(DMODE == 1)                                                                                     \
+            s = EXACT ? s / dg : sf_div_short(s, dg, rdg);                                                 \
+        else if(DMODE == 2)                                                                                \
+            s = s * dg;                                                                                    \
+        res = (r == (J)) ? s : res;                                                                        \
+        if((J) < 7 && (J) + 1 < maxm)                                                                      \
+        {                                                                                                  \
+            const T yj = ONE ? sf_from_lane(s, (J) * LPR) : __shfl(s, g0 + (J) * LPR, 64);                 \
+            KEEP = gc[(J) < 7 ? (J) : 0] * yj;                                                             \
+        }                                                                                                  \
+    }
+        // (two lanes of products per test: a lane beyond nl holds +0 products, and s - (+0) is s -- half the tests of a walk lane
+        //  by lane; one wave runs a unit and issues every instruction in order, tests included.  The in-group terms nearest row
+        //  first: the order of the host loop, ascending columns.)
+        T unused = (T)0;
+        SF_ROUND(0, (void)0, gy0)
+        SF_ROUND(1, s -= gy0, gy1)
+        SF_ROUND(2, s -= gy1; s -= gy0, gy2)
+        SF_ROUND(3, s -= gy2; s -= gy1; s -= gy0, gy3)
+        SF_ROUND(4, s -= gy3; s -= gy2; s -= gy1; s -= gy0, gy4)
+        SF_ROUND(5, s -= gy4; s -= gy3; s -= gy2; s -= gy1; s -= gy0, gy5)
+        SF_ROUND(6, s -= gy5; s -= gy4; s -= gy3; s -= gy2; s -= gy1; s -= gy0, gy6)
+        SF_ROUND(7, s -= gy6; s -= gy5; s -= gy4; s -= gy3; s -= gy2; s -= gy1; s -= gy0, unused)
+#undef SF_ROUND
+        (void)unused;
         return res;
     }
 }
@@ -734,7 +739,9 @@ int sf_run(const SfPlan* S, int n, int dm, const T* diag, T* w, const int* order
     static const int cap_env   = getenv("RAMD_TRSV_SF_POLLCAP") ? atoi(getenv("RAMD_TRSV_SF_POLLCAP")) : 8;
     static const int gat_env   = getenv("RAMD_TRSV_SF_GATHER") ? atoi(getenv("RAMD_TRSV_SF_GATHER")) : 4; // (2: no waits, diagnostic)
     // two generations of requests in flight per waiting unit, the second `stagger` x 64 cycles behind the first (0: one generation)
-    static const int stag_env  = getenv("RAMD_TRSV_SF_STAGGER") ? atoi(getenv("RAMD_TRSV_SF_STAGGER")) : 8;
+    // (measured on the RCM shell, lower / upper ms per triangle: 0: 2.95 / 4.38, 2 to 8: 2.91 / 4.55, 24: 3.02 / 4.54 -- what the
+    //  second generation gains in phase it loses in the consumer CU's memory queue; off by default)
+    static const int stag_env  = getenv("RAMD_TRSV_SF_STAGGER") ? atoi(getenv("RAMD_TRSV_SF_STAGGER")) : 0;
     const int        flags     = (gat_env == 2 ? 1 : 0) | (stag_env > 0 ? 2 : 0);
     // ticket words of the launch: [0] start tickets, [32 (1 + s)] units of stream s -- the plan's own, zeroed before every launch
     RAMD_HIP(hipMemsetAsync(S->tickets, 0, sizeof(unsigned) * 32 * (1 + kSfStreams), b.cur));

@@ -13,8 +13,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HDR = os.path.join(ROOT, "include", "rocalution_amd.h")
 
 
-def _declared():
-    return set(re.findall(r"\b(ramd_[a-z0-9_]+)\s*\(", open(HDR).read())) - {"ramd_exchange_cb", "ramd_allreduce_cb"}
+def _declared(offscope=False):
+    """entry points the header declares; the blocks behind RAMD_WITH_OFFSCOPE (SPAI / FSAI / RS-AMG / Gershgorin: out of
+    scope, not in the default build) only on request"""
+    text = open(HDR).read()
+    blocks = re.findall(r"#ifdef RAMD_WITH_OFFSCOPE.*?#endif", text, flags=re.S)
+    if offscope:
+        text = "\n".join(blocks)
+    else:
+        for b in blocks:
+            text = text.replace(b, "")
+    return set(re.findall(r"\b(ramd_[a-z0-9_]+)\s*\(", text)) - {"ramd_exchange_cb", "ramd_allreduce_cb"}
 
 
 def test_abi_header_library_and_ctypes_table_agree():
@@ -22,7 +31,11 @@ def test_abi_header_library_and_ctypes_table_agree():
     lib = build.build()
     out = subprocess.check_output(["nm", "-D", "--defined-only", lib]).decode()
     exported = set(re.findall(r" T (ramd_[a-z0-9_]+)", out))
-    declared = _declared()
+    declared, optional = _declared(), _declared(offscope=True)
+    assert set(capi.OPTIONAL) == optional and not (optional & declared)
+    if exported & optional:  # a library built with -DRAMD_WITH_OFFSCOPE exports all of them
+        assert optional <= exported
+        exported -= optional
     assert declared == exported, (sorted(declared - exported), sorted(exported - declared))
     assert set(capi.SIGNATURES) == declared
     capi.load()  # dlopen + every prototype attached

@@ -21,6 +21,17 @@ def ra():
     return ra
 
 
+def _capi():
+    from rocalution_amd import capi
+    return capi
+
+
+def _need_offscope(symbol):
+    """SPAI / FSAI / RS-AMG / Gershgorin are outside SURVEY.md's scope and behind RAMD_WITH_OFFSCOPE since round 6"""
+    if not _capi().has(symbol):
+        pytest.skip(symbol + " is not in the default build (RAMD_EXTRA_CXXFLAGS=-DRAMD_WITH_OFFSCOPE)")
+
+
 def eq(a, b):
     a, b = np.asarray(a), np.asarray(b)
     assert a.shape == b.shape
@@ -189,6 +200,7 @@ def test_csr_matrix_algebra_vs_golden(ra, name):
 def test_spai_matrix_vs_golden(ra, name):
     """SPAI: per-row least squares by Householder QR on the device -- pattern identical, values identical on the
     integer-valued operators and within 1e-13 on the random ones"""
+    _need_offscope("ramd_mat_spai")
     g = load_golden(name)
     A = _mat(ra, g)
     A.SPAI()
@@ -258,6 +270,7 @@ def test_ilup_thread_per_row_path_in_a_fresh_process():
 
 def test_fsai_factor_vs_golden(ra):
     """FSAI(1): per-row dense LU on the lower pattern and the scaling -- factor arrays identical to the genuine library"""
+    _need_offscope("ramd_mat_fsai")
     for name in ("gr3030", "poisson8", "lap2d7"):
         g = load_golden(name)
         A = _mat(ra, g)
@@ -311,13 +324,15 @@ def test_amg_pmis_aggregation_vs_golden(ra, name):
     # the default strategy: the reference's sequential greedy sweep, restated as a sync-free device sweep
     gconn, gagg, groots = A.AMGGreedyAggregate(0.01)
     eq(gconn.numpy(), g["amg_conn"]); eq(gagg.numpy(), g["amg_gagg"]); eq(groots.numpy(), g["amg_groots"])
-    # classical AMG: PMIS C/F splitting (hash + strong in-degree weights) and direct interpolation
-    cf, S_ = A.RSPMISCoarsening(0.25)
-    eq(cf.numpy(), g["rs_cf"]); eq(S_.numpy(), g["rs_S"])
-    Prs = ra.LocalMatrix()
-    A.RSDirectInterpolation(cf, S_, Prs)
-    rp, ci, va = Prs.CopyToCSR()
-    eq(rp, g["rs_P_rowptr"]); eq(ci, g["rs_P_col"]); eq(va, g["rs_P_val"])
+    # classical AMG: PMIS C/F splitting (hash + strong in-degree weights) and direct interpolation (out of scope: only in a
+    # library built with -DRAMD_WITH_OFFSCOPE)
+    if _capi().has("ramd_mat_rs_pmis_coarsening"):
+        cf, S_ = A.RSPMISCoarsening(0.25)
+        eq(cf.numpy(), g["rs_cf"]); eq(S_.numpy(), g["rs_S"])
+        Prs = ra.LocalMatrix()
+        A.RSDirectInterpolation(cf, S_, Prs)
+        rp, ci, va = Prs.CopyToCSR()
+        eq(rp, g["rs_P_rowptr"]); eq(ci, g["rs_P_col"]); eq(va, g["rs_P_val"])
     # smoothed aggregation: (I - relax D_f^-1 A_f) P_tent, both lumping strategies
     for key, relax, lump in (("amg_Ps", 2.0 / 3.0, 0), ("amg_Ps1", 0.5, 1)):
         Ps = ra.LocalMatrix()
@@ -816,8 +831,9 @@ def test_matrix_utilities_vs_host_loops(ra, dtype):
             else:
                 d = va[j]
         hi = max(hi, dtype(s + d)); lo = min(lo, dtype(d - s))
-    glo, ghi = A.Gershgorin()
-    assert (glo, ghi) == (float(lo), float(hi))
+    if _capi().has("ramd_mat_gershgorin"):  # (out of scope: only in a library built with -DRAMD_WITH_OFFSCOPE)
+        glo, ghi = A.Gershgorin()
+        assert (glo, ghi) == (float(lo), float(hi))
     # triangular parts
     for upper, diag in ((0, 0), (0, 1), (1, 0), (1, 1)):
         T = ra.LocalMatrix(dtype)
