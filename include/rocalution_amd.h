@@ -176,7 +176,7 @@ int ramd_mat_apply(ramd_mat_t m, ramd_vec_t x, ramd_vec_t y);
 int ramd_mat_apply_add(ramd_mat_t m, ramd_vec_t x, double scalar, ramd_vec_t y);
 /* what the CSR product learned about the matrix on its first call (no reference counterpart): state 0 = not analysed yet,
  * 1 = the rows fall into `entries` patterns of column offsets (col - row) of at most `width` entries, the kernel rebuilds the
- * columns from one byte per row; -1 = not structured (too many patterns or rows longer than 16): columns are read;
+ * columns from one byte per row; -1 = not structured (too many patterns or rows longer than 28): columns are read;
  * 2 = no dictionary, but most rows carry the column list of the row before them (the unknowns of one mesh node of an FE
  * matrix): only the first row of such a group has its columns read */
 int ramd_mat_pattern_info(ramd_mat_t m, int* state, int* entries, int* width);

@@ -190,6 +190,8 @@ struct ramd_mat_s
     void* tri      = nullptr; // ramd::TriState* (level-ordered solve plans), trisolve.hip
     // workspace of the fused CSR SpMV + <x,y> (spmv.hip)
     int     band_dist = -1; // far-band distance in rows for the band-aware traversal (-1 unknown, 0 none)
+    int     shift_rows = -1; // 1: most rows carry the columns of the row before them shifted by one (a stencil: gathers of
+                             // consecutive rows fall on consecutive elements of x); 0: not; -1 unknown (csr_analyse_shift)
     // row patterns of the CSR SpMV (spmv.hip, csr_analyse_pattern): rows whose column offsets col - row coincide share a
     // dictionary entry, and the kernel rebuilds the columns from one byte per row instead of reading 4 bytes per entry
     int            pat_state = 0; // 0 unknown, 1 usable, -1 not usable (too many patterns / rows too long)

@@ -50,6 +50,7 @@ void mat_free_analysis(ramd_mat_s* m)
     dev_free(&m->dot_part1);
     m->dot_nblk  = 0;
     m->band_dist = -1;
+    m->shift_rows = -1;
     dev_free(&m->pat_id);
     dev_free(&m->pat_dict);
     dev_free(&m->blk_rp);
@@ -406,6 +407,7 @@ int ramd_mat_clone(ramd_mat_t src, ramd_mat_t* out)
         dup_i(&m->coo_gptr, src->coo_gptr, (int64_t)src->coo_ngroups + 1);
     }
     m->band_dist = src->band_dist;
+    m->shift_rows = src->shift_rows;
     if(s != RAMD_OK)
     {
         ramd_mat_destroy(m);

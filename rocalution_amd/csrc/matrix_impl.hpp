@@ -16,8 +16,9 @@ int    mat_alloc_csr(ramd_mat_s* m, int nrow, int ncol, int64_t nnz);
 // spmv.hip: detect a far band (3-D stencil plane distance) for the band-aware row-block traversal
 int csr_analyse_band(ramd_mat_s* m);
 int csr_analyse_groups(ramd_mat_s* m);
+int csr_analyse_shift(ramd_mat_s* m); // rows that are their predecessor shifted by one column (stencils): ramd_mat_s::shift_rows
 // row patterns (spmv.hip): rows whose column offsets col - row coincide share a dictionary entry of kPatMaxW slots
-constexpr int kPatMaxW = 16; // longest row a pattern may have
+constexpr int kPatMaxW = 28; // longest row a pattern may have (round 6: the 27 entries of the reference's own 3-D operator; 16 before)
 constexpr int kPatMax  = 64; // dictionary entries
 constexpr int kPatEnd  = -2147483647 - 1; // dictionary entry of an ELL slot that holds no column (col < 0)
 // x tiles of a structured CSR product (spmv.hip, k_csr_xl): the distinct column offsets of the dictionary fall into a few

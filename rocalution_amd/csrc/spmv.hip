@@ -82,8 +82,11 @@ struct CsrDotWs
 // pass k + 1 are requested before the rows of pass k are walked and wait in registers meanwhile.  Measured slower (0.173
 // against 0.154-0.159 ms on the config-3 surrogate): the waves of the other five workgroups of the CU already cover that
 // latency, and the held packets cost registers.
-template <typename T, int MODE, bool DOT, bool PAT, bool GRP = false, bool PIPE = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PAT ? RAMD_CSR_PAT_WAVES : 6, 8))) void k_csr_tr(int nrow, int nblk, int per_xcd,
+// CHK: entries per LDS pass.  kCsrChunk (2048) holds the 256 rows of a block when they are short; the rows of a 27-point stencil
+// (6 912 entries per block) took 3.4 passes of it, a quarter of the rows walking while the others stand at the barrier -- the
+// long-row instantiations stage 4096 or (row patterns: no columns in LDS) 8192 entries per pass.
+template <typename T, int MODE, bool DOT, bool PAT, bool GRP = false, bool PIPE = false, int CHK = kCsrChunk>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHK > kCsrChunk ? 2 : (PAT ? RAMD_CSR_PAT_WAVES : 6), 8))) void k_csr_tr(int nrow, int nblk, int per_xcd,
                                                    const int* __restrict__ rp,
                                                    const int* __restrict__ ci,
                                                    const T* __restrict__ val,
@@ -93,8 +96,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PAT ? RA
 {
     using VP          = typename ValPk<T>::type;
     constexpr int VN  = ValPk<T>::N;
-    __shared__ T      sval[kCsrChunk];
-    __shared__ int    scol[PAT ? kPatMax * kPatMaxW : kCsrChunk]; // PAT: the dictionary of column offsets instead
+    __shared__ T      sval[CHK];
+    __shared__ int    scol[PAT ? kPatMax * kPatMaxW : CHK]; // PAT: the dictionary of column offsets instead
     const int blk  = xcd_block(nblk, per_xcd, bm);
     double    dacc = 0.0;
     if(blk >= 0)
@@ -131,18 +134,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PAT ? RA
         bool have_xrow = false;
         if(MODE == 1 && row < nrow)
             sum = y[row];
-        v4i32 c[kCsrChunk / (4 * kBlock)];
-        VP    a[kCsrChunk / (VN * kBlock)];
+        v4i32 c[CHK / (4 * kBlock)];
+        VP    a[CHK / (VN * kBlock)];
         auto  request = [&](int cb) { // the packets of the pass that starts at entry cb
 #pragma unroll
-            for(int k = 0; k < (PAT ? 0 : kCsrChunk / (4 * kBlock)); ++k)
+            for(int k = 0; k < (PAT ? 0 : CHK / (4 * kBlock)); ++k)
             {
                 const int j = cb + (k * kBlock + threadIdx.x) * 4;
                 if(j < end && (!GRP || grp.need[j >> 2]))
                     c[k] = nt_load(reinterpret_cast<const v4i32*>(ci + j));
             }
 #pragma unroll
-            for(int k = 0; k < kCsrChunk / (VN * kBlock); ++k)
+            for(int k = 0; k < CHK / (VN * kBlock); ++k)
             {
                 const int j = cb + (k * kBlock + threadIdx.x) * VN;
                 if(j < end)
@@ -151,28 +154,28 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PAT ? RA
         };
         if(PIPE)
             request(start & ~3);
-        for(int cb = start & ~3; cb < end; cb += kCsrChunk)
+        for(int cb = start & ~3; cb < end; cb += CHK)
         {
             if(!PIPE)
                 request(cb);
 #pragma unroll
-            for(int k = 0; k < (PAT ? 0 : kCsrChunk / (4 * kBlock)); ++k)
+            for(int k = 0; k < (PAT ? 0 : CHK / (4 * kBlock)); ++k)
             {
                 const int g = (k * kBlock + threadIdx.x) * 4;
                 if(cb + g < end)
                     *reinterpret_cast<v4i32*>(scol + g) = c[k];
             }
 #pragma unroll
-            for(int k = 0; k < kCsrChunk / (VN * kBlock); ++k)
+            for(int k = 0; k < CHK / (VN * kBlock); ++k)
             {
                 const int g = (k * kBlock + threadIdx.x) * VN;
                 if(cb + g < end)
                     *reinterpret_cast<VP*>(sval + g) = a[k];
             }
             __syncthreads();
-            if(PIPE && cb + kCsrChunk < end)
-                request(cb + kCsrChunk);
-            const int lo = max(rs, cb), hi = min(re, cb + kCsrChunk);
+            if(PIPE && cb + CHK < end)
+                request(cb + CHK);
+            const int lo = max(rs, cb), hi = min(re, cb + CHK);
             // masked batches of kGatherW entries: all gathers of a batch are issued before the first use,
             // the products are added IN ORDER.  (A row of 7 used to cost one batch of 4 plus three
             // one-by-one gathers = 4 dependent L2 round trips; now it is one batch.)
@@ -990,6 +993,137 @@ __global__ __launch_bounds__(64 * NWV) void k_csr_w4(int nrow, int nblk, int per
     }
 }
 
+// CSR SpMV for rows of 16+ entries, products formed WHERE THE PACKETS LAND (k_csr_wp, round 6).  k_csr_w4 on the reference's own
+// 3-D operator (27 entries per row, 256^3): 1.42 ms = 0.50 of the roofline, behind the vendor's csrmv (1.14 ms) -- a quad walks
+// its row in three dependent rounds (LDS read -> gather -> broadcast sum) and sixteen rows are all a pass holds.  Here a lane
+// keeps the packets it loads: four consecutive entries (one column packet, the value packets over them), four gathers of x, four
+// products -- every gather of a 1024-entry pass independent of every other, issued back to back -- and only the PRODUCTS pass
+// through the wave's piece of LDS (8 bytes per entry instead of 12).  Lane t then sums row t of the wave from LDS, left to
+// right in storage order: the additions of the host loop, bit-identical; the sum ends in the lane that stores it.  A wave owns
+// its 64 rows from the first packet to the store, no workgroup barrier (as k_csr_w4).
+constexpr int kWpChunk = 1024; // entries per wave and pass
+template <typename T, int MODE, bool DOT, int NWV>
+__global__ __launch_bounds__(64 * NWV) void k_csr_wp(int nrow, int nblk, int per_xcd, const int* __restrict__ rp,
+                                                   const int* __restrict__ ci, const T* __restrict__ val,
+                                                   const T* __restrict__ x, T* __restrict__ y, T scalar, CsrDotWs ws,
+                                                   int slot, BandMap bm)
+{
+    using VP          = typename ValPk<T>::type;
+    constexpr int VN  = ValPk<T>::N; // values per 16-byte packet (2 or 4)
+    constexpr int CH  = kWpChunk;
+    constexpr int NCP = CH / 4 / 64; // column packets (4 entries each) per lane and pass
+    constexpr int VPC = 4 / VN; // value packets over one column packet
+    constexpr int SB  = 8; // products a lane reads ahead of its additions
+    __shared__ __attribute__((aligned(16))) T sprod[NWV][CH];
+    const int blk  = xcd_block(nblk, per_xcd, bm);
+    double    dacc = 0.0;
+    if(blk >= 0)
+    {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const int wbase = (blk * NWV + wave) * 64;
+        T*        sp    = sprod[wave];
+        if(wbase < nrow) // (wave-uniform)
+        {
+            const int row = wbase + lane;
+            int       rs = 0, re = 0;
+            if(row < nrow)
+            {
+                rs = rp[row];
+                re = rp[row + 1];
+            }
+            const int last = min(63, nrow - 1 - wbase);
+            const int S    = __builtin_amdgcn_readlane(rs, 0);
+            const int E    = __shfl(re, last, 64);
+            if(row >= nrow)
+                rs = re = E;
+            T sum = (MODE == 1 && row < nrow) ? y[row] : (T)0;
+            for(int cb = S & ~3; cb < E; cb += CH)
+            {
+                // (no test around a request: a packet behind the wave's last entry asks for the pass's first packet instead, an
+                //  entry behind it gathers x[0] -- requests in a straight line, nothing waits for anything before the products)
+                v4i32 c[NCP];
+                VP    a[NCP][VPC];
+                T     xv[NCP][4];
+#pragma unroll
+                for(int k = 0; k < NCP; ++k)
+                {
+                    const int g  = cb + (k * 64 + lane) * 4;
+                    const int gl = g < E ? g : cb;
+                    c[k]         = nt_load(reinterpret_cast<const v4i32*>(ci + gl));
+#pragma unroll
+                    for(int h = 0; h < VPC; ++h)
+                        a[k][h] = nt_load(reinterpret_cast<const VP*>(val + gl + h * VN));
+                }
+#pragma unroll
+                for(int k = 0; k < NCP; ++k)
+                {
+                    const int g = cb + (k * 64 + lane) * 4;
+#pragma unroll
+                    for(int i = 0; i < 4; ++i)
+                        xv[k][i] = x[g + i < E ? c[k][i] : 0]; // (an entry behind the wave's last one may lie behind the matrix' last one)
+                }
+#pragma unroll
+                for(int k = 0; k < NCP; ++k)
+                {
+                    const int g = cb + (k * 64 + lane) * 4;
+                    if(g < E)
+                    {
+#pragma unroll
+                        for(int h = 0; h < VPC; ++h)
+                        {
+                            VP pr;
+#pragma unroll
+                            for(int i = 0; i < VN; ++i)
+                                pr[i] = (MODE != 1) ? a[k][h][i] * xv[k][h * VN + i] : scalar * a[k][h][i] * xv[k][h * VN + i];
+                            *reinterpret_cast<VP*>(sp + (g - cb) + h * VN) = pr;
+                        }
+                    }
+                }
+                // (one wave: its LDS operations complete in order; the barrier only keeps the compiler from moving reads up)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const int lo = max(rs, cb), hi = min(re, cb + CH);
+                for(int j = lo; j < hi; j += SB)
+                {
+                    T p[SB];
+#pragma unroll
+                    for(int e = 0; e < SB; ++e)
+                        p[e] = sp[min(j + e, hi - 1) - cb];
+#pragma unroll
+                    for(int e = 0; e < SB; ++e)
+                    {
+                        const T t = sum + p[e];
+                        sum       = (j + e < hi) ? t : sum; // (a select, not an addition of zero: -0 + +0 is +0)
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier(); // the next pass overwrites what this one read
+            }
+            if(row < nrow)
+            {
+                T xrow = (T)0;
+                if((DOT && !ws.dotv) || MODE == 2)
+                    xrow = x[row];
+                if(MODE == 2)
+                {
+                    T t = (T)(-1) * sum + static_cast<const T*>(ws.jrhs)[row];
+                    t   = static_cast<const T*>(ws.jdinv)[row] * t;
+                    sum = xrow + scalar * t;
+                }
+                nt_store(sum, y + row);
+                if(DOT)
+                    dacc = (double)sum * (double)(ws.dotv ? static_cast<const T*>(ws.dotv)[row] : xrow);
+            }
+        }
+    }
+    if(DOT)
+    {
+        const double wsum = wave_reduce_sum(dacc);
+        if((threadIdx.x & 63) == 0 && blk >= 0)
+            ws.part1[blk * NWV + (threadIdx.x >> 6)] = wsum;
+    }
+}
+
 // Measured and removed (round 4): k_csr_w4 with look-ahead -- the row offsets of a wave's four 16-row pieces requested at once,
 // the first pass of piece k + 1 on its way while piece k is walked (two packet sets used alternately, pieces unrolled with
 // compile-time numbers; 142 VGPRs, 3 waves per SIMD, or 128 with 4): 0.1655 / 0.1707 ms against 0.1604 ms of k_csr_w4 on the
@@ -1355,6 +1489,51 @@ int csr_analyse_band(ramd_mat_s* m)
     const int cnt = (int)(std::upper_bound(h.begin(), h.end(), med) - std::lower_bound(h.begin(), h.end(), med));
     if(cnt * 2 >= samples && med % kCsrRows == 0 && (int64_t)med * 8 >= (1 << 20) && med < m->nrow / 16)
         m->band_dist = med;
+    return RAMD_OK;
+}
+
+// Do consecutive rows gather consecutive elements of x?  (A stencil on a lattice: row r + 1 has the columns of row r, each + 1.)
+// Then a gather in which lane t serves row t -- the row walk of k_csr_tr -- touches a handful of lines per instruction, and
+// that kernel beats the wave-private forms whose lanes serve the entries of a few rows (k_csr_w4 / k_csr_wp: counters on the
+// 27-point operator at 256^3 show the data-return path of the L1 busy 95 % of the time, 63 accesses per gather instruction:
+// 1.12 ms against 1.22 / 1.34).  2048 sampled rows; where most are shifts of their predecessor the row walk is taken.
+__global__ __launch_bounds__(kBlock) void k_shift_sample(int nrow, int stride, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                         int* __restrict__ out)
+{
+    const int s   = blockIdx.x * blockDim.x + threadIdx.x;
+    // (scattered rows, not every stride-th one: a stride that is a multiple of the lattice's line length samples one x only)
+    const int row = (int)(((int64_t)s * stride + (int64_t)((unsigned)s * 2654435761u % (unsigned)stride)) % nrow);
+    int       ok  = 0;
+    if(row + 1 < nrow)
+    {
+        const int a = rp[row], b = rp[row + 1], e = rp[row + 2];
+        ok          = (b - a == e - b) ? 1 : 0;
+        for(int k = 0; ok && k < b - a; ++k)
+            ok = ci[b + k] == ci[a + k] + 1 ? 1 : 0;
+    }
+    out[s] = ok;
+}
+int csr_analyse_shift(ramd_mat_s* m)
+{
+    m->shift_rows = 0;
+    if(m->format != RAMD_CSR || m->nrow < 4096)
+        return RAMD_OK;
+    Backend&  b       = backend();
+    const int samples = 2048;
+    int*      d       = nullptr;
+    RAMD_TRY(dev_alloc(&d, samples));
+    hipLaunchKernelGGL(k_shift_sample, dim3(samples / kBlock), dim3(kBlock), 0, b.cur, m->nrow, std::max(1, m->nrow / samples), m->rp,
+                       m->ci, d);
+    std::vector<int> h((size_t)samples);
+    hipError_t       e = hipMemcpyAsync(h.data(), d, sizeof(int) * samples, hipMemcpyDeviceToHost, b.cur);
+    if(e == hipSuccess)
+        e = hipStreamSynchronize(b.cur);
+    dev_free(&d);
+    RAMD_HIP(e);
+    int cnt = 0;
+    for(int v : h)
+        cnt += v;
+    m->shift_rows = cnt * 2 >= samples ? 1 : 0;
     return RAMD_OK;
 }
 
@@ -1889,9 +2068,18 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
     static const int pipe_env = getenv("RAMD_CSR_PIPE") ? atoi(getenv("RAMD_CSR_PIPE")) : 0;
     const bool use_pipe = pipe_env != 0;
     static const int w4_env = getenv("RAMD_CSR_W4") ? atoi(getenv("RAMD_CSR_W4")) : -1; // (0 / 1: force; default: rows of 16+ entries)
+    const bool w4_rows = !use_pat && !use_grp && !(q4_env > 0) && !use_col2 && (int64_t)m->nnz >= (int64_t)16 * m->nrow;
+    if(w4_rows && w4_env < 0 && m->shift_rows < 0)
+        RAMD_TRY(csr_analyse_shift(const_cast<ramd_mat_s*>(m)));
+    // (rows of 16+ entries take a wave-private form -- unless they are the rows of a stencil: see csr_analyse_shift)
     const bool use_w4  = !use_pat && !use_grp && !(q4_env > 0) && !use_col2
-                         && (w4_env >= 0 ? w4_env != 0 : (int64_t)m->nnz >= (int64_t)16 * m->nrow);
+                         && (w4_env >= 0 ? w4_env != 0 : (w4_rows && m->shift_rows != 1));
+    // rows of 16+ entries that walk their rows in k_csr_tr (stencils; row patterns of long rows): entries per LDS pass
+    static const int lchunk_env = getenv("RAMD_CSR_LCHUNK") ? atoi(getenv("RAMD_CSR_LCHUNK")) : -1; // (2048 / 4096 / 8192; default by form)
+    const bool long_rows  = (int64_t)m->nnz >= (int64_t)16 * m->nrow && !use_grp && !(q4_env > 0) && !use_col2 && !use_xl && !use_pat2;
+    const int  long_chunk = !long_rows ? 0 : (lchunk_env >= 0 ? lchunk_env : (use_pat ? 8192 : 4096));
     static const int w4_waves = getenv("RAMD_CSR_W4_WAVES") ? atoi(getenv("RAMD_CSR_W4_WAVES")) : 4; // (1: one wave per workgroup)
+    static const int wp_env   = getenv("RAMD_CSR_WP") ? atoi(getenv("RAMD_CSR_WP")) : 1; // (0: k_csr_w4 where k_csr_wp would run)
     const bool q4      = !use_pat && q4_env > 0; // measured EQUAL to k_csr_tr on the shell surrogate (0.162 vs 0.160 ms): opt-in
     const int  nblk    = (m->nrow + rows_per_wg - 1) / rows_per_wg;
     const int  per_xcd = (nblk + 7) / 8;
@@ -1934,12 +2122,21 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
         else if(use_col2)                                                                                  \
             hipLaunchKernelGGL((k_csr_pat2<T, MODE, DOT, 2, false>), dim3(((per_xcd + 1) / 2) * 8), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
                                per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, m->blk_rp); \
+        else if(use_pat && long_chunk == 8192)                                                             \
+            hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT, true, false, false, 8192>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
+                               per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, CsrGroups{}, m->blk_rp);  \
+        else if(use_pat && long_chunk == 4096)                                                             \
+            hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT, true, false, false, 4096>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
+                               per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, CsrGroups{}, m->blk_rp);  \
         else if(use_pat)                                                                                   \
             hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT, true>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
                                per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, CsrGroups{}, m->blk_rp);  \
         else if(use_grp)                                                                                   \
             hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT, false, true>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
                                per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, cgr, m->blk_rp); \
+        else if(use_w4 && wp_env != 0 && w4_waves != 1)                                                    \
+            hipLaunchKernelGGL((k_csr_wp<T, MODE, DOT, 4>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk,  \
+                               per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm);        \
         else if(use_w4 && w4_waves == 1)                                                                   \
             hipLaunchKernelGGL((k_csr_w4<T, MODE, DOT, 1>), dim3(((nblk * 4 + 7) / 8) * 8), dim3(64), 0, b.cur, m->nrow,     \
                                nblk * 4, (nblk * 4 + 7) / 8, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot,        \
@@ -1947,6 +2144,9 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
         else if(use_w4)                                                                                    \
             hipLaunchKernelGGL((k_csr_w4<T, MODE, DOT, 4>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk,  \
                                per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm);        \
+        else if(long_chunk >= 4096 && !use_w4)                                                             \
+            hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT, false, false, false, 4096>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
+                               per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, CsrGroups{}, m->blk_rp);  \
         else if(use_pipe)                                                                                  \
             hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT, false, false, true>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
                                per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, CsrGroups{}, m->blk_rp);  \

@@ -276,18 +276,19 @@ __global__ __launch_bounds__(kBlock) void k_trsv(int nrow, const int* __restrict
         bool progress = true;
         if(!fin)
         {
-            // (every request of the attempt is issued before the first answer is looked at: a slot without an entry asks for
-            //  the row's own position, whose answer nobody reads.  With a test around every request -- rounds 1 to 5 -- the
-            //  compiler waited for each answer before the next request: kDepChunk trips through memory per attempt, not one.)
+            // (Round 6 tried to issue every request of the attempt before the first answer is looked at, as the sync-free grouped
+            //  form now does -- a slot without an entry asking for the row's own position: min 69 instead of 86 ms per triangle
+            //  on the RCM shell, but single launches of SECONDS: 64 x 8 requests per attempt from every waiting wave of a grid
+            //  that is as large as the matrix starve the few rows that can advance.  The test per request stays.)
             typename Sentinel<T>::bits bits[kDepChunk];
+            bool                       all = true;
 #pragma unroll
             for(int e = 0; e < kDepChunk; ++e)
-                bits[e] = poll_load(w + (c[e] >= 0 ? (int64_t)c[e] : t));
-            __builtin_amdgcn_sched_barrier(0);
-            bool all = true;
-#pragma unroll
-            for(int e = 0; e < kDepChunk; ++e)
-                all = all && (c[e] < 0 || bits[e] != Sentinel<T>::value);
+                if(c[e] >= 0)
+                {
+                    bits[e] = poll_load(w + c[e]);
+                    all     = all && (bits[e] != Sentinel<T>::value);
+                }
             if(all)
             {
 #pragma unroll
@@ -5009,6 +5010,7 @@ static int ilup_t(ramd_mat_s* m, int p, bool level)
         std::swap(m->nnz, S->nnz);
         mat_free_analysis(m);
         m->band_dist = -1;
+        m->shift_rows = -1;
         (void)fail(RAMD_OK);
         return ilu0_long_rows_t<T>(m);
     }

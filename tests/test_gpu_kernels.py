@@ -1024,7 +1024,7 @@ def test_fused_mgs_block_tiny_vectors(ra, n):
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_csr_row_patterns_in_a_fresh_process(dtype):
     """row-pattern SpMV (csr_analyse_pattern): a 3-D stencil falls into <= 27 patterns and takes the dictionary kernel, a
-    random matrix and a matrix with a 17-entry row do not; results bit-exact against the oracle either way, also after the
+    random matrix and a matrix with a 29-entry row do not (patterns hold up to 28 entries since round 6: the 27 of the reference's own 3-D operator); results bit-exact against the oracle either way, also after the
     values were replaced and for a rectangular block"""
     import os
     import subprocess
@@ -1056,7 +1056,7 @@ rp, ci, va = gen.poisson7(21, np.float64)
 n = len(rp) - 1
 va = va * np.random.default_rng(1).uniform(0.5, 1.5, len(va))       # values play no role in the pattern
 A, st = check(rp, ci, va, n, n, 1)
-assert st[1] <= 27 and st[2] == 16, st
+assert st[1] <= 27 and st[2] == 28, st
 # the same operator as ELL and as HYB: the analysis runs on the slot tuples of the ELL block (empty slots included)
 for fmt in (ra.ELL, ra.HYB):
     B = ra.LocalMatrix(dtype); B.SetDataPtrCSR(rp, ci, va.astype(dtype))
@@ -1078,16 +1078,16 @@ rows = [sorted(set(rng.integers(0, m, 5).tolist())) for _ in range(m)]
 rpr = np.zeros(m + 1, np.int32); rpr[1:] = np.cumsum([len(r) for r in rows])
 cir = np.array([c for r in rows for c in r], np.int32); var = rng.uniform(-1, 1, len(cir))
 check(rpr, cir, var, m, m, -1)
-# one row of 17 entries in an otherwise structured matrix
-rows = [[i] for i in range(m)]; rows[77] = list(range(60, 77)) ; rows[78] = []
+# one row of 29 entries in an otherwise structured matrix
+rows = [[i] for i in range(m)]; rows[77] = list(range(48, 77)) ; rows[78] = []
 rpl = np.zeros(m + 1, np.int32); rpl[1:] = np.cumsum([len(r) for r in rows])
 cil = np.array([c for r in rows for c in r], np.int32); val = rng.uniform(-1, 1, len(cil))
 check(rpl, cil, val, m, m, -1)
-rows[77] = list(range(61, 77))                                         # 16 entries: fits; an empty row is a pattern too
+rows[77] = list(range(49, 77))                                         # 28 entries: fits; an empty row is a pattern too
 rpl = np.zeros(m + 1, np.int32); rpl[1:] = np.cumsum([len(r) for r in rows])
 cil = np.array([c for r in rows for c in r], np.int32); val = rng.uniform(-1, 1, len(cil))
 A2, st = check(rpl, cil, val, m, m, 1)
-assert st[1] == 3 and st[2] == 16, st
+assert st[1] == 3 and st[2] == 28, st
 print("OK")
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), np.dtype(dtype).name)
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RAMD_CSR_PAT="1"), stdout=subprocess.PIPE,
@@ -1127,7 +1127,7 @@ def test_csr_row_patterns_give_up_quickly_on_a_large_unstructured_matrix(ra, ora
 SPMV_VARIANTS = ["RAMD_CSR_Q4=1", "RAMD_CSR_PAT=1", "RAMD_CSR_PAT=1,RAMD_CSR_XL=1", "RAMD_CSR_PAT=0",
                  "RAMD_CSR_PAT=0,RAMD_CSR_GRP=1", "RAMD_CSR_PAT=1,RAMD_CSR_PAT2=0", "RAMD_ELL2=1,RAMD_CSR_PAT=1", "RAMD_ELL2=1,RAMD_CSR_PAT=0",
                  "RAMD_CSR_PAT=0,RAMD_CSR_COL2=2", "RAMD_CSR_PAT=1,RAMD_CSR_NORP=1", "RAMD_CSR_PAT=0,RAMD_CSR_W4=1",
-                 "RAMD_CSR_PAT=0,RAMD_CSR_W4=1,RAMD_CSR_W4_WAVES=1", "RAMD_CSR_PAT=0,RAMD_CSR_PIPE=1", "RAMD_CSR_PAT=1,RAMD_MC_FOLD=0",
+                 "RAMD_CSR_PAT=0,RAMD_CSR_W4=1,RAMD_CSR_W4_WAVES=1", "RAMD_CSR_PAT=0,RAMD_CSR_W4=1,RAMD_CSR_WP=0", "RAMD_CSR_PAT=0,RAMD_CSR_PIPE=1", "RAMD_CSR_PAT=1,RAMD_MC_FOLD=0",
                  "RAMD_MC_RB=2", "RAMD_MC_RB=0"]
 
 
@@ -1151,7 +1151,7 @@ def _spmv_family():
 def test_spmv_variants_forced_in_a_fresh_process(variant):
     """the CSR SpMV has an opt-in four-lanes-per-row walk (k_csr_q4), and CSR / ELL / HYB products and the multi-colour
     sweeps rebuild the columns of structured matrices from row patterns (by default only from 2^20 entries on; with RAMD_CSR_XL=1
-    the CSR product stages the x pieces its 256-row blocks need in LDS, k_csr_xl, instead of gathering x; RAMD_CSR_W4=1: wave-private passes with four lanes per row, k_csr_w4; RAMD_CSR_PIPE=1: the next
+    the CSR product stages the x pieces its 256-row blocks need in LDS, k_csr_xl, instead of gathering x; RAMD_CSR_W4=1: wave-private passes -- products formed where the packets land, k_csr_wp, or (RAMD_CSR_WP=0) four lanes per row, k_csr_w4; RAMD_CSR_PIPE=1: the next
     pass requested before the row walk; with row patterns the SGS sweeps fold colour 0 into its readers, RAMD_MC_FOLD=0: do not; RAMD_MC_RB=2: the one-pass red-black lattice form of the SGS apply, k_mc_rb, on every two-colour lattice operator however small, =0: never); each forced
     on (or off) for EVERY matrix of the SpMV / ApplyAdd / fused-dot / Jacobi-sweep / format / multi-colour / solver-history
     tests: results must not change (bit-exact: same values, same order).  The sixteen processes run several at a time

@@ -1,4 +1,4 @@
-"""a few SpMV launches at N^3 for PMC passes:  python tools/spmv_only.py [N] [reps] [format]"""
+"""a few SpMV launches at N^3 for PMC passes:  python tools/spmv_only.py [N] [reps] [format] [poisson|lap27]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +8,12 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 fmt = sys.argv[3] if len(sys.argv) > 3 else "csr"
 ra.init_rocalution()
-A = ra.LocalMatrix(); A.GenPoisson7(N)
+which = sys.argv[4] if len(sys.argv) > 4 else "poisson"
+A = ra.LocalMatrix()
+if which == "lap27":
+    A.GenLaplace27(N)
+else:
+    A.GenPoisson7(N)
 n = N ** 3
 x = ra.LocalVector(); x.Allocate("x", n); x.Ones()
 y = ra.LocalVector(); y.Allocate("y", n)
