@@ -2075,9 +2075,9 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
     const bool use_w4  = !use_pat && !use_grp && !(q4_env > 0) && !use_col2
                          && (w4_env >= 0 ? w4_env != 0 : (w4_rows && m->shift_rows != 1));
     // rows of 16+ entries that walk their rows in k_csr_tr (stencils; row patterns of long rows): entries per LDS pass
-    static const int lchunk_env = getenv("RAMD_CSR_LCHUNK") ? atoi(getenv("RAMD_CSR_LCHUNK")) : -1; // (2048 / 4096 / 8192; default by form)
+    static const int lchunk_env = getenv("RAMD_CSR_LCHUNK") ? atoi(getenv("RAMD_CSR_LCHUNK")) : -1; // (2048 / 4096 / 8192; 4096 measured best on the 27-point operator: 1.13 ms against 1.66 ms at 8192 with row patterns)
     const bool long_rows  = (int64_t)m->nnz >= (int64_t)16 * m->nrow && !use_grp && !(q4_env > 0) && !use_col2 && !use_xl && !use_pat2;
-    const int  long_chunk = !long_rows ? 0 : (lchunk_env >= 0 ? lchunk_env : (use_pat ? 8192 : 4096));
+    const int  long_chunk = !long_rows ? 0 : (lchunk_env >= 0 ? lchunk_env : 4096);
     static const int w4_waves = getenv("RAMD_CSR_W4_WAVES") ? atoi(getenv("RAMD_CSR_W4_WAVES")) : 4; // (1: one wave per workgroup)
     static const int wp_env   = getenv("RAMD_CSR_WP") ? atoi(getenv("RAMD_CSR_WP")) : 1; // (0: k_csr_w4 where k_csr_wp would run)
     const bool q4      = !use_pat && q4_env > 0; // measured EQUAL to k_csr_tr on the shell surrogate (0.162 vs 0.160 ms): opt-in

@@ -2349,8 +2349,8 @@ __global__ __launch_bounds__(kBlock) void k_ct_fill_grec(int n, const int* __res
 
 // The compute wave's loads are issued by hand (inline asm) and waited for by hand: left to the compiler, the counter waits
 // of a software pipeline with scalar control flow in the loop body come out as drains (vmcnt(0) at the loop header, the
-// state of the prologue merged into every trip).  The hardware retires vector memory operations in order, so with a fixed
-// number of operations per step "the record issued D steps ago has arrived" is exactly s_waitcnt vmcnt(D * operations);
+// state of the prologue merged into every trip).  The hardware returns LOADS in the order they were issued, so with a fixed
+// number of loads per step "the record issued D steps ago has arrived" is exactly s_waitcnt vmcnt(D * loads per step);
 // tying the registers through an empty asm after the wait keeps the compiler from using them earlier.
 __device__ __forceinline__ const void* ct_uniform(const void* p) // (a wave-uniform pointer the compiler may not recognise as one)
 {
@@ -3110,8 +3110,11 @@ __global__ __launch_bounds__(128) void k_trsv_rec(int ntiles, CtDims dims, const
         {
             const v4i32 rec = rec_next; // (requested during the step before)
             rec_next        = step_rec[uni(st[(j + 1) % DEPTH].g)];
-            // this step's quads were loaded DEPTH steps ago: DEPTH - 1 steps' operations were issued after them
-            ct_wait_vm<(DEPTH - 1) * OPS>();
+            // this step's quads were loaded DEPTH steps ago: the LOADS of DEPTH - 1 steps were issued after them.  (Not their
+            // stores: a store may be acknowledged before an older load's data is there -- only loads return in issue order;
+            // counting the step's store as well, as rounds 3 to 5 did, waits for too little when loads are slow.  See
+            // trsv_lattice.hip LatSched, where a shared device showed it.)
+            ct_wait_vm<(DEPTH - 1) * (OPS - 1)>();
             arrived(st[j]);
             step(st[j], rec);
             fetch_rec(st[j]);

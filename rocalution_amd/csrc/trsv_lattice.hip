@@ -210,9 +210,9 @@ __global__ __launch_bounds__(kBlock) void k_lat_fill_sentinel(int64_t n, T* __re
 // ---------------------------------------------------------------- the solve
 // Every vector memory operation of the pencil loop is issued by hand, unconditionally, in a fixed order -- lanes and phases
 // that have nothing to move read a block of zeros / write a per-workgroup dump line instead of being masked off -- so that
-// "the loads issued at the previous block boundary have arrived" is an exact operation count (the hardware retires vector
-// memory operations in order): s_waitcnt vmcnt(N) with N computed from the template parameters below, never a drain in the
-// steady state.  (Left to the compiler the boundary code came out with vmcnt(0) in front of every store and 326 VGPRs.)
+// "the loads issued at the previous block boundary have arrived" is an exact operation count (the hardware returns LOADS in
+// order -- see LatSched: the stores in between are not counted): s_waitcnt vmcnt(N) with N computed from the template
+// parameters below, never a drain in the steady state.  (Left to the compiler the boundary code came out with vmcnt(0) in front of every store and 326 VGPRs.)
 // A count may only err towards waiting longer: N has to be <= the operations really issued after the one waited for.
 template <int I, int N, typename F>
 __device__ __forceinline__ void lat_for(F&& f)
@@ -227,9 +227,15 @@ template <int N>
 __device__ __forceinline__ void lat_wait()
 {
     static_assert(N >= 0, "vmcnt");
+#ifdef RAMD_LAT_DRAIN // (diagnostic build: every counted wait is a drain)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N < 63 ? N : 63) : "memory");
+#endif
 }
-// (s_nop after a store: its data registers may be rewritten by the next instruction the compiler places)
+// (s_nop after a store: its data registers may be rewritten by the next instruction the compiler places, and the compiler's hazard
+// pass does not look inside an asm statement.  gfx950 wants TWO wait states after a store of more than 8 bytes: with one, the first
+// data register was seen holding the next instruction's result -- but only when other processes kept the memory pipeline busy.)
 __device__ __forceinline__ v2f64 lat_ld_pair(const double* p)
 {
     v2f64 r;
@@ -288,7 +294,7 @@ __device__ __forceinline__ LatT<float>::V2 lat_ld_pair_sc1(const float* p)
 }
 __device__ __forceinline__ void lat_st_pair_nt(double* p, v2f64 v)
 {
-    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void lat_st_pair_nt(float* p, LatT<float>::V2 v)
 {
@@ -304,7 +310,7 @@ __device__ __forceinline__ void lat_st_elem_nt(float* p, float v)
 }
 __device__ __forceinline__ void lat_st_pair_sc1(double* p, v2f64 v)
 {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void lat_st_pair_sc1(float* p, LatT<float>::V2 v)
 {
@@ -342,12 +348,19 @@ __device__ __forceinline__ void lat_tie(X& v) // (nothing that reads v may move 
 template <int NC, int IO>
 struct LatSched
 {
+    // LOADS only.  vmcnt counts loads and stores alike, but only the loads return in the order they were issued: a store that
+    // was issued after a load may be acknowledged before the load's data is there (the compiler's own wait insertion treats a
+    // mix of pending loads and stores on this target as "out of order" for that reason).  A load with M younger loads has
+    // arrived once vmcnt <= M, whatever the stores in between do; counting the stores as well (rounds 5 and before) waits for
+    // too little as soon as loads are slow and stores are not: found in round 6 when six processes shared the device -- a
+    // quarter of the solves used the coefficients of eight steps earlier (errors of 1e-7: the ILU(0) factors of the Poisson
+    // operator change that little along a grid line), alone on the device none did.
     static constexpr int ops(int u, int st)
     {
-        return st == 0 ? (u % 16 == 0 ? IO : 0)
+        return st == 0 ? 0 // (the natural-order stores of block ph - 2)
                : st == 1 ? (u % 16 == 0 ? IO : 0)
-               : st == 2 ? (u % 4 == 3 ? 1 : 0)
-               : st == 3 ? (u % 4 == 0 ? 2 : 0)
+               : st == 2 ? 0 // (the publication of a face batch)
+               : st == 3 ? (u % 4 == 0 ? 1 : 0) // (the sentinel reset is a store; the poll of the next batch)
                          : (u % 2 == 1 ? NC : 0);
     }
     static constexpr int upto(int u, int st) // operations of the body up to and including stage st of step u
