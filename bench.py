@@ -318,7 +318,8 @@ def roof(name, bytes_alg, p, traffic=None):
 TRI_FORMS = {0: "none", 1: "level-scheduled rows (k_trsv)", 2: "box tiles, record form (k_trsv_rec)",
              3: "box tiles with row groups (k_trsv_rec, grouped)", 4: "lattice pencils (k_trsv_lat)",
              6: "row groups handed from wave to wave (k_trsv_sf: a deep, narrow dependency graph of long rows; tiles = units of whole "
-                "row groups of one group level, steps = row groups)"}
+                "row groups of one group level, steps = row groups)",
+             7: "sheared pencils of the 27-point stencil (k_trsv_box)"}
 
 
 def tri_plan_stats(lib, capi):
@@ -333,7 +334,7 @@ def tri_plan_stats(lib, capi):
         d = dict(form=TRI_FORMS.get(int(st[0]), str(st[0])), rows=int(st[1]), dependency_levels=int(st[2]),
                  tiles=int(st[3]), steps=int(st[4]), values_handed_between_tiles=int(st[5]), max_rows_per_tile=int(st[6]),
                  longest_row=int(st[7]), lanes_per_row=int(st[8]))
-        if st[0] == 4:
+        if st[0] in (4, 7):
             d["lattice"] = [int(st[9]), int(st[10]), int(st[11])]
             d["plan_bytes"] = int(st[12])
         elif st[0] in (1, 6):

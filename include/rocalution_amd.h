@@ -238,7 +238,9 @@ int ramd_mat_lu_solve(ramd_mat_t m, ramd_vec_t in, ramd_vec_t out); /* :349 */
  * Form 6: [1] rows; [2] GROUP levels (one hand-off each); [3] units (whole row groups of one group level, one wave each);
  * [4] row groups; [5] 0; [6] rows a unit holds at most (64 / lanes per row); [7] most entries of a row outside its group;
  * [8] lanes per row; [9] rows of the longest group; [12] the reason the box-tile form was not taken (as above); [14] bytes of the
- * out-of-group entries as stored (positions + coefficients) */
+ * out-of-group entries as stored (positions + coefficients).
+ * Form 7 (sheared pencils of the 27-point stencil, csrc/trsv_box27.hip): [2] dependency levels (planes x + 2 y + 4 z); [3] pencils;
+ * [4] pencils x steps; [6] 64; [7] 13; [8] 1; [9]-[11] the lattice; [12] bytes of the packed coefficients */
 int ramd_tri_plan_stats(int which, long long* out16);
 /* test hook of the sync-free grouped form's division (trsv_syncfree.hip sf_div: the fp64 division sequence of gfx950 with the
  * part that depends on the divisor alone formed once per plan; no reference counterpart -- the reference divides,

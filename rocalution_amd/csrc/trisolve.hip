@@ -25,6 +25,7 @@
 #include "trsv_handoff.hpp"
 #include "trsv_lattice.hpp"
 #include "trsv_syncfree.hpp"
+#include "trsv_box27.hpp"
 
 #include <algorithm>
 #include <type_traits>
@@ -677,6 +678,9 @@ struct TriPlan
     LatPlan* lat = nullptr;
     // sync-free grouped form (k_trsv_sf): a deep, narrow dependency graph of long rows, one row group per hand-off
     SfPlan* sf = nullptr;
+    // 27-point form (trsv_box27.hip): the triangle of the full 3 x 3 x 3 stencil on a lattice, pencils marched along x; like
+    // the lattice form it reads and writes natural-order vectors, unlike it the output vector is its hand-off medium
+    BoxPlan* box = nullptr;
     // what the analysis found (ramd_tri_plan_stats): chains, external values of all tiles, box edges
     int       st_chains = 0, st_box[3] = {0, 0, 0};
     int       st_why    = 0; // why this plan is not in box-tile form (ct_why_text)
@@ -685,6 +689,7 @@ struct TriPlan
     {
         lat_release(&lat);
         sf_release(&sf);
+        box_release(&box);
         dev_free(&ct_tile_step);
         dev_free(&ct_step_pos);
         dev_free(&ct_step_ent);
@@ -5954,6 +5959,21 @@ static void tri_note_stats(const ramd_mat_s* m, const TriPlan* P, int which)
         o[12] = (long long)(li.coef_bytes + li.face_bytes);
         return;
     }
+    if(P->box)
+    {
+        BoxInfo bi;
+        box_info(P->box, &bi);
+        o[0] = 7;
+        o[2] = (long long)bi.nx + 2LL * bi.ny + 4LL * bi.nz - 6; // dependency levels: planes x + 2 y + 4 z
+        o[3] = bi.ntiles;
+        o[4] = (long long)bi.ntiles * bi.nsteps;
+        o[6] = 64;
+        o[7] = 13;
+        o[8] = 1;
+        o[9] = bi.nx, o[10] = bi.ny, o[11] = bi.nz;
+        o[12] = (long long)bi.coef_bytes;
+        return;
+    }
     o[0] = !P->ct ? (P->sf ? 6 : 1) : (P->ct_grp ? 3 : 2); // (5 was the band form of round 5)
     o[2] = P->nlevels;
     if(P->sf)
@@ -6026,6 +6046,26 @@ int ramd_mat_lu_analyse(ramd_mat_t m)
         st->U.release();
         if(sl != RAMD_ERR_UNSUPPORTED)
             return sl;
+        // ... or on the 27-point stencil: L into the plan's own vector, U from there into the output vector
+        sl = m->dtype == RAMD_F64 ? box_build<double>(m, true, true, &st->L.box) : box_build<float>(m, true, true, &st->L.box);
+        if(sl == RAMD_OK)
+            sl = m->dtype == RAMD_F64 ? box_build<double>(m, false, false, &st->U.box) : box_build<float>(m, false, false, &st->U.box);
+        if(sl == RAMD_OK)
+        {
+            st->L.n = st->U.n = m->nrow;
+            st->haveL = st->haveU = true;
+            dev_free(&st->lu_rhs_idx);
+            dev_free(&st->l_order_cache);
+            dev_free(&st->l_level_cache);
+            m->lu_analysed = true;
+            tri_note_stats(m, &st->L, 0);
+            tri_note_stats(m, &st->U, 1);
+            return RAMD_OK;
+        }
+        st->L.release();
+        st->U.release();
+        if(sl != RAMD_ERR_UNSUPPORTED)
+            return sl;
     }
     if(m->dtype == RAMD_F64)
     {
@@ -6066,8 +6106,21 @@ int ramd_mat_lu_solve(ramd_mat_t m, ramd_vec_t in, ramd_vec_t out)
         RAMD_FAIL(RAMD_ERR_STATE, "LUSolve before LUAnalyse");
     TriState* st = tri_state(m);
     if(!st || !st->haveL || !st->haveU || (st->L.lat != nullptr) != (st->U.lat != nullptr)
-       || (!st->L.lat && (!st->lu_rhs_idx || !st->L.order || !st->U.order)))
+       || (st->L.box != nullptr) != (st->U.box != nullptr)
+       || (!st->L.lat && !st->L.box && (!st->lu_rhs_idx || !st->L.order || !st->U.order)))
         RAMD_FAIL(RAMD_ERR_STATE, "LUSolve: the plans of LUAnalyse are incomplete");
+    if(st->L.box && st->U.box)
+    {
+        if(!box_is_unit(st->L.box) || box_is_unit(st->U.box))
+            RAMD_FAIL(RAMD_ERR_STATE, "LUSolve: the 27-point plans of LUAnalyse carry the wrong diagonal flags");
+        if(m->dtype == RAMD_F64)
+        {
+            RAMD_TRY(box_run<double>(st->L.box, (const double*)in->d, (double*)box_scratch(st->L.box)));
+            return box_run<double>(st->U.box, (const double*)box_scratch(st->L.box), (double*)out->d);
+        }
+        RAMD_TRY(box_run<float>(st->L.box, (const float*)in->d, (float*)box_scratch(st->L.box)));
+        return box_run<float>(st->U.box, (const float*)box_scratch(st->L.box), (float*)out->d);
+    }
     if(st->L.lat && st->U.lat)
     {
         if(!lat_is_unit(st->L.lat) || lat_is_unit(st->U.lat))
@@ -6103,8 +6156,11 @@ int ramd_mat_l_analyse(ramd_mat_t m, int diag_unit)
     RAMD_TRY(tri_get(m, &st));
     m->l_analysed = false;
     st->Ls.release();
-    const int sl = m->dtype == RAMD_F64 ? lat_build<double>(m, true, diag_unit != 0, &st->Ls.lat)
-                                        : lat_build<float>(m, true, diag_unit != 0, &st->Ls.lat);
+    int sl = m->dtype == RAMD_F64 ? lat_build<double>(m, true, diag_unit != 0, &st->Ls.lat)
+                                  : lat_build<float>(m, true, diag_unit != 0, &st->Ls.lat);
+    if(sl == RAMD_ERR_UNSUPPORTED)
+        sl = m->dtype == RAMD_F64 ? box_build<double>(m, true, diag_unit != 0, &st->Ls.box)
+                                  : box_build<float>(m, true, diag_unit != 0, &st->Ls.box);
     if(sl == RAMD_OK)
         st->Ls.n = m->nrow;
     else if(sl != RAMD_ERR_UNSUPPORTED)
@@ -6139,6 +6195,9 @@ int ramd_mat_l_solve(ramd_mat_t m, ramd_vec_t in, ramd_vec_t out)
     if(st->Ls.lat)
         return m->dtype == RAMD_F64 ? lat_run<double>(st->Ls.lat, (const double*)in->d, (double*)out->d)
                                     : lat_run<float>(st->Ls.lat, (const float*)in->d, (float*)out->d);
+    if(st->Ls.box)
+        return m->dtype == RAMD_F64 ? box_run<double>(st->Ls.box, (const double*)in->d, (double*)out->d)
+                                    : box_run<float>(st->Ls.box, (const float*)in->d, (float*)out->d);
     if(m->dtype == RAMD_F64)
         return run_plan<double>(st, &st->Ls, m->l_diag_unit, (const double*)in->d, st->Ls.order,
                                 (double*)out->d);
@@ -6155,8 +6214,11 @@ int ramd_mat_u_analyse(ramd_mat_t m, int diag_unit)
     RAMD_TRY(tri_get(m, &st));
     m->u_analysed = false;
     st->Us.release();
-    const int sl = m->dtype == RAMD_F64 ? lat_build<double>(m, false, diag_unit != 0, &st->Us.lat)
-                                        : lat_build<float>(m, false, diag_unit != 0, &st->Us.lat);
+    int sl = m->dtype == RAMD_F64 ? lat_build<double>(m, false, diag_unit != 0, &st->Us.lat)
+                                  : lat_build<float>(m, false, diag_unit != 0, &st->Us.lat);
+    if(sl == RAMD_ERR_UNSUPPORTED)
+        sl = m->dtype == RAMD_F64 ? box_build<double>(m, false, diag_unit != 0, &st->Us.box)
+                                  : box_build<float>(m, false, diag_unit != 0, &st->Us.box);
     if(sl == RAMD_OK)
         st->Us.n = m->nrow;
     else if(sl != RAMD_ERR_UNSUPPORTED)
@@ -6191,6 +6253,9 @@ int ramd_mat_u_solve(ramd_mat_t m, ramd_vec_t in, ramd_vec_t out)
     if(st->Us.lat)
         return m->dtype == RAMD_F64 ? lat_run<double>(st->Us.lat, (const double*)in->d, (double*)out->d)
                                     : lat_run<float>(st->Us.lat, (const float*)in->d, (float*)out->d);
+    if(st->Us.box)
+        return m->dtype == RAMD_F64 ? box_run<double>(st->Us.box, (const double*)in->d, (double*)out->d)
+                                    : box_run<float>(st->Us.box, (const float*)in->d, (float*)out->d);
     if(m->dtype == RAMD_F64)
         return run_plan<double>(st, &st->Us, m->u_diag_unit, (const double*)in->d, st->Us.order,
                                 (double*)out->d);

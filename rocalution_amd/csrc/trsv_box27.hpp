@@ -7,7 +7,7 @@
 namespace ramd
 {
 
-struct BoxPlan; // opaque: coefficients in sweep order, tile table, ticket counter, scratch vector
+struct BoxPlan; // opaque: coefficients in sweep order, pencil table, outflow records (the hand-off medium), ticket counter, scratch vector
 
 struct BoxInfo
 {
@@ -21,8 +21,8 @@ struct BoxInfo
 // unit: the solve leaves the diagonal out (LUSolve's L stage, L / USolve with diag_unit); otherwise it divides by it.
 template <typename T>
 int box_build(const ramd_mat_s* m, bool lower, bool unit, BoxPlan** out);
-// out[r] = solution; in and out must be different vectors (out is the hand-off medium of the solve: it is filled with sentinels
-// first and every row is published into it)
+// out[r] = solution; in and out must be different vectors (the right-hand side is read ahead of the sweep, the solution written
+// behind it, 64 bytes of a grid line at a time)
 template <typename T>
 int  box_run(BoxPlan* P, const T* in, T* out);
 // a vector of the plan's own (n elements): where LUSolve keeps the result of its first stage

@@ -118,6 +118,104 @@ def test_solvers_vs_oracle(ra, S, oracle, grid, tag):
     assert np.linalg.norm(x.numpy() - ref["x"]) / np.linalg.norm(ref["x"]) < 1e-6
 
 
+PENCIL_GRIDS = [(8, 8, 8), (16, 16, 16), (33, 31, 5), (4, 3, 2), (9, 17, 20), (70, 9, 10), (5, 40, 3), (24, 24, 24)]
+
+
+@pytest.mark.parametrize("grid", PENCIL_GRIDS)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_pencil_solve_of_the_27_point_stencil_vs_oracle(ra, oracle, grid, dtype, monkeypatch):
+    """the pencil form of the triangular solve (csrc/trsv_box27.hip; default from 4096 rows on, forced here on every lattice it
+    recognises): LUSolve on the ILU(0) factors, LSolve / USolve with and without the stored diagonal on the unsymmetrically
+    scaled factors -- bit for bit against the host loops (host_matrix_csr.cpp:1163-1221, :1357-1404, :1420-1466); extents that
+    are no multiples of the 8 x 8 pencil, fewer planes than a pencil is deep, a lattice of one pencil"""
+    from rocalution_amd import capi
+    monkeypatch.setenv("RAMD_TRSV_BOX", "2")
+    lib = capi.load()
+    nx, ny, nz = grid
+    rp, ci, va = gen.laplace27(nx, ny, nz, dtype)
+    n = len(rp) - 1
+    rng = np.random.default_rng(nx * 131 + ny)
+    va = (va * rng.uniform(0.5, 1.5, len(va))).astype(dtype)  # (unsymmetric values: L and U differ, no two coefficients alike)
+    A = ra.LocalMatrix(dtype); A.SetDataPtrCSR(rp, ci, va, "A", len(va), n, n)
+    A.ILU0Factorize()
+    lu = oracle.ilu0(rp, ci, va)
+    eq(A.CopyToCSR()[2], lu)
+    st = (C.c_longlong * 16)()
+    b = rng.uniform(-1, 1, n).astype(dtype)
+    y = ra.LocalVector(dtype); y.Allocate("", n)
+    A.LUAnalyse()
+    if n >= 64:
+        for which in (0, 1):
+            capi.check(lib.ramd_tri_plan_stats(which, st))
+            assert st[0] == 7 and (st[9], st[10], st[11]) == grid, list(st)
+    for rep in range(3):
+        A.LUSolve(ra.LocalVector(dtype, data=b), y)
+        eq(y.numpy(), oracle.lusolve(rp, ci, lu, b))
+    for unit in (True, False):
+        A.LAnalyse(unit)
+        A.LSolve(ra.LocalVector(dtype, data=b), y)
+        eq(y.numpy(), oracle.lsolve(rp, ci, lu, b, unit))
+        A.UAnalyse(unit)
+        A.USolve(ra.LocalVector(dtype, data=b), y)
+        eq(y.numpy(), oracle.usolve(rp, ci, lu, b, unit))
+    A.LUSolve(ra.LocalVector(dtype, data=b), y)  # (the three analyses keep their own plans)
+    eq(y.numpy(), oracle.lusolve(rp, ci, lu, b))
+
+
+def test_pencil_solve_at_128_cubed_against_the_general_path(ra, monkeypatch):
+    """272 pencils, most of which find their neighbours' rows already there: the size at which a halo line that ran ahead of its
+    readers overwrote a ring column still in use (found in round 6 -- 64^3, with 72 pencils in lock step, never showed it).
+    The general plans (level-scheduled / box tiles, RAMD_TRSV_BOX=0) are the reference here: bit for bit, several solves"""
+    N = 128
+    n = N ** 3
+    A = ra.LocalMatrix(); A.GenLaplace27(N)
+    A.ILU0Factorize()
+    b = ra.LocalVector(data=np.random.default_rng(5).uniform(-1, 1, n))
+    y = ra.LocalVector(); y.Allocate("", n)
+    run = {"lu": (A.LUAnalyse, A.LUSolve), "l": (lambda: A.LAnalyse(True), A.LSolve), "u": (lambda: A.UAnalyse(False), A.USolve)}
+    for what, (analyse, solve) in run.items():
+        monkeypatch.setenv("RAMD_TRSV_BOX", "0")
+        analyse(); solve(b, y)
+        want = y.numpy().copy()
+        monkeypatch.setenv("RAMD_TRSV_BOX", "1")
+        analyse()
+        for rep in range(4):
+            y.Zeros()
+            solve(b, y)
+            assert np.array_equal(y.numpy(), want), (what, rep)
+
+
+def test_pencil_solve_refuses_what_is_not_the_full_stencil(ra, oracle, monkeypatch):
+    """a 27-point operator with entries removed (one row short of a neighbour), in a non-lexicographic numbering, or the 7-point
+    operator: the analysis falls back to the general plans, and the results are still the host loops' """
+    from rocalution_amd import capi
+    monkeypatch.setenv("RAMD_TRSV_BOX", "2")
+    lib = capi.load()
+    st = (C.c_longlong * 16)()
+    rp, ci, va = gen.laplace27(12, 12, 12)
+    n = len(rp) - 1
+    r = 5 + 12 * 6 + 144 * 7
+    k = rp[r] + 3  # (drop one lower entry of an interior row)
+    keep = np.ones(len(ci), bool); keep[k] = False
+    rp2 = rp.copy(); rp2[r + 1:] -= 1
+    perm = np.random.default_rng(2).permutation(n)
+    from scipy.sparse import csr_matrix
+    Mp = csr_matrix((va, ci, rp), shape=(n, n))[perm][:, perm].tocsr(); Mp.sort_indices()
+    cases = [(rp2, ci[keep], va[keep]), (Mp.indptr.astype(np.int32), Mp.indices.astype(np.int32), Mp.data), gen.poisson7(12)]
+    for rp_, ci_, va_ in cases:
+        m = len(rp_) - 1
+        A = ra.LocalMatrix(); A.SetDataPtrCSR(rp_, ci_, va_, "A", len(va_), m, m)
+        A.ILU0Factorize()
+        lu = oracle.ilu0(rp_, ci_, va_)
+        A.LUAnalyse()
+        capi.check(lib.ramd_tri_plan_stats(0, st))
+        assert st[0] != 7
+        b = np.random.default_rng(1).uniform(-1, 1, m)
+        y = ra.LocalVector(); y.Allocate("", m)
+        A.LUSolve(ra.LocalVector(data=b), y)
+        eq(y.numpy(), oracle.lusolve(rp_, ci_, lu, b))
+
+
 @pytest.mark.parametrize("variant", ["RAMD_CSR_PAT=1", "RAMD_CSR_PAT=0"])
 def test_this_file_with_the_row_patterns_forced_on_and_off(variant):
     """row patterns are taken from 2^20 entries on by default; forced on, every matrix of this file runs the pattern product,
