@@ -49,8 +49,27 @@ def forced_run(family, key, jobs):
 
     def run(cmd, env, timeout):
         p = _sp.run(cmd, cwd=ROOT, env=env, stdout=_sp.PIPE, stderr=_sp.STDOUT, text=True, timeout=timeout)
+        if p.returncode < 0:
+            # the whole pass died by a signal (seen once in round 6: SIGABRT of one of five passes sharing a fresh GPU box, not
+            # reproduced in 7 further runs of the family): keep its output for the post-mortem, run the pass again on its own
+            try:
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(ROOT, "gpurun_out", "forced_crash_%s_%s.log" % (family, key_of[id(cmd)])), "w") as f:
+                    f.write("rc=%d\n" % p.returncode + p.stdout)
+            except OSError:
+                pass
+            first = p
+            p = _sp.run(cmd, cwd=ROOT, env=env, stdout=_sp.PIPE, stderr=_sp.STDOUT, text=True, timeout=timeout)
+            p.stdout = ("[forced pass %s/%s died with signal %d; this is its second run]\n" % (family, key_of[id(cmd)], -first.returncode)
+                        + p.stdout)
+        logdir = os.environ.get("RAMD_TEST_LOGDIR")  # (the whole output of every forced pass, for a failure's beginning)
+        if logdir:
+            os.makedirs(logdir, exist_ok=True)
+            with open(os.path.join(logdir, "forced_%s_%s.log" % (family, key_of[id(cmd)])), "w") as f:
+                f.write("rc=%d\n" % p.returncode + p.stdout)
         return p.returncode, p.stdout
 
+    key_of = {id(cmd): k for k, (cmd, env, timeout) in jobs.items()}
     if (family, key) not in _RUNS:
         for k, (cmd, env, timeout) in jobs.items():
             if (family, k) not in _RUNS:
