@@ -665,9 +665,11 @@ def main():
             tkey = "spmv_%s_512%s" % (args.format, "_fp32" if mixed else "")
         if args.matrix == "shell" and args.format == "csr" and not mixed:
             tkey = "spmv_csr_shell"
+        if args.matrix == "lap27" and N == 256 and args.format in ("csr", "ell", "hyb") and not mixed:
+            tkey = "spmv_%s_lap27_256" % args.format
         r_spmv = roof(k_spmv, b_spmv, p_spmv, traffic_for(tkey) if tkey else None)
         if tri_pc and p_trsv["launches"] > 0:
-            tk = "trsv_512" if (args.matrix == "poisson" and N == 512) else None
+            tk = "trsv_512" if (args.matrix == "poisson" and N == 512) else ("trsv_lap27_256" if (args.matrix == "lap27" and N == 256) else None)
             if args.matrix == "shell":  # (counter passes exist for the surrogate and for its RCM numbering)
                 tk = "trsv_shell" if args.shell_variant == "lex" else "trsv_shell_" + args.shell_variant
             tri_plan = tri_plan_stats(lib, capi)
@@ -702,7 +704,8 @@ def main():
         if args.precond in ("mcsgs", "mcgs", "mcilu") and pr0[PROF_PRECOND]["launches"] > 0:
             kernels["precond_apply"] = roof("multi-coloured %s apply (%s)" % (args.precond.upper()[2:], mc_form(args.precond)),
                                             mcsgs_bytes(n, nnz, vb), pr0[PROF_PRECOND],
-                                            traffic_for(mc_traffic_key(args.precond)) if (args.matrix == "poisson" and N == 512 and not mixed) else None)
+                                            traffic_for(mc_traffic_key(args.precond)) if (args.matrix == "poisson" and N == 512 and not mixed)
+                                            else (traffic_for("mcsgs_lap27_256") if (args.matrix == "lap27" and N == 256 and args.precond == "mcsgs" and not mixed) else None))
         st_pat = C.c_int(0)
         capi.check(lib.ramd_mat_pattern_info(A._h, C.byref(st_pat), None, None))
         if st_pat.value in (1, 2) and args.format in ("csr", "ell", "hyb"):

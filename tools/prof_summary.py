@@ -21,6 +21,12 @@ WHAT = {"cg": "python bench.py --steps 100 --warmup 10 (512^3 CG+Jacobi, the hea
         "ell_rb": "python bench.py --format ell --solver bicgstab --precond mcsgs --steps 60 --warmup 10 (config 4: ELL interior, the default: k_mc_rb)",
         "hyb_rb": "python bench.py --format hyb --solver bicgstab --precond mcsgs --steps 60 --warmup 10 (config 4: HYB interior, the default: k_mc_rb)",
         "mixed": "python bench.py --solver mixed --steps 30 --warmup 3 (config 5: fp64 defect correction around fp32 CG+Jacobi)",
+        "lap27_cg": "python bench.py --matrix lap27 --grid 256 --steps 100 --warmup 10 (the reference's own 3-D operator, 27-point, 256^3: CG+Jacobi)",
+        "lap27_gmres": "python bench.py --matrix lap27 --grid 256 --solver gmres --precond ilu0 --steps 60 --warmup 10 (27-point 256^3: the pencil "
+                       "triangular solve k_trsv_box)",
+        "lap27_bicgstab": "python bench.py --matrix lap27 --grid 256 --solver bicgstab --precond mcsgs --steps 60 --warmup 10 (27-point 256^3: 8 colours)",
+        "lap27_ell": "python bench.py --matrix lap27 --grid 256 --format ell --steps 60 --warmup 10 (27-point 256^3, ELL with row patterns)",
+        "lap27_hyb": "python bench.py --matrix lap27 --grid 256 --format hyb --steps 60 --warmup 10 (27-point 256^3, HYB with row patterns)",
         "calib": "tools/_bin/membench calib (reads of 1 GiB with 16 / 8 / 4 bytes per lane, of 256 MiB with 1 byte per lane)"}
 
 
