@@ -57,23 +57,26 @@ N = 256
 n27 = N ** 3
 nnz27 = (3 * N - 2) ** 3
 t["spmv_csr_lap27_256_algorithmic"] = 12 * nnz27 + 4 * (n27 + 1) + 16 * n27
-put("spmv_csr_lap27_256", "lap27_cg", "k_csr_tr<double, 2, true")
-put("spmv_csr_lap27_256_columns_read", "lap27_cg", "k_csr_tr<double, 0, true")
-put("spmv_ell_lap27_256", "lap27_ell", "k_ell")
+# (k_csr_tr<T, MODE, DOT, PAT, ...>: PAT = columns from the row-pattern dictionary, the stored columns not read)
+put("spmv_csr_lap27_256", "lap27_cg", "k_csr_tr<double, 0, true, true")
+put("spmv_csr_lap27_256_columns_read", "lap27_cg", "k_csr_tr<double, 0, true, false")
+put("spmv_ell_lap27_256", "lap27_ell", "k_ell2<double, 0, true, true, true")
+put("spmv_ell_lap27_256_columns_read", "lap27_ell", "k_ell2<double, 0, true, true, false")
+t["spmv_ell_lap27_256_algorithmic"] = 12 * 27 * n27 + 16 * n27
 put("trsv_lap27_256_lower", "lap27_gmres", "k_trsv_box<double, true, true")
 put("trsv_lap27_256_upper", "lap27_gmres", "k_trsv_box<double, false, false")
 if "trsv_lap27_256_lower" in fresh and "trsv_lap27_256_upper" in fresh:
     t["trsv_lap27_256"] = (t["trsv_lap27_256_lower"] + t["trsv_lap27_256_upper"]) // 2
 t["trsv_lap27_256_algorithmic"] = 12 * ((nnz27 - n27) // 2) + 8 * n27 + 4 * n27 + 16 * n27
-sweeps = [k for k in raw.get("lap27_bicgstab", {}) if "k_mc_" in k]
-tot = 0
-for k in sweeps:
-    v = raw["lap27_bicgstab"][k]
-    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-        # (per APPLY: every sweep kernel's bytes per launch x its launches per apply = dispatches / applies)
-        tot += (2 * v["FETCH_SIZE"][0] + v["WRITE_SIZE"][0]) * 1024 * v["FETCH_SIZE"][1]
-if tot:
-    t["mcsgs_lap27_256_all_sweeps_of_the_pass"] = int(tot)
+# MC-SGS on the 27-point operator: 8 colours = 14 sweeps per apply (first forward, 6 forward, 6 backward, last backward); the
+# number of applies in the pass = launches of the first forward sweep
+sw = {k: v for k, v in raw.get("lap27_bicgstab", {}).items() if "k_mc_sweep<" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v}
+if sw:
+    applies = min(v["FETCH_SIZE"][1] for v in sw.values())
+    t["mcsgs_lap27_256"] = int(round(sum((2 * v["FETCH_SIZE"][0] + v["WRITE_SIZE"][0]) * 1024 * v["FETCH_SIZE"][1] for v in sw.values()) / applies))
+    t["mcsgs_lap27_256_sweeps_per_apply"] = int(round(sum(v["FETCH_SIZE"][1] for v in sw.values()) / applies))
+    fresh.append("mcsgs_lap27_256")
+t["mcsgs_lap27_256_algorithmic"] = 12 * (nnz27 - n27) + 40 * n27
 t["fresh_in_round_6"] = fresh
 t["notes"] = ("keys listed in fresh_in_round_6 come from this round's counter passes (tools/profile_r06.sh); the others are round 5's "
               "figures of kernels this round left alone.  trsv_lap27_256_*: the sheared-pencil solve of the 27-point stencil (k_trsv_box): "
