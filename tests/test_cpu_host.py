@@ -505,6 +505,46 @@ def test_lattice_solve_kernels_have_no_memory_operation_the_counts_do_not_know(t
         assert sum(1 for w in waits if w > 0) >= 16 + 2 + 8, (name, waits)
 
 
+def test_pencil_solve_of_the_27_point_stencil_counts_its_own_waits(tmp_path):
+    """k_trsv_box (csrc/trsv_box27.hip) does what k_trsv_lat does: loads and stores by hand, waits by count (box_wait<N>, N = the
+    operations of a block less the step's own).  The counts hold only if the compiler adds no vector memory operation inside the
+    block loop and copies no register whose load is in flight: all eight instantiations without scratch, spills or v_accvgpr; the
+    four counted waits of a block are the ones the constants in the kernel give (53 / 51 with the diagonal, 50 / 48 without, 63
+    for the polls); every hand-written 16-byte store is followed by two wait states (`s_nop 1`: the gfx950 hazard of round 6)."""
+    import re
+    hipcc = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    out = tmp_path / "box.s"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "rocalution_amd", "csrc"),
+           "--cuda-device-only", "-S", os.path.join(ROOT, "rocalution_amd", "csrc", "trsv_box27.hip"), "-o", str(out)]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:]
+    text = out.read_text()
+    meta = text[text.index("amdhsa.kernels:"):]
+    kern = re.findall(r"\.name:\s+(\S*k_trsv_box\S*).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+)\s+\.vgpr_spill_count:\s+(\d+)",
+                      meta, flags=re.S)
+    assert len(kern) == 8, [k[0] for k in kern]  # {fp64, fp32} x {lower, upper} x {unit, divide}
+    for name, scratch, vgpr, spill in kern:
+        assert int(scratch) == 0 and int(spill) == 0 and int(vgpr) <= 256, (name, scratch, vgpr, spill)
+        start = text.index("\n" + name + ":")
+        body = text[start:text.index("s_endpgm", start)]
+        assert "v_accvgpr" not in body and "scratch_" not in body and "buffer_store" not in body, name
+        waits = [int(w) for w in re.findall(r"s_waitcnt vmcnt\((\d+)\)", body)]
+        unit = "Lb1ELb1E" in name or "Lb0ELb1E" in name  # k_trsv_box<T, LOWER, UNIT>: the second bool of the mangled name
+        nco = 13 if unit else 14
+        block = 4 + 4 * (nco + 2) + 4
+        want = sorted([block - (nco + 2)] * 2 + [block - (nco + 2) - 2] * 2 + [min(63, block - 4)])
+        assert sorted(w for w in waits if w > 0) == want, (name, waits, want)
+        # (drains: the ticket, the pencil table, the queue's first fill, the re-poll loop, the end of a pencil, the debug stores)
+        assert sum(1 for w in waits if w == 0) <= 8, (name, waits)
+        wide = [m.end() for m in re.finditer(r"global_store_dwordx4[^\n]*\n", body)]
+        assert wide or "IfLb" in name, name  # (fp32 pairs are 8-byte stores)
+        for e in wide:
+            assert body[e:e + 40].lstrip().startswith("s_nop 1"), (name, body[e:e + 60])
+
+
 # ------------------------------------------------------------------ the plane-ahead loads of the red-black SGS kernel
 def test_red_black_sgs_kernel_keeps_its_loads_in_flight_across_the_barriers(tmp_path):
     """k_mc_rb (csrc/mcsgs.hip) issues the global loads of a stage one plane ahead and relies on the COMPILER counting its waits:
