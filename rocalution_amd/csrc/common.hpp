@@ -209,6 +209,7 @@ struct ramd_mat_s
     unsigned char* pat_id   = nullptr; // [nrow]
     int*           pat_dict = nullptr; // [pat_n * pat_w] column offsets in storage order
     int*           blk_rp   = nullptr; // [ceil(nrow / 256) + 1] row offsets of the 256-row blocks (k_csr_pat2: a compact, cache-resident copy)
+    int*           wav_rp   = nullptr; // [ceil(nrow / 64) + 1] row offsets of the 64-row groups (k_csr_wr: the same for a wave's rows)
     int            blk_span = 0; // most entries a 256-row block stages (from its 4-aligned start); 0: not measured yet
     double* dot_part1 = nullptr; // [dot_nblk] per-workgroup partials
     int     dot_nblk  = 0;

@@ -54,6 +54,7 @@ void mat_free_analysis(ramd_mat_s* m)
     dev_free(&m->pat_id);
     dev_free(&m->pat_dict);
     dev_free(&m->blk_rp);
+    dev_free(&m->wav_rp);
     m->blk_span = 0;
     dev_free(&m->xl_dict);
     m->xl_state = 0;

@@ -247,6 +247,158 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHK > kC
     }
 }
 
+// k_csr_wr (round 6): the row walk of k_csr_tr from WAVE-private LDS images, for rows of 16+ entries (the 27-point operator:
+// 6 912 entries per 256-row block).  k_csr_tr stages a workgroup's entries in passes of 4096 behind workgroup barriers: 1.7
+// passes per block, rows cut by the pass boundary, the waves of a workgroup waiting for each other 72 % of their cycles
+// (profiles/r06_pmc_csr_tr_lap27.txt).  Here every wave stages the entries of ITS 64 rows (one pass where they fit kWrCap:
+// 64 x 28), all packets requested at once, and walks them lane = row -- the x gathers of a step stay the 64 consecutive
+// elements they are in k_csr_tr (the element-order forms k_csr_w4 / k_csr_wp pay 21+ cache lines per gather instruction on
+// this operator) -- with no barrier after the dictionary's.  Same products in the same order per row, the same per-wave
+// partials of the fused dot: results identical to k_csr_tr bit for bit.  Measured on the 27-point operator at 256^3
+// (tools/spmv_time.py, alternating runs): row patterns 1.13 -> 0.88 ms (0.63 -> 0.81 of 8 TB/s on the CSR bytes), with the fused
+// dot 1.24 -> 0.94 ms, stored columns read 1.16 -> 1.12 ms.  What the steps gave: wave-private staging 1.13 -> 1.00; the walk
+// without a load under a branch (a lane past its row's end reads entry 0 and keeps its sum by a select) 0.98 -> 0.90; the compact
+// copy of the 64-row offsets, gather widths of 8 / 14 / 28 and half-size passes at twice the occupancy: nothing (+-2 %).
+// entries of a wave's LDS image per pass: with row patterns (8 bytes an entry) the rows of a wave in one pass, two workgroups per
+// CU; with the stored columns (12 bytes an entry) half of that, three workgroups per CU
+template <bool PAT>
+constexpr int kWrCapOf = PAT ? 2048 : 1024;
+template <typename T, int MODE, bool DOT, bool PAT, int GW>
+__global__ __launch_bounds__(kBlock) void k_csr_wr(int nrow, int nblk, int per_xcd, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                   const T* __restrict__ val, const T* __restrict__ x, T* __restrict__ y, T scalar,
+                                                   CsrDotWs ws, int slot, BandMap bm, CsrPattern pat, const int* __restrict__ wav_rp)
+{
+    using VP             = typename ValPk<T>::type;
+    constexpr int VN     = ValPk<T>::N;
+    constexpr int kWrCap = kWrCapOf<PAT>;
+    extern __shared__ __attribute__((aligned(16))) char wr_lds[];
+    T*   sval_all = reinterpret_cast<T*>(wr_lds); // [4][kWrCap]
+    int* scol     = reinterpret_cast<int*>(wr_lds + sizeof(T) * 4 * kWrCap); // PAT: the dictionary; else [4][kWrCap] columns
+    const int blk = xcd_block(nblk, per_xcd, bm);
+    double    dacc = 0.0;
+    if(blk >= 0)
+    {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const int w0   = blk * kCsrRows + 64 * wave;
+        const int row  = w0 + lane;
+        int       rs = 0, re = 0, dbase = 0;
+        if(PAT)
+        {
+            for(int i = threadIdx.x; i < pat.n * pat.w; i += kBlock)
+                scol[i] = pat.dict[i];
+            __syncthreads();
+        }
+        if(row < nrow)
+        {
+            rs = rp[row];
+            re = rp[row + 1];
+            if(PAT)
+                dbase = (int)pat.id[row] * pat.w - rs;
+        }
+        // (from the compact copy: a hit in the L2 -- rp[w0] itself is a miss of a stream as long as the row count, and the
+        //  addresses of the value packets hang on it; rs / re of the rows are needed only when the walk begins)
+        const int ngrp  = (nrow + 63) >> 6;
+        const int start = __builtin_amdgcn_readfirstlane(wav_rp[min(w0 >> 6, ngrp)]);
+        const int end   = __builtin_amdgcn_readfirstlane(wav_rp[min((w0 >> 6) + 1, ngrp)]);
+        T*        sv    = sval_all + wave * kWrCap;
+        int*      sc    = scol + wave * kWrCap;
+        T         sum   = (T)0;
+        T         xrow  = (T)0;
+        bool      have_xrow = false;
+        if(MODE == 1 && row < nrow)
+            sum = y[row];
+        for(int cb = start & ~3; cb < end; cb += kWrCap)
+        {
+            v4i32 c[kWrCap / (4 * 64)];
+            VP    a[kWrCap / (VN * 64)];
+#pragma unroll
+            for(int k = 0; k < (PAT ? 0 : kWrCap / (4 * 64)); ++k)
+            {
+                // (every lane loads: a packet behind the wave's entries re-reads the first one -- a load under a branch makes
+                //  the compiler wait for each packet on its own)
+                const int j = cb + (k * 64 + lane) * 4;
+                c[k]        = nt_load(reinterpret_cast<const v4i32*>(ci + (j < end ? j : cb)));
+            }
+#pragma unroll
+            for(int k = 0; k < kWrCap / (VN * 64); ++k)
+            {
+                const int j = cb + (k * 64 + lane) * VN;
+                a[k]        = nt_load(reinterpret_cast<const VP*>(val + (j < end ? j : cb)));
+            }
+#pragma unroll
+            for(int k = 0; k < (PAT ? 0 : kWrCap / (4 * 64)); ++k)
+            {
+                const int g = (k * 64 + lane) * 4;
+                if(cb + g < end)
+                    *reinterpret_cast<v4i32*>(sc + g) = c[k];
+            }
+#pragma unroll
+            for(int k = 0; k < kWrCap / (VN * 64); ++k)
+            {
+                const int g = (k * 64 + lane) * VN;
+                if(cb + g < end)
+                    *reinterpret_cast<VP*>(sv + g) = a[k];
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int lo = max(rs, cb), hi = min(re, cb + kWrCap);
+            // GW gathers in flight per row (two waves per SIMD leave this kernel the registers for a whole 27-entry row), and
+            // no load under a branch: a lane past its row's end reads entry 0 / x[0] and keeps its sum by a select
+            const int len = hi - lo;
+            for(int jb = 0; __ballot(jb < len) != 0ull; jb += GW)
+            {
+                int  cc[GW];
+                T    v[GW], xv[GW];
+                bool ok[GW];
+#pragma unroll
+                for(int e = 0; e < GW; ++e)
+                {
+                    ok[e]         = jb + e < len;
+                    const int idx = ok[e] ? lo - cb + jb + e : 0;
+                    v[e]          = sv[idx];
+                    const int col = PAT ? row + scol[ok[e] ? dbase + lo + jb + e : 0] : sc[idx];
+                    cc[e]         = ok[e] ? col : 0;
+                }
+#pragma unroll
+                for(int e = 0; e < GW; ++e)
+                    xv[e] = x[cc[e]];
+#pragma unroll
+                for(int e = 0; e < GW; ++e)
+                {
+                    const T s2 = MODE != 1 ? sum + v[e] * xv[e] : sum + scalar * v[e] * xv[e];
+                    sum        = ok[e] ? s2 : sum;
+                    if(PAT && (DOT || MODE == 2) && ok[e] && cc[e] == row)
+                    {
+                        xrow      = xv[e];
+                        have_xrow = true;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if(row < nrow)
+        {
+            if((DOT && !ws.dotv) || MODE == 2)
+                if(!have_xrow)
+                    xrow = x[row];
+            if(MODE == 2)
+            {
+                T t = (T)(-1) * sum + static_cast<const T*>(ws.jrhs)[row];
+                t   = static_cast<const T*>(ws.jdinv)[row] * t;
+                sum = xrow + scalar * t;
+            }
+            nt_store(sum, y + row);
+            if(DOT)
+                dacc = (double)sum * (double)(ws.dotv ? static_cast<const T*>(ws.dotv)[row] : xrow);
+        }
+    }
+    if(DOT)
+    {
+        const double wsum = wave_reduce_sum(dacc);
+        if((threadIdx.x & 63) == 0 && blk >= 0)
+            ws.part1[blk * (kBlock / 64) + (threadIdx.x >> 6)] = wsum;
+    }
+}
+
 // Row-pattern product, TWO row blocks per workgroup and a shorter dependency chain (k_csr_tr<PAT> reworked).  PMC passes on
 // k_csr_tr<PAT> at 512^3 (tools/pmc_spmv.sh, gpurun_out/r03bc): 82 % of the wave cycles are SQ_WAIT_ANY (parked at a
 // waitcnt or the barrier), 13 % issue; a wave lives 7.2 us -- the product is bound by the latency chain of a workgroup
@@ -271,6 +423,17 @@ __global__ __launch_bounds__(kBlock) void k_blk_rp(int nrow, int nblk, const int
     {
         const int64_t r = b * kCsrRows;
         blk_rp[b]       = rp[r < nrow ? r : nrow];
+    }
+}
+
+// (the same for groups of 64 rows: what a wave of k_csr_wr stages)
+__global__ __launch_bounds__(kBlock) void k_wav_rp(int nrow, int ngrp, const int* __restrict__ rp, int* __restrict__ wav_rp)
+{
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g <= ngrp; g += gsz)
+    {
+        const int64_t r = g * 64;
+        wav_rp[g]       = rp[r < nrow ? r : nrow];
     }
 }
 
@@ -2078,6 +2241,37 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
     static const int lchunk_env = getenv("RAMD_CSR_LCHUNK") ? atoi(getenv("RAMD_CSR_LCHUNK")) : -1; // (2048 / 4096 / 8192; 4096 measured best on the 27-point operator: 1.13 ms against 1.66 ms at 8192 with row patterns)
     const bool long_rows  = (int64_t)m->nnz >= (int64_t)16 * m->nrow && !use_grp && !(q4_env > 0) && !use_col2 && !use_xl && !use_pat2;
     const int  long_chunk = !long_rows ? 0 : (lchunk_env >= 0 ? lchunk_env : 4096);
+    // rows of 16+ entries that would walk their rows in k_csr_tr's 4096-entry passes: the wave-private row walk (k_csr_wr)
+    static const int wr_env = getenv("RAMD_CSR_WR") ? atoi(getenv("RAMD_CSR_WR")) : 1; // (0: k_csr_tr in long chunks)
+    const bool use_wr = wr_env != 0 && long_rows && long_chunk >= 4096 && !use_w4 && !use_pipe;
+    static const int wr_gw = getenv("RAMD_CSR_WR_GW") ? atoi(getenv("RAMD_CSR_WR_GW")) : 14; // (gathers in flight per row: 8 / 14 / 28)
+    auto wr_lds = [&](bool with_pat) -> size_t {
+        return with_pat ? sizeof(T) * 4 * kWrCapOf<true> + sizeof(int) * (size_t)kPatMax * kPatMaxW
+                        : (sizeof(T) + sizeof(int)) * 4 * kWrCapOf<false>;
+    };
+    if(use_wr && !m->wav_rp)
+    {
+        ramd_mat_s* mm   = const_cast<ramd_mat_s*>(m);
+        const int   ngrp = (m->nrow + 63) / 64;
+        RAMD_TRY(dev_alloc(&mm->wav_rp, (int64_t)ngrp + 1));
+        hipLaunchKernelGGL(k_wav_rp, dim3(ew_grid((int64_t)ngrp + 1)), dim3(kBlock), 0, b.cur, m->nrow, ngrp, m->rp, mm->wav_rp);
+    }
+    if(use_wr)
+    {
+        // (more than 64 KB of LDS per workgroup: opt in once per instantiation)
+        static bool raised = false;
+        if(!raised)
+        {
+            const int big = (int)std::max(wr_lds(true), wr_lds(false));
+#define WR_RAISE1(MODE, DOT, PATB, G) RAMD_HIP(hipFuncSetAttribute((const void*)k_csr_wr<T, MODE, DOT, PATB, G>, hipFuncAttributeMaxDynamicSharedMemorySize, big))
+#define WR_RAISE(MODE, DOT, PATB) WR_RAISE1(MODE, DOT, PATB, 8); WR_RAISE1(MODE, DOT, PATB, 14); WR_RAISE1(MODE, DOT, PATB, 28)
+            WR_RAISE(0, false, true); WR_RAISE(0, true, true); WR_RAISE(1, false, true); WR_RAISE(2, false, true);
+            WR_RAISE(0, false, false); WR_RAISE(0, true, false); WR_RAISE(1, false, false); WR_RAISE(2, false, false);
+#undef WR_RAISE
+#undef WR_RAISE1
+            raised = true;
+        }
+    }
     static const int w4_waves = getenv("RAMD_CSR_W4_WAVES") ? atoi(getenv("RAMD_CSR_W4_WAVES")) : 4; // (1: one wave per workgroup)
     static const int wp_env   = getenv("RAMD_CSR_WP") ? atoi(getenv("RAMD_CSR_WP")) : 1; // (0: k_csr_w4 where k_csr_wp would run)
     const bool q4      = !use_pat && q4_env > 0; // measured EQUAL to k_csr_tr on the shell surrogate (0.162 vs 0.160 ms): opt-in
@@ -2102,6 +2296,19 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
     }
     if(dot)
         prof_spmv_begin();
+#define WR_LAUNCH(MODE, DOT, PATB)                                                                         \
+    do                                                                                                     \
+    {                                                                                                      \
+        if(wr_gw == 8)                                                                                     \
+            hipLaunchKernelGGL((k_csr_wr<T, MODE, DOT, PATB, 8>), dim3(grid), dim3(kBlock), wr_lds(PATB), b.cur, m->nrow, nblk, \
+                               per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, m->wav_rp);  \
+        else if(wr_gw == 14)                                                                               \
+            hipLaunchKernelGGL((k_csr_wr<T, MODE, DOT, PATB, 14>), dim3(grid), dim3(kBlock), wr_lds(PATB), b.cur, m->nrow, nblk, \
+                               per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, m->wav_rp);  \
+        else                                                                                               \
+            hipLaunchKernelGGL((k_csr_wr<T, MODE, DOT, PATB, 28>), dim3(grid), dim3(kBlock), wr_lds(PATB), b.cur, m->nrow, nblk, \
+                               per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, m->wav_rp);  \
+    } while(0)
 #define LAUNCH(MODE, DOT)                                                                                  \
     do                                                                                                     \
     {                                                                                                      \
@@ -2122,6 +2329,10 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
         else if(use_col2)                                                                                  \
             hipLaunchKernelGGL((k_csr_pat2<T, MODE, DOT, 2, false>), dim3(((per_xcd + 1) / 2) * 8), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
                                per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, m->blk_rp); \
+        else if(use_wr && use_pat)                                                                         \
+            WR_LAUNCH(MODE, DOT, true);                                                                     \
+        else if(use_wr)                                                                                    \
+            WR_LAUNCH(MODE, DOT, false);                                                                    \
         else if(use_pat && long_chunk == 8192)                                                             \
             hipLaunchKernelGGL((k_csr_tr<T, MODE, DOT, true, false, false, 8192>), dim3(grid), dim3(kBlock), 0, b.cur, m->nrow, nblk, \
                                per_xcd, m->rp, m->ci, (const T*)m->val, x, y, scalar, ws, slot, bm, pat, CsrGroups{}, m->blk_rp);  \
@@ -2165,6 +2376,7 @@ static int launch_csr(const ramd_mat_s* m, const T* x, T* y, int mode, T scalar,
     else
         LAUNCH(1, false);
 #undef LAUNCH
+#undef WR_LAUNCH
     RAMD_HIP(hipGetLastError());
     if(dot)
     {

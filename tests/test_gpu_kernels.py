@@ -1128,6 +1128,7 @@ SPMV_VARIANTS = ["RAMD_CSR_Q4=1", "RAMD_CSR_PAT=1", "RAMD_CSR_PAT=1,RAMD_CSR_XL=
                  "RAMD_CSR_PAT=0,RAMD_CSR_GRP=1", "RAMD_CSR_PAT=1,RAMD_CSR_PAT2=0", "RAMD_ELL2=1,RAMD_CSR_PAT=1", "RAMD_ELL2=1,RAMD_CSR_PAT=0",
                  "RAMD_CSR_PAT=0,RAMD_CSR_COL2=2", "RAMD_CSR_PAT=1,RAMD_CSR_NORP=1", "RAMD_CSR_PAT=0,RAMD_CSR_W4=1",
                  "RAMD_CSR_PAT=0,RAMD_CSR_W4=1,RAMD_CSR_W4_WAVES=1", "RAMD_CSR_PAT=0,RAMD_CSR_W4=1,RAMD_CSR_WP=0", "RAMD_CSR_PAT=0,RAMD_CSR_PIPE=1", "RAMD_CSR_PAT=1,RAMD_MC_FOLD=0",
+                 "RAMD_CSR_PAT=0,RAMD_CSR_W4=0",
                  "RAMD_MC_RB=2", "RAMD_MC_RB=0"]
 
 
@@ -1151,7 +1152,7 @@ def _spmv_family():
 def test_spmv_variants_forced_in_a_fresh_process(variant):
     """the CSR SpMV has an opt-in four-lanes-per-row walk (k_csr_q4), and CSR / ELL / HYB products and the multi-colour
     sweeps rebuild the columns of structured matrices from row patterns (by default only from 2^20 entries on; with RAMD_CSR_XL=1
-    the CSR product stages the x pieces its 256-row blocks need in LDS, k_csr_xl, instead of gathering x; RAMD_CSR_W4=1: wave-private passes -- products formed where the packets land, k_csr_wp, or (RAMD_CSR_WP=0) four lanes per row, k_csr_w4; RAMD_CSR_PIPE=1: the next
+    the CSR product stages the x pieces its 256-row blocks need in LDS, k_csr_xl, instead of gathering x; RAMD_CSR_W4=1: wave-private passes -- products formed where the packets land, k_csr_wp, or (RAMD_CSR_WP=0) four lanes per row, k_csr_w4; RAMD_CSR_W4=0: rows of 16+ entries (the shell surrogates) in the wave-private row walk the stencils take, k_csr_wr, several passes per wave; RAMD_CSR_PIPE=1: the next
     pass requested before the row walk; with row patterns the SGS sweeps fold colour 0 into its readers, RAMD_MC_FOLD=0: do not; RAMD_MC_RB=2: the one-pass red-black lattice form of the SGS apply, k_mc_rb, on every two-colour lattice operator however small, =0: never); each forced
     on (or off) for EVERY matrix of the SpMV / ApplyAdd / fused-dot / Jacobi-sweep / format / multi-colour / solver-history
     tests: results must not change (bit-exact: same values, same order).  The sixteen processes run several at a time

@@ -216,11 +216,12 @@ def test_pencil_solve_refuses_what_is_not_the_full_stencil(ra, oracle, monkeypat
         eq(y.numpy(), oracle.lusolve(rp_, ci_, lu, b))
 
 
-@pytest.mark.parametrize("variant", ["RAMD_CSR_PAT=1", "RAMD_CSR_PAT=0"])
+@pytest.mark.parametrize("variant", ["RAMD_CSR_PAT=1", "RAMD_CSR_PAT=0", "RAMD_CSR_WR=0"])
 def test_this_file_with_the_row_patterns_forced_on_and_off(variant):
     """row patterns are taken from 2^20 entries on by default; forced on, every matrix of this file runs the pattern product,
     the pattern ELL / HYB products and the pattern colour sweeps with dictionaries of up to 27 entries per row; forced off, the
-    paths with the stored columns"""
+    paths with the stored columns; RAMD_CSR_WR=0: the CSR product in k_csr_tr's 4096-entry passes instead of the wave-private
+    row walk (k_csr_wr) these rows take by default"""
     env = dict(os.environ)
     env[variant.split("=")[0]] = variant.split("=")[1]
     cmd = [sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "-k",

@@ -58,8 +58,9 @@ n27 = N ** 3
 nnz27 = (3 * N - 2) ** 3
 t["spmv_csr_lap27_256_algorithmic"] = 12 * nnz27 + 4 * (n27 + 1) + 16 * n27
 # (k_csr_tr<T, MODE, DOT, PAT, ...>: PAT = columns from the row-pattern dictionary, the stored columns not read)
-put("spmv_csr_lap27_256", "lap27_cg", "k_csr_tr<double, 0, true, true")
-put("spmv_csr_lap27_256_columns_read", "lap27_cg", "k_csr_tr<double, 0, true, false")
+# (k_csr_wr<T, MODE, DOT, PAT, GW>: the wave-private row walk rows of 16+ entries take since the end of round 6)
+put("spmv_csr_lap27_256", "lap27_cg", "k_csr_wr<double, 0, true, true")
+put("spmv_csr_lap27_256_columns_read", "lap27_cg", "k_csr_wr<double, 0, true, false")
 put("spmv_ell_lap27_256", "lap27_ell", "k_ell2<double, 0, true, true, true")
 put("spmv_ell_lap27_256_columns_read", "lap27_ell", "k_ell2<double, 0, true, true, false")
 t["spmv_ell_lap27_256_algorithmic"] = 12 * 27 * n27 + 16 * n27
