@@ -247,13 +247,15 @@ __device__ __forceinline__ void box_ld(float& r, const float* p)
 {
     asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(p) : "memory");
 }
+template <int OFF = 0>
 __device__ __forceinline__ void box_poll(unsigned long long& r, const double* p)
 {
-    asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(r) : "v"(p) : "memory");
+    asm volatile("global_load_dwordx2 %0, %1, off offset:%2 sc1" : "=v"(r) : "v"(p), "n"(OFF) : "memory");
 }
+template <int OFF = 0>
 __device__ __forceinline__ void box_poll(unsigned int& r, const float* p)
 {
-    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(r) : "v"(p) : "memory");
+    asm volatile("global_load_dword %0, %1, off offset:%2 sc1" : "=v"(r) : "v"(p), "n"(OFF) : "memory");
 }
 __device__ __forceinline__ void box_st_nt(double* p, double v)
 {
@@ -396,7 +398,8 @@ __global__ __launch_bounds__(64) void k_trsv_box(BoxDims g, const int* __restric
                 box_tie(cq[i][d]);
             box_tie(rq[i]);
         }
-        int xf = hvalid ? -1 : 0x3fffffff; // the halo line's ring holds every element up to xf
+        int  xf    = hvalid ? -1 : 0x3fffffff; // the halo line's ring holds every element up to xf
+        bool hdone = false;
         B   hv[kPF];
         int hx = 0, hn = 0;
 #pragma unroll
@@ -449,11 +452,23 @@ __global__ __launch_bounds__(64) void k_trsv_box(BoxDims g, const int* __restric
                     dbg[4 * q + 1] = (long long)wall_clock64();
                 dbg[4 * q + 3] += spins;
             }
+            // (a complete halo line: the same +0 behind its end -- its readers are at element nx - 13 or later)
+            if(hvalid && xf == g.nx - 1 && !hdone)
+            {
+                ring[a_halo + (g.nx & (kRing - 1))] = (T)0;
+                hdone = true;
+            }
             hx = xf + 1;
             hn = hvalid ? min(kPF, g.nx - hx) : 0;
-#pragma unroll
-            for(int e = 0; e < kPF; ++e)
-                box_poll(hv[e], hp + (int64_t)(hvalid ? min(hx + e, g.nx - 1) : 0) * kFaceW);
+            // (one address, four instruction offsets: an element behind the line's end is a record of a later step -- never
+            //  accepted, inside the allocation by its slack)
+            {
+                const T* php = hp + (int64_t)(hvalid ? hx : 0) * kFaceW;
+                box_poll<0>(hv[0], php);
+                box_poll<kFaceW * (int)sizeof(T)>(hv[1], php);
+                box_poll<2 * kFaceW * (int)sizeof(T)>(hv[2], php);
+                box_poll<3 * kFaceW * (int)sizeof(T)>(hv[3], php);
+            }
             // ---- four steps
             auto step = [&](auto step_index) {
                 constexpr int i = decltype(step_index)::value;
@@ -473,14 +488,18 @@ __global__ __launch_bounds__(64) void k_trsv_box(BoxDims g, const int* __restric
 #pragma unroll
                 for(int d = 0; d < kNDep; ++d)
                 {
-                    // (column x + 1 of a line still holds element x - 15 when x + 1 is behind the line's end)
-                    const T vv = (dxs[d] > 0 && x + 1 >= g.nx) ? (T)0 : v[d];
-                    sum -= cq[i][d] * vv;
+                    // (x + 1 behind the line's end: the column holds +0 by then -- see the write below and the halo phase)
+                    sum -= cq[i][d] * v[d];
                 }
                 if(!UNIT)
                     sum = sum / cq[i][NCO - 1];
                 if(act)
                     ring[a_own + (x & (kRing - 1))] = sum;
+                // the column element nx would take still holds element nx - 16; the readers of this line are past it (the one
+                // furthest behind reads element x - 7 now) and will read it as "x + 1" at the line's end: +0, as the host loop's
+                // row has no such entry (a line shorter than 16 never wrote that column)
+                if(valid && x == g.nx - 8)
+                    ring[a_own + (g.nx & (kRing - 1))] = (T)0;
                 // the outflow lines' rows of this step: one record, contiguous.  (The other lanes store into the record's two
                 // spare slots: a line this wave writes anyway -- one dump for all waves would be the busiest address of the chip.)
                 box_st(fp + ((int64_t)t * kFaceW + ((act && fs_own >= 0) ? 0 : fs_spare)), sum);
@@ -684,7 +703,8 @@ int box_build(const ramd_mat_s* m, bool lower, bool unit, BoxPlan** out)
     if(s == RAMD_OK && cached_malloc(&P->dump, (size_t)g.ntiles * 128 * sizeof(T) + kPad) != hipSuccess)
         s = RAMD_ERR_HIP;
     P->face_elems = (size_t)g.ntiles * g.T * kFaceW;
-    if(s == RAMD_OK && cached_malloc(&P->face, P->face_elems * sizeof(T) + kPad) != hipSuccess)
+    // (+ 8 records: the polls of a line's last block reach up to four steps behind the pencil's last record)
+    if(s == RAMD_OK && cached_malloc(&P->face, (P->face_elems + 8 * kFaceW) * sizeof(T) + kPad) != hipSuccess)
         s = RAMD_ERR_HIP;
     if(s == RAMD_OK
        && (hipMemcpyAsync(P->ptab, ptab.data(), sizeof(int) * ptab.size(), hipMemcpyHostToDevice, b.cur) != hipSuccess
