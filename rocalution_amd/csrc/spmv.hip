@@ -259,6 +259,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHK > kC
 // dot 1.24 -> 0.94 ms, stored columns read 1.16 -> 1.12 ms.  What the steps gave: wave-private staging 1.13 -> 1.00; the walk
 // without a load under a branch (a lane past its row's end reads entry 0 and keeps its sum by a select) 0.98 -> 0.90; the compact
 // copy of the 64-row offsets, gather widths of 8 / 14 / 28 and half-size passes at twice the occupancy: nothing (+-2 %).
+// The same select form of the walk inside k_csr_tr at 512^3 (7-entry rows, stored columns read): 2.38-2.39 -> 2.43-2.51 ms --
+// not kept there; and this kernel on the shell surrogate's 35-entry rows (RAMD_CSR_W4=0): 0.185 ms against k_csr_wp's 0.152.
 // entries of a wave's LDS image per pass: with row patterns (8 bytes an entry) the rows of a wave in one pass, two workgroups per
 // CU; with the stored columns (12 bytes an entry) half of that, three workgroups per CU
 template <bool PAT>
