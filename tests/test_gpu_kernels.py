@@ -11,7 +11,7 @@ from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["gr3030", "poisson8", "lap2d7", "rand300", "rand300ell"]
+CASES = ["gr3030", "poisson8", "lap2d7", "rand300", "rand300ell", "lap27_6"]  # (lap27_6: the reference's own 27-point operator, 6^3)
 
 
 @pytest.fixture(scope="module")

@@ -70,8 +70,8 @@ def _mk(S, tag, dtype=np.float64):
     return solver
 
 
-PC_CASES = ["gr3030", "poisson8", "lap2d7", "rand300", "rand300ell"]
-SOLVER_CASES_IT = ["gr3030", "poisson8", "lap2d7", "poisson16", "poisson32"]
+PC_CASES = ["gr3030", "poisson8", "lap2d7", "rand300", "rand300ell", "lap27_6"]
+SOLVER_CASES_IT = ["gr3030", "poisson8", "lap2d7", "poisson16", "poisson32", "lap27_6"]
 
 
 @pytest.mark.parametrize("name", PC_CASES)
@@ -176,7 +176,7 @@ SOLVER_TAGS = ["cg_none", "cg_jacobi", "gmres_none", "gmres_ilu0", "gmres_ilu1",
                "gmres_mcilu", "fcg_none", "fcg_jacobi", "fcg_mcsgs", "cr_none", "cr_jacobi", "fgmres_none",
                "fgmres_ilu0", "bicgstabl_none", "bicgstabl3_jacobi", "qmrcgstab_none", "qmrcgstab_mcsgs", "idr_none",
                "idr2_jacobi", "cg_sgs", "cg_ic", "bicgstab_gs", "fixedpoint_jacobi"]
-SOLVER_CASES = ["gr3030", "poisson8", "lap2d7", "poisson16", "poisson32"]
+SOLVER_CASES = ["gr3030", "poisson8", "lap2d7", "poisson16", "poisson32", "lap27_6"]
 
 
 def _check_hist(hist, ref_hist, bicgstab, rtol=2e-6):

@@ -16,8 +16,8 @@ import pytest
 from conftest import GOLDEN, load_golden
 from rocalution_amd import generators as gen
 
-KERNEL_CASES = ["gr3030", "poisson8", "lap2d7", "rand300", "rand300ell"]
-SOLVER_CASES = ["gr3030", "poisson8", "lap2d7", "poisson16", "poisson32"]
+KERNEL_CASES = ["gr3030", "poisson8", "lap2d7", "rand300", "rand300ell", "lap27_6"]
+SOLVER_CASES = ["gr3030", "poisson8", "lap2d7", "poisson16", "poisson32", "lap27_6"]
 BIG = {"poisson16": 16, "poisson32": 32}
 
 
@@ -48,7 +48,9 @@ def hist_close(mine, ref_file, iters):
 
 def test_generators_match_fixture_inputs():
     for name, f in (("gr3030", gen.gr_30_30), ("poisson8", lambda: gen.poisson7(8)),
-                    ("lap2d7", lambda: gen.laplace2d(7))):
+                    ("lap2d7", lambda: gen.laplace2d(7)),
+                    # the reference's own 3-D operator (gen_3d_laplacian, clients/include/utility.hpp:110-177), 6^3: round 6
+                    ("lap27_6", lambda: gen.laplace27(6))):
         g = load_golden(name)
         rp, ci, va = f()
         eq(rp, g["rowptr"]); eq(ci, g["col"]); eq(va, g["val"])
