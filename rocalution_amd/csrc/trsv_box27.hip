@@ -59,6 +59,7 @@ constexpr int kRing = 16, kRP = kRing + 1; // columns of a line's ring, elements
 constexpr int kLW = kBJ + 2; // lines per z-row in LDS: j = -2 .. 7
 constexpr int kLines = kLW * (kBK + 1); // k = -1 .. 7
 constexpr int kNDep = 13;
+constexpr int kNPair = 7; // coefficient PAIRS of a step: 13 dependencies + the diagonal (or a spare), 16 bytes per lane and load in fp64
 constexpr int kPF = 4; // steps per block = steps the coefficient queue runs ahead
 constexpr int kNHalo = 26;
 constexpr int kFaceW = 24; // elements of a pencil's outflow record per step: 22 lines read by other pencils (+ 2: 64-byte multiples)
@@ -173,14 +174,16 @@ __global__ __launch_bounds__(kBlock) void k_box_fill(int n, BoxDims g, int nco, 
         const int x = LOWER ? x0 : g.nx - 1 - x0, y = LOWER ? y0 : g.ny - 1 - y0, z = LOWER ? z0 : g.nz - 1 - z0;
         const int K = z / kBK, k = z % kBK, J = (y + k) / kBJ, j = (y + k) % kBJ; // (sheared: y' = y + k)
         const int lane = j + kBJ * k, t = x + kSkJ * j + kSkK * k;
-        T*        dst = coef + (((int64_t)trank[J + g.ntj * K] * g.T + t) * nco) * 64 + lane;
+        // slot s of the step: pair s / 2, lanes side by side, element s % 2 of the lane's pair
+        T* dst = coef + (((int64_t)trank[J + g.ntj * K] * g.T + t) * kNPair) * 128 + 2 * lane;
+        auto slot = [](int sl) { return (int64_t)(sl >> 1) * 128 + (sl & 1); };
         for(int a = rp[r]; a < rp[r + 1]; ++a)
         {
             const int c = ci[a];
             if(c == (int)r)
             {
                 if(nco > kNDep)
-                    dst[(int64_t)kNDep * 64] = val[a];
+                    dst[slot(kNDep)] = val[a];
                 continue;
             }
             if(LOWER ? c > (int)r : c < (int)r)
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(kBlock) void k_box_fill(int n, BoxDims g, int nco, 
             const int dx = d2 - dj * g.nx;
             const int i  = (dk + 1) * 9 + (dj + 1) * 3 + (dx + 1);
             // slot in the order of the host loop: lower: entry i (0 .. 12); upper: entry i - 14
-            dst[(int64_t)(LOWER ? i : i - 14) * 64] = val[a];
+            dst[slot(LOWER ? i : i - 14)] = val[a];
         }
     }
 }
@@ -217,26 +220,39 @@ __device__ __forceinline__ void box_tie(X& v)
 {
     asm volatile("" : "+v"(v));
 }
-// (OFF: bytes, an instruction offset -- one address register pair serves eight loads of a step)
+// a lane's pair of coefficients (OFF: bytes, an instruction offset -- one address register pair serves four loads of a step)
+template <typename T>
+struct BoxPair;
+template <>
+struct BoxPair<double>
+{
+    typedef double type __attribute__((ext_vector_type(2)));
+};
+template <>
+struct BoxPair<float>
+{
+    typedef float type __attribute__((ext_vector_type(2)));
+};
 template <int OFF>
-__device__ __forceinline__ void box_ld_nt(double& r, const double* p)
+__device__ __forceinline__ void box_ld_pair_nt(BoxPair<double>::type& r, const double* p)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=v"(r) : "v"(p), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void box_ld_pair_nt(BoxPair<float>::type& r, const float* p)
 {
     asm volatile("global_load_dwordx2 %0, %1, off offset:%2 nt" : "=v"(r) : "v"(p), "n"(OFF) : "memory");
 }
-template <int OFF>
-__device__ __forceinline__ void box_ld_nt(float& r, const float* p)
+// the kNPair coefficient pairs of one step: 128 elements apart, from p.  (A step used to issue 14 loads of 8 bytes per lane; the
+// ISSUE of its 17 memory instructions was 45 % of the step -- measured with s_memtime stamps --, the waits for their data nothing.)
+template <typename T, int D = 0>
+__device__ __forceinline__ void box_ld_step(typename BoxPair<T>::type (&c)[kNPair], const T* p)
 {
-    asm volatile("global_load_dword %0, %1, off offset:%2 nt" : "=v"(r) : "v"(p), "n"(OFF) : "memory");
-}
-// the NCO coefficients of one step: 64 elements apart, from p
-template <typename T, int NCO, int D = 0>
-__device__ __forceinline__ void box_ld_step(T (&c)[NCO], const T* p)
-{
-    if constexpr(D < NCO)
+    if constexpr(D < kNPair)
     {
-        constexpr int kPer = 4096 / (64 * (int)sizeof(T)); // loads per 4 KB of instruction offset
-        box_ld_nt<(D % kPer) * 64 * (int)sizeof(T)>(c[D], p + (D / kPer) * kPer * 64);
-        box_ld_step<T, NCO, D + 1>(c, p);
+        constexpr int kPer = 4096 / (128 * (int)sizeof(T)); // loads per 4 KB of instruction offset
+        box_ld_pair_nt<(D % kPer) * 128 * (int)sizeof(T)>(c[D], p + (D / kPer) * kPer * 128);
+        box_ld_step<T, D + 1>(c, p);
     }
 }
 __device__ __forceinline__ void box_ld(double& r, const double* p)
@@ -303,7 +319,8 @@ __global__ __launch_bounds__(64) void k_trsv_box(BoxDims g, const int* __restric
 {
     using B                = typename Sentinel<T>::bits;
     constexpr int NCO      = kNDep + (UNIT ? 0 : 1);
-    constexpr int kStepOps = NCO + 2; // a step: the store into the outflow record, NCO coefficients, one right-hand side
+    constexpr int kStepOps = kNPair + 2; // a step: the store into the outflow record, the coefficient pairs, one right-hand side
+    using P2               = typename BoxPair<T>::type;
     constexpr int kFlushOps = 2; // ... an odd step also the two stores of a flush
     constexpr int kBlockOps = kPF + kPF * kStepOps + 2 * kFlushOps; // polls, four steps, two flushes
     extern __shared__ __attribute__((aligned(16))) char box_lds[];
@@ -357,7 +374,9 @@ __global__ __launch_bounds__(64) void k_trsv_box(BoxDims g, const int* __restric
         const int  hy = kBJ * J + hj - hk, hz = kBK * K + hk;
         const bool hvalid = lane < kNHalo && hy >= 0 && hy < g.ny && hz >= 0 && hz < g.nz;
         // (a line of the lattice next to this pencil lies in a pencil of the table)
-        const int pq = hvalid ? trank[(J + dJ) + g.ntj * (K + dK)] : 0;
+        // (a lane without a halo line polls its own pencil's first record: every idle lane of the chip on ONE address was the
+        //  busiest line of the L2 once already -- see the dump slots)
+        const int pq = hvalid ? trank[(J + dJ) + g.ntj * (K + dK)] : q;
         const T*  hp = face + ((int64_t)pq * g.T * kFaceW + (hvalid ? p_first : 0)); // element x: hp[x * kFaceW]
         T*        fp = face + ((int64_t)q * g.T * kFaceW + (fs_own >= 0 ? fs_own : 0)); // step t: fp[t * kFaceW]
         const int fs_spare = kFaceW - 2 + (lane & 1) - (fs_own >= 0 ? fs_own : 0);
@@ -378,13 +397,14 @@ __global__ __launch_bounds__(64) void k_trsv_box(BoxDims g, const int* __restric
         // rings start at +0
         for(int i = lane; i < kLines * kRP; i += 64)
             ring[i] = (T)0;
-        const T* cb = coef + ((int64_t)q * g.T) * NCO * 64 + lane;
+        const T* cb = coef + ((int64_t)q * g.T) * kNPair * 128 + 2 * lane;
         // queue: coefficients and right-hand side of the next four steps
-        T cq[kPF][NCO], rq[kPF];
+        P2 cq[kPF][kNPair];
+        T  rq[kPF];
 #pragma unroll
         for(int i = 0; i < kPF; ++i)
         {
-            box_ld_step<T, NCO>(cq[i], cb + (int64_t)i * NCO * 64);
+            box_ld_step<T>(cq[i], cb + (int64_t)i * kNPair * 128);
             const int x = i - s_own;
             box_ld(rq[i], in + gidx(gb, valid ? min(max(x, 0), g.nx - 1) : 0) * (valid ? 1 : 0));
         }
@@ -394,7 +414,7 @@ __global__ __launch_bounds__(64) void k_trsv_box(BoxDims g, const int* __restric
         for(int i = 0; i < kPF; ++i)
         {
 #pragma unroll
-            for(int d = 0; d < NCO; ++d)
+            for(int d = 0; d < kNPair; ++d)
                 box_tie(cq[i][d]);
             box_tie(rq[i]);
         }
@@ -477,7 +497,7 @@ __global__ __launch_bounds__(64) void k_trsv_box(BoxDims g, const int* __restric
                 // (everything issued since this step's loads, one block ago: a block less the step's own operations)
                 box_wait<kBlockOps - kStepOps - (i & 1 ? kFlushOps : 0)>();
 #pragma unroll
-                for(int d = 0; d < NCO; ++d)
+                for(int d = 0; d < kNPair; ++d)
                     box_tie(cq[i][d]);
                 box_tie(rq[i]);
                 T v[kNDep];
@@ -489,10 +509,10 @@ __global__ __launch_bounds__(64) void k_trsv_box(BoxDims g, const int* __restric
                 for(int d = 0; d < kNDep; ++d)
                 {
                     // (x + 1 behind the line's end: the column holds +0 by then -- see the write below and the halo phase)
-                    sum -= cq[i][d] * v[d];
+                    sum -= cq[i][d >> 1][d & 1] * v[d];
                 }
                 if(!UNIT)
-                    sum = sum / cq[i][NCO - 1];
+                    sum = sum / cq[i][kNDep >> 1][kNDep & 1];
                 if(act)
                     ring[a_own + (x & (kRing - 1))] = sum;
                 // the column element nx would take still holds element nx - 16; the readers of this line are past it (the one
@@ -523,7 +543,7 @@ __global__ __launch_bounds__(64) void k_trsv_box(BoxDims g, const int* __restric
                 }
                 // refill the queue slot for step t + 4
                 const int tn = min(t + kPF, g.T - 1);
-                box_ld_step<T, NCO>(cq[i], cb + (int64_t)tn * NCO * 64);
+                box_ld_step<T>(cq[i], cb + (int64_t)tn * kNPair * 128);
                 const int xn = x + kPF;
                 box_ld(rq[i], in + gidx(gb, valid ? min(max(xn, 0), g.nx - 1) : 0) * (valid ? 1 : 0));
             };
@@ -549,7 +569,7 @@ struct BoxPlan
     int      dtype = RAMD_F64;
     int      n     = 0;
     int*     ptab  = nullptr; // [ntiles] J | K << 16, in ticket order (J + 2 K ascending)
-    void*    coef  = nullptr; // [ntiles][T][NCO][64]
+    void*    coef  = nullptr; // [ntiles][T][kNPair][64][2]
     void*    scratch = nullptr; // [n]
     void*    dump    = nullptr; // [ntiles][128] where the idle lanes of a flush store
     int*     trank   = nullptr; // [ntj * ntk] pencil -> ticket
@@ -695,7 +715,7 @@ int box_build(const ramd_mat_s* m, bool lower, bool unit, BoxPlan** out)
     if(s == RAMD_OK)
         s = dev_alloc(&P->counter, 4);
     const int nco = kNDep + (unit ? 0 : 1);
-    P->coef_bytes = (size_t)g.ntiles * g.T * nco * 64 * sizeof(T);
+    P->coef_bytes = (size_t)g.ntiles * g.T * kNPair * 128 * sizeof(T);
     if(s == RAMD_OK && cached_malloc(&P->coef, P->coef_bytes + kPad) != hipSuccess)
         s = RAMD_ERR_HIP;
     if(s == RAMD_OK && cached_malloc(&P->scratch, (size_t)n * sizeof(T) + kPad) != hipSuccess)

