@@ -28,9 +28,13 @@
 //     what is missing;
 //   * pencils are taken by ticket in order of J + 2 K: a pencil only waits for pencils with lower tickets, i.e. for waves
 //     that are running.  One pencil per CU is in flight (box_run).
-// Measured at 256^3 (16.8 M rows, 1056 pencils of 292 steps): 1.04 ms per triangle = 0.37 of the HBM roofline on the CSR
+// Measured at 256^3 (16.8 M rows, 1056 pencils of 292 steps): 1.02 ms per triangle = 0.38 of the HBM roofline on the CSR
 // bytes of the triangle; the timeline (RAMD_TRSV_BOX_DBG) shows 0.45 us per step and 11 us from a pencil's first block to
 // its successor's (18 steps of skew and block granularity + the visibility of an agent-scope store), 95 such hops deep.
+// Where a step's time goes (s_memtime stamps in one pencil; 0.35 us per step alone, 0.45 on the busy chip): the waits for
+// loads nothing, the LDS reads and the chain of 13 multiply-subtract pairs a quarter, the halo bookkeeping of a block an eighth,
+// the rest the serial issue of a lone wave.  Tried on top and not kept: the ten products of the next row formed beside the
+// current row's chain (0.352 -> 0.336 us alone, nothing at 256^3), masks and address arithmetic taken out (nothing).
 // The upper solve is the same sweep on the mirrored lattice (x, y, z counted from their far ends): its dependency list is the
 // lower one reversed.  Arithmetic per row: the subtractions in ascending column order, unfused multiply and subtract, then the
 // division by the stored diagonal -- src/base/host/host_matrix_csr.cpp:1163-1221 (LUSolve), :1357-1404 (LSolve), :1420-1466
