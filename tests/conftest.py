@@ -78,6 +78,21 @@ def forced_run(family, key, jobs):
     return None if key is None else _RUNS[(family, key)].result()
 
 
+_FORCED_WAITERS = ("test_parity_suite_with_box_tiles_forced", "with_the_lattice_form_forced", "test_parity_suite_with_the_sync_free",
+                   "test_spmv_variants_forced_in_a_fresh_process")
+
+
+def pytest_collection_modifyitems(config, items):
+    """the tests that only WAIT for a forced-form pass go to the end of the run: by then the passes, started at collection time,
+    have finished beside the tests of this process (order among themselves and among the others unchanged)"""
+    if os.environ.get("RAMD_TEST_PRESTART", "1") == "0":
+        return
+    waiters = [it for it in items if any(w in it.nodeid for w in _FORCED_WAITERS)]
+    if waiters and len(waiters) < len(items):
+        rest     = [it for it in items if not any(w in it.nodeid for w in _FORCED_WAITERS)]
+        items[:] = rest + waiters
+
+
 def pytest_collection_finish(session):
     """The forced-form families start as soon as the collection knows they are wanted (a GPU run that selected their tests), not
     when the run reaches their files: they work beside the tests of this process instead of making it wait (round 6: the suite
