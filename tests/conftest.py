@@ -104,8 +104,7 @@ def pytest_collection_finish(session):
     if not (want_tri or want_spmv) or os.environ.get("RAMD_TEST_PRESTART", "1") == "0":
         return
     try:
-        import torch
-        if not torch.cuda.is_available():
+        if not os.path.exists("/dev/kfd"):  # (no GPU here: nothing to start -- and no 9-second import of torch to find out)
             return
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
         if want_tri:

@@ -317,7 +317,13 @@ def _amg_local_runs(ra, S, kind):
     return n, local
 
 
-@pytest.mark.parametrize("kind", ["poisson_slab", "gr3030x", "thin"])
+# ("thin": slabs a few planes thick, 40 s of host-side Galerkin products -- a widened row, not the hot path: behind
+#  RAMD_TEST_SOAK=1 since round 6, when the fixtures of the 27-point operator took the suite past its 600 s; the other two
+#  operators and the larger-slabs / decoupled / isolated-rows tests of the same code stay in every run)
+_AMG_KINDS = ["poisson_slab", "gr3030x"] + (["thin"] if os.environ.get("RAMD_TEST_SOAK", "0") not in ("", "0") else [])
+
+
+@pytest.mark.parametrize("kind", _AMG_KINDS)
 def test_aggregation_amg_on_the_global_matrix(ra, S, kind):
     """UAAMG / SAAMG with OperatorType = GlobalMatrix (global_matrix.cpp:1038-1880, :2607-3558; unsmoothed_amg.cpp /
     smoothed_amg.cpp), PMIS: the aggregates cross the rank boundaries as the reference's do, and -- the reference has no
