@@ -34,6 +34,9 @@ def oracle():
 # are independent of each other and of the process that runs this suite, so a family of them is started together (at most
 # RAMD_TEST_JOBS at a time, default 5) the first time one of its members is asked for, and every parametrised test only waits
 # for its own member.  Nothing is skipped: each member still has to pass in full ("a suite that fits its budget").
+# (Tried at the end of round 6 and taken out again: starting the families at collection time, beside the tests of this process,
+# and moving the waiting tests to the end -- the two-rank and eight-rank tests, processes of their own, ran two to four times as
+# long next to five more pytest processes: 626-667 s instead of 649.)
 import concurrent.futures as _cf
 import subprocess as _sp
 
@@ -48,7 +51,6 @@ def forced_run(family, key, jobs):
         _POOL = _cf.ThreadPoolExecutor(max_workers=max(1, int(os.environ.get("RAMD_TEST_JOBS", "5"))))
 
     def run(cmd, env, timeout):
-        env = dict(env, RAMD_TEST_PRESTART="0")  # (a pass never starts families of its own)
         p = _sp.run(cmd, cwd=ROOT, env=env, stdout=_sp.PIPE, stderr=_sp.STDOUT, text=True, timeout=timeout)
         if p.returncode < 0:
             # the whole pass died by a signal (seen once in round 6: SIGABRT of one of five passes sharing a fresh GPU box, not
@@ -71,47 +73,8 @@ def forced_run(family, key, jobs):
         return p.returncode, p.stdout
 
     key_of = {id(cmd): k for k, (cmd, env, timeout) in jobs.items()}
-    if key is None or (family, key) not in _RUNS:
+    if (family, key) not in _RUNS:
         for k, (cmd, env, timeout) in jobs.items():
             if (family, k) not in _RUNS:
                 _RUNS[(family, k)] = _POOL.submit(run, cmd, env, timeout)
-    return None if key is None else _RUNS[(family, key)].result()
-
-
-_FORCED_WAITERS = ("test_parity_suite_with_box_tiles_forced", "with_the_lattice_form_forced", "test_parity_suite_with_the_sync_free",
-                   "test_spmv_variants_forced_in_a_fresh_process")
-
-
-def pytest_collection_modifyitems(config, items):
-    """the tests that only WAIT for a forced-form pass go to the end of the run: by then the passes, started at collection time,
-    have finished beside the tests of this process (order among themselves and among the others unchanged)"""
-    if os.environ.get("RAMD_TEST_PRESTART", "1") == "0":
-        return
-    waiters = [it for it in items if any(w in it.nodeid for w in _FORCED_WAITERS)]
-    if waiters and len(waiters) < len(items):
-        rest     = [it for it in items if not any(w in it.nodeid for w in _FORCED_WAITERS)]
-        items[:] = rest + waiters
-
-
-def pytest_collection_finish(session):
-    """The forced-form families start as soon as the collection knows they are wanted (a GPU run that selected their tests), not
-    when the run reaches their files: they work beside the tests of this process instead of making it wait (round 6: the suite
-    had grown to 650 s with the fixtures of the 27-point operator; no test was taken out)."""
-    names = [it.nodeid for it in session.items]
-    want_tri = any("test_parity_suite_with_box_tiles_forced" in n or "with_the_lattice_form_forced" in n or "syncfree" in n and "forced" in n
-                   for n in names)
-    want_spmv = any("test_spmv_variants_forced_in_a_fresh_process" in n for n in names)
-    if not (want_tri or want_spmv) or os.environ.get("RAMD_TEST_PRESTART", "1") == "0":
-        return
-    try:
-        if not os.path.exists("/dev/kfd"):  # (no GPU here: nothing to start -- and no 9-second import of torch to find out)
-            return
-        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-        if want_tri:
-            from test_gpu_box_tiles_forced import _tri_family
-            forced_run("tri", None, _tri_family())
-        if want_spmv:
-            from test_gpu_kernels import _spmv_family
-            forced_run("spmv", None, _spmv_family())
-    except Exception as e:  # (the tests themselves start their family when asked; a failed early start only costs time)
-        print("forced-form families not started early: %r" % (e,))
+    return _RUNS[(family, key)].result()

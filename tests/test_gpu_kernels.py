@@ -1124,12 +1124,14 @@ def test_csr_row_patterns_give_up_quickly_on_a_large_unstructured_matrix(ra, ora
     eq(y.numpy(), oracle.csr_apply(rp, ci, va, xh))
 
 
-SPMV_VARIANTS = ["RAMD_CSR_Q4=1", "RAMD_CSR_PAT=1", "RAMD_CSR_PAT=1,RAMD_CSR_XL=1", "RAMD_CSR_PAT=0",
+# (three switches of the colour sweeps ride along with SpMV variants they have no kernel in common with -- RAMD_MC_RB=2 with the
+#  four-lane product, RAMD_MC_FOLD=0 with the LDS-staged x pieces, RAMD_MC_RB=0 with the two-block columns product: three
+#  interpreter starts less)
+SPMV_VARIANTS = ["RAMD_CSR_Q4=1,RAMD_MC_RB=2", "RAMD_CSR_PAT=1", "RAMD_CSR_PAT=1,RAMD_CSR_XL=1,RAMD_MC_FOLD=0", "RAMD_CSR_PAT=0",
                  "RAMD_CSR_PAT=0,RAMD_CSR_GRP=1", "RAMD_CSR_PAT=1,RAMD_CSR_PAT2=0", "RAMD_ELL2=1,RAMD_CSR_PAT=1", "RAMD_ELL2=1,RAMD_CSR_PAT=0",
-                 "RAMD_CSR_PAT=0,RAMD_CSR_COL2=2", "RAMD_CSR_PAT=1,RAMD_CSR_NORP=1", "RAMD_CSR_PAT=0,RAMD_CSR_W4=1",
-                 "RAMD_CSR_PAT=0,RAMD_CSR_W4=1,RAMD_CSR_W4_WAVES=1", "RAMD_CSR_PAT=0,RAMD_CSR_W4=1,RAMD_CSR_WP=0", "RAMD_CSR_PAT=0,RAMD_CSR_PIPE=1", "RAMD_CSR_PAT=1,RAMD_MC_FOLD=0",
-                 "RAMD_CSR_PAT=0,RAMD_CSR_W4=0",
-                 "RAMD_MC_RB=2", "RAMD_MC_RB=0"]
+                 "RAMD_CSR_PAT=0,RAMD_CSR_COL2=2,RAMD_MC_RB=0", "RAMD_CSR_PAT=1,RAMD_CSR_NORP=1", "RAMD_CSR_PAT=0,RAMD_CSR_W4=1",
+                 "RAMD_CSR_PAT=0,RAMD_CSR_W4=1,RAMD_CSR_W4_WAVES=1", "RAMD_CSR_PAT=0,RAMD_CSR_W4=1,RAMD_CSR_WP=0", "RAMD_CSR_PAT=0,RAMD_CSR_PIPE=1",
+                 "RAMD_CSR_PAT=0,RAMD_CSR_W4=0"]
 
 
 def _spmv_family():
