@@ -309,6 +309,13 @@ __global__ __launch_bounds__(kBlock) void k_csr_wr(int nrow, int nblk, int per_x
         bool      have_xrow = false;
         if(MODE == 1 && row < nrow)
             sum = y[row];
+        // x[row] for the epilogues (fused dot against x, Jacobi sweep): requested here, one coalesced load per wave -- picking it
+        // out of the row's own gathers (k_csr_tr<PAT>) is three vector instructions per entry of a 27-entry row
+        if(((DOT && !ws.dotv) || MODE == 2) && row < nrow)
+        {
+            xrow      = x[row];
+            have_xrow = true;
+        }
         for(int cb = start & ~3; cb < end; cb += kWrCap)
         {
             v4i32 c[kWrCap / (4 * 64)];
@@ -368,11 +375,6 @@ __global__ __launch_bounds__(kBlock) void k_csr_wr(int nrow, int nblk, int per_x
                 {
                     const T s2 = MODE != 1 ? sum + v[e] * xv[e] : sum + scalar * v[e] * xv[e];
                     sum        = ok[e] ? s2 : sum;
-                    if(PAT && (DOT || MODE == 2) && ok[e] && cc[e] == row)
-                    {
-                        xrow      = xv[e];
-                        have_xrow = true;
-                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
