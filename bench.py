@@ -655,7 +655,7 @@ def main():
         if args.format == "csr":
             b_spmv = spmv_bytes(n, nnz, vb)
             k_spmv = ("fp32 inner CSR SpMV + fused <p,q> (k_csr_pat2<float> for structured matrices, else k_csr_tr<float>; the few fp64 outer residual SpMVs are in the average)"
-                      if mixed else "CSR SpMV (k_csr_pat2 for structured matrices -- columns from the row-pattern dictionary, two row blocks per workgroup: traffic below the algorithmic CSR bytes -- else k_csr_tr, or k_csr_w4 for rows of 16+ entries; with the fused dot where the solver uses it)")
+                      if mixed else "CSR SpMV (k_csr_pat2 for structured matrices -- columns from the row-pattern dictionary, two row blocks per workgroup: traffic below the algorithmic CSR bytes -- else k_csr_tr; rows of 16+ entries: k_csr_wr on stencils / long row patterns, k_csr_wp otherwise; with the fused dot where the solver uses it)")
         else:
             nnz_fmt = 7 * n if args.matrix == "poisson" else (27 * n if args.matrix == "lap27" else nnz)
             b_spmv = 4 * nnz_fmt + vb * (2 * n + nnz_fmt)
@@ -793,7 +793,7 @@ def main():
                           roofline=roof("sparse triangular solve, one launch per triangle: %s" % tp3.get("lower", {}).get("form", "?"),
                                         trsv_bytes(n3, nnz3, 8), p3[PROF_TRSV], traffic_for("trsv_shell_rcm")),
                           tri_plan=tp3,
-                          kernels={"spmv": roof("CSR SpMV (k_csr_w4: rows of 16+ entries, four rows per wave)", spmv_bytes(n3, nnz3, 8),
+                          kernels={"spmv": roof("CSR SpMV (k_csr_wp: rows of 16+ entries, wave-private passes, lane t sums row t)", spmv_bytes(n3, nnz3, 8),
                                                 p3[PROF_SPMV], traffic_for("spmv_csr_shell"))})
                 del A3, ones3, rhs3, x3, sys3
                 if not args.no_cpu_baseline:
