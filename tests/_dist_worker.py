@@ -28,6 +28,8 @@ def _matrix(kind):
         return gen.poisson7(12)
     if kind == "gr3030":
         return gen.gr_30_30()
+    if kind == "lap27":  # the reference's own 3-D operator (gen_3d_laplacian, clients/include/utility.hpp:110-177), 9 x 8 x 10
+        return gen.laplace27(9, 8, 10)
     return gen.random_sparse(500, 5, seed=3)
 
 

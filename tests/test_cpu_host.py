@@ -241,7 +241,7 @@ def _spawn(mode, kind, world=2, timeout=300, env=None):
         return [dict(np.load(os.path.join(d, "r%d.npz" % r))) for r in range(world)]
 
 
-@pytest.mark.parametrize("kind", ["poisson", "gr3030", "random"])
+@pytest.mark.parametrize("kind", ["poisson", "gr3030", "random", "lap27"])
 def test_two_rank_gloo_spmv_and_cg_match_single_rank(kind, oracle):
     """world_size-2 gloo run of the decomposition (product host logic + oracle kernels) == 1-rank oracle"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))

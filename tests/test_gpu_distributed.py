@@ -89,7 +89,7 @@ def _check_two_ranks(kind, oracle, mode, world=2, env=None):
     assert np.linalg.norm(xs3 - refm["x"]) / np.linalg.norm(refm["x"]) < 1e-5
 
 
-@pytest.mark.parametrize("kind", ["poisson_slab", "gr3030", "random"])
+@pytest.mark.parametrize("kind", ["poisson_slab", "gr3030", "random", "lap27"])
 def test_two_ranks_one_gpu(kind, oracle):
     _check_two_ranks(kind, oracle, "gpu")
 
