@@ -803,6 +803,42 @@ def main():
             except Exception as e:
                 extras["gmres30_ilu0_shell_rcm"] = dict(error=repr(e))
             log("extras: gmres30_ilu0_shell_rcm %.1f s" % (time.perf_counter() - t_x))
+            t_x = time.perf_counter()
+            # The reference's own 3-D operator (gen_3d_laplacian, clients/include/utility.hpp:110-177: the 27-point Laplacian its
+            # samples and benchmarks generate) at 256^3, the three solver / preconditioner pairs of BASELINE.json, generated on the
+            # device: driver-timed figures for the operator on which none of the 7-point lattice kernels applies (`bench.py
+            # --matrix lap27 --grid 256 ...` gives the same lines one by one, with the CPU and vendor columns)
+            try:
+                N27 = 256
+                n27 = N27 ** 3
+                A27 = ra.LocalMatrix(); A27.GenLaplace27(N27)
+                nnz27 = A27.GetNnz()
+                ones27 = ra.LocalVector(); ones27.Allocate("ones", n27); ones27.Ones()
+                rhs27 = ra.LocalVector(); rhs27.Allocate("rhs", n27)
+                x27 = ra.LocalVector(); x27.Allocate("x", n27)
+                A27.Apply(ones27, rhs27)
+                sys27 = (A27, rhs27, x27, lambda: A27.GenLaplace27(N27), ra.CSR)
+                e27 = dict(workload="3-D 27-point Laplacian %d^3 (n=%d, nnz=%d), CSR fp64, rhs=A*1, x0=0, generated on the device" % (N27, n27, nnz27))
+                for name, sc, pc, bs, iters in (("cg_jacobi", S.CG, S.Jacobi, None, min(K, 100)), ("gmres30_ilu0", S.GMRES, S.ILU, 30, min(K, 60)),
+                                                ("bicgstab_mcsgs", S.BiCGStab, S.MultiColoredSGS, None, min(K, 60))):
+                    d7, i7, r7, tb7, p7 = run(iters, sc, pc, bs, warm=min(W, 10), prof_iters=iters, system=sys27)
+                    leg = dict(iters_per_s=round(i7 / d7, 2), iters=i7, ms_per_step=round(d7 / i7 * 1e3, 4), build_s=round(tb7, 3),
+                               kernels={"spmv": roof("CSR SpMV (k_csr_wr: rows of 16+ entries walked lane = row from wave-private LDS images; row patterns)",
+                                                     spmv_bytes(n27, nnz27, 8), p7[PROF_SPMV], traffic_for("spmv_csr_lap27_256"))})
+                    if name == "gmres30_ilu0" and p7[PROF_TRSV]["launches"] > 0:
+                        tp7 = tri_plan_stats(lib, capi)
+                        leg["roofline"] = roof("sparse triangular solve, one launch per triangle: %s" % tp7.get("lower", {}).get("form", "?"),
+                                               trsv_bytes(n27, nnz27, 8), p7[PROF_TRSV], traffic_for("trsv_lap27_256"))
+                        leg["tri_plan"] = tp7
+                    if name == "bicgstab_mcsgs" and p7[PROF_PRECOND]["launches"] > 0:
+                        leg["roofline"] = roof("multi-coloured SGS apply (%s)" % mc_form("mcsgs"), mcsgs_bytes(n27, nnz27, 8),
+                                               p7[PROF_PRECOND], traffic_for("mcsgs_lap27_256"))
+                    e27[name] = leg
+                del A27, ones27, rhs27, x27, sys27
+                extras["lap27_256"] = e27
+            except Exception as e:
+                extras["lap27_256"] = dict(error=repr(e))
+            log("extras: lap27_256 %.1f s" % (time.perf_counter() - t_x))
     else:
         if args.matrix != "poisson":
             raise SystemExit("the distributed driver generates z-slabs of the Poisson operator")
