@@ -840,10 +840,14 @@ def main():
                 extras["lap27_256"] = dict(error=repr(e))
             log("extras: lap27_256 %.1f s" % (time.perf_counter() - t_x))
     else:
-        if args.matrix != "poisson":
-            raise SystemExit("the distributed driver generates z-slabs of the Poisson operator")
-        n, nnz = N ** 3, 7 * N ** 3 - 6 * N ** 2
-        wl = "3-D 7-point Poisson %d^3 (n=%d, nnz=%d)" % (N, n, nnz)
+        if args.matrix not in ("poisson", "lap27"):
+            raise SystemExit("the distributed driver generates z-slabs of the Poisson operator or of the 27-point Laplacian")
+        if args.matrix == "lap27":  # the operator the reference's MPI benchmark generates per rank (clients/include/common.hpp:926-1249)
+            n, nnz = N ** 3, (3 * N - 2) ** 3
+            wl = "3-D 27-point Laplacian %d^3 (n=%d, nnz=%d)" % (N, n, nnz)
+        else:
+            n, nnz = N ** 3, 7 * N ** 3 - 6 * N ** 2
+            wl = "3-D 7-point Poisson %d^3 (n=%d, nnz=%d)" % (N, n, nnz)
         z0, z1 = (N * rank) // world, (N * (rank + 1)) // world
         g = C.c_void_p()
         SK = {"cg": capi.SOLVER_CG, "gmres": capi.SOLVER_GMRES, "bicgstab": capi.SOLVER_BICGSTAB}
@@ -858,7 +862,7 @@ def main():
             capi.check(lib.ramd_gsolver_init_inner(g, 1e-5, 1e-2, 1e20, 100000))
         else:
             capi.check(lib.ramd_gsolver_create(comm, SK[args.solver], PK[args.precond], C.byref(g)))
-        capi.check(lib.ramd_gsolver_setup_poisson(g, N, z0, z1))
+        capi.check((lib.ramd_gsolver_setup_laplace27 if args.matrix == "lap27" else lib.ramd_gsolver_setup_poisson)(g, N, z0, z1))
 
         def run(iters, warm=0):
             capi.check(lib.ramd_gsolver_init(g, NEVER[0], NEVER[1], NEVER[2], 0, warm + iters))
@@ -912,11 +916,15 @@ def main():
         n_loc = k * N * N
         nnz_int = n_loc + 4 * (N - 1) * N * k + 2 * (k - 1) * N * N
         nnz_ghost = ((1 if z0 > 0 else 0) + (1 if z1 < N else 0)) * N * N
+        if args.matrix == "lap27":  # (3N - 2)^2 entries per pair of planes one apart or equal
+            nnz_int = (3 * N - 2) ** 2 * (3 * k - 2)
+            nnz_ghost = ((1 if z0 > 0 else 0) + (1 if z1 < N else 0)) * (3 * N - 2) ** 2
         vb = 4 if mixed else 8
         if args.format == "csr":
             b_loc = spmv_bytes(n_loc, nnz_int, vb)
         else:
-            b_loc = 4 * 7 * n_loc + vb * (2 * n_loc + 7 * n_loc)
+            w_fmt = 27 if args.matrix == "lap27" else 7
+            b_loc = 4 * w_fmt * n_loc + vb * (2 * n_loc + w_fmt * n_loc)
         # interior launches carry the fused dot in most solvers; ghost COO ApplyAdd launches are in the same channel:
         # separate them by duration rank is fragile, so the channel average is reported together with the count per iteration
         mine = dict(rank=rank, rows=n_loc, interior_nnz=nnz_int, ghost_nnz=nnz_ghost, spmv_launches_per_iter=round(pr[PROF_SPMV]["count"] / max(itp, 1), 2),

@@ -720,6 +720,15 @@ public:
         this->doInitHalo();
     }
 
+    // ... and of the reference's own 27-point operator (clients/include/common.hpp:926-1249 generates it per rank)
+    void GenerateLaplace27Slab(int nx, int ny, int nz, int z_begin, int z_end)
+    {
+        this->m_interior.MoveToAccelerator();
+        this->m_ghost.MoveToAccelerator();
+        RAMD_CHECK(ramd_mat_gen_laplace27_slab(this->m_interior.handle(), this->m_ghost.handle(), nx, ny, nz, z_begin, z_end));
+        this->doInitHalo();
+    }
+
     // global_matrix.cpp:924-1009, device-resident: pack | halo over xGMI || interior SpMV | ghost +=
     void Apply(const GlobalVector<ValueType>& in, GlobalVector<ValueType>* out) const
     {

@@ -260,6 +260,10 @@ int ramd_mat_gen_poisson7(ramd_mat_t m, int N);
  * (clients/include/utility.hpp:110-177: 26 on the diagonal, -1 at every lattice neighbour of the 3 x 3 x 3 box, ascending
  * columns) on an nx x ny x nz lattice, x fastest (the reference generates cubes: nx = ny = nz = ndim) */
 int ramd_mat_gen_laplace27(ramd_mat_t m, int nx, int ny, int nz);
+/* the planes [z_begin, z_end) of that operator split into interior and ghost parts like ramd_mat_gen_poisson7_slab (ghost columns:
+ * [plane z_begin - 1 | plane z_end], in-plane index y nx + x): a rank's piece in the reference's MPI generator
+ * (clients/include/common.hpp:926-1249) */
+int ramd_mat_gen_laplace27_slab(ramd_mat_t interior, ramd_mat_t ghost, int nx, int ny, int nz, int z_begin, int z_end);
 /* rows [row_begin,row_end) of the same operator split into interior (local columns) and ghost
  * (remote columns, renumbered into the halo receive buffer) parts -- the per-rank pieces a
  * GlobalMatrix holds (src/base/global_matrix.cpp:913-921). */
@@ -634,6 +638,8 @@ int ramd_gsolver_init_inner(ramd_gsolver_t g, double abs_tol, double rel_tol, do
 int ramd_gsolver_destroy(ramd_gsolver_t g);
 /* rank's slab of the 3-D 7-point Poisson operator N^3: planes [z_begin, z_end) */
 int ramd_gsolver_setup_poisson(ramd_gsolver_t g, int N, int z_begin, int z_end);
+/* the same decomposition of the 27-point Laplacian N^3 (ramd_mat_gen_laplace27_slab): whole planes to the lower and upper neighbour */
+int ramd_gsolver_setup_laplace27(ramd_gsolver_t g, int N, int z_begin, int z_end);
 /* general operator: interior CSR (local columns), ghost CSR (columns = positions in the receive
  * buffer), boundary index list and neighbour offsets (ParallelManager setters) */
 int ramd_gsolver_setup_csr(ramd_gsolver_t g, int64_t global_nrow, int local_nrow, int64_t int_nnz,

@@ -124,6 +124,7 @@ SIGNATURES = {
     "ramd_mat_u_solve": (i32, [mat_t, vec_t, vec_t]),
     "ramd_mat_gen_poisson7": (i32, [mat_t, i32]),
     "ramd_mat_gen_laplace27": (i32, [mat_t, i32, i32, i32]),
+    "ramd_mat_gen_laplace27_slab": (i32, [ptr, ptr, i32, i32, i32, i32, i32]),
     "ramd_mat_gen_poisson7_slab": (i32, [mat_t, mat_t, i32, i64, i64]),
     # fused ops / scalar records
     "ramd_mat_ic_factorize": (i32, [mat_t, vec_t]),
@@ -247,6 +248,7 @@ SIGNATURES = {
     "ramd_gsolver_init_inner": (i32, [ptr, f64, f64, f64, i32]),
     "ramd_gsolver_destroy": (i32, [ptr]),
     "ramd_gsolver_setup_poisson": (i32, [ptr, i32, i32, i32]),
+    "ramd_gsolver_setup_laplace27": (i32, [ptr, i32, i32, i32]),
     "ramd_gsolver_setup_csr": (i32, [ptr, i64, i32, i64, ptr, ptr, ptr, i64, ptr, ptr, ptr, i32, ptr, ptr,
                                      ptr, ptr]),
     "ramd_gsolver_convert": (i32, [ptr, i32]),

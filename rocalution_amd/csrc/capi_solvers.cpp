@@ -911,7 +911,17 @@ int ramd_gsolver_destroy(ramd_gsolver_t g)
     return RAMD_OK;
 }
 
+static int gsolver_setup_slab(ramd_gsolver_t g, int N, int z_begin, int z_end, bool lap27);
 int ramd_gsolver_setup_poisson(ramd_gsolver_t g, int N, int z_begin, int z_end)
+{
+    return gsolver_setup_slab(g, N, z_begin, z_end, false);
+}
+int ramd_gsolver_setup_laplace27(ramd_gsolver_t g, int N, int z_begin, int z_end)
+{
+    return gsolver_setup_slab(g, N, z_begin, z_end, true);
+}
+// (both operators couple a plane to the planes next to it and to nothing else: one halo plan)
+static int gsolver_setup_slab(ramd_gsolver_t g, int N, int z_begin, int z_end, bool lap27)
 {
     if(!g || N < 1 || z_begin < 0 || z_end > N || z_begin >= z_end)
         return RAMD_ERR_ARG;
@@ -950,7 +960,10 @@ int ramd_gsolver_setup_poisson(ramd_gsolver_t g, int N, int z_begin, int z_end)
     g->pm.SetReceivers((int)peers.size(), peers.data(), roff.data());
     g->pm.SetSenders((int)peers.size(), peers.data(), soff.data());
     g->A.SetParallelManager(g->pm);
-    g->A.GeneratePoisson7Slab(N, lo, hi);
+    if(lap27)
+        g->A.GenerateLaplace27Slab(N, N, N, z_begin, z_end);
+    else
+        g->A.GeneratePoisson7Slab(N, lo, hi);
     g->A.CompactGhost();
     g->alloc_vectors();
     g->setup = true;

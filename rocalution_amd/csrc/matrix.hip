@@ -202,6 +202,52 @@ __global__ __launch_bounds__(kBlock) void k_lap27_count(int nx, int ny, int nz, 
         cnt[r]      = lap27_span(x, nx) * lap27_span(y, ny) * lap27_span(z, nz);
     }
 }
+// rows of the planes [z0, z1): the entries inside the slab (ghost = 0) or in the planes z0 - 1 / z1 (ghost = 1)
+__global__ __launch_bounds__(kBlock) void k_lap27_slab_count(int nx, int ny, int nz, int z0, int z1, int ghost, int* __restrict__ cnt)
+{
+    const int64_t nxny = (int64_t)nx * ny, nloc = nxny * (z1 - z0);
+    const int64_t gsz  = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nloc; i += gsz)
+    {
+        const int x = (int)(i % nx), y = (int)((i / nx) % ny), z = z0 + (int)(i / nxny);
+        int       planes = 0;
+        for(int sz = -1; sz <= 1; ++sz)
+            if(z + sz >= 0 && z + sz < nz && ((z + sz >= z0 && z + sz < z1) != (ghost != 0)))
+                ++planes;
+        cnt[i] = lap27_span(x, nx) * lap27_span(y, ny) * planes;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_lap27_slab_fill(int nx, int ny, int nz, int z0, int z1, int ghost, int n_lower,
+                                                            const int* __restrict__ rp, int* __restrict__ ci, T* __restrict__ val)
+{
+    const int64_t nxny = (int64_t)nx * ny, nloc = nxny * (z1 - z0);
+    const int64_t gsz  = (int64_t)gridDim.x * blockDim.x;
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nloc; i += gsz)
+    {
+        const int x = (int)(i % nx), y = (int)((i / nx) % ny), z = z0 + (int)(i / nxny);
+        int       p = rp[i];
+        for(int sz = -1; sz <= 1; ++sz)
+        {
+            if(z + sz < 0 || z + sz >= nz || ((z + sz >= z0 && z + sz < z1) == (ghost != 0)))
+                continue;
+            for(int sy = -1; sy <= 1; ++sy)
+            {
+                if(y + sy < 0 || y + sy >= ny)
+                    continue;
+                for(int sx = -1; sx <= 1; ++sx)
+                {
+                    if(x + sx < 0 || x + sx >= nx)
+                        continue;
+                    const int64_t inplane = (int64_t)(y + sy) * nx + (x + sx);
+                    ci[p]  = !ghost ? (int)((int64_t)(z + sz - z0) * nxny + inplane) : (int)((z + sz < z0 ? 0 : n_lower) + inplane);
+                    val[p] = (sz == 0 && sy == 0 && sx == 0) ? (T)26 : (T)-1;
+                    ++p;
+                }
+            }
+        }
+    }
+}
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_lap27_fill(int nx, int ny, int nz, const int* __restrict__ rp, int* __restrict__ ci,
                                                        T* __restrict__ val)
@@ -608,6 +654,64 @@ int ramd_mat_gen_laplace27(ramd_mat_t m, int nx, int ny, int nz)
     }
     dev_free(&rp);
     return s;
+}
+
+// the z-slab [z0, z1) of the same operator, split like ramd_mat_gen_poisson7_slab: entries whose column lies in the slab (interior,
+// local columns) / in the plane below or above it (ghost, columns renumbered into the halo receive buffer [lower plane | upper
+// plane], in-plane index y nx + x) -- what a rank of the reference's MPI generator holds (clients/include/common.hpp:926-1249
+// builds the same 27-point operator per rank)
+static int gen_lap27_slab_part(ramd_mat_t m, int nx, int ny, int nz, int z0, int z1, int ghost)
+{
+    Backend&      b    = backend();
+    const int64_t nxny = (int64_t)nx * ny, nloc = nxny * (z1 - z0);
+    int *         cnt = nullptr, *rp = nullptr;
+    RAMD_TRY(dev_alloc(&cnt, nloc + 1));
+    int s = dev_alloc(&rp, nloc + 1);
+    if(s == RAMD_OK && hipMemsetAsync(cnt + nloc, 0, sizeof(int), b.cur) != hipSuccess)
+        s = RAMD_ERR_HIP;
+    const int grid = ew_grid(nloc);
+    if(s == RAMD_OK)
+    {
+        hipLaunchKernelGGL(k_lap27_slab_count, dim3(grid), dim3(kBlock), 0, b.cur, nx, ny, nz, z0, z1, ghost, cnt);
+        s = device_exclusive_scan(cnt, rp, nloc + 1);
+    }
+    int last = 0;
+    if(s == RAMD_OK
+       && (hipMemcpyAsync(&last, rp + nloc, sizeof(int), hipMemcpyDeviceToHost, b.cur) != hipSuccess
+           || hipStreamSynchronize(b.cur) != hipSuccess))
+        s = RAMD_ERR_HIP;
+    dev_free(&cnt);
+    const int64_t n_lower = z0 > 0 ? nxny : 0, n_upper = z1 < nz ? nxny : 0;
+    if(s == RAMD_OK)
+        s = mat_alloc_csr(m, (int)nloc, ghost ? (int)(n_lower + n_upper) : (int)nloc, (int64_t)last);
+    if(s == RAMD_OK)
+    {
+        hipError_t e = hipMemcpyAsync(m->rp, rp, sizeof(int) * ((size_t)nloc + 1), hipMemcpyDeviceToDevice, b.cur);
+        if(last > 0)
+        {
+            if(m->dtype == RAMD_F64)
+                hipLaunchKernelGGL((k_lap27_slab_fill<double>), dim3(grid), dim3(kBlock), 0, b.cur, nx, ny, nz, z0, z1, ghost, (int)n_lower,
+                                   m->rp, m->ci, (double*)m->val);
+            else
+                hipLaunchKernelGGL((k_lap27_slab_fill<float>), dim3(grid), dim3(kBlock), 0, b.cur, nx, ny, nz, z0, z1, ghost, (int)n_lower,
+                                   m->rp, m->ci, (float*)m->val);
+        }
+        if(e != hipSuccess || hipGetLastError() != hipSuccess || hipStreamSynchronize(b.cur) != hipSuccess)
+            s = RAMD_ERR_HIP;
+    }
+    dev_free(&rp);
+    return s;
+}
+
+int ramd_mat_gen_laplace27_slab(ramd_mat_t interior, ramd_mat_t ghost, int nx, int ny, int nz, int z_begin, int z_end)
+{
+    CHECK_MAT(interior);
+    CHECK_MAT(ghost);
+    if(nx < 1 || ny < 1 || nz < 1 || z_begin < 0 || z_end > nz || z_begin >= z_end
+       || (int64_t)nx * ny * (z_end - z_begin) >= (1ll << 31) / 27)
+        RAMD_FAIL(RAMD_ERR_ARG, "laplace27_slab: planes [z_begin, z_end) of an nx x ny x nz lattice, inside the int32 index range");
+    RAMD_TRY(gen_lap27_slab_part(interior, nx, ny, nz, z_begin, z_end, 0));
+    return gen_lap27_slab_part(ghost, nx, ny, nz, z_begin, z_end, 1);
 }
 
 int ramd_mat_gen_poisson7_slab(ramd_mat_t interior, ramd_mat_t ghost, int N, int64_t row_begin,

@@ -187,6 +187,10 @@ class DistributedSolver:
     def setup_poisson(self, N, z_begin, z_end):
         self._capi.check(self._lib.ramd_gsolver_setup_poisson(self._g, N, z_begin, z_end))
 
+    def setup_laplace27(self, N, z_begin, z_end):
+        """planes [z_begin, z_end) of the reference's 27-point Laplacian N^3 (clients/include/common.hpp:926-1249), generated on the device"""
+        self._capi.check(self._lib.ramd_gsolver_setup_laplace27(self._g, N, z_begin, z_end))
+
     def setup_csr(self, global_nrow, piece, plan):
         irp, ici, iva = piece["interior"]
         grp, gci, gva = piece["ghost"]

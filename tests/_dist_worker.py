@@ -126,13 +126,14 @@ def gpu_worker(rank, world, initfile, kind, outdir, rccl=False):
     ra.init_rocalution(rank if rccl else 0)
     comm = D.init_rccl_comm(rank, world, dist) if rccl else D.make_callback_comm(rank, world, dist)
     out = {}
-    if kind == "poisson_slab":
+    if kind in ("poisson_slab", "lap27_slab"):
         N = 12
         z0, z1 = (N * rank) // world, (N * (rank + 1)) // world
         n = N ** 3
         lo, hi = z0 * N * N, z1 * N * N
         g = D.DistributedSolver(comm, capi.SOLVER_CG, capi.PC_JACOBI)
-        g.setup_poisson(N, z0, z1)
+        slab = (lambda gg: gg.setup_laplace27(N, z0, z1)) if kind == "lap27_slab" else (lambda gg: gg.setup_poisson(N, z0, z1))
+        slab(g)
     else:
         rp, ci, va = _matrix(kind)
         if kind == "random":
@@ -152,8 +153,8 @@ def gpu_worker(rank, world, initfile, kind, outdir, rccl=False):
     it, st, res = g.result()
     # same system again after converting the interior to ELL (ghost -> COO), BiCGStab + BlockJacobi(MC-SGS)
     g2 = D.DistributedSolver(comm, capi.SOLVER_BICGSTAB, capi.PC_MCSGS)
-    if kind == "poisson_slab":
-        g2.setup_poisson(N, z0, z1)
+    if kind in ("poisson_slab", "lap27_slab"):
+        slab(g2)
     else:
         g2.setup_csr(n, piece, plan)
     g2.init(1e-15, 1e-6, 1e8, 500)
@@ -164,8 +165,8 @@ def gpu_worker(rank, world, initfile, kind, outdir, rccl=False):
     it2, st2, res2 = g2.result()
     # config-5 shape: fp64 defect correction around fp32 CG+Jacobi, both levels Global
     g3 = D.DistributedSolver(comm, capi.SOLVER_CG, capi.PC_JACOBI, mixed=True)
-    if kind == "poisson_slab":
-        g3.setup_poisson(N, z0, z1)
+    if kind in ("poisson_slab", "lap27_slab"):
+        slab(g3)
     else:
         g3.setup_csr(n, piece, plan)
     g3.init(1e-15, 1e-6, 1e8, 500)
@@ -179,8 +180,8 @@ def gpu_worker(rank, world, initfile, kind, outdir, rccl=False):
     for sk, pk in ([(capi.SOLVER_BICGSTAB, capi.PC_ILU0), (capi.SOLVER_BICGSTAB, capi.PC_MCSGS)] if kind == "random"
                    else [(capi.SOLVER_CG, capi.PC_SAAMG), (capi.SOLVER_CG, capi.PC_IC), (capi.SOLVER_CG, capi.PC_UAAMG)]):
         g4 = D.DistributedSolver(comm, sk, pk)
-        if kind == "poisson_slab":
-            g4.setup_poisson(N, z0, z1)
+        if kind in ("poisson_slab", "lap27_slab"):
+            slab(g4)
         else:
             g4.setup_csr(n, piece, plan)
         g4.init(1e-15, 1e-8, 1e8, 500)
@@ -195,8 +196,8 @@ def gpu_worker(rank, world, initfile, kind, outdir, rccl=False):
     for sk, pk, fmt in ((capi.SOLVER_BICGSTAB, capi.PC_MCSGS, ra.ELL), (capi.SOLVER_BICGSTAB, capi.PC_MCSGS, ra.HYB),
                         (capi.SOLVER_GMRES, capi.PC_ILU0, ra.CSR)):
         g5 = D.DistributedSolver(comm, sk, pk)
-        if kind == "poisson_slab":
-            g5.setup_poisson(N, z0, z1)
+        if kind in ("poisson_slab", "lap27_slab"):
+            slab(g5)
         else:
             g5.setup_csr(n, piece, plan)
         g5.init(1e-15, 1e-6, 1e8, 500)

@@ -32,6 +32,8 @@ def _check_two_ranks(kind, oracle, mode, world=2, env=None):
     from rocalution_amd import generators as gen
     if kind == "poisson_slab":
         rp, ci, va = gen.poisson7(12)
+    elif kind == "lap27_slab":  # the device generator of a rank's planes (ramd_mat_gen_laplace27_slab) against the whole operator
+        rp, ci, va = gen.laplace27(12)
     else:
         rp, ci, va = W._matrix(kind)
         if kind == "random":
@@ -89,7 +91,7 @@ def _check_two_ranks(kind, oracle, mode, world=2, env=None):
     assert np.linalg.norm(xs3 - refm["x"]) / np.linalg.norm(refm["x"]) < 1e-5
 
 
-@pytest.mark.parametrize("kind", ["poisson_slab", "gr3030", "random", "lap27"])
+@pytest.mark.parametrize("kind", ["poisson_slab", "gr3030", "random", "lap27", "lap27_slab"])
 def test_two_ranks_one_gpu(kind, oracle):
     _check_two_ranks(kind, oracle, "gpu")
 
